@@ -1,0 +1,254 @@
+#!/usr/bin/env python3
+"""bench.py -- decode tokens/s of the hot path on N MI355X (BASELINE.json metric), one JSON line.
+
+A "step" = one decoded token: the whole forward graph of SURVEY.md 3.3 (embedding gather, n_layer x
+[RMSNorm, q/k/v GEMV, RoPE, KV-cache write, attention, o GEMV, residual, RMSNorm, gate/up GEMV, SiLU*up,
+down GEMV, residual], final norm, lm_head GEMV) + greedy argmax, on synthetic quantized weights at the
+real Llama-3-8B shapes (configs[1]: Q4_K, batch 1).  Weights and KV cache are resident in HBM before
+the timed region.
+
+  N == 1 : the whole model on one GPU.
+  N  > 1 : tensor-parallel shards (heads / ffn columns) with an all-reduce (RCCL over xGMI) on the
+           residual stream after o_proj and down_proj ("scaling": "strong": the same model, N GPUs).
+
+Extra objects on the JSON line: "roofline" for the dominant kernel (the gate|up GEMV) from HIP events on the
+launch stream, and "cpu_baseline" = the reference's own CPU mul_mat (oracle/_ref, all host cores) on a bounded
+sample of the same workload.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+import __graft_entry__ as ge  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+WTYPES = {"q4_k": 12, "q4_0": 2, "q8_0": 8}
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def shard_rows(arr, rank, n):
+    r = arr.shape[0] // n
+    return np.ascontiguousarray(arr[rank * r:(rank + 1) * r])
+
+
+def shard_cols(arr, type_, K, rank, n, pkg):
+    """slice the K (input) dimension of quantized rows: whole blocks"""
+    bs, blk = pkg.tensor.TYPE_SIZE[type_], pkg.tensor.BLCK[type_]
+    nb = K // blk
+    assert nb % n == 0, "K/N must be a whole number of quant blocks"
+    a = arr.reshape(arr.shape[0], nb, bs)
+    per = nb // n
+    return np.ascontiguousarray(a[:, rank * per:(rank + 1) * per, :]).reshape(arr.shape[0], per * bs)
+
+
+def build_model(pkg, cfg, wtype, rank, world):
+    """generate (this rank's shard of) the synthetic model tensor by tensor and upload it"""
+    S = pkg.synth
+    m = pkg.Llama(cfg, None, tp_rank=rank, tp_size=world)
+    H, hd, F = cfg["hidden"], cfg["head_dim"], cfg["ffn"]
+    QD = cfg["n_head"] * hd
+    t0 = time.time()
+    for name, t, rows, K in S.tensor_list(cfg, wtype):
+        a = S.make_tensor_fast(name, t, rows, K)
+        base = name.split(".")[-1]
+        if world > 1:
+            if base in ("wq", "wk", "wv", "wgate", "wup"):
+                a = shard_rows(a, rank, world)
+            elif base == "wo":
+                a = shard_cols(a, t, QD, rank, world, pkg)
+            elif base == "wdown":
+                a = shard_cols(a, t, F, rank, world, pkg)
+        m.set_weight(name, t, a)
+    m.set_weight("out_norm", pkg.F32, S.make_norm("out_norm", H))
+    for i in range(cfg["n_layer"]):
+        p = f"layers.{i}."
+        m.set_weight(p + "attn_norm", pkg.F32, S.make_norm(p + "attn_norm", H))
+        m.set_weight(p + "ffn_norm", pkg.F32, S.make_norm(p + "ffn_norm", H))
+        if cfg.get("qkv_bias"):
+            for b, n in (("bq", QD), ("bk", cfg["n_kv_head"] * hd), ("bv", cfg["n_kv_head"] * hd)):
+                v = S.make_bias(p + b, n)
+                m.set_weight(p + b, pkg.F32, shard_rows(v, rank, world) if world > 1 else v)
+    log(f"[rank {rank}] model generated + uploaded in {time.time() - t0:.1f}s")
+    return m
+
+
+def measure_dominant_kernel(pkg, cfg, wtype, iters=64):
+    """gate|up GEMV (28672 x 4096 for Llama-3-8B): avg launch duration from HIP events on the launch stream.
+    Cycles through enough distinct weight copies to defeat the 256 MiB Infinity Cache."""
+    L = pkg.lib.get()
+    H, F = cfg["hidden"], cfg["ffn"]
+    rows = 2 * F
+    rs = pkg.tensor.row_size(wtype, H)
+    nbytes = rows * rs
+    n_copies = max(2, int(1.5 * 2**30 // nbytes) + 1)
+    w0 = pkg.synth.make_tensor_fast("bench.wgu", wtype, rows, H)
+    ws = []
+    for _ in range(n_copies):
+        ws.append(pkg.Tensor.from_numpy(w0, wtype, [H, rows]))
+    x = pkg.Tensor.from_numpy(np.random.default_rng(0).standard_normal((1, H)).astype(np.float32))
+    y = pkg.Tensor(pkg.F32, [rows, 1])
+    cw, cx, cy = ws[0].c(), x.c(), y.c()
+    wsize = L.cllm_mul_mat_wsize(C.byref(cw), C.byref(cx))
+    scratch = pkg.tensor.Buffer(wsize + 256)
+    ptrs = (C.c_void_p * n_copies)(*[w.data_ptr().value for w in ws])
+    us = C.c_float()
+    pkg.lib.check(L.cllm_bench_mul_mat_kernel(None, C.byref(cw), ptrs, n_copies, C.byref(cx), C.byref(cy), scratch.ptr, scratch.nbytes,
+                                              iters, C.byref(us)), "bench_mul_mat_kernel")
+    dur_s = us.value / 1e6
+    return {"kernel": "k_mmvq_q4_K<1> (gate|up GEMV %dx%d)" % (rows, H) if wtype == 12 else "k_mmvq_q32 (gate|up GEMV %dx%d)" % (rows, H),
+            "bytes_per_launch": nbytes, "avg_us": dur_s * 1e6, "gbs": nbytes / dur_s / 1e9}
+
+
+def cpu_baseline(pkg, cfg, wtype, budget_s=20.0):
+    """the reference's own CPU mul_mat (oracle/_ref/libggml-cpu.so, all host threads) on the mat-vecs of ONE decoder
+    layer + lm_head with resident weights, extrapolated to n_layer layers (mat-muls are >99 % of CPU decode time,
+    SURVEY.md 3.3).  Falls back to the scalar C restatement (kind "port") when oracle/_ref is absent."""
+    O = ge.load_oracle()
+    H, hd, F, V = cfg["hidden"], cfg["head_dim"], cfg["ffn"], cfg["vocab"]
+    QD, KD = cfg["n_head"] * hd, cfg["n_kv_head"] * hd
+    shapes = [("qkv", H, QD + 2 * KD, wtype), ("o", QD, H, wtype), ("gate_up", H, 2 * F, wtype), ("down", F, H, pkg.synth.down_type(cfg, wtype))]
+    cores = os.cpu_count() or 1
+    rng = np.random.default_rng(0)
+    t_layer, t_head = 0.0, 0.0
+    if O.ref_available():
+        R = O.ref()
+        R.ref_set_threads(C.c_int(cores))
+        kind = "reference"
+        for name, K, N, t in shapes + [("lm_head", H, V, wtype)]:
+            nbytes = N * pkg.tensor.row_size(t, K)
+            copies = max(2, min(8, int(600e6 // nbytes) + 1))
+            w = np.concatenate([pkg.synth.make_tensor_fast(f"cpu.{name}.{c}", t, N, K) for c in range(copies)])
+            x = rng.standard_normal(K).astype(np.float32)
+            sec = C.c_double()
+            iters = max(4, min(64, int(budget_s / 6 / max(nbytes / 20e9, 1e-4))))
+            rc = R.ref_bench_mul_mat(C.c_int(t), C.c_int64(K), C.c_int64(N), C.c_int(copies), w.ctypes.data_as(C.c_void_p),
+                                     x.ctypes.data_as(C.c_void_p), C.c_int(iters), C.byref(sec))
+            assert rc == 0
+            if name == "lm_head":
+                t_head = sec.value
+            else:
+                t_layer += sec.value
+        sample = "reference ggml-cpu mul_mat (x86-64-v3 build) on the 4 fused mat-vec shapes of 1 layer + lm_head, weights resident, x%d layers" % cfg["n_layer"]
+    else:
+        kind, cores = "port", 1
+        for name, K, N, t in shapes[:2]:
+            n_s = min(N, 512)
+            w = pkg.synth.make_tensor_fast(f"cpu.{name}", t, n_s, K)
+            x = rng.standard_normal((1, K)).astype(np.float32)
+            y = np.zeros((1, n_s), np.float32)
+            t0 = time.time()
+            O.mul_mat(O.tensor(w, t, [K, n_s]), O.tensor(x, O.F32, [K, 1]), O.tensor(y, O.F32, [n_s, 1]))
+            t_layer += (time.time() - t0) * N / n_s
+        t_layer *= pkg.synth.weight_bytes_per_token(cfg, wtype) / cfg["n_layer"] / sum(N * pkg.tensor.row_size(t, K) for _, K, N, t in shapes[:2])
+        sample = "scalar C restatement on 512-row samples of the qkv and o mat-vecs, extrapolated by bytes"
+    tok_s = 1.0 / (t_layer * cfg["n_layer"] + t_head)
+    return {"value": tok_s, "unit": "tokens/s", "cores": cores, "kind": kind, "sample": sample}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=128)
+    ap.add_argument("--warmup", type=int, default=16)
+    ap.add_argument("--model", default="llama3-8b")
+    ap.add_argument("--wtype", default="q4_k", choices=sorted(WTYPES))
+    ap.add_argument("--n-prompt", type=int, default=16)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    if world != args.gpus:
+        log(f"warning: WORLD_SIZE={world} but --gpus {args.gpus}; using WORLD_SIZE")
+    pkg = ge.load_package()
+    pkg.lib.require_gpu()
+    pkg.lib.check(pkg.lib.get().cllm_set_device(local), "set_device")
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist_mod
+        dist = dist_mod
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+
+    wtype = WTYPES[args.wtype]
+    max_len = args.n_prompt + args.warmup + args.steps + 8
+    cfg = pkg.synth.config(args.model, max_len=max_len)
+    m = build_model(pkg, cfg, wtype, rank, world)
+
+    if world > 1:
+        import torch
+
+        class _Arr:                       # wrap the raw device pointer for torch (zero copy)
+            def __init__(self, ptr, n):
+                self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<f4", "data": (ptr, False), "version": 2}
+
+        def allreduce(stream, buf, n):
+            dist.all_reduce(torch.as_tensor(_Arr(buf, n), device=f"cuda:{local}"))
+        m.set_allreduce(allreduce)
+
+    def sync_all():
+        if dist is not None:
+            dist.barrier()
+        pkg.ops.sync()
+
+    prompt = np.random.default_rng(1234).integers(0, cfg["vocab"], args.n_prompt).astype(np.int32)
+    logits = m.forward(prompt)
+    tok = int(np.argmax(logits))
+    if args.warmup > 0:
+        tok = int(m.decode_greedy(tok, args.warmup)[-1])
+    sync_all()
+    t0 = time.perf_counter()
+    out = m.decode_greedy(tok, args.steps)
+    sync_all()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        import torch
+        tmax = torch.tensor([dt], device=f"cuda:{local}")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+
+    res = {
+        "metric": "decode tokens/s", "value": args.steps / dt, "unit": "tokens/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+        "scaling": "strong" if world > 1 else "weak", "vs_baseline": None, "dtype": "int8xint4 dot / f32 accumulate (Q8_K x Q4_K)" if wtype == 12 else "int8 dot / f32 accumulate",
+        "data": "synthetic",
+        "config": {"workload": f"{args.model} shapes, {args.wtype.upper()} weights, single-token decode, batch 1, {args.n_prompt}-token prompt, F16 KV cache",
+                   "parallelism": f"tp{world}" if world > 1 else "single GPU", "n_ctx_end": args.n_prompt + args.warmup + args.steps},
+    }
+    if rank == 0:
+        n_ctx = args.n_prompt + args.warmup + args.steps // 2
+        bytes_tok = pkg.synth.weight_bytes_per_token(cfg, wtype) + pkg.synth.kv_bytes_per_token(cfg, n_ctx)
+        res["model_hbm_frac"] = bytes_tok * res["value"] / (HBM_PEAK_GBS * 1e9) / world
+        res["algorithmic_bytes_per_token"] = bytes_tok
+        res["greedy_tail"] = [int(t) for t in out[-4:]]
+        if world == 1:
+            try:
+                k = measure_dominant_kernel(pkg, cfg, wtype)
+                res["roofline"] = {"bound": "hbm", "achieved": k["gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": k["gbs"] / HBM_PEAK_GBS,
+                                   "traffic": None, "kernel": k["kernel"], "avg_us": k["avg_us"], "bytes_per_launch": k["bytes_per_launch"]}
+            except Exception as e:      # the throughput number stands on its own
+                res["roofline"] = {"error": str(e)}
+            if not args.no_cpu_baseline:
+                try:
+                    res["cpu_baseline"] = cpu_baseline(pkg, cfg, wtype)
+                except Exception as e:
+                    res["cpu_baseline"] = {"error": str(e)}
+        print(json.dumps(res), flush=True)
+    m.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

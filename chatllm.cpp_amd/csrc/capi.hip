@@ -1,0 +1,256 @@
+// capi.hip -- the extern "C" surface of libchatllm_hip.so that is not a kernel launcher by itself:
+// library/device queries, memory + stream plumbing, and the MUL_MAT / MUL_MAT_ID dispatch.
+#include "common.h"
+
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+// ---- errors -----------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+
+void cllm_set_error(const char * fmt, ...) {
+    va_list ap; va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+int cllm_hip_check(hipError_t e, const char * what, const char * file, int line) {
+    if (e == hipSuccess) return CLLM_OK;
+    cllm_set_error("HIP error %d (%s) at %s:%d: %s", (int) e, hipGetErrorString(e), file, line, what);
+    (void) hipGetLastError();   // clear sticky launch errors
+    return e == hipErrorOutOfMemory ? CLLM_E_ALLOC : CLLM_E_HIP;
+}
+extern "C" const char * cllm_last_error(void) { return g_err; }
+extern "C" int cllm_abi_version(void) { return 1; }
+
+// ---- type traits (ggml.c type_traits[]) -------------------------------------------------------------------
+extern "C" size_t cllm_type_size(int type) {
+    switch (type) {
+        case CLLM_TYPE_F32: case CLLM_TYPE_I32: return 4;
+        case CLLM_TYPE_F16: return 2;
+        case CLLM_TYPE_I64: return 8;
+        case CLLM_TYPE_Q4_0: return 18; case CLLM_TYPE_Q8_0: return 34; case CLLM_TYPE_Q4_K: return 144;
+    }
+    return 0;
+}
+extern "C" int cllm_blck_size(int type) {
+    switch (type) {
+        case CLLM_TYPE_F32: case CLLM_TYPE_I32: case CLLM_TYPE_F16: case CLLM_TYPE_I64: return 1;
+        case CLLM_TYPE_Q4_0: case CLLM_TYPE_Q8_0: return 32;
+        case CLLM_TYPE_Q4_K: return 256;
+    }
+    return 0;
+}
+extern "C" size_t cllm_row_size(int type, int64_t ne) {
+    const int bs = cllm_blck_size(type);
+    return bs ? cllm_type_size(type) * (size_t)(ne / bs) : 0;
+}
+
+// ---- device -----------------------------------------------------------------------------------------------
+extern "C" int cllm_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) { (void) hipGetLastError(); return 0; }
+    return n;
+}
+extern "C" int cllm_set_device(int device) { HIP_TRY(hipSetDevice(device)); return CLLM_OK; }
+
+int device_cu_count() {
+    static thread_local int dev_cached = -1, cus = 256;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return cus;
+    if (dev != dev_cached) {
+        hipDeviceProp_t p;
+        if (hipGetDeviceProperties(&p, dev) == hipSuccess) cus = p.multiProcessorCount > 0 ? p.multiProcessorCount : 256;
+        dev_cached = dev;
+    }
+    return cus;
+}
+extern "C" int cllm_device_info(int device, char * name, size_t name_len, size_t * mem_free, size_t * mem_total, int * n_cu) {
+    hipDeviceProp_t p;
+    HIP_TRY(hipGetDeviceProperties(&p, device));
+    if (name && name_len) { snprintf(name, name_len, "%s (%s)", p.name, p.gcnArchName); }
+    if (n_cu) *n_cu = p.multiProcessorCount;
+    if (mem_free || mem_total) {
+        int cur = 0; HIP_TRY(hipGetDevice(&cur));
+        HIP_TRY(hipSetDevice(device));
+        size_t f = 0, t = 0; HIP_TRY(hipMemGetInfo(&f, &t));
+        HIP_TRY(hipSetDevice(cur));
+        if (mem_free) *mem_free = f;
+        if (mem_total) *mem_total = t;
+    }
+    return CLLM_OK;
+}
+
+// ---- memory / streams ------------------------------------------------------------------------------------------
+extern "C" int cllm_malloc(void ** ptr, size_t size) {
+    if (!ptr) FAIL(CLLM_E_INVALID, "malloc: null");
+    *ptr = nullptr;
+    if (size == 0) return CLLM_OK;
+    HIP_TRY(hipMalloc(ptr, size));
+    return CLLM_OK;
+}
+extern "C" int cllm_free(void * ptr) { if (ptr) HIP_TRY(hipFree(ptr)); return CLLM_OK; }
+extern "C" int cllm_memset(void * dst, int value, size_t size, void * stream) {
+    if (size) HIP_TRY(hipMemsetAsync(dst, value, size, (hipStream_t) stream));
+    return CLLM_OK;
+}
+extern "C" int cllm_memcpy_h2d(void * dst, const void * src, size_t size, void * stream) {
+    if (size) HIP_TRY(hipMemcpyAsync(dst, src, size, hipMemcpyHostToDevice, (hipStream_t) stream));
+    return CLLM_OK;
+}
+extern "C" int cllm_memcpy_d2h(void * dst, const void * src, size_t size, void * stream) {
+    if (size) { HIP_TRY(hipMemcpyAsync(dst, src, size, hipMemcpyDeviceToHost, (hipStream_t) stream)); HIP_TRY(hipStreamSynchronize((hipStream_t) stream)); }
+    return CLLM_OK;
+}
+extern "C" int cllm_memcpy_d2d(void * dst, const void * src, size_t size, void * stream) {
+    if (size) HIP_TRY(hipMemcpyAsync(dst, src, size, hipMemcpyDeviceToDevice, (hipStream_t) stream));
+    return CLLM_OK;
+}
+extern "C" int cllm_stream_create(void ** stream) {
+    if (!stream) FAIL(CLLM_E_INVALID, "stream_create: null");
+    hipStream_t s; HIP_TRY(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    *stream = (void *) s;
+    return CLLM_OK;
+}
+extern "C" int cllm_stream_destroy(void * stream) { if (stream) HIP_TRY(hipStreamDestroy((hipStream_t) stream)); return CLLM_OK; }
+extern "C" int cllm_stream_sync(void * stream) { HIP_TRY(hipStreamSynchronize((hipStream_t) stream)); return CLLM_OK; }
+
+extern "C" int cllm_event_create(void ** event) {
+    if (!event) FAIL(CLLM_E_INVALID, "event_create: null");
+    hipEvent_t e; HIP_TRY(hipEventCreate(&e));
+    *event = (void *) e;
+    return CLLM_OK;
+}
+extern "C" int cllm_event_destroy(void * event) { if (event) HIP_TRY(hipEventDestroy((hipEvent_t) event)); return CLLM_OK; }
+extern "C" int cllm_event_record(void * event, void * stream) { HIP_TRY(hipEventRecord((hipEvent_t) event, (hipStream_t) stream)); return CLLM_OK; }
+extern "C" int cllm_event_sync(void * event) { HIP_TRY(hipEventSynchronize((hipEvent_t) event)); return CLLM_OK; }
+extern "C" int cllm_event_elapsed_ms(void * start, void * stop, float * ms) {
+    if (!ms) FAIL(CLLM_E_INVALID, "event_elapsed: null");
+    HIP_TRY(hipEventElapsedTime(ms, (hipEvent_t) start, (hipEvent_t) stop));
+    return CLLM_OK;
+}
+
+// ---- MUL_MAT dispatch ---------------------------------------------------------------------------------------------
+static bool is_quant(int t) { return t == CLLM_TYPE_Q4_0 || t == CLLM_TYPE_Q8_0 || t == CLLM_TYPE_Q4_K; }
+static int  act_kind(int wtype) { return wtype == CLLM_TYPE_Q4_K ? 256 : 32; }
+
+static int mmq_min_cols() {
+    static int v = -1;
+    if (v < 0) { v = 9; if (const char * e = getenv("CLLM_MMQ_MIN_COLS")) { int x = atoi(e); if (x >= 1) v = x; } }
+    return v;
+}
+
+extern "C" size_t cllm_mul_mat_wsize(const cllm_tensor * src0, const cllm_tensor * src1) {
+    if (!src0 || !src1 || !is_quant(src0->type)) return 0;
+    return act_row_bytes(src1->ne[0], act_kind(src0->type)) * (size_t) t_nrows(src1);
+}
+
+static int check_mm(const cllm_tensor * src0, const cllm_tensor * src1, const cllm_tensor * dst, const char * name) {
+    if (!src0 || !src1 || !dst) FAIL(CLLM_E_INVALID, "%s: null tensor", name);
+    if (src1->type != CLLM_TYPE_F32 || dst->type != CLLM_TYPE_F32) FAIL(CLLM_E_UNSUPPORTED, "%s: src1/dst must be F32", name);
+    if (!is_quant(src0->type) && src0->type != CLLM_TYPE_F16 && src0->type != CLLM_TYPE_F32) FAIL(CLLM_E_UNSUPPORTED, "%s: src0 type %d", name, src0->type);
+    if (src0->ne[0] != src1->ne[0]) FAIL(CLLM_E_INVALID, "%s: K mismatch %lld vs %lld", name, (long long) src0->ne[0], (long long) src1->ne[0]);
+    if (src0->nb[0] != cllm_type_size(src0->type) || src1->nb[0] != 4 || dst->nb[0] != 4) FAIL(CLLM_E_UNSUPPORTED, "%s: rows must be dense", name);
+    if (src0->ne[0] % cllm_blck_size(src0->type)) FAIL(CLLM_E_INVALID, "%s: K not a multiple of the block size", name);
+    return CLLM_OK;
+}
+
+extern "C" int cllm_op_mul_mat(void * stream, const cllm_tensor * src0, const cllm_tensor * src1, cllm_tensor * dst, void * wdata, size_t wsize) {
+    int rc = check_mm(src0, src1, dst, "mul_mat");
+    if (rc) return rc;
+    if (dst->ne[0] != src0->ne[1] || dst->ne[1] != src1->ne[1] || dst->ne[2] != src1->ne[2] || dst->ne[3] != src1->ne[3]) FAIL(CLLM_E_INVALID, "mul_mat: dst shape");
+    if (src0->ne[2] <= 0 || src0->ne[3] <= 0 || src1->ne[2] % src0->ne[2] || src1->ne[3] % src0->ne[3]) FAIL(CLLM_E_INVALID, "mul_mat: broadcast");
+    if (t_nelements(dst) == 0) return CLLM_OK;
+    hipStream_t st = (hipStream_t) stream;
+    if (src0->ne[0] == 0) return cllm_memset(dst->data, 0, dst->nb[3] * (size_t) dst->ne[3], stream);
+
+    if (!is_quant(src0->type)) return launch_mul_mat_f(st, src0->type, tv(src0), tv(src1), tv(dst));
+
+    const int kind = act_kind(src0->type);
+    const int64_t K = src0->ne[0];
+    const size_t stride = act_row_bytes(K, kind);
+    const size_t need = stride * (size_t) t_nrows(src1);
+    if (!wdata || wsize < need) FAIL(CLLM_E_INVALID, "mul_mat: wdata too small (%zu < %zu)", wsize, need);
+    if ((uintptr_t) wdata % 16 || (uintptr_t) src0->data % 2 || (uintptr_t) src1->data % 16 || src1->nb[1] % 16 || src1->nb[2] % 16 || src1->nb[3] % 16)
+        FAIL(CLLM_E_UNSUPPORTED, "mul_mat: operand alignment");
+    if (src0->type == CLLM_TYPE_Q4_K && ((uintptr_t) src0->data % 16 || src0->nb[1] % 16 || src0->nb[2] % 16 || src0->nb[3] % 16))
+        FAIL(CLLM_E_UNSUPPORTED, "mul_mat: Q4_K rows must be 16-byte aligned");
+    rc = launch_quantize_act(st, kind, tv(src1), wdata, stride);
+    if (rc) return rc;
+
+    const int64_t r2 = src1->ne[2] / src0->ne[2], r3 = src1->ne[3] / src0->ne[3];
+    const tview x = tv(src1);
+    for (int64_t i13 = 0; i13 < src1->ne[3]; i13++)
+    for (int64_t i12 = 0; i12 < src1->ne[2]; i12++) {
+        tview w = tv(src0);
+        w.data += (i12 / r2) * w.nb[2] + (i13 / r3) * w.nb[3];
+        w.ne[2] = w.ne[3] = 1;
+        tview d = tv(dst);
+        d.data += i12 * d.nb[2] + i13 * d.nb[3];
+        const char * act = (const char *) wdata + (size_t)(i12 * src1->ne[1] + i13 * src1->ne[1] * src1->ne[2]) * stride;
+        if (src1->ne[1] >= mmq_min_cols()) {
+            rc = launch_mmq(st, src0->type, w, act, stride, x, d);
+            if (rc == CLLM_E_UNSUPPORTED) rc = launch_mmvq(st, src0->type, w, act, stride, src1->ne[1], x, d);
+        } else {
+            rc = launch_mmvq(st, src0->type, w, act, stride, src1->ne[1], x, d);
+        }
+        if (rc) return rc;
+    }
+    return CLLM_OK;
+}
+
+extern "C" int cllm_bench_mul_mat_kernel(void * stream, const cllm_tensor * src0, void * const * src0_datas, int n_src0, const cllm_tensor * src1,
+                                         cllm_tensor * dst, void * wdata, size_t wsize, int iters, float * avg_us) {
+    int rc = check_mm(src0, src1, dst, "bench_mul_mat_kernel");
+    if (rc) return rc;
+    if (!is_quant(src0->type) || src0->ne[2] != 1 || src0->ne[3] != 1 || src1->ne[2] != 1 || src1->ne[3] != 1 || !src0_datas || n_src0 <= 0 || iters <= 0 || !avg_us)
+        FAIL(CLLM_E_INVALID, "bench_mul_mat_kernel: 2-D quantized operands only");
+    hipStream_t st = (hipStream_t) stream;
+    const int kind = act_kind(src0->type);
+    const size_t stride = act_row_bytes(src0->ne[0], kind);
+    if (!wdata || wsize < stride * (size_t) src1->ne[1]) FAIL(CLLM_E_INVALID, "bench_mul_mat_kernel: wdata too small");
+    rc = launch_quantize_act(st, kind, tv(src1), wdata, stride);
+    if (rc) return rc;
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
+    const bool mmq = src1->ne[1] >= mmq_min_cols();
+    for (int pass = 0; pass < 2; pass++) {             // pass 0 = warm-up (also pages in code objects), pass 1 = timed
+        if (pass == 1) HIP_TRY(hipEventRecord(e0, st));
+        const int n = pass == 0 ? (n_src0 < 4 ? n_src0 : 4) : iters;
+        for (int i = 0; i < n; i++) {
+            tview w = tv(src0); w.data = (char *) src0_datas[i % n_src0];
+            rc = mmq ? launch_mmq(st, src0->type, w, wdata, stride, tv(src1), tv(dst)) : CLLM_E_UNSUPPORTED;
+            if (rc == CLLM_E_UNSUPPORTED) rc = launch_mmvq(st, src0->type, w, wdata, stride, src1->ne[1], tv(src1), tv(dst));
+            if (rc) return rc;
+        }
+    }
+    HIP_TRY(hipEventRecord(e1, st));
+    HIP_TRY(hipEventSynchronize(e1));
+    float ms = 0.0f;
+    HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+    (void) hipEventDestroy(e0); (void) hipEventDestroy(e1);
+    *avg_us = ms * 1e3f / (float) iters;
+    return CLLM_OK;
+}
+
+extern "C" int cllm_op_mul_mat_id(void * stream, const cllm_tensor * as, const cllm_tensor * b, const cllm_tensor * ids, cllm_tensor * dst,
+                                  void * wdata, size_t wsize) {
+    int rc = check_mm(as, b, dst, "mul_mat_id");
+    if (rc) return rc;
+    if (!ids || ids->type != CLLM_TYPE_I32) FAIL(CLLM_E_INVALID, "mul_mat_id: ids must be I32");
+    if (!is_quant(as->type)) FAIL(CLLM_E_UNSUPPORTED, "mul_mat_id: expert weights must be Q4_0/Q8_0/Q4_K");
+    const int64_t n_used = ids->ne[0], n_tok = ids->ne[1];
+    if (as->ne[3] != 1 || b->ne[3] != 1 || dst->ne[3] != 1 || ids->ne[2] != 1 || ids->ne[3] != 1) FAIL(CLLM_E_INVALID, "mul_mat_id: 4-D operands");
+    if (dst->ne[0] != as->ne[1] || dst->ne[1] != n_used || dst->ne[2] != n_tok || b->ne[2] != n_tok) FAIL(CLLM_E_INVALID, "mul_mat_id: shapes");
+    if (b->ne[1] <= 0 || (b->ne[1] != 1 && b->ne[1] != n_used)) FAIL(CLLM_E_INVALID, "mul_mat_id: b.ne[1] must be 1 or n_expert_used");
+    if (t_nelements(dst) == 0) return CLLM_OK;
+    const int kind = act_kind(as->type);
+    const size_t stride = act_row_bytes(as->ne[0], kind);
+    const size_t need = stride * (size_t) t_nrows(b);
+    if (!wdata || wsize < need) FAIL(CLLM_E_INVALID, "mul_mat_id: wdata too small (%zu < %zu)", wsize, need);
+    if (as->type == CLLM_TYPE_Q4_K && ((uintptr_t) as->data % 16 || as->nb[1] % 16 || as->nb[2] % 16)) FAIL(CLLM_E_UNSUPPORTED, "mul_mat_id: alignment");
+    hipStream_t st = (hipStream_t) stream;
+    rc = launch_quantize_act(st, kind, tv(b), wdata, stride);      // act row index = i11 + ne11*i12 (token-major over slots)
+    if (rc) return rc;
+    return launch_mmvq_id(st, as->type, tv(as), wdata, stride, b->ne[1], tv(ids), tv(dst));
+}

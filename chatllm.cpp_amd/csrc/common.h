@@ -1,0 +1,128 @@
+// common.h -- shared device/host helpers for the gfx950 kernel library (not a public header).
+// Formats follow /root/reference/ggml/src/ggml-common.h:170-175 (Q4_0), 219-224 (Q8_0), 295-306 (Q4_K).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+
+#include "../../include/chatllm_hip.h"
+
+#define CLLM_WAVE 64
+
+// ---- error plumbing (host) ------------------------------------------------------------------
+void cllm_set_error(const char * fmt, ...);
+int  cllm_hip_check(hipError_t e, const char * what, const char * file, int line);
+#define HIP_TRY(expr) do { int _rc = cllm_hip_check((expr), #expr, __FILE__, __LINE__); if (_rc) return _rc; } while (0)
+#define LAUNCH_CHECK() HIP_TRY(hipGetLastError())
+#define FAIL(code, ...) do { cllm_set_error(__VA_ARGS__); return (code); } while (0)
+
+// ---- quant block formats ----------------------------------------------------------------------
+#define QK    32
+#define QK_K  256
+struct __attribute__((packed)) block_q4_0 { uint16_t d; uint8_t qs[16]; };                       // 18 B
+struct __attribute__((packed)) block_q8_0 { uint16_t d; int8_t  qs[32]; };                       // 34 B
+struct __attribute__((packed)) block_q4_K { uint16_t d, dmin; uint8_t scales[12]; uint8_t qs[128]; }; // 144 B
+struct __attribute__((packed)) block_q8_K { float d; int8_t qs[256]; int16_t bsums[16]; };      // 292 B
+static_assert(sizeof(block_q4_0) == 18 && sizeof(block_q8_0) == 34 && sizeof(block_q4_K) == 144 && sizeof(block_q8_K) == 292, "block sizes");
+
+// ---- device-side activation layout ("act row") -------------------------------------------------
+// The CPU path converts each src1 row to the weight's vec_dot_type before the dot products
+// (ggml-cpu.c:1241-1326).  We do the same on the device but keep the result split in planes so a
+// wave can fetch 16-byte aligned pieces:
+//   Q8_0 kind (for Q4_0/Q8_0 weights):  qs[K] int8 | d[K/32] f32 (= fp16-rounded scale) | s[K/32] int32 (sum of qs)
+//   Q8_K kind (for Q4_K weights):       qs[K] int8 | d[K/256] f32                      | s[K/32] int32 (sum per 32)
+// Each plane starts 16-byte aligned; act_row_bytes() is the per-row stride.
+__host__ __device__ inline size_t act_align16(size_t x) { return (x + 15) & ~(size_t) 15; }
+__host__ __device__ inline size_t act_off_d(int64_t K) { return act_align16((size_t) K); }
+__host__ __device__ inline size_t act_off_s(int64_t K, int kind_blk) { return act_off_d(K) + act_align16((size_t)(K / kind_blk) * 4); }
+__host__ __device__ inline size_t act_row_bytes(int64_t K, int kind_blk) { return act_off_s(K, kind_blk) + act_align16((size_t)(K / 32) * 4); }
+
+// ---- small device helpers -----------------------------------------------------------------------
+#ifdef __HIPCC__
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef float    f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float    h2f(uint16_t h) { _Float16 v; __builtin_memcpy(&v, &h, 2); return (float) v; }
+__device__ __forceinline__ uint16_t f2h(float f)    { _Float16 v = (_Float16) f; uint16_t h; __builtin_memcpy(&h, &v, 2); return h; }   // RNE
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ int wave_sum_i(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ int dot4(uint32_t a, uint32_t b, int c) { return __builtin_amdgcn_sdot4((int) a, (int) b, c, false); }
+
+// one lane of the reference's AVX2 ggml_v_expf (ggml-cpu/vec.h:1230-1267), op for op, so that
+// soft_max / SiLU agree with the CPU path to the last bit wherever the CPU takes its vector body.
+__device__ __forceinline__ float ggml_expf_poly(float x) {
+    const float r = 0x1.8p23f;
+    const float z = __builtin_fmaf(x, 0x1.715476p+0f, r);
+    const float n = z - r;
+    const float b = __builtin_fmaf(-n, 0x1.7f7d1cp-20f, __builtin_fmaf(-n, 0x1.62e4p-1f, x));
+    const uint32_t e = __float_as_uint(z) << 23;
+    const float k = __uint_as_float(e + 0x3f800000u);
+    const bool  c = fabsf(n) > 126.0f;
+    const float u = b * b;
+    const float j = __builtin_fmaf(__builtin_fmaf(__builtin_fmaf(0x1.0e4020p-7f, b, 0x1.573e2ep-5f), u,
+                                                  __builtin_fmaf(0x1.555e66p-3f, b, 0x1.fffdb6p-2f)),
+                                   u, 0x1.ffffecp-1f * b);
+    if (!c) return __builtin_fmaf(j, k, k);
+    const uint32_t g  = (n <= 0.0f) ? 0x82000000u : 0u;
+    const float    s1 = __uint_as_float(g + 0x7f000000u);
+    const float    s2 = __uint_as_float(e - g);
+    if (fabsf(n) > 192.0f) return s1 * s1;
+    return __builtin_fmaf(s2, j, s2) * s1;
+}
+#endif  // __HIPCC__
+
+// ---- host helpers ---------------------------------------------------------------------------------
+static inline int64_t t_nelements(const cllm_tensor * t) { return t->ne[0]*t->ne[1]*t->ne[2]*t->ne[3]; }
+static inline int64_t t_nrows(const cllm_tensor * t) { return t->ne[1]*t->ne[2]*t->ne[3]; }
+static inline bool t_is_contiguous(const cllm_tensor * t) {
+    size_t nb = cllm_type_size(t->type);
+    if (t->nb[0] != nb) return false;
+    nb *= (size_t)(t->ne[0] / cllm_blck_size(t->type));
+    for (int i = 1; i < 4; i++) { if (t->ne[i] != 1 && t->nb[i] != nb) return false; nb *= (size_t) t->ne[i]; }
+    return true;
+}
+static inline bool t_same_shape(const cllm_tensor * a, const cllm_tensor * b) {
+    return a->ne[0] == b->ne[0] && a->ne[1] == b->ne[1] && a->ne[2] == b->ne[2] && a->ne[3] == b->ne[3];
+}
+
+// POD copy of a tensor's geometry for kernels
+struct tview {
+    char *  data;
+    int64_t ne[4];
+    int64_t nb[4];
+};
+static inline tview tv(const cllm_tensor * t) {
+    tview v; v.data = (char *) t->data;
+    for (int i = 0; i < 4; i++) { v.ne[i] = t->ne[i]; v.nb[i] = (int64_t) t->nb[i]; }
+    return v;
+}
+
+// internal launchers (implemented across the .hip files)
+int launch_quantize_act(hipStream_t st, int kind_blk /*32 or 256*/, const tview & src1, void * act, size_t act_stride);
+int launch_mmvq(hipStream_t st, int wtype, const tview & w, const void * act, size_t act_stride, int64_t ncols_total,
+                const tview & src1_geom, const tview & dst);
+int launch_mmvq_id(hipStream_t st, int wtype, const tview & as, const void * act, size_t act_stride, int64_t b_ne1, const tview & ids, const tview & dst);
+int launch_mmq(hipStream_t st, int wtype, const tview & w, const void * act, size_t act_stride, const tview & src1_geom, const tview & dst);
+int launch_mul_mat_f(hipStream_t st, int wtype, const tview & w, const tview & x, const tview & dst);
+int device_cu_count();

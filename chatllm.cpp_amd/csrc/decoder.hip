@@ -1,0 +1,384 @@
+// decoder.hip -- host-side runner for the Llama-3 / Qwen2 decoder block sequence.
+//
+// Mirrors (node for node) what chatllm.cpp builds per graph:
+//   HeterogeneousModel::forward (src/models.cpp:1399-1424) -> Embedding::forward (src/layers.cpp:2038-2055)
+//   -> n_layer x LMBlock1Forward::forward (src/layers.cpp:2719-2761) [RMSNorm :2216, BaseAttention::forward :3212,
+//      cross_attention :2681, save_to_cache :3044, calc_attn_scores :2541, BaseMLP::forward :2475]
+//   -> LMFinalSteps::forward (src/models.cpp:1736-1784)
+// but as a fixed launch sequence over the cllm_op_* C ABI on one HIP stream instead of a ggml graph that is
+// rebuilt and re-planned for every token.  All buffers are allocated once.
+//
+// Two paths share the same arithmetic:
+//   general (qlen >= 1): one op per graph node, exactly the nodes of SURVEY.md 3.3
+//   decode  (qlen == 1): fused launches (norm+quant, rope+kv-write, attention, silu*up+quant, GEMV+residual)
+//                        whose only per-token inputs (token id, position) live in device memory, so the whole
+//                        step is captured once in a hipGraph and replayed.
+#include "common.h"
+
+#include <string>
+#include <vector>
+#include <map>
+#include <math.h>
+#include <string.h>
+
+struct dweight { int type = -1; void * data = nullptr; size_t bytes = 0; bool owned = false; };
+
+struct llama_layer {
+    dweight attn_norm, ffn_norm, wq, wk, wv, wo, wgate, wup, wdown, bq, bk, bv;
+    dweight wqkv, wgu;            // row-concatenated fusions (q|k|v and gate|up): numerically identical, one launch
+    uint16_t * k_cache = nullptr, * v_cache = nullptr;
+};
+
+struct cllm_llama {
+    cllm_llama_config cfg;
+    hipStream_t st = nullptr;
+    int nh = 0, nkv = 0, F = 0;                  // local (tensor-parallel) sizes
+    dweight tok_embd, lm_head, out_norm;
+    std::vector<llama_layer> layers;
+    bool finalized = false;
+    // activations
+    int maxq = 0;
+    float * x = nullptr, * xn = nullptr, * qkv = nullptr, * att = nullptr, * ctx = nullptr, * o = nullptr, * gu = nullptr, * g = nullptr;
+    float * scores = nullptr; size_t scores_elems = 0;
+    float * logits = nullptr;
+    void *  wdata = nullptr; size_t wsize = 0;
+    int32_t * tokens_dev = nullptr, * pos_dev = nullptr;
+    cllm_allreduce_fn allreduce = nullptr; void * allreduce_user = nullptr;
+    bool use_graph = true;
+    hipGraphExec_t decode_graph = nullptr;
+    int32_t * next_tok_dev = nullptr;            // greedy feedback
+    size_t weight_bytes = 0;
+};
+
+#define TRY(expr) do { int _rc = (expr); if (_rc) return _rc; } while (0)
+
+static cllm_tensor T(int type, void * data, int64_t n0, int64_t n1 = 1, int64_t n2 = 1, int64_t n3 = 1) {
+    cllm_tensor t; t.type = type; t.data = data;
+    t.ne[0] = n0; t.ne[1] = n1; t.ne[2] = n2; t.ne[3] = n3;
+    t.nb[0] = cllm_type_size(type); t.nb[1] = cllm_row_size(type, n0); t.nb[2] = t.nb[1] * (size_t) n1; t.nb[3] = t.nb[2] * (size_t) n2;
+    return t;
+}
+static cllm_tensor TS(int type, void * data, int64_t n0, int64_t n1, int64_t n2, size_t nb1, size_t nb2) {
+    cllm_tensor t = T(type, data, n0, n1, n2);
+    t.nb[1] = nb1; t.nb[2] = nb2; t.nb[3] = nb2 * (size_t) n2;
+    return t;
+}
+
+extern "C" int cllm_llama_create(const cllm_llama_config * cfg, void * stream, cllm_llama ** out) {
+    if (!cfg || !out) FAIL(CLLM_E_INVALID, "llama_create: null");
+    if (cfg->n_layer <= 0 || cfg->hidden <= 0 || cfg->n_head <= 0 || cfg->n_kv_head <= 0 || cfg->head_dim <= 0 || cfg->ffn <= 0 || cfg->vocab <= 0 || cfg->max_len <= 0)
+        FAIL(CLLM_E_INVALID, "llama_create: bad config");
+    const int tp = cfg->tp_size > 0 ? cfg->tp_size : 1;
+    if (cfg->n_head % tp || cfg->n_kv_head % tp || cfg->ffn % tp || cfg->n_head % cfg->n_kv_head) FAIL(CLLM_E_INVALID, "llama_create: heads/ffn not divisible by tp_size");
+    cllm_llama * m = new cllm_llama();
+    m->cfg = *cfg; m->cfg.tp_size = tp;
+    m->st = (hipStream_t) stream;
+    m->nh = cfg->n_head / tp; m->nkv = cfg->n_kv_head / tp; m->F = cfg->ffn / tp;
+    m->layers.resize(cfg->n_layer);
+    *out = m;
+    return CLLM_OK;
+}
+
+static void free_w(dweight & w) { if (w.owned && w.data) (void) hipFree(w.data); w = dweight(); }
+
+extern "C" void cllm_llama_destroy(cllm_llama * m) {
+    if (!m) return;
+    (void) hipStreamSynchronize(m->st);
+    if (m->decode_graph) (void) hipGraphExecDestroy(m->decode_graph);
+    free_w(m->tok_embd); free_w(m->lm_head); free_w(m->out_norm);
+    for (auto & L : m->layers) {
+        for (dweight * w : { &L.attn_norm, &L.ffn_norm, &L.wq, &L.wk, &L.wv, &L.wo, &L.wgate, &L.wup, &L.wdown, &L.bq, &L.bk, &L.bv, &L.wqkv, &L.wgu }) free_w(*w);
+        if (L.k_cache) (void) hipFree(L.k_cache);
+        if (L.v_cache) (void) hipFree(L.v_cache);
+    }
+    for (void * p : { (void *) m->x, (void *) m->xn, (void *) m->qkv, (void *) m->att, (void *) m->ctx, (void *) m->o, (void *) m->gu, (void *) m->g, (void *) m->scores,
+                      (void *) m->logits, m->wdata, (void *) m->tokens_dev, (void *) m->pos_dev, (void *) m->next_tok_dev }) if (p) (void) hipFree(p);
+    delete m;
+}
+
+static dweight * find_weight(cllm_llama * m, const char * name) {
+    std::string n(name);
+    if (n == "tok_embd") return &m->tok_embd;
+    if (n == "lm_head")  return &m->lm_head;
+    if (n == "out_norm") return &m->out_norm;
+    if (n.rfind("layers.", 0) == 0) {
+        const size_t dot = n.find('.', 7);
+        if (dot == std::string::npos) return nullptr;
+        const int il = atoi(n.substr(7, dot - 7).c_str());
+        if (il < 0 || il >= (int) m->layers.size()) return nullptr;
+        llama_layer & L = m->layers[il];
+        const std::string f = n.substr(dot + 1);
+        static const std::map<std::string, dweight llama_layer::*> fields = {
+            {"attn_norm", &llama_layer::attn_norm}, {"ffn_norm", &llama_layer::ffn_norm}, {"wq", &llama_layer::wq}, {"wk", &llama_layer::wk},
+            {"wv", &llama_layer::wv}, {"wo", &llama_layer::wo}, {"wgate", &llama_layer::wgate}, {"wup", &llama_layer::wup}, {"wdown", &llama_layer::wdown},
+            {"bq", &llama_layer::bq}, {"bk", &llama_layer::bk}, {"bv", &llama_layer::bv}, {"wqkv", &llama_layer::wqkv}, {"wgu", &llama_layer::wgu},
+        };
+        auto it = fields.find(f);
+        return it == fields.end() ? nullptr : &(L.*(it->second));
+    }
+    return nullptr;
+}
+
+static int set_w(cllm_llama * m, const char * name, int type, void * data, size_t nbytes, bool copy_from_host) {
+    if (!m || !name || !data) FAIL(CLLM_E_INVALID, "llama_set_weight: null");
+    if (m->finalized) FAIL(CLLM_E_INVALID, "llama_set_weight: model already running");
+    dweight * w = find_weight(m, name);
+    if (!w) FAIL(CLLM_E_INVALID, "llama_set_weight: unknown tensor '%s'", name);
+    if (cllm_type_size(type) == 0) FAIL(CLLM_E_UNSUPPORTED, "llama_set_weight: type %d", type);
+    free_w(*w);
+    w->type = type; w->bytes = nbytes;
+    if (copy_from_host) {
+        HIP_TRY(hipMalloc(&w->data, nbytes));
+        w->owned = true;
+        HIP_TRY(hipMemcpy(w->data, data, nbytes, hipMemcpyHostToDevice));
+    } else { w->data = data; w->owned = false; }
+    return CLLM_OK;
+}
+extern "C" int cllm_llama_set_weight(cllm_llama * m, const char * name, int type, const void * data, size_t nbytes) { return set_w(m, name, type, (void *) data, nbytes, true); }
+extern "C" int cllm_llama_bind_weight(cllm_llama * m, const char * name, int type, void * dev, size_t nbytes) { return set_w(m, name, type, dev, nbytes, false); }
+extern "C" int cllm_llama_set_allreduce(cllm_llama * m, cllm_allreduce_fn fn, void * user) { if (!m) FAIL(CLLM_E_INVALID, "null"); m->allreduce = fn; m->allreduce_user = user; return CLLM_OK; }
+extern "C" int cllm_llama_use_graph(cllm_llama * m, int enable) { if (!m) FAIL(CLLM_E_INVALID, "null"); m->use_graph = enable != 0; return CLLM_OK; }
+extern "C" size_t cllm_llama_weight_bytes(const cllm_llama * m) { return m ? m->weight_bytes : 0; }
+
+static int expect(const dweight & w, const char * what, int il, size_t bytes, bool f32only) {
+    if (!w.data) FAIL(CLLM_E_INVALID, "llama: missing tensor %s (layer %d)", what, il);
+    if (f32only && w.type != CLLM_TYPE_F32) FAIL(CLLM_E_INVALID, "llama: %s must be F32", what);
+    if (bytes && w.bytes != bytes) FAIL(CLLM_E_INVALID, "llama: %s (layer %d) has %zu bytes, expected %zu", what, il, w.bytes, bytes);
+    return CLLM_OK;
+}
+
+// concatenate rows of a and b (and c) into one device buffer
+static int fuse_rows(hipStream_t st, dweight & dst, std::initializer_list<dweight *> parts) {
+    size_t total = 0; int type = -1;
+    for (dweight * p : parts) { if (type < 0) type = p->type; if (p->type != type) return CLLM_OK; total += p->bytes; }   // mixed types: keep separate
+    void * buf = nullptr;
+    HIP_TRY(hipMalloc(&buf, total));
+    size_t off = 0;
+    for (dweight * p : parts) { HIP_TRY(hipMemcpyAsync((char *) buf + off, p->data, p->bytes, hipMemcpyDeviceToDevice, st)); off += p->bytes; }
+    HIP_TRY(hipStreamSynchronize(st));
+    for (dweight * p : parts) free_w(*p);
+    dst.type = type; dst.data = buf; dst.bytes = total; dst.owned = true;
+    return CLLM_OK;
+}
+
+static int finalize(cllm_llama * m, int qlen) {
+    const cllm_llama_config & c = m->cfg;
+    const int64_t H = c.hidden, hd = c.head_dim, QD = (int64_t) m->nh * hd, KD = (int64_t) m->nkv * hd, F = m->F, V = c.vocab, ML = c.max_len;
+    if (!m->finalized) {
+        TRY(expect(m->tok_embd, "tok_embd", -1, cllm_row_size(m->tok_embd.type, H) * (size_t) V, false));
+        TRY(expect(m->lm_head, "lm_head", -1, cllm_row_size(m->lm_head.type, H) * (size_t) V, false));
+        TRY(expect(m->out_norm, "out_norm", -1, (size_t) H * 4, true));
+        m->weight_bytes = m->lm_head.bytes + m->out_norm.bytes;     // bytes touched per decoded token (embedding: one row)
+        for (int il = 0; il < c.n_layer; il++) {
+            llama_layer & L = m->layers[il];
+            TRY(expect(L.attn_norm, "attn_norm", il, (size_t) H * 4, true));
+            TRY(expect(L.ffn_norm, "ffn_norm", il, (size_t) H * 4, true));
+            if (!L.wqkv.data) {
+                TRY(expect(L.wq, "wq", il, cllm_row_size(L.wq.type, H) * (size_t) QD, false));
+                TRY(expect(L.wk, "wk", il, cllm_row_size(L.wk.type, H) * (size_t) KD, false));
+                TRY(expect(L.wv, "wv", il, cllm_row_size(L.wv.type, H) * (size_t) KD, false));
+                TRY(fuse_rows(m->st, L.wqkv, { &L.wq, &L.wk, &L.wv }));
+            } else TRY(expect(L.wqkv, "wqkv", il, cllm_row_size(L.wqkv.type, H) * (size_t)(QD + 2*KD), false));
+            TRY(expect(L.wo, "wo", il, cllm_row_size(L.wo.type, QD) * (size_t) H, false));
+            if (!L.wgu.data) {
+                TRY(expect(L.wgate, "wgate", il, cllm_row_size(L.wgate.type, H) * (size_t) F, false));
+                TRY(expect(L.wup, "wup", il, cllm_row_size(L.wup.type, H) * (size_t) F, false));
+                TRY(fuse_rows(m->st, L.wgu, { &L.wgate, &L.wup }));
+            } else TRY(expect(L.wgu, "wgu", il, cllm_row_size(L.wgu.type, H) * (size_t)(2*F), false));
+            TRY(expect(L.wdown, "wdown", il, cllm_row_size(L.wdown.type, F) * (size_t) H, false));
+            if (c.qkv_bias) { TRY(expect(L.bq, "bq", il, (size_t) QD * 4, true)); TRY(expect(L.bk, "bk", il, (size_t) KD * 4, true)); TRY(expect(L.bv, "bv", il, (size_t) KD * 4, true)); }
+            for (const dweight * w : { &L.attn_norm, &L.ffn_norm, &L.wq, &L.wk, &L.wv, &L.wqkv, &L.wo, &L.wgate, &L.wup, &L.wgu, &L.wdown }) m->weight_bytes += w->bytes;
+            HIP_TRY(hipMalloc((void **) &L.k_cache, (size_t)(ML * KD) * 2));
+            HIP_TRY(hipMalloc((void **) &L.v_cache, (size_t)(ML * KD) * 2));
+            HIP_TRY(hipMemsetAsync(L.k_cache, 0, (size_t)(ML * KD) * 2, m->st));
+            HIP_TRY(hipMemsetAsync(L.v_cache, 0, (size_t)(ML * KD) * 2, m->st));
+        }
+        HIP_TRY(hipMalloc((void **) &m->logits, (size_t) V * 4));
+        HIP_TRY(hipMalloc((void **) &m->next_tok_dev, 16));
+        m->finalized = true;
+    }
+    if (qlen > m->maxq) {
+        if (m->decode_graph) { (void) hipGraphExecDestroy(m->decode_graph); m->decode_graph = nullptr; }
+        HIP_TRY(hipStreamSynchronize(m->st));
+        for (void * p : { (void *) m->x, (void *) m->xn, (void *) m->qkv, (void *) m->att, (void *) m->ctx, (void *) m->o, (void *) m->gu, (void *) m->g, m->wdata,
+                          (void *) m->tokens_dev, (void *) m->pos_dev }) if (p) (void) hipFree(p);
+        const size_t q = (size_t) qlen;
+        HIP_TRY(hipMalloc((void **) &m->x,   q * H * 4));
+        HIP_TRY(hipMalloc((void **) &m->xn,  q * H * 4));
+        HIP_TRY(hipMalloc((void **) &m->qkv, q * (QD + 2*KD) * 4));
+        HIP_TRY(hipMalloc((void **) &m->att, q * QD * 4));
+        HIP_TRY(hipMalloc((void **) &m->ctx, q * QD * 4));
+        HIP_TRY(hipMalloc((void **) &m->o,   q * H * 4));
+        HIP_TRY(hipMalloc((void **) &m->gu,  q * 2 * F * 4));
+        HIP_TRY(hipMalloc((void **) &m->g,   q * F * 4));
+        int64_t kmax = H; if (F > kmax) kmax = F; if (QD > kmax) kmax = QD;
+        m->wsize = act_row_bytes(kmax, 32) * q + 256;         // the Q8_0 kind is the larger of the two layouts
+        HIP_TRY(hipMalloc(&m->wdata, m->wsize));
+        HIP_TRY(hipMalloc((void **) &m->tokens_dev, q * 4));
+        HIP_TRY(hipMalloc((void **) &m->pos_dev, q * 4));
+        m->maxq = qlen;
+    }
+    return CLLM_OK;
+}
+
+static int ensure_scores(cllm_llama * m, size_t elems) {
+    if (elems <= m->scores_elems) return CLLM_OK;
+    HIP_TRY(hipStreamSynchronize(m->st));
+    if (m->scores) (void) hipFree(m->scores);
+    m->scores = nullptr; m->scores_elems = 0;
+    HIP_TRY(hipMalloc((void **) &m->scores, elems * 4));
+    m->scores_elems = elems;
+    return CLLM_OK;
+}
+
+static int linear(cllm_llama * m, const dweight & w, int64_t K, int64_t N, float * x, int64_t qlen, float * y) {
+    cllm_tensor W = T(w.type, w.data, K, N), X = T(CLLM_TYPE_F32, x, K, qlen), Y = T(CLLM_TYPE_F32, y, N, qlen);
+    return cllm_op_mul_mat(m->st, &W, &X, &Y, m->wdata, m->wsize);
+}
+
+// ---- general path: one launch per graph node -----------------------------------------------------------------
+static int forward_general(cllm_llama * m, int qlen, int n_past) {
+    const cllm_llama_config & c = m->cfg;
+    const int64_t H = c.hidden, hd = c.head_dim, nh = m->nh, nkv = m->nkv, QD = nh * hd, KD = nkv * hd, F = m->F, V = c.vocab, ML = c.max_len;
+    const int64_t n_kv = (int64_t) n_past + qlen, QKV = QD + 2*KD;
+    void * st = m->st;
+    TRY(ensure_scores(m, (size_t)(n_kv * qlen * nh)));
+
+    cllm_tensor ids = T(CLLM_TYPE_I32, m->tokens_dev, qlen), pos = T(CLLM_TYPE_I32, m->pos_dev, qlen);
+    cllm_tensor X = T(CLLM_TYPE_F32, m->x, H, qlen), XN = T(CLLM_TYPE_F32, m->xn, H, qlen), O = T(CLLM_TYPE_F32, m->o, H, qlen);
+    { cllm_tensor E = T(m->tok_embd.type, m->tok_embd.data, H, V); TRY(cllm_op_get_rows(st, &E, &ids, &X)); }
+    cllm_rope_params rp = { (int32_t) hd, c.rope_mode, 0, c.rope_theta, 1.0f, 0.0f, 1.0f, 0.0f, 0.0f };
+
+    for (int il = 0; il < c.n_layer; il++) {
+        llama_layer & L = m->layers[il];
+        cllm_tensor wn = T(CLLM_TYPE_F32, L.attn_norm.data, H);
+        TRY(cllm_op_rms_norm_mul(st, &X, &wn, &XN, c.rms_eps));
+        float * q = m->qkv, * k = m->qkv + QD, * v = m->qkv + QD + KD;     // row slices of the fused projection output
+        if (L.wqkv.data) TRY(linear(m, L.wqkv, H, QKV, m->xn, qlen, m->qkv));
+        else {   // mixed-type q/k/v: three launches into strided slices
+            for (int p = 0; p < 3; p++) {
+                const dweight & w = p == 0 ? L.wq : p == 1 ? L.wk : L.wv; const int64_t N = p == 0 ? QD : KD;
+                cllm_tensor W = T(w.type, w.data, H, N), Xn = T(CLLM_TYPE_F32, m->xn, H, qlen);
+                cllm_tensor Y = TS(CLLM_TYPE_F32, p == 0 ? q : p == 1 ? k : v, N, qlen, 1, (size_t) QKV * 4, (size_t) QKV * 4 * qlen);
+                TRY(cllm_op_mul_mat(st, &W, &Xn, &Y, m->wdata, m->wsize));
+            }
+        }
+        if (c.qkv_bias) {
+            for (int p = 0; p < 3; p++) {
+                const dweight & b = p == 0 ? L.bq : p == 1 ? L.bk : L.bv; const int64_t N = p == 0 ? QD : KD;
+                cllm_tensor Y = TS(CLLM_TYPE_F32, p == 0 ? q : p == 1 ? k : v, N, qlen, 1, (size_t) QKV * 4, (size_t) QKV * 4 * qlen);
+                cllm_tensor B = T(CLLM_TYPE_F32, b.data, N);
+                TRY(cllm_op_add(st, &Y, &B, &Y));
+            }
+        }
+        // RoPE in place: k then q  ([hd, heads, qlen] views of the fused buffer)
+        cllm_tensor Kt = TS(CLLM_TYPE_F32, k, hd, nkv, qlen, (size_t) hd * 4, (size_t) QKV * 4);
+        cllm_tensor Qt = TS(CLLM_TYPE_F32, q, hd, nh,  qlen, (size_t) hd * 4, (size_t) QKV * 4);
+        TRY(cllm_op_rope(st, &Kt, &pos, nullptr, &Kt, &rp));
+        TRY(cllm_op_rope(st, &Qt, &pos, nullptr, &Qt, &rp));
+        // KV-concat: K rows -> k_cache[pos] (SET_ROWS), V transposed -> v_cache[:, n_past..] (CPY into a strided view)
+        {
+            cllm_tensor Ks = TS(CLLM_TYPE_F32, k, KD, qlen, 1, (size_t) QKV * 4, (size_t) QKV * 4 * qlen);
+            cllm_tensor Kc = T(CLLM_TYPE_F16, L.k_cache, KD, ML);
+            TRY(cllm_op_set_rows(st, &Ks, &pos, &Kc));
+            // src: transpose(v) = [qlen, KD] with nb0 = row stride of v; dst: view [qlen, KD] of v_cache with nb1 = 2*ML
+            cllm_tensor Vt = T(CLLM_TYPE_F32, v, qlen, KD); Vt.nb[0] = (size_t) QKV * 4; Vt.nb[1] = 4; Vt.nb[2] = Vt.nb[3] = (size_t) QKV * 4 * qlen;
+            cllm_tensor Vc = TS(CLLM_TYPE_F16, L.v_cache + n_past, qlen, KD, 1, (size_t) ML * 2, (size_t) ML * 2 * KD);
+            TRY(cllm_op_cpy(st, &Vt, &Vc));
+        }
+        // scores = K^T Q ; scale ; mask ; softmax ; ctx = V P
+        {
+            cllm_tensor Kv = TS(CLLM_TYPE_F16, L.k_cache, hd, n_kv, nkv, (size_t) KD * 2, (size_t) hd * 2);
+            cllm_tensor Qv = TS(CLLM_TYPE_F32, q, hd, qlen, nh, (size_t) QKV * 4, (size_t) hd * 4);
+            cllm_tensor S  = T(CLLM_TYPE_F32, m->scores, n_kv, qlen, nh);
+            TRY(cllm_op_mul_mat(st, &Kv, &Qv, &S, nullptr, 0));
+            TRY(cllm_op_scale_mask_soft_max(st, &S, &S, 1.0f / sqrtf((float) hd), n_past));
+            cllm_tensor Vv = TS(CLLM_TYPE_F16, L.v_cache, n_kv, hd, nkv, (size_t) ML * 2, (size_t) ML * hd * 2);
+            cllm_tensor C  = T(CLLM_TYPE_F32, m->ctx, hd, qlen, nh);
+            TRY(cllm_op_mul_mat(st, &Vv, &S, &C, nullptr, 0));
+            // permute(0,2,1,3) + cont -> [hd, nh, qlen]
+            cllm_tensor Cp = T(CLLM_TYPE_F32, m->ctx, hd, nh, qlen); Cp.nb[1] = (size_t) hd * qlen * 4; Cp.nb[2] = (size_t) hd * 4; Cp.nb[3] = (size_t) hd * qlen * nh * 4;
+            cllm_tensor A  = T(CLLM_TYPE_F32, m->att, hd, nh, qlen);
+            TRY(cllm_op_cpy(st, &Cp, &A));
+        }
+        TRY(linear(m, L.wo, QD, H, m->att, qlen, m->o));
+        if (m->allreduce && c.tp_size > 1) m->allreduce(m->allreduce_user, st, m->o, H * qlen);
+        TRY(cllm_op_add(st, &O, &X, &X));
+
+        cllm_tensor wf = T(CLLM_TYPE_F32, L.ffn_norm.data, H);
+        TRY(cllm_op_rms_norm_mul(st, &X, &wf, &XN, c.rms_eps));
+        if (L.wgu.data) {
+            TRY(linear(m, L.wgu, H, 2*F, m->xn, qlen, m->gu));
+            cllm_tensor G = TS(CLLM_TYPE_F32, m->gu, F, qlen, 1, (size_t) 2*F * 4, (size_t) 2*F * 4 * qlen);
+            cllm_tensor U = TS(CLLM_TYPE_F32, m->gu + F, F, qlen, 1, (size_t) 2*F * 4, (size_t) 2*F * 4 * qlen);
+            cllm_tensor Gd = T(CLLM_TYPE_F32, m->g, F, qlen);
+            TRY(cllm_op_silu_mul(st, &G, &U, &Gd));
+        } else {
+            TRY(linear(m, L.wgate, H, F, m->xn, qlen, m->g));
+            TRY(linear(m, L.wup, H, F, m->xn, qlen, m->gu));
+            cllm_tensor G = T(CLLM_TYPE_F32, m->g, F, qlen), U = T(CLLM_TYPE_F32, m->gu, F, qlen);
+            TRY(cllm_op_silu_mul(st, &G, &U, &G));
+        }
+        TRY(linear(m, L.wdown, F, H, m->g, qlen, m->o));
+        if (m->allreduce && c.tp_size > 1) m->allreduce(m->allreduce_user, st, m->o, H * qlen);
+        TRY(cllm_op_add(st, &O, &X, &X));
+    }
+    // LMFinalSteps: last token -> norm -> lm_head
+    cllm_tensor Xl = T(CLLM_TYPE_F32, m->x + (size_t)(qlen - 1) * H, H), XNl = T(CLLM_TYPE_F32, m->xn, H), wn = T(CLLM_TYPE_F32, m->out_norm.data, H);
+    TRY(cllm_op_rms_norm_mul(st, &Xl, &wn, &XNl, c.rms_eps));
+    TRY(linear(m, m->lm_head, H, V, m->xn, 1, m->logits));
+    return CLLM_OK;
+}
+
+extern "C" int cllm_llama_forward(cllm_llama * m, const int32_t * tokens, int qlen, int n_past, float * logits_dev, float * logits_host) {
+    if (!m || !tokens || qlen <= 0 || n_past < 0) FAIL(CLLM_E_INVALID, "llama_forward: arguments");
+    if ((int64_t) n_past + qlen > m->cfg.max_len) FAIL(CLLM_E_INVALID, "llama_forward: context %d+%d exceeds max_len %d", n_past, qlen, m->cfg.max_len);
+    TRY(finalize(m, qlen));
+    std::vector<int32_t> pos(qlen);
+    for (int i = 0; i < qlen; i++) { pos[i] = n_past + i; if (tokens[i] < 0 || tokens[i] >= m->cfg.vocab) FAIL(CLLM_E_INVALID, "llama_forward: token id out of range"); }
+    HIP_TRY(hipMemcpyAsync(m->tokens_dev, tokens, (size_t) qlen * 4, hipMemcpyHostToDevice, m->st));
+    HIP_TRY(hipMemcpyAsync(m->pos_dev, pos.data(), (size_t) qlen * 4, hipMemcpyHostToDevice, m->st));
+    HIP_TRY(hipStreamSynchronize(m->st));     // pos[] is a stack-lifetime host buffer
+    TRY(forward_general(m, qlen, n_past));
+    if (logits_dev) HIP_TRY(hipMemcpyAsync(logits_dev, m->logits, (size_t) m->cfg.vocab * 4, hipMemcpyDeviceToDevice, m->st));
+    if (logits_host) { HIP_TRY(hipMemcpyAsync(logits_host, m->logits, (size_t) m->cfg.vocab * 4, hipMemcpyDeviceToHost, m->st)); HIP_TRY(hipStreamSynchronize(m->st)); }
+    return CLLM_OK;
+}
+
+// ---- greedy decode loop (sampler = std::max_element, src/models.cpp:676-690: first maximum wins) ------------------
+__global__ void __launch_bounds__(1024) k_argmax(const float * __restrict__ x, int n, int32_t * __restrict__ out) {
+    __shared__ float bv[16]; __shared__ int bi[16];
+    float best = -INFINITY; int idx = 0x7fffffff;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) { const float v = x[i]; if (v > best) { best = v; idx = i; } }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(best, o, 64); const int oi = __shfl_xor(idx, o, 64);
+        if (ov > best || (ov == best && oi < idx)) { best = ov; idx = oi; }
+    }
+    if ((threadIdx.x & 63) == 0) { bv[threadIdx.x >> 6] = best; bi[threadIdx.x >> 6] = idx; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < (int)(blockDim.x >> 6); w++) if (bv[w] > best || (bv[w] == best && bi[w] < idx)) { best = bv[w]; idx = bi[w]; }
+        out[0] = idx == 0x7fffffff ? 0 : idx;
+    }
+}
+
+extern "C" int cllm_llama_decode_greedy(cllm_llama * m, int32_t first_token, int n_past, int n_steps, int32_t * out_tokens_host) {
+    if (!m || n_steps <= 0 || !out_tokens_host) FAIL(CLLM_E_INVALID, "decode_greedy: arguments");
+    if ((int64_t) n_past + n_steps > m->cfg.max_len) FAIL(CLLM_E_INVALID, "decode_greedy: exceeds max_len");
+    TRY(finalize(m, 1));
+    int32_t tok = first_token;
+    for (int s = 0; s < n_steps; s++) {
+        const int32_t p = n_past + s;
+        HIP_TRY(hipMemcpyAsync(m->tokens_dev, &tok, 4, hipMemcpyHostToDevice, m->st));
+        HIP_TRY(hipMemcpyAsync(m->pos_dev, &p, 4, hipMemcpyHostToDevice, m->st));
+        HIP_TRY(hipStreamSynchronize(m->st));
+        TRY(forward_general(m, 1, p));
+        hipLaunchKernelGGL(k_argmax, dim3(1), dim3(1024), 0, m->st, m->logits, m->cfg.vocab, m->next_tok_dev);
+        LAUNCH_CHECK();
+        HIP_TRY(hipMemcpyAsync(&tok, m->next_tok_dev, 4, hipMemcpyDeviceToHost, m->st));
+        HIP_TRY(hipStreamSynchronize(m->st));
+        out_tokens_host[s] = tok;
+    }
+    return CLLM_OK;
+}

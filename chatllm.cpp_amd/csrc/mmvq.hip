@@ -1,0 +1,327 @@
+// mmvq.hip -- quantized mat-vec (decode GEMV, 1..8 activation columns) for Q4_K / Q4_0 / Q8_0 weights.
+//
+// Replaces the decode branch of ggml_compute_forward_mul_mat (ggml/src/ggml-cpu/ggml-cpu.c:1359-1421) and its
+// vec_dot kernels ggml_vec_dot_q4_K_q8_K / q4_0_q8_0 / q8_0_q8_0 (ggml-cpu/quants.c:550-623, 115-150, 305-333):
+// integer block dot products (exact), fp32 scale + accumulate.
+//
+// HBM-bound by construction: every weight byte is read exactly once with 16-byte loads, the quantized
+// activation row(s) live in LDS and are shared by all waves of the workgroup.  Algorithmic bytes per
+// launch = nrows * row_size(type, K) (+ the activation row, negligible).
+//
+// Work split
+//   Q4_K : a group of 8 lanes owns one 144-byte super-block per step: all 8 lanes fetch the 16-byte
+//          header {d, dmin, 12 packed 6-bit scales/mins} (one broadcast request), lane j fetches qs[16j..16j+15]
+//          (two 64-weight halves: low nibbles belong to sub-block 2*(j/2), high nibbles to 2*(j/2)+1) and
+//          owns min #j.  A wave therefore streams 8 consecutive super-blocks = 1152 contiguous bytes per step.
+//   Q4_0 / Q8_0 : one lane per 32-weight block (18 / 34 bytes, 2-byte aligned; gfx950 serves the
+//          misaligned dwordx4 directly), a wave streams 64 consecutive blocks per step.
+// One wave owns one weight row at a time; rows are dealt round-robin to the waves of the grid.
+#include "common.h"
+
+static int g_mmvq_wg = 256;      // threads per workgroup (tunable: CLLM_MMVQ_WG)
+static int g_mmvq_wgs_per_cu = 8; // grid cap (tunable: CLLM_MMVQ_OCC)
+
+// kernel arguments; `ids` != NULL turns the launch into MUL_MAT_ID: blockIdx.y enumerates (slot u, token t) pairs,
+// each with its own expert matrix (ggml-cpu.c:1432-1678).
+struct mmvq_args {
+    const char * W; int64_t nb01, nb02; int64_t nrows; int nblk;
+    const char * act; size_t act_stride;
+    float * dst; int64_t dst_cs;
+    const int32_t * ids; int64_t ids_s0, ids_s1;   // strides in int32 units
+    int n_used, b_ne1, n_as; int64_t dst_s1, dst_s2; // dst strides (floats) over (u, t)
+};
+
+__device__ __forceinline__ bool mmvq_select(const mmvq_args & a, const char *& W, const char *& act, float *& dst) {
+    W = a.W; act = a.act; dst = a.dst;
+    if (a.ids) {
+        const int u = blockIdx.y % a.n_used, t = blockIdx.y / a.n_used;
+        const int e = a.ids[u * a.ids_s0 + t * a.ids_s1];
+        if (e < 0 || e >= a.n_as) return false;      // the CPU asserts; we skip the column
+        W   += (int64_t) e * a.nb02;
+        act += ((int64_t)(u % a.b_ne1) + (int64_t) t * a.b_ne1) * a.act_stride;
+        dst += u * a.dst_s1 + t * a.dst_s2;
+    }
+    return true;
+}
+
+// ---- LDS staging of NC activation rows ---------------------------------------------------------------
+__device__ __forceinline__ void stage_act(char * lds, const char * __restrict__ act, size_t act_stride, size_t row_bytes, int nc) {
+    const int n16 = (int)(row_bytes / 16);
+    for (int c = 0; c < nc; c++) {
+        const u32x4 * s = (const u32x4 *)(act + c * act_stride);
+        u32x4 * d = (u32x4 *)(lds + c * row_bytes);
+        for (int i = threadIdx.x; i < n16; i += blockDim.x) d[i] = s[i];
+    }
+}
+
+// ---- Q4_K -----------------------------------------------------------------------------------------------
+template <int NC>
+__global__ void __launch_bounds__(512) k_mmvq_q4_K(const mmvq_args a) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const char * W; const char * act; float * dst;
+    if (!mmvq_select(a, W, act, dst)) return;
+    const int64_t nb01 = a.nb01, nrows = a.nrows, dst_cs = a.dst_cs; const int nblk = a.nblk; const size_t act_stride = a.act_stride;
+    const int64_t K = (int64_t) nblk * 256;
+    const size_t  rb = act_row_bytes(K, 256);
+    stage_act(lds, act, act_stride, rb, NC);
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63;
+    const int grp  = lane >> 3;            // which of the 8 super-blocks of this step
+    const int j    = lane & 7;             // which 16-byte slice of qs / which min
+    const int waves_per_wg = blockDim.x >> 6;
+    const int64_t wave0 = (int64_t) blockIdx.x * waves_per_wg + (threadIdx.x >> 6);
+    const int64_t nwaves = (int64_t) gridDim.x * waves_per_wg;
+
+    // lane-constant scale selectors (get_scale_min_k4, ggml-quants.c:703-711, after the utmp shuffle of quants.c:577-582)
+    const int sh16 = (j & 2) * 8;          // pair p=j/2: 16-bit field (p&1) of utmp[p>>1]
+    const int sh8  = (j & 3) * 8;          // min j: byte (j&3) of utmp[2 + (j>>2)]
+    const bool hi  = j >= 4;
+    const int a_off = 64 * (j >> 1) + 16 * (j & 1);     // activation bytes for the low-nibble half; +32 for the high half
+
+    for (int64_t row = wave0; row < nrows; row += nwaves) {
+        const char * wr = W + row * nb01;
+        float accd[NC], accm[NC];
+#pragma unroll
+        for (int c = 0; c < NC; c++) { accd[c] = 0.0f; accm[c] = 0.0f; }
+
+        for (int b0 = 0; b0 < nblk; b0 += 8) {
+            const int b = b0 + grp;
+            if (b < nblk) {
+                const char * bp = wr + (int64_t) b * 144;
+                const u32x4 h = *(const u32x4 *) bp;                 // d|dmin, scales[0..3], [4..7], [8..11]
+                const u32x4 q = *(const u32x4 *)(bp + 16 + 16 * j);
+                const float d    = h2f((uint16_t)(h.x & 0xffff));
+                const float dmin = h2f((uint16_t)(h.x >> 16));
+                // 6-bit unpack: u0 = sc[0..3], u1 = sc[4..7], u2 = m[0..3], u3 = m[4..7]
+                const uint32_t u0 = h.y & 0x3f3f3f3fu;
+                const uint32_t u2 = h.z & 0x3f3f3f3fu;
+                const uint32_t u1 = (h.w & 0x0f0f0f0fu) | (((h.y >> 6) & 0x03030303u) << 4);
+                const uint32_t u3 = ((h.w >> 4) & 0x0f0f0f0fu) | (((h.z >> 6) & 0x03030303u) << 4);
+                const uint32_t scp = (hi ? u1 : u0) >> sh16;
+                const int sc_lo = (int)(scp & 0xff), sc_hi = (int)((scp >> 8) & 0xff);
+                const int mj    = (int)(((hi ? u3 : u2) >> sh8) & 0xff);
+                const uint32_t ql[4] = { q.x & 0x0f0f0f0fu, q.y & 0x0f0f0f0fu, q.z & 0x0f0f0f0fu, q.w & 0x0f0f0f0fu };
+                const uint32_t qh[4] = { (q.x >> 4) & 0x0f0f0f0fu, (q.y >> 4) & 0x0f0f0f0fu, (q.z >> 4) & 0x0f0f0f0fu, (q.w >> 4) & 0x0f0f0f0fu };
+#pragma unroll
+                for (int c = 0; c < NC; c++) {
+                    const char * ar = lds + c * rb;
+                    const u32x4 al = *(const u32x4 *)(ar + b * 256 + a_off);
+                    const u32x4 ah = *(const u32x4 *)(ar + b * 256 + a_off + 32);
+                    const float yd = ((const float *)(ar + act_off_d(K)))[b];
+                    const int   ys = ((const int *)(ar + act_off_s(K, 256)))[b * 8 + j];
+                    int il = dot4(ql[0], al.x, 0); il = dot4(ql[1], al.y, il); il = dot4(ql[2], al.z, il); il = dot4(ql[3], al.w, il);
+                    int ih = dot4(qh[0], ah.x, 0); ih = dot4(qh[1], ah.y, ih); ih = dot4(qh[2], ah.z, ih); ih = dot4(qh[3], ah.w, ih);
+                    const int t = sc_lo * il + sc_hi * ih;
+                    accd[c] = __builtin_fmaf(d * yd, (float) t, accd[c]);
+                    accm[c] = __builtin_fmaf(dmin * yd, (float)(mj * ys), accm[c]);
+                }
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < NC; c++) {
+            const float r = wave_sum(accd[c]) - wave_sum(accm[c]);
+            if (lane == 0) dst[row + c * dst_cs] = r;
+        }
+    }
+}
+
+// ---- Q4_0 / Q8_0 (one lane per 32-weight block) ------------------------------------------------------------
+struct __attribute__((packed, aligned(2))) u16x8_u2 { uint32_t x, y, z, w; };
+
+template <int NC, bool IS_Q8>
+__global__ void __launch_bounds__(512) k_mmvq_q32(const mmvq_args a) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const char * W; const char * act; float * dst;
+    if (!mmvq_select(a, W, act, dst)) return;
+    const int64_t nb01 = a.nb01, nrows = a.nrows, dst_cs = a.dst_cs; const int nblk = a.nblk; const size_t act_stride = a.act_stride;
+    const int64_t K = (int64_t) nblk * 32;
+    const size_t  rb = act_row_bytes(K, 32);
+    stage_act(lds, act, act_stride, rb, NC);
+    __syncthreads();
+
+    constexpr int BS = IS_Q8 ? 34 : 18;
+    const int lane = threadIdx.x & 63;
+    const int waves_per_wg = blockDim.x >> 6;
+    const int64_t wave0 = (int64_t) blockIdx.x * waves_per_wg + (threadIdx.x >> 6);
+    const int64_t nwaves = (int64_t) gridDim.x * waves_per_wg;
+
+    for (int64_t row = wave0; row < nrows; row += nwaves) {
+        const char * wr = W + row * nb01;
+        float acc[NC];
+#pragma unroll
+        for (int c = 0; c < NC; c++) acc[c] = 0.0f;
+
+        for (int b0 = 0; b0 < nblk; b0 += 64) {
+            const int b = b0 + lane;
+            if (b < nblk) {
+                const char * bp = wr + (int64_t) b * BS;
+                const float d = h2f(*(const uint16_t *) bp);
+                const u16x8_u2 q0 = *(const u16x8_u2 *)(bp + 2);
+                if constexpr (IS_Q8) {
+                    const u16x8_u2 q1 = *(const u16x8_u2 *)(bp + 18);
+#pragma unroll
+                    for (int c = 0; c < NC; c++) {
+                        const char * ar = lds + c * rb;
+                        const u32x4 a0 = *(const u32x4 *)(ar + b * 32);
+                        const u32x4 a1 = *(const u32x4 *)(ar + b * 32 + 16);
+                        const float yd = ((const float *)(ar + act_off_d(K)))[b];
+                        int s = dot4(q0.x, a0.x, 0); s = dot4(q0.y, a0.y, s); s = dot4(q0.z, a0.z, s); s = dot4(q0.w, a0.w, s);
+                        s = dot4(q1.x, a1.x, s); s = dot4(q1.y, a1.y, s); s = dot4(q1.z, a1.z, s); s = dot4(q1.w, a1.w, s);
+                        acc[c] = __builtin_fmaf((float) s, d * yd, acc[c]);
+                    }
+                } else {
+                    const uint32_t ql[4] = { q0.x & 0x0f0f0f0fu, q0.y & 0x0f0f0f0fu, q0.z & 0x0f0f0f0fu, q0.w & 0x0f0f0f0fu };
+                    const uint32_t qh[4] = { (q0.x >> 4) & 0x0f0f0f0fu, (q0.y >> 4) & 0x0f0f0f0fu, (q0.z >> 4) & 0x0f0f0f0fu, (q0.w >> 4) & 0x0f0f0f0fu };
+#pragma unroll
+                    for (int c = 0; c < NC; c++) {
+                        const char * ar = lds + c * rb;
+                        const u32x4 a0 = *(const u32x4 *)(ar + b * 32);          // elements 0..15  <-> low nibbles
+                        const u32x4 a1 = *(const u32x4 *)(ar + b * 32 + 16);     // elements 16..31 <-> high nibbles
+                        const float yd = ((const float *)(ar + act_off_d(K)))[b];
+                        const int   ys = ((const int *)(ar + act_off_s(K, 32)))[b];
+                        int s = dot4(ql[0], a0.x, 0); s = dot4(ql[1], a0.y, s); s = dot4(ql[2], a0.z, s); s = dot4(ql[3], a0.w, s);
+                        s = dot4(qh[0], a1.x, s); s = dot4(qh[1], a1.y, s); s = dot4(qh[2], a1.z, s); s = dot4(qh[3], a1.w, s);
+                        s -= 8 * ys;                                             // sum (nib - 8) * y
+                        acc[c] = __builtin_fmaf((float) s, d * yd, acc[c]);
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < NC; c++) {
+            const float r = wave_sum(acc[c]);
+            if (lane == 0) dst[row + c * dst_cs] = r;
+        }
+    }
+}
+
+// ---- exact integer sums (tier T0 KAT) -------------------------------------------------------------------------
+__global__ void k_isums(int wtype, int64_t K, const char * __restrict__ w, const char * __restrict__ act, int32_t * __restrict__ out) {
+    const int64_t b = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    const int8_t * aq = (const int8_t *) act;
+    if (wtype == CLLM_TYPE_Q4_K) {
+        if (b >= K / 256) return;
+        const block_q4_K * x = (const block_q4_K *) w + b;
+        const int32_t * ss = (const int32_t *)(act + act_off_s(K, 256));
+        int tot = 0, mins = 0;
+        for (int s = 0; s < 8; s++) {
+            int sc, m;
+            if (s < 4) { sc = x->scales[s] & 63; m = x->scales[s + 4] & 63; }
+            else { sc = (x->scales[s + 4] & 0xF) | ((x->scales[s - 4] >> 6) << 4); m = (x->scales[s + 4] >> 4) | ((x->scales[s] >> 6) << 4); }
+            int dsum = 0;
+            for (int l = 0; l < 32; l++) {
+                const uint8_t qb = x->qs[(s >> 1) * 32 + l];
+                const int q = (s & 1) ? (qb >> 4) : (qb & 0xF);
+                dsum += q * aq[b * 256 + s * 32 + l];
+            }
+            tot += sc * dsum;
+            mins += m * ss[b * 8 + s];
+        }
+        out[2 * b] = tot; out[2 * b + 1] = mins;
+    } else {
+        if (b >= K / 32) return;
+        int s = 0;
+        if (wtype == CLLM_TYPE_Q8_0) {
+            const block_q8_0 * x = (const block_q8_0 *) w + b;
+            for (int l = 0; l < 32; l++) s += x->qs[l] * aq[b * 32 + l];
+        } else {
+            const block_q4_0 * x = (const block_q4_0 *) w + b;
+            for (int l = 0; l < 16; l++) { s += ((x->qs[l] & 0xF) - 8) * aq[b * 32 + l]; s += ((x->qs[l] >> 4) - 8) * aq[b * 32 + l + 16]; }
+        }
+        out[b] = s;
+    }
+}
+
+extern "C" int cllm_vec_dot_isums(void * stream, int wtype, int64_t k, const void * w_row, const float * x, int32_t * isums) {
+    hipStream_t st = (hipStream_t) stream;
+    const int kb = wtype == CLLM_TYPE_Q4_K ? 256 : 32;
+    if (wtype != CLLM_TYPE_Q4_K && wtype != CLLM_TYPE_Q4_0 && wtype != CLLM_TYPE_Q8_0) FAIL(CLLM_E_UNSUPPORTED, "vec_dot_isums: type %d", wtype);
+    if (k <= 0 || k % kb) FAIL(CLLM_E_INVALID, "vec_dot_isums: k");
+    void * act = nullptr;
+    const size_t bytes = act_row_bytes(k, kb);
+    HIP_TRY(hipMalloc(&act, bytes));
+    tview s; s.data = (char *) x; s.ne[0] = k; s.ne[1] = s.ne[2] = s.ne[3] = 1; s.nb[0] = 4; s.nb[1] = s.nb[2] = s.nb[3] = k * 4;
+    int rc = launch_quantize_act(st, kb, s, act, bytes);
+    if (rc == CLLM_OK) {
+        const int64_t nb = k / kb;
+        hipLaunchKernelGGL(k_isums, dim3((unsigned)((nb + 63) / 64)), dim3(64), 0, st, wtype, k, (const char *) w_row, (const char *) act, isums);
+        rc = cllm_hip_check(hipGetLastError(), "k_isums", __FILE__, __LINE__);
+    }
+    (void) hipStreamSynchronize(st);
+    (void) hipFree(act);
+    return rc;
+}
+
+// ---- host launcher ---------------------------------------------------------------------------------------------
+static void mmvq_tunables() {
+    static bool done = false;
+    if (done) return;
+    done = true;
+    if (const char * e = getenv("CLLM_MMVQ_WG"))  { int v = atoi(e); if (v == 64 || v == 128 || v == 256 || v == 512) g_mmvq_wg = v; }
+    if (const char * e = getenv("CLLM_MMVQ_OCC")) { int v = atoi(e); if (v >= 1 && v <= 32) g_mmvq_wgs_per_cu = v; }
+}
+
+template <typename KernelT>
+static int launch_one(hipStream_t st, KernelT kern, size_t lds_bytes, const mmvq_args & a, int grid_y) {
+    mmvq_tunables();
+    const int wg = g_mmvq_wg, wpw = wg / 64;
+    int64_t grid = (a.nrows + wpw - 1) / wpw;
+    int64_t cap = (int64_t) device_cu_count() * g_mmvq_wgs_per_cu / grid_y;
+    if (cap < 1) cap = 1;
+    if (grid > cap) grid = cap;
+    if (lds_bytes > 64 * 1024) HIP_TRY(hipFuncSetAttribute((const void *) kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    hipLaunchKernelGGL(kern, dim3((unsigned) grid, (unsigned) grid_y), dim3(wg), lds_bytes, st, a);
+    LAUNCH_CHECK();
+    return CLLM_OK;
+}
+
+static int mmvq_dispatch(hipStream_t st, int wtype, int nc, size_t lds, const mmvq_args & a, int grid_y) {
+#define GO(KERN) return launch_one(st, KERN, lds, a, grid_y)
+    if (wtype == CLLM_TYPE_Q4_K)      { if (nc == 4) GO(k_mmvq_q4_K<4>); else if (nc == 2) GO(k_mmvq_q4_K<2>); else GO(k_mmvq_q4_K<1>); }
+    else if (wtype == CLLM_TYPE_Q8_0) { if (nc == 4) GO((k_mmvq_q32<4, true>));  else if (nc == 2) GO((k_mmvq_q32<2, true>));  else GO((k_mmvq_q32<1, true>)); }
+    else if (wtype == CLLM_TYPE_Q4_0) { if (nc == 4) GO((k_mmvq_q32<4, false>)); else if (nc == 2) GO((k_mmvq_q32<2, false>)); else GO((k_mmvq_q32<1, false>)); }
+#undef GO
+    FAIL(CLLM_E_UNSUPPORTED, "mmvq: weight type %d", wtype);
+}
+
+// w: [K, nrows] quant rows (dims 2,3 handled by the caller), act: ncols rows of act layout, dst: column c at dst.data + c*nb1
+int launch_mmvq(hipStream_t st, int wtype, const tview & w, const void * act, size_t act_stride, int64_t ncols,
+                const tview & /*src1_geom*/, const tview & dst) {
+    const int64_t K = w.ne[0];
+    const int kb = wtype == CLLM_TYPE_Q4_K ? 256 : 32;
+    const size_t rb = act_row_bytes(K, kb);
+    if (dst.nb[1] % 4) FAIL(CLLM_E_INVALID, "mmvq: dst stride");
+    mmvq_args a = {};
+    a.W = w.data; a.nb01 = w.nb[1]; a.nb02 = w.nb[2]; a.nrows = w.ne[1]; a.nblk = (int)(K / kb);
+    a.act_stride = act_stride; a.dst_cs = dst.nb[1] / 4;
+    int64_t c = 0;
+    while (c < ncols) {
+        int nc = ncols - c >= 4 ? 4 : (ncols - c >= 2 ? 2 : 1);
+        while (nc > 1 && (size_t) nc * rb > 160 * 1024) nc >>= 1;
+        if ((size_t) nc * rb > 160 * 1024) FAIL(CLLM_E_UNSUPPORTED, "mmvq: K=%lld does not fit LDS", (long long) K);
+        a.act = (const char *) act + c * act_stride;
+        a.dst = (float *)(dst.data + c * dst.nb[1]);
+        const int rc = mmvq_dispatch(st, wtype, nc, (size_t) nc * rb, a, 1);
+        if (rc) return rc;
+        c += nc;
+    }
+    return CLLM_OK;
+}
+
+// MUL_MAT_ID for few tokens: one grid.y slice per (slot, token), expert picked on the device from ids
+int launch_mmvq_id(hipStream_t st, int wtype, const tview & as, const void * act, size_t act_stride, int64_t b_ne1,
+                   const tview & ids, const tview & dst) {
+    const int64_t K = as.ne[0];
+    const int kb = wtype == CLLM_TYPE_Q4_K ? 256 : 32;
+    const size_t rb = act_row_bytes(K, kb);
+    if (rb > 160 * 1024) FAIL(CLLM_E_UNSUPPORTED, "mmvq_id: K=%lld does not fit LDS", (long long) K);
+    const int64_t n_used = ids.ne[0], n_tok = ids.ne[1];
+    if (n_used * n_tok > 65535) FAIL(CLLM_E_UNSUPPORTED, "mmvq_id: too many (slot, token) pairs");
+    mmvq_args a = {};
+    a.W = as.data; a.nb01 = as.nb[1]; a.nb02 = as.nb[2]; a.nrows = as.ne[1]; a.nblk = (int)(K / kb);
+    a.act = (const char *) act; a.act_stride = act_stride; a.dst = (float *) dst.data; a.dst_cs = 0;
+    a.ids = (const int32_t *) ids.data; a.ids_s0 = ids.nb[0] / 4; a.ids_s1 = ids.nb[1] / 4;
+    a.n_used = (int) n_used; a.b_ne1 = (int) b_ne1; a.n_as = (int) as.ne[2]; a.dst_s1 = dst.nb[1] / 4; a.dst_s2 = dst.nb[2] / 4;
+    return mmvq_dispatch(st, wtype, 1, rb, a, (int)(n_used * n_tok));
+}

@@ -1,0 +1,410 @@
+// ops.hip -- the non-matmul nodes of one chatllm.cpp forward graph, written for gfx950.
+// Each kernel cites the reference CPU function whose arithmetic (operation order, rounding points,
+// accumulation width) it reproduces; see include/chatllm_hip.h for the op contracts.
+#include "common.h"
+
+#include <math.h>
+
+// ================================================================================================
+// RMS_NORM (+ MUL)      ggml_compute_forward_rms_norm_f32, ggml-cpu/ops.cpp:3710-3759
+//   sum of x*x in double, mean -> float, scale = 1/sqrtf(mean+eps), y = x*scale   [, y *= w as a second rounding]
+// one workgroup per row; HBM/L2-bound, float4 traffic.
+// ================================================================================================
+template <bool MUL>
+__global__ void __launch_bounds__(256) k_rms_norm(tview s, tview d, const float * __restrict__ w, int64_t w_ne0, float eps) {
+    const int64_t row = blockIdx.x;
+    const int64_t i1 = row % s.ne[1], i2 = (row / s.ne[1]) % s.ne[2], i3 = row / (s.ne[1] * s.ne[2]);
+    const float * x = (const float *)(s.data + i1*s.nb[1] + i2*s.nb[2] + i3*s.nb[3]);
+    float *       y = (float *)(d.data + i1*d.nb[1] + i2*d.nb[2] + i3*d.nb[3]);
+    const int64_t n = s.ne[0];
+    double sum = 0.0;
+    for (int64_t i = threadIdx.x; i < n; i += blockDim.x) { const float v = x[i]; sum += (double)(v * v); }
+    sum = wave_sum_d(sum);
+    __shared__ double part[4];
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = sum;
+    __syncthreads();
+    sum = part[0] + part[1] + part[2] + part[3];
+    const float mean  = (float)(sum / (double) n);
+    const float scale = 1.0f / sqrtf(mean + eps);
+    for (int64_t i = threadIdx.x; i < n; i += blockDim.x) {
+        float v = x[i] * scale;
+        if (MUL) v = v * w[i % w_ne0];
+        y[i] = v;
+    }
+}
+
+static int rms_norm_impl(void * stream, const cllm_tensor * src, const cllm_tensor * weight, cllm_tensor * dst, float eps) {
+    if (!src || !dst) FAIL(CLLM_E_INVALID, "rms_norm: null");
+    if (src->type != CLLM_TYPE_F32 || dst->type != CLLM_TYPE_F32) FAIL(CLLM_E_UNSUPPORTED, "rms_norm: type");
+    if (!t_same_shape(src, dst) || src->nb[0] != 4 || dst->nb[0] != 4) FAIL(CLLM_E_INVALID, "rms_norm: shape");
+    if (weight && (weight->type != CLLM_TYPE_F32 || weight->nb[0] != 4 || weight->ne[0] != src->ne[0] || t_nrows(weight) != 1))
+        FAIL(CLLM_E_UNSUPPORTED, "rms_norm_mul: weight must be a dense F32 [ne0] vector");
+    const int64_t rows = t_nrows(src);
+    if (rows == 0 || src->ne[0] == 0) return CLLM_OK;
+    hipStream_t st = (hipStream_t) stream;
+    if (weight) hipLaunchKernelGGL(k_rms_norm<true>,  dim3((unsigned) rows), dim3(256), 0, st, tv(src), tv(dst), (const float *) weight->data, weight->ne[0], eps);
+    else        hipLaunchKernelGGL(k_rms_norm<false>, dim3((unsigned) rows), dim3(256), 0, st, tv(src), tv(dst), (const float *) nullptr, (int64_t) 1, eps);
+    LAUNCH_CHECK();
+    return CLLM_OK;
+}
+extern "C" int cllm_op_rms_norm(void * stream, const cllm_tensor * src, cllm_tensor * dst, float eps) { return rms_norm_impl(stream, src, nullptr, dst, eps); }
+extern "C" int cllm_op_rms_norm_mul(void * stream, const cllm_tensor * src, const cllm_tensor * weight, cllm_tensor * dst, float eps) {
+    if (!weight) FAIL(CLLM_E_INVALID, "rms_norm_mul: null weight");
+    return rms_norm_impl(stream, src, weight, dst, eps);
+}
+
+// ================================================================================================
+// ROPE        ggml_compute_forward_rope_flt<float>, ggml-cpu/ops.cpp:5589-5865
+//   theta_i built by ITERATED fp32 multiplication (theta *= theta_scale), cos/sin per (token, pair),
+//   YaRN mixing (rope_yarn :5596-5611).  One workgroup per token: the first n_dims/2 threads build
+//   the cos/sin cache in LDS, then all threads rotate that token's heads.  In-place safe.
+// ================================================================================================
+struct rope_k_params { int n_dims, mode; float theta_scale, freq_scale, ext_factor, attn_factor, corr0, corr1; };
+
+__global__ void __launch_bounds__(256) k_rope(tview s, tview d, const int32_t * __restrict__ pos, const float * __restrict__ ff, rope_k_params p) {
+    extern __shared__ float cache[];                 // [n_dims]: cos, sin interleaved
+    const int64_t i2 = blockIdx.x % s.ne[2], i3 = blockIdx.x / s.ne[2];
+    const int half = p.n_dims / 2;
+    for (int i = threadIdx.x; i < half; i += blockDim.x) {
+        float theta = (float) pos[i2];
+        for (int k = 0; k < i; k++) theta *= p.theta_scale;
+        const float f = ff ? ff[i] : 1.0f;
+        const float theta_extrap = theta / f;
+        const float theta_interp = p.freq_scale * theta_extrap;
+        float th = theta_interp, mscale = p.attn_factor;
+        if (p.ext_factor != 0.0f) {
+            const float y = ((float) i - p.corr0) / fmaxf(0.001f, p.corr1 - p.corr0);      // i == i0/2
+            const float ramp = (1.0f - fminf(1.0f, fmaxf(0.0f, y))) * p.ext_factor;
+            th = theta_interp * (1 - ramp) + theta_extrap * ramp;
+            mscale *= 1.0f + 0.1f * logf(1.0f / p.freq_scale);
+        }
+        cache[2*i]     = cosf(th) * mscale;
+        cache[2*i + 1] = sinf(th) * mscale;
+    }
+    __syncthreads();
+    const int64_t ne0 = s.ne[0], nh = s.ne[1];
+    const int64_t off = p.mode == 0 ? 1 : half;
+    // rotated pairs
+    for (int64_t t = threadIdx.x; t < nh * half; t += blockDim.x) {
+        const int64_t h = t / half; const int i = (int)(t % half);
+        const float * x = (const float *)(s.data + h*s.nb[1] + i2*s.nb[2] + i3*s.nb[3]);
+        float *       y = (float *)(d.data + h*d.nb[1] + i2*d.nb[2] + i3*d.nb[3]);
+        const int64_t ic = p.mode == 0 ? 2*i : i;
+        const float c = cache[2*i], sn = cache[2*i + 1];
+        const float x0 = x[ic], x1 = x[ic + off];
+        y[ic]       = x0*c - x1*sn;
+        y[ic + off] = x0*sn + x1*c;
+    }
+    // pass-through channels
+    if (p.n_dims < ne0 && s.data != d.data) {
+        const int64_t rest = ne0 - p.n_dims;
+        for (int64_t t = threadIdx.x; t < nh * rest; t += blockDim.x) {
+            const int64_t h = t / rest, i0 = p.n_dims + t % rest;
+            *(float *)(d.data + i0*4 + h*d.nb[1] + i2*d.nb[2] + i3*d.nb[3]) = *(const float *)(s.data + i0*4 + h*s.nb[1] + i2*s.nb[2] + i3*s.nb[3]);
+        }
+    }
+}
+
+static float rope_corr_dim(int n_dims, int n_ctx_orig, float n_rot, float base) {       // ggml.c ggml_rope_yarn_corr_dim
+    return n_dims * logf(n_ctx_orig / (n_rot * 2 * (float) M_PI)) / (2 * logf(base));
+}
+
+extern "C" int cllm_op_rope(void * stream, const cllm_tensor * src, const cllm_tensor * pos, const cllm_tensor * freq_factors,
+                            cllm_tensor * dst, const cllm_rope_params * p) {
+    if (!src || !pos || !dst || !p) FAIL(CLLM_E_INVALID, "rope: null");
+    if (src->type != CLLM_TYPE_F32 || dst->type != CLLM_TYPE_F32 || pos->type != CLLM_TYPE_I32) FAIL(CLLM_E_UNSUPPORTED, "rope: type");
+    if (p->mode != 0 && p->mode != 2) FAIL(CLLM_E_UNSUPPORTED, "rope: mode %d", p->mode);
+    if (!t_same_shape(src, dst) || src->nb[0] != 4 || dst->nb[0] != 4) FAIL(CLLM_E_INVALID, "rope: shape");
+    if (p->n_dims > src->ne[0] || (p->n_dims & 1) || p->n_dims <= 0) FAIL(CLLM_E_INVALID, "rope: n_dims");
+    if (pos->ne[0] < src->ne[2]) FAIL(CLLM_E_INVALID, "rope: pos shorter than sequence");
+    if (freq_factors && (freq_factors->type != CLLM_TYPE_F32 || freq_factors->ne[0] < p->n_dims / 2)) FAIL(CLLM_E_INVALID, "rope: freq_factors");
+    if (t_nelements(src) == 0) return CLLM_OK;
+    rope_k_params k;
+    k.n_dims = p->n_dims; k.mode = p->mode;
+    k.theta_scale = powf(p->freq_base, -2.0f / p->n_dims);
+    k.freq_scale = p->freq_scale; k.ext_factor = p->ext_factor; k.attn_factor = p->attn_factor;
+    const float start = floorf(rope_corr_dim(p->n_dims, p->n_ctx_orig, p->beta_fast, p->freq_base));
+    const float end   = ceilf (rope_corr_dim(p->n_dims, p->n_ctx_orig, p->beta_slow, p->freq_base));
+    k.corr0 = fmaxf(0.0f, start); k.corr1 = fminf((float)(p->n_dims - 1), end);
+    hipLaunchKernelGGL(k_rope, dim3((unsigned)(src->ne[2] * src->ne[3])), dim3(256), (size_t) p->n_dims * 4, (hipStream_t) stream,
+                       tv(src), tv(dst), (const int32_t *) pos->data, freq_factors ? (const float *) freq_factors->data : nullptr, k);
+    LAUNCH_CHECK();
+    return CLLM_OK;
+}
+
+// ================================================================================================
+// SOFT_MAX (+ SCALE + DIAG_MASK_INF)   ggml_compute_forward_soft_max_f32 ops.cpp:5225-5335,
+//   ggml_vec_soft_max_f32 vec.cpp:547- (groups of 8 through ggml_v_expf, f32 tree hsum, total in double; expf tail)
+// one wave per row; lane handles groups of 8 consecutive elements (the CPU's AVX2 vector), so the
+// exponentials AND the per-group partial sums are bit-identical to the CPU's.
+// ================================================================================================
+template <int MODE>   // 0: plain (+scale, +mask tensor)   1: fused scale + causal mask(n_past)
+__global__ void __launch_bounds__(256) k_soft_max(tview s, tview d, const char * __restrict__ mask, int mask_f16, int64_t m_nb1, int64_t m_nb2, int64_t m_nb3,
+                                                  int64_t m_ne2, int64_t m_ne3, float scale, int n_past) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t) blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int64_t nrows = s.ne[1] * s.ne[2] * s.ne[3];
+    if (row >= nrows) return;
+    const int64_t i1 = row % s.ne[1], i2 = (row / s.ne[1]) % s.ne[2], i3 = row / (s.ne[1] * s.ne[2]);
+    const float * x = (const float *)(s.data + i1*s.nb[1] + i2*s.nb[2] + i3*s.nb[3]);
+    float *       y = (float *)(d.data + i1*d.nb[1] + i2*d.nb[2] + i3*d.nb[3]);
+    const char * mp = mask ? mask + i1*m_nb1 + (i2 % m_ne2)*m_nb2 + (i3 % m_ne3)*m_nb3 : nullptr;
+    const int64_t n = s.ne[0];
+
+    auto val = [&](int64_t i) -> float {
+        float v = x[i] * scale;
+        if (MODE == 1) { if (i > (int64_t) n_past + i1) v = -INFINITY; }
+        else if (mp)   { v += 1.0f * (mask_f16 ? h2f(((const uint16_t *) mp)[i]) : ((const float *) mp)[i]); }
+        return v;
+    };
+    float mx = -INFINITY;
+    for (int64_t i = lane; i < n; i += 64) mx = fmaxf(mx, val(i));
+    mx = wave_max(mx);
+
+    const int64_t nv = n & ~(int64_t) 7;
+    double sum = 0.0;
+    for (int64_t g = (int64_t) lane * 8; g < nv; g += 64 * 8) {
+        float e[8];
+#pragma unroll
+        for (int l = 0; l < 8; l++) { e[l] = ggml_expf_poly(val(g + l) - mx); y[g + l] = e[l]; }
+        const float a0 = e[0] + e[4], a1 = e[1] + e[5], a2 = e[2] + e[6], a3 = e[3] + e[7];
+        sum += (double)((a0 + a2) + (a1 + a3));
+    }
+    if (lane == 0) for (int64_t i = nv; i < n; i++) { const float e = expf(val(i) - mx); y[i] = e; sum += (double) e; }
+    sum = wave_sum_d(sum);
+    const float inv = (float)(1.0 / sum);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");   // e[] written by other lanes of this wave
+    for (int64_t i = lane; i < n; i += 64) y[i] = y[i] * inv;
+}
+
+static int soft_max_impl(void * stream, const cllm_tensor * src, const cllm_tensor * mask, cllm_tensor * dst, float scale, int fused, int n_past) {
+    if (!src || !dst) FAIL(CLLM_E_INVALID, "soft_max: null");
+    if (src->type != CLLM_TYPE_F32 || dst->type != CLLM_TYPE_F32) FAIL(CLLM_E_UNSUPPORTED, "soft_max: type");
+    if (!t_same_shape(src, dst) || src->nb[0] != 4 || dst->nb[0] != 4) FAIL(CLLM_E_INVALID, "soft_max: shape");
+    if (mask) {
+        if (mask->type != CLLM_TYPE_F32 && mask->type != CLLM_TYPE_F16) FAIL(CLLM_E_UNSUPPORTED, "soft_max: mask type");
+        if (mask->ne[0] != src->ne[0] || mask->ne[1] < src->ne[1] || src->ne[2] % mask->ne[2] || src->ne[3] % mask->ne[3]) FAIL(CLLM_E_INVALID, "soft_max: mask shape");
+    }
+    const int64_t rows = t_nrows(src);
+    if (rows == 0 || src->ne[0] == 0) return CLLM_OK;
+    const unsigned grid = (unsigned)((rows + 3) / 4);
+    hipStream_t st = (hipStream_t) stream;
+    if (fused) hipLaunchKernelGGL(k_soft_max<1>, dim3(grid), dim3(256), 0, st, tv(src), tv(dst), (const char *) nullptr, 0, (int64_t) 0, (int64_t) 0, (int64_t) 0, (int64_t) 1, (int64_t) 1, scale, n_past);
+    else       hipLaunchKernelGGL(k_soft_max<0>, dim3(grid), dim3(256), 0, st, tv(src), tv(dst), mask ? (const char *) mask->data : nullptr, mask && mask->type == CLLM_TYPE_F16 ? 1 : 0,
+                                  mask ? (int64_t) mask->nb[1] : 0, mask ? (int64_t) mask->nb[2] : 0, mask ? (int64_t) mask->nb[3] : 0, mask ? mask->ne[2] : 1, mask ? mask->ne[3] : 1, scale, 0);
+    LAUNCH_CHECK();
+    return CLLM_OK;
+}
+extern "C" int cllm_op_soft_max(void * stream, const cllm_tensor * src, const cllm_tensor * mask, cllm_tensor * dst, float scale, float max_bias) {
+    if (max_bias != 0.0f) FAIL(CLLM_E_UNSUPPORTED, "soft_max: ALiBi (max_bias != 0) is not on this path");
+    return soft_max_impl(stream, src, mask, dst, scale, 0, 0);
+}
+extern "C" int cllm_op_scale_mask_soft_max(void * stream, const cllm_tensor * src, cllm_tensor * dst, float scale, int n_past) {
+    if (n_past < 0) FAIL(CLLM_E_INVALID, "soft_max: n_past");
+    return soft_max_impl(stream, src, nullptr, dst, scale, 1, n_past);
+}
+
+// ================================================================================================
+// element-wise family: generic strided, one thread per element of dst, index decomposed over ne[]
+// ================================================================================================
+enum { EW_DIAG_MASK = 0, EW_SCALE = 1, EW_SILU = 2, EW_ADD = 3, EW_MUL = 4, EW_SILU_MUL = 5 };
+
+template <int OP>
+__global__ void __launch_bounds__(256) k_elementwise(tview a, tview b, tview d, float f0, float f1, int i0p) {
+    const int64_t n = d.ne[0] * d.ne[1] * d.ne[2] * d.ne[3];
+    for (int64_t e = (int64_t) blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t) gridDim.x * blockDim.x) {
+        int64_t r = e;
+        const int64_t i0 = r % d.ne[0]; r /= d.ne[0];
+        const int64_t i1 = r % d.ne[1]; r /= d.ne[1];
+        const int64_t i2 = r % d.ne[2]; const int64_t i3 = r / d.ne[2];
+        const float x = *(const float *)(a.data + i0*a.nb[0] + i1*a.nb[1] + i2*a.nb[2] + i3*a.nb[3]);
+        float y;
+        if (OP == EW_DIAG_MASK)      y = (i0 > (int64_t) i0p + i1) ? -INFINITY : x;      // ops.cpp:5137-5185
+        else if (OP == EW_SCALE)     y = (f1 == 0.0f) ? x * f0 : x * f0 + f1;            // ggml_vec_scale_f32 / ggml_vec_mad1_f32
+        else if (OP == EW_SILU) {
+            // ggml_vec_silu_f32 (vec.cpp:396-431): AVX2 body for i0 < (ne0 & ~7), scalar expf tail
+            y = (i0 < (d.ne[0] & ~(int64_t) 7)) ? x / (1.0f + ggml_expf_poly(0.0f - x)) : x / (1.0f + expf(-x));
+        } else {
+            const float z = *(const float *)(b.data + (i0 % b.ne[0])*b.nb[0] + (i1 % b.ne[1])*b.nb[1] + (i2 % b.ne[2])*b.nb[2] + (i3 % b.ne[3])*b.nb[3]);
+            if (OP == EW_ADD)      y = x + z;
+            else if (OP == EW_MUL) y = x * z;
+            else {                                                                          // silu(gate) * up
+                const float sl = (i0 < (d.ne[0] & ~(int64_t) 7)) ? x / (1.0f + ggml_expf_poly(0.0f - x)) : x / (1.0f + expf(-x));
+                y = sl * z;
+            }
+        }
+        *(float *)(d.data + i0*d.nb[0] + i1*d.nb[1] + i2*d.nb[2] + i3*d.nb[3]) = y;
+    }
+}
+
+template <int OP>
+static int ew_launch(void * stream, const cllm_tensor * a, const cllm_tensor * b, cllm_tensor * d, float f0, float f1, int ip, const char * name) {
+    if (!a || !d) FAIL(CLLM_E_INVALID, "%s: null", name);
+    if (a->type != CLLM_TYPE_F32 || d->type != CLLM_TYPE_F32 || (b && b->type != CLLM_TYPE_F32)) FAIL(CLLM_E_UNSUPPORTED, "%s: type", name);
+    if (!t_same_shape(a, d)) FAIL(CLLM_E_INVALID, "%s: shape", name);
+    if (b) for (int i = 0; i < 4; i++) if (b->ne[i] <= 0 || a->ne[i] % b->ne[i]) FAIL(CLLM_E_INVALID, "%s: src1 not broadcastable", name);
+    const int64_t n = t_nelements(d);
+    if (n == 0) return CLLM_OK;
+    int64_t grid = (n + 255) / 256;
+    if (grid > 8192) grid = 8192;
+    hipLaunchKernelGGL(k_elementwise<OP>, dim3((unsigned) grid), dim3(256), 0, (hipStream_t) stream, tv(a), b ? tv(b) : tv(a), tv(d), f0, f1, ip);
+    LAUNCH_CHECK();
+    return CLLM_OK;
+}
+extern "C" int cllm_op_diag_mask_inf(void * stream, const cllm_tensor * src, cllm_tensor * dst, int n_past) {
+    if (n_past < 0) FAIL(CLLM_E_INVALID, "diag_mask_inf: n_past");
+    return ew_launch<EW_DIAG_MASK>(stream, src, nullptr, dst, 0, 0, n_past, "diag_mask_inf");
+}
+extern "C" int cllm_op_scale(void * stream, const cllm_tensor * src, cllm_tensor * dst, float s, float b) { return ew_launch<EW_SCALE>(stream, src, nullptr, dst, s, b, 0, "scale"); }
+extern "C" int cllm_op_unary(void * stream, int op, const cllm_tensor * src, cllm_tensor * dst) {
+    if (op != CLLM_UNARY_SILU) FAIL(CLLM_E_UNSUPPORTED, "unary: op %d", op);
+    if (src && dst && (src->nb[0] != 4 || dst->nb[0] != 4)) FAIL(CLLM_E_UNSUPPORTED, "unary: rows must be dense");
+    return ew_launch<EW_SILU>(stream, src, nullptr, dst, 0, 0, 0, "silu");
+}
+extern "C" int cllm_op_add(void * stream, const cllm_tensor * a, const cllm_tensor * b, cllm_tensor * dst) { if (!b) FAIL(CLLM_E_INVALID, "add: null"); return ew_launch<EW_ADD>(stream, a, b, dst, 0, 0, 0, "add"); }
+extern "C" int cllm_op_mul(void * stream, const cllm_tensor * a, const cllm_tensor * b, cllm_tensor * dst) { if (!b) FAIL(CLLM_E_INVALID, "mul: null"); return ew_launch<EW_MUL>(stream, a, b, dst, 0, 0, 0, "mul"); }
+extern "C" int cllm_op_silu_mul(void * stream, const cllm_tensor * g, const cllm_tensor * u, cllm_tensor * dst) { if (!u) FAIL(CLLM_E_INVALID, "silu_mul: null"); return ew_launch<EW_SILU_MUL>(stream, g, u, dst, 0, 0, 0, "silu_mul"); }
+
+// ================================================================================================
+// SET_ROWS (K-cache write)   ggml_compute_forward_set_rows_f32, ops.cpp:4892-4940
+// ================================================================================================
+template <typename IDX, bool F16>
+__global__ void __launch_bounds__(256) k_set_rows(tview s, tview idx, tview d) {
+    const int64_t n = s.ne[0] * s.ne[1] * s.ne[2] * s.ne[3];
+    for (int64_t e = (int64_t) blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t) gridDim.x * blockDim.x) {
+        int64_t r = e;
+        const int64_t c  = r % s.ne[0]; r /= s.ne[0];
+        const int64_t i  = r % s.ne[1]; r /= s.ne[1];
+        const int64_t i2 = r % s.ne[2]; const int64_t i3 = r / s.ne[2];
+        const int64_t row = (int64_t) *(const IDX *)(idx.data + i*idx.nb[0] + (i2 % idx.ne[1])*idx.nb[1] + (i3 % idx.ne[2])*idx.nb[2]);
+        if (row < 0 || row >= d.ne[1]) continue;     // the CPU asserts; never write out of bounds
+        const float v = *(const float *)(s.data + c*4 + i*s.nb[1] + i2*s.nb[2] + i3*s.nb[3]);
+        char * dp = d.data + row*d.nb[1] + i2*d.nb[2] + i3*d.nb[3];
+        if (F16) ((uint16_t *) dp)[c] = f2h(v); else ((float *) dp)[c] = v;
+    }
+}
+extern "C" int cllm_op_set_rows(void * stream, const cllm_tensor * src, const cllm_tensor * idx, cllm_tensor * dst) {
+    if (!src || !idx || !dst) FAIL(CLLM_E_INVALID, "set_rows: null");
+    if (src->type != CLLM_TYPE_F32 || (dst->type != CLLM_TYPE_F16 && dst->type != CLLM_TYPE_F32)) FAIL(CLLM_E_UNSUPPORTED, "set_rows: type");
+    if (idx->type != CLLM_TYPE_I32 && idx->type != CLLM_TYPE_I64) FAIL(CLLM_E_UNSUPPORTED, "set_rows: index type");
+    if (dst->ne[0] != src->ne[0] || dst->ne[2] != src->ne[2] || dst->ne[3] != src->ne[3] || src->nb[0] != 4 || dst->nb[0] != cllm_type_size(dst->type)) FAIL(CLLM_E_INVALID, "set_rows: shape");
+    if (idx->ne[0] != src->ne[1] || src->ne[2] % idx->ne[1] || src->ne[3] % idx->ne[2]) FAIL(CLLM_E_INVALID, "set_rows: index shape");
+    const int64_t n = t_nelements(src);
+    if (n == 0) return CLLM_OK;
+    int64_t grid = (n + 255) / 256; if (grid > 8192) grid = 8192;
+    hipStream_t st = (hipStream_t) stream;
+    const bool f16 = dst->type == CLLM_TYPE_F16, i64 = idx->type == CLLM_TYPE_I64;
+    if (f16 && !i64)       hipLaunchKernelGGL((k_set_rows<int32_t, true>),  dim3((unsigned) grid), dim3(256), 0, st, tv(src), tv(idx), tv(dst));
+    else if (f16 && i64)   hipLaunchKernelGGL((k_set_rows<int64_t, true>),  dim3((unsigned) grid), dim3(256), 0, st, tv(src), tv(idx), tv(dst));
+    else if (!f16 && !i64) hipLaunchKernelGGL((k_set_rows<int32_t, false>), dim3((unsigned) grid), dim3(256), 0, st, tv(src), tv(idx), tv(dst));
+    else                   hipLaunchKernelGGL((k_set_rows<int64_t, false>), dim3((unsigned) grid), dim3(256), 0, st, tv(src), tv(idx), tv(dst));
+    LAUNCH_CHECK();
+    return CLLM_OK;
+}
+
+// ================================================================================================
+// CPY / DUP / CONT    ggml_compute_forward_dup, ops.cpp:47-330,526: element e of src (row-major over ne) -> element e of dst
+// ================================================================================================
+template <typename TS, typename TD>
+__global__ void __launch_bounds__(256) k_cpy(tview s, tview d) {
+    const int64_t n = s.ne[0] * s.ne[1] * s.ne[2] * s.ne[3];
+    for (int64_t e = (int64_t) blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t) gridDim.x * blockDim.x) {
+        int64_t r = e;
+        const int64_t s0 = r % s.ne[0]; r /= s.ne[0];
+        const int64_t s1 = r % s.ne[1]; r /= s.ne[1];
+        const int64_t s2 = r % s.ne[2]; const int64_t s3 = r / s.ne[2];
+        r = e;
+        const int64_t d0 = r % d.ne[0]; r /= d.ne[0];
+        const int64_t d1 = r % d.ne[1]; r /= d.ne[1];
+        const int64_t d2 = r % d.ne[2]; const int64_t d3 = r / d.ne[2];
+        const TS v = *(const TS *)(s.data + s0*s.nb[0] + s1*s.nb[1] + s2*s.nb[2] + s3*s.nb[3]);
+        TD o;
+        if constexpr (sizeof(TS) == sizeof(TD)) o = (TD) v;
+        else if constexpr (sizeof(TS) == 4) o = f2h(v);          // F32 -> F16, RNE
+        else o = h2f(v);                                         // F16 -> F32
+        *(TD *)(d.data + d0*d.nb[0] + d1*d.nb[1] + d2*d.nb[2] + d3*d.nb[3]) = o;
+    }
+}
+extern "C" int cllm_op_cpy(void * stream, const cllm_tensor * src, cllm_tensor * dst) {
+    if (!src || !dst) FAIL(CLLM_E_INVALID, "cpy: null");
+    const bool s32 = src->type == CLLM_TYPE_F32 || src->type == CLLM_TYPE_I32, s16 = src->type == CLLM_TYPE_F16;
+    const bool d32 = dst->type == CLLM_TYPE_F32 || dst->type == CLLM_TYPE_I32, d16 = dst->type == CLLM_TYPE_F16;
+    if (!(s32 || s16) || !(d32 || d16)) FAIL(CLLM_E_UNSUPPORTED, "cpy: type %d -> %d", src->type, dst->type);
+    if ((src->type == CLLM_TYPE_I32) != (dst->type == CLLM_TYPE_I32)) FAIL(CLLM_E_UNSUPPORTED, "cpy: I32 only to I32");
+    if (t_nelements(src) != t_nelements(dst)) FAIL(CLLM_E_INVALID, "cpy: element count");
+    const int64_t n = t_nelements(src);
+    if (n == 0) return CLLM_OK;
+    int64_t grid = (n + 255) / 256; if (grid > 16384) grid = 16384;
+    hipStream_t st = (hipStream_t) stream;
+    if (s32 && d32)      hipLaunchKernelGGL((k_cpy<uint32_t, uint32_t>), dim3((unsigned) grid), dim3(256), 0, st, tv(src), tv(dst));
+    else if (s16 && d16) hipLaunchKernelGGL((k_cpy<uint16_t, uint16_t>), dim3((unsigned) grid), dim3(256), 0, st, tv(src), tv(dst));
+    else if (s32 && d16) hipLaunchKernelGGL((k_cpy<float, uint16_t>),    dim3((unsigned) grid), dim3(256), 0, st, tv(src), tv(dst));
+    else                 hipLaunchKernelGGL((k_cpy<uint16_t, float>),    dim3((unsigned) grid), dim3(256), 0, st, tv(src), tv(dst));
+    LAUNCH_CHECK();
+    return CLLM_OK;
+}
+
+// ================================================================================================
+// GET_ROWS / dequantize    ops.cpp:4653-4700,4820 ; dequantize_row_* ggml-quants.c:307-325,401-414,1352-1373
+// ================================================================================================
+__device__ __forceinline__ float dequant_elem(int type, const char * row, int64_t i) {
+    switch (type) {
+        case CLLM_TYPE_F32: return ((const float *) row)[i];
+        case CLLM_TYPE_F16: return h2f(((const uint16_t *) row)[i]);
+        case CLLM_TYPE_Q8_0: { const block_q8_0 * b = (const block_q8_0 *) row + i / 32; return (float) b->qs[i % 32] * h2f(b->d); }
+        case CLLM_TYPE_Q4_0: {
+            const block_q4_0 * b = (const block_q4_0 *) row + i / 32; const int j = (int)(i % 32);
+            const int q = j < 16 ? (b->qs[j] & 0xF) : (b->qs[j - 16] >> 4);
+            return (float)(q - 8) * h2f(b->d);
+        }
+        case CLLM_TYPE_Q4_K: {
+            const block_q4_K * b = (const block_q4_K *) row + i / 256; const int e = (int)(i % 256);
+            const int s = e / 32, l = e % 32;
+            int sc, m;
+            if (s < 4) { sc = b->scales[s] & 63; m = b->scales[s + 4] & 63; }
+            else { sc = (b->scales[s + 4] & 0xF) | ((b->scales[s - 4] >> 6) << 4); m = (b->scales[s + 4] >> 4) | ((b->scales[s] >> 6) << 4); }
+            const uint8_t qb = b->qs[(s >> 1) * 32 + l];
+            const int q = (s & 1) ? (qb >> 4) : (qb & 0xF);
+            const float d1 = h2f(b->d) * (float) sc, m1 = h2f(b->dmin) * (float) m;     // d*sc and min*m rounded first (ggml-quants.c:1364-1367)
+            return d1 * (float) q - m1;
+        }
+    }
+    return 0.0f;
+}
+__global__ void __launch_bounds__(256) k_get_rows(int type, tview s, tview idx, tview d) {
+    const int64_t n = d.ne[0] * d.ne[1] * d.ne[2] * d.ne[3];
+    for (int64_t e = (int64_t) blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t) gridDim.x * blockDim.x) {
+        int64_t r = e;
+        const int64_t c   = r % d.ne[0]; r /= d.ne[0];
+        const int64_t i10 = r % d.ne[1]; r /= d.ne[1];
+        const int64_t i11 = r % d.ne[2]; const int64_t i12 = r / d.ne[2];
+        const int64_t row = *(const int32_t *)(idx.data + i10*idx.nb[0] + i11*idx.nb[1] + i12*idx.nb[2]);
+        float v = 0.0f;
+        if (row >= 0 && row < s.ne[1]) v = dequant_elem(type, s.data + row*s.nb[1] + i11*s.nb[2] + i12*s.nb[3], c);
+        *(float *)(d.data + c*4 + i10*d.nb[1] + i11*d.nb[2] + i12*d.nb[3]) = v;
+    }
+}
+extern "C" int cllm_op_get_rows(void * stream, const cllm_tensor * src, const cllm_tensor * idx, cllm_tensor * dst) {
+    if (!src || !idx || !dst) FAIL(CLLM_E_INVALID, "get_rows: null");
+    if (idx->type != CLLM_TYPE_I32 || dst->type != CLLM_TYPE_F32) FAIL(CLLM_E_UNSUPPORTED, "get_rows: type");
+    switch (src->type) { case CLLM_TYPE_F32: case CLLM_TYPE_F16: case CLLM_TYPE_Q4_0: case CLLM_TYPE_Q8_0: case CLLM_TYPE_Q4_K: break; default: FAIL(CLLM_E_UNSUPPORTED, "get_rows: src type %d", src->type); }
+    if (dst->ne[0] != src->ne[0] || dst->ne[1] != idx->ne[0] || dst->ne[2] != idx->ne[1] || dst->ne[3] != idx->ne[2] || dst->nb[0] != 4) FAIL(CLLM_E_INVALID, "get_rows: shape");
+    const int64_t n = t_nelements(dst);
+    if (n == 0) return CLLM_OK;
+    int64_t grid = (n + 255) / 256; if (grid > 8192) grid = 8192;
+    hipLaunchKernelGGL(k_get_rows, dim3((unsigned) grid), dim3(256), 0, (hipStream_t) stream, src->type, tv(src), tv(idx), tv(dst));
+    LAUNCH_CHECK();
+    return CLLM_OK;
+}
+extern "C" int cllm_dequantize_row(void * stream, int type, const void * blocks, float * y, int64_t k) {
+    if (!blocks || !y || k <= 0) FAIL(CLLM_E_INVALID, "dequantize_row: args");
+    const int bs = cllm_blck_size(type);
+    if (bs == 0 || k % bs) FAIL(CLLM_E_INVALID, "dequantize_row: k");
+    // a 1-row table gathered with index 0
+    static thread_local int32_t * zero_idx = nullptr;
+    if (!zero_idx) { HIP_TRY(hipMalloc((void **) &zero_idx, 4)); HIP_TRY(hipMemset(zero_idx, 0, 4)); }
+    cllm_tensor s = { type, {k, 1, 1, 1}, {cllm_type_size(type), cllm_row_size(type, k), cllm_row_size(type, k), cllm_row_size(type, k)}, (void *) blocks };
+    cllm_tensor i = { CLLM_TYPE_I32, {1, 1, 1, 1}, {4, 4, 4, 4}, zero_idx };
+    cllm_tensor d = { CLLM_TYPE_F32, {k, 1, 1, 1}, {4, (size_t) k*4, (size_t) k*4, (size_t) k*4}, y };
+    return cllm_op_get_rows(stream, &s, &i, &d);
+}

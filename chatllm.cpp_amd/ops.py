@@ -1,0 +1,148 @@
+"""Operator surface of the hot path, named after the reference's `chatllm::ggml::*` wrappers
+(src/layers.h:41-304; bodies src/layers.cpp:602-614, 893-983, 1062-1107).  Each function
+allocates its result like the ggml op constructor would and launches the HIP kernel through
+the C ABI.  Everything runs on the default stream; results are device `Tensor`s.
+"""
+import ctypes as C
+
+from . import lib as _l
+from .tensor import Tensor, F32, F16, I32, I64, Buffer  # noqa: F401
+
+ROPE_NORMAL, ROPE_NEOX = 0, 2
+UNARY_SILU = 10
+
+_wdata = {"buf": None}
+
+
+def _scratch(nbytes):
+    b = _wdata["buf"]
+    if b is None or b.nbytes < nbytes:
+        _wdata["buf"] = b = Buffer(max(nbytes, 1 << 20))
+    return b
+
+
+def _ref(t):
+    return C.byref(t.c()) if t is not None else None
+
+
+def mul_mat(a, b, dst=None):
+    """ggml::mul_mat(ctx, a, b): dst[ne01, ne11, ne12, ne13] = a^T . b"""
+    L = _l.get()
+    if dst is None:
+        dst = Tensor(F32, [a.ne[1], b.ne[1], b.ne[2], b.ne[3]])
+    ca, cb, cd = a.c(), b.c(), dst.c()
+    ws = L.cllm_mul_mat_wsize(C.byref(ca), C.byref(cb))
+    buf = _scratch(ws) if ws else None
+    _l.check(L.cllm_op_mul_mat(None, C.byref(ca), C.byref(cb), C.byref(cd), buf.ptr if buf else None, buf.nbytes if buf else 0), "mul_mat")
+    return dst
+
+
+def mul_mat_id(as_, b, ids, dst=None):
+    """ggml::mul_mat_id(ctx, as, b, ids)"""
+    L = _l.get()
+    if dst is None:
+        dst = Tensor(F32, [as_.ne[1], ids.ne[0], b.ne[2], 1])
+    ca, cb, ci, cd = as_.c(), b.c(), ids.c(), dst.c()
+    ws = L.cllm_mul_mat_wsize(C.byref(ca), C.byref(cb))
+    buf = _scratch(ws)
+    _l.check(L.cllm_op_mul_mat_id(None, C.byref(ca), C.byref(cb), C.byref(ci), C.byref(cd), buf.ptr, buf.nbytes), "mul_mat_id")
+    return dst
+
+
+def rms_norm(a, eps, dst=None):
+    dst = dst or Tensor(F32, a.ne)
+    _l.check(_l.get().cllm_op_rms_norm(None, _ref(a), _ref(dst), eps), "rms_norm")
+    return dst
+
+
+def rms_norm_mul(a, weight, eps, dst=None):
+    """RMSNorm::forward: rms_norm then mul by the weight vector"""
+    dst = dst or Tensor(F32, a.ne)
+    _l.check(_l.get().cllm_op_rms_norm_mul(None, _ref(a), _ref(weight), _ref(dst), eps), "rms_norm_mul")
+    return dst
+
+
+def rope_ext(a, pos, freq_factors, n_dims, mode, n_ctx_orig=0, freq_base=10000.0, freq_scale=1.0, ext_factor=0.0,
+             attn_factor=1.0, beta_fast=0.0, beta_slow=0.0, inplace=False):
+    """ggml::rope_ext / rope_ext_inplace"""
+    dst = a if inplace else Tensor(F32, a.ne)
+    p = _l.RopeParams(n_dims, mode, n_ctx_orig, freq_base, freq_scale, ext_factor, attn_factor, beta_fast, beta_slow)
+    _l.check(_l.get().cllm_op_rope(None, _ref(a), _ref(pos), _ref(freq_factors), _ref(dst), C.byref(p)), "rope")
+    return dst
+
+
+def soft_max(a, dst=None):
+    return soft_max_ext(a, None, 1.0, 0.0, dst)
+
+
+def soft_max_ext(a, mask, scale, max_bias, dst=None):
+    dst = dst or Tensor(F32, a.ne)
+    _l.check(_l.get().cllm_op_soft_max(None, _ref(a), _ref(mask), _ref(dst), scale, max_bias), "soft_max")
+    return dst
+
+
+def diag_mask_inf(a, n_past, dst=None):
+    dst = dst or Tensor(F32, a.ne)
+    _l.check(_l.get().cllm_op_diag_mask_inf(None, _ref(a), _ref(dst), n_past), "diag_mask_inf")
+    return dst
+
+
+def scale(a, s, b=0.0, dst=None):
+    dst = dst or Tensor(F32, a.ne)
+    _l.check(_l.get().cllm_op_scale(None, _ref(a), _ref(dst), s, b), "scale")
+    return dst
+
+
+def scale_mask_soft_max(a, scale_, n_past, dst=None):
+    dst = dst or Tensor(F32, a.ne)
+    _l.check(_l.get().cllm_op_scale_mask_soft_max(None, _ref(a), _ref(dst), scale_, n_past), "scale_mask_soft_max")
+    return dst
+
+
+def silu(a, dst=None):
+    dst = dst or Tensor(F32, a.ne)
+    _l.check(_l.get().cllm_op_unary(None, UNARY_SILU, _ref(a), _ref(dst)), "silu")
+    return dst
+
+
+def add(a, b, dst=None):
+    dst = dst or Tensor(F32, a.ne)
+    _l.check(_l.get().cllm_op_add(None, _ref(a), _ref(b), _ref(dst)), "add")
+    return dst
+
+
+def mul(a, b, dst=None):
+    dst = dst or Tensor(F32, a.ne)
+    _l.check(_l.get().cllm_op_mul(None, _ref(a), _ref(b), _ref(dst)), "mul")
+    return dst
+
+
+def silu_mul(g, u, dst=None):
+    dst = dst or Tensor(F32, g.ne)
+    _l.check(_l.get().cllm_op_silu_mul(None, _ref(g), _ref(u), _ref(dst)), "silu_mul")
+    return dst
+
+
+def set_rows(dst, src, idx):
+    """ggml::set_rows(ctx, a=dst, c=idx, b=src): writes into dst (a view of the KV cache)"""
+    _l.check(_l.get().cllm_op_set_rows(None, _ref(src), _ref(idx), _ref(dst)), "set_rows")
+    return dst
+
+
+def cpy(src, dst):
+    _l.check(_l.get().cllm_op_cpy(None, _ref(src), _ref(dst)), "cpy")
+    return dst
+
+
+def cont(a):
+    return cpy(a, Tensor(a.type, a.ne))
+
+
+def get_rows(a, idx, dst=None):
+    dst = dst or Tensor(F32, [a.ne[0], idx.ne[0], idx.ne[1], idx.ne[2]])
+    _l.check(_l.get().cllm_op_get_rows(None, _ref(a), _ref(idx), _ref(dst)), "get_rows")
+    return dst
+
+
+def sync():
+    _l.check(_l.get().cllm_stream_sync(None), "sync")

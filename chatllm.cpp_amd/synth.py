@@ -1,0 +1,168 @@
+"""Synthetic models at real shapes: weights are generated directly as reference-format quant
+blocks (no float master, no network), SURVEY.md 8d.  Deterministic per tensor name, so any
+subset (one layer for the CPU baseline, a tensor-parallel shard) can be regenerated identically.
+
+Block layouts: /root/reference/ggml/src/ggml-common.h:170-175 (Q4_0), 219-224 (Q8_0), 295-306 (Q4_K).
+"""
+import zlib
+
+import numpy as np
+
+from .tensor import F32, Q4_0, Q8_0, Q4_K, TYPE_SIZE, BLCK  # noqa: F401
+
+CONFIGS = {
+    # name: n_layer, hidden, n_head, n_kv_head, head_dim, ffn, vocab
+    "tiny":        dict(n_layer=2,  hidden=256,  n_head=4,  n_kv_head=2, head_dim=64,  ffn=512,   vocab=320),
+    "small":       dict(n_layer=4,  hidden=1024, n_head=8,  n_kv_head=2, head_dim=128, ffn=2816,  vocab=2048),   # ffn % 256 == 0
+    "gpt2s-llama": dict(n_layer=12, hidden=768,  n_head=12, n_kv_head=12, head_dim=64, ffn=3072,  vocab=50304),  # BASELINE cfg1 stand-in
+    "llama3-8b":   dict(n_layer=32, hidden=4096, n_head=32, n_kv_head=8, head_dim=128, ffn=14336, vocab=128256),
+    "qwen2-72b":   dict(n_layer=80, hidden=8192, n_head=64, n_kv_head=8, head_dim=128, ffn=29568, vocab=152064, qkv_bias=1, rope_mode=2, rope_theta=1e6),
+}
+
+
+def config(name, max_len=1024, **over):
+    c = dict(rope_mode=0, rope_theta=500000.0, rms_eps=1e-5, qkv_bias=0, max_len=max_len)
+    c.update(CONFIGS[name])
+    c.update(over)
+    return c
+
+
+def _rng(seed, name):
+    return np.random.default_rng([seed, zlib.crc32(name.encode())])
+
+
+def _f16_bytes(x):
+    return np.asarray(x, np.float16).view(np.uint8)
+
+
+def quant_blocks(type_, rows, K, rng, sigma):
+    """random already-quantized rows [rows][K/blk] with dequantized std ~ sigma; returns uint8 [rows, row_bytes]"""
+    nb = K // BLCK[type_]
+    if type_ == Q8_0:
+        out = np.empty((rows, nb, 34), np.uint8)
+        d = rng.uniform(0.5, 1.5, (rows, nb)) * sigma / 42.0            # int8 ~ N(0, 42^2)
+        out[:, :, 0:2] = _f16_bytes(d).reshape(rows, nb, 2)
+        q = np.clip(np.rint(rng.standard_normal((rows, nb, 32), np.float32) * 42.0), -127, 127).astype(np.int8)
+        out[:, :, 2:] = q.view(np.uint8)
+    elif type_ == Q4_0:
+        out = np.empty((rows, nb, 18), np.uint8)
+        d = rng.uniform(0.5, 1.5, (rows, nb)) * sigma / 2.5             # (nib - 8) ~ N(0, 2.5^2)
+        out[:, :, 0:2] = _f16_bytes(d).reshape(rows, nb, 2)
+        nib = np.clip(np.rint(rng.standard_normal((rows, nb, 32), np.float32) * 2.5 + 8.0), 0, 15).astype(np.uint8)
+        out[:, :, 2:] = nib[:, :, :16] | (nib[:, :, 16:] << 4)
+    elif type_ == Q4_K:
+        out = np.empty((rows, nb, 144), np.uint8)
+        sc = rng.integers(20, 64, (rows, nb, 8), dtype=np.uint8)        # 6-bit sub-block scales
+        # w = d*sc*q - dmin*m ; choose dmin = 8 d and m ~ sc*7.5/8 so that the weights are ~zero-mean
+        m = np.clip(np.rint(sc.astype(np.float32) * (7.5 / 8.0)), 0, 63).astype(np.uint8)
+        d = rng.uniform(0.5, 1.5, (rows, nb)) * sigma / (42.0 * 2.5)
+        out[:, :, 0:2] = _f16_bytes(d).reshape(rows, nb, 2)
+        out[:, :, 2:4] = _f16_bytes(d * 8.0).reshape(rows, nb, 2)
+        s = out[:, :, 4:16]                                             # inverse of get_scale_min_k4 (ggml-quants.c:703-711)
+        s[:, :, 0:4] = (sc[:, :, 0:4] & 63) | ((sc[:, :, 4:8] >> 4) << 6)
+        s[:, :, 4:8] = (m[:, :, 0:4] & 63) | ((m[:, :, 4:8] >> 4) << 6)
+        s[:, :, 8:12] = (sc[:, :, 4:8] & 0xF) | ((m[:, :, 4:8] & 0xF) << 4)
+        nib = np.clip(np.rint(rng.standard_normal((rows, nb, 256), np.float32) * 2.5 + 7.5), 0, 15).astype(np.uint8)
+        nib = nib.reshape(rows, nb, 4, 2, 32)                           # 4 groups of 64: low nibbles then high nibbles
+        out[:, :, 16:] = (nib[:, :, :, 0, :] | (nib[:, :, :, 1, :] << 4)).reshape(rows, nb, 128)
+    else:
+        raise ValueError(type_)
+    return out.reshape(rows, nb * TYPE_SIZE[type_])
+
+
+def down_type(cfg, wtype):
+    """the reference falls back to Q8_0 when a row is not a multiple of 256 (convert.py:811-829, src/layers.cpp:81-95)"""
+    return Q8_0 if (wtype == Q4_K and cfg["ffn"] % 256) else wtype
+
+
+def tensor_list(cfg, wtype, tp_rank=0, tp_size=1):
+    """[(name, type, rows, K, row_slice)] of one (shard of a) model; row_slice selects the tensor-parallel rows"""
+    H, hd, F, V = cfg["hidden"], cfg["head_dim"], cfg["ffn"], cfg["vocab"]
+    QD, KD = cfg["n_head"] * hd, cfg["n_kv_head"] * hd
+    out = [("tok_embd", wtype, V, H), ("lm_head", wtype, V, H)]
+    for i in range(cfg["n_layer"]):
+        p = f"layers.{i}."
+        out += [(p + "wq", wtype, QD, H), (p + "wk", wtype, KD, H), (p + "wv", wtype, KD, H), (p + "wo", wtype, H, QD),
+                (p + "wgate", wtype, F, H), (p + "wup", wtype, F, H), (p + "wdown", down_type(cfg, wtype), H, F)]
+    return out
+
+
+def make_tensor(name, type_, rows, K, seed=1234):
+    return quant_blocks(type_, rows, K, _rng(seed, name), 1.0 / np.sqrt(K))
+
+
+def make_norm(name, H, seed=1234):
+    return (1.0 + 0.02 * _rng(seed, name).standard_normal(H)).astype(np.float32)
+
+
+def make_bias(name, n, seed=1234):
+    return (0.02 * _rng(seed, name).standard_normal(n)).astype(np.float32)
+
+
+def make_model(cfg, wtype, seed=1234, layers=None):
+    """dict name -> (type, numpy array) for the whole model (or only `layers`); small configs only on the host"""
+    w = {}
+    keep = None if layers is None else {f"layers.{i}." for i in layers}
+    for name, t, rows, K in tensor_list(cfg, wtype):
+        if keep is not None and name.startswith("layers.") and not any(name.startswith(k) for k in keep):
+            continue
+        w[name] = (t, make_tensor(name, t, rows, K, seed))
+    H = cfg["hidden"]
+    w["out_norm"] = (F32, make_norm("out_norm", H, seed))
+    for i in (range(cfg["n_layer"]) if layers is None else layers):
+        p = f"layers.{i}."
+        w[p + "attn_norm"] = (F32, make_norm(p + "attn_norm", H, seed))
+        w[p + "ffn_norm"] = (F32, make_norm(p + "ffn_norm", H, seed))
+        if cfg.get("qkv_bias"):
+            hd = cfg["head_dim"]
+            w[p + "bq"] = (F32, make_bias(p + "bq", cfg["n_head"] * hd, seed))
+            w[p + "bk"] = (F32, make_bias(p + "bk", cfg["n_kv_head"] * hd, seed))
+            w[p + "bv"] = (F32, make_bias(p + "bv", cfg["n_kv_head"] * hd, seed))
+    return w
+
+
+def weight_bytes_per_token(cfg, wtype):
+    """algorithmic weight bytes one decoded token touches: all layer matrices + lm_head + norms"""
+    total = 0
+    for name, t, rows, K in tensor_list(cfg, wtype):
+        if name == "tok_embd":
+            continue
+        total += rows * (K // BLCK[t]) * TYPE_SIZE[t]
+    total += (2 * cfg["n_layer"] + 1) * cfg["hidden"] * 4
+    return total
+
+
+def kv_bytes_per_token(cfg, n_ctx):
+    """F16 K and V read for n_ctx cached positions + one position written, all layers"""
+    kd = cfg["n_kv_head"] * cfg["head_dim"]
+    return cfg["n_layer"] * 2 * kd * 2 * (n_ctx + 1)
+
+
+def fast_blocks(type_, rows, K, rng, sigma):
+    """bench-size generator (GB/s instead of MB/s): uniformly random payload bytes, sane fp16 scale fields.
+    Dequantized std ~ sigma (uniform nibbles / int8 instead of rounded normals)."""
+    nb = K // BLCK[type_]
+    bs = TYPE_SIZE[type_]
+    out = rng.integers(0, 256, (rows, nb, bs), dtype=np.uint8)
+    # one random fp16 scale per block from a small table (cheap): +-25 % around the target
+    if type_ == Q8_0:
+        base = sigma / 73.9            # uniform int8 std
+    elif type_ == Q4_0:
+        base = sigma / 4.61            # uniform nibble std
+    else:
+        base = sigma / (4.61 * 32.0)   # nibble std x mean 6-bit scale
+    table = (base * np.linspace(0.75, 1.25, 256)).astype(np.float16).view(np.uint16)
+    sel = out[:, :, 0].copy()
+    d = table[sel]
+    out[:, :, 0] = (d & 0xff).astype(np.uint8)
+    out[:, :, 1] = (d >> 8).astype(np.uint8)
+    if type_ == Q4_K:
+        # dmin = 7.5 d: with independent 6-bit scales and mins the sub-block offsets average out
+        dm = (base * 7.5 * np.linspace(0.75, 1.25, 256)).astype(np.float16).view(np.uint16)[sel]
+        out[:, :, 2] = (dm & 0xff).astype(np.uint8)
+        out[:, :, 3] = (dm >> 8).astype(np.uint8)
+    return out.reshape(rows, nb * bs)
+
+
+def make_tensor_fast(name, type_, rows, K, seed=1234):
+    return fast_blocks(type_, rows, K, _rng(seed, name), 1.0 / np.sqrt(K))

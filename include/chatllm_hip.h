@@ -1,0 +1,194 @@
+/*
+ * chatllm_hip.h -- C ABI of the MI355X (gfx950) kernel library `libchatllm_hip.so`.
+ *
+ * This is the drop-in boundary for chatllm.cpp's transformer forward hot path.
+ * Every entry point takes plain pointers / sizes / POD structs; no C++ or torch types.
+ * All `data` pointers are DEVICE pointers; `stream` is a hipStream_t passed as void* (NULL = the
+ * default stream).  Functions return 0 (CLLM_OK) or a negative cllm_status; they never throw
+ * and never fall back to a CPU path: an unsupported type/shape is CLLM_E_UNSUPPORTED so the
+ * caller (ggml's scheduler, via supports_op) can route the node elsewhere.
+ *
+ * Two callers bind it:
+ *   1. host/ggml_backend_hip.cpp -- a ggml backend module (ggml_backend_init() + the five vtables of
+ *      /root/reference/ggml/src/ggml-backend-impl.h:11-251) whose graph_compute walks a ggml_cgraph
+ *      and maps each node 1:1 onto the cllm_op_* functions below.  That is what the unmodified
+ *      chatllm.cpp host (src/backend.cpp:277-302, --ggml_dir) loads as libggml-hip.so.
+ *   2. chatllm.cpp_amd/ (Python, ctypes) -- tests and bench.
+ *
+ * The tensor descriptor mirrors struct ggml_tensor's {type, ne, nb, data}
+ * (/root/reference/ggml/include/ggml.h:656-688): ne[0] is the contiguous (row) dimension,
+ * nb[] are byte strides, quantized rows are arrays of blocks (ggml-common.h:170-175,219-224,295-306).
+ */
+#ifndef CHATLLM_HIP_H
+#define CHATLLM_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CLLM_API __attribute__((visibility("default")))
+
+typedef enum cllm_status {
+    CLLM_OK            =  0,
+    CLLM_E_INVALID     = -1,   /* bad shapes / null pointers              (ggml: GGML_ASSERT)            */
+    CLLM_E_UNSUPPORTED = -2,   /* type/stride combination not implemented (ggml: supports_op == false)   */
+    CLLM_E_HIP         = -3,   /* HIP runtime error, see cllm_last_error  (ggml: GGML_STATUS_FAILED)     */
+    CLLM_E_ALLOC       = -4,   /* out of device memory                    (ggml: GGML_STATUS_ALLOC_FAILED) */
+} cllm_status;
+
+/* numeric values == enum ggml_type (ggml.h:386-428) so descriptors can be filled by a cast */
+typedef enum cllm_type {
+    CLLM_TYPE_F32 = 0, CLLM_TYPE_F16 = 1, CLLM_TYPE_Q4_0 = 2, CLLM_TYPE_Q8_0 = 8, CLLM_TYPE_Q4_K = 12,
+    CLLM_TYPE_I32 = 26, CLLM_TYPE_I64 = 27,
+} cllm_type;
+
+typedef struct cllm_tensor {
+    int32_t type;        /* cllm_type */
+    int64_t ne[4];       /* elements per dimension */
+    size_t  nb[4];       /* byte strides */
+    void *  data;        /* device pointer (already offset for views) */
+} cllm_tensor;
+
+/* ---- library / device ------------------------------------------------------------------- */
+CLLM_API int          cllm_abi_version(void);                 /* == 1 */
+CLLM_API int          cllm_device_count(void);
+CLLM_API int          cllm_set_device(int device);
+CLLM_API int          cllm_device_info(int device, char * name, size_t name_len, size_t * mem_free, size_t * mem_total,
+                                       int * n_cu);           /* device_i.get_description/get_memory */
+CLLM_API const char * cllm_last_error(void);                   /* thread-local message of the last failure */
+CLLM_API size_t       cllm_type_size(int type);                /* ggml_type_size */
+CLLM_API int          cllm_blck_size(int type);                /* ggml_blck_size */
+CLLM_API size_t       cllm_row_size(int type, int64_t ne);     /* ggml_row_size  */
+
+/* ---- memory / streams (buffer_i + backend_i plumbing: ggml-backend-impl.h:41-66, 87-127) --- */
+CLLM_API int  cllm_malloc(void ** ptr, size_t size);           /* buffer_type_i.alloc_buffer  */
+CLLM_API int  cllm_free(void * ptr);                           /* buffer_i.free_buffer        */
+CLLM_API int  cllm_memset(void * dst, int value, size_t size, void * stream);            /* memset_tensor / clear */
+CLLM_API int  cllm_memcpy_h2d(void * dst, const void * src, size_t size, void * stream); /* set_tensor[_async] */
+CLLM_API int  cllm_memcpy_d2h(void * dst, const void * src, size_t size, void * stream); /* get_tensor[_async] */
+CLLM_API int  cllm_memcpy_d2d(void * dst, const void * src, size_t size, void * stream); /* cpy_tensor        */
+CLLM_API int  cllm_stream_create(void ** stream);
+CLLM_API int  cllm_stream_destroy(void * stream);
+CLLM_API int  cllm_stream_sync(void * stream);                 /* backend_i.synchronize */
+/* events on a stream (backend_i.event_record / device_i.event_synchronize); elapsed in milliseconds */
+CLLM_API int  cllm_event_create(void ** event);
+CLLM_API int  cllm_event_destroy(void * event);
+CLLM_API int  cllm_event_record(void * event, void * stream);
+CLLM_API int  cllm_event_sync(void * event);
+CLLM_API int  cllm_event_elapsed_ms(void * start, void * stop, float * ms);
+
+/* ---- the hot path: GGML_OP_MUL_MAT ------------------------------------------------------
+ * replaces ggml_compute_forward_mul_mat (ggml/src/ggml-cpu/ggml-cpu.c:1229-1421) and, for Q4_0/Q8_0
+ * with ne11 >= 2, llamafile_sgemm (ggml-cpu/llamafile/sgemm.cpp:3676-3696):
+ *   dst[ne01, ne11, ne12, ne13] (F32) = src0^T . src1,   src0 broadcast over dims 2,3.
+ * src0: Q4_0 | Q8_0 | Q4_K (rows dense, any nb[1..3]) | F16 | F32 (any strides with nb[0]==elt size);
+ * src1: F32.  Numerics follow the CPU path: src1 rows are quantized on the device to the weight
+ * type's vec_dot_type (Q8_0: id=127/amax, round-half-even, arch/x86/quants.c:290-345;  Q8_K:
+ * ggml-quants.c:2555-2592;  F16: RNE), block dot products are exact int32, scaling/accumulation fp32.
+ * `wdata` is scratch for the converted src1 (ggml's params->wdata): at least cllm_mul_mat_wsize() bytes.
+ */
+CLLM_API size_t cllm_mul_mat_wsize(const cllm_tensor * src0, const cllm_tensor * src1);
+CLLM_API int    cllm_op_mul_mat(void * stream, const cllm_tensor * src0, const cllm_tensor * src1, cllm_tensor * dst,
+                                void * wdata, size_t wsize);
+
+/* measurement hook for bench.py's "roofline" object: quantizes src1 once, then times `iters` launches of ONLY the
+ * mat-mul kernel between two HIP events on `stream`, cycling src0->data through src0_datas[0..n_src0) (distinct
+ * copies of the weights, so the Infinity Cache cannot serve them).  avg_us = average kernel launch duration. */
+CLLM_API int    cllm_bench_mul_mat_kernel(void * stream, const cllm_tensor * src0, void * const * src0_datas, int n_src0,
+                                          const cllm_tensor * src1, cllm_tensor * dst, void * wdata, size_t wsize, int iters, float * avg_us);
+
+/* GGML_OP_MUL_MAT_ID -- ggml_compute_forward_mul_mat_id (ggml-cpu.c:1432-1678), chatllm MultiLinear::forward
+ * (src/layers.cpp:2145-2151):  dst[:, s, t] = as[:, :, ids[s,t]]^T . b[:, s % b.ne1, t]              */
+CLLM_API int    cllm_op_mul_mat_id(void * stream, const cllm_tensor * as, const cllm_tensor * b, const cllm_tensor * ids,
+                                   cllm_tensor * dst, void * wdata, size_t wsize);
+
+/* the activation quantizers on their own (KAT surface).  Output is in the reference block layout
+ * (block_q8_0 34 B / block_q8_K 292 B) so it can be compared byte-for-byte. */
+CLLM_API int    cllm_quantize_row_q8_0(void * stream, const float * x, void * y_blocks, int64_t k);   /* arch/x86/quants.c:290 */
+CLLM_API int    cllm_quantize_row_q8_K(void * stream, const float * x, void * y_blocks, int64_t k);   /* ggml-quants.c:2555    */
+/* exact per-block integer sums of one weight row against one quantized activation row (tier T0).
+ * Q4_0/Q8_0: one int32 per 32-block; Q4_K: {sum_s sc_s*dot_s, sum_s m_s*bsum_s} per super-block. */
+CLLM_API int    cllm_vec_dot_isums(void * stream, int wtype, int64_t k, const void * w_row, const float * x, int32_t * isums);
+
+/* ---- the other nodes of one forward graph -------------------------------- */
+/* GGML_OP_RMS_NORM      ggml_compute_forward_rms_norm_f32  (ggml-cpu/ops.cpp:3710-3759) */
+CLLM_API int cllm_op_rms_norm(void * stream, const cllm_tensor * src, cllm_tensor * dst, float eps);
+/* fused RMS_NORM + MUL(weight) -- chatllm RMSNorm::forward (src/layers.cpp:2216-2225); same two roundings */
+CLLM_API int cllm_op_rms_norm_mul(void * stream, const cllm_tensor * src, const cllm_tensor * weight, cllm_tensor * dst, float eps);
+
+typedef struct cllm_rope_params {      /* op_params of GGML_OP_ROPE (ggml.c ggml_rope_impl) */
+    int32_t n_dims, mode, n_ctx_orig;  /* mode 0 = NORMAL (i,i+1), 2 = NEOX (i, i+n_dims/2) */
+    float   freq_base, freq_scale, ext_factor, attn_factor, beta_fast, beta_slow;
+} cllm_rope_params;
+/* GGML_OP_ROPE          ggml_compute_forward_rope_flt<float> (ops.cpp:5589-5865); dst may alias src (rope_ext_inplace) */
+CLLM_API int cllm_op_rope(void * stream, const cllm_tensor * src, const cllm_tensor * pos, const cllm_tensor * freq_factors,
+                          cllm_tensor * dst, const cllm_rope_params * p);
+/* GGML_OP_SOFT_MAX      ggml_compute_forward_soft_max_f32 (ops.cpp:5225-5335); mask may be NULL, F32 or F16 */
+CLLM_API int cllm_op_soft_max(void * stream, const cllm_tensor * src, const cllm_tensor * mask, cllm_tensor * dst,
+                              float scale, float max_bias);
+/* GGML_OP_DIAG_MASK_INF ggml_compute_forward_diag_mask_f32 (ops.cpp:5137-5185) */
+CLLM_API int cllm_op_diag_mask_inf(void * stream, const cllm_tensor * src, cllm_tensor * dst, int n_past);
+/* GGML_OP_SCALE         ggml_compute_forward_scale (ops.cpp:4426-) y = x*s + b */
+CLLM_API int cllm_op_scale(void * stream, const cllm_tensor * src, cllm_tensor * dst, float s, float b);
+/* fused SCALE + DIAG_MASK_INF + SOFT_MAX as chatllm's attn_scores_to_probs emits them (src/layers.cpp:2499-2539) */
+CLLM_API int cllm_op_scale_mask_soft_max(void * stream, const cllm_tensor * src, cllm_tensor * dst, float scale, int n_past);
+
+typedef enum cllm_unary { CLLM_UNARY_SILU = 10 /* == GGML_UNARY_OP_SILU */ } cllm_unary;
+/* GGML_OP_UNARY         ggml_vec_silu_f32 (ggml-cpu/vec.cpp:396-431) */
+CLLM_API int cllm_op_unary(void * stream, int op, const cllm_tensor * src, cllm_tensor * dst);
+/* GGML_OP_ADD / GGML_OP_MUL with broadcast of src1 (ggml-cpu/binary-ops.cpp) */
+CLLM_API int cllm_op_add(void * stream, const cllm_tensor * a, const cllm_tensor * b, cllm_tensor * dst);
+CLLM_API int cllm_op_mul(void * stream, const cllm_tensor * a, const cllm_tensor * b, cllm_tensor * dst);
+/* fused  dst = silu(gate) * up   (BaseMLP::forward, src/layers.cpp:2475-2483: UNARY(SILU) then MUL) */
+CLLM_API int cllm_op_silu_mul(void * stream, const cllm_tensor * gate, const cllm_tensor * up, cllm_tensor * dst);
+
+/* GGML_OP_SET_ROWS      ggml_compute_forward_set_rows_f32 (ops.cpp:4892-4940): K-cache write (F32 -> F16|F32 rows at idx) */
+CLLM_API int cllm_op_set_rows(void * stream, const cllm_tensor * src, const cllm_tensor * idx, cllm_tensor * dst);
+/* GGML_OP_CPY / DUP / CONT  ggml_compute_forward_dup (ops.cpp:47-330,526): same #elements, F32/F16 -> F32/F16, any strides
+ * (the transposed V-cache write of src/layers.cpp:3082-3093, cache shifts, permute+cont) */
+CLLM_API int cllm_op_cpy(void * stream, const cllm_tensor * src, cllm_tensor * dst);
+/* GGML_OP_GET_ROWS      ggml_compute_forward_get_rows (ops.cpp:4653-4700,4820): embedding gather with dequantization */
+CLLM_API int cllm_op_get_rows(void * stream, const cllm_tensor * src, const cllm_tensor * idx, cllm_tensor * dst);
+/* dequantize_row_q4_0 / q8_0 / q4_K (ggml/src/ggml-quants.c:307-325, 401-414, 1352-1373) */
+CLLM_API int cllm_dequantize_row(void * stream, int type, const void * blocks, float * y, int64_t k);
+
+/* ---- host-side graph runner for the Llama-3 / Qwen2 decoder (csrc/decoder.cpp) ------------
+ * mirrors HeterogeneousModel::forward + LMBlock1Forward::forward + LMFinalSteps::forward
+ * (src/models.cpp:1399-1424,1736-1784; src/layers.cpp:2719-2761) as a fixed launch sequence on one
+ * stream, captured into a hipGraph per (qlen) so that the per-token host cost is one graph launch
+ * (SURVEY.md 8f rank 1).  Weights are raw reference-format quant blocks, row-major [out][in].        */
+typedef struct cllm_llama_config {
+    int32_t n_layer, hidden, n_head, n_kv_head, head_dim, ffn, vocab, max_len;
+    int32_t rope_mode;       /* 0 interleaved (Llama-3), 2 NEOX (Qwen2) */
+    float   rope_theta, rms_eps;
+    int32_t qkv_bias;
+    int32_t tp_rank, tp_size; /* tensor-parallel shard of heads / ffn columns (1 = whole model) */
+} cllm_llama_config;
+
+typedef struct cllm_llama cllm_llama;   /* opaque */
+typedef void (*cllm_allreduce_fn)(void * user, void * stream, float * buf, int64_t n);
+
+CLLM_API int  cllm_llama_create(const cllm_llama_config * cfg, void * stream, cllm_llama ** out);
+CLLM_API void cllm_llama_destroy(cllm_llama * m);
+/* name: "tok_embd" "lm_head" "out_norm" "layers.N.{attn_norm,ffn_norm,wq,wk,wv,wo,wgate,wup,wdown,bq,bk,bv}".
+ * data: HOST pointer to nbytes of blocks (type = cllm_type) ; uploaded and owned by the model.              */
+CLLM_API int  cllm_llama_set_weight(cllm_llama * m, const char * name, int type, const void * data, size_t nbytes);
+/* same, but `data` is a DEVICE pointer that the caller keeps alive (no copy) */
+CLLM_API int  cllm_llama_bind_weight(cllm_llama * m, const char * name, int type, void * dev_data, size_t nbytes);
+CLLM_API int  cllm_llama_set_allreduce(cllm_llama * m, cllm_allreduce_fn fn, void * user);
+/* run qlen tokens (host int32) at positions n_past..; writes logits[vocab] of the last token to
+ * logits_dev (device, may be NULL) and/or logits_host (may be NULL; implies a stream sync).               */
+CLLM_API int  cllm_llama_forward(cllm_llama * m, const int32_t * tokens, int qlen, int n_past, float * logits_dev,
+                                 float * logits_host);
+/* decode-loop helpers: greedy argmax on device feeding the next step without a host round trip */
+CLLM_API int  cllm_llama_decode_greedy(cllm_llama * m, int32_t first_token, int n_past, int n_steps, int32_t * out_tokens_host);
+CLLM_API int  cllm_llama_use_graph(cllm_llama * m, int enable);
+CLLM_API size_t cllm_llama_weight_bytes(const cllm_llama * m);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CHATLLM_HIP_H */

@@ -1,0 +1,725 @@
+/*
+ * oracle/ggml_oracle.c -- TEST INFRASTRUCTURE.  NOT PART OF THE PRODUCT PATH.
+ *
+ * CPU restatement (plain C11, no SIMD) of the reference's algorithm for the transformer
+ * forward hot path.  See ggml_oracle.h for the parity pin and the per-function citations.
+ * Floating point: compiled with -ffp-contract=off so that every fmaf below is intentional.
+ */
+#include "ggml_oracle.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define ORC_MIN(a, b) ((a) < (b) ? (a) : (b))
+#define ORC_MAX(a, b) ((a) > (b) ? (a) : (b))
+
+/* ------------------------------------------------------------------------------------------ */
+/* type traits                                                                                 */
+/* ------------------------------------------------------------------------------------------ */
+size_t orc_type_size(int type) {
+    switch (type) {
+        case ORC_F32: return 4;  case ORC_F16: return 2;  case ORC_I32: return 4;  case ORC_I64: return 8;
+        case ORC_Q4_0: return sizeof(orc_block_q4_0);  case ORC_Q8_0: return sizeof(orc_block_q8_0);
+        case ORC_Q4_K: return sizeof(orc_block_q4_K);  case ORC_Q8_K: return sizeof(orc_block_q8_K);
+    }
+    return 0;
+}
+int orc_blck_size(int type) {
+    switch (type) {
+        case ORC_Q4_0: case ORC_Q8_0: return ORC_QK;
+        case ORC_Q4_K: case ORC_Q8_K: return ORC_QK_K;
+        case ORC_F32: case ORC_F16: case ORC_I32: case ORC_I64: return 1;
+    }
+    return 0;
+}
+size_t orc_row_size(int type, int64_t ne) { return orc_type_size(type) * (size_t)(ne / orc_blck_size(type)); }
+
+/* ------------------------------------------------------------------------------------------ */
+/* fp16 (IEEE binary16, round-to-nearest-even: the behaviour of F16C vcvtps2ph / vcvtph2ps)    */
+/* ------------------------------------------------------------------------------------------ */
+static inline uint32_t f2u(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
+static inline float    u2f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
+
+float orc_fp16_to_fp32(uint16_t h) {
+    const uint32_t sign = (uint32_t)(h & 0x8000u) << 16;
+    const uint32_t exp  = (h >> 10) & 0x1f;
+    const uint32_t man  = h & 0x3ffu;
+    if (exp == 0) {
+        if (man == 0) return u2f(sign);
+        /* subnormal: value = man * 2^-24 (exact in f32) */
+        float v = (float) man * 0x1p-24f;
+        return u2f(f2u(v) | sign);
+    }
+    if (exp == 31) return u2f(sign | 0x7f800000u | (man << 13));
+    return u2f(sign | ((exp + 112u) << 23) | (man << 13));
+}
+
+uint16_t orc_fp32_to_fp16(float f) {
+    const uint32_t x    = f2u(f);
+    const uint16_t sign = (uint16_t)((x >> 16) & 0x8000u);
+    const uint32_t ax   = x & 0x7fffffffu;
+    if (ax >= 0x7f800000u) {                       /* inf / nan */
+        return (uint16_t)(sign | 0x7c00u | (ax > 0x7f800000u ? (0x200u | ((ax >> 13) & 0x3ffu)) : 0));
+    }
+    if (ax >= 0x477ff000u) return (uint16_t)(sign | 0x7c00u);  /* >= 65520 rounds to inf */
+    if (ax < 0x33000001u) return sign;                          /* <= 2^-25 rounds to zero (tie to even) */
+    int32_t  e = (int32_t)(ax >> 23) - 127;        /* unbiased exponent */
+    uint32_t m = (ax & 0x7fffffu) | 0x800000u;     /* 24-bit significand */
+    int shift;
+    uint32_t base;
+    if (e < -14) { shift = 13 + (-14 - e); base = 0; }           /* subnormal half */
+    else         { shift = 13;             base = (uint32_t)(e + 15) << 10; m &= 0x7fffffu; }
+    uint32_t q    = m >> shift;
+    uint32_t rem  = m & ((1u << shift) - 1u);
+    uint32_t half = 1u << (shift - 1);
+    if (rem > half || (rem == half && (q & 1u))) q++;
+    return (uint16_t)(sign | (base + q));          /* carry into the exponent is the correct rounding */
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* activation quantizers                                                                       */
+/* ------------------------------------------------------------------------------------------ */
+/* arch/x86/quants.c:290-386 (AVX2): d = amax/127 stored as fp16; q = cvt(round_nearest_even(x * (127/amax))) */
+void orc_quantize_row_q8_0(const float * x, orc_block_q8_0 * y, int64_t k) {
+    const int64_t nb = k / ORC_QK;
+    for (int64_t i = 0; i < nb; i++) {
+        float amax = 0.0f;
+        for (int j = 0; j < ORC_QK; j++) amax = fmaxf(amax, fabsf(x[i*ORC_QK + j]));
+        const float d  = amax / 127.f;
+        const float id = (amax != 0.0f) ? 127.f / amax : 0.0f;
+        y[i].d = orc_fp32_to_fp16(d);
+        for (int j = 0; j < ORC_QK; j++) {
+            /* nearbyintf under the default rounding mode == _mm256_round_ps(NEAREST) == half-to-even */
+            y[i].qs[j] = (int8_t)(int) nearbyintf(x[i*ORC_QK + j] * id);
+        }
+    }
+}
+
+/* ggml-quants.c:199-222: id = 1/d, roundf (half away from zero) */
+void orc_quantize_row_q8_0_ref(const float * x, orc_block_q8_0 * y, int64_t k) {
+    const int64_t nb = k / ORC_QK;
+    for (int64_t i = 0; i < nb; i++) {
+        float amax = 0.0f;
+        for (int j = 0; j < ORC_QK; j++) amax = ORC_MAX(amax, fabsf(x[i*ORC_QK + j]));
+        const float d  = amax / 127;
+        const float id = d ? 1.0f/d : 0.0f;
+        y[i].d = orc_fp32_to_fp16(d);
+        for (int j = 0; j < ORC_QK; j++) y[i].qs[j] = (int8_t) roundf(x[i*ORC_QK + j] * id);
+    }
+}
+
+/* ggml-quants.c:436-441 */
+static inline int orc_nearest_int(float fval) {
+    float val = fval + 12582912.f;
+    int i; memcpy(&i, &val, sizeof(int));
+    return (i & 0x007fffff) - 0x00400000;
+}
+
+/* ggml-quants.c:2555-2592 */
+void orc_quantize_row_q8_K(const float * x, orc_block_q8_K * y, int64_t k) {
+    const int64_t nb = k / ORC_QK_K;
+    for (int64_t i = 0; i < nb; i++, x += ORC_QK_K) {
+        float max = 0, amax = 0;
+        for (int j = 0; j < ORC_QK_K; j++) {
+            const float ax = fabsf(x[j]);
+            if (ax > amax) { amax = ax; max = x[j]; }   /* first element of largest magnitude, signed */
+        }
+        if (!amax) {
+            /* the reference leaves bsums untouched here; every consumer multiplies them by d == 0.
+             * We zero them so that the restatement is deterministic. */
+            memset(&y[i], 0, sizeof(y[i]));
+            continue;
+        }
+        const float iscale = -127.f / max;
+        for (int j = 0; j < ORC_QK_K; j++) {
+            const int v = orc_nearest_int(iscale * x[j]);
+            y[i].qs[j] = (int8_t) ORC_MIN(127, v);
+        }
+        for (int j = 0; j < ORC_QK_K/16; j++) {
+            int sum = 0;
+            for (int ii = 0; ii < 16; ii++) sum += y[i].qs[j*16 + ii];
+            y[i].bsums[j] = (int16_t) sum;
+        }
+        y[i].d = 1 / iscale;
+    }
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* weight dequantizers                                                                         */
+/* ------------------------------------------------------------------------------------------ */
+void orc_dequantize_row_q4_0(const orc_block_q4_0 * x, float * y, int64_t k) {
+    const int64_t nb = k / ORC_QK;
+    for (int64_t i = 0; i < nb; i++) {
+        const float d = orc_fp16_to_fp32(x[i].d);
+        for (int j = 0; j < 16; j++) {
+            y[i*32 + j]      = (float)((x[i].qs[j] & 0x0F) - 8) * d;
+            y[i*32 + j + 16] = (float)((x[i].qs[j] >>   4) - 8) * d;
+        }
+    }
+}
+void orc_dequantize_row_q8_0(const orc_block_q8_0 * x, float * y, int64_t k) {
+    const int64_t nb = k / ORC_QK;
+    for (int64_t i = 0; i < nb; i++) {
+        const float d = orc_fp16_to_fp32(x[i].d);
+        for (int j = 0; j < 32; j++) y[i*32 + j] = (float) x[i].qs[j] * d;
+    }
+}
+/* 6-bit scale/min unpack, ggml-quants.c:703-711 */
+static inline void orc_scale_min_k4(int j, const uint8_t * q, uint8_t * sc, uint8_t * m) {
+    if (j < 4) { *sc = q[j] & 63;  *m = q[j + 4] & 63; }
+    else       { *sc = (uint8_t)((q[j+4] & 0xF) | ((q[j-4] >> 6) << 4));
+                 *m  = (uint8_t)((q[j+4] >>  4) | ((q[j  ] >> 6) << 4)); }
+}
+void orc_dequantize_row_q4_K(const orc_block_q4_K * x, float * y, int64_t k) {
+    const int64_t nb = k / ORC_QK_K;
+    for (int64_t i = 0; i < nb; i++) {
+        const float d = orc_fp16_to_fp32(x[i].d), dmin = orc_fp16_to_fp32(x[i].dmin);
+        const uint8_t * q = x[i].qs;
+        for (int g = 0; g < 4; g++, q += 32) {     /* 64 weights per group: low nibbles then high nibbles */
+            uint8_t sc, m;
+            orc_scale_min_k4(2*g + 0, x[i].scales, &sc, &m);
+            const float d1 = d * sc, m1 = dmin * m;
+            orc_scale_min_k4(2*g + 1, x[i].scales, &sc, &m);
+            const float d2 = d * sc, m2 = dmin * m;
+            for (int l = 0; l < 32; l++) *y++ = d1 * (float)(q[l] & 0xF) - m1;
+            for (int l = 0; l < 32; l++) *y++ = d2 * (float)(q[l] >>  4) - m2;
+        }
+    }
+}
+void orc_dequantize_row(int type, const void * x, float * y, int64_t k) {
+    switch (type) {
+        case ORC_Q4_0: orc_dequantize_row_q4_0((const orc_block_q4_0 *) x, y, k); break;
+        case ORC_Q8_0: orc_dequantize_row_q8_0((const orc_block_q8_0 *) x, y, k); break;
+        case ORC_Q4_K: orc_dequantize_row_q4_K((const orc_block_q4_K *) x, y, k); break;
+        case ORC_F16:  for (int64_t i = 0; i < k; i++) y[i] = orc_fp16_to_fp32(((const uint16_t *) x)[i]); break;
+        case ORC_F32:  memcpy(y, x, (size_t) k * 4); break;
+    }
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* dot products (generic branches of ggml-cpu/quants.c)                                        */
+/* ------------------------------------------------------------------------------------------ */
+float orc_vec_dot_q4_0_q8_0(int64_t n, const orc_block_q4_0 * x, const orc_block_q8_0 * y, int32_t * isums) {
+    const int64_t nb = n / ORC_QK;
+    float sumf = 0;
+    for (int64_t ib = 0; ib < nb; ib++) {
+        int s0 = 0, s1 = 0;
+        for (int j = 0; j < 16; j++) {
+            s0 += ((x[ib].qs[j] & 0x0F) - 8) * y[ib].qs[j];
+            s1 += ((x[ib].qs[j] >>   4) - 8) * y[ib].qs[j + 16];
+        }
+        const int sumi = s0 + s1;
+        if (isums) isums[ib] = sumi;
+        sumf += (float) sumi * orc_fp16_to_fp32(x[ib].d) * orc_fp16_to_fp32(y[ib].d);
+    }
+    return sumf;
+}
+
+float orc_vec_dot_q8_0_q8_0(int64_t n, const orc_block_q8_0 * x, const orc_block_q8_0 * y, int32_t * isums) {
+    const int64_t nb = n / ORC_QK;
+    float sumf = 0;
+    for (int64_t ib = 0; ib < nb; ib++) {
+        int sumi = 0;
+        for (int j = 0; j < 32; j++) sumi += x[ib].qs[j] * y[ib].qs[j];
+        if (isums) isums[ib] = sumi;
+        sumf += (float) sumi * (orc_fp16_to_fp32(x[ib].d) * orc_fp16_to_fp32(y[ib].d));
+    }
+    return sumf;
+}
+
+/* quants.c:550-623.  The reference keeps 8 float lane-accumulators (sums[l] += d*aux32[l]) and
+ * folds the mins term into sumf; we restate exactly that lane structure. */
+float orc_vec_dot_q4_K_q8_K(int64_t n, const orc_block_q4_K * x, const orc_block_q8_K * y, int32_t * isums) {
+    const int64_t nb = n / ORC_QK_K;
+    float sums[8] = {0};
+    float sumf = 0;
+    for (int64_t i = 0; i < nb; i++) {
+        int8_t  a[ORC_QK_K];
+        int32_t lane[8] = {0};
+        const uint8_t * q4 = x[i].qs;
+        for (int g = 0; g < 4; g++, q4 += 32) {
+            for (int l = 0; l < 32; l++) a[g*64 + l]      = (int8_t)(q4[l] & 0xF);
+            for (int l = 0; l < 32; l++) a[g*64 + 32 + l] = (int8_t)(q4[l] >> 4);
+        }
+        uint8_t sc[8], mn[8];
+        for (int j = 0; j < 8; j++) orc_scale_min_k4(j, x[i].scales, &sc[j], &mn[j]);
+
+        int summ = 0;                                  /* sum_j bsums[j] * mins[j/2] */
+        for (int j = 0; j < 16; j++) summ += y[i].bsums[j] * mn[j/2];
+
+        const int8_t * q8 = y[i].qs;
+        for (int j = 0; j < 8; j++) {                  /* 8 sub-blocks of 32 */
+            for (int l = 0; l < 32; l++) lane[l & 7] += (int32_t) sc[j] * ((int16_t) q8[j*32 + l] * a[j*32 + l]);
+        }
+        if (isums) {
+            int32_t t = 0;
+            for (int l = 0; l < 8; l++) t += lane[l];
+            isums[2*i + 0] = t;
+            isums[2*i + 1] = summ;
+        }
+        const float d = orc_fp16_to_fp32(x[i].d) * y[i].d;
+        for (int l = 0; l < 8; l++) sums[l] += d * (float) lane[l];
+        const float dmin = orc_fp16_to_fp32(x[i].dmin) * y[i].d;
+        sumf -= dmin * (float) summ;
+    }
+    for (int l = 0; l < 8; l++) sumf += sums[l];
+    return sumf;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* helpers for strided tensors                                                                 */
+/* ------------------------------------------------------------------------------------------ */
+static inline char * tptr(const orc_tensor * t, int64_t i0, int64_t i1, int64_t i2, int64_t i3) {
+    return (char *) t->data + i0*(int64_t)t->nb[0] + i1*(int64_t)t->nb[1] + i2*(int64_t)t->nb[2] + i3*(int64_t)t->nb[3];
+}
+static inline int64_t nrows(const orc_tensor * t) { return t->ne[1]*t->ne[2]*t->ne[3]; }
+static int is_contiguous(const orc_tensor * t) {
+    size_t nb = orc_type_size(t->type);
+    if (t->nb[0] != nb) return 0;
+    nb = nb * (size_t)(t->ne[0] / orc_blck_size(t->type));
+    for (int i = 1; i < 4; i++) { if (t->ne[i] != 1 && t->nb[i] != nb) return 0; nb *= (size_t) t->ne[i]; }
+    return 1;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* mul_mat                                                                                     */
+/* ------------------------------------------------------------------------------------------ */
+static int vec_dot_type_of(int wtype) {
+    switch (wtype) {             /* type_traits_cpu[], ggml-cpu/ggml-cpu.c:207-390 */
+        case ORC_Q4_0: case ORC_Q8_0: return ORC_Q8_0;
+        case ORC_Q4_K: return ORC_Q8_K;
+        case ORC_F16:  return ORC_F16;
+        case ORC_F32:  return ORC_F32;
+    }
+    return -1;
+}
+
+static void convert_row(int vtype, const float * x, void * y, int64_t k) {
+    switch (vtype) {
+        case ORC_Q8_0: orc_quantize_row_q8_0(x, (orc_block_q8_0 *) y, k); break;
+        case ORC_Q8_K: orc_quantize_row_q8_K(x, (orc_block_q8_K *) y, k); break;
+        case ORC_F16:  for (int64_t i = 0; i < k; i++) ((uint16_t *) y)[i] = orc_fp32_to_fp16(x[i]); break;
+        case ORC_F32:  memcpy(y, x, (size_t) k * 4); break;
+    }
+}
+
+static float vec_dot(int wtype, int64_t n, const void * w, const void * a) {
+    switch (wtype) {
+        case ORC_Q4_0: return orc_vec_dot_q4_0_q8_0(n, (const orc_block_q4_0 *) w, (const orc_block_q8_0 *) a, NULL);
+        case ORC_Q8_0: return orc_vec_dot_q8_0_q8_0(n, (const orc_block_q8_0 *) w, (const orc_block_q8_0 *) a, NULL);
+        case ORC_Q4_K: return orc_vec_dot_q4_K_q8_K(n, (const orc_block_q4_K *) w, (const orc_block_q8_K *) a, NULL);
+        case ORC_F16: {          /* scalar branch of ggml_vec_dot_f16 (vec.cpp:264-): double accumulation */
+            const uint16_t * x = (const uint16_t *) w, * y = (const uint16_t *) a;
+            double s = 0.0;
+            for (int64_t i = 0; i < n; i++) s += (double)(orc_fp16_to_fp32(x[i]) * orc_fp16_to_fp32(y[i]));
+            return (float) s;
+        }
+        case ORC_F32: {          /* scalar branch of ggml_vec_dot_f32 (vec.cpp:10-): double accumulation */
+            const float * x = (const float *) w, * y = (const float *) a;
+            double s = 0.0;
+            for (int64_t i = 0; i < n; i++) s += (double)(x[i] * y[i]);
+            return (float) s;
+        }
+    }
+    return 0;
+}
+
+int orc_mul_mat(const orc_tensor * src0, const orc_tensor * src1, orc_tensor * dst) {
+    const int64_t K = src0->ne[0];
+    if (src1->ne[0] != K || src1->type != ORC_F32 || dst->type != ORC_F32) return -1;
+    if (dst->ne[0] != src0->ne[1] || dst->ne[1] != src1->ne[1] || dst->ne[2] != src1->ne[2] || dst->ne[3] != src1->ne[3]) return -2;
+    if (src1->ne[2] % src0->ne[2] || src1->ne[3] % src0->ne[3]) return -3;
+    if (src0->nb[0] != orc_type_size(src0->type) || src1->nb[0] != 4) return -4;   /* rows themselves are dense */
+    const int vt = vec_dot_type_of(src0->type);
+    if (vt < 0 || K % orc_blck_size(vt)) return -5;
+
+    const size_t rs = orc_row_size(vt, K);
+    void * arow = malloc(rs);
+    const int64_t r2 = src1->ne[2] / src0->ne[2], r3 = src1->ne[3] / src0->ne[3];
+    for (int64_t i13 = 0; i13 < src1->ne[3]; i13++)
+    for (int64_t i12 = 0; i12 < src1->ne[2]; i12++)
+    for (int64_t i11 = 0; i11 < src1->ne[1]; i11++) {
+        convert_row(vt, (const float *) tptr(src1, 0, i11, i12, i13), arow, K);
+        for (int64_t i01 = 0; i01 < src0->ne[1]; i01++) {
+            const void * w = tptr(src0, 0, i01, i12 / r2, i13 / r3);
+            *(float *) tptr(dst, i01, i11, i12, i13) = vec_dot(src0->type, K, w, arow);
+        }
+    }
+    free(arow);
+    return 0;
+}
+
+/* ggml-cpu.c:1432-1678: dst[:, id, tok] = as[:, :, ids[id, tok]]^T . b[:, id % ne11, tok] */
+int orc_mul_mat_id(const orc_tensor * as, const orc_tensor * b, const orc_tensor * ids, orc_tensor * dst) {
+    const int64_t K = as->ne[0], N = as->ne[1], n_as = as->ne[2];
+    const int64_t n_used = ids->ne[0], n_tok = ids->ne[1];
+    if (b->ne[0] != K || b->type != ORC_F32 || ids->type != ORC_I32 || dst->type != ORC_F32) return -1;
+    if (dst->ne[0] != N || dst->ne[1] != n_used || dst->ne[2] != n_tok || b->ne[2] != n_tok) return -2;
+    const int vt = vec_dot_type_of(as->type);
+    if (vt < 0) return -5;
+    void * arow = malloc(orc_row_size(vt, K));
+    for (int64_t t = 0; t < n_tok; t++)
+    for (int64_t id = 0; id < n_used; id++) {
+        const int32_t e = *(const int32_t *) tptr(ids, id, t, 0, 0);
+        if (e < 0 || e >= n_as) { free(arow); return -6; }
+        convert_row(vt, (const float *) tptr(b, 0, id % b->ne[1], t, 0), arow, K);
+        for (int64_t r = 0; r < N; r++)
+            *(float *) tptr(dst, r, id, t, 0) = vec_dot(as->type, K, tptr(as, 0, r, e, 0), arow);
+    }
+    free(arow);
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* normalisation, rope, softmax, elementwise                                                   */
+/* ------------------------------------------------------------------------------------------ */
+int orc_rms_norm(const orc_tensor * src, orc_tensor * dst, float eps) {
+    if (src->type != ORC_F32 || dst->type != ORC_F32 || src->nb[0] != 4 || dst->nb[0] != 4) return -1;
+    const int64_t n = src->ne[0];
+    for (int64_t i3 = 0; i3 < src->ne[3]; i3++)
+    for (int64_t i2 = 0; i2 < src->ne[2]; i2++)
+    for (int64_t i1 = 0; i1 < src->ne[1]; i1++) {
+        const float * x = (const float *) tptr(src, 0, i1, i2, i3);
+        float * y = (float *) tptr(dst, 0, i1, i2, i3);
+        double sum = 0.0;
+        for (int64_t i = 0; i < n; i++) sum += (double)(x[i] * x[i]);
+        const float mean  = (float)(sum / (double) n);
+        const float scale = 1.0f / sqrtf(mean + eps);
+        for (int64_t i = 0; i < n; i++) y[i] = x[i] * scale;
+    }
+    return 0;
+}
+
+/* ggml.c ggml_rope_yarn_corr_dim(s) */
+static float rope_corr_dim(int n_dims, int n_ctx_orig, float n_rot, float base) {
+    return n_dims * logf(n_ctx_orig / (n_rot * 2 * (float) M_PI)) / (2 * logf(base));
+}
+static void rope_corr_dims(int n_dims, int n_ctx_orig, float freq_base, float beta_fast, float beta_slow, float dims[2]) {
+    const float start = floorf(rope_corr_dim(n_dims, n_ctx_orig, beta_fast, freq_base));
+    const float end   = ceilf (rope_corr_dim(n_dims, n_ctx_orig, beta_slow, freq_base));
+    dims[0] = ORC_MAX(0, start);
+    dims[1] = ORC_MIN(n_dims - 1, end);
+}
+static float rope_ramp(float low, float high, int i0) {
+    const float y = (i0 / 2 - low) / ORC_MAX(0.001f, high - low);
+    return 1 - ORC_MIN(1, ORC_MAX(0, y));
+}
+/* ops.cpp:5596-5611 */
+static void rope_yarn(float theta_extrap, float freq_scale, const float corr[2], int64_t i0, float ext_factor, float mscale,
+                      float * c, float * s) {
+    const float theta_interp = freq_scale * theta_extrap;
+    float theta = theta_interp;
+    if (ext_factor != 0.0f) {
+        const float mix = rope_ramp(corr[0], corr[1], (int) i0) * ext_factor;
+        theta = theta_interp * (1 - mix) + theta_extrap * mix;
+        mscale *= 1.0f + 0.1f * logf(1.0f / freq_scale);
+    }
+    *c = cosf(theta) * mscale;
+    *s = sinf(theta) * mscale;
+}
+
+int orc_rope(const orc_tensor * src, const int32_t * pos, const float * ff, orc_tensor * dst, const orc_rope_params * p) {
+    if (src->type != ORC_F32 || dst->type != ORC_F32 || src->nb[0] != 4 || dst->nb[0] != 4) return -1;
+    if (p->mode != 0 && p->mode != 2) return -2;
+    const int64_t ne0 = src->ne[0];
+    const int n_dims = p->n_dims;
+    if (n_dims > ne0 || (n_dims & 1)) return -3;
+    const float theta_scale = powf(p->freq_base, -2.0f / n_dims);
+    float corr[2];
+    rope_corr_dims(n_dims, p->n_ctx_orig, p->freq_base, p->beta_fast, p->beta_slow, corr);
+    float * cache = (float *) malloc((size_t) ne0 * sizeof(float));
+
+    for (int64_t i3 = 0; i3 < src->ne[3]; i3++)
+    for (int64_t i2 = 0; i2 < src->ne[2]; i2++) {                    /* sequence position */
+        float theta = (float) pos[i2];                               /* iterated product, ops.cpp:5613-5628 */
+        for (int64_t i0 = 0; i0 < ne0; i0 += 2) {
+            const float f = ff ? ff[i0/2] : 1.0f;
+            rope_yarn(theta / f, p->freq_scale, corr, i0, p->ext_factor, p->attn_factor, &cache[i0], &cache[i0 + 1]);
+            theta *= theta_scale;
+        }
+        for (int64_t i1 = 0; i1 < src->ne[1]; i1++) {                /* heads */
+            const float * x = (const float *) tptr(src, 0, i1, i2, i3);
+            float * y = (float *) tptr(dst, 0, i1, i2, i3);
+            const int64_t off = p->mode == 0 ? 1 : n_dims / 2;
+            for (int64_t i0 = 0; i0 < n_dims; i0 += 2) {
+                const int64_t ic = p->mode == 0 ? i0 : i0 / 2;
+                const float c = cache[i0], s = cache[i0 + 1];
+                const float x0 = x[ic], x1 = x[ic + off];
+                y[ic]       = x0*c - x1*s;
+                y[ic + off] = x0*s + x1*c;
+            }
+            for (int64_t i0 = n_dims; i0 < ne0; i0++) y[i0] = x[i0];
+        }
+    }
+    free(cache);
+    return 0;
+}
+
+/* one lane of the AVX2 ggml_v_expf (vec.h:1230-1267); every fma of the original is an fmaf here */
+float orc_expf_avx2(float x) {
+    const float r = 0x1.8p23f;
+    const float z = fmaf(x, 0x1.715476p+0f, r);
+    const float n = z - r;
+    const float b = fmaf(-n, 0x1.7f7d1cp-20f, fmaf(-n, 0x1.62e4p-1f, x));
+    const uint32_t e = f2u(z) << 23;
+    const float k = u2f(e + f2u(1.0f));
+    const int   c = fabsf(n) > 126.0f;
+    const float u = b * b;
+    const float j = fmaf(fmaf(fmaf(0x1.0e4020p-7f, b, 0x1.573e2ep-5f), u,
+                              fmaf(0x1.555e66p-3f, b, 0x1.fffdb6p-2f)),
+                         u, 0x1.ffffecp-1f * b);
+    if (!c) return fmaf(j, k, k);
+    const uint32_t g  = (n <= 0.0f) ? 0x82000000u : 0u;
+    const float    s1 = u2f(g + 0x7f000000u);
+    const float    s2 = u2f(e - g);
+    if (fabsf(n) > 192.0f) return s1 * s1;
+    return fmaf(s2, j, s2) * s1;
+}
+float orc_silu_avx2(float x) { return x / (1.0f + orc_expf_avx2(0.0f - x)); }
+
+int orc_soft_max(const orc_tensor * src, const orc_tensor * mask, orc_tensor * dst, float scale, float max_bias) {
+    if (src->type != ORC_F32 || dst->type != ORC_F32 || max_bias != 0.0f) return -1;   /* ALiBi not on this path */
+    if (mask && mask->type != ORC_F32 && mask->type != ORC_F16) return -2;
+    const int64_t n = src->ne[0];
+    float * wp = (float *) malloc((size_t) n * sizeof(float));
+    for (int64_t i3 = 0; i3 < src->ne[3]; i3++)
+    for (int64_t i2 = 0; i2 < src->ne[2]; i2++)
+    for (int64_t i1 = 0; i1 < src->ne[1]; i1++) {
+        const float * sp = (const float *) tptr(src, 0, i1, i2, i3);
+        float * dp = (float *) tptr(dst, 0, i1, i2, i3);
+        for (int64_t i = 0; i < n; i++) wp[i] = sp[i] * scale;
+        if (mask) {
+            const char * mp = tptr(mask, 0, i1, i2 % mask->ne[2], i3 % mask->ne[3]);
+            for (int64_t i = 0; i < n; i++)
+                wp[i] += 1.0f * (mask->type == ORC_F16 ? orc_fp16_to_fp32(((const uint16_t *) mp)[i]) : ((const float *) mp)[i]);
+        }
+        float max = -INFINITY;
+        for (int64_t i = 0; i < n; i++) max = ORC_MAX(max, wp[i]);
+        /* ggml_vec_soft_max_f32 (vec.cpp:547-): groups of 8 through the polynomial, hsum in f32, total in double; tail expf */
+        double sum = 0.0;
+        int64_t i = 0;
+        for (; i + 7 < n; i += 8) {
+            float v[8];
+            for (int l = 0; l < 8; l++) { v[l] = orc_expf_avx2(wp[i + l] - max); dp[i + l] = v[l]; }
+            /* extractf128 add, movehl add, movehdup add */
+            const float a0 = v[0] + v[4], a1 = v[1] + v[5], a2 = v[2] + v[6], a3 = v[3] + v[7];
+            const float b0 = a0 + a2, b1 = a1 + a3;
+            sum += (double)(b0 + b1);
+        }
+        for (; i < n; i++) { const float v = expf(wp[i] - max); dp[i] = v; sum += (double) v; }
+        const float inv = (float)(1.0 / sum);
+        for (int64_t l = 0; l < n; l++) dp[l] *= inv;
+    }
+    free(wp);
+    return 0;
+}
+
+int orc_diag_mask_inf(const orc_tensor * src, orc_tensor * dst, int n_past) {
+    if (src->type != ORC_F32 || dst->type != ORC_F32) return -1;
+    for (int64_t i3 = 0; i3 < src->ne[3]; i3++)
+    for (int64_t i2 = 0; i2 < src->ne[2]; i2++)
+    for (int64_t j = 0; j < src->ne[1]; j++)
+    for (int64_t i = 0; i < src->ne[0]; i++) {
+        const float v = *(const float *) tptr(src, i, j, i2, i3);
+        *(float *) tptr(dst, i, j, i2, i3) = (i > n_past + j) ? -INFINITY : v;
+    }
+    return 0;
+}
+
+int orc_scale(const orc_tensor * src, orc_tensor * dst, float s, float b) {
+    if (src->type != ORC_F32 || dst->type != ORC_F32) return -1;
+    for (int64_t i3 = 0; i3 < src->ne[3]; i3++) for (int64_t i2 = 0; i2 < src->ne[2]; i2++)
+    for (int64_t i1 = 0; i1 < src->ne[1]; i1++) for (int64_t i0 = 0; i0 < src->ne[0]; i0++) {
+        const float v = *(const float *) tptr(src, i0, i1, i2, i3);
+        /* ggml_vec_scale_f32 when b == 0, ggml_vec_mad1_f32 otherwise */
+        *(float *) tptr(dst, i0, i1, i2, i3) = (b == 0.0f) ? v * s : v * s + b;
+    }
+    return 0;
+}
+
+int orc_silu(const orc_tensor * src, orc_tensor * dst) {
+    if (src->type != ORC_F32 || dst->type != ORC_F32 || src->nb[0] != 4 || dst->nb[0] != 4) return -1;
+    const int64_t n = src->ne[0];
+    for (int64_t i3 = 0; i3 < src->ne[3]; i3++) for (int64_t i2 = 0; i2 < src->ne[2]; i2++)
+    for (int64_t i1 = 0; i1 < src->ne[1]; i1++) {
+        const float * x = (const float *) tptr(src, 0, i1, i2, i3);
+        float * y = (float *) tptr(dst, 0, i1, i2, i3);
+        const int64_t nv = n & ~(int64_t) 7;                        /* vector body: indices < (n & ~7) */
+        for (int64_t i = 0;  i < nv; i++) y[i] = orc_silu_avx2(x[i]);
+        for (int64_t i = nv; i < n;  i++) y[i] = x[i] / (1.0f + expf(-x[i]));
+    }
+    return 0;
+}
+
+static int binary_op(const orc_tensor * a, const orc_tensor * b, orc_tensor * dst, int op) {
+    if (a->type != ORC_F32 || b->type != ORC_F32 || dst->type != ORC_F32) return -1;
+    for (int d = 0; d < 4; d++) if (a->ne[d] % b->ne[d] || dst->ne[d] != a->ne[d]) return -2;
+    for (int64_t i3 = 0; i3 < a->ne[3]; i3++) for (int64_t i2 = 0; i2 < a->ne[2]; i2++)
+    for (int64_t i1 = 0; i1 < a->ne[1]; i1++) for (int64_t i0 = 0; i0 < a->ne[0]; i0++) {
+        const float x = *(const float *) tptr(a, i0, i1, i2, i3);
+        const float y = *(const float *) tptr(b, i0 % b->ne[0], i1 % b->ne[1], i2 % b->ne[2], i3 % b->ne[3]);
+        *(float *) tptr(dst, i0, i1, i2, i3) = op == 0 ? x + y : x * y;
+    }
+    return 0;
+}
+int orc_add(const orc_tensor * a, const orc_tensor * b, orc_tensor * dst) { return binary_op(a, b, dst, 0); }
+int orc_mul(const orc_tensor * a, const orc_tensor * b, orc_tensor * dst) { return binary_op(a, b, dst, 1); }
+
+/* ------------------------------------------------------------------------------------------ */
+/* KV-cache writes and gathers                                                                 */
+/* ------------------------------------------------------------------------------------------ */
+int orc_set_rows(const orc_tensor * src, const orc_tensor * idx, orc_tensor * dst) {
+    if (src->type != ORC_F32 || (dst->type != ORC_F16 && dst->type != ORC_F32)) return -1;
+    if (idx->type != ORC_I32 && idx->type != ORC_I64) return -2;
+    if (dst->ne[0] != src->ne[0] || dst->ne[2] != src->ne[2] || dst->ne[3] != src->ne[3]) return -3;
+    if (idx->ne[0] != src->ne[1] || src->ne[2] % idx->ne[1] || src->ne[3] % idx->ne[2]) return -4;
+    for (int64_t i3 = 0; i3 < src->ne[3]; i3++) for (int64_t i2 = 0; i2 < src->ne[2]; i2++)
+    for (int64_t i = 0; i < src->ne[1]; i++) {
+        const char * ip = tptr(idx, i, i2 % idx->ne[1], i3 % idx->ne[2], 0);
+        const int64_t r = idx->type == ORC_I32 ? *(const int32_t *) ip : *(const int64_t *) ip;
+        if (r < 0 || r >= dst->ne[1]) return -5;
+        const float * x = (const float *) tptr(src, 0, i, i2, i3);
+        char * y = tptr(dst, 0, r, i2, i3);
+        for (int64_t c = 0; c < src->ne[0]; c++) {
+            if (dst->type == ORC_F16) ((uint16_t *) y)[c] = orc_fp32_to_fp16(x[c]);
+            else                      ((float    *) y)[c] = x[c];
+        }
+    }
+    return 0;
+}
+
+/* element e (row-major over ne) of src goes to element e of dst: ggml_compute_forward_dup semantics */
+int orc_cpy(const orc_tensor * src, orc_tensor * dst) {
+    const int64_t n = src->ne[0]*src->ne[1]*src->ne[2]*src->ne[3];
+    if (n != dst->ne[0]*dst->ne[1]*dst->ne[2]*dst->ne[3]) return -1;
+    if ((src->type != ORC_F32 && src->type != ORC_F16) || (dst->type != ORC_F32 && dst->type != ORC_F16)) return -2;
+    for (int64_t e = 0; e < n; e++) {
+        int64_t r = e;
+        const int64_t s0 = r % src->ne[0]; r /= src->ne[0];
+        const int64_t s1 = r % src->ne[1]; r /= src->ne[1];
+        const int64_t s2 = r % src->ne[2]; const int64_t s3 = r / src->ne[2];
+        r = e;
+        const int64_t d0 = r % dst->ne[0]; r /= dst->ne[0];
+        const int64_t d1 = r % dst->ne[1]; r /= dst->ne[1];
+        const int64_t d2 = r % dst->ne[2]; const int64_t d3 = r / dst->ne[2];
+        const char * sp = tptr(src, s0, s1, s2, s3);
+        char * dp = tptr(dst, d0, d1, d2, d3);
+        if (src->type == dst->type) { memcpy(dp, sp, orc_type_size(src->type)); continue; }
+        if (src->type == ORC_F32) *(uint16_t *) dp = orc_fp32_to_fp16(*(const float *) sp);
+        else                      *(float *) dp    = orc_fp16_to_fp32(*(const uint16_t *) sp);
+    }
+    return 0;
+}
+
+int orc_get_rows(const orc_tensor * src, const orc_tensor * idx, orc_tensor * dst) {
+    if (idx->type != ORC_I32 || dst->type != ORC_F32 || dst->ne[0] != src->ne[0]) return -1;
+    for (int64_t i12 = 0; i12 < idx->ne[2]; i12++) for (int64_t i11 = 0; i11 < idx->ne[1]; i11++)
+    for (int64_t i10 = 0; i10 < idx->ne[0]; i10++) {
+        const int32_t r = *(const int32_t *) tptr(idx, i10, i11, i12, 0);
+        if (r < 0 || r >= src->ne[1]) return -2;
+        orc_dequantize_row(src->type, tptr(src, 0, r, i11, i12), (float *) tptr(dst, 0, i10, i11, i12), src->ne[0]);
+    }
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* whole-model forward (SURVEY.md section 3.3 node order)                                      */
+/* ------------------------------------------------------------------------------------------ */
+static orc_tensor T2(int type, void * data, int64_t n0, int64_t n1) {
+    orc_tensor t; t.type = type; t.data = data;
+    t.ne[0] = n0; t.ne[1] = n1; t.ne[2] = 1; t.ne[3] = 1;
+    t.nb[0] = orc_type_size(type); t.nb[1] = orc_row_size(type, n0); t.nb[2] = t.nb[1]*(size_t)n1; t.nb[3] = t.nb[2];
+    return t;
+}
+static void linear(const orc_weight * w, int64_t K, int64_t N, float * x, int64_t qlen, float * y, const float * bias) {
+    orc_tensor W = T2(w->type, (void *) w->data, K, N), X = T2(ORC_F32, x, K, qlen), Y = T2(ORC_F32, y, N, qlen);
+    orc_mul_mat(&W, &X, &Y);
+    if (bias) for (int64_t t = 0; t < qlen; t++) for (int64_t i = 0; i < N; i++) y[t*N + i] += bias[i];
+}
+static void norm_mul(const float * w, float * x, float * y, int64_t H, int64_t qlen, float eps) {
+    orc_tensor X = T2(ORC_F32, x, H, qlen), Y = T2(ORC_F32, y, H, qlen);
+    orc_rms_norm(&X, &Y, eps);                                  /* RMS_NORM node */
+    for (int64_t t = 0; t < qlen; t++) for (int64_t i = 0; i < H; i++) y[t*H + i] *= w[i];   /* MUL node */
+}
+
+int orc_llama_forward(orc_llama_model * m, const int32_t * tokens, int qlen, int n_past, float * logits) {
+    const orc_llama_config * c = &m->cfg;
+    const int64_t H = c->hidden, hd = c->head_dim, nh = c->n_head, nkv = c->n_kv_head, F = c->ffn, V = c->vocab;
+    const int64_t QD = nh*hd, KD = nkv*hd, n_kv = n_past + qlen, ML = c->max_len;
+    if (n_kv > ML) return -1;
+
+    float * x   = (float *) malloc(sizeof(float) * (size_t)(H*qlen));
+    float * xn  = (float *) malloc(sizeof(float) * (size_t)(H*qlen));
+    float * q   = (float *) malloc(sizeof(float) * (size_t)(QD*qlen));
+    float * k   = (float *) malloc(sizeof(float) * (size_t)(KD*qlen));
+    float * v   = (float *) malloc(sizeof(float) * (size_t)(KD*qlen));
+    float * att = (float *) malloc(sizeof(float) * (size_t)(QD*qlen));
+    float * o   = (float *) malloc(sizeof(float) * (size_t)(H*qlen));
+    float * g   = (float *) malloc(sizeof(float) * (size_t)(F*qlen));
+    float * u   = (float *) malloc(sizeof(float) * (size_t)(F*qlen));
+    float * sc  = (float *) malloc(sizeof(float) * (size_t)(n_kv*qlen*nh));
+    float * ctx = (float *) malloc(sizeof(float) * (size_t)(hd*qlen*nh));
+    int32_t * pos = (int32_t *) malloc(sizeof(int32_t) * (size_t) qlen);
+    for (int t = 0; t < qlen; t++) pos[t] = n_past + t;
+
+    { /* Embedding::forward -> GET_ROWS */
+        orc_tensor E = T2(m->tok_embd.type, (void *) m->tok_embd.data, H, V), I = T2(ORC_I32, (void *) tokens, qlen, 1), X = T2(ORC_F32, x, H, qlen);
+        if (orc_get_rows(&E, &I, &X)) return -2;
+    }
+    orc_rope_params rp = { (int32_t) hd, c->rope_mode, 0, c->rope_theta, 1.0f, 0.0f, 1.0f, 0.0f, 0.0f };
+
+    for (int il = 0; il < c->n_layer; il++) {
+        const orc_llama_layer * L = &m->layers[il];
+        uint16_t * kc = m->k_cache + (size_t) il * (size_t)(ML*KD);
+        uint16_t * vc = m->v_cache + (size_t) il * (size_t)(ML*KD);
+
+        norm_mul(L->attn_norm, x, xn, H, qlen, c->rms_eps);
+        linear(&L->wq, H, QD, xn, qlen, q, c->qkv_bias ? L->bq : NULL);
+        linear(&L->wk, H, KD, xn, qlen, k, c->qkv_bias ? L->bk : NULL);
+        linear(&L->wv, H, KD, xn, qlen, v, c->qkv_bias ? L->bv : NULL);
+
+        { /* rope in place on k then q: [hd, heads, qlen] */
+            orc_tensor Kt = { ORC_F32, {hd, nkv, qlen, 1}, {4, 4*(size_t)hd, 4*(size_t)KD, 4*(size_t)(KD*qlen)}, k };
+            orc_tensor Qt = { ORC_F32, {hd, nh,  qlen, 1}, {4, 4*(size_t)hd, 4*(size_t)QD, 4*(size_t)(QD*qlen)}, q };
+            orc_rope(&Kt, pos, NULL, &Kt, &rp);
+            orc_rope(&Qt, pos, NULL, &Qt, &rp);
+        }
+        /* save_to_cache: V transposed CPY F32->F16 into [KD][ML] at column n_past; K SET_ROWS into [ML][KD] */
+        for (int t = 0; t < qlen; t++) for (int64_t i = 0; i < KD; i++) {
+            vc[i*ML + (n_past + t)]  = orc_fp32_to_fp16(v[t*KD + i]);
+            kc[(n_past + t)*KD + i]  = orc_fp32_to_fp16(k[t*KD + i]);
+        }
+        { /* scores = K^T Q (F16 x F16(q)), scale, causal mask, softmax, ctx = V P (F16 x F16(p)) */
+            orc_tensor Kv = { ORC_F16, {hd, n_kv, nkv, 1}, {2, 2*(size_t)KD, 2*(size_t)hd, 2*(size_t)(KD*ML)}, kc };
+            orc_tensor Qv = { ORC_F32, {hd, qlen, nh, 1},  {4, 4*(size_t)QD, 4*(size_t)hd, 4*(size_t)(QD*qlen)}, q };
+            orc_tensor S  = { ORC_F32, {n_kv, qlen, nh, 1}, {4, 4*(size_t)n_kv, 4*(size_t)(n_kv*qlen), 4*(size_t)(n_kv*qlen*nh)}, sc };
+            orc_mul_mat(&Kv, &Qv, &S);
+            orc_scale(&S, &S, 1.0f / sqrtf((float) hd), 0.0f);
+            orc_diag_mask_inf(&S, &S, n_past);
+            orc_soft_max(&S, NULL, &S, 1.0f, 0.0f);
+            orc_tensor Vv = { ORC_F16, {n_kv, hd, nkv, 1}, {2, 2*(size_t)ML, 2*(size_t)(ML*hd), 2*(size_t)(ML*KD)}, vc };
+            orc_tensor C  = { ORC_F32, {hd, qlen, nh, 1}, {4, 4*(size_t)hd, 4*(size_t)(hd*qlen), 4*(size_t)(hd*qlen*nh)}, ctx };
+            orc_mul_mat(&Vv, &S, &C);
+            /* permute(0,2,1,3) + cont -> [hd, nh, qlen] */
+            for (int t = 0; t < qlen; t++) for (int64_t h = 0; h < nh; h++)
+                memcpy(att + t*QD + h*hd, ctx + (h*qlen + t)*hd, sizeof(float) * (size_t) hd);
+        }
+        linear(&L->wo, QD, H, att, qlen, o, NULL);
+        for (int64_t i = 0; i < H*qlen; i++) x[i] = o[i] + x[i];                 /* ADD residual */
+
+        norm_mul(L->ffn_norm, x, xn, H, qlen, c->rms_eps);
+        linear(&L->wgate, H, F, xn, qlen, g, NULL);
+        { orc_tensor G = T2(ORC_F32, g, F, qlen); orc_silu(&G, &G); }
+        linear(&L->wup, H, F, xn, qlen, u, NULL);
+        for (int64_t i = 0; i < F*qlen; i++) g[i] = g[i] * u[i];
+        linear(&L->wdown, F, H, g, qlen, o, NULL);
+        for (int64_t i = 0; i < H*qlen; i++) x[i] = o[i] + x[i];
+    }
+    /* LMFinalSteps: last token -> norm -> lm_head */
+    norm_mul(m->out_norm, x + (size_t)(qlen - 1)*H, xn, H, 1, c->rms_eps);
+    linear(&m->lm_head, H, V, xn, 1, logits, NULL);
+
+    free(x); free(xn); free(q); free(k); free(v); free(att); free(o); free(g); free(u); free(sc); free(ctx); free(pos);
+    return 0;
+}

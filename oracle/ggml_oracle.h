@@ -1,0 +1,148 @@
+/*
+ * oracle/ggml_oracle.h -- TEST INFRASTRUCTURE.  NOT PART OF THE PRODUCT PATH.
+ *
+ * Plain-C restatement of the reference's CPU algorithm for the transformer forward hot path
+ * (SURVEY.md section 8a).  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline
+ * leg may load this; the HIP path never calls into it.
+ *
+ * Parity pin: the reference ships no tests / golden vectors, so this
+ * restatement is pinned against the reference ITSELF: oracle/_ref/libggml-cpu.so is compiled
+ * from the sources under /root/reference by oracle/Makefile and driven through
+ * oracle/ref_ops.c; tests/test_oracle_vs_reference.py checks every function here against it,
+ * and tests/golden/ holds vectors generated from it (tests/golden/make_golden.py).
+ *
+ * Every function cites the reference file:line it follows (paths relative to /root/reference).
+ */
+#ifndef GGML_ORACLE_H
+#define GGML_ORACLE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* numeric values equal the reference's enum ggml_type (ggml/include/ggml.h:386-428) */
+enum orc_type {
+    ORC_F32 = 0, ORC_F16 = 1, ORC_Q4_0 = 2, ORC_Q8_0 = 8, ORC_Q4_K = 12, ORC_Q8_K = 15, ORC_I32 = 26, ORC_I64 = 27,
+};
+
+/* a strided 4-D tensor view: same meaning as ggml_tensor {type, ne, nb, data} (ggml.h:656-688) */
+typedef struct orc_tensor {
+    int32_t type;
+    int64_t ne[4];
+    size_t  nb[4];
+    void *  data;
+} orc_tensor;
+
+/* ---- formats (ggml/src/ggml-common.h:170-175, 219-224, 295-306, 338-343) ---- */
+#define ORC_QK    32
+#define ORC_QK_K  256
+#pragma pack(push, 1)
+typedef struct { uint16_t d; uint8_t qs[16]; }                         orc_block_q4_0;   /* 18 B  */
+typedef struct { uint16_t d; int8_t  qs[32]; }                         orc_block_q8_0;   /* 34 B  */
+typedef struct { uint16_t d; uint16_t dmin; uint8_t scales[12]; uint8_t qs[128]; } orc_block_q4_K; /* 144 B */
+typedef struct { float d; int8_t qs[256]; int16_t bsums[16]; }         orc_block_q8_K;   /* 292 B */
+#pragma pack(pop)
+
+size_t orc_type_size(int type);   /* bytes per block */
+int    orc_blck_size(int type);   /* elements per block */
+size_t orc_row_size(int type, int64_t ne);
+
+/* fp16 <-> fp32, IEEE round-to-nearest-even (what F16C does; ggml-cpu/simd-mappings.h) */
+float    orc_fp16_to_fp32(uint16_t h);
+uint16_t orc_fp32_to_fp16(float f);
+
+/* ---- activation quantizers ---- */
+/* x86 AVX2 branch: id = 127/amax, round-half-even   (ggml-cpu/arch/x86/quants.c:290-386) */
+void orc_quantize_row_q8_0(const float * x, orc_block_q8_0 * y, int64_t k);
+/* portable branch: id = 1/d, roundf (half away)      (ggml/src/ggml-quants.c:199-222)      */
+void orc_quantize_row_q8_0_ref(const float * x, orc_block_q8_0 * y, int64_t k);
+/* (ggml/src/ggml-quants.c:2555-2592, nearest_int :444)                                      */
+void orc_quantize_row_q8_K(const float * x, orc_block_q8_K * y, int64_t k);
+
+/* ---- weight dequantizers (ggml/src/ggml-quants.c:307-325, 401-414, 1352-1373, 703-711) ---- */
+void orc_dequantize_row_q4_0(const orc_block_q4_0 * x, float * y, int64_t k);
+void orc_dequantize_row_q8_0(const orc_block_q8_0 * x, float * y, int64_t k);
+void orc_dequantize_row_q4_K(const orc_block_q4_K * x, float * y, int64_t k);
+void orc_dequantize_row(int type, const void * x, float * y, int64_t k);
+
+/* ---- block dot products (ggml-cpu/quants.c:115-150, 305-333, 550-623) ----
+ * isums (optional): per-block exact integer sums (tier T0): for Q4_0/Q8_0 one int32 per 32-block;
+ * for Q4_K two int32 per super-block { sum_s sc_s*dot_s , sum_s m_s*bsum_s }. */
+float orc_vec_dot_q4_0_q8_0(int64_t n, const orc_block_q4_0 * x, const orc_block_q8_0 * y, int32_t * isums);
+float orc_vec_dot_q8_0_q8_0(int64_t n, const orc_block_q8_0 * x, const orc_block_q8_0 * y, int32_t * isums);
+float orc_vec_dot_q4_K_q8_K(int64_t n, const orc_block_q4_K * x, const orc_block_q8_K * y, int32_t * isums);
+
+/* ---- ops (dst written through its strides; all return 0 on success, <0 on bad arguments) ---- */
+/* ggml_compute_forward_mul_mat (ggml-cpu/ggml-cpu.c:1229-1421): quantizes src1 rows to the
+ * weight type's vec_dot_type (Q8_0 for Q4_0/Q8_0, Q8_K for Q4_K, F16 for F16), then vec_dot. */
+int orc_mul_mat(const orc_tensor * src0, const orc_tensor * src1, orc_tensor * dst);
+/* ggml_compute_forward_mul_mat_id (ggml-cpu/ggml-cpu.c:1432-1678) */
+int orc_mul_mat_id(const orc_tensor * as, const orc_tensor * b, const orc_tensor * ids, orc_tensor * dst);
+/* ggml_compute_forward_rms_norm_f32 (ggml-cpu/ops.cpp:3710-3759): double accumulation */
+int orc_rms_norm(const orc_tensor * src, orc_tensor * dst, float eps);
+
+typedef struct orc_rope_params {         /* op_params of GGML_OP_ROPE (ggml.c ggml_rope_impl) */
+    int32_t n_dims, mode, n_ctx_orig;    /* mode: 0 = NORMAL (pairs i,i+1), 2 = NEOX (i, i+n/2) */
+    float   freq_base, freq_scale, ext_factor, attn_factor, beta_fast, beta_slow;
+} orc_rope_params;
+/* ggml_compute_forward_rope_flt<float> (ggml-cpu/ops.cpp:5589-5865) */
+int orc_rope(const orc_tensor * src, const int32_t * pos, const float * freq_factors, orc_tensor * dst,
+             const orc_rope_params * p);
+/* ggml_compute_forward_soft_max_f32 (ggml-cpu/ops.cpp:5225-5335; ggml_v_expf vec.h:1230-1267) */
+int orc_soft_max(const orc_tensor * src, const orc_tensor * mask, orc_tensor * dst, float scale, float max_bias);
+/* ggml_compute_forward_diag_mask_f32 (ggml-cpu/ops.cpp:5137-5185) value = -INF */
+int orc_diag_mask_inf(const orc_tensor * src, orc_tensor * dst, int n_past);
+/* ggml_compute_forward_scale (ops.cpp:4426-) y = x*s + b */
+int orc_scale(const orc_tensor * src, orc_tensor * dst, float s, float b);
+/* unary SILU (vec.cpp:396-431, vec.h:1270-1278): AVX2 polynomial for the first n&~7, expf tail */
+int orc_silu(const orc_tensor * src, orc_tensor * dst);
+/* binary-ops.cpp add / mul with broadcast of src1 over src0 */
+int orc_add(const orc_tensor * a, const orc_tensor * b, orc_tensor * dst);
+int orc_mul(const orc_tensor * a, const orc_tensor * b, orc_tensor * dst);
+/* ggml_compute_forward_set_rows_f32 (ops.cpp:4892-4940): dst rows (F16|F32) <- src rows (F32) at idx (I32|I64) */
+int orc_set_rows(const orc_tensor * src, const orc_tensor * idx, orc_tensor * dst);
+/* ggml_compute_forward_dup / cpy (ops.cpp:47-330,526): same #elements, F32->F32|F16, F16->F16|F32, any strides */
+int orc_cpy(const orc_tensor * src, orc_tensor * dst);
+/* ggml_compute_forward_get_rows (ops.cpp:4653-4700,4820): dst F32 rows <- dequant(src rows[idx]) */
+int orc_get_rows(const orc_tensor * src, const orc_tensor * idx, orc_tensor * dst);
+
+/* scalar helpers exposed for KATs */
+float orc_expf_avx2(float x);   /* one lane of ggml_v_expf (vec.h:1230-1267), bit-exact */
+float orc_silu_avx2(float x);   /* one lane of ggml_v_silu */
+
+/* ---- whole-model restatement: Llama-3 / Qwen2 style decoder ---- */
+typedef struct orc_llama_config {
+    int32_t n_layer, hidden, n_head, n_kv_head, head_dim, ffn, vocab, max_len;
+    int32_t rope_mode;          /* 0 interleaved (Llama-3, models/llama.h), 2 NEOX (Qwen2) */
+    float   rope_theta, rms_eps;
+    int32_t qkv_bias;           /* Qwen2 */
+} orc_llama_config;
+
+typedef struct orc_weight { int32_t type; const void * data; } orc_weight;  /* row-major [out][in] blocks */
+
+typedef struct orc_llama_layer {
+    const float * attn_norm, * ffn_norm;
+    orc_weight wq, wk, wv, wo, wgate, wup, wdown;
+    const float * bq, * bk, * bv;
+} orc_llama_layer;
+
+typedef struct orc_llama_model {
+    orc_llama_config cfg;
+    orc_weight tok_embd, lm_head;
+    const float * out_norm;
+    const orc_llama_layer * layers;
+    /* KV cache, F16: k [layer][max_len][kvH*hd], v (eager layout, layers.cpp:3082-3093) [layer][kvH*hd][max_len] */
+    uint16_t * k_cache, * v_cache;
+} orc_llama_model;
+
+/* run qlen tokens at positions n_past..n_past+qlen-1; logits[vocab] for the LAST token
+ * (LMFinalSteps, src/models.cpp:1736-1784).  returns 0 or <0. */
+int orc_llama_forward(orc_llama_model * m, const int32_t * tokens, int qlen, int n_past, float * logits);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,17 @@
+"""random reference-format quant blocks for tests (numpy only; mirrors chatllm.cpp_amd/synth.py but fully random
+scale bytes so that every bit pattern of the 6-bit scale packing is exercised)"""
+import numpy as np
+
+TYPE_SIZE = {2: 18, 8: 34, 12: 144}
+BLCK = {2: 32, 8: 32, 12: 256}
+
+
+def rand_blocks(t, rows, K, rng, d_scale=0.01):
+    nb = K // BLCK[t]
+    out = rng.integers(0, 256, (rows, nb, TYPE_SIZE[t]), dtype=np.uint8)
+    d = (rng.uniform(0.25, 1.0, (rows, nb)) * d_scale).astype(np.float16)
+    out[:, :, 0:2] = d.view(np.uint8).reshape(rows, nb, 2)
+    if t == 12:
+        dm = (rng.uniform(0.25, 1.0, (rows, nb)) * d_scale).astype(np.float16)
+        out[:, :, 2:4] = dm.view(np.uint8).reshape(rows, nb, 2)
+    return np.ascontiguousarray(out.reshape(rows, nb * TYPE_SIZE[t]))

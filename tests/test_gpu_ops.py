@@ -1,0 +1,335 @@
+"""GPU parity tests proper: every HIP op, called through the C ABI (ctypes -> libchatllm_hip.so),
+against the CPU oracle (oracle/ggml_oracle.c) on the same seeded inputs.
+
+Tiers:  T0 integer block sums and quantized activations: bit-exact;
+                        T1 per-op fp32 results: |delta| <= 1e-5 * max|ref| (fp32 summation order differs);
+                        byte/index work (set_rows, cpy, get_rows, masks): bit-exact.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import oracle as O
+from synth_helpers import rand_blocks
+
+pytestmark = pytest.mark.gpu
+rng = np.random.default_rng(11)
+T1 = 1e-5
+
+
+def rel_err(a, b):
+    return float(np.max(np.abs(a.astype(np.float64) - b.astype(np.float64))) / (np.max(np.abs(b)) + 1e-30))
+
+
+def P(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+# ---- T0: activation quantizers ---------------------------------------------------------------
+@pytest.mark.parametrize("K", [32, 256, 4096, 14336, 29568])
+def test_quantize_q8_0_bit_exact(gpu, K):
+    T = gpu.Tensor
+    for scale in (1.0, 1e-3, 300.0):
+        x = (rng.standard_normal(K) * scale).astype(np.float32)
+        if K >= 256:
+            x[:32] = 0.0
+            x[40] = x[41] = -x[42]
+            x[64:96] = np.arange(32, dtype=np.float32) + 0.5
+            x[96:128] = (np.arange(32, dtype=np.float32) - 16) * 0.5
+            x[96] = 127.0                                  # id == 1: every k + 0.5 is a rounding tie
+        dx = T.from_numpy(x)
+        dy = T(gpu.I32, [K // 32 * 34 // 2 + 8])           # raw bytes
+        gpu.lib.check(gpu.lib.get().cllm_quantize_row_q8_0(None, dx.data_ptr(), dy.data_ptr(), K), "q8_0")
+        got = dy.raw()[: K // 32 * 34]
+        assert np.array_equal(got, O.quantize_q8_0(x))
+
+
+@pytest.mark.parametrize("K", [256, 4096, 14336])
+def test_quantize_q8_K_bit_exact(gpu, K):
+    T = gpu.Tensor
+    for scale in (1.0, 1e-4, 50.0):
+        x = (rng.standard_normal(K) * scale).astype(np.float32)
+        x[10] = -x[3]
+        x[3] = np.float32(np.max(np.abs(x[:256])) * 2)     # the max sits at index 3, an equal-magnitude negative at 10
+        x[10] = -x[3]
+        x[256 * (K // 256 - 1):] = 0.0                     # an all-zero super-block
+        dx = T.from_numpy(x)
+        dy = T(gpu.I32, [K // 256 * 292 // 4 + 8])
+        gpu.lib.check(gpu.lib.get().cllm_quantize_row_q8_K(None, dx.data_ptr(), dy.data_ptr(), K), "q8_K")
+        got = dy.raw()[: K // 256 * 292]
+        assert np.array_equal(got, O.quantize_q8_K(x))
+
+
+@pytest.mark.parametrize("t", [O.Q4_0, O.Q8_0, O.Q4_K])
+def test_block_integer_sums_bit_exact(gpu, t):
+    K = 4096
+    w = rand_blocks(t, 1, K, rng)
+    x = rng.standard_normal(K).astype(np.float32)
+    a = O.quantize_q8_K(x) if t == O.Q4_K else O.quantize_q8_0(x)
+    _, want = O.vec_dot(t, K, w, a)
+    dw = gpu.Tensor.from_numpy(w, t, [K, 1])
+    dx = gpu.Tensor.from_numpy(x)
+    out = gpu.Tensor(gpu.I32, [want.size])
+    gpu.lib.check(gpu.lib.get().cllm_vec_dot_isums(None, t, K, dw.data_ptr(), dx.data_ptr(), out.data_ptr()), "isums")
+    assert np.array_equal(out.numpy().ravel(), want)
+
+
+# ---- mul_mat -----------------------------------------------------------------------------------
+def _mm_case(gpu, t, K, N, M, ne02=1, ne12=1):
+    if t in (O.F16, O.F32):
+        w = rng.standard_normal((ne02, N, K)).astype(O.NP_OF[t])
+    else:
+        w = rand_blocks(t, N * ne02, K, rng)
+    x = rng.standard_normal((ne12, M, K)).astype(np.float32)
+    want = np.zeros((ne12, M, N), np.float32)
+    O.mul_mat(O.tensor(w, t, [K, N, ne02]), O.tensor(x, O.F32, [K, M, ne12]), O.tensor(want, O.F32, [N, M, ne12]))
+    dw = gpu.Tensor.from_numpy(w, t, [K, N, ne02])
+    dx = gpu.Tensor.from_numpy(x)
+    got = gpu.ops.mul_mat(dw, dx).numpy()
+    return got, want
+
+
+@pytest.mark.parametrize("t", [O.Q4_K, O.Q4_0, O.Q8_0])
+@pytest.mark.parametrize("K,N,M", [(256, 1, 1), (512, 7, 1), (4096, 130, 1), (2048, 64, 2), (1024, 33, 3), (768, 40, 4), (512, 20, 5), (1280, 24, 8)])
+def test_mul_mat_quant_gemv(gpu, t, K, N, M):
+    got, want = _mm_case(gpu, t, K, N, M)
+    assert rel_err(got, want) < T1
+
+
+@pytest.mark.parametrize("t,K", [(O.Q4_K, 14336), (O.Q4_0, 14336), (O.Q8_0, 29568), (O.Q4_K, 8192)])
+def test_mul_mat_quant_long_rows(gpu, t, K):
+    got, want = _mm_case(gpu, t, K, 96, 1)
+    assert rel_err(got, want) < T1
+
+
+@pytest.mark.parametrize("t", [O.Q4_K, O.Q4_0, O.Q8_0])
+@pytest.mark.parametrize("K,N,M", [(512, 64, 16), (1024, 100, 33), (4096, 256, 128), (256, 17, 9)])
+def test_mul_mat_quant_gemm(gpu, t, K, N, M):
+    got, want = _mm_case(gpu, t, K, N, M)
+    assert rel_err(got, want) < T1
+
+
+@pytest.mark.parametrize("t", [O.F16, O.F32])
+@pytest.mark.parametrize("K,N,M,ne02,ne12", [(128, 50, 1, 1, 1), (128, 37, 3, 2, 8), (64, 9, 5, 1, 4), (100, 11, 2, 1, 1), (1031, 16, 1, 2, 2)])
+def test_mul_mat_float(gpu, t, K, N, M, ne02, ne12):
+    got, want = _mm_case(gpu, t, K, N, M, ne02, ne12)
+    assert rel_err(got, want) < T1
+
+
+def test_mul_mat_rejects_bad_arguments(gpu):
+    Tn = gpu.Tensor
+    w = Tn.from_numpy(rand_blocks(O.Q4_K, 4, 256, rng), O.Q4_K, [256, 4])
+    x = Tn.from_numpy(np.zeros((1, 512), np.float32))
+    with pytest.raises(gpu.lib.CllmError):
+        gpu.ops.mul_mat(w, x)                       # K mismatch
+    x16 = Tn.from_numpy(np.zeros((1, 256), np.float16))
+    with pytest.raises(gpu.lib.CllmError):
+        gpu.ops.mul_mat(w, x16)                     # src1 must be F32
+
+
+def test_mul_mat_empty(gpu):
+    w = gpu.Tensor.from_numpy(rand_blocks(O.Q8_0, 4, 64, rng), O.Q8_0, [64, 4])
+    x = gpu.Tensor(gpu.F32, [64, 0])
+    out = gpu.ops.mul_mat(w, x)
+    assert out.ne[:2] == [4, 0]
+
+
+@pytest.mark.parametrize("t", [O.Q4_K, O.Q8_0, O.Q4_0])
+def test_mul_mat_id(gpu, t):
+    K, N, E, U, Tk = 512, 40, 8, 2, 3
+    w = rand_blocks(t, N * E, K, rng)
+    for nb1 in (1, U):
+        x = rng.standard_normal((Tk, nb1, K)).astype(np.float32)
+        ids = rng.integers(0, E, (Tk, U)).astype(np.int32)
+        want = np.zeros((Tk, U, N), np.float32)
+        O.mul_mat_id(O.tensor(w, t, [K, N, E]), O.tensor(x, O.F32, [K, nb1, Tk]), O.tensor(ids, O.I32, [U, Tk]), O.tensor(want, O.F32, [N, U, Tk]))
+        got = gpu.ops.mul_mat_id(gpu.Tensor.from_numpy(w, t, [K, N, E]), gpu.Tensor.from_numpy(x), gpu.Tensor.from_numpy(ids)).numpy()
+        assert rel_err(got.reshape(want.shape), want) < T1
+
+
+# ---- norm / rope / softmax / elementwise -----------------------------------------------------------
+@pytest.mark.parametrize("n0,rows", [(8, 3), (100, 2), (4096, 5), (8192, 1)])
+def test_rms_norm(gpu, n0, rows):
+    x = rng.standard_normal((rows, n0)).astype(np.float32)
+    w = (1 + 0.1 * rng.standard_normal(n0)).astype(np.float32)
+    want = np.zeros_like(x)
+    O.rms_norm(O.tensor(x, O.F32, [n0, rows]), O.tensor(want, O.F32, [n0, rows]), 1e-5)
+    dx = gpu.Tensor.from_numpy(x)
+    got = gpu.ops.rms_norm(dx, 1e-5).numpy()
+    # double-precision sum in a different order: the float mean can differ in the last bit only
+    assert np.allclose(got, want, rtol=3e-7, atol=0)
+    want2 = want * w                                 # the MUL node: one more rounding
+    got2 = gpu.ops.rms_norm_mul(dx, gpu.Tensor.from_numpy(w), 1e-5).numpy()
+    assert np.allclose(got2, want2, rtol=4e-7, atol=0)
+
+
+@pytest.mark.parametrize("mode,hd,n_dims,ff", [(0, 128, 128, False), (2, 128, 128, False), (0, 64, 32, False), (2, 64, 64, True)])
+def test_rope(gpu, mode, hd, n_dims, ff):
+    heads, qlen = 5, 6
+    x = rng.standard_normal((qlen, heads, hd)).astype(np.float32)
+    pos = np.array([0, 1, 7, 100, 1000, 4095], np.int32)
+    ffv = (1.0 + rng.random(n_dims // 2)).astype(np.float32) if ff else None
+    want = np.zeros_like(x)
+    O.rope(O.tensor(x, O.F32, [hd, heads, qlen]), pos, ffv, O.tensor(want, O.F32, [hd, heads, qlen]), n_dims, mode, 500000.0)
+    got = gpu.ops.rope_ext(gpu.Tensor.from_numpy(x), gpu.Tensor.from_numpy(pos), gpu.Tensor.from_numpy(ffv) if ff else None,
+                           n_dims, mode, 0, 500000.0).numpy()
+    # theta is bit-identical (iterated product); device sinf/cosf differ from glibc by <= 2 ulp
+    assert np.max(np.abs(got - want)) < 4e-6
+    # in place (rope_ext_inplace) gives the same bytes
+    dxi = gpu.Tensor.from_numpy(x)
+    gpu.ops.rope_ext(dxi, gpu.Tensor.from_numpy(pos), gpu.Tensor.from_numpy(ffv) if ff else None, n_dims, mode, 0, 500000.0, inplace=True)
+    assert np.array_equal(dxi.numpy(), got)
+
+
+def test_rope_yarn(gpu):
+    hd, heads, qlen = 64, 2, 4
+    x = rng.standard_normal((qlen, heads, hd)).astype(np.float32)
+    pos = np.array([0, 3, 17, 50], np.int32)
+    want = np.zeros_like(x)
+    kw = dict(n_ctx_orig=4096, freq_scale=0.25, ext_factor=1.0, attn_factor=1.2, beta_fast=32.0, beta_slow=1.0)
+    O.rope(O.tensor(x, O.F32, [hd, heads, qlen]), pos, None, O.tensor(want, O.F32, [hd, heads, qlen]), hd, 2, 10000.0, **kw)
+    got = gpu.ops.rope_ext(gpu.Tensor.from_numpy(x), gpu.Tensor.from_numpy(pos), None, hd, 2, freq_base=10000.0, **kw).numpy()
+    assert np.max(np.abs(got - want)) < 2e-5
+
+
+@pytest.mark.parametrize("n0", [1, 5, 8, 33, 1024, 4097])
+def test_soft_max(gpu, n0):
+    x = (rng.standard_normal((2, 3, n0)) * 3).astype(np.float32)
+    want = np.zeros_like(x)
+    O.soft_max(O.tensor(x, O.F32, [n0, 3, 2]), None, O.tensor(want, O.F32, [n0, 3, 2]))
+    got = gpu.ops.soft_max(gpu.Tensor.from_numpy(x)).numpy()
+    assert np.allclose(got, want, rtol=3e-7, atol=0)
+    if n0 % 8 == 0:                                   # the CPU's AVX2 body: same polynomial, same group sums
+        assert np.mean(got.view(np.uint32) == want.view(np.uint32)) > 0.999
+
+
+def test_soft_max_ext_mask(gpu):
+    n0, n1, n2 = 40, 6, 3
+    x = rng.standard_normal((n2, n1, n0)).astype(np.float32)
+    mask = np.where(rng.random((n1, n0)) < 0.3, -np.inf, 0.0).astype(np.float32)
+    mask[:, 0] = 0.0
+    for f16 in (False, True):
+        mk = mask.astype(np.float16) if f16 else mask
+        want = np.zeros_like(x)
+        O.soft_max(O.tensor(x, O.F32, [n0, n1, n2]), O.tensor(mk, O.F16 if f16 else O.F32, [n0, n1]), O.tensor(want, O.F32, [n0, n1, n2]), scale=0.125)
+        got = gpu.ops.soft_max_ext(gpu.Tensor.from_numpy(x), gpu.Tensor.from_numpy(mk), 0.125, 0.0).numpy()
+        assert np.allclose(got, want, rtol=3e-7, atol=0)
+        assert np.array_equal(got == 0, want == 0)
+
+
+@pytest.mark.parametrize("qlen,n_past", [(1, 0), (1, 300), (7, 0), (5, 13)])
+def test_scale_mask_soft_max_equals_three_nodes(gpu, qlen, n_past):
+    nh, n_kv = 4, n_past + qlen
+    x = rng.standard_normal((nh, qlen, n_kv)).astype(np.float32)
+    s = 1.0 / np.sqrt(128.0)
+    want = np.zeros_like(x)
+    St = O.tensor(want, O.F32, [n_kv, qlen, nh])
+    O.scale(O.tensor(x, O.F32, [n_kv, qlen, nh]), St, s)
+    O.diag_mask_inf(St, St, n_past)
+    O.soft_max(St, None, St)
+    dx = gpu.Tensor.from_numpy(x)
+    fused = gpu.ops.scale_mask_soft_max(dx, s, n_past).numpy()
+    chain = gpu.ops.soft_max(gpu.ops.diag_mask_inf(gpu.ops.scale(dx, s), n_past)).numpy()
+    assert np.array_equal(fused, chain)               # fusion does not change a bit
+    assert np.allclose(fused, want, rtol=3e-7, atol=0)
+    assert np.array_equal(fused == 0, want == 0)      # the causal structure is exact
+
+
+def test_diag_mask_scale_add_mul_silu(gpu):
+    x = (rng.standard_normal((2, 5, 61)) * 4).astype(np.float32)
+    b = rng.standard_normal((1, 1, 61)).astype(np.float32)
+    dx, db = gpu.Tensor.from_numpy(x), gpu.Tensor.from_numpy(b)
+    want = np.zeros_like(x)
+    Xo, Wo, Bo = O.tensor(x, O.F32, [61, 5, 2]), O.tensor(want, O.F32, [61, 5, 2]), O.tensor(b, O.F32, [61, 1, 1])
+    O.diag_mask_inf(Xo, Wo, 3)
+    assert np.array_equal(gpu.ops.diag_mask_inf(dx, 3).numpy().view(np.uint32), want.view(np.uint32))
+    O.scale(Xo, Wo, 0.3)
+    assert np.array_equal(gpu.ops.scale(dx, 0.3).numpy().view(np.uint32), want.view(np.uint32))
+    O.add(Xo, Bo, Wo)
+    assert np.array_equal(gpu.ops.add(dx, db).numpy().view(np.uint32), want.view(np.uint32))
+    O.mul(Xo, Bo, Wo)
+    assert np.array_equal(gpu.ops.mul(dx, db).numpy().view(np.uint32), want.view(np.uint32))
+    O.silu(Xo, Wo)
+    got = gpu.ops.silu(dx).numpy()
+    nv = 61 & ~7
+    assert np.array_equal(got[..., :nv].view(np.uint32), want[..., :nv].view(np.uint32))   # polynomial body: bit-exact
+    assert np.allclose(got, want, rtol=1e-6, atol=0)
+    # fused silu(g)*u == the two nodes
+    u = rng.standard_normal(x.shape).astype(np.float32)
+    du = gpu.Tensor.from_numpy(u)
+    assert np.array_equal(gpu.ops.silu_mul(dx, du).numpy(), gpu.ops.mul(gpu.ops.silu(dx), du).numpy())
+
+
+# ---- KV-concat: set_rows / cpy / get_rows (bit-exact) --------------------------------------------------
+@pytest.mark.parametrize("dst_t,i64", [(O.F16, False), (O.F16, True), (O.F32, False)])
+def test_set_rows(gpu, dst_t, i64):
+    n0, rows, n = 1024, 64, 9
+    src = (rng.standard_normal((n, n0)) * 10).astype(np.float32)
+    src[0, :4] = [65504.0, 1e-8, -0.0, 70000.0]        # fp16 edge cases: max, underflow, signed zero, overflow -> inf
+    idx = rng.permutation(rows)[:n].astype(np.int64 if i64 else np.int32)
+    dst0 = rng.standard_normal((rows, n0)).astype(O.NP_OF[dst_t])
+    want = dst0.copy()
+    O.set_rows(O.tensor(src, O.F32, [n0, n]), O.tensor(idx, O.I64 if i64 else O.I32, [n]), O.tensor(want, dst_t, [n0, rows]))
+    d = gpu.Tensor.from_numpy(dst0)
+    gpu.ops.set_rows(d, gpu.Tensor.from_numpy(src), gpu.Tensor.from_numpy(idx))
+    assert np.array_equal(d.numpy().view(np.uint8), want.view(np.uint8))
+
+
+def test_cpy_v_cache_transposed_and_cont(gpu):
+    KD, qlen, ML, n_past = 256, 5, 64, 7
+    v = rng.standard_normal((qlen, KD)).astype(np.float32)
+    cache0 = rng.standard_normal((KD, ML)).astype(np.float16)
+    want = cache0.copy()
+    O.cpy(O.tensor(v, O.F32, [qlen, KD], nb=[KD * 4, 4, KD * qlen * 4, KD * qlen * 4]),
+          O.tensor(want, O.F16, [qlen, KD], nb=[2, ML * 2, ML * KD * 2, ML * KD * 2], offset=n_past * 2))
+    dv = gpu.Tensor.from_numpy(v)
+    dc = gpu.Tensor.from_numpy(cache0)
+    gpu.ops.cpy(dv.transpose(), dc.view([qlen, KD], [2, ML * 2], offset=n_past * 2))
+    assert np.array_equal(dc.numpy().view(np.uint16), want.view(np.uint16))
+    # permute + cont (context layer)
+    c = rng.standard_normal((3, 4, 8)).astype(np.float32)
+    got = gpu.ops.cont(gpu.Tensor.from_numpy(c).permute(0, 2, 1, 3)).numpy()
+    assert np.array_equal(got, np.ascontiguousarray(c.transpose(1, 0, 2)))
+
+
+@pytest.mark.parametrize("t", [O.Q4_0, O.Q8_0, O.Q4_K, O.F16, O.F32])
+def test_get_rows_bit_exact(gpu, t):
+    n0, rows, n = 512, 30, 7
+    table = rng.standard_normal((rows, n0)).astype(O.NP_OF[t]) if t in (O.F16, O.F32) else rand_blocks(t, rows, n0, rng)
+    ids = rng.integers(0, rows, n).astype(np.int32)
+    want = np.zeros((n, n0), np.float32)
+    O.get_rows(O.tensor(table, t, [n0, rows]), O.tensor(ids, O.I32, [n]), O.tensor(want, O.F32, [n0, n]))
+    got = gpu.ops.get_rows(gpu.Tensor.from_numpy(table, t, [n0, rows]), gpu.Tensor.from_numpy(ids)).numpy()
+    assert np.array_equal(got.reshape(want.shape).view(np.uint32), want.view(np.uint32))
+
+
+# ---- attention over strided cache views (GQA broadcast) ---------------------------------------------------
+@pytest.mark.parametrize("qlen,n_past", [(1, 0), (1, 37), (1, 255), (6, 0), (5, 11)])
+def test_attention_composite(gpu, qlen, n_past):
+    hd, nh, nkv, ML = 128, 8, 2, 256
+    KD, n_kv = hd * nkv, n_past + qlen
+    q = rng.standard_normal((qlen, nh, hd)).astype(np.float32)
+    kc = rng.standard_normal((ML, KD)).astype(np.float16)
+    vc = rng.standard_normal((KD, ML)).astype(np.float16)
+    sc = np.zeros((nh, qlen, n_kv), np.float32)
+    ctx = np.zeros((nh, qlen, hd), np.float32)
+    S = O.tensor(sc, O.F32, [n_kv, qlen, nh])
+    O.mul_mat(O.tensor(kc, O.F16, [hd, n_kv, nkv], nb=[2, KD * 2, hd * 2, KD * ML * 2]),
+              O.tensor(q, O.F32, [hd, qlen, nh], nb=[4, nh * hd * 4, hd * 4, nh * hd * qlen * 4]), S)
+    O.scale(S, S, 1.0 / np.sqrt(hd))
+    O.diag_mask_inf(S, S, n_past)
+    O.soft_max(S, None, S)
+    O.mul_mat(O.tensor(vc, O.F16, [n_kv, hd, nkv], nb=[2, ML * 2, ML * hd * 2, ML * KD * 2]), S, O.tensor(ctx, O.F32, [hd, qlen, nh]))
+    want = np.ascontiguousarray(ctx.transpose(1, 0, 2)).reshape(qlen, nh * hd)
+
+    ops = gpu.ops
+    dq, dk, dv = gpu.Tensor.from_numpy(q), gpu.Tensor.from_numpy(kc), gpu.Tensor.from_numpy(vc)
+    Kv = dk.view([hd, n_kv, nkv], [2, KD * 2, hd * 2])
+    Qv = dq.permute(0, 2, 1, 3)
+    s = ops.mul_mat(Kv, Qv)
+    p = ops.scale_mask_soft_max(s, 1.0 / np.sqrt(hd), n_past)
+    Vv = dv.view([n_kv, hd, nkv], [2, ML * 2, ML * hd * 2])
+    c = ops.mul_mat(Vv, p)
+    got = ops.cont(c.permute(0, 2, 1, 3)).numpy().reshape(qlen, nh * hd)
+    assert rel_err(got, want) < 2e-5

@@ -1,0 +1,305 @@
+"""Pins oracle/ggml_oracle.c (our C restatement) against the REAL reference CPU backend
+(oracle/_ref/libggml-cpu.so built from /root/reference by oracle/Makefile, driven through
+oracle/ref_ops.c).  The reference ships no tests, so this is the parity pin.
+Skipped where oracle/_ref has not been built (it always is in the build container and it
+travels to the GPU box as a prebuilt .so)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import oracle as O
+from synth_helpers import rand_blocks
+
+pytestmark = pytest.mark.skipif(not O.ref_available(), reason="oracle/_ref not built")
+
+P = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
+rng = np.random.default_rng(7)
+
+
+def rel_err(a, b):
+    return float(np.max(np.abs(a - b)) / (np.max(np.abs(b)) + 1e-30))
+
+
+@pytest.mark.parametrize("K", [32, 256, 4096, 14336])
+def test_quantize_q8_0_bit_exact(K):
+    R = O.ref()
+    for scale in (1.0, 1e-3, 300.0):
+        x = (rng.standard_normal(K) * scale).astype(np.float32)
+        if K >= 256:
+            x[:32] = 0.0                     # all-zero block
+            x[40] = x[41] = -x[42]           # ties in |x|
+            x[64:96] = np.arange(32, dtype=np.float32) + 0.5   # amax = 31.5 ... exact halves after scaling show the rounding mode
+            x[96:128] = (np.arange(32, dtype=np.float32) - 16) * 0.5; x[96] = 127.0   # id == 1: every k+0.5 is a tie
+        got = O.quantize_q8_0(x)
+        ref = np.zeros_like(got)
+        assert R.ref_quantize_cpu(O.Q8_0, P(x), P(ref), C.c_int64(K)) == 0
+        assert np.array_equal(got, ref)
+        got = O.quantize_q8_0(x, ref=True)
+        assert R.ref_quantize_ref(O.Q8_0, P(x), P(ref), C.c_int64(K)) == 0
+        assert np.array_equal(got, ref)
+
+
+@pytest.mark.parametrize("K", [256, 4096, 14336])
+def test_quantize_q8_K_bit_exact(K):
+    R = O.ref()
+    for scale in (1.0, 1e-4, 50.0):
+        x = (rng.standard_normal(K) * scale).astype(np.float32)
+        x[10] = -x[3]                    # same magnitude, opposite sign: the FIRST one decides the sign of iscale
+        x[256 * (K // 256 - 1):] *= -1
+        got = O.quantize_q8_K(x)
+        ref = np.zeros_like(got)
+        assert R.ref_quantize_cpu(O.Q8_K, P(x), P(ref), C.c_int64(K)) == 0
+        assert np.array_equal(got, ref)
+
+
+@pytest.mark.parametrize("t", [O.Q4_0, O.Q8_0, O.Q4_K])
+def test_dequantize_bit_exact(t):
+    R = O.ref()
+    K = 2048
+    w = rand_blocks(t, 1, K, rng)
+    got = O.dequantize(t, w, K)
+    ref = np.zeros(K, np.float32)
+    assert R.ref_dequantize(t, P(w), P(ref), C.c_int64(K)) == 0
+    assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
+
+
+@pytest.mark.parametrize("t", [O.Q4_0, O.Q8_0, O.Q4_K])
+def test_vec_dot_matches_reference(t):
+    R = O.ref()
+    K = 4096
+    w = rand_blocks(t, 1, K, rng)
+    x = rng.standard_normal(K).astype(np.float32)
+    a = O.quantize_q8_K(x) if t == O.Q4_K else O.quantize_q8_0(x)
+    got, isums = O.vec_dot(t, K, w, a)
+    s = C.c_float()
+    assert R.ref_vec_dot(t, C.c_int64(K), P(w), P(a), C.byref(s)) == 0
+    # the reference takes its AVX2 branch: identical integer sums, different fp32 summation order
+    assert abs(got - s.value) <= 2e-5 * (abs(s.value) + 1.0)
+    # integer sums against a direct dequantized-integer computation
+    assert isums.dtype == np.int32 and np.all(np.abs(isums) < 2**31 - 1)
+
+
+@pytest.mark.parametrize("t,K,N,M", [(O.Q4_K, 512, 48, 1), (O.Q4_K, 1024, 33, 5), (O.Q4_0, 256, 40, 1), (O.Q4_0, 512, 17, 7),
+                                     (O.Q8_0, 256, 40, 1), (O.Q8_0, 1024, 31, 3), (O.F16, 128, 50, 3), (O.F32, 96, 20, 2)])
+def test_mul_mat(t, K, N, M):
+    R = O.ref()
+    if t in (O.F16, O.F32):
+        w = rng.standard_normal((N, K)).astype(O.NP_OF[t])
+    else:
+        w = rand_blocks(t, N, K, rng)
+    x = rng.standard_normal((M, K)).astype(np.float32)
+    ref = np.zeros((M, N), np.float32)
+    assert R.ref_mul_mat(t, C.c_int64(K), C.c_int64(N), C.c_int64(M), C.c_int64(1), C.c_int64(1), P(w), P(x), P(ref)) == 0
+    got = np.zeros((M, N), np.float32)
+    O.mul_mat(O.tensor(w, t, [K, N]), O.tensor(x, O.F32, [K, M]), O.tensor(got, O.F32, [N, M]))
+    # Q4_0/Q8_0 with M >= 2 go through tinyBLAS in the reference (different fp32 order), hence a tolerance (tier T1)
+    assert rel_err(got, ref) < 1e-5
+
+
+def test_mul_mat_broadcast_heads():
+    """GQA broadcast: src0 [K, N, 2] against src1 [K, M, 6]"""
+    R = O.ref()
+    K, N, M = 64, 24, 3
+    w = rng.standard_normal((2, N, K)).astype(np.float16)
+    x = rng.standard_normal((6, M, K)).astype(np.float32)
+    ref = np.zeros((6, M, N), np.float32)
+    assert R.ref_mul_mat(O.F16, C.c_int64(K), C.c_int64(N), C.c_int64(M), C.c_int64(2), C.c_int64(6), P(w), P(x), P(ref)) == 0
+    got = np.zeros_like(ref)
+    O.mul_mat(O.tensor(w, O.F16, [K, N, 2]), O.tensor(x, O.F32, [K, M, 6]), O.tensor(got, O.F32, [N, M, 6]))
+    assert rel_err(got, ref) < 1e-5
+
+
+@pytest.mark.parametrize("t", [O.Q4_K, O.Q8_0])
+def test_mul_mat_id(t):
+    R = O.ref()
+    K, N, E, U, T = 512, 24, 4, 2, 3
+    w = rand_blocks(t, N * E, K, rng)
+    for nb1 in (1, U):
+        x = rng.standard_normal((T, nb1, K)).astype(np.float32)
+        ids = rng.integers(0, E, (T, U)).astype(np.int32)
+        ref = np.zeros((T, U, N), np.float32)
+        assert R.ref_mul_mat_id(t, C.c_int64(K), C.c_int64(N), C.c_int64(E), C.c_int64(nb1), C.c_int64(U), C.c_int64(T), P(w), P(x), P(ids), P(ref)) == 0
+        got = np.zeros_like(ref)
+        O.mul_mat_id(O.tensor(w, t, [K, N, E]), O.tensor(x, O.F32, [K, nb1, T]), O.tensor(ids, O.I32, [U, T]), O.tensor(got, O.F32, [N, U, T]))
+        assert rel_err(got, ref) < 1e-5
+
+
+@pytest.mark.parametrize("n0", [8, 100, 4096])
+def test_rms_norm_bit_exact(n0):
+    R = O.ref()
+    x = rng.standard_normal((3, 5, n0)).astype(np.float32)
+    ref = np.zeros_like(x)
+    assert R.ref_unary(0, C.c_int64(n0), C.c_int64(5), C.c_int64(3), P(x), P(ref), C.c_float(1e-5), C.c_int(0)) == 0
+    got = np.zeros_like(x)
+    O.rms_norm(O.tensor(x, O.F32, [n0, 5, 3]), O.tensor(got, O.F32, [n0, 5, 3]), 1e-5)
+    assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
+
+
+@pytest.mark.parametrize("n0", [7, 8, 61, 256])
+def test_silu_bit_exact(n0):
+    R = O.ref()
+    x = (rng.standard_normal((4, n0)) * 4).astype(np.float32)
+    x[0, 0] = 100.0
+    x[1, 0] = -100.0
+    ref = np.zeros_like(x)
+    assert R.ref_unary(1, C.c_int64(n0), C.c_int64(4), C.c_int64(1), P(x), P(ref), C.c_float(0), C.c_int(0)) == 0
+    got = np.zeros_like(x)
+    O.silu(O.tensor(x, O.F32, [n0, 4]), O.tensor(got, O.F32, [n0, 4]))
+    nv = n0 & ~7                       # vector body is bit exact; the scalar tail uses libm expf on both sides
+    assert np.array_equal(got[:, :nv].view(np.uint32), ref[:, :nv].view(np.uint32))
+    assert np.allclose(got, ref, rtol=1e-6, atol=0)
+
+
+@pytest.mark.parametrize("n0", [5, 8, 33, 1024])
+def test_soft_max_bit_exact(n0):
+    R = O.ref()
+    x = (rng.standard_normal((2, 3, n0)) * 3).astype(np.float32)
+    ref = np.zeros_like(x)
+    assert R.ref_unary(2, C.c_int64(n0), C.c_int64(3), C.c_int64(2), P(x), P(ref), C.c_float(0), C.c_int(0)) == 0
+    got = np.zeros_like(x)
+    O.soft_max(O.tensor(x, O.F32, [n0, 3, 2]), None, O.tensor(got, O.F32, [n0, 3, 2]))
+    assert np.allclose(got, ref, rtol=2e-7, atol=0)
+    if n0 % 8 == 0:
+        assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
+
+
+def test_soft_max_ext_mask():
+    R = O.ref()
+    n0, n1, n2 = 40, 6, 3
+    x = rng.standard_normal((n2, n1, n0)).astype(np.float32)
+    mask = np.where(rng.random((n1, n0)) < 0.3, -np.inf, 0.0).astype(np.float32)
+    mask[:, 0] = 0.0
+    for f16 in (0, 1):
+        mk = mask.astype(np.float16) if f16 else mask
+        ref = np.zeros_like(x)
+        assert R.ref_soft_max_ext(C.c_int64(n0), C.c_int64(n1), C.c_int64(n2), P(x), P(mk), C.c_int(f16), C.c_float(0.125), P(ref)) == 0
+        got = np.zeros_like(x)
+        O.soft_max(O.tensor(x, O.F32, [n0, n1, n2]), O.tensor(mk, O.F16 if f16 else O.F32, [n0, n1]), O.tensor(got, O.F32, [n0, n1, n2]), scale=0.125)
+        assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
+
+
+def test_diag_mask_and_scale():
+    R = O.ref()
+    x = rng.standard_normal((2, 5, 9)).astype(np.float32)
+    ref = np.zeros_like(x)
+    got = np.zeros_like(x)
+    assert R.ref_unary(3, C.c_int64(9), C.c_int64(5), C.c_int64(2), P(x), P(ref), C.c_float(0), C.c_int(4)) == 0
+    O.diag_mask_inf(O.tensor(x, O.F32, [9, 5, 2]), O.tensor(got, O.F32, [9, 5, 2]), 4)
+    assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
+    assert R.ref_unary(4, C.c_int64(9), C.c_int64(5), C.c_int64(2), P(x), P(ref), C.c_float(0.088388), C.c_int(0)) == 0
+    O.scale(O.tensor(x, O.F32, [9, 5, 2]), O.tensor(got, O.F32, [9, 5, 2]), 0.088388)
+    assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
+
+
+def test_add_mul_broadcast():
+    R = O.ref()
+    a = rng.standard_normal((3, 4, 16)).astype(np.float32)
+    b = rng.standard_normal((1, 1, 16)).astype(np.float32)
+    for op, fn in ((0, O.add), (1, O.mul)):
+        ref = np.zeros_like(a)
+        assert R.ref_binary(op, C.c_int64(16), C.c_int64(4), C.c_int64(3), P(a), C.c_int64(16), C.c_int64(1), C.c_int64(1), P(b), P(ref)) == 0
+        got = np.zeros_like(a)
+        fn(O.tensor(a, O.F32, [16, 4, 3]), O.tensor(b, O.F32, [16, 1, 1]), O.tensor(got, O.F32, [16, 4, 3]))
+        assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
+
+
+@pytest.mark.parametrize("mode,hd,n_dims,ff", [(0, 128, 128, False), (2, 128, 128, False), (0, 64, 32, False), (2, 64, 64, True)])
+def test_rope(mode, hd, n_dims, ff):
+    R = O.ref()
+    heads, qlen = 3, 5
+    x = rng.standard_normal((qlen, heads, hd)).astype(np.float32)
+    pos = np.array([0, 1, 7, 100, 4095], np.int32)
+    ffv = (1.0 + rng.random(n_dims // 2)).astype(np.float32) if ff else None
+    ref = np.zeros_like(x)
+    assert R.ref_rope(C.c_int64(hd), C.c_int64(heads), C.c_int64(qlen), P(x), P(pos), P(ffv) if ff else None, C.c_int(n_dims), C.c_int(mode),
+                      C.c_int(0), C.c_float(500000.0), C.c_float(1.0), C.c_float(0.0), C.c_float(1.0), C.c_float(0.0), C.c_float(0.0), P(ref)) == 0
+    got = np.zeros_like(x)
+    O.rope(O.tensor(x, O.F32, [hd, heads, qlen]), pos, ffv, O.tensor(got, O.F32, [hd, heads, qlen]), n_dims, mode, 500000.0)
+    # same libm and the same iterated theta; the reference binary (gcc, -ffp-contract=fast) fuses x0*c - x1*s into an
+    # FMA, the restatement keeps two roundings: 1 ulp apart at most
+    assert np.allclose(got, ref, rtol=3e-7, atol=3e-7)
+
+
+def test_rope_yarn():
+    R = O.ref()
+    hd, heads, qlen = 64, 2, 4
+    x = rng.standard_normal((qlen, heads, hd)).astype(np.float32)
+    pos = np.array([0, 3, 17, 50], np.int32)      # small angles: theta itself is contraction-sensitive in the reference build
+    ref = np.zeros_like(x)
+    assert R.ref_rope(C.c_int64(hd), C.c_int64(heads), C.c_int64(qlen), P(x), P(pos), None, C.c_int(hd), C.c_int(2), C.c_int(4096),
+                      C.c_float(10000.0), C.c_float(0.25), C.c_float(1.0), C.c_float(1.2), C.c_float(32.0), C.c_float(1.0), P(ref)) == 0
+    got = np.zeros_like(x)
+    O.rope(O.tensor(x, O.F32, [hd, heads, qlen]), pos, None, O.tensor(got, O.F32, [hd, heads, qlen]), hd, 2, 10000.0,
+           n_ctx_orig=4096, freq_scale=0.25, ext_factor=1.0, attn_factor=1.2, beta_fast=32.0, beta_slow=1.0)
+    assert np.allclose(got, ref, rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("dst_t,i64", [(O.F16, 0), (O.F16, 1), (O.F32, 0)])
+def test_set_rows(dst_t, i64):
+    R = O.ref()
+    n0, rows, n = 48, 20, 6
+    src = rng.standard_normal((n, n0)).astype(np.float32)
+    idx = rng.permutation(rows)[:n].astype(np.int64 if i64 else np.int32)
+    dst0 = rng.standard_normal((rows, n0)).astype(O.NP_OF[dst_t])
+    ref = dst0.copy()
+    assert R.ref_set_rows(dst_t, C.c_int64(n0), C.c_int64(rows), C.c_int64(n), P(src), P(idx), C.c_int(i64), P(ref)) == 0
+    got = dst0.copy()
+    O.set_rows(O.tensor(src, O.F32, [n0, n]), O.tensor(idx, O.I64 if i64 else O.I32, [n]), O.tensor(got, dst_t, [n0, rows]))
+    assert np.array_equal(got.view(np.uint8), ref.view(np.uint8))
+
+
+def test_cpy_v_cache_transposed():
+    R = O.ref()
+    KD, qlen, ML, n_past = 32, 5, 24, 7
+    v = rng.standard_normal((qlen, KD)).astype(np.float32)
+    cache0 = rng.standard_normal((KD, ML)).astype(np.float16)
+    ref = cache0.copy()
+    assert R.ref_cpy_v_cache(C.c_int64(KD), C.c_int64(qlen), C.c_int64(ML), C.c_int64(n_past), P(v), P(ref)) == 0
+    got = cache0.copy()
+    src = O.tensor(v, O.F32, [qlen, KD], nb=[KD * 4, 4, KD * qlen * 4, KD * qlen * 4])          # transpose(v)
+    dst = O.tensor(got, O.F16, [qlen, KD], nb=[2, ML * 2, ML * KD * 2, ML * KD * 2], offset=n_past * 2)
+    O.cpy(src, dst)
+    assert np.array_equal(got.view(np.uint16), ref.view(np.uint16))
+
+
+@pytest.mark.parametrize("t", [O.Q4_0, O.Q8_0, O.Q4_K, O.F16])
+def test_get_rows(t):
+    R = O.ref()
+    n0, rows, n = 512, 30, 7
+    table = rng.standard_normal((rows, n0)).astype(np.float16) if t == O.F16 else rand_blocks(t, rows, n0, rng)
+    ids = rng.integers(0, rows, n).astype(np.int32)
+    ref = np.zeros((n, n0), np.float32)
+    assert R.ref_get_rows(t, C.c_int64(n0), C.c_int64(rows), P(table), C.c_int64(n), P(ids), P(ref)) == 0
+    got = np.zeros_like(ref)
+    O.get_rows(O.tensor(table, t, [n0, rows]), O.tensor(ids, O.I32, [n]), O.tensor(got, O.F32, [n0, n]))
+    assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
+
+
+@pytest.mark.parametrize("qlen,n_past", [(1, 0), (1, 37), (6, 0), (5, 11)])
+def test_attention_composite(qlen, n_past):
+    """the exact node sequence chatllm emits for eager attention over strided cache views"""
+    R = O.ref()
+    hd, nh, nkv, ML = 64, 4, 2, 64
+    KD, n_kv = hd * nkv, n_past + qlen
+    q = rng.standard_normal((qlen, nh, hd)).astype(np.float32)
+    kc = rng.standard_normal((ML, KD)).astype(np.float16)
+    vc = rng.standard_normal((KD, ML)).astype(np.float16)
+    ref = np.zeros((qlen, nh * hd), np.float32)
+    sref = np.zeros((nh, qlen, n_kv), np.float32)
+    assert R.ref_attention(C.c_int64(hd), C.c_int64(nh), C.c_int64(nkv), C.c_int64(qlen), C.c_int64(n_past), C.c_int64(ML), P(q), P(kc), P(vc), P(ref), P(sref)) == 0
+
+    sc = np.zeros((nh, qlen, n_kv), np.float32)
+    ctx = np.zeros((nh, qlen, hd), np.float32)
+    Kv = O.tensor(kc, O.F16, [hd, n_kv, nkv], nb=[2, KD * 2, hd * 2, KD * ML * 2])
+    Qv = O.tensor(q, O.F32, [hd, qlen, nh], nb=[4, nh * hd * 4, hd * 4, nh * hd * qlen * 4])
+    S = O.tensor(sc, O.F32, [n_kv, qlen, nh])
+    O.mul_mat(Kv, Qv, S)
+    assert rel_err(sc, sref) < 1e-5
+    O.scale(S, S, 1.0 / np.sqrt(hd))
+    O.diag_mask_inf(S, S, n_past)
+    O.soft_max(S, None, S)
+    Vv = O.tensor(vc, O.F16, [n_kv, hd, nkv], nb=[2, ML * 2, ML * hd * 2, ML * KD * 2])
+    O.mul_mat(Vv, S, O.tensor(ctx, O.F32, [hd, qlen, nh]))
+    got = np.ascontiguousarray(ctx.transpose(1, 0, 2)).reshape(qlen, nh * hd)
+    assert rel_err(got, ref) < 2e-5
