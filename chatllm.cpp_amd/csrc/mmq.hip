@@ -1,3 +1,265 @@
-// mmq.hip -- quantized mat-mat (prefill GEMM) on int8 MFMA.  (placeholder: filled in below)
+// mmq.hip -- quantized mat-mat (prefill GEMM) on the CDNA4 int8 matrix cores.
+//
+// Replaces, for ne11 >= 9 columns, ggml_compute_forward_mul_mat (ggml-cpu.c:1229-1421) over the Q4_K vec_dot
+// (ggml-cpu/quants.c:550-623) and, for Q4_0/Q8_0, llamafile's tinyBLAS_Q0 (ggml-cpu/llamafile/sgemm.cpp:1346-1790,
+// 3910-3982).  SAME arithmetic as the CPU path: src1 is quantized to Q8_0 / Q8_K first, every
+// 32-element block dot product is an exact int32 (here: one v_mfma_i32_16x16x32_i8 per 16x16 output patch),
+// scaling and accumulation are fp32.  Only the fp32 summation ORDER differs from the CPU (tier T1).
+//
+// Tiling (per workgroup of 4 waves): 128 weight rows (n) x 64 tokens (m), K walked in steps of 256 elements
+// (one Q4_K super-block / eight 32-blocks).  Per step the weight tile is unpacked to int8 in LDS ([n][256+16],
+// the 16-byte pad makes the ds_read_b64 fragment reads conflict-free), the activation tile is copied from the
+// act rows, block scales go to small [s][*] planes.  Wave w owns a 32(m) x 64(n) quadrant: 2x4 MFMA patches.
+//   A operand = activations (rows = tokens), B operand = weights (cols = weight rows)
+//   D[m][n]: lane holds n = lane&15 and the four tokens m = 4*(lane>>4) + r         (cdna_hip_programming.md section 3)
+// Per 32-block and patch: 1 MFMA (16 x 16 x 32 MACs) + 4 VALU ops to fold the block scale in:
+//   Q4_K : acc_i += sc[n][s] * D      (v_mad_i32_i24, exact)   ; per super-block: acc_f += (d[n]*dx[m]) * acc_i - (dmin[n]*dx[m]) * sum_s m[n][s]*sx[m][s]
+//   Q4_0/Q8_0 : acc_f += float(D) * (dw[n][s] * dx[m][s])
+// blockIdx.x walks the token tiles fastest so that concurrently resident workgroups share weight tiles in L2.
 #include "common.h"
-int launch_mmq(hipStream_t, int, const tview &, const void *, size_t, const tview &, const tview &) { return CLLM_E_UNSUPPORTED; }
+
+typedef int   i32x4 __attribute__((ext_vector_type(4)));
+
+#define MMQ_BN 128
+#define MMQ_BM 64
+#define MMQ_MI 2            // 16-row token patches per wave (wave quadrant = 32 tokens x 64 weight rows)
+#define MMQ_LD 272           // bytes per LDS tile row: 256 int8 + 16 pad
+
+template <int TYPE> struct mmq_traits;
+template <> struct mmq_traits<CLLM_TYPE_Q4_K> { static constexpr int kb = 256; };
+template <> struct mmq_traits<CLLM_TYPE_Q4_0> { static constexpr int kb = 32; };
+template <> struct mmq_traits<CLLM_TYPE_Q8_0> { static constexpr int kb = 32; };
+
+struct mmq_args {
+    const char * W; int64_t nb01; int64_t N; int64_t K;
+    const char * act; size_t act_stride; int64_t M;
+    float * dst; int64_t ldd;     // dst[m * ldd + n]
+};
+
+// LDS map (bytes)
+//   Wt  : MMQ_BN * MMQ_LD                    int8 weights
+//   Xt  : MMQ_BM * MMQ_LD                    int8 activations
+//   Wsc : Q4_K: sc[n][8] u8 | mn[n][8] u8 | d[n] f32 | dmin[n] f32       others: dw[8][n] f32
+//   Xsc : Q4_K: dx[m] f32 | sx[8][m] i32                                   others: dx[8][m] f32
+constexpr int LDS_WT = 0;
+constexpr int LDS_XT = LDS_WT + MMQ_BN * MMQ_LD;
+constexpr int LDS_WS = LDS_XT + MMQ_BM * MMQ_LD;
+constexpr int LDS_WS_BYTES = MMQ_BN * 8 * 4;                 // 4 KB either way (Q4_K uses 8+8+4+4 = 24 B per row)
+constexpr int LDS_XS = LDS_WS + LDS_WS_BYTES;
+constexpr int LDS_XS_BYTES = MMQ_BM * 9 * 4;
+constexpr int LDS_TOTAL = LDS_XS + LDS_XS_BYTES;
+
+__device__ __forceinline__ uint32_t nib_minus8(uint32_t nib4) {   // four nibbles (one per byte, 0..15) -> four int8 (nib - 8)
+    return (((nib4 | 0x80808080u) - 0x08080808u) ^ 0x80808080u);
+}
+
+template <int TYPE>
+__global__ void __launch_bounds__(256, 2) k_mmq(const mmq_args a) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    constexpr bool IS_K = TYPE == CLLM_TYPE_Q4_K;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t m0 = (int64_t) blockIdx.x * MMQ_BM, n0 = (int64_t) blockIdx.y * MMQ_BN;
+    const int wn = (wave & 1) * 64, wm = (wave >> 1) * (MMQ_MI * 16);       // this wave's quadrant inside the tile
+    const int l15 = lane & 15, l4 = lane >> 4;
+
+    char * Wt = lds + LDS_WT; char * Xt = lds + LDS_XT; char * Ws = lds + LDS_WS; char * Xs = lds + LDS_XS;
+    const int64_t K = a.K;
+    const int64_t act_d = (int64_t) act_off_d(K), act_s = (int64_t) act_off_s(K, mmq_traits<TYPE>::kb);
+
+    float acc_f[MMQ_MI][4][4];                                         // [m patch][n patch][r]
+#pragma unroll
+    for (int i = 0; i < MMQ_MI; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) acc_f[i][j][r] = 0.0f;
+
+    for (int64_t k0 = 0; k0 < K; k0 += 256) {
+        __syncthreads();                                          // previous step's fragments are consumed
+        // ---- stage activations: 128 rows x 256 int8 (16 chunks of 16 B per row) ----
+        for (int c = tid; c < MMQ_BM * 16; c += 256) {
+            const int row = c >> 4, ch = c & 15;
+            const int64_t m = m0 + row;
+            u32x4 v = {0, 0, 0, 0};
+            if (m < a.M && k0 + ch * 16 < K) v = *(const u32x4 *)(a.act + m * a.act_stride + k0 + ch * 16);
+            *(u32x4 *)(Xt + row * MMQ_LD + ch * 16) = v;
+        }
+        if (IS_K) {
+            for (int c = tid; c < MMQ_BM * 9; c += 256) {         // dx[m], sx[8][m]
+                const int row = c % MMQ_BM, f = c / MMQ_BM;
+                const int64_t m = m0 + row;
+                uint32_t v = 0;
+                if (m < a.M) {
+                    const char * ar = a.act + m * a.act_stride;
+                    v = f == 0 ? *(const uint32_t *)(ar + act_d + (k0 / 256) * 4) : *(const uint32_t *)(ar + act_s + ((k0 / 32) + (f - 1)) * 4);
+                }
+                *(uint32_t *)(Xs + (f * MMQ_BM + row) * 4) = v;
+            }
+        } else {
+            for (int c = tid; c < MMQ_BM * 8; c += 256) {         // dx[8][m]
+                const int row = c % MMQ_BM, s = c / MMQ_BM;
+                const int64_t m = m0 + row;
+                uint32_t v = 0;
+                if (m < a.M && k0 + s * 32 < K) v = *(const uint32_t *)(a.act + m * a.act_stride + act_d + ((k0 / 32) + s) * 4);
+                *(uint32_t *)(Xs + (s * MMQ_BM + row) * 4) = v;
+            }
+        }
+        // ---- stage weights ----
+        if (IS_K) {
+            for (int c = tid; c < MMQ_BN * 9; c += 256) {         // 9 chunks of 16 B per 144-byte super-block
+                const int row = c / 9, ch = c % 9;
+                const int64_t n = n0 + row;
+                u32x4 v = {0, 0, 0, 0};
+                if (n < a.N) v = *(const u32x4 *)(a.W + n * a.nb01 + (k0 / 256) * 144 + ch * 16);
+                if (ch == 0) {
+                    const uint32_t u0 = v.y & 0x3f3f3f3fu, u2 = v.z & 0x3f3f3f3fu;
+                    const uint32_t u1 = (v.w & 0x0f0f0f0fu) | (((v.y >> 6) & 0x03030303u) << 4);
+                    const uint32_t u3 = ((v.w >> 4) & 0x0f0f0f0fu) | (((v.z >> 6) & 0x03030303u) << 4);
+                    *(u32x2 *)(Ws + row * 8) = u32x2{u0, u1};                                   // sc[n][8]
+                    *(u32x2 *)(Ws + MMQ_BN * 8 + row * 8) = u32x2{u2, u3};                      // mn[n][8]
+                    *(float *)(Ws + MMQ_BN * 16 + row * 4) = h2f((uint16_t)(v.x & 0xffff));     // d[n]
+                    *(float *)(Ws + MMQ_BN * 20 + row * 4) = h2f((uint16_t)(v.x >> 16));        // dmin[n]
+                } else {
+                    const int j = ch - 1, off = 64 * (j >> 1) + 16 * (j & 1);
+                    *(u32x4 *)(Wt + row * MMQ_LD + off)      = u32x4{v.x & 0x0f0f0f0fu, v.y & 0x0f0f0f0fu, v.z & 0x0f0f0f0fu, v.w & 0x0f0f0f0fu};
+                    *(u32x4 *)(Wt + row * MMQ_LD + off + 32) = u32x4{(v.x >> 4) & 0x0f0f0f0fu, (v.y >> 4) & 0x0f0f0f0fu, (v.z >> 4) & 0x0f0f0f0fu, (v.w >> 4) & 0x0f0f0f0fu};
+                }
+            }
+        } else {
+            constexpr int BS = TYPE == CLLM_TYPE_Q8_0 ? 34 : 18;
+            struct __attribute__((packed, aligned(2))) q16 { uint32_t x, y, z, w; };
+            for (int c = tid; c < MMQ_BN * 8; c += 256) {         // one 32-block per task
+                const int row = c >> 3, s = c & 7;
+                const int64_t n = n0 + row, b = k0 / 32 + s;
+                float d = 0.0f;
+                u32x4 lo = {0, 0, 0, 0}, hi = {0, 0, 0, 0};
+                if (n < a.N && b * 32 < K) {
+                    const char * bp = a.W + n * a.nb01 + b * BS;
+                    d = h2f(*(const uint16_t *) bp);
+                    const q16 q0 = *(const q16 *)(bp + 2);
+                    if (TYPE == CLLM_TYPE_Q8_0) {
+                        const q16 q1 = *(const q16 *)(bp + 18);
+                        lo = u32x4{q0.x, q0.y, q0.z, q0.w}; hi = u32x4{q1.x, q1.y, q1.z, q1.w};
+                    } else {
+                        lo = u32x4{nib_minus8(q0.x & 0x0f0f0f0fu), nib_minus8(q0.y & 0x0f0f0f0fu), nib_minus8(q0.z & 0x0f0f0f0fu), nib_minus8(q0.w & 0x0f0f0f0fu)};
+                        hi = u32x4{nib_minus8((q0.x >> 4) & 0x0f0f0f0fu), nib_minus8((q0.y >> 4) & 0x0f0f0f0fu), nib_minus8((q0.z >> 4) & 0x0f0f0f0fu), nib_minus8((q0.w >> 4) & 0x0f0f0f0fu)};
+                    }
+                }
+                *(u32x4 *)(Wt + row * MMQ_LD + s * 32)      = lo;
+                *(u32x4 *)(Wt + row * MMQ_LD + s * 32 + 16) = hi;
+                *(float *)(Ws + (s * MMQ_BN + row) * 4) = d;       // dw[8][n]
+            }
+        }
+        __syncthreads();
+
+        // ---- compute ----
+        int acc_i[MMQ_MI][4][4];
+        if (IS_K) {
+#pragma unroll
+            for (int i = 0; i < MMQ_MI; i++)
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) acc_i[i][j][r] = 0;
+        }
+        uint64_t scb[4];                                           // Q4_K: the 8 sub-block scales of this lane's weight row, per n patch
+        if (IS_K) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) scb[j] = *(const uint64_t *)(Ws + (wn + j * 16 + l15) * 8);
+        }
+#pragma unroll 1
+        for (int s = 0; s < 8; s++) {
+            long fa[MMQ_MI], fb[4];
+#pragma unroll
+            for (int i = 0; i < MMQ_MI; i++) fa[i] = *(const long *)(Xt + (wm + i * 16 + l15) * MMQ_LD + s * 32 + l4 * 8);
+#pragma unroll
+            for (int j = 0; j < 4; j++) fb[j] = *(const long *)(Wt + (wn + j * 16 + l15) * MMQ_LD + s * 32 + l4 * 8);
+            if (IS_K) {
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const int sc = (int)((scb[j] >> (8 * s)) & 0xff);
+#pragma unroll
+                    for (int i = 0; i < MMQ_MI; i++) {
+                        const i32x4 d = __builtin_amdgcn_mfma_i32_16x16x32_i8(fa[i], fb[j], i32x4{0, 0, 0, 0}, 0, 0, 0);
+#pragma unroll
+                        for (int r = 0; r < 4; r++) acc_i[i][j][r] = __mul24(sc, d[r]) + acc_i[i][j][r];
+                    }
+                }
+            } else {
+                float dw[4]; f32x4 dx[MMQ_MI];
+#pragma unroll
+                for (int j = 0; j < 4; j++) dw[j] = *(const float *)(Ws + (s * MMQ_BN + wn + j * 16 + l15) * 4);
+#pragma unroll
+                for (int i = 0; i < MMQ_MI; i++) dx[i] = *(const f32x4 *)(Xs + (s * MMQ_BM + wm + i * 16 + l4 * 4) * 4);
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+#pragma unroll
+                    for (int i = 0; i < MMQ_MI; i++) {
+                        const i32x4 d = __builtin_amdgcn_mfma_i32_16x16x32_i8(fa[i], fb[j], i32x4{0, 0, 0, 0}, 0, 0, 0);
+#pragma unroll
+                        for (int r = 0; r < 4; r++) acc_f[i][j][r] = __builtin_fmaf((float) d[r], dw[j] * dx[i][r], acc_f[i][j][r]);
+                    }
+            }
+        }
+        if (IS_K) {
+            // per super-block float update, including the mins term  sum_s mn[n][s] * sx[m][s]  (exact int32)
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int nl = wn + j * 16 + l15;
+                const uint64_t mnb = *(const uint64_t *)(Ws + MMQ_BN * 8 + nl * 8);
+                const float dn = *(const float *)(Ws + MMQ_BN * 16 + nl * 4), dmn = *(const float *)(Ws + MMQ_BN * 20 + nl * 4);
+#pragma unroll
+                for (int i = 0; i < MMQ_MI; i++) {
+                    const int ml = wm + i * 16 + l4 * 4;
+                    const f32x4 dx = *(const f32x4 *)(Xs + ml * 4);
+                    int mins[4] = {0, 0, 0, 0};
+#pragma unroll
+                    for (int s = 0; s < 8; s++) {
+                        const i32x4 sx = *(const i32x4 *)(Xs + ((1 + s) * MMQ_BM + ml) * 4);
+                        const int mn = (int)((mnb >> (8 * s)) & 0xff);
+#pragma unroll
+                        for (int r = 0; r < 4; r++) mins[r] = __mul24(mn, sx[r]) + mins[r];
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        acc_f[i][j][r] = __builtin_fmaf(dn * dx[r], (float) acc_i[i][j][r], acc_f[i][j][r]);
+                        acc_f[i][j][r] = __builtin_fmaf(-(dmn * dx[r]), (float) mins[r], acc_f[i][j][r]);
+                    }
+                }
+            }
+        }
+    }
+    // ---- epilogue: dst[m][n] ----
+#pragma unroll
+    for (int i = 0; i < MMQ_MI; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int64_t n = n0 + wn + j * 16 + l15;
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int64_t m = m0 + wm + i * 16 + l4 * 4 + r;
+                if (n < a.N && m < a.M) a.dst[m * a.ldd + n] = acc_f[i][j][r];
+            }
+        }
+}
+
+int launch_mmq(hipStream_t st, int wtype, const tview & w, const void * act, size_t act_stride, const tview & x, const tview & d) {
+    if (getenv("CLLM_NO_MMQ")) return CLLM_E_UNSUPPORTED;
+    if (d.nb[1] % 4) FAIL(CLLM_E_INVALID, "mmq: dst stride");
+    mmq_args a;
+    a.W = w.data; a.nb01 = w.nb[1]; a.N = w.ne[1]; a.K = w.ne[0];
+    a.act = (const char *) act; a.act_stride = act_stride; a.M = x.ne[1];
+    a.dst = (float *) d.data; a.ldd = d.nb[1] / 4;
+    dim3 grid((unsigned)((a.M + MMQ_BM - 1) / MMQ_BM), (unsigned)((a.N + MMQ_BN - 1) / MMQ_BN));
+    if (grid.y > 65535) FAIL(CLLM_E_UNSUPPORTED, "mmq: too many row tiles");
+#define GO(T) do { static bool attr = false; \
+        if (!attr) { HIP_TRY(hipFuncSetAttribute((const void *) k_mmq<T>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL)); attr = true; } \
+        hipLaunchKernelGGL(k_mmq<T>, grid, dim3(256), LDS_TOTAL, st, a); } while (0)
+    if (wtype == CLLM_TYPE_Q4_K) GO(CLLM_TYPE_Q4_K);
+    else if (wtype == CLLM_TYPE_Q4_0) GO(CLLM_TYPE_Q4_0);
+    else if (wtype == CLLM_TYPE_Q8_0) GO(CLLM_TYPE_Q8_0);
+    else return CLLM_E_UNSUPPORTED;
+#undef GO
+    LAUNCH_CHECK();
+    return CLLM_OK;
+}

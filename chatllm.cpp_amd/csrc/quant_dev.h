@@ -1,0 +1,88 @@
+// quant_dev.h -- device-side activation quantizers on 4 consecutive values per lane (shared by quantize.hip and the
+// fused decode kernels).  Bit-exact restatements of
+//   quantize_row_q8_0 (x86 AVX2 branch)  ggml/src/ggml-cpu/arch/x86/quants.c:290-345
+//   quantize_row_q8_K_ref                ggml/src/ggml-quants.c:2555-2592 (nearest_int :436-441)
+#pragma once
+#include "common.h"
+
+__device__ __forceinline__ uint32_t pack4(int q0, int q1, int q2, int q3) {
+    return (uint32_t)(q0 & 0xff) | ((uint32_t)(q1 & 0xff) << 8) | ((uint32_t)(q2 & 0xff) << 16) | ((uint32_t)(q3 & 0xff) << 24);
+}
+
+// 8 consecutive lanes hold one 32-block (4 values each).  Returns the packed int8 quads; *d (fp16-rounded scale as
+// f32) and *s (sum of the block's int8) are valid on every lane of the 8-lane group.
+__device__ __forceinline__ uint32_t quant4_q8_0(f32x4 v, float * d_out, int * s_out) {
+    float amax = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
+    amax = fmaxf(amax, __shfl_xor(amax, 1, 64));
+    amax = fmaxf(amax, __shfl_xor(amax, 2, 64));
+    amax = fmaxf(amax, __shfl_xor(amax, 4, 64));
+    const float d  = amax / 127.f;
+    const float id = (amax != 0.0f) ? 127.f / amax : 0.0f;
+    const int q0 = (int) rintf(v.x * id), q1 = (int) rintf(v.y * id), q2 = (int) rintf(v.z * id), q3 = (int) rintf(v.w * id);
+    int s = q0 + q1 + q2 + q3;
+    s += __shfl_xor(s, 1, 64);
+    s += __shfl_xor(s, 2, 64);
+    s += __shfl_xor(s, 4, 64);
+    *d_out = h2f(f2h(d));              // the CPU stores d as fp16 and reads it back for the dot product
+    *s_out = s;
+    return pack4(q0, q1, q2, q3);
+}
+
+__device__ __forceinline__ int nearest_int_dev(float fval) {
+    const float val = fval + 12582912.f;
+    return (int)(__float_as_uint(val) & 0x007fffff) - 0x00400000;
+}
+
+// a whole wave (64 lanes x 4 values) holds one 256-block; lane l owns elements 4l..4l+3.
+// *d valid on all lanes; *s = sum over this lane's 32-sub-block (valid on all 8 lanes of the group).
+__device__ __forceinline__ uint32_t quant4_q8_K(f32x4 v, int lane, float * d_out, int * s_out) {
+    unsigned long long key = 0;        // (|x| bits, ~index): max picks the FIRST element of largest magnitude
+    const float ax[4] = { fabsf(v.x), fabsf(v.y), fabsf(v.z), fabsf(v.w) };
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const unsigned long long k2 = ((unsigned long long) __float_as_uint(ax[i]) << 32) | (unsigned long long)(0xffffffffu - (uint32_t)(lane * 4 + i));
+        key = k2 > key ? k2 : key;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned long long other = __shfl_xor(key, o, 64);
+        key = other > key ? other : key;
+    }
+    const float amax = __uint_as_float((uint32_t)(key >> 32));
+    const int   imax = (int)(0xffffffffu - (uint32_t) key);
+    const float mine = (imax & 3) == 0 ? v.x : (imax & 3) == 1 ? v.y : (imax & 3) == 2 ? v.z : v.w;
+    const float maxv = __shfl(mine, imax >> 2, 64);
+    int q0 = 0, q1 = 0, q2 = 0, q3 = 0;
+    float d = 0.0f;
+    if (amax != 0.0f) {
+        const float iscale = -127.f / maxv;
+        q0 = min(127, nearest_int_dev(iscale * v.x));
+        q1 = min(127, nearest_int_dev(iscale * v.y));
+        q2 = min(127, nearest_int_dev(iscale * v.z));
+        q3 = min(127, nearest_int_dev(iscale * v.w));
+        d = 1 / iscale;
+    }
+    int s = q0 + q1 + q2 + q3;
+    s += __shfl_xor(s, 1, 64);
+    s += __shfl_xor(s, 2, 64);
+    s += __shfl_xor(s, 4, 64);
+    *d_out = d;
+    *s_out = s;
+    return pack4(q0, q1, q2, q3);
+}
+
+// store one lane's quad into an act row (layout in common.h); e0 = element index of the lane's first value
+template <int KIND>    // 32: Q8_0 kind, 256: Q8_K kind
+__device__ __forceinline__ void act_store(char * act_row, int64_t K, int64_t e0, int lane, uint32_t packed, float d, int s) {
+    *(uint32_t *)(act_row + e0) = packed;
+    if ((lane & 7) == 0) ((int32_t *)(act_row + act_off_s(K, KIND)))[e0 / 32] = s;
+    if (KIND == 32) { if ((lane & 7) == 0) ((float *)(act_row + act_off_d(K)))[e0 / 32] = d; }
+    else            { if ((lane & 63) == 0) ((float *)(act_row + act_off_d(K)))[e0 / 256] = d; }
+}
+
+template <int KIND>
+__device__ __forceinline__ void quant4_store(char * act_row, int64_t K, int64_t e0, int lane, f32x4 v) {
+    float d; int s; uint32_t p;
+    if (KIND == 32) p = quant4_q8_0(v, &d, &s); else p = quant4_q8_K(v, lane, &d, &s);
+    act_store<KIND>(act_row, K, e0, lane, p, d, s);
+}

@@ -7,6 +7,7 @@
 //         q = min(127, nearest_int(iscale*x)), d = 1/iscale, bsums
 // All results are bit-exact w.r.t. the CPU (checked in tests/test_quantize.py).
 #include "common.h"
+#include "quant_dev.h"
 
 // 8 lanes per 32-block, 4 elements per lane, 8 blocks per wave.
 __global__ void __launch_bounds__(256) k_quantize_q8_0(const char * __restrict__ src, int64_t K, int64_t ne1, int64_t ne2,
@@ -15,35 +16,9 @@ __global__ void __launch_bounds__(256) k_quantize_q8_0(const char * __restrict__
     const int64_t row = blockIdx.y;                        // flattened i11 + ne11*(i12 + ne12*i13)
     const int64_t i1 = row % ne1, i2 = (row / ne1) % ne2, i3 = row / (ne1 * ne2);
     const float * x = (const float *)(src + i1*nb1 + i2*nb2 + i3*nb3);
-    char * a = act + row * act_stride;
-    int8_t *  qs = (int8_t *) a;
-    float *   dd = (float *)(a + act_off_d(K));
-    int32_t * ss = (int32_t *)(a + act_off_s(K, 32));
-
     const int64_t e0 = ((int64_t) blockIdx.x * blockDim.x + threadIdx.x) * 4;
     if (e0 >= K) return;                                   // K % 32 == 0 -> whole 8-lane groups drop out together
-    const f32x4 v = *(const f32x4 *)(x + e0);
-    float amax = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
-    amax = fmaxf(amax, __shfl_xor(amax, 1, 64));
-    amax = fmaxf(amax, __shfl_xor(amax, 2, 64));
-    amax = fmaxf(amax, __shfl_xor(amax, 4, 64));
-    const float d  = amax / 127.f;
-    const float id = (amax != 0.0f) ? 127.f / amax : 0.0f;
-    const int q0 = (int) rintf(v.x * id), q1 = (int) rintf(v.y * id), q2 = (int) rintf(v.z * id), q3 = (int) rintf(v.w * id);
-    *(uint32_t *)(qs + e0) = (uint32_t)(q0 & 0xff) | ((uint32_t)(q1 & 0xff) << 8) | ((uint32_t)(q2 & 0xff) << 16) | ((uint32_t)(q3 & 0xff) << 24);
-    int s = q0 + q1 + q2 + q3;
-    s += __shfl_xor(s, 1, 64);
-    s += __shfl_xor(s, 2, 64);
-    s += __shfl_xor(s, 4, 64);
-    if ((threadIdx.x & 7) == 0) {
-        dd[e0 / 32] = h2f(f2h(d));                         // the CPU stores d as fp16 and reads it back for the dot
-        ss[e0 / 32] = s;
-    }
-}
-
-__device__ __forceinline__ int nearest_int(float fval) {   // ggml-quants.c:436-441
-    const float val = fval + 12582912.f;
-    return (int)(__float_as_uint(val) & 0x007fffff) - 0x00400000;
+    quant4_store<32>(act + row * act_stride, K, e0, threadIdx.x & 63, *(const f32x4 *)(x + e0));
 }
 
 // one wave per 256-block, 4 elements per lane.
@@ -53,55 +28,11 @@ __global__ void __launch_bounds__(256) k_quantize_q8_K(const char * __restrict__
     const int64_t row = blockIdx.y;
     const int64_t i1 = row % ne1, i2 = (row / ne1) % ne2, i3 = row / (ne1 * ne2);
     const float * x = (const float *)(src + i1*nb1 + i2*nb2 + i3*nb3);
-    char * a = act + row * act_stride;
-    int8_t *  qs = (int8_t *) a;
-    float *   dd = (float *)(a + act_off_d(K));
-    int32_t * ss = (int32_t *)(a + act_off_s(K, 256));
-
     const int lane = threadIdx.x & 63;
     const int64_t blk = (int64_t) blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6);
     if (blk * 256 >= K) return;
     const int64_t e0 = blk * 256 + lane * 4;
-    const f32x4 v = *(const f32x4 *)(x + e0);
-
-    // first element of largest magnitude: key = (|x| bits, ~index) maximised
-    unsigned long long key = 0;
-    {
-        const float ax[4] = { fabsf(v.x), fabsf(v.y), fabsf(v.z), fabsf(v.w) };
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-            const unsigned long long k2 = ((unsigned long long) __float_as_uint(ax[i]) << 32) | (unsigned long long)(0xffffffffu - (uint32_t)(lane * 4 + i));
-            key = k2 > key ? k2 : key;
-        }
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        const unsigned long long other = __shfl_xor(key, o, 64);
-        key = other > key ? other : key;
-    }
-    const float amax = __uint_as_float((uint32_t)(key >> 32));
-    const int   imax = (int)(0xffffffffu - (uint32_t) key);
-    // fetch the signed value of that element from its owner lane
-    const float mine = (imax & 3) == 0 ? v.x : (imax & 3) == 1 ? v.y : (imax & 3) == 2 ? v.z : v.w;
-    const float maxv = __shfl(mine, imax >> 2, 64);
-
-    int q0 = 0, q1 = 0, q2 = 0, q3 = 0;
-    float d = 0.0f;
-    if (amax != 0.0f) {
-        const float iscale = -127.f / maxv;
-        q0 = min(127, nearest_int(iscale * v.x));
-        q1 = min(127, nearest_int(iscale * v.y));
-        q2 = min(127, nearest_int(iscale * v.z));
-        q3 = min(127, nearest_int(iscale * v.w));
-        d = 1 / iscale;
-    }
-    *(uint32_t *)(qs + e0) = (uint32_t)(q0 & 0xff) | ((uint32_t)(q1 & 0xff) << 8) | ((uint32_t)(q2 & 0xff) << 16) | ((uint32_t)(q3 & 0xff) << 24);
-    int s = q0 + q1 + q2 + q3;
-    s += __shfl_xor(s, 1, 64);
-    s += __shfl_xor(s, 2, 64);
-    s += __shfl_xor(s, 4, 64);
-    if ((lane & 7) == 0) ss[e0 / 32] = s;
-    if (lane == 0) dd[blk] = d;
+    quant4_store<256>(act + row * act_stride, K, e0, lane, *(const f32x4 *)(x + e0));
 }
 
 int launch_quantize_act(hipStream_t st, int kind_blk, const tview & s, void * act, size_t act_stride) {

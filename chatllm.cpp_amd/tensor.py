@@ -96,7 +96,10 @@ class Tensor:
         if n:
             _l.check(_l.get().cllm_memcpy_d2h(out.ctypes.data_as(C.c_void_p), self.data_ptr(), n, None), "d2h")
         if self.type in NP_OF:
-            return out.view(NP_OF[self.type]).reshape(list(reversed(self.ne)))
+            shape = list(reversed(self.ne))
+            while len(shape) > 1 and shape[0] == 1:      # drop the unused outer dimensions (ne[3], ne[2], ...)
+                shape.pop(0)
+            return out.view(NP_OF[self.type]).reshape(shape)
         return out
 
     def c(self):

@@ -332,4 +332,6 @@ def test_attention_composite(gpu, qlen, n_past):
     Vv = dv.view([n_kv, hd, nkv], [2, ML * 2, ML * hd * 2])
     c = ops.mul_mat(Vv, p)
     got = ops.cont(c.permute(0, 2, 1, 3)).numpy().reshape(qlen, nh * hd)
-    assert rel_err(got, want) < 2e-5
+    # the probabilities are rounded to fp16 before V.P (CPU semantics): a 1e-7 difference in P can flip one of those
+    # roundings (5e-4 relative on that element), hence the looser bound on the composite
+    assert rel_err(got, want) < 3e-4
