@@ -126,3 +126,10 @@ int launch_mmvq_id(hipStream_t st, int wtype, const tview & as, const void * act
 int launch_mmq(hipStream_t st, int wtype, const tview & w, const void * act, size_t act_stride, const tview & src1_geom, const tview & dst);
 int launch_mul_mat_f(hipStream_t st, int wtype, const tview & w, const tview & x, const tview & dst);
 int device_cu_count();
+int launch_mmvq_act(hipStream_t st, int wtype, const void * W, int64_t K, int64_t nrows, const void * act, float * dst, const float * bias, const float * resid);
+int launch_norm_quant(hipStream_t st, int kind, const float * x, const float * w, int64_t H, float eps, void * act);
+int launch_quant_row(hipStream_t st, int kind, const float * x, int64_t K, void * act);
+int launch_silu_mul_quant(hipStream_t st, int kind, const float * gu, int64_t F, void * act, float * g_out);
+int launch_rope_kv(hipStream_t st, float * qkv, const int32_t * pos_dev, int nh, int nkv, int hd, int mode, float freq_base, uint16_t * k_cache, uint16_t * v_cache, int64_t ML);
+int launch_attn_decode(hipStream_t st, const float * qkv, const int32_t * pos_dev, int nh, int nkv, int hd, const uint16_t * k_cache, const uint16_t * v_cache, int64_t ML, float * att);
+int launch_argmax_advance(hipStream_t st, const float * logits, int n, int32_t * tok_dev, int32_t * pos_dev, int32_t * out_ring, int32_t * counter);

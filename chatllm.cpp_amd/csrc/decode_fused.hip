@@ -1,0 +1,284 @@
+// decode_fused.hip -- fused single-token (decode) kernels used by the decoder runner (decoder.hip).
+//
+// Same arithmetic, operation order and rounding points as the individual graph nodes they replace:
+//   k_norm_quant      RMS_NORM + MUL(weight) + the activation quantization that MUL_MAT does to its src1
+//   k_rope_kv         ROPE(k), ROPE(q) in place + SET_ROWS(K -> f16 cache row pos) + CPY(V^T -> f16 cache column pos)
+//   k_attn_decode     MUL_MAT(K,Q) + SCALE + DIAG_MASK_INF + SOFT_MAX + MUL_MAT(V,P) [+ PERMUTE/CONT] for one query token
+//   k_silu_mul_quant  UNARY(SILU) + MUL + quantization of the down-projection's src1
+//   k_argmax_advance  greedy sampler (std::max_element, first maximum) feeding the next step on the device
+// The only per-token inputs (token id, position) are read from device memory, so a whole decode step is a static
+// launch sequence that the runner captures once in a hipGraph.
+#include "common.h"
+#include "quant_dev.h"
+
+#include <math.h>
+
+// ---------------------------------------------------------------------------------------------------------------
+// RMS_NORM + MUL + quantize: one workgroup of 1024 threads, one float4 per thread per pass.
+//   ggml_compute_forward_rms_norm_f32 (ops.cpp:3710-3759) -> MUL -> quantize_row_q8_0 / q8_K (as mul_mat's src1)
+// ---------------------------------------------------------------------------------------------------------------
+template <int KIND>
+__global__ void __launch_bounds__(1024) k_norm_quant(const float * __restrict__ x, const float * __restrict__ w, int64_t H, float eps,
+                                                     char * __restrict__ act) {
+    __shared__ double part[16];
+    const int tid = threadIdx.x, lane = tid & 63;
+    double sum = 0.0;
+    for (int64_t e = (int64_t) tid * 4; e < H; e += 4096) {
+        const f32x4 v = *(const f32x4 *)(x + e);
+        sum += (double)(v.x * v.x); sum += (double)(v.y * v.y); sum += (double)(v.z * v.z); sum += (double)(v.w * v.w);
+    }
+    sum = wave_sum_d(sum);
+    if (lane == 0) part[tid >> 6] = sum;
+    __syncthreads();
+    sum = 0.0;
+#pragma unroll
+    for (int i = 0; i < 16; i++) sum += part[i];
+    const float mean  = (float)(sum / (double) H);
+    const float scale = 1.0f / sqrtf(mean + eps);
+    for (int64_t e = (int64_t) tid * 4; e < H; e += 4096) {          // H % 256 == 0: whole waves stay together
+        const f32x4 v = *(const f32x4 *)(x + e);
+        const f32x4 g = *(const f32x4 *)(w + e);
+        f32x4 y;
+        y.x = (v.x * scale) * g.x; y.y = (v.y * scale) * g.y; y.z = (v.z * scale) * g.z; y.w = (v.w * scale) * g.w;
+        quant4_store<KIND>(act, H, e, lane, y);
+    }
+}
+
+int launch_norm_quant(hipStream_t st, int kind, const float * x, const float * w, int64_t H, float eps, void * act) {
+    if (H % 256) FAIL(CLLM_E_UNSUPPORTED, "norm_quant: hidden size must be a multiple of 256");
+    if (kind == 32) hipLaunchKernelGGL(k_norm_quant<32>,  dim3(1), dim3(1024), 0, st, x, w, H, eps, (char *) act);
+    else            hipLaunchKernelGGL(k_norm_quant<256>, dim3(1), dim3(1024), 0, st, x, w, H, eps, (char *) act);
+    LAUNCH_CHECK();
+    return CLLM_OK;
+}
+
+// plain quantization of one dense row (attention output -> src1 of o_proj)
+template <int KIND>
+__global__ void __launch_bounds__(256) k_quant_row(const float * __restrict__ x, int64_t K, char * __restrict__ act) {
+    const int64_t e = ((int64_t) blockIdx.x * 256 + threadIdx.x) * 4;
+    if (e >= K) return;
+    quant4_store<KIND>(act, K, e, threadIdx.x & 63, *(const f32x4 *)(x + e));
+}
+int launch_quant_row(hipStream_t st, int kind, const float * x, int64_t K, void * act) {
+    if (K % 256) FAIL(CLLM_E_UNSUPPORTED, "quant_row: K must be a multiple of 256");
+    const unsigned grid = (unsigned)((K / 4 + 255) / 256);
+    if (kind == 32) hipLaunchKernelGGL(k_quant_row<32>,  dim3(grid), dim3(256), 0, st, x, K, (char *) act);
+    else            hipLaunchKernelGGL(k_quant_row<256>, dim3(grid), dim3(256), 0, st, x, K, (char *) act);
+    LAUNCH_CHECK();
+    return CLLM_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// SiLU(gate) * up + quantize (F % 256 == 0 for Q8_K kind, % 32 for Q8_0 kind).  gu = [gate(F) | up(F)]
+//   ggml_vec_silu_f32 (vec.cpp:396-431): polynomial body for i < (F & ~7), libm tail
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float silu_ref(float x, bool body) { return body ? x / (1.0f + ggml_expf_poly(0.0f - x)) : x / (1.0f + expf(-x)); }
+
+template <int KIND>
+__global__ void __launch_bounds__(256) k_silu_mul_quant(const float * __restrict__ gu, int64_t F, char * __restrict__ act, float * __restrict__ g_out) {
+    const int64_t e = ((int64_t) blockIdx.x * 256 + threadIdx.x) * 4;
+    if (e >= F) return;
+    const f32x4 g = *(const f32x4 *)(gu + e), u = *(const f32x4 *)(gu + F + e);
+    const int64_t nv = F & ~(int64_t) 7;
+    f32x4 y;
+    y.x = silu_ref(g.x, e + 0 < nv) * u.x; y.y = silu_ref(g.y, e + 1 < nv) * u.y;
+    y.z = silu_ref(g.z, e + 2 < nv) * u.z; y.w = silu_ref(g.w, e + 3 < nv) * u.w;
+    if (g_out) *(f32x4 *)(g_out + e) = y;
+    quant4_store<KIND>(act, F, e, threadIdx.x & 63, y);
+}
+int launch_silu_mul_quant(hipStream_t st, int kind, const float * gu, int64_t F, void * act, float * g_out) {
+    if (F % kind) FAIL(CLLM_E_UNSUPPORTED, "silu_mul_quant: F=%lld not a multiple of %d", (long long) F, kind);
+    const unsigned grid = (unsigned)((F / 4 + 255) / 256);
+    if (kind == 32) hipLaunchKernelGGL(k_silu_mul_quant<32>,  dim3(grid), dim3(256), 0, st, gu, F, (char *) act, g_out);
+    else            hipLaunchKernelGGL(k_silu_mul_quant<256>, dim3(grid), dim3(256), 0, st, gu, F, (char *) act, g_out);
+    LAUNCH_CHECK();
+    return CLLM_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// RoPE(k), RoPE(q) + KV-cache write for ONE token whose position is read from device memory.
+//   ggml_compute_forward_rope_flt (ops.cpp:5589-5865; theta by iterated multiplication) ; from_float f32->f16 (RNE)
+// qkv = [q (nh*hd) | k (nkv*hd) | v (nkv*hd)] floats; k_cache [ML][KD] f16; v_cache [KD][ML] f16 (eager layout)
+// ---------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_rope_kv(float * __restrict__ qkv, const int32_t * __restrict__ pos_dev, int nh, int nkv, int hd, int mode,
+                                                 float theta_scale, uint16_t * __restrict__ k_cache, uint16_t * __restrict__ v_cache, int64_t ML) {
+    extern __shared__ float cache[];                        // cos, sin interleaved [hd]
+    const int half = hd / 2;
+    const int pos = pos_dev[0];
+    for (int i = threadIdx.x; i < half; i += blockDim.x) {
+        float theta = (float) pos;
+        for (int k = 0; k < i; k++) theta *= theta_scale;
+        cache[2*i] = cosf(theta); cache[2*i + 1] = sinf(theta);          // freq_scale 1, attn_factor 1, no YaRN on this path
+    }
+    __syncthreads();
+    const int QD = nh * hd, KD = nkv * hd;
+    const int off = mode == 0 ? 1 : half;
+    float * q = qkv, * k = qkv + QD; const float * v = qkv + QD + KD;
+    for (int t = threadIdx.x; t < (nh + nkv) * half; t += blockDim.x) {
+        const int h = t / half, i = t % half;
+        const int ic = mode == 0 ? 2*i : i;
+        const float c = cache[2*i], s = cache[2*i + 1];
+        if (h < nh) {
+            float * x = q + h * hd;
+            const float x0 = x[ic], x1 = x[ic + off];
+            x[ic] = x0*c - x1*s; x[ic + off] = x0*s + x1*c;
+        } else {
+            const int hk = h - nh;
+            float * x = k + hk * hd;
+            const float x0 = x[ic], x1 = x[ic + off];
+            const float y0 = x0*c - x1*s, y1 = x0*s + x1*c;
+            x[ic] = y0; x[ic + off] = y1;
+            uint16_t * kr = k_cache + (int64_t) pos * KD + hk * hd;
+            kr[ic] = f2h(y0); kr[ic + off] = f2h(y1);
+        }
+    }
+    for (int t = threadIdx.x; t < KD; t += blockDim.x) v_cache[(int64_t) t * ML + pos] = f2h(v[t]);
+}
+int launch_rope_kv(hipStream_t st, float * qkv, const int32_t * pos_dev, int nh, int nkv, int hd, int mode, float freq_base,
+                   uint16_t * k_cache, uint16_t * v_cache, int64_t ML) {
+    const float theta_scale = powf(freq_base, -2.0f / hd);
+    hipLaunchKernelGGL(k_rope_kv, dim3(1), dim3(256), (size_t) hd * 4, st, qkv, pos_dev, nh, nkv, hd, mode, theta_scale, k_cache, v_cache, ML);
+    LAUNCH_CHECK();
+    return CLLM_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Attention for one query token, one workgroup per query head.
+//   scores[i] = sum_d f16(K[i][d]) * f16r(q[d])          ggml_vec_dot_f16 semantics: src1 rounded to fp16, fp32 accumulate
+//   p = soft_max(scores * scale)  (every cached position is visible to the newest token: the causal mask is empty)
+//       ggml_vec_soft_max_f32: groups of 8 through ggml_v_expf, f32 tree sum per group, total in double, expf tail
+//   ctx[d] = sum_i f16(V[d][i]) * f16r(p[i])
+// ---------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_attn_decode(const float * __restrict__ qkv, const int32_t * __restrict__ pos_dev, int nh, int nkv, int hd,
+                                                     float scale, const uint16_t * __restrict__ k_cache, const uint16_t * __restrict__ v_cache,
+                                                     int64_t ML, float * __restrict__ att) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];       // [hd] q (fp16-rounded) | [n_kv] scores / probabilities
+    __shared__ double red_d[1];
+    __shared__ float  red_f[4];
+    const int h = blockIdx.x, g = h / (nh / nkv);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n_kv = pos_dev[0] + 1;
+    const int KD = nkv * hd;
+    float * qs = sm; float * sc = sm + hd;
+    for (int d = tid; d < hd; d += 256) qs[d] = h2f(f2h(qkv[h * hd + d]));
+    __syncthreads();
+
+    // Lane grouping follows launch_T() in matmul_f.hip (G lanes per row, G*8 <= K, 8 <= G <= 64) so that the
+    // fp32 summation order -- and therefore every bit of the result -- equals the unfused MUL_MAT nodes.
+    int G = 64; while (G > 8 && G * 8 > hd) G >>= 1;
+    {
+        const int gl = lane % G, sub = lane / G, rpw = 64 / G;
+        for (int i0 = wave * rpw + sub; i0 < n_kv; i0 += 4 * rpw) {
+            const uint16_t * kr = k_cache + (int64_t) i0 * KD + g * hd;
+            float acc = 0.0f;
+            const int K8 = hd & ~7;
+            for (int d = K8 + gl; d < hd; d += G) acc = __builtin_fmaf(h2f(kr[d]), qs[d], acc);
+            for (int d = gl * 8; d < K8; d += G * 8) {
+                const u32x4 r = *(const u32x4 *)(kr + d);
+                const uint32_t wv[4] = { r.x, r.y, r.z, r.w };
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    acc = __builtin_fmaf(h2f((uint16_t)(wv[j] & 0xffff)), qs[d + 2*j], acc);
+                    acc = __builtin_fmaf(h2f((uint16_t)(wv[j] >> 16)), qs[d + 2*j + 1], acc);
+                }
+            }
+            for (int o = G / 2; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+            if (gl == 0) sc[i0] = acc * scale;                           // the SCALE node
+        }
+    }
+    __syncthreads();
+
+    // ---- soft_max over sc[0..n_kv): same partition as k_soft_max (one wave, lane = groups of 8) ----
+    float mx = -INFINITY;
+    for (int i = tid; i < n_kv; i += 256) mx = fmaxf(mx, sc[i]);
+    mx = wave_max(mx);
+    if (lane == 0) red_f[wave] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red_f[0], red_f[1]), fmaxf(red_f[2], red_f[3]));
+    if (wave == 0) {
+        const int nv = n_kv & ~7;
+        double sum = 0.0;
+        for (int gi = lane * 8; gi < nv; gi += 64 * 8) {
+            float e[8];
+#pragma unroll
+            for (int l = 0; l < 8; l++) { e[l] = ggml_expf_poly(sc[gi + l] - mx); sc[gi + l] = e[l]; }
+            const float a0 = e[0] + e[4], a1 = e[1] + e[5], a2 = e[2] + e[6], a3 = e[3] + e[7];
+            sum += (double)((a0 + a2) + (a1 + a3));
+        }
+        if (lane == 0) for (int i = nv; i < n_kv; i++) { const float e = expf(sc[i] - mx); sc[i] = e; sum += (double) e; }
+        sum = wave_sum_d(sum);
+        if (lane == 0) red_d[0] = sum;
+    }
+    __syncthreads();
+    const float inv = (float)(1.0 / red_d[0]);
+    for (int i = tid; i < n_kv; i += 256) sc[i] = h2f(f2h(sc[i] * inv));   // probability, then its fp16 rounding for V.P
+    __syncthreads();
+
+    // ---- ctx = V . P ----
+    G = 64; while (G > 8 && G * 8 > n_kv) G >>= 1;
+    {
+        const int gl = lane % G, sub = lane / G, rpw = 64 / G;
+        for (int d0 = wave * rpw + sub; d0 < hd; d0 += 4 * rpw) {
+            const uint16_t * vr = v_cache + ((int64_t) g * hd + d0) * ML;
+            float acc = 0.0f;
+            if (n_kv >= 8) {
+                const int n8 = n_kv & ~7;
+                for (int i = n8 + gl; i < n_kv; i += G) acc = __builtin_fmaf(h2f(vr[i]), sc[i], acc);
+                for (int i = gl * 8; i < n8; i += G * 8) {
+                    const u32x4 r = *(const u32x4 *)(vr + i);
+                    const uint32_t wv[4] = { r.x, r.y, r.z, r.w };
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        acc = __builtin_fmaf(h2f((uint16_t)(wv[j] & 0xffff)), sc[i + 2*j], acc);
+                        acc = __builtin_fmaf(h2f((uint16_t)(wv[j] >> 16)), sc[i + 2*j + 1], acc);
+                    }
+                }
+            } else {
+                for (int i = gl; i < n_kv; i += G) acc = __builtin_fmaf(h2f(vr[i]), sc[i], acc);   // the scalar kernel of matmul_f.hip (K < 8)
+            }
+            for (int o = G / 2; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+            if (gl == 0) att[h * hd + d0] = acc;
+        }
+    }
+}
+int launch_attn_decode(hipStream_t st, const float * qkv, const int32_t * pos_dev, int nh, int nkv, int hd, const uint16_t * k_cache,
+                       const uint16_t * v_cache, int64_t ML, float * att) {
+    if (hd % 8 || (ML % 8) || nh % nkv) FAIL(CLLM_E_UNSUPPORTED, "attn_decode: head_dim and max_len must be multiples of 8");
+    const size_t lds = (size_t)(hd + ML) * 4;
+    if (lds > 150 * 1024) FAIL(CLLM_E_UNSUPPORTED, "attn_decode: max_len %lld does not fit LDS", (long long) ML);
+    static bool attr = false;
+    if (lds > 48 * 1024 && !attr) { HIP_TRY(hipFuncSetAttribute((const void *) k_attn_decode, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024)); attr = true; }
+    hipLaunchKernelGGL(k_attn_decode, dim3(nh), dim3(256), lds, st, qkv, pos_dev, nh, nkv, hd, 1.0f / sqrtf((float) hd), k_cache, v_cache, ML, att);
+    LAUNCH_CHECK();
+    return CLLM_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// embedding gather for the token held in device memory is cllm_op_get_rows; greedy sampling + advance:
+// ---------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(1024) k_argmax_advance(const float * __restrict__ x, int n, int32_t * __restrict__ tok_dev, int32_t * __restrict__ pos_dev,
+                                                         int32_t * __restrict__ out_ring, int32_t * __restrict__ counter) {
+    __shared__ float bv[16]; __shared__ int bi[16];
+    float best = -INFINITY; int idx = 0x7fffffff;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) { const float v = x[i]; if (v > best) { best = v; idx = i; } }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(best, o, 64); const int oi = __shfl_xor(idx, o, 64);
+        if (ov > best || (ov == best && oi < idx)) { best = ov; idx = oi; }
+    }
+    if ((threadIdx.x & 63) == 0) { bv[threadIdx.x >> 6] = best; bi[threadIdx.x >> 6] = idx; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < (int)(blockDim.x >> 6); w++) if (bv[w] > best || (bv[w] == best && bi[w] < idx)) { best = bv[w]; idx = bi[w]; }
+        if (idx == 0x7fffffff) idx = 0;
+        tok_dev[0] = idx;                 // next step's input token
+        pos_dev[0] = pos_dev[0] + 1;      // and its position
+        out_ring[counter[0]] = idx;
+        counter[0] = counter[0] + 1;
+    }
+}
+int launch_argmax_advance(hipStream_t st, const float * logits, int n, int32_t * tok_dev, int32_t * pos_dev, int32_t * out_ring, int32_t * counter) {
+    hipLaunchKernelGGL(k_argmax_advance, dim3(1), dim3(1024), 0, st, logits, n, tok_dev, pos_dev, out_ring, counter);
+    LAUNCH_CHECK();
+    return CLLM_OK;
+}

@@ -26,6 +26,7 @@ struct dweight { int type = -1; void * data = nullptr; size_t bytes = 0; bool ow
 struct llama_layer {
     dweight attn_norm, ffn_norm, wq, wk, wv, wo, wgate, wup, wdown, bq, bk, bv;
     dweight wqkv, wgu;            // row-concatenated fusions (q|k|v and gate|up): numerically identical, one launch
+    dweight bqkv;                 // concatenated q|k|v bias (Qwen2)
     uint16_t * k_cache = nullptr, * v_cache = nullptr;
 };
 
@@ -47,6 +48,8 @@ struct cllm_llama {
     bool use_graph = true;
     hipGraphExec_t decode_graph = nullptr;
     int32_t * next_tok_dev = nullptr;            // greedy feedback
+    int32_t * out_ring = nullptr, * counter_dev = nullptr;   // device-side greedy loop: generated ids + how many
+    bool own_stream = false, fused_ok = false, fused_warm = false;
     size_t weight_bytes = 0;
 };
 
@@ -73,6 +76,9 @@ extern "C" int cllm_llama_create(const cllm_llama_config * cfg, void * stream, c
     cllm_llama * m = new cllm_llama();
     m->cfg = *cfg; m->cfg.tp_size = tp;
     m->st = (hipStream_t) stream;
+    if (!m->st) {   // graphs cannot be captured on the legacy NULL stream: own a blocking stream (it still orders against NULL-stream work)
+        if (hipStreamCreate(&m->st) != hipSuccess) { (void) hipGetLastError(); m->st = nullptr; } else m->own_stream = true;
+    }
     m->nh = cfg->n_head / tp; m->nkv = cfg->n_kv_head / tp; m->F = cfg->ffn / tp;
     m->layers.resize(cfg->n_layer);
     *out = m;
@@ -87,12 +93,13 @@ extern "C" void cllm_llama_destroy(cllm_llama * m) {
     if (m->decode_graph) (void) hipGraphExecDestroy(m->decode_graph);
     free_w(m->tok_embd); free_w(m->lm_head); free_w(m->out_norm);
     for (auto & L : m->layers) {
-        for (dweight * w : { &L.attn_norm, &L.ffn_norm, &L.wq, &L.wk, &L.wv, &L.wo, &L.wgate, &L.wup, &L.wdown, &L.bq, &L.bk, &L.bv, &L.wqkv, &L.wgu }) free_w(*w);
+        for (dweight * w : { &L.attn_norm, &L.ffn_norm, &L.wq, &L.wk, &L.wv, &L.wo, &L.wgate, &L.wup, &L.wdown, &L.bq, &L.bk, &L.bv, &L.wqkv, &L.wgu, &L.bqkv }) free_w(*w);
         if (L.k_cache) (void) hipFree(L.k_cache);
         if (L.v_cache) (void) hipFree(L.v_cache);
     }
     for (void * p : { (void *) m->x, (void *) m->xn, (void *) m->qkv, (void *) m->att, (void *) m->ctx, (void *) m->o, (void *) m->gu, (void *) m->g, (void *) m->scores,
-                      (void *) m->logits, m->wdata, (void *) m->tokens_dev, (void *) m->pos_dev, (void *) m->next_tok_dev }) if (p) (void) hipFree(p);
+                      (void *) m->logits, m->wdata, (void *) m->tokens_dev, (void *) m->pos_dev, (void *) m->next_tok_dev, (void *) m->out_ring, (void *) m->counter_dev }) if (p) (void) hipFree(p);
+    if (m->own_stream) (void) hipStreamDestroy(m->st);
     delete m;
 }
 
@@ -186,7 +193,15 @@ static int finalize(cllm_llama * m, int qlen) {
                 TRY(fuse_rows(m->st, L.wgu, { &L.wgate, &L.wup }));
             } else TRY(expect(L.wgu, "wgu", il, cllm_row_size(L.wgu.type, H) * (size_t)(2*F), false));
             TRY(expect(L.wdown, "wdown", il, cllm_row_size(L.wdown.type, F) * (size_t) H, false));
-            if (c.qkv_bias) { TRY(expect(L.bq, "bq", il, (size_t) QD * 4, true)); TRY(expect(L.bk, "bk", il, (size_t) KD * 4, true)); TRY(expect(L.bv, "bv", il, (size_t) KD * 4, true)); }
+            if (c.qkv_bias) {
+                TRY(expect(L.bq, "bq", il, (size_t) QD * 4, true)); TRY(expect(L.bk, "bk", il, (size_t) KD * 4, true)); TRY(expect(L.bv, "bv", il, (size_t) KD * 4, true));
+                void * bb = nullptr;
+                HIP_TRY(hipMalloc(&bb, (size_t)(QD + 2*KD) * 4));
+                HIP_TRY(hipMemcpyAsync(bb, L.bq.data, (size_t) QD * 4, hipMemcpyDeviceToDevice, m->st));
+                HIP_TRY(hipMemcpyAsync((char *) bb + QD * 4, L.bk.data, (size_t) KD * 4, hipMemcpyDeviceToDevice, m->st));
+                HIP_TRY(hipMemcpyAsync((char *) bb + (QD + KD) * 4, L.bv.data, (size_t) KD * 4, hipMemcpyDeviceToDevice, m->st));
+                L.bqkv.type = CLLM_TYPE_F32; L.bqkv.data = bb; L.bqkv.bytes = (size_t)(QD + 2*KD) * 4; L.bqkv.owned = true;
+            }
             for (const dweight * w : { &L.attn_norm, &L.ffn_norm, &L.wq, &L.wk, &L.wv, &L.wqkv, &L.wo, &L.wgate, &L.wup, &L.wgu, &L.wdown }) m->weight_bytes += w->bytes;
             HIP_TRY(hipMalloc((void **) &L.k_cache, (size_t)(ML * KD) * 2));
             HIP_TRY(hipMalloc((void **) &L.v_cache, (size_t)(ML * KD) * 2));
@@ -195,6 +210,16 @@ static int finalize(cllm_llama * m, int qlen) {
         }
         HIP_TRY(hipMalloc((void **) &m->logits, (size_t) V * 4));
         HIP_TRY(hipMalloc((void **) &m->next_tok_dev, 16));
+        HIP_TRY(hipMalloc((void **) &m->out_ring, (size_t) ML * 4));
+        HIP_TRY(hipMalloc((void **) &m->counter_dev, 16));
+        // the fused single-token path needs the row-concatenated projections and block-aligned widths
+        m->fused_ok = m->own_stream && H % 256 == 0 && QD % 256 == 0 && hd % 8 == 0 && ML % 8 == 0 && (size_t)(hd + ML) * 4 <= 150 * 1024;
+        for (const llama_layer & L : m->layers) {
+            if (!L.wqkv.data || !L.wgu.data) m->fused_ok = false;
+            else if (F % (L.wdown.type == CLLM_TYPE_Q4_K ? 256 : 32)) m->fused_ok = false;
+            for (const dweight * w : { &L.wqkv, &L.wo, &L.wgu, &L.wdown }) if (w->data && w->type != CLLM_TYPE_Q4_K && w->type != CLLM_TYPE_Q4_0 && w->type != CLLM_TYPE_Q8_0) m->fused_ok = false;
+        }
+        if (m->lm_head.type != CLLM_TYPE_Q4_K && m->lm_head.type != CLLM_TYPE_Q4_0 && m->lm_head.type != CLLM_TYPE_Q8_0) m->fused_ok = false;
         m->finalized = true;
     }
     if (qlen > m->maxq) {
@@ -345,6 +370,63 @@ extern "C" int cllm_llama_forward(cllm_llama * m, const int32_t * tokens, int ql
     return CLLM_OK;
 }
 
+// ---- fused single-token step: 10 launches per layer, every per-token input read from device memory ----------------------
+static int kind_of(int wtype) { return wtype == CLLM_TYPE_Q4_K ? 256 : 32; }
+
+static int decode_step_fused(cllm_llama * m, bool sample) {
+    const cllm_llama_config & c = m->cfg;
+    const int64_t H = c.hidden, hd = c.head_dim, QD = (int64_t) m->nh * hd, KD = (int64_t) m->nkv * hd, F = m->F, V = c.vocab, ML = c.max_len;
+    hipStream_t st = m->st;
+    const bool tp = m->allreduce && c.tp_size > 1;
+    {
+        cllm_tensor E = T(m->tok_embd.type, m->tok_embd.data, H, V), ids = T(CLLM_TYPE_I32, m->tokens_dev, 1), X = T(CLLM_TYPE_F32, m->x, H, 1);
+        TRY(cllm_op_get_rows(st, &E, &ids, &X));
+    }
+    for (int il = 0; il < c.n_layer; il++) {
+        llama_layer & L = m->layers[il];
+        TRY(launch_norm_quant(st, kind_of(L.wqkv.type), m->x, (const float *) L.attn_norm.data, H, c.rms_eps, m->wdata));
+        TRY(launch_mmvq_act(st, L.wqkv.type, L.wqkv.data, H, QD + 2*KD, m->wdata, m->qkv, c.qkv_bias ? (const float *) L.bqkv.data : nullptr, nullptr));
+        TRY(launch_rope_kv(st, m->qkv, m->pos_dev, m->nh, m->nkv, (int) hd, c.rope_mode, c.rope_theta, L.k_cache, L.v_cache, ML));
+        TRY(launch_attn_decode(st, m->qkv, m->pos_dev, m->nh, m->nkv, (int) hd, L.k_cache, L.v_cache, ML, m->att));
+        TRY(launch_quant_row(st, kind_of(L.wo.type), m->att, QD, m->wdata));
+        if (!tp) TRY(launch_mmvq_act(st, L.wo.type, L.wo.data, QD, H, m->wdata, m->x, nullptr, m->x));          // x = o + x
+        else {
+            TRY(launch_mmvq_act(st, L.wo.type, L.wo.data, QD, H, m->wdata, m->o, nullptr, nullptr));
+            m->allreduce(m->allreduce_user, st, m->o, H);
+            cllm_tensor O = T(CLLM_TYPE_F32, m->o, H), X = T(CLLM_TYPE_F32, m->x, H);
+            TRY(cllm_op_add(st, &O, &X, &X));
+        }
+        TRY(launch_norm_quant(st, kind_of(L.wgu.type), m->x, (const float *) L.ffn_norm.data, H, c.rms_eps, m->wdata));
+        TRY(launch_mmvq_act(st, L.wgu.type, L.wgu.data, H, 2*F, m->wdata, m->gu, nullptr, nullptr));
+        TRY(launch_silu_mul_quant(st, kind_of(L.wdown.type), m->gu, F, m->wdata, nullptr));
+        if (!tp) TRY(launch_mmvq_act(st, L.wdown.type, L.wdown.data, F, H, m->wdata, m->x, nullptr, m->x));
+        else {
+            TRY(launch_mmvq_act(st, L.wdown.type, L.wdown.data, F, H, m->wdata, m->o, nullptr, nullptr));
+            m->allreduce(m->allreduce_user, st, m->o, H);
+            cllm_tensor O = T(CLLM_TYPE_F32, m->o, H), X = T(CLLM_TYPE_F32, m->x, H);
+            TRY(cllm_op_add(st, &O, &X, &X));
+        }
+    }
+    TRY(launch_norm_quant(st, kind_of(m->lm_head.type), m->x, (const float *) m->out_norm.data, H, c.rms_eps, m->wdata));
+    TRY(launch_mmvq_act(st, m->lm_head.type, m->lm_head.data, H, V, m->wdata, m->logits, nullptr, nullptr));
+    if (sample) TRY(launch_argmax_advance(st, m->logits, (int) V, m->tokens_dev, m->pos_dev, m->out_ring, m->counter_dev));
+    return CLLM_OK;
+}
+
+// capture one sampled step into a graph (after one eager warm-up step has set every function attribute)
+static int ensure_decode_graph(cllm_llama * m) {
+    if (m->decode_graph || !m->use_graph || (m->allreduce && m->cfg.tp_size > 1)) return CLLM_OK;
+    hipGraph_t graph = nullptr;
+    HIP_TRY(hipStreamBeginCapture(m->st, hipStreamCaptureModeRelaxed));
+    const int rc = decode_step_fused(m, true);
+    const hipError_t e = hipStreamEndCapture(m->st, &graph);
+    if (rc) { if (graph) (void) hipGraphDestroy(graph); return rc; }
+    HIP_TRY(e);
+    HIP_TRY(hipGraphInstantiate(&m->decode_graph, graph, nullptr, nullptr, 0));
+    (void) hipGraphDestroy(graph);
+    return CLLM_OK;
+}
+
 // ---- greedy decode loop (sampler = std::max_element, src/models.cpp:676-690: first maximum wins) ------------------
 __global__ void __launch_bounds__(1024) k_argmax(const float * __restrict__ x, int n, int32_t * __restrict__ out) {
     __shared__ float bv[16]; __shared__ int bi[16];
@@ -364,9 +446,27 @@ __global__ void __launch_bounds__(1024) k_argmax(const float * __restrict__ x, i
 }
 
 extern "C" int cllm_llama_decode_greedy(cllm_llama * m, int32_t first_token, int n_past, int n_steps, int32_t * out_tokens_host) {
-    if (!m || n_steps <= 0 || !out_tokens_host) FAIL(CLLM_E_INVALID, "decode_greedy: arguments");
+    if (!m || n_steps <= 0 || !out_tokens_host || n_past < 0) FAIL(CLLM_E_INVALID, "decode_greedy: arguments");
     if ((int64_t) n_past + n_steps > m->cfg.max_len) FAIL(CLLM_E_INVALID, "decode_greedy: exceeds max_len");
+    if (first_token < 0 || first_token >= m->cfg.vocab) FAIL(CLLM_E_INVALID, "decode_greedy: token id out of range");
     TRY(finalize(m, 1));
+    if (m->fused_ok && !getenv("CLLM_NO_FUSED")) {
+        const int32_t init[2] = { first_token, n_past }, zero = 0;
+        HIP_TRY(hipMemcpyAsync(m->tokens_dev, &init[0], 4, hipMemcpyHostToDevice, m->st));
+        HIP_TRY(hipMemcpyAsync(m->pos_dev, &init[1], 4, hipMemcpyHostToDevice, m->st));
+        HIP_TRY(hipMemcpyAsync(m->counter_dev, &zero, 4, hipMemcpyHostToDevice, m->st));
+        HIP_TRY(hipStreamSynchronize(m->st));
+        int s = 0;
+        if (!m->fused_warm) { TRY(decode_step_fused(m, true)); m->fused_warm = true; s = 1; HIP_TRY(hipStreamSynchronize(m->st)); }
+        if (s < n_steps) TRY(ensure_decode_graph(m));
+        for (; s < n_steps; s++) {
+            if (m->decode_graph) HIP_TRY(hipGraphLaunch(m->decode_graph, m->st));
+            else TRY(decode_step_fused(m, true));
+        }
+        HIP_TRY(hipMemcpyAsync(out_tokens_host, m->out_ring, (size_t) n_steps * 4, hipMemcpyDeviceToHost, m->st));
+        HIP_TRY(hipStreamSynchronize(m->st));
+        return CLLM_OK;
+    }
     int32_t tok = first_token;
     for (int s = 0; s < n_steps; s++) {
         const int32_t p = n_past + s;
@@ -380,5 +480,20 @@ extern "C" int cllm_llama_decode_greedy(cllm_llama * m, int32_t first_token, int
         HIP_TRY(hipStreamSynchronize(m->st));
         out_tokens_host[s] = tok;
     }
+    return CLLM_OK;
+}
+
+/* one fused decode step WITHOUT sampling: logits of `token` at position n_past (for parity tests of the fused path) */
+extern "C" int cllm_llama_decode_fused_logits(cllm_llama * m, int32_t token, int n_past, float * logits_host) {
+    if (!m || !logits_host || n_past < 0 || n_past >= m->cfg.max_len || token < 0 || token >= m->cfg.vocab) FAIL(CLLM_E_INVALID, "decode_fused_logits: arguments");
+    TRY(finalize(m, 1));
+    if (!m->fused_ok) FAIL(CLLM_E_UNSUPPORTED, "decode_fused_logits: this model/config cannot take the fused path");
+    const int32_t init[2] = { token, n_past };
+    HIP_TRY(hipMemcpyAsync(m->tokens_dev, &init[0], 4, hipMemcpyHostToDevice, m->st));
+    HIP_TRY(hipMemcpyAsync(m->pos_dev, &init[1], 4, hipMemcpyHostToDevice, m->st));
+    HIP_TRY(hipStreamSynchronize(m->st));
+    TRY(decode_step_fused(m, false));
+    HIP_TRY(hipMemcpyAsync(logits_host, m->logits, (size_t) m->cfg.vocab * 4, hipMemcpyDeviceToHost, m->st));
+    HIP_TRY(hipStreamSynchronize(m->st));
     return CLLM_OK;
 }

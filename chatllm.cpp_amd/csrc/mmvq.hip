@@ -29,6 +29,8 @@ struct mmvq_args {
     float * dst; int64_t dst_cs;
     const int32_t * ids; int64_t ids_s0, ids_s1;   // strides in int32 units
     int n_used, b_ne1, n_as; int64_t dst_s1, dst_s2; // dst strides (floats) over (u, t)
+    const float * bias;                            // optional fused ADD of a per-row bias   (Linear::forward, src/layers.cpp:2111-2129)
+    const float * resid;                           // optional fused ADD of the residual     (LMBlock1Forward::forward :2740,:2758), indexed like dst
 };
 
 __device__ __forceinline__ bool mmvq_select(const mmvq_args & a, const char *& W, const char *& act, float *& dst) {
@@ -120,8 +122,12 @@ __global__ void __launch_bounds__(512) k_mmvq_q4_K(const mmvq_args a) {
         }
 #pragma unroll
         for (int c = 0; c < NC; c++) {
-            const float r = wave_sum(accd[c]) - wave_sum(accm[c]);
-            if (lane == 0) dst[row + c * dst_cs] = r;
+            float r = wave_sum(accd[c]) - wave_sum(accm[c]);
+            if (lane == 0) {
+                if (a.bias)  r = r + a.bias[row];
+                if (a.resid) r = r + a.resid[row + c * dst_cs];
+                dst[row + c * dst_cs] = r;
+            }
         }
     }
 }
@@ -190,8 +196,12 @@ __global__ void __launch_bounds__(512) k_mmvq_q32(const mmvq_args a) {
         }
 #pragma unroll
         for (int c = 0; c < NC; c++) {
-            const float r = wave_sum(acc[c]);
-            if (lane == 0) dst[row + c * dst_cs] = r;
+            float r = wave_sum(acc[c]);
+            if (lane == 0) {
+                if (a.bias)  r = r + a.bias[row];
+                if (a.resid) r = r + a.resid[row + c * dst_cs];
+                dst[row + c * dst_cs] = r;
+            }
         }
     }
 }
@@ -324,4 +334,17 @@ int launch_mmvq_id(hipStream_t st, int wtype, const tview & as, const void * act
     a.ids = (const int32_t *) ids.data; a.ids_s0 = ids.nb[0] / 4; a.ids_s1 = ids.nb[1] / 4;
     a.n_used = (int) n_used; a.b_ne1 = (int) b_ne1; a.n_as = (int) as.ne[2]; a.dst_s1 = dst.nb[1] / 4; a.dst_s2 = dst.nb[2] / 4;
     return mmvq_dispatch(st, wtype, 1, rb, a, (int)(n_used * n_tok));
+}
+
+// single pre-quantized activation row (decode): dst[row] = W[row] . act (+ bias[row]) (+ resid[row]); dst may alias resid
+int launch_mmvq_act(hipStream_t st, int wtype, const void * W, int64_t K, int64_t nrows, const void * act, float * dst,
+                    const float * bias, const float * resid) {
+    const int kb = wtype == CLLM_TYPE_Q4_K ? 256 : 32;
+    if (K % kb) FAIL(CLLM_E_INVALID, "mmvq_act: K");
+    const size_t rb = act_row_bytes(K, kb);
+    if (rb > 160 * 1024) FAIL(CLLM_E_UNSUPPORTED, "mmvq_act: K=%lld does not fit LDS", (long long) K);
+    mmvq_args a = {};
+    a.W = (const char *) W; a.nb01 = (int64_t) cllm_row_size(wtype, K); a.nb02 = 0; a.nrows = nrows; a.nblk = (int)(K / kb);
+    a.act = (const char *) act; a.act_stride = rb; a.dst = dst; a.dst_cs = 0; a.bias = bias; a.resid = resid;
+    return mmvq_dispatch(st, wtype, 1, rb, a, 1);
 }

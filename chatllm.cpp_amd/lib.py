@@ -86,6 +86,7 @@ SIGNATURES = {
     "cllm_llama_set_allreduce": (C.c_int, [_P, ALLREDUCE_FN, _P]),
     "cllm_llama_forward": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, _P]),
     "cllm_llama_decode_greedy": (C.c_int, [_P, C.c_int32, C.c_int, C.c_int, _P]),
+    "cllm_llama_decode_fused_logits": (C.c_int, [_P, C.c_int32, C.c_int, _P]),
     "cllm_llama_use_graph": (C.c_int, [_P, C.c_int]),
     "cllm_llama_weight_bytes": (C.c_size_t, [_P]),
 }

@@ -60,6 +60,15 @@ class Llama:
         self.n_past = n_past + n_steps
         return out
 
+    def decode_fused_logits(self, token, n_past=None):
+        """logits of `token` at position n_past through the fused single-token kernels (no sampling)"""
+        if n_past is None:
+            n_past = self.n_past
+        logits = np.zeros(self.cfg["vocab"], np.float32)
+        _l.check(_l.get().cllm_llama_decode_fused_logits(self.h, int(token), n_past, logits.ctypes.data_as(C.c_void_p)), "decode_fused_logits")
+        self.n_past = n_past + 1
+        return logits
+
     def weight_bytes(self):
         return _l.get().cllm_llama_weight_bytes(self.h)
 

@@ -185,6 +185,8 @@ CLLM_API int  cllm_llama_forward(cllm_llama * m, const int32_t * tokens, int qle
                                  float * logits_host);
 /* decode-loop helpers: greedy argmax on device feeding the next step without a host round trip */
 CLLM_API int  cllm_llama_decode_greedy(cllm_llama * m, int32_t first_token, int n_past, int n_steps, int32_t * out_tokens_host);
+/* one step of the FUSED single-token path without sampling (parity surface: must equal cllm_llama_forward bit for bit) */
+CLLM_API int  cllm_llama_decode_fused_logits(cllm_llama * m, int32_t token, int n_past, float * logits_host);
 CLLM_API int  cllm_llama_use_graph(cllm_llama * m, int enable);
 CLLM_API size_t cllm_llama_weight_bytes(const cllm_llama * m);
 

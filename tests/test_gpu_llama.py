@@ -175,9 +175,42 @@ def test_end_to_end_statistics_against_the_oracle_run(gpu, name, wtype, plen):
         lr, lg = ref.forward([t]), dev.forward([t])
     assert agree == decided and decided > 0       # greedy ids identical wherever they are decidable
     assert max(diffs) < 0.25, diffs               # never beyond the activation-quantization noise floor
-    if name == "tiny":
-        assert np.median(diffs) < 1e-2 and min(diffs) < 1e-5, diffs
+    assert diffs[0] < 1e-4 or name != "tiny", diffs   # the prefill itself (no earlier flip to inherit) agrees to fp32 round-off
     dev.close()
+
+
+@pytest.mark.parametrize("wtype,over", [(O.Q8_0, {}), (O.Q4_0, {}), (O.Q4_K, {}), (O.Q4_K, dict(rope_mode=2, qkv_bias=1, rope_theta=1e6, ffn=544))])
+def test_fused_decode_path_is_bit_identical_to_the_node_by_node_path(gpu, wtype, over):
+    """norm+quant, rope+kv-write, fused attention, silu*up+quant, GEMV+bias/residual epilogues: same bits as the unfused nodes"""
+    cfg = gpu.synth.config("tiny", max_len=64, **over)
+    w = gpu.synth.make_model(cfg, wtype, seed=4)
+    a, b = gpu.Llama(cfg, w), gpu.Llama(cfg, w)
+    prompt = np.random.default_rng(4).integers(0, cfg["vocab"], 9).astype(np.int32)
+    la, lb = a.forward(prompt), b.forward(prompt)
+    assert np.array_equal(la, lb)
+    for t in np.random.default_rng(5).integers(0, cfg["vocab"], 40):      # n_kv runs 10..49: every lane-grouping regime of V.P
+        la, lb = a.forward([int(t)]), b.decode_fused_logits(int(t))
+        assert np.array_equal(la, lb)
+    a.close()
+    b.close()
+
+
+def test_decode_greedy_graph_replay_matches_stepwise(gpu):
+    cfg = gpu.synth.config("small", max_len=128)
+    w = gpu.synth.make_model(cfg, O.Q4_K, seed=6)
+    prompt = np.random.default_rng(6).integers(0, cfg["vocab"], 12).astype(np.int32)
+    a, b = gpu.Llama(cfg, w), gpu.Llama(cfg, w)
+    first = int(np.argmax(a.forward(prompt)))
+    assert first == int(np.argmax(b.forward(prompt)))
+    toks = []
+    t = first
+    for _ in range(40):
+        t = int(np.argmax(a.forward([t])))
+        toks.append(t)
+    got = list(b.decode_greedy(first, 25)) + list(b.decode_greedy(toks[24], 15))   # two calls: the graph is re-used with a new start
+    assert got == toks
+    a.close()
+    b.close()
 
 
 def test_decode_greedy_loop_matches_stepwise(gpu):
