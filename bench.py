@@ -177,6 +177,7 @@ def main():
     ap.add_argument("--wtype", default="q4_k", choices=sorted(WTYPES))
     ap.add_argument("--n-prompt", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="launch the fused decode kernels eagerly (for rocprofv3 kernel traces)")
     args = ap.parse_args()
 
     rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
@@ -195,9 +196,11 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
 
     wtype = WTYPES[args.wtype]
-    max_len = args.n_prompt + args.warmup + args.steps + 8
+    max_len = (args.n_prompt + args.warmup + args.steps + 8 + 63) // 64 * 64
     cfg = pkg.synth.config(args.model, max_len=max_len)
     m = build_model(pkg, cfg, wtype, rank, world)
+    if args.no_graph:
+        m.use_graph(False)
 
     if world > 1:
         import torch

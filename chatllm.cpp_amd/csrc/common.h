@@ -45,7 +45,10 @@ typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 typedef float    f32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ float    h2f(uint16_t h) { _Float16 v; __builtin_memcpy(&v, &h, 2); return (float) v; }
-__device__ __forceinline__ uint16_t f2h(float f)    { _Float16 v = (_Float16) f; uint16_t h; __builtin_memcpy(&h, &v, 2); return h; }   // RNE
+// f32 -> f16, round-to-nearest-even of the f32 VALUE.  The empty asm pins the operand in a VGPR first: without it the
+// compiler may fold a preceding multiply/fma into v_fma_mixlo_f16 (ONE rounding, straight to fp16), whereas the CPU path
+// rounds the product to f32 and then to fp16 (two roundings) -- they differ on ties (observed: 1 soft-max probability in ~10^4).
+__device__ __forceinline__ uint16_t f2h(float f)    { asm volatile("" : "+v"(f)); _Float16 v = (_Float16) f; uint16_t h; __builtin_memcpy(&h, &v, 2); return h; }
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
@@ -68,6 +71,15 @@ __device__ __forceinline__ int wave_sum_i(int v) {
     return v;
 }
 __device__ __forceinline__ int dot4(uint32_t a, uint32_t b, int c) { return __builtin_amdgcn_sdot4((int) a, (int) b, c, false); }
+
+// cos/sin of a RoPE angle.  ONE definition shared by k_rope (ops.hip) and k_rope_kv (decode_fused.hip): whether the
+// compiler pairs cosf+sinf into a sincos or not changes the last bit for some angles, and a 1-ulp difference in q/k
+// can flip their fp16 rounding -- the fused and node-by-node paths must agree to the bit.
+static __device__ __noinline__ float libm_expf(float x) { return expf(x); }     // scalar tail of soft_max / SiLU: one shared body
+static __device__ __noinline__ void rope_cos_sin(float theta, float * c, float * s) {
+    *c = cosf(theta);
+    *s = sinf(theta);
+}
 
 // one lane of the reference's AVX2 ggml_v_expf (ggml-cpu/vec.h:1230-1267), op for op, so that
 // soft_max / SiLU agree with the CPU path to the last bit wherever the CPU takes its vector body.

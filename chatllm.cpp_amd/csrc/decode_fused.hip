@@ -14,28 +14,25 @@
 #include <math.h>
 
 // ---------------------------------------------------------------------------------------------------------------
-// RMS_NORM + MUL + quantize: one workgroup of 1024 threads, one float4 per thread per pass.
+// RMS_NORM + MUL + quantize: one workgroup of 256 threads.
 //   ggml_compute_forward_rms_norm_f32 (ops.cpp:3710-3759) -> MUL -> quantize_row_q8_0 / q8_K (as mul_mat's src1)
 // ---------------------------------------------------------------------------------------------------------------
 template <int KIND>
-__global__ void __launch_bounds__(1024) k_norm_quant(const float * __restrict__ x, const float * __restrict__ w, int64_t H, float eps,
-                                                     char * __restrict__ act) {
-    __shared__ double part[16];
+__global__ void __launch_bounds__(256) k_norm_quant(const float * __restrict__ x, const float * __restrict__ w, int64_t H, float eps,
+                                                    char * __restrict__ act) {
+    // the sum of squares uses EXACTLY the partition and reduction tree of k_rms_norm (ops.hip) so that the fused and
+    // the node-by-node paths produce the same bits
+    __shared__ double part[4];
     const int tid = threadIdx.x, lane = tid & 63;
     double sum = 0.0;
-    for (int64_t e = (int64_t) tid * 4; e < H; e += 4096) {
-        const f32x4 v = *(const f32x4 *)(x + e);
-        sum += (double)(v.x * v.x); sum += (double)(v.y * v.y); sum += (double)(v.z * v.z); sum += (double)(v.w * v.w);
-    }
+    for (int64_t i = tid; i < H; i += 256) { const float v = x[i]; sum += (double)(v * v); }
     sum = wave_sum_d(sum);
     if (lane == 0) part[tid >> 6] = sum;
     __syncthreads();
-    sum = 0.0;
-#pragma unroll
-    for (int i = 0; i < 16; i++) sum += part[i];
+    sum = part[0] + part[1] + part[2] + part[3];
     const float mean  = (float)(sum / (double) H);
     const float scale = 1.0f / sqrtf(mean + eps);
-    for (int64_t e = (int64_t) tid * 4; e < H; e += 4096) {          // H % 256 == 0: whole waves stay together
+    for (int64_t e = (int64_t) tid * 4; e < H; e += 1024) {          // H % 256 == 0: whole waves stay together
         const f32x4 v = *(const f32x4 *)(x + e);
         const f32x4 g = *(const f32x4 *)(w + e);
         f32x4 y;
@@ -46,8 +43,8 @@ __global__ void __launch_bounds__(1024) k_norm_quant(const float * __restrict__ 
 
 int launch_norm_quant(hipStream_t st, int kind, const float * x, const float * w, int64_t H, float eps, void * act) {
     if (H % 256) FAIL(CLLM_E_UNSUPPORTED, "norm_quant: hidden size must be a multiple of 256");
-    if (kind == 32) hipLaunchKernelGGL(k_norm_quant<32>,  dim3(1), dim3(1024), 0, st, x, w, H, eps, (char *) act);
-    else            hipLaunchKernelGGL(k_norm_quant<256>, dim3(1), dim3(1024), 0, st, x, w, H, eps, (char *) act);
+    if (kind == 32) hipLaunchKernelGGL(k_norm_quant<32>,  dim3(1), dim3(256), 0, st, x, w, H, eps, (char *) act);
+    else            hipLaunchKernelGGL(k_norm_quant<256>, dim3(1), dim3(256), 0, st, x, w, H, eps, (char *) act);
     LAUNCH_CHECK();
     return CLLM_OK;
 }
@@ -72,7 +69,7 @@ int launch_quant_row(hipStream_t st, int kind, const float * x, int64_t K, void 
 // SiLU(gate) * up + quantize (F % 256 == 0 for Q8_K kind, % 32 for Q8_0 kind).  gu = [gate(F) | up(F)]
 //   ggml_vec_silu_f32 (vec.cpp:396-431): polynomial body for i < (F & ~7), libm tail
 // ---------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ float silu_ref(float x, bool body) { return body ? x / (1.0f + ggml_expf_poly(0.0f - x)) : x / (1.0f + expf(-x)); }
+__device__ __forceinline__ float silu_ref(float x, bool body) { return body ? x / (1.0f + ggml_expf_poly(0.0f - x)) : x / (1.0f + libm_expf(-x)); }
 
 template <int KIND>
 __global__ void __launch_bounds__(256) k_silu_mul_quant(const float * __restrict__ gu, int64_t F, char * __restrict__ act, float * __restrict__ g_out) {
@@ -108,7 +105,9 @@ __global__ void __launch_bounds__(256) k_rope_kv(float * __restrict__ qkv, const
     for (int i = threadIdx.x; i < half; i += blockDim.x) {
         float theta = (float) pos;
         for (int k = 0; k < i; k++) theta *= theta_scale;
-        cache[2*i] = cosf(theta); cache[2*i + 1] = sinf(theta);          // freq_scale 1, attn_factor 1, no YaRN on this path
+        float cs, sn;
+        rope_cos_sin(theta, &cs, &sn);                                   // freq_scale 1, attn_factor 1, no YaRN on this path
+        cache[2*i] = cs * 1.0f; cache[2*i + 1] = sn * 1.0f;
     }
     __syncthreads();
     const int QD = nh * hd, KD = nkv * hd;
@@ -151,7 +150,7 @@ int launch_rope_kv(hipStream_t st, float * qkv, const int32_t * pos_dev, int nh,
 // ---------------------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_attn_decode(const float * __restrict__ qkv, const int32_t * __restrict__ pos_dev, int nh, int nkv, int hd,
                                                      float scale, const uint16_t * __restrict__ k_cache, const uint16_t * __restrict__ v_cache,
-                                                     int64_t ML, float * __restrict__ att) {
+                                                     int64_t ML, float * __restrict__ att, float * __restrict__ dbg) {
     extern __shared__ __attribute__((aligned(16))) float sm[];       // [hd] q (fp16-rounded) | [n_kv] scores / probabilities
     __shared__ double red_d[1];
     __shared__ float  red_f[4];
@@ -205,7 +204,7 @@ __global__ void __launch_bounds__(256) k_attn_decode(const float * __restrict__ 
             const float a0 = e[0] + e[4], a1 = e[1] + e[5], a2 = e[2] + e[6], a3 = e[3] + e[7];
             sum += (double)((a0 + a2) + (a1 + a3));
         }
-        if (lane == 0) for (int i = nv; i < n_kv; i++) { const float e = expf(sc[i] - mx); sc[i] = e; sum += (double) e; }
+        if (lane == 0) for (int i = nv; i < n_kv; i++) { const float e = libm_expf(sc[i] - mx); sc[i] = e; sum += (double) e; }
         sum = wave_sum_d(sum);
         if (lane == 0) red_d[0] = sum;
     }
@@ -213,6 +212,7 @@ __global__ void __launch_bounds__(256) k_attn_decode(const float * __restrict__ 
     const float inv = (float)(1.0 / red_d[0]);
     for (int i = tid; i < n_kv; i += 256) sc[i] = h2f(f2h(sc[i] * inv));   // probability, then its fp16 rounding for V.P
     __syncthreads();
+    if (dbg) { for (int i = tid; i < n_kv; i += 256) dbg[(int64_t) h * ML + i] = sc[i]; if (tid == 0) { dbg[(int64_t) nh * ML + 2*h] = mx; dbg[(int64_t) nh * ML + 2*h + 1] = inv; } }
 
     // ---- ctx = V . P ----
     G = 64; while (G > 8 && G * 8 > n_kv) G >>= 1;
@@ -241,6 +241,9 @@ __global__ void __launch_bounds__(256) k_attn_decode(const float * __restrict__ 
         }
     }
 }
+static float * g_attn_dbg = nullptr;
+extern "C" __attribute__((visibility("default"))) void cllm_debug_set_attn_probs(float * dev_buf) { g_attn_dbg = dev_buf; }   // tools only
+
 int launch_attn_decode(hipStream_t st, const float * qkv, const int32_t * pos_dev, int nh, int nkv, int hd, const uint16_t * k_cache,
                        const uint16_t * v_cache, int64_t ML, float * att) {
     if (hd % 8 || (ML % 8) || nh % nkv) FAIL(CLLM_E_UNSUPPORTED, "attn_decode: head_dim and max_len must be multiples of 8");
@@ -248,9 +251,15 @@ int launch_attn_decode(hipStream_t st, const float * qkv, const int32_t * pos_de
     if (lds > 150 * 1024) FAIL(CLLM_E_UNSUPPORTED, "attn_decode: max_len %lld does not fit LDS", (long long) ML);
     static bool attr = false;
     if (lds > 48 * 1024 && !attr) { HIP_TRY(hipFuncSetAttribute((const void *) k_attn_decode, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024)); attr = true; }
-    hipLaunchKernelGGL(k_attn_decode, dim3(nh), dim3(256), lds, st, qkv, pos_dev, nh, nkv, hd, 1.0f / sqrtf((float) hd), k_cache, v_cache, ML, att);
+    hipLaunchKernelGGL(k_attn_decode, dim3(nh), dim3(256), lds, st, qkv, pos_dev, nh, nkv, hd, 1.0f / sqrtf((float) hd), k_cache, v_cache, ML, att, g_attn_dbg);
     LAUNCH_CHECK();
     return CLLM_OK;
+}
+
+extern "C" int cllm_op_attn_decode(void * stream, const float * q, const int32_t * pos_dev, int n_head, int n_kv_head, int head_dim,
+                                   const void * k_cache, const void * v_cache, int64_t max_len, float * out) {
+    if (!q || !pos_dev || !k_cache || !v_cache || !out || n_head <= 0 || n_kv_head <= 0 || head_dim <= 0) FAIL(CLLM_E_INVALID, "attn_decode: arguments");
+    return launch_attn_decode((hipStream_t) stream, q, pos_dev, n_head, n_kv_head, head_dim, (const uint16_t *) k_cache, (const uint16_t *) v_cache, max_len, out);
 }
 
 // ---------------------------------------------------------------------------------------------------------------

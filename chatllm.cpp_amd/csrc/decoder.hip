@@ -20,6 +20,7 @@
 #include <map>
 #include <math.h>
 #include <string.h>
+#include <stdio.h>
 
 struct dweight { int type = -1; void * data = nullptr; size_t bytes = 0; bool owned = false; };
 
@@ -450,6 +451,7 @@ extern "C" int cllm_llama_decode_greedy(cllm_llama * m, int32_t first_token, int
     if ((int64_t) n_past + n_steps > m->cfg.max_len) FAIL(CLLM_E_INVALID, "decode_greedy: exceeds max_len");
     if (first_token < 0 || first_token >= m->cfg.vocab) FAIL(CLLM_E_INVALID, "decode_greedy: token id out of range");
     TRY(finalize(m, 1));
+    if (getenv("CLLM_DEBUG")) fprintf(stderr, "[cllm] decode_greedy: fused_ok=%d own_stream=%d use_graph=%d graph=%p\n", (int) m->fused_ok, (int) m->own_stream, (int) m->use_graph, (void *) m->decode_graph);
     if (m->fused_ok && !getenv("CLLM_NO_FUSED")) {
         const int32_t init[2] = { first_token, n_past }, zero = 0;
         HIP_TRY(hipMemcpyAsync(m->tokens_dev, &init[0], 4, hipMemcpyHostToDevice, m->st));
@@ -494,6 +496,17 @@ extern "C" int cllm_llama_decode_fused_logits(cllm_llama * m, int32_t token, int
     HIP_TRY(hipStreamSynchronize(m->st));
     TRY(decode_step_fused(m, false));
     HIP_TRY(hipMemcpyAsync(logits_host, m->logits, (size_t) m->cfg.vocab * 4, hipMemcpyDeviceToHost, m->st));
+    HIP_TRY(hipStreamSynchronize(m->st));
+    return CLLM_OK;
+}
+
+/* debug/test hook: copy an internal activation buffer of the LAST forward to the host ("x", "qkv", "att", "gu", "logits") */
+extern "C" int cllm_llama_debug_read(cllm_llama * m, const char * what, float * host, int64_t n) {
+    if (!m || !what || !host || n <= 0) FAIL(CLLM_E_INVALID, "debug_read: arguments");
+    const std::string w(what);
+    const float * src = w == "x" ? m->x : w == "qkv" ? m->qkv : w == "att" ? m->att : w == "gu" ? m->gu : w == "logits" ? m->logits : nullptr;
+    if (!src) FAIL(CLLM_E_INVALID, "debug_read: unknown buffer '%s'", what);
+    HIP_TRY(hipMemcpyAsync(host, src, (size_t) n * 4, hipMemcpyDeviceToHost, m->st));
     HIP_TRY(hipStreamSynchronize(m->st));
     return CLLM_OK;
 }

@@ -78,8 +78,10 @@ __global__ void __launch_bounds__(256) k_rope(tview s, tview d, const int32_t * 
             th = theta_interp * (1 - ramp) + theta_extrap * ramp;
             mscale *= 1.0f + 0.1f * logf(1.0f / p.freq_scale);
         }
-        cache[2*i]     = cosf(th) * mscale;
-        cache[2*i + 1] = sinf(th) * mscale;
+        float cs, sn;
+        rope_cos_sin(th, &cs, &sn);
+        cache[2*i]     = cs * mscale;
+        cache[2*i + 1] = sn * mscale;
     }
     __syncthreads();
     const int64_t ne0 = s.ne[0], nh = s.ne[1];
@@ -170,7 +172,7 @@ __global__ void __launch_bounds__(256) k_soft_max(tview s, tview d, const char *
         const float a0 = e[0] + e[4], a1 = e[1] + e[5], a2 = e[2] + e[6], a3 = e[3] + e[7];
         sum += (double)((a0 + a2) + (a1 + a3));
     }
-    if (lane == 0) for (int64_t i = nv; i < n; i++) { const float e = expf(val(i) - mx); y[i] = e; sum += (double) e; }
+    if (lane == 0) for (int64_t i = nv; i < n; i++) { const float e = libm_expf(val(i) - mx); y[i] = e; sum += (double) e; }
     sum = wave_sum_d(sum);
     const float inv = (float)(1.0 / sum);
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");   // e[] written by other lanes of this wave
@@ -223,13 +225,13 @@ __global__ void __launch_bounds__(256) k_elementwise(tview a, tview b, tview d, 
         else if (OP == EW_SCALE)     y = (f1 == 0.0f) ? x * f0 : x * f0 + f1;            // ggml_vec_scale_f32 / ggml_vec_mad1_f32
         else if (OP == EW_SILU) {
             // ggml_vec_silu_f32 (vec.cpp:396-431): AVX2 body for i0 < (ne0 & ~7), scalar expf tail
-            y = (i0 < (d.ne[0] & ~(int64_t) 7)) ? x / (1.0f + ggml_expf_poly(0.0f - x)) : x / (1.0f + expf(-x));
+            y = (i0 < (d.ne[0] & ~(int64_t) 7)) ? x / (1.0f + ggml_expf_poly(0.0f - x)) : x / (1.0f + libm_expf(-x));
         } else {
             const float z = *(const float *)(b.data + (i0 % b.ne[0])*b.nb[0] + (i1 % b.ne[1])*b.nb[1] + (i2 % b.ne[2])*b.nb[2] + (i3 % b.ne[3])*b.nb[3]);
             if (OP == EW_ADD)      y = x + z;
             else if (OP == EW_MUL) y = x * z;
             else {                                                                          // silu(gate) * up
-                const float sl = (i0 < (d.ne[0] & ~(int64_t) 7)) ? x / (1.0f + ggml_expf_poly(0.0f - x)) : x / (1.0f + expf(-x));
+                const float sl = (i0 < (d.ne[0] & ~(int64_t) 7)) ? x / (1.0f + ggml_expf_poly(0.0f - x)) : x / (1.0f + libm_expf(-x));
                 y = sl * z;
             }
         }

@@ -71,6 +71,7 @@ SIGNATURES = {
     "cllm_op_diag_mask_inf": (C.c_int, [_P, _T, _T, C.c_int]),
     "cllm_op_scale": (C.c_int, [_P, _T, _T, C.c_float, C.c_float]),
     "cllm_op_scale_mask_soft_max": (C.c_int, [_P, _T, _T, C.c_float, C.c_int]),
+    "cllm_op_attn_decode": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, _P, _P, C.c_int64, _P]),
     "cllm_op_unary": (C.c_int, [_P, C.c_int, _T, _T]),
     "cllm_op_add": (C.c_int, [_P, _T, _T, _T]),
     "cllm_op_mul": (C.c_int, [_P, _T, _T, _T]),
@@ -87,6 +88,7 @@ SIGNATURES = {
     "cllm_llama_forward": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, _P]),
     "cllm_llama_decode_greedy": (C.c_int, [_P, C.c_int32, C.c_int, C.c_int, _P]),
     "cllm_llama_decode_fused_logits": (C.c_int, [_P, C.c_int32, C.c_int, _P]),
+    "cllm_llama_debug_read": (C.c_int, [_P, C.c_char_p, _P, C.c_int64]),
     "cllm_llama_use_graph": (C.c_int, [_P, C.c_int]),
     "cllm_llama_weight_bytes": (C.c_size_t, [_P]),
 }

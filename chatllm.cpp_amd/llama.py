@@ -69,6 +69,11 @@ class Llama:
         self.n_past = n_past + 1
         return logits
 
+    def debug_read(self, what, n):
+        out = np.zeros(n, np.float32)
+        _l.check(_l.get().cllm_llama_debug_read(self.h, what.encode(), out.ctypes.data_as(C.c_void_p), n), "debug_read")
+        return out
+
     def weight_bytes(self):
         return _l.get().cllm_llama_weight_bytes(self.h)
 

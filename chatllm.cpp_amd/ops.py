@@ -99,6 +99,14 @@ def scale_mask_soft_max(a, scale_, n_past, dst=None):
     return dst
 
 
+def attn_decode(q, pos, n_head, n_kv_head, head_dim, k_cache, v_cache, max_len, dst=None):
+    """fused single-token attention; q: [hd, n_head] F32, pos: I32 [1] device tensor holding n_past"""
+    dst = dst or Tensor(F32, [head_dim * n_head])
+    _l.check(_l.get().cllm_op_attn_decode(None, q.data_ptr(), pos.data_ptr(), n_head, n_kv_head, head_dim, k_cache.data_ptr(), v_cache.data_ptr(),
+                                          max_len, dst.data_ptr()), "attn_decode")
+    return dst
+
+
 def silu(a, dst=None):
     dst = dst or Tensor(F32, a.ne)
     _l.check(_l.get().cllm_op_unary(None, UNARY_SILU, _ref(a), _ref(dst)), "silu")

@@ -136,6 +136,13 @@ CLLM_API int cllm_op_scale(void * stream, const cllm_tensor * src, cllm_tensor *
 /* fused SCALE + DIAG_MASK_INF + SOFT_MAX as chatllm's attn_scores_to_probs emits them (src/layers.cpp:2499-2539) */
 CLLM_API int cllm_op_scale_mask_soft_max(void * stream, const cllm_tensor * src, cllm_tensor * dst, float scale, int n_past);
 
+/* fused single-token attention as chatllm's eager path emits it for qlen == 1 (src/layers.cpp:2541-2561, 2499-2539):
+ *   MUL_MAT(K view, Q) + SCALE(1/sqrt(hd)) + DIAG_MASK_INF + SOFT_MAX + MUL_MAT(V view, P) + PERMUTE + CONT
+ * q: [hd, n_head] F32 (post-RoPE); k_cache: [max_len][n_kv_head*hd] F16; v_cache: [n_kv_head*hd][max_len] F16 (transposed);
+ * the number of cached positions is *pos_dev + 1 (read on the device); out: [hd * n_head] F32.  Bit-identical to the nodes. */
+CLLM_API int cllm_op_attn_decode(void * stream, const float * q, const int32_t * pos_dev, int n_head, int n_kv_head, int head_dim,
+                                 const void * k_cache, const void * v_cache, int64_t max_len, float * out);
+
 typedef enum cllm_unary { CLLM_UNARY_SILU = 10 /* == GGML_UNARY_OP_SILU */ } cllm_unary;
 /* GGML_OP_UNARY         ggml_vec_silu_f32 (ggml-cpu/vec.cpp:396-431) */
 CLLM_API int cllm_op_unary(void * stream, int op, const cllm_tensor * src, cllm_tensor * dst);
@@ -188,6 +195,8 @@ CLLM_API int  cllm_llama_decode_greedy(cllm_llama * m, int32_t first_token, int 
 /* one step of the FUSED single-token path without sampling (parity surface: must equal cllm_llama_forward bit for bit) */
 CLLM_API int  cllm_llama_decode_fused_logits(cllm_llama * m, int32_t token, int n_past, float * logits_host);
 CLLM_API int  cllm_llama_use_graph(cllm_llama * m, int enable);
+/* test hook: read an internal activation buffer of the last step ("x", "qkv", "att", "gu", "logits") */
+CLLM_API int  cllm_llama_debug_read(cllm_llama * m, const char * what, float * host, int64_t n);
 CLLM_API size_t cllm_llama_weight_bytes(const cllm_llama * m);
 
 #ifdef __cplusplus
