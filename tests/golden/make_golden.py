@@ -1,0 +1,101 @@
+#!/usr/bin/env python3
+"""Generates tests/golden/*.npz from the REAL reference (run in the build container, where /root/reference and
+oracle/_ref exist):
+  * op-level vectors through oracle/_ref/libref_ops.so (the reference's ggml CPU backend, x86-64-v3 build)
+  * model-level vectors through oracle/_ref/ref_chat (the reference's chatllm.cpp host + CPU backend) on the synthetic
+    GGMM models of tools/make_ggmm.py
+The fixtures are small and committed; the reference itself does not travel to the GPU box.
+    python tests/golden/make_golden.py
+"""
+import ctypes as C
+import os
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import __graft_entry__ as ge  # noqa: E402
+from synth_helpers import rand_blocks  # noqa: E402
+import make_ggmm  # noqa: E402
+
+O = ge.load_oracle()
+pkg = ge.load_package()
+R = O.ref()
+P = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
+rng = np.random.default_rng(20260924)
+out = {}
+
+# ---- activation quantizers (bit-exact contract) ----
+for K in (256, 4096):
+    x = (rng.standard_normal(K) * 2).astype(np.float32)
+    x[:32] = 0
+    x[40] = x[41] = -x[42]
+    x[64:96] = np.arange(32, dtype=np.float32) + 0.5
+    q0 = np.zeros(K // 32 * 34, np.uint8)
+    qk = np.zeros(K // 256 * 292, np.uint8)
+    assert R.ref_quantize_cpu(8, P(x), P(q0), C.c_int64(K)) == 0 and R.ref_quantize_cpu(15, P(x), P(qk), C.c_int64(K)) == 0
+    out[f"quant_x_{K}"], out[f"quant_q8_0_{K}"], out[f"quant_q8_K_{K}"] = x, q0, qk
+
+# ---- mul_mat: GEMV (M=1) and GEMM (M=12) for the three weight formats ----
+for t, name in ((12, "q4_K"), (2, "q4_0"), (8, "q8_0")):
+    for M in (1, 12):
+        K, N = 1024, 48
+        w = rand_blocks(t, N, K, rng)
+        x = rng.standard_normal((M, K)).astype(np.float32)
+        y = np.zeros((M, N), np.float32)
+        assert R.ref_mul_mat(t, C.c_int64(K), C.c_int64(N), C.c_int64(M), C.c_int64(1), C.c_int64(1), P(w), P(x), P(y)) == 0
+        out[f"mm_{name}_{M}_w"], out[f"mm_{name}_{M}_x"], out[f"mm_{name}_{M}_y"] = w, x, y
+    deq = np.zeros(1024, np.float32)
+    assert R.ref_dequantize(t, P(out[f"mm_{name}_1_w"][0]), P(deq), C.c_int64(1024)) == 0
+    out[f"dequant_{name}"] = deq
+
+# ---- rms_norm, rope (both modes), soft_max, silu, eager attention composite ----
+x = rng.standard_normal((3, 512)).astype(np.float32)
+y = np.zeros_like(x)
+assert R.ref_unary(0, C.c_int64(512), C.c_int64(3), C.c_int64(1), P(x), P(y), C.c_float(1e-5), C.c_int(0)) == 0
+out["rms_x"], out["rms_y"] = x, y
+x = (rng.standard_normal((4, 77)) * 3).astype(np.float32)
+for op, name in ((1, "silu"), (2, "softmax")):
+    y = np.zeros_like(x)
+    assert R.ref_unary(op, C.c_int64(77), C.c_int64(4), C.c_int64(1), P(x), P(y), C.c_float(0), C.c_int(0)) == 0
+    out[f"{name}_x"], out[f"{name}_y"] = x, y
+x = rng.standard_normal((5, 3, 128)).astype(np.float32)
+pos = np.array([0, 3, 17, 200, 1023], np.int32)
+for mode in (0, 2):
+    y = np.zeros_like(x)
+    assert R.ref_rope(C.c_int64(128), C.c_int64(3), C.c_int64(5), P(x), P(pos), None, C.c_int(128), C.c_int(mode), C.c_int(0), C.c_float(500000.0),
+                      C.c_float(1.0), C.c_float(0.0), C.c_float(1.0), C.c_float(0.0), C.c_float(0.0), P(y)) == 0
+    out[f"rope_y_mode{mode}"] = y
+out["rope_x"], out["rope_pos"] = x, pos
+hd, nh, nkv, ML, qlen, n_past = 64, 4, 2, 48, 3, 21
+q = rng.standard_normal((qlen, nh, hd)).astype(np.float32)
+kc = rng.standard_normal((ML, hd * nkv)).astype(np.float16)
+vc = rng.standard_normal((hd * nkv, ML)).astype(np.float16)
+att = np.zeros((qlen, nh * hd), np.float32)
+assert R.ref_attention(C.c_int64(hd), C.c_int64(nh), C.c_int64(nkv), C.c_int64(qlen), C.c_int64(n_past), C.c_int64(ML), P(q), P(kc), P(vc), P(att), None) == 0
+out["attn_q"], out["attn_kc"], out["attn_vc"], out["attn_out"] = q, kc, vc, att
+out["attn_dims"] = np.array([hd, nh, nkv, ML, qlen, n_past], np.int32)
+np.savez_compressed(os.path.join(HERE, "ops_reference.npz"), **out)
+print("ops_reference.npz:", len(out), "arrays")
+
+# ---- model level: the reference HOST (ref_chat) on synthetic GGMM files ----
+ref_chat = os.path.join(ROOT, "oracle", "_ref", "ref_chat")
+model = {}
+prompt = [1, 17, 42, 300, 7, 99, 250, 12, 5]
+cfg = pkg.synth.config("tiny", max_len=64)
+for wt, name in ((12, "q4_k"), (2, "q4_0"), (8, "q8_0")):
+    with tempfile.TemporaryDirectory() as td:
+        mp, lp = os.path.join(td, "m.bin"), os.path.join(td, "l.bin")
+        make_ggmm.write_model(mp, cfg, wt, seed=1234)
+        ids = subprocess.check_output([ref_chat, mp, "cpu", "4", "12", lp] + [str(p) for p in prompt], stderr=subprocess.DEVNULL, text=True).split()
+        model[f"{name}_ids"] = np.array([int(i) for i in ids], np.int32)
+        model[f"{name}_logits"] = np.fromfile(lp, np.float32).reshape(13, cfg["vocab"])
+model["prompt"] = np.array(prompt, np.int32)
+np.savez_compressed(os.path.join(HERE, "tiny_llama3_reference.npz"), **model)
+print("tiny_llama3_reference.npz:", {k: v.shape for k, v in model.items()})

@@ -1,0 +1,132 @@
+"""Committed golden vectors produced by the REAL reference (tests/golden/make_golden.py: ggml CPU backend for the ops,
+the chatllm.cpp host `ref_chat` for whole models).  CPU part: the oracle reproduces them (this is what pins the oracle on
+machines without /root/reference).  GPU part (-m gpu): the HIP path reproduces them through the C ABI."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle as O
+
+G = np.load(os.path.join(os.path.dirname(__file__), "golden", "ops_reference.npz"))
+M = np.load(os.path.join(os.path.dirname(__file__), "golden", "tiny_llama3_reference.npz"))
+TYPES = ((O.Q4_K, "q4_K"), (O.Q4_0, "q4_0"), (O.Q8_0, "q8_0"))
+
+
+def rel(a, b):
+    return float(np.max(np.abs(a - b)) / (np.max(np.abs(b)) + 1e-30))
+
+
+# ---------------------------------------------------------------- CPU: oracle vs golden
+@pytest.mark.parametrize("K", [256, 4096])
+def test_oracle_quantizers_match_golden_bytes(K):
+    x = G[f"quant_x_{K}"]
+    assert np.array_equal(O.quantize_q8_0(x), G[f"quant_q8_0_{K}"])
+    assert np.array_equal(O.quantize_q8_K(x), G[f"quant_q8_K_{K}"])
+
+
+@pytest.mark.parametrize("t,name", TYPES)
+def test_oracle_mul_mat_and_dequant_match_golden(t, name):
+    assert np.array_equal(O.dequantize(t, G[f"mm_{name}_1_w"][0], 1024), G[f"dequant_{name}"])
+    for Mc in (1, 12):
+        w, x, y = G[f"mm_{name}_{Mc}_w"], G[f"mm_{name}_{Mc}_x"], G[f"mm_{name}_{Mc}_y"]
+        got = np.zeros_like(y)
+        O.mul_mat(O.tensor(w, t, [1024, 48]), O.tensor(x, O.F32, [1024, Mc]), O.tensor(got, O.F32, [48, Mc]))
+        assert rel(got, y) < 1e-5
+
+
+def test_oracle_norm_rope_softmax_silu_attention_match_golden():
+    got = np.zeros_like(G["rms_y"])
+    O.rms_norm(O.tensor(G["rms_x"], O.F32, [512, 3]), O.tensor(got, O.F32, [512, 3]), 1e-5)
+    assert np.array_equal(got, G["rms_y"])
+    got = np.zeros_like(G["softmax_y"])
+    O.soft_max(O.tensor(G["softmax_x"], O.F32, [77, 4]), None, O.tensor(got, O.F32, [77, 4]))
+    assert np.allclose(got, G["softmax_y"], rtol=2e-7, atol=0)
+    got = np.zeros_like(G["silu_y"])
+    O.silu(O.tensor(G["silu_x"], O.F32, [77, 4]), O.tensor(got, O.F32, [77, 4]))
+    assert np.array_equal(got[:, :72], G["silu_y"][:, :72]) and np.allclose(got, G["silu_y"], rtol=1e-6, atol=0)
+    for mode in (0, 2):
+        got = np.zeros_like(G["rope_x"])
+        O.rope(O.tensor(G["rope_x"], O.F32, [128, 3, 5]), G["rope_pos"], None, O.tensor(got, O.F32, [128, 3, 5]), 128, mode, 500000.0)
+        assert np.allclose(got, G[f"rope_y_mode{mode}"], rtol=3e-7, atol=3e-7)
+
+
+@pytest.mark.parametrize("t,name", ((O.Q4_K, "q4_k"), (O.Q4_0, "q4_0"), (O.Q8_0, "q8_0")))
+def test_oracle_whole_model_matches_the_reference_host(pkg, t, name):
+    """the scalar-order restatement vs chatllm.cpp itself (AVX2 CPU backend) on the same GGMM file.  Both are "the CPU
+    path"; their fp32 summation order differs, so they agree to fp32 round-off until one of the path's own roundings
+    (int8 activations, fp16 K/V/P) flips, and stay inside the quantization-noise floor afterwards."""
+    cfg = pkg.synth.config("tiny", max_len=64)
+    m = O.Llama(cfg, pkg.synth.make_model(cfg, t, seed=1234))
+    ids, logits = M[f"{name}_ids"], M[f"{name}_logits"]
+    lg = m.forward(M["prompt"])
+    assert float(np.max(np.abs(lg - logits[0]))) < 1e-4        # the prompt chunk: no earlier flip to inherit
+    agree = decided = 0
+    for s in range(13):
+        d = float(np.max(np.abs(lg - logits[s])))
+        assert d < 0.25 * float(logits[s].std()), (s, d)
+        top2 = np.partition(logits[s], -2)[-2:]
+        if top2[1] - top2[0] > 2 * d:
+            decided += 1
+            agree += int(np.argmax(lg) == ids[s])
+        if s < 12:
+            lg = m.forward([int(ids[s])])
+    assert decided >= 8 and agree == decided
+
+
+# ---------------------------------------------------------------- GPU: HIP path vs golden
+@pytest.mark.gpu
+@pytest.mark.parametrize("K", [256, 4096])
+def test_gpu_quantizers_match_golden_bytes(gpu, K):
+    x = gpu.Tensor.from_numpy(G[f"quant_x_{K}"])
+    y0, yk = gpu.Tensor(gpu.I32, [K // 32 * 34 // 4 + 8]), gpu.Tensor(gpu.I32, [K // 256 * 292 // 4 + 8])
+    gpu.lib.check(gpu.lib.get().cllm_quantize_row_q8_0(None, x.data_ptr(), y0.data_ptr(), K), "q8_0")
+    gpu.lib.check(gpu.lib.get().cllm_quantize_row_q8_K(None, x.data_ptr(), yk.data_ptr(), K), "q8_K")
+    assert np.array_equal(y0.raw()[: K // 32 * 34], G[f"quant_q8_0_{K}"])
+    assert np.array_equal(yk.raw()[: K // 256 * 292], G[f"quant_q8_K_{K}"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("t,name", TYPES)
+def test_gpu_mul_mat_matches_golden(gpu, t, name):
+    for Mc in (1, 12):                                  # GEMV kernel and int8-MFMA GEMM kernel
+        w, x, y = G[f"mm_{name}_{Mc}_w"], G[f"mm_{name}_{Mc}_x"], G[f"mm_{name}_{Mc}_y"]
+        got = gpu.ops.mul_mat(gpu.Tensor.from_numpy(w, t, [1024, 48]), gpu.Tensor.from_numpy(x)).numpy().reshape(y.shape)
+        assert rel(got, y) < 1e-5
+
+
+@pytest.mark.gpu
+def test_gpu_attention_composite_matches_golden(gpu):
+    hd, nh, nkv, ML, qlen, n_past = [int(v) for v in G["attn_dims"]]
+    KD, n_kv = hd * nkv, n_past + qlen
+    ops = gpu.ops
+    dq, dk, dv = gpu.Tensor.from_numpy(G["attn_q"]), gpu.Tensor.from_numpy(G["attn_kc"]), gpu.Tensor.from_numpy(G["attn_vc"])
+    s = ops.mul_mat(dk.view([hd, n_kv, nkv], [2, KD * 2, hd * 2]), dq.permute(0, 2, 1, 3))
+    p = ops.scale_mask_soft_max(s, 1.0 / np.sqrt(hd), n_past)
+    c = ops.mul_mat(dv.view([n_kv, hd, nkv], [2, ML * 2, ML * hd * 2]), p)
+    got = ops.cont(c.permute(0, 2, 1, 3)).numpy().reshape(qlen, nh * hd)
+    assert rel(got, G["attn_out"]) < 3e-4               # fp16 rounding of P can flip (see test_gpu_ops)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("t,name", ((O.Q4_K, "q4_k"), (O.Q4_0, "q4_0"), (O.Q8_0, "q8_0")))
+def test_gpu_whole_model_against_the_reference_host(gpu, t, name):
+    """decoder runner vs chatllm.cpp's own CPU run on the same synthetic GGMM weights: prefill to fp32 round-off,
+    greedy ids identical wherever the reference's margin decides them, never beyond the quantization-noise floor"""
+    cfg = gpu.synth.config("tiny", max_len=64)
+    m = gpu.Llama(cfg, gpu.synth.make_model(cfg, t, seed=1234))
+    ids, logits = M[f"{name}_ids"], M[f"{name}_logits"]
+    lg = m.forward(M["prompt"])
+    assert float(np.max(np.abs(lg - logits[0]))) < 1e-4
+    agree = decided = 0
+    for s in range(13):
+        d = float(np.max(np.abs(lg - logits[s])))
+        assert d < 0.25 * float(logits[s].std())
+        top2 = np.partition(logits[s], -2)[-2:]
+        if top2[1] - top2[0] > 2 * d:
+            decided += 1
+            agree += int(np.argmax(lg) == ids[s])
+        if s < 12:
+            lg = m.forward([int(ids[s])])
+    assert decided >= 8 and agree == decided
+    m.close()

@@ -1,0 +1,110 @@
+#!/usr/bin/env python3
+"""Write a synthetic Llama-3-architecture model in chatllm.cpp's GGMM file format, with the SAME pre-quantized
+blocks chatllm.cpp_amd/synth.py feeds to our own runner.  Used to drive the real reference host (oracle/_ref/main):
+CPU backend vs `-ngl all` on our libggml-hip.so module with identical weights.
+
+File layout (restated from SURVEY.md 8c; reader: /root/reference/src/models.cpp:1996-2047, src/chat.cpp:1425-1459):
+  "ggmm", i32 version=1, u32 off_config, off_tokenizer, off_tensors, JSON meta padded to 4 bytes,
+  @off_config   : i32 model_type (0x1700 = Llama3), i32 file version, BaseConfig (11 x i32), i32 num_kv_heads, f32 rope_theta
+  @off_tokenizer: {i32 len, bytes, u8 type}* i32 -1 ; merges {i32 len, bytes}* i32 -1
+  @off_tensors  : {i32 name_len, name, i32 ndim, i32 dims[ndim] (outer -> inner), i32 ggml_type, pad to 16, payload}*
+"""
+import argparse
+import json
+import os
+import struct
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import __graft_entry__ as ge  # noqa: E402
+
+WT = {"q4_k": 12, "q4_0": 2, "q8_0": 8}
+HF_NAME = {"wq": "self_attn.q_proj.weight", "wk": "self_attn.k_proj.weight", "wv": "self_attn.v_proj.weight", "wo": "self_attn.o_proj.weight",
+           "wgate": "mlp.gate_proj.weight", "wup": "mlp.up_proj.weight", "wdown": "mlp.down_proj.weight",
+           "attn_norm": "input_layernorm.weight", "ffn_norm": "post_attention_layernorm.weight"}
+
+
+def bytes_to_unicode():
+    bs = list(range(33, 127)) + list(range(161, 173)) + list(range(174, 256))
+    cs = bs[:]
+    n = 0
+    for b in range(256):
+        if b not in bs:
+            bs.append(b)
+            cs.append(256 + n)
+            n += 1
+    return dict(zip(bs, map(chr, cs)))
+
+
+def write_model(path, cfg, wtype, seed=1234, model_name="SynthLlama3"):
+    pkg = ge.load_package()
+    V, H = cfg["vocab"], cfg["hidden"]
+    assert V >= 262
+    b2u = bytes_to_unicode()
+    toks = [(b2u[b].encode(), 1) for b in range(256)]
+    toks += [(s.encode(), 3) for s in ["<|begin_of_text|>", "<|end_of_text|>", "<|start_header_id|>", "<|end_header_id|>", "<|eot_id|>"]]
+    while len(toks) < V:
+        toks.append((f"<|pad{len(toks)}|>".encode(), 3))
+    with open(path, "wb") as f:
+        f.write(b"ggmm")
+        f.write(struct.pack("4i", 1, 0, 0, 0))
+        meta = json.dumps({"model_name": model_name}).encode()
+        f.write(meta + b"\0" * (-len(meta) % 4))
+
+        def mark(off):
+            p = f.tell()
+            f.seek(off)
+            f.write(struct.pack("i", p))
+            f.seek(0, 2)
+        mark(8)
+        f.write(struct.pack("2i", 0x1700, 1))
+        f.write(struct.pack("11i", wtype, V, H, cfg["n_head"], cfg["n_layer"], cfg["ffn"], cfg["max_len"], 256, 257, -1, -1))
+        f.write(struct.pack("i", cfg["n_kv_head"]))
+        f.write(struct.pack("<f", cfg["rope_theta"]))
+        mark(12)
+        for t, tt in toks:
+            f.write(struct.pack("i", len(t)))
+            f.write(t)
+            f.write(struct.pack("B", tt))
+        f.write(struct.pack("i", -1))
+        f.write(struct.pack("i", -1))
+        mark(16)
+
+        def dump(name, type_, dims_outer_to_inner, payload):
+            nb = name.encode()
+            f.write(struct.pack("i", len(nb)))
+            f.write(nb)
+            f.write(struct.pack("i", len(dims_outer_to_inner)))
+            f.write(struct.pack(f"{len(dims_outer_to_inner)}i", *dims_outer_to_inner))
+            f.write(struct.pack("i", type_))
+            f.write(b"\0" * (-f.tell() % 16))
+            f.write(np.ascontiguousarray(payload).tobytes())
+
+        w = pkg.synth.make_model(cfg, wtype, seed=seed)
+        shape = {n: (rows, K) for n, _, rows, K in pkg.synth.tensor_list(cfg, wtype)}
+        dump("model.embed_tokens.weight", w["tok_embd"][0], [V, H], w["tok_embd"][1])
+        for i in range(cfg["n_layer"]):
+            p, hp = f"layers.{i}.", f"model.layers.{i}."
+            for k in ("attn_norm", "wdown", "wgate", "wup", "ffn_norm", "wk", "wo", "wq", "wv"):
+                t, arr = w[p + k]
+                dims = [H] if k.endswith("norm") else list(shape[p + k])
+                dump(hp + HF_NAME[k], t, dims, arr)
+        dump("model.norm.weight", 0, [H], w["out_norm"][1])
+        dump("lm_head.weight", w["lm_head"][0], [V, H], w["lm_head"][1])
+    return path
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--config", default="tiny")
+    ap.add_argument("--wtype", default="q4_k", choices=sorted(WT))
+    ap.add_argument("--max-len", type=int, default=256)
+    ap.add_argument("--out", required=True)
+    a = ap.parse_args()
+    pkg = ge.load_package()
+    cfg = pkg.synth.config(a.config, max_len=a.max_len)
+    write_model(a.out, cfg, WT[a.wtype])
+    print(a.out, os.path.getsize(a.out), "bytes")
