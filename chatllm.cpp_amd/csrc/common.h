@@ -50,26 +50,80 @@ __device__ __forceinline__ float    h2f(uint16_t h) { _Float16 v; __builtin_memc
 // rounds the product to f32 and then to fp16 (two roundings) -- they differ on ties (observed: 1 soft-max probability in ~10^4).
 __device__ __forceinline__ uint16_t f2h(float f)    { asm volatile("" : "+v"(f)); _Float16 v = (_Float16) f; uint16_t h; __builtin_memcpy(&h, &v, 2); return h; }
 
+// ---- cross-lane reductions on DPP (no LDS crossbar: a ds_bpermute costs ~100 cycles, a DPP move ~8) ------------------------
+// xor-1 / xor-2 inside quads, then mirror inside 8 and 16 lanes: after the four steps every lane of a 16-lane row holds the
+// row total; the four row totals are combined through SGPRs (v_readlane).  All call sites share these helpers, so the fp32
+// summation order is the same everywhere (fused and node-by-node paths stay bit-identical).
+#define DPP_QUAD_XOR1   0xB1    // quad_perm [1,0,3,2]
+#define DPP_QUAD_XOR2   0x4E    // quad_perm [2,3,0,1]
+#define DPP_HALF_MIRROR 0x141   // lane i <-> 7 - i inside each 8 lanes
+#define DPP_ROW_MIRROR  0x140   // lane i <-> 15 - i inside each 16 lanes
+template <int CTRL> __device__ __forceinline__ int   dpp_i(int v)   { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, true); }
+template <int CTRL> __device__ __forceinline__ float dpp_f(float v) { return __int_as_float(dpp_i<CTRL>(__float_as_int(v))); }
+template <int CTRL> __device__ __forceinline__ double dpp_d(double v) {
+    const long long b = __double_as_longlong(v);
+    const int lo = dpp_i<CTRL>((int) b), hi = dpp_i<CTRL>((int)(b >> 32));
+    return __longlong_as_double(((long long) hi << 32) | (unsigned int) lo);
+}
+template <int CTRL> __device__ __forceinline__ unsigned long long dpp_u64(unsigned long long v) {
+    const int lo = dpp_i<CTRL>((int) v), hi = dpp_i<CTRL>((int)(v >> 32));
+    return ((unsigned long long)(unsigned int) hi << 32) | (unsigned int) lo;
+}
+__device__ __forceinline__ float lane_f(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
+__device__ __forceinline__ double lane_d(double v, int l) {
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_readlane((int) b, l), hi = __builtin_amdgcn_readlane((int)(b >> 32), l);
+    return __longlong_as_double(((long long) hi << 32) | (unsigned int) lo);
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    v += dpp_f<DPP_QUAD_XOR1>(v); v += dpp_f<DPP_QUAD_XOR2>(v); v += dpp_f<DPP_HALF_MIRROR>(v); v += dpp_f<DPP_ROW_MIRROR>(v);
+    return (lane_f(v, 0) + lane_f(v, 16)) + (lane_f(v, 32) + lane_f(v, 48));
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-    return v;
+    v = fmaxf(v, dpp_f<DPP_QUAD_XOR1>(v)); v = fmaxf(v, dpp_f<DPP_QUAD_XOR2>(v)); v = fmaxf(v, dpp_f<DPP_HALF_MIRROR>(v)); v = fmaxf(v, dpp_f<DPP_ROW_MIRROR>(v));
+    return fmaxf(fmaxf(lane_f(v, 0), lane_f(v, 16)), fmaxf(lane_f(v, 32), lane_f(v, 48)));
 }
 __device__ __forceinline__ double wave_sum_d(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    v += dpp_d<DPP_QUAD_XOR1>(v); v += dpp_d<DPP_QUAD_XOR2>(v); v += dpp_d<DPP_HALF_MIRROR>(v); v += dpp_d<DPP_ROW_MIRROR>(v);
+    return (lane_d(v, 0) + lane_d(v, 16)) + (lane_d(v, 32) + lane_d(v, 48));
 }
 __device__ __forceinline__ int wave_sum_i(int v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    v += dpp_i<DPP_QUAD_XOR1>(v); v += dpp_i<DPP_QUAD_XOR2>(v); v += dpp_i<DPP_HALF_MIRROR>(v); v += dpp_i<DPP_ROW_MIRROR>(v);
+    return (__builtin_amdgcn_readlane(v, 0) + __builtin_amdgcn_readlane(v, 16)) + (__builtin_amdgcn_readlane(v, 32) + __builtin_amdgcn_readlane(v, 48));
 }
+__device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v) {
+    unsigned long long o;
+    o = dpp_u64<DPP_QUAD_XOR1>(v);   v = o > v ? o : v;
+    o = dpp_u64<DPP_QUAD_XOR2>(v);   v = o > v ? o : v;
+    o = dpp_u64<DPP_HALF_MIRROR>(v); v = o > v ? o : v;
+    o = dpp_u64<DPP_ROW_MIRROR>(v);  v = o > v ? o : v;
+    unsigned long long r[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) r[i] = ((unsigned long long)(unsigned int) __builtin_amdgcn_readlane((int)(v >> 32), 16 * i) << 32) | (unsigned int) __builtin_amdgcn_readlane((int) v, 16 * i);
+    const unsigned long long a = r[0] > r[1] ? r[0] : r[1], b = r[2] > r[3] ? r[2] : r[3];
+    return a > b ? a : b;
+}
+// per-thread part of RMS_NORM's sum of squares for a 256-thread partition (thread t owns i = t, t+256, ...), accumulated in
+// double in increasing i like the CPU loop (ops.cpp:3727-3730).  Loads are issued eight at a time so that their latencies
+// overlap; ONE definition shared by k_rms_norm and the fused GEMV prologue keeps the two bit-identical.
+__device__ __forceinline__ double rms_partial_sumsq_256(const float * __restrict__ x, int64_t n, int tid) {
+    double sum = 0.0;
+    int64_t i = tid;
+    for (; i + 7 * 256 < n; i += 8 * 256) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) v[u] = x[i + u * 256];
+#pragma unroll
+        for (int u = 0; u < 8; u++) sum += (double)(v[u] * v[u]);
+    }
+    for (; i < n; i += 256) { const float v = x[i]; sum += (double)(v * v); }
+    return sum;
+}
+
+// reductions inside groups of 8 consecutive lanes (one 32-element quant block = 8 lanes x 4 values)
+__device__ __forceinline__ float group8_max(float v) { v = fmaxf(v, dpp_f<DPP_QUAD_XOR1>(v)); v = fmaxf(v, dpp_f<DPP_QUAD_XOR2>(v)); return fmaxf(v, dpp_f<DPP_HALF_MIRROR>(v)); }
+__device__ __forceinline__ int   group8_sum_i(int v) { v += dpp_i<DPP_QUAD_XOR1>(v); v += dpp_i<DPP_QUAD_XOR2>(v); return v + dpp_i<DPP_HALF_MIRROR>(v); }
 __device__ __forceinline__ int dot4(uint32_t a, uint32_t b, int c) { return __builtin_amdgcn_sdot4((int) a, (int) b, c, false); }
 
 // cos/sin of a RoPE angle.  ONE definition shared by k_rope (ops.hip) and k_rope_kv (decode_fused.hip): whether the
@@ -139,9 +193,11 @@ int launch_mmq(hipStream_t st, int wtype, const tview & w, const void * act, siz
 int launch_mul_mat_f(hipStream_t st, int wtype, const tview & w, const tview & x, const tview & dst);
 int device_cu_count();
 int launch_mmvq_act(hipStream_t st, int wtype, const void * W, int64_t K, int64_t nrows, const void * act, float * dst, const float * bias, const float * resid);
+int launch_mmvq_fused(hipStream_t st, int wtype, const void * W, int64_t K, int64_t nrows, int pro, const float * px, const float * pw, float eps, int epi, float * dst, const float * bias, const float * resid);
 int launch_norm_quant(hipStream_t st, int kind, const float * x, const float * w, int64_t H, float eps, void * act);
 int launch_quant_row(hipStream_t st, int kind, const float * x, int64_t K, void * act);
 int launch_silu_mul_quant(hipStream_t st, int kind, const float * gu, int64_t F, void * act, float * g_out);
 int launch_rope_kv(hipStream_t st, float * qkv, const int32_t * pos_dev, int nh, int nkv, int hd, int mode, float freq_base, uint16_t * k_cache, uint16_t * v_cache, int64_t ML);
 int launch_attn_decode(hipStream_t st, const float * qkv, const int32_t * pos_dev, int nh, int nkv, int hd, const uint16_t * k_cache, const uint16_t * v_cache, int64_t ML, float * att);
+int launch_rope_kv_attn_decode(hipStream_t st, const float * qkv, const int32_t * pos_dev, int nh, int nkv, int hd, int mode, float freq_base, uint16_t * k_cache, uint16_t * v_cache, int64_t ML, float * att);
 int launch_argmax_advance(hipStream_t st, const float * logits, int n, int32_t * tok_dev, int32_t * pos_dev, int32_t * out_ring, int32_t * counter);

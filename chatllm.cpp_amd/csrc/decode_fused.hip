@@ -24,8 +24,7 @@ __global__ void __launch_bounds__(256) k_norm_quant(const float * __restrict__ x
     // the node-by-node paths produce the same bits
     __shared__ double part[4];
     const int tid = threadIdx.x, lane = tid & 63;
-    double sum = 0.0;
-    for (int64_t i = tid; i < H; i += 256) { const float v = x[i]; sum += (double)(v * v); }
+    double sum = rms_partial_sumsq_256(x, H, tid);
     sum = wave_sum_d(sum);
     if (lane == 0) part[tid >> 6] = sum;
     __syncthreads();
@@ -57,7 +56,7 @@ __global__ void __launch_bounds__(256) k_quant_row(const float * __restrict__ x,
     quant4_store<KIND>(act, K, e, threadIdx.x & 63, *(const f32x4 *)(x + e));
 }
 int launch_quant_row(hipStream_t st, int kind, const float * x, int64_t K, void * act) {
-    if (K % 256) FAIL(CLLM_E_UNSUPPORTED, "quant_row: K must be a multiple of 256");
+    if (K % kind) FAIL(CLLM_E_UNSUPPORTED, "quant_row: K must be a multiple of %d", kind);
     const unsigned grid = (unsigned)((K / 4 + 255) / 256);
     if (kind == 32) hipLaunchKernelGGL(k_quant_row<32>,  dim3(grid), dim3(256), 0, st, x, K, (char *) act);
     else            hipLaunchKernelGGL(k_quant_row<256>, dim3(grid), dim3(256), 0, st, x, K, (char *) act);
@@ -148,19 +147,59 @@ int launch_rope_kv(hipStream_t st, float * qkv, const int32_t * pos_dev, int nh,
 //       ggml_vec_soft_max_f32: groups of 8 through ggml_v_expf, f32 tree sum per group, total in double, expf tail
 //   ctx[d] = sum_i f16(V[d][i]) * f16r(p[i])
 // ---------------------------------------------------------------------------------------------------------------
+// ROPE = true: q and k arrive UN-rotated in qkv; every workgroup rotates its own q head and its group's k head, rounds
+// the new k / v to fp16 exactly as the cache write would, uses them straight from LDS for position `pos`, and the first
+// head of each GQA group stores them into the caches (so RoPE + SET_ROWS + CPY cost no launch of their own).
+static float * g_attn_dbg = nullptr;
+extern "C" __attribute__((visibility("default"))) void cllm_debug_set_attn_probs(float * dev_buf) { g_attn_dbg = dev_buf; }   // tools only
+
+template <bool ROPE>
 __global__ void __launch_bounds__(256) k_attn_decode(const float * __restrict__ qkv, const int32_t * __restrict__ pos_dev, int nh, int nkv, int hd,
-                                                     float scale, const uint16_t * __restrict__ k_cache, const uint16_t * __restrict__ v_cache,
-                                                     int64_t ML, float * __restrict__ att, float * __restrict__ dbg) {
-    extern __shared__ __attribute__((aligned(16))) float sm[];       // [hd] q (fp16-rounded) | [n_kv] scores / probabilities
+                                                     float scale, uint16_t * __restrict__ k_cache, uint16_t * __restrict__ v_cache,
+                                                     int64_t ML, float * __restrict__ att, float * __restrict__ dbg, int mode, float theta_scale) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];       // [hd] q (fp16-rounded) | [hd] new k | [hd] new v | [hd] cos/sin | [n_kv] scores
     __shared__ double red_d[1];
     __shared__ float  red_f[4];
-    const int h = blockIdx.x, g = h / (nh / nkv);
+    const int h = blockIdx.x, r2 = nh / nkv, g = h / r2;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int n_kv = pos_dev[0] + 1;
-    const int KD = nkv * hd;
-    float * qs = sm; float * sc = sm + hd;
-    for (int d = tid; d < hd; d += 256) qs[d] = h2f(f2h(qkv[h * hd + d]));
-    __syncthreads();
+    const int pos = pos_dev[0];
+    const int n_kv = pos + 1;
+    const int KD = nkv * hd, QD = nh * hd;
+    float * qs = sm; float * knew = sm + hd; float * vnew = sm + 2 * hd; float * cs = sm + 3 * hd; float * sc = sm + 4 * hd;
+    if (ROPE) {
+        const int half = hd / 2;
+        for (int i = tid; i < half; i += 256) {
+            float theta = (float) pos;
+            for (int k = 0; k < i; k++) theta *= theta_scale;
+            float c, s_;
+            rope_cos_sin(theta, &c, &s_);
+            cs[2*i] = c * 1.0f; cs[2*i + 1] = s_ * 1.0f;
+        }
+        __syncthreads();
+        const int off = mode == 0 ? 1 : half;
+        const float * qh = qkv + h * hd; const float * kh = qkv + QD + g * hd; const float * vh = qkv + QD + KD + g * hd;
+        for (int t = tid; t < 2 * half; t += 256) {
+            const int which = t / half, i = t % half;
+            const int ic = mode == 0 ? 2*i : i;
+            const float c = cs[2*i], s_ = cs[2*i + 1];
+            const float * x = which == 0 ? qh : kh;
+            const float x0 = x[ic], x1 = x[ic + off];
+            const float y0 = x0*c - x1*s_, y1 = x0*s_ + x1*c;
+            float * o = which == 0 ? qs : knew;
+            o[ic] = h2f(f2h(y0)); o[ic + off] = h2f(f2h(y1));         // q: src1 of K.Q is rounded to fp16; k: the cache is fp16
+        }
+        for (int d = tid; d < hd; d += 256) vnew[d] = h2f(f2h(vh[d]));
+        __syncthreads();
+        if (h % r2 == 0) {
+            for (int d = tid; d < hd; d += 256) {
+                k_cache[(int64_t) pos * KD + g * hd + d] = f2h(knew[d]);
+                v_cache[((int64_t) g * hd + d) * ML + pos] = f2h(vnew[d]);
+            }
+        }
+    } else {
+        for (int d = tid; d < hd; d += 256) qs[d] = h2f(f2h(qkv[h * hd + d]));
+        __syncthreads();
+    }
 
     // Lane grouping follows launch_T() in matmul_f.hip (G lanes per row, G*8 <= K, 8 <= G <= 64) so that the
     // fp32 summation order -- and therefore every bit of the result -- equals the unfused MUL_MAT nodes.
@@ -169,16 +208,22 @@ __global__ void __launch_bounds__(256) k_attn_decode(const float * __restrict__ 
         const int gl = lane % G, sub = lane / G, rpw = 64 / G;
         for (int i0 = wave * rpw + sub; i0 < n_kv; i0 += 4 * rpw) {
             const uint16_t * kr = k_cache + (int64_t) i0 * KD + g * hd;
+            const bool fresh = ROPE && i0 == pos;                         // the row that is being written right now: take it from LDS
             float acc = 0.0f;
             const int K8 = hd & ~7;
-            for (int d = K8 + gl; d < hd; d += G) acc = __builtin_fmaf(h2f(kr[d]), qs[d], acc);
+            for (int d = K8 + gl; d < hd; d += G) acc = __builtin_fmaf(fresh ? knew[d] : h2f(kr[d]), qs[d], acc);
             for (int d = gl * 8; d < K8; d += G * 8) {
-                const u32x4 r = *(const u32x4 *)(kr + d);
-                const uint32_t wv[4] = { r.x, r.y, r.z, r.w };
+                if (fresh) {
 #pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    acc = __builtin_fmaf(h2f((uint16_t)(wv[j] & 0xffff)), qs[d + 2*j], acc);
-                    acc = __builtin_fmaf(h2f((uint16_t)(wv[j] >> 16)), qs[d + 2*j + 1], acc);
+                    for (int j = 0; j < 8; j++) acc = __builtin_fmaf(knew[d + j], qs[d + j], acc);
+                } else {
+                    const u32x4 r = *(const u32x4 *)(kr + d);
+                    const uint32_t wv[4] = { r.x, r.y, r.z, r.w };
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        acc = __builtin_fmaf(h2f((uint16_t)(wv[j] & 0xffff)), qs[d + 2*j], acc);
+                        acc = __builtin_fmaf(h2f((uint16_t)(wv[j] >> 16)), qs[d + 2*j + 1], acc);
+                    }
                 }
             }
             for (int o = G / 2; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
@@ -220,42 +265,55 @@ __global__ void __launch_bounds__(256) k_attn_decode(const float * __restrict__ 
         const int gl = lane % G, sub = lane / G, rpw = 64 / G;
         for (int d0 = wave * rpw + sub; d0 < hd; d0 += 4 * rpw) {
             const uint16_t * vr = v_cache + ((int64_t) g * hd + d0) * ML;
+            const float vfresh = ROPE ? vnew[d0] : 0.0f;
             float acc = 0.0f;
             if (n_kv >= 8) {
                 const int n8 = n_kv & ~7;
-                for (int i = n8 + gl; i < n_kv; i += G) acc = __builtin_fmaf(h2f(vr[i]), sc[i], acc);
+                for (int i = n8 + gl; i < n_kv; i += G) acc = __builtin_fmaf((ROPE && i == pos) ? vfresh : h2f(vr[i]), sc[i], acc);
                 for (int i = gl * 8; i < n8; i += G * 8) {
                     const u32x4 r = *(const u32x4 *)(vr + i);
                     const uint32_t wv[4] = { r.x, r.y, r.z, r.w };
 #pragma unroll
                     for (int j = 0; j < 4; j++) {
-                        acc = __builtin_fmaf(h2f((uint16_t)(wv[j] & 0xffff)), sc[i + 2*j], acc);
-                        acc = __builtin_fmaf(h2f((uint16_t)(wv[j] >> 16)), sc[i + 2*j + 1], acc);
+                        const float v0 = (ROPE && i + 2*j == pos) ? vfresh : h2f((uint16_t)(wv[j] & 0xffff));
+                        const float v1 = (ROPE && i + 2*j + 1 == pos) ? vfresh : h2f((uint16_t)(wv[j] >> 16));
+                        acc = __builtin_fmaf(v0, sc[i + 2*j], acc);
+                        acc = __builtin_fmaf(v1, sc[i + 2*j + 1], acc);
                     }
                 }
             } else {
-                for (int i = gl; i < n_kv; i += G) acc = __builtin_fmaf(h2f(vr[i]), sc[i], acc);   // the scalar kernel of matmul_f.hip (K < 8)
+                for (int i = gl; i < n_kv; i += G) acc = __builtin_fmaf((ROPE && i == pos) ? vfresh : h2f(vr[i]), sc[i], acc);   // the scalar kernel of matmul_f.hip (K < 8)
             }
             for (int o = G / 2; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
             if (gl == 0) att[h * hd + d0] = acc;
         }
     }
 }
-static float * g_attn_dbg = nullptr;
-extern "C" __attribute__((visibility("default"))) void cllm_debug_set_attn_probs(float * dev_buf) { g_attn_dbg = dev_buf; }   // tools only
-
-int launch_attn_decode(hipStream_t st, const float * qkv, const int32_t * pos_dev, int nh, int nkv, int hd, const uint16_t * k_cache,
-                       const uint16_t * v_cache, int64_t ML, float * att) {
+static int attn_launch(hipStream_t st, bool rope, const float * qkv, const int32_t * pos_dev, int nh, int nkv, int hd, uint16_t * k_cache, uint16_t * v_cache,
+                       int64_t ML, float * att, int mode, float freq_base) {
     if (hd % 8 || (ML % 8) || nh % nkv) FAIL(CLLM_E_UNSUPPORTED, "attn_decode: head_dim and max_len must be multiples of 8");
-    const size_t lds = (size_t)(hd + ML) * 4;
+    const size_t lds = (size_t)(4 * hd + ML) * 4;
     if (lds > 150 * 1024) FAIL(CLLM_E_UNSUPPORTED, "attn_decode: max_len %lld does not fit LDS", (long long) ML);
-    static bool attr = false;
-    if (lds > 48 * 1024 && !attr) { HIP_TRY(hipFuncSetAttribute((const void *) k_attn_decode, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024)); attr = true; }
-    hipLaunchKernelGGL(k_attn_decode, dim3(nh), dim3(256), lds, st, qkv, pos_dev, nh, nkv, hd, 1.0f / sqrtf((float) hd), k_cache, v_cache, ML, att, g_attn_dbg);
+    static bool attr0 = false, attr1 = false;
+    if (lds > 48 * 1024) {
+        if (!rope && !attr0) { HIP_TRY(hipFuncSetAttribute((const void *) k_attn_decode<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024)); attr0 = true; }
+        if (rope && !attr1)  { HIP_TRY(hipFuncSetAttribute((const void *) k_attn_decode<true>,  hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024)); attr1 = true; }
+    }
+    const float scale = 1.0f / sqrtf((float) hd), theta_scale = powf(freq_base, -2.0f / hd);
+    if (rope) hipLaunchKernelGGL(k_attn_decode<true>,  dim3(nh), dim3(256), lds, st, qkv, pos_dev, nh, nkv, hd, scale, k_cache, v_cache, ML, att, g_attn_dbg, mode, theta_scale);
+    else      hipLaunchKernelGGL(k_attn_decode<false>, dim3(nh), dim3(256), lds, st, qkv, pos_dev, nh, nkv, hd, scale, k_cache, v_cache, ML, att, g_attn_dbg, mode, theta_scale);
     LAUNCH_CHECK();
     return CLLM_OK;
 }
-
+int launch_attn_decode(hipStream_t st, const float * qkv, const int32_t * pos_dev, int nh, int nkv, int hd, const uint16_t * k_cache,
+                       const uint16_t * v_cache, int64_t ML, float * att) {
+    return attn_launch(st, false, qkv, pos_dev, nh, nkv, hd, (uint16_t *) k_cache, (uint16_t *) v_cache, ML, att, 0, 10000.0f);
+}
+// RoPE + KV-cache write + attention in one launch (qkv holds the UN-rotated projections)
+int launch_rope_kv_attn_decode(hipStream_t st, const float * qkv, const int32_t * pos_dev, int nh, int nkv, int hd, int mode, float freq_base,
+                               uint16_t * k_cache, uint16_t * v_cache, int64_t ML, float * att) {
+    return attn_launch(st, true, qkv, pos_dev, nh, nkv, hd, k_cache, v_cache, ML, att, mode, freq_base);
+}
 extern "C" int cllm_op_attn_decode(void * stream, const float * q, const int32_t * pos_dev, int n_head, int n_kv_head, int head_dim,
                                    const void * k_cache, const void * v_cache, int64_t max_len, float * out) {
     if (!q || !pos_dev || !k_cache || !v_cache || !out || n_head <= 0 || n_kv_head <= 0 || head_dim <= 0) FAIL(CLLM_E_INVALID, "attn_decode: arguments");

@@ -383,23 +383,22 @@ static int decode_step_fused(cllm_llama * m, bool sample) {
         cllm_tensor E = T(m->tok_embd.type, m->tok_embd.data, H, V), ids = T(CLLM_TYPE_I32, m->tokens_dev, 1), X = T(CLLM_TYPE_F32, m->x, H, 1);
         TRY(cllm_op_get_rows(st, &E, &ids, &X));
     }
+    // 6 launches per layer: [norm+quant+qkv GEMV(+bias)] [rope+kv-write+attention] [quant+o GEMV+residual]
+    //                       [norm+quant+gate|up GEMV+silu*up] [quant] [down GEMV+residual]
     for (int il = 0; il < c.n_layer; il++) {
         llama_layer & L = m->layers[il];
-        TRY(launch_norm_quant(st, kind_of(L.wqkv.type), m->x, (const float *) L.attn_norm.data, H, c.rms_eps, m->wdata));
-        TRY(launch_mmvq_act(st, L.wqkv.type, L.wqkv.data, H, QD + 2*KD, m->wdata, m->qkv, c.qkv_bias ? (const float *) L.bqkv.data : nullptr, nullptr));
-        TRY(launch_rope_kv(st, m->qkv, m->pos_dev, m->nh, m->nkv, (int) hd, c.rope_mode, c.rope_theta, L.k_cache, L.v_cache, ML));
-        TRY(launch_attn_decode(st, m->qkv, m->pos_dev, m->nh, m->nkv, (int) hd, L.k_cache, L.v_cache, ML, m->att));
-        TRY(launch_quant_row(st, kind_of(L.wo.type), m->att, QD, m->wdata));
-        if (!tp) TRY(launch_mmvq_act(st, L.wo.type, L.wo.data, QD, H, m->wdata, m->x, nullptr, m->x));          // x = o + x
+        TRY(launch_mmvq_fused(st, L.wqkv.type, L.wqkv.data, H, QD + 2*KD, 1, m->x, (const float *) L.attn_norm.data, c.rms_eps, 0, m->qkv,
+                              c.qkv_bias ? (const float *) L.bqkv.data : nullptr, nullptr));
+        TRY(launch_rope_kv_attn_decode(st, m->qkv, m->pos_dev, m->nh, m->nkv, (int) hd, c.rope_mode, c.rope_theta, L.k_cache, L.v_cache, ML, m->att));
+        if (!tp) TRY(launch_mmvq_fused(st, L.wo.type, L.wo.data, QD, H, 2, m->att, nullptr, 0.0f, 0, m->x, nullptr, m->x));          // x = o + x
         else {
-            TRY(launch_mmvq_act(st, L.wo.type, L.wo.data, QD, H, m->wdata, m->o, nullptr, nullptr));
+            TRY(launch_mmvq_fused(st, L.wo.type, L.wo.data, QD, H, 2, m->att, nullptr, 0.0f, 0, m->o, nullptr, nullptr));
             m->allreduce(m->allreduce_user, st, m->o, H);
             cllm_tensor O = T(CLLM_TYPE_F32, m->o, H), X = T(CLLM_TYPE_F32, m->x, H);
             TRY(cllm_op_add(st, &O, &X, &X));
         }
-        TRY(launch_norm_quant(st, kind_of(L.wgu.type), m->x, (const float *) L.ffn_norm.data, H, c.rms_eps, m->wdata));
-        TRY(launch_mmvq_act(st, L.wgu.type, L.wgu.data, H, 2*F, m->wdata, m->gu, nullptr, nullptr));
-        TRY(launch_silu_mul_quant(st, kind_of(L.wdown.type), m->gu, F, m->wdata, nullptr));
+        TRY(launch_mmvq_fused(st, L.wgu.type, L.wgu.data, H, F, 1, m->x, (const float *) L.ffn_norm.data, c.rms_eps, 1, m->g, nullptr, nullptr));
+        TRY(launch_quant_row(st, kind_of(L.wdown.type), m->g, F, m->wdata));
         if (!tp) TRY(launch_mmvq_act(st, L.wdown.type, L.wdown.data, F, H, m->wdata, m->x, nullptr, m->x));
         else {
             TRY(launch_mmvq_act(st, L.wdown.type, L.wdown.data, F, H, m->wdata, m->o, nullptr, nullptr));
@@ -408,8 +407,7 @@ static int decode_step_fused(cllm_llama * m, bool sample) {
             TRY(cllm_op_add(st, &O, &X, &X));
         }
     }
-    TRY(launch_norm_quant(st, kind_of(m->lm_head.type), m->x, (const float *) m->out_norm.data, H, c.rms_eps, m->wdata));
-    TRY(launch_mmvq_act(st, m->lm_head.type, m->lm_head.data, H, V, m->wdata, m->logits, nullptr, nullptr));
+    TRY(launch_mmvq_fused(st, m->lm_head.type, m->lm_head.data, H, V, 1, m->x, (const float *) m->out_norm.data, c.rms_eps, 0, m->logits, nullptr, nullptr));
     if (sample) TRY(launch_argmax_advance(st, m->logits, (int) V, m->tokens_dev, m->pos_dev, m->out_ring, m->counter_dev));
     return CLLM_OK;
 }

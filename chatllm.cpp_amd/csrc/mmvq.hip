@@ -17,9 +17,11 @@
 //          misaligned dwordx4 directly), a wave streams 64 consecutive blocks per step.
 // One wave owns one weight row at a time; rows are dealt round-robin to the waves of the grid.
 #include "common.h"
+#include "quant_dev.h"
 
 static int g_mmvq_wg = 256;      // threads per workgroup (tunable: CLLM_MMVQ_WG)
 static int g_mmvq_wgs_per_cu = 8; // grid cap (tunable: CLLM_MMVQ_OCC)
+static int g_mmvq_fused_wg = 1024, g_mmvq_fused_occ = 2;   // fused-prologue launches (tunable: CLLM_MMVQ_FWG, CLLM_MMVQ_FOCC)
 
 // kernel arguments; `ids` != NULL turns the launch into MUL_MAT_ID: blockIdx.y enumerates (slot u, token t) pairs,
 // each with its own expert matrix (ggml-cpu.c:1432-1678).
@@ -31,6 +33,13 @@ struct mmvq_args {
     int n_used, b_ne1, n_as; int64_t dst_s1, dst_s2; // dst strides (floats) over (u, t)
     const float * bias;                            // optional fused ADD of a per-row bias   (Linear::forward, src/layers.cpp:2111-2129)
     const float * resid;                           // optional fused ADD of the residual     (LMBlock1Forward::forward :2740,:2758), indexed like dst
+    // prologue: how the quantized activation row gets into LDS
+    //   0: copied from the act row in global memory (written by the quantize kernel)
+    //   1: RMS_NORM(px) * pw, then quantized, computed by every workgroup itself (decode: saves a launch per mat-vec)
+    //   2: px quantized by every workgroup itself
+    int pro; const float * px; const float * pw; float eps;
+    // epilogue 1: rows r and r + nrows are the gate / up projections; dst[r] = silu(gate_r) * up_r   (BaseMLP::forward)
+    int epi;
 };
 
 __device__ __forceinline__ bool mmvq_select(const mmvq_args & a, const char *& W, const char *& act, float *& dst) {
@@ -46,7 +55,7 @@ __device__ __forceinline__ bool mmvq_select(const mmvq_args & a, const char *& W
     return true;
 }
 
-// ---- LDS staging of NC activation rows ---------------------------------------------------------------
+// ---- LDS activation row(s): staged from global, or produced in place (fused RMS_NORM / quantization) -----------------
 __device__ __forceinline__ void stage_act(char * lds, const char * __restrict__ act, size_t act_stride, size_t row_bytes, int nc) {
     const int n16 = (int)(row_bytes / 16);
     for (int c = 0; c < nc; c++) {
@@ -56,16 +65,50 @@ __device__ __forceinline__ void stage_act(char * lds, const char * __restrict__ 
     }
 }
 
+template <int KIND>
+__device__ __forceinline__ void build_act(char * lds, const mmvq_args & a, const char * act, int64_t K, size_t rb, int nc) {
+    if (a.pro == 0) { stage_act(lds, act, a.act_stride, rb, nc); return; }
+    const int tid = threadIdx.x, lane = tid & 63;
+    float scale = 1.0f;
+    if (a.pro == 1) {
+        // sum of squares: the partition and reduction tree of k_rms_norm (ops.hip) -- launched with 256 threads -- so that
+        // fused and node-by-node paths agree to the bit
+        // (only the first 256 threads take part: larger workgroups share one prologue between more waves)
+        __shared__ double part[4];
+        if (tid < 256) {
+            double sum = rms_partial_sumsq_256(a.px, K, tid);
+            sum = wave_sum_d(sum);
+            if (lane == 0) part[tid >> 6] = sum;
+        }
+        __syncthreads();
+        double sum;
+        sum = part[0] + part[1] + part[2] + part[3];
+        const float mean = (float)(sum / (double) K);
+        scale = 1.0f / sqrtf(mean + a.eps);
+    }
+    for (int64_t e = (int64_t) tid * 4; e < K; e += (int64_t) blockDim.x * 4) {       // K % 256 == 0: whole waves stay together
+        f32x4 v = *(const f32x4 *)(a.px + e);
+        if (a.pro == 1) {
+            const f32x4 g = *(const f32x4 *)(a.pw + e);
+            v.x = (v.x * scale) * g.x; v.y = (v.y * scale) * g.y; v.z = (v.z * scale) * g.z; v.w = (v.w * scale) * g.w;
+        }
+        quant4_store<KIND>(lds, K, e, lane, v);
+    }
+}
+
+__device__ __forceinline__ float silu_gate(float x, bool body) { return body ? x / (1.0f + ggml_expf_poly(0.0f - x)) : x / (1.0f + libm_expf(-x)); }
+
 // ---- Q4_K -----------------------------------------------------------------------------------------------
 template <int NC>
-__global__ void __launch_bounds__(512) k_mmvq_q4_K(const mmvq_args a) {
+__global__ void __launch_bounds__(1024) k_mmvq_q4_K(const mmvq_args a) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
+    constexpr int KB = 256;
     const char * W; const char * act; float * dst;
     if (!mmvq_select(a, W, act, dst)) return;
-    const int64_t nb01 = a.nb01, nrows = a.nrows, dst_cs = a.dst_cs; const int nblk = a.nblk; const size_t act_stride = a.act_stride;
+    const int64_t nb01 = a.nb01, nrows = a.nrows, dst_cs = a.dst_cs; const int nblk = a.nblk;
     const int64_t K = (int64_t) nblk * 256;
     const size_t  rb = act_row_bytes(K, 256);
-    stage_act(lds, act, act_stride, rb, NC);
+    build_act<KB>(lds, a, act, K, rb, NC);
     __syncthreads();
 
     const int lane = threadIdx.x & 63;
@@ -81,12 +124,11 @@ __global__ void __launch_bounds__(512) k_mmvq_q4_K(const mmvq_args a) {
     const bool hi  = j >= 4;
     const int a_off = 64 * (j >> 1) + 16 * (j & 1);     // activation bytes for the low-nibble half; +32 for the high half
 
-    for (int64_t row = wave0; row < nrows; row += nwaves) {
+    auto row_dot = [&](int64_t row, float (&out)[NC]) {
         const char * wr = W + row * nb01;
         float accd[NC], accm[NC];
 #pragma unroll
         for (int c = 0; c < NC; c++) { accd[c] = 0.0f; accm[c] = 0.0f; }
-
         for (int b0 = 0; b0 < nblk; b0 += 8) {
             const int b = b0 + grp;
             if (b < nblk) {
@@ -121,12 +163,26 @@ __global__ void __launch_bounds__(512) k_mmvq_q4_K(const mmvq_args a) {
             }
         }
 #pragma unroll
-        for (int c = 0; c < NC; c++) {
-            float r = wave_sum(accd[c]) - wave_sum(accm[c]);
-            if (lane == 0) {
-                if (a.bias)  r = r + a.bias[row];
-                if (a.resid) r = r + a.resid[row + c * dst_cs];
-                dst[row + c * dst_cs] = r;
+        for (int c = 0; c < NC; c++) out[c] = wave_sum(accd[c]) - wave_sum(accm[c]);
+    };
+
+    for (int64_t row = wave0; row < nrows; row += nwaves) {
+        float r[NC];
+        row_dot(row, r);
+        if (a.epi == 1) {                                  // gate row -> silu, times the matching up row
+            float u[NC];
+            row_dot(row + nrows, u);
+            const bool body = row < (nrows & ~(int64_t) 7);
+#pragma unroll
+            for (int c = 0; c < NC; c++) r[c] = silu_gate(r[c], body) * u[c];
+        }
+        if (lane == 0) {
+#pragma unroll
+            for (int c = 0; c < NC; c++) {
+                float v = r[c];
+                if (a.bias)  v = v + a.bias[row];
+                if (a.resid) v = v + a.resid[row + c * dst_cs];
+                dst[row + c * dst_cs] = v;
             }
         }
     }
@@ -136,14 +192,15 @@ __global__ void __launch_bounds__(512) k_mmvq_q4_K(const mmvq_args a) {
 struct __attribute__((packed, aligned(2))) u16x8_u2 { uint32_t x, y, z, w; };
 
 template <int NC, bool IS_Q8>
-__global__ void __launch_bounds__(512) k_mmvq_q32(const mmvq_args a) {
+__global__ void __launch_bounds__(1024) k_mmvq_q32(const mmvq_args a) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
+    constexpr int KB = 32;
     const char * W; const char * act; float * dst;
     if (!mmvq_select(a, W, act, dst)) return;
-    const int64_t nb01 = a.nb01, nrows = a.nrows, dst_cs = a.dst_cs; const int nblk = a.nblk; const size_t act_stride = a.act_stride;
+    const int64_t nb01 = a.nb01, nrows = a.nrows, dst_cs = a.dst_cs; const int nblk = a.nblk;
     const int64_t K = (int64_t) nblk * 32;
     const size_t  rb = act_row_bytes(K, 32);
-    stage_act(lds, act, act_stride, rb, NC);
+    build_act<KB>(lds, a, act, K, rb, NC);
     __syncthreads();
 
     constexpr int BS = IS_Q8 ? 34 : 18;
@@ -152,12 +209,11 @@ __global__ void __launch_bounds__(512) k_mmvq_q32(const mmvq_args a) {
     const int64_t wave0 = (int64_t) blockIdx.x * waves_per_wg + (threadIdx.x >> 6);
     const int64_t nwaves = (int64_t) gridDim.x * waves_per_wg;
 
-    for (int64_t row = wave0; row < nrows; row += nwaves) {
+    auto row_dot = [&](int64_t row, float (&out)[NC]) {
         const char * wr = W + row * nb01;
         float acc[NC];
 #pragma unroll
         for (int c = 0; c < NC; c++) acc[c] = 0.0f;
-
         for (int b0 = 0; b0 < nblk; b0 += 64) {
             const int b = b0 + lane;
             if (b < nblk) {
@@ -195,12 +251,26 @@ __global__ void __launch_bounds__(512) k_mmvq_q32(const mmvq_args a) {
             }
         }
 #pragma unroll
-        for (int c = 0; c < NC; c++) {
-            float r = wave_sum(acc[c]);
-            if (lane == 0) {
-                if (a.bias)  r = r + a.bias[row];
-                if (a.resid) r = r + a.resid[row + c * dst_cs];
-                dst[row + c * dst_cs] = r;
+        for (int c = 0; c < NC; c++) out[c] = wave_sum(acc[c]);
+    };
+
+    for (int64_t row = wave0; row < nrows; row += nwaves) {
+        float r[NC];
+        row_dot(row, r);
+        if (a.epi == 1) {
+            float u[NC];
+            row_dot(row + nrows, u);
+            const bool body = row < (nrows & ~(int64_t) 7);
+#pragma unroll
+            for (int c = 0; c < NC; c++) r[c] = silu_gate(r[c], body) * u[c];
+        }
+        if (lane == 0) {
+#pragma unroll
+            for (int c = 0; c < NC; c++) {
+                float v = r[c];
+                if (a.bias)  v = v + a.bias[row];
+                if (a.resid) v = v + a.resid[row + c * dst_cs];
+                dst[row + c * dst_cs] = v;
             }
         }
     }
@@ -270,14 +340,18 @@ static void mmvq_tunables() {
     done = true;
     if (const char * e = getenv("CLLM_MMVQ_WG"))  { int v = atoi(e); if (v == 64 || v == 128 || v == 256 || v == 512) g_mmvq_wg = v; }
     if (const char * e = getenv("CLLM_MMVQ_OCC")) { int v = atoi(e); if (v >= 1 && v <= 32) g_mmvq_wgs_per_cu = v; }
+    if (const char * e = getenv("CLLM_MMVQ_FWG"))  { int v = atoi(e); if (v == 256 || v == 512 || v == 1024) g_mmvq_fused_wg = v; }
+    if (const char * e = getenv("CLLM_MMVQ_FOCC")) { int v = atoi(e); if (v >= 1 && v <= 32) g_mmvq_fused_occ = v; }
+    if (const char * e = getenv("CLLM_MMVQ_WG"))   { int v = atoi(e); if (v == 1024) g_mmvq_wg = v; }
 }
 
 template <typename KernelT>
 static int launch_one(hipStream_t st, KernelT kern, size_t lds_bytes, const mmvq_args & a, int grid_y) {
     mmvq_tunables();
-    const int wg = g_mmvq_wg, wpw = wg / 64;
+    // in-kernel prologues are redundant work per workgroup: use few, fat workgroups (16 waves share one prologue)
+    const int wg = a.pro != 0 ? g_mmvq_fused_wg : g_mmvq_wg, wpw = wg / 64;
     int64_t grid = (a.nrows + wpw - 1) / wpw;
-    int64_t cap = (int64_t) device_cu_count() * g_mmvq_wgs_per_cu / grid_y;
+    int64_t cap = (int64_t) device_cu_count() * (a.pro != 0 ? g_mmvq_fused_occ : g_mmvq_wgs_per_cu) / grid_y;
     if (cap < 1) cap = 1;
     if (grid > cap) grid = cap;
     if (lds_bytes > 64 * 1024) HIP_TRY(hipFuncSetAttribute((const void *) kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -346,5 +420,21 @@ int launch_mmvq_act(hipStream_t st, int wtype, const void * W, int64_t K, int64_
     mmvq_args a = {};
     a.W = (const char *) W; a.nb01 = (int64_t) cllm_row_size(wtype, K); a.nb02 = 0; a.nrows = nrows; a.nblk = (int)(K / kb);
     a.act = (const char *) act; a.act_stride = rb; a.dst = dst; a.dst_cs = 0; a.bias = bias; a.resid = resid;
+    return mmvq_dispatch(st, wtype, 1, rb, a, 1);
+}
+
+// decode mat-vec with the activation produced inside the kernel:
+//   pro 1: act = quantize(rms_norm(px) * pw)     pro 2: act = quantize(px)
+//   epi 1: W holds 2*nrows rows (gate | up), dst[r] = silu(W[r].act) * (W[r + nrows].act)
+int launch_mmvq_fused(hipStream_t st, int wtype, const void * W, int64_t K, int64_t nrows, int pro, const float * px, const float * pw, float eps,
+                      int epi, float * dst, const float * bias, const float * resid) {
+    const int kb = wtype == CLLM_TYPE_Q4_K ? 256 : 32;
+    if (K % 256) FAIL(CLLM_E_UNSUPPORTED, "mmvq_fused: K must be a multiple of 256");
+    const size_t rb = act_row_bytes(K, kb);
+    if (rb > 160 * 1024) FAIL(CLLM_E_UNSUPPORTED, "mmvq_fused: K=%lld does not fit LDS", (long long) K);
+    mmvq_args a = {};
+    a.W = (const char *) W; a.nb01 = (int64_t) cllm_row_size(wtype, K); a.nrows = nrows; a.nblk = (int)(K / kb);
+    a.act_stride = rb; a.dst = dst; a.bias = bias; a.resid = resid;
+    a.pro = pro; a.px = px; a.pw = pw; a.eps = eps; a.epi = epi;
     return mmvq_dispatch(st, wtype, 1, rb, a, 1);
 }

@@ -17,8 +17,7 @@ __global__ void __launch_bounds__(256) k_rms_norm(tview s, tview d, const float 
     const float * x = (const float *)(s.data + i1*s.nb[1] + i2*s.nb[2] + i3*s.nb[3]);
     float *       y = (float *)(d.data + i1*d.nb[1] + i2*d.nb[2] + i3*d.nb[3]);
     const int64_t n = s.ne[0];
-    double sum = 0.0;
-    for (int64_t i = threadIdx.x; i < n; i += blockDim.x) { const float v = x[i]; sum += (double)(v * v); }
+    double sum = rms_partial_sumsq_256(x, n, threadIdx.x);
     sum = wave_sum_d(sum);
     __shared__ double part[4];
     if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = sum;

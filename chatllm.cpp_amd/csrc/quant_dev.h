@@ -13,16 +13,11 @@ __device__ __forceinline__ uint32_t pack4(int q0, int q1, int q2, int q3) {
 // f32) and *s (sum of the block's int8) are valid on every lane of the 8-lane group.
 __device__ __forceinline__ uint32_t quant4_q8_0(f32x4 v, float * d_out, int * s_out) {
     float amax = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
-    amax = fmaxf(amax, __shfl_xor(amax, 1, 64));
-    amax = fmaxf(amax, __shfl_xor(amax, 2, 64));
-    amax = fmaxf(amax, __shfl_xor(amax, 4, 64));
+    amax = group8_max(amax);
     const float d  = amax / 127.f;
     const float id = (amax != 0.0f) ? 127.f / amax : 0.0f;
     const int q0 = (int) rintf(v.x * id), q1 = (int) rintf(v.y * id), q2 = (int) rintf(v.z * id), q3 = (int) rintf(v.w * id);
-    int s = q0 + q1 + q2 + q3;
-    s += __shfl_xor(s, 1, 64);
-    s += __shfl_xor(s, 2, 64);
-    s += __shfl_xor(s, 4, 64);
+    const int s = group8_sum_i(q0 + q1 + q2 + q3);
     *d_out = h2f(f2h(d));              // the CPU stores d as fp16 and reads it back for the dot product
     *s_out = s;
     return pack4(q0, q1, q2, q3);
@@ -43,15 +38,11 @@ __device__ __forceinline__ uint32_t quant4_q8_K(f32x4 v, int lane, float * d_out
         const unsigned long long k2 = ((unsigned long long) __float_as_uint(ax[i]) << 32) | (unsigned long long)(0xffffffffu - (uint32_t)(lane * 4 + i));
         key = k2 > key ? k2 : key;
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        const unsigned long long other = __shfl_xor(key, o, 64);
-        key = other > key ? other : key;
-    }
+    key = wave_max_u64(key);
     const float amax = __uint_as_float((uint32_t)(key >> 32));
-    const int   imax = (int)(0xffffffffu - (uint32_t) key);
+    const int   imax = (int)(0xffffffffu - (uint32_t) key);              // wave-uniform
     const float mine = (imax & 3) == 0 ? v.x : (imax & 3) == 1 ? v.y : (imax & 3) == 2 ? v.z : v.w;
-    const float maxv = __shfl(mine, imax >> 2, 64);
+    const float maxv = lane_f(mine, __builtin_amdgcn_readfirstlane(imax >> 2));
     int q0 = 0, q1 = 0, q2 = 0, q3 = 0;
     float d = 0.0f;
     if (amax != 0.0f) {
@@ -62,10 +53,7 @@ __device__ __forceinline__ uint32_t quant4_q8_K(f32x4 v, int lane, float * d_out
         q3 = min(127, nearest_int_dev(iscale * v.w));
         d = 1 / iscale;
     }
-    int s = q0 + q1 + q2 + q3;
-    s += __shfl_xor(s, 1, 64);
-    s += __shfl_xor(s, 2, 64);
-    s += __shfl_xor(s, 4, 64);
+    const int s = group8_sum_i(q0 + q1 + q2 + q3);
     *d_out = d;
     *s_out = s;
     return pack4(q0, q1, q2, q3);
