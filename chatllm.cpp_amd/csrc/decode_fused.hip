@@ -205,29 +205,67 @@ __global__ void __launch_bounds__(256) k_attn_decode(const float * __restrict__ 
     // fp32 summation order -- and therefore every bit of the result -- equals the unfused MUL_MAT nodes.
     int G = 64; while (G > 8 && G * 8 > hd) G >>= 1;
     {
-        const int gl = lane % G, sub = lane / G, rpw = 64 / G;
-        for (int i0 = wave * rpw + sub; i0 < n_kv; i0 += 4 * rpw) {
-            const uint16_t * kr = k_cache + (int64_t) i0 * KD + g * hd;
-            const bool fresh = ROPE && i0 == pos;                         // the row that is being written right now: take it from LDS
-            float acc = 0.0f;
-            const int K8 = hd & ~7;
-            for (int d = K8 + gl; d < hd; d += G) acc = __builtin_fmaf(fresh ? knew[d] : h2f(kr[d]), qs[d], acc);
-            for (int d = gl * 8; d < K8; d += G * 8) {
-                if (fresh) {
+        // U cache rows per lane group are fetched before any of them is consumed (their HBM/L2 latencies overlap); the
+        // arithmetic of each row is unchanged
+        constexpr int U = 4;
+        const int gl = lane % G, sub = lane / G, rpw = 64 / G, stride = 4 * rpw;
+        const int K8 = hd & ~7;
+        const bool one_chunk = (K8 == hd) && (G * 8 == hd);                     // head_dim 64/128/256...: exactly one 16-byte chunk per lane
+        for (int ib = wave * rpw + sub; ib < n_kv; ib += U * stride) {
+            if (one_chunk) {
+                u32x4 r[U]; bool ok[U], fresh[U];
 #pragma unroll
-                    for (int j = 0; j < 8; j++) acc = __builtin_fmaf(knew[d + j], qs[d + j], acc);
-                } else {
-                    const u32x4 r = *(const u32x4 *)(kr + d);
-                    const uint32_t wv[4] = { r.x, r.y, r.z, r.w };
+                for (int u = 0; u < U; u++) {
+                    const int i0 = ib + u * stride;
+                    ok[u] = i0 < n_kv; fresh[u] = ROPE && i0 == pos;
+                    r[u] = u32x4{0, 0, 0, 0};
+                    if (ok[u] && !fresh[u]) r[u] = *(const u32x4 *)(k_cache + (int64_t) i0 * KD + g * hd + gl * 8);
+                }
 #pragma unroll
-                    for (int j = 0; j < 4; j++) {
-                        acc = __builtin_fmaf(h2f((uint16_t)(wv[j] & 0xffff)), qs[d + 2*j], acc);
-                        acc = __builtin_fmaf(h2f((uint16_t)(wv[j] >> 16)), qs[d + 2*j + 1], acc);
+                for (int u = 0; u < U; u++) {
+                    if (!ok[u]) continue;                                         // whole lane groups drop out together
+                    const int d = gl * 8;
+                    float acc = 0.0f;
+                    if (fresh[u]) {
+#pragma unroll
+                        for (int j = 0; j < 8; j++) acc = __builtin_fmaf(knew[d + j], qs[d + j], acc);
+                    } else {
+                        const uint32_t wv[4] = { r[u].x, r[u].y, r[u].z, r[u].w };
+#pragma unroll
+                        for (int j = 0; j < 4; j++) {
+                            acc = __builtin_fmaf(h2f((uint16_t)(wv[j] & 0xffff)), qs[d + 2*j], acc);
+                            acc = __builtin_fmaf(h2f((uint16_t)(wv[j] >> 16)), qs[d + 2*j + 1], acc);
+                        }
                     }
+                    for (int o = G / 2; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+                    if (gl == 0) sc[ib + u * stride] = acc * scale;            // the SCALE node
+                }
+            } else {
+                for (int u = 0; u < U; u++) {
+                    const int i0 = ib + u * stride;
+                    if (i0 >= n_kv) break;
+                    const uint16_t * kr = k_cache + (int64_t) i0 * KD + g * hd;
+                    const bool fr = ROPE && i0 == pos;
+                    float acc = 0.0f;
+                    for (int d = K8 + gl; d < hd; d += G) acc = __builtin_fmaf(fr ? knew[d] : h2f(kr[d]), qs[d], acc);
+                    for (int d = gl * 8; d < K8; d += G * 8) {
+                        if (fr) {
+#pragma unroll
+                            for (int j = 0; j < 8; j++) acc = __builtin_fmaf(knew[d + j], qs[d + j], acc);
+                        } else {
+                            const u32x4 r = *(const u32x4 *)(kr + d);
+                            const uint32_t wv[4] = { r.x, r.y, r.z, r.w };
+#pragma unroll
+                            for (int j = 0; j < 4; j++) {
+                                acc = __builtin_fmaf(h2f((uint16_t)(wv[j] & 0xffff)), qs[d + 2*j], acc);
+                                acc = __builtin_fmaf(h2f((uint16_t)(wv[j] >> 16)), qs[d + 2*j + 1], acc);
+                            }
+                        }
+                    }
+                    for (int o = G / 2; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+                    if (gl == 0) sc[i0] = acc * scale;
                 }
             }
-            for (int o = G / 2; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
-            if (gl == 0) sc[i0] = acc * scale;                           // the SCALE node
         }
     }
     __syncthreads();
@@ -262,33 +300,55 @@ __global__ void __launch_bounds__(256) k_attn_decode(const float * __restrict__ 
     // ---- ctx = V . P ----
     G = 64; while (G > 8 && G * 8 > n_kv) G >>= 1;
     {
-        const int gl = lane % G, sub = lane / G, rpw = 64 / G;
-        for (int d0 = wave * rpw + sub; d0 < hd; d0 += 4 * rpw) {
-            const uint16_t * vr = v_cache + ((int64_t) g * hd + d0) * ML;
-            const float vfresh = ROPE ? vnew[d0] : 0.0f;
-            float acc = 0.0f;
-            if (n_kv >= 8) {
-                const int n8 = n_kv & ~7;
-                for (int i = n8 + gl; i < n_kv; i += G) acc = __builtin_fmaf((ROPE && i == pos) ? vfresh : h2f(vr[i]), sc[i], acc);
-                for (int i = gl * 8; i < n8; i += G * 8) {
-                    const u32x4 r = *(const u32x4 *)(vr + i);
-                    const uint32_t wv[4] = { r.x, r.y, r.z, r.w };
+        // each lane group walks U head-dim rows at once: all first-step loads (tail element + first 16-byte chunk) of the
+        // U rows are issued before they are consumed; later chunks (long contexts) follow row by row
+        constexpr int U = 4;
+        const int gl = lane % G, sub = lane / G, rpw = 64 / G, stride = 4 * rpw;
+        const int n8 = n_kv & ~7;
+        for (int db = wave * rpw + sub; db < hd; db += U * stride) {
+            uint16_t t0[U]; u32x4 c0[U]; bool ok[U];
+            const int it = n8 + gl, iv = gl * 8;
 #pragma unroll
-                    for (int j = 0; j < 4; j++) {
-                        const float v0 = (ROPE && i + 2*j == pos) ? vfresh : h2f((uint16_t)(wv[j] & 0xffff));
-                        const float v1 = (ROPE && i + 2*j + 1 == pos) ? vfresh : h2f((uint16_t)(wv[j] >> 16));
-                        acc = __builtin_fmaf(v0, sc[i + 2*j], acc);
-                        acc = __builtin_fmaf(v1, sc[i + 2*j + 1], acc);
-                    }
+            for (int u = 0; u < U; u++) {
+                const int d0 = db + u * stride;
+                ok[u] = d0 < hd;
+                const uint16_t * vr = v_cache + ((int64_t) g * hd + (ok[u] ? d0 : 0)) * ML;
+                t0[u] = 0; c0[u] = u32x4{0, 0, 0, 0};
+                if (ok[u] && n_kv >= 8) {
+                    if (it < n_kv) t0[u] = vr[it];
+                    if (iv < n8) c0[u] = *(const u32x4 *)(vr + iv);
                 }
-            } else {
-                for (int i = gl; i < n_kv; i += G) acc = __builtin_fmaf((ROPE && i == pos) ? vfresh : h2f(vr[i]), sc[i], acc);   // the scalar kernel of matmul_f.hip (K < 8)
             }
-            for (int o = G / 2; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
-            if (gl == 0) att[h * hd + d0] = acc;
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                if (!ok[u]) continue;
+                const int d0 = db + u * stride;
+                const uint16_t * vr = v_cache + ((int64_t) g * hd + d0) * ML;
+                const float vfresh = ROPE ? vnew[d0] : 0.0f;
+                float acc = 0.0f;
+                if (n_kv >= 8) {
+                    for (int i = it; i < n_kv; i += G) acc = __builtin_fmaf((ROPE && i == pos) ? vfresh : h2f(i == it ? t0[u] : vr[i]), sc[i], acc);
+                    for (int i = iv; i < n8; i += G * 8) {
+                        const u32x4 r = i == iv ? c0[u] : *(const u32x4 *)(vr + i);
+                        const uint32_t wv[4] = { r.x, r.y, r.z, r.w };
+#pragma unroll
+                        for (int j = 0; j < 4; j++) {
+                            const float v0 = (ROPE && i + 2*j == pos) ? vfresh : h2f((uint16_t)(wv[j] & 0xffff));
+                            const float v1 = (ROPE && i + 2*j + 1 == pos) ? vfresh : h2f((uint16_t)(wv[j] >> 16));
+                            acc = __builtin_fmaf(v0, sc[i + 2*j], acc);
+                            acc = __builtin_fmaf(v1, sc[i + 2*j + 1], acc);
+                        }
+                    }
+                } else {
+                    for (int i = gl; i < n_kv; i += G) acc = __builtin_fmaf((ROPE && i == pos) ? vfresh : h2f(vr[i]), sc[i], acc);   // the scalar kernel of matmul_f.hip (K < 8)
+                }
+                for (int o = G / 2; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+                if (gl == 0) att[h * hd + d0] = acc;
+            }
         }
     }
 }
+
 static int attn_launch(hipStream_t st, bool rope, const float * qkv, const int32_t * pos_dev, int nh, int nkv, int hd, uint16_t * k_cache, uint16_t * v_cache,
                        int64_t ML, float * att, int mode, float freq_base) {
     if (hd % 8 || (ML % 8) || nh % nkv) FAIL(CLLM_E_UNSUPPORTED, "attn_decode: head_dim and max_len must be multiples of 8");
