@@ -109,6 +109,21 @@ def measure_dominant_kernel(pkg, cfg, wtype, iters=64):
             "bytes_per_launch": nbytes, "avg_us": dur_s * 1e6, "gbs": nbytes / dur_s / 1e9}
 
 
+def pmc_traffic(kernel_label):
+    """HBM bytes per launch of the dominant kernel from the PMC pass committed under profiles/ (FETCH_SIZE, corrected x2 for
+    gfx950 as MI355X_MICROARCH.md prescribes); counters cannot be sampled from inside this process, so: the committed number
+    for exactly this kernel + shape, else null."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_summary.json")) as f:
+            tab = json.load(f)
+        for k, v in tab.items():
+            if k.startswith("k_mmvq_q4_K<1> gate|up") and "k_mmvq_q4_K<1> (gate|up GEMV 28672x4096)" == kernel_label:
+                return v["hbm_read_bytes"]
+    except Exception:
+        pass
+    return None
+
+
 def cpu_baseline(pkg, cfg, wtype, budget_s=20.0):
     """the reference's own CPU mul_mat (oracle/_ref/libggml-cpu.so, all host threads) on the mat-vecs of ONE decoder
     layer + lm_head with resident weights, extrapolated to n_layer layers (mat-muls are >99 % of CPU decode time,
@@ -252,7 +267,7 @@ def main():
             try:
                 k = measure_dominant_kernel(pkg, cfg, wtype)
                 res["roofline"] = {"bound": "hbm", "achieved": k["gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": k["gbs"] / HBM_PEAK_GBS,
-                                   "traffic": None, "kernel": k["kernel"], "avg_us": k["avg_us"], "bytes_per_launch": k["bytes_per_launch"]}
+                                   "traffic": pmc_traffic(k["kernel"]), "kernel": k["kernel"], "avg_us": k["avg_us"], "bytes_per_launch": k["bytes_per_launch"]}
             except Exception as e:      # the throughput number stands on its own
                 res["roofline"] = {"error": str(e)}
             if not args.no_cpu_baseline:
