@@ -383,20 +383,38 @@ extern "C" int cllm_op_attn_decode(void * stream, const float * q, const int32_t
 // ---------------------------------------------------------------------------------------------------------------
 // embedding gather for the token held in device memory is cllm_op_get_rows; greedy sampling + advance:
 // ---------------------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(1024) k_argmax_advance(const float * __restrict__ x, int n, int32_t * __restrict__ tok_dev, int32_t * __restrict__ pos_dev,
-                                                         int32_t * __restrict__ out_ring, int32_t * __restrict__ counter) {
-    __shared__ float bv[16]; __shared__ int bi[16];
+// greedy sampler in two short launches (a single workgroup scanning 128K logits took 43 us):
+//   stage 1: 256 workgroups each reduce a contiguous slice to (value, index), first maximum wins
+//   stage 2: one workgroup reduces the 256 partials in slice order and advances the device-side loop state
+__device__ __forceinline__ void argmax_combine(float & best, int & idx, float ov, int oi) {
+    if (ov > best || (ov == best && oi < idx)) { best = ov; idx = oi; }
+}
+__global__ void __launch_bounds__(256) k_argmax_partial(const float * __restrict__ x, int n, float * __restrict__ pv, int * __restrict__ pi) {
+    __shared__ float bv[4]; __shared__ int bi[4];
+    const int per = (n + gridDim.x - 1) / gridDim.x;
+    const int lo = blockIdx.x * per, hi = min(n, lo + per);
     float best = -INFINITY; int idx = 0x7fffffff;
-    for (int i = threadIdx.x; i < n; i += blockDim.x) { const float v = x[i]; if (v > best) { best = v; idx = i; } }
+    for (int i = lo + threadIdx.x; i < hi; i += 256) { const float v = x[i]; if (v > best) { best = v; idx = i; } }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        const float ov = __shfl_xor(best, o, 64); const int oi = __shfl_xor(idx, o, 64);
-        if (ov > best || (ov == best && oi < idx)) { best = ov; idx = oi; }
-    }
+    for (int o = 32; o > 0; o >>= 1) argmax_combine(best, idx, __shfl_xor(best, o, 64), __shfl_xor(idx, o, 64));
     if ((threadIdx.x & 63) == 0) { bv[threadIdx.x >> 6] = best; bi[threadIdx.x >> 6] = idx; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        for (int w = 1; w < (int)(blockDim.x >> 6); w++) if (bv[w] > best || (bv[w] == best && bi[w] < idx)) { best = bv[w]; idx = bi[w]; }
+        for (int w = 1; w < 4; w++) argmax_combine(best, idx, bv[w], bi[w]);
+        pv[blockIdx.x] = best; pi[blockIdx.x] = idx;
+    }
+}
+__global__ void __launch_bounds__(256) k_argmax_final(const float * __restrict__ pv, const int * __restrict__ pi, int np, int32_t * __restrict__ tok_dev,
+                                                      int32_t * __restrict__ pos_dev, int32_t * __restrict__ out_ring, int32_t * __restrict__ counter) {
+    __shared__ float bv[4]; __shared__ int bi[4];
+    float best = -INFINITY; int idx = 0x7fffffff;
+    for (int i = threadIdx.x; i < np; i += 256) argmax_combine(best, idx, pv[i], pi[i]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) argmax_combine(best, idx, __shfl_xor(best, o, 64), __shfl_xor(idx, o, 64));
+    if ((threadIdx.x & 63) == 0) { bv[threadIdx.x >> 6] = best; bi[threadIdx.x >> 6] = idx; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 4; w++) argmax_combine(best, idx, bv[w], bi[w]);
         if (idx == 0x7fffffff) idx = 0;
         tok_dev[0] = idx;                 // next step's input token
         pos_dev[0] = pos_dev[0] + 1;      // and its position
@@ -404,8 +422,12 @@ __global__ void __launch_bounds__(1024) k_argmax_advance(const float * __restric
         counter[0] = counter[0] + 1;
     }
 }
-int launch_argmax_advance(hipStream_t st, const float * logits, int n, int32_t * tok_dev, int32_t * pos_dev, int32_t * out_ring, int32_t * counter) {
-    hipLaunchKernelGGL(k_argmax_advance, dim3(1), dim3(1024), 0, st, logits, n, tok_dev, pos_dev, out_ring, counter);
+int launch_argmax_advance(hipStream_t st, const float * logits, int n, int32_t * tok_dev, int32_t * pos_dev, int32_t * out_ring, int32_t * counter,
+                          float * part_v, int * part_i) {
+    const int np = 256;
+    hipLaunchKernelGGL(k_argmax_partial, dim3(np), dim3(256), 0, st, logits, n, part_v, part_i);
+    LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_argmax_final, dim3(1), dim3(256), 0, st, (const float *) part_v, (const int *) part_i, np, tok_dev, pos_dev, out_ring, counter);
     LAUNCH_CHECK();
     return CLLM_OK;
 }

@@ -212,7 +212,7 @@ static int finalize(cllm_llama * m, int qlen) {
         HIP_TRY(hipMalloc((void **) &m->logits, (size_t) V * 4));
         HIP_TRY(hipMalloc((void **) &m->next_tok_dev, 16));
         HIP_TRY(hipMalloc((void **) &m->out_ring, (size_t) ML * 4));
-        HIP_TRY(hipMalloc((void **) &m->counter_dev, 16));
+        HIP_TRY(hipMalloc((void **) &m->counter_dev, (16 + 512) * 4));    // loop counter + 256 (value, index) argmax partials
         // the fused single-token path needs the row-concatenated projections and block-aligned widths
         m->fused_ok = m->own_stream && H % 256 == 0 && QD % 256 == 0 && hd % 8 == 0 && ML % 8 == 0 && (size_t)(hd + ML) * 4 <= 150 * 1024;
         for (const llama_layer & L : m->layers) {
@@ -383,8 +383,8 @@ static int decode_step_fused(cllm_llama * m, bool sample) {
         cllm_tensor E = T(m->tok_embd.type, m->tok_embd.data, H, V), ids = T(CLLM_TYPE_I32, m->tokens_dev, 1), X = T(CLLM_TYPE_F32, m->x, H, 1);
         TRY(cllm_op_get_rows(st, &E, &ids, &X));
     }
-    // 6 launches per layer: [norm+quant+qkv GEMV(+bias)] [rope+kv-write+attention] [quant+o GEMV+residual]
-    //                       [norm+quant+gate|up GEMV+silu*up] [quant] [down GEMV+residual]
+    // 5 launches per layer: [norm+quant+qkv GEMV(+bias)] [rope+kv-write+attention] [quant+o GEMV+residual]
+    //                       [norm+quant+gate|up GEMV] [silu*up+quant+down GEMV+residual]
     for (int il = 0; il < c.n_layer; il++) {
         llama_layer & L = m->layers[il];
         TRY(launch_mmvq_fused(st, L.wqkv.type, L.wqkv.data, H, QD + 2*KD, 1, m->x, (const float *) L.attn_norm.data, c.rms_eps, 0, m->qkv,
@@ -397,18 +397,17 @@ static int decode_step_fused(cllm_llama * m, bool sample) {
             cllm_tensor O = T(CLLM_TYPE_F32, m->o, H), X = T(CLLM_TYPE_F32, m->x, H);
             TRY(cllm_op_add(st, &O, &X, &X));
         }
-        TRY(launch_mmvq_fused(st, L.wgu.type, L.wgu.data, H, F, 1, m->x, (const float *) L.ffn_norm.data, c.rms_eps, 1, m->g, nullptr, nullptr));
-        TRY(launch_quant_row(st, kind_of(L.wdown.type), m->g, F, m->wdata));
-        if (!tp) TRY(launch_mmvq_act(st, L.wdown.type, L.wdown.data, F, H, m->wdata, m->x, nullptr, m->x));
+        TRY(launch_mmvq_fused(st, L.wgu.type, L.wgu.data, H, 2*F, 1, m->x, (const float *) L.ffn_norm.data, c.rms_eps, 0, m->gu, nullptr, nullptr));
+        if (!tp) TRY(launch_mmvq_fused(st, L.wdown.type, L.wdown.data, F, H, 3, m->gu, nullptr, 0.0f, 0, m->x, nullptr, m->x));   // act = quant(silu(gate)*up); x = down + x
         else {
-            TRY(launch_mmvq_act(st, L.wdown.type, L.wdown.data, F, H, m->wdata, m->o, nullptr, nullptr));
+            TRY(launch_mmvq_fused(st, L.wdown.type, L.wdown.data, F, H, 3, m->gu, nullptr, 0.0f, 0, m->o, nullptr, nullptr));
             m->allreduce(m->allreduce_user, st, m->o, H);
             cllm_tensor O = T(CLLM_TYPE_F32, m->o, H), X = T(CLLM_TYPE_F32, m->x, H);
             TRY(cllm_op_add(st, &O, &X, &X));
         }
     }
     TRY(launch_mmvq_fused(st, m->lm_head.type, m->lm_head.data, H, V, 1, m->x, (const float *) m->out_norm.data, c.rms_eps, 0, m->logits, nullptr, nullptr));
-    if (sample) TRY(launch_argmax_advance(st, m->logits, (int) V, m->tokens_dev, m->pos_dev, m->out_ring, m->counter_dev));
+    if (sample) TRY(launch_argmax_advance(st, m->logits, (int) V, m->tokens_dev, m->pos_dev, m->out_ring, m->counter_dev, (float *)(m->counter_dev + 16), (int *)(m->counter_dev + 16 + 256)));
     return CLLM_OK;
 }
 

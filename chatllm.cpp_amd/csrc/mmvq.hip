@@ -21,6 +21,7 @@
 
 static int g_mmvq_wg = 256;      // threads per workgroup (tunable: CLLM_MMVQ_WG)
 static int g_mmvq_wgs_per_cu = 8; // grid cap (tunable: CLLM_MMVQ_OCC)
+static int g_mmvq_nt = 0;   // measured: no gain from non-temporal loads on these shapes
 static int g_mmvq_fused_wg = 1024, g_mmvq_fused_occ = 2;   // fused-prologue launches (tunable: CLLM_MMVQ_FWG, CLLM_MMVQ_FOCC)
 
 // kernel arguments; `ids` != NULL turns the launch into MUL_MAT_ID: blockIdx.y enumerates (slot u, token t) pairs,
@@ -37,9 +38,11 @@ struct mmvq_args {
     //   0: copied from the act row in global memory (written by the quantize kernel)
     //   1: RMS_NORM(px) * pw, then quantized, computed by every workgroup itself (decode: saves a launch per mat-vec)
     //   2: px quantized by every workgroup itself
+    //   3: silu(px[i]) * px[K + i] quantized by every workgroup itself (px = [gate | up], BaseMLP::forward)
     int pro; const float * px; const float * pw; float eps;
     // epilogue 1: rows r and r + nrows are the gate / up projections; dst[r] = silu(gate_r) * up_r   (BaseMLP::forward)
     int epi;
+    int nt;                                        // weights are streamed once: non-temporal loads (tunable CLLM_MMVQ_NT)
 };
 
 __device__ __forceinline__ bool mmvq_select(const mmvq_args & a, const char *& W, const char *& act, float *& dst) {
@@ -65,6 +68,8 @@ __device__ __forceinline__ void stage_act(char * lds, const char * __restrict__ 
     }
 }
 
+__device__ __forceinline__ float silu_gate(float x, bool body) { return body ? x / (1.0f + ggml_expf_poly(0.0f - x)) : x / (1.0f + libm_expf(-x)); }
+
 template <int KIND>
 __device__ __forceinline__ void build_act(char * lds, const mmvq_args & a, const char * act, int64_t K, size_t rb, int nc) {
     if (a.pro == 0) { stage_act(lds, act, a.act_stride, rb, nc); return; }
@@ -88,6 +93,12 @@ __device__ __forceinline__ void build_act(char * lds, const mmvq_args & a, const
     }
     for (int64_t e = (int64_t) tid * 4; e < K; e += (int64_t) blockDim.x * 4) {       // K % 256 == 0: whole waves stay together
         f32x4 v = *(const f32x4 *)(a.px + e);
+        if (a.pro == 3) {
+            const f32x4 u = *(const f32x4 *)(a.px + K + e);
+            const int64_t nv = K & ~(int64_t) 7;              // ggml_vec_silu_f32: polynomial body below nv, libm tail
+            v.x = silu_gate(v.x, e + 0 < nv) * u.x; v.y = silu_gate(v.y, e + 1 < nv) * u.y;
+            v.z = silu_gate(v.z, e + 2 < nv) * u.z; v.w = silu_gate(v.w, e + 3 < nv) * u.w;
+        }
         if (a.pro == 1) {
             const f32x4 g = *(const f32x4 *)(a.pw + e);
             v.x = (v.x * scale) * g.x; v.y = (v.y * scale) * g.y; v.z = (v.z * scale) * g.z; v.w = (v.w * scale) * g.w;
@@ -96,13 +107,13 @@ __device__ __forceinline__ void build_act(char * lds, const mmvq_args & a, const
     }
 }
 
-__device__ __forceinline__ float silu_gate(float x, bool body) { return body ? x / (1.0f + ggml_expf_poly(0.0f - x)) : x / (1.0f + libm_expf(-x)); }
 
 // ---- Q4_K -----------------------------------------------------------------------------------------------
 template <int NC>
 __global__ void __launch_bounds__(1024) k_mmvq_q4_K(const mmvq_args a) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     constexpr int KB = 256;
+    const bool NT = a.nt != 0;
     const char * W; const char * act; float * dst;
     if (!mmvq_select(a, W, act, dst)) return;
     const int64_t nb01 = a.nb01, nrows = a.nrows, dst_cs = a.dst_cs; const int nblk = a.nblk;
@@ -129,36 +140,50 @@ __global__ void __launch_bounds__(1024) k_mmvq_q4_K(const mmvq_args a) {
         float accd[NC], accm[NC];
 #pragma unroll
         for (int c = 0; c < NC; c++) { accd[c] = 0.0f; accm[c] = 0.0f; }
-        for (int b0 = 0; b0 < nblk; b0 += 8) {
-            const int b = b0 + grp;
-            if (b < nblk) {
-                const char * bp = wr + (int64_t) b * 144;
-                const u32x4 h = *(const u32x4 *) bp;                 // d|dmin, scales[0..3], [4..7], [8..11]
-                const u32x4 q = *(const u32x4 *)(bp + 16 + 16 * j);
-                const float d    = h2f((uint16_t)(h.x & 0xffff));
-                const float dmin = h2f((uint16_t)(h.x >> 16));
-                // 6-bit unpack: u0 = sc[0..3], u1 = sc[4..7], u2 = m[0..3], u3 = m[4..7]
-                const uint32_t u0 = h.y & 0x3f3f3f3fu;
-                const uint32_t u2 = h.z & 0x3f3f3f3fu;
-                const uint32_t u1 = (h.w & 0x0f0f0f0fu) | (((h.y >> 6) & 0x03030303u) << 4);
-                const uint32_t u3 = ((h.w >> 4) & 0x0f0f0f0fu) | (((h.z >> 6) & 0x03030303u) << 4);
-                const uint32_t scp = (hi ? u1 : u0) >> sh16;
-                const int sc_lo = (int)(scp & 0xff), sc_hi = (int)((scp >> 8) & 0xff);
-                const int mj    = (int)(((hi ? u3 : u2) >> sh8) & 0xff);
-                const uint32_t ql[4] = { q.x & 0x0f0f0f0fu, q.y & 0x0f0f0f0fu, q.z & 0x0f0f0f0fu, q.w & 0x0f0f0f0fu };
-                const uint32_t qh[4] = { (q.x >> 4) & 0x0f0f0f0fu, (q.y >> 4) & 0x0f0f0f0fu, (q.z >> 4) & 0x0f0f0f0fu, (q.w >> 4) & 0x0f0f0f0fu };
+        // U steps (8 super-blocks each) are fetched before any is consumed, so their HBM latencies overlap
+        constexpr int U = 1;     // (U = 4 was measured SLOWER: 78 VGPRs cost two waves per SIMD; occupancy hides the latency better)
+        for (int b0 = 0; b0 < nblk; b0 += 8 * U) {
+            u32x4 hh[U], qq[U];
 #pragma unroll
-                for (int c = 0; c < NC; c++) {
-                    const char * ar = lds + c * rb;
-                    const u32x4 al = *(const u32x4 *)(ar + b * 256 + a_off);
-                    const u32x4 ah = *(const u32x4 *)(ar + b * 256 + a_off + 32);
-                    const float yd = ((const float *)(ar + act_off_d(K)))[b];
-                    const int   ys = ((const int *)(ar + act_off_s(K, 256)))[b * 8 + j];
-                    int il = dot4(ql[0], al.x, 0); il = dot4(ql[1], al.y, il); il = dot4(ql[2], al.z, il); il = dot4(ql[3], al.w, il);
-                    int ih = dot4(qh[0], ah.x, 0); ih = dot4(qh[1], ah.y, ih); ih = dot4(qh[2], ah.z, ih); ih = dot4(qh[3], ah.w, ih);
-                    const int t = sc_lo * il + sc_hi * ih;
-                    accd[c] = __builtin_fmaf(d * yd, (float) t, accd[c]);
-                    accm[c] = __builtin_fmaf(dmin * yd, (float)(mj * ys), accm[c]);
+            for (int u = 0; u < U; u++) {
+                const int b = b0 + 8 * u + grp;
+                hh[u] = u32x4{0, 0, 0, 0}; qq[u] = u32x4{0, 0, 0, 0};
+                if (b < nblk) {
+                    const char * bp = wr + (int64_t) b * 144;
+                    hh[u] = NT ? __builtin_nontemporal_load((const u32x4 *) bp) : *(const u32x4 *) bp;   // d|dmin, scales[0..3], [4..7], [8..11]
+                    qq[u] = NT ? __builtin_nontemporal_load((const u32x4 *)(bp + 16 + 16 * j)) : *(const u32x4 *)(bp + 16 + 16 * j);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const int b = b0 + 8 * u + grp;
+                if (b < nblk) {
+                    const u32x4 h = hh[u], q = qq[u];
+                    const float d    = h2f((uint16_t)(h.x & 0xffff));
+                    const float dmin = h2f((uint16_t)(h.x >> 16));
+                    // 6-bit unpack: u0 = sc[0..3], u1 = sc[4..7], u2 = m[0..3], u3 = m[4..7]
+                    const uint32_t u0 = h.y & 0x3f3f3f3fu;
+                    const uint32_t u2 = h.z & 0x3f3f3f3fu;
+                    const uint32_t u1 = (h.w & 0x0f0f0f0fu) | (((h.y >> 6) & 0x03030303u) << 4);
+                    const uint32_t u3 = ((h.w >> 4) & 0x0f0f0f0fu) | (((h.z >> 6) & 0x03030303u) << 4);
+                    const uint32_t scp = (hi ? u1 : u0) >> sh16;
+                    const int sc_lo = (int)(scp & 0xff), sc_hi = (int)((scp >> 8) & 0xff);
+                    const int mj    = (int)(((hi ? u3 : u2) >> sh8) & 0xff);
+                    const uint32_t ql[4] = { q.x & 0x0f0f0f0fu, q.y & 0x0f0f0f0fu, q.z & 0x0f0f0f0fu, q.w & 0x0f0f0f0fu };
+                    const uint32_t qh[4] = { (q.x >> 4) & 0x0f0f0f0fu, (q.y >> 4) & 0x0f0f0f0fu, (q.z >> 4) & 0x0f0f0f0fu, (q.w >> 4) & 0x0f0f0f0fu };
+#pragma unroll
+                    for (int c = 0; c < NC; c++) {
+                        const char * ar = lds + c * rb;
+                        const u32x4 al = *(const u32x4 *)(ar + b * 256 + a_off);
+                        const u32x4 ah = *(const u32x4 *)(ar + b * 256 + a_off + 32);
+                        const float yd = ((const float *)(ar + act_off_d(K)))[b];
+                        const int   ys = ((const int *)(ar + act_off_s(K, 256)))[b * 8 + j];
+                        int il = dot4(ql[0], al.x, 0); il = dot4(ql[1], al.y, il); il = dot4(ql[2], al.z, il); il = dot4(ql[3], al.w, il);
+                        int ih = dot4(qh[0], ah.x, 0); ih = dot4(qh[1], ah.y, ih); ih = dot4(qh[2], ah.z, ih); ih = dot4(qh[3], ah.w, ih);
+                        const int t = sc_lo * il + sc_hi * ih;
+                        accd[c] = __builtin_fmaf(d * yd, (float) t, accd[c]);
+                        accm[c] = __builtin_fmaf(dmin * yd, (float)(mj * ys), accm[c]);
+                    }
                 }
             }
         }
@@ -340,20 +365,23 @@ static void mmvq_tunables() {
     done = true;
     if (const char * e = getenv("CLLM_MMVQ_WG"))  { int v = atoi(e); if (v == 64 || v == 128 || v == 256 || v == 512) g_mmvq_wg = v; }
     if (const char * e = getenv("CLLM_MMVQ_OCC")) { int v = atoi(e); if (v >= 1 && v <= 32) g_mmvq_wgs_per_cu = v; }
+    if (const char * e = getenv("CLLM_MMVQ_NT"))   { g_mmvq_nt = atoi(e) != 0; }
     if (const char * e = getenv("CLLM_MMVQ_FWG"))  { int v = atoi(e); if (v == 256 || v == 512 || v == 1024) g_mmvq_fused_wg = v; }
     if (const char * e = getenv("CLLM_MMVQ_FOCC")) { int v = atoi(e); if (v >= 1 && v <= 32) g_mmvq_fused_occ = v; }
     if (const char * e = getenv("CLLM_MMVQ_WG"))   { int v = atoi(e); if (v == 1024) g_mmvq_wg = v; }
 }
 
 template <typename KernelT>
-static int launch_one(hipStream_t st, KernelT kern, size_t lds_bytes, const mmvq_args & a, int grid_y) {
+static int launch_one(hipStream_t st, KernelT kern, size_t lds_bytes, const mmvq_args & a_in, int grid_y) {
+    mmvq_args a = a_in;
     mmvq_tunables();
+    a.nt = g_mmvq_nt;
     // in-kernel prologues are redundant work per workgroup: use few, fat workgroups (16 waves share one prologue)
     const int wg = a.pro != 0 ? g_mmvq_fused_wg : g_mmvq_wg, wpw = wg / 64;
     int64_t grid = (a.nrows + wpw - 1) / wpw;
     int64_t cap = (int64_t) device_cu_count() * (a.pro != 0 ? g_mmvq_fused_occ : g_mmvq_wgs_per_cu) / grid_y;
     if (cap < 1) cap = 1;
-    if (grid > cap) grid = cap;
+    if (grid > cap) grid = cap;     // (balancing rows per wave exactly was measured slower than simply using more workgroups)
     if (lds_bytes > 64 * 1024) HIP_TRY(hipFuncSetAttribute((const void *) kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     hipLaunchKernelGGL(kern, dim3((unsigned) grid, (unsigned) grid_y), dim3(wg), lds_bytes, st, a);
     LAUNCH_CHECK();
@@ -429,7 +457,7 @@ int launch_mmvq_act(hipStream_t st, int wtype, const void * W, int64_t K, int64_
 int launch_mmvq_fused(hipStream_t st, int wtype, const void * W, int64_t K, int64_t nrows, int pro, const float * px, const float * pw, float eps,
                       int epi, float * dst, const float * bias, const float * resid) {
     const int kb = wtype == CLLM_TYPE_Q4_K ? 256 : 32;
-    if (K % 256) FAIL(CLLM_E_UNSUPPORTED, "mmvq_fused: K must be a multiple of 256");
+    if (K % kb || (kb == 32 && K % 32)) FAIL(CLLM_E_UNSUPPORTED, "mmvq_fused: K must be a multiple of the activation block");
     const size_t rb = act_row_bytes(K, kb);
     if (rb > 160 * 1024) FAIL(CLLM_E_UNSUPPORTED, "mmvq_fused: K=%lld does not fit LDS", (long long) K);
     mmvq_args a = {};

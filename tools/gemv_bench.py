@@ -19,7 +19,7 @@ SHAPES = [("qkv", 4096, 6144), ("o", 4096, 4096), ("gate_up", 4096, 28672), ("do
           ("q72_down_q8", 29568, 8192)]
 
 
-def run(types, cols, iters, shapes):
+def run(types, cols, iters, shapes, hot=False):
     pkg = ge.load_package()
     L = pkg.lib.get()
     pkg.lib.require_gpu()
@@ -30,7 +30,7 @@ def run(types, cols, iters, shapes):
             if K % pkg.tensor.BLCK[t]:
                 continue
             nbytes = N * pkg.tensor.row_size(t, K)
-            n_copies = max(2, int(1.2 * 2**30 // nbytes) + 1)
+            n_copies = 1 if hot else max(2, int(1.2 * 2**30 // nbytes) + 1)   # hot: same weights every launch (L2 / Infinity Cache resident)
             w0 = pkg.synth.make_tensor_fast("b." + name, t, N, K)
             ws = [pkg.Tensor.from_numpy(w0, t, [K, N]) for _ in range(n_copies)]
             x = pkg.Tensor.from_numpy(rng.standard_normal((cols, K)).astype(np.float32))
@@ -55,6 +55,7 @@ if __name__ == "__main__":
     ap.add_argument("--iters", type=int, default=64)
     ap.add_argument("--shapes", default="")
     ap.add_argument("--sweep", action="store_true")
+    ap.add_argument("--hot", action="store_true")
     a = ap.parse_args()
     shapes = [s for s in SHAPES if not a.shapes or s[0] in a.shapes.split(",")]
     if a.sweep:
@@ -64,4 +65,4 @@ if __name__ == "__main__":
                 subprocess.call([sys.executable, __file__, "--types", a.types, "--cols", str(a.cols), "--iters", str(a.iters),
                                  "--shapes", a.shapes or "qkv,gate_up,down"], env=env)
     else:
-        run(a.types.split(","), a.cols, a.iters, shapes)
+        run(a.types.split(","), a.cols, a.iters, shapes, a.hot)
