@@ -104,21 +104,40 @@ __device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v)
     const unsigned long long a = r[0] > r[1] ? r[0] : r[1], b = r[2] > r[3] ? r[2] : r[3];
     return a > b ? a : b;
 }
-// per-thread part of RMS_NORM's sum of squares for a 256-thread partition (thread t owns i = t, t+256, ...), accumulated in
-// double in increasing i like the CPU loop (ops.cpp:3727-3730).  Loads are issued eight at a time so that their latencies
-// overlap; ONE definition shared by k_rms_norm and the fused GEMV prologue keeps the two bit-identical.
-__device__ __forceinline__ double rms_partial_sumsq_256(const float * __restrict__ x, int64_t n, int tid) {
+// RMS_NORM's sum of squares over one row, by a 1024-thread workgroup: thread t owns the 4-element groups t, t+1024, ...
+// (accumulated in double in increasing index like the CPU loop, ops.cpp:3727-3730), a DPP wave reduction, then the 16 wave
+// partials in wave order.  ONE definition shared by k_rms_norm and the fused GEMV prologue keeps the two bit-identical.
+// `first` = the caller's already-loaded group t (ignored when t >= n/4); `part` = 16 doubles of LDS.  Contains a barrier.
+__device__ __forceinline__ f32x4 rms_load4(const float * __restrict__ x, int64_t q, bool aligned) {
+    if (aligned) return *(const f32x4 *)(x + 4 * q);
+    return f32x4{ x[4*q], x[4*q + 1], x[4*q + 2], x[4*q + 3] };
+}
+__device__ __forceinline__ double rms_block_sumsq_1024(const float * __restrict__ x, int64_t n, f32x4 first, double * part) {
+    const int tid = threadIdx.x;
+    const int64_t nq = n >> 2;
+    const bool aligned = (((uintptr_t) x) & 15) == 0;
     double sum = 0.0;
-    int64_t i = tid;
-    for (; i + 7 * 256 < n; i += 8 * 256) {
-        float v[8];
-#pragma unroll
-        for (int u = 0; u < 8; u++) v[u] = x[i + u * 256];
-#pragma unroll
-        for (int u = 0; u < 8; u++) sum += (double)(v[u] * v[u]);
+    f32x4 v = first;
+    for (int64_t q = tid; q < nq; q += 1024) {
+        if (q != tid) v = rms_load4(x, q, aligned);
+        sum += (double)(v.x * v.x); sum += (double)(v.y * v.y); sum += (double)(v.z * v.z); sum += (double)(v.w * v.w);
     }
-    for (; i < n; i += 256) { const float v = x[i]; sum += (double)(v * v); }
-    return sum;
+    if (4 * nq + tid < n) { const float t = x[4 * nq + tid]; sum += (double)(t * t); }
+    sum = wave_sum_d(sum);
+    if ((tid & 63) == 0) part[tid >> 6] = sum;
+    __syncthreads();
+    double tot = part[0];
+#pragma unroll
+    for (int w = 1; w < 16; w++) tot += part[w];
+    return tot;
+}
+
+// load through the scalar cache (p must be wave-uniform; the data must not have been written by this kernel before).
+// Scalar loads have their own counter (lgkmcnt), so they do not serialise against outstanding vector-memory prefetches.
+__device__ __forceinline__ float uniform_load_f32(const float * p) {
+    float v;
+    asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(p) : "memory");
+    return v;
 }
 
 // reductions inside groups of 8 consecutive lanes (one 32-element quant block = 8 lanes x 4 values)
@@ -193,11 +212,7 @@ int launch_mmq(hipStream_t st, int wtype, const tview & w, const void * act, siz
 int launch_mul_mat_f(hipStream_t st, int wtype, const tview & w, const tview & x, const tview & dst);
 int device_cu_count();
 int launch_mmvq_act(hipStream_t st, int wtype, const void * W, int64_t K, int64_t nrows, const void * act, float * dst, const float * bias, const float * resid);
-int launch_mmvq_fused(hipStream_t st, int wtype, const void * W, int64_t K, int64_t nrows, int pro, const float * px, const float * pw, float eps, int epi, float * dst, const float * bias, const float * resid);
-int launch_norm_quant(hipStream_t st, int kind, const float * x, const float * w, int64_t H, float eps, void * act);
-int launch_quant_row(hipStream_t st, int kind, const float * x, int64_t K, void * act);
-int launch_silu_mul_quant(hipStream_t st, int kind, const float * gu, int64_t F, void * act, float * g_out);
-int launch_rope_kv(hipStream_t st, float * qkv, const int32_t * pos_dev, int nh, int nkv, int hd, int mode, float freq_base, uint16_t * k_cache, uint16_t * v_cache, int64_t ML);
+int launch_mmvq_fused(hipStream_t st, int wtype, const void * W, int64_t K, int64_t nrows, int pro, const float * px, const float * pw, float eps, float * dst, const float * bias, const float * resid);
 int launch_attn_decode(hipStream_t st, const float * qkv, const int32_t * pos_dev, int nh, int nkv, int hd, const uint16_t * k_cache, const uint16_t * v_cache, int64_t ML, float * att);
 int launch_rope_kv_attn_decode(hipStream_t st, const float * qkv, const int32_t * pos_dev, int nh, int nkv, int hd, int mode, float freq_base, uint16_t * k_cache, uint16_t * v_cache, int64_t ML, float * att);
 int launch_argmax_advance(hipStream_t st, const float * logits, int n, int32_t * tok_dev, int32_t * pos_dev, int32_t * out_ring, int32_t * counter, float * part_v, int * part_i);

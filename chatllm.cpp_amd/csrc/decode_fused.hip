@@ -1,144 +1,16 @@
 // decode_fused.hip -- fused single-token (decode) kernels used by the decoder runner (decoder.hip).
 //
 // Same arithmetic, operation order and rounding points as the individual graph nodes they replace:
-//   k_norm_quant      RMS_NORM + MUL(weight) + the activation quantization that MUL_MAT does to its src1
-//   k_rope_kv         ROPE(k), ROPE(q) in place + SET_ROWS(K -> f16 cache row pos) + CPY(V^T -> f16 cache column pos)
-//   k_attn_decode     MUL_MAT(K,Q) + SCALE + DIAG_MASK_INF + SOFT_MAX + MUL_MAT(V,P) [+ PERMUTE/CONT] for one query token
-//   k_silu_mul_quant  UNARY(SILU) + MUL + quantization of the down-projection's src1
-//   k_argmax_advance  greedy sampler (std::max_element, first maximum) feeding the next step on the device
+//   k_attn_decode     [ROPE(q), ROPE(k) + SET_ROWS(K -> f16 cache row pos) + CPY(V^T -> f16 cache column pos)] +
+//                     MUL_MAT(K,Q) + SCALE + DIAG_MASK_INF + SOFT_MAX + MUL_MAT(V,P) [+ PERMUTE/CONT] for one query token
+//   k_argmax_*        greedy sampler (std::max_element, first maximum) feeding the next step on the device
+// (RMS_NORM + MUL, SiLU * up and the activation quantization of MUL_MAT's src1 are prologues of the GEMV, mmvq.hip.)
 // The only per-token inputs (token id, position) are read from device memory, so a whole decode step is a static
 // launch sequence that the runner captures once in a hipGraph.
 #include "common.h"
 #include "quant_dev.h"
 
 #include <math.h>
-
-// ---------------------------------------------------------------------------------------------------------------
-// RMS_NORM + MUL + quantize: one workgroup of 256 threads.
-//   ggml_compute_forward_rms_norm_f32 (ops.cpp:3710-3759) -> MUL -> quantize_row_q8_0 / q8_K (as mul_mat's src1)
-// ---------------------------------------------------------------------------------------------------------------
-template <int KIND>
-__global__ void __launch_bounds__(256) k_norm_quant(const float * __restrict__ x, const float * __restrict__ w, int64_t H, float eps,
-                                                    char * __restrict__ act) {
-    // the sum of squares uses EXACTLY the partition and reduction tree of k_rms_norm (ops.hip) so that the fused and
-    // the node-by-node paths produce the same bits
-    __shared__ double part[4];
-    const int tid = threadIdx.x, lane = tid & 63;
-    double sum = rms_partial_sumsq_256(x, H, tid);
-    sum = wave_sum_d(sum);
-    if (lane == 0) part[tid >> 6] = sum;
-    __syncthreads();
-    sum = part[0] + part[1] + part[2] + part[3];
-    const float mean  = (float)(sum / (double) H);
-    const float scale = 1.0f / sqrtf(mean + eps);
-    for (int64_t e = (int64_t) tid * 4; e < H; e += 1024) {          // H % 256 == 0: whole waves stay together
-        const f32x4 v = *(const f32x4 *)(x + e);
-        const f32x4 g = *(const f32x4 *)(w + e);
-        f32x4 y;
-        y.x = (v.x * scale) * g.x; y.y = (v.y * scale) * g.y; y.z = (v.z * scale) * g.z; y.w = (v.w * scale) * g.w;
-        quant4_store<KIND>(act, H, e, lane, y);
-    }
-}
-
-int launch_norm_quant(hipStream_t st, int kind, const float * x, const float * w, int64_t H, float eps, void * act) {
-    if (H % 256) FAIL(CLLM_E_UNSUPPORTED, "norm_quant: hidden size must be a multiple of 256");
-    if (kind == 32) hipLaunchKernelGGL(k_norm_quant<32>,  dim3(1), dim3(256), 0, st, x, w, H, eps, (char *) act);
-    else            hipLaunchKernelGGL(k_norm_quant<256>, dim3(1), dim3(256), 0, st, x, w, H, eps, (char *) act);
-    LAUNCH_CHECK();
-    return CLLM_OK;
-}
-
-// plain quantization of one dense row (attention output -> src1 of o_proj)
-template <int KIND>
-__global__ void __launch_bounds__(256) k_quant_row(const float * __restrict__ x, int64_t K, char * __restrict__ act) {
-    const int64_t e = ((int64_t) blockIdx.x * 256 + threadIdx.x) * 4;
-    if (e >= K) return;
-    quant4_store<KIND>(act, K, e, threadIdx.x & 63, *(const f32x4 *)(x + e));
-}
-int launch_quant_row(hipStream_t st, int kind, const float * x, int64_t K, void * act) {
-    if (K % kind) FAIL(CLLM_E_UNSUPPORTED, "quant_row: K must be a multiple of %d", kind);
-    const unsigned grid = (unsigned)((K / 4 + 255) / 256);
-    if (kind == 32) hipLaunchKernelGGL(k_quant_row<32>,  dim3(grid), dim3(256), 0, st, x, K, (char *) act);
-    else            hipLaunchKernelGGL(k_quant_row<256>, dim3(grid), dim3(256), 0, st, x, K, (char *) act);
-    LAUNCH_CHECK();
-    return CLLM_OK;
-}
-
-// ---------------------------------------------------------------------------------------------------------------
-// SiLU(gate) * up + quantize (F % 256 == 0 for Q8_K kind, % 32 for Q8_0 kind).  gu = [gate(F) | up(F)]
-//   ggml_vec_silu_f32 (vec.cpp:396-431): polynomial body for i < (F & ~7), libm tail
-// ---------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ float silu_ref(float x, bool body) { return body ? x / (1.0f + ggml_expf_poly(0.0f - x)) : x / (1.0f + libm_expf(-x)); }
-
-template <int KIND>
-__global__ void __launch_bounds__(256) k_silu_mul_quant(const float * __restrict__ gu, int64_t F, char * __restrict__ act, float * __restrict__ g_out) {
-    const int64_t e = ((int64_t) blockIdx.x * 256 + threadIdx.x) * 4;
-    if (e >= F) return;
-    const f32x4 g = *(const f32x4 *)(gu + e), u = *(const f32x4 *)(gu + F + e);
-    const int64_t nv = F & ~(int64_t) 7;
-    f32x4 y;
-    y.x = silu_ref(g.x, e + 0 < nv) * u.x; y.y = silu_ref(g.y, e + 1 < nv) * u.y;
-    y.z = silu_ref(g.z, e + 2 < nv) * u.z; y.w = silu_ref(g.w, e + 3 < nv) * u.w;
-    if (g_out) *(f32x4 *)(g_out + e) = y;
-    quant4_store<KIND>(act, F, e, threadIdx.x & 63, y);
-}
-int launch_silu_mul_quant(hipStream_t st, int kind, const float * gu, int64_t F, void * act, float * g_out) {
-    if (F % kind) FAIL(CLLM_E_UNSUPPORTED, "silu_mul_quant: F=%lld not a multiple of %d", (long long) F, kind);
-    const unsigned grid = (unsigned)((F / 4 + 255) / 256);
-    if (kind == 32) hipLaunchKernelGGL(k_silu_mul_quant<32>,  dim3(grid), dim3(256), 0, st, gu, F, (char *) act, g_out);
-    else            hipLaunchKernelGGL(k_silu_mul_quant<256>, dim3(grid), dim3(256), 0, st, gu, F, (char *) act, g_out);
-    LAUNCH_CHECK();
-    return CLLM_OK;
-}
-
-// ---------------------------------------------------------------------------------------------------------------
-// RoPE(k), RoPE(q) + KV-cache write for ONE token whose position is read from device memory.
-//   ggml_compute_forward_rope_flt (ops.cpp:5589-5865; theta by iterated multiplication) ; from_float f32->f16 (RNE)
-// qkv = [q (nh*hd) | k (nkv*hd) | v (nkv*hd)] floats; k_cache [ML][KD] f16; v_cache [KD][ML] f16 (eager layout)
-// ---------------------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_rope_kv(float * __restrict__ qkv, const int32_t * __restrict__ pos_dev, int nh, int nkv, int hd, int mode,
-                                                 float theta_scale, uint16_t * __restrict__ k_cache, uint16_t * __restrict__ v_cache, int64_t ML) {
-    extern __shared__ float cache[];                        // cos, sin interleaved [hd]
-    const int half = hd / 2;
-    const int pos = pos_dev[0];
-    for (int i = threadIdx.x; i < half; i += blockDim.x) {
-        float theta = (float) pos;
-        for (int k = 0; k < i; k++) theta *= theta_scale;
-        float cs, sn;
-        rope_cos_sin(theta, &cs, &sn);                                   // freq_scale 1, attn_factor 1, no YaRN on this path
-        cache[2*i] = cs * 1.0f; cache[2*i + 1] = sn * 1.0f;
-    }
-    __syncthreads();
-    const int QD = nh * hd, KD = nkv * hd;
-    const int off = mode == 0 ? 1 : half;
-    float * q = qkv, * k = qkv + QD; const float * v = qkv + QD + KD;
-    for (int t = threadIdx.x; t < (nh + nkv) * half; t += blockDim.x) {
-        const int h = t / half, i = t % half;
-        const int ic = mode == 0 ? 2*i : i;
-        const float c = cache[2*i], s = cache[2*i + 1];
-        if (h < nh) {
-            float * x = q + h * hd;
-            const float x0 = x[ic], x1 = x[ic + off];
-            x[ic] = x0*c - x1*s; x[ic + off] = x0*s + x1*c;
-        } else {
-            const int hk = h - nh;
-            float * x = k + hk * hd;
-            const float x0 = x[ic], x1 = x[ic + off];
-            const float y0 = x0*c - x1*s, y1 = x0*s + x1*c;
-            x[ic] = y0; x[ic + off] = y1;
-            uint16_t * kr = k_cache + (int64_t) pos * KD + hk * hd;
-            kr[ic] = f2h(y0); kr[ic + off] = f2h(y1);
-        }
-    }
-    for (int t = threadIdx.x; t < KD; t += blockDim.x) v_cache[(int64_t) t * ML + pos] = f2h(v[t]);
-}
-int launch_rope_kv(hipStream_t st, float * qkv, const int32_t * pos_dev, int nh, int nkv, int hd, int mode, float freq_base,
-                   uint16_t * k_cache, uint16_t * v_cache, int64_t ML) {
-    const float theta_scale = powf(freq_base, -2.0f / hd);
-    hipLaunchKernelGGL(k_rope_kv, dim3(1), dim3(256), (size_t) hd * 4, st, qkv, pos_dev, nh, nkv, hd, mode, theta_scale, k_cache, v_cache, ML);
-    LAUNCH_CHECK();
-    return CLLM_OK;
-}
 
 // ---------------------------------------------------------------------------------------------------------------
 // Attention for one query token, one workgroup per query head.

@@ -387,26 +387,26 @@ static int decode_step_fused(cllm_llama * m, bool sample) {
     //                       [norm+quant+gate|up GEMV] [silu*up+quant+down GEMV+residual]
     for (int il = 0; il < c.n_layer; il++) {
         llama_layer & L = m->layers[il];
-        TRY(launch_mmvq_fused(st, L.wqkv.type, L.wqkv.data, H, QD + 2*KD, 1, m->x, (const float *) L.attn_norm.data, c.rms_eps, 0, m->qkv,
+        TRY(launch_mmvq_fused(st, L.wqkv.type, L.wqkv.data, H, QD + 2*KD, 1, m->x, (const float *) L.attn_norm.data, c.rms_eps, m->qkv,
                               c.qkv_bias ? (const float *) L.bqkv.data : nullptr, nullptr));
         TRY(launch_rope_kv_attn_decode(st, m->qkv, m->pos_dev, m->nh, m->nkv, (int) hd, c.rope_mode, c.rope_theta, L.k_cache, L.v_cache, ML, m->att));
-        if (!tp) TRY(launch_mmvq_fused(st, L.wo.type, L.wo.data, QD, H, 2, m->att, nullptr, 0.0f, 0, m->x, nullptr, m->x));          // x = o + x
+        if (!tp) TRY(launch_mmvq_fused(st, L.wo.type, L.wo.data, QD, H, 2, m->att, nullptr, 0.0f, m->x, nullptr, m->x));          // x = o + x
         else {
-            TRY(launch_mmvq_fused(st, L.wo.type, L.wo.data, QD, H, 2, m->att, nullptr, 0.0f, 0, m->o, nullptr, nullptr));
+            TRY(launch_mmvq_fused(st, L.wo.type, L.wo.data, QD, H, 2, m->att, nullptr, 0.0f, m->o, nullptr, nullptr));
             m->allreduce(m->allreduce_user, st, m->o, H);
             cllm_tensor O = T(CLLM_TYPE_F32, m->o, H), X = T(CLLM_TYPE_F32, m->x, H);
             TRY(cllm_op_add(st, &O, &X, &X));
         }
-        TRY(launch_mmvq_fused(st, L.wgu.type, L.wgu.data, H, 2*F, 1, m->x, (const float *) L.ffn_norm.data, c.rms_eps, 0, m->gu, nullptr, nullptr));
-        if (!tp) TRY(launch_mmvq_fused(st, L.wdown.type, L.wdown.data, F, H, 3, m->gu, nullptr, 0.0f, 0, m->x, nullptr, m->x));   // act = quant(silu(gate)*up); x = down + x
+        TRY(launch_mmvq_fused(st, L.wgu.type, L.wgu.data, H, 2*F, 1, m->x, (const float *) L.ffn_norm.data, c.rms_eps, m->gu, nullptr, nullptr));
+        if (!tp) TRY(launch_mmvq_fused(st, L.wdown.type, L.wdown.data, F, H, 3, m->gu, nullptr, 0.0f, m->x, nullptr, m->x));   // act = quant(silu(gate)*up); x = down + x
         else {
-            TRY(launch_mmvq_fused(st, L.wdown.type, L.wdown.data, F, H, 3, m->gu, nullptr, 0.0f, 0, m->o, nullptr, nullptr));
+            TRY(launch_mmvq_fused(st, L.wdown.type, L.wdown.data, F, H, 3, m->gu, nullptr, 0.0f, m->o, nullptr, nullptr));
             m->allreduce(m->allreduce_user, st, m->o, H);
             cllm_tensor O = T(CLLM_TYPE_F32, m->o, H), X = T(CLLM_TYPE_F32, m->x, H);
             TRY(cllm_op_add(st, &O, &X, &X));
         }
     }
-    TRY(launch_mmvq_fused(st, m->lm_head.type, m->lm_head.data, H, V, 1, m->x, (const float *) m->out_norm.data, c.rms_eps, 0, m->logits, nullptr, nullptr));
+    TRY(launch_mmvq_fused(st, m->lm_head.type, m->lm_head.data, H, V, 1, m->x, (const float *) m->out_norm.data, c.rms_eps, m->logits, nullptr, nullptr));
     if (sample) TRY(launch_argmax_advance(st, m->logits, (int) V, m->tokens_dev, m->pos_dev, m->out_ring, m->counter_dev, (float *)(m->counter_dev + 16), (int *)(m->counter_dev + 16 + 256)));
     return CLLM_OK;
 }

@@ -21,8 +21,8 @@
 
 static int g_mmvq_wg = 256;      // threads per workgroup (tunable: CLLM_MMVQ_WG)
 static int g_mmvq_wgs_per_cu = 8; // grid cap (tunable: CLLM_MMVQ_OCC)
-static int g_mmvq_nt = 0;   // measured: no gain from non-temporal loads on these shapes
-static int g_mmvq_fused_wg = 1024, g_mmvq_fused_occ = 2;   // fused-prologue launches (tunable: CLLM_MMVQ_FWG, CLLM_MMVQ_FOCC)
+static int g_mmvq_fused_occ = 1;  // fused-prologue (decode) launches with K <= 4096: 1024-thread workgroups per CU (tunable: CLLM_MMVQ_FOCC)
+static int g_mmvq_depth = 2;      // prefetch depth of the decode launches: 4, 2 or 1 steps (tunable: CLLM_MMVQ_DEPTH)
 
 // kernel arguments; `ids` != NULL turns the launch into MUL_MAT_ID: blockIdx.y enumerates (slot u, token t) pairs,
 // each with its own expert matrix (ggml-cpu.c:1432-1678).
@@ -40,9 +40,6 @@ struct mmvq_args {
     //   2: px quantized by every workgroup itself
     //   3: silu(px[i]) * px[K + i] quantized by every workgroup itself (px = [gate | up], BaseMLP::forward)
     int pro; const float * px; const float * pw; float eps;
-    // epilogue 1: rows r and r + nrows are the gate / up projections; dst[r] = silu(gate_r) * up_r   (BaseMLP::forward)
-    int epi;
-    int nt;                                        // weights are streamed once: non-temporal loads (tunable CLLM_MMVQ_NT)
 };
 
 __device__ __forceinline__ bool mmvq_select(const mmvq_args & a, const char *& W, const char *& act, float *& dst) {
@@ -70,64 +67,96 @@ __device__ __forceinline__ void stage_act(char * lds, const char * __restrict__ 
 
 __device__ __forceinline__ float silu_gate(float x, bool body) { return body ? x / (1.0f + ggml_expf_poly(0.0f - x)) : x / (1.0f + libm_expf(-x)); }
 
-template <int KIND>
-__device__ __forceinline__ void build_act(char * lds, const mmvq_args & a, const char * act, int64_t K, size_t rb, int nc) {
-    if (a.pro == 0) { stage_act(lds, act, a.act_stride, rb, nc); return; }
+// `after_first_loads` runs right after this thread's first activation loads have been ISSUED and before anything waits
+// on them: the Q4_K kernel issues its weight prefetch there, so the HBM latency of the weights overlaps the whole prologue
+// (the activation loads are older in program order, so the s_waitcnt for them does not wait for the weights).
+template <int KIND, bool FUSED, int NPRE, typename F>
+__device__ __forceinline__ void build_act(char * lds, const mmvq_args & a, const char * act, int64_t K, size_t rb, int nc, F && after_first_loads) {
+    if constexpr (!FUSED) { after_first_loads(); stage_act(lds, act, a.act_stride, rb, nc); return; }   // a.pro == 0 by construction
     const int tid = threadIdx.x, lane = tid & 63;
+    const int64_t e0 = (int64_t) tid * 4, estep = (int64_t) blockDim.x * 4;
+    // This thread's first NPRE activation groups are loaded unconditionally (clamped, pointer-selected) BEFORE the weight
+    // prefetch is issued: a wave's loads return in order, so an activation load issued behind the prefetch would wait for
+    // all of it, and straight-line loads keep the compiler's vmcnt bookkeeping exact.
+    // (NPRE = 1 covers K <= 4096 with 1024 threads, NPRE = 4 K <= 16384; longer rows fall through to the tail loop)
+    const float * gp = a.pro == 1 ? a.pw : a.pro == 3 ? a.px + K : a.px;
+    f32x4 vv[NPRE], gg[NPRE];
+#pragma unroll
+    for (int u = 0; u < NPRE; u++) {
+        const int64_t e = e0 + u * estep, ec = e < K ? e : 0;
+        vv[u] = *(const f32x4 *)(a.px + ec);
+        gg[u] = *(const f32x4 *)(gp + ec);
+    }
+    after_first_loads();
     float scale = 1.0f;
     if (a.pro == 1) {
-        // sum of squares: the partition and reduction tree of k_rms_norm (ops.hip) -- launched with 256 threads -- so that
-        // fused and node-by-node paths agree to the bit
-        // (only the first 256 threads take part: larger workgroups share one prologue between more waves)
-        __shared__ double part[4];
-        if (tid < 256) {
-            double sum = rms_partial_sumsq_256(a.px, K, tid);
-            sum = wave_sum_d(sum);
-            if (lane == 0) part[tid >> 6] = sum;
-        }
-        __syncthreads();
-        double sum;
-        sum = part[0] + part[1] + part[2] + part[3];
+        // sum of squares: the 1024-thread partition and reduction tree of k_rms_norm (ops.hip), so that the fused and the
+        // node-by-node paths agree to the bit
+        __shared__ double part[16];
+        const double sum = rms_block_sumsq_1024(a.px, K, vv[0], part);
         const float mean = (float)(sum / (double) K);
         scale = 1.0f / sqrtf(mean + a.eps);
     }
-    for (int64_t e = (int64_t) tid * 4; e < K; e += (int64_t) blockDim.x * 4) {       // K % 256 == 0: whole waves stay together
-        f32x4 v = *(const f32x4 *)(a.px + e);
+    const int64_t nv = K & ~(int64_t) 7;                      // ggml_vec_silu_f32: polynomial body below nv, libm tail
+    auto emit = [&](int64_t e, f32x4 v, f32x4 g) {
         if (a.pro == 3) {
-            const f32x4 u = *(const f32x4 *)(a.px + K + e);
-            const int64_t nv = K & ~(int64_t) 7;              // ggml_vec_silu_f32: polynomial body below nv, libm tail
-            v.x = silu_gate(v.x, e + 0 < nv) * u.x; v.y = silu_gate(v.y, e + 1 < nv) * u.y;
-            v.z = silu_gate(v.z, e + 2 < nv) * u.z; v.w = silu_gate(v.w, e + 3 < nv) * u.w;
+            v.x = silu_gate(v.x, e + 0 < nv) * g.x; v.y = silu_gate(v.y, e + 1 < nv) * g.y;
+            v.z = silu_gate(v.z, e + 2 < nv) * g.z; v.w = silu_gate(v.w, e + 3 < nv) * g.w;
         }
-        if (a.pro == 1) {
-            const f32x4 g = *(const f32x4 *)(a.pw + e);
-            v.x = (v.x * scale) * g.x; v.y = (v.y * scale) * g.y; v.z = (v.z * scale) * g.z; v.w = (v.w * scale) * g.w;
-        }
+        if (a.pro == 1) { v.x = (v.x * scale) * g.x; v.y = (v.y * scale) * g.y; v.z = (v.z * scale) * g.z; v.w = (v.w * scale) * g.w; }
         quant4_store<KIND>(lds, K, e, lane, v);
+    };
+#pragma unroll
+    for (int u = 0; u < NPRE; u++) {                          // K % 256 == 0 (% 32 for Q8_0 acts): whole lane groups stay together
+        const int64_t e = e0 + u * estep;
+        if (e < K) emit(e, vv[u], gg[u]);
     }
+    for (int64_t e = e0 + NPRE * estep; e < K; e += estep) emit(e, *(const f32x4 *)(a.px + e), *(const f32x4 *)(gp + e));
 }
 
 
 // ---- Q4_K -----------------------------------------------------------------------------------------------
-template <int NC>
+// The (row, step) pairs a wave owns form one linear sequence of steps (a step = 8 super-blocks = 1152 contiguous bytes);
+// the loads of the first P steps are issued BEFORE the activation prologue and every consumed step immediately re-issues
+// the load P steps ahead.  Decode launches use P = 8 with one 1024-thread workgroup per CU: a 4096x4096 matrix is then
+// 2 steps per wave -- the whole matrix is in flight before the prologue starts -- and even gate|up (14 steps per wave)
+// has 9 MB per XCD outstanding at any time.  Accumulation order inside a row does not depend on P.
+template <int NC, int P, bool FUSED, int NPRE = 4>
 __global__ void __launch_bounds__(1024) k_mmvq_q4_K(const mmvq_args a) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     constexpr int KB = 256;
-    const bool NT = a.nt != 0;
     const char * W; const char * act; float * dst;
     if (!mmvq_select(a, W, act, dst)) return;
     const int64_t nb01 = a.nb01, nrows = a.nrows, dst_cs = a.dst_cs; const int nblk = a.nblk;
     const int64_t K = (int64_t) nblk * 256;
     const size_t  rb = act_row_bytes(K, 256);
-    build_act<KB>(lds, a, act, K, rb, NC);
-    __syncthreads();
 
     const int lane = threadIdx.x & 63;
     const int grp  = lane >> 3;            // which of the 8 super-blocks of this step
     const int j    = lane & 7;             // which 16-byte slice of qs / which min
     const int waves_per_wg = blockDim.x >> 6;
-    const int64_t wave0 = (int64_t) blockIdx.x * waves_per_wg + (threadIdx.x >> 6);
+    const int64_t wave0 = (int64_t) blockIdx.x * waves_per_wg + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);     // scalar
     const int64_t nwaves = (int64_t) gridDim.x * waves_per_wg;
+    const int S = (nblk + 7) >> 3;         // steps per row
+
+    // Loads are unconditional (out-of-range steps re-read block 0 of row 0 and are masked when consumed) so that the loop
+    // body is straight-line code and the compiler's s_waitcnt vmcnt(N) counts stay exact: a consumed step waits for its
+    // own two loads only, not for the 2 (P - 1) younger ones.
+    u32x4 hh[P], qq[P];
+    int64_t irow = wave0; int is = 0;      // issue cursor
+    auto issue = [&](u32x4 & h, u32x4 & q) {
+        const int b = 8 * is + grp;
+        const bool ok = irow < nrows && b < nblk;
+        const char * bp = ok ? W + irow * nb01 + (int64_t) b * 144 : W;
+        h = *(const u32x4 *) bp;                        // d|dmin, scales[0..3], [4..7], [8..11] (one broadcast request per 8 lanes)
+        q = *(const u32x4 *)(bp + 16 + 16 * j);
+        if (++is == S) { is = 0; irow += nwaves; }
+    };
+    build_act<KB, FUSED, NPRE>(lds, a, act, K, rb, NC, [&] {
+#pragma unroll
+        for (int p = 0; p < P; p++) issue(hh[p], qq[p]);
+    });
+    __syncthreads();
 
     // lane-constant scale selectors (get_scale_min_k4, ggml-quants.c:703-711, after the utmp shuffle of quants.c:577-582)
     const int sh16 = (j & 2) * 8;          // pair p=j/2: 16-bit field (p&1) of utmp[p>>1]
@@ -135,79 +164,59 @@ __global__ void __launch_bounds__(1024) k_mmvq_q4_K(const mmvq_args a) {
     const bool hi  = j >= 4;
     const int a_off = 64 * (j >> 1) + 16 * (j & 1);     // activation bytes for the low-nibble half; +32 for the high half
 
-    auto row_dot = [&](int64_t row, float (&out)[NC]) {
-        const char * wr = W + row * nb01;
-        float accd[NC], accm[NC];
+    float accd[NC], accm[NC];
 #pragma unroll
-        for (int c = 0; c < NC; c++) { accd[c] = 0.0f; accm[c] = 0.0f; }
-        // U steps (8 super-blocks each) are fetched before any is consumed, so their HBM latencies overlap
-        constexpr int U = 1;     // (U = 4 was measured SLOWER: 78 VGPRs cost two waves per SIMD; occupancy hides the latency better)
-        for (int b0 = 0; b0 < nblk; b0 += 8 * U) {
-            u32x4 hh[U], qq[U];
+    for (int c = 0; c < NC; c++) { accd[c] = 0.0f; accm[c] = 0.0f; }
+    int64_t crow = wave0; int cs = 0;      // consume cursor
+    while (crow < nrows) {
 #pragma unroll
-            for (int u = 0; u < U; u++) {
-                const int b = b0 + 8 * u + grp;
-                hh[u] = u32x4{0, 0, 0, 0}; qq[u] = u32x4{0, 0, 0, 0};
-                if (b < nblk) {
-                    const char * bp = wr + (int64_t) b * 144;
-                    hh[u] = NT ? __builtin_nontemporal_load((const u32x4 *) bp) : *(const u32x4 *) bp;   // d|dmin, scales[0..3], [4..7], [8..11]
-                    qq[u] = NT ? __builtin_nontemporal_load((const u32x4 *)(bp + 16 + 16 * j)) : *(const u32x4 *)(bp + 16 + 16 * j);
+        for (int p = 0; p < P; p++) {
+            const int b = 8 * cs + grp;
+            const bool ok = crow < nrows && b < nblk;
+            const int bb = ok ? b : 0;     // in-range LDS addresses for masked steps
+            {
+                const u32x4 h = hh[p], q = qq[p];
+                const float d    = h2f((uint16_t)(h.x & 0xffff));
+                const float dmin = h2f((uint16_t)(h.x >> 16));
+                // 6-bit unpack: u0 = sc[0..3], u1 = sc[4..7], u2 = m[0..3], u3 = m[4..7]
+                const uint32_t u0 = h.y & 0x3f3f3f3fu;
+                const uint32_t u2 = h.z & 0x3f3f3f3fu;
+                const uint32_t u1 = (h.w & 0x0f0f0f0fu) | (((h.y >> 6) & 0x03030303u) << 4);
+                const uint32_t u3 = ((h.w >> 4) & 0x0f0f0f0fu) | (((h.z >> 6) & 0x03030303u) << 4);
+                const uint32_t scp = (hi ? u1 : u0) >> sh16;
+                const int sc_lo = (int)(scp & 0xff), sc_hi = (int)((scp >> 8) & 0xff);
+                const int mj    = (int)(((hi ? u3 : u2) >> sh8) & 0xff);
+                const uint32_t ql[4] = { q.x & 0x0f0f0f0fu, q.y & 0x0f0f0f0fu, q.z & 0x0f0f0f0fu, q.w & 0x0f0f0f0fu };
+                const uint32_t qh[4] = { (q.x >> 4) & 0x0f0f0f0fu, (q.y >> 4) & 0x0f0f0f0fu, (q.z >> 4) & 0x0f0f0f0fu, (q.w >> 4) & 0x0f0f0f0fu };
+#pragma unroll
+                for (int c = 0; c < NC; c++) {
+                    const char * ar = lds + c * rb;
+                    const u32x4 al = *(const u32x4 *)(ar + bb * 256 + a_off);
+                    const u32x4 ah = *(const u32x4 *)(ar + bb * 256 + a_off + 32);
+                    const float yd = ((const float *)(ar + act_off_d(K)))[bb];
+                    const int   ys = ((const int *)(ar + act_off_s(K, 256)))[bb * 8 + j];
+                    int il = dot4(ql[0], al.x, 0); il = dot4(ql[1], al.y, il); il = dot4(ql[2], al.z, il); il = dot4(ql[3], al.w, il);
+                    int ih = dot4(qh[0], ah.x, 0); ih = dot4(qh[1], ah.y, ih); ih = dot4(qh[2], ah.z, ih); ih = dot4(qh[3], ah.w, ih);
+                    const int t = sc_lo * il + sc_hi * ih;
+                    const float nd = __builtin_fmaf(d * yd, (float) t, accd[c]);
+                    const float nm = __builtin_fmaf(dmin * yd, (float)(mj * ys), accm[c]);
+                    accd[c] = ok ? nd : accd[c];
+                    accm[c] = ok ? nm : accm[c];
                 }
             }
+            issue(hh[p], qq[p]);
+            if (++cs == S) {                // row complete: reduce over the wave, epilogue, store
 #pragma unroll
-            for (int u = 0; u < U; u++) {
-                const int b = b0 + 8 * u + grp;
-                if (b < nblk) {
-                    const u32x4 h = hh[u], q = qq[u];
-                    const float d    = h2f((uint16_t)(h.x & 0xffff));
-                    const float dmin = h2f((uint16_t)(h.x >> 16));
-                    // 6-bit unpack: u0 = sc[0..3], u1 = sc[4..7], u2 = m[0..3], u3 = m[4..7]
-                    const uint32_t u0 = h.y & 0x3f3f3f3fu;
-                    const uint32_t u2 = h.z & 0x3f3f3f3fu;
-                    const uint32_t u1 = (h.w & 0x0f0f0f0fu) | (((h.y >> 6) & 0x03030303u) << 4);
-                    const uint32_t u3 = ((h.w >> 4) & 0x0f0f0f0fu) | (((h.z >> 6) & 0x03030303u) << 4);
-                    const uint32_t scp = (hi ? u1 : u0) >> sh16;
-                    const int sc_lo = (int)(scp & 0xff), sc_hi = (int)((scp >> 8) & 0xff);
-                    const int mj    = (int)(((hi ? u3 : u2) >> sh8) & 0xff);
-                    const uint32_t ql[4] = { q.x & 0x0f0f0f0fu, q.y & 0x0f0f0f0fu, q.z & 0x0f0f0f0fu, q.w & 0x0f0f0f0fu };
-                    const uint32_t qh[4] = { (q.x >> 4) & 0x0f0f0f0fu, (q.y >> 4) & 0x0f0f0f0fu, (q.z >> 4) & 0x0f0f0f0fu, (q.w >> 4) & 0x0f0f0f0fu };
-#pragma unroll
-                    for (int c = 0; c < NC; c++) {
-                        const char * ar = lds + c * rb;
-                        const u32x4 al = *(const u32x4 *)(ar + b * 256 + a_off);
-                        const u32x4 ah = *(const u32x4 *)(ar + b * 256 + a_off + 32);
-                        const float yd = ((const float *)(ar + act_off_d(K)))[b];
-                        const int   ys = ((const int *)(ar + act_off_s(K, 256)))[b * 8 + j];
-                        int il = dot4(ql[0], al.x, 0); il = dot4(ql[1], al.y, il); il = dot4(ql[2], al.z, il); il = dot4(ql[3], al.w, il);
-                        int ih = dot4(qh[0], ah.x, 0); ih = dot4(qh[1], ah.y, ih); ih = dot4(qh[2], ah.z, ih); ih = dot4(qh[3], ah.w, ih);
-                        const int t = sc_lo * il + sc_hi * ih;
-                        accd[c] = __builtin_fmaf(d * yd, (float) t, accd[c]);
-                        accm[c] = __builtin_fmaf(dmin * yd, (float)(mj * ys), accm[c]);
+                for (int c = 0; c < NC; c++) {
+                    float v = wave_sum(accd[c]) - wave_sum(accm[c]);
+                    if (crow < nrows) {     // wave-uniform; bias / resid come through the scalar cache (their own counter)
+                        if (a.bias)  v = v + uniform_load_f32(a.bias + crow);
+                        if (a.resid) v = v + uniform_load_f32(a.resid + crow + c * dst_cs);
+                        if (lane == 0) dst[crow + c * dst_cs] = v;
                     }
+                    accd[c] = 0.0f; accm[c] = 0.0f;
                 }
-            }
-        }
-#pragma unroll
-        for (int c = 0; c < NC; c++) out[c] = wave_sum(accd[c]) - wave_sum(accm[c]);
-    };
-
-    for (int64_t row = wave0; row < nrows; row += nwaves) {
-        float r[NC];
-        row_dot(row, r);
-        if (a.epi == 1) {                                  // gate row -> silu, times the matching up row
-            float u[NC];
-            row_dot(row + nrows, u);
-            const bool body = row < (nrows & ~(int64_t) 7);
-#pragma unroll
-            for (int c = 0; c < NC; c++) r[c] = silu_gate(r[c], body) * u[c];
-        }
-        if (lane == 0) {
-#pragma unroll
-            for (int c = 0; c < NC; c++) {
-                float v = r[c];
-                if (a.bias)  v = v + a.bias[row];
-                if (a.resid) v = v + a.resid[row + c * dst_cs];
-                dst[row + c * dst_cs] = v;
+                cs = 0; crow += nwaves;
             }
         }
     }
@@ -216,7 +225,7 @@ __global__ void __launch_bounds__(1024) k_mmvq_q4_K(const mmvq_args a) {
 // ---- Q4_0 / Q8_0 (one lane per 32-weight block) ------------------------------------------------------------
 struct __attribute__((packed, aligned(2))) u16x8_u2 { uint32_t x, y, z, w; };
 
-template <int NC, bool IS_Q8>
+template <int NC, bool IS_Q8, bool FUSED>
 __global__ void __launch_bounds__(1024) k_mmvq_q32(const mmvq_args a) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     constexpr int KB = 32;
@@ -225,7 +234,7 @@ __global__ void __launch_bounds__(1024) k_mmvq_q32(const mmvq_args a) {
     const int64_t nb01 = a.nb01, nrows = a.nrows, dst_cs = a.dst_cs; const int nblk = a.nblk;
     const int64_t K = (int64_t) nblk * 32;
     const size_t  rb = act_row_bytes(K, 32);
-    build_act<KB>(lds, a, act, K, rb, NC);
+    build_act<KB, FUSED, 4>(lds, a, act, K, rb, NC, [] {});
     __syncthreads();
 
     constexpr int BS = IS_Q8 ? 34 : 18;
@@ -282,13 +291,6 @@ __global__ void __launch_bounds__(1024) k_mmvq_q32(const mmvq_args a) {
     for (int64_t row = wave0; row < nrows; row += nwaves) {
         float r[NC];
         row_dot(row, r);
-        if (a.epi == 1) {
-            float u[NC];
-            row_dot(row + nrows, u);
-            const bool body = row < (nrows & ~(int64_t) 7);
-#pragma unroll
-            for (int c = 0; c < NC; c++) r[c] = silu_gate(r[c], body) * u[c];
-        }
         if (lane == 0) {
 #pragma unroll
             for (int c = 0; c < NC; c++) {
@@ -365,21 +367,20 @@ static void mmvq_tunables() {
     done = true;
     if (const char * e = getenv("CLLM_MMVQ_WG"))  { int v = atoi(e); if (v == 64 || v == 128 || v == 256 || v == 512) g_mmvq_wg = v; }
     if (const char * e = getenv("CLLM_MMVQ_OCC")) { int v = atoi(e); if (v >= 1 && v <= 32) g_mmvq_wgs_per_cu = v; }
-    if (const char * e = getenv("CLLM_MMVQ_NT"))   { g_mmvq_nt = atoi(e) != 0; }
-    if (const char * e = getenv("CLLM_MMVQ_FWG"))  { int v = atoi(e); if (v == 256 || v == 512 || v == 1024) g_mmvq_fused_wg = v; }
-    if (const char * e = getenv("CLLM_MMVQ_FOCC")) { int v = atoi(e); if (v >= 1 && v <= 32) g_mmvq_fused_occ = v; }
+    if (const char * e = getenv("CLLM_MMVQ_DEPTH")) { int v = atoi(e); if (v == 1 || v == 2 || v == 4) g_mmvq_depth = v; }
+    if (const char * e = getenv("CLLM_MMVQ_FOCC")) { int v = atoi(e); if (v >= 1 && v <= 2) g_mmvq_fused_occ = v; }
     if (const char * e = getenv("CLLM_MMVQ_WG"))   { int v = atoi(e); if (v == 1024) g_mmvq_wg = v; }
 }
 
 template <typename KernelT>
-static int launch_one(hipStream_t st, KernelT kern, size_t lds_bytes, const mmvq_args & a_in, int grid_y) {
+static int launch_one(hipStream_t st, KernelT kern, size_t lds_bytes, const mmvq_args & a_in, int grid_y, int fused_occ = 1) {
     mmvq_args a = a_in;
     mmvq_tunables();
-    a.nt = g_mmvq_nt;
-    // in-kernel prologues are redundant work per workgroup: use few, fat workgroups (16 waves share one prologue)
-    const int wg = a.pro != 0 ? g_mmvq_fused_wg : g_mmvq_wg, wpw = wg / 64;
+    // in-kernel prologues are redundant work per workgroup: use few, fat workgroups (16 waves share one prologue; the
+    // RMS_NORM prologue's reduction tree is defined for exactly 1024 threads)
+    const int wg = a.pro != 0 ? 1024 : g_mmvq_wg, wpw = wg / 64;
     int64_t grid = (a.nrows + wpw - 1) / wpw;
-    int64_t cap = (int64_t) device_cu_count() * (a.pro != 0 ? g_mmvq_fused_occ : g_mmvq_wgs_per_cu) / grid_y;
+    int64_t cap = (int64_t) device_cu_count() * (a.pro != 0 ? fused_occ : g_mmvq_wgs_per_cu) / grid_y;
     if (cap < 1) cap = 1;
     if (grid > cap) grid = cap;     // (balancing rows per wave exactly was measured slower than simply using more workgroups)
     if (lds_bytes > 64 * 1024) HIP_TRY(hipFuncSetAttribute((const void *) kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -389,10 +390,33 @@ static int launch_one(hipStream_t st, KernelT kern, size_t lds_bytes, const mmvq
 }
 
 static int mmvq_dispatch(hipStream_t st, int wtype, int nc, size_t lds, const mmvq_args & a, int grid_y) {
-#define GO(KERN) return launch_one(st, KERN, lds, a, grid_y)
-    if (wtype == CLLM_TYPE_Q4_K)      { if (nc == 4) GO(k_mmvq_q4_K<4>); else if (nc == 2) GO(k_mmvq_q4_K<2>); else GO(k_mmvq_q4_K<1>); }
-    else if (wtype == CLLM_TYPE_Q8_0) { if (nc == 4) GO((k_mmvq_q32<4, true>));  else if (nc == 2) GO((k_mmvq_q32<2, true>));  else GO((k_mmvq_q32<1, true>)); }
-    else if (wtype == CLLM_TYPE_Q4_0) { if (nc == 4) GO((k_mmvq_q32<4, false>)); else if (nc == 2) GO((k_mmvq_q32<2, false>)); else GO((k_mmvq_q32<1, false>)); }
+#define GO(...) return launch_one(st, __VA_ARGS__, lds, a, grid_y)
+    const bool fused = a.pro != 0;          // activation built inside the kernel (decode launches, nc == 1)
+    if (fused && nc != 1) FAIL(CLLM_E_INVALID, "mmvq: fused prologue needs a single column");
+    if (wtype == CLLM_TYPE_Q4_K) {
+        if (nc == 4) GO(k_mmvq_q4_K<4, 1, false>); else if (nc == 2) GO(k_mmvq_q4_K<2, 1, false>);
+        if (!fused) GO(k_mmvq_q4_K<1, 1, false>);
+        // decode launches.  K <= 4096 needs one activation group per thread and <= 64 VGPRs: two 1024-thread workgroups per
+        // CU; longer rows keep four groups in registers across the prefetch and run one workgroup per CU.
+        // prefetch depth = the steps a wave owns (rounded up to a power of two), at most g_mmvq_depth
+        mmvq_tunables();
+        const bool small = a.nblk <= 16;
+        const int occ = small ? g_mmvq_fused_occ : 1;
+        const int64_t waves = (int64_t) device_cu_count() * occ * 16;
+        const int64_t steps = ((a.nrows + waves - 1) / waves) * ((a.nblk + 7) / 8);
+        int depth = 1;
+        while (depth < g_mmvq_depth && depth < steps) depth <<= 1;
+#define GOF(...) return launch_one(st, __VA_ARGS__, lds, a, grid_y, occ)
+        if (small) { if (depth >= 2) GOF(k_mmvq_q4_K<1, 2, true, 1>); else GOF(k_mmvq_q4_K<1, 1, true, 1>); }
+        if (depth == 4) GOF(k_mmvq_q4_K<1, 4, true, 4>); else if (depth == 2) GOF(k_mmvq_q4_K<1, 2, true, 4>); else GOF(k_mmvq_q4_K<1, 1, true, 4>);
+#undef GOF
+    } else if (wtype == CLLM_TYPE_Q8_0) {
+        if (nc == 4) GO(k_mmvq_q32<4, true, false>); else if (nc == 2) GO(k_mmvq_q32<2, true, false>);
+        else if (fused) GO(k_mmvq_q32<1, true, true>); else GO(k_mmvq_q32<1, true, false>);
+    } else if (wtype == CLLM_TYPE_Q4_0) {
+        if (nc == 4) GO(k_mmvq_q32<4, false, false>); else if (nc == 2) GO(k_mmvq_q32<2, false, false>);
+        else if (fused) GO(k_mmvq_q32<1, false, true>); else GO(k_mmvq_q32<1, false, false>);
+    }
 #undef GO
     FAIL(CLLM_E_UNSUPPORTED, "mmvq: weight type %d", wtype);
 }
@@ -453,9 +477,9 @@ int launch_mmvq_act(hipStream_t st, int wtype, const void * W, int64_t K, int64_
 
 // decode mat-vec with the activation produced inside the kernel:
 //   pro 1: act = quantize(rms_norm(px) * pw)     pro 2: act = quantize(px)
-//   epi 1: W holds 2*nrows rows (gate | up), dst[r] = silu(W[r].act) * (W[r + nrows].act)
+//   pro 3: act = quantize(silu(px[0..K)) * px[K..2K))
 int launch_mmvq_fused(hipStream_t st, int wtype, const void * W, int64_t K, int64_t nrows, int pro, const float * px, const float * pw, float eps,
-                      int epi, float * dst, const float * bias, const float * resid) {
+                      float * dst, const float * bias, const float * resid) {
     const int kb = wtype == CLLM_TYPE_Q4_K ? 256 : 32;
     if (K % kb || (kb == 32 && K % 32)) FAIL(CLLM_E_UNSUPPORTED, "mmvq_fused: K must be a multiple of the activation block");
     const size_t rb = act_row_bytes(K, kb);
@@ -463,6 +487,6 @@ int launch_mmvq_fused(hipStream_t st, int wtype, const void * W, int64_t K, int6
     mmvq_args a = {};
     a.W = (const char *) W; a.nb01 = (int64_t) cllm_row_size(wtype, K); a.nrows = nrows; a.nblk = (int)(K / kb);
     a.act_stride = rb; a.dst = dst; a.bias = bias; a.resid = resid;
-    a.pro = pro; a.px = px; a.pw = pw; a.eps = eps; a.epi = epi;
+    a.pro = pro; a.px = px; a.pw = pw; a.eps = eps;
     return mmvq_dispatch(st, wtype, 1, rb, a, 1);
 }

@@ -11,18 +11,16 @@
 // one workgroup per row; HBM/L2-bound, float4 traffic.
 // ================================================================================================
 template <bool MUL>
-__global__ void __launch_bounds__(256) k_rms_norm(tview s, tview d, const float * __restrict__ w, int64_t w_ne0, float eps) {
+__global__ void __launch_bounds__(1024) k_rms_norm(tview s, tview d, const float * __restrict__ w, int64_t w_ne0, float eps) {
     const int64_t row = blockIdx.x;
     const int64_t i1 = row % s.ne[1], i2 = (row / s.ne[1]) % s.ne[2], i3 = row / (s.ne[1] * s.ne[2]);
     const float * x = (const float *)(s.data + i1*s.nb[1] + i2*s.nb[2] + i3*s.nb[3]);
     float *       y = (float *)(d.data + i1*d.nb[1] + i2*d.nb[2] + i3*d.nb[3]);
     const int64_t n = s.ne[0];
-    double sum = rms_partial_sumsq_256(x, n, threadIdx.x);
-    sum = wave_sum_d(sum);
-    __shared__ double part[4];
-    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = sum;
-    __syncthreads();
-    sum = part[0] + part[1] + part[2] + part[3];
+    __shared__ double part[16];
+    const bool aligned = (((uintptr_t) x) & 15) == 0;
+    const f32x4 first = (int64_t) threadIdx.x < (n >> 2) ? rms_load4(x, threadIdx.x, aligned) : f32x4{0, 0, 0, 0};
+    const double sum = rms_block_sumsq_1024(x, n, first, part);
     const float mean  = (float)(sum / (double) n);
     const float scale = 1.0f / sqrtf(mean + eps);
     for (int64_t i = threadIdx.x; i < n; i += blockDim.x) {
@@ -41,8 +39,8 @@ static int rms_norm_impl(void * stream, const cllm_tensor * src, const cllm_tens
     const int64_t rows = t_nrows(src);
     if (rows == 0 || src->ne[0] == 0) return CLLM_OK;
     hipStream_t st = (hipStream_t) stream;
-    if (weight) hipLaunchKernelGGL(k_rms_norm<true>,  dim3((unsigned) rows), dim3(256), 0, st, tv(src), tv(dst), (const float *) weight->data, weight->ne[0], eps);
-    else        hipLaunchKernelGGL(k_rms_norm<false>, dim3((unsigned) rows), dim3(256), 0, st, tv(src), tv(dst), (const float *) nullptr, (int64_t) 1, eps);
+    if (weight) hipLaunchKernelGGL(k_rms_norm<true>,  dim3((unsigned) rows), dim3(1024), 0, st, tv(src), tv(dst), (const float *) weight->data, weight->ne[0], eps);
+    else        hipLaunchKernelGGL(k_rms_norm<false>, dim3((unsigned) rows), dim3(1024), 0, st, tv(src), tv(dst), (const float *) nullptr, (int64_t) 1, eps);
     LAUNCH_CHECK();
     return CLLM_OK;
 }

@@ -4,7 +4,7 @@ import os
 import subprocess
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(HERE, "libchatllm_hip.so")
+SO_PATH = os.environ.get("CLLM_LIB") or os.path.join(HERE, "libchatllm_hip.so")      # CLLM_LIB: A/B a differently built library (tools)
 HEADER = os.path.join(os.path.dirname(HERE), "include", "chatllm_hip.h")
 
 
@@ -60,6 +60,8 @@ SIGNATURES = {
     "cllm_mul_mat_wsize": (C.c_size_t, [_T, _T]),
     "cllm_op_mul_mat": (C.c_int, [_P, _T, _T, _T, _P, C.c_size_t]),
     "cllm_bench_mul_mat_kernel": (C.c_int, [_P, _T, C.POINTER(C.c_void_p), C.c_int, _T, _T, _P, C.c_size_t, C.c_int, C.POINTER(C.c_float)]),
+    "cllm_bench_gemv_fused": (C.c_int, [_P, C.c_int, C.POINTER(C.c_void_p), C.c_int, C.c_int64, C.c_int64, C.c_int, _P, _P, C.c_float, _P, _P, C.c_int,
+                                        C.POINTER(C.c_float)]),
     "cllm_op_mul_mat_id": (C.c_int, [_P, _T, _T, _T, _T, _P, C.c_size_t]),
     "cllm_quantize_row_q8_0": (C.c_int, [_P, _P, _P, C.c_int64]),
     "cllm_quantize_row_q8_K": (C.c_int, [_P, _P, _P, C.c_int64]),
@@ -117,6 +119,8 @@ def get():
             raise CllmError(f"{SO_PATH} not built: run `python -c 'import __graft_entry__ as g; g.build()'`")
         lib = C.CDLL(SO_PATH)
         for name, (res, args) in SIGNATURES.items():
+            if "CLLM_LIB" in os.environ and not hasattr(lib, name):
+                continue                     # A/B runs against an older build: newer entry points are simply absent
             fn = getattr(lib, name)          # AttributeError if the symbol is missing
             fn.restype, fn.argtypes = res, args
         _lib = lib

@@ -19,6 +19,41 @@ SHAPES = [("qkv", 4096, 6144), ("o", 4096, 4096), ("gate_up", 4096, 28672), ("do
           ("q72_down_q8", 29568, 8192)]
 
 
+FUSED = [("qkv", 4096, 6144, 1, False), ("o", 4096, 4096, 2, True), ("gate_up", 4096, 28672, 1, False), ("down", 14336, 4096, 3, True),
+         ("lm_head", 4096, 128256, 1, False)]
+
+
+def run_fused(types, iters, hot=False, force_pro=0, only=""):
+    """the decode launches: activation prologue (1 RMS_NORM+quantize, 2 quantize, 3 SiLU*up+quantize) inside the mat-vec"""
+    pkg = ge.load_package()
+    L = pkg.lib.get()
+    pkg.lib.require_gpu()
+    rng = np.random.default_rng(0)
+    for tn in types:
+        t = T[tn]
+        for name, K, N, pro, resid in FUSED:
+            if only and name not in only.split(","):
+                continue
+            if force_pro and pro != 3:
+                pro = force_pro
+            nbytes = N * pkg.tensor.row_size(t, K)
+            n_copies = 1 if hot else max(2, int(1.2 * 2**30 // nbytes) + 1)
+            w0 = pkg.synth.make_tensor_fast("b." + name, t, N, K)
+            ws = [pkg.Tensor.from_numpy(w0, t, [K, N]) for _ in range(n_copies)]
+            x = pkg.Tensor.from_numpy(rng.standard_normal((1, K * (2 if pro == 3 else 1))).astype(np.float32))
+            g = pkg.Tensor.from_numpy((1 + 0.1 * rng.standard_normal((1, K))).astype(np.float32))
+            y = pkg.Tensor(pkg.F32, [N, 1])
+            r = pkg.Tensor.from_numpy(rng.standard_normal((1, N)).astype(np.float32))
+            ptrs = (C.c_void_p * n_copies)(*[w.data_ptr().value for w in ws])
+            us = C.c_float()
+            pkg.lib.check(L.cllm_bench_gemv_fused(None, t, ptrs, n_copies, K, N, pro, x.data_ptr(), g.data_ptr(), 1e-5, y.data_ptr(),
+                                                  r.data_ptr() if resid else None, iters, C.byref(us)), "bench")
+            gbs = nbytes / (us.value * 1e-6) / 1e9
+            print(f"fused {tn:5s} {name:9s} K={K:6d} N={N:6d} pro={pro} {nbytes/1e6:8.1f} MB {us.value:9.2f} us {gbs:8.1f} GB/s  {gbs/80:5.1f}% of 8TB/s  "
+                  f"[depth<={os.environ.get('CLLM_MMVQ_DEPTH','dflt')}]", flush=True)
+            del ws
+
+
 def run(types, cols, iters, shapes, hot=False):
     pkg = ge.load_package()
     L = pkg.lib.get()
@@ -56,9 +91,13 @@ if __name__ == "__main__":
     ap.add_argument("--shapes", default="")
     ap.add_argument("--sweep", action="store_true")
     ap.add_argument("--hot", action="store_true")
+    ap.add_argument("--fused", action="store_true")
+    ap.add_argument("--pro", type=int, default=0)
     a = ap.parse_args()
     shapes = [s for s in SHAPES if not a.shapes or s[0] in a.shapes.split(",")]
-    if a.sweep:
+    if a.fused:
+        run_fused(a.types.split(","), a.iters, a.hot, a.pro, a.shapes)
+    elif a.sweep:
         for wg in (128, 256, 512):
             for occ in (4, 8, 16):
                 env = dict(os.environ, CLLM_MMVQ_WG=str(wg), CLLM_MMVQ_OCC=str(occ))
