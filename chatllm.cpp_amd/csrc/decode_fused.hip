@@ -25,130 +25,186 @@
 static float * g_attn_dbg = nullptr;
 extern "C" __attribute__((visibility("default"))) void cllm_debug_set_attn_probs(float * dev_buf) { g_attn_dbg = dev_buf; }   // tools only
 
+// Latency structure (one launch is ~4.5 us of fixed cost, the rest is a chain of dependent memory round trips): the
+// loads of this head's q / k / v projections are issued first, then the first batch of K-cache rows and V-cache rows
+// (they depend only on the position), and only then does the workgroup wait for the projections and do the RoPE /
+// rounding work -- the cache latencies overlap it.  1024 threads: 64 lane groups keep 256 cache rows in flight.
 template <bool ROPE>
-__global__ void __launch_bounds__(256) k_attn_decode(const float * __restrict__ qkv, const int32_t * __restrict__ pos_dev, int nh, int nkv, int hd,
-                                                     float scale, uint16_t * __restrict__ k_cache, uint16_t * __restrict__ v_cache,
-                                                     int64_t ML, float * __restrict__ att, float * __restrict__ dbg, int mode, float theta_scale) {
-    extern __shared__ __attribute__((aligned(16))) float sm[];       // [hd] q (fp16-rounded) | [hd] new k | [hd] new v | [hd] cos/sin | [n_kv] scores
+__global__ void __launch_bounds__(1024) k_attn_decode(const float * __restrict__ qkv, const int32_t * __restrict__ pos_dev, int nh, int nkv, int hd,
+                                                      float scale, uint16_t * __restrict__ k_cache, uint16_t * __restrict__ v_cache,
+                                                      int64_t ML, float * __restrict__ att, float * __restrict__ dbg, int mode, float theta_scale) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];       // [hd] q (fp16-rounded) | [hd] new k | [hd] new v | [n_kv] scores
     __shared__ double red_d[1];
-    __shared__ float  red_f[4];
+    __shared__ float  red_f[16];
     const int h = blockIdx.x, r2 = nh / nkv, g = h / r2;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthr = blockDim.x, nw = nthr >> 6;
+    const int KD = nkv * hd, QD = nh * hd;
+    const int half = hd / 2;
+    float * qs = sm; float * knew = sm + hd; float * vnew = sm + 2 * hd; float * sc = sm + 3 * hd;
+
+    // ---- (1) this head's projections: one (q or k) pair or one v element per thread, loads issued before anything waits ----
+    const int off = mode == 0 ? 1 : half;
+    const float * qh = qkv + h * hd; const float * kh = qkv + QD + g * hd; const float * vh = qkv + QD + KD + g * hd;
+    float px0 = 0.0f, px1 = 0.0f, pv = 0.0f;
+    const bool pair_fast = ROPE && 2 * half + hd <= nthr;             // every pair / v element has its own thread
+    if (pair_fast) {
+        if (tid < 2 * half) {
+            const int which = tid / half, i = tid % half, ic = mode == 0 ? 2*i : i;
+            const float * x = which == 0 ? qh : kh;
+            px0 = x[ic]; px1 = x[ic + off];
+        } else if (tid < 2 * half + hd) pv = vh[tid - 2 * half];
+    }
     const int pos = pos_dev[0];
     const int n_kv = pos + 1;
-    const int KD = nkv * hd, QD = nh * hd;
-    float * qs = sm; float * knew = sm + hd; float * vnew = sm + 2 * hd; float * cs = sm + 3 * hd; float * sc = sm + 4 * hd;
+
+    // ---- (2) first batch of cache rows (lane grouping of launch_T() in matmul_f.hip: G lanes per row, G*8 <= K, 8 <= G <= 64,
+    //          so that the fp32 summation order -- and every bit of the result -- equals the unfused MUL_MAT nodes) ----
+    constexpr int U = 4;
+    int G = 64; while (G > 8 && G * 8 > hd) G >>= 1;
+    const int K8 = hd & ~7;
+    const bool one_chunk = (K8 == hd) && (G * 8 == hd);               // head_dim 64/128/256/512: exactly one 16-byte chunk per lane
+    const int gl = lane % G, sub = lane / G, rpw = 64 / G, stride = nw * rpw;
+    const int ib0 = wave * rpw + sub;
+    u32x4 kr0[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+        const int i0 = ib0 + u * stride;
+        kr0[u] = u32x4{0, 0, 0, 0};
+        if (one_chunk && i0 < n_kv && !(ROPE && i0 == pos)) kr0[u] = *(const u32x4 *)(k_cache + (int64_t) i0 * KD + g * hd + gl * 8);
+    }
+    int GV = 64; while (GV > 8 && GV * 8 > n_kv) GV >>= 1;
+    const int glv = lane % GV, subv = lane / GV, rpwv = 64 / GV, stridev = nw * rpwv;
+    const int n8 = n_kv & ~7;
+    const int db0 = wave * rpwv + subv, itv = n8 + glv, ivv = glv * 8;
+    uint16_t vt0[U]; u32x4 vc0[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+        const int d0 = db0 + u * stridev;
+        vt0[u] = 0; vc0[u] = u32x4{0, 0, 0, 0};
+        if (d0 < hd && n_kv >= 8) {
+            const uint16_t * vr = v_cache + ((int64_t) g * hd + d0) * ML;
+            if (itv < n_kv) vt0[u] = vr[itv];
+            if (ivv < n8) vc0[u] = *(const u32x4 *)(vr + ivv);
+        }
+    }
+
+    // ---- (3) RoPE, fp16 rounding, cache write ----
     if (ROPE) {
-        const int half = hd / 2;
-        for (int i = tid; i < half; i += 256) {
-            float theta = (float) pos;
-            for (int k = 0; k < i; k++) theta *= theta_scale;
-            float c, s_;
-            rope_cos_sin(theta, &c, &s_);
-            cs[2*i] = c * 1.0f; cs[2*i + 1] = s_ * 1.0f;
+        if (pair_fast) {
+            if (tid < 2 * half) {
+                const int which = tid / half, i = tid % half, ic = mode == 0 ? 2*i : i;
+                float theta = (float) pos;
+                for (int k = 0; k < i; k++) theta *= theta_scale;
+                float c, s_;
+                rope_cos_sin(theta, &c, &s_);
+                c = c * 1.0f; s_ = s_ * 1.0f;
+                const float y0 = px0*c - px1*s_, y1 = px0*s_ + px1*c;
+                float * o = which == 0 ? qs : knew;
+                o[ic] = h2f(f2h(y0)); o[ic + off] = h2f(f2h(y1));         // q: src1 of K.Q is rounded to fp16; k: the cache is fp16
+            } else if (tid < 2 * half + hd) vnew[tid - 2 * half] = h2f(f2h(pv));
+        } else {
+            float * cs = sc;                                            // scores are not live yet
+            for (int i = tid; i < half; i += nthr) {
+                float theta = (float) pos;
+                for (int k = 0; k < i; k++) theta *= theta_scale;
+                float c, s_;
+                rope_cos_sin(theta, &c, &s_);
+                cs[2*i] = c * 1.0f; cs[2*i + 1] = s_ * 1.0f;
+            }
+            __syncthreads();
+            for (int t = tid; t < 2 * half; t += nthr) {
+                const int which = t / half, i = t % half, ic = mode == 0 ? 2*i : i;
+                const float c = cs[2*i], s_ = cs[2*i + 1];
+                const float * x = which == 0 ? qh : kh;
+                const float x0 = x[ic], x1 = x[ic + off];
+                const float y0 = x0*c - x1*s_, y1 = x0*s_ + x1*c;
+                float * o = which == 0 ? qs : knew;
+                o[ic] = h2f(f2h(y0)); o[ic + off] = h2f(f2h(y1));
+            }
+            for (int d = tid; d < hd; d += nthr) vnew[d] = h2f(f2h(vh[d]));
         }
-        __syncthreads();
-        const int off = mode == 0 ? 1 : half;
-        const float * qh = qkv + h * hd; const float * kh = qkv + QD + g * hd; const float * vh = qkv + QD + KD + g * hd;
-        for (int t = tid; t < 2 * half; t += 256) {
-            const int which = t / half, i = t % half;
-            const int ic = mode == 0 ? 2*i : i;
-            const float c = cs[2*i], s_ = cs[2*i + 1];
-            const float * x = which == 0 ? qh : kh;
-            const float x0 = x[ic], x1 = x[ic + off];
-            const float y0 = x0*c - x1*s_, y1 = x0*s_ + x1*c;
-            float * o = which == 0 ? qs : knew;
-            o[ic] = h2f(f2h(y0)); o[ic + off] = h2f(f2h(y1));         // q: src1 of K.Q is rounded to fp16; k: the cache is fp16
-        }
-        for (int d = tid; d < hd; d += 256) vnew[d] = h2f(f2h(vh[d]));
         __syncthreads();
         if (h % r2 == 0) {
-            for (int d = tid; d < hd; d += 256) {
+            for (int d = tid; d < hd; d += nthr) {
                 k_cache[(int64_t) pos * KD + g * hd + d] = f2h(knew[d]);
                 v_cache[((int64_t) g * hd + d) * ML + pos] = f2h(vnew[d]);
             }
         }
     } else {
-        for (int d = tid; d < hd; d += 256) qs[d] = h2f(f2h(qkv[h * hd + d]));
+        for (int d = tid; d < hd; d += nthr) qs[d] = h2f(f2h(qkv[h * hd + d]));
         __syncthreads();
     }
 
-    // Lane grouping follows launch_T() in matmul_f.hip (G lanes per row, G*8 <= K, 8 <= G <= 64) so that the
-    // fp32 summation order -- and therefore every bit of the result -- equals the unfused MUL_MAT nodes.
-    int G = 64; while (G > 8 && G * 8 > hd) G >>= 1;
-    {
-        // U cache rows per lane group are fetched before any of them is consumed (their HBM/L2 latencies overlap); the
-        // arithmetic of each row is unchanged
-        constexpr int U = 4;
-        const int gl = lane % G, sub = lane / G, rpw = 64 / G, stride = 4 * rpw;
-        const int K8 = hd & ~7;
-        const bool one_chunk = (K8 == hd) && (G * 8 == hd);                     // head_dim 64/128/256...: exactly one 16-byte chunk per lane
-        for (int ib = wave * rpw + sub; ib < n_kv; ib += U * stride) {
-            if (one_chunk) {
-                u32x4 r[U]; bool ok[U], fresh[U];
+    // ---- (4) scores[i] = K[i] . q * scale ----
+    for (int ib = ib0; ib < n_kv; ib += U * stride) {
+        if (one_chunk) {
+            u32x4 r[U];
 #pragma unroll
-                for (int u = 0; u < U; u++) {
-                    const int i0 = ib + u * stride;
-                    ok[u] = i0 < n_kv; fresh[u] = ROPE && i0 == pos;
+            for (int u = 0; u < U; u++) {
+                const int i0 = ib + u * stride;
+                r[u] = kr0[u];
+                if (ib != ib0) {
                     r[u] = u32x4{0, 0, 0, 0};
-                    if (ok[u] && !fresh[u]) r[u] = *(const u32x4 *)(k_cache + (int64_t) i0 * KD + g * hd + gl * 8);
+                    if (i0 < n_kv && !(ROPE && i0 == pos)) r[u] = *(const u32x4 *)(k_cache + (int64_t) i0 * KD + g * hd + gl * 8);
                 }
+            }
 #pragma unroll
-                for (int u = 0; u < U; u++) {
-                    if (!ok[u]) continue;                                         // whole lane groups drop out together
-                    const int d = gl * 8;
-                    float acc = 0.0f;
-                    if (fresh[u]) {
+            for (int u = 0; u < U; u++) {
+                const int i0 = ib + u * stride;
+                if (i0 >= n_kv) continue;                                     // whole lane groups drop out together
+                const int d = gl * 8;
+                float acc = 0.0f;
+                if (ROPE && i0 == pos) {
+#pragma unroll
+                    for (int j = 0; j < 8; j++) acc = __builtin_fmaf(knew[d + j], qs[d + j], acc);
+                } else {
+                    const uint32_t wv[4] = { r[u].x, r[u].y, r[u].z, r[u].w };
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        acc = __builtin_fmaf(h2f((uint16_t)(wv[j] & 0xffff)), qs[d + 2*j], acc);
+                        acc = __builtin_fmaf(h2f((uint16_t)(wv[j] >> 16)), qs[d + 2*j + 1], acc);
+                    }
+                }
+                for (int o = G / 2; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+                if (gl == 0) sc[i0] = acc * scale;                            // the SCALE node
+            }
+        } else {
+            for (int u = 0; u < U; u++) {
+                const int i0 = ib + u * stride;
+                if (i0 >= n_kv) break;
+                const uint16_t * kr = k_cache + (int64_t) i0 * KD + g * hd;
+                const bool fr = ROPE && i0 == pos;
+                float acc = 0.0f;
+                for (int d = K8 + gl; d < hd; d += G) acc = __builtin_fmaf(fr ? knew[d] : h2f(kr[d]), qs[d], acc);
+                for (int d = gl * 8; d < K8; d += G * 8) {
+                    if (fr) {
 #pragma unroll
                         for (int j = 0; j < 8; j++) acc = __builtin_fmaf(knew[d + j], qs[d + j], acc);
                     } else {
-                        const uint32_t wv[4] = { r[u].x, r[u].y, r[u].z, r[u].w };
+                        const u32x4 r = *(const u32x4 *)(kr + d);
+                        const uint32_t wv[4] = { r.x, r.y, r.z, r.w };
 #pragma unroll
                         for (int j = 0; j < 4; j++) {
                             acc = __builtin_fmaf(h2f((uint16_t)(wv[j] & 0xffff)), qs[d + 2*j], acc);
                             acc = __builtin_fmaf(h2f((uint16_t)(wv[j] >> 16)), qs[d + 2*j + 1], acc);
                         }
                     }
-                    for (int o = G / 2; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
-                    if (gl == 0) sc[ib + u * stride] = acc * scale;            // the SCALE node
                 }
-            } else {
-                for (int u = 0; u < U; u++) {
-                    const int i0 = ib + u * stride;
-                    if (i0 >= n_kv) break;
-                    const uint16_t * kr = k_cache + (int64_t) i0 * KD + g * hd;
-                    const bool fr = ROPE && i0 == pos;
-                    float acc = 0.0f;
-                    for (int d = K8 + gl; d < hd; d += G) acc = __builtin_fmaf(fr ? knew[d] : h2f(kr[d]), qs[d], acc);
-                    for (int d = gl * 8; d < K8; d += G * 8) {
-                        if (fr) {
-#pragma unroll
-                            for (int j = 0; j < 8; j++) acc = __builtin_fmaf(knew[d + j], qs[d + j], acc);
-                        } else {
-                            const u32x4 r = *(const u32x4 *)(kr + d);
-                            const uint32_t wv[4] = { r.x, r.y, r.z, r.w };
-#pragma unroll
-                            for (int j = 0; j < 4; j++) {
-                                acc = __builtin_fmaf(h2f((uint16_t)(wv[j] & 0xffff)), qs[d + 2*j], acc);
-                                acc = __builtin_fmaf(h2f((uint16_t)(wv[j] >> 16)), qs[d + 2*j + 1], acc);
-                            }
-                        }
-                    }
-                    for (int o = G / 2; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
-                    if (gl == 0) sc[i0] = acc * scale;
-                }
+                for (int o = G / 2; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+                if (gl == 0) sc[i0] = acc * scale;
             }
         }
     }
     __syncthreads();
 
-    // ---- soft_max over sc[0..n_kv): same partition as k_soft_max (one wave, lane = groups of 8) ----
+    // ---- (5) soft_max over sc[0..n_kv): same partition as k_soft_max (one wave, lane = groups of 8) ----
     float mx = -INFINITY;
-    for (int i = tid; i < n_kv; i += 256) mx = fmaxf(mx, sc[i]);
+    for (int i = tid; i < n_kv; i += nthr) mx = fmaxf(mx, sc[i]);
     mx = wave_max(mx);
     if (lane == 0) red_f[wave] = mx;
     __syncthreads();
-    mx = fmaxf(fmaxf(red_f[0], red_f[1]), fmaxf(red_f[2], red_f[3]));
+    mx = red_f[0];
+    for (int w = 1; w < nw; w++) mx = fmaxf(mx, red_f[w]);
     if (wave == 0) {
         const int nv = n_kv & ~7;
         double sum = 0.0;
@@ -165,58 +221,52 @@ __global__ void __launch_bounds__(256) k_attn_decode(const float * __restrict__ 
     }
     __syncthreads();
     const float inv = (float)(1.0 / red_d[0]);
-    for (int i = tid; i < n_kv; i += 256) sc[i] = h2f(f2h(sc[i] * inv));   // probability, then its fp16 rounding for V.P
+    for (int i = tid; i < n_kv; i += nthr) sc[i] = h2f(f2h(sc[i] * inv));   // probability, then its fp16 rounding for V.P
     __syncthreads();
-    if (dbg) { for (int i = tid; i < n_kv; i += 256) dbg[(int64_t) h * ML + i] = sc[i]; if (tid == 0) { dbg[(int64_t) nh * ML + 2*h] = mx; dbg[(int64_t) nh * ML + 2*h + 1] = inv; } }
+    if (dbg) { for (int i = tid; i < n_kv; i += nthr) dbg[(int64_t) h * ML + i] = sc[i]; if (tid == 0) { dbg[(int64_t) nh * ML + 2*h] = mx; dbg[(int64_t) nh * ML + 2*h + 1] = inv; } }
 
-    // ---- ctx = V . P ----
-    G = 64; while (G > 8 && G * 8 > n_kv) G >>= 1;
-    {
-        // each lane group walks U head-dim rows at once: all first-step loads (tail element + first 16-byte chunk) of the
-        // U rows are issued before they are consumed; later chunks (long contexts) follow row by row
-        constexpr int U = 4;
-        const int gl = lane % G, sub = lane / G, rpw = 64 / G, stride = 4 * rpw;
-        const int n8 = n_kv & ~7;
-        for (int db = wave * rpw + sub; db < hd; db += U * stride) {
-            uint16_t t0[U]; u32x4 c0[U]; bool ok[U];
-            const int it = n8 + gl, iv = gl * 8;
+    // ---- (6) ctx = V . P: each lane group walks U head-dim rows at once; the first-step loads (tail element + first
+    //          16-byte chunk) of the first U rows were issued in (2); later chunks (long contexts) follow row by row ----
+    for (int db = db0; db < hd; db += U * stridev) {
+        uint16_t t0[U]; u32x4 c0[U];
 #pragma unroll
-            for (int u = 0; u < U; u++) {
-                const int d0 = db + u * stride;
-                ok[u] = d0 < hd;
-                const uint16_t * vr = v_cache + ((int64_t) g * hd + (ok[u] ? d0 : 0)) * ML;
+        for (int u = 0; u < U; u++) {
+            const int d0 = db + u * stridev;
+            t0[u] = vt0[u]; c0[u] = vc0[u];
+            if (db != db0) {
                 t0[u] = 0; c0[u] = u32x4{0, 0, 0, 0};
-                if (ok[u] && n_kv >= 8) {
-                    if (it < n_kv) t0[u] = vr[it];
-                    if (iv < n8) c0[u] = *(const u32x4 *)(vr + iv);
+                if (d0 < hd && n_kv >= 8) {
+                    const uint16_t * vr = v_cache + ((int64_t) g * hd + d0) * ML;
+                    if (itv < n_kv) t0[u] = vr[itv];
+                    if (ivv < n8) c0[u] = *(const u32x4 *)(vr + ivv);
                 }
             }
+        }
 #pragma unroll
-            for (int u = 0; u < U; u++) {
-                if (!ok[u]) continue;
-                const int d0 = db + u * stride;
-                const uint16_t * vr = v_cache + ((int64_t) g * hd + d0) * ML;
-                const float vfresh = ROPE ? vnew[d0] : 0.0f;
-                float acc = 0.0f;
-                if (n_kv >= 8) {
-                    for (int i = it; i < n_kv; i += G) acc = __builtin_fmaf((ROPE && i == pos) ? vfresh : h2f(i == it ? t0[u] : vr[i]), sc[i], acc);
-                    for (int i = iv; i < n8; i += G * 8) {
-                        const u32x4 r = i == iv ? c0[u] : *(const u32x4 *)(vr + i);
-                        const uint32_t wv[4] = { r.x, r.y, r.z, r.w };
+        for (int u = 0; u < U; u++) {
+            const int d0 = db + u * stridev;
+            if (d0 >= hd) continue;
+            const uint16_t * vr = v_cache + ((int64_t) g * hd + d0) * ML;
+            const float vfresh = ROPE ? vnew[d0] : 0.0f;
+            float acc = 0.0f;
+            if (n_kv >= 8) {
+                for (int i = itv; i < n_kv; i += GV) acc = __builtin_fmaf((ROPE && i == pos) ? vfresh : h2f(i == itv ? t0[u] : vr[i]), sc[i], acc);
+                for (int i = ivv; i < n8; i += GV * 8) {
+                    const u32x4 r = i == ivv ? c0[u] : *(const u32x4 *)(vr + i);
+                    const uint32_t wv[4] = { r.x, r.y, r.z, r.w };
 #pragma unroll
-                        for (int j = 0; j < 4; j++) {
-                            const float v0 = (ROPE && i + 2*j == pos) ? vfresh : h2f((uint16_t)(wv[j] & 0xffff));
-                            const float v1 = (ROPE && i + 2*j + 1 == pos) ? vfresh : h2f((uint16_t)(wv[j] >> 16));
-                            acc = __builtin_fmaf(v0, sc[i + 2*j], acc);
-                            acc = __builtin_fmaf(v1, sc[i + 2*j + 1], acc);
-                        }
+                    for (int j = 0; j < 4; j++) {
+                        const float v0 = (ROPE && i + 2*j == pos) ? vfresh : h2f((uint16_t)(wv[j] & 0xffff));
+                        const float v1 = (ROPE && i + 2*j + 1 == pos) ? vfresh : h2f((uint16_t)(wv[j] >> 16));
+                        acc = __builtin_fmaf(v0, sc[i + 2*j], acc);
+                        acc = __builtin_fmaf(v1, sc[i + 2*j + 1], acc);
                     }
-                } else {
-                    for (int i = gl; i < n_kv; i += G) acc = __builtin_fmaf((ROPE && i == pos) ? vfresh : h2f(vr[i]), sc[i], acc);   // the scalar kernel of matmul_f.hip (K < 8)
                 }
-                for (int o = G / 2; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
-                if (gl == 0) att[h * hd + d0] = acc;
+            } else {
+                for (int i = glv; i < n_kv; i += GV) acc = __builtin_fmaf((ROPE && i == pos) ? vfresh : h2f(vr[i]), sc[i], acc);   // the scalar kernel of matmul_f.hip (K < 8)
             }
+            for (int o = GV / 2; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+            if (glv == 0) att[h * hd + d0] = acc;
         }
     }
 }
@@ -224,7 +274,7 @@ __global__ void __launch_bounds__(256) k_attn_decode(const float * __restrict__ 
 static int attn_launch(hipStream_t st, bool rope, const float * qkv, const int32_t * pos_dev, int nh, int nkv, int hd, uint16_t * k_cache, uint16_t * v_cache,
                        int64_t ML, float * att, int mode, float freq_base) {
     if (hd % 8 || (ML % 8) || nh % nkv) FAIL(CLLM_E_UNSUPPORTED, "attn_decode: head_dim and max_len must be multiples of 8");
-    const size_t lds = (size_t)(4 * hd + ML) * 4;
+    const size_t lds = (size_t)(3 * hd + (ML > hd ? ML : hd)) * 4;      // q | new k | new v | scores (reused for the cos/sin table)
     if (lds > 150 * 1024) FAIL(CLLM_E_UNSUPPORTED, "attn_decode: max_len %lld does not fit LDS", (long long) ML);
     static bool attr0 = false, attr1 = false;
     if (lds > 48 * 1024) {
@@ -232,8 +282,8 @@ static int attn_launch(hipStream_t st, bool rope, const float * qkv, const int32
         if (rope && !attr1)  { HIP_TRY(hipFuncSetAttribute((const void *) k_attn_decode<true>,  hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024)); attr1 = true; }
     }
     const float scale = 1.0f / sqrtf((float) hd), theta_scale = powf(freq_base, -2.0f / hd);
-    if (rope) hipLaunchKernelGGL(k_attn_decode<true>,  dim3(nh), dim3(256), lds, st, qkv, pos_dev, nh, nkv, hd, scale, k_cache, v_cache, ML, att, g_attn_dbg, mode, theta_scale);
-    else      hipLaunchKernelGGL(k_attn_decode<false>, dim3(nh), dim3(256), lds, st, qkv, pos_dev, nh, nkv, hd, scale, k_cache, v_cache, ML, att, g_attn_dbg, mode, theta_scale);
+    if (rope) hipLaunchKernelGGL(k_attn_decode<true>,  dim3(nh), dim3(1024), lds, st, qkv, pos_dev, nh, nkv, hd, scale, k_cache, v_cache, ML, att, g_attn_dbg, mode, theta_scale);
+    else      hipLaunchKernelGGL(k_attn_decode<false>, dim3(nh), dim3(1024), lds, st, qkv, pos_dev, nh, nkv, hd, scale, k_cache, v_cache, ML, att, g_attn_dbg, mode, theta_scale);
     LAUNCH_CHECK();
     return CLLM_OK;
 }
