@@ -235,7 +235,7 @@ extern "C" int cllm_bench_mul_mat_kernel(void * stream, const cllm_tensor * src0
 
 // times the DECODE form of the mat-vec (activation prologue inside the kernel, exactly what cllm_llama's fused step launches)
 extern "C" int cllm_bench_gemv_fused(void * stream, int wtype, void * const * w_datas, int n_w, int64_t K, int64_t nrows, int pro,
-                                     const float * px, const float * pw, float eps, float * dst, const float * resid, int iters, float * avg_us) {
+                                     const float * px, const float * pw, float eps, int epi, float * dst, const float * resid, int iters, float * avg_us) {
     if (!is_quant(wtype) || !w_datas || n_w <= 0 || iters <= 0 || !avg_us || !px || !dst || pro < 1 || pro > 3) FAIL(CLLM_E_INVALID, "bench_gemv_fused: arguments");
     hipStream_t st = (hipStream_t) stream;
     hipEvent_t e0, e1;
@@ -244,7 +244,7 @@ extern "C" int cllm_bench_gemv_fused(void * stream, int wtype, void * const * w_
         if (pass == 1) HIP_TRY(hipEventRecord(e0, st));
         const int n = pass == 0 ? (n_w < 4 ? n_w : 4) : iters;
         for (int i = 0; i < n; i++) {
-            const int rc = launch_mmvq_fused(st, wtype, w_datas[i % n_w], K, nrows, pro, px, pw, eps, dst, nullptr, resid);
+            const int rc = launch_mmvq_fused(st, wtype, w_datas[i % n_w], K, nrows, pro, px, pw, eps, epi, dst, nullptr, resid);
             if (rc) return rc;
         }
     }

@@ -26,7 +26,8 @@ struct dweight { int type = -1; void * data = nullptr; size_t bytes = 0; bool ow
 
 struct llama_layer {
     dweight attn_norm, ffn_norm, wq, wk, wv, wo, wgate, wup, wdown, bq, bk, bv;
-    dweight wqkv, wgu;            // row-concatenated fusions (q|k|v and gate|up): numerically identical, one launch
+    dweight wqkv, wgu;            // row fusions, numerically identical, one launch: q|k|v concatenated; gate/up INTERLEAVED (row 2u = gate_u,
+                                  // row 2u+1 = up_u) so that one wave owns both rows of a feature and can apply SiLU(gate)*up itself
     dweight bqkv;                 // concatenated q|k|v bias (Qwen2)
     uint16_t * k_cache = nullptr, * v_cache = nullptr;
 };
@@ -169,6 +170,20 @@ static int fuse_rows(hipStream_t st, dweight & dst, std::initializer_list<dweigh
     return CLLM_OK;
 }
 
+// dst rows alternate a_0, b_0, a_1, b_1, ... (a and b have the same type and row size)
+static int interleave_rows(hipStream_t st, dweight & dst, dweight & a, dweight & b, size_t row_bytes) {
+    if (a.type != b.type || a.bytes != b.bytes || a.bytes % row_bytes) return CLLM_OK;     // mixed: keep separate
+    void * buf = nullptr;
+    HIP_TRY(hipMalloc(&buf, a.bytes + b.bytes));
+    const size_t rows = a.bytes / row_bytes;
+    HIP_TRY(hipMemcpy2DAsync(buf, 2 * row_bytes, a.data, row_bytes, row_bytes, rows, hipMemcpyDeviceToDevice, st));
+    HIP_TRY(hipMemcpy2DAsync((char *) buf + row_bytes, 2 * row_bytes, b.data, row_bytes, row_bytes, rows, hipMemcpyDeviceToDevice, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    dst.type = a.type; dst.data = buf; dst.bytes = a.bytes + b.bytes; dst.owned = true;
+    free_w(a); free_w(b);
+    return CLLM_OK;
+}
+
 static int finalize(cllm_llama * m, int qlen) {
     const cllm_llama_config & c = m->cfg;
     const int64_t H = c.hidden, hd = c.head_dim, QD = (int64_t) m->nh * hd, KD = (int64_t) m->nkv * hd, F = m->F, V = c.vocab, ML = c.max_len;
@@ -191,7 +206,7 @@ static int finalize(cllm_llama * m, int qlen) {
             if (!L.wgu.data) {
                 TRY(expect(L.wgate, "wgate", il, cllm_row_size(L.wgate.type, H) * (size_t) F, false));
                 TRY(expect(L.wup, "wup", il, cllm_row_size(L.wup.type, H) * (size_t) F, false));
-                TRY(fuse_rows(m->st, L.wgu, { &L.wgate, &L.wup }));
+                TRY(interleave_rows(m->st, L.wgu, L.wgate, L.wup, cllm_row_size(L.wgate.type, H)));
             } else TRY(expect(L.wgu, "wgu", il, cllm_row_size(L.wgu.type, H) * (size_t)(2*F), false));
             TRY(expect(L.wdown, "wdown", il, cllm_row_size(L.wdown.type, F) * (size_t) H, false));
             if (c.qkv_bias) {
@@ -335,8 +350,9 @@ static int forward_general(cllm_llama * m, int qlen, int n_past) {
         TRY(cllm_op_rms_norm_mul(st, &X, &wf, &XN, c.rms_eps));
         if (L.wgu.data) {
             TRY(linear(m, L.wgu, H, 2*F, m->xn, qlen, m->gu));
-            cllm_tensor G = TS(CLLM_TYPE_F32, m->gu, F, qlen, 1, (size_t) 2*F * 4, (size_t) 2*F * 4 * qlen);
-            cllm_tensor U = TS(CLLM_TYPE_F32, m->gu + F, F, qlen, 1, (size_t) 2*F * 4, (size_t) 2*F * 4 * qlen);
+            cllm_tensor G = TS(CLLM_TYPE_F32, m->gu, F, qlen, 1, (size_t) 2*F * 4, (size_t) 2*F * 4 * qlen);           // even elements
+            cllm_tensor U = TS(CLLM_TYPE_F32, m->gu + 1, F, qlen, 1, (size_t) 2*F * 4, (size_t) 2*F * 4 * qlen);       // odd elements
+            G.nb[0] = 8; U.nb[0] = 8;
             cllm_tensor Gd = T(CLLM_TYPE_F32, m->g, F, qlen);
             TRY(cllm_op_silu_mul(st, &G, &U, &Gd));
         } else {
@@ -384,29 +400,35 @@ static int decode_step_fused(cllm_llama * m, bool sample) {
         TRY(cllm_op_get_rows(st, &E, &ids, &X));
     }
     // 5 launches per layer: [norm+quant+qkv GEMV(+bias)] [rope+kv-write+attention] [quant+o GEMV+residual]
-    //                       [norm+quant+gate|up GEMV] [silu*up+quant+down GEMV+residual]
+    //                       [norm+quant+gate/up GEMV+silu*up] [quant+down GEMV+residual]
     for (int il = 0; il < c.n_layer; il++) {
         llama_layer & L = m->layers[il];
-        TRY(launch_mmvq_fused(st, L.wqkv.type, L.wqkv.data, H, QD + 2*KD, 1, m->x, (const float *) L.attn_norm.data, c.rms_eps, m->qkv,
+        TRY(launch_mmvq_fused(st, L.wqkv.type, L.wqkv.data, H, QD + 2*KD, 1, m->x, (const float *) L.attn_norm.data, c.rms_eps, 0, m->qkv,
                               c.qkv_bias ? (const float *) L.bqkv.data : nullptr, nullptr));
         TRY(launch_rope_kv_attn_decode(st, m->qkv, m->pos_dev, m->nh, m->nkv, (int) hd, c.rope_mode, c.rope_theta, L.k_cache, L.v_cache, ML, m->att));
-        if (!tp) TRY(launch_mmvq_fused(st, L.wo.type, L.wo.data, QD, H, 2, m->att, nullptr, 0.0f, m->x, nullptr, m->x));          // x = o + x
+        if (!tp) TRY(launch_mmvq_fused(st, L.wo.type, L.wo.data, QD, H, 2, m->att, nullptr, 0.0f, 0, m->x, nullptr, m->x));          // x = o + x
         else {
-            TRY(launch_mmvq_fused(st, L.wo.type, L.wo.data, QD, H, 2, m->att, nullptr, 0.0f, m->o, nullptr, nullptr));
+            TRY(launch_mmvq_fused(st, L.wo.type, L.wo.data, QD, H, 2, m->att, nullptr, 0.0f, 0, m->o, nullptr, nullptr));
             m->allreduce(m->allreduce_user, st, m->o, H);
             cllm_tensor O = T(CLLM_TYPE_F32, m->o, H), X = T(CLLM_TYPE_F32, m->x, H);
             TRY(cllm_op_add(st, &O, &X, &X));
         }
-        TRY(launch_mmvq_fused(st, L.wgu.type, L.wgu.data, H, 2*F, 1, m->x, (const float *) L.ffn_norm.data, c.rms_eps, m->gu, nullptr, nullptr));
-        if (!tp) TRY(launch_mmvq_fused(st, L.wdown.type, L.wdown.data, F, H, 3, m->gu, nullptr, 0.0f, m->x, nullptr, m->x));   // act = quant(silu(gate)*up); x = down + x
+        // Q4_K gate/up: the wave that owns a feature's row pair applies SiLU(gate)*up itself, the down mat-vec only quantizes;
+        // otherwise the down mat-vec's prologue does SiLU*up on the interleaved pairs
+        const bool silu_epi = L.wgu.type == CLLM_TYPE_Q4_K && F % 8 == 0;
+        const float * dsrc = silu_epi ? m->g : m->gu;
+        const int dpro = silu_epi ? 2 : 3;
+        TRY(launch_mmvq_fused(st, L.wgu.type, L.wgu.data, H, 2*F, 1, m->x, (const float *) L.ffn_norm.data, c.rms_eps, silu_epi ? 1 : 0,
+                              silu_epi ? m->g : m->gu, nullptr, nullptr));
+        if (!tp) TRY(launch_mmvq_fused(st, L.wdown.type, L.wdown.data, F, H, dpro, dsrc, nullptr, 0.0f, 0, m->x, nullptr, m->x));   // x = down + x
         else {
-            TRY(launch_mmvq_fused(st, L.wdown.type, L.wdown.data, F, H, 3, m->gu, nullptr, 0.0f, m->o, nullptr, nullptr));
+            TRY(launch_mmvq_fused(st, L.wdown.type, L.wdown.data, F, H, dpro, dsrc, nullptr, 0.0f, 0, m->o, nullptr, nullptr));
             m->allreduce(m->allreduce_user, st, m->o, H);
             cllm_tensor O = T(CLLM_TYPE_F32, m->o, H), X = T(CLLM_TYPE_F32, m->x, H);
             TRY(cllm_op_add(st, &O, &X, &X));
         }
     }
-    TRY(launch_mmvq_fused(st, m->lm_head.type, m->lm_head.data, H, V, 1, m->x, (const float *) m->out_norm.data, c.rms_eps, m->logits, nullptr, nullptr));
+    TRY(launch_mmvq_fused(st, m->lm_head.type, m->lm_head.data, H, V, 1, m->x, (const float *) m->out_norm.data, c.rms_eps, 0, m->logits, nullptr, nullptr));
     if (sample) TRY(launch_argmax_advance(st, m->logits, (int) V, m->tokens_dev, m->pos_dev, m->out_ring, m->counter_dev, (float *)(m->counter_dev + 16), (int *)(m->counter_dev + 16 + 256)));
     return CLLM_OK;
 }

@@ -40,6 +40,9 @@ struct mmvq_args {
     //   2: px quantized by every workgroup itself
     //   3: silu(px[i]) * px[K + i] quantized by every workgroup itself (px = [gate | up], BaseMLP::forward)
     int pro; const float * px; const float * pw; float eps;
+    // epilogue 1 (Q4_K decode launches): rows 2u / 2u+1 are the gate / up projections of feature u (the runner interleaves
+    // them), dst[u] = silu(gate_u) * up_u   (BaseMLP::forward; polynomial SiLU body only: nrows/2 % 8 == 0)
+    int epi;
 };
 
 __device__ __forceinline__ bool mmvq_select(const mmvq_args & a, const char *& W, const char *& act, float *& dst) {
@@ -79,13 +82,15 @@ __device__ __forceinline__ void build_act(char * lds, const mmvq_args & a, const
     // prefetch is issued: a wave's loads return in order, so an activation load issued behind the prefetch would wait for
     // all of it, and straight-line loads keep the compiler's vmcnt bookkeeping exact.
     // (NPRE = 1 covers K <= 4096 with 1024 threads, NPRE = 4 K <= 16384; longer rows fall through to the tail loop)
-    const float * gp = a.pro == 1 ? a.pw : a.pro == 3 ? a.px + K : a.px;
+    // pro 3: px holds interleaved (gate_e, up_e) pairs -- two 16-byte loads cover this thread's four features
+    const float * vp = a.px; const float * gp = a.pro == 1 ? a.pw : a.pro == 3 ? a.px + 4 : a.px;
+    const int vmul = a.pro == 3 ? 2 : 1;
     f32x4 vv[NPRE], gg[NPRE];
 #pragma unroll
     for (int u = 0; u < NPRE; u++) {
         const int64_t e = e0 + u * estep, ec = e < K ? e : 0;
-        vv[u] = *(const f32x4 *)(a.px + ec);
-        gg[u] = *(const f32x4 *)(gp + ec);
+        vv[u] = *(const f32x4 *)(vp + ec * vmul);
+        gg[u] = *(const f32x4 *)(gp + ec * vmul);
     }
     after_first_loads();
     float scale = 1.0f;
@@ -100,6 +105,8 @@ __device__ __forceinline__ void build_act(char * lds, const mmvq_args & a, const
     const int64_t nv = K & ~(int64_t) 7;                      // ggml_vec_silu_f32: polynomial body below nv, libm tail
     auto emit = [&](int64_t e, f32x4 v, f32x4 g) {
         if (a.pro == 3) {
+            const f32x4 p0 = v, p1 = g;                       // (g0, u0, g1, u1), (g2, u2, g3, u3)
+            v = f32x4{p0.x, p0.z, p1.x, p1.z}; g = f32x4{p0.y, p0.w, p1.y, p1.w};
             v.x = silu_gate(v.x, e + 0 < nv) * g.x; v.y = silu_gate(v.y, e + 1 < nv) * g.y;
             v.z = silu_gate(v.z, e + 2 < nv) * g.z; v.w = silu_gate(v.w, e + 3 < nv) * g.w;
         }
@@ -111,16 +118,16 @@ __device__ __forceinline__ void build_act(char * lds, const mmvq_args & a, const
         const int64_t e = e0 + u * estep;
         if (e < K) emit(e, vv[u], gg[u]);
     }
-    for (int64_t e = e0 + NPRE * estep; e < K; e += estep) emit(e, *(const f32x4 *)(a.px + e), *(const f32x4 *)(gp + e));
+    for (int64_t e = e0 + NPRE * estep; e < K; e += estep) emit(e, *(const f32x4 *)(vp + e * vmul), *(const f32x4 *)(gp + e * vmul));
 }
 
 
 // ---- Q4_K -----------------------------------------------------------------------------------------------
 // The (row, step) pairs a wave owns form one linear sequence of steps (a step = 8 super-blocks = 1152 contiguous bytes);
 // the loads of the first P steps are issued BEFORE the activation prologue and every consumed step immediately re-issues
-// the load P steps ahead.  Decode launches use P = 8 with one 1024-thread workgroup per CU: a 4096x4096 matrix is then
-// 2 steps per wave -- the whole matrix is in flight before the prologue starts -- and even gate|up (14 steps per wave)
-// has 9 MB per XCD outstanding at any time.  Accumulation order inside a row does not depend on P.
+// the load P steps ahead.  Decode launches use P = 2 with one 1024-thread workgroup per CU (measured: deeper prefetch is
+// SLOWER on MI355X -- 4 steps -2 %, 8 steps -15 % tokens/s -- more requests in flight than the memory system wants).
+// Accumulation order inside a row does not depend on P.
 template <int NC, int P, bool FUSED, int NPRE = 4>
 __global__ void __launch_bounds__(1024) k_mmvq_q4_K(const mmvq_args a) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -135,22 +142,32 @@ __global__ void __launch_bounds__(1024) k_mmvq_q4_K(const mmvq_args a) {
     const int grp  = lane >> 3;            // which of the 8 super-blocks of this step
     const int j    = lane & 7;             // which 16-byte slice of qs / which min
     const int waves_per_wg = blockDim.x >> 6;
-    const int64_t wave0 = (int64_t) blockIdx.x * waves_per_wg + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);     // scalar
+    const int wave_in_wg = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);                                           // scalar
     const int64_t nwaves = (int64_t) gridDim.x * waves_per_wg;
     const int S = (nblk + 7) >> 3;         // steps per row
+
+    // A wave owns `units`: one row, or (epilogue 1) the gate / up row pair of one feature.  Units are dealt in rounds of
+    // nwaves: in a full round wave (b, w) takes unit round*nwaves + 16 b + w (a workgroup streams 16 consecutive rows); the
+    // last, partial round is dealt workgroup-interleaved (w * gridDim + b) so that every CU gets the same share of it.
+    const int RU = a.epi == 1 ? 2 : 1;
+    const int64_t nunits = nrows / RU;
+    const int64_t kfull = nunits / nwaves, nrem = nunits - kfull * nwaves;
+    const int64_t lin = (int64_t) blockIdx.x * waves_per_wg + wave_in_wg, alt = (int64_t) wave_in_wg * gridDim.x + blockIdx.x;
+    const int64_t nmine = kfull + (alt < nrem ? 1 : 0);                    // units of this wave
+    auto unit_of = [&](int64_t k) { return k * nwaves + (k < kfull ? lin : alt); };
 
     // Loads are unconditional (out-of-range steps re-read block 0 of row 0 and are masked when consumed) so that the loop
     // body is straight-line code and the compiler's s_waitcnt vmcnt(N) counts stay exact: a consumed step waits for its
     // own two loads only, not for the 2 (P - 1) younger ones.
     u32x4 hh[P], qq[P];
-    int64_t irow = wave0; int is = 0;      // issue cursor
+    int64_t ik = 0; int isub = 0, is = 0;      // issue cursor: (unit ordinal, row of the unit, step of the row)
     auto issue = [&](u32x4 & h, u32x4 & q) {
         const int b = 8 * is + grp;
-        const bool ok = irow < nrows && b < nblk;
-        const char * bp = ok ? W + irow * nb01 + (int64_t) b * 144 : W;
+        const bool ok = ik < nmine && b < nblk;
+        const char * bp = ok ? W + (unit_of(ik) * RU + isub) * nb01 + (int64_t) b * 144 : W;
         h = *(const u32x4 *) bp;                        // d|dmin, scales[0..3], [4..7], [8..11] (one broadcast request per 8 lanes)
         q = *(const u32x4 *)(bp + 16 + 16 * j);
-        if (++is == S) { is = 0; irow += nwaves; }
+        if (++is == S) { is = 0; if (++isub == RU) { isub = 0; ik++; } }
     };
     build_act<KB, FUSED, NPRE>(lds, a, act, K, rb, NC, [&] {
 #pragma unroll
@@ -167,12 +184,13 @@ __global__ void __launch_bounds__(1024) k_mmvq_q4_K(const mmvq_args a) {
     float accd[NC], accm[NC];
 #pragma unroll
     for (int c = 0; c < NC; c++) { accd[c] = 0.0f; accm[c] = 0.0f; }
-    int64_t crow = wave0; int cs = 0;      // consume cursor
-    while (crow < nrows) {
+    int64_t ck = 0; int csub = 0, cs = 0;      // consume cursor
+    float gate = 0.0f;
+    while (ck < nmine) {
 #pragma unroll
         for (int p = 0; p < P; p++) {
             const int b = 8 * cs + grp;
-            const bool ok = crow < nrows && b < nblk;
+            const bool ok = ck < nmine && b < nblk;
             const int bb = ok ? b : 0;     // in-range LDS addresses for masked steps
             {
                 const u32x4 h = hh[p], q = qq[p];
@@ -206,17 +224,24 @@ __global__ void __launch_bounds__(1024) k_mmvq_q4_K(const mmvq_args a) {
             }
             issue(hh[p], qq[p]);
             if (++cs == S) {                // row complete: reduce over the wave, epilogue, store
+                const int64_t cunit = unit_of(ck), crow = cunit * RU + csub;
 #pragma unroll
                 for (int c = 0; c < NC; c++) {
                     float v = wave_sum(accd[c]) - wave_sum(accm[c]);
-                    if (crow < nrows) {     // wave-uniform; bias / resid come through the scalar cache (their own counter)
-                        if (a.bias)  v = v + uniform_load_f32(a.bias + crow);
-                        if (a.resid) v = v + uniform_load_f32(a.resid + crow + c * dst_cs);
-                        if (lane == 0) dst[crow + c * dst_cs] = v;
+                    if (ck < nmine) {   // wave-uniform; bias / resid come through the scalar cache (their own counter)
+                        if (FUSED && NC == 1 && a.epi == 1) {
+                            if (csub == 0) gate = v;
+                            else if (lane == 0) dst[cunit] = (gate / (1.0f + ggml_expf_poly(0.0f - gate))) * v;
+                        } else {
+                            if (a.bias)  v = v + uniform_load_f32(a.bias + crow);
+                            if (a.resid) v = v + uniform_load_f32(a.resid + crow + c * dst_cs);
+                            if (lane == 0) dst[crow + c * dst_cs] = v;
+                        }
                     }
                     accd[c] = 0.0f; accm[c] = 0.0f;
                 }
-                cs = 0; crow += nwaves;
+                cs = 0;
+                if (++csub == RU) { csub = 0; ck++; }
             }
         }
     }
@@ -379,7 +404,8 @@ static int launch_one(hipStream_t st, KernelT kern, size_t lds_bytes, const mmvq
     // in-kernel prologues are redundant work per workgroup: use few, fat workgroups (16 waves share one prologue; the
     // RMS_NORM prologue's reduction tree is defined for exactly 1024 threads)
     const int wg = a.pro != 0 ? 1024 : g_mmvq_wg, wpw = wg / 64;
-    int64_t grid = (a.nrows + wpw - 1) / wpw;
+    const int64_t units = a.epi == 1 ? a.nrows / 2 : a.nrows;
+    int64_t grid = (units + wpw - 1) / wpw;
     int64_t cap = (int64_t) device_cu_count() * (a.pro != 0 ? fused_occ : g_mmvq_wgs_per_cu) / grid_y;
     if (cap < 1) cap = 1;
     if (grid > cap) grid = cap;     // (balancing rows per wave exactly was measured slower than simply using more workgroups)
@@ -477,9 +503,10 @@ int launch_mmvq_act(hipStream_t st, int wtype, const void * W, int64_t K, int64_
 
 // decode mat-vec with the activation produced inside the kernel:
 //   pro 1: act = quantize(rms_norm(px) * pw)     pro 2: act = quantize(px)
-//   pro 3: act = quantize(silu(px[0..K)) * px[K..2K))
+//   pro 3: act = quantize(silu(px[2i]) * px[2i+1]), i < K
+//   epi 1: W rows alternate gate_u, up_u; dst[u] = silu(W[2u].act) * (W[2u+1].act), u < nrows / 2
 int launch_mmvq_fused(hipStream_t st, int wtype, const void * W, int64_t K, int64_t nrows, int pro, const float * px, const float * pw, float eps,
-                      float * dst, const float * bias, const float * resid) {
+                      int epi, float * dst, const float * bias, const float * resid) {
     const int kb = wtype == CLLM_TYPE_Q4_K ? 256 : 32;
     if (K % kb || (kb == 32 && K % 32)) FAIL(CLLM_E_UNSUPPORTED, "mmvq_fused: K must be a multiple of the activation block");
     const size_t rb = act_row_bytes(K, kb);
@@ -487,6 +514,7 @@ int launch_mmvq_fused(hipStream_t st, int wtype, const void * W, int64_t K, int6
     mmvq_args a = {};
     a.W = (const char *) W; a.nb01 = (int64_t) cllm_row_size(wtype, K); a.nrows = nrows; a.nblk = (int)(K / kb);
     a.act_stride = rb; a.dst = dst; a.bias = bias; a.resid = resid;
-    a.pro = pro; a.px = px; a.pw = pw; a.eps = eps;
+    a.pro = pro; a.px = px; a.pw = pw; a.eps = eps; a.epi = epi;
+    if (epi == 1 && (wtype != CLLM_TYPE_Q4_K || nrows % 2 || (nrows / 2) % 8 || bias || resid)) FAIL(CLLM_E_UNSUPPORTED, "mmvq_fused: SiLU epilogue needs Q4_K gate/up row pairs, features %% 8 == 0");
     return mmvq_dispatch(st, wtype, 1, rb, a, 1);
 }

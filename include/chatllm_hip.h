@@ -101,10 +101,11 @@ CLLM_API int    cllm_bench_mul_mat_kernel(void * stream, const cllm_tensor * src
                                           const cllm_tensor * src1, cllm_tensor * dst, void * wdata, size_t wsize, int iters, float * avg_us);
 
 /* same, for the decode form of the mat-vec (single column, the activation is produced inside the kernel):
- *   pro 1: act = quantize(rms_norm(px[0..K)) * pw)   pro 2: act = quantize(px)   pro 3: act = quantize(silu(px[0..K)) * px[K..2K))
- * dst[r] = W[r] . act (+ resid[r]).  These are the launches cllm_llama_decode_* issues per layer. */
+ *   pro 1: act = quantize(rms_norm(px[0..K)) * pw)   pro 2: act = quantize(px)   pro 3: act = quantize(silu(px[2i]) * px[2i+1])
+ * dst[r] = W[r] . act (+ resid[r]);  epi 1: W rows alternate gate_u, up_u and dst[u] = silu(W[2u].act) * (W[2u+1].act).
+ * These are the launches cllm_llama_decode_* issues per layer. */
 CLLM_API int    cllm_bench_gemv_fused(void * stream, int wtype, void * const * w_datas, int n_w, int64_t K, int64_t nrows, int pro,
-                                      const float * px, const float * pw, float eps, float * dst, const float * resid, int iters, float * avg_us);
+                                      const float * px, const float * pw, float eps, int epi, float * dst, const float * resid, int iters, float * avg_us);
 
 /* GGML_OP_MUL_MAT_ID -- ggml_compute_forward_mul_mat_id (ggml-cpu.c:1432-1678), chatllm MultiLinear::forward
  * (src/layers.cpp:2145-2151):  dst[:, s, t] = as[:, :, ids[s,t]]^T . b[:, s % b.ne1, t]              */

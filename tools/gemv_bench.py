@@ -19,7 +19,8 @@ SHAPES = [("qkv", 4096, 6144), ("o", 4096, 4096), ("gate_up", 4096, 28672), ("do
           ("q72_down_q8", 29568, 8192)]
 
 
-FUSED = [("qkv", 4096, 6144, 1, False), ("o", 4096, 4096, 2, True), ("gate_up", 4096, 28672, 1, False), ("down", 14336, 4096, 3, True),
+FUSED = [("qkv", 4096, 6144, 1, False), ("o", 4096, 4096, 2, True), ("gate_up", 4096, 28672, 1, False), ("gate_up_silu", 4096, 28672, 1, False),
+         ("down", 14336, 4096, 3, True), ("down_q", 14336, 4096, 2, True),
          ("lm_head", 4096, 128256, 1, False)]
 
 
@@ -34,7 +35,7 @@ def run_fused(types, iters, hot=False, force_pro=0, only=""):
         for name, K, N, pro, resid in FUSED:
             if only and name not in only.split(","):
                 continue
-            if force_pro and pro != 3:
+            if force_pro and pro == 1:
                 pro = force_pro
             nbytes = N * pkg.tensor.row_size(t, K)
             n_copies = 1 if hot else max(2, int(1.2 * 2**30 // nbytes) + 1)
@@ -46,7 +47,7 @@ def run_fused(types, iters, hot=False, force_pro=0, only=""):
             r = pkg.Tensor.from_numpy(rng.standard_normal((1, N)).astype(np.float32))
             ptrs = (C.c_void_p * n_copies)(*[w.data_ptr().value for w in ws])
             us = C.c_float()
-            pkg.lib.check(L.cllm_bench_gemv_fused(None, t, ptrs, n_copies, K, N, pro, x.data_ptr(), g.data_ptr(), 1e-5, y.data_ptr(),
+            pkg.lib.check(L.cllm_bench_gemv_fused(None, t, ptrs, n_copies, K, N, pro, x.data_ptr(), g.data_ptr(), 1e-5, 1 if name == "gate_up_silu" else 0, y.data_ptr(),
                                                   r.data_ptr() if resid else None, iters, C.byref(us)), "bench")
             gbs = nbytes / (us.value * 1e-6) / 1e9
             print(f"fused {tn:5s} {name:9s} K={K:6d} N={N:6d} pro={pro} {nbytes/1e6:8.1f} MB {us.value:9.2f} us {gbs:8.1f} GB/s  {gbs/80:5.1f}% of 8TB/s  "
