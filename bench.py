@@ -83,7 +83,8 @@ def build_model(pkg, cfg, wtype, rank, world):
 
 
 def measure_dominant_kernel(pkg, cfg, wtype, iters=64):
-    """gate|up GEMV (28672 x 4096 for Llama-3-8B): avg launch duration from HIP events on the launch stream.
+    """the decode step's gate/up mat-vec exactly as the runner launches it (RMS_NORM + quantize prologue, 2*ffn x hidden
+    weight rows, SiLU(gate)*up epilogue for Q4_K): avg launch duration from HIP events on the launch stream.
     Cycles through enough distinct weight copies to defeat the 256 MiB Infinity Cache."""
     L = pkg.lib.get()
     H, F = cfg["hidden"], cfg["ffn"]
@@ -95,18 +96,18 @@ def measure_dominant_kernel(pkg, cfg, wtype, iters=64):
     ws = []
     for _ in range(n_copies):
         ws.append(pkg.Tensor.from_numpy(w0, wtype, [H, rows]))
-    x = pkg.Tensor.from_numpy(np.random.default_rng(0).standard_normal((1, H)).astype(np.float32))
+    rng = np.random.default_rng(0)
+    x = pkg.Tensor.from_numpy(rng.standard_normal((1, H)).astype(np.float32))
+    g = pkg.Tensor.from_numpy((1 + 0.1 * rng.standard_normal((1, H))).astype(np.float32))
     y = pkg.Tensor(pkg.F32, [rows, 1])
-    cw, cx, cy = ws[0].c(), x.c(), y.c()
-    wsize = L.cllm_mul_mat_wsize(C.byref(cw), C.byref(cx))
-    scratch = pkg.tensor.Buffer(wsize + 256)
     ptrs = (C.c_void_p * n_copies)(*[w.data_ptr().value for w in ws])
     us = C.c_float()
-    pkg.lib.check(L.cllm_bench_mul_mat_kernel(None, C.byref(cw), ptrs, n_copies, C.byref(cx), C.byref(cy), scratch.ptr, scratch.nbytes,
-                                              iters, C.byref(us)), "bench_mul_mat_kernel")
+    epi = 1 if (wtype == 12 and F % 8 == 0) else 0
+    pkg.lib.check(L.cllm_bench_gemv_fused(None, wtype, ptrs, n_copies, H, rows, 1, x.data_ptr(), g.data_ptr(), cfg["rms_eps"], epi, y.data_ptr(), None,
+                                          iters, C.byref(us)), "bench_gemv_fused")
     dur_s = us.value / 1e6
-    return {"kernel": "k_mmvq_q4_K<1> (gate|up GEMV %dx%d)" % (rows, H) if wtype == 12 else "k_mmvq_q32 (gate|up GEMV %dx%d)" % (rows, H),
-            "bytes_per_launch": nbytes, "avg_us": dur_s * 1e6, "gbs": nbytes / dur_s / 1e9}
+    name = "k_mmvq_q4_K<1, 2, true, 1>" if wtype == 12 else "k_mmvq_q32<1, %s, true>" % ("true" if wtype == 8 else "false")
+    return {"kernel": "%s (gate/up GEMV %dx%d, decode form)" % (name, rows, H), "bytes_per_launch": nbytes, "avg_us": dur_s * 1e6, "gbs": nbytes / dur_s / 1e9}
 
 
 def pmc_traffic(kernel_label):
@@ -117,7 +118,7 @@ def pmc_traffic(kernel_label):
         with open(os.path.join(ROOT, "profiles", "r01_pmc_summary.json")) as f:
             tab = json.load(f)
         for k, v in tab.items():
-            if k.startswith("k_mmvq_q4_K<1> gate|up") and "k_mmvq_q4_K<1> (gate|up GEMV 28672x4096)" == kernel_label:
+            if k == kernel_label:
                 return v["hbm_read_bytes"]
     except Exception:
         pass

@@ -132,6 +132,15 @@ __device__ __forceinline__ double rms_block_sumsq_1024(const float * __restrict_
     return tot;
 }
 
+// scale = 1 / sqrt(sum / n + eps) exactly as ops.cpp:3731-3736 (double division, float sqrt, float division).  For a power
+// of two n the division is an exact exponent shift: multiply by 1/n instead (same bits, ~25 instructions less on the
+// decode kernels' cold critical path); the general division sits in a noinline function off the straight-line code.
+static __device__ __noinline__ double rms_div(double sum, double n) { return sum / n; }
+__device__ __forceinline__ float rms_scale(double sum, int64_t n, float eps) {
+    const double m = (n & (n - 1)) == 0 ? sum * (1.0 / (double) n) : rms_div(sum, (double) n);
+    return 1.0f / sqrtf((float) m + eps);
+}
+
 // load through the scalar cache (p must be wave-uniform; the data must not have been written by this kernel before).
 // Scalar loads have their own counter (lgkmcnt), so they do not serialise against outstanding vector-memory prefetches.
 __device__ __forceinline__ float uniform_load_f32(const float * p) {
@@ -212,6 +221,7 @@ int launch_mmq(hipStream_t st, int wtype, const tview & w, const void * act, siz
 int launch_mul_mat_f(hipStream_t st, int wtype, const tview & w, const tview & x, const tview & dst);
 int device_cu_count();
 int launch_mmvq_act(hipStream_t st, int wtype, const void * W, int64_t K, int64_t nrows, const void * act, float * dst, const float * bias, const float * resid);
+int launch_gemv_q4_K_decode(hipStream_t st, const void * W, int64_t K, int64_t nrows, int pro, const float * px, const float * pw, float eps, int epi, float * dst, const float * bias, const float * resid);
 int launch_mmvq_fused(hipStream_t st, int wtype, const void * W, int64_t K, int64_t nrows, int pro, const float * px, const float * pw, float eps, int epi, float * dst, const float * bias, const float * resid);
 int launch_attn_decode(hipStream_t st, const float * qkv, const int32_t * pos_dev, int nh, int nkv, int hd, const uint16_t * k_cache, const uint16_t * v_cache, int64_t ML, float * att);
 int launch_rope_kv_attn_decode(hipStream_t st, const float * qkv, const int32_t * pos_dev, int nh, int nkv, int hd, int mode, float freq_base, uint16_t * k_cache, uint16_t * v_cache, int64_t ML, float * att);

@@ -1,0 +1,165 @@
+// gemv_decode.hip -- the decode step's Q4_K mat-vec: one activation column, produced inside the kernel.
+//
+//   prologue PRO 1: act = quantize_q8_K(RMS_NORM(px) * pw)     (LMBlock1Forward: input_layernorm / post_attention_layernorm -> Linear)
+//            PRO 2: act = quantize_q8_K(px)                    (attention output -> o_proj, SiLU*up -> down_proj)
+//            PRO 3: act = quantize_q8_K(silu(px[2i]) * px[2i+1])  (interleaved gate/up pairs -> down_proj, BaseMLP::forward)
+//   epilogue EPI 1: W rows alternate gate_u, up_u; dst[u] = silu(W[2u].act) * (W[2u+1].act)
+//   dst[r] = W[r] . act (+ bias[r]) (+ resid[r])               (Linear::forward src/layers.cpp:2111-2129, residual adds :2740,:2758)
+// Same arithmetic as RMS_NORM -> MUL -> quantize_row_q8_K -> MUL_MAT (-> ADD) on the node-by-node path, bit for bit:
+// the reductions (rms_block_sumsq_1024, quant4_q8_K, q4k_step, wave_sum) are the shared definitions.
+//
+// What shapes this kernel (measured with the in-kernel stamps of tools/gemv_phase_probe.py):
+//   * a launch starts with a cold instruction cache and its instruction fetches queue behind its own weight stream, so
+//     everything before the main loop is kept short: the prologue is a template parameter (no code for the others), nothing
+//     is divided at run time (the dealing of rows to waves is precomputed on the host), the arguments are individual
+//     kernel parameters in the order they are needed;
+//   * the activation loads are issued first, then two steps of weight prefetch, then the prologue computes while they fly
+//     (a deeper burst only delays the prologue: 16 waves x 16 loads take 1.7 us just to issue);
+//   * one 1024-thread workgroup per CU: 16 waves share one prologue; steady state keeps two steps per wave in flight and
+//     streams at ~6.2 TB/s.
+#include "common.h"
+#include "quant_dev.h"
+#include "q4k.h"
+
+static unsigned long long * g_gemv_ts = nullptr;
+extern "C" __attribute__((visibility("default"))) void cllm_debug_set_mmvq_ts(unsigned long long * dev_buf) { g_gemv_ts = dev_buf; }   // tools only
+
+struct gemv_deal { int nunits, kfull, nrem, nblk; };      // units = rows (or gate/up row pairs); kfull full rounds of nwaves units + nrem
+
+__device__ __forceinline__ float silu_poly(float x) { return x / (1.0f + ggml_expf_poly(0.0f - x)); }
+__device__ __forceinline__ float silu_any(float x, bool body) { return body ? silu_poly(x) : x / (1.0f + libm_expf(-x)); }
+
+#define TS(k) do { if (ts && threadIdx.x == 0) ts[blockIdx.x * 8 + (k)] = wall_clock64(); } while (0)
+
+template <int PRO, int EPI, int NPRE>
+__global__ void __launch_bounds__(1024) k_gemv_q4_K_dec(const float * __restrict__ px, const float * __restrict__ pw, const char * __restrict__ W,
+                                                        const gemv_deal deal, float eps, float * __restrict__ dst, const float * __restrict__ bias,
+                                                        const float * resid, unsigned long long * ts) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    constexpr int P = 2, RU = EPI == 1 ? 2 : 1;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int nblk = deal.nblk, K = nblk * 256;
+
+    // ---- (1) this thread's activation groups: unconditional (clamped) loads, issued before anything else ----
+    // pro 3: px holds interleaved (gate_e, up_e) pairs -- two 16-byte loads cover this thread's four features
+    const float * gp = PRO == 1 ? pw : PRO == 3 ? px + 4 : px;
+    constexpr int vmul = PRO == 3 ? 2 : 1;
+    const int e0 = tid * 4;
+    f32x4 vv[NPRE], gg[NPRE];
+#pragma unroll
+    for (int u = 0; u < NPRE; u++) {
+        const int e = e0 + u * 4096, ec = e < K ? e : 0;
+        vv[u] = *(const f32x4 *)(px + ec * vmul);
+        if (PRO != 2) gg[u] = *(const f32x4 *)(gp + ec * vmul);
+    }
+    TS(0);
+
+    // ---- (2) two steps of weight prefetch.  Units are dealt in rounds of nwaves: in a full round wave (b, w) takes unit
+    //          round*nwaves + 16 b + w (a workgroup streams 16 consecutive rows); the last, partial round is dealt
+    //          workgroup-interleaved (w * gridDim + b) so that every CU gets the same share of it. ----
+    const int grp = lane >> 3, j = lane & 7;
+    const int wave_in_wg = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nwaves = gridDim.x * 16;
+    const int lin = blockIdx.x * 16 + wave_in_wg, alt = wave_in_wg * gridDim.x + blockIdx.x;
+    const int nmine = deal.kfull + (alt < deal.nrem ? 1 : 0);
+    const int S = (nblk + 7) >> 3;                                  // steps per row
+    const unsigned nb01 = (unsigned) nblk * 144u;
+    auto unit_of = [&](int k) { return k * nwaves + (k < deal.kfull ? lin : alt); };
+    u32x4 hh[P], qq[P];
+    int ik = 0, isub = 0, is = 0;                                   // issue cursor: (unit ordinal, row of the unit, step of the row)
+    auto issue = [&](u32x4 & h, u32x4 & q) {                        // unconditional: out-of-range steps re-read block 0 and are masked
+        const int b = 8 * is + grp;
+        const bool ok = ik < nmine && b < nblk;
+        const char * bp = W;
+        if (ok) bp = W + (unsigned long long)(unsigned)(unit_of(ik) * RU + isub) * nb01 + (unsigned) b * 144u;
+        h = *(const u32x4 *) bp;
+        q = *(const u32x4 *)(bp + 16 + 16 * j);
+        if (++is == S) { is = 0; if (++isub == RU) { isub = 0; ik++; } }
+    };
+#pragma unroll
+    for (int p = 0; p < P; p++) issue(hh[p], qq[p]);
+    TS(1);
+
+    // ---- (3) the activation row: [RMS_NORM * weight | SiLU * up |] quantize -> LDS (act layout of common.h) ----
+    float scale = 1.0f;
+    if (PRO == 1) {
+        __shared__ double part[16];
+        const double sum = rms_block_sumsq_1024(px, K, vv[0], part);
+        scale = rms_scale(sum, K, eps);
+    }
+    const int nv = K & ~7;                                          // ggml_vec_silu_f32: polynomial body below nv, libm tail
+#pragma unroll
+    for (int u = 0; u < NPRE; u++) {                                // K % 256 == 0: whole waves stay together
+        const int e = e0 + u * 4096;
+        if (e < K) {
+            f32x4 v = vv[u];
+            if (PRO == 3) {
+                const f32x4 p0 = vv[u], p1 = gg[u];                 // (g0, u0, g1, u1), (g2, u2, g3, u3)
+                v.x = silu_any(p0.x, e + 0 < nv) * p0.y; v.y = silu_any(p0.z, e + 1 < nv) * p0.w;
+                v.z = silu_any(p1.x, e + 2 < nv) * p1.y; v.w = silu_any(p1.z, e + 3 < nv) * p1.w;
+            }
+            if (PRO == 1) { const f32x4 g = gg[u]; v.x = (v.x * scale) * g.x; v.y = (v.y * scale) * g.y; v.z = (v.z * scale) * g.z; v.w = (v.w * scale) * g.w; }
+            quant4_store<256>(lds, K, e, lane, v);
+        }
+    }
+    TS(2);
+    __syncthreads();
+    TS(3);
+
+    // ---- (4) stream the rows ----
+    const q4k_sel L = q4k_lane_sel(lane);
+    const int off_d = (int) act_off_d(K), off_s = (int) act_off_s(K, 256);
+    float accd = 0.0f, accm = 0.0f, gate = 0.0f;
+    int ck = 0, csub = 0, cs = 0;                                   // consume cursor
+    while (ck < nmine) {
+#pragma unroll
+        for (int p = 0; p < P; p++) {
+            const int b = 8 * cs + grp;
+            const bool ok = ck < nmine && b < nblk;
+            q4k_step(hh[p], qq[p], lds, off_d, off_s, ok ? b : 0, ok, L, accd, accm);
+            issue(hh[p], qq[p]);
+            if (++cs == S) {                                        // row complete: reduce over the wave, epilogue, store
+                float v = wave_sum(accd) - wave_sum(accm);
+                if (ck < nmine) {                                   // wave-uniform; bias / resid come through the scalar cache
+                    const int cunit = unit_of(ck), crow = cunit * RU + csub;
+                    if (EPI == 1) {
+                        if (csub == 0) gate = v;
+                        else if (lane == 0) dst[cunit] = silu_poly(gate) * v;
+                    } else {
+                        if (bias)  v = v + uniform_load_f32(bias + crow);
+                        if (resid) v = v + uniform_load_f32(resid + crow);
+                        if (lane == 0) dst[crow] = v;
+                    }
+                }
+                accd = 0.0f; accm = 0.0f; cs = 0;
+                if (++csub == RU) { csub = 0; ck++; }
+            }
+        }
+    }
+    TS(4);
+    if (ts) { __syncthreads(); TS(5); }
+}
+#undef TS
+
+// K multiple of 256, K <= 16384, nrows * row bytes < 4 GiB; returns CLLM_E_UNSUPPORTED for shapes the general kernels must take
+int launch_gemv_q4_K_decode(hipStream_t st, const void * W, int64_t K, int64_t nrows, int pro, const float * px, const float * pw, float eps,
+                            int epi, float * dst, const float * bias, const float * resid) {
+    if (K % 256 || K > 16384 || pro < 1 || pro > 3 || nrows <= 0 || (uint64_t) nrows * (uint64_t)(K / 256 * 144) >= (1ull << 32)) return CLLM_E_UNSUPPORTED;
+    if (epi == 1 && (pro != 1 || nrows % 2 || (nrows / 2) % 8 || bias || resid)) FAIL(CLLM_E_UNSUPPORTED, "gemv_decode: SiLU epilogue needs gate/up row pairs, features %% 8 == 0");
+    const int64_t units = epi == 1 ? nrows / 2 : nrows;
+    int64_t grid = (units + 15) / 16;
+    if (grid > device_cu_count()) grid = device_cu_count();
+    const int64_t nwaves = grid * 16;
+    gemv_deal deal;
+    deal.nunits = (int) units; deal.kfull = (int)(units / nwaves); deal.nrem = (int)(units % nwaves); deal.nblk = (int)(K / 256);
+    const size_t lds = act_row_bytes(K, 256);
+    const bool small = K <= 4096;
+#define GO(PRO_, EPI_, NPRE_) hipLaunchKernelGGL((k_gemv_q4_K_dec<PRO_, EPI_, NPRE_>), dim3((unsigned) grid), dim3(1024), lds, st, px, pw, (const char *) W, deal, eps, dst, bias, resid, g_gemv_ts)
+    if (pro == 1 && epi == 1) { if (small) GO(1, 1, 1); else GO(1, 1, 4); }
+    else if (pro == 1)        { if (small) GO(1, 0, 1); else GO(1, 0, 4); }
+    else if (pro == 2)        { if (small) GO(2, 0, 1); else GO(2, 0, 4); }
+    else                      { if (small) GO(3, 0, 1); else GO(3, 0, 4); }
+#undef GO
+    LAUNCH_CHECK();
+    return CLLM_OK;
+}

@@ -18,11 +18,11 @@
 // One wave owns one weight row at a time; rows are dealt round-robin to the waves of the grid.
 #include "common.h"
 #include "quant_dev.h"
+#include "q4k.h"
 
 static int g_mmvq_wg = 256;      // threads per workgroup (tunable: CLLM_MMVQ_WG)
 static int g_mmvq_wgs_per_cu = 8; // grid cap (tunable: CLLM_MMVQ_OCC)
-static int g_mmvq_fused_occ = 1;  // fused-prologue (decode) launches with K <= 4096: 1024-thread workgroups per CU (tunable: CLLM_MMVQ_FOCC)
-static int g_mmvq_depth = 2;      // prefetch depth of the decode launches: 4, 2 or 1 steps (tunable: CLLM_MMVQ_DEPTH)
+static int g_mmvq_burst = 8;      // decode launches: weight steps prefetched before the prologue, 2 / 4 / 8 (tunable: CLLM_MMVQ_BURST)
 
 // kernel arguments; `ids` != NULL turns the launch into MUL_MAT_ID: blockIdx.y enumerates (slot u, token t) pairs,
 // each with its own expert matrix (ggml-cpu.c:1432-1678).
@@ -43,6 +43,7 @@ struct mmvq_args {
     // epilogue 1 (Q4_K decode launches): rows 2u / 2u+1 are the gate / up projections of feature u (the runner interleaves
     // them), dst[u] = silu(gate_u) * up_u   (BaseMLP::forward; polynomial SiLU body only: nrows/2 % 8 == 0)
     int epi;
+    unsigned long long * ts;                       // tools only: per-workgroup phase timestamps (cllm_debug_set_mmvq_ts), else NULL
 };
 
 __device__ __forceinline__ bool mmvq_select(const mmvq_args & a, const char *& W, const char *& act, float *& dst) {
@@ -73,9 +74,12 @@ __device__ __forceinline__ float silu_gate(float x, bool body) { return body ? x
 // `after_first_loads` runs right after this thread's first activation loads have been ISSUED and before anything waits
 // on them: the Q4_K kernel issues its weight prefetch there, so the HBM latency of the weights overlaps the whole prologue
 // (the activation loads are older in program order, so the s_waitcnt for them does not wait for the weights).
-template <int KIND, bool FUSED, int NPRE, typename F>
+// PRO >= 0 fixes the prologue at compile time (a launch fetches its code cold -- ~1 us per KB of straight-line code on
+// the critical path -- so a decode kernel must not carry the prologues it does not run); PRO = -1 reads a.pro.
+template <int KIND, int PRO, int NPRE, typename F>
 __device__ __forceinline__ void build_act(char * lds, const mmvq_args & a, const char * act, int64_t K, size_t rb, int nc, F && after_first_loads) {
-    if constexpr (!FUSED) { after_first_loads(); stage_act(lds, act, a.act_stride, rb, nc); return; }   // a.pro == 0 by construction
+    const int pro = PRO >= 0 ? PRO : a.pro;
+    if (pro == 0) { after_first_loads(); stage_act(lds, act, a.act_stride, rb, nc); return; }
     const int tid = threadIdx.x, lane = tid & 63;
     const int64_t e0 = (int64_t) tid * 4, estep = (int64_t) blockDim.x * 4;
     // This thread's first NPRE activation groups are loaded unconditionally (clamped, pointer-selected) BEFORE the weight
@@ -83,42 +87,42 @@ __device__ __forceinline__ void build_act(char * lds, const mmvq_args & a, const
     // all of it, and straight-line loads keep the compiler's vmcnt bookkeeping exact.
     // (NPRE = 1 covers K <= 4096 with 1024 threads, NPRE = 4 K <= 16384; longer rows fall through to the tail loop)
     // pro 3: px holds interleaved (gate_e, up_e) pairs -- two 16-byte loads cover this thread's four features
-    const float * vp = a.px; const float * gp = a.pro == 1 ? a.pw : a.pro == 3 ? a.px + 4 : a.px;
-    const int vmul = a.pro == 3 ? 2 : 1;
+    const float * vp = a.px; const float * gp = pro == 1 ? a.pw : pro == 3 ? a.px + 4 : a.px;
+    const int vmul = pro == 3 ? 2 : 1;
     f32x4 vv[NPRE], gg[NPRE];
 #pragma unroll
     for (int u = 0; u < NPRE; u++) {
         const int64_t e = e0 + u * estep, ec = e < K ? e : 0;
         vv[u] = *(const f32x4 *)(vp + ec * vmul);
-        gg[u] = *(const f32x4 *)(gp + ec * vmul);
+        if (pro != 2) gg[u] = *(const f32x4 *)(gp + ec * vmul);
     }
     after_first_loads();
     float scale = 1.0f;
-    if (a.pro == 1) {
+    if (pro == 1) {
         // sum of squares: the 1024-thread partition and reduction tree of k_rms_norm (ops.hip), so that the fused and the
         // node-by-node paths agree to the bit
         __shared__ double part[16];
         const double sum = rms_block_sumsq_1024(a.px, K, vv[0], part);
-        const float mean = (float)(sum / (double) K);
-        scale = 1.0f / sqrtf(mean + a.eps);
+        scale = rms_scale(sum, K, a.eps);
     }
     const int64_t nv = K & ~(int64_t) 7;                      // ggml_vec_silu_f32: polynomial body below nv, libm tail
     auto emit = [&](int64_t e, f32x4 v, f32x4 g) {
-        if (a.pro == 3) {
+        if (pro == 3) {
             const f32x4 p0 = v, p1 = g;                       // (g0, u0, g1, u1), (g2, u2, g3, u3)
             v = f32x4{p0.x, p0.z, p1.x, p1.z}; g = f32x4{p0.y, p0.w, p1.y, p1.w};
             v.x = silu_gate(v.x, e + 0 < nv) * g.x; v.y = silu_gate(v.y, e + 1 < nv) * g.y;
             v.z = silu_gate(v.z, e + 2 < nv) * g.z; v.w = silu_gate(v.w, e + 3 < nv) * g.w;
         }
-        if (a.pro == 1) { v.x = (v.x * scale) * g.x; v.y = (v.y * scale) * g.y; v.z = (v.z * scale) * g.z; v.w = (v.w * scale) * g.w; }
+        if (pro == 1) { v.x = (v.x * scale) * g.x; v.y = (v.y * scale) * g.y; v.z = (v.z * scale) * g.z; v.w = (v.w * scale) * g.w; }
         quant4_store<KIND>(lds, K, e, lane, v);
     };
 #pragma unroll
     for (int u = 0; u < NPRE; u++) {                          // K % 256 == 0 (% 32 for Q8_0 acts): whole lane groups stay together
         const int64_t e = e0 + u * estep;
-        if (e < K) emit(e, vv[u], gg[u]);
+        if (e < K) emit(e, vv[u], pro != 2 ? gg[u] : vv[u]);
     }
-    for (int64_t e = e0 + NPRE * estep; e < K; e += estep) emit(e, *(const f32x4 *)(vp + e * vmul), *(const f32x4 *)(gp + e * vmul));
+    if (NPRE != 1)                                            // NPRE == 1 is only dispatched for K <= 4096
+        for (int64_t e = e0 + NPRE * estep; e < K; e += estep) emit(e, *(const f32x4 *)(vp + e * vmul), *(const f32x4 *)(gp + e * vmul));
 }
 
 
@@ -128,12 +132,19 @@ __device__ __forceinline__ void build_act(char * lds, const mmvq_args & a, const
 // the load P steps ahead.  Decode launches use P = 2 with one 1024-thread workgroup per CU (measured: deeper prefetch is
 // SLOWER on MI355X -- 4 steps -2 %, 8 steps -15 % tokens/s -- more requests in flight than the memory system wants).
 // Accumulation order inside a row does not depend on P.
-template <int NC, int P, bool FUSED, int NPRE = 4>
+#define TS(k) do { if (FUSED && a.ts && threadIdx.x == 0) a.ts[blockIdx.x * 8 + (k)] = wall_clock64(); } while (0)
+// PRO = 0: plain launch (activation rows quantized by k_quantize_*, NC columns, optional MUL_MAT_ID expert selection);
+// PRO = 1..3: decode launch, single column, the activation row is produced by the prologue; EPI = 1: SiLU(gate)*up epilogue
+// PP >= P: steps prefetched before the prologue (the memory system is idle then, so a deep burst is free), P: steps kept
+// in flight in steady state (deeper is slower, see above).
+template <int NC, int P, int PRO, int EPI = 0, int NPRE = 4, int PP = P>
 __global__ void __launch_bounds__(1024) k_mmvq_q4_K(const mmvq_args a) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
+    constexpr bool FUSED = PRO != 0;
+    TS(0);
     constexpr int KB = 256;
-    const char * W; const char * act; float * dst;
-    if (!mmvq_select(a, W, act, dst)) return;
+    const char * W = a.W; const char * act = a.act; float * dst = a.dst;
+    if (!FUSED) { if (!mmvq_select(a, W, act, dst)) return; }
     const int64_t nb01 = a.nb01, nrows = a.nrows, dst_cs = a.dst_cs; const int nblk = a.nblk;
     const int64_t K = (int64_t) nblk * 256;
     const size_t  rb = act_row_bytes(K, 256);
@@ -149,7 +160,7 @@ __global__ void __launch_bounds__(1024) k_mmvq_q4_K(const mmvq_args a) {
     // A wave owns `units`: one row, or (epilogue 1) the gate / up row pair of one feature.  Units are dealt in rounds of
     // nwaves: in a full round wave (b, w) takes unit round*nwaves + 16 b + w (a workgroup streams 16 consecutive rows); the
     // last, partial round is dealt workgroup-interleaved (w * gridDim + b) so that every CU gets the same share of it.
-    const int RU = a.epi == 1 ? 2 : 1;
+    constexpr int RU = EPI == 1 ? 2 : 1;
     const int64_t nunits = nrows / RU;
     const int64_t kfull = nunits / nwaves, nrem = nunits - kfull * nwaves;
     const int64_t lin = (int64_t) blockIdx.x * waves_per_wg + wave_in_wg, alt = (int64_t) wave_in_wg * gridDim.x + blockIdx.x;
@@ -159,77 +170,53 @@ __global__ void __launch_bounds__(1024) k_mmvq_q4_K(const mmvq_args a) {
     // Loads are unconditional (out-of-range steps re-read block 0 of row 0 and are masked when consumed) so that the loop
     // body is straight-line code and the compiler's s_waitcnt vmcnt(N) counts stay exact: a consumed step waits for its
     // own two loads only, not for the 2 (P - 1) younger ones.
-    u32x4 hh[P], qq[P];
+    u32x4 hh[PP], qq[PP];
     int64_t ik = 0; int isub = 0, is = 0;      // issue cursor: (unit ordinal, row of the unit, step of the row)
     auto issue = [&](u32x4 & h, u32x4 & q) {
         const int b = 8 * is + grp;
         const bool ok = ik < nmine && b < nblk;
         const char * bp = ok ? W + (unit_of(ik) * RU + isub) * nb01 + (int64_t) b * 144 : W;
+        // (non-temporal loads were measured 4 % SLOWER here: the header and the quants of a block share cache lines)
         h = *(const u32x4 *) bp;                        // d|dmin, scales[0..3], [4..7], [8..11] (one broadcast request per 8 lanes)
         q = *(const u32x4 *)(bp + 16 + 16 * j);
         if (++is == S) { is = 0; if (++isub == RU) { isub = 0; ik++; } }
     };
-    build_act<KB, FUSED, NPRE>(lds, a, act, K, rb, NC, [&] {
+    build_act<KB, PRO, NPRE>(lds, a, act, K, rb, NC, [&] {
 #pragma unroll
-        for (int p = 0; p < P; p++) issue(hh[p], qq[p]);
+        for (int p = 0; p < PP; p++) issue(hh[p], qq[p]);
+        TS(1);
     });
+    TS(2);
     __syncthreads();
+    TS(3);
 
-    // lane-constant scale selectors (get_scale_min_k4, ggml-quants.c:703-711, after the utmp shuffle of quants.c:577-582)
-    const int sh16 = (j & 2) * 8;          // pair p=j/2: 16-bit field (p&1) of utmp[p>>1]
-    const int sh8  = (j & 3) * 8;          // min j: byte (j&3) of utmp[2 + (j>>2)]
-    const bool hi  = j >= 4;
-    const int a_off = 64 * (j >> 1) + 16 * (j & 1);     // activation bytes for the low-nibble half; +32 for the high half
+    const q4k_sel L = q4k_lane_sel(lane);
+    const int off_d = (int) act_off_d(K), off_s = (int) act_off_s(K, 256);
 
     float accd[NC], accm[NC];
 #pragma unroll
     for (int c = 0; c < NC; c++) { accd[c] = 0.0f; accm[c] = 0.0f; }
     int64_t ck = 0; int csub = 0, cs = 0;      // consume cursor
     float gate = 0.0f;
+    int cold = PP - P;                         // consumed steps that were covered by the prologue burst: no re-issue for them
     while (ck < nmine) {
 #pragma unroll
-        for (int p = 0; p < P; p++) {
+        for (int p = 0; p < PP; p++) {
             const int b = 8 * cs + grp;
             const bool ok = ck < nmine && b < nblk;
             const int bb = ok ? b : 0;     // in-range LDS addresses for masked steps
-            {
-                const u32x4 h = hh[p], q = qq[p];
-                const float d    = h2f((uint16_t)(h.x & 0xffff));
-                const float dmin = h2f((uint16_t)(h.x >> 16));
-                // 6-bit unpack: u0 = sc[0..3], u1 = sc[4..7], u2 = m[0..3], u3 = m[4..7]
-                const uint32_t u0 = h.y & 0x3f3f3f3fu;
-                const uint32_t u2 = h.z & 0x3f3f3f3fu;
-                const uint32_t u1 = (h.w & 0x0f0f0f0fu) | (((h.y >> 6) & 0x03030303u) << 4);
-                const uint32_t u3 = ((h.w >> 4) & 0x0f0f0f0fu) | (((h.z >> 6) & 0x03030303u) << 4);
-                const uint32_t scp = (hi ? u1 : u0) >> sh16;
-                const int sc_lo = (int)(scp & 0xff), sc_hi = (int)((scp >> 8) & 0xff);
-                const int mj    = (int)(((hi ? u3 : u2) >> sh8) & 0xff);
-                const uint32_t ql[4] = { q.x & 0x0f0f0f0fu, q.y & 0x0f0f0f0fu, q.z & 0x0f0f0f0fu, q.w & 0x0f0f0f0fu };
-                const uint32_t qh[4] = { (q.x >> 4) & 0x0f0f0f0fu, (q.y >> 4) & 0x0f0f0f0fu, (q.z >> 4) & 0x0f0f0f0fu, (q.w >> 4) & 0x0f0f0f0fu };
 #pragma unroll
-                for (int c = 0; c < NC; c++) {
-                    const char * ar = lds + c * rb;
-                    const u32x4 al = *(const u32x4 *)(ar + bb * 256 + a_off);
-                    const u32x4 ah = *(const u32x4 *)(ar + bb * 256 + a_off + 32);
-                    const float yd = ((const float *)(ar + act_off_d(K)))[bb];
-                    const int   ys = ((const int *)(ar + act_off_s(K, 256)))[bb * 8 + j];
-                    int il = dot4(ql[0], al.x, 0); il = dot4(ql[1], al.y, il); il = dot4(ql[2], al.z, il); il = dot4(ql[3], al.w, il);
-                    int ih = dot4(qh[0], ah.x, 0); ih = dot4(qh[1], ah.y, ih); ih = dot4(qh[2], ah.z, ih); ih = dot4(qh[3], ah.w, ih);
-                    const int t = sc_lo * il + sc_hi * ih;
-                    const float nd = __builtin_fmaf(d * yd, (float) t, accd[c]);
-                    const float nm = __builtin_fmaf(dmin * yd, (float)(mj * ys), accm[c]);
-                    accd[c] = ok ? nd : accd[c];
-                    accm[c] = ok ? nm : accm[c];
-                }
-            }
-            issue(hh[p], qq[p]);
+            for (int c = 0; c < NC; c++) q4k_step(hh[p], qq[p], lds + c * rb, off_d, off_s, bb, ok, L, accd[c], accm[c]);
+            if (PP == P) issue(hh[p], qq[p]);
+            else if (cold > 0) cold--;      // (scalar)
+            else issue(hh[(p + P) % PP], qq[(p + P) % PP]);
             if (++cs == S) {                // row complete: reduce over the wave, epilogue, store
                 const int64_t cunit = unit_of(ck), crow = cunit * RU + csub;
 #pragma unroll
                 for (int c = 0; c < NC; c++) {
                     float v = wave_sum(accd[c]) - wave_sum(accm[c]);
                     if (ck < nmine) {   // wave-uniform; bias / resid come through the scalar cache (their own counter)
-                        if (FUSED && NC == 1 && a.epi == 1) {
+                        if (EPI == 1) {
                             if (csub == 0) gate = v;
                             else if (lane == 0) dst[cunit] = (gate / (1.0f + ggml_expf_poly(0.0f - gate))) * v;
                         } else {
@@ -245,12 +232,15 @@ __global__ void __launch_bounds__(1024) k_mmvq_q4_K(const mmvq_args a) {
             }
         }
     }
+    TS(4);
+    if (FUSED && a.ts) { __syncthreads(); TS(5); }
 }
+#undef TS
 
 // ---- Q4_0 / Q8_0 (one lane per 32-weight block) ------------------------------------------------------------
 struct __attribute__((packed, aligned(2))) u16x8_u2 { uint32_t x, y, z, w; };
 
-template <int NC, bool IS_Q8, bool FUSED>
+template <int NC, bool IS_Q8, bool FUSED>        // FUSED: decode launch, prologue chosen at run time by a.pro
 __global__ void __launch_bounds__(1024) k_mmvq_q32(const mmvq_args a) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     constexpr int KB = 32;
@@ -259,7 +249,7 @@ __global__ void __launch_bounds__(1024) k_mmvq_q32(const mmvq_args a) {
     const int64_t nb01 = a.nb01, nrows = a.nrows, dst_cs = a.dst_cs; const int nblk = a.nblk;
     const int64_t K = (int64_t) nblk * 32;
     const size_t  rb = act_row_bytes(K, 32);
-    build_act<KB, FUSED, 4>(lds, a, act, K, rb, NC, [] {});
+    build_act<KB, FUSED ? -1 : 0, 4>(lds, a, act, K, rb, NC, [] {});
     __syncthreads();
 
     constexpr int BS = IS_Q8 ? 34 : 18;
@@ -391,14 +381,13 @@ static void mmvq_tunables() {
     if (done) return;
     done = true;
     if (const char * e = getenv("CLLM_MMVQ_WG"))  { int v = atoi(e); if (v == 64 || v == 128 || v == 256 || v == 512) g_mmvq_wg = v; }
+    if (const char * e = getenv("CLLM_MMVQ_BURST")) { int v = atoi(e); if (v == 2 || v == 4 || v == 8) g_mmvq_burst = v; }
     if (const char * e = getenv("CLLM_MMVQ_OCC")) { int v = atoi(e); if (v >= 1 && v <= 32) g_mmvq_wgs_per_cu = v; }
-    if (const char * e = getenv("CLLM_MMVQ_DEPTH")) { int v = atoi(e); if (v == 1 || v == 2 || v == 4) g_mmvq_depth = v; }
-    if (const char * e = getenv("CLLM_MMVQ_FOCC")) { int v = atoi(e); if (v >= 1 && v <= 2) g_mmvq_fused_occ = v; }
     if (const char * e = getenv("CLLM_MMVQ_WG"))   { int v = atoi(e); if (v == 1024) g_mmvq_wg = v; }
 }
 
 template <typename KernelT>
-static int launch_one(hipStream_t st, KernelT kern, size_t lds_bytes, const mmvq_args & a_in, int grid_y, int fused_occ = 1) {
+static int launch_one(hipStream_t st, KernelT kern, size_t lds_bytes, const mmvq_args & a_in, int grid_y) {
     mmvq_args a = a_in;
     mmvq_tunables();
     // in-kernel prologues are redundant work per workgroup: use few, fat workgroups (16 waves share one prologue; the
@@ -406,7 +395,7 @@ static int launch_one(hipStream_t st, KernelT kern, size_t lds_bytes, const mmvq
     const int wg = a.pro != 0 ? 1024 : g_mmvq_wg, wpw = wg / 64;
     const int64_t units = a.epi == 1 ? a.nrows / 2 : a.nrows;
     int64_t grid = (units + wpw - 1) / wpw;
-    int64_t cap = (int64_t) device_cu_count() * (a.pro != 0 ? fused_occ : g_mmvq_wgs_per_cu) / grid_y;
+    int64_t cap = (int64_t) device_cu_count() * (a.pro != 0 ? 1 : g_mmvq_wgs_per_cu) / grid_y;
     if (cap < 1) cap = 1;
     if (grid > cap) grid = cap;     // (balancing rows per wave exactly was measured slower than simply using more workgroups)
     if (lds_bytes > 64 * 1024) HIP_TRY(hipFuncSetAttribute((const void *) kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -420,22 +409,27 @@ static int mmvq_dispatch(hipStream_t st, int wtype, int nc, size_t lds, const mm
     const bool fused = a.pro != 0;          // activation built inside the kernel (decode launches, nc == 1)
     if (fused && nc != 1) FAIL(CLLM_E_INVALID, "mmvq: fused prologue needs a single column");
     if (wtype == CLLM_TYPE_Q4_K) {
-        if (nc == 4) GO(k_mmvq_q4_K<4, 1, false>); else if (nc == 2) GO(k_mmvq_q4_K<2, 1, false>);
-        if (!fused) GO(k_mmvq_q4_K<1, 1, false>);
-        // decode launches.  K <= 4096 needs one activation group per thread and <= 64 VGPRs: two 1024-thread workgroups per
-        // CU; longer rows keep four groups in registers across the prefetch and run one workgroup per CU.
-        // prefetch depth = the steps a wave owns (rounded up to a power of two), at most g_mmvq_depth
-        mmvq_tunables();
+        if (nc == 4) GO(k_mmvq_q4_K<4, 1, 0>); else if (nc == 2) GO(k_mmvq_q4_K<2, 1, 0>);
+        if (!fused) GO(k_mmvq_q4_K<1, 1, 0>);
+        // decode launches: one 1024-thread workgroup per CU, two steps of weight prefetch.  K <= 4096 needs one activation
+        // group per thread; longer rows keep four groups in registers across the prefetch.
+        constexpr int P = 2;
         const bool small = a.nblk <= 16;
-        const int occ = small ? g_mmvq_fused_occ : 1;
-        const int64_t waves = (int64_t) device_cu_count() * occ * 16;
-        const int64_t steps = ((a.nrows + waves - 1) / waves) * ((a.nblk + 7) / 8);
-        int depth = 1;
-        while (depth < g_mmvq_depth && depth < steps) depth <<= 1;
-#define GOF(...) return launch_one(st, __VA_ARGS__, lds, a, grid_y, occ)
-        if (small) { if (depth >= 2) GOF(k_mmvq_q4_K<1, 2, true, 1>); else GOF(k_mmvq_q4_K<1, 1, true, 1>); }
-        if (depth == 4) GOF(k_mmvq_q4_K<1, 4, true, 4>); else if (depth == 2) GOF(k_mmvq_q4_K<1, 2, true, 4>); else GOF(k_mmvq_q4_K<1, 1, true, 4>);
-#undef GOF
+        mmvq_tunables();
+        // burst depth: the steps a wave owns, rounded up to a power of two, at most g_mmvq_burst
+        const int64_t waves = (int64_t) device_cu_count() * 16, units = a.epi == 1 ? a.nrows / 2 : a.nrows;
+        const int64_t steps = ((units + waves - 1) / waves) * (a.epi == 1 ? 2 : 1) * ((a.nblk + 7) / 8);
+        int burst = P;
+        while (burst < g_mmvq_burst && burst < steps) burst <<= 1;
+        if (!small && a.pro == 1 && burst > 4) burst = 4;       // (the 8-deep burst + four activation groups would spill)
+#define GOB(PRO_, EPI_, NPRE_) do { if (burst >= 8) GO(k_mmvq_q4_K<1, P, PRO_, EPI_, NPRE_, 8>); if (burst >= 4) GO(k_mmvq_q4_K<1, P, PRO_, EPI_, NPRE_, 4>); \
+                                    GO(k_mmvq_q4_K<1, P, PRO_, EPI_, NPRE_, 2>); } while (0)
+        if (a.pro == 1 && a.epi == 1) { if (small) GOB(1, 1, 1); else GOB(1, 1, 4); }
+        if (a.pro == 1) { if (small) GOB(1, 0, 1); else GOB(1, 0, 4); }
+        if (a.pro == 2) { if (small) GOB(2, 0, 1); else GOB(2, 0, 4); }
+        if (a.pro == 3) { if (small) GOB(3, 0, 1); else GOB(3, 0, 4); }
+#undef GOB
+        FAIL(CLLM_E_INVALID, "mmvq: prologue %d", a.pro);
     } else if (wtype == CLLM_TYPE_Q8_0) {
         if (nc == 4) GO(k_mmvq_q32<4, true, false>); else if (nc == 2) GO(k_mmvq_q32<2, true, false>);
         else if (fused) GO(k_mmvq_q32<1, true, true>); else GO(k_mmvq_q32<1, true, false>);
@@ -515,6 +509,11 @@ int launch_mmvq_fused(hipStream_t st, int wtype, const void * W, int64_t K, int6
     a.W = (const char *) W; a.nb01 = (int64_t) cllm_row_size(wtype, K); a.nrows = nrows; a.nblk = (int)(K / kb);
     a.act_stride = rb; a.dst = dst; a.bias = bias; a.resid = resid;
     a.pro = pro; a.px = px; a.pw = pw; a.eps = eps; a.epi = epi;
+    if (wtype == CLLM_TYPE_Q4_K) {
+        const int rc = launch_gemv_q4_K_decode(st, W, K, nrows, pro, px, pw, eps, epi, dst, bias, resid);
+        if (rc != CLLM_E_UNSUPPORTED) return rc;           // (very long rows / huge matrices fall through to the general kernel)
+        if (epi == 1) FAIL(CLLM_E_UNSUPPORTED, "mmvq_fused: SiLU epilogue only on the decode kernel's shapes");
+    }
     if (epi == 1 && (wtype != CLLM_TYPE_Q4_K || nrows % 2 || (nrows / 2) % 8 || bias || resid)) FAIL(CLLM_E_UNSUPPORTED, "mmvq_fused: SiLU epilogue needs Q4_K gate/up row pairs, features %% 8 == 0");
     return mmvq_dispatch(st, wtype, 1, rb, a, 1);
 }

@@ -31,18 +31,14 @@ __device__ __forceinline__ int nearest_int_dev(float fval) {
 // a whole wave (64 lanes x 4 values) holds one 256-block; lane l owns elements 4l..4l+3.
 // *d valid on all lanes; *s = sum over this lane's 32-sub-block (valid on all 8 lanes of the group).
 __device__ __forceinline__ uint32_t quant4_q8_K(f32x4 v, int lane, float * d_out, int * s_out) {
-    unsigned long long key = 0;        // (|x| bits, ~index): max picks the FIRST element of largest magnitude
-    const float ax[4] = { fabsf(v.x), fabsf(v.y), fabsf(v.z), fabsf(v.w) };
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-        const unsigned long long k2 = ((unsigned long long) __float_as_uint(ax[i]) << 32) | (unsigned long long)(0xffffffffu - (uint32_t)(lane * 4 + i));
-        key = k2 > key ? k2 : key;
-    }
-    key = wave_max_u64(key);
-    const float amax = __uint_as_float((uint32_t)(key >> 32));
-    const int   imax = (int)(0xffffffffu - (uint32_t) key);              // wave-uniform
-    const float mine = (imax & 3) == 0 ? v.x : (imax & 3) == 1 ? v.y : (imax & 3) == 2 ? v.z : v.w;
-    const float maxv = lane_f(mine, __builtin_amdgcn_readfirstlane(imax >> 2));
+    // max picks the FIRST element of largest magnitude (quants.c:2562-2566): wave max of |x|, then the first lane that
+    // holds it (ballot + find-first-set, scalar) and the first such element inside that lane
+    (void) lane;
+    const float a0 = fabsf(v.x), a1 = fabsf(v.y), a2 = fabsf(v.z), a3 = fabsf(v.w);
+    const float amax = wave_max(fmaxf(fmaxf(a0, a1), fmaxf(a2, a3)));
+    const float mine = a0 == amax ? v.x : a1 == amax ? v.y : a2 == amax ? v.z : v.w;
+    const unsigned long long has = __ballot(a0 == amax || a1 == amax || a2 == amax || a3 == amax);
+    const float maxv = lane_f(mine, (int) __builtin_ctzll(has));              // has != 0: some lane holds the maximum
     int q0 = 0, q1 = 0, q2 = 0, q3 = 0;
     float d = 0.0f;
     if (amax != 0.0f) {
