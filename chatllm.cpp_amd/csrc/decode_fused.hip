@@ -271,6 +271,225 @@ __global__ void __launch_bounds__(1024) k_attn_decode(const float * __restrict__
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// The same attention for the common head sizes (64 / 128), as SMALL code: a launch starts with a cold instruction cache
+// (~1 us per KB of straight-line code on the critical path, tools/gemv_phase_probe.py), and the general kernel above is
+// 25 KB.  Compile-time head size and RoPE pairing, no integer divisions (the GQA group comes from blockIdx.y), and the
+// cos/sin of the position come from a table built once per token (k_rope_table) instead of once per head and layer.
+// Arithmetic and summation order are those of the general kernel (= of the unfused graph nodes).
+// ---------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64) k_rope_table(const int32_t * __restrict__ pos_dev, int half, float theta_scale, float * __restrict__ cs) {
+    for (int i = threadIdx.x; i < half; i += 64) {
+        float theta = (float) pos_dev[0];
+        for (int k = 0; k < i; k++) theta *= theta_scale;        // iterated fp32 multiplication, ops.cpp:5639-5650
+        float c, s_;
+        rope_cos_sin(theta, &c, &s_);
+        cs[2*i] = c * 1.0f; cs[2*i + 1] = s_ * 1.0f;
+    }
+}
+int launch_rope_table(hipStream_t st, const int32_t * pos_dev, int hd, float freq_base, float * cs) {
+    hipLaunchKernelGGL(k_rope_table, dim3(1), dim3(64), 0, st, pos_dev, hd / 2, powf(freq_base, -2.0f / hd), cs);
+    LAUNCH_CHECK();
+    return CLLM_OK;
+}
+
+__device__ __forceinline__ int uniform_load_i32(const int32_t * p) {
+    int v;
+    asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(p) : "memory");
+    return v;
+}
+
+template <int HD, int MODE>      // MODE 0: adjacent pairs (GGML_ROPE_TYPE_NORMAL), 2: NEOX halves
+__global__ void __launch_bounds__(1024) k_attn_dec(const float * __restrict__ qkv, const int32_t * __restrict__ pos_dev, const float * __restrict__ rope_cs,
+                                                   int nh, int nkv, float scale, uint16_t * __restrict__ k_cache, uint16_t * __restrict__ v_cache,
+                                                   int ML, float * __restrict__ att) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];       // [HD] q (fp16-rounded) | [HD] new k | [HD] new v | [n_kv] scores
+    __shared__ double red_d[1];
+    __shared__ float  red_f[16];
+    constexpr int half = HD / 2, G = HD / 8, RPW = 64 / G, off = MODE == 0 ? 1 : half, U = 4;
+    const int r2 = gridDim.x, g = blockIdx.y, h = g * r2 + blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int KD = nkv * HD, QD = nh * HD;
+    float * qs = sm; float * knew = sm + HD; float * vnew = sm + 2 * HD; float * sc = sm + 3 * HD;
+
+    // ---- (1) this head's projections + the cos/sin of its pairs: loads issued before anything waits ----
+    float px0 = 0.0f, px1 = 0.0f, pc = 0.0f, ps = 0.0f;
+    const bool is_pair = tid < 2 * half, is_v = !is_pair && tid < 2 * half + HD;
+    const int which = tid >= half ? 1 : 0, pi = tid - which * half, ic = MODE == 0 ? 2 * pi : pi;
+    if (is_pair) {
+        const float * x = which == 0 ? qkv + h * HD : qkv + QD + g * HD;
+        px0 = x[ic]; px1 = x[ic + off];
+        pc = rope_cs[2 * pi]; ps = rope_cs[2 * pi + 1];
+    } else if (is_v) px0 = qkv[QD + KD + g * HD + (tid - 2 * half)];
+    const int pos = uniform_load_i32(pos_dev);
+    const int n_kv = pos + 1;
+
+    // ---- (2) first batch of cache rows: G lanes per K row (one 16-byte chunk per lane), GV lanes per V^T row ----
+    const int gl = lane & (G - 1), sub = lane / G, stride = 16 * RPW;
+    const int ib0 = wave * RPW + sub;
+    u32x4 kr0[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+        const int i0 = ib0 + u * stride;
+        kr0[u] = u32x4{0, 0, 0, 0};
+        if (i0 < pos) kr0[u] = *(const u32x4 *)(k_cache + (int64_t) i0 * KD + g * HD + gl * 8);      // row `pos` is the new k (LDS)
+    }
+    int lgv = 6; while (lgv > 3 && (8 << lgv) > n_kv) lgv--;        // GV = 1 << lgv: GV * 8 <= n_kv, 8 <= GV <= 64 (launch_T(), matmul_f.hip)
+    const int GV = 1 << lgv, glv = lane & (GV - 1), subv = lane >> lgv, stridev = 16 * (64 >> lgv);
+    const int n8 = n_kv & ~7;
+    const int db0 = wave * (64 >> lgv) + subv, itv = n8 + glv, ivv = glv * 8;
+    uint16_t vt0[U]; u32x4 vc0[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+        const int d0 = db0 + u * stridev;
+        vt0[u] = 0; vc0[u] = u32x4{0, 0, 0, 0};
+        if (d0 < HD && n_kv >= 8) {
+            const uint16_t * vr = v_cache + ((int64_t) g * HD + d0) * ML;
+            if (itv < n_kv) vt0[u] = vr[itv];
+            if (ivv < n8) vc0[u] = *(const u32x4 *)(vr + ivv);
+        }
+    }
+
+    // ---- (3) RoPE, fp16 rounding, cache write ----
+    if (is_pair) {
+        const float y0 = px0*pc - px1*ps, y1 = px0*ps + px1*pc;
+        float * o = which == 0 ? qs : knew;
+        o[ic] = h2f(f2h(y0)); o[ic + off] = h2f(f2h(y1));             // q: src1 of K.Q is rounded to fp16; k: the cache is fp16
+    } else if (is_v) vnew[tid - 2 * half] = h2f(f2h(px0));
+    __syncthreads();
+    if (blockIdx.x == 0 && tid < HD) {
+        k_cache[(int64_t) pos * KD + g * HD + tid] = f2h(knew[tid]);
+        v_cache[((int64_t) g * HD + tid) * ML + pos] = f2h(vnew[tid]);
+    }
+
+    // ---- (4) scores[i] = K[i] . q * scale ----
+    for (int ib = ib0; ib < n_kv; ib += U * stride) {
+        u32x4 r[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int i0 = ib + u * stride;
+            r[u] = kr0[u];
+            if (ib != ib0) {
+                r[u] = u32x4{0, 0, 0, 0};
+                if (i0 < pos) r[u] = *(const u32x4 *)(k_cache + (int64_t) i0 * KD + g * HD + gl * 8);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int i0 = ib + u * stride;
+            if (i0 >= n_kv) continue;                                     // whole lane groups drop out together
+            const int d = gl * 8;
+            float acc = 0.0f;
+            if (i0 == pos) {
+#pragma unroll
+                for (int j = 0; j < 8; j++) acc = __builtin_fmaf(knew[d + j], qs[d + j], acc);
+            } else {
+                const uint32_t wv[4] = { r[u].x, r[u].y, r[u].z, r[u].w };
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    acc = __builtin_fmaf(h2f((uint16_t)(wv[j] & 0xffff)), qs[d + 2*j], acc);
+                    acc = __builtin_fmaf(h2f((uint16_t)(wv[j] >> 16)), qs[d + 2*j + 1], acc);
+                }
+            }
+#pragma unroll
+            for (int o = G / 2; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+            if (gl == 0) sc[i0] = acc * scale;                            // the SCALE node
+        }
+    }
+    __syncthreads();
+
+    // ---- (5) soft_max over sc[0..n_kv): same partition as k_soft_max (one wave, lane = groups of 8) ----
+    float mx = -INFINITY;
+    for (int i = tid; i < n_kv; i += 1024) mx = fmaxf(mx, sc[i]);
+    mx = wave_max(mx);
+    if (lane == 0) red_f[wave] = mx;
+    __syncthreads();
+    mx = red_f[0];
+#pragma unroll
+    for (int w = 1; w < 16; w++) mx = fmaxf(mx, red_f[w]);
+    if (wave == 0) {
+        const int nv = n_kv & ~7;
+        double sum = 0.0;
+        for (int gi = lane * 8; gi < nv; gi += 64 * 8) {
+            float e[8];
+#pragma unroll
+            for (int l = 0; l < 8; l++) { e[l] = ggml_expf_poly(sc[gi + l] - mx); sc[gi + l] = e[l]; }
+            const float a0 = e[0] + e[4], a1 = e[1] + e[5], a2 = e[2] + e[6], a3 = e[3] + e[7];
+            sum += (double)((a0 + a2) + (a1 + a3));
+        }
+        if (lane == 0) for (int i = nv; i < n_kv; i++) { const float e = libm_expf(sc[i] - mx); sc[i] = e; sum += (double) e; }
+        sum = wave_sum_d(sum);
+        if (lane == 0) red_d[0] = sum;
+    }
+    __syncthreads();
+    const float inv = (float)(1.0 / red_d[0]);
+    for (int i = tid; i < n_kv; i += 1024) sc[i] = h2f(f2h(sc[i] * inv));   // probability, then its fp16 rounding for V.P
+    __syncthreads();
+
+    // ---- (6) ctx = V . P ----
+    for (int db = db0; db < HD; db += U * stridev) {
+        uint16_t t0[U]; u32x4 c0[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int d0 = db + u * stridev;
+            t0[u] = vt0[u]; c0[u] = vc0[u];
+            if (db != db0) {
+                t0[u] = 0; c0[u] = u32x4{0, 0, 0, 0};
+                if (d0 < HD && n_kv >= 8) {
+                    const uint16_t * vr = v_cache + ((int64_t) g * HD + d0) * ML;
+                    if (itv < n_kv) t0[u] = vr[itv];
+                    if (ivv < n8) c0[u] = *(const u32x4 *)(vr + ivv);
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int d0 = db + u * stridev;
+            if (d0 >= HD) continue;
+            const uint16_t * vr = v_cache + ((int64_t) g * HD + d0) * ML;
+            const float vfresh = vnew[d0];
+            float acc = 0.0f;
+            if (n_kv >= 8) {
+                for (int i = itv; i < n_kv; i += GV) acc = __builtin_fmaf(i == pos ? vfresh : h2f(i == itv ? t0[u] : vr[i]), sc[i], acc);
+                for (int i = ivv; i < n8; i += GV * 8) {
+                    const u32x4 r = i == ivv ? c0[u] : *(const u32x4 *)(vr + i);
+                    const uint32_t wv[4] = { r.x, r.y, r.z, r.w };
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        const float v0 = (i + 2*j == pos) ? vfresh : h2f((uint16_t)(wv[j] & 0xffff));
+                        const float v1 = (i + 2*j + 1 == pos) ? vfresh : h2f((uint16_t)(wv[j] >> 16));
+                        acc = __builtin_fmaf(v0, sc[i + 2*j], acc);
+                        acc = __builtin_fmaf(v1, sc[i + 2*j + 1], acc);
+                    }
+                }
+            } else {
+                for (int i = glv; i < n_kv; i += GV) acc = __builtin_fmaf(i == pos ? vfresh : h2f(vr[i]), sc[i], acc);   // the scalar kernel of matmul_f.hip (K < 8)
+            }
+            for (int o = GV / 2; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+            if (glv == 0) att[h * HD + d0] = acc;
+        }
+    }
+}
+
+// RoPE + KV-cache write + attention with the position's cos/sin table (launch_rope_table); CLLM_E_UNSUPPORTED -> use the general kernel
+int launch_attn_dec_table(hipStream_t st, const float * qkv, const int32_t * pos_dev, const float * rope_cs, int nh, int nkv, int hd, int mode,
+                          uint16_t * k_cache, uint16_t * v_cache, int64_t ML, float * att) {
+    if ((hd != 64 && hd != 128) || nh % nkv || ML % 8 || ML > (1 << 30) || g_attn_dbg) return CLLM_E_UNSUPPORTED;
+    const size_t lds = (size_t)(3 * hd + ML) * 4;
+    if (lds > 150 * 1024) return CLLM_E_UNSUPPORTED;
+    const float scale = 1.0f / sqrtf((float) hd);
+    const dim3 grid(nh / nkv, nkv);
+#define GO(HD_, MODE_) do { \
+        static bool attr = false; \
+        if (lds > 48 * 1024 && !attr) { HIP_TRY(hipFuncSetAttribute((const void *) k_attn_dec<HD_, MODE_>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024)); attr = true; } \
+        hipLaunchKernelGGL((k_attn_dec<HD_, MODE_>), grid, dim3(1024), lds, st, qkv, pos_dev, rope_cs, nh, nkv, scale, k_cache, v_cache, (int) ML, att); } while (0)
+    if (hd == 128) { if (mode == 0) GO(128, 0); else GO(128, 2); }      // any other mode pairs NEOX-style, as in the general kernel
+    else           { if (mode == 0) GO(64, 0);  else GO(64, 2); }
+#undef GO
+    LAUNCH_CHECK();
+    return CLLM_OK;
+}
+
 static int attn_launch(hipStream_t st, bool rope, const float * qkv, const int32_t * pos_dev, int nh, int nkv, int hd, uint16_t * k_cache, uint16_t * v_cache,
                        int64_t ML, float * att, int mode, float freq_base) {
     if (hd % 8 || (ML % 8) || nh % nkv) FAIL(CLLM_E_UNSUPPORTED, "attn_decode: head_dim and max_len must be multiples of 8");

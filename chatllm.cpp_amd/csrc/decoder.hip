@@ -227,7 +227,7 @@ static int finalize(cllm_llama * m, int qlen) {
         HIP_TRY(hipMalloc((void **) &m->logits, (size_t) V * 4));
         HIP_TRY(hipMalloc((void **) &m->next_tok_dev, 16));
         HIP_TRY(hipMalloc((void **) &m->out_ring, (size_t) ML * 4));
-        HIP_TRY(hipMalloc((void **) &m->counter_dev, (16 + 512) * 4));    // loop counter + 256 (value, index) argmax partials
+        HIP_TRY(hipMalloc((void **) &m->counter_dev, (16 + 512 + 512) * 4));    // loop counter + 256 (value, index) argmax partials + cos/sin table of the position
         // the fused single-token path needs the row-concatenated projections and block-aligned widths
         m->fused_ok = m->own_stream && H % 256 == 0 && QD % 256 == 0 && hd % 8 == 0 && ML % 8 == 0 && (size_t)(hd + ML) * 4 <= 150 * 1024;
         for (const llama_layer & L : m->layers) {
@@ -399,13 +399,19 @@ static int decode_step_fused(cllm_llama * m, bool sample) {
         cllm_tensor E = T(m->tok_embd.type, m->tok_embd.data, H, V), ids = T(CLLM_TYPE_I32, m->tokens_dev, 1), X = T(CLLM_TYPE_F32, m->x, H, 1);
         TRY(cllm_op_get_rows(st, &E, &ids, &X));
     }
+    // cos/sin of this step's position, once per token instead of once per head and layer (head sizes the compact kernel takes)
+    float * rope_cs = (float *)(m->counter_dev + 16 + 512);
+    const bool cs_table = (hd == 64 || hd == 128);
+    if (cs_table) TRY(launch_rope_table(st, m->pos_dev, (int) hd, c.rope_theta, rope_cs));
     // 5 launches per layer: [norm+quant+qkv GEMV(+bias)] [rope+kv-write+attention] [quant+o GEMV+residual]
     //                       [norm+quant+gate/up GEMV+silu*up] [quant+down GEMV+residual]
     for (int il = 0; il < c.n_layer; il++) {
         llama_layer & L = m->layers[il];
         TRY(launch_mmvq_fused(st, L.wqkv.type, L.wqkv.data, H, QD + 2*KD, 1, m->x, (const float *) L.attn_norm.data, c.rms_eps, 0, m->qkv,
                               c.qkv_bias ? (const float *) L.bqkv.data : nullptr, nullptr));
-        TRY(launch_rope_kv_attn_decode(st, m->qkv, m->pos_dev, m->nh, m->nkv, (int) hd, c.rope_mode, c.rope_theta, L.k_cache, L.v_cache, ML, m->att));
+        int arc = cs_table ? launch_attn_dec_table(st, m->qkv, m->pos_dev, rope_cs, m->nh, m->nkv, (int) hd, c.rope_mode, L.k_cache, L.v_cache, ML, m->att) : CLLM_E_UNSUPPORTED;
+        if (arc == CLLM_E_UNSUPPORTED) arc = launch_rope_kv_attn_decode(st, m->qkv, m->pos_dev, m->nh, m->nkv, (int) hd, c.rope_mode, c.rope_theta, L.k_cache, L.v_cache, ML, m->att);
+        TRY(arc);
         if (!tp) TRY(launch_mmvq_fused(st, L.wo.type, L.wo.data, QD, H, 2, m->att, nullptr, 0.0f, 0, m->x, nullptr, m->x));          // x = o + x
         else {
             TRY(launch_mmvq_fused(st, L.wo.type, L.wo.data, QD, H, 2, m->att, nullptr, 0.0f, 0, m->o, nullptr, nullptr));
