@@ -24,7 +24,9 @@
 static unsigned long long * g_gemv_ts = nullptr;
 extern "C" __attribute__((visibility("default"))) void cllm_debug_set_mmvq_ts(unsigned long long * dev_buf) { g_gemv_ts = dev_buf; }   // tools only
 
-struct gemv_deal { int nunits, kfull, nrem, nblk; };      // units = rows (or gate/up row pairs); kfull full rounds of nwaves units + nrem
+// The kernel parameters are individual scalars in the order the kernel needs them: the first 16 dwords are preloaded into
+// SGPRs at wave launch (-mllvm -amdgpu-kernarg-preload-count=16), so the activation loads do not wait for a kernarg fetch.
+//   units = rows (or gate/up row pairs), dealt as kfull full rounds of nwaves units + nrem (host-computed: no division here)
 
 __device__ __forceinline__ float silu_poly(float x) { return x / (1.0f + ggml_expf_poly(0.0f - x)); }
 __device__ __forceinline__ float silu_any(float x, bool body) { return body ? silu_poly(x) : x / (1.0f + libm_expf(-x)); }
@@ -33,12 +35,12 @@ __device__ __forceinline__ float silu_any(float x, bool body) { return body ? si
 
 template <int PRO, int EPI, int NPRE>
 __global__ void __launch_bounds__(1024) k_gemv_q4_K_dec(const float * __restrict__ px, const float * __restrict__ pw, const char * __restrict__ W,
-                                                        const gemv_deal deal, float eps, float * __restrict__ dst, const float * __restrict__ bias,
-                                                        const float * resid, unsigned long long * ts) {
+                                                        int nblk, int kfull, int nrem, float eps, float * __restrict__ dst,
+                                                        const float * __restrict__ bias, const float * resid, unsigned long long * ts) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     constexpr int P = 2, RU = EPI == 1 ? 2 : 1;
     const int tid = threadIdx.x, lane = tid & 63;
-    const int nblk = deal.nblk, K = nblk * 256;
+    const int K = nblk * 256;
 
     // ---- (1) this thread's activation groups: unconditional (clamped) loads, issued before anything else ----
     // pro 3: px holds interleaved (gate_e, up_e) pairs -- two 16-byte loads cover this thread's four features
@@ -61,10 +63,10 @@ __global__ void __launch_bounds__(1024) k_gemv_q4_K_dec(const float * __restrict
     const int wave_in_wg = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nwaves = gridDim.x * 16;
     const int lin = blockIdx.x * 16 + wave_in_wg, alt = wave_in_wg * gridDim.x + blockIdx.x;
-    const int nmine = deal.kfull + (alt < deal.nrem ? 1 : 0);
+    const int nmine = kfull + (alt < nrem ? 1 : 0);
     const int S = (nblk + 7) >> 3;                                  // steps per row
     const unsigned nb01 = (unsigned) nblk * 144u;
-    auto unit_of = [&](int k) { return k * nwaves + (k < deal.kfull ? lin : alt); };
+    auto unit_of = [&](int k) { return k * nwaves + (k < kfull ? lin : alt); };
     u32x4 hh[P], qq[P];
     int ik = 0, isub = 0, is = 0;                                   // issue cursor: (unit ordinal, row of the unit, step of the row)
     auto issue = [&](u32x4 & h, u32x4 & q) {                        // unconditional: out-of-range steps re-read block 0 and are masked
@@ -150,11 +152,10 @@ int launch_gemv_q4_K_decode(hipStream_t st, const void * W, int64_t K, int64_t n
     int64_t grid = (units + 15) / 16;
     if (grid > device_cu_count()) grid = device_cu_count();
     const int64_t nwaves = grid * 16;
-    gemv_deal deal;
-    deal.nunits = (int) units; deal.kfull = (int)(units / nwaves); deal.nrem = (int)(units % nwaves); deal.nblk = (int)(K / 256);
+    const int kfull = (int)(units / nwaves), nrem = (int)(units % nwaves), nblk = (int)(K / 256);
     const size_t lds = act_row_bytes(K, 256);
     const bool small = K <= 4096;
-#define GO(PRO_, EPI_, NPRE_) hipLaunchKernelGGL((k_gemv_q4_K_dec<PRO_, EPI_, NPRE_>), dim3((unsigned) grid), dim3(1024), lds, st, px, pw, (const char *) W, deal, eps, dst, bias, resid, g_gemv_ts)
+#define GO(PRO_, EPI_, NPRE_) hipLaunchKernelGGL((k_gemv_q4_K_dec<PRO_, EPI_, NPRE_>), dim3((unsigned) grid), dim3(1024), lds, st, px, pw, (const char *) W, nblk, kfull, nrem, eps, dst, bias, resid, g_gemv_ts)
     if (pro == 1 && epi == 1) { if (small) GO(1, 1, 1); else GO(1, 1, 4); }
     else if (pro == 1)        { if (small) GO(1, 0, 1); else GO(1, 0, 4); }
     else if (pro == 2)        { if (small) GO(2, 0, 1); else GO(2, 0, 4); }
