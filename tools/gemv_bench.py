@@ -51,7 +51,7 @@ def run_fused(types, iters, hot=False, force_pro=0, only=""):
                                                   r.data_ptr() if resid else None, iters, C.byref(us)), "bench")
             gbs = nbytes / (us.value * 1e-6) / 1e9
             print(f"fused {tn:5s} {name:9s} K={K:6d} N={N:6d} pro={pro} {nbytes/1e6:8.1f} MB {us.value:9.2f} us {gbs:8.1f} GB/s  {gbs/80:5.1f}% of 8TB/s  "
-                  f"[depth<={os.environ.get('CLLM_MMVQ_DEPTH','dflt')}]", flush=True)
+                  "", flush=True)
             del ws
 
 
