@@ -218,7 +218,8 @@ int launch_mmvq(hipStream_t st, int wtype, const tview & w, const void * act, si
                 const tview & src1_geom, const tview & dst);
 int launch_mmvq_id(hipStream_t st, int wtype, const tview & as, const void * act, size_t act_stride, int64_t b_ne1, const tview & ids, const tview & dst);
 int launch_mmq(hipStream_t st, int wtype, const tview & w, const void * act, size_t act_stride, const tview & src1_geom, const tview & dst);
-int launch_mul_mat_f(hipStream_t st, int wtype, const tview & w, const tview & x, const tview & dst);
+int launch_mul_mat_f(hipStream_t st, int wtype, const tview & w, const tview & x, const tview & d, int causal = 0, int n_past = 0);   // causal: mma_f16.hip
+int launch_mma_f16(hipStream_t st, const tview & w, const tview & x, const tview & d, int causal, int n_past);
 int device_cu_count();
 int launch_mmvq_act(hipStream_t st, int wtype, const void * W, int64_t K, int64_t nrows, const void * act, float * dst, const float * bias, const float * resid);
 int launch_gemv_q4_K_decode(hipStream_t st, const void * W, int64_t K, int64_t nrows, int pro, const float * px, const float * pw, float eps, int epi, float * dst, const float * bias, const float * resid);

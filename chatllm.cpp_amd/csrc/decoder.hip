@@ -332,11 +332,11 @@ static int forward_general(cllm_llama * m, int qlen, int n_past) {
             cllm_tensor Kv = TS(CLLM_TYPE_F16, L.k_cache, hd, n_kv, nkv, (size_t) KD * 2, (size_t) hd * 2);
             cllm_tensor Qv = TS(CLLM_TYPE_F32, q, hd, qlen, nh, (size_t) QKV * 4, (size_t) hd * 4);
             cllm_tensor S  = T(CLLM_TYPE_F32, m->scores, n_kv, qlen, nh);
-            TRY(cllm_op_mul_mat(st, &Kv, &Qv, &S, nullptr, 0));
+            TRY(launch_mul_mat_f((hipStream_t) st, CLLM_TYPE_F16, tv(&Kv), tv(&Qv), tv(&S), 1, n_past));       // causal 1: fully masked tiles are not computed
             TRY(cllm_op_scale_mask_soft_max(st, &S, &S, 1.0f / sqrtf((float) hd), n_past));
             cllm_tensor Vv = TS(CLLM_TYPE_F16, L.v_cache, n_kv, hd, nkv, (size_t) ML * 2, (size_t) ML * hd * 2);
             cllm_tensor C  = T(CLLM_TYPE_F32, m->ctx, hd, qlen, nh);
-            TRY(cllm_op_mul_mat(st, &Vv, &S, &C, nullptr, 0));
+            TRY(launch_mul_mat_f((hipStream_t) st, CLLM_TYPE_F16, tv(&Vv), tv(&S), tv(&C), 2, n_past));         // causal 2: k stops where P is exactly 0
             // permute(0,2,1,3) + cont -> [hd, nh, qlen]
             cllm_tensor Cp = T(CLLM_TYPE_F32, m->ctx, hd, nh, qlen); Cp.nb[1] = (size_t) hd * qlen * 4; Cp.nb[2] = (size_t) hd * 4; Cp.nb[3] = (size_t) hd * qlen * nh * 4;
             cllm_tensor A  = T(CLLM_TYPE_F32, m->att, hd, nh, qlen);

@@ -155,13 +155,18 @@ __global__ void __launch_bounds__(256) k_soft_max(tview s, tview d, const char *
         else if (mp)   { v += 1.0f * (mask_f16 ? h2f(((const uint16_t *) mp)[i]) : ((const float *) mp)[i]); }
         return v;
     };
+    // MODE 1: everything from n_vis on is masked (-inf -> probability exactly 0): those entries are neither read nor
+    // exponentiated, whole groups of 8 beyond it contribute an exact 0.0 to the sum, and zeros are stored for them
+    const int64_t n_vis = MODE == 1 ? (n_past + i1 + 1 < n ? n_past + i1 + 1 : n) : n;
     float mx = -INFINITY;
-    for (int64_t i = lane; i < n; i += 64) mx = fmaxf(mx, val(i));
+    for (int64_t i = lane; i < n_vis; i += 64) mx = fmaxf(mx, val(i));
     mx = wave_max(mx);
 
     const int64_t nv = n & ~(int64_t) 7;
+    const int64_t nv_vis = MODE == 1 ? (((n_vis + 7) & ~(int64_t) 7) < nv ? ((n_vis + 7) & ~(int64_t) 7) : nv) : nv;
     double sum = 0.0;
-    for (int64_t g = (int64_t) lane * 8; g < nv; g += 64 * 8) {
+    if (MODE == 1) for (int64_t i = nv_vis + lane; i < nv; i += 64) y[i] = 0.0f;
+    for (int64_t g = (int64_t) lane * 8; g < nv_vis; g += 64 * 8) {
         float e[8];
 #pragma unroll
         for (int l = 0; l < 8; l++) { e[l] = ggml_expf_poly(val(g + l) - mx); y[g + l] = e[l]; }
@@ -172,7 +177,8 @@ __global__ void __launch_bounds__(256) k_soft_max(tview s, tview d, const char *
     sum = wave_sum_d(sum);
     const float inv = (float)(1.0 / sum);
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");   // e[] written by other lanes of this wave
-    for (int64_t i = lane; i < n; i += 64) y[i] = y[i] * inv;
+    const int64_t n_live = MODE == 1 ? (nv_vis < nv ? nv_vis : n) : n;      // the stored zeros stay zeros
+    for (int64_t i = lane; i < n_live; i += 64) y[i] = y[i] * inv;
 }
 
 static int soft_max_impl(void * stream, const cllm_tensor * src, const cllm_tensor * mask, cllm_tensor * dst, float scale, int fused, int n_past) {

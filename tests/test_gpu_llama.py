@@ -143,6 +143,21 @@ def test_decoder_is_bit_identical_to_the_verified_op_walk(gpu, wtype):
     dev.close()
 
 
+def test_decoder_long_prompt_matrix_core_attention_is_bit_identical_to_the_walk(gpu):
+    """prompts of more than one 128-token tile: K.Q / V.P run on the matrix cores with the runner's causal tile skipping
+    (mma_f16.hip); the walk calls the same ops without the causal hints -- every visible entry must agree to the bit"""
+    cfg = gpu.synth.config("tiny", max_len=320)
+    w = gpu.synth.make_model(cfg, O.Q4_K, seed=5)
+    dev, walk = gpu.Llama(cfg, w), Walk(gpu, cfg, w)
+    r = np.random.default_rng(7)
+    for n in (200, 70, 1, 33):                       # chunked prefill: later chunks see n_past > 0
+        toks = r.integers(0, cfg["vocab"], n).astype(np.int32)
+        assert np.array_equal(dev.forward(toks), walk.forward(toks)), f"chunk of {n}"
+    for name, err in walk.worst.items():
+        assert err < OP_TOL[name], (name, err)
+    dev.close()
+
+
 def test_decoder_qwen2_style_is_bit_identical_to_the_walk(gpu):
     """NEOX rope, qkv bias, down_proj falling back to Q8_0 because ffn % 256 != 0"""
     cfg = gpu.synth.config("tiny", max_len=32, rope_mode=2, qkv_bias=1, rope_theta=1e6, ffn=544)

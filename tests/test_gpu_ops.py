@@ -111,7 +111,9 @@ def test_mul_mat_quant_gemm(gpu, t, K, N, M):
 
 
 @pytest.mark.parametrize("t", [O.F16, O.F32])
-@pytest.mark.parametrize("K,N,M,ne02,ne12", [(128, 50, 1, 1, 1), (128, 37, 3, 2, 8), (64, 9, 5, 1, 4), (100, 11, 2, 1, 1), (1031, 16, 1, 2, 2)])
+@pytest.mark.parametrize("K,N,M,ne02,ne12", [(128, 50, 1, 1, 1), (128, 37, 3, 2, 8), (64, 9, 5, 1, 4), (100, 11, 2, 1, 1), (1031, 16, 1, 2, 2),
+                                             # >= 32 columns: the F16 case runs on the matrix cores (mma_f16.hip): full tiles, ragged N / M / K, GQA broadcast
+                                             (128, 256, 128, 1, 1), (128, 200, 77, 2, 8), (328, 130, 33, 1, 4), (72, 17, 40, 1, 1), (8, 3, 32, 1, 2)])
 def test_mul_mat_float(gpu, t, K, N, M, ne02, ne12):
     got, want = _mm_case(gpu, t, K, N, M, ne02, ne12)
     assert rel_err(got, want) < T1
@@ -305,7 +307,7 @@ def test_get_rows_bit_exact(gpu, t):
 
 
 # ---- attention over strided cache views (GQA broadcast) ---------------------------------------------------
-@pytest.mark.parametrize("qlen,n_past", [(1, 0), (1, 37), (1, 255), (6, 0), (5, 11)])
+@pytest.mark.parametrize("qlen,n_past", [(1, 0), (1, 37), (1, 255), (6, 0), (5, 11), (64, 0), (200, 56), (33, 150)])
 def test_attention_composite(gpu, qlen, n_past):
     hd, nh, nkv, ML = 128, 8, 2, 256
     KD, n_kv = hd * nkv, n_past + qlen
