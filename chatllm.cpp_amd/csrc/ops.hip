@@ -181,6 +181,57 @@ __global__ void __launch_bounds__(256) k_soft_max(tview s, tview d, const char *
     for (int64_t i = lane; i < n_live; i += 64) y[i] = y[i] * inv;
 }
 
+// fused scale + causal mask + soft_max with the row held in registers (prefill score rows: one read, one write instead of
+// two of each).  Same lane -> group-of-8 mapping, same max set, same summation order as k_soft_max<1>: bit-identical.
+// Needs n % 8 == 0, n <= 512 * NG, 16-byte aligned rows.
+template <int NG>
+__global__ void __launch_bounds__(256) k_soft_max_causal_reg(tview s, tview d, float scale, int n_past) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t) blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int64_t nrows = s.ne[1] * s.ne[2] * s.ne[3];
+    if (row >= nrows) return;
+    const int64_t i1 = row % s.ne[1], i2 = (row / s.ne[1]) % s.ne[2], i3 = row / (s.ne[1] * s.ne[2]);
+    const float * x = (const float *)(s.data + i1*s.nb[1] + i2*s.nb[2] + i3*s.nb[3]);
+    float *       y = (float *)(d.data + i1*d.nb[1] + i2*d.nb[2] + i3*d.nb[3]);
+    const int n = (int) s.ne[0];
+    const int n_vis = n_past + (int) i1 + 1 < n ? n_past + (int) i1 + 1 : n;       // entries >= n_vis are masked
+    float e[NG][8];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int t = 0; t < NG; t++) {
+        const int g0 = (lane + 64 * t) * 8;
+        if (g0 < n_vis) {
+            const f32x4 lo = *(const f32x4 *)(x + g0), hi = *(const f32x4 *)(x + g0 + 4);
+            const float v[8] = { lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w };
+#pragma unroll
+            for (int l = 0; l < 8; l++) { e[t][l] = g0 + l < n_vis ? v[l] * scale : -INFINITY; mx = fmaxf(mx, e[t][l]); }
+        }
+    }
+    mx = wave_max(mx);
+    double sum = 0.0;
+#pragma unroll
+    for (int t = 0; t < NG; t++) {
+        const int g0 = (lane + 64 * t) * 8;
+        if (g0 < n_vis) {
+#pragma unroll
+            for (int l = 0; l < 8; l++) e[t][l] = ggml_expf_poly(e[t][l] - mx);
+            const float a0 = e[t][0] + e[t][4], a1 = e[t][1] + e[t][5], a2 = e[t][2] + e[t][6], a3 = e[t][3] + e[t][7];
+            sum += (double)((a0 + a2) + (a1 + a3));
+        }
+    }
+    sum = wave_sum_d(sum);
+    const float inv = (float)(1.0 / sum);
+#pragma unroll
+    for (int t = 0; t < NG; t++) {
+        const int g0 = (lane + 64 * t) * 8;
+        if (g0 < n) {
+            f32x4 lo = {0, 0, 0, 0}, hi = {0, 0, 0, 0};
+            if (g0 < n_vis) { lo = f32x4{e[t][0] * inv, e[t][1] * inv, e[t][2] * inv, e[t][3] * inv}; hi = f32x4{e[t][4] * inv, e[t][5] * inv, e[t][6] * inv, e[t][7] * inv}; }
+            *(f32x4 *)(y + g0) = lo; *(f32x4 *)(y + g0 + 4) = hi;
+        }
+    }
+}
+
 static int soft_max_impl(void * stream, const cllm_tensor * src, const cllm_tensor * mask, cllm_tensor * dst, float scale, int fused, int n_past) {
     if (!src || !dst) FAIL(CLLM_E_INVALID, "soft_max: null");
     if (src->type != CLLM_TYPE_F32 || dst->type != CLLM_TYPE_F32) FAIL(CLLM_E_UNSUPPORTED, "soft_max: type");
@@ -193,6 +244,14 @@ static int soft_max_impl(void * stream, const cllm_tensor * src, const cllm_tens
     if (rows == 0 || src->ne[0] == 0) return CLLM_OK;
     const unsigned grid = (unsigned)((rows + 3) / 4);
     hipStream_t st = (hipStream_t) stream;
+    const int64_t n = src->ne[0];
+    const bool al16 = !((((uintptr_t) src->data | src->nb[1] | src->nb[2] | src->nb[3] | (uintptr_t) dst->data | dst->nb[1] | dst->nb[2] | dst->nb[3])) & 15);
+    if (fused && n % 8 == 0 && n >= 512 && n <= 8192 && al16) {      // long (prefill) rows: register-resident single pass
+        if (n <= 4096) hipLaunchKernelGGL(k_soft_max_causal_reg<8>,  dim3(grid), dim3(256), 0, st, tv(src), tv(dst), scale, n_past);
+        else           hipLaunchKernelGGL(k_soft_max_causal_reg<16>, dim3(grid), dim3(256), 0, st, tv(src), tv(dst), scale, n_past);
+        LAUNCH_CHECK();
+        return CLLM_OK;
+    }
     if (fused) hipLaunchKernelGGL(k_soft_max<1>, dim3(grid), dim3(256), 0, st, tv(src), tv(dst), (const char *) nullptr, 0, (int64_t) 0, (int64_t) 0, (int64_t) 0, (int64_t) 1, (int64_t) 1, scale, n_past);
     else       hipLaunchKernelGGL(k_soft_max<0>, dim3(grid), dim3(256), 0, st, tv(src), tv(dst), mask ? (const char *) mask->data : nullptr, mask && mask->type == CLLM_TYPE_F16 ? 1 : 0,
                                   mask ? (int64_t) mask->nb[1] : 0, mask ? (int64_t) mask->nb[2] : 0, mask ? (int64_t) mask->nb[3] : 0, mask ? mask->ne[2] : 1, mask ? mask->ne[3] : 1, scale, 0);
