@@ -220,14 +220,32 @@ def main():
 
     if world > 1:
         import torch
+        L = pkg.lib.get()
+        try:
+            # native path: RCCL communicator owned by the C library; the all-reduces are stream-ordered launches inside the decode graph
+            idbuf = torch.zeros(128, dtype=torch.uint8, device=f"cuda:{local}")
+            if rank == 0:
+                raw = (C.c_char * 128)()
+                pkg.lib.check(L.cllm_tp_unique_id(raw), "tp_unique_id")
+                idbuf.copy_(torch.frombuffer(bytearray(raw.raw), dtype=torch.uint8))
+            dist.broadcast(idbuf, 0)
+            raw = (C.c_char * 128).from_buffer_copy(bytes(idbuf.cpu().numpy().tobytes()))
+            comm = C.c_void_p()
+            pkg.lib.check(L.cllm_tp_init(raw, rank, world, C.byref(comm)), "tp_init")
+            m.set_tp_comm(comm)
+            log(f"[rank {rank}] tensor parallel over RCCL (native communicator, all-reduce inside the decode graph)")
+        except Exception as e:                        # noqa: BLE001 -- fall back to torch.distributed through the host callback
+            log(f"[rank {rank}] native RCCL path unavailable ({e}); using the torch.distributed callback")
 
-        class _Arr:                       # wrap the raw device pointer for torch (zero copy)
-            def __init__(self, ptr, n):
-                self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<f4", "data": (ptr, False), "version": 2}
+            class _Arr:                       # wrap the raw device pointer for torch (zero copy)
+                def __init__(self, ptr, n):
+                    self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<f4", "data": (ptr, False), "version": 2}
 
-        def allreduce(stream, buf, n):
-            dist.all_reduce(torch.as_tensor(_Arr(buf, n), device=f"cuda:{local}"))
-        m.set_allreduce(allreduce)
+            def allreduce(stream, buf, n):
+                pkg.ops.sync()                        # the runner's kernels are on its own stream: order them before torch's collective ...
+                dist.all_reduce(torch.as_tensor(_Arr(buf, n), device=f"cuda:{local}"))
+                torch.cuda.current_stream().synchronize()          # ... and the collective before the runner continues
+            m.set_allreduce(allreduce)
 
     def sync_all():
         if dist is not None:

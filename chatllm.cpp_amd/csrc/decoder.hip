@@ -47,6 +47,7 @@ struct cllm_llama {
     void *  wdata = nullptr; size_t wsize = 0;
     int32_t * tokens_dev = nullptr, * pos_dev = nullptr;
     cllm_allreduce_fn allreduce = nullptr; void * allreduce_user = nullptr;
+    void * tp_comm = nullptr;         // RCCL communicator (cllm_tp_init): the all-reduce runs on the runner's stream, inside the decode graph
     bool use_graph = true;
     hipGraphExec_t decode_graph = nullptr;
     int32_t * next_tok_dev = nullptr;            // greedy feedback
@@ -146,6 +147,15 @@ static int set_w(cllm_llama * m, const char * name, int type, void * data, size_
 extern "C" int cllm_llama_set_weight(cllm_llama * m, const char * name, int type, const void * data, size_t nbytes) { return set_w(m, name, type, (void *) data, nbytes, true); }
 extern "C" int cllm_llama_bind_weight(cllm_llama * m, const char * name, int type, void * dev, size_t nbytes) { return set_w(m, name, type, dev, nbytes, false); }
 extern "C" int cllm_llama_set_allreduce(cllm_llama * m, cllm_allreduce_fn fn, void * user) { if (!m) FAIL(CLLM_E_INVALID, "null"); m->allreduce = fn; m->allreduce_user = user; return CLLM_OK; }
+extern "C" int cllm_llama_set_tp_comm(cllm_llama * m, void * comm) { if (!m) FAIL(CLLM_E_INVALID, "null"); m->tp_comm = comm; return CLLM_OK; }
+extern "C" int cllm_tp_all_reduce_f32(void * comm, void * stream, float * buf, size_t n);
+// sum `n` floats of `buf` over the tensor-parallel group, stream-ordered: RCCL if a communicator is bound, else the host callback
+static int tp_allreduce(cllm_llama * m, hipStream_t st, float * buf, int64_t n) {
+    if (m->tp_comm) return cllm_tp_all_reduce_f32(m->tp_comm, st, buf, (size_t) n);
+    if (m->allreduce) { m->allreduce(m->allreduce_user, st, buf, n); return CLLM_OK; }
+    FAIL(CLLM_E_INVALID, "llama: tp_size > 1 needs cllm_llama_set_tp_comm or cllm_llama_set_allreduce");
+}
+static bool tp_on(const cllm_llama * m) { return m->cfg.tp_size > 1 && (m->tp_comm || m->allreduce); }
 extern "C" int cllm_llama_use_graph(cllm_llama * m, int enable) { if (!m) FAIL(CLLM_E_INVALID, "null"); m->use_graph = enable != 0; return CLLM_OK; }
 extern "C" size_t cllm_llama_weight_bytes(const cllm_llama * m) { return m ? m->weight_bytes : 0; }
 
@@ -343,7 +353,7 @@ static int forward_general(cllm_llama * m, int qlen, int n_past) {
             TRY(cllm_op_cpy(st, &Cp, &A));
         }
         TRY(linear(m, L.wo, QD, H, m->att, qlen, m->o));
-        if (m->allreduce && c.tp_size > 1) m->allreduce(m->allreduce_user, st, m->o, H * qlen);
+        if (tp_on(m)) TRY(tp_allreduce(m, (hipStream_t) st, m->o, H * qlen));
         TRY(cllm_op_add(st, &O, &X, &X));
 
         cllm_tensor wf = T(CLLM_TYPE_F32, L.ffn_norm.data, H);
@@ -362,7 +372,7 @@ static int forward_general(cllm_llama * m, int qlen, int n_past) {
             TRY(cllm_op_silu_mul(st, &G, &U, &G));
         }
         TRY(linear(m, L.wdown, F, H, m->g, qlen, m->o));
-        if (m->allreduce && c.tp_size > 1) m->allreduce(m->allreduce_user, st, m->o, H * qlen);
+        if (tp_on(m)) TRY(tp_allreduce(m, (hipStream_t) st, m->o, H * qlen));
         TRY(cllm_op_add(st, &O, &X, &X));
     }
     // LMFinalSteps: last token -> norm -> lm_head
@@ -394,7 +404,7 @@ static int decode_step_fused(cllm_llama * m, bool sample) {
     const cllm_llama_config & c = m->cfg;
     const int64_t H = c.hidden, hd = c.head_dim, QD = (int64_t) m->nh * hd, KD = (int64_t) m->nkv * hd, F = m->F, V = c.vocab, ML = c.max_len;
     hipStream_t st = m->st;
-    const bool tp = m->allreduce && c.tp_size > 1;
+    const bool tp = tp_on(m);
     {
         cllm_tensor E = T(m->tok_embd.type, m->tok_embd.data, H, V), ids = T(CLLM_TYPE_I32, m->tokens_dev, 1), X = T(CLLM_TYPE_F32, m->x, H, 1);
         TRY(cllm_op_get_rows(st, &E, &ids, &X));
@@ -415,7 +425,7 @@ static int decode_step_fused(cllm_llama * m, bool sample) {
         if (!tp) TRY(launch_mmvq_fused(st, L.wo.type, L.wo.data, QD, H, 2, m->att, nullptr, 0.0f, 0, m->x, nullptr, m->x));          // x = o + x
         else {
             TRY(launch_mmvq_fused(st, L.wo.type, L.wo.data, QD, H, 2, m->att, nullptr, 0.0f, 0, m->o, nullptr, nullptr));
-            m->allreduce(m->allreduce_user, st, m->o, H);
+            TRY(tp_allreduce(m, st, m->o, H));
             cllm_tensor O = T(CLLM_TYPE_F32, m->o, H), X = T(CLLM_TYPE_F32, m->x, H);
             TRY(cllm_op_add(st, &O, &X, &X));
         }
@@ -429,7 +439,7 @@ static int decode_step_fused(cllm_llama * m, bool sample) {
         if (!tp) TRY(launch_mmvq_fused(st, L.wdown.type, L.wdown.data, F, H, dpro, dsrc, nullptr, 0.0f, 0, m->x, nullptr, m->x));   // x = down + x
         else {
             TRY(launch_mmvq_fused(st, L.wdown.type, L.wdown.data, F, H, dpro, dsrc, nullptr, 0.0f, 0, m->o, nullptr, nullptr));
-            m->allreduce(m->allreduce_user, st, m->o, H);
+            TRY(tp_allreduce(m, st, m->o, H));
             cllm_tensor O = T(CLLM_TYPE_F32, m->o, H), X = T(CLLM_TYPE_F32, m->x, H);
             TRY(cllm_op_add(st, &O, &X, &X));
         }
@@ -441,7 +451,7 @@ static int decode_step_fused(cllm_llama * m, bool sample) {
 
 // capture one sampled step into a graph (after one eager warm-up step has set every function attribute)
 static int ensure_decode_graph(cllm_llama * m) {
-    if (m->decode_graph || !m->use_graph || (m->allreduce && m->cfg.tp_size > 1)) return CLLM_OK;
+    if (m->decode_graph || !m->use_graph || (m->cfg.tp_size > 1 && !m->tp_comm)) return CLLM_OK;     // a host callback cannot be captured; RCCL can
     hipGraph_t graph = nullptr;
     HIP_TRY(hipStreamBeginCapture(m->st, hipStreamCaptureModeRelaxed));
     const int rc = decode_step_fused(m, true);

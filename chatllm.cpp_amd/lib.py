@@ -87,6 +87,11 @@ SIGNATURES = {
     "cllm_llama_set_weight": (C.c_int, [_P, C.c_char_p, C.c_int, _P, C.c_size_t]),
     "cllm_llama_bind_weight": (C.c_int, [_P, C.c_char_p, C.c_int, _P, C.c_size_t]),
     "cllm_llama_set_allreduce": (C.c_int, [_P, ALLREDUCE_FN, _P]),
+    "cllm_tp_unique_id": (C.c_int, [_P]),
+    "cllm_tp_init": (C.c_int, [_P, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+    "cllm_tp_destroy": (C.c_int, [_P]),
+    "cllm_tp_all_reduce_f32": (C.c_int, [_P, _P, _P, C.c_size_t]),
+    "cllm_llama_set_tp_comm": (C.c_int, [_P, _P]),
     "cllm_llama_forward": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, _P]),
     "cllm_llama_decode_greedy": (C.c_int, [_P, C.c_int32, C.c_int, C.c_int, _P]),
     "cllm_llama_decode_fused_logits": (C.c_int, [_P, C.c_int32, C.c_int, _P]),

@@ -36,6 +36,10 @@ class Llama:
         self._cb = _l.ALLREDUCE_FN(lambda user, stream, buf, n: fn(stream, buf, n))
         _l.check(_l.get().cllm_llama_set_allreduce(self.h, self._cb, None), "set_allreduce")
 
+    def set_tp_comm(self, comm):
+        """bind an RCCL communicator (lib cllm_tp_init): all-reduces run on the runner's stream, inside the decode graph"""
+        _l.check(_l.get().cllm_llama_set_tp_comm(self.h, comm), "set_tp_comm")
+
     def use_graph(self, enable):
         _l.check(_l.get().cllm_llama_use_graph(self.h, 1 if enable else 0), "use_graph")
 

@@ -193,6 +193,15 @@ CLLM_API int  cllm_llama_set_weight(cllm_llama * m, const char * name, int type,
 /* same, but `data` is a DEVICE pointer that the caller keeps alive (no copy) */
 CLLM_API int  cllm_llama_bind_weight(cllm_llama * m, const char * name, int type, void * dev_data, size_t nbytes);
 CLLM_API int  cllm_llama_set_allreduce(cllm_llama * m, cllm_allreduce_fn fn, void * user);
+/* Tensor parallelism over RCCL/xGMI (cfg.tp_size > 1; the reference only splits by layer, SplitMethod::Row is a TODO in
+ * src/backend.cpp:677-778): one all-reduce(sum) of [hidden] fp32 after o_proj and after down_proj, issued on the runner's own
+ * stream, hence part of the captured decode graph.  Rank 0 creates the 128-byte id, the host broadcasts it, every rank calls
+ * cllm_tp_init (collective) and binds the communicator to its model.  librccl.so is dlopen'ed on first use. */
+CLLM_API int  cllm_tp_unique_id(void * out128);
+CLLM_API int  cllm_tp_init(const void * id128, int rank, int nranks, void ** comm_out);
+CLLM_API int  cllm_tp_destroy(void * comm);
+CLLM_API int  cllm_tp_all_reduce_f32(void * comm, void * stream, float * buf, size_t n);
+CLLM_API int  cllm_llama_set_tp_comm(cllm_llama * m, void * comm);
 /* run qlen tokens (host int32) at positions n_past..; writes logits[vocab] of the last token to
  * logits_dev (device, may be NULL) and/or logits_host (may be NULL; implies a stream sync).               */
 CLLM_API int  cllm_llama_forward(cllm_llama * m, const int32_t * tokens, int qlen, int n_past, float * logits_dev,

@@ -1,0 +1,78 @@
+"""Tensor-parallel plumbing on ONE GPU (the multi-GPU run itself is the driver's): an RCCL communicator of one rank is
+created through the C ABI, its all-reduce is stream-ordered and capturable, and a rank-0 shard of a tp_size-2 model decodes
+identically whether its (single-rank, hence identity) all-reduce goes through RCCL inside the captured decode graph or
+through a host callback launched eagerly."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import bench
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def comm(gpu):
+    L = gpu.lib.get()
+    raw = (C.c_char * 128)()
+    gpu.lib.check(L.cllm_tp_unique_id(raw), "tp_unique_id")
+    c = C.c_void_p()
+    gpu.lib.check(L.cllm_tp_init(raw, 0, 1, C.byref(c)), "tp_init")
+    yield c
+    gpu.lib.check(L.cllm_tp_destroy(c), "tp_destroy")
+
+
+def test_single_rank_all_reduce_is_identity_and_stream_ordered(gpu, comm):
+    L = gpu.lib.get()
+    x = np.random.default_rng(0).standard_normal(4096).astype(np.float32)
+    d = gpu.Tensor.from_numpy(x.reshape(1, -1))
+    gpu.lib.check(L.cllm_tp_all_reduce_f32(comm, None, d.data_ptr(), x.size), "all_reduce")
+    assert np.array_equal(d.numpy().ravel(), x)
+
+
+def test_bad_arguments_are_rejected(gpu):
+    L = gpu.lib.get()
+    c = C.c_void_p()
+    assert L.cllm_tp_init(None, 0, 1, C.byref(c)) != 0
+    raw = (C.c_char * 128)()
+    assert L.cllm_tp_init(raw, 3, 2, C.byref(c)) != 0          # rank outside the group
+
+
+def _rank0_shard_model(gpu, cfg, wtype, seed):
+    w = gpu.synth.make_model(cfg, wtype, seed=seed)
+    hd = cfg["head_dim"]
+    QD, F = cfg["n_head"] * hd, cfg["ffn"]
+    sh = {}
+    for name, (t, arr) in w.items():
+        base = name.split(".")[-1]
+        if base in ("wq", "wk", "wv", "wgate", "wup"):
+            arr = bench.shard_rows(arr, 0, 2)
+        elif base == "wo":
+            arr = bench.shard_cols(arr, t, QD, 0, 2, gpu)
+        elif base == "wdown":
+            arr = bench.shard_cols(arr, t, F, 0, 2, gpu)
+        sh[name] = (t, arr)
+    return sh
+
+
+def test_rccl_all_reduce_inside_the_decode_graph_matches_the_host_callback(gpu, comm):
+    cfg = gpu.synth.config("small", max_len=64, ffn=2048)        # ffn / 256 divisible by the group size
+    w = _rank0_shard_model(gpu, cfg, gpu.Q4_K, seed=11)
+    prompt = np.random.default_rng(3).integers(0, cfg["vocab"], 7).astype(np.int32)
+
+    a = gpu.Llama(cfg, w, tp_rank=0, tp_size=2)
+    a.set_tp_comm(comm)                                   # RCCL, captured in the hipGraph
+    la = a.forward(prompt)
+    ids_a = a.decode_greedy(int(np.argmax(la)), 24)
+
+    b = gpu.Llama(cfg, w, tp_rank=0, tp_size=2)
+    calls = []
+    b.set_allreduce(lambda stream, buf, n: calls.append(n))   # identity all-reduce of a one-rank "group", eager launches
+    lb = b.forward(prompt)
+    ids_b = b.decode_greedy(int(np.argmax(lb)), 24)
+
+    assert np.array_equal(la, lb)
+    assert np.array_equal(ids_a, ids_b)
+    assert len(calls) == 2 * cfg["n_layer"] * (1 + 24)    # two all-reduces per layer per forward
+    a.close(); b.close()
