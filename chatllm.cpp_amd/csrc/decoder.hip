@@ -415,36 +415,49 @@ static int decode_step_fused(cllm_llama * m, bool sample) {
     if (cs_table) TRY(launch_rope_table(st, m->pos_dev, (int) hd, c.rope_theta, rope_cs));
     // 5 launches per layer: [norm+quant+qkv GEMV(+bias)] [rope+kv-write+attention] [quant+o GEMV+residual]
     //                       [norm+quant+gate/up GEMV+silu*up] [quant+down GEMV+residual]
+    // Tensor parallel: o / down write partial sums to m->o, all-reduced in place; the residual add x += o is folded into the NEXT
+    // mat-vec's RMS_NORM prologue (which stores the new x into the other of two ping-pong buffers) when that kernel takes it,
+    // else done by an ADD launch.
+    float * xc = m->x;                       // current residual stream
+    const float * pend = nullptr;            // all-reduced partial not yet added to xc
+    auto norm_gemv = [&](const dweight & w, int64_t nrows, const float * nw, int epi, float * dst, const float * bias) -> int {
+        if (pend) {
+            float * xo = xc == m->x ? m->xn : m->x;
+            int rc = w.type == CLLM_TYPE_Q4_K ? launch_gemv_q4_K_decode(st, w.data, H, nrows, 1, xc, nw, c.rms_eps, epi, dst, bias, nullptr, pend, xo) : CLLM_E_UNSUPPORTED;
+            if (rc == CLLM_OK) { xc = xo; pend = nullptr; return rc; }
+            if (rc != CLLM_E_UNSUPPORTED) return rc;
+            cllm_tensor O = T(CLLM_TYPE_F32, (void *) pend, H), X = T(CLLM_TYPE_F32, xc, H);
+            TRY(cllm_op_add(st, &O, &X, &X));
+            pend = nullptr;
+        }
+        return launch_mmvq_fused(st, w.type, w.data, H, nrows, 1, xc, nw, c.rms_eps, epi, dst, bias, nullptr);
+    };
     for (int il = 0; il < c.n_layer; il++) {
         llama_layer & L = m->layers[il];
-        TRY(launch_mmvq_fused(st, L.wqkv.type, L.wqkv.data, H, QD + 2*KD, 1, m->x, (const float *) L.attn_norm.data, c.rms_eps, 0, m->qkv,
-                              c.qkv_bias ? (const float *) L.bqkv.data : nullptr, nullptr));
+        TRY(norm_gemv(L.wqkv, QD + 2*KD, (const float *) L.attn_norm.data, 0, m->qkv, c.qkv_bias ? (const float *) L.bqkv.data : nullptr));
         int arc = cs_table ? launch_attn_dec_table(st, m->qkv, m->pos_dev, rope_cs, m->nh, m->nkv, (int) hd, c.rope_mode, L.k_cache, L.v_cache, ML, m->att) : CLLM_E_UNSUPPORTED;
         if (arc == CLLM_E_UNSUPPORTED) arc = launch_rope_kv_attn_decode(st, m->qkv, m->pos_dev, m->nh, m->nkv, (int) hd, c.rope_mode, c.rope_theta, L.k_cache, L.v_cache, ML, m->att);
         TRY(arc);
-        if (!tp) TRY(launch_mmvq_fused(st, L.wo.type, L.wo.data, QD, H, 2, m->att, nullptr, 0.0f, 0, m->x, nullptr, m->x));          // x = o + x
+        if (!tp) TRY(launch_mmvq_fused(st, L.wo.type, L.wo.data, QD, H, 2, m->att, nullptr, 0.0f, 0, xc, nullptr, xc));          // x = o + x
         else {
             TRY(launch_mmvq_fused(st, L.wo.type, L.wo.data, QD, H, 2, m->att, nullptr, 0.0f, 0, m->o, nullptr, nullptr));
             TRY(tp_allreduce(m, st, m->o, H));
-            cllm_tensor O = T(CLLM_TYPE_F32, m->o, H), X = T(CLLM_TYPE_F32, m->x, H);
-            TRY(cllm_op_add(st, &O, &X, &X));
+            pend = m->o;
         }
         // Q4_K gate/up: the wave that owns a feature's row pair applies SiLU(gate)*up itself, the down mat-vec only quantizes;
         // otherwise the down mat-vec's prologue does SiLU*up on the interleaved pairs
         const bool silu_epi = L.wgu.type == CLLM_TYPE_Q4_K && F % 8 == 0;
         const float * dsrc = silu_epi ? m->g : m->gu;
         const int dpro = silu_epi ? 2 : 3;
-        TRY(launch_mmvq_fused(st, L.wgu.type, L.wgu.data, H, 2*F, 1, m->x, (const float *) L.ffn_norm.data, c.rms_eps, silu_epi ? 1 : 0,
-                              silu_epi ? m->g : m->gu, nullptr, nullptr));
-        if (!tp) TRY(launch_mmvq_fused(st, L.wdown.type, L.wdown.data, F, H, dpro, dsrc, nullptr, 0.0f, 0, m->x, nullptr, m->x));   // x = down + x
+        TRY(norm_gemv(L.wgu, 2*F, (const float *) L.ffn_norm.data, silu_epi ? 1 : 0, silu_epi ? m->g : m->gu, nullptr));
+        if (!tp) TRY(launch_mmvq_fused(st, L.wdown.type, L.wdown.data, F, H, dpro, dsrc, nullptr, 0.0f, 0, xc, nullptr, xc));   // x = down + x
         else {
             TRY(launch_mmvq_fused(st, L.wdown.type, L.wdown.data, F, H, dpro, dsrc, nullptr, 0.0f, 0, m->o, nullptr, nullptr));
             TRY(tp_allreduce(m, st, m->o, H));
-            cllm_tensor O = T(CLLM_TYPE_F32, m->o, H), X = T(CLLM_TYPE_F32, m->x, H);
-            TRY(cllm_op_add(st, &O, &X, &X));
+            pend = m->o;
         }
     }
-    TRY(launch_mmvq_fused(st, m->lm_head.type, m->lm_head.data, H, V, 1, m->x, (const float *) m->out_norm.data, c.rms_eps, 0, m->logits, nullptr, nullptr));
+    TRY(norm_gemv(m->lm_head, V, (const float *) m->out_norm.data, 0, m->logits, nullptr));
     if (sample) TRY(launch_argmax_advance(st, m->logits, (int) V, m->tokens_dev, m->pos_dev, m->out_ring, m->counter_dev, (float *)(m->counter_dev + 16), (int *)(m->counter_dev + 16 + 256)));
     return CLLM_OK;
 }

@@ -34,8 +34,9 @@ __device__ __forceinline__ float silu_any(float x, bool body) { return body ? si
 #define TS(k) do { if (ts && threadIdx.x == 0) ts[blockIdx.x * 8 + (k)] = wall_clock64(); } while (0)
 
 template <int PRO, int EPI, int NPRE>
-__global__ void __launch_bounds__(1024) k_gemv_q4_K_dec(const float * __restrict__ px, const float * __restrict__ pw, const char * __restrict__ W,
-                                                        int nblk, int kfull, int nrem, float eps, float * __restrict__ dst,
+__global__ void __launch_bounds__(1024) k_gemv_q4_K_dec(const float * __restrict__ px, const float * __restrict__ pw, const float * __restrict__ padd,
+                                                        const char * __restrict__ W, int nblk, int kfull, int nrem, float eps,
+                                                        float * __restrict__ dst, float * __restrict__ xout,
                                                         const float * __restrict__ bias, const float * resid, unsigned long long * ts) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     constexpr int P = 2, RU = EPI == 1 ? 2 : 1;
@@ -54,6 +55,11 @@ __global__ void __launch_bounds__(1024) k_gemv_q4_K_dec(const float * __restrict
         vv[u] = *(const f32x4 *)(px + ec * vmul);
         if (PRO != 2) gg[u] = *(const f32x4 *)(gp + ec * vmul);
     }
+    // tensor parallel (PRO 1, NPRE 1): the all-reduced partial of the previous mat-vec is added to the residual stream here
+    // (x + padd feeds the norm; workgroup 0 stores it to xout, a different buffer than px) instead of in a launch of its own
+    f32x4 pa = {0, 0, 0, 0};
+    const bool add = PRO == 1 && NPRE == 1 && padd != nullptr;
+    if (add) pa = *(const f32x4 *)(padd + (e0 < K ? e0 : 0));
     TS(0);
 
     // ---- (2) two steps of weight prefetch.  Units are dealt in rounds of nwaves: in a full round wave (b, w) takes unit
@@ -84,6 +90,10 @@ __global__ void __launch_bounds__(1024) k_gemv_q4_K_dec(const float * __restrict
 
     // ---- (3) the activation row: [RMS_NORM * weight | SiLU * up |] quantize -> LDS (act layout of common.h) ----
     float scale = 1.0f;
+    if (add) {
+        vv[0].x = vv[0].x + pa.x; vv[0].y = vv[0].y + pa.y; vv[0].z = vv[0].z + pa.z; vv[0].w = vv[0].w + pa.w;
+        if (blockIdx.x == 0 && e0 < K) *(f32x4 *)(xout + e0) = vv[0];
+    }
     if (PRO == 1) {
         __shared__ double part[16];
         const double sum = rms_block_sumsq_1024(px, K, vv[0], part);
@@ -145,7 +155,8 @@ __global__ void __launch_bounds__(1024) k_gemv_q4_K_dec(const float * __restrict
 
 // K multiple of 256, K <= 16384, nrows * row bytes < 4 GiB; returns CLLM_E_UNSUPPORTED for shapes the general kernels must take
 int launch_gemv_q4_K_decode(hipStream_t st, const void * W, int64_t K, int64_t nrows, int pro, const float * px, const float * pw, float eps,
-                            int epi, float * dst, const float * bias, const float * resid) {
+                            int epi, float * dst, const float * bias, const float * resid, const float * padd, float * xout) {
+    if (padd && (pro != 1 || K > 4096 || !xout || xout == px)) return CLLM_E_UNSUPPORTED;
     if (K % 256 || K > 16384 || pro < 1 || pro > 3 || nrows <= 0 || (uint64_t) nrows * (uint64_t)(K / 256 * 144) >= (1ull << 32)) return CLLM_E_UNSUPPORTED;
     if (epi == 1 && (pro != 1 || nrows % 2 || (nrows / 2) % 8 || bias || resid)) FAIL(CLLM_E_UNSUPPORTED, "gemv_decode: SiLU epilogue needs gate/up row pairs, features %% 8 == 0");
     const int64_t units = epi == 1 ? nrows / 2 : nrows;
@@ -155,7 +166,7 @@ int launch_gemv_q4_K_decode(hipStream_t st, const void * W, int64_t K, int64_t n
     const int kfull = (int)(units / nwaves), nrem = (int)(units % nwaves), nblk = (int)(K / 256);
     const size_t lds = act_row_bytes(K, 256);
     const bool small = K <= 4096;
-#define GO(PRO_, EPI_, NPRE_) hipLaunchKernelGGL((k_gemv_q4_K_dec<PRO_, EPI_, NPRE_>), dim3((unsigned) grid), dim3(1024), lds, st, px, pw, (const char *) W, nblk, kfull, nrem, eps, dst, bias, resid, g_gemv_ts)
+#define GO(PRO_, EPI_, NPRE_) hipLaunchKernelGGL((k_gemv_q4_K_dec<PRO_, EPI_, NPRE_>), dim3((unsigned) grid), dim3(1024), lds, st, px, pw, padd, (const char *) W, nblk, kfull, nrem, eps, dst, xout, bias, resid, g_gemv_ts)
     if (pro == 1 && epi == 1) { if (small) GO(1, 1, 1); else GO(1, 1, 4); }
     else if (pro == 1)        { if (small) GO(1, 0, 1); else GO(1, 0, 4); }
     else if (pro == 2)        { if (small) GO(2, 0, 1); else GO(2, 0, 4); }

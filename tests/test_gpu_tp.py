@@ -75,4 +75,20 @@ def test_rccl_all_reduce_inside_the_decode_graph_matches_the_host_callback(gpu, 
     assert np.array_equal(la, lb)
     assert np.array_equal(ids_a, ids_b)
     assert len(calls) == 2 * cfg["n_layer"] * (1 + 24)    # two all-reduces per layer per forward
-    a.close(); b.close()
+
+    # the fused TP step folds "x += all-reduced partial" into the next mat-vec's RMS_NORM prologue; the node-by-node path adds
+    # with an ADD node: same bits
+    import os
+    c = gpu.Llama(cfg, w, tp_rank=0, tp_size=2)
+    c.set_allreduce(lambda stream, buf, n: None)
+    lc = c.forward(prompt)
+    os.environ["CLLM_NO_FUSED"] = "1"
+    try:
+        ids_c = c.decode_greedy(int(np.argmax(lc)), 24)
+    finally:
+        del os.environ["CLLM_NO_FUSED"]
+    assert np.array_equal(ids_a, ids_c)
+    la2 = a.decode_fused_logits(int(ids_a[-1]))
+    lc2 = c.forward([int(ids_c[-1])])
+    assert np.array_equal(la2, lc2)
+    a.close(); b.close(); c.close()
