@@ -137,8 +137,23 @@ __device__ __forceinline__ double rms_block_sumsq_1024(const float * __restrict_
 // decode kernels' cold critical path); the general division sits in a noinline function off the straight-line code.
 static __device__ __noinline__ double rms_div(double sum, double n) { return sum / n; }
 __device__ __forceinline__ float rms_scale(double sum, int64_t n, float eps) {
-    const double m = (n & (n - 1)) == 0 ? sum * (1.0 / (double) n) : rms_div(sum, (double) n);
+    const double m = (n & (n - 1)) == 0 ? ldexp(sum, -(int) __builtin_ctzll((unsigned long long) n)) : rms_div(sum, (double) n);
     return 1.0f / sqrtf((float) m + eps);
+}
+
+// the same sum for rows of at most 4096 elements (n % 4 == 0): every thread owns at most one group, no loop, no tail --
+// identical bits, a fraction of the code (decode kernels: code before the main loop is fetched cold)
+__device__ __forceinline__ double rms_block_sumsq_1024_one(f32x4 v, bool has, double * part) {
+    const int tid = threadIdx.x;
+    double sum = 0.0;
+    if (has) { sum += (double)(v.x * v.x); sum += (double)(v.y * v.y); sum += (double)(v.z * v.z); sum += (double)(v.w * v.w); }
+    sum = wave_sum_d(sum);
+    if ((tid & 63) == 0) part[tid >> 6] = sum;
+    __syncthreads();
+    double tot = part[0];
+#pragma unroll
+    for (int w = 1; w < 16; w++) tot += part[w];
+    return tot;
 }
 
 // load through the scalar cache (p must be wave-uniform; the data must not have been written by this kernel before).

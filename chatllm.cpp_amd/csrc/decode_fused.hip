@@ -23,6 +23,8 @@
 // the new k / v to fp16 exactly as the cache write would, uses them straight from LDS for position `pos`, and the first
 // head of each GQA group stores them into the caches (so RoPE + SET_ROWS + CPY cost no launch of their own).
 static float * g_attn_dbg = nullptr;
+static unsigned long long * g_attn_ts = nullptr;
+extern "C" __attribute__((visibility("default"))) void cllm_debug_set_attn_ts(unsigned long long * dev_buf) { g_attn_ts = dev_buf; }   // tools only
 extern "C" __attribute__((visibility("default"))) void cllm_debug_set_attn_probs(float * dev_buf) { g_attn_dbg = dev_buf; }   // tools only
 
 // Latency structure (one launch is ~4.5 us of fixed cost, the rest is a chain of dependent memory round trips): the
@@ -302,7 +304,8 @@ __device__ __forceinline__ int uniform_load_i32(const int32_t * p) {
 template <int HD, int MODE>      // MODE 0: adjacent pairs (GGML_ROPE_TYPE_NORMAL), 2: NEOX halves
 __global__ void __launch_bounds__(1024) k_attn_dec(const float * __restrict__ qkv, const int32_t * __restrict__ pos_dev, const float * __restrict__ rope_cs,
                                                    int nh, int nkv, float scale, uint16_t * __restrict__ k_cache, uint16_t * __restrict__ v_cache,
-                                                   int ML, float * __restrict__ att) {
+                                                   int ML, float * __restrict__ att, unsigned long long * ts) {
+#define TS(k) do { if (ts && threadIdx.x == 0) ts[(blockIdx.y * gridDim.x + blockIdx.x) * 8 + (k)] = wall_clock64(); } while (0)
     extern __shared__ __attribute__((aligned(16))) float sm[];       // [HD] q (fp16-rounded) | [HD] new k | [HD] new v | [n_kv] scores
     __shared__ double red_d[1];
     __shared__ float  red_f[16];
@@ -350,6 +353,7 @@ __global__ void __launch_bounds__(1024) k_attn_dec(const float * __restrict__ qk
         }
     }
 
+    TS(0);
     // ---- (3) RoPE, fp16 rounding, cache write ----
     if (is_pair) {
         const float y0 = px0*pc - px1*ps, y1 = px0*ps + px1*pc;
@@ -362,6 +366,7 @@ __global__ void __launch_bounds__(1024) k_attn_dec(const float * __restrict__ qk
         v_cache[((int64_t) g * HD + tid) * ML + pos] = f2h(vnew[tid]);
     }
 
+    TS(1);
     // ---- (4) scores[i] = K[i] . q * scale ----
     for (int ib = ib0; ib < n_kv; ib += U * stride) {
         u32x4 r[U];
@@ -397,6 +402,7 @@ __global__ void __launch_bounds__(1024) k_attn_dec(const float * __restrict__ qk
         }
     }
     __syncthreads();
+    TS(2);
 
     // ---- (5) soft_max over sc[0..n_kv): same partition as k_soft_max (one wave, lane = groups of 8) ----
     float mx = -INFINITY;
@@ -425,6 +431,7 @@ __global__ void __launch_bounds__(1024) k_attn_dec(const float * __restrict__ qk
     const float inv = (float)(1.0 / red_d[0]);
     for (int i = tid; i < n_kv; i += 1024) sc[i] = h2f(f2h(sc[i] * inv));   // probability, then its fp16 rounding for V.P
     __syncthreads();
+    TS(3);
 
     // ---- (6) ctx = V . P ----
     for (int db = db0; db < HD; db += U * stridev) {
@@ -469,6 +476,8 @@ __global__ void __launch_bounds__(1024) k_attn_dec(const float * __restrict__ qk
             if (glv == 0) att[h * HD + d0] = acc;
         }
     }
+    TS(4);
+#undef TS
 }
 
 // RoPE + KV-cache write + attention with the position's cos/sin table (launch_rope_table); CLLM_E_UNSUPPORTED -> use the general kernel
@@ -482,7 +491,7 @@ int launch_attn_dec_table(hipStream_t st, const float * qkv, const int32_t * pos
 #define GO(HD_, MODE_) do { \
         static bool attr = false; \
         if (lds > 48 * 1024 && !attr) { HIP_TRY(hipFuncSetAttribute((const void *) k_attn_dec<HD_, MODE_>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024)); attr = true; } \
-        hipLaunchKernelGGL((k_attn_dec<HD_, MODE_>), grid, dim3(1024), lds, st, qkv, pos_dev, rope_cs, nh, nkv, scale, k_cache, v_cache, (int) ML, att); } while (0)
+        hipLaunchKernelGGL((k_attn_dec<HD_, MODE_>), grid, dim3(1024), lds, st, qkv, pos_dev, rope_cs, nh, nkv, scale, k_cache, v_cache, (int) ML, att, g_attn_ts); } while (0)
     if (hd == 128) { if (mode == 0) GO(128, 0); else GO(128, 2); }      // any other mode pairs NEOX-style, as in the general kernel
     else           { if (mode == 0) GO(64, 0);  else GO(64, 2); }
 #undef GO

@@ -96,7 +96,7 @@ __global__ void __launch_bounds__(1024) k_gemv_q4_K_dec(const float * __restrict
     }
     if (PRO == 1) {
         __shared__ double part[16];
-        const double sum = rms_block_sumsq_1024(px, K, vv[0], part);
+        const double sum = NPRE == 1 ? rms_block_sumsq_1024_one(vv[0], e0 < K, part) : rms_block_sumsq_1024(px, K, vv[0], part);
         scale = rms_scale(sum, K, eps);
     }
     const int nv = K & ~7;                                          // ggml_vec_silu_f32: polynomial body below nv, libm tail
