@@ -21,14 +21,14 @@
 typedef int   i32x4 __attribute__((ext_vector_type(4)));
 
 #define MMQ_BN 128
-#define MMQ_BM 64
-#define MMQ_MI 2            // 16-row token patches per wave (wave quadrant = 32 tokens x 64 weight rows)
+// token tile: MI 16-row patches per wave, two wave rows -> BM = 32 * MI tokens per workgroup.  Q4_0 / Q8_0 take 128 tokens (the
+// weight unpack is amortised over twice the MACs); Q4_K carries int32 + fp32 accumulators and would spill: 64 tokens.
 #define MMQ_LD 272           // bytes per LDS tile row: 256 int8 + 16 pad
 
 template <int TYPE> struct mmq_traits;
-template <> struct mmq_traits<CLLM_TYPE_Q4_K> { static constexpr int kb = 256; };
-template <> struct mmq_traits<CLLM_TYPE_Q4_0> { static constexpr int kb = 32; };
-template <> struct mmq_traits<CLLM_TYPE_Q8_0> { static constexpr int kb = 32; };
+template <> struct mmq_traits<CLLM_TYPE_Q4_K> { static constexpr int kb = 256, MI = 2; };
+template <> struct mmq_traits<CLLM_TYPE_Q4_0> { static constexpr int kb = 32,  MI = 4; };
+template <> struct mmq_traits<CLLM_TYPE_Q8_0> { static constexpr int kb = 32,  MI = 4; };
 
 struct mmq_args {
     const char * W; int64_t nb01; int64_t N; int64_t K;
@@ -43,11 +43,10 @@ struct mmq_args {
 //   Xsc : Q4_K: dx[m] f32 | sx[8][m] i32                                   others: dx[8][m] f32
 constexpr int LDS_WT = 0;
 constexpr int LDS_XT = LDS_WT + MMQ_BN * MMQ_LD;
-constexpr int LDS_WS = LDS_XT + MMQ_BM * MMQ_LD;
 constexpr int LDS_WS_BYTES = MMQ_BN * 8 * 4;                 // 4 KB either way (Q4_K uses 8+8+4+4 = 24 B per row)
-constexpr int LDS_XS = LDS_WS + LDS_WS_BYTES;
-constexpr int LDS_XS_BYTES = MMQ_BM * 9 * 4;
-constexpr int LDS_TOTAL = LDS_XS + LDS_XS_BYTES;
+constexpr int lds_ws(int bm) { return LDS_XT + bm * MMQ_LD; }
+constexpr int lds_xs(int bm) { return lds_ws(bm) + LDS_WS_BYTES; }
+constexpr int lds_total(int bm) { return lds_xs(bm) + bm * 9 * 4; }
 
 __device__ __forceinline__ uint32_t nib_minus8(uint32_t nib4) {   // four nibbles (one per byte, 0..15) -> four int8 (nib - 8)
     return (((nib4 | 0x80808080u) - 0x08080808u) ^ 0x80808080u);
@@ -57,6 +56,8 @@ template <int TYPE>
 __global__ void __launch_bounds__(256, 2) k_mmq(const mmq_args a) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     constexpr bool IS_K = TYPE == CLLM_TYPE_Q4_K;
+    constexpr int MMQ_MI = mmq_traits<TYPE>::MI, MMQ_BM = 32 * MMQ_MI;
+    constexpr int LDS_WS = lds_ws(MMQ_BM), LDS_XS = lds_xs(MMQ_BM);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t m0 = (int64_t) blockIdx.x * MMQ_BM, n0 = (int64_t) blockIdx.y * MMQ_BN;
     const int wn = (wave & 1) * 64, wm = (wave >> 1) * (MMQ_MI * 16);       // this wave's quadrant inside the tile
@@ -74,83 +75,119 @@ __global__ void __launch_bounds__(256, 2) k_mmq(const mmq_args a) {
 #pragma unroll
             for (int r = 0; r < 4; r++) acc_f[i][j][r] = 0.0f;
 
-    for (int64_t k0 = 0; k0 < K; k0 += 256) {
-        __syncthreads();                                          // previous step's fragments are consumed
-        // ---- stage activations: 128 rows x 256 int8 (16 chunks of 16 B per row) ----
-        for (int c = tid; c < MMQ_BM * 16; c += 256) {
-            const int row = c >> 4, ch = c & 15;
+    // ---- staging is split in two: global -> registers (issued one K step ahead, so the loads fly during the MFMA work of the
+    //      current step) and registers -> LDS (unpack + store, between the two barriers of a step) ----
+    constexpr int BS = TYPE == CLLM_TYPE_Q8_0 ? 34 : 18;
+    struct __attribute__((packed, aligned(2))) q16 { uint32_t x, y, z, w; };
+    constexpr int NXA = MMQ_BM * 16 / 256;                         // activation chunk tasks per thread
+    constexpr int NXS = IS_K ? (MMQ_BM * 9 + 255) / 256 : MMQ_BM * 8 / 256;      // activation scale tasks per thread
+    constexpr int NWT = IS_K ? 5 : 4;                              // weight tasks per thread
+    u32x4 rx[NXA]; uint32_t rxs[NXS]; u32x4 rw[NWT]; u32x4 rw2[IS_K ? 1 : 4]; float rwd[IS_K ? 1 : 4];
+    auto prefetch = [&](int64_t k0) {
+#pragma unroll
+        for (int t = 0; t < NXA; t++) {                            // activations: MMQ_BM rows x 256 int8 (16 chunks of 16 B per row)
+            const int c = tid + 256 * t, row = c >> 4, ch = c & 15;
             const int64_t m = m0 + row;
-            u32x4 v = {0, 0, 0, 0};
-            if (m < a.M && k0 + ch * 16 < K) v = *(const u32x4 *)(a.act + m * a.act_stride + k0 + ch * 16);
-            *(u32x4 *)(Xt + row * MMQ_LD + ch * 16) = v;
+            rx[t] = u32x4{0, 0, 0, 0};
+            if (m < a.M && k0 + ch * 16 < K) rx[t] = *(const u32x4 *)(a.act + m * a.act_stride + k0 + ch * 16);
         }
-        if (IS_K) {
-            for (int c = tid; c < MMQ_BM * 9; c += 256) {         // dx[m], sx[8][m]
-                const int row = c % MMQ_BM, f = c / MMQ_BM;
-                const int64_t m = m0 + row;
-                uint32_t v = 0;
-                if (m < a.M) {
-                    const char * ar = a.act + m * a.act_stride;
-                    v = f == 0 ? *(const uint32_t *)(ar + act_d + (k0 / 256) * 4) : *(const uint32_t *)(ar + act_s + ((k0 / 32) + (f - 1)) * 4);
-                }
-                *(uint32_t *)(Xs + (f * MMQ_BM + row) * 4) = v;
-            }
-        } else {
-            for (int c = tid; c < MMQ_BM * 8; c += 256) {         // dx[8][m]
-                const int row = c % MMQ_BM, s = c / MMQ_BM;
-                const int64_t m = m0 + row;
-                uint32_t v = 0;
-                if (m < a.M && k0 + s * 32 < K) v = *(const uint32_t *)(a.act + m * a.act_stride + act_d + ((k0 / 32) + s) * 4);
-                *(uint32_t *)(Xs + (s * MMQ_BM + row) * 4) = v;
-            }
-        }
-        // ---- stage weights ----
-        if (IS_K) {
-            for (int c = tid; c < MMQ_BN * 9; c += 256) {         // 9 chunks of 16 B per 144-byte super-block
-                const int row = c / 9, ch = c % 9;
-                const int64_t n = n0 + row;
-                u32x4 v = {0, 0, 0, 0};
-                if (n < a.N) v = *(const u32x4 *)(a.W + n * a.nb01 + (k0 / 256) * 144 + ch * 16);
-                if (ch == 0) {
-                    const uint32_t u0 = v.y & 0x3f3f3f3fu, u2 = v.z & 0x3f3f3f3fu;
-                    const uint32_t u1 = (v.w & 0x0f0f0f0fu) | (((v.y >> 6) & 0x03030303u) << 4);
-                    const uint32_t u3 = ((v.w >> 4) & 0x0f0f0f0fu) | (((v.z >> 6) & 0x03030303u) << 4);
-                    *(u32x2 *)(Ws + row * 8) = u32x2{u0, u1};                                   // sc[n][8]
-                    *(u32x2 *)(Ws + MMQ_BN * 8 + row * 8) = u32x2{u2, u3};                      // mn[n][8]
-                    *(float *)(Ws + MMQ_BN * 16 + row * 4) = h2f((uint16_t)(v.x & 0xffff));     // d[n]
-                    *(float *)(Ws + MMQ_BN * 20 + row * 4) = h2f((uint16_t)(v.x >> 16));        // dmin[n]
-                } else {
-                    const int j = ch - 1, off = 64 * (j >> 1) + 16 * (j & 1);
-                    *(u32x4 *)(Wt + row * MMQ_LD + off)      = u32x4{v.x & 0x0f0f0f0fu, v.y & 0x0f0f0f0fu, v.z & 0x0f0f0f0fu, v.w & 0x0f0f0f0fu};
-                    *(u32x4 *)(Wt + row * MMQ_LD + off + 32) = u32x4{(v.x >> 4) & 0x0f0f0f0fu, (v.y >> 4) & 0x0f0f0f0fu, (v.z >> 4) & 0x0f0f0f0fu, (v.w >> 4) & 0x0f0f0f0fu};
-                }
-            }
-        } else {
-            constexpr int BS = TYPE == CLLM_TYPE_Q8_0 ? 34 : 18;
-            struct __attribute__((packed, aligned(2))) q16 { uint32_t x, y, z, w; };
-            for (int c = tid; c < MMQ_BN * 8; c += 256) {         // one 32-block per task
-                const int row = c >> 3, s = c & 7;
-                const int64_t n = n0 + row, b = k0 / 32 + s;
-                float d = 0.0f;
-                u32x4 lo = {0, 0, 0, 0}, hi = {0, 0, 0, 0};
-                if (n < a.N && b * 32 < K) {
-                    const char * bp = a.W + n * a.nb01 + b * BS;
-                    d = h2f(*(const uint16_t *) bp);
-                    const q16 q0 = *(const q16 *)(bp + 2);
-                    if (TYPE == CLLM_TYPE_Q8_0) {
-                        const q16 q1 = *(const q16 *)(bp + 18);
-                        lo = u32x4{q0.x, q0.y, q0.z, q0.w}; hi = u32x4{q1.x, q1.y, q1.z, q1.w};
-                    } else {
-                        lo = u32x4{nib_minus8(q0.x & 0x0f0f0f0fu), nib_minus8(q0.y & 0x0f0f0f0fu), nib_minus8(q0.z & 0x0f0f0f0fu), nib_minus8(q0.w & 0x0f0f0f0fu)};
-                        hi = u32x4{nib_minus8((q0.x >> 4) & 0x0f0f0f0fu), nib_minus8((q0.y >> 4) & 0x0f0f0f0fu), nib_minus8((q0.z >> 4) & 0x0f0f0f0fu), nib_minus8((q0.w >> 4) & 0x0f0f0f0fu)};
+#pragma unroll
+        for (int t = 0; t < NXS; t++) {
+            const int c = tid + 256 * t;
+            rxs[t] = 0;
+            if (IS_K) {
+                if (c < MMQ_BM * 9) {                              // dx[m], sx[8][m]
+                    const int row = c % MMQ_BM, f = c / MMQ_BM;
+                    const int64_t m = m0 + row;
+                    if (m < a.M) {
+                        const char * ar = a.act + m * a.act_stride;
+                        rxs[t] = f == 0 ? *(const uint32_t *)(ar + act_d + (k0 / 256) * 4) : *(const uint32_t *)(ar + act_s + ((k0 / 32) + (f - 1)) * 4);
                     }
                 }
-                *(u32x4 *)(Wt + row * MMQ_LD + s * 32)      = lo;
-                *(u32x4 *)(Wt + row * MMQ_LD + s * 32 + 16) = hi;
-                *(float *)(Ws + (s * MMQ_BN + row) * 4) = d;       // dw[8][n]
+            } else {                                               // dx[8][m]
+                const int row = c % MMQ_BM, sb = c / MMQ_BM;
+                const int64_t m = m0 + row;
+                if (m < a.M && k0 + sb * 32 < K) rxs[t] = *(const uint32_t *)(a.act + m * a.act_stride + act_d + ((k0 / 32) + sb) * 4);
             }
         }
+#pragma unroll
+        for (int t = 0; t < NWT; t++) {
+            const int c = tid + 256 * t;
+            rw[t] = u32x4{0, 0, 0, 0};
+            if (IS_K) {
+                if (c < MMQ_BN * 9) {                              // 9 chunks of 16 B per 144-byte super-block
+                    const int row = c / 9, ch = c % 9;
+                    const int64_t n = n0 + row;
+                    if (n < a.N) rw[t] = *(const u32x4 *)(a.W + n * a.nb01 + (k0 / 256) * 144 + ch * 16);
+                }
+            } else {                                               // one 32-block per task
+                const int row = c >> 3, sb = c & 7;
+                const int64_t n = n0 + row, b = k0 / 32 + sb;
+                rwd[IS_K ? 0 : t] = 0.0f; rw2[IS_K ? 0 : t] = u32x4{0, 0, 0, 0};
+                if (n < a.N && b * 32 < K) {
+                    const char * bp = a.W + n * a.nb01 + b * BS;
+                    rwd[IS_K ? 0 : t] = h2f(*(const uint16_t *) bp);
+                    const q16 q0 = *(const q16 *)(bp + 2);
+                    rw[t] = u32x4{q0.x, q0.y, q0.z, q0.w};
+                    if (TYPE == CLLM_TYPE_Q8_0) { const q16 q1 = *(const q16 *)(bp + 18); rw2[IS_K ? 0 : t] = u32x4{q1.x, q1.y, q1.z, q1.w}; }
+                }
+            }
+        }
+    };
+    auto commit = [&]() {
+#pragma unroll
+        for (int t = 0; t < NXA; t++) {
+            const int c = tid + 256 * t, row = c >> 4, ch = c & 15;
+            *(u32x4 *)(Xt + row * MMQ_LD + ch * 16) = rx[t];
+        }
+#pragma unroll
+        for (int t = 0; t < NXS; t++) {
+            const int c = tid + 256 * t;
+            if (!IS_K || c < MMQ_BM * 9) *(uint32_t *)(Xs + ((c / MMQ_BM) * MMQ_BM + c % MMQ_BM) * 4) = rxs[t];
+        }
+#pragma unroll
+        for (int t = 0; t < NWT; t++) {
+            const int c = tid + 256 * t;
+            if (IS_K) {
+                if (c < MMQ_BN * 9) {
+                    const int row = c / 9, ch = c % 9;
+                    const u32x4 v = rw[t];
+                    if (ch == 0) {
+                        const uint32_t u0 = v.y & 0x3f3f3f3fu, u2 = v.z & 0x3f3f3f3fu;
+                        const uint32_t u1 = (v.w & 0x0f0f0f0fu) | (((v.y >> 6) & 0x03030303u) << 4);
+                        const uint32_t u3 = ((v.w >> 4) & 0x0f0f0f0fu) | (((v.z >> 6) & 0x03030303u) << 4);
+                        *(u32x2 *)(Ws + row * 8) = u32x2{u0, u1};                                   // sc[n][8]
+                        *(u32x2 *)(Ws + MMQ_BN * 8 + row * 8) = u32x2{u2, u3};                      // mn[n][8]
+                        *(float *)(Ws + MMQ_BN * 16 + row * 4) = h2f((uint16_t)(v.x & 0xffff));     // d[n]
+                        *(float *)(Ws + MMQ_BN * 20 + row * 4) = h2f((uint16_t)(v.x >> 16));        // dmin[n]
+                    } else {
+                        const int j = ch - 1, off = 64 * (j >> 1) + 16 * (j & 1);
+                        *(u32x4 *)(Wt + row * MMQ_LD + off)      = u32x4{v.x & 0x0f0f0f0fu, v.y & 0x0f0f0f0fu, v.z & 0x0f0f0f0fu, v.w & 0x0f0f0f0fu};
+                        *(u32x4 *)(Wt + row * MMQ_LD + off + 32) = u32x4{(v.x >> 4) & 0x0f0f0f0fu, (v.y >> 4) & 0x0f0f0f0fu, (v.z >> 4) & 0x0f0f0f0fu, (v.w >> 4) & 0x0f0f0f0fu};
+                    }
+                }
+            } else {
+                const int row = c >> 3, sb = c & 7;
+                const u32x4 q0 = rw[t];
+                u32x4 lo, hi;
+                if (TYPE == CLLM_TYPE_Q8_0) { lo = q0; hi = rw2[IS_K ? 0 : t]; }
+                else {
+                    lo = u32x4{nib_minus8(q0.x & 0x0f0f0f0fu), nib_minus8(q0.y & 0x0f0f0f0fu), nib_minus8(q0.z & 0x0f0f0f0fu), nib_minus8(q0.w & 0x0f0f0f0fu)};
+                    hi = u32x4{nib_minus8((q0.x >> 4) & 0x0f0f0f0fu), nib_minus8((q0.y >> 4) & 0x0f0f0f0fu), nib_minus8((q0.z >> 4) & 0x0f0f0f0fu), nib_minus8((q0.w >> 4) & 0x0f0f0f0fu)};
+                }
+                *(u32x4 *)(Wt + row * MMQ_LD + sb * 32)      = lo;
+                *(u32x4 *)(Wt + row * MMQ_LD + sb * 32 + 16) = hi;
+                *(float *)(Ws + (sb * MMQ_BN + row) * 4) = rwd[IS_K ? 0 : t];       // dw[8][n]
+            }
+        }
+    };
+
+    prefetch(0);
+    for (int64_t k0 = 0; k0 < K; k0 += 256) {
+        __syncthreads();                                          // previous step's fragments are consumed
+        commit();
         __syncthreads();
+        if (k0 + 256 < K) prefetch(k0 + 256);
 
         // ---- compute ----
         int acc_i[MMQ_MI][4][4];
@@ -250,11 +287,12 @@ int launch_mmq(hipStream_t st, int wtype, const tview & w, const void * act, siz
     a.W = w.data; a.nb01 = w.nb[1]; a.N = w.ne[1]; a.K = w.ne[0];
     a.act = (const char *) act; a.act_stride = act_stride; a.M = x.ne[1];
     a.dst = (float *) d.data; a.ldd = d.nb[1] / 4;
-    dim3 grid((unsigned)((a.M + MMQ_BM - 1) / MMQ_BM), (unsigned)((a.N + MMQ_BN - 1) / MMQ_BN));
-    if (grid.y > 65535) FAIL(CLLM_E_UNSUPPORTED, "mmq: too many row tiles");
+    if ((a.N + MMQ_BN - 1) / MMQ_BN > 65535) FAIL(CLLM_E_UNSUPPORTED, "mmq: too many row tiles");
 #define GO(T) do { static bool attr = false; \
-        if (!attr) { HIP_TRY(hipFuncSetAttribute((const void *) k_mmq<T>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL)); attr = true; } \
-        hipLaunchKernelGGL(k_mmq<T>, grid, dim3(256), LDS_TOTAL, st, a); } while (0)
+        constexpr int BM = 32 * mmq_traits<T>::MI, LDS = lds_total(BM); \
+        const dim3 grid((unsigned)((a.M + BM - 1) / BM), (unsigned)((a.N + MMQ_BN - 1) / MMQ_BN)); \
+        if (!attr) { HIP_TRY(hipFuncSetAttribute((const void *) k_mmq<T>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS)); attr = true; } \
+        hipLaunchKernelGGL(k_mmq<T>, grid, dim3(256), LDS, st, a); } while (0)
     if (wtype == CLLM_TYPE_Q4_K) GO(CLLM_TYPE_Q4_K);
     else if (wtype == CLLM_TYPE_Q4_0) GO(CLLM_TYPE_Q4_0);
     else if (wtype == CLLM_TYPE_Q8_0) GO(CLLM_TYPE_Q8_0);
