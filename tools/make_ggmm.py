@@ -39,7 +39,7 @@ def bytes_to_unicode():
     return dict(zip(bs, map(chr, cs)))
 
 
-def write_model(path, cfg, wtype, seed=1234, model_name="SynthLlama3"):
+def write_model(path, cfg, wtype, seed=1234, model_name="SynthLlama3", fast=False):
     pkg = ge.load_package()
     V, H = cfg["vocab"], cfg["hidden"]
     assert V >= 262
@@ -83,7 +83,15 @@ def write_model(path, cfg, wtype, seed=1234, model_name="SynthLlama3"):
             f.write(b"\0" * (-f.tell() % 16))
             f.write(np.ascontiguousarray(payload).tobytes())
 
-        w = pkg.synth.make_model(cfg, wtype, seed=seed)
+        if fast:           # big models: the cheap generator bench.py uses (block bytes drawn directly)
+            S = pkg.synth
+            w = {name: (t, S.make_tensor_fast(name, t, rows, K, seed)) for name, t, rows, K in S.tensor_list(cfg, wtype)}
+            w["out_norm"] = (0, S.make_norm("out_norm", H, seed))
+            for i in range(cfg["n_layer"]):
+                for k in ("attn_norm", "ffn_norm"):
+                    w[f"layers.{i}.{k}"] = (0, S.make_norm(f"layers.{i}.{k}", H, seed))
+        else:
+            w = pkg.synth.make_model(cfg, wtype, seed=seed)
         shape = {n: (rows, K) for n, _, rows, K in pkg.synth.tensor_list(cfg, wtype)}
         dump("model.embed_tokens.weight", w["tok_embd"][0], [V, H], w["tok_embd"][1])
         for i in range(cfg["n_layer"]):
@@ -103,8 +111,9 @@ if __name__ == "__main__":
     ap.add_argument("--wtype", default="q4_k", choices=sorted(WT))
     ap.add_argument("--max-len", type=int, default=256)
     ap.add_argument("--out", required=True)
+    ap.add_argument("--fast", action="store_true")
     a = ap.parse_args()
     pkg = ge.load_package()
     cfg = pkg.synth.config(a.config, max_len=a.max_len)
-    write_model(a.out, cfg, WT[a.wtype])
+    write_model(a.out, cfg, WT[a.wtype], fast=a.fast)
     print(a.out, os.path.getsize(a.out), "bytes")
