@@ -102,11 +102,11 @@ def measure_dominant_kernel(pkg, cfg, wtype, iters=64):
     y = pkg.Tensor(pkg.F32, [rows, 1])
     ptrs = (C.c_void_p * n_copies)(*[w.data_ptr().value for w in ws])
     us = C.c_float()
-    epi = 1 if (wtype == 12 and F % 8 == 0) else 0
+    epi = 1 if F % 8 == 0 else 0
     pkg.lib.check(L.cllm_bench_gemv_fused(None, wtype, ptrs, n_copies, H, rows, 1, x.data_ptr(), g.data_ptr(), cfg["rms_eps"], epi, y.data_ptr(), None,
                                           iters, C.byref(us)), "bench_gemv_fused")
     dur_s = us.value / 1e6
-    name = "k_gemv_q4_K_dec<1, %d, %d>" % (epi, 1 if H <= 4096 else 4) if wtype == 12 else "k_mmvq_q32<1, %s, true>" % ("true" if wtype == 8 else "false")
+    name = "k_gemv_dec<%d, 1, %d, %d>" % (wtype, epi, 1 if H <= 4096 else 4)
     return {"kernel": "%s (gate/up GEMV %dx%d, decode form)" % (name, rows, H), "bytes_per_launch": nbytes, "avg_us": dur_s * 1e6, "gbs": nbytes / dur_s / 1e9}
 
 

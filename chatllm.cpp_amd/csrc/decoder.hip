@@ -423,7 +423,7 @@ static int decode_step_fused(cllm_llama * m, bool sample) {
     auto norm_gemv = [&](const dweight & w, int64_t nrows, const float * nw, int epi, float * dst, const float * bias) -> int {
         if (pend) {
             float * xo = xc == m->x ? m->xn : m->x;
-            int rc = w.type == CLLM_TYPE_Q4_K ? launch_gemv_q4_K_decode(st, w.data, H, nrows, 1, xc, nw, c.rms_eps, epi, dst, bias, nullptr, pend, xo) : CLLM_E_UNSUPPORTED;
+            int rc = launch_gemv_decode(st, w.type, w.data, H, nrows, 1, xc, nw, c.rms_eps, epi, dst, bias, nullptr, pend, xo);
             if (rc == CLLM_OK) { xc = xo; pend = nullptr; return rc; }
             if (rc != CLLM_E_UNSUPPORTED) return rc;
             cllm_tensor O = T(CLLM_TYPE_F32, (void *) pend, H), X = T(CLLM_TYPE_F32, xc, H);
@@ -444,9 +444,9 @@ static int decode_step_fused(cllm_llama * m, bool sample) {
             TRY(tp_allreduce(m, st, m->o, H));
             pend = m->o;
         }
-        // Q4_K gate/up: the wave that owns a feature's row pair applies SiLU(gate)*up itself, the down mat-vec only quantizes;
+        // gate/up: the wave that owns a feature's row pair applies SiLU(gate)*up itself, the down mat-vec only quantizes;
         // otherwise the down mat-vec's prologue does SiLU*up on the interleaved pairs
-        const bool silu_epi = L.wgu.type == CLLM_TYPE_Q4_K && F % 8 == 0;
+        const bool silu_epi = F % 8 == 0 && H <= 16384;       // (every quantized type the decode kernel takes)
         const float * dsrc = silu_epi ? m->g : m->gu;
         const int dpro = silu_epi ? 2 : 3;
         TRY(norm_gemv(L.wgu, 2*F, (const float *) L.ffn_norm.data, silu_epi ? 1 : 0, silu_epi ? m->g : m->gu, nullptr));

@@ -1,4 +1,4 @@
-// gemv_decode.hip -- the decode step's Q4_K mat-vec: one activation column, produced inside the kernel.
+// gemv_decode.hip -- the decode step's quantized mat-vec (Q4_K / Q4_0 / Q8_0 weights): one activation column, produced inside the kernel.
 //
 //   prologue PRO 1: act = quantize_q8_K(RMS_NORM(px) * pw)     (LMBlock1Forward: input_layernorm / post_attention_layernorm -> Linear)
 //            PRO 2: act = quantize_q8_K(px)                    (attention output -> o_proj, SiLU*up -> down_proj)
@@ -20,6 +20,7 @@
 #include "common.h"
 #include "quant_dev.h"
 #include "q4k.h"
+#include "q32.h"
 
 static unsigned long long * g_gemv_ts = nullptr;
 extern "C" __attribute__((visibility("default"))) void cllm_debug_set_mmvq_ts(unsigned long long * dev_buf) { g_gemv_ts = dev_buf; }   // tools only
@@ -33,15 +34,21 @@ __device__ __forceinline__ float silu_any(float x, bool body) { return body ? si
 
 #define TS(k) do { if (ts && threadIdx.x == 0) ts[blockIdx.x * 8 + (k)] = wall_clock64(); } while (0)
 
-template <int PRO, int EPI, int NPRE>
-__global__ void __launch_bounds__(1024) k_gemv_q4_K_dec(const float * __restrict__ px, const float * __restrict__ pw, const float * __restrict__ padd,
+// FMT: CLLM_TYPE_Q4_K (8 lanes per 144-byte super-block, activation quantized to Q8_K) or CLLM_TYPE_Q4_0 / Q8_0 (one lane per
+// 18 / 34-byte block, activation quantized to Q8_0).  nblk = weight blocks per row.
+template <int FMT, int PRO, int EPI, int NPRE>
+__global__ void __launch_bounds__(1024) k_gemv_dec(const float * __restrict__ px, const float * __restrict__ pw, const float * __restrict__ padd,
                                                         const char * __restrict__ W, int nblk, int kfull, int nrem, float eps,
                                                         float * __restrict__ dst, float * __restrict__ xout,
                                                         const float * __restrict__ bias, const float * resid, unsigned long long * ts) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     constexpr int P = 2, RU = EPI == 1 ? 2 : 1;
+    constexpr bool IS_K = FMT == CLLM_TYPE_Q4_K, IS_Q8 = FMT == CLLM_TYPE_Q8_0;
+    constexpr int KIND = IS_K ? 256 : 32;                           // elements per weight block = activation quantization block
+    constexpr int BS = IS_K ? 144 : IS_Q8 ? 34 : 18;                // bytes per weight block
+    constexpr int BPS = IS_K ? 8 : 64;                              // blocks a wave consumes per step
     const int tid = threadIdx.x, lane = tid & 63;
-    const int K = nblk * 256;
+    const int K = nblk * KIND;
 
     // ---- (1) this thread's activation groups: unconditional (clamped) loads, issued before anything else ----
     // pro 3: px holds interleaved (gate_e, up_e) pairs -- two 16-byte loads cover this thread's four features
@@ -70,22 +77,30 @@ __global__ void __launch_bounds__(1024) k_gemv_q4_K_dec(const float * __restrict
     const int nwaves = gridDim.x * 16;
     const int lin = blockIdx.x * 16 + wave_in_wg, alt = wave_in_wg * gridDim.x + blockIdx.x;
     const int nmine = kfull + (alt < nrem ? 1 : 0);
-    const int S = (nblk + 7) >> 3;                                  // steps per row
-    const unsigned nb01 = (unsigned) nblk * 144u;
+    const int S = (nblk + BPS - 1) / BPS;                           // steps per row
+    const unsigned nb01 = (unsigned) nblk * (unsigned) BS;
     auto unit_of = [&](int k) { return k * nwaves + (k < kfull ? lin : alt); };
-    u32x4 hh[P], qq[P];
+    // per step and lane: Q4_K header (hh) + 16 quant bytes (qq); Q4_0 / Q8_0: fp16 scale (hh.x) + 16 (qq) [+ 16 (q2)] quant bytes
+    u32x4 hh[P], qq[P], q2[IS_Q8 ? P : 1];
     int ik = 0, isub = 0, is = 0;                                   // issue cursor: (unit ordinal, row of the unit, step of the row)
-    auto issue = [&](u32x4 & h, u32x4 & q) {                        // unconditional: out-of-range steps re-read block 0 and are masked
-        const int b = 8 * is + grp;
+    auto issue = [&](int p) {                                       // unconditional: out-of-range steps re-read block 0 and are masked
+        const int b = IS_K ? 8 * is + grp : 64 * is + lane;
         const bool ok = ik < nmine && b < nblk;
         const char * bp = W;
-        if (ok) bp = W + (unsigned long long)(unsigned)(unit_of(ik) * RU + isub) * nb01 + (unsigned) b * 144u;
-        h = *(const u32x4 *) bp;
-        q = *(const u32x4 *)(bp + 16 + 16 * j);
+        if (ok) bp = W + (unsigned long long)(unsigned)(unit_of(ik) * RU + isub) * nb01 + (unsigned) b * (unsigned) BS;
+        if (IS_K) {
+            hh[p] = *(const u32x4 *) bp;
+            qq[p] = *(const u32x4 *)(bp + 16 + 16 * j);
+        } else {
+            hh[p].x = *(const uint16_t *) bp;
+            const u16x8_u2 r0 = *(const u16x8_u2 *)(bp + 2);
+            qq[p] = u32x4{r0.x, r0.y, r0.z, r0.w};
+            if (IS_Q8) { const u16x8_u2 r1 = *(const u16x8_u2 *)(bp + 18); q2[IS_Q8 ? p : 0] = u32x4{r1.x, r1.y, r1.z, r1.w}; }
+        }
         if (++is == S) { is = 0; if (++isub == RU) { isub = 0; ik++; } }
     };
 #pragma unroll
-    for (int p = 0; p < P; p++) issue(hh[p], qq[p]);
+    for (int p = 0; p < P; p++) issue(p);
     TS(1);
 
     // ---- (3) the activation row: [RMS_NORM * weight | SiLU * up |] quantize -> LDS (act layout of common.h) ----
@@ -101,7 +116,7 @@ __global__ void __launch_bounds__(1024) k_gemv_q4_K_dec(const float * __restrict
     }
     const int nv = K & ~7;                                          // ggml_vec_silu_f32: polynomial body below nv, libm tail
 #pragma unroll
-    for (int u = 0; u < NPRE; u++) {                                // K % 256 == 0: whole waves stay together
+    for (int u = 0; u < NPRE; u++) {                                // K % KIND == 0: whole quantization lane groups stay together
         const int e = e0 + u * 4096;
         if (e < K) {
             f32x4 v = vv[u];
@@ -111,7 +126,7 @@ __global__ void __launch_bounds__(1024) k_gemv_q4_K_dec(const float * __restrict
                 v.z = silu_any(p1.x, e + 2 < nv) * p1.y; v.w = silu_any(p1.z, e + 3 < nv) * p1.w;
             }
             if (PRO == 1) { const f32x4 g = gg[u]; v.x = (v.x * scale) * g.x; v.y = (v.y * scale) * g.y; v.z = (v.z * scale) * g.z; v.w = (v.w * scale) * g.w; }
-            quant4_store<256>(lds, K, e, lane, v);
+            quant4_store<KIND>(lds, K, e, lane, v);
         }
     }
     TS(2);
@@ -120,18 +135,19 @@ __global__ void __launch_bounds__(1024) k_gemv_q4_K_dec(const float * __restrict
 
     // ---- (4) stream the rows ----
     const q4k_sel L = q4k_lane_sel(lane);
-    const int off_d = (int) act_off_d(K), off_s = (int) act_off_s(K, 256);
+    const int off_d = (int) act_off_d(K), off_s = (int) act_off_s(K, KIND);
     float accd = 0.0f, accm = 0.0f, gate = 0.0f;
     int ck = 0, csub = 0, cs = 0;                                   // consume cursor
     while (ck < nmine) {
 #pragma unroll
         for (int p = 0; p < P; p++) {
-            const int b = 8 * cs + grp;
+            const int b = IS_K ? 8 * cs + grp : 64 * cs + lane;
             const bool ok = ck < nmine && b < nblk;
-            q4k_step(hh[p], qq[p], lds, off_d, off_s, ok ? b : 0, ok, L, accd, accm);
-            issue(hh[p], qq[p]);
+            if (IS_K) q4k_step(hh[p], qq[p], lds, off_d, off_s, ok ? b : 0, ok, L, accd, accm);
+            else      q32_step<IS_Q8>(hh[p].x, qq[p], q2[IS_Q8 ? p : 0], lds, off_d, off_s, ok ? b : 0, ok, accd);
+            issue(p);
             if (++cs == S) {                                        // row complete: reduce over the wave, epilogue, store
-                float v = wave_sum(accd) - wave_sum(accm);
+                float v = IS_K ? wave_sum(accd) - wave_sum(accm) : wave_sum(accd);
                 if (ck < nmine) {                                   // wave-uniform; bias / resid come through the scalar cache
                     const int cunit = unit_of(ck), crow = cunit * RU + csub;
                     if (EPI == 1) {
@@ -153,25 +169,35 @@ __global__ void __launch_bounds__(1024) k_gemv_q4_K_dec(const float * __restrict
 }
 #undef TS
 
-// K multiple of 256, K <= 16384, nrows * row bytes < 4 GiB; returns CLLM_E_UNSUPPORTED for shapes the general kernels must take
-int launch_gemv_q4_K_decode(hipStream_t st, const void * W, int64_t K, int64_t nrows, int pro, const float * px, const float * pw, float eps,
-                            int epi, float * dst, const float * bias, const float * resid, const float * padd, float * xout) {
+// K a multiple of the block size, K <= 16384 (32768 for the plain-quantize prologue), nrows * row bytes < 4 GiB; returns
+// CLLM_E_UNSUPPORTED for shapes the general kernels must take
+int launch_gemv_decode(hipStream_t st, int wtype, const void * W, int64_t K, int64_t nrows, int pro, const float * px, const float * pw, float eps,
+                       int epi, float * dst, const float * bias, const float * resid, const float * padd, float * xout) {
+    const int kind = wtype == CLLM_TYPE_Q4_K ? 256 : 32;
+    if (wtype != CLLM_TYPE_Q4_K && wtype != CLLM_TYPE_Q4_0 && wtype != CLLM_TYPE_Q8_0) return CLLM_E_UNSUPPORTED;
+    if (K % kind || K > (pro == 2 ? 32768 : 16384) || pro < 1 || pro > 3 || nrows <= 0 || (uint64_t) nrows * (uint64_t) cllm_row_size(wtype, K) >= (1ull << 32)) return CLLM_E_UNSUPPORTED;
+    if (act_row_bytes(K, kind) > 160 * 1024) return CLLM_E_UNSUPPORTED;
     if (padd && (pro != 1 || K > 4096 || !xout || xout == px)) return CLLM_E_UNSUPPORTED;
-    if (K % 256 || K > 16384 || pro < 1 || pro > 3 || nrows <= 0 || (uint64_t) nrows * (uint64_t)(K / 256 * 144) >= (1ull << 32)) return CLLM_E_UNSUPPORTED;
     if (epi == 1 && (pro != 1 || nrows % 2 || (nrows / 2) % 8 || bias || resid)) FAIL(CLLM_E_UNSUPPORTED, "gemv_decode: SiLU epilogue needs gate/up row pairs, features %% 8 == 0");
     const int64_t units = epi == 1 ? nrows / 2 : nrows;
     int64_t grid = (units + 15) / 16;
     if (grid > device_cu_count()) grid = device_cu_count();
     const int64_t nwaves = grid * 16;
-    const int kfull = (int)(units / nwaves), nrem = (int)(units % nwaves), nblk = (int)(K / 256);
-    const size_t lds = act_row_bytes(K, 256);
-    const bool small = K <= 4096;
-#define GO(PRO_, EPI_, NPRE_) hipLaunchKernelGGL((k_gemv_q4_K_dec<PRO_, EPI_, NPRE_>), dim3((unsigned) grid), dim3(1024), lds, st, px, pw, padd, (const char *) W, nblk, kfull, nrem, eps, dst, xout, bias, resid, g_gemv_ts)
-    if (pro == 1 && epi == 1) { if (small) GO(1, 1, 1); else GO(1, 1, 4); }
-    else if (pro == 1)        { if (small) GO(1, 0, 1); else GO(1, 0, 4); }
-    else if (pro == 2)        { if (small) GO(2, 0, 1); else GO(2, 0, 4); }
-    else                      { if (small) GO(3, 0, 1); else GO(3, 0, 4); }
+    const int kfull = (int)(units / nwaves), nrem = (int)(units % nwaves), nblk = (int)(K / kind);
+    const size_t lds = act_row_bytes(K, kind);
+    const int npre = K <= 4096 ? 1 : K <= 16384 ? 4 : 8;
+#define GO3(FMT_, PRO_, EPI_, NPRE_) do { \
+        static bool attr = false; \
+        if (lds > 64 * 1024 && !attr) { HIP_TRY(hipFuncSetAttribute((const void *) k_gemv_dec<FMT_, PRO_, EPI_, NPRE_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr = true; } \
+        hipLaunchKernelGGL((k_gemv_dec<FMT_, PRO_, EPI_, NPRE_>), dim3((unsigned) grid), dim3(1024), lds, st, px, pw, padd, (const char *) W, nblk, kfull, nrem, eps, dst, xout, bias, resid, g_gemv_ts); } while (0)
+#define GO(FMT_) do { \
+        if (pro == 1 && epi == 1) { if (npre == 1) GO3(FMT_, 1, 1, 1); else GO3(FMT_, 1, 1, 4); } \
+        else if (pro == 1)        { if (npre == 1) GO3(FMT_, 1, 0, 1); else GO3(FMT_, 1, 0, 4); } \
+        else if (pro == 2)        { if (npre == 1) GO3(FMT_, 2, 0, 1); else if (npre == 4) GO3(FMT_, 2, 0, 4); else GO3(FMT_, 2, 0, 8); } \
+        else                      { if (npre == 1) GO3(FMT_, 3, 0, 1); else GO3(FMT_, 3, 0, 4); } } while (0)
+    if (wtype == CLLM_TYPE_Q4_K) GO(CLLM_TYPE_Q4_K); else if (wtype == CLLM_TYPE_Q4_0) GO(CLLM_TYPE_Q4_0); else GO(CLLM_TYPE_Q8_0);
 #undef GO
+#undef GO3
     LAUNCH_CHECK();
     return CLLM_OK;
 }

@@ -19,6 +19,7 @@
 #include "common.h"
 #include "quant_dev.h"
 #include "q4k.h"
+#include "q32.h"
 
 static int g_mmvq_wg = 256;      // threads per workgroup (tunable: CLLM_MMVQ_WG)
 static int g_mmvq_wgs_per_cu = 8; // grid cap (tunable: CLLM_MMVQ_OCC)
@@ -238,7 +239,6 @@ __global__ void __launch_bounds__(1024) k_mmvq_q4_K(const mmvq_args a) {
 #undef TS
 
 // ---- Q4_0 / Q8_0 (one lane per 32-weight block) ------------------------------------------------------------
-struct __attribute__((packed, aligned(2))) u16x8_u2 { uint32_t x, y, z, w; };
 
 template <int NC, bool IS_Q8, bool FUSED>        // FUSED: decode launch, prologue chosen at run time by a.pro
 __global__ void __launch_bounds__(1024) k_mmvq_q32(const mmvq_args a) {
@@ -263,40 +263,18 @@ __global__ void __launch_bounds__(1024) k_mmvq_q32(const mmvq_args a) {
         float acc[NC];
 #pragma unroll
         for (int c = 0; c < NC; c++) acc[c] = 0.0f;
+        const int off_d = (int) act_off_d(K), off_s = (int) act_off_s(K, 32);
         for (int b0 = 0; b0 < nblk; b0 += 64) {
             const int b = b0 + lane;
             if (b < nblk) {
                 const char * bp = wr + (int64_t) b * BS;
-                const float d = h2f(*(const uint16_t *) bp);
-                const u16x8_u2 q0 = *(const u16x8_u2 *)(bp + 2);
-                if constexpr (IS_Q8) {
-                    const u16x8_u2 q1 = *(const u16x8_u2 *)(bp + 18);
+                const uint32_t d16 = *(const uint16_t *) bp;
+                const u16x8_u2 r0 = *(const u16x8_u2 *)(bp + 2);
+                const u32x4 q0 = {r0.x, r0.y, r0.z, r0.w};
+                u32x4 q1 = {0, 0, 0, 0};
+                if constexpr (IS_Q8) { const u16x8_u2 r1 = *(const u16x8_u2 *)(bp + 18); q1 = u32x4{r1.x, r1.y, r1.z, r1.w}; }
 #pragma unroll
-                    for (int c = 0; c < NC; c++) {
-                        const char * ar = lds + c * rb;
-                        const u32x4 a0 = *(const u32x4 *)(ar + b * 32);
-                        const u32x4 a1 = *(const u32x4 *)(ar + b * 32 + 16);
-                        const float yd = ((const float *)(ar + act_off_d(K)))[b];
-                        int s = dot4(q0.x, a0.x, 0); s = dot4(q0.y, a0.y, s); s = dot4(q0.z, a0.z, s); s = dot4(q0.w, a0.w, s);
-                        s = dot4(q1.x, a1.x, s); s = dot4(q1.y, a1.y, s); s = dot4(q1.z, a1.z, s); s = dot4(q1.w, a1.w, s);
-                        acc[c] = __builtin_fmaf((float) s, d * yd, acc[c]);
-                    }
-                } else {
-                    const uint32_t ql[4] = { q0.x & 0x0f0f0f0fu, q0.y & 0x0f0f0f0fu, q0.z & 0x0f0f0f0fu, q0.w & 0x0f0f0f0fu };
-                    const uint32_t qh[4] = { (q0.x >> 4) & 0x0f0f0f0fu, (q0.y >> 4) & 0x0f0f0f0fu, (q0.z >> 4) & 0x0f0f0f0fu, (q0.w >> 4) & 0x0f0f0f0fu };
-#pragma unroll
-                    for (int c = 0; c < NC; c++) {
-                        const char * ar = lds + c * rb;
-                        const u32x4 a0 = *(const u32x4 *)(ar + b * 32);          // elements 0..15  <-> low nibbles
-                        const u32x4 a1 = *(const u32x4 *)(ar + b * 32 + 16);     // elements 16..31 <-> high nibbles
-                        const float yd = ((const float *)(ar + act_off_d(K)))[b];
-                        const int   ys = ((const int *)(ar + act_off_s(K, 32)))[b];
-                        int s = dot4(ql[0], a0.x, 0); s = dot4(ql[1], a0.y, s); s = dot4(ql[2], a0.z, s); s = dot4(ql[3], a0.w, s);
-                        s = dot4(qh[0], a1.x, s); s = dot4(qh[1], a1.y, s); s = dot4(qh[2], a1.z, s); s = dot4(qh[3], a1.w, s);
-                        s -= 8 * ys;                                             // sum (nib - 8) * y
-                        acc[c] = __builtin_fmaf((float) s, d * yd, acc[c]);
-                    }
-                }
+                for (int c = 0; c < NC; c++) q32_step<IS_Q8>(d16, q0, q1, lds + c * rb, off_d, off_s, b, true, acc[c]);
             }
         }
 #pragma unroll
@@ -509,11 +487,10 @@ int launch_mmvq_fused(hipStream_t st, int wtype, const void * W, int64_t K, int6
     a.W = (const char *) W; a.nb01 = (int64_t) cllm_row_size(wtype, K); a.nrows = nrows; a.nblk = (int)(K / kb);
     a.act_stride = rb; a.dst = dst; a.bias = bias; a.resid = resid;
     a.pro = pro; a.px = px; a.pw = pw; a.eps = eps; a.epi = epi;
-    if (wtype == CLLM_TYPE_Q4_K) {
-        const int rc = launch_gemv_q4_K_decode(st, W, K, nrows, pro, px, pw, eps, epi, dst, bias, resid);
+    {
+        const int rc = launch_gemv_decode(st, wtype, W, K, nrows, pro, px, pw, eps, epi, dst, bias, resid);
         if (rc != CLLM_E_UNSUPPORTED) return rc;           // (very long rows / huge matrices fall through to the general kernel)
         if (epi == 1) FAIL(CLLM_E_UNSUPPORTED, "mmvq_fused: SiLU epilogue only on the decode kernel's shapes");
     }
-    if (epi == 1 && (wtype != CLLM_TYPE_Q4_K || nrows % 2 || (nrows / 2) % 8 || bias || resid)) FAIL(CLLM_E_UNSUPPORTED, "mmvq_fused: SiLU epilogue needs Q4_K gate/up row pairs, features %% 8 == 0");
     return mmvq_dispatch(st, wtype, 1, rb, a, 1);
 }
