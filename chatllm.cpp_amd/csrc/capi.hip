@@ -177,8 +177,10 @@ extern "C" int cllm_op_mul_mat(void * stream, const cllm_tensor * src0, const cl
         FAIL(CLLM_E_UNSUPPORTED, "mul_mat: Q4_K rows must be 16-byte aligned");
     // a single dense activation column (decode): quantize it inside the mat-vec (one launch instead of two; the decode kernels)
     if (src1->ne[1] == 1 && src1->ne[2] == 1 && src1->ne[3] == 1 && src0->ne[2] == 1 && src0->ne[3] == 1 && src1->nb[0] == 4 && dst->nb[0] == 4 &&
-        src0->nb[1] == cllm_row_size(src0->type, K) && K % kind == 0 && act_row_bytes(K, kind) <= 160 * 1024)
-        return launch_mmvq_fused(st, src0->type, src0->data, K, src0->ne[1], 2, (const float *) src1->data, nullptr, 0.0f, 0, (float *) dst->data, nullptr, nullptr);
+        src0->nb[1] == cllm_row_size(src0->type, K) && K % kind == 0 && act_row_bytes(K, kind) <= 160 * 1024) {
+        rc = launch_gemv_decode(st, src0->type, src0->data, K, src0->ne[1], 2, (const float *) src1->data, nullptr, 0.0f, 0, (float *) dst->data, nullptr, nullptr);
+        if (rc != CLLM_E_UNSUPPORTED) return rc;          // very long rows: the two-launch path below
+    }
 
     rc = launch_quantize_act(st, kind, tv(src1), wdata, stride);
     if (rc) return rc;

@@ -239,7 +239,8 @@ static int finalize(cllm_llama * m, int qlen) {
         HIP_TRY(hipMalloc((void **) &m->out_ring, (size_t) ML * 4));
         HIP_TRY(hipMalloc((void **) &m->counter_dev, (16 + 512 + 512) * 4));    // loop counter + 256 (value, index) argmax partials + cos/sin table of the position
         // the fused single-token path needs the row-concatenated projections and block-aligned widths
-        m->fused_ok = m->own_stream && H % 256 == 0 && QD % 256 == 0 && hd % 8 == 0 && ML % 8 == 0 && (size_t)(hd + ML) * 4 <= 150 * 1024;
+        m->fused_ok = m->own_stream && H % 256 == 0 && QD % 256 == 0 && hd % 8 == 0 && ML % 8 == 0 && (size_t)(hd + ML) * 4 <= 150 * 1024 &&
+                      H <= 16384 && QD <= 32768 && F <= 32768 && F % 8 == 0;      // row lengths the decode mat-vec takes (gemv_decode.hip)
         for (const llama_layer & L : m->layers) {
             if (!L.wqkv.data || !L.wgu.data) m->fused_ok = false;
             else if (F % (L.wdown.type == CLLM_TYPE_Q4_K ? 256 : 32)) m->fused_ok = false;

@@ -1,4 +1,5 @@
-// mmvq.hip -- quantized mat-vec (decode GEMV, 1..8 activation columns) for Q4_K / Q4_0 / Q8_0 weights.
+// mmvq.hip -- quantized mat-vec for 1..8 PRE-QUANTIZED activation columns, Q4_K / Q4_0 / Q8_0 weights (small-batch MUL_MAT,
+// MUL_MAT_ID).  The single-column decode launches with the activation produced inside the kernel live in gemv_decode.hip.
 //
 // Replaces the decode branch of ggml_compute_forward_mul_mat (ggml/src/ggml-cpu/ggml-cpu.c:1359-1421) and its
 // vec_dot kernels ggml_vec_dot_q4_K_q8_K / q4_0_q8_0 / q8_0_q8_0 (ggml-cpu/quants.c:550-623, 115-150, 305-333):
@@ -23,7 +24,6 @@
 
 static int g_mmvq_wg = 256;      // threads per workgroup (tunable: CLLM_MMVQ_WG)
 static int g_mmvq_wgs_per_cu = 8; // grid cap (tunable: CLLM_MMVQ_OCC)
-static int g_mmvq_burst = 8;      // decode launches: weight steps prefetched before the prologue, 2 / 4 / 8 (tunable: CLLM_MMVQ_BURST)
 
 // kernel arguments; `ids` != NULL turns the launch into MUL_MAT_ID: blockIdx.y enumerates (slot u, token t) pairs,
 // each with its own expert matrix (ggml-cpu.c:1432-1678).
@@ -35,16 +35,6 @@ struct mmvq_args {
     int n_used, b_ne1, n_as; int64_t dst_s1, dst_s2; // dst strides (floats) over (u, t)
     const float * bias;                            // optional fused ADD of a per-row bias   (Linear::forward, src/layers.cpp:2111-2129)
     const float * resid;                           // optional fused ADD of the residual     (LMBlock1Forward::forward :2740,:2758), indexed like dst
-    // prologue: how the quantized activation row gets into LDS
-    //   0: copied from the act row in global memory (written by the quantize kernel)
-    //   1: RMS_NORM(px) * pw, then quantized, computed by every workgroup itself (decode: saves a launch per mat-vec)
-    //   2: px quantized by every workgroup itself
-    //   3: silu(px[i]) * px[K + i] quantized by every workgroup itself (px = [gate | up], BaseMLP::forward)
-    int pro; const float * px; const float * pw; float eps;
-    // epilogue 1 (Q4_K decode launches): rows 2u / 2u+1 are the gate / up projections of feature u (the runner interleaves
-    // them), dst[u] = silu(gate_u) * up_u   (BaseMLP::forward; polynomial SiLU body only: nrows/2 % 8 == 0)
-    int epi;
-    unsigned long long * ts;                       // tools only: per-workgroup phase timestamps (cllm_debug_set_mmvq_ts), else NULL
 };
 
 __device__ __forceinline__ bool mmvq_select(const mmvq_args & a, const char *& W, const char *& act, float *& dst) {
@@ -70,82 +60,18 @@ __device__ __forceinline__ void stage_act(char * lds, const char * __restrict__ 
     }
 }
 
-__device__ __forceinline__ float silu_gate(float x, bool body) { return body ? x / (1.0f + ggml_expf_poly(0.0f - x)) : x / (1.0f + libm_expf(-x)); }
-
-// `after_first_loads` runs right after this thread's first activation loads have been ISSUED and before anything waits
-// on them: the Q4_K kernel issues its weight prefetch there, so the HBM latency of the weights overlaps the whole prologue
-// (the activation loads are older in program order, so the s_waitcnt for them does not wait for the weights).
-// PRO >= 0 fixes the prologue at compile time (a launch fetches its code cold -- ~1 us per KB of straight-line code on
-// the critical path -- so a decode kernel must not carry the prologues it does not run); PRO = -1 reads a.pro.
-template <int KIND, int PRO, int NPRE, typename F>
-__device__ __forceinline__ void build_act(char * lds, const mmvq_args & a, const char * act, int64_t K, size_t rb, int nc, F && after_first_loads) {
-    const int pro = PRO >= 0 ? PRO : a.pro;
-    if (pro == 0) { after_first_loads(); stage_act(lds, act, a.act_stride, rb, nc); return; }
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int64_t e0 = (int64_t) tid * 4, estep = (int64_t) blockDim.x * 4;
-    // This thread's first NPRE activation groups are loaded unconditionally (clamped, pointer-selected) BEFORE the weight
-    // prefetch is issued: a wave's loads return in order, so an activation load issued behind the prefetch would wait for
-    // all of it, and straight-line loads keep the compiler's vmcnt bookkeeping exact.
-    // (NPRE = 1 covers K <= 4096 with 1024 threads, NPRE = 4 K <= 16384; longer rows fall through to the tail loop)
-    // pro 3: px holds interleaved (gate_e, up_e) pairs -- two 16-byte loads cover this thread's four features
-    const float * vp = a.px; const float * gp = pro == 1 ? a.pw : pro == 3 ? a.px + 4 : a.px;
-    const int vmul = pro == 3 ? 2 : 1;
-    f32x4 vv[NPRE], gg[NPRE];
-#pragma unroll
-    for (int u = 0; u < NPRE; u++) {
-        const int64_t e = e0 + u * estep, ec = e < K ? e : 0;
-        vv[u] = *(const f32x4 *)(vp + ec * vmul);
-        if (pro != 2) gg[u] = *(const f32x4 *)(gp + ec * vmul);
-    }
-    after_first_loads();
-    float scale = 1.0f;
-    if (pro == 1) {
-        // sum of squares: the 1024-thread partition and reduction tree of k_rms_norm (ops.hip), so that the fused and the
-        // node-by-node paths agree to the bit
-        __shared__ double part[16];
-        const double sum = rms_block_sumsq_1024(a.px, K, vv[0], part);
-        scale = rms_scale(sum, K, a.eps);
-    }
-    const int64_t nv = K & ~(int64_t) 7;                      // ggml_vec_silu_f32: polynomial body below nv, libm tail
-    auto emit = [&](int64_t e, f32x4 v, f32x4 g) {
-        if (pro == 3) {
-            const f32x4 p0 = v, p1 = g;                       // (g0, u0, g1, u1), (g2, u2, g3, u3)
-            v = f32x4{p0.x, p0.z, p1.x, p1.z}; g = f32x4{p0.y, p0.w, p1.y, p1.w};
-            v.x = silu_gate(v.x, e + 0 < nv) * g.x; v.y = silu_gate(v.y, e + 1 < nv) * g.y;
-            v.z = silu_gate(v.z, e + 2 < nv) * g.z; v.w = silu_gate(v.w, e + 3 < nv) * g.w;
-        }
-        if (pro == 1) { v.x = (v.x * scale) * g.x; v.y = (v.y * scale) * g.y; v.z = (v.z * scale) * g.z; v.w = (v.w * scale) * g.w; }
-        quant4_store<KIND>(lds, K, e, lane, v);
-    };
-#pragma unroll
-    for (int u = 0; u < NPRE; u++) {                          // K % 256 == 0 (% 32 for Q8_0 acts): whole lane groups stay together
-        const int64_t e = e0 + u * estep;
-        if (e < K) emit(e, vv[u], pro != 2 ? gg[u] : vv[u]);
-    }
-    if (NPRE != 1)                                            // NPRE == 1 is only dispatched for K <= 4096
-        for (int64_t e = e0 + NPRE * estep; e < K; e += estep) emit(e, *(const f32x4 *)(vp + e * vmul), *(const f32x4 *)(gp + e * vmul));
-}
-
-
 // ---- Q4_K -----------------------------------------------------------------------------------------------
 // The (row, step) pairs a wave owns form one linear sequence of steps (a step = 8 super-blocks = 1152 contiguous bytes);
 // the loads of the first P steps are issued BEFORE the activation prologue and every consumed step immediately re-issues
 // the load P steps ahead.  Decode launches use P = 2 with one 1024-thread workgroup per CU (measured: deeper prefetch is
 // SLOWER on MI355X -- 4 steps -2 %, 8 steps -15 % tokens/s -- more requests in flight than the memory system wants).
 // Accumulation order inside a row does not depend on P.
-#define TS(k) do { if (FUSED && a.ts && threadIdx.x == 0) a.ts[blockIdx.x * 8 + (k)] = wall_clock64(); } while (0)
-// PRO = 0: plain launch (activation rows quantized by k_quantize_*, NC columns, optional MUL_MAT_ID expert selection);
-// PRO = 1..3: decode launch, single column, the activation row is produced by the prologue; EPI = 1: SiLU(gate)*up epilogue
-// PP >= P: steps prefetched before the prologue (the memory system is idle then, so a deep burst is free), P: steps kept
-// in flight in steady state (deeper is slower, see above).
-template <int NC, int P, int PRO, int EPI = 0, int NPRE = 4, int PP = P>
+template <int NC, int P>
 __global__ void __launch_bounds__(1024) k_mmvq_q4_K(const mmvq_args a) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
-    constexpr bool FUSED = PRO != 0;
-    TS(0);
-    constexpr int KB = 256;
+    constexpr int EPI = 0, PP = P;
     const char * W = a.W; const char * act = a.act; float * dst = a.dst;
-    if (!FUSED) { if (!mmvq_select(a, W, act, dst)) return; }
+    if (!mmvq_select(a, W, act, dst)) return;
     const int64_t nb01 = a.nb01, nrows = a.nrows, dst_cs = a.dst_cs; const int nblk = a.nblk;
     const int64_t K = (int64_t) nblk * 256;
     const size_t  rb = act_row_bytes(K, 256);
@@ -182,14 +108,10 @@ __global__ void __launch_bounds__(1024) k_mmvq_q4_K(const mmvq_args a) {
         q = *(const u32x4 *)(bp + 16 + 16 * j);
         if (++is == S) { is = 0; if (++isub == RU) { isub = 0; ik++; } }
     };
-    build_act<KB, PRO, NPRE>(lds, a, act, K, rb, NC, [&] {
 #pragma unroll
-        for (int p = 0; p < PP; p++) issue(hh[p], qq[p]);
-        TS(1);
-    });
-    TS(2);
+    for (int p = 0; p < PP; p++) issue(hh[p], qq[p]);          // weight loads fly while the activation rows are staged
+    stage_act(lds, act, a.act_stride, rb, NC);
     __syncthreads();
-    TS(3);
 
     const q4k_sel L = q4k_lane_sel(lane);
     const int off_d = (int) act_off_d(K), off_s = (int) act_off_s(K, 256);
@@ -233,23 +155,19 @@ __global__ void __launch_bounds__(1024) k_mmvq_q4_K(const mmvq_args a) {
             }
         }
     }
-    TS(4);
-    if (FUSED && a.ts) { __syncthreads(); TS(5); }
 }
-#undef TS
 
 // ---- Q4_0 / Q8_0 (one lane per 32-weight block) ------------------------------------------------------------
 
-template <int NC, bool IS_Q8, bool FUSED>        // FUSED: decode launch, prologue chosen at run time by a.pro
+template <int NC, bool IS_Q8>
 __global__ void __launch_bounds__(1024) k_mmvq_q32(const mmvq_args a) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
-    constexpr int KB = 32;
     const char * W; const char * act; float * dst;
     if (!mmvq_select(a, W, act, dst)) return;
     const int64_t nb01 = a.nb01, nrows = a.nrows, dst_cs = a.dst_cs; const int nblk = a.nblk;
     const int64_t K = (int64_t) nblk * 32;
     const size_t  rb = act_row_bytes(K, 32);
-    build_act<KB, FUSED ? -1 : 0, 4>(lds, a, act, K, rb, NC, [] {});
+    stage_act(lds, act, a.act_stride, rb, NC);
     __syncthreads();
 
     constexpr int BS = IS_Q8 ? 34 : 18;
@@ -359,7 +277,6 @@ static void mmvq_tunables() {
     if (done) return;
     done = true;
     if (const char * e = getenv("CLLM_MMVQ_WG"))  { int v = atoi(e); if (v == 64 || v == 128 || v == 256 || v == 512) g_mmvq_wg = v; }
-    if (const char * e = getenv("CLLM_MMVQ_BURST")) { int v = atoi(e); if (v == 2 || v == 4 || v == 8) g_mmvq_burst = v; }
     if (const char * e = getenv("CLLM_MMVQ_OCC")) { int v = atoi(e); if (v >= 1 && v <= 32) g_mmvq_wgs_per_cu = v; }
     if (const char * e = getenv("CLLM_MMVQ_WG"))   { int v = atoi(e); if (v == 1024) g_mmvq_wg = v; }
 }
@@ -368,12 +285,9 @@ template <typename KernelT>
 static int launch_one(hipStream_t st, KernelT kern, size_t lds_bytes, const mmvq_args & a_in, int grid_y) {
     mmvq_args a = a_in;
     mmvq_tunables();
-    // in-kernel prologues are redundant work per workgroup: use few, fat workgroups (16 waves share one prologue; the
-    // RMS_NORM prologue's reduction tree is defined for exactly 1024 threads)
-    const int wg = a.pro != 0 ? 1024 : g_mmvq_wg, wpw = wg / 64;
-    const int64_t units = a.epi == 1 ? a.nrows / 2 : a.nrows;
-    int64_t grid = (units + wpw - 1) / wpw;
-    int64_t cap = (int64_t) device_cu_count() * (a.pro != 0 ? 1 : g_mmvq_wgs_per_cu) / grid_y;
+    const int wg = g_mmvq_wg, wpw = wg / 64;
+    int64_t grid = (a.nrows + wpw - 1) / wpw;
+    int64_t cap = (int64_t) device_cu_count() * g_mmvq_wgs_per_cu / grid_y;
     if (cap < 1) cap = 1;
     if (grid > cap) grid = cap;     // (balancing rows per wave exactly was measured slower than simply using more workgroups)
     if (lds_bytes > 64 * 1024) HIP_TRY(hipFuncSetAttribute((const void *) kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -384,37 +298,9 @@ static int launch_one(hipStream_t st, KernelT kern, size_t lds_bytes, const mmvq
 
 static int mmvq_dispatch(hipStream_t st, int wtype, int nc, size_t lds, const mmvq_args & a, int grid_y) {
 #define GO(...) return launch_one(st, __VA_ARGS__, lds, a, grid_y)
-    const bool fused = a.pro != 0;          // activation built inside the kernel (decode launches, nc == 1)
-    if (fused && nc != 1) FAIL(CLLM_E_INVALID, "mmvq: fused prologue needs a single column");
-    if (wtype == CLLM_TYPE_Q4_K) {
-        if (nc == 4) GO(k_mmvq_q4_K<4, 1, 0>); else if (nc == 2) GO(k_mmvq_q4_K<2, 1, 0>);
-        if (!fused) GO(k_mmvq_q4_K<1, 1, 0>);
-        // decode launches: one 1024-thread workgroup per CU, two steps of weight prefetch.  K <= 4096 needs one activation
-        // group per thread; longer rows keep four groups in registers across the prefetch.
-        constexpr int P = 2;
-        const bool small = a.nblk <= 16;
-        mmvq_tunables();
-        // burst depth: the steps a wave owns, rounded up to a power of two, at most g_mmvq_burst
-        const int64_t waves = (int64_t) device_cu_count() * 16, units = a.epi == 1 ? a.nrows / 2 : a.nrows;
-        const int64_t steps = ((units + waves - 1) / waves) * (a.epi == 1 ? 2 : 1) * ((a.nblk + 7) / 8);
-        int burst = P;
-        while (burst < g_mmvq_burst && burst < steps) burst <<= 1;
-        if (!small && a.pro == 1 && burst > 4) burst = 4;       // (the 8-deep burst + four activation groups would spill)
-#define GOB(PRO_, EPI_, NPRE_) do { if (burst >= 8) GO(k_mmvq_q4_K<1, P, PRO_, EPI_, NPRE_, 8>); if (burst >= 4) GO(k_mmvq_q4_K<1, P, PRO_, EPI_, NPRE_, 4>); \
-                                    GO(k_mmvq_q4_K<1, P, PRO_, EPI_, NPRE_, 2>); } while (0)
-        if (a.pro == 1 && a.epi == 1) { if (small) GOB(1, 1, 1); else GOB(1, 1, 4); }
-        if (a.pro == 1) { if (small) GOB(1, 0, 1); else GOB(1, 0, 4); }
-        if (a.pro == 2) { if (small) GOB(2, 0, 1); else GOB(2, 0, 4); }
-        if (a.pro == 3) { if (small) GOB(3, 0, 1); else GOB(3, 0, 4); }
-#undef GOB
-        FAIL(CLLM_E_INVALID, "mmvq: prologue %d", a.pro);
-    } else if (wtype == CLLM_TYPE_Q8_0) {
-        if (nc == 4) GO(k_mmvq_q32<4, true, false>); else if (nc == 2) GO(k_mmvq_q32<2, true, false>);
-        else if (fused) GO(k_mmvq_q32<1, true, true>); else GO(k_mmvq_q32<1, true, false>);
-    } else if (wtype == CLLM_TYPE_Q4_0) {
-        if (nc == 4) GO(k_mmvq_q32<4, false, false>); else if (nc == 2) GO(k_mmvq_q32<2, false, false>);
-        else if (fused) GO(k_mmvq_q32<1, false, true>); else GO(k_mmvq_q32<1, false, false>);
-    }
+    if (wtype == CLLM_TYPE_Q4_K)      { if (nc == 4) GO(k_mmvq_q4_K<4, 1>); else if (nc == 2) GO(k_mmvq_q4_K<2, 1>); else GO(k_mmvq_q4_K<1, 1>); }
+    else if (wtype == CLLM_TYPE_Q8_0) { if (nc == 4) GO(k_mmvq_q32<4, true>);  else if (nc == 2) GO(k_mmvq_q32<2, true>);  else GO(k_mmvq_q32<1, true>); }
+    else if (wtype == CLLM_TYPE_Q4_0) { if (nc == 4) GO(k_mmvq_q32<4, false>); else if (nc == 2) GO(k_mmvq_q32<2, false>); else GO(k_mmvq_q32<1, false>); }
 #undef GO
     FAIL(CLLM_E_UNSUPPORTED, "mmvq: weight type %d", wtype);
 }
@@ -473,24 +359,12 @@ int launch_mmvq_act(hipStream_t st, int wtype, const void * W, int64_t K, int64_
     return mmvq_dispatch(st, wtype, 1, rb, a, 1);
 }
 
-// decode mat-vec with the activation produced inside the kernel:
-//   pro 1: act = quantize(rms_norm(px) * pw)     pro 2: act = quantize(px)
-//   pro 3: act = quantize(silu(px[2i]) * px[2i+1]), i < K
+// decode mat-vec with the activation produced inside the kernel (gemv_decode.hip):
+//   pro 1: act = quantize(rms_norm(px) * pw)     pro 2: act = quantize(px)     pro 3: act = quantize(silu(px[2i]) * px[2i+1]), i < K
 //   epi 1: W rows alternate gate_u, up_u; dst[u] = silu(W[2u].act) * (W[2u+1].act), u < nrows / 2
 int launch_mmvq_fused(hipStream_t st, int wtype, const void * W, int64_t K, int64_t nrows, int pro, const float * px, const float * pw, float eps,
                       int epi, float * dst, const float * bias, const float * resid) {
-    const int kb = wtype == CLLM_TYPE_Q4_K ? 256 : 32;
-    if (K % kb || (kb == 32 && K % 32)) FAIL(CLLM_E_UNSUPPORTED, "mmvq_fused: K must be a multiple of the activation block");
-    const size_t rb = act_row_bytes(K, kb);
-    if (rb > 160 * 1024) FAIL(CLLM_E_UNSUPPORTED, "mmvq_fused: K=%lld does not fit LDS", (long long) K);
-    mmvq_args a = {};
-    a.W = (const char *) W; a.nb01 = (int64_t) cllm_row_size(wtype, K); a.nrows = nrows; a.nblk = (int)(K / kb);
-    a.act_stride = rb; a.dst = dst; a.bias = bias; a.resid = resid;
-    a.pro = pro; a.px = px; a.pw = pw; a.eps = eps; a.epi = epi;
-    {
-        const int rc = launch_gemv_decode(st, wtype, W, K, nrows, pro, px, pw, eps, epi, dst, bias, resid);
-        if (rc != CLLM_E_UNSUPPORTED) return rc;           // (very long rows / huge matrices fall through to the general kernel)
-        if (epi == 1) FAIL(CLLM_E_UNSUPPORTED, "mmvq_fused: SiLU epilogue only on the decode kernel's shapes");
-    }
-    return mmvq_dispatch(st, wtype, 1, rb, a, 1);
+    const int rc = launch_gemv_decode(st, wtype, W, K, nrows, pro, px, pw, eps, epi, dst, bias, resid);
+    if (rc == CLLM_E_UNSUPPORTED) cllm_set_error("mmvq_fused: type %d, K=%lld, prologue %d is outside the decode kernel's range", wtype, (long long) K, pro);
+    return rc;
 }
