@@ -49,10 +49,11 @@ struct cllm_llama {
     cllm_allreduce_fn allreduce = nullptr; void * allreduce_user = nullptr;
     void * tp_comm = nullptr;         // RCCL communicator (cllm_tp_init): the all-reduce runs on the runner's stream, inside the decode graph
     bool use_graph = true;
-    hipGraphExec_t decode_graph = nullptr;
+    hipGraphExec_t decode_graph = nullptr;       // one sampled decode step, short-context attention (one launch per layer)
+    hipGraphExec_t decode_graph_long = nullptr;  // the same with the split long-context attention (attn_long.hip)
     int32_t * next_tok_dev = nullptr;            // greedy feedback
     int32_t * out_ring = nullptr, * counter_dev = nullptr;   // device-side greedy loop: generated ids + how many
-    bool own_stream = false, fused_ok = false, fused_warm = false;
+    bool own_stream = false, fused_ok = false, fused_warm = false, fused_warm_long = false;
     size_t weight_bytes = 0;
 };
 
@@ -94,6 +95,7 @@ extern "C" void cllm_llama_destroy(cllm_llama * m) {
     if (!m) return;
     (void) hipStreamSynchronize(m->st);
     if (m->decode_graph) (void) hipGraphExecDestroy(m->decode_graph);
+    if (m->decode_graph_long) (void) hipGraphExecDestroy(m->decode_graph_long);
     free_w(m->tok_embd); free_w(m->lm_head); free_w(m->out_norm);
     for (auto & L : m->layers) {
         for (dweight * w : { &L.attn_norm, &L.ffn_norm, &L.wq, &L.wk, &L.wv, &L.wo, &L.wgate, &L.wup, &L.wdown, &L.bq, &L.bk, &L.bv, &L.wqkv, &L.wgu, &L.bqkv }) free_w(*w);
@@ -251,6 +253,7 @@ static int finalize(cllm_llama * m, int qlen) {
     }
     if (qlen > m->maxq) {
         if (m->decode_graph) { (void) hipGraphExecDestroy(m->decode_graph); m->decode_graph = nullptr; }
+        if (m->decode_graph_long) { (void) hipGraphExecDestroy(m->decode_graph_long); m->decode_graph_long = nullptr; }
         HIP_TRY(hipStreamSynchronize(m->st));
         for (void * p : { (void *) m->x, (void *) m->xn, (void *) m->qkv, (void *) m->att, (void *) m->ctx, (void *) m->o, (void *) m->gu, (void *) m->g, m->wdata,
                           (void *) m->tokens_dev, (void *) m->pos_dev }) if (p) (void) hipFree(p);
@@ -401,7 +404,10 @@ extern "C" int cllm_llama_forward(cllm_llama * m, const int32_t * tokens, int ql
 // ---- fused single-token step: 10 launches per layer, every per-token input read from device memory ----------------------
 static int kind_of(int wtype) { return wtype == CLLM_TYPE_Q4_K ? 256 : 32; }
 
-static int decode_step_fused(cllm_llama * m, bool sample) {
+// cached positions above which the split attention (three launches, every CU) beats the one-launch kernel (one CU per head)
+static int attn_long_threshold() { static const int v = getenv("CLLM_ATTN_LONG") ? atoi(getenv("CLLM_ATTN_LONG")) : 1024; return v < 512 ? 512 : v; }
+
+static int decode_step_fused(cllm_llama * m, bool sample, bool long_ctx) {
     const cllm_llama_config & c = m->cfg;
     const int64_t H = c.hidden, hd = c.head_dim, QD = (int64_t) m->nh * hd, KD = (int64_t) m->nkv * hd, F = m->F, V = c.vocab, ML = c.max_len;
     hipStream_t st = m->st;
@@ -436,7 +442,9 @@ static int decode_step_fused(cllm_llama * m, bool sample) {
     for (int il = 0; il < c.n_layer; il++) {
         llama_layer & L = m->layers[il];
         TRY(norm_gemv(L.wqkv, QD + 2*KD, (const float *) L.attn_norm.data, 0, m->qkv, c.qkv_bias ? (const float *) L.bqkv.data : nullptr));
-        int arc = cs_table ? launch_attn_dec_table(st, m->qkv, m->pos_dev, rope_cs, m->nh, m->nkv, (int) hd, c.rope_mode, L.k_cache, L.v_cache, ML, m->att) : CLLM_E_UNSUPPORTED;
+        int arc = CLLM_E_UNSUPPORTED;
+        if (cs_table && long_ctx) arc = launch_attn_long(st, m->qkv, m->pos_dev, rope_cs, m->nh, m->nkv, (int) hd, c.rope_mode, L.k_cache, L.v_cache, ML, m->scores, m->att);
+        if (arc == CLLM_E_UNSUPPORTED && cs_table) arc = launch_attn_dec_table(st, m->qkv, m->pos_dev, rope_cs, m->nh, m->nkv, (int) hd, c.rope_mode, L.k_cache, L.v_cache, ML, m->att);
         if (arc == CLLM_E_UNSUPPORTED) arc = launch_rope_kv_attn_decode(st, m->qkv, m->pos_dev, m->nh, m->nkv, (int) hd, c.rope_mode, c.rope_theta, L.k_cache, L.v_cache, ML, m->att);
         TRY(arc);
         if (!tp) TRY(launch_mmvq_fused(st, L.wo.type, L.wo.data, QD, H, 2, m->att, nullptr, 0.0f, 0, xc, nullptr, xc));          // x = o + x
@@ -464,15 +472,16 @@ static int decode_step_fused(cllm_llama * m, bool sample) {
 }
 
 // capture one sampled step into a graph (after one eager warm-up step has set every function attribute)
-static int ensure_decode_graph(cllm_llama * m) {
-    if (m->decode_graph || !m->use_graph || (m->cfg.tp_size > 1 && !m->tp_comm)) return CLLM_OK;     // a host callback cannot be captured; RCCL can
+static int ensure_decode_graph(cllm_llama * m, bool long_ctx) {
+    hipGraphExec_t & slot = long_ctx ? m->decode_graph_long : m->decode_graph;
+    if (slot || !m->use_graph || (m->cfg.tp_size > 1 && !m->tp_comm)) return CLLM_OK;     // a host callback cannot be captured; RCCL can
     hipGraph_t graph = nullptr;
     HIP_TRY(hipStreamBeginCapture(m->st, hipStreamCaptureModeRelaxed));
-    const int rc = decode_step_fused(m, true);
+    const int rc = decode_step_fused(m, true, long_ctx);
     const hipError_t e = hipStreamEndCapture(m->st, &graph);
     if (rc) { if (graph) (void) hipGraphDestroy(graph); return rc; }
     HIP_TRY(e);
-    HIP_TRY(hipGraphInstantiate(&m->decode_graph, graph, nullptr, nullptr, 0));
+    HIP_TRY(hipGraphInstantiate(&slot, graph, nullptr, nullptr, 0));
     (void) hipGraphDestroy(graph);
     return CLLM_OK;
 }
@@ -507,12 +516,19 @@ extern "C" int cllm_llama_decode_greedy(cllm_llama * m, int32_t first_token, int
         HIP_TRY(hipMemcpyAsync(m->pos_dev, &init[1], 4, hipMemcpyHostToDevice, m->st));
         HIP_TRY(hipMemcpyAsync(m->counter_dev, &zero, 4, hipMemcpyHostToDevice, m->st));
         HIP_TRY(hipStreamSynchronize(m->st));
-        int s = 0;
-        if (!m->fused_warm) { TRY(decode_step_fused(m, true)); m->fused_warm = true; s = 1; HIP_TRY(hipStreamSynchronize(m->st)); }
-        if (s < n_steps) TRY(ensure_decode_graph(m));
-        for (; s < n_steps; s++) {
-            if (m->decode_graph) HIP_TRY(hipGraphLaunch(m->decode_graph, m->st));
-            else TRY(decode_step_fused(m, true));
+        TRY(ensure_scores(m, (size_t) m->nh * m->cfg.max_len));
+        const int thr = attn_long_threshold();
+        for (int s = 0; s < n_steps; s++) {
+            const bool lng = n_past + s + 1 > thr;                 // cached positions this step attends to
+            bool & warm = lng ? m->fused_warm_long : m->fused_warm;
+            if (!warm) {                                           // one eager step sets every function attribute before the capture
+                TRY(decode_step_fused(m, true, lng)); warm = true; HIP_TRY(hipStreamSynchronize(m->st));
+                continue;
+            }
+            TRY(ensure_decode_graph(m, lng));
+            hipGraphExec_t ge = lng ? m->decode_graph_long : m->decode_graph;
+            if (ge) HIP_TRY(hipGraphLaunch(ge, m->st));
+            else TRY(decode_step_fused(m, true, lng));
         }
         HIP_TRY(hipMemcpyAsync(out_tokens_host, m->out_ring, (size_t) n_steps * 4, hipMemcpyDeviceToHost, m->st));
         HIP_TRY(hipStreamSynchronize(m->st));
@@ -543,7 +559,8 @@ extern "C" int cllm_llama_decode_fused_logits(cllm_llama * m, int32_t token, int
     HIP_TRY(hipMemcpyAsync(m->tokens_dev, &init[0], 4, hipMemcpyHostToDevice, m->st));
     HIP_TRY(hipMemcpyAsync(m->pos_dev, &init[1], 4, hipMemcpyHostToDevice, m->st));
     HIP_TRY(hipStreamSynchronize(m->st));
-    TRY(decode_step_fused(m, false));
+    TRY(ensure_scores(m, (size_t) m->nh * m->cfg.max_len));
+    TRY(decode_step_fused(m, false, n_past + 1 > attn_long_threshold()));
     HIP_TRY(hipMemcpyAsync(logits_host, m->logits, (size_t) m->cfg.vocab * 4, hipMemcpyDeviceToHost, m->st));
     HIP_TRY(hipStreamSynchronize(m->st));
     return CLLM_OK;

@@ -210,6 +210,21 @@ def test_fused_decode_path_is_bit_identical_to_the_node_by_node_path(gpu, wtype,
     b.close()
 
 
+@pytest.mark.parametrize("hd_cfg", ["tiny", "small"])
+def test_fused_decode_at_long_context_is_bit_identical_to_the_node_path(gpu, hd_cfg):
+    """> 1024 cached positions: the fused attention's pipelined cache loops and its all-wave exponentiation (group sums
+    accumulated by one wave in the node kernel's order) must still give the node-by-node bits"""
+    cfg = gpu.synth.config(hd_cfg, max_len=1280)
+    w = gpu.synth.make_model(cfg, O.Q4_K, seed=8)
+    a, b = gpu.Llama(cfg, w), gpu.Llama(cfg, w)
+    prompt = np.random.default_rng(8).integers(0, cfg["vocab"], 1150).astype(np.int32)
+    assert np.array_equal(a.forward(prompt), b.forward(prompt))
+    for t in np.random.default_rng(9).integers(0, cfg["vocab"], 12):      # n_kv 1151..1162: tails of 7, 0, 1, ... elements
+        assert np.array_equal(a.forward([int(t)]), b.decode_fused_logits(int(t)))
+    a.close()
+    b.close()
+
+
 def test_decode_greedy_graph_replay_matches_stepwise(gpu):
     cfg = gpu.synth.config("small", max_len=128)
     w = gpu.synth.make_model(cfg, O.Q4_K, seed=6)
