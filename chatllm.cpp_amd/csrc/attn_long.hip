@@ -13,6 +13,10 @@
 // buy 25 us at 4096 positions and 140 us at 16384.
 #include "common.h"
 
+static unsigned long long * g_long_ts = nullptr;
+extern "C" __attribute__((visibility("default"))) void cllm_debug_set_attn_long_ts(unsigned long long * dev_buf) { g_long_ts = dev_buf; }   // tools only
+#define TS(k) do { if (ts && threadIdx.x == 0) ts[(blockIdx.y * gridDim.x + blockIdx.x) * 8 + (k)] = wall_clock64(); } while (0)
+
 __device__ __forceinline__ int uniform_load_i32_(const int32_t * p) {
     int v;
     asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(p) : "memory");
@@ -23,7 +27,8 @@ __device__ __forceinline__ int uniform_load_i32_(const int32_t * p) {
 template <int HD, int MODE, int R2>
 __global__ void __launch_bounds__(256) k_attn_long_scores(const float * __restrict__ qkv, const int32_t * __restrict__ pos_dev, const float * __restrict__ rope_cs,
                                                           int nh, int nkv, float scale, uint16_t * __restrict__ k_cache, uint16_t * __restrict__ v_cache,
-                                                          int ML, float * __restrict__ S) {
+                                                          int ML, float * __restrict__ S, unsigned long long * ts) {
+    TS(0);
     __shared__ float qs[R2 * HD];          // the group's query heads after RoPE, rounded to fp16 (src1 of K.Q)
     __shared__ float knew[HD], vnew[HD];   // the new k (after RoPE) and v, rounded to fp16 like the cache
     constexpr int half = HD / 2, G = HD / 8, RPW = 64 / G, off = MODE == 0 ? 1 : half, U = 4;
@@ -53,7 +58,16 @@ __global__ void __launch_bounds__(256) k_attn_long_scores(const float * __restri
         }
     }
 
-    const int gl = lane & (G - 1), sub = lane / G, stride = 4 * RPW;
+    TS(1);
+    // A wave owns 16 consecutive positions per pass (U = 4 rounds of RPW = 4 rows, 16 lanes per row: 256 contiguous bytes of the
+    // row).  Each lane forms its 8-element partial per query head; the 16-lane reduction is NOT done with shuffles (4 heads x 4
+    // ds_bpermute stages per row made this loop LDS-crossbar bound, 2.7 us per pass): the partials go through LDS once, and lane
+    // (row, head) adds the row's 16 partials in the butterfly's order ((p0+p8)+(p4+p12))+... -> the same bits, 30x fewer LDS ops.
+    static_assert(G == 16 || G == 8, "head sizes 128 / 64");
+    constexpr int RPI = RPW * U;                                  // rows per wave and pass (16 for HD 128, 32 for HD 64)
+    constexpr int PSTR = G * R2 + 4;                              // floats per row in the exchange buffer (+4: conflict-free column reads)
+    __shared__ float part[4][RPI * PSTR];
+    const int gl = lane & (G - 1), sub = lane / G;
     const int d = gl * 8;
     float q[R2][8];
 #pragma unroll
@@ -61,19 +75,19 @@ __global__ void __launch_bounds__(256) k_attn_long_scores(const float * __restri
 #pragma unroll
         for (int j = 0; j < 8; j++) q[h][j] = qs[h * HD + d + j];
     const uint16_t * kbase = k_cache + g * HD + d;
+    float * mypart = part[wave];
     auto load_rows = [&](int ib, u32x4 (&r)[U]) {                // unconditional (clamped): exact vmcnt bookkeeping
 #pragma unroll
-        for (int u = 0; u < U; u++) { const int i0 = ib + u * stride; r[u] = *(const u32x4 *)(kbase + (int64_t)(i0 < pos ? i0 : 0) * KD); }
+        for (int u = 0; u < U; u++) { const int i0 = ib + u * RPW + sub; r[u] = *(const u32x4 *)(kbase + (int64_t)(i0 < pos ? i0 : 0) * KD); }
     };
     u32x4 cur[U], nxt[U];
-    const int ib0 = i_lo + wave * RPW + sub;
-    load_rows(ib0, cur);
-    for (int ib = ib0; ib < i_hi; ib += U * stride) {
-        load_rows(ib + U * stride, nxt);                         // the next pass is in flight while this one is consumed
+    constexpr int WSTEP = 4 * RPI;                                // positions per workgroup pass
+    load_rows(i_lo + wave * RPI, cur);
+    for (int ib = i_lo + wave * RPI; ib < i_hi; ib += WSTEP) {
+        load_rows(ib + WSTEP, nxt);                              // the next pass is in flight while this one is consumed
 #pragma unroll
         for (int u = 0; u < U; u++) {
-            const int i0 = ib + u * stride;
-            if (i0 >= i_hi) continue;                            // whole lane groups drop out together
+            const int rl = u * RPW + sub, i0 = ib + rl;
             float kv[8];
             if (i0 == pos) {
 #pragma unroll
@@ -88,14 +102,32 @@ __global__ void __launch_bounds__(256) k_attn_long_scores(const float * __restri
                 float acc = 0.0f;
 #pragma unroll
                 for (int j = 0; j < 8; j++) acc = __builtin_fmaf(kv[j], q[h][j], acc);
-#pragma unroll
-                for (int o = G / 2; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
-                if (gl == 0) S[(int64_t)(g * R2 + h) * ML + i0] = acc * scale;      // the SCALE node
+                mypart[rl * PSTR + gl * R2 + h] = acc;
             }
         }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");   // partials written by the other lanes of this wave
+        for (int t = lane; t < RPI * R2; t += 64) {              // lane t = (row, head)
+            const int rl = t / R2, h = t - rl * R2, i0 = ib + rl;
+            const float * pp = mypart + rl * PSTR + h;
+            float p[G];
+#pragma unroll
+            for (int l = 0; l < G; l++) p[l] = pp[l * R2];
+            float r;
+            if (G == 16) {
+                const float a0 = p[0] + p[8], a1 = p[1] + p[9], a2 = p[2] + p[10], a3 = p[3] + p[11], a4 = p[4] + p[12], a5 = p[5] + p[13], a6 = p[6] + p[14], a7 = p[7] + p[15];
+                const float b0 = a0 + a4, b1 = a1 + a5, b2 = a2 + a6, b3 = a3 + a7;
+                r = (b0 + b2) + (b1 + b3);
+            } else {
+                const float b0 = p[0] + p[4], b1 = p[1] + p[5], b2 = p[2] + p[6], b3 = p[3] + p[7];
+                r = (b0 + b2) + (b1 + b3);
+            }
+            if (i0 < i_hi) S[(int64_t)(g * R2 + h) * ML + i0] = r * scale;          // the SCALE node
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");   // the exchange buffer is reused by the next pass
 #pragma unroll
         for (int u = 0; u < U; u++) cur[u] = nxt[u];
     }
+    TS(2);
 }
 
 // ---- (2) soft_max over one head's scores; probabilities rounded to fp16 (as src1 of V.P) ------------------------------------
@@ -139,44 +171,81 @@ __global__ void __launch_bounds__(1024) k_attn_long_softmax(const int32_t * __re
 
 // ---- (3) ctx = V . P ------------------------------------------------------------------------------------------------------------
 // n_kv > 512 here, so a whole wave owns one V^T row (launch_T() in matmul_f.hip: G = 64): tail elements first, then 16-byte chunks
-// in increasing i, butterfly reduction.  One V chunk feeds the r2 heads of the group.
+// in increasing i, butterfly reduction.  One V chunk feeds the r2 heads of the group.  The probabilities (exactly representable in
+// fp16: they were rounded to it) are staged through LDS as fp16, one segment of SEG positions at a time, so that the inner loop's
+// only global loads are the V chunks (with the r2 x 32-byte P loads from L2 on its critical path this kernel took 44 us at 16K).
 template <int HD, int R2, int DR>
 __global__ void __launch_bounds__(256) k_attn_long_pv(const int32_t * __restrict__ pos_dev, int nh, int nkv, const uint16_t * __restrict__ v_cache, int ML,
                                                       const float * __restrict__ P, float * __restrict__ att) {
-    const int g = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    constexpr int SEG = 8192, RPWV = DR / 4, UC = 4;              // positions per staged segment, rows per wave, V chunks in flight
+    extern __shared__ __attribute__((aligned(16))) uint16_t psm[]; // [R2][SEG] fp16 probabilities
+    const int g = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n_kv = uniform_load_i32_(pos_dev) + 1, n8 = n_kv & ~7;
     const int it = n8 + lane, iv = lane * 8;
-    for (int d0 = blockIdx.x * DR + wave; d0 < (int)(blockIdx.x + 1) * DR && d0 < HD; d0 += 4) {
-        const uint16_t * vr = v_cache + ((int64_t) g * HD + d0) * ML;
-        float acc[R2];
-        const float vt = it < n_kv ? h2f(vr[it]) : 0.0f;
+    float acc[RPWV][R2];
+    const uint16_t * vrow[RPWV];
 #pragma unroll
-        for (int h = 0; h < R2; h++) acc[h] = it < n_kv ? __builtin_fmaf(vt, P[(int64_t)(g * R2 + h) * ML + it], 0.0f) : 0.0f;
-        u32x4 cur = *(const u32x4 *)(vr + (iv < n8 ? iv : 0));
-        for (int i = iv; i < n8; i += 512) {
-            const int inx = i + 512;
-            const u32x4 nxt = *(const u32x4 *)(vr + (inx < n8 ? inx : 0));       // unconditional (clamped) prefetch of the next chunk
-            const uint32_t wv[4] = { cur.x, cur.y, cur.z, cur.w };
-            float v[8];
+    for (int rr = 0; rr < RPWV; rr++) {
+        const int d0 = blockIdx.x * DR + wave + 4 * rr;
+        vrow[rr] = v_cache + ((int64_t) g * HD + (d0 < HD ? d0 : 0)) * ML;
+        const float vt = it < n_kv ? h2f(vrow[rr][it]) : 0.0f;
 #pragma unroll
-            for (int j = 0; j < 4; j++) { v[2*j] = h2f((uint16_t)(wv[j] & 0xffff)); v[2*j + 1] = h2f((uint16_t)(wv[j] >> 16)); }
-#pragma unroll
-            for (int h = 0; h < R2; h++) {
+        for (int h = 0; h < R2; h++) acc[rr][h] = it < n_kv ? __builtin_fmaf(vt, P[(int64_t)(g * R2 + h) * ML + it], 0.0f) : 0.0f;
+    }
+    for (int seg0 = 0; seg0 < n8; seg0 += SEG) {
+        const int seg1 = min(n8, seg0 + SEG);
+        __syncthreads();                                         // the previous segment has been consumed
+        for (int c = tid; c < R2 * (SEG / 8); c += 256) {        // 8 probabilities per task: two 16-byte loads, one 16-byte LDS store
+            const int h = c / (SEG / 8), i = seg0 + (c - h * (SEG / 8)) * 8;
+            if (i < seg1) {
                 const float * pr = P + (int64_t)(g * R2 + h) * ML + i;
                 const f32x4 p0 = *(const f32x4 *) pr, p1 = *(const f32x4 *)(pr + 4);
-                acc[h] = __builtin_fmaf(v[0], p0.x, acc[h]); acc[h] = __builtin_fmaf(v[1], p0.y, acc[h]);
-                acc[h] = __builtin_fmaf(v[2], p0.z, acc[h]); acc[h] = __builtin_fmaf(v[3], p0.w, acc[h]);
-                acc[h] = __builtin_fmaf(v[4], p1.x, acc[h]); acc[h] = __builtin_fmaf(v[5], p1.y, acc[h]);
-                acc[h] = __builtin_fmaf(v[6], p1.z, acc[h]); acc[h] = __builtin_fmaf(v[7], p1.w, acc[h]);
+                *(u32x4 *)(psm + h * SEG + (i - seg0)) = u32x4{ (uint32_t) f2h(p0.x) | ((uint32_t) f2h(p0.y) << 16), (uint32_t) f2h(p0.z) | ((uint32_t) f2h(p0.w) << 16),
+                                                               (uint32_t) f2h(p1.x) | ((uint32_t) f2h(p1.y) << 16), (uint32_t) f2h(p1.z) | ((uint32_t) f2h(p1.w) << 16) };
             }
-            cur = nxt;
         }
+        __syncthreads();
+#pragma unroll
+        for (int rr = 0; rr < RPWV; rr++) {
+            const uint16_t * vr = vrow[rr];
+            u32x4 ring[UC];
+#pragma unroll
+            for (int c = 0; c < UC; c++) { const int ic = seg0 + iv + 512 * c; ring[c] = *(const u32x4 *)(vr + (ic < seg1 ? ic : 0)); }
+            for (int i0 = seg0 + iv; i0 < seg1; i0 += 512 * UC) {
+#pragma unroll
+                for (int c = 0; c < UC; c++) {
+                    const int i = i0 + 512 * c;
+                    const u32x4 cur = ring[c];
+                    { const int inx = i + 512 * UC; ring[c] = *(const u32x4 *)(vr + (inx < seg1 ? inx : 0)); }    // unconditional (clamped) refill
+                    if (i < seg1) {
+                        const uint32_t wv[4] = { cur.x, cur.y, cur.z, cur.w };
+                        float v[8];
+#pragma unroll
+                        for (int j = 0; j < 4; j++) { v[2*j] = h2f((uint16_t)(wv[j] & 0xffff)); v[2*j + 1] = h2f((uint16_t)(wv[j] >> 16)); }
+#pragma unroll
+                        for (int h = 0; h < R2; h++) {
+                            const u32x4 pq = *(const u32x4 *)(psm + h * SEG + (i - seg0));
+                            const uint32_t pw[4] = { pq.x, pq.y, pq.z, pq.w };
+#pragma unroll
+                            for (int j = 0; j < 4; j++) {
+                                acc[rr][h] = __builtin_fmaf(v[2*j],     h2f((uint16_t)(pw[j] & 0xffff)), acc[rr][h]);
+                                acc[rr][h] = __builtin_fmaf(v[2*j + 1], h2f((uint16_t)(pw[j] >> 16)),    acc[rr][h]);
+                            }
+                        }
+                    }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int rr = 0; rr < RPWV; rr++) {
+        const int d0 = blockIdx.x * DR + wave + 4 * rr;
 #pragma unroll
         for (int h = 0; h < R2; h++) {
-            float r = acc[h];
+            float r = acc[rr][h];
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) r += __shfl_xor(r, o, 64);
-            if (lane == 0) att[(g * R2 + h) * HD + d0] = r;
+            if (lane == 0 && d0 < HD) att[(g * R2 + h) * HD + d0] = r;
         }
     }
 }
@@ -192,7 +261,7 @@ int launch_attn_long(hipStream_t st, const float * qkv, const int32_t * pos_dev,
     const int cus = device_cu_count();
     int nsplit = cus / nkv; if (nsplit < 1) nsplit = 1; if (nsplit > 64) nsplit = 64;
     constexpr int DR = 8;
-#define SC(HD_, MODE_, R2_) hipLaunchKernelGGL((k_attn_long_scores<HD_, MODE_, R2_>), dim3(nsplit, nkv), dim3(256), 0, st, qkv, pos_dev, rope_cs, nh, nkv, scale, k_cache, v_cache, (int) ML, S)
+#define SC(HD_, MODE_, R2_) hipLaunchKernelGGL((k_attn_long_scores<HD_, MODE_, R2_>), dim3(nsplit, nkv), dim3(256), 0, st, qkv, pos_dev, rope_cs, nh, nkv, scale, k_cache, v_cache, (int) ML, S, g_long_ts)
 #define SC2(HD_, R2_) do { if (mode == 0) SC(HD_, 0, R2_); else SC(HD_, 2, R2_); } while (0)
 #define SC3(HD_) do { if (r2 == 1) SC2(HD_, 1); else if (r2 == 2) SC2(HD_, 2); else if (r2 == 4) SC2(HD_, 4); else SC2(HD_, 8); } while (0)
     if (hd == 128) SC3(128); else SC3(64);
@@ -201,8 +270,14 @@ int launch_attn_long(hipStream_t st, const float * qkv, const int32_t * pos_dev,
     if (lds > 48 * 1024 && !attr) { HIP_TRY(hipFuncSetAttribute((const void *) k_attn_long_softmax, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024)); attr = true; }
     hipLaunchKernelGGL(k_attn_long_softmax, dim3(nh), dim3(1024), lds, st, pos_dev, (int) ML, S);
     LAUNCH_CHECK();
-#define PV(HD_, R2_) hipLaunchKernelGGL((k_attn_long_pv<HD_, R2_, DR>), dim3(HD_ / DR, nkv), dim3(256), 0, st, pos_dev, nh, nkv, (const uint16_t *) v_cache, (int) ML, (const float *) S, att)
+#define PV(HD_, R2_) hipLaunchKernelGGL((k_attn_long_pv<HD_, R2_, DR>), dim3(HD_ / DR, nkv), dim3(256), (size_t) R2_ * 8192 * 2, st, pos_dev, nh, nkv, (const uint16_t *) v_cache, (int) ML, (const float *) S, att)
 #define PV2(HD_) do { if (r2 == 1) PV(HD_, 1); else if (r2 == 2) PV(HD_, 2); else if (r2 == 4) PV(HD_, 4); else PV(HD_, 8); } while (0)
+    static bool attr_pv = false;
+    if (r2 == 8 && !attr_pv) {      // 8 x 16 KB of fp16 probabilities
+        HIP_TRY(hipFuncSetAttribute((const void *) k_attn_long_pv<128, 8, DR>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 8192 * 2));
+        HIP_TRY(hipFuncSetAttribute((const void *) k_attn_long_pv<64, 8, DR>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 8192 * 2));
+        attr_pv = true;
+    }
     if (hd == 128) PV2(128); else PV2(64);
     LAUNCH_CHECK();
 #undef SC
