@@ -13,6 +13,8 @@
 // buy 25 us at 4096 positions and 140 us at 16384.
 #include "common.h"
 
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+
 static unsigned long long * g_long_ts = nullptr;
 extern "C" __attribute__((visibility("default"))) void cllm_debug_set_attn_long_ts(unsigned long long * dev_buf) { g_long_ts = dev_buf; }   // tools only
 #define TS(k) do { if (ts && threadIdx.x == 0) ts[(blockIdx.y * gridDim.x + blockIdx.x) * 8 + (k)] = wall_clock64(); } while (0)
@@ -131,13 +133,14 @@ __global__ void __launch_bounds__(256) k_attn_long_scores(const float * __restri
 }
 
 // ---- (2) soft_max over one head's scores; probabilities rounded to fp16 (as src1 of V.P) ------------------------------------
-__global__ void __launch_bounds__(1024) k_attn_long_softmax(const int32_t * __restrict__ pos_dev, int ML, float * __restrict__ S) {
+__global__ void __launch_bounds__(1024) k_attn_long_softmax(const int32_t * __restrict__ pos_dev, int ML, const float * __restrict__ S, uint16_t * __restrict__ P16) {
     extern __shared__ __attribute__((aligned(16))) float sm[];    // [n_kv] scores | [n_kv / 8] group sums
     __shared__ double red_d[1];
     __shared__ float  red_f[16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n_kv = uniform_load_i32_(pos_dev) + 1, nv = n_kv & ~7;
-    float * row = S + (int64_t) blockIdx.x * ML;
+    const float * row = S + (int64_t) blockIdx.x * ML;
+    uint16_t * prow = P16 + (int64_t) blockIdx.x * ML;
     float * sc = sm; float * gsum = sm + ML;
     float mx = -INFINITY;
     for (int i = tid; i < n_kv; i += 1024) { const float v = row[i]; sc[i] = v; mx = fmaxf(mx, v); }
@@ -166,7 +169,7 @@ __global__ void __launch_bounds__(1024) k_attn_long_softmax(const int32_t * __re
     }
     __syncthreads();
     const float inv = (float)(1.0 / red_d[0]);
-    for (int i = tid; i < n_kv; i += 1024) row[i] = h2f(f2h(sc[i] * inv));
+    for (int i = tid; i < n_kv; i += 1024) prow[i] = f2h(sc[i] * inv);          // the fp16 rounding src1 of V.P gets (exact in fp32 later)
 }
 
 // ---- (3) ctx = V . P ------------------------------------------------------------------------------------------------------------
@@ -176,7 +179,7 @@ __global__ void __launch_bounds__(1024) k_attn_long_softmax(const int32_t * __re
 // only global loads are the V chunks (with the r2 x 32-byte P loads from L2 on its critical path this kernel took 44 us at 16K).
 template <int HD, int R2, int DR>
 __global__ void __launch_bounds__(256) k_attn_long_pv(const int32_t * __restrict__ pos_dev, int nh, int nkv, const uint16_t * __restrict__ v_cache, int ML,
-                                                      const float * __restrict__ P, float * __restrict__ att) {
+                                                      const uint16_t * __restrict__ P, float * __restrict__ att) {
     constexpr int SEG = 8192, RPWV = DR / 4, UC = 4;              // positions per staged segment, rows per wave, V chunks in flight
     extern __shared__ __attribute__((aligned(16))) uint16_t psm[]; // [R2][SEG] fp16 probabilities
     const int g = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -190,18 +193,26 @@ __global__ void __launch_bounds__(256) k_attn_long_pv(const int32_t * __restrict
         vrow[rr] = v_cache + ((int64_t) g * HD + (d0 < HD ? d0 : 0)) * ML;
         const float vt = it < n_kv ? h2f(vrow[rr][it]) : 0.0f;
 #pragma unroll
-        for (int h = 0; h < R2; h++) acc[rr][h] = it < n_kv ? __builtin_fmaf(vt, P[(int64_t)(g * R2 + h) * ML + it], 0.0f) : 0.0f;
+        for (int h = 0; h < R2; h++) acc[rr][h] = it < n_kv ? __builtin_fmaf(vt, h2f(P[(int64_t)(g * R2 + h) * ML + it]), 0.0f) : 0.0f;
     }
     for (int seg0 = 0; seg0 < n8; seg0 += SEG) {
         const int seg1 = min(n8, seg0 + SEG);
         __syncthreads();                                         // the previous segment has been consumed
-        for (int c = tid; c < R2 * (SEG / 8); c += 256) {        // 8 probabilities per task: two 16-byte loads, one 16-byte LDS store
-            const int h = c / (SEG / 8), i = seg0 + (c - h * (SEG / 8)) * 8;
-            if (i < seg1) {
-                const float * pr = P + (int64_t)(g * R2 + h) * ML + i;
-                const f32x4 p0 = *(const f32x4 *) pr, p1 = *(const f32x4 *)(pr + 4);
-                *(u32x4 *)(psm + h * SEG + (i - seg0)) = u32x4{ (uint32_t) f2h(p0.x) | ((uint32_t) f2h(p0.y) << 16), (uint32_t) f2h(p0.z) | ((uint32_t) f2h(p0.w) << 16),
-                                                               (uint32_t) f2h(p1.x) | ((uint32_t) f2h(p1.y) << 16), (uint32_t) f2h(p1.z) | ((uint32_t) f2h(p1.w) << 16) };
+        constexpr int NT = R2 * (SEG / 8) / 256;                 // 16-byte copy tasks per thread; all loads of a batch are in flight together
+#pragma unroll
+        constexpr int NB = NT < 8 ? NT : 8;
+#pragma unroll
+        for (int t0 = 0; t0 < NT; t0 += NB) {
+            u32x4 buf[NB];
+#pragma unroll
+            for (int t = 0; t < NB; t++) {
+                const int c = tid + 256 * (t0 + t), h = c / (SEG / 8), i = seg0 + (c - h * (SEG / 8)) * 8;
+                buf[t] = *(const u32x4 *)(P + (int64_t)(g * R2 + h) * ML + (i < seg1 ? i : 0));
+            }
+#pragma unroll
+            for (int t = 0; t < NB; t++) {
+                const int c = tid + 256 * (t0 + t), h = c / (SEG / 8), il = (c - h * (SEG / 8)) * 8;
+                *(u32x4 *)(psm + h * SEG + il) = buf[t];
             }
         }
         __syncthreads();
@@ -218,19 +229,14 @@ __global__ void __launch_bounds__(256) k_attn_long_pv(const int32_t * __restrict
                     const u32x4 cur = ring[c];
                     { const int inx = i + 512 * UC; ring[c] = *(const u32x4 *)(vr + (inx < seg1 ? inx : 0)); }    // unconditional (clamped) refill
                     if (i < seg1) {
-                        const uint32_t wv[4] = { cur.x, cur.y, cur.z, cur.w };
-                        float v[8];
-#pragma unroll
-                        for (int j = 0; j < 4; j++) { v[2*j] = h2f((uint16_t)(wv[j] & 0xffff)); v[2*j + 1] = h2f((uint16_t)(wv[j] >> 16)); }
+                        // both operands are fp16 in registers: fma((float) v, (float) p, acc) is one v_fma_mix_f32 per element
+                        // (the conversions are exact, so this is the cvt + fma of the other kernels bit for bit)
+                        const half8 v = __builtin_bit_cast(half8, cur);
 #pragma unroll
                         for (int h = 0; h < R2; h++) {
-                            const u32x4 pq = *(const u32x4 *)(psm + h * SEG + (i - seg0));
-                            const uint32_t pw[4] = { pq.x, pq.y, pq.z, pq.w };
+                            const half8 pq = __builtin_bit_cast(half8, *(const u32x4 *)(psm + h * SEG + (i - seg0)));
 #pragma unroll
-                            for (int j = 0; j < 4; j++) {
-                                acc[rr][h] = __builtin_fmaf(v[2*j],     h2f((uint16_t)(pw[j] & 0xffff)), acc[rr][h]);
-                                acc[rr][h] = __builtin_fmaf(v[2*j + 1], h2f((uint16_t)(pw[j] >> 16)),    acc[rr][h]);
-                            }
+                            for (int j = 0; j < 8; j++) acc[rr][h] = __builtin_fmaf((float) v[j], (float) pq[j], acc[rr][h]);
                         }
                     }
                 }
@@ -250,7 +256,7 @@ __global__ void __launch_bounds__(256) k_attn_long_pv(const int32_t * __restrict
     }
 }
 
-// CLLM_E_UNSUPPORTED -> the caller uses the single-launch kernels.  S: [nh][ML] floats of scratch.
+// CLLM_E_UNSUPPORTED -> the caller uses the single-launch kernels.  S: scratch of nh * ML * 6 bytes (fp32 scores + fp16 probabilities).
 int launch_attn_long(hipStream_t st, const float * qkv, const int32_t * pos_dev, const float * rope_cs, int nh, int nkv, int hd, int mode,
                      uint16_t * k_cache, uint16_t * v_cache, int64_t ML, float * S, float * att) {
     const int r2 = nkv > 0 ? nh / nkv : 0;
@@ -258,6 +264,7 @@ int launch_attn_long(hipStream_t st, const float * qkv, const int32_t * pos_dev,
     const size_t lds = (size_t)(ML + ML / 8) * 4;
     if (lds > 150 * 1024) return CLLM_E_UNSUPPORTED;
     const float scale = 1.0f / sqrtf((float) hd);
+    uint16_t * P16 = (uint16_t *)(S + (size_t) nh * ML);          // fp16 probabilities behind the fp32 scores
     const int cus = device_cu_count();
     int nsplit = cus / nkv; if (nsplit < 1) nsplit = 1; if (nsplit > 64) nsplit = 64;
     constexpr int DR = 8;
@@ -268,9 +275,9 @@ int launch_attn_long(hipStream_t st, const float * qkv, const int32_t * pos_dev,
     LAUNCH_CHECK();
     static bool attr = false;
     if (lds > 48 * 1024 && !attr) { HIP_TRY(hipFuncSetAttribute((const void *) k_attn_long_softmax, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024)); attr = true; }
-    hipLaunchKernelGGL(k_attn_long_softmax, dim3(nh), dim3(1024), lds, st, pos_dev, (int) ML, S);
+    hipLaunchKernelGGL(k_attn_long_softmax, dim3(nh), dim3(1024), lds, st, pos_dev, (int) ML, (const float *) S, P16);
     LAUNCH_CHECK();
-#define PV(HD_, R2_) hipLaunchKernelGGL((k_attn_long_pv<HD_, R2_, DR>), dim3(HD_ / DR, nkv), dim3(256), (size_t) R2_ * 8192 * 2, st, pos_dev, nh, nkv, (const uint16_t *) v_cache, (int) ML, (const float *) S, att)
+#define PV(HD_, R2_) hipLaunchKernelGGL((k_attn_long_pv<HD_, R2_, DR>), dim3(HD_ / DR, nkv), dim3(256), (size_t) R2_ * 8192 * 2, st, pos_dev, nh, nkv, (const uint16_t *) v_cache, (int) ML, (const uint16_t *) P16, att)
 #define PV2(HD_) do { if (r2 == 1) PV(HD_, 1); else if (r2 == 2) PV(HD_, 2); else if (r2 == 4) PV(HD_, 4); else PV(HD_, 8); } while (0)
     static bool attr_pv = false;
     if (r2 == 8 && !attr_pv) {      // 8 x 16 KB of fp16 probabilities

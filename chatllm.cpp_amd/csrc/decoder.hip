@@ -516,7 +516,7 @@ extern "C" int cllm_llama_decode_greedy(cllm_llama * m, int32_t first_token, int
         HIP_TRY(hipMemcpyAsync(m->pos_dev, &init[1], 4, hipMemcpyHostToDevice, m->st));
         HIP_TRY(hipMemcpyAsync(m->counter_dev, &zero, 4, hipMemcpyHostToDevice, m->st));
         HIP_TRY(hipStreamSynchronize(m->st));
-        TRY(ensure_scores(m, (size_t) m->nh * m->cfg.max_len));
+        TRY(ensure_scores(m, (size_t) m->nh * m->cfg.max_len * 3 / 2 + 64));
         const int thr = attn_long_threshold();
         for (int s = 0; s < n_steps; s++) {
             const bool lng = n_past + s + 1 > thr;                 // cached positions this step attends to
@@ -559,7 +559,7 @@ extern "C" int cllm_llama_decode_fused_logits(cllm_llama * m, int32_t token, int
     HIP_TRY(hipMemcpyAsync(m->tokens_dev, &init[0], 4, hipMemcpyHostToDevice, m->st));
     HIP_TRY(hipMemcpyAsync(m->pos_dev, &init[1], 4, hipMemcpyHostToDevice, m->st));
     HIP_TRY(hipStreamSynchronize(m->st));
-    TRY(ensure_scores(m, (size_t) m->nh * m->cfg.max_len));
+    TRY(ensure_scores(m, (size_t) m->nh * m->cfg.max_len * 3 / 2 + 64));
     TRY(decode_step_fused(m, false, n_past + 1 > attn_long_threshold()));
     HIP_TRY(hipMemcpyAsync(logits_host, m->logits, (size_t) m->cfg.vocab * 4, hipMemcpyDeviceToHost, m->st));
     HIP_TRY(hipStreamSynchronize(m->st));
