@@ -115,7 +115,7 @@ __global__ void __launch_bounds__(256) k_attn_long_scores(const float * __restri
 #pragma unroll
             for (int l = 0; l < G; l++) p[l] = pp[l * R2];
             float r;
-            if (G == 16) {
+            if constexpr (G == 16) {
                 const float a0 = p[0] + p[8], a1 = p[1] + p[9], a2 = p[2] + p[10], a3 = p[3] + p[11], a4 = p[4] + p[12], a5 = p[5] + p[13], a6 = p[6] + p[14], a7 = p[7] + p[15];
                 const float b0 = a0 + a4, b1 = a1 + a5, b2 = a2 + a6, b3 = a3 + a7;
                 r = (b0 + b2) + (b1 + b3);
@@ -199,7 +199,6 @@ __global__ void __launch_bounds__(256) k_attn_long_pv(const int32_t * __restrict
         const int seg1 = min(n8, seg0 + SEG);
         __syncthreads();                                         // the previous segment has been consumed
         constexpr int NT = R2 * (SEG / 8) / 256;                 // 16-byte copy tasks per thread; all loads of a batch are in flight together
-#pragma unroll
         constexpr int NB = NT < 8 ? NT : 8;
 #pragma unroll
         for (int t0 = 0; t0 < NT; t0 += NB) {
