@@ -232,6 +232,56 @@ __global__ void __launch_bounds__(256) k_soft_max_causal_reg(tview s, tview d, f
     }
 }
 
+// the same for rows too long for registers (8192 < n <= 32768): one 256-thread workgroup per row, the row staged in LDS.
+// All four waves exponentiate; the per-group float sums are accumulated by ONE wave in k_soft_max's order (lane l owns groups
+// l, l + 64, ...; double; DPP tree), so the result is still bit-identical to the single-wave kernel.
+__global__ void __launch_bounds__(256) k_soft_max_causal_lds(tview s, tview d, float scale, int n_past) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];      // [n] values | [n / 8] group sums
+    __shared__ float red_f[4];
+    __shared__ double red_d[1];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t row = blockIdx.x;
+    const int64_t i1 = row % s.ne[1], i2 = (row / s.ne[1]) % s.ne[2], i3 = row / (s.ne[1] * s.ne[2]);
+    const float * x = (const float *)(s.data + i1*s.nb[1] + i2*s.nb[2] + i3*s.nb[3]);
+    float *       y = (float *)(d.data + i1*d.nb[1] + i2*d.nb[2] + i3*d.nb[3]);
+    const int n = (int) s.ne[0];
+    const int n_vis = n_past + (int) i1 + 1 < n ? n_past + (int) i1 + 1 : n;
+    const int nv_vis = (n_vis + 7) & ~7;                              // n % 8 == 0: whole groups
+    float * gsum = sm + n;
+    float mx = -INFINITY;
+    for (int g0 = tid * 8; g0 < nv_vis; g0 += 256 * 8) {
+        const f32x4 lo = *(const f32x4 *)(x + g0), hi = *(const f32x4 *)(x + g0 + 4);
+        const float v[8] = { lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w };
+#pragma unroll
+        for (int l = 0; l < 8; l++) { const float t = g0 + l < n_vis ? v[l] * scale : -INFINITY; sm[g0 + l] = t; mx = fmaxf(mx, t); }
+    }
+    mx = wave_max(mx);
+    if (lane == 0) red_f[wave] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red_f[0], red_f[1]), fmaxf(red_f[2], red_f[3]));
+    for (int g0 = tid * 8; g0 < nv_vis; g0 += 256 * 8) {              // each thread re-reads what it wrote
+        float e[8];
+#pragma unroll
+        for (int l = 0; l < 8; l++) { e[l] = ggml_expf_poly(sm[g0 + l] - mx); sm[g0 + l] = e[l]; }
+        const float a0 = e[0] + e[4], a1 = e[1] + e[5], a2 = e[2] + e[6], a3 = e[3] + e[7];
+        gsum[g0 >> 3] = (a0 + a2) + (a1 + a3);
+    }
+    __syncthreads();
+    if (wave == 0) {
+        double sum = 0.0;
+        for (int gq = lane; gq < (nv_vis >> 3); gq += 64) sum += (double) gsum[gq];
+        sum = wave_sum_d(sum);
+        if (lane == 0) red_d[0] = sum;
+    }
+    __syncthreads();
+    const float inv = (float)(1.0 / red_d[0]);
+    for (int g0 = tid * 8; g0 < n; g0 += 256 * 8) {
+        f32x4 lo = {0, 0, 0, 0}, hi = {0, 0, 0, 0};
+        if (g0 < nv_vis) { lo = f32x4{sm[g0] * inv, sm[g0 + 1] * inv, sm[g0 + 2] * inv, sm[g0 + 3] * inv}; hi = f32x4{sm[g0 + 4] * inv, sm[g0 + 5] * inv, sm[g0 + 6] * inv, sm[g0 + 7] * inv}; }
+        *(f32x4 *)(y + g0) = lo; *(f32x4 *)(y + g0 + 4) = hi;
+    }
+}
+
 static int soft_max_impl(void * stream, const cllm_tensor * src, const cllm_tensor * mask, cllm_tensor * dst, float scale, int fused, int n_past) {
     if (!src || !dst) FAIL(CLLM_E_INVALID, "soft_max: null");
     if (src->type != CLLM_TYPE_F32 || dst->type != CLLM_TYPE_F32) FAIL(CLLM_E_UNSUPPORTED, "soft_max: type");
@@ -249,6 +299,14 @@ static int soft_max_impl(void * stream, const cllm_tensor * src, const cllm_tens
     if (fused && n % 8 == 0 && n >= 512 && n <= 8192 && al16) {      // long (prefill) rows: register-resident single pass
         if (n <= 4096) hipLaunchKernelGGL(k_soft_max_causal_reg<8>,  dim3(grid), dim3(256), 0, st, tv(src), tv(dst), scale, n_past);
         else           hipLaunchKernelGGL(k_soft_max_causal_reg<16>, dim3(grid), dim3(256), 0, st, tv(src), tv(dst), scale, n_past);
+        LAUNCH_CHECK();
+        return CLLM_OK;
+    }
+    if (fused && n % 8 == 0 && n > 8192 && n <= 32768 && al16 && rows <= 0x7fffffff) {      // very long rows: one workgroup per row, row in LDS
+        const size_t lds = (size_t)(n + n / 8) * 4;
+        static bool attr = false;
+        if (!attr) { HIP_TRY(hipFuncSetAttribute((const void *) k_soft_max_causal_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024)); attr = true; }
+        hipLaunchKernelGGL(k_soft_max_causal_lds, dim3((unsigned) rows), dim3(256), lds, st, tv(src), tv(dst), scale, n_past);
         LAUNCH_CHECK();
         return CLLM_OK;
     }

@@ -221,7 +221,8 @@ def test_soft_max_ext_mask(gpu):
 
 
 @pytest.mark.parametrize("qlen,n_past", [(1, 0), (1, 300), (7, 0), (5, 13),
-                                         (520, 0), (24, 1000), (40, 4400)])      # rows of >= 512 (multiple of 8): register-resident kernel
+                                         (520, 0), (24, 1000), (40, 4400),         # rows of >= 512 (multiple of 8): register-resident kernel
+                                         (24, 9000), (8, 20000)])                  # rows > 8192: one workgroup per row, row in LDS
 def test_scale_mask_soft_max_equals_three_nodes(gpu, qlen, n_past):
     nh, n_kv = 4, n_past + qlen
     x = rng.standard_normal((nh, qlen, n_kv)).astype(np.float32)
