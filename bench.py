@@ -187,7 +187,7 @@ def cpu_baseline(pkg, cfg, wtype, budget_s=20.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=128)
+    ap.add_argument("--steps", type=int, default=512, help="decode steps in the timed region (BASELINE cfg2: 16-token prompt, 512 decoded tokens)")
     ap.add_argument("--warmup", type=int, default=16)
     ap.add_argument("--model", default="llama3-8b")
     ap.add_argument("--wtype", default="q4_k", choices=sorted(WTYPES))
