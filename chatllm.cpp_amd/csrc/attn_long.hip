@@ -9,8 +9,8 @@
 //   k_attn_long_pv     : grid (row chunk, kv head): V^T rows of the chunk are read ONCE and dotted with the r2 probability rows
 // Every score, every probability and every context element is produced by the same lane-group arithmetic in the same order as in
 // k_attn_dec / the unfused MUL_MAT + SOFT_MAX nodes (only WHICH workgroup computes an element changes), so the results are
-// bit-identical to theirs.  Used by the runner above CLLM_ATTN_LONG cached positions (default 1024): two extra launches (~9 us)
-// buy 25 us at 4096 positions and 140 us at 16384.
+// bit-identical to theirs.  Used by the runner above CLLM_ATTN_LONG cached positions (default and minimum 512, the measured
+// crossover is ~400): two extra launches (~9 us) buy 25 us at 4096 positions and 140 us at 16384.
 #include "common.h"
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));

@@ -212,8 +212,8 @@ def test_fused_decode_path_is_bit_identical_to_the_node_by_node_path(gpu, wtype,
 
 @pytest.mark.parametrize("hd_cfg", ["tiny", "small"])
 def test_fused_decode_at_long_context_is_bit_identical_to_the_node_path(gpu, hd_cfg):
-    """> 1024 cached positions: the fused attention's pipelined cache loops and its all-wave exponentiation (group sums
-    accumulated by one wave in the node kernel's order) must still give the node-by-node bits"""
+    """long contexts take the split attention (attn_long.hip: scores / soft_max / V.P launches over the whole chip, lane-group
+    reduction through LDS, all-wave exponentiation with the group sums accumulated in the node kernel's order): same bits"""
     cfg = gpu.synth.config(hd_cfg, max_len=1280)
     w = gpu.synth.make_model(cfg, O.Q4_K, seed=8)
     a, b = gpu.Llama(cfg, w), gpu.Llama(cfg, w)

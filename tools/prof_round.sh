@@ -5,7 +5,7 @@ set -u
 R=/root/repo; O=$R/gpurun_out/round; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/p1 /tmp/p2 /tmp/p3
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p1 -- python $R/bench.py > $O/bench_under_rocprof.json 2> $O/bench_under_rocprof.err
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p1 -- python $R/bench.py --steps 48 --warmup 8 --no-cpu-baseline > $O/bench_under_rocprof.json 2> $O/bench_under_rocprof.err   # (rocprofv3 segfaults on >= 144 graph replays on this image)
 cp $(find /tmp/p1 -name "*kernel_stats.csv" | head -1) $O/bench_kernel_stats.csv
 python $R/tools/trace_token.py $(find /tmp/p1 -name "*kernel_trace.csv" | head -1) 12 > $O/decode_step_trace.txt
 python $R/bench.py > $O/bench.json 2> $O/bench.err
@@ -16,4 +16,11 @@ cp $(find /tmp/p3 -name "*counter_collection.csv" | head -1) $O/pmc_write_size.c
 python $R/tools/gemv_bench.py --fused --types q4_k > $O/gemv_fused.txt 2>&1
 python $R/tools/gemv_bench.py > $O/gemv_plain.txt 2>&1
 python $R/tools/gemv_phase_probe.py > $O/gemv_phases.txt 2>&1
+python $R/tools/attn_phase_probe.py 128 > $O/attn_phases.txt 2>&1
+python $R/tools/prefill_bench.py --reps 2 > $O/prefill.txt 2>&1
+python $R/tools/prefill_bench.py --reps 2 --wtype q4_k >> $O/prefill.txt 2>&1
+for n in 1008 4080 16368; do python $R/bench.py --n-prompt $n --steps 64 --warmup 8 --no-cpu-baseline 2>/dev/null | grep -o '"value": [0-9.]*\|n_ctx_end": [0-9]*' | tr '\n' ' '; echo; done > $O/decode_long_context.txt
+rm -rf /tmp/p4; rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVES --kernel-trace --output-format csv -d /tmp/p4 -- python $R/tools/gemv_bench.py --types q4_0,q4_k --cols 4096 --iters 4 --shapes gate_up > $O/pmc_mfma.log 2>&1
+cp $(find /tmp/p4 -name "*counter_collection.csv" | head -1) $O/pmc_mfma_mmq.csv
+python $R/tools/gemv_bench.py --types q4_0,q4_k --cols 4096 --iters 8 --shapes qkv,o,gate_up,down > $O/mmq_4096cols.txt 2>&1
 tail -3 $O/bench.json; cat $O/decode_step_trace.txt | head -16
