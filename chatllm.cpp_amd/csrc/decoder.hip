@@ -479,10 +479,22 @@ static int ensure_decode_graph(cllm_llama * m, bool long_ctx) {
     HIP_TRY(hipStreamBeginCapture(m->st, hipStreamCaptureModeRelaxed));
     const int rc = decode_step_fused(m, true, long_ctx);
     const hipError_t e = hipStreamEndCapture(m->st, &graph);
-    if (rc) { if (graph) (void) hipGraphDestroy(graph); return rc; }
-    HIP_TRY(e);
-    HIP_TRY(hipGraphInstantiate(&slot, graph, nullptr, nullptr, 0));
-    (void) hipGraphDestroy(graph);
+    hipError_t ei = hipSuccess;
+    if (!rc && e == hipSuccess) ei = hipGraphInstantiate(&slot, graph, nullptr, nullptr, 0);
+    if (graph) (void) hipGraphDestroy(graph);
+    if (rc || e != hipSuccess || ei != hipSuccess) {
+        // with a collective inside (tensor parallel) a failed capture is not fatal: the steps are launched eagerly instead
+        if (m->cfg.tp_size > 1 && m->tp_comm) {
+            (void) hipGetLastError();
+            slot = nullptr; m->use_graph = false;
+            fprintf(stderr, "[cllm] decode graph capture with RCCL inside failed (%s): launching the decode steps eagerly\n",
+                    rc ? cllm_last_error() : hipGetErrorString(e != hipSuccess ? e : ei));
+            return CLLM_OK;
+        }
+        if (rc) return rc;
+        HIP_TRY(e);
+        HIP_TRY(ei);
+    }
     return CLLM_OK;
 }
 
