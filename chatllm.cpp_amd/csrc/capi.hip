@@ -240,6 +240,31 @@ extern "C" int cllm_bench_mul_mat_kernel(void * stream, const cllm_tensor * src0
     return CLLM_OK;
 }
 
+// times `iters` MUL_MAT_ID launches (quantize of b included, as the op does it), cycling the ids through ids_list[0..n_ids)
+extern "C" int cllm_bench_mul_mat_id(void * stream, const cllm_tensor * as, const cllm_tensor * b, const cllm_tensor * ids, void * const * ids_datas, int n_ids,
+                                     cllm_tensor * dst, void * wdata, size_t wsize, int iters, float * avg_us) {
+    if (!as || !b || !ids || !dst || !ids_datas || n_ids <= 0 || iters <= 0 || !avg_us) FAIL(CLLM_E_INVALID, "bench_mul_mat_id: arguments");
+    hipStream_t st = (hipStream_t) stream;
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
+    for (int pass = 0; pass < 2; pass++) {
+        if (pass == 1) HIP_TRY(hipEventRecord(e0, st));
+        const int n = pass == 0 ? 2 : iters;
+        for (int i = 0; i < n; i++) {
+            cllm_tensor id = *ids; id.data = ids_datas[i % n_ids];
+            const int rc = cllm_op_mul_mat_id(stream, as, b, &id, dst, wdata, wsize);
+            if (rc) return rc;
+        }
+    }
+    HIP_TRY(hipEventRecord(e1, st));
+    HIP_TRY(hipEventSynchronize(e1));
+    float ms = 0.0f;
+    HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+    (void) hipEventDestroy(e0); (void) hipEventDestroy(e1);
+    *avg_us = ms * 1e3f / (float) iters;
+    return CLLM_OK;
+}
+
 // times the DECODE form of the mat-vec (activation prologue inside the kernel, exactly what cllm_llama's fused step launches)
 extern "C" int cllm_bench_gemv_fused(void * stream, int wtype, void * const * w_datas, int n_w, int64_t K, int64_t nrows, int pro,
                                      const float * px, const float * pw, float eps, int epi, float * dst, const float * resid, int iters, float * avg_us) {

@@ -100,6 +100,11 @@ CLLM_API int    cllm_op_mul_mat(void * stream, const cllm_tensor * src0, const c
 CLLM_API int    cllm_bench_mul_mat_kernel(void * stream, const cllm_tensor * src0, void * const * src0_datas, int n_src0,
                                           const cllm_tensor * src1, cllm_tensor * dst, void * wdata, size_t wsize, int iters, float * avg_us);
 
+/* same for GGML_OP_MUL_MAT_ID: `iters` launches of the whole op (activation quantization + expert mat-vecs), the ids cycled through
+ * ids_datas[0..n_ids) (device pointers laid out like ids->data) so that successive launches pick different experts */
+CLLM_API int    cllm_bench_mul_mat_id(void * stream, const cllm_tensor * as, const cllm_tensor * b, const cllm_tensor * ids, void * const * ids_datas, int n_ids,
+                                      cllm_tensor * dst, void * wdata, size_t wsize, int iters, float * avg_us);
+
 /* same, for the decode form of the mat-vec (single column, the activation is produced inside the kernel):
  *   pro 1: act = quantize(rms_norm(px[0..K)) * pw)   pro 2: act = quantize(px)   pro 3: act = quantize(silu(px[2i]) * px[2i+1])
  * dst[r] = W[r] . act (+ resid[r]);  epi 1: W rows alternate gate_u, up_u and dst[u] = silu(W[2u].act) * (W[2u+1].act).
