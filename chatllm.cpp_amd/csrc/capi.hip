@@ -240,6 +240,19 @@ extern "C" int cllm_bench_mul_mat_kernel(void * stream, const cllm_tensor * src0
     return CLLM_OK;
 }
 
+// One launch for a node pattern around a single-column quantized MUL_MAT (what a ggml backend's graph_compute can fuse):
+//   pro 1: dst = W . quantize(RMS_NORM(px, eps) * pw)        RMS_NORM -> MUL -> MUL_MAT
+//   pro 2: dst = W . quantize(px)                             MUL_MAT
+//   pro 4: dst = W . quantize(silu(px) * pw)                  UNARY(SILU) -> MUL -> MUL_MAT
+//   + resid (may be NULL): dst += resid                       ... -> ADD        (dst may alias resid, not px / pw)
+extern "C" int cllm_op_mul_mat_vec_fused(void * stream, const cllm_tensor * src0, int pro, const float * px, const float * pw, float eps,
+                                         const float * resid, float * dst) {
+    if (!src0 || !px || !dst || (pro != 1 && pro != 2 && pro != 4) || ((pro == 1 || pro == 4) && !pw)) FAIL(CLLM_E_INVALID, "mul_mat_vec_fused: arguments");
+    if (!is_quant(src0->type) || src0->ne[2] != 1 || src0->ne[3] != 1 || src0->nb[1] != cllm_row_size(src0->type, src0->ne[0])) FAIL(CLLM_E_UNSUPPORTED, "mul_mat_vec_fused: src0 must be a dense 2-D quantized matrix");
+    if (((uintptr_t) px | (uintptr_t) pw | (uintptr_t) src0->data) & 15) FAIL(CLLM_E_UNSUPPORTED, "mul_mat_vec_fused: alignment");
+    return launch_gemv_decode((hipStream_t) stream, src0->type, src0->data, src0->ne[0], src0->ne[1], pro, px, pw, eps, 0, dst, nullptr, resid);
+}
+
 // times `iters` MUL_MAT_ID launches (quantize of b included, as the op does it), cycling the ids through ids_list[0..n_ids)
 extern "C" int cllm_bench_mul_mat_id(void * stream, const cllm_tensor * as, const cllm_tensor * b, const cllm_tensor * ids, void * const * ids_datas, int n_ids,
                                      cllm_tensor * dst, void * wdata, size_t wsize, int iters, float * avg_us) {

@@ -3,6 +3,7 @@
 //   prologue PRO 1: act = quantize_q8_K(RMS_NORM(px) * pw)     (LMBlock1Forward: input_layernorm / post_attention_layernorm -> Linear)
 //            PRO 2: act = quantize_q8_K(px)                    (attention output -> o_proj, SiLU*up -> down_proj)
 //            PRO 3: act = quantize_q8_K(silu(px[2i]) * px[2i+1])  (interleaved gate/up pairs -> down_proj, BaseMLP::forward)
+//            PRO 4: act = quantize_q8_K(silu(px[i]) * pw[i])      (separate gate / up vectors: the reference's own graph, fused by the module)
 //   epilogue EPI 1: W rows alternate gate_u, up_u; dst[u] = silu(W[2u].act) * (W[2u+1].act)
 //   dst[r] = W[r] . act (+ bias[r]) (+ resid[r])               (Linear::forward src/layers.cpp:2111-2129, residual adds :2740,:2758)
 // Same arithmetic as RMS_NORM -> MUL -> quantize_row_q8_K -> MUL_MAT (-> ADD) on the node-by-node path, bit for bit:
@@ -52,7 +53,7 @@ __global__ void __launch_bounds__(1024) k_gemv_dec(const float * __restrict__ px
 
     // ---- (1) this thread's activation groups: unconditional (clamped) loads, issued before anything else ----
     // pro 3: px holds interleaved (gate_e, up_e) pairs -- two 16-byte loads cover this thread's four features
-    const float * gp = PRO == 1 ? pw : PRO == 3 ? px + 4 : px;
+    const float * gp = (PRO == 1 || PRO == 4) ? pw : PRO == 3 ? px + 4 : px;
     constexpr int vmul = PRO == 3 ? 2 : 1;
     const int e0 = tid * 4;
     f32x4 vv[NPRE], gg[NPRE];
@@ -125,6 +126,10 @@ __global__ void __launch_bounds__(1024) k_gemv_dec(const float * __restrict__ px
                 v.x = silu_any(p0.x, e + 0 < nv) * p0.y; v.y = silu_any(p0.z, e + 1 < nv) * p0.w;
                 v.z = silu_any(p1.x, e + 2 < nv) * p1.y; v.w = silu_any(p1.z, e + 3 < nv) * p1.w;
             }
+            if (PRO == 4) {
+                const f32x4 g = gg[u];
+                v.x = silu_any(v.x, e + 0 < nv) * g.x; v.y = silu_any(v.y, e + 1 < nv) * g.y; v.z = silu_any(v.z, e + 2 < nv) * g.z; v.w = silu_any(v.w, e + 3 < nv) * g.w;
+            }
             if (PRO == 1) { const f32x4 g = gg[u]; v.x = (v.x * scale) * g.x; v.y = (v.y * scale) * g.y; v.z = (v.z * scale) * g.z; v.w = (v.w * scale) * g.w; }
             quant4_store<KIND>(lds, K, e, lane, v);
         }
@@ -175,7 +180,7 @@ int launch_gemv_decode(hipStream_t st, int wtype, const void * W, int64_t K, int
                        int epi, float * dst, const float * bias, const float * resid, const float * padd, float * xout) {
     const int kind = wtype == CLLM_TYPE_Q4_K ? 256 : 32;
     if (wtype != CLLM_TYPE_Q4_K && wtype != CLLM_TYPE_Q4_0 && wtype != CLLM_TYPE_Q8_0) return CLLM_E_UNSUPPORTED;
-    if (K % kind || K > (pro == 2 ? 32768 : 16384) || pro < 1 || pro > 3 || nrows <= 0 || (uint64_t) nrows * (uint64_t) cllm_row_size(wtype, K) >= (1ull << 32)) return CLLM_E_UNSUPPORTED;
+    if (K % kind || K > ((pro == 2 || pro == 4) ? 32768 : 16384) || pro < 1 || pro > 4 || nrows <= 0 || (uint64_t) nrows * (uint64_t) cllm_row_size(wtype, K) >= (1ull << 32)) return CLLM_E_UNSUPPORTED;
     if (act_row_bytes(K, kind) > 160 * 1024) return CLLM_E_UNSUPPORTED;
     if (padd && (pro != 1 || K > 4096 || !xout || xout == px)) return CLLM_E_UNSUPPORTED;
     if (epi == 1 && (pro != 1 || nrows % 2 || (nrows / 2) % 8 || bias || resid)) FAIL(CLLM_E_UNSUPPORTED, "gemv_decode: SiLU epilogue needs gate/up row pairs, features %% 8 == 0");
@@ -194,6 +199,7 @@ int launch_gemv_decode(hipStream_t st, int wtype, const void * W, int64_t K, int
         if (pro == 1 && epi == 1) { if (npre == 1) GO3(FMT_, 1, 1, 1); else GO3(FMT_, 1, 1, 4); } \
         else if (pro == 1)        { if (npre == 1) GO3(FMT_, 1, 0, 1); else GO3(FMT_, 1, 0, 4); } \
         else if (pro == 2)        { if (npre == 1) GO3(FMT_, 2, 0, 1); else if (npre == 4) GO3(FMT_, 2, 0, 4); else GO3(FMT_, 2, 0, 8); } \
+        else if (pro == 4)        { if (npre == 1) GO3(FMT_, 4, 0, 1); else if (npre == 4) GO3(FMT_, 4, 0, 4); else GO3(FMT_, 4, 0, 8); } \
         else                      { if (npre == 1) GO3(FMT_, 3, 0, 1); else GO3(FMT_, 3, 0, 4); } } while (0)
     if (wtype == CLLM_TYPE_Q4_K) GO(CLLM_TYPE_Q4_K); else if (wtype == CLLM_TYPE_Q4_0) GO(CLLM_TYPE_Q4_0); else GO(CLLM_TYPE_Q8_0);
 #undef GO

@@ -10,6 +10,7 @@
 #include "ggml.h"
 #include "ggml-backend.h"
 #include "ggml-backend-impl.h"
+#include "ggml-impl.h"          // ggml_node_get_use_count: the graph-wide use counts the fusion pass relies on
 
 #include "../../include/chatllm_hip.h"
 
@@ -17,6 +18,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #define HIPB_LOG(...) do { fprintf(stderr, "[ggml-hip] " __VA_ARGS__); fputc('\n', stderr); } while (0)
@@ -150,13 +152,128 @@ int ensure_wdata(hip_backend_ctx * c, size_t need) {
     return CLLM_OK;
 }
 
+// ---- node-pattern fusion (decode graphs: a token is ~25 launches per layer node by node, ~5 us each) -------------------------------
+// A pattern is fused only if every intermediate it swallows is used by nobody else: the graph-wide use count
+// (ggml_node_get_use_count, shared by scheduler splits) must equal the uses found in THIS graph, and the tensor must not be a
+// graph output.  All fused launches are bit-identical to the node sequence they replace (same kernels' arithmetic).
+//   RMS_NORM -> MUL(weight) -> {MUL_MAT ...}      norm + weight + quantize in every consumer mat-vec's prologue (pro 1)
+//   UNARY(SILU) -> MUL(up) -> MUL_MAT             SiLU*up + quantize in the mat-vec's prologue (pro 4)
+//   MUL_MAT -> ADD(residual | bias)               epilogue
+//   SCALE -> DIAG_MASK_INF -> SOFT_MAX            cllm_op_scale_mask_soft_max
+struct fused_mv { int pro = 2; const float * px = nullptr; const float * pw = nullptr; float eps = 0.0f; const float * resid = nullptr; float * dst = nullptr; };
+struct fuse_plan {
+    std::vector<uint8_t> skip;          // node is produced inside a fused launch (or not needed at all)
+    std::vector<int>     mv;            // index into mvs for MUL_MAT nodes launched fused, else -1
+    std::vector<fused_mv> mvs;
+    std::vector<int>     sm_src;        // SOFT_MAX nodes: node index of the SCALE feeding the fused scale+mask+soft_max, else -1
+};
+
+bool f32_vec(const ggml_tensor * t) { return t && t->type == GGML_TYPE_F32 && t->nb[0] == 4 && t->ne[1] == 1 && t->ne[2] == 1 && t->ne[3] == 1 && ((uintptr_t) t->data & 15) == 0; }
+bool overlap(const void * a, size_t na, const void * b, size_t nb) { return (const char *) a < (const char *) b + nb && (const char *) b < (const char *) a + na; }
+
+fuse_plan make_plan(ggml_cgraph * g) {
+    const int n = ggml_graph_n_nodes(g);
+    fuse_plan P; P.skip.assign(n, 0); P.mv.assign(n, -1); P.sm_src.assign(n, -1);
+    static const bool off = getenv("CLLM_HIP_NO_FUSE") != nullptr;
+    if (off || n < 8) return P;
+    std::vector<int> local(n, 0);
+    std::vector<std::vector<int>> users(n);
+    {   // uses inside this graph (views count as uses of their source, exactly like ggml's use counts)
+        std::unordered_map<const ggml_tensor *, int> idx; idx.reserve((size_t) n * 2);
+        for (int i = 0; i < n; i++) idx[ggml_graph_node(g, i)] = i;
+        auto find = [&](const ggml_tensor * t) { auto it = idx.find(t); return it == idx.end() ? -1 : it->second; };
+        for (int j = 0; j < n; j++) {
+            const ggml_tensor * t = ggml_graph_node(g, j);
+            for (int k = 0; k < GGML_MAX_SRC; k++) if (t->src[k]) { const int i = find(t->src[k]); if (i >= 0 && i < j) { local[i]++; users[i].push_back(j); } }
+        }
+    }
+    auto only_local = [&](int i, int uses) {
+        const ggml_tensor * t = ggml_graph_node(g, i);
+        return !(t->flags & GGML_TENSOR_FLAG_OUTPUT) && local[i] == uses && ggml_node_get_use_count(g, i) == uses;
+    };
+    auto node_of = [&](const ggml_tensor * t, int before) { for (int i = before - 1; i >= 0 && i >= before - 64; i--) if (ggml_graph_node(g, i) == t) return i; return -1; };
+    auto mv_ok = [&](const ggml_tensor * mm) {      // a single-column quantized MUL_MAT the decode mat-vec takes
+        const ggml_tensor * w = mm->src[0], * x = mm->src[1];
+        return mm->op == GGML_OP_MUL_MAT && is_q(w->type) && w->ne[2] == 1 && w->ne[3] == 1 && w->nb[1] == ggml_row_size(w->type, w->ne[0]) && ((uintptr_t) w->data & 15) == 0 &&
+               x->type == GGML_TYPE_F32 && x->ne[1] == 1 && x->ne[2] == 1 && x->ne[3] == 1 && f32_vec(mm) &&
+               w->ne[0] <= 16384 && (uint64_t) w->ne[1] * w->nb[1] < (1ull << 32);
+    };
+    for (int i = 0; i < n; i++) {
+        ggml_tensor * t = ggml_graph_node(g, i);
+        // ---- RMS_NORM -> MUL(weight) -> mat-vecs
+        if (t->op == GGML_OP_MUL && t->src[0] && t->src[0]->op == GGML_OP_RMS_NORM && f32_vec(t) && f32_vec(t->src[0]->src[0]) && f32_vec(t->src[1]) &&
+            t->src[1]->ne[0] == t->ne[0] && t->ne[0] % 256 == 0) {
+            const int r = node_of(t->src[0], i);
+            bool ok = r >= 0 && only_local(r, 1) && only_local(i, local[i]) && local[i] > 0;
+            for (int j : users[i]) { const ggml_tensor * c = ggml_graph_node(g, j); ok = ok && mv_ok(c) && c->src[1] == t; }
+            if (ok) {
+                float eps; memcpy(&eps, t->src[0]->op_params, 4);
+                for (int j : users[i]) {
+                    fused_mv f; f.pro = 1; f.px = (const float *) t->src[0]->src[0]->data; f.pw = (const float *) t->src[1]->data; f.eps = eps; f.dst = (float *) ggml_graph_node(g, j)->data;
+                    P.mv[j] = (int) P.mvs.size(); P.mvs.push_back(f);
+                }
+                P.skip[r] = P.skip[i] = 1;
+            }
+        }
+        // ---- UNARY(SILU) -> MUL(up) -> mat-vec
+        if (t->op == GGML_OP_MUL && t->src[0] && t->src[0]->op == GGML_OP_UNARY && ggml_get_unary_op(t->src[0]) == GGML_UNARY_OP_SILU && f32_vec(t) && f32_vec(t->src[0]->src[0]) &&
+            f32_vec(t->src[1]) && t->src[1]->ne[0] == t->ne[0] && local[i] == 1) {
+            const int u = node_of(t->src[0], i), j = users[i][0];
+            const ggml_tensor * c = ggml_graph_node(g, j);
+            if (u >= 0 && only_local(u, 1) && only_local(i, 1) && mv_ok(c) && c->src[1] == t && t->ne[0] % 8 == 0 && c->src[0]->ne[0] <= 32768) {
+                fused_mv f; f.pro = 4; f.px = (const float *) t->src[0]->src[0]->data; f.pw = (const float *) t->src[1]->data; f.dst = (float *) c->data;
+                P.mv[j] = (int) P.mvs.size(); P.mvs.push_back(f);
+                P.skip[u] = P.skip[i] = 1;
+            }
+        }
+        // ---- SCALE -> DIAG_MASK_INF -> SOFT_MAX (no mask tensor, no ALiBi)
+        if (t->op == GGML_OP_SOFT_MAX && !t->src[1] && t->src[0]->op == GGML_OP_DIAG_MASK_INF && t->src[0]->src[0]->op == GGML_OP_SCALE) {
+            const int dm = node_of(t->src[0], i), sc = dm >= 0 ? node_of(t->src[0]->src[0], dm) : -1;
+            float s1, mb, bias; memcpy(&s1, t->op_params, 4); memcpy(&mb, (const float *) t->op_params + 1, 4);
+            if (sc >= 0) memcpy(&bias, (const float *) ggml_graph_node(g, sc)->op_params + 1, 4);
+            if (sc >= 0 && only_local(dm, 1) && only_local(sc, 1) && s1 == 1.0f && mb == 0.0f && bias == 0.0f) { P.sm_src[i] = sc; P.skip[dm] = P.skip[sc] = 1; }
+        }
+    }
+    // ---- mat-vec -> ADD: after the prologue patterns, so that it composes with them
+    for (int i = 0; i < n; i++) {
+        ggml_tensor * a = ggml_graph_node(g, i);
+        if (a->op != GGML_OP_ADD || !f32_vec(a)) continue;
+        for (int side = 0; side < 2; side++) {
+            const ggml_tensor * mm = a->src[side], * r = a->src[1 - side];
+            if (!mm || mm->op != GGML_OP_MUL_MAT || !mv_ok(mm) || !f32_vec(r) || r->ne[0] != a->ne[0]) continue;
+            const int j = node_of(mm, i);
+            if (j < 0 || !only_local(j, 1) || P.skip[j]) continue;
+            if (P.mv[j] < 0) { fused_mv f; f.pro = 2; f.px = (const float *) mm->src[1]->data; P.mv[j] = (int) P.mvs.size(); P.mvs.push_back(f); }
+            fused_mv & f = P.mvs[P.mv[j]];
+            const size_t kbytes = (size_t) mm->src[0]->ne[0] * 4, nbytes = (size_t) a->ne[0] * 4;
+            if (overlap(a->data, nbytes, f.px, kbytes) || (f.pw && overlap(a->data, nbytes, f.pw, kbytes))) { if (f.pro == 2 && !f.resid && !f.dst) { P.mvs.pop_back(); P.mv[j] = -1; } continue; }
+            f.resid = (const float *) r->data; f.dst = (float *) a->data;
+            P.skip[i] = 1;
+            break;
+        }
+    }
+    for (int j = 0; j < n; j++) if (P.mv[j] >= 0 && !P.mvs[P.mv[j]].dst) P.mvs[P.mv[j]].dst = (float *) ggml_graph_node(g, j)->data;
+    return P;
+}
+
 ggml_status be_graph_compute(ggml_backend_t backend, ggml_cgraph * g) {
     auto * c = (hip_backend_ctx *) backend->context;
     cllm_set_device(c->device);
     void * st = c->stream;
+    static const bool trace = getenv("CLLM_HIP_TRACE") != nullptr;
+    if (trace) {
+        HIPB_LOG("graph_compute: %d nodes", ggml_graph_n_nodes(g));
+        for (int i = 0; i < ggml_graph_n_nodes(g); i++) {
+            const ggml_tensor * n = ggml_graph_node(g, i);
+            fprintf(stderr, "  %3d %-14s %-24s [%lld,%lld,%lld,%lld] nb0=%zu", i, ggml_op_name(n->op), n->name, (long long) n->ne[0], (long long) n->ne[1], (long long) n->ne[2], (long long) n->ne[3], n->nb[0]);
+            for (int k = 0; k < 3; k++) if (n->src[k]) fprintf(stderr, "  s%d=%s(%s)[%lld,%lld,%lld]", k, n->src[k]->name, ggml_op_name(n->src[k]->op), (long long) n->src[k]->ne[0], (long long) n->src[k]->ne[1], (long long) n->src[k]->ne[2]);
+            fputc('\n', stderr);
+        }
+    }
+    const fuse_plan plan = make_plan(g);
     for (int i = 0; i < ggml_graph_n_nodes(g); i++) {
         ggml_tensor * n = ggml_graph_node(g, i);
-        if (ggml_is_empty(n)) continue;
+        if (ggml_is_empty(n) || plan.skip[i]) continue;
         const ggml_tensor * a = n->src[0], * b = n->src[1];
         int rc = CLLM_OK;
         cllm_tensor d = desc(n), da, db, dc;
@@ -164,7 +281,10 @@ ggml_status be_graph_compute(ggml_backend_t backend, ggml_cgraph * g) {
         if (b) db = desc(b);
         switch (n->op) {
             case GGML_OP_NONE: case GGML_OP_RESHAPE: case GGML_OP_VIEW: case GGML_OP_PERMUTE: case GGML_OP_TRANSPOSE: break;
-            case GGML_OP_MUL_MAT: {
+            case GGML_OP_MUL_MAT: if (plan.mv[i] >= 0) {
+                const fused_mv & f = plan.mvs[plan.mv[i]];
+                rc = cllm_op_mul_mat_vec_fused(st, &da, f.pro, f.px, f.pw, f.eps, f.resid, f.dst);
+            } else {
                 const size_t need = cllm_mul_mat_wsize(&da, &db);
                 if ((rc = ensure_wdata(c, need))) break;
                 rc = cllm_op_mul_mat(st, &da, &db, &d, c->wdata, c->wsize);
@@ -189,7 +309,12 @@ ggml_status be_graph_compute(ggml_backend_t backend, ggml_cgraph * g) {
                 if (n->src[2]) dc = desc(n->src[2]);
                 rc = cllm_op_rope(st, &da, &db, n->src[2] ? &dc : nullptr, &d, &p);
             } break;
-            case GGML_OP_SOFT_MAX: {
+            case GGML_OP_SOFT_MAX: if (plan.sm_src[i] >= 0) {
+                const ggml_tensor * sc = ggml_graph_node(g, plan.sm_src[i]);
+                float scale; memcpy(&scale, sc->op_params, 4);
+                cllm_tensor ds = desc(sc->src[0]);
+                rc = cllm_op_scale_mask_soft_max(st, &ds, &d, scale, n->src[0]->op_params[0]);
+            } else {
                 float scale, max_bias; memcpy(&scale, n->op_params, 4); memcpy(&max_bias, (const float *) n->op_params + 1, 4);
                 rc = cllm_op_soft_max(st, &da, b ? &db : nullptr, &d, scale, max_bias);
             } break;

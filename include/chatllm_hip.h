@@ -94,6 +94,14 @@ CLLM_API size_t cllm_mul_mat_wsize(const cllm_tensor * src0, const cllm_tensor *
 CLLM_API int    cllm_op_mul_mat(void * stream, const cllm_tensor * src0, const cllm_tensor * src1, cllm_tensor * dst,
                                 void * wdata, size_t wsize);
 
+/* One launch for a node pattern around a single-column quantized MUL_MAT -- what a ggml backend's graph_compute can fuse
+ * (chatllm.cpp_amd/host/ggml-hip.cpp does, with ggml's use counts):
+ *   pro 1: RMS_NORM(px, eps) -> MUL(pw) -> MUL_MAT(src0)      pro 2: MUL_MAT(src0, px)      pro 4: UNARY(SILU)(px) -> MUL(pw) -> MUL_MAT(src0)
+ *   resid != NULL: ... -> ADD(resid).   px / pw / resid / dst: dense F32 vectors (dst may alias resid, never px / pw).
+ * Bit-identical to the unfused cllm_op_* sequence.  CLLM_E_UNSUPPORTED for row lengths outside the decode kernel's range. */
+CLLM_API int    cllm_op_mul_mat_vec_fused(void * stream, const cllm_tensor * src0, int pro, const float * px, const float * pw, float eps,
+                                          const float * resid, float * dst);
+
 /* measurement hook for bench.py's "roofline" object: quantizes src1 once, then times `iters` launches of ONLY the
  * mat-mul kernel between two HIP events on `stream`, cycling src0->data through src0_datas[0..n_src0) (distinct
  * copies of the weights, so the Infinity Cache cannot serve them).  avg_us = average kernel launch duration. */

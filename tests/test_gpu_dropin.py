@@ -50,3 +50,28 @@ def test_reference_host_cpu_vs_our_module(gpu, tmp_path, wname, wt):
             decided += 1
             agree += int(ids_c[s] == ids_g[s])
     assert decided >= 6 and agree == decided
+
+
+@pytest.mark.skipif(not (os.path.exists(os.path.join(REF, "ref_chat")) and os.path.exists(os.path.join(REF, "libggml-hip.so"))),
+                    reason="oracle/_ref (reference host + module) not built")
+@pytest.mark.parametrize("wname,wt,over", [("q4_k", 12, {}), ("q4_0", 2, {}), ("q4_k", 12, dict(ffn=544))])
+def test_module_node_fusion_does_not_change_a_bit(gpu, tmp_path, wname, wt, over):
+    """graph_compute fuses RMS_NORM->MUL->MUL_MAT, SILU->MUL->MUL_MAT, MUL_MAT->ADD and SCALE->MASK->SOFT_MAX node patterns into single
+    launches; with CLLM_HIP_NO_FUSE=1 every node is its own launch: the logits of prompt + 10 decode steps must be identical bytes"""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import make_ggmm
+    cfg = gpu.synth.config("tiny", max_len=64, **over)
+    mp = str(tmp_path / "m.bin")
+    make_ggmm.write_model(mp, cfg, wt, seed=78)
+    prompt = [3, 100, 45, 260, 17]
+    out = {}
+    for mode in ("fused", "nodes"):
+        lp = str(tmp_path / f"l_{mode}.bin")
+        env = dict(os.environ)
+        if mode == "nodes":
+            env["CLLM_HIP_NO_FUSE"] = "1"
+        r = subprocess.run([os.path.join(REF, "ref_chat"), mp, "all", "4", "10", lp] + [str(p) for p in prompt], capture_output=True, text=True, env=env, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        out[mode] = (r.stdout.split(), open(lp, "rb").read())
+    assert out["fused"][0] == out["nodes"][0]
+    assert out["fused"][1] == out["nodes"][1]
