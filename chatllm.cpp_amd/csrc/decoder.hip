@@ -279,6 +279,9 @@ static int finalize(cllm_llama * m, int qlen) {
 static int ensure_scores(cllm_llama * m, size_t elems) {
     if (elems <= m->scores_elems) return CLLM_OK;
     HIP_TRY(hipStreamSynchronize(m->st));
+    // the captured decode graphs hold the old pointer (long-context attention scratch): drop them, they are re-captured on demand
+    if (m->decode_graph) { (void) hipGraphExecDestroy(m->decode_graph); m->decode_graph = nullptr; }
+    if (m->decode_graph_long) { (void) hipGraphExecDestroy(m->decode_graph_long); m->decode_graph_long = nullptr; }
     if (m->scores) (void) hipFree(m->scores);
     m->scores = nullptr; m->scores_elems = 0;
     HIP_TRY(hipMalloc((void **) &m->scores, elems * 4));
