@@ -225,6 +225,32 @@ def test_fused_decode_at_long_context_is_bit_identical_to_the_node_path(gpu, hd_
     b.close()
 
 
+def test_decode_graphs_survive_a_reallocation_of_the_attention_scratch(gpu):
+    """the long-context decode graph captures the score scratch; a later, larger prefill re-allocates it: the graphs must be
+    re-captured, not replayed on freed memory"""
+    cfg = gpu.synth.config("tiny", max_len=1400)
+    w = gpu.synth.make_model(cfg, O.Q4_K, seed=12)
+    r = np.random.default_rng(12)
+    p1, p2 = r.integers(0, cfg["vocab"], 600).astype(np.int32), r.integers(0, cfg["vocab"], 900).astype(np.int32)
+
+    def run(m, interleave):
+        t = int(np.argmax(m.forward(p1, n_past=0)))
+        a = m.decode_greedy(t, 20)                        # captures the long-context graph (> 512 cached positions)
+        if interleave:
+            t2 = int(np.argmax(m.forward(p2, n_past=0)))  # 900 x 900 scores per head: the scratch grows
+            b = m.decode_greedy(t2, 20)
+            return a, b
+        return a, None
+
+    m1, m2 = gpu.Llama(cfg, w), gpu.Llama(cfg, w)
+    a1, b1 = run(m1, True)
+    t2 = int(np.argmax(m2.forward(p2, n_past=0)))
+    b2 = m2.decode_greedy(t2, 20)                         # a fresh runner doing only the second half
+    a3, _ = run(gpu.Llama(cfg, w), False)
+    assert np.array_equal(a1, a3) and np.array_equal(b1, b2)
+    m1.close(); m2.close()
+
+
 def test_decode_greedy_graph_replay_matches_stepwise(gpu):
     cfg = gpu.synth.config("small", max_len=128)
     w = gpu.synth.make_model(cfg, O.Q4_K, seed=6)
