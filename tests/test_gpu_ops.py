@@ -104,7 +104,8 @@ def test_mul_mat_quant_long_rows(gpu, t, K):
 
 
 @pytest.mark.parametrize("t", [O.Q4_K, O.Q4_0, O.Q8_0])
-@pytest.mark.parametrize("K,N,M", [(512, 64, 16), (1024, 100, 33), (4096, 256, 128), (256, 17, 9)])
+@pytest.mark.parametrize("K,N,M", [(512, 64, 16), (1024, 100, 33), (4096, 256, 128), (256, 17, 9),
+                                   (768, 130, 70), (4352, 300, 257)])        # two token tiles, ragged N / M / K
 def test_mul_mat_quant_gemm(gpu, t, K, N, M):
     got, want = _mm_case(gpu, t, K, N, M)
     assert rel_err(got, want) < T1
