@@ -340,3 +340,26 @@ def test_attention_composite(gpu, qlen, n_past):
     # the probabilities are rounded to fp16 before V.P (CPU semantics): a 1e-7 difference in P can flip one of those
     # roundings (5e-4 relative on that element), hence the looser bound on the composite
     assert rel_err(got, want) < 3e-4
+
+
+# ---- fused single-token patterns (cllm_op_mul_mat_vec_fused) == the node sequence they replace, to the bit ----------------------
+@pytest.mark.parametrize("t,K,N,pro", [(O.Q4_K, 4096, 512, 1), (O.Q4_K, 8192, 256, 1), (O.Q4_K, 14336, 256, 4), (O.Q4_K, 29440, 128, 4),
+                                       (O.Q8_0, 29568, 128, 4), (O.Q4_0, 4096, 384, 1), (O.Q8_0, 2048, 100, 2), (O.Q4_K, 256, 33, 4)])
+def test_mul_mat_vec_fused_equals_the_node_sequence(gpu, t, K, N, pro):
+    ops, T = gpu.ops, gpu.Tensor
+    w = T.from_numpy(rand_blocks(t, N, K, rng), t, [K, N])
+    x = T.from_numpy(rng.standard_normal((1, K)).astype(np.float32))
+    g = T.from_numpy((1 + 0.1 * rng.standard_normal((1, K))).astype(np.float32))
+    r = T.from_numpy(rng.standard_normal((1, N)).astype(np.float32))
+    if pro == 1:
+        act = ops.rms_norm_mul(x, T.from_numpy(g.numpy().reshape(K)), 1e-5)
+    elif pro == 4:
+        act = ops.silu_mul(x, g)
+    else:
+        act = x
+    want = ops.add(ops.mul_mat(w, act), r).numpy()
+    out = T(gpu.F32, [N, 1])
+    cw = w.c()
+    gpu.lib.check(gpu.lib.get().cllm_op_mul_mat_vec_fused(None, C.byref(cw), pro, x.data_ptr(), g.data_ptr() if pro != 2 else None, 1e-5,
+                                                           r.data_ptr(), out.data_ptr()), "fused")
+    assert np.array_equal(out.numpy(), want)
