@@ -200,16 +200,18 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", 0))
     if world != args.gpus:
         log(f"warning: WORLD_SIZE={world} but --gpus {args.gpus}; using WORLD_SIZE")
-    pkg = ge.load_package()
-    pkg.lib.require_gpu()
-    pkg.lib.check(pkg.lib.get().cllm_set_device(local), "set_device")
     dist = None
-    if world > 1:
+    tp_setup = world > 1 or os.environ.get("CLLM_BENCH_TP_SELFTEST") == "1"          # (self-test: walk the communicator set-up with one rank)
+    if tp_setup:
+        # torch FIRST: it bundles its own HIP runtime; initialised after libchatllm_hip.so has loaded /opt/rocm's, it finds "No HIP GPUs"
         import torch
         import torch.distributed as dist_mod
         dist = dist_mod
         torch.cuda.set_device(local)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    pkg = ge.load_package()
+    pkg.lib.require_gpu()
+    pkg.lib.check(pkg.lib.get().cllm_set_device(local), "set_device")
 
     wtype = WTYPES[args.wtype]
     max_len = (args.n_prompt + args.warmup + args.steps + 8 + 63) // 64 * 64
@@ -218,24 +220,37 @@ def main():
     if args.no_graph:
         m.use_graph(False)
 
-    if world > 1:
+    if tp_setup:
         import torch
         L = pkg.lib.get()
-        try:
-            # native path: RCCL communicator owned by the C library; the all-reduces are stream-ordered launches inside the decode graph
-            idbuf = torch.zeros(128, dtype=torch.uint8, device=f"cuda:{local}")
-            if rank == 0:
+        # native path: RCCL communicator owned by the C library; the all-reduces are stream-ordered launches inside the decode graph.
+        # Every decision below is taken by ALL ranks together (a rank that fell back alone would leave the others in a collective).
+        native = False
+        idbuf = torch.zeros(129, dtype=torch.uint8, device=f"cuda:{local}")          # 128 id bytes + "valid"
+        if rank == 0:
+            try:
                 raw = (C.c_char * 128)()
                 pkg.lib.check(L.cllm_tp_unique_id(raw), "tp_unique_id")
-                idbuf.copy_(torch.frombuffer(bytearray(raw.raw), dtype=torch.uint8))
-            dist.broadcast(idbuf, 0)
-            raw = (C.c_char * 128).from_buffer_copy(bytes(idbuf.cpu().numpy().tobytes()))
+                idbuf.copy_(torch.frombuffer(bytearray(raw.raw) + bytearray([1]), dtype=torch.uint8))
+            except Exception as e:                    # noqa: BLE001
+                log(f"[rank 0] cllm_tp_unique_id failed: {e}")
+        dist.broadcast(idbuf, 0)
+        host_id = bytes(idbuf.cpu().numpy().tobytes())
+        if host_id[128] == 1:
+            okflag = torch.ones(1, dtype=torch.int32, device=f"cuda:{local}")
             comm = C.c_void_p()
-            pkg.lib.check(L.cllm_tp_init(raw, rank, world, C.byref(comm)), "tp_init")
-            m.set_tp_comm(comm)
-            log(f"[rank {rank}] tensor parallel over RCCL (native communicator, all-reduce inside the decode graph)")
-        except Exception as e:                        # noqa: BLE001 -- fall back to torch.distributed through the host callback
-            log(f"[rank {rank}] native RCCL path unavailable ({e}); using the torch.distributed callback")
+            try:
+                pkg.lib.check(L.cllm_tp_init((C.c_char * 128).from_buffer_copy(host_id[:128]), rank, world, C.byref(comm)), "tp_init")
+            except Exception as e:                    # noqa: BLE001
+                log(f"[rank {rank}] cllm_tp_init failed: {e}")
+                okflag.zero_()
+            dist.all_reduce(okflag, op=dist.ReduceOp.MIN)
+            native = int(okflag.item()) == 1
+            if native:
+                m.set_tp_comm(comm)
+                log(f"[rank {rank}] tensor parallel over RCCL (native communicator, all-reduce inside the decode graph)")
+        if not native:
+            log(f"[rank {rank}] native RCCL path unavailable; using the torch.distributed callback")
 
             class _Arr:                       # wrap the raw device pointer for torch (zero copy)
                 def __init__(self, ptr, n):

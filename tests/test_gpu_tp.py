@@ -92,3 +92,22 @@ def test_rccl_all_reduce_inside_the_decode_graph_matches_the_host_callback(gpu, 
     lc2 = c.forward([int(ids_c[-1])])
     assert np.array_equal(la2, lc2)
     a.close(); b.close(); c.close()
+
+
+def test_bench_tp_setup_under_torchrun_with_one_rank(gpu):
+    """bench.py's multi-GPU set-up (torch first, id broadcast, collective success flag, communicator bound to the runner) walked with
+    ONE rank under the driver's launcher -- the only part of the N > 1 path a single-GPU box can execute"""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, CLLM_BENCH_TP_SELFTEST="1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1", "--master-port", "29533",
+                        os.path.join(root, "bench.py"), "--gpus", "1", "--model", "small", "--steps", "8", "--warmup", "2", "--no-cpu-baseline"],
+                       capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert "tensor parallel over RCCL" in r.stderr
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    res = json.loads(line)
+    assert res["n_gpus"] == 1 and res["value"] > 0 and res["metric"] == "decode tokens/s"
