@@ -102,6 +102,14 @@ extern "C" int cllm_memcpy_d2h(void * dst, const void * src, size_t size, void *
     if (size) { HIP_TRY(hipMemcpyAsync(dst, src, size, hipMemcpyDeviceToHost, (hipStream_t) stream)); HIP_TRY(hipStreamSynchronize((hipStream_t) stream)); }
     return CLLM_OK;
 }
+// page-locked host memory: the staging area of a host binding's get_tensor (a D2H copy into pageable memory is several times slower)
+extern "C" int cllm_host_malloc(void ** ptr, size_t size) {
+    if (!ptr) FAIL(CLLM_E_INVALID, "host_malloc: null");
+    *ptr = nullptr;
+    if (hipHostMalloc(ptr, size ? size : 1, hipHostMallocDefault) != hipSuccess) { (void) hipGetLastError(); FAIL(CLLM_E_ALLOC, "host_malloc: %zu bytes", size); }
+    return CLLM_OK;
+}
+extern "C" int cllm_host_free(void * ptr) { if (ptr) HIP_TRY(hipHostFree(ptr)); return CLLM_OK; }
 extern "C" int cllm_memcpy_d2d(void * dst, const void * src, size_t size, void * stream) {
     if (size) HIP_TRY(hipMemcpyAsync(dst, src, size, hipMemcpyDeviceToDevice, (hipStream_t) stream));
     return CLLM_OK;
@@ -245,12 +253,31 @@ extern "C" int cllm_bench_mul_mat_kernel(void * stream, const cllm_tensor * src0
 //   pro 2: dst = W . quantize(px)                             MUL_MAT
 //   pro 4: dst = W . quantize(silu(px) * pw)                  UNARY(SILU) -> MUL -> MUL_MAT
 //   + resid (may be NULL): dst += resid                       ... -> ADD        (dst may alias resid, not px / pw)
-extern "C" int cllm_op_mul_mat_vec_fused(void * stream, const cllm_tensor * src0, int pro, const float * px, const float * pw, float eps,
+extern "C" int cllm_op_mul_mat_vec_fused(void * stream, const cllm_tensor * src0, int pro, const float * px, const float * pw, float eps, int epi,
                                          const float * resid, float * dst) {
-    if (!src0 || !px || !dst || (pro != 1 && pro != 2 && pro != 4) || ((pro == 1 || pro == 4) && !pw)) FAIL(CLLM_E_INVALID, "mul_mat_vec_fused: arguments");
+    if (!src0 || !px || !dst || (pro != 1 && pro != 2 && pro != 4) || ((pro == 1 || pro == 4) && !pw) || (epi != 0 && epi != 1)) FAIL(CLLM_E_INVALID, "mul_mat_vec_fused: arguments");
     if (!is_quant(src0->type) || src0->ne[2] != 1 || src0->ne[3] != 1 || src0->nb[1] != cllm_row_size(src0->type, src0->ne[0])) FAIL(CLLM_E_UNSUPPORTED, "mul_mat_vec_fused: src0 must be a dense 2-D quantized matrix");
     if (((uintptr_t) px | (uintptr_t) pw | (uintptr_t) src0->data) & 15) FAIL(CLLM_E_UNSUPPORTED, "mul_mat_vec_fused: alignment");
-    return launch_gemv_decode((hipStream_t) stream, src0->type, src0->data, src0->ne[0], src0->ne[1], pro, px, pw, eps, 0, dst, nullptr, resid);
+    return launch_gemv_decode((hipStream_t) stream, src0->type, src0->data, src0->ne[0], src0->ne[1], pro, px, pw, eps, epi, dst, nullptr, resid);
+}
+
+// device-side repack of weight rows for the merged launches: concatenation of n matrices, or the rows of two equally sized ones alternating
+extern "C" int cllm_pack_rows(void * stream, void * dst, const void * const * srcs, const int64_t * nrows, int n, size_t row_bytes, int interleave) {
+    if (!dst || !srcs || !nrows || n <= 0 || !row_bytes || (interleave && (n != 2 || nrows[0] != nrows[1]))) FAIL(CLLM_E_INVALID, "pack_rows: arguments");
+    hipStream_t st = (hipStream_t) stream;
+    if (interleave) {
+        for (int i = 0; i < 2; i++)
+            HIP_TRY(hipMemcpy2DAsync((char *) dst + i * row_bytes, 2 * row_bytes, srcs[i], row_bytes, row_bytes, (size_t) nrows[i], hipMemcpyDeviceToDevice, st));
+        return CLLM_OK;
+    }
+    size_t off = 0;
+    for (int i = 0; i < n; i++) {
+        if (!srcs[i] || nrows[i] < 0) FAIL(CLLM_E_INVALID, "pack_rows: source %d", i);
+        const size_t b = (size_t) nrows[i] * row_bytes;
+        if (b) HIP_TRY(hipMemcpyAsync((char *) dst + off, srcs[i], b, hipMemcpyDeviceToDevice, st));
+        off += b;
+    }
+    return CLLM_OK;
 }
 
 // times `iters` MUL_MAT_ID launches (quantize of b included, as the op does it), cycling the ids through ids_list[0..n_ids)

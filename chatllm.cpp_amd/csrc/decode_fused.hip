@@ -530,6 +530,39 @@ extern "C" int cllm_op_attn_decode(void * stream, const float * q, const int32_t
     return launch_attn_decode((hipStream_t) stream, q, pos_dev, n_head, n_kv_head, head_dim, (const uint16_t *) k_cache, (const uint16_t *) v_cache, max_len, out);
 }
 
+// The whole single-token attention block between the q/k/v projections and o_proj as ONE call (1 launch up to the long-context
+// threshold, 3 above it): ROPE(q), ROPE(k) + SET_ROWS(k_cache), CPY(v -> v_cache column), MUL_MAT(K,Q), SCALE, DIAG_MASK_INF,
+// SOFT_MAX, MUL_MAT(V,P), PERMUTE + CONT.  qkv: the UN-rotated projections [n_head*hd | n_kv_head*hd | n_kv_head*hd] F32.
+extern "C" int cllm_op_rope_table(void * stream, const int32_t * pos_dev, int head_dim, float freq_base, float * cs) {
+    if (!pos_dev || !cs || head_dim <= 0 || head_dim % 2) FAIL(CLLM_E_INVALID, "rope_table: arguments");
+    return launch_rope_table((hipStream_t) stream, pos_dev, head_dim, freq_base, cs);
+}
+extern "C" int cllm_attn_decode_supported(int n_head, int n_kv_head, int head_dim, int64_t max_len) {       // the shapes attn_launch() takes
+    if (n_head <= 0 || n_kv_head <= 0 || head_dim <= 0 || max_len <= 0) return 0;
+    if (head_dim % 8 || max_len % 8 || n_head % n_kv_head) return 0;
+    return (size_t)(3 * head_dim + (max_len > head_dim ? max_len : head_dim)) * 4 <= 150 * 1024;
+}
+extern "C" size_t cllm_attn_decode_wsize(int64_t n_kv, int n_head, int64_t max_len) {
+    return n_kv > attn_long_threshold() ? (size_t) n_head * (size_t) max_len * 6 : 0;
+}
+extern "C" int cllm_op_rope_kv_attn_decode(void * stream, const float * qkv, const int32_t * pos_dev, const float * rope_cs, float freq_base, int64_t n_kv,
+                                           int n_head, int n_kv_head, int head_dim, int rope_mode, void * k_cache, void * v_cache, int64_t max_len,
+                                           float * out, void * wdata, size_t wsize) {
+    if (!qkv || !pos_dev || !k_cache || !v_cache || !out || n_head <= 0 || n_kv_head <= 0 || head_dim <= 0 || n_kv <= 0 || n_kv > max_len)
+        FAIL(CLLM_E_INVALID, "rope_kv_attn_decode: arguments");
+    if (rope_mode != 0 && rope_mode != 2) FAIL(CLLM_E_UNSUPPORTED, "rope_kv_attn_decode: rope mode %d", rope_mode);
+    hipStream_t st = (hipStream_t) stream;
+    int rc = CLLM_E_UNSUPPORTED;
+    const size_t need = cllm_attn_decode_wsize(n_kv, n_head, max_len);
+    if (rope_cs && need && wdata && wsize >= need)
+        rc = launch_attn_long(st, qkv, pos_dev, rope_cs, n_head, n_kv_head, head_dim, rope_mode, (uint16_t *) k_cache, (uint16_t *) v_cache, max_len, (float *) wdata, out);
+    if (rc == CLLM_E_UNSUPPORTED && rope_cs)
+        rc = launch_attn_dec_table(st, qkv, pos_dev, rope_cs, n_head, n_kv_head, head_dim, rope_mode, (uint16_t *) k_cache, (uint16_t *) v_cache, max_len, out);
+    if (rc == CLLM_E_UNSUPPORTED)
+        rc = launch_rope_kv_attn_decode(st, qkv, pos_dev, n_head, n_kv_head, head_dim, rope_mode, freq_base, (uint16_t *) k_cache, (uint16_t *) v_cache, max_len, out);
+    return rc;
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // embedding gather for the token held in device memory is cllm_op_get_rows; greedy sampling + advance:
 // ---------------------------------------------------------------------------------------------------------------

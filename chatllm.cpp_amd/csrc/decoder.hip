@@ -408,7 +408,7 @@ extern "C" int cllm_llama_forward(cllm_llama * m, const int32_t * tokens, int ql
 static int kind_of(int wtype) { return wtype == CLLM_TYPE_Q4_K ? 256 : 32; }
 
 // cached positions above which the split attention (three launches, every CU) beats the one-launch kernel (one CU per head)
-static int attn_long_threshold() { static const int v = getenv("CLLM_ATTN_LONG") ? atoi(getenv("CLLM_ATTN_LONG")) : 512; return v < 512 ? 512 : v; }   // (V.P there assumes the 64-lane regime: >= 512)
+int attn_long_threshold() { static const int v = getenv("CLLM_ATTN_LONG") ? atoi(getenv("CLLM_ATTN_LONG")) : 512; return v < 512 ? 512 : v; }   // (V.P there assumes the 64-lane regime: >= 512)
 
 static int decode_step_fused(cllm_llama * m, bool sample, bool long_ctx) {
     const cllm_llama_config & c = m->cfg;

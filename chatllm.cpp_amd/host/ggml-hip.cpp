@@ -14,9 +14,12 @@
 
 #include "../../include/chatllm_hip.h"
 
+#include <chrono>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -26,8 +29,24 @@
 namespace {
 
 struct hip_device_ctx { int id; std::string name, desc; ggml_backend_buffer_type buft; };
-struct hip_backend_ctx { int device; void * stream = nullptr; void * wdata = nullptr; size_t wsize = 0; };
-struct hip_buffer_ctx { int device; void * base; };
+struct hip_backend_ctx { int device; void * stream = nullptr; void * wdata = nullptr; size_t wsize = 0; void * abuf = nullptr; size_t asize = 0; };
+struct hip_buffer_ctx { int device; void * base; uint64_t uid; uint64_t gen = 0; };     // gen: bumped by every write through the buffer interface
+uint64_t g_next_buffer_uid = 1;
+
+// CLLM_HIP_STATS=1: where a token's wall time goes, seen from the module (host = everything between our entry points: the reference's
+// graph build, scheduler split and allocation, sampling)
+struct wall_stats {
+    using clk = std::chrono::steady_clock;
+    clk::time_point last_exit = clk::now();
+    double host_us = 0, plan_us = 0, issue_us = 0, sync_us = 0, set_us = 0, get_us = 0; long graphs = 0, calls = 0, sets = 0, gets = 0;
+    static double us(clk::time_point a, clk::time_point b) { return std::chrono::duration<double, std::micro>(b - a).count(); }
+} g_ws;
+const bool g_stats = getenv("CLLM_HIP_STATS") != nullptr;
+struct ws_scope {        // time inside one of our entry points goes to `slot`, the time since the previous one to host_us
+    double & slot; wall_stats::clk::time_point t0;
+    explicit ws_scope(double & s) : slot(s), t0(wall_stats::clk::now()) { if (g_stats) g_ws.host_us += wall_stats::us(g_ws.last_exit, t0); }
+    ~ws_scope() { if (g_stats) { const auto t1 = wall_stats::clk::now(); slot += wall_stats::us(t0, t1); g_ws.last_exit = t1; } }
+};
 
 std::vector<hip_device_ctx *> g_devices;
 ggml_backend_reg g_reg;
@@ -46,24 +65,72 @@ bool f32_dense(const ggml_tensor * t) { return t && t->type == GGML_TYPE_F32 && 
 // ---------------------------------------------------------------------------------------------------------------------------
 // buffer
 // ---------------------------------------------------------------------------------------------------------------------------
-void buf_free(ggml_backend_buffer_t b) { auto * c = (hip_buffer_ctx *) b->context; cllm_set_device(c->device); cllm_free(c->base); delete c; }
+// Small set_tensor calls (chatllm writes the position vector of EVERY layer and the token id before each graph: 33 four-byte writes
+// per token for Llama-3-8B, 14 us each as a synchronous copy) go through a page-locked ring: the caller's bytes are consumed when
+// buf_set returns, the H2D copies are queued on the device's null stream and waited for ONCE, by whoever touches device memory next
+// (graph_compute, get_tensor, cpy_tensor, synchronize, free_buffer).
+constexpr size_t k_ring_bytes = 256u << 10, k_ring_max = 4096;
+struct set_ring { char * base = nullptr; size_t head = 0; bool failed = false; bool pending[64] = {}; std::mutex m; } g_ring;
+void flush_sets() {
+    std::lock_guard<std::mutex> lock(g_ring.m);
+    for (int d = 0; d < 64; d++) if (g_ring.pending[d]) { cllm_set_device(d); cllm_stream_sync(nullptr); g_ring.pending[d] = false; }
+}
+bool ring_set(int device, void * dst, const void * data, size_t size) {      // device already current
+    std::lock_guard<std::mutex> lock(g_ring.m);
+    if (!g_ring.base && !g_ring.failed) { void * p = nullptr; if (cllm_host_malloc(&p, k_ring_bytes) == CLLM_OK) g_ring.base = (char *) p; else g_ring.failed = true; }
+    if (!g_ring.base || device < 0 || device >= 64) return false;
+    const size_t slot = (size + 63) & ~(size_t) 63;
+    if (g_ring.head + slot > k_ring_bytes) {            // wrap: every queued copy must have read its slot
+        for (int d = 0; d < 64; d++) if (g_ring.pending[d]) { cllm_set_device(d); cllm_stream_sync(nullptr); g_ring.pending[d] = false; }
+        cllm_set_device(device);
+        g_ring.head = 0;
+    }
+    memcpy(g_ring.base + g_ring.head, data, size);
+    if (cllm_memcpy_h2d(dst, g_ring.base + g_ring.head, size, nullptr) != CLLM_OK) return false;
+    g_ring.head += slot; g_ring.pending[device] = true;
+    return true;
+}
+
+void packs_forget(uint64_t uid);
+void buf_free(ggml_backend_buffer_t b) { flush_sets(); auto * c = (hip_buffer_ctx *) b->context; cllm_set_device(c->device); packs_forget(c->uid); cllm_free(c->base); delete c; }
 void * buf_base(ggml_backend_buffer_t b) { return ((hip_buffer_ctx *) b->context)->base; }
 void buf_memset(ggml_backend_buffer_t b, ggml_tensor * t, uint8_t v, size_t off, size_t size) {
-    cllm_set_device(((hip_buffer_ctx *) b->context)->device);
+    cllm_set_device(((hip_buffer_ctx *) b->context)->device); ((hip_buffer_ctx *) b->context)->gen++;
     cllm_memset((char *) t->data + off, v, size, nullptr); cllm_stream_sync(nullptr);
 }
 void buf_set(ggml_backend_buffer_t b, ggml_tensor * t, const void * data, size_t off, size_t size) {
+    ws_scope ws(g_ws.set_us); g_ws.sets++;
     // called with 1,024,000-byte slices at arbitrary offsets while a model loads (src/chat.cpp:1322-1338): layout stays native
-    cllm_set_device(((hip_buffer_ctx *) b->context)->device);
+    auto * c = (hip_buffer_ctx *) b->context;
+    cllm_set_device(c->device); c->gen++;
+    if (size <= k_ring_max && ring_set(c->device, (char *) t->data + off, data, size)) return;
     cllm_memcpy_h2d((char *) t->data + off, data, size, nullptr); cllm_stream_sync(nullptr);
 }
+// get_tensor (the logits of every token: 513 KB for Llama-3): through a page-locked staging area -- the D2H copy into the host's pageable
+// destination is several times slower than DMA into pinned memory + a memcpy
+void * g_stage = nullptr; size_t g_stage_size = 0;
+constexpr size_t k_stage_chunk = 4u << 20;
 void buf_get(ggml_backend_buffer_t b, const ggml_tensor * t, void * data, size_t off, size_t size) {
+    ws_scope ws(g_ws.get_us); g_ws.gets++;
+    flush_sets();
     cllm_set_device(((hip_buffer_ctx *) b->context)->device);
-    cllm_memcpy_d2h(data, (const char *) t->data + off, size, nullptr);
+    const size_t want = size < k_stage_chunk ? size : k_stage_chunk;
+    if (size >= 4096 && g_stage_size < want) {
+        if (g_stage) cllm_host_free(g_stage);
+        g_stage = nullptr; g_stage_size = 0;
+        if (cllm_host_malloc(&g_stage, k_stage_chunk) == CLLM_OK) g_stage_size = k_stage_chunk;
+    }
+    if (size < 4096 || !g_stage) { cllm_memcpy_d2h(data, (const char *) t->data + off, size, nullptr); return; }
+    for (size_t done = 0; done < size; done += g_stage_size) {
+        const size_t n = size - done < g_stage_size ? size - done : g_stage_size;
+        cllm_memcpy_d2h(g_stage, (const char *) t->data + off + done, n, nullptr);     // synchronous
+        memcpy((char *) data + done, g_stage, n);
+    }
 }
 bool buf_cpy(ggml_backend_buffer_t b, const ggml_tensor * src, ggml_tensor * dst) {
     if (!ggml_is_contiguous(src) || !ggml_is_contiguous(dst) || ggml_nbytes(src) != ggml_nbytes(dst)) return false;
-    cllm_set_device(((hip_buffer_ctx *) b->context)->device);
+    flush_sets();
+    cllm_set_device(((hip_buffer_ctx *) b->context)->device); ((hip_buffer_ctx *) b->context)->gen++;
     if (ggml_backend_buffer_is_host(src->buffer)) { cllm_memcpy_h2d(dst->data, src->data, ggml_nbytes(src), nullptr); cllm_stream_sync(nullptr); return true; }
     if (src->buffer && src->buffer->iface.get_base == buf_base) {     // another buffer of this module (any device: peer access through hipMemcpy)
         cllm_memcpy_d2d(dst->data, src->data, ggml_nbytes(src), nullptr); cllm_stream_sync(nullptr); return true;
@@ -71,10 +138,64 @@ bool buf_cpy(ggml_backend_buffer_t b, const ggml_tensor * src, ggml_tensor * dst
     return false;
 }
 void buf_clear(ggml_backend_buffer_t b, uint8_t v) {
-    auto * c = (hip_buffer_ctx *) b->context; cllm_set_device(c->device);
+    auto * c = (hip_buffer_ctx *) b->context; cllm_set_device(c->device); c->gen++;
     cllm_memset(c->base, v, b->size, nullptr); cllm_stream_sync(nullptr);
 }
 const ggml_backend_buffer_i k_buffer_i = { buf_free, buf_base, nullptr, buf_memset, buf_set, buf_get, buf_cpy, buf_clear, nullptr };
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// packed weights: mat-vecs that read the same activation become ONE launch over a row-repacked copy of their weight matrices
+//   q | k | v concatenated (the three projections of an attention block), gate / up with alternating rows (SiLU(gate)*up in the epilogue).
+// The copy is made on the device the first time the pattern is seen (cllm_pack_rows) and stays valid as long as none of the source
+// buffers is written through the buffer interface (generation counters) or freed.  It costs HBM -- the originals belong to the host and
+// stay -- so the total is capped: CLLM_HIP_PACK_GB (default: a quarter of the device), and a tenth of the device must stay free.
+// CLLM_HIP_PACK=0 turns it off.
+// ---------------------------------------------------------------------------------------------------------------------------
+struct pack_entry { void * data = nullptr; size_t bytes = 0; int n = 0; int device = 0; const void * src[3] = {}; uint64_t uid[3] = {}, gen[3] = {}; bool refused = false; };
+std::unordered_map<const void *, pack_entry> g_packs;          // keyed by the first source's data pointer
+size_t g_pack_bytes = 0;
+std::mutex g_pack_mutex;                                        // (accessory models own their own contexts and may run on other threads)
+void packs_forget(uint64_t uid) {
+    std::lock_guard<std::mutex> lock(g_pack_mutex);
+    for (auto it = g_packs.begin(); it != g_packs.end();) {
+        bool hit = false;
+        for (int i = 0; i < it->second.n; i++) hit = hit || it->second.uid[i] == uid;
+        if (hit) { if (it->second.data) { cllm_free(it->second.data); g_pack_bytes -= it->second.bytes; } it = g_packs.erase(it); } else ++it;
+    }
+}
+bool ours(const ggml_tensor * t) { return t && t->buffer && t->buffer->iface.free_buffer == buf_free && !t->view_src; }
+// the packed copy of n (2 or 3) same-type, same-row-length weight matrices, or nullptr (not ours / over budget / allocation failed)
+void * get_pack(int device, void * stream, const ggml_tensor * const * w, int n, bool interleave) {
+    static const bool off = getenv("CLLM_HIP_PACK") && atoi(getenv("CLLM_HIP_PACK")) == 0;
+    if (off) return nullptr;
+    for (int i = 0; i < n; i++) if (!ours(w[i]) || ((const hip_buffer_ctx *) w[i]->buffer->context)->device != device) return nullptr;
+    std::lock_guard<std::mutex> lock(g_pack_mutex);
+    pack_entry & e = g_packs[w[0]->data];
+    bool valid = e.n == n && e.device == device;
+    for (int i = 0; i < n && valid; i++) {
+        const auto * bc = (const hip_buffer_ctx *) w[i]->buffer->context;
+        valid = e.src[i] == w[i]->data && e.uid[i] == bc->uid && e.gen[i] == bc->gen;
+    }
+    if (valid) return e.refused ? nullptr : e.data;
+    if (e.data) { cllm_stream_sync(stream); cllm_free(e.data); g_pack_bytes -= e.bytes; }
+    e = pack_entry(); e.n = n; e.device = device; e.refused = true;
+    size_t bytes = 0; int64_t rows[3]; const void * srcs[3];
+    for (int i = 0; i < n; i++) {
+        const auto * bc = (const hip_buffer_ctx *) w[i]->buffer->context;
+        e.src[i] = w[i]->data; e.uid[i] = bc->uid; e.gen[i] = bc->gen;
+        rows[i] = w[i]->ne[1]; srcs[i] = w[i]->data; bytes += (size_t) w[i]->ne[1] * w[i]->nb[1];
+    }
+    size_t mfree = 0, mtotal = 0;
+    cllm_device_info(device, nullptr, 0, &mfree, &mtotal, nullptr);
+    static const double cap_gb = getenv("CLLM_HIP_PACK_GB") ? atof(getenv("CLLM_HIP_PACK_GB")) : -1.0;
+    const size_t cap = cap_gb >= 0 ? (size_t)(cap_gb * 1e9) : mtotal / 4;
+    if (g_pack_bytes + bytes > cap || mfree < bytes + mtotal / 10) return nullptr;
+    void * p = nullptr;
+    if (cllm_malloc(&p, bytes) != CLLM_OK) return nullptr;
+    if (cllm_pack_rows(stream, p, srcs, rows, n, w[0]->nb[1], interleave ? 1 : 0) != CLLM_OK || cllm_stream_sync(stream) != CLLM_OK) { cllm_free(p); return nullptr; }
+    e.data = p; e.bytes = bytes; e.refused = false; g_pack_bytes += bytes;
+    return p;
+}
 
 // ---------------------------------------------------------------------------------------------------------------------------
 // buffer type
@@ -85,7 +206,7 @@ ggml_backend_buffer_t buft_alloc(ggml_backend_buffer_type_t t, size_t size) {
     cllm_set_device(d->id);
     void * p = nullptr;
     if (cllm_malloc(&p, size ? size : 1) != CLLM_OK) { HIPB_LOG("alloc of %zu bytes failed: %s", size, cllm_last_error()); return nullptr; }
-    return ggml_backend_buffer_init(t, k_buffer_i, new hip_buffer_ctx{ d->id, p }, size);
+    return ggml_backend_buffer_init(t, k_buffer_i, new hip_buffer_ctx{ d->id, p, g_next_buffer_uid++ }, size);
 }
 size_t buft_align(ggml_backend_buffer_type_t) { return 256; }
 bool buft_is_host(ggml_backend_buffer_type_t) { return false; }
@@ -136,10 +257,15 @@ void be_free(ggml_backend_t b) {
     auto * c = (hip_backend_ctx *) b->context;
     cllm_set_device(c->device); cllm_stream_sync(c->stream);
     if (c->wdata) cllm_free(c->wdata);
+    if (c->abuf) cllm_free(c->abuf);
     cllm_stream_destroy(c->stream);
     delete c; delete b;
 }
-void be_sync(ggml_backend_t b) { auto * c = (hip_backend_ctx *) b->context; cllm_set_device(c->device); cllm_stream_sync(c->stream); cllm_stream_sync(nullptr); }
+void be_sync(ggml_backend_t b) {
+    ws_scope ws(g_ws.sync_us);
+    flush_sets();
+    auto * c = (hip_backend_ctx *) b->context; cllm_set_device(c->device); cllm_stream_sync(c->stream); cllm_stream_sync(nullptr);
+}
 
 int ensure_wdata(hip_backend_ctx * c, size_t need) {
     if (need <= c->wsize) return CLLM_OK;
@@ -152,6 +278,17 @@ int ensure_wdata(hip_backend_ctx * c, size_t need) {
     return CLLM_OK;
 }
 
+int ensure_abuf(hip_backend_ctx * c, size_t need) {      // fused attention: cos/sin table | q,k,v projections | long-context scores
+    if (need <= c->asize) return CLLM_OK;
+    cllm_stream_sync(c->stream);
+    if (c->abuf) cllm_free(c->abuf);
+    c->abuf = nullptr; c->asize = 0;
+    const size_t sz = need + need / 4 + 4096;
+    if (int rc = cllm_malloc(&c->abuf, sz)) return rc;
+    c->asize = sz;
+    return CLLM_OK;
+}
+
 // ---- node-pattern fusion (decode graphs: a token is ~25 launches per layer node by node, ~5 us each) -------------------------------
 // A pattern is fused only if every intermediate it swallows is used by nobody else: the graph-wide use count
 // (ggml_node_get_use_count, shared by scheduler splits) must equal the uses found in THIS graph, and the tensor must not be a
@@ -160,32 +297,192 @@ int ensure_wdata(hip_backend_ctx * c, size_t need) {
 //   UNARY(SILU) -> MUL(up) -> MUL_MAT             SiLU*up + quantize in the mat-vec's prologue (pro 4)
 //   MUL_MAT -> ADD(residual | bias)               epilogue
 //   SCALE -> DIAG_MASK_INF -> SOFT_MAX            cllm_op_scale_mask_soft_max
-struct fused_mv { int pro = 2; const float * px = nullptr; const float * pw = nullptr; float eps = 0.0f; const float * resid = nullptr; float * dst = nullptr; };
+//   {MUL_MAT q, k, v} of a fused attention block      one launch over the packed q|k|v weights (get_pack)
+//   {MUL_MAT gate, up} -> SILU -> MUL -> MUL_MAT       one launch over the row-interleaved gate/up weights with the SiLU*up epilogue; the
+//                                                      consumer mat-vec then only quantizes (pro 2)
+struct fused_mv {
+    int pro = 2; const float * px = nullptr; const float * pw = nullptr; float eps = 0.0f; const float * resid = nullptr; float * dst = nullptr;
+    int node = -1;                      // the MUL_MAT node
+    int ga = -1, gb = -1;               // pro 4: the nodes producing px (gate) and pw (up)
+    int group = -1;                     // member of a merged launch (fuse_plan::groups)
+};
+struct merge_group {
+    int n = 0, member[3] = { -1, -1, -1 };      // entries of mvs, in packed row order
+    bool interleave = false;                     // gate/up: SiLU*up epilogue, output = half the rows
+    int consumer = -1;                           // gate/up: the entry of mvs (pro 4) that reads the activation
+    int state = 0;                               // at run time: 0 not reached, 1 launched merged, 2 members launch separately
+};
+//   ROPE(q) ROPE(k) SET_ROWS(k) CPY(v) MUL_MAT(K,Q) SCALE DIAG_MASK_INF SOFT_MAX MUL_MAT(V,P) PERMUTE CONT
+//                                                 the single-token attention block of KVCacheAttention (src/layers.cpp:3044-3123,
+//                                                 2499-2561) as cllm_op_rope_kv_attn_decode (level 2: the q/k/v mat-vecs write into
+//                                                 module scratch) or, with a RoPE flavour that call does not take (YaRN, frequency
+//                                                 factors, partial rotation), the last seven as cllm_op_attn_decode (level 1)
+struct fused_attn {
+    int level = 0;
+    int wq = -1, wk = -1, wv = -1;      // level 2: entries of mvs producing the un-rotated q / k / v
+    const float * q = nullptr;          // level 1: the rotated q
+    const int32_t * pos = nullptr;      // I32 [1] on the device: the position == cached length - 1
+    int nh = 0, nkv = 0, hd = 0, mode = 0;
+    float freq_base = 0.0f;
+    int64_t n_kv = 0, ML = 0;
+    void * k_cache = nullptr, * v_cache = nullptr;
+    float * out = nullptr;
+};
 struct fuse_plan {
     std::vector<uint8_t> skip;          // node is produced inside a fused launch (or not needed at all)
     std::vector<int>     mv;            // index into mvs for MUL_MAT nodes launched fused, else -1
     std::vector<fused_mv> mvs;
     std::vector<int>     sm_src;        // SOFT_MAX nodes: node index of the SCALE feeding the fused scale+mask+soft_max, else -1
+    std::vector<int>     attn;          // CONT nodes: index into attns of the fused attention launched in their place, else -1
+    std::vector<fused_attn> attns;
+    std::vector<merge_group> groups;
 };
 
 bool f32_vec(const ggml_tensor * t) { return t && t->type == GGML_TYPE_F32 && t->nb[0] == 4 && t->ne[1] == 1 && t->ne[2] == 1 && t->ne[3] == 1 && ((uintptr_t) t->data & 15) == 0; }
 bool overlap(const void * a, size_t na, const void * b, size_t nb) { return (const char *) a < (const char *) b + nb && (const char *) b < (const char *) a + na; }
 
+// planning runs once per graph_compute, before the first launch: flat, allocation-free containers (reused between calls)
+struct int_span {
+    const int * b, * e;
+    const int * begin() const { return b; }
+    const int * end() const { return e; }
+    int operator[](size_t k) const { return b[k]; }
+};
+struct user_lists {                 // the consumers of every node, in node order (CSR)
+    std::vector<int> start, list;
+    int_span operator[](int i) const { return { list.data() + start[i], list.data() + start[i + 1] }; }
+};
+struct node_index {                 // ggml_tensor * -> position in the graph (open addressing)
+    std::vector<const ggml_tensor *> key; std::vector<int> val; size_t mask = 0;
+    static size_t h(const void * p) { return (size_t)(((uintptr_t) p >> 4) * 0x9E3779B97F4A7C15ull >> 24); }
+    void build(ggml_cgraph * g, int n) {
+        size_t cap = 64; while (cap < (size_t) n * 2) cap <<= 1;
+        key.assign(cap, nullptr); val.resize(cap); mask = cap - 1;
+        for (int i = 0; i < n; i++) { const ggml_tensor * t = ggml_graph_node(g, i); size_t s = h(t) & mask; while (key[s]) s = (s + 1) & mask; key[s] = t; val[s] = i; }
+    }
+    int operator()(const ggml_tensor * t) const { for (size_t s = h(t) & mask;; s = (s + 1) & mask) { if (key[s] == t) return val[s]; if (!key[s]) return -1; } }
+};
+
+void plan_attention(ggml_cgraph * g, fuse_plan & P, const std::vector<int> & local, const std::vector<int> & writer,
+                    const user_lists & users, const node_index & find) {
+    static const int max_level = getenv("CLLM_HIP_FUSE_ATTN") ? atoi(getenv("CLLM_HIP_FUSE_ATTN")) : 2;
+    if (max_level <= 0) return;
+    const int n = ggml_graph_n_nodes(g);
+    auto node = [&](int i) { return ggml_graph_node(g, i); };
+    auto only_local = [&](int i, int uses) {
+        return i >= 0 && !(node(i)->flags & GGML_TENSOR_FLAG_OUTPUT) && local[i] == uses && ggml_node_get_use_count(g, i) == uses;
+    };
+    // x -> RESHAPE* -> ROPE -> RESHAPE* -> end : returns the ROPE and the node under it; every node of the chain is collected
+    auto through_reshapes = [&](const ggml_tensor * t, std::vector<int> & chain) {
+        while (t && t->op == GGML_OP_RESHAPE) { chain.push_back(find(t)); t = t->src[0]; }
+        return t;
+    };
+    for (int i = 0; i < n; i++) {
+        if (P.sm_src[i] < 0) continue;
+        const ggml_tensor * sm = node(i), * scn = node(P.sm_src[i]);
+        const ggml_tensor * kq = scn->src[0];
+        const int ikq = find(kq);
+        if (ikq < 0 || kq->op != GGML_OP_MUL_MAT || !only_local(ikq, 1) || !only_local(i, 1)) continue;
+        const ggml_tensor * kp = kq->src[0], * qp = kq->src[1];
+        if (kp->type != GGML_TYPE_F16 || qp->type != GGML_TYPE_F32 || qp->op != GGML_OP_PERMUTE) continue;
+        const int64_t hd = kp->ne[0], n_kv = kp->ne[1], nkv = kp->ne[2], nh = qp->ne[2];
+        if (kp->ne[3] != 1 || qp->ne[0] != hd || qp->ne[1] != 1 || qp->ne[3] != 1 || nkv <= 0 || nh <= 0 || nh % nkv || n_kv < 1) continue;
+        const size_t KD = (size_t) hd * nkv;
+        if (kp->nb[0] != 2 || kp->nb[1] != KD * 2 || kp->nb[2] != (size_t) hd * 2 || qp->nb[0] != 4 || qp->nb[2] != (size_t) hd * 4) continue;
+        float scale; memcpy(&scale, scn->op_params, 4);
+        if (scale != 1.0f / sqrtf((float) hd) || sm->src[0]->op_params[0] != (int32_t)(n_kv - 1)) continue;
+        // ---- V.P -> PERMUTE -> CONT
+        const int ikqv = users[i][0];
+        const ggml_tensor * kqv = node(ikqv);
+        if (kqv->op != GGML_OP_MUL_MAT || kqv->src[1] != sm || !only_local(ikqv, 1)) continue;
+        const ggml_tensor * vv = kqv->src[0];
+        if (vv->type != GGML_TYPE_F16 || vv->ne[0] != n_kv || vv->ne[1] != hd || vv->ne[2] != nkv || vv->ne[3] != 1 || vv->nb[0] != 2 || vv->nb[1] % 2) continue;
+        const int64_t ML = (int64_t)(vv->nb[1] / 2);
+        if (ML < n_kv || vv->nb[2] != (size_t) hd * vv->nb[1] || !cllm_attn_decode_supported((int) nh, (int) nkv, (int) hd, ML)) continue;
+        const int iperm = users[ikqv][0];
+        const ggml_tensor * perm = node(iperm);
+        if (perm->op != GGML_OP_PERMUTE || perm->src[0] != kqv || !only_local(iperm, 1) || perm->ne[0] != hd || perm->ne[1] != nh || perm->ne[2] != 1) continue;
+        const int icont = users[iperm][0];
+        const ggml_tensor * cont = node(icont);
+        if (cont->op != GGML_OP_CONT || cont->src[0] != perm || !f32_dense(cont) || !ggml_is_contiguous(cont) || ((uintptr_t) cont->data & 15)) continue;
+        // ---- q: PERMUTE(ROPE(RESHAPE*(q vector), pos))
+        const ggml_tensor * qrope = qp->src[0];
+        const int iqp = find(qp), iqrope = find(qrope);
+        if (qrope->op != GGML_OP_ROPE || iqp < 0 || iqrope < 0 || !only_local(iqp, 1) || !only_local(iqrope, 1)) continue;
+        const ggml_tensor * pos = qrope->src[1];
+        if (!pos || pos->type != GGML_TYPE_I32 || ggml_nelements(pos) != 1 || !pos->data) continue;
+        // ---- the cache writes of this step: SET_ROWS(k_cache, RESHAPE*(ROPE(RESHAPE*(k vector), pos)), pos) and CPY(TRANSPOSE(v vector) -> column n_kv - 1)
+        int iset = -1, icpy = -1;
+        const char * vcol = (const char *) vv->data + (size_t)(n_kv - 1) * 2;
+        for (int j = ikq - 1; j >= 0 && j >= ikq - 64 && (iset < 0 || icpy < 0); j--) {
+            const ggml_tensor * t = node(j);
+            if (iset < 0 && t->op == GGML_OP_SET_ROWS && t->data == kp->data) iset = j;
+            if (icpy < 0 && t->op == GGML_OP_CPY && t->src[1] && (const char *) t->src[1]->data == vcol) icpy = j;
+        }
+        if (iset < 0 || icpy < 0) continue;
+        const ggml_tensor * setr = node(iset), * cpy = node(icpy);
+        if (setr->type != GGML_TYPE_F16 || setr->ne[0] != (int64_t) KD || setr->nb[0] != 2 || setr->nb[1] != KD * 2 || !setr->src[1] || setr->src[1]->data != pos->data ||
+            setr->src[1]->type != GGML_TYPE_I32 || ggml_nelements(setr->src[1]) != 1) continue;
+        const ggml_tensor * vdst = cpy->src[1], * vT = cpy->src[0];
+        if (vdst->type != GGML_TYPE_F16 || vdst->ne[0] != 1 || vdst->ne[1] != (int64_t) KD || vdst->nb[1] != (size_t) ML * 2 || vT->type != GGML_TYPE_F32 ||
+            vT->op != GGML_OP_TRANSPOSE || vT->ne[0] != 1 || vT->ne[1] != (int64_t) KD || vT->nb[1] != 4) continue;
+        std::vector<int> kchain, qchain;
+        const ggml_tensor * krope = through_reshapes(setr->src[0], kchain);
+        if (!krope || krope->op != GGML_OP_ROPE || !krope->src[1] || krope->src[1]->data != pos->data || ggml_nelements(krope) != (int64_t) KD || krope->ne[0] != hd) continue;
+        if (memcmp(krope->op_params + 1, qrope->op_params + 1, 10 * sizeof(int32_t)) || krope->src[2] != qrope->src[2]) continue;
+        kchain.push_back(find(krope));
+        const ggml_tensor * ks = through_reshapes(krope->src[0], kchain);
+        const ggml_tensor * qs = through_reshapes(qrope->src[0], qchain);
+        const ggml_tensor * vs = vT->src[0];
+        const int iks = find(ks), iqs = find(qs), ivs = find(vs), ivT = find(vT);
+
+        fused_attn A;
+        A.pos = (const int32_t *) pos->data; A.nh = (int) nh; A.nkv = (int) nkv; A.hd = (int) hd; A.n_kv = n_kv; A.ML = ML;
+        A.k_cache = kp->data; A.v_cache = vv->data; A.out = (float *) cont->data;
+        A.mode = qrope->op_params[2]; memcpy(&A.freq_base, qrope->op_params + 5, 4);
+        float freq_scale, ext_factor, attn_factor;
+        memcpy(&freq_scale, qrope->op_params + 6, 4); memcpy(&ext_factor, qrope->op_params + 7, 4); memcpy(&attn_factor, qrope->op_params + 8, 4);
+        bool l2 = max_level >= 2 && (A.mode == 0 || A.mode == 2) && qrope->op_params[1] == hd && freq_scale == 1.0f && ext_factor == 0.0f && attn_factor == 1.0f &&
+                  !qrope->src[2] && hd % 4 == 0 && local[iset] == 0 && local[icpy] == 0 && only_local(ivT, 1);
+        l2 = l2 && iks >= 0 && iqs >= 0 && ivs >= 0 && only_local(iks, 1) && only_local(iqs, 1) && only_local(ivs, 1) &&
+             writer[iks] >= 0 && writer[iqs] >= 0 && writer[ivs] >= 0 && ggml_nelements(ks) == (int64_t) KD && ggml_nelements(vs) == (int64_t) KD && ggml_nelements(qs) == hd * nh;
+        for (int j : kchain) l2 = l2 && only_local(j, 1);
+        for (int j : qchain) l2 = l2 && only_local(j, 1);
+        if (l2) {
+            A.level = 2; A.wq = writer[iqs]; A.wk = writer[iks]; A.wv = writer[ivs];
+            for (int j : kchain) P.skip[j] = 1;
+            for (int j : qchain) P.skip[j] = 1;
+            P.skip[iqrope] = P.skip[iset] = P.skip[icpy] = 1;
+        } else {
+            A.level = 1; A.q = (const float *) qp->data;
+        }
+        P.skip[ikq] = P.skip[i] = P.skip[ikqv] = 1;         // (SCALE and DIAG_MASK_INF are already swallowed by the soft_max pattern)
+        P.attn[icont] = (int) P.attns.size(); P.attns.push_back(A);
+    }
+}
+
 fuse_plan make_plan(ggml_cgraph * g) {
     const int n = ggml_graph_n_nodes(g);
-    fuse_plan P; P.skip.assign(n, 0); P.mv.assign(n, -1); P.sm_src.assign(n, -1);
+    fuse_plan P; P.skip.assign(n, 0); P.mv.assign(n, -1); P.sm_src.assign(n, -1); P.attn.assign(n, -1);
     static const bool off = getenv("CLLM_HIP_NO_FUSE") != nullptr;
     if (off || n < 8) return P;
-    std::vector<int> local(n, 0);
-    std::vector<std::vector<int>> users(n);
-    {   // uses inside this graph (views count as uses of their source, exactly like ggml's use counts)
-        std::unordered_map<const ggml_tensor *, int> idx; idx.reserve((size_t) n * 2);
-        for (int i = 0; i < n; i++) idx[ggml_graph_node(g, i)] = i;
-        auto find = [&](const ggml_tensor * t) { auto it = idx.find(t); return it == idx.end() ? -1 : it->second; };
-        for (int j = 0; j < n; j++) {
-            const ggml_tensor * t = ggml_graph_node(g, j);
-            for (int k = 0; k < GGML_MAX_SRC; k++) if (t->src[k]) { const int i = find(t->src[k]); if (i >= 0 && i < j) { local[i]++; users[i].push_back(j); } }
-        }
+    std::vector<int> local(n, 0), writer(n, -1);        // writer[i]: entry of mvs whose launch produces node i
+    static thread_local node_index find;
+    static thread_local user_lists users;
+    static thread_local std::vector<int> edges;
+    find.build(g, n);
+    // uses inside this graph (views count as uses of their source, exactly like ggml's use counts)
+    edges.clear();
+    for (int j = 0; j < n; j++) {
+        const ggml_tensor * t = ggml_graph_node(g, j);
+        for (int k = 0; k < GGML_MAX_SRC; k++) if (t->src[k]) { const int i = find(t->src[k]); if (i >= 0 && i < j) { local[i]++; edges.push_back(i); edges.push_back(j); } }
+    }
+    users.start.assign(n + 1, 0);
+    for (int i = 0; i < n; i++) users.start[i + 1] = users.start[i] + local[i];
+    users.list.resize(edges.size() / 2);
+    {
+        std::vector<int> fill(users.start.begin(), users.start.end() - 1);
+        for (size_t e = 0; e < edges.size(); e += 2) users.list[fill[edges[e]]++] = edges[e + 1];      // edges are in consumer order: so is every list
     }
     auto only_local = [&](int i, int uses) {
         const ggml_tensor * t = ggml_graph_node(g, i);
@@ -209,8 +506,8 @@ fuse_plan make_plan(ggml_cgraph * g) {
             if (ok) {
                 float eps; memcpy(&eps, t->src[0]->op_params, 4);
                 for (int j : users[i]) {
-                    fused_mv f; f.pro = 1; f.px = (const float *) t->src[0]->src[0]->data; f.pw = (const float *) t->src[1]->data; f.eps = eps; f.dst = (float *) ggml_graph_node(g, j)->data;
-                    P.mv[j] = (int) P.mvs.size(); P.mvs.push_back(f);
+                    fused_mv f; f.pro = 1; f.px = (const float *) t->src[0]->src[0]->data; f.pw = (const float *) t->src[1]->data; f.eps = eps; f.dst = (float *) ggml_graph_node(g, j)->data; f.node = j;
+                    P.mv[j] = writer[j] = (int) P.mvs.size(); P.mvs.push_back(f);
                 }
                 P.skip[r] = P.skip[i] = 1;
             }
@@ -222,7 +519,8 @@ fuse_plan make_plan(ggml_cgraph * g) {
             const ggml_tensor * c = ggml_graph_node(g, j);
             if (u >= 0 && only_local(u, 1) && only_local(i, 1) && mv_ok(c) && c->src[1] == t && t->ne[0] % 8 == 0 && c->src[0]->ne[0] <= 32768) {
                 fused_mv f; f.pro = 4; f.px = (const float *) t->src[0]->src[0]->data; f.pw = (const float *) t->src[1]->data; f.dst = (float *) c->data;
-                P.mv[j] = (int) P.mvs.size(); P.mvs.push_back(f);
+                f.node = j; f.ga = find(t->src[0]->src[0]); f.gb = find(t->src[1]);
+                P.mv[j] = writer[j] = (int) P.mvs.size(); P.mvs.push_back(f);
                 P.skip[u] = P.skip[i] = 1;
             }
         }
@@ -243,14 +541,41 @@ fuse_plan make_plan(ggml_cgraph * g) {
             if (!mm || mm->op != GGML_OP_MUL_MAT || !mv_ok(mm) || !f32_vec(r) || r->ne[0] != a->ne[0]) continue;
             const int j = node_of(mm, i);
             if (j < 0 || !only_local(j, 1) || P.skip[j]) continue;
-            if (P.mv[j] < 0) { fused_mv f; f.pro = 2; f.px = (const float *) mm->src[1]->data; P.mv[j] = (int) P.mvs.size(); P.mvs.push_back(f); }
+            if (P.mv[j] < 0) { fused_mv f; f.pro = 2; f.px = (const float *) mm->src[1]->data; f.node = j; P.mv[j] = (int) P.mvs.size(); P.mvs.push_back(f); }
             fused_mv & f = P.mvs[P.mv[j]];
             const size_t kbytes = (size_t) mm->src[0]->ne[0] * 4, nbytes = (size_t) a->ne[0] * 4;
             if (overlap(a->data, nbytes, f.px, kbytes) || (f.pw && overlap(a->data, nbytes, f.pw, kbytes))) { if (f.pro == 2 && !f.resid && !f.dst) { P.mvs.pop_back(); P.mv[j] = -1; } continue; }
             f.resid = (const float *) r->data; f.dst = (float *) a->data;
             P.skip[i] = 1;
+            writer[j] = -1; writer[i] = P.mv[j];
             break;
         }
+    }
+    plan_attention(g, P, local, writer, users, find);
+    // ---- merged launches over packed weights (the decision whether a packed copy exists is taken at run time: get_pack)
+    auto same_input = [&](const fused_mv & a, const fused_mv & b) {
+        const ggml_tensor * wa = ggml_graph_node(g, a.node)->src[0], * wb = ggml_graph_node(g, b.node)->src[0];
+        return a.pro == 1 && b.pro == 1 && a.px == b.px && a.pw == b.pw && a.eps == b.eps && !a.resid && !b.resid && a.group < 0 && b.group < 0 &&
+               wa->type == wb->type && wa->ne[0] == wb->ne[0] && wa->nb[1] == wb->nb[1];
+    };
+    for (const fused_attn & A : P.attns) {
+        if (A.level != 2 || A.wq == A.wk || A.wq == A.wv || A.wk == A.wv) continue;
+        if (!same_input(P.mvs[A.wq], P.mvs[A.wk]) || !same_input(P.mvs[A.wq], P.mvs[A.wv])) continue;
+        merge_group G; G.n = 3; G.member[0] = A.wq; G.member[1] = A.wk; G.member[2] = A.wv;
+        for (int k = 0; k < 3; k++) P.mvs[G.member[k]].group = (int) P.groups.size();
+        P.groups.push_back(G);
+    }
+    for (size_t m = 0; m < P.mvs.size(); m++) {
+        const fused_mv & d = P.mvs[m];
+        if (d.pro != 4 || d.ga < 0 || d.gb < 0 || d.ga == d.gb || P.mv[d.ga] < 0 || P.mv[d.gb] < 0 || P.skip[d.ga] || P.skip[d.gb]) continue;
+        const fused_mv & a = P.mvs[P.mv[d.ga]], & b = P.mvs[P.mv[d.gb]];
+        const ggml_tensor * ta = ggml_graph_node(g, d.ga), * tb = ggml_graph_node(g, d.gb);
+        if (!same_input(a, b) || a.dst != (float *) ta->data || b.dst != (float *) tb->data || !only_local(d.ga, 1) || !only_local(d.gb, 1)) continue;
+        const int64_t F = ta->ne[0];
+        if (tb->ne[0] != F || F % 8 || ta->src[0]->ne[1] != F || tb->src[0]->ne[1] != F) continue;
+        merge_group G; G.n = 2; G.member[0] = P.mv[d.ga]; G.member[1] = P.mv[d.gb]; G.interleave = true; G.consumer = (int) m;
+        P.mvs[G.member[0]].group = P.mvs[G.member[1]].group = (int) P.groups.size();
+        P.groups.push_back(G);
     }
     for (int j = 0; j < n; j++) if (P.mv[j] >= 0 && !P.mvs[P.mv[j]].dst) P.mvs[P.mv[j]].dst = (float *) ggml_graph_node(g, j)->data;
     return P;
@@ -270,10 +595,39 @@ ggml_status be_graph_compute(ggml_backend_t backend, ggml_cgraph * g) {
             fputc('\n', stderr);
         }
     }
-    const fuse_plan plan = make_plan(g);
+    ws_scope ws(g_ws.issue_us);
+    flush_sets();                               // queued small set_tensor copies (null stream; this stream does not wait for it by itself)
+    cllm_set_device(c->device);
+    fuse_plan plan = make_plan(g);
+    if (g_stats) g_ws.plan_us += wall_stats::us(ws.t0, wall_stats::clk::now());
+    // fused attention: [cos/sin table 1 KB][q | k | v projections][scores of the long-context form]
+    // scratch of the fused forms: [cos/sin table 1 KB][q | k | v projections][SiLU(gate)*up activation][scores of the long-context attention]
+    size_t qkv_bytes = 0, act_bytes = 0, score_bytes = 0;
+    for (const fused_attn & A : plan.attns) if (A.level == 2) {
+        const size_t q = ((size_t) A.hd * (A.nh + 2 * A.nkv) * 4 + 255) & ~(size_t) 255, sb = cllm_attn_decode_wsize(A.n_kv, A.nh, A.ML);
+        if (q > qkv_bytes) qkv_bytes = q;
+        if (sb > score_bytes) score_bytes = sb;
+    }
+    for (const merge_group & G : plan.groups) if (G.interleave) {
+        const size_t a = ((size_t) ggml_graph_node(g, plan.mvs[G.member[0]].node)->ne[0] * 4 + 255) & ~(size_t) 255;
+        if (a > act_bytes) act_bytes = a;
+    }
+    float * a_cs = nullptr, * a_qkv = nullptr, * a_act = nullptr; void * a_scores = nullptr;
+    if (qkv_bytes || act_bytes) {
+        if (int rc = ensure_abuf(c, 1024 + qkv_bytes + act_bytes + score_bytes)) { HIPB_LOG("fusion scratch: %s", cllm_last_error()); return rc == CLLM_E_ALLOC ? GGML_STATUS_ALLOC_FAILED : GGML_STATUS_FAILED; }
+        a_cs = (float *) c->abuf; a_qkv = (float *)((char *) c->abuf + 1024); a_act = (float *)((char *) c->abuf + 1024 + qkv_bytes);
+        a_scores = (char *) c->abuf + 1024 + qkv_bytes + act_bytes;
+        for (const fused_attn & A : plan.attns) if (A.level == 2) {
+            plan.mvs[A.wq].dst = a_qkv; plan.mvs[A.wk].dst = a_qkv + (size_t) A.hd * A.nh; plan.mvs[A.wv].dst = a_qkv + (size_t) A.hd * (A.nh + A.nkv);
+        }
+    }
+    int merged = 0;
+    const int32_t * tab_pos = nullptr; int tab_hd = 0; float tab_fb = 0.0f;      // what a_cs holds (computed once per graph, not per layer)
+    int launches = 0;
     for (int i = 0; i < ggml_graph_n_nodes(g); i++) {
         ggml_tensor * n = ggml_graph_node(g, i);
         if (ggml_is_empty(n) || plan.skip[i]) continue;
+        launches += !(n->op == GGML_OP_NONE || n->op == GGML_OP_RESHAPE || n->op == GGML_OP_VIEW || n->op == GGML_OP_PERMUTE || n->op == GGML_OP_TRANSPOSE);
         const ggml_tensor * a = n->src[0], * b = n->src[1];
         int rc = CLLM_OK;
         cllm_tensor d = desc(n), da, db, dc;
@@ -283,7 +637,25 @@ ggml_status be_graph_compute(ggml_backend_t backend, ggml_cgraph * g) {
             case GGML_OP_NONE: case GGML_OP_RESHAPE: case GGML_OP_VIEW: case GGML_OP_PERMUTE: case GGML_OP_TRANSPOSE: break;
             case GGML_OP_MUL_MAT: if (plan.mv[i] >= 0) {
                 const fused_mv & f = plan.mvs[plan.mv[i]];
-                rc = cllm_op_mul_mat_vec_fused(st, &da, f.pro, f.px, f.pw, f.eps, f.resid, f.dst);
+                if (f.group >= 0) {
+                    merge_group & G = plan.groups[f.group];
+                    if (G.state == 0) {         // the first member in node order launches for all of them -- if a packed copy of the weights can be had
+                        const ggml_tensor * w[3]; int64_t rows = 0;
+                        for (int k = 0; k < G.n; k++) { w[k] = ggml_graph_node(g, plan.mvs[G.member[k]].node)->src[0]; rows += w[k]->ne[1]; }
+                        void * W = get_pack(c->device, st, w, G.n, G.interleave);
+                        G.state = 2;
+                        if (W) {
+                            cllm_tensor dw = desc(w[0]); dw.ne[1] = rows; dw.nb[2] = dw.nb[3] = (size_t) rows * dw.nb[1]; dw.data = W;
+                            rc = cllm_op_mul_mat_vec_fused(st, &dw, 1, f.px, f.pw, f.eps, G.interleave ? 1 : 0, nullptr, G.interleave ? a_act : plan.mvs[G.member[0]].dst);
+                            if (rc == CLLM_OK) {
+                                G.state = 1; merged++;
+                                if (G.consumer >= 0) { fused_mv & d = plan.mvs[G.consumer]; d.pro = 2; d.px = a_act; d.pw = nullptr; }
+                            } else if (rc == CLLM_E_UNSUPPORTED) rc = CLLM_OK;      // shape the merged form does not take: launch the members
+                        }
+                    }
+                    if (G.state == 1 || rc != CLLM_OK) break;
+                }
+                rc = cllm_op_mul_mat_vec_fused(st, &da, f.pro, f.px, f.pw, f.eps, 0, f.resid, f.dst);
             } else {
                 const size_t need = cllm_mul_mat_wsize(&da, &db);
                 if ((rc = ensure_wdata(c, need))) break;
@@ -319,13 +691,39 @@ ggml_status be_graph_compute(ggml_backend_t backend, ggml_cgraph * g) {
                 rc = cllm_op_soft_max(st, &da, b ? &db : nullptr, &d, scale, max_bias);
             } break;
             case GGML_OP_SET_ROWS: rc = cllm_op_set_rows(st, &da, &db, &d); break;          // dst is a view of the cache (node->data)
-            case GGML_OP_CPY: case GGML_OP_DUP: case GGML_OP_CONT: rc = cllm_op_cpy(st, &da, &d); break;
+            case GGML_OP_CPY: case GGML_OP_DUP: case GGML_OP_CONT: if (plan.attn[i] >= 0) {
+                const fused_attn & A = plan.attns[plan.attn[i]];
+                if (A.level == 2) {
+                    const bool table = A.hd == 64 || A.hd == 128;       // head sizes of the compact kernels
+                    if (table && !(tab_pos == A.pos && tab_hd == A.hd && tab_fb == A.freq_base)) {
+                        if ((rc = cllm_op_rope_table(st, A.pos, A.hd, A.freq_base, a_cs))) break;
+                        tab_pos = A.pos; tab_hd = A.hd; tab_fb = A.freq_base;
+                    }
+                    rc = cllm_op_rope_kv_attn_decode(st, a_qkv, A.pos, table ? a_cs : nullptr, A.freq_base, A.n_kv, A.nh, A.nkv, A.hd, A.mode, A.k_cache, A.v_cache, A.ML,
+                                                     A.out, score_bytes ? a_scores : nullptr, score_bytes);
+                } else rc = cllm_op_attn_decode(st, A.q, A.pos, A.nh, A.nkv, A.hd, A.k_cache, A.v_cache, A.ML, A.out);
+            } else rc = cllm_op_cpy(st, &da, &d); break;
             case GGML_OP_GET_ROWS: rc = cllm_op_get_rows(st, &da, &db, &d); break;
             default: HIPB_LOG("graph_compute: op %s reached the device although supports_op() declined it", ggml_op_name(n->op)); return GGML_STATUS_FAILED;
         }
         if (rc != CLLM_OK) {
             HIPB_LOG("node %d (%s, '%s') failed: %s", i, ggml_op_name(n->op), n->name, cllm_last_error());
             return rc == CLLM_E_ALLOC ? GGML_STATUS_ALLOC_FAILED : GGML_STATUS_FAILED;
+        }
+    }
+    if (g_stats) {
+        int a1 = 0, a2 = 0;
+        for (const fused_attn & A : plan.attns) (A.level == 2 ? a2 : a1)++;
+        for (const merge_group & G : plan.groups) if (G.state == 1) launches -= G.n - 1;
+        HIPB_LOG("graph_compute: %d nodes -> %d calls (%d fused mat-vecs, %d merged over packed weights, attention fused at level 1: %d, level 2: %d)",
+                 ggml_graph_n_nodes(g), launches, (int) plan.mvs.size(), merged, a1, a2);
+        g_ws.calls += launches;
+        if (++g_ws.graphs % 64 == 0) {
+            const double n = 64.0;
+            HIPB_LOG("per graph over the last 64: host %.0f us | graph_compute %.0f us (of which planning %.0f us, %.0f calls) | synchronize %.0f us | "
+                     "set_tensor %.0f us (%.1f calls) | get_tensor %.0f us (%.1f calls)",
+                     g_ws.host_us / n, g_ws.issue_us / n, g_ws.plan_us / n, g_ws.calls / n, g_ws.sync_us / n, g_ws.set_us / n, g_ws.sets / n, g_ws.get_us / n, g_ws.gets / n);
+            g_ws.host_us = g_ws.plan_us = g_ws.issue_us = g_ws.sync_us = g_ws.set_us = g_ws.get_us = 0; g_ws.calls = g_ws.sets = g_ws.gets = 0;
         }
     }
     return GGML_STATUS_SUCCESS;       // asynchronous: the host calls synchronize() before it reads (src/backend.cpp:824-825)

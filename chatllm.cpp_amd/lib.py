@@ -49,6 +49,8 @@ SIGNATURES = {
     "cllm_memcpy_h2d": (C.c_int, [_P, _P, C.c_size_t, _P]),
     "cllm_memcpy_d2h": (C.c_int, [_P, _P, C.c_size_t, _P]),
     "cllm_memcpy_d2d": (C.c_int, [_P, _P, C.c_size_t, _P]),
+    "cllm_host_malloc": (C.c_int, [C.POINTER(C.c_void_p), C.c_size_t]),
+    "cllm_host_free": (C.c_int, [_P]),
     "cllm_stream_create": (C.c_int, [C.POINTER(C.c_void_p)]),
     "cllm_stream_destroy": (C.c_int, [_P]),
     "cllm_stream_sync": (C.c_int, [_P]),
@@ -59,7 +61,8 @@ SIGNATURES = {
     "cllm_event_elapsed_ms": (C.c_int, [_P, _P, C.POINTER(C.c_float)]),
     "cllm_mul_mat_wsize": (C.c_size_t, [_T, _T]),
     "cllm_op_mul_mat": (C.c_int, [_P, _T, _T, _T, _P, C.c_size_t]),
-    "cllm_op_mul_mat_vec_fused": (C.c_int, [_P, _T, C.c_int, _P, _P, C.c_float, _P, _P]),
+    "cllm_op_mul_mat_vec_fused": (C.c_int, [_P, _T, C.c_int, _P, _P, C.c_float, C.c_int, _P, _P]),
+    "cllm_pack_rows": (C.c_int, [_P, _P, C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.c_int, C.c_size_t, C.c_int]),
     "cllm_bench_mul_mat_kernel": (C.c_int, [_P, _T, C.POINTER(C.c_void_p), C.c_int, _T, _T, _P, C.c_size_t, C.c_int, C.POINTER(C.c_float)]),
     "cllm_bench_mul_mat_id": (C.c_int, [_P, _T, _T, _T, C.POINTER(C.c_void_p), C.c_int, _T, _P, C.c_size_t, C.c_int, C.POINTER(C.c_float)]),
     "cllm_bench_gemv_fused": (C.c_int, [_P, C.c_int, C.POINTER(C.c_void_p), C.c_int, C.c_int64, C.c_int64, C.c_int, _P, _P, C.c_float, C.c_int, _P, _P, C.c_int,
@@ -76,6 +79,10 @@ SIGNATURES = {
     "cllm_op_scale": (C.c_int, [_P, _T, _T, C.c_float, C.c_float]),
     "cllm_op_scale_mask_soft_max": (C.c_int, [_P, _T, _T, C.c_float, C.c_int]),
     "cllm_op_attn_decode": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, _P, _P, C.c_int64, _P]),
+    "cllm_op_rope_table": (C.c_int, [_P, _P, C.c_int, C.c_float, _P]),
+    "cllm_attn_decode_supported": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int64]),
+    "cllm_attn_decode_wsize": (C.c_size_t, [C.c_int64, C.c_int, C.c_int64]),
+    "cllm_op_rope_kv_attn_decode": (C.c_int, [_P, _P, _P, _P, C.c_float, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, C.c_int64, _P, _P, C.c_size_t]),
     "cllm_op_unary": (C.c_int, [_P, C.c_int, _T, _T]),
     "cllm_op_add": (C.c_int, [_P, _T, _T, _T]),
     "cllm_op_mul": (C.c_int, [_P, _T, _T, _T]),

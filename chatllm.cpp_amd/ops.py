@@ -107,6 +107,23 @@ def attn_decode(q, pos, n_head, n_kv_head, head_dim, k_cache, v_cache, max_len, 
     return dst
 
 
+def rope_kv_attn_decode(qkv, pos, n_kv, n_head, n_kv_head, head_dim, rope_mode, freq_base, k_cache, v_cache, max_len, table=True, dst=None):
+    """KVCacheAttention for one token in one call: RoPE(q,k), K/V cache write at `pos`, scores, softmax, V.P (src/layers.cpp:3044-3123,
+    2499-2561); qkv: the un-rotated projections, pos: I32 [1] device tensor == n_kv - 1"""
+    L = _l.get()
+    dst = dst or Tensor(F32, [head_dim * n_head])
+    cs = None
+    if table:
+        cs = Tensor(F32, [head_dim])
+        _l.check(L.cllm_op_rope_table(None, pos.data_ptr(), head_dim, freq_base, cs.data_ptr()), "rope_table")
+    ws = L.cllm_attn_decode_wsize(n_kv, n_head, max_len)
+    buf = _scratch(ws) if ws else None
+    _l.check(L.cllm_op_rope_kv_attn_decode(None, qkv.data_ptr(), pos.data_ptr(), cs.data_ptr() if cs else None, freq_base, n_kv, n_head, n_kv_head, head_dim,
+                                           rope_mode, k_cache.data_ptr(), v_cache.data_ptr(), max_len, dst.data_ptr(), buf.ptr if buf else None,
+                                           buf.nbytes if buf else 0), "rope_kv_attn_decode")
+    return dst
+
+
 def silu(a, dst=None):
     dst = dst or Tensor(F32, a.ne)
     _l.check(_l.get().cllm_op_unary(None, UNARY_SILU, _ref(a), _ref(dst)), "silu")

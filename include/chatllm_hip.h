@@ -70,6 +70,8 @@ CLLM_API int  cllm_memset(void * dst, int value, size_t size, void * stream);   
 CLLM_API int  cllm_memcpy_h2d(void * dst, const void * src, size_t size, void * stream); /* set_tensor[_async] */
 CLLM_API int  cllm_memcpy_d2h(void * dst, const void * src, size_t size, void * stream); /* get_tensor[_async] */
 CLLM_API int  cllm_memcpy_d2d(void * dst, const void * src, size_t size, void * stream); /* cpy_tensor        */
+CLLM_API int  cllm_host_malloc(void ** ptr, size_t size);      /* page-locked host memory (staging for get_tensor; device_i.get_host_buffer_type) */
+CLLM_API int  cllm_host_free(void * ptr);
 CLLM_API int  cllm_stream_create(void ** stream);
 CLLM_API int  cllm_stream_destroy(void * stream);
 CLLM_API int  cllm_stream_sync(void * stream);                 /* backend_i.synchronize */
@@ -98,9 +100,14 @@ CLLM_API int    cllm_op_mul_mat(void * stream, const cllm_tensor * src0, const c
  * (chatllm.cpp_amd/host/ggml-hip.cpp does, with ggml's use counts):
  *   pro 1: RMS_NORM(px, eps) -> MUL(pw) -> MUL_MAT(src0)      pro 2: MUL_MAT(src0, px)      pro 4: UNARY(SILU)(px) -> MUL(pw) -> MUL_MAT(src0)
  *   resid != NULL: ... -> ADD(resid).   px / pw / resid / dst: dense F32 vectors (dst may alias resid, never px / pw).
+ *   epi 1 (pro 1 only, no resid): src0 holds the gate and up projections of BaseMLP::forward (src/layers.cpp:2475-2483) with their rows
+ *   alternating (cllm_pack_rows, interleave) and dst[i] = silu(row 2i . x) * (row 2i+1 . x): MUL_MAT, MUL_MAT, UNARY(SILU), MUL in one launch.
  * Bit-identical to the unfused cllm_op_* sequence.  CLLM_E_UNSUPPORTED for row lengths outside the decode kernel's range. */
-CLLM_API int    cllm_op_mul_mat_vec_fused(void * stream, const cllm_tensor * src0, int pro, const float * px, const float * pw, float eps,
+CLLM_API int    cllm_op_mul_mat_vec_fused(void * stream, const cllm_tensor * src0, int pro, const float * px, const float * pw, float eps, int epi,
                                           const float * resid, float * dst);
+/* device-side repack of weight rows so that mat-vecs reading the same activation become one launch: dst = srcs[0] rows | srcs[1] rows | ...
+ * (interleave 0; e.g. q, k, v) or a_0, b_0, a_1, b_1, ... of two matrices with the same number of rows (interleave 1; gate, up). */
+CLLM_API int    cllm_pack_rows(void * stream, void * dst, const void * const * srcs, const int64_t * nrows, int n, size_t row_bytes, int interleave);
 
 /* measurement hook for bench.py's "roofline" object: quantizes src1 once, then times `iters` launches of ONLY the
  * mat-mul kernel between two HIP events on `stream`, cycling src0->data through src0_datas[0..n_src0) (distinct
@@ -162,6 +169,21 @@ CLLM_API int cllm_op_scale_mask_soft_max(void * stream, const cllm_tensor * src,
  * the number of cached positions is *pos_dev + 1 (read on the device); out: [hd * n_head] F32.  Bit-identical to the nodes. */
 CLLM_API int cllm_op_attn_decode(void * stream, const float * q, const int32_t * pos_dev, int n_head, int n_kv_head, int head_dim,
                                  const void * k_cache, const void * v_cache, int64_t max_len, float * out);
+
+/* the whole single-token attention block of KVCacheAttention (src/layers.cpp:3044-3123 save_to_cache, 957-983 rope, 2541-2561 scores,
+ * 2499-2539 probs) in one call -- 1 launch up to 512 cached positions, 3 above:
+ *   ROPE(q), ROPE(k) -> SET_ROWS(k_cache row pos), CPY(v -> v_cache column pos), then the node sequence of cllm_op_attn_decode.
+ * qkv: the UN-rotated projections [n_head*hd | n_kv_head*hd | n_kv_head*hd] F32; pos_dev: I32 position on the device (== n_kv - 1);
+ * rope_cs: cllm_op_rope_table() of pos_dev (NULL: computed in the kernel from freq_base); rope_mode 0 (pairs i,i+1) or 2 (NEOX),
+ * n_dims == head_dim, no YaRN / frequency factors (ggml_compute_forward_rope_flt, ops.cpp:5589-5865); n_kv: host copy of the cached
+ * length, used only to pick the kernel; wdata: cllm_attn_decode_wsize(n_kv, ..) bytes (may be NULL when that is 0).
+ * Bit-identical to the unfused nodes. */
+CLLM_API int    cllm_op_rope_table(void * stream, const int32_t * pos_dev, int head_dim, float freq_base, float * cs /* head_dim floats */);
+CLLM_API int    cllm_attn_decode_supported(int n_head, int n_kv_head, int head_dim, int64_t max_len);
+CLLM_API size_t cllm_attn_decode_wsize(int64_t n_kv, int n_head, int64_t max_len);
+CLLM_API int    cllm_op_rope_kv_attn_decode(void * stream, const float * qkv, const int32_t * pos_dev, const float * rope_cs, float freq_base, int64_t n_kv,
+                                            int n_head, int n_kv_head, int head_dim, int rope_mode, void * k_cache, void * v_cache, int64_t max_len,
+                                            float * out, void * wdata, size_t wsize);
 
 typedef enum cllm_unary { CLLM_UNARY_SILU = 10 /* == GGML_UNARY_OP_SILU */ } cllm_unary;
 /* GGML_OP_UNARY         ggml_vec_silu_f32 (ggml-cpu/vec.cpp:396-431) */

@@ -8,7 +8,7 @@
  *   NGL: "cpu" (no -ngl: the reference CPU path) or an -ngl spec such as "all" (our libggml-hip.so module, --ggml_dir = exe dir)
  * It feeds the prompt ids as one chunk, then N_DECODE greedy steps (argmax, first maximum, like Sampler greedy
  * src/models.cpp:676-690), prints the generated ids on stdout and writes every step's logits (float32, vocab each)
- * to LOGITS.bin.  With TEACHER=path it reads the ids to feed at each decode step from a text file instead of its own
+ * to LOGITS.bin ("-": not written).  With TEACHER=path it reads the ids to feed at each decode step from a text file instead of its own
  * argmax (teacher forcing, so that two runs stay comparable step by step).
  */
 #include "chat.h"
@@ -43,8 +43,9 @@ int main(int argc, char ** argv) {
         if (ngl != "cpu") args.model_n_gpu_layers["any"] = ngl;
         chatllm::ModelObject obj(path, args);
         chatllm::GenerationConfig gen(obj.model->get_max_length(), obj.model->get_max_length(), false, false, 1, 1.0f, 0.0f, threads, "greedy", 0.0f, 1.0f);
-        FILE * fo = fopen(logits_path, "wb");
-        if (!fo) { fprintf(stderr, "cannot open %s\n", logits_path); return 3; }
+        const bool keep = std::string(logits_path) != "-";          // "-": throughput runs, nothing written
+        FILE * fo = keep ? fopen(logits_path, "wb") : nullptr;
+        if (keep && !fo) { fprintf(stderr, "cannot open %s\n", logits_path); return 3; }
         std::vector<float> logits;
         std::vector<int> in = ids;
         int n_past = 0;
@@ -52,12 +53,12 @@ int main(int argc, char ** argv) {
             obj.model->set_n_past(n_past);
             if (!obj.model->generate_next_token(in, gen, logits)) { fprintf(stderr, "generate_next_token failed\n"); return 4; }
             n_past += (int) in.size();
-            fwrite(logits.data(), sizeof(float), logits.size(), fo);
+            if (fo) fwrite(logits.data(), sizeof(float), logits.size(), fo);
             const int tok = (int)(std::max_element(logits.begin(), logits.end()) - logits.begin());
             printf("%d%s", tok, s == n_decode ? "\n" : " ");
             in.assign(1, s < (int) teacher.size() ? teacher[s] : tok);
         }
-        fclose(fo);
+        if (fo) fclose(fo);
     } catch (const std::exception & e) {
         fprintf(stderr, "error: %s\n", e.what());
         return 1;

@@ -56,8 +56,9 @@ def test_reference_host_cpu_vs_our_module(gpu, tmp_path, wname, wt):
                     reason="oracle/_ref (reference host + module) not built")
 @pytest.mark.parametrize("wname,wt,over", [("q4_k", 12, {}), ("q4_0", 2, {}), ("q4_k", 12, dict(ffn=544))])
 def test_module_node_fusion_does_not_change_a_bit(gpu, tmp_path, wname, wt, over):
-    """graph_compute fuses RMS_NORM->MUL->MUL_MAT, SILU->MUL->MUL_MAT, MUL_MAT->ADD and SCALE->MASK->SOFT_MAX node patterns into single
-    launches; with CLLM_HIP_NO_FUSE=1 every node is its own launch: the logits of prompt + 10 decode steps must be identical bytes"""
+    """graph_compute fuses RMS_NORM->MUL->MUL_MAT, SILU->MUL->MUL_MAT, MUL_MAT->ADD, SCALE->MASK->SOFT_MAX and the single-token attention
+    block into single launches and merges mat-vecs over packed weights; with CLLM_HIP_NO_FUSE=1 every node is its own launch: the logits
+    of prompt + 10 decode steps must be identical bytes at every level"""
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import make_ggmm
     cfg = gpu.synth.config("tiny", max_len=64, **over)
@@ -65,13 +66,25 @@ def test_module_node_fusion_does_not_change_a_bit(gpu, tmp_path, wname, wt, over
     make_ggmm.write_model(mp, cfg, wt, seed=78)
     prompt = [3, 100, 45, 260, 17]
     out = {}
-    for mode in ("fused", "nodes"):
+    # fused: everything (attention block at level 2 = RoPE + cache writes + attention in one call); attn1: attention without the RoPE /
+    # cache-write nodes; attn0: mat-vec and soft_max patterns only; nodes: one call per node
+    # nopack: no merged launches over row-repacked weight copies (q|k|v, gate/up)
+    for mode, extra in (("fused", {}), ("nopack", {"CLLM_HIP_PACK": "0"}), ("attn1", {"CLLM_HIP_FUSE_ATTN": "1"}), ("attn0", {"CLLM_HIP_FUSE_ATTN": "0"}),
+                        ("nodes", {"CLLM_HIP_NO_FUSE": "1"})):
         lp = str(tmp_path / f"l_{mode}.bin")
-        env = dict(os.environ)
-        if mode == "nodes":
-            env["CLLM_HIP_NO_FUSE"] = "1"
+        env = dict(os.environ, CLLM_HIP_STATS="1", **extra)
         r = subprocess.run([os.path.join(REF, "ref_chat"), mp, "all", "4", "10", lp] + [str(p) for p in prompt], capture_output=True, text=True, env=env, timeout=300)
         assert r.returncode == 0, r.stderr[-2000:]
-        out[mode] = (r.stdout.split(), open(lp, "rb").read())
-    assert out["fused"][0] == out["nodes"][0]
-    assert out["fused"][1] == out["nodes"][1]
+        stats = [ln for ln in r.stderr.splitlines() if "graph_compute:" in ln and "calls" in ln]
+        out[mode] = (r.stdout.split(), open(lp, "rb").read(), stats)
+    n_layer = cfg["n_layer"]
+    assert any(f"level 2: {n_layer})" in ln for ln in out["fused"][2]), out["fused"][2][-3:]          # the patterns were really taken
+    assert any(f"level 1: {n_layer}," in ln for ln in out["attn1"][2]), out["attn1"][2][-3:]
+    assert all("level 1: 0, level 2: 0" in ln for ln in out["attn0"][2])
+    import re
+    merged = max(int(re.search(r"(\d+) merged", ln).group(1)) for ln in out["fused"][2])
+    assert merged == 2 * n_layer if not over else merged >= n_layer, out["fused"][2][-3:]             # q|k|v and gate/up of every layer
+    assert all(" 0 merged" in ln for ln in out["nopack"][2])
+    for mode in ("fused", "nopack", "attn1", "attn0"):
+        assert out[mode][0] == out["nodes"][0], mode
+        assert out[mode][1] == out["nodes"][1], mode

@@ -342,6 +342,63 @@ def test_attention_composite(gpu, qlen, n_past):
     assert rel_err(got, want) < 3e-4
 
 
+# ---- the single-token attention block in one call == the node sequence chatllm emits (KVCacheAttention, src/layers.cpp:3044-3123) --------
+@pytest.mark.parametrize("hd,nh,nkv,ML,n_past,mode,table", [
+    (128, 32, 8, 1024, 0, 0, True), (128, 32, 8, 1024, 37, 0, True), (128, 32, 8, 1024, 300, 2, True), (128, 32, 8, 1024, 511, 0, True),
+    (128, 8, 8, 2048, 700, 0, True),        # above the long-context threshold: three launches, R2 = 1
+    (128, 32, 8, 4096, 3000, 2, True),      # long, GQA 4
+    (64, 4, 2, 64, 11, 0, True), (64, 4, 2, 64, 63, 2, True),
+    (128, 32, 8, 1024, 100, 0, False),      # no table: the general kernel computes cos/sin itself
+    (96, 6, 2, 256, 40, 2, True)])          # head size the compact kernels do not take -> general kernel
+def test_rope_kv_attn_decode_equals_the_node_sequence(gpu, hd, nh, nkv, ML, n_past, mode, table):
+    ops, T = gpu.ops, gpu.Tensor
+    QD, KD, n_kv, fb = hd * nh, hd * nkv, n_past + 1, 500000.0
+    qkv = rng.standard_normal(QD + 2 * KD).astype(np.float32)
+    kc0 = rng.standard_normal((ML, KD)).astype(np.float16)
+    vc0 = rng.standard_normal((KD, ML)).astype(np.float16)
+    pos = T.from_numpy(np.array([n_past], np.int32))
+
+    # -- node by node: ROPE(k) -> SET_ROWS, TRANSPOSE(v) -> CPY, ROPE(q), MUL_MAT(K,Q), SCALE+MASK+SOFT_MAX, MUL_MAT(V,P), PERMUTE+CONT
+    dk, dv = T.from_numpy(kc0), T.from_numpy(vc0)
+    q = T.from_numpy(qkv[:QD].reshape(1, nh, hd))
+    k = T.from_numpy(qkv[QD:QD + KD].reshape(1, nkv, hd))
+    v = T.from_numpy(qkv[QD + KD:].reshape(1, KD))
+    ops.cpy(v.transpose(), dv.view([1, KD], [2, ML * 2], offset=n_past * 2))
+    kr = ops.rope_ext(k, pos, None, hd, mode, freq_base=fb, inplace=True)
+    ops.set_rows(dk.view([KD, ML], [2, KD * 2]), kr.reshape(KD, 1), pos)
+    qr = ops.rope_ext(q, pos, None, hd, mode, freq_base=fb, inplace=True)
+    s = ops.mul_mat(dk.view([hd, n_kv, nkv], [2, KD * 2, hd * 2]), qr.permute(0, 2, 1, 3))
+    p = ops.scale_mask_soft_max(s, float(np.float32(1.0) / np.sqrt(np.float32(hd))), n_past)
+    c = ops.mul_mat(dv.view([n_kv, hd, nkv], [2, ML * 2, ML * hd * 2]), p)
+    want = ops.cont(c.permute(0, 2, 1, 3)).numpy().reshape(QD)
+    want_k, want_v = dk.numpy().view(np.uint16), dv.numpy().view(np.uint16)
+
+    # -- post-RoPE form (caches already written): cllm_op_attn_decode
+    if ML <= 4096:
+        got1 = ops.attn_decode(qr, pos, nh, nkv, hd, dk, dv, ML).numpy().reshape(QD)
+        assert np.array_equal(got1.view(np.uint32), want.view(np.uint32))
+
+    # -- everything in one call, on fresh caches
+    fk, fv = T.from_numpy(kc0), T.from_numpy(vc0)
+    got = ops.rope_kv_attn_decode(T.from_numpy(qkv), pos, n_kv, nh, nkv, hd, mode, fb, fk, fv, ML, table=table).numpy().reshape(QD)
+    assert np.array_equal(fk.numpy().view(np.uint16), want_k)
+    assert np.array_equal(fv.numpy().view(np.uint16), want_v)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+
+
+def test_rope_kv_attn_decode_rejects_what_it_cannot_do(gpu):
+    L, T = gpu.lib.get(), gpu.Tensor
+    assert L.cllm_attn_decode_supported(32, 8, 128, 1024) == 1
+    assert L.cllm_attn_decode_supported(32, 8, 128, 1 << 17) == 0          # scores of one head no longer fit the LDS
+    assert L.cllm_attn_decode_supported(32, 5, 128, 1024) == 0
+    assert L.cllm_attn_decode_wsize(100, 32, 1024) == 0 and L.cllm_attn_decode_wsize(600, 32, 1024) == 32 * 1024 * 6
+    x = T.from_numpy(np.zeros(4096, np.float32)); pos = T.from_numpy(np.zeros(1, np.int32)); kc = T.from_numpy(np.zeros((64, 256), np.float16))
+    rc = L.cllm_op_rope_kv_attn_decode(None, x.data_ptr(), pos.data_ptr(), None, 1e4, 1, 4, 2, 128, 1, kc.data_ptr(), kc.data_ptr(), 64, x.data_ptr(), None, 0)
+    assert rc != 0 and b"rope mode" in L.cllm_last_error()
+    rc = L.cllm_op_rope_kv_attn_decode(None, x.data_ptr(), pos.data_ptr(), None, 1e4, 65, 4, 2, 128, 0, kc.data_ptr(), kc.data_ptr(), 64, x.data_ptr(), None, 0)
+    assert rc != 0
+
+
 # ---- fused single-token patterns (cllm_op_mul_mat_vec_fused) == the node sequence they replace, to the bit ----------------------
 @pytest.mark.parametrize("t,K,N,pro", [(O.Q4_K, 4096, 512, 1), (O.Q4_K, 8192, 256, 1), (O.Q4_K, 14336, 256, 4), (O.Q4_K, 29440, 128, 4),
                                        (O.Q8_0, 29568, 128, 4), (O.Q4_0, 4096, 384, 1), (O.Q8_0, 2048, 100, 2), (O.Q4_K, 256, 33, 4)])
@@ -360,6 +417,39 @@ def test_mul_mat_vec_fused_equals_the_node_sequence(gpu, t, K, N, pro):
     want = ops.add(ops.mul_mat(w, act), r).numpy()
     out = T(gpu.F32, [N, 1])
     cw = w.c()
-    gpu.lib.check(gpu.lib.get().cllm_op_mul_mat_vec_fused(None, C.byref(cw), pro, x.data_ptr(), g.data_ptr() if pro != 2 else None, 1e-5,
+    gpu.lib.check(gpu.lib.get().cllm_op_mul_mat_vec_fused(None, C.byref(cw), pro, x.data_ptr(), g.data_ptr() if pro != 2 else None, 1e-5, 0,
                                                            r.data_ptr(), out.data_ptr()), "fused")
     assert np.array_equal(out.numpy(), want)
+
+
+@pytest.mark.parametrize("t,K,F", [(O.Q4_K, 4096, 14336), (O.Q4_0, 4096, 512), (O.Q8_0, 1024, 264), (O.Q4_K, 256, 512)])
+def test_packed_rows_merge_mat_vecs_without_changing_a_bit(gpu, t, K, F):
+    """cllm_pack_rows + one launch == the separate launches: q|k|v concatenated; gate/up interleaved with the SiLU*up epilogue"""
+    ops, T, L = gpu.ops, gpu.Tensor, gpu.lib.get()
+    rb = O.row_size(t, K) if hasattr(O, "row_size") else L.cllm_row_size(t, K)
+    x = T.from_numpy(rng.standard_normal((1, K)).astype(np.float32))
+    g = T.from_numpy((1 + 0.1 * rng.standard_normal(K)).astype(np.float32))
+    act = ops.rms_norm_mul(x, g, 1e-5)
+
+    def fused(w, nrows, epi, n_out):
+        out = T(gpu.F32, [n_out, 1])
+        cw = T(t, [K, nrows], buf=w.buf).c()
+        gpu.lib.check(L.cllm_op_mul_mat_vec_fused(None, C.byref(cw), 1, x.data_ptr(), g.data_ptr(), 1e-5, epi, None, out.data_ptr()), "fused")
+        return out.numpy().reshape(n_out)
+
+    def pack(ws, interleave):
+        rows = [w.ne[1] for w in ws]
+        dst = T(t, [K, sum(rows)])
+        srcs = (C.c_void_p * len(ws))(*[w.data_ptr().value for w in ws])
+        nr = (C.c_int64 * len(ws))(*rows)
+        gpu.lib.check(L.cllm_pack_rows(None, dst.data_ptr(), srcs, nr, len(ws), rb, interleave), "pack")
+        return dst
+
+    # q | k | v
+    ws = [T.from_numpy(rand_blocks(t, n, K, rng), t, [K, n]) for n in (F // 2, 64, 64)]
+    want = np.concatenate([ops.mul_mat(w, act).numpy().reshape(-1) for w in ws])
+    assert np.array_equal(fused(pack(ws, 0), F // 2 + 128, 0, F // 2 + 128).view(np.uint32), want.view(np.uint32))
+    # gate / up -> silu(gate) * up
+    wg, wu = (T.from_numpy(rand_blocks(t, F, K, rng), t, [K, F]) for _ in range(2))
+    want = ops.mul(ops.silu(ops.mul_mat(wg, act)), ops.mul_mat(wu, act)).numpy().reshape(-1)
+    assert np.array_equal(fused(pack([wg, wu], 1), 2 * F, 1, F).view(np.uint32), want.view(np.uint32))
