@@ -29,7 +29,7 @@ sys.path.insert(0, ROOT)
 import __graft_entry__ as ge  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
-WTYPES = {"q4_k": 12, "q4_0": 2, "q8_0": 8}
+WTYPES = {"q4_k": 12, "q4_0": 2, "q4_1": 3, "q8_0": 8}
 
 
 def log(*a):

@@ -29,14 +29,14 @@ extern "C" size_t cllm_type_size(int type) {
         case CLLM_TYPE_F32: case CLLM_TYPE_I32: return 4;
         case CLLM_TYPE_F16: return 2;
         case CLLM_TYPE_I64: return 8;
-        case CLLM_TYPE_Q4_0: return 18; case CLLM_TYPE_Q8_0: return 34; case CLLM_TYPE_Q4_K: return 144;
+        case CLLM_TYPE_Q4_0: return 18; case CLLM_TYPE_Q4_1: return 20; case CLLM_TYPE_Q8_0: return 34; case CLLM_TYPE_Q4_K: return 144;
     }
     return 0;
 }
 extern "C" int cllm_blck_size(int type) {
     switch (type) {
         case CLLM_TYPE_F32: case CLLM_TYPE_I32: case CLLM_TYPE_F16: case CLLM_TYPE_I64: return 1;
-        case CLLM_TYPE_Q4_0: case CLLM_TYPE_Q8_0: return 32;
+        case CLLM_TYPE_Q4_0: case CLLM_TYPE_Q4_1: case CLLM_TYPE_Q8_0: return 32;
         case CLLM_TYPE_Q4_K: return 256;
     }
     return 0;
@@ -139,8 +139,8 @@ extern "C" int cllm_event_elapsed_ms(void * start, void * stop, float * ms) {
 }
 
 // ---- MUL_MAT dispatch ---------------------------------------------------------------------------------------------
-static bool is_quant(int t) { return t == CLLM_TYPE_Q4_0 || t == CLLM_TYPE_Q8_0 || t == CLLM_TYPE_Q4_K; }
-static int  act_kind(int wtype) { return wtype == CLLM_TYPE_Q4_K ? 256 : 32; }
+static bool is_quant(int t) { return is_quant_type(t); }
+static int  act_kind(int wtype) { return act_kind_of(wtype); }
 
 static int mmq_min_cols() {
     static int v = -1;
@@ -160,6 +160,7 @@ static int check_mm(const cllm_tensor * src0, const cllm_tensor * src1, const cl
     if (src0->ne[0] != src1->ne[0]) FAIL(CLLM_E_INVALID, "%s: K mismatch %lld vs %lld", name, (long long) src0->ne[0], (long long) src1->ne[0]);
     if (src0->nb[0] != cllm_type_size(src0->type) || src1->nb[0] != 4 || dst->nb[0] != 4) FAIL(CLLM_E_UNSUPPORTED, "%s: rows must be dense", name);
     if (src0->ne[0] % cllm_blck_size(src0->type)) FAIL(CLLM_E_INVALID, "%s: K not a multiple of the block size", name);
+    if (src0->type == CLLM_TYPE_Q4_1 && ((uintptr_t) src0->data % 4 || src0->nb[1] % 4 || src0->nb[2] % 4 || src0->nb[3] % 4)) FAIL(CLLM_E_UNSUPPORTED, "%s: Q4_1 rows must be 4-byte aligned", name);
     return CLLM_OK;
 }
 
@@ -185,7 +186,7 @@ extern "C" int cllm_op_mul_mat(void * stream, const cllm_tensor * src0, const cl
         FAIL(CLLM_E_UNSUPPORTED, "mul_mat: Q4_K rows must be 16-byte aligned");
     // a single dense activation column (decode): quantize it inside the mat-vec (one launch instead of two; the decode kernels)
     if (src1->ne[1] == 1 && src1->ne[2] == 1 && src1->ne[3] == 1 && src0->ne[2] == 1 && src0->ne[3] == 1 && src1->nb[0] == 4 && dst->nb[0] == 4 &&
-        src0->nb[1] == cllm_row_size(src0->type, K) && K % kind == 0 && act_row_bytes(K, kind) <= 160 * 1024) {
+        src0->nb[1] == cllm_row_size(src0->type, K) && K % act_blk(kind) == 0 && act_row_bytes(K, kind) <= 160 * 1024) {
         rc = launch_gemv_decode(st, src0->type, src0->data, K, src0->ne[1], 2, (const float *) src1->data, nullptr, 0.0f, 0, (float *) dst->data, nullptr, nullptr);
         if (rc != CLLM_E_UNSUPPORTED) return rc;          // very long rows: the two-launch path below
     }
@@ -334,7 +335,7 @@ extern "C" int cllm_op_mul_mat_id(void * stream, const cllm_tensor * as, const c
     int rc = check_mm(as, b, dst, "mul_mat_id");
     if (rc) return rc;
     if (!ids || ids->type != CLLM_TYPE_I32) FAIL(CLLM_E_INVALID, "mul_mat_id: ids must be I32");
-    if (!is_quant(as->type)) FAIL(CLLM_E_UNSUPPORTED, "mul_mat_id: expert weights must be Q4_0/Q8_0/Q4_K");
+    if (!is_quant(as->type)) FAIL(CLLM_E_UNSUPPORTED, "mul_mat_id: expert weights must be Q4_0/Q4_1/Q8_0/Q4_K");
     const int64_t n_used = ids->ne[0], n_tok = ids->ne[1];
     if (as->ne[3] != 1 || b->ne[3] != 1 || dst->ne[3] != 1 || ids->ne[2] != 1 || ids->ne[3] != 1) FAIL(CLLM_E_INVALID, "mul_mat_id: 4-D operands");
     if (dst->ne[0] != as->ne[1] || dst->ne[1] != n_used || dst->ne[2] != n_tok || b->ne[2] != n_tok) FAIL(CLLM_E_INVALID, "mul_mat_id: shapes");

@@ -22,8 +22,11 @@ int  cllm_hip_check(hipError_t e, const char * what, const char * file, int line
 #define QK_K  256
 struct __attribute__((packed)) block_q4_0 { uint16_t d; uint8_t qs[16]; };                       // 18 B
 struct __attribute__((packed)) block_q8_0 { uint16_t d; int8_t  qs[32]; };                       // 34 B
+struct __attribute__((packed)) block_q4_1 { uint16_t d, m; uint8_t qs[16]; };                    // 20 B: w = nib * d + m
+struct __attribute__((packed)) block_q8_1 { uint16_t d, s; int8_t  qs[32]; };                    // 36 B: s = d * sum(qs)
 struct __attribute__((packed)) block_q4_K { uint16_t d, dmin; uint8_t scales[12]; uint8_t qs[128]; }; // 144 B
 struct __attribute__((packed)) block_q8_K { float d; int8_t qs[256]; int16_t bsums[16]; };      // 292 B
+static_assert(sizeof(block_q4_1) == 20 && sizeof(block_q8_1) == 36, "block sizes");
 static_assert(sizeof(block_q4_0) == 18 && sizeof(block_q8_0) == 34 && sizeof(block_q4_K) == 144 && sizeof(block_q8_K) == 292, "block sizes");
 
 // ---- device-side activation layout ("act row") -------------------------------------------------
@@ -32,11 +35,18 @@ static_assert(sizeof(block_q4_0) == 18 && sizeof(block_q8_0) == 34 && sizeof(blo
 // wave can fetch 16-byte aligned pieces:
 //   Q8_0 kind (for Q4_0/Q8_0 weights):  qs[K] int8 | d[K/32] f32 (= fp16-rounded scale) | s[K/32] int32 (sum of qs)
 //   Q8_K kind (for Q4_K weights):       qs[K] int8 | d[K/256] f32                      | s[K/32] int32 (sum per 32)
-// Each plane starts 16-byte aligned; act_row_bytes() is the per-row stride.
+//   Q8_1 kind (for Q4_1 weights):       the Q8_0 planes, but s[K/32] is an f32: fp16(d_unrounded * sum of qs), block_q8_1::s
+// Each plane starts 16-byte aligned; act_row_bytes() is the per-row stride.  A "kind" is the quantization block size (32 / 256);
+// ACT_Q8_1 names the third flavour and maps to block size 32.
+enum { ACT_Q8_0 = 32, ACT_Q8_K = 256, ACT_Q8_1 = 33 };
+__host__ __device__ inline int    act_blk(int kind) { return kind == ACT_Q8_1 ? 32 : kind; }
 __host__ __device__ inline size_t act_align16(size_t x) { return (x + 15) & ~(size_t) 15; }
 __host__ __device__ inline size_t act_off_d(int64_t K) { return act_align16((size_t) K); }
-__host__ __device__ inline size_t act_off_s(int64_t K, int kind_blk) { return act_off_d(K) + act_align16((size_t)(K / kind_blk) * 4); }
-__host__ __device__ inline size_t act_row_bytes(int64_t K, int kind_blk) { return act_off_s(K, kind_blk) + act_align16((size_t)(K / 32) * 4); }
+__host__ __device__ inline size_t act_off_s(int64_t K, int kind) { return act_off_d(K) + act_align16((size_t)(K / act_blk(kind)) * 4); }
+__host__ __device__ inline size_t act_row_bytes(int64_t K, int kind) { return act_off_s(K, kind) + act_align16((size_t)(K / 32) * 4); }
+// the activation format a weight type's dot product reads (type_traits_cpu[].vec_dot_type, ggml-cpu/ggml-cpu.c:207-390)
+__host__ __device__ inline int    act_kind_of(int wtype) { return wtype == CLLM_TYPE_Q4_K ? ACT_Q8_K : wtype == CLLM_TYPE_Q4_1 ? ACT_Q8_1 : ACT_Q8_0; }
+__host__ __device__ inline bool   is_quant_type(int t) { return t == CLLM_TYPE_Q4_0 || t == CLLM_TYPE_Q4_1 || t == CLLM_TYPE_Q8_0 || t == CLLM_TYPE_Q4_K; }
 
 // ---- small device helpers -----------------------------------------------------------------------
 #ifdef __HIPCC__
@@ -228,7 +238,7 @@ static inline tview tv(const cllm_tensor * t) {
 }
 
 // internal launchers (implemented across the .hip files)
-int launch_quantize_act(hipStream_t st, int kind_blk /*32 or 256*/, const tview & src1, void * act, size_t act_stride);
+int launch_quantize_act(hipStream_t st, int kind /* ACT_Q8_0 | ACT_Q8_K | ACT_Q8_1 */, const tview & src1, void * act, size_t act_stride);
 int launch_mmvq(hipStream_t st, int wtype, const tview & w, const void * act, size_t act_stride, int64_t ncols_total,
                 const tview & src1_geom, const tview & dst);
 int launch_mmvq_id(hipStream_t st, int wtype, const tview & as, const void * act, size_t act_stride, int64_t b_ne1, const tview & ids, const tview & dst);

@@ -246,9 +246,9 @@ static int finalize(cllm_llama * m, int qlen) {
         for (const llama_layer & L : m->layers) {
             if (!L.wqkv.data || !L.wgu.data) m->fused_ok = false;
             else if (F % (L.wdown.type == CLLM_TYPE_Q4_K ? 256 : 32)) m->fused_ok = false;
-            for (const dweight * w : { &L.wqkv, &L.wo, &L.wgu, &L.wdown }) if (w->data && w->type != CLLM_TYPE_Q4_K && w->type != CLLM_TYPE_Q4_0 && w->type != CLLM_TYPE_Q8_0) m->fused_ok = false;
+            for (const dweight * w : { &L.wqkv, &L.wo, &L.wgu, &L.wdown }) if (w->data && !is_quant_type(w->type)) m->fused_ok = false;
         }
-        if (m->lm_head.type != CLLM_TYPE_Q4_K && m->lm_head.type != CLLM_TYPE_Q4_0 && m->lm_head.type != CLLM_TYPE_Q8_0) m->fused_ok = false;
+        if (!is_quant_type(m->lm_head.type)) m->fused_ok = false;
         m->finalized = true;
     }
     if (qlen > m->maxq) {
@@ -405,7 +405,6 @@ extern "C" int cllm_llama_forward(cllm_llama * m, const int32_t * tokens, int ql
 }
 
 // ---- fused single-token step: 10 launches per layer, every per-token input read from device memory ----------------------
-static int kind_of(int wtype) { return wtype == CLLM_TYPE_Q4_K ? 256 : 32; }
 
 // cached positions above which the split attention (three launches, every CU) beats the one-launch kernel (one CU per head)
 int attn_long_threshold() { static const int v = getenv("CLLM_ATTN_LONG") ? atoi(getenv("CLLM_ATTN_LONG")) : 512; return v < 512 ? 512 : v; }   // (V.P there assumes the 64-lane regime: >= 512)

@@ -1,4 +1,4 @@
-// gemv_decode.hip -- the decode step's quantized mat-vec (Q4_K / Q4_0 / Q8_0 weights): one activation column, produced inside the kernel.
+// gemv_decode.hip -- the decode step's quantized mat-vec (Q4_K / Q4_0 / Q4_1 / Q8_0 weights): one activation column, produced inside the kernel.
 //
 //   prologue PRO 1: act = quantize_q8_K(RMS_NORM(px) * pw)     (LMBlock1Forward: input_layernorm / post_attention_layernorm -> Linear)
 //            PRO 2: act = quantize_q8_K(px)                    (attention output -> o_proj, SiLU*up -> down_proj)
@@ -35,8 +35,8 @@ __device__ __forceinline__ float silu_any(float x, bool body) { return body ? si
 
 #define TS(k) do { if (ts && threadIdx.x == 0) ts[blockIdx.x * 8 + (k)] = wall_clock64(); } while (0)
 
-// FMT: CLLM_TYPE_Q4_K (8 lanes per 144-byte super-block, activation quantized to Q8_K) or CLLM_TYPE_Q4_0 / Q8_0 (one lane per
-// 18 / 34-byte block, activation quantized to Q8_0).  nblk = weight blocks per row.
+// FMT: CLLM_TYPE_Q4_K (8 lanes per 144-byte super-block, activation quantized to Q8_K) or CLLM_TYPE_Q4_0 / Q4_1 / Q8_0 (one lane per
+// 18 / 20 / 34-byte block, activation quantized to Q8_0 / Q8_1).  nblk = weight blocks per row.
 template <int FMT, int PRO, int EPI, int NPRE>
 __global__ void __launch_bounds__(1024) k_gemv_dec(const float * __restrict__ px, const float * __restrict__ pw, const float * __restrict__ padd,
                                                         const char * __restrict__ W, int nblk, int kfull, int nrem, float eps,
@@ -44,9 +44,9 @@ __global__ void __launch_bounds__(1024) k_gemv_dec(const float * __restrict__ px
                                                         const float * __restrict__ bias, const float * resid, unsigned long long * ts) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     constexpr int P = 2, RU = EPI == 1 ? 2 : 1;
-    constexpr bool IS_K = FMT == CLLM_TYPE_Q4_K, IS_Q8 = FMT == CLLM_TYPE_Q8_0;
+    constexpr bool IS_K = FMT == CLLM_TYPE_Q4_K, IS_Q8 = FMT == CLLM_TYPE_Q8_0, IS_Q41 = FMT == CLLM_TYPE_Q4_1;
     constexpr int KIND = IS_K ? 256 : 32;                           // elements per weight block = activation quantization block
-    constexpr int BS = IS_K ? 144 : IS_Q8 ? 34 : 18;                // bytes per weight block
+    constexpr int BS = IS_K ? 144 : q32_fmt<IS_K ? CLLM_TYPE_Q4_0 : FMT>::BS;      // bytes per weight block
     constexpr int BPS = IS_K ? 8 : 64;                              // blocks a wave consumes per step
     const int tid = threadIdx.x, lane = tid & 63;
     const int K = nblk * KIND;
@@ -93,10 +93,9 @@ __global__ void __launch_bounds__(1024) k_gemv_dec(const float * __restrict__ px
             hh[p] = *(const u32x4 *) bp;
             qq[p] = *(const u32x4 *)(bp + 16 + 16 * j);
         } else {
-            hh[p].x = *(const uint16_t *) bp;
-            const u16x8_u2 r0 = *(const u16x8_u2 *)(bp + 2);
-            qq[p] = u32x4{r0.x, r0.y, r0.z, r0.w};
-            if (IS_Q8) { const u16x8_u2 r1 = *(const u16x8_u2 *)(bp + 18); q2[IS_Q8 ? p : 0] = u32x4{r1.x, r1.y, r1.z, r1.w}; }
+            uint32_t h;
+            q32_load<IS_K ? CLLM_TYPE_Q4_0 : FMT>(bp, h, qq[p], q2[IS_Q8 ? p : 0]);
+            hh[p].x = h;
         }
         if (++is == S) { is = 0; if (++isub == RU) { isub = 0; ik++; } }
     };
@@ -131,7 +130,7 @@ __global__ void __launch_bounds__(1024) k_gemv_dec(const float * __restrict__ px
                 v.x = silu_any(v.x, e + 0 < nv) * g.x; v.y = silu_any(v.y, e + 1 < nv) * g.y; v.z = silu_any(v.z, e + 2 < nv) * g.z; v.w = silu_any(v.w, e + 3 < nv) * g.w;
             }
             if (PRO == 1) { const f32x4 g = gg[u]; v.x = (v.x * scale) * g.x; v.y = (v.y * scale) * g.y; v.z = (v.z * scale) * g.z; v.w = (v.w * scale) * g.w; }
-            quant4_store<KIND>(lds, K, e, lane, v);
+            quant4_store<KIND, IS_Q41>(lds, K, e, lane, v);
         }
     }
     TS(2);
@@ -140,7 +139,7 @@ __global__ void __launch_bounds__(1024) k_gemv_dec(const float * __restrict__ px
 
     // ---- (4) stream the rows ----
     const q4k_sel L = q4k_lane_sel(lane);
-    const int off_d = (int) act_off_d(K), off_s = (int) act_off_s(K, KIND);
+    const int off_d = (int) act_off_d(K), off_s = (int) act_off_s(K, KIND);      // (the Q8_1 flavour has the Q8_0 geometry)
     float accd = 0.0f, accm = 0.0f, gate = 0.0f;
     int ck = 0, csub = 0, cs = 0;                                   // consume cursor
     while (ck < nmine) {
@@ -149,7 +148,7 @@ __global__ void __launch_bounds__(1024) k_gemv_dec(const float * __restrict__ px
             const int b = IS_K ? 8 * cs + grp : 64 * cs + lane;
             const bool ok = ck < nmine && b < nblk;
             if (IS_K) q4k_step(hh[p], qq[p], lds, off_d, off_s, ok ? b : 0, ok, L, accd, accm);
-            else      q32_step<IS_Q8>(hh[p].x, qq[p], q2[IS_Q8 ? p : 0], lds, off_d, off_s, ok ? b : 0, ok, accd);
+            else      q32_step<IS_K ? CLLM_TYPE_Q4_0 : FMT>(hh[p].x, qq[p], q2[IS_Q8 ? p : 0], lds, off_d, off_s, ok ? b : 0, ok, accd);
             issue(p);
             if (++cs == S) {                                        // row complete: reduce over the wave, epilogue, store
                 float v = IS_K ? wave_sum(accd) - wave_sum(accm) : wave_sum(accd);
@@ -179,7 +178,7 @@ __global__ void __launch_bounds__(1024) k_gemv_dec(const float * __restrict__ px
 int launch_gemv_decode(hipStream_t st, int wtype, const void * W, int64_t K, int64_t nrows, int pro, const float * px, const float * pw, float eps,
                        int epi, float * dst, const float * bias, const float * resid, const float * padd, float * xout) {
     const int kind = wtype == CLLM_TYPE_Q4_K ? 256 : 32;
-    if (wtype != CLLM_TYPE_Q4_K && wtype != CLLM_TYPE_Q4_0 && wtype != CLLM_TYPE_Q8_0) return CLLM_E_UNSUPPORTED;
+    if (!is_quant_type(wtype)) return CLLM_E_UNSUPPORTED;
     if (K % kind || K > ((pro == 2 || pro == 4) ? 32768 : 16384) || pro < 1 || pro > 4 || nrows <= 0 || (uint64_t) nrows * (uint64_t) cllm_row_size(wtype, K) >= (1ull << 32)) return CLLM_E_UNSUPPORTED;
     if (act_row_bytes(K, kind) > 160 * 1024) return CLLM_E_UNSUPPORTED;
     if (padd && (pro != 1 || K > 4096 || !xout || xout == px)) return CLLM_E_UNSUPPORTED;
@@ -201,7 +200,7 @@ int launch_gemv_decode(hipStream_t st, int wtype, const void * W, int64_t K, int
         else if (pro == 2)        { if (npre == 1) GO3(FMT_, 2, 0, 1); else if (npre == 4) GO3(FMT_, 2, 0, 4); else GO3(FMT_, 2, 0, 8); } \
         else if (pro == 4)        { if (npre == 1) GO3(FMT_, 4, 0, 1); else if (npre == 4) GO3(FMT_, 4, 0, 4); else GO3(FMT_, 4, 0, 8); } \
         else                      { if (npre == 1) GO3(FMT_, 3, 0, 1); else GO3(FMT_, 3, 0, 4); } } while (0)
-    if (wtype == CLLM_TYPE_Q4_K) GO(CLLM_TYPE_Q4_K); else if (wtype == CLLM_TYPE_Q4_0) GO(CLLM_TYPE_Q4_0); else GO(CLLM_TYPE_Q8_0);
+    if (wtype == CLLM_TYPE_Q4_K) GO(CLLM_TYPE_Q4_K); else if (wtype == CLLM_TYPE_Q4_0) GO(CLLM_TYPE_Q4_0); else if (wtype == CLLM_TYPE_Q4_1) GO(CLLM_TYPE_Q4_1); else GO(CLLM_TYPE_Q8_0);
 #undef GO
 #undef GO3
     LAUNCH_CHECK();

@@ -29,6 +29,7 @@ template <int TYPE> struct mmq_traits;
 template <> struct mmq_traits<CLLM_TYPE_Q4_K> { static constexpr int kb = 256, MI = 2; };
 template <> struct mmq_traits<CLLM_TYPE_Q4_0> { static constexpr int kb = 32,  MI = 4; };
 template <> struct mmq_traits<CLLM_TYPE_Q8_0> { static constexpr int kb = 32,  MI = 4; };
+template <> struct mmq_traits<CLLM_TYPE_Q4_1> { static constexpr int kb = 32,  MI = 2; };      // two more scale planes and operands per patch: 64 tokens
 
 struct mmq_args {
     const char * W; int64_t nb01; int64_t N; int64_t K;
@@ -39,14 +40,13 @@ struct mmq_args {
 // LDS map (bytes)
 //   Wt  : MMQ_BN * MMQ_LD                    int8 weights
 //   Xt  : MMQ_BM * MMQ_LD                    int8 activations
-//   Wsc : Q4_K: sc[n][8] u8 | mn[n][8] u8 | d[n] f32 | dmin[n] f32       others: dw[8][n] f32
-//   Xsc : Q4_K: dx[m] f32 | sx[8][m] i32                                   others: dx[8][m] f32
+//   Wsc : Q4_K: sc[n][8] u8 | mn[n][8] u8 | d[n] f32 | dmin[n] f32       others: dw[8][n] f32 [Q4_1: | mw[8][n] f32]
+//   Xsc : Q4_K: dx[m] f32 | sx[8][m] i32                                   others: dx[8][m] f32 [Q4_1: | sx[8][m] f32]
 constexpr int LDS_WT = 0;
 constexpr int LDS_XT = LDS_WT + MMQ_BN * MMQ_LD;
-constexpr int LDS_WS_BYTES = MMQ_BN * 8 * 4;                 // 4 KB either way (Q4_K uses 8+8+4+4 = 24 B per row)
 constexpr int lds_ws(int bm) { return LDS_XT + bm * MMQ_LD; }
-constexpr int lds_xs(int bm) { return lds_ws(bm) + LDS_WS_BYTES; }
-constexpr int lds_total(int bm) { return lds_xs(bm) + bm * 9 * 4; }
+constexpr int lds_xs(int bm, bool q41) { return lds_ws(bm) + MMQ_BN * (q41 ? 16 : 8) * 4; }      // 4 KB (Q4_K uses 8+8+4+4 = 24 B per row), Q4_1: 8 KB
+constexpr int lds_total(int bm, bool q41) { return lds_xs(bm, q41) + bm * (q41 ? 16 : 9) * 4; }   // two workgroups per CU must fit 160 KB
 
 __device__ __forceinline__ uint32_t nib_minus8(uint32_t nib4) {   // four nibbles (one per byte, 0..15) -> four int8 (nib - 8)
     return (((nib4 | 0x80808080u) - 0x08080808u) ^ 0x80808080u);
@@ -55,9 +55,9 @@ __device__ __forceinline__ uint32_t nib_minus8(uint32_t nib4) {   // four nibble
 template <int TYPE>
 __global__ void __launch_bounds__(256, 2) k_mmq(const mmq_args a) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
-    constexpr bool IS_K = TYPE == CLLM_TYPE_Q4_K;
+    constexpr bool IS_K = TYPE == CLLM_TYPE_Q4_K, IS_41 = TYPE == CLLM_TYPE_Q4_1;
     constexpr int MMQ_MI = mmq_traits<TYPE>::MI, MMQ_BM = 32 * MMQ_MI;
-    constexpr int LDS_WS = lds_ws(MMQ_BM), LDS_XS = lds_xs(MMQ_BM);
+    constexpr int LDS_WS = lds_ws(MMQ_BM), LDS_XS = lds_xs(MMQ_BM, TYPE == CLLM_TYPE_Q4_1);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t m0 = (int64_t) blockIdx.x * MMQ_BM, n0 = (int64_t) blockIdx.y * MMQ_BN;
     const int wn = (wave & 1) * 64, wm = (wave >> 1) * (MMQ_MI * 16);       // this wave's quadrant inside the tile
@@ -65,7 +65,7 @@ __global__ void __launch_bounds__(256, 2) k_mmq(const mmq_args a) {
 
     char * Wt = lds + LDS_WT; char * Xt = lds + LDS_XT; char * Ws = lds + LDS_WS; char * Xs = lds + LDS_XS;
     const int64_t K = a.K;
-    const int64_t act_d = (int64_t) act_off_d(K), act_s = (int64_t) act_off_s(K, mmq_traits<TYPE>::kb);
+    const int64_t act_d = (int64_t) act_off_d(K), act_s = (int64_t) act_off_s(K, mmq_traits<TYPE>::kb);      // (Q8_1 flavour: Q8_0 geometry)
 
     float acc_f[MMQ_MI][4][4];                                         // [m patch][n patch][r]
 #pragma unroll
@@ -77,12 +77,12 @@ __global__ void __launch_bounds__(256, 2) k_mmq(const mmq_args a) {
 
     // ---- staging is split in two: global -> registers (issued one K step ahead, so the loads fly during the MFMA work of the
     //      current step) and registers -> LDS (unpack + store, between the two barriers of a step) ----
-    constexpr int BS = TYPE == CLLM_TYPE_Q8_0 ? 34 : 18;
+    constexpr int BS = TYPE == CLLM_TYPE_Q8_0 ? 34 : IS_41 ? 20 : 18, QOFF = IS_41 ? 4 : 2;      // block bytes, offset of the quants
     struct __attribute__((packed, aligned(2))) q16 { uint32_t x, y, z, w; };
     constexpr int NXA = MMQ_BM * 16 / 256;                         // activation chunk tasks per thread
-    constexpr int NXS = IS_K ? (MMQ_BM * 9 + 255) / 256 : MMQ_BM * 8 / 256;      // activation scale tasks per thread
+    constexpr int NXS = IS_K ? (MMQ_BM * 9 + 255) / 256 : MMQ_BM * (IS_41 ? 16 : 8) / 256;      // activation scale tasks per thread
     constexpr int NWT = IS_K ? 5 : 4;                              // weight tasks per thread
-    u32x4 rx[NXA]; uint32_t rxs[NXS]; u32x4 rw[NWT]; u32x4 rw2[IS_K ? 1 : 4]; float rwd[IS_K ? 1 : 4];
+    u32x4 rx[NXA]; uint32_t rxs[NXS]; u32x4 rw[NWT]; u32x4 rw2[IS_K ? 1 : 4]; float rwd[IS_K ? 1 : 4]; float rwm[IS_41 ? 4 : 1];
     auto prefetch = [&](int64_t k0) {
 #pragma unroll
         for (int t = 0; t < NXA; t++) {                            // activations: MMQ_BM rows x 256 int8 (16 chunks of 16 B per row)
@@ -104,10 +104,10 @@ __global__ void __launch_bounds__(256, 2) k_mmq(const mmq_args a) {
                         rxs[t] = f == 0 ? *(const uint32_t *)(ar + act_d + (k0 / 256) * 4) : *(const uint32_t *)(ar + act_s + ((k0 / 32) + (f - 1)) * 4);
                     }
                 }
-            } else {                                               // dx[8][m]
-                const int row = c % MMQ_BM, sb = c / MMQ_BM;
+            } else {                                               // dx[8][m] (Q4_1: then sx[8][m], the f32 s plane)
+                const int row = c % MMQ_BM, pl = c / MMQ_BM, sb = pl & 7;
                 const int64_t m = m0 + row;
-                if (m < a.M && k0 + sb * 32 < K) rxs[t] = *(const uint32_t *)(a.act + m * a.act_stride + act_d + ((k0 / 32) + sb) * 4);
+                if (m < a.M && k0 + sb * 32 < K) rxs[t] = *(const uint32_t *)(a.act + m * a.act_stride + (pl < 8 ? act_d : act_s) + ((k0 / 32) + sb) * 4);
             }
         }
 #pragma unroll
@@ -123,11 +123,12 @@ __global__ void __launch_bounds__(256, 2) k_mmq(const mmq_args a) {
             } else {                                               // one 32-block per task
                 const int row = c >> 3, sb = c & 7;
                 const int64_t n = n0 + row, b = k0 / 32 + sb;
-                rwd[IS_K ? 0 : t] = 0.0f; rw2[IS_K ? 0 : t] = u32x4{0, 0, 0, 0};
+                rwd[IS_K ? 0 : t] = 0.0f; rw2[IS_K ? 0 : t] = u32x4{0, 0, 0, 0}; if (IS_41) rwm[IS_41 ? t : 0] = 0.0f;
                 if (n < a.N && b * 32 < K) {
                     const char * bp = a.W + n * a.nb01 + b * BS;
                     rwd[IS_K ? 0 : t] = h2f(*(const uint16_t *) bp);
-                    const q16 q0 = *(const q16 *)(bp + 2);
+                    if (IS_41) rwm[IS_41 ? t : 0] = h2f(*(const uint16_t *)(bp + 2));
+                    const q16 q0 = *(const q16 *)(bp + QOFF);
                     rw[t] = u32x4{q0.x, q0.y, q0.z, q0.w};
                     if (TYPE == CLLM_TYPE_Q8_0) { const q16 q1 = *(const q16 *)(bp + 18); rw2[IS_K ? 0 : t] = u32x4{q1.x, q1.y, q1.z, q1.w}; }
                 }
@@ -171,13 +172,17 @@ __global__ void __launch_bounds__(256, 2) k_mmq(const mmq_args a) {
                 const u32x4 q0 = rw[t];
                 u32x4 lo, hi;
                 if (TYPE == CLLM_TYPE_Q8_0) { lo = q0; hi = rw2[IS_K ? 0 : t]; }
-                else {
+                else if (IS_41) {                                  // nibbles stay 0..15: the minimum comes in through m_w * s_x
+                    lo = u32x4{q0.x & 0x0f0f0f0fu, q0.y & 0x0f0f0f0fu, q0.z & 0x0f0f0f0fu, q0.w & 0x0f0f0f0fu};
+                    hi = u32x4{(q0.x >> 4) & 0x0f0f0f0fu, (q0.y >> 4) & 0x0f0f0f0fu, (q0.z >> 4) & 0x0f0f0f0fu, (q0.w >> 4) & 0x0f0f0f0fu};
+                } else {
                     lo = u32x4{nib_minus8(q0.x & 0x0f0f0f0fu), nib_minus8(q0.y & 0x0f0f0f0fu), nib_minus8(q0.z & 0x0f0f0f0fu), nib_minus8(q0.w & 0x0f0f0f0fu)};
                     hi = u32x4{nib_minus8((q0.x >> 4) & 0x0f0f0f0fu), nib_minus8((q0.y >> 4) & 0x0f0f0f0fu), nib_minus8((q0.z >> 4) & 0x0f0f0f0fu), nib_minus8((q0.w >> 4) & 0x0f0f0f0fu)};
                 }
                 *(u32x4 *)(Wt + row * MMQ_LD + sb * 32)      = lo;
                 *(u32x4 *)(Wt + row * MMQ_LD + sb * 32 + 16) = hi;
                 *(float *)(Ws + (sb * MMQ_BN + row) * 4) = rwd[IS_K ? 0 : t];       // dw[8][n]
+                if (IS_41) *(float *)(Ws + ((8 + sb) * MMQ_BN + row) * 4) = rwm[IS_41 ? t : 0];      // mw[8][n]
             }
         }
     };
@@ -236,6 +241,19 @@ __global__ void __launch_bounds__(256, 2) k_mmq(const mmq_args a) {
 #pragma unroll
                         for (int r = 0; r < 4; r++) acc_f[i][j][r] = __builtin_fmaf((float) d[r], dw[j] * dx[i][r], acc_f[i][j][r]);
                     }
+                if (IS_41) {                                       // + m_w[n][s] * s_x[m][s]  (ggml_vec_dot_q4_1_q8_1, quants.c:182)
+                    float mw[4]; f32x4 sx[MMQ_MI];
+#pragma unroll
+                    for (int j = 0; j < 4; j++) mw[j] = *(const float *)(Ws + ((8 + s) * MMQ_BN + wn + j * 16 + l15) * 4);
+#pragma unroll
+                    for (int i = 0; i < MMQ_MI; i++) sx[i] = *(const f32x4 *)(Xs + ((8 + s) * MMQ_BM + wm + i * 16 + l4 * 4) * 4);
+#pragma unroll
+                    for (int j = 0; j < 4; j++)
+#pragma unroll
+                        for (int i = 0; i < MMQ_MI; i++)
+#pragma unroll
+                            for (int r = 0; r < 4; r++) acc_f[i][j][r] = __builtin_fmaf(mw[j], sx[i][r], acc_f[i][j][r]);
+                }
             }
         }
         if (IS_K) {
@@ -289,13 +307,14 @@ int launch_mmq(hipStream_t st, int wtype, const tview & w, const void * act, siz
     a.dst = (float *) d.data; a.ldd = d.nb[1] / 4;
     if ((a.N + MMQ_BN - 1) / MMQ_BN > 65535) FAIL(CLLM_E_UNSUPPORTED, "mmq: too many row tiles");
 #define GO(T) do { static bool attr = false; \
-        constexpr int BM = 32 * mmq_traits<T>::MI, LDS = lds_total(BM); \
+        constexpr int BM = 32 * mmq_traits<T>::MI, LDS = lds_total(BM, T == CLLM_TYPE_Q4_1); \
         const dim3 grid((unsigned)((a.M + BM - 1) / BM), (unsigned)((a.N + MMQ_BN - 1) / MMQ_BN)); \
         if (!attr) { HIP_TRY(hipFuncSetAttribute((const void *) k_mmq<T>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS)); attr = true; } \
         hipLaunchKernelGGL(k_mmq<T>, grid, dim3(256), LDS, st, a); } while (0)
     if (wtype == CLLM_TYPE_Q4_K) GO(CLLM_TYPE_Q4_K);
     else if (wtype == CLLM_TYPE_Q4_0) GO(CLLM_TYPE_Q4_0);
     else if (wtype == CLLM_TYPE_Q8_0) GO(CLLM_TYPE_Q8_0);
+    else if (wtype == CLLM_TYPE_Q4_1) GO(CLLM_TYPE_Q4_1);
     else return CLLM_E_UNSUPPORTED;
 #undef GO
     LAUNCH_CHECK();

@@ -159,7 +159,7 @@ __global__ void __launch_bounds__(1024) k_mmvq_q4_K(const mmvq_args a) {
 
 // ---- Q4_0 / Q8_0 (one lane per 32-weight block) ------------------------------------------------------------
 
-template <int NC, bool IS_Q8>
+template <int NC, int FMT>
 __global__ void __launch_bounds__(1024) k_mmvq_q32(const mmvq_args a) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const char * W; const char * act; float * dst;
@@ -170,7 +170,7 @@ __global__ void __launch_bounds__(1024) k_mmvq_q32(const mmvq_args a) {
     stage_act(lds, act, a.act_stride, rb, NC);
     __syncthreads();
 
-    constexpr int BS = IS_Q8 ? 34 : 18;
+    constexpr int BS = q32_fmt<FMT>::BS;
     const int lane = threadIdx.x & 63;
     const int waves_per_wg = blockDim.x >> 6;
     const int64_t wave0 = (int64_t) blockIdx.x * waves_per_wg + (threadIdx.x >> 6);
@@ -186,13 +186,10 @@ __global__ void __launch_bounds__(1024) k_mmvq_q32(const mmvq_args a) {
             const int b = b0 + lane;
             if (b < nblk) {
                 const char * bp = wr + (int64_t) b * BS;
-                const uint32_t d16 = *(const uint16_t *) bp;
-                const u16x8_u2 r0 = *(const u16x8_u2 *)(bp + 2);
-                const u32x4 q0 = {r0.x, r0.y, r0.z, r0.w};
-                u32x4 q1 = {0, 0, 0, 0};
-                if constexpr (IS_Q8) { const u16x8_u2 r1 = *(const u16x8_u2 *)(bp + 18); q1 = u32x4{r1.x, r1.y, r1.z, r1.w}; }
+                uint32_t d16; u32x4 q0, q1 = {0, 0, 0, 0};
+                q32_load<FMT>(bp, d16, q0, q1);
 #pragma unroll
-                for (int c = 0; c < NC; c++) q32_step<IS_Q8>(d16, q0, q1, lds + c * rb, off_d, off_s, b, true, acc[c]);
+                for (int c = 0; c < NC; c++) q32_step<FMT>(d16, q0, q1, lds + c * rb, off_d, off_s, b, true, acc[c]);
             }
         }
 #pragma unroll
@@ -243,6 +240,9 @@ __global__ void k_isums(int wtype, int64_t K, const char * __restrict__ w, const
         if (wtype == CLLM_TYPE_Q8_0) {
             const block_q8_0 * x = (const block_q8_0 *) w + b;
             for (int l = 0; l < 32; l++) s += x->qs[l] * aq[b * 32 + l];
+        } else if (wtype == CLLM_TYPE_Q4_1) {
+            const block_q4_1 * x = (const block_q4_1 *) w + b;
+            for (int l = 0; l < 16; l++) { s += (x->qs[l] & 0xF) * aq[b * 32 + l]; s += (x->qs[l] >> 4) * aq[b * 32 + l + 16]; }
         } else {
             const block_q4_0 * x = (const block_q4_0 *) w + b;
             for (int l = 0; l < 16; l++) { s += ((x->qs[l] & 0xF) - 8) * aq[b * 32 + l]; s += ((x->qs[l] >> 4) - 8) * aq[b * 32 + l + 16]; }
@@ -254,13 +254,13 @@ __global__ void k_isums(int wtype, int64_t K, const char * __restrict__ w, const
 extern "C" int cllm_vec_dot_isums(void * stream, int wtype, int64_t k, const void * w_row, const float * x, int32_t * isums) {
     hipStream_t st = (hipStream_t) stream;
     const int kb = wtype == CLLM_TYPE_Q4_K ? 256 : 32;
-    if (wtype != CLLM_TYPE_Q4_K && wtype != CLLM_TYPE_Q4_0 && wtype != CLLM_TYPE_Q8_0) FAIL(CLLM_E_UNSUPPORTED, "vec_dot_isums: type %d", wtype);
+    if (!is_quant_type(wtype)) FAIL(CLLM_E_UNSUPPORTED, "vec_dot_isums: type %d", wtype);
     if (k <= 0 || k % kb) FAIL(CLLM_E_INVALID, "vec_dot_isums: k");
     void * act = nullptr;
     const size_t bytes = act_row_bytes(k, kb);
     HIP_TRY(hipMalloc(&act, bytes));
     tview s; s.data = (char *) x; s.ne[0] = k; s.ne[1] = s.ne[2] = s.ne[3] = 1; s.nb[0] = 4; s.nb[1] = s.nb[2] = s.nb[3] = k * 4;
-    int rc = launch_quantize_act(st, kb, s, act, bytes);
+    int rc = launch_quantize_act(st, act_kind_of(wtype), s, act, bytes);
     if (rc == CLLM_OK) {
         const int64_t nb = k / kb;
         hipLaunchKernelGGL(k_isums, dim3((unsigned)((nb + 63) / 64)), dim3(64), 0, st, wtype, k, (const char *) w_row, (const char *) act, isums);
@@ -299,8 +299,9 @@ static int launch_one(hipStream_t st, KernelT kern, size_t lds_bytes, const mmvq
 static int mmvq_dispatch(hipStream_t st, int wtype, int nc, size_t lds, const mmvq_args & a, int grid_y) {
 #define GO(...) return launch_one(st, __VA_ARGS__, lds, a, grid_y)
     if (wtype == CLLM_TYPE_Q4_K)      { if (nc == 4) GO(k_mmvq_q4_K<4, 1>); else if (nc == 2) GO(k_mmvq_q4_K<2, 1>); else GO(k_mmvq_q4_K<1, 1>); }
-    else if (wtype == CLLM_TYPE_Q8_0) { if (nc == 4) GO(k_mmvq_q32<4, true>);  else if (nc == 2) GO(k_mmvq_q32<2, true>);  else GO(k_mmvq_q32<1, true>); }
-    else if (wtype == CLLM_TYPE_Q4_0) { if (nc == 4) GO(k_mmvq_q32<4, false>); else if (nc == 2) GO(k_mmvq_q32<2, false>); else GO(k_mmvq_q32<1, false>); }
+    else if (wtype == CLLM_TYPE_Q8_0) { if (nc == 4) GO(k_mmvq_q32<4, CLLM_TYPE_Q8_0>); else if (nc == 2) GO(k_mmvq_q32<2, CLLM_TYPE_Q8_0>); else GO(k_mmvq_q32<1, CLLM_TYPE_Q8_0>); }
+    else if (wtype == CLLM_TYPE_Q4_0) { if (nc == 4) GO(k_mmvq_q32<4, CLLM_TYPE_Q4_0>); else if (nc == 2) GO(k_mmvq_q32<2, CLLM_TYPE_Q4_0>); else GO(k_mmvq_q32<1, CLLM_TYPE_Q4_0>); }
+    else if (wtype == CLLM_TYPE_Q4_1) { if (nc == 4) GO(k_mmvq_q32<4, CLLM_TYPE_Q4_1>); else if (nc == 2) GO(k_mmvq_q32<2, CLLM_TYPE_Q4_1>); else GO(k_mmvq_q32<1, CLLM_TYPE_Q4_1>); }
 #undef GO
     FAIL(CLLM_E_UNSUPPORTED, "mmvq: weight type %d", wtype);
 }

@@ -478,6 +478,11 @@ __device__ __forceinline__ float dequant_elem(int type, const char * row, int64_
             const int q = j < 16 ? (b->qs[j] & 0xF) : (b->qs[j - 16] >> 4);
             return (float)(q - 8) * h2f(b->d);
         }
+        case CLLM_TYPE_Q4_1: {                     // dequantize_row_q4_1 (ggml-quants.c:327-345): nib * d + m
+            const block_q4_1 * b = (const block_q4_1 *) row + i / 32; const int j = (int)(i % 32);
+            const int q = j < 16 ? (b->qs[j] & 0xF) : (b->qs[j - 16] >> 4);
+            return (float) q * h2f(b->d) + h2f(b->m);
+        }
         case CLLM_TYPE_Q4_K: {
             const block_q4_K * b = (const block_q4_K *) row + i / 256; const int e = (int)(i % 256);
             const int s = e / 32, l = e % 32;
@@ -508,7 +513,7 @@ __global__ void __launch_bounds__(256) k_get_rows(int type, tview s, tview idx, 
 extern "C" int cllm_op_get_rows(void * stream, const cllm_tensor * src, const cllm_tensor * idx, cllm_tensor * dst) {
     if (!src || !idx || !dst) FAIL(CLLM_E_INVALID, "get_rows: null");
     if (idx->type != CLLM_TYPE_I32 || dst->type != CLLM_TYPE_F32) FAIL(CLLM_E_UNSUPPORTED, "get_rows: type");
-    switch (src->type) { case CLLM_TYPE_F32: case CLLM_TYPE_F16: case CLLM_TYPE_Q4_0: case CLLM_TYPE_Q8_0: case CLLM_TYPE_Q4_K: break; default: FAIL(CLLM_E_UNSUPPORTED, "get_rows: src type %d", src->type); }
+    switch (src->type) { case CLLM_TYPE_F32: case CLLM_TYPE_F16: case CLLM_TYPE_Q4_0: case CLLM_TYPE_Q4_1: case CLLM_TYPE_Q8_0: case CLLM_TYPE_Q4_K: break; default: FAIL(CLLM_E_UNSUPPORTED, "get_rows: src type %d", src->type); }
     if (dst->ne[0] != src->ne[0] || dst->ne[1] != idx->ne[0] || dst->ne[2] != idx->ne[1] || dst->ne[3] != idx->ne[2] || dst->nb[0] != 4) FAIL(CLLM_E_INVALID, "get_rows: shape");
     const int64_t n = t_nelements(dst);
     if (n == 0) return CLLM_OK;

@@ -11,6 +11,8 @@ __device__ __forceinline__ uint32_t pack4(int q0, int q1, int q2, int q3) {
 
 // 8 consecutive lanes hold one 32-block (4 values each).  Returns the packed int8 quads; *d (fp16-rounded scale as
 // f32) and *s (sum of the block's int8) are valid on every lane of the 8-lane group.
+// Q81 (quantize_row_q8_1, arch/x86/quants.c:388-480): the same quants; *s = the bits of fp16(d * sum) as f32, d NOT yet rounded.
+template <bool Q81 = false>
 __device__ __forceinline__ uint32_t quant4_q8_0(f32x4 v, float * d_out, int * s_out) {
     float amax = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
     amax = group8_max(amax);
@@ -19,7 +21,7 @@ __device__ __forceinline__ uint32_t quant4_q8_0(f32x4 v, float * d_out, int * s_
     const int q0 = (int) rintf(v.x * id), q1 = (int) rintf(v.y * id), q2 = (int) rintf(v.z * id), q3 = (int) rintf(v.w * id);
     const int s = group8_sum_i(q0 + q1 + q2 + q3);
     *d_out = h2f(f2h(d));              // the CPU stores d as fp16 and reads it back for the dot product
-    *s_out = s;
+    *s_out = Q81 ? __float_as_int(h2f(f2h(d * (float) s))) : s;
     return pack4(q0, q1, q2, q3);
 }
 
@@ -64,9 +66,9 @@ __device__ __forceinline__ void act_store(char * act_row, int64_t K, int64_t e0,
     else            { if ((lane & 63) == 0) ((float *)(act_row + act_off_d(K)))[e0 / 256] = d; }
 }
 
-template <int KIND>
+template <int KIND, bool Q81 = false>
 __device__ __forceinline__ void quant4_store(char * act_row, int64_t K, int64_t e0, int lane, f32x4 v) {
     float d; int s; uint32_t p;
-    if (KIND == 32) p = quant4_q8_0(v, &d, &s); else p = quant4_q8_K(v, lane, &d, &s);
+    if (KIND == 32) p = quant4_q8_0<Q81>(v, &d, &s); else p = quant4_q8_K(v, lane, &d, &s);
     act_store<KIND>(act_row, K, e0, lane, p, d, s);
 }

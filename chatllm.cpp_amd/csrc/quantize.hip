@@ -9,7 +9,8 @@
 #include "common.h"
 #include "quant_dev.h"
 
-// 8 lanes per 32-block, 4 elements per lane, 8 blocks per wave.
+// 8 lanes per 32-block, 4 elements per lane, 8 blocks per wave.  Q81: the Q8_1 flavour (s plane = fp16(d * sum) as f32).
+template <bool Q81>
 __global__ void __launch_bounds__(256) k_quantize_q8_0(const char * __restrict__ src, int64_t K, int64_t ne1, int64_t ne2,
                                                        int64_t nb1, int64_t nb2, int64_t nb3,
                                                        char * __restrict__ act, size_t act_stride) {
@@ -18,7 +19,7 @@ __global__ void __launch_bounds__(256) k_quantize_q8_0(const char * __restrict__
     const float * x = (const float *)(src + i1*nb1 + i2*nb2 + i3*nb3);
     const int64_t e0 = ((int64_t) blockIdx.x * blockDim.x + threadIdx.x) * 4;
     if (e0 >= K) return;                                   // K % 32 == 0 -> whole 8-lane groups drop out together
-    quant4_store<32>(act + row * act_stride, K, e0, threadIdx.x & 63, *(const f32x4 *)(x + e0));
+    quant4_store<32, Q81>(act + row * act_stride, K, e0, threadIdx.x & 63, *(const f32x4 *)(x + e0));
 }
 
 // one wave per 256-block, 4 elements per lane.
@@ -35,7 +36,8 @@ __global__ void __launch_bounds__(256) k_quantize_q8_K(const char * __restrict__
     quant4_store<256>(act + row * act_stride, K, e0, lane, *(const f32x4 *)(x + e0));
 }
 
-int launch_quantize_act(hipStream_t st, int kind_blk, const tview & s, void * act, size_t act_stride) {
+int launch_quantize_act(hipStream_t st, int kind, const tview & s, void * act, size_t act_stride) {
+    const int kind_blk = act_blk(kind);
     const int64_t K = s.ne[0];
     const int64_t rows = s.ne[1] * s.ne[2] * s.ne[3];
     if (K % kind_blk) FAIL(CLLM_E_INVALID, "quantize_act: K=%lld not a multiple of %d", (long long) K, kind_blk);
@@ -43,7 +45,8 @@ int launch_quantize_act(hipStream_t st, int kind_blk, const tview & s, void * ac
     if (rows > 65535) FAIL(CLLM_E_UNSUPPORTED, "quantize_act: too many rows (%lld)", (long long) rows);
     if (kind_blk == 32) {
         dim3 grid((unsigned)((K / 4 + 255) / 256), (unsigned) rows);
-        hipLaunchKernelGGL(k_quantize_q8_0, grid, dim3(256), 0, st, s.data, K, s.ne[1], s.ne[2], s.nb[1], s.nb[2], s.nb[3], (char *) act, act_stride);
+        if (kind == ACT_Q8_1) hipLaunchKernelGGL(k_quantize_q8_0<true>,  grid, dim3(256), 0, st, s.data, K, s.ne[1], s.ne[2], s.nb[1], s.nb[2], s.nb[3], (char *) act, act_stride);
+        else                  hipLaunchKernelGGL(k_quantize_q8_0<false>, grid, dim3(256), 0, st, s.data, K, s.ne[1], s.ne[2], s.nb[1], s.nb[2], s.nb[3], (char *) act, act_stride);
     } else {
         dim3 grid((unsigned)((K / 256 + 3) / 4), (unsigned) rows);
         hipLaunchKernelGGL(k_quantize_q8_K, grid, dim3(256), 0, st, s.data, K, s.ne[1], s.ne[2], s.nb[1], s.nb[2], s.nb[3], (char *) act, act_stride);
@@ -61,6 +64,15 @@ __global__ void k_act_to_q8_0_blocks(const char * __restrict__ act, int64_t K, b
     y[b].d = f2h(dd[b]);
     for (int j = 0; j < 32; j++) y[b].qs[j] = qs[b*32 + j];
 }
+__global__ void k_act_to_q8_1_blocks(const char * __restrict__ act, int64_t K, block_q8_1 * __restrict__ y) {
+    const int64_t b = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= K / 32) return;
+    const int8_t * qs = (const int8_t *) act;
+    const float *  dd = (const float *)(act + act_off_d(K));
+    const float *  ss = (const float *)(act + act_off_s(K, ACT_Q8_1));
+    y[b].d = f2h(dd[b]); y[b].s = f2h(ss[b]);
+    for (int j = 0; j < 32; j++) y[b].qs[j] = qs[b*32 + j];
+}
 __global__ void k_act_to_q8_K_blocks(const char * __restrict__ act, int64_t K, block_q8_K * __restrict__ y) {
     const int64_t b = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= K / 256) return;
@@ -74,17 +86,19 @@ __global__ void k_act_to_q8_K_blocks(const char * __restrict__ act, int64_t K, b
     }
 }
 
-static int quantize_to_blocks(void * stream, int kind_blk, const float * x, void * y, int64_t k) {
+static int quantize_to_blocks(void * stream, int kind, const float * x, void * y, int64_t k) {
+    const int kind_blk = act_blk(kind);
     hipStream_t st = (hipStream_t) stream;
     if (!x || !y || k <= 0 || k % kind_blk) FAIL(CLLM_E_INVALID, "quantize_row: bad arguments");
     void * act = nullptr;
-    const size_t bytes = act_row_bytes(k, kind_blk);
+    const size_t bytes = act_row_bytes(k, kind);
     HIP_TRY(hipMalloc(&act, bytes));
     tview s; s.data = (char *) x; s.ne[0] = k; s.ne[1] = s.ne[2] = s.ne[3] = 1; s.nb[0] = 4; s.nb[1] = s.nb[2] = s.nb[3] = k * 4;
-    int rc = launch_quantize_act(st, kind_blk, s, act, bytes);
+    int rc = launch_quantize_act(st, kind, s, act, bytes);
     if (rc == CLLM_OK) {
         const int64_t nb = k / kind_blk;
-        if (kind_blk == 32) hipLaunchKernelGGL(k_act_to_q8_0_blocks, dim3((unsigned)((nb + 63) / 64)), dim3(64), 0, st, (const char *) act, k, (block_q8_0 *) y);
+        if (kind == ACT_Q8_1) hipLaunchKernelGGL(k_act_to_q8_1_blocks, dim3((unsigned)((nb + 63) / 64)), dim3(64), 0, st, (const char *) act, k, (block_q8_1 *) y);
+        else if (kind_blk == 32) hipLaunchKernelGGL(k_act_to_q8_0_blocks, dim3((unsigned)((nb + 63) / 64)), dim3(64), 0, st, (const char *) act, k, (block_q8_0 *) y);
         else                hipLaunchKernelGGL(k_act_to_q8_K_blocks, dim3((unsigned)((nb + 63) / 64)), dim3(64), 0, st, (const char *) act, k, (block_q8_K *) y);
         rc = cllm_hip_check(hipGetLastError(), "act_to_blocks", __FILE__, __LINE__);
     }
@@ -94,4 +108,5 @@ static int quantize_to_blocks(void * stream, int kind_blk, const float * x, void
 }
 
 extern "C" int cllm_quantize_row_q8_0(void * stream, const float * x, void * y, int64_t k) { return quantize_to_blocks(stream, 32, x, y, k); }
+extern "C" int cllm_quantize_row_q8_1(void * stream, const float * x, void * y, int64_t k) { return quantize_to_blocks(stream, ACT_Q8_1, x, y, k); }
 extern "C" int cllm_quantize_row_q8_K(void * stream, const float * x, void * y, int64_t k) { return quantize_to_blocks(stream, 256, x, y, k); }

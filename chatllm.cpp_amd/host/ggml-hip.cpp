@@ -58,7 +58,7 @@ cllm_tensor desc(const ggml_tensor * t) {
     d.data = t->data;
     return d;
 }
-bool is_q(ggml_type t) { return t == GGML_TYPE_Q4_0 || t == GGML_TYPE_Q8_0 || t == GGML_TYPE_Q4_K; }
+bool is_q(ggml_type t) { return t == GGML_TYPE_Q4_0 || t == GGML_TYPE_Q4_1 || t == GGML_TYPE_Q8_0 || t == GGML_TYPE_Q4_K; }
 bool dense_rows(const ggml_tensor * t) { return t->nb[0] == ggml_type_size(t->type); }
 bool f32_dense(const ggml_tensor * t) { return t && t->type == GGML_TYPE_F32 && t->nb[0] == 4; }
 

@@ -69,6 +69,7 @@ SIGNATURES = {
                                         C.POINTER(C.c_float)]),
     "cllm_op_mul_mat_id": (C.c_int, [_P, _T, _T, _T, _T, _P, C.c_size_t]),
     "cllm_quantize_row_q8_0": (C.c_int, [_P, _P, _P, C.c_int64]),
+    "cllm_quantize_row_q8_1": (C.c_int, [_P, _P, _P, C.c_int64]),
     "cllm_quantize_row_q8_K": (C.c_int, [_P, _P, _P, C.c_int64]),
     "cllm_vec_dot_isums": (C.c_int, [_P, C.c_int, C.c_int64, _P, _P, _P]),
     "cllm_op_rms_norm": (C.c_int, [_P, _T, _T, C.c_float]),

@@ -2,13 +2,13 @@
 blocks (no float master, no network), SURVEY.md 8d.  Deterministic per tensor name, so any
 subset (one layer for the CPU baseline, a tensor-parallel shard) can be regenerated identically.
 
-Block layouts: /root/reference/ggml/src/ggml-common.h:170-175 (Q4_0), 219-224 (Q8_0), 295-306 (Q4_K).
+Block layouts: /root/reference/ggml/src/ggml-common.h:170-175 (Q4_0), 177-189 (Q4_1), 219-224 (Q8_0), 295-306 (Q4_K).
 """
 import zlib
 
 import numpy as np
 
-from .tensor import F32, Q4_0, Q8_0, Q4_K, TYPE_SIZE, BLCK  # noqa: F401
+from .tensor import F32, Q4_0, Q4_1, Q8_0, Q4_K, TYPE_SIZE, BLCK  # noqa: F401
 
 CONFIGS = {
     # name: n_layer, hidden, n_head, n_kv_head, head_dim, ffn, vocab
@@ -50,6 +50,13 @@ def quant_blocks(type_, rows, K, rng, sigma):
         out[:, :, 0:2] = _f16_bytes(d).reshape(rows, nb, 2)
         nib = np.clip(np.rint(rng.standard_normal((rows, nb, 32), np.float32) * 2.5 + 8.0), 0, 15).astype(np.uint8)
         out[:, :, 2:] = nib[:, :, :16] | (nib[:, :, 16:] << 4)
+    elif type_ == Q4_1:
+        out = np.empty((rows, nb, 20), np.uint8)
+        d = rng.uniform(0.5, 1.5, (rows, nb)) * sigma / 2.5             # w = nib * d + m with m = -7.5 d .. -8.5 d: ~zero-mean
+        out[:, :, 0:2] = _f16_bytes(d).reshape(rows, nb, 2)
+        out[:, :, 2:4] = _f16_bytes(-d * rng.uniform(7.0, 9.0, (rows, nb))).reshape(rows, nb, 2)
+        nib = np.clip(np.rint(rng.standard_normal((rows, nb, 32), np.float32) * 2.5 + 8.0), 0, 15).astype(np.uint8)
+        out[:, :, 4:] = nib[:, :, :16] | (nib[:, :, 16:] << 4)
     elif type_ == Q4_K:
         out = np.empty((rows, nb, 144), np.uint8)
         sc = rng.integers(20, 64, (rows, nb, 8), dtype=np.uint8)        # 6-bit sub-block scales
@@ -147,7 +154,7 @@ def fast_blocks(type_, rows, K, rng, sigma):
     # one random fp16 scale per block from a small table (cheap): +-25 % around the target
     if type_ == Q8_0:
         base = sigma / 73.9            # uniform int8 std
-    elif type_ == Q4_0:
+    elif type_ in (Q4_0, Q4_1):
         base = sigma / 4.61            # uniform nibble std
     else:
         base = sigma / (4.61 * 32.0)   # nibble std x mean 6-bit scale
@@ -156,6 +163,10 @@ def fast_blocks(type_, rows, K, rng, sigma):
     d = table[sel]
     out[:, :, 0] = (d & 0xff).astype(np.uint8)
     out[:, :, 1] = (d >> 8).astype(np.uint8)
+    if type_ == Q4_1:
+        dm = (-(base * 7.5) * np.linspace(0.75, 1.25, 256)).astype(np.float16).view(np.uint16)[sel]      # m = -7.5 d: zero-mean weights
+        out[:, :, 2] = (dm & 0xff).astype(np.uint8)
+        out[:, :, 3] = (dm >> 8).astype(np.uint8)
     if type_ == Q4_K:
         # dmin = 7.5 d: with independent 6-bit scales and mins the sub-block offsets average out
         dm = (base * 7.5 * np.linspace(0.75, 1.25, 256)).astype(np.float16).view(np.uint16)[sel]

@@ -41,7 +41,7 @@ typedef enum cllm_status {
 
 /* numeric values == enum ggml_type (ggml.h:386-428) so descriptors can be filled by a cast */
 typedef enum cllm_type {
-    CLLM_TYPE_F32 = 0, CLLM_TYPE_F16 = 1, CLLM_TYPE_Q4_0 = 2, CLLM_TYPE_Q8_0 = 8, CLLM_TYPE_Q4_K = 12,
+    CLLM_TYPE_F32 = 0, CLLM_TYPE_F16 = 1, CLLM_TYPE_Q4_0 = 2, CLLM_TYPE_Q4_1 = 3, CLLM_TYPE_Q8_0 = 8, CLLM_TYPE_Q4_K = 12,
     CLLM_TYPE_I32 = 26, CLLM_TYPE_I64 = 27,
 } cllm_type;
 
@@ -86,10 +86,11 @@ CLLM_API int  cllm_event_elapsed_ms(void * start, void * stop, float * ms);
  * replaces ggml_compute_forward_mul_mat (ggml/src/ggml-cpu/ggml-cpu.c:1229-1421) and, for Q4_0/Q8_0
  * with ne11 >= 2, llamafile_sgemm (ggml-cpu/llamafile/sgemm.cpp:3676-3696):
  *   dst[ne01, ne11, ne12, ne13] (F32) = src0^T . src1,   src0 broadcast over dims 2,3.
- * src0: Q4_0 | Q8_0 | Q4_K (rows dense, any nb[1..3]) | F16 | F32 (any strides with nb[0]==elt size);
+ * src0: Q4_0 | Q4_1 | Q8_0 | Q4_K (rows dense, any nb[1..3]) | F16 | F32 (any strides with nb[0]==elt size);
  * src1: F32.  Numerics follow the CPU path: src1 rows are quantized on the device to the weight
- * type's vec_dot_type (Q8_0: id=127/amax, round-half-even, arch/x86/quants.c:290-345;  Q8_K:
- * ggml-quants.c:2555-2592;  F16: RNE), block dot products are exact int32, scaling/accumulation fp32.
+ * type's vec_dot_type (Q8_0: id=127/amax, round-half-even, arch/x86/quants.c:290-345;  Q8_1 for Q4_1: the
+ * same plus s = fp16(d*sum q), :388-480;  Q8_K: ggml-quants.c:2555-2592;  F16: RNE), block dot products are
+ * exact int32, scaling/accumulation fp32.
  * `wdata` is scratch for the converted src1 (ggml's params->wdata): at least cllm_mul_mat_wsize() bytes.
  */
 CLLM_API size_t cllm_mul_mat_wsize(const cllm_tensor * src0, const cllm_tensor * src1);
@@ -135,9 +136,10 @@ CLLM_API int    cllm_op_mul_mat_id(void * stream, const cllm_tensor * as, const 
 /* the activation quantizers on their own (KAT surface).  Output is in the reference block layout
  * (block_q8_0 34 B / block_q8_K 292 B) so it can be compared byte-for-byte. */
 CLLM_API int    cllm_quantize_row_q8_0(void * stream, const float * x, void * y_blocks, int64_t k);   /* arch/x86/quants.c:290 */
+CLLM_API int    cllm_quantize_row_q8_1(void * stream, const float * x, void * y_blocks, int64_t k);   /* arch/x86/quants.c:388 */
 CLLM_API int    cllm_quantize_row_q8_K(void * stream, const float * x, void * y_blocks, int64_t k);   /* ggml-quants.c:2555    */
 /* exact per-block integer sums of one weight row against one quantized activation row (tier T0).
- * Q4_0/Q8_0: one int32 per 32-block; Q4_K: {sum_s sc_s*dot_s, sum_s m_s*bsum_s} per super-block. */
+ * Q4_0/Q4_1/Q8_0: one int32 per 32-block; Q4_K: {sum_s sc_s*dot_s, sum_s m_s*bsum_s} per super-block. */
 CLLM_API int    cllm_vec_dot_isums(void * stream, int wtype, int64_t k, const void * w_row, const float * x, int32_t * isums);
 
 /* ---- the other nodes of one forward graph -------------------------------- */

@@ -21,13 +21,14 @@ size_t orc_type_size(int type) {
     switch (type) {
         case ORC_F32: return 4;  case ORC_F16: return 2;  case ORC_I32: return 4;  case ORC_I64: return 8;
         case ORC_Q4_0: return sizeof(orc_block_q4_0);  case ORC_Q8_0: return sizeof(orc_block_q8_0);
+        case ORC_Q4_1: return sizeof(orc_block_q4_1);  case ORC_Q8_1: return sizeof(orc_block_q8_1);
         case ORC_Q4_K: return sizeof(orc_block_q4_K);  case ORC_Q8_K: return sizeof(orc_block_q8_K);
     }
     return 0;
 }
 int orc_blck_size(int type) {
     switch (type) {
-        case ORC_Q4_0: case ORC_Q8_0: return ORC_QK;
+        case ORC_Q4_0: case ORC_Q8_0: case ORC_Q4_1: case ORC_Q8_1: return ORC_QK;
         case ORC_Q4_K: case ORC_Q8_K: return ORC_QK_K;
         case ORC_F32: case ORC_F16: case ORC_I32: case ORC_I64: return 1;
     }
@@ -96,6 +97,25 @@ void orc_quantize_row_q8_0(const float * x, orc_block_q8_0 * y, int64_t k) {
     }
 }
 
+/* arch/x86/quants.c:388-480 (AVX2): the Q8_0 arithmetic, plus s = fp16(d * sum q) where d is the fp32 quotient (not its fp16 rounding) */
+void orc_quantize_row_q8_1(const float * x, orc_block_q8_1 * y, int64_t k) {
+    const int64_t nb = k / ORC_QK;
+    for (int64_t i = 0; i < nb; i++) {
+        float amax = 0.0f;
+        for (int j = 0; j < ORC_QK; j++) amax = fmaxf(amax, fabsf(x[i*ORC_QK + j]));
+        const float d  = amax / 127.f;
+        const float id = (amax != 0.0f) ? 127.f / amax : 0.0f;
+        y[i].d = orc_fp32_to_fp16(d);
+        int sum = 0;
+        for (int j = 0; j < ORC_QK; j++) {
+            const int q = (int) nearbyintf(x[i*ORC_QK + j] * id);
+            y[i].qs[j] = (int8_t) q;
+            sum += q;
+        }
+        y[i].s = orc_fp32_to_fp16(d * (float) sum);
+    }
+}
+
 /* ggml-quants.c:199-222: id = 1/d, roundf (half away from zero) */
 void orc_quantize_row_q8_0_ref(const float * x, orc_block_q8_0 * y, int64_t k) {
     const int64_t nb = k / ORC_QK;
@@ -158,6 +178,16 @@ void orc_dequantize_row_q4_0(const orc_block_q4_0 * x, float * y, int64_t k) {
         }
     }
 }
+void orc_dequantize_row_q4_1(const orc_block_q4_1 * x, float * y, int64_t k) {
+    const int64_t nb = k / ORC_QK;
+    for (int64_t i = 0; i < nb; i++) {
+        const float d = orc_fp16_to_fp32(x[i].d), m = orc_fp16_to_fp32(x[i].m);
+        for (int j = 0; j < 16; j++) {
+            y[i*32 + j]      = (float)(x[i].qs[j] & 0x0F) * d + m;
+            y[i*32 + j + 16] = (float)(x[i].qs[j] >>   4) * d + m;
+        }
+    }
+}
 void orc_dequantize_row_q8_0(const orc_block_q8_0 * x, float * y, int64_t k) {
     const int64_t nb = k / ORC_QK;
     for (int64_t i = 0; i < nb; i++) {
@@ -191,6 +221,7 @@ void orc_dequantize_row(int type, const void * x, float * y, int64_t k) {
     switch (type) {
         case ORC_Q4_0: orc_dequantize_row_q4_0((const orc_block_q4_0 *) x, y, k); break;
         case ORC_Q8_0: orc_dequantize_row_q8_0((const orc_block_q8_0 *) x, y, k); break;
+        case ORC_Q4_1: orc_dequantize_row_q4_1((const orc_block_q4_1 *) x, y, k); break;
         case ORC_Q4_K: orc_dequantize_row_q4_K((const orc_block_q4_K *) x, y, k); break;
         case ORC_F16:  for (int64_t i = 0; i < k; i++) y[i] = orc_fp16_to_fp32(((const uint16_t *) x)[i]); break;
         case ORC_F32:  memcpy(y, x, (size_t) k * 4); break;
@@ -212,6 +243,22 @@ float orc_vec_dot_q4_0_q8_0(int64_t n, const orc_block_q4_0 * x, const orc_block
         const int sumi = s0 + s1;
         if (isums) isums[ib] = sumi;
         sumf += (float) sumi * orc_fp16_to_fp32(x[ib].d) * orc_fp16_to_fp32(y[ib].d);
+    }
+    return sumf;
+}
+
+float orc_vec_dot_q4_1_q8_1(int64_t n, const orc_block_q4_1 * x, const orc_block_q8_1 * y, int32_t * isums) {
+    const int64_t nb = n / ORC_QK;
+    float sumf = 0;
+    for (int64_t ib = 0; ib < nb; ib++) {
+        int s0 = 0, s1 = 0;
+        for (int j = 0; j < 16; j++) {
+            s0 += (x[ib].qs[j] & 0x0F) * y[ib].qs[j];
+            s1 += (x[ib].qs[j] >>   4) * y[ib].qs[j + 16];
+        }
+        const int sumi = s0 + s1;
+        if (isums) isums[ib] = sumi;
+        sumf += (orc_fp16_to_fp32(x[ib].d) * orc_fp16_to_fp32(y[ib].d)) * (float) sumi + orc_fp16_to_fp32(x[ib].m) * orc_fp16_to_fp32(y[ib].s);
     }
     return sumf;
 }
@@ -288,6 +335,7 @@ static int is_contiguous(const orc_tensor * t) {
 static int vec_dot_type_of(int wtype) {
     switch (wtype) {             /* type_traits_cpu[], ggml-cpu/ggml-cpu.c:207-390 */
         case ORC_Q4_0: case ORC_Q8_0: return ORC_Q8_0;
+        case ORC_Q4_1: return ORC_Q8_1;
         case ORC_Q4_K: return ORC_Q8_K;
         case ORC_F16:  return ORC_F16;
         case ORC_F32:  return ORC_F32;
@@ -298,6 +346,7 @@ static int vec_dot_type_of(int wtype) {
 static void convert_row(int vtype, const float * x, void * y, int64_t k) {
     switch (vtype) {
         case ORC_Q8_0: orc_quantize_row_q8_0(x, (orc_block_q8_0 *) y, k); break;
+        case ORC_Q8_1: orc_quantize_row_q8_1(x, (orc_block_q8_1 *) y, k); break;
         case ORC_Q8_K: orc_quantize_row_q8_K(x, (orc_block_q8_K *) y, k); break;
         case ORC_F16:  for (int64_t i = 0; i < k; i++) ((uint16_t *) y)[i] = orc_fp32_to_fp16(x[i]); break;
         case ORC_F32:  memcpy(y, x, (size_t) k * 4); break;
@@ -308,6 +357,7 @@ static float vec_dot(int wtype, int64_t n, const void * w, const void * a) {
     switch (wtype) {
         case ORC_Q4_0: return orc_vec_dot_q4_0_q8_0(n, (const orc_block_q4_0 *) w, (const orc_block_q8_0 *) a, NULL);
         case ORC_Q8_0: return orc_vec_dot_q8_0_q8_0(n, (const orc_block_q8_0 *) w, (const orc_block_q8_0 *) a, NULL);
+        case ORC_Q4_1: return orc_vec_dot_q4_1_q8_1(n, (const orc_block_q4_1 *) w, (const orc_block_q8_1 *) a, NULL);
         case ORC_Q4_K: return orc_vec_dot_q4_K_q8_K(n, (const orc_block_q4_K *) w, (const orc_block_q8_K *) a, NULL);
         case ORC_F16: {          /* scalar branch of ggml_vec_dot_f16 (vec.cpp:264-): double accumulation */
             const uint16_t * x = (const uint16_t *) w, * y = (const uint16_t *) a;

@@ -25,7 +25,7 @@ extern "C" {
 
 /* numeric values equal the reference's enum ggml_type (ggml/include/ggml.h:386-428) */
 enum orc_type {
-    ORC_F32 = 0, ORC_F16 = 1, ORC_Q4_0 = 2, ORC_Q8_0 = 8, ORC_Q4_K = 12, ORC_Q8_K = 15, ORC_I32 = 26, ORC_I64 = 27,
+    ORC_F32 = 0, ORC_F16 = 1, ORC_Q4_0 = 2, ORC_Q4_1 = 3, ORC_Q8_0 = 8, ORC_Q8_1 = 9, ORC_Q4_K = 12, ORC_Q8_K = 15, ORC_I32 = 26, ORC_I64 = 27,
 };
 
 /* a strided 4-D tensor view: same meaning as ggml_tensor {type, ne, nb, data} (ggml.h:656-688) */
@@ -36,12 +36,14 @@ typedef struct orc_tensor {
     void *  data;
 } orc_tensor;
 
-/* ---- formats (ggml/src/ggml-common.h:170-175, 219-224, 295-306, 338-343) ---- */
+/* ---- formats (ggml/src/ggml-common.h:170-175, 177-189, 219-224, 226-237, 295-306, 338-343) ---- */
 #define ORC_QK    32
 #define ORC_QK_K  256
 #pragma pack(push, 1)
 typedef struct { uint16_t d; uint8_t qs[16]; }                         orc_block_q4_0;   /* 18 B  */
 typedef struct { uint16_t d; int8_t  qs[32]; }                         orc_block_q8_0;   /* 34 B  */
+typedef struct { uint16_t d; uint16_t m; uint8_t qs[16]; }             orc_block_q4_1;   /* 20 B: w = nib * d + m */
+typedef struct { uint16_t d; uint16_t s; int8_t qs[32]; }              orc_block_q8_1;   /* 36 B: s = d * sum(qs) */
 typedef struct { uint16_t d; uint16_t dmin; uint8_t scales[12]; uint8_t qs[128]; } orc_block_q4_K; /* 144 B */
 typedef struct { float d; int8_t qs[256]; int16_t bsums[16]; }         orc_block_q8_K;   /* 292 B */
 #pragma pack(pop)
@@ -59,12 +61,16 @@ uint16_t orc_fp32_to_fp16(float f);
 void orc_quantize_row_q8_0(const float * x, orc_block_q8_0 * y, int64_t k);
 /* portable branch: id = 1/d, roundf (half away)      (ggml/src/ggml-quants.c:199-222)      */
 void orc_quantize_row_q8_0_ref(const float * x, orc_block_q8_0 * y, int64_t k);
+/* x86 AVX2 branch of quantize_row_q8_1: as Q8_0 plus s = fp16(d * sum q) with the UNROUNDED d
+ * (ggml-cpu/arch/x86/quants.c:388-480; portable: ggml-quants.c:225-258)                    */
+void orc_quantize_row_q8_1(const float * x, orc_block_q8_1 * y, int64_t k);
 /* (ggml/src/ggml-quants.c:2555-2592, nearest_int :444)                                      */
 void orc_quantize_row_q8_K(const float * x, orc_block_q8_K * y, int64_t k);
 
 /* ---- weight dequantizers (ggml/src/ggml-quants.c:307-325, 401-414, 1352-1373, 703-711) ---- */
 void orc_dequantize_row_q4_0(const orc_block_q4_0 * x, float * y, int64_t k);
 void orc_dequantize_row_q8_0(const orc_block_q8_0 * x, float * y, int64_t k);
+void orc_dequantize_row_q4_1(const orc_block_q4_1 * x, float * y, int64_t k);      /* ggml-quants.c:327-345 */
 void orc_dequantize_row_q4_K(const orc_block_q4_K * x, float * y, int64_t k);
 void orc_dequantize_row(int type, const void * x, float * y, int64_t k);
 
@@ -73,11 +79,13 @@ void orc_dequantize_row(int type, const void * x, float * y, int64_t k);
  * for Q4_K two int32 per super-block { sum_s sc_s*dot_s , sum_s m_s*bsum_s }. */
 float orc_vec_dot_q4_0_q8_0(int64_t n, const orc_block_q4_0 * x, const orc_block_q8_0 * y, int32_t * isums);
 float orc_vec_dot_q8_0_q8_0(int64_t n, const orc_block_q8_0 * x, const orc_block_q8_0 * y, int32_t * isums);
+/* ggml-cpu/quants.c:152-186: sum_b (d_w d_a) * sum_j nib_j a_j + m_w * s_a */
+float orc_vec_dot_q4_1_q8_1(int64_t n, const orc_block_q4_1 * x, const orc_block_q8_1 * y, int32_t * isums);
 float orc_vec_dot_q4_K_q8_K(int64_t n, const orc_block_q4_K * x, const orc_block_q8_K * y, int32_t * isums);
 
 /* ---- ops (dst written through its strides; all return 0 on success, <0 on bad arguments) ---- */
 /* ggml_compute_forward_mul_mat (ggml-cpu/ggml-cpu.c:1229-1421): quantizes src1 rows to the
- * weight type's vec_dot_type (Q8_0 for Q4_0/Q8_0, Q8_K for Q4_K, F16 for F16), then vec_dot. */
+ * weight type's vec_dot_type (Q8_0 for Q4_0/Q8_0, Q8_1 for Q4_1, Q8_K for Q4_K, F16 for F16), then vec_dot. */
 int orc_mul_mat(const orc_tensor * src0, const orc_tensor * src1, orc_tensor * dst);
 /* ggml_compute_forward_mul_mat_id (ggml-cpu/ggml-cpu.c:1432-1678) */
 int orc_mul_mat_id(const orc_tensor * as, const orc_tensor * b, const orc_tensor * ids, orc_tensor * dst);

@@ -10,9 +10,9 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 
-F32, F16, Q4_0, Q8_0, Q4_K, Q8_K, I32, I64 = 0, 1, 2, 8, 12, 15, 26, 27
-TYPE_SIZE = {F32: 4, F16: 2, Q4_0: 18, Q8_0: 34, Q4_K: 144, Q8_K: 292, I32: 4, I64: 8}
-BLCK = {F32: 1, F16: 1, Q4_0: 32, Q8_0: 32, Q4_K: 256, Q8_K: 256, I32: 1, I64: 1}
+F32, F16, Q4_0, Q4_1, Q8_0, Q8_1, Q4_K, Q8_K, I32, I64 = 0, 1, 2, 3, 8, 9, 12, 15, 26, 27
+TYPE_SIZE = {F32: 4, F16: 2, Q4_0: 18, Q4_1: 20, Q8_0: 34, Q8_1: 36, Q4_K: 144, Q8_K: 292, I32: 4, I64: 8}
+BLCK = {F32: 1, F16: 1, Q4_0: 32, Q4_1: 32, Q8_0: 32, Q8_1: 32, Q4_K: 256, Q8_K: 256, I32: 1, I64: 1}
 NP_OF = {F32: np.float32, F16: np.float16, I32: np.int32, I64: np.int64}
 
 
@@ -43,7 +43,7 @@ def lib():
         _lib.orc_fp16_to_fp32.argtypes = [C.c_uint16]
         _lib.orc_fp32_to_fp16.restype = C.c_uint16
         _lib.orc_fp32_to_fp16.argtypes = [C.c_float]
-        for n in ("orc_vec_dot_q4_0_q8_0", "orc_vec_dot_q8_0_q8_0", "orc_vec_dot_q4_K_q8_K"):
+        for n in ("orc_vec_dot_q4_0_q8_0", "orc_vec_dot_q8_0_q8_0", "orc_vec_dot_q4_1_q8_1", "orc_vec_dot_q4_K_q8_K"):
             getattr(_lib, n).restype = C.c_float
             getattr(_lib, n).argtypes = [C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
         _lib.orc_expf_avx2.restype = C.c_float
@@ -82,6 +82,13 @@ def quantize_q8_0(x, ref=False):
     return y
 
 
+def quantize_q8_1(x):
+    x = np.ascontiguousarray(x, np.float32)
+    y = np.zeros(x.size // 32 * 36, np.uint8)
+    lib().orc_quantize_row_q8_1(_p(x), _p(y), C.c_int64(x.size))
+    return y
+
+
 def quantize_q8_K(x):
     x = np.ascontiguousarray(x, np.float32)
     y = np.zeros(x.size // 256 * 292, np.uint8)
@@ -98,7 +105,7 @@ def dequantize(type_, blocks, k):
 
 def vec_dot(wtype, n, w, a):
     """returns (float result, exact int32 block sums)"""
-    fn = {Q4_0: lib().orc_vec_dot_q4_0_q8_0, Q8_0: lib().orc_vec_dot_q8_0_q8_0, Q4_K: lib().orc_vec_dot_q4_K_q8_K}[wtype]
+    fn = {Q4_0: lib().orc_vec_dot_q4_0_q8_0, Q8_0: lib().orc_vec_dot_q8_0_q8_0, Q4_1: lib().orc_vec_dot_q4_1_q8_1, Q4_K: lib().orc_vec_dot_q4_K_q8_K}[wtype]
     isums = np.zeros(n // 32 if wtype != Q4_K else 2 * (n // 256), np.int32)
     s = fn(C.c_int64(n), _p(np.ascontiguousarray(w)), _p(np.ascontiguousarray(a)), _p(isums))
     return np.float32(s), isums

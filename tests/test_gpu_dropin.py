@@ -16,7 +16,7 @@ REF = os.path.join(ROOT, "oracle", "_ref")
 
 @pytest.mark.skipif(not (os.path.exists(os.path.join(REF, "ref_chat")) and os.path.exists(os.path.join(REF, "libggml-hip.so"))),
                     reason="oracle/_ref (reference host + module) not built")
-@pytest.mark.parametrize("wname,wt", [("q4_k", 12), ("q8_0", 8), ("q4_0", 2)])
+@pytest.mark.parametrize("wname,wt", [("q4_k", 12), ("q8_0", 8), ("q4_0", 2), ("q4_1", 3)])
 def test_reference_host_cpu_vs_our_module(gpu, tmp_path, wname, wt):
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import make_ggmm
@@ -54,7 +54,7 @@ def test_reference_host_cpu_vs_our_module(gpu, tmp_path, wname, wt):
 
 @pytest.mark.skipif(not (os.path.exists(os.path.join(REF, "ref_chat")) and os.path.exists(os.path.join(REF, "libggml-hip.so"))),
                     reason="oracle/_ref (reference host + module) not built")
-@pytest.mark.parametrize("wname,wt,over", [("q4_k", 12, {}), ("q4_0", 2, {}), ("q4_k", 12, dict(ffn=544))])
+@pytest.mark.parametrize("wname,wt,over", [("q4_k", 12, {}), ("q4_0", 2, {}), ("q4_1", 3, {}), ("q4_k", 12, dict(ffn=544))])
 def test_module_node_fusion_does_not_change_a_bit(gpu, tmp_path, wname, wt, over):
     """graph_compute fuses RMS_NORM->MUL->MUL_MAT, SILU->MUL->MUL_MAT, MUL_MAT->ADD, SCALE->MASK->SOFT_MAX and the single-token attention
     block into single launches and merges mat-vecs over packed weights; with CLLM_HIP_NO_FUSE=1 every node is its own launch: the logits

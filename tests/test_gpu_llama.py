@@ -128,7 +128,7 @@ class Walk:
 OP_TOL = {"mul_mat": 1e-5, "rms_norm": 1e-6, "rope(abs)": 4e-6, "attn scores": 1e-5, "soft_max": 1e-6, "attn V.P": 1e-5, "silu*up": 1e-6}
 
 
-@pytest.mark.parametrize("wtype", [O.Q8_0, O.Q4_0, O.Q4_K])
+@pytest.mark.parametrize("wtype", [O.Q8_0, O.Q4_0, O.Q4_K, O.Q4_1])
 def test_decoder_is_bit_identical_to_the_verified_op_walk(gpu, wtype):
     cfg = gpu.synth.config("tiny", max_len=48)
     w = gpu.synth.make_model(cfg, wtype, seed=1)
@@ -171,7 +171,7 @@ def test_decoder_qwen2_style_is_bit_identical_to_the_walk(gpu):
     dev.close()
 
 
-@pytest.mark.parametrize("name,wtype,plen", [("tiny", O.Q8_0, 9), ("tiny", O.Q4_0, 9), ("tiny", O.Q4_K, 9), ("small", O.Q4_K, 40)])
+@pytest.mark.parametrize("name,wtype,plen", [("tiny", O.Q8_0, 9), ("tiny", O.Q4_0, 9), ("tiny", O.Q4_K, 9), ("tiny", O.Q4_1, 9), ("small", O.Q4_K, 40)])
 def test_end_to_end_statistics_against_the_oracle_run(gpu, name, wtype, plen):
     cfg = gpu.synth.config(name, max_len=96)
     w = gpu.synth.make_model(cfg, wtype, seed=2)
@@ -194,7 +194,7 @@ def test_end_to_end_statistics_against_the_oracle_run(gpu, name, wtype, plen):
     dev.close()
 
 
-@pytest.mark.parametrize("wtype,over", [(O.Q8_0, {}), (O.Q4_0, {}), (O.Q4_K, {}), (O.Q4_K, dict(rope_mode=2, qkv_bias=1, rope_theta=1e6, ffn=544))])
+@pytest.mark.parametrize("wtype,over", [(O.Q8_0, {}), (O.Q4_0, {}), (O.Q4_K, {}), (O.Q4_1, {}), (O.Q4_K, dict(rope_mode=2, qkv_bias=1, rope_theta=1e6, ffn=544))])
 def test_fused_decode_path_is_bit_identical_to_the_node_by_node_path(gpu, wtype, over):
     """norm+quant, rope+kv-write, fused attention, silu*up+quant, GEMV+bias/residual epilogues: same bits as the unfused nodes"""
     cfg = gpu.synth.config("tiny", max_len=64, **over)

@@ -45,6 +45,23 @@ def test_quantize_q8_0_bit_exact(gpu, K):
         assert np.array_equal(got, O.quantize_q8_0(x))
 
 
+@pytest.mark.parametrize("K", [32, 256, 4096, 14336])
+def test_quantize_q8_1_bit_exact(gpu, K):
+    """the activation format of Q4_1 weights (quantize_row_q8_1, x86 branch): Q8_0's quants + s = fp16(d * sum q)"""
+    T = gpu.Tensor
+    for scale in (1.0, 1e-3, 300.0, 6e4):
+        x = (rng.standard_normal(K) * scale).astype(np.float32)
+        if K >= 256:
+            x[:32] = 0.0
+            x[64:96] = np.arange(32, dtype=np.float32) + 0.5
+            x[96:128] = np.abs(x[96:128])
+        dx = T.from_numpy(x)
+        dy = T(gpu.I32, [K // 32 * 36 // 4 + 8])
+        gpu.lib.check(gpu.lib.get().cllm_quantize_row_q8_1(None, dx.data_ptr(), dy.data_ptr(), K), "q8_1")
+        got = dy.raw()[: K // 32 * 36]
+        assert np.array_equal(got, O.quantize_q8_1(x))
+
+
 @pytest.mark.parametrize("K", [256, 4096, 14336])
 def test_quantize_q8_K_bit_exact(gpu, K):
     T = gpu.Tensor
@@ -61,12 +78,12 @@ def test_quantize_q8_K_bit_exact(gpu, K):
         assert np.array_equal(got, O.quantize_q8_K(x))
 
 
-@pytest.mark.parametrize("t", [O.Q4_0, O.Q8_0, O.Q4_K])
+@pytest.mark.parametrize("t", [O.Q4_0, O.Q4_1, O.Q8_0, O.Q4_K])
 def test_block_integer_sums_bit_exact(gpu, t):
     K = 4096
     w = rand_blocks(t, 1, K, rng)
     x = rng.standard_normal(K).astype(np.float32)
-    a = O.quantize_q8_K(x) if t == O.Q4_K else O.quantize_q8_0(x)
+    a = O.quantize_q8_K(x) if t == O.Q4_K else O.quantize_q8_1(x) if t == O.Q4_1 else O.quantize_q8_0(x)
     _, want = O.vec_dot(t, K, w, a)
     dw = gpu.Tensor.from_numpy(w, t, [K, 1])
     dx = gpu.Tensor.from_numpy(x)
@@ -90,20 +107,20 @@ def _mm_case(gpu, t, K, N, M, ne02=1, ne12=1):
     return got, want
 
 
-@pytest.mark.parametrize("t", [O.Q4_K, O.Q4_0, O.Q8_0])
+@pytest.mark.parametrize("t", [O.Q4_K, O.Q4_0, O.Q8_0, O.Q4_1])
 @pytest.mark.parametrize("K,N,M", [(256, 1, 1), (512, 7, 1), (4096, 130, 1), (2048, 64, 2), (1024, 33, 3), (768, 40, 4), (512, 20, 5), (1280, 24, 8)])
 def test_mul_mat_quant_gemv(gpu, t, K, N, M):
     got, want = _mm_case(gpu, t, K, N, M)
     assert rel_err(got, want) < T1
 
 
-@pytest.mark.parametrize("t,K", [(O.Q4_K, 14336), (O.Q4_0, 14336), (O.Q8_0, 29568), (O.Q4_K, 8192)])
+@pytest.mark.parametrize("t,K", [(O.Q4_K, 14336), (O.Q4_0, 14336), (O.Q8_0, 29568), (O.Q4_K, 8192), (O.Q4_1, 14336), (O.Q4_1, 29568)])
 def test_mul_mat_quant_long_rows(gpu, t, K):
     got, want = _mm_case(gpu, t, K, 96, 1)
     assert rel_err(got, want) < T1
 
 
-@pytest.mark.parametrize("t", [O.Q4_K, O.Q4_0, O.Q8_0])
+@pytest.mark.parametrize("t", [O.Q4_K, O.Q4_0, O.Q8_0, O.Q4_1])
 @pytest.mark.parametrize("K,N,M", [(512, 64, 16), (1024, 100, 33), (4096, 256, 128), (256, 17, 9),
                                    (768, 130, 70), (4352, 300, 257)])        # two token tiles, ragged N / M / K
 def test_mul_mat_quant_gemm(gpu, t, K, N, M):
@@ -138,7 +155,7 @@ def test_mul_mat_empty(gpu):
     assert out.ne[:2] == [4, 0]
 
 
-@pytest.mark.parametrize("t", [O.Q4_K, O.Q8_0, O.Q4_0])
+@pytest.mark.parametrize("t", [O.Q4_K, O.Q8_0, O.Q4_0, O.Q4_1])
 def test_mul_mat_id(gpu, t):
     K, N, E, U, Tk = 512, 40, 8, 2, 3
     w = rand_blocks(t, N * E, K, rng)
@@ -298,7 +315,7 @@ def test_cpy_v_cache_transposed_and_cont(gpu):
     assert np.array_equal(got, np.ascontiguousarray(c.transpose(1, 0, 2)))
 
 
-@pytest.mark.parametrize("t", [O.Q4_0, O.Q8_0, O.Q4_K, O.F16, O.F32])
+@pytest.mark.parametrize("t", [O.Q4_0, O.Q4_1, O.Q8_0, O.Q4_K, O.F16, O.F32])
 def test_get_rows_bit_exact(gpu, t):
     n0, rows, n = 512, 30, 7
     table = rng.standard_normal((rows, n0)).astype(O.NP_OF[t]) if t in (O.F16, O.F32) else rand_blocks(t, rows, n0, rng)
@@ -401,7 +418,8 @@ def test_rope_kv_attn_decode_rejects_what_it_cannot_do(gpu):
 
 # ---- fused single-token patterns (cllm_op_mul_mat_vec_fused) == the node sequence they replace, to the bit ----------------------
 @pytest.mark.parametrize("t,K,N,pro", [(O.Q4_K, 4096, 512, 1), (O.Q4_K, 8192, 256, 1), (O.Q4_K, 14336, 256, 4), (O.Q4_K, 29440, 128, 4),
-                                       (O.Q8_0, 29568, 128, 4), (O.Q4_0, 4096, 384, 1), (O.Q8_0, 2048, 100, 2), (O.Q4_K, 256, 33, 4)])
+                                       (O.Q8_0, 29568, 128, 4), (O.Q4_0, 4096, 384, 1), (O.Q8_0, 2048, 100, 2), (O.Q4_K, 256, 33, 4),
+                                       (O.Q4_1, 4096, 200, 1), (O.Q4_1, 14336, 64, 4), (O.Q4_1, 1024, 33, 2)])
 def test_mul_mat_vec_fused_equals_the_node_sequence(gpu, t, K, N, pro):
     ops, T = gpu.ops, gpu.Tensor
     w = T.from_numpy(rand_blocks(t, N, K, rng), t, [K, N])
@@ -422,7 +440,7 @@ def test_mul_mat_vec_fused_equals_the_node_sequence(gpu, t, K, N, pro):
     assert np.array_equal(out.numpy(), want)
 
 
-@pytest.mark.parametrize("t,K,F", [(O.Q4_K, 4096, 14336), (O.Q4_0, 4096, 512), (O.Q8_0, 1024, 264), (O.Q4_K, 256, 512)])
+@pytest.mark.parametrize("t,K,F", [(O.Q4_K, 4096, 14336), (O.Q4_0, 4096, 512), (O.Q8_0, 1024, 264), (O.Q4_K, 256, 512), (O.Q4_1, 2048, 1024)])
 def test_packed_rows_merge_mat_vecs_without_changing_a_bit(gpu, t, K, F):
     """cllm_pack_rows + one launch == the separate launches: q|k|v concatenated; gate/up interleaved with the SiLU*up epilogue"""
     ops, T, L = gpu.ops, gpu.Tensor, gpu.lib.get()

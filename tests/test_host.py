@@ -14,7 +14,7 @@ def test_synth_q4_K_scale_packing_round_trips(pkg):
 
 def test_synth_q8_0_q4_0_statistics(pkg):
     rng = np.random.default_rng(4)
-    for t in (O.Q8_0, O.Q4_0):
+    for t in (O.Q8_0, O.Q4_0, O.Q4_1):
         w = pkg.synth.quant_blocks(t, 2, 2048, rng, 0.05)
         x = O.dequantize(t, w[1], 2048)
         assert 0.02 < x.std() < 0.1 and abs(x.mean()) < 0.02

@@ -40,6 +40,22 @@ def test_quantize_q8_0_bit_exact(K):
         assert np.array_equal(got, ref)
 
 
+@pytest.mark.parametrize("K", [32, 256, 4096, 14336])
+def test_quantize_q8_1_bit_exact(K):
+    """the activation format of Q4_1 weights: Q8_0's quants plus s = fp16(d * sum q)"""
+    R = O.ref()
+    for scale in (1.0, 1e-3, 300.0, 6e4):
+        x = (rng.standard_normal(K) * scale).astype(np.float32)
+        if K >= 256:
+            x[:32] = 0.0
+            x[64:96] = np.arange(32, dtype=np.float32) + 0.5
+            x[96:128] = np.abs(x[96:128])             # all-positive block: the largest |s|
+        got = O.quantize_q8_1(x)
+        ref = np.zeros_like(got)
+        assert R.ref_quantize_cpu(O.Q8_1, P(x), P(ref), C.c_int64(K)) == 0
+        assert np.array_equal(got, ref)
+
+
 @pytest.mark.parametrize("K", [256, 4096, 14336])
 def test_quantize_q8_K_bit_exact(K):
     R = O.ref()
@@ -53,7 +69,7 @@ def test_quantize_q8_K_bit_exact(K):
         assert np.array_equal(got, ref)
 
 
-@pytest.mark.parametrize("t", [O.Q4_0, O.Q8_0, O.Q4_K])
+@pytest.mark.parametrize("t", [O.Q4_0, O.Q4_1, O.Q8_0, O.Q4_K])
 def test_dequantize_bit_exact(t):
     R = O.ref()
     K = 2048
@@ -64,13 +80,13 @@ def test_dequantize_bit_exact(t):
     assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
 
 
-@pytest.mark.parametrize("t", [O.Q4_0, O.Q8_0, O.Q4_K])
+@pytest.mark.parametrize("t", [O.Q4_0, O.Q4_1, O.Q8_0, O.Q4_K])
 def test_vec_dot_matches_reference(t):
     R = O.ref()
     K = 4096
     w = rand_blocks(t, 1, K, rng)
     x = rng.standard_normal(K).astype(np.float32)
-    a = O.quantize_q8_K(x) if t == O.Q4_K else O.quantize_q8_0(x)
+    a = O.quantize_q8_K(x) if t == O.Q4_K else O.quantize_q8_1(x) if t == O.Q4_1 else O.quantize_q8_0(x)
     got, isums = O.vec_dot(t, K, w, a)
     s = C.c_float()
     assert R.ref_vec_dot(t, C.c_int64(K), P(w), P(a), C.byref(s)) == 0
@@ -81,6 +97,7 @@ def test_vec_dot_matches_reference(t):
 
 
 @pytest.mark.parametrize("t,K,N,M", [(O.Q4_K, 512, 48, 1), (O.Q4_K, 1024, 33, 5), (O.Q4_0, 256, 40, 1), (O.Q4_0, 512, 17, 7),
+                                     (O.Q4_1, 256, 40, 1), (O.Q4_1, 1024, 19, 6),
                                      (O.Q8_0, 256, 40, 1), (O.Q8_0, 1024, 31, 3), (O.F16, 128, 50, 3), (O.F32, 96, 20, 2)])
 def test_mul_mat(t, K, N, M):
     R = O.ref()
@@ -110,7 +127,7 @@ def test_mul_mat_broadcast_heads():
     assert rel_err(got, ref) < 1e-5
 
 
-@pytest.mark.parametrize("t", [O.Q4_K, O.Q8_0])
+@pytest.mark.parametrize("t", [O.Q4_K, O.Q8_0, O.Q4_1])
 def test_mul_mat_id(t):
     R = O.ref()
     K, N, E, U, T = 512, 24, 4, 2, 3
