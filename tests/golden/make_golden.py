@@ -99,3 +99,36 @@ for wt, name in ((12, "q4_k"), (2, "q4_0"), (8, "q8_0")):
 model["prompt"] = np.array(prompt, np.int32)
 np.savez_compressed(os.path.join(HERE, "tiny_llama3_reference.npz"), **model)
 print("tiny_llama3_reference.npz:", {k: v.shape for k, v in model.items()})
+
+# ---- Q4_1 (added after the files above were committed: separate files and a separate random stream, so those stay byte-identical) ----
+rng41 = np.random.default_rng(20260925)
+q41 = {}
+for K in (256, 4096):
+    x = (rng41.standard_normal(K) * 2).astype(np.float32)
+    x[:32] = 0
+    x[64:96] = np.arange(32, dtype=np.float32) + 0.5
+    q1 = np.zeros(K // 32 * 36, np.uint8)
+    assert R.ref_quantize_cpu(9, P(x), P(q1), C.c_int64(K)) == 0
+    q41[f"quant_x_{K}"], q41[f"quant_q8_1_{K}"] = x, q1
+for M in (1, 12):
+    K, N = 1024, 48
+    w = rand_blocks(3, N, K, rng41)
+    x = rng41.standard_normal((M, K)).astype(np.float32)
+    y = np.zeros((M, N), np.float32)
+    assert R.ref_mul_mat(3, C.c_int64(K), C.c_int64(N), C.c_int64(M), C.c_int64(1), C.c_int64(1), P(w), P(x), P(y)) == 0
+    q41[f"mm_q4_1_{M}_w"], q41[f"mm_q4_1_{M}_x"], q41[f"mm_q4_1_{M}_y"] = w, x, y
+deq = np.zeros(1024, np.float32)
+assert R.ref_dequantize(3, P(q41["mm_q4_1_1_w"][0]), P(deq), C.c_int64(1024)) == 0
+q41["dequant_q4_1"] = deq
+# (with the prompt of the other three models the oracle hits one of the path's own rounding flips -- an int8 activation one step off -- at
+#  the second token: 3e-2 on the logits, every other two-token prompt tried agrees to 2e-6; the Q4_1 fixture uses a prompt without one)
+prompt41 = [5, 9, 42, 300, 7, 99, 250, 12, 100]
+with tempfile.TemporaryDirectory() as td:
+    mp, lp = os.path.join(td, "m.bin"), os.path.join(td, "l.bin")
+    make_ggmm.write_model(mp, cfg, 3, seed=1234)
+    ids = subprocess.check_output([ref_chat, mp, "cpu", "4", "12", lp] + [str(p) for p in prompt41], stderr=subprocess.DEVNULL, text=True).split()
+    q41["model_prompt"] = np.array(prompt41, np.int32)
+    q41["model_ids"] = np.array([int(i) for i in ids], np.int32)
+    q41["model_logits"] = np.fromfile(lp, np.float32).reshape(13, cfg["vocab"])
+np.savez_compressed(os.path.join(HERE, "q4_1_reference.npz"), **q41)
+print("q4_1_reference.npz:", len(q41), "arrays")

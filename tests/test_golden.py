@@ -10,7 +10,18 @@ import oracle as O
 
 G = np.load(os.path.join(os.path.dirname(__file__), "golden", "ops_reference.npz"))
 M = np.load(os.path.join(os.path.dirname(__file__), "golden", "tiny_llama3_reference.npz"))
-TYPES = ((O.Q4_K, "q4_K"), (O.Q4_0, "q4_0"), (O.Q8_0, "q8_0"))
+G41 = np.load(os.path.join(os.path.dirname(__file__), "golden", "q4_1_reference.npz"))       # Q4_1 vectors (added later: own file)
+TYPES = ((O.Q4_K, "q4_K"), (O.Q4_0, "q4_0"), (O.Q8_0, "q8_0"), (O.Q4_1, "q4_1"))
+
+
+def _g(key):
+    return G41[key] if key in G41.files else G[key]
+
+
+def _model(name):
+    if name == "q4_1":
+        return G41["model_prompt"], G41["model_ids"], G41["model_logits"]
+    return M["prompt"], M[f"{name}_ids"], M[f"{name}_logits"]
 
 
 def rel(a, b):
@@ -23,13 +34,14 @@ def test_oracle_quantizers_match_golden_bytes(K):
     x = G[f"quant_x_{K}"]
     assert np.array_equal(O.quantize_q8_0(x), G[f"quant_q8_0_{K}"])
     assert np.array_equal(O.quantize_q8_K(x), G[f"quant_q8_K_{K}"])
+    assert np.array_equal(O.quantize_q8_1(G41[f"quant_x_{K}"]), G41[f"quant_q8_1_{K}"])
 
 
 @pytest.mark.parametrize("t,name", TYPES)
 def test_oracle_mul_mat_and_dequant_match_golden(t, name):
-    assert np.array_equal(O.dequantize(t, G[f"mm_{name}_1_w"][0], 1024), G[f"dequant_{name}"])
+    assert np.array_equal(O.dequantize(t, _g(f"mm_{name}_1_w")[0], 1024), _g(f"dequant_{name}"))
     for Mc in (1, 12):
-        w, x, y = G[f"mm_{name}_{Mc}_w"], G[f"mm_{name}_{Mc}_x"], G[f"mm_{name}_{Mc}_y"]
+        w, x, y = _g(f"mm_{name}_{Mc}_w"), _g(f"mm_{name}_{Mc}_x"), _g(f"mm_{name}_{Mc}_y")
         got = np.zeros_like(y)
         O.mul_mat(O.tensor(w, t, [1024, 48]), O.tensor(x, O.F32, [1024, Mc]), O.tensor(got, O.F32, [48, Mc]))
         assert rel(got, y) < 1e-5
@@ -51,15 +63,15 @@ def test_oracle_norm_rope_softmax_silu_attention_match_golden():
         assert np.allclose(got, G[f"rope_y_mode{mode}"], rtol=3e-7, atol=3e-7)
 
 
-@pytest.mark.parametrize("t,name", ((O.Q4_K, "q4_k"), (O.Q4_0, "q4_0"), (O.Q8_0, "q8_0")))
+@pytest.mark.parametrize("t,name", ((O.Q4_K, "q4_k"), (O.Q4_0, "q4_0"), (O.Q8_0, "q8_0"), (O.Q4_1, "q4_1")))
 def test_oracle_whole_model_matches_the_reference_host(pkg, t, name):
     """the scalar-order restatement vs chatllm.cpp itself (AVX2 CPU backend) on the same GGMM file.  Both are "the CPU
     path"; their fp32 summation order differs, so they agree to fp32 round-off until one of the path's own roundings
     (int8 activations, fp16 K/V/P) flips, and stay inside the quantization-noise floor afterwards."""
     cfg = pkg.synth.config("tiny", max_len=64)
     m = O.Llama(cfg, pkg.synth.make_model(cfg, t, seed=1234))
-    ids, logits = M[f"{name}_ids"], M[f"{name}_logits"]
-    lg = m.forward(M["prompt"])
+    prompt, ids, logits = _model(name)
+    lg = m.forward(prompt)
     assert float(np.max(np.abs(lg - logits[0]))) < 1e-4        # the prompt chunk: no earlier flip to inherit
     agree = decided = 0
     for s in range(13):
@@ -84,13 +96,16 @@ def test_gpu_quantizers_match_golden_bytes(gpu, K):
     gpu.lib.check(gpu.lib.get().cllm_quantize_row_q8_K(None, x.data_ptr(), yk.data_ptr(), K), "q8_K")
     assert np.array_equal(y0.raw()[: K // 32 * 34], G[f"quant_q8_0_{K}"])
     assert np.array_equal(yk.raw()[: K // 256 * 292], G[f"quant_q8_K_{K}"])
+    x1, y1 = gpu.Tensor.from_numpy(G41[f"quant_x_{K}"]), gpu.Tensor(gpu.I32, [K // 32 * 36 // 4 + 8])
+    gpu.lib.check(gpu.lib.get().cllm_quantize_row_q8_1(None, x1.data_ptr(), y1.data_ptr(), K), "q8_1")
+    assert np.array_equal(y1.raw()[: K // 32 * 36], G41[f"quant_q8_1_{K}"])
 
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("t,name", TYPES)
 def test_gpu_mul_mat_matches_golden(gpu, t, name):
     for Mc in (1, 12):                                  # GEMV kernel and int8-MFMA GEMM kernel
-        w, x, y = G[f"mm_{name}_{Mc}_w"], G[f"mm_{name}_{Mc}_x"], G[f"mm_{name}_{Mc}_y"]
+        w, x, y = _g(f"mm_{name}_{Mc}_w"), _g(f"mm_{name}_{Mc}_x"), _g(f"mm_{name}_{Mc}_y")
         got = gpu.ops.mul_mat(gpu.Tensor.from_numpy(w, t, [1024, 48]), gpu.Tensor.from_numpy(x)).numpy().reshape(y.shape)
         assert rel(got, y) < 1e-5
 
@@ -109,14 +124,14 @@ def test_gpu_attention_composite_matches_golden(gpu):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("t,name", ((O.Q4_K, "q4_k"), (O.Q4_0, "q4_0"), (O.Q8_0, "q8_0")))
+@pytest.mark.parametrize("t,name", ((O.Q4_K, "q4_k"), (O.Q4_0, "q4_0"), (O.Q8_0, "q8_0"), (O.Q4_1, "q4_1")))
 def test_gpu_whole_model_against_the_reference_host(gpu, t, name):
     """decoder runner vs chatllm.cpp's own CPU run on the same synthetic GGMM weights: prefill to fp32 round-off,
     greedy ids identical wherever the reference's margin decides them, never beyond the quantization-noise floor"""
     cfg = gpu.synth.config("tiny", max_len=64)
     m = gpu.Llama(cfg, gpu.synth.make_model(cfg, t, seed=1234))
-    ids, logits = M[f"{name}_ids"], M[f"{name}_logits"]
-    lg = m.forward(M["prompt"])
+    prompt, ids, logits = _model(name)
+    lg = m.forward(prompt)
     assert float(np.max(np.abs(lg - logits[0]))) < 1e-4
     agree = decided = 0
     for s in range(13):
