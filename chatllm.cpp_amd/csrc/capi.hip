@@ -123,6 +123,33 @@ extern "C" int cllm_stream_create(void ** stream) {
 extern "C" int cllm_stream_destroy(void * stream) { if (stream) HIP_TRY(hipStreamDestroy((hipStream_t) stream)); return CLLM_OK; }
 extern "C" int cllm_stream_sync(void * stream) { HIP_TRY(hipStreamSynchronize((hipStream_t) stream)); return CLLM_OK; }
 
+// ---- capture / replay of a launch sequence (what ggml_backend_i.graph_plan_create / graph_plan_compute are for, ggml-backend-impl.h:104-113) ----
+// Everything launched on `stream` between begin and end becomes one executable graph; replaying it costs one host call and removes the
+// per-launch gaps on the GPU.  end returns CLLM_E_UNSUPPORTED (and *graph_exec = NULL) if something in the sequence could not be captured.
+extern "C" int cllm_graph_capture_begin(void * stream) {
+    if (!stream) FAIL(CLLM_E_INVALID, "graph_capture_begin: the null stream cannot be captured");
+    HIP_TRY(hipStreamBeginCapture((hipStream_t) stream, hipStreamCaptureModeRelaxed));
+    return CLLM_OK;
+}
+extern "C" int cllm_graph_capture_end(void * stream, void ** graph_exec) {
+    if (!stream || !graph_exec) FAIL(CLLM_E_INVALID, "graph_capture_end: arguments");
+    *graph_exec = nullptr;
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    hipError_t e = hipStreamEndCapture((hipStream_t) stream, &graph);
+    if (e == hipSuccess) e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+    if (graph) (void) hipGraphDestroy(graph);
+    if (e != hipSuccess) { (void) hipGetLastError(); FAIL(CLLM_E_UNSUPPORTED, "graph_capture_end: %s", hipGetErrorString(e)); }
+    *graph_exec = (void *) exec;
+    return CLLM_OK;
+}
+extern "C" int cllm_graph_launch(void * graph_exec, void * stream) {
+    if (!graph_exec) FAIL(CLLM_E_INVALID, "graph_launch: null");
+    HIP_TRY(hipGraphLaunch((hipGraphExec_t) graph_exec, (hipStream_t) stream));
+    return CLLM_OK;
+}
+extern "C" int cllm_graph_destroy(void * graph_exec) { if (graph_exec) HIP_TRY(hipGraphExecDestroy((hipGraphExec_t) graph_exec)); return CLLM_OK; }
+
 extern "C" int cllm_event_create(void ** event) {
     if (!event) FAIL(CLLM_E_INVALID, "event_create: null");
     hipEvent_t e; HIP_TRY(hipEventCreate(&e));

@@ -54,6 +54,10 @@ SIGNATURES = {
     "cllm_stream_create": (C.c_int, [C.POINTER(C.c_void_p)]),
     "cllm_stream_destroy": (C.c_int, [_P]),
     "cllm_stream_sync": (C.c_int, [_P]),
+    "cllm_graph_capture_begin": (C.c_int, [_P]),
+    "cllm_graph_capture_end": (C.c_int, [_P, C.POINTER(C.c_void_p)]),
+    "cllm_graph_launch": (C.c_int, [_P, _P]),
+    "cllm_graph_destroy": (C.c_int, [_P]),
     "cllm_event_create": (C.c_int, [C.POINTER(C.c_void_p)]),
     "cllm_event_destroy": (C.c_int, [_P]),
     "cllm_event_record": (C.c_int, [_P, _P]),

@@ -75,6 +75,12 @@ CLLM_API int  cllm_host_free(void * ptr);
 CLLM_API int  cllm_stream_create(void ** stream);
 CLLM_API int  cllm_stream_destroy(void * stream);
 CLLM_API int  cllm_stream_sync(void * stream);                 /* backend_i.synchronize */
+/* capture of everything launched on `stream` between begin and end into one replayable graph (ggml_backend_i.graph_plan_create /
+ * graph_plan_compute, ggml-backend-impl.h:104-113); capture_end: CLLM_E_UNSUPPORTED and *graph_exec = NULL if the sequence cannot be captured */
+CLLM_API int  cllm_graph_capture_begin(void * stream);
+CLLM_API int  cllm_graph_capture_end(void * stream, void ** graph_exec);
+CLLM_API int  cllm_graph_launch(void * graph_exec, void * stream);
+CLLM_API int  cllm_graph_destroy(void * graph_exec);
 /* events on a stream (backend_i.event_record / device_i.event_synchronize); elapsed in milliseconds */
 CLLM_API int  cllm_event_create(void ** event);
 CLLM_API int  cllm_event_destroy(void * event);

@@ -15,6 +15,7 @@
 #include "backend.h"
 
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <fstream>
@@ -49,7 +50,10 @@ int main(int argc, char ** argv) {
         std::vector<float> logits;
         std::vector<int> in = ids;
         int n_past = 0;
+        const int skip = n_decode > 40 ? 16 : 0;            // steps left out of the decode timing (first launches, captures, page faults)
+        auto t0 = std::chrono::steady_clock::now();
         for (int s = 0; s <= n_decode; s++) {
+            if (s == 1 + skip) t0 = std::chrono::steady_clock::now();
             obj.model->set_n_past(n_past);
             if (!obj.model->generate_next_token(in, gen, logits)) { fprintf(stderr, "generate_next_token failed\n"); return 4; }
             n_past += (int) in.size();
@@ -59,6 +63,11 @@ int main(int argc, char ** argv) {
             in.assign(1, s < (int) teacher.size() ? teacher[s] : tok);
         }
         if (fo) fclose(fo);
+        if (n_decode > skip) {
+            const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+            fprintf(stderr, "decode: %d tokens in %.1f ms = %.3f ms/token = %.1f tok/s (context %d -> %d)\n", n_decode - skip, ms, ms / (n_decode - skip),
+                    (n_decode - skip) * 1e3 / ms, (int) ids.size() + skip, (int) ids.size() + n_decode);
+        }
     } catch (const std::exception & e) {
         fprintf(stderr, "error: %s\n", e.what());
         return 1;

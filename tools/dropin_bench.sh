@@ -9,6 +9,6 @@ cd $R/oracle/_ref
 for ngl in ${NGL:-all}; do
   for n in ${NS:-144 400 144 400}; do
     s=$(date +%s%N); ./ref_chat $M $ngl ${THREADS:-16} $n - $IDS > /tmp/ids_$n.txt 2>/tmp/err_$n.txt; rc=$?; e=$(date +%s%N)
-    echo "ngl=$ngl n_decode=$n wall_ms=$(( (e - s) / 1000000 )) rc=$rc"; tail -2 /tmp/err_$n.txt | cut -c1-200
+    echo "ngl=$ngl n_decode=$n wall_ms=$(( (e - s) / 1000000 )) rc=$rc"; grep "^decode:" /tmp/err_$n.txt | cut -c1-200
   done
 done
