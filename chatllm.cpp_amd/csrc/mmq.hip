@@ -216,7 +216,11 @@ __global__ void __launch_bounds__(256, 2) k_mmq(const mmq_args a) {
             for (int i = 0; i < MMQ_MI; i++) fa[i] = *(const long *)(Xt + (wm + i * 16 + l15) * MMQ_LD + s * 32 + l4 * 8);
 #pragma unroll
             for (int j = 0; j < 4; j++) fb[j] = *(const long *)(Wt + (wn + j * 16 + l15) * MMQ_LD + s * 32 + l4 * 8);
-            if (IS_K) {
+            // Q4_0 / Q4_1 / Q8_0: the 4 x MI patches of a 32-block are software-pipelined: the MFMA of patch p+1 is issued BEFORE the VALU work that folds
+            // patch p's block scale in (sched_barrier pins that order), so the matrix core runs under the VALU instead of the wave
+            // idling in s_nop until its result may be read (the compiler's own schedule: one D register set, 8 wait states per patch).
+            constexpr int NP = 4 * MMQ_MI;
+            if (IS_K) {             // (the same pipelining measured 2 % slower here: the kernel is at the VGPR limit already)
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
                     const int sc = (int)((scb[j] >> (8 * s)) & 0xff);
@@ -233,14 +237,24 @@ __global__ void __launch_bounds__(256, 2) k_mmq(const mmq_args a) {
                 for (int j = 0; j < 4; j++) dw[j] = *(const float *)(Ws + (s * MMQ_BN + wn + j * 16 + l15) * 4);
 #pragma unroll
                 for (int i = 0; i < MMQ_MI; i++) dx[i] = *(const f32x4 *)(Xs + (s * MMQ_BM + wm + i * 16 + l4 * 4) * 4);
+                // int32 -> f32 without v_cvt: the accumulator starts at the bit pattern of 1.5 * 2^23, so D's bits ARE the float
+                // 12582912 + sum (exact: |sum| <= 32 * 127 * 127 < 2^22 keeps it inside the binade with ulp 1); one packed subtract
+                // recovers float(sum) for two results at a time
+                constexpr int MAGIC_I = 0x4B400000; constexpr float MAGIC_F = 12582912.0f;
+                const i32x4 c0 = { MAGIC_I, MAGIC_I, MAGIC_I, MAGIC_I };
+                i32x4 dcur = __builtin_amdgcn_mfma_i32_16x16x32_i8(fa[0], fb[0], c0, 0, 0, 0);
 #pragma unroll
-                for (int j = 0; j < 4; j++)
+                for (int p = 0; p < NP; p++) {
+                    const int i = p % MMQ_MI, j = p / MMQ_MI;
+                    i32x4 dnext = dcur;
+                    if (p + 1 < NP) dnext = __builtin_amdgcn_mfma_i32_16x16x32_i8(fa[(p + 1) % MMQ_MI], fb[(p + 1) / MMQ_MI], c0, 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    const f32x4 df = __builtin_bit_cast(f32x4, dcur);      // (the whole vector: bit_cast of ONE element of an ext_vector reads element 0 with this compiler)
 #pragma unroll
-                    for (int i = 0; i < MMQ_MI; i++) {
-                        const i32x4 d = __builtin_amdgcn_mfma_i32_16x16x32_i8(fa[i], fb[j], i32x4{0, 0, 0, 0}, 0, 0, 0);
-#pragma unroll
-                        for (int r = 0; r < 4; r++) acc_f[i][j][r] = __builtin_fmaf((float) d[r], dw[j] * dx[i][r], acc_f[i][j][r]);
-                    }
+                    for (int r = 0; r < 4; r++) acc_f[i][j][r] = __builtin_fmaf(df[r] - MAGIC_F, dw[j] * dx[i][r], acc_f[i][j][r]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    dcur = dnext;
+                }
                 if (IS_41) {                                       // + m_w[n][s] * s_x[m][s]  (ggml_vec_dot_q4_1_q8_1, quants.c:182)
                     float mw[4]; f32x4 sx[MMQ_MI];
 #pragma unroll
