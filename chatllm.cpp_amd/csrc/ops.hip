@@ -328,7 +328,7 @@ extern "C" int cllm_op_scale_mask_soft_max(void * stream, const cllm_tensor * sr
 // ================================================================================================
 // element-wise family: generic strided, one thread per element of dst, index decomposed over ne[]
 // ================================================================================================
-enum { EW_DIAG_MASK = 0, EW_SCALE = 1, EW_SILU = 2, EW_ADD = 3, EW_MUL = 4, EW_SILU_MUL = 5 };
+enum { EW_DIAG_MASK = 0, EW_SCALE = 1, EW_SILU = 2, EW_ADD = 3, EW_MUL = 4, EW_SILU_MUL = 5, EW_DIV = 6 };
 
 template <int OP>
 __global__ void __launch_bounds__(256) k_elementwise(tview a, tview b, tview d, float f0, float f1, int i0p) {
@@ -349,6 +349,7 @@ __global__ void __launch_bounds__(256) k_elementwise(tview a, tview b, tview d, 
             const float z = *(const float *)(b.data + (i0 % b.ne[0])*b.nb[0] + (i1 % b.ne[1])*b.nb[1] + (i2 % b.ne[2])*b.nb[2] + (i3 % b.ne[3])*b.nb[3]);
             if (OP == EW_ADD)      y = x + z;
             else if (OP == EW_MUL) y = x * z;
+            else if (OP == EW_DIV) y = __fdiv_rn(x, z);                                     // IEEE division (ggml_vec_div_f32)
             else {                                                                          // silu(gate) * up
                 const float sl = (i0 < (d.ne[0] & ~(int64_t) 7)) ? x / (1.0f + ggml_expf_poly(0.0f - x)) : x / (1.0f + libm_expf(-x));
                 y = sl * z;
@@ -384,7 +385,71 @@ extern "C" int cllm_op_unary(void * stream, int op, const cllm_tensor * src, cll
 }
 extern "C" int cllm_op_add(void * stream, const cllm_tensor * a, const cllm_tensor * b, cllm_tensor * dst) { if (!b) FAIL(CLLM_E_INVALID, "add: null"); return ew_launch<EW_ADD>(stream, a, b, dst, 0, 0, 0, "add"); }
 extern "C" int cllm_op_mul(void * stream, const cllm_tensor * a, const cllm_tensor * b, cllm_tensor * dst) { if (!b) FAIL(CLLM_E_INVALID, "mul: null"); return ew_launch<EW_MUL>(stream, a, b, dst, 0, 0, 0, "mul"); }
+extern "C" int cllm_op_div(void * stream, const cllm_tensor * a, const cllm_tensor * b, cllm_tensor * dst) { if (!b) FAIL(CLLM_E_INVALID, "div: null"); return ew_launch<EW_DIV>(stream, a, b, dst, 0, 0, 0, "div"); }
 extern "C" int cllm_op_silu_mul(void * stream, const cllm_tensor * g, const cllm_tensor * u, cllm_tensor * dst) { if (!u) FAIL(CLLM_E_INVALID, "silu_mul: null"); return ew_launch<EW_SILU_MUL>(stream, g, u, dst, 0, 0, 0, "silu_mul"); }
+
+// ================================================================================================
+// SUM_ROWS / TOP_K: the router of a sparse-MoE block (GenericSparseMLP::forward, src/layers.cpp:3755-3815): rows of n_expert values
+// ================================================================================================
+// ggml_compute_forward_sum_rows_f32 (ops.cpp:1451-1482) -> ggml_vec_sum_f32 (vec.h:1510-1520): sequential, accumulated in double
+__global__ void __launch_bounds__(256) k_sum_rows(tview s, tview d) {
+    const int64_t rows = s.ne[1] * s.ne[2] * s.ne[3];
+    for (int64_t r = (int64_t) blockIdx.x * blockDim.x + threadIdx.x; r < rows; r += (int64_t) gridDim.x * blockDim.x) {
+        const int64_t i1 = r % s.ne[1], i2 = (r / s.ne[1]) % s.ne[2], i3 = r / (s.ne[1] * s.ne[2]);
+        const float * x = (const float *)(s.data + i1*s.nb[1] + i2*s.nb[2] + i3*s.nb[3]);
+        double sum = 0.0;
+        for (int64_t i = 0; i < s.ne[0]; i++) sum += (double) x[i];
+        *(float *)(d.data + i1*d.nb[1] + i2*d.nb[2] + i3*d.nb[3]) = (float) sum;
+    }
+}
+extern "C" int cllm_op_sum_rows(void * stream, const cllm_tensor * src, cllm_tensor * dst) {
+    if (!src || !dst) FAIL(CLLM_E_INVALID, "sum_rows: null");
+    if (src->type != CLLM_TYPE_F32 || dst->type != CLLM_TYPE_F32 || src->nb[0] != 4 || dst->nb[0] != 4) FAIL(CLLM_E_UNSUPPORTED, "sum_rows: dense F32 rows");
+    if (dst->ne[0] != 1 || dst->ne[1] != src->ne[1] || dst->ne[2] != src->ne[2] || dst->ne[3] != src->ne[3]) FAIL(CLLM_E_INVALID, "sum_rows: shape");
+    const int64_t rows = src->ne[1] * src->ne[2] * src->ne[3];
+    if (rows == 0) return CLLM_OK;
+    int64_t grid = (rows + 255) / 256; if (grid > 4096) grid = 4096;
+    hipLaunchKernelGGL(k_sum_rows, dim3((unsigned) grid), dim3(256), 0, (hipStream_t) stream, tv(src), tv(dst));
+    LAUNCH_CHECK();
+    return CLLM_OK;
+}
+// ggml_compute_forward_top_k_f32 (ops.cpp:8057-8094): the indices of the k largest values in descending order (std::partial_sort with
+// data[a] > data[b]), then the first two swapped ("the order is not important").  Equal values: the lower index first (the reference
+// leaves that to its heap; softmax probabilities of distinct logits do not tie).  One thread per row: rows are n_expert long.
+__global__ void __launch_bounds__(256) k_top_k(tview s, tview d, int k) {
+    const int64_t rows = s.ne[1] * s.ne[2] * s.ne[3];
+    const int n = (int) s.ne[0];
+    for (int64_t r = (int64_t) blockIdx.x * blockDim.x + threadIdx.x; r < rows; r += (int64_t) gridDim.x * blockDim.x) {
+        const int64_t i1 = r % s.ne[1], i2 = (r / s.ne[1]) % s.ne[2], i3 = r / (s.ne[1] * s.ne[2]);
+        const float * x = (const float *)(s.data + i1*s.nb[1] + i2*s.nb[2] + i3*s.nb[3]);
+        int32_t * out = (int32_t *)(d.data + i1*d.nb[1] + i2*d.nb[2] + i3*d.nb[3]);
+        float prev_v = INFINITY; int prev_i = -1;                       // the last pick: the next one comes strictly after it in (value desc, index asc)
+        for (int j = 0; j < k; j++) {
+            float best = -INFINITY; int bi = -1;
+            for (int i = 0; i < n; i++) {
+                const float v = x[i];
+                const bool after = v < prev_v || (v == prev_v && i > prev_i);
+                if (after && (bi < 0 || v > best)) { best = v; bi = i; }
+            }
+            if (bi < 0) bi = 0;                                           // NaNs: the CPU's comparator is not a strict weak order there either
+            out[j] = bi; prev_v = best; prev_i = bi;
+        }
+        if (k > 1) { const int32_t t = out[0]; out[0] = out[1]; out[1] = t; }
+    }
+}
+extern "C" int cllm_op_top_k(void * stream, const cllm_tensor * src, cllm_tensor * dst) {
+    if (!src || !dst) FAIL(CLLM_E_INVALID, "top_k: null");
+    if (src->type != CLLM_TYPE_F32 || dst->type != CLLM_TYPE_I32 || src->nb[0] != 4 || dst->nb[0] != 4) FAIL(CLLM_E_UNSUPPORTED, "top_k: F32 rows -> I32 rows");
+    const int64_t k = dst->ne[0];
+    if (k < 1 || k > src->ne[0] || dst->ne[1] != src->ne[1] || dst->ne[2] != src->ne[2] || dst->ne[3] != src->ne[3]) FAIL(CLLM_E_INVALID, "top_k: shape");
+    if (src->ne[0] > 4096) FAIL(CLLM_E_UNSUPPORTED, "top_k: rows of %lld values", (long long) src->ne[0]);
+    const int64_t rows = src->ne[1] * src->ne[2] * src->ne[3];
+    if (rows == 0) return CLLM_OK;
+    int64_t grid = (rows + 255) / 256; if (grid > 4096) grid = 4096;
+    hipLaunchKernelGGL(k_top_k, dim3((unsigned) grid), dim3(256), 0, (hipStream_t) stream, tv(src), tv(dst), (int) k);
+    LAUNCH_CHECK();
+    return CLLM_OK;
+}
 
 // ================================================================================================
 // SET_ROWS (K-cache write)   ggml_compute_forward_set_rows_f32, ops.cpp:4892-4940

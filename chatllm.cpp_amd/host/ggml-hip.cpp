@@ -255,7 +255,9 @@ bool dev_supports_op(ggml_backend_dev_t, const ggml_tensor * op) {
             return is_q(a->type) && f32_dense(b) && op->src[2] && op->src[2]->type == GGML_TYPE_I32 && a->ne[3] == 1 && b->ne[3] == 1 &&
                    (b->ne[1] == 1 || b->ne[1] == op->src[2]->ne[0]) && op->src[2]->ne[0] * op->src[2]->ne[1] <= 65535;
         case GGML_OP_RMS_NORM: return f32_dense(a) && op->type == GGML_TYPE_F32;
-        case GGML_OP_ADD: case GGML_OP_MUL: return a->type == GGML_TYPE_F32 && b->type == GGML_TYPE_F32 && op->type == GGML_TYPE_F32 && ggml_can_repeat(b, a);
+        case GGML_OP_ADD: case GGML_OP_MUL: case GGML_OP_DIV: return a->type == GGML_TYPE_F32 && b->type == GGML_TYPE_F32 && op->type == GGML_TYPE_F32 && ggml_can_repeat(b, a);
+        case GGML_OP_SUM_ROWS: return f32_dense(a) && f32_dense(op);
+        case GGML_OP_TOP_K: return f32_dense(a) && op->type == GGML_TYPE_I32 && a->ne[0] <= 4096;
         case GGML_OP_SCALE: case GGML_OP_DIAG_MASK_INF: return a->type == GGML_TYPE_F32 && op->type == GGML_TYPE_F32;
         case GGML_OP_UNARY: return ggml_get_unary_op(op) == GGML_UNARY_OP_SILU && f32_dense(a) && f32_dense(op);
         case GGML_OP_ROPE: {
@@ -402,8 +404,9 @@ void plan_attention(ggml_cgraph * g, fuse_plan & P, const std::vector<int> & loc
         return i >= 0 && !(node(i)->flags & GGML_TENSOR_FLAG_OUTPUT) && local[i] == uses && ggml_node_get_use_count(g, i) == uses;
     };
     // x -> RESHAPE* -> ROPE -> RESHAPE* -> end : returns the ROPE and the node under it; every node of the chain is collected
-    auto through_reshapes = [&](const ggml_tensor * t, std::vector<int> & chain) {
-        while (t && t->op == GGML_OP_RESHAPE) { chain.push_back(find(t)); t = t->src[0]; }
+    auto through_reshapes = [&](const ggml_tensor * t, std::vector<int> & chain) {      // (a VIEW of everything at offset 0 is a reshape too)
+        while (t && (t->op == GGML_OP_RESHAPE || (t->op == GGML_OP_VIEW && t->src[0] && t->data == t->src[0]->data && ggml_nelements(t) == ggml_nelements(t->src[0]) &&
+                                                   ggml_is_contiguous(t) && ggml_is_contiguous(t->src[0])))) { chain.push_back(find(t)); t = t->src[0]; }
         return t;
     };
     for (int i = 0; i < n; i++) {
@@ -440,18 +443,26 @@ void plan_attention(ggml_cgraph * g, fuse_plan & P, const std::vector<int> & loc
         if (qrope->op != GGML_OP_ROPE || iqp < 0 || iqrope < 0 || !only_local(iqp, 1) || !only_local(iqrope, 1)) continue;
         const ggml_tensor * pos = qrope->src[1];
         if (!pos || pos->type != GGML_TYPE_I32 || ggml_nelements(pos) != 1 || !pos->data) continue;
-        // ---- the cache writes of this step: SET_ROWS(k_cache, RESHAPE*(ROPE(RESHAPE*(k vector), pos)), pos) and CPY(TRANSPOSE(v vector) -> column n_kv - 1)
+        // ---- the cache writes of this step: K row n_kv - 1 <- RESHAPE*(ROPE(RESHAPE*(k vector), pos)), by SET_ROWS(k_cache, ., pos)
+        //      (KVCacheAttention) or by CPY into a view of that row (the sliding-window attention classes); CPY(TRANSPOSE(v vector) -> column n_kv - 1)
         int iset = -1, icpy = -1;
-        const char * vcol = (const char *) vv->data + (size_t)(n_kv - 1) * 2;
+        const char * vcol = (const char *) vv->data + (size_t)(n_kv - 1) * 2, * krow = (const char *) kp->data + (size_t)(n_kv - 1) * KD * 2;
         for (int j = ikq - 1; j >= 0 && j >= ikq - 64 && (iset < 0 || icpy < 0); j--) {
             const ggml_tensor * t = node(j);
             if (iset < 0 && t->op == GGML_OP_SET_ROWS && t->data == kp->data) iset = j;
-            if (icpy < 0 && t->op == GGML_OP_CPY && t->src[1] && (const char *) t->src[1]->data == vcol) icpy = j;
+            if (iset < 0 && t->op == GGML_OP_CPY && t->src[1] && (const char *) t->src[1]->data == krow && (const char *) kp->data != (const char *) vv->data) iset = j;
+            if (icpy < 0 && t->op == GGML_OP_CPY && t->src[1] && (const char *) t->src[1]->data == vcol && j != iset) icpy = j;
         }
-        if (iset < 0 || icpy < 0) continue;
+        if (iset < 0 || icpy < 0 || iset == icpy) continue;
         const ggml_tensor * setr = node(iset), * cpy = node(icpy);
-        if (setr->type != GGML_TYPE_F16 || setr->ne[0] != (int64_t) KD || setr->nb[0] != 2 || setr->nb[1] != KD * 2 || !setr->src[1] || setr->src[1]->data != pos->data ||
-            setr->src[1]->type != GGML_TYPE_I32 || ggml_nelements(setr->src[1]) != 1) continue;
+        if (setr->op == GGML_OP_SET_ROWS) {
+            if (setr->type != GGML_TYPE_F16 || setr->ne[0] != (int64_t) KD || setr->nb[0] != 2 || setr->nb[1] != KD * 2 || !setr->src[1] || setr->src[1]->data != pos->data ||
+                setr->src[1]->type != GGML_TYPE_I32 || ggml_nelements(setr->src[1]) != 1) continue;
+        } else {
+            const ggml_tensor * kdst = setr->src[1];
+            if (kdst->type != GGML_TYPE_F16 || ggml_nelements(kdst) != (int64_t) KD || !ggml_is_contiguous(kdst) || setr->src[0]->type != GGML_TYPE_F32 ||
+                ggml_nelements(setr->src[0]) != (int64_t) KD || !ggml_is_contiguous(setr->src[0])) continue;
+        }
         const ggml_tensor * vdst = cpy->src[1], * vT = cpy->src[0];
         if (vdst->type != GGML_TYPE_F16 || vdst->ne[0] != 1 || vdst->ne[1] != (int64_t) KD || vdst->nb[1] != (size_t) ML * 2 || vT->type != GGML_TYPE_F32 ||
             vT->op != GGML_OP_TRANSPOSE || vT->ne[0] != 1 || vT->ne[1] != (int64_t) KD || vT->nb[1] != 4) continue;
@@ -725,6 +736,9 @@ ggml_status be_graph_compute(ggml_backend_t backend, ggml_cgraph * g) {
             case GGML_OP_RMS_NORM: { float eps; memcpy(&eps, n->op_params, 4); rc = CALL(cllm_op_rms_norm, st, &da, &d, eps); } break;
             case GGML_OP_ADD: rc = CALL(cllm_op_add, st, &da, &db, &d); break;
             case GGML_OP_MUL: rc = CALL(cllm_op_mul, st, &da, &db, &d); break;
+            case GGML_OP_DIV: rc = CALL(cllm_op_div, st, &da, &db, &d); break;
+            case GGML_OP_SUM_ROWS: rc = CALL(cllm_op_sum_rows, st, &da, &d); break;
+            case GGML_OP_TOP_K: rc = CALL(cllm_op_top_k, st, &da, &d); break;
             case GGML_OP_SCALE: { float s, bias; memcpy(&s, n->op_params, 4); memcpy(&bias, (const float *) n->op_params + 1, 4); rc = CALL(cllm_op_scale, st, &da, &d, s, bias); } break;
             case GGML_OP_DIAG_MASK_INF: rc = CALL(cllm_op_diag_mask_inf, st, &da, &d, n->op_params[0]); break;
             case GGML_OP_UNARY: rc = CALL(cllm_op_unary, st, CLLM_UNARY_SILU, &da, &d); break;

@@ -91,6 +91,9 @@ SIGNATURES = {
     "cllm_op_unary": (C.c_int, [_P, C.c_int, _T, _T]),
     "cllm_op_add": (C.c_int, [_P, _T, _T, _T]),
     "cllm_op_mul": (C.c_int, [_P, _T, _T, _T]),
+    "cllm_op_div": (C.c_int, [_P, _T, _T, _T]),
+    "cllm_op_sum_rows": (C.c_int, [_P, _T, _T]),
+    "cllm_op_top_k": (C.c_int, [_P, _T, _T]),
     "cllm_op_silu_mul": (C.c_int, [_P, _T, _T, _T]),
     "cllm_op_set_rows": (C.c_int, [_P, _T, _T, _T]),
     "cllm_op_cpy": (C.c_int, [_P, _T, _T]),

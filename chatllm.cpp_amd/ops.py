@@ -142,6 +142,25 @@ def mul(a, b, dst=None):
     return dst
 
 
+def div(a, b, dst=None):
+    dst = dst or Tensor(F32, a.ne)
+    _l.check(_l.get().cllm_op_div(None, _ref(a), _ref(b), _ref(dst)), "div")
+    return dst
+
+
+def sum_rows(a, dst=None):
+    dst = dst or Tensor(F32, [1, a.ne[1], a.ne[2], a.ne[3]])
+    _l.check(_l.get().cllm_op_sum_rows(None, _ref(a), _ref(dst)), "sum_rows")
+    return dst
+
+
+def top_k(a, k, dst=None):
+    """ggml::top_k: I32 [k, ...] indices of the k largest of each row (the reference's order: descending, first two swapped)"""
+    dst = dst or Tensor(I32, [k, a.ne[1], a.ne[2], a.ne[3]])
+    _l.check(_l.get().cllm_op_top_k(None, _ref(a), _ref(dst)), "top_k")
+    return dst
+
+
 def silu_mul(g, u, dst=None):
     dst = dst or Tensor(F32, g.ne)
     _l.check(_l.get().cllm_op_silu_mul(None, _ref(g), _ref(u), _ref(dst)), "silu_mul")

@@ -199,6 +199,13 @@ CLLM_API int cllm_op_unary(void * stream, int op, const cllm_tensor * src, cllm_
 /* GGML_OP_ADD / GGML_OP_MUL with broadcast of src1 (ggml-cpu/binary-ops.cpp) */
 CLLM_API int cllm_op_add(void * stream, const cllm_tensor * a, const cllm_tensor * b, cllm_tensor * dst);
 CLLM_API int cllm_op_mul(void * stream, const cllm_tensor * a, const cllm_tensor * b, cllm_tensor * dst);
+/* GGML_OP_DIV  (ggml_vec_div_f32, vec.h:104: IEEE division, src1 broadcast like ADD / MUL) */
+CLLM_API int cllm_op_div(void * stream, const cllm_tensor * a, const cllm_tensor * b, cllm_tensor * dst);
+/* GGML_OP_SUM_ROWS  ggml_compute_forward_sum_rows_f32 (ops.cpp:1451-1482): dst[0, i1, i2, i3] = sum over i0, accumulated in double */
+CLLM_API int cllm_op_sum_rows(void * stream, const cllm_tensor * src, cllm_tensor * dst);
+/* GGML_OP_TOP_K  ggml_compute_forward_top_k_f32 (ops.cpp:8057-8094): dst I32 [k, ...] = indices of the k largest of each row, descending,
+ * first two swapped; the expert selection of GenericSparseMLP::select_experts (src/layers.cpp:3817-3840) */
+CLLM_API int cllm_op_top_k(void * stream, const cllm_tensor * src, cllm_tensor * dst);
 /* fused  dst = silu(gate) * up   (BaseMLP::forward, src/layers.cpp:2475-2483: UNARY(SILU) then MUL) */
 CLLM_API int cllm_op_silu_mul(void * stream, const cllm_tensor * gate, const cllm_tensor * up, cllm_tensor * dst);
 

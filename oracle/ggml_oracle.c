@@ -609,12 +609,44 @@ static int binary_op(const orc_tensor * a, const orc_tensor * b, orc_tensor * ds
     for (int64_t i1 = 0; i1 < a->ne[1]; i1++) for (int64_t i0 = 0; i0 < a->ne[0]; i0++) {
         const float x = *(const float *) tptr(a, i0, i1, i2, i3);
         const float y = *(const float *) tptr(b, i0 % b->ne[0], i1 % b->ne[1], i2 % b->ne[2], i3 % b->ne[3]);
-        *(float *) tptr(dst, i0, i1, i2, i3) = op == 0 ? x + y : x * y;
+        *(float *) tptr(dst, i0, i1, i2, i3) = op == 0 ? x + y : op == 1 ? x * y : x / y;
     }
     return 0;
 }
 int orc_add(const orc_tensor * a, const orc_tensor * b, orc_tensor * dst) { return binary_op(a, b, dst, 0); }
 int orc_mul(const orc_tensor * a, const orc_tensor * b, orc_tensor * dst) { return binary_op(a, b, dst, 1); }
+int orc_div(const orc_tensor * a, const orc_tensor * b, orc_tensor * dst) { return binary_op(a, b, dst, 2); }
+
+/* ggml_compute_forward_sum_rows_f32 (ops.cpp:1451-1482) with ggml_vec_sum_f32 (vec.h:1510-1520): sequential, double accumulator */
+int orc_sum_rows(const orc_tensor * src, orc_tensor * dst) {
+    if (src->type != ORC_F32 || dst->type != ORC_F32 || dst->ne[0] != 1) return -1;
+    for (int64_t i3 = 0; i3 < src->ne[3]; i3++) for (int64_t i2 = 0; i2 < src->ne[2]; i2++) for (int64_t i1 = 0; i1 < src->ne[1]; i1++) {
+        double sum = 0.0;
+        for (int64_t i0 = 0; i0 < src->ne[0]; i0++) sum += (double) *(const float *) tptr(src, i0, i1, i2, i3);
+        *(float *) tptr(dst, 0, i1, i2, i3) = (float) sum;
+    }
+    return 0;
+}
+/* ggml_compute_forward_top_k_f32 (ops.cpp:8057-8094): k largest in descending order (ties: lower index first), first two swapped */
+int orc_top_k(const orc_tensor * src, orc_tensor * dst) {
+    if (src->type != ORC_F32 || dst->type != ORC_I32 || dst->ne[0] > src->ne[0]) return -1;
+    const int64_t n = src->ne[0], k = dst->ne[0];
+    for (int64_t i3 = 0; i3 < src->ne[3]; i3++) for (int64_t i2 = 0; i2 < src->ne[2]; i2++) for (int64_t i1 = 0; i1 < src->ne[1]; i1++) {
+        int32_t * out = (int32_t *) tptr(dst, 0, i1, i2, i3);
+        for (int64_t j = 0; j < k; j++) {
+            int64_t bi = -1; float best = 0;
+            for (int64_t i = 0; i < n; i++) {
+                int taken = 0;
+                for (int64_t t = 0; t < j; t++) taken |= out[t] == (int32_t) i;
+                const float v = *(const float *) tptr(src, i, i1, i2, i3);
+                if (!taken && (bi < 0 || v > best)) { best = v; bi = i; }
+            }
+            out[j] = (int32_t) bi;
+        }
+        if (k > 1) { const int32_t t = out[0]; out[0] = out[1]; out[1] = t; }
+    }
+    return 0;
+}
 
 /* ------------------------------------------------------------------------------------------ */
 /* KV-cache writes and gathers                                                                 */

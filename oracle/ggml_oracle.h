@@ -110,6 +110,10 @@ int orc_silu(const orc_tensor * src, orc_tensor * dst);
 /* binary-ops.cpp add / mul with broadcast of src1 over src0 */
 int orc_add(const orc_tensor * a, const orc_tensor * b, orc_tensor * dst);
 int orc_mul(const orc_tensor * a, const orc_tensor * b, orc_tensor * dst);
+int orc_div(const orc_tensor * a, const orc_tensor * b, orc_tensor * dst);     /* vec.h:104: IEEE division */
+/* the router of a sparse-MoE block (GenericSparseMLP::forward, src/layers.cpp:3755-3815) */
+int orc_sum_rows(const orc_tensor * src, orc_tensor * dst);                     /* ops.cpp:1451-1482, double accumulator (vec.h:1510-1520) */
+int orc_top_k(const orc_tensor * src, orc_tensor * dst);                        /* ops.cpp:8057-8094: descending, first two swapped */
 /* ggml_compute_forward_set_rows_f32 (ops.cpp:4892-4940): dst rows (F16|F32) <- src rows (F32) at idx (I32|I64) */
 int orc_set_rows(const orc_tensor * src, const orc_tensor * idx, orc_tensor * dst);
 /* ggml_compute_forward_dup / cpy (ops.cpp:47-330,526): same #elements, F32->F32|F16, F16->F16|F32, any strides */

@@ -168,6 +168,18 @@ def mul(a, b, dst):
     _chk(lib().orc_mul(C.byref(a), C.byref(b), C.byref(dst)), "mul")
 
 
+def div(a, b, dst):
+    _chk(lib().orc_div(C.byref(a), C.byref(b), C.byref(dst)), "div")
+
+
+def sum_rows(src, dst):
+    _chk(lib().orc_sum_rows(C.byref(src), C.byref(dst)), "sum_rows")
+
+
+def top_k(src, dst):
+    _chk(lib().orc_top_k(C.byref(src), C.byref(dst)), "top_k")
+
+
 def set_rows(src, idx, dst):
     _chk(lib().orc_set_rows(C.byref(src), C.byref(idx), C.byref(dst)), "set_rows")
 

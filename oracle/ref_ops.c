@@ -133,7 +133,31 @@ int ref_soft_max_ext(int64_t n0, int64_t n1, int64_t n2, const float * x, const 
     return rc;
 }
 
-/* binary with broadcast: a [n0,n1,n2], b [m0,m1,m2]; op 0 add, 1 mul */
+/* the router ops of a sparse-MoE block on a dense f32 [n0, n1, n2]: sum_rows -> f32 [1, n1, n2]; top_k -> i32 [k, n1, n2] */
+int ref_sum_rows(int64_t n0, int64_t n1, int64_t n2, const float * x, float * out) {
+    struct ggml_context * ctx = ctx_new((size_t)(n0*n1*n2) * 8);
+    if (!ctx) return -1;
+    struct ggml_tensor * a = ggml_new_tensor_3d(ctx, GGML_TYPE_F32, n0, n1, n2);
+    memcpy(a->data, x, (size_t)(n0*n1*n2) * 4);
+    struct ggml_tensor * c = ggml_sum_rows(ctx, a);
+    int rc = run(ctx, c);
+    if (!rc) memcpy(out, c->data, (size_t)(n1*n2) * 4);
+    ggml_free(ctx);
+    return rc;
+}
+int ref_top_k(int64_t n0, int64_t n1, int64_t n2, const float * x, int k, int32_t * out) {
+    struct ggml_context * ctx = ctx_new((size_t)(n0*n1*n2) * 12);
+    if (!ctx) return -1;
+    struct ggml_tensor * a = ggml_new_tensor_3d(ctx, GGML_TYPE_F32, n0, n1, n2);
+    memcpy(a->data, x, (size_t)(n0*n1*n2) * 4);
+    struct ggml_tensor * c = ggml_top_k(ctx, a, k);
+    int rc = run(ctx, c);
+    if (!rc) memcpy(out, c->data, (size_t)(k*n1*n2) * 4);
+    ggml_free(ctx);
+    return rc;
+}
+
+/* binary with broadcast: a [n0,n1,n2], b [m0,m1,m2]; op 0 add, 1 mul, 2 div */
 int ref_binary(int op, int64_t n0, int64_t n1, int64_t n2, const float * x, int64_t m0, int64_t m1, int64_t m2, const float * y, float * out) {
     struct ggml_context * ctx = ctx_new((size_t)(n0*n1*n2) * 12 + (size_t)(m0*m1*m2) * 4);
     if (!ctx) return -1;
@@ -141,7 +165,7 @@ int ref_binary(int op, int64_t n0, int64_t n1, int64_t n2, const float * x, int6
     struct ggml_tensor * b = ggml_new_tensor_3d(ctx, GGML_TYPE_F32, m0, m1, m2);
     memcpy(a->data, x, (size_t)(n0*n1*n2) * 4);
     memcpy(b->data, y, (size_t)(m0*m1*m2) * 4);
-    struct ggml_tensor * c = op == 0 ? ggml_add(ctx, a, b) : ggml_mul(ctx, a, b);
+    struct ggml_tensor * c = op == 0 ? ggml_add(ctx, a, b) : op == 1 ? ggml_mul(ctx, a, b) : ggml_div(ctx, a, b);
     int rc = run(ctx, c);
     if (!rc) memcpy(out, c->data, (size_t)(n0*n1*n2) * 4);
     ggml_free(ctx);

@@ -91,3 +91,49 @@ def test_module_node_fusion_does_not_change_a_bit(gpu, tmp_path, wname, wt, over
     for mode in ("fused", "graph", "nopack", "attn1", "attn0"):
         assert out[mode][0] == out["nodes"][0], mode
         assert out[mode][1] == out["nodes"][1], mode
+
+
+@pytest.mark.skipif(not (os.path.exists(os.path.join(REF, "ref_chat")) and os.path.exists(os.path.join(REF, "libggml-hip.so"))),
+                    reason="oracle/_ref (reference host + module) not built")
+@pytest.mark.parametrize("wname,wt", [("q4_k", 12), ("q8_0", 8)])
+def test_reference_host_mixtral_cpu_vs_our_module(gpu, tmp_path, wname, wt):
+    """BASELINE cfg5's architecture end to end: a synthetic Mixtral (8 experts, top 2, sliding-window attention class) through the
+    unmodified host -- router mat-vec, SOFT_MAX, TOP_K, GET_ROWS, SUM_ROWS, DIV, three MUL_MAT_ID, MUL, ADD of strided views -- on its
+    CPU backend and with every layer on our module; every node of the decode graph must run on the device (one graph_compute per token)"""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import make_ggmm
+    cfg = gpu.synth.config("tiny", max_len=64)
+    mp = str(tmp_path / "mx.bin")
+    make_ggmm.write_mixtral(mp, cfg, wt, seed=91)
+    prompt = [5, 9, 42, 300, 7, 99, 250]
+    n_dec = 12
+
+    def run(ngl, teacher=None, **extra):
+        lp = str(tmp_path / f"l_{ngl}.bin")
+        env = dict(os.environ, CLLM_HIP_STATS="1", **extra)
+        if teacher is not None:
+            tf = str(tmp_path / "teacher.txt")
+            open(tf, "w").write(" ".join(str(t) for t in teacher))
+            env["TEACHER"] = tf
+        r = subprocess.run([os.path.join(REF, "ref_chat"), mp, ngl, "4", str(n_dec), lp] + [str(p) for p in prompt], capture_output=True, text=True, env=env, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        return [int(t) for t in r.stdout.split()], np.fromfile(lp, np.float32).reshape(n_dec + 1, cfg["vocab"]), r.stderr
+
+    ids_c, lg_c, _ = run("cpu")
+    ids_g, lg_g, err = run("all", teacher=ids_c)
+    _, lg_n, _ = run("all", teacher=ids_c, CLLM_HIP_NO_FUSE="1")
+    assert lg_g.tobytes() == lg_n.tobytes()                              # node fusion (incl. the sliding-window class's attention block) changes no bit
+    graphs = [ln for ln in err.splitlines() if "graph_compute:" in ln and "calls" in ln]
+    assert sum(f"level 2: {cfg['n_layer']})" in ln for ln in graphs) == len(graphs), graphs[:3]        # K row written by CPY instead of SET_ROWS: matched too
+    # the reference feeds this architecture one token per graph (batch_input = false, models/mistral.h:101): prompt + decode graphs,
+    # and not one more -- no scheduler split, nothing fell back to the CPU backend
+    assert len(graphs) == len(prompt) + n_dec, (len(graphs), graphs[:4])
+    agree = decided = 0
+    for s in range(n_dec + 1):
+        d = float(np.max(np.abs(lg_c[s] - lg_g[s])))
+        assert d < 0.25 * float(lg_c[s].std()), (s, d)
+        top2 = np.partition(lg_c[s], -2)[-2:]
+        if top2[1] - top2[0] > 2 * d:
+            decided += 1
+            agree += int(ids_c[s] == ids_g[s])
+    assert decided >= 6 and agree == decided

@@ -326,6 +326,26 @@ def test_get_rows_bit_exact(gpu, t):
     assert np.array_equal(got.reshape(want.shape).view(np.uint32), want.view(np.uint32))
 
 
+# ---- the router of a sparse-MoE block: SUM_ROWS, DIV, TOP_K (bit-exact: sums in double, IEEE division, indices) ------------------
+@pytest.mark.parametrize("n0,n1,n2,k", [(8, 5, 1, 2), (8, 1, 1, 2), (64, 7, 2, 6), (3, 4, 1, 1), (160, 300, 1, 8)])
+def test_moe_router_ops_bit_exact(gpu, n0, n1, n2, k):
+    ops, T = gpu.ops, gpu.Tensor
+    x = rng.standard_normal((n2, n1, n0)).astype(np.float32)
+    x = (np.exp(x) / np.exp(x).sum(-1, keepdims=True)).astype(np.float32)
+    x[0, 0, :min(n0, 3)] = x[0, 0, 0]                        # a tie: lower index first
+    dx = T.from_numpy(x)
+    want = np.zeros((n2, n1, 1), np.float32)
+    O.sum_rows(O.tensor(x, O.F32, [n0, n1, n2]), O.tensor(want, O.F32, [1, n1, n2]))
+    assert np.array_equal(ops.sum_rows(dx).numpy().reshape(want.shape).view(np.uint32), want.view(np.uint32))
+    wantk = np.zeros((n2, n1, k), np.int32)
+    O.top_k(O.tensor(x, O.F32, [n0, n1, n2]), O.tensor(wantk, O.I32, [k, n1, n2]))
+    assert np.array_equal(ops.top_k(dx, k).numpy().reshape(wantk.shape), wantk)
+    y = (np.abs(rng.standard_normal((n2, n1, 1))) + 0.1).astype(np.float32)
+    wantd = np.zeros_like(x)
+    O.div(O.tensor(x, O.F32, [n0, n1, n2]), O.tensor(y, O.F32, [1, n1, n2]), O.tensor(wantd, O.F32, [n0, n1, n2]))
+    assert np.array_equal(ops.div(dx, T.from_numpy(y)).numpy().reshape(x.shape).view(np.uint32), wantd.view(np.uint32))
+
+
 # ---- attention over strided cache views (GQA broadcast) ---------------------------------------------------
 @pytest.mark.parametrize("qlen,n_past", [(1, 0), (1, 37), (1, 255), (6, 0), (5, 11), (64, 0), (200, 56), (33, 150)])
 def test_attention_composite(gpu, qlen, n_past):

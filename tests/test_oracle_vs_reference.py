@@ -320,3 +320,27 @@ def test_attention_composite(qlen, n_past):
     O.mul_mat(Vv, S, O.tensor(ctx, O.F32, [hd, qlen, nh]))
     got = np.ascontiguousarray(ctx.transpose(1, 0, 2)).reshape(qlen, nh * hd)
     assert rel_err(got, ref) < 2e-5
+
+
+def test_moe_router_ops_bit_exact():
+    """SUM_ROWS (double accumulator), DIV (IEEE) and TOP_K (descending, first two swapped) as GenericSparseMLP::forward uses them"""
+    R = O.ref()
+    for n0, n1, n2, k in ((8, 5, 1, 2), (8, 1, 1, 2), (64, 7, 2, 6), (3, 4, 1, 1), (160, 3, 1, 8)):
+        x = rng.standard_normal((n2, n1, n0)).astype(np.float32)
+        x = np.exp(x) / np.exp(x).sum(-1, keepdims=True).astype(np.float32)          # router probabilities
+        ref = np.zeros((n2, n1, 1), np.float32)
+        assert R.ref_sum_rows(C.c_int64(n0), C.c_int64(n1), C.c_int64(n2), P(x), P(ref)) == 0
+        got = np.zeros_like(ref)
+        O.sum_rows(O.tensor(x, O.F32, [n0, n1, n2]), O.tensor(got, O.F32, [1, n1, n2]))
+        assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
+        refk = np.zeros((n2, n1, k), np.int32)
+        assert R.ref_top_k(C.c_int64(n0), C.c_int64(n1), C.c_int64(n2), P(x), C.c_int(k), P(refk)) == 0
+        gotk = np.zeros_like(refk)
+        O.top_k(O.tensor(x, O.F32, [n0, n1, n2]), O.tensor(gotk, O.I32, [k, n1, n2]))
+        assert np.array_equal(gotk, refk)
+        y = (np.abs(rng.standard_normal((n2, n1, 1))) + 0.1).astype(np.float32)
+        refd = np.zeros_like(x)
+        assert R.ref_binary(2, C.c_int64(n0), C.c_int64(n1), C.c_int64(n2), P(x), C.c_int64(1), C.c_int64(n1), C.c_int64(n2), P(y), P(refd)) == 0
+        gotd = np.zeros_like(x)
+        O.div(O.tensor(x, O.F32, [n0, n1, n2]), O.tensor(y, O.F32, [1, n1, n2]), O.tensor(gotd, O.F32, [n0, n1, n2]))
+        assert np.array_equal(gotd.view(np.uint32), refd.view(np.uint32))

@@ -105,6 +105,75 @@ def write_model(path, cfg, wtype, seed=1234, model_name="SynthLlama3", fast=Fals
     return path
 
 
+def write_mixtral(path, cfg, wtype, seed=1234, n_expert=8, n_used=2):
+    """a Mixtral-architecture model (MODEL_TYPE_MIXTRAL 0x601, models/mistral.h:44-170): 8 experts / top 2 as the reference's template
+    requires, sliding window 4096, llama-v2 style vocabulary records {i32 len, bytes, f32 score} (src/tokenizer.cpp:310-372, 430-441);
+    expert weights as individual tensors block_sparse_moe.experts.E.w1/w2/w3 (gate/down/up), router block_sparse_moe.gate"""
+    pkg = ge.load_package()
+    S = pkg.synth
+    V, H, F, hd = cfg["vocab"], cfg["hidden"], cfg["ffn"], cfg["head_dim"]
+    QD, KD = cfg["n_head"] * hd, cfg["n_kv_head"] * hd
+    assert QD == H, "the reference derives head_dim from hidden / heads for this architecture"
+    with open(path, "wb") as f:
+        f.write(b"ggmm")
+        f.write(struct.pack("4i", 1, 0, 0, 0))
+        meta = json.dumps({"model_name": "SynthMixtral"}).encode()
+        f.write(meta + b"\0" * (-len(meta) % 4))
+
+        def mark(off):
+            p = f.tell()
+            f.seek(off)
+            f.write(struct.pack("i", p))
+            f.seek(0, 2)
+        mark(8)
+        f.write(struct.pack("2i", 0x601, 1))
+        f.write(struct.pack("11i", wtype, V, H, cfg["n_head"], cfg["n_layer"], F, cfg["max_len"], 1, 2, -1, -1))
+        f.write(struct.pack("2i", cfg["n_kv_head"], 4096))          # num_key_value_heads, sliding_window
+        f.write(struct.pack("<f", cfg["rope_theta"]))
+        f.write(struct.pack("2i", n_used, n_expert))                # num_experts_per_tok, num_local_experts
+        mark(12)
+        toks = [b"<unk>", b"<s>", b"</s>"] + [f"<0x{b:02X}>".encode() for b in range(256)]
+        while len(toks) < V:
+            toks.append(f"t{len(toks)}".encode())
+        for t in toks[:V]:
+            f.write(struct.pack("i", len(t)))
+            f.write(t)
+            f.write(struct.pack("<f", 0.0))
+        f.write(struct.pack("i", -1))
+        mark(16)
+
+        def dump(name, type_, dims_outer_to_inner, payload):
+            nb = name.encode()
+            f.write(struct.pack("i", len(nb)))
+            f.write(nb)
+            f.write(struct.pack("i", len(dims_outer_to_inner)))
+            f.write(struct.pack(f"{len(dims_outer_to_inner)}i", *dims_outer_to_inner))
+            f.write(struct.pack("i", type_))
+            f.write(b"\0" * (-f.tell() % 16))
+            f.write(np.ascontiguousarray(payload).tobytes())
+
+        def q(name, rows, K):
+            dump("model." + name if not name.startswith("lm_head") else name, wtype, [rows, K], S.make_tensor("mixtral." + name, wtype, rows, K, seed))
+
+        q("embed_tokens.weight", V, H)
+        for i in range(cfg["n_layer"]):
+            hp = f"layers.{i}."
+            dump("model." + hp + "input_layernorm.weight", 0, [H], S.make_norm("mixtral." + hp + "attn_norm", H, seed))
+            for e in range(n_expert):
+                q(hp + f"block_sparse_moe.experts.{e}.w1.weight", F, H)
+                q(hp + f"block_sparse_moe.experts.{e}.w2.weight", H, F)
+                q(hp + f"block_sparse_moe.experts.{e}.w3.weight", F, H)
+            q(hp + "block_sparse_moe.gate.weight", n_expert, H)
+            dump("model." + hp + "post_attention_layernorm.weight", 0, [H], S.make_norm("mixtral." + hp + "ffn_norm", H, seed))
+            q(hp + "self_attn.k_proj.weight", KD, H)
+            q(hp + "self_attn.o_proj.weight", H, QD)
+            q(hp + "self_attn.q_proj.weight", QD, H)
+            q(hp + "self_attn.v_proj.weight", KD, H)
+        dump("model.norm.weight", 0, [H], S.make_norm("mixtral.out_norm", H, seed))
+        q("lm_head.weight", V, H)
+    return path
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--config", default="tiny")
@@ -112,8 +181,12 @@ if __name__ == "__main__":
     ap.add_argument("--max-len", type=int, default=256)
     ap.add_argument("--out", required=True)
     ap.add_argument("--fast", action="store_true")
+    ap.add_argument("--arch", default="llama3", choices=["llama3", "mixtral"])
     a = ap.parse_args()
     pkg = ge.load_package()
     cfg = pkg.synth.config(a.config, max_len=a.max_len)
-    write_model(a.out, cfg, WT[a.wtype], fast=a.fast)
+    if a.arch == "mixtral":
+        write_mixtral(a.out, cfg, WT[a.wtype])
+    else:
+        write_model(a.out, cfg, WT[a.wtype], fast=a.fast)
     print(a.out, os.path.getsize(a.out), "bytes")
