@@ -193,7 +193,7 @@ void packs_forget(uint64_t uid) {
 }
 bool ours(const ggml_tensor * t) { return t && t->buffer && t->buffer->iface.free_buffer == buf_free && !t->view_src; }
 // the packed copy of n (2 or 3) same-type, same-row-length weight matrices, or nullptr (not ours / over budget / allocation failed)
-void * get_pack(int device, void * stream, const ggml_tensor * const * w, int n, bool interleave) {
+void * get_pack(int device, void * stream, const ggml_tensor * const * w, int n, bool interleave, bool flat = false) {      // flat: byte blobs (bias vectors)
     static const bool off = getenv("CLLM_HIP_PACK") && atoi(getenv("CLLM_HIP_PACK")) == 0;
     if (off) return nullptr;
     for (int i = 0; i < n; i++) if (!ours(w[i]) || ((const hip_buffer_ctx *) w[i]->buffer->context)->device != device) return nullptr;
@@ -211,7 +211,7 @@ void * get_pack(int device, void * stream, const ggml_tensor * const * w, int n,
     for (int i = 0; i < n; i++) {
         const auto * bc = (const hip_buffer_ctx *) w[i]->buffer->context;
         e.src[i] = w[i]->data; e.uid[i] = bc->uid; e.gen[i] = bc->gen;
-        rows[i] = w[i]->ne[1]; srcs[i] = w[i]->data; bytes += (size_t) w[i]->ne[1] * w[i]->nb[1];
+        rows[i] = flat ? (int64_t) ggml_nbytes(w[i]) : w[i]->ne[1]; srcs[i] = w[i]->data; bytes += flat ? ggml_nbytes(w[i]) : (size_t) w[i]->ne[1] * w[i]->nb[1];
     }
     size_t mfree = 0, mtotal = 0;
     cllm_device_info(device, nullptr, 0, &mfree, &mtotal, nullptr);
@@ -220,7 +220,7 @@ void * get_pack(int device, void * stream, const ggml_tensor * const * w, int n,
     if (g_pack_bytes + bytes > cap || mfree < bytes + mtotal / 10) return nullptr;
     void * p = nullptr;
     if (cllm_malloc(&p, bytes) != CLLM_OK) return nullptr;
-    if (cllm_pack_rows(stream, p, srcs, rows, n, w[0]->nb[1], interleave ? 1 : 0) != CLLM_OK || cllm_stream_sync(stream) != CLLM_OK) { cllm_free(p); return nullptr; }
+    if (cllm_pack_rows(stream, p, srcs, rows, n, flat ? 1 : w[0]->nb[1], interleave ? 1 : 0) != CLLM_OK || cllm_stream_sync(stream) != CLLM_OK) { cllm_free(p); return nullptr; }
     e.data = p; e.bytes = bytes; e.refused = false; g_pack_bytes += bytes;
     return p;
 }
@@ -333,6 +333,7 @@ int ensure_abuf(hip_backend_ctx * c, size_t need) {      // fused attention: cos
 //                                                      consumer mat-vec then only quantizes (pro 2)
 struct fused_mv {
     int pro = 2; const float * px = nullptr; const float * pw = nullptr; float eps = 0.0f; const float * resid = nullptr; float * dst = nullptr;
+    const ggml_tensor * resid_t = nullptr;      // the ADD's other operand (a bias when it is a weight leaf)
     int node = -1;                      // the MUL_MAT node
     int ga = -1, gb = -1;               // pro 4: the nodes producing px (gate) and pw (up)
     int group = -1;                     // member of a merged launch (fuse_plan::groups)
@@ -340,6 +341,7 @@ struct fused_mv {
 struct merge_group {
     int n = 0, member[3] = { -1, -1, -1 };      // entries of mvs, in packed row order
     bool interleave = false;                     // gate/up: SiLU*up epilogue, output = half the rows
+    bool bias = false;                           // q|k|v with biases (Qwen2): the three bias vectors are packed too and ride in the epilogue
     int consumer = -1;                           // gate/up: the entry of mvs (pro 4) that reads the activation
     int state = 0;                               // at run time: 0 not reached, 1 launched merged, 2 members launch separately
 };
@@ -585,7 +587,7 @@ fuse_plan make_plan(ggml_cgraph * g) {
             fused_mv & f = P.mvs[P.mv[j]];
             const size_t kbytes = (size_t) mm->src[0]->ne[0] * 4, nbytes = (size_t) a->ne[0] * 4;
             if (overlap(a->data, nbytes, f.px, kbytes) || (f.pw && overlap(a->data, nbytes, f.pw, kbytes))) { if (f.pro == 2 && !f.resid && !f.dst) { P.mvs.pop_back(); P.mv[j] = -1; } continue; }
-            f.resid = (const float *) r->data; f.dst = (float *) a->data;
+            f.resid = (const float *) r->data; f.resid_t = r; f.dst = (float *) a->data;
             P.skip[i] = 1;
             writer[j] = -1; writer[i] = P.mv[j];
             break;
@@ -593,15 +595,22 @@ fuse_plan make_plan(ggml_cgraph * g) {
     }
     plan_attention(g, P, local, writer, users, find);
     // ---- merged launches over packed weights (the decision whether a packed copy exists is taken at run time: get_pack)
-    auto same_input = [&](const fused_mv & a, const fused_mv & b) {
+    auto is_bias = [&](const fused_mv & f) {     // the epilogue operand is a weight vector of the projection's length: never an activation
+        const ggml_tensor * w = ggml_graph_node(g, f.node)->src[0];
+        return f.resid_t && f.resid_t->op == GGML_OP_NONE && ours(f.resid_t) && f.resid_t->type == GGML_TYPE_F32 && ggml_is_contiguous(f.resid_t) &&
+               ggml_nelements(f.resid_t) == w->ne[1] && ((uintptr_t) f.resid_t->data & 15) == 0;
+    };
+    auto same_input = [&](const fused_mv & a, const fused_mv & b, bool with_bias) {
         const ggml_tensor * wa = ggml_graph_node(g, a.node)->src[0], * wb = ggml_graph_node(g, b.node)->src[0];
-        return a.pro == 1 && b.pro == 1 && a.px == b.px && a.pw == b.pw && a.eps == b.eps && !a.resid && !b.resid && a.group < 0 && b.group < 0 &&
+        const bool epi_ok = with_bias ? (is_bias(a) && is_bias(b)) : (!a.resid && !b.resid);
+        return a.pro == 1 && b.pro == 1 && a.px == b.px && a.pw == b.pw && a.eps == b.eps && epi_ok && a.group < 0 && b.group < 0 &&
                wa->type == wb->type && wa->ne[0] == wb->ne[0] && wa->nb[1] == wb->nb[1];
     };
     for (const fused_attn & A : P.attns) {
         if (A.level != 2 || A.wq == A.wk || A.wq == A.wv || A.wk == A.wv) continue;
-        if (!same_input(P.mvs[A.wq], P.mvs[A.wk]) || !same_input(P.mvs[A.wq], P.mvs[A.wv])) continue;
-        merge_group G; G.n = 3; G.member[0] = A.wq; G.member[1] = A.wk; G.member[2] = A.wv;
+        const bool with_bias = P.mvs[A.wq].resid != nullptr;
+        if (!same_input(P.mvs[A.wq], P.mvs[A.wk], with_bias) || !same_input(P.mvs[A.wq], P.mvs[A.wv], with_bias)) continue;
+        merge_group G; G.n = 3; G.member[0] = A.wq; G.member[1] = A.wk; G.member[2] = A.wv; G.bias = with_bias;
         for (int k = 0; k < 3; k++) P.mvs[G.member[k]].group = (int) P.groups.size();
         P.groups.push_back(G);
     }
@@ -610,7 +619,7 @@ fuse_plan make_plan(ggml_cgraph * g) {
         if (d.pro != 4 || d.ga < 0 || d.gb < 0 || d.ga == d.gb || P.mv[d.ga] < 0 || P.mv[d.gb] < 0 || P.skip[d.ga] || P.skip[d.gb]) continue;
         const fused_mv & a = P.mvs[P.mv[d.ga]], & b = P.mvs[P.mv[d.gb]];
         const ggml_tensor * ta = ggml_graph_node(g, d.ga), * tb = ggml_graph_node(g, d.gb);
-        if (!same_input(a, b) || a.dst != (float *) ta->data || b.dst != (float *) tb->data || !only_local(d.ga, 1) || !only_local(d.gb, 1)) continue;
+        if (!same_input(a, b, false) || a.dst != (float *) ta->data || b.dst != (float *) tb->data || !only_local(d.ga, 1) || !only_local(d.gb, 1)) continue;
         const int64_t F = ta->ne[0];
         if (tb->ne[0] != F || F % 8 || ta->src[0]->ne[1] != F || tb->src[0]->ne[1] != F) continue;
         merge_group G; G.n = 2; G.member[0] = P.mv[d.ga]; G.member[1] = P.mv[d.gb]; G.interleave = true; G.consumer = (int) m;
@@ -709,10 +718,17 @@ ggml_status be_graph_compute(ggml_backend_t backend, ggml_cgraph * g) {
                         const ggml_tensor * w[3]; int64_t rows = 0;
                         for (int k = 0; k < G.n; k++) { w[k] = ggml_graph_node(g, plan.mvs[G.member[k]].node)->src[0]; rows += w[k]->ne[1]; }
                         void * W = get_pack(c->device, st, w, G.n, G.interleave);
+                        const float * Bv = nullptr;
+                        if (W && G.bias) {
+                            const ggml_tensor * bt[3];
+                            for (int k = 0; k < G.n; k++) bt[k] = plan.mvs[G.member[k]].resid_t;
+                            Bv = (const float *) get_pack(c->device, st, bt, G.n, false, true);
+                            if (!Bv) W = nullptr;
+                        }
                         G.state = 2;
                         if (W) {
                             cllm_tensor dw = desc(w[0]); dw.ne[1] = rows; dw.nb[2] = dw.nb[3] = (size_t) rows * dw.nb[1]; dw.data = W;
-                            rc = CALL(cllm_op_mul_mat_vec_fused, st, &dw, 1, f.px, f.pw, f.eps, G.interleave ? 1 : 0, nullptr, G.interleave ? a_act : plan.mvs[G.member[0]].dst);
+                            rc = CALL(cllm_op_mul_mat_vec_fused, st, &dw, 1, f.px, f.pw, f.eps, G.interleave ? 1 : 0, Bv, G.interleave ? a_act : plan.mvs[G.member[0]].dst);
                             if (rc == CLLM_OK) {
                                 G.state = 1; merged++;
                                 if (G.consumer >= 0) { fused_mv & d = plan.mvs[G.consumer]; d.pro = 2; d.px = a_act; d.pw = nullptr; }

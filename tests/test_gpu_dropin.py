@@ -137,3 +137,46 @@ def test_reference_host_mixtral_cpu_vs_our_module(gpu, tmp_path, wname, wt):
             decided += 1
             agree += int(ids_c[s] == ids_g[s])
     assert decided >= 6 and agree == decided
+
+
+@pytest.mark.skipif(not (os.path.exists(os.path.join(REF, "ref_chat")) and os.path.exists(os.path.join(REF, "libggml-hip.so"))),
+                    reason="oracle/_ref (reference host + module) not built")
+@pytest.mark.parametrize("wname,wt", [("q4_k", 12), ("q4_0", 2)])
+def test_reference_host_qwen2_cpu_vs_our_module(gpu, tmp_path, wname, wt):
+    """BASELINE cfg4's architecture (Qwen2: q/k/v biases, NEOX RoPE) through the unmodified host: CPU backend vs our module; the bias ADDs
+    ride in the mat-vec epilogues, the attention block fuses at level 2, and fusion changes no bit"""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import make_ggmm
+    cfg = gpu.synth.config("tiny", max_len=64, qkv_bias=1, rope_mode=2, rope_theta=1e6)
+    mp = str(tmp_path / "qw.bin")
+    make_ggmm.write_model(mp, cfg, wt, seed=93, arch="qwen2")
+    prompt = [5, 9, 42, 300, 7, 99, 250]
+    n_dec = 12
+
+    def run(ngl, teacher=None, **extra):
+        lp = str(tmp_path / f"l_{ngl}.bin")
+        env = dict(os.environ, CLLM_HIP_STATS="1", **extra)
+        if teacher is not None:
+            tf = str(tmp_path / "teacher.txt")
+            open(tf, "w").write(" ".join(str(t) for t in teacher))
+            env["TEACHER"] = tf
+        r = subprocess.run([os.path.join(REF, "ref_chat"), mp, ngl, "4", str(n_dec), lp] + [str(p) for p in prompt], capture_output=True, text=True, env=env, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        return [int(t) for t in r.stdout.split()], np.fromfile(lp, np.float32).reshape(n_dec + 1, cfg["vocab"]), r.stderr
+
+    ids_c, lg_c, _ = run("cpu")
+    ids_g, lg_g, err = run("all", teacher=ids_c)
+    _, lg_n, _ = run("all", teacher=ids_c, CLLM_HIP_NO_FUSE="1")
+    assert lg_g.tobytes() == lg_n.tobytes()
+    graphs = [ln for ln in err.splitlines() if "graph_compute:" in ln and "calls" in ln]
+    assert len(graphs) == n_dec + 1 and sum(f"level 2: {cfg['n_layer']})" in ln for ln in graphs) == n_dec, graphs[:3]
+    assert sum(f" {2 * cfg['n_layer']} merged" in ln for ln in graphs) == n_dec, graphs[-2:]       # q|k|v (with the packed biases) and gate/up of every layer
+    agree = decided = 0
+    for s in range(n_dec + 1):
+        d = float(np.max(np.abs(lg_c[s] - lg_g[s])))
+        assert d < 0.25 * float(lg_c[s].std()), (s, d)
+        top2 = np.partition(lg_c[s], -2)[-2:]
+        if top2[1] - top2[0] > 2 * d:
+            decided += 1
+            agree += int(ids_c[s] == ids_g[s])
+    assert decided >= 6 and agree == decided

@@ -344,3 +344,38 @@ def test_moe_router_ops_bit_exact():
         gotd = np.zeros_like(x)
         O.div(O.tensor(x, O.F32, [n0, n1, n2]), O.tensor(y, O.F32, [1, n1, n2]), O.tensor(gotd, O.F32, [n0, n1, n2]))
         assert np.array_equal(gotd.view(np.uint32), refd.view(np.uint32))
+
+
+@pytest.mark.parametrize("arch,over,wt", [("qwen2", dict(qkv_bias=1, rope_mode=2, rope_theta=1e6), O.Q4_K), ("qwen2", dict(qkv_bias=1, rope_mode=2, rope_theta=1e6), O.Q8_0),
+                                          ("llama3", {}, O.Q4_1)])
+def test_oracle_whole_model_vs_reference_host_live(pkg, tmp_path, arch, over, wt):
+    """the oracle's whole-model walk against the reference HOST run here (oracle/_ref/ref_chat on a synthetic GGMM file): the Qwen2
+    architecture (q/k/v biases, NEOX RoPE -- BASELINE cfg4) next to the Llama-3 fixtures of tests/golden"""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    ref_chat = os.path.join(root, "oracle", "_ref", "ref_chat")
+    if not os.path.exists(ref_chat):
+        pytest.skip("oracle/_ref/ref_chat not built")
+    sys.path.insert(0, os.path.join(root, "tools"))
+    import make_ggmm
+    cfg = pkg.synth.config("tiny", max_len=64, **over)
+    mp, lp = str(tmp_path / "m.bin"), str(tmp_path / "l.bin")
+    make_ggmm.write_model(mp, cfg, wt, seed=1234, arch=arch)
+    prompt = [5, 9, 42, 300, 7, 99, 250, 12, 100]
+    ids = subprocess.check_output([ref_chat, mp, "cpu", "4", "8", lp] + [str(p) for p in prompt], stderr=subprocess.DEVNULL, text=True).split()
+    logits = np.fromfile(lp, np.float32).reshape(9, cfg["vocab"])
+    m = O.Llama(cfg, pkg.synth.make_model(cfg, wt, seed=1234))
+    lg = m.forward(np.array(prompt, np.int32))
+    agree = decided = 0
+    for s in range(9):
+        d = float(np.max(np.abs(lg - logits[s])))
+        assert d < 0.25 * float(logits[s].std()), (s, d)
+        top2 = np.partition(logits[s], -2)[-2:]
+        if top2[1] - top2[0] > 2 * d:
+            decided += 1
+            agree += int(np.argmax(lg) == int(ids[s]))
+        if s < 8:
+            lg = m.forward([int(ids[s])])
+    assert decided >= 5 and agree == decided

@@ -39,13 +39,19 @@ def bytes_to_unicode():
     return dict(zip(bs, map(chr, cs)))
 
 
-def write_model(path, cfg, wtype, seed=1234, model_name="SynthLlama3", fast=False):
+def write_model(path, cfg, wtype, seed=1234, model_name="SynthLlama3", fast=False, arch="llama3"):
+    """arch "llama3" (MODEL_TYPE_LLAMA3 0x1700, models/llama.h:102-106) or "qwen2" (MODEL_TYPE_QWEN2 0x710, models/qwen.h:74-104: q/k/v biases,
+    NEOX RoPE; the weights come from cfg with qkv_bias=1, rope_mode=2)"""
     pkg = ge.load_package()
     V, H = cfg["vocab"], cfg["hidden"]
     assert V >= 262
     b2u = bytes_to_unicode()
     toks = [(b2u[b].encode(), 1) for b in range(256)]
-    toks += [(s.encode(), 3) for s in ["<|begin_of_text|>", "<|end_of_text|>", "<|start_header_id|>", "<|end_header_id|>", "<|eot_id|>"]]
+    if arch == "qwen2":
+        assert cfg.get("qkv_bias") and cfg.get("rope_mode") == 2
+        toks += [(s.encode(), 3) for s in ["<|endoftext|>", "<|im_start|>", "<|im_end|>"]]
+    else:
+        toks += [(s.encode(), 3) for s in ["<|begin_of_text|>", "<|end_of_text|>", "<|start_header_id|>", "<|end_header_id|>", "<|eot_id|>"]]
     while len(toks) < V:
         toks.append((f"<|pad{len(toks)}|>".encode(), 3))
     with open(path, "wb") as f:
@@ -60,9 +66,11 @@ def write_model(path, cfg, wtype, seed=1234, model_name="SynthLlama3", fast=Fals
             f.write(struct.pack("i", p))
             f.seek(0, 2)
         mark(8)
-        f.write(struct.pack("2i", 0x1700, 1))
+        f.write(struct.pack("2i", 0x710 if arch == "qwen2" else 0x1700, 1))
         f.write(struct.pack("11i", wtype, V, H, cfg["n_head"], cfg["n_layer"], cfg["ffn"], cfg["max_len"], 256, 257, -1, -1))
         f.write(struct.pack("i", cfg["n_kv_head"]))
+        if arch == "qwen2":
+            f.write(struct.pack("i", cfg["max_len"]))               # sliding_window (not used below max_len)
         f.write(struct.pack("<f", cfg["rope_theta"]))
         mark(12)
         for t, tt in toks:
@@ -100,6 +108,9 @@ def write_model(path, cfg, wtype, seed=1234, model_name="SynthLlama3", fast=Fals
                 t, arr = w[p + k]
                 dims = [H] if k.endswith("norm") else list(shape[p + k])
                 dump(hp + HF_NAME[k], t, dims, arr)
+            if arch == "qwen2":
+                for b, nm in (("bq", "q_proj"), ("bk", "k_proj"), ("bv", "v_proj")):
+                    dump(hp + f"self_attn.{nm}.bias", 0, [len(w[p + b][1])], w[p + b][1])
         dump("model.norm.weight", 0, [H], w["out_norm"][1])
         dump("lm_head.weight", w["lm_head"][0], [V, H], w["lm_head"][1])
     return path
@@ -181,12 +192,12 @@ if __name__ == "__main__":
     ap.add_argument("--max-len", type=int, default=256)
     ap.add_argument("--out", required=True)
     ap.add_argument("--fast", action="store_true")
-    ap.add_argument("--arch", default="llama3", choices=["llama3", "mixtral"])
+    ap.add_argument("--arch", default="llama3", choices=["llama3", "mixtral", "qwen2"])
     a = ap.parse_args()
     pkg = ge.load_package()
-    cfg = pkg.synth.config(a.config, max_len=a.max_len)
+    cfg = pkg.synth.config(a.config, max_len=a.max_len, **(dict(qkv_bias=1, rope_mode=2, rope_theta=1e6) if a.arch == "qwen2" else {}))
     if a.arch == "mixtral":
         write_mixtral(a.out, cfg, WT[a.wtype])
     else:
-        write_model(a.out, cfg, WT[a.wtype], fast=a.fast)
+        write_model(a.out, cfg, WT[a.wtype], fast=a.fast, arch=a.arch)
     print(a.out, os.path.getsize(a.out), "bytes")
