@@ -3,7 +3,7 @@
 # backend, Llama-3-8B shapes Q4_K synthetic model in GGMM format.  Run on the GPU box: bash tools/dropin_bench.sh
 set -u
 R=/root/repo; M=/tmp/llama3-8b-q4k.bin
-python $R/tools/make_ggmm.py --config llama3-8b --wtype q4_k --max-len 512 --fast --out $M || exit 1
+[ -s $M ] || python $R/tools/make_ggmm.py --config llama3-8b --wtype q4_k --max-len 512 --fast --out $M || exit 1
 IDS="1 5 9 200 31 7 11 300 2 77 123 4567 89 1000 2000 3000"
 cd $R/oracle/_ref
 for ngl in ${NGL:-all}; do

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """GEMV kernel micro-benchmark (GPU box): HIP-event timed launches of the mat-mul kernel only, per shape/type.
-usage: python tools/gemv_bench.py [--types q4_k,q4_0,q8_0] [--cols 1] [--iters 64]
+usage: python tools/gemv_bench.py [--types q4_k,q4_0,q4_1,q8_0] [--cols 1] [--iters 64]
 Tunables are read from the environment once per process (CLLM_MMVQ_WG, CLLM_MMVQ_OCC): sweep with --sweep."""
 import argparse
 import ctypes as C
@@ -14,7 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import __graft_entry__ as ge  # noqa: E402
 
-T = {"q4_k": 12, "q4_0": 2, "q8_0": 8}
+T = {"q4_k": 12, "q4_0": 2, "q4_1": 3, "q8_0": 8}
 SHAPES = [("qkv", 4096, 6144), ("o", 4096, 4096), ("gate_up", 4096, 28672), ("down", 14336, 4096), ("lm_head", 4096, 128256),
           ("q72_down_q8", 29568, 8192)]
 
