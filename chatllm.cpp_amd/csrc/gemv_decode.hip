@@ -93,9 +93,9 @@ __global__ void __launch_bounds__(1024) k_gemv_dec(const float * __restrict__ px
             hh[p] = *(const u32x4 *) bp;
             qq[p] = *(const u32x4 *)(bp + 16 + 16 * j);
         } else {
-            uint32_t h;
-            q32_load<IS_K ? CLLM_TYPE_Q4_0 : FMT>(bp, h, qq[p], q2[IS_Q8 ? p : 0]);
-            hh[p].x = h;
+            uint32_t t, odd;             // the aligned window as loaded; q32_align() at the point of use
+            q32_load_raw<IS_K ? CLLM_TYPE_Q4_0 : FMT>(bp, qq[p], q2[IS_Q8 ? p : 0], t, odd);
+            hh[p].x = t; hh[p].y = odd;
         }
         if (++is == S) { is = 0; if (++isub == RU) { isub = 0; ik++; } }
     };
@@ -148,7 +148,11 @@ __global__ void __launch_bounds__(1024) k_gemv_dec(const float * __restrict__ px
             const int b = IS_K ? 8 * cs + grp : 64 * cs + lane;
             const bool ok = ck < nmine && b < nblk;
             if (IS_K) q4k_step(hh[p], qq[p], lds, off_d, off_s, ok ? b : 0, ok, L, accd, accm);
-            else      q32_step<IS_K ? CLLM_TYPE_Q4_0 : FMT>(hh[p].x, qq[p], q2[IS_Q8 ? p : 0], lds, off_d, off_s, ok ? b : 0, ok, accd);
+            else {
+                uint32_t h; u32x4 w0, w1 = {0, 0, 0, 0};
+                q32_align<IS_K ? CLLM_TYPE_Q4_0 : FMT>(qq[p], q2[IS_Q8 ? p : 0], hh[p].x, hh[p].y, h, w0, w1);
+                q32_step<IS_K ? CLLM_TYPE_Q4_0 : FMT>(h, w0, w1, lds, off_d, off_s, ok ? b : 0, ok, accd);
+            }
             issue(p);
             if (++cs == S) {                                        // row complete: reduce over the wave, epilogue, store
                 float v = IS_K ? wave_sum(accd) - wave_sum(accm) : wave_sum(accd);
