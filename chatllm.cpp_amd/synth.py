@@ -16,6 +16,7 @@ CONFIGS = {
     "small":       dict(n_layer=4,  hidden=1024, n_head=8,  n_kv_head=2, head_dim=128, ffn=2816,  vocab=2048),   # ffn % 256 == 0
     "gpt2s-llama": dict(n_layer=12, hidden=768,  n_head=12, n_kv_head=12, head_dim=64, ffn=3072,  vocab=50304),  # BASELINE cfg1 stand-in
     "llama3-8b":   dict(n_layer=32, hidden=4096, n_head=32, n_kv_head=8, head_dim=128, ffn=14336, vocab=128256),
+    "mixtral-8x7b": dict(n_layer=32, hidden=4096, n_head=32, n_kv_head=8, head_dim=128, ffn=14336, vocab=32000, rope_theta=1e6),   # + 8 experts, top 2 (tools/make_ggmm.py --arch mixtral)
     "qwen2-72b":   dict(n_layer=80, hidden=8192, n_head=64, n_kv_head=8, head_dim=128, ffn=29568, vocab=152064, qkv_bias=1, rope_mode=2, rope_theta=1e6),
 }
 

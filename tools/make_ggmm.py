@@ -116,7 +116,7 @@ def write_model(path, cfg, wtype, seed=1234, model_name="SynthLlama3", fast=Fals
     return path
 
 
-def write_mixtral(path, cfg, wtype, seed=1234, n_expert=8, n_used=2):
+def write_mixtral(path, cfg, wtype, seed=1234, n_expert=8, n_used=2, fast=False):
     """a Mixtral-architecture model (MODEL_TYPE_MIXTRAL 0x601, models/mistral.h:44-170): 8 experts / top 2 as the reference's template
     requires, sliding window 4096, llama-v2 style vocabulary records {i32 len, bytes, f32 score} (src/tokenizer.cpp:310-372, 430-441);
     expert weights as individual tensors block_sparse_moe.experts.E.w1/w2/w3 (gate/down/up), router block_sparse_moe.gate"""
@@ -163,8 +163,10 @@ def write_mixtral(path, cfg, wtype, seed=1234, n_expert=8, n_used=2):
             f.write(b"\0" * (-f.tell() % 16))
             f.write(np.ascontiguousarray(payload).tobytes())
 
+        gen = S.make_tensor_fast if fast else S.make_tensor        # fast: real-shape models (block bytes drawn directly)
+
         def q(name, rows, K):
-            dump("model." + name if not name.startswith("lm_head") else name, wtype, [rows, K], S.make_tensor("mixtral." + name, wtype, rows, K, seed))
+            dump("model." + name if not name.startswith("lm_head") else name, wtype, [rows, K], gen("mixtral." + name, wtype, rows, K, seed))
 
         q("embed_tokens.weight", V, H)
         for i in range(cfg["n_layer"]):
@@ -197,7 +199,7 @@ if __name__ == "__main__":
     pkg = ge.load_package()
     cfg = pkg.synth.config(a.config, max_len=a.max_len, **(dict(qkv_bias=1, rope_mode=2, rope_theta=1e6) if a.arch == "qwen2" else {}))
     if a.arch == "mixtral":
-        write_mixtral(a.out, cfg, WT[a.wtype])
+        write_mixtral(a.out, cfg, WT[a.wtype], fast=a.fast)
     else:
         write_model(a.out, cfg, WT[a.wtype], fast=a.fast, arch=a.arch)
     print(a.out, os.path.getsize(a.out), "bytes")
