@@ -374,6 +374,13 @@ extern "C" int cllm_op_mul_mat_id(void * stream, const cllm_tensor * as, const c
     if (!wdata || wsize < need) FAIL(CLLM_E_INVALID, "mul_mat_id: wdata too small (%zu < %zu)", wsize, need);
     if (as->type == CLLM_TYPE_Q4_K && ((uintptr_t) as->data % 16 || as->nb[1] % 16 || as->nb[2] % 16)) FAIL(CLLM_E_UNSUPPORTED, "mul_mat_id: alignment");
     hipStream_t st = (hipStream_t) stream;
+    // one token (decode): the decode mat-vec with the expert picked per grid slice, activation quantized inside (one launch per MUL_MAT_ID)
+    if (n_tok == 1 && ids->nb[0] == 4 && b->nb[0] == 4 && dst->nb[0] == 4 && as->nb[1] == cllm_row_size(as->type, as->ne[0]) && b->nb[1] % 16 == 0 && dst->nb[1] % 4 == 0 &&
+        ((uintptr_t) b->data & 15) == 0 && ((uintptr_t) as->data & 15) == 0 && as->nb[2] % 16 == 0) {
+        rc = launch_gemv_decode_id(st, as->type, as->data, as->nb[2], as->ne[0], as->ne[1], (const float *) b->data, b->ne[1] == 1 ? 0 : (int64_t)(b->nb[1] / 4),
+                                   (const int32_t *) ids->data, (int) n_used, (float *) dst->data, (int64_t)(dst->nb[1] / 4));
+        if (rc != CLLM_E_UNSUPPORTED) return rc;
+    }
     rc = launch_quantize_act(st, kind, tv(b), wdata, stride);      // act row index = i11 + ne11*i12 (token-major over slots)
     if (rc) return rc;
     return launch_mmvq_id(st, as->type, tv(as), wdata, stride, b->ne[1], tv(ids), tv(dst));

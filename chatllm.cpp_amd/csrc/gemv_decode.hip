@@ -37,12 +37,21 @@ __device__ __forceinline__ float silu_any(float x, bool body) { return body ? si
 
 // FMT: CLLM_TYPE_Q4_K (8 lanes per 144-byte super-block, activation quantized to Q8_K) or CLLM_TYPE_Q4_0 / Q4_1 / Q8_0 (one lane per
 // 18 / 20 / 34-byte block, activation quantized to Q8_0 / Q8_1).  nblk = weight blocks per row.
-template <int FMT, int PRO, int EPI, int NPRE>
+// MOE (MUL_MAT_ID for one token, ggml_compute_forward_mul_mat_id ggml-cpu.c:1432-1678): blockIdx.y is the slot; the slot's expert comes from
+// device memory (ids[slot], the TOP_K node's output), W / px / dst move by the slot: dst[:, slot] = W[:, :, ids[slot]]^T . x[:, slot or 0]
+template <int FMT, int PRO, int EPI, int NPRE, bool MOE = false>
 __global__ void __launch_bounds__(1024) k_gemv_dec(const float * __restrict__ px, const float * __restrict__ pw, const float * __restrict__ padd,
                                                         const char * __restrict__ W, int nblk, int kfull, int nrem, float eps,
                                                         float * __restrict__ dst, float * __restrict__ xout,
-                                                        const float * __restrict__ bias, const float * resid, unsigned long long * ts) {
+                                                        const float * __restrict__ bias, const float * resid, unsigned long long * ts,
+                                                        const int32_t * __restrict__ ids, unsigned long long w_expert_bytes, int px_slot_stride, int dst_slot_stride) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
+    if constexpr (MOE) {
+        int e;
+        asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(e) : "s"(ids + blockIdx.y) : "memory");
+        W += (unsigned long long)(unsigned) e * w_expert_bytes;
+        px += (long) blockIdx.y * px_slot_stride; dst += (long) blockIdx.y * dst_slot_stride;
+    }
     constexpr int P = 2, RU = EPI == 1 ? 2 : 1;
     constexpr bool IS_K = FMT == CLLM_TYPE_Q4_K, IS_Q8 = FMT == CLLM_TYPE_Q8_0, IS_Q41 = FMT == CLLM_TYPE_Q4_1;
     constexpr int KIND = IS_K ? 256 : 32;                           // elements per weight block = activation quantization block
@@ -197,7 +206,8 @@ int launch_gemv_decode(hipStream_t st, int wtype, const void * W, int64_t K, int
 #define GO3(FMT_, PRO_, EPI_, NPRE_) do { \
         static bool attr = false; \
         if (lds > 64 * 1024 && !attr) { HIP_TRY(hipFuncSetAttribute((const void *) k_gemv_dec<FMT_, PRO_, EPI_, NPRE_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr = true; } \
-        hipLaunchKernelGGL((k_gemv_dec<FMT_, PRO_, EPI_, NPRE_>), dim3((unsigned) grid), dim3(1024), lds, st, px, pw, padd, (const char *) W, nblk, kfull, nrem, eps, dst, xout, bias, resid, g_gemv_ts); } while (0)
+        hipLaunchKernelGGL((k_gemv_dec<FMT_, PRO_, EPI_, NPRE_>), dim3((unsigned) grid), dim3(1024), lds, st, px, pw, padd, (const char *) W, nblk, kfull, nrem, eps, dst, xout, bias, resid, g_gemv_ts, \
+                           (const int32_t *) nullptr, 0ull, 0, 0); } while (0)
 #define GO(FMT_) do { \
         if (pro == 1 && epi == 1) { if (npre == 1) GO3(FMT_, 1, 1, 1); else GO3(FMT_, 1, 1, 4); } \
         else if (pro == 1)        { if (npre == 1) GO3(FMT_, 1, 0, 1); else GO3(FMT_, 1, 0, 4); } \
@@ -207,6 +217,34 @@ int launch_gemv_decode(hipStream_t st, int wtype, const void * W, int64_t K, int
     if (wtype == CLLM_TYPE_Q4_K) GO(CLLM_TYPE_Q4_K); else if (wtype == CLLM_TYPE_Q4_0) GO(CLLM_TYPE_Q4_0); else if (wtype == CLLM_TYPE_Q4_1) GO(CLLM_TYPE_Q4_1); else GO(CLLM_TYPE_Q8_0);
 #undef GO
 #undef GO3
+    LAUNCH_CHECK();
+    return CLLM_OK;
+}
+
+// MUL_MAT_ID for ONE token: n_slots x (dst[:, slot] = W_expert(ids[slot]) . quantize(px + slot * px_slot_stride)), the activation quantized inside
+// the kernel (prologue 2) -- one launch instead of quantize + mat-vec, and the decode kernel's streaming.  CLLM_E_UNSUPPORTED: general path.
+int launch_gemv_decode_id(hipStream_t st, int wtype, const void * W, size_t w_expert_bytes, int64_t K, int64_t nrows, const float * px, int64_t px_slot_stride,
+                          const int32_t * ids, int n_slots, float * dst, int64_t dst_slot_stride) {
+    const int kind = wtype == CLLM_TYPE_Q4_K ? 256 : 32;
+    if (!is_quant_type(wtype) || K % kind || K > 32768 || nrows <= 0 || n_slots < 1 || n_slots > 64 || (uint64_t) nrows * (uint64_t) cllm_row_size(wtype, K) >= (1ull << 32)) return CLLM_E_UNSUPPORTED;
+    if (act_row_bytes(K, kind) > 160 * 1024 || px_slot_stride > INT32_MAX || dst_slot_stride > INT32_MAX) return CLLM_E_UNSUPPORTED;
+    int64_t grid = (nrows + 15) / 16;
+    int64_t cap = device_cu_count() / n_slots; if (cap < 1) cap = 1;
+    if (grid > cap) grid = cap;
+    const int64_t nwaves = grid * 16;
+    const int kfull = (int)(nrows / nwaves), nrem = (int)(nrows % nwaves), nblk = (int)(K / kind);
+    const size_t lds = act_row_bytes(K, kind);
+    const int npre = K <= 4096 ? 1 : K <= 16384 ? 4 : 8;
+#define GOM(FMT_, NPRE_) do { \
+        static bool attr = false; \
+        if (lds > 64 * 1024 && !attr) { HIP_TRY(hipFuncSetAttribute((const void *) k_gemv_dec<FMT_, 2, 0, NPRE_, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr = true; } \
+        hipLaunchKernelGGL((k_gemv_dec<FMT_, 2, 0, NPRE_, true>), dim3((unsigned) grid, (unsigned) n_slots), dim3(1024), lds, st, px, (const float *) nullptr, (const float *) nullptr, (const char *) W, \
+                           nblk, kfull, nrem, 0.0f, dst, (float *) nullptr, (const float *) nullptr, (const float *) nullptr, (unsigned long long *) nullptr, ids, \
+                           (unsigned long long) w_expert_bytes, (int) px_slot_stride, (int) dst_slot_stride); } while (0)
+#define GOMT(FMT_) do { if (npre == 1) GOM(FMT_, 1); else if (npre == 4) GOM(FMT_, 4); else GOM(FMT_, 8); } while (0)
+    if (wtype == CLLM_TYPE_Q4_K) GOMT(CLLM_TYPE_Q4_K); else if (wtype == CLLM_TYPE_Q4_0) GOMT(CLLM_TYPE_Q4_0); else if (wtype == CLLM_TYPE_Q4_1) GOMT(CLLM_TYPE_Q4_1); else GOMT(CLLM_TYPE_Q8_0);
+#undef GOMT
+#undef GOM
     LAUNCH_CHECK();
     return CLLM_OK;
 }

@@ -451,6 +451,46 @@ extern "C" int cllm_op_top_k(void * stream, const cllm_tensor * src, cllm_tensor
     return CLLM_OK;
 }
 
+// The tail of GenericSparseMLP::forward / forward_with_experts (src/layers.cpp:3792-3872) as one launch:
+//   weights = GET_ROWS(probs, ids); weights /= SUM_ROWS(weights)  [norm_topk_prob]; experts *= weights; out = experts[:,0] + experts[:,1] + ... (+ resid)
+// Same operations in the same order as the nodes (double-accumulated sum, IEEE division, left-to-right adds): bit-identical.
+__global__ void __launch_bounds__(256) k_moe_combine(tview e, tview p, tview ids, tview r, tview d, int k, int has_resid) {
+    const int64_t H = d.ne[0], n = d.ne[0] * d.ne[1];
+    for (int64_t x = (int64_t) blockIdx.x * blockDim.x + threadIdx.x; x < n; x += (int64_t) gridDim.x * blockDim.x) {
+        const int64_t h = x % H, t = x / H;
+        double s = 0.0;
+        for (int j = 0; j < k; j++) {
+            const int32_t id = *(const int32_t *)(ids.data + j*ids.nb[0] + t*ids.nb[1]);
+            s += (double) *(const float *)(p.data + (int64_t) id*4 + t*p.nb[1]);
+        }
+        const float sum = (float) s;
+        float acc = 0.0f;
+        for (int j = 0; j < k; j++) {
+            const int32_t id = *(const int32_t *)(ids.data + j*ids.nb[0] + t*ids.nb[1]);
+            const float w = __fdiv_rn(*(const float *)(p.data + (int64_t) id*4 + t*p.nb[1]), sum);
+            const float y = *(const float *)(e.data + h*4 + j*e.nb[1] + t*e.nb[2]) * w;
+            acc = j == 0 ? y : acc + y;
+        }
+        if (has_resid) acc = acc + *(const float *)(r.data + h*4 + t*r.nb[1]);
+        *(float *)(d.data + h*4 + t*d.nb[1]) = acc;
+    }
+}
+extern "C" int cllm_op_moe_combine(void * stream, const cllm_tensor * experts, const cllm_tensor * probs, const cllm_tensor * ids, const cllm_tensor * resid,
+                                   cllm_tensor * dst) {
+    if (!experts || !probs || !ids || !dst) FAIL(CLLM_E_INVALID, "moe_combine: null");
+    if (experts->type != CLLM_TYPE_F32 || probs->type != CLLM_TYPE_F32 || ids->type != CLLM_TYPE_I32 || dst->type != CLLM_TYPE_F32 || (resid && resid->type != CLLM_TYPE_F32))
+        FAIL(CLLM_E_UNSUPPORTED, "moe_combine: types");
+    const int64_t H = experts->ne[0], k = experts->ne[1], T = experts->ne[2];
+    if (k < 1 || k > 64 || ids->ne[0] != k || ids->ne[1] != T || probs->ne[1] != T || dst->ne[0] != H || dst->ne[1] != T || experts->ne[3] != 1 ||
+        experts->nb[0] != 4 || probs->nb[0] != 4 || dst->nb[0] != 4 || (resid && (resid->ne[0] != H || resid->ne[1] != T || resid->nb[0] != 4)))
+        FAIL(CLLM_E_INVALID, "moe_combine: shapes");
+    if (H * T == 0) return CLLM_OK;
+    int64_t grid = (H * T + 255) / 256; if (grid > 8192) grid = 8192;
+    hipLaunchKernelGGL(k_moe_combine, dim3((unsigned) grid), dim3(256), 0, (hipStream_t) stream, tv(experts), tv(probs), tv(ids), resid ? tv(resid) : tv(dst), tv(dst), (int) k, resid ? 1 : 0);
+    LAUNCH_CHECK();
+    return CLLM_OK;
+}
+
 // ================================================================================================
 // SET_ROWS (K-cache write)   ggml_compute_forward_set_rows_f32, ops.cpp:4892-4940
 // ================================================================================================

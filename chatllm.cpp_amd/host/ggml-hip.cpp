@@ -361,8 +361,17 @@ struct fused_attn {
     void * k_cache = nullptr, * v_cache = nullptr;
     float * out = nullptr;
 };
+//   UNARY(SILU) -> MUL                               cllm_op_silu_mul (consumers other than a single-column mat-vec: the expert block of a sparse MoE)
+//   RMS_NORM -> MUL(weight)                          cllm_op_rms_norm_mul (where the norm cannot go into its consumers' prologues)
+//   GET_ROWS(probs, ids) -> SUM_ROWS -> DIV -> MUL(experts) -> ADD of the slot views (-> ADD residual)
+//                                                    cllm_op_moe_combine: the tail of GenericSparseMLP::forward (src/layers.cpp:3792-3872)
+struct fused_moe { const ggml_tensor * experts = nullptr, * probs = nullptr, * ids = nullptr, * resid = nullptr; };
+enum { ALT_NONE = 0, ALT_SILU_MUL = 1 /* src0 is the SiLU */, ALT_RMS_NORM_MUL = 2, ALT_MOE_COMBINE = 3, ALT_MUL_SILU = 4 /* src1 is the SiLU */ };
 struct fuse_plan {
     std::vector<uint8_t> skip;          // node is produced inside a fused launch (or not needed at all)
+    std::vector<uint8_t> alt;           // the node is launched as one of the ALT_* forms
+    std::vector<int>     moe;           // ALT_MOE_COMBINE: index into moes
+    std::vector<fused_moe> moes;
     std::vector<int>     mv;            // index into mvs for MUL_MAT nodes launched fused, else -1
     std::vector<fused_mv> mvs;
     std::vector<int>     sm_src;        // SOFT_MAX nodes: node index of the SCALE feeding the fused scale+mask+soft_max, else -1
@@ -505,7 +514,7 @@ void plan_attention(ggml_cgraph * g, fuse_plan & P, const std::vector<int> & loc
 
 fuse_plan make_plan(ggml_cgraph * g) {
     const int n = ggml_graph_n_nodes(g);
-    fuse_plan P; P.skip.assign(n, 0); P.mv.assign(n, -1); P.sm_src.assign(n, -1); P.attn.assign(n, -1);
+    fuse_plan P; P.skip.assign(n, 0); P.mv.assign(n, -1); P.sm_src.assign(n, -1); P.attn.assign(n, -1); P.alt.assign(n, ALT_NONE); P.moe.assign(n, -1);
     static const bool off = getenv("CLLM_HIP_NO_FUSE") != nullptr;
     if (off || n < 8) return P;
     std::vector<int> local(n, 0), writer(n, -1);        // writer[i]: entry of mvs whose launch produces node i
@@ -627,6 +636,87 @@ fuse_plan make_plan(ggml_cgraph * g) {
         P.groups.push_back(G);
     }
     for (int j = 0; j < n; j++) if (P.mv[j] >= 0 && !P.mvs[P.mv[j]].dst) P.mvs[P.mv[j]].dst = (float *) ggml_graph_node(g, j)->data;
+    // ---- what the patterns above left: element-wise pairs and the tail of a sparse-MoE block
+    auto strip = [&](const ggml_tensor * t) { while (t && t->op == GGML_OP_RESHAPE) t = t->src[0]; return t; };
+    auto all_once = [&](const ggml_tensor * from, const ggml_tensor * to) {      // the RESHAPE chain from `from` down to (excluding) `to`: every node used once
+        for (const ggml_tensor * t = from; t && t != to; t = t->src[0]) { if (t->op != GGML_OP_RESHAPE || !only_local(find(t), 1)) return false; }
+        return true;
+    };
+    for (int i = 0; i < n; i++) {
+        ggml_tensor * t = ggml_graph_node(g, i);
+        if (P.skip[i] || t->op != GGML_OP_MUL || t->type != GGML_TYPE_F32) continue;
+        const ggml_tensor * a = t->src[0], * b = t->src[1];
+        // UNARY(SILU) on either side, same shape, dense
+        for (int side = 0; side < 2; side++) {
+            const ggml_tensor * u = side ? b : a, * o = side ? a : b;
+            const int iu = find(u);
+            if (u->op == GGML_OP_UNARY && ggml_get_unary_op(u) == GGML_UNARY_OP_SILU && iu >= 0 && !P.skip[iu] && only_local(iu, 1) && ggml_are_same_shape(u, o) &&
+                ggml_are_same_shape(u, t) && f32_dense(u->src[0]) && f32_dense(o) && f32_dense(t) && ggml_is_contiguous(u->src[0]) && ggml_is_contiguous(o) && ggml_is_contiguous(t)) {
+                P.alt[i] = side ? ALT_MUL_SILU : ALT_SILU_MUL; P.skip[iu] = 1;
+                break;
+            }
+        }
+        if (P.alt[i]) continue;
+        // RMS_NORM -> MUL(weight vector)
+        const int ir = find(a);
+        if (a->op == GGML_OP_RMS_NORM && ir >= 0 && !P.skip[ir] && only_local(ir, 1) && f32_dense(a->src[0]) && ggml_is_contiguous(a->src[0]) && ggml_is_contiguous(t) &&
+            b->type == GGML_TYPE_F32 && ggml_is_contiguous(b) && ggml_nelements(b) == t->ne[0] && b->ne[0] == t->ne[0]) {
+            P.alt[i] = ALT_RMS_NORM_MUL; P.skip[ir] = 1;
+            continue;
+        }
+        // experts [H, k, T] * weights [1, k, T], weights = RESHAPE(DIV(RESHAPE(GET_ROWS(RESHAPE(probs), ids)), SUM_ROWS(same)))
+        if (a->ne[3] != 1 || b->ne[0] != 1 || b->ne[1] != a->ne[1] || b->ne[2] != a->ne[2] || !f32_dense(a) || !ggml_is_contiguous(a) || !ggml_is_contiguous(t)) continue;
+        const int64_t H = a->ne[0], k = a->ne[1], T = a->ne[2];
+        const ggml_tensor * dv = strip(b);
+        if (!dv || dv->op != GGML_OP_DIV || !all_once(b, dv) || !only_local(find(dv), 1)) continue;
+        const ggml_tensor * wr = dv->src[0], * sr = dv->src[1];
+        const int iwr = find(wr), isr = find(sr);
+        if (sr->op != GGML_OP_SUM_ROWS || sr->src[0] != wr || !only_local(isr, 1) || wr->op != GGML_OP_RESHAPE || iwr < 0 || local[iwr] != 2 || ggml_node_get_use_count(g, iwr) != 2 ||
+            wr->ne[0] != k || wr->ne[1] != T) continue;
+        const ggml_tensor * gr = wr->src[0];
+        const int igr = find(gr);
+        if (gr->op != GGML_OP_GET_ROWS || !only_local(igr, 1) || gr->ne[0] != 1) continue;
+        const ggml_tensor * probs = strip(gr->src[0]), * ids = gr->src[1];
+        if (!probs || probs->type != GGML_TYPE_F32 || !ggml_is_contiguous(probs) || probs->ne[1] != T || ggml_nelements(probs) != probs->ne[0] * T ||
+            ids->type != GGML_TYPE_I32 || ids->ne[0] != k || ids->ne[1] != T || ids->nb[0] != 4) continue;
+        // the k slot views and the ADD chain
+        if (local[i] != (int) k || ggml_node_get_use_count(g, i) != (int) k || (t->flags & GGML_TENSOR_FLAG_OUTPUT) || k < 1 || k > 64) continue;
+        std::vector<int> views((size_t) k, -1);
+        bool ok = true;
+        for (int u : users[i]) {
+            const ggml_tensor * v = ggml_graph_node(g, u);
+            const size_t off = (size_t)((const char *) v->data - (const char *) t->data);
+            if (v->op != GGML_OP_VIEW || v->src[0] != t || v->ne[0] != H || v->ne[1] != T || v->ne[2] != 1 || v->nb[1] != t->nb[2] || off % t->nb[1] || off / t->nb[1] >= (size_t) k ||
+                views[off / t->nb[1]] >= 0 || !only_local(u, 1)) { ok = false; break; }
+            views[off / t->nb[1]] = u;
+        }
+        if (!ok) continue;
+        int cur = views[0];
+        std::vector<int> adds;
+        for (int64_t j = 1; j < k && ok; j++) {
+            const int ia = users[cur][0];
+            const ggml_tensor * ad = ggml_graph_node(g, ia);
+            ok = ad->op == GGML_OP_ADD && ad->src[0] == ggml_graph_node(g, cur) && ad->src[1] == ggml_graph_node(g, views[(size_t) j]) && users[views[(size_t) j]][0] == ia &&
+                 f32_dense(ad) && ggml_is_contiguous(ad) && (j == k - 1 || only_local(ia, 1));
+            adds.push_back(ia); cur = ia;
+        }
+        if (!ok || k < 2) continue;
+        fused_moe M; M.experts = a; M.probs = probs; M.ids = ids;
+        int fin = cur;
+        if (only_local(cur, 1)) {             // ... -> ADD(moe_out, residual)
+            const int ia = users[cur][0];
+            const ggml_tensor * ad = ggml_graph_node(g, ia);
+            if (ad->op == GGML_OP_ADD && !P.skip[ia] && ad->src[0] == ggml_graph_node(g, cur) && f32_dense(ad->src[1]) && ggml_is_contiguous(ad->src[1]) &&
+                ad->src[1]->ne[0] == H && ggml_nelements(ad->src[1]) == H * T && ggml_is_contiguous(ad) && ad->data != ad->src[0]->data) { M.resid = ad->src[1]; fin = ia; }
+        }
+        for (const ggml_tensor * r = b; r != dv; r = r->src[0]) P.skip[find(r)] = 1;
+        P.skip[find(dv)] = P.skip[isr] = P.skip[iwr] = P.skip[igr] = 1;
+        for (const ggml_tensor * r = gr->src[0]; r != probs; r = r->src[0]) if (find(r) >= 0) P.skip[find(r)] = 1;       // (RESHAPEs: no launches anyway)
+        P.skip[i] = 1;
+        for (int ia : adds) P.skip[ia] = 1;
+        if (M.resid) P.skip[cur] = 1;
+        P.skip[fin] = 0; P.alt[fin] = ALT_MOE_COMBINE; P.moe[fin] = (int) P.moes.size(); P.moes.push_back(M);
+    }
     return P;
 }
 
@@ -750,8 +840,25 @@ ggml_status be_graph_compute(ggml_backend_t backend, ggml_cgraph * g) {
                 rc = CALL(cllm_op_mul_mat_id, st, &da, &db, &dc, &d, c->wdata, c->wsize);
             } break;
             case GGML_OP_RMS_NORM: { float eps; memcpy(&eps, n->op_params, 4); rc = CALL(cllm_op_rms_norm, st, &da, &d, eps); } break;
-            case GGML_OP_ADD: rc = CALL(cllm_op_add, st, &da, &db, &d); break;
-            case GGML_OP_MUL: rc = CALL(cllm_op_mul, st, &da, &db, &d); break;
+            case GGML_OP_ADD: if (plan.alt[i] == ALT_MOE_COMBINE) {
+                const fused_moe & M = plan.moes[plan.moe[i]];
+                cllm_tensor de = desc(M.experts), dp = desc(M.probs), di = desc(M.ids), dr;
+                dp.ne[0] = M.probs->ne[0]; dp.ne[1] = M.experts->ne[2]; dp.ne[2] = dp.ne[3] = 1; dp.nb[1] = (size_t) dp.ne[0] * 4; dp.nb[2] = dp.nb[3] = dp.nb[1] * (size_t) dp.ne[1];
+                if (M.resid) { dr = desc(M.resid); dr.ne[0] = M.experts->ne[0]; dr.ne[1] = M.experts->ne[2]; dr.ne[2] = dr.ne[3] = 1; dr.nb[1] = (size_t) dr.ne[0] * 4; dr.nb[2] = dr.nb[3] = dr.nb[1] * (size_t) dr.ne[1]; }
+                cllm_tensor dd = d; dd.ne[0] = M.experts->ne[0]; dd.ne[1] = M.experts->ne[2]; dd.ne[2] = dd.ne[3] = 1; dd.nb[1] = (size_t) dd.ne[0] * 4; dd.nb[2] = dd.nb[3] = dd.nb[1] * (size_t) dd.ne[1];
+                rc = CALL(cllm_op_moe_combine, st, &de, &dp, &di, M.resid ? &dr : nullptr, &dd);
+            } else rc = CALL(cllm_op_add, st, &da, &db, &d); break;
+            case GGML_OP_MUL: if (plan.alt[i] == ALT_SILU_MUL || plan.alt[i] == ALT_MUL_SILU) {
+                const bool a_is_silu = plan.alt[i] == ALT_SILU_MUL;
+                const ggml_tensor * gate = (a_is_silu ? a : b)->src[0], * up = a_is_silu ? b : a;
+                cllm_tensor dg = desc(gate), du = desc(up);
+                rc = CALL(cllm_op_silu_mul, st, &dg, &du, &d);
+            } else if (plan.alt[i] == ALT_RMS_NORM_MUL) {
+                float eps; memcpy(&eps, a->op_params, 4);
+                cllm_tensor dx = desc(a->src[0]), dwt = desc(b);
+                dwt.ne[0] = n->ne[0]; dwt.ne[1] = dwt.ne[2] = dwt.ne[3] = 1; dwt.nb[1] = dwt.nb[2] = dwt.nb[3] = (size_t) n->ne[0] * 4;
+                rc = CALL(cllm_op_rms_norm_mul, st, &dx, &dwt, &d, eps);
+            } else rc = CALL(cllm_op_mul, st, &da, &db, &d); break;
             case GGML_OP_DIV: rc = CALL(cllm_op_div, st, &da, &db, &d); break;
             case GGML_OP_SUM_ROWS: rc = CALL(cllm_op_sum_rows, st, &da, &d); break;
             case GGML_OP_TOP_K: rc = CALL(cllm_op_top_k, st, &da, &d); break;

@@ -161,6 +161,13 @@ def top_k(a, k, dst=None):
     return dst
 
 
+def moe_combine(experts, probs, ids, resid=None, dst=None):
+    """GenericSparseMLP's tail: normalized top-k weights applied to the expert outputs, summed over the slots (+ residual)"""
+    dst = dst or Tensor(F32, [experts.ne[0], experts.ne[2]])
+    _l.check(_l.get().cllm_op_moe_combine(None, _ref(experts), _ref(probs), _ref(ids), _ref(resid), _ref(dst)), "moe_combine")
+    return dst
+
+
 def silu_mul(g, u, dst=None):
     dst = dst or Tensor(F32, g.ne)
     _l.check(_l.get().cllm_op_silu_mul(None, _ref(g), _ref(u), _ref(dst)), "silu_mul")

@@ -206,6 +206,11 @@ CLLM_API int cllm_op_sum_rows(void * stream, const cllm_tensor * src, cllm_tenso
 /* GGML_OP_TOP_K  ggml_compute_forward_top_k_f32 (ops.cpp:8057-8094): dst I32 [k, ...] = indices of the k largest of each row, descending,
  * first two swapped; the expert selection of GenericSparseMLP::select_experts (src/layers.cpp:3817-3840) */
 CLLM_API int cllm_op_top_k(void * stream, const cllm_tensor * src, cllm_tensor * dst);
+/* the tail of a sparse-MoE block (GenericSparseMLP::forward + forward_with_experts, src/layers.cpp:3792-3872) in one launch:
+ *   w = GET_ROWS(probs, ids); w /= SUM_ROWS(w); dst = experts[:,0,:]*w0 + experts[:,1,:]*w1 + ... (+ resid)
+ * experts F32 [H, k, T], probs F32 [n_expert, T], ids I32 [k, T], resid / dst F32 [H, T].  Bit-identical to the node sequence. */
+CLLM_API int cllm_op_moe_combine(void * stream, const cllm_tensor * experts, const cllm_tensor * probs, const cllm_tensor * ids, const cllm_tensor * resid,
+                                 cllm_tensor * dst);
 /* fused  dst = silu(gate) * up   (BaseMLP::forward, src/layers.cpp:2475-2483: UNARY(SILU) then MUL) */
 CLLM_API int cllm_op_silu_mul(void * stream, const cllm_tensor * gate, const cllm_tensor * up, cllm_tensor * dst);
 

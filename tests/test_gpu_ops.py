@@ -346,6 +346,30 @@ def test_moe_router_ops_bit_exact(gpu, n0, n1, n2, k):
     assert np.array_equal(ops.div(dx, T.from_numpy(y)).numpy().reshape(x.shape).view(np.uint32), wantd.view(np.uint32))
 
 
+@pytest.mark.parametrize("H,k,T,ne,with_resid", [(4096, 2, 1, 8, True), (256, 2, 5, 8, False), (100, 4, 3, 16, True)])
+def test_moe_combine_equals_the_node_sequence(gpu, H, k, T, ne, with_resid):
+    ops, T_ = gpu.ops, gpu.Tensor
+    e = T_.from_numpy(rng.standard_normal((T, k, H)).astype(np.float32))
+    pr = rng.standard_normal((T, ne)).astype(np.float32)
+    pr = (np.exp(pr) / np.exp(pr).sum(-1, keepdims=True)).astype(np.float32)
+    p = T_.from_numpy(pr)
+    ids = ops.top_k(p, k)
+    r = T_.from_numpy(rng.standard_normal((T, H)).astype(np.float32))
+    # node by node, as the reference's graph: GET_ROWS(probs [1, n_expert, T], ids) -> [k, T] -> SUM_ROWS -> DIV -> MUL -> ADD of slot views (-> ADD resid)
+    w = ops.get_rows(p.reshape(1, ne, T), ids).reshape(k, T)
+    wn = ops.div(w, ops.sum_rows(w)).reshape(1, k, T)
+    y = ops.mul(e, wn)
+    acc = y.view([H, T], [4, y.nb[2]], offset=0)
+    for j in range(1, k):
+        acc = ops.add(acc, y.view([H, T], [4, y.nb[2]], offset=j * y.nb[1]))
+    if k == 1:
+        acc = ops.cont(acc)
+    want = (ops.add(acc, r) if with_resid else acc)
+    want = ops.cont(want).numpy() if not want.is_contiguous() else want.numpy()
+    got = ops.moe_combine(e, p, ids, r if with_resid else None).numpy()
+    assert np.array_equal(got.view(np.uint32).reshape(-1), want.view(np.uint32).reshape(-1))
+
+
 # ---- attention over strided cache views (GQA broadcast) ---------------------------------------------------
 @pytest.mark.parametrize("qlen,n_past", [(1, 0), (1, 37), (1, 255), (6, 0), (5, 11), (64, 0), (200, 56), (33, 150)])
 def test_attention_composite(gpu, qlen, n_past):
