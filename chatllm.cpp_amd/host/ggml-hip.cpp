@@ -540,11 +540,12 @@ fuse_plan make_plan(ggml_cgraph * g) {
         return !(t->flags & GGML_TENSOR_FLAG_OUTPUT) && local[i] == uses && ggml_node_get_use_count(g, i) == uses;
     };
     auto node_of = [&](const ggml_tensor * t, int before) { for (int i = before - 1; i >= 0 && i >= before - 64; i--) if (ggml_graph_node(g, i) == t) return i; return -1; };
-    auto mv_ok = [&](const ggml_tensor * mm) {      // a single-column quantized MUL_MAT the decode mat-vec takes
+    // a single-column quantized MUL_MAT the decode mat-vec takes; row length: 16384 with the norm prologue, 32768 with the others (gemv_decode.hip)
+    auto mv_ok = [&](const ggml_tensor * mm, int64_t kmax = 32768) {
         const ggml_tensor * w = mm->src[0], * x = mm->src[1];
         return mm->op == GGML_OP_MUL_MAT && is_q(w->type) && w->ne[2] == 1 && w->ne[3] == 1 && w->nb[1] == ggml_row_size(w->type, w->ne[0]) && ((uintptr_t) w->data & 15) == 0 &&
                x->type == GGML_TYPE_F32 && x->ne[1] == 1 && x->ne[2] == 1 && x->ne[3] == 1 && f32_vec(mm) &&
-               w->ne[0] <= 16384 && (uint64_t) w->ne[1] * w->nb[1] < (1ull << 32);
+               w->ne[0] <= kmax && (uint64_t) w->ne[1] * w->nb[1] < (1ull << 32);
     };
     for (int i = 0; i < n; i++) {
         ggml_tensor * t = ggml_graph_node(g, i);
@@ -553,7 +554,7 @@ fuse_plan make_plan(ggml_cgraph * g) {
             t->src[1]->ne[0] == t->ne[0] && t->ne[0] % 256 == 0) {
             const int r = node_of(t->src[0], i);
             bool ok = r >= 0 && only_local(r, 1) && only_local(i, local[i]) && local[i] > 0;
-            for (int j : users[i]) { const ggml_tensor * c = ggml_graph_node(g, j); ok = ok && mv_ok(c) && c->src[1] == t; }
+            for (int j : users[i]) { const ggml_tensor * c = ggml_graph_node(g, j); ok = ok && mv_ok(c, 16384) && c->src[1] == t; }
             if (ok) {
                 float eps; memcpy(&eps, t->src[0]->op_params, 4);
                 for (int j : users[i]) {

@@ -98,6 +98,10 @@ def write_model(path, cfg, wtype, seed=1234, model_name="SynthLlama3", fast=Fals
             for i in range(cfg["n_layer"]):
                 for k in ("attn_norm", "ffn_norm"):
                     w[f"layers.{i}.{k}"] = (0, S.make_norm(f"layers.{i}.{k}", H, seed))
+                if cfg.get("qkv_bias"):
+                    hd = cfg["head_dim"]
+                    for b, nb_ in (("bq", cfg["n_head"] * hd), ("bk", cfg["n_kv_head"] * hd), ("bv", cfg["n_kv_head"] * hd)):
+                        w[f"layers.{i}.{b}"] = (0, S.make_bias(f"layers.{i}.{b}", nb_, seed))
         else:
             w = pkg.synth.make_model(cfg, wtype, seed=seed)
         shape = {n: (rows, K) for n, _, rows, K in pkg.synth.tensor_list(cfg, wtype)}
