@@ -357,6 +357,21 @@ extern "C" int cllm_bench_gemv_fused(void * stream, int wtype, void * const * w_
     return CLLM_OK;
 }
 
+// gate and up expert mat-vecs of ONE token + UNARY(SILU) + MUL (MultiMLP::forward, src/layers.cpp:3674-3688) in one launch:
+// as_gu = the gate and up expert tensors with their rows alternating inside every expert (cllm_pack_rows over [K, F * E], interleave 1):
+// [K, 2F, E]; dst[u, slot] = silu(gate_e[u] . x) * (up_e[u] . x), e = ids[slot]; b: [K, 1 | n_used, 1], dst: [F, n_used, 1]
+extern "C" int cllm_op_mul_mat_id_silu_mul(void * stream, const cllm_tensor * as_gu, const cllm_tensor * b, const cllm_tensor * ids, cllm_tensor * dst) {
+    if (!as_gu || !b || !ids || !dst) FAIL(CLLM_E_INVALID, "mul_mat_id_silu_mul: null");
+    if (!is_quant(as_gu->type) || b->type != CLLM_TYPE_F32 || dst->type != CLLM_TYPE_F32 || ids->type != CLLM_TYPE_I32) FAIL(CLLM_E_UNSUPPORTED, "mul_mat_id_silu_mul: types");
+    const int64_t n_used = ids->ne[0];
+    if (ids->ne[1] != 1 || as_gu->ne[0] != b->ne[0] || as_gu->ne[1] % 2 || dst->ne[0] != as_gu->ne[1] / 2 || dst->ne[1] != n_used || dst->ne[2] != 1 || b->ne[2] != 1 ||
+        (b->ne[1] != 1 && b->ne[1] != n_used)) FAIL(CLLM_E_INVALID, "mul_mat_id_silu_mul: shapes (one token)");
+    if (ids->nb[0] != 4 || b->nb[0] != 4 || dst->nb[0] != 4 || as_gu->nb[1] != cllm_row_size(as_gu->type, as_gu->ne[0]) || b->nb[1] % 16 || dst->nb[1] % 4 ||
+        ((uintptr_t) b->data & 15) || ((uintptr_t) as_gu->data & 15) || as_gu->nb[2] % 16) FAIL(CLLM_E_UNSUPPORTED, "mul_mat_id_silu_mul: layout");
+    return launch_gemv_decode_id((hipStream_t) stream, as_gu->type, as_gu->data, as_gu->nb[2], as_gu->ne[0], as_gu->ne[1], (const float *) b->data,
+                                 b->ne[1] == 1 ? 0 : (int64_t)(b->nb[1] / 4), (const int32_t *) ids->data, (int) n_used, (float *) dst->data, (int64_t)(dst->nb[1] / 4), 1);
+}
+
 extern "C" int cllm_op_mul_mat_id(void * stream, const cllm_tensor * as, const cllm_tensor * b, const cllm_tensor * ids, cllm_tensor * dst,
                                   void * wdata, size_t wsize) {
     int rc = check_mm(as, b, dst, "mul_mat_id");

@@ -254,7 +254,7 @@ int launch_rope_table(hipStream_t st, const int32_t * pos_dev, int hd, float fre
 int launch_attn_dec_table(hipStream_t st, const float * qkv, const int32_t * pos_dev, const float * rope_cs, int nh, int nkv, int hd, int mode, uint16_t * k_cache, uint16_t * v_cache, int64_t ML, float * att);
 int launch_attn_long(hipStream_t st, const float * qkv, const int32_t * pos_dev, const float * rope_cs, int nh, int nkv, int hd, int mode, uint16_t * k_cache, uint16_t * v_cache, int64_t ML, float * S, float * att);
 int launch_gemv_decode_id(hipStream_t st, int wtype, const void * W, size_t w_expert_bytes, int64_t K, int64_t nrows, const float * px, int64_t px_slot_stride,
-                          const int32_t * ids, int n_slots, float * dst, int64_t dst_slot_stride);
+                          const int32_t * ids, int n_slots, float * dst, int64_t dst_slot_stride, int epi = 0);
 int attn_long_threshold();      // decoder.hip: cached positions above which the split (3-launch) attention is used
 int launch_rope_kv_attn_decode(hipStream_t st, const float * qkv, const int32_t * pos_dev, int nh, int nkv, int hd, int mode, float freq_base, uint16_t * k_cache, uint16_t * v_cache, int64_t ML, float * att);
 int launch_argmax_advance(hipStream_t st, const float * logits, int n, int32_t * tok_dev, int32_t * pos_dev, int32_t * out_ring, int32_t * counter, float * part_v, int * part_i);

@@ -223,25 +223,29 @@ int launch_gemv_decode(hipStream_t st, int wtype, const void * W, int64_t K, int
 
 // MUL_MAT_ID for ONE token: n_slots x (dst[:, slot] = W_expert(ids[slot]) . quantize(px + slot * px_slot_stride)), the activation quantized inside
 // the kernel (prologue 2) -- one launch instead of quantize + mat-vec, and the decode kernel's streaming.  CLLM_E_UNSUPPORTED: general path.
+// epi 1: every expert's rows alternate gate_u, up_u (cllm_pack_rows, interleave); dst[u, slot] = silu(gate_u . x) * (up_u . x), u < nrows / 2
 int launch_gemv_decode_id(hipStream_t st, int wtype, const void * W, size_t w_expert_bytes, int64_t K, int64_t nrows, const float * px, int64_t px_slot_stride,
-                          const int32_t * ids, int n_slots, float * dst, int64_t dst_slot_stride) {
+                          const int32_t * ids, int n_slots, float * dst, int64_t dst_slot_stride, int epi) {
     const int kind = wtype == CLLM_TYPE_Q4_K ? 256 : 32;
     if (!is_quant_type(wtype) || K % kind || K > 32768 || nrows <= 0 || n_slots < 1 || n_slots > 64 || (uint64_t) nrows * (uint64_t) cllm_row_size(wtype, K) >= (1ull << 32)) return CLLM_E_UNSUPPORTED;
     if (act_row_bytes(K, kind) > 160 * 1024 || px_slot_stride > INT32_MAX || dst_slot_stride > INT32_MAX) return CLLM_E_UNSUPPORTED;
-    int64_t grid = (nrows + 15) / 16;
+    if (epi != 0 && (epi != 1 || nrows % 2 || (nrows / 2) % 8)) return CLLM_E_UNSUPPORTED;
+    const int64_t units = epi == 1 ? nrows / 2 : nrows;
+    int64_t grid = (units + 15) / 16;
     int64_t cap = device_cu_count() / n_slots; if (cap < 1) cap = 1;
     if (grid > cap) grid = cap;
     const int64_t nwaves = grid * 16;
-    const int kfull = (int)(nrows / nwaves), nrem = (int)(nrows % nwaves), nblk = (int)(K / kind);
+    const int kfull = (int)(units / nwaves), nrem = (int)(units % nwaves), nblk = (int)(K / kind);
     const size_t lds = act_row_bytes(K, kind);
     const int npre = K <= 4096 ? 1 : K <= 16384 ? 4 : 8;
-#define GOM(FMT_, NPRE_) do { \
+#define GOM(FMT_, EPI_, NPRE_) do { \
         static bool attr = false; \
-        if (lds > 64 * 1024 && !attr) { HIP_TRY(hipFuncSetAttribute((const void *) k_gemv_dec<FMT_, 2, 0, NPRE_, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr = true; } \
-        hipLaunchKernelGGL((k_gemv_dec<FMT_, 2, 0, NPRE_, true>), dim3((unsigned) grid, (unsigned) n_slots), dim3(1024), lds, st, px, (const float *) nullptr, (const float *) nullptr, (const char *) W, \
+        if (lds > 64 * 1024 && !attr) { HIP_TRY(hipFuncSetAttribute((const void *) k_gemv_dec<FMT_, 2, EPI_, NPRE_, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr = true; } \
+        hipLaunchKernelGGL((k_gemv_dec<FMT_, 2, EPI_, NPRE_, true>), dim3((unsigned) grid, (unsigned) n_slots), dim3(1024), lds, st, px, (const float *) nullptr, (const float *) nullptr, (const char *) W, \
                            nblk, kfull, nrem, 0.0f, dst, (float *) nullptr, (const float *) nullptr, (const float *) nullptr, (unsigned long long *) nullptr, ids, \
                            (unsigned long long) w_expert_bytes, (int) px_slot_stride, (int) dst_slot_stride); } while (0)
-#define GOMT(FMT_) do { if (npre == 1) GOM(FMT_, 1); else if (npre == 4) GOM(FMT_, 4); else GOM(FMT_, 8); } while (0)
+#define GOMT(FMT_) do { if (epi == 1) { if (npre == 1) GOM(FMT_, 1, 1); else if (npre == 4) GOM(FMT_, 1, 4); else GOM(FMT_, 1, 8); } \
+                        else          { if (npre == 1) GOM(FMT_, 0, 1); else if (npre == 4) GOM(FMT_, 0, 4); else GOM(FMT_, 0, 8); } } while (0)
     if (wtype == CLLM_TYPE_Q4_K) GOMT(CLLM_TYPE_Q4_K); else if (wtype == CLLM_TYPE_Q4_0) GOMT(CLLM_TYPE_Q4_0); else if (wtype == CLLM_TYPE_Q4_1) GOMT(CLLM_TYPE_Q4_1); else GOMT(CLLM_TYPE_Q8_0);
 #undef GOMT
 #undef GOM

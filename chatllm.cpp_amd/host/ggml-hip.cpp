@@ -211,7 +211,8 @@ void * get_pack(int device, void * stream, const ggml_tensor * const * w, int n,
     for (int i = 0; i < n; i++) {
         const auto * bc = (const hip_buffer_ctx *) w[i]->buffer->context;
         e.src[i] = w[i]->data; e.uid[i] = bc->uid; e.gen[i] = bc->gen;
-        rows[i] = flat ? (int64_t) ggml_nbytes(w[i]) : w[i]->ne[1]; srcs[i] = w[i]->data; bytes += flat ? ggml_nbytes(w[i]) : (size_t) w[i]->ne[1] * w[i]->nb[1];
+        if (!flat && w[i]->ne[2] > 1 && w[i]->nb[2] != (size_t) w[i]->ne[1] * w[i]->nb[1]) return nullptr;      // expert slabs must be contiguous
+        rows[i] = flat ? (int64_t) ggml_nbytes(w[i]) : w[i]->ne[1] * w[i]->ne[2]; srcs[i] = w[i]->data; bytes += flat ? ggml_nbytes(w[i]) : (size_t) rows[i] * w[i]->nb[1];
     }
     size_t mfree = 0, mtotal = 0;
     cllm_device_info(device, nullptr, 0, &mfree, &mtotal, nullptr);
@@ -365,13 +366,16 @@ struct fused_attn {
 //   RMS_NORM -> MUL(weight)                          cllm_op_rms_norm_mul (where the norm cannot go into its consumers' prologues)
 //   GET_ROWS(probs, ids) -> SUM_ROWS -> DIV -> MUL(experts) -> ADD of the slot views (-> ADD residual)
 //                                                    cllm_op_moe_combine: the tail of GenericSparseMLP::forward (src/layers.cpp:3792-3872)
+//   {MUL_MAT_ID gate, MUL_MAT_ID up} -> UNARY(SILU) -> MUL     one token: cllm_op_mul_mat_id_silu_mul over the per-expert interleaved pack
 struct fused_moe { const ggml_tensor * experts = nullptr, * probs = nullptr, * ids = nullptr, * resid = nullptr; };
-enum { ALT_NONE = 0, ALT_SILU_MUL = 1 /* src0 is the SiLU */, ALT_RMS_NORM_MUL = 2, ALT_MOE_COMBINE = 3, ALT_MUL_SILU = 4 /* src1 is the SiLU */ };
+struct moe_gate_up { int mul = -1, gate = -1, up = -1, unary = -1; void * W = nullptr; };      // node indices; W: the pack, resolved before the walk
+enum { ALT_NONE = 0, ALT_SILU_MUL = 1 /* src0 is the SiLU */, ALT_RMS_NORM_MUL = 2, ALT_MOE_COMBINE = 3, ALT_MUL_SILU = 4 /* src1 is the SiLU */, ALT_MOE_GATE_UP = 5 };
 struct fuse_plan {
     std::vector<uint8_t> skip;          // node is produced inside a fused launch (or not needed at all)
     std::vector<uint8_t> alt;           // the node is launched as one of the ALT_* forms
     std::vector<int>     moe;           // ALT_MOE_COMBINE: index into moes
     std::vector<fused_moe> moes;
+    std::vector<moe_gate_up> gus;       // candidates (P.moe[mul node] indexes them once resolved)
     std::vector<int>     mv;            // index into mvs for MUL_MAT nodes launched fused, else -1
     std::vector<fused_mv> mvs;
     std::vector<int>     sm_src;        // SOFT_MAX nodes: node index of the SCALE feeding the fused scale+mask+soft_max, else -1
@@ -654,6 +658,16 @@ fuse_plan make_plan(ggml_cgraph * g) {
             if (u->op == GGML_OP_UNARY && ggml_get_unary_op(u) == GGML_UNARY_OP_SILU && iu >= 0 && !P.skip[iu] && only_local(iu, 1) && ggml_are_same_shape(u, o) &&
                 ggml_are_same_shape(u, t) && f32_dense(u->src[0]) && f32_dense(o) && f32_dense(t) && ggml_is_contiguous(u->src[0]) && ggml_is_contiguous(o) && ggml_is_contiguous(t)) {
                 P.alt[i] = side ? ALT_MUL_SILU : ALT_SILU_MUL; P.skip[iu] = 1;
+                // both operands straight from one-token MUL_MAT_IDs over the same activation and ids: candidate for the merged expert launch
+                const ggml_tensor * gm = u->src[0], * um = o;
+                const int igm = find(gm), ium = find(um);
+                if (gm->op == GGML_OP_MUL_MAT_ID && um->op == GGML_OP_MUL_MAT_ID && igm >= 0 && ium >= 0 && only_local(igm, 1) && only_local(ium, 1) &&
+                    gm->src[1] == um->src[1] && gm->src[2] == um->src[2] && gm->src[2]->ne[1] == 1 && gm->src[2]->nb[0] == 4 &&
+                    gm->src[0]->type == um->src[0]->type && is_q(gm->src[0]->type) && ggml_are_same_shape(gm->src[0], um->src[0]) && gm->src[0]->nb[1] == um->src[0]->nb[1] &&
+                    gm->src[0]->ne[1] % 8 == 0 && gm->src[0]->ne[0] <= 32768 && gm->src[1]->nb[0] == 4 && gm->src[1]->nb[1] % 16 == 0 && ((uintptr_t) gm->src[1]->data & 15) == 0) {
+                    moe_gate_up G; G.mul = i; G.gate = igm; G.up = ium; G.unary = iu;
+                    P.gus.push_back(G);
+                }
                 break;
             }
         }
@@ -784,6 +798,14 @@ ggml_status be_graph_compute(ggml_backend_t backend, ggml_cgraph * g) {
             plan.mvs[A.wq].dst = a_qkv; plan.mvs[A.wk].dst = a_qkv + (size_t) A.hd * A.nh; plan.mvs[A.wv].dst = a_qkv + (size_t) A.hd * (A.nh + A.nkv);
         }
     }
+    // merged expert gate/up launches: only where a packed (per-expert interleaved) copy of the two weight tensors can be had
+    for (moe_gate_up & G : plan.gus) {
+        const ggml_tensor * w[2] = { ggml_graph_node(g, G.gate)->src[0], ggml_graph_node(g, G.up)->src[0] };
+        G.W = get_pack(c->device, st, w, 2, true);
+        if (!G.W) continue;
+        plan.skip[G.gate] = plan.skip[G.up] = 1;            // (the UNARY is skipped already)
+        plan.alt[G.mul] = ALT_MOE_GATE_UP; plan.moe[G.mul] = (int)(&G - plan.gus.data());
+    }
     int merged = 0, launches = 0;
     // one walk over the nodes; sw != nullptr: serialize the calls instead of making them (same decisions, same host-side state changes)
     auto walk = [&](fuse_plan & plan, sig_writer * sw) -> ggml_status {
@@ -849,7 +871,13 @@ ggml_status be_graph_compute(ggml_backend_t backend, ggml_cgraph * g) {
                 cllm_tensor dd = d; dd.ne[0] = M.experts->ne[0]; dd.ne[1] = M.experts->ne[2]; dd.ne[2] = dd.ne[3] = 1; dd.nb[1] = (size_t) dd.ne[0] * 4; dd.nb[2] = dd.nb[3] = dd.nb[1] * (size_t) dd.ne[1];
                 rc = CALL(cllm_op_moe_combine, st, &de, &dp, &di, M.resid ? &dr : nullptr, &dd);
             } else rc = CALL(cllm_op_add, st, &da, &db, &d); break;
-            case GGML_OP_MUL: if (plan.alt[i] == ALT_SILU_MUL || plan.alt[i] == ALT_MUL_SILU) {
+            case GGML_OP_MUL: if (plan.alt[i] == ALT_MOE_GATE_UP) {
+                const moe_gate_up & G = plan.gus[plan.moe[i]];
+                const ggml_tensor * gm = ggml_graph_node(g, G.gate);
+                cllm_tensor dw = desc(gm->src[0]), dx = desc(gm->src[1]), di = desc(gm->src[2]);
+                dw.ne[1] *= 2; dw.nb[2] *= 2; dw.nb[3] = dw.nb[2] * (size_t) dw.ne[2]; dw.data = G.W;
+                rc = CALL(cllm_op_mul_mat_id_silu_mul, st, &dw, &dx, &di, &d);
+            } else if (plan.alt[i] == ALT_SILU_MUL || plan.alt[i] == ALT_MUL_SILU) {
                 const bool a_is_silu = plan.alt[i] == ALT_SILU_MUL;
                 const ggml_tensor * gate = (a_is_silu ? a : b)->src[0], * up = a_is_silu ? b : a;
                 cllm_tensor dg = desc(gate), du = desc(up);

@@ -161,6 +161,19 @@ def top_k(a, k, dst=None):
     return dst
 
 
+def mul_mat_id_silu_mul(as_gate, as_up, b, ids, dst=None):
+    """MultiMLP::forward's gate / up / SiLU / MUL for one token in one launch (the two expert tensors are packed first: rows alternating)"""
+    L = _l.get()
+    K, F, E = as_gate.ne[0], as_gate.ne[1], as_gate.ne[2]
+    packed = Tensor(as_gate.type, [K, 2 * F, E])
+    srcs = (C.c_void_p * 2)(as_gate.data_ptr().value, as_up.data_ptr().value)
+    rows = (C.c_int64 * 2)(F * E, F * E)
+    _l.check(L.cllm_pack_rows(None, packed.data_ptr(), srcs, rows, 2, as_gate.nb[1], 1), "pack_rows")
+    dst = dst or Tensor(F32, [F, ids.ne[0], 1])
+    _l.check(L.cllm_op_mul_mat_id_silu_mul(None, _ref(packed), _ref(b), _ref(ids), _ref(dst)), "mul_mat_id_silu_mul")
+    return dst
+
+
 def moe_combine(experts, probs, ids, resid=None, dst=None):
     """GenericSparseMLP's tail: normalized top-k weights applied to the expert outputs, summed over the slots (+ residual)"""
     dst = dst or Tensor(F32, [experts.ne[0], experts.ne[2]])

@@ -116,6 +116,11 @@ CLLM_API int    cllm_op_mul_mat_vec_fused(void * stream, const cllm_tensor * src
  * (interleave 0; e.g. q, k, v) or a_0, b_0, a_1, b_1, ... of two matrices with the same number of rows (interleave 1; gate, up). */
 CLLM_API int    cllm_pack_rows(void * stream, void * dst, const void * const * srcs, const int64_t * nrows, int n, size_t row_bytes, int interleave);
 
+/* gate and up expert mat-vecs of ONE token + UNARY(SILU) + MUL (MultiMLP::forward, src/layers.cpp:3674-3688) in one launch.
+ * as_gu: [K, 2F, E], every expert's gate and up rows alternating (cllm_pack_rows over the two [K, F*E] tensors, interleave 1);
+ * dst[u, slot] = silu(gate_e[u] . x) * (up_e[u] . x) with e = ids[slot] read on the device.  Bit-identical to the four nodes. */
+CLLM_API int    cllm_op_mul_mat_id_silu_mul(void * stream, const cllm_tensor * as_gu, const cllm_tensor * b, const cllm_tensor * ids, cllm_tensor * dst);
+
 /* measurement hook for bench.py's "roofline" object: quantizes src1 once, then times `iters` launches of ONLY the
  * mat-mul kernel between two HIP events on `stream`, cycling src0->data through src0_datas[0..n_src0) (distinct
  * copies of the weights, so the Infinity Cache cannot serve them).  avg_us = average kernel launch duration. */

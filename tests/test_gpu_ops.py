@@ -346,6 +346,18 @@ def test_moe_router_ops_bit_exact(gpu, n0, n1, n2, k):
     assert np.array_equal(ops.div(dx, T.from_numpy(y)).numpy().reshape(x.shape).view(np.uint32), wantd.view(np.uint32))
 
 
+@pytest.mark.parametrize("t,K,F,E,k", [(O.Q4_K, 4096, 1024, 8, 2), (O.Q8_0, 512, 264, 4, 2), (O.Q4_0, 1024, 512, 8, 3), (O.Q4_1, 256, 64, 8, 2)])
+def test_mul_mat_id_silu_mul_equals_the_four_nodes(gpu, t, K, F, E, k):
+    ops, T = gpu.ops, gpu.Tensor
+    wg = T.from_numpy(rand_blocks(t, F * E, K, rng), t, [K, F, E])
+    wu = T.from_numpy(rand_blocks(t, F * E, K, rng), t, [K, F, E])
+    x = T.from_numpy(rng.standard_normal((1, 1, K)).astype(np.float32))
+    ids = T.from_numpy(rng.choice(E, k, replace=False).astype(np.int32).reshape(1, k))
+    want = ops.mul(ops.mul_mat_id(wu, x, ids), ops.silu(ops.mul_mat_id(wg, x, ids))).numpy()
+    got = ops.mul_mat_id_silu_mul(wg, wu, x, ids).numpy()
+    assert np.array_equal(got.view(np.uint32).reshape(-1), want.view(np.uint32).reshape(-1))
+
+
 @pytest.mark.parametrize("H,k,T,ne,with_resid", [(4096, 2, 1, 8, True), (256, 2, 5, 8, False), (100, 4, 3, 16, True)])
 def test_moe_combine_equals_the_node_sequence(gpu, H, k, T, ne, with_resid):
     ops, T_ = gpu.ops, gpu.Tensor
