@@ -149,14 +149,14 @@ __global__ void __launch_bounds__(1024) k_gemv_dec(const float * __restrict__ px
     // ---- (4) stream the rows ----
     const q4k_sel L = q4k_lane_sel(lane);
     const int off_d = (int) act_off_d(K), off_s = (int) act_off_s(K, KIND);      // (the Q8_1 flavour has the Q8_0 geometry)
-    float accd = 0.0f, accm = 0.0f, gate = 0.0f;
+    float accd = 0.0f, gate = 0.0f;
     int ck = 0, csub = 0, cs = 0;                                   // consume cursor
     while (ck < nmine) {
 #pragma unroll
         for (int p = 0; p < P; p++) {
             const int b = IS_K ? 8 * cs + grp : 64 * cs + lane;
             const bool ok = ck < nmine && b < nblk;
-            if (IS_K) q4k_step(hh[p], qq[p], lds, off_d, off_s, ok ? b : 0, ok, L, accd, accm);
+            if (IS_K) q4k_step(hh[p], qq[p], lds, off_d, off_s, ok ? b : 0, ok, L, accd);
             else {
                 uint32_t h; u32x4 w0, w1 = {0, 0, 0, 0};
                 q32_align<IS_K ? CLLM_TYPE_Q4_0 : FMT>(qq[p], q2[IS_Q8 ? p : 0], hh[p].x, hh[p].y, h, w0, w1);
@@ -164,7 +164,7 @@ __global__ void __launch_bounds__(1024) k_gemv_dec(const float * __restrict__ px
             }
             issue(p);
             if (++cs == S) {                                        // row complete: reduce over the wave, epilogue, store
-                float v = IS_K ? wave_sum(accd) - wave_sum(accm) : wave_sum(accd);
+                float v = wave_sum(accd);
                 if (ck < nmine) {                                   // wave-uniform; bias / resid come through the scalar cache
                     const int cunit = unit_of(ck), crow = cunit * RU + csub;
                     if (EPI == 1) {
@@ -176,7 +176,7 @@ __global__ void __launch_bounds__(1024) k_gemv_dec(const float * __restrict__ px
                         if (lane == 0) dst[crow] = v;
                     }
                 }
-                accd = 0.0f; accm = 0.0f; cs = 0;
+                accd = 0.0f; cs = 0;
                 if (++csub == RU) { csub = 0; ck++; }
             }
         }

@@ -116,9 +116,9 @@ __global__ void __launch_bounds__(1024) k_mmvq_q4_K(const mmvq_args a) {
     const q4k_sel L = q4k_lane_sel(lane);
     const int off_d = (int) act_off_d(K), off_s = (int) act_off_s(K, 256);
 
-    float accd[NC], accm[NC];
+    float accd[NC];
 #pragma unroll
-    for (int c = 0; c < NC; c++) { accd[c] = 0.0f; accm[c] = 0.0f; }
+    for (int c = 0; c < NC; c++) accd[c] = 0.0f;
     int64_t ck = 0; int csub = 0, cs = 0;      // consume cursor
     float gate = 0.0f;
     int cold = PP - P;                         // consumed steps that were covered by the prologue burst: no re-issue for them
@@ -129,7 +129,7 @@ __global__ void __launch_bounds__(1024) k_mmvq_q4_K(const mmvq_args a) {
             const bool ok = ck < nmine && b < nblk;
             const int bb = ok ? b : 0;     // in-range LDS addresses for masked steps
 #pragma unroll
-            for (int c = 0; c < NC; c++) q4k_step(hh[p], qq[p], lds + c * rb, off_d, off_s, bb, ok, L, accd[c], accm[c]);
+            for (int c = 0; c < NC; c++) q4k_step(hh[p], qq[p], lds + c * rb, off_d, off_s, bb, ok, L, accd[c]);
             if (PP == P) issue(hh[p], qq[p]);
             else if (cold > 0) cold--;      // (scalar)
             else issue(hh[(p + P) % PP], qq[(p + P) % PP]);
@@ -137,7 +137,7 @@ __global__ void __launch_bounds__(1024) k_mmvq_q4_K(const mmvq_args a) {
                 const int64_t cunit = unit_of(ck), crow = cunit * RU + csub;
 #pragma unroll
                 for (int c = 0; c < NC; c++) {
-                    float v = wave_sum(accd[c]) - wave_sum(accm[c]);
+                    float v = wave_sum(accd[c]);
                     if (ck < nmine) {   // wave-uniform; bias / resid come through the scalar cache (their own counter)
                         if (EPI == 1) {
                             if (csub == 0) gate = v;
@@ -148,7 +148,7 @@ __global__ void __launch_bounds__(1024) k_mmvq_q4_K(const mmvq_args a) {
                             if (lane == 0) dst[crow + c * dst_cs] = v;
                         }
                     }
-                    accd[c] = 0.0f; accm[c] = 0.0f;
+                    accd[c] = 0.0f;
                 }
                 cs = 0;
                 if (++csub == RU) { csub = 0; ck++; }

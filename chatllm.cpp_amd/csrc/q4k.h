@@ -23,8 +23,12 @@ __device__ __forceinline__ q4k_sel q4k_lane_sel(int lane) {
 
 // h = block header, q = this lane's 16 quant bytes, ar = quantized activation row (act layout, common.h) in LDS,
 // off_d / off_s = its scale / sub-block-sum planes, bb = super-block index (in range), ok = step is real (not a masked dummy)
+// ONE accumulator per lane: acc += (d yd) * sum_sub sc*dot  -  (dmin yd) * m*bsum.  (Two accumulators -- the scale part and the mins part
+// summed separately and subtracted at the end of the row, the structure of the reference's AVX2 loop -- cost a second wave reduction per
+// row: with 4096-long rows, two steps each, that was a measurable share of the mat-vec.  The order of fp32 additions is a tolerance-level
+// choice; every path shares this function, so they all stay bit-identical to each other.)
 __device__ __forceinline__ void q4k_step(const u32x4 h, const u32x4 q, const char * ar, int off_d, int off_s, int bb, bool ok, const q4k_sel & L,
-                                         float & accd, float & accm) {
+                                         float & acc) {
     const float d    = h2f((uint16_t)(h.x & 0xffff));
     const float dmin = h2f((uint16_t)(h.x >> 16));
     // 6-bit unpack: u0 = sc[0..3], u1 = sc[4..7], u2 = m[0..3], u3 = m[4..7]
@@ -44,8 +48,7 @@ __device__ __forceinline__ void q4k_step(const u32x4 h, const u32x4 q, const cha
     int il = dot4(ql[0], al.x, 0); il = dot4(ql[1], al.y, il); il = dot4(ql[2], al.z, il); il = dot4(ql[3], al.w, il);
     int ih = dot4(qh[0], ah.x, 0); ih = dot4(qh[1], ah.y, ih); ih = dot4(qh[2], ah.z, ih); ih = dot4(qh[3], ah.w, ih);
     const int t = sc_lo * il + sc_hi * ih;
-    const float nd = __builtin_fmaf(d * yd, (float) t, accd);
-    const float nm = __builtin_fmaf(dmin * yd, (float)(mj * ys), accm);
-    accd = ok ? nd : accd;
-    accm = ok ? nm : accm;
+    const float nd = __builtin_fmaf(d * yd, (float) t, acc);
+    const float na = __builtin_fmaf(-(dmin * yd), (float)(mj * ys), nd);
+    acc = ok ? na : acc;
 }
