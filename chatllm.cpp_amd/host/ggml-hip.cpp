@@ -136,9 +136,11 @@ void buf_set(ggml_backend_buffer_t b, ggml_tensor * t, const void * data, size_t
 // destination is several times slower than DMA into pinned memory + a memcpy
 void * g_stage = nullptr; size_t g_stage_size = 0;
 constexpr size_t k_stage_chunk = 4u << 20;
+std::mutex g_stage_mutex;
 void buf_get(ggml_backend_buffer_t b, const ggml_tensor * t, void * data, size_t off, size_t size) {
     ws_scope ws(g_ws.get_us); g_ws.gets++;
     flush_sets();
+    std::lock_guard<std::mutex> lock(g_stage_mutex);            // one staging area (accessory models may read from other threads)
     cllm_set_device(((hip_buffer_ctx *) b->context)->device);
     const size_t want = size < k_stage_chunk ? size : k_stage_chunk;
     if (size >= 4096 && g_stage_size < want) {
