@@ -9,7 +9,7 @@
  * caller (ggml's scheduler, via supports_op) can route the node elsewhere.
  *
  * Two callers bind it:
- *   1. host/ggml_backend_hip.cpp -- a ggml backend module (ggml_backend_init() + the five vtables of
+ *   1. chatllm.cpp_amd/host/ggml-hip.cpp -- a ggml backend module (ggml_backend_init() + the five vtables of
  *      /root/reference/ggml/src/ggml-backend-impl.h:11-251) whose graph_compute walks a ggml_cgraph
  *      and maps each node 1:1 onto the cllm_op_* functions below.  That is what the unmodified
  *      chatllm.cpp host (src/backend.cpp:277-302, --ggml_dir) loads as libggml-hip.so.
@@ -229,7 +229,7 @@ CLLM_API int cllm_op_get_rows(void * stream, const cllm_tensor * src, const cllm
 /* dequantize_row_q4_0 / q8_0 / q4_K (ggml/src/ggml-quants.c:307-325, 401-414, 1352-1373) */
 CLLM_API int cllm_dequantize_row(void * stream, int type, const void * blocks, float * y, int64_t k);
 
-/* ---- host-side graph runner for the Llama-3 / Qwen2 decoder (csrc/decoder.cpp) ------------
+/* ---- host-side graph runner for the Llama-3 / Qwen2 decoder (chatllm.cpp_amd/csrc/decoder.hip) ------------
  * mirrors HeterogeneousModel::forward + LMBlock1Forward::forward + LMFinalSteps::forward
  * (src/models.cpp:1399-1424,1736-1784; src/layers.cpp:2719-2761) as a fixed launch sequence on one
  * stream, captured into a hipGraph per (qlen) so that the per-token host cost is one graph launch

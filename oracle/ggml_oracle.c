@@ -11,6 +11,9 @@
 #include <stdlib.h>
 #include <string.h>
 
+/* two statements of the reference are plain C that gcc -O3 (-ffp-contract=fast) compiles to one fma; fused here explicitly */
+#define ORC_Q41_SUMMS(m, s, acc) fmaf((m), (s), (acc))
+#define ORC_F32_TAIL(x, y, acc)  fmaf((x), (y), (acc))
 #define ORC_MIN(a, b) ((a) < (b) ? (a) : (b))
 #define ORC_MAX(a, b) ((a) > (b) ? (a) : (b))
 
@@ -315,6 +318,164 @@ float orc_vec_dot_q4_K_q8_K(int64_t n, const orc_block_q4_K * x, const orc_block
 }
 
 /* ------------------------------------------------------------------------------------------ */
+/* dot products, x86 AVX2 branches (ggml-cpu/arch/x86/quants.c) -- LANE-EXACT restatements      */
+/*                                                                                            */
+/* The reference build on the benchmark host takes the AVX2 branches: 8 fp32 lane accumulators */
+/* (lane L = dword L of every 32-byte chunk), ONE fused multiply-add per block and lane in      */
+/* block order, then hsum_float_8.  Integer sums are exact in any order; the fp32 chain is      */
+/* not, so these functions restate its order -- they are bit-identical to libggml-cpu.so       */
+/* (tests/test_oracle_vs_reference.py), for every N: tinyBLAS_Q0_AVX (llamafile/sgemm.cpp:      */
+/* 1346-1790, the n >= 2 path of Q4_0 / Q8_0) keeps the same per-element chain.                */
+/* ------------------------------------------------------------------------------------------ */
+static int g_order = ORC_ORDER_AVX2;
+void orc_set_order(int order) { g_order = order; }
+int  orc_get_order(void) { return g_order; }
+
+/* hsum_float_8 (arch/x86/quants.c:43-49) */
+static inline float hsum8(const float x[8]) {
+    float r0 = x[4] + x[0], r1 = x[5] + x[1], r2 = x[6] + x[2], r3 = x[7] + x[3];
+    r0 = r0 + r2; r1 = r1 + r3;
+    return r0 + r1;
+}
+
+/* arch/x86/quants.c:543-577: lanes 0..3 = elements 0..15 (low nibbles), lanes 4..7 = elements 16..31 (high nibbles) */
+float orc_vec_dot_q4_0_q8_0_avx2(int64_t n, const orc_block_q4_0 * x, const orc_block_q8_0 * y) {
+    const int64_t nb = n / ORC_QK;
+    float acc[8] = {0};
+    for (int64_t ib = 0; ib < nb; ib++) {
+        const float d = orc_fp16_to_fp32(x[ib].d) * orc_fp16_to_fp32(y[ib].d);
+        for (int L = 0; L < 8; L++) {
+            int s = 0;
+            for (int e = 0; e < 4; e++) {
+                const int i = 4 * L + e;
+                const int w = i < 16 ? (x[ib].qs[i] & 0x0F) - 8 : (x[ib].qs[i - 16] >> 4) - 8;
+                s += w * y[ib].qs[i];
+            }
+            acc[L] = fmaf(d, (float) s, acc[L]);
+        }
+    }
+    return hsum8(acc);
+}
+
+/* arch/x86/quants.c:1012-1040 */
+float orc_vec_dot_q8_0_q8_0_avx2(int64_t n, const orc_block_q8_0 * x, const orc_block_q8_0 * y) {
+    const int64_t nb = n / ORC_QK;
+    float acc[8] = {0};
+    for (int64_t ib = 0; ib < nb; ib++) {
+        const float d = orc_fp16_to_fp32(x[ib].d) * orc_fp16_to_fp32(y[ib].d);
+        for (int L = 0; L < 8; L++) {
+            int s = 0;
+            for (int e = 0; e < 4; e++) s += x[ib].qs[4 * L + e] * y[ib].qs[4 * L + e];
+            acc[L] = fmaf(d, (float) s, acc[L]);
+        }
+    }
+    return hsum8(acc);
+}
+
+/* arch/x86/quants.c:701-760: summs += m_w * s_a is a scalar statement that gcc -O3 contracts into one fma
+ * (-ffp-contract=fast is gcc's default for GNU C; verified bit for bit against the reference build) */
+float orc_vec_dot_q4_1_q8_1_avx2(int64_t n, const orc_block_q4_1 * x, const orc_block_q8_1 * y) {
+    const int64_t nb = n / ORC_QK;
+    float acc[8] = {0};
+    float summs = 0.0f;
+    for (int64_t ib = 0; ib < nb; ib++) {
+        const float d0 = orc_fp16_to_fp32(x[ib].d), d1 = orc_fp16_to_fp32(y[ib].d);
+        summs = ORC_Q41_SUMMS(orc_fp16_to_fp32(x[ib].m), orc_fp16_to_fp32(y[ib].s), summs);
+        const float d0d1 = d0 * d1;
+        for (int L = 0; L < 8; L++) {
+            int s = 0;
+            for (int e = 0; e < 4; e++) {
+                const int i = 4 * L + e;
+                const int w = i < 16 ? (x[ib].qs[i] & 0x0F) : (x[ib].qs[i - 16] >> 4);
+                s += w * y[ib].qs[i];
+            }
+            acc[L] = fmaf(d0d1, (float) s, acc[L]);
+        }
+    }
+    return hsum8(acc) + summs;
+}
+
+/* arch/x86/quants.c:1742-1822: per super-block and lane L, sumi[L] = sum over the four 64-weight chunks of
+ * sc_lo * (q4l . q8l)[dword L] + sc_hi * (q4h . q8h)[dword L]; acc[L] = fma(d, sumi[L], acc[L]);
+ * acc_m[k] = fma(dmin, m[2k] S[2k] + m[2k+1] S[2k+1], acc_m[k]), S = bsums of the 32-weight sub-blocks, dmin = -(y.d) * x.dmin */
+float orc_vec_dot_q4_K_q8_K_avx2(int64_t n, const orc_block_q4_K * x, const orc_block_q8_K * y) {
+    const int64_t nb = n / ORC_QK_K;
+    float acc[8] = {0}, acc_m[4] = {0};
+    for (int64_t i = 0; i < nb; i++) {
+        const float d = y[i].d * orc_fp16_to_fp32(x[i].d);
+        const float dmin = -y[i].d * orc_fp16_to_fp32(x[i].dmin);
+        uint8_t sc[8], mn[8];
+        for (int j = 0; j < 8; j++) orc_scale_min_k4(j, x[i].scales, &sc[j], &mn[j]);
+        for (int k = 0; k < 4; k++) {
+            const int S0 = y[i].bsums[4*k + 0] + y[i].bsums[4*k + 1], S1 = y[i].bsums[4*k + 2] + y[i].bsums[4*k + 3];
+            const int prod = mn[2*k] * S0 + mn[2*k + 1] * S1;
+            acc_m[k] = fmaf(dmin, (float) prod, acc_m[k]);
+        }
+        int32_t sumi[8] = {0};
+        for (int c = 0; c < 4; c++) {
+            const uint8_t * q4 = x[i].qs + 32 * c;
+            const int8_t  * q8 = y[i].qs + 64 * c;
+            for (int L = 0; L < 8; L++) {
+                int pl = 0, ph = 0;
+                for (int e = 0; e < 4; e++) {
+                    pl += (q4[4*L + e] & 0x0F) * q8[4*L + e];
+                    ph += (q4[4*L + e] >> 4)   * q8[32 + 4*L + e];
+                }
+                sumi[L] += sc[2*c] * pl + sc[2*c + 1] * ph;
+            }
+        }
+        for (int L = 0; L < 8; L++) acc[L] = fmaf(d, (float) sumi[L], acc[L]);
+    }
+    const float m02 = acc_m[0] + acc_m[2], m13 = acc_m[1] + acc_m[3];
+    return hsum8(acc) + (m02 + m13);
+}
+
+/* ggml_vec_dot_f16, AVX2 + F16C (ggml-cpu/vec.cpp:264-, simd-mappings.h:528-620): four 8-lane accumulators over steps of 32,
+ * GGML_F32x8_REDUCE, leftovers in double */
+float orc_vec_dot_f16_avx2(int64_t n, const uint16_t * x, const uint16_t * y) {
+    const int64_t np = n & ~(int64_t) 31;
+    float sum[4][8] = {{0}};
+    for (int64_t i = 0; i < np; i += 32)
+        for (int j = 0; j < 4; j++)
+            for (int l = 0; l < 8; l++) sum[j][l] = fmaf(orc_fp16_to_fp32(x[i + 8*j + l]), orc_fp16_to_fp32(y[i + 8*j + l]), sum[j][l]);
+    float t0[4];
+    for (int l = 0; l < 8; l++) { sum[0][l] = sum[0][l] + sum[2][l]; sum[1][l] = sum[1][l] + sum[3][l]; }
+    for (int l = 0; l < 8; l++) sum[0][l] = sum[0][l] + sum[1][l];
+    for (int l = 0; l < 4; l++) t0[l] = sum[0][l] + sum[0][l + 4];
+    double sumf = (double)((t0[0] + t0[1]) + (t0[2] + t0[3]));
+    for (int64_t i = np; i < n; i++) sumf += (double)(orc_fp16_to_fp32(x[i]) * orc_fp16_to_fp32(y[i]));
+    return (float) sumf;
+}
+/* ggml_vec_dot_f32, AVX2 (ggml-cpu/vec.cpp:11-): the same lanes; leftovers `sumf += x[i]*y[i]` in float (contracted by gcc) */
+float orc_vec_dot_f32_avx2(int64_t n, const float * x, const float * y) {
+    const int64_t np = n & ~(int64_t) 31;
+    float sum[4][8] = {{0}};
+    for (int64_t i = 0; i < np; i += 32)
+        for (int j = 0; j < 4; j++)
+            for (int l = 0; l < 8; l++) sum[j][l] = fmaf(x[i + 8*j + l], y[i + 8*j + l], sum[j][l]);
+    float t0[4];
+    for (int l = 0; l < 8; l++) { sum[0][l] = sum[0][l] + sum[2][l]; sum[1][l] = sum[1][l] + sum[3][l]; }
+    for (int l = 0; l < 8; l++) sum[0][l] = sum[0][l] + sum[1][l];
+    for (int l = 0; l < 4; l++) t0[l] = sum[0][l] + sum[0][l + 4];
+    float sumf = (t0[0] + t0[1]) + (t0[2] + t0[3]);
+    for (int64_t i = np; i < n; i++) sumf = ORC_F32_TAIL(x[i], y[i], sumf);
+    return sumf;
+}
+
+/* tinyBLAS<8, __m256, ...> (llamafile/sgemm.cpp:477-640): the n >= 2 path of F16 / F32 src0 when k % 8 == 0 and m % 4 == 0:
+ * ONE 8-lane accumulator per output element over steps of 8, hsum (:247-266 == hsum_float_8) */
+static float tiny8_f16(int64_t n, const uint16_t * x, const uint16_t * y) {
+    float acc[8] = {0};
+    for (int64_t i = 0; i < n; i += 8) for (int l = 0; l < 8; l++) acc[l] = fmaf(orc_fp16_to_fp32(x[i + l]), orc_fp16_to_fp32(y[i + l]), acc[l]);
+    return hsum8(acc);
+}
+static float tiny8_f32(int64_t n, const float * x, const float * y) {
+    float acc[8] = {0};
+    for (int64_t i = 0; i < n; i += 8) for (int l = 0; l < 8; l++) acc[l] = fmaf(x[i + l], y[i + l], acc[l]);
+    return hsum8(acc);
+}
+
+/* ------------------------------------------------------------------------------------------ */
 /* helpers for strided tensors                                                                 */
 /* ------------------------------------------------------------------------------------------ */
 static inline char * tptr(const orc_tensor * t, int64_t i0, int64_t i1, int64_t i2, int64_t i3) {
@@ -355,17 +516,23 @@ static void convert_row(int vtype, const float * x, void * y, int64_t k) {
 
 static float vec_dot(int wtype, int64_t n, const void * w, const void * a) {
     switch (wtype) {
-        case ORC_Q4_0: return orc_vec_dot_q4_0_q8_0(n, (const orc_block_q4_0 *) w, (const orc_block_q8_0 *) a, NULL);
-        case ORC_Q8_0: return orc_vec_dot_q8_0_q8_0(n, (const orc_block_q8_0 *) w, (const orc_block_q8_0 *) a, NULL);
-        case ORC_Q4_1: return orc_vec_dot_q4_1_q8_1(n, (const orc_block_q4_1 *) w, (const orc_block_q8_1 *) a, NULL);
-        case ORC_Q4_K: return orc_vec_dot_q4_K_q8_K(n, (const orc_block_q4_K *) w, (const orc_block_q8_K *) a, NULL);
-        case ORC_F16: {          /* scalar branch of ggml_vec_dot_f16 (vec.cpp:264-): double accumulation */
+        case ORC_Q4_0: return g_order == ORC_ORDER_AVX2 ? orc_vec_dot_q4_0_q8_0_avx2(n, (const orc_block_q4_0 *) w, (const orc_block_q8_0 *) a)
+                                                        : orc_vec_dot_q4_0_q8_0(n, (const orc_block_q4_0 *) w, (const orc_block_q8_0 *) a, NULL);
+        case ORC_Q8_0: return g_order == ORC_ORDER_AVX2 ? orc_vec_dot_q8_0_q8_0_avx2(n, (const orc_block_q8_0 *) w, (const orc_block_q8_0 *) a)
+                                                        : orc_vec_dot_q8_0_q8_0(n, (const orc_block_q8_0 *) w, (const orc_block_q8_0 *) a, NULL);
+        case ORC_Q4_1: return g_order == ORC_ORDER_AVX2 ? orc_vec_dot_q4_1_q8_1_avx2(n, (const orc_block_q4_1 *) w, (const orc_block_q8_1 *) a)
+                                                        : orc_vec_dot_q4_1_q8_1(n, (const orc_block_q4_1 *) w, (const orc_block_q8_1 *) a, NULL);
+        case ORC_Q4_K: return g_order == ORC_ORDER_AVX2 ? orc_vec_dot_q4_K_q8_K_avx2(n, (const orc_block_q4_K *) w, (const orc_block_q8_K *) a)
+                                                        : orc_vec_dot_q4_K_q8_K(n, (const orc_block_q4_K *) w, (const orc_block_q8_K *) a, NULL);
+        case ORC_F16: {
+            if (g_order == ORC_ORDER_AVX2) return orc_vec_dot_f16_avx2(n, (const uint16_t *) w, (const uint16_t *) a);          /* scalar branch of ggml_vec_dot_f16 (vec.cpp:264-): double accumulation */
             const uint16_t * x = (const uint16_t *) w, * y = (const uint16_t *) a;
             double s = 0.0;
             for (int64_t i = 0; i < n; i++) s += (double)(orc_fp16_to_fp32(x[i]) * orc_fp16_to_fp32(y[i]));
             return (float) s;
         }
         case ORC_F32: {          /* scalar branch of ggml_vec_dot_f32 (vec.cpp:10-): double accumulation */
+            if (g_order == ORC_ORDER_AVX2) return orc_vec_dot_f32_avx2(n, (const float *) w, (const float *) a);
             const float * x = (const float *) w, * y = (const float *) a;
             double s = 0.0;
             for (int64_t i = 0; i < n; i++) s += (double)(x[i] * y[i]);
@@ -391,9 +558,14 @@ int orc_mul_mat(const orc_tensor * src0, const orc_tensor * src1, orc_tensor * d
     for (int64_t i12 = 0; i12 < src1->ne[2]; i12++)
     for (int64_t i11 = 0; i11 < src1->ne[1]; i11++) {
         convert_row(vt, (const float *) tptr(src1, 0, i11, i12, i13), arow, K);
+        /* llamafile_sgemm takes F16 / F32 src0 for n >= 2, k % 8 == 0, m % 4 == 0 (sgemm.cpp:3691, 488, 503-517) */
+        const int tiny = g_order == ORC_ORDER_AVX2 && (src0->type == ORC_F16 || src0->type == ORC_F32) && src1->ne[1] >= 2 && K % 8 == 0 && src0->ne[1] % 4 == 0;
         for (int64_t i01 = 0; i01 < src0->ne[1]; i01++) {
             const void * w = tptr(src0, 0, i01, i12 / r2, i13 / r3);
-            *(float *) tptr(dst, i01, i11, i12, i13) = vec_dot(src0->type, K, w, arow);
+            float v;
+            if (tiny) v = src0->type == ORC_F16 ? tiny8_f16(K, (const uint16_t *) w, (const uint16_t *) arow) : tiny8_f32(K, (const float *) w, (const float *) arow);
+            else v = vec_dot(src0->type, K, w, arow);
+            *(float *) tptr(dst, i01, i11, i12, i13) = v;
         }
     }
     free(arow);

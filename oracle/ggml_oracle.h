@@ -83,6 +83,19 @@ float orc_vec_dot_q8_0_q8_0(int64_t n, const orc_block_q8_0 * x, const orc_block
 float orc_vec_dot_q4_1_q8_1(int64_t n, const orc_block_q4_1 * x, const orc_block_q8_1 * y, int32_t * isums);
 float orc_vec_dot_q4_K_q8_K(int64_t n, const orc_block_q4_K * x, const orc_block_q8_K * y, int32_t * isums);
 
+/* ---- the same dot products in the order of the x86 AVX2 branches (arch/x86/quants.c:543-577, 701-760, 1012-1040,
+ * 1742-1822; vec.cpp:11-, 264-): bit-identical to the reference build (libggml-cpu.so, -march=x86-64-v3).
+ * orc_set_order() selects which restatement mul_mat / mul_mat_id / the whole-model forward use (default: AVX2). */
+enum { ORC_ORDER_GENERIC = 0, ORC_ORDER_AVX2 = 1 };
+void  orc_set_order(int order);
+int   orc_get_order(void);
+float orc_vec_dot_q4_0_q8_0_avx2(int64_t n, const orc_block_q4_0 * x, const orc_block_q8_0 * y);
+float orc_vec_dot_q8_0_q8_0_avx2(int64_t n, const orc_block_q8_0 * x, const orc_block_q8_0 * y);
+float orc_vec_dot_q4_1_q8_1_avx2(int64_t n, const orc_block_q4_1 * x, const orc_block_q8_1 * y);
+float orc_vec_dot_q4_K_q8_K_avx2(int64_t n, const orc_block_q4_K * x, const orc_block_q8_K * y);
+float orc_vec_dot_f16_avx2(int64_t n, const uint16_t * x, const uint16_t * y);
+float orc_vec_dot_f32_avx2(int64_t n, const float * x, const float * y);
+
 /* ---- ops (dst written through its strides; all return 0 on success, <0 on bad arguments) ---- */
 /* ggml_compute_forward_mul_mat (ggml-cpu/ggml-cpu.c:1229-1421): quantizes src1 rows to the
  * weight type's vec_dot_type (Q8_0 for Q4_0/Q8_0, Q8_1 for Q4_1, Q8_K for Q4_K, F16 for F16), then vec_dot. */
