@@ -47,7 +47,7 @@ __global__ void __launch_bounds__(256) k_attn_long_scores(const float * __restri
         const int which = t / half, i = t - which * half, ic = MODE == 0 ? 2 * i : i;
         const float * x = which < R2 ? qkv + (g * R2 + which) * HD : qkv + QD + g * HD;
         const float x0 = x[ic], x1 = x[ic + off], c = rope_cs[2 * i], s_ = rope_cs[2 * i + 1];
-        const float y0 = x0*c - x1*s_, y1 = x0*s_ + x1*c;
+        const float y0 = rope_rot_a(x0, x1, c, s_), y1 = rope_rot_b(x0, x1, c, s_);
         float * o = which < R2 ? qs + which * HD : knew;
         o[ic] = h2f(f2h(y0)); o[ic + off] = h2f(f2h(y1));
     }

@@ -7,6 +7,7 @@
 #include <stddef.h>
 
 #include "../../include/chatllm_hip.h"
+#include "glibc_math.h"
 
 #define CLLM_WAVE 64
 
@@ -182,11 +183,18 @@ __device__ __forceinline__ int dot4(uint32_t a, uint32_t b, int c) { return __bu
 // cos/sin of a RoPE angle.  ONE definition shared by k_rope (ops.hip) and k_rope_kv (decode_fused.hip): whether the
 // compiler pairs cosf+sinf into a sincos or not changes the last bit for some angles, and a 1-ulp difference in q/k
 // can flip their fp16 rounding -- the fused and node-by-node paths must agree to the bit.
-static __device__ __noinline__ float libm_expf(float x) { return expf(x); }     // scalar tail of soft_max / SiLU: one shared body
+// The CPU path calls the host's libm here (glibc 2.35): glibc_math.h reproduces its expf / sinf / cosf bit for bit (checked against the
+// libm of this image over 6e8 inputs, oracle/glibc_math_check.c), where the device's own math library is only ~1 ulp close.
+static __device__ __noinline__ float libm_expf(float x) { return gm_expf(x); }     // scalar tail of soft_max / SiLU: one shared body
 static __device__ __noinline__ void rope_cos_sin(float theta, float * c, float * s) {
-    *c = cosf(theta);
-    *s = sinf(theta);
+    *c = gm_cosf(theta);
+    *s = gm_sinf(theta);
 }
+
+// rotate_pairs (ggml-cpu/ops.cpp:5700-5718) as the reference build compiles it: gcc contracts each expression into ONE fma around the
+// rounded x1 product (determined bit for bit against libggml-cpu.so; the oracle states the same)
+__device__ __forceinline__ float rope_rot_a(float x0, float x1, float c, float s) { return __builtin_fmaf(x0, c, -(x1 * s)); }
+__device__ __forceinline__ float rope_rot_b(float x0, float x1, float c, float s) { return __builtin_fmaf(x0, s, x1 * c); }
 
 // one lane of the reference's AVX2 ggml_v_expf (ggml-cpu/vec.h:1230-1267), op for op, so that
 // soft_max / SiLU agree with the CPU path to the last bit wherever the CPU takes its vector body.

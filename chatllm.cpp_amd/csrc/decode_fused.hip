@@ -100,7 +100,7 @@ __global__ void __launch_bounds__(1024) k_attn_decode(const float * __restrict__
                 float c, s_;
                 rope_cos_sin(theta, &c, &s_);
                 c = c * 1.0f; s_ = s_ * 1.0f;
-                const float y0 = px0*c - px1*s_, y1 = px0*s_ + px1*c;
+                const float y0 = rope_rot_a(px0, px1, c, s_), y1 = rope_rot_b(px0, px1, c, s_);
                 float * o = which == 0 ? qs : knew;
                 o[ic] = h2f(f2h(y0)); o[ic + off] = h2f(f2h(y1));         // q: src1 of K.Q is rounded to fp16; k: the cache is fp16
             } else if (tid < 2 * half + hd) vnew[tid - 2 * half] = h2f(f2h(pv));
@@ -119,7 +119,7 @@ __global__ void __launch_bounds__(1024) k_attn_decode(const float * __restrict__
                 const float c = cs[2*i], s_ = cs[2*i + 1];
                 const float * x = which == 0 ? qh : kh;
                 const float x0 = x[ic], x1 = x[ic + off];
-                const float y0 = x0*c - x1*s_, y1 = x0*s_ + x1*c;
+                const float y0 = rope_rot_a(x0, x1, c, s_), y1 = rope_rot_b(x0, x1, c, s_);
                 float * o = which == 0 ? qs : knew;
                 o[ic] = h2f(f2h(y0)); o[ic + off] = h2f(f2h(y1));
             }
@@ -356,7 +356,7 @@ __global__ void __launch_bounds__(1024) k_attn_dec(const float * __restrict__ qk
     TS(0);
     // ---- (3) RoPE, fp16 rounding, cache write ----
     if (is_pair) {
-        const float y0 = px0*pc - px1*ps, y1 = px0*ps + px1*pc;
+        const float y0 = rope_rot_a(px0, px1, pc, ps), y1 = rope_rot_b(px0, px1, pc, ps);
         float * o = which == 0 ? qs : knew;
         o[ic] = h2f(f2h(y0)); o[ic + off] = h2f(f2h(y1));             // q: src1 of K.Q is rounded to fp16; k: the cache is fp16
     } else if (is_v) vnew[tid - 2 * half] = h2f(f2h(px0));

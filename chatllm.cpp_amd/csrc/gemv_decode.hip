@@ -146,25 +146,35 @@ __global__ void __launch_bounds__(1024) k_gemv_dec(const float * __restrict__ px
     __syncthreads();
     TS(3);
 
-    // ---- (4) stream the rows ----
+    // ---- (4) stream the rows.  Every step turns its blocks into chain records (exact integer sums + scales); the fp32 chains of the
+    //          reference's AVX2 order run over them in lanes 0..11 (q4k.h / q32.h) ----
     const q4k_sel L = q4k_lane_sel(lane);
     const int off_d = (int) act_off_d(K), off_s = (int) act_off_s(K, KIND);      // (the Q8_1 flavour has the Q8_0 geometry)
-    float accd = 0.0f, gate = 0.0f;
+    constexpr int CHB = IS_K ? Q4K_CHAIN_BYTES : Q32_CHAIN_BYTES;
+    char * chain = lds + act_row_bytes(K, KIND) + wave_in_wg * CHB;
+    const int l16 = lane & 15;
+    float acc = 0.0f, gate = 0.0f;
     int ck = 0, csub = 0, cs = 0;                                   // consume cursor
     while (ck < nmine) {
 #pragma unroll
         for (int p = 0; p < P; p++) {
             const int b = IS_K ? 8 * cs + grp : 64 * cs + lane;
             const bool ok = ck < nmine && b < nblk;
-            if (IS_K) q4k_step(hh[p], qq[p], lds, off_d, off_s, ok ? b : 0, ok, L, accd);
+            if (IS_K) q4k_emit(hh[p], qq[p], lds, off_d, off_s, ok ? b : 0, ok, L, chain + (cs & 1) * (4 * Q4K_PAIR_BYTES));
             else {
                 uint32_t h; u32x4 w0, w1 = {0, 0, 0, 0};
                 q32_align<IS_K ? CLLM_TYPE_Q4_0 : FMT>(qq[p], q2[IS_Q8 ? p : 0], hh[p].x, hh[p].y, h, w0, w1);
-                q32_step<IS_K ? CLLM_TYPE_Q4_0 : FMT>(h, w0, w1, lds, off_d, off_s, ok ? b : 0, ok, accd);
+                q32_emit<IS_K ? CLLM_TYPE_Q4_0 : FMT>(h, w0, w1, lds, off_d, off_s, ok ? b : 0, ok, lane, chain);
             }
             issue(p);
-            if (++cs == S) {                                        // row complete: reduce over the wave, epilogue, store
-                float v = wave_sum(accd);
+            const bool row_done = cs + 1 == S;
+            if (!IS_K || (cs & 1) || row_done) {                    // Q4_K: every second step (16 super-blocks) and at the row's end
+                wave_lds_fence();
+                if (IS_K) q4k_chain(chain, (cs & 1) ? 8 : 4, l16, acc); else q32_chain<IS_K ? CLLM_TYPE_Q4_0 : FMT>(chain, l16, acc);
+                wave_lds_fence();
+            }
+            if (++cs == S) {                                        // row complete: finish the chains, epilogue, store (lane 0)
+                float v = chain_finish<IS_K ? 1 : IS_Q41 ? 2 : 0>(acc);
                 if (ck < nmine) {                                   // wave-uniform; bias / resid come through the scalar cache
                     const int cunit = unit_of(ck), crow = cunit * RU + csub;
                     if (EPI == 1) {
@@ -176,7 +186,7 @@ __global__ void __launch_bounds__(1024) k_gemv_dec(const float * __restrict__ px
                         if (lane == 0) dst[crow] = v;
                     }
                 }
-                accd = 0.0f; cs = 0;
+                acc = 0.0f; cs = 0;
                 if (++csub == RU) { csub = 0; ck++; }
             }
         }
@@ -193,7 +203,7 @@ int launch_gemv_decode(hipStream_t st, int wtype, const void * W, int64_t K, int
     const int kind = wtype == CLLM_TYPE_Q4_K ? 256 : 32;
     if (!is_quant_type(wtype)) return CLLM_E_UNSUPPORTED;
     if (K % kind || K > ((pro == 2 || pro == 4) ? 32768 : 16384) || pro < 1 || pro > 4 || nrows <= 0 || (uint64_t) nrows * (uint64_t) cllm_row_size(wtype, K) >= (1ull << 32)) return CLLM_E_UNSUPPORTED;
-    if (act_row_bytes(K, kind) > 160 * 1024) return CLLM_E_UNSUPPORTED;
+    if (act_row_bytes(K, kind) + 16 * Q32_CHAIN_BYTES > 160 * 1024) return CLLM_E_UNSUPPORTED;
     if (padd && (pro != 1 || K > 4096 || !xout || xout == px)) return CLLM_E_UNSUPPORTED;
     if (epi == 1 && (pro != 1 || nrows % 2 || (nrows / 2) % 8 || bias || resid)) FAIL(CLLM_E_UNSUPPORTED, "gemv_decode: SiLU epilogue needs gate/up row pairs, features %% 8 == 0");
     const int64_t units = epi == 1 ? nrows / 2 : nrows;
@@ -201,7 +211,7 @@ int launch_gemv_decode(hipStream_t st, int wtype, const void * W, int64_t K, int
     if (grid > device_cu_count()) grid = device_cu_count();
     const int64_t nwaves = grid * 16;
     const int kfull = (int)(units / nwaves), nrem = (int)(units % nwaves), nblk = (int)(K / kind);
-    const size_t lds = act_row_bytes(K, kind);
+    const size_t lds = act_row_bytes(K, kind) + 16 * (size_t)(wtype == CLLM_TYPE_Q4_K ? Q4K_CHAIN_BYTES : Q32_CHAIN_BYTES);     // + the waves' chain records
     const int npre = K <= 4096 ? 1 : K <= 16384 ? 4 : 8;
 #define GO3(FMT_, PRO_, EPI_, NPRE_) do { \
         static bool attr = false; \
@@ -228,7 +238,7 @@ int launch_gemv_decode_id(hipStream_t st, int wtype, const void * W, size_t w_ex
                           const int32_t * ids, int n_slots, float * dst, int64_t dst_slot_stride, int epi) {
     const int kind = wtype == CLLM_TYPE_Q4_K ? 256 : 32;
     if (!is_quant_type(wtype) || K % kind || K > 32768 || nrows <= 0 || n_slots < 1 || n_slots > 64 || (uint64_t) nrows * (uint64_t) cllm_row_size(wtype, K) >= (1ull << 32)) return CLLM_E_UNSUPPORTED;
-    if (act_row_bytes(K, kind) > 160 * 1024 || px_slot_stride > INT32_MAX || dst_slot_stride > INT32_MAX) return CLLM_E_UNSUPPORTED;
+    if (act_row_bytes(K, kind) + 16 * Q32_CHAIN_BYTES > 160 * 1024 || px_slot_stride > INT32_MAX || dst_slot_stride > INT32_MAX) return CLLM_E_UNSUPPORTED;
     if (epi != 0 && (epi != 1 || nrows % 2 || (nrows / 2) % 8)) return CLLM_E_UNSUPPORTED;
     const int64_t units = epi == 1 ? nrows / 2 : nrows;
     int64_t grid = (units + 15) / 16;
@@ -236,7 +246,7 @@ int launch_gemv_decode_id(hipStream_t st, int wtype, const void * W, size_t w_ex
     if (grid > cap) grid = cap;
     const int64_t nwaves = grid * 16;
     const int kfull = (int)(units / nwaves), nrem = (int)(units % nwaves), nblk = (int)(K / kind);
-    const size_t lds = act_row_bytes(K, kind);
+    const size_t lds = act_row_bytes(K, kind) + 16 * (size_t)(wtype == CLLM_TYPE_Q4_K ? Q4K_CHAIN_BYTES : Q32_CHAIN_BYTES);
     const int npre = K <= 4096 ? 1 : K <= 16384 ? 4 : 8;
 #define GOM(FMT_, EPI_, NPRE_) do { \
         static bool attr = false; \

@@ -34,64 +34,103 @@ template <> struct ld8<float> {
     static __device__ __forceinline__ float cvt(float y) { return y; }
 };
 
-// grid.x over groups of src0 rows (i01), grid.y = ne02*ne03
-template <typename T, int G, bool VEC>
-__global__ void __launch_bounds__(256) k_mul_mat_f(tview w, tview x, tview d) {
-    constexpr int NCB = 4;
-    const int tid = threadIdx.x;
-    const int gl = tid % G;                                   // lane inside the group
-    const int64_t i01 = (int64_t) blockIdx.x * (256 / G) + tid / G;
+// ---- accumulation ORDER: the reference's, lane for lane, so that the results are bit-identical to libggml-cpu.so ----------------------
+//   VD (ggml_vec_dot_f16 / _f32, vec.cpp:264- / 11-, AVX2: simd-mappings.h:528-620): 32 fp32 accumulators, accumulator a takes elements
+//      a, a + 32, a + 64, ... in order with one fma each; GGML_F32x8_REDUCE's tree; the K mod 32 leftovers one by one (F16: in double,
+//      F32: a float fma).  Taken for one src1 column, or when tinyBLAS declines.
+//   T8 (tinyBLAS<8, __m256, ...>, llamafile/sgemm.cpp:477-640): with >= 2 src1 columns, K % 8 == 0 and ne01 % 4 == 0 the reference runs
+//      ONE 8-lane accumulator per output element over steps of 8, then hsum.
+// Mapping: VD -- 16 lanes per src0 row, lane c carries accumulators 2c and 2c + 1; T8 -- 8 lanes per row, lane l carries accumulator l.
+// Four src1 columns share every src0 load.  (The many-column prefill contractions run on the matrix cores, mma_f16.hip: tolerance tier.)
+#include "q4k.h"        // lane_xor4_i, DPP_ROW_ROR8
+__device__ __forceinline__ float lane_xor4_f(float v) { return __int_as_float(lane_xor4_i(__float_as_int(v))); }
+
+struct mmf_cols { const char * xc[4]; float * dc[4]; bool ok[4]; };
+__device__ __forceinline__ void mmf_columns(const tview & x, const tview & d, int64_t c0, int64_t ncol, int64_t i02, int64_t i03, int64_t r2, int64_t r3, mmf_cols & C) {
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        int64_t q = c0 + c; C.ok[c] = q < ncol; if (!C.ok[c]) q = c0;
+        const int64_t i11 = q % x.ne[1]; q /= x.ne[1];
+        const int64_t i12 = i02 * r2 + q % r2, i13 = i03 * r3 + q / r2;
+        C.xc[c] = x.data + i11*x.nb[1] + i12*x.nb[2] + i13*x.nb[3];
+        C.dc[c] = (float *)(d.data + i11*d.nb[1] + i12*d.nb[2] + i13*d.nb[3]);
+    }
+}
+
+// grid.x over groups of 16 src0 rows (i01), grid.y = ne02*ne03
+template <typename T>
+__global__ void __launch_bounds__(256) k_mul_mat_f_vd(tview w, tview x, tview d) {
+    const int tid = threadIdx.x, c16 = tid & 15;
+    const int64_t i01 = (int64_t) blockIdx.x * 16 + (tid >> 4);
+    const int64_t i02 = blockIdx.y % w.ne[2], i03 = blockIdx.y / w.ne[2];
+    const bool active = i01 < w.ne[1];
+    const int64_t K = w.ne[0], np = K & ~(int64_t) 31;
+    const int64_t r2 = x.ne[2] / w.ne[2], r3 = x.ne[3] / w.ne[3];
+    const char * wrow = w.data + (active ? i01 : 0) * w.nb[1] + i02 * w.nb[2] + i03 * w.nb[3];
+    const int64_t ncol = x.ne[1] * r2 * r3;                   // src1 columns that use this src0 slice
+    for (int64_t c0 = 0; c0 < ncol; c0 += 4) {
+        mmf_cols C;
+        mmf_columns(x, d, c0, ncol, i02, i03, r2, r3, C);
+        float a0[4] = {0.0f, 0.0f, 0.0f, 0.0f}, a1[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (active) for (int64_t i = 0; i < np; i += 32) {
+            const int64_t e = i + 2 * c16;
+            const float w0 = ld8<T>::one(wrow + e * sizeof(T)), w1 = ld8<T>::one(wrow + (e + 1) * sizeof(T));
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                a0[c] = __builtin_fmaf(w0, ld8<T>::cvt(*(const float *)(C.xc[c] + e * 4)), a0[c]);
+                a1[c] = __builtin_fmaf(w1, ld8<T>::cvt(*(const float *)(C.xc[c] + e * 4 + 4)), a1[c]);
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            // accumulator a = 8j + l sits in lane (a / 2): x0 += x2, x1 += x3 (lanes c ^ 8); x0 += x1 (c ^ 4); lo + hi (c ^ 2); hadd, hadd
+            float v0 = a0[c], v1 = a1[c];
+            v0 = v0 + dpp_f<DPP_ROW_ROR8>(v0); v1 = v1 + dpp_f<DPP_ROW_ROR8>(v1);
+            v0 = v0 + lane_xor4_f(v0);         v1 = v1 + lane_xor4_f(v1);
+            v0 = v0 + dpp_f<DPP_QUAD_XOR2>(v0); v1 = v1 + dpp_f<DPP_QUAD_XOR2>(v1);
+            float u = v0 + v1;
+            u = u + dpp_f<DPP_QUAD_XOR1>(u);
+            if (active && c16 == 0 && C.ok[c]) {
+                if (sizeof(T) == 2) {
+                    double s = (double) u;
+                    for (int64_t e = np; e < K; e++) s += (double)(ld8<T>::one(wrow + e * sizeof(T)) * ld8<T>::cvt(*(const float *)(C.xc[c] + e * 4)));
+                    u = (float) s;
+                } else {
+                    for (int64_t e = np; e < K; e++) u = __builtin_fmaf(ld8<T>::one(wrow + e * sizeof(T)), *(const float *)(C.xc[c] + e * 4), u);
+                }
+                C.dc[c][i01] = u;
+            }
+        }
+    }
+}
+
+// grid.x over groups of 32 src0 rows, grid.y = ne02*ne03; K % 8 == 0
+template <typename T>
+__global__ void __launch_bounds__(256) k_mul_mat_f_t8(tview w, tview x, tview d) {
+    const int tid = threadIdx.x, l = tid & 7;
+    const int64_t i01 = (int64_t) blockIdx.x * 32 + (tid >> 3);
     const int64_t i02 = blockIdx.y % w.ne[2], i03 = blockIdx.y / w.ne[2];
     const bool active = i01 < w.ne[1];
     const int64_t K = w.ne[0];
     const int64_t r2 = x.ne[2] / w.ne[2], r3 = x.ne[3] / w.ne[3];
     const char * wrow = w.data + (active ? i01 : 0) * w.nb[1] + i02 * w.nb[2] + i03 * w.nb[3];
-    const int64_t ncol = x.ne[1] * r2 * r3;                   // src1 columns that use this src0 slice
-
-    for (int64_t c0 = 0; c0 < ncol; c0 += NCB) {
-        const char * xc[NCB]; float * dc[NCB]; bool ok[NCB];
+    const int64_t ncol = x.ne[1] * r2 * r3;
+    for (int64_t c0 = 0; c0 < ncol; c0 += 4) {
+        mmf_cols C;
+        mmf_columns(x, d, c0, ncol, i02, i03, r2, r3, C);
+        float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (active) for (int64_t k = l; k < K; k += 8) {
+            const float wv = ld8<T>::one(wrow + k * sizeof(T));
 #pragma unroll
-        for (int c = 0; c < NCB; c++) {
-            int64_t q = c0 + c; ok[c] = q < ncol; if (!ok[c]) q = c0;
-            const int64_t i11 = q % x.ne[1]; q /= x.ne[1];
-            const int64_t i12 = i02 * r2 + q % r2, i13 = i03 * r3 + q / r2;
-            xc[c] = x.data + i11*x.nb[1] + i12*x.nb[2] + i13*x.nb[3];
-            dc[c] = (float *)(d.data + i11*d.nb[1] + i12*d.nb[2] + i13*d.nb[3]);
-        }
-        float acc[NCB] = {0.0f, 0.0f, 0.0f, 0.0f};
-        if (active) {
-            if (VEC) {
-                const int64_t K8 = K & ~(int64_t) 7;
-                for (int64_t k = K8 + gl; k < K; k += G) {                 // ragged tail (n_kv is arbitrary for V.P)
-                    const float wv = ld8<T>::one(wrow + k * sizeof(T));
-#pragma unroll
-                    for (int c = 0; c < NCB; c++) acc[c] = __builtin_fmaf(wv, ld8<T>::cvt(*(const float *)(xc[c] + k * 4)), acc[c]);
-                }
-                for (int64_t k = (int64_t) gl * 8; k < K8; k += G * 8) {
-                    float wv[8];
-                    ld8<T>::load(wrow + k * sizeof(T), wv);
-#pragma unroll
-                    for (int c = 0; c < NCB; c++) {
-                        float xv[8];
-                        ld8<float>::load(xc[c] + k * 4, xv);
-#pragma unroll
-                        for (int i = 0; i < 8; i++) acc[c] = __builtin_fmaf(wv[i], ld8<T>::cvt(xv[i]), acc[c]);
-                    }
-                }
-            } else {
-                for (int64_t k = gl; k < K; k += G) {
-                    const float wv = ld8<T>::one(wrow + k * sizeof(T));
-#pragma unroll
-                    for (int c = 0; c < NCB; c++) acc[c] = __builtin_fmaf(wv, ld8<T>::cvt(*(const float *)(xc[c] + k * 4)), acc[c]);
-                }
-            }
+            for (int c = 0; c < 4; c++) acc[c] = __builtin_fmaf(wv, ld8<T>::cvt(*(const float *)(C.xc[c] + k * 4)), acc[c]);
         }
 #pragma unroll
-        for (int c = 0; c < NCB; c++) {
-            float v = acc[c];
-#pragma unroll
-            for (int o = G / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-            if (active && gl == 0 && ok[c]) dc[c][i01] = v;
+        for (int c = 0; c < 4; c++) {
+            float v = acc[c];                                  // hsum: x[i] + x[4 + i]; [0] + [2], [1] + [3]; [0] + [1]
+            v = v + lane_xor4_f(v);
+            v = v + dpp_f<DPP_QUAD_XOR2>(v);
+            v = v + dpp_f<DPP_QUAD_XOR1>(v);
+            if (active && l == 0 && C.ok[c]) C.dc[c][i01] = v;
         }
     }
 }
@@ -99,18 +138,11 @@ __global__ void __launch_bounds__(256) k_mul_mat_f(tview w, tview x, tview d) {
 template <typename T>
 static int launch_T(hipStream_t st, const tview & w, const tview & x, const tview & d) {
     const int64_t K = w.ne[0];
-    // vector path needs 16-byte aligned src0 rows; src1 rows only need their natural 4-byte alignment
-    const bool vec = K >= 8 && ((uintptr_t) w.data % 16 == 0) && w.nb[1] % 16 == 0 && w.nb[2] % 16 == 0 && w.nb[3] % 16 == 0 &&
-                     ((uintptr_t) x.data % 4 == 0) && x.nb[1] % 4 == 0 && x.nb[2] % 4 == 0 && x.nb[3] % 4 == 0;
-    int G = 64;
-    if (vec) { while (G > 8 && (int64_t) G * 8 > K) G >>= 1; } else { while (G > 8 && G > K) G >>= 1; }
-    const int64_t rows_per_wg = 256 / G;
-    dim3 grid((unsigned)((w.ne[1] + rows_per_wg - 1) / rows_per_wg), (unsigned)(w.ne[2] * w.ne[3]));
-    if (grid.y > 65535) FAIL(CLLM_E_UNSUPPORTED, "mul_mat_f: too many batches");
-#define GO(GG) do { if (vec) hipLaunchKernelGGL((k_mul_mat_f<T, GG, true>), grid, dim3(256), 0, st, w, x, d); \
-                    else     hipLaunchKernelGGL((k_mul_mat_f<T, GG, false>), grid, dim3(256), 0, st, w, x, d); } while (0)
-    switch (G) { case 64: GO(64); break; case 32: GO(32); break; case 16: GO(16); break; default: GO(8); break; }
-#undef GO
+    if (w.ne[2] * w.ne[3] > 65535) FAIL(CLLM_E_UNSUPPORTED, "mul_mat_f: too many batches");
+    // llamafile_sgemm takes the product when n >= 2, k % 8 == 0, m % 4 == 0 (sgemm.cpp:3691, 488, 503-517); else the vec_dot loop
+    const bool t8 = x.ne[1] >= 2 && K % 8 == 0 && w.ne[1] % 4 == 0;
+    if (t8) hipLaunchKernelGGL((k_mul_mat_f_t8<T>), dim3((unsigned)((w.ne[1] + 31) / 32), (unsigned)(w.ne[2] * w.ne[3])), dim3(256), 0, st, w, x, d);
+    else    hipLaunchKernelGGL((k_mul_mat_f_vd<T>), dim3((unsigned)((w.ne[1] + 15) / 16), (unsigned)(w.ne[2] * w.ne[3])), dim3(256), 0, st, w, x, d);
     LAUNCH_CHECK();
     return CLLM_OK;
 }

@@ -115,6 +115,8 @@ __global__ void __launch_bounds__(1024) k_mmvq_q4_K(const mmvq_args a) {
 
     const q4k_sel L = q4k_lane_sel(lane);
     const int off_d = (int) act_off_d(K), off_s = (int) act_off_s(K, 256);
+    char * chain = lds + NC * rb + (size_t) wave_in_wg * NC * Q4K_CHAIN_BYTES;      // this wave's chain records, one buffer per column
+    const int l16 = lane & 15;
 
     float accd[NC];
 #pragma unroll
@@ -129,15 +131,22 @@ __global__ void __launch_bounds__(1024) k_mmvq_q4_K(const mmvq_args a) {
             const bool ok = ck < nmine && b < nblk;
             const int bb = ok ? b : 0;     // in-range LDS addresses for masked steps
 #pragma unroll
-            for (int c = 0; c < NC; c++) q4k_step(hh[p], qq[p], lds + c * rb, off_d, off_s, bb, ok, L, accd[c]);
+            for (int c = 0; c < NC; c++) q4k_emit(hh[p], qq[p], lds + c * rb, off_d, off_s, bb, ok, L, chain + c * Q4K_CHAIN_BYTES + (cs & 1) * (4 * Q4K_PAIR_BYTES));
             if (PP == P) issue(hh[p], qq[p]);
             else if (cold > 0) cold--;      // (scalar)
             else issue(hh[(p + P) % PP], qq[(p + P) % PP]);
-            if (++cs == S) {                // row complete: reduce over the wave, epilogue, store
+            const bool row_done = cs + 1 == S;
+            if ((cs & 1) || row_done) {     // the fp32 chains in the reference's AVX2 order (q4k.h): every 16 super-blocks and at the row's end
+                wave_lds_fence();
+#pragma unroll
+                for (int c = 0; c < NC; c++) q4k_chain(chain + c * Q4K_CHAIN_BYTES, (cs & 1) ? 8 : 4, l16, accd[c]);
+                wave_lds_fence();
+            }
+            if (++cs == S) {                // row complete: finish the chains, epilogue, store (lane 0)
                 const int64_t cunit = unit_of(ck), crow = cunit * RU + csub;
 #pragma unroll
                 for (int c = 0; c < NC; c++) {
-                    float v = wave_sum(accd[c]);
+                    float v = chain_finish<1>(accd[c]);
                     if (ck < nmine) {   // wave-uniform; bias / resid come through the scalar cache (their own counter)
                         if (EPI == 1) {
                             if (csub == 0) gate = v;
@@ -173,40 +182,35 @@ __global__ void __launch_bounds__(1024) k_mmvq_q32(const mmvq_args a) {
     constexpr int BS = q32_fmt<FMT>::BS;
     const int lane = threadIdx.x & 63;
     const int waves_per_wg = blockDim.x >> 6;
-    const int64_t wave0 = (int64_t) blockIdx.x * waves_per_wg + (threadIdx.x >> 6);
+    const int64_t wave0 = (int64_t) blockIdx.x * waves_per_wg + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int64_t nwaves = (int64_t) gridDim.x * waves_per_wg;
 
-    auto row_dot = [&](int64_t row, float (&out)[NC]) {
+    char * chain = lds + NC * rb + (size_t)(threadIdx.x >> 6) * NC * Q32_CHAIN_BYTES;      // this wave's chain records, one buffer per column
+    const int l16 = lane & 15;
+    const int off_d = (int) act_off_d(K), off_s = (int) act_off_s(K, 32);
+    for (int64_t row = wave0; row < nrows; row += nwaves) {
         const char * wr = W + row * nb01;
         float acc[NC];
 #pragma unroll
         for (int c = 0; c < NC; c++) acc[c] = 0.0f;
-        const int off_d = (int) act_off_d(K), off_s = (int) act_off_s(K, 32);
         for (int b0 = 0; b0 < nblk; b0 += 64) {
             const int b = b0 + lane;
-            if (b < nblk) {
-                const char * bp = wr + (int64_t) b * BS;
-                uint32_t d16; u32x4 q0, q1 = {0, 0, 0, 0};
-                q32_load<FMT>(bp, d16, q0, q1);
+            const bool ok = b < nblk;
+            uint32_t d16 = 0; u32x4 q0 = {0, 0, 0, 0}, q1 = {0, 0, 0, 0};
+            if (ok) q32_load<FMT>(wr + (int64_t) b * BS, d16, q0, q1);
 #pragma unroll
-                for (int c = 0; c < NC; c++) q32_step<FMT>(d16, q0, q1, lds + c * rb, off_d, off_s, b, true, acc[c]);
-            }
+            for (int c = 0; c < NC; c++) q32_emit<FMT>(d16, q0, q1, lds + c * rb, off_d, off_s, ok ? b : 0, ok, lane, chain + c * Q32_CHAIN_BYTES);
+            wave_lds_fence();               // the fp32 chains in the reference's AVX2 order (q32.h), one step (64 blocks) at a time
+#pragma unroll
+            for (int c = 0; c < NC; c++) q32_chain<FMT>(chain + c * Q32_CHAIN_BYTES, l16, acc[c]);
+            wave_lds_fence();
         }
 #pragma unroll
-        for (int c = 0; c < NC; c++) out[c] = wave_sum(acc[c]);
-    };
-
-    for (int64_t row = wave0; row < nrows; row += nwaves) {
-        float r[NC];
-        row_dot(row, r);
-        if (lane == 0) {
-#pragma unroll
-            for (int c = 0; c < NC; c++) {
-                float v = r[c];
-                if (a.bias)  v = v + a.bias[row];
-                if (a.resid) v = v + a.resid[row + c * dst_cs];
-                dst[row + c * dst_cs] = v;
-            }
+        for (int c = 0; c < NC; c++) {
+            float v = chain_finish<q32_fmt<FMT>::IS_Q41 ? 2 : 0>(acc[c]);
+            if (a.bias)  v = v + a.bias[row];
+            if (a.resid) v = v + a.resid[row + c * dst_cs];
+            if (lane == 0) dst[row + c * dst_cs] = v;
         }
     }
 }
@@ -282,10 +286,12 @@ static void mmvq_tunables() {
 }
 
 template <typename KernelT>
-static int launch_one(hipStream_t st, KernelT kern, size_t lds_bytes, const mmvq_args & a_in, int grid_y) {
+static int launch_one(hipStream_t st, KernelT kern, size_t lds_bytes, size_t chain_per_wave, const mmvq_args & a_in, int grid_y) {
     mmvq_args a = a_in;
     mmvq_tunables();
     const int wg = g_mmvq_wg, wpw = wg / 64;
+    lds_bytes += (size_t) wpw * chain_per_wave;              // activation rows | the waves' chain records (q4k.h / q32.h)
+    if (lds_bytes > 160 * 1024) FAIL(CLLM_E_UNSUPPORTED, "mmvq: %zu bytes of LDS", lds_bytes);
     int64_t grid = (a.nrows + wpw - 1) / wpw;
     int64_t cap = (int64_t) device_cu_count() * g_mmvq_wgs_per_cu / grid_y;
     if (cap < 1) cap = 1;
@@ -297,7 +303,8 @@ static int launch_one(hipStream_t st, KernelT kern, size_t lds_bytes, const mmvq
 }
 
 static int mmvq_dispatch(hipStream_t st, int wtype, int nc, size_t lds, const mmvq_args & a, int grid_y) {
-#define GO(...) return launch_one(st, __VA_ARGS__, lds, a, grid_y)
+    const size_t chain = (size_t) nc * (wtype == CLLM_TYPE_Q4_K ? Q4K_CHAIN_BYTES : Q32_CHAIN_BYTES);
+#define GO(...) return launch_one(st, __VA_ARGS__, lds, chain, a, grid_y)
     if (wtype == CLLM_TYPE_Q4_K)      { if (nc == 4) GO(k_mmvq_q4_K<4, 1>); else if (nc == 2) GO(k_mmvq_q4_K<2, 1>); else GO(k_mmvq_q4_K<1, 1>); }
     else if (wtype == CLLM_TYPE_Q8_0) { if (nc == 4) GO(k_mmvq_q32<4, CLLM_TYPE_Q8_0>); else if (nc == 2) GO(k_mmvq_q32<2, CLLM_TYPE_Q8_0>); else GO(k_mmvq_q32<1, CLLM_TYPE_Q8_0>); }
     else if (wtype == CLLM_TYPE_Q4_0) { if (nc == 4) GO(k_mmvq_q32<4, CLLM_TYPE_Q4_0>); else if (nc == 2) GO(k_mmvq_q32<2, CLLM_TYPE_Q4_0>); else GO(k_mmvq_q32<1, CLLM_TYPE_Q4_0>); }
@@ -319,8 +326,10 @@ int launch_mmvq(hipStream_t st, int wtype, const tview & w, const void * act, si
     int64_t c = 0;
     while (c < ncols) {
         int nc = ncols - c >= 4 ? 4 : (ncols - c >= 2 ? 2 : 1);
-        while (nc > 1 && (size_t) nc * rb > 160 * 1024) nc >>= 1;
-        if ((size_t) nc * rb > 160 * 1024) FAIL(CLLM_E_UNSUPPORTED, "mmvq: K=%lld does not fit LDS", (long long) K);
+        mmvq_tunables();
+        const size_t chw = (size_t)(g_mmvq_wg / 64) * (wtype == CLLM_TYPE_Q4_K ? Q4K_CHAIN_BYTES : Q32_CHAIN_BYTES);
+        while (nc > 1 && (size_t) nc * (rb + chw) > 160 * 1024) nc >>= 1;
+        if ((size_t) nc * (rb + chw) > 160 * 1024) FAIL(CLLM_E_UNSUPPORTED, "mmvq: K=%lld does not fit LDS", (long long) K);
         a.act = (const char *) act + c * act_stride;
         a.dst = (float *)(dst.data + c * dst.nb[1]);
         const int rc = mmvq_dispatch(st, wtype, nc, (size_t) nc * rb, a, 1);

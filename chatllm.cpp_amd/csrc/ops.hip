@@ -90,8 +90,8 @@ __global__ void __launch_bounds__(256) k_rope(tview s, tview d, const int32_t * 
         const int64_t ic = p.mode == 0 ? 2*i : i;
         const float c = cache[2*i], sn = cache[2*i + 1];
         const float x0 = x[ic], x1 = x[ic + off];
-        y[ic]       = x0*c - x1*sn;
-        y[ic + off] = x0*sn + x1*c;
+        y[ic]       = rope_rot_a(x0, x1, c, sn);
+        y[ic + off] = rope_rot_b(x0, x1, c, sn);
     }
     // pass-through channels
     if (p.n_dims < ne0 && s.data != d.data) {

@@ -63,32 +63,63 @@ __device__ __forceinline__ void q32_load(const char * bp, uint32_t & h, u32x4 & 
     q32_align<FMT>(a, b, t, odd, h, q0, q1);
 }
 
+// ---- the fp32 accumulation in the ORDER of the reference's x86 AVX2 branches (arch/x86/quants.c:543-577 Q4_0, 701-760 Q4_1,
+// 1012-1040 Q8_0; tinyBLAS_Q0_AVX, llamafile/sgemm.cpp:1346-1790, keeps the same per-element chain): per 32-weight block i (row order)
+// and AVX lane A (elements 4A..4A+3):  acc[A] = fma(d_w d_a, (float) isum[A], acc[A]);  result = hsum_float_8(acc) [+ summs, Q4_1:
+// summs = fma(m_w, s_a, summs) over the blocks].  One lane owns one block and produces its eight integer sums; the serial chains run in
+// lanes 0..7 (lane 8: summs) over per-wave LDS records, one step (64 blocks) at a time -- see q4k.h for the scheme.
+//   records of a wave: 9 rows of 64 floats (row = slot of AVX lane A, row 8 = Q4_1's s_a; 272-byte pitch: conflict-free ds_read_b128),
+//   then d[64] and (Q4_1) m_w[64]
+#include "q4k.h"
+#define Q32_ROW_BYTES   272
+#define Q32_CHAIN_BYTES (9 * Q32_ROW_BYTES + 512)
+
 // h / q0 / q1 as loaded above, ar = quantized activation row (Q8_0 / Q8_1 kind, common.h) in LDS, bb = block index (in range),
-// ok = the block is real (not a masked dummy)
+// ok = the block is real (masked blocks write zero records), rec = the wave's record buffer
 template <int FMT>
-__device__ __forceinline__ void q32_step(uint32_t h, const u32x4 q0, const u32x4 q1, const char * ar, int off_d, int off_s, int bb, bool ok, float & acc) {
+__device__ __forceinline__ void q32_emit(uint32_t h, const u32x4 q0, const u32x4 q1, const char * ar, int off_d, int off_s, int bb, bool ok, int lane, char * rec) {
     const float d = h2f((uint16_t) h);
-    const u32x4 a0 = *(const u32x4 *)(ar + bb * 32);          // elements 0..15  (nibble formats: <-> low nibbles)
-    const u32x4 a1 = *(const u32x4 *)(ar + bb * 32 + 16);     // elements 16..31 (nibble formats: <-> high nibbles)
+    const u32x4 a0 = *(const u32x4 *)(ar + bb * 32);          // elements 0..15  (nibble formats: <-> low nibbles)  = AVX lanes 0..3
+    const u32x4 a1 = *(const u32x4 *)(ar + bb * 32 + 16);     // elements 16..31 (nibble formats: <-> high nibbles) = AVX lanes 4..7
     const float yd = ((const float *)(ar + off_d))[bb];
-    int s;
-    float na;
+    int s[8];
     if constexpr (q32_fmt<FMT>::IS_Q8) {
-        s = dot4(q0.x, a0.x, 0); s = dot4(q0.y, a0.y, s); s = dot4(q0.z, a0.z, s); s = dot4(q0.w, a0.w, s);
-        s = dot4(q1.x, a1.x, s); s = dot4(q1.y, a1.y, s); s = dot4(q1.z, a1.z, s); s = dot4(q1.w, a1.w, s);
-        na = __builtin_fmaf((float) s, d * yd, acc);
+        s[0] = dot4(q0.x, a0.x, 0); s[1] = dot4(q0.y, a0.y, 0); s[2] = dot4(q0.z, a0.z, 0); s[3] = dot4(q0.w, a0.w, 0);
+        s[4] = dot4(q1.x, a1.x, 0); s[5] = dot4(q1.y, a1.y, 0); s[6] = dot4(q1.z, a1.z, 0); s[7] = dot4(q1.w, a1.w, 0);
     } else {
-        const uint32_t ql[4] = { q0.x & 0x0f0f0f0fu, q0.y & 0x0f0f0f0fu, q0.z & 0x0f0f0f0fu, q0.w & 0x0f0f0f0fu };
-        const uint32_t qh[4] = { (q0.x >> 4) & 0x0f0f0f0fu, (q0.y >> 4) & 0x0f0f0f0fu, (q0.z >> 4) & 0x0f0f0f0fu, (q0.w >> 4) & 0x0f0f0f0fu };
-        s = dot4(ql[0], a0.x, 0); s = dot4(ql[1], a0.y, s); s = dot4(ql[2], a0.z, s); s = dot4(ql[3], a0.w, s);
-        s = dot4(qh[0], a1.x, s); s = dot4(qh[1], a1.y, s); s = dot4(qh[2], a1.z, s); s = dot4(qh[3], a1.w, s);
-        if constexpr (q32_fmt<FMT>::IS_Q41) {                  // (d_w d_a) * sum nib*a  +  m_w * s_a
-            const float ys = ((const float *)(ar + off_s))[bb];
-            na = __builtin_fmaf(h2f((uint16_t)(h >> 16)), ys, __builtin_fmaf((float) s, d * yd, acc));
-        } else {
-            s -= 8 * ((const int *)(ar + off_s))[bb];          // sum (nib - 8) * a
-            na = __builtin_fmaf((float) s, d * yd, acc);
+        constexpr bool SUB8 = !q32_fmt<FMT>::IS_Q41;          // Q4_0: (nib - 8) . a = nib . a + (-8, -8, -8, -8) . a
+        auto c0 = [&](uint32_t a) { return SUB8 ? dot4(0xf8f8f8f8u, a, 0) : 0; };
+        s[0] = dot4(q0.x & 0x0f0f0f0fu, a0.x, c0(a0.x)); s[1] = dot4(q0.y & 0x0f0f0f0fu, a0.y, c0(a0.y));
+        s[2] = dot4(q0.z & 0x0f0f0f0fu, a0.z, c0(a0.z)); s[3] = dot4(q0.w & 0x0f0f0f0fu, a0.w, c0(a0.w));
+        s[4] = dot4((q0.x >> 4) & 0x0f0f0f0fu, a1.x, c0(a1.x)); s[5] = dot4((q0.y >> 4) & 0x0f0f0f0fu, a1.y, c0(a1.y));
+        s[6] = dot4((q0.z >> 4) & 0x0f0f0f0fu, a1.z, c0(a1.z)); s[7] = dot4((q0.w >> 4) & 0x0f0f0f0fu, a1.w, c0(a1.w));
+    }
+    float * X = (float *) rec + lane;
+    // slot of AVX lane A = 4(A&1) + (A&2) + (A>>2): [A0 A4 A2 A6 | A1 A5 A3 A7] (chain_finish, q4k.h)
+    constexpr int R = Q32_ROW_BYTES / 4;
+    X[0 * R] = ok ? (float) s[0] : 0.0f; X[1 * R] = ok ? (float) s[4] : 0.0f; X[2 * R] = ok ? (float) s[2] : 0.0f; X[3 * R] = ok ? (float) s[6] : 0.0f;
+    X[4 * R] = ok ? (float) s[1] : 0.0f; X[5 * R] = ok ? (float) s[5] : 0.0f; X[6 * R] = ok ? (float) s[3] : 0.0f; X[7 * R] = ok ? (float) s[7] : 0.0f;
+    X[9 * R] = ok ? d * yd : 0.0f;
+    if constexpr (q32_fmt<FMT>::IS_Q41) {
+        const float ys = ((const float *)(ar + off_s))[bb];
+        X[8 * R] = ok ? ys : 0.0f;
+        X[9 * R + 64] = ok ? h2f((uint16_t)(h >> 16)) : 0.0f;
+    }
+}
+
+// walk the 64 blocks of one step in order; l16 = lane & 15 (lanes 0..7: acc[], lane 8: Q4_1's summs, others idle)
+template <int FMT>
+__device__ __forceinline__ void q32_chain(const char * chain, int l16, float & acc) {
+    const char * xr = chain + (l16 < 8 ? l16 : 8) * Q32_ROW_BYTES;
+    const char * dr = chain + 9 * Q32_ROW_BYTES + ((q32_fmt<FMT>::IS_Q41 && l16 == 8) ? 256 : 0);
+    for (int i0 = 0; i0 < 64; i0 += 16) {
+        f32x4 xv[4], dv[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) { xv[u] = *(const f32x4 *)(xr + (i0 + 4 * u) * 4); dv[u] = *(const f32x4 *)(dr + (i0 + 4 * u) * 4); }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            acc = __builtin_fmaf(dv[u].x, xv[u].x, acc); acc = __builtin_fmaf(dv[u].y, xv[u].y, acc);
+            acc = __builtin_fmaf(dv[u].z, xv[u].z, acc); acc = __builtin_fmaf(dv[u].w, xv[u].w, acc);
         }
     }
-    acc = ok ? na : acc;
 }

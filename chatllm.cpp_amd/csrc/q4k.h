@@ -1,34 +1,68 @@
-// q4k.h -- one step of the Q4_K x Q8_K mat-vec for one lane (shared by the plain kernel in mmvq.hip and the decode
-// kernel in gemv_decode.hip, so that both accumulate every row in exactly the same order).
-//   ggml_vec_dot_q4_K_q8_K (ggml-cpu/quants.c:550-623): integer block dot products (exact), fp32 scale + accumulate.
-// Work split: a group of 8 lanes owns one 144-byte super-block per step; all 8 lanes fetch the 16-byte header
-// {d, dmin, 12 packed 6-bit scales/mins} (one broadcast request), lane j fetches qs[16j..16j+15] (two 64-weight halves:
-// low nibbles belong to sub-block 2*(j/2), high nibbles to 2*(j/2)+1) and owns min #j.
+// q4k.h -- the Q4_K x Q8_K mat-vec of one wave, in the accumulation ORDER of the reference's x86 AVX2 branch
+// (ggml_vec_dot_q4_K_q8_K, ggml-cpu/arch/x86/quants.c:1742-1822), so that the result is bit-identical to libggml-cpu.so:
+//   per super-block i (in row order) and AVX lane A = 0..7 (dword A of every 32-byte chunk of qs / q8):
+//       sumi[A] = sum over the four 64-weight chunks c of  sc[2c] * (q4l . q8l)[A] + sc[2c+1] * (q4h . q8h)[A]      (exact int32)
+//       acc[A]  = fma(y.d * x.d, (float) sumi[A], acc[A])                                                            (serial over i)
+//       acc_m[k] = fma(-y.d * x.dmin, (float)(m[2k] S[2k] + m[2k+1] S[2k+1]), acc_m[k]),  S = sums of q8 over the 32-weight sub-blocks
+//   result = hsum_float_8(acc) + ((acc_m[0] + acc_m[2]) + (acc_m[1] + acc_m[3]))
+// Shared by the multi-column kernel (mmvq.hip) and the decode kernel (gemv_decode.hip): one definition, one order.
+//
+// Work split (unchanged: it is what makes the loads coalesce): a group of 8 lanes owns one 144-byte super-block per step; all 8 lanes
+// fetch the 16-byte header {d, dmin, 12 packed 6-bit scales/mins} (one broadcast request), lane j fetches qs[16j..16j+15] = chunk
+// c = j/2, bytes 16(j&1).. of it = the dwords of AVX lanes 4(j&1) + k, k = 0..3.  The integer partial sums are reduce-scattered over
+// the 8 lanes (any order: exact), so that lane j ends up with sumi[A(j)], A(j) = 4(j&1) + (j&2) + (j>>2).  The serial fp32 chain cannot
+// be spread over the wave: every lane group writes its {float(sumi), d} and {float(prod), dmin} records to a per-wave LDS buffer and,
+// every two steps (16 super-blocks), lanes 0..11 walk the records in block order -- lanes 0..7 carry acc[], lanes 8..11 acc_m[].
 #pragma once
 #include "common.h"
 
-struct q4k_sel { int sh16, sh8, a_off; bool hi; int j; };
+#define DPP_ROW_SHL4 0x104
+#define DPP_ROW_SHR4 0x114
+#define DPP_ROW_ROR8 0x128
 
-// lane-constant scale selectors (get_scale_min_k4, ggml-quants.c:703-711, after the utmp shuffle of quants.c:577-582)
+// value of lane (l ^ 4) of the same 8 lanes (no single DPP pattern does it: two masked row shifts)
+__device__ __forceinline__ int lane_xor4_i(int v) {
+    const int r = __builtin_amdgcn_update_dpp(0, v, DPP_ROW_SHL4, 0xf, 0x5, false);      // lanes 0-3, 8-11 of a row <- lane + 4
+    return __builtin_amdgcn_update_dpp(r, v, DPP_ROW_SHR4, 0xf, 0xA, false);             // lanes 4-7, 12-15        <- lane - 4
+}
+// compiler-level ordering of the wave's own LDS records (the LDS executes one wave's DS operations in order)
+__device__ __forceinline__ void wave_lds_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// ---- chain records: per wave, 8 pairs of super-blocks x 12 slots x {x_i, d_i, x_i+1, d_i+1} floats (+ 64 B so that the idle lanes
+//      12..15 of a row read inside the buffer) ----
+#define Q4K_PAIR_BYTES  192
+#define Q4K_CHAIN_BYTES (8 * Q4K_PAIR_BYTES + 64)
+
+struct q4k_sel {
+    int sh16, sh8, a_off, s_idx;   // scale pair / min selectors, activation byte offset, index of this lane's sub-block sum
+    int w_off, wm_off;             // record offsets of this lane inside the wave's chain buffer (step parity adds 4 pairs)
+    bool hi, mhi, b2, b4, wm;
+};
+
+// lane-constant selectors (get_scale_min_k4, ggml-quants.c:703-711, after the utmp shuffle of arch/x86/quants.c:1773-1778)
 __device__ __forceinline__ q4k_sel q4k_lane_sel(int lane) {
     q4k_sel L;
-    const int j = lane & 7;
-    L.j = j;
-    L.sh16 = (j & 2) * 8;          // pair p=j/2: 16-bit field (p&1) of utmp[p>>1]
-    L.sh8  = (j & 3) * 8;          // min j: byte (j&3) of utmp[2 + (j>>2)]
+    const int j = lane & 7, g = lane >> 3, p = j >> 1;
+    L.sh16 = (j & 2) * 8;                       // chunk c = j/2: scales (2c, 2c+1) = 16-bit field (c&1) of u0 / u1
     L.hi   = j >= 4;
-    L.a_off = 64 * (j >> 1) + 16 * (j & 1);     // activation bytes for the low-nibble half; +32 for the high half
+    L.a_off = 64 * (j >> 1) + 16 * (j & 1);     // activation bytes of the low-nibble half; +32: the high-nibble half
+    // mins: lanes (2p, 2p+1) own mins (2k, 2k+1) with k = [0, 2, 1, 3][p], so that acc_m's final adds are neighbour exchanges
+    const int k = (p & 1) * 2 + (p >> 1), mi = 2 * k + (j & 1);
+    L.s_idx = mi; L.mhi = mi >= 4; L.sh8 = (mi & 3) * 8;
+    L.b2 = (j & 2) != 0; L.b4 = (j & 4) != 0; L.wm = (j & 1) == 0;
+    L.w_off  = (g >> 1) * Q4K_PAIR_BYTES + j * 16 + (g & 1) * 8;
+    L.wm_off = (g >> 1) * Q4K_PAIR_BYTES + (8 + p) * 16 + (g & 1) * 8;
     return L;
 }
 
-// h = block header, q = this lane's 16 quant bytes, ar = quantized activation row (act layout, common.h) in LDS,
-// off_d / off_s = its scale / sub-block-sum planes, bb = super-block index (in range), ok = step is real (not a masked dummy)
-// ONE accumulator per lane: acc += (d yd) * sum_sub sc*dot  -  (dmin yd) * m*bsum.  (Two accumulators -- the scale part and the mins part
-// summed separately and subtracted at the end of the row, the structure of the reference's AVX2 loop -- cost a second wave reduction per
-// row: with 4096-long rows, two steps each, that was a measurable share of the mat-vec.  The order of fp32 additions is a tolerance-level
-// choice; every path shares this function, so they all stay bit-identical to each other.)
-__device__ __forceinline__ void q4k_step(const u32x4 h, const u32x4 q, const char * ar, int off_d, int off_s, int bb, bool ok, const q4k_sel & L,
-                                         float & acc) {
+// one super-block of one activation column: h = block header, q = this lane's 16 quant bytes, ar = quantized activation row (act layout,
+// common.h) in LDS, off_d / off_s = its scale / sub-block-sum planes, bb = super-block index (in range), ok = the block is real (masked
+// blocks write zero records: fma(0, 0, acc) == acc), rec = the wave's chain buffer + 4 pairs for odd steps
+__device__ __forceinline__ void q4k_emit(const u32x4 h, const u32x4 q, const char * ar, int off_d, int off_s, int bb, bool ok, const q4k_sel & L, char * rec) {
     const float d    = h2f((uint16_t)(h.x & 0xffff));
     const float dmin = h2f((uint16_t)(h.x >> 16));
     // 6-bit unpack: u0 = sc[0..3], u1 = sc[4..7], u2 = m[0..3], u3 = m[4..7]
@@ -38,17 +72,53 @@ __device__ __forceinline__ void q4k_step(const u32x4 h, const u32x4 q, const cha
     const uint32_t u3 = ((h.w >> 4) & 0x0f0f0f0fu) | (((h.z >> 6) & 0x03030303u) << 4);
     const uint32_t scp = (L.hi ? u1 : u0) >> L.sh16;
     const int sc_lo = (int)(scp & 0xff), sc_hi = (int)((scp >> 8) & 0xff);
-    const int mj    = (int)(((L.hi ? u3 : u2) >> L.sh8) & 0xff);
-    const uint32_t ql[4] = { q.x & 0x0f0f0f0fu, q.y & 0x0f0f0f0fu, q.z & 0x0f0f0f0fu, q.w & 0x0f0f0f0fu };
-    const uint32_t qh[4] = { (q.x >> 4) & 0x0f0f0f0fu, (q.y >> 4) & 0x0f0f0f0fu, (q.z >> 4) & 0x0f0f0f0fu, (q.w >> 4) & 0x0f0f0f0fu };
+    const int mj    = (int)(((L.mhi ? u3 : u2) >> L.sh8) & 0xff);
     const u32x4 al = *(const u32x4 *)(ar + bb * 256 + L.a_off);
     const u32x4 ah = *(const u32x4 *)(ar + bb * 256 + L.a_off + 32);
     const float yd = ((const float *)(ar + off_d))[bb];
-    const int   ys = ((const int *)(ar + off_s))[bb * 8 + L.j];
-    int il = dot4(ql[0], al.x, 0); il = dot4(ql[1], al.y, il); il = dot4(ql[2], al.z, il); il = dot4(ql[3], al.w, il);
-    int ih = dot4(qh[0], ah.x, 0); ih = dot4(qh[1], ah.y, ih); ih = dot4(qh[2], ah.z, ih); ih = dot4(qh[3], ah.w, ih);
-    const int t = sc_lo * il + sc_hi * ih;
-    const float nd = __builtin_fmaf(d * yd, (float) t, acc);
-    const float na = __builtin_fmaf(-(dmin * yd), (float)(mj * ys), nd);
-    acc = ok ? na : acc;
+    const int   ys = ((const int *)(ar + off_s))[bb * 8 + L.s_idx];
+    // the four dwords of this lane = AVX lanes 4(j&1) + k of chunk j/2
+    const int t0 = sc_lo * dot4(q.x & 0x0f0f0f0fu, al.x, 0) + sc_hi * dot4((q.x >> 4) & 0x0f0f0f0fu, ah.x, 0);
+    const int t1 = sc_lo * dot4(q.y & 0x0f0f0f0fu, al.y, 0) + sc_hi * dot4((q.y >> 4) & 0x0f0f0f0fu, ah.y, 0);
+    const int t2 = sc_lo * dot4(q.z & 0x0f0f0f0fu, al.z, 0) + sc_hi * dot4((q.z >> 4) & 0x0f0f0f0fu, ah.z, 0);
+    const int t3 = sc_lo * dot4(q.w & 0x0f0f0f0fu, al.w, 0) + sc_hi * dot4((q.w >> 4) & 0x0f0f0f0fu, ah.w, 0);
+    // reduce-scatter over the four chunks (lanes j, j^2, j^4, j^6): lane j keeps dword k = (j&2) + (j>>2)
+    int k0 = L.b2 ? t2 : t0, k1 = L.b2 ? t3 : t1;
+    const int s0 = L.b2 ? t0 : t2, s1 = L.b2 ? t1 : t3;
+    k0 += dpp_i<DPP_QUAD_XOR2>(s0); k1 += dpp_i<DPP_QUAD_XOR2>(s1);
+    const int keep = L.b4 ? k1 : k0, send = L.b4 ? k0 : k1;
+    const int sumi = keep + lane_xor4_i(send);
+    // mins: prod[k] = m[2k] S[2k] + m[2k+1] S[2k+1] on the lane pair
+    int pm = mj * ys;
+    pm += dpp_i<DPP_QUAD_XOR1>(pm);
+    float x = (float) sumi, dd = yd * d, xm = (float) pm, dm = (-yd) * dmin;
+    if (!ok) { x = 0.0f; dd = 0.0f; xm = 0.0f; dm = 0.0f; }
+    *(float2 *)(rec + L.w_off) = float2{x, dd};
+    if (L.wm) *(float2 *)(rec + L.wm_off) = float2{xm, dm};
+}
+
+// walk `npairs` (a multiple of 4) pairs of records in block order; l16 = lane & 15 (lanes 0..7: acc[], 8..11: acc_m[], 12..15: idle)
+__device__ __forceinline__ void q4k_chain(const char * chain, int npairs, int l16, float & acc) {
+    for (int q0 = 0; q0 < npairs; q0 += 4) {
+        f32x4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) v[u] = *(const f32x4 *)(chain + (q0 + u) * Q4K_PAIR_BYTES + l16 * 16);
+#pragma unroll
+        for (int u = 0; u < 4; u++) { acc = __builtin_fmaf(v[u].y, v[u].x, acc); acc = __builtin_fmaf(v[u].w, v[u].z, acc); }
+    }
+}
+
+// row result from the chain accumulators (valid in lane 0 of every 16 lanes): hsum_float_8 over lanes 0..7 -- the records sit in the
+// slot order [A0 A4 A2 A6 | A1 A5 A3 A7], so the reference's three adds (x[i] + x[4+i]; [0]+[2], [1]+[3]; [0]+[1]) are neighbour
+// exchanges -- plus, from lanes 8..11 (slots [m0 m2 m1 m3]), (m0 + m2) + (m1 + m3)
+// TAIL 1: Q4_K (lanes 8..11 reduced as above); TAIL 2: one scalar chain in lane 8 (Q4_1's summs); TAIL 0: none
+template <int TAIL>
+__device__ __forceinline__ float chain_finish(float acc) {
+    float h = acc;
+    h = h + dpp_f<DPP_QUAD_XOR1>(h);
+    h = h + dpp_f<DPP_QUAD_XOR2>(h);
+    const float hs = h + dpp_f<DPP_HALF_MIRROR>(h);
+    if (TAIL == 1) return hs + dpp_f<DPP_ROW_ROR8>(h);
+    if (TAIL == 2) return hs + dpp_f<DPP_ROW_ROR8>(acc);
+    return hs;
 }

@@ -668,8 +668,10 @@ int orc_rope(const orc_tensor * src, const int32_t * pos, const float * ff, orc_
                 const int64_t ic = p->mode == 0 ? i0 : i0 / 2;
                 const float c = cache[i0], s = cache[i0 + 1];
                 const float x0 = x[ic], x1 = x[ic + off];
-                y[ic]       = x0*c - x1*s;
-                y[ic + off] = x0*s + x1*c;
+                /* rotate_pairs (ops.cpp:5700-5718) as the reference build compiles it: gcc contracts each expression into one fma
+                 * around the rounded x1 product (verified bit for bit against libggml-cpu.so) */
+                y[ic]       = fmaf(x0, c, -(x1*s));
+                y[ic + off] = fmaf(x0, s, x1*c);
             }
             for (int64_t i0 = n_dims; i0 < ne0; i0++) y[i0] = x[i0];
         }
