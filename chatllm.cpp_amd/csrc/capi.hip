@@ -169,9 +169,12 @@ extern "C" int cllm_event_elapsed_ms(void * start, void * stop, float * ms) {
 static bool is_quant(int t) { return is_quant_type(t); }
 static int  act_kind(int wtype) { return act_kind_of(wtype); }
 
+// Columns from which the quantized product runs on the matrix cores (mmq.hip: exact integer block sums, its own fp32 summation order =
+// tolerance tier).  Below, the multi-column mat-vec runs in chunks of <= 4 columns: it accumulates in the reference's AVX2 order, so short
+// prompts (BASELINE cfg2: 16 tokens) stay BIT-IDENTICAL to the CPU path end to end.  Default 33; CLLM_MMQ_MIN_COLS=9 is the speed crossover.
 static int mmq_min_cols() {
     static int v = -1;
-    if (v < 0) { v = 9; if (const char * e = getenv("CLLM_MMQ_MIN_COLS")) { int x = atoi(e); if (x >= 1) v = x; } }
+    if (v < 0) { v = 33; if (const char * e = getenv("CLLM_MMQ_MIN_COLS")) { int x = atoi(e); if (x >= 1) v = x; } }
     return v;
 }
 

@@ -9,8 +9,20 @@
 // launch sequence that the runner captures once in a hipGraph.
 #include "common.h"
 #include "quant_dev.h"
+#include "q4k.h"
 
 #include <math.h>
+
+// GGML_F32x8_REDUCE (simd-mappings.h:545-560) over the 32 accumulators of ggml_vec_dot_f16, held two per lane by 16 lanes (accumulator
+// a = 8 j + l in lane a / 2): x0 += x2, x1 += x3 (lanes c ^ 8); x0 += x1 (c ^ 4); lo + hi halves (c ^ 2); hadd, hadd (in-lane, c ^ 1)
+__device__ __forceinline__ float lane_xor4_ff(float v) { return __int_as_float(lane_xor4_i(__float_as_int(v))); }
+__device__ __forceinline__ float vd32_reduce(float a0, float a1) {
+    a0 = a0 + dpp_f<DPP_ROW_ROR8>(a0); a1 = a1 + dpp_f<DPP_ROW_ROR8>(a1);
+    a0 = a0 + lane_xor4_ff(a0);        a1 = a1 + lane_xor4_ff(a1);
+    a0 = a0 + dpp_f<DPP_QUAD_XOR2>(a0); a1 = a1 + dpp_f<DPP_QUAD_XOR2>(a1);
+    const float u = a0 + a1;
+    return u + dpp_f<DPP_QUAD_XOR1>(u);
+}
 
 // ---------------------------------------------------------------------------------------------------------------
 // Attention for one query token, one workgroup per query head.
@@ -59,36 +71,9 @@ __global__ void __launch_bounds__(1024) k_attn_decode(const float * __restrict__
     const int pos = pos_dev[0];
     const int n_kv = pos + 1;
 
-    // ---- (2) first batch of cache rows (lane grouping of launch_T() in matmul_f.hip: G lanes per row, G*8 <= K, 8 <= G <= 64,
-    //          so that the fp32 summation order -- and every bit of the result -- equals the unfused MUL_MAT nodes) ----
-    constexpr int U = 4;
-    int G = 64; while (G > 8 && G * 8 > hd) G >>= 1;
-    const int K8 = hd & ~7;
-    const bool one_chunk = (K8 == hd) && (G * 8 == hd);               // head_dim 64/128/256/512: exactly one 16-byte chunk per lane
-    const int gl = lane % G, sub = lane / G, rpw = 64 / G, stride = nw * rpw;
-    const int ib0 = wave * rpw + sub;
-    u32x4 kr0[U];
-#pragma unroll
-    for (int u = 0; u < U; u++) {
-        const int i0 = ib0 + u * stride;
-        kr0[u] = u32x4{0, 0, 0, 0};
-        if (one_chunk && i0 < n_kv && !(ROPE && i0 == pos)) kr0[u] = *(const u32x4 *)(k_cache + (int64_t) i0 * KD + g * hd + gl * 8);
-    }
-    int GV = 64; while (GV > 8 && GV * 8 > n_kv) GV >>= 1;
-    const int glv = lane % GV, subv = lane / GV, rpwv = 64 / GV, stridev = nw * rpwv;
-    const int n8 = n_kv & ~7;
-    const int db0 = wave * rpwv + subv, itv = n8 + glv, ivv = glv * 8;
-    uint16_t vt0[U]; u32x4 vc0[U];
-#pragma unroll
-    for (int u = 0; u < U; u++) {
-        const int d0 = db0 + u * stridev;
-        vt0[u] = 0; vc0[u] = u32x4{0, 0, 0, 0};
-        if (d0 < hd && n_kv >= 8) {
-            const uint16_t * vr = v_cache + ((int64_t) g * hd + d0) * ML;
-            if (itv < n_kv) vt0[u] = vr[itv];
-            if (ivv < n8) vc0[u] = *(const u32x4 *)(vr + ivv);
-        }
-    }
+    // ---- (2) lane grouping: 16 lanes per cache row, accumulators of ggml_vec_dot_f16 two per lane (see k_attn_dec below) ----
+    const int c16 = lane & 15, sub = lane >> 4, nrg = nw * 4;
+    const int hnp = hd & ~31;
 
     // ---- (3) RoPE, fp16 rounding, cache write ----
     if (ROPE) {
@@ -137,64 +122,19 @@ __global__ void __launch_bounds__(1024) k_attn_decode(const float * __restrict__
         __syncthreads();
     }
 
-    // ---- (4) scores[i] = K[i] . q * scale ----
-    for (int ib = ib0; ib < n_kv; ib += U * stride) {
-        if (one_chunk) {
-            u32x4 r[U];
-#pragma unroll
-            for (int u = 0; u < U; u++) {
-                const int i0 = ib + u * stride;
-                r[u] = kr0[u];
-                if (ib != ib0) {
-                    r[u] = u32x4{0, 0, 0, 0};
-                    if (i0 < n_kv && !(ROPE && i0 == pos)) r[u] = *(const u32x4 *)(k_cache + (int64_t) i0 * KD + g * hd + gl * 8);
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < U; u++) {
-                const int i0 = ib + u * stride;
-                if (i0 >= n_kv) continue;                                     // whole lane groups drop out together
-                const int d = gl * 8;
-                float acc = 0.0f;
-                if (ROPE && i0 == pos) {
-#pragma unroll
-                    for (int j = 0; j < 8; j++) acc = __builtin_fmaf(knew[d + j], qs[d + j], acc);
-                } else {
-                    const uint32_t wv[4] = { r[u].x, r[u].y, r[u].z, r[u].w };
-#pragma unroll
-                    for (int j = 0; j < 4; j++) {
-                        acc = __builtin_fmaf(h2f((uint16_t)(wv[j] & 0xffff)), qs[d + 2*j], acc);
-                        acc = __builtin_fmaf(h2f((uint16_t)(wv[j] >> 16)), qs[d + 2*j + 1], acc);
-                    }
-                }
-                for (int o = G / 2; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
-                if (gl == 0) sc[i0] = acc * scale;                            // the SCALE node
-            }
-        } else {
-            for (int u = 0; u < U; u++) {
-                const int i0 = ib + u * stride;
-                if (i0 >= n_kv) break;
-                const uint16_t * kr = k_cache + (int64_t) i0 * KD + g * hd;
-                const bool fr = ROPE && i0 == pos;
-                float acc = 0.0f;
-                for (int d = K8 + gl; d < hd; d += G) acc = __builtin_fmaf(fr ? knew[d] : h2f(kr[d]), qs[d], acc);
-                for (int d = gl * 8; d < K8; d += G * 8) {
-                    if (fr) {
-#pragma unroll
-                        for (int j = 0; j < 8; j++) acc = __builtin_fmaf(knew[d + j], qs[d + j], acc);
-                    } else {
-                        const u32x4 r = *(const u32x4 *)(kr + d);
-                        const uint32_t wv[4] = { r.x, r.y, r.z, r.w };
-#pragma unroll
-                        for (int j = 0; j < 4; j++) {
-                            acc = __builtin_fmaf(h2f((uint16_t)(wv[j] & 0xffff)), qs[d + 2*j], acc);
-                            acc = __builtin_fmaf(h2f((uint16_t)(wv[j] >> 16)), qs[d + 2*j + 1], acc);
-                        }
-                    }
-                }
-                for (int o = G / 2; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
-                if (gl == 0) sc[i0] = acc * scale;
-            }
+    // ---- (4) scores[i] = K[i] . q * scale, in ggml_vec_dot_f16's order ----
+    for (int i0 = wave * 4 + sub; i0 < n_kv; i0 += nrg) {
+        const uint16_t * kr = k_cache + (int64_t) i0 * KD + g * hd;
+        const bool fr = ROPE && i0 == pos;
+        float a0 = 0.0f, a1 = 0.0f;
+        for (int e = 2 * c16; e < hnp; e += 32) {
+            const float k0 = fr ? knew[e] : h2f(kr[e]), k1 = fr ? knew[e + 1] : h2f(kr[e + 1]);
+            a0 = __builtin_fmaf(k0, qs[e], a0); a1 = __builtin_fmaf(k1, qs[e + 1], a1);
+        }
+        float v = vd32_reduce(a0, a1);
+        if (c16 == 0) {
+            if (hnp < hd) { double s = (double) v; for (int e = hnp; e < hd; e++) s += (double)((fr ? knew[e] : h2f(kr[e])) * qs[e]); v = (float) s; }
+            sc[i0] = v * scale;                                           // the SCALE node
         }
     }
     __syncthreads();
@@ -227,49 +167,29 @@ __global__ void __launch_bounds__(1024) k_attn_decode(const float * __restrict__
     __syncthreads();
     if (dbg) { for (int i = tid; i < n_kv; i += nthr) dbg[(int64_t) h * ML + i] = sc[i]; if (tid == 0) { dbg[(int64_t) nh * ML + 2*h] = mx; dbg[(int64_t) nh * ML + 2*h + 1] = inv; } }
 
-    // ---- (6) ctx = V . P: each lane group walks U head-dim rows at once; the first-step loads (tail element + first
-    //          16-byte chunk) of the first U rows were issued in (2); later chunks (long contexts) follow row by row ----
-    for (int db = db0; db < hd; db += U * stridev) {
-        uint16_t t0[U]; u32x4 c0[U];
-#pragma unroll
-        for (int u = 0; u < U; u++) {
-            const int d0 = db + u * stridev;
-            t0[u] = vt0[u]; c0[u] = vc0[u];
-            if (db != db0) {
-                t0[u] = 0; c0[u] = u32x4{0, 0, 0, 0};
-                if (d0 < hd && n_kv >= 8) {
-                    const uint16_t * vr = v_cache + ((int64_t) g * hd + d0) * ML;
-                    if (itv < n_kv) t0[u] = vr[itv];
-                    if (ivv < n8) c0[u] = *(const u32x4 *)(vr + ivv);
-                }
-            }
+    // ---- (6) ctx = V . P in the same order: chunks of 32 cached positions, then the n_kv mod 32 leftovers in double ----
+    float * tailp = sm + 3 * hd + (ML > hd ? ML : hd) + (wave * 4 + sub) * 32;
+    const int np = n_kv & ~31, ntail = n_kv - np;
+    for (int d0 = wave * 4 + sub; d0 < hd; d0 += nrg) {
+        const uint16_t * vr = v_cache + ((int64_t) g * hd + d0) * ML;
+        const float vfresh = ROPE ? vnew[d0] : 0.0f;
+        float a0 = 0.0f, a1 = 0.0f;
+        for (int e = 2 * c16; e < np; e += 32) {
+            const float v0 = (ROPE && e == pos) ? vfresh : h2f(vr[e]), v1 = (ROPE && e + 1 == pos) ? vfresh : h2f(vr[e + 1]);
+            a0 = __builtin_fmaf(v0, sc[e], a0); a1 = __builtin_fmaf(v1, sc[e + 1], a1);
         }
-#pragma unroll
-        for (int u = 0; u < U; u++) {
-            const int d0 = db + u * stridev;
-            if (d0 >= hd) continue;
-            const uint16_t * vr = v_cache + ((int64_t) g * hd + d0) * ML;
-            const float vfresh = ROPE ? vnew[d0] : 0.0f;
-            float acc = 0.0f;
-            if (n_kv >= 8) {
-                for (int i = itv; i < n_kv; i += GV) acc = __builtin_fmaf((ROPE && i == pos) ? vfresh : h2f(i == itv ? t0[u] : vr[i]), sc[i], acc);
-                for (int i = ivv; i < n8; i += GV * 8) {
-                    const u32x4 r = i == ivv ? c0[u] : *(const u32x4 *)(vr + i);
-                    const uint32_t wv[4] = { r.x, r.y, r.z, r.w };
-#pragma unroll
-                    for (int j = 0; j < 4; j++) {
-                        const float v0 = (ROPE && i + 2*j == pos) ? vfresh : h2f((uint16_t)(wv[j] & 0xffff));
-                        const float v1 = (ROPE && i + 2*j + 1 == pos) ? vfresh : h2f((uint16_t)(wv[j] >> 16));
-                        acc = __builtin_fmaf(v0, sc[i + 2*j], acc);
-                        acc = __builtin_fmaf(v1, sc[i + 2*j + 1], acc);
-                    }
-                }
-            } else {
-                for (int i = glv; i < n_kv; i += GV) acc = __builtin_fmaf((ROPE && i == pos) ? vfresh : h2f(vr[i]), sc[i], acc);   // the scalar kernel of matmul_f.hip (K < 8)
-            }
-            for (int o = GV / 2; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
-            if (glv == 0) att[h * hd + d0] = acc;
+        const float res = vd32_reduce(a0, a1);
+        for (int t = 0; t < 2; t++) {
+            const int e = np + 2 * c16 + t;
+            if (e < n_kv) tailp[2 * c16 + t] = ((ROPE && e == pos) ? vfresh : h2f(vr[e])) * sc[e];
         }
+        wave_lds_fence();
+        if (c16 == 0) {
+            double s = (double) res;
+            for (int t = 0; t < ntail; t++) s += (double) tailp[t];
+            att[h * hd + d0] = (float) s;
+        }
+        wave_lds_fence();
     }
 }
 
@@ -309,7 +229,7 @@ __global__ void __launch_bounds__(1024) k_attn_dec(const float * __restrict__ qk
     extern __shared__ __attribute__((aligned(16))) float sm[];       // [HD] q (fp16-rounded) | [HD] new k | [HD] new v | [n_kv] scores
     __shared__ double red_d[1];
     __shared__ float  red_f[16];
-    constexpr int half = HD / 2, G = HD / 8, RPW = 64 / G, off = MODE == 0 ? 1 : half, U = 4;
+    constexpr int half = HD / 2, off = MODE == 0 ? 1 : half, U = 4;
     const int r2 = gridDim.x, g = blockIdx.y, h = g * r2 + blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int KD = nkv * HD, QD = nh * HD;
@@ -327,30 +247,30 @@ __global__ void __launch_bounds__(1024) k_attn_dec(const float * __restrict__ qk
     const int pos = uniform_load_i32(pos_dev);
     const int n_kv = pos + 1;
 
-    // ---- (2) first batch of cache rows: G lanes per K row (one 16-byte chunk per lane), GV lanes per V^T row ----
-    const int gl = lane & (G - 1), sub = lane / G, stride = 16 * RPW;
-    const int ib0 = wave * RPW + sub;
-    u32x4 kr0[U];
+    // ---- (2) first batch of cache rows.  Accumulation ORDER of ggml_vec_dot_f16 (vec.cpp:264-, AVX2 + F16C: simd-mappings.h:528-620), so
+    //          that scores and context equal the reference's bit for bit: 32 fp32 accumulators, accumulator a takes elements a, a + 32, ...
+    //          in order (one fma each), GGML_F32x8_REDUCE's tree, leftovers (n mod 32) one by one in double.  16 lanes per row, lane c
+    //          carries accumulators 2c and 2c + 1: one dword (two fp16) per 32-element chunk. ----
+    constexpr int NCH = HD / 32, VU = HD / 64, VPF = 8;
+    const int c16 = lane & 15, sub = lane >> 4;
+    const int ib0 = wave * 4 + sub;                                   // K rows ib0 + 64 u; V^T rows ib0 + 64 u
+    uint32_t kr0[U][NCH];
 #pragma unroll
     for (int u = 0; u < U; u++) {
-        const int i0 = ib0 + u * stride;
-        kr0[u] = u32x4{0, 0, 0, 0};
-        if (i0 < pos) kr0[u] = *(const u32x4 *)(k_cache + (int64_t) i0 * KD + g * HD + gl * 8);      // row `pos` is the new k (LDS)
-    }
-    int lgv = 6; while (lgv > 3 && (8 << lgv) > n_kv) lgv--;        // GV = 1 << lgv: GV * 8 <= n_kv, 8 <= GV <= 64 (launch_T(), matmul_f.hip)
-    const int GV = 1 << lgv, glv = lane & (GV - 1), subv = lane >> lgv, stridev = 16 * (64 >> lgv);
-    const int n8 = n_kv & ~7;
-    const int db0 = wave * (64 >> lgv) + subv, itv = n8 + glv, ivv = glv * 8;
-    uint16_t vt0[U]; u32x4 vc0[U];
+        const int i0 = ib0 + u * 64;
 #pragma unroll
-    for (int u = 0; u < U; u++) {
-        const int d0 = db0 + u * stridev;
-        vt0[u] = 0; vc0[u] = u32x4{0, 0, 0, 0};
-        if (d0 < HD && n_kv >= 8) {
-            const uint16_t * vr = v_cache + ((int64_t) g * HD + d0) * ML;
-            if (itv < n_kv) vt0[u] = vr[itv];
-            if (ivv < n8) vc0[u] = *(const u32x4 *)(vr + ivv);
+        for (int i = 0; i < NCH; i++) {
+            kr0[u][i] = 0;
+            if (i0 < pos) kr0[u][i] = *(const uint32_t *)(k_cache + (int64_t) i0 * KD + g * HD + 32 * i + 2 * c16);      // row `pos` is the new k (LDS)
         }
+    }
+    const int np = n_kv & ~31, nch = np >> 5;
+    uint32_t vc0[VU][VPF];
+#pragma unroll
+    for (int u = 0; u < VU; u++) {
+        const uint16_t * vr = v_cache + ((int64_t) g * HD + ib0 + u * 64) * ML;
+#pragma unroll
+        for (int i = 0; i < VPF; i++) { vc0[u][i] = 0; if (i < nch) vc0[u][i] = *(const uint32_t *)(vr + 32 * i + 2 * c16); }
     }
 
     TS(0);
@@ -368,37 +288,30 @@ __global__ void __launch_bounds__(1024) k_attn_dec(const float * __restrict__ qk
 
     TS(1);
     // ---- (4) scores[i] = K[i] . q * scale ----
-    for (int ib = ib0; ib < n_kv; ib += U * stride) {
-        u32x4 r[U];
+    for (int ib = ib0; ib < n_kv; ib += U * 64) {
+        uint32_t r[U][NCH];
 #pragma unroll
         for (int u = 0; u < U; u++) {
-            const int i0 = ib + u * stride;
-            r[u] = kr0[u];
-            if (ib != ib0) {
-                r[u] = u32x4{0, 0, 0, 0};
-                if (i0 < pos) r[u] = *(const u32x4 *)(k_cache + (int64_t) i0 * KD + g * HD + gl * 8);
+            const int i0 = ib + u * 64;
+#pragma unroll
+            for (int i = 0; i < NCH; i++) {
+                r[u][i] = kr0[u][i];
+                if (ib != ib0) { r[u][i] = 0; if (i0 < pos) r[u][i] = *(const uint32_t *)(k_cache + (int64_t) i0 * KD + g * HD + 32 * i + 2 * c16); }
             }
         }
 #pragma unroll
         for (int u = 0; u < U; u++) {
-            const int i0 = ib + u * stride;
-            if (i0 >= n_kv) continue;                                     // whole lane groups drop out together
-            const int d = gl * 8;
-            float acc = 0.0f;
-            if (i0 == pos) {
+            const int i0 = ib + u * 64;
+            if (i0 >= n_kv) continue;                                     // whole 16-lane rows drop out together
+            float a0 = 0.0f, a1 = 0.0f;
 #pragma unroll
-                for (int j = 0; j < 8; j++) acc = __builtin_fmaf(knew[d + j], qs[d + j], acc);
-            } else {
-                const uint32_t wv[4] = { r[u].x, r[u].y, r[u].z, r[u].w };
-#pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    acc = __builtin_fmaf(h2f((uint16_t)(wv[j] & 0xffff)), qs[d + 2*j], acc);
-                    acc = __builtin_fmaf(h2f((uint16_t)(wv[j] >> 16)), qs[d + 2*j + 1], acc);
-                }
+            for (int i = 0; i < NCH; i++) {
+                const int e = 32 * i + 2 * c16;
+                const float k0 = i0 == pos ? knew[e] : h2f((uint16_t)(r[u][i] & 0xffff)), k1 = i0 == pos ? knew[e + 1] : h2f((uint16_t)(r[u][i] >> 16));
+                a0 = __builtin_fmaf(k0, qs[e], a0); a1 = __builtin_fmaf(k1, qs[e + 1], a1);
             }
-#pragma unroll
-            for (int o = G / 2; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
-            if (gl == 0) sc[i0] = acc * scale;                            // the SCALE node
+            const float v = vd32_reduce(a0, a1);
+            if (c16 == 0) sc[i0] = v * scale;                             // the SCALE node
         }
     }
     __syncthreads();
@@ -433,48 +346,49 @@ __global__ void __launch_bounds__(1024) k_attn_dec(const float * __restrict__ qk
     __syncthreads();
     TS(3);
 
-    // ---- (6) ctx = V . P ----
-    for (int db = db0; db < HD; db += U * stridev) {
-        uint16_t t0[U]; u32x4 c0[U];
+    // ---- (6) ctx = V . P: chunks of 32 cached positions in order, then the n_kv mod 32 leftovers in double (products staged in LDS) ----
+    float * tailp = sc + ML + (wave * 4 + sub) * 32;
+    const int ntail = n_kv - np;
 #pragma unroll
-        for (int u = 0; u < U; u++) {
-            const int d0 = db + u * stridev;
-            t0[u] = vt0[u]; c0[u] = vc0[u];
-            if (db != db0) {
-                t0[u] = 0; c0[u] = u32x4{0, 0, 0, 0};
-                if (d0 < HD && n_kv >= 8) {
-                    const uint16_t * vr = v_cache + ((int64_t) g * HD + d0) * ML;
-                    if (itv < n_kv) t0[u] = vr[itv];
-                    if (ivv < n8) c0[u] = *(const u32x4 *)(vr + ivv);
+    for (int u = 0; u < VU; u++) {
+        const int d0 = ib0 + u * 64;
+        const uint16_t * vr = v_cache + ((int64_t) g * HD + d0) * ML;
+        const float vfresh = vnew[d0];
+        float a0 = 0.0f, a1 = 0.0f;
+#pragma unroll
+        for (int i = 0; i < VPF; i++) {
+            if (i < nch) {
+                const int e = 32 * i + 2 * c16;
+                const float v0 = e == pos ? vfresh : h2f((uint16_t)(vc0[u][i] & 0xffff)), v1 = e + 1 == pos ? vfresh : h2f((uint16_t)(vc0[u][i] >> 16));
+                a0 = __builtin_fmaf(v0, sc[e], a0); a1 = __builtin_fmaf(v1, sc[e + 1], a1);
+            }
+        }
+        for (int i8 = VPF; i8 < nch; i8 += 8) {
+            uint32_t rr[8];
+#pragma unroll
+            for (int i = 0; i < 8; i++) { rr[i] = 0; if (i8 + i < nch) rr[i] = *(const uint32_t *)(vr + 32 * (i8 + i) + 2 * c16); }
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                if (i8 + i < nch) {
+                    const int e = 32 * (i8 + i) + 2 * c16;
+                    const float v0 = e == pos ? vfresh : h2f((uint16_t)(rr[i] & 0xffff)), v1 = e + 1 == pos ? vfresh : h2f((uint16_t)(rr[i] >> 16));
+                    a0 = __builtin_fmaf(v0, sc[e], a0); a1 = __builtin_fmaf(v1, sc[e + 1], a1);
                 }
             }
         }
+        const float res = vd32_reduce(a0, a1);
 #pragma unroll
-        for (int u = 0; u < U; u++) {
-            const int d0 = db + u * stridev;
-            if (d0 >= HD) continue;
-            const uint16_t * vr = v_cache + ((int64_t) g * HD + d0) * ML;
-            const float vfresh = vnew[d0];
-            float acc = 0.0f;
-            if (n_kv >= 8) {
-                for (int i = itv; i < n_kv; i += GV) acc = __builtin_fmaf(i == pos ? vfresh : h2f(i == itv ? t0[u] : vr[i]), sc[i], acc);
-                for (int i = ivv; i < n8; i += GV * 8) {
-                    const u32x4 r = i == ivv ? c0[u] : *(const u32x4 *)(vr + i);
-                    const uint32_t wv[4] = { r.x, r.y, r.z, r.w };
-#pragma unroll
-                    for (int j = 0; j < 4; j++) {
-                        const float v0 = (i + 2*j == pos) ? vfresh : h2f((uint16_t)(wv[j] & 0xffff));
-                        const float v1 = (i + 2*j + 1 == pos) ? vfresh : h2f((uint16_t)(wv[j] >> 16));
-                        acc = __builtin_fmaf(v0, sc[i + 2*j], acc);
-                        acc = __builtin_fmaf(v1, sc[i + 2*j + 1], acc);
-                    }
-                }
-            } else {
-                for (int i = glv; i < n_kv; i += GV) acc = __builtin_fmaf(i == pos ? vfresh : h2f(vr[i]), sc[i], acc);   // the scalar kernel of matmul_f.hip (K < 8)
-            }
-            for (int o = GV / 2; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
-            if (glv == 0) att[h * HD + d0] = acc;
+        for (int t = 0; t < 2; t++) {
+            const int e = np + 2 * c16 + t;
+            if (e < n_kv) tailp[2 * c16 + t] = (e == pos ? vfresh : h2f(vr[e])) * sc[e];
         }
+        wave_lds_fence();
+        if (c16 == 0) {
+            double s = (double) res;
+            for (int t = 0; t < ntail; t++) s += (double) tailp[t];
+            att[h * HD + d0] = (float) s;
+        }
+        wave_lds_fence();
     }
     TS(4);
 #undef TS
@@ -484,7 +398,7 @@ __global__ void __launch_bounds__(1024) k_attn_dec(const float * __restrict__ qk
 int launch_attn_dec_table(hipStream_t st, const float * qkv, const int32_t * pos_dev, const float * rope_cs, int nh, int nkv, int hd, int mode,
                           uint16_t * k_cache, uint16_t * v_cache, int64_t ML, float * att) {
     if ((hd != 64 && hd != 128) || nh % nkv || ML % 8 || ML > (1 << 30) || g_attn_dbg) return CLLM_E_UNSUPPORTED;
-    const size_t lds = (size_t)(3 * hd + ML) * 4;
+    const size_t lds = (size_t)(3 * hd + ML) * 4 + 64 * 32 * 4;      // q | new k | new v | scores | leftover products of 64 lane groups
     if (lds > 150 * 1024) return CLLM_E_UNSUPPORTED;
     const float scale = 1.0f / sqrtf((float) hd);
     const dim3 grid(nh / nkv, nkv);
@@ -502,7 +416,7 @@ int launch_attn_dec_table(hipStream_t st, const float * qkv, const int32_t * pos
 static int attn_launch(hipStream_t st, bool rope, const float * qkv, const int32_t * pos_dev, int nh, int nkv, int hd, uint16_t * k_cache, uint16_t * v_cache,
                        int64_t ML, float * att, int mode, float freq_base) {
     if (hd % 8 || (ML % 8) || nh % nkv) FAIL(CLLM_E_UNSUPPORTED, "attn_decode: head_dim and max_len must be multiples of 8");
-    const size_t lds = (size_t)(3 * hd + (ML > hd ? ML : hd)) * 4;      // q | new k | new v | scores (reused for the cos/sin table)
+    const size_t lds = (size_t)(3 * hd + (ML > hd ? ML : hd)) * 4 + 64 * 32 * 4;      // q | new k | new v | scores (reused for the cos/sin table) | leftover products
     if (lds > 150 * 1024) FAIL(CLLM_E_UNSUPPORTED, "attn_decode: max_len %lld does not fit LDS", (long long) ML);
     static bool attr0 = false, attr1 = false;
     if (lds > 48 * 1024) {

@@ -52,7 +52,10 @@ __global__ void __launch_bounds__(1024) k_gemv_dec(const float * __restrict__ px
         W += (unsigned long long)(unsigned) e * w_expert_bytes;
         px += (long) blockIdx.y * px_slot_stride; dst += (long) blockIdx.y * dst_slot_stride;
     }
-    constexpr int P = 2, RU = EPI == 1 ? 2 : 1;
+#ifndef GEMV_P
+#define GEMV_P 2
+#endif
+    constexpr int P = GEMV_P, RU = EPI == 1 ? 2 : 1;
     constexpr bool IS_K = FMT == CLLM_TYPE_Q4_K, IS_Q8 = FMT == CLLM_TYPE_Q8_0, IS_Q41 = FMT == CLLM_TYPE_Q4_1;
     constexpr int KIND = IS_K ? 256 : 32;                           // elements per weight block = activation quantization block
     constexpr int BS = IS_K ? 144 : q32_fmt<IS_K ? CLLM_TYPE_Q4_0 : FMT>::BS;      // bytes per weight block

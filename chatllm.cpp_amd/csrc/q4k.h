@@ -78,23 +78,32 @@ __device__ __forceinline__ void q4k_emit(const u32x4 h, const u32x4 q, const cha
     const float yd = ((const float *)(ar + off_d))[bb];
     const int   ys = ((const int *)(ar + off_s))[bb * 8 + L.s_idx];
     // the four dwords of this lane = AVX lanes 4(j&1) + k of chunk j/2
-    const int t0 = sc_lo * dot4(q.x & 0x0f0f0f0fu, al.x, 0) + sc_hi * dot4((q.x >> 4) & 0x0f0f0f0fu, ah.x, 0);
-    const int t1 = sc_lo * dot4(q.y & 0x0f0f0f0fu, al.y, 0) + sc_hi * dot4((q.y >> 4) & 0x0f0f0f0fu, ah.y, 0);
-    const int t2 = sc_lo * dot4(q.z & 0x0f0f0f0fu, al.z, 0) + sc_hi * dot4((q.z >> 4) & 0x0f0f0f0fu, ah.z, 0);
-    const int t3 = sc_lo * dot4(q.w & 0x0f0f0f0fu, al.w, 0) + sc_hi * dot4((q.w >> 4) & 0x0f0f0f0fu, ah.w, 0);
+    // (24-bit multiplies: scales < 64, |dot| <= 4 * 15 * 127 -- the 32-bit v_mul_lo_u32 / v_mad_u64_u32 the compiler picks otherwise run at a quarter rate)
+    const int t0 = __mul24(sc_lo, dot4(q.x & 0x0f0f0f0fu, al.x, 0)) + __mul24(sc_hi, dot4((q.x >> 4) & 0x0f0f0f0fu, ah.x, 0));
+    const int t1 = __mul24(sc_lo, dot4(q.y & 0x0f0f0f0fu, al.y, 0)) + __mul24(sc_hi, dot4((q.y >> 4) & 0x0f0f0f0fu, ah.y, 0));
+    const int t2 = __mul24(sc_lo, dot4(q.z & 0x0f0f0f0fu, al.z, 0)) + __mul24(sc_hi, dot4((q.z >> 4) & 0x0f0f0f0fu, ah.z, 0));
+    const int t3 = __mul24(sc_lo, dot4(q.w & 0x0f0f0f0fu, al.w, 0)) + __mul24(sc_hi, dot4((q.w >> 4) & 0x0f0f0f0fu, ah.w, 0));
     // reduce-scatter over the four chunks (lanes j, j^2, j^4, j^6): lane j keeps dword k = (j&2) + (j>>2)
     int k0 = L.b2 ? t2 : t0, k1 = L.b2 ? t3 : t1;
     const int s0 = L.b2 ? t0 : t2, s1 = L.b2 ? t1 : t3;
     k0 += dpp_i<DPP_QUAD_XOR2>(s0); k1 += dpp_i<DPP_QUAD_XOR2>(s1);
     const int keep = L.b4 ? k1 : k0, send = L.b4 ? k0 : k1;
+#ifdef Q4K_NOSCATTER     // (timing experiments only)
+    const int sumi = (t0 + t1) + (t2 + t3) + (keep & 0) + (send & 0);
+#else
     const int sumi = keep + lane_xor4_i(send);
+#endif
     // mins: prod[k] = m[2k] S[2k] + m[2k+1] S[2k+1] on the lane pair
-    int pm = mj * ys;
+    int pm = __mul24(mj, ys);                   // |ys| <= 32 * 127
     pm += dpp_i<DPP_QUAD_XOR1>(pm);
     float x = (float) sumi, dd = yd * d, xm = (float) pm, dm = (-yd) * dmin;
     if (!ok) { x = 0.0f; dd = 0.0f; xm = 0.0f; dm = 0.0f; }
+#ifdef Q4K_NOWRITE       // (timing experiments only)
+    asm volatile("" :: "v"(x), "v"(dd), "v"(xm), "v"(dm), "v"(rec));
+#else
     *(float2 *)(rec + L.w_off) = float2{x, dd};
-    if (L.wm) *(float2 *)(rec + L.wm_off) = float2{xm, dm};
+    *(float2 *)(rec + L.wm_off) = float2{xm, dm};
+#endif       // (both lanes of the pair hold the same record: no branch)
 }
 
 // walk `npairs` (a multiple of 4) pairs of records in block order; l16 = lane & 15 (lanes 0..7: acc[], 8..11: acc_m[], 12..15: idle)
