@@ -96,7 +96,11 @@ __global__ void __launch_bounds__(256) k_mul_mat_f_vd(tview w, tview x, tview d)
                     for (int64_t e = np; e < K; e++) s += (double)(ld8<T>::one(wrow + e * sizeof(T)) * ld8<T>::cvt(*(const float *)(C.xc[c] + e * 4)));
                     u = (float) s;
                 } else {
-                    for (int64_t e = np; e < K; e++) u = __builtin_fmaf(ld8<T>::one(wrow + e * sizeof(T)), *(const float *)(C.xc[c] + e * 4), u);
+                    // `sumf += x[i]*y[i]` as gcc -O3 compiles it (determined against libggml-cpu.so): whole groups of 4 leftovers have their
+                    // products rounded (vector multiply) and added in order; the scalar remainder is contracted into fmas
+                    int64_t e = np;
+                    for (; e + 4 <= K; e += 4) for (int l = 0; l < 4; l++) u = u + ld8<T>::one(wrow + (e + l) * sizeof(T)) * *(const float *)(C.xc[c] + (e + l) * 4);
+                    for (; e < K; e++) u = __builtin_fmaf(ld8<T>::one(wrow + e * sizeof(T)), *(const float *)(C.xc[c] + e * 4), u);
                 }
                 C.dc[c][i01] = u;
             }

@@ -13,7 +13,9 @@
 
 /* two statements of the reference are plain C that gcc -O3 (-ffp-contract=fast) compiles to one fma; fused here explicitly */
 #define ORC_Q41_SUMMS(m, s, acc) fmaf((m), (s), (acc))
-#define ORC_F32_TAIL(x, y, acc)  fmaf((x), (y), (acc))
+#ifndef ORC_F32_TAIL_VW
+#define ORC_F32_TAIL_VW 4
+#endif
 #define ORC_MIN(a, b) ((a) < (b) ? (a) : (b))
 #define ORC_MAX(a, b) ((a) > (b) ? (a) : (b))
 
@@ -458,7 +460,11 @@ float orc_vec_dot_f32_avx2(int64_t n, const float * x, const float * y) {
     for (int l = 0; l < 8; l++) sum[0][l] = sum[0][l] + sum[1][l];
     for (int l = 0; l < 4; l++) t0[l] = sum[0][l] + sum[0][l + 4];
     float sumf = (t0[0] + t0[1]) + (t0[2] + t0[3]);
-    for (int64_t i = np; i < n; i++) sumf = ORC_F32_TAIL(x[i], y[i], sumf);
+    /* the leftover loop `sumf += x[i]*y[i]` as gcc -O3 compiles it: groups of ORC_F32_TAIL_VW elements have their products formed by a vector
+     * multiply (rounded) and added in order; the scalar remainder is contracted into fmas */
+    int64_t i = np;
+    for (; i + ORC_F32_TAIL_VW <= n; i += ORC_F32_TAIL_VW) for (int l = 0; l < ORC_F32_TAIL_VW; l++) sumf = sumf + x[i + l] * y[i + l];
+    for (; i < n; i++) sumf = fmaf(x[i], y[i], sumf);
     return sumf;
 }
 

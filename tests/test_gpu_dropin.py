@@ -24,7 +24,7 @@ def test_reference_host_cpu_vs_our_module(gpu, tmp_path, wname, wt):
     mp = str(tmp_path / "m.bin")
     make_ggmm.write_model(mp, cfg, wt, seed=77)
     prompt = [3, 100, 45, 260, 17, 9, 201]
-    n_dec = 12
+    n_dec = 24
 
     def run(ngl, teacher=None):
         lp = str(tmp_path / f"l_{ngl}.bin")
@@ -33,23 +33,16 @@ def test_reference_host_cpu_vs_our_module(gpu, tmp_path, wname, wt):
             tf = str(tmp_path / "teacher.txt")
             open(tf, "w").write(" ".join(str(t) for t in teacher))
             env["TEACHER"] = tf
+        env["CLLM_HIP_STATS"] = "1"
         r = subprocess.run([os.path.join(REF, "ref_chat"), mp, ngl, "4", str(n_dec), lp] + [str(p) for p in prompt], capture_output=True, text=True, env=env, timeout=300)
         assert r.returncode == 0, r.stderr[-2000:]
         return [int(t) for t in r.stdout.split()], np.fromfile(lp, np.float32).reshape(n_dec + 1, cfg["vocab"]), r.stderr
 
     ids_c, lg_c, _ = run("cpu")
-    ids_g, lg_g, err = run("all", teacher=ids_c)          # teacher-forced on the CPU ids: comparable step by step
-    assert "HIP0" in err or "hip" in err.lower() or True
-    # (even the prompt chunk can contain a rounding flip: 2 layers x 7 tokens x ~2500 quantized activations)
-    agree = decided = 0
-    for s in range(n_dec + 1):
-        d = float(np.max(np.abs(lg_c[s] - lg_g[s])))
-        assert d < 0.25 * float(lg_c[s].std()), (s, d)
-        top2 = np.partition(lg_c[s], -2)[-2:]
-        if top2[1] - top2[0] > 2 * d:
-            decided += 1
-            agree += int(ids_c[s] == ids_g[s])
-    assert decided >= 6 and agree == decided
+    ids_g, lg_g, err = run("all")                         # FREE-RUNNING: each run feeds its own argmax back
+    assert "HIP0" in err or "ggml-hip" in err, err[-500:]      # the module was really loaded (CLLM_HIP_STATS lines)
+    assert ids_c == ids_g                                 # greedy token ids identical ...
+    assert np.array_equal(lg_c.view(np.uint32), lg_g.view(np.uint32))      # ... and every logit of every step has the same bits
 
 
 @pytest.mark.skipif(not (os.path.exists(os.path.join(REF, "ref_chat")) and os.path.exists(os.path.join(REF, "libggml-hip.so"))),
@@ -115,6 +108,7 @@ def test_reference_host_mixtral_cpu_vs_our_module(gpu, tmp_path, wname, wt):
             tf = str(tmp_path / "teacher.txt")
             open(tf, "w").write(" ".join(str(t) for t in teacher))
             env["TEACHER"] = tf
+        env["CLLM_HIP_STATS"] = "1"
         r = subprocess.run([os.path.join(REF, "ref_chat"), mp, ngl, "4", str(n_dec), lp] + [str(p) for p in prompt], capture_output=True, text=True, env=env, timeout=300)
         assert r.returncode == 0, r.stderr[-2000:]
         return [int(t) for t in r.stdout.split()], np.fromfile(lp, np.float32).reshape(n_dec + 1, cfg["vocab"]), r.stderr
@@ -128,15 +122,10 @@ def test_reference_host_mixtral_cpu_vs_our_module(gpu, tmp_path, wname, wt):
     # the reference feeds this architecture one token per graph (batch_input = false, models/mistral.h:101): prompt + decode graphs,
     # and not one more -- no scheduler split, nothing fell back to the CPU backend
     assert len(graphs) == len(prompt) + n_dec, (len(graphs), graphs[:4])
-    agree = decided = 0
-    for s in range(n_dec + 1):
-        d = float(np.max(np.abs(lg_c[s] - lg_g[s])))
-        assert d < 0.25 * float(lg_c[s].std()), (s, d)
-        top2 = np.partition(lg_c[s], -2)[-2:]
-        if top2[1] - top2[0] > 2 * d:
-            decided += 1
-            agree += int(ids_c[s] == ids_g[s])
-    assert decided >= 6 and agree == decided
+    # bit-exact token ids at greedy AND bit-identical logits (the run on the module was teacher-forced on the CPU ids only to share it with the
+    # no-fusion run: with identical logits its own argmax is the same id)
+    assert np.array_equal(lg_c.view(np.uint32), lg_g.view(np.uint32)), [int(np.sum(lg_c[i].view(np.uint32) != lg_g[i].view(np.uint32))) for i in range(n_dec + 1)]
+    assert ids_c == ids_g
 
 
 @pytest.mark.skipif(not (os.path.exists(os.path.join(REF, "ref_chat")) and os.path.exists(os.path.join(REF, "libggml-hip.so"))),
@@ -160,6 +149,7 @@ def test_reference_host_qwen2_cpu_vs_our_module(gpu, tmp_path, wname, wt):
             tf = str(tmp_path / "teacher.txt")
             open(tf, "w").write(" ".join(str(t) for t in teacher))
             env["TEACHER"] = tf
+        env["CLLM_HIP_STATS"] = "1"
         r = subprocess.run([os.path.join(REF, "ref_chat"), mp, ngl, "4", str(n_dec), lp] + [str(p) for p in prompt], capture_output=True, text=True, env=env, timeout=300)
         assert r.returncode == 0, r.stderr[-2000:]
         return [int(t) for t in r.stdout.split()], np.fromfile(lp, np.float32).reshape(n_dec + 1, cfg["vocab"]), r.stderr
@@ -171,23 +161,18 @@ def test_reference_host_qwen2_cpu_vs_our_module(gpu, tmp_path, wname, wt):
     graphs = [ln for ln in err.splitlines() if "graph_compute:" in ln and "calls" in ln]
     assert len(graphs) == n_dec + 1 and sum(f"level 2: {cfg['n_layer']})" in ln for ln in graphs) == n_dec, graphs[:3]
     assert sum(f" {2 * cfg['n_layer']} merged" in ln for ln in graphs) == n_dec, graphs[-2:]       # q|k|v (with the packed biases) and gate/up of every layer
-    agree = decided = 0
-    for s in range(n_dec + 1):
-        d = float(np.max(np.abs(lg_c[s] - lg_g[s])))
-        assert d < 0.25 * float(lg_c[s].std()), (s, d)
-        top2 = np.partition(lg_c[s], -2)[-2:]
-        if top2[1] - top2[0] > 2 * d:
-            decided += 1
-            agree += int(ids_c[s] == ids_g[s])
-    assert decided >= 6 and agree == decided
+    # bit-exact token ids at greedy AND bit-identical logits (the run on the module was teacher-forced on the CPU ids only to share it with the
+    # no-fusion run: with identical logits its own argmax is the same id)
+    assert np.array_equal(lg_c.view(np.uint32), lg_g.view(np.uint32)), [int(np.sum(lg_c[i].view(np.uint32) != lg_g[i].view(np.uint32))) for i in range(n_dec + 1)]
+    assert ids_c == ids_g
 
 
 @pytest.mark.skipif(not (os.path.exists(os.path.join(REF, "ref_chat")) and os.path.exists(os.path.join(REF, "libggml-hip.so"))),
                     reason="oracle/_ref (reference host + module) not built")
 def test_baseline_cfg1_gpt2_small_sized_q8_0_greedy_64(gpu, tmp_path):
     """BASELINE cfg1 (D1: a GPT-2-small-sized Llama-architecture stand-in, L=12, H=768, 12 heads, F=3072, V=50304, Q8_0): the
-    reference host greedy-decodes 64 tokens on its CPU backend; the same host on our module, teacher-forced on those ids, must agree step
-    by step (ids wherever the CPU run's margin decides, logits inside the quantization-noise floor)"""
+    reference host greedy-decodes 64 tokens on its CPU backend; the same host on our module, FREE-RUNNING, produces the same ids and
+    bit-identical logits at every step"""
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import make_ggmm
     cfg = gpu.synth.config("gpt2s-llama", max_len=128)
@@ -208,13 +193,8 @@ def test_baseline_cfg1_gpt2_small_sized_q8_0_greedy_64(gpu, tmp_path):
         return [int(t) for t in r.stdout.split()], np.fromfile(lp, np.float32).reshape(n_dec + 1, cfg["vocab"])
 
     ids_c, lg_c = run("cpu")
-    ids_g, lg_g = run("all", teacher=ids_c)
-    agree = decided = 0
-    for s in range(n_dec + 1):
-        d = float(np.max(np.abs(lg_c[s] - lg_g[s])))
-        assert d < 0.25 * float(lg_c[s].std()), (s, d)
-        top2 = np.partition(lg_c[s], -2)[-2:]
-        if top2[1] - top2[0] > 2 * d:
-            decided += 1
-            agree += int(ids_c[s] == ids_g[s])
-    assert decided >= 16 and agree == decided          # (the cheap generator gives flat logits: about 4 steps in 10 have a decisive margin)
+    ids_g, lg_g = run("all")
+    # bit-exact token ids at greedy AND bit-identical logits (the run on the module was teacher-forced on the CPU ids only to share it with the
+    # no-fusion run: with identical logits its own argmax is the same id)
+    assert np.array_equal(lg_c.view(np.uint32), lg_g.view(np.uint32)), [int(np.sum(lg_c[i].view(np.uint32) != lg_g[i].view(np.uint32))) for i in range(n_dec + 1)]
+    assert ids_c == ids_g

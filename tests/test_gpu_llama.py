@@ -171,26 +171,21 @@ def test_decoder_qwen2_style_is_bit_identical_to_the_walk(gpu):
     dev.close()
 
 
-@pytest.mark.parametrize("name,wtype,plen", [("tiny", O.Q8_0, 9), ("tiny", O.Q4_0, 9), ("tiny", O.Q4_K, 9), ("tiny", O.Q4_1, 9), ("small", O.Q4_K, 40)])
-def test_end_to_end_statistics_against_the_oracle_run(gpu, name, wtype, plen):
-    cfg = gpu.synth.config(name, max_len=96)
+@pytest.mark.parametrize("name,wtype,plen,over", [("tiny", O.Q8_0, 9, {}), ("tiny", O.Q4_0, 9, {}), ("tiny", O.Q4_K, 9, {}), ("tiny", O.Q4_1, 9, {}), ("small", O.Q4_K, 30, {}),
+                                                  ("tiny", O.Q4_K, 12, dict(rope_mode=2, qkv_bias=1, rope_theta=1e6, ffn=544))])
+def test_end_to_end_is_bit_identical_to_the_oracle_run(gpu, name, wtype, plen, over):
+    """FREE-RUNNING greedy generation, runner vs the oracle's whole-model walk (itself bit-identical to the reference host, test_golden.py):
+    every logit of every step has the same bits -- prompt chunk through the exact-order multi-column kernels, decode through the fused kernels"""
+    cfg = gpu.synth.config(name, max_len=96, **over)
     w = gpu.synth.make_model(cfg, wtype, seed=2)
     ref, dev = O.Llama(cfg, w), gpu.Llama(cfg, w)
     prompt = np.random.default_rng(2).integers(0, cfg["vocab"], plen).astype(np.int32)
     lr, lg = ref.forward(prompt), dev.forward(prompt)
-    diffs, agree, decided = [], 0, 0
-    for _ in range(24 if name == "tiny" else 6):
-        d = float(np.max(np.abs(lr - lg)))
-        diffs.append(d / float(lr.std()))
-        top2 = np.partition(lr, -2)[-2:]
-        if top2[1] - top2[0] > 2 * d:             # the oracle's own margin decides the token
-            decided += 1
-            agree += int(np.argmax(lr) == np.argmax(lg))
-        t = int(np.argmax(lr))                    # teacher-forced on the oracle's ids
-        lr, lg = ref.forward([t]), dev.forward([t])
-    assert agree == decided and decided > 0       # greedy ids identical wherever they are decidable
-    assert max(diffs) < 0.25, diffs               # never beyond the activation-quantization noise floor
-    assert diffs[0] < 1e-4 or name != "tiny", diffs   # the prefill itself (no earlier flip to inherit) agrees to fp32 round-off
+    for step in range(24 if name == "tiny" else 8):
+        assert np.array_equal(lr.view(np.uint32), lg.view(np.uint32)), (step, float(np.max(np.abs(lr - lg))))
+        tr, tg = int(np.argmax(lr)), int(np.argmax(lg))
+        assert tr == tg
+        lr, lg = ref.forward([tr]), dev.decode_fused_logits(tg)
     dev.close()
 
 
@@ -211,16 +206,23 @@ def test_fused_decode_path_is_bit_identical_to_the_node_by_node_path(gpu, wtype,
 
 
 @pytest.mark.parametrize("hd_cfg", ["tiny", "small"])
-def test_fused_decode_at_long_context_is_bit_identical_to_the_node_path(gpu, hd_cfg):
-    """long contexts take the split attention (attn_long.hip: scores / soft_max / V.P launches over the whole chip, lane-group
-    reduction through LDS, all-wave exponentiation with the group sums accumulated in the node kernel's order): same bits"""
+def test_fused_decode_at_long_context_vs_the_node_path(gpu, hd_cfg):
+    """up to 1024 cached positions the one-launch attention accumulates in ggml_vec_dot_f16's order like the node path: same bits.
+    Beyond, the split attention (attn_long.hip: scores / soft_max / V.P launches over the whole chip) keeps its own fp32 summation
+    order -- the reference's 32 serial chains over n_kv cannot be spread over the chip: tolerance tier (T1 on the attention output,
+    here seen through the logits)"""
     cfg = gpu.synth.config(hd_cfg, max_len=1280)
     w = gpu.synth.make_model(cfg, O.Q4_K, seed=8)
     a, b = gpu.Llama(cfg, w), gpu.Llama(cfg, w)
-    prompt = np.random.default_rng(8).integers(0, cfg["vocab"], 1150).astype(np.int32)
+    prompt = np.random.default_rng(8).integers(0, cfg["vocab"], 1000).astype(np.int32)
     assert np.array_equal(a.forward(prompt), b.forward(prompt))
-    for t in np.random.default_rng(9).integers(0, cfg["vocab"], 12):      # n_kv 1151..1162: tails of 7, 0, 1, ... elements
-        assert np.array_equal(a.forward([int(t)]), b.decode_fused_logits(int(t)))
+    toks = np.random.default_rng(9).integers(0, cfg["vocab"], 40)
+    for i, t in enumerate(toks):                                            # n_kv 1001..1040: the threshold is crossed after 24 steps
+        la, lb = a.forward([int(t)]), b.decode_fused_logits(int(t))
+        if 1001 + i <= 1024:
+            assert np.array_equal(la, lb), i
+        else:
+            assert float(np.max(np.abs(la - lb))) < 0.25 * float(la.std()), i       # (a rounding flip of the int8 activations may follow)
     a.close()
     b.close()
 
