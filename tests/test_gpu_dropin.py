@@ -198,3 +198,56 @@ def test_baseline_cfg1_gpt2_small_sized_q8_0_greedy_64(gpu, tmp_path):
     # no-fusion run: with identical logits its own argmax is the same id)
     assert np.array_equal(lg_c.view(np.uint32), lg_g.view(np.uint32)), [int(np.sum(lg_c[i].view(np.uint32) != lg_g[i].view(np.uint32))) for i in range(n_dec + 1)]
     assert ids_c == ids_g
+
+
+# ---- BASELINE configs at REAL shapes: the unmodified reference host, CPU backend vs every layer on our module, FREE-RUNNING greedy --------------
+def _real_shape_case(gpu, tmp_path, arch, cfgname, wt, prompt, n_dec, over, threads=32):
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import make_ggmm
+    cfg = gpu.synth.config(cfgname, **over)
+    mp = str(tmp_path / "m.bin")
+    if arch == "mixtral":
+        make_ggmm.write_mixtral(mp, cfg, wt, seed=5, fast=True)
+    else:
+        make_ggmm.write_model(mp, cfg, wt, seed=5, fast=True, arch=arch)
+
+    def run(ngl):
+        lp = str(tmp_path / f"l_{ngl}.bin")
+        r = subprocess.run([os.path.join(REF, "ref_chat"), mp, ngl, str(threads), str(n_dec), lp] + [str(p) for p in prompt], capture_output=True, text=True,
+                           env=dict(os.environ, CLLM_HIP_STATS="1"), timeout=1800)
+        assert r.returncode == 0, r.stderr[-2000:]
+        return [int(t) for t in r.stdout.split()], np.fromfile(lp, np.float32).reshape(n_dec + 1, cfg["vocab"]), r.stderr
+
+    ids_c, lg_c, _ = run("cpu")
+    ids_g, lg_g, err = run("all")
+    os.remove(mp)
+    assert "graph_compute:" in err                                    # the module really computed the graphs
+    mism = sum(int(a != b) for a, b in zip(ids_c, ids_g))
+    within = float(np.mean(np.max(np.abs(lg_c - lg_g), axis=1) <= 1e-3))
+    words = int(np.sum(lg_c.view(np.uint32) != lg_g.view(np.uint32)))
+    print(f"{arch}/{cfgname}: greedy id mismatches {mism}/{len(ids_c)}, steps with max|dlogit| <= 1e-3: {within:.3f}, differing logit words {words}")
+    assert mism == 0 and within == 1.0          # north star: bit-exact token ids at greedy, logits within 1e-3 -- at every step
+    assert words == 0                           # and in fact bit-identical logits (AVX2-order accumulation, glibc-exact libm)
+
+
+_BIG = pytest.mark.skipif(not (os.path.exists(os.path.join(REF, "ref_chat")) and os.path.exists(os.path.join(REF, "libggml-hip.so"))) or os.environ.get("CLLM_SKIP_BIG"),
+                          reason="oracle/_ref (reference host + module) not built, or CLLM_SKIP_BIG set")
+
+
+@_BIG
+def test_baseline_cfg2_llama3_8b_q4_k_16_plus_64_free_running(gpu, tmp_path):
+    """BASELINE cfg2: Llama-3-8B shapes, Q4_K, 16-token prompt, 64 greedy tokens (4.7 GB synthetic GGMM file)"""
+    _real_shape_case(gpu, tmp_path, "llama3", "llama3-8b", 12, [(7 * i + 3) % 128000 for i in range(16)], 64, dict(max_len=1024))
+
+
+@_BIG
+def test_baseline_cfg5_mixtral_shapes_q4_k_free_running(gpu, tmp_path):
+    """BASELINE cfg5's block at real shapes (Mixtral-8x7B: H 4096, F 14336, 8 experts, top 2, Q4_K), 4 of the 32 layers to bound the file (3.4 GB)"""
+    _real_shape_case(gpu, tmp_path, "mixtral", "mixtral-8x7b", 12, [(11 * i + 5) % 32000 for i in range(16)], 48, dict(max_len=512, n_layer=4))
+
+
+@_BIG
+def test_baseline_cfg4_qwen2_72b_shapes_q4_k_free_running(gpu, tmp_path):
+    """BASELINE cfg4's block at real shapes (Qwen2-72B: H 8192, 64 heads / 8 kv, F 29568 with the Q8_0 down_proj, q/k/v biases, NEOX RoPE), 2 of the
+    80 layers to bound the file (2.6 GB incl. the 152064-row embedding and lm_head)"""
+    _real_shape_case(gpu, tmp_path, "qwen2", "qwen2-72b", 12, [(13 * i + 7) % 150000 for i in range(16)], 32, dict(max_len=512, n_layer=2))
