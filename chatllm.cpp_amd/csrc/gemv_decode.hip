@@ -205,6 +205,10 @@ int launch_gemv_decode(hipStream_t st, int wtype, const void * W, int64_t K, int
                        int epi, float * dst, const float * bias, const float * resid, const float * padd, float * xout) {
     const int kind = wtype == CLLM_TYPE_Q4_K ? 256 : 32;
     if (!is_quant_type(wtype)) return CLLM_E_UNSUPPORTED;
+    if (wtype == CLLM_TYPE_Q4_K && !padd && !g_gemv_ts) {          // the LDS-staged form (gemv_rows.hip) where the shape suits it
+        const int rc = launch_gemv_rows(st, W, K, nrows, pro, px, pw, eps, epi, dst, bias, resid);
+        if (rc != CLLM_E_UNSUPPORTED) return rc;
+    }
     if (K % kind || K > ((pro == 2 || pro == 4) ? 32768 : 16384) || pro < 1 || pro > 4 || nrows <= 0 || (uint64_t) nrows * (uint64_t) cllm_row_size(wtype, K) >= (1ull << 32)) return CLLM_E_UNSUPPORTED;
     if (act_row_bytes(K, kind) + 16 * Q32_CHAIN_BYTES > 160 * 1024) return CLLM_E_UNSUPPORTED;
     if (padd && (pro != 1 || K > 4096 || !xout || xout == px)) return CLLM_E_UNSUPPORTED;

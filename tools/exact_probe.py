@@ -27,6 +27,8 @@ def report(name, got, want):
     bad = int(np.sum(bits(got) != bits(want)))
     rel = float(np.max(np.abs(got.astype(np.float64) - want)) / (np.max(np.abs(want)) + 1e-30))
     print(f"{'OK  ' if bad == 0 else 'DIFF'} {name}: {bad}/{want.size} words differ, max rel {rel:.2e}", flush=True)
+    if bad and bad > 4:
+        print('     first got', got[:6].tolist(), 'want', want[:6].tolist())
     if bad and bad <= 4:
         i = np.nonzero(bits(got) != bits(want))[0]
         print("     idx", i.tolist(), "got", got[i].tolist(), "want", want[i].tolist())
@@ -55,7 +57,7 @@ def main():
     # ---- the decode mat-vec with prologues (gemv_decode.hip): norm / plain / SiLU prologues, residual epilogue ----
     L = gpu.lib.get()
     for t in (O.Q4_K, O.Q4_0, O.Q8_0, O.Q4_1):
-        for K, N in ((4096, 6144), (4096, 512), (14336, 256), (2048, 100)):
+        for K, N in ((4096, 6144), (4096, 512), (14336, 256), (2048, 100), (4096, 16384), (1024, 64), (8192, 1032)):
             w = rand_blocks(t, N, K, rng)
             x = rng.standard_normal(K).astype(np.float32)
             nw = (1 + 0.1 * rng.standard_normal(K)).astype(np.float32)
