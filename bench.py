@@ -11,9 +11,14 @@ the timed region.
   N  > 1 : tensor-parallel shards (heads / ffn columns) with an all-reduce (RCCL over xGMI) on the
            residual stream after o_proj and down_proj ("scaling": "strong": the same model, N GPUs).
 
-Extra objects on the JSON line: "roofline" for the dominant kernel (the gate|up GEMV) from HIP events on the
-launch stream, and "cpu_baseline" = the reference's own CPU mul_mat (oracle/_ref, all host cores) on a bounded
-sample of the same workload.
+Extra objects on the JSON line (rank 0, N = 1):
+  "roofline"     the dominant kernel (the gate|up GEMV): HIP events on the launch stream; "traffic" = the PMC figure committed under profiles/
+                 for exactly this kernel ("traffic_source" names the file: counters cannot be sampled from inside this process)
+  "cpu_baseline" the reference HOST itself (oracle/_ref/ref_chat = chatllm.cpp's graph builder + ggml scheduler + CPU backend, compiled from
+                 /root/reference) decoding the same synthetic model end to end on this box's cores: median of 3 runs; "host_cores" = cores of the
+                 box, "cores" = threads used; "matvec_bound" = the mat-vec-only upper bound of the CPU path
+  "dropin"       the SAME unmodified host with every layer on our ggml module (-ngl all): the through-the-boundary number
+  "prefill"      BASELINE cfg3: Llama-3-8B shapes, Q4_0, one 4096-token prompt through the runner (median of 3), fraction of the matrix-core peak
 """
 import argparse
 import ctypes as C
@@ -110,19 +115,22 @@ def measure_dominant_kernel(pkg, cfg, wtype, iters=64):
     return {"kernel": "%s (gate/up GEMV %dx%d, decode form)" % (name, rows, H), "bytes_per_launch": nbytes, "avg_us": dur_s * 1e6, "gbs": nbytes / dur_s / 1e9}
 
 
+PMC_SUMMARY = os.path.join("profiles", "r02_pmc_summary.json")
+
+
 def pmc_traffic(kernel_label):
     """HBM bytes per launch of the dominant kernel from the PMC pass committed under profiles/ (FETCH_SIZE, corrected x2 for
     gfx950 as MI355X_MICROARCH.md prescribes); counters cannot be sampled from inside this process, so: the committed number
-    for exactly this kernel + shape, else null."""
+    for exactly this kernel + shape (and the file it comes from), else null."""
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_pmc_summary.json")) as f:
+        with open(os.path.join(ROOT, PMC_SUMMARY)) as f:
             tab = json.load(f)
         for k, v in tab.items():
             if k == kernel_label:
-                return v["hbm_read_bytes"]
+                return v["hbm_read_bytes"], PMC_SUMMARY + " (rocprofv3 --pmc FETCH_SIZE of this kernel and shape, x2 per MI355X_MICROARCH.md; collected by tools/prof_round.sh)"
     except Exception:
         pass
-    return None
+    return None, None
 
 
 def cpu_baseline(pkg, cfg, wtype, budget_s=20.0):
@@ -181,41 +189,87 @@ def cpu_baseline(pkg, cfg, wtype, budget_s=20.0):
         t_layer *= pkg.synth.weight_bytes_per_token(cfg, wtype) / cfg["n_layer"] / sum(N * pkg.tensor.row_size(t, K) for _, K, N, t in shapes[:2])
         sample = "scalar C restatement on 512-row samples of the qkv and o mat-vecs, extrapolated by bytes"
     tok_s = 1.0 / (t_layer * cfg["n_layer"] + t_head)
-    return {"value": tok_s, "unit": "tokens/s", "cores": cores, "kind": kind, "sample": sample}
+    return {"value": tok_s, "unit": "tokens/s", "threads": cores, "kind": kind, "sample": sample}
 
 
-def cpu_host_end_to_end(cfg, wtype_name, model_name, budget_tokens=12):
-    """the reference's own HOST (oracle/_ref/ref_chat: chatllm.cpp's model zoo, graph builder, ggml scheduler and CPU backend) decoding
-    the same synthetic model end to end -- what a user of the reference gets on this box's CPU.  Lower than cpu_baseline.value (which
-    times only the mat-vecs, fused shapes, weights resident): the host pays a thread-pool barrier per graph node.  None if unavailable."""
+def host_cores():
+    try:
+        return len(os.sched_getaffinity(0))
+    except AttributeError:
+        return os.cpu_count() or 1
+
+
+def write_ggmm(model_name, wtype_name, max_len, td):
+    import subprocess
+    mp = os.path.join(td, f"{model_name}-{wtype_name}.bin")
+    rc = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "make_ggmm.py"), "--config", model_name, "--wtype", wtype_name, "--max-len", str(max_len), "--fast",
+                         "--out", mp], capture_output=True, text=True)
+    if rc.returncode != 0:
+        raise RuntimeError("make_ggmm failed: " + rc.stderr[-400:])
+    return mp
+
+
+PROMPT_IDS = [1, 5, 9, 200, 31, 7, 11, 300, 2, 77, 123, 4567, 89, 1000, 2000, 3000]
+
+
+def run_ref_chat(mp, ngl, threads, n_decode, env=None, timeout=900):
+    """oracle/_ref/ref_chat MODEL NGL THREADS N_DECODE - IDS...: returns (tokens/s of its own decode timer, stderr)"""
     import re
     import subprocess
-    import tempfile
     ref = os.path.join(ROOT, "oracle", "_ref", "ref_chat")
-    if not os.path.exists(ref):
-        return None
-    try:
-        cores = len(os.sched_getaffinity(0))
-    except AttributeError:
-        cores = os.cpu_count() or 1
-    with tempfile.TemporaryDirectory(dir="/tmp") as td:
-        mp = os.path.join(td, "m.bin")
-        rc = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "make_ggmm.py"), "--config", model_name, "--wtype", wtype_name, "--max-len", "256", "--fast",
-                             "--out", mp], capture_output=True, text=True)
-        if rc.returncode != 0:
-            return None
-        best = None
-        for th in sorted({c for c in (64, 32) if c <= cores} or {cores}, reverse=True):
-            r = subprocess.run([ref, mp, "cpu", str(th), str(budget_tokens), "-"] + [str(i) for i in range(1, 17)], capture_output=True, text=True, timeout=600)
-            m = re.search(r"decode: (\d+) tokens in ([0-9.]+) ms", r.stderr)
-            if r.returncode == 0 and m:
-                v = int(m.group(1)) * 1e3 / float(m.group(2))
-                if best is None or v > best[0]:
-                    best = (v, th, int(m.group(1)))
-    if best is None:
-        return None
-    return {"value": best[0], "unit": "tokens/s", "threads": best[1],
-            "sample": "oracle/_ref/ref_chat (the reference host + its CPU backend) decoding %d tokens after a 16-token prompt, same synthetic model written as a GGMM file" % best[2]}
+    r = subprocess.run([ref, mp, ngl, str(threads), str(n_decode), "-"] + [str(i) for i in PROMPT_IDS], capture_output=True, text=True, timeout=timeout,
+                       env=dict(os.environ, **(env or {})))
+    m = re.search(r"decode: (\d+) tokens in ([0-9.]+) ms", r.stderr)
+    if r.returncode != 0 or not m:
+        raise RuntimeError("ref_chat failed: " + r.stderr[-400:])
+    return int(m.group(1)) * 1e3 / float(m.group(2)), r.stderr
+
+
+def cpu_host_end_to_end(mp, n_tokens=12):
+    """the reference's own HOST decoding the synthetic model end to end on its CPU backend -- what a user of the reference gets on this box:
+    thread count = the better of 32 / 64 (or all cores of a smaller box) on one probe run, then the median of 3 runs"""
+    cores = host_cores()
+    cand = sorted({c for c in (64, 32) if c <= cores} or {cores}, reverse=True)
+    probe = {th: run_ref_chat(mp, "cpu", th, n_tokens)[0] for th in cand}
+    th = max(probe, key=probe.get)
+    runs = sorted(run_ref_chat(mp, "cpu", th, n_tokens)[0] for _ in range(3))
+    return {"value": runs[1], "unit": "tokens/s", "cores": th, "host_cores": cores, "kind": "reference", "runs": runs,
+            "sample": "oracle/_ref/ref_chat (chatllm.cpp's host + ggml CPU backend, built from /root/reference, x86-64-v3) decoding %d tokens after a 16-token prompt, "
+                      "same synthetic model as a GGMM file; median of 3 runs at %d threads (best of %s)" % (n_tokens, th, cand)}
+
+
+def dropin_through_the_boundary(mp, n_decode=144):
+    """the unmodified reference host with every layer on our ggml module (libggml-hip.so -> the C ABI): decode tokens/s by the host's own timer
+    (the first 16 steps are left out: first launches, captures), calls per token from the module's statistics"""
+    import re
+    tok_s, err = run_ref_chat(mp, "all", 16, n_decode, env={"CLLM_HIP_STATS": "1"})
+    calls = [int(x) for x in re.findall(r"graph_compute: \d+ nodes -> (\d+) calls", err)]
+    per_graph = re.findall(r"per graph over the last 64: (.*)", err)
+    return {"tok_s": tok_s, "ms_per_token": 1e3 / tok_s, "calls_per_token": calls[-1] if calls else None, "n_decode": n_decode,
+            "host": "oracle/_ref/ref_chat -ngl all (unmodified chatllm.cpp host, ggml scheduler; module = chatllm.cpp_amd/host/ggml-hip.cpp)",
+            "breakdown_us": per_graph[-1] if per_graph else None}
+
+
+def prefill_cfg3(pkg, model_name, n_prompt=4096, reps=3):
+    """BASELINE cfg3: Q4_0 weights, one n_prompt-token prompt through the runner (cllm_llama_forward): median wall time, algorithmic FLOPs of SURVEY 8d"""
+    cfg = pkg.synth.config(model_name, max_len=(n_prompt + 63) // 64 * 64)
+    m = build_model(pkg, cfg, WTYPES["q4_0"], 0, 1)
+    prompt = np.random.default_rng(1234).integers(0, cfg["vocab"], n_prompt).astype(np.int32)
+    m.forward(prompt, n_past=0)
+    pkg.ops.sync()
+    ts = []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        m.forward(prompt, n_past=0)
+        pkg.ops.sync()
+        ts.append(time.perf_counter() - t0)
+    m.close()
+    dt = sorted(ts)[len(ts) // 2]
+    H, hd, F, L = cfg["hidden"], cfg["head_dim"], cfg["ffn"], cfg["n_layer"]
+    QD, KD = cfg["n_head"] * hd, cfg["n_kv_head"] * hd
+    flops = 2.0 * L * (H * (QD + 2 * KD) + QD * H + 3 * H * F) * n_prompt + 2.0 * 2 * n_prompt * n_prompt * hd * cfg["n_head"] * L
+    return {"ms": dt * 1e3, "tok_s": n_prompt / dt, "n_prompt": n_prompt, "wtype": "q4_0", "algorithmic_tflops": flops / dt / 1e12,
+            "mfma_frac": flops / dt / 5.0e15, "mfma_peak": "5.0e15 int8 dense (the linear layers run v_mfma_i32_*_i8; attention on f16 MFMA)", "frac_of_f16_peak_2.5e15": flops / dt / 2.5e15}
 
 
 def main():
@@ -226,7 +280,8 @@ def main():
     ap.add_argument("--model", default="llama3-8b")
     ap.add_argument("--wtype", default="q4_k", choices=sorted(WTYPES))
     ap.add_argument("--n-prompt", type=int, default=16)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the host runs (cpu_baseline, dropin) and the prefill leg")
+    ap.add_argument("--no-prefill", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch the fused decode kernels eagerly (for rocprofv3 kernel traces)")
     args = ap.parse_args()
 
@@ -334,24 +389,42 @@ def main():
         if world == 1:
             try:
                 k = measure_dominant_kernel(pkg, cfg, wtype)
+                traffic, tsrc = pmc_traffic(k["kernel"])
                 res["roofline"] = {"bound": "hbm", "achieved": k["gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": k["gbs"] / HBM_PEAK_GBS,
-                                   "traffic": pmc_traffic(k["kernel"]), "kernel": k["kernel"], "avg_us": k["avg_us"], "bytes_per_launch": k["bytes_per_launch"]}
+                                   "traffic": traffic, "traffic_source": tsrc, "kernel": k["kernel"], "avg_us": k["avg_us"], "bytes_per_launch": k["bytes_per_launch"]}
             except Exception as e:      # the throughput number stands on its own
                 res["roofline"] = {"error": str(e)}
+            res["host_cores"] = host_cores()
             if not args.no_cpu_baseline:
-                try:
-                    res["cpu_baseline"] = cpu_baseline(pkg, cfg, wtype)
+                import tempfile
+                m.close()                                    # the host runs below load their own copy of the model
+                m = None
+                with tempfile.TemporaryDirectory(dir="/tmp") as td:
+                    mp = None
                     try:
-                        e2e = cpu_host_end_to_end(cfg, args.wtype, args.model)
-                    except Exception as e:      # the baseline is a report, never a reason to lose the bench line
-                        log(f"cpu host end-to-end baseline failed: {e!r}")
-                        e2e = None
-                    if e2e:
-                        res["cpu_baseline"]["host_end_to_end"] = e2e
-                except Exception as e:
-                    res["cpu_baseline"] = {"error": str(e)}
+                        mp = write_ggmm(args.model, args.wtype, 512, td)
+                    except Exception as e:      # the baselines are reports, never a reason to lose the bench line
+                        log(f"GGMM file: {e!r}")
+                    try:
+                        res["cpu_baseline"] = cpu_host_end_to_end(mp) if mp else {"error": "no GGMM file"}
+                    except Exception as e:
+                        res["cpu_baseline"] = {"error": str(e)}
+                    try:
+                        res["cpu_baseline"]["matvec_bound"] = cpu_baseline(pkg, cfg, wtype)
+                    except Exception as e:
+                        log(f"mat-vec CPU bound failed: {e!r}")
+                    try:
+                        res["dropin"] = dropin_through_the_boundary(mp) if mp else {"error": "no GGMM file"}
+                    except Exception as e:
+                        res["dropin"] = {"error": str(e)}
+                if not args.no_prefill and args.model == "llama3-8b":
+                    try:
+                        res["prefill"] = prefill_cfg3(pkg, args.model)
+                    except Exception as e:
+                        res["prefill"] = {"error": str(e)}
         print(json.dumps(res), flush=True)
-    m.close()
+    if m is not None:
+        m.close()
     if dist is not None:
         dist.destroy_process_group()
 

@@ -198,6 +198,8 @@ static int interleave_rows(hipStream_t st, dweight & dst, dweight & a, dweight &
 
 static int finalize(cllm_llama * m, int qlen) {
     const cllm_llama_config & c = m->cfg;
+    // a sharded model without a collective would silently produce logits from partial o / down sums
+    if (c.tp_size > 1 && !m->tp_comm && !m->allreduce) FAIL(CLLM_E_INVALID, "llama: tp_size %d needs cllm_llama_set_tp_comm or cllm_llama_set_allreduce before the first forward", c.tp_size);
     const int64_t H = c.hidden, hd = c.head_dim, QD = (int64_t) m->nh * hd, KD = (int64_t) m->nkv * hd, F = m->F, V = c.vocab, ML = c.max_len;
     if (!m->finalized) {
         TRY(expect(m->tok_embd, "tok_embd", -1, cllm_row_size(m->tok_embd.type, H) * (size_t) V, false));

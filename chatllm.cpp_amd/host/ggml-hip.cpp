@@ -14,6 +14,7 @@
 
 #include "../../include/chatllm_hip.h"
 
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -36,8 +37,8 @@ struct hip_backend_ctx {
     // captured graph of the list that came twice in a row
     std::vector<uint8_t> last_sig, graph_sig; void * graph_exec = nullptr; bool graph_broken = false; long replays = 0, captures = 0;
 };
-struct hip_buffer_ctx { int device; void * base; uint64_t uid; uint64_t gen = 0; };     // gen: bumped by every write through the buffer interface
-uint64_t g_next_buffer_uid = 1;
+struct hip_buffer_ctx { int device; void * base; uint64_t uid; std::atomic<uint64_t> gen{0}; };     // gen: bumped by every write through the buffer interface
+std::atomic<uint64_t> g_next_buffer_uid{1};     // (accessory models own their own contexts and may run on other threads)
 
 // CLLM_HIP_STATS=1: where a token's wall time goes, seen from the module (host = everything between our entry points: the reference's
 // graph build, scheduler split and allocation, sampling)
@@ -84,26 +85,44 @@ void i32_forget(const void * lo, size_t n) {          // caller holds g_ring.m
     const char * a = (const char *) lo, * b = a + n;
     for (auto it = g_i32_vals.begin(); it != g_i32_vals.end();) { const char * k = (const char *) it->first; if (k + 4 > a && k < b) it = g_i32_vals.erase(it); else ++it; }
 }
-constexpr size_t k_ring_bytes = 256u << 10, k_ring_max = 4096;
-struct set_ring { char * base = nullptr; size_t head = 0; bool failed = false; bool pending[64] = {}; std::mutex m; } g_ring;
-void flush_sets() {
-    std::lock_guard<std::mutex> lock(g_ring.m);
-    for (int d = 0; d < 64; d++) if (g_ring.pending[d]) { cllm_set_device(d); cllm_stream_sync(nullptr); g_ring.pending[d] = false; }
-}
-bool ring_set(int device, void * dst, const void * data, size_t size) {      // device already current
-    std::lock_guard<std::mutex> lock(g_ring.m);
-    if (!g_ring.base && !g_ring.failed) { void * p = nullptr; if (cllm_host_malloc(&p, k_ring_bytes) == CLLM_OK) g_ring.base = (char *) p; else g_ring.failed = true; }
-    if (!g_ring.base || device < 0 || device >= 64) return false;
-    const size_t slot = (size + 63) & ~(size_t) 63;
-    if (g_ring.head + slot > k_ring_bytes) {            // wrap: every queued copy must have read its slot
-        for (int d = 0; d < 64; d++) if (g_ring.pending[d]) { cllm_set_device(d); cllm_stream_sync(nullptr); g_ring.pending[d] = false; }
-        cllm_set_device(device);
-        g_ring.head = 0;
+// Two page-locked rings share the scheme: `small` for the per-token scalars above, `bulk` for the loader -- chatllm uploads a model in 1,024,000-byte
+// slices (TensorInfo::read_tensor_data, src/chat.cpp:1322-1338): a blocking copy + synchronize per slice leaves the DMA engine idle while the host
+// reads the next slice from the file.  Through the bulk ring the slice is copied into pinned memory (its bytes are consumed when buf_set returns,
+// as the interface requires), the H2D copy is queued and the host goes on reading; the ring is waited for only when it wraps (every 64 MiB).
+struct set_ring {
+    size_t cap, max; char * base = nullptr; size_t head = 0; bool failed = false; bool pending[64] = {}; std::mutex m;
+    set_ring(size_t cap_, size_t max_) : cap(cap_), max(max_) {}
+};
+set_ring g_ring(256u << 10, 4096), g_bulk(64u << 20, 8u << 20);
+void flush_ring(set_ring & r) {
+    std::lock_guard<std::mutex> lock(r.m);
+    for (int d = 0; d < 64; d++) if (r.pending[d]) {
+        cllm_set_device(d);
+        if (cllm_stream_sync(nullptr) != CLLM_OK) GGML_LOG_ERROR("[ggml-hip] queued set_tensor copies on device %d failed: %s\n", d, cllm_last_error());
+        r.pending[d] = false;
     }
-    memcpy(g_ring.base + g_ring.head, data, size);
-    if (cllm_memcpy_h2d(dst, g_ring.base + g_ring.head, size, nullptr) != CLLM_OK) return false;
-    g_ring.head += slot; g_ring.pending[device] = true;
+}
+void flush_sets() { flush_ring(g_ring); flush_ring(g_bulk); }
+bool ring_set(set_ring & r, int device, void * dst, const void * data, size_t size) {      // device already current
+    std::lock_guard<std::mutex> lock(r.m);
+    if (!r.base && !r.failed) { void * p = nullptr; if (cllm_host_malloc(&p, r.cap) == CLLM_OK) r.base = (char *) p; else r.failed = true; }
+    if (!r.base || device < 0 || device >= 64 || size > r.max) return false;
+    const size_t slot = (size + 63) & ~(size_t) 63;
+    if (r.head + slot > r.cap) {            // wrap: every queued copy must have read its slot
+        for (int d = 0; d < 64; d++) if (r.pending[d]) { cllm_set_device(d); cllm_stream_sync(nullptr); r.pending[d] = false; }
+        cllm_set_device(device);
+        r.head = 0;
+    }
+    memcpy(r.base + r.head, data, size);
+    if (cllm_memcpy_h2d(dst, r.base + r.head, size, nullptr) != CLLM_OK) return false;
+    r.head += slot; r.pending[device] = true;
     return true;
+}
+// a host buffer of any size into device memory: through the bulk ring (asynchronous), else a blocking copy
+bool upload(int device, void * dst, const void * data, size_t size) {
+    static const bool sync_loader = getenv("CLLM_HIP_SYNC_LOAD") != nullptr;       // (A/B: the blocking path)
+    if (!sync_loader && ring_set(g_bulk, device, dst, data, size)) return true;
+    return cllm_memcpy_h2d(dst, data, size, nullptr) == CLLM_OK && cllm_stream_sync(nullptr) == CLLM_OK;
 }
 
 void packs_forget(uint64_t uid);
@@ -117,7 +136,7 @@ void * buf_base(ggml_backend_buffer_t b) { return ((hip_buffer_ctx *) b->context
 void buf_memset(ggml_backend_buffer_t b, ggml_tensor * t, uint8_t v, size_t off, size_t size) {
     cllm_set_device(((hip_buffer_ctx *) b->context)->device); ((hip_buffer_ctx *) b->context)->gen++;
     { std::lock_guard<std::mutex> lock(g_ring.m); i32_forget((char *) t->data + off, size); }
-    cllm_memset((char *) t->data + off, v, size, nullptr); cllm_stream_sync(nullptr);
+    if (cllm_memset((char *) t->data + off, v, size, nullptr) != CLLM_OK || cllm_stream_sync(nullptr) != CLLM_OK) GGML_LOG_ERROR("[ggml-hip] memset_tensor '%s' failed: %s\n", t->name, cllm_last_error());
 }
 void buf_set(ggml_backend_buffer_t b, ggml_tensor * t, const void * data, size_t off, size_t size) {
     ws_scope ws(g_ws.set_us); g_ws.sets++;
@@ -129,8 +148,8 @@ void buf_set(ggml_backend_buffer_t b, ggml_tensor * t, const void * data, size_t
         i32_forget((char *) t->data + off, size);
         if (size == 4 && off == 0 && t->type == GGML_TYPE_I32 && g_i32_vals.size() < 4096) memcpy(&g_i32_vals[t->data], data, 4);
     }
-    if (size <= k_ring_max && ring_set(c->device, (char *) t->data + off, data, size)) return;
-    cllm_memcpy_h2d((char *) t->data + off, data, size, nullptr); cllm_stream_sync(nullptr);
+    if (size <= g_ring.max && ring_set(g_ring, c->device, (char *) t->data + off, data, size)) return;
+    if (!upload(c->device, (char *) t->data + off, data, size)) GGML_LOG_ERROR("[ggml-hip] set_tensor '%s' (%zu bytes at %zu) failed: %s\n", t->name, size, off, cllm_last_error());
 }
 // get_tensor (the logits of every token: 513 KB for Llama-3): through a page-locked staging area -- the D2H copy into the host's pageable
 // destination is several times slower than DMA into pinned memory + a memcpy
@@ -148,10 +167,16 @@ void buf_get(ggml_backend_buffer_t b, const ggml_tensor * t, void * data, size_t
         g_stage = nullptr; g_stage_size = 0;
         if (cllm_host_malloc(&g_stage, k_stage_chunk) == CLLM_OK) g_stage_size = k_stage_chunk;
     }
-    if (size < 4096 || !g_stage) { cllm_memcpy_d2h(data, (const char *) t->data + off, size, nullptr); return; }
+    if (size < 4096 || !g_stage) {
+        if (cllm_memcpy_d2h(data, (const char *) t->data + off, size, nullptr) != CLLM_OK) GGML_LOG_ERROR("[ggml-hip] get_tensor '%s' failed: %s\n", t->name, cllm_last_error());
+        return;
+    }
     for (size_t done = 0; done < size; done += g_stage_size) {
         const size_t n = size - done < g_stage_size ? size - done : g_stage_size;
-        cllm_memcpy_d2h(g_stage, (const char *) t->data + off + done, n, nullptr);     // synchronous
+        if (cllm_memcpy_d2h(g_stage, (const char *) t->data + off + done, n, nullptr) != CLLM_OK) {     // synchronous
+            GGML_LOG_ERROR("[ggml-hip] get_tensor '%s' failed: %s\n", t->name, cllm_last_error());
+            return;
+        }
         memcpy((char *) data + done, g_stage, n);
     }
 }
@@ -160,16 +185,20 @@ bool buf_cpy(ggml_backend_buffer_t b, const ggml_tensor * src, ggml_tensor * dst
     flush_sets();
     cllm_set_device(((hip_buffer_ctx *) b->context)->device); ((hip_buffer_ctx *) b->context)->gen++;
     { std::lock_guard<std::mutex> lock(g_ring.m); i32_forget(dst->data, ggml_nbytes(dst)); }
-    if (ggml_backend_buffer_is_host(src->buffer)) { cllm_memcpy_h2d(dst->data, src->data, ggml_nbytes(src), nullptr); cllm_stream_sync(nullptr); return true; }
+    if (ggml_backend_buffer_is_host(src->buffer)) {
+        if (cllm_memcpy_h2d(dst->data, src->data, ggml_nbytes(src), nullptr) != CLLM_OK || cllm_stream_sync(nullptr) != CLLM_OK) { GGML_LOG_ERROR("[ggml-hip] cpy_tensor (host -> '%s') failed: %s\n", dst->name, cllm_last_error()); return false; }
+        return true;
+    }
     if (src->buffer && src->buffer->iface.get_base == buf_base) {     // another buffer of this module (any device: peer access through hipMemcpy)
-        cllm_memcpy_d2d(dst->data, src->data, ggml_nbytes(src), nullptr); cllm_stream_sync(nullptr); return true;
+        if (cllm_memcpy_d2d(dst->data, src->data, ggml_nbytes(src), nullptr) != CLLM_OK || cllm_stream_sync(nullptr) != CLLM_OK) { GGML_LOG_ERROR("[ggml-hip] cpy_tensor ('%s' -> '%s') failed: %s\n", src->name, dst->name, cllm_last_error()); return false; }
+        return true;
     }
     return false;
 }
 void buf_clear(ggml_backend_buffer_t b, uint8_t v) {
     auto * c = (hip_buffer_ctx *) b->context; cllm_set_device(c->device); c->gen++;
     { std::lock_guard<std::mutex> lock(g_ring.m); i32_forget(c->base, b->size); }
-    cllm_memset(c->base, v, b->size, nullptr); cllm_stream_sync(nullptr);
+    if (cllm_memset(c->base, v, b->size, nullptr) != CLLM_OK || cllm_stream_sync(nullptr) != CLLM_OK) GGML_LOG_ERROR("[ggml-hip] clear failed: %s\n", cllm_last_error());
 }
 const ggml_backend_buffer_i k_buffer_i = { buf_free, buf_base, nullptr, buf_memset, buf_set, buf_get, buf_cpy, buf_clear, nullptr };
 
@@ -204,7 +233,7 @@ void * get_pack(int device, void * stream, const ggml_tensor * const * w, int n,
     bool valid = e.n == n && e.device == device;
     for (int i = 0; i < n && valid; i++) {
         const auto * bc = (const hip_buffer_ctx *) w[i]->buffer->context;
-        valid = e.src[i] == w[i]->data && e.uid[i] == bc->uid && e.gen[i] == bc->gen;
+        valid = e.src[i] == w[i]->data && e.uid[i] == bc->uid && e.gen[i] == bc->gen.load();
     }
     if (valid) return e.refused ? nullptr : e.data;
     if (e.data) { cllm_stream_sync(stream); cllm_free(e.data); g_pack_bytes -= e.bytes; }
@@ -212,7 +241,7 @@ void * get_pack(int device, void * stream, const ggml_tensor * const * w, int n,
     size_t bytes = 0; int64_t rows[3]; const void * srcs[3];
     for (int i = 0; i < n; i++) {
         const auto * bc = (const hip_buffer_ctx *) w[i]->buffer->context;
-        e.src[i] = w[i]->data; e.uid[i] = bc->uid; e.gen[i] = bc->gen;
+        e.src[i] = w[i]->data; e.uid[i] = bc->uid; e.gen[i] = bc->gen.load();
         if (!flat && w[i]->ne[2] > 1 && w[i]->nb[2] != (size_t) w[i]->ne[1] * w[i]->nb[1]) return nullptr;      // expert slabs must be contiguous
         rows[i] = flat ? (int64_t) ggml_nbytes(w[i]) : w[i]->ne[1] * w[i]->ne[2]; srcs[i] = w[i]->data; bytes += flat ? ggml_nbytes(w[i]) : (size_t) rows[i] * w[i]->nb[1];
     }
@@ -237,7 +266,7 @@ ggml_backend_buffer_t buft_alloc(ggml_backend_buffer_type_t t, size_t size) {
     cllm_set_device(d->id);
     void * p = nullptr;
     if (cllm_malloc(&p, size ? size : 1) != CLLM_OK) { HIPB_LOG("alloc of %zu bytes failed: %s", size, cllm_last_error()); return nullptr; }
-    return ggml_backend_buffer_init(t, k_buffer_i, new hip_buffer_ctx{ d->id, p, g_next_buffer_uid++ }, size);
+    return ggml_backend_buffer_init(t, k_buffer_i, new hip_buffer_ctx{ d->id, p, g_next_buffer_uid.fetch_add(1) }, size);
 }
 size_t buft_align(ggml_backend_buffer_type_t) { return 256; }
 bool buft_is_host(ggml_backend_buffer_type_t) { return false; }
@@ -252,11 +281,16 @@ bool dev_supports_op(ggml_backend_dev_t, const ggml_tensor * op) {
         case GGML_OP_NONE: case GGML_OP_RESHAPE: case GGML_OP_VIEW: case GGML_OP_PERMUTE: case GGML_OP_TRANSPOSE: return true;
         case GGML_OP_MUL_MAT:
             if (!f32_dense(b) || op->type != GGML_TYPE_F32 || !dense_rows(a)) return false;
-            if (is_q(a->type)) return a->ne[0] % 32 == 0 && (a->type != GGML_TYPE_Q4_K || (a->nb[1] % 16 == 0)) && b->nb[1] % 16 == 0;
-            return a->type == GGML_TYPE_F16 || a->type == GGML_TYPE_F32;
+            // (the predicates of cllm_op_mul_mat / check_mm that do not depend on the data pointers: what is declined here runs on the CPU backend
+            // instead of failing in graph_compute; buffers of this module are 256-byte aligned and ggml-alloc keeps that alignment)
+            if (is_q(a->type)) return a->ne[0] % 32 == 0 && b->nb[1] % 16 == 0 && b->nb[2] % 16 == 0 && b->nb[3] % 16 == 0 &&
+                                      (a->type != GGML_TYPE_Q4_K || (a->nb[1] % 16 == 0 && a->nb[2] % 16 == 0 && a->nb[3] % 16 == 0)) &&
+                                      (a->type != GGML_TYPE_Q4_1 || (a->nb[1] % 4 == 0 && a->nb[2] % 4 == 0 && a->nb[3] % 4 == 0));
+            return (a->type == GGML_TYPE_F16 || a->type == GGML_TYPE_F32) && a->ne[2] * a->ne[3] <= 65535;
         case GGML_OP_MUL_MAT_ID:
-            return is_q(a->type) && f32_dense(b) && op->src[2] && op->src[2]->type == GGML_TYPE_I32 && a->ne[3] == 1 && b->ne[3] == 1 &&
-                   (b->ne[1] == 1 || b->ne[1] == op->src[2]->ne[0]) && op->src[2]->ne[0] * op->src[2]->ne[1] <= 65535;
+            return is_q(a->type) && f32_dense(b) && op->src[2] && op->src[2]->type == GGML_TYPE_I32 && a->ne[3] == 1 && b->ne[3] == 1 && a->ne[0] % 32 == 0 &&
+                   (b->ne[1] == 1 || b->ne[1] == op->src[2]->ne[0]) && op->src[2]->ne[0] * op->src[2]->ne[1] <= 65535 && b->nb[1] % 16 == 0 && b->nb[2] % 16 == 0 &&
+                   (a->type != GGML_TYPE_Q4_K || (a->nb[1] % 16 == 0 && a->nb[2] % 16 == 0)) && (a->type != GGML_TYPE_Q4_1 || (a->nb[1] % 4 == 0 && a->nb[2] % 4 == 0));
         case GGML_OP_RMS_NORM: return f32_dense(a) && op->type == GGML_TYPE_F32;
         case GGML_OP_ADD: case GGML_OP_MUL: case GGML_OP_DIV: return a->type == GGML_TYPE_F32 && b->type == GGML_TYPE_F32 && op->type == GGML_TYPE_F32 && ggml_can_repeat(b, a);
         case GGML_OP_SUM_ROWS: return f32_dense(a) && f32_dense(op);
@@ -340,6 +374,7 @@ struct fused_mv {
     int node = -1;                      // the MUL_MAT node
     int ga = -1, gb = -1;               // pro 4: the nodes producing px (gate) and pw (up)
     int group = -1;                     // member of a merged launch (fuse_plan::groups)
+    bool alias = false;                 // dst overlaps an input every workgroup reads in its prologue (ggml-alloc re-used a freed parent's block): stage the output
 };
 struct merge_group {
     int n = 0, member[3] = { -1, -1, -1 };      // entries of mvs, in packed row order
@@ -358,6 +393,7 @@ struct fused_attn {
     int wq = -1, wk = -1, wv = -1;      // level 2: entries of mvs producing the un-rotated q / k / v
     const float * q = nullptr;          // level 1: the rotated q
     const int32_t * pos = nullptr;      // I32 [1] on the device: the position == cached length - 1
+    bool alias = false;                 // level 1: out overlaps the rotated q other heads still read: stage the output
     int nh = 0, nkv = 0, hd = 0, mode = 0;
     float freq_base = 0.0f;
     int64_t n_kv = 0, ML = 0;
@@ -619,7 +655,7 @@ fuse_plan make_plan(ggml_cgraph * g) {
     auto same_input = [&](const fused_mv & a, const fused_mv & b, bool with_bias) {
         const ggml_tensor * wa = ggml_graph_node(g, a.node)->src[0], * wb = ggml_graph_node(g, b.node)->src[0];
         const bool epi_ok = with_bias ? (is_bias(a) && is_bias(b)) : (!a.resid && !b.resid);
-        return a.pro == 1 && b.pro == 1 && a.px == b.px && a.pw == b.pw && a.eps == b.eps && epi_ok && a.group < 0 && b.group < 0 &&
+        return a.pro == 1 && b.pro == 1 && a.px == b.px && a.pw == b.pw && a.eps == b.eps && epi_ok && a.group < 0 && b.group < 0 && !a.alias && !b.alias &&
                wa->type == wb->type && wa->ne[0] == wb->ne[0] && wa->nb[1] == wb->nb[1];
     };
     for (const fused_attn & A : P.attns) {
@@ -643,6 +679,19 @@ fuse_plan make_plan(ggml_cgraph * g) {
         P.groups.push_back(G);
     }
     for (int j = 0; j < n; j++) if (P.mv[j] >= 0 && !P.mvs[P.mv[j]].dst) P.mvs[P.mv[j]].dst = (float *) ggml_graph_node(g, j)->data;
+    // A fused mat-vec has no grid-wide barrier between its prologue (EVERY workgroup reads all of px / pw) and the first stores of dst.
+    // ggml-alloc allocates a node before it frees the node's parents, but the tensors a fused launch swallows (the norm's input is not one of
+    // them; `up` of SILU->MUL(up)->MUL_MAT, the normalised activation ...) may already be free when dst is placed -- so dst can land on an
+    // input.  Such launches write to module scratch and are copied into place afterwards (graph_compute); an in-place residual (dst == resid)
+    // is fine: every element is read and written by the same lane.
+    static const bool force_stage = getenv("CLLM_HIP_FORCE_STAGE") != nullptr;      // (tests: take the staged path everywhere)
+    for (fused_mv & f : P.mvs) {
+        if (f.node < 0 || !f.dst) continue;
+        const ggml_tensor * w = ggml_graph_node(g, f.node)->src[0];
+        const size_t nb = (size_t) w->ne[1] * 4, kb = (size_t) w->ne[0] * 4;
+        f.alias = force_stage || (f.px && overlap(f.dst, nb, f.px, kb)) || (f.pw && overlap(f.dst, nb, f.pw, kb));
+    }
+    for (fused_attn & A : P.attns) if (A.level == 1) A.alias = force_stage || overlap(A.out, (size_t) A.nh * A.hd * 4, A.q, (size_t) A.nh * A.hd * 4);
     // ---- what the patterns above left: element-wise pairs and the tail of a sparse-MoE block
     auto strip = [&](const ggml_tensor * t) { while (t && t->op == GGML_OP_RESHAPE) t = t->src[0]; return t; };
     auto all_once = [&](const ggml_tensor * from, const ggml_tensor * to) {      // the RESHAPE chain from `from` down to (excluding) `to`: every node used once
@@ -746,7 +795,8 @@ fuse_plan make_plan(ggml_cgraph * g) {
 // launches are captured on the way.  Any difference -- another address, shape, scalar, fusion decision -- simply issues the calls.
 // Measured (Llama-3-8B Q4_K through the unmodified host, one MI355X): the host time inside graph_compute drops from 586 to 74 us per
 // token, but the token is GPU-bound -- issue + synchronize is 1.75 ms either way (the launches were already running ahead of the GPU) --
-// so wall time does not move.  It is therefore OFF by default (CLLM_HIP_GRAPH=1 turns it on: useful where host cores are scarce).
+// so wall time barely moves -- but the host thread is free ~0.5 ms earlier per token and the GPU sees no launch gaps.  ON by default
+// (CLLM_HIP_GRAPH=0 turns it off); every replayed list is byte-identical to the calls it stands for (tests/test_gpu_dropin.py).
 struct sig_writer {
     std::vector<uint8_t> & b;
     void raw(const void * p, size_t n) { const uint8_t * q = (const uint8_t *) p; b.insert(b.end(), q, q + n); }
@@ -791,11 +841,15 @@ ggml_status be_graph_compute(ggml_backend_t backend, ggml_cgraph * g) {
         const size_t a = ((size_t) ggml_graph_node(g, plan.mvs[G.member[0]].node)->ne[0] * 4 + 255) & ~(size_t) 255;
         if (a > act_bytes) act_bytes = a;
     }
-    float * a_cs = nullptr, * a_qkv = nullptr, * a_act = nullptr; void * a_scores = nullptr;
-    if (qkv_bytes || act_bytes) {
-        if (int rc = ensure_abuf(c, 1024 + qkv_bytes + act_bytes + score_bytes)) { HIPB_LOG("fusion scratch: %s", cllm_last_error()); return rc == CLLM_E_ALLOC ? GGML_STATUS_ALLOC_FAILED : GGML_STATUS_FAILED; }
+    size_t stage_bytes = 0;              // outputs of fused launches whose dst aliases one of their inputs (see make_plan)
+    for (const fused_mv & f : plan.mvs) if (f.alias) { const size_t b = ((size_t) ggml_graph_node(g, f.node)->src[0]->ne[1] * 4 + 255) & ~(size_t) 255; if (b > stage_bytes) stage_bytes = b; }
+    for (const fused_attn & A : plan.attns) if (A.alias) { const size_t b = ((size_t) A.nh * A.hd * 4 + 255) & ~(size_t) 255; if (b > stage_bytes) stage_bytes = b; }
+    float * a_cs = nullptr, * a_qkv = nullptr, * a_act = nullptr, * a_stage = nullptr; void * a_scores = nullptr;
+    if (qkv_bytes || act_bytes || stage_bytes) {
+        if (int rc = ensure_abuf(c, 1024 + qkv_bytes + act_bytes + score_bytes + stage_bytes)) { HIPB_LOG("fusion scratch: %s", cllm_last_error()); return rc == CLLM_E_ALLOC ? GGML_STATUS_ALLOC_FAILED : GGML_STATUS_FAILED; }
         a_cs = (float *) c->abuf; a_qkv = (float *)((char *) c->abuf + 1024); a_act = (float *)((char *) c->abuf + 1024 + qkv_bytes);
         a_scores = (char *) c->abuf + 1024 + qkv_bytes + act_bytes;
+        a_stage = (float *)((char *) c->abuf + 1024 + qkv_bytes + act_bytes + score_bytes);
         for (const fused_attn & A : plan.attns) if (A.level == 2) {
             plan.mvs[A.wq].dst = a_qkv; plan.mvs[A.wk].dst = a_qkv + (size_t) A.hd * A.nh; plan.mvs[A.wv].dst = a_qkv + (size_t) A.hd * (A.nh + A.nkv);
         }
@@ -852,7 +906,10 @@ ggml_status be_graph_compute(ggml_backend_t backend, ggml_cgraph * g) {
                     }
                     if (G.state == 1 || rc != CLLM_OK) break;
                 }
-                rc = CALL(cllm_op_mul_mat_vec_fused, st, &da, f.pro, f.px, f.pw, f.eps, 0, f.resid, f.dst);
+                if (f.alias) {       // staged: dst overlaps px / pw (with an in-place residual the staged launch still reads resid == the final dst: no hazard)
+                    rc = CALL(cllm_op_mul_mat_vec_fused, st, &da, f.pro, f.px, f.pw, f.eps, 0, f.resid, a_stage);
+                    if (rc == CLLM_OK) rc = CALL(cllm_memcpy_d2d, (void *) f.dst, (const void *) a_stage, (size_t) a->ne[1] * 4, st);
+                } else rc = CALL(cllm_op_mul_mat_vec_fused, st, &da, f.pro, f.px, f.pw, f.eps, 0, f.resid, f.dst);
             } else {
                 const size_t need = cllm_mul_mat_wsize(&da, &db);
                 if ((rc = ensure_wdata(c, need))) break;
@@ -930,6 +987,9 @@ ggml_status be_graph_compute(ggml_backend_t backend, ggml_cgraph * g) {
                     }
                     rc = CALL(cllm_op_rope_kv_attn_decode, st, a_qkv, A.pos, table ? a_cs : nullptr, A.freq_base, sw ? (int64_t)(cllm_attn_decode_wsize(A.n_kv, A.nh, A.ML) != 0) : A.n_kv, A.nh, A.nkv, A.hd, A.mode, A.k_cache, A.v_cache, A.ML,
                                                      A.out, score_bytes ? a_scores : nullptr, score_bytes);
+                } else if (A.alias) {
+                    rc = CALL(cllm_op_attn_decode, st, A.q, A.pos, A.nh, A.nkv, A.hd, A.k_cache, A.v_cache, A.ML, a_stage);
+                    if (rc == CLLM_OK) rc = CALL(cllm_memcpy_d2d, (void *) A.out, (const void *) a_stage, (size_t) A.nh * A.hd * 4, st);
                 } else rc = CALL(cllm_op_attn_decode, st, A.q, A.pos, A.nh, A.nkv, A.hd, A.k_cache, A.v_cache, A.ML, A.out);
             } else rc = CALL(cllm_op_cpy, st, &da, &d); break;
             case GGML_OP_GET_ROWS: rc = CALL(cllm_op_get_rows, st, &da, &db, &d); break;
@@ -943,7 +1003,7 @@ ggml_status be_graph_compute(ggml_backend_t backend, ggml_cgraph * g) {
     return GGML_STATUS_SUCCESS;
 #undef CALL
     };
-    static const bool no_graph = !(getenv("CLLM_HIP_GRAPH") && atoi(getenv("CLLM_HIP_GRAPH")) != 0);
+    static const bool no_graph = getenv("CLLM_HIP_GRAPH") && atoi(getenv("CLLM_HIP_GRAPH")) == 0;      // default: replay; CLLM_HIP_GRAPH=0 issues every call
     bool replayed = false;
     if (no_graph || c->graph_broken) {
         const ggml_status rs = walk(plan, nullptr);
@@ -1064,9 +1124,8 @@ GGML_BACKEND_API int ggml_backend_score(void);
 }
 
 ggml_backend_reg_t ggml_backend_init(void) {
-    static bool done = false;
-    if (!done) {
-        done = true;
+    static std::once_flag once;
+    std::call_once(once, [] {
         const int n = cllm_device_count();
         g_dev_objs.reserve(n);
         for (int i = 0; i < n; i++) {
@@ -1079,7 +1138,7 @@ ggml_backend_reg_t ggml_backend_init(void) {
             d->buft = ggml_backend_buffer_type{ k_buft_i, &g_dev_objs.back(), d };
         }
         g_reg = ggml_backend_reg{ GGML_BACKEND_API_VERSION, k_reg_i, nullptr };
-    }
+    });
     return &g_reg;
 }
 int ggml_backend_score(void) { return cllm_device_count() > 0 ? 100 : 0; }

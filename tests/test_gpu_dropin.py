@@ -63,7 +63,10 @@ def test_module_node_fusion_does_not_change_a_bit(gpu, tmp_path, wname, wt, over
     # cache-write nodes; attn0: mat-vec and soft_max patterns only; nodes: one call per node
     # nopack: no merged launches over row-repacked weight copies (q|k|v, gate/up)
     # graph: a decode step's launch list is captured the second time it comes and replayed from then on (opt-in)
-    for mode, extra in (("fused", {}), ("graph", {"CLLM_HIP_GRAPH": "1"}), ("nopack", {"CLLM_HIP_PACK": "0"}), ("attn1", {"CLLM_HIP_FUSE_ATTN": "1"}), ("attn0", {"CLLM_HIP_FUSE_ATTN": "0"}),
+    # stage: every fused mat-vec / level-1 attention writes to module scratch and is copied into place -- the path taken when ggml-alloc hands a
+    # fused launch an output block that overlaps one of its inputs (a freed parent's memory); nograph: every call issued, no launch-list replay
+    for mode, extra in (("fused", {}), ("nograph", {"CLLM_HIP_GRAPH": "0"}), ("nopack", {"CLLM_HIP_PACK": "0"}), ("stage", {"CLLM_HIP_FORCE_STAGE": "1", "CLLM_HIP_PACK": "0"}),
+                        ("stage1", {"CLLM_HIP_FORCE_STAGE": "1", "CLLM_HIP_FUSE_ATTN": "1"}), ("attn1", {"CLLM_HIP_FUSE_ATTN": "1"}), ("attn0", {"CLLM_HIP_FUSE_ATTN": "0"}),
                         ("nodes", {"CLLM_HIP_NO_FUSE": "1"})):
         lp = str(tmp_path / f"l_{mode}.bin")
         env = dict(os.environ, CLLM_HIP_STATS="1", **extra)
@@ -79,9 +82,9 @@ def test_module_node_fusion_does_not_change_a_bit(gpu, tmp_path, wname, wt, over
     merged = max(int(re.search(r"(\d+) merged", ln).group(1)) for ln in out["fused"][2])
     assert merged == 2 * n_layer if not over else merged >= n_layer, out["fused"][2][-3:]             # q|k|v and gate/up of every layer
     assert all(" 0 merged" in ln for ln in out["nopack"][2])
-    assert sum("replayed from the captured graph" in ln for ln in out["graph"][2]) >= 7, out["graph"][2]     # 10 decode steps: issue, capture, then replays
-    assert not any("replayed" in ln for ln in out["fused"][2])
-    for mode in ("fused", "graph", "nopack", "attn1", "attn0"):
+    assert sum("replayed from the captured graph" in ln for ln in out["fused"][2]) >= 7, out["fused"][2]     # 10 decode steps: issue, capture, then replays (the default)
+    assert not any("replayed" in ln for ln in out["nograph"][2])
+    for mode in ("fused", "nograph", "nopack", "stage", "stage1", "attn1", "attn0"):
         assert out[mode][0] == out["nodes"][0], mode
         assert out[mode][1] == out["nodes"][1], mode
 
