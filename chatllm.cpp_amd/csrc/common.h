@@ -167,6 +167,10 @@ __device__ __forceinline__ double rms_block_sumsq_1024_one(f32x4 v, bool has, do
     return tot;
 }
 
+// workgroup barrier for data exchanged through LDS only: __syncthreads() also drains vmcnt, i.e. waits for every global load in flight --
+// which is exactly what a latency-bound kernel prefetches ACROSS its phases.  LDS operations of a wave complete in order: lgkmcnt(0) + s_barrier.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 // load through the scalar cache (p must be wave-uniform; the data must not have been written by this kernel before).
 // Scalar loads have their own counter (lgkmcnt), so they do not serialise against outstanding vector-memory prefetches.
 __device__ __forceinline__ float uniform_load_f32(const float * p) {

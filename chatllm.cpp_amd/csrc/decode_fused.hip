@@ -259,10 +259,8 @@ __global__ void __launch_bounds__(1024) k_attn_dec(const float * __restrict__ qk
     for (int u = 0; u < U; u++) {
         const int i0 = ib0 + u * 64;
 #pragma unroll
-        for (int i = 0; i < NCH; i++) {
-            kr0[u][i] = 0;
-            if (i0 < pos) kr0[u][i] = *(const uint32_t *)(k_cache + (int64_t) i0 * KD + g * HD + 32 * i + 2 * c16);      // row `pos` is the new k (LDS)
-        }
+        for (int i = 0; i < NCH; i++)        // unconditional (clamped) loads: branches around loads cost the compiler its vmcnt bookkeeping (it then waits with vmcnt(0))
+            kr0[u][i] = *(const uint32_t *)(k_cache + (int64_t)(i0 < pos ? i0 : 0) * KD + g * HD + 32 * i + 2 * c16);      // row `pos` is the new k (LDS)
     }
     const int np = n_kv & ~31, nch = np >> 5;
     uint32_t vc0[VU][VPF];
@@ -270,7 +268,7 @@ __global__ void __launch_bounds__(1024) k_attn_dec(const float * __restrict__ qk
     for (int u = 0; u < VU; u++) {
         const uint16_t * vr = v_cache + ((int64_t) g * HD + ib0 + u * 64) * ML;
 #pragma unroll
-        for (int i = 0; i < VPF; i++) { vc0[u][i] = 0; if (i < nch) vc0[u][i] = *(const uint32_t *)(vr + 32 * i + 2 * c16); }
+        for (int i = 0; i < VPF; i++) vc0[u][i] = *(const uint32_t *)(vr + 32 * (i < nch ? i : 0) + 2 * c16);
     }
 
     TS(0);
@@ -280,7 +278,7 @@ __global__ void __launch_bounds__(1024) k_attn_dec(const float * __restrict__ qk
         float * o = which == 0 ? qs : knew;
         o[ic] = h2f(f2h(y0)); o[ic + off] = h2f(f2h(y1));             // q: src1 of K.Q is rounded to fp16; k: the cache is fp16
     } else if (is_v) vnew[tid - 2 * half] = h2f(f2h(px0));
-    __syncthreads();
+    lds_barrier();
     if (blockIdx.x == 0 && tid < HD) {
         k_cache[(int64_t) pos * KD + g * HD + tid] = f2h(knew[tid]);
         v_cache[((int64_t) g * HD + tid) * ML + pos] = f2h(vnew[tid]);
@@ -296,7 +294,7 @@ __global__ void __launch_bounds__(1024) k_attn_dec(const float * __restrict__ qk
 #pragma unroll
             for (int i = 0; i < NCH; i++) {
                 r[u][i] = kr0[u][i];
-                if (ib != ib0) { r[u][i] = 0; if (i0 < pos) r[u][i] = *(const uint32_t *)(k_cache + (int64_t) i0 * KD + g * HD + 32 * i + 2 * c16); }
+                if (ib != ib0) r[u][i] = *(const uint32_t *)(k_cache + (int64_t)(i0 < pos ? i0 : 0) * KD + g * HD + 32 * i + 2 * c16);
             }
         }
 #pragma unroll
@@ -314,15 +312,26 @@ __global__ void __launch_bounds__(1024) k_attn_dec(const float * __restrict__ qk
             if (c16 == 0) sc[i0] = v * scale;                             // the SCALE node
         }
     }
-    __syncthreads();
+    lds_barrier();
     TS(2);
 
+    // ---- the next VPF chunks of the V^T rows and the leftover elements are requested here: the soft_max hides their latency (contexts up to
+    //      16 chunks = 512 positions never wait in (6); small code on purpose: a launch starts with a cold instruction cache) ----
+    uint32_t vc1[VU][VPF]; uint16_t vtl[VU][2];
+#pragma unroll
+    for (int u = 0; u < VU; u++) {
+        const uint16_t * vr = v_cache + ((int64_t) g * HD + ib0 + u * 64) * ML;
+#pragma unroll
+        for (int i = 0; i < VPF; i++) vc1[u][i] = *(const uint32_t *)(vr + 32 * (VPF + i < nch ? VPF + i : 0) + 2 * c16);
+#pragma unroll
+        for (int t = 0; t < 2; t++) { const int e = np + 2 * c16 + t; vtl[u][t] = vr[e < n_kv ? e : 0]; }
+    }
     // ---- (5) soft_max over sc[0..n_kv): same partition as k_soft_max (one wave, lane = groups of 8) ----
     float mx = -INFINITY;
     for (int i = tid; i < n_kv; i += 1024) mx = fmaxf(mx, sc[i]);
     mx = wave_max(mx);
     if (lane == 0) red_f[wave] = mx;
-    __syncthreads();
+    lds_barrier();
     mx = red_f[0];
 #pragma unroll
     for (int w = 1; w < 16; w++) mx = fmaxf(mx, red_f[w]);
@@ -340,10 +349,10 @@ __global__ void __launch_bounds__(1024) k_attn_dec(const float * __restrict__ qk
         sum = wave_sum_d(sum);
         if (lane == 0) red_d[0] = sum;
     }
-    __syncthreads();
+    lds_barrier();
     const float inv = (float)(1.0 / red_d[0]);
     for (int i = tid; i < n_kv; i += 1024) sc[i] = h2f(f2h(sc[i] * inv));   // probability, then its fp16 rounding for V.P
-    __syncthreads();
+    lds_barrier();
     TS(3);
 
     // ---- (6) ctx = V . P: chunks of 32 cached positions in order, then the n_kv mod 32 leftovers in double (products staged in LDS) ----
@@ -366,7 +375,7 @@ __global__ void __launch_bounds__(1024) k_attn_dec(const float * __restrict__ qk
         for (int i8 = VPF; i8 < nch; i8 += 8) {
             uint32_t rr[8];
 #pragma unroll
-            for (int i = 0; i < 8; i++) { rr[i] = 0; if (i8 + i < nch) rr[i] = *(const uint32_t *)(vr + 32 * (i8 + i) + 2 * c16); }
+            for (int i = 0; i < 8; i++) { rr[i] = vc1[u][i]; if (i8 != VPF) rr[i] = *(const uint32_t *)(vr + 32 * (i8 + i < nch ? i8 + i : 0) + 2 * c16); }
 #pragma unroll
             for (int i = 0; i < 8; i++) {
                 if (i8 + i < nch) {
@@ -380,7 +389,7 @@ __global__ void __launch_bounds__(1024) k_attn_dec(const float * __restrict__ qk
 #pragma unroll
         for (int t = 0; t < 2; t++) {
             const int e = np + 2 * c16 + t;
-            if (e < n_kv) tailp[2 * c16 + t] = (e == pos ? vfresh : h2f(vr[e])) * sc[e];
+            if (e < n_kv) tailp[2 * c16 + t] = (e == pos ? vfresh : h2f(vtl[u][t])) * sc[e];
         }
         wave_lds_fence();
         if (c16 == 0) {
