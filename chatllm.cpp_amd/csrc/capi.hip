@@ -235,7 +235,12 @@ extern "C" int cllm_op_mul_mat(void * stream, const cllm_tensor * src0, const cl
         d.data += i12 * d.nb[2] + i13 * d.nb[3];
         const char * act = (const char *) wdata + (size_t)(i12 * src1->ne[1] + i13 * src1->ne[1] * src1->ne[2]) * stride;
         if (src1->ne[1] >= mmq_min_cols()) {
-            rc = launch_mmq(st, src0->type, w, act, stride, x, d);
+            rc = CLLM_E_UNSUPPORTED;
+            if (prefill_f16_enabled()) {            // opt-in: dequantize -> dense fp16 GEMM (dense_f16.hip); a different computation than the reference's
+                tview x1 = x; x1.data += i12 * x.nb[2] + i13 * x.nb[3];
+                rc = launch_dense_f16(st, src0->type, w, x1, d);
+            }
+            if (rc == CLLM_E_UNSUPPORTED) rc = launch_mmq(st, src0->type, w, act, stride, x, d);
             if (rc == CLLM_E_UNSUPPORTED) rc = launch_mmvq(st, src0->type, w, act, stride, src1->ne[1], x, d);
         } else {
             rc = launch_mmvq(st, src0->type, w, act, stride, src1->ne[1], x, d);

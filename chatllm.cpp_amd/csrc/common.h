@@ -260,6 +260,8 @@ int launch_mma_f16(hipStream_t st, const tview & w, const tview & x, const tview
 int device_cu_count();
 int launch_mmvq_act(hipStream_t st, int wtype, const void * W, int64_t K, int64_t nrows, const void * act, float * dst, const float * bias, const float * resid);
 int launch_gemv_decode(hipStream_t st, int wtype, const void * W, int64_t K, int64_t nrows, int pro, const float * px, const float * pw, float eps, int epi, float * dst, const float * bias, const float * resid, const float * padd = nullptr, float * xout = nullptr);
+bool prefill_f16_enabled();
+int launch_dense_f16(hipStream_t st, int wtype, const tview & w, const tview & x, const tview & d);
 int launch_gemv_rows(hipStream_t st, const void * W, int64_t K, int64_t nrows, int pro, const float * px, const float * pw, float eps, int epi, float * dst, const float * bias, const float * resid);
 int launch_mmvq_fused(hipStream_t st, int wtype, const void * W, int64_t K, int64_t nrows, int pro, const float * px, const float * pw, float eps, int epi, float * dst, const float * bias, const float * resid);
 int launch_attn_decode(hipStream_t st, const float * qkv, const int32_t * pos_dev, int nh, int nkv, int hd, const uint16_t * k_cache, const uint16_t * v_cache, int64_t ML, float * att);

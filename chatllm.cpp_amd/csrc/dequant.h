@@ -1,0 +1,34 @@
+// dequant.h -- one element of a quantized row as dequantize_row_* produces it (ggml-quants.c:307-325 Q4_0, 327-345 Q4_1, 401-414 Q8_0,
+// 1352-1373 Q4_K with get_scale_min_k4 :703-711): shared by GET_ROWS (ops.hip) and the dense fp16 prefill path (dense_f16.hip)
+#pragma once
+#include "common.h"
+
+__device__ __forceinline__ float dequant_elem(int type, const char * row, int64_t i) {
+    switch (type) {
+        case CLLM_TYPE_F32: return ((const float *) row)[i];
+        case CLLM_TYPE_F16: return h2f(((const uint16_t *) row)[i]);
+        case CLLM_TYPE_Q8_0: { const block_q8_0 * b = (const block_q8_0 *) row + i / 32; return (float) b->qs[i % 32] * h2f(b->d); }
+        case CLLM_TYPE_Q4_0: {
+            const block_q4_0 * b = (const block_q4_0 *) row + i / 32; const int j = (int)(i % 32);
+            const int q = j < 16 ? (b->qs[j] & 0xF) : (b->qs[j - 16] >> 4);
+            return (float)(q - 8) * h2f(b->d);
+        }
+        case CLLM_TYPE_Q4_1: {                     // dequantize_row_q4_1 (ggml-quants.c:327-345): nib * d + m
+            const block_q4_1 * b = (const block_q4_1 *) row + i / 32; const int j = (int)(i % 32);
+            const int q = j < 16 ? (b->qs[j] & 0xF) : (b->qs[j - 16] >> 4);
+            return (float) q * h2f(b->d) + h2f(b->m);
+        }
+        case CLLM_TYPE_Q4_K: {
+            const block_q4_K * b = (const block_q4_K *) row + i / 256; const int e = (int)(i % 256);
+            const int s = e / 32, l = e % 32;
+            int sc, m;
+            if (s < 4) { sc = b->scales[s] & 63; m = b->scales[s + 4] & 63; }
+            else { sc = (b->scales[s + 4] & 0xF) | ((b->scales[s - 4] >> 6) << 4); m = (b->scales[s + 4] >> 4) | ((b->scales[s] >> 6) << 4); }
+            const uint8_t qb = b->qs[(s >> 1) * 32 + l];
+            const int q = (s & 1) ? (qb >> 4) : (qb & 0xF);
+            const float d1 = h2f(b->d) * (float) sc, m1 = h2f(b->dmin) * (float) m;     // d*sc and min*m rounded first (ggml-quants.c:1364-1367)
+            return d1 * (float) q - m1;
+        }
+    }
+    return 0.0f;
+}
