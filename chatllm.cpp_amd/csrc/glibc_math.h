@@ -23,17 +23,36 @@ GM_FN uint64_t gm_asuint64(double f) { uint64_t u; memcpy(&u, &f, 8); return u; 
 GM_FN double   gm_asdouble(uint64_t u){ double f; memcpy(&f, &u, 8); return f; }
 
 // ---- expf (e_expf.c, exp2f_data.c: N = 32) -----------------------------------------------------------------------------------------
-GM_FN uint64_t gm_exp2f_tab(int i) {       // T[i] = asuint64(2^(i/32)) - (i << 47)
-    switch (i & 31) {
-        case 0: return 0x3ff0000000000000ull; case 1: return 0x3fefd9b0d3158574ull; case 2: return 0x3fefb5586cf9890full; case 3: return 0x3fef9301d0125b51ull;
-        case 4: return 0x3fef72b83c7d517bull; case 5: return 0x3fef54873168b9aaull; case 6: return 0x3fef387a6e756238ull; case 7: return 0x3fef1e9df51fdee1ull;
-        case 8: return 0x3fef06fe0a31b715ull; case 9: return 0x3feef1a7373aa9cbull; case 10: return 0x3feedea64c123422ull; case 11: return 0x3feece086061892dull;
-        case 12: return 0x3feebfdad5362a27ull; case 13: return 0x3feeb42b569d4f82ull; case 14: return 0x3feeab07dd485429ull; case 15: return 0x3feea47eb03a5585ull;
-        case 16: return 0x3feea09e667f3bcdull; case 17: return 0x3fee9f75e8ec5f74ull; case 18: return 0x3feea11473eb0187ull; case 19: return 0x3feea589994cce13ull;
-        case 20: return 0x3feeace5422aa0dbull; case 21: return 0x3feeb737b0cdc5e5ull; case 22: return 0x3feec49182a3f090ull; case 23: return 0x3feed503b23e255dull;
-        case 24: return 0x3feee89f995ad3adull; case 25: return 0x3feeff76f2fb5e47ull; case 26: return 0x3fef199bdd85529cull; case 27: return 0x3fef3720dcef9069ull;
-        case 28: return 0x3fef5818dcfba487ull; case 29: return 0x3fef7c97337b9b5full; case 30: return 0x3fefa4afa2a490daull; default: return 0x3fefd0765b6e4540ull;
-    }
+// T[i] = asuint64(2^(i/32)) - (i << 47); a table in constant memory on the device (a 32-way switch compiles to a branch tree that costs the
+// one lane running a soft_max tail ~100 cycles per element)
+#if defined(__HIPCC__)
+__device__ __constant__ static const uint64_t gm_exp2f_T_dev[32] = {
+    0x3ff0000000000000ull, 0x3fefd9b0d3158574ull, 0x3fefb5586cf9890full, 0x3fef9301d0125b51ull,
+    0x3fef72b83c7d517bull, 0x3fef54873168b9aaull, 0x3fef387a6e756238ull, 0x3fef1e9df51fdee1ull,
+    0x3fef06fe0a31b715ull, 0x3feef1a7373aa9cbull, 0x3feedea64c123422ull, 0x3feece086061892dull,
+    0x3feebfdad5362a27ull, 0x3feeb42b569d4f82ull, 0x3feeab07dd485429ull, 0x3feea47eb03a5585ull,
+    0x3feea09e667f3bcdull, 0x3fee9f75e8ec5f74ull, 0x3feea11473eb0187ull, 0x3feea589994cce13ull,
+    0x3feeace5422aa0dbull, 0x3feeb737b0cdc5e5ull, 0x3feec49182a3f090ull, 0x3feed503b23e255dull,
+    0x3feee89f995ad3adull, 0x3feeff76f2fb5e47ull, 0x3fef199bdd85529cull, 0x3fef3720dcef9069ull,
+    0x3fef5818dcfba487ull, 0x3fef7c97337b9b5full, 0x3fefa4afa2a490daull, 0x3fefd0765b6e4540ull
+};
+#endif
+static const uint64_t gm_exp2f_T_host[32] = {
+    0x3ff0000000000000ull, 0x3fefd9b0d3158574ull, 0x3fefb5586cf9890full, 0x3fef9301d0125b51ull,
+    0x3fef72b83c7d517bull, 0x3fef54873168b9aaull, 0x3fef387a6e756238ull, 0x3fef1e9df51fdee1ull,
+    0x3fef06fe0a31b715ull, 0x3feef1a7373aa9cbull, 0x3feedea64c123422ull, 0x3feece086061892dull,
+    0x3feebfdad5362a27ull, 0x3feeb42b569d4f82ull, 0x3feeab07dd485429ull, 0x3feea47eb03a5585ull,
+    0x3feea09e667f3bcdull, 0x3fee9f75e8ec5f74ull, 0x3feea11473eb0187ull, 0x3feea589994cce13ull,
+    0x3feeace5422aa0dbull, 0x3feeb737b0cdc5e5ull, 0x3feec49182a3f090ull, 0x3feed503b23e255dull,
+    0x3feee89f995ad3adull, 0x3feeff76f2fb5e47ull, 0x3fef199bdd85529cull, 0x3fef3720dcef9069ull,
+    0x3fef5818dcfba487ull, 0x3fef7c97337b9b5full, 0x3fefa4afa2a490daull, 0x3fefd0765b6e4540ull
+};
+GM_FN uint64_t gm_exp2f_tab(int i) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return gm_exp2f_T_dev[i & 31];
+#else
+    return gm_exp2f_T_host[i & 31];
+#endif
 }
 GM_FN float gm_expf(float x) {
     const double xd = (double) x;
