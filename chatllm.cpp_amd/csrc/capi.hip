@@ -408,3 +408,38 @@ extern "C" int cllm_op_mul_mat_id(void * stream, const cllm_tensor * as, const c
     if (rc) return rc;
     return launch_mmvq_id(st, as->type, tv(as), wdata, stride, b->ne[1], tv(ids), tv(dst));
 }
+
+// ================================================================================================
+// flash attention (fattn.hip)
+// ================================================================================================
+extern "C" size_t cllm_flash_attn_wsize(const cllm_tensor * q) {
+    return q ? fattn_wsize(q->ne[1], q->ne[2], q->ne[3], q->ne[0]) : 0;
+}
+extern "C" int cllm_op_flash_attn_ext(void * stream, const cllm_tensor * q, const cllm_tensor * k, const cllm_tensor * v, const cllm_tensor * mask,
+                                      cllm_tensor * dst, float scale, float max_bias, float logit_softcap, void * wdata, size_t wsize) {
+    if (!q || !k || !v || !dst || !q->data || !k->data || !v->data || !dst->data) FAIL(CLLM_E_INVALID, "flash_attn_ext: null tensor");
+    if (max_bias != 0.0f || logit_softcap != 0.0f) FAIL(CLLM_E_UNSUPPORTED, "flash_attn_ext: ALiBi / logit soft-cap are not on this path");
+    if (q->type != CLLM_TYPE_F32 || dst->type != CLLM_TYPE_F32 || k->type != v->type || (mask && mask->type != CLLM_TYPE_F16)) FAIL(CLLM_E_UNSUPPORTED, "flash_attn_ext: types");
+    if (dst->ne[0] != v->ne[0] || dst->ne[1] != q->ne[2] || dst->ne[2] != q->ne[1] || dst->ne[3] != q->ne[3]) FAIL(CLLM_E_INVALID, "flash_attn_ext: dst shape");
+    if (dst->nb[0] != 4 || k->nb[0] != cllm_type_size(k->type) || v->nb[0] != cllm_type_size(v->type)) FAIL(CLLM_E_UNSUPPORTED, "flash_attn_ext: rows must be dense");
+    if (mask && (mask->ne[0] < k->ne[1] || mask->ne[1] < q->ne[1] || (mask->ne[2] != 1 && mask->ne[2] != q->ne[2]) || (mask->ne[3] != 1 && mask->ne[3] != q->ne[3])))
+        FAIL(CLLM_E_INVALID, "flash_attn_ext: mask shape");
+    const tview m = mask ? tv(mask) : tview();
+    // dst [D, H, N, B]: element (dv, h, n, b) at n nb[2] + h nb[1] + b nb[3]
+    const int rc = launch_fattn((hipStream_t) stream, tv(q), tv(k), k->type, tv(v), 0, mask ? &m : nullptr, -1, (char *) dst->data,
+                                (int64_t) dst->nb[2], (int64_t) dst->nb[1], (int64_t) dst->nb[3], scale, wdata, wsize);
+    if (rc == CLLM_E_UNSUPPORTED) FAIL(rc, "flash_attn_ext: shape / layout not taken (D %lld, n_kv %lld)", (long long) q->ne[0], (long long) k->ne[1]);
+    return rc;
+}
+extern "C" int cllm_op_attn_prefill(void * stream, const cllm_tensor * q, const cllm_tensor * k, const cllm_tensor * vt, cllm_tensor * dst, float scale, int n_past) {
+    if (!q || !k || !vt || !dst || !q->data || !k->data || !vt->data || !dst->data) FAIL(CLLM_E_INVALID, "attn_prefill: null tensor");
+    if (q->type != CLLM_TYPE_F32 || dst->type != CLLM_TYPE_F32 || k->type != CLLM_TYPE_F16 || vt->type != CLLM_TYPE_F16 || n_past < 0) FAIL(CLLM_E_UNSUPPORTED, "attn_prefill: types");
+    if (dst->ne[0] != vt->ne[1] || dst->ne[1] != q->ne[1] || dst->ne[2] != q->ne[2] || dst->ne[3] != q->ne[3] || dst->nb[0] != 4 || k->nb[0] != 2 || vt->nb[0] != 2) FAIL(CLLM_E_INVALID, "attn_prefill: shapes");
+    if (k->ne[1] != n_past + q->ne[1]) FAIL(CLLM_E_INVALID, "attn_prefill: n_kv != n_past + qlen");
+    tview v = tv(vt);
+    v.ne[0] = v.nb[1] / 2;                       // the row really holds max_length positions; n_kv comes from k
+    const int rc = launch_fattn((hipStream_t) stream, tv(q), tv(k), k->type, v, 1, nullptr, n_past, (char *) dst->data,
+                                (int64_t) dst->nb[1], (int64_t) dst->nb[2], (int64_t) dst->nb[3], scale, nullptr, 0);
+    if (rc == CLLM_E_UNSUPPORTED) FAIL(rc, "attn_prefill: shape / layout not taken");
+    return rc;
+}

@@ -72,6 +72,9 @@ SIGNATURES = {
     "cllm_bench_gemv_fused": (C.c_int, [_P, C.c_int, C.POINTER(C.c_void_p), C.c_int, C.c_int64, C.c_int64, C.c_int, _P, _P, C.c_float, C.c_int, _P, _P, C.c_int,
                                         C.POINTER(C.c_float)]),
     "cllm_op_mul_mat_id": (C.c_int, [_P, _T, _T, _T, _T, _P, C.c_size_t]),
+    "cllm_flash_attn_wsize": (C.c_size_t, [_T]),
+    "cllm_op_flash_attn_ext": (C.c_int, [_P, _T, _T, _T, _T, _T, C.c_float, C.c_float, C.c_float, _P, C.c_size_t]),
+    "cllm_op_attn_prefill": (C.c_int, [_P, _T, _T, _T, _T, C.c_float, C.c_int]),
     "cllm_op_mul_mat_id_silu_mul": (C.c_int, [_P, _T, _T, _T, _T]),
     "cllm_quantize_row_q8_0": (C.c_int, [_P, _P, _P, C.c_int64]),
     "cllm_quantize_row_q8_1": (C.c_int, [_P, _P, _P, C.c_int64]),

@@ -99,6 +99,25 @@ def scale_mask_soft_max(a, scale_, n_past, dst=None):
     return dst
 
 
+def flash_attention(q, k, v, mask, scale, max_bias=0.0, logit_softcap=0.0, dst=None):
+    """ggml::flash_attention(ctx, q, k, v, mask, scale) (src/layers.cpp:1506-1518): q [D, N, H, B] F32; k, v [D, n_kv, Hkv, B] F16 | Q8_0;
+    mask F16 [n_kv, N] or None -> [D, H, N, B] F32"""
+    L = _l.get()
+    dst = dst or Tensor(F32, [v.ne[0], q.ne[2], q.ne[1], q.ne[3]])
+    cq = q.c()
+    ws = L.cllm_flash_attn_wsize(C.byref(cq))
+    buf = _scratch(ws)
+    _l.check(L.cllm_op_flash_attn_ext(None, C.byref(cq), _ref(k), _ref(v), _ref(mask), _ref(dst), scale, max_bias, logit_softcap, buf.ptr, buf.nbytes), "flash_attn_ext")
+    return dst
+
+
+def attn_prefill(q, k, vt, scale, n_past, dst=None):
+    """the eager prefill attention block as one flash kernel: q [D, N, H] F32, k [D, n_kv, Hkv] F16 rows, vt [n_kv, D, Hkv] F16 -> [D, N, H] F32"""
+    dst = dst or Tensor(F32, [vt.ne[1], q.ne[1], q.ne[2], q.ne[3]])
+    _l.check(_l.get().cllm_op_attn_prefill(None, _ref(q), _ref(k), _ref(vt), _ref(dst), scale, n_past), "attn_prefill")
+    return dst
+
+
 def attn_decode(q, pos, n_head, n_kv_head, head_dim, k_cache, v_cache, max_len, dst=None):
     """fused single-token attention; q: [hd, n_head] F32, pos: I32 [1] device tensor holding n_past"""
     dst = dst or Tensor(F32, [head_dim * n_head])

@@ -176,6 +176,22 @@ CLLM_API int cllm_op_scale(void * stream, const cllm_tensor * src, cllm_tensor *
 /* fused SCALE + DIAG_MASK_INF + SOFT_MAX as chatllm's attn_scores_to_probs emits them (src/layers.cpp:2499-2539) */
 CLLM_API int cllm_op_scale_mask_soft_max(void * stream, const cllm_tensor * src, cllm_tensor * dst, float scale, int n_past);
 
+/* GGML_OP_FLASH_ATTN_EXT  ggml_compute_forward_flash_attn_ext_f16 (ggml-cpu/ops.cpp:8114-8344, tiled :8346-8640, split-KV :8642-8770),
+ * as CoreAttention emits it with `-fa` (src/layers.cpp:2634-2656):  dst[:, h, n] = soft_max_kv(scale * K.q + mask) . V
+ * q F32 [D, N, H, B] (rows dense); k, v: F16 or Q8_0 [D, n_kv, Hkv, B] rows (--cache_dtype, src/layers.cpp:2925-2945); mask NULL or
+ * F16 [n_kv, >= N, 1|H, 1|B]; dst F32 [D, H, N, B] contiguous.  D = 64 | 128, H % Hkv == 0, max_bias == 0 and logit_softcap == 0
+ * (anything else: CLLM_E_UNSUPPORTED, the host keeps the node on the CPU).  TOLERANCE tier: Q is converted to K's vec_dot_type as
+ * on the CPU (fp16, or quantize_row_q8_0), scores and the online soft-max are fp32, P is rounded to fp16 for the P.V product; the
+ * CPU op itself changes summation order with shape and thread count.  wdata: cllm_flash_attn_wsize() bytes (split-KV partials). */
+CLLM_API size_t cllm_flash_attn_wsize(const cllm_tensor * q);
+CLLM_API int    cllm_op_flash_attn_ext(void * stream, const cllm_tensor * q, const cllm_tensor * k, const cllm_tensor * v, const cllm_tensor * mask,
+                                       cllm_tensor * dst, float scale, float max_bias, float logit_softcap, void * wdata, size_t wsize);
+/* the prefill attention block of the eager path, MUL_MAT(K, Q) + SCALE + DIAG_MASK_INF + SOFT_MAX + MUL_MAT(V^T, P) (src/layers.cpp:2499-2561),
+ * as ONE flash kernel (qlen > 32: the tolerance tier, as the MFMA mat-muls it replaces):  q F32 [D, N, H]; k F16 [D, n_kv, Hkv] rows;
+ * vt F16 [n_kv, D, Hkv] (the transposed V cache view); dst F32 [D, N, H] (any 16-byte aligned strides); causal with n_past. */
+CLLM_API int    cllm_op_attn_prefill(void * stream, const cllm_tensor * q, const cllm_tensor * k, const cllm_tensor * vt, cllm_tensor * dst,
+                                     float scale, int n_past);
+
 /* fused single-token attention as chatllm's eager path emits it for qlen == 1 (src/layers.cpp:2541-2561, 2499-2539):
  *   MUL_MAT(K view, Q) + SCALE(1/sqrt(hd)) + DIAG_MASK_INF + SOFT_MAX + MUL_MAT(V view, P) + PERMUTE + CONT
  * q: [hd, n_head] F32 (post-RoPE); k_cache: [max_len][n_kv_head*hd] F16; v_cache: [n_kv_head*hd][max_len] F16 (transposed);

@@ -745,6 +745,62 @@ int orc_soft_max(const orc_tensor * src, const orc_tensor * mask, orc_tensor * d
     return 0;
 }
 
+int orc_flash_attn_ext(const orc_tensor * q, const orc_tensor * k, const orc_tensor * v, const orc_tensor * mask, orc_tensor * dst, float scale) {
+    if (q->type != ORC_F32 || dst->type != ORC_F32 || k->type != v->type || (k->type != ORC_F16 && k->type != ORC_Q8_0)) return -1;
+    if (mask && mask->type != ORC_F16) return -2;
+    const int64_t DK = k->ne[0], DV = v->ne[0], N = q->ne[1], H = q->ne[2], B = q->ne[3], n_kv = k->ne[1];
+    if (q->ne[0] != DK || DK % 32 || DV % 32 || H % k->ne[2] || H % v->ne[2] || B % k->ne[3] || dst->ne[0] != DV || dst->ne[1] != H || dst->ne[2] != N) return -3;
+    const int64_t rk2 = H / k->ne[2], rk3 = B / k->ne[3], rv2 = H / v->ne[2], rv3 = B / v->ne[3];
+    uint16_t * Qh = (uint16_t *) malloc((size_t) DK * 2 + (size_t)(DK / 32) * sizeof(orc_block_q8_0));
+    orc_block_q8_0 * Qq = (orc_block_q8_0 *)(Qh + DK);
+    uint16_t * VKQ16 = (uint16_t *) malloc((size_t) DV * 2);
+    float * VKQ32 = (float *) malloc((size_t) DV * 8), * V32 = VKQ32 + DV;
+    for (int64_t iq3 = 0; iq3 < B; iq3++)
+    for (int64_t iq2 = 0; iq2 < H; iq2++)
+    for (int64_t iq1 = 0; iq1 < N; iq1++) {
+        const float * pq = (const float *) tptr(q, 0, iq1, iq2, iq3);
+        if (k->type == ORC_F16) for (int64_t i = 0; i < DK; i++) Qh[i] = orc_fp32_to_fp16(pq[i]);      /* from_float of the vec_dot_type */
+        else orc_quantize_row_q8_0(pq, Qq, DK);
+        float S = 0.0f, M = -INFINITY;
+        if (v->type == ORC_F16) memset(VKQ16, 0, (size_t) DV * 2); else memset(VKQ32, 0, (size_t) DV * 4);
+        const uint16_t * mp = mask ? (const uint16_t *) tptr(mask, 0, iq1, iq2 % mask->ne[2], iq3 % mask->ne[3]) : NULL;
+        for (int64_t ic = 0; ic < n_kv; ic++) {
+            const float mv = mp ? 1.0f * orc_fp16_to_fp32(mp[ic]) : 0.0f;
+            if (mv == -INFINITY) continue;
+            const char * kd = tptr(k, 0, ic, iq2 / rk2, iq3 / rk3);
+            float s = k->type == ORC_F16 ? orc_vec_dot_f16_avx2(DK, (const uint16_t *) kd, Qh)
+                                         : orc_vec_dot_q8_0_q8_0_avx2(DK, (const orc_block_q8_0 *) kd, Qq);
+            s = s * scale;
+            s += mv;
+            const float Mold = M;
+            float ms = 1.0f, vs = 1.0f;
+            const char * vd = tptr(v, 0, ic, iq2 / rv2, iq3 / rv3);
+            if (v->type == ORC_F16) {
+                if (s > M) {
+                    M = s; ms = expf(Mold - M);
+                    for (int64_t d = 0; d < DV; d++) VKQ16[d] = orc_fp32_to_fp16(orc_fp16_to_fp32(VKQ16[d]) * ms);            /* ggml_vec_scale_f16 */
+                } else vs = expf(s - M);
+                for (int64_t d = 0; d < DV; d++)                                                                                 /* ggml_vec_mad_f16: F32Cx8 fmadd */
+                    VKQ16[d] = orc_fp32_to_fp16(fmaf(orc_fp16_to_fp32(((const uint16_t *) vd)[d]), vs, orc_fp16_to_fp32(VKQ16[d])));
+            } else {
+                if (s > M) {
+                    M = s; ms = expf(Mold - M);
+                    for (int64_t d = 0; d < DV; d++) VKQ32[d] *= ms;
+                } else vs = expf(s - M);
+                orc_dequantize_row_q8_0((const orc_block_q8_0 *) vd, V32, DV);
+                for (int64_t d = 0; d < DV; d++) VKQ32[d] = fmaf(V32[d], vs, VKQ32[d]);                                          /* ggml_vec_mad_f32 */
+            }
+            S = S * ms + vs;
+        }
+        if (v->type == ORC_F16) for (int64_t d = 0; d < DV; d++) VKQ32[d] = orc_fp16_to_fp32(VKQ16[d]);
+        const float S_inv = S == 0.0f ? 0.0f : 1.0f / S;
+        float * dp = (float *) tptr(dst, 0, iq2, iq1, iq3);
+        for (int64_t d = 0; d < DV; d++) dp[d] = VKQ32[d] * S_inv;
+    }
+    free(Qh); free(VKQ16); free(VKQ32);
+    return 0;
+}
+
 int orc_diag_mask_inf(const orc_tensor * src, orc_tensor * dst, int n_past) {
     if (src->type != ORC_F32 || dst->type != ORC_F32) return -1;
     for (int64_t i3 = 0; i3 < src->ne[3]; i3++)

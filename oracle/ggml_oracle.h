@@ -114,6 +114,13 @@ int orc_rope(const orc_tensor * src, const int32_t * pos, const float * freq_fac
              const orc_rope_params * p);
 /* ggml_compute_forward_soft_max_f32 (ggml-cpu/ops.cpp:5225-5335; ggml_v_expf vec.h:1230-1267) */
 int orc_soft_max(const orc_tensor * src, const orc_tensor * mask, orc_tensor * dst, float scale, float max_bias);
+/* ggml_compute_forward_flash_attn_ext_f16_one_chunk (ggml-cpu/ops.cpp:8114-8344) -- the per-query online soft-max the reference
+ * takes with one thread for N < 64 queries and n_kv < 512 (and always for a quantized K/V cache); its tiled (:8346-8640) and
+ * split-KV (:8642-8770) variants differ from it in summation order only, so they are compared with a tolerance.
+ * q F32 [D, N, H, B]; k, v F16 | Q8_0 [D, n_kv, Hkv, B]; mask NULL | F16 [n_kv, >= N, 1|H, 1|B]; dst F32 [D, H, N, B].
+ * Q is converted to K's vec_dot_type (fp16 / quantize_row_q8_0), the dot is the AVX2-order vec_dot, V accumulates in fp16
+ * (F16 V: ggml_vec_mad_f16, vec.h:456-) or fp32 (dequantized Q8_0 V: ggml_vec_mad_f32). */
+int orc_flash_attn_ext(const orc_tensor * q, const orc_tensor * k, const orc_tensor * v, const orc_tensor * mask, orc_tensor * dst, float scale);
 /* ggml_compute_forward_diag_mask_f32 (ggml-cpu/ops.cpp:5137-5185) value = -INF */
 int orc_diag_mask_inf(const orc_tensor * src, orc_tensor * dst, int n_past);
 /* ggml_compute_forward_scale (ops.cpp:4426-) y = x*s + b */

@@ -148,6 +148,11 @@ def soft_max(src, mask, dst, scale=1.0):
                             C.c_float(0.0)), "soft_max")
 
 
+def flash_attn_ext(q, k, v, mask, dst, scale):
+    _chk(lib().orc_flash_attn_ext(C.byref(q), C.byref(k), C.byref(v), C.byref(mask) if mask is not None else None, C.byref(dst),
+                                  C.c_float(scale)), "flash_attn_ext")
+
+
 def diag_mask_inf(src, dst, n_past):
     _chk(lib().orc_diag_mask_inf(C.byref(src), C.byref(dst), C.c_int(n_past)), "diag_mask_inf")
 

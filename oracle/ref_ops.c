@@ -282,6 +282,28 @@ int ref_attention(int64_t hd, int64_t nh, int64_t nkv, int64_t qlen, int64_t n_p
     return rc;
 }
 
+/* flash attention as chatllm builds it with `-fa` (src/layers.cpp:2634-2656): q [D, N, H] f32 (already permuted), K / V caches
+ * of `kv_type` (F16 | Q8_0 ...) given as dense rows [D, n_kv, Hkv], mask f16 [n_kv, N] or NULL -> out [D, H, N] */
+int ref_flash_attn(int kv_type, int64_t D, int64_t N, int64_t H, int64_t Hkv, int64_t n_kv, const float * q, const void * k, const void * v,
+                   const uint16_t * mask, float scale, float * out) {
+    const size_t rb = ggml_row_size((enum ggml_type) kv_type, D);
+    struct ggml_context * ctx = ctx_new((size_t)(D*N*H) * 16 + rb * (size_t)(n_kv*Hkv) * 2 + (size_t)(n_kv*N) * 2 + (64u << 20));
+    if (!ctx) return -1;
+    struct ggml_tensor * qq = ggml_new_tensor_3d(ctx, GGML_TYPE_F32, D, N, H);
+    struct ggml_tensor * kk = ggml_new_tensor_3d(ctx, (enum ggml_type) kv_type, D, n_kv, Hkv);
+    struct ggml_tensor * vv = ggml_new_tensor_3d(ctx, (enum ggml_type) kv_type, D, n_kv, Hkv);
+    memcpy(qq->data, q, (size_t)(D*N*H) * 4);
+    memcpy(kk->data, k, rb * (size_t)(n_kv*Hkv));
+    memcpy(vv->data, v, rb * (size_t)(n_kv*Hkv));
+    struct ggml_tensor * mm = NULL;
+    if (mask) { mm = ggml_new_tensor_2d(ctx, GGML_TYPE_F16, n_kv, N); memcpy(mm->data, mask, (size_t)(n_kv*N) * 2); }
+    struct ggml_tensor * c = ggml_flash_attn_ext(ctx, qq, kk, vv, mm, scale, 0.0f, 0.0f);
+    int rc = run(ctx, c);
+    if (!rc) memcpy(out, c->data, (size_t)(D*H*N) * 4);
+    ggml_free(ctx);
+    return rc;
+}
+
 /* ---- CPU baseline leg of bench.py: the reference's own mul_mat (all host threads), weights resident ----
  * w: n_copies distinct [K, N] matrices back to back (so the host LLC cannot hold the working set), x: [K] f32.
  * Runs `iters` single-token mat-vecs cycling through the copies; returns seconds per mat-vec. */

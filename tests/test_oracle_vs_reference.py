@@ -385,3 +385,67 @@ def test_oracle_whole_model_vs_reference_host_live(pkg, tmp_path, arch, over, wt
         assert int(np.argmax(lg)) == int(ids[s])
         if s < 8:
             lg = m.forward([int(ids[s])])
+
+
+def _fa_case(kv_t, D, N, H, Hkv, n_kv, n_past, masked, seed=3):
+    r = np.random.default_rng(seed)
+    q = r.standard_normal((H, N, D)).astype(np.float32)
+    if kv_t == O.F16:
+        k = (r.standard_normal((Hkv, n_kv, D)) * 0.7).astype(np.float16)
+        v = r.standard_normal((Hkv, n_kv, D)).astype(np.float16)
+    else:
+        k = rand_blocks(O.Q8_0, Hkv * n_kv, D, r).reshape(Hkv, n_kv, -1)
+        v = rand_blocks(O.Q8_0, Hkv * n_kv, D, r).reshape(Hkv, n_kv, -1)
+    mask = None
+    if masked:                                   # CoreAttention::before_eval (src/layers.cpp:2585-2618): causal, -inf above the diagonal
+        m = np.zeros((N, n_kv), np.float32)
+        for j in range(N):
+            m[j, 1 + j + n_past:] = -np.inf
+        mask = m.astype(np.float16)
+    return q, k, v, mask
+
+
+def _fa_oracle(kv_t, D, N, H, Hkv, n_kv, q, k, v, mask, scale):
+    out = np.zeros((N, H, D), np.float32)
+    rb = O.row_size(kv_t, D)
+    O.flash_attn_ext(O.tensor(q, O.F32, [D, N, H]), O.tensor(k, kv_t, [D, n_kv, Hkv], nb=[O.row_size(kv_t, 1) if kv_t == O.F16 else 34, rb, rb * n_kv, rb * n_kv * Hkv]),
+                     O.tensor(v, kv_t, [D, n_kv, Hkv], nb=[O.row_size(kv_t, 1) if kv_t == O.F16 else 34, rb, rb * n_kv, rb * n_kv * Hkv]),
+                     O.tensor(mask, O.F16, [n_kv, N]) if mask is not None else None, O.tensor(out, O.F32, [D, H, N]), scale)
+    return out
+
+
+# one thread, N < 64 queries and n_kv < 512 (or a quantized cache): the reference runs flash_attn_ext_f16_one_chunk, which the oracle restates
+@pytest.mark.parametrize("kv_t,D,N,H,Hkv,n_kv,n_past,masked", [
+    (O.F16, 64, 1, 4, 2, 1, 0, True), (O.F16, 64, 1, 4, 2, 38, 37, True), (O.F16, 128, 7, 8, 2, 47, 40, True), (O.F16, 128, 1, 4, 4, 300, 299, False),
+    (O.F16, 64, 33, 2, 1, 33, 0, True), (O.Q8_0, 128, 1, 8, 2, 600, 599, True), (O.Q8_0, 64, 70, 4, 2, 90, 20, True), (O.Q8_0, 128, 5, 4, 1, 21, 16, False)])
+def test_flash_attn_ext_one_chunk_bit_exact(kv_t, D, N, H, Hkv, n_kv, n_past, masked):
+    R = O.ref()
+    R.ref_set_threads(C.c_int(1))
+    try:
+        q, k, v, mask = _fa_case(kv_t, D, N, H, Hkv, n_kv, n_past, masked)
+        scale = 1.0 / np.sqrt(D)
+        ref = np.zeros((N, H, D), np.float32)
+        assert R.ref_flash_attn(kv_t, C.c_int64(D), C.c_int64(N), C.c_int64(H), C.c_int64(Hkv), C.c_int64(n_kv), P(q), P(k), P(v), P(mask) if mask is not None else None,
+                                C.c_float(scale), P(ref)) == 0
+        got = _fa_oracle(kv_t, D, N, H, Hkv, n_kv, q, k, v, mask, scale)
+        assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
+    finally:
+        R.ref_set_threads(C.c_int(min(8, __import__("os").cpu_count() or 1)))
+
+
+# the reference's other two orders: tiled (N >= 64, F16 cache) and split-KV (N == 1, n_kv >= 512, several threads)
+# (the fp16 V accumulator of one_chunk loses ~1e-2 of max|out| over 1500 positions; the split-KV order accumulates 8 shorter runs)
+@pytest.mark.parametrize("N,n_kv,n_past,threads,tol", [(80, 100, 20, 1, 4e-3), (64, 64, 0, 4, 4e-3), (1, 1500, 1499, 8, 2e-2)])
+def test_flash_attn_ext_other_orders_within_tolerance(N, n_kv, n_past, threads, tol):
+    R = O.ref()
+    R.ref_set_threads(C.c_int(threads))
+    try:
+        D, H, Hkv = 128, 8, 2
+        q, k, v, mask = _fa_case(O.F16, D, N, H, Hkv, n_kv, n_past, True)
+        scale = 1.0 / np.sqrt(D)
+        ref = np.zeros((N, H, D), np.float32)
+        assert R.ref_flash_attn(O.F16, C.c_int64(D), C.c_int64(N), C.c_int64(H), C.c_int64(Hkv), C.c_int64(n_kv), P(q), P(k), P(v), P(mask), C.c_float(scale), P(ref)) == 0
+        got = _fa_oracle(O.F16, D, N, H, Hkv, n_kv, q, k, v, mask, scale)
+        assert rel_err(got, ref) < tol           # fp16 V accumulation (oracle, one_chunk) vs fp32 tiles / partials
+    finally:
+        R.ref_set_threads(C.c_int(min(8, __import__("os").cpu_count() or 1)))
