@@ -431,6 +431,7 @@ extern "C" int cllm_op_flash_attn_ext(void * stream, const cllm_tensor * q, cons
     if (rc == CLLM_E_UNSUPPORTED) FAIL(rc, "flash_attn_ext: shape / layout not taken (D %lld, n_kv %lld)", (long long) q->ne[0], (long long) k->ne[1]);
     return rc;
 }
+extern "C" int cllm_attn_prefill_min_cols(void) { return flash_prefill_min_cols(); }
 extern "C" int cllm_op_attn_prefill(void * stream, const cllm_tensor * q, const cllm_tensor * k, const cllm_tensor * vt, cllm_tensor * dst, float scale, int n_past) {
     if (!q || !k || !vt || !dst || !q->data || !k->data || !vt->data || !dst->data) FAIL(CLLM_E_INVALID, "attn_prefill: null tensor");
     if (q->type != CLLM_TYPE_F32 || dst->type != CLLM_TYPE_F32 || k->type != CLLM_TYPE_F16 || vt->type != CLLM_TYPE_F16 || n_past < 0) FAIL(CLLM_E_UNSUPPORTED, "attn_prefill: types");

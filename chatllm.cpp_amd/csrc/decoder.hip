@@ -302,7 +302,6 @@ static int forward_general(cllm_llama * m, int qlen, int n_past) {
     const int64_t H = c.hidden, hd = c.head_dim, nh = m->nh, nkv = m->nkv, QD = nh * hd, KD = nkv * hd, F = m->F, V = c.vocab, ML = c.max_len;
     const int64_t n_kv = (int64_t) n_past + qlen, QKV = QD + 2*KD;
     void * st = m->st;
-    TRY(ensure_scores(m, (size_t)(n_kv * qlen * nh)));
 
     cllm_tensor ids = T(CLLM_TYPE_I32, m->tokens_dev, qlen), pos = T(CLLM_TYPE_I32, m->pos_dev, qlen);
     cllm_tensor X = T(CLLM_TYPE_F32, m->x, H, qlen), XN = T(CLLM_TYPE_F32, m->xn, H, qlen), O = T(CLLM_TYPE_F32, m->o, H, qlen);
@@ -350,16 +349,26 @@ static int forward_general(cllm_llama * m, int qlen, int n_past) {
         {
             cllm_tensor Kv = TS(CLLM_TYPE_F16, L.k_cache, hd, n_kv, nkv, (size_t) KD * 2, (size_t) hd * 2);
             cllm_tensor Qv = TS(CLLM_TYPE_F32, q, hd, qlen, nh, (size_t) QKV * 4, (size_t) hd * 4);
+            cllm_tensor Vv = TS(CLLM_TYPE_F16, L.v_cache, n_kv, hd, nkv, (size_t) ML * 2, (size_t) ML * hd * 2);
+            int frc = CLLM_E_UNSUPPORTED;
+            if (qlen >= flash_prefill_min_cols()) {     // the tolerance tier (as the MFMA mat-muls below): one flash kernel, the scores never reach HBM
+                tview vt = tv(&Vv); vt.ne[0] = ML;
+                frc = launch_fattn((hipStream_t) st, tv(&Qv), tv(&Kv), CLLM_TYPE_F16, vt, 1, nullptr, n_past, (char *) m->att, (int64_t) QD * 4, (int64_t) hd * 4,
+                                   (int64_t) QD * 4 * qlen, 1.0f / sqrtf((float) hd), nullptr, 0);
+                if (frc != CLLM_OK && frc != CLLM_E_UNSUPPORTED) return frc;
+            }
+            if (frc == CLLM_E_UNSUPPORTED) {
+            TRY(ensure_scores(m, (size_t)(n_kv * qlen * nh)));
             cllm_tensor S  = T(CLLM_TYPE_F32, m->scores, n_kv, qlen, nh);
             TRY(launch_mul_mat_f((hipStream_t) st, CLLM_TYPE_F16, tv(&Kv), tv(&Qv), tv(&S), 1, n_past));       // causal 1: fully masked tiles are not computed
             TRY(cllm_op_scale_mask_soft_max(st, &S, &S, 1.0f / sqrtf((float) hd), n_past));
-            cllm_tensor Vv = TS(CLLM_TYPE_F16, L.v_cache, n_kv, hd, nkv, (size_t) ML * 2, (size_t) ML * hd * 2);
             cllm_tensor C  = T(CLLM_TYPE_F32, m->ctx, hd, qlen, nh);
             TRY(launch_mul_mat_f((hipStream_t) st, CLLM_TYPE_F16, tv(&Vv), tv(&S), tv(&C), 2, n_past));         // causal 2: k stops where P is exactly 0
             // permute(0,2,1,3) + cont -> [hd, nh, qlen]
             cllm_tensor Cp = T(CLLM_TYPE_F32, m->ctx, hd, nh, qlen); Cp.nb[1] = (size_t) hd * qlen * 4; Cp.nb[2] = (size_t) hd * 4; Cp.nb[3] = (size_t) hd * qlen * nh * 4;
             cllm_tensor A  = T(CLLM_TYPE_F32, m->att, hd, nh, qlen);
             TRY(cllm_op_cpy(st, &Cp, &A));
+            }
         }
         TRY(linear(m, L.wo, QD, H, m->att, qlen, m->o));
         if (tp_on(m)) TRY(tp_allreduce(m, (hipStream_t) st, m->o, H * qlen));

@@ -22,6 +22,7 @@
 // waves.  Decode (few rows): the r heads of a GQA group are packed as rows of one tile (R = r) so K/V are read once per
 // group, NW = 1, and the positions are split over gridDim.x workgroups whose partial (m, l, O) are merged by k_fattn_merge.
 #include "common.h"
+#include <stdlib.h>
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 half4 __attribute__((ext_vector_type(4)));
@@ -317,6 +318,15 @@ __global__ void __launch_bounds__(64) k_fattn_merge(const fattn_args a) {
     for (int i = 0; i < D / 64; i++) dp[lane + 64 * i] = acc[i] * inv;
 }
 
+int flash_prefill_min_cols() {
+    static const int v = [] {
+        const char * off = getenv("CLLM_FLASH_PREFILL");
+        if (off && atoi(off) == 0) return 1 << 30;
+        const char * e = getenv("CLLM_MMA_MIN_COLS");          // the same threshold as the MFMA mat-muls it replaces (matmul_f.hip): <= 32 columns stay exact
+        return e ? atoi(e) : 33;
+    }();
+    return v;
+}
 size_t fattn_wsize(int64_t N, int64_t H, int64_t B, int64_t D) { return (size_t) B * H * N * 64 * (D + 4) * 4; }
 
 template <int D, int KVT, int VL, int MASK>

@@ -2,6 +2,7 @@
 // Each kernel cites the reference CPU function whose arithmetic (operation order, rounding points,
 // accumulation width) it reproduces; see include/chatllm_hip.h for the op contracts.
 #include "common.h"
+#include "quant_dev.h"
 
 #include <math.h>
 
@@ -509,8 +510,42 @@ __global__ void __launch_bounds__(256) k_set_rows(tview s, tview idx, tview d) {
         if (F16) ((uint16_t *) dp)[c] = f2h(v); else ((float *) dp)[c] = v;
     }
 }
+// Q8_0 rows (--cache_dtype q8_0, src/layers.cpp:2925-2945): from_float of the CPU traits = quantize_row_q8_0 (x86 branch), 8 lanes per 32-block
+template <typename IDX>
+__global__ void __launch_bounds__(256) k_set_rows_q8_0(tview s, tview idx, tview d) {
+    const int64_t nb = s.ne[0] / 32, nblk = nb * s.ne[1] * s.ne[2] * s.ne[3];
+    const int sub = threadIdx.x & 7;
+    for (int64_t g0 = ((int64_t) blockIdx.x * blockDim.x + threadIdx.x) >> 3; g0 - ((threadIdx.x & 63) >> 3) < nblk; g0 += ((int64_t) gridDim.x * blockDim.x) >> 3) {
+        const bool live = g0 < nblk;                            // whole waves stay in the loop: the 8-lane reductions read their neighbours by DPP
+        int64_t r = live ? g0 : nblk - 1;
+        const int64_t blk = r % nb; r /= nb;
+        const int64_t i  = r % s.ne[1]; r /= s.ne[1];
+        const int64_t i2 = r % s.ne[2]; const int64_t i3 = r / s.ne[2];
+        const int64_t row = (int64_t) *(const IDX *)(idx.data + i*idx.nb[0] + (i2 % idx.ne[1])*idx.nb[1] + (i3 % idx.ne[2])*idx.nb[2]);
+        const f32x4 v = *(const f32x4 *)(s.data + (blk * 32 + sub * 4) * 4 + i*s.nb[1] + i2*s.nb[2] + i3*s.nb[3]);
+        float dd; int ss;
+        const uint32_t p = quant4_q8_0<false>(v, &dd, &ss);
+        if (!live || row < 0 || row >= d.ne[1]) continue;
+        char * dp = d.data + row*d.nb[1] + i2*d.nb[2] + i3*d.nb[3] + blk * 34;
+        if (sub == 0) *(uint16_t *) dp = f2h(dd);
+        *(uint16_t *)(dp + 2 + sub * 4) = (uint16_t) p; *(uint16_t *)(dp + 4 + sub * 4) = (uint16_t)(p >> 16);
+    }
+}
 extern "C" int cllm_op_set_rows(void * stream, const cllm_tensor * src, const cllm_tensor * idx, cllm_tensor * dst) {
     if (!src || !idx || !dst) FAIL(CLLM_E_INVALID, "set_rows: null");
+    if (src->type == CLLM_TYPE_F32 && dst->type == CLLM_TYPE_Q8_0) {
+        if (idx->type != CLLM_TYPE_I32 && idx->type != CLLM_TYPE_I64) FAIL(CLLM_E_UNSUPPORTED, "set_rows: index type");
+        if (dst->ne[0] != src->ne[0] || dst->ne[2] != src->ne[2] || dst->ne[3] != src->ne[3] || src->nb[0] != 4 || dst->nb[0] != 34 || src->ne[0] % 32) FAIL(CLLM_E_INVALID, "set_rows: shape");
+        if (idx->ne[0] != src->ne[1] || src->ne[2] % idx->ne[1] || src->ne[3] % idx->ne[2]) FAIL(CLLM_E_INVALID, "set_rows: index shape");
+        if ((((uintptr_t) src->data | src->nb[1] | src->nb[2] | src->nb[3]) & 15) || (((uintptr_t) dst->data | dst->nb[1] | dst->nb[2] | dst->nb[3]) & 1)) FAIL(CLLM_E_UNSUPPORTED, "set_rows: alignment");
+        const int64_t nblk = t_nelements(src) / 32;
+        if (nblk == 0) return CLLM_OK;
+        int64_t grid = (nblk * 8 + 255) / 256; if (grid > 8192) grid = 8192;
+        if (idx->type == CLLM_TYPE_I64) hipLaunchKernelGGL((k_set_rows_q8_0<int64_t>), dim3((unsigned) grid), dim3(256), 0, (hipStream_t) stream, tv(src), tv(idx), tv(dst));
+        else                            hipLaunchKernelGGL((k_set_rows_q8_0<int32_t>), dim3((unsigned) grid), dim3(256), 0, (hipStream_t) stream, tv(src), tv(idx), tv(dst));
+        LAUNCH_CHECK();
+        return CLLM_OK;
+    }
     if (src->type != CLLM_TYPE_F32 || (dst->type != CLLM_TYPE_F16 && dst->type != CLLM_TYPE_F32)) FAIL(CLLM_E_UNSUPPORTED, "set_rows: type");
     if (idx->type != CLLM_TYPE_I32 && idx->type != CLLM_TYPE_I64) FAIL(CLLM_E_UNSUPPORTED, "set_rows: index type");
     if (dst->ne[0] != src->ne[0] || dst->ne[2] != src->ne[2] || dst->ne[3] != src->ne[3] || src->nb[0] != 4 || dst->nb[0] != cllm_type_size(dst->type)) FAIL(CLLM_E_INVALID, "set_rows: shape");
@@ -551,8 +586,34 @@ __global__ void __launch_bounds__(256) k_cpy(tview s, tview d) {
         *(TD *)(d.data + d0*d.nb[0] + d1*d.nb[1] + d2*d.nb[2] + d3*d.nb[3]) = o;
     }
 }
+// same quantized type on both sides (CONT of the permuted Q8_0 K-cache view, src/layers.cpp:3144-3146): whole rows move, 2 bytes per thread step
+__global__ void __launch_bounds__(256) k_cpy_qrows(tview s, tview d, int row_bytes) {
+    const int64_t h = row_bytes / 2, n = h * s.ne[1] * s.ne[2] * s.ne[3];
+    for (int64_t e = (int64_t) blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t) gridDim.x * blockDim.x) {
+        int64_t r = e;
+        const int64_t c = r % h; r /= h;
+        const int64_t row = r;
+        const int64_t s1 = r % s.ne[1]; r /= s.ne[1];
+        const int64_t s2 = r % s.ne[2]; const int64_t s3 = r / s.ne[2];
+        r = row;
+        const int64_t d1 = r % d.ne[1]; r /= d.ne[1];
+        const int64_t d2 = r % d.ne[2]; const int64_t d3 = r / d.ne[2];
+        *(uint16_t *)(d.data + c*2 + d1*d.nb[1] + d2*d.nb[2] + d3*d.nb[3]) = *(const uint16_t *)(s.data + c*2 + s1*s.nb[1] + s2*s.nb[2] + s3*s.nb[3]);
+    }
+}
 extern "C" int cllm_op_cpy(void * stream, const cllm_tensor * src, cllm_tensor * dst) {
     if (!src || !dst) FAIL(CLLM_E_INVALID, "cpy: null");
+    if (src->type == dst->type && is_quant_type(src->type)) {
+        const size_t rb = cllm_row_size(src->type, src->ne[0]);
+        if (src->ne[0] != dst->ne[0] || t_nelements(src) != t_nelements(dst) || src->nb[0] != cllm_type_size(src->type) || dst->nb[0] != src->nb[0] || rb % 2) FAIL(CLLM_E_UNSUPPORTED, "cpy: quantized rows must stay whole");
+        if ((((uintptr_t) src->data | src->nb[1] | src->nb[2] | src->nb[3] | (uintptr_t) dst->data | dst->nb[1] | dst->nb[2] | dst->nb[3]) & 1)) FAIL(CLLM_E_UNSUPPORTED, "cpy: alignment");
+        const int64_t n = (int64_t)(rb / 2) * src->ne[1] * src->ne[2] * src->ne[3];
+        if (n == 0) return CLLM_OK;
+        int64_t grid = (n + 255) / 256; if (grid > 16384) grid = 16384;
+        hipLaunchKernelGGL(k_cpy_qrows, dim3((unsigned) grid), dim3(256), 0, (hipStream_t) stream, tv(src), tv(dst), (int) rb);
+        LAUNCH_CHECK();
+        return CLLM_OK;
+    }
     const bool s32 = src->type == CLLM_TYPE_F32 || src->type == CLLM_TYPE_I32, s16 = src->type == CLLM_TYPE_F16;
     const bool d32 = dst->type == CLLM_TYPE_F32 || dst->type == CLLM_TYPE_I32, d16 = dst->type == CLLM_TYPE_F16;
     if (!(s32 || s16) || !(d32 || d16)) FAIL(CLLM_E_UNSUPPORTED, "cpy: type %d -> %d", src->type, dst->type);

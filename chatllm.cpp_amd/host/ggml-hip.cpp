@@ -305,10 +305,25 @@ bool dev_supports_op(ggml_backend_dev_t, const ggml_tensor * op) {
             float max_bias; memcpy(&max_bias, (const float *) op->op_params + 1, 4);
             return f32_dense(a) && f32_dense(op) && max_bias == 0.0f && !op->src[2] && (!b || b->type == GGML_TYPE_F32 || b->type == GGML_TYPE_F16);
         }
-        case GGML_OP_SET_ROWS: return f32_dense(a) && (op->type == GGML_TYPE_F16 || op->type == GGML_TYPE_F32) && (b->type == GGML_TYPE_I32 || b->type == GGML_TYPE_I64);
+        case GGML_OP_SET_ROWS:
+            if (op->type == GGML_TYPE_Q8_0) return f32_dense(a) && a->ne[0] % 32 == 0 && a->nb[1] % 16 == 0 && a->nb[2] % 16 == 0 && a->nb[3] % 16 == 0 && (b->type == GGML_TYPE_I32 || b->type == GGML_TYPE_I64);
+            return f32_dense(a) && (op->type == GGML_TYPE_F16 || op->type == GGML_TYPE_F32) && (b->type == GGML_TYPE_I32 || b->type == GGML_TYPE_I64);
+        case GGML_OP_FLASH_ATTN_EXT: {      // what cllm_op_flash_attn_ext takes (`-fa`, src/layers.cpp:2634-2656); anything else stays on the CPU backend
+            const ggml_tensor * v = op->src[2], * m = op->src[3];
+            float max_bias, softcap; memcpy(&max_bias, (const float *) op->op_params + 1, 4); memcpy(&softcap, (const float *) op->op_params + 2, 4);
+            if (!a || !b || !v || op->src[4] || max_bias != 0.0f || softcap != 0.0f || op->type != GGML_TYPE_F32 || a->type != GGML_TYPE_F32 || a->nb[0] != 4) return false;
+            if (b->type != v->type || (b->type != GGML_TYPE_F16 && b->type != GGML_TYPE_Q8_0) || b->nb[0] != ggml_type_size(b->type) || v->nb[0] != ggml_type_size(v->type)) return false;
+            const int64_t D = a->ne[0];
+            if ((D != 64 && D != 128) || b->ne[0] != D || v->ne[0] != D || v->ne[1] != b->ne[1] || b->ne[2] <= 0 || a->ne[2] % b->ne[2] || v->ne[2] != b->ne[2] || a->ne[3] != b->ne[3] || a->ne[3] != v->ne[3]) return false;
+            if (a->nb[1] % 16 || a->nb[2] % 16 || a->nb[3] % 16 || !ggml_is_contiguous(op)) return false;
+            if (b->type == GGML_TYPE_F16 && (b->nb[1] % 16 || b->nb[2] % 16 || b->nb[3] % 16 || v->nb[1] % 16 || v->nb[2] % 16 || v->nb[3] % 16)) return false;
+            if (m && (m->type != GGML_TYPE_F16 || !ggml_is_contiguous(m) || m->ne[0] < b->ne[1] || m->ne[1] < a->ne[1])) return false;
+            return a->ne[2] <= 65535 && a->ne[3] <= 65535;
+        }
         case GGML_OP_CPY: case GGML_OP_DUP: case GGML_OP_CONT: {
             const ggml_type s = a->type, d = op->type;
             const bool fs = s == GGML_TYPE_F32 || s == GGML_TYPE_F16, fd = d == GGML_TYPE_F32 || d == GGML_TYPE_F16;
+            if (s == d && is_q(s)) return a->ne[0] == op->ne[0] && a->nb[0] == ggml_type_size(s) && op->nb[0] == ggml_type_size(s);      // whole quantized rows (CONT of the Q8_0 K-cache view)
             return (fs && fd) || (s == GGML_TYPE_I32 && d == GGML_TYPE_I32);
         }
         case GGML_OP_GET_ROWS: return (is_q(a->type) || a->type == GGML_TYPE_F16 || a->type == GGML_TYPE_F32) && b->type == GGML_TYPE_I32 && op->type == GGML_TYPE_F32;
@@ -407,11 +422,15 @@ struct fused_attn {
 //   {MUL_MAT_ID gate, MUL_MAT_ID up} -> UNARY(SILU) -> MUL     one token: cllm_op_mul_mat_id_silu_mul over the per-expert interleaved pack
 struct fused_moe { const ggml_tensor * experts = nullptr, * probs = nullptr, * ids = nullptr, * resid = nullptr; };
 struct moe_gate_up { int mul = -1, gate = -1, up = -1, unary = -1; void * W = nullptr; };      // node indices; W: the pack, resolved before the walk
-enum { ALT_NONE = 0, ALT_SILU_MUL = 1 /* src0 is the SiLU */, ALT_RMS_NORM_MUL = 2, ALT_MOE_COMBINE = 3, ALT_MUL_SILU = 4 /* src1 is the SiLU */, ALT_MOE_GATE_UP = 5 };
+//   MUL_MAT(K, Q) SCALE DIAG_MASK_INF SOFT_MAX MUL_MAT(V^T, P)   with more than 32 query rows (the tolerance tier of the MFMA mat-muls):
+//                                                    cllm_op_attn_prefill, one flash kernel in place of the V.P node; the scores never reach HBM
+struct fused_fa { int ikq = -1, n_past = 0; float scale = 1.0f; bool alias = false; size_t bytes = 0; };   // alias: dst overlaps q (ggml-alloc reuses the dead q block): staged
+enum { ALT_NONE = 0, ALT_SILU_MUL = 1 /* src0 is the SiLU */, ALT_RMS_NORM_MUL = 2, ALT_MOE_COMBINE = 3, ALT_MUL_SILU = 4 /* src1 is the SiLU */, ALT_MOE_GATE_UP = 5, ALT_FLASH_PREFILL = 6 };
 struct fuse_plan {
     std::vector<uint8_t> skip;          // node is produced inside a fused launch (or not needed at all)
     std::vector<uint8_t> alt;           // the node is launched as one of the ALT_* forms
-    std::vector<int>     moe;           // ALT_MOE_COMBINE: index into moes
+    std::vector<int>     moe;           // ALT_MOE_COMBINE: index into moes; ALT_FLASH_PREFILL: index into fas
+    std::vector<fused_fa> fas;
     std::vector<fused_moe> moes;
     std::vector<moe_gate_up> gus;       // candidates (P.moe[mul node] indexes them once resolved)
     std::vector<int>     mv;            // index into mvs for MUL_MAT nodes launched fused, else -1
@@ -456,6 +475,7 @@ void plan_attention(ggml_cgraph * g, fuse_plan & P, const std::vector<int> & loc
     auto only_local = [&](int i, int uses) {
         return i >= 0 && !(node(i)->flags & GGML_TENSOR_FLAG_OUTPUT) && local[i] == uses && ggml_node_get_use_count(g, i) == uses;
     };
+    static const int flash_min = cllm_attn_prefill_min_cols();
     // x -> RESHAPE* -> ROPE -> RESHAPE* -> end : returns the ROPE and the node under it; every node of the chain is collected
     auto through_reshapes = [&](const ggml_tensor * t, std::vector<int> & chain) {      // (a VIEW of everything at offset 0 is a reshape too)
         while (t && (t->op == GGML_OP_RESHAPE || (t->op == GGML_OP_VIEW && t->src[0] && t->data == t->src[0]->data && ggml_nelements(t) == ggml_nelements(t->src[0]) &&
@@ -469,6 +489,27 @@ void plan_attention(ggml_cgraph * g, fuse_plan & P, const std::vector<int> & loc
         const int ikq = find(kq);
         if (ikq < 0 || kq->op != GGML_OP_MUL_MAT || !only_local(ikq, 1) || !only_local(i, 1)) continue;
         const ggml_tensor * kp = kq->src[0], * qp = kq->src[1];
+        if (kp->type == GGML_TYPE_F16 && qp->type == GGML_TYPE_F32 && qp->ne[1] >= flash_min && users[i].end() - users[i].begin() == 1) {      // ---- prefill: the flash kernel
+            const int ikqv = users[i][0];
+            const ggml_tensor * kqv = node(ikqv), * vv = kqv->src[0];
+            const int64_t hd = kp->ne[0], n_kv = kp->ne[1], nkv = kp->ne[2], nh = qp->ne[2], ql = qp->ne[1];
+            const int n_past = sm->src[0]->op_params[0];
+            auto al16 = [](const ggml_tensor * t) { return (((uintptr_t) t->data | t->nb[1] | t->nb[2] | t->nb[3]) & 15) == 0; };
+            if (kqv->op == GGML_OP_MUL_MAT && kqv->src[1] == sm && P.mv[ikqv] < 0 && !P.skip[ikqv] && (hd == 64 || hd == 128) && kp->ne[3] == 1 && qp->ne[3] == 1 && qp->ne[0] == hd &&
+                nkv > 0 && nh % nkv == 0 && n_past >= 0 && n_kv == n_past + ql && kp->nb[0] == 2 && qp->nb[0] == 4 && al16(kp) && al16(qp) && al16(kqv) && kqv->type == GGML_TYPE_F32 && kqv->nb[0] == 4 &&
+                vv->type == GGML_TYPE_F16 && vv->ne[0] == n_kv && vv->ne[1] == hd && vv->ne[2] == nkv && vv->ne[3] == 1 && vv->nb[0] == 2 && al16(vv) && (int64_t)(vv->nb[1] / 2) >= n_kv &&
+                ggml_is_contiguous(kqv) && sm->src[0]->src[0] == scn) {
+                fused_fa F; F.ikq = ikq; F.n_past = n_past; memcpy(&F.scale, scn->op_params, 4);
+                static const bool force_stage = getenv("CLLM_HIP_FORCE_STAGE") != nullptr;
+                size_t qext = 0;                            // the bytes the (permuted) q view spans
+                for (int k = 0; k < 4; k++) qext += (size_t)(qp->ne[k] - 1) * qp->nb[k];
+                F.bytes = ggml_nbytes(kqv);
+                F.alias = force_stage || overlap(kqv->data, F.bytes, qp->data, qext + 4);
+                P.skip[ikq] = P.skip[i] = 1;
+                P.alt[ikqv] = ALT_FLASH_PREFILL; P.moe[ikqv] = (int) P.fas.size(); P.fas.push_back(F);
+            }
+            continue;
+        }
         if (kp->type != GGML_TYPE_F16 || qp->type != GGML_TYPE_F32 || qp->op != GGML_OP_PERMUTE) continue;
         const int64_t hd = kp->ne[0], n_kv = kp->ne[1], nkv = kp->ne[2], nh = qp->ne[2];
         if (kp->ne[3] != 1 || qp->ne[0] != hd || qp->ne[1] != 1 || qp->ne[3] != 1 || nkv <= 0 || nh <= 0 || nh % nkv || n_kv < 1) continue;
@@ -844,6 +885,7 @@ ggml_status be_graph_compute(ggml_backend_t backend, ggml_cgraph * g) {
     size_t stage_bytes = 0;              // outputs of fused launches whose dst aliases one of their inputs (see make_plan)
     for (const fused_mv & f : plan.mvs) if (f.alias) { const size_t b = ((size_t) ggml_graph_node(g, f.node)->src[0]->ne[1] * 4 + 255) & ~(size_t) 255; if (b > stage_bytes) stage_bytes = b; }
     for (const fused_attn & A : plan.attns) if (A.alias) { const size_t b = ((size_t) A.nh * A.hd * 4 + 255) & ~(size_t) 255; if (b > stage_bytes) stage_bytes = b; }
+    for (const fused_fa & F : plan.fas) if (F.alias) { const size_t b = (F.bytes + 255) & ~(size_t) 255; if (b > stage_bytes) stage_bytes = b; }
     float * a_cs = nullptr, * a_qkv = nullptr, * a_act = nullptr, * a_stage = nullptr; void * a_scores = nullptr;
     if (qkv_bytes || act_bytes || stage_bytes) {
         if (int rc = ensure_abuf(c, 1024 + qkv_bytes + act_bytes + score_bytes + stage_bytes)) { HIPB_LOG("fusion scratch: %s", cllm_last_error()); return rc == CLLM_E_ALLOC ? GGML_STATUS_ALLOC_FAILED : GGML_STATUS_FAILED; }
@@ -879,7 +921,16 @@ ggml_status be_graph_compute(ggml_backend_t backend, ggml_cgraph * g) {
         if (b) db = desc(b);
         switch (n->op) {
             case GGML_OP_NONE: case GGML_OP_RESHAPE: case GGML_OP_VIEW: case GGML_OP_PERMUTE: case GGML_OP_TRANSPOSE: break;
-            case GGML_OP_MUL_MAT: if (plan.mv[i] >= 0) {
+            case GGML_OP_MUL_MAT: if (plan.alt[i] == ALT_FLASH_PREFILL) {
+                const fused_fa & F = plan.fas[plan.moe[i]];
+                const ggml_tensor * kq = ggml_graph_node(g, F.ikq);
+                cllm_tensor dk = desc(kq->src[0]), dq = desc(kq->src[1]);
+                if (F.alias) {
+                    cllm_tensor ds = d; ds.data = a_stage;
+                    rc = CALL(cllm_op_attn_prefill, st, &dq, &dk, &da, &ds, F.scale, F.n_past);
+                    if (rc == CLLM_OK) rc = CALL(cllm_memcpy_d2d, (void *) n->data, (const void *) a_stage, F.bytes, st);
+                } else rc = CALL(cllm_op_attn_prefill, st, &dq, &dk, &da, &d, F.scale, F.n_past);
+            } else if (plan.mv[i] >= 0) {
                 const fused_mv & f = plan.mvs[plan.mv[i]];
                 if (f.group >= 0) {
                     merge_group & G = plan.groups[f.group];
@@ -971,6 +1022,14 @@ ggml_status be_graph_compute(ggml_backend_t backend, ggml_cgraph * g) {
                 rc = CALL(cllm_op_soft_max, st, &da, b ? &db : nullptr, &d, scale, max_bias);
             } break;
             case GGML_OP_SET_ROWS: rc = CALL(cllm_op_set_rows, st, &da, &db, &d); break;          // dst is a view of the cache (node->data)
+            case GGML_OP_FLASH_ATTN_EXT: {
+                float scale, max_bias, softcap; memcpy(&scale, n->op_params, 4); memcpy(&max_bias, (const float *) n->op_params + 1, 4); memcpy(&softcap, (const float *) n->op_params + 2, 4);
+                dc = desc(n->src[2]);
+                cllm_tensor dm; if (n->src[3]) dm = desc(n->src[3]);
+                const size_t need = cllm_flash_attn_wsize(&da);
+                if ((rc = ensure_wdata(c, need))) break;
+                rc = CALL(cllm_op_flash_attn_ext, st, &da, &db, &dc, n->src[3] ? &dm : nullptr, &d, scale, max_bias, softcap, c->wdata, c->wsize);
+            } break;
             case GGML_OP_CPY: case GGML_OP_DUP: case GGML_OP_CONT: if (plan.attn[i] >= 0) {
                 const fused_attn & A = plan.attns[plan.attn[i]];
                 if (A.level == 2) {
@@ -1051,8 +1110,10 @@ ggml_status be_graph_compute(ggml_backend_t backend, ggml_cgraph * g) {
         for (const merge_group & G : plan.groups) if (G.state == 1) launches -= G.n - 1;
         int merged_n = 0;
         for (const merge_group & G : plan.groups) merged_n += G.state == 1;
-        HIPB_LOG("graph_compute: %d nodes -> %d calls%s (%d fused mat-vecs, %d merged over packed weights, attention fused at level 1: %d, level 2: %d)",
-                 ggml_graph_n_nodes(g), launches, replayed ? ", replayed from the captured graph" : "", (int) plan.mvs.size(), merged_n, a1, a2);
+        int fa_nodes = 0;
+        for (int i = 0; i < ggml_graph_n_nodes(g); i++) fa_nodes += ggml_graph_node(g, i)->op == GGML_OP_FLASH_ATTN_EXT;
+        HIPB_LOG("graph_compute: %d nodes -> %d calls%s (%d fused mat-vecs, %d merged over packed weights, attention fused at level 1: %d, level 2: %d, flash prefill: %d, flash_attn_ext: %d)",
+                 ggml_graph_n_nodes(g), launches, replayed ? ", replayed from the captured graph" : "", (int) plan.mvs.size(), merged_n, a1, a2, (int) plan.fas.size(), fa_nodes);
         g_ws.calls += launches;
         if (++g_ws.graphs % 64 == 0) {
             const double n = 64.0;

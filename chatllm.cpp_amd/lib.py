@@ -74,6 +74,7 @@ SIGNATURES = {
     "cllm_op_mul_mat_id": (C.c_int, [_P, _T, _T, _T, _T, _P, C.c_size_t]),
     "cllm_flash_attn_wsize": (C.c_size_t, [_T]),
     "cllm_op_flash_attn_ext": (C.c_int, [_P, _T, _T, _T, _T, _T, C.c_float, C.c_float, C.c_float, _P, C.c_size_t]),
+    "cllm_attn_prefill_min_cols": (C.c_int, []),
     "cllm_op_attn_prefill": (C.c_int, [_P, _T, _T, _T, _T, C.c_float, C.c_int]),
     "cllm_op_mul_mat_id_silu_mul": (C.c_int, [_P, _T, _T, _T, _T]),
     "cllm_quantize_row_q8_0": (C.c_int, [_P, _P, _P, C.c_int64]),

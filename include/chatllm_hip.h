@@ -189,6 +189,7 @@ CLLM_API int    cllm_op_flash_attn_ext(void * stream, const cllm_tensor * q, con
 /* the prefill attention block of the eager path, MUL_MAT(K, Q) + SCALE + DIAG_MASK_INF + SOFT_MAX + MUL_MAT(V^T, P) (src/layers.cpp:2499-2561),
  * as ONE flash kernel (qlen > 32: the tolerance tier, as the MFMA mat-muls it replaces):  q F32 [D, N, H]; k F16 [D, n_kv, Hkv] rows;
  * vt F16 [n_kv, D, Hkv] (the transposed V cache view); dst F32 [D, N, H] (any 16-byte aligned strides); causal with n_past. */
+CLLM_API int    cllm_attn_prefill_min_cols(void);   /* query rows from which callers should use it (33; CLLM_MMA_MIN_COLS; CLLM_FLASH_PREFILL=0: never) */
 CLLM_API int    cllm_op_attn_prefill(void * stream, const cllm_tensor * q, const cllm_tensor * k, const cllm_tensor * vt, cllm_tensor * dst,
                                      float scale, int n_past);
 

@@ -40,7 +40,9 @@ int main(int argc, char ** argv) {
     exe_dir = slash == std::string::npos ? "." : exe_dir.substr(0, slash);
     try {
         chatllm::ComputeManager::init(exe_dir);
-        chatllm::ModelObject::extra_args args(-1, "", false, threads, 4096, "f16");
+        // REF_CHAT_CACHE: --cache_dtype (f16 | q8_0 ...);  REF_CHAT_FA=1: -fa 1 (src/main.cpp:551-556, 974-978)
+        chatllm::ModelObject::extra_args args(-1, "", false, threads, 4096, getenv("REF_CHAT_CACHE") ? getenv("REF_CHAT_CACHE") : "f16");
+        if (const char * fa = getenv("REF_CHAT_FA")) args.flash_attention = fa;
         if (ngl != "cpu") args.model_n_gpu_layers["any"] = ngl;
         chatllm::ModelObject obj(path, args);
         chatllm::GenerationConfig gen(obj.model->get_max_length(), obj.model->get_max_length(), false, false, 1, 1.0f, 0.0f, threads, "greedy", 0.0f, 1.0f);
