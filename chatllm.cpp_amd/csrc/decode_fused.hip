@@ -147,17 +147,17 @@ __global__ void __launch_bounds__(1024) k_attn_decode(const float * __restrict__
     __syncthreads();
     mx = red_f[0];
     for (int w = 1; w < nw; w++) mx = fmaxf(mx, red_f[w]);
+    const int nv = n_kv & ~7;                  // (all threads compute the exponentials; the sum keeps the reference's order: see k_attn_dec)
+    for (int i = tid; i < n_kv; i += nthr) sc[i] = i < nv ? ggml_expf_poly(sc[i] - mx) : libm_expf(sc[i] - mx);
+    __syncthreads();
     if (wave == 0) {
-        const int nv = n_kv & ~7;
         double sum = 0.0;
         for (int gi = lane * 8; gi < nv; gi += 64 * 8) {
-            float e[8];
-#pragma unroll
-            for (int l = 0; l < 8; l++) { e[l] = ggml_expf_poly(sc[gi + l] - mx); sc[gi + l] = e[l]; }
-            const float a0 = e[0] + e[4], a1 = e[1] + e[5], a2 = e[2] + e[6], a3 = e[3] + e[7];
+            const f32x4 lo = *(const f32x4 *)(sc + gi), up = *(const f32x4 *)(sc + gi + 4);
+            const float a0 = lo.x + up.x, a1 = lo.y + up.y, a2 = lo.z + up.z, a3 = lo.w + up.w;
             sum += (double)((a0 + a2) + (a1 + a3));
         }
-        if (lane == 0) for (int i = nv; i < n_kv; i++) { const float e = libm_expf(sc[i] - mx); sc[i] = e; sum += (double) e; }
+        if (lane == 0) for (int i = nv; i < n_kv; i++) sum += (double) sc[i];
         sum = wave_sum_d(sum);
         if (lane == 0) red_d[0] = sum;
     }
@@ -335,17 +335,19 @@ __global__ void __launch_bounds__(1024) k_attn_dec(const float * __restrict__ qk
     mx = red_f[0];
 #pragma unroll
     for (int w = 1; w < 16; w++) mx = fmaxf(mx, red_f[w]);
+    // every exponential is independent: all threads compute them (the groups of 8 through the AVX2 polynomial, the n_kv mod 8 leftovers through
+    // expf, as ggml_vec_soft_max_f32 does); only the SUM keeps the reference's order (one wave, lane = groups of 8 -> double; leftovers last)
+    const int nv = n_kv & ~7;
+    for (int i = tid; i < n_kv; i += 1024) sc[i] = i < nv ? ggml_expf_poly(sc[i] - mx) : libm_expf(sc[i] - mx);
+    lds_barrier();
     if (wave == 0) {
-        const int nv = n_kv & ~7;
         double sum = 0.0;
         for (int gi = lane * 8; gi < nv; gi += 64 * 8) {
-            float e[8];
-#pragma unroll
-            for (int l = 0; l < 8; l++) { e[l] = ggml_expf_poly(sc[gi + l] - mx); sc[gi + l] = e[l]; }
-            const float a0 = e[0] + e[4], a1 = e[1] + e[5], a2 = e[2] + e[6], a3 = e[3] + e[7];
+            const f32x4 lo = *(const f32x4 *)(sc + gi), up = *(const f32x4 *)(sc + gi + 4);
+            const float a0 = lo.x + up.x, a1 = lo.y + up.y, a2 = lo.z + up.z, a3 = lo.w + up.w;
             sum += (double)((a0 + a2) + (a1 + a3));
         }
-        if (lane == 0) for (int i = nv; i < n_kv; i++) { const float e = libm_expf(sc[i] - mx); sc[i] = e; sum += (double) e; }
+        if (lane == 0) for (int i = nv; i < n_kv; i++) sum += (double) sc[i];
         sum = wave_sum_d(sum);
         if (lane == 0) red_d[0] = sum;
     }

@@ -318,15 +318,17 @@ __global__ void __launch_bounds__(64) k_fattn_merge(const fattn_args a) {
     for (int i = 0; i < D / 64; i++) dp[lane + 64 * i] = acc[i] * inv;
 }
 
+static int g_flash_min = -1;             // -1: not read yet
 int flash_prefill_min_cols() {
-    static const int v = [] {
+    if (g_flash_min < 0) {
         const char * off = getenv("CLLM_FLASH_PREFILL");
-        if (off && atoi(off) == 0) return 1 << 30;
         const char * e = getenv("CLLM_MMA_MIN_COLS");          // the same threshold as the MFMA mat-muls it replaces (matmul_f.hip): <= 32 columns stay exact
-        return e ? atoi(e) : 33;
-    }();
-    return v;
+        g_flash_min = off && atoi(off) == 0 ? 1 << 30 : e ? atoi(e) : 33;
+    }
+    return g_flash_min;
 }
+// tests: switch the runner's prefill attention between the flash kernel and the node sequence inside one process (<= 0: back to the environment)
+extern "C" __attribute__((visibility("default"))) void cllm_debug_set_attn_prefill_min_cols(int n) { g_flash_min = n > 0 ? n : -1; }
 size_t fattn_wsize(int64_t N, int64_t H, int64_t B, int64_t D) { return (size_t) B * H * N * 64 * (D + 4) * 4; }
 
 template <int D, int KVT, int VL, int MASK>
