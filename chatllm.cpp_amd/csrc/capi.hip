@@ -159,6 +159,18 @@ extern "C" int cllm_event_create(void ** event) {
 extern "C" int cllm_event_destroy(void * event) { if (event) HIP_TRY(hipEventDestroy((hipEvent_t) event)); return CLLM_OK; }
 extern "C" int cllm_event_record(void * event, void * stream) { HIP_TRY(hipEventRecord((hipEvent_t) event, (hipStream_t) stream)); return CLLM_OK; }
 extern "C" int cllm_event_sync(void * event) { HIP_TRY(hipEventSynchronize((hipEvent_t) event)); return CLLM_OK; }
+extern "C" int cllm_stream_wait_event(void * stream, void * event) {
+    if (!event) FAIL(CLLM_E_INVALID, "stream_wait_event: null event");
+    HIP_TRY(hipStreamWaitEvent((hipStream_t) stream, (hipEvent_t) event, 0));
+    return CLLM_OK;
+}
+extern "C" int cllm_memcpy_peer_async(void * dst, int dst_device, const void * src, int src_device, size_t bytes, void * stream) {
+    if (!bytes) return CLLM_OK;
+    if (!dst || !src) FAIL(CLLM_E_INVALID, "memcpy_peer_async: null");
+    if (dst_device == src_device) HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, (hipStream_t) stream));
+    else                          HIP_TRY(hipMemcpyPeerAsync(dst, dst_device, src, src_device, bytes, (hipStream_t) stream));
+    return CLLM_OK;
+}
 extern "C" int cllm_event_elapsed_ms(void * start, void * stop, float * ms) {
     if (!ms) FAIL(CLLM_E_INVALID, "event_elapsed: null");
     HIP_TRY(hipEventElapsedTime(ms, (hipEvent_t) start, (hipEvent_t) stop));

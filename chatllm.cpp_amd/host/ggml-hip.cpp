@@ -32,7 +32,7 @@ namespace {
 
 struct hip_device_ctx { int id; std::string name, desc; ggml_backend_buffer_type buft; };
 struct hip_backend_ctx {
-    int device; void * stream = nullptr; void * wdata = nullptr; size_t wsize = 0; void * abuf = nullptr; size_t asize = 0;
+    int device; void * stream = nullptr; void * wdata = nullptr; size_t wsize = 0; void * abuf = nullptr; size_t asize = 0; void * copy_event = nullptr;
     // replay of a token's launch list (graph_compute): the serialized arguments of every C-ABI call of the last graph, and the
     // captured graph of the list that came twice in a row
     std::vector<uint8_t> last_sig, graph_sig; void * graph_exec = nullptr; bool graph_broken = false; long replays = 0, captures = 0;
@@ -341,6 +341,7 @@ void be_free(ggml_backend_t b) {
     if (c->wdata) cllm_free(c->wdata);
     if (c->abuf) cllm_free(c->abuf);
     if (c->graph_exec) cllm_graph_destroy(c->graph_exec);
+    if (c->copy_event) cllm_event_destroy(c->copy_event);
     cllm_stream_destroy(c->stream);
     delete c; delete b;
 }
@@ -1127,15 +1128,50 @@ ggml_status be_graph_compute(ggml_backend_t backend, ggml_cgraph * g) {
     return GGML_STATUS_SUCCESS;       // asynchronous: the host calls synchronize() before it reads (src/backend.cpp:824-825)
 }
 
+// ---- events and the asynchronous copy between two backends of this module (ggml-backend-impl.h:87-127).  The scheduler uses them for the
+//      activations that cross a layer split (`-ngl 0:40;1:40`, ggml-backend.cpp:414-433, 1473-1477): without them it synchronizes both devices and
+//      goes through the blocking buffer copy at every boundary. ----
+bool be_is_ours(ggml_backend_t b);
+void be_event_record(ggml_backend_t b, ggml_backend_event_t e) {
+    auto * c = (hip_backend_ctx *) b->context; cllm_set_device(c->device);
+    if (cllm_event_record(e->context, c->stream) != CLLM_OK) GGML_LOG_ERROR("[ggml-hip] event_record failed: %s\n", cllm_last_error());
+}
+void be_event_wait(ggml_backend_t b, ggml_backend_event_t e) {
+    auto * c = (hip_backend_ctx *) b->context; cllm_set_device(c->device);
+    if (cllm_stream_wait_event(c->stream, e->context) != CLLM_OK) GGML_LOG_ERROR("[ggml-hip] event_wait failed: %s\n", cllm_last_error());
+}
+// src is complete once everything queued on backend_src so far has run; backend_dst must not touch dst before the copy has landed:
+// the copy goes on the SOURCE stream, an event recorded behind it is what the destination stream waits for.
+bool be_cpy_tensor_async(ggml_backend_t bs, ggml_backend_t bd, const ggml_tensor * src, ggml_tensor * dst) {
+    if (!be_is_ours(bs) || !be_is_ours(bd) || !src->buffer || !dst->buffer || src->buffer->iface.get_base != buf_base || dst->buffer->iface.get_base != buf_base) return false;
+    if (!ggml_is_contiguous(src) || !ggml_is_contiguous(dst) || ggml_nbytes(src) != ggml_nbytes(dst)) return false;
+    auto * cs = (hip_backend_ctx *) bs->context; auto * cd = (hip_backend_ctx *) bd->context;
+    auto * xs = (hip_buffer_ctx *) src->buffer->context; auto * xd = (hip_buffer_ctx *) dst->buffer->context;
+    if (xs->device != cs->device || xd->device != cd->device) return false;       // (a tensor living on a third device: the blocking path)
+    flush_sets();                                  // staged host writes to either tensor are ordered before the copy
+    xd->gen++;
+    { std::lock_guard<std::mutex> lock(g_ring.m); i32_forget(dst->data, ggml_nbytes(dst)); }
+    cllm_set_device(cs->device);
+    if (cllm_memcpy_peer_async(dst->data, cd->device, src->data, cs->device, ggml_nbytes(src), cs->stream) != CLLM_OK) { GGML_LOG_ERROR("[ggml-hip] cpy_tensor_async ('%s' -> '%s') failed: %s\n", src->name, dst->name, cllm_last_error()); return false; }
+    if (bs != bd) {
+        if (!cs->copy_event) { if (cllm_event_create(&cs->copy_event) != CLLM_OK) { cs->copy_event = nullptr; cllm_stream_sync(cs->stream); return true; } }
+        if (cllm_event_record(cs->copy_event, cs->stream) != CLLM_OK) { cllm_stream_sync(cs->stream); return true; }
+        cllm_set_device(cd->device);
+        if (cllm_stream_wait_event(cd->stream, cs->copy_event) != CLLM_OK) { cllm_set_device(cs->device); cllm_stream_sync(cs->stream); }
+    }
+    return true;
+}
 const ggml_backend_i k_backend_i = {
     be_name, be_free,
-    nullptr, nullptr, nullptr,          // set/get_tensor_async, cpy_tensor_async: the scheduler falls back to the synchronous buffer calls
+    nullptr, nullptr,                   // set/get_tensor_async: the buffer calls stage through the pinned ring already
+    be_cpy_tensor_async,
     be_sync,
     nullptr, nullptr, nullptr, nullptr, // graph plans
     be_graph_compute,
-    nullptr, nullptr,                   // events
+    be_event_record, be_event_wait,
     nullptr,                            // graph_optimize
 };
+bool be_is_ours(ggml_backend_t b) { return b && b->iface.get_name == be_name; }
 ggml_guid k_guid = { 0x63, 0x6c, 0x6c, 0x6d, 0x2d, 0x68, 0x69, 0x70, 0x2d, 0x67, 0x66, 0x78, 0x39, 0x35, 0x30, 0x01 };
 
 // ---------------------------------------------------------------------------------------------------------------------------
@@ -1148,7 +1184,7 @@ enum ggml_backend_dev_type dev_type(ggml_backend_dev_t) { return GGML_BACKEND_DE
 void dev_props(ggml_backend_dev_t d, ggml_backend_dev_props * p) {
     p->name = dev_name(d); p->description = dev_desc(d); p->type = GGML_BACKEND_DEVICE_TYPE_GPU; p->device_id = nullptr;
     dev_memory(d, &p->memory_free, &p->memory_total);
-    p->caps = { /*async*/ true, /*host_buffer*/ false, /*buffer_from_host_ptr*/ false, /*events*/ false };
+    p->caps = { /*async*/ true, /*host_buffer*/ false, /*buffer_from_host_ptr*/ false, /*events*/ true };
 }
 ggml_backend_t dev_init(ggml_backend_dev_t d, const char *) {
     auto * dc = (hip_device_ctx *) d->context;
@@ -1159,12 +1195,20 @@ ggml_backend_t dev_init(ggml_backend_dev_t d, const char *) {
 }
 ggml_backend_buffer_type_t dev_buft(ggml_backend_dev_t d) { return &((hip_device_ctx *) d->context)->buft; }
 bool dev_supports_buft(ggml_backend_dev_t d, ggml_backend_buffer_type_t t) { return t->iface.get_name == buft_name && t->context == d->context; }
+ggml_backend_event_t dev_event_new(ggml_backend_dev_t d) {
+    cllm_set_device(((hip_device_ctx *) d->context)->id);
+    void * e = nullptr;
+    if (cllm_event_create(&e) != CLLM_OK) { GGML_LOG_ERROR("[ggml-hip] event_new failed: %s\n", cllm_last_error()); return nullptr; }
+    return new ggml_backend_event{ d, e };
+}
+void dev_event_free(ggml_backend_dev_t, ggml_backend_event_t e) { if (e) { cllm_event_destroy(e->context); delete e; } }
+void dev_event_synchronize(ggml_backend_dev_t, ggml_backend_event_t e) { if (cllm_event_sync(e->context) != CLLM_OK) GGML_LOG_ERROR("[ggml-hip] event_synchronize failed: %s\n", cllm_last_error()); }
 const ggml_backend_device_i k_device_i = {
     dev_name, dev_desc, dev_memory, dev_type, dev_props, dev_init, dev_buft,
     nullptr, nullptr,                   // host buffer type, buffer_from_host_ptr (SURVEY.md 8b note: keep NULL)
     dev_supports_op, dev_supports_buft,
     nullptr,                            // offload_op
-    nullptr, nullptr, nullptr,          // events
+    dev_event_new, dev_event_free, dev_event_synchronize,
 };
 std::vector<ggml_backend_device> g_dev_objs;
 

@@ -62,6 +62,8 @@ SIGNATURES = {
     "cllm_event_destroy": (C.c_int, [_P]),
     "cllm_event_record": (C.c_int, [_P, _P]),
     "cllm_event_sync": (C.c_int, [_P]),
+    "cllm_stream_wait_event": (C.c_int, [_P, _P]),
+    "cllm_memcpy_peer_async": (C.c_int, [_P, C.c_int, _P, C.c_int, C.c_size_t, _P]),
     "cllm_event_elapsed_ms": (C.c_int, [_P, _P, C.POINTER(C.c_float)]),
     "cllm_mul_mat_wsize": (C.c_size_t, [_T, _T]),
     "cllm_op_mul_mat": (C.c_int, [_P, _T, _T, _T, _P, C.c_size_t]),

@@ -87,6 +87,11 @@ CLLM_API int  cllm_event_destroy(void * event);
 CLLM_API int  cllm_event_record(void * event, void * stream);
 CLLM_API int  cllm_event_sync(void * event);
 CLLM_API int  cllm_event_elapsed_ms(void * start, void * stop, float * ms);
+/* cross-stream / cross-device ordering for ggml_backend_i.event_wait and cpy_tensor_async (ggml-backend-impl.h:87-127; scheduler use:
+ * ggml-backend.cpp:414-433, 1473-1477): `stream` waits for `event`; an asynchronous device-to-device copy between two devices of this
+ * process, queued on `stream` (hipMemcpyPeerAsync; same device: a plain d2d copy). */
+CLLM_API int  cllm_stream_wait_event(void * stream, void * event);
+CLLM_API int  cllm_memcpy_peer_async(void * dst, int dst_device, const void * src, int src_device, size_t bytes, void * stream);
 
 /* ---- the hot path: GGML_OP_MUL_MAT ------------------------------------------------------
  * replaces ggml_compute_forward_mul_mat (ggml/src/ggml-cpu/ggml-cpu.c:1229-1421) and, for Q4_0/Q8_0

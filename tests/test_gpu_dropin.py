@@ -327,3 +327,12 @@ def test_reference_host_long_prompt_uses_the_flash_prefill(gpu, tmp_path):
     dev_n, _ = _tolerance_tier(lg_c, lg_n, ids_c, 0.25)
     print(f"70-token prompt: flash prefill max|dlogit| = {dev:.2e} sigma, node sequence (MFMA mat-muls) {dev_n:.2e} sigma")
     assert dev < 2 * dev_n + 1e-3                                    # the fused form is no worse than the node sequence it replaces
+
+
+@pytest.mark.skipif(not (os.path.exists(os.path.join(REF, "ref_backend_async")) and os.path.exists(os.path.join(REF, "libggml-hip.so"))),
+                    reason="oracle/_ref (reference ggml + module) not built")
+def test_module_events_and_async_copy_between_backends(gpu):
+    """ggml_backend_i.cpy_tensor_async / event_record / event_wait and the device's event_new / event_synchronize (ggml-backend-impl.h:87-127),
+    driven through the reference's public ggml-backend API the way its scheduler does at a layer split: two backends (streams), a -> b -> a"""
+    r = subprocess.run([os.path.join(REF, "ref_backend_async"), os.path.join(REF, "libggml-hip.so"), str(3 << 20)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and r.stdout.startswith("OK"), (r.stdout, r.stderr[-1500:])
