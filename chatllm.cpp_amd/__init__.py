@@ -14,9 +14,9 @@ The directory name contains a dot, so import it with `load_package()` from the r
     mod = importlib.util.module_from_spec(spec); sys.modules["chatllm_cpp_amd"] = mod; spec.loader.exec_module(mod)
 """
 from . import lib as lib          # noqa: F401  (ctypes binding, loads lazily)
-from .tensor import Tensor, F32, F16, Q4_0, Q4_1, Q8_0, Q4_K, I32, I64  # noqa: F401
+from .tensor import Tensor, F32, F16, Q4_0, Q4_1, Q8_0, Q4_K, Q5_K, Q6_K, I32, I64  # noqa: F401
 from . import ops                 # noqa: F401
 from . import synth               # noqa: F401
 from .llama import Llama          # noqa: F401
 
-__all__ = ["lib", "Tensor", "ops", "synth", "Llama", "F32", "F16", "Q4_0", "Q4_1", "Q8_0", "Q4_K", "I32", "I64"]
+__all__ = ["lib", "Tensor", "ops", "synth", "Llama", "F32", "F16", "Q4_0", "Q4_1", "Q8_0", "Q4_K", "Q5_K", "Q6_K", "I32", "I64"]

@@ -30,6 +30,7 @@ extern "C" size_t cllm_type_size(int type) {
         case CLLM_TYPE_F16: return 2;
         case CLLM_TYPE_I64: return 8;
         case CLLM_TYPE_Q4_0: return 18; case CLLM_TYPE_Q4_1: return 20; case CLLM_TYPE_Q8_0: return 34; case CLLM_TYPE_Q4_K: return 144;
+        case CLLM_TYPE_Q5_K: return 176; case CLLM_TYPE_Q6_K: return 210;
     }
     return 0;
 }
@@ -37,7 +38,7 @@ extern "C" int cllm_blck_size(int type) {
     switch (type) {
         case CLLM_TYPE_F32: case CLLM_TYPE_I32: case CLLM_TYPE_F16: case CLLM_TYPE_I64: return 1;
         case CLLM_TYPE_Q4_0: case CLLM_TYPE_Q4_1: case CLLM_TYPE_Q8_0: return 32;
-        case CLLM_TYPE_Q4_K: return 256;
+        case CLLM_TYPE_Q4_K: case CLLM_TYPE_Q5_K: case CLLM_TYPE_Q6_K: return 256;
     }
     return 0;
 }
@@ -178,7 +179,7 @@ extern "C" int cllm_event_elapsed_ms(void * start, void * stop, float * ms) {
 }
 
 // ---- MUL_MAT dispatch ---------------------------------------------------------------------------------------------
-static bool is_quant(int t) { return is_quant_type(t); }
+static bool is_quant(int t) { return is_quant_type(t) || is_kq_type(t); }
 static int  act_kind(int wtype) { return act_kind_of(wtype); }
 
 // Columns from which the quantized product runs on the matrix cores (mmq.hip: exact integer block sums, its own fp32 summation order =
@@ -216,6 +217,24 @@ extern "C" int cllm_op_mul_mat(void * stream, const cllm_tensor * src0, const cl
     if (src0->ne[0] == 0) return cllm_memset(dst->data, 0, dst->nb[3] * (size_t) dst->ne[3], stream);
 
     if (!is_quant(src0->type)) return launch_mul_mat_f(st, src0->type, tv(src0), tv(src1), tv(dst));
+    if (is_kq_type(src0->type)) {                      // Q5_K / Q6_K: the exact-order kernel for any number of columns (gemv_kq.hip)
+        const size_t stride = act_row_bytes(src0->ne[0], ACT_Q8_K), need = stride * (size_t) t_nrows(src1);
+        if (!wdata || wsize < need) FAIL(CLLM_E_INVALID, "mul_mat: wdata too small (%zu < %zu)", wsize, need);
+        if ((uintptr_t) wdata % 16 || (uintptr_t) src1->data % 16 || src1->nb[1] % 16 || src1->nb[2] % 16 || src1->nb[3] % 16) FAIL(CLLM_E_UNSUPPORTED, "mul_mat: operand alignment");
+        if ((rc = launch_quantize_act(st, ACT_Q8_K, tv(src1), wdata, stride))) return rc;
+        const int64_t r2 = src1->ne[2] / src0->ne[2], r3 = src1->ne[3] / src0->ne[3];
+        for (int64_t i13 = 0; i13 < src1->ne[3]; i13++)
+        for (int64_t i12 = 0; i12 < src1->ne[2]; i12++) {
+            tview w = tv(src0);
+            w.data += (i12 / r2) * w.nb[2] + (i13 / r3) * w.nb[3];
+            const char * act = (const char *) wdata + (size_t)(i12 * src1->ne[1] + i13 * src1->ne[1] * src1->ne[2]) * stride;
+            if (dst->nb[1] % 4) FAIL(CLLM_E_INVALID, "mul_mat: dst stride");
+            rc = launch_gemv_kq(st, src0->type, w, act, stride, src1->ne[1], (float *)((char *) dst->data + i12 * dst->nb[2] + i13 * dst->nb[3]), (int64_t)(dst->nb[1] / 4));
+            if (rc == CLLM_E_UNSUPPORTED) FAIL(rc, "mul_mat: Q5_K / Q6_K shape or alignment not taken");
+            if (rc) return rc;
+        }
+        return CLLM_OK;
+    }
 
     const int kind = act_kind(src0->type);
     const int64_t K = src0->ne[0];
@@ -266,7 +285,7 @@ extern "C" int cllm_bench_mul_mat_kernel(void * stream, const cllm_tensor * src0
                                          cllm_tensor * dst, void * wdata, size_t wsize, int iters, float * avg_us) {
     int rc = check_mm(src0, src1, dst, "bench_mul_mat_kernel");
     if (rc) return rc;
-    if (!is_quant(src0->type) || src0->ne[2] != 1 || src0->ne[3] != 1 || src1->ne[2] != 1 || src1->ne[3] != 1 || !src0_datas || n_src0 <= 0 || iters <= 0 || !avg_us)
+    if (!is_quant_type(src0->type) || src0->ne[2] != 1 || src0->ne[3] != 1 || src1->ne[2] != 1 || src1->ne[3] != 1 || !src0_datas || n_src0 <= 0 || iters <= 0 || !avg_us)
         FAIL(CLLM_E_INVALID, "bench_mul_mat_kernel: 2-D quantized operands only");
     hipStream_t st = (hipStream_t) stream;
     const int kind = act_kind(src0->type);
@@ -304,7 +323,7 @@ extern "C" int cllm_bench_mul_mat_kernel(void * stream, const cllm_tensor * src0
 extern "C" int cllm_op_mul_mat_vec_fused(void * stream, const cllm_tensor * src0, int pro, const float * px, const float * pw, float eps, int epi,
                                          const float * resid, float * dst) {
     if (!src0 || !px || !dst || (pro != 1 && pro != 2 && pro != 4) || ((pro == 1 || pro == 4) && !pw) || (epi != 0 && epi != 1)) FAIL(CLLM_E_INVALID, "mul_mat_vec_fused: arguments");
-    if (!is_quant(src0->type) || src0->ne[2] != 1 || src0->ne[3] != 1 || src0->nb[1] != cllm_row_size(src0->type, src0->ne[0])) FAIL(CLLM_E_UNSUPPORTED, "mul_mat_vec_fused: src0 must be a dense 2-D quantized matrix");
+    if (!is_quant_type(src0->type) || src0->ne[2] != 1 || src0->ne[3] != 1 || src0->nb[1] != cllm_row_size(src0->type, src0->ne[0])) FAIL(CLLM_E_UNSUPPORTED, "mul_mat_vec_fused: src0 must be a dense 2-D quantized matrix");
     if (((uintptr_t) px | (uintptr_t) pw | (uintptr_t) src0->data) & 15) FAIL(CLLM_E_UNSUPPORTED, "mul_mat_vec_fused: alignment");
     return launch_gemv_decode((hipStream_t) stream, src0->type, src0->data, src0->ne[0], src0->ne[1], pro, px, pw, eps, epi, dst, nullptr, resid);
 }
@@ -356,7 +375,7 @@ extern "C" int cllm_bench_mul_mat_id(void * stream, const cllm_tensor * as, cons
 // times the DECODE form of the mat-vec (activation prologue inside the kernel, exactly what cllm_llama's fused step launches)
 extern "C" int cllm_bench_gemv_fused(void * stream, int wtype, void * const * w_datas, int n_w, int64_t K, int64_t nrows, int pro,
                                      const float * px, const float * pw, float eps, int epi, float * dst, const float * resid, int iters, float * avg_us) {
-    if (!is_quant(wtype) || !w_datas || n_w <= 0 || iters <= 0 || !avg_us || !px || !dst || pro < 1 || pro > 3) FAIL(CLLM_E_INVALID, "bench_gemv_fused: arguments");
+    if (!is_quant_type(wtype) || !w_datas || n_w <= 0 || iters <= 0 || !avg_us || !px || !dst || pro < 1 || pro > 3) FAIL(CLLM_E_INVALID, "bench_gemv_fused: arguments");
     hipStream_t st = (hipStream_t) stream;
     hipEvent_t e0, e1;
     HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
@@ -382,7 +401,7 @@ extern "C" int cllm_bench_gemv_fused(void * stream, int wtype, void * const * w_
 // [K, 2F, E]; dst[u, slot] = silu(gate_e[u] . x) * (up_e[u] . x), e = ids[slot]; b: [K, 1 | n_used, 1], dst: [F, n_used, 1]
 extern "C" int cllm_op_mul_mat_id_silu_mul(void * stream, const cllm_tensor * as_gu, const cllm_tensor * b, const cllm_tensor * ids, cllm_tensor * dst) {
     if (!as_gu || !b || !ids || !dst) FAIL(CLLM_E_INVALID, "mul_mat_id_silu_mul: null");
-    if (!is_quant(as_gu->type) || b->type != CLLM_TYPE_F32 || dst->type != CLLM_TYPE_F32 || ids->type != CLLM_TYPE_I32) FAIL(CLLM_E_UNSUPPORTED, "mul_mat_id_silu_mul: types");
+    if (!is_quant_type(as_gu->type) || b->type != CLLM_TYPE_F32 || dst->type != CLLM_TYPE_F32 || ids->type != CLLM_TYPE_I32) FAIL(CLLM_E_UNSUPPORTED, "mul_mat_id_silu_mul: types");
     const int64_t n_used = ids->ne[0];
     if (ids->ne[1] != 1 || as_gu->ne[0] != b->ne[0] || as_gu->ne[1] % 2 || dst->ne[0] != as_gu->ne[1] / 2 || dst->ne[1] != n_used || dst->ne[2] != 1 || b->ne[2] != 1 ||
         (b->ne[1] != 1 && b->ne[1] != n_used)) FAIL(CLLM_E_INVALID, "mul_mat_id_silu_mul: shapes (one token)");
@@ -397,7 +416,7 @@ extern "C" int cllm_op_mul_mat_id(void * stream, const cllm_tensor * as, const c
     int rc = check_mm(as, b, dst, "mul_mat_id");
     if (rc) return rc;
     if (!ids || ids->type != CLLM_TYPE_I32) FAIL(CLLM_E_INVALID, "mul_mat_id: ids must be I32");
-    if (!is_quant(as->type)) FAIL(CLLM_E_UNSUPPORTED, "mul_mat_id: expert weights must be Q4_0/Q4_1/Q8_0/Q4_K");
+    if (!is_quant_type(as->type)) FAIL(CLLM_E_UNSUPPORTED, "mul_mat_id: expert weights must be Q4_0/Q4_1/Q8_0/Q4_K");
     const int64_t n_used = ids->ne[0], n_tok = ids->ne[1];
     if (as->ne[3] != 1 || b->ne[3] != 1 || dst->ne[3] != 1 || ids->ne[2] != 1 || ids->ne[3] != 1) FAIL(CLLM_E_INVALID, "mul_mat_id: 4-D operands");
     if (dst->ne[0] != as->ne[1] || dst->ne[1] != n_used || dst->ne[2] != n_tok || b->ne[2] != n_tok) FAIL(CLLM_E_INVALID, "mul_mat_id: shapes");

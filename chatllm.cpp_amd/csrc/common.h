@@ -27,6 +27,9 @@ struct __attribute__((packed)) block_q4_1 { uint16_t d, m; uint8_t qs[16]; };   
 struct __attribute__((packed)) block_q8_1 { uint16_t d, s; int8_t  qs[32]; };                    // 36 B: s = d * sum(qs)
 struct __attribute__((packed)) block_q4_K { uint16_t d, dmin; uint8_t scales[12]; uint8_t qs[128]; }; // 144 B
 struct __attribute__((packed)) block_q8_K { float d; int8_t qs[256]; int16_t bsums[16]; };      // 292 B
+struct __attribute__((packed)) block_q5_K { uint16_t d, dmin; uint8_t scales[12]; uint8_t qh[32]; uint8_t qs[128]; };   // 176 B (ggml-common.h:308-321)
+struct __attribute__((packed)) block_q6_K { uint8_t ql[128]; uint8_t qh[64]; int8_t scales[16]; uint16_t d; };          // 210 B (ggml-common.h:323-336)
+static_assert(sizeof(block_q5_K) == 176 && sizeof(block_q6_K) == 210, "block sizes");
 static_assert(sizeof(block_q4_1) == 20 && sizeof(block_q8_1) == 36, "block sizes");
 static_assert(sizeof(block_q4_0) == 18 && sizeof(block_q8_0) == 34 && sizeof(block_q4_K) == 144 && sizeof(block_q8_K) == 292, "block sizes");
 
@@ -46,7 +49,8 @@ __host__ __device__ inline size_t act_off_d(int64_t K) { return act_align16((siz
 __host__ __device__ inline size_t act_off_s(int64_t K, int kind) { return act_off_d(K) + act_align16((size_t)(K / act_blk(kind)) * 4); }
 __host__ __device__ inline size_t act_row_bytes(int64_t K, int kind) { return act_off_s(K, kind) + act_align16((size_t)(K / 32) * 4); }
 // the activation format a weight type's dot product reads (type_traits_cpu[].vec_dot_type, ggml-cpu/ggml-cpu.c:207-390)
-__host__ __device__ inline int    act_kind_of(int wtype) { return wtype == CLLM_TYPE_Q4_K ? ACT_Q8_K : wtype == CLLM_TYPE_Q4_1 ? ACT_Q8_1 : ACT_Q8_0; }
+__host__ __device__ inline bool   is_kq_type(int t) { return t == CLLM_TYPE_Q5_K || t == CLLM_TYPE_Q6_K; }        // gemv_kq.hip: mat-mul and GET_ROWS, no fused forms
+__host__ __device__ inline int    act_kind_of(int wtype) { return (wtype == CLLM_TYPE_Q4_K || is_kq_type(wtype)) ? ACT_Q8_K : wtype == CLLM_TYPE_Q4_1 ? ACT_Q8_1 : ACT_Q8_0; }
 __host__ __device__ inline bool   is_quant_type(int t) { return t == CLLM_TYPE_Q4_0 || t == CLLM_TYPE_Q4_1 || t == CLLM_TYPE_Q8_0 || t == CLLM_TYPE_Q4_K; }
 
 // ---- small device helpers -----------------------------------------------------------------------
@@ -266,6 +270,7 @@ int flash_prefill_min_cols();          // query rows from which the eager attent
 size_t fattn_wsize(int64_t N, int64_t H, int64_t B, int64_t D);
 int launch_fattn(hipStream_t st, const tview & q, const tview & k, int ktype, const tview & v, int vl, const tview * mask, int causal_past,
                  char * dst, int64_t nbn, int64_t nbh, int64_t nbb, float scale, void * wdata, size_t wsize);
+int launch_gemv_kq(hipStream_t st, int wtype, const tview & w, const void * act, size_t act_stride, int64_t M, float * dst, int64_t ldd);
 int launch_dense_f16(hipStream_t st, int wtype, const tview & w, const tview & x, const tview & d);
 int launch_gemv_rows(hipStream_t st, const void * W, int64_t K, int64_t nrows, int pro, const float * px, const float * pw, float eps, int epi, float * dst, const float * bias, const float * resid);
 int launch_mmvq_fused(hipStream_t st, int wtype, const void * W, int64_t K, int64_t nrows, int pro, const float * px, const float * pw, float eps, int epi, float * dst, const float * bias, const float * resid);

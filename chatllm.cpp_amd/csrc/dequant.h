@@ -29,6 +29,26 @@ __device__ __forceinline__ float dequant_elem(int type, const char * row, int64_
             const float d1 = h2f(b->d) * (float) sc, m1 = h2f(b->dmin) * (float) m;     // d*sc and min*m rounded first (ggml-quants.c:1364-1367)
             return d1 * (float) q - m1;
         }
+        case CLLM_TYPE_Q5_K: {                     // dequantize_row_q5_K (ggml-quants.c:1554-1579)
+            const block_q5_K * b = (const block_q5_K *) row + i / 256; const int e = (int)(i % 256);
+            const int s = e / 32, l = e % 32;
+            int sc, m;
+            if (s < 4) { sc = b->scales[s] & 63; m = b->scales[s + 4] & 63; }
+            else { sc = (b->scales[s + 4] & 0xF) | ((b->scales[s - 4] >> 6) << 4); m = (b->scales[s + 4] >> 4) | ((b->scales[s] >> 6) << 4); }
+            const uint8_t qb = b->qs[(s >> 1) * 32 + l];
+            const int q = ((s & 1) ? (qb >> 4) : (qb & 0xF)) + (((b->qh[l] >> s) & 1) ? 16 : 0);
+            const float d1 = h2f(b->d) * (float) sc, m1 = h2f(b->dmin) * (float) m;
+            return d1 * (float) q - m1;
+        }
+        case CLLM_TYPE_Q6_K: {                     // dequantize_row_q6_K (ggml-quants.c:1762-1791): (d * sc) * q, q = 6 bits - 32
+            const block_q6_K * b = (const block_q6_K *) row + i / 256; const int e = (int)(i % 256);
+            const int j = e / 128, g = (e % 128) / 32, l = e % 32;
+            const uint8_t lb = b->ql[64 * j + 32 * (g & 1) + l];
+            const int lo = g < 2 ? (lb & 0xF) : (lb >> 4);
+            const int q = (int)(int8_t)(lo | (((b->qh[32 * j + l] >> (2 * g)) & 3) << 4)) - 32;
+            const float ds = h2f(b->d) * (float) b->scales[8 * j + 2 * g + l / 16];
+            return ds * (float) q;
+        }
     }
     return 0.0f;
 }

@@ -603,7 +603,7 @@ __global__ void __launch_bounds__(256) k_cpy_qrows(tview s, tview d, int row_byt
 }
 extern "C" int cllm_op_cpy(void * stream, const cllm_tensor * src, cllm_tensor * dst) {
     if (!src || !dst) FAIL(CLLM_E_INVALID, "cpy: null");
-    if (src->type == dst->type && is_quant_type(src->type)) {
+    if (src->type == dst->type && (is_quant_type(src->type) || is_kq_type(src->type))) {
         const size_t rb = cllm_row_size(src->type, src->ne[0]);
         if (src->ne[0] != dst->ne[0] || t_nelements(src) != t_nelements(dst) || src->nb[0] != cllm_type_size(src->type) || dst->nb[0] != src->nb[0] || rb % 2) FAIL(CLLM_E_UNSUPPORTED, "cpy: quantized rows must stay whole");
         if ((((uintptr_t) src->data | src->nb[1] | src->nb[2] | src->nb[3] | (uintptr_t) dst->data | dst->nb[1] | dst->nb[2] | dst->nb[3]) & 1)) FAIL(CLLM_E_UNSUPPORTED, "cpy: alignment");
@@ -651,7 +651,7 @@ __global__ void __launch_bounds__(256) k_get_rows(int type, tview s, tview idx, 
 extern "C" int cllm_op_get_rows(void * stream, const cllm_tensor * src, const cllm_tensor * idx, cllm_tensor * dst) {
     if (!src || !idx || !dst) FAIL(CLLM_E_INVALID, "get_rows: null");
     if (idx->type != CLLM_TYPE_I32 || dst->type != CLLM_TYPE_F32) FAIL(CLLM_E_UNSUPPORTED, "get_rows: type");
-    switch (src->type) { case CLLM_TYPE_F32: case CLLM_TYPE_F16: case CLLM_TYPE_Q4_0: case CLLM_TYPE_Q4_1: case CLLM_TYPE_Q8_0: case CLLM_TYPE_Q4_K: break; default: FAIL(CLLM_E_UNSUPPORTED, "get_rows: src type %d", src->type); }
+    switch (src->type) { case CLLM_TYPE_F32: case CLLM_TYPE_F16: case CLLM_TYPE_Q4_0: case CLLM_TYPE_Q4_1: case CLLM_TYPE_Q8_0: case CLLM_TYPE_Q4_K: case CLLM_TYPE_Q5_K: case CLLM_TYPE_Q6_K: break; default: FAIL(CLLM_E_UNSUPPORTED, "get_rows: src type %d", src->type); }
     if (dst->ne[0] != src->ne[0] || dst->ne[1] != idx->ne[0] || dst->ne[2] != idx->ne[1] || dst->ne[3] != idx->ne[2] || dst->nb[0] != 4) FAIL(CLLM_E_INVALID, "get_rows: shape");
     const int64_t n = t_nelements(dst);
     if (n == 0) return CLLM_OK;

@@ -8,7 +8,7 @@ import zlib
 
 import numpy as np
 
-from .tensor import F32, Q4_0, Q4_1, Q8_0, Q4_K, TYPE_SIZE, BLCK  # noqa: F401
+from .tensor import F32, Q4_0, Q4_1, Q8_0, Q4_K, Q5_K, Q6_K, TYPE_SIZE, BLCK  # noqa: F401
 
 CONFIGS = {
     # name: n_layer, hidden, n_head, n_kv_head, head_dim, ffn, vocab
@@ -73,6 +73,38 @@ def quant_blocks(type_, rows, K, rng, sigma):
         nib = np.clip(np.rint(rng.standard_normal((rows, nb, 256), np.float32) * 2.5 + 7.5), 0, 15).astype(np.uint8)
         nib = nib.reshape(rows, nb, 4, 2, 32)                           # 4 groups of 64: low nibbles then high nibbles
         out[:, :, 16:] = (nib[:, :, :, 0, :] | (nib[:, :, :, 1, :] << 4)).reshape(rows, nb, 128)
+    elif type_ == Q5_K:                                                 # Q4_K's header + a fifth bit per weight (ggml-common.h:308-321)
+        out = np.empty((rows, nb, 176), np.uint8)
+        sc = rng.integers(20, 64, (rows, nb, 8), dtype=np.uint8)
+        m = np.clip(np.rint(sc.astype(np.float32) * (15.5 / 8.0)), 0, 63).astype(np.uint8)          # w = d*sc*q - dmin*m, q ~ N(15.5, 5^2): ~zero-mean
+        d = rng.uniform(0.5, 1.5, (rows, nb)) * sigma / (42.0 * 5.0)
+        out[:, :, 0:2] = _f16_bytes(d).reshape(rows, nb, 2)
+        out[:, :, 2:4] = _f16_bytes(d * 8.0).reshape(rows, nb, 2)
+        s = out[:, :, 4:16]
+        s[:, :, 0:4] = (sc[:, :, 0:4] & 63) | ((sc[:, :, 4:8] >> 4) << 6)
+        s[:, :, 4:8] = (m[:, :, 0:4] & 63) | ((m[:, :, 4:8] >> 4) << 6)
+        s[:, :, 8:12] = (sc[:, :, 4:8] & 0xF) | ((m[:, :, 4:8] & 0xF) << 4)
+        q = np.clip(np.rint(rng.standard_normal((rows, nb, 256), np.float32) * 5.0 + 15.5), 0, 31).astype(np.uint8)
+        q = q.reshape(rows, nb, 4, 2, 32)                               # 4 groups of 64: low nibbles then high nibbles; bit 4 -> qh bit 2g + half
+        out[:, :, 48:] = ((q[:, :, :, 0, :] & 15) | ((q[:, :, :, 1, :] & 15) << 4)).reshape(rows, nb, 128)
+        qh = np.zeros((rows, nb, 32), np.uint8)
+        for g in range(4):
+            qh |= ((q[:, :, g, 0, :] >> 4) << (2 * g)) | ((q[:, :, g, 1, :] >> 4) << (2 * g + 1))
+        out[:, :, 16:48] = qh
+    elif type_ == Q6_K:                                                 # ql[128] qh[64] scales[16] d (ggml-common.h:323-336): w = d * sc * (q - 32)
+        out = np.empty((rows, nb, 210), np.uint8)
+        sc = rng.integers(40, 128, (rows, nb, 16)).astype(np.int8) * rng.choice(np.array([1, 1, 1, -1], np.int8), (rows, nb, 16))
+        d = rng.uniform(0.5, 1.5, (rows, nb)) * sigma / (84.0 * 10.0)
+        out[:, :, 208:210] = _f16_bytes(d).reshape(rows, nb, 2)
+        out[:, :, 192:208] = sc.view(np.uint8)
+        q = np.clip(np.rint(rng.standard_normal((rows, nb, 256), np.float32) * 10.0 + 32.0), 0, 63).astype(np.uint8)
+        q = q.reshape(rows, nb, 2, 4, 32)                               # halves of 128: four groups of 32 (dequantize_row_q6_K, ggml-quants.c:1762-1791)
+        ql = np.empty((rows, nb, 2, 64), np.uint8)
+        ql[:, :, :, 0:32] = (q[:, :, :, 0, :] & 15) | ((q[:, :, :, 2, :] & 15) << 4)
+        ql[:, :, :, 32:64] = (q[:, :, :, 1, :] & 15) | ((q[:, :, :, 3, :] & 15) << 4)
+        out[:, :, 0:128] = ql.reshape(rows, nb, 128)
+        qh = (q[:, :, :, 0, :] >> 4) | ((q[:, :, :, 1, :] >> 4) << 2) | ((q[:, :, :, 2, :] >> 4) << 4) | ((q[:, :, :, 3, :] >> 4) << 6)
+        out[:, :, 128:192] = qh.reshape(rows, nb, 64)
     else:
         raise ValueError(type_)
     return out.reshape(rows, nb * TYPE_SIZE[type_])
@@ -80,18 +112,20 @@ def quant_blocks(type_, rows, K, rng, sigma):
 
 def down_type(cfg, wtype):
     """the reference falls back to Q8_0 when a row is not a multiple of 256 (convert.py:811-829, src/layers.cpp:81-95)"""
-    return Q8_0 if (wtype == Q4_K and cfg["ffn"] % 256) else wtype
+    return Q8_0 if (wtype in (Q4_K, Q5_K, Q6_K) and cfg["ffn"] % 256) else wtype
 
 
 def tensor_list(cfg, wtype, tp_rank=0, tp_size=1):
     """[(name, type, rows, K, row_slice)] of one (shard of a) model; row_slice selects the tensor-parallel rows"""
     H, hd, F, V = cfg["hidden"], cfg["head_dim"], cfg["ffn"], cfg["vocab"]
     QD, KD = cfg["n_head"] * hd, cfg["n_kv_head"] * hd
-    out = [("tok_embd", wtype, V, H), ("lm_head", wtype, V, H)]
+    mix = cfg.get("mix") or {}                  # per-tensor types by suffix, like the Q4_K_M / Q5_K_M mixes of third-party files: {"wv": Q6_K, "lm_head": Q6_K}
+    t = lambda n: mix.get(n, wtype)             # noqa: E731
+    out = [("tok_embd", t("tok_embd"), V, H), ("lm_head", t("lm_head"), V, H)]
     for i in range(cfg["n_layer"]):
         p = f"layers.{i}."
-        out += [(p + "wq", wtype, QD, H), (p + "wk", wtype, KD, H), (p + "wv", wtype, KD, H), (p + "wo", wtype, H, QD),
-                (p + "wgate", wtype, F, H), (p + "wup", wtype, F, H), (p + "wdown", down_type(cfg, wtype), H, F)]
+        out += [(p + "wq", t("wq"), QD, H), (p + "wk", t("wk"), KD, H), (p + "wv", t("wv"), KD, H), (p + "wo", t("wo"), H, QD),
+                (p + "wgate", t("wgate"), F, H), (p + "wup", t("wup"), F, H), (p + "wdown", down_type(cfg, t("wdown")), H, F)]
     return out
 
 

@@ -28,13 +28,14 @@ size_t orc_type_size(int type) {
         case ORC_Q4_0: return sizeof(orc_block_q4_0);  case ORC_Q8_0: return sizeof(orc_block_q8_0);
         case ORC_Q4_1: return sizeof(orc_block_q4_1);  case ORC_Q8_1: return sizeof(orc_block_q8_1);
         case ORC_Q4_K: return sizeof(orc_block_q4_K);  case ORC_Q8_K: return sizeof(orc_block_q8_K);
+        case ORC_Q5_K: return sizeof(orc_block_q5_K);  case ORC_Q6_K: return sizeof(orc_block_q6_K);
     }
     return 0;
 }
 int orc_blck_size(int type) {
     switch (type) {
         case ORC_Q4_0: case ORC_Q8_0: case ORC_Q4_1: case ORC_Q8_1: return ORC_QK;
-        case ORC_Q4_K: case ORC_Q8_K: return ORC_QK_K;
+        case ORC_Q4_K: case ORC_Q5_K: case ORC_Q6_K: case ORC_Q8_K: return ORC_QK_K;
         case ORC_F32: case ORC_F16: case ORC_I32: case ORC_I64: return 1;
     }
     return 0;
@@ -222,12 +223,51 @@ void orc_dequantize_row_q4_K(const orc_block_q4_K * x, float * y, int64_t k) {
         }
     }
 }
+void orc_dequantize_row_q5_K(const orc_block_q5_K * x, float * y, int64_t k) {
+    const int64_t nb = k / ORC_QK_K;
+    for (int64_t i = 0; i < nb; i++) {
+        const float d = orc_fp16_to_fp32(x[i].d), dmin = orc_fp16_to_fp32(x[i].dmin);
+        const uint8_t * ql = x[i].qs, * qh = x[i].qh;
+        uint8_t u1 = 1, u2 = 2;
+        for (int g = 0; g < 4; g++, ql += 32, u1 <<= 2, u2 <<= 2) {
+            uint8_t sc, m;
+            orc_scale_min_k4(2*g + 0, x[i].scales, &sc, &m);
+            const float d1 = d * sc, m1 = dmin * m;
+            orc_scale_min_k4(2*g + 1, x[i].scales, &sc, &m);
+            const float d2 = d * sc, m2 = dmin * m;
+            for (int l = 0; l < 32; l++) *y++ = d1 * (float)((ql[l] & 0xF) + ((qh[l] & u1) ? 16 : 0)) - m1;
+            for (int l = 0; l < 32; l++) *y++ = d2 * (float)((ql[l] >>  4) + ((qh[l] & u2) ? 16 : 0)) - m2;
+        }
+    }
+}
+void orc_dequantize_row_q6_K(const orc_block_q6_K * x, float * y, int64_t k) {
+    const int64_t nb = k / ORC_QK_K;
+    for (int64_t i = 0; i < nb; i++) {
+        const float d = orc_fp16_to_fp32(x[i].d);
+        const uint8_t * ql = x[i].ql, * qh = x[i].qh;
+        const int8_t * sc = x[i].scales;
+        for (int n = 0; n < ORC_QK_K; n += 128, y += 128, ql += 64, qh += 32, sc += 8)
+            for (int l = 0; l < 32; l++) {
+                const int is = l / 16;
+                const int8_t q1 = (int8_t)((ql[l +  0] & 0xF) | (((qh[l] >> 0) & 3) << 4)) - 32;
+                const int8_t q2 = (int8_t)((ql[l + 32] & 0xF) | (((qh[l] >> 2) & 3) << 4)) - 32;
+                const int8_t q3 = (int8_t)((ql[l +  0]  >> 4) | (((qh[l] >> 4) & 3) << 4)) - 32;
+                const int8_t q4 = (int8_t)((ql[l + 32]  >> 4) | (((qh[l] >> 6) & 3) << 4)) - 32;
+                y[l +  0] = d * sc[is + 0] * q1;
+                y[l + 32] = d * sc[is + 2] * q2;
+                y[l + 64] = d * sc[is + 4] * q3;
+                y[l + 96] = d * sc[is + 6] * q4;
+            }
+    }
+}
 void orc_dequantize_row(int type, const void * x, float * y, int64_t k) {
     switch (type) {
         case ORC_Q4_0: orc_dequantize_row_q4_0((const orc_block_q4_0 *) x, y, k); break;
         case ORC_Q8_0: orc_dequantize_row_q8_0((const orc_block_q8_0 *) x, y, k); break;
         case ORC_Q4_1: orc_dequantize_row_q4_1((const orc_block_q4_1 *) x, y, k); break;
         case ORC_Q4_K: orc_dequantize_row_q4_K((const orc_block_q4_K *) x, y, k); break;
+        case ORC_Q5_K: orc_dequantize_row_q5_K((const orc_block_q5_K *) x, y, k); break;
+        case ORC_Q6_K: orc_dequantize_row_q6_K((const orc_block_q6_K *) x, y, k); break;
         case ORC_F16:  for (int64_t i = 0; i < k; i++) y[i] = orc_fp16_to_fp32(((const uint16_t *) x)[i]); break;
         case ORC_F32:  memcpy(y, x, (size_t) k * 4); break;
     }
@@ -432,6 +472,67 @@ float orc_vec_dot_q4_K_q8_K_avx2(int64_t n, const orc_block_q4_K * x, const orc_
     return hsum8(acc) + (m02 + m13);
 }
 
+#ifndef ORC_Q5K_SUMMS
+#define ORC_Q5K_SUMMS(dmin, v, acc) ((acc) + (dmin) * (v))          /* `summs += dmin * hsum` as compiled in the reference build */
+#endif
+/* ggml_vec_dot_q5_K_q8_K, AVX2 (arch/x86/quants.c:1916-2030): Q4_K's lanes with a fifth bit from qh; the mins in ONE scalar chain */
+float orc_vec_dot_q5_K_q8_K_avx2(int64_t n, const orc_block_q5_K * x, const orc_block_q8_K * y) {
+    const int64_t nb = n / ORC_QK_K;
+    float acc[8] = {0}, summs = 0.0f;
+    for (int64_t i = 0; i < nb; i++) {
+        const float d = y[i].d * orc_fp16_to_fp32(x[i].d);
+        const float dmin = -y[i].d * orc_fp16_to_fp32(x[i].dmin);
+        uint8_t sc[8], mn[8];
+        for (int j = 0; j < 8; j++) orc_scale_min_k4(j, x[i].scales, &sc[j], &mn[j]);
+        int hsum = 0;
+        for (int j = 0; j < 8; j++) hsum += mn[j] * (y[i].bsums[2*j] + y[i].bsums[2*j + 1]);
+        summs = ORC_Q5K_SUMMS(dmin, (float) hsum, summs);
+        int32_t sumi[8] = {0};
+        for (int c = 0; c < 4; c++) {
+            const uint8_t * q5 = x[i].qs + 32 * c, * qh = x[i].qh;
+            const int8_t  * q8 = y[i].qs + 64 * c;
+            for (int L = 0; L < 8; L++) {
+                int pl = 0, ph = 0;
+                for (int e = 0; e < 4; e++) {
+                    const int b = 4*L + e;
+                    pl += ((q5[b] & 0x0F) + (((qh[b] >> (2*c))     & 1) << 4)) * q8[b];
+                    ph += ((q5[b] >> 4)   + (((qh[b] >> (2*c + 1)) & 1) << 4)) * q8[32 + b];
+                }
+                sumi[L] += sc[2*c] * pl + sc[2*c + 1] * ph;
+            }
+        }
+        for (int L = 0; L < 8; L++) acc[L] = fmaf(d, (float) sumi[L], acc[L]);
+    }
+    return hsum8(acc) + summs;
+}
+/* ggml_vec_dot_q6_K_q8_K, AVX2 (arch/x86/quants.c:2130-2225): per 128 elements four 32-element groups g, lane A takes bytes 4A..4A+3 of
+ * each; the int8 scale of a group's first / second 16 elements goes to lanes 0..3 / 4..7 (get_scale_shuffle) */
+float orc_vec_dot_q6_K_q8_K_avx2(int64_t n, const orc_block_q6_K * x, const orc_block_q8_K * y) {
+    const int64_t nb = n / ORC_QK_K;
+    float acc[8] = {0};
+    for (int64_t i = 0; i < nb; i++) {
+        const float d = y[i].d * orc_fp16_to_fp32(x[i].d);
+        int32_t sumi[8] = {0};
+        for (int j = 0; j < 2; j++) {
+            const uint8_t * ql = x[i].ql + 64 * j, * qh = x[i].qh + 32 * j;
+            const int8_t * q8 = y[i].qs + 128 * j, * sc = x[i].scales + 8 * j;
+            for (int g = 0; g < 4; g++)
+                for (int L = 0; L < 8; L++) {
+                    int p = 0;
+                    for (int e = 0; e < 4; e++) {
+                        const int b = 4*L + e;
+                        const int lo = g < 2 ? (ql[32 * (g & 1) + b] & 0xF) : (ql[32 * (g & 1) + b] >> 4);
+                        const int q = (lo | (((qh[b] >> (2*g)) & 3) << 4)) - 32;
+                        p += q * q8[32 * g + b];
+                    }
+                    sumi[L] += sc[2*g + (L >> 2)] * p;
+                }
+        }
+        for (int L = 0; L < 8; L++) acc[L] = fmaf(d, (float) sumi[L], acc[L]);
+    }
+    return hsum8(acc);
+}
+
 /* ggml_vec_dot_f16, AVX2 + F16C (ggml-cpu/vec.cpp:264-, simd-mappings.h:528-620): four 8-lane accumulators over steps of 32,
  * GGML_F32x8_REDUCE, leftovers in double */
 float orc_vec_dot_f16_avx2(int64_t n, const uint16_t * x, const uint16_t * y) {
@@ -503,7 +604,7 @@ static int vec_dot_type_of(int wtype) {
     switch (wtype) {             /* type_traits_cpu[], ggml-cpu/ggml-cpu.c:207-390 */
         case ORC_Q4_0: case ORC_Q8_0: return ORC_Q8_0;
         case ORC_Q4_1: return ORC_Q8_1;
-        case ORC_Q4_K: return ORC_Q8_K;
+        case ORC_Q4_K: case ORC_Q5_K: case ORC_Q6_K: return ORC_Q8_K;
         case ORC_F16:  return ORC_F16;
         case ORC_F32:  return ORC_F32;
     }
@@ -530,6 +631,8 @@ static float vec_dot(int wtype, int64_t n, const void * w, const void * a) {
                                                         : orc_vec_dot_q4_1_q8_1(n, (const orc_block_q4_1 *) w, (const orc_block_q8_1 *) a, NULL);
         case ORC_Q4_K: return g_order == ORC_ORDER_AVX2 ? orc_vec_dot_q4_K_q8_K_avx2(n, (const orc_block_q4_K *) w, (const orc_block_q8_K *) a)
                                                         : orc_vec_dot_q4_K_q8_K(n, (const orc_block_q4_K *) w, (const orc_block_q8_K *) a, NULL);
+        case ORC_Q5_K: return orc_vec_dot_q5_K_q8_K_avx2(n, (const orc_block_q5_K *) w, (const orc_block_q8_K *) a);
+        case ORC_Q6_K: return orc_vec_dot_q6_K_q8_K_avx2(n, (const orc_block_q6_K *) w, (const orc_block_q8_K *) a);
         case ORC_F16: {
             if (g_order == ORC_ORDER_AVX2) return orc_vec_dot_f16_avx2(n, (const uint16_t *) w, (const uint16_t *) a);          /* scalar branch of ggml_vec_dot_f16 (vec.cpp:264-): double accumulation */
             const uint16_t * x = (const uint16_t *) w, * y = (const uint16_t *) a;

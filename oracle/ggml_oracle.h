@@ -25,7 +25,7 @@ extern "C" {
 
 /* numeric values equal the reference's enum ggml_type (ggml/include/ggml.h:386-428) */
 enum orc_type {
-    ORC_F32 = 0, ORC_F16 = 1, ORC_Q4_0 = 2, ORC_Q4_1 = 3, ORC_Q8_0 = 8, ORC_Q8_1 = 9, ORC_Q4_K = 12, ORC_Q8_K = 15, ORC_I32 = 26, ORC_I64 = 27,
+    ORC_F32 = 0, ORC_F16 = 1, ORC_Q4_0 = 2, ORC_Q4_1 = 3, ORC_Q8_0 = 8, ORC_Q8_1 = 9, ORC_Q4_K = 12, ORC_Q5_K = 13, ORC_Q6_K = 14, ORC_Q8_K = 15, ORC_I32 = 26, ORC_I64 = 27,
 };
 
 /* a strided 4-D tensor view: same meaning as ggml_tensor {type, ne, nb, data} (ggml.h:656-688) */
@@ -45,6 +45,8 @@ typedef struct { uint16_t d; int8_t  qs[32]; }                         orc_block
 typedef struct { uint16_t d; uint16_t m; uint8_t qs[16]; }             orc_block_q4_1;   /* 20 B: w = nib * d + m */
 typedef struct { uint16_t d; uint16_t s; int8_t qs[32]; }              orc_block_q8_1;   /* 36 B: s = d * sum(qs) */
 typedef struct { uint16_t d; uint16_t dmin; uint8_t scales[12]; uint8_t qs[128]; } orc_block_q4_K; /* 144 B */
+typedef struct { uint16_t d; uint16_t dmin; uint8_t scales[12]; uint8_t qh[32]; uint8_t qs[128]; } orc_block_q5_K; /* 176 B: Q4_K + a fifth bit (ggml-common.h:308-321) */
+typedef struct { uint8_t ql[128]; uint8_t qh[64]; int8_t scales[16]; uint16_t d; }                  orc_block_q6_K; /* 210 B: 6-bit quants - 32, int8 scale per 16 (ggml-common.h:323-336) */
 typedef struct { float d; int8_t qs[256]; int16_t bsums[16]; }         orc_block_q8_K;   /* 292 B */
 #pragma pack(pop)
 
@@ -72,6 +74,8 @@ void orc_dequantize_row_q4_0(const orc_block_q4_0 * x, float * y, int64_t k);
 void orc_dequantize_row_q8_0(const orc_block_q8_0 * x, float * y, int64_t k);
 void orc_dequantize_row_q4_1(const orc_block_q4_1 * x, float * y, int64_t k);      /* ggml-quants.c:327-345 */
 void orc_dequantize_row_q4_K(const orc_block_q4_K * x, float * y, int64_t k);
+void orc_dequantize_row_q5_K(const orc_block_q5_K * x, float * y, int64_t k);      /* ggml-quants.c:1554-1579 */
+void orc_dequantize_row_q6_K(const orc_block_q6_K * x, float * y, int64_t k);      /* ggml-quants.c:1762-1791 */
 void orc_dequantize_row(int type, const void * x, float * y, int64_t k);
 
 /* ---- block dot products (ggml-cpu/quants.c:115-150, 305-333, 550-623) ----
@@ -93,6 +97,10 @@ float orc_vec_dot_q4_0_q8_0_avx2(int64_t n, const orc_block_q4_0 * x, const orc_
 float orc_vec_dot_q8_0_q8_0_avx2(int64_t n, const orc_block_q8_0 * x, const orc_block_q8_0 * y);
 float orc_vec_dot_q4_1_q8_1_avx2(int64_t n, const orc_block_q4_1 * x, const orc_block_q8_1 * y);
 float orc_vec_dot_q4_K_q8_K_avx2(int64_t n, const orc_block_q4_K * x, const orc_block_q8_K * y);
+/* Q5_K / Q6_K: only the x86 AVX2 order is restated (arch/x86/quants.c:1916-2030, 2130-2225): 8 lane accumulators, one fma per super-block;
+ * Q5_K's mins go through one scalar chain `summs` */
+float orc_vec_dot_q5_K_q8_K_avx2(int64_t n, const orc_block_q5_K * x, const orc_block_q8_K * y);
+float orc_vec_dot_q6_K_q8_K_avx2(int64_t n, const orc_block_q6_K * x, const orc_block_q8_K * y);
 float orc_vec_dot_f16_avx2(int64_t n, const uint16_t * x, const uint16_t * y);
 float orc_vec_dot_f32_avx2(int64_t n, const float * x, const float * y);
 

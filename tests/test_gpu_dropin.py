@@ -336,3 +336,23 @@ def test_module_events_and_async_copy_between_backends(gpu):
     driven through the reference's public ggml-backend API the way its scheduler does at a layer split: two backends (streams), a -> b -> a"""
     r = subprocess.run([os.path.join(REF, "ref_backend_async"), os.path.join(REF, "libggml-hip.so"), str(3 << 20)], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0 and r.stdout.startswith("OK"), (r.stdout, r.stderr[-1500:])
+
+
+@pytest.mark.skipif(not (os.path.exists(os.path.join(REF, "ref_chat")) and os.path.exists(os.path.join(REF, "libggml-hip.so"))),
+                    reason="oracle/_ref (reference host + module) not built")
+@pytest.mark.parametrize("name,wt,mix", [("q6_k", 14, None), ("q5_k", 13, None), ("q4_k_m", 12, {"wv": 14, "wdown": 14, "lm_head": 14, "tok_embd": 14, "wo": 13})])
+def test_reference_host_other_k_quants_bit_identical(gpu, tmp_path, name, wt, mix):
+    """the k-quants third-party GGMM files carry besides Q4_K -- Q5_K, Q6_K, and a Q4_K_M-style mix (Q6_K embedding / output / v / down, Q5_K o):
+    every node stays on the module and the free-running generation is bit-identical to the reference's CPU run"""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import make_ggmm
+    cfg = gpu.synth.config("tiny", max_len=64, mix=mix)
+    mp = str(tmp_path / "m.bin")
+    make_ggmm.write_model(mp, cfg, wt, seed=81)
+    prompt = [3, 100, 45, 260, 17, 9, 201]
+    ids_c, lg_c, _ = _host_run(tmp_path, mp, "cpu", 16, prompt, cfg["vocab"])
+    ids_g, lg_g, err = _host_run(tmp_path, mp, "all", 16, prompt, cfg["vocab"])
+    graphs = [ln for ln in err.splitlines() if "graph_compute:" in ln and "calls" in ln]
+    assert len(graphs) == 17, len(graphs)                  # one graph per step: nothing fell back to the CPU backend
+    assert ids_c == ids_g
+    assert np.array_equal(lg_c.view(np.uint32), lg_g.view(np.uint32))

@@ -115,6 +115,15 @@ def test_mul_mat_quant_gemv(gpu, t, K, N, M):
     assert np.array_equal(got.view(np.uint32).ravel(), want.view(np.uint32).ravel()), rel_err(got, want)
 
 
+@pytest.mark.parametrize("t", [O.Q5_K, O.Q6_K])
+@pytest.mark.parametrize("K,N,M,ne02,ne12", [(256, 1, 1, 1, 1), (512, 7, 1, 1, 1), (4096, 130, 1, 1, 1), (2048, 64, 2, 1, 1), (1024, 33, 5, 1, 1), (1280, 24, 8, 1, 1), (768, 40, 9, 1, 1),
+                                             (512, 19, 40, 1, 1), (256, 12, 3, 2, 4), (14336, 48, 1, 1, 1)])
+def test_mul_mat_k_quants_any_columns_bit_exact(gpu, t, K, N, M, ne02, ne12):
+    """Q5_K / Q6_K (gemv_kq.hip): 8 lanes per row, lane = AVX lane, serial fma chain in a register -- bit-identical to libggml-cpu.so for every column count"""
+    got, want = _mm_case(gpu, t, K, N, M, ne02, ne12)
+    assert np.array_equal(got.view(np.uint32).ravel(), want.view(np.uint32).ravel()), rel_err(got, want)
+
+
 @pytest.mark.parametrize("t,K", [(O.Q4_K, 14336), (O.Q4_0, 14336), (O.Q8_0, 29568), (O.Q4_K, 8192), (O.Q4_1, 14336), (O.Q4_1, 29568)])
 def test_mul_mat_quant_long_rows(gpu, t, K):
     got, want = _mm_case(gpu, t, K, 96, 1)
@@ -327,7 +336,7 @@ def test_cpy_v_cache_transposed_and_cont(gpu):
     assert np.array_equal(got, np.ascontiguousarray(c.transpose(1, 0, 2)))
 
 
-@pytest.mark.parametrize("t", [O.Q4_0, O.Q4_1, O.Q8_0, O.Q4_K, O.F16, O.F32])
+@pytest.mark.parametrize("t", [O.Q4_0, O.Q4_1, O.Q8_0, O.Q4_K, O.Q5_K, O.Q6_K, O.F16, O.F32])
 def test_get_rows_bit_exact(gpu, t):
     n0, rows, n = 512, 30, 7
     table = rng.standard_normal((rows, n0)).astype(O.NP_OF[t]) if t in (O.F16, O.F32) else rand_blocks(t, rows, n0, rng)

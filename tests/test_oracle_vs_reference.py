@@ -69,7 +69,7 @@ def test_quantize_q8_K_bit_exact(K):
         assert np.array_equal(got, ref)
 
 
-@pytest.mark.parametrize("t", [O.Q4_0, O.Q4_1, O.Q8_0, O.Q4_K])
+@pytest.mark.parametrize("t", [O.Q4_0, O.Q4_1, O.Q8_0, O.Q4_K, O.Q5_K, O.Q6_K])
 def test_dequantize_bit_exact(t):
     R = O.ref()
     K = 2048
@@ -105,7 +105,24 @@ def test_vec_dot_matches_reference(t):
     assert isums.dtype == np.int32 and np.all(np.abs(isums) < 2**31 - 1)
 
 
-@pytest.mark.parametrize("t,K,N,M", [(O.Q4_K, 512, 48, 1), (O.Q4_K, 1024, 33, 5), (O.Q4_K, 4096, 16, 40), (O.Q4_0, 256, 40, 1), (O.Q4_0, 512, 17, 7), (O.Q4_0, 4096, 64, 33),
+@pytest.mark.parametrize("t", [O.Q5_K, O.Q6_K])
+def test_vec_dot_k_quants_avx2_order_bit_exact(t):
+    """Q5_K / Q6_K: only the AVX2 order is restated; 8 lane accumulators + (Q5_K) the scalar mins chain"""
+    R = O.ref()
+    fn = {O.Q5_K: "orc_vec_dot_q5_K_q8_K_avx2", O.Q6_K: "orc_vec_dot_q6_K_q8_K_avx2"}[t]
+    f = getattr(O.lib(), fn); f.restype = C.c_float; f.argtypes = [C.c_int64, C.c_void_p, C.c_void_p]
+    s = C.c_float()
+    for K in (256, 4096, 14336):
+        for _ in range(30):
+            w = rand_blocks(t, 1, K, rng)
+            x = (rng.standard_normal(K) * rng.choice([1e-2, 1.0, 30.0])).astype(np.float32)
+            a = O.quantize_q8_K(x)
+            assert R.ref_vec_dot(t, C.c_int64(K), P(w), P(a), C.byref(s)) == 0
+            assert np.float32(f(C.c_int64(K), P(np.ascontiguousarray(w)), P(np.ascontiguousarray(a)))).view(np.uint32) == np.float32(s.value).view(np.uint32)
+
+
+@pytest.mark.parametrize("t,K,N,M", [(O.Q5_K, 512, 48, 1), (O.Q5_K, 1024, 33, 5), (O.Q6_K, 512, 48, 1), (O.Q6_K, 2048, 17, 7), (O.Q6_K, 256, 16, 40),
+                                     (O.Q4_K, 512, 48, 1), (O.Q4_K, 1024, 33, 5), (O.Q4_K, 4096, 16, 40), (O.Q4_0, 256, 40, 1), (O.Q4_0, 512, 17, 7), (O.Q4_0, 4096, 64, 33),
                                      (O.Q4_1, 256, 40, 1), (O.Q4_1, 1024, 19, 6),
                                      (O.Q8_0, 256, 40, 1), (O.Q8_0, 1024, 31, 3), (O.Q8_0, 512, 40, 19), (O.F16, 128, 50, 3), (O.F32, 96, 20, 2),
                                      (O.F16, 128, 500, 1), (O.F16, 128, 64, 16), (O.F16, 128, 63, 16), (O.F16, 1000, 128, 4), (O.F16, 1001, 128, 5), (O.F16, 77, 128, 1),
@@ -292,7 +309,7 @@ def test_cpy_v_cache_transposed():
     assert np.array_equal(got.view(np.uint16), ref.view(np.uint16))
 
 
-@pytest.mark.parametrize("t", [O.Q4_0, O.Q8_0, O.Q4_K, O.F16])
+@pytest.mark.parametrize("t", [O.Q4_0, O.Q8_0, O.Q4_K, O.Q5_K, O.Q6_K, O.F16])
 def test_get_rows(t):
     R = O.ref()
     n0, rows, n = 512, 30, 7

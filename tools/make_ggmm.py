@@ -21,7 +21,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import __graft_entry__ as ge  # noqa: E402
 
-WT = {"q4_k": 12, "q4_0": 2, "q4_1": 3, "q8_0": 8}
+WT = {"q4_k": 12, "q4_0": 2, "q4_1": 3, "q8_0": 8, "q5_k": 13, "q6_k": 14}
 HF_NAME = {"wq": "self_attn.q_proj.weight", "wk": "self_attn.k_proj.weight", "wv": "self_attn.v_proj.weight", "wo": "self_attn.o_proj.weight",
            "wgate": "mlp.gate_proj.weight", "wup": "mlp.up_proj.weight", "wdown": "mlp.down_proj.weight",
            "attn_norm": "input_layernorm.weight", "ffn_norm": "post_attention_layernorm.weight"}
