@@ -45,7 +45,7 @@ std::atomic<uint64_t> g_next_buffer_uid{1};     // (accessory models own their o
 struct wall_stats {
     using clk = std::chrono::steady_clock;
     clk::time_point last_exit = clk::now();
-    double host_us = 0, plan_us = 0, issue_us = 0, sync_us = 0, set_us = 0, get_us = 0; long graphs = 0, calls = 0, sets = 0, gets = 0;
+    double host_us = 0, plan_us = 0, issue_us = 0, sync_us = 0, set_us = 0, get_us = 0, alloc_us = 0; long graphs = 0, calls = 0, sets = 0, gets = 0, allocs = 0;
     static double us(clk::time_point a, clk::time_point b) { return std::chrono::duration<double, std::micro>(b - a).count(); }
 } g_ws;
 const bool g_stats = getenv("CLLM_HIP_STATS") != nullptr;
@@ -128,6 +128,7 @@ bool upload(int device, void * dst, const void * data, size_t size) {
 
 void packs_forget(uint64_t uid);
 void buf_free(ggml_backend_buffer_t b) {
+    ws_scope ws(g_ws.alloc_us); g_ws.allocs++;
     flush_sets();
     auto * c = (hip_buffer_ctx *) b->context;
     { std::lock_guard<std::mutex> lock(g_ring.m); i32_forget(c->base, b->size); }
@@ -263,6 +264,7 @@ void * get_pack(int device, void * stream, const ggml_tensor * const * w, int n,
 // ---------------------------------------------------------------------------------------------------------------------------
 const char * buft_name(ggml_backend_buffer_type_t t) { return ((hip_device_ctx *) t->context)->name.c_str(); }
 ggml_backend_buffer_t buft_alloc(ggml_backend_buffer_type_t t, size_t size) {
+    ws_scope ws(g_ws.alloc_us); g_ws.allocs++;
     auto * d = (hip_device_ctx *) t->context;
     cllm_set_device(d->id);
     void * p = nullptr;
@@ -1121,10 +1123,11 @@ ggml_status be_graph_compute(ggml_backend_t backend, ggml_cgraph * g) {
         if (++g_ws.graphs % 64 == 0) {
             const double n = 64.0;
             HIPB_LOG("per graph over the last 64: host %.0f us | graph_compute %.0f us (of which planning %.0f us, %.0f calls) | synchronize %.0f us | "
-                     "set_tensor %.0f us (%.1f calls) | get_tensor %.0f us (%.1f calls)",
-                     g_ws.host_us / n, g_ws.issue_us / n, g_ws.plan_us / n, g_ws.calls / n, g_ws.sync_us / n, g_ws.set_us / n, g_ws.sets / n, g_ws.get_us / n, g_ws.gets / n);
+                     "set_tensor %.0f us (%.1f calls) | get_tensor %.0f us (%.1f calls) | buffer alloc/free %.0f us (%.2f calls)",
+                     g_ws.host_us / n, g_ws.issue_us / n, g_ws.plan_us / n, g_ws.calls / n, g_ws.sync_us / n, g_ws.set_us / n, g_ws.sets / n, g_ws.get_us / n, g_ws.gets / n,
+                     g_ws.alloc_us / n, g_ws.allocs / n);
             HIPB_LOG("launch lists replayed from a captured graph so far: %ld (captures: %ld)", c->replays, c->captures);
-            g_ws.host_us = g_ws.plan_us = g_ws.issue_us = g_ws.sync_us = g_ws.set_us = g_ws.get_us = 0; g_ws.calls = g_ws.sets = g_ws.gets = 0;
+            g_ws.host_us = g_ws.plan_us = g_ws.issue_us = g_ws.sync_us = g_ws.set_us = g_ws.get_us = g_ws.alloc_us = 0; g_ws.calls = g_ws.sets = g_ws.gets = g_ws.allocs = 0;
         }
     }
     return GGML_STATUS_SUCCESS;       // asynchronous: the host calls synchronize() before it reads (src/backend.cpp:824-825)

@@ -193,16 +193,22 @@ def fast_blocks(type_, rows, K, rng, sigma):
         base = sigma / 4.61            # uniform nibble std
     else:
         base = sigma / (4.61 * 32.0)   # nibble std x mean 6-bit scale
+    if type_ == Q6_K:
+        base = sigma / (18.5 * 74.0)   # 6-bit std x int8 scale std; the fp16 scale closes the block
     table = (base * np.linspace(0.75, 1.25, 256)).astype(np.float16).view(np.uint16)
     sel = out[:, :, 0].copy()
     d = table[sel]
+    if type_ == Q6_K:
+        out[:, :, 208] = (d & 0xff).astype(np.uint8)
+        out[:, :, 209] = (d >> 8).astype(np.uint8)
+        return out.reshape(rows, nb * bs)
     out[:, :, 0] = (d & 0xff).astype(np.uint8)
     out[:, :, 1] = (d >> 8).astype(np.uint8)
     if type_ == Q4_1:
         dm = (-(base * 7.5) * np.linspace(0.75, 1.25, 256)).astype(np.float16).view(np.uint16)[sel]      # m = -7.5 d: zero-mean weights
         out[:, :, 2] = (dm & 0xff).astype(np.uint8)
         out[:, :, 3] = (dm >> 8).astype(np.uint8)
-    if type_ == Q4_K:
+    if type_ in (Q4_K, Q5_K):
         # dmin = 7.5 d: with independent 6-bit scales and mins the sub-block offsets average out
         dm = (base * 7.5 * np.linspace(0.75, 1.25, 256)).astype(np.float16).view(np.uint16)[sel]
         out[:, :, 2] = (dm & 0xff).astype(np.uint8)
