@@ -187,6 +187,17 @@ __device__ __forceinline__ float uniform_load_f32(const float * p) {
 __device__ __forceinline__ float group8_max(float v) { v = fmaxf(v, dpp_f<DPP_QUAD_XOR1>(v)); v = fmaxf(v, dpp_f<DPP_QUAD_XOR2>(v)); return fmaxf(v, dpp_f<DPP_HALF_MIRROR>(v)); }
 __device__ __forceinline__ int   group8_sum_i(int v) { v += dpp_i<DPP_QUAD_XOR1>(v); v += dpp_i<DPP_QUAD_XOR2>(v); return v + dpp_i<DPP_HALF_MIRROR>(v); }
 __device__ __forceinline__ int dot4(uint32_t a, uint32_t b, int c) { return __builtin_amdgcn_sdot4((int) a, (int) b, c, false); }
+// Eight dot products with a zero accumulator as eight instructions: the builtin becomes v_mov_b32 0 + v_dot4c_i32_i8 (two-address form) each; the
+// VOP3P form takes the inline constant.  The dot pipeline's results must not be read by another VALU instruction for 3 wait states
+// (the compiler's hazard recognizer knows that for the builtin but not inside inline asm: a lone asm dot followed by a multiply returns
+// garbage), so the eight go out back to back with one s_nop behind the last (tools/micro/dot4_test.hip checks the instruction itself).
+__device__ __forceinline__ void dot4z_x8(const uint32_t (&a)[8], const uint32_t (&b)[8], int (&r)[8]) {
+    asm("v_dot4_i32_i8 %0, %8, %16, 0\n\tv_dot4_i32_i8 %1, %9, %17, 0\n\tv_dot4_i32_i8 %2, %10, %18, 0\n\tv_dot4_i32_i8 %3, %11, %19, 0\n\t"
+        "v_dot4_i32_i8 %4, %12, %20, 0\n\tv_dot4_i32_i8 %5, %13, %21, 0\n\tv_dot4_i32_i8 %6, %14, %22, 0\n\tv_dot4_i32_i8 %7, %15, %23, 0\n\ts_nop 2"
+        : "=&v"(r[0]), "=&v"(r[1]), "=&v"(r[2]), "=&v"(r[3]), "=&v"(r[4]), "=&v"(r[5]), "=&v"(r[6]), "=&v"(r[7])
+        : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), "v"(a[6]), "v"(a[7]),
+          "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(b[3]), "v"(b[4]), "v"(b[5]), "v"(b[6]), "v"(b[7]));
+}
 
 // cos/sin of a RoPE angle.  ONE definition shared by k_rope (ops.hip) and k_rope_kv (decode_fused.hip): whether the
 // compiler pairs cosf+sinf into a sincos or not changes the last bit for some angles, and a 1-ulp difference in q/k

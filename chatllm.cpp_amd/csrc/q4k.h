@@ -79,10 +79,15 @@ __device__ __forceinline__ void q4k_emit(const u32x4 h, const u32x4 q, const cha
     const int   ys = ((const int *)(ar + off_s))[bb * 8 + L.s_idx];
     // the four dwords of this lane = AVX lanes 4(j&1) + k of chunk j/2
     // (24-bit multiplies: scales < 64, |dot| <= 4 * 15 * 127 -- the 32-bit v_mul_lo_u32 / v_mad_u64_u32 the compiler picks otherwise run at a quarter rate)
-    const int t0 = __mul24(sc_lo, dot4(q.x & 0x0f0f0f0fu, al.x, 0)) + __mul24(sc_hi, dot4((q.x >> 4) & 0x0f0f0f0fu, ah.x, 0));
-    const int t1 = __mul24(sc_lo, dot4(q.y & 0x0f0f0f0fu, al.y, 0)) + __mul24(sc_hi, dot4((q.y >> 4) & 0x0f0f0f0fu, ah.y, 0));
-    const int t2 = __mul24(sc_lo, dot4(q.z & 0x0f0f0f0fu, al.z, 0)) + __mul24(sc_hi, dot4((q.z >> 4) & 0x0f0f0f0fu, ah.z, 0));
-    const int t3 = __mul24(sc_lo, dot4(q.w & 0x0f0f0f0fu, al.w, 0)) + __mul24(sc_hi, dot4((q.w >> 4) & 0x0f0f0f0fu, ah.w, 0));
+    const uint32_t wq[8] = { q.x & 0x0f0f0f0fu, (q.x >> 4) & 0x0f0f0f0fu, q.y & 0x0f0f0f0fu, (q.y >> 4) & 0x0f0f0f0fu,
+                             q.z & 0x0f0f0f0fu, (q.z >> 4) & 0x0f0f0f0fu, q.w & 0x0f0f0f0fu, (q.w >> 4) & 0x0f0f0f0fu };
+    const uint32_t wa[8] = { al.x, ah.x, al.y, ah.y, al.z, ah.z, al.w, ah.w };
+    int dp[8];
+    dot4z_x8(wq, wa, dp);
+    const int t0 = __mul24(sc_lo, dp[0]) + __mul24(sc_hi, dp[1]);
+    const int t1 = __mul24(sc_lo, dp[2]) + __mul24(sc_hi, dp[3]);
+    const int t2 = __mul24(sc_lo, dp[4]) + __mul24(sc_hi, dp[5]);
+    const int t3 = __mul24(sc_lo, dp[6]) + __mul24(sc_hi, dp[7]);
     // reduce-scatter over the four chunks (lanes j, j^2, j^4, j^6): lane j keeps dword k = (j&2) + (j>>2)
     int k0 = L.b2 ? t2 : t0, k1 = L.b2 ? t3 : t1;
     const int s0 = L.b2 ? t0 : t2, s1 = L.b2 ? t1 : t3;
