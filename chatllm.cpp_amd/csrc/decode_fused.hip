@@ -530,6 +530,33 @@ __global__ void __launch_bounds__(256) k_argmax_final(const float * __restrict__
         counter[0] = counter[0] + 1;
     }
 }
+__global__ void __launch_bounds__(256) k_argmax_publish(const float * __restrict__ pv, const int * __restrict__ pi, int np, int32_t * __restrict__ tok_dev,
+                                                        int32_t * __restrict__ tok_host, int32_t * const * __restrict__ inc, int n_inc) {
+    __shared__ float bv[4]; __shared__ int bi[4];
+    float best = -INFINITY; int idx = 0x7fffffff;
+    for (int i = threadIdx.x; i < np; i += 256) argmax_combine(best, idx, pv[i], pi[i]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) argmax_combine(best, idx, __shfl_xor(best, o, 64), __shfl_xor(idx, o, 64));
+    if ((threadIdx.x & 63) == 0) { bv[threadIdx.x >> 6] = best; bi[threadIdx.x >> 6] = idx; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 4; w++) argmax_combine(best, idx, bv[w], bi[w]);
+        if (idx == 0x7fffffff) idx = 0;
+        tok_dev[0] = idx;
+        if (tok_host) { tok_host[0] = idx; __threadfence_system(); }
+    }
+    for (int i = threadIdx.x; i < n_inc; i += 256) inc[i][0] = inc[i][0] + 1;
+}
+extern "C" int cllm_op_argmax_advance(void * stream, const float * logits, int64_t n, int32_t * tok_dev, int32_t * tok_host, int32_t * const * inc_ptrs_dev, int n_inc,
+                                      void * scratch) {
+    if (!logits || n <= 0 || n > INT32_MAX || !tok_dev || !scratch || n_inc < 0 || (n_inc && !inc_ptrs_dev)) FAIL(CLLM_E_INVALID, "argmax_advance: arguments");
+    float * pv = (float *) scratch; int * pi = (int *)((char *) scratch + 1024);
+    hipLaunchKernelGGL(k_argmax_partial, dim3(256), dim3(256), 0, (hipStream_t) stream, logits, (int) n, pv, pi);
+    LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_argmax_publish, dim3(1), dim3(256), 0, (hipStream_t) stream, (const float *) pv, (const int *) pi, 256, tok_dev, tok_host, inc_ptrs_dev, n_inc);
+    LAUNCH_CHECK();
+    return CLLM_OK;
+}
 int launch_argmax_advance(hipStream_t st, const float * logits, int n, int32_t * tok_dev, int32_t * pos_dev, int32_t * out_ring, int32_t * counter,
                           float * part_v, int * part_i) {
     const int np = 256;

@@ -36,6 +36,16 @@ struct hip_backend_ctx {
     // replay of a token's launch list (graph_compute): the serialized arguments of every C-ABI call of the last graph, and the
     // captured graph of the list that came twice in a row
     std::vector<uint8_t> last_sig, graph_sig; void * graph_exec = nullptr; bool graph_broken = false; long replays = 0, captures = 0;
+    // decode-ahead (see ahead_launch): the next step of a greedy decode started while the host is still busy with the current token
+    struct scalar_set { const void * ptr; int32_t val; };
+    struct {
+        bool armed = false, inflight = false;
+        void * ev = nullptr, * table_dev = nullptr, * scratch = nullptr, * snap = nullptr; size_t snap_bytes = 0; int32_t * tok_host = nullptr;
+        const void * ids_ptr = nullptr, * logits_ptr = nullptr; size_t logits_bytes = 0;
+        struct out_range { const char * ptr; size_t bytes, snap_off; }; std::vector<out_range> outs;      // every OUTPUT tensor of the graph (snapshots)
+        std::vector<scalar_set> last_sets, pred; std::vector<const void *> table;
+        int misses = 0; long graphs = 0, skip_until = 0, hits = 0, launched = 0;
+    } ahead;
 };
 struct hip_buffer_ctx { int device; void * base; uint64_t uid; std::atomic<uint64_t> gen{0}; };     // gen: bumped by every write through the buffer interface
 std::atomic<uint64_t> g_next_buffer_uid{1};     // (accessory models own their own contexts and may run on other threads)
@@ -81,6 +91,15 @@ bool f32_dense(const ggml_tensor * t) { return t && t->type == GGML_TYPE_F32 && 
 // position tensor, all holding the same value -- knowing that, graph_compute builds the RoPE cos/sin table once per graph instead of
 // once per layer (32 launches of 5 us per token for Llama-3-8B).  Any other write into the range forgets the entry.
 std::unordered_map<const void *, int32_t> g_i32_vals;
+// the 4-byte I32 tensors the host wrote since the last graph_compute, per device, in order (token id + one position per layer for chatllm):
+// what decode-ahead predicts for the next step and checks its prediction against
+std::vector<hip_backend_ctx::scalar_set> g_scalar_sets[64];
+hip_backend_ctx * g_ahead_ctx[64] = {};          // the backend whose captured step may be running ahead on that device
+// a write through the buffer interface that is not one of those scalars must not race a step running ahead (it may target memory that step uses)
+void ahead_quiesce(int device) {
+    hip_backend_ctx * c = device >= 0 && device < 64 ? g_ahead_ctx[device] : nullptr;
+    if (c && c->ahead.inflight) { cllm_set_device(c->device); cllm_stream_sync(c->stream); }
+}
 void i32_forget(const void * lo, size_t n) {          // caller holds g_ring.m
     if (g_i32_vals.empty()) return;
     const char * a = (const char *) lo, * b = a + n;
@@ -131,11 +150,14 @@ void buf_free(ggml_backend_buffer_t b) {
     ws_scope ws(g_ws.alloc_us); g_ws.allocs++;
     flush_sets();
     auto * c = (hip_buffer_ctx *) b->context;
+    ahead_quiesce(c->device);                      // a step running ahead may still use this memory
+    if (c->device >= 0 && c->device < 64 && g_ahead_ctx[c->device]) g_ahead_ctx[c->device]->ahead.armed = false;
     { std::lock_guard<std::mutex> lock(g_ring.m); i32_forget(c->base, b->size); }
     cllm_set_device(c->device); packs_forget(c->uid); cllm_free(c->base); delete c;
 }
 void * buf_base(ggml_backend_buffer_t b) { return ((hip_buffer_ctx *) b->context)->base; }
 void buf_memset(ggml_backend_buffer_t b, ggml_tensor * t, uint8_t v, size_t off, size_t size) {
+    ahead_quiesce(((hip_buffer_ctx *) b->context)->device);
     cllm_set_device(((hip_buffer_ctx *) b->context)->device); ((hip_buffer_ctx *) b->context)->gen++;
     { std::lock_guard<std::mutex> lock(g_ring.m); i32_forget((char *) t->data + off, size); }
     if (cllm_memset((char *) t->data + off, v, size, nullptr) != CLLM_OK || cllm_stream_sync(nullptr) != CLLM_OK) GGML_LOG_ERROR("[ggml-hip] memset_tensor '%s' failed: %s\n", t->name, cllm_last_error());
@@ -145,11 +167,21 @@ void buf_set(ggml_backend_buffer_t b, ggml_tensor * t, const void * data, size_t
     // called with 1,024,000-byte slices at arbitrary offsets while a model loads (src/chat.cpp:1322-1338): layout stays native
     auto * c = (hip_buffer_ctx *) b->context;
     cllm_set_device(c->device); c->gen++;
+    bool scalar = true;
     {
         std::lock_guard<std::mutex> lock(g_ring.m);
         i32_forget((char *) t->data + off, size);
         if (size == 4 && off == 0 && t->type == GGML_TYPE_I32 && g_i32_vals.size() < 4096) memcpy(&g_i32_vals[t->data], data, 4);
+        if (size == 4 && off == 0 && t->type == GGML_TYPE_I32 && c->device < 64) {
+            hip_backend_ctx::scalar_set ss; ss.ptr = t->data; memcpy(&ss.val, data, 4);
+            if (g_scalar_sets[c->device].size() < 1024) g_scalar_sets[c->device].push_back(ss);
+        } else scalar = false;
     }
+    if (!scalar) ahead_quiesce(c->device);
+    // While a step runs ahead the device already holds the scalars that step needs, and ggml-alloc may have handed their memory to later nodes of the
+    // same graph (the token id's block becomes part of the logits): a write now would land in the middle of -- or after -- the run and clobber it.
+    // The value is recorded above; graph_compute either finds it equal to the prediction (nothing to write) or writes all of them before the real run.
+    else if (c->device < 64 && g_ahead_ctx[c->device] && g_ahead_ctx[c->device]->ahead.inflight) return;
     if (size <= g_ring.max && ring_set(g_ring, c->device, (char *) t->data + off, data, size)) return;
     if (!upload(c->device, (char *) t->data + off, data, size)) GGML_LOG_ERROR("[ggml-hip] set_tensor '%s' (%zu bytes at %zu) failed: %s\n", t->name, size, off, cllm_last_error());
 }
@@ -158,9 +190,24 @@ void buf_set(ggml_backend_buffer_t b, ggml_tensor * t, const void * data, size_t
 void * g_stage = nullptr; size_t g_stage_size = 0;
 constexpr size_t k_stage_chunk = 4u << 20;
 std::mutex g_stage_mutex;
+void ahead_launch(hip_backend_ctx * c);
+void buf_get_impl(ggml_backend_buffer_t b, const char * src, const char * name, void * data, size_t size);
 void buf_get(ggml_backend_buffer_t b, const ggml_tensor * t, void * data, size_t off, size_t size) {
     ws_scope ws(g_ws.get_us); g_ws.gets++;
     flush_sets();
+    const int device = ((hip_buffer_ctx *) b->context)->device;
+    hip_backend_ctx * ac = device >= 0 && device < 64 ? g_ahead_ctx[device] : nullptr;
+    const char * src = (const char *) t->data + off;
+    if (ac && ac->ahead.inflight) {
+        bool served = false;
+        for (const auto & o : ac->ahead.outs)      // the step running ahead overwrites the graph's outputs: their snapshots
+            if (src >= o.ptr && src + size <= o.ptr + o.bytes) { src = (const char *) ac->ahead.snap + o.snap_off + (src - o.ptr); served = true; break; }
+        if (!served) ahead_quiesce(device);        // anything else: what the step running ahead leaves behind
+    }
+    buf_get_impl(b, src, t->name, data, size);
+    if (ac && ac->ahead.armed && !ac->ahead.inflight && (const void *) t->data == ac->ahead.logits_ptr && off == 0 && size == ac->ahead.logits_bytes) ahead_launch(ac);
+}
+void buf_get_impl(ggml_backend_buffer_t b, const char * src, const char * name, void * data, size_t size) {
     std::lock_guard<std::mutex> lock(g_stage_mutex);            // one staging area (accessory models may read from other threads)
     cllm_set_device(((hip_buffer_ctx *) b->context)->device);
     const size_t want = size < k_stage_chunk ? size : k_stage_chunk;
@@ -170,13 +217,13 @@ void buf_get(ggml_backend_buffer_t b, const ggml_tensor * t, void * data, size_t
         if (cllm_host_malloc(&g_stage, k_stage_chunk) == CLLM_OK) g_stage_size = k_stage_chunk;
     }
     if (size < 4096 || !g_stage) {
-        if (cllm_memcpy_d2h(data, (const char *) t->data + off, size, nullptr) != CLLM_OK) GGML_LOG_ERROR("[ggml-hip] get_tensor '%s' failed: %s\n", t->name, cllm_last_error());
+        if (cllm_memcpy_d2h(data, src, size, nullptr) != CLLM_OK) GGML_LOG_ERROR("[ggml-hip] get_tensor '%s' failed: %s\n", name, cllm_last_error());
         return;
     }
     for (size_t done = 0; done < size; done += g_stage_size) {
         const size_t n = size - done < g_stage_size ? size - done : g_stage_size;
-        if (cllm_memcpy_d2h(g_stage, (const char *) t->data + off + done, n, nullptr) != CLLM_OK) {     // synchronous
-            GGML_LOG_ERROR("[ggml-hip] get_tensor '%s' failed: %s\n", t->name, cllm_last_error());
+        if (cllm_memcpy_d2h(g_stage, src + done, n, nullptr) != CLLM_OK) {     // synchronous
+            GGML_LOG_ERROR("[ggml-hip] get_tensor '%s' failed: %s\n", name, cllm_last_error());
             return;
         }
         memcpy((char *) data + done, g_stage, n);
@@ -185,6 +232,8 @@ void buf_get(ggml_backend_buffer_t b, const ggml_tensor * t, void * data, size_t
 bool buf_cpy(ggml_backend_buffer_t b, const ggml_tensor * src, ggml_tensor * dst) {
     if (!ggml_is_contiguous(src) || !ggml_is_contiguous(dst) || ggml_nbytes(src) != ggml_nbytes(dst)) return false;
     flush_sets();
+    ahead_quiesce(((hip_buffer_ctx *) b->context)->device);
+    if (src->buffer && src->buffer->iface.get_base == buf_base) ahead_quiesce(((hip_buffer_ctx *) src->buffer->context)->device);
     cllm_set_device(((hip_buffer_ctx *) b->context)->device); ((hip_buffer_ctx *) b->context)->gen++;
     { std::lock_guard<std::mutex> lock(g_ring.m); i32_forget(dst->data, ggml_nbytes(dst)); }
     if (ggml_backend_buffer_is_host(src->buffer)) {
@@ -198,7 +247,7 @@ bool buf_cpy(ggml_backend_buffer_t b, const ggml_tensor * src, ggml_tensor * dst
     return false;
 }
 void buf_clear(ggml_backend_buffer_t b, uint8_t v) {
-    auto * c = (hip_buffer_ctx *) b->context; cllm_set_device(c->device); c->gen++;
+    auto * c = (hip_buffer_ctx *) b->context; ahead_quiesce(c->device); cllm_set_device(c->device); c->gen++;
     { std::lock_guard<std::mutex> lock(g_ring.m); i32_forget(c->base, b->size); }
     if (cllm_memset(c->base, v, b->size, nullptr) != CLLM_OK || cllm_stream_sync(nullptr) != CLLM_OK) GGML_LOG_ERROR("[ggml-hip] clear failed: %s\n", cllm_last_error());
 }
@@ -346,6 +395,12 @@ void be_free(ggml_backend_t b) {
     if (c->abuf) cllm_free(c->abuf);
     if (c->graph_exec) cllm_graph_destroy(c->graph_exec);
     if (c->copy_event) cllm_event_destroy(c->copy_event);
+    if (c->device < 64 && g_ahead_ctx[c->device] == c) g_ahead_ctx[c->device] = nullptr;
+    if (c->ahead.ev) cllm_event_destroy(c->ahead.ev);
+    if (c->ahead.tok_host) cllm_host_free(c->ahead.tok_host);
+    if (c->ahead.table_dev) cllm_free(c->ahead.table_dev);
+    if (c->ahead.scratch) cllm_free(c->ahead.scratch);
+    if (c->ahead.snap) cllm_free(c->ahead.snap);
     cllm_stream_destroy(c->stream);
     delete c; delete b;
 }
@@ -856,6 +911,53 @@ struct sig_writer {
     template <class... A> void call(const void * fn, A... a) { put(fn); int dummy[] = { 0, (arg(a), 0)... }; (void) dummy; }
 };
 
+// ---- decode-ahead.  chatllm's host is synchronous: compute, synchronize, read the logits, sample, build the next graph (~0.5 ms for Llama-3-8B),
+//      compute ...  -- the GPU idles while the host works.  In the steady state of a greedy decode the next step is known before the host asks for it:
+//      same captured launch list, token = argmax(logits), every position + 1.  So right after the host has read the logits the module starts that step
+//      itself (argmax + scalar updates on the device, then the captured graph); when the host's graph_compute arrives, its launch list and the scalars
+//      it wrote are compared with the prediction: equal -> the work is already running (or done), nothing is launched; different -> the step runs again
+//      the normal way (what ran ahead only touched the logits, scratch and the cache row of the next position, all of which the real step rewrites).
+//      Guards: only after a replayed step; only if the logits are the graph's single output; positions stay inside the caches; any other access through
+//      the buffer interface waits for the step running ahead (ahead_quiesce) and the logits stay readable from a snapshot; two misses in a row switch
+//      it off for the next 64 graphs (a sampling host costs itself at most a few % that way).  CLLM_HIP_AHEAD=0 turns it off.
+void ahead_launch(hip_backend_ctx * c) {
+    auto & A = c->ahead;
+    A.armed = false;
+    cllm_set_device(c->device);
+    if (!A.ev && cllm_event_create(&A.ev) != CLLM_OK) return;
+    if (!A.tok_host) { void * p = nullptr; if (cllm_host_malloc(&p, 64) != CLLM_OK) return; A.tok_host = (int32_t *) p; }
+    if (!A.table_dev && cllm_malloc(&A.table_dev, 1024 * sizeof(void *)) != CLLM_OK) return;
+    if (!A.scratch && cllm_malloc(&A.scratch, 2048) != CLLM_OK) return;
+    size_t snap_need = 0;
+    for (auto & o : A.outs) { o.snap_off = snap_need; snap_need += (o.bytes + 255) & ~(size_t) 255; }
+    if (A.snap_bytes < snap_need) {
+        if (A.snap) { cllm_stream_sync(c->stream); cllm_free(A.snap); A.snap = nullptr; A.snap_bytes = 0; }
+        if (cllm_malloc(&A.snap, snap_need) != CLLM_OK) return;
+        A.snap_bytes = snap_need;
+    }
+    std::vector<const void *> table;
+    A.pred.clear();
+    for (const auto & ss : A.last_sets) { A.pred.push_back(ss); if (ss.ptr != A.ids_ptr) { table.push_back(ss.ptr); A.pred.back().val = ss.val + 1; } }
+    if (table.size() > 1024) return;
+    if (table != A.table) {
+        if (!table.empty() && (cllm_memcpy_h2d(A.table_dev, table.data(), table.size() * sizeof(void *), nullptr) != CLLM_OK || cllm_stream_sync(nullptr) != CLLM_OK)) return;
+        A.table = table;
+    }
+    void * st = c->stream;
+    for (const auto & o : A.outs) if (cllm_memcpy_d2d((char *) A.snap + o.snap_off, o.ptr, o.bytes, st) != CLLM_OK) { cllm_stream_sync(st); return; }
+    if (cllm_op_argmax_advance(st, (const float *) A.logits_ptr, (int64_t)(A.logits_bytes / 4), (int32_t *) A.ids_ptr, A.tok_host, (int32_t * const *) A.table_dev, (int) table.size(), A.scratch) != CLLM_OK) return;
+    if (cllm_event_record(A.ev, st) != CLLM_OK) { cllm_stream_sync(st); return; }
+    if (cllm_graph_launch(c->graph_exec, st) != CLLM_OK) { cllm_stream_sync(st); return; }
+    static const bool ahead_sync = getenv("CLLM_HIP_AHEAD_SYNC") != nullptr;       // (debugging: run the step ahead to completion before returning)
+    if (ahead_sync) cllm_stream_sync(st);
+    cllm_event_sync(A.ev);                 // the snapshot and the scalars are in place before the host goes on (its own writes of the same scalars come later)
+    {   // the device now holds the predicted scalars: keep the host-side mirror in step (the host will write the same values again)
+        std::lock_guard<std::mutex> lock(g_ring.m);
+        for (const auto & ss : A.pred) { const int32_t v = ss.ptr == A.ids_ptr ? A.tok_host[0] : ss.val; auto it = g_i32_vals.find(ss.ptr); if (it != g_i32_vals.end()) it->second = v; }
+    }
+    A.inflight = true; A.launched++;
+}
+
 ggml_status be_graph_compute(ggml_backend_t backend, ggml_cgraph * g) {
     auto * c = (hip_backend_ctx *) backend->context;
     cllm_set_device(c->device);
@@ -873,6 +975,9 @@ ggml_status be_graph_compute(ggml_backend_t backend, ggml_cgraph * g) {
     ws_scope ws(g_ws.issue_us);
     flush_sets();                               // queued small set_tensor copies (null stream; this stream does not wait for it by itself)
     cllm_set_device(c->device);
+    std::vector<hip_backend_ctx::scalar_set> cur_sets;
+    { std::lock_guard<std::mutex> lock(g_ring.m); if (c->device < 64) cur_sets.swap(g_scalar_sets[c->device]); }
+    c->ahead.graphs++;
     fuse_plan plan = make_plan(g);
     if (g_stats) g_ws.plan_us += wall_stats::us(ws.t0, wall_stats::clk::now());
     // fused attention: [cos/sin table 1 KB][q | k | v projections][scores of the long-context form]
@@ -1080,7 +1185,25 @@ ggml_status be_graph_compute(ggml_backend_t backend, ggml_cgraph * g) {
         ggml_status rs = walk(probe, &sw);
         if (rs != GGML_STATUS_SUCCESS) return rs;
         const int n_calls = launches;
-        if (c->graph_exec && sig == c->graph_sig) {
+        bool ahead_hit = false;
+        if (c->ahead.inflight) {                   // a step is running ahead: is it the one the host is asking for?
+            auto & A = c->ahead;
+            A.inflight = false;
+            bool ok = c->graph_exec && sig == c->graph_sig && cur_sets.size() == A.pred.size();
+            for (size_t k = 0; ok && k < cur_sets.size(); k++)
+                ok = cur_sets[k].ptr == A.pred[k].ptr && cur_sets[k].val == (A.pred[k].ptr == A.ids_ptr ? A.tok_host[0] : A.pred[k].val);
+            if (ok) { ahead_hit = true; A.hits++; A.misses = 0; }
+            else {
+                if (++A.misses >= 2) { A.skip_until = A.graphs + 64; A.misses = 0; }
+                cllm_stream_sync(st);              // the step that ran ahead is not the one asked for: let it finish, then put the host's scalars in place (buf_set held them back)
+                for (const auto & ss : cur_sets) if (cllm_memcpy_h2d((void *) ss.ptr, &ss.val, 4, nullptr) != CLLM_OK) { HIPB_LOG("scalar write failed: %s", cllm_last_error()); return GGML_STATUS_FAILED; }
+                if (cllm_stream_sync(nullptr) != CLLM_OK) return GGML_STATUS_FAILED;
+            }
+        }
+        if (ahead_hit) {
+            replayed = true; c->replays++;         // nothing to launch
+            for (size_t k = 0; k < plan.groups.size(); k++) plan.groups[k].state = probe.groups[k].state;
+        } else if (c->graph_exec && sig == c->graph_sig) {
             if (cllm_graph_launch(c->graph_exec, st) != CLLM_OK) { HIPB_LOG("graph replay failed: %s", cllm_last_error()); return GGML_STATUS_FAILED; }
             replayed = true; c->replays++;
             for (size_t k = 0; k < plan.groups.size(); k++) plan.groups[k].state = probe.groups[k].state;      // (statistics)
@@ -1109,6 +1232,34 @@ ggml_status be_graph_compute(ggml_backend_t backend, ggml_cgraph * g) {
         }
         c->last_sig.swap(sig);
     }
+    {   // arm decode-ahead for the token after this one (see ahead_launch)
+        static const bool ahead_off = getenv("CLLM_HIP_AHEAD") && atoi(getenv("CLLM_HIP_AHEAD")) == 0;
+        auto & A = c->ahead;
+        A.armed = false;
+        const int nn = ggml_graph_n_nodes(g);
+        if (!ahead_off && replayed && c->graph_exec && A.graphs >= A.skip_until && !cur_sets.empty() && nn > 0 && !plan.attns.empty() && c->device < 64) {
+            const ggml_tensor * out = ggml_graph_node(g, nn - 1), * ids = nullptr;
+            int n_out = 0; A.outs.clear(); bool ok = out->type == GGML_TYPE_F32 && ggml_is_contiguous(out) && out->data && ggml_nbytes(out) % 4 == 0 && ggml_nbytes(out) >= 8;
+            int64_t min_ml = INT64_MAX;
+            for (const fused_attn & F : plan.attns) { ok = ok && F.level == 2; if (F.ML < min_ml) min_ml = F.ML; }
+            for (int i = 0; ok && i < nn; i++) {
+                const ggml_tensor * t = ggml_graph_node(g, i);
+                if (t->flags & GGML_TENSOR_FLAG_OUTPUT) { n_out++; if (t->data && ggml_is_contiguous(t)) A.outs.push_back({ (const char *) t->data, ggml_nbytes(t), 0 }); else ok = false; }
+                if (!plan.skip[i] && (t->op == GGML_OP_SET_ROWS || t->op == GGML_OP_FLASH_ATTN_EXT || t->op == GGML_OP_MUL_MAT_ID)) ok = false;      // cache writes outside the fused block, growing masks, experts: not predicted
+                if (!ids && t->op == GGML_OP_GET_ROWS && t->src[1] && t->src[1]->type == GGML_TYPE_I32 && ggml_nelements(t->src[1]) == 1) ids = t->src[1];
+            }
+            if (!(out->flags & GGML_TENSOR_FLAG_OUTPUT)) A.outs.push_back({ (const char *) out->data, ggml_nbytes(out), 0 });
+            ok = ok && ids && ids->data && n_out <= 8;
+            bool has_ids = false;
+            for (const auto & ss : cur_sets) { if (ids && ss.ptr == ids->data) has_ids = true; else if ((int64_t) ss.val + 1 >= min_ml || ss.val < 0) ok = false; }
+            static const bool dbg = getenv("CLLM_HIP_AHEAD_DEBUG") != nullptr;
+            if (dbg) HIPB_LOG("ahead: ok=%d has_ids=%d ids=%p n_out=%d out_flag=%d min_ml=%lld sets=%zu out=%s(%s) bytes=%zu", (int) ok, (int) has_ids, ids ? ids->data : nullptr, n_out, (int)((out->flags & GGML_TENSOR_FLAG_OUTPUT) != 0), (long long) min_ml, cur_sets.size(), out->name, ggml_op_name(out->op), ggml_nbytes(out));
+            if (ok && has_ids) {
+                A.ids_ptr = ids->data; A.logits_ptr = out->data; A.logits_bytes = ggml_nbytes(out); A.last_sets = cur_sets;
+                A.armed = true; g_ahead_ctx[c->device] = c;
+            }
+        }
+    }
     if (g_stats) {
         int a1 = 0, a2 = 0;
         for (const fused_attn & A : plan.attns) (A.level == 2 ? a2 : a1)++;
@@ -1126,7 +1277,7 @@ ggml_status be_graph_compute(ggml_backend_t backend, ggml_cgraph * g) {
                      "set_tensor %.0f us (%.1f calls) | get_tensor %.0f us (%.1f calls) | buffer alloc/free %.0f us (%.2f calls)",
                      g_ws.host_us / n, g_ws.issue_us / n, g_ws.plan_us / n, g_ws.calls / n, g_ws.sync_us / n, g_ws.set_us / n, g_ws.sets / n, g_ws.get_us / n, g_ws.gets / n,
                      g_ws.alloc_us / n, g_ws.allocs / n);
-            HIPB_LOG("launch lists replayed from a captured graph so far: %ld (captures: %ld)", c->replays, c->captures);
+            HIPB_LOG("launch lists replayed from a captured graph so far: %ld (captures: %ld); steps started ahead of the host: %ld, of which the host then asked for: %ld", c->replays, c->captures, c->ahead.launched, c->ahead.hits);
             g_ws.host_us = g_ws.plan_us = g_ws.issue_us = g_ws.sync_us = g_ws.set_us = g_ws.get_us = g_ws.alloc_us = 0; g_ws.calls = g_ws.sets = g_ws.gets = g_ws.allocs = 0;
         }
     }

@@ -74,6 +74,7 @@ SIGNATURES = {
     "cllm_bench_gemv_fused": (C.c_int, [_P, C.c_int, C.POINTER(C.c_void_p), C.c_int, C.c_int64, C.c_int64, C.c_int, _P, _P, C.c_float, C.c_int, _P, _P, C.c_int,
                                         C.POINTER(C.c_float)]),
     "cllm_op_mul_mat_id": (C.c_int, [_P, _T, _T, _T, _T, _P, C.c_size_t]),
+    "cllm_op_argmax_advance": (C.c_int, [_P, _P, C.c_int64, _P, _P, _P, C.c_int, _P]),
     "cllm_flash_attn_wsize": (C.c_size_t, [_T]),
     "cllm_op_flash_attn_ext": (C.c_int, [_P, _T, _T, _T, _T, _T, C.c_float, C.c_float, C.c_float, _P, C.c_size_t]),
     "cllm_attn_prefill_min_cols": (C.c_int, []),

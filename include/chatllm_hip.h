@@ -198,6 +198,13 @@ CLLM_API int    cllm_attn_prefill_min_cols(void);   /* query rows from which cal
 CLLM_API int    cllm_op_attn_prefill(void * stream, const cllm_tensor * q, const cllm_tensor * k, const cllm_tensor * vt, cllm_tensor * dst,
                                      float scale, int n_past);
 
+/* Greedy decode-ahead support for a host-side caller that replays a captured step: tok = index of the first maximum of logits[n]
+ * (std::max_element, the greedy sampler of src/models.cpp) written to *tok_dev (device) and *tok_host (page-locked host memory the device can
+ * write: cllm_host_malloc), and every int32 the n_inc device pointers of inc_ptrs_dev[] point at is incremented by one (the positions of the
+ * next step).  scratch: 2 KB of device memory. */
+CLLM_API int cllm_op_argmax_advance(void * stream, const float * logits, int64_t n, int32_t * tok_dev, int32_t * tok_host,
+                                    int32_t * const * inc_ptrs_dev, int n_inc, void * scratch);
+
 /* fused single-token attention as chatllm's eager path emits it for qlen == 1 (src/layers.cpp:2541-2561, 2499-2539):
  *   MUL_MAT(K view, Q) + SCALE(1/sqrt(hd)) + DIAG_MASK_INF + SOFT_MAX + MUL_MAT(V view, P) + PERMUTE + CONT
  * q: [hd, n_head] F32 (post-RoPE); k_cache: [max_len][n_kv_head*hd] F16; v_cache: [n_kv_head*hd][max_len] F16 (transposed);

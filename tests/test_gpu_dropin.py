@@ -356,3 +356,33 @@ def test_reference_host_other_k_quants_bit_identical(gpu, tmp_path, name, wt, mi
     assert len(graphs) == 17, len(graphs)                  # one graph per step: nothing fell back to the CPU backend
     assert ids_c == ids_g
     assert np.array_equal(lg_c.view(np.uint32), lg_g.view(np.uint32))
+
+
+@pytest.mark.skipif(not (os.path.exists(os.path.join(REF, "ref_chat")) and os.path.exists(os.path.join(REF, "libggml-hip.so"))),
+                    reason="oracle/_ref (reference host + module) not built")
+def test_module_decode_ahead_hits_and_misses_stay_bit_identical(gpu, tmp_path):
+    """decode-ahead (ggml-hip.cpp ahead_launch): after the host has read a step's logits the module starts the next greedy step itself; when the
+    host's graph arrives it is compared with the prediction.  Free-running greedy: every step is a hit.  A teacher that feeds OTHER tokens than the
+    argmax: every step is a miss (the step runs again the normal way, with the host's scalars written after the wrong one finished).  Either way every
+    logit equals the CPU run's bits, and the module counts what it did."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import make_ggmm
+    import re
+    cfg = gpu.synth.config("tiny", max_len=128)
+    mp = str(tmp_path / "m.bin")
+    make_ggmm.write_model(mp, cfg, 12, seed=83)
+    prompt = [3, 100, 45, 260, 17]
+    n_dec = 100
+    ids_c, lg_c, _ = _host_run(tmp_path, mp, "cpu", n_dec, prompt, cfg["vocab"])
+    ids_g, lg_g, err = _host_run(tmp_path, mp, "all", n_dec, prompt, cfg["vocab"])
+    assert ids_c == ids_g and np.array_equal(lg_c.view(np.uint32), lg_g.view(np.uint32))
+    m = re.findall(r"steps started ahead of the host: (\d+), of which the host then asked for: (\d+)", err)
+    assert m and int(m[-1][0]) >= 50 and int(m[-1][1]) >= int(m[-1][0]) - 1, m                        # greedy: (almost) every step was a hit
+    ids_off, lg_off, _ = _host_run(tmp_path, mp, "all", n_dec, prompt, cfg["vocab"], CLLM_HIP_AHEAD="0")
+    assert np.array_equal(lg_off.view(np.uint32), lg_c.view(np.uint32))
+    teacher = [(37 * i + 11) % cfg["vocab"] for i in range(n_dec + 1)]                               # not the argmax: every prediction is wrong
+    _, lt_c, _ = _host_run(tmp_path, mp, "cpu", n_dec, prompt, cfg["vocab"], teacher=teacher)
+    _, lt_g, err = _host_run(tmp_path, mp, "all", n_dec, prompt, cfg["vocab"], teacher=teacher)
+    assert np.array_equal(lt_c.view(np.uint32), lt_g.view(np.uint32))
+    m = re.findall(r"steps started ahead of the host: (\d+), of which the host then asked for: (\d+)", err)
+    assert m and int(m[-1][1]) <= 2 and 1 <= int(m[-1][0]) <= 12, m                                   # two misses in a row switch it off for 64 graphs
