@@ -908,7 +908,8 @@ struct sig_writer {
     void arg(cllm_rope_params * r) { arg((const cllm_rope_params *) r); }
     void arg(std::nullptr_t) { put((uint8_t) 0); }
     template <class T> typename std::enable_if<std::is_arithmetic<T>::value || std::is_pointer<T>::value || std::is_enum<T>::value>::type arg(T v) { put(v); }
-    template <class... A> void call(const void * fn, A... a) { put(fn); int dummy[] = { 0, (arg(a), 0)... }; (void) dummy; }
+    std::vector<size_t> * marks = nullptr;        // (CLLM_HIP_SIG_DEBUG: where every call starts)
+    template <class... A> void call(const void * fn, A... a) { if (marks) marks->push_back(b.size()); put(fn); int dummy[] = { 0, (arg(a), 0)... }; (void) dummy; }
 };
 
 // ---- decode-ahead.  chatllm's host is synchronous: compute, synchronize, read the logits, sample, build the next graph (~0.5 ms for Llama-3-8B),
@@ -1182,7 +1183,15 @@ ggml_status be_graph_compute(ggml_backend_t backend, ggml_cgraph * g) {
         sig.clear();
         fuse_plan probe = plan;                    // the walk changes the plan (merge decisions): sign on a copy
         sig_writer sw{ sig };
+        static const bool sig_dbg = getenv("CLLM_HIP_SIG_DEBUG") != nullptr;
+        static thread_local std::vector<size_t> marks;
+        if (sig_dbg) { marks.clear(); sw.marks = &marks; }
         ggml_status rs = walk(probe, &sw);
+        if (sig_dbg && sig != c->last_sig && sig.size() == c->last_sig.size()) {           // same shape of list, different bytes: which call, which byte?
+            size_t off = 0; while (off < sig.size() && sig[off] == c->last_sig[off]) off++;
+            size_t k = 0; while (k + 1 < marks.size() && marks[k + 1] <= off) k++;
+            HIPB_LOG("launch list differs from the previous graph's in call %zu of %zu, byte %zu of that call", k, marks.size(), off - marks[k]);
+        } else if (sig_dbg && sig != c->last_sig) HIPB_LOG("launch list differs from the previous graph's in length: %zu vs %zu bytes", sig.size(), c->last_sig.size());
         if (rs != GGML_STATUS_SUCCESS) return rs;
         const int n_calls = launches;
         bool ahead_hit = false;
@@ -1245,7 +1254,7 @@ ggml_status be_graph_compute(ggml_backend_t backend, ggml_cgraph * g) {
             for (int i = 0; ok && i < nn; i++) {
                 const ggml_tensor * t = ggml_graph_node(g, i);
                 if (t->flags & GGML_TENSOR_FLAG_OUTPUT) { n_out++; if (t->data && ggml_is_contiguous(t)) A.outs.push_back({ (const char *) t->data, ggml_nbytes(t), 0 }); else ok = false; }
-                if (!plan.skip[i] && (t->op == GGML_OP_SET_ROWS || t->op == GGML_OP_FLASH_ATTN_EXT || t->op == GGML_OP_MUL_MAT_ID)) ok = false;      // cache writes outside the fused block, growing masks, experts: not predicted
+                if (!plan.skip[i] && (t->op == GGML_OP_SET_ROWS || t->op == GGML_OP_FLASH_ATTN_EXT)) ok = false;      // cache writes outside the fused block, growing masks: not predicted (experts are picked on the device: nothing to predict)
                 if (!ids && t->op == GGML_OP_GET_ROWS && t->src[1] && t->src[1]->type == GGML_TYPE_I32 && ggml_nelements(t->src[1]) == 1) ids = t->src[1];
             }
             if (!(out->flags & GGML_TENSOR_FLAG_OUTPUT)) A.outs.push_back({ (const char *) out->data, ggml_nbytes(out), 0 });
