@@ -100,7 +100,7 @@ __global__ void __launch_bounds__(1024) k_gemv_dec(const float * __restrict__ px
         const int b = IS_K ? 8 * is + grp : 64 * is + lane;
         const bool ok = ik < nmine && b < nblk;
         const char * bp = W;
-        if (ok) bp = W + (unsigned long long)(unsigned)(unit_of(ik) * RU + isub) * nb01 + (unsigned) b * (unsigned) BS;
+        if (ok) bp = W + (unsigned long long)(unsigned)(unit_of(ik) * RU + isub) * nb01 + __umul24((unsigned) b, (unsigned) BS);      // (b < 2^24: the 32-bit v_mul_lo_u32 runs at a quarter rate)
         if (IS_K) {
             hh[p] = *(const u32x4 *) bp;
             qq[p] = *(const u32x4 *)(bp + 16 + 16 * j);

@@ -102,7 +102,7 @@ __device__ __forceinline__ void q4k_emit(const u32x4 h, const u32x4 q, const cha
     int pm = __mul24(mj, ys);                   // |ys| <= 32 * 127
     pm += dpp_i<DPP_QUAD_XOR1>(pm);
     float x = (float) sumi, dd = yd * d, xm = (float) pm, dm = (-yd) * dmin;
-    if (!ok) { x = 0.0f; dd = 0.0f; xm = 0.0f; dm = 0.0f; }
+    if (!ok) { dd = 0.0f; dm = 0.0f; }           // a masked block: fma(0, x, acc) == acc for the finite x it carries (two selects instead of four)
 #ifdef Q4K_NOWRITE       // (timing experiments only)
     asm volatile("" :: "v"(x), "v"(dd), "v"(xm), "v"(dm), "v"(rec));
 #else
