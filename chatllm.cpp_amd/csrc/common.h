@@ -277,6 +277,8 @@ int launch_mmvq_act(hipStream_t st, int wtype, const void * W, int64_t K, int64_
 int launch_gemv_decode(hipStream_t st, int wtype, const void * W, int64_t K, int64_t nrows, int pro, const float * px, const float * pw, float eps, int epi, float * dst, const float * bias, const float * resid, const float * padd = nullptr, float * xout = nullptr);
 bool prefill_f16_enabled();
 // fattn.hip: flash attention (tolerance tier).  vl 0: V rows by position [D, n_kv, ..]; vl 1: V^T rows [n_kv, D, ..] (the default V cache)
+int launch_attn_long_flash(hipStream_t st, const float * qkv, const int32_t * pos_dev, const float * rope_cs, int nh, int nkv, int hd, int mode,
+                           uint16_t * k_cache, uint16_t * v_cache, int64_t ML, float * S, size_t s_bytes, float * att);      // fattn.hip; CLLM_E_UNSUPPORTED: use launch_attn_long
 int flash_prefill_min_cols();          // query rows from which the eager attention block runs as the flash kernel (CLLM_FLASH_PREFILL=0: never)
 size_t fattn_wsize(int64_t N, int64_t H, int64_t B, int64_t D);
 int launch_fattn(hipStream_t st, const tview & q, const tview & k, int ktype, const tview & v, int vl, const tview * mask, int causal_past,

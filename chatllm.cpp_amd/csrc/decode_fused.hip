@@ -480,6 +480,8 @@ extern "C" int cllm_op_rope_kv_attn_decode(void * stream, const float * qkv, con
     int rc = CLLM_E_UNSUPPORTED;
     const size_t need = cllm_attn_decode_wsize(n_kv, n_head, max_len);
     if (rope_cs && need && wdata && wsize >= need)
+        rc = launch_attn_long_flash(st, qkv, pos_dev, rope_cs, n_head, n_kv_head, head_dim, rope_mode, (uint16_t *) k_cache, (uint16_t *) v_cache, max_len, (float *) wdata, wsize, out);
+    if (rc == CLLM_E_UNSUPPORTED && rope_cs && need && wdata && wsize >= need)
         rc = launch_attn_long(st, qkv, pos_dev, rope_cs, n_head, n_kv_head, head_dim, rope_mode, (uint16_t *) k_cache, (uint16_t *) v_cache, max_len, (float *) wdata, out);
     if (rc == CLLM_E_UNSUPPORTED && rope_cs)
         rc = launch_attn_dec_table(st, qkv, pos_dev, rope_cs, n_head, n_kv_head, head_dim, rope_mode, (uint16_t *) k_cache, (uint16_t *) v_cache, max_len, out);

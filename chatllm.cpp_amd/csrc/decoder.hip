@@ -459,7 +459,8 @@ static int decode_step_fused(cllm_llama * m, bool sample, bool long_ctx) {
         llama_layer & L = m->layers[il];
         TRY(norm_gemv(L.wqkv, QD + 2*KD, (const float *) L.attn_norm.data, 0, m->qkv, c.qkv_bias ? (const float *) L.bqkv.data : nullptr));
         int arc = CLLM_E_UNSUPPORTED;
-        if (cs_table && long_ctx) arc = launch_attn_long(st, m->qkv, m->pos_dev, rope_cs, m->nh, m->nkv, (int) hd, c.rope_mode, L.k_cache, L.v_cache, ML, m->scores, m->att);
+        if (cs_table && long_ctx) arc = launch_attn_long_flash(st, m->qkv, m->pos_dev, rope_cs, m->nh, m->nkv, (int) hd, c.rope_mode, L.k_cache, L.v_cache, ML, m->scores, m->scores_elems * 4, m->att);
+        if (arc == CLLM_E_UNSUPPORTED && cs_table && long_ctx) arc = launch_attn_long(st, m->qkv, m->pos_dev, rope_cs, m->nh, m->nkv, (int) hd, c.rope_mode, L.k_cache, L.v_cache, ML, m->scores, m->att);
         if (arc == CLLM_E_UNSUPPORTED && cs_table) arc = launch_attn_dec_table(st, m->qkv, m->pos_dev, rope_cs, m->nh, m->nkv, (int) hd, c.rope_mode, L.k_cache, L.v_cache, ML, m->att);
         if (arc == CLLM_E_UNSUPPORTED) arc = launch_rope_kv_attn_decode(st, m->qkv, m->pos_dev, m->nh, m->nkv, (int) hd, c.rope_mode, c.rope_theta, L.k_cache, L.v_cache, ML, m->att);
         TRY(arc);

@@ -30,6 +30,7 @@ typedef float    f32x16 __attribute__((ext_vector_type(16)));
 
 #define FA_VSTR 136                  // bytes per V^T row in LDS: 64 positions * 2 B + 8 B (conflict-free ds_read_b64 over 32 rows)
 #define FA_LOG2E 1.4426950408889634f
+#define FA_MAX_SPLITS 256            // split-KV decode: at most this many partials per (head, query)
 
 struct fattn_args {
     const char * q; int64_t q_nb1, q_nb2, q_nb3;            // F32 [D, N, H, B]
@@ -40,6 +41,7 @@ struct fattn_args {
     char * dst; int64_t d_nbn, d_nbh, d_nbb;                // F32 element (dv, h, n, b) at dst + n d_nbn + h d_nbh + b d_nbb + 4 dv
     float * part;                                           // splits > 1: [B][H][N][splits][D + 4] = O (unnormalized), m (log2 domain), l
     int N, H, Hkv, R, n_kv, n_past, splits, chunk;
+    const int32_t * n_kv_dev;                               // decode inside a captured step: the number of cached positions is *n_kv_dev + 1 (n_kv: the upper bound)
     float sc2;                                              // scale * log2(e)
 };
 
@@ -83,6 +85,7 @@ __global__ void __launch_bounds__(NW * 64) k_fattn(const fattn_args a) {
     if (MASK == 1) qb = nqb - 1 - qb;                                  // the long (late) query blocks first
     const int y = blockIdx.y, b = blockIdx.z;
     const int hk = y * a.R / (a.H / a.Hkv);
+    const bool wave_live = qb * BQ + wave * 32 < rows;
     const int rho = qb * BQ + wave * 32 + l31;
     const bool rvalid = rho < rows;
     const int rc = rvalid ? rho : rows - 1;
@@ -120,8 +123,9 @@ __global__ void __launch_bounds__(NW * 64) k_fattn(const fattn_args a) {
     const char * vb = a.v + (int64_t) hk * a.v_nb2 + (int64_t) b * a.v_nb3;
     const char * mrow = MASK == 2 ? a.mask + (int64_t) n * a.m_nb1 + (int64_t)(h % a.m_ne2) * a.m_nb2 + (int64_t)(b % a.m_ne3) * a.m_nb3 : nullptr;
 
+    const int n_kv = a.n_kv_dev ? min(a.n_kv, a.n_kv_dev[0] + 1) : a.n_kv;
     const int kv_lo = split * a.chunk;
-    int kv_hi = min(a.n_kv, kv_lo + a.chunk);
+    int kv_hi = min(n_kv, kv_lo + a.chunk);
     if (MASK == 1) kv_hi = min(kv_hi, a.n_past + min(a.N - 1, (qb * BQ + BQ - 1) / a.R) + 1);
     const int lim = MASK == 1 ? a.n_past + n : 0;                      // causal: position kv is visible to row n iff kv <= n_past + n
 
@@ -132,9 +136,104 @@ __global__ void __launch_bounds__(NW * 64) k_fattn(const fattn_args a) {
         for (int r = 0; r < 16; r++) o[i][r] = 0.0f;
     float m_run = -INFINITY, l_run = 0.0f;
 
+    // ---- K / V staging is split in two: global -> registers (issued one tile ahead: the loads fly under the MFMA work of the current tile) and
+    //      registers -> LDS (conversion, swizzle, transposition; between the two barriers of a tile).  Q8_0 rows keep their raw 16-bit pieces in
+    //      the registers (34-byte blocks: 2-byte alignment) and are dequantized on the way into LDS.
+    constexpr bool Q8 = KVT == CLLM_TYPE_Q8_0;
+    constexpr int NKC = (64 * CPR + NT - 1) / NT;                     // K chunks (8 elements) per thread
+    constexpr int NVU = VL == 1 ? (D * 8 + NT - 1) / NT : (16 * CPR + NT - 1) / NT;      // V^T chunks (VL 1) / 4-row x 8-element units (VL 0) per thread
+    struct raw8 { uint32_t h[4]; uint32_t d; };                      // Q8_0: four 16-bit pieces of 8 quants + the block scale
+    u32x4 kreg[Q8 ? 1 : NKC]; raw8 kraw[Q8 ? NKC : 1];
+    u32x4 vreg[Q8 ? 1 : (VL == 1 ? NVU : 4 * NVU)]; raw8 vraw[Q8 ? 4 * NVU : 1];
+    auto q8_load = [&](const char * row, int e0) {
+        raw8 r; const char * p = row + (e0 >> 5) * 34;
+        r.d = *(const uint16_t *) p;
+        const uint16_t * qs = (const uint16_t *)(p + 2 + (e0 & 31));
+#pragma unroll
+        for (int i = 0; i < 4; i++) r.h[i] = qs[i];
+        return r;
+    };
+    auto q8_cvt = [&](const raw8 & r) {
+        const float d = h2f((uint16_t) r.d);
+        u32x4 out;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const _Float16 lo = (_Float16)(d * (float)(int8_t)(r.h[i] & 0xff)), up = (_Float16)(d * (float)(int8_t)(r.h[i] >> 8));
+            uint16_t x, y; __builtin_memcpy(&x, &lo, 2); __builtin_memcpy(&y, &up, 2);
+            out[i] = (uint32_t) x | ((uint32_t) y << 16);
+        }
+        return out;
+    };
+    auto load_tile = [&](int kv0) {
+#pragma unroll
+        for (int t = 0; t < NKC; t++) {
+            const int c = tid + t * NT, row = c / CPR, col = c % CPR, kv = min(kv0 + (c < 64 * CPR ? row : 0), kv_hi - 1);
+            if (Q8) kraw[Q8 ? t : 0] = q8_load(kb + (int64_t) kv * a.k_nb1, col * 8);
+            else    kreg[Q8 ? 0 : t] = *(const u32x4 *)(kb + (int64_t) kv * a.k_nb1 + col * 16);
+        }
+        if (VL == 1) {
+#pragma unroll
+            for (int t = 0; t < NVU; t++) {
+                const int c = tid + t * NT, dv = (c >> 3) % D, kc = c & 7, kvs = kv0 + 8 * kc;
+                const int kvl = min(kvs, (n_kv - 1) & ~7);
+                vreg[Q8 ? 0 : t] = *(const u32x4 *)(vb + (int64_t) dv * a.v_nb1 + (int64_t) kvl * 2);
+            }
+        } else {
+#pragma unroll
+            for (int t = 0; t < NVU; t++) {
+                const int u = (tid + t * NT) % (16 * CPR), kvg = u / CPR, dvg = u % CPR;
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const int kv = min(kv0 + 4 * kvg + i, kv_hi - 1);
+                    if (Q8) vraw[Q8 ? 4 * t + i : 0] = q8_load(vb + (int64_t) kv * a.v_nb1, dvg * 8);
+                    else    vreg[Q8 ? 0 : 4 * t + i] = *(const u32x4 *)(vb + (int64_t) kv * a.v_nb1 + dvg * 16);
+                }
+            }
+        }
+    };
+    auto store_tile = [&](int kv0) {
+#pragma unroll
+        for (int t = 0; t < NKC; t++) {
+            const int c = tid + t * NT, row = c / CPR, col = c % CPR;
+            if (c < 64 * CPR) *(u32x4 *)(Kl + row * (D * 2) + ((col ^ (row & (CPR - 1))) << 4)) = Q8 ? q8_cvt(kraw[Q8 ? t : 0]) : kreg[Q8 ? 0 : t];
+        }
+        if (VL == 1) {
+#pragma unroll
+            for (int t = 0; t < NVU; t++) {
+                const int c = tid + t * NT, dv = c >> 3, kc = c & 7, kvs = kv0 + 8 * kc;
+                u32x4 x = vreg[Q8 ? 0 : t];
+                const int left = n_kv - kvs;                           // elements of this chunk that exist (the rest of the cache row is not ours: may be anything)
+#pragma unroll
+                for (int w = 0; w < 4; w++) {
+                    if (2 * w >= left) x[w] = 0;
+                    else if (2 * w + 1 >= left) x[w] &= 0xffffu;
+                }
+                if (c < D * 8) { char * p = Vl + dv * FA_VSTR + kc * 16; *(u32x2 *) p = u32x2{x.x, x.y}; *(u32x2 *)(p + 8) = u32x2{x.z, x.w}; }
+            }
+        } else {
+#pragma unroll
+            for (int t = 0; t < NVU; t++) {
+                const int u = tid + t * NT, kvg = u / CPR, dvg = u % CPR;
+                u32x4 x[4];
+#pragma unroll
+                for (int i = 0; i < 4; i++) x[i] = Q8 ? q8_cvt(vraw[Q8 ? 4 * t + i : 0]) : vreg[Q8 ? 0 : 4 * t + i];
+                if (u < 16 * CPR) {
+#pragma unroll
+                    for (int e = 0; e < 8; e++) {                      // 4 x 4 transposition in registers: V rows by position -> V^T rows by feature
+                        const uint32_t sel = (e & 1) ? 0x07060302u : 0x05040100u;
+                        const uint32_t lo = __builtin_amdgcn_perm(x[1][e >> 1], x[0][e >> 1], sel), up = __builtin_amdgcn_perm(x[3][e >> 1], x[2][e >> 1], sel);
+                        *(u32x2 *)(Vl + (8 * dvg + e) * FA_VSTR + kvg * 8) = u32x2{lo, up};
+                    }
+                }
+            }
+        }
+    };
+
+    if (kv_lo < kv_hi) load_tile(kv_lo);
     for (int kv0 = kv_lo; kv0 < kv_hi; kv0 += 64) {
         // ---- the mask of this tile (tensor form): the lane's 32 positions in 8 groups of 4
         float mv[2][16];
+        bool skip = false;
         if (MASK == 2) {
             int any = 0;
 #pragma unroll
@@ -158,56 +257,16 @@ __global__ void __launch_bounds__(NW * 64) k_fattn(const fattn_args a) {
                         any |= (f != -INFINITY) && rvalid;
                     }
                 }
-            if (!__syncthreads_or(any)) continue;                      // nothing of this tile is visible to the workgroup's rows
+            skip = !__syncthreads_or(any);                             // (also: the previous tile's fragments have been read) nothing of this tile visible: no staging, no math
         } else {
             __syncthreads();                                           // the previous tile's fragments have been read
         }
-
-        // ---- stage K (row-major, 16-byte chunks XOR-swizzled by row) and V^T ([dv][kv]) as fp16
-#pragma unroll 4
-        for (int c = tid; c < 64 * CPR; c += NT) {
-            const int row = c / CPR, col = c % CPR, kv = min(kv0 + row, kv_hi - 1);
-            u32x4 t;
-            if (KVT == CLLM_TYPE_Q8_0) t = fa_q8_8(kb + (int64_t) kv * a.k_nb1, col * 8);
-            else                       t = *(const u32x4 *)(kb + (int64_t) kv * a.k_nb1 + col * 16);
-            *(u32x4 *)(Kl + row * (D * 2) + ((col ^ (row & (CPR - 1))) << 4)) = t;
-        }
-        if (VL == 1) {
-#pragma unroll 4
-            for (int c = tid; c < D * 8; c += NT) {
-                const int dv = c >> 3, kc = c & 7, kvs = kv0 + 8 * kc;
-                const int kvl = min(kvs, (a.n_kv - 1) & ~7);
-                u32x4 t = *(const u32x4 *)(vb + (int64_t) dv * a.v_nb1 + (int64_t) kvl * 2);
-                const int left = a.n_kv - kvs;                         // elements of this chunk that exist (the rest of the row is not ours)
-#pragma unroll
-                for (int w = 0; w < 4; w++) {
-                    if (2 * w >= left) t[w] = 0;
-                    else if (2 * w + 1 >= left) t[w] &= 0xffffu;
-                }
-                char * p = Vl + dv * FA_VSTR + kc * 16;
-                *(u32x2 *) p = u32x2{t.x, t.y}; *(u32x2 *)(p + 8) = u32x2{t.z, t.w};
-            }
-        } else {
-#pragma unroll 2
-            for (int u = tid; u < 16 * CPR; u += NT) {
-                const int kvg = u / CPR, dvg = u % CPR;
-                u32x4 t[4];
-#pragma unroll
-                for (int i = 0; i < 4; i++) {
-                    const int kv = min(kv0 + 4 * kvg + i, kv_hi - 1);
-                    if (KVT == CLLM_TYPE_Q8_0) t[i] = fa_q8_8(vb + (int64_t) kv * a.v_nb1, dvg * 8);
-                    else                       t[i] = *(const u32x4 *)(vb + (int64_t) kv * a.v_nb1 + dvg * 16);
-                }
-#pragma unroll
-                for (int e = 0; e < 8; e++) {
-                    const uint32_t sel = (e & 1) ? 0x07060302u : 0x05040100u;
-                    const uint32_t lo = __builtin_amdgcn_perm(t[1][e >> 1], t[0][e >> 1], sel), up = __builtin_amdgcn_perm(t[3][e >> 1], t[2][e >> 1], sel);
-                    *(u32x2 *)(Vl + (8 * dvg + e) * FA_VSTR + kvg * 8) = u32x2{lo, up};
-                }
-            }
-        }
+        if (!skip) store_tile(kv0);
+        if (kv0 + 64 < kv_hi) load_tile(kv0 + 64);                     // the next tile's loads fly under this tile's math
+        if (skip) continue;
         __syncthreads();
 
+        if (!wave_live) continue;                                      // (decode: the group's rows fit one wave; the others only help staging)
         // ---- S^T = K . Q^T
         f32x16 s[2];
 #pragma unroll
@@ -293,29 +352,43 @@ __global__ void __launch_bounds__(NW * 64) k_fattn(const fattn_args a) {
     }
 }
 
-// merge the split-KV partials of one (b, h, n): one wave (ggml_flash_attn_ext_reduce_partials, ops.cpp:8642-8710)
+// merge the split-KV partials of one (b, h, n) (ggml_flash_attn_ext_reduce_partials, ops.cpp:8642-8710): 256 threads = D output elements x
+// (256 / D) interleaved groups of splits, so that the loads of different splits are independent and coalesced
 template <int D>
-__global__ void __launch_bounds__(64) k_fattn_merge(const fattn_args a) {
-    const int lane = threadIdx.x, n = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+__global__ void __launch_bounds__(1024) k_fattn_merge(const fattn_args a) {
+    constexpr int G = 1024 / D;
+    __shared__ float red[1024];
+    __shared__ float wgt[FA_MAX_SPLITS];
+    __shared__ float Lsh;
+    const int tid = threadIdx.x, dv = tid % D, g = tid / D, n = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
     const float * pp = a.part + (((int64_t) b * a.H + h) * a.N + n) * a.splits * (D + 4);
-    float M = -INFINITY;
-    for (int s = lane; s < a.splits; s += 64) M = fmaxf(M, pp[(int64_t) s * (D + 4) + D]);
-    M = wave_max(M);
-    const float Ms = M == -INFINITY ? 0.0f : M;
-    float L = 0.0f, acc[D / 64];
+    float m = tid < a.splits ? pp[(int64_t) tid * (D + 4) + D] : -INFINITY, l = tid < a.splits ? pp[(int64_t) tid * (D + 4) + D + 1] : 0.0f;
+    red[tid] = m;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if (tid < o) red[tid] = fmaxf(red[tid], red[tid + o]); __syncthreads(); }      // splits <= 256
+    const float M = red[0], Ms = M == -INFINITY ? 0.0f : M;
+    __syncthreads();
+    const float w = tid < a.splits ? __builtin_amdgcn_exp2f(m - Ms) : 0.0f;
+    if (tid < FA_MAX_SPLITS) wgt[tid] = w;
+    red[tid] = w * l;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if (tid < o) red[tid] += red[tid + o]; __syncthreads(); }
+    if (tid == 0) Lsh = red[0];
+    __syncthreads();
+    const float L = Lsh;
+    __syncthreads();
+    float acc = 0.0f;
+#pragma unroll 4
+    for (int s = g; s < a.splits; s += G) acc += wgt[s] * pp[(int64_t) s * (D + 4) + dv];
+    red[tid] = acc;
+    __syncthreads();
+    if (g == 0) {
 #pragma unroll
-    for (int i = 0; i < D / 64; i++) acc[i] = 0.0f;
-    for (int s = 0; s < a.splits; s++) {
-        const float * ps = pp + (int64_t) s * (D + 4);
-        const float w = exp2f(ps[D] - Ms);
-        L += w * ps[D + 1];
-#pragma unroll
-        for (int i = 0; i < D / 64; i++) acc[i] += w * ps[lane + 64 * i];
+        for (int k = 1; k < G; k++) acc += red[dv + k * D];
+        const float inv = L == 0.0f ? 0.0f : 1.0f / L;
+        float * dp = (float *)(a.dst + (int64_t) n * a.d_nbn + (int64_t) h * a.d_nbh + (int64_t) b * a.d_nbb);
+        dp[dv] = acc * inv;
     }
-    const float inv = L == 0.0f ? 0.0f : 1.0f / L;
-    float * dp = (float *)(a.dst + (int64_t) n * a.d_nbn + (int64_t) h * a.d_nbh + (int64_t) b * a.d_nbb);
-#pragma unroll
-    for (int i = 0; i < D / 64; i++) dp[lane + 64 * i] = acc[i] * inv;
 }
 
 static int g_flash_min = -1;             // -1: not read yet
@@ -329,16 +402,16 @@ int flash_prefill_min_cols() {
 }
 // tests: switch the runner's prefill attention between the flash kernel and the node sequence inside one process (<= 0: back to the environment)
 extern "C" __attribute__((visibility("default"))) void cllm_debug_set_attn_prefill_min_cols(int n) { g_flash_min = n > 0 ? n : -1; }
-size_t fattn_wsize(int64_t N, int64_t H, int64_t B, int64_t D) { return (size_t) B * H * N * 64 * (D + 4) * 4; }
+size_t fattn_wsize(int64_t N, int64_t H, int64_t B, int64_t D) { return (size_t) B * H * N * FA_MAX_SPLITS * (D + 4) * 4; }
 
 template <int D, int KVT, int VL, int MASK>
 static int fattn_launch(hipStream_t st, const fattn_args & a, int B, bool decode) {
     const size_t lds = 64 * D * 2 + D * FA_VSTR;
     if (decode) {
         const dim3 grid((unsigned) a.splits, (unsigned)(a.H / a.R), (unsigned) B);
-        hipLaunchKernelGGL((k_fattn<D, KVT, VL, MASK, 1>), grid, dim3(64), lds, st, a);
+        hipLaunchKernelGGL((k_fattn<D, KVT, VL, MASK, 4>), grid, dim3(256), lds, st, a);     // four waves stage the tile (one load latency); the wave that owns the rows computes
         LAUNCH_CHECK();
-        if (a.splits > 1) { hipLaunchKernelGGL((k_fattn_merge<D>), dim3((unsigned) a.N, (unsigned) a.H, (unsigned) B), dim3(64), 0, st, a); LAUNCH_CHECK(); }
+        if (a.splits > 1) { hipLaunchKernelGGL((k_fattn_merge<D>), dim3((unsigned) a.N, (unsigned) a.H, (unsigned) B), dim3(1024), 0, st, a); LAUNCH_CHECK(); }
     } else {
         const dim3 grid((unsigned)((a.N + 127) / 128), (unsigned) a.H, (unsigned) B);
         hipLaunchKernelGGL((k_fattn<D, KVT, VL, MASK, 4>), grid, dim3(256), lds, st, a);
@@ -383,9 +456,11 @@ int launch_fattn(hipStream_t st, const tview & q, const tview & k, int ktype, co
     const int r = (int)(H / Hkv);
     const bool decode = N * r <= 32;
     a.R = decode ? r : 1;
-    a.splits = 1; a.chunk = (int)((n_kv + 63) / 64 * 64); a.part = nullptr;
+    a.splits = 1; a.chunk = (int)((n_kv + 63) / 64 * 64); a.part = nullptr; a.n_kv_dev = nullptr;
     if (decode && n_kv > 64) {
-        const int tiles = (int)((n_kv + 63) / 64), per = (tiles + 63) / 64;           // at most 64 splits
+        const int tiles = (int)((n_kv + 63) / 64);      // ~2 workgroups per CU, each walking `per` tiles with the next tile's loads in flight
+        static const int div = getenv("CLLM_FA_DIV") ? atoi(getenv("CLLM_FA_DIV")) : 64;
+        int per = tiles / div; if (per < 1) per = 1; if (per < (tiles + FA_MAX_SPLITS - 1) / FA_MAX_SPLITS) per = (tiles + FA_MAX_SPLITS - 1) / FA_MAX_SPLITS;
         a.chunk = per * 64; a.splits = (tiles + per - 1) / per;
         if (a.splits > 1) {
             if (!wdata || wsize < (size_t) B * H * N * a.splits * (D + 4) * 4 || ((uintptr_t) wdata & 15)) FAIL(CLLM_E_INVALID, "flash_attn_ext: wdata too small");
@@ -407,4 +482,65 @@ int launch_fattn(hipStream_t st, const tview & q, const tview & k, int ktype, co
 #undef FA_MASKS
 #undef FA_GO
     return CLLM_E_UNSUPPORTED;
+}
+
+// ---- single-token attention above attn_long_threshold() cached positions inside a captured decode step (the runner's graph, the module's
+//      launch list): RoPE of q and k + both cache writes in one small launch (the same arithmetic as k_attn_dec: bit-identical cache contents),
+//      then the split-KV flash kernel with the number of positions read on the device, then the merge.  Tolerance tier (like attn_long.hip, which
+//      it replaces unless CLLM_ATTN_LONG_FLASH=0): ~2x faster at 4K-16K positions.
+template <int HD, int MODE>
+__global__ void __launch_bounds__(HD) k_rope_kv_prep(const float * __restrict__ qkv, const int32_t * __restrict__ pos_dev, const float * __restrict__ rope_cs, int nh, int nkv,
+                                                     uint16_t * __restrict__ k_cache, uint16_t * __restrict__ v_cache, int ML, float * __restrict__ qrot) {
+    constexpr int half = HD / 2, off = MODE == 0 ? 1 : half;
+    const int tid = threadIdx.x, blk = blockIdx.x, pos = pos_dev[0], KD = nkv * HD, QD = nh * HD;
+    const bool is_q = blk < nh;
+    const int g = blk - nh;
+    const float * x = is_q ? qkv + blk * HD : qkv + QD + g * HD;
+    if (tid < half) {
+        const int ic = MODE == 0 ? 2 * tid : tid;
+        const float x0 = x[ic], x1 = x[ic + off], c = rope_cs[2 * tid], sn = rope_cs[2 * tid + 1];
+        const float y0 = rope_rot_a(x0, x1, c, sn), y1 = rope_rot_b(x0, x1, c, sn);
+        if (is_q) { qrot[blk * HD + ic] = y0; qrot[blk * HD + ic + off] = y1; }
+        else { k_cache[(int64_t) pos * KD + g * HD + ic] = f2h(y0); k_cache[(int64_t) pos * KD + g * HD + ic + off] = f2h(y1); }
+    }
+    if (!is_q) v_cache[((int64_t) g * HD + tid) * ML + pos] = f2h(qkv[QD + KD + g * HD + tid]);
+}
+
+int launch_attn_long_flash(hipStream_t st, const float * qkv, const int32_t * pos_dev, const float * rope_cs, int nh, int nkv, int hd, int mode,
+                           uint16_t * k_cache, uint16_t * v_cache, int64_t ML, float * S, size_t s_bytes, float * att) {
+    static const bool off = getenv("CLLM_ATTN_LONG_FLASH") && atoi(getenv("CLLM_ATTN_LONG_FLASH")) == 0;
+    if (off || !rope_cs || (hd != 64 && hd != 128) || nkv <= 0 || nh % nkv || (int64_t) nh / nkv > 32 || ML % 8 || ML > (1 << 30) || ((uintptr_t) S & 15)) return CLLM_E_UNSUPPORTED;
+    const size_t q_bytes = ((size_t) nh * hd * 4 + 255) & ~(size_t) 255;
+    if (s_bytes <= q_bytes) return CLLM_E_UNSUPPORTED;
+    int max_splits = (int)((s_bytes - q_bytes) / ((size_t) nh * (hd + 4) * 4));
+    if (max_splits > FA_MAX_SPLITS) max_splits = FA_MAX_SPLITS;
+    if (max_splits < 4) return CLLM_E_UNSUPPORTED;
+    float * qrot = S;
+    if (hd == 128) { if (mode == 0) hipLaunchKernelGGL((k_rope_kv_prep<128, 0>), dim3(nh + nkv), dim3(128), 0, st, qkv, pos_dev, rope_cs, nh, nkv, k_cache, v_cache, (int) ML, qrot);
+                     else           hipLaunchKernelGGL((k_rope_kv_prep<128, 2>), dim3(nh + nkv), dim3(128), 0, st, qkv, pos_dev, rope_cs, nh, nkv, k_cache, v_cache, (int) ML, qrot); }
+    else           { if (mode == 0) hipLaunchKernelGGL((k_rope_kv_prep<64, 0>),  dim3(nh + nkv), dim3(64),  0, st, qkv, pos_dev, rope_cs, nh, nkv, k_cache, v_cache, (int) ML, qrot);
+                     else           hipLaunchKernelGGL((k_rope_kv_prep<64, 2>),  dim3(nh + nkv), dim3(64),  0, st, qkv, pos_dev, rope_cs, nh, nkv, k_cache, v_cache, (int) ML, qrot); }
+    LAUNCH_CHECK();
+    const int KD = nkv * hd;
+    fattn_args a;
+    a.q = (const char *) qrot; a.q_nb1 = (int64_t) nh * hd * 4; a.q_nb2 = (int64_t) hd * 4; a.q_nb3 = a.q_nb1;
+    a.k = (const char *) k_cache; a.k_nb1 = (int64_t) KD * 2; a.k_nb2 = (int64_t) hd * 2; a.k_nb3 = a.k_nb1 * ML;
+    a.v = (const char *) v_cache; a.v_nb1 = ML * 2; a.v_nb2 = ML * hd * 2; a.v_nb3 = a.v_nb2 * nkv;
+    a.mask = nullptr; a.m_nb1 = a.m_nb2 = a.m_nb3 = 0; a.m_ne2 = a.m_ne3 = 1; a.m_al = 0;
+    a.dst = (char *) att; a.d_nbn = (int64_t) nh * hd * 4; a.d_nbh = (int64_t) hd * 4; a.d_nbb = a.d_nbn;
+    a.part = (float *)((char *) S + q_bytes);
+    a.N = 1; a.H = nh; a.Hkv = nkv; a.R = nh / nkv; a.n_kv = (int) ML; a.n_past = -1; a.sc2 = (1.0f / sqrtf((float) hd)) * FA_LOG2E;
+    a.n_kv_dev = pos_dev;
+    const int tiles = (int)((ML + 63) / 64);
+    int per = (tiles + max_splits - 1) / max_splits; if (per < tiles / 32) per = tiles / 32; if (per < 1) per = 1;
+    a.chunk = per * 64; a.splits = (tiles + per - 1) / per;
+    const size_t lds = 64 * (size_t) hd * 2 + (size_t) hd * FA_VSTR;
+    const dim3 grid((unsigned) a.splits, (unsigned) nkv, 1);
+    if (hd == 128) hipLaunchKernelGGL((k_fattn<128, CLLM_TYPE_F16, 1, 0, 4>), grid, dim3(256), lds, st, a);
+    else           hipLaunchKernelGGL((k_fattn<64,  CLLM_TYPE_F16, 1, 0, 4>), grid, dim3(256), lds, st, a);
+    LAUNCH_CHECK();
+    if (hd == 128) hipLaunchKernelGGL((k_fattn_merge<128>), dim3(1, (unsigned) nh, 1), dim3(1024), 0, st, a);
+    else           hipLaunchKernelGGL((k_fattn_merge<64>),  dim3(1, (unsigned) nh, 1), dim3(1024), 0, st, a);
+    LAUNCH_CHECK();
+    return CLLM_OK;
 }
