@@ -185,6 +185,7 @@ static int  act_kind(int wtype) { return act_kind_of(wtype); }
 // Columns from which the quantized product runs on the matrix cores (mmq.hip: exact integer block sums, its own fp32 summation order =
 // tolerance tier).  Below, the multi-column mat-vec runs in chunks of <= 4 columns: it accumulates in the reference's AVX2 order, so short
 // prompts (BASELINE cfg2: 16 tokens) stay BIT-IDENTICAL to the CPU path end to end.  Default 33; CLLM_MMQ_MIN_COLS=9 is the speed crossover.
+int mmq_min_cols_get();
 static int mmq_min_cols() {
     static int v = -1;
     if (v < 0) { v = 33; if (const char * e = getenv("CLLM_MMQ_MIN_COLS")) { int x = atoi(e); if (x >= 1) v = x; } }
@@ -279,6 +280,33 @@ extern "C" int cllm_op_mul_mat(void * stream, const cllm_tensor * src0, const cl
         if (rc) return rc;
     }
     return CLLM_OK;
+}
+
+int mmq_min_cols_get() { return mmq_min_cols(); }
+extern "C" int cllm_op_mul_mat_ex(void * stream, const cllm_tensor * src0, const cllm_tensor * src1, cllm_tensor * dst, void * wdata, size_t wsize, int pro,
+                                  const cllm_tensor * resid) {
+    if (!src0 || !src1 || !dst) FAIL(CLLM_E_INVALID, "mul_mat_ex: null tensor");
+    if (pro != 0 && pro != 3) FAIL(CLLM_E_INVALID, "mul_mat_ex: pro %d", pro);
+    if (!is_quant_type(src0->type) || src0->ne[2] != 1 || src0->ne[3] != 1 || src1->ne[2] != 1 || src1->ne[3] != 1 || src1->type != CLLM_TYPE_F32 || dst->type != CLLM_TYPE_F32)
+        FAIL(CLLM_E_UNSUPPORTED, "mul_mat_ex: 2-D quantized src0, F32 src1 / dst");
+    const int64_t K = src0->ne[0], M = src1->ne[1];
+    if (src1->ne[0] != (pro == 3 ? 2 * K : K) || dst->ne[0] != src0->ne[1] || dst->ne[1] != M || src1->nb[0] != 4 || dst->nb[0] != 4 || dst->nb[1] % 4) FAIL(CLLM_E_INVALID, "mul_mat_ex: shapes");
+    if (resid && (resid->type != CLLM_TYPE_F32 || resid->ne[0] != dst->ne[0] || resid->ne[1] != M || resid->nb[0] != 4 || resid->nb[1] % 4)) FAIL(CLLM_E_INVALID, "mul_mat_ex: resid");
+    if (M < mmq_min_cols() || prefill_f16_enabled()) return CLLM_E_UNSUPPORTED;
+    if (src0->nb[0] != cllm_type_size(src0->type) || K % cllm_blck_size(src0->type)) FAIL(CLLM_E_INVALID, "mul_mat_ex: src0 rows");
+    const int kind = act_kind(src0->type);
+    const size_t stride = act_row_bytes(K, kind), need = stride * (size_t) M;
+    if (!wdata || wsize < need) FAIL(CLLM_E_INVALID, "mul_mat_ex: wdata too small (%zu < %zu)", wsize, need);
+    if ((uintptr_t) wdata % 16 || (uintptr_t) src0->data % 2 || (uintptr_t) src1->data % 16 || src1->nb[1] % 16) FAIL(CLLM_E_UNSUPPORTED, "mul_mat_ex: operand alignment");
+    if (src0->type == CLLM_TYPE_Q4_K && ((uintptr_t) src0->data % 16 || src0->nb[1] % 16)) FAIL(CLLM_E_UNSUPPORTED, "mul_mat_ex: Q4_K rows must be 16-byte aligned");
+    if (src0->type == CLLM_TYPE_Q4_1 && ((uintptr_t) src0->data % 4 || src0->nb[1] % 4)) FAIL(CLLM_E_UNSUPPORTED, "mul_mat_ex: Q4_1 rows must be 4-byte aligned");
+    hipStream_t st = (hipStream_t) stream;
+    int rc = pro == 3 ? launch_quantize_act_silu(st, kind, tv(src1), wdata, stride) : launch_quantize_act(st, kind, tv(src1), wdata, stride);
+    if (rc) return rc;
+    tview x = tv(src1); if (pro == 3) x.ne[0] = K;
+    rc = launch_mmq(st, src0->type, tv(src0), wdata, stride, x, tv(dst), resid ? (const float *) resid->data : nullptr, resid ? (int64_t)(resid->nb[1] / 4) : 0);
+    if (rc == CLLM_E_UNSUPPORTED) FAIL(rc, "mul_mat_ex: the matrix-core kernel does not take this shape");
+    return rc;
 }
 
 extern "C" int cllm_bench_mul_mat_kernel(void * stream, const cllm_tensor * src0, void * const * src0_datas, int n_src0, const cllm_tensor * src1,

@@ -236,6 +236,9 @@ __device__ __forceinline__ float ggml_expf_poly(float x) {
     if (fabsf(n) > 192.0f) return s1 * s1;
     return __builtin_fmaf(s2, j, s2) * s1;
 }
+// SiLU as ggml_vec_silu_f32 computes it (vec.cpp:396-431): the AVX2 polynomial for the elements below n & ~7 of a row, expf for the leftovers
+__device__ __forceinline__ float silu_poly(float x) { return x / (1.0f + ggml_expf_poly(0.0f - x)); }
+__device__ __forceinline__ float silu_any(float x, bool body) { return body ? silu_poly(x) : x / (1.0f + libm_expf(-x)); }
 #endif  // __HIPCC__
 
 // ---- host helpers ---------------------------------------------------------------------------------
@@ -266,10 +269,13 @@ static inline tview tv(const cllm_tensor * t) {
 
 // internal launchers (implemented across the .hip files)
 int launch_quantize_act(hipStream_t st, int kind /* ACT_Q8_0 | ACT_Q8_K | ACT_Q8_1 */, const tview & src1, void * act, size_t act_stride);
+// the same over silu(gate) * up, src1 rows holding 2 K interleaved (gate_e, up_e) pairs (the runner's packed gate/up projection): UNARY(SILU) + MUL + quantize in one pass
+int launch_quantize_act_silu(hipStream_t st, int kind, const tview & gu, void * act, size_t act_stride);
+int mmq_min_cols_get();       // capi.hip: columns from which MUL_MAT runs on the matrix cores
 int launch_mmvq(hipStream_t st, int wtype, const tview & w, const void * act, size_t act_stride, int64_t ncols_total,
                 const tview & src1_geom, const tview & dst);
 int launch_mmvq_id(hipStream_t st, int wtype, const tview & as, const void * act, size_t act_stride, int64_t b_ne1, const tview & ids, const tview & dst);
-int launch_mmq(hipStream_t st, int wtype, const tview & w, const void * act, size_t act_stride, const tview & src1_geom, const tview & dst);
+int launch_mmq(hipStream_t st, int wtype, const tview & w, const void * act, size_t act_stride, const tview & src1_geom, const tview & dst, const float * resid = nullptr, int64_t ldr = 0);
 int launch_mul_mat_f(hipStream_t st, int wtype, const tview & w, const tview & x, const tview & d, int causal = 0, int n_past = 0);   // causal: mma_f16.hip
 int launch_mma_f16(hipStream_t st, const tview & w, const tview & x, const tview & d, int causal, int n_past);
 int device_cu_count();

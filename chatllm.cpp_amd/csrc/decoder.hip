@@ -291,6 +291,13 @@ static int ensure_scores(cllm_llama * m, size_t elems) {
     return CLLM_OK;
 }
 
+// prefill (more than 32 columns): MUL_MAT with the SiLU*up quantizer prologue and / or the residual add in the epilogue (cllm_op_mul_mat_ex);
+// CLLM_E_UNSUPPORTED: the caller issues the node sequence
+static int linear_ex(cllm_llama * m, const dweight & w, int64_t K, int64_t N, float * x, int64_t qlen, float * y, int pro, float * resid) {
+    if (!is_quant_type(w.type) || getenv("CLLM_NO_PREFILL_FUSE")) return CLLM_E_UNSUPPORTED;
+    cllm_tensor W = T(w.type, w.data, K, N), X = T(CLLM_TYPE_F32, x, pro == 3 ? 2 * K : K, qlen), Y = T(CLLM_TYPE_F32, y, N, qlen), R = T(CLLM_TYPE_F32, resid, N, qlen);
+    return cllm_op_mul_mat_ex(m->st, &W, &X, &Y, m->wdata, m->wsize, pro, resid ? &R : nullptr);
+}
 static int linear(cllm_llama * m, const dweight & w, int64_t K, int64_t N, float * x, int64_t qlen, float * y) {
     cllm_tensor W = T(w.type, w.data, K, N), X = T(CLLM_TYPE_F32, x, K, qlen), Y = T(CLLM_TYPE_F32, y, N, qlen);
     return cllm_op_mul_mat(m->st, &W, &X, &Y, m->wdata, m->wsize);
@@ -370,14 +377,24 @@ static int forward_general(cllm_llama * m, int qlen, int n_past) {
             TRY(cllm_op_cpy(st, &Cp, &A));
             }
         }
+        int orc = tp_on(m) ? CLLM_E_UNSUPPORTED : linear_ex(m, L.wo, QD, H, m->att, qlen, m->x, 0, m->x);      // x = wo . att + x in the GEMM's epilogue
+        if (orc != CLLM_OK && orc != CLLM_E_UNSUPPORTED) return orc;
+        if (orc == CLLM_E_UNSUPPORTED) {
         TRY(linear(m, L.wo, QD, H, m->att, qlen, m->o));
         if (tp_on(m)) TRY(tp_allreduce(m, (hipStream_t) st, m->o, H * qlen));
         TRY(cllm_op_add(st, &O, &X, &X));
+        }
 
         cllm_tensor wf = T(CLLM_TYPE_F32, L.ffn_norm.data, H);
         TRY(cllm_op_rms_norm_mul(st, &X, &wf, &XN, c.rms_eps));
+        int drc = CLLM_E_UNSUPPORTED;
         if (L.wgu.data) {
             TRY(linear(m, L.wgu, H, 2*F, m->xn, qlen, m->gu));
+            if (!tp_on(m)) drc = linear_ex(m, L.wdown, F, H, m->gu, qlen, m->x, 3, m->x);      // x = wdown . (silu(gate) * up) + x: SiLU*up in the quantizer, the add in the epilogue
+            if (drc != CLLM_OK && drc != CLLM_E_UNSUPPORTED) return drc;
+        }
+        if (drc == CLLM_OK) continue;
+        if (L.wgu.data) {
             cllm_tensor G = TS(CLLM_TYPE_F32, m->gu, F, qlen, 1, (size_t) 2*F * 4, (size_t) 2*F * 4 * qlen);           // even elements
             cllm_tensor U = TS(CLLM_TYPE_F32, m->gu + 1, F, qlen, 1, (size_t) 2*F * 4, (size_t) 2*F * 4 * qlen);       // odd elements
             G.nb[0] = 8; U.nb[0] = 8;

@@ -30,8 +30,6 @@ extern "C" __attribute__((visibility("default"))) void cllm_debug_set_mmvq_ts(un
 // SGPRs at wave launch (-mllvm -amdgpu-kernarg-preload-count=16), so the activation loads do not wait for a kernarg fetch.
 //   units = rows (or gate/up row pairs), dealt as kfull full rounds of nwaves units + nrem (host-computed: no division here)
 
-__device__ __forceinline__ float silu_poly(float x) { return x / (1.0f + ggml_expf_poly(0.0f - x)); }
-__device__ __forceinline__ float silu_any(float x, bool body) { return body ? silu_poly(x) : x / (1.0f + libm_expf(-x)); }
 
 #define TS(k) do { if (ts && threadIdx.x == 0) ts[blockIdx.x * 8 + (k)] = wall_clock64(); } while (0)
 

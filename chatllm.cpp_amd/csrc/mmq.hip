@@ -35,6 +35,7 @@ struct mmq_args {
     const char * W; int64_t nb01; int64_t N; int64_t K;
     const char * act; size_t act_stride; int64_t M;
     float * dst; int64_t ldd;     // dst[m * ldd + n]
+    const float * resid; int64_t ldr;      // optional: dst = acc + resid[m * ldr + n] (the MUL_MAT -> ADD pair; resid may be dst itself)
 };
 
 // LDS map (bytes)
@@ -307,18 +308,18 @@ __global__ void __launch_bounds__(256, 2) k_mmq(const mmq_args a) {
 #pragma unroll
             for (int r = 0; r < 4; r++) {
                 const int64_t m = m0 + wm + i * 16 + l4 * 4 + r;
-                if (n < a.N && m < a.M) a.dst[m * a.ldd + n] = acc_f[i][j][r];
+                if (n < a.N && m < a.M) a.dst[m * a.ldd + n] = a.resid ? acc_f[i][j][r] + a.resid[m * a.ldr + n] : acc_f[i][j][r];
             }
         }
 }
 
-int launch_mmq(hipStream_t st, int wtype, const tview & w, const void * act, size_t act_stride, const tview & x, const tview & d) {
+int launch_mmq(hipStream_t st, int wtype, const tview & w, const void * act, size_t act_stride, const tview & x, const tview & d, const float * resid, int64_t ldr) {
     if (getenv("CLLM_NO_MMQ")) return CLLM_E_UNSUPPORTED;
     if (d.nb[1] % 4) FAIL(CLLM_E_INVALID, "mmq: dst stride");
     mmq_args a;
     a.W = w.data; a.nb01 = w.nb[1]; a.N = w.ne[1]; a.K = w.ne[0];
     a.act = (const char *) act; a.act_stride = act_stride; a.M = x.ne[1];
-    a.dst = (float *) d.data; a.ldd = d.nb[1] / 4;
+    a.dst = (float *) d.data; a.ldd = d.nb[1] / 4; a.resid = resid; a.ldr = ldr;
     if ((a.N + MMQ_BN - 1) / MMQ_BN > 65535) FAIL(CLLM_E_UNSUPPORTED, "mmq: too many row tiles");
 #define GO(T) do { static bool attr = false; \
         constexpr int BM = 32 * mmq_traits<T>::MI, LDS = lds_total(BM, T == CLLM_TYPE_Q4_1); \

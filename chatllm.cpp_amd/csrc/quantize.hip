@@ -10,7 +10,18 @@
 #include "quant_dev.h"
 
 // 8 lanes per 32-block, 4 elements per lane, 8 blocks per wave.  Q81: the Q8_1 flavour (s plane = fp16(d * sum) as f32).
-template <bool Q81>
+// SILU: the row holds 2 K interleaved (gate_e, up_e) pairs; the values quantized are silu(gate_e) * up_e (UNARY(SILU) + MUL of BaseMLP::forward)
+template <bool SILU>
+__device__ __forceinline__ f32x4 quant_src4(const float * x, int64_t e0, int64_t K) {
+    if (!SILU) return *(const f32x4 *)(x + e0);
+    const f32x4 p0 = *(const f32x4 *)(x + 2 * e0), p1 = *(const f32x4 *)(x + 2 * e0 + 4);      // (g0, u0, g1, u1), (g2, u2, g3, u3)
+    const int64_t nv = K & ~(int64_t) 7;
+    f32x4 v;
+    v.x = silu_any(p0.x, e0 + 0 < nv) * p0.y; v.y = silu_any(p0.z, e0 + 1 < nv) * p0.w;
+    v.z = silu_any(p1.x, e0 + 2 < nv) * p1.y; v.w = silu_any(p1.z, e0 + 3 < nv) * p1.w;
+    return v;
+}
+template <bool Q81, bool SILU>
 __global__ void __launch_bounds__(256) k_quantize_q8_0(const char * __restrict__ src, int64_t K, int64_t ne1, int64_t ne2,
                                                        int64_t nb1, int64_t nb2, int64_t nb3,
                                                        char * __restrict__ act, size_t act_stride) {
@@ -19,10 +30,11 @@ __global__ void __launch_bounds__(256) k_quantize_q8_0(const char * __restrict__
     const float * x = (const float *)(src + i1*nb1 + i2*nb2 + i3*nb3);
     const int64_t e0 = ((int64_t) blockIdx.x * blockDim.x + threadIdx.x) * 4;
     if (e0 >= K) return;                                   // K % 32 == 0 -> whole 8-lane groups drop out together
-    quant4_store<32, Q81>(act + row * act_stride, K, e0, threadIdx.x & 63, *(const f32x4 *)(x + e0));
+    quant4_store<32, Q81>(act + row * act_stride, K, e0, threadIdx.x & 63, quant_src4<SILU>(x, e0, K));
 }
 
 // one wave per 256-block, 4 elements per lane.
+template <bool SILU>
 __global__ void __launch_bounds__(256) k_quantize_q8_K(const char * __restrict__ src, int64_t K, int64_t ne1, int64_t ne2,
                                                        int64_t nb1, int64_t nb2, int64_t nb3,
                                                        char * __restrict__ act, size_t act_stride) {
@@ -33,27 +45,30 @@ __global__ void __launch_bounds__(256) k_quantize_q8_K(const char * __restrict__
     const int64_t blk = (int64_t) blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6);
     if (blk * 256 >= K) return;
     const int64_t e0 = blk * 256 + lane * 4;
-    quant4_store<256>(act + row * act_stride, K, e0, lane, *(const f32x4 *)(x + e0));
+    quant4_store<256>(act + row * act_stride, K, e0, lane, quant_src4<SILU>(x, e0, K));
 }
 
-int launch_quantize_act(hipStream_t st, int kind, const tview & s, void * act, size_t act_stride) {
+template <bool SILU>
+static int quantize_act_impl(hipStream_t st, int kind, const tview & s, void * act, size_t act_stride) {
     const int kind_blk = act_blk(kind);
-    const int64_t K = s.ne[0];
+    const int64_t K = SILU ? s.ne[0] / 2 : s.ne[0];
     const int64_t rows = s.ne[1] * s.ne[2] * s.ne[3];
-    if (K % kind_blk) FAIL(CLLM_E_INVALID, "quantize_act: K=%lld not a multiple of %d", (long long) K, kind_blk);
+    if (K % kind_blk || (SILU && s.ne[0] % 2)) FAIL(CLLM_E_INVALID, "quantize_act: K=%lld not a multiple of %d", (long long) K, kind_blk);
     if (rows <= 0 || K <= 0) return CLLM_OK;
     if (rows > 65535) FAIL(CLLM_E_UNSUPPORTED, "quantize_act: too many rows (%lld)", (long long) rows);
     if (kind_blk == 32) {
         dim3 grid((unsigned)((K / 4 + 255) / 256), (unsigned) rows);
-        if (kind == ACT_Q8_1) hipLaunchKernelGGL(k_quantize_q8_0<true>,  grid, dim3(256), 0, st, s.data, K, s.ne[1], s.ne[2], s.nb[1], s.nb[2], s.nb[3], (char *) act, act_stride);
-        else                  hipLaunchKernelGGL(k_quantize_q8_0<false>, grid, dim3(256), 0, st, s.data, K, s.ne[1], s.ne[2], s.nb[1], s.nb[2], s.nb[3], (char *) act, act_stride);
+        if (kind == ACT_Q8_1) hipLaunchKernelGGL((k_quantize_q8_0<true, SILU>),  grid, dim3(256), 0, st, s.data, K, s.ne[1], s.ne[2], s.nb[1], s.nb[2], s.nb[3], (char *) act, act_stride);
+        else                  hipLaunchKernelGGL((k_quantize_q8_0<false, SILU>), grid, dim3(256), 0, st, s.data, K, s.ne[1], s.ne[2], s.nb[1], s.nb[2], s.nb[3], (char *) act, act_stride);
     } else {
         dim3 grid((unsigned)((K / 256 + 3) / 4), (unsigned) rows);
-        hipLaunchKernelGGL(k_quantize_q8_K, grid, dim3(256), 0, st, s.data, K, s.ne[1], s.ne[2], s.nb[1], s.nb[2], s.nb[3], (char *) act, act_stride);
+        hipLaunchKernelGGL((k_quantize_q8_K<SILU>), grid, dim3(256), 0, st, s.data, K, s.ne[1], s.ne[2], s.nb[1], s.nb[2], s.nb[3], (char *) act, act_stride);
     }
     LAUNCH_CHECK();
     return CLLM_OK;
 }
+int launch_quantize_act(hipStream_t st, int kind, const tview & s, void * act, size_t act_stride) { return quantize_act_impl<false>(st, kind, s, act, act_stride); }
+int launch_quantize_act_silu(hipStream_t st, int kind, const tview & s, void * act, size_t act_stride) { return quantize_act_impl<true>(st, kind, s, act, act_stride); }
 
 // ---- KAT surface: act row -> reference block layout ------------------------------------------------
 __global__ void k_act_to_q8_0_blocks(const char * __restrict__ act, int64_t K, block_q8_0 * __restrict__ y) {
