@@ -53,11 +53,11 @@ __global__ void __launch_bounds__(1024) k_gemv_dec(const float * __restrict__ px
 #ifndef GEMV_P
 #define GEMV_P 2
 #endif
-    constexpr int P = GEMV_P, RU = EPI == 1 ? 2 : 1;
+    constexpr int P = (FMT == CLLM_TYPE_Q4_K) ? (GEMV_P + 1) / 2 : GEMV_P, RU = EPI == 1 ? 2 : 1;      // steps of prefetch (a Q4_K step is 16 super-blocks = 2304 B per wave, the others' 64 blocks)
     constexpr bool IS_K = FMT == CLLM_TYPE_Q4_K, IS_Q8 = FMT == CLLM_TYPE_Q8_0, IS_Q41 = FMT == CLLM_TYPE_Q4_1;
     constexpr int KIND = IS_K ? 256 : 32;                           // elements per weight block = activation quantization block
     constexpr int BS = IS_K ? 144 : q32_fmt<IS_K ? CLLM_TYPE_Q4_0 : FMT>::BS;      // bytes per weight block
-    constexpr int BPS = IS_K ? 8 : 64;                              // blocks a wave consumes per step
+    constexpr int BPS = IS_K ? 16 : 64;                             // blocks a wave consumes per step (Q4_K: 4 lanes per super-block, q4k_emit4)
     const int tid = threadIdx.x, lane = tid & 63;
     const int K = nblk * KIND;
 
@@ -83,7 +83,7 @@ __global__ void __launch_bounds__(1024) k_gemv_dec(const float * __restrict__ px
     // ---- (2) two steps of weight prefetch.  Units are dealt in rounds of nwaves: in a full round wave (b, w) takes unit
     //          round*nwaves + 16 b + w (a workgroup streams 16 consecutive rows); the last, partial round is dealt
     //          workgroup-interleaved (w * gridDim + b) so that every CU gets the same share of it. ----
-    const int grp = lane >> 3, j = lane & 7;
+    const int grp = IS_K ? lane >> 2 : lane >> 3, j = IS_K ? lane & 3 : lane & 7;
     const int wave_in_wg = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nwaves = gridDim.x * 16;
     const int lin = blockIdx.x * 16 + wave_in_wg, alt = wave_in_wg * gridDim.x + blockIdx.x;
@@ -92,16 +92,17 @@ __global__ void __launch_bounds__(1024) k_gemv_dec(const float * __restrict__ px
     const unsigned nb01 = (unsigned) nblk * (unsigned) BS;
     auto unit_of = [&](int k) { return k * nwaves + (k < kfull ? lin : alt); };
     // per step and lane: Q4_K header (hh) + 16 quant bytes (qq); Q4_0 / Q8_0: fp16 scale (hh.x) + 16 (qq) [+ 16 (q2)] quant bytes
-    u32x4 hh[P], qq[P], q2[IS_Q8 ? P : 1];
+    u32x4 hh[P], qq[P], q2[(IS_Q8 || IS_K) ? P : 1];
     int ik = 0, isub = 0, is = 0;                                   // issue cursor: (unit ordinal, row of the unit, step of the row)
     auto issue = [&](int p) {                                       // unconditional: out-of-range steps re-read block 0 and are masked
-        const int b = IS_K ? 8 * is + grp : 64 * is + lane;
+        const int b = IS_K ? 16 * is + grp : 64 * is + lane;
         const bool ok = ik < nmine && b < nblk;
         const char * bp = W;
         if (ok) bp = W + (unsigned long long)(unsigned)(unit_of(ik) * RU + isub) * nb01 + __umul24((unsigned) b, (unsigned) BS);      // (b < 2^24: the 32-bit v_mul_lo_u32 runs at a quarter rate)
         if (IS_K) {
             hh[p] = *(const u32x4 *) bp;
-            qq[p] = *(const u32x4 *)(bp + 16 + 16 * j);
+            qq[p] = *(const u32x4 *)(bp + 16 + 32 * j);
+            q2[(IS_Q8 || IS_K) ? p : 0] = *(const u32x4 *)(bp + 32 + 32 * j);
         } else {
             uint32_t t, odd;             // the aligned window as loaded; q32_align() at the point of use
             q32_load_raw<IS_K ? CLLM_TYPE_Q4_0 : FMT>(bp, qq[p], q2[IS_Q8 ? p : 0], t, odd);
@@ -149,7 +150,7 @@ __global__ void __launch_bounds__(1024) k_gemv_dec(const float * __restrict__ px
 
     // ---- (4) stream the rows.  Every step turns its blocks into chain records (exact integer sums + scales); the fp32 chains of the
     //          reference's AVX2 order run over them in lanes 0..11 (q4k.h / q32.h) ----
-    const q4k_sel L = q4k_lane_sel(lane);
+    const q4k_sel4 L = q4k_lane_sel4(lane);
     const int off_d = (int) act_off_d(K), off_s = (int) act_off_s(K, KIND);      // (the Q8_1 flavour has the Q8_0 geometry)
     constexpr int CHB = IS_K ? Q4K_CHAIN_BYTES : Q32_CHAIN_BYTES;
     char * chain = lds + act_row_bytes(K, KIND) + wave_in_wg * CHB;
@@ -159,19 +160,18 @@ __global__ void __launch_bounds__(1024) k_gemv_dec(const float * __restrict__ px
     while (ck < nmine) {
 #pragma unroll
         for (int p = 0; p < P; p++) {
-            const int b = IS_K ? 8 * cs + grp : 64 * cs + lane;
+            const int b = IS_K ? 16 * cs + grp : 64 * cs + lane;
             const bool ok = ck < nmine && b < nblk;
-            if (IS_K) q4k_emit(hh[p], qq[p], lds, off_d, off_s, ok ? b : 0, ok, L, chain + (cs & 1) * (4 * Q4K_PAIR_BYTES));
+            if (IS_K) q4k_emit4(hh[p], qq[p], q2[(IS_Q8 || IS_K) ? p : 0], lds, off_d, off_s, ok ? b : 0, ok, L, chain);
             else {
                 uint32_t h; u32x4 w0, w1 = {0, 0, 0, 0};
                 q32_align<IS_K ? CLLM_TYPE_Q4_0 : FMT>(qq[p], q2[IS_Q8 ? p : 0], hh[p].x, hh[p].y, h, w0, w1);
                 q32_emit<IS_K ? CLLM_TYPE_Q4_0 : FMT>(h, w0, w1, lds, off_d, off_s, ok ? b : 0, ok, lane, chain);
             }
             issue(p);
-            const bool row_done = cs + 1 == S;
-            if (!IS_K || (cs & 1) || row_done) {                    // Q4_K: every second step (16 super-blocks) and at the row's end
+            {                                                       // every step: 16 super-blocks (Q4_K) / 64 blocks of records
                 wave_lds_fence();
-                if (IS_K) q4k_chain(chain, (cs & 1) ? 8 : 4, l16, acc); else q32_chain<IS_K ? CLLM_TYPE_Q4_0 : FMT>(chain, l16, acc);
+                if (IS_K) q4k_chain(chain, 8, l16, acc); else q32_chain<IS_K ? CLLM_TYPE_Q4_0 : FMT>(chain, l16, acc);
                 wave_lds_fence();
             }
             if (++cs == S) {                                        // row complete: finish the chains, epilogue, store (lane 0)

@@ -111,6 +111,60 @@ __device__ __forceinline__ void q4k_emit(const u32x4 h, const u32x4 q, const cha
 #endif       // (both lanes of the pair hold the same record: no branch)
 }
 
+// ---- the same records from FOUR lanes per super-block (the decode mat-vec, gemv_decode.hip): lane j owns the whole 64-weight chunk j (32 quant
+//      bytes = the low- and high-nibble dwords of all 8 AVX lanes), so the per-lane costs -- header unpack, scale selection, conversions, record
+//      stores -- are paid once per 32 weight bytes instead of once per 16, the mins need no lane exchange (chunk j holds sub-blocks 2j, 2j+1 = pair
+//      k = j), and the reduce-scatter runs inside a quad: lane j ends with sumi[A], A = 4 (j >> 1) + 2 (j & 1) + {0, 1}.  Same integers, same records.
+struct q4k_sel4 { int sh16, a_off, s_off, w_off, wm_off; bool hi, b2, b1; };
+__device__ __forceinline__ q4k_sel4 q4k_lane_sel4(int lane) {
+    q4k_sel4 L;
+    const int j = lane & 3, g = lane >> 2;
+    L.hi = j >= 2; L.sh16 = (j & 1) * 16;
+    L.a_off = 64 * j; L.s_off = 8 * j;
+    L.b2 = (j & 2) != 0; L.b1 = (j & 1) != 0;
+    const int slot = (j >> 1) | ((j & 1) << 1);                  // AVX lanes (A0, A0 + 1) sit in slots (slot, slot + 4) of [A0 A4 A2 A6 | A1 A5 A3 A7]
+    const int mslot = ((j & 1) << 1) | (j >> 1);                 // acc_m[k = j] in [m0 m2 m1 m3]
+    L.w_off  = (g >> 1) * Q4K_PAIR_BYTES + slot * 16 + (g & 1) * 8;
+    L.wm_off = (g >> 1) * Q4K_PAIR_BYTES + (8 + mslot) * 16 + (g & 1) * 8;
+    return L;
+}
+__device__ __forceinline__ void q4k_emit4(const u32x4 h, const u32x4 qa, const u32x4 qb, const char * ar, int off_d, int off_s, int bb, bool ok, const q4k_sel4 & L, char * rec) {
+    const float d    = h2f((uint16_t)(h.x & 0xffff));
+    const float dmin = h2f((uint16_t)(h.x >> 16));
+    const uint32_t u0 = h.y & 0x3f3f3f3fu;
+    const uint32_t u2 = h.z & 0x3f3f3f3fu;
+    const uint32_t u1 = (h.w & 0x0f0f0f0fu) | (((h.y >> 6) & 0x03030303u) << 4);
+    const uint32_t u3 = ((h.w >> 4) & 0x0f0f0f0fu) | (((h.z >> 6) & 0x03030303u) << 4);
+    const uint32_t scp = (L.hi ? u1 : u0) >> L.sh16, mnp = (L.hi ? u3 : u2) >> L.sh16;
+    const int sc_lo = (int)(scp & 0xff), sc_hi = (int)((scp >> 8) & 0xff), m_lo = (int)(mnp & 0xff), m_hi = (int)((mnp >> 8) & 0xff);
+    const char * ab = ar + bb * 256 + L.a_off;
+    const u32x4 al0 = *(const u32x4 *) ab, al1 = *(const u32x4 *)(ab + 16), ah0 = *(const u32x4 *)(ab + 32), ah1 = *(const u32x4 *)(ab + 48);
+    const float yd = ((const float *)(ar + off_d))[bb];
+    const u32x2 ys = *(const u32x2 *)(ar + off_s + bb * 32 + L.s_off);
+    const uint32_t wl[8] = { qa.x & 0x0f0f0f0fu, qa.y & 0x0f0f0f0fu, qa.z & 0x0f0f0f0fu, qa.w & 0x0f0f0f0fu, qb.x & 0x0f0f0f0fu, qb.y & 0x0f0f0f0fu, qb.z & 0x0f0f0f0fu, qb.w & 0x0f0f0f0fu };
+    const uint32_t wh[8] = { (qa.x >> 4) & 0x0f0f0f0fu, (qa.y >> 4) & 0x0f0f0f0fu, (qa.z >> 4) & 0x0f0f0f0fu, (qa.w >> 4) & 0x0f0f0f0fu,
+                             (qb.x >> 4) & 0x0f0f0f0fu, (qb.y >> 4) & 0x0f0f0f0fu, (qb.z >> 4) & 0x0f0f0f0fu, (qb.w >> 4) & 0x0f0f0f0fu };
+    const uint32_t xl[8] = { al0.x, al0.y, al0.z, al0.w, al1.x, al1.y, al1.z, al1.w };
+    const uint32_t xh[8] = { ah0.x, ah0.y, ah0.z, ah0.w, ah1.x, ah1.y, ah1.z, ah1.w };
+    int dl[8], dh[8], t[8];
+    dot4z_x8(wl, xl, dl);
+    dot4z_x8(wh, xh, dh);
+#pragma unroll
+    for (int A = 0; A < 8; A++) t[A] = __mul24(sc_lo, dl[A]) + __mul24(sc_hi, dh[A]);
+    int k[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) { const int keep = L.b2 ? t[4 + i] : t[i], send = L.b2 ? t[i] : t[4 + i]; k[i] = keep + dpp_i<DPP_QUAD_XOR2>(send); }
+    int r[2];
+#pragma unroll
+    for (int i = 0; i < 2; i++) { const int keep = L.b1 ? k[2 + i] : k[i], send = L.b1 ? k[i] : k[2 + i]; r[i] = keep + dpp_i<DPP_QUAD_XOR1>(send); }
+    const int pm = __mul24(m_lo, (int) ys.x) + __mul24(m_hi, (int) ys.y);        // prod[k = j] = m[2j] S[2j] + m[2j+1] S[2j+1]
+    float dd = yd * d, dm = (-yd) * dmin;
+    if (!ok) { dd = 0.0f; dm = 0.0f; }
+    *(float2 *)(rec + L.w_off)      = float2{(float) r[0], dd};
+    *(float2 *)(rec + L.w_off + 64) = float2{(float) r[1], dd};
+    *(float2 *)(rec + L.wm_off)     = float2{(float) pm, dm};
+}
+
 // walk `npairs` (a multiple of 4) pairs of records in block order; l16 = lane & 15 (lanes 0..7: acc[], 8..11: acc_m[], 12..15: idle)
 __device__ __forceinline__ void q4k_chain(const char * chain, int npairs, int l16, float & acc) {
     for (int q0 = 0; q0 < npairs; q0 += 4) {
