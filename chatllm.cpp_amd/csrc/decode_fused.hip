@@ -221,7 +221,8 @@ __device__ __forceinline__ int uniform_load_i32(const int32_t * p) {
     return v;
 }
 
-template <int HD, int MODE>      // MODE 0: adjacent pairs (GGML_ROPE_TYPE_NORMAL), 2: NEOX halves
+template <int HD, int MODE, int PARTS>      // MODE 0: adjacent pairs (GGML_ROPE_TYPE_NORMAL), 2: NEOX halves; PARTS: workgroups per head (each redoes RoPE, scores and
+                                            // soft_max -- the same bits -- and takes 1 / PARTS of the V.P rows: one row per 16-lane group instead of two)
 __global__ void __launch_bounds__(1024) k_attn_dec(const float * __restrict__ qkv, const int32_t * __restrict__ pos_dev, const float * __restrict__ rope_cs,
                                                    int nh, int nkv, float scale, uint16_t * __restrict__ k_cache, uint16_t * __restrict__ v_cache,
                                                    int ML, float * __restrict__ att, unsigned long long * ts) {
@@ -251,7 +252,8 @@ __global__ void __launch_bounds__(1024) k_attn_dec(const float * __restrict__ qk
     //          that scores and context equal the reference's bit for bit: 32 fp32 accumulators, accumulator a takes elements a, a + 32, ...
     //          in order (one fma each), GGML_F32x8_REDUCE's tree, leftovers (n mod 32) one by one in double.  16 lanes per row, lane c
     //          carries accumulators 2c and 2c + 1: one dword (two fp16) per 32-element chunk. ----
-    constexpr int NCH = HD / 32, VU = HD / 64, VPF = 8;
+    constexpr int NCH = HD / 32, VU = HD / 64 / PARTS, VPF = 8;
+    const int vrow0 = PARTS > 1 ? (int) blockIdx.z * VU * 64 : 0;       // first V^T row of this part
     const int c16 = lane & 15, sub = lane >> 4;
     const int ib0 = wave * 4 + sub;                                   // K rows ib0 + 64 u; V^T rows ib0 + 64 u
     uint32_t kr0[U][NCH];
@@ -266,7 +268,7 @@ __global__ void __launch_bounds__(1024) k_attn_dec(const float * __restrict__ qk
     uint32_t vc0[VU][VPF];
 #pragma unroll
     for (int u = 0; u < VU; u++) {
-        const uint16_t * vr = v_cache + ((int64_t) g * HD + ib0 + u * 64) * ML;
+        const uint16_t * vr = v_cache + ((int64_t) g * HD + vrow0 + ib0 + u * 64) * ML;
 #pragma unroll
         for (int i = 0; i < VPF; i++) vc0[u][i] = *(const uint32_t *)(vr + 32 * (i < nch ? i : 0) + 2 * c16);
     }
@@ -279,7 +281,7 @@ __global__ void __launch_bounds__(1024) k_attn_dec(const float * __restrict__ qk
         o[ic] = h2f(f2h(y0)); o[ic + off] = h2f(f2h(y1));             // q: src1 of K.Q is rounded to fp16; k: the cache is fp16
     } else if (is_v) vnew[tid - 2 * half] = h2f(f2h(px0));
     lds_barrier();
-    if (blockIdx.x == 0 && tid < HD) {
+    if (blockIdx.x == 0 && (PARTS == 1 || blockIdx.z == 0) && tid < HD) {
         k_cache[(int64_t) pos * KD + g * HD + tid] = f2h(knew[tid]);
         v_cache[((int64_t) g * HD + tid) * ML + pos] = f2h(vnew[tid]);
     }
@@ -320,7 +322,7 @@ __global__ void __launch_bounds__(1024) k_attn_dec(const float * __restrict__ qk
     uint32_t vc1[VU][VPF]; uint16_t vtl[VU][2];
 #pragma unroll
     for (int u = 0; u < VU; u++) {
-        const uint16_t * vr = v_cache + ((int64_t) g * HD + ib0 + u * 64) * ML;
+        const uint16_t * vr = v_cache + ((int64_t) g * HD + vrow0 + ib0 + u * 64) * ML;
 #pragma unroll
         for (int i = 0; i < VPF; i++) vc1[u][i] = *(const uint32_t *)(vr + 32 * (VPF + i < nch ? VPF + i : 0) + 2 * c16);
 #pragma unroll
@@ -362,7 +364,7 @@ __global__ void __launch_bounds__(1024) k_attn_dec(const float * __restrict__ qk
     const int ntail = n_kv - np;
 #pragma unroll
     for (int u = 0; u < VU; u++) {
-        const int d0 = ib0 + u * 64;
+        const int d0 = vrow0 + ib0 + u * 64;
         const uint16_t * vr = v_cache + ((int64_t) g * HD + d0) * ML;
         const float vfresh = vnew[d0];
         float a0 = 0.0f, a1 = 0.0f;
@@ -412,11 +414,11 @@ int launch_attn_dec_table(hipStream_t st, const float * qkv, const int32_t * pos
     const size_t lds = (size_t)(3 * hd + ML) * 4 + 64 * 32 * 4;      // q | new k | new v | scores | leftover products of 64 lane groups
     if (lds > 150 * 1024) return CLLM_E_UNSUPPORTED;
     const float scale = 1.0f / sqrtf((float) hd);
-    const dim3 grid(nh / nkv, nkv);
+    const dim3 grid(nh / nkv, nkv, hd == 128 ? 2 : 1);
 #define GO(HD_, MODE_) do { \
         static bool attr = false; \
-        if (lds > 48 * 1024 && !attr) { HIP_TRY(hipFuncSetAttribute((const void *) k_attn_dec<HD_, MODE_>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024)); attr = true; } \
-        hipLaunchKernelGGL((k_attn_dec<HD_, MODE_>), grid, dim3(1024), lds, st, qkv, pos_dev, rope_cs, nh, nkv, scale, k_cache, v_cache, (int) ML, att, g_attn_ts); } while (0)
+        if (lds > 48 * 1024 && !attr) { HIP_TRY(hipFuncSetAttribute((const void *) k_attn_dec<HD_, MODE_, (HD_ == 128 ? 2 : 1)>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024)); attr = true; } \
+        hipLaunchKernelGGL((k_attn_dec<HD_, MODE_, (HD_ == 128 ? 2 : 1)>), grid, dim3(1024), lds, st, qkv, pos_dev, rope_cs, nh, nkv, scale, k_cache, v_cache, (int) ML, att, g_attn_ts); } while (0)
     if (hd == 128) { if (mode == 0) GO(128, 0); else GO(128, 2); }      // any other mode pairs NEOX-style, as in the general kernel
     else           { if (mode == 0) GO(64, 0);  else GO(64, 2); }
 #undef GO
