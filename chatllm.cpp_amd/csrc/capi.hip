@@ -356,6 +356,25 @@ extern "C" int cllm_op_mul_mat_vec_fused(void * stream, const cllm_tensor * src0
     return launch_gemv_decode((hipStream_t) stream, src0->type, src0->data, src0->ne[0], src0->ne[1], pro, px, pw, eps, epi, dst, nullptr, resid);
 }
 
+// The router of a sparse-MoE block for one token (GenericSparseMLP::forward src/layers.cpp:3792-3830: RMS_NORM -> MUL -> MUL_MAT(gate) -> SOFT_MAX -> TOP_K)
+// as one launch: xnorm F32 [K] = RMS_NORM(x, eps) * norm_w; probs F32 [n_expert] = SOFT_MAX(gate_w . quantize(xnorm)); ids I32 [k] = TOP_K(probs).
+// xnorm may be x itself (in place) but must not overlap it otherwise.  CLLM_E_UNSUPPORTED (nothing launched): shapes for the node-by-node ops.
+extern "C" int cllm_op_moe_router(void * stream, const cllm_tensor * x, const cllm_tensor * norm_w, float eps, const cllm_tensor * gate_w,
+                                  cllm_tensor * xnorm, cllm_tensor * probs, cllm_tensor * ids) {
+    if (!x || !norm_w || !gate_w || !xnorm || !probs || !ids) FAIL(CLLM_E_INVALID, "moe_router: null");
+    const int64_t K = gate_w->ne[0], n = gate_w->ne[1], k = ids->ne[0];
+    if (x->type != CLLM_TYPE_F32 || norm_w->type != CLLM_TYPE_F32 || xnorm->type != CLLM_TYPE_F32 || probs->type != CLLM_TYPE_F32 || ids->type != CLLM_TYPE_I32 ||
+        x->nb[0] != 4 || norm_w->nb[0] != 4 || xnorm->nb[0] != 4 || probs->nb[0] != 4 || ids->nb[0] != 4)
+        FAIL(CLLM_E_UNSUPPORTED, "moe_router: dense F32 vectors, I32 ids");
+    if (x->ne[0] != K || norm_w->ne[0] != K || xnorm->ne[0] != K || probs->ne[0] != n || t_nelements(x) != K || t_nelements(xnorm) != K || t_nelements(probs) != n || t_nelements(ids) != k)
+        FAIL(CLLM_E_INVALID, "moe_router: shapes (one token)");
+    if (!is_quant_type(gate_w->type) || gate_w->ne[2] != 1 || gate_w->ne[3] != 1 || gate_w->nb[1] != cllm_row_size(gate_w->type, K)) return CLLM_E_UNSUPPORTED;
+    if (((uintptr_t) x->data | (uintptr_t) norm_w->data | (uintptr_t) gate_w->data | (uintptr_t) xnorm->data) & 15) return CLLM_E_UNSUPPORTED;
+    if (xnorm->data != x->data && (const char *) xnorm->data < (const char *) x->data + K * 4 && (const char *) x->data < (const char *) xnorm->data + K * 4) FAIL(CLLM_E_INVALID, "moe_router: xnorm overlaps x");
+    return launch_moe_router((hipStream_t) stream, gate_w->type, gate_w->data, K, n, (const float *) x->data, (const float *) norm_w->data, eps,
+                             (float *) xnorm->data, (float *) probs->data, (int32_t *) ids->data, (int) k);
+}
+
 // device-side repack of weight rows for the merged launches: concatenation of n matrices, or the rows of two equally sized ones alternating
 extern "C" int cllm_pack_rows(void * stream, void * dst, const void * const * srcs, const int64_t * nrows, int n, size_t row_bytes, int interleave) {
     if (!dst || !srcs || !nrows || n <= 0 || !row_bytes || (interleave && (n != 2 || nrows[0] != nrows[1]))) FAIL(CLLM_E_INVALID, "pack_rows: arguments");
@@ -437,6 +456,25 @@ extern "C" int cllm_op_mul_mat_id_silu_mul(void * stream, const cllm_tensor * as
         ((uintptr_t) b->data & 15) || ((uintptr_t) as_gu->data & 15) || as_gu->nb[2] % 16) FAIL(CLLM_E_UNSUPPORTED, "mul_mat_id_silu_mul: layout");
     return launch_gemv_decode_id((hipStream_t) stream, as_gu->type, as_gu->data, as_gu->nb[2], as_gu->ne[0], as_gu->ne[1], (const float *) b->data,
                                  b->ne[1] == 1 ? 0 : (int64_t)(b->nb[1] / 4), (const int32_t *) ids->data, (int) n_used, (float *) dst->data, (int64_t)(dst->nb[1] / 4), 1);
+}
+
+// MUL_MAT_ID(down experts) of ONE token over TWO slots + the tail of the sparse-MoE block (GenericSparseMLP::forward src/layers.cpp:3840-3872) in one launch:
+//   dst[r] = (as[ids[0]][r] . b[:, 0]) * w0 + (as[ids[1]][r] . b[:, 1]) * w1 (+ resid[r]),   w_j = probs[ids[j]] / (probs[ids[0]] + probs[ids[1]])
+// as [K, H, E] quantized, b F32 [K, 2, 1], ids I32 [2, 1], probs F32 [E, 1], resid / dst F32 [H, 1]; dst may be resid itself, nothing else.
+// Bit-identical to cllm_op_mul_mat_id -> cllm_op_moe_combine.  CLLM_E_UNSUPPORTED (nothing launched): use those two.
+extern "C" int cllm_op_mul_mat_id_combine(void * stream, const cllm_tensor * as, const cllm_tensor * b, const cllm_tensor * ids, const cllm_tensor * probs,
+                                          const cllm_tensor * resid, cllm_tensor * dst) {
+    if (!as || !b || !ids || !probs || !dst) FAIL(CLLM_E_INVALID, "mul_mat_id_combine: null");
+    if (!is_quant_type(as->type) || b->type != CLLM_TYPE_F32 || dst->type != CLLM_TYPE_F32 || ids->type != CLLM_TYPE_I32 || probs->type != CLLM_TYPE_F32 || (resid && resid->type != CLLM_TYPE_F32))
+        FAIL(CLLM_E_UNSUPPORTED, "mul_mat_id_combine: types");
+    const int64_t K = as->ne[0], H = as->ne[1], E = as->ne[2];
+    if (b->ne[0] != K || b->ne[2] != 1 || b->ne[3] != 1 || ids->ne[1] != 1 || t_nelements(ids) != ids->ne[0] || probs->ne[0] != E || t_nelements(probs) != E || dst->ne[0] != H || t_nelements(dst) != H ||
+        (resid && (resid->ne[0] != H || t_nelements(resid) != H))) FAIL(CLLM_E_INVALID, "mul_mat_id_combine: shapes (one token)");
+    if (ids->ne[0] != 2 || b->ne[1] != 2) return CLLM_E_UNSUPPORTED;
+    if (ids->nb[0] != 4 || b->nb[0] != 4 || dst->nb[0] != 4 || probs->nb[0] != 4 || (resid && resid->nb[0] != 4) || as->nb[1] != cllm_row_size(as->type, K) || b->nb[1] % 16 ||
+        ((uintptr_t) b->data & 15) || ((uintptr_t) as->data & 15) || as->nb[2] % 16) return CLLM_E_UNSUPPORTED;
+    return launch_gemv_decode_id_combine((hipStream_t) stream, as->type, as->data, as->nb[2], K, H, (const float *) b->data, (int64_t)(b->nb[1] / 4), (const int32_t *) ids->data,
+                                         (const float *) probs->data, resid ? (const float *) resid->data : nullptr, (float *) dst->data);
 }
 
 extern "C" int cllm_op_mul_mat_id(void * stream, const cllm_tensor * as, const cllm_tensor * b, const cllm_tensor * ids, cllm_tensor * dst,

@@ -237,6 +237,44 @@ __device__ __forceinline__ float ggml_expf_poly(float x) {
     return __builtin_fmaf(s2, j, s2) * s1;
 }
 // SiLU as ggml_vec_silu_f32 computes it (vec.cpp:396-431): the AVX2 polynomial for the elements below n & ~7 of a row, expf for the leftovers
+// SOFT_MAX of one row of n <= 512 values held in LDS by ONE wave (no scale, no mask): the lane -> group-of-8 partition, the exponentials and the
+// summation order of k_soft_max (ops.hip), which follow ggml_vec_soft_max_f32 (vec.cpp:547-).  y (LDS) receives the probabilities.
+__device__ __forceinline__ void wave_soft_max_plain(const float * x, float * y, int n, int lane) {
+    float mx = -INFINITY;
+    for (int i = lane; i < n; i += 64) mx = fmaxf(mx, x[i]);
+    mx = wave_max(mx);
+    const int nv = n & ~7;
+    double sum = 0.0;
+    for (int g = lane * 8; g < nv; g += 64 * 8) {
+        float e[8];
+#pragma unroll
+        for (int l = 0; l < 8; l++) { e[l] = ggml_expf_poly(x[g + l] - mx); y[g + l] = e[l]; }
+        const float a0 = e[0] + e[4], a1 = e[1] + e[5], a2 = e[2] + e[6], a3 = e[3] + e[7];
+        sum += (double)((a0 + a2) + (a1 + a3));
+    }
+    if (lane == 0) for (int i = nv; i < n; i++) { const float e = libm_expf(x[i] - mx); y[i] = e; sum += (double) e; }
+    sum = wave_sum_d(sum);
+    const float inv = (float)(1.0 / sum);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    for (int i = lane; i < n; i += 64) y[i] = y[i] * inv;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+}
+// TOP_K of one row (ggml_compute_forward_top_k_f32 ops.cpp:8057-8094): the indices of the k largest values in descending order, the first two
+// swapped; equal values: the lower index first.  One thread.
+__device__ __forceinline__ void top_k_row(const float * x, int n, int k, int32_t * out) {
+    float prev_v = INFINITY; int prev_i = -1;                       // the last pick: the next one comes strictly after it in (value desc, index asc)
+    for (int j = 0; j < k; j++) {
+        float best = -INFINITY; int bi = -1;
+        for (int i = 0; i < n; i++) {
+            const float v = x[i];
+            const bool after = v < prev_v || (v == prev_v && i > prev_i);
+            if (after && (bi < 0 || v > best)) { best = v; bi = i; }
+        }
+        if (bi < 0) bi = 0;                                           // NaNs: the CPU's comparator is not a strict weak order there either
+        out[j] = bi; prev_v = best; prev_i = bi;
+    }
+    if (k > 1) { const int32_t t = out[0]; out[0] = out[1]; out[1] = t; }
+}
 __device__ __forceinline__ float silu_poly(float x) { return x / (1.0f + ggml_expf_poly(0.0f - x)); }
 __device__ __forceinline__ float silu_any(float x, bool body) { return body ? silu_poly(x) : x / (1.0f + libm_expf(-x)); }
 #endif  // __HIPCC__
@@ -289,6 +327,10 @@ int flash_prefill_min_cols();          // query rows from which the eager attent
 size_t fattn_wsize(int64_t N, int64_t H, int64_t B, int64_t D);
 int launch_fattn(hipStream_t st, const tview & q, const tview & k, int ktype, const tview & v, int vl, const tview * mask, int causal_past,
                  char * dst, int64_t nbn, int64_t nbh, int64_t nbb, float scale, void * wdata, size_t wsize);
+int launch_gemv_decode_id_combine(hipStream_t st, int wtype, const void * W, size_t w_expert_bytes, int64_t K, int64_t nrows, const float * px, int64_t px_slot_stride,
+                                  const int32_t * ids, const float * probs, const float * resid, float * dst);
+int launch_moe_router(hipStream_t st, int wtype, const void * W, int64_t K, int64_t n, const float * px, const float * pw, float eps,
+                      float * xnorm, float * probs, int32_t * ids, int k);
 int launch_gemv_kq(hipStream_t st, int wtype, const tview & w, const void * act, size_t act_stride, int64_t M, float * dst, int64_t ldd);
 int launch_dense_f16(hipStream_t st, int wtype, const tview & w, const tview & x, const tview & d);
 int launch_gemv_rows(hipStream_t st, const void * W, int64_t K, int64_t nrows, int pro, const float * px, const float * pw, float eps, int epi, float * dst, const float * bias, const float * resid);

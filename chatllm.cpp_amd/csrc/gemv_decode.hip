@@ -5,6 +5,11 @@
 //            PRO 3: act = quantize_q8_K(silu(px[2i]) * px[2i+1])  (interleaved gate/up pairs -> down_proj, BaseMLP::forward)
 //            PRO 4: act = quantize_q8_K(silu(px[i]) * pw[i])      (separate gate / up vectors: the reference's own graph, fused by the module)
 //   epilogue EPI 1: W rows alternate gate_u, up_u; dst[u] = silu(W[2u].act) * (W[2u+1].act)
+//            EPI 3: MUL_MAT_ID(down experts) of one token with TWO slots + the block's tail (GenericSparseMLP::forward src/layers.cpp:3840-3872): a unit is
+//                   one output row, its two sub-rows are the two picked experts' rows over the two slots' activations;
+//                   dst[r] = (y0[r] * w0 + y1[r] * w1) (+ resid[r]), w = probs[ids] / (probs[ids[0]] + probs[ids[1]])   (pw = probs, ids = the TOP_K output)
+//            EPI 2: the sparse-MoE router (GenericSparseMLP::forward src/layers.cpp:3792-3830): ONE workgroup; the rows are the experts' logits,
+//                   dst = SOFT_MAX(logits), r_ids = TOP_K(dst, r_k), xout = the normalised activation (the experts' input)
 //   dst[r] = W[r] . act (+ bias[r]) (+ resid[r])               (Linear::forward src/layers.cpp:2111-2129, residual adds :2740,:2758)
 // Same arithmetic as RMS_NORM -> MUL -> quantize_row_q8_K -> MUL_MAT (-> ADD) on the node-by-node path, bit for bit:
 // the reductions (rms_block_sumsq_1024, quant4_q8_K, q4k_step, wave_sum) are the shared definitions.
@@ -42,18 +47,30 @@ __global__ void __launch_bounds__(1024) k_gemv_dec(const float * __restrict__ px
                                                         const char * __restrict__ W, int nblk, int kfull, int nrem, float eps,
                                                         float * __restrict__ dst, float * __restrict__ xout,
                                                         const float * __restrict__ bias, const float * resid, unsigned long long * ts,
-                                                        const int32_t * __restrict__ ids, unsigned long long w_expert_bytes, int px_slot_stride, int dst_slot_stride) {
+                                                        const int32_t * __restrict__ ids, unsigned long long w_expert_bytes, int px_slot_stride, int dst_slot_stride,
+                                                        int32_t * __restrict__ r_ids, int r_k) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
+    __shared__ float r_logit[EPI == 2 ? 64 : 1], r_prob[EPI == 2 ? 64 : 1];
     if constexpr (MOE) {
         int e;
         asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(e) : "s"(ids + blockIdx.y) : "memory");
         W += (unsigned long long)(unsigned) e * w_expert_bytes;
         px += (long) blockIdx.y * px_slot_stride; dst += (long) blockIdx.y * dst_slot_stride;
     }
+    const char * W0 = W, * W1 = W;
+    float cw0 = 0.0f, cw1 = 0.0f;
+    if constexpr (EPI == 3) {
+        int e0, e1;
+        asm volatile("s_load_dword %0, %2, 0x0\n\ts_load_dword %1, %2, 0x4\n\ts_waitcnt lgkmcnt(0)" : "=&s"(e0), "=&s"(e1) : "s"(ids) : "memory");
+        W0 = W + (unsigned long long)(unsigned) e0 * w_expert_bytes; W1 = W + (unsigned long long)(unsigned) e1 * w_expert_bytes;
+        const float p0 = uniform_load_f32(pw + e0), p1 = uniform_load_f32(pw + e1);      // k_moe_combine's order: double sum from 0, IEEE divisions
+        const float sum = (float)(((double) 0.0 + (double) p0) + (double) p1);
+        cw0 = __fdiv_rn(p0, sum); cw1 = __fdiv_rn(p1, sum);
+    }
 #ifndef GEMV_P
 #define GEMV_P 2
 #endif
-    constexpr int P = (FMT == CLLM_TYPE_Q4_K) ? (GEMV_P + 1) / 2 : GEMV_P, RU = EPI == 1 ? 2 : 1;      // steps of prefetch (a Q4_K step is 16 super-blocks = 2304 B per wave, the others' 64 blocks)
+    constexpr int P = (FMT == CLLM_TYPE_Q4_K) ? (GEMV_P + 1) / 2 : GEMV_P, RU = (EPI == 1 || EPI == 3) ? 2 : 1;      // steps of prefetch (a Q4_K step is 16 super-blocks = 2304 B per wave, the others' 64 blocks)
     constexpr bool IS_K = FMT == CLLM_TYPE_Q4_K, IS_Q8 = FMT == CLLM_TYPE_Q8_0, IS_Q41 = FMT == CLLM_TYPE_Q4_1;
     constexpr int KIND = IS_K ? 256 : 32;                           // elements per weight block = activation quantization block
     constexpr int BS = IS_K ? 144 : q32_fmt<IS_K ? CLLM_TYPE_Q4_0 : FMT>::BS;      // bytes per weight block
@@ -66,12 +83,13 @@ __global__ void __launch_bounds__(1024) k_gemv_dec(const float * __restrict__ px
     const float * gp = (PRO == 1 || PRO == 4) ? pw : PRO == 3 ? px + 4 : px;
     constexpr int vmul = PRO == 3 ? 2 : 1;
     const int e0 = tid * 4;
-    f32x4 vv[NPRE], gg[NPRE];
+    f32x4 vv[NPRE], gg[(PRO != 2 || EPI == 3) ? NPRE : 1];      // (EPI 3: gg = the second slot's activation)
 #pragma unroll
     for (int u = 0; u < NPRE; u++) {
         const int e = e0 + u * 4096, ec = e < K ? e : 0;
         vv[u] = *(const f32x4 *)(px + ec * vmul);
         if (PRO != 2) gg[u] = *(const f32x4 *)(gp + ec * vmul);
+        if (EPI == 3) gg[u] = *(const f32x4 *)(px + px_slot_stride + ec);
     }
     // tensor parallel (PRO 1, NPRE 1): the all-reduced partial of the previous mat-vec is added to the residual stream here
     // (x + padd feeds the norm; workgroup 0 stores it to xout, a different buffer than px) instead of in a launch of its own
@@ -98,7 +116,8 @@ __global__ void __launch_bounds__(1024) k_gemv_dec(const float * __restrict__ px
         const int b = IS_K ? 16 * is + grp : 64 * is + lane;
         const bool ok = ik < nmine && b < nblk;
         const char * bp = W;
-        if (ok) bp = W + (unsigned long long)(unsigned)(unit_of(ik) * RU + isub) * nb01 + __umul24((unsigned) b, (unsigned) BS);      // (b < 2^24: the 32-bit v_mul_lo_u32 runs at a quarter rate)
+        if (EPI == 3) { if (ok) bp = (isub ? W1 : W0) + (unsigned long long)(unsigned) unit_of(ik) * nb01 + __umul24((unsigned) b, (unsigned) BS); }
+        else if (ok) bp = W + (unsigned long long)(unsigned)(unit_of(ik) * RU + isub) * nb01 + __umul24((unsigned) b, (unsigned) BS);      // (b < 2^24: the 32-bit v_mul_lo_u32 runs at a quarter rate)
         if (IS_K) {
             hh[p] = *(const u32x4 *) bp;
             qq[p] = *(const u32x4 *)(bp + 16 + 32 * j);
@@ -141,7 +160,9 @@ __global__ void __launch_bounds__(1024) k_gemv_dec(const float * __restrict__ px
                 v.x = silu_any(v.x, e + 0 < nv) * g.x; v.y = silu_any(v.y, e + 1 < nv) * g.y; v.z = silu_any(v.z, e + 2 < nv) * g.z; v.w = silu_any(v.w, e + 3 < nv) * g.w;
             }
             if (PRO == 1) { const f32x4 g = gg[u]; v.x = (v.x * scale) * g.x; v.y = (v.y * scale) * g.y; v.z = (v.z * scale) * g.z; v.w = (v.w * scale) * g.w; }
+            if (EPI == 2) *(f32x4 *)(xout + e) = v;
             quant4_store<KIND, IS_Q41>(lds, K, e, lane, v);
+            if (EPI == 3) quant4_store<KIND, IS_Q41>(lds + act_row_bytes(K, KIND), K, e, lane, gg[u]);
         }
     }
     TS(2);
@@ -153,7 +174,8 @@ __global__ void __launch_bounds__(1024) k_gemv_dec(const float * __restrict__ px
     const q4k_sel4 L = q4k_lane_sel4(lane);
     const int off_d = (int) act_off_d(K), off_s = (int) act_off_s(K, KIND);      // (the Q8_1 flavour has the Q8_0 geometry)
     constexpr int CHB = IS_K ? Q4K_CHAIN_BYTES : Q32_CHAIN_BYTES;
-    char * chain = lds + act_row_bytes(K, KIND) + wave_in_wg * CHB;
+    const int arb = (int) act_row_bytes(K, KIND);
+    char * chain = lds + (EPI == 3 ? 2 : 1) * arb + wave_in_wg * CHB;
     const int l16 = lane & 15;
     float acc = 0.0f, gate = 0.0f;
     int ck = 0, csub = 0, cs = 0;                                   // consume cursor
@@ -162,11 +184,12 @@ __global__ void __launch_bounds__(1024) k_gemv_dec(const float * __restrict__ px
         for (int p = 0; p < P; p++) {
             const int b = IS_K ? 16 * cs + grp : 64 * cs + lane;
             const bool ok = ck < nmine && b < nblk;
-            if (IS_K) q4k_emit4(hh[p], qq[p], q2[(IS_Q8 || IS_K) ? p : 0], lds, off_d, off_s, ok ? b : 0, ok, L, chain);
+            const char * arow = EPI == 3 ? lds + csub * arb : lds;
+            if (IS_K) q4k_emit4(hh[p], qq[p], q2[(IS_Q8 || IS_K) ? p : 0], arow, off_d, off_s, ok ? b : 0, ok, L, chain);
             else {
                 uint32_t h; u32x4 w0, w1 = {0, 0, 0, 0};
                 q32_align<IS_K ? CLLM_TYPE_Q4_0 : FMT>(qq[p], q2[IS_Q8 ? p : 0], hh[p].x, hh[p].y, h, w0, w1);
-                q32_emit<IS_K ? CLLM_TYPE_Q4_0 : FMT>(h, w0, w1, lds, off_d, off_s, ok ? b : 0, ok, lane, chain);
+                q32_emit<IS_K ? CLLM_TYPE_Q4_0 : FMT>(h, w0, w1, arow, off_d, off_s, ok ? b : 0, ok, lane, chain);
             }
             issue(p);
             {                                                       // every step: 16 super-blocks (Q4_K) / 64 blocks of records
@@ -181,6 +204,15 @@ __global__ void __launch_bounds__(1024) k_gemv_dec(const float * __restrict__ px
                     if (EPI == 1) {
                         if (csub == 0) gate = v;
                         else if (lane == 0) dst[cunit] = silu_poly(gate) * v;
+                    } else if (EPI == 2) {
+                        if (lane == 0) r_logit[crow] = v;
+                    } else if (EPI == 3) {                          // MUL by the slot's weight, ADD of the slot views, ADD of the residual: separate roundings
+                        if (csub == 0) gate = v;
+                        else {
+                            float o = __fadd_rn(__fmul_rn(gate, cw0), __fmul_rn(v, cw1));
+                            if (resid) o = __fadd_rn(o, uniform_load_f32(resid + cunit));
+                            if (lane == 0) dst[cunit] = o;
+                        }
                     } else {
                         if (bias)  v = v + uniform_load_f32(bias + crow);
                         if (resid) v = v + uniform_load_f32(resid + crow);
@@ -193,6 +225,15 @@ __global__ void __launch_bounds__(1024) k_gemv_dec(const float * __restrict__ px
         }
     }
     TS(4);
+    if constexpr (EPI == 2) {                                       // SOFT_MAX -> TOP_K over the logits: one wave, the partition of k_soft_max / the picks of k_top_k
+        __syncthreads();
+        if (wave_in_wg == 0) {
+            const int n = kfull * 16 + nrem;
+            wave_soft_max_plain(r_logit, r_prob, n, lane);
+            for (int i = lane; i < n; i += 64) dst[i] = r_prob[i];
+            if (lane == 0) top_k_row(r_prob, n, r_k, r_ids);
+        }
+    }
     if (ts) { __syncthreads(); TS(5); }
 }
 #undef TS
@@ -222,7 +263,7 @@ int launch_gemv_decode(hipStream_t st, int wtype, const void * W, int64_t K, int
         static bool attr = false; \
         if (lds > 64 * 1024 && !attr) { HIP_TRY(hipFuncSetAttribute((const void *) k_gemv_dec<FMT_, PRO_, EPI_, NPRE_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr = true; } \
         hipLaunchKernelGGL((k_gemv_dec<FMT_, PRO_, EPI_, NPRE_>), dim3((unsigned) grid), dim3(1024), lds, st, px, pw, padd, (const char *) W, nblk, kfull, nrem, eps, dst, xout, bias, resid, g_gemv_ts, \
-                           (const int32_t *) nullptr, 0ull, 0, 0); } while (0)
+                           (const int32_t *) nullptr, 0ull, 0, 0, (int32_t *) nullptr, 0); } while (0)
 #define GO(FMT_) do { \
         if (pro == 1 && epi == 1) { if (npre == 1) GO3(FMT_, 1, 1, 1); else GO3(FMT_, 1, 1, 4); } \
         else if (pro == 1)        { if (npre == 1) GO3(FMT_, 1, 0, 1); else GO3(FMT_, 1, 0, 4); } \
@@ -258,12 +299,62 @@ int launch_gemv_decode_id(hipStream_t st, int wtype, const void * W, size_t w_ex
         if (lds > 64 * 1024 && !attr) { HIP_TRY(hipFuncSetAttribute((const void *) k_gemv_dec<FMT_, 2, EPI_, NPRE_, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr = true; } \
         hipLaunchKernelGGL((k_gemv_dec<FMT_, 2, EPI_, NPRE_, true>), dim3((unsigned) grid, (unsigned) n_slots), dim3(1024), lds, st, px, (const float *) nullptr, (const float *) nullptr, (const char *) W, \
                            nblk, kfull, nrem, 0.0f, dst, (float *) nullptr, (const float *) nullptr, (const float *) nullptr, (unsigned long long *) nullptr, ids, \
-                           (unsigned long long) w_expert_bytes, (int) px_slot_stride, (int) dst_slot_stride); } while (0)
+                           (unsigned long long) w_expert_bytes, (int) px_slot_stride, (int) dst_slot_stride, (int32_t *) nullptr, 0); } while (0)
 #define GOMT(FMT_) do { if (epi == 1) { if (npre == 1) GOM(FMT_, 1, 1); else if (npre == 4) GOM(FMT_, 1, 4); else GOM(FMT_, 1, 8); } \
                         else          { if (npre == 1) GOM(FMT_, 0, 1); else if (npre == 4) GOM(FMT_, 0, 4); else GOM(FMT_, 0, 8); } } while (0)
     if (wtype == CLLM_TYPE_Q4_K) GOMT(CLLM_TYPE_Q4_K); else if (wtype == CLLM_TYPE_Q4_0) GOMT(CLLM_TYPE_Q4_0); else if (wtype == CLLM_TYPE_Q4_1) GOMT(CLLM_TYPE_Q4_1); else GOMT(CLLM_TYPE_Q8_0);
 #undef GOMT
 #undef GOM
+    LAUNCH_CHECK();
+    return CLLM_OK;
+}
+
+// The router of a sparse-MoE block for ONE token as one launch of one workgroup (the reference's nodes RMS_NORM -> MUL -> MUL_MAT(gate) -> SOFT_MAX ->
+// TOP_K, GenericSparseMLP::forward src/layers.cpp:3792-3830): xnorm[K] = RMS_NORM(px) * pw, probs[n] = SOFT_MAX(W . quantize(xnorm)), ids[k] = TOP_K(probs).
+// Same reductions in the same order as the separate kernels: bit-identical.  n <= 64 experts, K <= 16384; CLLM_E_UNSUPPORTED otherwise.
+int launch_moe_router(hipStream_t st, int wtype, const void * W, int64_t K, int64_t n, const float * px, const float * pw, float eps,
+                      float * xnorm, float * probs, int32_t * ids, int k) {
+    const int kind = wtype == CLLM_TYPE_Q4_K ? 256 : 32;
+    if (!is_quant_type(wtype) || K % kind || K % 4 || K > 16384 || n < 1 || n > 64 || k < 1 || k > n) return CLLM_E_UNSUPPORTED;
+    if (act_row_bytes(K, kind) + 16 * Q32_CHAIN_BYTES > 160 * 1024) return CLLM_E_UNSUPPORTED;
+    const int kfull = (int)(n / 16), nrem = (int)(n % 16), nblk = (int)(K / kind);
+    const size_t lds = act_row_bytes(K, kind) + 16 * (size_t)(wtype == CLLM_TYPE_Q4_K ? Q4K_CHAIN_BYTES : Q32_CHAIN_BYTES);
+#define GOR(FMT_, NPRE_) do { \
+        static bool attr = false; \
+        if (lds > 64 * 1024 && !attr) { HIP_TRY(hipFuncSetAttribute((const void *) k_gemv_dec<FMT_, 1, 2, NPRE_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr = true; } \
+        hipLaunchKernelGGL((k_gemv_dec<FMT_, 1, 2, NPRE_>), dim3(1), dim3(1024), lds, st, px, pw, (const float *) nullptr, (const char *) W, nblk, kfull, nrem, eps, probs, xnorm, \
+                           (const float *) nullptr, (const float *) nullptr, (unsigned long long *) nullptr, (const int32_t *) nullptr, 0ull, 0, 0, ids, k); } while (0)
+#define GORT(FMT_) do { if (K <= 4096) GOR(FMT_, 1); else GOR(FMT_, 4); } while (0)
+    if (wtype == CLLM_TYPE_Q4_K) GORT(CLLM_TYPE_Q4_K); else if (wtype == CLLM_TYPE_Q4_0) GORT(CLLM_TYPE_Q4_0); else if (wtype == CLLM_TYPE_Q4_1) GORT(CLLM_TYPE_Q4_1); else GORT(CLLM_TYPE_Q8_0);
+#undef GORT
+#undef GOR
+    LAUNCH_CHECK();
+    return CLLM_OK;
+}
+
+// MUL_MAT_ID(down experts) for ONE token with TWO slots + the tail of the sparse-MoE block in one launch (EPI 3 above):
+//   dst[r] = (W[ids[0]][r] . quantize(px[:, 0])) * w0 + (W[ids[1]][r] . quantize(px[:, 1])) * w1 (+ resid[r]),  w_j = probs[ids[j]] / (probs[ids[0]] + probs[ids[1]])
+// the arithmetic of MUL_MAT_ID -> GET_ROWS -> SUM_ROWS -> DIV -> MUL -> ADD (-> ADD) in their order: bit-identical.  dst may be resid; CLLM_E_UNSUPPORTED otherwise
+int launch_gemv_decode_id_combine(hipStream_t st, int wtype, const void * W, size_t w_expert_bytes, int64_t K, int64_t nrows, const float * px, int64_t px_slot_stride,
+                                  const int32_t * ids, const float * probs, const float * resid, float * dst) {
+    const int kind = wtype == CLLM_TYPE_Q4_K ? 256 : 32;
+    if (!is_quant_type(wtype) || K % kind || K > 32768 || nrows <= 0 || (uint64_t) nrows * (uint64_t) cllm_row_size(wtype, K) >= (1ull << 32) || px_slot_stride > INT32_MAX || px_slot_stride % 4) return CLLM_E_UNSUPPORTED;
+    const size_t lds = 2 * act_row_bytes(K, kind) + 16 * (size_t)(wtype == CLLM_TYPE_Q4_K ? Q4K_CHAIN_BYTES : Q32_CHAIN_BYTES);
+    if (2 * act_row_bytes(K, kind) + 16 * Q32_CHAIN_BYTES > 160 * 1024) return CLLM_E_UNSUPPORTED;
+    int64_t grid = (nrows + 15) / 16;
+    if (grid > device_cu_count()) grid = device_cu_count();
+    const int64_t nwaves = grid * 16;
+    const int kfull = (int)(nrows / nwaves), nrem = (int)(nrows % nwaves), nblk = (int)(K / kind);
+    const int npre = K <= 4096 ? 1 : K <= 16384 ? 4 : 8;
+#define GOC(FMT_, NPRE_) do { \
+        static bool attr = false; \
+        if (lds > 64 * 1024 && !attr) { HIP_TRY(hipFuncSetAttribute((const void *) k_gemv_dec<FMT_, 2, 3, NPRE_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr = true; } \
+        hipLaunchKernelGGL((k_gemv_dec<FMT_, 2, 3, NPRE_>), dim3((unsigned) grid), dim3(1024), lds, st, px, probs, (const float *) nullptr, (const char *) W, nblk, kfull, nrem, 0.0f, dst, (float *) nullptr, \
+                           (const float *) nullptr, resid, (unsigned long long *) nullptr, ids, (unsigned long long) w_expert_bytes, (int) px_slot_stride, 0, (int32_t *) nullptr, 0); } while (0)
+#define GOCT(FMT_) do { if (npre == 1) GOC(FMT_, 1); else if (npre == 4) GOC(FMT_, 4); else GOC(FMT_, 8); } while (0)
+    if (wtype == CLLM_TYPE_Q4_K) GOCT(CLLM_TYPE_Q4_K); else if (wtype == CLLM_TYPE_Q4_0) GOCT(CLLM_TYPE_Q4_0); else if (wtype == CLLM_TYPE_Q4_1) GOCT(CLLM_TYPE_Q4_1); else GOCT(CLLM_TYPE_Q8_0);
+#undef GOCT
+#undef GOC
     LAUNCH_CHECK();
     return CLLM_OK;
 }

@@ -424,18 +424,7 @@ __global__ void __launch_bounds__(256) k_top_k(tview s, tview d, int k) {
         const int64_t i1 = r % s.ne[1], i2 = (r / s.ne[1]) % s.ne[2], i3 = r / (s.ne[1] * s.ne[2]);
         const float * x = (const float *)(s.data + i1*s.nb[1] + i2*s.nb[2] + i3*s.nb[3]);
         int32_t * out = (int32_t *)(d.data + i1*d.nb[1] + i2*d.nb[2] + i3*d.nb[3]);
-        float prev_v = INFINITY; int prev_i = -1;                       // the last pick: the next one comes strictly after it in (value desc, index asc)
-        for (int j = 0; j < k; j++) {
-            float best = -INFINITY; int bi = -1;
-            for (int i = 0; i < n; i++) {
-                const float v = x[i];
-                const bool after = v < prev_v || (v == prev_v && i > prev_i);
-                if (after && (bi < 0 || v > best)) { best = v; bi = i; }
-            }
-            if (bi < 0) bi = 0;                                           // NaNs: the CPU's comparator is not a strict weak order there either
-            out[j] = bi; prev_v = best; prev_i = bi;
-        }
-        if (k > 1) { const int32_t t = out[0]; out[0] = out[1]; out[1] = t; }
+        top_k_row(x, n, k, out);
     }
 }
 extern "C" int cllm_op_top_k(void * stream, const cllm_tensor * src, cllm_tensor * dst) {

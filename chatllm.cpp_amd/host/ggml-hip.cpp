@@ -25,6 +25,7 @@
 #include <type_traits>
 #include <unordered_map>
 #include <vector>
+#include <functional>
 
 #define HIPB_LOG(...) do { fprintf(stderr, "[ggml-hip] " __VA_ARGS__); fputc('\n', stderr); } while (0)
 
@@ -480,18 +481,21 @@ struct fused_attn {
 //   GET_ROWS(probs, ids) -> SUM_ROWS -> DIV -> MUL(experts) -> ADD of the slot views (-> ADD residual)
 //                                                    cllm_op_moe_combine: the tail of GenericSparseMLP::forward (src/layers.cpp:3792-3872)
 //   {MUL_MAT_ID gate, MUL_MAT_ID up} -> UNARY(SILU) -> MUL     one token: cllm_op_mul_mat_id_silu_mul over the per-expert interleaved pack
-struct fused_moe { const ggml_tensor * experts = nullptr, * probs = nullptr, * ids = nullptr, * resid = nullptr; };
+struct fused_moe { const ggml_tensor * experts = nullptr, * probs = nullptr, * ids = nullptr, * resid = nullptr; int down = -1; /* the MUL_MAT_ID node folded into the launch */ };
+//   RMS_NORM -> MUL(weight) -> {MUL_MAT(router) -> SOFT_MAX -> TOP_K, experts}     one token: cllm_op_moe_router (launched at the TOP_K node)
+struct moe_router { const ggml_tensor * x = nullptr, * w = nullptr, * gate = nullptr, * xnorm = nullptr, * probs = nullptr; float eps = 0; };
 struct moe_gate_up { int mul = -1, gate = -1, up = -1, unary = -1; void * W = nullptr; };      // node indices; W: the pack, resolved before the walk
 //   MUL_MAT(K, Q) SCALE DIAG_MASK_INF SOFT_MAX MUL_MAT(V^T, P)   with more than 32 query rows (the tolerance tier of the MFMA mat-muls):
 //                                                    cllm_op_attn_prefill, one flash kernel in place of the V.P node; the scores never reach HBM
 struct fused_fa { int ikq = -1, n_past = 0; float scale = 1.0f; bool alias = false; size_t bytes = 0; };   // alias: dst overlaps q (ggml-alloc reuses the dead q block): staged
-enum { ALT_NONE = 0, ALT_SILU_MUL = 1 /* src0 is the SiLU */, ALT_RMS_NORM_MUL = 2, ALT_MOE_COMBINE = 3, ALT_MUL_SILU = 4 /* src1 is the SiLU */, ALT_MOE_GATE_UP = 5, ALT_FLASH_PREFILL = 6 };
+enum { ALT_NONE = 0, ALT_SILU_MUL = 1 /* src0 is the SiLU */, ALT_RMS_NORM_MUL = 2, ALT_MOE_COMBINE = 3, ALT_MUL_SILU = 4 /* src1 is the SiLU */, ALT_MOE_GATE_UP = 5, ALT_FLASH_PREFILL = 6, ALT_MOE_ROUTER = 7 };
 struct fuse_plan {
     std::vector<uint8_t> skip;          // node is produced inside a fused launch (or not needed at all)
     std::vector<uint8_t> alt;           // the node is launched as one of the ALT_* forms
     std::vector<int>     moe;           // ALT_MOE_COMBINE: index into moes; ALT_FLASH_PREFILL: index into fas
     std::vector<fused_fa> fas;
     std::vector<fused_moe> moes;
+    std::vector<moe_router> routers;    // ALT_MOE_ROUTER: P.moe[top_k node] indexes them
     std::vector<moe_gate_up> gus;       // candidates (P.moe[mul node] indexes them once resolved)
     std::vector<int>     mv;            // index into mvs for MUL_MAT nodes launched fused, else -1
     std::vector<fused_mv> mvs;
@@ -828,6 +832,46 @@ fuse_plan make_plan(ggml_cgraph * g) {
         const int ir = find(a);
         if (a->op == GGML_OP_RMS_NORM && ir >= 0 && !P.skip[ir] && only_local(ir, 1) && f32_dense(a->src[0]) && ggml_is_contiguous(a->src[0]) && ggml_is_contiguous(t) &&
             b->type == GGML_TYPE_F32 && ggml_is_contiguous(b) && ggml_nelements(b) == t->ne[0] && b->ne[0] == t->ne[0]) {
+            // one token, and among the consumers a small router mat-vec -> SOFT_MAX -> TOP_K: the whole head of the sparse-MoE block in one launch
+            int imm = -1, ism = -1, itk = -1;
+            if (ggml_nelements(t) == t->ne[0] && t->ne[0] % 4 == 0 && !(((uintptr_t) t->data | (uintptr_t) a->src[0]->data | (uintptr_t) b->data) & 15) &&
+                (t->data == a->src[0]->data || !overlap(t->data, (size_t) t->ne[0] * 4, a->src[0]->data, (size_t) t->ne[0] * 4)))
+                for (int u : users[i]) {
+                    const ggml_tensor * c = ggml_graph_node(g, u);
+                    if (c->op == GGML_OP_MUL_MAT && c->src[1] == t && mv_ok(c, 16384) && c->src[0]->ne[1] <= 64 && P.mv[u] < 0 && !P.skip[u] && only_local(u, 1)) { imm = u; break; }
+                }
+            if (imm >= 0) {
+                const int u = users[imm][0];
+                const ggml_tensor * sm = ggml_graph_node(g, u);
+                float s1, mb; memcpy(&s1, sm->op_params, 4); memcpy(&mb, (const float *) sm->op_params + 1, 4);
+                if (sm->op == GGML_OP_SOFT_MAX && !sm->src[1] && sm->src[0] == ggml_graph_node(g, imm) && s1 == 1.0f && mb == 0.0f && f32_vec(sm) && !P.skip[u] && P.sm_src[u] < 0 &&
+                    !(sm->flags & GGML_TENSOR_FLAG_OUTPUT)) ism = u;
+            }
+            if (ism >= 0) {
+                int cnt = 0;
+                for (int u : users[ism]) { const ggml_tensor * c = ggml_graph_node(g, u); if (c->op == GGML_OP_TOP_K && c->src[0] == ggml_graph_node(g, ism)) { itk = u; cnt++; } }
+                const ggml_tensor * tk = itk >= 0 ? ggml_graph_node(g, itk) : nullptr;
+                if (cnt != 1 || tk->type != GGML_TYPE_I32 || tk->nb[0] != 4 || ggml_nelements(tk) != tk->ne[0] || tk->ne[0] > ggml_graph_node(g, ism)->ne[0] || P.skip[itk]) itk = -1;
+            }
+            if (itk >= 0) {
+                // everything else that reads the normalised activation or the probabilities must run after the launch (which stands at the TOP_K node)
+                std::function<bool(int)> later = [&](int j) {
+                    for (int u : users[j]) {
+                        if (u == imm || u == ism || u == itk) continue;
+                        const ggml_tensor * c = ggml_graph_node(g, u);
+                        const bool noop = c->op == GGML_OP_RESHAPE || c->op == GGML_OP_VIEW || c->op == GGML_OP_PERMUTE || c->op == GGML_OP_TRANSPOSE;
+                        if (noop ? !later(u) : u < itk) return false;
+                    }
+                    return true;
+                };
+                if (later(i) && later(ism)) {
+                    moe_router R; R.x = a->src[0]; R.w = b; R.gate = ggml_graph_node(g, imm)->src[0]; R.xnorm = t; R.probs = ggml_graph_node(g, ism);
+                    memcpy(&R.eps, a->op_params, 4);
+                    P.skip[ir] = P.skip[i] = P.skip[imm] = P.skip[ism] = 1;
+                    P.alt[itk] = ALT_MOE_ROUTER; P.moe[itk] = (int) P.routers.size(); P.routers.push_back(R);
+                    continue;
+                }
+            }
             P.alt[i] = ALT_RMS_NORM_MUL; P.skip[ir] = 1;
             continue;
         }
@@ -870,11 +914,31 @@ fuse_plan make_plan(ggml_cgraph * g) {
         if (!ok || k < 2) continue;
         fused_moe M; M.experts = a; M.probs = probs; M.ids = ids;
         int fin = cur;
+        // every thread of k_moe_combine reads its element of all k slots (and of the residual), then writes its element of dst: dst may BE slot 0 of
+        // a one-token experts tensor or the residual (ggml-alloc computes these ADDs in place), but must not overlap them any other way
+        auto dst_ok = [&](const ggml_tensor * out, const ggml_tensor * resid) {
+            const char * dp = (const char *) out->data;
+            const size_t nb = (size_t)(H * T) * 4;
+            if (overlap(dp, nb, a->data, ggml_nbytes(a)) && !(T == 1 && dp == (const char *) a->data)) return false;
+            return !resid || dp == (const char *) resid->data || !overlap(dp, nb, resid->data, nb);
+        };
         if (only_local(cur, 1)) {             // ... -> ADD(moe_out, residual)
             const int ia = users[cur][0];
             const ggml_tensor * ad = ggml_graph_node(g, ia);
             if (ad->op == GGML_OP_ADD && !P.skip[ia] && ad->src[0] == ggml_graph_node(g, cur) && f32_dense(ad->src[1]) && ggml_is_contiguous(ad->src[1]) &&
-                ad->src[1]->ne[0] == H && ggml_nelements(ad->src[1]) == H * T && ggml_is_contiguous(ad) && ad->data != ad->src[0]->data) { M.resid = ad->src[1]; fin = ia; }
+                ad->src[1]->ne[0] == H && ggml_nelements(ad->src[1]) == H * T && ggml_is_contiguous(ad) && dst_ok(ad, ad->src[1])) { M.resid = ad->src[1]; fin = ia; }
+        }
+        if (!M.resid && !dst_ok(ggml_graph_node(g, cur), nullptr)) continue;
+        {   // the experts are the down projection's MUL_MAT_ID of one token over two slots: mat-vecs and tail in one launch (cllm_op_mul_mat_id_combine)
+            const int ia = find(a);
+            const ggml_tensor * out = ggml_graph_node(g, fin), * w = a->src[0], * x = a->src[1];
+            static const bool no_down = getenv("CLLM_HIP_NO_MOE_DOWN_FUSE") != nullptr;
+            if (!no_down && a->op == GGML_OP_MUL_MAT_ID && ia >= 0 && !P.skip[ia] && only_local(ia, 1) && k == 2 && T == 1 && a->src[2] == ids && is_q(w->type) && w->ne[3] == 1 &&
+                w->nb[1] == ggml_row_size(w->type, w->ne[0]) && w->nb[2] % 16 == 0 && ((uintptr_t) w->data & 15) == 0 && w->ne[0] <= 32768 && (uint64_t) w->ne[1] * w->nb[1] < (1ull << 32) &&
+                x->type == GGML_TYPE_F32 && x->ne[1] == 2 && x->ne[2] == 1 && x->ne[3] == 1 && x->nb[0] == 4 && x->nb[1] % 16 == 0 && ((uintptr_t) x->data & 15) == 0 &&
+                probs->ne[0] == w->ne[2] && ggml_nelements(probs) == probs->ne[0] &&
+                !overlap(out->data, (size_t) H * 4, x->data, ggml_nbytes(x)) && !overlap(out->data, (size_t) H * 4, probs->data, ggml_nbytes(probs)) &&
+                !overlap(out->data, (size_t) H * 4, ids->data, ggml_nbytes(ids))) { M.down = ia; P.skip[ia] = 1; }
         }
         for (const ggml_tensor * r = b; r != dv; r = r->src[0]) P.skip[find(r)] = 1;
         P.skip[find(dv)] = P.skip[isr] = P.skip[iwr] = P.skip[igr] = 1;
@@ -980,6 +1044,11 @@ ggml_status be_graph_compute(ggml_backend_t backend, ggml_cgraph * g) {
     { std::lock_guard<std::mutex> lock(g_ring.m); if (c->device < 64) cur_sets.swap(g_scalar_sets[c->device]); }
     c->ahead.graphs++;
     fuse_plan plan = make_plan(g);
+    if (trace) {
+        for (const fused_mv & f : plan.mvs) if (f.node >= 0) fprintf(stderr, "  plan: mat-vec node %d pro %d%s%s%s\n", f.node, f.pro, f.resid ? " +resid" : "", f.alias ? " STAGED (dst overlaps an input)" : "", f.group >= 0 ? " grouped" : "");
+        for (const fused_attn & A : plan.attns) fprintf(stderr, "  plan: attention level %d%s\n", A.level, A.alias ? " STAGED" : "");
+        for (int i = 0; i < ggml_graph_n_nodes(g); i++) if (!plan.skip[i]) { const ggml_tensor * n = ggml_graph_node(g, i); if (n->op == GGML_OP_ADD || n->op == GGML_OP_MUL || n->op == GGML_OP_CPY || n->op == GGML_OP_CONT) fprintf(stderr, "  plan: node %d %s launched on its own (alt %d)\n", i, ggml_op_name(n->op), plan.alt[i]); }
+    }
     if (g_stats) g_ws.plan_us += wall_stats::us(ws.t0, wall_stats::clk::now());
     // fused attention: [cos/sin table 1 KB][q | k | v projections][scores of the long-context form]
     // scratch of the fused forms: [cos/sin table 1 KB][q | k | v projections][SiLU(gate)*up activation][scores of the long-context attention]
@@ -1090,7 +1159,11 @@ ggml_status be_graph_compute(ggml_backend_t backend, ggml_cgraph * g) {
                 dp.ne[0] = M.probs->ne[0]; dp.ne[1] = M.experts->ne[2]; dp.ne[2] = dp.ne[3] = 1; dp.nb[1] = (size_t) dp.ne[0] * 4; dp.nb[2] = dp.nb[3] = dp.nb[1] * (size_t) dp.ne[1];
                 if (M.resid) { dr = desc(M.resid); dr.ne[0] = M.experts->ne[0]; dr.ne[1] = M.experts->ne[2]; dr.ne[2] = dr.ne[3] = 1; dr.nb[1] = (size_t) dr.ne[0] * 4; dr.nb[2] = dr.nb[3] = dr.nb[1] * (size_t) dr.ne[1]; }
                 cllm_tensor dd = d; dd.ne[0] = M.experts->ne[0]; dd.ne[1] = M.experts->ne[2]; dd.ne[2] = dd.ne[3] = 1; dd.nb[1] = (size_t) dd.ne[0] * 4; dd.nb[2] = dd.nb[3] = dd.nb[1] * (size_t) dd.ne[1];
-                rc = CALL(cllm_op_moe_combine, st, &de, &dp, &di, M.resid ? &dr : nullptr, &dd);
+                if (M.down >= 0) {
+                    const ggml_tensor * mm = ggml_graph_node(g, M.down);
+                    cllm_tensor dw = desc(mm->src[0]), dx = desc(mm->src[1]);
+                    rc = CALL(cllm_op_mul_mat_id_combine, st, &dw, &dx, &di, &dp, M.resid ? &dr : nullptr, &dd);
+                } else rc = CALL(cllm_op_moe_combine, st, &de, &dp, &di, M.resid ? &dr : nullptr, &dd);
             } else rc = CALL(cllm_op_add, st, &da, &db, &d); break;
             case GGML_OP_MUL: if (plan.alt[i] == ALT_MOE_GATE_UP) {
                 const moe_gate_up & G = plan.gus[plan.moe[i]];
@@ -1111,7 +1184,13 @@ ggml_status be_graph_compute(ggml_backend_t backend, ggml_cgraph * g) {
             } else rc = CALL(cllm_op_mul, st, &da, &db, &d); break;
             case GGML_OP_DIV: rc = CALL(cllm_op_div, st, &da, &db, &d); break;
             case GGML_OP_SUM_ROWS: rc = CALL(cllm_op_sum_rows, st, &da, &d); break;
-            case GGML_OP_TOP_K: rc = CALL(cllm_op_top_k, st, &da, &d); break;
+            case GGML_OP_TOP_K: if (plan.alt[i] == ALT_MOE_ROUTER) {
+                const moe_router & R = plan.routers[plan.moe[i]];
+                cllm_tensor dx = desc(R.x), dwt = desc(R.w), dg = desc(R.gate), dn = desc(R.xnorm), dp = desc(R.probs);
+                const int64_t K = R.xnorm->ne[0];
+                for (cllm_tensor * v : { &dx, &dwt, &dn }) { v->ne[0] = K; v->ne[1] = v->ne[2] = v->ne[3] = 1; v->nb[1] = v->nb[2] = v->nb[3] = (size_t) K * 4; }
+                rc = CALL(cllm_op_moe_router, st, &dx, &dwt, R.eps, &dg, &dn, &dp, &d);
+            } else rc = CALL(cllm_op_top_k, st, &da, &d); break;
             case GGML_OP_SCALE: { float s, bias; memcpy(&s, n->op_params, 4); memcpy(&bias, (const float *) n->op_params + 1, 4); rc = CALL(cllm_op_scale, st, &da, &d, s, bias); } break;
             case GGML_OP_DIAG_MASK_INF: rc = CALL(cllm_op_diag_mask_inf, st, &da, &d, n->op_params[0]); break;
             case GGML_OP_UNARY: rc = CALL(cllm_op_unary, st, CLLM_UNARY_SILU, &da, &d); break;
@@ -1277,8 +1356,9 @@ ggml_status be_graph_compute(ggml_backend_t backend, ggml_cgraph * g) {
         for (const merge_group & G : plan.groups) merged_n += G.state == 1;
         int fa_nodes = 0;
         for (int i = 0; i < ggml_graph_n_nodes(g); i++) fa_nodes += ggml_graph_node(g, i)->op == GGML_OP_FLASH_ATTN_EXT;
-        HIPB_LOG("graph_compute: %d nodes -> %d calls%s (%d fused mat-vecs, %d merged over packed weights, attention fused at level 1: %d, level 2: %d, flash prefill: %d, flash_attn_ext: %d)",
-                 ggml_graph_n_nodes(g), launches, replayed ? ", replayed from the captured graph" : "", (int) plan.mvs.size(), merged_n, a1, a2, (int) plan.fas.size(), fa_nodes);
+        HIPB_LOG("graph_compute: %d nodes -> %d calls%s (%d fused mat-vecs, %d merged over packed weights, attention fused at level 1: %d, level 2: %d, flash prefill: %d, flash_attn_ext: %d, MoE routers: %d)",
+                 ggml_graph_n_nodes(g), launches, replayed ? ", replayed from the captured graph" : "", (int) plan.mvs.size(), merged_n, a1, a2, (int) plan.fas.size(), fa_nodes,
+                 (int) plan.routers.size());
         g_ws.calls += launches;
         if (++g_ws.graphs % 64 == 0) {
             const double n = 64.0;

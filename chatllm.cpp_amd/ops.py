@@ -193,6 +193,20 @@ def mul_mat_id_silu_mul(as_gate, as_up, b, ids, dst=None):
     return dst
 
 
+def mul_mat_id_combine(as_down, b, ids, probs, resid=None, dst=None):
+    """MUL_MAT_ID(down experts) over two slots + normalized top-2 weights + slot sum (+ residual) for one token in one launch"""
+    dst = dst or Tensor(F32, [as_down.ne[1], 1])
+    _l.check(_l.get().cllm_op_mul_mat_id_combine(None, _ref(as_down), _ref(b), _ref(ids), _ref(probs), _ref(resid), _ref(dst)), "mul_mat_id_combine")
+    return dst
+
+
+def moe_router(x, norm_w, eps, gate_w, k):
+    """GenericSparseMLP's head for one token in one launch: (xnorm, probs, ids) = (RMS_NORM(x) * w, SOFT_MAX(gate . xnorm), TOP_K(probs, k))"""
+    xnorm = Tensor(F32, [x.ne[0]]); probs = Tensor(F32, [gate_w.ne[1]]); ids = Tensor(I32, [k])
+    _l.check(_l.get().cllm_op_moe_router(None, _ref(x), _ref(norm_w), float(eps), _ref(gate_w), _ref(xnorm), _ref(probs), _ref(ids)), "moe_router")
+    return xnorm, probs, ids
+
+
 def moe_combine(experts, probs, ids, resid=None, dst=None):
     """GenericSparseMLP's tail: normalized top-k weights applied to the expert outputs, summed over the slots (+ residual)"""
     dst = dst or Tensor(F32, [experts.ne[0], experts.ne[2]])

@@ -253,6 +253,17 @@ CLLM_API int cllm_op_top_k(void * stream, const cllm_tensor * src, cllm_tensor *
  * experts F32 [H, k, T], probs F32 [n_expert, T], ids I32 [k, T], resid / dst F32 [H, T].  Bit-identical to the node sequence. */
 CLLM_API int cllm_op_moe_combine(void * stream, const cllm_tensor * experts, const cllm_tensor * probs, const cllm_tensor * ids, const cllm_tensor * resid,
                                  cllm_tensor * dst);
+/* the down-projection MUL_MAT_ID of ONE token over TWO slots together with the block's tail (GenericSparseMLP::forward, src/layers.cpp:3840-3872; the
+ * nodes MUL_MAT_ID -> GET_ROWS -> SUM_ROWS -> DIV -> MUL -> ADD of the slot views -> ADD residual) in one launch; as [K, H, E] quantized, b F32 [K, 2, 1],
+ * ids I32 [2, 1], probs F32 [E, 1], resid (may be NULL) / dst F32 [H, 1]; dst may be resid.  Bit-identical to cllm_op_mul_mat_id + cllm_op_moe_combine;
+ * CLLM_E_UNSUPPORTED = use those. */
+CLLM_API int cllm_op_mul_mat_id_combine(void * stream, const cllm_tensor * as, const cllm_tensor * b, const cllm_tensor * ids, const cllm_tensor * probs,
+                                        const cllm_tensor * resid, cllm_tensor * dst);
+/* the head of a sparse-MoE block for ONE token (GenericSparseMLP::forward, src/layers.cpp:3792-3830: the post-attention RMS_NORM -> MUL, the
+ * router MUL_MAT(gate.weight), SOFT_MAX, TOP_K) in one launch: xnorm F32 [K] (the experts' input; may be x itself), probs F32 [n_expert <= 64],
+ * ids I32 [k].  gate_w: dense quantized [K <= 16384, n_expert].  Bit-identical to the node sequence; CLLM_E_UNSUPPORTED = use the separate ops. */
+CLLM_API int cllm_op_moe_router(void * stream, const cllm_tensor * x, const cllm_tensor * norm_w, float eps, const cllm_tensor * gate_w,
+                                cllm_tensor * xnorm, cllm_tensor * probs, cllm_tensor * ids);
 /* fused  dst = silu(gate) * up   (BaseMLP::forward, src/layers.cpp:2475-2483: UNARY(SILU) then MUL) */
 CLLM_API int cllm_op_silu_mul(void * stream, const cllm_tensor * gate, const cllm_tensor * up, cllm_tensor * dst);
 

@@ -125,6 +125,7 @@ def test_reference_host_mixtral_cpu_vs_our_module(gpu, tmp_path, wname, wt):
     # the reference feeds this architecture one token per graph (batch_input = false, models/mistral.h:101): prompt + decode graphs,
     # and not one more -- no scheduler split, nothing fell back to the CPU backend
     assert len(graphs) == len(prompt) + n_dec, (len(graphs), graphs[:4])
+    assert all(f"MoE routers: {cfg['n_layer']})" in ln for ln in graphs), graphs[:3]       # norm + router mat-vec + SOFT_MAX + TOP_K: one launch per block
     # bit-exact token ids at greedy AND bit-identical logits (the run on the module was teacher-forced on the CPU ids only to share it with the
     # no-fusion run: with identical logits its own argmax is the same id)
     assert np.array_equal(lg_c.view(np.uint32), lg_g.view(np.uint32)), [int(np.sum(lg_c[i].view(np.uint32) != lg_g[i].view(np.uint32))) for i in range(n_dec + 1)]

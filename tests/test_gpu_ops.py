@@ -379,6 +379,54 @@ def test_mul_mat_id_silu_mul_equals_the_four_nodes(gpu, t, K, F, E, k):
     assert np.array_equal(got.view(np.uint32).reshape(-1), want.view(np.uint32).reshape(-1))
 
 
+@pytest.mark.parametrize("t,K,ne,k", [(O.Q4_K, 4096, 8, 2), (O.Q4_K, 256, 8, 2), (O.Q8_0, 512, 4, 2), (O.Q4_0, 1024, 16, 3), (O.Q4_1, 256, 60, 6),
+                                      (O.Q4_K, 14336, 64, 8), (O.Q4_0, 4096, 7, 1), (O.Q8_0, 8192, 33, 4)])
+def test_moe_router_equals_the_node_sequence(gpu, t, K, ne, k):
+    """cllm_op_moe_router = RMS_NORM -> MUL -> MUL_MAT(gate) -> SOFT_MAX -> TOP_K of the reference's graph, bit for bit (device nodes and CPU oracle)"""
+    ops, T = gpu.ops, gpu.Tensor
+    wb = rand_blocks(t, ne, K, rng, d_scale=0.05)
+    w = T.from_numpy(wb, t, [K, ne])
+    xh = (rng.standard_normal(K) * 1.7).astype(np.float32); gh = (1.0 + 0.1 * rng.standard_normal(K)).astype(np.float32)
+    x = T.from_numpy(xh); g = T.from_numpy(gh)
+    xn = ops.rms_norm_mul(x, g, 1e-5)
+    pr = ops.soft_max(ops.mul_mat(w, xn))
+    want_ids = ops.top_k(pr, k).numpy().reshape(-1)
+    got_xn, got_pr, got_ids = ops.moe_router(x, g, 1e-5, w, k)
+    assert np.array_equal(got_xn.numpy().view(np.uint32).reshape(-1), xn.numpy().view(np.uint32).reshape(-1))
+    assert np.array_equal(got_pr.numpy().view(np.uint32).reshape(-1), pr.numpy().view(np.uint32).reshape(-1))
+    assert np.array_equal(got_ids.numpy().reshape(-1), want_ids)
+    # the CPU oracle on the same inputs
+    n1 = np.zeros(K, np.float32); O.rms_norm(O.tensor(xh, O.F32, [K]), O.tensor(n1, O.F32, [K]), 1e-5)
+    n2 = np.zeros(K, np.float32); O.mul(O.tensor(n1, O.F32, [K]), O.tensor(gh, O.F32, [K]), O.tensor(n2, O.F32, [K]))
+    lg = np.zeros(ne, np.float32); O.mul_mat(O.tensor(wb, t, [K, ne]), O.tensor(n2, O.F32, [K]), O.tensor(lg, O.F32, [ne]))
+    pc = np.zeros(ne, np.float32); O.soft_max(O.tensor(lg, O.F32, [ne]), None, O.tensor(pc, O.F32, [ne]))
+    ic = np.zeros(k, np.int32); O.top_k(O.tensor(pc, O.F32, [ne]), O.tensor(ic, O.I32, [k]))
+    assert np.array_equal(got_pr.numpy().view(np.uint32).reshape(-1), pc.view(np.uint32))
+    assert np.array_equal(got_ids.numpy().reshape(-1), ic)
+
+
+@pytest.mark.parametrize("t,K,H,E,with_resid", [(O.Q4_K, 14336, 4096, 8, True), (O.Q4_K, 512, 256, 8, False), (O.Q8_0, 512, 264, 4, True), (O.Q4_0, 1024, 100, 8, True),
+                                                (O.Q4_1, 4096, 512, 3, False), (O.Q4_K, 20480, 64, 4, True)])
+def test_mul_mat_id_combine_equals_the_two_launches(gpu, t, K, H, E, with_resid):
+    """cllm_op_mul_mat_id_combine = cllm_op_mul_mat_id (down experts, two slots) -> cllm_op_moe_combine, bit for bit; also in place on the residual"""
+    ops, T = gpu.ops, gpu.Tensor
+    w = T.from_numpy(rand_blocks(t, H * E, K, rng), t, [K, H, E])
+    x = T.from_numpy(rng.standard_normal((1, 2, K)).astype(np.float32))
+    pr = rng.standard_normal((1, E)).astype(np.float32)
+    pr = (np.exp(pr) / np.exp(pr).sum(-1, keepdims=True)).astype(np.float32)
+    p = T.from_numpy(pr)
+    ids = ops.top_k(p, 2)
+    rh = rng.standard_normal((1, H)).astype(np.float32)
+    r = T.from_numpy(rh) if with_resid else None
+    want = ops.moe_combine(ops.mul_mat_id(w, x, ids), p, ids, r).numpy()
+    got = ops.mul_mat_id_combine(w, x, ids, p, r).numpy()
+    assert np.array_equal(got.view(np.uint32).reshape(-1), want.view(np.uint32).reshape(-1))
+    if with_resid:
+        r2 = T.from_numpy(rh)
+        ops.mul_mat_id_combine(w, x, ids, p, r2, dst=r2)
+        assert np.array_equal(r2.numpy().view(np.uint32).reshape(-1), want.view(np.uint32).reshape(-1))
+
+
 @pytest.mark.parametrize("H,k,T,ne,with_resid", [(4096, 2, 1, 8, True), (256, 2, 5, 8, False), (100, 4, 3, 16, True)])
 def test_moe_combine_equals_the_node_sequence(gpu, H, k, T, ne, with_resid):
     ops, T_ = gpu.ops, gpu.Tensor

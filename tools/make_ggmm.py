@@ -199,9 +199,12 @@ if __name__ == "__main__":
     ap.add_argument("--out", required=True)
     ap.add_argument("--fast", action="store_true")
     ap.add_argument("--arch", default="llama3", choices=["llama3", "mixtral", "qwen2"])
+    ap.add_argument("--layers", type=int, default=0, help="override the number of blocks (profiling a few real-shape layers)")
     a = ap.parse_args()
     pkg = ge.load_package()
-    cfg = pkg.synth.config(a.config, max_len=a.max_len, **(dict(qkv_bias=1, rope_mode=2, rope_theta=1e6) if a.arch == "qwen2" else {}))
+    over = dict(qkv_bias=1, rope_mode=2, rope_theta=1e6) if a.arch == "qwen2" else {}
+    if a.layers: over["n_layer"] = a.layers
+    cfg = pkg.synth.config(a.config, max_len=a.max_len, **over)
     if a.arch == "mixtral":
         write_mixtral(a.out, cfg, WT[a.wtype], fast=a.fast)
     else:
