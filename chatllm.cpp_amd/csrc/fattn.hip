@@ -30,6 +30,7 @@ typedef float    f32x16 __attribute__((ext_vector_type(16)));
 
 #define FA_VSTR 136                  // bytes per V^T row in LDS: 64 positions * 2 B + 8 B (conflict-free ds_read_b64 over 32 rows)
 #define FA_LOG2E 1.4426950408889634f
+#define FA_TAU 8.0f                  // lazy soft-max reference: rescale only when a maximum grows by more than 2^8
 #define FA_MAX_SPLITS 256            // split-KV decode: at most this many partials per (head, query)
 
 struct fattn_args {
@@ -74,7 +75,7 @@ __device__ __forceinline__ u32x4 fa_q8_8(const char * row, int e0) {
 }
 
 template <int D, int KVT, int VL, int MASK, int NW>
-__global__ void __launch_bounds__(NW * 64) k_fattn(const fattn_args a) {
+__global__ void __launch_bounds__(NW * 64, 2) k_fattn(const fattn_args a) {
     constexpr int NT = NW * 64, BQ = NW * 32, KS = D / 16, NB = D / 32, CPR = D / 8;
     extern __shared__ __attribute__((aligned(16))) char fa_smem[];
     char * Kl = fa_smem, * Vl = fa_smem + 64 * D * 2;
@@ -281,36 +282,51 @@ __global__ void __launch_bounds__(NW * 64) k_fattn(const fattn_args a) {
             }
         }
 
-        // ---- online soft-max (base 2) of the row held by this lane pair
-        float mx = m_run;
+        // ---- online soft-max (base 2) of the row held by this lane pair.  The exponent reference m_run follows the running maximum lazily:
+        //      it moves (and O, l are rescaled) only when a tile's maximum exceeds it by more than FA_TAU, so p <= 2^FA_TAU (fp16 holds it with the
+        //      same relative precision) and the rescale of the 64 O registers leaves the steady state of the loop
+        const bool full = MASK != 2 && kv0 + 64 <= kv_hi && (MASK == 0 || kv0 + 63 <= a.n_past + (qb * BQ + wave * 32) / a.R);      // nothing of this tile is masked for this wave
+        float mx = -INFINITY;
 #pragma unroll
         for (int j = 0; j < 2; j++)
 #pragma unroll
-            for (int r = 0; r < 16; r++) {
-                const int kv = kv0 + 32 * j + fa_crow(r, hi);
-                float t = s[j][r] * a.sc2;
-                if (MASK == 2) t += mv[j][r];                          // -inf beyond kv_hi
-                else if (MASK == 1) t = (kv <= lim && kv < kv_hi) ? t : -INFINITY;
-                else t = kv < kv_hi ? t : -INFINITY;
-                s[j][r] = t;
-                mx = fmaxf(mx, t);
-            }
+            for (int r = 0; r < 16; r++) s[j][r] = s[j][r] * a.sc2;
+        if (!full) {
+#pragma unroll
+            for (int j = 0; j < 2; j++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    const int kv = kv0 + 32 * j + fa_crow(r, hi);
+                    float t = s[j][r];
+                    if (MASK == 2) t += mv[j][r];                      // -inf beyond kv_hi
+                    else if (MASK == 1) t = (kv <= lim && kv < kv_hi) ? t : -INFINITY;
+                    else t = kv < kv_hi ? t : -INFINITY;
+                    s[j][r] = t;
+                }
+        }
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) mx = fmaxf(mx, s[j][r]);
         mx = fa_pair_max(mx);
-        const float msafe = mx == -INFINITY ? 0.0f : mx;               // a row with nothing visible yet: every p = exp2(-inf) = 0
-        const float alpha = __builtin_amdgcn_exp2f(m_run - msafe);                      // m_run = -inf -> 0
+        const bool grow = mx > m_run + FA_TAU;                         // (m_run = -inf: any finite maximum)
+        if (__any(grow)) {
+            const float m_new = grow ? mx : m_run;
+            const float alpha = grow ? __builtin_amdgcn_exp2f(m_run - m_new) : 1.0f;      // m_run = -inf -> 0
+            l_run *= alpha;
+#pragma unroll
+            for (int i = 0; i < NB; i++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) o[i][r] *= alpha;
+            m_run = m_new;
+        }
+        const float msafe = m_run == -INFINITY ? 0.0f : m_run;         // a row with nothing visible yet: every p = exp2(-inf) = 0
         float psum = 0.0f;
 #pragma unroll
         for (int j = 0; j < 2; j++)
 #pragma unroll
             for (int r = 0; r < 16; r++) { const float p = __builtin_amdgcn_exp2f(s[j][r] - msafe); s[j][r] = p; psum += p; }
-        l_run = l_run * alpha + psum;
-        m_run = mx;
-        if (!__all(alpha == 1.0f)) {
-#pragma unroll
-            for (int i = 0; i < NB; i++)
-#pragma unroll
-                for (int r = 0; r < 16; r++) o[i][r] *= alpha;
-        }
+        l_run += psum;
 
         // ---- O^T += V^T . P^T
 #pragma unroll

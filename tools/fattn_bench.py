@@ -30,7 +30,7 @@ def timeit(fn, iters=10):
 
 def prefill(N):
     r = np.random.default_rng(1)
-    ML, KD = N, D * Hkv
+    ML, KD = int(os.environ.get("FA_ML", N)), D * Hkv      # FA_ML: rows of the transposed V cache (a power of two camps on few L2 channels)
     q = T.from_numpy(r.standard_normal((N, H, D)).astype(np.float32), gpu.F32, [D, H, N]).permute(0, 2, 1, 3)
     kc = T.from_numpy((r.standard_normal((ML, KD)) * 0.5).astype(np.float16), gpu.F16, [KD, ML])
     vc = T.from_numpy(r.standard_normal((KD, ML)).astype(np.float16), gpu.F16, [ML, KD])
@@ -41,6 +41,8 @@ def prefill(N):
     dst = T(gpu.F32, [D, N, H])
     t = timeit(lambda: ops.attn_prefill(q, k, vt, scale, 0, dst))
     print(f"prefill N={N}: fused causal kernel      {t*1e3:8.3f} ms  {flops/t/1e12:7.1f} TFLOP/s (causal flops)")
+    if os.environ.get("FA_ONLY_FUSED"):
+        return
     # FLASH_ATTN_EXT with the mask tensor the host uploads; V rows by position
     v = T.from_numpy(r.standard_normal((Hkv, N, D)).astype(np.float16), gpu.F16, [D, N, Hkv])
     m = np.zeros((N, N), np.float16)
@@ -87,6 +89,8 @@ def decode(n_kv, kv_t):
 if __name__ == "__main__":
     for n in ([int(sys.argv[1])] if len(sys.argv) > 1 else [512, 4096]):
         prefill(n)
+    if os.environ.get("FA_ONLY_FUSED"):
+        sys.exit(0)
     for n_kv in (300, 1024, 4096, 16384):
         decode(n_kv, gpu.F16)
     for n_kv in (4096, 16384):
