@@ -130,6 +130,7 @@ __global__ void __launch_bounds__(NW * 64, 2) k_fattn(const fattn_args a) {
     if (MASK == 1) kv_hi = min(kv_hi, a.n_past + min(a.N - 1, (qb * BQ + BQ - 1) / a.R) + 1);
     const int lim = MASK == 1 ? a.n_past + n : 0;                      // causal: position kv is visible to row n iff kv <= n_past + n
 
+    const float mask_mul = FA_LOG2E / a.sc2;                           // mask values are added to the RAW scores: (s + mask log2e / sc2) sc2 = s sc2 + mask log2e
     f32x16 o[NB];
 #pragma unroll
     for (int i = 0; i < NB; i++)
@@ -196,20 +197,22 @@ __global__ void __launch_bounds__(NW * 64, 2) k_fattn(const fattn_args a) {
 #pragma unroll
         for (int t = 0; t < NKC; t++) {
             const int c = tid + t * NT, row = c / CPR, col = c % CPR;
-            if (c < 64 * CPR) *(u32x4 *)(Kl + row * (D * 2) + ((col ^ (row & (CPR - 1))) << 4)) = Q8 ? q8_cvt(kraw[Q8 ? t : 0]) : kreg[Q8 ? 0 : t];
+            if ((64 * CPR) % NT == 0 || c < 64 * CPR) *(u32x4 *)(Kl + row * (D * 2) + ((col ^ (row & (CPR - 1))) << 4)) = Q8 ? q8_cvt(kraw[Q8 ? t : 0]) : kreg[Q8 ? 0 : t];
         }
         if (VL == 1) {
 #pragma unroll
             for (int t = 0; t < NVU; t++) {
                 const int c = tid + t * NT, dv = c >> 3, kc = c & 7, kvs = kv0 + 8 * kc;
                 u32x4 x = vreg[Q8 ? 0 : t];
-                const int left = n_kv - kvs;                           // elements of this chunk that exist (the rest of the cache row is not ours: may be anything)
+                if (kv0 + 64 > n_kv) {                                 // (block-uniform: only the cache's last, partial tile)
+                    const int left = n_kv - kvs;                       // elements of this chunk that exist (the rest of the cache row is not ours: may be anything)
 #pragma unroll
-                for (int w = 0; w < 4; w++) {
-                    if (2 * w >= left) x[w] = 0;
-                    else if (2 * w + 1 >= left) x[w] &= 0xffffu;
+                    for (int w = 0; w < 4; w++) {
+                        const uint32_t keep = 2 * w + 1 < left ? 0xffffffffu : 2 * w < left ? 0xffffu : 0u;
+                        x[w] &= keep;
+                    }
                 }
-                if (c < D * 8) { char * p = Vl + dv * FA_VSTR + kc * 16; *(u32x2 *) p = u32x2{x.x, x.y}; *(u32x2 *)(p + 8) = u32x2{x.z, x.w}; }
+                if ((D * 8) % NT == 0 || c < D * 8) { char * p = Vl + dv * FA_VSTR + kc * 16; *(u32x2 *) p = u32x2{x.x, x.y}; *(u32x2 *)(p + 8) = u32x2{x.z, x.w}; }
             }
         } else {
 #pragma unroll
@@ -218,7 +221,7 @@ __global__ void __launch_bounds__(NW * 64, 2) k_fattn(const fattn_args a) {
                 u32x4 x[4];
 #pragma unroll
                 for (int i = 0; i < 4; i++) x[i] = Q8 ? q8_cvt(vraw[Q8 ? 4 * t + i : 0]) : vreg[Q8 ? 0 : 4 * t + i];
-                if (u < 16 * CPR) {
+                if ((16 * CPR) % NT == 0 || u < 16 * CPR) {
 #pragma unroll
                     for (int e = 0; e < 8; e++) {                      // 4 x 4 transposition in registers: V rows by position -> V^T rows by feature
                         const uint32_t sel = (e & 1) ? 0x07060302u : 0x05040100u;
@@ -254,7 +257,7 @@ __global__ void __launch_bounds__(NW * 64, 2) k_fattn(const fattn_args a) {
 #pragma unroll
                     for (int e = 0; e < 4; e++) {
                         const float f = kvb + e < kv_hi ? h2f(w[e]) : -INFINITY;
-                        mv[j][4 * g + e] = f * FA_LOG2E;
+                        mv[j][4 * g + e] = f * mask_mul;                   // in units of the raw score (the scale is applied later)
                         any |= (f != -INFINITY) && rvalid;
                     }
                 }
@@ -287,10 +290,6 @@ __global__ void __launch_bounds__(NW * 64, 2) k_fattn(const fattn_args a) {
         //      same relative precision) and the rescale of the 64 O registers leaves the steady state of the loop
         const bool full = MASK != 2 && kv0 + 64 <= kv_hi && (MASK == 0 || kv0 + 63 <= a.n_past + (qb * BQ + wave * 32) / a.R);      // nothing of this tile is masked for this wave
         float mx = -INFINITY;
-#pragma unroll
-        for (int j = 0; j < 2; j++)
-#pragma unroll
-            for (int r = 0; r < 16; r++) s[j][r] = s[j][r] * a.sc2;
         if (!full) {
 #pragma unroll
             for (int j = 0; j < 2; j++)
@@ -308,7 +307,7 @@ __global__ void __launch_bounds__(NW * 64, 2) k_fattn(const fattn_args a) {
         for (int j = 0; j < 2; j++)
 #pragma unroll
             for (int r = 0; r < 16; r++) mx = fmaxf(mx, s[j][r]);
-        mx = fa_pair_max(mx);
+        mx = fa_pair_max(mx) * a.sc2;                                  // sc2 > 0: the maximum of the scaled scores
         const bool grow = mx > m_run + FA_TAU;                         // (m_run = -inf: any finite maximum)
         if (__any(grow)) {
             const float m_new = grow ? mx : m_run;
@@ -325,7 +324,7 @@ __global__ void __launch_bounds__(NW * 64, 2) k_fattn(const fattn_args a) {
 #pragma unroll
         for (int j = 0; j < 2; j++)
 #pragma unroll
-            for (int r = 0; r < 16; r++) { const float p = __builtin_amdgcn_exp2f(s[j][r] - msafe); s[j][r] = p; psum += p; }
+            for (int r = 0; r < 16; r++) { const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[j][r], a.sc2, -msafe)); s[j][r] = p; psum += p; }
         l_run += psum;
 
         // ---- O^T += V^T . P^T
