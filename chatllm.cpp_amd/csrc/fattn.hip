@@ -30,6 +30,7 @@ typedef float    f32x16 __attribute__((ext_vector_type(16)));
 
 #define FA_VSTR 136                  // bytes per V^T row in LDS: 64 positions * 2 B + 8 B (conflict-free ds_read_b64 over 32 rows)
 #define FA_LOG2E 1.4426950408889634f
+#define FA_PD 4                      // LDS fragment reads are issued this many MFMAs ahead
 #define FA_TAU 8.0f                  // lazy soft-max reference: rescale only when a maximum grows by more than 2^8
 #define FA_MAX_SPLITS 256            // split-KV decode: at most this many partials per (head, query)
 
@@ -271,18 +272,28 @@ __global__ void __launch_bounds__(NW * 64, 2) k_fattn(const fattn_args a) {
         __syncthreads();
 
         if (!wave_live) continue;                                      // (decode: the group's rows fit one wave; the others only help staging)
-        // ---- S^T = K . Q^T
+        // ---- S^T = K . Q^T.  The K fragments are read FA_PD MFMAs ahead of their use (the compiler's own order is read -> wait -> MFMA, one LDS
+        //      latency per MFMA); sched_barrier pins the order
         f32x16 s[2];
 #pragma unroll
-        for (int j = 0; j < 2; j++) {
+        for (int j = 0; j < 2; j++)
 #pragma unroll
             for (int r = 0; r < 16; r++) s[j][r] = 0.0f;
-            const int row = 32 * j + l31;
+        {
+            auto kfrag = [&](int idx) {
+                const int row = 32 * (idx / KS) + l31, ks = idx % KS;
+                return *(const half8 *)(Kl + row * (D * 2) + (((2 * ks + hi) ^ (row & (CPR - 1))) << 4));
+            };
+            half8 kf[FA_PD];
 #pragma unroll
-            for (int ks = 0; ks < KS; ks++) {
-                const half8 kf = *(const half8 *)(Kl + row * (D * 2) + (((2 * ks + hi) ^ (row & (CPR - 1))) << 4));
-                s[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], s[j], 0, 0, 0);
+            for (int p = 0; p < FA_PD; p++) kf[p] = kfrag(p);
+#pragma unroll
+            for (int idx = 0; idx < 2 * KS; idx++) {
+                __builtin_amdgcn_sched_barrier(0);
+                s[idx / KS] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[idx % FA_PD], qf[idx % KS], s[idx / KS], 0, 0, 0);
+                if (idx + FA_PD < 2 * KS) kf[idx % FA_PD] = kfrag(idx + FA_PD);
             }
+            __builtin_amdgcn_sched_barrier(0);
         }
 
         // ---- online soft-max (base 2) of the row held by this lane pair.  The exponent reference m_run follows the running maximum lazily:
@@ -327,22 +338,30 @@ __global__ void __launch_bounds__(NW * 64, 2) k_fattn(const fattn_args a) {
             for (int r = 0; r < 16; r++) { const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[j][r], a.sc2, -msafe)); s[j][r] = p; psum += p; }
         l_run += psum;
 
-        // ---- O^T += V^T . P^T
+        // ---- O^T += V^T . P^T: 4 NB MFMAs, V^T fragments read FA_PD ahead
+        {
+            half8 pb[4];
 #pragma unroll
-        for (int j = 0; j < 2; j++)
+            for (int q = 0; q < 4; q++)
 #pragma unroll
-            for (int kk = 0; kk < 2; kk++) {
-                half8 pb;
+                for (int e = 0; e < 8; e++) pb[q][e] = (_Float16) s[q >> 1][8 * (q & 1) + e];
+            auto vfrag = [&](int idx) {                                // idx = 4-kv-group q (j, kk) major, dv block i minor
+                const int q = idx / NB, i = idx % NB;
+                const char * p = Vl + (32 * i + l31) * FA_VSTR + (32 * (q >> 1) + 16 * (q & 1) + 4 * hi) * 2;
+                const half4 v0 = *(const half4 *) p, v1 = *(const half4 *)(p + 16);
+                return half8{v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+            };
+            half8 vf[FA_PD];
 #pragma unroll
-                for (int e = 0; e < 8; e++) pb[e] = (_Float16) s[j][8 * kk + e];
+            for (int p = 0; p < FA_PD; p++) vf[p] = vfrag(p);
 #pragma unroll
-                for (int i = 0; i < NB; i++) {
-                    const char * p = Vl + (32 * i + l31) * FA_VSTR + (32 * j + 16 * kk + 4 * hi) * 2;
-                    const half4 v0 = *(const half4 *) p, v1 = *(const half4 *)(p + 16);
-                    const half8 vf = half8{v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-                    o[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pb, o[i], 0, 0, 0);
-                }
+            for (int idx = 0; idx < 4 * NB; idx++) {
+                __builtin_amdgcn_sched_barrier(0);
+                o[idx % NB] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[idx % FA_PD], pb[idx / NB], o[idx % NB], 0, 0, 0);
+                if (idx + FA_PD < 4 * NB) vf[idx % FA_PD] = vfrag(idx + FA_PD);
             }
+            __builtin_amdgcn_sched_barrier(0);
+        }
     }
 
     // ---- epilogue: lane holds O^T[dv = 32 i + crow(r, hi), q = l31]: groups of 4 consecutive dv

@@ -26,10 +26,16 @@ typedef int   i32x4 __attribute__((ext_vector_type(4)));
 #define MMQ_LD 272           // bytes per LDS tile row: 256 int8 + 16 pad
 
 template <int TYPE> struct mmq_traits;
-template <> struct mmq_traits<CLLM_TYPE_Q4_K> { static constexpr int kb = 256, MI = 2; };
-template <> struct mmq_traits<CLLM_TYPE_Q4_0> { static constexpr int kb = 32,  MI = 4; };
-template <> struct mmq_traits<CLLM_TYPE_Q8_0> { static constexpr int kb = 32,  MI = 4; };
-template <> struct mmq_traits<CLLM_TYPE_Q4_1> { static constexpr int kb = 32,  MI = 2; };      // two more scale planes and operands per patch: 64 tokens
+// NW waves per workgroup, laid out 2 (n) x NW/2 (m); a wave owns 64 (n) x 16 MI (m).  Q4_0 / Q8_0 with EIGHT waves of 64 x 32 over the same 128 x 128 tile
+// (four waves per SIMD, -DMMQ_NW_Q0=8) measured 136.0 ms against 132.4 ms for cfg3: the kernel is bound by the fold's VALU work AND the LDS fragment / scale
+// reads together (9 KB per 32-block step and wave), and the smaller wave tile reads 1.5 x the fragments -- more waves do not help, so four it stays
+#ifndef MMQ_NW_Q0
+#define MMQ_NW_Q0 4
+#endif
+template <> struct mmq_traits<CLLM_TYPE_Q4_K> { static constexpr int kb = 256, MI = 2, NW = 4; };
+template <> struct mmq_traits<CLLM_TYPE_Q4_0> { static constexpr int kb = 32,  MI = 16 / MMQ_NW_Q0, NW = MMQ_NW_Q0; };
+template <> struct mmq_traits<CLLM_TYPE_Q8_0> { static constexpr int kb = 32,  MI = 16 / MMQ_NW_Q0, NW = MMQ_NW_Q0; };
+template <> struct mmq_traits<CLLM_TYPE_Q4_1> { static constexpr int kb = 32,  MI = 2, NW = 4; };      // two more scale planes and operands per patch: 64 tokens
 
 struct mmq_args {
     const char * W; int64_t nb01; int64_t N; int64_t K;
@@ -54,10 +60,10 @@ __device__ __forceinline__ uint32_t nib_minus8(uint32_t nib4) {   // four nibble
 }
 
 template <int TYPE>
-__global__ void __launch_bounds__(256, 2) k_mmq(const mmq_args a) {
+__global__ void __launch_bounds__(mmq_traits<TYPE>::NW * 64, mmq_traits<TYPE>::NW / 2) k_mmq(const mmq_args a) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     constexpr bool IS_K = TYPE == CLLM_TYPE_Q4_K, IS_41 = TYPE == CLLM_TYPE_Q4_1;
-    constexpr int MMQ_MI = mmq_traits<TYPE>::MI, MMQ_BM = 32 * MMQ_MI;
+    constexpr int MMQ_MI = mmq_traits<TYPE>::MI, NT = mmq_traits<TYPE>::NW * 64, MMQ_BM = (mmq_traits<TYPE>::NW / 2) * 16 * MMQ_MI;
     constexpr int LDS_WS = lds_ws(MMQ_BM), LDS_XS = lds_xs(MMQ_BM, TYPE == CLLM_TYPE_Q4_1);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t m0 = (int64_t) blockIdx.x * MMQ_BM, n0 = (int64_t) blockIdx.y * MMQ_BN;
@@ -80,21 +86,21 @@ __global__ void __launch_bounds__(256, 2) k_mmq(const mmq_args a) {
     //      current step) and registers -> LDS (unpack + store, between the two barriers of a step) ----
     constexpr int BS = TYPE == CLLM_TYPE_Q8_0 ? 34 : IS_41 ? 20 : 18, QOFF = IS_41 ? 4 : 2;      // block bytes, offset of the quants
     struct __attribute__((packed, aligned(2))) q16 { uint32_t x, y, z, w; };
-    constexpr int NXA = MMQ_BM * 16 / 256;                         // activation chunk tasks per thread
-    constexpr int NXS = IS_K ? (MMQ_BM * 9 + 255) / 256 : MMQ_BM * (IS_41 ? 16 : 8) / 256;      // activation scale tasks per thread
-    constexpr int NWT = IS_K ? 5 : 4;                              // weight tasks per thread
-    u32x4 rx[NXA]; uint32_t rxs[NXS]; u32x4 rw[NWT]; u32x4 rw2[IS_K ? 1 : 4]; float rwd[IS_K ? 1 : 4]; float rwm[IS_41 ? 4 : 1];
+    constexpr int NXA = MMQ_BM * 16 / NT;                          // activation chunk tasks per thread
+    constexpr int NXS = IS_K ? (MMQ_BM * 9 + NT - 1) / NT : MMQ_BM * (IS_41 ? 16 : 8) / NT;      // activation scale tasks per thread
+    constexpr int NWT = IS_K ? (MMQ_BN * 9 + NT - 1) / NT : MMQ_BN * 8 / NT;      // weight tasks per thread
+    u32x4 rx[NXA]; uint32_t rxs[NXS]; u32x4 rw[NWT]; u32x4 rw2[IS_K ? 1 : NWT]; float rwd[IS_K ? 1 : NWT]; float rwm[IS_41 ? NWT : 1];
     auto prefetch = [&](int64_t k0) {
 #pragma unroll
         for (int t = 0; t < NXA; t++) {                            // activations: MMQ_BM rows x 256 int8 (16 chunks of 16 B per row)
-            const int c = tid + 256 * t, row = c >> 4, ch = c & 15;
+            const int c = tid + NT * t, row = c >> 4, ch = c & 15;
             const int64_t m = m0 + row;
             rx[t] = u32x4{0, 0, 0, 0};
             if (m < a.M && k0 + ch * 16 < K) rx[t] = *(const u32x4 *)(a.act + m * a.act_stride + k0 + ch * 16);
         }
 #pragma unroll
         for (int t = 0; t < NXS; t++) {
-            const int c = tid + 256 * t;
+            const int c = tid + NT * t;
             rxs[t] = 0;
             if (IS_K) {
                 if (c < MMQ_BM * 9) {                              // dx[m], sx[8][m]
@@ -113,7 +119,7 @@ __global__ void __launch_bounds__(256, 2) k_mmq(const mmq_args a) {
         }
 #pragma unroll
         for (int t = 0; t < NWT; t++) {
-            const int c = tid + 256 * t;
+            const int c = tid + NT * t;
             rw[t] = u32x4{0, 0, 0, 0};
             if (IS_K) {
                 if (c < MMQ_BN * 9) {                              // 9 chunks of 16 B per 144-byte super-block
@@ -139,17 +145,17 @@ __global__ void __launch_bounds__(256, 2) k_mmq(const mmq_args a) {
     auto commit = [&]() {
 #pragma unroll
         for (int t = 0; t < NXA; t++) {
-            const int c = tid + 256 * t, row = c >> 4, ch = c & 15;
+            const int c = tid + NT * t, row = c >> 4, ch = c & 15;
             *(u32x4 *)(Xt + row * MMQ_LD + ch * 16) = rx[t];
         }
 #pragma unroll
         for (int t = 0; t < NXS; t++) {
-            const int c = tid + 256 * t;
+            const int c = tid + NT * t;
             if (!IS_K || c < MMQ_BM * 9) *(uint32_t *)(Xs + ((c / MMQ_BM) * MMQ_BM + c % MMQ_BM) * 4) = rxs[t];
         }
 #pragma unroll
         for (int t = 0; t < NWT; t++) {
-            const int c = tid + 256 * t;
+            const int c = tid + NT * t;
             if (IS_K) {
                 if (c < MMQ_BN * 9) {
                     const int row = c / 9, ch = c % 9;
@@ -322,10 +328,10 @@ int launch_mmq(hipStream_t st, int wtype, const tview & w, const void * act, siz
     a.dst = (float *) d.data; a.ldd = d.nb[1] / 4; a.resid = resid; a.ldr = ldr;
     if ((a.N + MMQ_BN - 1) / MMQ_BN > 65535) FAIL(CLLM_E_UNSUPPORTED, "mmq: too many row tiles");
 #define GO(T) do { static bool attr = false; \
-        constexpr int BM = 32 * mmq_traits<T>::MI, LDS = lds_total(BM, T == CLLM_TYPE_Q4_1); \
+        constexpr int BM = (mmq_traits<T>::NW / 2) * 16 * mmq_traits<T>::MI, LDS = lds_total(BM, T == CLLM_TYPE_Q4_1); \
         const dim3 grid((unsigned)((a.M + BM - 1) / BM), (unsigned)((a.N + MMQ_BN - 1) / MMQ_BN)); \
         if (!attr) { HIP_TRY(hipFuncSetAttribute((const void *) k_mmq<T>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS)); attr = true; } \
-        hipLaunchKernelGGL(k_mmq<T>, grid, dim3(256), LDS, st, a); } while (0)
+        hipLaunchKernelGGL(k_mmq<T>, grid, dim3(mmq_traits<T>::NW * 64), LDS, st, a); } while (0)
     if (wtype == CLLM_TYPE_Q4_K) GO(CLLM_TYPE_Q4_K);
     else if (wtype == CLLM_TYPE_Q4_0) GO(CLLM_TYPE_Q4_0);
     else if (wtype == CLLM_TYPE_Q8_0) GO(CLLM_TYPE_Q8_0);
