@@ -313,7 +313,7 @@ int mmq_min_cols_get();       // capi.hip: columns from which MUL_MAT runs on th
 int launch_mmvq(hipStream_t st, int wtype, const tview & w, const void * act, size_t act_stride, int64_t ncols_total,
                 const tview & src1_geom, const tview & dst);
 int launch_mmvq_id(hipStream_t st, int wtype, const tview & as, const void * act, size_t act_stride, int64_t b_ne1, const tview & ids, const tview & dst);
-int launch_mmq(hipStream_t st, int wtype, const tview & w, const void * act, size_t act_stride, const tview & src1_geom, const tview & dst, const float * resid = nullptr, int64_t ldr = 0);
+int launch_mmq(hipStream_t st, int wtype, const tview & w, const void * act, size_t act_stride, const tview & src1_geom, const tview & dst, const float * resid = nullptr, int64_t ldr = 0, int epi = 0);
 int launch_mul_mat_f(hipStream_t st, int wtype, const tview & w, const tview & x, const tview & d, int causal = 0, int n_past = 0);   // causal: mma_f16.hip
 int launch_mma_f16(hipStream_t st, const tview & w, const tview & x, const tview & d, int causal, int n_past);
 int device_cu_count();
@@ -329,6 +329,9 @@ int launch_fattn(hipStream_t st, const tview & q, const tview & k, int ktype, co
                  char * dst, int64_t nbn, int64_t nbh, int64_t nbb, float scale, void * wdata, size_t wsize);
 int launch_gemv_decode_id_combine(hipStream_t st, int wtype, const void * W, size_t w_expert_bytes, int64_t K, int64_t nrows, const float * px, int64_t px_slot_stride,
                                   const int32_t * ids, const float * probs, const float * resid, float * dst);
+int launch_quantize_act_norm(hipStream_t st, int kind, const tview & s, const float * norm_w, float eps, void * act, size_t act_stride);
+int launch_rope_kv_store(hipStream_t st, float * qkv, int64_t QKV, const int32_t * pos, int64_t n_tok, int nh, int nkv, int hd, int mode, float freq_base,
+                         void * k_cache, void * v_cache, int64_t ML);
 int launch_moe_router(hipStream_t st, int wtype, const void * W, int64_t K, int64_t n, const float * px, const float * pw, float eps,
                       float * xnorm, float * probs, int32_t * ids, int k);
 int launch_gemv_kq(hipStream_t st, int wtype, const tview & w, const void * act, size_t act_stride, int64_t M, float * dst, int64_t ldd);

@@ -293,10 +293,11 @@ static int ensure_scores(cllm_llama * m, size_t elems) {
 
 // prefill (more than 32 columns): MUL_MAT with the SiLU*up quantizer prologue and / or the residual add in the epilogue (cllm_op_mul_mat_ex);
 // CLLM_E_UNSUPPORTED: the caller issues the node sequence
-static int linear_ex(cllm_llama * m, const dweight & w, int64_t K, int64_t N, float * x, int64_t qlen, float * y, int pro, float * resid) {
+static int linear_ex(cllm_llama * m, const dweight & w, int64_t K, int64_t N, float * x, int64_t qlen, float * y, int pro, float * resid, const float * norm_w = nullptr, int epi = 0) {
     if (!is_quant_type(w.type) || getenv("CLLM_NO_PREFILL_FUSE")) return CLLM_E_UNSUPPORTED;
-    cllm_tensor W = T(w.type, w.data, K, N), X = T(CLLM_TYPE_F32, x, pro == 3 ? 2 * K : K, qlen), Y = T(CLLM_TYPE_F32, y, N, qlen), R = T(CLLM_TYPE_F32, resid, N, qlen);
-    return cllm_op_mul_mat_ex(m->st, &W, &X, &Y, m->wdata, m->wsize, pro, resid ? &R : nullptr);
+    cllm_tensor W = T(w.type, w.data, K, N), X = T(CLLM_TYPE_F32, x, pro == 3 ? 2 * K : K, qlen), Y = T(CLLM_TYPE_F32, y, epi ? N / 2 : N, qlen), R = T(CLLM_TYPE_F32, resid, N, qlen);
+    cllm_tensor G = T(CLLM_TYPE_F32, (void *) norm_w, K);
+    return cllm_op_mul_mat_ex(m->st, &W, &X, &Y, m->wdata, m->wsize, pro, norm_w ? &G : nullptr, m->cfg.rms_eps, epi, resid ? &R : nullptr);
 }
 static int linear(cllm_llama * m, const dweight & w, int64_t K, int64_t N, float * x, int64_t qlen, float * y) {
     cllm_tensor W = T(w.type, w.data, K, N), X = T(CLLM_TYPE_F32, x, K, qlen), Y = T(CLLM_TYPE_F32, y, N, qlen);
@@ -318,9 +319,12 @@ static int forward_general(cllm_llama * m, int qlen, int n_past) {
     for (int il = 0; il < c.n_layer; il++) {
         llama_layer & L = m->layers[il];
         cllm_tensor wn = T(CLLM_TYPE_F32, L.attn_norm.data, H);
-        TRY(cllm_op_rms_norm_mul(st, &X, &wn, &XN, c.rms_eps));
         float * q = m->qkv, * k = m->qkv + QD, * v = m->qkv + QD + KD;     // row slices of the fused projection output
-        if (L.wqkv.data) TRY(linear(m, L.wqkv, H, QKV, m->xn, qlen, m->qkv));
+        int nrc = L.wqkv.data && H <= 16384 ? linear_ex(m, L.wqkv, H, QKV, m->x, qlen, m->qkv, 1, nullptr, (const float *) L.attn_norm.data) : CLLM_E_UNSUPPORTED;      // norm in the quantizer
+        if (nrc != CLLM_OK && nrc != CLLM_E_UNSUPPORTED) return nrc;
+        if (nrc == CLLM_E_UNSUPPORTED) TRY(cllm_op_rms_norm_mul(st, &X, &wn, &XN, c.rms_eps));
+        if (nrc == CLLM_OK) {}
+        else if (L.wqkv.data) TRY(linear(m, L.wqkv, H, QKV, m->xn, qlen, m->qkv));
         else {   // mixed-type q/k/v: three launches into strided slices
             for (int p = 0; p < 3; p++) {
                 const dweight & w = p == 0 ? L.wq : p == 1 ? L.wk : L.wv; const int64_t N = p == 0 ? QD : KD;
@@ -337,6 +341,10 @@ static int forward_general(cllm_llama * m, int qlen, int n_past) {
                 TRY(cllm_op_add(st, &Y, &B, &Y));
             }
         }
+        // RoPE + the cache writes: one launch (the same bits as the four below); CLLM_NO_PREFILL_FUSE: the node sequence
+        const bool rope_fused = !getenv("CLLM_NO_PREFILL_FUSE") && qlen > 1;
+        if (rope_fused) TRY(launch_rope_kv_store((hipStream_t) st, m->qkv, QKV, m->pos_dev, qlen, (int) nh, (int) nkv, (int) hd, c.rope_mode, c.rope_theta, L.k_cache, L.v_cache, ML));
+        else {
         // RoPE in place: k then q  ([hd, heads, qlen] views of the fused buffer)
         cllm_tensor Kt = TS(CLLM_TYPE_F32, k, hd, nkv, qlen, (size_t) hd * 4, (size_t) QKV * 4);
         cllm_tensor Qt = TS(CLLM_TYPE_F32, q, hd, nh,  qlen, (size_t) hd * 4, (size_t) QKV * 4);
@@ -351,6 +359,7 @@ static int forward_general(cllm_llama * m, int qlen, int n_past) {
             cllm_tensor Vt = T(CLLM_TYPE_F32, v, qlen, KD); Vt.nb[0] = (size_t) QKV * 4; Vt.nb[1] = 4; Vt.nb[2] = Vt.nb[3] = (size_t) QKV * 4 * qlen;
             cllm_tensor Vc = TS(CLLM_TYPE_F16, L.v_cache + n_past, qlen, KD, 1, (size_t) ML * 2, (size_t) ML * 2 * KD);
             TRY(cllm_op_cpy(st, &Vt, &Vc));
+        }
         }
         // scores = K^T Q ; scale ; mask ; softmax ; ctx = V P
         {
@@ -386,8 +395,15 @@ static int forward_general(cllm_llama * m, int qlen, int n_past) {
         }
 
         cllm_tensor wf = T(CLLM_TYPE_F32, L.ffn_norm.data, H);
-        TRY(cllm_op_rms_norm_mul(st, &X, &wf, &XN, c.rms_eps));
         int drc = CLLM_E_UNSUPPORTED;
+        if (L.wgu.data && !tp_on(m) && H <= 16384) {       // norm in the gate/up quantizer; SiLU * up in down's quantizer (a memory-bound pass: the same work in the
+            // gate/up GEMM's epilogue, epi 1, costs its VALU-bound main loop more than the smaller store saves: 131.5 vs 129.x ms); the residual add in down's epilogue
+            drc = linear_ex(m, L.wgu, H, 2*F, m->x, qlen, m->gu, 1, nullptr, (const float *) L.ffn_norm.data);
+            if (drc == CLLM_OK) drc = linear_ex(m, L.wdown, F, H, m->gu, qlen, m->x, 3, m->x);
+            if (drc != CLLM_OK && drc != CLLM_E_UNSUPPORTED) return drc;
+        }
+        if (drc == CLLM_OK) continue;
+        TRY(cllm_op_rms_norm_mul(st, &X, &wf, &XN, c.rms_eps));
         if (L.wgu.data) {
             TRY(linear(m, L.wgu, H, 2*F, m->xn, qlen, m->gu));
             if (!tp_on(m)) drc = linear_ex(m, L.wdown, F, H, m->gu, qlen, m->x, 3, m->x);      // x = wdown . (silu(gate) * up) + x: SiLU*up in the quantizer, the add in the epilogue

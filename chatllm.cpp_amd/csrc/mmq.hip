@@ -42,6 +42,7 @@ struct mmq_args {
     const char * act; size_t act_stride; int64_t M;
     float * dst; int64_t ldd;     // dst[m * ldd + n]
     const float * resid; int64_t ldr;      // optional: dst = acc + resid[m * ldr + n] (the MUL_MAT -> ADD pair; resid may be dst itself)
+    int epi;                               // 1: weight rows alternate gate_u, up_u; dst[m * ldd + u] = silu(acc[2u]) * acc[2u + 1]  (UNARY(SILU) -> MUL of BaseMLP::forward)
 };
 
 // LDS map (bytes)
@@ -306,6 +307,22 @@ __global__ void __launch_bounds__(mmq_traits<TYPE>::NW * 64, mmq_traits<TYPE>::N
         }
     }
     // ---- epilogue: dst[m][n] ----
+    if (a.epi == 1) {                      // the lane pair (2u, 2u + 1) holds gate_u and up_u of the same tokens: the even lane takes its neighbour's value and stores
+        const int64_t nv = (a.N / 2) & ~(int64_t) 7;               // ggml_vec_silu_f32: polynomial body below nv, libm tail (rows of a.N / 2 features)
+#pragma unroll
+        for (int i = 0; i < MMQ_MI; i++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int64_t n = n0 + wn + j * 16 + l15, u = n >> 1;
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const int64_t m = m0 + wm + i * 16 + l4 * 4 + r;
+                    const float up = dpp_f<DPP_QUAD_XOR1>(acc_f[i][j][r]);
+                    if (!(lane & 1) && n + 1 < a.N && m < a.M) a.dst[m * a.ldd + u] = silu_any(acc_f[i][j][r], u < nv) * up;
+                }
+            }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < MMQ_MI; i++)
 #pragma unroll
@@ -319,13 +336,14 @@ __global__ void __launch_bounds__(mmq_traits<TYPE>::NW * 64, mmq_traits<TYPE>::N
         }
 }
 
-int launch_mmq(hipStream_t st, int wtype, const tview & w, const void * act, size_t act_stride, const tview & x, const tview & d, const float * resid, int64_t ldr) {
+int launch_mmq(hipStream_t st, int wtype, const tview & w, const void * act, size_t act_stride, const tview & x, const tview & d, const float * resid, int64_t ldr, int epi) {
     if (getenv("CLLM_NO_MMQ")) return CLLM_E_UNSUPPORTED;
     if (d.nb[1] % 4) FAIL(CLLM_E_INVALID, "mmq: dst stride");
     mmq_args a;
     a.W = w.data; a.nb01 = w.nb[1]; a.N = w.ne[1]; a.K = w.ne[0];
     a.act = (const char *) act; a.act_stride = act_stride; a.M = x.ne[1];
-    a.dst = (float *) d.data; a.ldd = d.nb[1] / 4; a.resid = resid; a.ldr = ldr;
+    a.dst = (float *) d.data; a.ldd = d.nb[1] / 4; a.resid = resid; a.ldr = ldr; a.epi = epi;
+    if (epi && (epi != 1 || resid || a.N % 2)) FAIL(CLLM_E_INVALID, "mmq: epilogue %d", epi);
     if ((a.N + MMQ_BN - 1) / MMQ_BN > 65535) FAIL(CLLM_E_UNSUPPORTED, "mmq: too many row tiles");
 #define GO(T) do { static bool attr = false; \
         constexpr int BM = (mmq_traits<T>::NW / 2) * 16 * mmq_traits<T>::MI, LDS = lds_total(BM, T == CLLM_TYPE_Q4_1); \

@@ -131,6 +131,54 @@ extern "C" int cllm_op_rope(void * stream, const cllm_tensor * src, const cllm_t
     return CLLM_OK;
 }
 
+// The runner's prefill: ROPE(k) -> SET_ROWS(k_cache), TRANSPOSE(v) -> CPY(v_cache column), ROPE(q) of one token per workgroup in ONE launch
+// (KVCacheAttention::forward src/layers.cpp:2925-2945, 3082-3093).  The cos / sin values, the rotation and the fp32 -> fp16 conversions are those of
+// k_rope / k_set_rows / k_cpy above (plain RoPE: no frequency factors, freq_scale 1, no YaRN -- the cllm_llama configuration): same bits in q and in
+// the caches.  qkv: [q | k | v] rows of QKV floats per token; q is rotated in place, k and v are only read.
+__global__ void __launch_bounds__(256) k_rope_kv_store(float * __restrict__ qkv, int64_t QKV, const int32_t * __restrict__ pos, int nh, int nkv, int hd, int mode, float theta_scale,
+                                                       uint16_t * __restrict__ k_cache, uint16_t * __restrict__ v_cache, int64_t ML) {
+    extern __shared__ float cache[];                 // [hd]: cos, sin interleaved
+    const int64_t tok = blockIdx.x;
+    const int half = hd / 2, p = pos[tok];
+    for (int i = threadIdx.x; i < half; i += blockDim.x) {
+        float theta = (float) p;
+        for (int k = 0; k < i; k++) theta *= theta_scale;
+        float cs, sn;
+        rope_cos_sin(theta, &cs, &sn);
+        cache[2*i] = cs; cache[2*i + 1] = sn;
+    }
+    __syncthreads();
+    const int64_t QD = (int64_t) nh * hd, KD = (int64_t) nkv * hd;
+    const int off = mode == 0 ? 1 : half;
+    float * q = qkv + tok * QKV;
+    const float * k = q + QD, * v = k + KD;
+    for (int t = threadIdx.x; t < nh * half; t += blockDim.x) {
+        const int h = t / half, i = t % half, ic = mode == 0 ? 2*i : i;
+        const float c = cache[2*i], sn = cache[2*i + 1];
+        float * x = q + (int64_t) h * hd;
+        const float x0 = x[ic], x1 = x[ic + off];
+        x[ic] = rope_rot_a(x0, x1, c, sn); x[ic + off] = rope_rot_b(x0, x1, c, sn);
+    }
+    if (p < 0 || p >= ML) return;                    // (the CPU asserts; never write out of bounds)
+    uint16_t * kr = k_cache + (int64_t) p * KD;
+    for (int t = threadIdx.x; t < nkv * half; t += blockDim.x) {
+        const int h = t / half, i = t % half, ic = mode == 0 ? 2*i : i;
+        const float c = cache[2*i], sn = cache[2*i + 1];
+        const float * x = k + (int64_t) h * hd;
+        const float x0 = x[ic], x1 = x[ic + off];
+        kr[(int64_t) h * hd + ic] = f2h(rope_rot_a(x0, x1, c, sn)); kr[(int64_t) h * hd + ic + off] = f2h(rope_rot_b(x0, x1, c, sn));
+    }
+    for (int64_t d = threadIdx.x; d < KD; d += blockDim.x) v_cache[d * ML + p] = f2h(v[d]);
+}
+int launch_rope_kv_store(hipStream_t st, float * qkv, int64_t QKV, const int32_t * pos, int64_t n_tok, int nh, int nkv, int hd, int mode, float freq_base,
+                         void * k_cache, void * v_cache, int64_t ML) {
+    if ((mode != 0 && mode != 2) || hd <= 0 || (hd & 1) || n_tok <= 0) return CLLM_E_UNSUPPORTED;
+    hipLaunchKernelGGL(k_rope_kv_store, dim3((unsigned) n_tok), dim3(256), (size_t) hd * 4, st, qkv, QKV, pos, nh, nkv, hd, mode, powf(freq_base, -2.0f / hd),
+                       (uint16_t *) k_cache, (uint16_t *) v_cache, ML);
+    LAUNCH_CHECK();
+    return CLLM_OK;
+}
+
 // ================================================================================================
 // SOFT_MAX (+ SCALE + DIAG_MASK_INF)   ggml_compute_forward_soft_max_f32 ops.cpp:5225-5335,
 //   ggml_vec_soft_max_f32 vec.cpp:547- (groups of 8 through ggml_v_expf, f32 tree hsum, total in double; expf tail)

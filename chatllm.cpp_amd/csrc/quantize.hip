@@ -70,6 +70,47 @@ static int quantize_act_impl(hipStream_t st, int kind, const tview & s, void * a
 int launch_quantize_act(hipStream_t st, int kind, const tview & s, void * act, size_t act_stride) { return quantize_act_impl<false>(st, kind, s, act, act_stride); }
 int launch_quantize_act_silu(hipStream_t st, int kind, const tview & s, void * act, size_t act_stride) { return quantize_act_impl<true>(st, kind, s, act, act_stride); }
 
+// RMS_NORM -> MUL(weight) -> quantize of whole rows in one pass (the input_layernorm / post_attention_layernorm in front of a prefill MUL_MAT,
+// LMBlock1Forward src/layers.cpp:2730-2760): one 1024-thread workgroup per row; the sum of squares, the scale and the two multiplications are those of
+// k_rms_norm<true> (ops.hip) on the same values, the quantizer is the one above: the act row is bit-identical to the two launches.  K <= 16384, K % 4 == 0.
+template <int KIND, bool Q81>
+__global__ void __launch_bounds__(1024) k_rms_norm_quantize(const char * __restrict__ src, int64_t K, int64_t ne1, int64_t ne2, int64_t nb1, int64_t nb2, int64_t nb3,
+                                                           const float * __restrict__ w, float eps, char * __restrict__ act, size_t act_stride) {
+    const int64_t row = blockIdx.x;
+    const int64_t i1 = row % ne1, i2 = (row / ne1) % ne2, i3 = row / (ne1 * ne2);
+    const float * x = (const float *)(src + i1*nb1 + i2*nb2 + i3*nb3);
+    __shared__ double part[16];
+    const int tid = threadIdx.x, lane = tid & 63;
+    f32x4 vv[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) { const int64_t e = (int64_t) tid * 4 + u * 4096; vv[u] = e < K ? *(const f32x4 *)(x + e) : f32x4{0, 0, 0, 0}; }
+    const double sum = rms_block_sumsq_1024(x, K, vv[0], part);
+    const float scale = rms_scale(sum, K, eps);
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+        const int64_t e = (int64_t) tid * 4 + u * 4096;
+        if (e < K) {
+            const f32x4 g = *(const f32x4 *)(w + e);
+            f32x4 v = vv[u];
+            v.x = (v.x * scale) * g.x; v.y = (v.y * scale) * g.y; v.z = (v.z * scale) * g.z; v.w = (v.w * scale) * g.w;
+            quant4_store<KIND, Q81>(act + row * act_stride, K, e, lane, v);
+        }
+    }
+}
+int launch_quantize_act_norm(hipStream_t st, int kind, const tview & s, const float * norm_w, float eps, void * act, size_t act_stride) {
+    const int kind_blk = act_blk(kind);
+    const int64_t K = s.ne[0], rows = s.ne[1] * s.ne[2] * s.ne[3];
+    if (K % kind_blk || K % 4 || K > 16384 || ((uintptr_t) s.data & 15) || s.nb[1] % 16 || s.nb[2] % 16 || s.nb[3] % 16 || ((uintptr_t) norm_w & 15)) return CLLM_E_UNSUPPORTED;
+    if (rows <= 0 || K <= 0) return CLLM_OK;
+    const dim3 grid((unsigned) rows);
+    if (kind_blk == 32) {
+        if (kind == ACT_Q8_1) hipLaunchKernelGGL((k_rms_norm_quantize<32, true>),  grid, dim3(1024), 0, st, s.data, K, s.ne[1], s.ne[2], s.nb[1], s.nb[2], s.nb[3], norm_w, eps, (char *) act, act_stride);
+        else                  hipLaunchKernelGGL((k_rms_norm_quantize<32, false>), grid, dim3(1024), 0, st, s.data, K, s.ne[1], s.ne[2], s.nb[1], s.nb[2], s.nb[3], norm_w, eps, (char *) act, act_stride);
+    } else hipLaunchKernelGGL((k_rms_norm_quantize<256, false>), grid, dim3(1024), 0, st, s.data, K, s.ne[1], s.ne[2], s.nb[1], s.nb[2], s.nb[3], norm_w, eps, (char *) act, act_stride);
+    LAUNCH_CHECK();
+    return CLLM_OK;
+}
+
 // ---- KAT surface: act row -> reference block layout ------------------------------------------------
 __global__ void k_act_to_q8_0_blocks(const char * __restrict__ act, int64_t K, block_q8_0 * __restrict__ y) {
     const int64_t b = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;

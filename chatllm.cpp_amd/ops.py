@@ -37,6 +37,19 @@ def mul_mat(a, b, dst=None):
     return dst
 
 
+def mul_mat_ex(a, b, pro=0, norm_w=None, eps=0.0, epi=0, resid=None, dst=None):
+    """the prefill form of the node patterns around a quantized MUL_MAT (cllm_op_mul_mat_ex): norm / SiLU*up prologue, SiLU*up / residual epilogue"""
+    L = _l.get()
+    K = a.ne[0]
+    if dst is None:
+        dst = Tensor(F32, [a.ne[1] // 2 if epi else a.ne[1], b.ne[1]])
+    geom = Tensor(F32, [K, b.ne[1]]) if pro == 3 else b                      # (only its shape is used: the scratch size)
+    ws = L.cllm_mul_mat_wsize(_ref(a), _ref(geom))
+    buf = _scratch(ws)
+    _l.check(L.cllm_op_mul_mat_ex(None, _ref(a), _ref(b), _ref(dst), buf.ptr, buf.nbytes, pro, _ref(norm_w), float(eps), epi, _ref(resid)), "mul_mat_ex")
+    return dst
+
+
 def mul_mat_id(as_, b, ids, dst=None):
     """ggml::mul_mat_id(ctx, as, b, ids)"""
     L = _l.get()

@@ -108,13 +108,16 @@ CLLM_API size_t cllm_mul_mat_wsize(const cllm_tensor * src0, const cllm_tensor *
 CLLM_API int    cllm_op_mul_mat(void * stream, const cllm_tensor * src0, const cllm_tensor * src1, cllm_tensor * dst,
                                 void * wdata, size_t wsize);
 
-/* The prefill form of the node patterns around a quantized MUL_MAT (BaseMLP::forward / the residual adds of LMBlock1Forward, src/layers.cpp:2475-2483, 2719-):
- *   pro 0: MUL_MAT(src0, src1)                      pro 3: src1 holds 2 K interleaved (gate_e, up_e) pairs per row; the mat-mul runs over silu(gate) * up
- *   resid != NULL: ... -> ADD(resid)  (resid F32 of dst's shape; may be dst itself)
- * Only for src1->ne[1] >= the matrix-core threshold (33 columns; CLLM_E_UNSUPPORTED below: the caller issues the nodes).  The fused quantizer and the
- * epilogue add produce the bits of the separate SiLU / MUL / quantize / ADD passes. */
+/* The prefill form of the node patterns around a quantized MUL_MAT (LMBlock1Forward / BaseMLP::forward, src/layers.cpp:2475-2483, 2719-2760):
+ *   pro 0: MUL_MAT(src0, src1)
+ *   pro 1: RMS_NORM(src1, eps) -> MUL(norm_w) -> MUL_MAT       (norm_w: dense F32 [K]; the normalised activation is never stored)
+ *   pro 3: src1 holds 2 K interleaved (gate_e, up_e) pairs per row; the mat-mul runs over silu(gate) * up
+ *   epi 1: src0's rows alternate gate_u, up_u (cllm_pack_rows, interleave); dst F32 [N / 2, M] = silu(gate_u . x) * (up_u . x)   (MUL_MAT x 2 -> UNARY(SILU) -> MUL)
+ *   resid != NULL (epi 0): ... -> ADD(resid)  (resid F32 of dst's shape; may be dst itself)
+ * Only for src1->ne[1] >= the matrix-core threshold (33 columns; CLLM_E_UNSUPPORTED below it: the caller issues the nodes).  The fused quantizers and
+ * epilogues produce the bits of the separate RMS_NORM / MUL / SiLU / quantize / ADD passes. */
 CLLM_API int    cllm_op_mul_mat_ex(void * stream, const cllm_tensor * src0, const cllm_tensor * src1, cllm_tensor * dst, void * wdata, size_t wsize,
-                                   int pro, const cllm_tensor * resid);
+                                   int pro, const cllm_tensor * norm_w, float eps, int epi, const cllm_tensor * resid);
 
 /* One launch for a node pattern around a single-column quantized MUL_MAT -- what a ggml backend's graph_compute can fuse
  * (chatllm.cpp_amd/host/ggml-hip.cpp does, with ggml's use counts):

@@ -379,6 +379,36 @@ def test_mul_mat_id_silu_mul_equals_the_four_nodes(gpu, t, K, F, E, k):
     assert np.array_equal(got.view(np.uint32).reshape(-1), want.view(np.uint32).reshape(-1))
 
 
+@pytest.mark.parametrize("t,K,N,M", [(O.Q4_0, 4096, 512, 200), (O.Q4_K, 2048, 256, 77), (O.Q8_0, 512, 136, 64), (O.Q4_1, 1024, 264, 130), (O.Q4_K, 8192, 128, 40)])
+def test_mul_mat_ex_equals_the_node_sequences(gpu, t, K, N, M):
+    """cllm_op_mul_mat_ex (prefill): the norm prologue, the SiLU * up prologue / epilogue and the residual epilogue against the separate launches, bit for bit"""
+    ops, T = gpu.ops, gpu.Tensor
+    w = T.from_numpy(rand_blocks(t, N, K, rng), t, [K, N])
+    xh = rng.standard_normal((M, K)).astype(np.float32)
+    x = T.from_numpy(xh); g = T.from_numpy((1.0 + 0.1 * rng.standard_normal(K)).astype(np.float32))
+    bits = lambda a: a.numpy().view(np.uint32).reshape(-1)
+    # RMS_NORM -> MUL -> MUL_MAT
+    want = ops.mul_mat(w, ops.rms_norm_mul(x, g, 1e-5))
+    assert np.array_equal(bits(ops.mul_mat_ex(w, x, pro=1, norm_w=g, eps=1e-5)), bits(want))
+    # ... -> ADD(resid), in place on the residual
+    r = T.from_numpy(rng.standard_normal((M, N)).astype(np.float32))
+    want_r = ops.add(ops.mul_mat(w, x), r)
+    r2 = T.from_numpy(r.numpy())
+    ops.mul_mat_ex(w, x, resid=r2, dst=r2)
+    assert np.array_equal(bits(r2), bits(want_r))
+    # rows alternate gate_u, up_u: MUL_MAT -> (even, odd) -> SILU -> MUL in the epilogue; with the norm prologue in front
+    y = ops.mul_mat(w, ops.rms_norm_mul(x, g, 1e-5))                              # [N, M]: gate at even, up at odd features
+    gate = y.view([N // 2, M], [8, y.nb[1]], offset=0); up = y.view([N // 2, M], [8, y.nb[1]], offset=4)
+    want_s = ops.mul(ops.silu(ops.cont(gate)), ops.cont(up))
+    assert np.array_equal(bits(ops.mul_mat_ex(w, x, pro=1, norm_w=g, eps=1e-5, epi=1)), bits(want_s))
+    # the SiLU * up quantizer prologue (interleaved pairs in src1)
+    if K * 2 <= 8192:
+        x2 = T.from_numpy(rng.standard_normal((M, 2 * K)).astype(np.float32))
+        ge = x2.view([K, M], [8, x2.nb[1]], offset=0); ue = x2.view([K, M], [8, x2.nb[1]], offset=4)
+        want_p = ops.mul_mat(w, ops.mul(ops.silu(ops.cont(ge)), ops.cont(ue)))
+        assert np.array_equal(bits(ops.mul_mat_ex(w, x2, pro=3)), bits(want_p))
+
+
 @pytest.mark.parametrize("t,K,ne,k", [(O.Q4_K, 4096, 8, 2), (O.Q4_K, 256, 8, 2), (O.Q8_0, 512, 4, 2), (O.Q4_0, 1024, 16, 3), (O.Q4_1, 256, 60, 6),
                                       (O.Q4_K, 14336, 64, 8), (O.Q4_0, 4096, 7, 1), (O.Q8_0, 8192, 33, 4)])
 def test_moe_router_equals_the_node_sequence(gpu, t, K, ne, k):
@@ -529,7 +559,7 @@ def test_rope_kv_attn_decode_equals_the_node_sequence(gpu, hd, nh, nkv, ML, n_pa
     if n_kv <= 1024:
         assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
     else:       # the split long-context kernels keep their own fp32 summation order (the reference's serial chains over n_kv do not spread over the chip)
-        assert rel_err(got, want) < 3e-4
+        assert rel_err(got, want) < 6e-4                 # (P is rounded to fp16 before the P.V product: 2^-11 relative per probability)
 
 
 def test_rope_kv_attn_decode_rejects_what_it_cannot_do(gpu):
