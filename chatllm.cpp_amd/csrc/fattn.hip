@@ -30,7 +30,9 @@ typedef float    f32x16 __attribute__((ext_vector_type(16)));
 
 #define FA_VSTR 136                  // bytes per V^T row in LDS: 64 positions * 2 B + 8 B (conflict-free ds_read_b64 over 32 rows)
 #define FA_LOG2E 1.4426950408889634f
-#define FA_PD 4                      // LDS fragment reads are issued this many MFMAs ahead
+#ifndef FA_PD
+#define FA_PD 4                      // LDS fragment reads are issued this many MFMAs ahead (2 and 8 measured the same: the loop is not latency-bound any more)
+#endif
 #define FA_TAU 8.0f                  // lazy soft-max reference: rescale only when a maximum grows by more than 2^8
 #define FA_MAX_SPLITS 256            // split-KV decode: at most this many partials per (head, query)
 

@@ -27,6 +27,6 @@ python $R/tools/kq_bench.py > $O/k_quants_gemv.txt 2>&1
 ( cd $R && LAYERS=4 bash tools/prof_prefill.sh round_r2_prefill > /dev/null 2>&1; cp $R/gpurun_out/round_r2_prefill/prefill_kernel_stats.csv $O/prefill_kernel_stats.csv )
 ( cd $R && bash tools/pmc_kernel.sh "k_gemv_dec<12, 1, 1, 1" round_r2_pmc -- python $R/tools/gemv_bench.py --fused --types q4_k --shapes gate_up_silu --iters 8 > /dev/null 2>&1; cp $R/gpurun_out/round_r2_pmc/pmc.txt $O/pmc_sq_gate_up.txt )
 ( NS="144 400 144" bash $R/tools/dropin_bench.sh; echo "--- -fa 1 (FLASH_ATTN_EXT on the module) ---"; REF_CHAT_FA=1 NS="144 400" bash $R/tools/dropin_bench.sh; echo "--- -fa 1 --cache_dtype q8_0 ---"; REF_CHAT_FA=1 REF_CHAT_CACHE=q8_0 NS="144" bash $R/tools/dropin_bench.sh ) > $O/dropin_reference_host.txt 2>&1
-( N=144 bash $R/tools/dropin_mixtral.sh ) > $O/dropin_mixtral.txt 2>&1
+( bash $R/tools/dropin_mixtral.sh ) > $O/dropin_mixtral.txt 2>&1
 $R/oracle/_ref/ref_backend_async $R/oracle/_ref/libggml-hip.so 4194304 > $O/backend_async_events.txt 2>&1
 tail -c 600 $O/bench.json; cat $O/decode_step_trace.txt | head -12; cat $O/pmc_summary.json | head -20
