@@ -1,242 +1,10 @@
-// gemv_decode.hip -- the decode step's quantized mat-vec (Q4_K / Q4_0 / Q4_1 / Q8_0 weights): one activation column, produced inside the kernel.
-//
-//   prologue PRO 1: act = quantize_q8_K(RMS_NORM(px) * pw)     (LMBlock1Forward: input_layernorm / post_attention_layernorm -> Linear)
-//            PRO 2: act = quantize_q8_K(px)                    (attention output -> o_proj, SiLU*up -> down_proj)
-//            PRO 3: act = quantize_q8_K(silu(px[2i]) * px[2i+1])  (interleaved gate/up pairs -> down_proj, BaseMLP::forward)
-//            PRO 4: act = quantize_q8_K(silu(px[i]) * pw[i])      (separate gate / up vectors: the reference's own graph, fused by the module)
-//   epilogue EPI 1: W rows alternate gate_u, up_u; dst[u] = silu(W[2u].act) * (W[2u+1].act)
-//            EPI 3: MUL_MAT_ID(down experts) of one token with TWO slots + the block's tail (GenericSparseMLP::forward src/layers.cpp:3840-3872): a unit is
-//                   one output row, its two sub-rows are the two picked experts' rows over the two slots' activations;
-//                   dst[r] = (y0[r] * w0 + y1[r] * w1) (+ resid[r]), w = probs[ids] / (probs[ids[0]] + probs[ids[1]])   (pw = probs, ids = the TOP_K output)
-//            EPI 2: the sparse-MoE router (GenericSparseMLP::forward src/layers.cpp:3792-3830): ONE workgroup; the rows are the experts' logits,
-//                   dst = SOFT_MAX(logits), r_ids = TOP_K(dst, r_k), xout = the normalised activation (the experts' input)
-//   dst[r] = W[r] . act (+ bias[r]) (+ resid[r])               (Linear::forward src/layers.cpp:2111-2129, residual adds :2740,:2758)
-// Same arithmetic as RMS_NORM -> MUL -> quantize_row_q8_K -> MUL_MAT (-> ADD) on the node-by-node path, bit for bit:
-// the reductions (rms_block_sumsq_1024, quant4_q8_K, q4k_step, wave_sum) are the shared definitions.
-//
-// What shapes this kernel (measured with the in-kernel stamps of tools/gemv_phase_probe.py):
-//   * a launch starts with a cold instruction cache and its instruction fetches queue behind its own weight stream, so
-//     everything before the main loop is kept short: the prologue is a template parameter (no code for the others), nothing
-//     is divided at run time (the dealing of rows to waves is precomputed on the host), the arguments are individual
-//     kernel parameters in the order they are needed;
-//   * the activation loads are issued first, then two steps of weight prefetch, then the prologue computes while they fly
-//     (a deeper burst only delays the prologue: 16 waves x 16 loads take 1.7 us just to issue);
-//   * one 1024-thread workgroup per CU: 16 waves share one prologue; steady state keeps two steps per wave in flight and
-//     streams at ~6.2 TB/s.
-#include "common.h"
-#include "quant_dev.h"
-#include "q4k.h"
-#include "q32.h"
+// gemv_decode.hip -- the launchers of the decode step's quantized mat-vec (the kernel: gemv_decode_kernel.h).  The sparse-MoE forms (router, down + combine)
+// are instantiated in gemv_moe.hip: their code stays out of this code object, whose layout the decode step's launch-to-launch time is sensitive to
+// (the same kernels, bit for bit, measured 1.8 % slower per decode step with the MoE instantiations placed among them).
+#include "gemv_decode_kernel.h"
 
 static unsigned long long * g_gemv_ts = nullptr;
 extern "C" __attribute__((visibility("default"))) void cllm_debug_set_mmvq_ts(unsigned long long * dev_buf) { g_gemv_ts = dev_buf; }   // tools only
-
-// The kernel parameters are individual scalars in the order the kernel needs them: the first 16 dwords are preloaded into
-// SGPRs at wave launch (-mllvm -amdgpu-kernarg-preload-count=16), so the activation loads do not wait for a kernarg fetch.
-//   units = rows (or gate/up row pairs), dealt as kfull full rounds of nwaves units + nrem (host-computed: no division here)
-
-
-#define TS(k) do { if (ts && threadIdx.x == 0) ts[blockIdx.x * 8 + (k)] = wall_clock64(); } while (0)
-
-// FMT: CLLM_TYPE_Q4_K (8 lanes per 144-byte super-block, activation quantized to Q8_K) or CLLM_TYPE_Q4_0 / Q4_1 / Q8_0 (one lane per
-// 18 / 20 / 34-byte block, activation quantized to Q8_0 / Q8_1).  nblk = weight blocks per row.
-// MOE (MUL_MAT_ID for one token, ggml_compute_forward_mul_mat_id ggml-cpu.c:1432-1678): blockIdx.y is the slot; the slot's expert comes from
-// device memory (ids[slot], the TOP_K node's output), W / px / dst move by the slot: dst[:, slot] = W[:, :, ids[slot]]^T . x[:, slot or 0]
-template <int FMT, int PRO, int EPI, int NPRE, bool MOE = false>
-__global__ void __launch_bounds__(1024) k_gemv_dec(const float * __restrict__ px, const float * __restrict__ pw, const float * __restrict__ padd,
-                                                        const char * __restrict__ W, int nblk, int kfull, int nrem, float eps,
-                                                        float * __restrict__ dst, float * __restrict__ xout,
-                                                        const float * __restrict__ bias, const float * resid, unsigned long long * ts,
-                                                        const int32_t * __restrict__ ids, unsigned long long w_expert_bytes, int px_slot_stride, int dst_slot_stride,
-                                                        int32_t * __restrict__ r_ids, int r_k) {
-    extern __shared__ __attribute__((aligned(16))) char lds[];
-    __shared__ float r_logit[EPI == 2 ? 64 : 1], r_prob[EPI == 2 ? 64 : 1];
-    if constexpr (MOE) {
-        int e;
-        asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(e) : "s"(ids + blockIdx.y) : "memory");
-        W += (unsigned long long)(unsigned) e * w_expert_bytes;
-        px += (long) blockIdx.y * px_slot_stride; dst += (long) blockIdx.y * dst_slot_stride;
-    }
-    const char * W0 = W, * W1 = W;
-    float cw0 = 0.0f, cw1 = 0.0f;
-    if constexpr (EPI == 3) {
-        int e0, e1;
-        asm volatile("s_load_dword %0, %2, 0x0\n\ts_load_dword %1, %2, 0x4\n\ts_waitcnt lgkmcnt(0)" : "=&s"(e0), "=&s"(e1) : "s"(ids) : "memory");
-        W0 = W + (unsigned long long)(unsigned) e0 * w_expert_bytes; W1 = W + (unsigned long long)(unsigned) e1 * w_expert_bytes;
-        const float p0 = uniform_load_f32(pw + e0), p1 = uniform_load_f32(pw + e1);      // k_moe_combine's order: double sum from 0, IEEE divisions
-        const float sum = (float)(((double) 0.0 + (double) p0) + (double) p1);
-        cw0 = __fdiv_rn(p0, sum); cw1 = __fdiv_rn(p1, sum);
-    }
-#ifndef GEMV_P
-#define GEMV_P 2
-#endif
-    constexpr int P = (FMT == CLLM_TYPE_Q4_K) ? (GEMV_P + 1) / 2 : GEMV_P, RU = (EPI == 1 || EPI == 3) ? 2 : 1;      // steps of prefetch (a Q4_K step is 16 super-blocks = 2304 B per wave, the others' 64 blocks)
-    constexpr bool IS_K = FMT == CLLM_TYPE_Q4_K, IS_Q8 = FMT == CLLM_TYPE_Q8_0, IS_Q41 = FMT == CLLM_TYPE_Q4_1;
-    constexpr int KIND = IS_K ? 256 : 32;                           // elements per weight block = activation quantization block
-    constexpr int BS = IS_K ? 144 : q32_fmt<IS_K ? CLLM_TYPE_Q4_0 : FMT>::BS;      // bytes per weight block
-    constexpr int BPS = IS_K ? 16 : 64;                             // blocks a wave consumes per step (Q4_K: 4 lanes per super-block, q4k_emit4)
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int K = nblk * KIND;
-
-    // ---- (1) this thread's activation groups: unconditional (clamped) loads, issued before anything else ----
-    // pro 3: px holds interleaved (gate_e, up_e) pairs -- two 16-byte loads cover this thread's four features
-    const float * gp = (PRO == 1 || PRO == 4) ? pw : PRO == 3 ? px + 4 : px;
-    constexpr int vmul = PRO == 3 ? 2 : 1;
-    const int e0 = tid * 4;
-    f32x4 vv[NPRE], gg[(PRO != 2 || EPI == 3) ? NPRE : 1];      // (EPI 3: gg = the second slot's activation)
-#pragma unroll
-    for (int u = 0; u < NPRE; u++) {
-        const int e = e0 + u * 4096, ec = e < K ? e : 0;
-        vv[u] = *(const f32x4 *)(px + ec * vmul);
-        if (PRO != 2) gg[u] = *(const f32x4 *)(gp + ec * vmul);
-        if (EPI == 3) gg[u] = *(const f32x4 *)(px + px_slot_stride + ec);
-    }
-    // tensor parallel (PRO 1, NPRE 1): the all-reduced partial of the previous mat-vec is added to the residual stream here
-    // (x + padd feeds the norm; workgroup 0 stores it to xout, a different buffer than px) instead of in a launch of its own
-    f32x4 pa = {0, 0, 0, 0};
-    const bool add = PRO == 1 && NPRE == 1 && padd != nullptr;
-    if (add) pa = *(const f32x4 *)(padd + (e0 < K ? e0 : 0));
-    TS(0);
-
-    // ---- (2) two steps of weight prefetch.  Units are dealt in rounds of nwaves: in a full round wave (b, w) takes unit
-    //          round*nwaves + 16 b + w (a workgroup streams 16 consecutive rows); the last, partial round is dealt
-    //          workgroup-interleaved (w * gridDim + b) so that every CU gets the same share of it. ----
-    const int grp = IS_K ? lane >> 2 : lane >> 3, j = IS_K ? lane & 3 : lane & 7;
-    const int wave_in_wg = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int nwaves = gridDim.x * 16;
-    const int lin = blockIdx.x * 16 + wave_in_wg, alt = wave_in_wg * gridDim.x + blockIdx.x;
-    const int nmine = kfull + (alt < nrem ? 1 : 0);
-    const int S = (nblk + BPS - 1) / BPS;                           // steps per row
-    const unsigned nb01 = (unsigned) nblk * (unsigned) BS;
-    auto unit_of = [&](int k) { return k * nwaves + (k < kfull ? lin : alt); };
-    // per step and lane: Q4_K header (hh) + 16 quant bytes (qq); Q4_0 / Q8_0: fp16 scale (hh.x) + 16 (qq) [+ 16 (q2)] quant bytes
-    u32x4 hh[P], qq[P], q2[(IS_Q8 || IS_K) ? P : 1];
-    int ik = 0, isub = 0, is = 0;                                   // issue cursor: (unit ordinal, row of the unit, step of the row)
-    auto issue = [&](int p) {                                       // unconditional: out-of-range steps re-read block 0 and are masked
-        const int b = IS_K ? 16 * is + grp : 64 * is + lane;
-        const bool ok = ik < nmine && b < nblk;
-        const char * bp = W;
-        if (EPI == 3) { if (ok) bp = (isub ? W1 : W0) + (unsigned long long)(unsigned) unit_of(ik) * nb01 + __umul24((unsigned) b, (unsigned) BS); }
-        else if (ok) bp = W + (unsigned long long)(unsigned)(unit_of(ik) * RU + isub) * nb01 + __umul24((unsigned) b, (unsigned) BS);      // (b < 2^24: the 32-bit v_mul_lo_u32 runs at a quarter rate)
-        if (IS_K) {
-            hh[p] = *(const u32x4 *) bp;
-            qq[p] = *(const u32x4 *)(bp + 16 + 32 * j);
-            q2[(IS_Q8 || IS_K) ? p : 0] = *(const u32x4 *)(bp + 32 + 32 * j);
-        } else {
-            uint32_t t, odd;             // the aligned window as loaded; q32_align() at the point of use
-            q32_load_raw<IS_K ? CLLM_TYPE_Q4_0 : FMT>(bp, qq[p], q2[IS_Q8 ? p : 0], t, odd);
-            hh[p].x = t; hh[p].y = odd;
-        }
-        if (++is == S) { is = 0; if (++isub == RU) { isub = 0; ik++; } }
-    };
-#pragma unroll
-    for (int p = 0; p < P; p++) issue(p);
-    TS(1);
-
-    // ---- (3) the activation row: [RMS_NORM * weight | SiLU * up |] quantize -> LDS (act layout of common.h) ----
-    float scale = 1.0f;
-    if (add) {
-        vv[0].x = vv[0].x + pa.x; vv[0].y = vv[0].y + pa.y; vv[0].z = vv[0].z + pa.z; vv[0].w = vv[0].w + pa.w;
-        if (blockIdx.x == 0 && e0 < K) *(f32x4 *)(xout + e0) = vv[0];
-    }
-    if (PRO == 1) {
-        __shared__ double part[16];
-        const double sum = NPRE == 1 ? rms_block_sumsq_1024_one(vv[0], e0 < K, part) : rms_block_sumsq_1024(px, K, vv[0], part);
-        scale = rms_scale(sum, K, eps);
-    }
-    const int nv = K & ~7;                                          // ggml_vec_silu_f32: polynomial body below nv, libm tail
-#pragma unroll
-    for (int u = 0; u < NPRE; u++) {                                // K % KIND == 0: whole quantization lane groups stay together
-        const int e = e0 + u * 4096;
-        if (e < K) {
-            f32x4 v = vv[u];
-            if (PRO == 3) {
-                const f32x4 p0 = vv[u], p1 = gg[u];                 // (g0, u0, g1, u1), (g2, u2, g3, u3)
-                v.x = silu_any(p0.x, e + 0 < nv) * p0.y; v.y = silu_any(p0.z, e + 1 < nv) * p0.w;
-                v.z = silu_any(p1.x, e + 2 < nv) * p1.y; v.w = silu_any(p1.z, e + 3 < nv) * p1.w;
-            }
-            if (PRO == 4) {
-                const f32x4 g = gg[u];
-                v.x = silu_any(v.x, e + 0 < nv) * g.x; v.y = silu_any(v.y, e + 1 < nv) * g.y; v.z = silu_any(v.z, e + 2 < nv) * g.z; v.w = silu_any(v.w, e + 3 < nv) * g.w;
-            }
-            if (PRO == 1) { const f32x4 g = gg[u]; v.x = (v.x * scale) * g.x; v.y = (v.y * scale) * g.y; v.z = (v.z * scale) * g.z; v.w = (v.w * scale) * g.w; }
-            if (EPI == 2) *(f32x4 *)(xout + e) = v;
-            quant4_store<KIND, IS_Q41>(lds, K, e, lane, v);
-            if (EPI == 3) quant4_store<KIND, IS_Q41>(lds + act_row_bytes(K, KIND), K, e, lane, gg[u]);
-        }
-    }
-    TS(2);
-    __syncthreads();
-    TS(3);
-
-    // ---- (4) stream the rows.  Every step turns its blocks into chain records (exact integer sums + scales); the fp32 chains of the
-    //          reference's AVX2 order run over them in lanes 0..11 (q4k.h / q32.h) ----
-    const q4k_sel4 L = q4k_lane_sel4(lane);
-    const int off_d = (int) act_off_d(K), off_s = (int) act_off_s(K, KIND);      // (the Q8_1 flavour has the Q8_0 geometry)
-    constexpr int CHB = IS_K ? Q4K_CHAIN_BYTES : Q32_CHAIN_BYTES;
-    const int arb = (int) act_row_bytes(K, KIND);
-    char * chain = lds + (EPI == 3 ? 2 : 1) * arb + wave_in_wg * CHB;
-    const int l16 = lane & 15;
-    float acc = 0.0f, gate = 0.0f;
-    int ck = 0, csub = 0, cs = 0;                                   // consume cursor
-    while (ck < nmine) {
-#pragma unroll
-        for (int p = 0; p < P; p++) {
-            const int b = IS_K ? 16 * cs + grp : 64 * cs + lane;
-            const bool ok = ck < nmine && b < nblk;
-            const char * arow = EPI == 3 ? lds + csub * arb : lds;
-            if (IS_K) q4k_emit4(hh[p], qq[p], q2[(IS_Q8 || IS_K) ? p : 0], arow, off_d, off_s, ok ? b : 0, ok, L, chain);
-            else {
-                uint32_t h; u32x4 w0, w1 = {0, 0, 0, 0};
-                q32_align<IS_K ? CLLM_TYPE_Q4_0 : FMT>(qq[p], q2[IS_Q8 ? p : 0], hh[p].x, hh[p].y, h, w0, w1);
-                q32_emit<IS_K ? CLLM_TYPE_Q4_0 : FMT>(h, w0, w1, arow, off_d, off_s, ok ? b : 0, ok, lane, chain);
-            }
-            issue(p);
-            {                                                       // every step: 16 super-blocks (Q4_K) / 64 blocks of records
-                wave_lds_fence();
-                if (IS_K) q4k_chain(chain, 8, l16, acc); else q32_chain<IS_K ? CLLM_TYPE_Q4_0 : FMT>(chain, l16, acc);
-                wave_lds_fence();
-            }
-            if (++cs == S) {                                        // row complete: finish the chains, epilogue, store (lane 0)
-                float v = chain_finish<IS_K ? 1 : IS_Q41 ? 2 : 0>(acc);
-                if (ck < nmine) {                                   // wave-uniform; bias / resid come through the scalar cache
-                    const int cunit = unit_of(ck), crow = cunit * RU + csub;
-                    if (EPI == 1) {
-                        if (csub == 0) gate = v;
-                        else if (lane == 0) dst[cunit] = silu_poly(gate) * v;
-                    } else if (EPI == 2) {
-                        if (lane == 0) r_logit[crow] = v;
-                    } else if (EPI == 3) {                          // MUL by the slot's weight, ADD of the slot views, ADD of the residual: separate roundings
-                        if (csub == 0) gate = v;
-                        else {
-                            float o = __fadd_rn(__fmul_rn(gate, cw0), __fmul_rn(v, cw1));
-                            if (resid) o = __fadd_rn(o, uniform_load_f32(resid + cunit));
-                            if (lane == 0) dst[cunit] = o;
-                        }
-                    } else {
-                        if (bias)  v = v + uniform_load_f32(bias + crow);
-                        if (resid) v = v + uniform_load_f32(resid + crow);
-                        if (lane == 0) dst[crow] = v;
-                    }
-                }
-                acc = 0.0f; cs = 0;
-                if (++csub == RU) { csub = 0; ck++; }
-            }
-        }
-    }
-    TS(4);
-    if constexpr (EPI == 2) {                                       // SOFT_MAX -> TOP_K over the logits: one wave, the partition of k_soft_max / the picks of k_top_k
-        __syncthreads();
-        if (wave_in_wg == 0) {
-            const int n = kfull * 16 + nrem;
-            wave_soft_max_plain(r_logit, r_prob, n, lane);
-            for (int i = lane; i < n; i += 64) dst[i] = r_prob[i];
-            if (lane == 0) top_k_row(r_prob, n, r_k, r_ids);
-        }
-    }
-    if (ts) { __syncthreads(); TS(5); }
-}
-#undef TS
 
 // K a multiple of the block size, K <= 16384 (32768 for the plain-quantize prologue), nrows * row bytes < 4 GiB; returns
 // CLLM_E_UNSUPPORTED for shapes the general kernels must take
@@ -263,7 +31,7 @@ int launch_gemv_decode(hipStream_t st, int wtype, const void * W, int64_t K, int
         static bool attr = false; \
         if (lds > 64 * 1024 && !attr) { HIP_TRY(hipFuncSetAttribute((const void *) k_gemv_dec<FMT_, PRO_, EPI_, NPRE_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr = true; } \
         hipLaunchKernelGGL((k_gemv_dec<FMT_, PRO_, EPI_, NPRE_>), dim3((unsigned) grid), dim3(1024), lds, st, px, pw, padd, (const char *) W, nblk, kfull, nrem, eps, dst, xout, bias, resid, g_gemv_ts, \
-                           (const int32_t *) nullptr, 0ull, 0, 0, (int32_t *) nullptr, 0); } while (0)
+                           (const int32_t *) nullptr, 0ull, 0, 0); } while (0)
 #define GO(FMT_) do { \
         if (pro == 1 && epi == 1) { if (npre == 1) GO3(FMT_, 1, 1, 1); else GO3(FMT_, 1, 1, 4); } \
         else if (pro == 1)        { if (npre == 1) GO3(FMT_, 1, 0, 1); else GO3(FMT_, 1, 0, 4); } \
@@ -299,7 +67,7 @@ int launch_gemv_decode_id(hipStream_t st, int wtype, const void * W, size_t w_ex
         if (lds > 64 * 1024 && !attr) { HIP_TRY(hipFuncSetAttribute((const void *) k_gemv_dec<FMT_, 2, EPI_, NPRE_, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr = true; } \
         hipLaunchKernelGGL((k_gemv_dec<FMT_, 2, EPI_, NPRE_, true>), dim3((unsigned) grid, (unsigned) n_slots), dim3(1024), lds, st, px, (const float *) nullptr, (const float *) nullptr, (const char *) W, \
                            nblk, kfull, nrem, 0.0f, dst, (float *) nullptr, (const float *) nullptr, (const float *) nullptr, (unsigned long long *) nullptr, ids, \
-                           (unsigned long long) w_expert_bytes, (int) px_slot_stride, (int) dst_slot_stride, (int32_t *) nullptr, 0); } while (0)
+                           (unsigned long long) w_expert_bytes, (int) px_slot_stride, (int) dst_slot_stride); } while (0)
 #define GOMT(FMT_) do { if (epi == 1) { if (npre == 1) GOM(FMT_, 1, 1); else if (npre == 4) GOM(FMT_, 1, 4); else GOM(FMT_, 1, 8); } \
                         else          { if (npre == 1) GOM(FMT_, 0, 1); else if (npre == 4) GOM(FMT_, 0, 4); else GOM(FMT_, 0, 8); } } while (0)
     if (wtype == CLLM_TYPE_Q4_K) GOMT(CLLM_TYPE_Q4_K); else if (wtype == CLLM_TYPE_Q4_0) GOMT(CLLM_TYPE_Q4_0); else if (wtype == CLLM_TYPE_Q4_1) GOMT(CLLM_TYPE_Q4_1); else GOMT(CLLM_TYPE_Q8_0);
@@ -309,52 +77,3 @@ int launch_gemv_decode_id(hipStream_t st, int wtype, const void * W, size_t w_ex
     return CLLM_OK;
 }
 
-// The router of a sparse-MoE block for ONE token as one launch of one workgroup (the reference's nodes RMS_NORM -> MUL -> MUL_MAT(gate) -> SOFT_MAX ->
-// TOP_K, GenericSparseMLP::forward src/layers.cpp:3792-3830): xnorm[K] = RMS_NORM(px) * pw, probs[n] = SOFT_MAX(W . quantize(xnorm)), ids[k] = TOP_K(probs).
-// Same reductions in the same order as the separate kernels: bit-identical.  n <= 64 experts, K <= 16384; CLLM_E_UNSUPPORTED otherwise.
-int launch_moe_router(hipStream_t st, int wtype, const void * W, int64_t K, int64_t n, const float * px, const float * pw, float eps,
-                      float * xnorm, float * probs, int32_t * ids, int k) {
-    const int kind = wtype == CLLM_TYPE_Q4_K ? 256 : 32;
-    if (!is_quant_type(wtype) || K % kind || K % 4 || K > 16384 || n < 1 || n > 64 || k < 1 || k > n) return CLLM_E_UNSUPPORTED;
-    if (act_row_bytes(K, kind) + 16 * Q32_CHAIN_BYTES > 160 * 1024) return CLLM_E_UNSUPPORTED;
-    const int kfull = (int)(n / 16), nrem = (int)(n % 16), nblk = (int)(K / kind);
-    const size_t lds = act_row_bytes(K, kind) + 16 * (size_t)(wtype == CLLM_TYPE_Q4_K ? Q4K_CHAIN_BYTES : Q32_CHAIN_BYTES);
-#define GOR(FMT_, NPRE_) do { \
-        static bool attr = false; \
-        if (lds > 64 * 1024 && !attr) { HIP_TRY(hipFuncSetAttribute((const void *) k_gemv_dec<FMT_, 1, 2, NPRE_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr = true; } \
-        hipLaunchKernelGGL((k_gemv_dec<FMT_, 1, 2, NPRE_>), dim3(1), dim3(1024), lds, st, px, pw, (const float *) nullptr, (const char *) W, nblk, kfull, nrem, eps, probs, xnorm, \
-                           (const float *) nullptr, (const float *) nullptr, (unsigned long long *) nullptr, (const int32_t *) nullptr, 0ull, 0, 0, ids, k); } while (0)
-#define GORT(FMT_) do { if (K <= 4096) GOR(FMT_, 1); else GOR(FMT_, 4); } while (0)
-    if (wtype == CLLM_TYPE_Q4_K) GORT(CLLM_TYPE_Q4_K); else if (wtype == CLLM_TYPE_Q4_0) GORT(CLLM_TYPE_Q4_0); else if (wtype == CLLM_TYPE_Q4_1) GORT(CLLM_TYPE_Q4_1); else GORT(CLLM_TYPE_Q8_0);
-#undef GORT
-#undef GOR
-    LAUNCH_CHECK();
-    return CLLM_OK;
-}
-
-// MUL_MAT_ID(down experts) for ONE token with TWO slots + the tail of the sparse-MoE block in one launch (EPI 3 above):
-//   dst[r] = (W[ids[0]][r] . quantize(px[:, 0])) * w0 + (W[ids[1]][r] . quantize(px[:, 1])) * w1 (+ resid[r]),  w_j = probs[ids[j]] / (probs[ids[0]] + probs[ids[1]])
-// the arithmetic of MUL_MAT_ID -> GET_ROWS -> SUM_ROWS -> DIV -> MUL -> ADD (-> ADD) in their order: bit-identical.  dst may be resid; CLLM_E_UNSUPPORTED otherwise
-int launch_gemv_decode_id_combine(hipStream_t st, int wtype, const void * W, size_t w_expert_bytes, int64_t K, int64_t nrows, const float * px, int64_t px_slot_stride,
-                                  const int32_t * ids, const float * probs, const float * resid, float * dst) {
-    const int kind = wtype == CLLM_TYPE_Q4_K ? 256 : 32;
-    if (!is_quant_type(wtype) || K % kind || K > 32768 || nrows <= 0 || (uint64_t) nrows * (uint64_t) cllm_row_size(wtype, K) >= (1ull << 32) || px_slot_stride > INT32_MAX || px_slot_stride % 4) return CLLM_E_UNSUPPORTED;
-    const size_t lds = 2 * act_row_bytes(K, kind) + 16 * (size_t)(wtype == CLLM_TYPE_Q4_K ? Q4K_CHAIN_BYTES : Q32_CHAIN_BYTES);
-    if (2 * act_row_bytes(K, kind) + 16 * Q32_CHAIN_BYTES > 160 * 1024) return CLLM_E_UNSUPPORTED;
-    int64_t grid = (nrows + 15) / 16;
-    if (grid > device_cu_count()) grid = device_cu_count();
-    const int64_t nwaves = grid * 16;
-    const int kfull = (int)(nrows / nwaves), nrem = (int)(nrows % nwaves), nblk = (int)(K / kind);
-    const int npre = K <= 4096 ? 1 : K <= 16384 ? 4 : 8;
-#define GOC(FMT_, NPRE_) do { \
-        static bool attr = false; \
-        if (lds > 64 * 1024 && !attr) { HIP_TRY(hipFuncSetAttribute((const void *) k_gemv_dec<FMT_, 2, 3, NPRE_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr = true; } \
-        hipLaunchKernelGGL((k_gemv_dec<FMT_, 2, 3, NPRE_>), dim3((unsigned) grid), dim3(1024), lds, st, px, probs, (const float *) nullptr, (const char *) W, nblk, kfull, nrem, 0.0f, dst, (float *) nullptr, \
-                           (const float *) nullptr, resid, (unsigned long long *) nullptr, ids, (unsigned long long) w_expert_bytes, (int) px_slot_stride, 0, (int32_t *) nullptr, 0); } while (0)
-#define GOCT(FMT_) do { if (npre == 1) GOC(FMT_, 1); else if (npre == 4) GOC(FMT_, 4); else GOC(FMT_, 8); } while (0)
-    if (wtype == CLLM_TYPE_Q4_K) GOCT(CLLM_TYPE_Q4_K); else if (wtype == CLLM_TYPE_Q4_0) GOCT(CLLM_TYPE_Q4_0); else if (wtype == CLLM_TYPE_Q4_1) GOCT(CLLM_TYPE_Q4_1); else GOCT(CLLM_TYPE_Q8_0);
-#undef GOCT
-#undef GOC
-    LAUNCH_CHECK();
-    return CLLM_OK;
-}
