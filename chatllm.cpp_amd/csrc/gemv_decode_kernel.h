@@ -35,6 +35,13 @@
 //   units = rows (or gate/up row pairs), dealt as kfull full rounds of nwaves units + nrem (host-computed: no division here)
 
 
+// the weight stream's cache policy.  -DGEMV_NT (non-temporal global_load into VGPRs) measured 580 vs 681 tok/s, gate/up 18.4 vs 14.6 us: the guide's
+// nt gain is for the LDS-DMA stream (global_load_lds ... nt), not for this register path -- default policy stays
+#ifdef GEMV_NT
+#define GEMV_WLOAD(p) __builtin_nontemporal_load(p)
+#else
+#define GEMV_WLOAD(p) (*(p))
+#endif
 #define TS(k) do { if (ts && threadIdx.x == 0) ts[blockIdx.x * 8 + (k)] = wall_clock64(); } while (0)
 
 // FMT: CLLM_TYPE_Q4_K (8 lanes per 144-byte super-block, activation quantized to Q8_K) or CLLM_TYPE_Q4_0 / Q4_1 / Q8_0 (one lane per
@@ -119,9 +126,9 @@ __global__ void __launch_bounds__(1024) k_gemv_dec(const float * __restrict__ px
         if (EPI == 3) { if (ok) bp = (isub ? W1 : W0) + (unsigned long long)(unsigned) unit_of(ik) * nb01 + __umul24((unsigned) b, (unsigned) BS); }
         else if (ok) bp = W + (unsigned long long)(unsigned)(unit_of(ik) * RU + isub) * nb01 + __umul24((unsigned) b, (unsigned) BS);      // (b < 2^24: the 32-bit v_mul_lo_u32 runs at a quarter rate)
         if (IS_K) {
-            hh[p] = *(const u32x4 *) bp;
-            qq[p] = *(const u32x4 *)(bp + 16 + 32 * j);
-            q2[(IS_Q8 || IS_K) ? p : 0] = *(const u32x4 *)(bp + 32 + 32 * j);
+            hh[p] = GEMV_WLOAD((const u32x4 *) bp);
+            qq[p] = GEMV_WLOAD((const u32x4 *)(bp + 16 + 32 * j));
+            q2[(IS_Q8 || IS_K) ? p : 0] = GEMV_WLOAD((const u32x4 *)(bp + 32 + 32 * j));
         } else {
             uint32_t t, odd;             // the aligned window as loaded; q32_align() at the point of use
             q32_load_raw<IS_K ? CLLM_TYPE_Q4_0 : FMT>(bp, qq[p], q2[IS_Q8 ? p : 0], t, odd);
