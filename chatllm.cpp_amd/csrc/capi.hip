@@ -283,29 +283,35 @@ extern "C" int cllm_op_mul_mat(void * stream, const cllm_tensor * src0, const cl
 }
 
 int mmq_min_cols_get() { return mmq_min_cols(); }
+// the number of src1 columns from which cllm_op_mul_mat_ex takes a mat-mul (below it: CLLM_E_UNSUPPORTED); INT_MAX-like when the opt-in fp16 prefill path is on
+extern "C" int cllm_mul_mat_ex_min_cols(void) { return prefill_f16_enabled() ? (1 << 30) : mmq_min_cols(); }
+
 extern "C" int cllm_op_mul_mat_ex(void * stream, const cllm_tensor * src0, const cllm_tensor * src1, cllm_tensor * dst, void * wdata, size_t wsize, int pro,
                                   const cllm_tensor * norm_w, float eps, int epi, const cllm_tensor * resid) {
     if (!src0 || !src1 || !dst) FAIL(CLLM_E_INVALID, "mul_mat_ex: null tensor");
-    if ((pro != 0 && pro != 1 && pro != 3) || (epi != 0 && epi != 1) || (pro == 1 && !norm_w) || (epi && resid)) FAIL(CLLM_E_INVALID, "mul_mat_ex: pro %d epi %d", pro, epi);
+    if ((pro != 0 && pro != 1 && pro != 3 && pro != 4 && pro != 5) || (epi != 0 && epi != 1) || ((pro == 1 || pro == 4) && !norm_w) || (epi && resid)) FAIL(CLLM_E_INVALID, "mul_mat_ex: pro %d epi %d", pro, epi);
     if (!is_quant_type(src0->type) || src0->ne[2] != 1 || src0->ne[3] != 1 || src1->ne[2] != 1 || src1->ne[3] != 1 || src1->type != CLLM_TYPE_F32 || dst->type != CLLM_TYPE_F32)
         FAIL(CLLM_E_UNSUPPORTED, "mul_mat_ex: 2-D quantized src0, F32 src1 / dst");
     const int64_t K = src0->ne[0], M = src1->ne[1], Nd = epi ? src0->ne[1] / 2 : src0->ne[1];
     if (src1->ne[0] != (pro == 3 ? 2 * K : K) || (epi && src0->ne[1] % 2) || dst->ne[0] != Nd || dst->ne[1] != M || src1->nb[0] != 4 || dst->nb[0] != 4 || dst->nb[1] % 4) FAIL(CLLM_E_INVALID, "mul_mat_ex: shapes");
     if (resid && (resid->type != CLLM_TYPE_F32 || resid->ne[0] != dst->ne[0] || resid->ne[1] != M || resid->nb[0] != 4 || resid->nb[1] % 4)) FAIL(CLLM_E_INVALID, "mul_mat_ex: resid");
     if (pro == 1 && (norm_w->type != CLLM_TYPE_F32 || norm_w->nb[0] != 4 || norm_w->ne[0] != K || t_nelements(norm_w) != K)) FAIL(CLLM_E_INVALID, "mul_mat_ex: norm weight");
+    if (pro == 4 && (norm_w->type != CLLM_TYPE_F32 || norm_w->nb[0] != 4 || norm_w->ne[0] != K || norm_w->ne[1] != M || norm_w->ne[2] != 1 || norm_w->ne[3] != 1)) FAIL(CLLM_E_INVALID, "mul_mat_ex: up tensor");
     if (M < mmq_min_cols() || prefill_f16_enabled()) return CLLM_E_UNSUPPORTED;
     if (src0->nb[0] != cllm_type_size(src0->type) || K % cllm_blck_size(src0->type)) FAIL(CLLM_E_INVALID, "mul_mat_ex: src0 rows");
     const int kind = act_kind(src0->type);
     const size_t stride = act_row_bytes(K, kind), need = stride * (size_t) M;
     if (!wdata || wsize < need) FAIL(CLLM_E_INVALID, "mul_mat_ex: wdata too small (%zu < %zu)", wsize, need);
-    if ((uintptr_t) wdata % 16 || (uintptr_t) src0->data % 2 || (uintptr_t) src1->data % 16 || src1->nb[1] % 16) FAIL(CLLM_E_UNSUPPORTED, "mul_mat_ex: operand alignment");
+    if ((uintptr_t) wdata % 16 || (uintptr_t) src0->data % 2 || (pro != 5 && ((uintptr_t) src1->data % 16 || src1->nb[1] % 16))) FAIL(CLLM_E_UNSUPPORTED, "mul_mat_ex: operand alignment");
     if (src0->type == CLLM_TYPE_Q4_K && ((uintptr_t) src0->data % 16 || src0->nb[1] % 16)) FAIL(CLLM_E_UNSUPPORTED, "mul_mat_ex: Q4_K rows must be 16-byte aligned");
     if (src0->type == CLLM_TYPE_Q4_1 && ((uintptr_t) src0->data % 4 || src0->nb[1] % 4)) FAIL(CLLM_E_UNSUPPORTED, "mul_mat_ex: Q4_1 rows must be 4-byte aligned");
     hipStream_t st = (hipStream_t) stream;
     int rc = pro == 3 ? launch_quantize_act_silu(st, kind, tv(src1), wdata, stride)
            : pro == 1 ? launch_quantize_act_norm(st, kind, tv(src1), (const float *) norm_w->data, eps, wdata, stride)
+           : pro == 4 ? launch_quantize_act_silu2(st, kind, tv(src1), tv(norm_w), wdata, stride)
+           : pro == 5 ? CLLM_OK                                      // wdata holds this src1's act rows already (the previous call of this stream quantized them)
            : launch_quantize_act(st, kind, tv(src1), wdata, stride);
-    if (rc == CLLM_E_UNSUPPORTED) FAIL(rc, "mul_mat_ex: the norm prologue takes rows of at most 16384 16-byte aligned values");
+    if (rc == CLLM_E_UNSUPPORTED) FAIL(rc, "mul_mat_ex: this prologue takes 16-byte aligned rows (norm: of at most 16384 values)");
     if (rc) return rc;
     tview x = tv(src1); if (pro == 3) x.ne[0] = K;
     rc = launch_mmq(st, src0->type, tv(src0), wdata, stride, x, tv(dst), resid ? (const float *) resid->data : nullptr, resid ? (int64_t)(resid->nb[1] / 4) : 0, epi);

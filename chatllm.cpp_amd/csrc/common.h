@@ -329,6 +329,7 @@ int launch_fattn(hipStream_t st, const tview & q, const tview & k, int ktype, co
                  char * dst, int64_t nbn, int64_t nbh, int64_t nbb, float scale, void * wdata, size_t wsize);
 int launch_gemv_decode_id_combine(hipStream_t st, int wtype, const void * W, size_t w_expert_bytes, int64_t K, int64_t nrows, const float * px, int64_t px_slot_stride,
                                   const int32_t * ids, const float * probs, const float * resid, float * dst);
+int launch_quantize_act_silu2(hipStream_t st, int kind, const tview & g, const tview & u, void * act, size_t act_stride);
 int launch_quantize_act_norm(hipStream_t st, int kind, const tview & s, const float * norm_w, float eps, void * act, size_t act_stride);
 int launch_rope_kv_store(hipStream_t st, float * qkv, int64_t QKV, const int32_t * pos, int64_t n_tok, int nh, int nkv, int hd, int mode, float freq_base,
                          void * k_cache, void * v_cache, int64_t ML);

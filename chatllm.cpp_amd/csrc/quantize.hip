@@ -70,6 +70,37 @@ static int quantize_act_impl(hipStream_t st, int kind, const tview & s, void * a
 int launch_quantize_act(hipStream_t st, int kind, const tview & s, void * act, size_t act_stride) { return quantize_act_impl<false>(st, kind, s, act, act_stride); }
 int launch_quantize_act_silu(hipStream_t st, int kind, const tview & s, void * act, size_t act_stride) { return quantize_act_impl<true>(st, kind, s, act, act_stride); }
 
+// UNARY(SILU)(gate) -> MUL(up) -> quantize with gate and up as SEPARATE [K, rows] tensors (the reference's own graph: BaseMLP::forward src/layers.cpp:2475-2483);
+// the values quantized are silu(gate) * up as the two element-wise nodes produce them (polynomial body below K & ~7, libm tail)
+template <int KIND, bool Q81>
+__global__ void __launch_bounds__(256) k_quantize_silu2(const char * __restrict__ gsrc, const char * __restrict__ usrc, int64_t K, int64_t g_nb1, int64_t u_nb1,
+                                                        char * __restrict__ act, size_t act_stride) {
+    const int64_t row = blockIdx.y;
+    const float * g = (const float *)(gsrc + row * g_nb1), * u = (const float *)(usrc + row * u_nb1);
+    const int lane = threadIdx.x & 63;
+    const int64_t e0 = ((int64_t) blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (e0 >= K) return;                                   // K % KIND == 0 and KIND | 256: whole lane groups drop out together
+    const f32x4 a = *(const f32x4 *)(g + e0), b = *(const f32x4 *)(u + e0);
+    const int64_t nv = K & ~(int64_t) 7;
+    f32x4 v;
+    v.x = silu_any(a.x, e0 + 0 < nv) * b.x; v.y = silu_any(a.y, e0 + 1 < nv) * b.y; v.z = silu_any(a.z, e0 + 2 < nv) * b.z; v.w = silu_any(a.w, e0 + 3 < nv) * b.w;
+    quant4_store<KIND, Q81>(act + row * act_stride, K, e0, lane, v);
+}
+int launch_quantize_act_silu2(hipStream_t st, int kind, const tview & g, const tview & u, void * act, size_t act_stride) {
+    const int kind_blk = act_blk(kind);
+    const int64_t K = g.ne[0], rows = g.ne[1];
+    if (K % kind_blk || g.ne[2] != 1 || g.ne[3] != 1 || u.ne[0] != K || u.ne[1] != rows || u.ne[2] != 1 || u.ne[3] != 1 || ((uintptr_t) g.data & 15) || ((uintptr_t) u.data & 15) ||
+        g.nb[1] % 16 || u.nb[1] % 16 || rows > 65535) return CLLM_E_UNSUPPORTED;
+    if (rows <= 0 || K <= 0) return CLLM_OK;
+    const dim3 grid((unsigned)((K / 4 + 255) / 256), (unsigned) rows);
+    if (kind_blk == 32) {
+        if (kind == ACT_Q8_1) hipLaunchKernelGGL((k_quantize_silu2<32, true>),  grid, dim3(256), 0, st, g.data, u.data, K, g.nb[1], u.nb[1], (char *) act, act_stride);
+        else                  hipLaunchKernelGGL((k_quantize_silu2<32, false>), grid, dim3(256), 0, st, g.data, u.data, K, g.nb[1], u.nb[1], (char *) act, act_stride);
+    } else hipLaunchKernelGGL((k_quantize_silu2<256, false>), grid, dim3(256), 0, st, g.data, u.data, K, g.nb[1], u.nb[1], (char *) act, act_stride);
+    LAUNCH_CHECK();
+    return CLLM_OK;
+}
+
 // RMS_NORM -> MUL(weight) -> quantize of whole rows in one pass (the input_layernorm / post_attention_layernorm in front of a prefill MUL_MAT,
 // LMBlock1Forward src/layers.cpp:2730-2760): one 1024-thread workgroup per row; the sum of squares, the scale and the two multiplications are those of
 // k_rms_norm<true> (ops.hip) on the same values, the quantizer is the one above: the act row is bit-identical to the two launches.  K <= 16384, K % 4 == 0.

@@ -484,6 +484,9 @@ struct fused_attn {
 struct fused_moe { const ggml_tensor * experts = nullptr, * probs = nullptr, * ids = nullptr, * resid = nullptr; int down = -1; /* the MUL_MAT_ID node folded into the launch */ };
 //   RMS_NORM -> MUL(weight) -> {MUL_MAT(router) -> SOFT_MAX -> TOP_K, experts}     one token: cllm_op_moe_router (launched at the TOP_K node)
 struct moe_router { const ggml_tensor * x = nullptr, * w = nullptr, * gate = nullptr, * xnorm = nullptr, * probs = nullptr; float eps = 0; };
+//   prefill (>= cllm_mul_mat_ex_min_cols() columns): RMS_NORM -> MUL -> {MUL_MAT ...} (norm in the quantizer; further projections of the same activation reuse
+//   the act rows), UNARY(SILU) -> MUL -> MUL_MAT (SiLU * up in the quantizer), MUL_MAT -> ADD (residual in the epilogue): cllm_op_mul_mat_ex at the MUL_MAT node
+struct pf_mm { int pro = 0; const ggml_tensor * x = nullptr, * w2 = nullptr; float eps = 0; const ggml_tensor * resid = nullptr, * out = nullptr; };
 struct moe_gate_up { int mul = -1, gate = -1, up = -1, unary = -1; void * W = nullptr; };      // node indices; W: the pack, resolved before the walk
 //   MUL_MAT(K, Q) SCALE DIAG_MASK_INF SOFT_MAX MUL_MAT(V^T, P)   with more than 32 query rows (the tolerance tier of the MFMA mat-muls):
 //                                                    cllm_op_attn_prefill, one flash kernel in place of the V.P node; the scores never reach HBM
@@ -496,6 +499,7 @@ struct fuse_plan {
     std::vector<fused_fa> fas;
     std::vector<fused_moe> moes;
     std::vector<moe_router> routers;    // ALT_MOE_ROUTER: P.moe[top_k node] indexes them
+    std::vector<pf_mm> pfs; std::vector<int> pf;       // prefill mat-muls with a fused prologue / epilogue: pf[MUL_MAT node] indexes pfs
     std::vector<moe_gate_up> gus;       // candidates (P.moe[mul node] indexes them once resolved)
     std::vector<int>     mv;            // index into mvs for MUL_MAT nodes launched fused, else -1
     std::vector<fused_mv> mvs;
@@ -661,7 +665,7 @@ void plan_attention(ggml_cgraph * g, fuse_plan & P, const std::vector<int> & loc
 
 fuse_plan make_plan(ggml_cgraph * g) {
     const int n = ggml_graph_n_nodes(g);
-    fuse_plan P; P.skip.assign(n, 0); P.mv.assign(n, -1); P.sm_src.assign(n, -1); P.attn.assign(n, -1); P.alt.assign(n, ALT_NONE); P.moe.assign(n, -1);
+    fuse_plan P; P.skip.assign(n, 0); P.mv.assign(n, -1); P.sm_src.assign(n, -1); P.attn.assign(n, -1); P.alt.assign(n, ALT_NONE); P.moe.assign(n, -1); P.pf.assign(n, -1);
     static const bool off = getenv("CLLM_HIP_NO_FUSE") != nullptr;
     if (off || n < 8) return P;
     std::vector<int> local(n, 0), writer(n, -1);        // writer[i]: entry of mvs whose launch produces node i
@@ -747,6 +751,78 @@ fuse_plan make_plan(ggml_cgraph * g) {
             f.resid = (const float *) r->data; f.resid_t = r; f.dst = (float *) a->data;
             P.skip[i] = 1;
             writer[j] = -1; writer[i] = P.mv[j];
+            break;
+        }
+    }
+    // ---- prefill: the same three patterns around a many-column quantized MUL_MAT (cllm_op_mul_mat_ex; the runner's prefill has them too)
+    static const bool no_pf = getenv("CLLM_HIP_NO_PREFILL_FUSE") != nullptr;
+    static const int pf_min = cllm_mul_mat_ex_min_cols();
+    auto pf_ok = [&](const ggml_tensor * mm) {
+        if (mm->op != GGML_OP_MUL_MAT) return false;
+        const ggml_tensor * w = mm->src[0], * x = mm->src[1];
+        const uintptr_t wal = w->type == GGML_TYPE_Q4_K ? 15 : w->type == GGML_TYPE_Q4_1 ? 3 : 1;
+        return is_q(w->type) && w->ne[2] == 1 && w->ne[3] == 1 && w->nb[1] == ggml_row_size(w->type, w->ne[0]) && !((uintptr_t) w->data & wal) && !(w->nb[1] & wal) &&
+               x->type == GGML_TYPE_F32 && x->ne[2] == 1 && x->ne[3] == 1 && x->ne[1] >= pf_min && x->ne[1] <= 65535 && x->nb[0] == 4 && x->nb[1] % 16 == 0 && !((uintptr_t) x->data & 15) &&
+               mm->type == GGML_TYPE_F32 && mm->nb[0] == 4 && mm->nb[1] % 4 == 0 && mm->ne[2] == 1 && mm->ne[3] == 1;
+    };
+    auto act_class = [](ggml_type t) { return t == GGML_TYPE_Q4_K ? 0 : t == GGML_TYPE_Q4_1 ? 1 : 2; };
+    auto uses_wdata = [](const ggml_tensor * t) { return t->op == GGML_OP_MUL_MAT || t->op == GGML_OP_MUL_MAT_ID || t->op == GGML_OP_FLASH_ATTN_EXT; };
+    if (!no_pf) for (int i = 0; i < n; i++) {
+        ggml_tensor * t = ggml_graph_node(g, i);
+        if (P.skip[i] || t->op != GGML_OP_MUL || t->type != GGML_TYPE_F32 || t->ne[1] < pf_min || t->ne[2] != 1 || t->ne[3] != 1 || !ggml_is_contiguous(t)) continue;
+        const ggml_tensor * a = t->src[0], * b = t->src[1];
+        // RMS_NORM -> MUL(weight vector) -> projections
+        const int ir = find(a);
+        if (a->op == GGML_OP_RMS_NORM && ir >= 0 && !P.skip[ir] && only_local(ir, 1) && only_local(i, local[i]) && local[i] > 0 && a->src[0]->type == GGML_TYPE_F32 &&
+            ggml_is_contiguous(a->src[0]) && !((uintptr_t) a->src[0]->data & 15) && t->ne[0] % 4 == 0 && t->ne[0] <= 16384 &&
+            b->type == GGML_TYPE_F32 && ggml_is_contiguous(b) && ggml_nelements(b) == t->ne[0] && !((uintptr_t) b->data & 15)) {
+            bool ok = true;
+            for (int j : users[i]) { const ggml_tensor * c = ggml_graph_node(g, j); ok = ok && pf_ok(c) && c->src[1] == t && P.pf[j] < 0 && !P.skip[j]; }
+            if (!ok) continue;
+            int prev = -1;
+            for (int j : users[i]) {
+                pf_mm F; F.pro = 1; F.x = a->src[0]; F.w2 = b; memcpy(&F.eps, a->op_params, 4);
+                if (prev >= 0 && act_class(ggml_graph_node(g, j)->src[0]->type) == act_class(ggml_graph_node(g, prev)->src[0]->type)) {
+                    bool clean = true;                 // nothing between the two projections may touch the module's act scratch
+                    for (int k = prev + 1; k < j; k++) clean = clean && !uses_wdata(ggml_graph_node(g, k));
+                    if (clean) F.pro = 5;
+                }
+                P.pf[j] = (int) P.pfs.size(); P.pfs.push_back(F);
+                prev = j;
+            }
+            P.skip[ir] = P.skip[i] = 1;
+            continue;
+        }
+        // UNARY(SILU)(gate) -> MUL(up) -> MUL_MAT
+        for (int side = 0; side < 2; side++) {
+            const ggml_tensor * u = side ? b : a, * o = side ? a : b;
+            const int iu = find(u);
+            if (u->op != GGML_OP_UNARY || ggml_get_unary_op(u) != GGML_UNARY_OP_SILU || iu < 0 || P.skip[iu] || !only_local(iu, 1) || !only_local(i, 1)) continue;
+            const int j = users[i][0];
+            const ggml_tensor * c = ggml_graph_node(g, j), * gate = u->src[0];
+            if (!pf_ok(c) || c->src[1] != t || P.pf[j] >= 0 || P.skip[j] || !ggml_are_same_shape(gate, t) || !ggml_are_same_shape(o, t) || gate->type != GGML_TYPE_F32 || o->type != GGML_TYPE_F32 ||
+                !ggml_is_contiguous(gate) || !ggml_is_contiguous(o) || ((uintptr_t) gate->data & 15) || ((uintptr_t) o->data & 15) || t->ne[0] % 4) continue;
+            pf_mm F; F.pro = 4; F.x = gate; F.w2 = o;
+            P.pf[j] = (int) P.pfs.size(); P.pfs.push_back(F);
+            P.skip[iu] = P.skip[i] = 1;
+            break;
+        }
+    }
+    // MUL_MAT -> ADD(residual): the ADD directly follows (only views in between: its destination is then not the live memory of anything that still runs)
+    if (!no_pf) for (int i = 0; i < n; i++) {
+        ggml_tensor * ad = ggml_graph_node(g, i);
+        if (P.skip[i] || ad->op != GGML_OP_ADD || ad->type != GGML_TYPE_F32 || !ggml_is_contiguous(ad)) continue;
+        for (int side = 0; side < 2; side++) {
+            const ggml_tensor * mm = ad->src[side], * r = ad->src[1 - side];
+            const int j = mm ? find(mm) : -1;
+            if (j < 0 || j >= i || !pf_ok(mm) || P.skip[j] || !only_local(j, 1) || !r || r->type != GGML_TYPE_F32 || !ggml_are_same_shape(r, ad) || !ggml_are_same_shape(mm, ad) || !ggml_is_contiguous(r) ||
+                !ggml_is_contiguous(mm)) continue;
+            bool adjacent = true;
+            for (int k = j + 1; k < i; k++) { const ggml_op op = ggml_graph_node(g, k)->op; adjacent = adjacent && (op == GGML_OP_RESHAPE || op == GGML_OP_VIEW || op == GGML_OP_PERMUTE || op == GGML_OP_TRANSPOSE); }
+            if (!adjacent || (ad->data != r->data && overlap(ad->data, ggml_nbytes(ad), r->data, ggml_nbytes(r)))) continue;
+            if (P.pf[j] < 0) { pf_mm F; F.pro = 0; F.x = mm->src[1]; P.pf[j] = (int) P.pfs.size(); P.pfs.push_back(F); }
+            P.pfs[P.pf[j]].resid = r; P.pfs[P.pf[j]].out = ad;
+            P.skip[i] = 1;
             break;
         }
     }
@@ -1141,6 +1217,15 @@ ggml_status be_graph_compute(ggml_backend_t backend, ggml_cgraph * g) {
                     rc = CALL(cllm_op_mul_mat_vec_fused, st, &da, f.pro, f.px, f.pw, f.eps, 0, f.resid, a_stage);
                     if (rc == CLLM_OK) rc = CALL(cllm_memcpy_d2d, (void *) f.dst, (const void *) a_stage, (size_t) a->ne[1] * 4, st);
                 } else rc = CALL(cllm_op_mul_mat_vec_fused, st, &da, f.pro, f.px, f.pw, f.eps, 0, f.resid, f.dst);
+            } else if (plan.pf[i] >= 0) {
+                const pf_mm & F = plan.pfs[plan.pf[i]];
+                const size_t need = cllm_mul_mat_wsize(&da, &db);
+                if ((rc = ensure_wdata(c, need))) break;
+                cllm_tensor dx = F.pro == 5 ? db : desc(F.x), dw2, dr, dout = F.out ? desc(F.out) : d;
+                if (F.pro == 1) { dx.ne[0] = db.ne[0]; dx.ne[1] = db.ne[1]; dx.ne[2] = dx.ne[3] = 1; dx.nb[1] = (size_t) db.ne[0] * 4; dx.nb[2] = dx.nb[3] = dx.nb[1] * (size_t) db.ne[1]; }
+                if (F.w2) { dw2 = desc(F.w2); if (F.pro == 1) { dw2.ne[0] = db.ne[0]; dw2.ne[1] = dw2.ne[2] = dw2.ne[3] = 1; dw2.nb[1] = dw2.nb[2] = dw2.nb[3] = (size_t) db.ne[0] * 4; } }
+                if (F.resid) dr = desc(F.resid);
+                rc = CALL(cllm_op_mul_mat_ex, st, &da, &dx, &dout, c->wdata, c->wsize, F.pro, F.w2 ? &dw2 : nullptr, F.eps, 0, F.resid ? &dr : nullptr);
             } else {
                 const size_t need = cllm_mul_mat_wsize(&da, &db);
                 if ((rc = ensure_wdata(c, need))) break;
@@ -1356,9 +1441,9 @@ ggml_status be_graph_compute(ggml_backend_t backend, ggml_cgraph * g) {
         for (const merge_group & G : plan.groups) merged_n += G.state == 1;
         int fa_nodes = 0;
         for (int i = 0; i < ggml_graph_n_nodes(g); i++) fa_nodes += ggml_graph_node(g, i)->op == GGML_OP_FLASH_ATTN_EXT;
-        HIPB_LOG("graph_compute: %d nodes -> %d calls%s (%d fused mat-vecs, %d merged over packed weights, attention fused at level 1: %d, level 2: %d, flash prefill: %d, flash_attn_ext: %d, MoE routers: %d)",
+        HIPB_LOG("graph_compute: %d nodes -> %d calls%s (%d fused mat-vecs, %d merged over packed weights, attention fused at level 1: %d, level 2: %d, flash prefill: %d, flash_attn_ext: %d, MoE routers: %d, prefill mat-muls with fused prologue / epilogue: %d)",
                  ggml_graph_n_nodes(g), launches, replayed ? ", replayed from the captured graph" : "", (int) plan.mvs.size(), merged_n, a1, a2, (int) plan.fas.size(), fa_nodes,
-                 (int) plan.routers.size());
+                 (int) plan.routers.size(), (int) plan.pfs.size());
         g_ws.calls += launches;
         if (++g_ws.graphs % 64 == 0) {
             const double n = 64.0;

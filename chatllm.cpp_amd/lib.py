@@ -67,6 +67,7 @@ SIGNATURES = {
     "cllm_event_elapsed_ms": (C.c_int, [_P, _P, C.POINTER(C.c_float)]),
     "cllm_mul_mat_wsize": (C.c_size_t, [_T, _T]),
     "cllm_op_mul_mat": (C.c_int, [_P, _T, _T, _T, _P, C.c_size_t]),
+    "cllm_mul_mat_ex_min_cols": (C.c_int, []),
     "cllm_op_mul_mat_ex": (C.c_int, [_P, _T, _T, _T, _P, C.c_size_t, C.c_int, _T, C.c_float, C.c_int, _T]),
     "cllm_op_mul_mat_vec_fused": (C.c_int, [_P, _T, C.c_int, _P, _P, C.c_float, C.c_int, _P, _P]),
     "cllm_pack_rows": (C.c_int, [_P, _P, C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.c_int, C.c_size_t, C.c_int]),

@@ -112,10 +112,14 @@ CLLM_API int    cllm_op_mul_mat(void * stream, const cllm_tensor * src0, const c
  *   pro 0: MUL_MAT(src0, src1)
  *   pro 1: RMS_NORM(src1, eps) -> MUL(norm_w) -> MUL_MAT       (norm_w: dense F32 [K]; the normalised activation is never stored)
  *   pro 3: src1 holds 2 K interleaved (gate_e, up_e) pairs per row; the mat-mul runs over silu(gate) * up
+ *   pro 4: UNARY(SILU)(src1) -> MUL(norm_w) -> MUL_MAT with gate = src1 and up = norm_w as separate F32 [K, M] tensors (the reference's own graph)
+ *   pro 5: src1's act rows are already in wdata -- the previous cllm_op_mul_mat_ex / cllm_op_mul_mat on this stream quantized the SAME src1 (same K, M,
+ *          weight block kind) and nothing else touched wdata since (several projections of one activation: q, k, v; gate, up); src1 gives the shape only
  *   epi 1: src0's rows alternate gate_u, up_u (cllm_pack_rows, interleave); dst F32 [N / 2, M] = silu(gate_u . x) * (up_u . x)   (MUL_MAT x 2 -> UNARY(SILU) -> MUL)
  *   resid != NULL (epi 0): ... -> ADD(resid)  (resid F32 of dst's shape; may be dst itself)
  * Only for src1->ne[1] >= the matrix-core threshold (33 columns; CLLM_E_UNSUPPORTED below it: the caller issues the nodes).  The fused quantizers and
  * epilogues produce the bits of the separate RMS_NORM / MUL / SiLU / quantize / ADD passes. */
+CLLM_API int    cllm_mul_mat_ex_min_cols(void);
 CLLM_API int    cllm_op_mul_mat_ex(void * stream, const cllm_tensor * src0, const cllm_tensor * src1, cllm_tensor * dst, void * wdata, size_t wsize,
                                    int pro, const cllm_tensor * norm_w, float eps, int epi, const cllm_tensor * resid);
 

@@ -52,6 +52,18 @@ int main(int argc, char ** argv) {
         std::vector<float> logits;
         std::vector<int> in = ids;
         int n_past = 0;
+        if (const char * reps = getenv("REF_CHAT_PREFILL_REPS")) {      // prompt evaluation alone (BASELINE cfg3): one untimed pass, then `reps` timed ones from an empty cache
+            const int n = atoi(reps);
+            double best = 1e30, sum = 0;
+            for (int r = 0; r <= n; r++) {
+                obj.model->set_n_past(0);
+                const auto p0 = std::chrono::steady_clock::now();
+                if (!obj.model->generate_next_token(ids, gen, logits)) { fprintf(stderr, "generate_next_token failed\n"); return 4; }
+                const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - p0).count();
+                if (r > 0) { sum += ms; if (ms < best) best = ms; }
+            }
+            if (n > 0) fprintf(stderr, "prefill: %d tokens, mean %.1f ms, best %.1f ms = %.0f tok/s\n", (int) ids.size(), sum / n, best, ids.size() * 1e3 / best);
+        }
         const int skip = n_decode > 40 ? 16 : 0;            // steps left out of the decode timing (first launches, captures, page faults)
         auto t0 = std::chrono::steady_clock::now();
         for (int s = 0; s <= n_decode; s++) {

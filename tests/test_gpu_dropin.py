@@ -125,7 +125,7 @@ def test_reference_host_mixtral_cpu_vs_our_module(gpu, tmp_path, wname, wt):
     # the reference feeds this architecture one token per graph (batch_input = false, models/mistral.h:101): prompt + decode graphs,
     # and not one more -- no scheduler split, nothing fell back to the CPU backend
     assert len(graphs) == len(prompt) + n_dec, (len(graphs), graphs[:4])
-    assert all(f"MoE routers: {cfg['n_layer']})" in ln for ln in graphs), graphs[:3]       # norm + router mat-vec + SOFT_MAX + TOP_K: one launch per block
+    assert all(f"MoE routers: {cfg['n_layer']}," in ln for ln in graphs), graphs[:3]       # norm + router mat-vec + SOFT_MAX + TOP_K: one launch per block
     # bit-exact token ids at greedy AND bit-identical logits (the run on the module was teacher-forced on the CPU ids only to share it with the
     # no-fusion run: with identical logits its own argmax is the same id)
     assert np.array_equal(lg_c.view(np.uint32), lg_g.view(np.uint32)), [int(np.sum(lg_c[i].view(np.uint32) != lg_g[i].view(np.uint32))) for i in range(n_dec + 1)]
@@ -328,6 +328,11 @@ def test_reference_host_long_prompt_uses_the_flash_prefill(gpu, tmp_path):
     dev_n, _ = _tolerance_tier(lg_c, lg_n, ids_c, 0.25)
     print(f"70-token prompt: flash prefill max|dlogit| = {dev:.2e} sigma, node sequence (MFMA mat-muls) {dev_n:.2e} sigma")
     assert dev < 2 * dev_n + 1e-3                                    # the fused form is no worse than the node sequence it replaces
+    # the prompt graph's quantized mat-muls carry their neighbours: norm / SiLU * up in the quantizer, q / k / v and gate / up share one quantization, residual
+    # adds in the epilogue (7 per layer) -- and that changes no bit against the same mat-muls issued node by node
+    assert f"prefill mat-muls with fused prologue / epilogue: {7 * cfg['n_layer']})" in stats[0], stats[0]
+    ids_p, lg_p, _ = _host_run(tmp_path, mp, "all", 8, prompt, cfg["vocab"], teacher=ids_c, CLLM_HIP_NO_PREFILL_FUSE="1")
+    assert lg_g.tobytes() == lg_p.tobytes()
 
 
 @pytest.mark.skipif(not (os.path.exists(os.path.join(REF, "ref_backend_async")) and os.path.exists(os.path.join(REF, "libggml-hip.so"))),

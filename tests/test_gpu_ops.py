@@ -401,6 +401,14 @@ def test_mul_mat_ex_equals_the_node_sequences(gpu, t, K, N, M):
     gate = y.view([N // 2, M], [8, y.nb[1]], offset=0); up = y.view([N // 2, M], [8, y.nb[1]], offset=4)
     want_s = ops.mul(ops.silu(ops.cont(gate)), ops.cont(up))
     assert np.array_equal(bits(ops.mul_mat_ex(w, x, pro=1, norm_w=g, eps=1e-5, epi=1)), bits(want_s))
+    # UNARY(SILU)(gate) -> MUL(up) -> MUL_MAT with separate gate / up tensors (pro 4), + the residual
+    gt = T.from_numpy(rng.standard_normal((M, K)).astype(np.float32)); ut = T.from_numpy(rng.standard_normal((M, K)).astype(np.float32))
+    want_4 = ops.add(ops.mul_mat(w, ops.mul(ops.silu(gt), ut)), r)
+    assert np.array_equal(bits(ops.mul_mat_ex(w, gt, pro=4, norm_w=ut, resid=r)), bits(want_4))
+    # a second projection of the same activation reuses the act rows of the previous call (pro 5)
+    w2 = T.from_numpy(rand_blocks(t, N, K, rng), t, [K, N])
+    ops.mul_mat_ex(w, x, pro=1, norm_w=g, eps=1e-5)
+    assert np.array_equal(bits(ops.mul_mat_ex(w2, x, pro=5)), bits(ops.mul_mat(w2, ops.rms_norm_mul(x, g, 1e-5))))
     # the SiLU * up quantizer prologue (interleaved pairs in src1)
     if K * 2 <= 8192:
         x2 = T.from_numpy(rng.standard_normal((M, 2 * K)).astype(np.float32))
