@@ -269,7 +269,10 @@ def prefill_cfg3(pkg, model_name, n_prompt=4096, reps=3):
     QD, KD = cfg["n_head"] * hd, cfg["n_kv_head"] * hd
     flops = 2.0 * L * (H * (QD + 2 * KD) + QD * H + 3 * H * F) * n_prompt + 2.0 * 2 * n_prompt * n_prompt * hd * cfg["n_head"] * L
     return {"ms": dt * 1e3, "tok_s": n_prompt / dt, "n_prompt": n_prompt, "wtype": "q4_0", "algorithmic_tflops": flops / dt / 1e12,
-            "mfma_frac": flops / dt / 5.0e15, "mfma_peak": "5.0e15 int8 dense (the linear layers run v_mfma_i32_*_i8; attention on f16 MFMA)", "frac_of_f16_peak_2.5e15": flops / dt / 2.5e15}
+            "mfma_frac": flops / dt / 5.0e15, "mfma_peak": "5.0e15 int8 dense (the linear layers run v_mfma_i32_*_i8; attention on f16 MFMA)", "frac_of_f16_peak_2.5e15": flops / dt / 2.5e15,
+            # NOT measured by this run (too long for the default bench): the same prompt through the unmodified reference host, recorded by tools/dropin_prefill.sh
+            "recorded_through_reference_host": {"module_ms": 137.9, "host_cpu_backend_ms": 89086.6, "host_cpu_threads": 64,
+                                                 "source": "profiles/r02_dropin_prefill_cfg3.txt (bash tools/dropin_prefill.sh; NGL=cpu THREADS=64 REPS=1 for the CPU run)"}}
 
 
 def main():
