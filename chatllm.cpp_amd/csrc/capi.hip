@@ -192,6 +192,22 @@ static int mmq_min_cols() {
     return v;
 }
 
+// ---- prefill mode (common.h) ----
+static int g_prefill_mode = -1;
+int prefill_mode() {
+    if (g_prefill_mode < 0) {
+        const char * e = getenv("CLLM_PREFILL");
+        g_prefill_mode = (e && (!strcmp(e, "fast") || !strcmp(e, "f16"))) ? 0 : 1;
+    }
+    return g_prefill_mode;
+}
+extern "C" int cllm_set_prefill_mode(int mode) {
+    if (mode != 0 && mode != 1) FAIL(CLLM_E_INVALID, "set_prefill_mode: 0 (fast) or 1 (exact)");
+    g_prefill_mode = mode;
+    return CLLM_OK;
+}
+extern "C" int cllm_get_prefill_mode(void) { return prefill_mode(); }
+
 extern "C" size_t cllm_mul_mat_wsize(const cllm_tensor * src0, const cllm_tensor * src1) {
     if (!src0 || !src1 || !is_quant(src0->type)) return 0;
     return act_row_bytes(src1->ne[0], act_kind(src0->type)) * (size_t) t_nrows(src1);
@@ -272,6 +288,7 @@ extern "C" int cllm_op_mul_mat(void * stream, const cllm_tensor * src0, const cl
                 tview x1 = x; x1.data += i12 * x.nb[2] + i13 * x.nb[3];
                 rc = launch_dense_f16(st, src0->type, w, x1, d);
             }
+            if (rc == CLLM_E_UNSUPPORTED && prefill_mode() == 1) rc = launch_mmx(st, src0->type, w, act, stride, x, d);      // the reference's order on the matrix cores
             if (rc == CLLM_E_UNSUPPORTED) rc = launch_mmq(st, src0->type, w, act, stride, x, d);
             if (rc == CLLM_E_UNSUPPORTED) rc = launch_mmvq(st, src0->type, w, act, stride, src1->ne[1], x, d);
         } else {
@@ -314,7 +331,8 @@ extern "C" int cllm_op_mul_mat_ex(void * stream, const cllm_tensor * src0, const
     if (rc == CLLM_E_UNSUPPORTED) FAIL(rc, "mul_mat_ex: this prologue takes 16-byte aligned rows (norm: of at most 16384 values)");
     if (rc) return rc;
     tview x = tv(src1); if (pro == 3) x.ne[0] = K;
-    rc = launch_mmq(st, src0->type, tv(src0), wdata, stride, x, tv(dst), resid ? (const float *) resid->data : nullptr, resid ? (int64_t)(resid->nb[1] / 4) : 0, epi);
+    rc = prefill_mode() == 1 ? launch_mmx(st, src0->type, tv(src0), wdata, stride, x, tv(dst), resid ? (const float *) resid->data : nullptr, resid ? (int64_t)(resid->nb[1] / 4) : 0, epi)
+                             : launch_mmq(st, src0->type, tv(src0), wdata, stride, x, tv(dst), resid ? (const float *) resid->data : nullptr, resid ? (int64_t)(resid->nb[1] / 4) : 0, epi);
     if (rc == CLLM_E_UNSUPPORTED) FAIL(rc, "mul_mat_ex: the matrix-core kernel does not take this shape");
     return rc;
 }
@@ -339,7 +357,7 @@ extern "C" int cllm_bench_mul_mat_kernel(void * stream, const cllm_tensor * src0
         const int n = pass == 0 ? (n_src0 < 4 ? n_src0 : 4) : iters;
         for (int i = 0; i < n; i++) {
             tview w = tv(src0); w.data = (char *) src0_datas[i % n_src0];
-            rc = mmq ? launch_mmq(st, src0->type, w, wdata, stride, tv(src1), tv(dst)) : CLLM_E_UNSUPPORTED;
+            rc = !mmq ? CLLM_E_UNSUPPORTED : prefill_mode() == 1 ? launch_mmx(st, src0->type, w, wdata, stride, tv(src1), tv(dst)) : launch_mmq(st, src0->type, w, wdata, stride, tv(src1), tv(dst));
             if (rc == CLLM_E_UNSUPPORTED) rc = launch_mmvq(st, src0->type, w, wdata, stride, src1->ne[1], tv(src1), tv(dst));
             if (rc) return rc;
         }
@@ -544,6 +562,11 @@ extern "C" int cllm_op_attn_prefill(void * stream, const cllm_tensor * q, const 
     if (q->type != CLLM_TYPE_F32 || dst->type != CLLM_TYPE_F32 || k->type != CLLM_TYPE_F16 || vt->type != CLLM_TYPE_F16 || n_past < 0) FAIL(CLLM_E_UNSUPPORTED, "attn_prefill: types");
     if (dst->ne[0] != vt->ne[1] || dst->ne[1] != q->ne[1] || dst->ne[2] != q->ne[2] || dst->ne[3] != q->ne[3] || dst->nb[0] != 4 || k->nb[0] != 2 || vt->nb[0] != 2) FAIL(CLLM_E_INVALID, "attn_prefill: shapes");
     if (k->ne[1] != n_past + q->ne[1]) FAIL(CLLM_E_INVALID, "attn_prefill: n_kv != n_past + qlen");
+    if (prefill_mode() == 1 && q->ne[3] == 1 && k->ne[3] == 1) {       // the reference's order: K.Q, soft_max, V.P on the exact kernels (mmf_exact.hip)
+        tview ve = tv(vt); ve.ne[0] = k->ne[1];
+        const int rc = attn_prefill_exact((hipStream_t) stream, tv(q), tv(k), ve, (char *) dst->data, (int64_t) dst->nb[1], (int64_t) dst->nb[2], scale, n_past);
+        if (rc != CLLM_E_UNSUPPORTED) return rc;
+    }
     tview v = tv(vt);
     v.ne[0] = v.nb[1] / 2;                       // the row really holds max_length positions; n_kv comes from k
     const int rc = launch_fattn((hipStream_t) stream, tv(q), tv(k), k->type, v, 1, nullptr, n_past, (char *) dst->data,

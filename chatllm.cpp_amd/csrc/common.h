@@ -320,6 +320,15 @@ int device_cu_count();
 int launch_mmvq_act(hipStream_t st, int wtype, const void * W, int64_t K, int64_t nrows, const void * act, float * dst, const float * bias, const float * resid);
 int launch_gemv_decode(hipStream_t st, int wtype, const void * W, int64_t K, int64_t nrows, int pro, const float * px, const float * pw, float eps, int epi, float * dst, const float * bias, const float * resid, const float * padd = nullptr, float * xout = nullptr);
 bool prefill_f16_enabled();
+// how MUL_MAT with more than 32 activation columns and the prompt's attention block are computed (capi.hip; CLLM_PREFILL=exact | fast | f16, cllm_set_prefill_mode):
+//   1 (default) exact: mmx.hip + mmf_exact.hip, the reference's accumulation order -- bit-identical to the CPU for every prompt length
+//   0 fast: int8-MFMA GEMM (mmq.hip) + flash kernel (fattn.hip), their own fp32 summation order (tolerance tier)
+int prefill_mode();
+int launch_mmx(hipStream_t st, int wtype, const tview & w, const void * act, size_t act_stride, const tview & src1_geom, const tview & dst, const float * resid = nullptr, int64_t ldr = 0, int epi = 0);
+int launch_mmf_exact(hipStream_t st, const tview & w, const tview & x, const tview & d, int causal, int n_past);
+// the eager attention block of a prompt in the reference's order: K.Q (causal) -> SCALE + DIAG_MASK_INF + SOFT_MAX -> V.P; q [hd, qlen, nh] F32, k [hd, n_kv, nkv] F16,
+// vt [n_kv, hd, nkv] F16 (V^T rows); dst element (d, q, h) at d * 4 + q * nbn + h * nbh
+int attn_prefill_exact(hipStream_t st, const tview & q, const tview & k, const tview & vt, char * dst, int64_t nbn, int64_t nbh, float scale, int n_past);
 // fattn.hip: flash attention (tolerance tier).  vl 0: V rows by position [D, n_kv, ..]; vl 1: V^T rows [n_kv, D, ..] (the default V cache)
 int launch_attn_long_flash(hipStream_t st, const float * qkv, const int32_t * pos_dev, const float * rope_cs, int nh, int nkv, int hd, int mode,
                            uint16_t * k_cache, uint16_t * v_cache, int64_t ML, float * S, size_t s_bytes, float * att);      // fattn.hip; CLLM_E_UNSUPPORTED: use launch_attn_long

@@ -551,6 +551,35 @@ __global__ void __launch_bounds__(256) k_argmax_publish(const float * __restrict
     }
     for (int i = threadIdx.x; i < n_inc; i += 256) inc[i][0] = inc[i][0] + 1;
 }
+// the same with ABSOLUTE values: every (pointer, value) record of set_table_dev[] is stored (no read-modify-write of memory the previous graph's later
+// nodes may have reused)
+struct argmax_set_rec { int32_t * ptr; int32_t val; int32_t pad; };
+__global__ void __launch_bounds__(256) k_argmax_publish_set(const float * __restrict__ pv, const int * __restrict__ pi, int np, int32_t * __restrict__ tok_dev,
+                                                            int32_t * __restrict__ tok_host, const argmax_set_rec * __restrict__ recs, int n_set) {
+    __shared__ float bv[4]; __shared__ int bi[4];
+    float best = -INFINITY; int idx = 0x7fffffff;
+    for (int i = threadIdx.x; i < np; i += 256) argmax_combine(best, idx, pv[i], pi[i]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) argmax_combine(best, idx, __shfl_xor(best, o, 64), __shfl_xor(idx, o, 64));
+    if ((threadIdx.x & 63) == 0) { bv[threadIdx.x >> 6] = best; bi[threadIdx.x >> 6] = idx; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 4; w++) argmax_combine(best, idx, bv[w], bi[w]);
+        if (idx == 0x7fffffff) idx = 0;
+        tok_dev[0] = idx;
+        if (tok_host) { tok_host[0] = idx; __threadfence_system(); }
+    }
+    for (int i = threadIdx.x; i < n_set; i += 256) recs[i].ptr[0] = recs[i].val;
+}
+extern "C" int cllm_op_argmax_set(void * stream, const float * logits, int64_t n, int32_t * tok_dev, int32_t * tok_host, const void * set_table_dev, int n_set, void * scratch) {
+    if (!logits || n <= 0 || n > INT32_MAX || !tok_dev || !scratch || n_set < 0 || (n_set && !set_table_dev)) FAIL(CLLM_E_INVALID, "argmax_set: arguments");
+    float * pv = (float *) scratch; int * pi = (int *)((char *) scratch + 1024);
+    hipLaunchKernelGGL(k_argmax_partial, dim3(256), dim3(256), 0, (hipStream_t) stream, logits, (int) n, pv, pi);
+    LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_argmax_publish_set, dim3(1), dim3(256), 0, (hipStream_t) stream, (const float *) pv, (const int *) pi, 256, tok_dev, tok_host, (const argmax_set_rec *) set_table_dev, n_set);
+    LAUNCH_CHECK();
+    return CLLM_OK;
+}
 extern "C" int cllm_op_argmax_advance(void * stream, const float * logits, int64_t n, int32_t * tok_dev, int32_t * tok_host, int32_t * const * inc_ptrs_dev, int n_inc,
                                       void * scratch) {
     if (!logits || n <= 0 || n > INT32_MAX || !tok_dev || !scratch || n_inc < 0 || (n_inc && !inc_ptrs_dev)) FAIL(CLLM_E_INVALID, "argmax_advance: arguments");

@@ -367,7 +367,7 @@ static int forward_general(cllm_llama * m, int qlen, int n_past) {
             cllm_tensor Qv = TS(CLLM_TYPE_F32, q, hd, qlen, nh, (size_t) QKV * 4, (size_t) hd * 4);
             cllm_tensor Vv = TS(CLLM_TYPE_F16, L.v_cache, n_kv, hd, nkv, (size_t) ML * 2, (size_t) ML * hd * 2);
             int frc = CLLM_E_UNSUPPORTED;
-            if (qlen >= flash_prefill_min_cols()) {     // the tolerance tier (as the MFMA mat-muls below): one flash kernel, the scores never reach HBM
+            if (qlen >= flash_prefill_min_cols() && prefill_mode() != 1) {     // fast mode, the tolerance tier (as the MFMA mat-muls below): one flash kernel, the scores never reach HBM
                 tview vt = tv(&Vv); vt.ne[0] = ML;
                 frc = launch_fattn((hipStream_t) st, tv(&Qv), tv(&Kv), CLLM_TYPE_F16, vt, 1, nullptr, n_past, (char *) m->att, (int64_t) QD * 4, (int64_t) hd * 4,
                                    (int64_t) QD * 4 * qlen, 1.0f / sqrtf((float) hd), nullptr, 0);

@@ -438,7 +438,9 @@ int flash_prefill_min_cols() {
 }
 // tests: switch the runner's prefill attention between the flash kernel and the node sequence inside one process (<= 0: back to the environment)
 extern "C" __attribute__((visibility("default"))) void cllm_debug_set_attn_prefill_min_cols(int n) { g_flash_min = n > 0 ? n : -1; }
-size_t fattn_wsize(int64_t N, int64_t H, int64_t B, int64_t D) { return (size_t) B * H * N * FA_MAX_SPLITS * (D + 4) * 4; }
+// split-KV partials exist only on the decode path (N * (H / Hkv) <= 32 query rows per KV head, so N <= 32): a prompt needs no scratch at all
+// (it used to be sized for every N: 8.9 GB for a 2048-token -fa prefill that never touched it)
+size_t fattn_wsize(int64_t N, int64_t H, int64_t B, int64_t D) { return N > 32 ? 0 : (size_t) B * H * N * FA_MAX_SPLITS * (D + 4) * 4; }
 
 template <int D, int KVT, int VL, int MASK>
 static int fattn_launch(hipStream_t st, const fattn_args & a, int B, bool decode) {
@@ -498,8 +500,9 @@ int launch_fattn(hipStream_t st, const tview & q, const tview & k, int ktype, co
         static const int div = getenv("CLLM_FA_DIV") ? atoi(getenv("CLLM_FA_DIV")) : 64;
         int per = tiles / div; if (per < 1) per = 1; if (per < (tiles + FA_MAX_SPLITS - 1) / FA_MAX_SPLITS) per = (tiles + FA_MAX_SPLITS - 1) / FA_MAX_SPLITS;
         a.chunk = per * 64; a.splits = (tiles + per - 1) / per;
+        if (a.splits > 1 && !wdata) { a.splits = 1; a.chunk = (int)((n_kv + 63) / 64 * 64); }      // a caller without scratch (cllm_op_attn_prefill): one workgroup walks the whole cache
         if (a.splits > 1) {
-            if (!wdata || wsize < (size_t) B * H * N * a.splits * (D + 4) * 4 || ((uintptr_t) wdata & 15)) FAIL(CLLM_E_INVALID, "flash_attn_ext: wdata too small");
+            if (wsize < (size_t) B * H * N * a.splits * (D + 4) * 4 || ((uintptr_t) wdata & 15)) FAIL(CLLM_E_INVALID, "flash_attn_ext: wdata too small");
             a.part = (float *) wdata;
         }
     }

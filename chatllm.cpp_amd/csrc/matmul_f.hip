@@ -155,7 +155,8 @@ int launch_mul_mat_f(hipStream_t st, int wtype, const tview & w, const tview & x
     // many src1 columns (prefill attention): matrix cores (mma_f16.hip); few columns (decode): the lane-group mat-vec below
     static const int mma_min_cols = getenv("CLLM_MMA_MIN_COLS") ? atoi(getenv("CLLM_MMA_MIN_COLS")) : 33;      // (below: the exact-order kernels, so that prompts of <= 32 tokens stay bit-identical to the CPU path)
     if (wtype == CLLM_TYPE_F16 && x.ne[1] >= mma_min_cols) {
-        const int rc = launch_mma_f16(st, w, x, d, causal, n_past);
+        const int rc = prefill_mode() == 1 ? launch_mmf_exact(st, w, x, d, causal, n_past)       // the reference's order on the f32 matrix cores (mmf_exact.hip)
+                                           : launch_mma_f16(st, w, x, d, causal, n_past);
         if (rc != CLLM_E_UNSUPPORTED) return rc;
     }
     if (wtype == CLLM_TYPE_F16) return launch_T<uint16_t>(st, w, x, d);

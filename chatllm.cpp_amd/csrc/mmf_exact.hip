@@ -1,0 +1,257 @@
+// mmf_exact.hip -- MUL_MAT with F16 src0 and MANY F32 src1 columns (the prompt's attention contractions K.Q and V.P) in the reference's
+// accumulation ORDER, on the f32 matrix cores: bit-identical to libggml-cpu.so for every prompt length.
+//
+// Reference (ggml_compute_forward_mul_mat, ggml-cpu/ggml-cpu.c:1229-1421): src1 rows are rounded to fp16 (vec_dot_type of F16), then either
+//   T8: tinyBLAS<8, __m256, __m256, ggml_fp16_t, ggml_fp16_t, float> (llamafile/sgemm.cpp:3835-3842, 477-640; taken for >= 2 columns, K % 8 == 0, rows % 4 == 0):
+//       ONE 8-lane accumulator per output element, acc[l] = fma(w[8 s + l], x[8 s + l], acc[l]) over the steps s in order, hsum_float_8; or
+//   VD: ggml_vec_dot_f16 (vec.cpp:264-, AVX2 + F16C): 32 accumulators, acc[a] = fma(w[32 s + a], x[32 s + a], acc[a]), GGML_F32x8_REDUCE's tree,
+//       the K mod 32 leftovers added in double.
+// v_mfma_f32_16x16x4_f32 IS a k-ordered fmaf chain: D = fma(a3, b3, fma(a2, b2, fma(a1, b1, fma(a0, b0, C)))), one rounding per step, bit for bit
+// (tools/micro/mfma_probe.hip, profiles/r03_mfma_layout_probe.txt).  So accumulator a of a 16 x 16 patch of outputs is one MFMA accumulator tile,
+// fed four chain steps per instruction: lane (i, g) supplies element 8 (4 u + g) + a (T8) / 32 (4 u + g) + a (VD) of row i.  The products of two
+// fp16 values are exact in fp32, so the chain is the reference's.  64 FLOP / clk / SIMD = the packed-fp32 VALU peak, with the VALU left free.
+//
+// Tiles: operands staged in LDS as fp16 (src1 rounded with RNE on the way in), 128 elements of K per stage.  T8: workgroup 64 (rows) x 64 (columns),
+// a wave owns 32 x 32 = 4 patches x 8 accumulators (128 registers); VD: workgroup 32 x 32, a wave owns one patch x 32 accumulators.
+// Causal structure of the prompt (the runner / the module's attention pattern pass it): causal 1 (K.Q) skips tiles whose scores are all masked;
+// causal 2 (V.P) ends the K loop where the probabilities of the tile's last column end -- fma(w, 0, acc) == acc, the skipped steps change no bit.
+#include "common.h"
+
+typedef _Float16 h8v __attribute__((ext_vector_type(8)));
+
+struct mmfx_args {
+    tview w, x, d;
+    int causal, n_past;
+};
+
+#define MMFX_KC 128
+#define MMFX_LD (MMFX_KC * 2 + 16)
+
+__device__ __forceinline__ u32x4 load8h(const char * p, int64_t e0, int64_t lim, bool al16) {      // elements e0..e0+7 of an fp16 row (p -> element e0), zero from `lim` on
+    if (e0 + 8 <= lim && al16) return *(const u32x4 *) p;
+    uint32_t r[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int i = 0; i < 8; i++) if (e0 + i < lim) r[i >> 1] |= (uint32_t) *(const uint16_t *)(p + 2 * i) << (16 * (i & 1));
+    return u32x4{r[0], r[1], r[2], r[3]};
+}
+__device__ __forceinline__ u32x4 load8f_as_h(const char * p, int64_t e0, int64_t lim, bool al16) { // elements e0..e0+7 of an f32 row, rounded to fp16 (RNE), zero from `lim` on
+    float v[8];
+    if (e0 + 8 <= lim && al16) {
+        const f32x4 a = *(const f32x4 *) p, b = *(const f32x4 *)(p + 16);
+        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+    } else {
+#pragma unroll
+        for (int i = 0; i < 8; i++) v[i] = e0 + i < lim ? *(const float *)(p + 4 * i) : 0.0f;
+    }
+    uint32_t r[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) r[i] = (uint32_t) f2h(v[2 * i]) | ((uint32_t) f2h(v[2 * i + 1]) << 16);
+    return u32x4{r[0], r[1], r[2], r[3]};
+}
+__device__ __forceinline__ void h8_to_f(const u32x4 r, float (&f)[8]) {
+    const h8v h = __builtin_bit_cast(h8v, r);
+#pragma unroll
+    for (int i = 0; i < 8; i++) f[i] = (float) h[i];
+}
+
+// grid: x = column tiles (fastest), y = row tiles, z = src1's dims 2, 3
+template <bool VD>
+__global__ void __launch_bounds__(256, 2) k_mmf_exact(const mmfx_args a) {
+    __shared__ __attribute__((aligned(16))) char lds[(VD ? 32 + 32 : 64 + 64) * MMFX_LD + (VD ? 2 * 32 * 64 : 0)];
+    constexpr int BN = VD ? 32 : 64, BM = VD ? 32 : 64, PW = VD ? 1 : 2;       // PW x PW patches per wave
+    constexpr int NACC = VD ? 32 : 8;
+    const tview & w = a.w; const tview & x = a.x; const tview & d = a.d;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, g = lane >> 4;
+    const int64_t m0 = (int64_t) blockIdx.x * BM, n0 = (int64_t) blockIdx.y * BN;
+    const int64_t i12 = blockIdx.z % x.ne[2], i13 = blockIdx.z / x.ne[2];
+    const int64_t r2 = x.ne[2] / w.ne[2], r3 = x.ne[3] / w.ne[3];
+    const int64_t K = w.ne[0], N = w.ne[1], M = x.ne[1];
+    // causal 1: score (row n = position, column m = query) is masked when n > n_past + m: a tile whose first row lies beyond the last column's horizon is not computed
+    if (a.causal == 1 && n0 > (int64_t) a.n_past + (m0 + BM - 1 < M - 1 ? m0 + BM - 1 : M - 1)) return;
+    const char * wb = w.data + (i12 / r2) * w.nb[2] + (i13 / r3) * w.nb[3];
+    const char * xb = x.data + i12 * x.nb[2] + i13 * x.nb[3];
+    char * db = d.data + i12 * d.nb[2] + i13 * d.nb[3];
+    const bool w_al = ((((uintptr_t) wb) | (uintptr_t) w.nb[1]) & 15) == 0, x_al = ((((uintptr_t) xb) | (uintptr_t) x.nb[1]) & 15) == 0;
+    // the K range: VD's chains cover K & ~31 (the leftovers go through the double tail); causal 2 ends it at the tile's last visible position
+    const int64_t Kmain = VD ? (K & ~(int64_t) 31) : K;
+    int64_t kvis = K;                                                         // elements at or beyond kvis are zero in every column of this tile
+    if (a.causal == 2) { const int64_t last = (m0 + BM - 1 < M - 1 ? m0 + BM - 1 : M - 1); kvis = (int64_t) a.n_past + last + 1 < K ? (int64_t) a.n_past + last + 1 : K; }
+    const int64_t kend = Kmain < kvis ? Kmain : kvis;                         // main chains: [0, kend) rounded up to whole stages (zero-filled)
+    char * Wt = lds; char * Xt = lds + BN * MMFX_LD;
+    const int wn = (wave & 1) * (PW * 16), wm = (wave >> 1) * (PW * 16);
+
+    f32x4 D[PW][PW][NACC];
+#pragma unroll
+    for (int i = 0; i < PW; i++)
+#pragma unroll
+        for (int j = 0; j < PW; j++)
+#pragma unroll
+            for (int q = 0; q < NACC; q++) D[i][j][q] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+
+    for (int64_t k0 = 0; k0 < kend; k0 += MMFX_KC) {
+        __syncthreads();
+        // ---- stage: BN weight rows and BM activation rows x 128 elements as fp16 ----
+        for (int c = tid; c < (BN + BM) * 16; c += 256) {
+            const int row = c >> 4, ch = c & 15;
+            const int64_t e0 = k0 + ch * 8;
+            u32x4 v = u32x4{0, 0, 0, 0};
+            if (row < BN) {
+                const int64_t n = n0 + row;
+                if (n < N && e0 < kend) v = load8h(wb + n * w.nb[1] + e0 * 2, e0, kend, w_al);
+                *(u32x4 *)(Wt + row * MMFX_LD + ch * 16) = v;
+            } else {
+                const int64_t m = m0 + (row - BN);
+                // causal 2: column m's probabilities end at n_past + m (what lies beyond was never written: read as zero)
+                const int64_t lim = a.causal == 2 ? ((int64_t) a.n_past + m + 1 < kend ? (int64_t) a.n_past + m + 1 : kend) : kend;
+                if (m < M && e0 < lim) v = load8f_as_h(xb + m * x.nb[1] + e0 * 4, e0, lim, x_al);
+                *(u32x4 *)(Xt + (row - BN) * MMFX_LD + ch * 16) = v;
+            }
+        }
+        __syncthreads();
+        // ---- the chains: four steps per MFMA, lane group g supplies step 4 u + g ----
+        if constexpr (!VD) {
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                float xf[PW][8], wf[PW][8];
+#pragma unroll
+                for (int i = 0; i < PW; i++) h8_to_f(*(const u32x4 *)(Xt + (wm + i * 16 + l15) * MMFX_LD + u * 64 + g * 16), xf[i]);
+#pragma unroll
+                for (int j = 0; j < PW; j++) h8_to_f(*(const u32x4 *)(Wt + (wn + j * 16 + l15) * MMFX_LD + u * 64 + g * 16), wf[j]);
+#pragma unroll
+                for (int i = 0; i < PW; i++)
+#pragma unroll
+                    for (int j = 0; j < PW; j++)
+#pragma unroll
+                        for (int L = 0; L < 8; L++) D[i][j][L] = __builtin_amdgcn_mfma_f32_16x16x4f32(xf[i][L], wf[j][L], D[i][j][L], 0, 0, 0);
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; q++) {                                     // vector q of the four: accumulators 8 q + l
+                float xf[8], wf[8];
+                h8_to_f(*(const u32x4 *)(Xt + (wm + l15) * MMFX_LD + g * 64 + q * 16), xf);
+                h8_to_f(*(const u32x4 *)(Wt + (wn + l15) * MMFX_LD + g * 64 + q * 16), wf);
+#pragma unroll
+                for (int L = 0; L < 8; L++) D[0][0][8 * q + L] = __builtin_amdgcn_mfma_f32_16x16x4f32(xf[L], wf[L], D[0][0][8 * q + L], 0, 0, 0);
+            }
+        }
+    }
+
+    // ---- VD: the K mod 32 leftovers of the tile's rows / columns -> LDS (fp16, zero-padded to 32) ----
+    const int nleft = VD ? (int)(K - Kmain) : 0;
+    char * Wl = lds + (BN + BM) * MMFX_LD; char * Xl = Wl + 32 * 64;
+    if (VD && nleft > 0) {
+        __syncthreads();
+        for (int c = tid; c < 64 * 4; c += 256) {
+            const int row = c >> 2, ch = c & 3;
+            const int64_t e0 = Kmain + ch * 8;
+            u32x4 v = u32x4{0, 0, 0, 0};
+            if (row < 32) {
+                const int64_t n = n0 + row;
+                if (n < N && e0 < K) v = load8h(wb + n * w.nb[1] + e0 * 2, e0, K, false);
+                *(u32x4 *)(Wl + row * 64 + ch * 16) = v;
+            } else {
+                const int64_t m = m0 + (row - 32);
+                const int64_t lim = a.causal == 2 ? ((int64_t) a.n_past + m + 1 < K ? (int64_t) a.n_past + m + 1 : K) : K;
+                if (m < M && e0 < lim) v = load8f_as_h(xb + m * x.nb[1] + e0 * 4, e0, lim, false);
+                *(u32x4 *)(Xl + (row - 32) * 64 + ch * 16) = v;
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---- reduce + store: lane holds row n = .. + l15 and the four columns m = .. + 4 g + v ----
+#pragma unroll
+    for (int i = 0; i < PW; i++)
+#pragma unroll
+        for (int j = 0; j < PW; j++) {
+            const int64_t n = n0 + wn + j * 16 + l15;
+#pragma unroll
+            for (int v = 0; v < 4; v++) {
+                const int64_t m = m0 + wm + i * 16 + 4 * g + v;
+                float res;
+                if constexpr (!VD) {                                          // hsum_float_8
+                    float s[8];
+#pragma unroll
+                    for (int L = 0; L < 8; L++) s[L] = D[i][j][L][v];
+                    float r0 = s[4] + s[0], r1 = s[5] + s[1], r2_ = s[6] + s[2], r3_ = s[7] + s[3];
+                    r0 = r0 + r2_; r1 = r1 + r3_;
+                    res = r0 + r1;
+                } else {                                                      // GGML_F32x8_REDUCE, then the leftovers in double
+                    float s0[8];
+#pragma unroll
+                    for (int L = 0; L < 8; L++) { const float p = D[0][0][L][v] + D[0][0][16 + L][v], q = D[0][0][8 + L][v] + D[0][0][24 + L][v]; s0[L] = p + q; }
+                    float t0[4];
+#pragma unroll
+                    for (int L = 0; L < 4; L++) t0[L] = s0[L] + s0[L + 4];
+                    double sumf = (double)((t0[0] + t0[1]) + (t0[2] + t0[3]));
+                    if (nleft > 0) {
+                        const uint16_t * wl = (const uint16_t *)(Wl + (wn + l15) * 64), * xl = (const uint16_t *)(Xl + (wm + 4 * g + v) * 64);
+                        for (int e = 0; e < nleft; e++) sumf += (double)(h2f(wl[e]) * h2f(xl[e]));
+                    }
+                    res = (float) sumf;
+                }
+                if (n < N && m < M) *(float *)(db + m * d.nb[1] + n * 4) = res;
+            }
+        }
+}
+
+// w: F16 [K, N, ne02, ne03] (dense rows), x: F32 [K, M, ne12, ne13] (dense rows), d: F32 [N, M, ne12, ne13] (dense rows); CLLM_E_UNSUPPORTED: shapes this kernel does not take
+int launch_mmf_exact(hipStream_t st, const tview & w, const tview & x, const tview & d, int causal, int n_past) {
+    if (w.nb[0] != 2 || x.nb[0] != 4 || d.nb[0] != 4 || (w.nb[1] | w.nb[2] | w.nb[3]) % 2 || (x.nb[1] | x.nb[2] | x.nb[3] | d.nb[1] | d.nb[2] | d.nb[3]) % 4) return CLLM_E_UNSUPPORTED;
+    const int64_t K = w.ne[0], N = w.ne[1], M = x.ne[1], Z = x.ne[2] * x.ne[3];
+    if (K <= 0 || N <= 0 || M <= 0 || Z <= 0 || Z > 65535) return CLLM_E_UNSUPPORTED;
+    mmfx_args a; a.w = w; a.x = x; a.d = d; a.causal = causal; a.n_past = n_past;
+    // llamafile_sgemm takes the product when n >= 2, k % 8 == 0, m % 4 == 0 (sgemm.cpp:3691, 488, 503-517); else the vec_dot loop
+    const bool t8 = M >= 2 && K % 8 == 0 && N % 4 == 0;
+    if (t8) {
+        if ((N + 63) / 64 > 65535) return CLLM_E_UNSUPPORTED;
+        hipLaunchKernelGGL((k_mmf_exact<false>), dim3((unsigned)((M + 63) / 64), (unsigned)((N + 63) / 64), (unsigned) Z), dim3(256), 0, st, a);
+    } else {
+        if ((N + 31) / 32 > 65535) return CLLM_E_UNSUPPORTED;
+        hipLaunchKernelGGL((k_mmf_exact<true>), dim3((unsigned)((M + 31) / 32), (unsigned)((N + 31) / 32), (unsigned) Z), dim3(256), 0, st, a);
+    }
+    LAUNCH_CHECK();
+    return CLLM_OK;
+}
+
+// ---- the prompt's eager attention block in the reference's order (calc_attn_scores / attn_scores_to_probs, src/layers.cpp:2541-2561, 2499-2539):
+//      S = K.Q (scores never needed beyond the causal horizon are not computed), P = SOFT_MAX(DIAG_MASK_INF(SCALE(S))), ctx = V.P.
+//      The score matrix [n_kv, qlen, heads] goes through a library-owned scratch buffer, a group of heads at a time (<= 1 GiB).
+static void * g_attn_scr = nullptr; static size_t g_attn_scr_bytes = 0;
+int attn_prefill_exact(hipStream_t st, const tview & q, const tview & k, const tview & vt, char * dst, int64_t nbn, int64_t nbh, float scale, int n_past) {
+    const int64_t hd = q.ne[0], qlen = q.ne[1], nh = q.ne[2], n_kv = k.ne[1], nkv = k.ne[2];
+    if (nkv <= 0 || nh % nkv || k.ne[0] != hd || vt.ne[0] != n_kv || vt.ne[1] <= 0 || vt.ne[2] != nkv || q.ne[3] != 1 || k.ne[3] != 1 || n_kv != (int64_t) n_past + qlen) return CLLM_E_UNSUPPORTED;
+    const int64_t r2 = nh / nkv;
+    const size_t per_head = (size_t) n_kv * (size_t) qlen * 4;
+    const size_t cap = (size_t) 1 << 30;
+    int64_t hc = (int64_t)(cap / per_head) / r2 * r2;                 // heads per pass: whole GQA groups
+    if (hc < r2) hc = r2;
+    if (hc > nh) hc = nh;
+    const size_t need = per_head * (size_t) hc;
+    if (need > g_attn_scr_bytes) {
+        HIP_TRY(hipStreamSynchronize(st));
+        if (g_attn_scr) (void) hipFree(g_attn_scr);
+        g_attn_scr = nullptr; g_attn_scr_bytes = 0;
+        HIP_TRY(hipMalloc(&g_attn_scr, need));
+        g_attn_scr_bytes = need;
+    }
+    for (int64_t h0 = 0; h0 < nh; h0 += hc) {
+        const int64_t nhc = h0 + hc <= nh ? hc : nh - h0;
+        tview qv = q; qv.data += h0 * q.nb[2]; qv.ne[2] = nhc; qv.ne[3] = 1;
+        tview kv = k; kv.data += (h0 / r2) * k.nb[2]; kv.ne[2] = nhc / r2; kv.ne[3] = 1;
+        tview S; S.data = (char *) g_attn_scr; S.ne[0] = n_kv; S.ne[1] = qlen; S.ne[2] = nhc; S.ne[3] = 1;
+        S.nb[0] = 4; S.nb[1] = n_kv * 4; S.nb[2] = n_kv * qlen * 4; S.nb[3] = S.nb[2] * nhc;
+        int rc = launch_mmf_exact(st, kv, qv, S, 1, n_past);
+        if (rc) return rc;
+        cllm_tensor St; St.type = CLLM_TYPE_F32; St.data = S.data;
+        for (int i = 0; i < 4; i++) { St.ne[i] = S.ne[i]; St.nb[i] = (size_t) S.nb[i]; }
+        rc = cllm_op_scale_mask_soft_max((void *) st, &St, &St, scale, n_past);
+        if (rc) return rc;
+        tview vv = vt; vv.data += (h0 / r2) * vt.nb[2]; vv.ne[0] = n_kv; vv.ne[2] = nhc / r2; vv.ne[3] = 1;
+        tview d; d.data = dst + h0 * nbh; d.ne[0] = vt.ne[1]; d.ne[1] = qlen; d.ne[2] = nhc; d.ne[3] = 1;
+        d.nb[0] = 4; d.nb[1] = nbn; d.nb[2] = nbh; d.nb[3] = nbh * nhc;
+        rc = launch_mmf_exact(st, vv, S, d, 2, n_past);
+        if (rc) return rc;
+    }
+    return CLLM_OK;
+}

@@ -42,9 +42,10 @@ struct hip_backend_ctx {
     struct {
         bool armed = false, inflight = false;
         void * ev = nullptr, * table_dev = nullptr, * scratch = nullptr, * snap = nullptr; size_t snap_bytes = 0; int32_t * tok_host = nullptr;
+        struct set_rec { const void * ptr; int32_t val, pad; }; set_rec * tab_host = nullptr;      // page-locked: the (pointer, absolute value) records of the step started ahead
         const void * ids_ptr = nullptr, * logits_ptr = nullptr; size_t logits_bytes = 0;
         struct out_range { const char * ptr; size_t bytes, snap_off; }; std::vector<out_range> outs;      // every OUTPUT tensor of the graph (snapshots)
-        std::vector<scalar_set> last_sets, pred; std::vector<const void *> table;
+        std::vector<scalar_set> last_sets, pred;
         int misses = 0; long graphs = 0, skip_until = 0, hits = 0, launched = 0;
     } ahead;
 };
@@ -176,6 +177,7 @@ void buf_set(ggml_backend_buffer_t b, ggml_tensor * t, const void * data, size_t
         if (size == 4 && off == 0 && t->type == GGML_TYPE_I32 && c->device < 64) {
             hip_backend_ctx::scalar_set ss; ss.ptr = t->data; memcpy(&ss.val, data, 4);
             if (g_scalar_sets[c->device].size() < 1024) g_scalar_sets[c->device].push_back(ss);
+            else scalar = false;                          // not recorded: must not be held back either (written through below, after the step running ahead has finished)
         } else scalar = false;
     }
     if (!scalar) ahead_quiesce(c->device);
@@ -372,6 +374,10 @@ bool dev_supports_op(ggml_backend_dev_t, const ggml_tensor * op) {
             if (a->nb[1] % 16 || a->nb[2] % 16 || a->nb[3] % 16 || !ggml_is_contiguous(op)) return false;
             if (b->type == GGML_TYPE_F16 && (b->nb[1] % 16 || b->nb[2] % 16 || b->nb[3] % 16 || v->nb[1] % 16 || v->nb[2] % 16 || v->nb[3] % 16)) return false;
             if (m && (m->type != GGML_TYPE_F16 || !ggml_is_contiguous(m) || m->ne[0] < b->ne[1] || m->ne[1] < a->ne[1])) return false;
+            // the C ABI's own predicates (cllm_op_flash_attn_ext): a mask broadcasts over heads / batches only as 1 or the full count (ggml allows any divisor)
+            if (m && ((m->ne[2] != 1 && m->ne[2] != a->ne[2]) || (m->ne[3] != 1 && m->ne[3] != a->ne[3]))) return false;
+            // (q's data pointer must be 16-byte aligned as well: every block ggml-alloc hands out is aligned to the buffer type's 256 bytes and the reference's
+            //  q is a PERMUTE of a contiguous projection -- checked again at run time, where a mismatch is an error rather than a fallback)
             return a->ne[2] <= 65535 && a->ne[3] <= 65535;
         }
         case GGML_OP_CPY: case GGML_OP_DUP: case GGML_OP_CONT: {
@@ -400,6 +406,7 @@ void be_free(ggml_backend_t b) {
     if (c->ahead.ev) cllm_event_destroy(c->ahead.ev);
     if (c->ahead.tok_host) cllm_host_free(c->ahead.tok_host);
     if (c->ahead.table_dev) cllm_free(c->ahead.table_dev);
+    if (c->ahead.tab_host) cllm_host_free(c->ahead.tab_host);
     if (c->ahead.scratch) cllm_free(c->ahead.scratch);
     if (c->ahead.snap) cllm_free(c->ahead.snap);
     cllm_stream_destroy(c->stream);
@@ -1067,7 +1074,8 @@ void ahead_launch(hip_backend_ctx * c) {
     cllm_set_device(c->device);
     if (!A.ev && cllm_event_create(&A.ev) != CLLM_OK) return;
     if (!A.tok_host) { void * p = nullptr; if (cllm_host_malloc(&p, 64) != CLLM_OK) return; A.tok_host = (int32_t *) p; }
-    if (!A.table_dev && cllm_malloc(&A.table_dev, 1024 * sizeof(void *)) != CLLM_OK) return;
+    if (!A.table_dev && cllm_malloc(&A.table_dev, 1024 * 16) != CLLM_OK) return;
+    if (!A.tab_host) { void * p = nullptr; if (cllm_host_malloc(&p, 1024 * 16) != CLLM_OK) return; A.tab_host = (decltype(A.tab_host)) p; }
     if (!A.scratch && cllm_malloc(&A.scratch, 2048) != CLLM_OK) return;
     size_t snap_need = 0;
     for (auto & o : A.outs) { o.snap_off = snap_need; snap_need += (o.bytes + 255) & ~(size_t) 255; }
@@ -1076,17 +1084,22 @@ void ahead_launch(hip_backend_ctx * c) {
         if (cllm_malloc(&A.snap, snap_need) != CLLM_OK) return;
         A.snap_bytes = snap_need;
     }
-    std::vector<const void *> table;
+    // the scalars of the next step as ABSOLUTE values (the position scalars + 1; the token id comes from the argmax): the device words are not read -- ggml-alloc may
+    // have handed their blocks to later nodes of the graph that just ran.  One record per distinct pointer (the host's last write of a step wins).
     A.pred.clear();
-    for (const auto & ss : A.last_sets) { A.pred.push_back(ss); if (ss.ptr != A.ids_ptr) { table.push_back(ss.ptr); A.pred.back().val = ss.val + 1; } }
-    if (table.size() > 1024) return;
-    if (table != A.table) {
-        if (!table.empty() && (cllm_memcpy_h2d(A.table_dev, table.data(), table.size() * sizeof(void *), nullptr) != CLLM_OK || cllm_stream_sync(nullptr) != CLLM_OK)) return;
-        A.table = table;
+    int n_rec = 0;
+    for (const auto & ss : A.last_sets) {
+        A.pred.push_back(ss);
+        if (ss.ptr == A.ids_ptr) continue;
+        A.pred.back().val = ss.val + 1;
+        int k = 0; while (k < n_rec && A.tab_host[k].ptr != ss.ptr) k++;
+        if (k == n_rec) { if (n_rec >= 1024) return; n_rec++; }
+        A.tab_host[k].ptr = ss.ptr; A.tab_host[k].val = ss.val + 1; A.tab_host[k].pad = 0;
     }
     void * st = c->stream;
+    if (n_rec && cllm_memcpy_h2d(A.table_dev, A.tab_host, (size_t) n_rec * 16, st) != CLLM_OK) return;      // queued on the step's stream from page-locked memory; done before the event below
     for (const auto & o : A.outs) if (cllm_memcpy_d2d((char *) A.snap + o.snap_off, o.ptr, o.bytes, st) != CLLM_OK) { cllm_stream_sync(st); return; }
-    if (cllm_op_argmax_advance(st, (const float *) A.logits_ptr, (int64_t)(A.logits_bytes / 4), (int32_t *) A.ids_ptr, A.tok_host, (int32_t * const *) A.table_dev, (int) table.size(), A.scratch) != CLLM_OK) return;
+    if (cllm_op_argmax_set(st, (const float *) A.logits_ptr, (int64_t)(A.logits_bytes / 4), (int32_t *) A.ids_ptr, A.tok_host, A.table_dev, n_rec, A.scratch) != CLLM_OK) return;
     if (cllm_event_record(A.ev, st) != CLLM_OK) { cllm_stream_sync(st); return; }
     if (cllm_graph_launch(c->graph_exec, st) != CLLM_OK) { cllm_stream_sync(st); return; }
     static const bool ahead_sync = getenv("CLLM_HIP_AHEAD_SYNC") != nullptr;       // (debugging: run the step ahead to completion before returning)
@@ -1118,6 +1131,16 @@ ggml_status be_graph_compute(ggml_backend_t backend, ggml_cgraph * g) {
     cllm_set_device(c->device);
     std::vector<hip_backend_ctx::scalar_set> cur_sets;
     { std::lock_guard<std::mutex> lock(g_ring.m); if (c->device < 64) cur_sets.swap(g_scalar_sets[c->device]); }
+    if (c->device < 64 && g_ahead_ctx[c->device] && g_ahead_ctx[c->device] != c && g_ahead_ctx[c->device]->ahead.inflight) {
+        // another backend context of this device (a draft / embedding / accessory model) has a step running ahead: buf_set held this graph's scalar writes back
+        // for THAT context's hit test -- they are ours.  Let the step finish, put them in place, and leave that context to run its next step the normal way.
+        hip_backend_ctx * o = g_ahead_ctx[c->device];
+        ahead_quiesce(c->device);
+        o->ahead.inflight = false; o->ahead.armed = false; o->ahead.misses = 0;
+        cllm_set_device(c->device);
+        for (const auto & ss : cur_sets) if (cllm_memcpy_h2d((void *) ss.ptr, &ss.val, 4, nullptr) != CLLM_OK) { HIPB_LOG("scalar write failed: %s", cllm_last_error()); return GGML_STATUS_FAILED; }
+        if (cllm_stream_sync(nullptr) != CLLM_OK) return GGML_STATUS_FAILED;
+    }
     c->ahead.graphs++;
     fuse_plan plan = make_plan(g);
     if (trace) {

@@ -68,6 +68,8 @@ SIGNATURES = {
     "cllm_mul_mat_wsize": (C.c_size_t, [_T, _T]),
     "cllm_op_mul_mat": (C.c_int, [_P, _T, _T, _T, _P, C.c_size_t]),
     "cllm_mul_mat_ex_min_cols": (C.c_int, []),
+    "cllm_set_prefill_mode": (C.c_int, [C.c_int]),
+    "cllm_get_prefill_mode": (C.c_int, []),
     "cllm_op_mul_mat_ex": (C.c_int, [_P, _T, _T, _T, _P, C.c_size_t, C.c_int, _T, C.c_float, C.c_int, _T]),
     "cllm_op_mul_mat_vec_fused": (C.c_int, [_P, _T, C.c_int, _P, _P, C.c_float, C.c_int, _P, _P]),
     "cllm_pack_rows": (C.c_int, [_P, _P, C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.c_int, C.c_size_t, C.c_int]),
@@ -77,6 +79,7 @@ SIGNATURES = {
                                         C.POINTER(C.c_float)]),
     "cllm_op_mul_mat_id": (C.c_int, [_P, _T, _T, _T, _T, _P, C.c_size_t]),
     "cllm_op_argmax_advance": (C.c_int, [_P, _P, C.c_int64, _P, _P, _P, C.c_int, _P]),
+    "cllm_op_argmax_set": (C.c_int, [_P, _P, C.c_int64, _P, _P, _P, C.c_int, _P]),
     "cllm_flash_attn_wsize": (C.c_size_t, [_T]),
     "cllm_op_flash_attn_ext": (C.c_int, [_P, _T, _T, _T, _T, _T, C.c_float, C.c_float, C.c_float, _P, C.c_size_t]),
     "cllm_attn_prefill_min_cols": (C.c_int, []),

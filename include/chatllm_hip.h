@@ -120,6 +120,15 @@ CLLM_API int    cllm_op_mul_mat(void * stream, const cllm_tensor * src0, const c
  * Only for src1->ne[1] >= the matrix-core threshold (33 columns; CLLM_E_UNSUPPORTED below it: the caller issues the nodes).  The fused quantizers and
  * epilogues produce the bits of the separate RMS_NORM / MUL / SiLU / quantize / ADD passes. */
 CLLM_API int    cllm_mul_mat_ex_min_cols(void);
+/* How MUL_MAT with more than 32 activation columns and the prompt's attention block (cllm_op_attn_prefill, F16 MUL_MAT with > 32 columns) are computed:
+ *   1 (default; CLLM_PREFILL=exact): the reference's accumulation ORDER for every prompt length -- the integer block sums of tinyBLAS_Q0_AVX / ggml_vec_dot_q4_K_q8_K
+ *     (llamafile/sgemm.cpp:1346-1790, arch/x86/quants.c:1742-1822) on the K = 4 matrix-core instruction, their fp32 chains in block order; ggml_vec_dot_f16 /
+ *     tinyBLAS<8> (vec.cpp:264-, sgemm.cpp:477-640) as fmaf chains on the f32 matrix cores: results bit-identical to libggml-cpu.so;
+ *   0 (CLLM_PREFILL=fast): int8-MFMA GEMM + flash attention kernel, their own fp32 summation order (tolerance tier; the discontinuous activation quantizers
+ *     downstream amplify that to ~0.1 sigma of the logits).
+ * Process-wide; not meant to change while work is in flight. */
+CLLM_API int    cllm_set_prefill_mode(int mode);
+CLLM_API int    cllm_get_prefill_mode(void);
 CLLM_API int    cllm_op_mul_mat_ex(void * stream, const cllm_tensor * src0, const cllm_tensor * src1, cllm_tensor * dst, void * wdata, size_t wsize,
                                    int pro, const cllm_tensor * norm_w, float eps, int epi, const cllm_tensor * resid);
 
@@ -207,7 +216,8 @@ CLLM_API size_t cllm_flash_attn_wsize(const cllm_tensor * q);
 CLLM_API int    cllm_op_flash_attn_ext(void * stream, const cllm_tensor * q, const cllm_tensor * k, const cllm_tensor * v, const cllm_tensor * mask,
                                        cllm_tensor * dst, float scale, float max_bias, float logit_softcap, void * wdata, size_t wsize);
 /* the prefill attention block of the eager path, MUL_MAT(K, Q) + SCALE + DIAG_MASK_INF + SOFT_MAX + MUL_MAT(V^T, P) (src/layers.cpp:2499-2561),
- * as ONE flash kernel (qlen > 32: the tolerance tier, as the MFMA mat-muls it replaces):  q F32 [D, N, H]; k F16 [D, n_kv, Hkv] rows;
+ * in one call (qlen > 32).  Prefill mode 1 (default): K.Q -> soft_max -> V.P on the exact-order kernels (bit-identical to the node sequence and to the CPU; the
+ * scores pass through a library-owned scratch buffer); mode 0: ONE flash kernel (tolerance tier).  q F32 [D, N, H]; k F16 [D, n_kv, Hkv] rows;
  * vt F16 [n_kv, D, Hkv] (the transposed V cache view); dst F32 [D, N, H] (any 16-byte aligned strides); causal with n_past. */
 CLLM_API int    cllm_attn_prefill_min_cols(void);   /* query rows from which callers should use it (33; CLLM_MMA_MIN_COLS; CLLM_FLASH_PREFILL=0: never) */
 CLLM_API int    cllm_op_attn_prefill(void * stream, const cllm_tensor * q, const cllm_tensor * k, const cllm_tensor * vt, cllm_tensor * dst,
@@ -219,6 +229,10 @@ CLLM_API int    cllm_op_attn_prefill(void * stream, const cllm_tensor * q, const
  * next step).  scratch: 2 KB of device memory. */
 CLLM_API int cllm_op_argmax_advance(void * stream, const float * logits, int64_t n, int32_t * tok_dev, int32_t * tok_host,
                                     int32_t * const * inc_ptrs_dev, int n_inc, void * scratch);
+/* the same with ABSOLUTE values instead of increments: set_table_dev[] = n_set records { int32_t * ptr; int32_t val; int32_t pad; } (16 bytes each, device memory);
+ * *ptr = val for every record (distinct pointers).  What the module's decode-ahead uses: the memory of a per-token scalar may have been reused by later nodes
+ * of the previous graph, so its old content is not something to increment. */
+CLLM_API int cllm_op_argmax_set(void * stream, const float * logits, int64_t n, int32_t * tok_dev, int32_t * tok_host, const void * set_table_dev, int n_set, void * scratch);
 
 /* fused single-token attention as chatllm's eager path emits it for qlen == 1 (src/layers.cpp:2541-2561, 2499-2539):
  *   MUL_MAT(K view, Q) + SCALE(1/sqrt(hd)) + DIAG_MASK_INF + SOFT_MAX + MUL_MAT(V view, P) + PERMUTE + CONT

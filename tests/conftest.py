@@ -44,3 +44,18 @@ def gpu(pkg):
     pkg.lib.get()
     pkg.lib.require_gpu()
     return pkg
+
+
+import contextlib
+
+
+@contextlib.contextmanager
+def prefill_mode(pkg, mode):
+    """switch how > 32-column mat-muls and the prompt's attention block are computed (1: the reference's order, the default; 0: the fast tolerance-tier kernels)"""
+    L = pkg.lib.get()
+    old = L.cllm_get_prefill_mode()
+    assert L.cllm_set_prefill_mode(mode) == 0
+    try:
+        yield
+    finally:
+        L.cllm_set_prefill_mode(old)

@@ -245,6 +245,21 @@ def test_baseline_cfg2_llama3_8b_q4_k_16_plus_64_free_running(gpu, tmp_path):
 
 
 @_BIG
+@pytest.mark.parametrize("wname,wt", [("q4_0", 2), ("q4_k", 12)])
+def test_llama3_8b_512_token_prompt_free_running(gpu, tmp_path, wname, wt):
+    """a prompt far beyond the 32-column limit of round 2's exact kernels at Llama-3-8B shapes: 512 tokens as one graph, then 8 greedy tokens, free-running;
+    0 id mismatches, every logit word identical (mmx.hip + mmf_exact.hip behind the module's prefill patterns)"""
+    _real_shape_case(gpu, tmp_path, "llama3", "llama3-8b", wt, [(7 * i + 11) % 32000 for i in range(512)], 8, dict(max_len=640), threads=64)
+
+
+@_BIG
+@pytest.mark.skipif(bool(os.environ.get("CLLM_SKIP_CFG3")), reason="CLLM_SKIP_CFG3 set (the reference's CPU run of the 4096-token prompt takes ~100 s on the box's host)")
+def test_baseline_cfg3_llama3_8b_q4_0_4096_token_prompt_free_running(gpu, tmp_path):
+    """BASELINE cfg3: Llama-3-8B shapes, Q4_0, ONE 4096-token prompt (a single graph), then 4 greedy tokens, free-running, CPU host vs every layer on the module"""
+    _real_shape_case(gpu, tmp_path, "llama3", "llama3-8b", 2, [(7 * i + 11) % 32000 for i in range(4096)], 4, dict(max_len=4608), threads=64)
+
+
+@_BIG
 def test_baseline_cfg5_mixtral_shapes_q4_k_free_running(gpu, tmp_path):
     """BASELINE cfg5's block at real shapes (Mixtral-8x7B: H 4096, F 14336, 8 experts, top 2, Q4_K), 4 of the 32 layers to bound the file (3.4 GB)"""
     _real_shape_case(gpu, tmp_path, "mixtral", "mixtral-8x7b", 12, [(11 * i + 5) % 32000 for i in range(16)], 48, dict(max_len=512, n_layer=4))
@@ -309,9 +324,34 @@ def test_reference_host_flash_attention_on_our_module(gpu, tmp_path, cache):
 
 @pytest.mark.skipif(not (os.path.exists(os.path.join(REF, "ref_chat")) and os.path.exists(os.path.join(REF, "libggml-hip.so"))),
                     reason="oracle/_ref (reference host + module) not built")
-def test_reference_host_long_prompt_uses_the_flash_prefill(gpu, tmp_path):
-    """the default (eager) attention with a prompt of more than 32 tokens: MUL_MAT + SCALE + DIAG_MASK_INF + SOFT_MAX + MUL_MAT of every layer
-    run as one flash kernel (tolerance tier, like the MFMA mat-muls of the same prompt); the decode steps after it are the exact kernels again"""
+@pytest.mark.parametrize("wname,wt,nprompt", [("q4_0", 2, 70), ("q4_k", 12, 200), ("q8_0", 8, 45), ("q4_1", 3, 33)])
+def test_reference_host_long_prompt_is_bit_identical_free_running(gpu, tmp_path, wname, wt, nprompt):
+    """the default (eager) attention with a prompt of more than 32 tokens, default prefill mode: the quantized mat-muls run on mmx.hip (with the module's
+    prologue / epilogue fusions), MUL_MAT + SCALE + DIAG_MASK_INF + SOFT_MAX + MUL_MAT of every layer as one cllm_op_attn_prefill call on the exact-order
+    kernels -- FREE-RUNNING, every logit of the prompt and of the decode steps after it has the bits of the reference's CPU run"""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import make_ggmm
+    cfg = gpu.synth.config("small", max_len=256)
+    mp = str(tmp_path / "m.bin")
+    make_ggmm.write_model(mp, cfg, wt, seed=80)
+    prompt = [(7 * i + 3) % cfg["vocab"] for i in range(nprompt)]
+    ids_c, lg_c, _ = _host_run(tmp_path, mp, "cpu", 8, prompt, cfg["vocab"])
+    ids_g, lg_g, err = _host_run(tmp_path, mp, "all", 8, prompt, cfg["vocab"])
+    stats = [ln for ln in err.splitlines() if "graph_compute:" in ln and "calls" in ln]
+    assert f"flash prefill: {cfg['n_layer']}" in stats[0], stats[0]           # the attention pattern was taken (one call per layer)
+    assert f"prefill mat-muls with fused prologue / epilogue: {7 * cfg['n_layer']})" in stats[0], stats[0]
+    assert ids_c == ids_g
+    assert np.array_equal(lg_c.view(np.uint32), lg_g.view(np.uint32)), [int(np.sum(lg_c[i].view(np.uint32) != lg_g[i].view(np.uint32))) for i in range(9)]
+    # and the same bits without the module's prefill patterns (one call per node)
+    ids_p, lg_p, _ = _host_run(tmp_path, mp, "all", 8, prompt, cfg["vocab"], CLLM_HIP_NO_PREFILL_FUSE="1", CLLM_HIP_FUSE_ATTN="0")
+    assert lg_g.tobytes() == lg_p.tobytes()
+
+
+@pytest.mark.skipif(not (os.path.exists(os.path.join(REF, "ref_chat")) and os.path.exists(os.path.join(REF, "libggml-hip.so"))),
+                    reason="oracle/_ref (reference host + module) not built")
+def test_reference_host_long_prompt_fast_mode_uses_the_flash_prefill(gpu, tmp_path):
+    """CLLM_PREFILL=fast: MUL_MAT + SCALE + DIAG_MASK_INF + SOFT_MAX + MUL_MAT of every layer run as one flash kernel and the mat-muls on the int8 MFMA GEMM
+    (tolerance tier); the decode steps after it are the exact kernels again"""
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import make_ggmm
     cfg = gpu.synth.config("small", max_len=128)
@@ -319,19 +359,19 @@ def test_reference_host_long_prompt_uses_the_flash_prefill(gpu, tmp_path):
     make_ggmm.write_model(mp, cfg, 2, seed=80)
     prompt = [(7 * i + 3) % cfg["vocab"] for i in range(70)]
     ids_c, lg_c, _ = _host_run(tmp_path, mp, "cpu", 8, prompt, cfg["vocab"])
-    ids_g, lg_g, err = _host_run(tmp_path, mp, "all", 8, prompt, cfg["vocab"], teacher=ids_c)
+    ids_g, lg_g, err = _host_run(tmp_path, mp, "all", 8, prompt, cfg["vocab"], teacher=ids_c, CLLM_PREFILL="fast")
     stats = [ln for ln in err.splitlines() if "graph_compute:" in ln and "calls" in ln]
     assert f"flash prefill: {cfg['n_layer']}" in stats[0], stats[0]
     assert all("flash prefill: 0" in ln for ln in stats[1:])
     dev, clear = _tolerance_tier(lg_c, lg_g, ids_c, 0.25)
-    ids_n, lg_n, _ = _host_run(tmp_path, mp, "all", 8, prompt, cfg["vocab"], teacher=ids_c, CLLM_FLASH_PREFILL="0")
+    ids_n, lg_n, _ = _host_run(tmp_path, mp, "all", 8, prompt, cfg["vocab"], teacher=ids_c, CLLM_PREFILL="fast", CLLM_FLASH_PREFILL="0")
     dev_n, _ = _tolerance_tier(lg_c, lg_n, ids_c, 0.25)
-    print(f"70-token prompt: flash prefill max|dlogit| = {dev:.2e} sigma, node sequence (MFMA mat-muls) {dev_n:.2e} sigma")
+    print(f"70-token prompt, fast mode: flash prefill max|dlogit| = {dev:.2e} sigma, node sequence (MFMA mat-muls) {dev_n:.2e} sigma")
     assert dev < 2 * dev_n + 1e-3                                    # the fused form is no worse than the node sequence it replaces
     # the prompt graph's quantized mat-muls carry their neighbours: norm / SiLU * up in the quantizer, q / k / v and gate / up share one quantization, residual
     # adds in the epilogue (7 per layer) -- and that changes no bit against the same mat-muls issued node by node
     assert f"prefill mat-muls with fused prologue / epilogue: {7 * cfg['n_layer']})" in stats[0], stats[0]
-    ids_p, lg_p, _ = _host_run(tmp_path, mp, "all", 8, prompt, cfg["vocab"], teacher=ids_c, CLLM_HIP_NO_PREFILL_FUSE="1")
+    ids_p, lg_p, _ = _host_run(tmp_path, mp, "all", 8, prompt, cfg["vocab"], teacher=ids_c, CLLM_PREFILL="fast", CLLM_HIP_NO_PREFILL_FUSE="1")
     assert lg_g.tobytes() == lg_p.tobytes()
 
 

@@ -13,6 +13,7 @@ import numpy as np
 import pytest
 
 import oracle as O
+from conftest import prefill_mode
 from synth_helpers import rand_blocks
 
 pytestmark = pytest.mark.gpu
@@ -192,5 +193,9 @@ def test_attn_prefill_against_the_node_sequence(gpu, D, N, H, Hkv, n_past, ML):
     dk = T.from_numpy(kc, gpu.F16, [KD, ML]).view([D, n_kv, Hkv], [2, KD * 2, D * 2])
     dv = T.from_numpy(vc, gpu.F16, [ML, KD]).view([n_kv, D, Hkv], [2, ML * 2, ML * D * 2])
     got = gpu.ops.attn_prefill(dq, dk, dv, scale, n_past).numpy().reshape(H, N, D)
+    # the default (prefill mode 1): K.Q -> soft_max -> V.P in the reference's order (mmf_exact.hip): every word equals the node sequence's
+    assert np.array_equal(got.view(np.uint32), ctx.view(np.uint32)), rel_err(got, ctx)
+    with prefill_mode(gpu, 0):             # CLLM_PREFILL=fast: ONE flash kernel, tolerance tier
+        got = gpu.ops.attn_prefill(dq, dk, dv, scale, n_past).numpy().reshape(H, N, D)
     assert np.all(np.isfinite(got))
     assert rel_err(got, ctx) < FA_EXACT

@@ -11,6 +11,7 @@ import numpy as np
 import pytest
 
 import oracle as O
+from conftest import prefill_mode
 from synth_helpers import rand_blocks
 
 pytestmark = pytest.mark.gpu
@@ -134,13 +135,30 @@ def test_mul_mat_quant_long_rows(gpu, t, K):
 @pytest.mark.parametrize("K,N,M", [(512, 64, 16), (1024, 100, 33), (4096, 256, 128), (256, 17, 9),
                                    (768, 130, 70), (4352, 300, 257)])        # two token tiles, ragged N / M / K
 def test_mul_mat_quant_gemm(gpu, t, K, N, M):
-    """up to 32 columns: the exact-order mat-vec in column chunks (bit-identical); beyond, the int8-MFMA GEMM: exact integer block sums, its own
-    fp32 summation order (tier T1)"""
+    """any number of columns, bit-identical to the oracle == libggml-cpu.so: up to 32 columns the exact-order mat-vec in column chunks; beyond, mmx.hip
+    (integer block sums on the K = 4 matrix-core instruction, the fp32 chains in the reference's block order)"""
     got, want = _mm_case(gpu, t, K, N, M)
-    if M <= 32:
-        assert np.array_equal(got.view(np.uint32).ravel(), want.view(np.uint32).ravel()), rel_err(got, want)
-    else:
-        assert rel_err(got, want) < T1
+    assert np.array_equal(got.view(np.uint32).ravel(), want.view(np.uint32).ravel()), rel_err(got, want)
+
+
+@pytest.mark.parametrize("t", [O.Q4_K, O.Q4_0, O.Q8_0, O.Q4_1])
+@pytest.mark.parametrize("K,N,M", [(14336, 70, 40), (4128, 65, 33), (256, 5, 100), (2048, 129, 513), (32, 3, 64)])
+def test_mul_mat_quant_exact_many_columns(gpu, t, K, N, M):
+    """mmx.hip at its edges: long rows (56 super-blocks), K that is not a multiple of the 256-element stage (32-block types), one-block rows,
+    ragged row / token tiles, several token tiles -- every output word equals the reference's"""
+    if t == O.Q4_K and K % 256:
+        pytest.skip("Q4_K rows are whole super-blocks")
+    got, want = _mm_case(gpu, t, K, N, M)
+    assert np.array_equal(got.view(np.uint32).ravel(), want.view(np.uint32).ravel()), rel_err(got, want)
+
+
+@pytest.mark.parametrize("t", [O.Q4_K, O.Q4_0, O.Q8_0, O.Q4_1])
+@pytest.mark.parametrize("K,N,M", [(1024, 100, 33), (4096, 256, 128), (768, 130, 70), (4352, 300, 257)])
+def test_mul_mat_quant_gemm_fast_mode(gpu, t, K, N, M):
+    """prefill mode 0 (CLLM_PREFILL=fast): the int8-MFMA GEMM (mmq.hip): exact integer block sums, its own fp32 summation order (tier T1)"""
+    with prefill_mode(gpu, 0):
+        got, want = _mm_case(gpu, t, K, N, M)
+    assert rel_err(got, want) < T1
 
 
 @pytest.mark.parametrize("t", [O.F16, O.F32])
@@ -148,13 +166,23 @@ def test_mul_mat_quant_gemm(gpu, t, K, N, M):
                                              # >= 32 columns: the F16 case runs on the matrix cores (mma_f16.hip): full tiles, ragged N / M / K, GQA broadcast
                                              (128, 256, 128, 1, 1), (128, 200, 77, 2, 8), (328, 130, 33, 1, 4), (72, 17, 40, 1, 1), (8, 3, 32, 1, 2)])
 def test_mul_mat_float(gpu, t, K, N, M, ne02, ne12):
-    """up to 32 columns (F16) / always (F32): ggml_vec_dot_f16 / _f32's order, or tinyBLAS<8>'s where the reference takes it -- bit-identical;
-    beyond, the F16 contraction runs on the matrix cores (tier T1)"""
+    """ggml_vec_dot_f16 / _f32's order, or tinyBLAS<8>'s where the reference takes it -- bit-identical for every column count (beyond 32 columns the F16
+    contraction runs as fmaf chains on the f32 matrix cores, mmf_exact.hip); prefill mode 0: the fp16 MFMA kernel (tier T1)"""
     got, want = _mm_case(gpu, t, K, N, M, ne02, ne12)
-    if M <= 32 or t == O.F32:
-        assert np.array_equal(got.view(np.uint32).ravel(), want.view(np.uint32).ravel()), rel_err(got, want)
-    else:
+    assert np.array_equal(got.view(np.uint32).ravel(), want.view(np.uint32).ravel()), rel_err(got, want)
+    if M > 32 and t == O.F16:
+        with prefill_mode(gpu, 0):
+            got, want = _mm_case(gpu, t, K, N, M, ne02, ne12)
         assert rel_err(got, want) < T1
+
+
+@pytest.mark.parametrize("K,N,M,ne02,ne12", [(128, 300, 200, 2, 8), (128, 301, 70, 1, 4), (200, 128, 64, 2, 2), (203, 64, 40, 1, 1), (1000, 128, 100, 1, 2),
+                                             (1029, 128, 33, 2, 4), (24, 8, 64, 1, 1), (31, 5, 64, 1, 1), (4096, 128, 64, 1, 1)])
+def test_mul_mat_f16_exact_many_columns(gpu, K, N, M, ne02, ne12):
+    """mmf_exact.hip in both of the reference's orders: tinyBLAS<8> (K % 8 == 0, rows % 4 == 0) and ggml_vec_dot_f16 (otherwise: 32 accumulators, leftovers in
+    double), K.Q-like (K = 128, many rows) and V.P-like (K = positions) shapes, ragged tiles, K below one chain step, GQA broadcast"""
+    got, want = _mm_case(gpu, O.F16, K, N, M, ne02, ne12)
+    assert np.array_equal(got.view(np.uint32).ravel(), want.view(np.uint32).ravel()), rel_err(got, want)
 
 
 def test_mul_mat_rejects_bad_arguments(gpu):
