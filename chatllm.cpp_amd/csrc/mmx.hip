@@ -15,11 +15,13 @@
 // its mins term m[2k] S[2k] + m[2k+1] S[2k+1] is a fifth K = 4 product with S split as 64 hi + lo (every operand exact in fp16).
 //
 // Tiling: 4 waves per workgroup, two workgroups per CU.  Q4_0 / Q4_1 / Q8_0: 64 weight rows (n) x 64 tokens (m), a wave owns 32 x 32 = 2 x 2 patches
-// (128 accumulator registers); Q4_K (12 chains per output): 64 (n) x 32 (m), a wave owns 16 (n) x 32 (m).  K walked in steps of 256 elements:
+// (128 accumulator registers); Q4_K (12 chains per output): 64 (n) x 32 (m), a wave owns 16 (n) x 32 (m).  K walked in steps of 128 (Q4_K: 256) elements:
 // global -> registers one step ahead, registers -> LDS (unpack to fp16) between the two barriers of a step.
 //   A operand = activations (rows = tokens), B operand = weights (cols = weight rows); D[v]: AVX lane 4 t + (v >> 2), token 4 (lane >> 4) + (v & 3), row lane & 15
 //   (layouts checked on the device by tools/micro/mfma_probe.hip)
 #include "common.h"
+#include <stdio.h>
+#include <stdlib.h>
 
 typedef _Float16 h4v __attribute__((ext_vector_type(4)));
 typedef _Float16 h2v __attribute__((ext_vector_type(2)));
@@ -74,7 +76,11 @@ template <int OFF> __device__ __forceinline__ void nib16_to_h(uint32_t n0, uint3
     o0 = u32x4{a.x, a.y, b.x, b.y}; o1 = u32x4{c.x, c.y, d.x, d.y};
 }
 __device__ __forceinline__ uint32_t h2_splat(float v) { const _Float16 h = (_Float16) v; uint16_t b; __builtin_memcpy(&b, &h, 2); return (uint32_t) b * 0x00010001u; }
+#ifdef MMX_SCALAR_FMA        // (A/B: two v_fma_f32 instead of one v_pk_fma_f32; build the file with -fno-slp-vectorize)
+__device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) { return f32x2{__builtin_fmaf(a.x, b.x, c.x), __builtin_fmaf(a.y, b.y, c.y)}; }
+#else
 __device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+#endif
 
 template <int TYPE>
 __global__ void __launch_bounds__(256, 2) k_mmx(const mmx_args a) {
@@ -82,9 +88,11 @@ __global__ void __launch_bounds__(256, 2) k_mmx(const mmx_args a) {
     using T = mmx_traits<TYPE>;
     constexpr bool IS_K = TYPE == CLLM_TYPE_Q4_K, IS_41 = TYPE == CLLM_TYPE_Q4_1, IS_Q8 = TYPE == CLLM_TYPE_Q8_0;
     constexpr int MI = T::MI, NJ = T::NJ, BN = T::WN * NJ * 16, BM = T::WM * MI * 16, NT = 256;
-    constexpr int LD = 512 + (IS_K ? 32 : 0) + 16;                  // bytes per tile row: 256 fp16 (+ the mins pseudo-block) + pad (conflict-free ds_read_b64 fragments)
-    constexpr int NPL = IS_41 ? 16 : IS_K ? 2 : 8;                  // f32 scale planes per weight row: dw[8] (+ mw[8]) / d, dmin
-    constexpr int XPL = IS_41 ? 16 : IS_K ? 1 : 8;                  // per token: dx[8] (+ sx[8]) / dx
+    constexpr int KS = IS_K ? 256 : 128, NBK = KS / 32;             // elements of K per stage (the 32-block types stage 128: half the prefetch registers -- with 256 the kernel
+                                                                    // spilled, and a scratch reload between the prefetch loads and the MFMA loop drains the prefetch)
+    constexpr int LD = KS * 2 + (IS_K ? 32 : 0) + 16;               // bytes per tile row: KS fp16 (+ the mins pseudo-block) + pad (conflict-free ds_read_b64 fragments)
+    constexpr int NPL = IS_41 ? 2 * NBK : IS_K ? 2 : NBK;           // f32 scale planes per weight row: dw[NBK] (+ mw[NBK]) / d, dmin
+    constexpr int XPL = IS_41 ? 2 * NBK : IS_K ? 1 : NBK;           // per token: dx[NBK] (+ sx[NBK]) / dx
     constexpr int LDS_XT = 0, LDS_WT = BM * LD, LDS_WS = LDS_WT + BN * LD, LDS_XS = LDS_WS + BN * NPL * 4;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t m0 = (int64_t) blockIdx.x * BM, n0 = (int64_t) blockIdx.y * BN;
@@ -114,15 +122,17 @@ __global__ void __launch_bounds__(256, 2) k_mmx(const mmx_args a) {
     // ---- staging: global -> registers (one K step ahead), registers -> LDS (unpack to fp16) ----
     constexpr int BS = IS_Q8 ? 34 : IS_41 ? 20 : 18, QOFF = IS_41 ? 4 : 2;
     struct __attribute__((packed, aligned(2))) q16 { uint32_t x, y, z, w; };
-    constexpr int NXA = BM * 16 / NT;                               // activation tasks per thread: (token, 16 int8)
+    constexpr int CPR = KS / 16;                                    // 16-byte chunks of int8 per token and stage
+    constexpr int NXA = BM * CPR / NT;                              // activation tasks per thread: (token, 16 int8)
     constexpr int NXS = IS_K ? 1 : (BM * XPL + NT - 1) / NT;        // activation scale tasks (Q4_K: dx and the eight sub-block sums of token tid % BM ... see below)
-    constexpr int NWT = IS_K ? BN * 4 / NT : BN * 8 / NT;           // weight tasks: Q4_K (row, 64-weight chunk) = 1; others (row, 32-block) = 2
+    constexpr int NWT = IS_K ? BN * 4 / NT : BN * NBK / NT;         // weight tasks: Q4_K (row, 64-weight chunk) = 1; others (row, 32-block) = 1
     u32x4 rx[NXA]; uint32_t rxs[IS_K ? 3 : NXS];
-    u32x4 rw[NWT], rw2[(IS_K || IS_Q8) ? NWT : 1], rwh[IS_K ? NWT : 1]; float rwd[IS_K ? 1 : NWT], rwm[IS_41 ? NWT : 1];
+    u32x4 rw[NWT], rw2[(IS_K || IS_Q8) ? NWT : 1], rwh[IS_K ? NWT : 1]; uint32_t rwd[IS_K ? 1 : NWT];      // rwd: the block's raw fp16 d (Q4_1: d | m << 16) -- converted at commit time:
+    // a conversion here would make the prefetch wait for its own loads (s_waitcnt right behind them) and the global latency would sit in front of every K step
     auto prefetch = [&](int64_t k0) {
 #pragma unroll
         for (int t = 0; t < NXA; t++) {
-            const int c = tid + NT * t, row = c >> 4, ch = c & 15;
+            const int c = tid + NT * t, row = c / CPR, ch = c % CPR;
             const int64_t m = m0 + row;
             rx[t] = u32x4{0, 0, 0, 0};
             if (m < a.M && k0 + ch * 16 < K) rx[t] = *(const u32x4 *)(a.act + m * a.act_stride + k0 + ch * 16);
@@ -145,9 +155,9 @@ __global__ void __launch_bounds__(256, 2) k_mmx(const mmx_args a) {
                 const int c = tid + NT * t;
                 rxs[t] = 0;
                 if (c < BM * XPL) {
-                    const int row = c % BM, pl = c / BM, sb = pl & 7;
+                    const int row = c % BM, pl = c / BM, sb = pl % NBK;
                     const int64_t m = m0 + row;
-                    if (m < a.M && k0 + sb * 32 < K) rxs[t] = *(const uint32_t *)(a.act + m * a.act_stride + (pl < 8 ? act_d : act_s) + ((k0 / 32) + sb) * 4);
+                    if (m < a.M && k0 + sb * 32 < K) rxs[t] = *(const uint32_t *)(a.act + m * a.act_stride + (pl < NBK ? act_d : act_s) + ((k0 / 32) + sb) * 4);
                 }
             }
         }
@@ -166,13 +176,12 @@ __global__ void __launch_bounds__(256, 2) k_mmx(const mmx_args a) {
                     rw2[t] = *(const u32x4 *)(bp + 32 + 32 * c4);
                 }
             } else {                                                // (row, 32-block sb)
-                const int row = c >> 3, sb = c & 7;
+                const int row = c / NBK, sb = c % NBK;
                 const int64_t n = n0 + row, b = k0 / 32 + sb;
-                rwd[IS_K ? 0 : t] = 0.0f; if (IS_Q8) rw2[IS_Q8 ? t : 0] = u32x4{0, 0, 0, 0}; if (IS_41) rwm[IS_41 ? t : 0] = 0.0f;
+                rwd[IS_K ? 0 : t] = 0; if (IS_Q8) rw2[IS_Q8 ? t : 0] = u32x4{0, 0, 0, 0};
                 if (n < a.N && b * 32 < K) {
                     const char * bp = a.W + n * a.nb01 + b * BS;
-                    rwd[IS_K ? 0 : t] = h2f(*(const uint16_t *) bp);
-                    if (IS_41) rwm[IS_41 ? t : 0] = h2f(*(const uint16_t *)(bp + 2));
+                    if (IS_41) rwd[IS_K ? 0 : t] = *(const uint32_t *) bp; else rwd[IS_K ? 0 : t] = *(const uint16_t *) bp;
                     const q16 q0 = *(const q16 *)(bp + QOFF);
                     rw[t] = u32x4{q0.x, q0.y, q0.z, q0.w};
                     if (IS_Q8) { const q16 q1 = *(const q16 *)(bp + 18); rw2[IS_Q8 ? t : 0] = u32x4{q1.x, q1.y, q1.z, q1.w}; }
@@ -183,7 +192,7 @@ __global__ void __launch_bounds__(256, 2) k_mmx(const mmx_args a) {
     auto commit = [&]() {
 #pragma unroll
         for (int t = 0; t < NXA; t++) {                             // 16 int8 -> 16 fp16
-            const int c = tid + NT * t, row = c >> 4, ch = c & 15;
+            const int c = tid + NT * t, row = c / CPR, ch = c % CPR;
             u32x4 o0, o1;
             i8x16_to_h(rx[t], o0, o1);
             *(u32x4 *)(Xt + row * LD + ch * 32)      = o0;
@@ -238,7 +247,7 @@ __global__ void __launch_bounds__(256, 2) k_mmx(const mmx_args a) {
                 *(h4v *)(Wt + row * LD + 512 + 8 * c4) = mv;
                 if (c4 == 0) { *(float *)(Ws + row * 4) = h2f((uint16_t)(h.x & 0xffff)); *(float *)(Ws + (BN + row) * 4) = h2f((uint16_t)(h.x >> 16)); }
             } else {
-                const int row = c >> 3, sb = c & 7;
+                const int row = c / NBK, sb = c % NBK;
                 const u32x4 q0 = rw[t];
                 u32x4 o[4];
                 if constexpr (IS_Q8) {
@@ -250,8 +259,8 @@ __global__ void __launch_bounds__(256, 2) k_mmx(const mmx_args a) {
                 }
                 char * wr = Wt + row * LD + sb * 64;
                 *(u32x4 *)(wr) = o[0]; *(u32x4 *)(wr + 16) = o[1]; *(u32x4 *)(wr + 32) = o[2]; *(u32x4 *)(wr + 48) = o[3];
-                *(float *)(Ws + (sb * BN + row) * 4) = rwd[IS_K ? 0 : t];                           // dw[8][n]
-                if (IS_41) *(float *)(Ws + ((8 + sb) * BN + row) * 4) = rwm[IS_41 ? t : 0];         // mw[8][n]
+                *(float *)(Ws + (sb * BN + row) * 4) = h2f((uint16_t)(rwd[IS_K ? 0 : t] & 0xffff));          // dw[8][n]
+                if (IS_41) *(float *)(Ws + ((NBK + sb) * BN + row) * 4) = h2f((uint16_t)(rwd[IS_K ? 0 : t] >> 16));      // mw[NBK][n]
             }
         }
     };
@@ -259,11 +268,18 @@ __global__ void __launch_bounds__(256, 2) k_mmx(const mmx_args a) {
     const f32x16 zero16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     const int frag_off = l15 * LD + l4 * 8;                         // row l15 of a patch, AVX lane l4 of the instruction's four
     prefetch(0);
-    for (int64_t k0 = 0; k0 < K; k0 += 256) {
+    for (int64_t k0 = 0; k0 < K; k0 += KS) {
+#ifdef MMX_NOSTAGE           // (timing experiments only: stage the first step, compute on it for every step)
+        if (k0 == 0) { __syncthreads(); commit(); __syncthreads(); }
+#else
         __syncthreads();                                            // the previous step's fragments are consumed
         commit();
         __syncthreads();
-        if (k0 + 256 < K) prefetch(k0 + 256);
+        if (k0 + KS < K) prefetch(k0 + KS);
+#endif
+#ifdef MMX_NOCOMPUTE
+        continue;
+#endif
 
         if constexpr (IS_K) {
 #pragma unroll
@@ -297,7 +313,7 @@ __global__ void __launch_bounds__(256, 2) k_mmx(const mmx_args a) {
                     }
                 }
         } else {
-            const int nb = (int)((K - k0) / 32 < 8 ? (K - k0) / 32 : 8);      // real 32-blocks of this step
+            const int nb = (int)((K - k0) / 32 < NBK ? (K - k0) / 32 : NBK);  // real 32-blocks of this step
 #pragma unroll 1
             for (int s = 0; s < nb; s++) {
                 h4v fx[MI][2], fw[NJ][2];
@@ -310,28 +326,40 @@ __global__ void __launch_bounds__(256, 2) k_mmx(const mmx_args a) {
                 for (int j = 0; j < NJ; j++) dw[j] = *(const float *)(Ws + (s * BN + wn + j * 16 + l15) * 4);
 #pragma unroll
                 for (int i = 0; i < MI; i++) dx[i] = *(const f32x4 *)(Xs + (s * BM + wm + i * 16 + l4 * 4) * 4);
+                // software pipeline over the MI x NJ patches of this block, ONE pair of result tiles: M0(0) M1(0) | F0(p) M0(p+1) F1(p) M1(p+1) ... -- every fold
+                // (16 fma chains steps) runs under the MFMA issued just before it, and a tile is rewritten only after its fold (the compiler's own schedule
+                // issued both MFMAs of a patch and then idled until the first result: the two pipes ran one after the other)
+                constexpr int NP = MI * NJ;
+                f32x16 D0 = __builtin_amdgcn_mfma_f32_16x16x4f16(fx[0][0], fw[0][0], zero16, 0, 0, 0);
+                f32x16 D1 = __builtin_amdgcn_mfma_f32_16x16x4f16(fx[0][1], fw[0][1], zero16, 0, 0, 0);
 #pragma unroll
-                for (int i = 0; i < MI; i++)
+                for (int p = 0; p < NP; p++) {
+                    const int i = p / NJ, j = p % NJ, i2 = (p + 1) / NJ, j2 = (p + 1) % NJ;
+                    // d = d_w * d_x (arch/x86/quants.c:556, 1021; sgemm.cpp tinyBLAS_Q0_AVX: unhalf(A.d) * unhalf(B.d))
+                    const f32x2 dd0 = f32x2{dw[j] * dx[i].x, dw[j] * dx[i].y}, dd1 = f32x2{dw[j] * dx[i].z, dw[j] * dx[i].w};
+                    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                    for (int j = 0; j < NJ; j++) {
-                        const f32x16 D0 = __builtin_amdgcn_mfma_f32_16x16x4f16(fx[i][0], fw[j][0], zero16, 0, 0, 0);
-                        const f32x16 D1 = __builtin_amdgcn_mfma_f32_16x16x4f16(fx[i][1], fw[j][1], zero16, 0, 0, 0);
-                        // d = d_w * d_x (arch/x86/quants.c:556, 1021; sgemm.cpp tinyBLAS_Q0_AVX: unhalf(A.d) * unhalf(B.d))
-                        const f32x2 dd0 = f32x2{dw[j] * dx[i].x, dw[j] * dx[i].y}, dd1 = f32x2{dw[j] * dx[i].z, dw[j] * dx[i].w};
-#pragma unroll
-                        for (int b = 0; b < 4; b++) {
-                            acc[i][j][b][0]     = pk_fma(dd0, f32x2{D0[4 * b], D0[4 * b + 1]}, acc[i][j][b][0]);
-                            acc[i][j][b][1]     = pk_fma(dd1, f32x2{D0[4 * b + 2], D0[4 * b + 3]}, acc[i][j][b][1]);
-                            acc[i][j][4 + b][0] = pk_fma(dd0, f32x2{D1[4 * b], D1[4 * b + 1]}, acc[i][j][4 + b][0]);
-                            acc[i][j][4 + b][1] = pk_fma(dd1, f32x2{D1[4 * b + 2], D1[4 * b + 3]}, acc[i][j][4 + b][1]);
-                        }
+                    for (int b = 0; b < 4; b++) {
+                        acc[i][j][b][0] = pk_fma(dd0, f32x2{D0[4 * b], D0[4 * b + 1]}, acc[i][j][b][0]);
+                        acc[i][j][b][1] = pk_fma(dd1, f32x2{D0[4 * b + 2], D0[4 * b + 3]}, acc[i][j][b][1]);
                     }
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (p + 1 < NP) D0 = __builtin_amdgcn_mfma_f32_16x16x4f16(fx[i2][0], fw[j2][0], zero16, 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int b = 0; b < 4; b++) {
+                        acc[i][j][4 + b][0] = pk_fma(dd0, f32x2{D1[4 * b], D1[4 * b + 1]}, acc[i][j][4 + b][0]);
+                        acc[i][j][4 + b][1] = pk_fma(dd1, f32x2{D1[4 * b + 2], D1[4 * b + 3]}, acc[i][j][4 + b][1]);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (p + 1 < NP) D1 = __builtin_amdgcn_mfma_f32_16x16x4f16(fx[i2][1], fw[j2][1], zero16, 0, 0, 0);
+                }
                 if constexpr (IS_41) {                              // summs = fma(m_w, s_x, summs) (arch/x86/quants.c:726; gcc contracts the statement)
                     float mw[NJ]; f32x4 sx[MI];
 #pragma unroll
-                    for (int j = 0; j < NJ; j++) mw[j] = *(const float *)(Ws + ((8 + s) * BN + wn + j * 16 + l15) * 4);
+                    for (int j = 0; j < NJ; j++) mw[j] = *(const float *)(Ws + ((NBK + s) * BN + wn + j * 16 + l15) * 4);
 #pragma unroll
-                    for (int i = 0; i < MI; i++) sx[i] = *(const f32x4 *)(Xs + ((8 + s) * BM + wm + i * 16 + l4 * 4) * 4);
+                    for (int i = 0; i < MI; i++) sx[i] = *(const f32x4 *)(Xs + ((NBK + s) * BM + wm + i * 16 + l4 * 4) * 4);
 #pragma unroll
                     for (int i = 0; i < MI; i++)
 #pragma unroll
@@ -378,8 +406,9 @@ __global__ void __launch_bounds__(256, 2) k_mmx(const mmx_args a) {
 template <int TYPE> static constexpr int mmx_lds() {
     using T = mmx_traits<TYPE>;
     constexpr bool IS_K = TYPE == CLLM_TYPE_Q4_K, IS_41 = TYPE == CLLM_TYPE_Q4_1;
-    constexpr int BN = T::WN * T::NJ * 16, BM = T::WM * T::MI * 16, LD = 512 + (IS_K ? 32 : 0) + 16;
-    return (BM + BN) * LD + BN * (IS_41 ? 16 : IS_K ? 2 : 8) * 4 + BM * (IS_41 ? 16 : IS_K ? 1 : 8) * 4;
+    constexpr int KS = IS_K ? 256 : 128, NBK = KS / 32;
+    constexpr int BN = T::WN * T::NJ * 16, BM = T::WM * T::MI * 16, LD = KS * 2 + (IS_K ? 32 : 0) + 16;
+    return (BM + BN) * LD + BN * (IS_41 ? 2 * NBK : IS_K ? 2 : NBK) * 4 + BM * (IS_41 ? 2 * NBK : IS_K ? 1 : NBK) * 4;
 }
 
 // the exact-order mat-mul: any M >= 1; K % 32 == 0 (Q4_K: % 256); CLLM_E_UNSUPPORTED: not this kernel's type
@@ -396,6 +425,12 @@ int launch_mmx(hipStream_t st, int wtype, const tview & w, const void * act, siz
         const dim3 grid((unsigned)((a.M + BM - 1) / BM), (unsigned)((a.N + BN - 1) / BN)); \
         if (!attr) { HIP_TRY(hipFuncSetAttribute((const void *) k_mmx<T>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS)); attr = true; } \
         hipLaunchKernelGGL(k_mmx<T>, grid, dim3(256), LDS, st, a); } while (0)
+    static const bool dbg = getenv("CLLM_DEBUG") != nullptr;
+    if (dbg) {
+        int nb = 0;
+        (void) hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *) k_mmx<CLLM_TYPE_Q4_0>, 256, mmx_lds<CLLM_TYPE_Q4_0>());
+        fprintf(stderr, "[cllm] mmx: occupancy query: %d workgroups of 256 threads per CU (Q4_0 form, %d bytes of LDS)\n", nb, mmx_lds<CLLM_TYPE_Q4_0>());
+    }
     if (wtype == CLLM_TYPE_Q4_K) GO(CLLM_TYPE_Q4_K);
     else if (wtype == CLLM_TYPE_Q4_0) GO(CLLM_TYPE_Q4_0);
     else if (wtype == CLLM_TYPE_Q8_0) GO(CLLM_TYPE_Q8_0);

@@ -179,7 +179,7 @@ def test_long_prompts_are_bit_identical_to_the_oracle_run(gpu, name, wtype, chun
     """the default prefill mode: prompts of ANY length -- quantized mat-muls through mmx.hip, K.Q / V.P through mmf_exact.hip (tinyBLAS<8>'s order where the
     position count allows it, ggml_vec_dot_f16's otherwise), chunked prefill with n_past > 0 -- then FREE-RUNNING greedy decode: every logit of every
     step has the bits of the oracle's whole-model walk (itself bit-identical to the reference host, test_golden.py)"""
-    cfg = gpu.synth.config(name, max_len=sum(chunks) + 16)
+    cfg = gpu.synth.config(name, max_len=(sum(chunks) + 16 + 63) // 64 * 64)
     w = gpu.synth.make_model(cfg, wtype, seed=21)
     ref, dev = O.Llama(cfg, w), gpu.Llama(cfg, w)
     r = np.random.default_rng(21)
@@ -236,7 +236,10 @@ def test_decoder_qwen2_style_is_bit_identical_to_the_walk(gpu):
 
 
 @pytest.mark.parametrize("name,wtype,plen,over", [("tiny", O.Q8_0, 9, {}), ("tiny", O.Q4_0, 9, {}), ("tiny", O.Q4_K, 9, {}), ("tiny", O.Q4_1, 9, {}), ("small", O.Q4_K, 30, {}),
-                                                  ("tiny", O.Q4_K, 12, dict(rope_mode=2, qkv_bias=1, rope_theta=1e6, ffn=544))])
+                                                  ("tiny", O.Q4_K, 12, dict(rope_mode=2, qkv_bias=1, rope_theta=1e6, ffn=544)),
+                                                  # head size 128, every projection Q4_K: the decode steps run as ONE persistent launch over all layers (decode_persist.hip);
+                                                  # ffn > 4096: the down projection's four-group prologue; NEOX pairs
+                                                  ("small", O.Q4_K, 17, dict(ffn=4352)), ("small", O.Q4_K, 11, dict(rope_mode=2, rope_theta=1e6, n_layer=3))])
 def test_end_to_end_is_bit_identical_to_the_oracle_run(gpu, name, wtype, plen, over):
     """FREE-RUNNING greedy generation, runner vs the oracle's whole-model walk (itself bit-identical to the reference host, test_golden.py):
     every logit of every step has the same bits -- prompt chunk through the exact-order multi-column kernels, decode through the fused kernels"""
@@ -253,10 +256,12 @@ def test_end_to_end_is_bit_identical_to_the_oracle_run(gpu, name, wtype, plen, o
     dev.close()
 
 
-@pytest.mark.parametrize("wtype,over", [(O.Q8_0, {}), (O.Q4_0, {}), (O.Q4_K, {}), (O.Q4_1, {}), (O.Q4_K, dict(rope_mode=2, qkv_bias=1, rope_theta=1e6, ffn=544))])
+@pytest.mark.parametrize("wtype,over", [(O.Q8_0, {}), (O.Q4_0, {}), (O.Q4_K, {}), (O.Q4_1, {}), (O.Q4_K, dict(rope_mode=2, qkv_bias=1, rope_theta=1e6, ffn=544)),
+                                        (O.Q4_K, dict(base="small")), (O.Q4_K, dict(base="small", ffn=4352, n_layer=2))])       # (the persistent all-layers launch)
 def test_fused_decode_path_is_bit_identical_to_the_node_by_node_path(gpu, wtype, over):
     """norm+quant, rope+kv-write, fused attention, silu*up+quant, GEMV+bias/residual epilogues: same bits as the unfused nodes"""
-    cfg = gpu.synth.config("tiny", max_len=64, **over)
+    over = dict(over)
+    cfg = gpu.synth.config(over.pop("base", "tiny"), max_len=64, **over)
     w = gpu.synth.make_model(cfg, wtype, seed=4)
     a, b = gpu.Llama(cfg, w), gpu.Llama(cfg, w)
     prompt = np.random.default_rng(4).integers(0, cfg["vocab"], 9).astype(np.int32)
