@@ -357,7 +357,8 @@ extern "C" int cllm_bench_mul_mat_kernel(void * stream, const cllm_tensor * src0
         const int n = pass == 0 ? (n_src0 < 4 ? n_src0 : 4) : iters;
         for (int i = 0; i < n; i++) {
             tview w = tv(src0); w.data = (char *) src0_datas[i % n_src0];
-            rc = !mmq ? CLLM_E_UNSUPPORTED : prefill_mode() == 1 ? launch_mmx(st, src0->type, w, wdata, stride, tv(src1), tv(dst)) : launch_mmq(st, src0->type, w, wdata, stride, tv(src1), tv(dst));
+            rc = !mmq ? CLLM_E_UNSUPPORTED : prefill_f16_enabled() ? launch_dense_f16(st, src0->type, w, tv(src1), tv(dst))
+                                           : prefill_mode() == 1 ? launch_mmx(st, src0->type, w, wdata, stride, tv(src1), tv(dst)) : launch_mmq(st, src0->type, w, wdata, stride, tv(src1), tv(dst));
             if (rc == CLLM_E_UNSUPPORTED) rc = launch_mmvq(st, src0->type, w, wdata, stride, src1->ne[1], tv(src1), tv(dst));
             if (rc) return rc;
         }

@@ -277,6 +277,17 @@ __device__ __forceinline__ void top_k_row(const float * x, int n, int k, int32_t
 }
 __device__ __forceinline__ float silu_poly(float x) { return x / (1.0f + ggml_expf_poly(0.0f - x)); }
 __device__ __forceinline__ float silu_any(float x, bool body) { return body ? silu_poly(x) : x / (1.0f + libm_expf(-x)); }
+// ---- workgroup -> output tile of a prefill GEMM, L2-aware.  A 1-D grid of TM * TN workgroups (TM token tiles, TN weight-row tiles).  The dispatcher places workgroup
+// b on XCD b % 8 (private 4 MB L2s): every XCD gets one CONTIGUOUS chunk of the logical tile order (bijective for any count), and the logical order walks a group
+// of GM token tiles x all row tiles with the token tile fastest, so the ~64 workgroups an XCD runs concurrently share GM activation tiles (each re-read from HBM
+// once per 64 / GM row tiles instead of once per row tile) and 64 / GM weight tiles.  Placement-dependent for speed only.
+__device__ __forceinline__ void gemm_tile_of(unsigned id, unsigned TM, unsigned TN, unsigned GM, unsigned & mt, unsigned & nt) {
+    const unsigned nwg = TM * TN, q = nwg >> 3, r = nwg & 7, xcd = id & 7, k = id >> 3;
+    const unsigned l = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;            // logical index: XCD-contiguous
+    const unsigned full = TM / GM, per_full = GM * TN;
+    if (l < full * per_full) { const unsigned mg = l / per_full, rr = l % per_full; nt = rr / GM; mt = GM * mg + rr % GM; }
+    else { const unsigned rr = l - full * per_full, rem = TM - GM * full; nt = rr / rem; mt = GM * full + rr % rem; }
+}
 #endif  // __HIPCC__
 
 // ---- host helpers ---------------------------------------------------------------------------------
@@ -345,7 +356,7 @@ int launch_rope_kv_store(hipStream_t st, float * qkv, int64_t QKV, const int32_t
 int launch_moe_router(hipStream_t st, int wtype, const void * W, int64_t K, int64_t n, const float * px, const float * pw, float eps,
                       float * xnorm, float * probs, int32_t * ids, int k);
 int launch_gemv_kq(hipStream_t st, int wtype, const tview & w, const void * act, size_t act_stride, int64_t M, float * dst, int64_t ldd);
-int launch_dense_f16(hipStream_t st, int wtype, const tview & w, const tview & x, const tview & d);
+int launch_dense_f16(hipStream_t st, int wtype, const tview & w, const tview & x, const tview & d, const float * resid = nullptr, int64_t ldr = 0, int epi = 0);
 int launch_gemv_rows(hipStream_t st, const void * W, int64_t K, int64_t nrows, int pro, const float * px, const float * pw, float eps, int epi, float * dst, const float * bias, const float * resid);
 int launch_mmvq_fused(hipStream_t st, int wtype, const void * W, int64_t K, int64_t nrows, int pro, const float * px, const float * pw, float eps, int epi, float * dst, const float * bias, const float * resid);
 int launch_attn_decode(hipStream_t st, const float * qkv, const int32_t * pos_dev, int nh, int nkv, int hd, const uint16_t * k_cache, const uint16_t * v_cache, int64_t ML, float * att);

@@ -28,19 +28,22 @@
 
 // ---- device-wide barrier -------------------------------------------------------------------------------------------------------------------------------------
 struct pg_bar {                 // every polled word on its own 128-byte line
-    unsigned cnt[8 * 32];       // arrivals of the workgroups with blockIdx % 8 == x (the dispatcher's XCD round-robin: contention stays inside an XCD; correctness does not depend on it)
-    unsigned top[32];           // groups that completed the phase
-    unsigned gen[8 * 32];       // last completed phase, one copy per group
+    unsigned cnt[2][8 * 32];    // arrivals of the workgroups with blockIdx % 8 == x (the dispatcher's XCD round-robin: contention stays inside an XCD; correctness does not
+                                // depend on it), one set per phase PARITY: a workgroup without work in a phase (attention: 2 n_head workgroups) arrives for it right after
+                                // arriving for the previous one, so arrivals of two consecutive phases interleave -- never of three: the arrival for phase p + 2 comes after
+                                // the wait for p + 1, which every workgroup reaches only after phase p completed
+    unsigned top[2][32];        // groups that completed the phase, per parity
+    unsigned gen[8 * 32];       // last completed phase (atomic max), one copy per group
     unsigned err[32];           // != 0: a wait timed out (phase number) -- every later wait returns at once
 };
 #define PG_RLX __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
-__device__ __forceinline__ void pg_arrive(pg_bar * b, unsigned phase) {                     // ONE thread, after the workgroup's stores are drained
-    const unsigned x = blockIdx.x & 7, nx = (gridDim.x - x + 7) >> 3;
-    const unsigned old = __hip_atomic_fetch_add(&b->cnt[x * 32], 1u, PG_RLX);
-    if (old + 1 == phase * nx) {
+__device__ __forceinline__ void pg_arrive(pg_bar * b, unsigned phase) {                     // ONE thread, after the workgroup's stores are drained; phase >= 1
+    const unsigned x = blockIdx.x & 7, nx = (gridDim.x - x + 7) >> 3, s = phase & 1, k = (phase + 1) >> 1;      // k: phases of this parity up to and including this one
+    const unsigned old = __hip_atomic_fetch_add(&b->cnt[s][x * 32], 1u, PG_RLX);
+    if (old + 1 == k * nx) {
         const unsigned ngrp = gridDim.x < 8 ? gridDim.x : 8;
-        const unsigned o2 = __hip_atomic_fetch_add(&b->top[0], 1u, PG_RLX);
-        if (o2 + 1 == phase * ngrp) for (unsigned i = 0; i < ngrp; i++) __hip_atomic_store(&b->gen[i * 32], phase, PG_RLX);
+        const unsigned o2 = __hip_atomic_fetch_add(&b->top[s][0], 1u, PG_RLX);
+        if (o2 + 1 == k * ngrp) for (unsigned i = 0; i < ngrp; i++) __hip_atomic_fetch_max(&b->gen[i * 32], phase, PG_RLX);      // (max: the releases of two consecutive phases come from different threads)
     }
 }
 __device__ __forceinline__ bool pg_wait(pg_bar * b, unsigned phase) {                       // ONE thread
@@ -48,7 +51,9 @@ __device__ __forceinline__ bool pg_wait(pg_bar * b, unsigned phase) {           
     for (unsigned spins = 0; spins < (1u << 20); spins++) {                                  // ~1 s at worst
         if (__hip_atomic_load(&b->gen[x * 32], PG_RLX) >= phase) return true;
         if ((spins & 1023) == 1023 && __hip_atomic_load(&b->err[0], PG_RLX) != 0) return false;
+#ifndef PG_NOSLEEP
         __builtin_amdgcn_s_sleep(2);
+#endif
     }
     __hip_atomic_store(&b->err[0], phase, PG_RLX);
     return false;
@@ -97,7 +102,8 @@ struct pg_args {
 //   EPI 0: dst[r] = W[r] . act (+ resid[r]);  EPI 1: rows alternate gate_u, up_u: dst[u] = silu(W[2u] . act) * (W[2u+1] . act)
 template <int PRO, int EPI, int NPRE, int P>
 __device__ __forceinline__ bool pg_gemv(char * lds, double * part, int * flag, const float * px, const float * __restrict__ pw, const char * __restrict__ W, const pg_op op, float eps,
-                                        float * dst, const float * resid, pg_bar * bar, unsigned wait_phase) {
+                                        float * dst, const float * resid, pg_bar * bar, unsigned wait_phase, unsigned long long * tsp) {
+#define PG_TSP(k) do { if (tsp && blockIdx.x == 0 && threadIdx.x == 0) tsp[k] = wall_clock64(); } while (0)
     constexpr int RU = EPI == 1 ? 2 : 1;
     int tid_ = threadIdx.x;
     asm volatile("" : "+v"(tid_));             // opaque per phase: the lane constants derived from it must not be hoisted out of the layer loop (five phases' worth of them
@@ -131,6 +137,7 @@ __device__ __forceinline__ bool pg_gemv(char * lds, double * part, int * flag, c
 
     // ---- (2) the previous phase's outputs are complete ----
     if (!pg_acquire(bar, wait_phase, flag)) return false;
+    PG_TSP(2);
 
     // ---- (3) the activation row: [RMS_NORM * weight |] quantize -> LDS ----
     const int e0 = tid * 4;
@@ -176,6 +183,7 @@ __device__ __forceinline__ bool pg_gemv(char * lds, double * part, int * flag, c
     }
     }
     __syncthreads();
+    PG_TSP(3);
 
     // ---- (4) stream the rows ----
     const q4k_sel4 L = q4k_lane_sel4(lane);
@@ -216,6 +224,8 @@ __device__ __forceinline__ bool pg_gemv(char * lds, double * part, int * flag, c
             }
         }
     }
+    PG_TSP(4);
+#undef PG_TSP
     return true;
 }
 
@@ -406,13 +416,14 @@ __global__ void __launch_bounds__(1024) k_decode_layers(const pg_args a) {
     const int r2 = a.nh / a.nkv, n_attn = a.nh * 2;
     const bool attn_wg = (int) blockIdx.x < n_attn;
     const int hx = blockIdx.x % r2, ag = (blockIdx.x / r2) % a.nkv, apart = blockIdx.x / (r2 * a.nkv);
-#define PG_TS(k) do { if (a.ts && blockIdx.x == 0 && threadIdx.x == 0) a.ts[(il * 5 + ph) * 2 + (k)] = wall_clock64(); } while (0)
+#define PG_TS(k) do { if (a.ts && blockIdx.x == 0 && threadIdx.x == 0) a.ts[(il * 5 + ph) * 8 + (k)] = wall_clock64(); } while (0)
+#define PG_TSPTR (a.ts ? a.ts + (il * 5 + ph) * 8 : nullptr)
     for (int il = 0; il < a.n_layer; il++) {
         const pg_layer & L = a.layers[il];
         int ph = 0;
         // [norm + quantize + q|k|v]   (waits for the previous layer's down projection; the first layer's x comes from the embedding launch: phase 0 is complete at once)
         PG_TS(0);
-        if (!pg_gemv<1, 0, 1, PG_P>(lds, part, flag, a.x, L.attn_norm, L.wqkv, a.qkv_op, a.eps, a.qkv, nullptr, bar, phase)) return;
+        if (!pg_gemv<1, 0, 1, PG_P>(lds, part, flag, a.x, L.attn_norm, L.wqkv, a.qkv_op, a.eps, a.qkv, nullptr, bar, phase, PG_TSPTR)) return;
         pg_publish(bar, ++phase); PG_TS(1); ph = 1;
         // [RoPE + cache write + attention]
         PG_TS(0);
@@ -420,23 +431,28 @@ __global__ void __launch_bounds__(1024) k_decode_layers(const pg_args a) {
         pg_publish(bar, ++phase); PG_TS(1); ph = 2;
         // [quantize + o + residual]
         PG_TS(0);
-        if (!pg_gemv<2, 0, 1, 1>(lds, part, flag, a.att, nullptr, L.wo, a.o_op, a.eps, a.x, a.x, bar, phase)) return;
+        if (!pg_gemv<2, 0, 1, 1>(lds, part, flag, a.att, nullptr, L.wo, a.o_op, a.eps, a.x, a.x, bar, phase, PG_TSPTR)) return;
         pg_publish(bar, ++phase); PG_TS(1); ph = 3;
         // [norm + quantize + gate/up + SiLU * up]
         PG_TS(0);
-        if (!pg_gemv<1, 1, 1, PG_P>(lds, part, flag, a.x, L.ffn_norm, L.wgu, a.gu_op, a.eps, a.g, nullptr, bar, phase)) return;
+        if (!pg_gemv<1, 1, 1, PG_P>(lds, part, flag, a.x, L.ffn_norm, L.wgu, a.gu_op, a.eps, a.g, nullptr, bar, phase, PG_TSPTR)) return;
         pg_publish(bar, ++phase); PG_TS(1); ph = 4;
         // [quantize + down + residual]
         PG_TS(0);
-        if (!pg_gemv<2, 0, NPRE_DOWN, PG_P>(lds, part, flag, a.g, nullptr, L.wdown, a.down_op, a.eps, a.x, a.x, bar, phase)) return;
+        if (!pg_gemv<2, 0, NPRE_DOWN, PG_P>(lds, part, flag, a.g, nullptr, L.wdown, a.down_op, a.eps, a.x, a.x, bar, phase, PG_TSPTR)) return;
         pg_publish(bar, ++phase); PG_TS(1);
     }
 #undef PG_TS
+#undef PG_TSPTR
 }
 
 // ---- host side ---------------------------------------------------------------------------------------------------------------------------------------------------
 size_t decode_layers_state_bytes(int n_layer) { return sizeof(pg_bar) + (size_t) n_layer * sizeof(pg_layer); }
-bool decode_layers_enabled() { static const bool on = !(getenv("CLLM_DECODE_PERSIST") && atoi(getenv("CLLM_DECODE_PERSIST")) == 0); return on; }
+// OPT-IN (CLLM_DECODE_PERSIST=1): measured SLOWER than the five launches per layer on MI355X (616 vs 714 tok/s, profiles/r03_decode_persistent_launch.txt): a device-wide
+// barrier under the weight stream costs more than a launch boundary, and weight loads requested ahead of the barrier wait delay the barrier's own loads
+static int g_persist = -1;
+bool decode_layers_enabled() { if (g_persist < 0) g_persist = getenv("CLLM_DECODE_PERSIST") && atoi(getenv("CLLM_DECODE_PERSIST")) != 0; return g_persist != 0; }
+extern "C" __attribute__((visibility("default"))) void cllm_debug_set_decode_persist(int on) { g_persist = on ? 1 : 0; }      // tests: both decode paths inside one process
 
 // CLLM_E_UNSUPPORTED (nothing launched): the five-launch path takes the step.  state: decode_layers_state_bytes() of device memory owned by the caller;
 // layer_tab[i] = { wqkv, wo, wgu, wdown, attn_norm, ffn_norm, k_cache, v_cache } (8 pointers per layer, host memory; uploaded once: layers_ready)

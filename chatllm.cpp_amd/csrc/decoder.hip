@@ -267,7 +267,7 @@ static int finalize(cllm_llama * m, int qlen) {
         for (const llama_layer & L : m->layers) for (const dweight * w : { &L.wqkv, &L.wo, &L.wgu, &L.wdown }) if (w->type != CLLM_TYPE_Q4_K) m->persist_ok = false;
         if (m->persist_ok) {
             HIP_TRY(hipMalloc(&m->persist_state, decode_layers_state_bytes(c.n_layer)));
-            if (getenv("CLLM_PERSIST_TS")) { HIP_TRY(hipMalloc((void **) &m->persist_ts, (size_t) c.n_layer * 10 * 8)); HIP_TRY(hipMemset(m->persist_ts, 0, (size_t) c.n_layer * 10 * 8)); }
+            if (getenv("CLLM_PERSIST_TS")) { HIP_TRY(hipMalloc((void **) &m->persist_ts, (size_t) c.n_layer * 40 * 8)); HIP_TRY(hipMemset(m->persist_ts, 0, (size_t) c.n_layer * 40 * 8)); }
             for (const llama_layer & L : m->layers) for (const void * p : { (const void *) L.wqkv.data, (const void *) L.wo.data, (const void *) L.wgu.data, (const void *) L.wdown.data,
                                                                             (const void *) L.attn_norm.data, (const void *) L.ffn_norm.data, (const void *) L.k_cache, (const void *) L.v_cache }) m->persist_tab.push_back(p);
         }

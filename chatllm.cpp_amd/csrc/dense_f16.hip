@@ -1,87 +1,238 @@
-// dense_f16.hip -- OPT-IN prefill contraction on the fp16 matrix cores: dequantize -> dense GEMM (north star: "MFMA tiles ... for the dense
-// bf16/fp16 prefill contraction"; SURVEY 7.1 step 5 path B; the reference's own CUDA backend does the same above its mmq limits,
-// ggml-cuda.cu:1229, 2262-2265: dequantize the weights, convert the activations, call the BLAS GEMM).
+// dense_f16.hip -- OPT-IN prefill contraction on the fp16 matrix cores with the block dequantization INSIDE the GEMM (north star: "per-wavefront block
+// dequant staged through LDS ... MFMA tiles only for the dense bf16/fp16 prefill contraction"; SURVEY 7.1 step 5 path B; what the reference's own CUDA
+// backend does above its mmq limits, ggml-cuda.cu:1229, 2262-2265: dequantize the weights, convert the activations, dense GEMM).
 //
-//   CLLM_PREFILL=f16   W (Q4_0 / Q4_1 / Q8_0 / Q4_K) -> fp16 [N, K] (dequantize_row_*'s values, rounded to fp16), X f32 -> fp16 (RNE),
-//                      D[N, M] = W . X^T in fp32 by the library GEMM (rocBLAS gemm_ex, f16 inputs, f32 accumulate: a plain dense GEMM is
-//                      what the vendor library is for)
+//   CLLM_PREFILL=f16   D[N, M] = dequantize(W)[N, K] . fp16(X)[M, K]^T, fp32 accumulate:  W (Q4_0 / Q4_1 / Q8_0 / Q4_K) is unpacked and scaled to fp16 while its
+//                      tile is staged into LDS -- dequantize_row_*'s values (ggml-quants.c:307-325, 401-414, 1352-1373) rounded to fp16 -- so the dequantized
+//                      weights never exist in HBM; X is rounded to fp16 (RNE) by one small pass; v_mfma_f32_32x32x16_f16.
 //
-// This is NOT the reference CPU computation (which quantizes the activations to Q8_0 / Q8_K and takes integer block dot products): no
-// activation-quantization error, an fp16 rounding of the weights instead -- a different, usually slightly MORE accurate result.  It is
-// therefore off by default (the default prefill is the exact-integer int8-MFMA path, mmq.hip, parity tier T1; short prompts take the
-// bit-exact mat-vec path); DESIGN.md states the measured deviation next to the measured TFLOP/s.
+// This is NOT the reference CPU computation (which quantizes the activations to Q8_0 / Q8_K and takes integer block dot products): no activation-quantization
+// error, an fp16 rounding of the weights instead.  Off by default (the default prefill is the exact-order path, mmx.hip); tests/test_gpu_ops.py checks it
+// against the oracle's dequantize + float64 GEMM with a stated tolerance.
+//
+// Tiling: 128 weight rows (n) x 128 tokens (m) per 256-thread workgroup, K walked 64 elements per stage, two LDS stages (one barrier per stage: the next
+// stage is written while the current one feeds the matrix cores), global -> registers one stage ahead (raw bytes: nothing converted before the data is
+// needed), 144-byte tile rows (conflict-free ds_read_b128 fragments).  A wave owns 64 x 64 = 2 x 2 MFMA tiles.  A operand = tokens, B operand = weight rows:
+// D[v] = (token (v & 3) + 8 (v >> 2) + 4 (lane >> 5), row lane & 31): stores are 128-byte runs.
 #include "common.h"
-#include "dequant.h"
 
-#include <dlfcn.h>
-#include <rocblas/rocblas.h>        // types and enums only: the library is dlopen'ed on first use (it is large, and a process that also hosts
-                                    // PyTorch -- bench.py at N > 1 -- already carries another copy)
-static rocblas_handle g_rb = nullptr;
-static rocblas_status (*p_create)(rocblas_handle *) = nullptr;
-static rocblas_status (*p_set_stream)(rocblas_handle, hipStream_t) = nullptr;
-static rocblas_status (*p_gemm_ex)(rocblas_handle, rocblas_operation, rocblas_operation, rocblas_int, rocblas_int, rocblas_int, const void *, const void *, rocblas_datatype,
-                                   rocblas_int, const void *, rocblas_datatype, rocblas_int, const void *, const void *, rocblas_datatype, rocblas_int, void *, rocblas_datatype,
-                                   rocblas_int, rocblas_datatype, rocblas_gemm_algo, int32_t, uint32_t) = nullptr;
-static int load_rocblas() {
-    if (p_gemm_ex) return CLLM_OK;
-    void * h = dlopen("librocblas.so.5", RTLD_NOW | RTLD_LOCAL);
-    if (!h) h = dlopen("/opt/rocm/lib/librocblas.so", RTLD_NOW | RTLD_LOCAL);
-    if (!h) FAIL(CLLM_E_UNSUPPORTED, "dense_f16: librocblas not found (%s)", dlerror());
-    p_create = (decltype(p_create)) dlsym(h, "rocblas_create_handle");
-    p_set_stream = (decltype(p_set_stream)) dlsym(h, "rocblas_set_stream");
-    p_gemm_ex = (decltype(p_gemm_ex)) dlsym(h, "rocblas_gemm_ex");
-    if (!p_create || !p_set_stream || !p_gemm_ex) { p_gemm_ex = nullptr; FAIL(CLLM_E_UNSUPPORTED, "dense_f16: rocBLAS symbols missing"); }
-    return CLLM_OK;
-}
-static void * g_w16 = nullptr, * g_x16 = nullptr;
-static size_t g_w16_bytes = 0, g_x16_bytes = 0;
+typedef _Float16 h8v __attribute__((ext_vector_type(8)));
+typedef _Float16 h2v __attribute__((ext_vector_type(2)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-__global__ void __launch_bounds__(256) k_dequant_f16(int type, const char * __restrict__ w, int64_t nb1, int64_t K, int64_t nrows, uint16_t * __restrict__ out) {
-    const int64_t e = ((int64_t) blockIdx.x * 256 + threadIdx.x) * 2;
-    const int64_t row = blockIdx.y;
-    if (e >= K) return;
-    const char * r = w + row * nb1;
-    const uint32_t lo = f2h(dequant_elem(type, r, e)), hi = f2h(dequant_elem(type, r, e + 1));
-    *(uint32_t *)(out + row * K + e) = lo | (hi << 16);
+struct mmd_args {
+    const char * W; int64_t nb01; int64_t N; int64_t K;
+    const uint16_t * X; int64_t ldx; int64_t M;      // fp16 activations [M][ldx]
+    float * dst; int64_t ldd;
+    const float * resid; int64_t ldr; int epi;
+};
+#define MMD_KS 64
+#define MMD_LD (MMD_KS * 2 + 16)
+
+__device__ __forceinline__ void b2h(uint32_t u, uint32_t & lo, uint32_t & hi) {       // four unsigned bytes -> fp16 pairs 1024 + byte (0x64uu)
+    lo = __builtin_amdgcn_perm(0x64646464u, u, 0x04010400u);
+    hi = __builtin_amdgcn_perm(0x64646464u, u, 0x04030402u);
 }
-__global__ void __launch_bounds__(256) k_f32_to_f16(const char * __restrict__ x, int64_t nb1, int64_t K, uint16_t * __restrict__ out) {
+__device__ __forceinline__ uint32_t h2op_sub(uint32_t x, uint32_t c) { const h2v r = __builtin_bit_cast(h2v, x) - __builtin_bit_cast(h2v, c); return __builtin_bit_cast(uint32_t, r); }
+__device__ __forceinline__ uint32_t h2op_mul(uint32_t x, uint32_t c) { const h2v r = __builtin_bit_cast(h2v, x) * __builtin_bit_cast(h2v, c); return __builtin_bit_cast(uint32_t, r); }
+__device__ __forceinline__ uint32_t h2op_fma(uint32_t x, uint32_t a, uint32_t c) {
+    const h2v r = __builtin_elementwise_fma(__builtin_bit_cast(h2v, x), __builtin_bit_cast(h2v, a), __builtin_bit_cast(h2v, c));
+    return __builtin_bit_cast(uint32_t, r);
+}
+__device__ __forceinline__ uint32_t h2dup(uint16_t h) { return (uint32_t) h * 0x00010001u; }
+
+template <int TYPE>
+__global__ void __launch_bounds__(256, 2) k_mmd(const mmd_args a) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    constexpr bool IS_K = TYPE == CLLM_TYPE_Q4_K, IS_41 = TYPE == CLLM_TYPE_Q4_1, IS_Q8 = TYPE == CLLM_TYPE_Q8_0;
+    constexpr int BN = 128, BM = 128, STAGE = (BN + BM) * MMD_LD;
+    constexpr int BS = IS_Q8 ? 34 : IS_41 ? 20 : 18, QOFF = IS_41 ? 4 : 2;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    unsigned mt, nt;
+    gemm_tile_of(blockIdx.x, (unsigned)((a.M + BM - 1) / BM), (unsigned)((a.N + BN - 1) / BN), 4, mt, nt);
+    const int64_t m0 = (int64_t) mt * BM, n0 = (int64_t) nt * BN;
+    const int wn = (wave & 1) * 64, wm = (wave >> 1) * 64;
+    const int l31 = lane & 31, l5 = lane >> 5;
+    const int64_t K = a.K;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++) acc[i][j] = f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+
+    // ---- staging: global -> registers (raw), registers -> LDS (dequantize) ----
+    struct __attribute__((packed, aligned(2))) q16 { uint32_t x, y, z, w; };
+    const int wrow = tid >> 1, whalf = tid & 1;                     // weight task: (row, 32 of the stage's 64 elements)
+    u32x4 rq, rq2, rh; uint32_t rd;
+    u32x4 rx[4];
+    auto prefetch = [&](int64_t k0) {
+        const int64_t n = n0 + wrow, e0 = k0 + 32 * whalf;
+        rq = u32x4{0, 0, 0, 0}; rq2 = u32x4{0, 0, 0, 0}; rh = u32x4{0, 0, 0, 0}; rd = 0;
+        if (n < a.N && e0 < K) {
+            if constexpr (IS_K) {
+                const char * bp = a.W + n * a.nb01 + (k0 >> 8) * 144;
+                const int c = (int)((k0 & 255) >> 6);
+                rh = *(const u32x4 *) bp;
+                rq = *(const u32x4 *)(bp + 16 + 32 * c); rq2 = *(const u32x4 *)(bp + 32 + 32 * c);
+            } else {
+                const char * bp = a.W + n * a.nb01 + (e0 >> 5) * BS;
+                if (IS_41) rd = *(const uint32_t *) bp; else rd = *(const uint16_t *) bp;
+                const q16 q0 = *(const q16 *)(bp + QOFF);
+                rq = u32x4{q0.x, q0.y, q0.z, q0.w};
+                if (IS_Q8) { const q16 q1 = *(const q16 *)(bp + 18); rq2 = u32x4{q1.x, q1.y, q1.z, q1.w}; }
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            const int c = tid + 256 * t, row = c >> 3, ch = c & 7;
+            const int64_t m = m0 + row, e = k0 + ch * 8;
+            rx[t] = u32x4{0, 0, 0, 0};
+            if (m < a.M && e < K) rx[t] = *(const u32x4 *)(a.X + m * a.ldx + e);      // (K % 8 == 0: whole chunks)
+        }
+    };
+    auto commit = [&](int stage, int64_t k0) {
+        char * Wt = lds + stage * STAGE, * Xt = Wt + BN * MMD_LD;
+        uint32_t o[16];
+        if constexpr (IS_K) {
+            // sub-block 2 c + whalf of the super-block: y = d * sc * nib - dmin * m (dequantize_row_q4_K), here as one fp16 fma per pair with d * sc and dmin * m rounded to fp16
+            const int c = (int)((k0 & 255) >> 6), sbi = 2 * c + whalf;
+            const uint32_t u0 = rh.y & 0x3f3f3f3fu, u2 = rh.z & 0x3f3f3f3fu;
+            const uint32_t u1 = (rh.w & 0x0f0f0f0fu) | (((rh.y >> 6) & 0x03030303u) << 4);
+            const uint32_t u3 = ((rh.w >> 4) & 0x0f0f0f0fu) | (((rh.z >> 6) & 0x03030303u) << 4);
+            const float sc = (float)((((sbi & 4) ? u1 : u0) >> (8 * (sbi & 3))) & 0xff), mn = (float)((((sbi & 4) ? u3 : u2) >> (8 * (sbi & 3))) & 0xff);
+            const float d = h2f((uint16_t)(rh.x & 0xffff)), dmin = h2f((uint16_t)(rh.x >> 16));
+            const uint32_t d1 = h2dup(f2h(d * sc)), m1 = h2dup(f2h(-(dmin * mn))), k1024 = 0x64006400u;
+            const uint32_t q[8] = { rq.x, rq.y, rq.z, rq.w, rq2.x, rq2.y, rq2.z, rq2.w };
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                uint32_t lo, hi;
+                b2h(whalf ? (q[e] >> 4) & 0x0f0f0f0fu : q[e] & 0x0f0f0f0fu, lo, hi);
+                o[2 * e] = h2op_fma(h2op_sub(lo, k1024), d1, m1); o[2 * e + 1] = h2op_fma(h2op_sub(hi, k1024), d1, m1);
+            }
+        } else if constexpr (IS_Q8) {
+            const uint32_t dd = h2dup((uint16_t) rd);
+            const uint32_t q[8] = { rq.x, rq.y, rq.z, rq.w, rq2.x, rq2.y, rq2.z, rq2.w };
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                uint32_t lo, hi;
+                b2h(q[e] ^ 0x80808080u, lo, hi);
+                o[2 * e] = h2op_mul(h2op_sub(lo, 0x64806480u), dd); o[2 * e + 1] = h2op_mul(h2op_sub(hi, 0x64806480u), dd);
+            }
+        } else {
+            const uint32_t dd = h2dup((uint16_t)(rd & 0xffff)), mm = h2dup((uint16_t)(rd >> 16));
+            const uint32_t q[4] = { rq.x, rq.y, rq.z, rq.w };
+#pragma unroll
+            for (int e = 0; e < 4; e++) {                               // elements 4 e .. (low nibbles), 16 + 4 e .. (high nibbles)
+                uint32_t lo, hi, lo2, hi2;
+                b2h(q[e] & 0x0f0f0f0fu, lo, hi); b2h((q[e] >> 4) & 0x0f0f0f0fu, lo2, hi2);
+                if (IS_41) {
+                    o[2 * e] = h2op_fma(h2op_sub(lo, 0x64006400u), dd, mm); o[2 * e + 1] = h2op_fma(h2op_sub(hi, 0x64006400u), dd, mm);
+                    o[8 + 2 * e] = h2op_fma(h2op_sub(lo2, 0x64006400u), dd, mm); o[8 + 2 * e + 1] = h2op_fma(h2op_sub(hi2, 0x64006400u), dd, mm);
+                } else {
+                    o[2 * e] = h2op_mul(h2op_sub(lo, 0x64086408u), dd); o[2 * e + 1] = h2op_mul(h2op_sub(hi, 0x64086408u), dd);
+                    o[8 + 2 * e] = h2op_mul(h2op_sub(lo2, 0x64086408u), dd); o[8 + 2 * e + 1] = h2op_mul(h2op_sub(hi2, 0x64086408u), dd);
+                }
+            }
+        }
+        char * wr = Wt + wrow * MMD_LD + whalf * 64;
+#pragma unroll
+        for (int e = 0; e < 4; e++) *(u32x4 *)(wr + 16 * e) = u32x4{o[4 * e], o[4 * e + 1], o[4 * e + 2], o[4 * e + 3]};
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            const int c = tid + 256 * t, row = c >> 3, ch = c & 7;
+            *(u32x4 *)(Xt + row * MMD_LD + ch * 16) = rx[t];
+        }
+    };
+
+    prefetch(0);
+    commit(0, 0);
+    __syncthreads();
+    int stage = 0;
+    for (int64_t k0 = 0; k0 < K; k0 += MMD_KS) {
+        const bool more = k0 + MMD_KS < K;
+        if (more) prefetch(k0 + MMD_KS);
+        const char * Wt = lds + stage * STAGE, * Xt = Wt + BN * MMD_LD;
+#pragma unroll
+        for (int ks = 0; ks < 4; ks++) {
+            h8v ax[2], bw[2];
+#pragma unroll
+            for (int i = 0; i < 2; i++) ax[i] = *(const h8v *)(Xt + (wm + i * 32 + l31) * MMD_LD + ks * 32 + l5 * 16);
+#pragma unroll
+            for (int j = 0; j < 2; j++) bw[j] = *(const h8v *)(Wt + (wn + j * 32 + l31) * MMD_LD + ks * 32 + l5 * 16);
+#pragma unroll
+            for (int i = 0; i < 2; i++)
+#pragma unroll
+                for (int j = 0; j < 2; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ax[i], bw[j], acc[i][j], 0, 0, 0);
+        }
+        if (more) commit(stage ^ 1, k0 + MMD_KS);
+        __syncthreads();
+        stage ^= 1;
+    }
+
+    const int64_t nv = (a.N / 2) & ~(int64_t) 7;
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            const int64_t n = n0 + wn + j * 32 + l31;
+#pragma unroll
+            for (int v = 0; v < 16; v++) {
+                const int64_t m = m0 + wm + i * 32 + (v & 3) + 8 * (v >> 2) + 4 * l5;
+                const float r = acc[i][j][v];
+                if (a.epi == 1) {
+                    const float up = dpp_f<DPP_QUAD_XOR1>(r);
+                    const int64_t u = n >> 1;
+                    if (!(lane & 1) && n + 1 < a.N && m < a.M) a.dst[m * a.ldd + u] = silu_any(r, u < nv) * up;
+                } else if (n < a.N && m < a.M) a.dst[m * a.ldd + n] = a.resid ? r + a.resid[m * a.ldr + n] : r;
+            }
+        }
+}
+
+__global__ void __launch_bounds__(256) k_f32_to_f16(const char * __restrict__ x, int64_t nb1, int64_t K, uint16_t * __restrict__ out, int64_t ldo) {
     const int64_t e = ((int64_t) blockIdx.x * 256 + threadIdx.x) * 2;
     const int64_t row = blockIdx.y;
     if (e >= K) return;
     const float * r = (const float *)(x + row * nb1);
-    *(uint32_t *)(out + row * K + e) = (uint32_t) f2h(r[e]) | ((uint32_t) f2h(r[e + 1]) << 16);
+    *(uint32_t *)(out + row * ldo + e) = (uint32_t) f2h(r[e]) | ((uint32_t) f2h(e + 1 < K ? r[e + 1] : 0.0f) << 16);
 }
 
-static int ensure(void *& p, size_t & have, size_t need, hipStream_t st) {
-    if (need <= have) return CLLM_OK;
-    HIP_TRY(hipStreamSynchronize(st));
-    if (p) (void) hipFree(p);
-    p = nullptr; have = 0;
-    HIP_TRY(hipMalloc(&p, need));
-    have = need;
-    return CLLM_OK;
-}
+static void * g_x16 = nullptr; static size_t g_x16_bytes = 0;
+static int g_f16_mode = -1;
+bool prefill_f16_enabled() { if (g_f16_mode < 0) g_f16_mode = getenv("CLLM_PREFILL") && !strcmp(getenv("CLLM_PREFILL"), "f16"); return g_f16_mode != 0; }
+extern "C" __attribute__((visibility("default"))) void cllm_debug_set_prefill_f16(int on) { g_f16_mode = on ? 1 : 0; }      // tests: switch inside one process
 
-bool prefill_f16_enabled() { static const bool v = getenv("CLLM_PREFILL") && !strcmp(getenv("CLLM_PREFILL"), "f16"); return v; }
-
-// w: [K, N] quantized rows (2-D), x: [K, M] f32 rows (nb1 stride), d: [N, M] f32 (nb1 stride); CLLM_E_UNSUPPORTED -> the int8 path takes it
-int launch_dense_f16(hipStream_t st, int wtype, const tview & w, const tview & x, const tview & d) {
+// w: [K, N] quantized rows (2-D), x: [K, M] f32 rows (nb1 stride), d: [N, M] f32 (nb1 stride); CLLM_E_UNSUPPORTED -> the caller's other paths take it
+int launch_dense_f16(hipStream_t st, int wtype, const tview & w, const tview & x, const tview & d, const float * resid, int64_t ldr, int epi) {
     const int64_t K = w.ne[0], N = w.ne[1], M = x.ne[1];
-    if (K % 2 || d.nb[1] % 4 || N > INT32_MAX || M > INT32_MAX || K > INT32_MAX) return CLLM_E_UNSUPPORTED;
-    if (int rc = load_rocblas()) return rc;
-    if (!g_rb) { if (p_create(&g_rb) != rocblas_status_success) FAIL(CLLM_E_HIP, "dense_f16: rocblas_create_handle failed"); }
-    if (p_set_stream(g_rb, st) != rocblas_status_success) FAIL(CLLM_E_HIP, "dense_f16: rocblas_set_stream failed");
-    if (int rc = ensure(g_w16, g_w16_bytes, (size_t) N * K * 2, st)) return rc;
-    if (int rc = ensure(g_x16, g_x16_bytes, (size_t) M * K * 2, st)) return rc;
-    hipLaunchKernelGGL(k_dequant_f16, dim3((unsigned)((K / 2 + 255) / 256), (unsigned) N), dim3(256), 0, st, wtype, (const char *) w.data, w.nb[1], K, N, (uint16_t *) g_w16);
-    hipLaunchKernelGGL(k_f32_to_f16, dim3((unsigned)((K / 2 + 255) / 256), (unsigned) M), dim3(256), 0, st, (const char *) x.data, x.nb[1], K, (uint16_t *) g_x16);
+    if (K % 32 || d.nb[1] % 4 || x.nb[0] != 4 || (epi && (epi != 1 || resid || N % 2)) || (wtype == CLLM_TYPE_Q4_K && ((uintptr_t) w.data % 16 || w.nb[1] % 16))) return CLLM_E_UNSUPPORTED;
+    if (wtype == CLLM_TYPE_Q4_1 && ((uintptr_t) w.data % 4 || w.nb[1] % 4)) return CLLM_E_UNSUPPORTED;
+    if (((M + 127) / 128) * ((N + 127) / 128) > 0x7fffffff) return CLLM_E_UNSUPPORTED;
+    const int64_t ldx = (K + 7) & ~(int64_t) 7;
+    const size_t need = (size_t) M * ldx * 2;
+    if (need > g_x16_bytes) {
+        HIP_TRY(hipStreamSynchronize(st));
+        if (g_x16) (void) hipFree(g_x16);
+        g_x16 = nullptr; g_x16_bytes = 0;
+        HIP_TRY(hipMalloc(&g_x16, need));
+        g_x16_bytes = need;
+    }
+    hipLaunchKernelGGL(k_f32_to_f16, dim3((unsigned)((K / 2 + 255) / 256), (unsigned) M), dim3(256), 0, st, (const char *) x.data, x.nb[1], K, (uint16_t *) g_x16, ldx);
     LAUNCH_CHECK();
-    // column-major view: W16 is (K x N) with ld K, X16 is (K x M) with ld K, D is (N x M) with ld nb1 / 4:  D = W16^T . X16
-    const float alpha = 1.0f, beta = 0.0f;
-    const rocblas_status rs = p_gemm_ex(g_rb, rocblas_operation_transpose, rocblas_operation_none, (rocblas_int) N, (rocblas_int) M, (rocblas_int) K, &alpha,
-                                              g_w16, rocblas_datatype_f16_r, (rocblas_int) K, g_x16, rocblas_datatype_f16_r, (rocblas_int) K, &beta,
-                                              d.data, rocblas_datatype_f32_r, (rocblas_int)(d.nb[1] / 4), d.data, rocblas_datatype_f32_r, (rocblas_int)(d.nb[1] / 4),
-                                              rocblas_datatype_f32_r, rocblas_gemm_algo_standard, 0, 0);
-    if (rs != rocblas_status_success) FAIL(CLLM_E_HIP, "dense_f16: rocblas_gemm_ex failed (%d)", (int) rs);
+    mmd_args a;
+    a.W = w.data; a.nb01 = w.nb[1]; a.N = N; a.K = K; a.X = (const uint16_t *) g_x16; a.ldx = ldx; a.M = M;
+    a.dst = (float *) d.data; a.ldd = d.nb[1] / 4; a.resid = resid; a.ldr = ldr; a.epi = epi;
+    constexpr int LDS = 2 * 256 * MMD_LD;
+    const dim3 grid((unsigned)(((M + 127) / 128) * ((N + 127) / 128)));
+#define GO(T) do { static bool attr = false; \
+        if (!attr) { HIP_TRY(hipFuncSetAttribute((const void *) k_mmd<T>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS)); attr = true; } \
+        hipLaunchKernelGGL(k_mmd<T>, grid, dim3(256), LDS, st, a); } while (0)
+    if (wtype == CLLM_TYPE_Q4_K) GO(CLLM_TYPE_Q4_K);
+    else if (wtype == CLLM_TYPE_Q4_0) GO(CLLM_TYPE_Q4_0);
+    else if (wtype == CLLM_TYPE_Q8_0) GO(CLLM_TYPE_Q8_0);
+    else if (wtype == CLLM_TYPE_Q4_1) GO(CLLM_TYPE_Q4_1);
+    else return CLLM_E_UNSUPPORTED;
+#undef GO
+    LAUNCH_CHECK();
     return CLLM_OK;
 }

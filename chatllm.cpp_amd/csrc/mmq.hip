@@ -67,7 +67,9 @@ __global__ void __launch_bounds__(mmq_traits<TYPE>::NW * 64, mmq_traits<TYPE>::N
     constexpr int MMQ_MI = mmq_traits<TYPE>::MI, NT = mmq_traits<TYPE>::NW * 64, MMQ_BM = (mmq_traits<TYPE>::NW / 2) * 16 * MMQ_MI;
     constexpr int LDS_WS = lds_ws(MMQ_BM), LDS_XS = lds_xs(MMQ_BM, TYPE == CLLM_TYPE_Q4_1);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int64_t m0 = (int64_t) blockIdx.x * MMQ_BM, n0 = (int64_t) blockIdx.y * MMQ_BN;
+    unsigned mt, nt;                        // (L2-aware tile order: common.h gemm_tile_of)
+    gemm_tile_of(blockIdx.x, (unsigned)((a.M + MMQ_BM - 1) / MMQ_BM), (unsigned)((a.N + MMQ_BN - 1) / MMQ_BN), 128 / MMQ_BM * 4, mt, nt);
+    const int64_t m0 = (int64_t) mt * MMQ_BM, n0 = (int64_t) nt * MMQ_BN;
     const int wn = (wave & 1) * 64, wm = (wave >> 1) * (MMQ_MI * 16);       // this wave's quadrant inside the tile
     const int l15 = lane & 15, l4 = lane >> 4;
 
@@ -344,10 +346,11 @@ int launch_mmq(hipStream_t st, int wtype, const tview & w, const void * act, siz
     a.act = (const char *) act; a.act_stride = act_stride; a.M = x.ne[1];
     a.dst = (float *) d.data; a.ldd = d.nb[1] / 4; a.resid = resid; a.ldr = ldr; a.epi = epi;
     if (epi && (epi != 1 || resid || a.N % 2)) FAIL(CLLM_E_INVALID, "mmq: epilogue %d", epi);
-    if ((a.N + MMQ_BN - 1) / MMQ_BN > 65535) FAIL(CLLM_E_UNSUPPORTED, "mmq: too many row tiles");
+
 #define GO(T) do { static bool attr = false; \
         constexpr int BM = (mmq_traits<T>::NW / 2) * 16 * mmq_traits<T>::MI, LDS = lds_total(BM, T == CLLM_TYPE_Q4_1); \
-        const dim3 grid((unsigned)((a.M + BM - 1) / BM), (unsigned)((a.N + MMQ_BN - 1) / MMQ_BN)); \
+        if (((a.M + BM - 1) / BM) * ((a.N + MMQ_BN - 1) / MMQ_BN) > 0x7fffffff) FAIL(CLLM_E_UNSUPPORTED, "mmq: too many tiles"); \
+        const dim3 grid((unsigned)(((a.M + BM - 1) / BM) * ((a.N + MMQ_BN - 1) / MMQ_BN))); \
         if (!attr) { HIP_TRY(hipFuncSetAttribute((const void *) k_mmq<T>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS)); attr = true; } \
         hipLaunchKernelGGL(k_mmq<T>, grid, dim3(mmq_traits<T>::NW * 64), LDS, st, a); } while (0)
     if (wtype == CLLM_TYPE_Q4_K) GO(CLLM_TYPE_Q4_K);

@@ -95,7 +95,9 @@ __global__ void __launch_bounds__(256, 2) k_mmx(const mmx_args a) {
     constexpr int XPL = IS_41 ? 2 * NBK : IS_K ? 1 : NBK;           // per token: dx[NBK] (+ sx[NBK]) / dx
     constexpr int LDS_XT = 0, LDS_WT = BM * LD, LDS_WS = LDS_WT + BN * LD, LDS_XS = LDS_WS + BN * NPL * 4;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int64_t m0 = (int64_t) blockIdx.x * BM, n0 = (int64_t) blockIdx.y * BN;
+    unsigned mt, nt;                        // (L2-aware tile order: common.h gemm_tile_of)
+    gemm_tile_of(blockIdx.x, (unsigned)((a.M + BM - 1) / BM), (unsigned)((a.N + BN - 1) / BN), 512 / BM, mt, nt);
+    const int64_t m0 = (int64_t) mt * BM, n0 = (int64_t) nt * BN;
     const int wn = (wave % T::WN) * (NJ * 16), wm = (wave / T::WN) * (MI * 16);
     const int l15 = lane & 15, l4 = lane >> 4;
     char * Xt = lds + LDS_XT; char * Wt = lds + LDS_WT; char * Ws = lds + LDS_WS; char * Xs = lds + LDS_XS;
@@ -421,8 +423,8 @@ int launch_mmx(hipStream_t st, int wtype, const tview & w, const void * act, siz
     if (epi && (epi != 1 || resid || a.N % 2)) FAIL(CLLM_E_INVALID, "mmx: epilogue %d", epi);
 #define GO(T) do { static bool attr = false; \
         using TR = mmx_traits<T>; constexpr int BN = TR::WN * TR::NJ * 16, BM = TR::WM * TR::MI * 16, LDS = mmx_lds<T>(); \
-        if ((a.N + BN - 1) / BN > 65535) FAIL(CLLM_E_UNSUPPORTED, "mmx: too many row tiles"); \
-        const dim3 grid((unsigned)((a.M + BM - 1) / BM), (unsigned)((a.N + BN - 1) / BN)); \
+        if (((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN) > 0x7fffffff) FAIL(CLLM_E_UNSUPPORTED, "mmx: too many tiles"); \
+        const dim3 grid((unsigned)(((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN))); \
         if (!attr) { HIP_TRY(hipFuncSetAttribute((const void *) k_mmx<T>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS)); attr = true; } \
         hipLaunchKernelGGL(k_mmx<T>, grid, dim3(256), LDS, st, a); } while (0)
     static const bool dbg = getenv("CLLM_DEBUG") != nullptr;

@@ -161,6 +161,28 @@ def test_mul_mat_quant_gemm_fast_mode(gpu, t, K, N, M):
     assert rel_err(got, want) < T1
 
 
+@pytest.mark.parametrize("t", [O.Q4_K, O.Q4_0, O.Q8_0, O.Q4_1])
+@pytest.mark.parametrize("K,N,M", [(512, 64, 40), (4096, 256, 128), (768, 130, 70), (4352, 300, 257), (14336, 140, 33)])
+def test_mul_mat_quant_dense_f16_mode(gpu, t, K, N, M):
+    """CLLM_PREFILL=f16 (opt-in; north star: block dequant staged through LDS + fp16 MFMA tiles, dense_f16.hip): the weights are dequantized to fp16 inside the
+    GEMM's staging, the activations rounded to fp16 -- NOT the reference's computation (no activation quantization), so it is checked against the oracle's
+    dequantize_row_* values times the fp16-rounded activations in float64: |delta| <= 1.5e-3 * max|ref| (the fp16 rounding of the weights: 2^-11 per element)"""
+    import ctypes as C2
+    lib = C2.CDLL(gpu.lib.SO_PATH)
+    w = rand_blocks(t, N, K, rng)
+    x = rng.standard_normal((1, M, K)).astype(np.float32)
+    wd = np.stack([O.dequantize(t, w[r], K) for r in range(N)]).astype(np.float64)
+    want = x[0].astype(np.float16).astype(np.float64) @ wd.T                   # [M, N]
+    lib.cllm_debug_set_prefill_f16(1)
+    try:
+        with prefill_mode(gpu, 0):
+            got = gpu.ops.mul_mat(gpu.Tensor.from_numpy(w, t, [K, N]), gpu.Tensor.from_numpy(x)).numpy().reshape(M, N)
+    finally:
+        lib.cllm_debug_set_prefill_f16(0)
+    assert np.all(np.isfinite(got))
+    assert float(np.max(np.abs(got - want))) <= 1.5e-3 * float(np.max(np.abs(want))), float(np.max(np.abs(got - want)) / np.max(np.abs(want)))
+
+
 @pytest.mark.parametrize("t", [O.F16, O.F32])
 @pytest.mark.parametrize("K,N,M,ne02,ne12", [(128, 50, 1, 1, 1), (128, 37, 3, 2, 8), (64, 9, 5, 1, 4), (100, 11, 2, 1, 1), (1031, 16, 1, 2, 2),
                                              # >= 32 columns: the F16 case runs on the matrix cores (mma_f16.hip): full tiles, ragged N / M / K, GQA broadcast

@@ -1,0 +1,68 @@
+"""Worker of tests/test_gpu_tp.py::test_two_ranks_share_the_gpu_and_all_reduce_over_gloo: rank r of a 2-rank tensor-parallel group, BOTH ranks on GPU 0.
+The runner's all-reduce goes through the host callback (cllm_llama_set_allreduce): device -> host, gloo all_reduce (CPU), host -> device -- so the HIP
+tensor-parallel code of decoder.hip (sharded q/k/v/gate/up rows, o/down columns, partial sums folded into the next mat-vec's RMS_NORM prologue, residual
+ping-pong) sees REAL partial sums from another rank.  argv: rank world port out.npz seed"""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def main():
+    rank, world, port, out, seed = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), sys.argv[4], int(sys.argv[5])
+    import torch
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from conftest import load_package
+    import bench
+    pkg = load_package()
+    pkg.lib.require_gpu()
+    L = pkg.lib.get()
+    cfg = pkg.synth.config("small", max_len=64, ffn=3072)          # 8 heads / 2 kv heads, ffn / 256 divisible by the group size
+    w = pkg.synth.make_model(cfg, pkg.Q4_K, seed=seed)
+    hd = cfg["head_dim"]
+    QD, F = cfg["n_head"] * hd, cfg["ffn"]
+    sh = {}
+    for name, (t, arr) in w.items():
+        base = name.split(".")[-1]
+        if base in ("wq", "wk", "wv", "wgate", "wup"):
+            arr = bench.shard_rows(arr, rank, world)
+        elif base == "wo":
+            arr = bench.shard_cols(arr, t, QD, rank, world, pkg)
+        elif base == "wdown":
+            arr = bench.shard_cols(arr, t, F, rank, world, pkg)
+        sh[name] = (t, arr)
+    m = pkg.Llama(cfg, sh, tp_rank=rank, tp_size=world)
+    n_calls = [0]
+
+    def allreduce(stream, buf, n):
+        pkg.ops.sync()                                         # the runner's launches are stream-ordered: finish them, then the host round trip
+        host = np.empty(n, np.float32)
+        pkg.lib.check(L.cllm_memcpy_d2h(host.ctypes.data_as(C.c_void_p), C.c_void_p(buf), n * 4, None), "d2h")
+        t = torch.from_numpy(host)
+        dist.all_reduce(t)
+        pkg.lib.check(L.cllm_memcpy_h2d(C.c_void_p(buf), host.ctypes.data_as(C.c_void_p), n * 4, None), "h2d")
+        pkg.ops.sync()
+        n_calls[0] += 1
+    m.set_allreduce(allreduce)
+    prompt = np.random.default_rng(seed).integers(0, cfg["vocab"], 12).astype(np.int32)
+    teacher = np.random.default_rng(seed + 1).integers(0, cfg["vocab"], 10).astype(np.int32)
+    logits = [m.forward(prompt)]
+    for i, t in enumerate(teacher):                          # teacher-forced: the node-by-node path and the fused single-token path alternate
+        logits.append(m.forward([int(t)]) if i % 2 == 0 else m.decode_fused_logits(int(t)))
+    ids = m.decode_greedy(int(np.argmax(logits[-1])), 8)      # free-running through the fused TP step (eager launches: a host callback cannot be captured)
+    if rank == 0:
+        np.savez(out, logits=np.stack(logits), ids=ids, calls=n_calls[0])
+    m.close()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -27,13 +27,17 @@ if __name__ == "__main__":
     tok = int(np.argmax(m.forward(prompt)))
     m.decode_greedy(tok, a.steps)
     L = cfg["n_layer"]
-    ts = m.debug_read("persist_ts", L * 10 * 2).view(np.uint64).reshape(L, 5, 2).astype(np.float64) * 0.01      # wall_clock64: 100 MHz -> us
+    ts = m.debug_read("persist_ts", L * 40 * 2).view(np.uint64).reshape(L, 5, 8).astype(np.float64) * 0.01      # wall_clock64: 100 MHz -> us
     names = ["qkv (norm+quant+mat-vec)", "attention", "o (+residual)", "gate/up (+SiLU*up)", "down (+residual)"]
     dur = ts[:, :, 1] - ts[:, :, 0]
-    print(f"{a.model} Q4_K, persistent decode launch, workgroup 0, last token: us per phase, mean over layers 1..{L - 1} (min .. max)")
+    print(f"{a.model} Q4_K, persistent decode launch, workgroup 0, last token: us per phase, mean over layers 1..{L - 1} (min .. max) | prefetch issue + barrier wait, activation prologue, row loop, publish")
     for i, n in enumerate(names):
         d = dur[1:, i]
-        print(f"  {n:28s} {d.mean():7.2f}  ({d.min():6.2f} .. {d.max():6.2f})")
+        parts = ""
+        if i != 1:
+            t = ts[1:, i]
+            parts = f" | {np.mean(t[:, 2] - t[:, 0]):5.2f} {np.mean(t[:, 3] - t[:, 2]):5.2f} {np.mean(t[:, 4] - t[:, 3]):5.2f} {np.mean(t[:, 1] - t[:, 4]):5.2f}"
+        print(f"  {n:28s} {d.mean():7.2f}  ({d.min():6.2f} .. {d.max():6.2f}){parts}")
     per_layer = ts[1:, 0, 0] - ts[:-1, 0, 0]
     print(f"  layer to layer               {per_layer.mean():7.2f}  ({per_layer.min():6.2f} .. {per_layer.max():6.2f})")
     m.close()
