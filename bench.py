@@ -12,13 +12,14 @@ the timed region.
            residual stream after o_proj and down_proj ("scaling": "strong": the same model, N GPUs).
 
 Extra objects on the JSON line (rank 0, N = 1):
-  "roofline"     the dominant kernel (the gate|up GEMV): HIP events on the launch stream; "traffic" = the PMC figure committed under profiles/
-                 for exactly this kernel ("traffic_source" names the file: counters cannot be sampled from inside this process)
+  "roofline"     the dominant kernel (the gate|up GEMV): HIP events on the launch stream; "traffic" = HBM bytes per launch from a separate rocprofv3 --pmc FETCH_SIZE
+                 pass that bench.py spawns over the same kernel (--no-pmc: null)
   "cpu_baseline" the reference HOST itself (oracle/_ref/ref_chat = chatllm.cpp's graph builder + ggml scheduler + CPU backend, compiled from
                  /root/reference) decoding the same synthetic model end to end on this box's cores: median of 3 runs; "host_cores" = cores of the
                  box, "cores" = threads used; "matvec_bound" = the mat-vec-only upper bound of the CPU path
-  "dropin"       the SAME unmodified host with every layer on our ggml module (-ngl all): the through-the-boundary number
-  "prefill"      BASELINE cfg3: Llama-3-8B shapes, Q4_0, one 4096-token prompt through the runner (median of 3), fraction of the matrix-core peak
+  "dropin"       the SAME unmodified host with every layer on our ggml module (-ngl all): the through-the-boundary number (also "dropin_tok_s")
+  "prefill"      BASELINE cfg3: Llama-3-8B shapes, Q4_0, one 4096-token prompt through the runner (median of 3), fraction of the matrix-core peak, in the default
+                 (exact-order) mode and in the opt-in fast mode
 """
 import argparse
 import ctypes as C
@@ -115,22 +116,34 @@ def measure_dominant_kernel(pkg, cfg, wtype, iters=64):
     return {"kernel": "%s (gate/up GEMV %dx%d, decode form)" % (name, rows, H), "bytes_per_launch": nbytes, "avg_us": dur_s * 1e6, "gbs": nbytes / dur_s / 1e9}
 
 
-PMC_SUMMARY = os.path.join("profiles", "r02_pmc_summary.json")
-
-
-def pmc_traffic(kernel_label):
-    """HBM bytes per launch of the dominant kernel from the PMC pass committed under profiles/ (FETCH_SIZE, corrected x2 for
-    gfx950 as MI355X_MICROARCH.md prescribes); counters cannot be sampled from inside this process, so: the committed number
-    for exactly this kernel + shape (and the file it comes from), else null."""
+def pmc_traffic_live(kernel_substr, timeout=240):
+    """HBM bytes per launch of the dominant kernel, measured NOW: a separate rocprofv3 --pmc FETCH_SIZE pass (with --kernel-trace only, as MI355X_MICROARCH.md's HBM section
+    prescribes) over a few launches of exactly that kernel (tools/gemv_bench.py --fused, weight copies cycled so that nothing stays in the Infinity Cache); FETCH_SIZE is
+    reported in KB and, on gfx950, at 1/2 of the bytes of a wide coalesced stream: bytes = KB * 1024 * 2.  None when rocprofv3 is not there or the pass fails."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    if not shutil.which("rocprofv3"):
+        return None, "rocprofv3 not found"
+    td = tempfile.mkdtemp(dir="/tmp")
     try:
-        with open(os.path.join(ROOT, PMC_SUMMARY)) as f:
-            tab = json.load(f)
-        for k, v in tab.items():
-            if k == kernel_label:
-                return v["hbm_read_bytes"], PMC_SUMMARY + " (rocprofv3 --pmc FETCH_SIZE of this kernel and shape, x2 per MI355X_MICROARCH.md; collected by tools/prof_round.sh)"
-    except Exception:
-        pass
-    return None, None
+        cmd = ["rocprofv3", "--pmc", "FETCH_SIZE", "--kernel-trace", "--output-format", "csv", "-d", td, "--", sys.executable, os.path.join(ROOT, "tools", "gemv_bench.py"),
+               "--fused", "--types", "q4_k", "--shapes", "gate_up_silu", "--iters", "8"]
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"))
+        files = glob.glob(os.path.join(td, "**", "*counter_collection.csv"), recursive=True)
+        if not files:
+            return None, "no counter output (rc %d): %s" % (r.returncode, r.stderr[-200:])
+        vals = [float(row["Counter_Value"]) for row in csv.DictReader(open(files[0])) if row.get("Counter_Name") == "FETCH_SIZE" and kernel_substr in row["Kernel_Name"]]
+        if not vals:
+            return None, "kernel %s not in the counter output" % kernel_substr
+        vals = vals[len(vals) // 4:] or vals              # skip the warm-up launches
+        return int(sum(vals) / len(vals) * 1024 * 2), "rocprofv3 --pmc FETCH_SIZE --kernel-trace (separate pass spawned by bench.py, %d launches averaged; KB x 1024 x 2 per MI355X_MICROARCH.md)" % len(vals)
+    except Exception as e:      # noqa: BLE001
+        return None, "PMC pass failed: %r" % (e,)
+    finally:
+        shutil.rmtree(td, ignore_errors=True)
 
 
 def cpu_baseline(pkg, cfg, wtype, budget_s=20.0):
@@ -251,28 +264,41 @@ def dropin_through_the_boundary(mp, n_decode=144):
 
 
 def prefill_cfg3(pkg, model_name, n_prompt=4096, reps=3):
-    """BASELINE cfg3: Q4_0 weights, one n_prompt-token prompt through the runner (cllm_llama_forward): median wall time, algorithmic FLOPs of SURVEY 8d"""
+    """BASELINE cfg3: Q4_0 weights, one n_prompt-token prompt through the runner (cllm_llama_forward): median wall time and the algorithmic FLOPs of SURVEY 8d, in the default
+    mode (exact: the reference's accumulation order on the K = 4 / f32 matrix-core instructions, bit-identical to the CPU for every prompt length) and in the opt-in fast
+    mode (CLLM_PREFILL=fast: int8-MFMA GEMM + flash attention, tolerance tier)"""
     cfg = pkg.synth.config(model_name, max_len=(n_prompt + 63) // 64 * 64)
     m = build_model(pkg, cfg, WTYPES["q4_0"], 0, 1)
     prompt = np.random.default_rng(1234).integers(0, cfg["vocab"], n_prompt).astype(np.int32)
-    m.forward(prompt, n_past=0)
-    pkg.ops.sync()
-    ts = []
-    for _ in range(reps):
-        t0 = time.perf_counter()
-        m.forward(prompt, n_past=0)
-        pkg.ops.sync()
-        ts.append(time.perf_counter() - t0)
-    m.close()
-    dt = sorted(ts)[len(ts) // 2]
     H, hd, F, L = cfg["hidden"], cfg["head_dim"], cfg["ffn"], cfg["n_layer"]
     QD, KD = cfg["n_head"] * hd, cfg["n_kv_head"] * hd
     flops = 2.0 * L * (H * (QD + 2 * KD) + QD * H + 3 * H * F) * n_prompt + 2.0 * 2 * n_prompt * n_prompt * hd * cfg["n_head"] * L
-    return {"ms": dt * 1e3, "tok_s": n_prompt / dt, "n_prompt": n_prompt, "wtype": "q4_0", "algorithmic_tflops": flops / dt / 1e12,
-            "mfma_frac": flops / dt / 5.0e15, "mfma_peak": "5.0e15 int8 dense (the linear layers run v_mfma_i32_*_i8; attention on f16 MFMA)", "frac_of_f16_peak_2.5e15": flops / dt / 2.5e15,
-            # NOT measured by this run (too long for the default bench): the same prompt through the unmodified reference host, recorded by tools/dropin_prefill.sh
-            "recorded_through_reference_host": {"module_ms": 137.9, "host_cpu_backend_ms": 89086.6, "host_cpu_threads": 64,
-                                                 "source": "profiles/r02_dropin_prefill_cfg3.txt (bash tools/dropin_prefill.sh; NGL=cpu THREADS=64 REPS=1 for the CPU run)"}}
+    lib = pkg.lib.get()
+    out = {}
+    default_mode = lib.cllm_get_prefill_mode()
+    for name, mode in (("exact", 1), ("fast", 0)):
+        pkg.lib.check(lib.cllm_set_prefill_mode(mode), "set_prefill_mode")
+        try:
+            m.forward(prompt, n_past=0)
+            pkg.ops.sync()
+            ts = []
+            for _ in range(reps):
+                t0 = time.perf_counter()
+                m.forward(prompt, n_past=0)
+                pkg.ops.sync()
+                ts.append(time.perf_counter() - t0)
+        finally:
+            lib.cllm_set_prefill_mode(default_mode)
+        dt = sorted(ts)[len(ts) // 2]
+        out[name] = {"ms": dt * 1e3, "tok_s": n_prompt / dt, "algorithmic_tflops": flops / dt / 1e12, "frac_of_f16_mfma_peak_2.5e15": flops / dt / 2.5e15, "frac_of_int8_mfma_peak_5e15": flops / dt / 5.0e15}
+    m.close()
+    d = out["exact" if default_mode == 1 else "fast"]
+    res = {"mode": "exact" if default_mode == 1 else "fast", "ms": d["ms"], "tok_s": d["tok_s"], "n_prompt": n_prompt, "wtype": "q4_0", "algorithmic_tflops": d["algorithmic_tflops"],
+           "mfma_frac": d["frac_of_f16_mfma_peak_2.5e15"],
+           "mfma_peak": "2.5e15 dense fp16 (exact mode: block sums on v_mfma_f32_16x16x4_4b_f16, attention as fmaf chains on v_mfma_f32_16x16x4_f32 -- both legacy-rate instructions; "
+                        "its fp32 fold chains run on the VALU, which bounds it: profiles/r03_prefill_modes_gemm.txt)",
+           "modes": out}
+    return res
 
 
 def main():
@@ -285,6 +311,7 @@ def main():
     ap.add_argument("--n-prompt", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the host runs (cpu_baseline, dropin) and the prefill leg")
     ap.add_argument("--no-prefill", action="store_true")
+    ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 --pmc pass that measures the dominant kernel's HBM traffic (roofline.traffic = null)")
     ap.add_argument("--no-graph", action="store_true", help="launch the fused decode kernels eagerly (for rocprofv3 kernel traces)")
     args = ap.parse_args()
 
@@ -392,7 +419,7 @@ def main():
         if world == 1:
             try:
                 k = measure_dominant_kernel(pkg, cfg, wtype)
-                traffic, tsrc = pmc_traffic(k["kernel"])
+                traffic, tsrc = (None, "skipped (--no-pmc)") if args.no_pmc or wtype != 12 else pmc_traffic_live("k_gemv_dec")
                 res["roofline"] = {"bound": "hbm", "achieved": k["gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": k["gbs"] / HBM_PEAK_GBS,
                                    "traffic": traffic, "traffic_source": tsrc, "kernel": k["kernel"], "avg_us": k["avg_us"], "bytes_per_launch": k["bytes_per_launch"]}
             except Exception as e:      # the throughput number stands on its own
@@ -418,6 +445,7 @@ def main():
                         log(f"mat-vec CPU bound failed: {e!r}")
                     try:
                         res["dropin"] = dropin_through_the_boundary(mp) if mp else {"error": "no GGMM file"}
+                        res["dropin_tok_s"] = res["dropin"].get("tok_s")          # the through-the-boundary number (unmodified reference host on the module), first class
                     except Exception as e:
                         res["dropin"] = {"error": str(e)}
                 if not args.no_prefill and args.model == "llama3-8b":

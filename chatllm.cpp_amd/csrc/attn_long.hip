@@ -6,14 +6,27 @@
 //   k_attn_long_scores : grid (split, kv head): RoPE of the group's query heads and of the new k; K rows of one slice of
 //                        positions are read ONCE and dotted with all r2 query heads of the group -> scores[head][i] (global)
 //   k_attn_long_softmax: grid (head): soft_max over the head's score row, probabilities rounded to fp16 (in place)
-//   k_attn_long_pv     : grid (row chunk, kv head): V^T rows of the chunk are read ONCE and dotted with the r2 probability rows
-// Every score, every probability and every context element is produced by the same lane-group arithmetic in the same order as in
-// k_attn_dec / the unfused MUL_MAT + SOFT_MAX nodes (only WHICH workgroup computes an element changes), so the results are
-// bit-identical to theirs.  Used by the runner above CLLM_ATTN_LONG cached positions (default and minimum 512, the measured
-// crossover is ~400): two extra launches (~9 us) buy 25 us at 4096 positions and 140 us at 16384.
+//   k_attn_long_pv     : grid (row chunk, kv head, query head of the group): 16 V^T rows x the head's probability row
+// Every score and every context element is accumulated in the ORDER of the reference's ggml_vec_dot_f16 (vec.cpp:264-, AVX2 + F16C:
+// 32 fp32 accumulators, accumulator a takes elements a, a + 32, ... one fma each, GGML_F32x8_REDUCE's tree, the n mod 32 leftovers one by
+// one in double) with the lane layout of k_attn_dec: 16 lanes per row, lane c carries accumulators 2c and 2c + 1.  The soft_max is
+// k_soft_max's.  Only WHICH workgroup computes an element differs from k_attn_dec / the unfused MUL_MAT + SOFT_MAX nodes, so the
+// results are bit-identical to theirs -- and to libggml-cpu.so -- at every context length.  Used by the runner above CLLM_ATTN_LONG
+// cached positions (default and minimum 512).
 #include "common.h"
 
-typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+#include "q4k.h"
+typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+
+// GGML_F32x8_REDUCE over the 32 accumulators held two per lane by 16 lanes (decode_fused.hip's vd32_reduce: the same definition)
+__device__ __forceinline__ float al_xor4(float v) { return __int_as_float(lane_xor4_i(__float_as_int(v))); }
+__device__ __forceinline__ float al_vd32_reduce(float a0, float a1) {
+    a0 = a0 + dpp_f<DPP_ROW_ROR8>(a0); a1 = a1 + dpp_f<DPP_ROW_ROR8>(a1);
+    a0 = a0 + al_xor4(a0);             a1 = a1 + al_xor4(a1);
+    a0 = a0 + dpp_f<DPP_QUAD_XOR2>(a0); a1 = a1 + dpp_f<DPP_QUAD_XOR2>(a1);
+    const float u = a0 + a1;
+    return u + dpp_f<DPP_QUAD_XOR1>(u);
+}
 
 static unsigned long long * g_long_ts = nullptr;
 extern "C" __attribute__((visibility("default"))) void cllm_debug_set_attn_long_ts(unsigned long long * dev_buf) { g_long_ts = dev_buf; }   // tools only
@@ -33,12 +46,12 @@ __global__ void __launch_bounds__(256) k_attn_long_scores(const float * __restri
     TS(0);
     __shared__ float qs[R2 * HD];          // the group's query heads after RoPE, rounded to fp16 (src1 of K.Q)
     __shared__ float knew[HD], vnew[HD];   // the new k (after RoPE) and v, rounded to fp16 like the cache
-    constexpr int half = HD / 2, G = HD / 8, RPW = 64 / G, off = MODE == 0 ? 1 : half, U = 4;
+    constexpr int half = HD / 2, off = MODE == 0 ? 1 : half, U = 4;
     const int g = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int KD = nkv * HD, QD = nh * HD;
     const int pos = uniform_load_i32_(pos_dev), n_kv = pos + 1;
-    // slice of positions of this workgroup: rounded up to whole passes of 4 waves x RPW rows x U
-    constexpr int PASS = 4 * RPW * U;
+    // slice of positions of this workgroup: rounded up to whole passes of 4 waves x 4 rows x U
+    constexpr int PASS = 4 * 4 * U;
     const int chunk = (((n_kv + (int) gridDim.x - 1) / (int) gridDim.x + PASS - 1) / PASS) * PASS;
     const int i_lo = blockIdx.x * chunk, i_hi = min(n_kv, i_lo + chunk);
     if (i_lo >= n_kv) return;
@@ -61,73 +74,55 @@ __global__ void __launch_bounds__(256) k_attn_long_scores(const float * __restri
     }
 
     TS(1);
-    // A wave owns 16 consecutive positions per pass (U = 4 rounds of RPW = 4 rows, 16 lanes per row: 256 contiguous bytes of the
-    // row).  Each lane forms its 8-element partial per query head; the 16-lane reduction is NOT done with shuffles (4 heads x 4
-    // ds_bpermute stages per row made this loop LDS-crossbar bound, 2.7 us per pass): the partials go through LDS once, and lane
-    // (row, head) adds the row's 16 partials in the butterfly's order ((p0+p8)+(p4+p12))+... -> the same bits, 30x fewer LDS ops.
-    static_assert(G == 16 || G == 8, "head sizes 128 / 64");
-    constexpr int RPI = RPW * U;                                  // rows per wave and pass (16 for HD 128, 32 for HD 64)
-    constexpr int PSTR = G * R2 + 4;                              // floats per row in the exchange buffer (+4: conflict-free column reads)
-    __shared__ float part[4][RPI * PSTR];
-    const int gl = lane & (G - 1), sub = lane / G;
-    const int d = gl * 8;
-    float q[R2][8];
+    // A wave owns RPI consecutive positions per pass (U rounds of 4 rows, 16 lanes per row).  Lane c of a row carries the accumulators 2c and 2c + 1 of
+    // ggml_vec_dot_f16: one dword (two fp16) of the row per 32-element chunk, one fma per accumulator and chunk, then the reference's reduction tree (DPP).
+    constexpr int NCH = HD / 32, RPI = 4 * U;
+    const int c16 = lane & 15, sub = lane >> 4;
+    float qa[R2][NCH], qb[R2][NCH];
 #pragma unroll
     for (int h = 0; h < R2; h++)
 #pragma unroll
-        for (int j = 0; j < 8; j++) q[h][j] = qs[h * HD + d + j];
-    const uint16_t * kbase = k_cache + g * HD + d;
-    float * mypart = part[wave];
-    auto load_rows = [&](int ib, u32x4 (&r)[U]) {                // unconditional (clamped): exact vmcnt bookkeeping
+        for (int i = 0; i < NCH; i++) { qa[h][i] = qs[h * HD + 32 * i + 2 * c16]; qb[h][i] = qs[h * HD + 32 * i + 2 * c16 + 1]; }
+    float kna[NCH], knb[NCH];
 #pragma unroll
-        for (int u = 0; u < U; u++) { const int i0 = ib + u * RPW + sub; r[u] = *(const u32x4 *)(kbase + (int64_t)(i0 < pos ? i0 : 0) * KD); }
+    for (int i = 0; i < NCH; i++) { kna[i] = knew[32 * i + 2 * c16]; knb[i] = knew[32 * i + 2 * c16 + 1]; }
+    const uint16_t * kbase = k_cache + g * HD + 2 * c16;
+    auto load_rows = [&](int ib, uint32_t (&r)[U][NCH]) {        // unconditional (clamped): exact vmcnt bookkeeping
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int i0 = ib + u * 4 + sub;
+            const uint16_t * kr = kbase + (int64_t)(i0 < pos ? i0 : 0) * KD;
+#pragma unroll
+            for (int i = 0; i < NCH; i++) r[u][i] = *(const uint32_t *)(kr + 32 * i);
+        }
     };
-    u32x4 cur[U], nxt[U];
+    uint32_t cur[U][NCH], nxt[U][NCH];
     constexpr int WSTEP = 4 * RPI;                                // positions per workgroup pass
     load_rows(i_lo + wave * RPI, cur);
     for (int ib = i_lo + wave * RPI; ib < i_hi; ib += WSTEP) {
         load_rows(ib + WSTEP, nxt);                              // the next pass is in flight while this one is consumed
 #pragma unroll
         for (int u = 0; u < U; u++) {
-            const int rl = u * RPW + sub, i0 = ib + rl;
-            float kv[8];
-            if (i0 == pos) {
+            const int i0 = ib + u * 4 + sub;
+            float k0[NCH], k1[NCH];
 #pragma unroll
-                for (int j = 0; j < 8; j++) kv[j] = knew[d + j];
-            } else {
-                const uint32_t wv[4] = { cur[u].x, cur[u].y, cur[u].z, cur[u].w };
-#pragma unroll
-                for (int j = 0; j < 4; j++) { kv[2*j] = h2f((uint16_t)(wv[j] & 0xffff)); kv[2*j + 1] = h2f((uint16_t)(wv[j] >> 16)); }
+            for (int i = 0; i < NCH; i++) {
+                k0[i] = i0 == pos ? kna[i] : h2f((uint16_t)(cur[u][i] & 0xffff));
+                k1[i] = i0 == pos ? knb[i] : h2f((uint16_t)(cur[u][i] >> 16));
             }
 #pragma unroll
             for (int h = 0; h < R2; h++) {
-                float acc = 0.0f;
+                float a0 = 0.0f, a1 = 0.0f;
 #pragma unroll
-                for (int j = 0; j < 8; j++) acc = __builtin_fmaf(kv[j], q[h][j], acc);
-                mypart[rl * PSTR + gl * R2 + h] = acc;
+                for (int i = 0; i < NCH; i++) { a0 = __builtin_fmaf(k0[i], qa[h][i], a0); a1 = __builtin_fmaf(k1[i], qb[h][i], a1); }
+                const float v = al_vd32_reduce(a0, a1);
+                if (c16 == 0 && i0 < i_hi) S[(int64_t)(g * R2 + h) * ML + i0] = v * scale;          // the SCALE node
             }
         }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");   // partials written by the other lanes of this wave
-        for (int t = lane; t < RPI * R2; t += 64) {              // lane t = (row, head)
-            const int rl = t / R2, h = t - rl * R2, i0 = ib + rl;
-            const float * pp = mypart + rl * PSTR + h;
-            float p[G];
 #pragma unroll
-            for (int l = 0; l < G; l++) p[l] = pp[l * R2];
-            float r;
-            if constexpr (G == 16) {
-                const float a0 = p[0] + p[8], a1 = p[1] + p[9], a2 = p[2] + p[10], a3 = p[3] + p[11], a4 = p[4] + p[12], a5 = p[5] + p[13], a6 = p[6] + p[14], a7 = p[7] + p[15];
-                const float b0 = a0 + a4, b1 = a1 + a5, b2 = a2 + a6, b3 = a3 + a7;
-                r = (b0 + b2) + (b1 + b3);
-            } else {
-                const float b0 = p[0] + p[4], b1 = p[1] + p[5], b2 = p[2] + p[6], b3 = p[3] + p[7];
-                r = (b0 + b2) + (b1 + b3);
-            }
-            if (i0 < i_hi) S[(int64_t)(g * R2 + h) * ML + i0] = r * scale;          // the SCALE node
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");   // the exchange buffer is reused by the next pass
+        for (int u = 0; u < U; u++)
 #pragma unroll
-        for (int u = 0; u < U; u++) cur[u] = nxt[u];
+            for (int i = 0; i < NCH; i++) cur[u][i] = nxt[u][i];
     }
     TS(2);
 }
@@ -173,85 +168,61 @@ __global__ void __launch_bounds__(1024) k_attn_long_softmax(const int32_t * __re
 }
 
 // ---- (3) ctx = V . P ------------------------------------------------------------------------------------------------------------
-// n_kv > 512 here, so a whole wave owns one V^T row (launch_T() in matmul_f.hip: G = 64): tail elements first, then 16-byte chunks
-// in increasing i, butterfly reduction.  One V chunk feeds the r2 heads of the group.  The probabilities (exactly representable in
-// fp16: they were rounded to it) are staged through LDS as fp16, one segment of SEG positions at a time, so that the inner loop's
-// only global loads are the V chunks (with the r2 x 32-byte P loads from L2 on its critical path this kernel took 44 us at 16K).
-template <int HD, int R2, int DR>
+// ggml_vec_dot_f16 over the cached positions: accumulator a takes positions a, a + 32, ... in order, so a V^T row is 32 serial fma chains of
+// n_kv / 32 steps -- 16 lanes per row, two chains per lane (one dword of the row per 32-position chunk), the probability pairs from LDS (fp16: they
+// were rounded to it, the conversions are exact).  A workgroup is 16 rows x ONE query head (the r2 heads of a group re-read the V rows through L2:
+// the chains, not the bytes, bound this launch); the n_kv mod 32 leftovers are added one by one in double (products rounded to fp32 first).
+template <int HD>
 __global__ void __launch_bounds__(256) k_attn_long_pv(const int32_t * __restrict__ pos_dev, int nh, int nkv, const uint16_t * __restrict__ v_cache, int ML,
                                                       const uint16_t * __restrict__ P, float * __restrict__ att) {
-    constexpr int SEG = 8192, RPWV = DR / 4, UC = 4;              // positions per staged segment, rows per wave, V chunks in flight
-    extern __shared__ __attribute__((aligned(16))) uint16_t psm[]; // [R2][SEG] fp16 probabilities
-    const int g = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int n_kv = uniform_load_i32_(pos_dev) + 1, n8 = n_kv & ~7;
-    const int it = n8 + lane, iv = lane * 8;
-    float acc[RPWV][R2];
-    const uint16_t * vrow[RPWV];
+    extern __shared__ __attribute__((aligned(16))) uint16_t psm[]; // [n_kv rounded up to 8] fp16 probabilities of this head
+    __shared__ float tail[16][32];
+    const int g = blockIdx.y, r2 = gridDim.z, h = g * r2 + blockIdx.z, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n_kv = uniform_load_i32_(pos_dev) + 1, np = n_kv & ~31, nch = np >> 5, ntail = n_kv - np;
+    const int c16 = lane & 15, sub = lane >> 4, rl = wave * 4 + sub, d0 = blockIdx.x * 16 + rl;
+    const uint16_t * vr = v_cache + ((int64_t) g * HD + d0) * ML + 2 * c16;
+    constexpr int UC = 16;                                        // chunks in flight per lane
+    uint32_t ring[UC];
 #pragma unroll
-    for (int rr = 0; rr < RPWV; rr++) {
-        const int d0 = blockIdx.x * DR + wave + 4 * rr;
-        vrow[rr] = v_cache + ((int64_t) g * HD + (d0 < HD ? d0 : 0)) * ML;
-        const float vt = it < n_kv ? h2f(vrow[rr][it]) : 0.0f;
+    for (int c = 0; c < UC; c++) ring[c] = *(const uint32_t *)(vr + 32 * (c < nch ? c : 0));
+    const uint16_t t0 = vr[np + 0 < n_kv - 2 * c16 ? np : 0], t1 = vr[np + 1 < n_kv - 2 * c16 ? np + 1 : 0];      // leftovers np + 2 c16 (+ 1), clamped
+    const uint16_t * prow = P + (int64_t) h * ML;
+    for (int i = tid * 8; i < n_kv; i += 256 * 8) *(u32x4 *)(psm + i) = *(const u32x4 *)(prow + i);      // (ML % 8 == 0: whole 16-byte chunks are inside the row)
+    __syncthreads();
+    float a0 = 0.0f, a1 = 0.0f;
+    // both operands are fp16 in registers: fma((float) v, (float) p, acc) is one v_fma_mix_f32 (the conversions are exact: the cvt + fma of the other kernels bit for bit)
+    const uint32_t * pp = (const uint32_t *) psm + c16;
+    const uint32_t * vp = (const uint32_t *) vr;
+    auto step = [&](uint32_t vw, uint32_t pw) {
+        asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[1,1,0]" : "+v"(a0) : "v"(vw), "v"(pw));      // low halves
+        asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,1,0]" : "+v"(a1) : "v"(vw), "v"(pw));      // high halves
+    };
+    int i0 = 0;
+    for (; i0 + 2 * UC <= nch; i0 += UC) {                        // whole groups whose refills are inside the row: no clamps, immediate offsets
 #pragma unroll
-        for (int h = 0; h < R2; h++) acc[rr][h] = it < n_kv ? __builtin_fmaf(vt, h2f(P[(int64_t)(g * R2 + h) * ML + it]), 0.0f) : 0.0f;
-    }
-    for (int seg0 = 0; seg0 < n8; seg0 += SEG) {
-        const int seg1 = min(n8, seg0 + SEG);
-        __syncthreads();                                         // the previous segment has been consumed
-        constexpr int NT = R2 * (SEG / 8) / 256;                 // 16-byte copy tasks per thread; all loads of a batch are in flight together
-        constexpr int NB = NT < 8 ? NT : 8;
-#pragma unroll
-        for (int t0 = 0; t0 < NT; t0 += NB) {
-            u32x4 buf[NB];
-#pragma unroll
-            for (int t = 0; t < NB; t++) {
-                const int c = tid + 256 * (t0 + t), h = c / (SEG / 8), i = seg0 + (c - h * (SEG / 8)) * 8;
-                buf[t] = *(const u32x4 *)(P + (int64_t)(g * R2 + h) * ML + (i < seg1 ? i : 0));
-            }
-#pragma unroll
-            for (int t = 0; t < NB; t++) {
-                const int c = tid + 256 * (t0 + t), h = c / (SEG / 8), il = (c - h * (SEG / 8)) * 8;
-                *(u32x4 *)(psm + h * SEG + il) = buf[t];
-            }
-        }
-        __syncthreads();
-#pragma unroll
-        for (int rr = 0; rr < RPWV; rr++) {
-            const uint16_t * vr = vrow[rr];
-            u32x4 ring[UC];
-#pragma unroll
-            for (int c = 0; c < UC; c++) { const int ic = seg0 + iv + 512 * c; ring[c] = *(const u32x4 *)(vr + (ic < seg1 ? ic : 0)); }
-            for (int i0 = seg0 + iv; i0 < seg1; i0 += 512 * UC) {
-#pragma unroll
-                for (int c = 0; c < UC; c++) {
-                    const int i = i0 + 512 * c;
-                    const u32x4 cur = ring[c];
-                    { const int inx = i + 512 * UC; ring[c] = *(const u32x4 *)(vr + (inx < seg1 ? inx : 0)); }    // unconditional (clamped) refill
-                    if (i < seg1) {
-                        // both operands are fp16 in registers: fma((float) v, (float) p, acc) is one v_fma_mix_f32 per element
-                        // (the conversions are exact, so this is the cvt + fma of the other kernels bit for bit)
-                        const half8 v = __builtin_bit_cast(half8, cur);
-#pragma unroll
-                        for (int h = 0; h < R2; h++) {
-                            const half8 pq = __builtin_bit_cast(half8, *(const u32x4 *)(psm + h * SEG + (i - seg0)));
-#pragma unroll
-                            for (int j = 0; j < 8; j++) acc[rr][h] = __builtin_fmaf((float) v[j], (float) pq[j], acc[rr][h]);
-                        }
-                    }
-                }
-            }
+        for (int c = 0; c < UC; c++) {
+            const uint32_t cur = ring[c];
+            ring[c] = vp[16 * (i0 + UC + c)];
+            step(cur, pp[16 * (i0 + c)]);
         }
     }
+    for (; i0 < nch; i0 += UC) {
 #pragma unroll
-    for (int rr = 0; rr < RPWV; rr++) {
-        const int d0 = blockIdx.x * DR + wave + 4 * rr;
-#pragma unroll
-        for (int h = 0; h < R2; h++) {
-            float r = acc[rr][h];
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) r += __shfl_xor(r, o, 64);
-            if (lane == 0 && d0 < HD) att[(g * R2 + h) * HD + d0] = r;
+        for (int c = 0; c < UC; c++) {
+            const int i = i0 + c;
+            const uint32_t cur = ring[c];
+            { const int inx = i + UC; ring[c] = vp[16 * (inx < nch ? inx : 0)]; }      // unconditional (clamped) refill
+            if (i < nch) step(cur, pp[16 * i]);
         }
+    }
+    const float res = al_vd32_reduce(a0, a1);
+    if (2 * c16 < ntail)     tail[rl][2 * c16]     = h2f(t0) * h2f(psm[np + 2 * c16]);
+    if (2 * c16 + 1 < ntail) tail[rl][2 * c16 + 1] = h2f(t1) * h2f(psm[np + 2 * c16 + 1]);
+    wave_lds_fence();
+    if (c16 == 0) {
+        double sacc = (double) res;
+        for (int t = 0; t < ntail; t++) sacc += (double) tail[rl][t];
+        att[h * HD + d0] = (float) sacc;
     }
 }
 
@@ -265,8 +236,7 @@ int launch_attn_long(hipStream_t st, const float * qkv, const int32_t * pos_dev,
     const float scale = 1.0f / sqrtf((float) hd);
     uint16_t * P16 = (uint16_t *)(S + (size_t) nh * ML);          // fp16 probabilities behind the fp32 scores
     const int cus = device_cu_count();
-    int nsplit = cus / nkv; if (nsplit < 1) nsplit = 1; if (nsplit > 64) nsplit = 64;
-    constexpr int DR = 8;
+    int nsplit = 2 * cus / nkv; if (nsplit < 1) nsplit = 1; if (nsplit > 128) nsplit = 128;      // two 256-thread workgroups per CU
 #define SC(HD_, MODE_, R2_) hipLaunchKernelGGL((k_attn_long_scores<HD_, MODE_, R2_>), dim3(nsplit, nkv), dim3(256), 0, st, qkv, pos_dev, rope_cs, nh, nkv, scale, k_cache, v_cache, (int) ML, S, g_long_ts)
 #define SC2(HD_, R2_) do { if (mode == 0) SC(HD_, 0, R2_); else SC(HD_, 2, R2_); } while (0)
 #define SC3(HD_) do { if (r2 == 1) SC2(HD_, 1); else if (r2 == 2) SC2(HD_, 2); else if (r2 == 4) SC2(HD_, 4); else SC2(HD_, 8); } while (0)
@@ -276,20 +246,17 @@ int launch_attn_long(hipStream_t st, const float * qkv, const int32_t * pos_dev,
     if (lds > 48 * 1024 && !attr) { HIP_TRY(hipFuncSetAttribute((const void *) k_attn_long_softmax, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024)); attr = true; }
     hipLaunchKernelGGL(k_attn_long_softmax, dim3(nh), dim3(1024), lds, st, pos_dev, (int) ML, (const float *) S, P16);
     LAUNCH_CHECK();
-#define PV(HD_, R2_) hipLaunchKernelGGL((k_attn_long_pv<HD_, R2_, DR>), dim3(HD_ / DR, nkv), dim3(256), (size_t) R2_ * 8192 * 2, st, pos_dev, nh, nkv, (const uint16_t *) v_cache, (int) ML, (const uint16_t *) P16, att)
-#define PV2(HD_) do { if (r2 == 1) PV(HD_, 1); else if (r2 == 2) PV(HD_, 2); else if (r2 == 4) PV(HD_, 4); else PV(HD_, 8); } while (0)
-    static bool attr_pv = false;
-    if (r2 == 8 && !attr_pv) {      // 8 x 16 KB of fp16 probabilities
-        HIP_TRY(hipFuncSetAttribute((const void *) k_attn_long_pv<128, 8, DR>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 8192 * 2));
-        HIP_TRY(hipFuncSetAttribute((const void *) k_attn_long_pv<64, 8, DR>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 8192 * 2));
-        attr_pv = true;
-    }
-    if (hd == 128) PV2(128); else PV2(64);
+    const size_t lds_pv = (size_t) ML * 2 + 16;
+    if (lds_pv > 150 * 1024) return CLLM_E_UNSUPPORTED;
+#define PV(HD_) do { \
+        static bool attr_pv = false; \
+        if (lds_pv > 48 * 1024 && !attr_pv) { HIP_TRY(hipFuncSetAttribute((const void *) k_attn_long_pv<HD_>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024)); attr_pv = true; } \
+        hipLaunchKernelGGL((k_attn_long_pv<HD_>), dim3(HD_ / 16, nkv, r2), dim3(256), lds_pv, st, pos_dev, nh, nkv, (const uint16_t *) v_cache, (int) ML, (const uint16_t *) P16, att); } while (0)
+    if (hd == 128) PV(128); else PV(64);
     LAUNCH_CHECK();
 #undef SC
 #undef SC2
 #undef SC3
 #undef PV
-#undef PV2
     return CLLM_OK;
 }

@@ -31,14 +31,16 @@ extern "C" size_t cllm_type_size(int type) {
         case CLLM_TYPE_I64: return 8;
         case CLLM_TYPE_Q4_0: return 18; case CLLM_TYPE_Q4_1: return 20; case CLLM_TYPE_Q8_0: return 34; case CLLM_TYPE_Q4_K: return 144;
         case CLLM_TYPE_Q5_K: return 176; case CLLM_TYPE_Q6_K: return 210;
+        case CLLM_TYPE_Q5_0: return 22; case CLLM_TYPE_Q5_1: return 24; case CLLM_TYPE_IQ4_NL: return 18; case CLLM_TYPE_MXFP4: return 17;
+        case CLLM_TYPE_Q2_K: return 84; case CLLM_TYPE_Q3_K: return 110;
     }
     return 0;
 }
 extern "C" int cllm_blck_size(int type) {
     switch (type) {
         case CLLM_TYPE_F32: case CLLM_TYPE_I32: case CLLM_TYPE_F16: case CLLM_TYPE_I64: return 1;
-        case CLLM_TYPE_Q4_0: case CLLM_TYPE_Q4_1: case CLLM_TYPE_Q8_0: return 32;
-        case CLLM_TYPE_Q4_K: case CLLM_TYPE_Q5_K: case CLLM_TYPE_Q6_K: return 256;
+        case CLLM_TYPE_Q4_0: case CLLM_TYPE_Q4_1: case CLLM_TYPE_Q8_0: case CLLM_TYPE_Q5_0: case CLLM_TYPE_Q5_1: case CLLM_TYPE_IQ4_NL: case CLLM_TYPE_MXFP4: return 32;
+        case CLLM_TYPE_Q4_K: case CLLM_TYPE_Q5_K: case CLLM_TYPE_Q6_K: case CLLM_TYPE_Q2_K: case CLLM_TYPE_Q3_K: return 256;
     }
     return 0;
 }
@@ -234,11 +236,11 @@ extern "C" int cllm_op_mul_mat(void * stream, const cllm_tensor * src0, const cl
     if (src0->ne[0] == 0) return cllm_memset(dst->data, 0, dst->nb[3] * (size_t) dst->ne[3], stream);
 
     if (!is_quant(src0->type)) return launch_mul_mat_f(st, src0->type, tv(src0), tv(src1), tv(dst));
-    if (is_kq_type(src0->type)) {                      // Q5_K / Q6_K: the exact-order kernel for any number of columns (gemv_kq.hip)
-        const size_t stride = act_row_bytes(src0->ne[0], ACT_Q8_K), need = stride * (size_t) t_nrows(src1);
+    if (is_kq_type(src0->type)) {                      // the coverage types: the exact-order kernel for any number of columns (gemv_kq.hip)
+        const size_t stride = act_row_bytes(src0->ne[0], act_kind(src0->type)), need = stride * (size_t) t_nrows(src1);
         if (!wdata || wsize < need) FAIL(CLLM_E_INVALID, "mul_mat: wdata too small (%zu < %zu)", wsize, need);
         if ((uintptr_t) wdata % 16 || (uintptr_t) src1->data % 16 || src1->nb[1] % 16 || src1->nb[2] % 16 || src1->nb[3] % 16) FAIL(CLLM_E_UNSUPPORTED, "mul_mat: operand alignment");
-        if ((rc = launch_quantize_act(st, ACT_Q8_K, tv(src1), wdata, stride))) return rc;
+        if ((rc = launch_quantize_act(st, act_kind(src0->type), tv(src1), wdata, stride))) return rc;
         const int64_t r2 = src1->ne[2] / src0->ne[2], r3 = src1->ne[3] / src0->ne[3];
         for (int64_t i13 = 0; i13 < src1->ne[3]; i13++)
         for (int64_t i12 = 0; i12 < src1->ne[2]; i12++) {
@@ -247,7 +249,7 @@ extern "C" int cllm_op_mul_mat(void * stream, const cllm_tensor * src0, const cl
             const char * act = (const char *) wdata + (size_t)(i12 * src1->ne[1] + i13 * src1->ne[1] * src1->ne[2]) * stride;
             if (dst->nb[1] % 4) FAIL(CLLM_E_INVALID, "mul_mat: dst stride");
             rc = launch_gemv_kq(st, src0->type, w, act, stride, src1->ne[1], (float *)((char *) dst->data + i12 * dst->nb[2] + i13 * dst->nb[3]), (int64_t)(dst->nb[1] / 4));
-            if (rc == CLLM_E_UNSUPPORTED) FAIL(rc, "mul_mat: Q5_K / Q6_K shape or alignment not taken");
+            if (rc == CLLM_E_UNSUPPORTED) FAIL(rc, "mul_mat: type %d: shape or alignment not taken", src0->type);
             if (rc) return rc;
         }
         return CLLM_OK;

@@ -30,6 +30,14 @@ struct __attribute__((packed)) block_q8_K { float d; int8_t qs[256]; int16_t bsu
 struct __attribute__((packed)) block_q5_K { uint16_t d, dmin; uint8_t scales[12]; uint8_t qh[32]; uint8_t qs[128]; };   // 176 B (ggml-common.h:308-321)
 struct __attribute__((packed)) block_q6_K { uint8_t ql[128]; uint8_t qh[64]; int8_t scales[16]; uint16_t d; };          // 210 B (ggml-common.h:323-336)
 static_assert(sizeof(block_q5_K) == 176 && sizeof(block_q6_K) == 210, "block sizes");
+// the other formats stock model files carry (ggml-common.h:190-216, 262-288, 415-419): mat-mul through gemv_kq.hip, GET_ROWS
+struct __attribute__((packed)) block_q5_0   { uint16_t d; uint8_t qh[4]; uint8_t qs[16]; };                  // 22 B: w = ((nib | bit << 4) - 16) * d
+struct __attribute__((packed)) block_q5_1   { uint16_t d, m; uint8_t qh[4]; uint8_t qs[16]; };               // 24 B: w = (nib | bit << 4) * d + m
+struct __attribute__((packed)) block_iq4_nl { uint16_t d; uint8_t qs[16]; };                                 // 18 B: w = kvalues_iq4nl[nib] * d
+struct __attribute__((packed)) block_mxfp4  { uint8_t e; uint8_t qs[16]; };                                  // 17 B: w = kvalues_mxfp4[nib] * 2^(e - 128)
+struct __attribute__((packed)) block_q2_K   { uint8_t scales[16]; uint8_t qs[64]; uint16_t d, dmin; };       // 84 B
+struct __attribute__((packed)) block_q3_K   { uint8_t hmask[32]; uint8_t qs[64]; uint8_t scales[12]; uint16_t d; };   // 110 B
+static_assert(sizeof(block_q5_0) == 22 && sizeof(block_q5_1) == 24 && sizeof(block_iq4_nl) == 18 && sizeof(block_mxfp4) == 17 && sizeof(block_q2_K) == 84 && sizeof(block_q3_K) == 110, "block sizes");
 static_assert(sizeof(block_q4_1) == 20 && sizeof(block_q8_1) == 36, "block sizes");
 static_assert(sizeof(block_q4_0) == 18 && sizeof(block_q8_0) == 34 && sizeof(block_q4_K) == 144 && sizeof(block_q8_K) == 292, "block sizes");
 
@@ -49,8 +57,12 @@ __host__ __device__ inline size_t act_off_d(int64_t K) { return act_align16((siz
 __host__ __device__ inline size_t act_off_s(int64_t K, int kind) { return act_off_d(K) + act_align16((size_t)(K / act_blk(kind)) * 4); }
 __host__ __device__ inline size_t act_row_bytes(int64_t K, int kind) { return act_off_s(K, kind) + act_align16((size_t)(K / 32) * 4); }
 // the activation format a weight type's dot product reads (type_traits_cpu[].vec_dot_type, ggml-cpu/ggml-cpu.c:207-390)
-__host__ __device__ inline bool   is_kq_type(int t) { return t == CLLM_TYPE_Q5_K || t == CLLM_TYPE_Q6_K; }        // gemv_kq.hip: mat-mul and GET_ROWS, no fused forms
-__host__ __device__ inline int    act_kind_of(int wtype) { return (wtype == CLLM_TYPE_Q4_K || is_kq_type(wtype)) ? ACT_Q8_K : wtype == CLLM_TYPE_Q4_1 ? ACT_Q8_1 : ACT_Q8_0; }
+// the coverage types (gemv_kq.hip: mat-mul for any number of columns in the reference's order, GET_ROWS; no fused decode forms)
+__host__ __device__ inline bool   is_kq_type(int t) {
+    return t == CLLM_TYPE_Q5_K || t == CLLM_TYPE_Q6_K || t == CLLM_TYPE_Q2_K || t == CLLM_TYPE_Q3_K || t == CLLM_TYPE_Q5_0 || t == CLLM_TYPE_Q5_1 || t == CLLM_TYPE_IQ4_NL || t == CLLM_TYPE_MXFP4;
+}
+__host__ __device__ inline bool   is_k256_type(int t) { return t == CLLM_TYPE_Q4_K || t == CLLM_TYPE_Q5_K || t == CLLM_TYPE_Q6_K || t == CLLM_TYPE_Q2_K || t == CLLM_TYPE_Q3_K; }
+__host__ __device__ inline int    act_kind_of(int wtype) { return is_k256_type(wtype) ? ACT_Q8_K : (wtype == CLLM_TYPE_Q4_1 || wtype == CLLM_TYPE_Q5_1) ? ACT_Q8_1 : ACT_Q8_0; }
 __host__ __device__ inline bool   is_quant_type(int t) { return t == CLLM_TYPE_Q4_0 || t == CLLM_TYPE_Q4_1 || t == CLLM_TYPE_Q8_0 || t == CLLM_TYPE_Q4_K; }
 
 // ---- small device helpers -----------------------------------------------------------------------
@@ -358,6 +370,7 @@ int launch_moe_router(hipStream_t st, int wtype, const void * W, int64_t K, int6
 int launch_gemv_kq(hipStream_t st, int wtype, const tview & w, const void * act, size_t act_stride, int64_t M, float * dst, int64_t ldd);
 int launch_dense_f16(hipStream_t st, int wtype, const tview & w, const tview & x, const tview & d, const float * resid = nullptr, int64_t ldr = 0, int epi = 0);
 int launch_gemv_rows(hipStream_t st, const void * W, int64_t K, int64_t nrows, int pro, const float * px, const float * pw, float eps, int epi, float * dst, const float * bias, const float * resid);
+int launch_gemv_rows32(hipStream_t st, int wtype, const void * W, int64_t K, int64_t nrows, int pro, const float * px, const float * pw, float eps, int epi, float * dst, const float * bias, const float * resid);
 int launch_mmvq_fused(hipStream_t st, int wtype, const void * W, int64_t K, int64_t nrows, int pro, const float * px, const float * pw, float eps, int epi, float * dst, const float * bias, const float * resid);
 int launch_attn_decode(hipStream_t st, const float * qkv, const int32_t * pos_dev, int nh, int nkv, int hd, const uint16_t * k_cache, const uint16_t * v_cache, int64_t ML, float * att);
 int launch_rope_table(hipStream_t st, const int32_t * pos_dev, int hd, float freq_base, float * cs);

@@ -470,11 +470,9 @@ extern "C" int cllm_llama_forward(cllm_llama * m, const int32_t * tokens, int ql
 
 // ---- fused single-token step: 10 launches per layer, every per-token input read from device memory ----------------------
 
-// cached positions above which the split attention (three launches, every CU) beats the one-launch kernel (one CU per head)
-// Up to this many cached positions the one-launch kernel runs: it accumulates in ggml_vec_dot_f16's order, bit-identical to the reference;
-// the split kernels beyond it keep their own fp32 summation order (tolerance tier: the reference's 32 serial chains over n_kv cannot be
-// spread over the chip).  Default 1024 (the measured speed crossover is ~400-500: CLLM_ATTN_LONG=512 trades the exactness of 512..1024 for it).
-int attn_long_threshold() { static const int v = getenv("CLLM_ATTN_LONG") ? atoi(getenv("CLLM_ATTN_LONG")) : 1024; return v < 512 ? 512 : v; }   // (V.P there assumes the 64-lane regime: >= 512)
+// cached positions above which the split attention (attn_long.hip: three launches, every CU) replaces the one-launch kernel (one CU per head).  Both accumulate in
+// ggml_vec_dot_f16's order -- the same bits -- so the threshold is purely a speed matter: the measured crossover is ~400-500 cached positions.
+int attn_long_threshold() { static const int v = getenv("CLLM_ATTN_LONG") ? atoi(getenv("CLLM_ATTN_LONG")) : 512; return v < 64 ? 64 : v; }
 
 static int decode_step_fused(cllm_llama * m, bool sample, bool long_ctx) {
     const cllm_llama_config & c = m->cfg;

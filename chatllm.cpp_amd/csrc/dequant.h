@@ -49,6 +49,41 @@ __device__ __forceinline__ float dequant_elem(int type, const char * row, int64_
             const float ds = h2f(b->d) * (float) b->scales[8 * j + 2 * g + l / 16];
             return ds * (float) q;
         }
+        case CLLM_TYPE_Q5_0: case CLLM_TYPE_Q5_1: {   // dequantize_row_q5_0 / _q5_1 (ggml-quants.c:348-399)
+            const bool q51 = type == CLLM_TYPE_Q5_1;
+            const uint8_t * b = (const uint8_t *) row + (i / 32) * (q51 ? 24 : 22); const int j = (int)(i % 32);
+            const uint8_t * qh = b + (q51 ? 4 : 2), * qs = qh + 4;
+            const uint32_t h = (uint32_t) qh[0] | ((uint32_t) qh[1] << 8) | ((uint32_t) qh[2] << 16) | ((uint32_t) qh[3] << 24);
+            const int q = (j < 16 ? (qs[j] & 0xF) : (qs[j - 16] >> 4)) | (int)(((h >> j) & 1u) << 4);
+            const float d = h2f((uint16_t)(b[0] | (b[1] << 8)));
+            return q51 ? (float) q * d + h2f((uint16_t)(b[2] | (b[3] << 8))) : (float)(q - 16) * d;
+        }
+        case CLLM_TYPE_IQ4_NL: case CLLM_TYPE_MXFP4: {   // dequantize_row_iq4_nl / _mxfp4 (ggml-quants.c:2512-2528, 417-436)
+            const bool mx = type == CLLM_TYPE_MXFP4;
+            const uint8_t * b = (const uint8_t *) row + (i / 32) * (mx ? 17 : 18); const int j = (int)(i % 32);
+            const uint8_t * qs = b + (mx ? 1 : 2);
+            const int nib = j < 16 ? (qs[j] & 0xF) : (qs[j - 16] >> 4);
+            const uint64_t tab = mx ? (nib < 8 ? 0x0c08060403020100ull : 0xf4f8fafcfdfeff00ull) : (nib < 8 ? 0xf6eaddcfbfad9881ull : 0x7159453526190d01ull);
+            const float v = (float)(int8_t)((tab >> (8 * (nib & 7))) & 0xff);
+            if (mx) return v * __uint_as_float(b[0] < 2 ? 0x00200000u << b[0] : (uint32_t)(b[0] - 1) << 23);
+            return h2f((uint16_t)(b[0] | (b[1] << 8))) * v;
+        }
+        case CLLM_TYPE_Q2_K: {                     // dequantize_row_q2_K (ggml-quants.c:784-815): (d * sc) * q - (dmin * m)
+            const block_q2_K * b = (const block_q2_K *) row + i / 256; const int e = (int)(i % 256);
+            const int n = e / 128, j = (e % 128) / 32, hh = (e % 32) / 16, l = e % 16;
+            const uint8_t sc = b->scales[8 * n + 2 * j + hh];
+            const float dl = h2f(b->d) * (float)(sc & 0xF), ml = h2f(b->dmin) * (float)(sc >> 4);
+            return dl * (float)((b->qs[32 * n + 16 * hh + l] >> (2 * j)) & 3) - ml;
+        }
+        case CLLM_TYPE_Q3_K: {                     // dequantize_row_q3_K (ggml-quants.c:1128-1176)
+            const block_q3_K * b = (const block_q3_K *) row + i / 256; const int e = (int)(i % 256);
+            const int n = e / 128, j = (e % 128) / 32, hh = (e % 32) / 16, l = e % 16, is = 8 * n + 2 * j + hh, bb = 16 * hh + l;
+            const uint8_t * s = b->scales;      // 6-bit scale `is`: low 4 bits in bytes 0..7 (nibbles), high 2 bits in bytes 8..11
+            const int lo = is < 8 ? (s[is] & 0xF) : (s[is - 8] >> 4), hi = (s[8 + (is & 3)] >> (2 * (is >> 2))) & 3;
+            const float dl = h2f(b->d) * (float)((lo | (hi << 4)) - 32);
+            const int q = (int)((b->qs[32 * n + bb] >> (2 * j)) & 3) - (((b->hmask[bb] >> (4 * n + j)) & 1) ? 0 : 4);
+            return dl * (float) q;
+        }
     }
     return 0.0f;
 }

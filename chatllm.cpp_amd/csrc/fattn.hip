@@ -547,8 +547,10 @@ __global__ void __launch_bounds__(HD) k_rope_kv_prep(const float * __restrict__ 
 
 int launch_attn_long_flash(hipStream_t st, const float * qkv, const int32_t * pos_dev, const float * rope_cs, int nh, int nkv, int hd, int mode,
                            uint16_t * k_cache, uint16_t * v_cache, int64_t ML, float * S, size_t s_bytes, float * att) {
-    static const bool off = getenv("CLLM_ATTN_LONG_FLASH") && atoi(getenv("CLLM_ATTN_LONG_FLASH")) == 0;
-    if (off || !rope_cs || (hd != 64 && hd != 128) || nkv <= 0 || nh % nkv || (int64_t) nh / nkv > 32 || ML % 8 || ML > (1 << 30) || ((uintptr_t) S & 15)) return CLLM_E_UNSUPPORTED;
+    // opt-in (CLLM_ATTN_LONG_FLASH=1): this form keeps the flash kernel's own summation order (tolerance tier); the default beyond attn_long_threshold() is
+    // attn_long.hip, which accumulates in the reference's order
+    static const bool on = getenv("CLLM_ATTN_LONG_FLASH") && atoi(getenv("CLLM_ATTN_LONG_FLASH")) == 1;
+    if (!on || !rope_cs || (hd != 64 && hd != 128) || nkv <= 0 || nh % nkv || (int64_t) nh / nkv > 32 || ML % 8 || ML > (1 << 30) || ((uintptr_t) S & 15)) return CLLM_E_UNSUPPORTED;
     const size_t q_bytes = ((size_t) nh * hd * 4 + 255) & ~(size_t) 255;
     if (s_bytes <= q_bytes) return CLLM_E_UNSUPPORTED;
     int max_splits = (int)((s_bytes - q_bytes) / ((size_t) nh * (hd + 4) * 4));

@@ -1,13 +1,18 @@
-// gemv_kq.hip -- MUL_MAT with Q5_K / Q6_K weights (the other k-quants third-party GGMM files carry: Q4_K_M / Q5_K_M mixes keep some
-// tensors in Q5_K and Q6_K), for any number of columns, BIT-IDENTICAL to the reference's x86 AVX2 dot products:
-//   ggml_vec_dot_q5_K_q8_K (ggml-cpu/arch/x86/quants.c:1916-2030)   8 lane accumulators acc[A] = fma(y.d x.d, (float) sumi[A], acc[A]) per
-//                                                                    super-block in order, + ONE scalar chain summs += (-y.d x.dmin) * sum m S
-//   ggml_vec_dot_q6_K_q8_K (ggml-cpu/arch/x86/quants.c:2130-2225)   the same lanes, int8 scale per 16 elements, no mins
+// gemv_kq.hip -- MUL_MAT for the COVERAGE weight types: every format a stock chatllm.cpp / GGML model file may carry besides the tuned ones (Q4_K_M / Q5_K_M mixes
+// keep tensors in Q5_K and Q6_K; older and third-party files use Q5_0 / Q5_1 / Q2_K / Q3_K / IQ4_NL; MXFP4), for any number of columns, BIT-IDENTICAL to the
+// reference's x86 AVX2 dot products (arch/x86/quants.c):
+//   q5_K :1916-2030   8 lane accumulators acc[A] = fma(y.d x.d, (float) sumi[A], acc[A]) per super-block in order, + ONE scalar chain summs += (-y.d x.dmin) * sum m S
+//   q6_K :2130-2225   the same lanes, int8 scale per 16 elements, no mins
+//   q2_K :1278-1354   acc[A] = fma(dmin, m[2A] S16[2A] + m[2A+1] S16[2A+1], acc[A]) then acc[A] = fma(d, sumi[A], acc[A]) (S16: activation sums per 16)
+//   q3_K :1470-1580   2 bits + a high-bit mask (value - 4 where the bit is clear), 6-bit scales - 32
+//   q5_0 :846-884, q5_1 :926-968    Q4_0's / Q4_1's chains with a fifth bit per weight
+//   iq4_nl :3632-3714, mxfp4 :760-844   int8 codebooks; even blocks in one 8-lane accumulator, odd ones in a second, added before the horizontal sum, an unpaired
+//                     last block in scalar code; with >= 2 activation columns IQ4_NL (and Q5_0) take tinyBLAS_Q0_AVX (llamafile/sgemm.cpp:1346-1790): ONE chain
 //   result = hsum_float_8(acc) [+ summs]
 // AVX lane A = dword A of every 32-byte chunk.  The simple, obviously-exact mapping: 8 GPU lanes per weight row, lane A computes sumi[A] of every
-// super-block itself and carries acc[A] in a register, so the serial fp32 chain needs no cross-lane traffic at all; the three adds of
-// hsum_float_8 are lane exchanges at the end.  Activations: the Q8_K act rows of quantize.hip (common.h layout).  Q6_K blocks are 210 bytes
-// (2-byte aligned): two 16-bit loads per dword.  This is the coverage path (it streams at a fraction of the Q4_K kernels' rate), not a tuned one.
+// block itself and carries acc[A] in a register, so the serial fp32 chain needs no cross-lane traffic at all; the three adds of
+// hsum_float_8 are lane exchanges at the end.  Activations: the act rows of quantize.hip (common.h layout: Q8_K, Q8_0 or Q8_1 kind).  Blocks that are only
+// 2-byte (1-byte: MXFP4) aligned are read in 16-bit (8-bit) pieces.  This is the coverage path (it streams at a fraction of the Q4_K kernels' rate), not a tuned one.
 #include "common.h"
 #include "q4k.h"
 
@@ -55,6 +60,44 @@ __global__ void __launch_bounds__(256) k_gemv_kq(const kq_args a) {
                 sc8[s] = (int8_t)(((s < 4 ? u0 : u1) >> (8 * (s & 3))) & 0xff);
                 mn[s]  = (int)(((s < 4 ? u2 : u3) >> (8 * (s & 3))) & 0xff);
             }
+        } else if (TYPE == CLLM_TYPE_Q2_K || TYPE == CLLM_TYPE_Q3_K) {
+            // term t = 4 n + j: plane j (bits 2j) of the 32-byte vector of the n-th 128 weights, bytes 4A..4A+3, against activations 128 n + 32 j + 4A..; its scale is the one of
+            // the 16-weight sub-block the bytes lie in: index 8 n + 2 j + (A >> 2)
+            constexpr bool Q2 = TYPE == CLLM_TYPE_Q2_K;
+            const char * blk = wr + (int64_t) b * (Q2 ? 84 : 110);
+            dw = h2f(*(const uint16_t *)(blk + (Q2 ? 80 : 108)));
+            int8_t s16[16];
+            if (Q2) {
+                dmin = h2f(*(const uint16_t *)(blk + 82));
+#pragma unroll
+                for (int k = 0; k < 4; k++) { const uint32_t v = ld2(blk + 4 * k);
+#pragma unroll
+                    for (int i = 0; i < 4; i++) s16[4 * k + i] = (int8_t)((v >> (8 * i)) & 0xff); }       // scale | min << 4
+            } else {
+                const uint32_t a0 = ld2(blk + 96), a1 = ld2(blk + 100), a2 = ld2(blk + 104);               // the sixteen 6-bit scales (ggml-quants.c:1141-1150), - 32
+                const uint32_t u[4] = { (a0 & 0x0f0f0f0fu) | (((a2 >> 0) & 0x03030303u) << 4), (a1 & 0x0f0f0f0fu) | (((a2 >> 2) & 0x03030303u) << 4),
+                                        ((a0 >> 4) & 0x0f0f0f0fu) | (((a2 >> 4) & 0x03030303u) << 4), ((a1 >> 4) & 0x0f0f0f0fu) | (((a2 >> 6) & 0x03030303u) << 4) };
+#pragma unroll
+                for (int k = 0; k < 4; k++)
+#pragma unroll
+                    for (int i = 0; i < 4; i++) s16[4 * k + i] = (int8_t)((int)((u[k] >> (8 * i)) & 0xff) - 32);
+            }
+            const uint32_t hm = Q2 ? 0u : ld2(blk + 4 * A);
+#pragma unroll
+            for (int n = 0; n < 2; n++) {
+                const uint32_t q = ld2(blk + (Q2 ? 16 : 32) + 32 * n + 4 * A);
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const int t = 4 * n + j;
+                    uint32_t v = (q >> (2 * j)) & 0x03030303u;
+                    if (!Q2) { v |= ((hm >> (4 * n + j)) & 0x01010101u) << 2; v = ((v | 0x80808080u) - 0x04040404u) ^ 0x80808080u; }      // per byte: (q | h << 2) - 4
+                    w[t] = v;
+                    const int8_t sc = (A >> 2) ? s16[8 * n + 2 * j + 1] : s16[8 * n + 2 * j];
+                    sc8[t] = Q2 ? (int8_t)(sc & 0xF) : sc;
+                    aoff[t] = 128 * n + 32 * j + 4 * A;
+                }
+            }
+            if (Q2) { mn[0] = ((uint8_t) s16[2 * A]) >> 4; mn[1] = ((uint8_t) s16[2 * A + 1]) >> 4; }
         } else {
             const char * blk = wr + (int64_t) b * 210;
             dw = h2f(*(const uint16_t *)(blk + 208));
@@ -80,6 +123,15 @@ __global__ void __launch_bounds__(256) k_gemv_kq(const kq_args a) {
 #pragma unroll
             for (int t = 0; t < 8; t++) sumi += (int) sc8[t] * dot4(w[t], *(const uint32_t *)(ar + b * 256 + aoff[t]), 0);
             const float yd = ((const float *)(ar + a.off_d))[b];
+            if (TYPE == CLLM_TYPE_Q2_K) {                                      // the mins first: S16[k] = sum of the activation quants 16 k .. 16 k + 15
+                int s16a = 0, s16b = 0;
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    s16a = dot4(0x01010101u, *(const uint32_t *)(ar + b * 256 + 32 * A + 4 * k), s16a);
+                    s16b = dot4(0x01010101u, *(const uint32_t *)(ar + b * 256 + 32 * A + 16 + 4 * k), s16b);
+                }
+                acc[c] = __builtin_fmaf((-yd) * dmin, (float)(mn[0] * s16a + mn[1] * s16b), acc[c]);
+            }
             acc[c] = __builtin_fmaf(yd * dw, (float) sumi, acc[c]);
             if (TYPE == CLLM_TYPE_Q5_K) {
                 const int * ys = (const int *)(ar + a.off_s) + b * 8;
@@ -101,23 +153,106 @@ __global__ void __launch_bounds__(256) k_gemv_kq(const kq_args a) {
     }
 }
 
-// act: Q8_K act rows (launch_quantize_act, kind ACT_Q8_K) of the M columns; dst[m * ldd + n]
+// ---- the 32-weight block formats: Q5_0 / Q5_1 / IQ4_NL / MXFP4.  Lane A owns elements 4A..4A+3 of every block: the low (A < 4) or high nibbles of quant bytes
+//      4 (A & 3) .. + 3.  CHAIN: one accumulator (Q5_0 / Q5_1 always; IQ4_NL with >= 2 columns); else even / odd blocks in two, the unpaired last block in scalar order ----
+__device__ __forceinline__ uint32_t ld1x4(const char * p) { const uint8_t * q = (const uint8_t *) p; return (uint32_t) q[0] | ((uint32_t) q[1] << 8) | ((uint32_t) q[2] << 16) | ((uint32_t) q[3] << 24); }
+// four 4-bit indices (one per byte of idx) -> four bytes of a 16-entry int8 table held as four dwords
+__device__ __forceinline__ uint32_t lut16(uint32_t idx, uint32_t t0, uint32_t t1, uint32_t t2, uint32_t t3) {
+    const uint32_t sel = idx & 0x07070707u;
+    const uint32_t lo = __builtin_amdgcn_perm(t1, t0, sel), hi = __builtin_amdgcn_perm(t3, t2, sel);
+    const uint32_t m = ((idx >> 3) & 0x01010101u) * 0xffu;
+    return (hi & m) | (lo & ~m);
+}
+template <int TYPE, int NC, bool CHAIN>
+__global__ void __launch_bounds__(256) k_gemv_b32(const kq_args a) {
+    constexpr bool Q50 = TYPE == CLLM_TYPE_Q5_0, Q51 = TYPE == CLLM_TYPE_Q5_1, NL = TYPE == CLLM_TYPE_IQ4_NL, MX = TYPE == CLLM_TYPE_MXFP4;
+    constexpr int BS = Q50 ? 22 : Q51 ? 24 : NL ? 18 : 17, QOFF = Q50 ? 6 : Q51 ? 8 : NL ? 2 : 1;
+    const int tid = blockIdx.x * 256 + threadIdx.x, A = tid & 7;
+    int row = tid >> 3;
+    const bool live = row < a.N;
+    if (!live) row = a.N - 1;
+    const char * wr = a.W + (int64_t) row * a.nb01;
+    float acc[NC], acc2[NC], summs[NC];
+#pragma unroll
+    for (int c = 0; c < NC; c++) { acc[c] = 0.0f; acc2[c] = 0.0f; summs[c] = 0.0f; }
+    const int npair = CHAIN ? a.nblk : (a.nblk & ~1);
+    // kvalues_iq4nl / kvalues_mxfp4 (ggml-common.h:1088-1096)
+    const uint32_t T0 = NL ? 0xbfad9881u : 0x03020100u, T1 = NL ? 0xf6eaddcfu : 0x0c080604u, T2 = NL ? 0x26190d01u : 0xfdfeff00u, T3 = NL ? 0x71594535u : 0xf4f8fafcu;
+    for (int b = 0; b < a.nblk; b++) {
+        const char * blk = wr + (int64_t) b * BS;
+        const uint32_t q4 = MX ? ld1x4(blk + QOFF + 4 * (A & 3)) : ld2(blk + QOFF + 4 * (A & 3));
+        const uint32_t nib = (q4 >> ((A >> 2) * 4)) & 0x0f0f0f0fu;
+        uint32_t w; float dw, mw = 0.0f;
+        if (Q50 || Q51) {
+            const uint32_t qh = ld2(blk + (Q50 ? 2 : 4));
+            const uint32_t bits = (qh >> (4 * A)) & 0xfu;                      // the fifth bits of elements 4A..4A+3 -> bit 4 of bytes 0..3
+            w = nib | (((bits * 0x00204081u) & 0x01010101u) << 4);
+            dw = h2f(*(const uint16_t *) blk);
+            if (Q51) mw = h2f(*(const uint16_t *)(blk + 2));
+        } else {
+            w = lut16(nib, T0, T1, T2, T3);
+            dw = MX ? __uint_as_float(*(const uint8_t *) blk < 2 ? 0x00200000u << *(const uint8_t *) blk : (uint32_t)(*(const uint8_t *) blk - 1) << 23)      // ggml_e8m0_to_fp32_half (ggml-impl.h:471-489)
+                    : h2f(*(const uint16_t *) blk);
+        }
+#pragma unroll
+        for (int c = 0; c < NC; c++) {
+            const int cc = c < a.ncols ? c : 0;
+            const char * ar = a.act + (int64_t) cc * a.act_stride;
+            const uint32_t av = *(const uint32_t *)(ar + b * 32 + 4 * A);
+            const int sumi = Q50 ? dot4(w, av, dot4(0xf0f0f0f0u, av, 0)) : dot4(w, av, 0);      // Q5_0: (q5 - 16) . a
+            const float yd = ((const float *)(ar + a.off_d))[b];
+            const float d = (NL || MX) ? yd * dw : dw * yd;
+            if (b < npair) {
+                if (CHAIN || !(b & 1)) acc[c] = __builtin_fmaf(d, (float) sumi, acc[c]); else acc2[c] = __builtin_fmaf(d, (float) sumi, acc2[c]);
+                if (Q51) summs[c] = __builtin_fmaf(mw, ((const float *)(ar + a.off_s))[b], summs[c]);      // summs += m_w * s_a, one fma in the reference build
+            } else summs[c] = d * (float) group8_sum_i(sumi);               // the unpaired last block: sumf += d * (sumi1 + sumi2) after the horizontal sum
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < NC; c++) {
+        float v = CHAIN ? acc[c] : acc[c] + acc2[c];
+        v = v + __int_as_float(lane_xor4_i(__float_as_int(v)));
+        v = v + dpp_f<DPP_QUAD_XOR2>(v);
+        v = v + dpp_f<DPP_QUAD_XOR1>(v);
+        if (Q51 || (!CHAIN && (a.nblk & 1))) v = v + summs[c];
+        if (live && A == 0 && c < a.ncols) a.dst[(int64_t) c * a.ldd + row] = v;
+    }
+}
+
+// act: the act rows (launch_quantize_act, kind act_kind_of(wtype)) of the M columns; dst[m * ldd + n]
 int launch_gemv_kq(hipStream_t st, int wtype, const tview & w, const void * act, size_t act_stride, int64_t M, float * dst, int64_t ldd) {
     const int64_t K = w.ne[0], N = w.ne[1];
-    if ((wtype != CLLM_TYPE_Q5_K && wtype != CLLM_TYPE_Q6_K) || K % 256 || N <= 0 || N > (1 << 28)) return CLLM_E_UNSUPPORTED;
-    if (wtype == CLLM_TYPE_Q5_K ? (((uintptr_t) w.data | (uintptr_t) w.nb[1]) & 15) : (((uintptr_t) w.data | (uintptr_t) w.nb[1]) & 1)) return CLLM_E_UNSUPPORTED;
+    const bool k256 = is_k256_type(wtype);
+    if (!is_kq_type(wtype) || K % (k256 ? 256 : 32) || N <= 0 || N > (1 << 28)) return CLLM_E_UNSUPPORTED;
+    const uintptr_t al = (uintptr_t) w.data | (uintptr_t) w.nb[1];
+    if (wtype == CLLM_TYPE_Q5_K ? (al & 15) : wtype == CLLM_TYPE_MXFP4 ? 0 : (al & 1)) return CLLM_E_UNSUPPORTED;
+    const int kind = act_kind_of(wtype);
     kq_args a;
-    a.W = w.data; a.nb01 = w.nb[1]; a.N = (int) N; a.nblk = (int)(K / 256);
-    a.act_stride = (int64_t) act_stride; a.off_d = (int) act_off_d(K); a.off_s = (int) act_off_s(K, ACT_Q8_K);
+    a.W = w.data; a.nb01 = w.nb[1]; a.N = (int) N; a.nblk = (int)(K / (k256 ? 256 : 32));
+    a.act_stride = (int64_t) act_stride; a.off_d = (int) act_off_d(K); a.off_s = (int) act_off_s(K, kind);
     a.ldd = ldd;
     const dim3 grid((unsigned)((N * 8 + 255) / 256));
+    const bool chain = M >= 2;                           // IQ4_NL: llamafile_sgemm serves n >= 2 (sgemm.cpp:3691, 4000-4013)
     for (int64_t m0 = 0; m0 < M; m0 += 8) {
         a.act = (const char *) act + (size_t) m0 * act_stride; a.dst = dst + m0 * ldd; a.ncols = (int)(M - m0 < 8 ? M - m0 : 8);
 #define GO(T) do { if (a.ncols == 1) hipLaunchKernelGGL((k_gemv_kq<T, 1>), grid, dim3(256), 0, st, a); \
                    else if (a.ncols <= 4) hipLaunchKernelGGL((k_gemv_kq<T, 4>), grid, dim3(256), 0, st, a); \
                    else hipLaunchKernelGGL((k_gemv_kq<T, 8>), grid, dim3(256), 0, st, a); } while (0)
-        if (wtype == CLLM_TYPE_Q5_K) GO(CLLM_TYPE_Q5_K); else GO(CLLM_TYPE_Q6_K);
+#define GB(T, CH) do { if (a.ncols == 1) hipLaunchKernelGGL((k_gemv_b32<T, 1, CH>), grid, dim3(256), 0, st, a); \
+                       else if (a.ncols <= 4) hipLaunchKernelGGL((k_gemv_b32<T, 4, CH>), grid, dim3(256), 0, st, a); \
+                       else hipLaunchKernelGGL((k_gemv_b32<T, 8, CH>), grid, dim3(256), 0, st, a); } while (0)
+        switch (wtype) {
+            case CLLM_TYPE_Q5_K: GO(CLLM_TYPE_Q5_K); break;
+            case CLLM_TYPE_Q6_K: GO(CLLM_TYPE_Q6_K); break;
+            case CLLM_TYPE_Q2_K: GO(CLLM_TYPE_Q2_K); break;
+            case CLLM_TYPE_Q3_K: GO(CLLM_TYPE_Q3_K); break;
+            case CLLM_TYPE_Q5_0: GB(CLLM_TYPE_Q5_0, true); break;
+            case CLLM_TYPE_Q5_1: GB(CLLM_TYPE_Q5_1, true); break;
+            case CLLM_TYPE_IQ4_NL: if (chain) GB(CLLM_TYPE_IQ4_NL, true); else GB(CLLM_TYPE_IQ4_NL, false); break;
+            default: GB(CLLM_TYPE_MXFP4, false); break;
+        }
 #undef GO
+#undef GB
         LAUNCH_CHECK();
     }
     return CLLM_OK;

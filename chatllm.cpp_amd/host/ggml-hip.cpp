@@ -78,7 +78,10 @@ cllm_tensor desc(const ggml_tensor * t) {
     return d;
 }
 bool is_q(ggml_type t) { return t == GGML_TYPE_Q4_0 || t == GGML_TYPE_Q4_1 || t == GGML_TYPE_Q8_0 || t == GGML_TYPE_Q4_K; }
-bool is_kq(ggml_type t) { return t == GGML_TYPE_Q5_K || t == GGML_TYPE_Q6_K; }      // mat-mul and GET_ROWS only (gemv_kq.hip): no fused launch takes them
+// the coverage types: mat-mul and GET_ROWS only (gemv_kq.hip): no fused launch takes them
+bool is_kq(ggml_type t) {
+    return t == GGML_TYPE_Q5_K || t == GGML_TYPE_Q6_K || t == GGML_TYPE_Q2_K || t == GGML_TYPE_Q3_K || t == GGML_TYPE_Q5_0 || t == GGML_TYPE_Q5_1 || t == GGML_TYPE_IQ4_NL || t == GGML_TYPE_MXFP4;
+}
 bool dense_rows(const ggml_tensor * t) { return t->nb[0] == ggml_type_size(t->type); }
 bool f32_dense(const ggml_tensor * t) { return t && t->type == GGML_TYPE_F32 && t->nb[0] == 4; }
 
@@ -341,7 +344,8 @@ bool dev_supports_op(ggml_backend_dev_t, const ggml_tensor * op) {
             if (is_q(a->type)) return a->ne[0] % 32 == 0 && b->nb[1] % 16 == 0 && b->nb[2] % 16 == 0 && b->nb[3] % 16 == 0 &&
                                       (a->type != GGML_TYPE_Q4_K || (a->nb[1] % 16 == 0 && a->nb[2] % 16 == 0 && a->nb[3] % 16 == 0)) &&
                                       (a->type != GGML_TYPE_Q4_1 || (a->nb[1] % 4 == 0 && a->nb[2] % 4 == 0 && a->nb[3] % 4 == 0));
-            if (is_kq(a->type)) return a->ne[0] % 256 == 0 && b->nb[1] % 16 == 0 && b->nb[2] % 16 == 0 && b->nb[3] % 16 == 0 && (a->type != GGML_TYPE_Q5_K || a->nb[1] % 16 == 0) && a->nb[1] % 2 == 0;
+            if (is_kq(a->type)) return a->ne[0] % ggml_blck_size(a->type) == 0 && b->nb[1] % 16 == 0 && b->nb[2] % 16 == 0 && b->nb[3] % 16 == 0 && (a->type != GGML_TYPE_Q5_K || a->nb[1] % 16 == 0) &&
+                                       (a->type == GGML_TYPE_MXFP4 || a->nb[1] % 2 == 0);
             return (a->type == GGML_TYPE_F16 || a->type == GGML_TYPE_F32) && a->ne[2] * a->ne[3] <= 65535;
         case GGML_OP_MUL_MAT_ID:
             return is_q(a->type) && f32_dense(b) && op->src[2] && op->src[2]->type == GGML_TYPE_I32 && a->ne[3] == 1 && b->ne[3] == 1 && a->ne[0] % 32 == 0 &&

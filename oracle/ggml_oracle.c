@@ -13,6 +13,9 @@
 
 /* two statements of the reference are plain C that gcc -O3 (-ffp-contract=fast) compiles to one fma; fused here explicitly */
 #define ORC_Q41_SUMMS(m, s, acc) fmaf((m), (s), (acc))
+#ifndef ORC_CODEBOOK_TAIL
+#define ORC_CODEBOOK_TAIL(d, v, acc) ((acc) + (d) * (v))          /* `sumf += d * (sumi1 + sumi2)` of the IQ4_NL / MXFP4 tail, as compiled in the reference build: two roundings */
+#endif
 #ifndef ORC_F32_TAIL_VW
 #define ORC_F32_TAIL_VW 4
 #endif
@@ -29,13 +32,16 @@ size_t orc_type_size(int type) {
         case ORC_Q4_1: return sizeof(orc_block_q4_1);  case ORC_Q8_1: return sizeof(orc_block_q8_1);
         case ORC_Q4_K: return sizeof(orc_block_q4_K);  case ORC_Q8_K: return sizeof(orc_block_q8_K);
         case ORC_Q5_K: return sizeof(orc_block_q5_K);  case ORC_Q6_K: return sizeof(orc_block_q6_K);
+        case ORC_Q5_0: return sizeof(orc_block_q5_0);  case ORC_Q5_1: return sizeof(orc_block_q5_1);
+        case ORC_IQ4_NL: return sizeof(orc_block_iq4_nl);  case ORC_MXFP4: return sizeof(orc_block_mxfp4);
+        case ORC_Q2_K: return sizeof(orc_block_q2_K);  case ORC_Q3_K: return sizeof(orc_block_q3_K);
     }
     return 0;
 }
 int orc_blck_size(int type) {
     switch (type) {
-        case ORC_Q4_0: case ORC_Q8_0: case ORC_Q4_1: case ORC_Q8_1: return ORC_QK;
-        case ORC_Q4_K: case ORC_Q5_K: case ORC_Q6_K: case ORC_Q8_K: return ORC_QK_K;
+        case ORC_Q4_0: case ORC_Q8_0: case ORC_Q4_1: case ORC_Q8_1: case ORC_Q5_0: case ORC_Q5_1: case ORC_IQ4_NL: case ORC_MXFP4: return ORC_QK;
+        case ORC_Q4_K: case ORC_Q5_K: case ORC_Q6_K: case ORC_Q8_K: case ORC_Q2_K: case ORC_Q3_K: return ORC_QK_K;
         case ORC_F32: case ORC_F16: case ORC_I32: case ORC_I64: return 1;
     }
     return 0;
@@ -260,6 +266,88 @@ void orc_dequantize_row_q6_K(const orc_block_q6_K * x, float * y, int64_t k) {
             }
     }
 }
+
+/* ---- the other formats stock model files carry ---- */
+static const int8_t orc_kvalues_iq4nl[16] = { -127, -104, -83, -65, -49, -35, -22, -10, 1, 13, 25, 38, 53, 69, 89, 113 };   /* ggml-common.h:1088-1090 */
+static const int8_t orc_kvalues_mxfp4[16] = { 0, 1, 2, 3, 4, 6, 8, 12, 0, -1, -2, -3, -4, -6, -8, -12 };                    /* ggml-common.h:1094-1096 */
+/* ggml_e8m0_to_fp32_half (ggml-impl.h:471-489): 2^(e - 128), the two smallest as denormal patterns */
+static inline float orc_e8m0_half(uint8_t e) { return u2f(e < 2 ? 0x00200000u << e : (uint32_t)(e - 1) << 23); }
+static inline uint32_t orc_qh32(const uint8_t * qh) { uint32_t v; memcpy(&v, qh, 4); return v; }
+/* element e (0..31) of a 5-bit block: nibble | fifth bit << 4 */
+static inline int orc_q5_elem(const uint8_t * qs, uint32_t qh, int e) {
+    const int nib = e < 16 ? (qs[e] & 0x0F) : (qs[e - 16] >> 4);
+    return nib | (int)(((qh >> e) & 1u) << 4);
+}
+static inline int orc_nib_elem(const uint8_t * qs, int e) { return e < 16 ? (qs[e] & 0x0F) : (qs[e - 16] >> 4); }
+
+void orc_dequantize_row_q5_0(const orc_block_q5_0 * x, float * y, int64_t k) {
+    const int64_t nb = k / ORC_QK;
+    for (int64_t i = 0; i < nb; i++) {
+        const float d = orc_fp16_to_fp32(x[i].d);
+        const uint32_t qh = orc_qh32(x[i].qh);
+        for (int e = 0; e < 32; e++) y[i*32 + e] = (float)(orc_q5_elem(x[i].qs, qh, e) - 16) * d;
+    }
+}
+void orc_dequantize_row_q5_1(const orc_block_q5_1 * x, float * y, int64_t k) {
+    const int64_t nb = k / ORC_QK;
+    for (int64_t i = 0; i < nb; i++) {
+        const float d = orc_fp16_to_fp32(x[i].d), m = orc_fp16_to_fp32(x[i].m);
+        const uint32_t qh = orc_qh32(x[i].qh);
+        for (int e = 0; e < 32; e++) y[i*32 + e] = (float) orc_q5_elem(x[i].qs, qh, e) * d + m;
+    }
+}
+void orc_dequantize_row_mxfp4(const orc_block_mxfp4 * x, float * y, int64_t k) {
+    const int64_t nb = k / ORC_QK;
+    for (int64_t i = 0; i < nb; i++) {
+        const float d = orc_e8m0_half(x[i].e);
+        for (int e = 0; e < 32; e++) y[i*32 + e] = (float) orc_kvalues_mxfp4[orc_nib_elem(x[i].qs, e)] * d;
+    }
+}
+void orc_dequantize_row_iq4_nl(const orc_block_iq4_nl * x, float * y, int64_t k) {
+    const int64_t nb = k / ORC_QK;
+    for (int64_t i = 0; i < nb; i++) {
+        const float d = orc_fp16_to_fp32(x[i].d);
+        for (int e = 0; e < 32; e++) y[i*32 + e] = d * (float) orc_kvalues_iq4nl[orc_nib_elem(x[i].qs, e)];
+    }
+}
+/* Q2_K / Q3_K element (n128 = which 128, j = 2-bit plane 0..3, h = which half of the 32 bytes, l = 0..15): index n128 * 128 + j * 32 + h * 16 + l */
+void orc_dequantize_row_q2_K(const orc_block_q2_K * x, float * y, int64_t k) {
+    const int64_t nb = k / ORC_QK_K;
+    for (int64_t i = 0; i < nb; i++) {
+        const float d = orc_fp16_to_fp32(x[i].d), min = orc_fp16_to_fp32(x[i].dmin);
+        for (int n = 0; n < 2; n++) for (int j = 0; j < 4; j++) for (int h = 0; h < 2; h++) {
+            const uint8_t sc = x[i].scales[8 * n + 2 * j + h];
+            const float dl = d * (float)(sc & 0xF), ml = min * (float)(sc >> 4);
+            for (int l = 0; l < 16; l++) *y++ = dl * (float)((x[i].qs[32 * n + 16 * h + l] >> (2 * j)) & 3) - ml;
+        }
+    }
+}
+/* the sixteen 6-bit scales of a Q3_K super-block, minus 32 (ggml-quants.c:1141-1150) */
+static void orc_q3k_scales(const uint8_t * sc12, int8_t * out) {
+    uint32_t aux[4]; memcpy(aux, sc12, 12);
+    const uint32_t kmask1 = 0x03030303u, kmask2 = 0x0f0f0f0fu, tmp = aux[2];
+    aux[2] = ((aux[0] >> 4) & kmask2) | (((tmp >> 4) & kmask1) << 4);
+    aux[3] = ((aux[1] >> 4) & kmask2) | (((tmp >> 6) & kmask1) << 4);
+    aux[0] = (aux[0] & kmask2) | (((tmp >> 0) & kmask1) << 4);
+    aux[1] = (aux[1] & kmask2) | (((tmp >> 2) & kmask1) << 4);
+    memcpy(out, aux, 16);
+    for (int s = 0; s < 16; s++) out[s] = (int8_t)(out[s] - 32);
+}
+void orc_dequantize_row_q3_K(const orc_block_q3_K * x, float * y, int64_t k) {
+    const int64_t nb = k / ORC_QK_K;
+    for (int64_t i = 0; i < nb; i++) {
+        const float d_all = orc_fp16_to_fp32(x[i].d);
+        int8_t sc[16]; orc_q3k_scales(x[i].scales, sc);
+        for (int n = 0; n < 2; n++) for (int j = 0; j < 4; j++) for (int h = 0; h < 2; h++) {
+            const float dl = d_all * (float) sc[8 * n + 2 * j + h];
+            for (int l = 0; l < 16; l++) {
+                const int b = 16 * h + l;
+                const int q = (int)((x[i].qs[32 * n + b] >> (2 * j)) & 3) - ((x[i].hmask[b] >> (4 * n + j)) & 1 ? 0 : 4);
+                *y++ = dl * (float) q;
+            }
+        }
+    }
+}
 void orc_dequantize_row(int type, const void * x, float * y, int64_t k) {
     switch (type) {
         case ORC_Q4_0: orc_dequantize_row_q4_0((const orc_block_q4_0 *) x, y, k); break;
@@ -268,6 +356,12 @@ void orc_dequantize_row(int type, const void * x, float * y, int64_t k) {
         case ORC_Q4_K: orc_dequantize_row_q4_K((const orc_block_q4_K *) x, y, k); break;
         case ORC_Q5_K: orc_dequantize_row_q5_K((const orc_block_q5_K *) x, y, k); break;
         case ORC_Q6_K: orc_dequantize_row_q6_K((const orc_block_q6_K *) x, y, k); break;
+        case ORC_Q5_0: orc_dequantize_row_q5_0((const orc_block_q5_0 *) x, y, k); break;
+        case ORC_Q5_1: orc_dequantize_row_q5_1((const orc_block_q5_1 *) x, y, k); break;
+        case ORC_IQ4_NL: orc_dequantize_row_iq4_nl((const orc_block_iq4_nl *) x, y, k); break;
+        case ORC_MXFP4: orc_dequantize_row_mxfp4((const orc_block_mxfp4 *) x, y, k); break;
+        case ORC_Q2_K: orc_dequantize_row_q2_K((const orc_block_q2_K *) x, y, k); break;
+        case ORC_Q3_K: orc_dequantize_row_q3_K((const orc_block_q3_K *) x, y, k); break;
         case ORC_F16:  for (int64_t i = 0; i < k; i++) y[i] = orc_fp16_to_fp32(((const uint16_t *) x)[i]); break;
         case ORC_F32:  memcpy(y, x, (size_t) k * 4); break;
     }
@@ -533,6 +627,126 @@ float orc_vec_dot_q6_K_q8_K_avx2(int64_t n, const orc_block_q6_K * x, const orc_
     return hsum8(acc);
 }
 
+
+/* arch/x86/quants.c:846-884: Q4_0's lanes and chain with 5-bit values (nib | bit << 4) - 16 */
+float orc_vec_dot_q5_0_q8_0_avx2(int64_t n, const orc_block_q5_0 * x, const orc_block_q8_0 * y) {
+    const int64_t nb = n / ORC_QK;
+    float acc[8] = {0};
+    for (int64_t ib = 0; ib < nb; ib++) {
+        const float d = orc_fp16_to_fp32(x[ib].d) * orc_fp16_to_fp32(y[ib].d);
+        const uint32_t qh = orc_qh32(x[ib].qh);
+        for (int L = 0; L < 8; L++) {
+            int s = 0;
+            for (int e = 0; e < 4; e++) s += (orc_q5_elem(x[ib].qs, qh, 4 * L + e) - 16) * y[ib].qs[4 * L + e];
+            acc[L] = fmaf(d, (float) s, acc[L]);
+        }
+    }
+    return hsum8(acc);
+}
+/* arch/x86/quants.c:926-968: Q4_1's lanes and chains (the scalar `summs += m * s` contracted by gcc, as for Q4_1) */
+float orc_vec_dot_q5_1_q8_1_avx2(int64_t n, const orc_block_q5_1 * x, const orc_block_q8_1 * y) {
+    const int64_t nb = n / ORC_QK;
+    float acc[8] = {0};
+    float summs = 0.0f;
+    for (int64_t ib = 0; ib < nb; ib++) {
+        const float dx = orc_fp16_to_fp32(x[ib].d), dy = orc_fp16_to_fp32(y[ib].d);
+        summs = ORC_Q41_SUMMS(orc_fp16_to_fp32(x[ib].m), orc_fp16_to_fp32(y[ib].s), summs);
+        const float dd = dx * dy;
+        const uint32_t qh = orc_qh32(x[ib].qh);
+        for (int L = 0; L < 8; L++) {
+            int s = 0;
+            for (int e = 0; e < 4; e++) s += orc_q5_elem(x[ib].qs, qh, 4 * L + e) * y[ib].qs[4 * L + e];
+            acc[L] = fmaf((float) s, dd, acc[L]);
+        }
+    }
+    return hsum8(acc) + summs;
+}
+/* the 16-entry codebook formats: arch/x86/quants.c:3632-3714 (IQ4_NL), 760-844 (MXFP4).  Blocks in pairs: even blocks accumulate in accum1, odd ones in
+ * accum2; hsum_float_8(accum1 + accum2); a last unpaired block in scalar code: sumf += d * (sumi1 + sumi2) (contracted by gcc).  chain = 1: the single
+ * accumulator of tinyBLAS_Q0_AVX (llamafile/sgemm.cpp:1346-1790), what mul_mat takes for IQ4_NL with >= 2 activation columns */
+static float codebook_dot(int64_t nb, const uint8_t * xb, size_t xs, const int8_t * tab, int mx, const orc_block_q8_0 * y, int chain) {
+    float acc1[8] = {0}, acc2[8] = {0};
+    int64_t ib = 0;
+    const int64_t npair = chain ? nb : (nb & ~(int64_t) 1);
+    for (; ib < npair; ib++) {
+        const uint8_t * b = xb + (size_t) ib * xs;
+        const uint8_t * qs = mx ? b + 1 : b + 2;
+        uint16_t dh; memcpy(&dh, b, 2);
+        const float d = mx ? orc_fp16_to_fp32(y[ib].d) * orc_e8m0_half(b[0]) : orc_fp16_to_fp32(y[ib].d) * orc_fp16_to_fp32(dh);
+        float * acc = (chain || !(ib & 1)) ? acc1 : acc2;
+        for (int L = 0; L < 8; L++) {
+            int s = 0;
+            for (int e = 0; e < 4; e++) s += tab[orc_nib_elem(qs, 4 * L + e)] * y[ib].qs[4 * L + e];
+            acc[L] = fmaf(d, (float) s, acc[L]);
+        }
+    }
+    float sum[8];
+    for (int L = 0; L < 8; L++) sum[L] = chain ? acc1[L] : acc1[L] + acc2[L];
+    float sumf = hsum8(sum);
+    for (; ib < nb; ib++) {
+        const uint8_t * b = xb + (size_t) ib * xs;
+        const uint8_t * qs = mx ? b + 1 : b + 2;
+        uint16_t dh; memcpy(&dh, b, 2);
+        const float d = mx ? orc_fp16_to_fp32(y[ib].d) * orc_e8m0_half(b[0]) : orc_fp16_to_fp32(y[ib].d) * orc_fp16_to_fp32(dh);
+        int s = 0;
+        for (int e = 0; e < 32; e++) s += tab[orc_nib_elem(qs, e)] * y[ib].qs[e];
+        sumf = ORC_CODEBOOK_TAIL(d, (float) s, sumf);
+    }
+    return sumf;
+}
+float orc_vec_dot_iq4_nl_q8_0_avx2(int64_t n, const orc_block_iq4_nl * x, const orc_block_q8_0 * y, int chain) {
+    return codebook_dot(n / ORC_QK, (const uint8_t *) x, sizeof(orc_block_iq4_nl), orc_kvalues_iq4nl, 0, y, chain);
+}
+float orc_vec_dot_mxfp4_q8_0_avx2(int64_t n, const orc_block_mxfp4 * x, const orc_block_q8_0 * y) {
+    return codebook_dot(n / ORC_QK, (const uint8_t *) x, sizeof(orc_block_mxfp4), orc_kvalues_mxfp4, 1, y, 0);
+}
+/* arch/x86/quants.c:1278-1354.  Per 128 weights one 32-byte vector of 2-bit fields; plane j (bits 2j) times the activations 32 j .. 32 j + 31 of the 128; lane A
+ * = bytes 4A..4A+3 of the vector, its scale the one of the 16-weight sub-block it lies in: scales[8 n + 2 j + (A >> 2)] */
+float orc_vec_dot_q2_K_q8_K_avx2(int64_t n, const orc_block_q2_K * x, const orc_block_q8_K * y) {
+    const int64_t nb = n / ORC_QK_K;
+    float acc[8] = {0};
+    for (int64_t i = 0; i < nb; i++) {
+        const float d = y[i].d * orc_fp16_to_fp32(x[i].d);
+        const float dmin = -y[i].d * orc_fp16_to_fp32(x[i].dmin);
+        for (int L = 0; L < 8; L++) {
+            const int prod = (x[i].scales[2*L] >> 4) * y[i].bsums[2*L] + (x[i].scales[2*L + 1] >> 4) * y[i].bsums[2*L + 1];
+            acc[L] = fmaf(dmin, (float) prod, acc[L]);
+        }
+        int32_t sumi[8] = {0};
+        for (int nn = 0; nn < 2; nn++) for (int j = 0; j < 4; j++) for (int L = 0; L < 8; L++) {
+            int p = 0;
+            for (int e = 0; e < 4; e++) {
+                const int b = 4*L + e;
+                p += (int)((x[i].qs[32 * nn + b] >> (2 * j)) & 3) * y[i].qs[128 * nn + 32 * j + b];
+            }
+            sumi[L] += (x[i].scales[8 * nn + 2 * j + (L >> 2)] & 0xF) * p;
+        }
+        for (int L = 0; L < 8; L++) acc[L] = fmaf(d, (float) sumi[L], acc[L]);
+    }
+    return hsum8(acc);
+}
+/* arch/x86/quants.c:1470-1580: the same lanes; value = 2-bit field - (hmask bit clear ? 4 : 0), scale = 6-bit - 32 */
+float orc_vec_dot_q3_K_q8_K_avx2(int64_t n, const orc_block_q3_K * x, const orc_block_q8_K * y) {
+    const int64_t nb = n / ORC_QK_K;
+    float acc[8] = {0};
+    for (int64_t i = 0; i < nb; i++) {
+        const float d = y[i].d * orc_fp16_to_fp32(x[i].d);
+        int8_t sc[16]; orc_q3k_scales(x[i].scales, sc);
+        int32_t sumi[8] = {0};
+        for (int nn = 0; nn < 2; nn++) for (int j = 0; j < 4; j++) for (int L = 0; L < 8; L++) {
+            int p = 0;
+            for (int e = 0; e < 4; e++) {
+                const int b = 4*L + e;
+                const int q = (int)((x[i].qs[32 * nn + b] >> (2 * j)) & 3) - ((x[i].hmask[b] >> (4 * nn + j)) & 1 ? 0 : 4);
+                p += q * y[i].qs[128 * nn + 32 * j + b];
+            }
+            sumi[L] += sc[8 * nn + 2 * j + (L >> 2)] * p;
+        }
+        for (int L = 0; L < 8; L++) acc[L] = fmaf(d, (float) sumi[L], acc[L]);
+    }
+    return hsum8(acc);
+}
+
 /* ggml_vec_dot_f16, AVX2 + F16C (ggml-cpu/vec.cpp:264-, simd-mappings.h:528-620): four 8-lane accumulators over steps of 32,
  * GGML_F32x8_REDUCE, leftovers in double */
 float orc_vec_dot_f16_avx2(int64_t n, const uint16_t * x, const uint16_t * y) {
@@ -602,9 +816,9 @@ static int is_contiguous(const orc_tensor * t) {
 /* ------------------------------------------------------------------------------------------ */
 static int vec_dot_type_of(int wtype) {
     switch (wtype) {             /* type_traits_cpu[], ggml-cpu/ggml-cpu.c:207-390 */
-        case ORC_Q4_0: case ORC_Q8_0: return ORC_Q8_0;
-        case ORC_Q4_1: return ORC_Q8_1;
-        case ORC_Q4_K: case ORC_Q5_K: case ORC_Q6_K: return ORC_Q8_K;
+        case ORC_Q4_0: case ORC_Q8_0: case ORC_Q5_0: case ORC_IQ4_NL: case ORC_MXFP4: return ORC_Q8_0;
+        case ORC_Q4_1: case ORC_Q5_1: return ORC_Q8_1;
+        case ORC_Q4_K: case ORC_Q5_K: case ORC_Q6_K: case ORC_Q2_K: case ORC_Q3_K: return ORC_Q8_K;
         case ORC_F16:  return ORC_F16;
         case ORC_F32:  return ORC_F32;
     }
@@ -633,6 +847,12 @@ static float vec_dot(int wtype, int64_t n, const void * w, const void * a) {
                                                         : orc_vec_dot_q4_K_q8_K(n, (const orc_block_q4_K *) w, (const orc_block_q8_K *) a, NULL);
         case ORC_Q5_K: return orc_vec_dot_q5_K_q8_K_avx2(n, (const orc_block_q5_K *) w, (const orc_block_q8_K *) a);
         case ORC_Q6_K: return orc_vec_dot_q6_K_q8_K_avx2(n, (const orc_block_q6_K *) w, (const orc_block_q8_K *) a);
+        case ORC_Q5_0: return orc_vec_dot_q5_0_q8_0_avx2(n, (const orc_block_q5_0 *) w, (const orc_block_q8_0 *) a);
+        case ORC_Q5_1: return orc_vec_dot_q5_1_q8_1_avx2(n, (const orc_block_q5_1 *) w, (const orc_block_q8_1 *) a);
+        case ORC_IQ4_NL: return orc_vec_dot_iq4_nl_q8_0_avx2(n, (const orc_block_iq4_nl *) w, (const orc_block_q8_0 *) a, 0);
+        case ORC_MXFP4: return orc_vec_dot_mxfp4_q8_0_avx2(n, (const orc_block_mxfp4 *) w, (const orc_block_q8_0 *) a);
+        case ORC_Q2_K: return orc_vec_dot_q2_K_q8_K_avx2(n, (const orc_block_q2_K *) w, (const orc_block_q8_K *) a);
+        case ORC_Q3_K: return orc_vec_dot_q3_K_q8_K_avx2(n, (const orc_block_q3_K *) w, (const orc_block_q8_K *) a);
         case ORC_F16: {
             if (g_order == ORC_ORDER_AVX2) return orc_vec_dot_f16_avx2(n, (const uint16_t *) w, (const uint16_t *) a);          /* scalar branch of ggml_vec_dot_f16 (vec.cpp:264-): double accumulation */
             const uint16_t * x = (const uint16_t *) w, * y = (const uint16_t *) a;
@@ -673,6 +893,7 @@ int orc_mul_mat(const orc_tensor * src0, const orc_tensor * src1, orc_tensor * d
             const void * w = tptr(src0, 0, i01, i12 / r2, i13 / r3);
             float v;
             if (tiny) v = src0->type == ORC_F16 ? tiny8_f16(K, (const uint16_t *) w, (const uint16_t *) arow) : tiny8_f32(K, (const float *) w, (const float *) arow);
+            else if (src0->type == ORC_IQ4_NL && src1->ne[1] >= 2) v = orc_vec_dot_iq4_nl_q8_0_avx2(K, (const orc_block_iq4_nl *) w, (const orc_block_q8_0 *) arow, 1);   /* tinyBLAS_Q0_AVX (sgemm.cpp:3691, 4000-4013) */
             else v = vec_dot(src0->type, K, w, arow);
             *(float *) tptr(dst, i01, i11, i12, i13) = v;
         }

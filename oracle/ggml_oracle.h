@@ -25,7 +25,7 @@ extern "C" {
 
 /* numeric values equal the reference's enum ggml_type (ggml/include/ggml.h:386-428) */
 enum orc_type {
-    ORC_F32 = 0, ORC_F16 = 1, ORC_Q4_0 = 2, ORC_Q4_1 = 3, ORC_Q8_0 = 8, ORC_Q8_1 = 9, ORC_Q4_K = 12, ORC_Q5_K = 13, ORC_Q6_K = 14, ORC_Q8_K = 15, ORC_I32 = 26, ORC_I64 = 27,
+    ORC_F32 = 0, ORC_F16 = 1, ORC_Q4_0 = 2, ORC_Q4_1 = 3, ORC_Q5_0 = 6, ORC_Q5_1 = 7, ORC_Q8_0 = 8, ORC_Q8_1 = 9, ORC_Q2_K = 10, ORC_Q3_K = 11, ORC_Q4_K = 12, ORC_Q5_K = 13, ORC_Q6_K = 14, ORC_Q8_K = 15, ORC_IQ4_NL = 20, ORC_I32 = 26, ORC_I64 = 27, ORC_MXFP4 = 39,
 };
 
 /* a strided 4-D tensor view: same meaning as ggml_tensor {type, ne, nb, data} (ggml.h:656-688) */
@@ -48,6 +48,13 @@ typedef struct { uint16_t d; uint16_t dmin; uint8_t scales[12]; uint8_t qs[128];
 typedef struct { uint16_t d; uint16_t dmin; uint8_t scales[12]; uint8_t qh[32]; uint8_t qs[128]; } orc_block_q5_K; /* 176 B: Q4_K + a fifth bit (ggml-common.h:308-321) */
 typedef struct { uint8_t ql[128]; uint8_t qh[64]; int8_t scales[16]; uint16_t d; }                  orc_block_q6_K; /* 210 B: 6-bit quants - 32, int8 scale per 16 (ggml-common.h:323-336) */
 typedef struct { float d; int8_t qs[256]; int16_t bsums[16]; }         orc_block_q8_K;   /* 292 B */
+/* the other 32-weight and k-quant formats stock model files carry (ggml-common.h:190-216, 262-288, 415-419) */
+typedef struct { uint16_t d; uint8_t qh[4]; uint8_t qs[16]; }              orc_block_q5_0;   /* 22 B: w = ((nib | bit << 4) - 16) * d */
+typedef struct { uint16_t d; uint16_t m; uint8_t qh[4]; uint8_t qs[16]; }  orc_block_q5_1;   /* 24 B: w = (nib | bit << 4) * d + m */
+typedef struct { uint16_t d; uint8_t qs[16]; }                             orc_block_iq4_nl; /* 18 B: w = kvalues_iq4nl[nib] * d */
+typedef struct { uint8_t e; uint8_t qs[16]; }                              orc_block_mxfp4;  /* 17 B: w = kvalues_mxfp4[nib] * 2^(e - 128) */
+typedef struct { uint8_t scales[16]; uint8_t qs[64]; uint16_t d; uint16_t dmin; }             orc_block_q2_K;   /* 84 B  */
+typedef struct { uint8_t hmask[32]; uint8_t qs[64]; uint8_t scales[12]; uint16_t d; }         orc_block_q3_K;   /* 110 B */
 #pragma pack(pop)
 
 size_t orc_type_size(int type);   /* bytes per block */
@@ -76,6 +83,12 @@ void orc_dequantize_row_q4_1(const orc_block_q4_1 * x, float * y, int64_t k);   
 void orc_dequantize_row_q4_K(const orc_block_q4_K * x, float * y, int64_t k);
 void orc_dequantize_row_q5_K(const orc_block_q5_K * x, float * y, int64_t k);      /* ggml-quants.c:1554-1579 */
 void orc_dequantize_row_q6_K(const orc_block_q6_K * x, float * y, int64_t k);      /* ggml-quants.c:1762-1791 */
+void orc_dequantize_row_q5_0(const orc_block_q5_0 * x, float * y, int64_t k);      /* ggml-quants.c:348-372 */
+void orc_dequantize_row_q5_1(const orc_block_q5_1 * x, float * y, int64_t k);      /* ggml-quants.c:374-399 */
+void orc_dequantize_row_mxfp4(const orc_block_mxfp4 * x, float * y, int64_t k);    /* ggml-quants.c:417-436 */
+void orc_dequantize_row_q2_K(const orc_block_q2_K * x, float * y, int64_t k);      /* ggml-quants.c:784-815 */
+void orc_dequantize_row_q3_K(const orc_block_q3_K * x, float * y, int64_t k);      /* ggml-quants.c:1128-1176 */
+void orc_dequantize_row_iq4_nl(const orc_block_iq4_nl * x, float * y, int64_t k);  /* ggml-quants.c:2512-2528 */
 void orc_dequantize_row(int type, const void * x, float * y, int64_t k);
 
 /* ---- block dot products (ggml-cpu/quants.c:115-150, 305-333, 550-623) ----
@@ -101,6 +114,16 @@ float orc_vec_dot_q4_K_q8_K_avx2(int64_t n, const orc_block_q4_K * x, const orc_
  * Q5_K's mins go through one scalar chain `summs` */
 float orc_vec_dot_q5_K_q8_K_avx2(int64_t n, const orc_block_q5_K * x, const orc_block_q8_K * y);
 float orc_vec_dot_q6_K_q8_K_avx2(int64_t n, const orc_block_q6_K * x, const orc_block_q8_K * y);
+/* Q5_0 / Q5_1 (arch/x86/quants.c:846-924, 926-1010): Q4_0 / Q4_1 with a fifth bit from qh.  IQ4_NL / MXFP4 (:3632-3714, 760-844): 16-entry int8 codebooks, TWO
+ * 8-lane accumulators (even / odd blocks) added before the horizontal sum, a last odd block in scalar code; with >= 2 activation columns Q5_0 and IQ4_NL go through
+ * tinyBLAS_Q0_AVX (llamafile/sgemm.cpp:1346-1790, dispatch :3984-4013): ONE accumulator per output, blocks in order (`chain` = 1 selects it).
+ * Q2_K / Q3_K (:1278-1354, 1470-1580): per super-block acc[A] = fma(d, sumi[A], acc[A]); Q2_K first folds the mins: acc[A] = fma(dmin, m[2A] S[2A] + m[2A+1] S[2A+1], acc[A]) */
+float orc_vec_dot_q5_0_q8_0_avx2(int64_t n, const orc_block_q5_0 * x, const orc_block_q8_0 * y);
+float orc_vec_dot_q5_1_q8_1_avx2(int64_t n, const orc_block_q5_1 * x, const orc_block_q8_1 * y);
+float orc_vec_dot_iq4_nl_q8_0_avx2(int64_t n, const orc_block_iq4_nl * x, const orc_block_q8_0 * y, int chain);
+float orc_vec_dot_mxfp4_q8_0_avx2(int64_t n, const orc_block_mxfp4 * x, const orc_block_q8_0 * y);
+float orc_vec_dot_q2_K_q8_K_avx2(int64_t n, const orc_block_q2_K * x, const orc_block_q8_K * y);
+float orc_vec_dot_q3_K_q8_K_avx2(int64_t n, const orc_block_q3_K * x, const orc_block_q8_K * y);
 float orc_vec_dot_f16_avx2(int64_t n, const uint16_t * x, const uint16_t * y);
 float orc_vec_dot_f32_avx2(int64_t n, const float * x, const float * y);
 

@@ -2,8 +2,8 @@
 scale bytes so that every bit pattern of the 6-bit scale packing is exercised)"""
 import numpy as np
 
-TYPE_SIZE = {2: 18, 3: 20, 8: 34, 12: 144, 13: 176, 14: 210}
-BLCK = {2: 32, 3: 32, 8: 32, 12: 256, 13: 256, 14: 256}
+TYPE_SIZE = {2: 18, 3: 20, 8: 34, 12: 144, 13: 176, 14: 210, 6: 22, 7: 24, 10: 84, 11: 110, 20: 18, 39: 17}
+BLCK = {2: 32, 3: 32, 8: 32, 12: 256, 13: 256, 14: 256, 6: 32, 7: 32, 10: 256, 11: 256, 20: 32, 39: 32}
 
 
 def rand_blocks(t, rows, K, rng, d_scale=0.01):
@@ -13,7 +13,22 @@ def rand_blocks(t, rows, K, rng, d_scale=0.01):
     if t == 14:         # Q6_K: the fp16 scale closes the block (ql[128] qh[64] scales[16] d); keep the int8 sub-scales moderate
         out[:, :, 208:210] = d.view(np.uint8).reshape(rows, nb, 2)
         return np.ascontiguousarray(out.reshape(rows, nb * TYPE_SIZE[t]))
+    if t == 39:         # MXFP4: one E8M0 exponent byte (2^(e - 128)), then the 16 code bytes: exponents around the other types' scales, and the two denormal patterns
+        out[:, :, 0] = rng.integers(114, 124, (rows, nb), dtype=np.uint8)
+        out[0, : min(nb, 2), 0] = np.arange(min(nb, 2), dtype=np.uint8)
+        return np.ascontiguousarray(out.reshape(rows, nb * TYPE_SIZE[t]))
+    if t == 10:         # Q2_K: scales[16] qs[64] d dmin
+        dm = (rng.uniform(0.25, 1.0, (rows, nb)) * d_scale).astype(np.float16)
+        out[:, :, 80:82] = d.view(np.uint8).reshape(rows, nb, 2)
+        out[:, :, 82:84] = dm.view(np.uint8).reshape(rows, nb, 2)
+        return np.ascontiguousarray(out.reshape(rows, nb * TYPE_SIZE[t]))
+    if t == 11:         # Q3_K: hmask[32] qs[64] scales[12] d
+        out[:, :, 108:110] = d.view(np.uint8).reshape(rows, nb, 2)
+        return np.ascontiguousarray(out.reshape(rows, nb * TYPE_SIZE[t]))
     out[:, :, 0:2] = d.view(np.uint8).reshape(rows, nb, 2)
+    if t == 7:          # Q5_1: fp16 minimum after the scale
+        m = (rng.uniform(-16.0, 4.0, (rows, nb)) * d_scale).astype(np.float16)
+        out[:, :, 2:4] = m.view(np.uint8).reshape(rows, nb, 2)
     if t == 3:          # Q4_1: fp16 minimum after the scale (w = nib * d + m), both signs
         m = (rng.uniform(-8.0, 2.0, (rows, nb)) * d_scale).astype(np.float16)
         out[:, :, 2:4] = m.view(np.uint8).reshape(rows, nb, 2)

@@ -109,11 +109,61 @@ def _mm_case(gpu, t, K, N, M, ne02=1, ne12=1):
 
 
 @pytest.mark.parametrize("t", [O.Q4_K, O.Q4_0, O.Q8_0, O.Q4_1])
-@pytest.mark.parametrize("K,N,M", [(256, 1, 1), (512, 7, 1), (4096, 130, 1), (2048, 64, 2), (1024, 33, 3), (768, 40, 4), (512, 20, 5), (1280, 24, 8)])
+@pytest.mark.parametrize("K,N,M", [(256, 1, 1), (512, 7, 1), (4096, 130, 1), (2048, 64, 2), (1024, 33, 3), (768, 40, 4), (512, 20, 5), (1280, 24, 8),
+                                   # one column, even row counts: the 32-block types take the rows-side-by-side kernel (gemv_rows32.hip): whole and ragged steps, many units per wave
+                                   (4096, 128, 1), (512, 64, 1), (1024, 8, 1), (2112, 24, 1), (4096, 8192, 1), (11008, 256, 1)])
 def test_mul_mat_quant_gemv(gpu, t, K, N, M):
     """1..8 columns: the mat-vec kernels accumulate in the reference's AVX2 order (q4k.h / q32.h) -- bit-identical to the oracle == libggml-cpu.so"""
+    if K % O.BLCK[t]:
+        pytest.skip("K is not a multiple of the type's block")
     got, want = _mm_case(gpu, t, K, N, M)
     assert np.array_equal(got.view(np.uint32).ravel(), want.view(np.uint32).ravel()), rel_err(got, want)
+
+
+@pytest.fixture()
+def rows32_mode(gpu):
+    """gemv_rows32.hip's form: 0 = k_gemv_dec takes the launch, 2 / 4 / 8 = that many rows per wave (8: prologue-1 launches only), 1 = the launcher's pick"""
+    L = gpu.lib.get()
+
+    def set_mode(m):
+        L.cllm_debug_set_gemv_rows32(int(m))
+    yield set_mode
+    L.cllm_debug_set_gemv_rows32(1)
+
+
+@pytest.mark.parametrize("t", [O.Q4_0, O.Q8_0, O.Q4_1])
+@pytest.mark.parametrize("mode", [0, 2, 4])
+@pytest.mark.parametrize("K,N", [(64, 4), (512, 64), (2112, 24), (4096, 1028), (14336, 96), (29568, 40), (1024, 20000)])
+def test_mul_mat_quant_gemv_every_rows32_form(gpu, rows32_mode, t, mode, K, N):
+    """the one-column mat-vec of the 32-block types through each form of the decode kernel (one row per wave; 2 / 4 rows side by side): every output word is the oracle's"""
+    rows32_mode(mode)
+    got, want = _mm_case(gpu, t, K, N, 1)
+    assert np.array_equal(got.view(np.uint32).ravel(), want.view(np.uint32).ravel()), rel_err(got, want)
+
+
+@pytest.mark.parametrize("t", [O.Q4_0, O.Q8_0, O.Q4_1])
+@pytest.mark.parametrize("mode", [2, 4, 8])
+@pytest.mark.parametrize("K,N,epi", [(4096, 384, 0), (4096, 4112, 1), (14336, 64, 0), (512, 18000, 1), (1056, 200, 0)])
+def test_gemv_rows32_prologue_1_forms_equal_the_node_sequence(gpu, rows32_mode, t, mode, K, N, epi):
+    """RMS_NORM * weight -> quantize -> mat-vec (+ bias + residual | SiLU(gate) * up) in one launch, 2 / 4 / 8 rows per wave == the node sequence through k_gemv_dec"""
+    ops, T, L = gpu.ops, gpu.Tensor, gpu.lib.get()
+    w = T.from_numpy(rand_blocks(t, N, K, rng), t, [K, N])
+    x = T.from_numpy(rng.standard_normal((1, K)).astype(np.float32))
+    g = T.from_numpy((1 + 0.1 * rng.standard_normal(K)).astype(np.float32))
+    r = T.from_numpy(rng.standard_normal((1, N)).astype(np.float32))
+    rows32_mode(0)
+    y = ops.mul_mat(w, ops.rms_norm_mul(x, g, 1e-5))
+    if epi:
+        yn = y.numpy().reshape(N // 2, 2)
+        gate, up = T.from_numpy(np.ascontiguousarray(yn[:, 0])), T.from_numpy(np.ascontiguousarray(yn[:, 1]))
+        want = ops.mul(ops.silu(gate), up).numpy().reshape(-1)
+    else:
+        want = ops.add(y, r).numpy().reshape(-1)
+    rows32_mode(mode)
+    out = T(gpu.F32, [N // 2 if epi else N, 1])
+    cw = w.c()
+    gpu.lib.check(L.cllm_op_mul_mat_vec_fused(None, C.byref(cw), 1, x.data_ptr(), g.data_ptr(), 1e-5, epi, None if epi else r.data_ptr(), out.data_ptr()), "fused")
+    assert np.array_equal(out.numpy().reshape(-1).view(np.uint32), want.view(np.uint32))
 
 
 @pytest.mark.parametrize("t", [O.Q5_K, O.Q6_K])
@@ -121,6 +171,18 @@ def test_mul_mat_quant_gemv(gpu, t, K, N, M):
                                              (512, 19, 40, 1, 1), (256, 12, 3, 2, 4), (14336, 48, 1, 1, 1)])
 def test_mul_mat_k_quants_any_columns_bit_exact(gpu, t, K, N, M, ne02, ne12):
     """Q5_K / Q6_K (gemv_kq.hip): 8 lanes per row, lane = AVX lane, serial fma chain in a register -- bit-identical to libggml-cpu.so for every column count"""
+    got, want = _mm_case(gpu, t, K, N, M, ne02, ne12)
+    assert np.array_equal(got.view(np.uint32).ravel(), want.view(np.uint32).ravel()), rel_err(got, want)
+
+
+@pytest.mark.parametrize("t", [O.Q5_0, O.Q5_1, O.IQ4_NL, O.MXFP4, O.Q2_K, O.Q3_K])
+@pytest.mark.parametrize("K,N,M,ne02,ne12", [(256, 1, 1, 1, 1), (512, 7, 1, 1, 1), (4096, 130, 1, 1, 1), (2048, 64, 2, 1, 1), (1024, 33, 5, 1, 1), (1280, 24, 8, 1, 1), (768, 40, 9, 1, 1),
+                                             (512, 19, 40, 1, 1), (256, 12, 3, 2, 4), (14336, 48, 1, 1, 1), (96, 10, 1, 1, 1), (96, 10, 3, 1, 1), (2080, 9, 1, 1, 1)])
+def test_mul_mat_other_formats_any_columns_bit_exact(gpu, t, K, N, M, ne02, ne12):
+    """Q5_0 / Q5_1 / IQ4_NL / MXFP4 / Q2_K / Q3_K (gemv_kq.hip): the formats other stock model files carry, every column count, bit-identical to libggml-cpu.so
+    -- including the codebook formats' paired accumulators with an unpaired last block (K = 96, 2080) and IQ4_NL's other order for >= 2 columns (tinyBLAS)"""
+    if K % O.BLCK[t]:
+        pytest.skip("K is not a multiple of the type's block")
     got, want = _mm_case(gpu, t, K, N, M, ne02, ne12)
     assert np.array_equal(got.view(np.uint32).ravel(), want.view(np.uint32).ravel()), rel_err(got, want)
 
@@ -386,7 +448,7 @@ def test_cpy_v_cache_transposed_and_cont(gpu):
     assert np.array_equal(got, np.ascontiguousarray(c.transpose(1, 0, 2)))
 
 
-@pytest.mark.parametrize("t", [O.Q4_0, O.Q4_1, O.Q8_0, O.Q4_K, O.Q5_K, O.Q6_K, O.F16, O.F32])
+@pytest.mark.parametrize("t", [O.Q4_0, O.Q4_1, O.Q8_0, O.Q4_K, O.Q5_K, O.Q6_K, O.F16, O.F32, O.Q5_0, O.Q5_1, O.IQ4_NL, O.MXFP4, O.Q2_K, O.Q3_K])
 def test_get_rows_bit_exact(gpu, t):
     n0, rows, n = 512, 30, 7
     table = rng.standard_normal((rows, n0)).astype(O.NP_OF[t]) if t in (O.F16, O.F32) else rand_blocks(t, rows, n0, rng)
@@ -578,6 +640,10 @@ def test_attention_composite(gpu, qlen, n_past):
     (128, 8, 8, 2048, 700, 0, True), (128, 8, 8, 2048, 1023, 0, True),       # n_kv 1024: the last context the one-launch kernel takes; R2 = 1
     (128, 8, 8, 2048, 1500, 0, True),       # above the long-context threshold: three launches, R2 = 1
     (128, 32, 8, 4096, 3000, 2, True),      # long, GQA 4
+    (128, 32, 8, 8192, 8190, 0, True),      # 255 whole chunks + 31 leftovers, the last slice of positions ragged
+    (128, 16, 2, 2048, 1055, 2, True),      # GQA 8
+    (64, 8, 4, 4096, 2049, 0, True),        # head size 64, two leftovers
+    (128, 32, 8, 16384, 12345, 0, True),
     (64, 4, 2, 64, 11, 0, True), (64, 4, 2, 64, 63, 2, True),
     (128, 32, 8, 1024, 100, 0, False),      # no table: the general kernel computes cos/sin itself
     (96, 6, 2, 256, 40, 2, True)])          # head size the compact kernels do not take -> general kernel
@@ -614,10 +680,8 @@ def test_rope_kv_attn_decode_equals_the_node_sequence(gpu, hd, nh, nkv, ML, n_pa
     got = ops.rope_kv_attn_decode(T.from_numpy(qkv), pos, n_kv, nh, nkv, hd, mode, fb, fk, fv, ML, table=table).numpy().reshape(QD)
     assert np.array_equal(fk.numpy().view(np.uint16), want_k)
     assert np.array_equal(fv.numpy().view(np.uint16), want_v)
-    if n_kv <= 1024:
-        assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
-    else:       # the split long-context kernels keep their own fp32 summation order (the reference's serial chains over n_kv do not spread over the chip)
-        assert rel_err(got, want) < 6e-4                 # (P is rounded to fp16 before the P.V product: 2^-11 relative per probability)
+    # every context length: the one-launch kernel up to 1024 cached positions, the three split launches of attn_long.hip beyond -- both in ggml_vec_dot_f16's order
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
 
 
 def test_rope_kv_attn_decode_rejects_what_it_cannot_do(gpu):
@@ -625,7 +689,7 @@ def test_rope_kv_attn_decode_rejects_what_it_cannot_do(gpu):
     assert L.cllm_attn_decode_supported(32, 8, 128, 1024) == 1
     assert L.cllm_attn_decode_supported(32, 8, 128, 1 << 17) == 0          # scores of one head no longer fit the LDS
     assert L.cllm_attn_decode_supported(32, 5, 128, 1024) == 0
-    assert L.cllm_attn_decode_wsize(100, 32, 2048) == 0 and L.cllm_attn_decode_wsize(1024, 32, 2048) == 0 and L.cllm_attn_decode_wsize(1100, 32, 2048) == 32 * 2048 * 6
+    assert L.cllm_attn_decode_wsize(100, 32, 2048) == 0 and L.cllm_attn_decode_wsize(512, 32, 2048) == 0 and L.cllm_attn_decode_wsize(513, 32, 2048) == 32 * 2048 * 6   # (CLLM_ATTN_LONG, default 512)
     x = T.from_numpy(np.zeros(4096, np.float32)); pos = T.from_numpy(np.zeros(1, np.int32)); kc = T.from_numpy(np.zeros((64, 256), np.float16))
     rc = L.cllm_op_rope_kv_attn_decode(None, x.data_ptr(), pos.data_ptr(), None, 1e4, 1, 4, 2, 128, 1, kc.data_ptr(), kc.data_ptr(), 64, x.data_ptr(), None, 0)
     assert rc != 0 and b"rope mode" in L.cllm_last_error()

@@ -24,7 +24,11 @@ FUSED = [("qkv", 4096, 6144, 1, False), ("o", 4096, 4096, 2, True), ("gate_up", 
          ("lm_head", 4096, 128256, 1, False)]
 
 
-def run_fused(types, iters, hot=False, force_pro=0, only=""):
+FUSED_Q72 = [("qkv", 8192, 10240, 1, False), ("o", 8192, 8192, 2, True), ("gate_up_silu", 8192, 59136, 1, False), ("down", 29568, 8192, 4, True),
+             ("lm_head", 8192, 152064, 1, False)]       # Qwen2-72B (BASELINE cfg4): the one-GPU launches
+
+
+def run_fused(types, iters, hot=False, force_pro=0, only="", shapes=None):
     """the decode launches: activation prologue (1 RMS_NORM+quantize, 2 quantize, 3 SiLU*up+quantize) inside the mat-vec"""
     pkg = ge.load_package()
     L = pkg.lib.get()
@@ -32,7 +36,7 @@ def run_fused(types, iters, hot=False, force_pro=0, only=""):
     rng = np.random.default_rng(0)
     for tn in types:
         t = T[tn]
-        for name, K, N, pro, resid in FUSED:
+        for name, K, N, pro, resid in (shapes or FUSED):
             if only and name not in only.split(","):
                 continue
             if force_pro and pro == 1:
@@ -94,10 +98,11 @@ if __name__ == "__main__":
     ap.add_argument("--hot", action="store_true")
     ap.add_argument("--fused", action="store_true")
     ap.add_argument("--pro", type=int, default=0)
+    ap.add_argument("--model", default="llama3-8b", choices=["llama3-8b", "qwen2-72b"], help="--fused: whose decode launches")
     a = ap.parse_args()
     shapes = [s for s in SHAPES if not a.shapes or s[0] in a.shapes.split(",")]
     if a.fused:
-        run_fused(a.types.split(","), a.iters, a.hot, a.pro, a.shapes)
+        run_fused(a.types.split(","), a.iters, a.hot, a.pro, a.shapes, FUSED_Q72 if a.model == "qwen2-72b" else None)
     elif a.sweep:
         for wg in (128, 256, 512):
             for occ in (4, 8, 16):
