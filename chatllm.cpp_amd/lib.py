@@ -114,6 +114,7 @@ SIGNATURES = {
     "cllm_op_set_rows": (C.c_int, [_P, _T, _T, _T]),
     "cllm_op_cpy": (C.c_int, [_P, _T, _T]),
     "cllm_op_get_rows": (C.c_int, [_P, _T, _T, _T]),
+    "cllm_op_quantize_rows": (C.c_int, [_P, C.c_int, _P, _P, C.c_int64, C.c_int64]),
     "cllm_dequantize_row": (C.c_int, [_P, C.c_int, _P, _P, C.c_int64]),
     "cllm_llama_create": (C.c_int, [C.POINTER(LlamaConfig), _P, C.POINTER(C.c_void_p)]),
     "cllm_llama_destroy": (None, [_P]),

@@ -296,6 +296,10 @@ CLLM_API int cllm_op_set_rows(void * stream, const cllm_tensor * src, const cllm
 CLLM_API int cllm_op_cpy(void * stream, const cllm_tensor * src, cllm_tensor * dst);
 /* GGML_OP_GET_ROWS      ggml_compute_forward_get_rows (ops.cpp:4653-4700,4820): embedding gather with dequantization */
 CLLM_API int cllm_op_get_rows(void * stream, const cllm_tensor * src, const cllm_tensor * idx, cllm_tensor * dst);
+/* WEIGHT quantizers on the device: quantize_row_{q8_0,q4_0,q4_1,q5_0,q5_1,q4_K}_ref and the F16 conversion (ggml/src/ggml-quants.c:36-222, 622-702, 1280-1350),
+ * byte-identical to the reference's from_float_ref.  Replaces the host-side loop of ggml::from_float (src/layers.cpp:358-373) that chatllm.cpp's loader runs when a
+ * tensor is re-quantized on load (src/chat.cpp:1246-1279): nrows rows of k fp32 values at x (device, contiguous, 16-byte aligned) -> rows of `type` blocks at y. */
+CLLM_API int cllm_op_quantize_rows(void * stream, int type, const float * x, void * y, int64_t k, int64_t nrows);
 /* dequantize_row_q4_0 / q8_0 / q4_K (ggml/src/ggml-quants.c:307-325, 401-414, 1352-1373) */
 CLLM_API int cllm_dequantize_row(void * stream, int type, const void * blocks, float * y, int64_t k);
 

@@ -811,6 +811,173 @@ static int is_contiguous(const orc_tensor * t) {
     return 1;
 }
 
+
+/* ------------------------------------------------------------------------------------------ */
+/* weight quantizers: the reference's from_float_ref (ggml-quants.c:36-197, 622-702, 1280-1350), what chatllm.cpp's loader calls when a    */
+/* tensor is re-quantized on load (src/chat.cpp:1246-1279 -> ggml::from_float, src/layers.cpp:358-373).  Plain C in the reference too       */
+/* (ISO C mode: no contraction), so every operation below is one rounding in the written order.                                             */
+/* ------------------------------------------------------------------------------------------ */
+/* the element of largest magnitude (the FIRST one on ties) decides sign and scale: d = max / -(2^(bits-1)) */
+static float signed_absmax(const float * x, int n) {
+    float amax = 0.0f, max = 0.0f;
+    for (int j = 0; j < n; j++) { const float v = x[j]; if (amax < fabsf(v)) { amax = fabsf(v); max = v; } }
+    return max;
+}
+static void minmax(const float * x, int n, float * mn, float * mx) {
+    float a = 3.402823466e+38f, b = -3.402823466e+38f;
+    for (int j = 0; j < n; j++) { const float v = x[j]; if (v < a) a = v; if (v > b) b = v; }
+    *mn = a; *mx = b;
+}
+void orc_quantize_row_q4_0_ref(const float * x, orc_block_q4_0 * y, int64_t k) {      /* ggml-quants.c:36-71 */
+    for (int64_t i = 0; i < k / ORC_QK; i++, x += ORC_QK) {
+        const float d = signed_absmax(x, ORC_QK) / -8, id = d ? 1.0f / d : 0.0f;
+        y[i].d = orc_fp32_to_fp16(d);
+        for (int j = 0; j < 16; j++) {
+            const float x0 = x[j] * id, x1 = x[j + 16] * id;
+            const uint8_t q0 = (uint8_t) ORC_MIN(15, (int8_t)(x0 + 8.5f)), q1 = (uint8_t) ORC_MIN(15, (int8_t)(x1 + 8.5f));
+            y[i].qs[j] = (uint8_t)(q0 | (q1 << 4));
+        }
+    }
+}
+void orc_quantize_row_q4_1_ref(const float * x, orc_block_q4_1 * y, int64_t k) {      /* ggml-quants.c:73-108 */
+    for (int64_t i = 0; i < k / ORC_QK; i++, x += ORC_QK) {
+        float mn, mx; minmax(x, ORC_QK, &mn, &mx);
+        const float d = (mx - mn) / 15, id = d ? 1.0f / d : 0.0f;
+        y[i].d = orc_fp32_to_fp16(d); y[i].m = orc_fp32_to_fp16(mn);
+        for (int j = 0; j < 16; j++) {
+            const float x0 = (x[j] - mn) * id, x1 = (x[j + 16] - mn) * id;
+            const uint8_t q0 = (uint8_t) ORC_MIN(15, (int8_t)(x0 + 0.5f)), q1 = (uint8_t) ORC_MIN(15, (int8_t)(x1 + 0.5f));
+            y[i].qs[j] = (uint8_t)(q0 | (q1 << 4));
+        }
+    }
+}
+void orc_quantize_row_q5_0_ref(const float * x, orc_block_q5_0 * y, int64_t k) {      /* ggml-quants.c:110-152 */
+    for (int64_t i = 0; i < k / ORC_QK; i++, x += ORC_QK) {
+        const float d = signed_absmax(x, ORC_QK) / -16, id = d ? 1.0f / d : 0.0f;
+        y[i].d = orc_fp32_to_fp16(d);
+        uint32_t qh = 0;
+        for (int j = 0; j < 16; j++) {
+            const float x0 = x[j] * id, x1 = x[j + 16] * id;
+            const uint8_t q0 = (uint8_t) ORC_MIN(31, (int8_t)(x0 + 16.5f)), q1 = (uint8_t) ORC_MIN(31, (int8_t)(x1 + 16.5f));
+            y[i].qs[j] = (uint8_t)((q0 & 0x0F) | ((q1 & 0x0F) << 4));
+            qh |= (uint32_t)((q0 & 0x10u) >> 4) << j;
+            qh |= (uint32_t)((q1 & 0x10u) >> 4) << (j + 16);
+        }
+        memcpy(y[i].qh, &qh, 4);
+    }
+}
+void orc_quantize_row_q5_1_ref(const float * x, orc_block_q5_1 * y, int64_t k) {      /* ggml-quants.c:154-197 */
+    for (int64_t i = 0; i < k / ORC_QK; i++, x += ORC_QK) {
+        float mn, mx; minmax(x, ORC_QK, &mn, &mx);
+        const float d = (mx - mn) / 31, id = d ? 1.0f / d : 0.0f;
+        y[i].d = orc_fp32_to_fp16(d); y[i].m = orc_fp32_to_fp16(mn);
+        uint32_t qh = 0;
+        for (int j = 0; j < 16; j++) {
+            const float x0 = (x[j] - mn) * id, x1 = (x[j + 16] - mn) * id;
+            const uint8_t q0 = (uint8_t)(x0 + 0.5f), q1 = (uint8_t)(x1 + 0.5f);
+            y[i].qs[j] = (uint8_t)((q0 & 0x0F) | ((q1 & 0x0F) << 4));
+            qh |= (uint32_t)((q0 & 0x10u) >> 4) << j;
+            qh |= (uint32_t)((q1 & 0x10u) >> 4) << (j + 16);
+        }
+        memcpy(y[i].qh, &qh, 4);
+    }
+}
+/* make_qkx2_quants (ggml-quants.c:622-702) with the arguments quantize_row_q4_K_ref passes: n = 32, nmax = 15, rmin = -1, rdelta = 0.1, nstep = 20, squared error.
+ * Weighted least squares for x ~ scale * L + min over L in 0..15: a first guess from the range, then 21 candidate scalings of the rounding grid; returns scale, *the_min = -min */
+static float qkx2_32(const float * x, const float * w, uint8_t * L, float * the_min) {
+    uint8_t Laux[32];
+    float min = x[0], max = x[0], sum_w = w[0], sum_x = sum_w * x[0];
+    for (int i = 1; i < 32; i++) {
+        if (x[i] < min) min = x[i];
+        if (x[i] > max) max = x[i];
+        sum_w += w[i];
+        sum_x += w[i] * x[i];
+    }
+    if (min > 0) min = 0;
+    if (max == min) { memset(L, 0, 32); *the_min = -min; return 0.0f; }
+    float iscale = 15 / (max - min), scale = 1 / iscale, best_error = 0;
+    for (int i = 0; i < 32; i++) {
+        const int l = orc_nearest_int(iscale * (x[i] - min));
+        L[i] = (uint8_t) ORC_MAX(0, ORC_MIN(15, l));
+        float diff = scale * L[i] + min - x[i];
+        diff = diff * diff;
+        best_error += w[i] * diff;
+    }
+    for (int is = 0; is <= 20; is++) {
+        iscale = (-1.0f + 0.1f * is + 15) / (max - min);
+        float sum_l = 0, sum_l2 = 0, sum_xl = 0;
+        for (int i = 0; i < 32; i++) {
+            int l = orc_nearest_int(iscale * (x[i] - min));
+            l = ORC_MAX(0, ORC_MIN(15, l));
+            Laux[i] = (uint8_t) l;
+            sum_l += w[i] * l;
+            sum_l2 += w[i] * l * l;
+            sum_xl += w[i] * l * x[i];
+        }
+        const float D = sum_w * sum_l2 - sum_l * sum_l;
+        if (D > 0) {
+            float this_scale = (sum_w * sum_xl - sum_x * sum_l) / D, this_min = (sum_l2 * sum_x - sum_l * sum_xl) / D;
+            if (this_min > 0) { this_min = 0; this_scale = sum_xl / sum_l2; }
+            float cur_error = 0;
+            for (int i = 0; i < 32; i++) {
+                float diff = this_scale * Laux[i] + this_min - x[i];
+                diff = diff * diff;
+                cur_error += w[i] * diff;
+            }
+            if (cur_error < best_error) { memcpy(L, Laux, 32); best_error = cur_error; scale = this_scale; min = this_min; }
+        }
+    }
+    *the_min = -min;
+    return scale;
+}
+void orc_quantize_row_q4_K_ref(const float * x, orc_block_q4_K * y, int64_t k) {      /* ggml-quants.c:1280-1350 */
+    for (int64_t i = 0; i < k / ORC_QK_K; i++, x += ORC_QK_K) {
+        uint8_t L[ORC_QK_K];
+        float scales[8], mins[8], max_scale = 0, max_min = 0;
+        for (int j = 0; j < 8; j++) {
+            float w[32], sum_x2 = 0;
+            for (int l = 0; l < 32; l++) sum_x2 += x[32*j + l] * x[32*j + l];
+            const float av_x = sqrtf(sum_x2 / 32);
+            for (int l = 0; l < 32; l++) w[l] = av_x + fabsf(x[32*j + l]);
+            scales[j] = qkx2_32(x + 32*j, w, L + 32*j, &mins[j]);
+            if (scales[j] > max_scale) max_scale = scales[j];
+            if (mins[j] > max_min) max_min = mins[j];
+        }
+        const float inv_scale = max_scale > 0 ? 63.f / max_scale : 0.f, inv_min = max_min > 0 ? 63.f / max_min : 0.f;
+        memset(y[i].scales, 0, 12);
+        for (int j = 0; j < 8; j++) {
+            uint8_t ls = (uint8_t) orc_nearest_int(inv_scale * scales[j]), lm = (uint8_t) orc_nearest_int(inv_min * mins[j]);
+            ls = ORC_MIN(63, ls); lm = ORC_MIN(63, lm);
+            if (j < 4) { y[i].scales[j] = ls; y[i].scales[j + 4] = lm; }
+            else { y[i].scales[j + 4] = (uint8_t)((ls & 0xF) | ((lm & 0xF) << 4)); y[i].scales[j - 4] |= (uint8_t)((ls >> 4) << 6); y[i].scales[j] |= (uint8_t)((lm >> 4) << 6); }
+        }
+        y[i].d = orc_fp32_to_fp16(max_scale / 63.f); y[i].dmin = orc_fp32_to_fp16(max_min / 63.f);
+        for (int j = 0; j < 8; j++) {
+            uint8_t sc, m; orc_scale_min_k4(j, y[i].scales, &sc, &m);
+            const float d = orc_fp16_to_fp32(y[i].d) * sc;
+            if (!d) continue;                                                       /* (L keeps the search's values) */
+            const float dm = orc_fp16_to_fp32(y[i].dmin) * m;
+            for (int ii = 0; ii < 32; ii++) {
+                const int l = orc_nearest_int((x[32*j + ii] + dm) / d);
+                L[32*j + ii] = (uint8_t) ORC_MAX(0, ORC_MIN(15, l));
+            }
+        }
+        for (int j = 0; j < 4; j++) for (int l = 0; l < 32; l++) y[i].qs[32*j + l] = (uint8_t)(L[64*j + l] | (L[64*j + 32 + l] << 4));
+    }
+}
+int orc_quantize_row_ref(int type, const float * x, void * y, int64_t k) {
+    switch (type) {
+        case ORC_Q8_0: orc_quantize_row_q8_0_ref(x, (orc_block_q8_0 *) y, k); return 0;
+        case ORC_Q4_0: orc_quantize_row_q4_0_ref(x, (orc_block_q4_0 *) y, k); return 0;
+        case ORC_Q4_1: orc_quantize_row_q4_1_ref(x, (orc_block_q4_1 *) y, k); return 0;
+        case ORC_Q5_0: orc_quantize_row_q5_0_ref(x, (orc_block_q5_0 *) y, k); return 0;
+        case ORC_Q5_1: orc_quantize_row_q5_1_ref(x, (orc_block_q5_1 *) y, k); return 0;
+        case ORC_Q4_K: orc_quantize_row_q4_K_ref(x, (orc_block_q4_K *) y, k); return 0;
+        case ORC_F16:  for (int64_t i = 0; i < k; i++) ((uint16_t *) y)[i] = orc_fp32_to_fp16(x[i]); return 0;
+    }
+    return -1;
+}
+
 /* ------------------------------------------------------------------------------------------ */
 /* mul_mat                                                                                     */
 /* ------------------------------------------------------------------------------------------ */

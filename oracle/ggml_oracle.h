@@ -76,6 +76,12 @@ void orc_quantize_row_q8_1(const float * x, orc_block_q8_1 * y, int64_t k);
 /* (ggml/src/ggml-quants.c:2555-2592, nearest_int :444)                                      */
 void orc_quantize_row_q8_K(const float * x, orc_block_q8_K * y, int64_t k);
 
+/* ---- weight quantizers: the reference's from_float_ref, what the loader's re-quantization calls (src/chat.cpp:1246-1279, src/layers.cpp:358-373) ---- */
+void orc_quantize_row_q4_0_ref(const float * x, orc_block_q4_0 * y, int64_t k);      /* ggml-quants.c:36-71 */
+void orc_quantize_row_q4_1_ref(const float * x, orc_block_q4_1 * y, int64_t k);      /* ggml-quants.c:73-108 */
+void orc_quantize_row_q4_K_ref(const float * x, orc_block_q4_K * y, int64_t k);      /* ggml-quants.c:1280-1350, make_qkx2_quants :622-702 */
+int  orc_quantize_row_ref(int type, const float * x, void * y, int64_t k);           /* Q8_0, Q4_0, Q4_1, Q5_0, Q5_1, Q4_K, F16; -1: type not restated */
+
 /* ---- weight dequantizers (ggml/src/ggml-quants.c:307-325, 401-414, 1352-1373, 703-711) ---- */
 void orc_dequantize_row_q4_0(const orc_block_q4_0 * x, float * y, int64_t k);
 void orc_dequantize_row_q8_0(const orc_block_q8_0 * x, float * y, int64_t k);
@@ -90,6 +96,8 @@ void orc_dequantize_row_q2_K(const orc_block_q2_K * x, float * y, int64_t k);   
 void orc_dequantize_row_q3_K(const orc_block_q3_K * x, float * y, int64_t k);      /* ggml-quants.c:1128-1176 */
 void orc_dequantize_row_iq4_nl(const orc_block_iq4_nl * x, float * y, int64_t k);  /* ggml-quants.c:2512-2528 */
 void orc_dequantize_row(int type, const void * x, float * y, int64_t k);
+void orc_quantize_row_q5_0_ref(const float * x, orc_block_q5_0 * y, int64_t k);      /* ggml-quants.c:110-152 */
+void orc_quantize_row_q5_1_ref(const float * x, orc_block_q5_1 * y, int64_t k);      /* ggml-quants.c:154-197 */
 
 /* ---- block dot products (ggml-cpu/quants.c:115-150, 305-333, 550-623) ----
  * isums (optional): per-block exact integer sums (tier T0): for Q4_0/Q8_0 one int32 per 32-block;

@@ -99,6 +99,14 @@ def quantize_q8_K(x):
     return y
 
 
+def quantize_ref(type_, x):
+    """the reference's from_float_ref (what chatllm.cpp's on-load re-quantization calls) restated: bytes of the quantized row"""
+    x = np.ascontiguousarray(x, np.float32)
+    y = np.zeros(TYPE_SIZE[type_] * (x.size // BLCK[type_]), np.uint8)
+    _chk(lib().orc_quantize_row_ref(C.c_int(type_), _p(x), _p(y), C.c_int64(x.size)), "quantize_row_ref")
+    return y
+
+
 def dequantize(type_, blocks, k):
     blocks = np.ascontiguousarray(blocks, np.uint8)
     y = np.zeros(k, np.float32)

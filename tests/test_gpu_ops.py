@@ -448,6 +448,26 @@ def test_cpy_v_cache_transposed_and_cont(gpu):
     assert np.array_equal(got, np.ascontiguousarray(c.transpose(1, 0, 2)))
 
 
+@pytest.mark.parametrize("t", [O.Q8_0, O.Q4_0, O.Q4_1, O.Q5_0, O.Q5_1, O.Q4_K, O.F16])
+def test_weight_quantizers_on_the_device_are_byte_identical(gpu, t):
+    """cllm_op_quantize_rows == the reference's from_float_ref (the loader's on-load re-quantization), byte for byte: random rows at three magnitudes plus the
+    special sub-blocks (all zero, constant, all positive, ties, values on the rounding grid); a re-quantized row then dequantizes to the same floats"""
+    T, L = gpu.Tensor, gpu.lib.get()
+    K, rows = 4096, 37
+    for scale in (1.0, 1e-3, 40.0):
+        x = (rng.standard_normal((rows, K)) * scale).astype(np.float32)
+        x[0, :32] = 0.0; x[0, 32:64] = 0.37; x[0, 64:96] = np.abs(x[0, 64:96]) + 0.1; x[0, 100] = -x[0, 101]
+        x[1, :512] = np.round(x[1, :512] * 4) / 4
+        x[2] = 0.0
+        want = np.concatenate([O.quantize_ref(t, x[r]) for r in range(rows)])
+        dx = T.from_numpy(x)
+        out = T.from_numpy(np.zeros(want.size, np.uint8))
+        gpu.lib.check(L.cllm_op_quantize_rows(None, t, dx.data_ptr(), out.data_ptr(), K, rows), "quantize_rows")
+        got = out.numpy().reshape(-1)
+        assert np.array_equal(got, want), int(np.argmax(got != want))
+    assert L.cllm_op_quantize_rows(None, O.Q6_K, dx.data_ptr(), out.data_ptr(), K, rows) != 0 and b"no device quantizer" in L.cllm_last_error()
+
+
 @pytest.mark.parametrize("t", [O.Q4_0, O.Q4_1, O.Q8_0, O.Q4_K, O.Q5_K, O.Q6_K, O.F16, O.F32, O.Q5_0, O.Q5_1, O.IQ4_NL, O.MXFP4, O.Q2_K, O.Q3_K])
 def test_get_rows_bit_exact(gpu, t):
     n0, rows, n = 512, 30, 7

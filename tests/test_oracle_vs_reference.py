@@ -69,6 +69,25 @@ def test_quantize_q8_K_bit_exact(K):
         assert np.array_equal(got, ref)
 
 
+@pytest.mark.parametrize("t", [O.Q8_0, O.Q4_0, O.Q4_1, O.Q5_0, O.Q5_1, O.Q4_K, O.F16])
+def test_weight_quantizers_bit_exact(t):
+    """from_float_ref of the weight types (the loader's re-quantization, src/chat.cpp:1246-1279): every byte equals the reference's"""
+    R = O.ref()
+    for K in (256, 4096, 14336):
+        for scale in (1.0, 1e-3, 40.0):
+            x = (rng.standard_normal(K) * scale).astype(np.float32)
+            x[:32] = 0.0                                   # an all-zero block / sub-block
+            x[32:64] = 0.37                                # a constant one (max == min)
+            x[64:96] = np.abs(x[64:96]) + 0.1              # all positive: the minimum is clamped to 0
+            x[100] = -x[101]                               # a tie in |x|: the first one decides
+            if K > 256:
+                x[256:512] = np.round(x[256:512] * 4) / 4  # values on a grid: exact halves in the rounding
+            got = O.quantize_ref(t, x)
+            ref = np.zeros_like(got)
+            assert R.ref_quantize_ref(t, P(x), P(ref), C.c_int64(K)) == 0
+            assert np.array_equal(got, ref), (K, scale, int(np.argmax(got != ref)))
+
+
 @pytest.mark.parametrize("t", [O.Q4_0, O.Q4_1, O.Q8_0, O.Q4_K, O.Q5_K, O.Q6_K, O.Q5_0, O.Q5_1, O.Q2_K, O.Q3_K, O.IQ4_NL, O.MXFP4])
 def test_dequantize_bit_exact(t):
     R = O.ref()
