@@ -461,9 +461,9 @@ def test_weight_quantizers_on_the_device_are_byte_identical(gpu, t):
         x[2] = 0.0
         want = np.concatenate([O.quantize_ref(t, x[r]) for r in range(rows)])
         dx = T.from_numpy(x)
-        out = T.from_numpy(np.zeros(want.size, np.uint8))
+        out = T(t, [K, rows])
         gpu.lib.check(L.cllm_op_quantize_rows(None, t, dx.data_ptr(), out.data_ptr(), K, rows), "quantize_rows")
-        got = out.numpy().reshape(-1)
+        got = out.numpy().view(np.uint8).reshape(-1)
         assert np.array_equal(got, want), int(np.argmax(got != want))
     assert L.cllm_op_quantize_rows(None, O.Q6_K, dx.data_ptr(), out.data_ptr(), K, rows) != 0 and b"no device quantizer" in L.cllm_last_error()
 
