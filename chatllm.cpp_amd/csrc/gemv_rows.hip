@@ -139,18 +139,6 @@ __global__ void __launch_bounds__(1024) k_gemv_rows(const float * __restrict__ p
     typedef __attribute__((address_space(3))) const uint32_t * lptr;
     typedef __attribute__((address_space(3))) const u32x4 * lptr4;
 
-    // bias / residual of this lane's row: loaded (asm: the compiler must not wait for it with a vmcnt(0) that would drain the DMA pipeline) when
-    // the unit starts; by the unit's end it is older than a slot we have waited for (loads retire in order) -- unless the whole unit was
-    // already in flight (SPU <= NS), where the row end waits explicitly
-    float bv = 0.0f, rv = 0.0f;
-    auto fetch_br = [&](int cu_) {
-        if (EPI == 0 && cu_ < nmine) {
-            const size_t row = (size_t)(unsigned)(u0 + cu_ * ustride) * RPW + rowg;
-            if (bias)  asm volatile("global_load_dword %0, %1, off" : "=v"(bv) : "v"(bias + row) : "memory");
-            if (resid) asm volatile("global_load_dword %0, %1, off" : "=v"(rv) : "v"(resid + row) : "memory");
-        }
-    };
-    fetch_br(0);
     float acc = 0.0f, accm = 0.0f;
     int cq = 0, cu = 0, cs = 0;                                       // consume cursor: slot ordinal, unit ordinal, slot of the unit
     while (cq < total) {
@@ -211,11 +199,17 @@ __global__ void __launch_bounds__(1024) k_gemv_rows(const float * __restrict__ p
             } else {
                 const int row = unit * RPW + rowg;
                 const bool st = RPW == 8 ? j == 0 : (lane & 15) == 0;
-                if ((bias || resid) && SPU <= NS) wait_vm<0>();
-                if (bias)  v = v + bv;
-                if (resid) v = v + rv;
+                if (bias || resid) {                                  // the unit's RPW values through the scalar cache: their own counter, no wait on the DMA stream
+                    float bsel = 0.0f, rsel = 0.0f;
+#pragma unroll
+                    for (int q = 0; q < RPW; q++) {
+                        if (bias)  { const float x = uniform_load_f32(bias  + (size_t) unit * RPW + q); bsel = rowg == q ? x : bsel; }
+                        if (resid) { const float x = uniform_load_f32(resid + (size_t) unit * RPW + q); rsel = rowg == q ? x : rsel; }
+                    }
+                    if (bias)  v = v + bsel;
+                    if (resid) v = v + rsel;
+                }
                 if (st) dst[row] = v;
-                fetch_br(cu + 1);
             }
             acc = 0.0f; accm = 0.0f; cs = 0; cu++;
         }

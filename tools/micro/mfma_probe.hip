@@ -162,6 +162,32 @@ int main() {
         printf("v_pk_fma_f32 == fmaf per component: %s (%d / 128 differ)\n", bad ? "NO" : "yes", bad);
         bad_total += bad;
     }
+    {   // ---- is the fp16 K = 4 MFMA a k-ordered fmaf chain on NON-integer data?  (products of two fp16 are exact in fp32; the question is where the sum is rounded) ----
+        _Float16 a[64 * 4], b[64 * 4]; float c[64 * 16], d[64 * 16];
+        for (int i = 0; i < 256; i++) { a[i] = (_Float16)(frand(seed) * 3.0f); b[i] = (_Float16)(frand(seed) * 0.37f); }
+        for (int i = 0; i < 1024; i++) c[i] = frand(seed) * 100.0f;
+        h4 * da = (h4 *) dev(a, 256); h4 * db = (h4 *) dev(b, 256); float * dc = dev(c, 1024), * dd = dev(d, 1024);
+        hipLaunchKernelGGL(k_16x16x4_4b, dim3(1), dim3(64), 0, 0, da, db, dc, dd);
+        hipMemcpy(d, dd, sizeof(d), hipMemcpyDeviceToHost);
+        int bad_seq = 0, bad_rev = 0, bad_once = 0, bad_pair = 0;
+        for (int l = 0; l < 64; l++) for (int v = 0; v < 16; v++) {
+            const int blk = v >> 2, i = 4 * (l >> 4) + (v & 3), j = l & 15;
+            const _Float16 * pa = a + (blk * 16 + i) * 4, * pb = b + (blk * 16 + j) * 4;
+            float seq = c[l * 16 + v], rev = c[l * 16 + v];
+            for (int k = 0; k < 4; k++) seq = fmaf((float) pa[k], (float) pb[k], seq);
+            for (int k = 3; k >= 0; k--) rev = fmaf((float) pa[k], (float) pb[k], rev);
+            double once = (double) c[l * 16 + v];
+            for (int k = 0; k < 4; k++) once += (double) pa[k] * (double) pb[k];
+            const float pair = (float)((double) c[l * 16 + v] + ((double) pa[0] * pb[0] + (double) pa[1] * pb[1])) ;
+            const float pair2 = (float)((double) pair + ((double) pa[2] * pb[2] + (double) pa[3] * pb[3]));
+            if (seq != d[l * 16 + v]) bad_seq++;
+            if (rev != d[l * 16 + v]) bad_rev++;
+            if ((float) once != d[l * 16 + v]) bad_once++;
+            if (pair2 != d[l * 16 + v]) bad_pair++;
+        }
+        printf("v_mfma_f32_16x16x4_4b_f16 on fractional data: differs from the k-ordered fmaf chain in %d / 1024, from the reversed chain in %d, from one rounding of the exact 4-term sum in %d, from two 2-term steps in %d\n",
+               bad_seq, bad_rev, bad_once, bad_pair);
+    }
     if (hipDeviceSynchronize() != hipSuccess) { printf("HIP error\n"); return 2; }
     return bad_total ? 1 : 0;
 }
