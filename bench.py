@@ -368,6 +368,29 @@ def main():
             if native:
                 m.set_tp_comm(comm)
                 log(f"[rank {rank}] tensor parallel over RCCL (native communicator, all-reduce inside the decode graph)")
+                if os.environ.get("CLLM_TP_ONESHOT") == "1":
+                    # opt-in: the decode-sized all-reduces ([hidden] fp32) as ONE kernel launch each -- every rank writes its partial vector into every peer's
+                    # IPC-mapped receive buffer and sums the slots in rank order (tp_oneshot.hip); prompt-sized messages stay on RCCL.  All ranks decide together.
+                    ok1 = torch.ones(1, dtype=torch.int32, device=f"cuda:{local}")
+                    osh = C.c_void_p()
+                    mine = (C.c_char * 64)()
+                    try:
+                        pkg.lib.check(L.cllm_tp_oneshot_create(rank, world, cfg["hidden"] * 8, C.byref(osh), mine), "tp_oneshot_create")
+                    except Exception as e:                # noqa: BLE001
+                        log(f"[rank {rank}] cllm_tp_oneshot_create failed: {e}")
+                        ok1.zero_()
+                    gathered = [None] * world
+                    dist.all_gather_object(gathered, bytes(mine.raw))
+                    if int(ok1.item()):
+                        try:
+                            pkg.lib.check(L.cllm_tp_oneshot_connect(osh, b"".join(gathered)), "tp_oneshot_connect")
+                        except Exception as e:            # noqa: BLE001
+                            log(f"[rank {rank}] cllm_tp_oneshot_connect failed: {e}")
+                            ok1.zero_()
+                    dist.all_reduce(ok1, op=dist.ReduceOp.MIN)
+                    if int(ok1.item()) == 1:
+                        m.set_tp_oneshot(osh)
+                        log(f"[rank {rank}] decode all-reduces through the one-shot direct-write kernel")
         if not native:
             log(f"[rank {rank}] native RCCL path unavailable; using the torch.distributed callback")
 

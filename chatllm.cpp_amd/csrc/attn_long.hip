@@ -56,6 +56,23 @@ __global__ void __launch_bounds__(256) k_attn_long_scores(const float * __restri
     const int i_lo = blockIdx.x * chunk, i_hi = min(n_kv, i_lo + chunk);
     if (i_lo >= n_kv) return;
 
+    // the first pass of K rows depends only on the position: requested before the RoPE work (its latency overlaps the projections' loads and the rotation)
+    constexpr int NCH = HD / 32, RPI = 4 * U;
+    const int c16 = lane & 15, sub = lane >> 4;
+    const uint16_t * kbase = k_cache + g * HD + 2 * c16;
+    auto load_rows = [&](int ib, uint32_t (&r)[U][NCH]) {        // unconditional (clamped): exact vmcnt bookkeeping
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int i0 = ib + u * 4 + sub;
+            const uint16_t * kr = kbase + (int64_t)(i0 < pos ? i0 : 0) * KD;
+#pragma unroll
+            for (int i = 0; i < NCH; i++) r[u][i] = *(const uint32_t *)(kr + 32 * i);
+        }
+    };
+    uint32_t cur[U][NCH], nxt[U][NCH];
+    constexpr int WSTEP = 4 * RPI;                                // positions per workgroup pass
+    load_rows(i_lo + wave * RPI, cur);
+
     for (int t = tid; t < (R2 + 1) * half; t += 256) {          // pairs of the r2 query heads, then of k
         const int which = t / half, i = t - which * half, ic = MODE == 0 ? 2 * i : i;
         const float * x = which < R2 ? qkv + (g * R2 + which) * HD : qkv + QD + g * HD;
@@ -76,8 +93,6 @@ __global__ void __launch_bounds__(256) k_attn_long_scores(const float * __restri
     TS(1);
     // A wave owns RPI consecutive positions per pass (U rounds of 4 rows, 16 lanes per row).  Lane c of a row carries the accumulators 2c and 2c + 1 of
     // ggml_vec_dot_f16: one dword (two fp16) of the row per 32-element chunk, one fma per accumulator and chunk, then the reference's reduction tree (DPP).
-    constexpr int NCH = HD / 32, RPI = 4 * U;
-    const int c16 = lane & 15, sub = lane >> 4;
     float qa[R2][NCH], qb[R2][NCH];
 #pragma unroll
     for (int h = 0; h < R2; h++)
@@ -86,19 +101,6 @@ __global__ void __launch_bounds__(256) k_attn_long_scores(const float * __restri
     float kna[NCH], knb[NCH];
 #pragma unroll
     for (int i = 0; i < NCH; i++) { kna[i] = knew[32 * i + 2 * c16]; knb[i] = knew[32 * i + 2 * c16 + 1]; }
-    const uint16_t * kbase = k_cache + g * HD + 2 * c16;
-    auto load_rows = [&](int ib, uint32_t (&r)[U][NCH]) {        // unconditional (clamped): exact vmcnt bookkeeping
-#pragma unroll
-        for (int u = 0; u < U; u++) {
-            const int i0 = ib + u * 4 + sub;
-            const uint16_t * kr = kbase + (int64_t)(i0 < pos ? i0 : 0) * KD;
-#pragma unroll
-            for (int i = 0; i < NCH; i++) r[u][i] = *(const uint32_t *)(kr + 32 * i);
-        }
-    };
-    uint32_t cur[U][NCH], nxt[U][NCH];
-    constexpr int WSTEP = 4 * RPI;                                // positions per workgroup pass
-    load_rows(i_lo + wave * RPI, cur);
     for (int ib = i_lo + wave * RPI; ib < i_hi; ib += WSTEP) {
         load_rows(ib + WSTEP, nxt);                              // the next pass is in flight while this one is consumed
 #pragma unroll
@@ -226,6 +228,133 @@ __global__ void __launch_bounds__(256) k_attn_long_pv(const int32_t * __restrict
     }
 }
 
+// ---- (2 + 3) soft_max INSIDE the V.P launch: the contexts whose score row fits the LDS next to the V ring (ML <= AL_FUSED_MAX_ML) take two launches instead of three ----
+// Every workgroup of a head (HD / 16 of them) redoes the head's soft_max with all of its 16 waves -- max, exponentials, group sums, the double sum by one wave in k_soft_max's order, fp16
+// probabilities: the same bits in each -- while the first V tiles of its four V.P waves are already in flight: a launch less (~4 us of fixed cost + a boundary) for ~3 us of redundant
+// exponentials.  The V^T rows travel HBM -> LDS by DMA (global_load_lds_dwordx4) into a per-wave ring of NS tiles of 4 rows x 512 positions: no VGPRs, whole tiles in
+// flight (the dword-per-lane loads of the chain layout kept too few bytes in flight).  The chain is the one of k_attn_long_pv: 16 lanes per row, two accumulators per
+// lane, one 32-position chunk per step from the ring (V) and the LDS probability row (P), v_fma_mix_f32 on the fp16 pairs.
+#define AL_TILE 512
+#define AL_NS 4
+#define AL_FUSED_MAX_ML 12288
+__device__ __forceinline__ void al_dma16(const char * base /* wave-uniform */, unsigned voff, unsigned lds_dst /* wave-uniform */) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(voff), "s"(base), "s"(lds_dst) : "memory");
+}
+template <int N> __device__ __forceinline__ void al_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
+
+template <int HD>
+__global__ void __launch_bounds__(1024) k_attn_long_softmax_pv(const int32_t * __restrict__ pos_dev, int nh, int nkv, const uint16_t * __restrict__ v_cache, int ML,
+                                                              const float * __restrict__ S, float * __restrict__ att) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];    // [ML] fp32 exponentials | [ML / 8] group sums | [ML] fp16 probabilities | 4 waves x NS x 4 KB of V
+    __shared__ double red_d[1];
+    __shared__ float  red_f[16];
+    __shared__ float tail[16][32];
+    // 16 waves: all of them do the soft_max; waves 0..3 own the V ring and the V.P chains (4 rows each), the others leave after the soft_max
+    const int g = blockIdx.y, r2 = gridDim.z, h = g * r2 + blockIdx.z, tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool pv_wave = wave < 4;
+    const int n_kv = uniform_load_i32_(pos_dev) + 1, nv = n_kv & ~7, np = n_kv & ~31, nch = np >> 5, ntail = n_kv - np;
+    const int c16 = lane & 15, sub = lane >> 4, rl = wave * 4 + sub, d0 = blockIdx.x * 16 + rl;
+    float * ex = (float *) lds; float * gsum = ex + ML; uint16_t * p16 = (uint16_t *)(gsum + ML / 8);
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char *) lds;
+    const unsigned ring = lds0 + (unsigned) ML * 4u + (unsigned)(ML / 8) * 4u + (unsigned) ML * 2u + (unsigned)(wave & 3) * (AL_NS * 4096u);
+
+    // ---- the V ring: tile t = positions 512 t .. 512 t + 511 of this wave's 4 rows; lane l moves 16 bytes (8 positions) per row ----
+    const int ntiles = (nch + 15) >> 4;
+    const char * vrow0 = (const char *)(v_cache + ((int64_t) g * HD + blockIdx.x * 16 + (wave & 3) * 4) * ML);
+    auto issue = [&](int t) {
+        if (pv_wave && t < ntiles) {
+            int p0 = t * AL_TILE + lane * 8;
+            if (p0 > ML - 8) p0 = ML - 8;                           // (a ragged last tile stays inside the row: those positions are not used)
+            const unsigned dst = __builtin_amdgcn_readfirstlane(ring + (unsigned)(t % AL_NS) * 4096u);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the slot's previous occupant has been read
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const char * rb = vrow0 + (size_t) r * (size_t) ML * 2;
+                const char * rbs = (const char *)(((unsigned long long)(unsigned) __builtin_amdgcn_readfirstlane((int)((unsigned long long) rb >> 32)) << 32) |
+                                                  (unsigned) __builtin_amdgcn_readfirstlane((int)(unsigned long long) rb));
+                al_dma16(rbs, (unsigned) p0 * 2u, dst + 1024u * r);
+            }
+        }
+    };
+#pragma unroll
+    for (int t = 0; t < AL_NS - 1; t++) issue(t);
+
+    // ---- soft_max of head h (k_attn_long_softmax's arithmetic; 256 threads instead of 1024: the partition of the sums is the same) ----
+    const float * row = S + (int64_t) h * ML;
+    float mx = -INFINITY;
+    for (int i = tid * 4; i < n_kv; i += 4096) {                    // (ML % 8 == 0: a 16-byte load stays inside the row; the tail past n_kv is masked)
+        const f32x4 v = *(const f32x4 *)(row + i);
+        *(f32x4 *)(ex + i) = v;
+        mx = fmaxf(mx, v.x); if (i + 1 < n_kv) mx = fmaxf(mx, v.y); if (i + 2 < n_kv) mx = fmaxf(mx, v.z); if (i + 3 < n_kv) mx = fmaxf(mx, v.w);
+    }
+    mx = wave_max(mx);
+    if (lane == 0) red_f[wave] = mx;
+    __syncthreads();
+    mx = red_f[0];
+#pragma unroll
+    for (int w = 1; w < 16; w++) mx = fmaxf(mx, red_f[w]);
+    for (int gi = tid * 8; gi < nv; gi += 1024 * 8) {
+        const f32x4 s0 = *(const f32x4 *)(ex + gi), s1 = *(const f32x4 *)(ex + gi + 4);      // (16-byte LDS accesses: the 32-byte lane stride is 8-way conflicted for dwords)
+        float e[8] = { ggml_expf_poly(s0.x - mx), ggml_expf_poly(s0.y - mx), ggml_expf_poly(s0.z - mx), ggml_expf_poly(s0.w - mx),
+                       ggml_expf_poly(s1.x - mx), ggml_expf_poly(s1.y - mx), ggml_expf_poly(s1.z - mx), ggml_expf_poly(s1.w - mx) };
+        *(f32x4 *)(ex + gi) = f32x4{e[0], e[1], e[2], e[3]}; *(f32x4 *)(ex + gi + 4) = f32x4{e[4], e[5], e[6], e[7]};
+        const float a0 = e[0] + e[4], a1 = e[1] + e[5], a2 = e[2] + e[6], a3 = e[3] + e[7];
+        gsum[gi >> 3] = (a0 + a2) + (a1 + a3);
+    }
+    __syncthreads();
+    if (wave == 0) {
+        double sum = 0.0;
+        for (int gq = lane; gq < (nv >> 3); gq += 64) sum += (double) gsum[gq];
+        if (lane == 0) for (int i = nv; i < n_kv; i++) { const float e = libm_expf(ex[i] - mx); ex[i] = e; sum += (double) e; }
+        sum = wave_sum_d(sum);
+        if (lane == 0) red_d[0] = sum;
+    }
+    __syncthreads();
+    const float inv = (float)(1.0 / red_d[0]);
+    for (int i = tid * 2; i < n_kv; i += 2048) {                    // the fp16 rounding src1 of V.P gets (exact in fp32 later)
+        const uint32_t lo = f2h(ex[i] * inv), hi = i + 1 < n_kv ? f2h(ex[i + 1] * inv) : 0u;
+        *(uint32_t *)(p16 + i) = lo | (hi << 16);
+    }
+    __syncthreads();
+    if (!pv_wave) return;
+
+    // ---- V.P: 32 serial chains per row, chunk by chunk ----
+    float a0 = 0.0f, a1 = 0.0f;
+    auto step = [&](uint32_t vw, uint32_t pw) {
+        asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[1,1,0]" : "+v"(a0) : "v"(vw), "v"(pw));      // low halves
+        asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,1,0]" : "+v"(a1) : "v"(vw), "v"(pw));      // high halves
+    };
+    typedef __attribute__((address_space(3))) const uint32_t * lptr;
+    const uint32_t * pp = (const uint32_t *) p16 + c16;
+    for (int t = 0; t < ntiles; t++) {
+        issue(t + AL_NS - 1);
+        const int later = (t + AL_NS - 1 < ntiles ? AL_NS - 1 : ntiles - 1 - t);      // tiles issued after tile t: four DMA instructions each
+        if (later >= 3) al_wait_vm<12>(); else if (later == 2) al_wait_vm<8>(); else if (later == 1) al_wait_vm<4>(); else al_wait_vm<0>();
+        lptr vp = (lptr)(size_t)(ring + (unsigned)(t % AL_NS) * 4096u + (unsigned) sub * 1024u + (unsigned) c16 * 4u);
+        const uint32_t * pt = pp + 256 * t;
+        const int nc = nch - 16 * t < 16 ? nch - 16 * t : 16;
+        if (nc == 16) {
+#pragma unroll
+            for (int c = 0; c < 16; c++) step(vp[16 * c], pt[16 * c]);
+        } else {
+            for (int c = 0; c < nc; c++) step(vp[16 * c], pt[16 * c]);
+        }
+    }
+    const float res = al_vd32_reduce(a0, a1);
+    if (ntail) {                                                     // the n_kv mod 32 leftovers, one by one in double (products rounded to fp32 first)
+        const uint16_t * vr = v_cache + ((int64_t) g * HD + d0) * ML;
+        if (2 * c16 < ntail)     tail[rl][2 * c16]     = h2f(vr[np + 2 * c16])     * h2f(p16[np + 2 * c16]);
+        if (2 * c16 + 1 < ntail) tail[rl][2 * c16 + 1] = h2f(vr[np + 2 * c16 + 1]) * h2f(p16[np + 2 * c16 + 1]);
+    }
+    wave_lds_fence();
+    if (c16 == 0) {
+        double sacc = (double) res;
+        for (int t = 0; t < ntail; t++) sacc += (double) tail[rl][t];
+        att[h * HD + d0] = (float) sacc;
+    }
+}
+
 // CLLM_E_UNSUPPORTED -> the caller uses the single-launch kernels.  S: scratch of nh * ML * 6 bytes (fp32 scores + fp16 probabilities).
 int launch_attn_long(hipStream_t st, const float * qkv, const int32_t * pos_dev, const float * rope_cs, int nh, int nkv, int hd, int mode,
                      uint16_t * k_cache, uint16_t * v_cache, int64_t ML, float * S, float * att) {
@@ -242,6 +371,18 @@ int launch_attn_long(hipStream_t st, const float * qkv, const int32_t * pos_dev,
 #define SC3(HD_) do { if (r2 == 1) SC2(HD_, 1); else if (r2 == 2) SC2(HD_, 2); else if (r2 == 4) SC2(HD_, 4); else SC2(HD_, 8); } while (0)
     if (hd == 128) SC3(128); else SC3(64);
     LAUNCH_CHECK();
+    static const bool no_fuse = getenv("CLLM_ATTN_LONG_3") && atoi(getenv("CLLM_ATTN_LONG_3")) == 1;      // (tools: the three-launch form at every length)
+    if (ML <= AL_FUSED_MAX_ML && ML % 32 == 0 && !no_fuse) {                       // soft_max inside the V.P launch
+        const size_t lds2 = (size_t) ML * 4 + (size_t)(ML / 8) * 4 + (size_t) ML * 2 + 4 * AL_NS * 4096;
+#define PV2(HD_) do { \
+            static bool attr2 = false; \
+            if (!attr2) { HIP_TRY(hipFuncSetAttribute((const void *) k_attn_long_softmax_pv<HD_>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024)); attr2 = true; } \
+            hipLaunchKernelGGL((k_attn_long_softmax_pv<HD_>), dim3(HD_ / 16, nkv, r2), dim3(1024), lds2, st, pos_dev, nh, nkv, (const uint16_t *) v_cache, (int) ML, (const float *) S, att); } while (0)
+        if (hd == 128) PV2(128); else PV2(64);
+#undef PV2
+        LAUNCH_CHECK();
+        return CLLM_OK;
+    }
     static bool attr = false;
     if (lds > 48 * 1024 && !attr) { HIP_TRY(hipFuncSetAttribute((const void *) k_attn_long_softmax, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024)); attr = true; }
     hipLaunchKernelGGL(k_attn_long_softmax, dim3(nh), dim3(1024), lds, st, pos_dev, (int) ML, (const float *) S, P16);

@@ -48,6 +48,7 @@ struct cllm_llama {
     int32_t * tokens_dev = nullptr, * pos_dev = nullptr;
     cllm_allreduce_fn allreduce = nullptr; void * allreduce_user = nullptr;
     void * tp_comm = nullptr;         // RCCL communicator (cllm_tp_init): the all-reduce runs on the runner's stream, inside the decode graph
+    void * tp_oneshot = nullptr;      // one-shot direct-write all-reduce over IPC-mapped peer buffers (tp_oneshot.hip): one launch, also inside the graph
     bool use_graph = true;
     hipGraphExec_t decode_graph = nullptr;       // one sampled decode step, short-context attention (one launch per layer)
     hipGraphExec_t decode_graph_long = nullptr;  // the same with the split long-context attention (attn_long.hip)
@@ -161,14 +162,20 @@ extern "C" int cllm_llama_set_weight(cllm_llama * m, const char * name, int type
 extern "C" int cllm_llama_bind_weight(cllm_llama * m, const char * name, int type, void * dev, size_t nbytes) { return set_w(m, name, type, dev, nbytes, false); }
 extern "C" int cllm_llama_set_allreduce(cllm_llama * m, cllm_allreduce_fn fn, void * user) { if (!m) FAIL(CLLM_E_INVALID, "null"); m->allreduce = fn; m->allreduce_user = user; return CLLM_OK; }
 extern "C" int cllm_llama_set_tp_comm(cllm_llama * m, void * comm) { if (!m) FAIL(CLLM_E_INVALID, "null"); m->tp_comm = comm; return CLLM_OK; }
+extern "C" int cllm_llama_set_tp_oneshot(cllm_llama * m, void * os) { if (!m) FAIL(CLLM_E_INVALID, "null"); m->tp_oneshot = os; return CLLM_OK; }
 extern "C" int cllm_tp_all_reduce_f32(void * comm, void * stream, float * buf, size_t n);
+extern "C" int cllm_tp_oneshot_all_reduce_f32(void * os, void * stream, float * buf, size_t n);
 // sum `n` floats of `buf` over the tensor-parallel group, stream-ordered: RCCL if a communicator is bound, else the host callback
 static int tp_allreduce(cllm_llama * m, hipStream_t st, float * buf, int64_t n) {
+    if (m->tp_oneshot) {                                           // decode-sized messages; larger ones (a prompt's [H, qlen]) fall through to RCCL / the callback
+        const int rc = cllm_tp_oneshot_all_reduce_f32(m->tp_oneshot, st, buf, (size_t) n);
+        if (rc != CLLM_E_UNSUPPORTED) return rc;
+    }
     if (m->tp_comm) return cllm_tp_all_reduce_f32(m->tp_comm, st, buf, (size_t) n);
     if (m->allreduce) { m->allreduce(m->allreduce_user, st, buf, n); return CLLM_OK; }
-    FAIL(CLLM_E_INVALID, "llama: tp_size > 1 needs cllm_llama_set_tp_comm or cllm_llama_set_allreduce");
+    FAIL(CLLM_E_INVALID, "llama: tp_size > 1 needs cllm_llama_set_tp_comm or cllm_llama_set_allreduce (cllm_llama_set_tp_oneshot covers messages up to its max_n)");
 }
-static bool tp_on(const cllm_llama * m) { return m->cfg.tp_size > 1 && (m->tp_comm || m->allreduce); }
+static bool tp_on(const cllm_llama * m) { return m->cfg.tp_size > 1 && (m->tp_comm || m->tp_oneshot || m->allreduce); }
 extern "C" int cllm_llama_use_graph(cllm_llama * m, int enable) { if (!m) FAIL(CLLM_E_INVALID, "null"); m->use_graph = enable != 0; return CLLM_OK; }
 extern "C" size_t cllm_llama_weight_bytes(const cllm_llama * m) { return m ? m->weight_bytes : 0; }
 
@@ -210,7 +217,7 @@ static int interleave_rows(hipStream_t st, dweight & dst, dweight & a, dweight &
 static int finalize(cllm_llama * m, int qlen) {
     const cllm_llama_config & c = m->cfg;
     // a sharded model without a collective would silently produce logits from partial o / down sums
-    if (c.tp_size > 1 && !m->tp_comm && !m->allreduce) FAIL(CLLM_E_INVALID, "llama: tp_size %d needs cllm_llama_set_tp_comm or cllm_llama_set_allreduce before the first forward", c.tp_size);
+    if (c.tp_size > 1 && !m->tp_comm && !m->tp_oneshot && !m->allreduce) FAIL(CLLM_E_INVALID, "llama: tp_size %d needs cllm_llama_set_tp_comm or cllm_llama_set_allreduce before the first forward", c.tp_size);
     const int64_t H = c.hidden, hd = c.head_dim, QD = (int64_t) m->nh * hd, KD = (int64_t) m->nkv * hd, F = m->F, V = c.vocab, ML = c.max_len;
     if (!m->finalized) {
         TRY(expect(m->tok_embd, "tok_embd", -1, cllm_row_size(m->tok_embd.type, H) * (size_t) V, false));
@@ -558,7 +565,7 @@ static int persist_check(cllm_llama * m) {
 // capture one sampled step into a graph (after one eager warm-up step has set every function attribute)
 static int ensure_decode_graph(cllm_llama * m, bool long_ctx) {
     hipGraphExec_t & slot = long_ctx ? m->decode_graph_long : m->decode_graph;
-    if (slot || !m->use_graph || (m->cfg.tp_size > 1 && !m->tp_comm)) return CLLM_OK;     // a host callback cannot be captured; RCCL can
+    if (slot || !m->use_graph || (m->cfg.tp_size > 1 && !m->tp_comm && !m->tp_oneshot)) return CLLM_OK;     // a host callback cannot be captured; RCCL and the one-shot kernel can
     hipGraph_t graph = nullptr;
     HIP_TRY(hipStreamBeginCapture(m->st, hipStreamCaptureModeRelaxed));
     const int rc = decode_step_fused(m, true, long_ctx);

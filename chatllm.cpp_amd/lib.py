@@ -126,6 +126,12 @@ SIGNATURES = {
     "cllm_tp_destroy": (C.c_int, [_P]),
     "cllm_tp_all_reduce_f32": (C.c_int, [_P, _P, _P, C.c_size_t]),
     "cllm_llama_set_tp_comm": (C.c_int, [_P, _P]),
+    "cllm_tp_oneshot_create": (C.c_int, [C.c_int, C.c_int, C.c_size_t, C.POINTER(C.c_void_p), _P]),
+    "cllm_tp_oneshot_connect": (C.c_int, [_P, _P]),
+    "cllm_tp_oneshot_all_reduce_f32": (C.c_int, [_P, _P, _P, C.c_size_t]),
+    "cllm_tp_oneshot_error": (C.c_int, [_P]),
+    "cllm_tp_oneshot_destroy": (C.c_int, [_P]),
+    "cllm_llama_set_tp_oneshot": (C.c_int, [_P, _P]),
     "cllm_llama_forward": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, _P]),
     "cllm_llama_decode_greedy": (C.c_int, [_P, C.c_int32, C.c_int, C.c_int, _P]),
     "cllm_llama_decode_fused_logits": (C.c_int, [_P, C.c_int32, C.c_int, _P]),

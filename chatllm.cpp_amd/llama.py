@@ -40,6 +40,10 @@ class Llama:
         """bind an RCCL communicator (lib cllm_tp_init): all-reduces run on the runner's stream, inside the decode graph"""
         _l.check(_l.get().cllm_llama_set_tp_comm(self.h, comm), "set_tp_comm")
 
+    def set_tp_oneshot(self, handle):
+        """bind a one-shot all-reduce group (lib cllm_tp_oneshot_create / _connect): one kernel launch per all-reduce, inside the decode graph"""
+        _l.check(_l.get().cllm_llama_set_tp_oneshot(self.h, handle), "set_tp_oneshot")
+
     def use_graph(self, enable):
         _l.check(_l.get().cllm_llama_use_graph(self.h, 1 if enable else 0), "use_graph")
 

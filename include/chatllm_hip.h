@@ -336,6 +336,15 @@ CLLM_API int  cllm_tp_init(const void * id128, int rank, int nranks, void ** com
 CLLM_API int  cllm_tp_destroy(void * comm);
 CLLM_API int  cllm_tp_all_reduce_f32(void * comm, void * stream, float * buf, size_t n);
 CLLM_API int  cllm_llama_set_tp_comm(cllm_llama * m, void * comm);
+/* One-shot direct-write all-reduce for the decode-sized messages (tp_oneshot.hip): every rank writes its partial vector into a slot of every peer's receive buffer
+ * (peer memory mapped through HIP IPC, one process per GPU), raises a flag, waits for everybody's flag in its own buffer and sums the slots in rank order: one kernel
+ * launch per all-reduce, inside the captured decode graph.  create -> exchange the 64-byte handles (rank-ordered) by any host-side means -> connect -> bind. */
+CLLM_API int  cllm_tp_oneshot_create(int rank, int nranks, size_t max_n, void ** out, void * handle64);
+CLLM_API int  cllm_tp_oneshot_connect(void * os, const void * handles);
+CLLM_API int  cllm_tp_oneshot_all_reduce_f32(void * os, void * stream, float * buf, size_t n);
+CLLM_API int  cllm_tp_oneshot_error(void * os);
+CLLM_API int  cllm_tp_oneshot_destroy(void * os);
+CLLM_API int  cllm_llama_set_tp_oneshot(cllm_llama * m, void * os);
 /* run qlen tokens (host int32) at positions n_past..; writes logits[vocab] of the last token to
  * logits_dev (device, may be NULL) and/or logits_host (may be NULL; implies a stream sync).               */
 CLLM_API int  cllm_llama_forward(cllm_llama * m, const int32_t * tokens, int qlen, int n_past, float * logits_dev,

@@ -113,6 +113,41 @@ def test_bench_tp_setup_under_torchrun_with_one_rank(gpu):
     assert res["n_gpus"] == 1 and res["value"] > 0 and res["metric"] == "decode tokens/s"
 
 
+def _run_two_ranks(tmp_path, seed, mode):
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    out = str(tmp_path / f"tp_{mode}.npz")
+    env = dict(os.environ, TP_WORKER_MODE=mode, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs = [subprocess.Popen([sys.executable, os.path.join(root, "tests", "tp_two_ranks_worker.py"), str(r), "2", str(port), out, str(seed)],
+                              stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env) for r in range(2)]
+    errs = []
+    for p in procs:
+        try:
+            _, e = p.communicate(timeout=600)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        errs.append(e)
+    assert all(p.returncode == 0 for p in procs), [e[-1500:] for e in errs]
+    return np.load(out)
+
+
+def test_one_shot_all_reduce_between_two_processes_equals_the_gloo_all_reduce(gpu, tmp_path):
+    """tp_oneshot.hip with two REAL ranks (two processes on this GPU, each other's receive buffer mapped through HIP IPC): every logit of the teacher-forced steps
+    and every free-running id equals the run whose all-reduce is a host round trip over gloo (a two-term sum has one order) -- and here the decode steps replay
+    from the captured graph with the all-reduce kernels inside."""
+    a = _run_two_ranks(tmp_path, 17, "gloo")
+    b = _run_two_ranks(tmp_path, 17, "oneshot")
+    assert int(b["oneshot_error"]) == 0
+    assert np.array_equal(a["logits"].view(np.uint32), b["logits"].view(np.uint32))
+    assert np.array_equal(a["ids"], b["ids"])
+
+
 def test_two_ranks_share_the_gpu_and_all_reduce_over_gloo(gpu, tmp_path):
     """The HIP tensor-parallel path with REAL partial sums: two processes, both on this GPU, each holding one shard of the model; the runner's all-reduce
     is the host callback over gloo (tests/tp_two_ranks_worker.py).  Against the unsharded runner on the same tokens: the sharded o / down outputs are sums of

@@ -50,16 +50,32 @@ def main():
         pkg.lib.check(L.cllm_memcpy_h2d(C.c_void_p(buf), host.ctypes.data_as(C.c_void_p), n * 4, None), "h2d")
         pkg.ops.sync()
         n_calls[0] += 1
-    m.set_allreduce(allreduce)
+    oneshot = None
+    if os.environ.get("TP_WORKER_MODE") == "oneshot":
+        # the one-shot direct-write all-reduce (tp_oneshot.hip): both processes map each other's receive buffer through HIP IPC; the 64-byte handles travel over gloo
+        oneshot = C.c_void_p()
+        mine = (C.c_char * 64)()
+        pkg.lib.check(L.cllm_tp_oneshot_create(rank, world, cfg["hidden"] * 64, C.byref(oneshot), mine), "oneshot_create")
+        gathered = [None] * world
+        dist.all_gather_object(gathered, bytes(mine.raw))
+        pkg.lib.check(L.cllm_tp_oneshot_connect(oneshot, b"".join(gathered)), "oneshot_connect")
+        dist.barrier()
+        m.set_tp_oneshot(oneshot)
+    else:
+        m.set_allreduce(allreduce)
     prompt = np.random.default_rng(seed).integers(0, cfg["vocab"], 12).astype(np.int32)
     teacher = np.random.default_rng(seed + 1).integers(0, cfg["vocab"], 10).astype(np.int32)
     logits = [m.forward(prompt)]
     for i, t in enumerate(teacher):                          # teacher-forced: the node-by-node path and the fused single-token path alternate
         logits.append(m.forward([int(t)]) if i % 2 == 0 else m.decode_fused_logits(int(t)))
     ids = m.decode_greedy(int(np.argmax(logits[-1])), 8)      # free-running through the fused TP step (eager launches: a host callback cannot be captured)
+    err = L.cllm_tp_oneshot_error(oneshot) if oneshot else 0
     if rank == 0:
-        np.savez(out, logits=np.stack(logits), ids=ids, calls=n_calls[0])
+        np.savez(out, logits=np.stack(logits), ids=ids, calls=n_calls[0], oneshot_error=err)
+    dist.barrier()                                           # (nobody unmaps a buffer a peer may still write)
     m.close()
+    if oneshot:
+        pkg.lib.check(L.cllm_tp_oneshot_destroy(oneshot), "oneshot_destroy")
     dist.barrier()
     dist.destroy_process_group()
 
