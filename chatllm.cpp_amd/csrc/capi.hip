@@ -184,14 +184,27 @@ extern "C" int cllm_event_elapsed_ms(void * start, void * stop, float * ms) {
 static bool is_quant(int t) { return is_quant_type(t) || is_kq_type(t); }
 static int  act_kind(int wtype) { return act_kind_of(wtype); }
 
-// Columns from which the quantized product runs on the matrix cores (mmq.hip: exact integer block sums, its own fp32 summation order =
-// tolerance tier).  Below, the multi-column mat-vec runs in chunks of <= 4 columns: it accumulates in the reference's AVX2 order, so short
-// prompts (BASELINE cfg2: 16 tokens) stay BIT-IDENTICAL to the CPU path end to end.  Default 33; CLLM_MMQ_MIN_COLS=9 is the speed crossover.
+// Columns from which the FAST / F16 prefill modes take a quantized product (mmq.hip: exact integer block sums, its own fp32 summation order = tolerance tier;
+// dense_f16.hip).  Below it every mode computes in the reference's AVX2 order, so short prompts (BASELINE cfg2: 16 tokens) stay BIT-IDENTICAL to the CPU path end to
+// end whatever the mode.  Default 33 (CLLM_MMQ_MIN_COLS).
 int mmq_min_cols_get();
 static int mmq_min_cols() {
     static int v = -1;
     if (v < 0) { v = 33; if (const char * e = getenv("CLLM_MMQ_MIN_COLS")) { int x = atoi(e); if (x >= 1) v = x; } }
     return v;
+}
+// Columns from which the exact-order GEMM (mmx.hip: one launch, the weights read once, a 64-token tile whatever the count) beats the exact-order mat-vec in chunks of
+// <= 4 columns (mmvq.hip: the weights re-read per chunk) -- the same bits either way.  Measured on Llama-3-8B shapes (profiles/r03_short_prompt_crossover.txt): the
+// wide projections (gate/up) cross at 4-5 columns, the hidden-sized ones (qkv, o, down) at 8-11.  CLLM_MMX_MIN_COLS overrides both.
+static int exact_gemm_min_cols(int64_t nrows) {
+    static int v = -2;
+    if (v == -2) { v = -1; if (const char * e = getenv("CLLM_MMX_MIN_COLS")) { int x = atoi(e); if (x >= 1) v = x; } }
+    return v > 0 ? v : nrows >= 16384 ? 5 : 10;
+}
+// 0: mat-vec in column chunks (mmvq), 1: exact-order GEMM (mmx), 2: the fast / f16 mode's kernels
+static int gemm_path(int64_t M, int64_t nrows) {
+    if (M >= mmq_min_cols() && (prefill_f16_enabled() || prefill_mode() == 0)) return 2;
+    return M >= exact_gemm_min_cols(nrows) ? 1 : 0;
 }
 
 // ---- prefill mode (common.h) ----
@@ -284,14 +297,15 @@ extern "C" int cllm_op_mul_mat(void * stream, const cllm_tensor * src0, const cl
         tview d = tv(dst);
         d.data += i12 * d.nb[2] + i13 * d.nb[3];
         const char * act = (const char *) wdata + (size_t)(i12 * src1->ne[1] + i13 * src1->ne[1] * src1->ne[2]) * stride;
-        if (src1->ne[1] >= mmq_min_cols()) {
+        const int path = gemm_path(src1->ne[1], src0->ne[1]);
+        if (path) {
             rc = CLLM_E_UNSUPPORTED;
-            if (prefill_f16_enabled()) {            // opt-in: dequantize -> dense fp16 GEMM (dense_f16.hip); a different computation than the reference's
+            if (path == 2 && prefill_f16_enabled()) {            // opt-in: dequantize -> dense fp16 GEMM (dense_f16.hip); a different computation than the reference's
                 tview x1 = x; x1.data += i12 * x.nb[2] + i13 * x.nb[3];
                 rc = launch_dense_f16(st, src0->type, w, x1, d);
             }
-            if (rc == CLLM_E_UNSUPPORTED && prefill_mode() == 1) rc = launch_mmx(st, src0->type, w, act, stride, x, d);      // the reference's order on the matrix cores
-            if (rc == CLLM_E_UNSUPPORTED) rc = launch_mmq(st, src0->type, w, act, stride, x, d);
+            if (rc == CLLM_E_UNSUPPORTED && path == 1) rc = launch_mmx(st, src0->type, w, act, stride, x, d);      // the reference's order on the matrix cores
+            if (rc == CLLM_E_UNSUPPORTED && path == 2) rc = launch_mmq(st, src0->type, w, act, stride, x, d);
             if (rc == CLLM_E_UNSUPPORTED) rc = launch_mmvq(st, src0->type, w, act, stride, src1->ne[1], x, d);
         } else {
             rc = launch_mmvq(st, src0->type, w, act, stride, src1->ne[1], x, d);
@@ -303,7 +317,7 @@ extern "C" int cllm_op_mul_mat(void * stream, const cllm_tensor * src0, const cl
 
 int mmq_min_cols_get() { return mmq_min_cols(); }
 // the number of src1 columns from which cllm_op_mul_mat_ex takes a mat-mul (below it: CLLM_E_UNSUPPORTED); INT_MAX-like when the opt-in fp16 prefill path is on
-extern "C" int cllm_mul_mat_ex_min_cols(void) { return prefill_f16_enabled() ? (1 << 30) : mmq_min_cols(); }
+extern "C" int cllm_mul_mat_ex_min_cols(void) { return prefill_f16_enabled() ? (1 << 30) : exact_gemm_min_cols(0); }
 
 extern "C" int cllm_op_mul_mat_ex(void * stream, const cllm_tensor * src0, const cllm_tensor * src1, cllm_tensor * dst, void * wdata, size_t wsize, int pro,
                                   const cllm_tensor * norm_w, float eps, int epi, const cllm_tensor * resid) {
@@ -316,7 +330,7 @@ extern "C" int cllm_op_mul_mat_ex(void * stream, const cllm_tensor * src0, const
     if (resid && (resid->type != CLLM_TYPE_F32 || resid->ne[0] != dst->ne[0] || resid->ne[1] != M || resid->nb[0] != 4 || resid->nb[1] % 4)) FAIL(CLLM_E_INVALID, "mul_mat_ex: resid");
     if (pro == 1 && (norm_w->type != CLLM_TYPE_F32 || norm_w->nb[0] != 4 || norm_w->ne[0] != K || t_nelements(norm_w) != K)) FAIL(CLLM_E_INVALID, "mul_mat_ex: norm weight");
     if (pro == 4 && (norm_w->type != CLLM_TYPE_F32 || norm_w->nb[0] != 4 || norm_w->ne[0] != K || norm_w->ne[1] != M || norm_w->ne[2] != 1 || norm_w->ne[3] != 1)) FAIL(CLLM_E_INVALID, "mul_mat_ex: up tensor");
-    if (M < mmq_min_cols() || prefill_f16_enabled()) return CLLM_E_UNSUPPORTED;
+    if (M < exact_gemm_min_cols(0) || prefill_f16_enabled()) return CLLM_E_UNSUPPORTED;
     if (src0->nb[0] != cllm_type_size(src0->type) || K % cllm_blck_size(src0->type)) FAIL(CLLM_E_INVALID, "mul_mat_ex: src0 rows");
     const int kind = act_kind(src0->type);
     const size_t stride = act_row_bytes(K, kind), need = stride * (size_t) M;
@@ -333,7 +347,7 @@ extern "C" int cllm_op_mul_mat_ex(void * stream, const cllm_tensor * src0, const
     if (rc == CLLM_E_UNSUPPORTED) FAIL(rc, "mul_mat_ex: this prologue takes 16-byte aligned rows (norm: of at most 16384 values)");
     if (rc) return rc;
     tview x = tv(src1); if (pro == 3) x.ne[0] = K;
-    rc = prefill_mode() == 1 ? launch_mmx(st, src0->type, tv(src0), wdata, stride, x, tv(dst), resid ? (const float *) resid->data : nullptr, resid ? (int64_t)(resid->nb[1] / 4) : 0, epi)
+    rc = gemm_path(M, src0->ne[1]) != 2 ? launch_mmx(st, src0->type, tv(src0), wdata, stride, x, tv(dst), resid ? (const float *) resid->data : nullptr, resid ? (int64_t)(resid->nb[1] / 4) : 0, epi)
                              : launch_mmq(st, src0->type, tv(src0), wdata, stride, x, tv(dst), resid ? (const float *) resid->data : nullptr, resid ? (int64_t)(resid->nb[1] / 4) : 0, epi);
     if (rc == CLLM_E_UNSUPPORTED) FAIL(rc, "mul_mat_ex: the matrix-core kernel does not take this shape");
     return rc;
@@ -353,14 +367,14 @@ extern "C" int cllm_bench_mul_mat_kernel(void * stream, const cllm_tensor * src0
     if (rc) return rc;
     hipEvent_t e0, e1;
     HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
-    const bool mmq = src1->ne[1] >= mmq_min_cols();
+    const int path = gemm_path(src1->ne[1], src0->ne[1]);
     for (int pass = 0; pass < 2; pass++) {             // pass 0 = warm-up (also pages in code objects), pass 1 = timed
         if (pass == 1) HIP_TRY(hipEventRecord(e0, st));
         const int n = pass == 0 ? (n_src0 < 4 ? n_src0 : 4) : iters;
         for (int i = 0; i < n; i++) {
             tview w = tv(src0); w.data = (char *) src0_datas[i % n_src0];
-            rc = !mmq ? CLLM_E_UNSUPPORTED : prefill_f16_enabled() ? launch_dense_f16(st, src0->type, w, tv(src1), tv(dst))
-                                           : prefill_mode() == 1 ? launch_mmx(st, src0->type, w, wdata, stride, tv(src1), tv(dst)) : launch_mmq(st, src0->type, w, wdata, stride, tv(src1), tv(dst));
+            rc = !path ? CLLM_E_UNSUPPORTED : (path == 2 && prefill_f16_enabled()) ? launch_dense_f16(st, src0->type, w, tv(src1), tv(dst))
+                                            : path == 1 ? launch_mmx(st, src0->type, w, wdata, stride, tv(src1), tv(dst)) : launch_mmq(st, src0->type, w, wdata, stride, tv(src1), tv(dst));
             if (rc == CLLM_E_UNSUPPORTED) rc = launch_mmvq(st, src0->type, w, wdata, stride, src1->ne[1], tv(src1), tv(dst));
             if (rc) return rc;
         }
