@@ -349,6 +349,27 @@ def test_reference_host_long_prompt_is_bit_identical_free_running(gpu, tmp_path,
 
 @pytest.mark.skipif(not (os.path.exists(os.path.join(REF, "ref_chat")) and os.path.exists(os.path.join(REF, "libggml-hip.so"))),
                     reason="oracle/_ref (reference host + module) not built")
+@pytest.mark.parametrize("arch,wname,wt,nprompt", [("llama", "q4_k", 12, 10), ("llama", "q4_0", 2, 12), ("llama", "q4_k", 12, 20), ("llama", "q8_0", 8, 32), ("llama", "q4_1", 3, 17),
+                                                   ("qwen2", "q4_k", 12, 70), ("qwen2", "q4_0", 2, 24), ("qwen2", "q8_0", 8, 140)])
+def test_reference_host_prompts_of_every_length_class_are_bit_identical_free_running(gpu, tmp_path, arch, wname, wt, nprompt):
+    """prompts between the exact GEMM's take-over (5 / 10 columns) and 32 tokens -- mat-muls on mmx.hip with the module's prompt patterns, the attention still node by
+    node -- and longer ones on the Qwen2 architecture (q / k / v biases, NEOX RoPE): FREE-RUNNING, every logit of the prompt and of the decode steps after it has the
+    bits of the reference's CPU run"""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import make_ggmm
+    over = dict(qkv_bias=1, rope_mode=2, rope_theta=1e6) if arch == "qwen2" else {}
+    cfg = gpu.synth.config("small", max_len=256, **over)
+    mp = str(tmp_path / "m.bin")
+    make_ggmm.write_model(mp, cfg, wt, seed=81, **({"arch": "qwen2"} if arch == "qwen2" else {}))
+    prompt = [(11 * i + 5) % cfg["vocab"] for i in range(nprompt)]
+    ids_c, lg_c, _ = _host_run(tmp_path, mp, "cpu", 8, prompt, cfg["vocab"])
+    ids_g, lg_g, _ = _host_run(tmp_path, mp, "all", 8, prompt, cfg["vocab"])
+    assert ids_c == ids_g
+    assert np.array_equal(lg_c.view(np.uint32), lg_g.view(np.uint32)), [int(np.sum(lg_c[i].view(np.uint32) != lg_g[i].view(np.uint32))) for i in range(9)]
+
+
+@pytest.mark.skipif(not (os.path.exists(os.path.join(REF, "ref_chat")) and os.path.exists(os.path.join(REF, "libggml-hip.so"))),
+                    reason="oracle/_ref (reference host + module) not built")
 def test_reference_host_long_prompt_fast_mode_uses_the_flash_prefill(gpu, tmp_path):
     """CLLM_PREFILL=fast: MUL_MAT + SCALE + DIAG_MASK_INF + SOFT_MAX + MUL_MAT of every layer run as one flash kernel and the mat-muls on the int8 MFMA GEMM
     (tolerance tier); the decode steps after it are the exact kernels again"""
