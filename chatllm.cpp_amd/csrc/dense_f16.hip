@@ -28,9 +28,6 @@ struct mmd_args {
 };
 #define MMD_KS 64
 #define MMD_LD (MMD_KS * 2 + 16)
-#ifndef MMD_XG
-#define MMD_XG 1            // 1: the activation fragments come straight from global memory (the fp16 copy is k-contiguous = the MFMA's fragment shape); 0: through LDS
-#endif
 
 __device__ __forceinline__ void b2h(uint32_t u, uint32_t & lo, uint32_t & hi) {       // four unsigned bytes -> fp16 pairs 1024 + byte (0x64uu)
     lo = __builtin_amdgcn_perm(0x64646464u, u, 0x04010400u);
@@ -48,7 +45,7 @@ template <int TYPE>
 __global__ void __launch_bounds__(256, 2) k_mmd(const mmd_args a) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     constexpr bool IS_K = TYPE == CLLM_TYPE_Q4_K, IS_41 = TYPE == CLLM_TYPE_Q4_1, IS_Q8 = TYPE == CLLM_TYPE_Q8_0;
-    constexpr int BN = 128, BM = 128, STAGE = (MMD_XG ? BN : BN + BM) * MMD_LD;
+    constexpr int BN = 128, BM = 128, STAGE = (BN + BM) * MMD_LD;
     constexpr int BS = IS_Q8 ? 34 : IS_41 ? 20 : 18, QOFF = IS_41 ? 4 : 2;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     unsigned mt, nt;
@@ -86,30 +83,12 @@ __global__ void __launch_bounds__(256, 2) k_mmd(const mmd_args a) {
                 if (IS_Q8) { const q16 q1 = *(const q16 *)(bp + 18); rq2 = u32x4{q1.x, q1.y, q1.z, q1.w}; }
             }
         }
-        if (!MMD_XG) {
 #pragma unroll
-            for (int t = 0; t < 4; t++) {
-                const int c = tid + 256 * t, row = c >> 3, ch = c & 7;
-                const int64_t m = m0 + row, e = k0 + ch * 8;
-                rx[t] = u32x4{0, 0, 0, 0};
-                if (m < a.M && e < K) rx[t] = *(const u32x4 *)(a.X + m * a.ldx + e);      // (K % 8 == 0: whole chunks)
-            }
-        }
-    };
-    // MMD_XG: this lane's fragments of a stage: token row wm + 32 i + l31, the 16 fp16 at k0 + 32 p + 16 l5 (p = 0, 1) = the two k-substeps 2p, 2p + 1 (the k order inside a
-    // stage is permuted the same way for the weights in LDS: the contraction does not care)
-    u32x4 xf[2][4], xn[2][4];
-    auto xfetch = [&](int64_t k0, u32x4 (&f)[2][4]) {
-#pragma unroll
-        for (int i = 0; i < 2; i++) {
-            const int64_t m = m0 + wm + i * 32 + l31;
-            const uint16_t * xr = a.X + (m < a.M ? m : a.M - 1) * a.ldx + k0 + 16 * l5;
-#pragma unroll
-            for (int p = 0; p < 2; p++) {
-                const bool ok = k0 + 32 * p + 16 * l5 < K;               // (K % 16 == 0 is required by the launcher in this mode)
-                f[i][2 * p]     = ok ? *(const u32x4 *)(xr + 32 * p)     : u32x4{0, 0, 0, 0};
-                f[i][2 * p + 1] = ok ? *(const u32x4 *)(xr + 32 * p + 8) : u32x4{0, 0, 0, 0};
-            }
+        for (int t = 0; t < 4; t++) {
+            const int c = tid + 256 * t, row = c >> 3, ch = c & 7;
+            const int64_t m = m0 + row, e = k0 + ch * 8;
+            rx[t] = u32x4{0, 0, 0, 0};
+            if (m < a.M && e < K) rx[t] = *(const u32x4 *)(a.X + m * a.ldx + e);      // (K % 8 == 0: whole chunks)
         }
     };
     auto commit = [&](int stage, int64_t k0) {
@@ -159,45 +138,34 @@ __global__ void __launch_bounds__(256, 2) k_mmd(const mmd_args a) {
         char * wr = Wt + wrow * MMD_LD + whalf * 64;
 #pragma unroll
         for (int e = 0; e < 4; e++) *(u32x4 *)(wr + 16 * e) = u32x4{o[4 * e], o[4 * e + 1], o[4 * e + 2], o[4 * e + 3]};
-        if (!MMD_XG) {
 #pragma unroll
-            for (int t = 0; t < 4; t++) {
-                const int c = tid + 256 * t, row = c >> 3, ch = c & 7;
-                *(u32x4 *)(Xt + row * MMD_LD + ch * 16) = rx[t];
-            }
+        for (int t = 0; t < 4; t++) {
+            const int c = tid + 256 * t, row = c >> 3, ch = c & 7;
+            *(u32x4 *)(Xt + row * MMD_LD + ch * 16) = rx[t];
         }
     };
 
     prefetch(0);
-    if (MMD_XG) xfetch(0, xf);
     commit(0, 0);
     __syncthreads();
     int stage = 0;
     for (int64_t k0 = 0; k0 < K; k0 += MMD_KS) {
         const bool more = k0 + MMD_KS < K;
         if (more) prefetch(k0 + MMD_KS);
-        if (MMD_XG && more) xfetch(k0 + MMD_KS, xn);
         const char * Wt = lds + stage * STAGE, * Xt = Wt + BN * MMD_LD;
 #pragma unroll
         for (int ks = 0; ks < 4; ks++) {
             h8v ax[2], bw[2];
-            // (MMD_XG: k-substep ks covers the stage's elements 32 (ks >> 1) + 16 l5 + 8 (ks & 1) .. + 7 in both operands)
 #pragma unroll
-            for (int i = 0; i < 2; i++) ax[i] = MMD_XG ? __builtin_bit_cast(h8v, xf[i][ks]) : *(const h8v *)(Xt + (wm + i * 32 + l31) * MMD_LD + ks * 32 + l5 * 16);
+            for (int i = 0; i < 2; i++) ax[i] = *(const h8v *)(Xt + (wm + i * 32 + l31) * MMD_LD + ks * 32 + l5 * 16);
 #pragma unroll
-            for (int j = 0; j < 2; j++) bw[j] = *(const h8v *)(Wt + (wn + j * 32 + l31) * MMD_LD + (MMD_XG ? (ks >> 1) * 64 + l5 * 32 + (ks & 1) * 16 : ks * 32 + l5 * 16));
+            for (int j = 0; j < 2; j++) bw[j] = *(const h8v *)(Wt + (wn + j * 32 + l31) * MMD_LD + ks * 32 + l5 * 16);
 #pragma unroll
             for (int i = 0; i < 2; i++)
 #pragma unroll
                 for (int j = 0; j < 2; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ax[i], bw[j], acc[i][j], 0, 0, 0);
         }
         if (more) commit(stage ^ 1, k0 + MMD_KS);
-        if (MMD_XG && more) {
-#pragma unroll
-            for (int i = 0; i < 2; i++)
-#pragma unroll
-                for (int q = 0; q < 4; q++) xf[i][q] = xn[i][q];
-        }
         __syncthreads();
         stage ^= 1;
     }
@@ -254,7 +222,7 @@ int launch_dense_f16(hipStream_t st, int wtype, const tview & w, const tview & x
     mmd_args a;
     a.W = w.data; a.nb01 = w.nb[1]; a.N = N; a.K = K; a.X = (const uint16_t *) g_x16; a.ldx = ldx; a.M = M;
     a.dst = (float *) d.data; a.ldd = d.nb[1] / 4; a.resid = resid; a.ldr = ldr; a.epi = epi;
-    constexpr int LDS = 2 * (MMD_XG ? 128 : 256) * MMD_LD;
+    constexpr int LDS = 2 * 256 * MMD_LD;
     const dim3 grid((unsigned)(((M + 127) / 128) * ((N + 127) / 128)));
 #define GO(T) do { static bool attr = false; \
         if (!attr) { HIP_TRY(hipFuncSetAttribute((const void *) k_mmd<T>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS)); attr = true; } \
