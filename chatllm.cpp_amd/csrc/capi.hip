@@ -527,7 +527,7 @@ extern "C" int cllm_op_mul_mat_id(void * stream, const cllm_tensor * as, const c
     int rc = check_mm(as, b, dst, "mul_mat_id");
     if (rc) return rc;
     if (!ids || ids->type != CLLM_TYPE_I32) FAIL(CLLM_E_INVALID, "mul_mat_id: ids must be I32");
-    if (!is_quant_type(as->type)) FAIL(CLLM_E_UNSUPPORTED, "mul_mat_id: expert weights must be Q4_0/Q4_1/Q8_0/Q4_K");
+    if (!is_quant(as->type)) FAIL(CLLM_E_UNSUPPORTED, "mul_mat_id: expert weights must be a quantized type");
     const int64_t n_used = ids->ne[0], n_tok = ids->ne[1];
     if (as->ne[3] != 1 || b->ne[3] != 1 || dst->ne[3] != 1 || ids->ne[2] != 1 || ids->ne[3] != 1) FAIL(CLLM_E_INVALID, "mul_mat_id: 4-D operands");
     if (dst->ne[0] != as->ne[1] || dst->ne[1] != n_used || dst->ne[2] != n_tok || b->ne[2] != n_tok) FAIL(CLLM_E_INVALID, "mul_mat_id: shapes");
@@ -548,6 +548,11 @@ extern "C" int cllm_op_mul_mat_id(void * stream, const cllm_tensor * as, const c
     }
     rc = launch_quantize_act(st, kind, tv(b), wdata, stride);      // act row index = i11 + ne11*i12 (token-major over slots)
     if (rc) return rc;
+    if (is_kq_type(as->type)) {                                     // the coverage types: one grid slice per (token, slot) of gemv_kq.hip
+        rc = launch_gemv_kq_id(st, as->type, tv(as), wdata, stride, b->ne[1], tv(ids), tv(dst));
+        if (rc == CLLM_E_UNSUPPORTED) FAIL(rc, "mul_mat_id: type %d: shape or alignment not taken", as->type);
+        return rc;
+    }
     return launch_mmvq_id(st, as->type, tv(as), wdata, stride, b->ne[1], tv(ids), tv(dst));
 }
 

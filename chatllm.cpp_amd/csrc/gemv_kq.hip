@@ -21,7 +21,20 @@ struct kq_args {
     const char * W; int64_t nb01; int N, nblk;
     const char * act; int64_t act_stride; int off_d, off_s;
     float * dst; int64_t ldd; int ncols;
+    // MUL_MAT_ID (ids != nullptr): blockIdx.y = token * n_used + slot; the expert comes from device memory, one column per launch slice
+    const int32_t * ids; int64_t ids_nb1 /* ints */, nb02, dst_tok /* floats */; int n_used, ne11;
 };
+// expert / activation row / destination of this grid slice (MUL_MAT_ID, ggml_compute_forward_mul_mat_id ggml-cpu.c:1432-1678: dst[:, slot, tok] = as[:, :, ids[slot, tok]]^T . b[:, slot % ne11, tok])
+__device__ __forceinline__ void kq_slice(const kq_args & a, const char * & W, const char * & act, float * & dst) {
+    W = a.W; act = a.act; dst = a.dst;
+    if (a.ids) {
+        const int pair = blockIdx.y, tok = pair / a.n_used, slot = pair - tok * a.n_used;
+        const int e = a.ids[(int64_t) tok * a.ids_nb1 + slot];
+        W += (int64_t) e * a.nb02;
+        act += (int64_t)(tok * a.ne11 + (a.ne11 == 1 ? 0 : slot)) * a.act_stride;
+        dst += (int64_t) tok * a.dst_tok + (int64_t) slot * a.ldd;
+    }
+}
 
 __device__ __forceinline__ uint32_t ld2(const char * p) { return (uint32_t) *(const uint16_t *) p | ((uint32_t) *(const uint16_t *)(p + 2) << 16); }
 
@@ -31,7 +44,9 @@ __global__ void __launch_bounds__(256) k_gemv_kq(const kq_args a) {
     int row = tid >> 3;
     const bool live = row < a.N;                       // whole waves stay: the final lane exchanges read their neighbours
     if (!live) row = a.N - 1;
-    const char * wr = a.W + (int64_t) row * a.nb01;
+    const char * Wb, * actb; float * dstb;
+    kq_slice(a, Wb, actb, dstb);
+    const char * wr = Wb + (int64_t) row * a.nb01;
     float acc[NC], summs[NC];
 #pragma unroll
     for (int c = 0; c < NC; c++) { acc[c] = 0.0f; summs[c] = 0.0f; }
@@ -118,7 +133,7 @@ __global__ void __launch_bounds__(256) k_gemv_kq(const kq_args a) {
 #pragma unroll
         for (int c = 0; c < NC; c++) {
             const int cc = c < a.ncols ? c : 0;
-            const char * ar = a.act + (int64_t) cc * a.act_stride;
+            const char * ar = actb + (int64_t) cc * a.act_stride;
             int sumi = 0;
 #pragma unroll
             for (int t = 0; t < 8; t++) sumi += (int) sc8[t] * dot4(w[t], *(const uint32_t *)(ar + b * 256 + aoff[t]), 0);
@@ -149,7 +164,7 @@ __global__ void __launch_bounds__(256) k_gemv_kq(const kq_args a) {
         v = v + dpp_f<DPP_QUAD_XOR2>(v);                                      // (.. 0) + (.. 2), (.. 1) + (.. 3)
         v = v + dpp_f<DPP_QUAD_XOR1>(v);
         if (TYPE == CLLM_TYPE_Q5_K) v = v + summs[c];
-        if (live && A == 0 && c < a.ncols) a.dst[(int64_t) c * a.ldd + row] = v;
+        if (live && A == 0 && c < a.ncols) dstb[(int64_t) c * a.ldd + row] = v;
     }
 }
 
@@ -171,7 +186,9 @@ __global__ void __launch_bounds__(256) k_gemv_b32(const kq_args a) {
     int row = tid >> 3;
     const bool live = row < a.N;
     if (!live) row = a.N - 1;
-    const char * wr = a.W + (int64_t) row * a.nb01;
+    const char * Wb, * actb; float * dstb;
+    kq_slice(a, Wb, actb, dstb);
+    const char * wr = Wb + (int64_t) row * a.nb01;
     float acc[NC], acc2[NC], summs[NC];
 #pragma unroll
     for (int c = 0; c < NC; c++) { acc[c] = 0.0f; acc2[c] = 0.0f; summs[c] = 0.0f; }
@@ -197,7 +214,7 @@ __global__ void __launch_bounds__(256) k_gemv_b32(const kq_args a) {
 #pragma unroll
         for (int c = 0; c < NC; c++) {
             const int cc = c < a.ncols ? c : 0;
-            const char * ar = a.act + (int64_t) cc * a.act_stride;
+            const char * ar = actb + (int64_t) cc * a.act_stride;
             const uint32_t av = *(const uint32_t *)(ar + b * 32 + 4 * A);
             const int sumi = Q50 ? dot4(w, av, dot4(0xf0f0f0f0u, av, 0)) : dot4(w, av, 0);      // Q5_0: (q5 - 16) . a
             const float yd = ((const float *)(ar + a.off_d))[b];
@@ -215,45 +232,67 @@ __global__ void __launch_bounds__(256) k_gemv_b32(const kq_args a) {
         v = v + dpp_f<DPP_QUAD_XOR2>(v);
         v = v + dpp_f<DPP_QUAD_XOR1>(v);
         if (Q51 || (!CHAIN && (a.nblk & 1))) v = v + summs[c];
-        if (live && A == 0 && c < a.ncols) a.dst[(int64_t) c * a.ldd + row] = v;
+        if (live && A == 0 && c < a.ncols) dstb[(int64_t) c * a.ldd + row] = v;
     }
 }
 
 // act: the act rows (launch_quantize_act, kind act_kind_of(wtype)) of the M columns; dst[m * ldd + n]
-int launch_gemv_kq(hipStream_t st, int wtype, const tview & w, const void * act, size_t act_stride, int64_t M, float * dst, int64_t ldd) {
-    const int64_t K = w.ne[0], N = w.ne[1];
+static int kq_check(int wtype, const tview & w, int64_t K, int64_t N) {
     const bool k256 = is_k256_type(wtype);
     if (!is_kq_type(wtype) || K % (k256 ? 256 : 32) || N <= 0 || N > (1 << 28)) return CLLM_E_UNSUPPORTED;
-    const uintptr_t al = (uintptr_t) w.data | (uintptr_t) w.nb[1];
+    const uintptr_t al = (uintptr_t) w.data | (uintptr_t) w.nb[1] | (uintptr_t) w.nb[2];
     if (wtype == CLLM_TYPE_Q5_K ? (al & 15) : wtype == CLLM_TYPE_MXFP4 ? 0 : (al & 1)) return CLLM_E_UNSUPPORTED;
-    const int kind = act_kind_of(wtype);
-    kq_args a;
-    a.W = w.data; a.nb01 = w.nb[1]; a.N = (int) N; a.nblk = (int)(K / (k256 ? 256 : 32));
-    a.act_stride = (int64_t) act_stride; a.off_d = (int) act_off_d(K); a.off_s = (int) act_off_s(K, kind);
-    a.ldd = ldd;
-    const dim3 grid((unsigned)((N * 8 + 255) / 256));
-    const bool chain = M >= 2;                           // IQ4_NL: llamafile_sgemm serves n >= 2 (sgemm.cpp:3691, 4000-4013)
-    for (int64_t m0 = 0; m0 < M; m0 += 8) {
-        a.act = (const char *) act + (size_t) m0 * act_stride; a.dst = dst + m0 * ldd; a.ncols = (int)(M - m0 < 8 ? M - m0 : 8);
+    return CLLM_OK;
+}
+static void kq_launch(hipStream_t st, int wtype, const kq_args & a, dim3 grid, bool chain) {
 #define GO(T) do { if (a.ncols == 1) hipLaunchKernelGGL((k_gemv_kq<T, 1>), grid, dim3(256), 0, st, a); \
                    else if (a.ncols <= 4) hipLaunchKernelGGL((k_gemv_kq<T, 4>), grid, dim3(256), 0, st, a); \
                    else hipLaunchKernelGGL((k_gemv_kq<T, 8>), grid, dim3(256), 0, st, a); } while (0)
 #define GB(T, CH) do { if (a.ncols == 1) hipLaunchKernelGGL((k_gemv_b32<T, 1, CH>), grid, dim3(256), 0, st, a); \
                        else if (a.ncols <= 4) hipLaunchKernelGGL((k_gemv_b32<T, 4, CH>), grid, dim3(256), 0, st, a); \
                        else hipLaunchKernelGGL((k_gemv_b32<T, 8, CH>), grid, dim3(256), 0, st, a); } while (0)
-        switch (wtype) {
-            case CLLM_TYPE_Q5_K: GO(CLLM_TYPE_Q5_K); break;
-            case CLLM_TYPE_Q6_K: GO(CLLM_TYPE_Q6_K); break;
-            case CLLM_TYPE_Q2_K: GO(CLLM_TYPE_Q2_K); break;
-            case CLLM_TYPE_Q3_K: GO(CLLM_TYPE_Q3_K); break;
-            case CLLM_TYPE_Q5_0: GB(CLLM_TYPE_Q5_0, true); break;
-            case CLLM_TYPE_Q5_1: GB(CLLM_TYPE_Q5_1, true); break;
-            case CLLM_TYPE_IQ4_NL: if (chain) GB(CLLM_TYPE_IQ4_NL, true); else GB(CLLM_TYPE_IQ4_NL, false); break;
-            default: GB(CLLM_TYPE_MXFP4, false); break;
-        }
+    switch (wtype) {
+        case CLLM_TYPE_Q5_K: GO(CLLM_TYPE_Q5_K); break;
+        case CLLM_TYPE_Q6_K: GO(CLLM_TYPE_Q6_K); break;
+        case CLLM_TYPE_Q2_K: GO(CLLM_TYPE_Q2_K); break;
+        case CLLM_TYPE_Q3_K: GO(CLLM_TYPE_Q3_K); break;
+        case CLLM_TYPE_Q5_0: GB(CLLM_TYPE_Q5_0, true); break;
+        case CLLM_TYPE_Q5_1: GB(CLLM_TYPE_Q5_1, true); break;
+        case CLLM_TYPE_IQ4_NL: if (chain) GB(CLLM_TYPE_IQ4_NL, true); else GB(CLLM_TYPE_IQ4_NL, false); break;
+        default: GB(CLLM_TYPE_MXFP4, false); break;
+    }
 #undef GO
 #undef GB
+}
+int launch_gemv_kq(hipStream_t st, int wtype, const tview & w, const void * act, size_t act_stride, int64_t M, float * dst, int64_t ldd) {
+    const int64_t K = w.ne[0], N = w.ne[1];
+    if (kq_check(wtype, w, K, N)) return CLLM_E_UNSUPPORTED;
+    const int kind = act_kind_of(wtype);
+    kq_args a = {};
+    a.W = w.data; a.nb01 = w.nb[1]; a.N = (int) N; a.nblk = (int)(K / (is_k256_type(wtype) ? 256 : 32));
+    a.act_stride = (int64_t) act_stride; a.off_d = (int) act_off_d(K); a.off_s = (int) act_off_s(K, kind);
+    a.ldd = ldd;
+    const dim3 grid((unsigned)((N * 8 + 255) / 256));
+    const bool chain = M >= 2;                           // IQ4_NL: llamafile_sgemm serves n >= 2 (sgemm.cpp:3691, 4000-4013)
+    for (int64_t m0 = 0; m0 < M; m0 += 8) {
+        a.act = (const char *) act + (size_t) m0 * act_stride; a.dst = dst + m0 * ldd; a.ncols = (int)(M - m0 < 8 ? M - m0 : 8);
+        kq_launch(st, wtype, a, grid, chain);
         LAUNCH_CHECK();
     }
+    return CLLM_OK;
+}
+// MUL_MAT_ID with coverage-type expert weights: as [K, N, n_as], act rows of b (row index = i11 + ne11 * token), ids [n_used, n_tok] I32 in device memory, dst [N, n_used, n_tok].
+// One grid slice per (token, slot): always the one-column order (mul_mat_id calls vec_dot: IQ4_NL's paired accumulators)
+int launch_gemv_kq_id(hipStream_t st, int wtype, const tview & as, const void * act, size_t act_stride, int64_t ne11, const tview & ids, const tview & dst) {
+    const int64_t K = as.ne[0], N = as.ne[1], n_used = ids.ne[0], n_tok = ids.ne[1];
+    if (kq_check(wtype, as, K, N) || n_used * n_tok > 65535 || n_used <= 0 || ids.nb[0] != 4 || ids.nb[1] % 4 || dst.nb[1] % 4 || dst.nb[2] % 4) return CLLM_E_UNSUPPORTED;
+    const int kind = act_kind_of(wtype);
+    kq_args a = {};
+    a.W = as.data; a.nb01 = as.nb[1]; a.N = (int) N; a.nblk = (int)(K / (is_k256_type(wtype) ? 256 : 32));
+    a.act = (const char *) act; a.act_stride = (int64_t) act_stride; a.off_d = (int) act_off_d(K); a.off_s = (int) act_off_s(K, kind);
+    a.dst = (float *) dst.data; a.ldd = (int64_t)(dst.nb[1] / 4); a.ncols = 1;
+    a.ids = (const int32_t *) ids.data; a.ids_nb1 = (int64_t)(ids.nb[1] / 4); a.nb02 = as.nb[2]; a.dst_tok = (int64_t)(dst.nb[2] / 4); a.n_used = (int) n_used; a.ne11 = (int) ne11;
+    kq_launch(st, wtype, a, dim3((unsigned)((N * 8 + 255) / 256), (unsigned)(n_used * n_tok)), false);
+    LAUNCH_CHECK();
     return CLLM_OK;
 }

@@ -348,6 +348,10 @@ bool dev_supports_op(ggml_backend_dev_t, const ggml_tensor * op) {
                                        (a->type == GGML_TYPE_MXFP4 || a->nb[1] % 2 == 0);
             return (a->type == GGML_TYPE_F16 || a->type == GGML_TYPE_F32) && a->ne[2] * a->ne[3] <= 65535;
         case GGML_OP_MUL_MAT_ID:
+            if (is_kq(a->type))        // the coverage types: one grid slice per (token, slot) of gemv_kq.hip (no fused MoE launch takes them)
+                return f32_dense(b) && op->src[2] && op->src[2]->type == GGML_TYPE_I32 && a->ne[3] == 1 && b->ne[3] == 1 && a->ne[0] % ggml_blck_size(a->type) == 0 && dense_rows(a) &&
+                       (b->ne[1] == 1 || b->ne[1] == op->src[2]->ne[0]) && op->src[2]->ne[0] * op->src[2]->ne[1] <= 65535 && b->nb[1] % 16 == 0 && b->nb[2] % 16 == 0 &&
+                       (a->type != GGML_TYPE_Q5_K || (a->nb[1] % 16 == 0 && a->nb[2] % 16 == 0)) && (a->type == GGML_TYPE_MXFP4 || (a->nb[1] % 2 == 0 && a->nb[2] % 2 == 0));
             return is_q(a->type) && f32_dense(b) && op->src[2] && op->src[2]->type == GGML_TYPE_I32 && a->ne[3] == 1 && b->ne[3] == 1 && a->ne[0] % 32 == 0 &&
                    (b->ne[1] == 1 || b->ne[1] == op->src[2]->ne[0]) && op->src[2]->ne[0] * op->src[2]->ne[1] <= 65535 && b->nb[1] % 16 == 0 && b->nb[2] % 16 == 0 &&
                    (a->type != GGML_TYPE_Q4_K || (a->nb[1] % 16 == 0 && a->nb[2] % 16 == 0)) && (a->type != GGML_TYPE_Q4_1 || (a->nb[1] % 4 == 0 && a->nb[2] % 4 == 0));

@@ -8,7 +8,7 @@ import zlib
 
 import numpy as np
 
-from .tensor import F32, Q4_0, Q4_1, Q8_0, Q4_K, Q5_K, Q6_K, TYPE_SIZE, BLCK  # noqa: F401
+from .tensor import F32, Q4_0, Q4_1, Q8_0, Q4_K, Q5_K, Q6_K, Q5_0, Q5_1, Q2_K, Q3_K, IQ4_NL, MXFP4, TYPE_SIZE, BLCK  # noqa: F401
 
 CONFIGS = {
     # name: n_layer, hidden, n_head, n_kv_head, head_dim, ffn, vocab
@@ -105,6 +105,49 @@ def quant_blocks(type_, rows, K, rng, sigma):
         out[:, :, 0:128] = ql.reshape(rows, nb, 128)
         qh = (q[:, :, :, 0, :] >> 4) | ((q[:, :, :, 1, :] >> 4) << 2) | ((q[:, :, :, 2, :] >> 4) << 4) | ((q[:, :, :, 3, :] >> 4) << 6)
         out[:, :, 128:192] = qh.reshape(rows, nb, 64)
+    elif type_ in (Q5_0, Q5_1):                                         # d [m] qh[4] qs[16] (ggml-common.h:197-216): w = (q5 - 16) d | q5 d + m
+        off = 2 if type_ == Q5_0 else 4
+        out = np.empty((rows, nb, TYPE_SIZE[type_]), np.uint8)
+        d = rng.uniform(0.5, 1.5, (rows, nb)) * sigma / 5.0
+        out[:, :, 0:2] = _f16_bytes(d).reshape(rows, nb, 2)
+        if type_ == Q5_1:
+            out[:, :, 2:4] = _f16_bytes(-d * rng.uniform(15.0, 17.0, (rows, nb))).reshape(rows, nb, 2)
+        q = np.clip(np.rint(rng.standard_normal((rows, nb, 32), np.float32) * 5.0 + 16.0), 0, 31).astype(np.uint32)
+        out[:, :, off + 4:] = ((q[:, :, :16] & 15) | ((q[:, :, 16:] & 15) << 4)).astype(np.uint8)
+        qh = np.zeros((rows, nb), np.uint32)
+        for e in range(32):
+            qh |= (q[:, :, e] >> 4) << e
+        out[:, :, off:off + 4] = qh.view(np.uint8).reshape(rows, nb, 4)
+    elif type_ in (IQ4_NL, MXFP4):                                      # d | e, qs[16]: 16-entry int8 codebooks (ggml-common.h:190-194, 415-419, 1088-1096)
+        out = np.empty((rows, nb, TYPE_SIZE[type_]), np.uint8)
+        off = 2 if type_ == IQ4_NL else 1
+        if type_ == IQ4_NL:
+            d = rng.uniform(0.5, 1.5, (rows, nb)) * sigma / 72.0        # kvalues_iq4nl: rms 72
+            out[:, :, 0:2] = _f16_bytes(d).reshape(rows, nb, 2)
+        else:
+            e = np.clip(np.rint(128.0 + np.log2(max(sigma, 1e-30) / 5.7) + rng.uniform(-0.5, 0.5, (rows, nb))), 2, 250)      # kvalues_mxfp4: rms 5.7, scale 2^(e - 128)
+            out[:, :, 0] = e.astype(np.uint8)
+        out[:, :, off:] = rng.integers(0, 256, (rows, nb, 16), dtype=np.uint8)
+    elif type_ == Q2_K:                                                 # scales[16] (scale | min << 4) qs[64] d dmin: w = d sc q - dmin m, q in 0..3
+        out = np.empty((rows, nb, 84), np.uint8)
+        sc = rng.integers(3, 11, (rows, nb, 16), dtype=np.uint8)
+        m = np.clip(np.rint(sc.astype(np.float32) * 1.5), 0, 15).astype(np.uint8)       # dmin = d: ~zero-mean
+        out[:, :, 0:16] = sc | (m << 4)
+        out[:, :, 16:80] = rng.integers(0, 256, (rows, nb, 64), dtype=np.uint8)
+        d = rng.uniform(0.5, 1.5, (rows, nb)) * sigma / (7.0 * 1.12)
+        out[:, :, 80:82] = _f16_bytes(d).reshape(rows, nb, 2)
+        out[:, :, 82:84] = _f16_bytes(d).reshape(rows, nb, 2)
+    elif type_ == Q3_K:                                                 # hmask[32] qs[64] scales[12] d: w = d (sc - 32) (q2 | h << 2) - 4): q in -4..3
+        out = np.empty((rows, nb, 110), np.uint8)
+        out[:, :, 0:96] = rng.integers(0, 256, (rows, nb, 96), dtype=np.uint8)
+        sc = (32 + rng.integers(8, 32, (rows, nb, 16)) * rng.choice(np.array([1, 1, 1, -1]), (rows, nb, 16))).astype(np.uint8)      # 6-bit codes, value - 32 in +-(8..31)
+        s = np.zeros((rows, nb, 12), np.uint8)                          # inverse of the unpack of ggml-quants.c:1141-1150
+        s[:, :, 0:8] = (sc[:, :, 0:8] & 15) | ((sc[:, :, 8:16] & 15) << 4)
+        for k in range(4):
+            s[:, :, 8:12] |= ((sc[:, :, 4 * k:4 * k + 4] >> 4) & 3) << (2 * k)
+        out[:, :, 96:108] = s
+        d = rng.uniform(0.5, 1.5, (rows, nb)) * sigma / (20.0 * 2.3)
+        out[:, :, 108:110] = _f16_bytes(d).reshape(rows, nb, 2)
     else:
         raise ValueError(type_)
     return out.reshape(rows, nb * TYPE_SIZE[type_])

@@ -427,6 +427,49 @@ def test_reference_host_other_k_quants_bit_identical(gpu, tmp_path, name, wt, mi
 
 @pytest.mark.skipif(not (os.path.exists(os.path.join(REF, "ref_chat")) and os.path.exists(os.path.join(REF, "libggml-hip.so"))),
                     reason="oracle/_ref (reference host + module) not built")
+@pytest.mark.parametrize("name,wt,mix,nprompt", [
+    ("legacy mix", 2, {"wq": 6, "wk": 7, "wv": 20, "wo": 11, "wgate": 10, "wup": 6, "wdown": 7, "lm_head": 20, "tok_embd": 6}, 7),       # Q5_0 / Q5_1 / IQ4_NL / Q3_K / Q2_K
+    ("legacy mix, long prompt", 2, {"wq": 6, "wk": 7, "wv": 20, "wo": 11, "wgate": 10, "wup": 6, "wdown": 7, "lm_head": 20, "tok_embd": 6}, 50),
+    ("q5_0", 6, None, 9), ("q5_1", 7, None, 9), ("iq4_nl", 20, None, 40), ("q2_k", 10, None, 9), ("q3_k", 11, None, 40), ("mxfp4", 39, None, 9)])
+def test_reference_host_other_formats_bit_identical(gpu, tmp_path, name, wt, mix, nprompt):
+    """model files in the formats older and third-party converters write -- Q5_0, Q5_1, IQ4_NL, Q2_K, Q3_K, MXFP4, pure and mixed per tensor -- through the unmodified
+    host: every node stays on the module (no CPU fallback) and the free-running generation has the bits of the reference's CPU run, for one-token graphs, short
+    prompts (one-column order) and long ones (IQ4_NL's other order under tinyBLAS)"""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import make_ggmm
+    cfg = gpu.synth.config("tiny", max_len=128, mix=mix)
+    mp = str(tmp_path / "m.bin")
+    make_ggmm.write_model(mp, cfg, wt, seed=85)
+    prompt = [(13 * i + 3) % cfg["vocab"] for i in range(nprompt)]
+    ids_c, lg_c, _ = _host_run(tmp_path, mp, "cpu", 10, prompt, cfg["vocab"])
+    ids_g, lg_g, err = _host_run(tmp_path, mp, "all", 10, prompt, cfg["vocab"])
+    graphs = [ln for ln in err.splitlines() if "graph_compute:" in ln and "calls" in ln]
+    assert len(graphs) == 11, len(graphs)                  # one graph per step: nothing fell back to the CPU backend
+    assert ids_c == ids_g
+    assert np.array_equal(lg_c.view(np.uint32), lg_g.view(np.uint32))
+
+
+@pytest.mark.skipif(not (os.path.exists(os.path.join(REF, "ref_chat")) and os.path.exists(os.path.join(REF, "libggml-hip.so"))),
+                    reason="oracle/_ref (reference host + module) not built")
+def test_reference_host_mixtral_with_q6_k_and_q5_k_experts_bit_identical(gpu, tmp_path):
+    """a Q4_K_M-style Mixtral file: expert down projections in Q6_K, expert up projections in Q5_K, the rest Q4_K -- MUL_MAT_ID over coverage-type experts runs on the
+    module (one grid slice per (token, slot)), nothing falls back to the CPU, the bits are the CPU run's"""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import make_ggmm
+    cfg = gpu.synth.config("tiny", max_len=64, rope_theta=1e6, mix={".w2.": 14, ".w3.": 13})
+    mp = str(tmp_path / "mx.bin")
+    make_ggmm.write_mixtral(mp, cfg, 12, seed=92)
+    prompt = [5, 9, 42, 300, 7]
+    ids_c, lg_c, _ = _host_run(tmp_path, mp, "cpu", 10, prompt, cfg["vocab"])
+    ids_g, lg_g, err = _host_run(tmp_path, mp, "all", 10, prompt, cfg["vocab"])
+    assert ids_c == ids_g
+    assert np.array_equal(lg_c.view(np.uint32), lg_g.view(np.uint32))
+    graphs = [ln for ln in err.splitlines() if "graph_compute:" in ln and "calls" in ln]
+    assert len(graphs) == len(prompt) + 10, len(graphs)    # (this architecture feeds the prompt one token per graph) one graph per step: no split to the CPU backend
+
+
+@pytest.mark.skipif(not (os.path.exists(os.path.join(REF, "ref_chat")) and os.path.exists(os.path.join(REF, "libggml-hip.so"))),
+                    reason="oracle/_ref (reference host + module) not built")
 def test_module_decode_ahead_hits_and_misses_stay_bit_identical(gpu, tmp_path):
     """decode-ahead (ggml-hip.cpp ahead_launch): after the host has read a step's logits the module starts the next greedy step itself; when the
     host's graph arrives it is compared with the prediction.  Free-running greedy: every step is a hit.  A teacher that feeds OTHER tokens than the

@@ -287,8 +287,10 @@ def test_mul_mat_empty(gpu):
     assert out.ne[:2] == [4, 0]
 
 
-@pytest.mark.parametrize("t", [O.Q4_K, O.Q8_0, O.Q4_0, O.Q4_1])
+@pytest.mark.parametrize("t", [O.Q4_K, O.Q8_0, O.Q4_0, O.Q4_1, O.Q5_K, O.Q6_K, O.Q2_K, O.Q3_K, O.Q5_0, O.Q5_1, O.IQ4_NL, O.MXFP4])
 def test_mul_mat_id(gpu, t):
+    """expert weights of every quantized type (Q4_K_M-style Mixtral files keep expert tensors in Q5_K / Q6_K; GPT-OSS experts are MXFP4): the tuned types through
+    mmvq / the decode mat-vec, the coverage types one grid slice per (token, slot) of gemv_kq.hip -- always vec_dot's one-column order"""
     K, N, E, U, Tk = 512, 40, 8, 2, 3
     w = rand_blocks(t, N * E, K, rng)
     for nb1 in (1, U):

@@ -169,8 +169,11 @@ def write_mixtral(path, cfg, wtype, seed=1234, n_expert=8, n_used=2, fast=False)
 
         gen = S.make_tensor_fast if fast else S.make_tensor        # fast: real-shape models (block bytes drawn directly)
 
+        mix = cfg.get("mix") or {}                                  # per-tensor types by name fragment (Q4_K_M-style files keep expert down projections in Q6_K): {".w2.": 14}
+
         def q(name, rows, K):
-            dump("model." + name if not name.startswith("lm_head") else name, wtype, [rows, K], gen("mixtral." + name, wtype, rows, K, seed))
+            t = next((v for k, v in mix.items() if k in name), wtype)
+            dump("model." + name if not name.startswith("lm_head") else name, t, [rows, K], gen("mixtral." + name, t, rows, K, seed))
 
         q("embed_tokens.weight", V, H)
         for i in range(cfg["n_layer"]):
