@@ -265,8 +265,8 @@ def dropin_through_the_boundary(mp, n_decode=144):
 
 def prefill_cfg3(pkg, model_name, n_prompt=4096, reps=3):
     """BASELINE cfg3: Q4_0 weights, one n_prompt-token prompt through the runner (cllm_llama_forward): median wall time and the algorithmic FLOPs of SURVEY 8d, in the default
-    mode (exact: the reference's accumulation order on the K = 4 / f32 matrix-core instructions, bit-identical to the CPU for every prompt length) and in the opt-in fast
-    mode (CLLM_PREFILL=fast: int8-MFMA GEMM + flash attention, tolerance tier)"""
+    mode (exact: the reference's accumulation order on the K = 4 / f32 matrix-core instructions, bit-identical to the CPU for every prompt length) and in the opt-in
+    modes (CLLM_PREFILL=fast: int8-MFMA GEMM + flash attention, tolerance tier; CLLM_PREFILL=f16: dequant -> fp16 MFMA GEMM, a different computation)"""
     cfg = pkg.synth.config(model_name, max_len=(n_prompt + 63) // 64 * 64)
     m = build_model(pkg, cfg, WTYPES["q4_0"], 0, 1)
     prompt = np.random.default_rng(1234).integers(0, cfg["vocab"], n_prompt).astype(np.int32)
@@ -276,8 +276,9 @@ def prefill_cfg3(pkg, model_name, n_prompt=4096, reps=3):
     lib = pkg.lib.get()
     out = {}
     default_mode = lib.cllm_get_prefill_mode()
-    for name, mode in (("exact", 1), ("fast", 0)):
+    for name, mode in (("exact", 1), ("fast", 0), ("f16", 0)):
         pkg.lib.check(lib.cllm_set_prefill_mode(mode), "set_prefill_mode")
+        lib.cllm_debug_set_prefill_f16(1 if name == "f16" else 0)          # f16: quantized weights x fp16 activations as a dense fp16 MFMA GEMM (dense_f16.hip), the north star's path B
         try:
             m.forward(prompt, n_past=0)
             pkg.ops.sync()
@@ -289,6 +290,7 @@ def prefill_cfg3(pkg, model_name, n_prompt=4096, reps=3):
                 ts.append(time.perf_counter() - t0)
         finally:
             lib.cllm_set_prefill_mode(default_mode)
+            lib.cllm_debug_set_prefill_f16(0)
         dt = sorted(ts)[len(ts) // 2]
         out[name] = {"ms": dt * 1e3, "tok_s": n_prompt / dt, "algorithmic_tflops": flops / dt / 1e12, "frac_of_f16_mfma_peak_2.5e15": flops / dt / 2.5e15, "frac_of_int8_mfma_peak_5e15": flops / dt / 5.0e15}
     m.close()
