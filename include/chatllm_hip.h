@@ -118,7 +118,7 @@ CLLM_API int    cllm_op_mul_mat(void * stream, const cllm_tensor * src0, const c
  *          weight block kind) and nothing else touched wdata since (several projections of one activation: q, k, v; gate, up); src1 gives the shape only
  *   epi 1: src0's rows alternate gate_u, up_u (cllm_pack_rows, interleave); dst F32 [N / 2, M] = silu(gate_u . x) * (up_u . x)   (MUL_MAT x 2 -> UNARY(SILU) -> MUL)
  *   resid != NULL (epi 0): ... -> ADD(resid)  (resid F32 of dst's shape; may be dst itself)
- * Only for src1->ne[1] >= the matrix-core threshold (33 columns; CLLM_E_UNSUPPORTED below it: the caller issues the nodes).  The fused quantizers and
+ * Only for src1->ne[1] >= cllm_mul_mat_ex_min_cols() (10 columns: where the exact-order GEMM beats the chunked mat-vec; CLLM_E_UNSUPPORTED below it: the caller issues the nodes).  The fused quantizers and
  * epilogues produce the bits of the separate RMS_NORM / MUL / SiLU / quantize / ADD passes. */
 CLLM_API int    cllm_mul_mat_ex_min_cols(void);
 /* How MUL_MAT with more than 32 activation columns and the prompt's attention block (cllm_op_attn_prefill, F16 MUL_MAT with > 32 columns) are computed:
