@@ -24,7 +24,7 @@ FUSED = [("qkv", 4096, 6144, 1, False), ("o", 4096, 4096, 2, True), ("gate_up", 
          ("lm_head", 4096, 128256, 1, False)]
 
 
-FUSED_Q72 = [("qkv", 8192, 10240, 1, False), ("o", 8192, 8192, 2, True), ("gate_up_silu", 8192, 59136, 1, False), ("down", 29568, 8192, 4, True),
+FUSED_Q72 = [("qkv", 8192, 10240, 1, False), ("o", 8192, 8192, 2, True), ("gate_up_silu", 8192, 59136, 1, False), ("down_q", 29568, 8192, 2, True),
              ("lm_head", 8192, 152064, 1, False)]       # Qwen2-72B (BASELINE cfg4): the one-GPU launches
 
 
