@@ -17,7 +17,9 @@ int launch_gemv_decode(hipStream_t st, int wtype, const void * W, int64_t K, int
         if (rc != CLLM_E_UNSUPPORTED) return rc;
     }
     if (wtype != CLLM_TYPE_Q4_K && !padd && !g_gemv_ts) {          // Q4_0 / Q4_1 / Q8_0: the LDS-staged one-lane-group-per-row form (gemv_rows32.hip)
-        const int rc = launch_gemv_rows32(st, wtype, W, K, nrows, pro, px, pw, eps, epi, dst, bias, resid);
+        int rc = launch_gemv_rows32(st, wtype, W, K, nrows, pro, px, pw, eps, epi, dst, bias, resid);
+        if (rc != CLLM_E_UNSUPPORTED) return rc;
+        rc = launch_gemv_team32(st, wtype, W, K, nrows, pro, px, pw, eps, epi, dst, bias, resid);      // few rows per CU: teams of waves per 8 rows (gemv_team32.hip)
         if (rc != CLLM_E_UNSUPPORTED) return rc;
     }
     if (K % kind || K > ((pro == 2 || pro == 4) ? 32768 : 16384) || pro < 1 || pro > 4 || nrows <= 0 || (uint64_t) nrows * (uint64_t) cllm_row_size(wtype, K) >= (1ull << 32)) return CLLM_E_UNSUPPORTED;

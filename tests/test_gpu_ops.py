@@ -166,6 +166,51 @@ def test_gemv_rows32_prologue_1_forms_equal_the_node_sequence(gpu, rows32_mode, 
     assert np.array_equal(out.numpy().reshape(-1).view(np.uint32), want.view(np.uint32))
 
 
+@pytest.fixture()
+def team32_mode(gpu):
+    """gemv_team32.hip: 0 = off, 4 / 5 / 8 / 16 = that many waves per team of 8 rows, 1 = the launcher's pick (few rows per CU only)"""
+    L = gpu.lib.get()
+
+    def set_mode(m):
+        L.cllm_debug_set_gemv_team32(int(m))
+    yield set_mode
+    L.cllm_debug_set_gemv_team32(1)
+    assert L.cllm_debug_gemv_team32_error() == 0, "a hand-off between the waves of a team timed out"
+
+
+@pytest.mark.parametrize("t", [O.Q4_0, O.Q8_0, O.Q4_1])
+@pytest.mark.parametrize("team", [1, 4, 5, 8, 16])
+@pytest.mark.parametrize("K,N", [(256, 8), (512, 64), (2112, 24), (4096, 1032), (4096, 4096), (14336, 96), (29568, 40), (1024, 20000)])
+def test_mul_mat_quant_gemv_every_team32_form(gpu, rows32_mode, team32_mode, t, team, K, N):
+    """the one-column mat-vec of the 32-block types through the team kernel (4 / 8 / 16 waves share 8 rows: emit waves -> LDS -> one chain wave): every output word is the oracle's;
+    one unit, ragged last steps, several units per team, more workgroups' worth of units than CUs"""
+    rows32_mode(0)
+    team32_mode(team)
+    got, want = _mm_case(gpu, t, K, N, 1)
+    assert np.array_equal(got.view(np.uint32).ravel(), want.view(np.uint32).ravel()), rel_err(got, want)
+
+
+@pytest.mark.parametrize("t", [O.Q4_0, O.Q8_0, O.Q4_1])
+@pytest.mark.parametrize("team", [1, 4, 5, 8, 16])
+@pytest.mark.parametrize("K,N,pro", [(4096, 4096, 1), (4096, 6144, 1), (14336, 4096, 4), (4096, 1024, 2), (8192, 8192, 1), (28672, 1024, 4), (1056, 200, 1), (512, 18000, 4)])
+def test_gemv_team32_fused_forms_equal_the_node_sequence(gpu, rows32_mode, team32_mode, t, team, K, N, pro):
+    """[RMS_NORM * weight | SiLU(gate) * up |] quantize -> mat-vec + residual in one launch of the team kernel == the node sequence through k_gemv_dec (the decode step's qkv / o / down shapes)"""
+    ops, T, L = gpu.ops, gpu.Tensor, gpu.lib.get()
+    w = T.from_numpy(rand_blocks(t, N, K, rng), t, [K, N])
+    x = T.from_numpy(rng.standard_normal((1, K)).astype(np.float32))
+    g = T.from_numpy((1 + 0.1 * rng.standard_normal((1, K))).astype(np.float32))
+    r = T.from_numpy(rng.standard_normal((1, N)).astype(np.float32))
+    rows32_mode(0)
+    team32_mode(0)
+    act = ops.rms_norm_mul(x, T.from_numpy(g.numpy().reshape(K)), 1e-5) if pro == 1 else ops.silu_mul(x, g) if pro == 4 else x
+    want = ops.add(ops.mul_mat(w, act), r).numpy().reshape(-1)
+    team32_mode(team)
+    out = T(gpu.F32, [N, 1])
+    cw = w.c()
+    gpu.lib.check(L.cllm_op_mul_mat_vec_fused(None, C.byref(cw), pro, x.data_ptr(), g.data_ptr() if pro != 2 else None, 1e-5, 0, r.data_ptr(), out.data_ptr()), "fused")
+    assert np.array_equal(out.numpy().reshape(-1).view(np.uint32), want.view(np.uint32))
+
+
 @pytest.mark.parametrize("t", [O.Q5_K, O.Q6_K])
 @pytest.mark.parametrize("K,N,M,ne02,ne12", [(256, 1, 1, 1, 1), (512, 7, 1, 1, 1), (4096, 130, 1, 1, 1), (2048, 64, 2, 1, 1), (1024, 33, 5, 1, 1), (1280, 24, 8, 1, 1), (768, 40, 9, 1, 1),
                                              (512, 19, 40, 1, 1), (256, 12, 3, 2, 4), (14336, 48, 1, 1, 1)])

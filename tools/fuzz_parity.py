@@ -69,12 +69,15 @@ def main():
         r = T.from_numpy(rng.standard_normal((1, N)).astype(np.float32))
         act = ops.rms_norm_mul(x, T.from_numpy(g.numpy().reshape(K)), 1e-5) if pro == 1 else ops.silu_mul(x, g) if pro == 4 else x
         L.cllm_debug_set_gemv_rows32(0)
+        L.cllm_debug_set_gemv_team32(0)
         want = ops.add(ops.mul_mat(w, act), r).numpy()
         L.cllm_debug_set_gemv_rows32(int(rng.choice([1, 1, 2, 4, 8])))
+        L.cllm_debug_set_gemv_team32(int(rng.choice([1, 1, 4, 5, 8, 16])))
         out = T(gpu.F32, [N, 1])
         cw = w.c()
         rc = L.cllm_op_mul_mat_vec_fused(None, C.byref(cw), pro, x.data_ptr(), g.data_ptr() if pro != 2 else None, 1e-5, 0, r.data_ptr(), out.data_ptr())
         L.cllm_debug_set_gemv_rows32(1)
+        L.cllm_debug_set_gemv_team32(1)
         note("fused mat-vec", rc == 0 and np.array_equal(out.numpy().view(np.uint32).ravel(), want.view(np.uint32).ravel()), f"type {t} K {K} N {N} pro {pro} rc {rc}")
 
     def mul_mat_id():
