@@ -34,7 +34,10 @@ __global__ void __launch_bounds__(1024) k_gemv_rows32(const float * __restrict__
     const int tid = threadIdx.x, lane = tid & 63;
     const int K = nblk * 32;
     const unsigned nb01 = (unsigned) nblk * (unsigned) BS;
-    constexpr bool NEED_C0 = !IS_Q8 && !IS_41;
+#ifndef R32_C0_PLANE
+#define R32_C0_PLANE 0                                 // 1: Q4_0's (-8, -8, -8, -8) . a per (block, AVX lane) from a plane the prologue leaves in LDS; 0: taken on the fly (the LDS pipe is the busy unit)
+#endif
+    constexpr bool IS_40 = !IS_Q8 && !IS_41, NEED_C0 = IS_40 && R32_C0_PLANE;
     const unsigned arb = (unsigned) act_row_bytes(K, IS_41 ? ACT_Q8_1 : ACT_Q8_0);      // the activation row; Q4_0: then K bytes of c0[block][AVX lane] (int32)
 
     // ---- (1) this thread's activation groups: loads issued before anything else (as k_gemv_dec) ----
@@ -101,7 +104,7 @@ __global__ void __launch_bounds__(1024) k_gemv_rows32(const float * __restrict__
             }
             if (PRO == 1) { const f32x4 g = gg[u]; v.x = (v.x * scale) * g.x; v.y = (v.y * scale) * g.y; v.z = (v.z * scale) * g.z; v.w = (v.w * scale) * g.w; }
             quant4_store<32, IS_41>(lds, K, e, lane, v);
-            if (!IS_Q8 && !IS_41) *(int *)(lds + arb + e) = dot4(0xf8f8f8f8u, *(const uint32_t *)(lds + e), 0);      // Q4_0: (nib - 8) . a = nib . a + c0, c0 = (-8, -8, -8, -8) . a per (block, AVX lane)
+            if (NEED_C0) *(int *)(lds + arb + e) = dot4(0xf8f8f8f8u, *(const uint32_t *)(lds + e), 0);      // Q4_0: (nib - 8) . a = nib . a + c0, c0 = (-8, -8, -8, -8) . a per (block, AVX lane)
         }
     }
     __syncthreads();
@@ -148,6 +151,10 @@ __global__ void __launch_bounds__(1024) k_gemv_rows32(const float * __restrict__
             } else {
                 r32_i4 c0 = {0, 0, 0, 0}, c1 = {0, 0, 0, 0};           // Q4_0: the prologue's c0 plane
                 if (NEED_C0) { c0 = *(const r32_i4 *)(act + arb + bb * 32); c1 = *(const r32_i4 *)(act + arb + bb * 32 + 16); }
+                else if (IS_40) {
+                    c0 = r32_i4{dot4(0xf8f8f8f8u, a0.x, 0), dot4(0xf8f8f8f8u, a0.y, 0), dot4(0xf8f8f8f8u, a0.z, 0), dot4(0xf8f8f8f8u, a0.w, 0)};
+                    c1 = r32_i4{dot4(0xf8f8f8f8u, a1.x, 0), dot4(0xf8f8f8f8u, a1.y, 0), dot4(0xf8f8f8f8u, a1.z, 0), dot4(0xf8f8f8f8u, a1.w, 0)};
+                }
                 s[0] = dot4(q0.x & 0x0f0f0f0fu, a0.x, c0.x); s[1] = dot4(q0.y & 0x0f0f0f0fu, a0.y, c0.y);
                 s[2] = dot4(q0.z & 0x0f0f0f0fu, a0.z, c0.z); s[3] = dot4(q0.w & 0x0f0f0f0fu, a0.w, c0.w);
                 s[4] = dot4((q0.x >> 4) & 0x0f0f0f0fu, a1.x, c1.x); s[5] = dot4((q0.y >> 4) & 0x0f0f0f0fu, a1.y, c1.y);
@@ -222,7 +229,7 @@ int launch_gemv_rows32(hipStream_t st, int wtype, const void * W, int64_t K, int
     if (!rpw) return CLLM_E_UNSUPPORTED;
     const int nunits = (int)(nrows / rpw);
     const int grid = (nunits + 15) / 16 < cus ? (nunits + 15) / 16 : cus;
-    const size_t lds = act_row_bytes(K, wtype == CLLM_TYPE_Q4_1 ? ACT_Q8_1 : ACT_Q8_0) + (wtype == CLLM_TYPE_Q4_0 ? (size_t) K : 0) + 16 * (size_t) R32_REC_BYTES;
+    const size_t lds = act_row_bytes(K, wtype == CLLM_TYPE_Q4_1 ? ACT_Q8_1 : ACT_Q8_0) + ((wtype == CLLM_TYPE_Q4_0 && R32_C0_PLANE) ? (size_t) K : 0) + 16 * (size_t) R32_REC_BYTES;
     if (lds > 159 * 1024) return CLLM_E_UNSUPPORTED;
     const int npre = K <= 4096 ? 1 : K <= 16384 ? 4 : 8;
 #define GOR(FMT_, PRO_, EPI_, NPRE_, RPW_) do { \

@@ -18,10 +18,11 @@
 #include "q32.h"
 
 // weight steps in flight per emit wave (requested before the prologue, which lasts about as long as the whole matrix takes to stream)
-#ifndef T32_P
-#define T32_P 3                                        // (6 in flight: the flood of weight requests delays the prologue's own loads and instruction fetches by more than the loop gains -- measured)
+// weight steps in flight per emit wave
+#define T32_P_OF(FMT_, NPRE_) 3                       // (6 / 4 for Q4_0 / Q8_0, with or without T32_ACT_FIRST: the prologue barrier comes 0.6-1.6 us later, the launch 1.5-2 us -- measured)
+#ifndef T32_ACT_FIRST
+#define T32_ACT_FIRST 0                                // 1: the weight requests go out only once the wave's activation groups have landed (slower: measured)
 #endif
-#define T32_P_OF(FMT_, NPRE_) T32_P
 typedef int t32_i4 __attribute__((ext_vector_type(4)));
 #define T32_SLOT_BYTES (64 * 9 * 4 + 2 * 256)          // one step's records: [row r][slot j or d][t] floats (8 x 9 x 8), then Q4_1's m_w[64], s_a[64]
 #define T32_SPINS (1 << 20)
@@ -36,14 +37,14 @@ struct t32_rec { f32x4 x0, x1, d0, d1, m0, m1, s0, s1; };
 template <int FMT, int PRO, int NPRE>
 __global__ void __launch_bounds__(1024) k_gemv_team32(const float * __restrict__ px, const float * __restrict__ pw, const char * __restrict__ W, int nblk, int nunits, float eps,
                                                       float * __restrict__ dst, const float * __restrict__ bias, const float * resid, int team /* waves per team: 4, 5, 8, 16 */,
-                                                      unsigned * __restrict__ err, int dbg, unsigned long long * ts) {
+                                                      unsigned * __restrict__ err, unsigned long long * ts) {
 #define T32_TS(k) do { if (ts && (threadIdx.x & 63) == 0) ts[(blockIdx.x * 16 + (threadIdx.x >> 6)) * 4 + (k)] = wall_clock64(); } while (0)
     T32_TS(0);
     extern __shared__ __attribute__((aligned(16))) char lds[];
-    __shared__ unsigned sy[4][4];                                      // per team: [0], [1] arrivals of the round of that parity, [2] rounds consumed by the chain wave
+    __shared__ unsigned sy[20];                                        // [wave] the rounds this emit wave has handed over; [16 + team] the rounds the team's chain wave has consumed
     constexpr bool IS_Q8 = FMT == CLLM_TYPE_Q8_0, IS_41 = FMT == CLLM_TYPE_Q4_1;
     constexpr int BS = q32_fmt<FMT>::BS, P = T32_P_OF(FMT, NPRE);
-    constexpr bool NEED_C0 = !IS_Q8 && !IS_41;
+    constexpr bool NEED_C0 = !IS_Q8 && !IS_41;                         // Q4_0's (nib - 8) . a = nib . a + c0: c0 = (-8, -8, -8, -8) . a per (block, AVX lane), a plane the prologue leaves behind the row
     const int tid = threadIdx.x, lane = tid & 63;
     const int K = nblk * 32;
     const unsigned nb01 = (unsigned) nblk * (unsigned) BS;
@@ -60,7 +61,7 @@ __global__ void __launch_bounds__(1024) k_gemv_team32(const float * __restrict__
         vv[u] = *(const f32x4 *)(px + ec * vmul);
         if (PRO != 2) gg[u] = *(const f32x4 *)(gp + ec * vmul);
     }
-    if (tid < 16) t32_lds_store(&sy[0][0] + tid, 0u);
+    if (tid < 20) t32_lds_store(&sy[0] + tid, 0u);
 
     // ---- (2) roles.  Team q = wave / team (waves past the last whole team idle); the wave of the team that sits on SIMD q & 3 chains, the others emit.
     //          The team's units: u0 + ustride * k ----
@@ -69,7 +70,7 @@ __global__ void __launch_bounds__(1024) k_gemv_team32(const float * __restrict__
     const int cr = (q * (65 - team)) & 3;                              // (q team + cr) & 3 == q & 3
     const bool in_team = q < nteams, is_emit = in_team && wr != cr;      // (the team's wave wr == cr chains)
     const int em = wr < cr ? wr : wr - 1;                              // emit index 0 .. E - 1
-    const int S = (nblk + 7) >> 3;                                     // steps of 8 blocks per unit
+    const int S = (nblk + 7) >> 3;                                     // steps of 8 blocks per unit (S >= E: launcher); the blocks past a row's end in its last step are masked
     const int ustride = nteams * gridDim.x, u0 = q * gridDim.x + blockIdx.x;
     const int nmine = (in_team && u0 < nunits) ? (nunits - u0 + ustride - 1) / ustride : 0;
     const int total = nmine * S;                                       // the team's step sequence: g = k * S + s; round R = steps R E .. R E + E - 1, one per emit wave
@@ -77,25 +78,32 @@ __global__ void __launch_bounds__(1024) k_gemv_team32(const float * __restrict__
     const bool odd = !IS_41 && (t & 1);                                // rows are whole dwords: a block starts in the upper half of its first dword exactly when its index is odd
     const uint32_t psel = odd ? 0x07060504u : 0x05040302u;
     const unsigned lane_off = (unsigned) r * nb01 + (unsigned) t * BS - (odd ? 2u : 0u);
-    // The emit loop below is kept free of control flow (waits and the masked LDS atomic are asm blocks, the cursors advance by selects, the trip counts are fixed
-    // up front): with branches in the body the compiler rotates the ring of loaded registers through copies behind a full vmcnt(0) wait -- one step in flight instead of P.
+    // The kernel is bound by the number of instructions its waves issue (every kind: the SIMDs issue about one per four cycles across their waves -- profiles/r03_team32_*),
+    // so the emit loop carries its cursors as running offsets (one add and a select per step) and has no control flow: waits are asm
+    // blocks, trip counts are fixed up front -- with branches in the body the compiler rotates the ring of loaded registers through copies behind a full vmcnt(0).
     u32x4 qa[P], qb[IS_Q8 ? P : 1];
     uint32_t qt[P];
-    int ig = em, ik = 0, is = em;                                      // issue cursor: team step number = ik S + is (S >= E: launcher)
-    auto issue = [&](int p) {                                          // unconditional: out-of-range lanes re-read the unit's first block and are masked
-        const bool in = ig < total, ok = in && 8 * is + t < nblk;
-        const int unit = in ? u0 + ik * ustride : (u0 < nunits ? u0 : 0);
-        const char * bp = W + ((unsigned) unit * (8u * nb01) + (ok ? lane_off + (unsigned)(8 * is) * BS : 0u));      // (the matrix is smaller than 4 GiB: launcher)
+    const unsigned dA = (unsigned) E * 8u * BS, dB = (unsigned) ustride * 8u * nb01 - (unsigned)(S - E) * 8u * BS;      // to the wave's next step: inside the unit / into the team's next unit
+    unsigned woff = (unsigned)(u0 < nunits ? u0 : 0) * (8u * nb01) + lane_off + (unsigned) em * 8u * BS;                // this lane's block of the wave's next requested step
+    const unsigned woff0 = woff;
+    int is = em;                                                       // its step inside the unit
+    int irem = (is_emit && em < total) ? (total - em + E - 1) / E : 0; // steps the wave has still to request (past the last: the first once more, never used)
+    auto issue = [&](int p) {
+        const unsigned o = irem > 0 ? woff : woff0;
+        irem--;
+        const char * bp = W + o;                                       // (the matrix is smaller than 4 GiB: launcher)
         if (IS_41) { qt[p] = *(const uint32_t *) bp; qa[p] = *(const u32x4 *)(bp + 4); }
         else {
             qa[p] = *(const u32x4 *) bp;
             if (IS_Q8) { qb[IS_Q8 ? p : 0] = *(const u32x4 *)(bp + 16); qt[p] = *(const uint32_t *)(bp + 32); }
             else qt[p] = *(const uint32_t *)(bp + 16);
         }
-        ig += E; is += E;
+        is += E;
         const bool wrap = is >= S;
-        is = wrap ? is - S : is; ik = wrap ? ik + 1 : ik;
+        is = wrap ? is - S : is;
+        woff += wrap ? dB : dA;
     };
+    if (T32_ACT_FIRST) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (is_emit) {
 #pragma unroll
         for (int p = 0; p < P; p++) issue(p);
@@ -125,7 +133,7 @@ __global__ void __launch_bounds__(1024) k_gemv_team32(const float * __restrict__
             }
             if (PRO == 1) { const f32x4 g = gg[u]; v.x = (v.x * scale) * g.x; v.y = (v.y * scale) * g.y; v.z = (v.z * scale) * g.z; v.w = (v.w * scale) * g.w; }
             quant4_store<32, IS_41>(lds, K, e, lane, v);
-            if (!IS_Q8 && !IS_41) *(int *)(lds + arb + e) = dot4(0xf8f8f8f8u, *(const uint32_t *)(lds + e), 0);      // Q4_0: (nib - 8) . a = nib . a + c0, c0 = (-8, -8, -8, -8) . a per (block, AVX lane)
+            if (NEED_C0) *(int *)(lds + arb + e) = dot4(0xf8f8f8f8u, *(const uint32_t *)(lds + e), 0);      // Q4_0: (nib - 8) . a = nib . a + c0, c0 = (-8, -8, -8, -8) . a per (block, AVX lane)
         }
     }
     __syncthreads();
@@ -137,29 +145,38 @@ __global__ void __launch_bounds__(1024) k_gemv_team32(const float * __restrict__
     const float * actd = (const float *)(lds + act_off_d(K));
     const float * acts = (const float *)(lds + act_off_s(K, IS_41 ? ACT_Q8_1 : ACT_Q8_0));
     char * slots = lds + arb + (NEED_C0 ? K : 0);                      // [wave][2][T32_SLOT_BYTES]
-    unsigned * cnt = &sy[q][0], * done = &sy[q][2];
+    unsigned * done = &sy[16 + q];
 
     if (is_emit) {
         // ---- (3) emit: this wave's step of every round, records into its own two slots ----
-        int cs = em, R = 0;                                            // step of its unit of the wave's next step, round
-        unsigned tmo = 0;                                              // sticky: a wait has timed out (reported once, at the end; later waits are skipped)
-        const unsigned done_a = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned *) done, cnt_a = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned *) cnt;
-        const unsigned one = 1u;
+        typedef __attribute__((address_space(3))) char * lds_p;
+        const unsigned done_a = (unsigned)(size_t)(lds_p)(char *) done;
+        unsigned flag_a = (unsigned)(size_t)(lds_p)(char *) &sy[wave];
+        unsigned nspin = 0;                                            // all the wave's waits together are bounded: past the bound they fall through and the error word is raised
+        int need = -1;                                                 // the slot of this parity is free once the chain wave has consumed round R - 2: done >= R - 1
+        unsigned stamp = 1u;                                           // R + 1
+        typedef __attribute__((address_space(3))) float * lds_f;
+        const unsigned rec0 = (unsigned)(size_t)(lds_p)(slots + (size_t)(wave * 2) * T32_SLOT_BYTES) + (unsigned)(r * 72 + t) * 4u;
+        unsigned rec = rec0;                                           // this lane's record column of the slot of round R (LDS address): X[slot * 8], X[64] = d_w d_x
+        const unsigned rec_x = rec0 ^ (rec0 + (unsigned) T32_SLOT_BYTES), m_off = (unsigned)(64 * 9 + lane - (r * 72 + t)) * 4u;      // (to the other slot; to Q4_1's m_w[lane])
+        int cs = em;                                                   // step of its unit of the wave's next step
         // the activation blocks of a step are read one step ahead (registers): the LDS latency stays off the step's dependency chain
-        u32x4 a0n, a1n; t32_i4 c0n = {0, 0, 0, 0}, c1n = {0, 0, 0, 0}; float ydn, ysn = 0.0f;
+        u32x4 a0n, a1n; t32_i4 c0n = {0, 0, 0, 0}, c1n = {0, 0, 0, 0}; float ydn, ysn = 0.0f; unsigned dnn = 0;
+        const char * act_t = act + t * 32;
+        const float * actd_t = actd + t, * acts_t = acts + t;
         auto act_fetch = [&](int s_next) {
-            const int b = 8 * s_next + t, bb = b < nblk ? b : 0;
-            a0n = *(const u32x4 *)(act + bb * 32); a1n = *(const u32x4 *)(act + bb * 32 + 16);
-            ydn = actd[bb];
-            if (IS_41) ysn = acts[bb];
-            if (NEED_C0) { c0n = *(const t32_i4 *)(act + arb + bb * 32); c1n = *(const t32_i4 *)(act + arb + bb * 32 + 16); }
+            const char * ab = act_t + s_next * 256;
+            a0n = *(const u32x4 *) ab; a1n = *(const u32x4 *)(ab + 16);
+            ydn = actd_t[s_next * 8];
+            if (IS_41) ysn = acts_t[s_next * 8];                       // (past the row's end: masked below together with m_w)
+            if (NEED_C0) { c0n = *(const t32_i4 *)(ab + arb); c1n = *(const t32_i4 *)(ab + arb + 16); }
+            dnn = t32_lds_load(done);
         };
         act_fetch(cs);
         auto step = [&](int p) {
-            // (ordered behind the previous step's asm blocks: otherwise the scheduler lifts the first uses of all P ring entries to the top of the loop body -- a full wait again)
+            // (ordered behind the previous step's asm block: otherwise the scheduler lifts the first uses of all P ring entries to the top of the loop body -- a full wait again)
             if (IS_Q8) asm volatile("" : "+v"(qa[p]), "+v"(qb[IS_Q8 ? p : 0]), "+v"(qt[p]));
             else       asm volatile("" : "+v"(qa[p]), "+v"(qt[p]));
-            const bool ok = 8 * cs + t < nblk;
             uint32_t h; u32x4 q0, q1 = {0, 0, 0, 0};
             if (IS_41) { h = qt[p]; q0 = qa[p]; }
             else {
@@ -172,10 +189,16 @@ __global__ void __launch_bounds__(1024) k_gemv_team32(const float * __restrict__
                     q1 = u32x4{pm(c.y, c.x), pm(c.z, c.y), pm(c.w, c.z), pm(qt[p], c.w)};
                 } else q0 = u32x4{pm(a.y, a.x), pm(a.z, a.y), pm(a.w, a.z), pm(qt[p], a.w)};
             }
+            // (the request that refills ring entry p is ordered behind the last uses of its old contents: their live ranges must not overlap, or the ring is
+            //  rotated through copies at the loop's end -- behind waits for every load in flight)
+            if (IS_Q8) asm volatile("" : "+v"(woff) : "v"(q0), "v"(q1), "v"(h));
+            else       asm volatile("" : "+v"(woff) : "v"(q0), "v"(h));
             issue(p);
             const u32x4 a0 = a0n, a1 = a1n; const t32_i4 c0 = c0n, c1 = c1n; const float yd = ydn, ys = ysn;
-            const int csn = cs + E >= S ? cs + E - S : cs + E;
-            act_fetch(csn);
+            unsigned dn = dnn;
+            const bool ok = t < nblk - 8 * cs;
+            cs += E; cs = cs >= S ? cs - S : cs;
+            act_fetch(cs);
             int sm[8];
             if (IS_Q8) {
                 sm[0] = dot4(q0.x, a0.x, 0); sm[1] = dot4(q0.y, a0.y, 0); sm[2] = dot4(q0.z, a0.z, 0); sm[3] = dot4(q0.w, a0.w, 0);
@@ -186,40 +209,30 @@ __global__ void __launch_bounds__(1024) k_gemv_team32(const float * __restrict__
                 sm[4] = dot4((q0.x >> 4) & 0x0f0f0f0fu, a1.x, c1.x); sm[5] = dot4((q0.y >> 4) & 0x0f0f0f0fu, a1.y, c1.y);
                 sm[6] = dot4((q0.z >> 4) & 0x0f0f0f0fu, a1.z, c1.z); sm[7] = dot4((q0.w >> 4) & 0x0f0f0f0fu, a1.w, c1.w);
             }
-            // the slot of this parity is free once the chain wave has consumed round R - 2: wait for done >= R - 1 (bounded; rounds 0 and 1: done >= 0)
-            {
-                const unsigned need = __builtin_amdgcn_readfirstlane(R >= 2 ? (unsigned)(R - 1) : 0u), skip = __builtin_amdgcn_readfirstlane(tmo | (unsigned)(dbg & 1));
-                unsigned v, n;
-                asm volatile("s_mov_b32 %1, 0\n\t"
-                             "s_cmp_lg_u32 %4, 0\n\t"
-                             "s_cbranch_scc1 2f\n"
-                             "1:\n\t"
-                             "ds_read_b32 %0, %2\n\t"
-                             "s_waitcnt lgkmcnt(0)\n\t"
-                             "v_cmp_le_u32 vcc, %3, %0\n\t"
-                             "s_cbranch_vccnz 2f\n\t"
-                             "s_sleep 1\n\t"
-                             "s_add_u32 %1, %1, 1\n\t"
-                             "s_cmp_lt_u32 %1, 0x100000\n\t"
-                             "s_cbranch_scc1 1b\n"
-                             "2:"
-                             : "=&v"(v), "=&s"(n) : "v"(done_a), "s"(need), "s"(skip) : "vcc", "scc", "memory");
-                tmo |= n >= 0x100000u ? 1u : 0u;
-            }
-            float * rec = (float *)(slots + (size_t)(wave * 2 + (R & 1)) * T32_SLOT_BYTES);
-            float * X = rec + r * 72 + t;                              // slot of AVX lane A = 4(A&1) + (A&2) + (A>>2): [A0 A4 A2 A6 | A1 A5 A3 A7] (the hsum below)
+            // wait for done >= need (the value read a step ahead usually says so already)
+            asm volatile("v_cmp_le_i32 vcc, %[need], %[dn]\n\t"
+                         "s_cbranch_vccnz 2f\n"
+                         "1:\n\t"
+                         "s_sleep 1\n\t"
+                         "ds_read_b32 %[dn], %[addr]\n\t"
+                         "s_add_u32 %[n], %[n], 1\n\t"
+                         "s_waitcnt lgkmcnt(0)\n\t"
+                         "v_cmp_le_i32 vcc, %[need], %[dn]\n\t"
+                         "s_cbranch_vccnz 2f\n\t"
+                         "s_cmp_lt_u32 %[n], 0x100000\n\t"
+                         "s_cbranch_scc1 1b\n"
+                         "2:"
+                         : [dn] "+v"(dn), [n] "+s"(nspin) : [need] "s"(need), [addr] "v"(done_a) : "vcc", "scc", "memory");
+            lds_f X = (lds_f)(size_t) rec;                             // slot of AVX lane A = 4(A&1) + (A&2) + (A>>2): [A0 A4 A2 A6 | A1 A5 A3 A7] (the hsum below)
             X[0 * 8] = (float) sm[0]; X[1 * 8] = (float) sm[4]; X[2 * 8] = (float) sm[2]; X[3 * 8] = (float) sm[6];
             X[4 * 8] = (float) sm[1]; X[5 * 8] = (float) sm[5]; X[6 * 8] = (float) sm[3]; X[7 * 8] = (float) sm[7];
-            X[8 * 8] = ok ? h2f((uint16_t) h) * yd : 0.0f;            // a masked block: fma(0, finite, acc) = acc
-            if (IS_41) { float * M = rec + 64 * 9; M[lane] = ok ? h2f((uint16_t)(h >> 16)) : 0.0f; M[64 + lane] = ys; }
-            // the arrival is counted behind the records in this wave's LDS instruction stream (the LDS executes a wave's instructions in order): no wait in between.
-            // One lane adds (exec = 1 around the instruction).
-            {
-                unsigned long long save;
-                asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, 1\n\tds_add_u32 %1, %2\n\ts_mov_b64 exec, %0"
-                             : "=&s"(save) : "v"(cnt_a + 4u * (unsigned)(R & 1)), "v"(one) : "memory");
-            }
-            cs = csn; R++;
+            X[8 * 8] = ok ? h2f((uint16_t) h) * yd : 0.0f;            // a block past the row's end: fma(0, finite, acc) = acc
+            if (IS_41) { lds_f M = (lds_f)(size_t)(rec + m_off); M[0] = ok ? h2f((uint16_t)(h >> 16)) : 0.0f; M[64] = ok ? ys : 0.0f; }
+            // the round goes to the chain wave: this wave's flag word = rounds handed over, written behind the records in the wave's LDS instruction stream
+            // (the LDS executes a wave's instructions in order: no wait in between; every lane writes the same word)
+            asm volatile("ds_write_b32 %0, %1" :: "v"(flag_a), "v"(stamp) : "memory");
+            rec ^= rec_x;
+            stamp += 1u; need += 1;
         };
         const int n_mine = em < total ? (total - em + E - 1) / E : 0, nfull = n_mine / P, ntail = n_mine - nfull * P;
         for (int gi = 0; gi < nfull; gi++) {                           // whole rotations of the prefetch ring
@@ -228,7 +241,7 @@ __global__ void __launch_bounds__(1024) k_gemv_team32(const float * __restrict__
         }
 #pragma unroll
         for (int p = 0; p < P - 1; p++) if (p < ntail) step(p);        // (wave-uniform)
-        if (tmo && lane == 0) atomicOr(err, 1u);
+        if (nspin >= 0x100000u && lane == 0) atomicOr(err, 1u);
         T32_TS(2);
         if (ts && lane == 0) ts[(blockIdx.x * 16 + wave) * 4 + 3] = clock64() - cyc1;
         return;
@@ -289,15 +302,21 @@ __global__ void __launch_bounds__(1024) k_gemv_team32(const float * __restrict__
         }
     };
     const int nrounds = (total + E - 1) / E;
+    const int fle = lane < E ? lane : E - 1;
     t32_rec A, B, Cc;
     epi_fetch(0);
     for (int R = 0, g0 = 0; R < nrounds; R++, g0 += E) {
         const int nR = total - g0 < E ? total - g0 : E, par = R & 1, last = nR - 1;
-        if (!dead && !(dbg & 1)) {
+        if (!dead) {                                                   // every emit wave of the round has handed over (its flag word = rounds handed over >= R + 1): lane e looks at wave e's
+            const unsigned * fl = &sy[wbase + (fle < cr ? fle : fle + 1)];
             int spins = 0;
-            while (t32_lds_load(cnt + par) != (unsigned) nR) { __builtin_amdgcn_s_sleep(1); if (++spins > T32_SPINS) { if (lane == 0) atomicOr(err, 2u); dead = true; break; } }
+            while (true) {
+                const unsigned v = t32_lds_load(fl);
+                if (!__builtin_amdgcn_ballot_w64(lane < nR && v < (unsigned)(R + 1))) break;
+                __builtin_amdgcn_s_sleep(1);
+                if (++spins > T32_SPINS) { if (lane == 0) atomicOr(err, 2u); dead = true; break; }
+            }
         }
-        if (lane == 0) t32_lds_store(cnt + par, 0u);                   // nobody counts into this parity again before `done` says so
         if (DEPTH == 3) {
             fetch(A, 0, par); fetch(B, last < 1 ? last : 1, par);      // (past the round's end: the last step once more, never used)
             for (int e = 0; e < nR; e += 3) {
@@ -356,11 +375,10 @@ int launch_gemv_team32(hipStream_t st, int wtype, const void * W, int64_t K, int
     if (lds > 158 * 1024) return CLLM_E_UNSUPPORTED;
     if (!g_t32_err) { HIP_TRY(hipMalloc((void **) &g_t32_err, 4)); HIP_TRY(hipMemset(g_t32_err, 0, 4)); }
     const int npre = K <= 4096 ? 1 : K <= 16384 ? 4 : 8;
-    static const int dbg = getenv("CLLM_TEAM32_DBG") ? atoi(getenv("CLLM_TEAM32_DBG")) : 0;
 #define GOT(FMT_, PRO_, NPRE_) do { \
         static bool attr = false; \
         if (!attr) { HIP_TRY(hipFuncSetAttribute((const void *) k_gemv_team32<FMT_, PRO_, NPRE_>, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024)); attr = true; } \
-        hipLaunchKernelGGL((k_gemv_team32<FMT_, PRO_, NPRE_>), dim3((unsigned) grid), dim3(1024), lds, st, px, pw, (const char *) W, nblk, nunits, eps, dst, bias, resid, team, g_t32_err, dbg, g_t32_ts); } while (0)
+        hipLaunchKernelGGL((k_gemv_team32<FMT_, PRO_, NPRE_>), dim3((unsigned) grid), dim3(1024), lds, st, px, pw, (const char *) W, nblk, nunits, eps, dst, bias, resid, team, g_t32_err, g_t32_ts); } while (0)
 #define GOP(FMT_) do { \
         if (pro == 1)      { if (npre == 1) GOT(FMT_, 1, 1); else GOT(FMT_, 1, 4); } \
         else if (pro == 2) { if (npre == 1) GOT(FMT_, 2, 1); else if (npre == 4) GOT(FMT_, 2, 4); else GOT(FMT_, 2, 8); } \
