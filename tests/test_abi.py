@@ -57,3 +57,20 @@ def test_product_package_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp")):
                 txt = open(os.path.join(dirpath, f), errors="ignore").read()
                 assert "liboracle" not in txt and "ggml_oracle" not in txt and "import oracle" not in txt, os.path.join(dirpath, f)
+
+
+def test_kernels_with_hand_issued_loads_do_not_spill():
+    """gemv_team32.hip issues the chain wave's LDS reads by asm and waits for them by count: a register of such a read must never be spilled or copied while the
+    read is in flight.  The allocator keeps them in place as long as nothing spills -- every instantiation must report 0 spilled registers and no scratch."""
+    import shutil
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        import pytest
+        pytest.skip("no hipcc")
+    src = os.path.join(ROOT, "chatllm.cpp_amd", "csrc", "gemv_team32.hip")
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-fvisibility=hidden", "-mllvm", "-amdgpu-kernarg-preload-count=16",
+           "--cuda-device-only", "-c", src, "-o", os.devnull, "-Rpass-analysis=kernel-resource-usage"]
+    out = subprocess.run(cmd, capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr[-2000:]
+    spills = re.findall(r"VGPRs Spill: (\d+)", out.stderr) + re.findall(r"SGPRs Spill: (\d+)", out.stderr) + re.findall(r"ScratchSize \[bytes/lane\]: (\d+)", out.stderr)
+    assert len(spills) >= 3 * 30 and all(int(x) == 0 for x in spills), sorted(set(spills))

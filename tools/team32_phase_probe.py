@@ -42,6 +42,10 @@ for tname, t in (("q4_0", 2), ("q8_0", 8)):
         L.cllm_stream_sync(None)
         st = host.reshape(NW, 4).astype(np.int64)
         st = st[st[:, 0] > 0]
+        if not len(st):
+            print(f"{tname} {name:8s} K={K} N={N} pro={pro}  avg launch {us.value:.2f} us: not a team-kernel launch (the launcher's pick)")
+            del ws
+            continue
         base = st[:, 0].min()
         print(f"{tname} {name:8s} K={K} N={N} pro={pro}  avg launch {us.value:.2f} us (with stamps), {len(st)} waves stamped")
         for k, lab in enumerate(["entry", "prologue barrier", "loop done"]):
