@@ -313,6 +313,31 @@ def test_fused_decode_path_is_bit_identical_to_the_node_by_node_path(gpu, wtype,
     b.close()
 
 
+@pytest.mark.parametrize("wtype", [O.Q4_0, O.Q8_0, O.Q4_1])
+@pytest.mark.parametrize("team,over", [(4, {}), (5, dict(qkv_bias=1, rope_mode=2, rope_theta=1e6)), (4, dict(ffn=2848))])
+def test_fused_decode_through_the_team_kernel_is_bit_identical_to_the_node_path(gpu, wtype, team, over):
+    """the decode step's qkv (+ bias), o and down (+ residual, in place) mat-vecs through gemv_team32.hip (forced: the launcher picks it for larger shapes only), every
+    other launch as usual: same logits, bit for bit, as the node-by-node path -- whole steps and a ragged last step (ffn = 2848: 89 blocks)"""
+    L = gpu.lib.get()
+    cfg = gpu.synth.config("small", max_len=64, **over)
+    w = gpu.synth.make_model(cfg, wtype, seed=14)
+    a, b = gpu.Llama(cfg, w), gpu.Llama(cfg, w)
+    prompt = np.random.default_rng(14).integers(0, cfg["vocab"], 7).astype(np.int32)
+    assert np.array_equal(a.forward(prompt), b.forward(prompt))
+    try:
+        for t in np.random.default_rng(15).integers(0, cfg["vocab"], 12):
+            L.cllm_debug_set_gemv_team32(0)
+            la = a.forward([int(t)])
+            L.cllm_debug_set_gemv_team32(team)
+            lb = b.decode_fused_logits(int(t))
+            assert np.array_equal(la, lb)
+    finally:
+        L.cllm_debug_set_gemv_team32(1)
+    assert L.cllm_debug_gemv_team32_error() == 0
+    a.close()
+    b.close()
+
+
 @pytest.mark.parametrize("hd_cfg", ["tiny", "small"])
 def test_fused_decode_at_long_context_vs_the_node_path(gpu, hd_cfg):
     """the one-launch attention (up to CLLM_ATTN_LONG cached positions) and the split attention beyond it (attn_long.hip: scores / soft_max / V.P launches over

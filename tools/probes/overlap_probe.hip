@@ -38,12 +38,12 @@ __global__ void __launch_bounds__(1024) k_stage(const char * __restrict__ W, siz
     ((unsigned *) lds)[tid] = pre[0].x;
     __syncthreads();
     unsigned acc = pre[0].x ^ pre[1].y ^ pre[2].z ^ ((unsigned *) lds)[(tid + 1) & 1023];
-    for (size_t i = (size_t) tid + 3 * 1024; i < nvec; i += 4096) {
-        u32x4 v[4];
+    for (size_t i = (size_t) tid + 3 * 1024; i < nvec; i += 8192) {
+        u32x4 v[8];
 #pragma unroll
-        for (int u = 0; u < 4; u++) { const size_t j = i + (size_t) u * 1024; v[u] = *(const u32x4 *)(base + (j < nvec ? j : 0) * 16); }
+        for (int u = 0; u < 8; u++) { const size_t j = i + (size_t) u * 1024; v[u] = __builtin_nontemporal_load((const u32x4 *)(base + (j < nvec ? j : 0) * 16)); }
 #pragma unroll
-        for (int u = 0; u < 4; u++) acc ^= v[u].x + v[u].y + v[u].z + v[u].w;
+        for (int u = 0; u < 8; u++) acc ^= v[u].x + v[u].y + v[u].z + v[u].w;
     }
     if (acc == 0x12345678u) out[tid] = acc;
     __syncthreads();
@@ -62,7 +62,8 @@ int main(int argc, char ** argv) {
     CHECK(hipFuncSetAttribute((const void *) k_stage, hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024));
     hipStream_t s[2]; CHECK(hipStreamCreateWithFlags(&s[0], hipStreamNonBlocking)); CHECK(hipStreamCreateWithFlags(&s[1], hipStreamNonBlocking));
     hipEvent_t e0, e1, ej; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1)); CHECK(hipEventCreate(&ej));
-    for (int mode = 0; mode < 2; mode++) for (int rep = 0; rep < 2; rep++) {
+    const int nmodes = argc > 3 ? atoi(argv[3]) : 2;
+    for (int mode = 0; mode < nmodes; mode++) for (int rep = 0; rep < 2; rep++) {
         CHECK(hipMemset(ctr, 0, 8)); CHECK(hipDeviceSynchronize());
         CHECK(hipEventRecord(e0, s[0]));
         if (mode == 1) { CHECK(hipStreamWaitEvent(s[1], e0, 0)); }
