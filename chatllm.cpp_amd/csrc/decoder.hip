@@ -555,6 +555,7 @@ static int decode_step_fused(cllm_llama * m, bool sample, bool long_ctx) {
 
 // after a synchronize: did a barrier of the persistent launch time out?  (it winds the kernel down instead of hanging the GPU; the step's results are void)
 static int persist_check(cllm_llama * m) {
+    TRY(gemv_team32_check());                                          // (the same kind of bounded wait inside a workgroup: gemv_team32.hip)
     if (!m->persist_used) return CLLM_OK;
     unsigned phase = 0;
     TRY(decode_layers_error(m->persist_state, &phase));

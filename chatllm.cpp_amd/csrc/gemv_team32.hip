@@ -349,6 +349,15 @@ extern "C" __attribute__((visibility("default"))) int cllm_debug_gemv_team32_err
     return (int) e;
 }
 
+// after a synchronize: did a hand-off between the waves of a team time out?  (the launch winds down instead of hanging; its results are void)
+int gemv_team32_check() {
+    if (!g_t32_err) return CLLM_OK;                                    // never launched
+    unsigned e = 0;
+    HIP_TRY(hipMemcpy(&e, g_t32_err, 4, hipMemcpyDeviceToHost));
+    if (e) FAIL(CLLM_E_HIP, "gemv_team32: a hand-off between the waves of a workgroup timed out (code %u); set CLLM_GEMV_TEAM32=0", e);
+    return CLLM_OK;
+}
+
 // K % 32 == 0, rows whole dwords, nrows % 8 == 0, one unit (8 rows) per team; CLLM_E_UNSUPPORTED: the caller's other kernels take the launch
 int launch_gemv_team32(hipStream_t st, int wtype, const void * W, int64_t K, int64_t nrows, int pro, const float * px, const float * pw, float eps, int epi, float * dst,
                        const float * bias, const float * resid) {
