@@ -68,7 +68,11 @@ __global__ void __launch_bounds__(1024) k_gemv_rows32(const float * __restrict__
     int iu = 0, is = 0;
     auto issue = [&](int p) {                                          // unconditional: out-of-range lanes re-read the unit's first block and are masked
         const bool ok = iu < nmine && LPR * is + t < nblk;
+#ifdef R32_FAKE_COALESCED        /* timing experiment only (wrong results): every lane 16 contiguous, aligned bytes of the step's region */
+        const char * bp = W + (size_t)(unsigned)(ok ? u0 + iu * ustride : u0 < nunits ? u0 : 0) * (size_t)(RPW * nb01) + (ok ? (unsigned)(is * 1152 + lane * 16) : 0u);
+#else
         const char * bp = W + (size_t)(unsigned)(ok ? u0 + iu * ustride : u0 < nunits ? u0 : 0) * (size_t)(RPW * nb01) + (ok ? lane_off + (unsigned)(LPR * is) * BS : 0u);
+#endif
         if (IS_41) { qt[p] = *(const uint32_t *) bp; qa[p] = *(const u32x4 *)(bp + 4); }
         else {
             qa[p] = *(const u32x4 *) bp;
@@ -161,12 +165,17 @@ __global__ void __launch_bounds__(1024) k_gemv_rows32(const float * __restrict__
                 s[6] = dot4((q0.z >> 4) & 0x0f0f0f0fu, a1.z, c1.z); s[7] = dot4((q0.w >> 4) & 0x0f0f0f0fu, a1.w, c1.w);
             }
             // slot of AVX lane A = 4(A&1) + (A&2) + (A>>2): [A0 A4 A2 A6 | A1 A5 A3 A7] (the hsum below)
+#ifdef R32_FAKE_NOREC
+            acc += __int_as_float((s[0] ^ s[1] ^ s[2] ^ s[3] ^ s[4] ^ s[5] ^ s[6] ^ s[7]) & 1) * yd + (ok ? h2f((uint16_t) h) : 0.0f);
+#else
             X[0 * LPR] = (float) s[0]; X[1 * LPR] = (float) s[4]; X[2 * LPR] = (float) s[2]; X[3 * LPR] = (float) s[6];
             X[4 * LPR] = (float) s[1]; X[5 * LPR] = (float) s[5]; X[6 * LPR] = (float) s[3]; X[7 * LPR] = (float) s[7];
             X[8 * LPR] = ok ? h2f((uint16_t) h) * yd : 0.0f;          // a masked block: fma(0, finite, acc) = acc
             if (IS_41) { M[lane] = ok ? h2f((uint16_t)(h >> 16)) : 0.0f; M[64 + lane] = acts[bb]; }
+#endif
             wave_lds_fence();
             // -- the chains: LPR blocks in row order
+#ifndef R32_FAKE_NOCHAIN       /* timing experiments only (wrong results): R32_FAKE_NOCHAIN, R32_FAKE_NOREC, R32_FAKE_COALESCED */
 #pragma unroll
             for (int i = 0; i < LPR; i += 4) {
                 const f32x4 xv = *(const f32x4 *)(xr + i), dv = *(const f32x4 *)(dr + i);
@@ -176,6 +185,7 @@ __global__ void __launch_bounds__(1024) k_gemv_rows32(const float * __restrict__
                     accs = __builtin_fmaf(mv.x, sv.x, accs); accs = __builtin_fmaf(mv.y, sv.y, accs); accs = __builtin_fmaf(mv.z, sv.z, accs); accs = __builtin_fmaf(mv.w, sv.w, accs);
                 }
             }
+#endif
             wave_lds_fence();
             if (++cs == S) {                                          // RPW rows complete: hsum_float_8 over the 8 slots (neighbour exchanges), epilogue, store
                 float hsum = acc;
