@@ -10,9 +10,9 @@
 // error, an fp16 rounding of the weights instead.  Off by default (the default prefill is the exact-order path, mmx.hip); tests/test_gpu_ops.py checks it
 // against the oracle's dequantize + float64 GEMM with a stated tolerance.
 //
-// Tiling: 128 weight rows (n) x 128 tokens (m) per 256-thread workgroup, K walked 64 elements per stage, two LDS stages (one barrier per stage: the next
+// Tiling: 128 x 128 or 256 x 256 (weight rows n x tokens m: the launcher's pick, below) per 256-thread workgroup, K walked 64 elements per stage, two LDS stages (one barrier per stage: the next
 // stage is written while the current one feeds the matrix cores), global -> registers one stage ahead (raw bytes: nothing converted before the data is
-// needed), 144-byte tile rows (conflict-free ds_read_b128 fragments).  A wave owns 64 x 64 = 2 x 2 MFMA tiles.  A operand = tokens, B operand = weight rows:
+// needed), 144-byte tile rows (conflict-free ds_read_b128 fragments).  A wave owns 2 x 2 or 4 x 4 MFMA tiles (accumulators in AGPRs).  A operand = tokens, B operand = weight rows:
 // D[v] = (token (v & 3) + 8 (v >> 2) + 4 (lane >> 5), row lane & 31): stores are 128-byte runs.
 #include "common.h"
 
@@ -41,33 +41,40 @@ __device__ __forceinline__ uint32_t h2op_fma(uint32_t x, uint32_t a, uint32_t c)
 }
 __device__ __forceinline__ uint32_t h2dup(uint16_t h) { return (uint32_t) h * 0x00010001u; }
 
-template <int TYPE>
-__global__ void __launch_bounds__(256, 2) k_mmd(const mmd_args a) {
+// BM tokens x BN weight rows per 256-thread workgroup; a wave owns (BM / 2) x (BN / 2) = MI x NJ MFMA tiles.  128 x 128 (2 x 2 tiles per wave, two workgroups per CU):
+// one LDS fragment read per MFMA -- the LDS pipe, not the matrix cores, is the busy unit.  256 x 256 (4 x 4 tiles per wave, one workgroup per CU): half a read per MFMA,
+// and the dequantization of a weight tile is shared by twice as many tokens.
+template <int TYPE, int BM, int BN>
+__global__ void __launch_bounds__(256, (BM + BN) <= 256 ? 2 : 1) k_mmd(const mmd_args a) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     constexpr bool IS_K = TYPE == CLLM_TYPE_Q4_K, IS_41 = TYPE == CLLM_TYPE_Q4_1, IS_Q8 = TYPE == CLLM_TYPE_Q8_0;
-    constexpr int BN = 128, BM = 128, STAGE = (BN + BM) * MMD_LD;
+    constexpr int STAGE = (BN + BM) * MMD_LD, WM = BM / 2, WN = BN / 2, MI = WM / 32, NJ = WN / 32, WT = BN / 128, XT = BM / 32;
     constexpr int BS = IS_Q8 ? 34 : IS_41 ? 20 : 18, QOFF = IS_41 ? 4 : 2;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     unsigned mt, nt;
     gemm_tile_of(blockIdx.x, (unsigned)((a.M + BM - 1) / BM), (unsigned)((a.N + BN - 1) / BN), 4, mt, nt);
     const int64_t m0 = (int64_t) mt * BM, n0 = (int64_t) nt * BN;
-    const int wn = (wave & 1) * 64, wm = (wave >> 1) * 64;
+    const int wn = (wave & 1) * WN, wm = (wave >> 1) * WM;
     const int l31 = lane & 31, l5 = lane >> 5;
     const int64_t K = a.K;
 
-    f32x16 acc[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; i++)
-#pragma unroll
-        for (int j = 0; j < 2; j++) acc[i][j] = f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    // the accumulators are NAMED variables, not an array: an array of 16 f32x16 is unrolled too late for the compiler to split it into registers -- it stays a stack
+    // object that is written back to scratch memory in every K stage (measured: 3.8x slower)
+#define MMD_TILES(F) F(0, 0) F(0, 1) F(0, 2) F(0, 3) F(1, 0) F(1, 1) F(1, 2) F(1, 3) F(2, 0) F(2, 1) F(2, 2) F(2, 3) F(3, 0) F(3, 1) F(3, 2) F(3, 3)
+#define MMD_DECL(i, j) [[maybe_unused]] f32x16 c##i##j = f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    MMD_TILES(MMD_DECL)
+#undef MMD_DECL
 
     // ---- staging: global -> registers (raw), registers -> LDS (dequantize) ----
     struct __attribute__((packed, aligned(2))) q16 { uint32_t x, y, z, w; };
-    const int wrow = tid >> 1, whalf = tid & 1;                     // weight task: (row, 32 of the stage's 64 elements)
-    u32x4 rq, rq2, rh; uint32_t rd;
-    u32x4 rx[4];
+    const int wrow0 = tid >> 1, whalf = tid & 1;                    // weight tasks: (row wrow0 + 128 w, 32 of the stage's 64 elements)
+    u32x4 rq_[WT], rq2_[WT], rh_[WT]; uint32_t rd_[WT];
+    u32x4 rx[XT];
     auto prefetch = [&](int64_t k0) {
-        const int64_t n = n0 + wrow, e0 = k0 + 32 * whalf;
+#pragma unroll
+      for (int w = 0; w < WT; w++) {
+        u32x4 & rq = rq_[w], & rq2 = rq2_[w], & rh = rh_[w]; uint32_t & rd = rd_[w];
+        const int64_t n = n0 + wrow0 + 128 * w, e0 = k0 + 32 * whalf;
         rq = u32x4{0, 0, 0, 0}; rq2 = u32x4{0, 0, 0, 0}; rh = u32x4{0, 0, 0, 0}; rd = 0;
         if (n < a.N && e0 < K) {
             if constexpr (IS_K) {
@@ -83,8 +90,9 @@ __global__ void __launch_bounds__(256, 2) k_mmd(const mmd_args a) {
                 if (IS_Q8) { const q16 q1 = *(const q16 *)(bp + 18); rq2 = u32x4{q1.x, q1.y, q1.z, q1.w}; }
             }
         }
+      }
 #pragma unroll
-        for (int t = 0; t < 4; t++) {
+        for (int t = 0; t < XT; t++) {
             const int c = tid + 256 * t, row = c >> 3, ch = c & 7;
             const int64_t m = m0 + row, e = k0 + ch * 8;
             rx[t] = u32x4{0, 0, 0, 0};
@@ -93,6 +101,10 @@ __global__ void __launch_bounds__(256, 2) k_mmd(const mmd_args a) {
     };
     auto commit = [&](int stage, int64_t k0) {
         char * Wt = lds + stage * STAGE, * Xt = Wt + BN * MMD_LD;
+#pragma unroll
+      for (int w = 0; w < WT; w++) {
+        const u32x4 rq = rq_[w], rq2 = rq2_[w], rh = rh_[w]; const uint32_t rd = rd_[w];
+        const int wrow = wrow0 + 128 * w;
         uint32_t o[16];
         if constexpr (IS_K) {
             // sub-block 2 c + whalf of the super-block: y = d * sc * nib - dmin * m (dequantize_row_q4_K), here as one fp16 fma per pair with d * sc and dmin * m rounded to fp16
@@ -138,13 +150,16 @@ __global__ void __launch_bounds__(256, 2) k_mmd(const mmd_args a) {
         char * wr = Wt + wrow * MMD_LD + whalf * 64;
 #pragma unroll
         for (int e = 0; e < 4; e++) *(u32x4 *)(wr + 16 * e) = u32x4{o[4 * e], o[4 * e + 1], o[4 * e + 2], o[4 * e + 3]};
+      }
 #pragma unroll
-        for (int t = 0; t < 4; t++) {
+        for (int t = 0; t < XT; t++) {
             const int c = tid + 256 * t, row = c >> 3, ch = c & 7;
             *(u32x4 *)(Xt + row * MMD_LD + ch * 16) = rx[t];
         }
     };
 
+    // (measured dead end: the next stage's dequantization placed between the MFMAs of the current one with a sched_group_barrier pipeline -- 128 x 128: 1481 -> 1766 us
+    //  on the gate/up GEMM, 256 x 256: hundreds of spilled registers)
     prefetch(0);
     commit(0, 0);
     __syncthreads();
@@ -155,15 +170,14 @@ __global__ void __launch_bounds__(256, 2) k_mmd(const mmd_args a) {
         const char * Wt = lds + stage * STAGE, * Xt = Wt + BN * MMD_LD;
 #pragma unroll
         for (int ks = 0; ks < 4; ks++) {
-            h8v ax[2], bw[2];
+            h8v ax[MI], bw[NJ];
 #pragma unroll
-            for (int i = 0; i < 2; i++) ax[i] = *(const h8v *)(Xt + (wm + i * 32 + l31) * MMD_LD + ks * 32 + l5 * 16);
+            for (int i = 0; i < MI; i++) ax[i] = *(const h8v *)(Xt + (wm + i * 32 + l31) * MMD_LD + ks * 32 + l5 * 16);
 #pragma unroll
-            for (int j = 0; j < 2; j++) bw[j] = *(const h8v *)(Wt + (wn + j * 32 + l31) * MMD_LD + ks * 32 + l5 * 16);
-#pragma unroll
-            for (int i = 0; i < 2; i++)
-#pragma unroll
-                for (int j = 0; j < 2; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ax[i], bw[j], acc[i][j], 0, 0, 0);
+            for (int j = 0; j < NJ; j++) bw[j] = *(const h8v *)(Wt + (wn + j * 32 + l31) * MMD_LD + ks * 32 + l5 * 16);
+#define MMD_MFMA(i, j) if constexpr (i < MI && j < NJ) c##i##j = __builtin_amdgcn_mfma_f32_32x32x16_f16(ax[i < MI ? i : 0], bw[j < NJ ? j : 0], c##i##j, 0, 0, 0);
+            MMD_TILES(MMD_MFMA)
+#undef MMD_MFMA
         }
         if (more) commit(stage ^ 1, k0 + MMD_KS);
         __syncthreads();
@@ -171,22 +185,31 @@ __global__ void __launch_bounds__(256, 2) k_mmd(const mmd_args a) {
     }
 
     const int64_t nv = (a.N / 2) & ~(int64_t) 7;
-#pragma unroll
-    for (int i = 0; i < 2; i++)
-#pragma unroll
-        for (int j = 0; j < 2; j++) {
-            const int64_t n = n0 + wn + j * 32 + l31;
+    auto store_tile = [&](int i, int j, const f32x16 & c) {
+        const int64_t n = n0 + wn + j * 32 + l31;
+        if (a.epi == 1) {
+            const int64_t u = n >> 1;
+            const bool nok = !(lane & 1) && n + 1 < a.N, body = u < nv;
 #pragma unroll
             for (int v = 0; v < 16; v++) {
                 const int64_t m = m0 + wm + i * 32 + (v & 3) + 8 * (v >> 2) + 4 * l5;
-                const float r = acc[i][j][v];
-                if (a.epi == 1) {
-                    const float up = dpp_f<DPP_QUAD_XOR1>(r);
-                    const int64_t u = n >> 1;
-                    if (!(lane & 1) && n + 1 < a.N && m < a.M) a.dst[m * a.ldd + u] = silu_any(r, u < nv) * up;
-                } else if (n < a.N && m < a.M) a.dst[m * a.ldd + n] = a.resid ? r + a.resid[m * a.ldr + n] : r;
+                const float r = c[v];
+                const float up = dpp_f<DPP_QUAD_XOR1>(r);
+                if (nok && m < a.M) a.dst[m * a.ldd + u] = silu_any(r, body) * up;
+            }
+        } else {
+#pragma unroll
+            for (int v = 0; v < 16; v++) {
+                const int64_t m = m0 + wm + i * 32 + (v & 3) + 8 * (v >> 2) + 4 * l5;
+                const float r = c[v];
+                if (n < a.N && m < a.M) a.dst[m * a.ldd + n] = a.resid ? r + a.resid[m * a.ldr + n] : r;
             }
         }
+    };
+#define MMD_STORE(i, j) if constexpr (i < MI && j < NJ) store_tile(i, j, c##i##j);
+    MMD_TILES(MMD_STORE)
+#undef MMD_STORE
+#undef MMD_TILES
 }
 
 __global__ void __launch_bounds__(256) k_f32_to_f16(const char * __restrict__ x, int64_t nb1, int64_t K, uint16_t * __restrict__ out, int64_t ldo) {
@@ -201,6 +224,8 @@ static void * g_x16 = nullptr; static size_t g_x16_bytes = 0;
 static int g_f16_mode = -1;
 bool prefill_f16_enabled() { if (g_f16_mode < 0) g_f16_mode = getenv("CLLM_PREFILL") && !strcmp(getenv("CLLM_PREFILL"), "f16"); return g_f16_mode != 0; }
 extern "C" __attribute__((visibility("default"))) void cllm_debug_set_prefill_f16(int on) { g_f16_mode = on ? 1 : 0; }      // tests: switch inside one process
+static int g_mmd_tile = -1;
+extern "C" __attribute__((visibility("default"))) void cllm_debug_set_mmd_tile(int tile) { g_mmd_tile = tile; }               // tests / tools: 0 pick, 128, 256
 
 // w: [K, N] quantized rows (2-D), x: [K, M] f32 rows (nb1 stride), d: [N, M] f32 (nb1 stride); CLLM_E_UNSUPPORTED -> the caller's other paths take it
 int launch_dense_f16(hipStream_t st, int wtype, const tview & w, const tview & x, const tview & d, const float * resid, int64_t ldr, int epi) {
@@ -222,11 +247,19 @@ int launch_dense_f16(hipStream_t st, int wtype, const tview & w, const tview & x
     mmd_args a;
     a.W = w.data; a.nb01 = w.nb[1]; a.N = N; a.K = K; a.X = (const uint16_t *) g_x16; a.ldx = ldx; a.M = M;
     a.dst = (float *) d.data; a.ldd = d.nb[1] / 4; a.resid = resid; a.ldr = ldr; a.epi = epi;
-    constexpr int LDS = 2 * 256 * MMD_LD;
-    const dim3 grid((unsigned)(((M + 127) / 128) * ((N + 127) / 128)));
-#define GO(T) do { static bool attr = false; \
-        if (!attr) { HIP_TRY(hipFuncSetAttribute((const void *) k_mmd<T>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS)); attr = true; } \
-        hipLaunchKernelGGL(k_mmd<T>, grid, dim3(256), LDS, st, a); } while (0)
+    // the tile: 256 x 256 where its workgroups fill the CUs evenly (a whole number of rounds, or four and more), else 128 x 128
+    if (g_mmd_tile < 0) g_mmd_tile = getenv("CLLM_MMD_TILE") ? atoi(getenv("CLLM_MMD_TILE")) : 0;  // tests / tools: 128 / 256 force
+    const int tile_env = g_mmd_tile;
+    const int64_t big_tiles = ((M + 255) / 256) * ((N + 255) / 256);
+    const int64_t cus = device_cu_count();
+    const bool big = tile_env == 256 || (tile_env != 128 && M >= 256 && big_tiles >= cus && (big_tiles % cus == 0 || big_tiles >= 4 * cus));      // (1.5 workgroups per CU: the half-empty second round costs more than the tile gains)
+#define GO(T) do { \
+        if (big) { constexpr int LDS = 2 * 512 * MMD_LD; static bool attr = false; \
+            if (!attr) { HIP_TRY(hipFuncSetAttribute((const void *) k_mmd<T, 256, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS)); attr = true; } \
+            hipLaunchKernelGGL((k_mmd<T, 256, 256>), dim3((unsigned) big_tiles), dim3(256), LDS, st, a); } \
+        else { constexpr int LDS = 2 * 256 * MMD_LD; static bool attr = false; \
+            if (!attr) { HIP_TRY(hipFuncSetAttribute((const void *) k_mmd<T, 128, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS)); attr = true; } \
+            hipLaunchKernelGGL((k_mmd<T, 128, 128>), dim3((unsigned)(((M + 127) / 128) * ((N + 127) / 128))), dim3(256), LDS, st, a); } } while (0)
     if (wtype == CLLM_TYPE_Q4_K) GO(CLLM_TYPE_Q4_K);
     else if (wtype == CLLM_TYPE_Q4_0) GO(CLLM_TYPE_Q4_0);
     else if (wtype == CLLM_TYPE_Q8_0) GO(CLLM_TYPE_Q8_0);

@@ -269,8 +269,9 @@ def test_mul_mat_quant_gemm_fast_mode(gpu, t, K, N, M):
 
 
 @pytest.mark.parametrize("t", [O.Q4_K, O.Q4_0, O.Q8_0, O.Q4_1])
-@pytest.mark.parametrize("K,N,M", [(512, 64, 40), (4096, 256, 128), (768, 130, 70), (4352, 300, 257), (14336, 140, 33)])
-def test_mul_mat_quant_dense_f16_mode(gpu, t, K, N, M):
+@pytest.mark.parametrize("tile", [128, 256])
+@pytest.mark.parametrize("K,N,M", [(512, 64, 40), (4096, 256, 128), (768, 130, 70), (4352, 300, 257), (14336, 140, 33), (1024, 520, 513)])
+def test_mul_mat_quant_dense_f16_mode(gpu, t, tile, K, N, M):
     """CLLM_PREFILL=f16 (opt-in; north star: block dequant staged through LDS + fp16 MFMA tiles, dense_f16.hip): the weights are dequantized to fp16 inside the
     GEMM's staging, the activations rounded to fp16 -- NOT the reference's computation (no activation quantization), so it is checked against the oracle's
     dequantize_row_* values times the fp16-rounded activations in float64: |delta| <= 1.5e-3 * max|ref| (the fp16 rounding of the weights: 2^-11 per element)"""
@@ -281,11 +282,13 @@ def test_mul_mat_quant_dense_f16_mode(gpu, t, K, N, M):
     wd = np.stack([O.dequantize(t, w[r], K) for r in range(N)]).astype(np.float64)
     want = x[0].astype(np.float16).astype(np.float64) @ wd.T                   # [M, N]
     lib.cllm_debug_set_prefill_f16(1)
+    lib.cllm_debug_set_mmd_tile(tile)                                           # both workgroup tiles (128 x 128, 256 x 256 tokens x rows), whole and ragged
     try:
         with prefill_mode(gpu, 0):
             got = gpu.ops.mul_mat(gpu.Tensor.from_numpy(w, t, [K, N]), gpu.Tensor.from_numpy(x)).numpy().reshape(M, N)
     finally:
         lib.cllm_debug_set_prefill_f16(0)
+        lib.cllm_debug_set_mmd_tile(0)
     assert np.all(np.isfinite(got))
     assert float(np.max(np.abs(got - want))) <= 1.5e-3 * float(np.max(np.abs(want))), float(np.max(np.abs(got - want)) / np.max(np.abs(want)))
 
