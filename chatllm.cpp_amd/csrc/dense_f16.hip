@@ -247,12 +247,12 @@ int launch_dense_f16(hipStream_t st, int wtype, const tview & w, const tview & x
     mmd_args a;
     a.W = w.data; a.nb01 = w.nb[1]; a.N = N; a.K = K; a.X = (const uint16_t *) g_x16; a.ldx = ldx; a.M = M;
     a.dst = (float *) d.data; a.ldd = d.nb[1] / 4; a.resid = resid; a.ldr = ldr; a.epi = epi;
-    // the tile: 256 x 256 where its workgroups fill the CUs evenly (a whole number of rounds, or four and more), else 128 x 128
+    // the tile: 128 x 128.  256 x 256 (CLLM_MMD_TILE=256 / cllm_debug_set_mmd_tile) is faster per GEMM in isolation where its workgroups fill the CUs evenly
+    // (o 254 -> 236 us, down 861 -> 786 us at 4096 tokens) but not in the running prefill: cfg3 113.8 ms with 128 x 128, 114.0 picked per shape, 117.5 ms with
+    // 256 x 256 everywhere (tools/prefill_f16_tile_ab.py, one process) -- so it is not picked.
     if (g_mmd_tile < 0) g_mmd_tile = getenv("CLLM_MMD_TILE") ? atoi(getenv("CLLM_MMD_TILE")) : 0;  // tests / tools: 128 / 256 force
-    const int tile_env = g_mmd_tile;
     const int64_t big_tiles = ((M + 255) / 256) * ((N + 255) / 256);
-    const int64_t cus = device_cu_count();
-    const bool big = tile_env == 256 || (tile_env != 128 && M >= 256 && big_tiles >= cus && (big_tiles % cus == 0 || big_tiles >= 4 * cus));      // (1.5 workgroups per CU: the half-empty second round costs more than the tile gains)
+    const bool big = g_mmd_tile == 256;
 #define GO(T) do { \
         if (big) { constexpr int LDS = 2 * 512 * MMD_LD; static bool attr = false; \
             if (!attr) { HIP_TRY(hipFuncSetAttribute((const void *) k_mmd<T, 256, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS)); attr = true; } \
