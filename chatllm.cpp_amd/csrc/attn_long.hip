@@ -375,23 +375,23 @@ int launch_attn_long(hipStream_t st, const float * qkv, const int32_t * pos_dev,
     if (ML <= AL_FUSED_MAX_ML && ML % 32 == 0 && !no_fuse) {                       // soft_max inside the V.P launch
         const size_t lds2 = (size_t) ML * 4 + (size_t)(ML / 8) * 4 + (size_t) ML * 2 + 4 * AL_NS * 4096;
 #define PV2(HD_) do { \
-            static bool attr2 = false; \
-            if (!attr2) { HIP_TRY(hipFuncSetAttribute((const void *) k_attn_long_softmax_pv<HD_>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024)); attr2 = true; } \
+            static uint64_t attr2 = 0; \
+            if (dev_flag_unset(attr2)) { HIP_TRY(hipFuncSetAttribute((const void *) k_attn_long_softmax_pv<HD_>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024)); dev_flag_set(attr2); } \
             hipLaunchKernelGGL((k_attn_long_softmax_pv<HD_>), dim3(HD_ / 16, nkv, r2), dim3(1024), lds2, st, pos_dev, nh, nkv, (const uint16_t *) v_cache, (int) ML, (const float *) S, att); } while (0)
         if (hd == 128) PV2(128); else PV2(64);
 #undef PV2
         LAUNCH_CHECK();
         return CLLM_OK;
     }
-    static bool attr = false;
-    if (lds > 48 * 1024 && !attr) { HIP_TRY(hipFuncSetAttribute((const void *) k_attn_long_softmax, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024)); attr = true; }
+    static uint64_t attr = 0;
+    if (lds > 48 * 1024 && dev_flag_unset(attr)) { HIP_TRY(hipFuncSetAttribute((const void *) k_attn_long_softmax, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024)); dev_flag_set(attr); }
     hipLaunchKernelGGL(k_attn_long_softmax, dim3(nh), dim3(1024), lds, st, pos_dev, (int) ML, (const float *) S, P16);
     LAUNCH_CHECK();
     const size_t lds_pv = (size_t) ML * 2 + 16;
     if (lds_pv > 150 * 1024) return CLLM_E_UNSUPPORTED;
 #define PV(HD_) do { \
-        static bool attr_pv = false; \
-        if (lds_pv > 48 * 1024 && !attr_pv) { HIP_TRY(hipFuncSetAttribute((const void *) k_attn_long_pv<HD_>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024)); attr_pv = true; } \
+        static uint64_t attr_pv = 0; \
+        if (lds_pv > 48 * 1024 && dev_flag_unset(attr_pv)) { HIP_TRY(hipFuncSetAttribute((const void *) k_attn_long_pv<HD_>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024)); dev_flag_set(attr_pv); } \
         hipLaunchKernelGGL((k_attn_long_pv<HD_>), dim3(HD_ / 16, nkv, r2), dim3(256), lds_pv, st, pos_dev, nh, nkv, (const uint16_t *) v_cache, (int) ML, (const uint16_t *) P16, att); } while (0)
     if (hd == 128) PV(128); else PV(64);
     LAUNCH_CHECK();

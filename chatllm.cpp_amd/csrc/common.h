@@ -340,6 +340,10 @@ int launch_mmq(hipStream_t st, int wtype, const tview & w, const void * act, siz
 int launch_mul_mat_f(hipStream_t st, int wtype, const tview & w, const tview & x, const tview & d, int causal = 0, int n_past = 0);   // causal: mma_f16.hip
 int launch_mma_f16(hipStream_t st, const tview & w, const tview & x, const tview & d, int causal, int n_past);
 int device_cu_count();
+// "done once PER DEVICE" flags (a bit per device id): hipFuncSetAttribute applies to the current device's copy of a kernel, and a host with several devices in one
+// process (chatllm.cpp's layer split over this module's devices) launches every kernel on each of them
+static inline bool dev_flag_unset(const uint64_t & m) { int d = 0; (void) hipGetDevice(&d); return !((m >> (d & 63)) & 1ull); }
+static inline void dev_flag_set(uint64_t & m) { int d = 0; (void) hipGetDevice(&d); m |= 1ull << (d & 63); }
 int launch_mmvq_act(hipStream_t st, int wtype, const void * W, int64_t K, int64_t nrows, const void * act, float * dst, const float * bias, const float * resid);
 int launch_gemv_decode(hipStream_t st, int wtype, const void * W, int64_t K, int64_t nrows, int pro, const float * px, const float * pw, float eps, int epi, float * dst, const float * bias, const float * resid, const float * padd = nullptr, float * xout = nullptr);
 bool prefill_f16_enabled();

@@ -416,8 +416,8 @@ int launch_attn_dec_table(hipStream_t st, const float * qkv, const int32_t * pos
     const float scale = 1.0f / sqrtf((float) hd);
     const dim3 grid(nh / nkv, nkv, hd == 128 ? 2 : 1);
 #define GO(HD_, MODE_) do { \
-        static bool attr = false; \
-        if (lds > 48 * 1024 && !attr) { HIP_TRY(hipFuncSetAttribute((const void *) k_attn_dec<HD_, MODE_, (HD_ == 128 ? 2 : 1)>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024)); attr = true; } \
+        static uint64_t attr = 0; \
+        if (lds > 48 * 1024 && dev_flag_unset(attr)) { HIP_TRY(hipFuncSetAttribute((const void *) k_attn_dec<HD_, MODE_, (HD_ == 128 ? 2 : 1)>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024)); dev_flag_set(attr); } \
         hipLaunchKernelGGL((k_attn_dec<HD_, MODE_, (HD_ == 128 ? 2 : 1)>), grid, dim3(1024), lds, st, qkv, pos_dev, rope_cs, nh, nkv, scale, k_cache, v_cache, (int) ML, att, g_attn_ts); } while (0)
     if (hd == 128) { if (mode == 0) GO(128, 0); else GO(128, 2); }      // any other mode pairs NEOX-style, as in the general kernel
     else           { if (mode == 0) GO(64, 0);  else GO(64, 2); }
@@ -431,10 +431,10 @@ static int attn_launch(hipStream_t st, bool rope, const float * qkv, const int32
     if (hd % 8 || (ML % 8) || nh % nkv) FAIL(CLLM_E_UNSUPPORTED, "attn_decode: head_dim and max_len must be multiples of 8");
     const size_t lds = (size_t)(3 * hd + (ML > hd ? ML : hd)) * 4 + 64 * 32 * 4;      // q | new k | new v | scores (reused for the cos/sin table) | leftover products
     if (lds > 150 * 1024) FAIL(CLLM_E_UNSUPPORTED, "attn_decode: max_len %lld does not fit LDS", (long long) ML);
-    static bool attr0 = false, attr1 = false;
+    static uint64_t attr0 = 0, attr1 = 0;
     if (lds > 48 * 1024) {
-        if (!rope && !attr0) { HIP_TRY(hipFuncSetAttribute((const void *) k_attn_decode<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024)); attr0 = true; }
-        if (rope && !attr1)  { HIP_TRY(hipFuncSetAttribute((const void *) k_attn_decode<true>,  hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024)); attr1 = true; }
+        if (!rope && dev_flag_unset(attr0)) { HIP_TRY(hipFuncSetAttribute((const void *) k_attn_decode<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024)); dev_flag_set(attr0); }
+        if (rope && dev_flag_unset(attr1))  { HIP_TRY(hipFuncSetAttribute((const void *) k_attn_decode<true>,  hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024)); dev_flag_set(attr1); }
     }
     const float scale = 1.0f / sqrtf((float) hd), theta_scale = powf(freq_base, -2.0f / hd);
     if (rope) hipLaunchKernelGGL(k_attn_decode<true>,  dim3(nh), dim3(1024), lds, st, qkv, pos_dev, nh, nkv, hd, scale, k_cache, v_cache, ML, att, g_attn_dbg, mode, theta_scale);

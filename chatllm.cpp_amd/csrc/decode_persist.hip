@@ -487,8 +487,8 @@ int launch_decode_layers(hipStream_t st, void * state, bool * layers_ready, cons
     a.bar = (pg_bar *) sb; a.ts = ts;
     HIP_TRY(hipMemsetAsync(sb, 0, sizeof(pg_bar), st));                 // every polled word starts at zero (a memset node: replayed with the graph)
     const bool npre4 = F > 4096;
-#define GOP(MODE_, NP_) do { static bool attr = false; \
-        if (!attr) { HIP_TRY(hipFuncSetAttribute((const void *) k_decode_layers<MODE_, NP_>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024)); attr = true; } \
+#define GOP(MODE_, NP_) do { static uint64_t attr = 0; \
+        if (dev_flag_unset(attr)) { HIP_TRY(hipFuncSetAttribute((const void *) k_decode_layers<MODE_, NP_>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024)); dev_flag_set(attr); } \
         hipLaunchKernelGGL((k_decode_layers<MODE_, NP_>), dim3((unsigned) grid), dim3(1024), lds, st, a); } while (0)
     if (rope_mode == 0) { if (npre4) GOP(0, 4); else GOP(0, 1); }
     else                { if (npre4) GOP(2, 4); else GOP(2, 1); }

@@ -254,11 +254,11 @@ int launch_dense_f16(hipStream_t st, int wtype, const tview & w, const tview & x
     const int64_t big_tiles = ((M + 255) / 256) * ((N + 255) / 256);
     const bool big = g_mmd_tile == 256;
 #define GO(T) do { \
-        if (big) { constexpr int LDS = 2 * 512 * MMD_LD; static bool attr = false; \
-            if (!attr) { HIP_TRY(hipFuncSetAttribute((const void *) k_mmd<T, 256, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS)); attr = true; } \
+        if (big) { constexpr int LDS = 2 * 512 * MMD_LD; static uint64_t attr = 0; \
+            if (dev_flag_unset(attr)) { HIP_TRY(hipFuncSetAttribute((const void *) k_mmd<T, 256, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS)); dev_flag_set(attr); } \
             hipLaunchKernelGGL((k_mmd<T, 256, 256>), dim3((unsigned) big_tiles), dim3(256), LDS, st, a); } \
-        else { constexpr int LDS = 2 * 256 * MMD_LD; static bool attr = false; \
-            if (!attr) { HIP_TRY(hipFuncSetAttribute((const void *) k_mmd<T, 128, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS)); attr = true; } \
+        else { constexpr int LDS = 2 * 256 * MMD_LD; static uint64_t attr = 0; \
+            if (dev_flag_unset(attr)) { HIP_TRY(hipFuncSetAttribute((const void *) k_mmd<T, 128, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS)); dev_flag_set(attr); } \
             hipLaunchKernelGGL((k_mmd<T, 128, 128>), dim3((unsigned)(((M + 127) / 128) * ((N + 127) / 128))), dim3(256), LDS, st, a); } } while (0)
     if (wtype == CLLM_TYPE_Q4_K) GO(CLLM_TYPE_Q4_K);
     else if (wtype == CLLM_TYPE_Q4_0) GO(CLLM_TYPE_Q4_0);

@@ -34,8 +34,8 @@ int launch_gemv_decode(hipStream_t st, int wtype, const void * W, int64_t K, int
     const size_t lds = act_row_bytes(K, kind) + 16 * (size_t)(wtype == CLLM_TYPE_Q4_K ? Q4K_CHAIN_BYTES : Q32_CHAIN_BYTES);     // + the waves' chain records
     const int npre = K <= 4096 ? 1 : K <= 16384 ? 4 : 8;
 #define GO3(FMT_, PRO_, EPI_, NPRE_) do { \
-        static bool attr = false; \
-        if (lds > 64 * 1024 && !attr) { HIP_TRY(hipFuncSetAttribute((const void *) k_gemv_dec<FMT_, PRO_, EPI_, NPRE_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr = true; } \
+        static uint64_t attr = 0; \
+        if (lds > 64 * 1024 && dev_flag_unset(attr)) { HIP_TRY(hipFuncSetAttribute((const void *) k_gemv_dec<FMT_, PRO_, EPI_, NPRE_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); dev_flag_set(attr); } \
         hipLaunchKernelGGL((k_gemv_dec<FMT_, PRO_, EPI_, NPRE_>), dim3((unsigned) grid), dim3(1024), lds, st, px, pw, padd, (const char *) W, nblk, kfull, nrem, eps, dst, xout, bias, resid, g_gemv_ts, \
                            (const int32_t *) nullptr, 0ull, 0, 0); } while (0)
 #define GO(FMT_) do { \
@@ -69,8 +69,8 @@ int launch_gemv_decode_id(hipStream_t st, int wtype, const void * W, size_t w_ex
     const size_t lds = act_row_bytes(K, kind) + 16 * (size_t)(wtype == CLLM_TYPE_Q4_K ? Q4K_CHAIN_BYTES : Q32_CHAIN_BYTES);
     const int npre = K <= 4096 ? 1 : K <= 16384 ? 4 : 8;
 #define GOM(FMT_, EPI_, NPRE_) do { \
-        static bool attr = false; \
-        if (lds > 64 * 1024 && !attr) { HIP_TRY(hipFuncSetAttribute((const void *) k_gemv_dec<FMT_, 2, EPI_, NPRE_, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr = true; } \
+        static uint64_t attr = 0; \
+        if (lds > 64 * 1024 && dev_flag_unset(attr)) { HIP_TRY(hipFuncSetAttribute((const void *) k_gemv_dec<FMT_, 2, EPI_, NPRE_, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); dev_flag_set(attr); } \
         hipLaunchKernelGGL((k_gemv_dec<FMT_, 2, EPI_, NPRE_, true>), dim3((unsigned) grid, (unsigned) n_slots), dim3(1024), lds, st, px, (const float *) nullptr, (const float *) nullptr, (const char *) W, \
                            nblk, kfull, nrem, 0.0f, dst, (float *) nullptr, (const float *) nullptr, (const float *) nullptr, (unsigned long long *) nullptr, ids, \
                            (unsigned long long) w_expert_bytes, (int) px_slot_stride, (int) dst_slot_stride); } while (0)

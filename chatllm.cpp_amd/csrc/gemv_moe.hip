@@ -13,8 +13,8 @@ int launch_moe_router(hipStream_t st, int wtype, const void * W, int64_t K, int6
     const int kfull = (int)(n / 16), nrem = (int)(n % 16), nblk = (int)(K / kind);
     const size_t lds = act_row_bytes(K, kind) + 16 * (size_t)(wtype == CLLM_TYPE_Q4_K ? Q4K_CHAIN_BYTES : Q32_CHAIN_BYTES) + 2 * 64 * sizeof(float);     // + logits, probabilities
 #define GOR(FMT_, NPRE_) do { \
-        static bool attr = false; \
-        if (lds > 64 * 1024 && !attr) { HIP_TRY(hipFuncSetAttribute((const void *) k_gemv_dec<FMT_, 1, 2, NPRE_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr = true; } \
+        static uint64_t attr = 0; \
+        if (lds > 64 * 1024 && dev_flag_unset(attr)) { HIP_TRY(hipFuncSetAttribute((const void *) k_gemv_dec<FMT_, 1, 2, NPRE_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); dev_flag_set(attr); } \
         hipLaunchKernelGGL((k_gemv_dec<FMT_, 1, 2, NPRE_>), dim3(1), dim3(1024), lds, st, px, pw, (const float *) nullptr, (const char *) W, nblk, kfull, nrem, eps, probs, xnorm, \
                            (const float *) nullptr, (const float *) nullptr, (unsigned long long *) nullptr, (const int32_t *) ids, 0ull, 0, k); } while (0)
 #define GORT(FMT_) do { if (K <= 4096) GOR(FMT_, 1); else GOR(FMT_, 4); } while (0)
@@ -40,8 +40,8 @@ int launch_gemv_decode_id_combine(hipStream_t st, int wtype, const void * W, siz
     const int kfull = (int)(nrows / nwaves), nrem = (int)(nrows % nwaves), nblk = (int)(K / kind);
     const int npre = K <= 4096 ? 1 : K <= 16384 ? 4 : 8;
 #define GOC(FMT_, NPRE_) do { \
-        static bool attr = false; \
-        if (lds > 64 * 1024 && !attr) { HIP_TRY(hipFuncSetAttribute((const void *) k_gemv_dec<FMT_, 2, 3, NPRE_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr = true; } \
+        static uint64_t attr = 0; \
+        if (lds > 64 * 1024 && dev_flag_unset(attr)) { HIP_TRY(hipFuncSetAttribute((const void *) k_gemv_dec<FMT_, 2, 3, NPRE_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); dev_flag_set(attr); } \
         hipLaunchKernelGGL((k_gemv_dec<FMT_, 2, 3, NPRE_>), dim3((unsigned) grid), dim3(1024), lds, st, px, probs, (const float *) nullptr, (const char *) W, nblk, kfull, nrem, 0.0f, dst, (float *) nullptr, \
                            (const float *) nullptr, resid, (unsigned long long *) nullptr, ids, (unsigned long long) w_expert_bytes, (int) px_slot_stride, 0); } while (0)
 #define GOCT(FMT_) do { if (npre == 1) GOC(FMT_, 1); else if (npre == 4) GOC(FMT_, 4); else GOC(FMT_, 8); } while (0)

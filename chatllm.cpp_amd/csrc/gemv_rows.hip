@@ -237,8 +237,8 @@ int launch_gemv_rows(hipStream_t st, const void * W, int64_t K, int64_t nrows, i
     if (lds > 159 * 1024) return CLLM_E_UNSUPPORTED;      // (+ the prologue's static 128 bytes)
     const int npre = K <= 4096 ? 1 : K <= 16384 ? 4 : 8;
 #define GOR(PRO_, EPI_, NPRE_, RPW_) do { \
-        static bool attr = false; \
-        if (!attr) { HIP_TRY(hipFuncSetAttribute((const void *) k_gemv_rows<PRO_, EPI_, NPRE_, RPW_>, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024)); attr = true; } \
+        static uint64_t attr = 0; \
+        if (dev_flag_unset(attr)) { HIP_TRY(hipFuncSetAttribute((const void *) k_gemv_rows<PRO_, EPI_, NPRE_, RPW_>, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024)); dev_flag_set(attr); } \
         hipLaunchKernelGGL((k_gemv_rows<PRO_, EPI_, NPRE_, RPW_>), dim3((unsigned) grid), dim3(1024), lds, st, px, pw, (const char *) W, nblk, nunits, eps, dst, bias, resid); } while (0)
 #define GOP(RPW_) do { \
         if (pro == 1 && epi == 1) { if (npre == 1) GOR(1, 1, 1, RPW_); else GOR(1, 1, 4, RPW_); } \

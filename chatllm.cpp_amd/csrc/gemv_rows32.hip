@@ -243,8 +243,8 @@ int launch_gemv_rows32(hipStream_t st, int wtype, const void * W, int64_t K, int
     if (lds > 159 * 1024) return CLLM_E_UNSUPPORTED;
     const int npre = K <= 4096 ? 1 : K <= 16384 ? 4 : 8;
 #define GOR(FMT_, PRO_, EPI_, NPRE_, RPW_) do { \
-        static bool attr = false; \
-        if (!attr) { HIP_TRY(hipFuncSetAttribute((const void *) k_gemv_rows32<FMT_, PRO_, EPI_, NPRE_, RPW_>, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024)); attr = true; } \
+        static uint64_t attr = 0; \
+        if (dev_flag_unset(attr)) { HIP_TRY(hipFuncSetAttribute((const void *) k_gemv_rows32<FMT_, PRO_, EPI_, NPRE_, RPW_>, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024)); dev_flag_set(attr); } \
         hipLaunchKernelGGL((k_gemv_rows32<FMT_, PRO_, EPI_, NPRE_, RPW_>), dim3((unsigned) grid), dim3(1024), lds, st, px, pw, (const char *) W, nblk, nunits, eps, dst, bias, resid); } while (0)
 #define GOW(FMT_, PRO_, EPI_, NPRE_) do { if (rpw == 2) GOR(FMT_, PRO_, EPI_, NPRE_, 2); else GOR(FMT_, PRO_, EPI_, NPRE_, 4); } while (0)
 #define GOW1(FMT_, EPI_, NPRE_) do { if (rpw == 8) GOR(FMT_, 1, EPI_, NPRE_, 8); else GOW(FMT_, 1, EPI_, NPRE_); } while (0)

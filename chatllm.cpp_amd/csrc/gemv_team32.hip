@@ -386,8 +386,8 @@ int launch_gemv_team32(hipStream_t st, int wtype, const void * W, int64_t K, int
     if (!g_t32_err) { HIP_TRY(hipMalloc((void **) &g_t32_err, 4)); HIP_TRY(hipMemset(g_t32_err, 0, 4)); }
     const int npre = K <= 4096 ? 1 : K <= 16384 ? 4 : 8;
 #define GOT(FMT_, PRO_, NPRE_) do { \
-        static bool attr = false; \
-        if (!attr) { HIP_TRY(hipFuncSetAttribute((const void *) k_gemv_team32<FMT_, PRO_, NPRE_>, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024)); attr = true; } \
+        static uint64_t attr = 0; \
+        if (dev_flag_unset(attr)) { HIP_TRY(hipFuncSetAttribute((const void *) k_gemv_team32<FMT_, PRO_, NPRE_>, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024)); dev_flag_set(attr); } \
         hipLaunchKernelGGL((k_gemv_team32<FMT_, PRO_, NPRE_>), dim3((unsigned) grid), dim3(1024), lds, st, px, pw, (const char *) W, nblk, nunits, eps, dst, bias, resid, team, g_t32_err, g_t32_ts); } while (0)
 #define GOP(FMT_) do { \
         if (pro == 1)      { if (npre == 1) GOT(FMT_, 1, 1); else GOT(FMT_, 1, 4); } \

@@ -347,11 +347,11 @@ int launch_mmq(hipStream_t st, int wtype, const tview & w, const void * act, siz
     a.dst = (float *) d.data; a.ldd = d.nb[1] / 4; a.resid = resid; a.ldr = ldr; a.epi = epi;
     if (epi && (epi != 1 || resid || a.N % 2)) FAIL(CLLM_E_INVALID, "mmq: epilogue %d", epi);
 
-#define GO(T) do { static bool attr = false; \
+#define GO(T) do { static uint64_t attr = 0; \
         constexpr int BM = (mmq_traits<T>::NW / 2) * 16 * mmq_traits<T>::MI, LDS = lds_total(BM, T == CLLM_TYPE_Q4_1); \
         if (((a.M + BM - 1) / BM) * ((a.N + MMQ_BN - 1) / MMQ_BN) > 0x7fffffff) FAIL(CLLM_E_UNSUPPORTED, "mmq: too many tiles"); \
         const dim3 grid((unsigned)(((a.M + BM - 1) / BM) * ((a.N + MMQ_BN - 1) / MMQ_BN))); \
-        if (!attr) { HIP_TRY(hipFuncSetAttribute((const void *) k_mmq<T>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS)); attr = true; } \
+        if (dev_flag_unset(attr)) { HIP_TRY(hipFuncSetAttribute((const void *) k_mmq<T>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS)); dev_flag_set(attr); } \
         hipLaunchKernelGGL(k_mmq<T>, grid, dim3(mmq_traits<T>::NW * 64), LDS, st, a); } while (0)
     if (wtype == CLLM_TYPE_Q4_K) GO(CLLM_TYPE_Q4_K);
     else if (wtype == CLLM_TYPE_Q4_0) GO(CLLM_TYPE_Q4_0);

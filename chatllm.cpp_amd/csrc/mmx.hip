@@ -421,11 +421,11 @@ int launch_mmx(hipStream_t st, int wtype, const tview & w, const void * act, siz
     a.act = (const char *) act; a.act_stride = act_stride; a.M = x.ne[1];
     a.dst = (float *) d.data; a.ldd = d.nb[1] / 4; a.resid = resid; a.ldr = ldr; a.epi = epi;
     if (epi && (epi != 1 || resid || a.N % 2)) FAIL(CLLM_E_INVALID, "mmx: epilogue %d", epi);
-#define GO(T) do { static bool attr = false; \
+#define GO(T) do { static uint64_t attr = 0; \
         using TR = mmx_traits<T>; constexpr int BN = TR::WN * TR::NJ * 16, BM = TR::WM * TR::MI * 16, LDS = mmx_lds<T>(); \
         if (((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN) > 0x7fffffff) FAIL(CLLM_E_UNSUPPORTED, "mmx: too many tiles"); \
         const dim3 grid((unsigned)(((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN))); \
-        if (!attr) { HIP_TRY(hipFuncSetAttribute((const void *) k_mmx<T>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS)); attr = true; } \
+        if (dev_flag_unset(attr)) { HIP_TRY(hipFuncSetAttribute((const void *) k_mmx<T>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS)); dev_flag_set(attr); } \
         hipLaunchKernelGGL(k_mmx<T>, grid, dim3(256), LDS, st, a); } while (0)
     static const bool dbg = getenv("CLLM_DEBUG") != nullptr;
     if (dbg) {

@@ -353,8 +353,8 @@ static int soft_max_impl(void * stream, const cllm_tensor * src, const cllm_tens
     }
     if (fused && n % 8 == 0 && n > 8192 && n <= 32768 && al16 && rows <= 0x7fffffff) {      // very long rows: one workgroup per row, row in LDS
         const size_t lds = (size_t)(n + n / 8) * 4;
-        static bool attr = false;
-        if (!attr) { HIP_TRY(hipFuncSetAttribute((const void *) k_soft_max_causal_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024)); attr = true; }
+        static uint64_t attr = 0;
+        if (dev_flag_unset(attr)) { HIP_TRY(hipFuncSetAttribute((const void *) k_soft_max_causal_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024)); dev_flag_set(attr); }
         hipLaunchKernelGGL(k_soft_max_causal_lds, dim3((unsigned) rows), dim3(256), lds, st, tv(src), tv(dst), scale, n_past);
         LAUNCH_CHECK();
         return CLLM_OK;
