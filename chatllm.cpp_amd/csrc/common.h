@@ -344,6 +344,9 @@ int device_cu_count();
 // process (chatllm.cpp's layer split over this module's devices) launches every kernel on each of them
 static inline bool dev_flag_unset(const uint64_t & m) { int d = 0; (void) hipGetDevice(&d); return !((m >> (d & 63)) & 1ull); }
 static inline void dev_flag_set(uint64_t & m) { int d = 0; (void) hipGetDevice(&d); m |= 1ull << (d & 63); }
+// per-device scratch: a buffer allocated on one device must not serve launches on another (index = device id & 63)
+#define CLLM_DEV_SLOTS 64
+static inline int dev_slot() { int d = 0; (void) hipGetDevice(&d); return d & (CLLM_DEV_SLOTS - 1); }
 int launch_mmvq_act(hipStream_t st, int wtype, const void * W, int64_t K, int64_t nrows, const void * act, float * dst, const float * bias, const float * resid);
 int launch_gemv_decode(hipStream_t st, int wtype, const void * W, int64_t K, int64_t nrows, int pro, const float * px, const float * pw, float eps, int epi, float * dst, const float * bias, const float * resid, const float * padd = nullptr, float * xout = nullptr);
 bool prefill_f16_enabled();

@@ -338,20 +338,22 @@ __global__ void __launch_bounds__(1024) k_gemv_team32(const float * __restrict__
     if (ts && lane == 0) ts[(blockIdx.x * 16 + wave) * 4 + 3] = clock64() - cyc1;
 }
 
-static unsigned * g_t32_err = nullptr;
+static unsigned * g_t32_err_dev[CLLM_DEV_SLOTS];                         // the error word, per device
 static int g_team32_mode = -1;
 static unsigned long long * g_t32_ts = nullptr;
 extern "C" __attribute__((visibility("default"))) void cllm_debug_set_team32_ts(unsigned long long * dev_buf) { g_t32_ts = dev_buf; }   // tools only: [256 workgroups][16 waves][4] stamps
 extern "C" __attribute__((visibility("default"))) void cllm_debug_set_gemv_team32(int mode) { g_team32_mode = mode; }      // tests / tools: 0 off, 1 pick, 4 / 5 / 8 / 16 force the team size
 extern "C" __attribute__((visibility("default"))) int cllm_debug_gemv_team32_error(void) {
     unsigned e = 0;
+    unsigned * g_t32_err = g_t32_err_dev[dev_slot()];
     if (g_t32_err && hipMemcpy(&e, g_t32_err, 4, hipMemcpyDeviceToHost) != hipSuccess) return -1;
     return (int) e;
 }
 
 // after a synchronize: did a hand-off between the waves of a team time out?  (the launch winds down instead of hanging; its results are void)
 int gemv_team32_check() {
-    if (!g_t32_err) return CLLM_OK;                                    // never launched
+    unsigned * g_t32_err = g_t32_err_dev[dev_slot()];
+    if (!g_t32_err) return CLLM_OK;                                    // never launched on this device
     unsigned e = 0;
     HIP_TRY(hipMemcpy(&e, g_t32_err, 4, hipMemcpyDeviceToHost));
     if (e) FAIL(CLLM_E_HIP, "gemv_team32: a hand-off between the waves of a workgroup timed out (code %u); set CLLM_GEMV_TEAM32=0", e);
@@ -383,6 +385,7 @@ int launch_gemv_team32(hipStream_t st, int wtype, const void * W, int64_t K, int
     int grid = (nunits + nteams - 1) / nteams; if (grid > cus) grid = cus;
     const size_t lds = act_row_bytes(K, wtype == CLLM_TYPE_Q4_1 ? ACT_Q8_1 : ACT_Q8_0) + (wtype == CLLM_TYPE_Q4_0 ? (size_t) K : 0) + 32 * (size_t) T32_SLOT_BYTES;
     if (lds > 158 * 1024) return CLLM_E_UNSUPPORTED;
+    unsigned * & g_t32_err = g_t32_err_dev[dev_slot()];
     if (!g_t32_err) { HIP_TRY(hipMalloc((void **) &g_t32_err, 4)); HIP_TRY(hipMemset(g_t32_err, 0, 4)); }
     const int npre = K <= 4096 ? 1 : K <= 16384 ? 4 : 8;
 #define GOT(FMT_, PRO_, NPRE_) do { \
