@@ -5,6 +5,10 @@
 #include <stdarg.h>
 #include <stdio.h>
 #include <string.h>
+#include <map>
+#include <mutex>
+#include <tuple>
+#include <vector>
 
 // ---- errors -----------------------------------------------------------------------------------------
 static thread_local char g_err[512] = "";
@@ -123,7 +127,38 @@ extern "C" int cllm_stream_create(void ** stream) {
     *stream = (void *) s;
     return CLLM_OK;
 }
-extern "C" int cllm_stream_destroy(void * stream) { if (stream) HIP_TRY(hipStreamDestroy((hipStream_t) stream)); return CLLM_OK; }
+// ---- library-owned scratch, per (device, stream, kind); see common.h ----
+namespace {
+struct scratch_entry { void * p = nullptr; size_t bytes = 0; std::vector<void *> outgrown; };
+std::mutex g_scratch_m;
+std::map<std::tuple<int, hipStream_t, int>, scratch_entry> g_scratch;
+}
+void * stream_scratch(hipStream_t st, int kind, size_t need) {
+    int dev = 0; (void) hipGetDevice(&dev);
+    std::lock_guard<std::mutex> lock(g_scratch_m);
+    scratch_entry & e = g_scratch[std::make_tuple(dev, st, kind)];
+    if (need <= e.bytes) return e.p;
+    void * np = nullptr;
+    if (hipMalloc(&np, need) != hipSuccess) { (void) hipGetLastError(); cllm_set_error("scratch: hipMalloc(%zu) failed", need); return nullptr; }
+    if (e.p) e.outgrown.push_back(e.p);               // a captured launch may still address it
+    e.p = np; e.bytes = need;
+    return np;
+}
+void stream_scratch_release(hipStream_t st) {
+    int dev = 0; (void) hipGetDevice(&dev);
+    std::lock_guard<std::mutex> lock(g_scratch_m);
+    for (auto it = g_scratch.begin(); it != g_scratch.end(); ) {
+        if (std::get<0>(it->first) == dev && std::get<1>(it->first) == st) {
+            if (it->second.p) (void) hipFree(it->second.p);
+            for (void * q : it->second.outgrown) (void) hipFree(q);
+            it = g_scratch.erase(it);
+        } else ++it;
+    }
+}
+extern "C" int cllm_stream_destroy(void * stream) {
+    if (stream) { HIP_TRY(hipStreamSynchronize((hipStream_t) stream)); stream_scratch_release((hipStream_t) stream); HIP_TRY(hipStreamDestroy((hipStream_t) stream)); }
+    return CLLM_OK;
+}
 extern "C" int cllm_stream_sync(void * stream) { HIP_TRY(hipStreamSynchronize((hipStream_t) stream)); return CLLM_OK; }
 
 // ---- capture / replay of a launch sequence (what ggml_backend_i.graph_plan_create / graph_plan_compute are for, ggml-backend-impl.h:104-113) ----

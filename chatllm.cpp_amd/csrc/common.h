@@ -162,10 +162,37 @@ __device__ __forceinline__ double rms_block_sumsq_1024(const float * __restrict_
 // scale = 1 / sqrt(sum / n + eps) exactly as ops.cpp:3731-3736 (double division, float sqrt, float division).  For a power
 // of two n the division is an exact exponent shift: multiply by 1/n instead (same bits, ~25 instructions less on the
 // decode kernels' cold critical path); the general division sits in a noinline function off the straight-line code.
+//
+// ORDER.  The reference adds the n squares serially in index order (ops.cpp:3736-3739); the workgroup adds them as a tree.  Two double sums of the same n
+// non-negative terms differ by at most 2 gamma_(n-1) = 2 (n - 1) u / (1 - (n - 1) u) of their value (u = 2^-53; Higham, Accuracy and Stability, 4.2), and the
+// only thing the rest of the op sees of the sum is (float)(sum / n): division and conversion are monotonic, so whenever the two ends of
+// sum (1 -+ (2 n + 16) u) give the SAME float, the serial sum gives it too and the tree's result is the reference's, bit for bit.  When they do not (the mean
+// lies within ~1e-12 of a float rounding boundary: about 3 rows in 10^5 at n = 4096) thread 0 redoes the sum in the reference's own order.  The branch
+// is uniform over the workgroup (every thread holds the same `sum`); x (+ add: the tensor-parallel partial folded into the residual) must still hold the
+// row, which is why the barriers sit here: no thread of an in-place launch stores before the serial pass has read.
 static __device__ __noinline__ double rms_div(double sum, double n) { return sum / n; }
-__device__ __forceinline__ float rms_scale(double sum, int64_t n, float eps) {
-    const double m = (n & (n - 1)) == 0 ? ldexp(sum, -(int) __builtin_ctzll((unsigned long long) n)) : rms_div(sum, (double) n);
-    return 1.0f / sqrtf((float) m + eps);
+static __device__ __noinline__ double rms_serial_sumsq(const float * x, const float * add, int64_t n) {
+    double sum = 0.0;
+    for (int64_t i = 0; i < n; i++) {
+        float v = __uint_as_float(__hip_atomic_load((const unsigned *)(x + i), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));      // (coherent: the persistent launch hands x over inside the kernel)
+        if (add) v = v + __uint_as_float(__hip_atomic_load((const unsigned *)(add + i), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        sum += (double)(v * v);
+    }
+    return sum;
+}
+__device__ __forceinline__ float rms_mean(double sum, int64_t n) {
+    return (float)((n & (n - 1)) == 0 ? ldexp(sum, -(int) __builtin_ctzll((unsigned long long) n)) : rms_div(sum, (double) n));
+}
+__device__ __forceinline__ float rms_scale(double sum, int64_t n, float eps, const float * x, const float * add, double * part) {
+    float m = rms_mean(sum, n);
+    const double d = sum * ((double)(2 * n + 16) * 0x1p-53);
+    if (!(rms_mean(sum - d, n) == rms_mean(sum + d, n))) {
+        __syncthreads();
+        if (threadIdx.x == 0) part[0] = rms_serial_sumsq(x, add, n);
+        __syncthreads();
+        m = rms_mean(part[0], n);
+    }
+    return 1.0f / sqrtf(m + eps);
 }
 
 // the same sum for rows of at most 4096 elements (n % 4 == 0): every thread owns at most one group, no loop, no tail --
@@ -347,6 +374,12 @@ static inline void dev_flag_set(uint64_t & m) { int d = 0; (void) hipGetDevice(&
 // per-device scratch: a buffer allocated on one device must not serve launches on another (index = device id & 63)
 #define CLLM_DEV_SLOTS 64
 static inline int dev_slot() { int d = 0; (void) hipGetDevice(&d); return d & (CLLM_DEV_SLOTS - 1); }
+// library-owned scratch (capi.hip): one block per (device, stream, kind).  Growing it never frees a block a launch may still hold: a captured launch list (the
+// host module replays hipGraphs whose signature covers only the public arguments) keeps the address it was captured with, so outgrown blocks stay alive until their
+// stream is destroyed; keyed by stream, two backend contexts of one device never share one.  nullptr: allocation failed (error set).
+enum { SCRATCH_ATTN_SCORES = 0, SCRATCH_X16 = 1 };
+void * stream_scratch(hipStream_t st, int kind, size_t need);
+void stream_scratch_release(hipStream_t st);
 int launch_mmvq_act(hipStream_t st, int wtype, const void * W, int64_t K, int64_t nrows, const void * act, float * dst, const float * bias, const float * resid);
 int launch_gemv_decode(hipStream_t st, int wtype, const void * W, int64_t K, int64_t nrows, int pro, const float * px, const float * pw, float eps, int epi, float * dst, const float * bias, const float * resid, const float * padd = nullptr, float * xout = nullptr);
 bool prefill_f16_enabled();

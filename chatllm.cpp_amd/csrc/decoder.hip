@@ -116,7 +116,7 @@ extern "C" void cllm_llama_destroy(cllm_llama * m) {
                       (void *) m->logits, m->wdata, (void *) m->tokens_dev, (void *) m->pos_dev, (void *) m->next_tok_dev, (void *) m->out_ring, (void *) m->counter_dev }) if (p) (void) hipFree(p);
     if (m->persist_state) (void) hipFree(m->persist_state);
     if (m->persist_ts) (void) hipFree(m->persist_ts);
-    if (m->own_stream) (void) hipStreamDestroy(m->st);
+    if (m->own_stream) { stream_scratch_release(m->st); (void) hipStreamDestroy(m->st); }
     delete m;
 }
 
@@ -165,6 +165,7 @@ extern "C" int cllm_llama_set_tp_comm(cllm_llama * m, void * comm) { if (!m) FAI
 extern "C" int cllm_llama_set_tp_oneshot(cllm_llama * m, void * os) { if (!m) FAIL(CLLM_E_INVALID, "null"); m->tp_oneshot = os; return CLLM_OK; }
 extern "C" int cllm_tp_all_reduce_f32(void * comm, void * stream, float * buf, size_t n);
 extern "C" int cllm_tp_oneshot_all_reduce_f32(void * os, void * stream, float * buf, size_t n);
+extern "C" int cllm_tp_oneshot_error(void * os);
 // sum `n` floats of `buf` over the tensor-parallel group, stream-ordered: RCCL if a communicator is bound, else the host callback
 static int tp_allreduce(cllm_llama * m, hipStream_t st, float * buf, int64_t n) {
     if (m->tp_oneshot) {                                           // decode-sized messages; larger ones (a prompt's [H, qlen]) fall through to RCCL / the callback
@@ -556,6 +557,8 @@ static int decode_step_fused(cllm_llama * m, bool sample, bool long_ctx) {
 // after a synchronize: did a barrier of the persistent launch time out?  (it winds the kernel down instead of hanging the GPU; the step's results are void)
 static int persist_check(cllm_llama * m) {
     TRY(gemv_team32_check());                                          // (the same kind of bounded wait inside a workgroup: gemv_team32.hip)
+    // the one-shot all-reduce sums whatever its slots hold after a timed-out flag wait (a slow or dead peer): the step's results are void
+    if (m->tp_oneshot && cllm_tp_oneshot_error(m->tp_oneshot)) FAIL(CLLM_E_HIP, "decode: a flag wait of the one-shot all-reduce timed out (a peer rank is late, dead or out of step): the step's logits are void");
     if (!m->persist_used) return CLLM_OK;
     unsigned phase = 0;
     TRY(decode_layers_error(m->persist_state, &phase));

@@ -220,7 +220,6 @@ __global__ void __launch_bounds__(256) k_f32_to_f16(const char * __restrict__ x,
     *(uint32_t *)(out + row * ldo + e) = (uint32_t) f2h(r[e]) | ((uint32_t) f2h(e + 1 < K ? r[e + 1] : 0.0f) << 16);
 }
 
-static void * g_x16_dev[CLLM_DEV_SLOTS]; static size_t g_x16_bytes_dev[CLLM_DEV_SLOTS];      // the fp16 activation copy, per device
 static int g_f16_mode = -1;
 bool prefill_f16_enabled() { if (g_f16_mode < 0) g_f16_mode = getenv("CLLM_PREFILL") && !strcmp(getenv("CLLM_PREFILL"), "f16"); return g_f16_mode != 0; }
 extern "C" __attribute__((visibility("default"))) void cllm_debug_set_prefill_f16(int on) { g_f16_mode = on ? 1 : 0; }      // tests: switch inside one process
@@ -235,14 +234,8 @@ int launch_dense_f16(hipStream_t st, int wtype, const tview & w, const tview & x
     if (((M + 127) / 128) * ((N + 127) / 128) > 0x7fffffff) return CLLM_E_UNSUPPORTED;
     const int64_t ldx = (K + 7) & ~(int64_t) 7;
     const size_t need = (size_t) M * ldx * 2;
-    void * & g_x16 = g_x16_dev[dev_slot()]; size_t & g_x16_bytes = g_x16_bytes_dev[dev_slot()];
-    if (need > g_x16_bytes) {
-        HIP_TRY(hipStreamSynchronize(st));
-        if (g_x16) (void) hipFree(g_x16);
-        g_x16 = nullptr; g_x16_bytes = 0;
-        HIP_TRY(hipMalloc(&g_x16, need));
-        g_x16_bytes = need;
-    }
+    void * g_x16 = stream_scratch(st, SCRATCH_X16, need);      // the fp16 activation copy: per (device, stream), outgrown blocks kept for captured launch lists
+    if (!g_x16) return CLLM_E_HIP;
     hipLaunchKernelGGL(k_f32_to_f16, dim3((unsigned)((K / 2 + 255) / 256), (unsigned) M), dim3(256), 0, st, (const char *) x.data, x.nb[1], K, (uint16_t *) g_x16, ldx);
     LAUNCH_CHECK();
     mmd_args a;

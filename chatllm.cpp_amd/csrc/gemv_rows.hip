@@ -100,7 +100,7 @@ __global__ void __launch_bounds__(1024) k_gemv_rows(const float * __restrict__ p
     if (PRO == 1) {
         __shared__ double part[16];
         const double sum = NPRE == 1 ? rms_block_sumsq_1024_one(vv[0], e0 < K, part) : rms_block_sumsq_1024(px, K, vv[0], part);
-        scale = rms_scale(sum, K, eps);
+        scale = rms_scale(sum, K, eps, px, nullptr, part);
     }
     const int nv = K & ~7;
 #pragma unroll

@@ -85,11 +85,13 @@ __global__ void __launch_bounds__(1024) k_gemv_team32(const float * __restrict__
     uint32_t qt[P];
     const unsigned dA = (unsigned) E * 8u * BS, dB = (unsigned) ustride * 8u * nb01 - (unsigned)(S - E) * 8u * BS;      // to the wave's next step: inside the unit / into the team's next unit
     unsigned woff = (unsigned)(u0 < nunits ? u0 : 0) * (8u * nb01) + lane_off + (unsigned) em * 8u * BS;                // this lane's block of the wave's next requested step
-    const unsigned woff0 = woff;
+    const unsigned wsafe = (unsigned)(u0 < nunits ? u0 : 0) * (8u * nb01) + lane_off;      // block t of the row's first step: inside the matrix for every lane (nblk >= 8)
     int is = em;                                                       // its step inside the unit
-    int irem = (is_emit && em < total) ? (total - em + E - 1) / E : 0; // steps the wave has still to request (past the last: the first once more, never used)
+    int irem = (is_emit && em < total) ? (total - em + E - 1) / E : 0; // steps the wave has still to request (past the last: a block that exists, never used)
     auto issue = [&](int p) {
-        const unsigned o = irem > 0 ? woff : woff0;
+        // lanes whose block lies past the row's end in its last step (nblk % 8 != 0: masked by d = 0 at emit) must not READ there either: for the last row of
+        // the matrix that is up to 7 blocks beyond the tensor -- they re-read a block that exists
+        const unsigned o = (irem > 0 && is * 8 + t < nblk) ? woff : wsafe;
         irem--;
         const char * bp = W + o;                                       // (the matrix is smaller than 4 GiB: launcher)
         if (IS_41) { qt[p] = *(const uint32_t *) bp; qa[p] = *(const u32x4 *)(bp + 4); }
@@ -114,7 +116,7 @@ __global__ void __launch_bounds__(1024) k_gemv_team32(const float * __restrict__
     if (PRO == 1) {
         __shared__ double part[16];
         const double sum = NPRE == 1 ? rms_block_sumsq_1024_one(vv[0], e0 < K, part) : rms_block_sumsq_1024(px, K, vv[0], part);
-        scale = rms_scale(sum, K, eps);
+        scale = rms_scale(sum, K, eps, px, nullptr, part);
     }
     const int nv = K & ~7;
 #pragma unroll

@@ -216,8 +216,7 @@ int launch_mmf_exact(hipStream_t st, const tview & w, const tview & x, const tvi
 
 // ---- the prompt's eager attention block in the reference's order (calc_attn_scores / attn_scores_to_probs, src/layers.cpp:2541-2561, 2499-2539):
 //      S = K.Q (scores never needed beyond the causal horizon are not computed), P = SOFT_MAX(DIAG_MASK_INF(SCALE(S))), ctx = V.P.
-//      The score matrix [n_kv, qlen, heads] goes through a library-owned scratch buffer, a group of heads at a time (<= 1 GiB).
-static void * g_attn_scr_dev[CLLM_DEV_SLOTS]; static size_t g_attn_scr_bytes_dev[CLLM_DEV_SLOTS];      // the score scratch, per device
+//      The score matrix [n_kv, qlen, heads] goes through a library-owned scratch buffer (stream_scratch, capi.hip), a group of heads at a time (<= 1 GiB).
 int attn_prefill_exact(hipStream_t st, const tview & q, const tview & k, const tview & vt, char * dst, int64_t nbn, int64_t nbh, float scale, int n_past) {
     const int64_t hd = q.ne[0], qlen = q.ne[1], nh = q.ne[2], n_kv = k.ne[1], nkv = k.ne[2];
     if (nkv <= 0 || nh % nkv || k.ne[0] != hd || vt.ne[0] != n_kv || vt.ne[1] <= 0 || vt.ne[2] != nkv || q.ne[3] != 1 || k.ne[3] != 1 || n_kv != (int64_t) n_past + qlen) return CLLM_E_UNSUPPORTED;
@@ -228,14 +227,8 @@ int attn_prefill_exact(hipStream_t st, const tview & q, const tview & k, const t
     if (hc < r2) hc = r2;
     if (hc > nh) hc = nh;
     const size_t need = per_head * (size_t) hc;
-    void * & g_attn_scr = g_attn_scr_dev[dev_slot()]; size_t & g_attn_scr_bytes = g_attn_scr_bytes_dev[dev_slot()];
-    if (need > g_attn_scr_bytes) {
-        HIP_TRY(hipStreamSynchronize(st));
-        if (g_attn_scr) (void) hipFree(g_attn_scr);
-        g_attn_scr = nullptr; g_attn_scr_bytes = 0;
-        HIP_TRY(hipMalloc(&g_attn_scr, need));
-        g_attn_scr_bytes = need;
-    }
+    void * g_attn_scr = stream_scratch(st, SCRATCH_ATTN_SCORES, need);      // per (device, stream); an outgrown block stays alive for the launch lists captured with it
+    if (!g_attn_scr) return CLLM_E_HIP;
     for (int64_t h0 = 0; h0 < nh; h0 += hc) {
         const int64_t nhc = h0 + hc <= nh ? hc : nh - h0;
         tview qv = q; qv.data += h0 * q.nb[2]; qv.ne[2] = nhc; qv.ne[3] = 1;

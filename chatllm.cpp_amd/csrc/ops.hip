@@ -22,7 +22,7 @@ __global__ void __launch_bounds__(1024) k_rms_norm(tview s, tview d, const float
     const bool aligned = (((uintptr_t) x) & 15) == 0;
     const f32x4 first = (int64_t) threadIdx.x < (n >> 2) ? rms_load4(x, threadIdx.x, aligned) : f32x4{0, 0, 0, 0};
     const double sum = rms_block_sumsq_1024(x, n, first, part);
-    const float scale = rms_scale(sum, n, eps);
+    const float scale = rms_scale(sum, n, eps, x, nullptr, part);
     for (int64_t i = threadIdx.x; i < n; i += blockDim.x) {
         float v = x[i] * scale;
         if (MUL) v = v * w[i % w_ne0];

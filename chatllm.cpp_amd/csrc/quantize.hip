@@ -116,7 +116,7 @@ __global__ void __launch_bounds__(1024) k_rms_norm_quantize(const char * __restr
 #pragma unroll
     for (int u = 0; u < 4; u++) { const int64_t e = (int64_t) tid * 4 + u * 4096; vv[u] = e < K ? *(const f32x4 *)(x + e) : f32x4{0, 0, 0, 0}; }
     const double sum = rms_block_sumsq_1024(x, K, vv[0], part);
-    const float scale = rms_scale(sum, K, eps);
+    const float scale = rms_scale(sum, K, eps, x, nullptr, part);
 #pragma unroll
     for (int u = 0; u < 4; u++) {
         const int64_t e = (int64_t) tid * 4 + u * 4096;

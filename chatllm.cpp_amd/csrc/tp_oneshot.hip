@@ -13,6 +13,7 @@
 //   while a slower rank still reads it.  The wait is bounded: on a timeout the error word is raised and the launch returns (no hang).
 #include "common.h"
 #include <string.h>
+#include <stdlib.h>
 
 #define TPO_MAX_RANKS 16
 
@@ -23,6 +24,7 @@ struct tp_oneshot {
     unsigned * seq;                            // device: all-reduces done so far
     unsigned * err;                            // device: set when a wait timed out
     bool opened[TPO_MAX_RANKS];
+    bool fine_grained;                         // the receive buffer is fine-grained (coherent across agents while a kernel runs)
 };
 struct tpo_args { char * peer[TPO_MAX_RANKS]; int rank, nranks; unsigned long long max_n; unsigned * seq, * err; };
 
@@ -72,12 +74,17 @@ int cllm_tp_oneshot_create(int rank, int nranks, size_t max_n, void ** out, void
     tp_oneshot * o = new tp_oneshot();
     o->rank = rank; o->nranks = nranks; o->max_n = max_n;
     const size_t bytes = tpo_bytes(nranks, max_n);
-    // fine-grained (coherent across agents) where the driver exports it; plain device memory otherwise (ranks that share one GPU: coherent through its L2)
+    // fine-grained memory (coherent across agents while a kernel runs) is what makes polling a flag that a REMOTE GPU writes over xGMI valid.  Plain (coarse-grained)
+    // device memory is coherent only inside one GPU (through its L2): accepted only when the caller states that every rank runs on this same device
+    // (CLLM_TP_ONESHOT_SAME_DEVICE=1: the two-processes-on-one-GPU tests) -- never silently, a stale flag would show up as wrong tokens, not as an error.
     hipError_t e = hipExtMallocWithFlags((void **) &o->local, bytes, hipDeviceMallocFinegrained);
     hipIpcMemHandle_t h;
     if (e == hipSuccess) { e = hipIpcGetMemHandle(&h, o->local); if (e != hipSuccess) { (void) hipFree(o->local); o->local = nullptr; } }
+    o->fine_grained = e == hipSuccess;
     if (e != hipSuccess) {
         (void) hipGetLastError();
+        const char * same = getenv("CLLM_TP_ONESHOT_SAME_DEVICE");
+        if (!same || strcmp(same, "1")) { delete o; FAIL(CLLM_E_UNSUPPORTED, "tp_oneshot_create: fine-grained IPC memory is not available (%s); the coarse-grained fallback is only valid when all ranks share one GPU (CLLM_TP_ONESHOT_SAME_DEVICE=1)", hipGetErrorString(e)); }
         HIP_TRY(hipMalloc((void **) &o->local, bytes));
         HIP_TRY(hipIpcGetMemHandle(&h, o->local));
     }
@@ -119,6 +126,9 @@ int cllm_tp_oneshot_all_reduce_f32(void * os, void * stream, float * buf, size_t
     LAUNCH_CHECK();
     return CLLM_OK;
 }
+// 1: the receive buffer is fine-grained memory, 0: coarse-grained (ranks sharing one GPU, CLLM_TP_ONESHOT_SAME_DEVICE=1), -1: null
+extern "C" __attribute__((visibility("default")))
+int cllm_tp_oneshot_fine_grained(void * os) { return os ? (int) ((tp_oneshot *) os)->fine_grained : -1; }
 // 1 if a wait timed out since creation (a peer died or the calls went out of step)
 extern "C" __attribute__((visibility("default")))
 int cllm_tp_oneshot_error(void * os) {

@@ -1592,13 +1592,20 @@ GGML_BACKEND_API int ggml_backend_score(void);
 ggml_backend_reg_t ggml_backend_init(void) {
     static std::once_flag once;
     std::call_once(once, [] {
-        const int n = cllm_device_count();
+        // CLLM_HIP_VIRTUAL_DEVICES=n: register n ggml devices over the physical ones (device i runs on GPU i % physical) -- the reference's own multi-device modes
+        // (layer split `-ngl "0:16;1:16"`, src/backend.cpp:677-778: a buffer type, a backend, a stream per device; activations cross through cpy_tensor_async +
+        // events) then run through the real scheduler on a one-GPU box.  Each ggml device has its own buffer type, so tensors of device 1 are foreign to device 0
+        // exactly as on two GPUs; what the physical sharing changes is only that the "peer" copy stays inside one HBM.
+        const int phys = cllm_device_count();
+        int n = phys;
+        if (const char * v = getenv("CLLM_HIP_VIRTUAL_DEVICES")) { const int k = atoi(v); if (k > 0 && phys > 0) n = k > 64 ? 64 : k; }
         g_dev_objs.reserve(n);
         for (int i = 0; i < n; i++) {
             auto * d = new hip_device_ctx();
             char name[256] = "MI355X"; int cus = 0;
-            cllm_device_info(i, name, sizeof(name), nullptr, nullptr, &cus);
-            d->id = i; d->name = "HIP" + std::to_string(i); d->desc = std::string(name) + ", " + std::to_string(cus) + " CUs (chatllm.cpp_amd)";
+            const int gpu = i % phys;
+            cllm_device_info(gpu, name, sizeof(name), nullptr, nullptr, &cus);
+            d->id = gpu; d->name = "HIP" + std::to_string(i); d->desc = std::string(name) + ", " + std::to_string(cus) + " CUs (chatllm.cpp_amd" + (n != phys ? ", GPU " + std::to_string(gpu) : std::string()) + ")";
             g_devices.push_back(d);
             g_dev_objs.push_back(ggml_backend_device{ k_device_i, &g_reg, d });
             d->buft = ggml_backend_buffer_type{ k_buft_i, &g_dev_objs.back(), d };

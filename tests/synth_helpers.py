@@ -36,3 +36,29 @@ def rand_blocks(t, rows, K, rng, d_scale=0.01):
         dm = (rng.uniform(0.25, 1.0, (rows, nb)) * d_scale).astype(np.float16)
         out[:, :, 2:4] = dm.view(np.uint8).reshape(rows, nb, 2)
     return np.ascontiguousarray(out.reshape(rows, nb * TYPE_SIZE[t]))
+
+
+def rms_boundary_rows(n, rows, rng):
+    """rows whose mean of squares sits on a float ROUNDING BOUNDARY to ~2^-54, with terms spread over 36 binades so that the double accumulation rounds at
+    every step: the float the reference's serial loop (ggml_compute_forward_rms_norm_f32, ops.cpp:3736-3741) rounds the mean to is then decided by the
+    ORDER of the additions -- a tree and the serial loop disagree on about half of these rows.  Exact rational arithmetic picks the last two elements."""
+    from fractions import Fraction
+    out = np.zeros((rows, n), np.float32)
+    for r in range(rows):
+        x = (rng.standard_normal(n) * 2.0 ** -12).astype(np.float32)
+        x[0] = np.float32(64.0)                                    # s0 = 4096: every later term loses its low bits to the accumulator's ulp (2^-40)
+        x[n - 2] = x[n - 1] = 0.0
+        sq = lambda v: Fraction(float(np.float32(v) * np.float32(v)))      # the float product the loop adds
+        rest = sum(sq(v) for v in x[: n - 2])
+        m = np.float32(float(rest / n) * (1 + 2.0 ** -10))         # a float a little above the mean so far ...
+        target = (Fraction(float(m)) + Fraction(float(np.spacing(m))) / 2) * n      # ... and the midpoint to its successor, as a sum
+        # coarse: the largest float whose float square stays below what is missing; fine: the same for the remainder (squares ~2^-30, spacing ~2^-54)
+        for j in (n - 2, n - 1):
+            miss = target - rest
+            v = np.float32(np.sqrt(float(miss)))
+            while sq(v) > miss:
+                v = np.nextafter(v, np.float32(0))
+            x[j] = v
+            rest += sq(v)
+        out[r] = x
+    return out

@@ -12,7 +12,7 @@ import pytest
 
 import oracle as O
 from conftest import prefill_mode
-from synth_helpers import rand_blocks
+from synth_helpers import rand_blocks, rms_boundary_rows
 
 pytestmark = pytest.mark.gpu
 rng = np.random.default_rng(11)
@@ -359,13 +359,66 @@ def test_rms_norm(gpu, n0, rows):
     O.rms_norm(O.tensor(x, O.F32, [n0, rows]), O.tensor(want, O.F32, [n0, rows]), 1e-5)
     dx = gpu.Tensor.from_numpy(x)
     got = gpu.ops.rms_norm(dx, 1e-5).numpy()
-    # double-precision sum of the squares in a different order than the CPU's serial loop: the two doubles differ by ~1e-16 relative, so
-    # the float mean -- and with it every output -- has the same bits unless it sits within that distance of a rounding boundary (~1e-7 per row)
-    assert np.allclose(got, want, rtol=3e-7, atol=0)
-    assert np.mean(got.view(np.uint32) == want.view(np.uint32)) > 0.99
+    # the workgroup adds the squares as a tree, the CPU serially: rms_scale (common.h) proves per row that the float mean cannot depend on the order, or redoes
+    # the sum in the reference's order -- every word is the oracle's (test_rms_norm_rows_on_a_rounding_boundary: the rows where the order decides)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
     want2 = want * w                                 # the MUL node: one more rounding
     got2 = gpu.ops.rms_norm_mul(dx, gpu.Tensor.from_numpy(w), 1e-5).numpy()
-    assert np.allclose(got2, want2, rtol=4e-7, atol=0)
+    assert np.array_equal(got2.view(np.uint32), want2.view(np.uint32))
+
+
+@pytest.mark.parametrize("n0", [4096, 1000, 8192, 14336])
+def test_rms_norm_rows_on_a_rounding_boundary(gpu, n0):
+    """rows whose mean of squares lies on a float rounding boundary (tests/synth_helpers.rms_boundary_rows): the float the reference rounds it to depends on the
+    ORDER of its serial double accumulation (ops.cpp:3736-3741); a tree sum gets about half of them wrong by one ulp of the mean.  Every word must be the oracle's."""
+    rows = 24
+    x = rms_boundary_rows(n0, rows, np.random.default_rng(n0))
+    order_matters = 0
+    for r in x:                                      # the test is only worth something if the order does decide: a pairwise sum must disagree with the serial one
+        s = (r * r).astype(np.float64)
+        ser = 0.0
+        for v in s:
+            ser += v
+        order_matters += np.float32(ser / n0) != np.float32(float(np.sum(s)) / n0)
+    assert order_matters >= 4, order_matters
+    w = (1 + 0.1 * rng.standard_normal(n0)).astype(np.float32)
+    want = np.zeros_like(x)
+    O.rms_norm(O.tensor(x, O.F32, [n0, rows]), O.tensor(want, O.F32, [n0, rows]), 1e-5)
+    dx = gpu.Tensor.from_numpy(x)
+    got = gpu.ops.rms_norm(dx, 1e-5).numpy()
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), int(np.sum(got.view(np.uint32) != want.view(np.uint32)))
+    got2 = gpu.ops.rms_norm_mul(dx, gpu.Tensor.from_numpy(w), 1e-5).numpy()
+    assert np.array_equal(got2.view(np.uint32), (want * w).view(np.uint32))
+    # in place (the serial pass reads the row before any thread stores)
+    gpu.ops.rms_norm(dx, 1e-5, dst=dx)
+    assert np.array_equal(dx.numpy().view(np.uint32), want.view(np.uint32))
+
+
+@pytest.mark.parametrize("t,K,N", [(O.Q4_K, 4096, 512), (O.Q4_K, 8192, 256), (O.Q4_0, 4096, 4096), (O.Q8_0, 4096, 384), (O.Q4_1, 4096, 200), (O.Q4_0, 4096, 28672)])
+def test_norm_prologues_on_a_rounding_boundary(gpu, t, K, N):
+    """the same rows through the RMS_NORM prologues of the decode mat-vecs (k_gemv_dec, k_gemv_rows32, k_gemv_team32) and of the prompt's quantizer
+    (k_rms_norm_quantize): equal to the oracle's RMS_NORM -> MUL -> MUL_MAT, bit for bit"""
+    ops, T, L = gpu.ops, gpu.Tensor, gpu.lib.get()
+    cols = 12
+    x = rms_boundary_rows(K, cols, np.random.default_rng(K + N))
+    g = (1 + 0.1 * rng.standard_normal(K)).astype(np.float32)
+    wq = rand_blocks(t, N, K, rng)
+    xn = np.zeros_like(x)
+    O.rms_norm(O.tensor(x, O.F32, [K, cols]), O.tensor(xn, O.F32, [K, cols]), 1e-5)
+    xn = xn * g
+    want = np.zeros((cols, N), np.float32)
+    O.mul_mat(O.tensor(wq, t, [K, N]), O.tensor(xn, O.F32, [K, cols]), O.tensor(want, O.F32, [N, cols]))
+    w = T.from_numpy(wq, t, [K, N])
+    dg = T.from_numpy(g.reshape(1, K))
+    cw = w.c()
+    for c in range(min(cols, 6)):                    # one token: the decode kernels' prologue
+        out = T(gpu.F32, [N, 1])
+        dx = T.from_numpy(x[c:c + 1])
+        gpu.lib.check(L.cllm_op_mul_mat_vec_fused(None, C.byref(cw), 1, dx.data_ptr(), dg.data_ptr(), 1e-5, 0, None, out.data_ptr()), "fused")
+        assert np.array_equal(out.numpy().reshape(N).view(np.uint32), want[c].view(np.uint32)), c
+    if N <= 4096:
+        got = ops.mul_mat_ex(w, T.from_numpy(x), pro=1, norm_w=T.from_numpy(g), eps=1e-5).numpy()      # a prompt: norm inside the quantizer
+        assert np.array_equal(got.reshape(want.shape).view(np.uint32), want.view(np.uint32))
 
 
 @pytest.mark.parametrize("mode,hd,n_dims,ff", [(0, 128, 128, False), (2, 128, 128, False), (0, 64, 32, False), (2, 64, 64, True)])

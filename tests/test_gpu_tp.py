@@ -121,7 +121,7 @@ def _run_two_ranks(tmp_path, seed, mode):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     out = str(tmp_path / f"tp_{mode}.npz")
-    env = dict(os.environ, TP_WORKER_MODE=mode, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env = dict(os.environ, TP_WORKER_MODE=mode, HSA_ENABLE_IPC_MODE_LEGACY="0", CLLM_TP_ONESHOT_SAME_DEVICE="1")      # (both ranks run on the one GPU: the coarse-grained fallback is valid here)
     procs = [subprocess.Popen([sys.executable, os.path.join(root, "tests", "tp_two_ranks_worker.py"), str(r), "2", str(port), out, str(seed)],
                               stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env) for r in range(2)]
     errs = []

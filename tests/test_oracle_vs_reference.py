@@ -224,6 +224,29 @@ def test_rms_norm_bit_exact(n0):
     assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
 
 
+@pytest.mark.parametrize("n0", [4096, 1000])
+def test_rms_norm_on_a_rounding_boundary_is_the_references_serial_sum(n0):
+    """rows whose mean of squares sits on a float rounding boundary (synth_helpers.rms_boundary_rows): the restatement adds in the reference's serial order
+    (ops.cpp:3736-3741), so it agrees with libggml-cpu.so where a pairwise sum would not -- these rows are what the GPU's order-exact RMS_NORM is tested on"""
+    from synth_helpers import rms_boundary_rows
+    R = O.ref()
+    rows = 16
+    x = rms_boundary_rows(n0, rows, np.random.default_rng(n0 + 1))
+    ref = np.zeros_like(x)
+    assert R.ref_unary(0, C.c_int64(n0), C.c_int64(rows), C.c_int64(1), P(x), P(ref), C.c_float(1e-5), C.c_int(0)) == 0
+    got = np.zeros_like(x)
+    O.rms_norm(O.tensor(x, O.F32, [n0, rows]), O.tensor(got, O.F32, [n0, rows]), 1e-5)
+    assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
+    pairwise_wrong = 0
+    for r in x:
+        sq = (r * r).astype(np.float64)
+        ser = 0.0
+        for v in sq:
+            ser += v
+        pairwise_wrong += np.float32(ser / n0) != np.float32(float(np.sum(sq)) / n0)      # (float mean of the serial sum vs of numpy's pairwise sum)
+    assert pairwise_wrong >= 3, pairwise_wrong          # the order decides on these rows
+
+
 @pytest.mark.parametrize("n0", [7, 8, 61, 256])
 def test_silu_bit_exact(n0):
     R = O.ref()
