@@ -42,34 +42,69 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
+def tp_split(n_units, world, rank):
+    """whole-unit split, the first n_units % world ranks hold one unit more (== cllm_tp_split, include/chatllm_hip.h): (first, count)"""
+    base, extra = divmod(n_units, world)
+    return base * rank + min(rank, extra), base + (1 if rank < extra else 0)
+
+
 def shard_rows(arr, rank, n):
     r = arr.shape[0] // n
     return np.ascontiguousarray(arr[rank * r:(rank + 1) * r])
 
 
 def shard_cols(arr, type_, K, rank, n, pkg):
-    """slice the K (input) dimension of quantized rows: whole blocks"""
+    """slice the K (input) dimension of quantized rows in WHOLE blocks; the blocks need not divide evenly (Qwen2-72B's Q8_0 down_proj: 924 blocks over 8 ranks)"""
     bs, blk = pkg.tensor.TYPE_SIZE[type_], pkg.tensor.BLCK[type_]
     nb = K // blk
-    assert nb % n == 0, "K/N must be a whole number of quant blocks"
+    first, cnt = tp_split(nb, n, rank)
     a = arr.reshape(arr.shape[0], nb, bs)
-    per = nb // n
-    return np.ascontiguousarray(a[:, rank * per:(rank + 1) * per, :]).reshape(arr.shape[0], per * bs)
+    return np.ascontiguousarray(a[:, first:first + cnt, :]).reshape(arr.shape[0], cnt * bs)
+
+
+def ffn_share(cfg, down_type, rank, world, pkg):
+    """this rank's ffn features = the columns of its down_proj blocks: (first feature, count)"""
+    blk = pkg.tensor.BLCK[down_type]
+    first, cnt = tp_split(cfg["ffn"] // blk, world, rank)
+    return first * blk, cnt * blk
+
+
+def shard_plan(pkg, cfg, wtype, world):
+    """shape math of the tensor-parallel shards (no GPU, no weights): per rank the local sizes and the bytes of every sharded tensor; raises where a split is impossible"""
+    S = pkg.synth
+    H, hd, F = cfg["hidden"], cfg["head_dim"], cfg["ffn"]
+    if cfg["n_head"] % world or cfg["n_kv_head"] % world:
+        raise ValueError(f"heads {cfg['n_head']} / kv heads {cfg['n_kv_head']} do not divide over {world} ranks")
+    dt = S.down_type(cfg, wtype)
+    rs = pkg.tensor.row_size
+    plan, covered = [], 0
+    for r in range(world):
+        f0, fl = ffn_share(cfg, dt, r, world, pkg)
+        assert f0 == covered and fl > 0 and fl % pkg.tensor.BLCK[dt] == 0 and fl % 8 == 0, (r, f0, fl)
+        covered += fl
+        nh, nkv = cfg["n_head"] // world, cfg["n_kv_head"] // world
+        plan.append({"rank": r, "n_head": nh, "n_kv_head": nkv, "ffn_first": f0, "ffn_local": fl, "down_type": dt, "down_blocks": fl // pkg.tensor.BLCK[dt],
+                     "bytes_per_layer": {"wqkv": (nh + 2 * nkv) * hd * rs(wtype, H), "wo": H * rs(wtype, nh * hd), "wgu": 2 * fl * rs(wtype, H), "wdown": H * rs(dt, fl)}})
+    assert covered == F
+    return plan
 
 
 def build_model(pkg, cfg, wtype, rank, world):
     """generate (this rank's shard of) the synthetic model tensor by tensor and upload it"""
     S = pkg.synth
-    m = pkg.Llama(cfg, None, tp_rank=rank, tp_size=world)
     H, hd, F = cfg["hidden"], cfg["head_dim"], cfg["ffn"]
     QD = cfg["n_head"] * hd
+    f0, fl = ffn_share(cfg, S.down_type(cfg, wtype), rank, world, pkg) if world > 1 else (0, F)
+    m = pkg.Llama(cfg, None, tp_rank=rank, tp_size=world, ffn_local=fl if world > 1 else 0)
     t0 = time.time()
     for name, t, rows, K in S.tensor_list(cfg, wtype):
         a = S.make_tensor_fast(name, t, rows, K)
         base = name.split(".")[-1]
         if world > 1:
-            if base in ("wq", "wk", "wv", "wgate", "wup"):
+            if base in ("wq", "wk", "wv"):
                 a = shard_rows(a, rank, world)
+            elif base in ("wgate", "wup"):
+                a = np.ascontiguousarray(a[f0:f0 + fl])           # the features of this rank's down_proj blocks
             elif base == "wo":
                 a = shard_cols(a, t, QD, rank, world, pkg)
             elif base == "wdown":
@@ -314,11 +349,20 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the host runs (cpu_baseline, dropin) and the prefill leg")
     ap.add_argument("--no-prefill", action="store_true")
     ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 --pmc pass that measures the dominant kernel's HBM traffic (roofline.traffic = null)")
+    ap.add_argument("--dry-run-shards", action="store_true", help="shape math of the N-rank tensor-parallel shards only (no GPU, no weights): one JSON object, then exit")
     ap.add_argument("--no-graph", action="store_true", help="launch the fused decode kernels eagerly (for rocprofv3 kernel traces)")
     args = ap.parse_args()
 
     rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
+    if args.dry_run_shards:
+        pkg = ge.load_package()
+        n = max(world, args.gpus)
+        cfg = pkg.synth.config(args.model, max_len=1024)
+        plan = shard_plan(pkg, cfg, WTYPES[args.wtype], n)
+        if rank == 0:
+            print(json.dumps({"model": args.model, "wtype": args.wtype, "ranks": n, "ffn": cfg["ffn"], "shards": plan}), flush=True)
+        return
     if world != args.gpus:
         log(f"warning: WORLD_SIZE={world} but --gpus {args.gpus}; using WORLD_SIZE")
     dist = None

@@ -81,19 +81,29 @@ static cllm_tensor TS(int type, void * data, int64_t n0, int64_t n1, int64_t n2,
     return t;
 }
 
+extern "C" int cllm_tp_split(int64_t n_units, int tp_size, int tp_rank, int64_t * first, int64_t * count) {
+    if (n_units < 0 || tp_size < 1 || tp_rank < 0 || tp_rank >= tp_size || !first || !count) FAIL(CLLM_E_INVALID, "tp_split: arguments");
+    const int64_t base = n_units / tp_size, extra = n_units % tp_size;
+    *count = base + (tp_rank < extra ? 1 : 0);
+    *first = base * tp_rank + (tp_rank < extra ? tp_rank : extra);
+    return CLLM_OK;
+}
+
 extern "C" int cllm_llama_create(const cllm_llama_config * cfg, void * stream, cllm_llama ** out) {
     if (!cfg || !out) FAIL(CLLM_E_INVALID, "llama_create: null");
     if (cfg->n_layer <= 0 || cfg->hidden <= 0 || cfg->n_head <= 0 || cfg->n_kv_head <= 0 || cfg->head_dim <= 0 || cfg->ffn <= 0 || cfg->vocab <= 0 || cfg->max_len <= 0)
         FAIL(CLLM_E_INVALID, "llama_create: bad config");
     const int tp = cfg->tp_size > 0 ? cfg->tp_size : 1;
-    if (cfg->n_head % tp || cfg->n_kv_head % tp || cfg->ffn % tp || cfg->n_head % cfg->n_kv_head) FAIL(CLLM_E_INVALID, "llama_create: heads/ffn not divisible by tp_size");
+    if (cfg->n_head % tp || cfg->n_kv_head % tp || cfg->n_head % cfg->n_kv_head) FAIL(CLLM_E_INVALID, "llama_create: heads not divisible by tp_size");
+    if (cfg->ffn_local < 0 || cfg->ffn_local > cfg->ffn) FAIL(CLLM_E_INVALID, "llama_create: ffn_local %d outside 0..ffn", cfg->ffn_local);
+    if (cfg->ffn_local == 0 && cfg->ffn % tp) FAIL(CLLM_E_INVALID, "llama_create: ffn %d is not divisible by tp_size %d: pass this rank's share as ffn_local (cllm_tp_split over the down projection's quant blocks)", cfg->ffn, tp);
     cllm_llama * m = new cllm_llama();
     m->cfg = *cfg; m->cfg.tp_size = tp;
     m->st = (hipStream_t) stream;
     if (!m->st) {   // graphs cannot be captured on the legacy NULL stream: own a blocking stream (it still orders against NULL-stream work)
         if (hipStreamCreate(&m->st) != hipSuccess) { (void) hipGetLastError(); m->st = nullptr; } else m->own_stream = true;
     }
-    m->nh = cfg->n_head / tp; m->nkv = cfg->n_kv_head / tp; m->F = cfg->ffn / tp;
+    m->nh = cfg->n_head / tp; m->nkv = cfg->n_kv_head / tp; m->F = cfg->ffn_local > 0 ? cfg->ffn_local : cfg->ffn / tp;
     m->layers.resize(cfg->n_layer);
     *out = m;
     return CLLM_OK;

@@ -36,7 +36,7 @@ int launch_gemv_decode(hipStream_t st, int wtype, const void * W, int64_t K, int
 #define GO3(FMT_, PRO_, EPI_, NPRE_) do { \
         static uint64_t attr = 0; \
         if (lds > 64 * 1024 && dev_flag_unset(attr)) { HIP_TRY(hipFuncSetAttribute((const void *) k_gemv_dec<FMT_, PRO_, EPI_, NPRE_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); dev_flag_set(attr); } \
-        hipLaunchKernelGGL((k_gemv_dec<FMT_, PRO_, EPI_, NPRE_>), dim3((unsigned) grid), dim3(1024), lds, st, px, pw, padd, (const char *) W, nblk, kfull, nrem | ((int) grid << 16), eps, dst, xout, bias, resid, g_gemv_ts, \
+        hipLaunchKernelGGL((k_gemv_dec<FMT_, PRO_, EPI_, NPRE_>), dim3((unsigned) grid), dim3(1024), lds, st, px, pw, padd, (const char *) W, nblk, kfull, nrem, eps, dst, xout, bias, resid, g_gemv_ts, \
                            (const int32_t *) nullptr, 0ull, 0, 0); } while (0)
 #define GO(FMT_) do { \
         if (pro == 1 && epi == 1) { if (npre == 1) GO3(FMT_, 1, 1, 1); else GO3(FMT_, 1, 1, 4); } \
@@ -72,7 +72,7 @@ int launch_gemv_decode_id(hipStream_t st, int wtype, const void * W, size_t w_ex
         static uint64_t attr = 0; \
         if (lds > 64 * 1024 && dev_flag_unset(attr)) { HIP_TRY(hipFuncSetAttribute((const void *) k_gemv_dec<FMT_, 2, EPI_, NPRE_, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); dev_flag_set(attr); } \
         hipLaunchKernelGGL((k_gemv_dec<FMT_, 2, EPI_, NPRE_, true>), dim3((unsigned) grid, (unsigned) n_slots), dim3(1024), lds, st, px, (const float *) nullptr, (const float *) nullptr, (const char *) W, \
-                           nblk, kfull, nrem | ((int) grid << 16), 0.0f, dst, (float *) nullptr, (const float *) nullptr, (const float *) nullptr, (unsigned long long *) nullptr, ids, \
+                           nblk, kfull, nrem, 0.0f, dst, (float *) nullptr, (const float *) nullptr, (const float *) nullptr, (unsigned long long *) nullptr, ids, \
                            (unsigned long long) w_expert_bytes, (int) px_slot_stride, (int) dst_slot_stride); } while (0)
 #define GOMT(FMT_) do { if (epi == 1) { if (npre == 1) GOM(FMT_, 1, 1); else if (npre == 4) GOM(FMT_, 1, 4); else GOM(FMT_, 1, 8); } \
                         else          { if (npre == 1) GOM(FMT_, 0, 1); else if (npre == 4) GOM(FMT_, 0, 4); else GOM(FMT_, 0, 8); } } while (0)

@@ -43,10 +43,6 @@
 #define GEMV_WLOAD(p) (*(p))
 #endif
 #define TS(k) do { if (ts && threadIdx.x == 0) ts[blockIdx.x * 8 + (k)] = wall_clock64(); } while (0)
-// stamps 0 / 1 (entry, loads issued) are only READ at their place (a scalar clock read) and stored together with stamp 2: `ts` lives beyond the 16 preloaded
-// kernel-argument dwords, and a store at the top of the kernel put a scalar-memory wait in front of the weight requests of every launch
-#define TS_READ(v) const unsigned long long v = wall_clock64()
-#define TS_PUT(k, v) do { if (ts && threadIdx.x == 0) ts[blockIdx.x * 8 + (k)] = (v); } while (0)
 
 // FMT: CLLM_TYPE_Q4_K (8 lanes per 144-byte super-block, activation quantized to Q8_K) or CLLM_TYPE_Q4_0 / Q4_1 / Q8_0 (one lane per
 // 18 / 20 / 34-byte block, activation quantized to Q8_0 / Q8_1).  nblk = weight blocks per row.
@@ -54,7 +50,7 @@
 // device memory (ids[slot], the TOP_K node's output), W / px / dst move by the slot: dst[:, slot] = W[:, :, ids[slot]]^T . x[:, slot or 0]
 template <int FMT, int PRO, int EPI, int NPRE, bool MOE = false>
 __global__ void __launch_bounds__(1024) k_gemv_dec(const float * __restrict__ px, const float * __restrict__ pw, const float * __restrict__ padd,
-                                                        const char * __restrict__ W, int nblk, int kfull, int nrem_grid, float eps,
+                                                        const char * __restrict__ W, int nblk, int kfull, int nrem, float eps,
                                                         float * __restrict__ dst, float * __restrict__ xout,
                                                         const float * __restrict__ bias, const float * resid, unsigned long long * ts,
                                                         const int32_t * __restrict__ ids, unsigned long long w_expert_bytes, int px_slot_stride, int dst_slot_stride) {
@@ -86,13 +82,6 @@ __global__ void __launch_bounds__(1024) k_gemv_dec(const float * __restrict__ px
     constexpr int KIND = IS_K ? 256 : 32;                           // elements per weight block = activation quantization block
     constexpr int BS = IS_K ? 144 : q32_fmt<IS_K ? CLLM_TYPE_Q4_0 : FMT>::BS;      // bytes per weight block
     constexpr int BPS = IS_K ? 16 : 64;                             // blocks a wave consumes per step (Q4_K: 4 lanes per super-block, q4k_emit4)
-#ifndef GEMV_PIPE
-#define GEMV_PIPE 1
-#endif
-    // PIPE (long rows, plain quantization: the down projection): activation group u (elements 4096 u ..) is exactly what row step u reads, so only group 0 is
-    // quantized before the rows start; group u + 1 is quantized between the emit and the chain of the first row's step u, behind one LDS barrier per step --
-    // the quantizer's VALU work (2 us for 14336 elements on every CU) runs under the weight stream instead of in front of it.  Same values, same bits.
-    constexpr bool PIPE = GEMV_PIPE && PRO == 2 && IS_K && NPRE > 1 && !MOE && EPI == 0;
     const int tid = threadIdx.x, lane = tid & 63;
     const int K = nblk * KIND;
 
@@ -114,21 +103,15 @@ __global__ void __launch_bounds__(1024) k_gemv_dec(const float * __restrict__ px
     f32x4 pa = {0, 0, 0, 0};
     const bool add = PRO == 1 && NPRE == 1 && padd != nullptr;
     if (add) pa = *(const f32x4 *)(padd + (e0 < K ? e0 : 0));
-    TS_READ(t_entry);
-#ifdef GEMV_ACTBAR
-    // every wave's activation request is in the CU's memory pipeline before any wave's weight requests: the pipeline is a FIFO, and a late wave's (L2-hit)
-    // activation load otherwise queues behind the (HBM) weight requests of the waves that started earlier
-    asm volatile("s_barrier" ::: "memory");
-#endif
+    TS(0);
 
     // ---- (2) two steps of weight prefetch.  Units are dealt in rounds of nwaves: in a full round wave (b, w) takes unit
     //          round*nwaves + 16 b + w (a workgroup streams 16 consecutive rows); the last, partial round is dealt
     //          workgroup-interleaved (w * gridDim + b) so that every CU gets the same share of it. ----
     const int grp = IS_K ? lane >> 2 : lane >> 3, j = IS_K ? lane & 3 : lane & 7;
     const int wave_in_wg = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int gdim = nrem_grid >> 16, nrem = nrem_grid & 0xffff;   // (gridDim.x is a hidden argument beyond the preloaded dwords: the launcher packs it next to nrem < 16 * grid)
-    const int nwaves = gdim * 16;
-    const int lin = blockIdx.x * 16 + wave_in_wg, alt = wave_in_wg * gdim + blockIdx.x;
+    const int nwaves = gridDim.x * 16;
+    const int lin = blockIdx.x * 16 + wave_in_wg, alt = wave_in_wg * gridDim.x + blockIdx.x;
     const int nmine = kfull + (alt < nrem ? 1 : 0);
     const int S = (nblk + BPS - 1) / BPS;                           // steps per row
     const unsigned nb01 = (unsigned) nblk * (unsigned) BS;
@@ -155,7 +138,7 @@ __global__ void __launch_bounds__(1024) k_gemv_dec(const float * __restrict__ px
     };
 #pragma unroll
     for (int p = 0; p < P; p++) issue(p);
-    TS_READ(t_issued);
+    TS(1);
 
     // ---- (3) the activation row: [RMS_NORM * weight | SiLU * up |] quantize -> LDS (act layout of common.h) ----
     float scale = 1.0f;
@@ -170,7 +153,7 @@ __global__ void __launch_bounds__(1024) k_gemv_dec(const float * __restrict__ px
     }
     const int nv = K & ~7;                                          // ggml_vec_silu_f32: polynomial body below nv, libm tail
 #pragma unroll
-    for (int u = 0; u < (PIPE ? 1 : NPRE); u++) {                    // K % KIND == 0: whole quantization lane groups stay together
+    for (int u = 0; u < NPRE; u++) {                                // K % KIND == 0: whole quantization lane groups stay together
         const int e = e0 + u * 4096;
         if (e < K) {
             f32x4 v = vv[u];
@@ -189,7 +172,6 @@ __global__ void __launch_bounds__(1024) k_gemv_dec(const float * __restrict__ px
             if (EPI == 3) quant4_store<KIND, IS_Q41>(lds + act_row_bytes(K, KIND), K, e, lane, gg[u]);
         }
     }
-    TS_PUT(0, t_entry); TS_PUT(1, t_issued);
     TS(2);
     __syncthreads();
     TS(3);
@@ -204,7 +186,7 @@ __global__ void __launch_bounds__(1024) k_gemv_dec(const float * __restrict__ px
     const int l16 = lane & 15;
     float acc = 0.0f, gate = 0.0f;
     int ck = 0, csub = 0, cs = 0;                                   // consume cursor
-    while (ck < nmine || (PIPE && ck == 0)) {                       // (PIPE: every wave walks the first row's steps -- they hold the barriers -- with or without a row)
+    while (ck < nmine) {
 #pragma unroll
         for (int p = 0; p < P; p++) {
             const int b = IS_K ? 16 * cs + grp : 64 * cs + lane;
@@ -217,22 +199,11 @@ __global__ void __launch_bounds__(1024) k_gemv_dec(const float * __restrict__ px
                 q32_emit<IS_K ? CLLM_TYPE_Q4_0 : FMT>(h, w0, w1, arow, off_d, off_s, ok ? b : 0, ok, lane, chain);
             }
             issue(p);
-            const bool pipe_next = PIPE && ck == 0 && cs + 1 < S;   // wave- and workgroup-uniform
-            if constexpr (PIPE) {
-                if (pipe_next) {                                    // the next step's activation group
-                    f32x4 v = vv[1];
-#pragma unroll
-                    for (int u = 2; u < NPRE; u++) if (cs + 1 == u) v = vv[u];
-                    const int e = e0 + (cs + 1) * 4096;
-                    if (e < K) quant4_store<KIND, IS_Q41>(lds, K, e, lane, v);
-                }
-            }
             {                                                       // every step: 16 super-blocks (Q4_K) / 64 blocks of records
                 wave_lds_fence();
                 if (IS_K) q4k_chain(chain, 8, l16, acc); else q32_chain<IS_K ? CLLM_TYPE_Q4_0 : FMT>(chain, l16, acc);
                 wave_lds_fence();
             }
-            if constexpr (PIPE) { if (pipe_next) lds_barrier(); }
             if (++cs == S) {                                        // row complete: finish the chains, epilogue, store (lane 0)
                 float v = chain_finish<IS_K ? 1 : IS_Q41 ? 2 : 0>(acc);
                 if (ck < nmine) {                                   // wave-uniform; bias / resid come through the scalar cache

@@ -15,7 +15,7 @@ int launch_moe_router(hipStream_t st, int wtype, const void * W, int64_t K, int6
 #define GOR(FMT_, NPRE_) do { \
         static uint64_t attr = 0; \
         if (lds > 64 * 1024 && dev_flag_unset(attr)) { HIP_TRY(hipFuncSetAttribute((const void *) k_gemv_dec<FMT_, 1, 2, NPRE_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); dev_flag_set(attr); } \
-        hipLaunchKernelGGL((k_gemv_dec<FMT_, 1, 2, NPRE_>), dim3(1), dim3(1024), lds, st, px, pw, (const float *) nullptr, (const char *) W, nblk, kfull, nrem | (1 << 16), eps, probs, xnorm, \
+        hipLaunchKernelGGL((k_gemv_dec<FMT_, 1, 2, NPRE_>), dim3(1), dim3(1024), lds, st, px, pw, (const float *) nullptr, (const char *) W, nblk, kfull, nrem, eps, probs, xnorm, \
                            (const float *) nullptr, (const float *) nullptr, (unsigned long long *) nullptr, (const int32_t *) ids, 0ull, 0, k); } while (0)
 #define GORT(FMT_) do { if (K <= 4096) GOR(FMT_, 1); else GOR(FMT_, 4); } while (0)
     if (wtype == CLLM_TYPE_Q4_K) GORT(CLLM_TYPE_Q4_K); else if (wtype == CLLM_TYPE_Q4_0) GORT(CLLM_TYPE_Q4_0); else if (wtype == CLLM_TYPE_Q4_1) GORT(CLLM_TYPE_Q4_1); else GORT(CLLM_TYPE_Q8_0);
@@ -42,7 +42,7 @@ int launch_gemv_decode_id_combine(hipStream_t st, int wtype, const void * W, siz
 #define GOC(FMT_, NPRE_) do { \
         static uint64_t attr = 0; \
         if (lds > 64 * 1024 && dev_flag_unset(attr)) { HIP_TRY(hipFuncSetAttribute((const void *) k_gemv_dec<FMT_, 2, 3, NPRE_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); dev_flag_set(attr); } \
-        hipLaunchKernelGGL((k_gemv_dec<FMT_, 2, 3, NPRE_>), dim3((unsigned) grid), dim3(1024), lds, st, px, probs, (const float *) nullptr, (const char *) W, nblk, kfull, nrem | ((int) grid << 16), 0.0f, dst, (float *) nullptr, \
+        hipLaunchKernelGGL((k_gemv_dec<FMT_, 2, 3, NPRE_>), dim3((unsigned) grid), dim3(1024), lds, st, px, probs, (const float *) nullptr, (const char *) W, nblk, kfull, nrem, 0.0f, dst, (float *) nullptr, \
                            (const float *) nullptr, resid, (unsigned long long *) nullptr, ids, (unsigned long long) w_expert_bytes, (int) px_slot_stride, 0); } while (0)
 #define GOCT(FMT_) do { if (npre == 1) GOC(FMT_, 1); else if (npre == 4) GOC(FMT_, 4); else GOC(FMT_, 8); } while (0)
     if (wtype == CLLM_TYPE_Q4_K) GOCT(CLLM_TYPE_Q4_K); else if (wtype == CLLM_TYPE_Q4_0) GOCT(CLLM_TYPE_Q4_0); else if (wtype == CLLM_TYPE_Q4_1) GOCT(CLLM_TYPE_Q4_1); else GOCT(CLLM_TYPE_Q8_0);

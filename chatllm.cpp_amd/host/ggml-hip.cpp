@@ -402,7 +402,7 @@ bool dev_supports_op(ggml_backend_dev_t, const ggml_tensor * op) {
 // ---------------------------------------------------------------------------------------------------------------------------
 // backend (stream): graph_compute
 // ---------------------------------------------------------------------------------------------------------------------------
-const char * be_name(ggml_backend_t b) { return g_devices[((hip_backend_ctx *) b->context)->device]->name.c_str(); }
+const char * be_name(ggml_backend_t b) { return ((hip_device_ctx *) b->device->context)->name.c_str(); }      // (the ggml device's name: several of them can sit on one GPU, CLLM_HIP_VIRTUAL_DEVICES)
 void be_free(ggml_backend_t b) {
     auto * c = (hip_backend_ctx *) b->context;
     cllm_set_device(c->device); cllm_stream_sync(c->stream);
@@ -1472,8 +1472,8 @@ ggml_status be_graph_compute(ggml_backend_t backend, ggml_cgraph * g) {
         for (const merge_group & G : plan.groups) merged_n += G.state == 1;
         int fa_nodes = 0;
         for (int i = 0; i < ggml_graph_n_nodes(g); i++) fa_nodes += ggml_graph_node(g, i)->op == GGML_OP_FLASH_ATTN_EXT;
-        HIPB_LOG("graph_compute: %d nodes -> %d calls%s (%d fused mat-vecs, %d merged over packed weights, attention fused at level 1: %d, level 2: %d, flash prefill: %d, flash_attn_ext: %d, MoE routers: %d, prefill mat-muls with fused prologue / epilogue: %d)",
-                 ggml_graph_n_nodes(g), launches, replayed ? ", replayed from the captured graph" : "", (int) plan.mvs.size(), merged_n, a1, a2, (int) plan.fas.size(), fa_nodes,
+        HIPB_LOG("%s graph_compute: %d nodes -> %d calls%s (%d fused mat-vecs, %d merged over packed weights, attention fused at level 1: %d, level 2: %d, flash prefill: %d, flash_attn_ext: %d, MoE routers: %d, prefill mat-muls with fused prologue / epilogue: %d)",
+                 be_name(backend), ggml_graph_n_nodes(g), launches, replayed ? ", replayed from the captured graph" : "", (int) plan.mvs.size(), merged_n, a1, a2, (int) plan.fas.size(), fa_nodes,
                  (int) plan.routers.size(), (int) plan.pfs.size());
         g_ws.calls += launches;
         if (++g_ws.graphs % 64 == 0) {

@@ -27,7 +27,7 @@ class LlamaConfig(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("n_layer", "hidden", "n_head", "n_kv_head", "head_dim", "ffn", "vocab", "max_len",
                                          "rope_mode")] + \
                [("rope_theta", C.c_float), ("rms_eps", C.c_float), ("qkv_bias", C.c_int32), ("tp_rank", C.c_int32),
-                ("tp_size", C.c_int32)]
+                ("tp_size", C.c_int32), ("ffn_local", C.c_int32)]
 
 
 ALLREDUCE_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64)
@@ -117,6 +117,7 @@ SIGNATURES = {
     "cllm_op_quantize_rows": (C.c_int, [_P, C.c_int, _P, _P, C.c_int64, C.c_int64]),
     "cllm_dequantize_row": (C.c_int, [_P, C.c_int, _P, _P, C.c_int64]),
     "cllm_llama_create": (C.c_int, [C.POINTER(LlamaConfig), _P, C.POINTER(C.c_void_p)]),
+    "cllm_tp_split": (C.c_int, [C.c_int64, C.c_int, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "cllm_llama_destroy": (None, [_P]),
     "cllm_llama_set_weight": (C.c_int, [_P, C.c_char_p, C.c_int, _P, C.c_size_t]),
     "cllm_llama_bind_weight": (C.c_int, [_P, C.c_char_p, C.c_int, _P, C.c_size_t]),

@@ -9,12 +9,12 @@ from . import lib as _l
 
 
 class Llama:
-    def __init__(self, cfg, weights=None, tp_rank=0, tp_size=1):
+    def __init__(self, cfg, weights=None, tp_rank=0, tp_size=1, ffn_local=0):
         _l.require_gpu()
         self.cfg = dict(cfg)
         c = _l.LlamaConfig(cfg["n_layer"], cfg["hidden"], cfg["n_head"], cfg["n_kv_head"], cfg["head_dim"], cfg["ffn"],
                            cfg["vocab"], cfg["max_len"], cfg.get("rope_mode", 0), cfg.get("rope_theta", 500000.0),
-                           cfg.get("rms_eps", 1e-5), 1 if cfg.get("qkv_bias") else 0, tp_rank, tp_size)
+                           cfg.get("rms_eps", 1e-5), 1 if cfg.get("qkv_bias") else 0, tp_rank, tp_size, ffn_local)
         self.h = C.c_void_p()
         _l.check(_l.get().cllm_llama_create(C.byref(c), None, C.byref(self.h)), "llama_create")
         self.n_past = 0

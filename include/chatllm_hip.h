@@ -314,7 +314,12 @@ typedef struct cllm_llama_config {
     float   rope_theta, rms_eps;
     int32_t qkv_bias;
     int32_t tp_rank, tp_size; /* tensor-parallel shard of heads / ffn columns (1 = whole model) */
+    int32_t ffn_local;        /* this rank's share of ffn; 0 = ffn / tp_size.  The down projection is cut in WHOLE quant blocks of its weight type, which need not divide evenly
+                               * (BASELINE cfg4: Qwen2-72B's Q8_0 down_proj has 29568 / 32 = 924 blocks -> 8 ranks get 116, 116, 116, 116, 115, 115, 115, 115: cllm_tp_split);
+                               * gate / up rows are the same features */
 } cllm_llama_config;
+/* whole-unit split of n_units (quant blocks, heads ...) over tp_size ranks: the first n_units % tp_size ranks hold one unit more.  *first / *count: rank's range. */
+CLLM_API int  cllm_tp_split(int64_t n_units, int tp_size, int tp_rank, int64_t * first, int64_t * count);
 
 typedef struct cllm_llama cllm_llama;   /* opaque */
 typedef void (*cllm_allreduce_fn)(void * user, void * stream, float * buf, int64_t n);

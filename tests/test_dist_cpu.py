@@ -56,28 +56,31 @@ def _worker(rank, world, port, q_out):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        for wtype in (O.Q4_K, O.Q8_0):
-            cfg = pkg.synth.config("small")                 # hd 128, 8 heads / 2 kv heads, ffn 2816, hidden 1024
+        # (Q8_0, 2848): 89 quant blocks in a down_proj row -- NOT divisible by the group: rank 0 holds 45 blocks, rank 1 holds 44 (bench.tp_split == cllm_tp_split),
+        # the gate / up rows follow the blocks (BASELINE cfg4: Qwen2-72B's Q8_0 down_proj, 924 blocks over 8 ranks)
+        for wtype, ffn in ((O.Q4_K, 3072), (O.Q8_0, 2816), (O.Q8_0, 2848)):
+            cfg = dict(pkg.synth.config("small"), ffn=ffn)  # hd 128, 8 heads / 2 kv heads, hidden 1024
             H, hd, F = cfg["hidden"], cfg["head_dim"], cfg["ffn"]
-            if wtype == O.Q4_K:
-                cfg = dict(cfg, ffn=3072)                   # ffn / 2 must be a whole number of 256-blocks for Q4_K columns
-                F = 3072
             full = {k.split(".")[-1]: v for k, v in pkg.synth.make_model(cfg, wtype, seed=3, layers=[0]).items() if k.startswith("layers.0.")}
             x = np.random.default_rng(5).standard_normal((1, H)).astype(np.float32)
             QD = cfg["n_head"] * hd
+            f0, fl = bench.ffn_share(cfg, full["wdown"][0], rank, world, pkg)
             sh = dict(full)
-            for k in ("wq", "wk", "wv", "wgate", "wup"):
+            for k in ("wq", "wk", "wv"):
                 sh[k] = (full[k][0], bench.shard_rows(full[k][1], rank, world))
+            for k in ("wgate", "wup"):
+                sh[k] = (full[k][0], np.ascontiguousarray(full[k][1][f0:f0 + fl]))
             sh["wo"] = (full["wo"][0], bench.shard_cols(full["wo"][1], full["wo"][0], QD, rank, world, pkg))
             sh["wdown"] = (full["wdown"][0], bench.shard_cols(full["wdown"][1], full["wdown"][0], F, rank, world, pkg))
-            o_p, d_p = _layer(O, cfg, sh, x, cfg["n_head"] // world, cfg["n_kv_head"] // world, F // world)
+            assert sh["wdown"][1].shape[1] == fl // pkg.tensor.BLCK[full["wdown"][0]] * pkg.tensor.TYPE_SIZE[full["wdown"][0]]
+            o_p, d_p = _layer(O, cfg, sh, x, cfg["n_head"] // world, cfg["n_kv_head"] // world, fl)
             to, td = torch.from_numpy(o_p.copy()), torch.from_numpy(d_p.copy())
             dist.all_reduce(to)                              # the residual-stream all-reduce of the north star
             dist.all_reduce(td)
             o_f, d_f = _layer(O, cfg, full, x, cfg["n_head"], cfg["n_kv_head"], F)
             eo = float(np.max(np.abs(to.numpy() - o_f)) / np.max(np.abs(o_f)))
             ed = float(np.max(np.abs(td.numpy() - d_f)) / np.max(np.abs(d_f)))
-            q_out.put((rank, wtype, eo, ed))
+            q_out.put((rank, (wtype, ffn), eo, ed))
     finally:
         dist.destroy_process_group()
 
@@ -92,6 +95,6 @@ def test_tensor_parallel_shards_reproduce_the_unsharded_layer():
     for p in procs:
         p.join(240)
         assert p.exitcode == 0
-    res = [q.get(timeout=10) for _ in range(world * 2)]
+    res = [q.get(timeout=10) for _ in range(world * 3)]
     for rank, wtype, eo, ed in res:
         assert eo < 1e-5 and ed < 1e-5, (rank, wtype, eo, ed)

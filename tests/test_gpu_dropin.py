@@ -496,3 +496,46 @@ def test_module_decode_ahead_hits_and_misses_stay_bit_identical(gpu, tmp_path):
     assert np.array_equal(lt_c.view(np.uint32), lt_g.view(np.uint32))
     m = re.findall(r"steps started ahead of the host: (\d+), of which the host then asked for: (\d+)", err)
     assert m and int(m[-1][1]) <= 2 and 1 <= int(m[-1][0]) <= 12, m                                   # two misses in a row switch it off for 64 graphs
+
+
+# ---- the boundary between `cpu` and `all`: partial offload and the reference's layer split (src/backend.cpp:677-778), through the real scheduler ----------------
+_SPLITS = [
+    # (CLLM_HIP_VIRTUAL_DEVICES, -ngl spec)
+    (0, "1"),                              # layer 0 on the module; layers 1..3, embedding and lm_head on the CPU: the residual crosses twice per graph
+    (0, "2,prolog"),                       # embedding + the first two layers
+    (0, "3,epilog"),                       # three layers + final norm / lm_head
+    (0, "prolog,epilog"),                  # only the embedding and the head on the module (every decoder layer on the CPU)
+    (2, "0:2;1:2"),                        # the layer split over TWO of the module's devices (both on this GPU), embedding / head on the CPU
+    (2, "0:2,prolog;1:2,epilog"),          # ... everything on the two devices: the residual crosses once, device to device (cpy_tensor_async + event)
+    (2, "0:1;1:2"),                        # two devices AND a CPU remainder
+    (3, "0:1,prolog;1:2;2:1,epilog"),      # three devices
+]
+
+
+@pytest.mark.skipif(not (os.path.exists(os.path.join(REF, "ref_chat")) and os.path.exists(os.path.join(REF, "libggml-hip.so"))),
+                    reason="oracle/_ref (reference host + module) not built")
+@pytest.mark.parametrize("wname,wt", [("q4_k", 12), ("q4_0", 2)])
+def test_reference_host_partial_offload_and_layer_split_are_bit_identical(gpu, tmp_path, wname, wt):
+    """SURVEY 7.2's minimum slice: MIXED CPU / GPU runs.  The unmodified host places some layers on our module and the rest on its CPU backend (`-ngl 1`,
+    `-ngl 2,prolog` ...), or splits them over several of the module's devices (`-ngl "0:2;1:2"`: CLLM_HIP_VIRTUAL_DEVICES registers n ggml devices on the one
+    GPU, each with its own buffer type, backend and stream, so ggml's scheduler cuts the graph, copies the residual across and orders the streams exactly
+    as on n GPUs).  Every placement must reproduce the CPU run: free-running greedy ids and every logit word, for a prompt (one multi-token graph) and the
+    single-token graphs after it."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import make_ggmm
+    cfg = gpu.synth.config("tiny", max_len=96, n_layer=4)
+    mp = str(tmp_path / "m4.bin")
+    make_ggmm.write_model(mp, cfg, wt, seed=404)
+    prompt = [(37 * i + 11) % cfg["vocab"] for i in range(19)]
+    n_dec = 14
+    ids_c, lg_c, _ = _host_run(tmp_path, mp, "cpu", n_dec, prompt, cfg["vocab"])
+    ids_a, lg_a, _ = _host_run(tmp_path, mp, "all", n_dec, prompt, cfg["vocab"])
+    assert ids_c == ids_a and np.array_equal(lg_c.view(np.uint32), lg_a.view(np.uint32))
+    for k, (nvirt, spec) in enumerate(_SPLITS):
+        extra = {"CLLM_HIP_VIRTUAL_DEVICES": str(nvirt)} if nvirt else {}
+        ids_s, lg_s, err = _host_run(tmp_path, mp, spec, n_dec, prompt, cfg["vocab"], SPLIT_CASE=str(k), **extra)
+        assert "ggml-hip" in err or "HIP0" in err, (spec, err[-300:])          # the module took part
+        if nvirt:
+            assert f"HIP{nvirt - 1}" in err, (spec, err[-600:])                # ... with its last device in use
+        assert ids_s == ids_c, (spec, ids_s, ids_c)
+        assert np.array_equal(lg_s.view(np.uint32), lg_c.view(np.uint32)), (spec, int(np.sum(lg_s.view(np.uint32) != lg_c.view(np.uint32))))

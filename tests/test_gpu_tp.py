@@ -148,11 +148,14 @@ def test_one_shot_all_reduce_between_two_processes_equals_the_gloo_all_reduce(gp
     assert np.array_equal(a["ids"], b["ids"])
 
 
-def test_two_ranks_share_the_gpu_and_all_reduce_over_gloo(gpu, tmp_path):
+@pytest.mark.parametrize("shape", ["even", "uneven"])
+def test_two_ranks_share_the_gpu_and_all_reduce_over_gloo(gpu, tmp_path, shape):
     """The HIP tensor-parallel path with REAL partial sums: two processes, both on this GPU, each holding one shard of the model; the runner's all-reduce
     is the host callback over gloo (tests/tp_two_ranks_worker.py).  Against the unsharded runner on the same tokens: the sharded o / down outputs are sums of
     two partials in another fp32 order (tier T1 per op), which the activation quantizers downstream may amplify -- teacher-forced logits within 0.25 sigma,
-    the argmax equal wherever the unsharded top-1 margin exceeds twice the observed deviation; free-running ids compared the same way."""
+    the argmax equal wherever the unsharded top-1 margin exceeds twice the observed deviation; free-running ids compared the same way.
+    shape "uneven": a Qwen2-style block whose Q8_0 down_proj has 89 quant blocks -- rank 0 holds 45 of them (and the matching gate / up rows), rank 1 holds 44
+    (cllm_llama_config.ffn_local; BASELINE cfg4 on 8 ranks is 4 x 116 + 4 x 115 of 924)."""
     import os
     import socket
     import subprocess
@@ -162,7 +165,7 @@ def test_two_ranks_share_the_gpu_and_all_reduce_over_gloo(gpu, tmp_path):
     out = str(tmp_path / "tp.npz")
     seed = 17
     procs = [subprocess.Popen([sys.executable, os.path.join(root, "tests", "tp_two_ranks_worker.py"), str(r), "2", str(port), out, str(seed)],
-                              stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(2)]
+                              stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=dict(os.environ, TP_WORKER_CFG=shape)) for r in range(2)]
     errs = []
     for p in procs:
         try:
@@ -174,7 +177,13 @@ def test_two_ranks_share_the_gpu_and_all_reduce_over_gloo(gpu, tmp_path):
         errs.append(e)
     assert all(p.returncode == 0 for p in procs), [e[-1500:] for e in errs]
     got = np.load(out)
-    cfg = gpu.synth.config("small", max_len=64, ffn=3072)
+    sys.path.insert(0, os.path.join(root, "tests"))
+    import tp_two_ranks_worker
+    os.environ["TP_WORKER_CFG"] = shape
+    try:
+        cfg = tp_two_ranks_worker.worker_cfg(gpu)
+    finally:
+        del os.environ["TP_WORKER_CFG"]
     w = gpu.synth.make_model(cfg, gpu.Q4_K, seed=seed)
     ref = gpu.Llama(cfg, w)
     prompt = np.random.default_rng(seed).integers(0, cfg["vocab"], 12).astype(np.int32)

@@ -13,6 +13,14 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
+def worker_cfg(pkg):
+    """TP_WORKER_CFG=uneven: Qwen2-style block (q/k/v biases, NEOX RoPE) whose ffn is NOT a multiple of 256 -- the reference then keeps down_proj in Q8_0
+    (convert.py:811-829), 2848 / 32 = 89 blocks: rank 0 holds 45, rank 1 holds 44 (BASELINE cfg4's 924 blocks over 8 ranks in small)"""
+    if os.environ.get("TP_WORKER_CFG") == "uneven":
+        return pkg.synth.config("small", max_len=64, ffn=2848, qkv_bias=1, rope_mode=2)
+    return pkg.synth.config("small", max_len=64, ffn=3072)          # 8 heads / 2 kv heads, ffn / 256 divisible by the group size
+
+
 def main():
     rank, world, port, out, seed = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), sys.argv[4], int(sys.argv[5])
     import torch
@@ -24,21 +32,24 @@ def main():
     pkg = load_package()
     pkg.lib.require_gpu()
     L = pkg.lib.get()
-    cfg = pkg.synth.config("small", max_len=64, ffn=3072)          # 8 heads / 2 kv heads, ffn / 256 divisible by the group size
+    cfg = worker_cfg(pkg)
     w = pkg.synth.make_model(cfg, pkg.Q4_K, seed=seed)
     hd = cfg["head_dim"]
     QD, F = cfg["n_head"] * hd, cfg["ffn"]
+    f0, fl = bench.ffn_share(cfg, pkg.synth.down_type(cfg, pkg.Q4_K), rank, world, pkg)      # whole quant blocks of the down projection: uneven where they do not divide
     sh = {}
     for name, (t, arr) in w.items():
         base = name.split(".")[-1]
-        if base in ("wq", "wk", "wv", "wgate", "wup"):
+        if base in ("wq", "wk", "wv", "bq", "bk", "bv"):
             arr = bench.shard_rows(arr, rank, world)
+        elif base in ("wgate", "wup"):
+            arr = np.ascontiguousarray(arr[f0:f0 + fl])
         elif base == "wo":
             arr = bench.shard_cols(arr, t, QD, rank, world, pkg)
         elif base == "wdown":
             arr = bench.shard_cols(arr, t, F, rank, world, pkg)
         sh[name] = (t, arr)
-    m = pkg.Llama(cfg, sh, tp_rank=rank, tp_size=world)
+    m = pkg.Llama(cfg, sh, tp_rank=rank, tp_size=world, ffn_local=fl)
     n_calls = [0]
 
     def allreduce(stream, buf, n):
