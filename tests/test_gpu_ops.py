@@ -358,12 +358,12 @@ def test_rms_norm(gpu, n0, rows):
     want = np.zeros_like(x)
     O.rms_norm(O.tensor(x, O.F32, [n0, rows]), O.tensor(want, O.F32, [n0, rows]), 1e-5)
     dx = gpu.Tensor.from_numpy(x)
-    got = gpu.ops.rms_norm(dx, 1e-5).numpy()
+    got = gpu.ops.rms_norm(dx, 1e-5).numpy().reshape(x.shape)
     # the workgroup adds the squares as a tree, the CPU serially: rms_scale (common.h) proves per row that the float mean cannot depend on the order, or redoes
     # the sum in the reference's order -- every word is the oracle's (test_rms_norm_rows_on_a_rounding_boundary: the rows where the order decides)
     assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
     want2 = want * w                                 # the MUL node: one more rounding
-    got2 = gpu.ops.rms_norm_mul(dx, gpu.Tensor.from_numpy(w), 1e-5).numpy()
+    got2 = gpu.ops.rms_norm_mul(dx, gpu.Tensor.from_numpy(w), 1e-5).numpy().reshape(x.shape)
     assert np.array_equal(got2.view(np.uint32), want2.view(np.uint32))
 
 

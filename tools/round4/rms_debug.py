@@ -14,7 +14,7 @@ for n0 in (8, 100, 4096, 8192, 8192, 16384, 12288, 5120, 1000):
         x = rng.standard_normal((rows, n0)).astype(np.float32)
         want = np.zeros_like(x)
         O.rms_norm(O.tensor(x, O.F32, [n0, rows]), O.tensor(want, O.F32, [n0, rows]), 1e-5)
-        got = pkg.ops.rms_norm(pkg.Tensor.from_numpy(x), 1e-5).numpy()
+        got = pkg.ops.rms_norm(pkg.Tensor.from_numpy(x), 1e-5).numpy().reshape(x.shape)
         if not np.array_equal(got.view(np.uint32), want.view(np.uint32)):
             bad += 1
             for r in range(rows):
