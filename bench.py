@@ -151,6 +151,117 @@ def measure_dominant_kernel(pkg, cfg, wtype, iters=64):
     return {"kernel": "%s (gate/up GEMV %dx%d, decode form)" % (name, rows, H), "bytes_per_launch": nbytes, "avg_us": dur_s * 1e6, "gbs": nbytes / dur_s / 1e9}
 
 
+def kernel_table(pkg, cfg, wtype, n_ctx, iters=48):
+    """the launches of one decoder layer + lm_head, each timed in this process with HIP events over back-to-back launches (launch-to-launch time, weight copies cycled
+    past the Infinity Cache): [{name, kernel, us, bytes, gbs, frac}] -- frac = algorithmic bytes / time / 8 TB/s.  Attention: 64 launches captured in a hipGraph."""
+    L = pkg.lib.get()
+    H, hd, F, V = cfg["hidden"], cfg["head_dim"], cfg["ffn"], cfg["vocab"]
+    QD, KD = cfg["n_head"] * hd, cfg["n_kv_head"] * hd
+    dt = pkg.synth.down_type(cfg, wtype)
+    rng = np.random.default_rng(0)
+    rows = []
+
+    def gemv(name, t, K, N, pro, epi, resid):
+        rs = pkg.tensor.row_size(t, K)
+        nbytes = N * rs
+        n_copies = max(2, int(1.2 * 2**30 // nbytes) + 1)
+        w0 = pkg.synth.make_tensor_fast("kt." + name, t, N, K)
+        ws = [pkg.Tensor.from_numpy(w0, t, [K, N]) for _ in range(n_copies)]
+        x = pkg.Tensor.from_numpy(rng.standard_normal((1, K)).astype(np.float32))
+        g = pkg.Tensor.from_numpy((1 + 0.1 * rng.standard_normal((1, K))).astype(np.float32))
+        y = pkg.Tensor(pkg.F32, [N, 1])
+        r = pkg.Tensor.from_numpy(rng.standard_normal((1, N)).astype(np.float32)) if resid else None
+        ptrs = (C.c_void_p * n_copies)(*[w.data_ptr().value for w in ws])
+        us = C.c_float()
+        pkg.lib.check(L.cllm_bench_gemv_fused(None, t, ptrs, n_copies, K, N, pro, x.data_ptr(), g.data_ptr(), cfg["rms_eps"], epi, y.data_ptr(),
+                                              r.data_ptr() if r is not None else None, iters, C.byref(us)), "bench_gemv_fused " + name)
+        rows.append({"name": name, "us": round(us.value, 3), "bytes": nbytes, "gbs": round(nbytes / us.value / 1e3, 1), "frac": round(nbytes / us.value / 1e3 / HBM_PEAK_GBS, 4)})
+        del ws
+
+    gemv("qkv (norm + quantize prologue)", wtype, H, QD + 2 * KD, 1, 0, False)
+    # attention: RoPE + KV write + scores + soft-max + V.P of one token at n_ctx cached positions
+    try:
+        ML = max(64, (n_ctx + 63) // 64 * 64)
+        st = C.c_void_p()
+        pkg.lib.check(L.cllm_stream_create(C.byref(st)), "stream_create")
+        qkv = pkg.Tensor.from_numpy(rng.standard_normal((1, QD + 2 * KD)).astype(np.float32))
+        kc = pkg.Tensor.from_numpy((rng.standard_normal((ML, KD)) * 0.5).astype(np.float16))
+        vc = pkg.Tensor.from_numpy((rng.standard_normal((KD, ML)) * 0.5).astype(np.float16))
+        pos = pkg.Tensor.from_numpy(np.array([n_ctx - 1], np.int32))
+        cs = pkg.Tensor(pkg.F32, [hd])
+        out = pkg.Tensor(pkg.F32, [QD])
+        ws = L.cllm_attn_decode_wsize(n_ctx, cfg["n_head"], ML)
+        buf = pkg.tensor.Buffer(ws) if ws else None
+
+        def launch():
+            return L.cllm_op_rope_kv_attn_decode(st, qkv.data_ptr(), pos.data_ptr(), cs.data_ptr(), cfg["rope_theta"], n_ctx, cfg["n_head"], cfg["n_kv_head"], hd,
+                                                 cfg.get("rope_mode", 0), kc.data_ptr(), vc.data_ptr(), ML, out.data_ptr(), buf.ptr if buf else None, buf.nbytes if buf else 0)
+        pkg.lib.check(L.cllm_op_rope_table(st, pos.data_ptr(), hd, cfg["rope_theta"], cs.data_ptr()), "rope_table")
+        pkg.lib.check(launch(), "attn warm-up")
+        pkg.lib.check(L.cllm_stream_sync(st), "sync")
+        pkg.lib.check(L.cllm_graph_capture_begin(st), "capture")
+        for _ in range(64):
+            pkg.lib.check(launch(), "attn capture")
+        ge_ = C.c_void_p()
+        pkg.lib.check(L.cllm_graph_capture_end(st, C.byref(ge_)), "capture_end")
+        e0, e1 = C.c_void_p(), C.c_void_p()
+        pkg.lib.check(L.cllm_event_create(C.byref(e0)), "event"); pkg.lib.check(L.cllm_event_create(C.byref(e1)), "event")
+        pkg.lib.check(L.cllm_graph_launch(ge_, st), "graph")
+        pkg.lib.check(L.cllm_event_record(e0, st), "record")
+        for _ in range(8):
+            pkg.lib.check(L.cllm_graph_launch(ge_, st), "graph")
+        pkg.lib.check(L.cllm_event_record(e1, st), "record")
+        pkg.lib.check(L.cllm_event_sync(e1), "event_sync")
+        ms = C.c_float()
+        pkg.lib.check(L.cllm_event_elapsed_ms(e0, e1, C.byref(ms)), "elapsed")
+        us = ms.value * 1e3 / (8 * 64)
+        kvb = 2 * n_ctx * KD * 2
+        rows.append({"name": "attention (RoPE, KV write, scores, soft-max, V.P; %d cached positions)" % n_ctx, "us": round(us, 3), "bytes": kvb, "gbs": round(kvb / us / 1e3, 1),
+                     "frac": round(kvb / us / 1e3 / HBM_PEAK_GBS, 4)})
+        L.cllm_graph_destroy(ge_); L.cllm_event_destroy(e0); L.cllm_event_destroy(e1); L.cllm_stream_destroy(st)
+    except Exception as e:      # noqa: BLE001
+        rows.append({"name": "attention", "error": str(e)})
+    gemv("o (quantize prologue, + residual)", wtype, QD, H, 2, 0, True)
+    gemv("gate/up (norm + quantize prologue, SiLU * up epilogue)", wtype, H, 2 * F, 1, 1 if F % 8 == 0 else 0, False)
+    gemv("down (quantize prologue, + residual)", dt, F, H, 2, 0, True)
+    gemv("lm_head (final norm prologue)", wtype, H, V, 1, 0, False)
+    layer = [r for r in rows[:5] if "us" in r]
+    return {"per_launch": rows, "layer_us": round(sum(r["us"] for r in layer), 2), "layer_bytes": sum(r["bytes"] for r in layer),
+            "layer_frac": round(sum(r["bytes"] for r in layer) / sum(r["us"] for r in layer) / 1e3 / HBM_PEAK_GBS, 4) if layer else None,
+            "how": "HIP events over back-to-back launches of each kernel in this process (launch-to-launch time), weight copies cycled past the Infinity Cache"}
+
+
+def ceilings(pkg, with_library_gemm=True):
+    """measured ceilings next to the nominal peaks: a pure streaming read (cllm_bench_read_bw: 2 GiB, 16-byte loads) and the library fp16 GEMM
+    (torch.matmul = hipBLASLt / rocBLAS at 8192^3, in a subprocess: torch brings its own HIP runtime)"""
+    import re
+    import subprocess
+    out = {"hbm_nominal_TBps": HBM_PEAK_GBS / 1e3, "fp16_mfma_nominal_TFLOPs": 2500.0}
+    try:
+        gbs = C.c_float()
+        pkg.lib.check(pkg.lib.get().cllm_bench_read_bw(None, 2 << 30, 6, C.byref(gbs)), "bench_read_bw")
+        out["hbm_read_TBps"] = round(gbs.value / 1e3, 3)
+    except Exception as e:      # noqa: BLE001
+        out["hbm_read_error"] = str(e)
+    if with_library_gemm:
+        try:
+            r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gemm_ceiling.py")], capture_output=True, text=True, timeout=300)
+            m = re.search(r"fp16 \d+\^3: [0-9.]+ ms\s+(\d+) TFLOP/s", r.stdout)
+            mb = re.search(r"bf16 \d+\^3: [0-9.]+ ms\s+(\d+) TFLOP/s", r.stdout)
+            mi = re.search(r"int8 \d+\^3: [0-9.]+ ms\s+(\d+) TOP/s", r.stdout)
+            if m:
+                out["fp16_gemm_TFLOPs"] = float(m.group(1))
+            if mb:
+                out["bf16_gemm_TFLOPs"] = float(mb.group(1))
+            if mi:
+                out["int8_gemm_TOPs"] = float(mi.group(1))
+            if not m:
+                out["library_gemm_error"] = (r.stderr or r.stdout)[-200:]
+        except Exception as e:      # noqa: BLE001
+            out["library_gemm_error"] = str(e)
+    return out
+
+
 def pmc_traffic_live(kernel_substr, timeout=240):
     """HBM bytes per launch of the dominant kernel, measured NOW: a separate rocprofv3 --pmc FETCH_SIZE pass (with --kernel-trace only, as MI355X_MICROARCH.md's HBM section
     prescribes) over a few launches of exactly that kernel (tools/gemv_bench.py --fused, weight copies cycled so that nothing stays in the Infinity Cache); FETCH_SIZE is
@@ -349,6 +460,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the host runs (cpu_baseline, dropin) and the prefill leg")
     ap.add_argument("--no-prefill", action="store_true")
     ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 --pmc pass that measures the dominant kernel's HBM traffic (roofline.traffic = null)")
+    ap.add_argument("--no-kernels", action="store_true", help="skip the per-launch kernel table and the measured ceilings")
+    ap.add_argument("--dropin-cfg5", action="store_true", help="also run BASELINE cfg5 (Mixtral-8x7B shapes, Q4_K, 26 GB GGMM file in /tmp) through the unmodified reference host on the module")
+    ap.add_argument("--dropin-cfg4", action="store_true", help="also run BASELINE cfg4 on ONE GPU (Qwen2-72B shapes, 50 GB GGMM file in /tmp) through the unmodified reference host on the module")
     ap.add_argument("--dry-run-shards", action="store_true", help="shape math of the N-rank tensor-parallel shards only (no GPU, no weights): one JSON object, then exit")
     ap.add_argument("--no-graph", action="store_true", help="launch the fused decode kernels eagerly (for rocprofv3 kernel traces)")
     args = ap.parse_args()
@@ -474,7 +588,7 @@ def main():
     res = {
         "metric": "decode tokens/s", "value": args.steps / dt, "unit": "tokens/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
-        "scaling": "strong" if world > 1 else "weak", "vs_baseline": None, "dtype": "int8xint4 dot / f32 accumulate (Q8_K x Q4_K)" if wtype == 12 else "int8 dot / f32 accumulate",
+        "scaling": "strong", "vs_baseline": None,      # the same model on N GPUs (tensor-parallel shards): total work is fixed as N grows "dtype": "int8xint4 dot / f32 accumulate (Q8_K x Q4_K)" if wtype == 12 else "int8 dot / f32 accumulate",
         "data": "synthetic",
         "config": {"workload": f"{args.model} shapes, {args.wtype.upper()} weights, single-token decode, batch 1, {args.n_prompt}-token prompt, F16 KV cache",
                    "parallelism": f"tp{world}" if world > 1 else "single GPU", "n_ctx_end": args.n_prompt + args.warmup + args.steps},
@@ -493,6 +607,12 @@ def main():
                                    "traffic": traffic, "traffic_source": tsrc, "kernel": k["kernel"], "avg_us": k["avg_us"], "bytes_per_launch": k["bytes_per_launch"]}
             except Exception as e:      # the throughput number stands on its own
                 res["roofline"] = {"error": str(e)}
+            if not args.no_kernels:
+                try:
+                    res["kernels"] = kernel_table(pkg, cfg, wtype, args.n_prompt + args.warmup + args.steps // 2)
+                except Exception as e:      # noqa: BLE001
+                    res["kernels"] = {"error": str(e)}
+                res["ceilings"] = ceilings(pkg, with_library_gemm=not args.no_cpu_baseline)
             res["host_cores"] = host_cores()
             if not args.no_cpu_baseline:
                 import tempfile
@@ -517,6 +637,21 @@ def main():
                         res["dropin_tok_s"] = res["dropin"].get("tok_s")          # the through-the-boundary number (unmodified reference host on the module), first class
                     except Exception as e:
                         res["dropin"] = {"error": str(e)}
+                for flag, key, arch, cname, ndec in ((args.dropin_cfg5, "dropin_cfg5", "mixtral", "mixtral-8x7b", 272), (args.dropin_cfg4, "dropin_cfg4_one_gpu", "qwen2", "qwen2-72b", 144)):
+                    if not flag:
+                        continue
+                    try:
+                        import subprocess
+                        mp5 = f"/tmp/{cname}-q4_k.bin"
+                        if not os.path.exists(mp5):
+                            rc = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "make_ggmm.py"), "--arch", arch, "--config", cname, "--wtype", "q4_k", "--max-len", "512",
+                                                 "--fast", "--out", mp5], capture_output=True, text=True)
+                            if rc.returncode != 0:
+                                raise RuntimeError("make_ggmm failed: " + rc.stderr[-300:])
+                        res[key] = dropin_through_the_boundary(mp5, n_decode=ndec)
+                        res[key]["model"] = cname + " shapes, Q4_K (down_proj per the reference's fallback rule), 16-token prompt"
+                    except Exception as e:      # noqa: BLE001
+                        res[key] = {"error": str(e)}
                 if not args.no_prefill and args.model == "llama3-8b":
                     try:
                         res["prefill"] = prefill_cfg3(pkg, args.model)

@@ -523,6 +523,43 @@ extern "C" int cllm_bench_gemv_fused(void * stream, int wtype, void * const * w_
     return CLLM_OK;
 }
 
+// measurement helper (bench.py `ceilings`): what a pure streaming read reaches on this device -- every lane sums 16-byte loads of a buffer larger than the Infinity Cache
+// ("record an achieved-copy ceiling" next to the 8 TB/s nominal peak).  4 loads in flight per lane, two 1024-thread workgroups per CU.
+__global__ void __launch_bounds__(1024) k_bench_read(const u32x4 * __restrict__ p, size_t n16, unsigned * out) {
+    unsigned acc = 0;
+    const size_t stride = (size_t) gridDim.x * blockDim.x;
+    size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i + 3 * stride < n16; i += 4 * stride) {
+        const u32x4 a = p[i], b = p[i + stride], c = p[i + 2 * stride], d = p[i + 3 * stride];
+        acc += (a.x ^ a.y ^ a.z ^ a.w) + (b.x ^ b.y ^ b.z ^ b.w) + (c.x ^ c.y ^ c.z ^ c.w) + (d.x ^ d.y ^ d.z ^ d.w);
+    }
+    for (; i < n16; i += stride) { const u32x4 a = p[i]; acc += a.x ^ a.y ^ a.z ^ a.w; }
+    if (acc == 0x12345678u) out[0] = acc;          // (keeps the loads alive; the buffer is filled with 0x01 bytes: never true)
+}
+extern "C" int cllm_bench_read_bw(void * stream, size_t bytes, int iters, float * gb_per_s) {
+    if (!gb_per_s || iters <= 0 || bytes < (1u << 20)) FAIL(CLLM_E_INVALID, "bench_read_bw: arguments");
+    hipStream_t st = (hipStream_t) stream;
+    char * buf = nullptr; unsigned * out = nullptr;
+    HIP_TRY(hipMalloc((void **) &buf, bytes + 16));
+    out = (unsigned *)(buf + (bytes & ~(size_t) 15));
+    HIP_TRY(hipMemsetAsync(buf, 1, bytes + 16, st));
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
+    const unsigned grid = (unsigned) device_cu_count() * 2;
+    for (int pass = 0; pass < 2; pass++) {
+        if (pass == 1) HIP_TRY(hipEventRecord(e0, st));
+        for (int i = 0; i < (pass == 0 ? 1 : iters); i++) hipLaunchKernelGGL(k_bench_read, dim3(grid), dim3(1024), 0, st, (const u32x4 *) buf, bytes / 16, out);
+    }
+    HIP_TRY(hipEventRecord(e1, st));
+    HIP_TRY(hipEventSynchronize(e1));
+    float ms = 0.0f;
+    HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+    (void) hipEventDestroy(e0); (void) hipEventDestroy(e1);
+    HIP_TRY(hipFree(buf));
+    *gb_per_s = (float)((double)(bytes / 16 * 16) * iters / (ms * 1e-3) / 1e9);
+    return CLLM_OK;
+}
+
 // gate and up expert mat-vecs of ONE token + UNARY(SILU) + MUL (MultiMLP::forward, src/layers.cpp:3674-3688) in one launch:
 // as_gu = the gate and up expert tensors with their rows alternating inside every expert (cllm_pack_rows over [K, F * E], interleave 1):
 // [K, 2F, E]; dst[u, slot] = silu(gate_e[u] . x) * (up_e[u] . x), e = ids[slot]; b: [K, 1 | n_used, 1], dst: [F, n_used, 1]

@@ -56,7 +56,7 @@ extern "C" int cllm_op_rms_norm_mul(void * stream, const cllm_tensor * src, cons
 //   YaRN mixing (rope_yarn :5596-5611).  One workgroup per token: the first n_dims/2 threads build
 //   the cos/sin cache in LDS, then all threads rotate that token's heads.  In-place safe.
 // ================================================================================================
-struct rope_k_params { int n_dims, mode; float theta_scale, freq_scale, ext_factor, attn_factor, corr0, corr1; };
+struct rope_k_params { int n_dims, mode; float theta_scale, freq_scale, ext_factor, attn_factor, corr0, corr1, mscale_yarn; };
 
 __global__ void __launch_bounds__(256) k_rope(tview s, tview d, const int32_t * __restrict__ pos, const float * __restrict__ ff, rope_k_params p) {
     extern __shared__ float cache[];                 // [n_dims]: cos, sin interleaved
@@ -72,8 +72,8 @@ __global__ void __launch_bounds__(256) k_rope(tview s, tview d, const int32_t * 
         if (p.ext_factor != 0.0f) {
             const float y = ((float) i - p.corr0) / fmaxf(0.001f, p.corr1 - p.corr0);      // i == i0/2
             const float ramp = (1.0f - fminf(1.0f, fmaxf(0.0f, y))) * p.ext_factor;
-            th = theta_interp * (1 - ramp) + theta_extrap * ramp;
-            mscale *= 1.0f + 0.1f * logf(1.0f / p.freq_scale);
+            th = __builtin_fmaf(theta_interp, 1 - ramp, theta_extrap * ramp);      // (gcc contracts the reference's statement into this fma: oracle rope_yarn)
+            mscale = p.mscale_yarn;                                                // attn_factor * fma(0.1f, logf(1 / freq_scale), 1.0f): the host's libm (launcher)
         }
         float cs, sn;
         rope_cos_sin(th, &cs, &sn);
@@ -125,6 +125,7 @@ extern "C" int cllm_op_rope(void * stream, const cllm_tensor * src, const cllm_t
     const float start = floorf(rope_corr_dim(p->n_dims, p->n_ctx_orig, p->beta_fast, p->freq_base));
     const float end   = ceilf (rope_corr_dim(p->n_dims, p->n_ctx_orig, p->beta_slow, p->freq_base));
     k.corr0 = fmaxf(0.0f, start); k.corr1 = fminf((float)(p->n_dims - 1), end);
+    k.mscale_yarn = p->attn_factor * fmaf(0.1f, logf(1.0f / p->freq_scale), 1.0f);      // glibc's logf on the host: the reference's own value (ops.cpp:5607)
     hipLaunchKernelGGL(k_rope, dim3((unsigned)(src->ne[2] * src->ne[3])), dim3(256), (size_t) p->n_dims * 4, (hipStream_t) stream,
                        tv(src), tv(dst), (const int32_t *) pos->data, freq_factors ? (const float *) freq_factors->data : nullptr, k);
     LAUNCH_CHECK();

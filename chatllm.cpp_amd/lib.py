@@ -75,6 +75,7 @@ SIGNATURES = {
     "cllm_pack_rows": (C.c_int, [_P, _P, C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.c_int, C.c_size_t, C.c_int]),
     "cllm_bench_mul_mat_kernel": (C.c_int, [_P, _T, C.POINTER(C.c_void_p), C.c_int, _T, _T, _P, C.c_size_t, C.c_int, C.POINTER(C.c_float)]),
     "cllm_bench_mul_mat_id": (C.c_int, [_P, _T, _T, _T, C.POINTER(C.c_void_p), C.c_int, _T, _P, C.c_size_t, C.c_int, C.POINTER(C.c_float)]),
+    "cllm_bench_read_bw": (C.c_int, [_P, C.c_size_t, C.c_int, C.POINTER(C.c_float)]),
     "cllm_bench_gemv_fused": (C.c_int, [_P, C.c_int, C.POINTER(C.c_void_p), C.c_int, C.c_int64, C.c_int64, C.c_int, _P, _P, C.c_float, C.c_int, _P, _P, C.c_int,
                                         C.POINTER(C.c_float)]),
     "cllm_op_mul_mat_id": (C.c_int, [_P, _T, _T, _T, _T, _P, C.c_size_t]),

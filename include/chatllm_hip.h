@@ -166,6 +166,8 @@ CLLM_API int    cllm_bench_mul_mat_id(void * stream, const cllm_tensor * as, con
  *   pro 1: act = quantize(rms_norm(px[0..K)) * pw)   pro 2: act = quantize(px)   pro 3: act = quantize(silu(px[2i]) * px[2i+1])
  * dst[r] = W[r] . act (+ resid[r]);  epi 1: W rows alternate gate_u, up_u and dst[u] = silu(W[2u].act) * (W[2u+1].act).
  * These are the launches cllm_llama_decode_* issues per layer. */
+/* measurement helper: GB/s of a pure streaming read of `bytes` (> the 256 MiB Infinity Cache) on the current device -- the achieved-read ceiling bench.py prints next to the nominal 8 TB/s */
+CLLM_API int    cllm_bench_read_bw(void * stream, size_t bytes, int iters, float * gb_per_s);
 CLLM_API int    cllm_bench_gemv_fused(void * stream, int wtype, void * const * w_datas, int n_w, int64_t K, int64_t nrows, int pro,
                                       const float * px, const float * pw, float eps, int epi, float * dst, const float * resid, int iters, float * avg_us);
 

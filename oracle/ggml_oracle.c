@@ -1131,8 +1131,10 @@ static void rope_yarn(float theta_extrap, float freq_scale, const float corr[2],
     float theta = theta_interp;
     if (ext_factor != 0.0f) {
         const float mix = rope_ramp(corr[0], corr[1], (int) i0) * ext_factor;
-        theta = theta_interp * (1 - mix) + theta_extrap * mix;
-        mscale *= 1.0f + 0.1f * logf(1.0f / freq_scale);
+        /* as the reference build compiles the two statements (gcc contracts a * b + c into one fma; found by enumerating the contraction forms against
+         * libggml-cpu.so, bit for bit: tests/test_oracle_vs_reference.py::test_rope_yarn) */
+        theta = fmaf(theta_interp, 1 - mix, theta_extrap * mix);
+        mscale *= fmaf(0.1f, logf(1.0f / freq_scale), 1.0f);
     }
     *c = cosf(theta) * mscale;
     *s = sinf(theta) * mscale;

@@ -29,6 +29,40 @@ def rel(a, b):
 
 
 # ---------------------------------------------------------------- CPU: oracle vs golden
+CV = np.load(os.path.join(os.path.dirname(__file__), "golden", "convert_py_reference.npz"))      # bytes written by the reference's converter (tests/golden/make_convert_golden.py)
+
+
+@pytest.mark.parametrize("t,name", [(O.Q8_0, "q8_0"), (O.Q4_0, "q4_0"), (O.Q4_1, "q4_1"), (O.Q4_K, "q4_k")])
+def test_convert_py_quantizers(t, name):
+    """the reference's torch quantizers (convert.py:328-568 -- what writes every stock chatllm model file; quantize_q4_k claims "byte-identical to the original" at
+    :491-494) against the oracle's from_float_ref restatement (itself pinned byte for byte to libggml-base.so): a second, independent statement of the encodings.
+    Q8_0 / Q4_1: every byte equal.  Q4_0: the converter divides by the scale and rounds half to even (`(x / scale + 8).round()`, convert.py:346) where ggml multiplies
+    by 1 / d and truncates x + 8.5 (ggml-quants.c:36-70), and it has no zero-block guard -- ties and all-zero blocks differ, by at most one step.  Q4_K: the
+    converter's search is vectorised float32 torch, the C reference's a scalar loop.  For those two the differing rows are counted and must decode to the same
+    weights within two quantization steps (so a stock model file and an on-load re-quantization of the same floats are the same model, not the same bytes)."""
+    n_rows = n_same = 0
+    exact = t in (O.Q8_0, O.Q4_1)
+    for key in [k for k in CV.files if k.startswith("x_")]:
+        x, want = CV[key], CV[name + key[1:]]
+        for r in range(x.shape[0]):
+            got = O.quantize_ref(t, x[r])
+            n_rows += 1
+            if np.array_equal(got, want[r]):
+                n_same += 1
+                continue
+            assert not exact, (name, key, r, int(np.argmax(got != want[r])))
+            K = x.shape[1]
+            a, b = O.dequantize(t, got, K), O.dequantize(t, want[r], K)
+            amax32 = np.abs(x[r]).reshape(-1, 32).max(axis=1).repeat(32)
+            step = amax32 / (8.0 if t == O.Q4_0 else 15.0) + 1e-12
+            if t == O.Q4_K:                          # sub-block scales are 6-bit fractions of the super-block's largest: a step of that grid on top
+                step = step + np.abs(x[r]).reshape(-1, 256).max(axis=1).repeat(256) / 63.0
+            assert np.all(np.abs(a - b) <= 2.0 * step + 1e-6), (key, r, float(np.max(np.abs(a - b) / step)))
+    if exact:
+        assert n_same == n_rows
+    print(f"{name}: {n_same} of {n_rows} rows byte-identical to convert.py")
+
+
 @pytest.mark.parametrize("K", [256, 4096])
 def test_oracle_quantizers_match_golden_bytes(K):
     x = G[f"quant_x_{K}"]

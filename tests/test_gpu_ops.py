@@ -442,12 +442,15 @@ def test_rope(gpu, mode, hd, n_dims, ff):
 def test_rope_yarn(gpu):
     hd, heads, qlen = 64, 2, 4
     x = rng.standard_normal((qlen, heads, hd)).astype(np.float32)
-    pos = np.array([0, 3, 17, 50], np.int32)
+    pos = np.array([0, 3, 17, 50, 333, 1000, 4095, 20000], np.int32)
+    qlen = len(pos)
+    x = rng.standard_normal((qlen, heads, hd)).astype(np.float32)
     want = np.zeros_like(x)
     kw = dict(n_ctx_orig=4096, freq_scale=0.25, ext_factor=1.0, attn_factor=1.2, beta_fast=32.0, beta_slow=1.0)
     O.rope(O.tensor(x, O.F32, [hd, heads, qlen]), pos, None, O.tensor(want, O.F32, [hd, heads, qlen]), hd, 2, 10000.0, **kw)
     got = gpu.ops.rope_ext(gpu.Tensor.from_numpy(x), gpu.Tensor.from_numpy(pos), None, hd, 2, freq_base=10000.0, **kw).numpy()
-    assert np.max(np.abs(got - want)) < 2e-5
+    # theta's YaRN mix and the magnitude correction are the reference build's two fmas, logf is the host's libm, cos / sin glibc's to the bit: every word equal
+    assert np.array_equal(got.reshape(want.shape).view(np.uint32), want.view(np.uint32)), float(np.max(np.abs(got.reshape(want.shape) - want)))
 
 
 @pytest.mark.parametrize("n0", [1, 5, 8, 33, 1024, 4097])
@@ -875,3 +878,17 @@ def test_packed_rows_merge_mat_vecs_without_changing_a_bit(gpu, t, K, F):
     wg, wu = (T.from_numpy(rand_blocks(t, F, K, rng), t, [K, F]) for _ in range(2))
     want = ops.mul(ops.silu(ops.mul_mat(wg, act)), ops.mul_mat(wu, act)).numpy().reshape(-1)
     assert np.array_equal(fused(pack([wg, wu], 1), 2 * F, 1, F).view(np.uint32), want.view(np.uint32))
+
+
+# ---- randomized differential run (tools/fuzz_parity.py): random shapes / types / column counts / context lengths, bit equality with the oracle ----
+def test_fuzz_parity_thirty_seconds(gpu):
+    """the fuzzer behind profiles/r03_fuzz_parity.txt as a test: 30 s of seeded random cases (MUL_MAT of every weight type and column count, the fused decode
+    mat-vec forms, MUL_MAT_ID, the single-token attention block, the device weight quantizers) -- every result must have the oracle's bits"""
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_parity.py"), "--seconds", "30", "--seed", "20260924"], capture_output=True, text=True, timeout=600)
+    tail = (r.stdout + r.stderr)[-1500:]
+    assert r.returncode == 0, tail
+    assert "0 mismatches" in r.stdout or "mismatches: 0" in r.stdout or "0 mismatch" in r.stdout, tail
