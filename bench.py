@@ -480,6 +480,7 @@ def main():
     if world != args.gpus:
         log(f"warning: WORLD_SIZE={world} but --gpus {args.gpus}; using WORLD_SIZE")
     dist = None
+    rccl_ranks = None
     tp_setup = world > 1 or os.environ.get("CLLM_BENCH_TP_SELFTEST") == "1"          # (self-test: walk the communicator set-up with one rank)
     if tp_setup:
         # torch FIRST: it bundles its own HIP runtime; initialised after libchatllm_hip.so has loaded /opt/rocm's, it finds "No HIP GPUs"
@@ -527,7 +528,12 @@ def main():
             native = int(okflag.item()) == 1
             if native:
                 m.set_tp_comm(comm)
-                log(f"[rank {rank}] tensor parallel over RCCL (native communicator, all-reduce inside the decode graph)")
+                nr, ur = C.c_int(), C.c_int()
+                pkg.lib.check(L.cllm_tp_comm_info(comm, C.byref(nr), C.byref(ur)), "tp_comm_info")
+                if nr.value != world or ur.value != rank:
+                    raise RuntimeError(f"RCCL reports rank {ur.value} of {nr.value}, the launcher said rank {rank} of {world}")
+                rccl_ranks = nr.value
+                log(f"[rank {rank}] tensor parallel over RCCL: the communicator reports rank {ur.value} of {nr.value} (all-reduce inside the decode graph)")
                 if os.environ.get("CLLM_TP_ONESHOT") == "1":
                     # opt-in: the decode-sized all-reduces ([hidden] fp32) as ONE kernel launch each -- every rank writes its partial vector into every peer's
                     # IPC-mapped receive buffer and sums the slots in rank order (tp_oneshot.hip); prompt-sized messages stay on RCCL.  All ranks decide together.
@@ -551,8 +557,13 @@ def main():
                     if int(ok1.item()) == 1:
                         m.set_tp_oneshot(osh)
                         log(f"[rank {rank}] decode all-reduces through the one-shot direct-write kernel")
+        if not native and os.environ.get("CLLM_BENCH_TORCH_ALLREDUCE") != "1":
+            # the fallback (torch.distributed.all_reduce behind a stream synchronize per collective, decode steps launched eagerly) measures host round trips, not the
+            # path this bench is about: it is an explicit debugging mode, never a silent substitute
+            raise RuntimeError("bench.py --gpus N: the RCCL communicator could not be created on every rank (see the messages above); "
+                               "CLLM_BENCH_TORCH_ALLREDUCE=1 runs the synchronising torch.distributed callback instead (not a valid scaling measurement)")
         if not native:
-            log(f"[rank {rank}] native RCCL path unavailable; using the torch.distributed callback")
+            log(f"[rank {rank}] native RCCL path unavailable; CLLM_BENCH_TORCH_ALLREDUCE=1: using the torch.distributed callback (NOT a valid scaling measurement)")
 
             class _Arr:                       # wrap the raw device pointer for torch (zero copy)
                 def __init__(self, ptr, n):
@@ -591,7 +602,8 @@ def main():
         "scaling": "strong", "vs_baseline": None,      # the same model on N GPUs (tensor-parallel shards): total work is fixed as N grows "dtype": "int8xint4 dot / f32 accumulate (Q8_K x Q4_K)" if wtype == 12 else "int8 dot / f32 accumulate",
         "data": "synthetic",
         "config": {"workload": f"{args.model} shapes, {args.wtype.upper()} weights, single-token decode, batch 1, {args.n_prompt}-token prompt, F16 KV cache",
-                   "parallelism": f"tp{world}" if world > 1 else "single GPU", "n_ctx_end": args.n_prompt + args.warmup + args.steps},
+                   "parallelism": f"tp{world}" if world > 1 else "single GPU", "n_ctx_end": args.n_prompt + args.warmup + args.steps,
+                   "rccl_ranks": rccl_ranks},
     }
     if rank == 0:
         n_ctx = args.n_prompt + args.warmup + args.steps // 2

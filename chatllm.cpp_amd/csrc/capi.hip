@@ -160,6 +160,9 @@ extern "C" int cllm_stream_destroy(void * stream) {
     return CLLM_OK;
 }
 extern "C" int cllm_stream_sync(void * stream) { HIP_TRY(hipStreamSynchronize((hipStream_t) stream)); return CLLM_OK; }
+// after a synchronize: did a bounded wait inside a kernel of the current device time out since the last call (gemv_team32.hip's hand-offs between the waves of a team)?
+// Such a launch winds down instead of hanging and its results are void: CLLM_E_HIP + cllm_last_error.  A host read of a mapped word: free on the per-token path.
+extern "C" int cllm_check_kernel_errors(void) { return gemv_team32_check(); }
 
 // ---- capture / replay of a launch sequence (what ggml_backend_i.graph_plan_create / graph_plan_compute are for, ggml-backend-impl.h:104-113) ----
 // Everything launched on `stream` between begin and end becomes one executable graph; replaying it costs one host call and removes the

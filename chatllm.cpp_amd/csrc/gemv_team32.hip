@@ -243,7 +243,7 @@ __global__ void __launch_bounds__(1024) k_gemv_team32(const float * __restrict__
         }
 #pragma unroll
         for (int p = 0; p < P - 1; p++) if (p < ntail) step(p);        // (wave-uniform)
-        if (nspin >= 0x100000u && lane == 0) atomicOr(err, 1u);
+        if (nspin >= 0x100000u && lane == 0) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         T32_TS(2);
         if (ts && lane == 0) ts[(blockIdx.x * 16 + wave) * 4 + 3] = clock64() - cyc1;
         return;
@@ -316,7 +316,7 @@ __global__ void __launch_bounds__(1024) k_gemv_team32(const float * __restrict__
                 const unsigned v = t32_lds_load(fl);
                 if (!__builtin_amdgcn_ballot_w64(lane < nR && v < (unsigned)(R + 1))) break;
                 __builtin_amdgcn_s_sleep(1);
-                if (++spins > T32_SPINS) { if (lane == 0) atomicOr(err, 2u); dead = true; break; }
+                if (++spins > T32_SPINS) { if (lane == 0) __hip_atomic_store(err, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); dead = true; break; }
             }
         }
         if (DEPTH == 3) {
@@ -340,24 +340,24 @@ __global__ void __launch_bounds__(1024) k_gemv_team32(const float * __restrict__
     if (ts && lane == 0) ts[(blockIdx.x * 16 + wave) * 4 + 3] = clock64() - cyc1;
 }
 
-static unsigned * g_t32_err_dev[CLLM_DEV_SLOTS];                         // the error word, per device
+// the error word, per device: ONE page-locked host word mapped into the device (a timed-out wait stores its code there -- a store nobody else makes), so the check
+// after a synchronize is a plain host read: no copy, no blocking call on the per-token path (the unmodified host's synchronize runs it too: cllm_check_kernel_errors)
+static unsigned * g_t32_err_dev[CLLM_DEV_SLOTS];
+static volatile unsigned * g_t32_err_host[CLLM_DEV_SLOTS];
 static int g_team32_mode = -1;
 static unsigned long long * g_t32_ts = nullptr;
 extern "C" __attribute__((visibility("default"))) void cllm_debug_set_team32_ts(unsigned long long * dev_buf) { g_t32_ts = dev_buf; }   // tools only: [256 workgroups][16 waves][4] stamps
 extern "C" __attribute__((visibility("default"))) void cllm_debug_set_gemv_team32(int mode) { g_team32_mode = mode; }      // tests / tools: 0 off, 1 pick, 4 / 5 / 8 / 16 force the team size
 extern "C" __attribute__((visibility("default"))) int cllm_debug_gemv_team32_error(void) {
-    unsigned e = 0;
-    unsigned * g_t32_err = g_t32_err_dev[dev_slot()];
-    if (g_t32_err && hipMemcpy(&e, g_t32_err, 4, hipMemcpyDeviceToHost) != hipSuccess) return -1;
-    return (int) e;
+    volatile unsigned * h = g_t32_err_host[dev_slot()];
+    return h ? (int) *h : 0;
 }
 
 // after a synchronize: did a hand-off between the waves of a team time out?  (the launch winds down instead of hanging; its results are void)
 int gemv_team32_check() {
-    unsigned * g_t32_err = g_t32_err_dev[dev_slot()];
-    if (!g_t32_err) return CLLM_OK;                                    // never launched on this device
-    unsigned e = 0;
-    HIP_TRY(hipMemcpy(&e, g_t32_err, 4, hipMemcpyDeviceToHost));
+    volatile unsigned * h = g_t32_err_host[dev_slot()];
+    if (!h) return CLLM_OK;                                            // never launched on this device
+    const unsigned e = *h;
     if (e) FAIL(CLLM_E_HIP, "gemv_team32: a hand-off between the waves of a workgroup timed out (code %u); set CLLM_GEMV_TEAM32=0", e);
     return CLLM_OK;
 }
@@ -388,7 +388,13 @@ int launch_gemv_team32(hipStream_t st, int wtype, const void * W, int64_t K, int
     const size_t lds = act_row_bytes(K, wtype == CLLM_TYPE_Q4_1 ? ACT_Q8_1 : ACT_Q8_0) + (wtype == CLLM_TYPE_Q4_0 ? (size_t) K : 0) + 32 * (size_t) T32_SLOT_BYTES;
     if (lds > 158 * 1024) return CLLM_E_UNSUPPORTED;
     unsigned * & g_t32_err = g_t32_err_dev[dev_slot()];
-    if (!g_t32_err) { HIP_TRY(hipMalloc((void **) &g_t32_err, 4)); HIP_TRY(hipMemset(g_t32_err, 0, 4)); }
+    if (!g_t32_err) {
+        unsigned * h = nullptr;
+        HIP_TRY(hipHostMalloc((void **) &h, 64, hipHostMallocMapped));
+        *h = 0;
+        HIP_TRY(hipHostGetDevicePointer((void **) &g_t32_err, h, 0));
+        g_t32_err_host[dev_slot()] = h;
+    }
     const int npre = K <= 4096 ? 1 : K <= 16384 ? 4 : 8;
 #define GOT(FMT_, PRO_, NPRE_) do { \
         static uint64_t attr = 0; \

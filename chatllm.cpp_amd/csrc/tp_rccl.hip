@@ -14,10 +14,11 @@ typedef int (*fn_comm_init_rank)(void **, int, tp_unique_id, int);
 typedef int (*fn_comm_destroy)(void *);
 typedef int (*fn_all_reduce)(const void *, void *, size_t, int, int, void *, hipStream_t);
 typedef const char * (*fn_get_error_string)(int);
+typedef int (*fn_comm_count)(const void *, int *);
 
 static struct {
     void * so; fn_get_unique_id get_unique_id; fn_comm_init_rank comm_init_rank; fn_comm_destroy comm_destroy; fn_all_reduce all_reduce;
-    fn_get_error_string get_error_string;
+    fn_get_error_string get_error_string; fn_comm_count comm_count, comm_user_rank;
 } g_rccl;
 
 static int rccl_load() {
@@ -31,6 +32,8 @@ static int rccl_load() {
     g_rccl.comm_destroy     = (fn_comm_destroy)     dlsym(so, "ncclCommDestroy");
     g_rccl.all_reduce       = (fn_all_reduce)       dlsym(so, "ncclAllReduce");
     g_rccl.get_error_string = (fn_get_error_string) dlsym(so, "ncclGetErrorString");
+    g_rccl.comm_count       = (fn_comm_count)       dlsym(so, "ncclCommCount");
+    g_rccl.comm_user_rank   = (fn_comm_count)       dlsym(so, "ncclCommUserRank");
     if (!g_rccl.get_unique_id || !g_rccl.comm_init_rank || !g_rccl.comm_destroy || !g_rccl.all_reduce) { dlclose(so); FAIL(CLLM_E_UNSUPPORTED, "tp: librccl.so lacks the NCCL entry points"); }
     g_rccl.so = so;
     return CLLM_OK;
@@ -56,6 +59,17 @@ extern "C" int cllm_tp_init(const void * id128, int rank, int nranks, void ** co
     const int rc = g_rccl.comm_init_rank(&comm, nranks, id, rank);       // collective: every rank of the group calls it
     if (rc) return rccl_fail(rc, "ncclCommInitRank");
     *comm_out = comm;
+    return CLLM_OK;
+}
+// what the communicator itself reports: ranks in the group and this rank's index (bench.py prints them: the run's parallelism as RCCL sees it, not as the launcher meant it)
+extern "C" int cllm_tp_comm_info(void * comm, int * nranks, int * rank) {
+    if (!comm || !nranks || !rank) FAIL(CLLM_E_INVALID, "tp_comm_info: null");
+    { const int rc_ = rccl_load(); if (rc_) return rc_; }
+    if (!g_rccl.comm_count || !g_rccl.comm_user_rank) FAIL(CLLM_E_UNSUPPORTED, "tp_comm_info: librccl.so lacks ncclCommCount / ncclCommUserRank");
+    int rc = g_rccl.comm_count(comm, nranks);
+    if (rc) return rccl_fail(rc, "ncclCommCount");
+    rc = g_rccl.comm_user_rank(comm, rank);
+    if (rc) return rccl_fail(rc, "ncclCommUserRank");
     return CLLM_OK;
 }
 extern "C" int cllm_tp_destroy(void * comm) {

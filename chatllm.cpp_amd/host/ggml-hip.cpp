@@ -33,7 +33,7 @@ namespace {
 
 struct hip_device_ctx { int id; std::string name, desc; ggml_backend_buffer_type buft; };
 struct hip_backend_ctx {
-    int device; void * stream = nullptr; void * wdata = nullptr; size_t wsize = 0; void * abuf = nullptr; size_t asize = 0; void * copy_event = nullptr;
+    int device; bool kernel_error = false; void * stream = nullptr; void * wdata = nullptr; size_t wsize = 0; void * abuf = nullptr; size_t asize = 0; void * copy_event = nullptr;
     // replay of a token's launch list (graph_compute): the serialized arguments of every C-ABI call of the last graph, and the
     // captured graph of the list that came twice in a row
     std::vector<uint8_t> last_sig, graph_sig; void * graph_exec = nullptr; bool graph_broken = false; long replays = 0, captures = 0;
@@ -424,6 +424,9 @@ void be_sync(ggml_backend_t b) {
     ws_scope ws(g_ws.sync_us);
     flush_sets();
     auto * c = (hip_backend_ctx *) b->context; cllm_set_device(c->device); cllm_stream_sync(c->stream); cllm_stream_sync(nullptr);
+    // a bounded wait inside a kernel that timed out leaves void results behind: synchronize() cannot return a status (ggml-backend-impl.h:96), so it is said
+    // loudly here and the next graph_compute of this backend fails
+    if (cllm_check_kernel_errors() != CLLM_OK) { GGML_LOG_ERROR("[ggml-hip] %s\n", cllm_last_error()); c->kernel_error = true; }
 }
 
 int ensure_wdata(hip_backend_ctx * c, size_t need) {
@@ -1123,6 +1126,7 @@ void ahead_launch(hip_backend_ctx * c) {
 ggml_status be_graph_compute(ggml_backend_t backend, ggml_cgraph * g) {
     auto * c = (hip_backend_ctx *) backend->context;
     cllm_set_device(c->device);
+    if (c->kernel_error) return GGML_STATUS_FAILED;            // (an earlier launch's in-kernel wait timed out: be_sync)
     void * st = c->stream;
     static const bool trace = getenv("CLLM_HIP_TRACE") != nullptr;
     if (trace) {

@@ -54,6 +54,7 @@ SIGNATURES = {
     "cllm_stream_create": (C.c_int, [C.POINTER(C.c_void_p)]),
     "cllm_stream_destroy": (C.c_int, [_P]),
     "cllm_stream_sync": (C.c_int, [_P]),
+    "cllm_check_kernel_errors": (C.c_int, []),
     "cllm_graph_capture_begin": (C.c_int, [_P]),
     "cllm_graph_capture_end": (C.c_int, [_P, C.POINTER(C.c_void_p)]),
     "cllm_graph_launch": (C.c_int, [_P, _P]),
@@ -125,6 +126,7 @@ SIGNATURES = {
     "cllm_llama_set_allreduce": (C.c_int, [_P, ALLREDUCE_FN, _P]),
     "cllm_tp_unique_id": (C.c_int, [_P]),
     "cllm_tp_init": (C.c_int, [_P, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+    "cllm_tp_comm_info": (C.c_int, [_P, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "cllm_tp_destroy": (C.c_int, [_P]),
     "cllm_tp_all_reduce_f32": (C.c_int, [_P, _P, _P, C.c_size_t]),
     "cllm_llama_set_tp_comm": (C.c_int, [_P, _P]),

@@ -78,6 +78,8 @@ CLLM_API int  cllm_stream_destroy(void * stream);
 CLLM_API int  cllm_stream_sync(void * stream);                 /* backend_i.synchronize */
 /* capture of everything launched on `stream` between begin and end into one replayable graph (ggml_backend_i.graph_plan_create /
  * graph_plan_compute, ggml-backend-impl.h:104-113); capture_end: CLLM_E_UNSUPPORTED and *graph_exec = NULL if the sequence cannot be captured */
+/* after a synchronize: CLLM_E_HIP if a bounded in-kernel wait of the current device timed out since the last call (the launch wound down, its results are void) */
+CLLM_API int  cllm_check_kernel_errors(void);
 CLLM_API int  cllm_graph_capture_begin(void * stream);
 CLLM_API int  cllm_graph_capture_end(void * stream, void ** graph_exec);
 CLLM_API int  cllm_graph_launch(void * graph_exec, void * stream);
@@ -340,6 +342,7 @@ CLLM_API int  cllm_llama_set_allreduce(cllm_llama * m, cllm_allreduce_fn fn, voi
  * cllm_tp_init (collective) and binds the communicator to its model.  librccl.so is dlopen'ed on first use. */
 CLLM_API int  cllm_tp_unique_id(void * out128);
 CLLM_API int  cllm_tp_init(const void * id128, int rank, int nranks, void ** comm_out);
+CLLM_API int  cllm_tp_comm_info(void * comm, int * nranks, int * rank);   /* ncclCommCount / ncclCommUserRank: the group as RCCL reports it */
 CLLM_API int  cllm_tp_destroy(void * comm);
 CLLM_API int  cllm_tp_all_reduce_f32(void * comm, void * stream, float * buf, size_t n);
 CLLM_API int  cllm_llama_set_tp_comm(cllm_llama * m, void * comm);
