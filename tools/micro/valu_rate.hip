@@ -63,7 +63,7 @@ int main() {
         run("v_fma_f32", k_rate<0, 0>, wps, 0, in, out, cus, ghz);
         run("v_pk_fma_f32", k_rate<1, 0>, wps, 0, in, out, cus, ghz);
     }
-    for (int wps : {1, 2}) {
+    for (int wps : {1, 2, 3, 4}) {
         run("v_fma_f32", k_rate<0, 1>, wps, 1, in, out, cus, ghz);
         run("v_pk_fma_f32", k_rate<1, 1>, wps, 1, in, out, cus, ghz);
         run("v_fma_f32", k_rate<0, 2>, wps, 2, in, out, cus, ghz);
