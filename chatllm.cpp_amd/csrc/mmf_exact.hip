@@ -62,7 +62,9 @@ __global__ void __launch_bounds__(256, 2) k_mmf_exact(const mmfx_args a) {
     constexpr int NACC = VD ? 32 : 8;
     const tview & w = a.w; const tview & x = a.x; const tview & d = a.d;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, g = lane >> 4;
-    const int64_t m0 = (int64_t) blockIdx.x * BM, n0 = (int64_t) blockIdx.y * BN;
+    // causal 2 (V.P): a column tile's K loop ends at its last visible position, so the work grows with the tile index -- the LONGEST tiles are dispatched first
+    // (the last tiles to start are then the shortest: the launch does not end on a few CUs walking 4096 positions)
+    const int64_t m0 = (int64_t)(a.causal == 2 ? gridDim.x - 1 - blockIdx.x : blockIdx.x) * BM, n0 = (int64_t) blockIdx.y * BN;
     const int64_t i12 = blockIdx.z % x.ne[2], i13 = blockIdx.z / x.ne[2];
     const int64_t r2 = x.ne[2] / w.ne[2], r3 = x.ne[3] / w.ne[3];
     const int64_t K = w.ne[0], N = w.ne[1], M = x.ne[1];
@@ -90,21 +92,54 @@ __global__ void __launch_bounds__(256, 2) k_mmf_exact(const mmfx_args a) {
 
     for (int64_t k0 = 0; k0 < kend; k0 += MMFX_KC) {
         __syncthreads();
-        // ---- stage: BN weight rows and BM activation rows x 128 elements as fp16 ----
-        for (int c = tid; c < (BN + BM) * 16; c += 256) {
-            const int row = c >> 4, ch = c & 15;
-            const int64_t e0 = k0 + ch * 8;
-            u32x4 v = u32x4{0, 0, 0, 0};
-            if (row < BN) {
-                const int64_t n = n0 + row;
-                if (n < N && e0 < kend) v = load8h(wb + n * w.nb[1] + e0 * 2, e0, kend, w_al);
+        // ---- stage: BN weight rows and BM activation rows x 128 elements as fp16.  Every thread owns TW weight chunks and TX activation chunks of 8 elements;
+        //      ALL their global loads are issued before the first is used (written as one loop with the conversion and the LDS store inside, the compiler kept
+        //      one load in flight: eight memory round trips per stage, and the matrix cores idle for two thirds of the launch).  Whole, 16-byte aligned chunks
+        //      take the wide path; a chunk cut by the row end / the causal horizon, or an unaligned one, goes element by element (load8h / load8f_as_h) ----
+        {
+            constexpr int TW = BN * 16 / 256, TX = BM * 16 / 256;
+            u32x4 rw_[TW]; f32x4 xa_[TX], xb_[TX]; bool fw_[TW], fx_[TX];
+#pragma unroll
+            for (int t = 0; t < TW; t++) {
+                const int c = tid + 256 * t, row = c >> 4, ch = c & 15;
+                const int64_t e0 = k0 + ch * 8, n = n0 + row;
+                fw_[t] = n < N && e0 + 8 <= kend && w_al;
+                rw_[t] = u32x4{0, 0, 0, 0};
+                if (fw_[t]) rw_[t] = *(const u32x4 *)(wb + n * w.nb[1] + e0 * 2);
+            }
+#pragma unroll
+            for (int t = 0; t < TX; t++) {
+                const int c = tid + 256 * t, row = c >> 4, ch = c & 15;
+                const int64_t e0 = k0 + ch * 8, m = m0 + row;
+                const int64_t lim = a.causal == 2 ? ((int64_t) a.n_past + m + 1 < kend ? (int64_t) a.n_past + m + 1 : kend) : kend;
+                fx_[t] = m < M && e0 + 8 <= lim && x_al;
+                xa_[t] = f32x4{0, 0, 0, 0}; xb_[t] = f32x4{0, 0, 0, 0};
+                if (fx_[t]) { const char * p = xb + m * x.nb[1] + e0 * 4; xa_[t] = *(const f32x4 *) p; xb_[t] = *(const f32x4 *)(p + 16); }
+            }
+#pragma unroll
+            for (int t = 0; t < TW; t++) {
+                const int c = tid + 256 * t, row = c >> 4, ch = c & 15;
+                const int64_t e0 = k0 + ch * 8, n = n0 + row;
+                u32x4 v = rw_[t];
+                if (!fw_[t] && n < N && e0 < kend) v = load8h(wb + n * w.nb[1] + e0 * 2, e0, kend, false);
                 *(u32x4 *)(Wt + row * MMFX_LD + ch * 16) = v;
-            } else {
-                const int64_t m = m0 + (row - BN);
+            }
+#pragma unroll
+            for (int t = 0; t < TX; t++) {
+                const int c = tid + 256 * t, row = c >> 4, ch = c & 15;
+                const int64_t e0 = k0 + ch * 8, m = m0 + row;
                 // causal 2: column m's probabilities end at n_past + m (what lies beyond was never written: read as zero)
                 const int64_t lim = a.causal == 2 ? ((int64_t) a.n_past + m + 1 < kend ? (int64_t) a.n_past + m + 1 : kend) : kend;
-                if (m < M && e0 < lim) v = load8f_as_h(xb + m * x.nb[1] + e0 * 4, e0, lim, x_al);
-                *(u32x4 *)(Xt + (row - BN) * MMFX_LD + ch * 16) = v;
+                u32x4 v;
+                if (fx_[t]) {
+                    const f32x4 a4 = xa_[t], b4 = xb_[t];
+                    v = u32x4{ (uint32_t) f2h(a4.x) | ((uint32_t) f2h(a4.y) << 16), (uint32_t) f2h(a4.z) | ((uint32_t) f2h(a4.w) << 16),
+                               (uint32_t) f2h(b4.x) | ((uint32_t) f2h(b4.y) << 16), (uint32_t) f2h(b4.z) | ((uint32_t) f2h(b4.w) << 16) };
+                } else {
+                    v = u32x4{0, 0, 0, 0};
+                    if (m < M && e0 < lim) v = load8f_as_h(xb + m * x.nb[1] + e0 * 4, e0, lim, false);
+                }
+                *(u32x4 *)(Xt + row * MMFX_LD + ch * 16) = v;
             }
         }
         __syncthreads();

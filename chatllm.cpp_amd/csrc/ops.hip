@@ -247,12 +247,19 @@ __global__ void __launch_bounds__(256) k_soft_max_causal_reg(tview s, tview d, f
     const int n_vis = n_past + (int) i1 + 1 < n ? n_past + (int) i1 + 1 : n;       // entries >= n_vis are masked
     float e[NG][8];
     float mx = -INFINITY;
+    // every group's loads are issued before the first value is used (unconditional, clamped to the row's start where the group is masked: inside the
+    // `if` the compiler waited for each group's pair of loads before requesting the next -- NG memory round trips per row)
+    f32x4 lo[NG], hi[NG];
+#pragma unroll
+    for (int t = 0; t < NG; t++) {
+        const int g0 = (lane + 64 * t) * 8, gc = g0 < n_vis ? g0 : 0;
+        lo[t] = *(const f32x4 *)(x + gc); hi[t] = *(const f32x4 *)(x + gc + 4);
+    }
 #pragma unroll
     for (int t = 0; t < NG; t++) {
         const int g0 = (lane + 64 * t) * 8;
         if (g0 < n_vis) {
-            const f32x4 lo = *(const f32x4 *)(x + g0), hi = *(const f32x4 *)(x + g0 + 4);
-            const float v[8] = { lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w };
+            const float v[8] = { lo[t].x, lo[t].y, lo[t].z, lo[t].w, hi[t].x, hi[t].y, hi[t].z, hi[t].w };
 #pragma unroll
             for (int l = 0; l < 8; l++) { e[t][l] = g0 + l < n_vis ? v[l] * scale : -INFINITY; mx = fmaxf(mx, e[t][l]); }
         }
