@@ -167,15 +167,40 @@ __device__ __forceinline__ double rms_block_sumsq_1024(const float * __restrict_
 // non-negative terms differ by at most 2 gamma_(n-1) = 2 (n - 1) u / (1 - (n - 1) u) of their value (u = 2^-53; Higham, Accuracy and Stability, 4.2), and the
 // only thing the rest of the op sees of the sum is (float)(sum / n): division and conversion are monotonic, so whenever the two ends of
 // sum (1 -+ (2 n + 16) u) give the SAME float, the serial sum gives it too and the tree's result is the reference's, bit for bit.  When they do not (the mean
-// lies within ~1e-12 of a float rounding boundary: about 3 rows in 10^5 at n = 4096) thread 0 redoes the sum in the reference's own order.  The branch
+// lies within ~1e-12 of a float rounding boundary: about 3 rows in 10^5 at n = 4096) thread 0 redoes the sum in the reference's own order (~20 us: the loads run 16 ahead of the dependent adds).  The branch
 // is uniform over the workgroup (every thread holds the same `sum`); x (+ add: the tensor-parallel partial folded into the residual) must still hold the
 // row, which is why the barriers sit here: no thread of an in-place launch stores before the serial pass has read.
 static __device__ __noinline__ double rms_div(double sum, double n) { return sum / n; }
+// (one thread, the reference's order; the loads run ahead of the dependent double adds: 64 values per batch.  COHERENT: the persistent launch hands x over inside
+//  the kernel -- L1-bypassing loads, a whole batch of them in flight; everywhere else the row was written by an earlier launch: plain wide loads)
+template <bool COHERENT>
 static __device__ __noinline__ double rms_serial_sumsq(const float * x, const float * add, int64_t n) {
+    constexpr int B = 64;                                  // values per batch: all their loads are in flight before the first add (the adds are one dependent chain)
     double sum = 0.0;
-    for (int64_t i = 0; i < n; i++) {
-        float v = __uint_as_float(__hip_atomic_load((const unsigned *)(x + i), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));      // (coherent: the persistent launch hands x over inside the kernel)
-        if (add) v = v + __uint_as_float(__hip_atomic_load((const unsigned *)(add + i), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    int64_t i = 0;
+    const bool wide = !COHERENT && (((uintptr_t) x | (uintptr_t) add) & 15) == 0;
+    for (; i + B <= n; i += B) {
+        float v[B];
+        if (COHERENT) {
+#pragma unroll
+            for (int k = 0; k < B; k++) v[k] = __uint_as_float(__hip_atomic_load((const unsigned *)(x + i + k), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        } else if (wide) {
+#pragma unroll
+            for (int k = 0; k < B / 4; k++) { const f32x4 q = *(const f32x4 *)(x + i + 4 * k); v[4 * k] = q.x; v[4 * k + 1] = q.y; v[4 * k + 2] = q.z; v[4 * k + 3] = q.w; }
+        } else {
+#pragma unroll
+            for (int k = 0; k < B; k++) v[k] = x[i + k];
+        }
+        if (add) {
+#pragma unroll
+            for (int k = 0; k < B; k++) v[k] = v[k] + (COHERENT ? __uint_as_float(__hip_atomic_load((const unsigned *)(add + i + k), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) : add[i + k]);
+        }
+#pragma unroll
+        for (int k = 0; k < B; k++) sum += (double)(v[k] * v[k]);
+    }
+    for (; i < n; i++) {
+        float v = COHERENT ? __uint_as_float(__hip_atomic_load((const unsigned *)(x + i), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) : x[i];
+        if (add) v = v + (COHERENT ? __uint_as_float(__hip_atomic_load((const unsigned *)(add + i), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) : add[i]);
         sum += (double)(v * v);
     }
     return sum;
@@ -183,12 +208,13 @@ static __device__ __noinline__ double rms_serial_sumsq(const float * x, const fl
 __device__ __forceinline__ float rms_mean(double sum, int64_t n) {
     return (float)((n & (n - 1)) == 0 ? ldexp(sum, -(int) __builtin_ctzll((unsigned long long) n)) : rms_div(sum, (double) n));
 }
+template <bool COHERENT = false>
 __device__ __forceinline__ float rms_scale(double sum, int64_t n, float eps, const float * x, const float * add, double * part) {
     float m = rms_mean(sum, n);
     const double d = sum * ((double)(2 * n + 16) * 0x1p-53);
     if (!(rms_mean(sum - d, n) == rms_mean(sum + d, n))) {
         __syncthreads();
-        if (threadIdx.x == 0) part[0] = rms_serial_sumsq(x, add, n);
+        if (threadIdx.x == 0) part[0] = rms_serial_sumsq<COHERENT>(x, add, n);
         __syncthreads();
         m = rms_mean(part[0], n);
     }

@@ -170,7 +170,7 @@ __device__ __forceinline__ bool pg_gemv(char * lds, double * part, int * flag, c
             for (int w = 1; w < 16; w++) tot += part[w];
             sum = tot;
         }
-        scale = rms_scale(sum, K, eps, px, nullptr, part);
+        scale = rms_scale<true>(sum, K, eps, px, nullptr, part);
     }
 #pragma unroll
     for (int u = 0; u < NPRE; u++) {

@@ -68,8 +68,14 @@ def test_kernels_with_hand_issued_loads_do_not_spill():
         import pytest
         pytest.skip("no hipcc")
     src = os.path.join(ROOT, "chatllm.cpp_amd", "csrc", "gemv_team32.hip")
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-fvisibility=hidden", "-mllvm", "-amdgpu-kernarg-preload-count=16",
-           "--cuda-device-only", "-c", src, "-o", os.devnull, "-Rpass-analysis=kernel-resource-usage"]
+    # the flags the library is built with, read from the Makefile (a copy here could drift from the real build)
+    mk = open(os.path.join(ROOT, "chatllm.cpp_amd", "csrc", "Makefile")).read()
+    m = re.search(r"^FLAGS\s*:=\s*(.*)$", mk, re.M)
+    assert m, "csrc/Makefile: FLAGS line not found"
+    arch = re.search(r"^ARCH\s*\?=\s*(\S+)", mk, re.M).group(1)
+    flags = m.group(1).replace("$(ARCH)", arch).split()
+    assert "-ffp-contract=off" in flags and any(f.startswith("--offload-arch=") for f in flags), flags
+    cmd = [hipcc] + flags + ["--cuda-device-only", "-c", src, "-o", os.devnull, "-Rpass-analysis=kernel-resource-usage"]
     out = subprocess.run(cmd, capture_output=True, text=True)
     assert out.returncode == 0, out.stderr[-2000:]
     spills = re.findall(r"VGPRs Spill: (\d+)", out.stderr) + re.findall(r"SGPRs Spill: (\d+)", out.stderr) + re.findall(r"ScratchSize \[bytes/lane\]: (\d+)", out.stderr)
