@@ -204,6 +204,11 @@ void buf_get(ggml_backend_buffer_t b, const ggml_tensor * t, void * data, size_t
     const int device = ((hip_buffer_ctx *) b->context)->device;
     hip_backend_ctx * ac = device >= 0 && device < 64 ? g_ahead_ctx[device] : nullptr;
     const char * src = (const char *) t->data + off;
+    // the host reads the logits: the next step is started FIRST (it snapshots the graph's outputs on its stream, then runs), and the 513 KB copy to the host below is
+    // served from that snapshot while the step already computes -- started after the copy, the GPU idled for the copy's ~70 us of every token
+    static const bool ahead_late = getenv("CLLM_HIP_AHEAD_LATE") != nullptr;       // (A/B switch: round 3's order)
+    const bool is_logits_read = ac && ac->ahead.armed && !ac->ahead.inflight && (const void *) t->data == ac->ahead.logits_ptr && off == 0 && size == ac->ahead.logits_bytes;
+    if (is_logits_read && !ahead_late) ahead_launch(ac);
     if (ac && ac->ahead.inflight) {
         bool served = false;
         for (const auto & o : ac->ahead.outs)      // the step running ahead overwrites the graph's outputs: their snapshots
@@ -211,7 +216,7 @@ void buf_get(ggml_backend_buffer_t b, const ggml_tensor * t, void * data, size_t
         if (!served) ahead_quiesce(device);        // anything else: what the step running ahead leaves behind
     }
     buf_get_impl(b, src, t->name, data, size);
-    if (ac && ac->ahead.armed && !ac->ahead.inflight && (const void *) t->data == ac->ahead.logits_ptr && off == 0 && size == ac->ahead.logits_bytes) ahead_launch(ac);
+    if (is_logits_read && ahead_late && ac->ahead.armed && !ac->ahead.inflight) ahead_launch(ac);
 }
 void buf_get_impl(ggml_backend_buffer_t b, const char * src, const char * name, void * data, size_t size) {
     std::lock_guard<std::mutex> lock(g_stage_mutex);            // one staging area (accessory models may read from other threads)
