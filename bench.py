@@ -481,6 +481,7 @@ def main():
         log(f"warning: WORLD_SIZE={world} but --gpus {args.gpus}; using WORLD_SIZE")
     dist = None
     rccl_ranks = None
+    allreduce_kind = None
     tp_setup = world > 1 or os.environ.get("CLLM_BENCH_TP_SELFTEST") == "1"          # (self-test: walk the communicator set-up with one rank)
     if tp_setup:
         # torch FIRST: it bundles its own HIP runtime; initialised after libchatllm_hip.so has loaded /opt/rocm's, it finds "No HIP GPUs"
@@ -533,10 +534,13 @@ def main():
                 if nr.value != world or ur.value != rank:
                     raise RuntimeError(f"RCCL reports rank {ur.value} of {nr.value}, the launcher said rank {rank} of {world}")
                 rccl_ranks = nr.value
+                allreduce_kind = "RCCL (ncclAllReduce inside the decode graph)"
                 log(f"[rank {rank}] tensor parallel over RCCL: the communicator reports rank {ur.value} of {nr.value} (all-reduce inside the decode graph)")
-                if os.environ.get("CLLM_TP_ONESHOT") == "1":
-                    # opt-in: the decode-sized all-reduces ([hidden] fp32) as ONE kernel launch each -- every rank writes its partial vector into every peer's
-                    # IPC-mapped receive buffer and sums the slots in rank order (tp_oneshot.hip); prompt-sized messages stay on RCCL.  All ranks decide together.
+                if os.environ.get("CLLM_TP_ONESHOT", "1") != "0":
+                    # the decode-sized all-reduces ([hidden] fp32: latency-bound, the wrong regime for a ring) as ONE kernel launch each -- every rank writes its partial vector
+                    # into every peer's IPC-mapped receive buffer and sums the slots in rank order (tp_oneshot.hip); prompt-sized messages stay on RCCL.  Taken only if it
+                    # can be set up on EVERY rank (fine-grained IPC memory; no coarse-grained fallback across GPUs) AND reproduces a known rank-order sum in a self-check of
+                    # six all-reduces right here; otherwise the decode steps keep RCCL.  All ranks decide together.  CLLM_TP_ONESHOT=0: RCCL only.
                     ok1 = torch.ones(1, dtype=torch.int32, device=f"cuda:{local}")
                     osh = C.c_void_p()
                     mine = (C.c_char * 64)()
@@ -545,18 +549,44 @@ def main():
                     except Exception as e:                # noqa: BLE001
                         log(f"[rank {rank}] cllm_tp_oneshot_create failed: {e}")
                         ok1.zero_()
-                    gathered = [None] * world
-                    dist.all_gather_object(gathered, bytes(mine.raw))
-                    if int(ok1.item()):
+                        osh = C.c_void_p()
+                    dist.all_reduce(ok1, op=dist.ReduceOp.MIN)                  # (nobody opens handles a peer could not create)
+                    if int(ok1.item()) == 1:
+                        gathered = [None] * world
+                        dist.all_gather_object(gathered, bytes(mine.raw))
                         try:
                             pkg.lib.check(L.cllm_tp_oneshot_connect(osh, b"".join(gathered)), "tp_oneshot_connect")
                         except Exception as e:            # noqa: BLE001
                             log(f"[rank {rank}] cllm_tp_oneshot_connect failed: {e}")
                             ok1.zero_()
-                    dist.all_reduce(ok1, op=dist.ReduceOp.MIN)
+                        dist.all_reduce(ok1, op=dist.ReduceOp.MIN)
+                    if int(ok1.item()) == 1:
+                        # self-check: six all-reduces of known vectors (both slot parities, the sequence counter), the rank-order fp32 sum must come back bit for bit
+                        n = cfg["hidden"]
+                        xs = [np.random.default_rng(1000 + r).standard_normal(n).astype(np.float32) for r in range(world)]
+                        try:
+                            for it in range(6):
+                                f = np.float32(it + 1)
+                                want = xs[0] * f
+                                for r in range(1, world):
+                                    want = want + xs[r] * f
+                                buf = pkg.Tensor.from_numpy((xs[rank] * f).reshape(1, n))
+                                pkg.lib.check(L.cllm_tp_oneshot_all_reduce_f32(osh, None, buf.data_ptr(), n), "tp_oneshot_all_reduce")
+                                pkg.ops.sync()
+                                got = buf.numpy().reshape(n)
+                                if L.cllm_tp_oneshot_error(osh) or not np.array_equal(got.view(np.uint32), want.view(np.uint32)):
+                                    log(f"[rank {rank}] one-shot all-reduce self-check failed at call {it} (max |d| {float(np.max(np.abs(got - want))):.3g})")
+                                    ok1.zero_()
+                        except Exception as e:            # noqa: BLE001
+                            log(f"[rank {rank}] one-shot all-reduce self-check raised: {e}")
+                            ok1.zero_()
+                        dist.all_reduce(ok1, op=dist.ReduceOp.MIN)
                     if int(ok1.item()) == 1:
                         m.set_tp_oneshot(osh)
-                        log(f"[rank {rank}] decode all-reduces through the one-shot direct-write kernel")
+                        allreduce_kind = "one-shot direct-write kernel (fine-grained IPC)" if L.cllm_tp_oneshot_fine_grained(osh) == 1 else "one-shot direct-write kernel (coarse-grained: ranks share one GPU)"
+                        log(f"[rank {rank}] decode all-reduces through the {allreduce_kind}; self-check passed")
+                    else:
+                        log(f"[rank {rank}] one-shot all-reduce not available on every rank: the decode all-reduces stay on RCCL")
         if not native and os.environ.get("CLLM_BENCH_TORCH_ALLREDUCE") != "1":
             # the fallback (torch.distributed.all_reduce behind a stream synchronize per collective, decode steps launched eagerly) measures host round trips, not the
             # path this bench is about: it is an explicit debugging mode, never a silent substitute
@@ -603,7 +633,7 @@ def main():
         "data": "synthetic",
         "config": {"workload": f"{args.model} shapes, {args.wtype.upper()} weights, single-token decode, batch 1, {args.n_prompt}-token prompt, F16 KV cache",
                    "parallelism": f"tp{world}" if world > 1 else "single GPU", "n_ctx_end": args.n_prompt + args.warmup + args.steps,
-                   "rccl_ranks": rccl_ranks},
+                   "rccl_ranks": rccl_ranks, "decode_allreduce": allreduce_kind},
     }
     if rank == 0:
         n_ctx = args.n_prompt + args.warmup + args.steps // 2

@@ -102,15 +102,20 @@ def test_bench_tp_setup_under_torchrun_with_one_rank(gpu):
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, CLLM_BENCH_TP_SELFTEST="1")
-    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1", "--master-port", "29533",
-                        os.path.join(root, "bench.py"), "--gpus", "1", "--model", "small", "--steps", "8", "--warmup", "2", "--no-cpu-baseline"],
-                       capture_output=True, text=True, env=env, timeout=600)
-    assert r.returncode == 0, r.stderr[-3000:]
-    assert "tensor parallel over RCCL" in r.stderr
-    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
-    res = json.loads(line)
-    assert res["n_gpus"] == 1 and res["value"] > 0 and res["metric"] == "decode tokens/s"
+    # twice: as on a node (the one-shot all-reduce needs fine-grained IPC memory on every rank, else the decode steps stay on RCCL -- either way said out loud), and with the
+    # "all ranks share this GPU" statement that admits coarse-grained memory: there the one-shot path must pass its start-up self-check and carry the steps
+    for extra, must in (({}, "decode all-reduces"), ({"CLLM_TP_ONESHOT_SAME_DEVICE": "1"}, "self-check passed")):
+        env = dict(os.environ, CLLM_BENCH_TP_SELFTEST="1", **extra)
+        r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1", "--master-port", "29533",
+                            os.path.join(root, "bench.py"), "--gpus", "1", "--model", "small", "--steps", "8", "--warmup", "2", "--no-cpu-baseline", "--no-kernels"],
+                           capture_output=True, text=True, env=env, timeout=600)
+        assert r.returncode == 0, r.stderr[-3000:]
+        assert "tensor parallel over RCCL" in r.stderr and "reports rank 0 of 1" in r.stderr
+        assert must in r.stderr, r.stderr[-2000:]
+        line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+        res = json.loads(line)
+        assert res["n_gpus"] == 1 and res["value"] > 0 and res["metric"] == "decode tokens/s"
+        assert res["config"]["rccl_ranks"] == 1 and res["config"]["decode_allreduce"]
 
 
 def _run_two_ranks(tmp_path, seed, mode):
