@@ -16,6 +16,7 @@
 // Causal structure of the prompt (the runner / the module's attention pattern pass it): causal 1 (K.Q) skips tiles whose scores are all masked;
 // causal 2 (V.P) ends the K loop where the probabilities of the tile's last column end -- fma(w, 0, acc) == acc, the skipped steps change no bit.
 #include "common.h"
+#include <stdlib.h>
 
 typedef _Float16 h8v __attribute__((ext_vector_type(8)));
 
@@ -55,10 +56,12 @@ __device__ __forceinline__ void h8_to_f(const u32x4 r, float (&f)[8]) {
 }
 
 // grid: x = column tiles (fastest), y = row tiles, z = src1's dims 2, 3
-template <bool VD>
-__global__ void __launch_bounds__(256, 2) k_mmf_exact(const mmfx_args a) {
-    __shared__ __attribute__((aligned(16))) char lds[(VD ? 32 + 32 : 64 + 64) * MMFX_LD + (VD ? 2 * 32 * 64 : 0)];
-    constexpr int BN = VD ? 32 : 64, BM = VD ? 32 : 64, PW = VD ? 1 : 2;       // PW x PW patches per wave
+// PM: patches per wave along the columns (T8: 2 -> 64 x 64 workgroup tile, 128 accumulator registers, two workgroups per CU; 1 -> 64 rows x 32 columns, 64 accumulator
+// registers, three workgroups per CU: the single-stage K.Q tiles are bound by their load / store latency, which more resident workgroups cover)
+template <bool VD, int PM>
+__global__ void __launch_bounds__(256, (VD || PM == 2) ? 2 : 3) k_mmf_exact(const mmfx_args a) {
+    __shared__ __attribute__((aligned(16))) char lds[(VD ? 32 + 32 : 64 + 32 * PM) * MMFX_LD + (VD ? 2 * 32 * 64 : 0)];
+    constexpr int BN = VD ? 32 : 64, BM = VD ? 32 : 32 * PM, PW = VD ? 1 : 2;       // PW (rows) x PM (columns) patches per wave
     constexpr int NACC = VD ? 32 : 8;
     const tview & w = a.w; const tview & x = a.x; const tview & d = a.d;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, g = lane >> 4;
@@ -80,11 +83,11 @@ __global__ void __launch_bounds__(256, 2) k_mmf_exact(const mmfx_args a) {
     if (a.causal == 2) { const int64_t last = (m0 + BM - 1 < M - 1 ? m0 + BM - 1 : M - 1); kvis = (int64_t) a.n_past + last + 1 < K ? (int64_t) a.n_past + last + 1 : K; }
     const int64_t kend = Kmain < kvis ? Kmain : kvis;                         // main chains: [0, kend) rounded up to whole stages (zero-filled)
     char * Wt = lds; char * Xt = lds + BN * MMFX_LD;
-    const int wn = (wave & 1) * (PW * 16), wm = (wave >> 1) * (PW * 16);
+    const int wn = (wave & 1) * (PW * 16), wm = (wave >> 1) * (PM * 16);
 
-    f32x4 D[PW][PW][NACC];
+    f32x4 D[PM][PW][NACC];
 #pragma unroll
-    for (int i = 0; i < PW; i++)
+    for (int i = 0; i < PM; i++)
 #pragma unroll
         for (int j = 0; j < PW; j++)
 #pragma unroll
@@ -147,13 +150,13 @@ __global__ void __launch_bounds__(256, 2) k_mmf_exact(const mmfx_args a) {
         if constexpr (!VD) {
 #pragma unroll
             for (int u = 0; u < 4; u++) {
-                float xf[PW][8], wf[PW][8];
+                float xf[PM][8], wf[PW][8];
 #pragma unroll
-                for (int i = 0; i < PW; i++) h8_to_f(*(const u32x4 *)(Xt + (wm + i * 16 + l15) * MMFX_LD + u * 64 + g * 16), xf[i]);
+                for (int i = 0; i < PM; i++) h8_to_f(*(const u32x4 *)(Xt + (wm + i * 16 + l15) * MMFX_LD + u * 64 + g * 16), xf[i]);
 #pragma unroll
                 for (int j = 0; j < PW; j++) h8_to_f(*(const u32x4 *)(Wt + (wn + j * 16 + l15) * MMFX_LD + u * 64 + g * 16), wf[j]);
 #pragma unroll
-                for (int i = 0; i < PW; i++)
+                for (int i = 0; i < PM; i++)
 #pragma unroll
                     for (int j = 0; j < PW; j++)
 #pragma unroll
@@ -196,7 +199,7 @@ __global__ void __launch_bounds__(256, 2) k_mmf_exact(const mmfx_args a) {
 
     // ---- reduce + store: lane holds row n = .. + l15 and the four columns m = .. + 4 g + v ----
 #pragma unroll
-    for (int i = 0; i < PW; i++)
+    for (int i = 0; i < PM; i++)
 #pragma unroll
         for (int j = 0; j < PW; j++) {
             const int64_t n = n0 + wn + j * 16 + l15;
@@ -240,10 +243,15 @@ int launch_mmf_exact(hipStream_t st, const tview & w, const tview & x, const tvi
     const bool t8 = M >= 2 && K % 8 == 0 && N % 4 == 0;
     if (t8) {
         if ((N + 63) / 64 > 65535) return CLLM_E_UNSUPPORTED;
-        hipLaunchKernelGGL((k_mmf_exact<false>), dim3((unsigned)((M + 63) / 64), (unsigned)((N + 63) / 64), (unsigned) Z), dim3(256), 0, st, a);
+        // the narrow tile (64 rows x 32 columns, three workgroups per CU) for both contractions of the prompt's attention: measured at cfg3 (profiles/r04_mmf_exact_tile.txt)
+        // 406.3 ms against 414.6-416.0 with the square tile and 413.5 with the narrow one on K.Q only -- a third resident workgroup covers the other two's stage loads
+        static const int force_pm = getenv("CLLM_MMF_PM") ? atoi(getenv("CLLM_MMF_PM")) : 0;      // (tools: 2 forces the 64 x 64 tile)
+        const int pm = force_pm == 2 ? 2 : 1;
+        if (pm == 1) hipLaunchKernelGGL((k_mmf_exact<false, 1>), dim3((unsigned)((M + 31) / 32), (unsigned)((N + 63) / 64), (unsigned) Z), dim3(256), 0, st, a);
+        else         hipLaunchKernelGGL((k_mmf_exact<false, 2>), dim3((unsigned)((M + 63) / 64), (unsigned)((N + 63) / 64), (unsigned) Z), dim3(256), 0, st, a);
     } else {
         if ((N + 31) / 32 > 65535) return CLLM_E_UNSUPPORTED;
-        hipLaunchKernelGGL((k_mmf_exact<true>), dim3((unsigned)((M + 31) / 32), (unsigned)((N + 31) / 32), (unsigned) Z), dim3(256), 0, st, a);
+        hipLaunchKernelGGL((k_mmf_exact<true, 1>), dim3((unsigned)((M + 31) / 32), (unsigned)((N + 31) / 32), (unsigned) Z), dim3(256), 0, st, a);
     }
     LAUNCH_CHECK();
     return CLLM_OK;
