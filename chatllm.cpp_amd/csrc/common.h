@@ -414,7 +414,8 @@ bool prefill_f16_enabled();
 //   0 fast: int8-MFMA GEMM (mmq.hip) + flash kernel (fattn.hip), their own fp32 summation order (tolerance tier)
 int prefill_mode();
 int launch_mmx(hipStream_t st, int wtype, const tview & w, const void * act, size_t act_stride, const tview & src1_geom, const tview & dst, const float * resid = nullptr, int64_t ldr = 0, int epi = 0);
-int launch_mmf_exact(hipStream_t st, const tview & w, const tview & x, const tview & d, int causal, int n_past);
+int launch_mmf_exact(hipStream_t st, const tview & w, const tview & x, const tview & d, int causal, int n_past, bool x_f16 = false);
+int launch_soft_max_causal_f16out(hipStream_t st, const tview & sv, float scale, int n_past);      // ops.hip
 // the eager attention block of a prompt in the reference's order: K.Q (causal) -> SCALE + DIAG_MASK_INF + SOFT_MAX -> V.P; q [hd, qlen, nh] F32, k [hd, n_kv, nkv] F16,
 // vt [n_kv, hd, nkv] F16 (V^T rows); dst element (d, q, h) at d * 4 + q * nbn + h * nbh
 int attn_prefill_exact(hipStream_t st, const tview & q, const tview & k, const tview & vt, char * dst, int64_t nbn, int64_t nbh, float scale, int n_past);

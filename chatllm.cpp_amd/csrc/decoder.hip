@@ -415,9 +415,18 @@ static int forward_general(cllm_llama * m, int qlen, int n_past) {
             TRY(ensure_scores(m, (size_t)(n_kv * qlen * nh)));
             cllm_tensor S  = T(CLLM_TYPE_F32, m->scores, n_kv, qlen, nh);
             TRY(launch_mul_mat_f((hipStream_t) st, CLLM_TYPE_F16, tv(&Kv), tv(&Qv), tv(&S), 1, n_past));       // causal 1: fully masked tiles are not computed
-            TRY(cllm_op_scale_mask_soft_max(st, &S, &S, 1.0f / sqrtf((float) hd), n_past));
             cllm_tensor C  = T(CLLM_TYPE_F32, m->ctx, hd, qlen, nh);
+            // exact mode, a prompt: the probabilities stay fp16 between the soft-max and V.P (the rounding V.P's src1 conversion would apply: same bits, half the bytes)
+            int prc = CLLM_E_UNSUPPORTED;
+            if (prefill_mode() == 1 && qlen > 32 && n_kv % 8 == 0 && hd % 4 == 0) {
+                prc = launch_soft_max_causal_f16out((hipStream_t) st, tv(&S), 1.0f / sqrtf((float) hd), n_past);
+                if (prc == CLLM_OK) { tview P = tv(&S); P.nb[0] = 2; prc = launch_mmf_exact((hipStream_t) st, tv(&Vv), P, tv(&C), 2, n_past, true); }
+                if (prc != CLLM_OK && prc != CLLM_E_UNSUPPORTED) return prc;
+            }
+            if (prc == CLLM_E_UNSUPPORTED) {
+            TRY(cllm_op_scale_mask_soft_max(st, &S, &S, 1.0f / sqrtf((float) hd), n_past));
             TRY(launch_mul_mat_f((hipStream_t) st, CLLM_TYPE_F16, tv(&Vv), tv(&S), tv(&C), 2, n_past));         // causal 2: k stops where P is exactly 0
+            }
             // permute(0,2,1,3) + cont -> [hd, nh, qlen]
             cllm_tensor Cp = T(CLLM_TYPE_F32, m->ctx, hd, nh, qlen); Cp.nb[1] = (size_t) hd * qlen * 4; Cp.nb[2] = (size_t) hd * 4; Cp.nb[3] = (size_t) hd * qlen * nh * 4;
             cllm_tensor A  = T(CLLM_TYPE_F32, m->att, hd, nh, qlen);

@@ -23,6 +23,7 @@ typedef _Float16 h8v __attribute__((ext_vector_type(8)));
 struct mmfx_args {
     tview w, x, d;
     int causal, n_past;
+    int x_f16;                  // src1 rows are already fp16 (the soft-max's OUT16 form): elements of 2 bytes, nothing to convert
 };
 
 #define MMFX_KC 128
@@ -117,7 +118,10 @@ __global__ void __launch_bounds__(256, (VD || PM == 2) ? 2 : 3) k_mmf_exact(cons
                 const int64_t lim = a.causal == 2 ? ((int64_t) a.n_past + m + 1 < kend ? (int64_t) a.n_past + m + 1 : kend) : kend;
                 fx_[t] = m < M && e0 + 8 <= lim && x_al;
                 xa_[t] = f32x4{0, 0, 0, 0}; xb_[t] = f32x4{0, 0, 0, 0};
-                if (fx_[t]) { const char * p = xb + m * x.nb[1] + e0 * 4; xa_[t] = *(const f32x4 *) p; xb_[t] = *(const f32x4 *)(p + 16); }
+                if (fx_[t]) {
+                    if (a.x_f16) xa_[t] = *(const f32x4 *)(xb + m * x.nb[1] + e0 * 2);           // eight fp16, taken as they are
+                    else { const char * p = xb + m * x.nb[1] + e0 * 4; xa_[t] = *(const f32x4 *) p; xb_[t] = *(const f32x4 *)(p + 16); }
+                }
             }
 #pragma unroll
             for (int t = 0; t < TW; t++) {
@@ -134,13 +138,14 @@ __global__ void __launch_bounds__(256, (VD || PM == 2) ? 2 : 3) k_mmf_exact(cons
                 // causal 2: column m's probabilities end at n_past + m (what lies beyond was never written: read as zero)
                 const int64_t lim = a.causal == 2 ? ((int64_t) a.n_past + m + 1 < kend ? (int64_t) a.n_past + m + 1 : kend) : kend;
                 u32x4 v;
-                if (fx_[t]) {
+                if (fx_[t] && a.x_f16) v = __builtin_bit_cast(u32x4, xa_[t]);
+                else if (fx_[t]) {
                     const f32x4 a4 = xa_[t], b4 = xb_[t];
                     v = u32x4{ (uint32_t) f2h(a4.x) | ((uint32_t) f2h(a4.y) << 16), (uint32_t) f2h(a4.z) | ((uint32_t) f2h(a4.w) << 16),
                                (uint32_t) f2h(b4.x) | ((uint32_t) f2h(b4.y) << 16), (uint32_t) f2h(b4.z) | ((uint32_t) f2h(b4.w) << 16) };
                 } else {
                     v = u32x4{0, 0, 0, 0};
-                    if (m < M && e0 < lim) v = load8f_as_h(xb + m * x.nb[1] + e0 * 4, e0, lim, false);
+                    if (m < M && e0 < lim) v = a.x_f16 ? load8h(xb + m * x.nb[1] + e0 * 2, e0, lim, false) : load8f_as_h(xb + m * x.nb[1] + e0 * 4, e0, lim, false);
                 }
                 *(u32x4 *)(Xt + row * MMFX_LD + ch * 16) = v;
             }
@@ -234,13 +239,14 @@ __global__ void __launch_bounds__(256, (VD || PM == 2) ? 2 : 3) k_mmf_exact(cons
 }
 
 // w: F16 [K, N, ne02, ne03] (dense rows), x: F32 [K, M, ne12, ne13] (dense rows), d: F32 [N, M, ne12, ne13] (dense rows); CLLM_E_UNSUPPORTED: shapes this kernel does not take
-int launch_mmf_exact(hipStream_t st, const tview & w, const tview & x, const tview & d, int causal, int n_past) {
-    if (w.nb[0] != 2 || x.nb[0] != 4 || d.nb[0] != 4 || (w.nb[1] | w.nb[2] | w.nb[3]) % 2 || (x.nb[1] | x.nb[2] | x.nb[3] | d.nb[1] | d.nb[2] | d.nb[3]) % 4) return CLLM_E_UNSUPPORTED;
+int launch_mmf_exact(hipStream_t st, const tview & w, const tview & x, const tview & d, int causal, int n_past, bool x_f16) {
+    if (w.nb[0] != 2 || x.nb[0] != (x_f16 ? 2 : 4) || d.nb[0] != 4 || (w.nb[1] | w.nb[2] | w.nb[3]) % 2 || (x.nb[1] | x.nb[2] | x.nb[3] | d.nb[1] | d.nb[2] | d.nb[3]) % 4) return CLLM_E_UNSUPPORTED;
     const int64_t K = w.ne[0], N = w.ne[1], M = x.ne[1], Z = x.ne[2] * x.ne[3];
     if (K <= 0 || N <= 0 || M <= 0 || Z <= 0 || Z > 65535) return CLLM_E_UNSUPPORTED;
-    mmfx_args a; a.w = w; a.x = x; a.d = d; a.causal = causal; a.n_past = n_past;
+    mmfx_args a; a.w = w; a.x = x; a.d = d; a.causal = causal; a.n_past = n_past; a.x_f16 = x_f16 ? 1 : 0;
     // llamafile_sgemm takes the product when n >= 2, k % 8 == 0, m % 4 == 0 (sgemm.cpp:3691, 488, 503-517); else the vec_dot loop
     const bool t8 = M >= 2 && K % 8 == 0 && N % 4 == 0;
+    if (x_f16 && !t8) return CLLM_E_UNSUPPORTED;                    // (fp16 src1 rows: the tinyBLAS form only -- the caller's choice of path guarantees it)
     if (t8) {
         if ((N + 63) / 64 > 65535) return CLLM_E_UNSUPPORTED;
         // the narrow tile (64 rows x 32 columns, three workgroups per CU) for both contractions of the prompt's attention: measured at cfg3 (profiles/r04_mmf_exact_tile.txt)
@@ -280,14 +286,21 @@ int attn_prefill_exact(hipStream_t st, const tview & q, const tview & k, const t
         S.nb[0] = 4; S.nb[1] = n_kv * 4; S.nb[2] = n_kv * qlen * 4; S.nb[3] = S.nb[2] * nhc;
         int rc = launch_mmf_exact(st, kv, qv, S, 1, n_past);
         if (rc) return rc;
-        cllm_tensor St; St.type = CLLM_TYPE_F32; St.data = S.data;
-        for (int i = 0; i < 4; i++) { St.ne[i] = S.ne[i]; St.nb[i] = (size_t) S.nb[i]; }
-        rc = cllm_op_scale_mask_soft_max((void *) st, &St, &St, scale, n_past);
+        // the probabilities as fp16 in place (what V.P's src1 conversion would make of them) where V.P runs in the tinyBLAS form; else f32 and the conversion while staging
+        const bool vp_t8 = qlen >= 2 && n_kv % 8 == 0 && vt.ne[1] % 4 == 0;
+        rc = vp_t8 ? launch_soft_max_causal_f16out(st, S, scale, n_past) : CLLM_E_UNSUPPORTED;
+        const bool p16 = rc == CLLM_OK;
+        if (rc == CLLM_E_UNSUPPORTED) {
+            cllm_tensor St; St.type = CLLM_TYPE_F32; St.data = S.data;
+            for (int i = 0; i < 4; i++) { St.ne[i] = S.ne[i]; St.nb[i] = (size_t) S.nb[i]; }
+            rc = cllm_op_scale_mask_soft_max((void *) st, &St, &St, scale, n_past);
+        }
         if (rc) return rc;
         tview vv = vt; vv.data += (h0 / r2) * vt.nb[2]; vv.ne[0] = n_kv; vv.ne[2] = nhc / r2; vv.ne[3] = 1;
         tview d; d.data = dst + h0 * nbh; d.ne[0] = vt.ne[1]; d.ne[1] = qlen; d.ne[2] = nhc; d.ne[3] = 1;
         d.nb[0] = 4; d.nb[1] = nbn; d.nb[2] = nbh; d.nb[3] = nbh * nhc;
-        rc = launch_mmf_exact(st, vv, S, d, 2, n_past);
+        tview P = S; if (p16) P.nb[0] = 2;                            // (same rows, same strides: the fp16 values sit at the start of each row)
+        rc = launch_mmf_exact(st, vv, P, d, 2, n_past, p16);
         if (rc) return rc;
     }
     return CLLM_OK;

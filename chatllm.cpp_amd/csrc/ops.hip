@@ -234,7 +234,9 @@ __global__ void __launch_bounds__(256) k_soft_max(tview s, tview d, const char *
 // fused scale + causal mask + soft_max with the row held in registers (prefill score rows: one read, one write instead of
 // two of each).  Same lane -> group-of-8 mapping, same max set, same summation order as k_soft_max<1>: bit-identical.
 // Needs n % 8 == 0, n <= 512 * NG, 16-byte aligned rows.
-template <int NG>
+// OUT16: the probabilities are stored as fp16 (RNE of the float product: exactly what ggml's from_float makes of them when V.P takes them as src1), at the start of the
+// row they came from -- the prompt's exact attention block (mmf_exact.hip) then reads half the bytes and converts nothing
+template <int NG, bool OUT16 = false>
 __global__ void __launch_bounds__(256) k_soft_max_causal_reg(tview s, tview d, float scale, int n_past) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t) blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
@@ -284,7 +286,10 @@ __global__ void __launch_bounds__(256) k_soft_max_causal_reg(tview s, tview d, f
         if (g0 < n) {
             f32x4 lo = {0, 0, 0, 0}, hi = {0, 0, 0, 0};
             if (g0 < n_vis) { lo = f32x4{e[t][0] * inv, e[t][1] * inv, e[t][2] * inv, e[t][3] * inv}; hi = f32x4{e[t][4] * inv, e[t][5] * inv, e[t][6] * inv, e[t][7] * inv}; }
-            *(f32x4 *)(y + g0) = lo; *(f32x4 *)(y + g0 + 4) = hi;
+            if constexpr (OUT16) {
+                *(u32x4 *)((char *) y + (size_t) g0 * 2) = u32x4{ (uint32_t) f2h(lo.x) | ((uint32_t) f2h(lo.y) << 16), (uint32_t) f2h(lo.z) | ((uint32_t) f2h(lo.w) << 16),
+                                                                  (uint32_t) f2h(hi.x) | ((uint32_t) f2h(hi.y) << 16), (uint32_t) f2h(hi.z) | ((uint32_t) f2h(hi.w) << 16) };
+            } else { *(f32x4 *)(y + g0) = lo; *(f32x4 *)(y + g0 + 4) = hi; }
         }
     }
 }
@@ -337,6 +342,18 @@ __global__ void __launch_bounds__(256) k_soft_max_causal_lds(tview s, tview d, f
         if (g0 < nv_vis) { lo = f32x4{sm[g0] * inv, sm[g0 + 1] * inv, sm[g0 + 2] * inv, sm[g0 + 3] * inv}; hi = f32x4{sm[g0 + 4] * inv, sm[g0 + 5] * inv, sm[g0 + 6] * inv, sm[g0 + 7] * inv}; }
         *(f32x4 *)(y + g0) = lo; *(f32x4 *)(y + g0 + 4) = hi;
     }
+}
+
+// SCALE + DIAG_MASK_INF + SOFT_MAX over f32 rows [n, rows ...] IN PLACE, the probabilities left as fp16 at the start of each row (see k_soft_max_causal_reg<.., true>);
+// CLLM_E_UNSUPPORTED: shapes the register-resident kernel does not take (the caller keeps f32)
+int launch_soft_max_causal_f16out(hipStream_t st, const tview & sv, float scale, int n_past) {
+    const int64_t n = sv.ne[0], rows = sv.ne[1] * sv.ne[2] * sv.ne[3];
+    if (n % 8 || n < 512 || n > 8192 || rows <= 0 || (((uintptr_t) sv.data | (uintptr_t) sv.nb[1] | (uintptr_t) sv.nb[2] | (uintptr_t) sv.nb[3]) & 15) || sv.nb[0] != 4) return CLLM_E_UNSUPPORTED;
+    const unsigned grid = (unsigned)((rows + 3) / 4);
+    if (n <= 4096) hipLaunchKernelGGL((k_soft_max_causal_reg<8, true>),  dim3(grid), dim3(256), 0, st, sv, sv, scale, n_past);
+    else           hipLaunchKernelGGL((k_soft_max_causal_reg<16, true>), dim3(grid), dim3(256), 0, st, sv, sv, scale, n_past);
+    LAUNCH_CHECK();
+    return CLLM_OK;
 }
 
 static int soft_max_impl(void * stream, const cllm_tensor * src, const cllm_tensor * mask, cllm_tensor * dst, float scale, int fused, int n_past) {
