@@ -41,6 +41,38 @@ __global__ void __launch_bounds__(256) k_rate(const float * in, float * out) {
     out[blockIdx.x * 256 + threadIdx.x] = s;
 }
 
+typedef float f32v __attribute__((ext_vector_type(32)));
+// the exact GEMM's real ratio: 32 x 64 fmas per two 16x16x4_4b MFMAs -- or per ONE 32x32x4_2b MFMA (the same 8192 MACs in one instruction: does the VALU port lose less?)
+template <int BIG>
+__global__ void __launch_bounds__(256) k_mix32(const float * in, float * out) {
+    float a[32];
+    const float x = in[threadIdx.x & 63], y = in[(threadIdx.x & 63) + 1];
+#pragma unroll
+    for (int q = 0; q < 32; q++) a[q] = (float) q;
+    const h4 a4 = {(_Float16) x, (_Float16) 1, (_Float16) 2, (_Float16) 3}, b4 = {(_Float16) y, (_Float16) 1, (_Float16) 1, (_Float16) 2};
+    f16v D[2] = {(f16v){0}, (f16v){0}}; f32v E = (f32v){0};
+    for (int it = 0; it < ITERS; it++) {
+        if (BIG) E = __builtin_amdgcn_mfma_f32_32x32x4f16(a4, b4, E, 0, 0, 0);
+        else { D[0] = __builtin_amdgcn_mfma_f32_16x16x4f16(a4, b4, D[0], 0, 0, 0); D[1] = __builtin_amdgcn_mfma_f32_16x16x4f16(a4, b4, D[1], 0, 0, 0); }
+#pragma unroll
+        for (int q = 0; q < 32; q++) asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(a[q]) : "v"(x), "v"(y));
+    }
+    float s = D[0][0] + D[1][0] + E[0];
+#pragma unroll
+    for (int q = 0; q < 32; q++) s += a[q];
+    out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+template <typename K> static void run32(const char * name, K kern, int wps, const float * in, float * out, int cus, double ghz) {
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    hipLaunchKernelGGL(kern, dim3(cus * wps), dim3(256), 0, 0, in, out);
+    hipEventRecord(e0, 0);
+    hipLaunchKernelGGL(kern, dim3(cus * wps), dim3(256), 0, 0, in, out);
+    hipEventRecord(e1, 0); hipEventSynchronize(e1);
+    float ms = 0; hipEventElapsedTime(&ms, e0, e1);
+    const double cyc = ms * 1e-3 * ghz * 1e9, per = (double) ITERS * wps;
+    printf("%-34s %d wave(s)/SIMD, 32x64 fmas per iteration: %7.1f us, %6.1f cycles per iteration and SIMD  (%5.2f fma-lanes / cycle / SIMD)\n", name, wps, ms * 1e3, cyc / per, 32.0 * 64.0 * per / cyc);
+}
+
 template <typename K> static void run(const char * name, K kern, int wps, int nmfma, const float * in, float * out, int cus, double ghz) {
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     hipLaunchKernelGGL(kern, dim3(cus * wps), dim3(256), 0, 0, in, out);
@@ -68,6 +100,10 @@ int main() {
         run("v_pk_fma_f32", k_rate<1, 1>, wps, 1, in, out, cus, ghz);
         run("v_fma_f32", k_rate<0, 2>, wps, 2, in, out, cus, ghz);
         run("v_pk_fma_f32", k_rate<1, 2>, wps, 2, in, out, cus, ghz);
+    }
+    for (int wps : {1, 2, 3}) {
+        run32("2 x v_mfma_f32_16x16x4_4b_f16 +", k_mix32<0>, wps, in, out, cus, ghz);
+        run32("1 x v_mfma_f32_32x32x4_2b_f16 +", k_mix32<1>, wps, in, out, cus, ghz);
     }
     return 0;
 }
