@@ -167,41 +167,36 @@ __device__ __forceinline__ double rms_block_sumsq_1024(const float * __restrict_
 // non-negative terms differ by at most 2 gamma_(n-1) = 2 (n - 1) u / (1 - (n - 1) u) of their value (u = 2^-53; Higham, Accuracy and Stability, 4.2), and the
 // only thing the rest of the op sees of the sum is (float)(sum / n): division and conversion are monotonic, so whenever the two ends of
 // sum (1 -+ (2 n + 16) u) give the SAME float, the serial sum gives it too and the tree's result is the reference's, bit for bit.  When they do not (the mean
-// lies within ~1e-12 of a float rounding boundary: about 3 rows in 10^5 at n = 4096) thread 0 redoes the sum in the reference's own order (~20 us: the loads run 16 ahead of the dependent adds).  The branch
+// lies within ~1e-12 of a float rounding boundary: about 3 rows in 10^5 at n = 4096) wave 0 redoes the sum in the reference's own order (rms_serial_sumsq below).  The branch
 // is uniform over the workgroup (every thread holds the same `sum`); x (+ add: the tensor-parallel partial folded into the residual) must still hold the
 // row, which is why the barriers sit here: no thread of an in-place launch stores before the serial pass has read.
 static __device__ __noinline__ double rms_div(double sum, double n) { return sum / n; }
-// (one thread, the reference's order; the loads run ahead of the dependent double adds: 64 values per batch.  COHERENT: the persistent launch hands x over inside
-//  the kernel -- L1-bypassing loads, a whole batch of them in flight; everywhere else the row was written by an earlier launch: plain wide loads)
+// (the reference's order, by wave 0: its 64 lanes load 64 consecutive values at once -- one register, the next batch requested before this one is added -- and square
+//  them; the serial chain then takes them lane by lane through v_readlane, every lane computing the same sum.  As a called function with a 64-value batch in one
+//  thread's registers this cost the 128-register decode kernels 4-17 spilled registers around the call.  COHERENT: the persistent launch hands x over inside the
+//  kernel -- L1-bypassing loads; everywhere else the row was written by an earlier launch.)
 template <bool COHERENT>
 static __device__ __noinline__ double rms_serial_sumsq(const float * x, const float * add, int64_t n) {
-    constexpr int B = 64;                                  // values per batch: all their loads are in flight before the first add (the adds are one dependent chain)
-    double sum = 0.0;
-    int64_t i = 0;
-    const bool wide = !COHERENT && (((uintptr_t) x | (uintptr_t) add) & 15) == 0;
-    for (; i + B <= n; i += B) {
-        float v[B];
-        if (COHERENT) {
-#pragma unroll
-            for (int k = 0; k < B; k++) v[k] = __uint_as_float(__hip_atomic_load((const unsigned *)(x + i + k), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-        } else if (wide) {
-#pragma unroll
-            for (int k = 0; k < B / 4; k++) { const f32x4 q = *(const f32x4 *)(x + i + 4 * k); v[4 * k] = q.x; v[4 * k + 1] = q.y; v[4 * k + 2] = q.z; v[4 * k + 3] = q.w; }
-        } else {
-#pragma unroll
-            for (int k = 0; k < B; k++) v[k] = x[i + k];
-        }
-        if (add) {
-#pragma unroll
-            for (int k = 0; k < B; k++) v[k] = v[k] + (COHERENT ? __uint_as_float(__hip_atomic_load((const unsigned *)(add + i + k), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) : add[i + k]);
-        }
-#pragma unroll
-        for (int k = 0; k < B; k++) sum += (double)(v[k] * v[k]);
-    }
-    for (; i < n; i++) {
+    const int lane = threadIdx.x & 63;
+    auto ld = [&](int64_t i) -> float {                     // element i (0 beyond the row), with the folded partial
+        if (i >= n) return 0.0f;
         float v = COHERENT ? __uint_as_float(__hip_atomic_load((const unsigned *)(x + i), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) : x[i];
         if (add) v = v + (COHERENT ? __uint_as_float(__hip_atomic_load((const unsigned *)(add + i), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) : add[i]);
-        sum += (double)(v * v);
+        return v;
+    };
+    double sum = 0.0;
+    float cur = ld(lane);
+    for (int64_t i = 0; i < n; i += 64) {
+        const float nxt = ld(i + 64 + lane);
+        const float sq = cur * cur;
+        const int sqb = (int) __float_as_uint(sq);
+        if (n - i >= 64) {
+#pragma unroll 8
+            for (int k = 0; k < 64; k++) sum += (double) __uint_as_float((unsigned) __builtin_amdgcn_readlane(sqb, k));
+        } else {
+            for (int k = 0; k < (int)(n - i); k++) sum += (double) __uint_as_float((unsigned) __builtin_amdgcn_readlane(sqb, k));
+        }
+        cur = nxt;
     }
     return sum;
 }
@@ -214,7 +209,7 @@ __device__ __forceinline__ float rms_scale(double sum, int64_t n, float eps, con
     const double d = sum * ((double)(2 * n + 16) * 0x1p-53);
     if (!(rms_mean(sum - d, n) == rms_mean(sum + d, n))) {
         __syncthreads();
-        if (threadIdx.x == 0) part[0] = rms_serial_sumsq<COHERENT>(x, add, n);
+        if (threadIdx.x < 64) { const double ss = rms_serial_sumsq<COHERENT>(x, add, n); if (threadIdx.x == 0) part[0] = ss; }
         __syncthreads();
         m = rms_mean(part[0], n);
     }

@@ -16,6 +16,7 @@
 // Causal structure of the prompt (the runner / the module's attention pattern pass it): causal 1 (K.Q) skips tiles whose scores are all masked;
 // causal 2 (V.P) ends the K loop where the probabilities of the tile's last column end -- fma(w, 0, acc) == acc, the skipped steps change no bit.
 #include "common.h"
+#include <type_traits>
 #include <stdlib.h>
 
 typedef _Float16 h8v __attribute__((ext_vector_type(8)));
@@ -24,7 +25,20 @@ struct mmfx_args {
     tview w, x, d;
     int causal, n_past;
     int x_f16;                  // src1 rows are already fp16 (the soft-max's OUT16 form): elements of 2 bytes, nothing to convert
+    int zfirst;                 // grid order: 0: x = column tiles, z = the batch (heads); 1: x = the batch, z = column tiles (see mmfx_block)
 };
+
+// Causal products: a column tile's work grows with its index, and the hardware dispatches workgroups in x-then-y-then-z order.  With the heads on z, "longest first"
+// held only inside a head: the last head's longest workgroups started when the rest of the chip was draining (K.Q by columns: 345 patches per wave slot on average, 256
+// in the longest wave -- a tail of up to 74 %).  zfirst puts the HEADS on x, so every head's longest tiles are dispatched before anybody's short ones; the head index is
+// permuted so that an XCD (workgroup id mod 8) keeps a contiguous range of heads -- the query heads of one K/V head share that XCD's L2.
+__device__ __forceinline__ void mmfx_block(const mmfx_args & a, unsigned & bm, unsigned & gm, unsigned & bz) {
+    if (a.zfirst) {
+        gm = gridDim.z; bm = blockIdx.z;
+        const unsigned Z = gridDim.x, bx = blockIdx.x;
+        bz = (Z & 7) == 0 ? (bx & 7) * (Z >> 3) + (bx >> 3) : bx;
+    } else { gm = gridDim.x; bm = blockIdx.x; bz = blockIdx.z; }
+}
 
 #define MMFX_KC 128
 #define MMFX_LD (MMFX_KC * 2 + 16)
@@ -68,8 +82,9 @@ __global__ void __launch_bounds__(256, (VD || PM == 2) ? 2 : 3) k_mmf_exact(cons
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, g = lane >> 4;
     // causal 2 (V.P): a column tile's K loop ends at its last visible position, so the work grows with the tile index -- the LONGEST tiles are dispatched first
     // (the last tiles to start are then the shortest: the launch does not end on a few CUs walking 4096 positions)
-    const int64_t m0 = (int64_t)(a.causal == 2 ? gridDim.x - 1 - blockIdx.x : blockIdx.x) * BM, n0 = (int64_t) blockIdx.y * BN;
-    const int64_t i12 = blockIdx.z % x.ne[2], i13 = blockIdx.z / x.ne[2];
+    unsigned bm_, gm_, bz_; mmfx_block(a, bm_, gm_, bz_);
+    const int64_t m0 = (int64_t)(a.causal == 2 ? gm_ - 1 - bm_ : bm_) * BM, n0 = (int64_t) blockIdx.y * BN;
+    const int64_t i12 = bz_ % x.ne[2], i13 = bz_ / x.ne[2];
     const int64_t r2 = x.ne[2] / w.ne[2], r3 = x.ne[3] / w.ne[3];
     const int64_t K = w.ne[0], N = w.ne[1], M = x.ne[1];
     // causal 1: score (row n = position, column m = query) is masked when n > n_past + m: a tile whose first row lies beyond the last column's horizon is not computed
@@ -238,12 +253,126 @@ __global__ void __launch_bounds__(256, (VD || PM == 2) ? 2 : 3) k_mmf_exact(cons
         }
 }
 
+// ---- the single-stage product (K <= 128: the prompt's K.Q, K = the head size) with NO LDS and NO barrier: the MFMA operand layout (lane = row l & 15, k group l >> 4:
+//      eight consecutive K elements per chain step) is 16 contiguous bytes of an fp16 row, i.e. one global_load_dwordx4 per lane -- the operands go from global memory
+//      straight into registers.  A WAVE owns 16 columns (queries): their Q values are converted once and held in 32 registers for the wave's life; it walks the K-cache
+//      rows in patches of 16, three patches' loads in flight ahead of the one being multiplied (four register buffers); waves never wait for each other.  Measured at
+//      cfg3 (32 heads, 4096 x 4096 causal, profiles/r04_prompt_attention_kq_forms.txt): 0.72 ms per launch against 1.00 (one workgroup per 64 x 32 tile) and 0.79 (a
+//      workgroup walking the row tiles of its column tile through two LDS buffers, one barrier per tile), all three with the heads on grid x; the 34.1 M MFMAs alone are
+//      0.46 ms, with the 32 conversions per 32 MFMAs 0.55 (tools/micro/mfma_f32_occupancy.hip: VALU instructions beside f32 MFMAs add their issue time).
+//      Same products, same chains, same reduction: the same bits.
+__global__ void __launch_bounds__(256, 3) k_mmf_exact_kq(const mmfx_args a) {
+    const tview & w = a.w; const tview & x = a.x; const tview & d = a.d;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, g = lane >> 4;
+    const int K = (int) w.ne[0], N = (int) w.ne[1], M = (int) x.ne[1];
+    unsigned bm_, gm_, bz_; mmfx_block(a, bm_, gm_, bz_);
+    const int m0 = ((int)(gm_ - 1 - bm_) * 4 + wave) * 16;                     // longest columns first (causal: the rows a column needs grow with it)
+    if (m0 >= M) return;
+    const unsigned z = bz_, ne12 = (unsigned) x.ne[2], r2 = (unsigned)(x.ne[2] / w.ne[2]), r3 = (unsigned)(x.ne[3] / w.ne[3]);
+    const unsigned i12 = z % ne12, i13 = z / ne12;
+    const char * wb = w.data + (int64_t)(i12 / r2) * w.nb[2] + (int64_t)(i13 / r3) * w.nb[3];
+    const char * xb = x.data + (int64_t) i12 * x.nb[2] + (int64_t) i13 * x.nb[3];
+    char * db = d.data + (int64_t) i12 * d.nb[2] + (int64_t) i13 * d.nb[3];
+    const int kch = K >> 3;                                                    // 8-element chunks per row (the launcher: K % 8 == 0, K <= 128, rows 16-byte aligned)
+    const int mlast = m0 + 15 < M - 1 ? m0 + 15 : M - 1;
+    const int np_all = (N + 15) >> 4;
+    // causal 1: score (row n, column m) is masked when n > n_past + m: patches whose first row lies beyond the last column's horizon are not computed
+    const int np_vis = ((a.n_past + mlast) >> 4) + 1;
+    const int npatch = a.causal == 1 && np_vis < np_all ? np_vis : np_all;
+
+    // chain step u of lane group g is chunk 4 u + g of the row (elements 32 u + 8 g ..+7); chunks beyond K read a clamped address and count as zeros
+    int coff[4]; bool cok[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) { const int c = 4 * u + g; cok[u] = c < kch; coff[u] = (cok[u] ? c : kch - 1); }
+    // this wave's Q values (column m0 + l15): f32 -> fp16 (RNE) -> f32, once
+    float xf[4][8];
+    {
+        const int m = m0 + l15;
+        const char * xp = xb + (int64_t)(m < M ? m : M - 1) * x.nb[1];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const f32x4 lo = *(const f32x4 *)(xp + coff[u] * 32), hi = *(const f32x4 *)(xp + coff[u] * 32 + 16);
+            const bool ok = cok[u] && m < M;
+            const float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+#pragma unroll
+            for (int i = 0; i < 8; i++) xf[u][i] = ok ? h2f(f2h(v[i])) : 0.0f;
+        }
+    }
+    const char * wp[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) wp[u] = wb + coff[u] * 16;
+    const int64_t wnb1 = w.nb[1];
+    // this lane's four destination columns (m = m0 + 4 g + v) at row l15 of patch 0
+    char * dp[4];
+#pragma unroll
+    for (int v = 0; v < 4; v++) { const int m = m0 + 4 * g + v; dp[v] = db + (int64_t)(m < M ? m : M - 1) * d.nb[1] + l15 * 4; }
+
+    u32x4 rw[4][4];                                                            // [buffer][chain step]
+    auto wload = [&](int pt, u32x4 (&r)[4]) {                                  // patch pt (clamped into the matrix) -> registers
+        int n = pt * 16 + l15; n = n < N ? n : N - 1;
+        const int64_t ro = (int64_t) n * wnb1;
+#pragma unroll
+        for (int u = 0; u < 4; u++) r[u] = *(const u32x4 *)(wp[u] + ro);
+    };
+    auto patch = [&](int pt, const u32x4 (&r)[4], auto full_tag) {
+        constexpr bool FULL = decltype(full_tag)::value;
+        f32x4 D[8];
+#pragma unroll
+        for (int L = 0; L < 8; L++) D[L] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        const bool rok = FULL || pt * 16 + l15 < N;
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            float wf[8];
+            const uint32_t keep = (cok[u] && rok) ? 0xffffffffu : 0u;
+            h8_to_f(u32x4{r[u].x & keep, r[u].y & keep, r[u].z & keep, r[u].w & keep}, wf);
+#pragma unroll
+            for (int L = 0; L < 8; L++) D[L] = __builtin_amdgcn_mfma_f32_16x16x4f32(xf[u][L], wf[L], D[L], 0, 0, 0);
+        }
+        const int n = pt * 16 + l15;
+#pragma unroll
+        for (int v = 0; v < 4; v++) {
+            float r0 = D[4][v] + D[0][v], r1 = D[5][v] + D[1][v], r2_ = D[6][v] + D[2][v], r3_ = D[7][v] + D[3][v];      // hsum_float_8
+            r0 = r0 + r2_; r1 = r1 + r3_;
+            float * q = (float *)(dp[v] + (int64_t) pt * 64);
+            if (FULL || (n < N && m0 + 4 * g + v < M)) *q = r0 + r1;
+        }
+    };
+    // groups of four patches (one per register buffer); a group past the end repeats the last patch (same values stored again) -- no branch inside the loop body
+    const int last = npatch - 1;
+    wload(0, rw[0]); wload(1 < last ? 1 : last, rw[1]); wload(2 < last ? 2 : last, rw[2]);
+    const int nfull = (m0 + 16 <= M) ? (N >> 4 < npatch ? N >> 4 : npatch) & ~3 : 0;       // leading groups wholly inside the matrix: stores without per-lane tests
+    int pt = 0;
+    for (; pt < nfull; pt += 4) {
+#pragma unroll
+        for (int s = 0; s < 4; s++) {
+            const int pn = pt + s + 3 < last ? pt + s + 3 : last;
+            wload(pn, rw[(s + 3) & 3]);
+            __builtin_amdgcn_sched_barrier(0);
+            patch(pt + s, rw[s], std::true_type{});
+        }
+    }
+    for (; pt < npatch; pt += 4) {
+#pragma unroll
+        for (int s = 0; s < 4; s++) {
+            const int pc = pt + s < last ? pt + s : last, pn = pt + s + 3 < last ? pt + s + 3 : last;
+            wload(pn, rw[(s + 3) & 3]);
+            __builtin_amdgcn_sched_barrier(0);
+            patch(pc, rw[s], std::false_type{});
+        }
+    }
+}
+
 // w: F16 [K, N, ne02, ne03] (dense rows), x: F32 [K, M, ne12, ne13] (dense rows), d: F32 [N, M, ne12, ne13] (dense rows); CLLM_E_UNSUPPORTED: shapes this kernel does not take
 int launch_mmf_exact(hipStream_t st, const tview & w, const tview & x, const tview & d, int causal, int n_past, bool x_f16) {
     if (w.nb[0] != 2 || x.nb[0] != (x_f16 ? 2 : 4) || d.nb[0] != 4 || (w.nb[1] | w.nb[2] | w.nb[3]) % 2 || (x.nb[1] | x.nb[2] | x.nb[3] | d.nb[1] | d.nb[2] | d.nb[3]) % 4) return CLLM_E_UNSUPPORTED;
     const int64_t K = w.ne[0], N = w.ne[1], M = x.ne[1], Z = x.ne[2] * x.ne[3];
     if (K <= 0 || N <= 0 || M <= 0 || Z <= 0 || Z > 65535) return CLLM_E_UNSUPPORTED;
     mmfx_args a; a.w = w; a.x = x; a.d = d; a.causal = causal; a.n_past = n_past; a.x_f16 = x_f16 ? 1 : 0;
+    static const int zf_mode = getenv("CLLM_MMF_ZFIRST") ? atoi(getenv("CLLM_MMF_ZFIRST")) : 1;      // (tools: 0 = the heads on grid z as before)
+    auto grid = [&](int64_t tm, int64_t tn) {                       // column tiles x row tiles x batch, in the order a.zfirst says
+        a.zfirst = (zf_mode && causal != 0 && tm <= 65535) ? 1 : 0;
+        return a.zfirst ? dim3((unsigned) Z, (unsigned) tn, (unsigned) tm) : dim3((unsigned) tm, (unsigned) tn, (unsigned) Z);
+    };
     // llamafile_sgemm takes the product when n >= 2, k % 8 == 0, m % 4 == 0 (sgemm.cpp:3691, 488, 503-517); else the vec_dot loop
     const bool t8 = M >= 2 && K % 8 == 0 && N % 4 == 0;
     if (x_f16 && !t8) return CLLM_E_UNSUPPORTED;                    // (fp16 src1 rows: the tinyBLAS form only -- the caller's choice of path guarantees it)
@@ -251,13 +380,22 @@ int launch_mmf_exact(hipStream_t st, const tview & w, const tview & x, const tvi
         if ((N + 63) / 64 > 65535) return CLLM_E_UNSUPPORTED;
         // the narrow tile (64 rows x 32 columns, three workgroups per CU) for both contractions of the prompt's attention: measured at cfg3 (profiles/r04_mmf_exact_tile.txt)
         // 406.3 ms against 414.6-416.0 with the square tile and 413.5 with the narrow one on K.Q only -- a third resident workgroup covers the other two's stage loads
+        static const int kq_mode = getenv("CLLM_MMF_KQ") ? atoi(getenv("CLLM_MMF_KQ")) : 1;       // (tools: 0 = the LDS-staged tiles for the single-stage shapes too)
+        const bool al16 = ((((uintptr_t) w.data) | (uintptr_t) w.nb[1] | (uintptr_t) w.nb[2] | (uintptr_t) w.nb[3] | ((uintptr_t) x.data) | (uintptr_t) x.nb[1] | (uintptr_t) x.nb[2] | (uintptr_t) x.nb[3]) & 15) == 0;
+        if (kq_mode && al16 && K <= MMFX_KC && !x_f16 && causal != 2 && M > 32 && N >= 256 && N < (1 << 30) && (M + 63) / 64 <= 65535) {      // a prompt's K.Q: waves walk the rows of their 16 columns
+            const dim3 gr = grid((M + 63) / 64, 1);
+            hipLaunchKernelGGL(k_mmf_exact_kq, gr, dim3(256), 0, st, a);
+            LAUNCH_CHECK();
+            return CLLM_OK;
+        }
         static const int force_pm = getenv("CLLM_MMF_PM") ? atoi(getenv("CLLM_MMF_PM")) : 0;      // (tools: 2 forces the 64 x 64 tile)
         const int pm = force_pm == 2 ? 2 : 1;
-        if (pm == 1) hipLaunchKernelGGL((k_mmf_exact<false, 1>), dim3((unsigned)((M + 31) / 32), (unsigned)((N + 63) / 64), (unsigned) Z), dim3(256), 0, st, a);
-        else         hipLaunchKernelGGL((k_mmf_exact<false, 2>), dim3((unsigned)((M + 63) / 64), (unsigned)((N + 63) / 64), (unsigned) Z), dim3(256), 0, st, a);
+        if (pm == 1) { const dim3 gr = grid((M + 31) / 32, (N + 63) / 64); hipLaunchKernelGGL((k_mmf_exact<false, 1>), gr, dim3(256), 0, st, a); }
+        else         { const dim3 gr = grid((M + 63) / 64, (N + 63) / 64); hipLaunchKernelGGL((k_mmf_exact<false, 2>), gr, dim3(256), 0, st, a); }
     } else {
         if ((N + 31) / 32 > 65535) return CLLM_E_UNSUPPORTED;
-        hipLaunchKernelGGL((k_mmf_exact<true, 1>), dim3((unsigned)((M + 31) / 32), (unsigned)((N + 31) / 32), (unsigned) Z), dim3(256), 0, st, a);
+        const dim3 gr = grid((M + 31) / 32, (N + 31) / 32);
+        hipLaunchKernelGGL((k_mmf_exact<true, 1>), gr, dim3(256), 0, st, a);
     }
     LAUNCH_CHECK();
     return CLLM_OK;

@@ -59,24 +59,37 @@ def test_product_package_never_imports_the_oracle():
                 assert "liboracle" not in txt and "ggml_oracle" not in txt and "import oracle" not in txt, os.path.join(dirpath, f)
 
 
-def test_kernels_with_hand_issued_loads_do_not_spill():
-    """gemv_team32.hip issues the chain wave's LDS reads by asm and waits for them by count: a register of such a read must never be spilled or copied while the
-    read is in flight.  The allocator keeps them in place as long as nothing spills -- every instantiation must report 0 spilled registers and no scratch."""
+def _resource_usage(name):
+    """hipcc -Rpass-analysis=kernel-resource-usage of one csrc file with the flags the library is built with (read from the Makefile: a copy here could drift)"""
     import shutil
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
         import pytest
         pytest.skip("no hipcc")
-    src = os.path.join(ROOT, "chatllm.cpp_amd", "csrc", "gemv_team32.hip")
-    # the flags the library is built with, read from the Makefile (a copy here could drift from the real build)
+    src = os.path.join(ROOT, "chatllm.cpp_amd", "csrc", name)
     mk = open(os.path.join(ROOT, "chatllm.cpp_amd", "csrc", "Makefile")).read()
     m = re.search(r"^FLAGS\s*:=\s*(.*)$", mk, re.M)
     assert m, "csrc/Makefile: FLAGS line not found"
     arch = re.search(r"^ARCH\s*\?=\s*(\S+)", mk, re.M).group(1)
     flags = m.group(1).replace("$(ARCH)", arch).split()
     assert "-ffp-contract=off" in flags and any(f.startswith("--offload-arch=") for f in flags), flags
-    cmd = [hipcc] + flags + ["--cuda-device-only", "-c", src, "-o", os.devnull, "-Rpass-analysis=kernel-resource-usage"]
-    out = subprocess.run(cmd, capture_output=True, text=True)
+    out = subprocess.run([hipcc] + flags + ["--cuda-device-only", "-c", src, "-o", os.devnull, "-Rpass-analysis=kernel-resource-usage"], capture_output=True, text=True)
     assert out.returncode == 0, out.stderr[-2000:]
-    spills = re.findall(r"VGPRs Spill: (\d+)", out.stderr) + re.findall(r"SGPRs Spill: (\d+)", out.stderr) + re.findall(r"ScratchSize \[bytes/lane\]: (\d+)", out.stderr)
+    return out.stderr
+
+
+def test_kernels_with_hand_issued_loads_do_not_spill():
+    """gemv_team32.hip issues the chain wave's LDS reads by asm and waits for them by count: a register of such a read must never be spilled or copied while the
+    read is in flight.  The allocator keeps them in place as long as nothing spills -- every instantiation must report 0 spilled registers and no scratch."""
+    err = _resource_usage("gemv_team32.hip")
+    spills = re.findall(r"VGPRs Spill: (\d+)", err) + re.findall(r"SGPRs Spill: (\d+)", err) + re.findall(r"ScratchSize \[bytes/lane\]: (\d+)", err)
     assert len(spills) >= 3 * 30 and all(int(x) == 0 for x in spills), sorted(set(spills))
+
+
+def test_the_decode_mat_vec_kernels_use_no_scratch():
+    """the single-token mat-vec launches last 4-15 us: a kernel that needs scratch pays for its set-up in every one of them.  (Round 4: the order-exact RMS_NORM's
+    serial fallback as a called function gave every norm-prologue instantiation of k_gemv_dec a call frame and up to 25 spilled registers, unnoticed by the
+    parity tests -- it now runs on wave 0's lanes in place.)"""
+    err = _resource_usage("gemv_decode.hip")
+    vals = re.findall(r"VGPRs Spill: (\d+)", err) + re.findall(r"ScratchSize \[bytes/lane\]: (\d+)", err)
+    assert len(vals) >= 2 * 40 and all(int(x) == 0 for x in vals), sorted(set(vals))
