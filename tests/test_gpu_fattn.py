@@ -169,7 +169,9 @@ def test_flash_attn_ext_declines_what_it_does_not_take(gpu):
 @pytest.mark.parametrize("D,N,H,Hkv,n_past,ML", [(128, 64, 8, 2, 0, 64), (128, 200, 8, 2, 0, 256), (128, 130, 4, 4, 261, 400), (64, 300, 4, 2, 33, 336),
                                                  # cached lengths that are multiples of 8 from 256 on: K.Q by columns and V.P straight from global memory into the MFMA layout
                                                  # (k_mmf_exact_kq / _vp): ragged column tiles, a past, head size 64, GQA, a masked last step
-                                                 (128, 320, 8, 2, 0, 320), (128, 200, 4, 4, 184, 384), (64, 296, 4, 2, 40, 336), (128, 1000, 2, 1, 24, 1024)])
+                                                 (128, 320, 8, 2, 0, 320), (128, 200, 4, 4, 184, 384), (64, 296, 4, 2, 40, 336), (128, 1000, 2, 1, 24, 1024),
+                                                 # 16 and 24 heads: the head index of a causal launch is permuted across the grid (an XCD keeps one K/V head) / left alone
+                                                 (64, 264, 16, 4, 0, 264), (64, 136, 24, 8, 128, 264)])
 def test_attn_prefill_against_the_node_sequence(gpu, D, N, H, Hkv, n_past, ML):
     """the fused prefill attention against the oracle's MUL_MAT + SCALE + DIAG_MASK_INF + SOFT_MAX + MUL_MAT over the cache views"""
     T = gpu.Tensor
