@@ -34,10 +34,11 @@ static_assert(sizeof(block_q5_K) == 176 && sizeof(block_q6_K) == 210, "block siz
 struct __attribute__((packed)) block_q5_0   { uint16_t d; uint8_t qh[4]; uint8_t qs[16]; };                  // 22 B: w = ((nib | bit << 4) - 16) * d
 struct __attribute__((packed)) block_q5_1   { uint16_t d, m; uint8_t qh[4]; uint8_t qs[16]; };               // 24 B: w = (nib | bit << 4) * d + m
 struct __attribute__((packed)) block_iq4_nl { uint16_t d; uint8_t qs[16]; };                                 // 18 B: w = kvalues_iq4nl[nib] * d
+struct __attribute__((packed)) block_iq4_xs { uint16_t d, scales_h; uint8_t scales_l[4]; uint8_t qs[128]; };  // 136 B: 256 weights, w = kvalues_iq4nl[nib] * d * (ls - 32), a 6-bit ls per 32 (ggml-common.h:421-427)
 struct __attribute__((packed)) block_mxfp4  { uint8_t e; uint8_t qs[16]; };                                  // 17 B: w = kvalues_mxfp4[nib] * 2^(e - 128)
 struct __attribute__((packed)) block_q2_K   { uint8_t scales[16]; uint8_t qs[64]; uint16_t d, dmin; };       // 84 B
 struct __attribute__((packed)) block_q3_K   { uint8_t hmask[32]; uint8_t qs[64]; uint8_t scales[12]; uint16_t d; };   // 110 B
-static_assert(sizeof(block_q5_0) == 22 && sizeof(block_q5_1) == 24 && sizeof(block_iq4_nl) == 18 && sizeof(block_mxfp4) == 17 && sizeof(block_q2_K) == 84 && sizeof(block_q3_K) == 110, "block sizes");
+static_assert(sizeof(block_q5_0) == 22 && sizeof(block_q5_1) == 24 && sizeof(block_iq4_nl) == 18 && sizeof(block_mxfp4) == 17 && sizeof(block_q2_K) == 84 && sizeof(block_q3_K) == 110 && sizeof(block_iq4_xs) == 136, "block sizes");
 static_assert(sizeof(block_q4_1) == 20 && sizeof(block_q8_1) == 36, "block sizes");
 static_assert(sizeof(block_q4_0) == 18 && sizeof(block_q8_0) == 34 && sizeof(block_q4_K) == 144 && sizeof(block_q8_K) == 292, "block sizes");
 
@@ -59,9 +60,9 @@ __host__ __device__ inline size_t act_row_bytes(int64_t K, int kind) { return ac
 // the activation format a weight type's dot product reads (type_traits_cpu[].vec_dot_type, ggml-cpu/ggml-cpu.c:207-390)
 // the coverage types (gemv_kq.hip: mat-mul for any number of columns in the reference's order, GET_ROWS; no fused decode forms)
 __host__ __device__ inline bool   is_kq_type(int t) {
-    return t == CLLM_TYPE_Q5_K || t == CLLM_TYPE_Q6_K || t == CLLM_TYPE_Q2_K || t == CLLM_TYPE_Q3_K || t == CLLM_TYPE_Q5_0 || t == CLLM_TYPE_Q5_1 || t == CLLM_TYPE_IQ4_NL || t == CLLM_TYPE_MXFP4;
+    return t == CLLM_TYPE_Q5_K || t == CLLM_TYPE_Q6_K || t == CLLM_TYPE_Q2_K || t == CLLM_TYPE_Q3_K || t == CLLM_TYPE_Q5_0 || t == CLLM_TYPE_Q5_1 || t == CLLM_TYPE_IQ4_NL || t == CLLM_TYPE_MXFP4 || t == CLLM_TYPE_IQ4_XS;
 }
-__host__ __device__ inline bool   is_k256_type(int t) { return t == CLLM_TYPE_Q4_K || t == CLLM_TYPE_Q5_K || t == CLLM_TYPE_Q6_K || t == CLLM_TYPE_Q2_K || t == CLLM_TYPE_Q3_K; }
+__host__ __device__ inline bool   is_k256_type(int t) { return t == CLLM_TYPE_Q4_K || t == CLLM_TYPE_Q5_K || t == CLLM_TYPE_Q6_K || t == CLLM_TYPE_Q2_K || t == CLLM_TYPE_Q3_K || t == CLLM_TYPE_IQ4_XS; }
 __host__ __device__ inline int    act_kind_of(int wtype) { return is_k256_type(wtype) ? ACT_Q8_K : (wtype == CLLM_TYPE_Q4_1 || wtype == CLLM_TYPE_Q5_1) ? ACT_Q8_1 : ACT_Q8_0; }
 __host__ __device__ inline bool   is_quant_type(int t) { return t == CLLM_TYPE_Q4_0 || t == CLLM_TYPE_Q4_1 || t == CLLM_TYPE_Q8_0 || t == CLLM_TYPE_Q4_K; }
 

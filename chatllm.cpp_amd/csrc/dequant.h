@@ -68,6 +68,15 @@ __device__ __forceinline__ float dequant_elem(int type, const char * row, int64_
             if (mx) return v * __uint_as_float(b[0] < 2 ? 0x00200000u << b[0] : (uint32_t)(b[0] - 1) << 23);
             return h2f((uint16_t)(b[0] | (b[1] << 8))) * v;
         }
+        case CLLM_TYPE_IQ4_XS: {                   // dequantize_row_iq4_xs (ggml-quants.c:2530-2551): (d * (ls - 32)) * kvalues_iq4nl[nib]
+            const block_iq4_xs * b = (const block_iq4_xs *) row + i / 256; const int e = (int)(i % 256), ib = e / 32, j = e % 32;
+            const int ls = ((b->scales_l[ib / 2] >> (4 * (ib % 2))) & 0xf) | (((b->scales_h >> (2 * ib)) & 3) << 4);
+            const float dl = h2f(b->d) * (float)(ls - 32);
+            const uint8_t qb = b->qs[16 * ib + (j & 15)];
+            const int nib = j < 16 ? (qb & 0xF) : (qb >> 4);
+            const uint64_t tab = nib < 8 ? 0xf6eaddcfbfad9881ull : 0x7159453526190d01ull;
+            return dl * (float)(int8_t)((tab >> (8 * (nib & 7))) & 0xff);
+        }
         case CLLM_TYPE_Q2_K: {                     // dequantize_row_q2_K (ggml-quants.c:784-815): (d * sc) * q - (dmin * m)
             const block_q2_K * b = (const block_q2_K *) row + i / 256; const int e = (int)(i % 256);
             const int n = e / 128, j = (e % 128) / 32, hh = (e % 32) / 16, l = e % 16;

@@ -6,6 +6,7 @@
 //   q2_K :1278-1354   acc[A] = fma(dmin, m[2A] S16[2A] + m[2A+1] S16[2A+1], acc[A]) then acc[A] = fma(d, sumi[A], acc[A]) (S16: activation sums per 16)
 //   q3_K :1470-1580   2 bits + a high-bit mask (value - 4 where the bit is clear), 6-bit scales - 32
 //   q5_0 :846-884, q5_1 :926-968    Q4_0's / Q4_1's chains with a fifth bit per weight
+//   iq4_xs :3716-3764   256-weight super-blocks of IQ4_NL codes with a 6-bit scale - 32 per 32: the K-quants' single fma per super-block and lane
 //   iq4_nl :3632-3714, mxfp4 :760-844   int8 codebooks; even blocks in one 8-lane accumulator, odd ones in a second, added before the horizontal sum, an unpaired
 //                     last block in scalar code; with >= 2 activation columns IQ4_NL (and Q5_0) take tinyBLAS_Q0_AVX (llamafile/sgemm.cpp:1346-1790): ONE chain
 //   result = hsum_float_8(acc) [+ summs]
@@ -38,6 +39,14 @@ __device__ __forceinline__ void kq_slice(const kq_args & a, const char * & W, co
 
 __device__ __forceinline__ uint32_t ld2(const char * p) { return (uint32_t) *(const uint16_t *) p | ((uint32_t) *(const uint16_t *)(p + 2) << 16); }
 
+__device__ __forceinline__ uint32_t ld1x4(const char * p) { const uint8_t * q = (const uint8_t *) p; return (uint32_t) q[0] | ((uint32_t) q[1] << 8) | ((uint32_t) q[2] << 16) | ((uint32_t) q[3] << 24); }
+// four 4-bit indices (one per byte of idx) -> four bytes of a 16-entry int8 table held as four dwords
+__device__ __forceinline__ uint32_t lut16(uint32_t idx, uint32_t t0, uint32_t t1, uint32_t t2, uint32_t t3) {
+    const uint32_t sel = idx & 0x07070707u;
+    const uint32_t lo = __builtin_amdgcn_perm(t1, t0, sel), hi = __builtin_amdgcn_perm(t3, t2, sel);
+    const uint32_t m = ((idx >> 3) & 0x01010101u) * 0xffu;
+    return (hi & m) | (lo & ~m);
+}
 template <int TYPE, int NC>
 __global__ void __launch_bounds__(256) k_gemv_kq(const kq_args a) {
     const int tid = blockIdx.x * 256 + threadIdx.x, A = tid & 7;
@@ -113,6 +122,20 @@ __global__ void __launch_bounds__(256) k_gemv_kq(const kq_args a) {
                 }
             }
             if (Q2) { mn[0] = ((uint8_t) s16[2 * A]) >> 4; mn[1] = ((uint8_t) s16[2 * A + 1]) >> 4; }
+        } else if (TYPE == CLLM_TYPE_IQ4_XS) {
+            // sub-block ib (32 weights = 16 bytes: low nibbles are elements 0..15, high nibbles 16..31): lane A takes elements 4A..4A+3 = the low (A < 4) or high nibbles of
+            // bytes 4 (A & 3) ..+3 through the IQ4_NL codebook; its scale is the 6-bit ls - 32 (scales_l nibble | two bits of scales_h)
+            const char * blk = wr + (int64_t) b * 136;
+            const uint32_t hd = *(const uint32_t *) blk, sl = *(const uint32_t *)(blk + 4);        // d | scales_h << 16, scales_l[4]
+            dw = h2f((uint16_t)(hd & 0xffff));
+            const uint32_t sh = hd >> 16;
+#pragma unroll
+            for (int ib = 0; ib < 8; ib++) {
+                const uint32_t q4 = *(const uint32_t *)(blk + 8 + 16 * ib + 4 * (A & 3));
+                w[ib] = lut16((q4 >> ((A >> 2) * 4)) & 0x0f0f0f0fu, 0xbfad9881u, 0xf6eaddcfu, 0x26190d01u, 0x71594535u);      // kvalues_iq4nl (ggml-common.h:1088-1090)
+                sc8[ib] = (int8_t)((int)(((sl >> (4 * ib)) & 0xfu) | (((sh >> (2 * ib)) & 3u) << 4)) - 32);
+                aoff[ib] = 32 * ib + 4 * A;
+            }
         } else {
             const char * blk = wr + (int64_t) b * 210;
             dw = h2f(*(const uint16_t *)(blk + 208));
@@ -170,14 +193,6 @@ __global__ void __launch_bounds__(256) k_gemv_kq(const kq_args a) {
 
 // ---- the 32-weight block formats: Q5_0 / Q5_1 / IQ4_NL / MXFP4.  Lane A owns elements 4A..4A+3 of every block: the low (A < 4) or high nibbles of quant bytes
 //      4 (A & 3) .. + 3.  CHAIN: one accumulator (Q5_0 / Q5_1 always; IQ4_NL with >= 2 columns); else even / odd blocks in two, the unpaired last block in scalar order ----
-__device__ __forceinline__ uint32_t ld1x4(const char * p) { const uint8_t * q = (const uint8_t *) p; return (uint32_t) q[0] | ((uint32_t) q[1] << 8) | ((uint32_t) q[2] << 16) | ((uint32_t) q[3] << 24); }
-// four 4-bit indices (one per byte of idx) -> four bytes of a 16-entry int8 table held as four dwords
-__device__ __forceinline__ uint32_t lut16(uint32_t idx, uint32_t t0, uint32_t t1, uint32_t t2, uint32_t t3) {
-    const uint32_t sel = idx & 0x07070707u;
-    const uint32_t lo = __builtin_amdgcn_perm(t1, t0, sel), hi = __builtin_amdgcn_perm(t3, t2, sel);
-    const uint32_t m = ((idx >> 3) & 0x01010101u) * 0xffu;
-    return (hi & m) | (lo & ~m);
-}
 template <int TYPE, int NC, bool CHAIN>
 __global__ void __launch_bounds__(256) k_gemv_b32(const kq_args a) {
     constexpr bool Q50 = TYPE == CLLM_TYPE_Q5_0, Q51 = TYPE == CLLM_TYPE_Q5_1, NL = TYPE == CLLM_TYPE_IQ4_NL, MX = TYPE == CLLM_TYPE_MXFP4;
@@ -241,7 +256,7 @@ static int kq_check(int wtype, const tview & w, int64_t K, int64_t N) {
     const bool k256 = is_k256_type(wtype);
     if (!is_kq_type(wtype) || K % (k256 ? 256 : 32) || N <= 0 || N > (1 << 28)) return CLLM_E_UNSUPPORTED;
     const uintptr_t al = (uintptr_t) w.data | (uintptr_t) w.nb[1] | (uintptr_t) w.nb[2];
-    if (wtype == CLLM_TYPE_Q5_K ? (al & 15) : wtype == CLLM_TYPE_MXFP4 ? 0 : (al & 1)) return CLLM_E_UNSUPPORTED;
+    if (wtype == CLLM_TYPE_Q5_K ? (al & 15) : wtype == CLLM_TYPE_IQ4_XS ? (al & 3) : wtype == CLLM_TYPE_MXFP4 ? 0 : (al & 1)) return CLLM_E_UNSUPPORTED;
     return CLLM_OK;
 }
 static void kq_launch(hipStream_t st, int wtype, const kq_args & a, dim3 grid, bool chain) {
@@ -256,6 +271,7 @@ static void kq_launch(hipStream_t st, int wtype, const kq_args & a, dim3 grid, b
         case CLLM_TYPE_Q6_K: GO(CLLM_TYPE_Q6_K); break;
         case CLLM_TYPE_Q2_K: GO(CLLM_TYPE_Q2_K); break;
         case CLLM_TYPE_Q3_K: GO(CLLM_TYPE_Q3_K); break;
+        case CLLM_TYPE_IQ4_XS: GO(CLLM_TYPE_IQ4_XS); break;
         case CLLM_TYPE_Q5_0: GB(CLLM_TYPE_Q5_0, true); break;
         case CLLM_TYPE_Q5_1: GB(CLLM_TYPE_Q5_1, true); break;
         case CLLM_TYPE_IQ4_NL: if (chain) GB(CLLM_TYPE_IQ4_NL, true); else GB(CLLM_TYPE_IQ4_NL, false); break;

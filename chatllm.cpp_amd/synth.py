@@ -8,7 +8,7 @@ import zlib
 
 import numpy as np
 
-from .tensor import F32, Q4_0, Q4_1, Q8_0, Q4_K, Q5_K, Q6_K, Q5_0, Q5_1, Q2_K, Q3_K, IQ4_NL, MXFP4, TYPE_SIZE, BLCK  # noqa: F401
+from .tensor import F32, Q4_0, Q4_1, Q8_0, Q4_K, Q5_K, Q6_K, Q5_0, Q5_1, Q2_K, Q3_K, IQ4_NL, MXFP4, IQ4_XS, TYPE_SIZE, BLCK  # noqa: F401
 
 CONFIGS = {
     # name: n_layer, hidden, n_head, n_kv_head, head_dim, ffn, vocab
@@ -128,6 +128,12 @@ def quant_blocks(type_, rows, K, rng, sigma):
             e = np.clip(np.rint(128.0 + np.log2(max(sigma, 1e-30) / 5.7) + rng.uniform(-0.5, 0.5, (rows, nb))), 2, 250)      # kvalues_mxfp4: rms 5.7, scale 2^(e - 128)
             out[:, :, 0] = e.astype(np.uint8)
         out[:, :, off:] = rng.integers(0, 256, (rows, nb, 16), dtype=np.uint8)
+    elif type_ == IQ4_XS:                                               # d scales_h scales_l[4] qs[128] (ggml-common.h:421-427): w = d (ls - 32) kvalues_iq4nl[nib], ls = 6 bits per 32
+        out = np.empty((rows, nb, 136), np.uint8)
+        d = rng.uniform(0.5, 1.5, (rows, nb)) * sigma / (72.0 * 18.0)   # codebook rms 72, |ls - 32| rms ~18
+        out[:, :, 0:2] = _f16_bytes(d).reshape(rows, nb, 2)
+        out[:, :, 2:8] = rng.integers(0, 256, (rows, nb, 6), dtype=np.uint8)          # every 6-bit scale pattern, both signs of ls - 32
+        out[:, :, 8:] = rng.integers(0, 256, (rows, nb, 128), dtype=np.uint8)
     elif type_ == Q2_K:                                                 # scales[16] (scale | min << 4) qs[64] d dmin: w = d sc q - dmin m, q in 0..3
         out = np.empty((rows, nb, 84), np.uint8)
         sc = rng.integers(3, 11, (rows, nb, 16), dtype=np.uint8)

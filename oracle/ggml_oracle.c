@@ -33,7 +33,7 @@ size_t orc_type_size(int type) {
         case ORC_Q4_K: return sizeof(orc_block_q4_K);  case ORC_Q8_K: return sizeof(orc_block_q8_K);
         case ORC_Q5_K: return sizeof(orc_block_q5_K);  case ORC_Q6_K: return sizeof(orc_block_q6_K);
         case ORC_Q5_0: return sizeof(orc_block_q5_0);  case ORC_Q5_1: return sizeof(orc_block_q5_1);
-        case ORC_IQ4_NL: return sizeof(orc_block_iq4_nl);  case ORC_MXFP4: return sizeof(orc_block_mxfp4);
+        case ORC_IQ4_NL: return sizeof(orc_block_iq4_nl);  case ORC_MXFP4: return sizeof(orc_block_mxfp4);  case ORC_IQ4_XS: return sizeof(orc_block_iq4_xs);
         case ORC_Q2_K: return sizeof(orc_block_q2_K);  case ORC_Q3_K: return sizeof(orc_block_q3_K);
     }
     return 0;
@@ -41,7 +41,7 @@ size_t orc_type_size(int type) {
 int orc_blck_size(int type) {
     switch (type) {
         case ORC_Q4_0: case ORC_Q8_0: case ORC_Q4_1: case ORC_Q8_1: case ORC_Q5_0: case ORC_Q5_1: case ORC_IQ4_NL: case ORC_MXFP4: return ORC_QK;
-        case ORC_Q4_K: case ORC_Q5_K: case ORC_Q6_K: case ORC_Q8_K: case ORC_Q2_K: case ORC_Q3_K: return ORC_QK_K;
+        case ORC_Q4_K: case ORC_Q5_K: case ORC_Q6_K: case ORC_Q8_K: case ORC_Q2_K: case ORC_Q3_K: case ORC_IQ4_XS: return ORC_QK_K;
         case ORC_F32: case ORC_F16: case ORC_I32: case ORC_I64: return 1;
     }
     return 0;
@@ -310,6 +310,17 @@ void orc_dequantize_row_iq4_nl(const orc_block_iq4_nl * x, float * y, int64_t k)
         for (int e = 0; e < 32; e++) y[i*32 + e] = d * (float) orc_kvalues_iq4nl[orc_nib_elem(x[i].qs, e)];
     }
 }
+void orc_dequantize_row_iq4_xs(const orc_block_iq4_xs * x, float * y, int64_t k) {
+    const int64_t nb = k / ORC_QK_K;
+    for (int64_t i = 0; i < nb; i++) {
+        const float d = orc_fp16_to_fp32(x[i].d);
+        for (int ib = 0; ib < 8; ib++) {
+            const int ls = ((x[i].scales_l[ib / 2] >> (4 * (ib % 2))) & 0xf) | (((x[i].scales_h >> (2 * ib)) & 3) << 4);
+            const float dl = d * (float)(ls - 32);
+            for (int e = 0; e < 32; e++) y[i*256 + ib*32 + e] = dl * (float) orc_kvalues_iq4nl[orc_nib_elem(x[i].qs + 16 * ib, e)];
+        }
+    }
+}
 /* Q2_K / Q3_K element (n128 = which 128, j = 2-bit plane 0..3, h = which half of the 32 bytes, l = 0..15): index n128 * 128 + j * 32 + h * 16 + l */
 void orc_dequantize_row_q2_K(const orc_block_q2_K * x, float * y, int64_t k) {
     const int64_t nb = k / ORC_QK_K;
@@ -359,6 +370,7 @@ void orc_dequantize_row(int type, const void * x, float * y, int64_t k) {
         case ORC_Q5_0: orc_dequantize_row_q5_0((const orc_block_q5_0 *) x, y, k); break;
         case ORC_Q5_1: orc_dequantize_row_q5_1((const orc_block_q5_1 *) x, y, k); break;
         case ORC_IQ4_NL: orc_dequantize_row_iq4_nl((const orc_block_iq4_nl *) x, y, k); break;
+        case ORC_IQ4_XS: orc_dequantize_row_iq4_xs((const orc_block_iq4_xs *) x, y, k); break;
         case ORC_MXFP4: orc_dequantize_row_mxfp4((const orc_block_mxfp4 *) x, y, k); break;
         case ORC_Q2_K: orc_dequantize_row_q2_K((const orc_block_q2_K *) x, y, k); break;
         case ORC_Q3_K: orc_dequantize_row_q3_K((const orc_block_q3_K *) x, y, k); break;
@@ -627,6 +639,28 @@ float orc_vec_dot_q6_K_q8_K_avx2(int64_t n, const orc_block_q6_K * x, const orc_
     return hsum8(acc);
 }
 
+
+/* ggml_vec_dot_iq4_xs_q8_K, AVX2 (arch/x86/quants.c:3716-3764): sub-block ib's 32 codebook values (elements 0..15 = low nibbles, 16..31 = high nibbles of its 16 bytes)
+ * against the activation's 32 int8: lane A sums elements 4A..4A+3 (mul_add_epi8 + madd_epi16 with the sub-block's scale ls - 32: exact integers), sumi1 / sumi2 (even /
+ * odd sub-blocks) are added as integers, then one fma per super-block and lane */
+float orc_vec_dot_iq4_xs_q8_K_avx2(int64_t n, const orc_block_iq4_xs * x, const orc_block_q8_K * y) {
+    const int64_t nb = n / ORC_QK_K;
+    float acc[8] = {0};
+    for (int64_t i = 0; i < nb; i++) {
+        const float d = orc_fp16_to_fp32(x[i].d) * y[i].d;
+        int32_t sumi[8] = {0};
+        for (int ib = 0; ib < 8; ib++) {
+            const int ls = (((x[i].scales_l[ib / 2] >> (4 * (ib % 2))) & 0xf) | (((x[i].scales_h >> (2 * ib)) & 3) << 4)) - 32;
+            for (int L = 0; L < 8; L++) {
+                int p = 0;
+                for (int e = 0; e < 4; e++) p += (int) orc_kvalues_iq4nl[orc_nib_elem(x[i].qs + 16 * ib, 4 * L + e)] * (int) y[i].qs[32 * ib + 4 * L + e];
+                sumi[L] += ls * p;
+            }
+        }
+        for (int L = 0; L < 8; L++) acc[L] = fmaf(d, (float) sumi[L], acc[L]);
+    }
+    return hsum8(acc);
+}
 
 /* arch/x86/quants.c:846-884: Q4_0's lanes and chain with 5-bit values (nib | bit << 4) - 16 */
 float orc_vec_dot_q5_0_q8_0_avx2(int64_t n, const orc_block_q5_0 * x, const orc_block_q8_0 * y) {
@@ -985,7 +1019,7 @@ static int vec_dot_type_of(int wtype) {
     switch (wtype) {             /* type_traits_cpu[], ggml-cpu/ggml-cpu.c:207-390 */
         case ORC_Q4_0: case ORC_Q8_0: case ORC_Q5_0: case ORC_IQ4_NL: case ORC_MXFP4: return ORC_Q8_0;
         case ORC_Q4_1: case ORC_Q5_1: return ORC_Q8_1;
-        case ORC_Q4_K: case ORC_Q5_K: case ORC_Q6_K: case ORC_Q2_K: case ORC_Q3_K: return ORC_Q8_K;
+        case ORC_Q4_K: case ORC_Q5_K: case ORC_Q6_K: case ORC_Q2_K: case ORC_Q3_K: case ORC_IQ4_XS: return ORC_Q8_K;
         case ORC_F16:  return ORC_F16;
         case ORC_F32:  return ORC_F32;
     }
@@ -1018,6 +1052,7 @@ static float vec_dot(int wtype, int64_t n, const void * w, const void * a) {
         case ORC_Q5_1: return orc_vec_dot_q5_1_q8_1_avx2(n, (const orc_block_q5_1 *) w, (const orc_block_q8_1 *) a);
         case ORC_IQ4_NL: return orc_vec_dot_iq4_nl_q8_0_avx2(n, (const orc_block_iq4_nl *) w, (const orc_block_q8_0 *) a, 0);
         case ORC_MXFP4: return orc_vec_dot_mxfp4_q8_0_avx2(n, (const orc_block_mxfp4 *) w, (const orc_block_q8_0 *) a);
+        case ORC_IQ4_XS: return orc_vec_dot_iq4_xs_q8_K_avx2(n, (const orc_block_iq4_xs *) w, (const orc_block_q8_K *) a);
         case ORC_Q2_K: return orc_vec_dot_q2_K_q8_K_avx2(n, (const orc_block_q2_K *) w, (const orc_block_q8_K *) a);
         case ORC_Q3_K: return orc_vec_dot_q3_K_q8_K_avx2(n, (const orc_block_q3_K *) w, (const orc_block_q8_K *) a);
         case ORC_F16: {
