@@ -249,7 +249,9 @@ def test_mul_mat_quant_gemm(gpu, t, K, N, M):
 
 
 @pytest.mark.parametrize("t", [O.Q4_K, O.Q4_0, O.Q8_0, O.Q4_1])
-@pytest.mark.parametrize("K,N,M", [(14336, 70, 40), (4128, 65, 33), (256, 5, 100), (2048, 129, 513), (32, 3, 64)])
+@pytest.mark.parametrize("K,N,M", [(14336, 70, 40), (4128, 65, 33), (256, 5, 100), (2048, 129, 513), (32, 3, 64),
+                                   # a prompt-sized product (>= 256 tokens, >= 1024 rows): Q4_0 / Q8_0 stage the activations from the once-converted fp16 copy
+                                   (512, 1056, 300), (1056, 1024, 257)])
 def test_mul_mat_quant_exact_many_columns(gpu, t, K, N, M):
     """mmx.hip at its edges: long rows (56 super-blocks), K that is not a multiple of the 256-element stage (32-block types), one-block rows,
     ragged row / token tiles, several token tiles -- every output word equals the reference's"""
