@@ -629,7 +629,9 @@ def main():
     res = {
         "metric": "decode tokens/s", "value": args.steps / dt, "unit": "tokens/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
-        "scaling": "strong", "vs_baseline": None,      # the same model on N GPUs (tensor-parallel shards): total work is fixed as N grows "dtype": "int8xint4 dot / f32 accumulate (Q8_K x Q4_K)" if wtype == 12 else "int8 dot / f32 accumulate",
+        # the same model on N GPUs (tensor-parallel shards): total work is fixed as N grows
+        "scaling": "strong", "vs_baseline": None,
+        "dtype": "int8xint4 dot / f32 accumulate (Q8_K x Q4_K)" if wtype == 12 else "int8 dot / f32 accumulate",
         "data": "synthetic",
         "config": {"workload": f"{args.model} shapes, {args.wtype.upper()} weights, single-token decode, batch 1, {args.n_prompt}-token prompt, F16 KV cache",
                    "parallelism": f"tp{world}" if world > 1 else "single GPU", "n_ctx_end": args.n_prompt + args.warmup + args.steps,

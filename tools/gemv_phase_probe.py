@@ -21,6 +21,9 @@ lib = C.CDLL(pkg.lib.SO_PATH)
 rng = np.random.default_rng(0)
 ts = pkg.tensor.Buffer(256 * 8 * 8)
 lib.cllm_debug_set_mmvq_ts.argtypes = [C.c_void_p]
+lib.cllm_debug_set_ring_ts.argtypes = [C.c_void_p]
+RING = "--ring" in sys.argv          # stamps of k_gemv_ring (gemv_ring.hip) instead of k_gemv_dec: run with CLLM_GEMV_RING=2|3
+set_ts = lib.cllm_debug_set_ring_ts if RING else lib.cllm_debug_set_mmvq_ts
 L.cllm_memset(ts.ptr, 0, 256 * 64, None)
 for name, K, N, pro, epi, resid in SHAPES:
     t = 12
@@ -34,10 +37,10 @@ for name, K, N, pro, epi, resid in SHAPES:
     r = pkg.Tensor.from_numpy(rng.standard_normal((1, N)).astype(np.float32))
     ptrs = (C.c_void_p * n_copies)(*[w.data_ptr().value for w in ws])
     us = C.c_float()
-    lib.cllm_debug_set_mmvq_ts(ts.ptr)
+    set_ts(ts.ptr)
     pkg.lib.check(L.cllm_bench_gemv_fused(None, t, ptrs, n_copies, K, N, pro, x.data_ptr(), g.data_ptr(), 1e-5, epi, y.data_ptr(),
                                           r.data_ptr() if resid else None, 16, C.byref(us)), "bench")
-    lib.cllm_debug_set_mmvq_ts(None)
+    set_ts(None)
     host = np.zeros(256 * 8, dtype=np.uint64)
     pkg.lib.check(L.cllm_memcpy_d2h(host.ctypes.data_as(C.c_void_p), ts.ptr, host.nbytes, None), "d2h")
     L.cllm_stream_sync(None)
