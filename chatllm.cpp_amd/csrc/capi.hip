@@ -138,23 +138,33 @@ void * stream_scratch(hipStream_t st, int kind, size_t need) {
     std::lock_guard<std::mutex> lock(g_scratch_m);
     scratch_entry & e = g_scratch[std::make_tuple(dev, st, kind)];
     if (need <= e.bytes) return e.p;
+    // geometric growth (at least twice the block it replaces, whole 2 MiB pages): a stream that sees prompts / contexts of slowly increasing size keeps
+    // log2(max / first) outgrown blocks whose sizes sum to less than the live one -- not one dead block per growth step
+    size_t want = need > 2 * e.bytes ? need : 2 * e.bytes;
+    want = (want + ((size_t) 2 << 20) - 1) & ~(((size_t) 2 << 20) - 1);
     void * np = nullptr;
-    if (hipMalloc(&np, need) != hipSuccess) { (void) hipGetLastError(); cllm_set_error("scratch: hipMalloc(%zu) failed", need); return nullptr; }
-    if (e.p) e.outgrown.push_back(e.p);               // a captured launch may still address it
-    e.p = np; e.bytes = need;
+    if (hipMalloc(&np, want) != hipSuccess) {
+        (void) hipGetLastError();
+        want = need;                                   // the doubled size does not fit: the exact one may
+        if (hipMalloc(&np, want) != hipSuccess) { (void) hipGetLastError(); cllm_set_error("scratch: hipMalloc(%zu) failed", need); return nullptr; }
+    }
+    if (e.p) e.outgrown.push_back(e.p);               // a captured launch may still address it: kept until the stream goes
+    e.p = np; e.bytes = want;
     return np;
 }
+// every block of `st`, whatever device is current now (the key's device is where the block lives; hipFree takes any device's pointer)
 void stream_scratch_release(hipStream_t st) {
-    int dev = 0; (void) hipGetDevice(&dev);
     std::lock_guard<std::mutex> lock(g_scratch_m);
     for (auto it = g_scratch.begin(); it != g_scratch.end(); ) {
-        if (std::get<0>(it->first) == dev && std::get<1>(it->first) == st) {
+        if (std::get<1>(it->first) == st) {
             if (it->second.p) (void) hipFree(it->second.p);
             for (void * q : it->second.outgrown) (void) hipFree(q);
             it = g_scratch.erase(it);
         } else ++it;
     }
 }
+// scratch of streams the library did not create (the null stream, a host's own): cllm_stream_destroy never sees them.  Call with the device idle.
+extern "C" int cllm_scratch_release(void * stream) { stream_scratch_release((hipStream_t) stream); return CLLM_OK; }
 extern "C" int cllm_stream_destroy(void * stream) {
     if (stream) { HIP_TRY(hipStreamSynchronize((hipStream_t) stream)); stream_scratch_release((hipStream_t) stream); HIP_TRY(hipStreamDestroy((hipStream_t) stream)); }
     return CLLM_OK;

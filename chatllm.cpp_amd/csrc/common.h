@@ -434,7 +434,7 @@ int launch_gemv_kq(hipStream_t st, int wtype, const tview & w, const void * act,
 int launch_gemv_kq_id(hipStream_t st, int wtype, const tview & as, const void * act, size_t act_stride, int64_t ne11, const tview & ids, const tview & dst);
 int launch_dense_f16(hipStream_t st, int wtype, const tview & w, const tview & x, const tview & d, const float * resid = nullptr, int64_t ldr = 0, int epi = 0);
 int launch_gemv_rows(hipStream_t st, const void * W, int64_t K, int64_t nrows, int pro, const float * px, const float * pw, float eps, int epi, float * dst, const float * bias, const float * resid);
-int launch_gemv_ring(hipStream_t st, const void * W, int64_t K, int64_t nrows, int pro, const float * px, const float * pw, float eps, int epi, float * dst, const float * bias, const float * resid);
+int kernel_error_word(unsigned ** dev_ptr);      // gemv_team32.hip: the device's mapped error word (bounded in-kernel waits report there)
 int launch_gemv_rows32(hipStream_t st, int wtype, const void * W, int64_t K, int64_t nrows, int pro, const float * px, const float * pw, float eps, int epi, float * dst, const float * bias, const float * resid);
 int gemv_team32_check();
 int launch_gemv_team32(hipStream_t st, int wtype, const void * W, int64_t K, int64_t nrows, int pro, const float * px, const float * pw, float eps, int epi, float * dst, const float * bias, const float * resid);

@@ -251,6 +251,11 @@ static int finalize(cllm_llama * m, int qlen) {
                 TRY(expect(L.wup, "wup", il, cllm_row_size(L.wup.type, H) * (size_t) F, false));
                 TRY(interleave_rows(m->st, L.wgu, L.wgate, L.wup, cllm_row_size(L.wgate.type, H)));
             } else TRY(expect(L.wgu, "wgu", il, cllm_row_size(L.wgu.type, H) * (size_t)(2*F), false));
+            // a rank's share of the FFN is cut in WHOLE quant blocks of the down projection's type (cllm_row_size truncates F / block: a misaligned share would pass
+            // the byte check below with a matching truncated buffer and run the kernels with K % block != 0), and in groups of 8 features for the SiLU epilogue
+            if (c.tp_size > 1 && (F % cllm_blck_size(L.wdown.type) || F % 8))
+                FAIL(CLLM_E_INVALID, "llama: layer %d: this rank's ffn share %lld is not a whole number of the down projection's quant blocks (%d) and of 8 features; cut with cllm_tp_split",
+                     il, (long long) F, cllm_blck_size(L.wdown.type));
             TRY(expect(L.wdown, "wdown", il, cllm_row_size(L.wdown.type, F) * (size_t) H, false));
             if (c.qkv_bias) {
                 TRY(expect(L.bq, "bq", il, (size_t) QD * 4, true)); TRY(expect(L.bk, "bk", il, (size_t) KD * 4, true)); TRY(expect(L.bv, "bv", il, (size_t) KD * 4, true));

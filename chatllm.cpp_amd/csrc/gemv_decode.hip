@@ -15,8 +15,6 @@ int launch_gemv_decode(hipStream_t st, int wtype, const void * W, int64_t K, int
     if (wtype == CLLM_TYPE_Q4_K && !padd && !g_gemv_ts) {          // the LDS-staged form (gemv_rows.hip) where the shape suits it
         const int rc = launch_gemv_rows(st, W, K, nrows, pro, px, pw, eps, epi, dst, bias, resid);
         if (rc != CLLM_E_UNSUPPORTED) return rc;
-        const int rr = launch_gemv_ring(st, W, K, nrows, pro, px, pw, eps, epi, dst, bias, resid);       // the weight stream through an LDS ring, running under the prologue (gemv_ring.hip)
-        if (rr != CLLM_E_UNSUPPORTED) return rr;
     }
     if (wtype != CLLM_TYPE_Q4_K && !padd && !g_gemv_ts) {          // Q4_0 / Q4_1 / Q8_0: the LDS-staged one-lane-group-per-row form (gemv_rows32.hip)
         int rc = launch_gemv_rows32(st, wtype, W, K, nrows, pro, px, pw, eps, epi, dst, bias, resid);

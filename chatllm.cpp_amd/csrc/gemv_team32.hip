@@ -353,12 +353,31 @@ extern "C" __attribute__((visibility("default"))) int cllm_debug_gemv_team32_err
     return h ? (int) *h : 0;
 }
 
-// after a synchronize: did a hand-off between the waves of a team time out?  (the launch winds down instead of hanging; its results are void)
+// after a synchronize: did a bounded in-kernel wait time out SINCE THE LAST CALL?  (the launch winds down instead of hanging; its results are void.)  The word is
+// cleared when it is reported -- the caller has synchronized, nothing is running that could store to it -- so one timed-out hand-off fails one check, not every
+// later one (include/chatllm_hip.h: cllm_check_kernel_errors)
 int gemv_team32_check() {
     volatile unsigned * h = g_t32_err_host[dev_slot()];
     if (!h) return CLLM_OK;                                            // never launched on this device
     const unsigned e = *h;
-    if (e) FAIL(CLLM_E_HIP, "gemv_team32: a hand-off between the waves of a workgroup timed out (code %u); set CLLM_GEMV_TEAM32=0", e);
+    if (e) {
+        *h = 0;
+        if (e >= 200) FAIL(CLLM_E_HIP, "gemv_ldr: a wait between the loader and the consumer waves of a workgroup timed out (code %u); set CLLM_GEMV_LDR=0", e);
+        FAIL(CLLM_E_HIP, "gemv_team32: a hand-off between the waves of a workgroup timed out (code %u); set CLLM_GEMV_TEAM32=0", e);
+    }
+    return CLLM_OK;
+}
+// the device's error word (shared by every kernel with bounded in-kernel waits): a page-locked host word mapped into the device
+int kernel_error_word(unsigned ** dev_ptr) {
+    unsigned * & g_t32_err = g_t32_err_dev[dev_slot()];
+    if (!g_t32_err) {
+        unsigned * h = nullptr;
+        HIP_TRY(hipHostMalloc((void **) &h, 64, hipHostMallocMapped));
+        *h = 0;
+        HIP_TRY(hipHostGetDevicePointer((void **) &g_t32_err, h, 0));
+        g_t32_err_host[dev_slot()] = h;
+    }
+    *dev_ptr = g_t32_err;
     return CLLM_OK;
 }
 
@@ -387,14 +406,8 @@ int launch_gemv_team32(hipStream_t st, int wtype, const void * W, int64_t K, int
     int grid = (nunits + nteams - 1) / nteams; if (grid > cus) grid = cus;
     const size_t lds = act_row_bytes(K, wtype == CLLM_TYPE_Q4_1 ? ACT_Q8_1 : ACT_Q8_0) + (wtype == CLLM_TYPE_Q4_0 ? (size_t) K : 0) + 32 * (size_t) T32_SLOT_BYTES;
     if (lds > 158 * 1024) return CLLM_E_UNSUPPORTED;
-    unsigned * & g_t32_err = g_t32_err_dev[dev_slot()];
-    if (!g_t32_err) {
-        unsigned * h = nullptr;
-        HIP_TRY(hipHostMalloc((void **) &h, 64, hipHostMallocMapped));
-        *h = 0;
-        HIP_TRY(hipHostGetDevicePointer((void **) &g_t32_err, h, 0));
-        g_t32_err_host[dev_slot()] = h;
-    }
+    unsigned * g_t32_err = nullptr;
+    { const int erc = kernel_error_word(&g_t32_err); if (erc) return erc; }
     const int npre = K <= 4096 ? 1 : K <= 16384 ? 4 : 8;
 #define GOT(FMT_, PRO_, NPRE_) do { \
         static uint64_t attr = 0; \

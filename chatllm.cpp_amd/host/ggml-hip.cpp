@@ -41,6 +41,7 @@ struct hip_backend_ctx {
     struct scalar_set { const void * ptr; int32_t val; };
     struct {
         bool armed = false, inflight = false;
+        bool snap_ready = false;       // the outputs' snapshot is complete although the step did not start (ahead_launch failed behind its argmax write): serve the pending read from it
         void * ev = nullptr, * table_dev = nullptr, * scratch = nullptr, * snap = nullptr; size_t snap_bytes = 0; int32_t * tok_host = nullptr;
         struct set_rec { const void * ptr; int32_t val, pad; }; set_rec * tab_host = nullptr;      // page-locked: the (pointer, absolute value) records of the step started ahead
         const void * ids_ptr = nullptr, * logits_ptr = nullptr; size_t logits_bytes = 0;
@@ -209,11 +210,12 @@ void buf_get(ggml_backend_buffer_t b, const ggml_tensor * t, void * data, size_t
     static const bool ahead_late = getenv("CLLM_HIP_AHEAD_LATE") != nullptr;       // (A/B switch: round 3's order)
     const bool is_logits_read = ac && ac->ahead.armed && !ac->ahead.inflight && (const void *) t->data == ac->ahead.logits_ptr && off == 0 && size == ac->ahead.logits_bytes;
     if (is_logits_read && !ahead_late) ahead_launch(ac);
-    if (ac && ac->ahead.inflight) {
+    if (ac && (ac->ahead.inflight || (is_logits_read && ac->ahead.snap_ready))) {
         bool served = false;
         for (const auto & o : ac->ahead.outs)      // the step running ahead overwrites the graph's outputs: their snapshots
             if (src >= o.ptr && src + size <= o.ptr + o.bytes) { src = (const char *) ac->ahead.snap + o.snap_off + (src - o.ptr); served = true; break; }
-        if (!served) ahead_quiesce(device);        // anything else: what the step running ahead leaves behind
+        if (!served && ac->ahead.inflight) ahead_quiesce(device);        // anything else: what the step running ahead leaves behind
+        ac->ahead.snap_ready = false;
     }
     buf_get_impl(b, src, t->name, data, size);
     if (is_logits_read && ahead_late && ac->ahead.armed && !ac->ahead.inflight) ahead_launch(ac);
@@ -1086,7 +1088,7 @@ struct sig_writer {
 //      it off for the next 64 graphs (a sampling host costs itself at most a few % that way).  CLLM_HIP_AHEAD=0 turns it off.
 void ahead_launch(hip_backend_ctx * c) {
     auto & A = c->ahead;
-    A.armed = false;
+    A.armed = false; A.snap_ready = false;
     cllm_set_device(c->device);
     if (!A.ev && cllm_event_create(&A.ev) != CLLM_OK) return;
     if (!A.tok_host) { void * p = nullptr; if (cllm_host_malloc(&p, 64) != CLLM_OK) return; A.tok_host = (int32_t *) p; }
@@ -1115,9 +1117,12 @@ void ahead_launch(hip_backend_ctx * c) {
     void * st = c->stream;
     if (n_rec && cllm_memcpy_h2d(A.table_dev, A.tab_host, (size_t) n_rec * 16, st) != CLLM_OK) return;      // queued on the step's stream from page-locked memory; done before the event below
     for (const auto & o : A.outs) if (cllm_memcpy_d2d((char *) A.snap + o.snap_off, o.ptr, o.bytes, st) != CLLM_OK) { cllm_stream_sync(st); return; }
-    if (cllm_op_argmax_set(st, (const float *) A.logits_ptr, (int64_t)(A.logits_bytes / 4), (int32_t *) A.ids_ptr, A.tok_host, A.table_dev, n_rec, A.scratch) != CLLM_OK) return;
-    if (cllm_event_record(A.ev, st) != CLLM_OK) { cllm_stream_sync(st); return; }
-    if (cllm_graph_launch(c->graph_exec, st) != CLLM_OK) { cllm_stream_sync(st); return; }
+    // From here on the arg-max below may already have written the token id -- into a block ggml-alloc may have made part of the logits.  If anything fails now the
+    // step does not run ahead, but the host's pending read must still see the logits as they were: the snapshot (complete once the stream is idle) serves it.
+    auto fail_behind_the_snapshot = [&]() { if (cllm_stream_sync(st) == CLLM_OK) A.snap_ready = true; };
+    if (cllm_op_argmax_set(st, (const float *) A.logits_ptr, (int64_t)(A.logits_bytes / 4), (int32_t *) A.ids_ptr, A.tok_host, A.table_dev, n_rec, A.scratch) != CLLM_OK) { fail_behind_the_snapshot(); return; }
+    if (cllm_event_record(A.ev, st) != CLLM_OK) { fail_behind_the_snapshot(); return; }
+    if (cllm_graph_launch(c->graph_exec, st) != CLLM_OK) { fail_behind_the_snapshot(); return; }
     static const bool ahead_sync = getenv("CLLM_HIP_AHEAD_SYNC") != nullptr;       // (debugging: run the step ahead to completion before returning)
     if (ahead_sync) cllm_stream_sync(st);
     cllm_event_sync(A.ev);                 // the snapshot and the scalars are in place before the host goes on (its own writes of the same scalars come later)

@@ -21,9 +21,7 @@ lib = C.CDLL(pkg.lib.SO_PATH)
 rng = np.random.default_rng(0)
 ts = pkg.tensor.Buffer(256 * 8 * 8)
 lib.cllm_debug_set_mmvq_ts.argtypes = [C.c_void_p]
-lib.cllm_debug_set_ring_ts.argtypes = [C.c_void_p]
-RING = "--ring" in sys.argv          # stamps of k_gemv_ring (gemv_ring.hip) instead of k_gemv_dec: run with CLLM_GEMV_RING=2|3
-set_ts = lib.cllm_debug_set_ring_ts if RING else lib.cllm_debug_set_mmvq_ts
+set_ts = lib.cllm_debug_set_mmvq_ts
 L.cllm_memset(ts.ptr, 0, 256 * 64, None)
 for name, K, N, pro, epi, resid in SHAPES:
     t = 12
