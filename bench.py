@@ -409,6 +409,34 @@ def dropin_through_the_boundary(mp, n_decode=144):
             "breakdown_us": per_graph[-1] if per_graph else None}
 
 
+def parity_full_depth(mp, vocab, n_decode=16, cpu_threads=32):
+    """the SAME GGMM file through the reference host twice -- its own CPU backend, then every layer on the module -- free-running greedy (each run feeds its own arg-max
+    back), the 16-token prompt + n_decode tokens; compares the ids and every logit word (src/models.cpp:1399-1424 walks ALL layers: so does this).  The logits go through
+    files in /tmp (ref_chat's own dump: float32, vocab per step)."""
+    import subprocess
+    import tempfile
+    ref = os.path.join(ROOT, "oracle", "_ref", "ref_chat")
+    out = {}
+    with tempfile.TemporaryDirectory(dir="/tmp") as td:
+        runs = {}
+        for tag, ngl, th in (("cpu", "cpu", min(cpu_threads, host_cores())), ("module", "all", 16)):
+            lp = os.path.join(td, tag + ".logits")
+            t0 = time.time()
+            r = subprocess.run([ref, mp, ngl, str(th), str(n_decode), lp] + [str(i) for i in PROMPT_IDS], capture_output=True, text=True, timeout=3000)
+            if r.returncode != 0:
+                raise RuntimeError(f"ref_chat ({tag}) failed: " + r.stderr[-400:])
+            runs[tag] = ([int(t) for t in r.stdout.split()], np.fromfile(lp, np.float32).reshape(-1, vocab))
+            out[tag + "_wall_s"] = round(time.time() - t0, 1)
+        (ids_c, lg_c), (ids_g, lg_g) = runs["cpu"], runs["module"]
+        n = min(len(lg_c), len(lg_g))
+        diff = (lg_c[:n].view(np.uint32) != lg_g[:n].view(np.uint32))
+        steps = np.nonzero(diff.any(axis=1))[0]
+        out.update({"ids_equal": ids_c == ids_g, "n_ids": len(ids_c), "logit_steps_compared": int(n), "logit_words_differing": int(diff.sum()),
+                    "first_differing_step": int(steps[0]) if len(steps) else None, "max_abs_dlogit": float(np.max(np.abs(lg_c[:n] - lg_g[:n]))),
+                    "cpu_threads": min(cpu_threads, host_cores())})
+    return out
+
+
 def prefill_cfg3(pkg, model_name, n_prompt=4096, reps=3):
     """BASELINE cfg3: Q4_0 weights, one n_prompt-token prompt through the runner (cllm_llama_forward): median wall time and the algorithmic FLOPs of SURVEY 8d, in the default
     mode (exact: the reference's accumulation order on the K = 4 / f32 matrix-core instructions, bit-identical to the CPU for every prompt length) and in the opt-in
@@ -449,6 +477,56 @@ def prefill_cfg3(pkg, model_name, n_prompt=4096, reps=3):
     return res
 
 
+def layer_split(pkg, cfg, iters=16):
+    """where a decoder layer's time goes, from the in-kernel stamps of the four mat-vec launches (s_memrealtime, 100 MHz; thread 0 of every workgroup): per launch
+    prologue (entry -> the activation row is in LDS and the barrier has opened), stream (barrier -> the workgroup's last row), boundary (launch-to-launch time minus the
+    in-kernel span: dispatch, ramp, drain).  Medians over the workgroups of the last of `iters` launches; the stamps cost ~0.3 us per launch."""
+    L = pkg.lib.get()
+    lib = C.CDLL(pkg.lib.SO_PATH)
+    lib.cllm_debug_set_mmvq_ts.argtypes = [C.c_void_p]
+    H, hd, F = cfg["hidden"], cfg["head_dim"], cfg["ffn"]
+    QD, KD = cfg["n_head"] * hd, cfg["n_kv_head"] * hd
+    rng = np.random.default_rng(0)
+    ts = pkg.tensor.Buffer(256 * 8 * 8)
+    out = {}
+    tot = {"prologue_us": 0.0, "stream_us": 0.0, "boundary_us": 0.0}
+    for name, K, N, pro, epi, resid in (("qkv", H, QD + 2 * KD, 1, 0, False), ("o", QD, H, 2, 0, True), ("gate_up", H, 2 * F, 1, 1, False), ("down", F, H, 2, 0, True)):
+        nbytes = N * pkg.tensor.row_size(12, K)
+        n_copies = max(2, int(1.2 * 2**30 // nbytes) + 1)
+        w0 = pkg.synth.make_tensor_fast("ls." + name, 12, N, K)
+        ws = [pkg.Tensor.from_numpy(w0, 12, [K, N]) for _ in range(n_copies)]
+        x = pkg.Tensor.from_numpy(rng.standard_normal((1, K)).astype(np.float32))
+        g = pkg.Tensor.from_numpy((1 + 0.1 * rng.standard_normal((1, K))).astype(np.float32))
+        y = pkg.Tensor(pkg.F32, [N, 1])
+        r = pkg.Tensor.from_numpy(rng.standard_normal((1, N)).astype(np.float32))
+        ptrs = (C.c_void_p * n_copies)(*[w.data_ptr().value for w in ws])
+        us = C.c_float()
+        L.cllm_memset(ts.ptr, 0, 256 * 64, None)
+        lib.cllm_debug_set_mmvq_ts(ts.ptr)
+        try:
+            pkg.lib.check(L.cllm_bench_gemv_fused(None, 12, ptrs, n_copies, K, N, pro, x.data_ptr(), g.data_ptr(), cfg["rms_eps"], epi, y.data_ptr(),
+                                                  r.data_ptr() if resid else None, iters, C.byref(us)), "bench_gemv_fused " + name)
+        finally:
+            lib.cllm_debug_set_mmvq_ts(None)
+        host = np.zeros(256 * 8, dtype=np.uint64)
+        pkg.lib.check(L.cllm_memcpy_d2h(host.ctypes.data_as(C.c_void_p), ts.ptr, host.nbytes, None), "d2h")
+        L.cllm_stream_sync(None)
+        st = host.reshape(256, 8)[:, :6].astype(np.int64)
+        st = st[st[:, 5] > 0]
+        t0 = st[:, 0].min()
+        pro_us = float(np.median(st[:, 3] - t0)) / 100.0
+        end_us = float((st[:, 5] - t0).max()) / 100.0
+        row = {"launch_us": round(us.value, 2), "prologue_us": round(pro_us, 2), "stream_us": round(end_us - pro_us, 2), "boundary_us": round(us.value - end_us, 2),
+               "stream_gbs": round(nbytes / (end_us - pro_us) / 1e3, 1)}
+        out[name] = row
+        for k in tot:
+            tot[k] += row[k]
+        del ws
+    out["per_layer_mat_vecs"] = {k: round(v, 2) for k, v in tot.items()}
+    out["note"] = "attention (one launch, latency-bound) is in `kernels`; stream_gbs counts the launch's whole matrix against the time after the barrier (the first step was requested at entry)"
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -463,6 +541,7 @@ def main():
     ap.add_argument("--no-kernels", action="store_true", help="skip the per-launch kernel table and the measured ceilings")
     ap.add_argument("--dropin-cfg5", action="store_true", help="also run BASELINE cfg5 (Mixtral-8x7B shapes, Q4_K, 26 GB GGMM file in /tmp) through the unmodified reference host on the module")
     ap.add_argument("--dropin-cfg4", action="store_true", help="also run BASELINE cfg4 on ONE GPU (Qwen2-72B shapes, 50 GB GGMM file in /tmp) through the unmodified reference host on the module")
+    ap.add_argument("--no-full-depth-parity", action="store_true", help="with --dropin-cfg4 / --dropin-cfg5: skip the CPU-host-vs-module comparison of ids and logit words over ALL layers")
     ap.add_argument("--dry-run-shards", action="store_true", help="shape math of the N-rank tensor-parallel shards only (no GPU, no weights): one JSON object, then exit")
     ap.add_argument("--no-graph", action="store_true", help="launch the fused decode kernels eagerly (for rocprofv3 kernel traces)")
     args = ap.parse_args()
@@ -495,7 +574,8 @@ def main():
     pkg.lib.check(pkg.lib.get().cllm_set_device(local), "set_device")
 
     wtype = WTYPES[args.wtype]
-    max_len = (args.n_prompt + args.warmup + args.steps + 8 + 63) // 64 * 64
+    cfg2_steps = 512                       # BASELINE cfg2: 16-token prompt, 512 decoded tokens -- measured next to the requested --steps when they differ
+    max_len = (args.n_prompt + max(args.warmup + args.steps, 16 + cfg2_steps) + 8 + 63) // 64 * 64
     cfg = pkg.synth.config(args.model, max_len=max_len)
     m = build_model(pkg, cfg, wtype, rank, world)
     if args.no_graph:
@@ -644,13 +724,35 @@ def main():
         res["algorithmic_bytes_per_token"] = bytes_tok
         res["greedy_tail"] = [int(t) for t in out[-4:]]
         if world == 1:
+            if args.steps != cfg2_steps and args.model == "llama3-8b":
+                # the same metric at BASELINE cfg2's own length (16-token prompt, 512 decoded tokens: n_ctx 32 -> 544), whatever --steps the caller timed
+                try:
+                    lg2 = m.forward(prompt, n_past=0)
+                    t2 = int(m.decode_greedy(int(np.argmax(lg2)), 16)[-1])
+                    pkg.ops.sync()
+                    t0 = time.perf_counter()
+                    m.decode_greedy(t2, cfg2_steps)
+                    pkg.ops.sync()
+                    dt2 = time.perf_counter() - t0
+                    b2 = pkg.synth.weight_bytes_per_token(cfg, wtype) + pkg.synth.kv_bytes_per_token(cfg, args.n_prompt + 16 + cfg2_steps // 2)
+                    res["decode_512"] = {"value": cfg2_steps / dt2, "unit": "tokens/s", "steps": cfg2_steps, "warmup": 16, "ms_per_step": dt2 / cfg2_steps * 1e3,
+                                         "model_frac": b2 * (cfg2_steps / dt2) / (HBM_PEAK_GBS * 1e9)}
+                except Exception as e:      # noqa: BLE001
+                    res["decode_512"] = {"error": str(e)}
             try:
                 k = measure_dominant_kernel(pkg, cfg, wtype)
                 traffic, tsrc = (None, "skipped (--no-pmc)") if args.no_pmc or wtype != 12 else pmc_traffic_live("k_gemv_dec")
                 res["roofline"] = {"bound": "hbm", "achieved": k["gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": k["gbs"] / HBM_PEAK_GBS,
-                                   "traffic": traffic, "traffic_source": tsrc, "kernel": k["kernel"], "avg_us": k["avg_us"], "bytes_per_launch": k["bytes_per_launch"]}
+                                   "traffic": traffic, "traffic_source": tsrc, "kernel": k["kernel"], "avg_us": k["avg_us"], "bytes_per_launch": k["bytes_per_launch"],
+                                   # the whole decode step against the same peak: algorithmic bytes per token x tokens/s / 8 TB/s (what the north star's 0.70 is about)
+                                   "model_frac": res["model_hbm_frac"]}
             except Exception as e:      # the throughput number stands on its own
                 res["roofline"] = {"error": str(e)}
+            if not args.no_kernels and wtype == 12:
+                try:
+                    res["layer_split"] = layer_split(pkg, cfg)
+                except Exception as e:      # noqa: BLE001
+                    res["layer_split"] = {"error": str(e)}
             if not args.no_kernels:
                 try:
                     res["kernels"] = kernel_table(pkg, cfg, wtype, args.n_prompt + args.warmup + args.steps // 2)
@@ -694,6 +796,11 @@ def main():
                                 raise RuntimeError("make_ggmm failed: " + rc.stderr[-300:])
                         res[key] = dropin_through_the_boundary(mp5, n_decode=ndec)
                         res[key]["model"] = cname + " shapes, Q4_K (down_proj per the reference's fallback rule), 16-token prompt"
+                        if not args.no_full_depth_parity:
+                            try:                      # ALL layers of the config, CPU host vs module, ids and logit words
+                                res[key]["parity"] = parity_full_depth(mp5, pkg.synth.config(cname, max_len=512)["vocab"], n_decode=16)
+                            except Exception as e:    # noqa: BLE001
+                                res[key]["parity"] = {"error": str(e)}
                     except Exception as e:      # noqa: BLE001
                         res[key] = {"error": str(e)}
                 if not args.no_prefill and args.model == "llama3-8b":

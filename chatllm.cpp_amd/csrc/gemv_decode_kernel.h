@@ -90,7 +90,31 @@ __global__ void __launch_bounds__(1024) k_gemv_dec(const float * __restrict__ px
     const float * gp = (PRO == 1 || PRO == 4) ? pw : PRO == 3 ? px + 4 : px;
     constexpr int vmul = PRO == 3 ? 2 : 1;
     const int e0 = tid * 4;
-    f32x4 vv[NPRE], gg[(PRO != 2 || EPI == 3) ? NPRE : 1];      // (EPI 3: gg = the second slot's activation)
+    // Q16 (the plain quantize_row_q8_K prologue in front of Q4_K weights, rows of more than 4096 values: down_proj): SIXTEEN values per lane, one 256-block per 16-lane
+    // row, four blocks per wave (quant16_q8_K, quant_dev.h).  The prologue is redone by all 256 workgroups and is VALU-THROUGHPUT-bound inside each for long rows: down's
+    // 56 blocks cost every CU 56 x ~90 wave-instructions with four values per lane, 14 x ~110 here (its prologue barrier opens at 2.5 instead of 3.4 us, the launch takes
+    // 9.8 instead of 10.6 us: profiles/r05_prologue_quant16.txt).  NOT for 4096-value rows: there four waves would do serially what sixteen do side by side (o +0.2 us;
+    // the RMS_NORM prologue of qkv / gate-up in this form, GEMV_Q16 = 2: +1.2 us each -- measured, same file).
+#ifndef GEMV_Q16
+#define GEMV_Q16 1          // (A/B builds: 0 = four values per lane everywhere, 1 = the plain-quantize prologue of long rows, 2 = + every RMS_NORM / plain prologue)
+#endif
+    constexpr bool Q16 = FMT == CLLM_TYPE_Q4_K && ((GEMV_Q16 >= 1 && PRO == 2 && EPI != 3 && (NPRE >= 4 || GEMV_Q16 >= 2)) || (GEMV_Q16 >= 2 && PRO == 1));
+    constexpr int NQ = NPRE == 8 ? 2 : 1;                        // passes of 64 blocks
+    const int qrow = lane >> 4, qp = lane & 15, qwave = tid >> 6;
+    f32x4 vv[Q16 ? 1 : NPRE], gg[(PRO != 2 || EPI == 3) ? NPRE : 1];      // (EPI 3: gg = the second slot's activation)
+    f32x4 w16[Q16 ? NQ : 1][4], g16[(Q16 && PRO == 1) ? NQ : 1][4];
+    if constexpr (Q16) {
+#pragma unroll
+        for (int q = 0; q < NQ; q++) {
+            const int blk = (qwave + 16 * q) * 4 + qrow, o = (blk < nblk ? blk : 0) * 256 + 16 * qp;
+#pragma unroll
+            for (int i = 0; i < 4; i++) w16[q][i] = *(const f32x4 *)(px + o + 4 * i);
+            if constexpr (PRO == 1) {
+#pragma unroll
+                for (int i = 0; i < 4; i++) g16[q][i] = *(const f32x4 *)(pw + o + 4 * i);
+            }
+        }
+    } else {
 #pragma unroll
     for (int u = 0; u < NPRE; u++) {
         const int e = e0 + u * 4096, ec = e < K ? e : 0;
@@ -98,11 +122,18 @@ __global__ void __launch_bounds__(1024) k_gemv_dec(const float * __restrict__ px
         if (PRO != 2) gg[u] = *(const f32x4 *)(gp + ec * vmul);
         if (EPI == 3) gg[u] = *(const f32x4 *)(px + px_slot_stride + ec);
     }
+    }
     // tensor parallel (PRO 1, NPRE 1): the all-reduced partial of the previous mat-vec is added to the residual stream here
     // (x + padd feeds the norm; workgroup 0 stores it to xout, a different buffer than px) instead of in a launch of its own
-    f32x4 pa = {0, 0, 0, 0};
+    f32x4 pa = {0, 0, 0, 0}, pa16[(Q16 && PRO == 1 && NPRE == 1) ? 4 : 1];
     const bool add = PRO == 1 && NPRE == 1 && padd != nullptr;
-    if (add) pa = *(const f32x4 *)(padd + (e0 < K ? e0 : 0));
+    if constexpr (Q16 && PRO == 1 && NPRE == 1) {
+        if (add) {
+            const int blk = qwave * 4 + qrow, o = (blk < nblk ? blk : 0) * 256 + 16 * qp;
+#pragma unroll
+            for (int i = 0; i < 4; i++) pa16[i] = *(const f32x4 *)(padd + o + 4 * i);
+        }
+    } else if (add) pa = *(const f32x4 *)(padd + (e0 < K ? e0 : 0));
     TS(0);
 
     // ---- (2) two steps of weight prefetch.  Units are dealt in rounds of nwaves: in a full round wave (b, w) takes unit
@@ -142,6 +173,46 @@ __global__ void __launch_bounds__(1024) k_gemv_dec(const float * __restrict__ px
 
     // ---- (3) the activation row: [RMS_NORM * weight | SiLU * up |] quantize -> LDS (act layout of common.h) ----
     float scale = 1.0f;
+    if constexpr (Q16 && PRO == 1) {
+        __shared__ double part[16];
+        // the sum of squares as a tree over the values in registers (per lane in increasing index, DPP wave reduction, the wave partials pairwise): rms_scale's interval
+        // test proves per row that the order cannot matter, else wave 0 redoes the sum in the reference's serial order (common.h)
+        double sum = 0.0;
+#pragma unroll
+        for (int q = 0; q < NQ; q++) {
+            const int blk = (qwave + 16 * q) * 4 + qrow;
+            const bool valid = blk < nblk;
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                f32x4 v = w16[q][i];
+                if constexpr (NPRE == 1) {
+                    if (add) {
+                        v.x = v.x + pa16[i].x; v.y = v.y + pa16[i].y; v.z = v.z + pa16[i].z; v.w = v.w + pa16[i].w;
+                        if (blockIdx.x == 0 && valid) *(f32x4 *)(xout + blk * 256 + 16 * qp + 4 * i) = v;
+                        w16[q][i] = v;
+                    }
+                }
+                if (valid) { sum += (double)(v.x * v.x); sum += (double)(v.y * v.y); sum += (double)(v.z * v.z); sum += (double)(v.w * v.w); }
+            }
+        }
+        sum = wave_sum_d(sum);
+        if (lane == 0) part[qwave] = sum;
+        __syncthreads();
+        const double tot = (((part[0] + part[1]) + (part[2] + part[3])) + ((part[4] + part[5]) + (part[6] + part[7]))) +
+                           (((part[8] + part[9]) + (part[10] + part[11])) + ((part[12] + part[13]) + (part[14] + part[15])));
+        scale = rms_scale(tot, K, eps, px, add ? padd : nullptr, part);
+#pragma unroll
+        for (int q = 0; q < NQ; q++) {
+            const int blk = (qwave + 16 * q) * 4 + qrow;
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                f32x4 v = w16[q][i]; const f32x4 g = g16[q][i];
+                v.x = (v.x * scale) * g.x; v.y = (v.y * scale) * g.y; v.z = (v.z * scale) * g.z; v.w = (v.w * scale) * g.w;
+                if (EPI == 2) { if (blk < nblk) *(f32x4 *)(xout + blk * 256 + 16 * qp + 4 * i) = v; }
+                w16[q][i] = v;
+            }
+        }
+    } else {
     if (add) {
         vv[0].x = vv[0].x + pa.x; vv[0].y = vv[0].y + pa.y; vv[0].z = vv[0].z + pa.z; vv[0].w = vv[0].w + pa.w;
         if (blockIdx.x == 0 && e0 < K) *(f32x4 *)(xout + e0) = vv[0];
@@ -151,7 +222,23 @@ __global__ void __launch_bounds__(1024) k_gemv_dec(const float * __restrict__ px
         const double sum = NPRE == 1 ? rms_block_sumsq_1024_one(vv[0], e0 < K, part) : rms_block_sumsq_1024(px, K, vv[0], part);
         scale = rms_scale(sum, K, eps, px, add ? padd : nullptr, part);
     }
+    }
     const int nv = K & ~7;                                          // ggml_vec_silu_f32: polynomial body below nv, libm tail
+    if constexpr (Q16) {
+#pragma unroll
+        for (int q = 0; q < NQ; q++) {
+            const int blk = (qwave + 16 * q) * 4 + qrow;
+            if ((qwave + 16 * q) * 4 < nblk) {                      // (wave-uniform: the tie path of quant16_q8_K holds a ballot)
+                float d; int ssum;
+                const u32x4 qv = quant16_q8_K(w16[q], qp, &d, &ssum);
+                if (blk < nblk) {
+                    *(u32x4 *)(lds + blk * 256 + 16 * qp) = qv;
+                    if ((qp & 1) == 0) ((int32_t *)(lds + act_off_s(K, 256)))[blk * 8 + (qp >> 1)] = ssum;
+                    if (qp == 0) ((float *)(lds + act_off_d(K)))[blk] = d;
+                }
+            }
+        }
+    } else {
 #pragma unroll
     for (int u = 0; u < NPRE; u++) {                                // K % KIND == 0: whole quantization lane groups stay together
         const int e = e0 + u * 4096;
@@ -171,6 +258,7 @@ __global__ void __launch_bounds__(1024) k_gemv_dec(const float * __restrict__ px
             quant4_store<KIND, IS_Q41>(lds, K, e, lane, v);
             if (EPI == 3) quant4_store<KIND, IS_Q41>(lds + act_row_bytes(K, KIND), K, e, lane, gg[u]);
         }
+    }
     }
     TS(2);
     __syncthreads();

@@ -57,6 +57,71 @@ __device__ __forceinline__ uint32_t quant4_q8_K(f32x4 v, int lane, float * d_out
     return pack4(q0, q1, q2, q3);
 }
 
+// ---- quantize_row_q8_K with SIXTEEN values per lane: a 16-lane DPP row holds one 256-block (lane p: elements 16 p .. 16 p + 15), a wave four blocks.
+// Same bytes as quant4_q8_K (= quantize_row_q8_K_ref, ggml-quants.c:2555-2592) at ~40 % of its instructions per element -- the per-block work (reductions,
+// the two IEEE divisions, the stores) is paid once per 16 values of a lane instead of once per 4, every reduction stays inside a DPP row (no readlane / ballot),
+// and the per-element work shrinks to two roundings: t = iscale * x, u = t + 1.5 * 2^23 -- nearest_int()'s own addition -- whose LOW BYTE is the two's-complement
+// quant (|t| <= 127 (1 + 2^-23) < 127.5: the reference's MIN(127, .) can never bind for a finite, non-zero maximum).
+//   * the maximum: "the first element of largest magnitude" matters only through its SIGN; max = the row's largest value unless -min is larger; only when both
+//     +amax and -amax occur (mx == -mn) is the first occurrence looked for (wave-uniform branch, rare).
+//   * sub-block sums: v_dot4 of the packed quants with (1, 1, 1, 1), the lane pair's two halves added through DPP.
+// d_out: valid on every lane of the row; s_out: the 32-element sub-block sum, valid on both lanes of the pair (p, p ^ 1).
+__device__ __forceinline__ float row16_max(float v) { v = fmaxf(v, dpp_f<DPP_QUAD_XOR1>(v)); v = fmaxf(v, dpp_f<DPP_QUAD_XOR2>(v)); v = fmaxf(v, dpp_f<DPP_HALF_MIRROR>(v)); return fmaxf(v, dpp_f<DPP_ROW_MIRROR>(v)); }
+__device__ __forceinline__ float row16_min(float v) { v = fminf(v, dpp_f<DPP_QUAD_XOR1>(v)); v = fminf(v, dpp_f<DPP_QUAD_XOR2>(v)); v = fminf(v, dpp_f<DPP_HALF_MIRROR>(v)); return fminf(v, dpp_f<DPP_ROW_MIRROR>(v)); }
+__device__ __forceinline__ int   row16_min_i(int v) { v = min(v, dpp_i<DPP_QUAD_XOR1>(v)); v = min(v, dpp_i<DPP_QUAD_XOR2>(v)); v = min(v, dpp_i<DPP_HALF_MIRROR>(v)); return min(v, dpp_i<DPP_ROW_MIRROR>(v)); }
+__device__ __forceinline__ int   row16_or_i(int v)  { v |= dpp_i<DPP_QUAD_XOR1>(v); v |= dpp_i<DPP_QUAD_XOR2>(v); v |= dpp_i<DPP_HALF_MIRROR>(v); return v | dpp_i<DPP_ROW_MIRROR>(v); }
+__device__ __forceinline__ uint32_t q16_byte4(float iscale, f32x4 x) {
+    const uint32_t b0 = __float_as_uint(iscale * x.x + 12582912.f), b1 = __float_as_uint(iscale * x.y + 12582912.f);
+    const uint32_t b2 = __float_as_uint(iscale * x.z + 12582912.f), b3 = __float_as_uint(iscale * x.w + 12582912.f);
+    const uint32_t lo = __builtin_amdgcn_perm(b1, b0, 0x0c0c0400u), hi = __builtin_amdgcn_perm(b3, b2, 0x0c0c0400u);      // (b0, b1, 0, 0), (b2, b3, 0, 0)
+    return __builtin_amdgcn_perm(hi, lo, 0x05040100u);
+}
+__device__ __forceinline__ u32x4 quant16_q8_K(const f32x4 (&v)[4], int p, float * d_out, int * s_out) {
+    float mx = fmaxf(fmaxf(v[0].x, v[0].y), fmaxf(v[0].z, v[0].w)), mn = fminf(fminf(v[0].x, v[0].y), fminf(v[0].z, v[0].w));
+#pragma unroll
+    for (int i = 1; i < 4; i++) {
+        mx = fmaxf(mx, fmaxf(fmaxf(v[i].x, v[i].y), fmaxf(v[i].z, v[i].w)));
+        mn = fminf(mn, fminf(fminf(v[i].x, v[i].y), fminf(v[i].z, v[i].w)));
+    }
+    mx = row16_max(mx); mn = row16_min(mn);
+    const float amax = fmaxf(mx, -mn);
+    float maxv = mx >= -mn ? mx : mn;
+    const bool tie = mx == -mn && amax != 0.0f;
+    if (__ballot(tie) != 0ull) {                // +amax and -amax both occur in some row of the wave: the sign of the FIRST one (quants.c:2562-2566); every lane takes part (DPP)
+        int first = 256; float val = 0.0f;
+#pragma unroll
+        for (int i = 3; i >= 0; i--) {
+            if (fabsf(v[i].w) == amax) { first = 16 * p + 4 * i + 3; val = v[i].w; }
+            if (fabsf(v[i].z) == amax) { first = 16 * p + 4 * i + 2; val = v[i].z; }
+            if (fabsf(v[i].y) == amax) { first = 16 * p + 4 * i + 1; val = v[i].y; }
+            if (fabsf(v[i].x) == amax) { first = 16 * p + 4 * i + 0; val = v[i].x; }
+        }
+        const int rowfirst = row16_min_i(first);
+        const float fv = __int_as_float(row16_or_i(first == rowfirst ? __float_as_int(val) : 0));      // exactly one lane of the row owns index rowfirst
+        if (tie) maxv = fv;
+    }
+    u32x4 q = {0u, 0u, 0u, 0u};
+    float d = 0.0f;
+    if (amax != 0.0f) {
+        const float iscale = -127.f / maxv;
+        q.x = q16_byte4(iscale, v[0]); q.y = q16_byte4(iscale, v[1]); q.z = q16_byte4(iscale, v[2]); q.w = q16_byte4(iscale, v[3]);
+        d = 1 / iscale;
+    }
+    int s = dot4(q.x, 0x01010101u, 0);
+    s = dot4(q.y, 0x01010101u, s); s = dot4(q.z, 0x01010101u, s); s = dot4(q.w, 0x01010101u, s);
+    *s_out = s + dpp_i<DPP_QUAD_XOR1>(s);
+    *d_out = d;
+    return q;
+}
+// the 16-lane row's block into an act row (Q8_K kind): 16 quant bytes per lane, the pair's sub-block sum, the block scale
+__device__ __forceinline__ void quant16_store(char * act_row, int64_t K, int blk, int p, const f32x4 (&v)[4]) {
+    float d; int s;
+    const u32x4 q = quant16_q8_K(v, p, &d, &s);
+    *(u32x4 *)(act_row + blk * 256 + 16 * p) = q;
+    if ((p & 1) == 0) ((int32_t *)(act_row + act_off_s(K, 256)))[blk * 8 + (p >> 1)] = s;
+    if (p == 0) ((float *)(act_row + act_off_d(K)))[blk] = d;
+}
+
 // store one lane's quad into an act row (layout in common.h); e0 = element index of the lane's first value
 template <int KIND>    // 32: Q8_0 kind, 256: Q8_K kind
 __device__ __forceinline__ void act_store(char * act_row, int64_t K, int64_t e0, int lane, uint32_t packed, float d, int s) {

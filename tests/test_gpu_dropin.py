@@ -272,6 +272,29 @@ def test_baseline_cfg4_qwen2_72b_shapes_q4_k_free_running(gpu, tmp_path):
     _real_shape_case(gpu, tmp_path, "qwen2", "qwen2-72b", 12, [(13 * i + 7) % 150000 for i in range(16)], 32, dict(max_len=512, n_layer=2))
 
 
+_FULL = pytest.mark.skipif(not os.environ.get("CLLM_FULL_DEPTH"), reason="CLLM_FULL_DEPTH=1 runs BASELINE cfg4 / cfg5 at FULL depth (26 / 50 GB GGMM files in /tmp, minutes of "
+                                                                    "CPU time for the reference's own run); their last record: profiles/r05_full_depth_parity_cfg4_cfg5.txt")
+
+
+@_BIG
+@_FULL
+@pytest.mark.parametrize("arch,cname", [("mixtral", "mixtral-8x7b"), ("qwen2", "qwen2-72b")])
+def test_baseline_cfg4_cfg5_full_depth_free_running(gpu, arch, cname):
+    """BASELINE cfg5 (Mixtral-8x7B shapes: 32 layers, 8 experts, top 2) and cfg4 (Qwen2-72B shapes: 80 layers, Q8_0 down_proj, biases, NEOX RoPE) at FULL depth,
+    Q4_K: the reference host on its CPU backend vs every layer on the module, free-running greedy over the 16-token prompt + 16 tokens -- equal ids, zero differing
+    logit words (src/models.cpp:1399-1424 walks all layers; the block-level cases above cover 4 and 2 of them)"""
+    sys.path.insert(0, ROOT)
+    import bench
+    mp = f"/tmp/{cname}-q4_k.bin"
+    if not os.path.exists(mp):
+        rc = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "make_ggmm.py"), "--arch", arch, "--config", cname, "--wtype", "q4_k", "--max-len", "512", "--fast", "--out", mp],
+                            capture_output=True, text=True)
+        assert rc.returncode == 0, rc.stderr[-500:]
+    p = bench.parity_full_depth(mp, gpu.synth.config(cname, max_len=512)["vocab"], n_decode=16)
+    print(f"{cname} full depth: {p}")
+    assert p["ids_equal"] and p["logit_words_differing"] == 0, p
+
+
 def _host_run(tmp_path, mp, ngl, n_dec, prompt, vocab, teacher=None, threads=4, **extra):
     lp = str(tmp_path / f"l_{ngl}_{len(extra)}.bin")
     env = dict(os.environ, CLLM_HIP_STATS="1", **extra)

@@ -828,7 +828,8 @@ def test_rope_kv_attn_decode_rejects_what_it_cannot_do(gpu):
 # ---- fused single-token patterns (cllm_op_mul_mat_vec_fused) == the node sequence they replace, to the bit ----------------------
 @pytest.mark.parametrize("t,K,N,pro", [(O.Q4_K, 4096, 512, 1), (O.Q4_K, 8192, 256, 1), (O.Q4_K, 14336, 256, 4), (O.Q4_K, 29440, 128, 4),
                                        (O.Q8_0, 29568, 128, 4), (O.Q4_0, 4096, 384, 1), (O.Q8_0, 2048, 100, 2), (O.Q4_K, 256, 33, 4),
-                                       (O.Q4_1, 4096, 200, 1), (O.Q4_1, 14336, 64, 4), (O.Q4_1, 1024, 33, 2)])
+                                       (O.Q4_1, 4096, 200, 1), (O.Q4_1, 14336, 64, 4), (O.Q4_1, 1024, 33, 2),
+                                       (O.Q4_K, 4096, 512, 2), (O.Q4_K, 14336, 256, 2), (O.Q4_K, 20480, 64, 2), (O.Q4_K, 256, 33, 2), (O.Q4_K, 1280, 40, 2)])
 def test_mul_mat_vec_fused_equals_the_node_sequence(gpu, t, K, N, pro):
     ops, T = gpu.ops, gpu.Tensor
     w = T.from_numpy(rand_blocks(t, N, K, rng), t, [K, N])
@@ -847,6 +848,42 @@ def test_mul_mat_vec_fused_equals_the_node_sequence(gpu, t, K, N, pro):
     gpu.lib.check(gpu.lib.get().cllm_op_mul_mat_vec_fused(None, C.byref(cw), pro, x.data_ptr(), g.data_ptr() if pro != 2 else None, 1e-5, 0,
                                                            r.data_ptr(), out.data_ptr()), "fused")
     assert np.array_equal(out.numpy(), want)
+
+
+@pytest.mark.parametrize("K", [1280, 14336, 17408])
+def test_fused_plain_quantize_prologue_on_ties_and_zero_blocks(gpu, K):
+    """the 16-values-per-lane quantize_row_q8_K of the decode mat-vec's plain-quantize prologue (quant16_q8_K): super-blocks whose largest magnitude occurs with BOTH
+    signs (the reference keeps the sign of the FIRST occurrence, ggml-quants.c:2562-2566) -- in different lanes, inside one lane, negative first, positive first --
+    an all-zero super-block, a super-block of one value; against quantize (oracle order) + mat-vec, to the bit"""
+    ops, T = gpu.ops, gpu.Tensor
+    t, N = O.Q4_K, 96
+    w = T.from_numpy(rand_blocks(t, N, K, rng), t, [K, N])
+    x = rng.standard_normal(K).astype(np.float32)
+    m = np.float32(7.25)
+    x[3], x[200] = -m, m                      # block 0: negative first, other lane
+    x[256 + 5], x[256 + 130] = m, -m          # block 1: positive first
+    x[512:768] = 0.0                          # block 2: all zero
+    x[768 + 34], x[768 + 41] = -m, m          # block 3: both inside one lane's 16 values, negative first
+    x[1024 + 41], x[1024 + 34] = -m, m        # block 4: inside one lane, positive first
+    nb = K // 256
+    x[256 * (nb - 1): 256 * nb] = np.float32(-0.375)      # last block: one value everywhere (every element is "the" maximum; the first one counts)
+    if nb > 8:
+        x[256 * 7: 256 * 8] = np.float32(0.0); x[256 * 7 + 255] = np.float32(-3.0)        # a single non-zero element at the block's end
+    xt = T.from_numpy(x.reshape(1, K))
+    r = T.from_numpy(rng.standard_normal((1, N)).astype(np.float32))
+    want = ops.add(ops.mul_mat(w, xt), r).numpy()
+    out = T(gpu.F32, [N, 1])
+    cw = w.c()
+    gpu.lib.check(gpu.lib.get().cllm_op_mul_mat_vec_fused(None, C.byref(cw), 2, xt.data_ptr(), None, 1e-5, 0, r.data_ptr(), out.data_ptr()), "fused")
+    assert np.array_equal(out.numpy(), want)
+    # and against the oracle's quantize_row_q8_K + vec_dot (AVX2 order) directly
+    wb = rand_blocks(t, N, K, np.random.default_rng(77))
+    w2 = T.from_numpy(wb, t, [K, N])
+    ref = np.zeros(N, np.float32)
+    O.mul_mat(O.tensor(wb, t, [K, N]), O.tensor(x, O.F32, [K, 1]), O.tensor(ref, O.F32, [N, 1]))
+    cw2 = w2.c()
+    gpu.lib.check(gpu.lib.get().cllm_op_mul_mat_vec_fused(None, C.byref(cw2), 2, xt.data_ptr(), None, 1e-5, 0, None, out.data_ptr()), "fused")
+    assert np.array_equal(out.numpy().reshape(-1).view(np.uint32), ref.view(np.uint32))
 
 
 @pytest.mark.parametrize("t,K,F", [(O.Q4_K, 4096, 14336), (O.Q4_0, 4096, 512), (O.Q8_0, 1024, 264), (O.Q4_K, 256, 512), (O.Q4_1, 2048, 1024)])
