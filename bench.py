@@ -514,8 +514,8 @@ def layer_split(pkg, cfg, iters=16):
         st = host.reshape(256, 8)[:, :6].astype(np.int64)
         st = st[st[:, 5] > 0]
         t0 = st[:, 0].min()
-        pro_us = float(np.median(st[:, 3] - t0)) / 100.0
-        end_us = float((st[:, 5] - t0).max()) / 100.0
+        pro_us = float(np.median(st[:, 3] - st[:, 0])) / 100.0           # per workgroup: its own entry -> its barrier
+        end_us = float(np.median(st[:, 5] - st[:, 0])) / 100.0           # per workgroup: its own entry -> its last row (the launch-to-launch time also holds the dispatch skew and the drain)
         row = {"launch_us": round(us.value, 2), "prologue_us": round(pro_us, 2), "stream_us": round(end_us - pro_us, 2), "boundary_us": round(us.value - end_us, 2),
                "stream_gbs": round(nbytes / (end_us - pro_us) / 1e3, 1)}
         out[name] = row

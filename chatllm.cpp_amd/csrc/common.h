@@ -174,7 +174,7 @@ __device__ __forceinline__ double rms_block_sumsq_1024(const float * __restrict_
 static __device__ __noinline__ double rms_div(double sum, double n) { return sum / n; }
 // (the reference's order, by wave 0: its 64 lanes load 64 consecutive values at once -- one register, the next batch requested before this one is added -- and square
 //  them; the serial chain then takes them lane by lane through v_readlane, every lane computing the same sum.  As a called function with a 64-value batch in one
-//  thread's registers this cost the 128-register decode kernels 4-17 spilled registers around the call.  COHERENT: the persistent launch hands x over inside the
+//  thread's registers this cost the 128-register decode kernels 4-17 spilled registers around the call.  COHERENT: a launch that is handed x inside the
 //  kernel -- L1-bypassing loads; everywhere else the row was written by an earlier launch.)
 template <bool COHERENT>
 static __device__ __noinline__ double rms_serial_sumsq(const float * x, const float * add, int64_t n) {

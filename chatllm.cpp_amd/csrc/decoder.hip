@@ -56,16 +56,7 @@ struct cllm_llama {
     int32_t * out_ring = nullptr, * counter_dev = nullptr;   // device-side greedy loop: generated ids + how many
     bool own_stream = false, fused_ok = false, fused_warm = false, fused_warm_long = false;
     size_t weight_bytes = 0;
-    // one persistent launch for all layers of a decode step (decode_persist.hip): barrier state + layer table on the device
-    void * persist_state = nullptr; bool persist_ok = false, persist_layers_ready = false, persist_used = false;
-    std::vector<const void *> persist_tab;
-    unsigned long long * persist_ts = nullptr;      // tools: in-kernel phase stamps of workgroup 0
 };
-// decode_persist.hip
-size_t decode_layers_state_bytes(int n_layer);
-int launch_decode_layers(hipStream_t st, void * state, bool * layers_ready, const void * const * layer_tab, int n_layer, int H, int nh, int nkv, int hd, int F, int ML, int rope_mode,
-                         float eps, float * x, float * qkv, float * att, float * g, const int32_t * pos_dev, const float * rope_cs, unsigned long long * ts);
-int decode_layers_error(const void * state, unsigned * phase);
 
 #define TRY(expr) do { int _rc = (expr); if (_rc) return _rc; } while (0)
 
@@ -124,8 +115,6 @@ extern "C" void cllm_llama_destroy(cllm_llama * m) {
     }
     for (void * p : { (void *) m->x, (void *) m->xn, (void *) m->qkv, (void *) m->att, (void *) m->ctx, (void *) m->o, (void *) m->gu, (void *) m->g, (void *) m->scores,
                       (void *) m->logits, m->wdata, (void *) m->tokens_dev, (void *) m->pos_dev, (void *) m->next_tok_dev, (void *) m->out_ring, (void *) m->counter_dev }) if (p) (void) hipFree(p);
-    if (m->persist_state) (void) hipFree(m->persist_state);
-    if (m->persist_ts) (void) hipFree(m->persist_ts);
     if (m->own_stream) { stream_scratch_release(m->st); (void) hipStreamDestroy(m->st); }
     delete m;
 }
@@ -285,15 +274,6 @@ static int finalize(cllm_llama * m, int qlen) {
             for (const dweight * w : { &L.wqkv, &L.wo, &L.wgu, &L.wdown }) if (w->data && !is_quant_type(w->type)) m->fused_ok = false;
         }
         if (!is_quant_type(m->lm_head.type)) m->fused_ok = false;
-        // the persistent all-layers launch: Llama-style blocks, every projection Q4_K, no biases, one GPU (decode_persist.hip states its own shape limits)
-        m->persist_ok = m->fused_ok && !c.qkv_bias && c.tp_size <= 1;
-        for (const llama_layer & L : m->layers) for (const dweight * w : { &L.wqkv, &L.wo, &L.wgu, &L.wdown }) if (w->type != CLLM_TYPE_Q4_K) m->persist_ok = false;
-        if (m->persist_ok) {
-            HIP_TRY(hipMalloc(&m->persist_state, decode_layers_state_bytes(c.n_layer)));
-            if (getenv("CLLM_PERSIST_TS")) { HIP_TRY(hipMalloc((void **) &m->persist_ts, (size_t) c.n_layer * 40 * 8)); HIP_TRY(hipMemset(m->persist_ts, 0, (size_t) c.n_layer * 40 * 8)); }
-            for (const llama_layer & L : m->layers) for (const void * p : { (const void *) L.wqkv.data, (const void *) L.wo.data, (const void *) L.wgu.data, (const void *) L.wdown.data,
-                                                                            (const void *) L.attn_norm.data, (const void *) L.ffn_norm.data, (const void *) L.k_cache, (const void *) L.v_cache }) m->persist_tab.push_back(p);
-        }
         m->finalized = true;
     }
     if (qlen > m->maxq) {
@@ -526,13 +506,6 @@ static int decode_step_fused(cllm_llama * m, bool sample, bool long_ctx) {
     // else done by an ADD launch.
     float * xc = m->x;                       // current residual stream
     const float * pend = nullptr;            // all-reduced partial not yet added to xc
-    bool layers_done = false;
-    if (m->persist_ok && cs_table && !long_ctx && !tp && F % 8 == 0) {      // all layers in ONE persistent launch (decode_persist.hip); CLLM_E_UNSUPPORTED: the five launches per layer below
-        const int prc = launch_decode_layers(st, m->persist_state, &m->persist_layers_ready, m->persist_tab.data(), c.n_layer, (int) H, m->nh, m->nkv, (int) hd, (int) F, (int) ML, c.rope_mode,
-                                             c.rms_eps, m->x, m->qkv, m->att, m->g, m->pos_dev, rope_cs, m->persist_ts);
-        if (prc == CLLM_OK) { layers_done = true; m->persist_used = true; }
-        else if (prc != CLLM_E_UNSUPPORTED) return prc;
-    }
     auto norm_gemv = [&](const dweight & w, int64_t nrows, const float * nw, int epi, float * dst, const float * bias) -> int {
         if (pend) {
             float * xo = xc == m->x ? m->xn : m->x;
@@ -545,7 +518,7 @@ static int decode_step_fused(cllm_llama * m, bool sample, bool long_ctx) {
         }
         return launch_mmvq_fused(st, w.type, w.data, H, nrows, 1, xc, nw, c.rms_eps, epi, dst, bias, nullptr);
     };
-    for (int il = 0; il < c.n_layer && !layers_done; il++) {
+    for (int il = 0; il < c.n_layer; il++) {
         llama_layer & L = m->layers[il];
         TRY(norm_gemv(L.wqkv, QD + 2*KD, (const float *) L.attn_norm.data, 0, m->qkv, c.qkv_bias ? (const float *) L.bqkv.data : nullptr));
         int arc = CLLM_E_UNSUPPORTED;
@@ -578,15 +551,11 @@ static int decode_step_fused(cllm_llama * m, bool sample, bool long_ctx) {
     return CLLM_OK;
 }
 
-// after a synchronize: did a barrier of the persistent launch time out?  (it winds the kernel down instead of hanging the GPU; the step's results are void)
-static int persist_check(cllm_llama * m) {
+// after a synchronize: did a bounded in-kernel wait time out?  (such a launch winds down instead of hanging the GPU; the step's results are void)
+static int kernel_wait_check(cllm_llama * m) {
     TRY(gemv_team32_check());                                          // (the same kind of bounded wait inside a workgroup: gemv_team32.hip)
     // the one-shot all-reduce sums whatever its slots hold after a timed-out flag wait (a slow or dead peer): the step's results are void
     if (m->tp_oneshot && cllm_tp_oneshot_error(m->tp_oneshot)) FAIL(CLLM_E_HIP, "decode: a flag wait of the one-shot all-reduce timed out (a peer rank is late, dead or out of step): the step's logits are void");
-    if (!m->persist_used) return CLLM_OK;
-    unsigned phase = 0;
-    TRY(decode_layers_error(m->persist_state, &phase));
-    if (phase) { m->persist_ok = false; FAIL(CLLM_E_HIP, "decode: the device-wide barrier of the persistent layer kernel timed out in phase %u (not every workgroup was resident?); set CLLM_DECODE_PERSIST=0", phase); }
     return CLLM_OK;
 }
 
@@ -663,7 +632,7 @@ extern "C" int cllm_llama_decode_greedy(cllm_llama * m, int32_t first_token, int
         }
         HIP_TRY(hipMemcpyAsync(out_tokens_host, m->out_ring, (size_t) n_steps * 4, hipMemcpyDeviceToHost, m->st));
         HIP_TRY(hipStreamSynchronize(m->st));
-        return persist_check(m);
+        return kernel_wait_check(m);
     }
     int32_t tok = first_token;
     for (int s = 0; s < n_steps; s++) {
@@ -694,14 +663,14 @@ extern "C" int cllm_llama_decode_fused_logits(cllm_llama * m, int32_t token, int
     TRY(decode_step_fused(m, false, n_past + 1 > attn_long_threshold()));
     HIP_TRY(hipMemcpyAsync(logits_host, m->logits, (size_t) m->cfg.vocab * 4, hipMemcpyDeviceToHost, m->st));
     HIP_TRY(hipStreamSynchronize(m->st));
-    return persist_check(m);
+    return kernel_wait_check(m);
 }
 
 /* debug/test hook: copy an internal activation buffer of the LAST forward to the host ("x", "qkv", "att", "gu", "logits") */
 extern "C" int cllm_llama_debug_read(cllm_llama * m, const char * what, float * host, int64_t n) {
     if (!m || !what || !host || n <= 0) FAIL(CLLM_E_INVALID, "debug_read: arguments");
     const std::string w(what);
-    const float * src = w == "x" ? m->x : w == "qkv" ? m->qkv : w == "att" ? m->att : w == "gu" ? m->gu : w == "logits" ? m->logits : w == "persist_ts" ? (const float *) m->persist_ts : nullptr;
+    const float * src = w == "x" ? m->x : w == "qkv" ? m->qkv : w == "att" ? m->att : w == "gu" ? m->gu : w == "logits" ? m->logits : nullptr;
     if (!src) FAIL(CLLM_E_INVALID, "debug_read: unknown buffer '%s'", what);
     HIP_TRY(hipMemcpyAsync(host, src, (size_t) n * 4, hipMemcpyDeviceToHost, m->st));
     HIP_TRY(hipStreamSynchronize(m->st));

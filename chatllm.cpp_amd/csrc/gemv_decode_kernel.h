@@ -98,15 +98,18 @@ __global__ void __launch_bounds__(1024) k_gemv_dec(const float * __restrict__ px
 #ifndef GEMV_Q16
 #define GEMV_Q16 1          // (A/B builds: 0 = four values per lane everywhere, 1 = the plain-quantize prologue of long rows, 2 = + every RMS_NORM / plain prologue)
 #endif
-    constexpr bool Q16 = FMT == CLLM_TYPE_Q4_K && ((GEMV_Q16 >= 1 && PRO == 2 && EPI != 3 && (NPRE >= 4 || GEMV_Q16 >= 2)) || (GEMV_Q16 >= 2 && PRO == 1));
-    constexpr int NQ = NPRE == 8 ? 2 : 1;                        // passes of 64 blocks
+    constexpr bool Q16 = FMT == CLLM_TYPE_Q4_K && ((GEMV_Q16 >= 1 && PRO == 2 && (NPRE >= 4 || (GEMV_Q16 >= 2 && EPI != 3))) || (GEMV_Q16 >= 2 && PRO == 1));
+    constexpr int NSL = EPI == 3 ? 2 : 1;                        // activation rows (EPI 3: the two slots of a sparse-MoE block's down projection, quantized back to back)
+    constexpr int NQ = (NPRE == 8 ? 2 : 1) * NSL;                // passes of 64 blocks
+    const int nbt = NSL * nblk;
     const int qrow = lane >> 4, qp = lane & 15, qwave = tid >> 6;
     f32x4 vv[Q16 ? 1 : NPRE], gg[(PRO != 2 || EPI == 3) ? NPRE : 1];      // (EPI 3: gg = the second slot's activation)
     f32x4 w16[Q16 ? NQ : 1][4], g16[(Q16 && PRO == 1) ? NQ : 1][4];
     if constexpr (Q16) {
 #pragma unroll
         for (int q = 0; q < NQ; q++) {
-            const int blk = (qwave + 16 * q) * 4 + qrow, o = (blk < nblk ? blk : 0) * 256 + 16 * qp;
+            const int bi = (qwave + 16 * q) * 4 + qrow, sl = (NSL > 1 && bi >= nblk) ? 1 : 0, blk = bi - sl * nblk;
+            const int o = (bi < nbt ? blk : 0) * 256 + 16 * qp + (NSL > 1 ? sl * px_slot_stride : 0);
 #pragma unroll
             for (int i = 0; i < 4; i++) w16[q][i] = *(const f32x4 *)(px + o + 4 * i);
             if constexpr (PRO == 1) {
@@ -227,14 +230,15 @@ __global__ void __launch_bounds__(1024) k_gemv_dec(const float * __restrict__ px
     if constexpr (Q16) {
 #pragma unroll
         for (int q = 0; q < NQ; q++) {
-            const int blk = (qwave + 16 * q) * 4 + qrow;
-            if ((qwave + 16 * q) * 4 < nblk) {                      // (wave-uniform: the tie path of quant16_q8_K holds a ballot)
+            const int bi = (qwave + 16 * q) * 4 + qrow, sl = (NSL > 1 && bi >= nblk) ? 1 : 0, blk = bi - sl * nblk;
+            if ((qwave + 16 * q) * 4 < nbt) {                       // (wave-uniform: the tie path of quant16_q8_K holds a ballot)
                 float d; int ssum;
                 const u32x4 qv = quant16_q8_K(w16[q], qp, &d, &ssum);
-                if (blk < nblk) {
-                    *(u32x4 *)(lds + blk * 256 + 16 * qp) = qv;
-                    if ((qp & 1) == 0) ((int32_t *)(lds + act_off_s(K, 256)))[blk * 8 + (qp >> 1)] = ssum;
-                    if (qp == 0) ((float *)(lds + act_off_d(K)))[blk] = d;
+                if (bi < nbt) {
+                    char * arow = lds + (NSL > 1 ? sl * (int) act_row_bytes(K, 256) : 0);
+                    *(u32x4 *)(arow + blk * 256 + 16 * qp) = qv;
+                    if ((qp & 1) == 0) ((int32_t *)(arow + act_off_s(K, 256)))[blk * 8 + (qp >> 1)] = ssum;
+                    if (qp == 0) ((float *)(arow + act_off_d(K)))[blk] = d;
                 }
             }
         }

@@ -41,20 +41,20 @@ __device__ __forceinline__ uint32_t quant4_q8_K(f32x4 v, int lane, float * d_out
     const float mine = a0 == amax ? v.x : a1 == amax ? v.y : a2 == amax ? v.z : v.w;
     const unsigned long long has = __ballot(a0 == amax || a1 == amax || a2 == amax || a3 == amax);
     const float maxv = lane_f(mine, (int) __builtin_ctzll(has));              // has != 0: some lane holds the maximum
-    int q0 = 0, q1 = 0, q2 = 0, q3 = 0;
+    // the quants: nearest_int()'s own two roundings (t = iscale * x, t + 1.5 * 2^23), whose LOW BYTE is the two's-complement quant -- |t| <= 127 (1 + 2^-23) < 127.5, so the
+    // reference's MIN(127, .) cannot bind for a finite non-zero maximum -- packed with three v_perm, summed with one v_dot4 against (1, 1, 1, 1) (q16_byte4 below)
+    uint32_t packed = 0u;
     float d = 0.0f;
     if (amax != 0.0f) {
         const float iscale = -127.f / maxv;
-        q0 = min(127, nearest_int_dev(iscale * v.x));
-        q1 = min(127, nearest_int_dev(iscale * v.y));
-        q2 = min(127, nearest_int_dev(iscale * v.z));
-        q3 = min(127, nearest_int_dev(iscale * v.w));
+        const uint32_t b0 = __float_as_uint(iscale * v.x + 12582912.f), b1 = __float_as_uint(iscale * v.y + 12582912.f);
+        const uint32_t b2 = __float_as_uint(iscale * v.z + 12582912.f), b3 = __float_as_uint(iscale * v.w + 12582912.f);
+        packed = __builtin_amdgcn_perm(__builtin_amdgcn_perm(b3, b2, 0x0c0c0400u), __builtin_amdgcn_perm(b1, b0, 0x0c0c0400u), 0x05040100u);
         d = 1 / iscale;
     }
-    const int s = group8_sum_i(q0 + q1 + q2 + q3);
     *d_out = d;
-    *s_out = s;
-    return pack4(q0, q1, q2, q3);
+    *s_out = group8_sum_i(dot4(packed, 0x01010101u, 0));
+    return packed;
 }
 
 // ---- quantize_row_q8_K with SIXTEEN values per lane: a 16-lane DPP row holds one 256-block (lane p: elements 16 p .. 16 p + 15), a wave four blocks.

@@ -148,46 +148,7 @@ def _debug_lib(gpu):
     import ctypes as C
     lib = C.CDLL(gpu.lib.SO_PATH)
     lib.cllm_debug_set_attn_prefill_min_cols.argtypes = [C.c_int]
-    lib.cllm_debug_set_decode_persist.argtypes = [C.c_int]
     return lib
-
-
-@pytest.mark.parametrize("over", [{}, dict(ffn=4352, n_layer=2), dict(rope_mode=2, rope_theta=1e6, n_layer=3)])
-def test_persistent_all_layers_launch_is_bit_identical(gpu, over):
-    """CLLM_DECODE_PERSIST=1 (opt-in, decode_persist.hip): all layers of a decode step in ONE persistent launch -- device-wide barrier between the phases,
-    write-through hand-off of the activation vectors across XCDs -- against the five launches per layer and against the oracle: the same bits, step by step,
-    eagerly and replayed from the captured graph"""
-    cfg = gpu.synth.config("small", max_len=128, **over)
-    w = gpu.synth.make_model(cfg, O.Q4_K, seed=31)
-    prompt = np.random.default_rng(31).integers(0, cfg["vocab"], 9).astype(np.int32)
-    lib = _debug_lib(gpu)
-    ref = O.Llama(cfg, w)
-    lr = ref.forward(prompt)
-    runs = {}
-    for persist in (1, 0):
-        lib.cllm_debug_set_decode_persist(persist)
-        try:
-            m = gpu.Llama(cfg, w)
-            lg = m.forward(prompt)
-            assert np.array_equal(lr.view(np.uint32), lg.view(np.uint32))
-            steps = []
-            t = int(np.argmax(lg))
-            for _ in range(6):
-                lg = m.decode_fused_logits(t)
-                steps.append(lg)
-                t = int(np.argmax(lg))
-            ids = m.decode_greedy(t, 40)                 # warm-up step, capture, replays
-            runs[persist] = (np.stack(steps), ids)
-            m.close()
-        finally:
-            lib.cllm_debug_set_decode_persist(0)
-    assert np.array_equal(runs[1][0].view(np.uint32), runs[0][0].view(np.uint32))
-    assert np.array_equal(runs[1][1], runs[0][1])
-    lo, t = lr, int(np.argmax(lr))
-    for i in range(6):                                   # and the oracle's whole-model walk
-        lo = ref.forward([t])
-        assert np.array_equal(lo.view(np.uint32), runs[1][0][i].view(np.uint32)), i
-        t = int(np.argmax(lo))
 
 
 @pytest.mark.parametrize("mode", [1, 0])
@@ -276,7 +237,7 @@ def test_decoder_qwen2_style_is_bit_identical_to_the_walk(gpu):
 
 @pytest.mark.parametrize("name,wtype,plen,over", [("tiny", O.Q8_0, 9, {}), ("tiny", O.Q4_0, 9, {}), ("tiny", O.Q4_K, 9, {}), ("tiny", O.Q4_1, 9, {}), ("small", O.Q4_K, 30, {}),
                                                   ("tiny", O.Q4_K, 12, dict(rope_mode=2, qkv_bias=1, rope_theta=1e6, ffn=544)),
-                                                  # head size 128, every projection Q4_K: the decode steps run as ONE persistent launch over all layers (decode_persist.hip);
+                                                  # head size 128, every projection Q4_K: the compact attention kernel + the fused mat-vecs;
                                                   # ffn > 4096: the down projection's four-group prologue; NEOX pairs
                                                   ("small", O.Q4_K, 17, dict(ffn=4352)), ("small", O.Q4_K, 11, dict(rope_mode=2, rope_theta=1e6, n_layer=3))])
 def test_end_to_end_is_bit_identical_to_the_oracle_run(gpu, name, wtype, plen, over):
@@ -296,7 +257,7 @@ def test_end_to_end_is_bit_identical_to_the_oracle_run(gpu, name, wtype, plen, o
 
 
 @pytest.mark.parametrize("wtype,over", [(O.Q8_0, {}), (O.Q4_0, {}), (O.Q4_K, {}), (O.Q4_1, {}), (O.Q4_K, dict(rope_mode=2, qkv_bias=1, rope_theta=1e6, ffn=544)),
-                                        (O.Q4_K, dict(base="small")), (O.Q4_K, dict(base="small", ffn=4352, n_layer=2))])       # (the persistent all-layers launch)
+                                        (O.Q4_K, dict(base="small")), (O.Q4_K, dict(base="small", ffn=4352, n_layer=2))])
 def test_fused_decode_path_is_bit_identical_to_the_node_by_node_path(gpu, wtype, over):
     """norm+quant, rope+kv-write, fused attention, silu*up+quant, GEMV+bias/residual epilogues: same bits as the unfused nodes"""
     over = dict(over)
