@@ -435,6 +435,9 @@ int launch_gemv_kq_id(hipStream_t st, int wtype, const tview & as, const void * 
 int launch_dense_f16(hipStream_t st, int wtype, const tview & w, const tview & x, const tview & d, const float * resid = nullptr, int64_t ldr = 0, int epi = 0);
 int launch_gemv_rows(hipStream_t st, const void * W, int64_t K, int64_t nrows, int pro, const float * px, const float * pw, float eps, int epi, float * dst, const float * bias, const float * resid);
 int kernel_error_word(unsigned ** dev_ptr);      // gemv_team32.hip: the device's mapped error word (bounded in-kernel waits report there)
+int launch_gemv_decode_tp_scatter(hipStream_t st, int wtype, const void * W, int64_t K, int64_t nrows, int pro, const float * px, const void * ctx_dev, int site);      // gemv_tp.hip
+int launch_gemv_decode_tp_gather(hipStream_t st, int wtype, const void * W, int64_t K, int64_t nrows, const float * px, const float * pw, float eps, int epi, float * dst,
+                                 const float * bias, const void * ctx_dev, int site, float * xout);
 int launch_gemv_rows32(hipStream_t st, int wtype, const void * W, int64_t K, int64_t nrows, int pro, const float * px, const float * pw, float eps, int epi, float * dst, const float * bias, const float * resid);
 int gemv_team32_check();
 int launch_gemv_team32(hipStream_t st, int wtype, const void * W, int64_t K, int64_t nrows, int pro, const float * px, const float * pw, float eps, int epi, float * dst, const float * bias, const float * resid);

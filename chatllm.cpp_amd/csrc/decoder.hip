@@ -49,6 +49,7 @@ struct cllm_llama {
     cllm_allreduce_fn allreduce = nullptr; void * allreduce_user = nullptr;
     void * tp_comm = nullptr;         // RCCL communicator (cllm_tp_init): the all-reduce runs on the runner's stream, inside the decode graph
     void * tp_oneshot = nullptr;      // one-shot direct-write all-reduce over IPC-mapped peer buffers (tp_oneshot.hip): one launch, also inside the graph
+    void * tp_fused = nullptr;        // the decode steps' all-reduces FUSED into the neighbouring mat-vecs (gemv_tp.hip): no all-reduce launch; prompts keep the collective above
     bool use_graph = true;
     hipGraphExec_t decode_graph = nullptr;       // one sampled decode step, short-context attention (one launch per layer)
     hipGraphExec_t decode_graph_long = nullptr;  // the same with the split long-context attention (attn_long.hip)
@@ -162,6 +163,21 @@ extern "C" int cllm_llama_bind_weight(cllm_llama * m, const char * name, int typ
 extern "C" int cllm_llama_set_allreduce(cllm_llama * m, cllm_allreduce_fn fn, void * user) { if (!m) FAIL(CLLM_E_INVALID, "null"); m->allreduce = fn; m->allreduce_user = user; return CLLM_OK; }
 extern "C" int cllm_llama_set_tp_comm(cllm_llama * m, void * comm) { if (!m) FAIL(CLLM_E_INVALID, "null"); m->tp_comm = comm; return CLLM_OK; }
 extern "C" int cllm_llama_set_tp_oneshot(cllm_llama * m, void * os) { if (!m) FAIL(CLLM_E_INVALID, "null"); m->tp_oneshot = os; return CLLM_OK; }
+extern "C" const void * cllm_tp_fused_dev(void * os);
+extern "C" int cllm_tp_fused_sites(void * os);
+extern "C" size_t cllm_tp_fused_max_n(void * os);
+extern "C" int cllm_tp_fused_advance(void * os, void * stream);
+extern "C" int cllm_tp_fused_error(void * os);
+// bind the receive buffers of the fused all-reduce (cllm_tp_fused_create / _connect): 2 n_layer sites of `hidden` values.  The single-token steps then run without
+// all-reduce launches; multi-token graphs (prompts) still need cllm_llama_set_tp_comm / _set_tp_oneshot / _set_allreduce.  NULL: back to the collective per all-reduce.
+extern "C" int cllm_llama_set_tp_fused(cllm_llama * m, void * os) {
+    if (!m) FAIL(CLLM_E_INVALID, "null");
+    if (os && (cllm_tp_fused_sites(os) < 2 * m->cfg.n_layer || cllm_tp_fused_max_n(os) < (size_t) m->cfg.hidden))
+        FAIL(CLLM_E_INVALID, "llama_set_tp_fused: the buffers hold %d sites of %zu values, the model needs %d of %d", cllm_tp_fused_sites(os), cllm_tp_fused_max_n(os), 2 * m->cfg.n_layer, m->cfg.hidden);
+    if (m->decode_graph) { (void) hipGraphExecDestroy(m->decode_graph); m->decode_graph = nullptr; }
+    m->tp_fused = os;
+    return CLLM_OK;
+}
 extern "C" int cllm_tp_all_reduce_f32(void * comm, void * stream, float * buf, size_t n);
 extern "C" int cllm_tp_oneshot_all_reduce_f32(void * os, void * stream, float * buf, size_t n);
 extern "C" int cllm_tp_oneshot_error(void * os);
@@ -506,7 +522,20 @@ static int decode_step_fused(cllm_llama * m, bool sample, bool long_ctx) {
     // else done by an ADD launch.
     float * xc = m->x;                       // current residual stream
     const float * pend = nullptr;            // all-reduced partial not yet added to xc
+    // fused all-reduce (gemv_tp.hip): o / down scatter their partial rows into every rank's buffer (site 2 il / 2 il + 1), the next RMS_NORM mat-vec gathers them
+    const bool fused_ar = tp && m->tp_fused != nullptr;
+    const void * fctx = fused_ar ? cllm_tp_fused_dev(m->tp_fused) : nullptr;
+    int pend_site = -1;
+    if (fused_ar) TRY(cllm_tp_fused_advance(m->tp_fused, st));
     auto norm_gemv = [&](const dweight & w, int64_t nrows, const float * nw, int epi, float * dst, const float * bias) -> int {
+        if (pend_site >= 0) {
+            float * xo = xc == m->x ? m->xn : m->x;
+            const int rc = launch_gemv_decode_tp_gather(st, w.type, w.data, H, nrows, xc, nw, c.rms_eps, epi, dst, bias, fctx, pend_site, xo);
+            if (rc == CLLM_E_UNSUPPORTED) FAIL(CLLM_E_UNSUPPORTED, "decode: the fused all-reduce cannot take this mat-vec (type %d, %lld x %lld); unbind it (cllm_llama_set_tp_fused(m, NULL))", w.type, (long long) H, (long long) nrows);
+            if (rc) return rc;
+            xc = xo; pend_site = -1;
+            return CLLM_OK;
+        }
         if (pend) {
             float * xo = xc == m->x ? m->xn : m->x;
             int rc = launch_gemv_decode(st, w.type, w.data, H, nrows, 1, xc, nw, c.rms_eps, epi, dst, bias, nullptr, pend, xo);
@@ -528,7 +557,12 @@ static int decode_step_fused(cllm_llama * m, bool sample, bool long_ctx) {
         if (arc == CLLM_E_UNSUPPORTED) arc = launch_rope_kv_attn_decode(st, m->qkv, m->pos_dev, m->nh, m->nkv, (int) hd, c.rope_mode, c.rope_theta, L.k_cache, L.v_cache, ML, m->att);
         TRY(arc);
         if (!tp) TRY(launch_mmvq_fused(st, L.wo.type, L.wo.data, QD, H, 2, m->att, nullptr, 0.0f, 0, xc, nullptr, xc));          // x = o + x
-        else {
+        else if (fused_ar) {
+            const int rc = launch_gemv_decode_tp_scatter(st, L.wo.type, L.wo.data, QD, H, 2, m->att, fctx, 2 * il);
+            if (rc == CLLM_E_UNSUPPORTED) FAIL(CLLM_E_UNSUPPORTED, "decode: the fused all-reduce cannot take o_proj (type %d, K %lld); unbind it (cllm_llama_set_tp_fused(m, NULL))", L.wo.type, (long long) QD);
+            if (rc) return rc;
+            pend_site = 2 * il;
+        } else {
             TRY(launch_mmvq_fused(st, L.wo.type, L.wo.data, QD, H, 2, m->att, nullptr, 0.0f, 0, m->o, nullptr, nullptr));
             TRY(tp_allreduce(m, st, m->o, H));
             pend = m->o;
@@ -540,7 +574,12 @@ static int decode_step_fused(cllm_llama * m, bool sample, bool long_ctx) {
         const int dpro = silu_epi ? 2 : 3;
         TRY(norm_gemv(L.wgu, 2*F, (const float *) L.ffn_norm.data, silu_epi ? 1 : 0, silu_epi ? m->g : m->gu, nullptr));
         if (!tp) TRY(launch_mmvq_fused(st, L.wdown.type, L.wdown.data, F, H, dpro, dsrc, nullptr, 0.0f, 0, xc, nullptr, xc));   // x = down + x
-        else {
+        else if (fused_ar) {
+            const int rc = launch_gemv_decode_tp_scatter(st, L.wdown.type, L.wdown.data, F, H, dpro, dsrc, fctx, 2 * il + 1);
+            if (rc == CLLM_E_UNSUPPORTED) FAIL(CLLM_E_UNSUPPORTED, "decode: the fused all-reduce cannot take down_proj (type %d, K %lld); unbind it (cllm_llama_set_tp_fused(m, NULL))", L.wdown.type, (long long) F);
+            if (rc) return rc;
+            pend_site = 2 * il + 1;
+        } else {
             TRY(launch_mmvq_fused(st, L.wdown.type, L.wdown.data, F, H, dpro, dsrc, nullptr, 0.0f, 0, m->o, nullptr, nullptr));
             TRY(tp_allreduce(m, st, m->o, H));
             pend = m->o;
@@ -556,13 +595,14 @@ static int kernel_wait_check(cllm_llama * m) {
     TRY(gemv_team32_check());                                          // (the same kind of bounded wait inside a workgroup: gemv_team32.hip)
     // the one-shot all-reduce sums whatever its slots hold after a timed-out flag wait (a slow or dead peer): the step's results are void
     if (m->tp_oneshot && cllm_tp_oneshot_error(m->tp_oneshot)) FAIL(CLLM_E_HIP, "decode: a flag wait of the one-shot all-reduce timed out (a peer rank is late, dead or out of step): the step's logits are void");
+    if (m->tp_fused && cllm_tp_fused_error(m->tp_fused)) FAIL(CLLM_E_HIP, "decode: a granule wait of the fused all-reduce timed out (a peer rank is late, dead or out of step): the step's logits are void");
     return CLLM_OK;
 }
 
 // capture one sampled step into a graph (after one eager warm-up step has set every function attribute)
 static int ensure_decode_graph(cllm_llama * m, bool long_ctx) {
     hipGraphExec_t & slot = long_ctx ? m->decode_graph_long : m->decode_graph;
-    if (slot || !m->use_graph || (m->cfg.tp_size > 1 && !m->tp_comm && !m->tp_oneshot)) return CLLM_OK;     // a host callback cannot be captured; RCCL and the one-shot kernel can
+    if (slot || !m->use_graph || (m->cfg.tp_size > 1 && !m->tp_comm && !m->tp_oneshot && !m->tp_fused)) return CLLM_OK;     // a host callback cannot be captured; RCCL, the one-shot kernel and the fused form can
     hipGraph_t graph = nullptr;
     HIP_TRY(hipStreamBeginCapture(m->st, hipStreamCaptureModeRelaxed));
     const int rc = decode_step_fused(m, true, long_ctx);

@@ -11,6 +11,12 @@
 //                   dst[r] = (y0[r] * w0 + y1[r] * w1) (+ resid[r]), w = probs[ids] / (probs[ids[0]] + probs[ids[1]])   (pw = probs, ids = the TOP_K output)
 //            EPI 2: the sparse-MoE router (GenericSparseMLP::forward src/layers.cpp:3792-3830): ONE workgroup; the rows are the experts' logits,
 //                   dst = SOFT_MAX(logits), ids (written) = TOP_K(dst, k = dst_slot_stride), xout = the normalised activation (the experts' input)
+//   tensor parallel, all-reduce FUSED into the neighbouring mat-vecs (gemv_tp.hip; the reference has no tensor parallelism: SplitMethod::Row is a TODO, src/backend.h:322-327):
+//            EPI 4: the row results are this rank's PARTIAL sums of an o / down projection; every row goes out as an 8-byte {value, step number} granule into this
+//                   rank's slot of EVERY rank's receive buffer (system-scope write-through stores, peer memory mapped through HIP IPC) -- no dst, no all-reduce launch
+//            PRO 5: PRO 1 whose residual input is  x + sum over ranks (rank order) of the granules of the previous o / down projection, polled from this rank's own
+//                   receive buffer until they carry this step's number; workgroup 0 stores the new residual stream to xout
+//            (`ids` = the device-side tp_fuse_dev context, `dst_slot_stride` (EPI 4) / `px_slot_stride` (PRO 5) = the site: 2 * layer + {0: o, 1: down})
 //   dst[r] = W[r] . act (+ bias[r]) (+ resid[r])               (Linear::forward src/layers.cpp:2111-2129, residual adds :2740,:2758)
 // Same arithmetic as RMS_NORM -> MUL -> quantize_row_q8_K -> MUL_MAT (-> ADD) on the node-by-node path, bit for bit:
 // the reductions (rms_block_sumsq_1024, quant4_q8_K, q4k_step, wave_sum) are the shared definitions.
@@ -43,6 +49,28 @@
 #define GEMV_WLOAD(p) (*(p))
 #endif
 #define TS(k) do { if (ts && threadIdx.x == 0) ts[blockIdx.x * 8 + (k)] = wall_clock64(); } while (0)
+
+// device-side context of the fused tensor-parallel all-reduce (tp_oneshot.hip cllm_tp_fused_*): receive buffers [site][rank][max_n] x 8-byte granules {value, step}
+struct tp_fuse_dev { char * peer[16]; int rank, nranks; unsigned max_n, pad; const unsigned * step; unsigned * err; };
+__device__ __forceinline__ u32x4 tpf_load16(const void * p) { u32x4 v; asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(v) : "v"(p) : "memory"); return v; }
+// the four elements e .. e + 3 of the all-reduced vector of `site`: every rank's granules from this rank's own buffer, summed in rank order (bounded wait)
+__device__ __forceinline__ f32x4 tpf_gather4(const tp_fuse_dev * cx, const char * own, int nranks, unsigned max_n, unsigned step, int site, int e) {
+    f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+    for (int r = 0; r < nranks; r++) {
+        const char * src = own + ((size_t)(site * nranks + r) * max_n + (size_t) e) * 8;
+        u32x4 h0, h1;
+        int spins = 0;
+        for (;;) {
+            h0 = tpf_load16(src); h1 = tpf_load16(src + 16);
+            if (h0.y == step && h0.w == step && h1.y == step && h1.w == step) break;
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > (1 << 21)) { __hip_atomic_store(cx->err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+        }
+        const f32x4 v = { __uint_as_float(h0.x), __uint_as_float(h0.z), __uint_as_float(h1.x), __uint_as_float(h1.z) };
+        if (r == 0) acc = v; else { acc.x = acc.x + v.x; acc.y = acc.y + v.y; acc.z = acc.z + v.z; acc.w = acc.w + v.w; }
+    }
+    return acc;
+}
 
 // FMT: CLLM_TYPE_Q4_K (8 lanes per 144-byte super-block, activation quantized to Q8_K) or CLLM_TYPE_Q4_0 / Q4_1 / Q8_0 (one lane per
 // 18 / 20 / 34-byte block, activation quantized to Q8_0 / Q8_1).  nblk = weight blocks per row.
@@ -87,7 +115,8 @@ __global__ void __launch_bounds__(1024) k_gemv_dec(const float * __restrict__ px
 
     // ---- (1) this thread's activation groups: unconditional (clamped) loads, issued before anything else ----
     // pro 3: px holds interleaved (gate_e, up_e) pairs -- two 16-byte loads cover this thread's four features
-    const float * gp = (PRO == 1 || PRO == 4) ? pw : PRO == 3 ? px + 4 : px;
+    constexpr bool NORM = PRO == 1 || PRO == 5;                     // the RMS_NORM prologues
+    const float * gp = (NORM || PRO == 4) ? pw : PRO == 3 ? px + 4 : px;
     constexpr int vmul = PRO == 3 ? 2 : 1;
     const int e0 = tid * 4;
     // Q16 (the plain quantize_row_q8_K prologue in front of Q4_K weights, rows of more than 4096 values: down_proj): SIXTEEN values per lane, one 256-block per 16-lane
@@ -130,6 +159,22 @@ __global__ void __launch_bounds__(1024) k_gemv_dec(const float * __restrict__ px
     // (x + padd feeds the norm; workgroup 0 stores it to xout, a different buffer than px) instead of in a launch of its own
     f32x4 pa = {0, 0, 0, 0}, pa16[(Q16 && PRO == 1 && NPRE == 1) ? 4 : 1];
     const bool add = PRO == 1 && NPRE == 1 && padd != nullptr;
+    if constexpr (PRO == 5) {
+        // the all-reduce of the previous o / down projection, folded in: every rank's partial rows wait (or arrive) as granules in this rank's buffer.  Polled BEFORE the
+        // weight prefetch goes out (the polls wait with vmcnt(0): behind the prefetch they would drain it anyway) -- a tensor-parallel step is bound by these arrivals
+        const tp_fuse_dev * cx = (const tp_fuse_dev *) ids;
+        const int nr = cx->nranks, rk = cx->rank; const unsigned mxn = cx->max_n, stp = *cx->step;
+        const char * own = cx->peer[rk];
+#pragma unroll
+        for (int u = 0; u < NPRE; u++) {
+            const int e = e0 + u * 4096;
+            if (e < K) {
+                const f32x4 g = tpf_gather4(cx, own, nr, mxn, stp, px_slot_stride, e);
+                vv[u].x = vv[u].x + g.x; vv[u].y = vv[u].y + g.y; vv[u].z = vv[u].z + g.z; vv[u].w = vv[u].w + g.w;
+                if (blockIdx.x == 0) *(f32x4 *)(xout + e) = vv[u];
+            }
+        }
+    }
     if constexpr (Q16 && PRO == 1 && NPRE == 1) {
         if (add) {
             const int blk = qwave * 4 + qrow, o = (blk < nblk ? blk : 0) * 256 + 16 * qp;
@@ -137,6 +182,14 @@ __global__ void __launch_bounds__(1024) k_gemv_dec(const float * __restrict__ px
             for (int i = 0; i < 4; i++) pa16[i] = *(const f32x4 *)(padd + o + 4 * i);
         }
     } else if (add) pa = *(const f32x4 *)(padd + (e0 < K ? e0 : 0));
+    // EPI 4: where this rank's partial rows go (lane r: rank r's receive buffer)
+    char * tp_dst = nullptr; unsigned tp_step = 0;
+    if constexpr (EPI == 4) {
+        const tp_fuse_dev * cx = (const tp_fuse_dev *) ids;
+        const int nr = cx->nranks;
+        tp_step = *cx->step;
+        if (lane < nr) tp_dst = cx->peer[lane] + (size_t)(dst_slot_stride * nr + cx->rank) * cx->max_n * 8;
+    }
     TS(0);
 
     // ---- (2) two steps of weight prefetch.  Units are dealt in rounds of nwaves: in a full round wave (b, w) takes unit
@@ -225,6 +278,34 @@ __global__ void __launch_bounds__(1024) k_gemv_dec(const float * __restrict__ px
         const double sum = NPRE == 1 ? rms_block_sumsq_1024_one(vv[0], e0 < K, part) : rms_block_sumsq_1024(px, K, vv[0], part);
         scale = rms_scale(sum, K, eps, px, add ? padd : nullptr, part);
     }
+    if constexpr (PRO == 5) {
+        // rms_block_sumsq_1024's order over the values in registers (x is not in memory: it is px + the gathered partials); rms_scale's interval test, and for the rare
+        // ambiguous row the reference's serial sum over a copy of the row in LDS (behind the chain records)
+        __shared__ double part[16];
+        double sum = 0.0;
+#pragma unroll
+        for (int u = 0; u < NPRE; u++) {
+            if (e0 + u * 4096 < K) { const f32x4 v = vv[u]; sum += (double)(v.x * v.x); sum += (double)(v.y * v.y); sum += (double)(v.z * v.z); sum += (double)(v.w * v.w); }
+        }
+        sum = wave_sum_d(sum);
+        if ((tid & 63) == 0) part[tid >> 6] = sum;
+        __syncthreads();
+        double tot = part[0];
+#pragma unroll
+        for (int w = 1; w < 16; w++) tot += part[w];
+        float m = rms_mean(tot, K);
+        const double dl = tot * ((double)(2 * (int64_t) K + 16) * 0x1p-53);
+        if (!(rms_mean(tot - dl, K) == rms_mean(tot + dl, K))) {
+            float * xs = (float *)(lds + act_row_bytes(K, KIND) + 16 * (IS_K ? Q4K_CHAIN_BYTES : Q32_CHAIN_BYTES));
+#pragma unroll
+            for (int u = 0; u < NPRE; u++) { const int e = e0 + u * 4096; if (e < K) *(f32x4 *)(xs + e) = vv[u]; }
+            __syncthreads();
+            if (tid < 64) { const double ss = rms_serial_sumsq<false>(xs, nullptr, K); if (tid == 0) part[0] = ss; }
+            __syncthreads();
+            m = rms_mean(part[0], K);
+        }
+        scale = 1.0f / sqrtf(m + eps);
+    }
     }
     const int nv = K & ~7;                                          // ggml_vec_silu_f32: polynomial body below nv, libm tail
     if constexpr (Q16) {
@@ -257,7 +338,7 @@ __global__ void __launch_bounds__(1024) k_gemv_dec(const float * __restrict__ px
                 const f32x4 g = gg[u];
                 v.x = silu_any(v.x, e + 0 < nv) * g.x; v.y = silu_any(v.y, e + 1 < nv) * g.y; v.z = silu_any(v.z, e + 2 < nv) * g.z; v.w = silu_any(v.w, e + 3 < nv) * g.w;
             }
-            if (PRO == 1) { const f32x4 g = gg[u]; v.x = (v.x * scale) * g.x; v.y = (v.y * scale) * g.y; v.z = (v.z * scale) * g.z; v.w = (v.w * scale) * g.w; }
+            if (NORM) { const f32x4 g = gg[u]; v.x = (v.x * scale) * g.x; v.y = (v.y * scale) * g.y; v.z = (v.z * scale) * g.z; v.w = (v.w * scale) * g.w; }
             if (EPI == 2) *(f32x4 *)(xout + e) = v;
             quant4_store<KIND, IS_Q41>(lds, K, e, lane, v);
             if (EPI == 3) quant4_store<KIND, IS_Q41>(lds + act_row_bytes(K, KIND), K, e, lane, gg[u]);
@@ -312,6 +393,9 @@ __global__ void __launch_bounds__(1024) k_gemv_dec(const float * __restrict__ px
                             if (resid) o = __fadd_rn(o, uniform_load_f32(resid + cunit));
                             if (lane == 0) dst[cunit] = o;
                         }
+                    } else if (EPI == 4) {
+                        const unsigned long long gr = ((unsigned long long) tp_step << 32) | (unsigned long long) __float_as_uint(lane_f(v, 0));
+                        if (tp_dst) __hip_atomic_store((unsigned long long *)(tp_dst + (size_t) crow * 8), gr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                     } else {
                         if (bias)  v = v + uniform_load_f32(bias + crow);
                         if (resid) v = v + uniform_load_f32(resid + crow);

@@ -1,16 +1,22 @@
 // tp_oneshot.hip -- one-shot direct-write all-reduce for the tensor-parallel decode messages ([hidden] fp32 = 16-32 KB, twice per layer).
 //
 // A ring all-reduce over xGMI (RCCL) pays 2 (N - 1) hops of launch-and-wait latency for a message that fits one packet burst; at this size the right shape is
-// ONE step: every rank writes its partial vector straight into a slot of every peer's receive buffer (peer memory mapped through HIP IPC: one process per GPU),
-// raises a flag there, waits until its own buffer holds everybody's flag, and sums the N slots IN RANK ORDER -- every rank computes the same bits, and for two
-// ranks the same bits as any other sum.  One kernel launch per all-reduce, no host round trip, capturable in the decode hipGraph (the sequence number lives in
-// device memory).  The reference has no tensor parallelism (SplitMethod::Row is a TODO, src/backend.h:322-327); SURVEY.md 8(e).
+// ONE step: every rank writes its partial vector straight into a slot of every peer's receive buffer (peer memory mapped through HIP IPC: one process per GPU)
+// and sums the N slots of its own buffer IN RANK ORDER -- every rank computes the same bits, and for two ranks the same bits as any other sum.  One kernel launch
+// per all-reduce, no host round trip, capturable in the decode hipGraph (the sequence number lives in device memory).  The reference has no tensor parallelism
+// (SplitMethod::Row is a TODO, src/backend.h:322-327); SURVEY.md 8(e).
 //
-//   buffer of a rank:  slots [2 parities][nranks][max_n] floats | flags [2 parities][nranks] uint32
-//   all-reduce number s (parity s & 1):  (1) buf -> slot[par][rank] of every rank's buffer   (2) system fence, flag[par][rank] = s everywhere
-//                                        (3) wait own flag[par][r] == s for all r              (4) buf = sum_r slot[par][r] (own buffer), r ascending
-//   A rank can be at most one all-reduce ahead of a peer (it needs the peer's flag of s to finish s), so two parities keep a slot from being overwritten
-//   while a slower rank still reads it.  The wait is bounded: on a timeout the error word is raised and the launch returns (no hang).
+// Round 5: DATA-TAGGED GRANULES instead of payload + fence + flag (MI355X_MICROARCH.md rows handoff-1to1 / handoff-flag: a separate flag costs 1.7-2.5 x the
+// tagged form, and scalar 4-byte system-scope stores are one fabric write each).  A granule is 8 bytes {value, sequence number}; a thread owns four elements, builds
+// their four granules and sends them as TWO 16-byte write-through stores (sc0 sc1) per peer; it then polls the same four granules of every rank's slot in its OWN
+// buffer with 16-byte sc0 sc1 loads until all tags carry this all-reduce's number and adds the values in rank order.  Thread <-> element is one-to-one on both
+// sides, so there is no fence, no flag, no barrier in the kernel, and it runs on as many workgroups as the vector has 1024-element pieces (4 for 4096, 8 for 8192).
+//
+//   buffer of a rank:  granules [2 parities][nranks][max_n] x 8 bytes
+//   all-reduce number s (parity s & 1):  (1) my granules -> slot[par][rank] of every rank's buffer   (2) poll own slot[par][r], all r, tag == s   (3) buf = sum, r ascending
+//   A rank can be at most one all-reduce ahead of a peer (it needs the peer's granules of s to finish s), so two parities keep a slot from being overwritten
+//   while a slower rank still reads it.  The wait is bounded: on a timeout the error word is raised and the launch returns (no hang).  The sequence number is
+//   advanced by the LAST workgroup to finish (every workgroup has read it by then).
 #include "common.h"
 #include <string.h>
 #include <stdlib.h>
@@ -28,48 +34,58 @@ struct tp_oneshot {
 };
 struct tpo_args { char * peer[TPO_MAX_RANKS]; int rank, nranks; unsigned long long max_n; unsigned * seq, * err; };
 
-__device__ __forceinline__ size_t tpo_slot_off(const tpo_args & a, int par, int r) { return ((size_t) par * a.nranks + r) * a.max_n * 4; }
-__device__ __forceinline__ size_t tpo_flag_off(const tpo_args & a, int par, int r) { return (size_t) 2 * a.nranks * a.max_n * 4 + ((size_t) par * a.nranks + r) * 4; }
+__device__ __forceinline__ size_t tpo_slot_off(const tpo_args & a, int par, int r) { return ((size_t) par * a.nranks + r) * a.max_n * 8; }
+// 16-byte system-scope (write-through / cache-bypassing) store and load: no builtin carries sc0 sc1 on a dwordx4
+__device__ __forceinline__ void tpo_store16(void * p, u32x4 v) { asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" :: "v"(p), "v"(v) : "memory"); }
+__device__ __forceinline__ u32x4 tpo_load16(const void * p) { u32x4 v; asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(v) : "v"(p) : "memory"); return v; }
 
-__global__ void __launch_bounds__(1024) k_tp_oneshot(const tpo_args a, float * __restrict__ buf, int n) {
-    const int tid = threadIdx.x;
+// seq[0] = all-reduces done, seq[1] = error word, seq[2] = workgroups of the running launch that have finished
+__global__ void __launch_bounds__(256) k_tp_oneshot(const tpo_args a, float * __restrict__ buf, int n) {
+    const int e = (blockIdx.x * 256 + threadIdx.x) * 4;              // this thread's four elements (n % 4 == 0: the launcher checks)
     const unsigned s = __hip_atomic_load(a.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
     const int par = (int)(s & 1u);
-    // (1) my partial vector into my slot of every rank's buffer (my own included): system-scope stores, write-through
-    for (int p = 0; p < a.nranks; p++) {
-        float * dst = (float *)(a.peer[p] + tpo_slot_off(a, par, a.rank));
-        for (int i = tid; i < n; i += 1024) __hip_atomic_store(dst + i, buf[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (e < n) {
+        const f32x4 mine = *(const f32x4 *)(buf + e);
+        const u32x4 g0 = { __float_as_uint(mine.x), s, __float_as_uint(mine.y), s }, g1 = { __float_as_uint(mine.z), s, __float_as_uint(mine.w), s };
+        // (1) my four granules into my slot of every rank's buffer (my own included)
+        for (int p = 0; p < a.nranks; p++) {
+            char * dst = a.peer[p] + tpo_slot_off(a, par, a.rank) + (size_t) e * 8;
+            tpo_store16(dst, g0); tpo_store16(dst + 16, g1);
+        }
+        // (2) + (3) everybody's granules of the same elements in MY buffer, summed in rank order
+        f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+        for (int r = 0; r < a.nranks; r++) {
+            const char * src = a.peer[a.rank] + tpo_slot_off(a, par, r) + (size_t) e * 8;
+            u32x4 h0, h1;
+            int spins = 0;
+            for (;;) {
+                h0 = tpo_load16(src); h1 = tpo_load16(src + 16);
+                if (h0.y == s && h0.w == s && h1.y == s && h1.w == s) break;
+                __builtin_amdgcn_s_sleep(1);
+                if (++spins > (1 << 21)) { __hip_atomic_store(a.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+            }
+            const f32x4 v = { __uint_as_float(h0.x), __uint_as_float(h0.z), __uint_as_float(h1.x), __uint_as_float(h1.z) };
+            if (r == 0) acc = v; else { acc.x = acc.x + v.x; acc.y = acc.y + v.y; acc.z = acc.z + v.z; acc.w = acc.w + v.w; }
+        }
+        *(f32x4 *)(buf + e) = acc;
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");                 // system scope: the data is visible before the flag
+    // the last workgroup to finish advances the sequence number: every workgroup of this launch has read it by then
     __syncthreads();
-    // (2) the flags
-    if (tid < a.nranks) __hip_atomic_store((unsigned *)(a.peer[tid] + tpo_flag_off(a, par, a.rank)), s, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    // (3) everybody's flag in MY buffer
-    if (tid < a.nranks) {
-        const unsigned * f = (const unsigned *)(a.peer[a.rank] + tpo_flag_off(a, par, tid));
-        int spins = 0;
-        while (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != s) {
-            __builtin_amdgcn_s_sleep(2);
-            if (++spins > (1 << 22)) { __hip_atomic_store(a.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+    if (threadIdx.x == 0) {
+        const unsigned done = __hip_atomic_fetch_add(a.seq + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (done == gridDim.x - 1) {
+            __hip_atomic_store(a.seq + 2, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(a.seq, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
-    __syncthreads();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
-    // (4) the sum, rank order
-    for (int i = tid; i < n; i += 1024) {
-        float v = __hip_atomic_load((const float *)(a.peer[a.rank] + tpo_slot_off(a, par, 0)) + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        for (int r = 1; r < a.nranks; r++) v = v + __hip_atomic_load((const float *)(a.peer[a.rank] + tpo_slot_off(a, par, r)) + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        buf[i] = v;
-    }
-    if (tid == 0) __hip_atomic_store(a.seq, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-static size_t tpo_bytes(int nranks, size_t max_n) { return ((size_t) 2 * nranks * max_n * 4 + (size_t) 2 * nranks * 4 + 255) & ~(size_t) 255; }
+static size_t tpo_bytes(int nranks, size_t max_n) { return ((size_t) 2 * nranks * max_n * 8 + 255) & ~(size_t) 255; }
 
 // rank's receive buffer; handle64 <- the 64-byte IPC handle the other ranks open (exchange it by any host-side means, e.g. torch.distributed.all_gather)
 extern "C" __attribute__((visibility("default")))
 int cllm_tp_oneshot_create(int rank, int nranks, size_t max_n, void ** out, void * handle64) {
-    if (!out || !handle64 || nranks < 1 || nranks > TPO_MAX_RANKS || rank < 0 || rank >= nranks || max_n == 0) FAIL(CLLM_E_INVALID, "tp_oneshot_create: arguments");
+    if (!out || !handle64 || nranks < 1 || nranks > TPO_MAX_RANKS || rank < 0 || rank >= nranks || max_n == 0 || max_n % 4) FAIL(CLLM_E_INVALID, "tp_oneshot_create: arguments");
     static_assert(sizeof(hipIpcMemHandle_t) == 64, "IPC handle size");
     tp_oneshot * o = new tp_oneshot();
     o->rank = rank; o->nranks = nranks; o->max_n = max_n;
@@ -89,8 +105,8 @@ int cllm_tp_oneshot_create(int rank, int nranks, size_t max_n, void ** out, void
         HIP_TRY(hipIpcGetMemHandle(&h, o->local));
     }
     HIP_TRY(hipMemset(o->local, 0, bytes));
-    HIP_TRY(hipMalloc((void **) &o->seq, 8));
-    HIP_TRY(hipMemset(o->seq, 0, 8));
+    HIP_TRY(hipMalloc((void **) &o->seq, 16));
+    HIP_TRY(hipMemset(o->seq, 0, 16));
     o->err = o->seq + 1;
     HIP_TRY(hipDeviceSynchronize());
     o->peer[rank] = o->local;
@@ -117,12 +133,12 @@ extern "C" __attribute__((visibility("default")))
 int cllm_tp_oneshot_all_reduce_f32(void * os, void * stream, float * buf, size_t n) {
     tp_oneshot * o = (tp_oneshot *) os;
     if (!o || !buf || n == 0) FAIL(CLLM_E_INVALID, "tp_oneshot_all_reduce: null");
-    if (n > o->max_n) return CLLM_E_UNSUPPORTED;                   // a prompt-sized message: the caller takes the ring all-reduce
+    if (n > o->max_n || n % 4 || (((uintptr_t) buf) & 15)) return CLLM_E_UNSUPPORTED;      // a prompt-sized (or unaligned) message: the caller takes the ring all-reduce
     for (int r = 0; r < o->nranks; r++) if (!o->peer[r]) FAIL(CLLM_E_INVALID, "tp_oneshot_all_reduce: cllm_tp_oneshot_connect first");
     tpo_args a;
     for (int r = 0; r < TPO_MAX_RANKS; r++) a.peer[r] = r < o->nranks ? o->peer[r] : nullptr;
     a.rank = o->rank; a.nranks = o->nranks; a.max_n = o->max_n; a.seq = o->seq; a.err = o->err;
-    hipLaunchKernelGGL(k_tp_oneshot, dim3(1), dim3(1024), 0, (hipStream_t) stream, a, buf, (int) n);
+    hipLaunchKernelGGL(k_tp_oneshot, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, (hipStream_t) stream, a, buf, (int) n);
     LAUNCH_CHECK();
     return CLLM_OK;
 }
@@ -145,6 +161,100 @@ int cllm_tp_oneshot_destroy(void * os) {
     for (int r = 0; r < o->nranks; r++) if (o->opened[r] && o->peer[r]) (void) hipIpcCloseMemHandle(o->peer[r]);
     if (o->local) (void) hipFree(o->local);
     if (o->seq) (void) hipFree(o->seq);
+    delete o;
+    return CLLM_OK;
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------------------------------------------------
+// The receive buffers of the all-reduce FUSED into the decode mat-vecs (gemv_tp.hip; kernel forms EPI 4 / PRO 5 of gemv_decode_kernel.h): granules [site][rank][max_n] x 8 bytes
+// per rank, peers mapped through HIP IPC exactly as above; the device-side context the kernels read (peer table, rank, step word, error word) lives in device memory.
+// ---------------------------------------------------------------------------------------------------------------------------------------------------------------
+struct tp_fuse_dev_h { char * peer[16]; int rank, nranks; unsigned max_n, pad; const unsigned * step; unsigned * err; };       // == tp_fuse_dev (gemv_decode_kernel.h)
+struct tp_fused {
+    int rank, nranks, n_sites; size_t max_n;
+    char * local; char * peer[TPO_MAX_RANKS]; bool opened[TPO_MAX_RANKS];
+    unsigned * words;                          // device: [0] step number, [1] error word
+    tp_fuse_dev_h * dev;                       // device copy of the context
+    bool fine_grained;
+};
+__global__ void k_tpf_advance(unsigned * step) { step[0] = step[0] + 1u; }
+
+extern "C" __attribute__((visibility("default")))
+int cllm_tp_fused_create(int rank, int nranks, int n_sites, size_t max_n, void ** out, void * handle64) {
+    if (!out || !handle64 || nranks < 1 || nranks > TPO_MAX_RANKS || rank < 0 || rank >= nranks || n_sites < 1 || max_n == 0 || max_n % 4) FAIL(CLLM_E_INVALID, "tp_fused_create: arguments");
+    tp_fused * o = new tp_fused();
+    o->rank = rank; o->nranks = nranks; o->n_sites = n_sites; o->max_n = max_n;
+    const size_t bytes = ((size_t) n_sites * nranks * max_n * 8 + 255) & ~(size_t) 255;
+    hipError_t e = hipExtMallocWithFlags((void **) &o->local, bytes, hipDeviceMallocFinegrained);      // see cllm_tp_oneshot_create: polling what a REMOTE GPU writes needs fine-grained memory
+    hipIpcMemHandle_t h;
+    if (e == hipSuccess) { e = hipIpcGetMemHandle(&h, o->local); if (e != hipSuccess) { (void) hipFree(o->local); o->local = nullptr; } }
+    o->fine_grained = e == hipSuccess;
+    if (e != hipSuccess) {
+        (void) hipGetLastError();
+        const char * same = getenv("CLLM_TP_ONESHOT_SAME_DEVICE");
+        if (!same || strcmp(same, "1")) { delete o; FAIL(CLLM_E_UNSUPPORTED, "tp_fused_create: fine-grained IPC memory is not available (%s); the coarse-grained fallback is only valid when all ranks share one GPU (CLLM_TP_ONESHOT_SAME_DEVICE=1)", hipGetErrorString(e)); }
+        HIP_TRY(hipMalloc((void **) &o->local, bytes));
+        HIP_TRY(hipIpcGetMemHandle(&h, o->local));
+    }
+    HIP_TRY(hipMemset(o->local, 0, bytes));
+    HIP_TRY(hipMalloc((void **) &o->words, 16));
+    HIP_TRY(hipMemset(o->words, 0, 16));
+    HIP_TRY(hipMalloc((void **) &o->dev, sizeof(tp_fuse_dev_h)));
+    HIP_TRY(hipDeviceSynchronize());
+    o->peer[rank] = o->local;
+    memcpy(handle64, &h, 64);
+    *out = o;
+    return CLLM_OK;
+}
+extern "C" __attribute__((visibility("default")))
+int cllm_tp_fused_connect(void * os, const void * handles) {
+    tp_fused * o = (tp_fused *) os;
+    if (!o || !handles) FAIL(CLLM_E_INVALID, "tp_fused_connect: null");
+    for (int r = 0; r < o->nranks; r++) {
+        if (r == o->rank) continue;
+        hipIpcMemHandle_t h; memcpy(&h, (const char *) handles + 64 * r, 64);
+        void * p = nullptr;
+        HIP_TRY(hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess));
+        o->peer[r] = (char *) p; o->opened[r] = true;
+    }
+    tp_fuse_dev_h hd;
+    memset(&hd, 0, sizeof(hd));
+    for (int r = 0; r < o->nranks; r++) hd.peer[r] = o->peer[r];
+    hd.rank = o->rank; hd.nranks = o->nranks; hd.max_n = (unsigned) o->max_n; hd.step = o->words; hd.err = o->words + 1;
+    HIP_TRY(hipMemcpy(o->dev, &hd, sizeof(hd), hipMemcpyHostToDevice));
+    return CLLM_OK;
+}
+// the device-side context (kernel argument of the EPI 4 / PRO 5 launches), the number of sites and the vector length the buffers hold
+extern "C" __attribute__((visibility("default"))) const void * cllm_tp_fused_dev(void * os) { return os ? (const void *) ((tp_fused *) os)->dev : nullptr; }
+extern "C" __attribute__((visibility("default"))) int cllm_tp_fused_sites(void * os) { return os ? ((tp_fused *) os)->n_sites : 0; }
+extern "C" __attribute__((visibility("default"))) size_t cllm_tp_fused_max_n(void * os) { return os ? ((tp_fused *) os)->max_n : 0; }
+extern "C" __attribute__((visibility("default"))) int cllm_tp_fused_fine_grained(void * os) { return os ? (int) ((tp_fused *) os)->fine_grained : -1; }
+// one step = one pass over the sites: every rank calls it once at the start of every decode step, stream-ordered (capturable)
+extern "C" __attribute__((visibility("default")))
+int cllm_tp_fused_advance(void * os, void * stream) {
+    tp_fused * o = (tp_fused *) os;
+    if (!o) FAIL(CLLM_E_INVALID, "tp_fused_advance: null");
+    hipLaunchKernelGGL(k_tpf_advance, dim3(1), dim3(1), 0, (hipStream_t) stream, o->words);
+    LAUNCH_CHECK();
+    return CLLM_OK;
+}
+extern "C" __attribute__((visibility("default")))
+int cllm_tp_fused_error(void * os) {
+    tp_fused * o = (tp_fused *) os;
+    if (!o) return 1;
+    unsigned e = 0;
+    if (hipMemcpy(&e, o->words + 1, 4, hipMemcpyDeviceToHost) != hipSuccess) return 1;
+    return (int) e;
+}
+extern "C" __attribute__((visibility("default")))
+int cllm_tp_fused_destroy(void * os) {
+    tp_fused * o = (tp_fused *) os;
+    if (!o) return CLLM_OK;
+    for (int r = 0; r < o->nranks; r++) if (o->opened[r] && o->peer[r]) (void) hipIpcCloseMemHandle(o->peer[r]);
+    if (o->local) (void) hipFree(o->local);
+    if (o->words) (void) hipFree(o->words);
+    if (o->dev) (void) hipFree(o->dev);
     delete o;
     return CLLM_OK;
 }

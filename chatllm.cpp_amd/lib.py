@@ -137,6 +137,16 @@ SIGNATURES = {
     "cllm_tp_oneshot_fine_grained": (C.c_int, [_P]),
     "cllm_tp_oneshot_destroy": (C.c_int, [_P]),
     "cllm_llama_set_tp_oneshot": (C.c_int, [_P, _P]),
+    "cllm_tp_fused_create": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_size_t, C.POINTER(C.c_void_p), _P]),
+    "cllm_tp_fused_connect": (C.c_int, [_P, _P]),
+    "cllm_tp_fused_dev": (C.c_void_p, [_P]),
+    "cllm_tp_fused_sites": (C.c_int, [_P]),
+    "cllm_tp_fused_max_n": (C.c_size_t, [_P]),
+    "cllm_tp_fused_fine_grained": (C.c_int, [_P]),
+    "cllm_tp_fused_advance": (C.c_int, [_P, _P]),
+    "cllm_tp_fused_error": (C.c_int, [_P]),
+    "cllm_tp_fused_destroy": (C.c_int, [_P]),
+    "cllm_llama_set_tp_fused": (C.c_int, [_P, _P]),
     "cllm_llama_forward": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, _P]),
     "cllm_llama_decode_greedy": (C.c_int, [_P, C.c_int32, C.c_int, C.c_int, _P]),
     "cllm_llama_decode_fused_logits": (C.c_int, [_P, C.c_int32, C.c_int, _P]),

@@ -44,6 +44,10 @@ class Llama:
         """bind a one-shot all-reduce group (lib cllm_tp_oneshot_create / _connect): one kernel launch per all-reduce, inside the decode graph"""
         _l.check(_l.get().cllm_llama_set_tp_oneshot(self.h, handle), "set_tp_oneshot")
 
+    def set_tp_fused(self, handle):
+        """bind the receive buffers of the fused all-reduce (lib cllm_tp_fused_create / _connect): the decode steps run without all-reduce launches"""
+        _l.check(_l.get().cllm_llama_set_tp_fused(self.h, handle), "set_tp_fused")
+
     def use_graph(self, enable):
         _l.check(_l.get().cllm_llama_use_graph(self.h, 1 if enable else 0), "use_graph")
 

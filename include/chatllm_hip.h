@@ -346,9 +346,10 @@ CLLM_API int  cllm_tp_comm_info(void * comm, int * nranks, int * rank);   /* ncc
 CLLM_API int  cllm_tp_destroy(void * comm);
 CLLM_API int  cllm_tp_all_reduce_f32(void * comm, void * stream, float * buf, size_t n);
 CLLM_API int  cllm_llama_set_tp_comm(cllm_llama * m, void * comm);
-/* One-shot direct-write all-reduce for the decode-sized messages (tp_oneshot.hip): every rank writes its partial vector into a slot of every peer's receive buffer
- * (peer memory mapped through HIP IPC, one process per GPU), raises a flag, waits for everybody's flag in its own buffer and sums the slots in rank order: one kernel
- * launch per all-reduce, inside the captured decode graph.  create -> exchange the 64-byte handles (rank-ordered) by any host-side means -> connect -> bind. */
+/* One-shot direct-write all-reduce for the decode-sized messages (tp_oneshot.hip): every rank writes its partial vector as 8-byte {value, sequence number} granules
+ * (16-byte write-through stores) into a slot of every peer's receive buffer (peer memory mapped through HIP IPC, one process per GPU), polls the granules of all ranks
+ * in its own buffer and sums them in rank order: one kernel launch per all-reduce, no flag and no fence, inside the captured decode graph.
+ * create -> exchange the 64-byte handles (rank-ordered) by any host-side means -> connect -> bind. */
 CLLM_API int  cllm_tp_oneshot_create(int rank, int nranks, size_t max_n, void ** out, void * handle64);
 CLLM_API int  cllm_tp_oneshot_connect(void * os, const void * handles);
 CLLM_API int  cllm_tp_oneshot_all_reduce_f32(void * os, void * stream, float * buf, size_t n);
@@ -356,6 +357,20 @@ CLLM_API int  cllm_tp_oneshot_error(void * os);           /* 1: a flag wait time
 CLLM_API int  cllm_tp_oneshot_fine_grained(void * os);    /* 1: fine-grained (cross-GPU coherent) receive buffer; 0: coarse-grained, only accepted with CLLM_TP_ONESHOT_SAME_DEVICE=1 */
 CLLM_API int  cllm_tp_oneshot_destroy(void * os);
 CLLM_API int  cllm_llama_set_tp_oneshot(cllm_llama * m, void * os);
+/* The all-reduce FUSED into the neighbouring mat-vecs of a single-token step (gemv_tp.hip; nothing in the reference to replace: SplitMethod::Row is a TODO,
+ * src/backend.h:322-327): the o / down projections send their partial rows as granules into every rank's receive buffer, the next RMS_NORM mat-vec gathers and adds them in
+ * rank order -- NO all-reduce launch (a tensor-parallel layer is 5 launches like a single-GPU one).  Receive buffers: n_sites (>= 2 n_layer) x nranks x max_n (>= hidden)
+ * granules per rank; create -> exchange the handles -> connect -> cllm_llama_set_tp_fused.  Prompts (multi-token graphs) keep using the communicator / one-shot / callback. */
+CLLM_API int          cllm_tp_fused_create(int rank, int nranks, int n_sites, size_t max_n, void ** out, void * handle64);
+CLLM_API int          cllm_tp_fused_connect(void * os, const void * handles);
+CLLM_API const void * cllm_tp_fused_dev(void * os);           /* the device-side context the kernels read */
+CLLM_API int          cllm_tp_fused_sites(void * os);
+CLLM_API size_t       cllm_tp_fused_max_n(void * os);
+CLLM_API int          cllm_tp_fused_fine_grained(void * os);  /* as cllm_tp_oneshot_fine_grained */
+CLLM_API int          cllm_tp_fused_advance(void * os, void * stream);   /* next step number: once per decode step on every rank (the runner does it) */
+CLLM_API int          cllm_tp_fused_error(void * os);         /* 1: a granule wait timed out since creation */
+CLLM_API int          cllm_tp_fused_destroy(void * os);
+CLLM_API int          cllm_llama_set_tp_fused(cllm_llama * m, void * os);
 /* run qlen tokens (host int32) at positions n_past..; writes logits[vocab] of the last token to
  * logits_dev (device, may be NULL) and/or logits_host (may be NULL; implies a stream sync).               */
 CLLM_API int  cllm_llama_forward(cllm_llama * m, const int32_t * tokens, int qlen, int n_past, float * logits_dev,

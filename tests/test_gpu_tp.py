@@ -153,6 +153,19 @@ def test_one_shot_all_reduce_between_two_processes_equals_the_gloo_all_reduce(gp
     assert np.array_equal(a["ids"], b["ids"])
 
 
+def test_fused_all_reduce_between_two_processes_equals_the_gloo_all_reduce(gpu, tmp_path):
+    """gemv_tp.hip with two REAL ranks (two processes on this GPU, each other's receive buffers mapped through HIP IPC): the single-token steps run WITHOUT any
+    all-reduce launch -- o / down send their partial rows as {value, step} granules into both ranks' buffers (EPI 4), the next RMS_NORM mat-vec gathers them in
+    rank order (PRO 5) -- eagerly and replayed from the captured graph; every logit of the teacher-forced steps and every free-running id equals the run whose
+    all-reduce is a host round trip over gloo (a two-term sum has one order)."""
+    a = _run_two_ranks(tmp_path, 23, "gloo")
+    b = _run_two_ranks(tmp_path, 23, "fused")
+    assert int(b["fused_error"]) == 0
+    assert np.array_equal(a["logits"].view(np.uint32), b["logits"].view(np.uint32))
+    assert np.array_equal(a["ids"], b["ids"])
+    assert int(b["calls"]) < int(a["calls"])                    # the fused steps made no all-reduce calls (the prompt and the node-by-node steps did)
+
+
 @pytest.mark.parametrize("shape", ["even", "uneven"])
 def test_two_ranks_share_the_gpu_and_all_reduce_over_gloo(gpu, tmp_path, shape):
     """The HIP tensor-parallel path with REAL partial sums: two processes, both on this GPU, each holding one shard of the model; the runner's all-reduce

@@ -74,6 +74,18 @@ def main():
         m.set_tp_oneshot(oneshot)
     else:
         m.set_allreduce(allreduce)
+    fused = None
+    if os.environ.get("TP_WORKER_MODE") == "fused":
+        # the all-reduce fused into the mat-vecs (gemv_tp.hip): prompts and the node-by-node steps keep the gloo callback, the fused single-token steps have no
+        # all-reduce launch at all -- the o / down launches write granules into both processes' receive buffers, the next RMS_NORM launch gathers them
+        fused = C.c_void_p()
+        mine = (C.c_char * 64)()
+        pkg.lib.check(L.cllm_tp_fused_create(rank, world, 2 * cfg["n_layer"], cfg["hidden"], C.byref(fused), mine), "fused_create")
+        gathered = [None] * world
+        dist.all_gather_object(gathered, bytes(mine.raw))
+        pkg.lib.check(L.cllm_tp_fused_connect(fused, b"".join(gathered)), "fused_connect")
+        dist.barrier()
+        m.set_tp_fused(fused)
     prompt = np.random.default_rng(seed).integers(0, cfg["vocab"], 12).astype(np.int32)
     teacher = np.random.default_rng(seed + 1).integers(0, cfg["vocab"], 10).astype(np.int32)
     logits = [m.forward(prompt)]
@@ -81,12 +93,15 @@ def main():
         logits.append(m.forward([int(t)]) if i % 2 == 0 else m.decode_fused_logits(int(t)))
     ids = m.decode_greedy(int(np.argmax(logits[-1])), 8)      # free-running through the fused TP step (eager launches: a host callback cannot be captured)
     err = L.cllm_tp_oneshot_error(oneshot) if oneshot else 0
+    ferr = L.cllm_tp_fused_error(fused) if fused else 0
     if rank == 0:
-        np.savez(out, logits=np.stack(logits), ids=ids, calls=n_calls[0], oneshot_error=err)
+        np.savez(out, logits=np.stack(logits), ids=ids, calls=n_calls[0], oneshot_error=err, fused_error=ferr)
     dist.barrier()                                           # (nobody unmaps a buffer a peer may still write)
     m.close()
     if oneshot:
         pkg.lib.check(L.cllm_tp_oneshot_destroy(oneshot), "oneshot_destroy")
+    if fused:
+        pkg.lib.check(L.cllm_tp_fused_destroy(fused), "fused_destroy")
     dist.barrier()
     dist.destroy_process_group()
 
