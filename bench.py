@@ -665,6 +665,52 @@ def main():
                         m.set_tp_oneshot(osh)
                         allreduce_kind = "one-shot direct-write kernel (fine-grained IPC)" if L.cllm_tp_oneshot_fine_grained(osh) == 1 else "one-shot direct-write kernel (coarse-grained: ranks share one GPU)"
                         log(f"[rank {rank}] decode all-reduces through the {allreduce_kind}; self-check passed")
+                        if os.environ.get("CLLM_TP_FUSED", "1") != "0":
+                            # NO all-reduce launch in the decode steps: o / down send their partial rows as granules into every rank's buffer, the next RMS_NORM mat-vec gathers
+                            # them in rank order (gemv_tp.hip).  Taken only if every rank can set it up AND four greedy steps from the same state give the ids and the logit
+                            # bits of the one-shot path (same rank-order sums) on every rank; otherwise the one-shot kernel stays.  CLLM_TP_FUSED=0: off.
+                            ok2 = torch.ones(1, dtype=torch.int32, device=f"cuda:{local}")
+                            fus = C.c_void_p()
+                            mine2 = (C.c_char * 64)()
+                            try:
+                                pkg.lib.check(L.cllm_tp_fused_create(rank, world, 2 * cfg["n_layer"], cfg["hidden"], C.byref(fus), mine2), "tp_fused_create")
+                            except Exception as e:            # noqa: BLE001
+                                log(f"[rank {rank}] cllm_tp_fused_create failed: {e}")
+                                ok2.zero_()
+                                fus = C.c_void_p()
+                            dist.all_reduce(ok2, op=dist.ReduceOp.MIN)
+                            if int(ok2.item()) == 1:
+                                g2 = [None] * world
+                                dist.all_gather_object(g2, bytes(mine2.raw))
+                                try:
+                                    pkg.lib.check(L.cllm_tp_fused_connect(fus, b"".join(g2)), "tp_fused_connect")
+                                except Exception as e:        # noqa: BLE001
+                                    log(f"[rank {rank}] cllm_tp_fused_connect failed: {e}")
+                                    ok2.zero_()
+                                dist.all_reduce(ok2, op=dist.ReduceOp.MIN)
+                            if int(ok2.item()) == 1:
+                                try:
+                                    probe = np.random.default_rng(4321).integers(0, cfg["vocab"], 8).astype(np.int32)
+                                    t0_ = int(np.argmax(m.forward(probe, n_past=0)))
+                                    ids_a = m.decode_greedy(t0_, 4)
+                                    lg_a = m.debug_read("logits", cfg["vocab"])
+                                    m.forward(probe, n_past=0)
+                                    m.set_tp_fused(fus)
+                                    ids_b = m.decode_greedy(t0_, 4)
+                                    lg_b = m.debug_read("logits", cfg["vocab"])
+                                    if L.cllm_tp_fused_error(fus) or not np.array_equal(ids_a, ids_b) or not np.array_equal(lg_a.view(np.uint32), lg_b.view(np.uint32)):
+                                        log(f"[rank {rank}] fused all-reduce self-check failed (ids {ids_a.tolist()} vs {ids_b.tolist()})")
+                                        ok2.zero_()
+                                except Exception as e:        # noqa: BLE001
+                                    log(f"[rank {rank}] fused all-reduce self-check raised: {e}")
+                                    ok2.zero_()
+                                dist.all_reduce(ok2, op=dist.ReduceOp.MIN)
+                                if int(ok2.item()) == 1:
+                                    allreduce_kind = "fused into the mat-vecs (granules scattered by o / down, gathered by the next RMS_NORM launch; no all-reduce launch)"
+                                    log(f"[rank {rank}] decode all-reduces {allreduce_kind}; self-check against the one-shot path passed")
+                                else:
+                                    m.set_tp_fused(None)
+                                    log(f"[rank {rank}] fused all-reduce not available on every rank: the decode all-reduces stay on the one-shot kernel")
                     else:
                         log(f"[rank {rank}] one-shot all-reduce not available on every rank: the decode all-reduces stay on RCCL")
         if not native and os.environ.get("CLLM_BENCH_TORCH_ALLREDUCE") != "1":

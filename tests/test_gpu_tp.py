@@ -118,15 +118,15 @@ def test_bench_tp_setup_under_torchrun_with_one_rank(gpu):
         assert res["config"]["rccl_ranks"] == 1 and res["config"]["decode_allreduce"]
 
 
-def _run_two_ranks(tmp_path, seed, mode):
+def _run_two_ranks(tmp_path, seed, mode, shape="even"):
     import os
     import socket
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
-    out = str(tmp_path / f"tp_{mode}.npz")
-    env = dict(os.environ, TP_WORKER_MODE=mode, HSA_ENABLE_IPC_MODE_LEGACY="0", CLLM_TP_ONESHOT_SAME_DEVICE="1")      # (both ranks run on the one GPU: the coarse-grained fallback is valid here)
+    out = str(tmp_path / f"tp_{mode}_{shape}.npz")
+    env = dict(os.environ, TP_WORKER_MODE=mode, TP_WORKER_CFG=shape, HSA_ENABLE_IPC_MODE_LEGACY="0", CLLM_TP_ONESHOT_SAME_DEVICE="1")      # (both ranks run on the one GPU: the coarse-grained fallback is valid here)
     procs = [subprocess.Popen([sys.executable, os.path.join(root, "tests", "tp_two_ranks_worker.py"), str(r), "2", str(port), out, str(seed)],
                               stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env) for r in range(2)]
     errs = []
@@ -153,13 +153,15 @@ def test_one_shot_all_reduce_between_two_processes_equals_the_gloo_all_reduce(gp
     assert np.array_equal(a["ids"], b["ids"])
 
 
-def test_fused_all_reduce_between_two_processes_equals_the_gloo_all_reduce(gpu, tmp_path):
+@pytest.mark.parametrize("shape", ["even", "uneven"])
+def test_fused_all_reduce_between_two_processes_equals_the_gloo_all_reduce(gpu, tmp_path, shape):
     """gemv_tp.hip with two REAL ranks (two processes on this GPU, each other's receive buffers mapped through HIP IPC): the single-token steps run WITHOUT any
     all-reduce launch -- o / down send their partial rows as {value, step} granules into both ranks' buffers (EPI 4), the next RMS_NORM mat-vec gathers them in
     rank order (PRO 5) -- eagerly and replayed from the captured graph; every logit of the teacher-forced steps and every free-running id equals the run whose
-    all-reduce is a host round trip over gloo (a two-term sum has one order)."""
-    a = _run_two_ranks(tmp_path, 23, "gloo")
-    b = _run_two_ranks(tmp_path, 23, "fused")
+    all-reduce is a host round trip over gloo (a two-term sum has one order).  "uneven": the Qwen2-style block of the test below (q / k / v biases, NEOX RoPE, a Q8_0
+    down_proj of 89 blocks cut 45 + 44: the scatter form of the 32-element formats)."""
+    a = _run_two_ranks(tmp_path, 23, "gloo", shape)
+    b = _run_two_ranks(tmp_path, 23, "fused", shape)
     assert int(b["fused_error"]) == 0
     assert np.array_equal(a["logits"].view(np.uint32), b["logits"].view(np.uint32))
     assert np.array_equal(a["ids"], b["ids"])
