@@ -588,6 +588,25 @@ extern "C" int cllm_op_mul_mat_id_silu_mul(void * stream, const cllm_tensor * as
                                  b->ne[1] == 1 ? 0 : (int64_t)(b->nb[1] / 4), (const int32_t *) ids->data, (int) n_used, (float *) dst->data, (int64_t)(dst->nb[1] / 4), 1);
 }
 
+// The router of a sparse-MoE block AND the experts' gate / up projections of ONE token in one launch (gemv_moe.hip, EPI 5): cllm_op_moe_router + cllm_op_mul_mat_id_silu_mul
+// without the router launch and without the normalised activation in memory.  x [K] F32 (the block's input), norm_w [K] F32, gate_w [K, E] quantized (the router),
+// as_gu [K, 2F, E] the per-expert interleaved gate / up pack of the SAME type, probs [E] F32 and ids [k] I32 written (for cllm_op_mul_mat_id_combine), dst [F, k] F32.
+// Bit-identical to the two calls.  CLLM_E_UNSUPPORTED (nothing launched): make the two calls.
+extern "C" int cllm_op_moe_router_gate_up(void * stream, const cllm_tensor * x, const cllm_tensor * norm_w, float eps, const cllm_tensor * gate_w, const cllm_tensor * as_gu,
+                                          cllm_tensor * probs, cllm_tensor * ids, cllm_tensor * dst) {
+    if (!x || !norm_w || !gate_w || !as_gu || !probs || !ids || !dst) FAIL(CLLM_E_INVALID, "moe_router_gate_up: null");
+    const int64_t K = gate_w->ne[0], E = gate_w->ne[1], k = ids->ne[0];
+    if (x->type != CLLM_TYPE_F32 || norm_w->type != CLLM_TYPE_F32 || probs->type != CLLM_TYPE_F32 || ids->type != CLLM_TYPE_I32 || dst->type != CLLM_TYPE_F32 ||
+        x->nb[0] != 4 || norm_w->nb[0] != 4 || probs->nb[0] != 4 || ids->nb[0] != 4 || dst->nb[0] != 4) FAIL(CLLM_E_UNSUPPORTED, "moe_router_gate_up: dense F32 vectors, I32 ids");
+    if (x->ne[0] != K || t_nelements(x) != K || norm_w->ne[0] != K || probs->ne[0] != E || t_nelements(probs) != E || t_nelements(ids) != k || as_gu->ne[0] != K || as_gu->ne[2] != E ||
+        as_gu->ne[1] % 2 || dst->ne[0] != as_gu->ne[1] / 2 || dst->ne[1] != k || dst->ne[2] != 1) FAIL(CLLM_E_INVALID, "moe_router_gate_up: shapes (one token)");
+    if (!is_quant_type(gate_w->type) || gate_w->type != as_gu->type || gate_w->ne[2] != 1 || gate_w->ne[3] != 1 || gate_w->nb[1] != cllm_row_size(gate_w->type, K) ||
+        as_gu->nb[1] != cllm_row_size(as_gu->type, K) || as_gu->nb[2] % 16 || dst->nb[1] % 4) return CLLM_E_UNSUPPORTED;
+    if (((uintptr_t) x->data | (uintptr_t) norm_w->data | (uintptr_t) gate_w->data | (uintptr_t) as_gu->data) & 15) return CLLM_E_UNSUPPORTED;
+    return launch_gemv_decode_id_router_silu((hipStream_t) stream, as_gu->type, as_gu->data, as_gu->nb[2], K, as_gu->ne[1], (const float *) x->data, (const float *) norm_w->data, eps,
+                                             gate_w->data, (int) E, (int) k, (float *) probs->data, (int32_t *) ids->data, (float *) dst->data, (int64_t)(dst->nb[1] / 4));
+}
+
 // MUL_MAT_ID(down experts) of ONE token over TWO slots + the tail of the sparse-MoE block (GenericSparseMLP::forward src/layers.cpp:3840-3872) in one launch:
 //   dst[r] = (as[ids[0]][r] . b[:, 0]) * w0 + (as[ids[1]][r] . b[:, 1]) * w1 (+ resid[r]),   w_j = probs[ids[j]] / (probs[ids[0]] + probs[ids[1]])
 // as [K, H, E] quantized, b F32 [K, 2, 1], ids I32 [2, 1], probs F32 [E, 1], resid / dst F32 [H, 1]; dst may be resid itself, nothing else.

@@ -430,6 +430,8 @@ int launch_rope_kv_store(hipStream_t st, float * qkv, int64_t QKV, const int32_t
                          void * k_cache, void * v_cache, int64_t ML);
 int launch_moe_router(hipStream_t st, int wtype, const void * W, int64_t K, int64_t n, const float * px, const float * pw, float eps,
                       float * xnorm, float * probs, int32_t * ids, int k);
+int launch_gemv_decode_id_router_silu(hipStream_t st, int wtype, const void * W, size_t w_expert_bytes, int64_t K, int64_t nrows, const float * px, const float * pw, float eps,
+                                      const void * Wr, int ne, int k, float * probs, int32_t * ids, float * dst, int64_t dst_slot_stride);      // gemv_moe.hip
 int launch_gemv_kq(hipStream_t st, int wtype, const tview & w, const void * act, size_t act_stride, int64_t M, float * dst, int64_t ldd);
 int launch_gemv_kq_id(hipStream_t st, int wtype, const tview & as, const void * act, size_t act_stride, int64_t ne11, const tview & ids, const tview & dst);
 int launch_dense_f16(hipStream_t st, int wtype, const tview & w, const tview & x, const tview & d, const float * resid = nullptr, int64_t ldr = 0, int epi = 0);

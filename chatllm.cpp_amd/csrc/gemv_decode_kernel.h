@@ -9,6 +9,9 @@
 //            EPI 3: MUL_MAT_ID(down experts) of one token with TWO slots + the block's tail (GenericSparseMLP::forward src/layers.cpp:3840-3872): a unit is
 //                   one output row, its two sub-rows are the two picked experts' rows over the two slots' activations;
 //                   dst[r] = (y0[r] * w0 + y1[r] * w1) (+ resid[r]), w = probs[ids] / (probs[ids[0]] + probs[ids[1]])   (pw = probs, ids = the TOP_K output)
+//            EPI 5 (MOE, PRO 1): EPI 1 over the experts picked INSIDE the launch -- every workgroup redoes the block's router behind its RMS_NORM prologue (logits = Wr . act
+//                   by one wave per expert, SOFT_MAX + TOP_K by one wave: EPI 2's code), workgroup (0, 0) publishes probs / ids for the down + combine launch; the
+//                   router launch of its own (6.6 us of a 75 us block) disappears (padd = router weights, xout = probs out, ids = ids OUT, px_slot_stride = experts)
 //            EPI 2: the sparse-MoE router (GenericSparseMLP::forward src/layers.cpp:3792-3830): ONE workgroup; the rows are the experts' logits,
 //                   dst = SOFT_MAX(logits), ids (written) = TOP_K(dst, k = dst_slot_stride), xout = the normalised activation (the experts' input)
 //   tensor parallel, all-reduce FUSED into the neighbouring mat-vecs (gemv_tp.hip; the reference has no tensor parallelism: SplitMethod::Row is a TODO, src/backend.h:322-327):
@@ -86,7 +89,7 @@ __global__ void __launch_bounds__(1024) k_gemv_dec(const float * __restrict__ px
     //  chain records in the dynamic LDS, so that the kernel-argument block and the static LDS of every other instantiation stay what they were: a 16-byte
     //  longer argument block + 8 bytes of static LDS measured +2..4 % on all of them)
     extern __shared__ __attribute__((aligned(16))) char lds[];
-    if constexpr (MOE) {
+    if constexpr (MOE && EPI != 5) {
         int e;
         asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(e) : "s"(ids + blockIdx.y) : "memory");
         W += (unsigned long long)(unsigned) e * w_expert_bytes;
@@ -105,7 +108,7 @@ __global__ void __launch_bounds__(1024) k_gemv_dec(const float * __restrict__ px
 #ifndef GEMV_P
 #define GEMV_P 2
 #endif
-    constexpr int P = (FMT == CLLM_TYPE_Q4_K) ? (GEMV_P + 1) / 2 : GEMV_P, RU = (EPI == 1 || EPI == 3) ? 2 : 1;      // steps of prefetch (a Q4_K step is 16 super-blocks = 2304 B per wave, the others' 64 blocks)
+    constexpr int P = (FMT == CLLM_TYPE_Q4_K) ? (GEMV_P + 1) / 2 : GEMV_P, RU = (EPI == 1 || EPI == 3 || EPI == 5) ? 2 : 1;      // steps of prefetch (a Q4_K step is 16 super-blocks = 2304 B per wave, the others' 64 blocks)
     constexpr bool IS_K = FMT == CLLM_TYPE_Q4_K, IS_Q8 = FMT == CLLM_TYPE_Q8_0, IS_Q41 = FMT == CLLM_TYPE_Q4_1;
     constexpr int KIND = IS_K ? 256 : 32;                           // elements per weight block = activation quantization block
     constexpr int BS = IS_K ? 144 : q32_fmt<IS_K ? CLLM_TYPE_Q4_0 : FMT>::BS;      // bytes per weight block
@@ -158,7 +161,7 @@ __global__ void __launch_bounds__(1024) k_gemv_dec(const float * __restrict__ px
     // tensor parallel (PRO 1, NPRE 1): the all-reduced partial of the previous mat-vec is added to the residual stream here
     // (x + padd feeds the norm; workgroup 0 stores it to xout, a different buffer than px) instead of in a launch of its own
     f32x4 pa = {0, 0, 0, 0}, pa16[(Q16 && PRO == 1 && NPRE == 1) ? 4 : 1];
-    const bool add = PRO == 1 && NPRE == 1 && padd != nullptr;
+    const bool add = PRO == 1 && NPRE == 1 && EPI != 5 && padd != nullptr;        // (EPI 5: padd carries the router's weights)
     if constexpr (PRO == 5) {
         // the all-reduce of the previous o / down projection, folded in: every rank's partial rows wait (or arrive) as granules in this rank's buffer.  Polled BEFORE the
         // weight prefetch goes out (the polls wait with vmcnt(0): behind the prefetch they would drain it anyway) -- a tensor-parallel step is bound by these arrivals
@@ -223,8 +226,10 @@ __global__ void __launch_bounds__(1024) k_gemv_dec(const float * __restrict__ px
         }
         if (++is == S) { is = 0; if (++isub == RU) { isub = 0; ik++; } }
     };
+    if constexpr (EPI != 5) {                                       // (EPI 5: the expert is not known yet -- the first requests go out behind the router, below)
 #pragma unroll
-    for (int p = 0; p < P; p++) issue(p);
+        for (int p = 0; p < P; p++) issue(p);
+    }
     TS(1);
 
     // ---- (3) the activation row: [RMS_NORM * weight | SiLU * up |] quantize -> LDS (act layout of common.h) ----
@@ -358,6 +363,50 @@ __global__ void __launch_bounds__(1024) k_gemv_dec(const float * __restrict__ px
     char * chain = lds + (EPI == 3 ? 2 : 1) * arb + wave_in_wg * CHB;
     const int l16 = lane & 15;
     float acc = 0.0f, gate = 0.0f;
+    if constexpr (EPI == 5) {
+        // ---- the block's router (GenericSparseMLP::forward src/layers.cpp:3792-3830: MUL_MAT(gate) -> SOFT_MAX -> TOP_K), redone by every workgroup: one wave per expert row
+        //      over the activation row just built, the records and chains of the row loop below; then one wave runs k_soft_max's partition and k_top_k's picks ----
+        const int ne = px_slot_stride;
+        const char * Wr = (const char *) padd;
+        float * r_logit = (float *)(lds + arb + 16 * CHB), * r_prob = r_logit + 64;
+        int32_t * r_ids = (int32_t *)(r_prob + 64);
+        for (int row = wave_in_wg; row < ne; row += 16) {
+            float racc = 0.0f;
+            for (int sx = 0; sx < S; sx++) {
+                const int b = IS_K ? 16 * sx + grp : 64 * sx + lane;
+                const bool ok = b < nblk;
+                const char * bp = Wr + (unsigned long long)(unsigned) row * nb01 + __umul24((unsigned)(ok ? b : 0), (unsigned) BS);
+                if (IS_K) {
+                    const u32x4 h = *(const u32x4 *) bp, qa = *(const u32x4 *)(bp + 16 + 32 * j), qb = *(const u32x4 *)(bp + 32 + 32 * j);
+                    q4k_emit4(h, qa, qb, lds, off_d, off_s, ok ? b : 0, ok, L, chain);
+                } else {
+                    u32x4 ra, rb = {0, 0, 0, 0}; uint32_t t, odd, h; u32x4 w0, w1 = {0, 0, 0, 0};
+                    q32_load_raw<IS_K ? CLLM_TYPE_Q4_0 : FMT>(bp, ra, rb, t, odd);
+                    q32_align<IS_K ? CLLM_TYPE_Q4_0 : FMT>(ra, rb, t, odd, h, w0, w1);
+                    q32_emit<IS_K ? CLLM_TYPE_Q4_0 : FMT>(h, w0, w1, lds, off_d, off_s, ok ? b : 0, ok, lane, chain);
+                }
+                wave_lds_fence();
+                if (IS_K) q4k_chain(chain, 8, l16, racc); else q32_chain<IS_K ? CLLM_TYPE_Q4_0 : FMT>(chain, l16, racc);
+                wave_lds_fence();
+            }
+            const float v = chain_finish<IS_K ? 1 : IS_Q41 ? 2 : 0>(racc);
+            if (lane == 0) r_logit[row] = v;
+        }
+        __syncthreads();
+        if (wave_in_wg == 0) {
+            wave_soft_max_plain(r_logit, r_prob, ne, lane);
+            if (lane == 0) top_k_row(r_prob, ne, (int) gridDim.y, r_ids);
+            if (blockIdx.x == 0 && blockIdx.y == 0) {                   // one workgroup publishes for the down + combine launch
+                for (int i = lane; i < ne; i += 64) xout[i] = r_prob[i];
+                if (lane == 0) for (int i = 0; i < (int) gridDim.y; i++) const_cast<int32_t *>(ids)[i] = r_ids[i];
+            }
+        }
+        __syncthreads();
+        W += (unsigned long long)(unsigned) r_ids[blockIdx.y] * w_expert_bytes;
+        dst += (long) blockIdx.y * dst_slot_stride;
+#pragma unroll
+        for (int p = 0; p < P; p++) issue(p);
+    }
     int ck = 0, csub = 0, cs = 0;                                   // consume cursor
     while (ck < nmine) {
 #pragma unroll
@@ -381,7 +430,7 @@ __global__ void __launch_bounds__(1024) k_gemv_dec(const float * __restrict__ px
                 float v = chain_finish<IS_K ? 1 : IS_Q41 ? 2 : 0>(acc);
                 if (ck < nmine) {                                   // wave-uniform; bias / resid come through the scalar cache
                     const int cunit = unit_of(ck), crow = cunit * RU + csub;
-                    if (EPI == 1) {
+                    if (EPI == 1 || EPI == 5) {
                         if (csub == 0) gate = v;
                         else if (lane == 0) dst[cunit] = silu_poly(gate) * v;
                     } else if (EPI == 2) {

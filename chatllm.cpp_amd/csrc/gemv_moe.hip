@@ -51,3 +51,33 @@ int launch_gemv_decode_id_combine(hipStream_t st, int wtype, const void * W, siz
     LAUNCH_CHECK();
     return CLLM_OK;
 }
+
+// The head of a sparse-MoE block AND its experts' gate / up projections for ONE token as one launch (EPI 5 above): RMS_NORM -> MUL -> MUL_MAT(router) -> SOFT_MAX -> TOP_K ->
+// {MUL_MAT_ID(gate), MUL_MAT_ID(up)} -> SiLU -> MUL (GenericSparseMLP::forward src/layers.cpp:3792-3872) -- every workgroup redoes the router behind its norm prologue, slot
+// blockIdx.y streams the rows of expert ids[slot].  probs[ne] / ids[k] are published for the down + combine launch.  W: the per-expert interleaved gate / up pack (rows 2u = gate_u,
+// 2u + 1 = up_u), nrows = 2 F; dst[u + slot * dst_slot_stride].  The same reductions in the same order as the separate launches: bit-identical.  CLLM_E_UNSUPPORTED otherwise.
+int launch_gemv_decode_id_router_silu(hipStream_t st, int wtype, const void * W, size_t w_expert_bytes, int64_t K, int64_t nrows, const float * px, const float * pw, float eps,
+                                      const void * Wr, int ne, int k, float * probs, int32_t * ids, float * dst, int64_t dst_slot_stride) {
+    const int kind = wtype == CLLM_TYPE_Q4_K ? 256 : 32;
+    if (!is_quant_type(wtype) || K % kind || K % 4 || K > 16384 || ne < 1 || ne > 64 || k < 1 || k > ne || nrows <= 0 || nrows % 2 || (nrows / 2) % 8 ||
+        (uint64_t) nrows * (uint64_t) cllm_row_size(wtype, K) >= (1ull << 32) || dst_slot_stride > INT32_MAX) return CLLM_E_UNSUPPORTED;
+    const size_t lds = act_row_bytes(K, kind) + 16 * (size_t)(wtype == CLLM_TYPE_Q4_K ? Q4K_CHAIN_BYTES : Q32_CHAIN_BYTES) + 3 * 64 * sizeof(float);     // + logits, probabilities, ids
+    if (act_row_bytes(K, kind) + 16 * Q32_CHAIN_BYTES + 3 * 64 * sizeof(float) > 160 * 1024) return CLLM_E_UNSUPPORTED;
+    const int64_t units = nrows / 2;
+    int64_t grid = (units + 15) / 16;
+    int64_t cap = device_cu_count() / k; if (cap < 1) cap = 1;
+    if (grid > cap) grid = cap;
+    const int64_t nwaves = grid * 16;
+    const int kfull = (int)(units / nwaves), nrem = (int)(units % nwaves), nblk = (int)(K / kind);
+#define GOX(FMT_, NPRE_) do { \
+        static uint64_t attr = 0; \
+        if (lds > 64 * 1024 && dev_flag_unset(attr)) { HIP_TRY(hipFuncSetAttribute((const void *) k_gemv_dec<FMT_, 1, 5, NPRE_, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); dev_flag_set(attr); } \
+        hipLaunchKernelGGL((k_gemv_dec<FMT_, 1, 5, NPRE_, true>), dim3((unsigned) grid, (unsigned) k), dim3(1024), lds, st, px, pw, (const float *) Wr, (const char *) W, nblk, kfull, nrem, eps, dst, probs, \
+                           (const float *) nullptr, (const float *) nullptr, (unsigned long long *) nullptr, (const int32_t *) ids, (unsigned long long) w_expert_bytes, ne, (int) dst_slot_stride); } while (0)
+#define GOXT(FMT_) do { if (K <= 4096) GOX(FMT_, 1); else GOX(FMT_, 4); } while (0)
+    if (wtype == CLLM_TYPE_Q4_K) GOXT(CLLM_TYPE_Q4_K); else if (wtype == CLLM_TYPE_Q4_0) GOXT(CLLM_TYPE_Q4_0); else if (wtype == CLLM_TYPE_Q4_1) GOXT(CLLM_TYPE_Q4_1); else GOXT(CLLM_TYPE_Q8_0);
+#undef GOXT
+#undef GOX
+    LAUNCH_CHECK();
+    return CLLM_OK;
+}

@@ -508,11 +508,13 @@ struct fused_attn {
 //   {MUL_MAT_ID gate, MUL_MAT_ID up} -> UNARY(SILU) -> MUL     one token: cllm_op_mul_mat_id_silu_mul over the per-expert interleaved pack
 struct fused_moe { const ggml_tensor * experts = nullptr, * probs = nullptr, * ids = nullptr, * resid = nullptr; int down = -1; /* the MUL_MAT_ID node folded into the launch */ };
 //   RMS_NORM -> MUL(weight) -> {MUL_MAT(router) -> SOFT_MAX -> TOP_K, experts}     one token: cllm_op_moe_router (launched at the TOP_K node)
-struct moe_router { const ggml_tensor * x = nullptr, * w = nullptr, * gate = nullptr, * xnorm = nullptr, * probs = nullptr; float eps = 0; };
+struct moe_router { const ggml_tensor * x = nullptr, * w = nullptr, * gate = nullptr, * xnorm = nullptr, * probs = nullptr; float eps = 0;
+                    int itk = -1; std::vector<int> xn_users, out_users; };      // itk: the TOP_K node; who else reads the normalised activation / the probabilities and ids (end nodes behind no-op views)
 //   prefill (>= cllm_mul_mat_ex_min_cols() columns): RMS_NORM -> MUL -> {MUL_MAT ...} (norm in the quantizer; further projections of the same activation reuse
 //   the act rows), UNARY(SILU) -> MUL -> MUL_MAT (SiLU * up in the quantizer), MUL_MAT -> ADD (residual in the epilogue): cllm_op_mul_mat_ex at the MUL_MAT node
 struct pf_mm { int pro = 0; const ggml_tensor * x = nullptr, * w2 = nullptr; float eps = 0; const ggml_tensor * resid = nullptr, * out = nullptr; };
-struct moe_gate_up { int mul = -1, gate = -1, up = -1, unary = -1; void * W = nullptr; };      // node indices; W: the pack, resolved before the walk
+struct moe_gate_up { int mul = -1, gate = -1, up = -1, unary = -1; void * W = nullptr; int router = -1; };      // node indices; W: the pack, resolved before the walk;
+                                                                                                                  // router: the block's router folded into this launch (cllm_op_moe_router_gate_up)
 //   MUL_MAT(K, Q) SCALE DIAG_MASK_INF SOFT_MAX MUL_MAT(V^T, P)   with more than 32 query rows (the tolerance tier of the MFMA mat-muls):
 //                                                    cllm_op_attn_prefill, one flash kernel in place of the V.P node; the scores never reach HBM
 struct fused_fa { int ikq = -1, n_past = 0; float scale = 1.0f; bool alias = false; size_t bytes = 0; };   // alias: dst overlaps q (ggml-alloc reuses the dead q block): staged
@@ -968,6 +970,15 @@ fuse_plan make_plan(ggml_cgraph * g) {
                 if (later(i) && later(ism)) {
                     moe_router R; R.x = a->src[0]; R.w = b; R.gate = ggml_graph_node(g, imm)->src[0]; R.xnorm = t; R.probs = ggml_graph_node(g, ism);
                     memcpy(&R.eps, a->op_params, 4);
+                    R.itk = itk;
+                    std::function<void(int, std::vector<int> &)> ends = [&](int j, std::vector<int> & out) {      // the end consumers of node j behind no-op views
+                        for (int u : users[j]) {
+                            if (u == imm || u == ism || u == itk) continue;
+                            const ggml_tensor * c = ggml_graph_node(g, u);
+                            if (c->op == GGML_OP_RESHAPE || c->op == GGML_OP_VIEW || c->op == GGML_OP_PERMUTE || c->op == GGML_OP_TRANSPOSE) ends(u, out); else out.push_back(u);
+                        }
+                    };
+                    ends(i, R.xn_users); ends(ism, R.out_users); ends(itk, R.out_users);
                     P.skip[ir] = P.skip[i] = P.skip[imm] = P.skip[ism] = 1;
                     P.alt[itk] = ALT_MOE_ROUTER; P.moe[itk] = (int) P.routers.size(); P.routers.push_back(R);
                     continue;
@@ -1204,6 +1215,22 @@ ggml_status be_graph_compute(ggml_backend_t backend, ggml_cgraph * g) {
         if (!G.W) continue;
         plan.skip[G.gate] = plan.skip[G.up] = 1;            // (the UNARY is skipped already)
         plan.alt[G.mul] = ALT_MOE_GATE_UP; plan.moe[G.mul] = (int)(&G - plan.gus.data());
+        // the block's router into the same launch (one launch less per sparse-MoE block): the experts read the ids of a router launch whose normalised activation feeds nothing but
+        // that router and these two MUL_MAT_IDs, router and experts share one weight type, and whatever else reads the probabilities / ids runs after this node (or is itself fused away)
+        static const bool fold = !getenv("CLLM_HIP_MOE_FOLD") || atoi(getenv("CLLM_HIP_MOE_FOLD")) != 0;
+        const ggml_tensor * gm = ggml_graph_node(g, G.gate);
+        for (size_t ri = 0; fold && ri < plan.routers.size(); ri++) {
+            moe_router & R = plan.routers[ri];
+            if (R.itk < 0 || plan.skip[R.itk] || plan.alt[R.itk] != ALT_MOE_ROUTER || ggml_graph_node(g, R.itk) != gm->src[2] || R.gate->type != gm->src[0]->type) continue;
+            const ggml_tensor * act = gm->src[1];
+            while (act != R.xnorm && (act->op == GGML_OP_RESHAPE || act->op == GGML_OP_VIEW) && act->src[0] && act->src[0]->data == act->data) act = act->src[0];
+            if (act != R.xnorm || ggml_nelements(gm->src[1]) != R.xnorm->ne[0]) continue;
+            bool ok = R.xn_users.size() == 2 && ((R.xn_users[0] == G.gate && R.xn_users[1] == G.up) || (R.xn_users[0] == G.up && R.xn_users[1] == G.gate));
+            for (int u : R.out_users) if (u != G.gate && u != G.up && !plan.skip[u] && u <= G.mul) ok = false;
+            if (!ok) continue;
+            G.router = (int) ri; plan.skip[R.itk] = 1;
+            break;
+        }
     }
     int merged = 0, launches = 0;
     // one walk over the nodes; sw != nullptr: serialize the calls instead of making them (same decisions, same host-side state changes)
@@ -1300,6 +1327,17 @@ ggml_status be_graph_compute(ggml_backend_t backend, ggml_cgraph * g) {
                 const ggml_tensor * gm = ggml_graph_node(g, G.gate);
                 cllm_tensor dw = desc(gm->src[0]), dx = desc(gm->src[1]), di = desc(gm->src[2]);
                 dw.ne[1] *= 2; dw.nb[2] *= 2; dw.nb[3] = dw.nb[2] * (size_t) dw.ne[2]; dw.data = G.W;
+                if (G.router >= 0) {
+                    const moe_router & R = plan.routers[G.router];
+                    cllm_tensor rx = desc(R.x), rw = desc(R.w), rg = desc(R.gate), rn = desc(R.xnorm), rp = desc(R.probs), rt = desc(ggml_graph_node(g, R.itk));
+                    const int64_t K = R.xnorm->ne[0];
+                    for (cllm_tensor * v : { &rx, &rw, &rn }) { v->ne[0] = K; v->ne[1] = v->ne[2] = v->ne[3] = 1; v->nb[1] = v->nb[2] = v->nb[3] = (size_t) K * 4; }
+                    rc = CALL(cllm_op_moe_router_gate_up, st, &rx, &rw, R.eps, &rg, &dw, &rp, &rt, &d);
+                    if (rc == CLLM_E_UNSUPPORTED) {              // the two launches it replaces
+                        rc = CALL(cllm_op_moe_router, st, &rx, &rw, R.eps, &rg, &rn, &rp, &rt);
+                        if (rc == CLLM_OK) rc = CALL(cllm_op_mul_mat_id_silu_mul, st, &dw, &dx, &di, &d);
+                    }
+                } else
                 rc = CALL(cllm_op_mul_mat_id_silu_mul, st, &dw, &dx, &di, &d);
             } else if (plan.alt[i] == ALT_SILU_MUL || plan.alt[i] == ALT_MUL_SILU) {
                 const bool a_is_silu = plan.alt[i] == ALT_SILU_MUL;

@@ -112,6 +112,7 @@ SIGNATURES = {
     "cllm_op_moe_combine": (C.c_int, [_P, _T, _T, _T, _T, _T]),
     "cllm_op_mul_mat_id_combine": (C.c_int, [_P, _T, _T, _T, _T, _T, _T]),
     "cllm_op_moe_router": (C.c_int, [_P, _T, _T, C.c_float, _T, _T, _T, _T]),
+    "cllm_op_moe_router_gate_up": (C.c_int, [_P, _T, _T, C.c_float, _T, _T, _T, _T, _T]),
     "cllm_op_silu_mul": (C.c_int, [_P, _T, _T, _T]),
     "cllm_op_set_rows": (C.c_int, [_P, _T, _T, _T]),
     "cllm_op_cpy": (C.c_int, [_P, _T, _T]),

@@ -220,6 +220,19 @@ def moe_router(x, norm_w, eps, gate_w, k):
     return xnorm, probs, ids
 
 
+def moe_router_gate_up(x, norm_w, eps, gate_w, as_gate, as_up, k):
+    """router + the experts' gate / up / SiLU / MUL of one token in ONE launch: (probs, ids, g) -- the bits of moe_router followed by mul_mat_id_silu_mul"""
+    L = _l.get()
+    K, F, E = as_gate.ne[0], as_gate.ne[1], as_gate.ne[2]
+    packed = Tensor(as_gate.type, [K, 2 * F, E])
+    srcs = (C.c_void_p * 2)(as_gate.data_ptr().value, as_up.data_ptr().value)
+    rows = (C.c_int64 * 2)(F * E, F * E)
+    _l.check(L.cllm_pack_rows(None, packed.data_ptr(), srcs, rows, 2, as_gate.nb[1], 1), "pack_rows")
+    probs = Tensor(F32, [E]); ids = Tensor(I32, [k]); dst = Tensor(F32, [F, k, 1])
+    _l.check(L.cllm_op_moe_router_gate_up(None, _ref(x), _ref(norm_w), float(eps), _ref(gate_w), _ref(packed), _ref(probs), _ref(ids), _ref(dst)), "moe_router_gate_up")
+    return probs, ids, dst
+
+
 def moe_combine(experts, probs, ids, resid=None, dst=None):
     """GenericSparseMLP's tail: normalized top-k weights applied to the expert outputs, summed over the slots (+ residual)"""
     dst = dst or Tensor(F32, [experts.ne[0], experts.ne[2]])

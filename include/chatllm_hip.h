@@ -285,6 +285,12 @@ CLLM_API int cllm_op_moe_combine(void * stream, const cllm_tensor * experts, con
  * CLLM_E_UNSUPPORTED = use those. */
 CLLM_API int cllm_op_mul_mat_id_combine(void * stream, const cllm_tensor * as, const cllm_tensor * b, const cllm_tensor * ids, const cllm_tensor * probs,
                                         const cllm_tensor * resid, cllm_tensor * dst);
+/* the head of a sparse-MoE block AND its experts' gate / up projections for ONE token in one launch (GenericSparseMLP::forward, src/layers.cpp:3792-3872: RMS_NORM -> MUL ->
+ * MUL_MAT(gate.weight) -> SOFT_MAX -> TOP_K -> {MUL_MAT_ID(gate), MUL_MAT_ID(up)} -> SiLU -> MUL): cllm_op_moe_router + cllm_op_mul_mat_id_silu_mul without the router launch --
+ * every workgroup redoes the router behind its norm prologue.  x / norm_w F32 [K], gate_w [K, E] and as_gu [K, 2F, E] (per-expert interleaved pack) of ONE quantized type,
+ * probs F32 [E] and ids I32 [k] written, dst F32 [F, k].  Bit-identical to the two calls; CLLM_E_UNSUPPORTED = make them. */
+CLLM_API int cllm_op_moe_router_gate_up(void * stream, const cllm_tensor * x, const cllm_tensor * norm_w, float eps, const cllm_tensor * gate_w, const cllm_tensor * as_gu,
+                                        cllm_tensor * probs, cllm_tensor * ids, cllm_tensor * dst);
 /* the head of a sparse-MoE block for ONE token (GenericSparseMLP::forward, src/layers.cpp:3792-3830: the post-attention RMS_NORM -> MUL, the
  * router MUL_MAT(gate.weight), SOFT_MAX, TOP_K) in one launch: xnorm F32 [K] (the experts' input; may be x itself), probs F32 [n_expert <= 64],
  * ids I32 [k].  gate_w: dense quantized [K <= 16384, n_expert].  Bit-identical to the node sequence; CLLM_E_UNSUPPORTED = use the separate ops. */

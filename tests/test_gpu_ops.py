@@ -683,6 +683,24 @@ def test_moe_router_equals_the_node_sequence(gpu, t, K, ne, k):
     assert np.array_equal(got_ids.numpy().reshape(-1), ic)
 
 
+@pytest.mark.parametrize("t,K,F,E,k", [(O.Q4_K, 4096, 1024, 8, 2), (O.Q4_K, 256, 64, 8, 2), (O.Q8_0, 512, 264, 4, 2), (O.Q4_0, 1024, 512, 16, 3), (O.Q4_1, 256, 64, 60, 6),
+                                       (O.Q4_K, 8192, 128, 33, 4), (O.Q4_K, 4096, 14336, 8, 2)])
+def test_moe_router_gate_up_equals_the_two_launches(gpu, t, K, F, E, k):
+    """cllm_op_moe_router_gate_up (the router redone inside the experts' gate / up launch: one launch less per sparse-MoE block) = cllm_op_moe_router followed by
+    cllm_op_mul_mat_id_silu_mul on its outputs: probabilities, ids and SiLU(gate) * up of every slot, bit for bit"""
+    ops, T = gpu.ops, gpu.Tensor
+    wr = T.from_numpy(rand_blocks(t, E, K, rng, d_scale=0.05), t, [K, E])
+    wg = T.from_numpy(rand_blocks(t, F * E, K, rng), t, [K, F, E])
+    wu = T.from_numpy(rand_blocks(t, F * E, K, rng), t, [K, F, E])
+    x = T.from_numpy((rng.standard_normal(K) * 1.7).astype(np.float32)); g = T.from_numpy((1.0 + 0.1 * rng.standard_normal(K)).astype(np.float32))
+    xn, pr, ids = ops.moe_router(x, g, 1e-5, wr, k)
+    want = ops.mul_mat_id_silu_mul(wg, wu, xn.view([K, 1, 1], [4, 4 * K, 4 * K]), ids.view([k, 1], [4, 4 * k])).numpy()
+    gp, gi, gd = ops.moe_router_gate_up(x, g, 1e-5, wr, wg, wu, k)
+    assert np.array_equal(gp.numpy().view(np.uint32).reshape(-1), pr.numpy().view(np.uint32).reshape(-1))
+    assert np.array_equal(gi.numpy().reshape(-1), ids.numpy().reshape(-1))
+    assert np.array_equal(gd.numpy().view(np.uint32).reshape(-1), want.view(np.uint32).reshape(-1))
+
+
 @pytest.mark.parametrize("t,K,H,E,with_resid", [(O.Q4_K, 14336, 4096, 8, True), (O.Q4_K, 512, 256, 8, False), (O.Q8_0, 512, 264, 4, True), (O.Q4_0, 1024, 100, 8, True),
                                                 (O.Q4_1, 4096, 512, 3, False), (O.Q4_K, 20480, 64, 4, True)])
 def test_mul_mat_id_combine_equals_the_two_launches(gpu, t, K, H, E, with_resid):
