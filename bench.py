@@ -737,7 +737,7 @@ def main():
         pkg.ops.sync()
 
     prompt = np.random.default_rng(1234).integers(0, cfg["vocab"], args.n_prompt).astype(np.int32)
-    logits = m.forward(prompt)
+    logits = m.forward(prompt, n_past=0)          # (the tensor-parallel self-checks above may have moved the position)
     tok = int(np.argmax(logits))
     if args.warmup > 0:
         tok = int(m.decode_greedy(tok, args.warmup)[-1])

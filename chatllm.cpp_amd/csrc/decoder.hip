@@ -174,8 +174,10 @@ extern "C" int cllm_llama_set_tp_fused(cllm_llama * m, void * os) {
     if (!m) FAIL(CLLM_E_INVALID, "null");
     if (os && (cllm_tp_fused_sites(os) < 2 * m->cfg.n_layer || cllm_tp_fused_max_n(os) < (size_t) m->cfg.hidden))
         FAIL(CLLM_E_INVALID, "llama_set_tp_fused: the buffers hold %d sites of %zu values, the model needs %d of %d", cllm_tp_fused_sites(os), cllm_tp_fused_max_n(os), 2 * m->cfg.n_layer, m->cfg.hidden);
-    if (m->decode_graph) { (void) hipGraphExecDestroy(m->decode_graph); m->decode_graph = nullptr; }
+    if (m->decode_graph) { (void) hipGraphExecDestroy(m->decode_graph); m->decode_graph = nullptr; }            // (captured with the other form of the all-reduce)
+    if (m->decode_graph_long) { (void) hipGraphExecDestroy(m->decode_graph_long); m->decode_graph_long = nullptr; }
     m->tp_fused = os;
+    m->fused_warm = m->fused_warm_long = false;       // the next step runs eagerly once more (the new launches set their function attributes outside a capture)
     return CLLM_OK;
 }
 extern "C" int cllm_tp_all_reduce_f32(void * comm, void * stream, float * buf, size_t n);
