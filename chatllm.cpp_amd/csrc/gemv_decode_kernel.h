@@ -278,10 +278,40 @@ __global__ void __launch_bounds__(1024) k_gemv_dec(const float * __restrict__ px
         vv[0].x = vv[0].x + pa.x; vv[0].y = vv[0].y + pa.y; vv[0].z = vv[0].z + pa.z; vv[0].w = vv[0].w + pa.w;
         if (blockIdx.x == 0 && e0 < K) *(f32x4 *)(xout + e0) = vv[0];
     }
+#ifndef GEMV_SCALE1
+#define GEMV_SCALE1 1       // 1 = ONE wave adds the 16 partial sums and derives the scale; the other 15 wait at a second barrier instead of redoing ~90 instructions each
+                            // (qkv 6.3 -> 6.1 us, decode +0.4 %: profiles/r05_prologue_scale_one_wave.txt; 0 = every wave redoes it)
+#endif
     if (PRO == 1) {
         __shared__ double part[16];
+        if constexpr (GEMV_SCALE1 && NPRE == 1) {
+            __shared__ float scale_w;
+            double sum = 0.0;
+            if (e0 < K) { const f32x4 v = vv[0]; sum += (double)(v.x * v.x); sum += (double)(v.y * v.y); sum += (double)(v.z * v.z); sum += (double)(v.w * v.w); }
+            sum = wave_sum_d(sum);
+            if (lane == 0) part[tid >> 6] = sum;
+            lds_barrier();
+            if (tid < 64) {
+                double tot = part[0];
+#pragma unroll
+                for (int w = 1; w < 16; w++) tot += part[w];
+                const float m = rms_mean(tot, K);
+                const double dl = tot * ((double)(2 * (int64_t) K + 16) * 0x1p-53);
+                const bool amb = !(rms_mean(tot - dl, K) == rms_mean(tot + dl, K));
+                if (tid == 0) scale_w = amb ? __int_as_float(0x7fc00000) : 1.0f / sqrtf(m + eps);
+            }
+            lds_barrier();
+            scale = scale_w;
+            if (scale != scale) {                                       // the rare ambiguous row (uniform): the reference's serial sum by wave 0 (rms_scale's fallback)
+                __syncthreads();
+                if (tid < 64) { const double ss = rms_serial_sumsq<false>(px, add ? padd : nullptr, K); if (tid == 0) part[0] = ss; }
+                __syncthreads();
+                scale = 1.0f / sqrtf(rms_mean(part[0], K) + eps);
+            }
+        } else {
         const double sum = NPRE == 1 ? rms_block_sumsq_1024_one(vv[0], e0 < K, part) : rms_block_sumsq_1024(px, K, vv[0], part);
         scale = rms_scale(sum, K, eps, px, add ? padd : nullptr, part);
+        }
     }
     if constexpr (PRO == 5) {
         // rms_block_sumsq_1024's order over the values in registers (x is not in memory: it is px + the gathered partials); rms_scale's interval test, and for the rare
