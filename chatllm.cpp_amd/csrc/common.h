@@ -452,4 +452,8 @@ int launch_gemv_decode_id(hipStream_t st, int wtype, const void * W, size_t w_ex
                           const int32_t * ids, int n_slots, float * dst, int64_t dst_slot_stride, int epi = 0);
 int attn_long_threshold();      // decoder.hip: cached positions above which the split (3-launch) attention is used
 int launch_rope_kv_attn_decode(hipStream_t st, const float * qkv, const int32_t * pos_dev, int nh, int nkv, int hd, int mode, float freq_base, uint16_t * k_cache, uint16_t * v_cache, int64_t ML, float * att);
+int launch_argmax_partial(hipStream_t st, const float * logits, int n, float * part_v, int * part_i);
+int launch_argmax_final_next(hipStream_t st, const float * part_v, const int * part_i, int np, int32_t * tok_dev, int32_t * pos_dev, int32_t * out_ring, int32_t * counter,
+                             int etype, const void * emb, size_t emb_nb1, int H, float * x_next, int hd, float freq_base, float * cs);
+int launch_gemv_rows_argmax(hipStream_t st, const void * W, int64_t K, int64_t nrows, const float * px, const float * pw, float eps, float * dst, float * part_v, int * part_i, int * np);
 int launch_argmax_advance(hipStream_t st, const float * logits, int n, int32_t * tok_dev, int32_t * pos_dev, int32_t * out_ring, int32_t * counter, float * part_v, int * part_i);

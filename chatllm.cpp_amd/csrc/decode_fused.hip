@@ -10,6 +10,7 @@
 #include "common.h"
 #include "quant_dev.h"
 #include "q4k.h"
+#include "dequant.h"
 
 #include <math.h>
 
@@ -533,6 +534,56 @@ __global__ void __launch_bounds__(256) k_argmax_final(const float * __restrict__
         out_ring[counter[0]] = idx;
         counter[0] = counter[0] + 1;
     }
+}
+// The second stage AND the head of the NEXT step in one launch (the runner's greedy loop: one workgroup is on the chip anyway): the token's embedding row (GET_ROWS,
+// dequant_elem: the bits of k_get_rows) into x_next and the cos / sin table of position pos + 1 (k_rope_table's code, by the last wave while thread 0 finishes the reduce).
+// A decode step then is [layers] [lm_head + first stage] [this]: three launches fewer than get_rows, rope_table, ..., lm_head, partial, final.
+__global__ void __launch_bounds__(1024) k_argmax_final_next(const float * __restrict__ pv, const int * __restrict__ pi, int np, int32_t * __restrict__ tok_dev,
+                                                            int32_t * __restrict__ pos_dev, int32_t * __restrict__ out_ring, int32_t * __restrict__ counter,
+                                                            int etype, const char * __restrict__ emb, size_t emb_nb1, int H, float * __restrict__ x_next,
+                                                            int half, float theta_scale, float * __restrict__ cs) {
+    __shared__ float bv[16]; __shared__ int bi[16]; __shared__ int tok_s;
+    const int tid = threadIdx.x;
+    const int pos_next = pos_dev[0] + 1;              // (read by everybody BEFORE the barrier thread 0 stores behind)
+    float best = -INFINITY; int idx = 0x7fffffff;
+    for (int i = tid; i < np; i += 1024) argmax_combine(best, idx, pv[i], pi[i]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) argmax_combine(best, idx, __shfl_xor(best, o, 64), __shfl_xor(idx, o, 64));
+    if ((tid & 63) == 0) { bv[tid >> 6] = best; bi[tid >> 6] = idx; }
+    __syncthreads();
+    if (tid == 0) {
+        for (int w = 1; w < 16; w++) argmax_combine(best, idx, bv[w], bi[w]);
+        if (idx == 0x7fffffff) idx = 0;
+        tok_s = idx;
+        tok_dev[0] = idx;                 // next step's input token
+        pos_dev[0] = pos_next;            // and its position
+        out_ring[counter[0]] = idx;
+        counter[0] = counter[0] + 1;
+    }
+    if (cs && tid >= 960)
+        for (int i = tid - 960; i < half; i += 64) {
+            float theta = (float) pos_next;
+            for (int k = 0; k < i; k++) theta *= theta_scale;        // iterated fp32 multiplication, ops.cpp:5639-5650
+            float c, s_;
+            rope_cos_sin(theta, &c, &s_);
+            cs[2*i] = c * 1.0f; cs[2*i + 1] = s_ * 1.0f;
+        }
+    __syncthreads();
+    const char * row = emb + (size_t) tok_s * emb_nb1;
+    for (int c = tid; c < H; c += 1024) x_next[c] = dequant_elem(etype, row, c);
+}
+int launch_argmax_partial(hipStream_t st, const float * logits, int n, float * part_v, int * part_i) {
+    hipLaunchKernelGGL(k_argmax_partial, dim3(256), dim3(256), 0, st, logits, n, part_v, part_i);
+    LAUNCH_CHECK();
+    return CLLM_OK;
+}
+// hd == 0: no cos / sin table (head sizes the compact attention kernel does not take)
+int launch_argmax_final_next(hipStream_t st, const float * part_v, const int * part_i, int np, int32_t * tok_dev, int32_t * pos_dev, int32_t * out_ring, int32_t * counter,
+                             int etype, const void * emb, size_t emb_nb1, int H, float * x_next, int hd, float freq_base, float * cs) {
+    hipLaunchKernelGGL(k_argmax_final_next, dim3(1), dim3(1024), 0, st, part_v, part_i, np, tok_dev, pos_dev, out_ring, counter, etype, (const char *) emb, emb_nb1, H, x_next,
+                       hd / 2, hd ? powf(freq_base, -2.0f / hd) : 0.0f, hd ? cs : (float *) nullptr);
+    LAUNCH_CHECK();
+    return CLLM_OK;
 }
 __global__ void __launch_bounds__(256) k_argmax_publish(const float * __restrict__ pv, const int * __restrict__ pi, int np, int32_t * __restrict__ tok_dev,
                                                         int32_t * __restrict__ tok_host, int32_t * const * __restrict__ inc, int n_inc) {

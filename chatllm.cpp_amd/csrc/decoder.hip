@@ -504,19 +504,28 @@ extern "C" int cllm_llama_forward(cllm_llama * m, const int32_t * tokens, int ql
 // ggml_vec_dot_f16's order -- the same bits -- so the threshold is purely a speed matter: the measured crossover is ~400-500 cached positions.
 int attn_long_threshold() { static const int v = getenv("CLLM_ATTN_LONG") ? atoi(getenv("CLLM_ATTN_LONG")) : 512; return v < 64 ? 64 : v; }
 
-static int decode_step_fused(cllm_llama * m, bool sample, bool long_ctx) {
+// the head of a step: the token's embedding row into m->x and the cos / sin table of its position.  The greedy loop runs it ONCE, in front of its first step: every sampled
+// step ends with k_argmax_final_next, which prepares both for the step after it (CLLM_DECODE_FOLD=0: every step starts with its own head, as before round 5)
+static bool decode_fold() { static const bool v = !(getenv("CLLM_DECODE_FOLD") && atoi(getenv("CLLM_DECODE_FOLD")) == 0); return v; }
+static int decode_head(cllm_llama * m) {
+    const cllm_llama_config & c = m->cfg;
+    const int64_t H = c.hidden, hd = c.head_dim, V = c.vocab;
+    cllm_tensor E = T(m->tok_embd.type, m->tok_embd.data, H, V), ids = T(CLLM_TYPE_I32, m->tokens_dev, 1), X = T(CLLM_TYPE_F32, m->x, H, 1);
+    TRY(cllm_op_get_rows(m->st, &E, &ids, &X));
+    // cos/sin of this step's position, once per token instead of once per head and layer (head sizes the compact kernel takes)
+    if (hd == 64 || hd == 128) TRY(launch_rope_table(m->st, m->pos_dev, (int) hd, c.rope_theta, (float *)(m->counter_dev + 16 + 512)));
+    return CLLM_OK;
+}
+
+// head == false (sampled steps of the greedy loop): x and the table were prepared by the previous step's last launch (or by decode_head in front of the loop)
+static int decode_step_fused(cllm_llama * m, bool sample, bool long_ctx, bool head = true) {
     const cllm_llama_config & c = m->cfg;
     const int64_t H = c.hidden, hd = c.head_dim, QD = (int64_t) m->nh * hd, KD = (int64_t) m->nkv * hd, F = m->F, V = c.vocab, ML = c.max_len;
     hipStream_t st = m->st;
     const bool tp = tp_on(m);
-    {
-        cllm_tensor E = T(m->tok_embd.type, m->tok_embd.data, H, V), ids = T(CLLM_TYPE_I32, m->tokens_dev, 1), X = T(CLLM_TYPE_F32, m->x, H, 1);
-        TRY(cllm_op_get_rows(st, &E, &ids, &X));
-    }
-    // cos/sin of this step's position, once per token instead of once per head and layer (head sizes the compact kernel takes)
+    if (head) TRY(decode_head(m));
     float * rope_cs = (float *)(m->counter_dev + 16 + 512);
     const bool cs_table = (hd == 64 || hd == 128);
-    if (cs_table) TRY(launch_rope_table(st, m->pos_dev, (int) hd, c.rope_theta, rope_cs));
     // 5 launches per layer: [norm+quant+qkv GEMV(+bias)] [rope+kv-write+attention] [quant+o GEMV+residual]
     //                       [norm+quant+gate/up GEMV+silu*up] [quant+down GEMV+residual]
     // Tensor parallel: o / down write partial sums to m->o, all-reduced in place; the residual add x += o is folded into the NEXT
@@ -587,8 +596,24 @@ static int decode_step_fused(cllm_llama * m, bool sample, bool long_ctx) {
             pend = m->o;
         }
     }
+    float * part_v = (float *)(m->counter_dev + 16); int * part_i = (int *)(m->counter_dev + 16 + 256);
+    if (sample && !head) {
+        // lm_head with the sampler's first stage in its epilogue (k_gemv_rows EPI 2: the values are still in registers) when that kernel takes the launch, then the second
+        // stage + the next step's head as one launch
+        int np = 256, rc = CLLM_E_UNSUPPORTED;
+        if (pend_site < 0 && !pend && m->lm_head.type == CLLM_TYPE_Q4_K)
+            rc = launch_gemv_rows_argmax(st, m->lm_head.data, H, V, xc, (const float *) m->out_norm.data, c.rms_eps, m->logits, part_v, part_i, &np);
+        if (rc == CLLM_E_UNSUPPORTED) {
+            TRY(norm_gemv(m->lm_head, V, (const float *) m->out_norm.data, 0, m->logits, nullptr));
+            TRY(launch_argmax_partial(st, m->logits, (int) V, part_v, part_i));
+            np = 256;
+        } else if (rc) return rc;
+        TRY(launch_argmax_final_next(st, part_v, part_i, np, m->tokens_dev, m->pos_dev, m->out_ring, m->counter_dev, m->tok_embd.type, m->tok_embd.data,
+                                     cllm_row_size(m->tok_embd.type, H), (int) H, m->x, cs_table ? (int) hd : 0, c.rope_theta, rope_cs));
+        return CLLM_OK;
+    }
     TRY(norm_gemv(m->lm_head, V, (const float *) m->out_norm.data, 0, m->logits, nullptr));
-    if (sample) TRY(launch_argmax_advance(st, m->logits, (int) V, m->tokens_dev, m->pos_dev, m->out_ring, m->counter_dev, (float *)(m->counter_dev + 16), (int *)(m->counter_dev + 16 + 256)));
+    if (sample) TRY(launch_argmax_advance(st, m->logits, (int) V, m->tokens_dev, m->pos_dev, m->out_ring, m->counter_dev, part_v, part_i));
     return CLLM_OK;
 }
 
@@ -607,7 +632,7 @@ static int ensure_decode_graph(cllm_llama * m, bool long_ctx) {
     if (slot || !m->use_graph || (m->cfg.tp_size > 1 && !m->tp_comm && !m->tp_oneshot && !m->tp_fused)) return CLLM_OK;     // a host callback cannot be captured; RCCL, the one-shot kernel and the fused form can
     hipGraph_t graph = nullptr;
     HIP_TRY(hipStreamBeginCapture(m->st, hipStreamCaptureModeRelaxed));
-    const int rc = decode_step_fused(m, true, long_ctx);
+    const int rc = decode_step_fused(m, true, long_ctx, !decode_fold());
     const hipError_t e = hipStreamEndCapture(m->st, &graph);
     hipError_t ei = hipSuccess;
     if (!rc && e == hipSuccess) ei = hipGraphInstantiate(&slot, graph, nullptr, nullptr, 0);
@@ -660,17 +685,19 @@ extern "C" int cllm_llama_decode_greedy(cllm_llama * m, int32_t first_token, int
         HIP_TRY(hipStreamSynchronize(m->st));
         TRY(ensure_scores(m, (size_t) m->nh * m->cfg.max_len * 3 / 2 + 64));
         const int thr = attn_long_threshold();
+        const bool fold = decode_fold();
+        if (fold) TRY(decode_head(m));                             // the first step's head; every step prepares the next one's
         for (int s = 0; s < n_steps; s++) {
             const bool lng = n_past + s + 1 > thr;                 // cached positions this step attends to
             bool & warm = lng ? m->fused_warm_long : m->fused_warm;
             if (!warm) {                                           // one eager step sets every function attribute before the capture
-                TRY(decode_step_fused(m, true, lng)); warm = true; HIP_TRY(hipStreamSynchronize(m->st));
+                TRY(decode_step_fused(m, true, lng, !fold)); warm = true; HIP_TRY(hipStreamSynchronize(m->st));
                 continue;
             }
             TRY(ensure_decode_graph(m, lng));
             hipGraphExec_t ge = lng ? m->decode_graph_long : m->decode_graph;
             if (ge) HIP_TRY(hipGraphLaunch(ge, m->st));
-            else TRY(decode_step_fused(m, true, lng));
+            else TRY(decode_step_fused(m, true, lng, !fold));
         }
         HIP_TRY(hipMemcpyAsync(out_tokens_host, m->out_ring, (size_t) n_steps * 4, hipMemcpyDeviceToHost, m->st));
         HIP_TRY(hipStreamSynchronize(m->st));

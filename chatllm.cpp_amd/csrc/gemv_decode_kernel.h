@@ -67,7 +67,10 @@ __device__ __forceinline__ f32x4 tpf_gather4(const tp_fuse_dev * cx, const char 
             h0 = tpf_load16(src); h1 = tpf_load16(src + 16);
             if (h0.y == step && h0.w == step && h1.y == step && h1.w == step) break;
             __builtin_amdgcn_s_sleep(1);
-            if (++spins > (1 << 21)) { __hip_atomic_store(cx->err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+            // (bounded, and a time-out anywhere ends every later wait at its next look: a dead peer costs one time-out, not one per slot and launch)
+            if ((++spins & 1023) == 0 && (spins > (1 << 21) || __hip_atomic_load(cx->err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+                __hip_atomic_store(cx->err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break;
+            }
         }
         const f32x4 v = { __uint_as_float(h0.x), __uint_as_float(h0.z), __uint_as_float(h1.x), __uint_as_float(h1.z) };
         if (r == 0) acc = v; else { acc.x = acc.x + v.x; acc.y = acc.y + v.y; acc.z = acc.z + v.z; acc.w = acc.w + v.w; }

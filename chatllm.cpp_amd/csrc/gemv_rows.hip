@@ -122,7 +122,7 @@ __global__ void __launch_bounds__(1024) k_gemv_rows(const float * __restrict__ p
         }
     }
     __syncthreads();
-    if (nmine == 0) return;
+    if (EPI != 2 && nmine == 0) return;                               // (EPI 2: every wave meets the barriers of the arg-max tail)
 
     // ---- (4) stream the rows ----
     const int j = lane & 7;
@@ -140,6 +140,7 @@ __global__ void __launch_bounds__(1024) k_gemv_rows(const float * __restrict__ p
     typedef __attribute__((address_space(3))) const u32x4 * lptr4;
 
     float acc = 0.0f, accm = 0.0f;
+    float bestv = -INFINITY; int besti = 0x7fffffff;                  // EPI 2: the largest value this lane has stored and its row (first maximum wins)
     int cq = 0, cu = 0, cs = 0;                                       // consume cursor: slot ordinal, unit ordinal, slot of the unit
     while (cq < total) {
         // wait for slot cq: slots issued after it = min(iq, total) - cq - 1, three DMA instructions each
@@ -199,7 +200,7 @@ __global__ void __launch_bounds__(1024) k_gemv_rows(const float * __restrict__ p
             } else {
                 const int row = unit * RPW + rowg;
                 const bool st = RPW == 8 ? j == 0 : (lane & 15) == 0;
-                if (bias || resid) {                                  // the unit's RPW values through the scalar cache: their own counter, no wait on the DMA stream
+                if (EPI != 2 && (bias || resid)) {                    // the unit's RPW values through the scalar cache: their own counter, no wait on the DMA stream
                     float bsel = 0.0f, rsel = 0.0f;
 #pragma unroll
                     for (int q = 0; q < RPW; q++) {
@@ -210,21 +211,40 @@ __global__ void __launch_bounds__(1024) k_gemv_rows(const float * __restrict__ p
                     if (resid) v = v + rsel;
                 }
                 if (st) dst[row] = v;
+                if (EPI == 2 && st && (v > bestv || (v == bestv && row < besti))) { bestv = v; besti = row; }
             }
             acc = 0.0f; accm = 0.0f; cs = 0; cu++;
+        }
+    }
+    if constexpr (EPI == 2) {
+        // the greedy sampler's first stage (k_argmax_partial, decode_fused.hip) on the values still in registers: (value, row) of this workgroup's largest logit, lowest row
+        // on ties, NaN never wins -- a total order, so the partition of the rows over lanes, waves and workgroups does not matter.  bias / resid carry the two output arrays.
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ov = __shfl_xor(bestv, o, 64); const int oi = __shfl_xor(besti, o, 64);
+            if (ov > bestv || (ov == bestv && oi < besti)) { bestv = ov; besti = oi; }
+        }
+        __syncthreads();                                              // every wave has consumed its last slot and the activation row: the LDS is free
+        float * lv = (float *) lds; int * li = (int *)(lds + 64);
+        if (lane == 0) { lv[wave] = bestv; li[wave] = besti; }
+        __syncthreads();
+        if (tid == 0) {
+            for (int w = 1; w < 16; w++) { const float ov = lv[w]; const int oi = li[w]; if (ov > bestv || (ov == bestv && oi < besti)) { bestv = ov; besti = oi; } }
+            ((float *) bias)[blockIdx.x] = bestv; ((int *) resid)[blockIdx.x] = besti;
         }
     }
 }
 
 // K % (256 * 2 * (8 / RPW)) == 0, nrows % RPW == 0, rows 16-byte aligned; CLLM_E_UNSUPPORTED: k_gemv_dec takes the launch
-int launch_gemv_rows(hipStream_t st, const void * W, int64_t K, int64_t nrows, int pro, const float * px, const float * pw, float eps, int epi, float * dst,
-                     const float * bias, const float * resid) {
+static int gemv_rows_go(hipStream_t st, const void * W, int64_t K, int64_t nrows, int pro, const float * px, const float * pw, float eps, int epi, float * dst,
+                        const float * bias, const float * resid, int * grid_out) {
     // 0: off; 1 (default): only where it measured faster than k_gemv_dec -- many rows per CU (lm_head: 78 -> 62 us; gate/up and the small
     // projections are a draw or slower: one unit per wave leaves no steady state); 2: everything it can take; 8 / 4: that too, with RPW forced
     static const int mode = getenv("CLLM_GEMV_ROWS") ? atoi(getenv("CLLM_GEMV_ROWS")) : 1;
     if (!mode || K % 256 || pro < 1 || pro > 4 || nrows <= 0 || (uint64_t) nrows * (uint64_t)(K / 256 * 144) >= (1ull << 32)) return CLLM_E_UNSUPPORTED;
     if (K > ((pro == 2 || pro == 4) ? 32768 : 16384)) return CLLM_E_UNSUPPORTED;
     if (epi == 1 && (pro != 1 || bias || resid)) return CLLM_E_UNSUPPORTED;
+    if (epi == 2 && (pro != 1 || !bias || !resid)) return CLLM_E_UNSUPPORTED;
     const int nblk = (int)(K / 256), cus = device_cu_count();
     if (mode == 1 && nrows / 8 < 32 * (int64_t) cus) return CLLM_E_UNSUPPORTED;
     int rpw = mode == 8 || mode == 4 ? mode : (nrows / 8 >= 8 * (int64_t) cus ? 8 : 4);      // RPW 8 from 8 waves per CU on
@@ -233,6 +253,7 @@ int launch_gemv_rows(hipStream_t st, const void * W, int64_t K, int64_t nrows, i
     if (epi == 1 && nrows % (2 * rpw)) return CLLM_E_UNSUPPORTED;
     const int nunits = (int)(nrows / rpw);
     int grid = nunits < cus ? nunits : cus;
+    if (epi == 2 && grid > 256) return CLLM_E_UNSUPPORTED;          // (the partial arrays hold 256 entries)
     const size_t lds = act_row_bytes(K, 256) + 16 * (size_t) ROWS_NS * ROWS_SLOT_BYTES;
     if (lds > 159 * 1024) return CLLM_E_UNSUPPORTED;      // (+ the prologue's static 128 bytes)
     const int npre = K <= 4096 ? 1 : K <= 16384 ? 4 : 8;
@@ -242,6 +263,7 @@ int launch_gemv_rows(hipStream_t st, const void * W, int64_t K, int64_t nrows, i
         hipLaunchKernelGGL((k_gemv_rows<PRO_, EPI_, NPRE_, RPW_>), dim3((unsigned) grid), dim3(1024), lds, st, px, pw, (const char *) W, nblk, nunits, eps, dst, bias, resid); } while (0)
 #define GOP(RPW_) do { \
         if (pro == 1 && epi == 1) { if (npre == 1) GOR(1, 1, 1, RPW_); else GOR(1, 1, 4, RPW_); } \
+        else if (pro == 1 && epi == 2) { if (npre == 1) GOR(1, 2, 1, RPW_); else GOR(1, 2, 4, RPW_); } \
         else if (pro == 1)        { if (npre == 1) GOR(1, 0, 1, RPW_); else GOR(1, 0, 4, RPW_); } \
         else if (pro == 2)        { if (npre == 1) GOR(2, 0, 1, RPW_); else if (npre == 4) GOR(2, 0, 4, RPW_); else GOR(2, 0, 8, RPW_); } \
         else if (pro == 4)        { if (npre == 1) GOR(4, 0, 1, RPW_); else if (npre == 4) GOR(4, 0, 4, RPW_); else GOR(4, 0, 8, RPW_); } \
@@ -250,5 +272,17 @@ int launch_gemv_rows(hipStream_t st, const void * W, int64_t K, int64_t nrows, i
 #undef GOP
 #undef GOR
     LAUNCH_CHECK();
+    if (grid_out) *grid_out = grid;
     return CLLM_OK;
+}
+int launch_gemv_rows(hipStream_t st, const void * W, int64_t K, int64_t nrows, int pro, const float * px, const float * pw, float eps, int epi, float * dst,
+                     const float * bias, const float * resid) {
+    if (epi != 0 && epi != 1) return CLLM_E_UNSUPPORTED;
+    return gemv_rows_go(st, W, K, nrows, pro, px, pw, eps, epi, dst, bias, resid, nullptr);
+}
+// dst = W . quantize(RMS_NORM(px) * pw) AND the greedy sampler's first stage in the same launch: part_v[b] / part_i[b] = the largest of workgroup b's rows and its index
+// (b < *np <= 256: the arrays k_argmax_final reduces).  CLLM_E_UNSUPPORTED: launch the mat-vec and k_argmax_partial separately.
+int launch_gemv_rows_argmax(hipStream_t st, const void * W, int64_t K, int64_t nrows, const float * px, const float * pw, float eps, float * dst, float * part_v, int * part_i, int * np) {
+    if (!part_v || !part_i || !np || nrows > INT32_MAX) return CLLM_E_UNSUPPORTED;
+    return gemv_rows_go(st, W, K, nrows, 1, px, pw, eps, 2, dst, (const float *) part_v, (const float *) part_i, np);
 }

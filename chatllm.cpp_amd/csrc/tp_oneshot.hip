@@ -62,7 +62,10 @@ __global__ void __launch_bounds__(256) k_tp_oneshot(const tpo_args a, float * __
                 h0 = tpo_load16(src); h1 = tpo_load16(src + 16);
                 if (h0.y == s && h0.w == s && h1.y == s && h1.w == s) break;
                 __builtin_amdgcn_s_sleep(1);
-                if (++spins > (1 << 21)) { __hip_atomic_store(a.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+                // bounded: a peer that never delivers costs ONE time-out, not one per slot and launch -- once the error word is up every later wait gives up at its next look
+                if ((++spins & 1023) == 0 && (spins > (1 << 21) || __hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+                    __hip_atomic_store(a.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break;
+                }
             }
             const f32x4 v = { __uint_as_float(h0.x), __uint_as_float(h0.z), __uint_as_float(h1.x), __uint_as_float(h1.z) };
             if (r == 0) acc = v; else { acc.x = acc.x + v.x; acc.y = acc.y + v.y; acc.z = acc.z + v.z; acc.w = acc.w + v.w; }

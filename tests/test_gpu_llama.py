@@ -377,6 +377,36 @@ def test_decode_greedy_loop_matches_stepwise(gpu):
     b.close()
 
 
+@pytest.mark.parametrize("hidden,vocab", [(512, 65536 + 8 * 37), (1024, 70000)])
+def test_decode_greedy_with_the_sampler_inside_the_lm_head_launch(gpu, hidden, vocab):
+    """a vocabulary large enough for k_gemv_rows to take the lm_head (>= 32 units of 8 rows per CU): the greedy loop then runs the sampler's first stage in that launch's epilogue
+    (EPI 2) and the second stage + the next step's embedding row and cos / sin table as one launch (k_argmax_final_next).  Same ids as token-by-token forward + numpy argmax, and the
+    last step's logits bit for bit; ties: half of the lm_head rows are duplicates of the other half, so EVERY maximum is a tie and the lower row must win"""
+    cfg = gpu.synth.config("tiny", max_len=64, hidden=hidden, n_head=hidden // 64, n_kv_head=2, ffn=1024, vocab=vocab)
+    w = gpu.synth.make_model(cfg, O.Q4_K, seed=21)
+    t_lm, lm = w["lm_head"]
+    half = vocab // 2
+    shape = lm.shape
+    lm = lm.reshape(vocab, -1).copy()
+    lm[half:2 * half] = lm[:half]
+    w["lm_head"] = (t_lm, lm.reshape(shape))
+    prompt = np.random.default_rng(21).integers(0, vocab, 6).astype(np.int32)
+    a = gpu.Llama(cfg, w)
+    first = int(np.argmax(a.forward(prompt)))
+    toks, last = [first], None
+    for _ in range(12):
+        last = a.forward([toks[-1]])
+        toks.append(int(np.argmax(last)))
+    assert all(t < half for t in toks)
+    b = gpu.Llama(cfg, w)
+    b.forward(prompt)
+    got = list(b.decode_greedy(first, 7)) + list(b.decode_greedy(toks[7], 5))
+    assert got == toks[1:]
+    assert np.array_equal(b.debug_read("logits", vocab).view(np.uint32), np.asarray(last, np.float32).reshape(-1).view(np.uint32))
+    a.close()
+    b.close()
+
+
 def test_context_overflow_and_bad_tokens_are_rejected(gpu):
     cfg = gpu.synth.config("tiny", max_len=8)
     m = gpu.Llama(cfg, gpu.synth.make_model(cfg, O.Q8_0))
