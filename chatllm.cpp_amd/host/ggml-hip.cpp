@@ -1450,6 +1450,15 @@ ggml_status be_graph_compute(ggml_backend_t backend, ggml_cgraph * g) {
                 ok = cur_sets[k].ptr == A.pred[k].ptr && cur_sets[k].val == (A.pred[k].ptr == A.ids_ptr ? A.tok_host[0] : A.pred[k].val);
             if (ok) { ahead_hit = true; A.hits++; A.misses = 0; }
             else {
+                static const bool adbg = getenv("CLLM_HIP_AHEAD_DEBUG") != nullptr;
+                if (adbg) {
+                    HIPB_LOG("ahead: MISS graph_exec=%d sig_equal=%d (sig %zu bytes, captured %zu) sets %zu predicted %zu", (int)(c->graph_exec != nullptr), (int)(sig == c->graph_sig), sig.size(), c->graph_sig.size(), cur_sets.size(), A.pred.size());
+                    for (size_t k = 0; k < cur_sets.size() && k < A.pred.size(); k++) {
+                        const int32_t want = A.pred[k].ptr == A.ids_ptr ? A.tok_host[0] : A.pred[k].val;
+                        if (cur_sets[k].ptr != A.pred[k].ptr || cur_sets[k].val != want)
+                            HIPB_LOG("ahead:   set %zu: host wrote %p = %d, predicted %p = %d%s", k, cur_sets[k].ptr, (int) cur_sets[k].val, A.pred[k].ptr, (int) want, A.pred[k].ptr == A.ids_ptr ? " (token id)" : "");
+                    }
+                }
                 if (++A.misses >= 2) { A.skip_until = A.graphs + 64; A.misses = 0; }
                 cllm_stream_sync(st);              // the step that ran ahead is not the one asked for: let it finish, then put the host's scalars in place (buf_set held them back)
                 for (const auto & ss : cur_sets) if (cllm_memcpy_h2d((void *) ss.ptr, &ss.val, 4, nullptr) != CLLM_OK) { HIPB_LOG("scalar write failed: %s", cllm_last_error()); return GGML_STATUS_FAILED; }

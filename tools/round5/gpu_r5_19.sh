@@ -10,6 +10,6 @@ cd ../..
 grep "^decode:" /tmp/mx_err.txt | tee -a $O/summary.txt
 grep -c "replayed from the captured" /tmp/mx_err.txt | tee -a $O/summary.txt
 grep "launch list differs" /tmp/mx_err.txt | sort | uniq -c | sort -rn | head -12 | tee -a $O/summary.txt
-grep "ahead:" /tmp/mx_err.txt | sort | uniq -c | sort -rn | head -6 | tee -a $O/summary.txt
+grep "ahead:" /tmp/mx_err.txt | grep -v "ok=1" | head -30 | tee -a $O/summary.txt
 grep "per graph\|replayed from a captured\|capture failed" /tmp/mx_err.txt | tail -4 | tee -a $O/summary.txt
 head -c 20000 /tmp/mx_err.txt > $O/err_head.txt
