@@ -222,6 +222,23 @@ __device__ __forceinline__ int uniform_load_i32(const int32_t * p) {
     return v;
 }
 
+#ifndef ATTN_FORCE_SERIAL_SUM
+#define ATTN_FORCE_SERIAL_SUM 0      // (test builds: 1 = always take the serial order)
+#endif
+// the soft_max's total in the reference's order (ggml_vec_soft_max_f32: group sums of 8 as floats, added one by one in double, then the leftovers): lane 0, broadcast
+static __device__ __noinline__ double soft_sum_serial(const float * e, int nv, int n) {
+    double sum = 0.0;
+    if ((threadIdx.x & 63) == 0) {
+        for (int gi = 0; gi < nv; gi += 8) {
+            const f32x4 lo = *(const f32x4 *)(e + gi), up = *(const f32x4 *)(e + gi + 4);
+            const float a0 = lo.x + up.x, a1 = lo.y + up.y, a2 = lo.z + up.z, a3 = lo.w + up.w;
+            sum += (double)((a0 + a2) + (a1 + a3));
+        }
+        for (int i = nv; i < n; i++) sum += (double) e[i];
+    }
+    return lane_d(sum, 0);
+}
+
 template <int HD, int MODE, int PARTS>      // MODE 0: adjacent pairs (GGML_ROPE_TYPE_NORMAL), 2: NEOX halves; PARTS: workgroups per head (each redoes RoPE, scores and
                                             // soft_max -- the same bits -- and takes 1 / PARTS of the V.P rows: one row per 16-lane group instead of two)
 __global__ void __launch_bounds__(1024) k_attn_dec(const float * __restrict__ qkv, const int32_t * __restrict__ pos_dev, const float * __restrict__ rope_cs,
@@ -229,7 +246,6 @@ __global__ void __launch_bounds__(1024) k_attn_dec(const float * __restrict__ qk
                                                    int ML, float * __restrict__ att, unsigned long long * ts) {
 #define TS(k) do { if (ts && threadIdx.x == 0) ts[(blockIdx.y * gridDim.x + blockIdx.x) * 8 + (k)] = wall_clock64(); } while (0)
     extern __shared__ __attribute__((aligned(16))) float sm[];       // [HD] q (fp16-rounded) | [HD] new k | [HD] new v | [n_kv] scores
-    __shared__ double red_d[1];
     __shared__ float  red_f[16];
     constexpr int half = HD / 2, off = MODE == 0 ? 1 : half, U = 4;
     const int r2 = gridDim.x, g = blockIdx.y, h = g * r2 + blockIdx.x;
@@ -288,31 +304,41 @@ __global__ void __launch_bounds__(1024) k_attn_dec(const float * __restrict__ qk
     }
 
     TS(1);
-    // ---- (4) scores[i] = K[i] . q * scale ----
-    for (int ib = ib0; ib < n_kv; ib += U * 64) {
-        uint32_t r[U][NCH];
+    // ---- (4) scores[i] = K[i] . q * scale.  Small code on purpose (a launch starts with a cold instruction cache): the cached rows i < pos in one branch-free loop body,
+    //          the batch in registers on entry (the first one was requested at kernel entry), the next one requested behind the math; the new row (pos: in LDS, the cache
+    //          write may not have landed) by one 16-lane group afterwards, in the same order ----
+    {
+        float qv[NCH][2];
 #pragma unroll
-        for (int u = 0; u < U; u++) {
-            const int i0 = ib + u * 64;
-#pragma unroll
-            for (int i = 0; i < NCH; i++) {
-                r[u][i] = kr0[u][i];
-                if (ib != ib0) r[u][i] = *(const uint32_t *)(k_cache + (int64_t)(i0 < pos ? i0 : 0) * KD + g * HD + 32 * i + 2 * c16);
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < U; u++) {
-            const int i0 = ib + u * 64;
-            if (i0 >= n_kv) continue;                                     // whole 16-lane rows drop out together
+        for (int i = 0; i < NCH; i++) { qv[i][0] = qs[32 * i + 2 * c16]; qv[i][1] = qs[32 * i + 2 * c16 + 1]; }
+        if (wave == 15 && sub == 3) {                                     // the new row first: its operands are in LDS, the cached rows may still be in flight
             float a0 = 0.0f, a1 = 0.0f;
 #pragma unroll
-            for (int i = 0; i < NCH; i++) {
-                const int e = 32 * i + 2 * c16;
-                const float k0 = i0 == pos ? knew[e] : h2f((uint16_t)(r[u][i] & 0xffff)), k1 = i0 == pos ? knew[e + 1] : h2f((uint16_t)(r[u][i] >> 16));
-                a0 = __builtin_fmaf(k0, qs[e], a0); a1 = __builtin_fmaf(k1, qs[e + 1], a1);
-            }
+            for (int i = 0; i < NCH; i++) { a0 = __builtin_fmaf(knew[32 * i + 2 * c16], qv[i][0], a0); a1 = __builtin_fmaf(knew[32 * i + 2 * c16 + 1], qv[i][1], a1); }
             const float v = vd32_reduce(a0, a1);
-            if (c16 == 0) sc[i0] = v * scale;                             // the SCALE node
+            if (c16 == 0) sc[pos] = v * scale;
+        }
+#pragma clang loop unroll(disable)
+        for (int ib = ib0; ib < pos; ib += U * 64) {
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const int i0 = ib + u * 64;
+                float a0 = 0.0f, a1 = 0.0f;
+#pragma unroll
+                for (int i = 0; i < NCH; i++) {
+                    a0 = __builtin_fmaf(h2f((uint16_t)(kr0[u][i] & 0xffff)), qv[i][0], a0); a1 = __builtin_fmaf(h2f((uint16_t)(kr0[u][i] >> 16)), qv[i][1], a1);
+                }
+                const float v = vd32_reduce(a0, a1);
+                if (c16 == 0 && i0 < pos) sc[i0] = v * scale;             // the SCALE node
+            }
+            if (ib + U * 64 < pos) {
+#pragma unroll
+                for (int u = 0; u < U; u++) {
+                    const int i0 = ib + (U + u) * 64;
+#pragma unroll
+                    for (int i = 0; i < NCH; i++) kr0[u][i] = *(const uint32_t *)(k_cache + (int64_t)(i0 < pos ? i0 : 0) * KD + g * HD + 32 * i + 2 * c16);
+                }
+            }
         }
     }
     lds_barrier();
@@ -339,7 +365,7 @@ __global__ void __launch_bounds__(1024) k_attn_dec(const float * __restrict__ qk
 #pragma unroll
     for (int w = 1; w < 16; w++) mx = fmaxf(mx, red_f[w]);
     // every exponential is independent: all threads compute them (the groups of 8 through the AVX2 polynomial, the n_kv mod 8 leftovers through
-    // expf, as ggml_vec_soft_max_f32 does); only the SUM keeps the reference's order (one wave, lane = groups of 8 -> double; leftovers last)
+    // expf, as ggml_vec_soft_max_f32 does); the total is one wave's (lane = groups of 8 -> double; leftovers last)
     const int nv = n_kv & ~7;
     for (int i = tid; i < n_kv; i += 1024) sc[i] = i < nv ? ggml_expf_poly(sc[i] - mx) : libm_expf(sc[i] - mx);
     lds_barrier();
@@ -352,15 +378,23 @@ __global__ void __launch_bounds__(1024) k_attn_dec(const float * __restrict__ qk
         }
         if (lane == 0) for (int i = nv; i < n_kv; i++) sum += (double) sc[i];
         sum = wave_sum_d(sum);
-        if (lane == 0) red_d[0] = sum;
+        // ORDER.  The reference adds the group sums serially in double (vec.cpp:547-); this is a tree.  Two double sums of the same m positive terms differ by at most
+        // (m + log2 m) 2^-53 of their value, and so do their reciprocals: the float the reciprocal rounds to can depend on the order only if it lies within that distance
+        // of a rounding boundary -- its low 29 mantissa bits within (m + 16) of 2^28.  Proved per row here (as rms_scale does for RMS_NORM); otherwise lane 0 redoes the
+        // sum in the reference's order (about one row in 2^20)
+        double rinv = 1.0 / sum;
+        const int low = (int)((unsigned long long) __double_as_longlong(rinv) & 0x1fffffffull) - 0x10000000;
+        if ((low < 0 ? -low : low) <= (n_kv >> 3) + 24 || ATTN_FORCE_SERIAL_SUM) rinv = 1.0 / soft_sum_serial(sc, nv, n_kv);
+        if (lane == 0) red_f[0] = (float) rinv;                       // (every thread read the maxima before the barrier above)
     }
     lds_barrier();
-    const float inv = (float)(1.0 / red_d[0]);
+    const float inv = red_f[0];
     for (int i = tid; i < n_kv; i += 1024) sc[i] = h2f(f2h(sc[i] * inv));   // probability, then its fp16 rounding for V.P
     lds_barrier();
     TS(3);
 
-    // ---- (6) ctx = V . P: chunks of 32 cached positions in order, then the n_kv mod 32 leftovers in double (products staged in LDS) ----
+    // ---- (6) ctx = V . P: chunks of 32 cached positions in order, then the n_kv mod 32 leftovers in double (products staged in LDS).  Small code: one body per chunk,
+    //          the first 8 chunks from vc0 (requested at kernel entry), the next 8 from vc1 (requested behind the scores), a plain loop beyond ----
     float * tailp = sc + ML + (wave * 4 + sub) * 32;
     const int ntail = n_kv - np;
 #pragma unroll
@@ -369,25 +403,25 @@ __global__ void __launch_bounds__(1024) k_attn_dec(const float * __restrict__ qk
         const uint16_t * vr = v_cache + ((int64_t) g * HD + d0) * ML;
         const float vfresh = vnew[d0];
         float a0 = 0.0f, a1 = 0.0f;
+        auto chunk = [&](uint32_t w, int ci) {
+            const int e = 32 * ci + 2 * c16;
+            typedef float f32x2_t __attribute__((ext_vector_type(2)));
+            const f32x2_t pr = *(const f32x2_t *)(sc + e);
+            const float v0 = e == pos ? vfresh : h2f((uint16_t)(w & 0xffff)), v1 = e + 1 == pos ? vfresh : h2f((uint16_t)(w >> 16));
+            a0 = __builtin_fmaf(v0, pr.x, a0); a1 = __builtin_fmaf(v1, pr.y, a1);
+        };
 #pragma unroll
-        for (int i = 0; i < VPF; i++) {
-            if (i < nch) {
-                const int e = 32 * i + 2 * c16;
-                const float v0 = e == pos ? vfresh : h2f((uint16_t)(vc0[u][i] & 0xffff)), v1 = e + 1 == pos ? vfresh : h2f((uint16_t)(vc0[u][i] >> 16));
-                a0 = __builtin_fmaf(v0, sc[e], a0); a1 = __builtin_fmaf(v1, sc[e + 1], a1);
-            }
-        }
-        for (int i8 = VPF; i8 < nch; i8 += 8) {
-            uint32_t rr[8];
+        for (int i = 0; i < VPF; i++) if (i < nch) chunk(vc0[u][i], i);                    // (uniform branches: nch comes from a scalar load)
+        if (nch > VPF) {
 #pragma unroll
-            for (int i = 0; i < 8; i++) { rr[i] = vc1[u][i]; if (i8 != VPF) rr[i] = *(const uint32_t *)(vr + 32 * (i8 + i < nch ? i8 + i : 0) + 2 * c16); }
+            for (int i = 0; i < VPF; i++) if (VPF + i < nch) chunk(vc1[u][i], VPF + i);
+#pragma clang loop unroll(disable)
+            for (int c8 = 2 * VPF; c8 < nch; c8 += VPF) {                                  // beyond 512 cached positions (attn_long.hip's regime by default): loads, then the math
+                uint32_t w[VPF];
 #pragma unroll
-            for (int i = 0; i < 8; i++) {
-                if (i8 + i < nch) {
-                    const int e = 32 * (i8 + i) + 2 * c16;
-                    const float v0 = e == pos ? vfresh : h2f((uint16_t)(rr[i] & 0xffff)), v1 = e + 1 == pos ? vfresh : h2f((uint16_t)(rr[i] >> 16));
-                    a0 = __builtin_fmaf(v0, sc[e], a0); a1 = __builtin_fmaf(v1, sc[e + 1], a1);
-                }
+                for (int i = 0; i < VPF; i++) w[i] = *(const uint32_t *)(vr + 32 * (c8 + i < nch ? c8 + i : 0) + 2 * c16);
+#pragma unroll
+                for (int i = 0; i < VPF; i++) if (c8 + i < nch) chunk(w[i], c8 + i);
             }
         }
         const float res = vd32_reduce(a0, a1);

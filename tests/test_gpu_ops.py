@@ -830,6 +830,41 @@ def test_rope_kv_attn_decode_equals_the_node_sequence(gpu, hd, nh, nkv, ML, n_pa
     assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
 
 
+@pytest.mark.parametrize("hd,nh,nkv,n_past", [(128, 32, 8, 299), (128, 32, 8, 318), (64, 8, 4, 40), (128, 16, 2, 480)])
+def test_attn_decode_leftover_sums_over_a_wide_exponent_range(gpu, hd, nh, nkv, n_past):
+    """ggml_vec_dot_f16 adds the n mod 32 leftover products one by one in double.  k_attn_dec proves per output row that no addition can round (exponents of the terms
+    within 23 binades) and then adds them as a tree, else keeps the serial loop.  Here the leftover positions of every second V^T row hold fp16 SUBNORMALS (products ~2^-28
+    beside a reduced sum ~2^-4: the serial path), the other rows ordinary values (the tree) -- each against the node sequence, to the bit"""
+    ops, T = gpu.ops, gpu.Tensor
+    ML, mode, fb = 1024, 0, 500000.0
+    QD, KD, n_kv = hd * nh, hd * nkv, n_past + 1
+    r = np.random.default_rng(n_past)
+    qkv = r.standard_normal(QD + 2 * KD).astype(np.float32)
+    kc0 = r.standard_normal((ML, KD)).astype(np.float16)
+    vc0 = r.standard_normal((KD, ML)).astype(np.float16)
+    npos = n_kv & ~31
+    tiny = (r.integers(-15, 16, (KD // 2, n_kv - npos)) * 2.0 ** -24).astype(np.float16)       # multiples of the smallest fp16 subnormal
+    vc0[0::2, npos:n_kv] = tiny
+    qkv[QD + KD:][0::2] *= 2.0 ** -22                                                              # the new token's v (the last leftover) as well
+    pos = T.from_numpy(np.array([n_past], np.int32))
+    dk, dv = T.from_numpy(kc0), T.from_numpy(vc0)
+    q = T.from_numpy(qkv[:QD].reshape(1, nh, hd))
+    k = T.from_numpy(qkv[QD:QD + KD].reshape(1, nkv, hd))
+    v = T.from_numpy(qkv[QD + KD:].reshape(1, KD))
+    ops.cpy(v.transpose(), dv.view([1, KD], [2, ML * 2], offset=n_past * 2))
+    kr = ops.rope_ext(k, pos, None, hd, mode, freq_base=fb, inplace=True)
+    ops.set_rows(dk.view([KD, ML], [2, KD * 2]), kr.reshape(KD, 1), pos)
+    qr = ops.rope_ext(q, pos, None, hd, mode, freq_base=fb, inplace=True)
+    s = ops.mul_mat(dk.view([hd, n_kv, nkv], [2, KD * 2, hd * 2]), qr.permute(0, 2, 1, 3))
+    p = ops.scale_mask_soft_max(s, float(np.float32(1.0) / np.sqrt(np.float32(hd))), n_past)
+    c = ops.mul_mat(dv.view([n_kv, hd, nkv], [2, ML * 2, ML * hd * 2]), p)
+    want = ops.cont(c.permute(0, 2, 1, 3)).numpy().reshape(QD)
+    fk, fv = T.from_numpy(kc0), T.from_numpy(vc0)
+    got = ops.rope_kv_attn_decode(T.from_numpy(qkv), pos, n_kv, nh, nkv, hd, mode, fb, fk, fv, ML, table=True).numpy().reshape(QD)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), int(np.sum(got.view(np.uint32) != want.view(np.uint32)))
+    assert np.array_equal(fv.numpy().view(np.uint16), dv.numpy().view(np.uint16))
+
+
 def test_rope_kv_attn_decode_rejects_what_it_cannot_do(gpu):
     L, T = gpu.lib.get(), gpu.Tensor
     assert L.cllm_attn_decode_supported(32, 8, 128, 1024) == 1
