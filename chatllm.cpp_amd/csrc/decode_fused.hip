@@ -247,6 +247,7 @@ __global__ void __launch_bounds__(1024) k_attn_dec(const float * __restrict__ qk
 #define TS(k) do { if (ts && threadIdx.x == 0) ts[(blockIdx.y * gridDim.x + blockIdx.x) * 8 + (k)] = wall_clock64(); } while (0)
     extern __shared__ __attribute__((aligned(16))) float sm[];       // [HD] q (fp16-rounded) | [HD] new k | [HD] new v | [n_kv] scores
     __shared__ float  red_f[16];
+    __shared__ uint64_t etab_s[32];                                   // glibc's exp2f table for the soft_max's n mod 8 leftovers (see (5))
     constexpr int half = HD / 2, off = MODE == 0 ? 1 : half, U = 4;
     const int r2 = gridDim.x, g = blockIdx.y, h = g * r2 + blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -264,6 +265,8 @@ __global__ void __launch_bounds__(1024) k_attn_dec(const float * __restrict__ qk
     } else if (is_v) px0 = qkv[QD + KD + g * HD + (tid - 2 * half)];
     const int pos = uniform_load_i32(pos_dev);
     const int n_kv = pos + 1;
+    uint64_t et = 0;
+    if (tid >= 992) et = gm_exp2f_T_dev[tid - 992];                   // half a wave fetches the table with the first loads; it is in LDS behind the RoPE barrier
 
     // ---- (2) first batch of cache rows.  Accumulation ORDER of ggml_vec_dot_f16 (vec.cpp:264-, AVX2 + F16C: simd-mappings.h:528-620), so
     //          that scores and context equal the reference's bit for bit: 32 fp32 accumulators, accumulator a takes elements a, a + 32, ...
@@ -297,6 +300,7 @@ __global__ void __launch_bounds__(1024) k_attn_dec(const float * __restrict__ qk
         float * o = which == 0 ? qs : knew;
         o[ic] = h2f(f2h(y0)); o[ic + off] = h2f(f2h(y1));             // q: src1 of K.Q is rounded to fp16; k: the cache is fp16
     } else if (is_v) vnew[tid - 2 * half] = h2f(f2h(px0));
+    if (tid >= 992) etab_s[tid - 992] = et;
     lds_barrier();
     if (blockIdx.x == 0 && (PARTS == 1 || blockIdx.z == 0) && tid < HD) {
         k_cache[(int64_t) pos * KD + g * HD + tid] = f2h(knew[tid]);
@@ -367,7 +371,13 @@ __global__ void __launch_bounds__(1024) k_attn_dec(const float * __restrict__ qk
     // every exponential is independent: all threads compute them (the groups of 8 through the AVX2 polynomial, the n_kv mod 8 leftovers through
     // expf, as ggml_vec_soft_max_f32 does); the total is one wave's (lane = groups of 8 -> double; leftovers last)
     const int nv = n_kv & ~7;
-    for (int i = tid; i < n_kv; i += 1024) sc[i] = i < nv ? ggml_expf_poly(sc[i] - mx) : libm_expf(sc[i] - mx);
+    for (int i = tid; i < n_kv; i += 1024) {
+        const float xv = sc[i] - mx;
+        float ev;
+        if (i < nv) ev = ggml_expf_poly(xv);
+        else { const uint64_t ki = gm_expf_ki(xv); ev = gm_expf_fin(xv, ki, etab_s[ki & 31]); }      // glibc's expf, inline, its table entry from LDS: a call + a constant-memory
+        sc[i] = ev;                                                                                  // load behind the maximum cost ~0.7 us in 7 steps of 8
+    }
     lds_barrier();
     if (wave == 0) {
         double sum = 0.0;

@@ -54,7 +54,13 @@ GM_FN uint64_t gm_exp2f_tab(int i) {
     return gm_exp2f_T_host[i & 31];
 #endif
 }
-GM_FN float gm_expf(float x) {
+// in two steps so that a device caller can fetch the table entry T[ki & 31] its own way between them (from LDS: decode_fused.hip) -- the arithmetic and its order are
+// those of the one-piece function
+GM_FN uint64_t gm_expf_ki(float x) {
+    // z = InvLn2N * xd feeds two additions only: gcc fuses both (kd = z + SHIFT, r = z - kd) and z itself is never rounded
+    return gm_asuint64(__builtin_fma(0x1.71547652b82fep+0 * 32, (double) x, 0x1.8p+52));
+}
+GM_FN float gm_expf_fin(float x, uint64_t ki, uint64_t t /* T[ki & 31] */) {
     const double xd = (double) x;
     const uint32_t abstop = (gm_asuint(x) >> 20) & 0x7ff;
     if (abstop >= 0x42b) {                                  // |x| >= 88 or nan
@@ -64,14 +70,9 @@ GM_FN float gm_expf(float x) {
         if (x < -0x1.9fe368p6f) return 0.0f;                                    // underflow
         if (x < -0x1.9d1d9ep6f) return gm_asfloat(1u);                          // may-underflow: 0x1.4p-75f squared = the smallest subnormal
     }
-    const double shift = 0x1.8p+52;
-    // z = InvLn2N * xd feeds two additions only: gcc fuses both (kd = z + SHIFT, r = z - kd) and z itself is never rounded
-    double kd = __builtin_fma(0x1.71547652b82fep+0 * 32, xd, shift);
-    const uint64_t ki = gm_asuint64(kd);
-    kd -= shift;
+    const double kd = gm_asdouble(ki) - 0x1.8p+52;
     const double r = __builtin_fma(0x1.71547652b82fep+0 * 32, xd, -kd);
     double z;
-    uint64_t t = gm_exp2f_tab((int)(ki & 31));
     t += ki << 47;
     const double s = gm_asdouble(t);
     // (the libm of this image runs its FMA build -- ifunc on x86-64-v3 hosts: the three multiply-adds are single roundings)
@@ -82,6 +83,7 @@ GM_FN float gm_expf(float x) {
     y = y * s;
     return (float) y;
 }
+GM_FN float gm_expf(float x) { const uint64_t ki = gm_expf_ki(x); return gm_expf_fin(x, ki, gm_exp2f_tab((int)(ki & 31))); }
 
 // ---- sinf / cosf (s_sinf.c, s_cosf.c, sincosf.h, sincosf_data.c) -----------------------------------------------------------------------
 GM_FN uint32_t gm_inv_pio4(int i) {        // the bits of 4/pi, 8 hex digits from every second digit on
