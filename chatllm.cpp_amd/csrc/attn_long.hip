@@ -162,10 +162,12 @@ __global__ void __launch_bounds__(1024) k_attn_long_softmax(const int32_t * __re
         for (int gq = lane; gq < (nv >> 3); gq += 64) sum += (double) gsum[gq];
         if (lane == 0) for (int i = nv; i < n_kv; i++) { const float e = libm_expf(sc[i] - mx); sc[i] = e; sum += (double) e; }
         sum = wave_sum_d(sum);
-        if (lane == 0) red_d[0] = sum;
+        double rinv = 1.0 / sum;                                      // (ORDER: soft_total_order_safe, common.h)
+        if (__builtin_expect(!soft_total_order_safe(rinv, n_kv >> 3), 0)) { wave_lds_fence(); rinv = 1.0 / soft_sum_serial_groups(gsum, nv >> 3, sc, nv, n_kv); }
+        if (lane == 0) red_d[0] = rinv;
     }
     __syncthreads();
-    const float inv = (float)(1.0 / red_d[0]);
+    const float inv = (float) red_d[0];
     for (int i = tid; i < n_kv; i += 1024) prow[i] = f2h(sc[i] * inv);          // the fp16 rounding src1 of V.P gets (exact in fp32 later)
 }
 
@@ -308,10 +310,12 @@ __global__ void __launch_bounds__(1024) k_attn_long_softmax_pv(const int32_t * _
         for (int gq = lane; gq < (nv >> 3); gq += 64) sum += (double) gsum[gq];
         if (lane == 0) for (int i = nv; i < n_kv; i++) { const float e = libm_expf(ex[i] - mx); ex[i] = e; sum += (double) e; }
         sum = wave_sum_d(sum);
-        if (lane == 0) red_d[0] = sum;
+        double rinv = 1.0 / sum;                                      // (ORDER: soft_total_order_safe, common.h)
+        if (__builtin_expect(!soft_total_order_safe(rinv, n_kv >> 3), 0)) { wave_lds_fence(); rinv = 1.0 / soft_sum_serial_groups(gsum, nv >> 3, ex, nv, n_kv); }
+        if (lane == 0) red_d[0] = rinv;
     }
     __syncthreads();
-    const float inv = (float)(1.0 / red_d[0]);
+    const float inv = (float) red_d[0];
     for (int i = tid * 2; i < n_kv; i += 2048) {                    // the fp16 rounding src1 of V.P gets (exact in fp32 later)
         const uint32_t lo = f2h(ex[i] * inv), hi = i + 1 < n_kv ? f2h(ex[i + 1] * inv) : 0u;
         *(uint32_t *)(p16 + i) = lo | (hi << 16);

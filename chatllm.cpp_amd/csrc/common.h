@@ -297,6 +297,40 @@ __device__ __forceinline__ float ggml_expf_poly(float x) {
     if (fabsf(n) > 192.0f) return s1 * s1;
     return __builtin_fmaf(s2, j, s2) * s1;
 }
+// ---- the soft_max's double total: ORDER.  ggml_vec_soft_max_f32 (vec.cpp:547-) adds the float sums of the groups of 8 one by one into a double, then the n mod 8
+// leftovers; the kernels here add them as a tree (per-lane partial sums, a DPP tree).  Two double sums of the same m positive terms differ by at most (m + log2 m) 2^-53 of
+// their value, and so do their reciprocals (+ one rounding of the division): the float that (float)(1.0 / sum) rounds to can depend on the order only if the reciprocal lies
+// within that distance of a float rounding boundary -- the low 29 bits of its mantissa within (m + 24) of 2^28 (about one row in 2^20).  Every soft_max kernel tests this per
+// row (as rms_scale does for RMS_NORM) and otherwise redoes the total serially in the reference's order.  SOFT_FORCE_SERIAL=1 (test builds): always serial.
+#ifndef SOFT_FORCE_SERIAL
+#define SOFT_FORCE_SERIAL 0
+#endif
+__device__ __forceinline__ bool soft_total_order_safe(double rinv, int m_terms) {
+    const int low = (int)((unsigned long long) __double_as_longlong(rinv) & 0x1fffffffull) - 0x10000000;
+    return !SOFT_FORCE_SERIAL && (low < 0 ? -low : low) > m_terms + 24;
+}
+// the total in the reference's order from the exponentials e[0 .. n) (any address space): lane 0 of the calling wave, the result broadcast
+static __device__ __noinline__ double soft_sum_serial(const float * e, int nv, int n) {
+    double sum = 0.0;
+    if ((threadIdx.x & 63) == 0) {
+        for (int gi = 0; gi < nv; gi += 8) {
+            const float a0 = e[gi] + e[gi + 4], a1 = e[gi + 1] + e[gi + 5], a2 = e[gi + 2] + e[gi + 6], a3 = e[gi + 3] + e[gi + 7];
+            sum += (double)((a0 + a2) + (a1 + a3));
+        }
+        for (int i = nv; i < n; i++) sum += (double) e[i];
+    }
+    return lane_d(sum, 0);
+}
+// the same from the group sums gs[0 .. ng) + the leftovers e[nv .. n)
+static __device__ __noinline__ double soft_sum_serial_groups(const float * gs, int ng, const float * e, int nv, int n) {
+    double sum = 0.0;
+    if ((threadIdx.x & 63) == 0) {
+        for (int gq = 0; gq < ng; gq++) sum += (double) gs[gq];
+        for (int i = nv; i < n; i++) sum += (double) e[i];
+    }
+    return lane_d(sum, 0);
+}
+
 // SiLU as ggml_vec_silu_f32 computes it (vec.cpp:396-431): the AVX2 polynomial for the elements below n & ~7 of a row, expf for the leftovers
 // SOFT_MAX of one row of n <= 512 values held in LDS by ONE wave (no scale, no mask): the lane -> group-of-8 partition, the exponentials and the
 // summation order of k_soft_max (ops.hip), which follow ggml_vec_soft_max_f32 (vec.cpp:547-).  y (LDS) receives the probabilities.
@@ -315,8 +349,10 @@ __device__ __forceinline__ void wave_soft_max_plain(const float * x, float * y, 
     }
     if (lane == 0) for (int i = nv; i < n; i++) { const float e = libm_expf(x[i] - mx); y[i] = e; sum += (double) e; }
     sum = wave_sum_d(sum);
-    const float inv = (float)(1.0 / sum);
+    double rinv = 1.0 / sum;
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    if (__builtin_expect(!soft_total_order_safe(rinv, n >> 3), 0)) rinv = 1.0 / soft_sum_serial(y, nv, n);
+    const float inv = (float) rinv;
     for (int i = lane; i < n; i += 64) y[i] = y[i] * inv;
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
 }

@@ -160,10 +160,12 @@ __global__ void __launch_bounds__(1024) k_attn_decode(const float * __restrict__
         }
         if (lane == 0) for (int i = nv; i < n_kv; i++) sum += (double) sc[i];
         sum = wave_sum_d(sum);
-        if (lane == 0) red_d[0] = sum;
+        double rinv = 1.0 / sum;                                      // (ORDER: soft_total_order_safe, common.h)
+        if (__builtin_expect(!soft_total_order_safe(rinv, n_kv >> 3), 0)) rinv = 1.0 / soft_sum_serial(sc, nv, n_kv);
+        if (lane == 0) red_d[0] = rinv;
     }
     __syncthreads();
-    const float inv = (float)(1.0 / red_d[0]);
+    const float inv = (float) red_d[0];
     for (int i = tid; i < n_kv; i += nthr) sc[i] = h2f(f2h(sc[i] * inv));   // probability, then its fp16 rounding for V.P
     __syncthreads();
     if (dbg) { for (int i = tid; i < n_kv; i += nthr) dbg[(int64_t) h * ML + i] = sc[i]; if (tid == 0) { dbg[(int64_t) nh * ML + 2*h] = mx; dbg[(int64_t) nh * ML + 2*h + 1] = inv; } }
@@ -220,23 +222,6 @@ __device__ __forceinline__ int uniform_load_i32(const int32_t * p) {
     int v;
     asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(p) : "memory");
     return v;
-}
-
-#ifndef ATTN_FORCE_SERIAL_SUM
-#define ATTN_FORCE_SERIAL_SUM 0      // (test builds: 1 = always take the serial order)
-#endif
-// the soft_max's total in the reference's order (ggml_vec_soft_max_f32: group sums of 8 as floats, added one by one in double, then the leftovers): lane 0, broadcast
-static __device__ __noinline__ double soft_sum_serial(const float * e, int nv, int n) {
-    double sum = 0.0;
-    if ((threadIdx.x & 63) == 0) {
-        for (int gi = 0; gi < nv; gi += 8) {
-            const f32x4 lo = *(const f32x4 *)(e + gi), up = *(const f32x4 *)(e + gi + 4);
-            const float a0 = lo.x + up.x, a1 = lo.y + up.y, a2 = lo.z + up.z, a3 = lo.w + up.w;
-            sum += (double)((a0 + a2) + (a1 + a3));
-        }
-        for (int i = nv; i < n; i++) sum += (double) e[i];
-    }
-    return lane_d(sum, 0);
 }
 
 template <int HD, int MODE, int PARTS>      // MODE 0: adjacent pairs (GGML_ROPE_TYPE_NORMAL), 2: NEOX halves; PARTS: workgroups per head (each redoes RoPE, scores and
@@ -388,13 +373,9 @@ __global__ void __launch_bounds__(1024) k_attn_dec(const float * __restrict__ qk
         }
         if (lane == 0) for (int i = nv; i < n_kv; i++) sum += (double) sc[i];
         sum = wave_sum_d(sum);
-        // ORDER.  The reference adds the group sums serially in double (vec.cpp:547-); this is a tree.  Two double sums of the same m positive terms differ by at most
-        // (m + log2 m) 2^-53 of their value, and so do their reciprocals: the float the reciprocal rounds to can depend on the order only if it lies within that distance
-        // of a rounding boundary -- its low 29 mantissa bits within (m + 16) of 2^28.  Proved per row here (as rms_scale does for RMS_NORM); otherwise lane 0 redoes the
-        // sum in the reference's order (about one row in 2^20)
+        // (ORDER: a tree, the reference adds serially -- proved not to matter per row, else redone serially: soft_total_order_safe, common.h)
         double rinv = 1.0 / sum;
-        const int low = (int)((unsigned long long) __double_as_longlong(rinv) & 0x1fffffffull) - 0x10000000;
-        if ((low < 0 ? -low : low) <= (n_kv >> 3) + 24 || ATTN_FORCE_SERIAL_SUM) rinv = 1.0 / soft_sum_serial(sc, nv, n_kv);
+        if (__builtin_expect(!soft_total_order_safe(rinv, n_kv >> 3), 0)) rinv = 1.0 / soft_sum_serial(sc, nv, n_kv);
         if (lane == 0) red_f[0] = (float) rinv;                       // (every thread read the maxima before the barrier above)
     }
     lds_barrier();

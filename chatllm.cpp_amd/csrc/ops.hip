@@ -225,8 +225,10 @@ __global__ void __launch_bounds__(256) k_soft_max(tview s, tview d, const char *
     }
     if (lane == 0) for (int64_t i = nv; i < n; i++) { const float e = libm_expf(val(i) - mx); y[i] = e; sum += (double) e; }
     sum = wave_sum_d(sum);
-    const float inv = (float)(1.0 / sum);
+    double rinv = 1.0 / sum;                                 // (ORDER: soft_total_order_safe, common.h)
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");   // e[] written by other lanes of this wave
+    if (__builtin_expect(!soft_total_order_safe(rinv, (int)(n >> 3)), 0)) rinv = 1.0 / soft_sum_serial(y, (int) nv, (int) n);      // (masked entries hold exact zeros)
+    const float inv = (float) rinv;
     const int64_t n_live = MODE == 1 ? (nv_vis < nv ? nv_vis : n) : n;      // the stored zeros stay zeros
     for (int64_t i = lane; i < n_live; i += 64) y[i] = y[i] * inv;
 }
@@ -279,7 +281,22 @@ __global__ void __launch_bounds__(256) k_soft_max_causal_reg(tview s, tview d, f
         }
     }
     sum = wave_sum_d(sum);
-    const float inv = (float)(1.0 / sum);
+    double rinv = 1.0 / sum;                                 // (ORDER: soft_total_order_safe, common.h)
+    if (__builtin_expect(!soft_total_order_safe(rinv, n >> 3), 0)) {        // the exponentials go to the output row first (it is rewritten below), then lane 0 adds them serially
+        float * yy = (float *) y;
+#pragma unroll
+        for (int t = 0; t < NG; t++) {
+            const int g0 = (lane + 64 * t) * 8;
+            if (g0 < n) {
+#pragma unroll
+                for (int l = 0; l < 8; l++) yy[g0 + l] = g0 < n_vis ? e[t][l] : 0.0f;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        rinv = 1.0 / soft_sum_serial(yy, n, n);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    }
+    const float inv = (float) rinv;
 #pragma unroll
     for (int t = 0; t < NG; t++) {
         const int g0 = (lane + 64 * t) * 8;
@@ -333,10 +350,12 @@ __global__ void __launch_bounds__(256) k_soft_max_causal_lds(tview s, tview d, f
         double sum = 0.0;
         for (int gq = lane; gq < (nv_vis >> 3); gq += 64) sum += (double) gsum[gq];
         sum = wave_sum_d(sum);
-        if (lane == 0) red_d[0] = sum;
+        double rinv = 1.0 / sum;                                      // (ORDER: soft_total_order_safe, common.h; groups beyond nv_vis are exact zeros in the reference's sum)
+        if (__builtin_expect(!soft_total_order_safe(rinv, n >> 3), 0)) rinv = 1.0 / soft_sum_serial_groups(gsum, nv_vis >> 3, sm, 0, 0);
+        if (lane == 0) red_d[0] = rinv;
     }
     __syncthreads();
-    const float inv = (float)(1.0 / red_d[0]);
+    const float inv = (float) red_d[0];
     for (int g0 = tid * 8; g0 < n; g0 += 256 * 8) {
         f32x4 lo = {0, 0, 0, 0}, hi = {0, 0, 0, 0};
         if (g0 < nv_vis) { lo = f32x4{sm[g0] * inv, sm[g0 + 1] * inv, sm[g0 + 2] * inv, sm[g0 + 3] * inv}; hi = f32x4{sm[g0 + 4] * inv, sm[g0 + 5] * inv, sm[g0 + 6] * inv, sm[g0 + 7] * inv}; }
