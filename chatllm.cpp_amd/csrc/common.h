@@ -35,6 +35,9 @@ struct __attribute__((packed)) block_q5_0   { uint16_t d; uint8_t qh[4]; uint8_t
 struct __attribute__((packed)) block_q5_1   { uint16_t d, m; uint8_t qh[4]; uint8_t qs[16]; };               // 24 B: w = (nib | bit << 4) * d + m
 struct __attribute__((packed)) block_iq4_nl { uint16_t d; uint8_t qs[16]; };                                 // 18 B: w = kvalues_iq4nl[nib] * d
 struct __attribute__((packed)) block_iq4_xs { uint16_t d, scales_h; uint8_t scales_l[4]; uint8_t qs[128]; };  // 136 B: 256 weights, w = kvalues_iq4nl[nib] * d * (ls - 32), a 6-bit ls per 32 (ggml-common.h:421-427)
+struct __attribute__((packed)) block_tq1_0  { uint8_t qs[48]; uint8_t qh[4]; uint16_t d; };                   // 54 B: 256 ternary weights, 5 per byte of qs (base 3), 4 per byte of qh: w = (trit - 1) * d (ggml-common.h:241-249)
+struct __attribute__((packed)) block_tq2_0  { uint8_t qs[64]; uint16_t d; };                                  // 66 B: 256 ternary weights, 2 bits each: w = (q - 1) * d (ggml-common.h:251-256)
+static_assert(sizeof(block_tq1_0) == 54 && sizeof(block_tq2_0) == 66, "block sizes");
 struct __attribute__((packed)) block_mxfp4  { uint8_t e; uint8_t qs[16]; };                                  // 17 B: w = kvalues_mxfp4[nib] * 2^(e - 128)
 struct __attribute__((packed)) block_q2_K   { uint8_t scales[16]; uint8_t qs[64]; uint16_t d, dmin; };       // 84 B
 struct __attribute__((packed)) block_q3_K   { uint8_t hmask[32]; uint8_t qs[64]; uint8_t scales[12]; uint16_t d; };   // 110 B
@@ -60,9 +63,9 @@ __host__ __device__ inline size_t act_row_bytes(int64_t K, int kind) { return ac
 // the activation format a weight type's dot product reads (type_traits_cpu[].vec_dot_type, ggml-cpu/ggml-cpu.c:207-390)
 // the coverage types (gemv_kq.hip: mat-mul for any number of columns in the reference's order, GET_ROWS; no fused decode forms)
 __host__ __device__ inline bool   is_kq_type(int t) {
-    return t == CLLM_TYPE_Q5_K || t == CLLM_TYPE_Q6_K || t == CLLM_TYPE_Q2_K || t == CLLM_TYPE_Q3_K || t == CLLM_TYPE_Q5_0 || t == CLLM_TYPE_Q5_1 || t == CLLM_TYPE_IQ4_NL || t == CLLM_TYPE_MXFP4 || t == CLLM_TYPE_IQ4_XS;
+    return t == CLLM_TYPE_Q5_K || t == CLLM_TYPE_Q6_K || t == CLLM_TYPE_Q2_K || t == CLLM_TYPE_Q3_K || t == CLLM_TYPE_Q5_0 || t == CLLM_TYPE_Q5_1 || t == CLLM_TYPE_IQ4_NL || t == CLLM_TYPE_MXFP4 || t == CLLM_TYPE_IQ4_XS || t == CLLM_TYPE_TQ1_0 || t == CLLM_TYPE_TQ2_0;
 }
-__host__ __device__ inline bool   is_k256_type(int t) { return t == CLLM_TYPE_Q4_K || t == CLLM_TYPE_Q5_K || t == CLLM_TYPE_Q6_K || t == CLLM_TYPE_Q2_K || t == CLLM_TYPE_Q3_K || t == CLLM_TYPE_IQ4_XS; }
+__host__ __device__ inline bool   is_k256_type(int t) { return t == CLLM_TYPE_Q4_K || t == CLLM_TYPE_Q5_K || t == CLLM_TYPE_Q6_K || t == CLLM_TYPE_Q2_K || t == CLLM_TYPE_Q3_K || t == CLLM_TYPE_IQ4_XS || t == CLLM_TYPE_TQ1_0 || t == CLLM_TYPE_TQ2_0; }
 __host__ __device__ inline int    act_kind_of(int wtype) { return is_k256_type(wtype) ? ACT_Q8_K : (wtype == CLLM_TYPE_Q4_1 || wtype == CLLM_TYPE_Q5_1) ? ACT_Q8_1 : ACT_Q8_0; }
 __host__ __device__ inline bool   is_quant_type(int t) { return t == CLLM_TYPE_Q4_0 || t == CLLM_TYPE_Q4_1 || t == CLLM_TYPE_Q8_0 || t == CLLM_TYPE_Q4_K; }
 

@@ -77,6 +77,20 @@ __device__ __forceinline__ float dequant_elem(int type, const char * row, int64_
             const uint64_t tab = nib < 8 ? 0xf6eaddcfbfad9881ull : 0x7159453526190d01ull;
             return dl * (float)(int8_t)((tab >> (8 * (nib & 7))) & 0xff);
         }
+        case CLLM_TYPE_TQ1_0: {                    // dequantize_row_tq1_0 (ggml-quants.c:2215-2252): trit = ((byte * 3^n mod 256) * 3) >> 8, planes of 32 / 16 / 4 bytes
+            const block_tq1_0 * b = (const block_tq1_0 *) row + i / 256; const int e = (int)(i % 256);
+            int byte, n;
+            if (e < 160)      { byte = b->qs[e % 32];              n = e / 32; }
+            else if (e < 240) { byte = b->qs[32 + (e - 160) % 16]; n = (e - 160) / 16; }
+            else              { byte = b->qh[(e - 240) % 4];       n = (e - 240) / 4; }
+            const int p3 = n == 0 ? 1 : n == 1 ? 3 : n == 2 ? 9 : n == 3 ? 27 : 81;
+            return (float)((int)((((unsigned)(byte * p3) & 0xffu) * 3u) >> 8) - 1) * h2f(b->d);
+        }
+        case CLLM_TYPE_TQ2_0: {                    // dequantize_row_tq2_0 (ggml-quants.c:2254-2271): (q - 1) * d, 2 bits per weight, planes of 32 bytes
+            const block_tq2_0 * b = (const block_tq2_0 *) row + i / 256; const int e = (int)(i % 256);
+            const int q = (b->qs[32 * (e / 128) + e % 32] >> (2 * ((e % 128) / 32))) & 3;
+            return (float)(q - 1) * h2f(b->d);
+        }
         case CLLM_TYPE_Q2_K: {                     // dequantize_row_q2_K (ggml-quants.c:784-815): (d * sc) * q - (dmin * m)
             const block_q2_K * b = (const block_q2_K *) row + i / 256; const int e = (int)(i % 256);
             const int n = e / 128, j = (e % 128) / 32, hh = (e % 32) / 16, l = e % 16;

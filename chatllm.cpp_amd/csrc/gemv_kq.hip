@@ -6,6 +6,7 @@
 //   q2_K :1278-1354   acc[A] = fma(dmin, m[2A] S16[2A] + m[2A+1] S16[2A+1], acc[A]) then acc[A] = fma(d, sumi[A], acc[A]) (S16: activation sums per 16)
 //   q3_K :1470-1580   2 bits + a high-bit mask (value - 4 where the bit is clear), 6-bit scales - 32
 //   q5_0 :846-884, q5_1 :926-968    Q4_0's / Q4_1's chains with a fifth bit per weight
+//   tq1_0 :1080-1210, tq2_0 :1212-1270   ternary weights; sumi[A] - (bsums[2A] + bsums[2A+1]), then (float) sumi * d + acc as TWO roundings (the build keeps the multiply and the add)
 //   iq4_xs :3716-3764   256-weight super-blocks of IQ4_NL codes with a 6-bit scale - 32 per 32: the K-quants' single fma per super-block and lane
 //   iq4_nl :3632-3714, mxfp4 :760-844   int8 codebooks; even blocks in one 8-lane accumulator, odd ones in a second, added before the horizontal sum, an unpaired
 //                     last block in scalar code; with >= 2 activation columns IQ4_NL (and Q5_0) take tinyBLAS_Q0_AVX (llamafile/sgemm.cpp:1346-1790): ONE chain
@@ -122,6 +123,34 @@ __global__ void __launch_bounds__(256) k_gemv_kq(const kq_args a) {
                 }
             }
             if (Q2) { mn[0] = ((uint8_t) s16[2 * A]) >> 4; mn[1] = ((uint8_t) s16[2 * A + 1]) >> 4; }
+        } else if (TYPE == CLLM_TYPE_TQ2_0) {
+            // plane l (bits 2l) of the j-th 32 bytes = elements 128 j + 32 l + (0..31): lane A takes bytes 4A..4A+3 of every plane; the weight is q - 1, the "- 1" comes off below
+            const char * blk = wr + (int64_t) b * 66;
+            dw = h2f(*(const uint16_t *)(blk + 64));
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+                const uint32_t q = ld2(blk + 32 * j + 4 * A);
+#pragma unroll
+                for (int l = 0; l < 4; l++) { w[4 * j + l] = (q >> (2 * l)) & 0x03030303u; sc8[4 * j + l] = 1; aoff[4 * j + l] = 128 * j + 32 * l + 4 * A; }
+            }
+        } else if (TYPE == CLLM_TYPE_TQ1_0) {
+            // chunk c of 32 elements: c < 5: plane c of qs[0..31] (bytes 4A..); c = 5, 6: planes (0, 1), (2, 3) of qs[32..47] (the low half of the chunk from the even plane);
+            // c = 7: plane 4 of qs[32..47], then the 16 elements of qh (plane A - 4 of its 4 bytes).  trit = ((byte * 3^n mod 256) * 3) >> 8 per byte, two 16-bit fields at a time
+            const char * blk = wr + (int64_t) b * 54;
+            dw = h2f(*(const uint16_t *)(blk + 52));
+            const uint32_t B0 = ld2(blk + 4 * A), B1 = ld2(blk + 32 + 4 * (A & 3)), QH = ld2(blk + 48);
+            auto trits = [](uint32_t bytes4, uint32_t p) -> uint32_t {
+                uint32_t ev = ((bytes4 & 0x00ff00ffu) * p) & 0x00ff00ffu, od = (((bytes4 >> 8) & 0x00ff00ffu) * p) & 0x00ff00ffu;
+                ev = ((ev * 3u) >> 8) & 0x00030003u; od = ((od * 3u) >> 8) & 0x00030003u;
+                return ev | (od << 8);
+            };
+            const bool hi = (A >> 2) != 0;
+            const uint32_t p3a = A == 4 ? 1u : A == 5 ? 3u : A == 6 ? 9u : 27u;
+            w[0] = trits(B0, 1u); w[1] = trits(B0, 3u); w[2] = trits(B0, 9u); w[3] = trits(B0, 27u); w[4] = trits(B0, 81u);
+            w[5] = trits(B1, hi ? 3u : 1u); w[6] = trits(B1, hi ? 27u : 9u);
+            w[7] = hi ? trits(QH, p3a) : trits(B1, 81u);
+#pragma unroll
+            for (int c8 = 0; c8 < 8; c8++) { sc8[c8] = 1; aoff[c8] = 32 * c8 + 4 * A; }
         } else if (TYPE == CLLM_TYPE_IQ4_XS) {
             // sub-block ib (32 weights = 16 bytes: low nibbles are elements 0..15, high nibbles 16..31): lane A takes elements 4A..4A+3 = the low (A < 4) or high nibbles of
             // bytes 4 (A & 3) ..+3 through the IQ4_NL codebook; its scale is the 6-bit ls - 32 (scales_l nibble | two bits of scales_h)
@@ -170,6 +199,10 @@ __global__ void __launch_bounds__(256) k_gemv_kq(const kq_args a) {
                 }
                 acc[c] = __builtin_fmaf((-yd) * dmin, (float)(mn[0] * s16a + mn[1] * s16b), acc[c]);
             }
+            if (TYPE == CLLM_TYPE_TQ1_0 || TYPE == CLLM_TYPE_TQ2_0) {          // every weight is (value - 1): minus the activation's sum over this lane's 32 elements (bsums[2A] + bsums[2A+1])
+                sumi -= ((const int *)(ar + a.off_s))[b * 8 + A];
+                acc[c] = (float) sumi * (yd * dw) + acc[c];                    // a multiply and an add: two roundings, as the reference build has them
+            } else
             acc[c] = __builtin_fmaf(yd * dw, (float) sumi, acc[c]);
             if (TYPE == CLLM_TYPE_Q5_K) {
                 const int * ys = (const int *)(ar + a.off_s) + b * 8;
@@ -272,6 +305,8 @@ static void kq_launch(hipStream_t st, int wtype, const kq_args & a, dim3 grid, b
         case CLLM_TYPE_Q2_K: GO(CLLM_TYPE_Q2_K); break;
         case CLLM_TYPE_Q3_K: GO(CLLM_TYPE_Q3_K); break;
         case CLLM_TYPE_IQ4_XS: GO(CLLM_TYPE_IQ4_XS); break;
+        case CLLM_TYPE_TQ1_0: GO(CLLM_TYPE_TQ1_0); break;
+        case CLLM_TYPE_TQ2_0: GO(CLLM_TYPE_TQ2_0); break;
         case CLLM_TYPE_Q5_0: GB(CLLM_TYPE_Q5_0, true); break;
         case CLLM_TYPE_Q5_1: GB(CLLM_TYPE_Q5_1, true); break;
         case CLLM_TYPE_IQ4_NL: if (chain) GB(CLLM_TYPE_IQ4_NL, true); else GB(CLLM_TYPE_IQ4_NL, false); break;

@@ -8,7 +8,7 @@ import zlib
 
 import numpy as np
 
-from .tensor import F32, Q4_0, Q4_1, Q8_0, Q4_K, Q5_K, Q6_K, Q5_0, Q5_1, Q2_K, Q3_K, IQ4_NL, MXFP4, IQ4_XS, TYPE_SIZE, BLCK  # noqa: F401
+from .tensor import F32, Q4_0, Q4_1, Q8_0, Q4_K, Q5_K, Q6_K, Q5_0, Q5_1, Q2_K, Q3_K, IQ4_NL, MXFP4, IQ4_XS, TQ1_0, TQ2_0, TYPE_SIZE, BLCK  # noqa: F401
 
 CONFIGS = {
     # name: n_layer, hidden, n_head, n_kv_head, head_dim, ffn, vocab
@@ -134,6 +134,16 @@ def quant_blocks(type_, rows, K, rng, sigma):
         out[:, :, 0:2] = _f16_bytes(d).reshape(rows, nb, 2)
         out[:, :, 2:8] = rng.integers(0, 256, (rows, nb, 6), dtype=np.uint8)          # every 6-bit scale pattern, both signs of ls - 32
         out[:, :, 8:] = rng.integers(0, 256, (rows, nb, 128), dtype=np.uint8)
+    elif type_ == TQ2_0:                                                # qs[64] d (ggml-common.h:251-256): w = (q - 1) d, q in 0..2 at 2 bits
+        out = np.empty((rows, nb, 66), np.uint8)
+        q = rng.integers(0, 3, (rows, nb, 64, 4), dtype=np.uint8)
+        out[:, :, :64] = q[..., 0] | (q[..., 1] << 2) | (q[..., 2] << 4) | (q[..., 3] << 6)
+        out[:, :, 64:66] = _f16_bytes(rng.uniform(0.5, 1.5, (rows, nb)) * sigma / 0.816).reshape(rows, nb, 2)
+    elif type_ == TQ1_0:                                                # qs[48] qh[4] d (ggml-common.h:241-249): five trits per byte as ceil(base-3 value * 256 / 243), four in qh
+        out = np.empty((rows, nb, 54), np.uint8)
+        out[:, :, :48] = ((rng.integers(0, 243, (rows, nb, 48)) * 256 + 242) // 243).astype(np.uint8)
+        out[:, :, 48:52] = ((rng.integers(0, 81, (rows, nb, 4)) * 3 * 256 + 242) // 243).astype(np.uint8)
+        out[:, :, 52:54] = _f16_bytes(rng.uniform(0.5, 1.5, (rows, nb)) * sigma / 0.816).reshape(rows, nb, 2)
     elif type_ == Q2_K:                                                 # scales[16] (scale | min << 4) qs[64] d dmin: w = d sc q - dmin m, q in 0..3
         out = np.empty((rows, nb, 84), np.uint8)
         sc = rng.integers(3, 11, (rows, nb, 16), dtype=np.uint8)

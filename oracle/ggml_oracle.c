@@ -34,6 +34,7 @@ size_t orc_type_size(int type) {
         case ORC_Q5_K: return sizeof(orc_block_q5_K);  case ORC_Q6_K: return sizeof(orc_block_q6_K);
         case ORC_Q5_0: return sizeof(orc_block_q5_0);  case ORC_Q5_1: return sizeof(orc_block_q5_1);
         case ORC_IQ4_NL: return sizeof(orc_block_iq4_nl);  case ORC_MXFP4: return sizeof(orc_block_mxfp4);  case ORC_IQ4_XS: return sizeof(orc_block_iq4_xs);
+        case ORC_TQ1_0: return sizeof(orc_block_tq1_0);  case ORC_TQ2_0: return sizeof(orc_block_tq2_0);
         case ORC_Q2_K: return sizeof(orc_block_q2_K);  case ORC_Q3_K: return sizeof(orc_block_q3_K);
     }
     return 0;
@@ -41,7 +42,7 @@ size_t orc_type_size(int type) {
 int orc_blck_size(int type) {
     switch (type) {
         case ORC_Q4_0: case ORC_Q8_0: case ORC_Q4_1: case ORC_Q8_1: case ORC_Q5_0: case ORC_Q5_1: case ORC_IQ4_NL: case ORC_MXFP4: return ORC_QK;
-        case ORC_Q4_K: case ORC_Q5_K: case ORC_Q6_K: case ORC_Q8_K: case ORC_Q2_K: case ORC_Q3_K: case ORC_IQ4_XS: return ORC_QK_K;
+        case ORC_Q4_K: case ORC_Q5_K: case ORC_Q6_K: case ORC_Q8_K: case ORC_Q2_K: case ORC_Q3_K: case ORC_IQ4_XS: case ORC_TQ1_0: case ORC_TQ2_0: return ORC_QK_K;
         case ORC_F32: case ORC_F16: case ORC_I32: case ORC_I64: return 1;
     }
     return 0;
@@ -321,6 +322,31 @@ void orc_dequantize_row_iq4_xs(const orc_block_iq4_xs * x, float * y, int64_t k)
         }
     }
 }
+/* the trit of element e (dequantize order, ggml-quants.c:2215-2252): 160 elements from qs[0..31] (plane n = e / 32: byte * 3^n mod 256, times 3, top two bits), 80 from
+ * qs[32..47] (planes of 16), 16 from qh (4 planes of 4) */
+static int orc_tq1_trit(const orc_block_tq1_0 * b, int e) {
+    static const uint8_t pow3[6] = {1, 3, 9, 27, 81, 243};
+    uint8_t q;
+    if (e < 160)      q = (uint8_t)(b->qs[e % 32] * pow3[e / 32]);
+    else if (e < 240) q = (uint8_t)(b->qs[32 + (e - 160) % 16] * pow3[(e - 160) / 16]);
+    else              q = (uint8_t)(b->qh[(e - 240) % 4] * pow3[(e - 240) / 4]);
+    return (int)(((uint16_t) q * 3) >> 8);
+}
+static int orc_tq2_q(const orc_block_tq2_0 * b, int e) { return (b->qs[32 * (e / 128) + e % 32] >> (2 * ((e % 128) / 32))) & 3; }
+void orc_dequantize_row_tq1_0(const orc_block_tq1_0 * x, float * y, int64_t k) {
+    const int64_t nb = k / ORC_QK_K;
+    for (int64_t i = 0; i < nb; i++) {
+        const float d = orc_fp16_to_fp32(x[i].d);
+        for (int e = 0; e < 256; e++) y[i*256 + e] = (float)(orc_tq1_trit(&x[i], e) - 1) * d;
+    }
+}
+void orc_dequantize_row_tq2_0(const orc_block_tq2_0 * x, float * y, int64_t k) {
+    const int64_t nb = k / ORC_QK_K;
+    for (int64_t i = 0; i < nb; i++) {
+        const float d = orc_fp16_to_fp32(x[i].d);
+        for (int e = 0; e < 256; e++) y[i*256 + e] = (float)(orc_tq2_q(&x[i], e) - 1) * d;
+    }
+}
 /* Q2_K / Q3_K element (n128 = which 128, j = 2-bit plane 0..3, h = which half of the 32 bytes, l = 0..15): index n128 * 128 + j * 32 + h * 16 + l */
 void orc_dequantize_row_q2_K(const orc_block_q2_K * x, float * y, int64_t k) {
     const int64_t nb = k / ORC_QK_K;
@@ -371,6 +397,8 @@ void orc_dequantize_row(int type, const void * x, float * y, int64_t k) {
         case ORC_Q5_1: orc_dequantize_row_q5_1((const orc_block_q5_1 *) x, y, k); break;
         case ORC_IQ4_NL: orc_dequantize_row_iq4_nl((const orc_block_iq4_nl *) x, y, k); break;
         case ORC_IQ4_XS: orc_dequantize_row_iq4_xs((const orc_block_iq4_xs *) x, y, k); break;
+        case ORC_TQ1_0: orc_dequantize_row_tq1_0((const orc_block_tq1_0 *) x, y, k); break;
+        case ORC_TQ2_0: orc_dequantize_row_tq2_0((const orc_block_tq2_0 *) x, y, k); break;
         case ORC_MXFP4: orc_dequantize_row_mxfp4((const orc_block_mxfp4 *) x, y, k); break;
         case ORC_Q2_K: orc_dequantize_row_q2_K((const orc_block_q2_K *) x, y, k); break;
         case ORC_Q3_K: orc_dequantize_row_q3_K((const orc_block_q3_K *) x, y, k); break;
@@ -658,6 +686,43 @@ float orc_vec_dot_iq4_xs_q8_K_avx2(int64_t n, const orc_block_iq4_xs * x, const 
             }
         }
         for (int L = 0; L < 8; L++) acc[L] = fmaf(d, (float) sumi[L], acc[L]);
+    }
+    return hsum8(acc);
+}
+
+/* ggml_vec_dot_tq1_0_q8_K / ggml_vec_dot_tq2_0_q8_K, AVX2 (arch/x86/quants.c:1080-1210, 1212-1270): 16-bit lane sums that cannot overflow, bsums subtracted LANE-wise
+ * (16-bit lane t takes bsums[t]), madd with ones (lanes 2L, 2L + 1 -> L), then (float) sumi * d + sumf: a multiply and an add in the source, and the reference build keeps them apart (two roundings; ORC_TQ_FMA = 1 fails the pin) */
+#ifndef ORC_TQ_FMA
+#define ORC_TQ_FMA 0
+#endif
+static float orc_tq_fold(float d, int32_t sumi, float acc) { return ORC_TQ_FMA ? fmaf((float) sumi, d, acc) : (float) sumi * d + acc; }
+float orc_vec_dot_tq1_0_q8_K_avx2(int64_t n, const orc_block_tq1_0 * x, const orc_block_q8_K * y) {
+    const int64_t nb = n / ORC_QK_K;
+    float acc[8] = {0};
+    for (int64_t i = 0; i < nb; i++) {
+        const float d = y[i].d * orc_fp16_to_fp32(x[i].d);
+        for (int L = 0; L < 8; L++) {
+            int32_t s = 0;
+            for (int c = 0; c < 8; c++)
+                for (int e = 0; e < 4; e++) s += orc_tq1_trit(&x[i], 32 * c + 4 * L + e) * (int) y[i].qs[32 * c + 4 * L + e];
+            s -= (int) y[i].bsums[2 * L] + (int) y[i].bsums[2 * L + 1];
+            acc[L] = orc_tq_fold(d, s, acc[L]);
+        }
+    }
+    return hsum8(acc);
+}
+float orc_vec_dot_tq2_0_q8_K_avx2(int64_t n, const orc_block_tq2_0 * x, const orc_block_q8_K * y) {
+    const int64_t nb = n / ORC_QK_K;
+    float acc[8] = {0};
+    for (int64_t i = 0; i < nb; i++) {
+        const float d = y[i].d * orc_fp16_to_fp32(x[i].d);
+        for (int L = 0; L < 8; L++) {
+            int32_t s = 0;
+            for (int c = 0; c < 8; c++)
+                for (int e = 0; e < 4; e++) s += orc_tq2_q(&x[i], 32 * c + 4 * L + e) * (int) y[i].qs[32 * c + 4 * L + e];
+            s -= (int) y[i].bsums[2 * L] + (int) y[i].bsums[2 * L + 1];
+            acc[L] = orc_tq_fold(d, s, acc[L]);
+        }
     }
     return hsum8(acc);
 }
@@ -1019,7 +1084,7 @@ static int vec_dot_type_of(int wtype) {
     switch (wtype) {             /* type_traits_cpu[], ggml-cpu/ggml-cpu.c:207-390 */
         case ORC_Q4_0: case ORC_Q8_0: case ORC_Q5_0: case ORC_IQ4_NL: case ORC_MXFP4: return ORC_Q8_0;
         case ORC_Q4_1: case ORC_Q5_1: return ORC_Q8_1;
-        case ORC_Q4_K: case ORC_Q5_K: case ORC_Q6_K: case ORC_Q2_K: case ORC_Q3_K: case ORC_IQ4_XS: return ORC_Q8_K;
+        case ORC_Q4_K: case ORC_Q5_K: case ORC_Q6_K: case ORC_Q2_K: case ORC_Q3_K: case ORC_IQ4_XS: case ORC_TQ1_0: case ORC_TQ2_0: return ORC_Q8_K;
         case ORC_F16:  return ORC_F16;
         case ORC_F32:  return ORC_F32;
     }
@@ -1053,6 +1118,8 @@ static float vec_dot(int wtype, int64_t n, const void * w, const void * a) {
         case ORC_IQ4_NL: return orc_vec_dot_iq4_nl_q8_0_avx2(n, (const orc_block_iq4_nl *) w, (const orc_block_q8_0 *) a, 0);
         case ORC_MXFP4: return orc_vec_dot_mxfp4_q8_0_avx2(n, (const orc_block_mxfp4 *) w, (const orc_block_q8_0 *) a);
         case ORC_IQ4_XS: return orc_vec_dot_iq4_xs_q8_K_avx2(n, (const orc_block_iq4_xs *) w, (const orc_block_q8_K *) a);
+        case ORC_TQ1_0: return orc_vec_dot_tq1_0_q8_K_avx2(n, (const orc_block_tq1_0 *) w, (const orc_block_q8_K *) a);
+        case ORC_TQ2_0: return orc_vec_dot_tq2_0_q8_K_avx2(n, (const orc_block_tq2_0 *) w, (const orc_block_q8_K *) a);
         case ORC_Q2_K: return orc_vec_dot_q2_K_q8_K_avx2(n, (const orc_block_q2_K *) w, (const orc_block_q8_K *) a);
         case ORC_Q3_K: return orc_vec_dot_q3_K_q8_K_avx2(n, (const orc_block_q3_K *) w, (const orc_block_q8_K *) a);
         case ORC_F16: {

@@ -2,8 +2,8 @@
 scale bytes so that every bit pattern of the 6-bit scale packing is exercised)"""
 import numpy as np
 
-TYPE_SIZE = {2: 18, 3: 20, 8: 34, 12: 144, 13: 176, 14: 210, 6: 22, 7: 24, 10: 84, 11: 110, 20: 18, 39: 17, 23: 136}
-BLCK = {2: 32, 3: 32, 8: 32, 12: 256, 13: 256, 14: 256, 6: 32, 7: 32, 10: 256, 11: 256, 20: 32, 39: 32, 23: 256}
+TYPE_SIZE = {2: 18, 3: 20, 8: 34, 12: 144, 13: 176, 14: 210, 6: 22, 7: 24, 10: 84, 11: 110, 20: 18, 39: 17, 23: 136, 34: 54, 35: 66}
+BLCK = {2: 32, 3: 32, 8: 32, 12: 256, 13: 256, 14: 256, 6: 32, 7: 32, 10: 256, 11: 256, 20: 32, 39: 32, 23: 256, 34: 256, 35: 256}
 
 
 def rand_blocks(t, rows, K, rng, d_scale=0.01):
@@ -21,6 +21,14 @@ def rand_blocks(t, rows, K, rng, d_scale=0.01):
         dm = (rng.uniform(0.25, 1.0, (rows, nb)) * d_scale).astype(np.float16)
         out[:, :, 80:82] = d.view(np.uint8).reshape(rows, nb, 2)
         out[:, :, 82:84] = dm.view(np.uint8).reshape(rows, nb, 2)
+        return np.ascontiguousarray(out.reshape(rows, nb * TYPE_SIZE[t]))
+    if t in (34, 35):   # TQ1_0: qs[48] qh[4] d (any byte decodes to trits 0..2); TQ2_0: qs[64] d, 2-bit values 0..2 (and a few 3s: "should not be", but the arithmetic is defined)
+        off = 52 if t == 34 else 64
+        if t == 35:
+            q = rng.integers(0, 3, (rows, nb, 64, 4), dtype=np.uint8)
+            q[rng.random((rows, nb, 64, 4)) < 0.01] = 3
+            out[:, :, :64] = q[..., 0] | (q[..., 1] << 2) | (q[..., 2] << 4) | (q[..., 3] << 6)
+        out[:, :, off:off + 2] = d.view(np.uint8).reshape(rows, nb, 2)
         return np.ascontiguousarray(out.reshape(rows, nb * TYPE_SIZE[t]))
     if t == 11:         # Q3_K: hmask[32] qs[64] scales[12] d
         out[:, :, 108:110] = d.view(np.uint8).reshape(rows, nb, 2)
