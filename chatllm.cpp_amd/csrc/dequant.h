@@ -2,7 +2,38 @@
 // 1352-1373 Q4_K with get_scale_min_k4 :703-711): shared by GET_ROWS (ops.hip) and the dense fp16 prefill path (dense_f16.hip)
 #pragma once
 #include "common.h"
+#include "iq_grids.h"
 
+// the grid formats: for the 32-element sub-block ib of a block and the 8-group l (elements 8 l .. 8 l + 7 of it), the FOUR signed codebook magnitudes of its half
+// `half` (int8 x 4), and the sub-block's scale nibble(s).  Shared by GET_ROWS (dequant_elem) and the mat-mul (gemv_kq.hip).  Layouts: ggml-common.h:346-390.
+__device__ __forceinline__ uint32_t iq_grid_w4(int type, const char * blk, int ib, int l, int half, int & ls_lo, int & ls_hi) {
+    const uint8_t * b8 = (const uint8_t *) blk;
+    auto u16 = [&](int o) { return (uint32_t) b8[o] | ((uint32_t) b8[o + 1] << 8); };
+    auto u32 = [&](int o) { return u16(o) | (u16(o + 2) << 16); };
+    uint32_t mag, s8;
+    if (type == CLLM_TYPE_IQ2_XXS) {
+        const uint32_t a0 = u32(2 + 8 * ib), a1 = u32(2 + 8 * ib + 4);
+        ls_lo = ls_hi = (int)(a1 >> 28);
+        mag = iq2_code_bytes4(IQ2XXS_CODE[(a0 >> (8 * l)) & 0xff], 4 * half); s8 = iq_ksigns((a1 >> (7 * l)) & 127);
+    } else if (type == CLLM_TYPE_IQ2_XS) {
+        const uint32_t q = u16(2 + 2 * (4 * ib + l)), sc = b8[66 + ib];
+        ls_lo = sc & 15; ls_hi = sc >> 4;
+        mag = iq2_code_bytes4(IQ2XS_CODE[q & 511], 4 * half); s8 = iq_ksigns(q >> 9);
+    } else if (type == CLLM_TYPE_IQ2_S) {
+        const uint32_t sc = b8[74 + ib], idx = b8[2 + 4 * ib + l] | (((uint32_t) b8[66 + ib] << (8 - 2 * l)) & 0x300);
+        ls_lo = sc & 15; ls_hi = sc >> 4;
+        mag = iq2_code_bytes4(IQ2S_CODE[idx], 4 * half); s8 = b8[2 + 32 + 4 * ib + l];
+    } else if (type == CLLM_TYPE_IQ3_XXS) {
+        const uint32_t a = u32(2 + 64 + 4 * ib);
+        ls_lo = ls_hi = (int)(a >> 28);
+        mag = iq3xxs_code_bytes4(IQ3XXS_CODE[b8[2 + 8 * ib + 2 * l + half]]); s8 = iq_ksigns((a >> (7 * l)) & 127);
+    } else {
+        const uint32_t idx = b8[2 + 8 * ib + 2 * l + half] | (((uint32_t) b8[66 + ib] << (8 - 2 * l - half)) & 256);
+        ls_lo = ls_hi = (b8[106 + ib / 2] >> (4 * (ib & 1))) & 15;
+        mag = iq3s_code_bytes4(IQ3S_CODE[idx]); s8 = b8[74 + 4 * ib + l];
+    }
+    return iq_apply_signs4(mag, (s8 >> (4 * half)) & 15u);
+}
 __device__ __forceinline__ float dequant_elem(int type, const char * row, int64_t i) {
     switch (type) {
         case CLLM_TYPE_F32: return ((const float *) row)[i];
@@ -76,6 +107,18 @@ __device__ __forceinline__ float dequant_elem(int type, const char * row, int64_
             const int nib = j < 16 ? (qb & 0xF) : (qb >> 4);
             const uint64_t tab = nib < 8 ? 0xf6eaddcfbfad9881ull : 0x7159453526190d01ull;
             return dl * (float)(int8_t)((tab >> (8 * (nib & 7))) & 0xff);
+        }
+        case CLLM_TYPE_IQ2_XXS: case CLLM_TYPE_IQ2_XS: case CLLM_TYPE_IQ2_S: case CLLM_TYPE_IQ3_XXS: case CLLM_TYPE_IQ3_S: {
+            // dequantize_row_iq2_xxs / _iq2_xs / _iq2_s / _iq3_xxs / _iq3_s (ggml-quants.c:2275-2460): y = db * magnitude * (+-1.f), db = d * (0.5f + ls) * 0.25f (IQ2), * 0.5f
+            // (IQ3_XXS), d * (1 + 2 ls) (IQ3_S) -- in these operation orders
+            const int bs = type == CLLM_TYPE_IQ2_XXS ? 66 : type == CLLM_TYPE_IQ2_XS ? 74 : type == CLLM_TYPE_IQ2_S ? 82 : type == CLLM_TYPE_IQ3_XXS ? 98 : 110;
+            const char * blk = row + (i / 256) * bs; const int e = (int)(i % 256), ib = e / 32, l = (e % 32) / 8, half = (e % 8) / 4, k = e % 4;
+            int ls_lo, ls_hi;
+            const uint32_t w4 = iq_grid_w4(type, blk, ib, l, half, ls_lo, ls_hi);
+            const int w = (int)(int8_t)((w4 >> (8 * k)) & 0xff), ls = (e % 32) < 16 ? ls_lo : ls_hi;
+            const float d = h2f(*(const uint16_t *) blk);
+            const float db = type == CLLM_TYPE_IQ3_S ? d * (float)(1 + 2 * ls) : type == CLLM_TYPE_IQ3_XXS ? d * (0.5f + (float) ls) * 0.5f : d * (0.5f + (float) ls) * 0.25f;
+            return db * (float)(w < 0 ? -w : w) * (w < 0 ? -1.0f : 1.0f);
         }
         case CLLM_TYPE_TQ1_0: {                    // dequantize_row_tq1_0 (ggml-quants.c:2215-2252): trit = ((byte * 3^n mod 256) * 3) >> 8, planes of 32 / 16 / 4 bytes
             const block_tq1_0 * b = (const block_tq1_0 *) row + i / 256; const int e = (int)(i % 256);

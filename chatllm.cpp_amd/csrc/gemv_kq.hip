@@ -6,6 +6,8 @@
 //   q2_K :1278-1354   acc[A] = fma(dmin, m[2A] S16[2A] + m[2A+1] S16[2A+1], acc[A]) then acc[A] = fma(d, sumi[A], acc[A]) (S16: activation sums per 16)
 //   q3_K :1470-1580   2 bits + a high-bit mask (value - 4 where the bit is clear), 6-bit scales - 32
 //   q5_0 :846-884, q5_1 :926-968    Q4_0's / Q4_1's chains with a fifth bit per weight
+//   iq2_xxs :2372-, iq2_xs :2490-, iq2_s :2787-, iq3_xxs :2972-, iq3_s :3096-   codebook ("grid") formats: signed magnitudes from iq_grids.h, an odd integer scale 2 ls + 1 per 16 or 32,
+//                     one fma per super-block and lane, the result scaled by 1/8 (IQ2), 1/4 (IQ3_XXS), 1 (IQ3_S) AFTER the horizontal sum
 //   tq1_0 :1080-1210, tq2_0 :1212-1270   ternary weights; sumi[A] - (bsums[2A] + bsums[2A+1]), then (float) sumi * d + acc as TWO roundings (the build keeps the multiply and the add)
 //   iq4_xs :3716-3764   256-weight super-blocks of IQ4_NL codes with a 6-bit scale - 32 per 32: the K-quants' single fma per super-block and lane
 //   iq4_nl :3632-3714, mxfp4 :760-844   int8 codebooks; even blocks in one 8-lane accumulator, odd ones in a second, added before the horizontal sum, an unpaired
@@ -16,6 +18,7 @@
 // hsum_float_8 are lane exchanges at the end.  Activations: the act rows of quantize.hip (common.h layout: Q8_K, Q8_0 or Q8_1 kind).  Blocks that are only
 // 2-byte (1-byte: MXFP4) aligned are read in 16-bit (8-bit) pieces.  This is the coverage path (it streams at a fraction of the Q4_K kernels' rate), not a tuned one.
 #include "common.h"
+#include "dequant.h"
 #include "q4k.h"
 
 
@@ -123,6 +126,18 @@ __global__ void __launch_bounds__(256) k_gemv_kq(const kq_args a) {
                 }
             }
             if (Q2) { mn[0] = ((uint8_t) s16[2 * A]) >> 4; mn[1] = ((uint8_t) s16[2 * A + 1]) >> 4; }
+        } else if (is_iq_grid_type(TYPE)) {
+            // sub-block ib, lane A: the 8-group l = A >> 1, its half A & 1 -> four signed magnitudes; the scale of the lane's 16: 2 ls + 1
+            constexpr int BS = TYPE == CLLM_TYPE_IQ2_XXS ? 66 : TYPE == CLLM_TYPE_IQ2_XS ? 74 : TYPE == CLLM_TYPE_IQ2_S ? 82 : TYPE == CLLM_TYPE_IQ3_XXS ? 98 : 110;
+            const char * blk = wr + (int64_t) b * BS;
+            dw = h2f(*(const uint16_t *) blk);
+#pragma unroll
+            for (int ib = 0; ib < 8; ib++) {
+                int ls_lo, ls_hi;
+                w[ib] = iq_grid_w4(TYPE, blk, ib, A >> 1, A & 1, ls_lo, ls_hi);
+                sc8[ib] = (int8_t)(2 * ((A >> 2) ? ls_hi : ls_lo) + 1);
+                aoff[ib] = 32 * ib + 4 * A;
+            }
         } else if (TYPE == CLLM_TYPE_TQ2_0) {
             // plane l (bits 2l) of the j-th 32 bytes = elements 128 j + 32 l + (0..31): lane A takes bytes 4A..4A+3 of every plane; the weight is q - 1, the "- 1" comes off below
             const char * blk = wr + (int64_t) b * 66;
@@ -220,6 +235,7 @@ __global__ void __launch_bounds__(256) k_gemv_kq(const kq_args a) {
         v = v + dpp_f<DPP_QUAD_XOR2>(v);                                      // (.. 0) + (.. 2), (.. 1) + (.. 3)
         v = v + dpp_f<DPP_QUAD_XOR1>(v);
         if (TYPE == CLLM_TYPE_Q5_K) v = v + summs[c];
+        if (is_iq_grid_type(TYPE)) v = (TYPE == CLLM_TYPE_IQ3_S ? 1.0f : TYPE == CLLM_TYPE_IQ3_XXS ? 0.25f : 0.125f) * v;
         if (live && A == 0 && c < a.ncols) dstb[(int64_t) c * a.ldd + row] = v;
     }
 }
@@ -307,6 +323,11 @@ static void kq_launch(hipStream_t st, int wtype, const kq_args & a, dim3 grid, b
         case CLLM_TYPE_IQ4_XS: GO(CLLM_TYPE_IQ4_XS); break;
         case CLLM_TYPE_TQ1_0: GO(CLLM_TYPE_TQ1_0); break;
         case CLLM_TYPE_TQ2_0: GO(CLLM_TYPE_TQ2_0); break;
+        case CLLM_TYPE_IQ2_XXS: GO(CLLM_TYPE_IQ2_XXS); break;
+        case CLLM_TYPE_IQ2_XS: GO(CLLM_TYPE_IQ2_XS); break;
+        case CLLM_TYPE_IQ2_S: GO(CLLM_TYPE_IQ2_S); break;
+        case CLLM_TYPE_IQ3_XXS: GO(CLLM_TYPE_IQ3_XXS); break;
+        case CLLM_TYPE_IQ3_S: GO(CLLM_TYPE_IQ3_S); break;
         case CLLM_TYPE_Q5_0: GB(CLLM_TYPE_Q5_0, true); break;
         case CLLM_TYPE_Q5_1: GB(CLLM_TYPE_Q5_1, true); break;
         case CLLM_TYPE_IQ4_NL: if (chain) GB(CLLM_TYPE_IQ4_NL, true); else GB(CLLM_TYPE_IQ4_NL, false); break;

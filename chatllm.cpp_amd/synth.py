@@ -8,7 +8,7 @@ import zlib
 
 import numpy as np
 
-from .tensor import F32, Q4_0, Q4_1, Q8_0, Q4_K, Q5_K, Q6_K, Q5_0, Q5_1, Q2_K, Q3_K, IQ4_NL, MXFP4, IQ4_XS, TQ1_0, TQ2_0, TYPE_SIZE, BLCK  # noqa: F401
+from .tensor import F32, Q4_0, Q4_1, Q8_0, Q4_K, Q5_K, Q6_K, Q5_0, Q5_1, Q2_K, Q3_K, IQ4_NL, MXFP4, IQ4_XS, TQ1_0, TQ2_0, IQ2_XXS, IQ2_XS, IQ2_S, IQ3_XXS, IQ3_S, TYPE_SIZE, BLCK  # noqa: F401
 
 CONFIGS = {
     # name: n_layer, hidden, n_head, n_kv_head, head_dim, ffn, vocab
@@ -134,6 +134,10 @@ def quant_blocks(type_, rows, K, rng, sigma):
         out[:, :, 0:2] = _f16_bytes(d).reshape(rows, nb, 2)
         out[:, :, 2:8] = rng.integers(0, 256, (rows, nb, 6), dtype=np.uint8)          # every 6-bit scale pattern, both signs of ls - 32
         out[:, :, 8:] = rng.integers(0, 256, (rows, nb, 128), dtype=np.uint8)
+    elif type_ in (IQ2_XXS, IQ2_XS, IQ2_S, IQ3_XXS, IQ3_S):             # the codebook formats (ggml-common.h:346-390): fp16 d, then indices / signs / scales -- every bit pattern is a valid block
+        out = rng.integers(0, 256, (rows, nb, TYPE_SIZE[type_]), dtype=np.uint8)
+        rms = {IQ2_XXS: 29.0 * 2.0, IQ2_XS: 29.0 * 2.0, IQ2_S: 29.0 * 2.0, IQ3_XXS: 33.0 * 4.0, IQ3_S: 9.2 * 16.0}[type_]        # magnitude rms x mean scale factor
+        out[:, :, 0:2] = _f16_bytes(rng.uniform(0.5, 1.5, (rows, nb)) * sigma / rms).reshape(rows, nb, 2)
     elif type_ == TQ2_0:                                                # qs[64] d (ggml-common.h:251-256): w = (q - 1) d, q in 0..2 at 2 bits
         out = np.empty((rows, nb, 66), np.uint8)
         q = rng.integers(0, 3, (rows, nb, 64, 4), dtype=np.uint8)

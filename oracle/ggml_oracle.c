@@ -35,6 +35,8 @@ size_t orc_type_size(int type) {
         case ORC_Q5_0: return sizeof(orc_block_q5_0);  case ORC_Q5_1: return sizeof(orc_block_q5_1);
         case ORC_IQ4_NL: return sizeof(orc_block_iq4_nl);  case ORC_MXFP4: return sizeof(orc_block_mxfp4);  case ORC_IQ4_XS: return sizeof(orc_block_iq4_xs);
         case ORC_TQ1_0: return sizeof(orc_block_tq1_0);  case ORC_TQ2_0: return sizeof(orc_block_tq2_0);
+        case ORC_IQ2_XXS: return sizeof(orc_block_iq2_xxs);  case ORC_IQ2_XS: return sizeof(orc_block_iq2_xs);  case ORC_IQ2_S: return sizeof(orc_block_iq2_s);
+        case ORC_IQ3_XXS: return sizeof(orc_block_iq3_xxs);  case ORC_IQ3_S: return sizeof(orc_block_iq3_s);
         case ORC_Q2_K: return sizeof(orc_block_q2_K);  case ORC_Q3_K: return sizeof(orc_block_q3_K);
     }
     return 0;
@@ -42,7 +44,7 @@ size_t orc_type_size(int type) {
 int orc_blck_size(int type) {
     switch (type) {
         case ORC_Q4_0: case ORC_Q8_0: case ORC_Q4_1: case ORC_Q8_1: case ORC_Q5_0: case ORC_Q5_1: case ORC_IQ4_NL: case ORC_MXFP4: return ORC_QK;
-        case ORC_Q4_K: case ORC_Q5_K: case ORC_Q6_K: case ORC_Q8_K: case ORC_Q2_K: case ORC_Q3_K: case ORC_IQ4_XS: case ORC_TQ1_0: case ORC_TQ2_0: return ORC_QK_K;
+        case ORC_Q4_K: case ORC_Q5_K: case ORC_Q6_K: case ORC_Q8_K: case ORC_Q2_K: case ORC_Q3_K: case ORC_IQ4_XS: case ORC_TQ1_0: case ORC_TQ2_0: case ORC_IQ2_XXS: case ORC_IQ2_XS: case ORC_IQ2_S: case ORC_IQ3_XXS: case ORC_IQ3_S: return ORC_QK_K;
         case ORC_F32: case ORC_F16: case ORC_I32: case ORC_I64: return 1;
     }
     return 0;
@@ -322,6 +324,101 @@ void orc_dequantize_row_iq4_xs(const orc_block_iq4_xs * x, float * y, int64_t k)
         }
     }
 }
+/* ---- the grid formats.  One decoder per format: the 256 signed codebook magnitudes of a super-block (int8), the odd integer scale of every 16 elements (the AVX2 dot
+ * products multiply by it) and the float the dequantizer multiplies by (db, in ITS operation order) ---- */
+#include "../chatllm.cpp_amd/csrc/iq_grids.h"
+typedef struct { int8_t w[256]; int sc16[16]; float db16[16]; float d; } orc_iq_dec;
+static void orc_iq_put8(orc_iq_dec * o, int e0, uint32_t lo4, uint32_t hi4, uint32_t signs8) {
+    const uint32_t a = iq_apply_signs4(lo4, signs8 & 15u), b = iq_apply_signs4(hi4, signs8 >> 4);
+    for (int k = 0; k < 4; k++) { o->w[e0 + k] = (int8_t)((a >> (8 * k)) & 0xff); o->w[e0 + 4 + k] = (int8_t)((b >> (8 * k)) & 0xff); }
+}
+static void orc_iq_decode(int type, const void * blk, orc_iq_dec * o) {
+    if (type == ORC_IQ2_XXS) {                      /* dequantize_row_iq2_xxs (ggml-quants.c:2275-2303): db = d * (0.5f + ls) * 0.25f */
+        const orc_block_iq2_xxs * b = (const orc_block_iq2_xxs *) blk;
+        o->d = orc_fp16_to_fp32(b->d);
+        for (int ib = 0; ib < 8; ib++) {
+            uint32_t aux[2]; memcpy(aux, b->qs + 4 * ib, 8);
+            const int ls = (int)(aux[1] >> 28);
+            for (int h = 0; h < 2; h++) { o->sc16[2 * ib + h] = 2 * ls + 1; o->db16[2 * ib + h] = o->d * (0.5f + (float) ls) * 0.25f; }
+            for (int l = 0; l < 4; l++) {
+                const uint32_t code = IQ2XXS_CODE[(aux[0] >> (8 * l)) & 0xff];
+                orc_iq_put8(o, 32 * ib + 8 * l, iq2_code_bytes4(code, 0), iq2_code_bytes4(code, 4), iq_ksigns((aux[1] >> (7 * l)) & 127));
+            }
+        }
+    } else if (type == ORC_IQ2_XS) {                /* dequantize_row_iq2_xs (:2307-2334): a 4-bit scale per 16 */
+        const orc_block_iq2_xs * b = (const orc_block_iq2_xs *) blk;
+        o->d = orc_fp16_to_fp32(b->d);
+        for (int ib = 0; ib < 8; ib++) {
+            for (int h = 0; h < 2; h++) { const int ls = (b->scales[ib] >> (4 * h)) & 0xf; o->sc16[2 * ib + h] = 2 * ls + 1; o->db16[2 * ib + h] = o->d * (0.5f + (float) ls) * 0.25f; }
+            for (int l = 0; l < 4; l++) {
+                const uint32_t q = b->qs[4 * ib + l], code = IQ2XS_CODE[q & 511];
+                orc_iq_put8(o, 32 * ib + 8 * l, iq2_code_bytes4(code, 0), iq2_code_bytes4(code, 4), iq_ksigns(q >> 9));
+            }
+        }
+    } else if (type == ORC_IQ2_S) {                 /* dequantize_row_iq2_s (:2338-2371): 10-bit grid index (qs | two bits of qh), explicit sign bytes */
+        const orc_block_iq2_s * b = (const orc_block_iq2_s *) blk;
+        o->d = orc_fp16_to_fp32(b->d);
+        for (int ib = 0; ib < 8; ib++) {
+            for (int h = 0; h < 2; h++) { const int ls = (b->scales[ib] >> (4 * h)) & 0xf; o->sc16[2 * ib + h] = 2 * ls + 1; o->db16[2 * ib + h] = o->d * (0.5f + (float) ls) * 0.25f; }
+            for (int l = 0; l < 4; l++) {
+                const uint32_t code = IQ2S_CODE[b->qs[4 * ib + l] | ((b->qh[ib] << (8 - 2 * l)) & 0x300)];
+                orc_iq_put8(o, 32 * ib + 8 * l, iq2_code_bytes4(code, 0), iq2_code_bytes4(code, 4), b->qs[32 + 4 * ib + l]);
+            }
+        }
+    } else if (type == ORC_IQ3_XXS) {               /* dequantize_row_iq3_xxs (:2375-2407): db = d * (0.5f + ls) * 0.5f */
+        const orc_block_iq3_xxs * b = (const orc_block_iq3_xxs *) blk;
+        o->d = orc_fp16_to_fp32(b->d);
+        for (int ib = 0; ib < 8; ib++) {
+            uint32_t aux; memcpy(&aux, b->qs + 64 + 4 * ib, 4);
+            const int ls = (int)(aux >> 28);
+            for (int h = 0; h < 2; h++) { o->sc16[2 * ib + h] = 2 * ls + 1; o->db16[2 * ib + h] = o->d * (0.5f + (float) ls) * 0.5f; }
+            for (int l = 0; l < 4; l++)
+                orc_iq_put8(o, 32 * ib + 8 * l, iq3xxs_code_bytes4(IQ3XXS_CODE[b->qs[8 * ib + 2 * l]]), iq3xxs_code_bytes4(IQ3XXS_CODE[b->qs[8 * ib + 2 * l + 1]]), iq_ksigns((aux >> (7 * l)) & 127));
+        }
+    } else {                                        /* dequantize_row_iq3_s (:2411-2460): db = d * (1 + 2 * ls), one 4-bit scale per 32 */
+        const orc_block_iq3_s * b = (const orc_block_iq3_s *) blk;
+        o->d = orc_fp16_to_fp32(b->d);
+        for (int ib = 0; ib < 8; ib++) {
+            const int ls = (b->scales[ib / 2] >> (4 * (ib & 1))) & 0xf;
+            for (int h = 0; h < 2; h++) { o->sc16[2 * ib + h] = 2 * ls + 1; o->db16[2 * ib + h] = o->d * (float)(1 + 2 * ls); }
+            for (int l = 0; l < 4; l++) {
+                const uint32_t i1 = b->qs[8 * ib + 2 * l] | ((b->qh[ib] << (8 - 2 * l)) & 256), i2 = b->qs[8 * ib + 2 * l + 1] | ((b->qh[ib] << (7 - 2 * l)) & 256);
+                orc_iq_put8(o, 32 * ib + 8 * l, iq3s_code_bytes4(IQ3S_CODE[i1]), iq3s_code_bytes4(IQ3S_CODE[i2]), b->signs[4 * ib + l]);
+            }
+        }
+    }
+}
+void orc_dequantize_row_iq_grid(int type, const void * x, float * y, int64_t k) {
+    const int64_t nb = k / ORC_QK_K; const size_t bs = orc_type_size(type);
+    orc_iq_dec o;
+    for (int64_t i = 0; i < nb; i++) {
+        orc_iq_decode(type, (const char *) x + i * bs, &o);
+        for (int e = 0; e < 256; e++) {             /* y = db * grid[j] * (sign ? -1.f : 1.f) */
+            const int m = o.w[e] < 0 ? -o.w[e] : o.w[e];
+            y[i*256 + e] = o.db16[e / 16] * (float) m * (o.w[e] < 0 ? -1.0f : 1.0f);
+        }
+    }
+}
+static inline float hsum8(const float x[8]);
+float orc_vec_dot_iq_grid_q8_K_avx2(int type, int64_t n, const void * x, const orc_block_q8_K * y) {
+    const int64_t nb = n / ORC_QK_K; const size_t bs = orc_type_size(type);
+    float acc[8] = {0};
+    orc_iq_dec o;
+    for (int64_t i = 0; i < nb; i++) {
+        orc_iq_decode(type, (const char *) x + i * bs, &o);
+        const float d = o.d * y[i].d;
+        for (int L = 0; L < 8; L++) {
+            int32_t sumi = 0;
+            for (int c = 0; c < 8; c++) {
+                int p = 0;
+                for (int e = 0; e < 4; e++) p += (int) o.w[32 * c + 4 * L + e] * (int) y[i].qs[32 * c + 4 * L + e];
+                sumi += o.sc16[2 * c + (L >> 2)] * p;
+            }
+            acc[L] = fmaf(d, (float) sumi, acc[L]);
+        }
+    }
+    return (type == ORC_IQ3_S ? 1.0f : type == ORC_IQ3_XXS ? 0.25f : 0.125f) * hsum8(acc);
+}
 /* the trit of element e (dequantize order, ggml-quants.c:2215-2252): 160 elements from qs[0..31] (plane n = e / 32: byte * 3^n mod 256, times 3, top two bits), 80 from
  * qs[32..47] (planes of 16), 16 from qh (4 planes of 4) */
 static int orc_tq1_trit(const orc_block_tq1_0 * b, int e) {
@@ -399,6 +496,7 @@ void orc_dequantize_row(int type, const void * x, float * y, int64_t k) {
         case ORC_IQ4_XS: orc_dequantize_row_iq4_xs((const orc_block_iq4_xs *) x, y, k); break;
         case ORC_TQ1_0: orc_dequantize_row_tq1_0((const orc_block_tq1_0 *) x, y, k); break;
         case ORC_TQ2_0: orc_dequantize_row_tq2_0((const orc_block_tq2_0 *) x, y, k); break;
+        case ORC_IQ2_XXS: case ORC_IQ2_XS: case ORC_IQ2_S: case ORC_IQ3_XXS: case ORC_IQ3_S: orc_dequantize_row_iq_grid(type, x, y, k); break;
         case ORC_MXFP4: orc_dequantize_row_mxfp4((const orc_block_mxfp4 *) x, y, k); break;
         case ORC_Q2_K: orc_dequantize_row_q2_K((const orc_block_q2_K *) x, y, k); break;
         case ORC_Q3_K: orc_dequantize_row_q3_K((const orc_block_q3_K *) x, y, k); break;
@@ -1084,7 +1182,7 @@ static int vec_dot_type_of(int wtype) {
     switch (wtype) {             /* type_traits_cpu[], ggml-cpu/ggml-cpu.c:207-390 */
         case ORC_Q4_0: case ORC_Q8_0: case ORC_Q5_0: case ORC_IQ4_NL: case ORC_MXFP4: return ORC_Q8_0;
         case ORC_Q4_1: case ORC_Q5_1: return ORC_Q8_1;
-        case ORC_Q4_K: case ORC_Q5_K: case ORC_Q6_K: case ORC_Q2_K: case ORC_Q3_K: case ORC_IQ4_XS: case ORC_TQ1_0: case ORC_TQ2_0: return ORC_Q8_K;
+        case ORC_Q4_K: case ORC_Q5_K: case ORC_Q6_K: case ORC_Q2_K: case ORC_Q3_K: case ORC_IQ4_XS: case ORC_TQ1_0: case ORC_TQ2_0: case ORC_IQ2_XXS: case ORC_IQ2_XS: case ORC_IQ2_S: case ORC_IQ3_XXS: case ORC_IQ3_S: return ORC_Q8_K;
         case ORC_F16:  return ORC_F16;
         case ORC_F32:  return ORC_F32;
     }
@@ -1120,6 +1218,7 @@ static float vec_dot(int wtype, int64_t n, const void * w, const void * a) {
         case ORC_IQ4_XS: return orc_vec_dot_iq4_xs_q8_K_avx2(n, (const orc_block_iq4_xs *) w, (const orc_block_q8_K *) a);
         case ORC_TQ1_0: return orc_vec_dot_tq1_0_q8_K_avx2(n, (const orc_block_tq1_0 *) w, (const orc_block_q8_K *) a);
         case ORC_TQ2_0: return orc_vec_dot_tq2_0_q8_K_avx2(n, (const orc_block_tq2_0 *) w, (const orc_block_q8_K *) a);
+        case ORC_IQ2_XXS: case ORC_IQ2_XS: case ORC_IQ2_S: case ORC_IQ3_XXS: case ORC_IQ3_S: return orc_vec_dot_iq_grid_q8_K_avx2(wtype, n, w, (const orc_block_q8_K *) a);
         case ORC_Q2_K: return orc_vec_dot_q2_K_q8_K_avx2(n, (const orc_block_q2_K *) w, (const orc_block_q8_K *) a);
         case ORC_Q3_K: return orc_vec_dot_q3_K_q8_K_avx2(n, (const orc_block_q3_K *) w, (const orc_block_q8_K *) a);
         case ORC_F16: {

@@ -25,7 +25,7 @@ extern "C" {
 
 /* numeric values equal the reference's enum ggml_type (ggml/include/ggml.h:386-428) */
 enum orc_type {
-    ORC_F32 = 0, ORC_F16 = 1, ORC_Q4_0 = 2, ORC_Q4_1 = 3, ORC_Q5_0 = 6, ORC_Q5_1 = 7, ORC_Q8_0 = 8, ORC_Q8_1 = 9, ORC_Q2_K = 10, ORC_Q3_K = 11, ORC_Q4_K = 12, ORC_Q5_K = 13, ORC_Q6_K = 14, ORC_Q8_K = 15, ORC_IQ4_NL = 20, ORC_IQ4_XS = 23, ORC_TQ1_0 = 34, ORC_TQ2_0 = 35, ORC_I32 = 26, ORC_I64 = 27, ORC_MXFP4 = 39,
+    ORC_F32 = 0, ORC_F16 = 1, ORC_Q4_0 = 2, ORC_Q4_1 = 3, ORC_Q5_0 = 6, ORC_Q5_1 = 7, ORC_Q8_0 = 8, ORC_Q8_1 = 9, ORC_Q2_K = 10, ORC_Q3_K = 11, ORC_Q4_K = 12, ORC_Q5_K = 13, ORC_Q6_K = 14, ORC_Q8_K = 15, ORC_IQ4_NL = 20, ORC_IQ2_XXS = 16, ORC_IQ2_XS = 17, ORC_IQ3_XXS = 18, ORC_IQ3_S = 21, ORC_IQ2_S = 22, ORC_IQ4_XS = 23, ORC_TQ1_0 = 34, ORC_TQ2_0 = 35, ORC_I32 = 26, ORC_I64 = 27, ORC_MXFP4 = 39,
 };
 
 /* a strided 4-D tensor view: same meaning as ggml_tensor {type, ne, nb, data} (ggml.h:656-688) */
@@ -53,6 +53,12 @@ typedef struct { uint16_t d; uint8_t qh[4]; uint8_t qs[16]; }              orc_b
 typedef struct { uint16_t d; uint16_t m; uint8_t qh[4]; uint8_t qs[16]; }  orc_block_q5_1;   /* 24 B: w = (nib | bit << 4) * d + m */
 typedef struct { uint16_t d; uint8_t qs[16]; }                             orc_block_iq4_nl; /* 18 B: w = kvalues_iq4nl[nib] * d */
 typedef struct { uint16_t d; uint16_t scales_h; uint8_t scales_l[4]; uint8_t qs[128]; } orc_block_iq4_xs; /* 136 B: 256 weights, w = kvalues_iq4nl[nib] * d * (ls - 32), ls = 6-bit scale per 32 (ggml-common.h:421-427) */
+/* the grid formats (ggml-common.h:346-390): 256 weights = 8 sub-blocks of 32; a weight is +-(a codebook magnitude) * d * (a small odd scale) * const; codebooks: ../chatllm.cpp_amd/csrc/iq_grids.h */
+typedef struct { uint16_t d; uint16_t qs[32]; } orc_block_iq2_xxs;                                              /* 66 B: per 32: 4 grid bytes | 4 x 7 sign bits + 4-bit scale */
+typedef struct { uint16_t d; uint16_t qs[32]; uint8_t scales[8]; } orc_block_iq2_xs;                            /* 74 B: per 8: 9-bit grid index | 7 sign bits; a 4-bit scale per 16 */
+typedef struct { uint16_t d; uint8_t qs[64]; uint8_t qh[8]; uint8_t scales[8]; } orc_block_iq2_s;              /* 82 B: qs[0..31] grid index low bytes, qs[32..63] sign bytes, qh 2 high bits per 8 */
+typedef struct { uint16_t d; uint8_t qs[96]; } orc_block_iq3_xxs;                                               /* 98 B: qs[0..63] grid indices (4 weights each), then per 32: 4 x 7 sign bits + 4-bit scale */
+typedef struct { uint16_t d; uint8_t qs[64]; uint8_t qh[8]; uint8_t signs[32]; uint8_t scales[4]; } orc_block_iq3_s;   /* 110 B: 9-bit grid indices (qs | qh bit), sign bytes, a 4-bit scale per 32 */
 typedef struct { uint8_t qs[48]; uint8_t qh[4]; uint16_t d; } orc_block_tq1_0;     /* 54 B: 256 ternary weights, 5 per byte of qs (base 3), 4 per byte of qh; w = (trit - 1) * d (ggml-common.h:241-249) */
 typedef struct { uint8_t qs[64]; uint16_t d; } orc_block_tq2_0;                    /* 66 B: 256 ternary weights, 2 bits each; w = (q - 1) * d (ggml-common.h:251-256) */
 typedef struct { uint8_t e; uint8_t qs[16]; }                              orc_block_mxfp4;  /* 17 B: w = kvalues_mxfp4[nib] * 2^(e - 128) */
@@ -99,6 +105,7 @@ void orc_dequantize_row_q2_K(const orc_block_q2_K * x, float * y, int64_t k);   
 void orc_dequantize_row_q3_K(const orc_block_q3_K * x, float * y, int64_t k);      /* ggml-quants.c:1128-1176 */
 void orc_dequantize_row_iq4_nl(const orc_block_iq4_nl * x, float * y, int64_t k);  /* ggml-quants.c:2512-2528 */
 void orc_dequantize_row_iq4_xs(const orc_block_iq4_xs * x, float * y, int64_t k);  /* ggml-quants.c:2530-2551 */
+void orc_dequantize_row_iq_grid(int type, const void * x, float * y, int64_t k);   /* dequantize_row_iq2_xxs / _iq2_xs / _iq2_s / _iq3_xxs / _iq3_s (ggml-quants.c:2275-2460) */
 void orc_dequantize_row_tq1_0(const orc_block_tq1_0 * x, float * y, int64_t k);    /* ggml-quants.c:2215-2252 */
 void orc_dequantize_row_tq2_0(const orc_block_tq2_0 * x, float * y, int64_t k);    /* ggml-quants.c:2254-2271 */
 void orc_dequantize_row(int type, const void * x, float * y, int64_t k);
@@ -141,6 +148,10 @@ float orc_vec_dot_iq4_xs_q8_K_avx2(int64_t n, const orc_block_iq4_xs * x, const 
 /* TQ1_0 / TQ2_0 (arch/x86/quants.c:1080-1210, 1212-1270): the 8 lanes again -- lane L takes elements 4L..4L+3 of every 32-element chunk; per super-block
  * sumi[L] = sum of trit * activation over its 32 elements - (bsums[2L] + bsums[2L+1]) (the "- 1" of every weight, taken from the activation's block sums lane-wise), then
  * sumf[L] = (float) sumi[L] * (d_y * d_x) + sumf[L] -- a multiply and an add, two roundings: the reference build does not contract `_mm256_add_ps(_mm256_mul_ps(..), sumf)` (pinned) */
+/* ggml_vec_dot_iq2_xxs / iq2_xs / iq2_s / iq3_xxs / iq3_s _q8_K, AVX2 (arch/x86/quants.c:2372-3300): the 8 lanes -- lane L takes elements 4L..4L+3 of every 32-element
+ * sub-block; sumi[L] = sum over sub-blocks of (odd integer scale of the lane's 16) * (signed codebook magnitudes . activation), ONE fma(d_x * d_y, (float) sumi[L], acc[L]) per
+ * super-block, result = c * hsum_float_8(acc), c = 1/8 (IQ2), 1/4 (IQ3_XXS), 1 (IQ3_S) */
+float orc_vec_dot_iq_grid_q8_K_avx2(int type, int64_t n, const void * x, const orc_block_q8_K * y);
 float orc_vec_dot_tq1_0_q8_K_avx2(int64_t n, const orc_block_tq1_0 * x, const orc_block_q8_K * y);
 float orc_vec_dot_tq2_0_q8_K_avx2(int64_t n, const orc_block_tq2_0 * x, const orc_block_q8_K * y);
 float orc_vec_dot_mxfp4_q8_0_avx2(int64_t n, const orc_block_mxfp4 * x, const orc_block_q8_0 * y);

@@ -2,8 +2,8 @@
 scale bytes so that every bit pattern of the 6-bit scale packing is exercised)"""
 import numpy as np
 
-TYPE_SIZE = {2: 18, 3: 20, 8: 34, 12: 144, 13: 176, 14: 210, 6: 22, 7: 24, 10: 84, 11: 110, 20: 18, 39: 17, 23: 136, 34: 54, 35: 66}
-BLCK = {2: 32, 3: 32, 8: 32, 12: 256, 13: 256, 14: 256, 6: 32, 7: 32, 10: 256, 11: 256, 20: 32, 39: 32, 23: 256, 34: 256, 35: 256}
+TYPE_SIZE = {2: 18, 3: 20, 8: 34, 12: 144, 13: 176, 14: 210, 6: 22, 7: 24, 10: 84, 11: 110, 20: 18, 39: 17, 23: 136, 34: 54, 35: 66, 16: 66, 17: 74, 22: 82, 18: 98, 21: 110}
+BLCK = {2: 32, 3: 32, 8: 32, 12: 256, 13: 256, 14: 256, 6: 32, 7: 32, 10: 256, 11: 256, 20: 32, 39: 32, 23: 256, 34: 256, 35: 256, 16: 256, 17: 256, 22: 256, 18: 256, 21: 256}
 
 
 def rand_blocks(t, rows, K, rng, d_scale=0.01):
