@@ -37,7 +37,7 @@ extern "C" size_t cllm_type_size(int type) {
         case CLLM_TYPE_Q5_K: return 176; case CLLM_TYPE_Q6_K: return 210;
         case CLLM_TYPE_Q5_0: return 22; case CLLM_TYPE_Q5_1: return 24; case CLLM_TYPE_IQ4_NL: return 18; case CLLM_TYPE_MXFP4: return 17;
         case CLLM_TYPE_Q2_K: return 84; case CLLM_TYPE_Q3_K: return 110; case CLLM_TYPE_IQ4_XS: return 136; case CLLM_TYPE_TQ1_0: return 54; case CLLM_TYPE_TQ2_0: return 66;
-        case CLLM_TYPE_IQ2_XXS: return 66; case CLLM_TYPE_IQ2_XS: return 74; case CLLM_TYPE_IQ2_S: return 82; case CLLM_TYPE_IQ3_XXS: return 98; case CLLM_TYPE_IQ3_S: return 110;
+        case CLLM_TYPE_IQ2_XXS: return 66; case CLLM_TYPE_IQ2_XS: return 74; case CLLM_TYPE_IQ2_S: return 82; case CLLM_TYPE_IQ3_XXS: return 98; case CLLM_TYPE_IQ3_S: return 110; case CLLM_TYPE_IQ1_S: return 50; case CLLM_TYPE_IQ1_M: return 56;
     }
     return 0;
 }
@@ -46,7 +46,7 @@ extern "C" int cllm_blck_size(int type) {
         case CLLM_TYPE_F32: case CLLM_TYPE_I32: case CLLM_TYPE_F16: case CLLM_TYPE_I64: return 1;
         case CLLM_TYPE_Q4_0: case CLLM_TYPE_Q4_1: case CLLM_TYPE_Q8_0: case CLLM_TYPE_Q5_0: case CLLM_TYPE_Q5_1: case CLLM_TYPE_IQ4_NL: case CLLM_TYPE_MXFP4: return 32;
         case CLLM_TYPE_Q4_K: case CLLM_TYPE_Q5_K: case CLLM_TYPE_Q6_K: case CLLM_TYPE_Q2_K: case CLLM_TYPE_Q3_K: case CLLM_TYPE_IQ4_XS: case CLLM_TYPE_TQ1_0: case CLLM_TYPE_TQ2_0:
-        case CLLM_TYPE_IQ2_XXS: case CLLM_TYPE_IQ2_XS: case CLLM_TYPE_IQ2_S: case CLLM_TYPE_IQ3_XXS: case CLLM_TYPE_IQ3_S: return 256;
+        case CLLM_TYPE_IQ2_XXS: case CLLM_TYPE_IQ2_XS: case CLLM_TYPE_IQ2_S: case CLLM_TYPE_IQ3_XXS: case CLLM_TYPE_IQ3_S: case CLLM_TYPE_IQ1_S: case CLLM_TYPE_IQ1_M: return 256;
     }
     return 0;
 }

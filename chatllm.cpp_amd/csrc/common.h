@@ -65,9 +65,9 @@ __host__ __device__ inline size_t act_row_bytes(int64_t K, int kind) { return ac
 __host__ __device__ inline bool   is_iq_grid_type(int t) { return t == CLLM_TYPE_IQ2_XXS || t == CLLM_TYPE_IQ2_XS || t == CLLM_TYPE_IQ2_S || t == CLLM_TYPE_IQ3_XXS || t == CLLM_TYPE_IQ3_S; }
 // the coverage types (gemv_kq.hip: mat-mul for any number of columns in the reference's order, GET_ROWS; no fused decode forms)
 __host__ __device__ inline bool   is_kq_type(int t) {
-    return t == CLLM_TYPE_Q5_K || t == CLLM_TYPE_Q6_K || t == CLLM_TYPE_Q2_K || t == CLLM_TYPE_Q3_K || t == CLLM_TYPE_Q5_0 || t == CLLM_TYPE_Q5_1 || t == CLLM_TYPE_IQ4_NL || t == CLLM_TYPE_MXFP4 || t == CLLM_TYPE_IQ4_XS || t == CLLM_TYPE_TQ1_0 || t == CLLM_TYPE_TQ2_0 || is_iq_grid_type(t);
+    return t == CLLM_TYPE_Q5_K || t == CLLM_TYPE_Q6_K || t == CLLM_TYPE_Q2_K || t == CLLM_TYPE_Q3_K || t == CLLM_TYPE_Q5_0 || t == CLLM_TYPE_Q5_1 || t == CLLM_TYPE_IQ4_NL || t == CLLM_TYPE_MXFP4 || t == CLLM_TYPE_IQ4_XS || t == CLLM_TYPE_TQ1_0 || t == CLLM_TYPE_TQ2_0 || is_iq_grid_type(t) || t == CLLM_TYPE_IQ1_S || t == CLLM_TYPE_IQ1_M;
 }
-__host__ __device__ inline bool   is_k256_type(int t) { return t == CLLM_TYPE_Q4_K || t == CLLM_TYPE_Q5_K || t == CLLM_TYPE_Q6_K || t == CLLM_TYPE_Q2_K || t == CLLM_TYPE_Q3_K || t == CLLM_TYPE_IQ4_XS || t == CLLM_TYPE_TQ1_0 || t == CLLM_TYPE_TQ2_0 || is_iq_grid_type(t); }
+__host__ __device__ inline bool   is_k256_type(int t) { return t == CLLM_TYPE_Q4_K || t == CLLM_TYPE_Q5_K || t == CLLM_TYPE_Q6_K || t == CLLM_TYPE_Q2_K || t == CLLM_TYPE_Q3_K || t == CLLM_TYPE_IQ4_XS || t == CLLM_TYPE_TQ1_0 || t == CLLM_TYPE_TQ2_0 || is_iq_grid_type(t) || t == CLLM_TYPE_IQ1_S || t == CLLM_TYPE_IQ1_M; }
 __host__ __device__ inline int    act_kind_of(int wtype) { return is_k256_type(wtype) ? ACT_Q8_K : (wtype == CLLM_TYPE_Q4_1 || wtype == CLLM_TYPE_Q5_1) ? ACT_Q8_1 : ACT_Q8_0; }
 __host__ __device__ inline bool   is_quant_type(int t) { return t == CLLM_TYPE_Q4_0 || t == CLLM_TYPE_Q4_1 || t == CLLM_TYPE_Q8_0 || t == CLLM_TYPE_Q4_K; }
 

@@ -34,6 +34,26 @@ __device__ __forceinline__ uint32_t iq_grid_w4(int type, const char * blk, int i
     }
     return iq_apply_signs4(mag, (s8 >> (4 * half)) & 15u);
 }
+// IQ1_S / IQ1_M (ggml-common.h:392-412): for sub-block ib and 8-group l the four values (-1 / 0 / 1, int8 x 4) of its half, the odd scale of the group's 16 and whether the
+// group's delta is -1/8.  IQ1_S: d | qs[32] | qh[8] (u16: 4 x 3 index bits, 3-bit scale, delta sign); IQ1_M: qs[32] | qh[16] (nibbles: 3 index bits + delta sign) | scales[8]
+__device__ __forceinline__ uint32_t iq1_w4(int type, const char * blk, int ib, int l, int half, int & ls, bool & neg) {
+    const uint8_t * b8 = (const uint8_t *) blk;
+    uint32_t idx;
+    if (type == CLLM_TYPE_IQ1_S) {
+        const uint32_t qh = (uint32_t) b8[34 + 2 * ib] | ((uint32_t) b8[35 + 2 * ib] << 8);
+        idx = b8[2 + 4 * ib + l] | (((qh >> (3 * l)) & 7u) << 8);
+        ls = 2 * (int)((qh >> 12) & 7u) + 1; neg = (qh & 0x8000u) != 0;
+    } else {
+        const uint32_t h = b8[32 + 2 * ib + (l >> 1)], sc = (uint32_t) b8[48 + 2 * (ib / 2)] | ((uint32_t) b8[49 + 2 * (ib / 2)] << 8);
+        idx = b8[4 * ib + l] | (((l & 1) ? (h << 4) : (h << 8)) & 0x700u);
+        ls = 2 * (int)((sc >> (6 * (ib % 2) + 3 * (l >> 1))) & 7u) + 1; neg = (h & ((l & 1) ? 0x80u : 0x08u)) != 0;
+    }
+    return iq1_code_bytes4(IQ1S_CODE[idx], 4 * half);
+}
+__device__ __forceinline__ float iq1m_d(const char * blk) {          // the fp16 scale in the top nibbles of the four 16-bit scale words
+    const uint8_t * b8 = (const uint8_t *) blk + 48;
+    return h2f((uint16_t)((b8[1] >> 4) | (b8[3] & 0xf0) | ((uint32_t)(b8[5] & 0xf0) << 4) | ((uint32_t)(b8[7] & 0xf0) << 8)));
+}
 __device__ __forceinline__ float dequant_elem(int type, const char * row, int64_t i) {
     switch (type) {
         case CLLM_TYPE_F32: return ((const float *) row)[i];
@@ -107,6 +127,13 @@ __device__ __forceinline__ float dequant_elem(int type, const char * row, int64_
             const int nib = j < 16 ? (qb & 0xF) : (qb >> 4);
             const uint64_t tab = nib < 8 ? 0xf6eaddcfbfad9881ull : 0x7159453526190d01ull;
             return dl * (float)(int8_t)((tab >> (8 * (nib & 7))) & 0xff);
+        }
+        case CLLM_TYPE_IQ1_S: case CLLM_TYPE_IQ1_M: {  // dequantize_row_iq1_s / _iq1_m (ggml-quants.c:2464-2536): y = dl * (value + delta), dl = d * (2 s + 1), delta = +-0.125f
+            const char * blk = row + (i / 256) * (type == CLLM_TYPE_IQ1_S ? 50 : 56); const int e = (int)(i % 256), ib = e / 32, l = (e % 32) / 8, half = (e % 8) / 4, k = e % 4;
+            int ls; bool neg;
+            const uint32_t w4 = iq1_w4(type, blk, ib, l, half, ls, neg);
+            const float d = type == CLLM_TYPE_IQ1_S ? h2f(*(const uint16_t *) blk) : iq1m_d(blk);
+            return (d * (float) ls) * ((float)(int8_t)((w4 >> (8 * k)) & 0xff) + (neg ? -0.125f : 0.125f));
         }
         case CLLM_TYPE_IQ2_XXS: case CLLM_TYPE_IQ2_XS: case CLLM_TYPE_IQ2_S: case CLLM_TYPE_IQ3_XXS: case CLLM_TYPE_IQ3_S: {
             // dequantize_row_iq2_xxs / _iq2_xs / _iq2_s / _iq3_xxs / _iq3_s (ggml-quants.c:2275-2460): y = db * magnitude * (+-1.f), db = d * (0.5f + ls) * 0.25f (IQ2), * 0.5f

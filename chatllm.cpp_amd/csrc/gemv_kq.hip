@@ -8,6 +8,8 @@
 //   q5_0 :846-884, q5_1 :926-968    Q4_0's / Q4_1's chains with a fifth bit per weight
 //   iq2_xxs :2372-, iq2_xs :2490-, iq2_s :2787-, iq3_xxs :2972-, iq3_s :3096-   codebook ("grid") formats: signed magnitudes from iq_grids.h, an odd integer scale 2 ls + 1 per 16 or 32,
 //                     one fma per super-block and lane, the result scaled by 1/8 (IQ2), 1/4 (IQ3_XXS), 1 (IQ3_S) AFTER the horizontal sum
+//   iq1_s :3306-3362, iq1_m :3425-3535   values -1 / 0 / 1 from the IQ1 codebook + a delta of +-1/8 per group: IQ1_S folds the delta part as ONE scalar chain accum1 += d * sumi1
+//                     (two roundings; sumi1 from the activation's block sums), IQ1_M as a second set of 8 lanes; result hsum(acc) + 0.125 (accum1 | hsum(acc2))
 //   tq1_0 :1080-1210, tq2_0 :1212-1270   ternary weights; sumi[A] - (bsums[2A] + bsums[2A+1]), then (float) sumi * d + acc as TWO roundings (the build keeps the multiply and the add)
 //   iq4_xs :3716-3764   256-weight super-blocks of IQ4_NL codes with a 6-bit scale - 32 per 32: the K-quants' single fma per super-block and lane
 //   iq4_nl :3632-3714, mxfp4 :760-844   int8 codebooks; even blocks in one 8-lane accumulator, odd ones in a second, added before the horizontal sum, an unpaired
@@ -138,6 +140,17 @@ __global__ void __launch_bounds__(256) k_gemv_kq(const kq_args a) {
                 sc8[ib] = (int8_t)(2 * ((A >> 2) ? ls_hi : ls_lo) + 1);
                 aoff[ib] = 32 * ib + 4 * A;
             }
+        } else if (TYPE == CLLM_TYPE_IQ1_S || TYPE == CLLM_TYPE_IQ1_M) {
+            // sub-block ib, lane A: 8-group l = A >> 1, half A & 1 -> four values in {-1, 0, 1}; mn[ib] = the group's scale with the delta's sign (IQ1_M: per lane; IQ1_S: per sub-block)
+            const char * blk = wr + (int64_t) b * (TYPE == CLLM_TYPE_IQ1_S ? 50 : 56);
+            dw = TYPE == CLLM_TYPE_IQ1_S ? h2f(*(const uint16_t *) blk) : iq1m_d(blk);
+#pragma unroll
+            for (int ib = 0; ib < 8; ib++) {
+                int ls; bool neg;
+                w[ib] = iq1_w4(TYPE, blk, ib, A >> 1, A & 1, ls, neg);
+                sc8[ib] = (int8_t) ls; mn[ib] = neg ? -ls : ls;
+                aoff[ib] = 32 * ib + 4 * A;
+            }
         } else if (TYPE == CLLM_TYPE_TQ2_0) {
             // plane l (bits 2l) of the j-th 32 bytes = elements 128 j + 32 l + (0..31): lane A takes bytes 4A..4A+3 of every plane; the weight is q - 1, the "- 1" comes off below
             const char * blk = wr + (int64_t) b * 66;
@@ -214,6 +227,19 @@ __global__ void __launch_bounds__(256) k_gemv_kq(const kq_args a) {
                 }
                 acc[c] = __builtin_fmaf((-yd) * dmin, (float)(mn[0] * s16a + mn[1] * s16b), acc[c]);
             }
+            if (TYPE == CLLM_TYPE_IQ1_S) {                                     // the delta part: sumi1 = sum over sub-blocks of (activation sum of the 32) * (+-scale); accum1 += d * sumi1 (two roundings)
+                const int * ys = (const int *)(ar + a.off_s) + b * 8;
+                int s1 = 0;
+#pragma unroll
+                for (int ib = 0; ib < 8; ib++) s1 += ys[ib] * mn[ib];
+                summs[c] = summs[c] + (yd * dw) * (float) s1;
+            }
+            if (TYPE == CLLM_TYPE_IQ1_M) {                                     // the delta part on the same 8 lanes: sumi2[A] = sum of (+-scale) * (activation sum of the lane's 4)
+                int s2 = 0;
+#pragma unroll
+                for (int t = 0; t < 8; t++) s2 += mn[t] * dot4(0x01010101u, *(const uint32_t *)(ar + b * 256 + aoff[t]), 0);
+                summs[c] = __builtin_fmaf(yd * dw, (float) s2, summs[c]);
+            }
             if (TYPE == CLLM_TYPE_TQ1_0 || TYPE == CLLM_TYPE_TQ2_0) {          // every weight is (value - 1): minus the activation's sum over this lane's 32 elements (bsums[2A] + bsums[2A+1])
                 sumi -= ((const int *)(ar + a.off_s))[b * 8 + A];
                 acc[c] = (float) sumi * (yd * dw) + acc[c];                    // a multiply and an add: two roundings, as the reference build has them
@@ -236,6 +262,12 @@ __global__ void __launch_bounds__(256) k_gemv_kq(const kq_args a) {
         v = v + dpp_f<DPP_QUAD_XOR1>(v);
         if (TYPE == CLLM_TYPE_Q5_K) v = v + summs[c];
         if (is_iq_grid_type(TYPE)) v = (TYPE == CLLM_TYPE_IQ3_S ? 1.0f : TYPE == CLLM_TYPE_IQ3_XXS ? 0.25f : 0.125f) * v;
+        if (TYPE == CLLM_TYPE_IQ1_S) v = v + 0.125f * summs[c];              // hsum_float_8(accum) + IQ1S_DELTA * accum1 (every lane holds the same scalar chain)
+        if (TYPE == CLLM_TYPE_IQ1_M) {                                        // hsum_float_8(accum1) + IQ1M_DELTA * hsum_float_8(accum2)
+            float u = summs[c];
+            u = u + __int_as_float(lane_xor4_i(__float_as_int(u))); u = u + dpp_f<DPP_QUAD_XOR2>(u); u = u + dpp_f<DPP_QUAD_XOR1>(u);
+            v = v + 0.125f * u;
+        }
         if (live && A == 0 && c < a.ncols) dstb[(int64_t) c * a.ldd + row] = v;
     }
 }
@@ -328,6 +360,8 @@ static void kq_launch(hipStream_t st, int wtype, const kq_args & a, dim3 grid, b
         case CLLM_TYPE_IQ2_S: GO(CLLM_TYPE_IQ2_S); break;
         case CLLM_TYPE_IQ3_XXS: GO(CLLM_TYPE_IQ3_XXS); break;
         case CLLM_TYPE_IQ3_S: GO(CLLM_TYPE_IQ3_S); break;
+        case CLLM_TYPE_IQ1_S: GO(CLLM_TYPE_IQ1_S); break;
+        case CLLM_TYPE_IQ1_M: GO(CLLM_TYPE_IQ1_M); break;
         case CLLM_TYPE_Q5_0: GB(CLLM_TYPE_Q5_0, true); break;
         case CLLM_TYPE_Q5_1: GB(CLLM_TYPE_Q5_1, true); break;
         case CLLM_TYPE_IQ4_NL: if (chain) GB(CLLM_TYPE_IQ4_NL, true); else GB(CLLM_TYPE_IQ4_NL, false); break;

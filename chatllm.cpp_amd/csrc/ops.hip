@@ -734,7 +734,7 @@ extern "C" int cllm_op_get_rows(void * stream, const cllm_tensor * src, const cl
     if (idx->type != CLLM_TYPE_I32 || dst->type != CLLM_TYPE_F32) FAIL(CLLM_E_UNSUPPORTED, "get_rows: type");
     switch (src->type) { case CLLM_TYPE_F32: case CLLM_TYPE_F16: case CLLM_TYPE_Q4_0: case CLLM_TYPE_Q4_1: case CLLM_TYPE_Q8_0: case CLLM_TYPE_Q4_K: case CLLM_TYPE_Q5_K: case CLLM_TYPE_Q6_K:
         case CLLM_TYPE_Q5_0: case CLLM_TYPE_Q5_1: case CLLM_TYPE_Q2_K: case CLLM_TYPE_Q3_K: case CLLM_TYPE_IQ4_NL: case CLLM_TYPE_MXFP4: case CLLM_TYPE_IQ4_XS: case CLLM_TYPE_TQ1_0: case CLLM_TYPE_TQ2_0:
-        case CLLM_TYPE_IQ2_XXS: case CLLM_TYPE_IQ2_XS: case CLLM_TYPE_IQ2_S: case CLLM_TYPE_IQ3_XXS: case CLLM_TYPE_IQ3_S: break;
+        case CLLM_TYPE_IQ2_XXS: case CLLM_TYPE_IQ2_XS: case CLLM_TYPE_IQ2_S: case CLLM_TYPE_IQ3_XXS: case CLLM_TYPE_IQ3_S: case CLLM_TYPE_IQ1_S: case CLLM_TYPE_IQ1_M: break;
         default: FAIL(CLLM_E_UNSUPPORTED, "get_rows: src type %d", src->type); }
     if (dst->ne[0] != src->ne[0] || dst->ne[1] != idx->ne[0] || dst->ne[2] != idx->ne[1] || dst->ne[3] != idx->ne[2] || dst->nb[0] != 4) FAIL(CLLM_E_INVALID, "get_rows: shape");
     const int64_t n = t_nelements(dst);

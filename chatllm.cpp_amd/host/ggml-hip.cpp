@@ -82,7 +82,7 @@ bool is_q(ggml_type t) { return t == GGML_TYPE_Q4_0 || t == GGML_TYPE_Q4_1 || t 
 // the coverage types: mat-mul and GET_ROWS only (gemv_kq.hip): no fused launch takes them
 bool is_kq(ggml_type t) {
     return t == GGML_TYPE_Q5_K || t == GGML_TYPE_Q6_K || t == GGML_TYPE_Q2_K || t == GGML_TYPE_Q3_K || t == GGML_TYPE_Q5_0 || t == GGML_TYPE_Q5_1 || t == GGML_TYPE_IQ4_NL || t == GGML_TYPE_MXFP4 || t == GGML_TYPE_IQ4_XS || t == GGML_TYPE_TQ1_0 || t == GGML_TYPE_TQ2_0 ||
-           t == GGML_TYPE_IQ2_XXS || t == GGML_TYPE_IQ2_XS || t == GGML_TYPE_IQ2_S || t == GGML_TYPE_IQ3_XXS || t == GGML_TYPE_IQ3_S;
+           t == GGML_TYPE_IQ2_XXS || t == GGML_TYPE_IQ2_XS || t == GGML_TYPE_IQ2_S || t == GGML_TYPE_IQ3_XXS || t == GGML_TYPE_IQ3_S || t == GGML_TYPE_IQ1_S || t == GGML_TYPE_IQ1_M;
 }
 bool dense_rows(const ggml_tensor * t) { return t->nb[0] == ggml_type_size(t->type); }
 bool f32_dense(const ggml_tensor * t) { return t && t->type == GGML_TYPE_F32 && t->nb[0] == 4; }

@@ -8,7 +8,7 @@ import zlib
 
 import numpy as np
 
-from .tensor import F32, Q4_0, Q4_1, Q8_0, Q4_K, Q5_K, Q6_K, Q5_0, Q5_1, Q2_K, Q3_K, IQ4_NL, MXFP4, IQ4_XS, TQ1_0, TQ2_0, IQ2_XXS, IQ2_XS, IQ2_S, IQ3_XXS, IQ3_S, TYPE_SIZE, BLCK  # noqa: F401
+from .tensor import F32, Q4_0, Q4_1, Q8_0, Q4_K, Q5_K, Q6_K, Q5_0, Q5_1, Q2_K, Q3_K, IQ4_NL, MXFP4, IQ4_XS, TQ1_0, TQ2_0, IQ2_XXS, IQ2_XS, IQ2_S, IQ3_XXS, IQ3_S, IQ1_S, IQ1_M, TYPE_SIZE, BLCK  # noqa: F401
 
 CONFIGS = {
     # name: n_layer, hidden, n_head, n_kv_head, head_dim, ffn, vocab
@@ -138,6 +138,17 @@ def quant_blocks(type_, rows, K, rng, sigma):
         out = rng.integers(0, 256, (rows, nb, TYPE_SIZE[type_]), dtype=np.uint8)
         rms = {IQ2_XXS: 29.0 * 2.0, IQ2_XS: 29.0 * 2.0, IQ2_S: 29.0 * 2.0, IQ3_XXS: 33.0 * 4.0, IQ3_S: 9.2 * 16.0}[type_]        # magnitude rms x mean scale factor
         out[:, :, 0:2] = _f16_bytes(rng.uniform(0.5, 1.5, (rows, nb)) * sigma / rms).reshape(rows, nb, 2)
+    elif type_ in (IQ1_S, IQ1_M):                                       # values -1 / 0 / 1 (+- 1/8) times d (2 s + 1), s in 0..7: rms ~0.83 * 9; IQ1_M keeps its fp16 d in the scales' top nibbles
+        out = rng.integers(0, 256, (rows, nb, TYPE_SIZE[type_]), dtype=np.uint8)
+        dv = _f16_bytes(rng.uniform(0.5, 1.5, (rows, nb)) * sigma / 7.5).reshape(rows, nb, 2)
+        if type_ == IQ1_S:
+            out[:, :, 0:2] = dv
+        else:
+            d16 = dv.copy().view(np.uint16).reshape(rows, nb).astype(np.uint32)
+            sc = out[:, :, 48:56].copy().view(np.uint16).reshape(rows, nb, 4)
+            for k in range(4):
+                sc[:, :, k] = (sc[:, :, k] & 0x0fff) | (((d16 >> (4 * k)) & 0xf) << 12).astype(np.uint16)
+            out[:, :, 48:56] = sc.view(np.uint8).reshape(rows, nb, 8)
     elif type_ == TQ2_0:                                                # qs[64] d (ggml-common.h:251-256): w = (q - 1) d, q in 0..2 at 2 bits
         out = np.empty((rows, nb, 66), np.uint8)
         q = rng.integers(0, 3, (rows, nb, 64, 4), dtype=np.uint8)

@@ -8,9 +8,9 @@ import numpy as np
 from . import lib as _l
 
 F32, F16, Q4_0, Q4_1, Q8_0, Q4_K, Q5_K, Q6_K, I32, I64 = 0, 1, 2, 3, 8, 12, 13, 14, 26, 27
-Q5_0, Q5_1, Q2_K, Q3_K, IQ4_NL, MXFP4, IQ4_XS, TQ1_0, TQ2_0, IQ2_XXS, IQ2_XS, IQ3_XXS, IQ3_S, IQ2_S = 6, 7, 10, 11, 20, 39, 23, 34, 35, 16, 17, 18, 21, 22          # mat-mul (any columns) and GET_ROWS
-TYPE_SIZE = {F32: 4, F16: 2, Q4_0: 18, Q4_1: 20, Q8_0: 34, Q4_K: 144, Q5_K: 176, Q6_K: 210, I32: 4, I64: 8, Q5_0: 22, Q5_1: 24, Q2_K: 84, Q3_K: 110, IQ4_NL: 18, MXFP4: 17, IQ4_XS: 136, TQ1_0: 54, TQ2_0: 66, IQ2_XXS: 66, IQ2_XS: 74, IQ2_S: 82, IQ3_XXS: 98, IQ3_S: 110}
-BLCK = {F32: 1, F16: 1, Q4_0: 32, Q4_1: 32, Q8_0: 32, Q4_K: 256, Q5_K: 256, Q6_K: 256, I32: 1, I64: 1, Q5_0: 32, Q5_1: 32, Q2_K: 256, Q3_K: 256, IQ4_NL: 32, MXFP4: 32, IQ4_XS: 256, TQ1_0: 256, TQ2_0: 256, IQ2_XXS: 256, IQ2_XS: 256, IQ2_S: 256, IQ3_XXS: 256, IQ3_S: 256}
+Q5_0, Q5_1, Q2_K, Q3_K, IQ4_NL, MXFP4, IQ4_XS, TQ1_0, TQ2_0, IQ2_XXS, IQ2_XS, IQ3_XXS, IQ3_S, IQ2_S, IQ1_S, IQ1_M = 6, 7, 10, 11, 20, 39, 23, 34, 35, 16, 17, 18, 21, 22, 19, 29          # mat-mul (any columns) and GET_ROWS
+TYPE_SIZE = {F32: 4, F16: 2, Q4_0: 18, Q4_1: 20, Q8_0: 34, Q4_K: 144, Q5_K: 176, Q6_K: 210, I32: 4, I64: 8, Q5_0: 22, Q5_1: 24, Q2_K: 84, Q3_K: 110, IQ4_NL: 18, MXFP4: 17, IQ4_XS: 136, TQ1_0: 54, TQ2_0: 66, IQ2_XXS: 66, IQ2_XS: 74, IQ2_S: 82, IQ3_XXS: 98, IQ3_S: 110, IQ1_S: 50, IQ1_M: 56}
+BLCK = {F32: 1, F16: 1, Q4_0: 32, Q4_1: 32, Q8_0: 32, Q4_K: 256, Q5_K: 256, Q6_K: 256, I32: 1, I64: 1, Q5_0: 32, Q5_1: 32, Q2_K: 256, Q3_K: 256, IQ4_NL: 32, MXFP4: 32, IQ4_XS: 256, TQ1_0: 256, TQ2_0: 256, IQ2_XXS: 256, IQ2_XS: 256, IQ2_S: 256, IQ3_XXS: 256, IQ3_S: 256, IQ1_S: 256, IQ1_M: 256}
 NP_OF = {F32: np.float32, F16: np.float16, I32: np.int32, I64: np.int64}
 
 

@@ -42,7 +42,7 @@ typedef enum cllm_status {
 /* numeric values == enum ggml_type (ggml.h:386-428) so descriptors can be filled by a cast */
 typedef enum cllm_type {
     CLLM_TYPE_F32 = 0, CLLM_TYPE_F16 = 1, CLLM_TYPE_Q4_0 = 2, CLLM_TYPE_Q4_1 = 3, CLLM_TYPE_Q8_0 = 8, CLLM_TYPE_Q4_K = 12, CLLM_TYPE_Q5_K = 13, CLLM_TYPE_Q6_K = 14,
-    CLLM_TYPE_Q5_0 = 6, CLLM_TYPE_Q5_1 = 7, CLLM_TYPE_Q2_K = 10, CLLM_TYPE_Q3_K = 11, CLLM_TYPE_IQ4_NL = 20, CLLM_TYPE_IQ2_XXS = 16, CLLM_TYPE_IQ2_XS = 17, CLLM_TYPE_IQ3_XXS = 18, CLLM_TYPE_IQ3_S = 21, CLLM_TYPE_IQ2_S = 22, CLLM_TYPE_IQ4_XS = 23, CLLM_TYPE_TQ1_0 = 34, CLLM_TYPE_TQ2_0 = 35, CLLM_TYPE_MXFP4 = 39,     /* MUL_MAT (any columns) and GET_ROWS */
+    CLLM_TYPE_Q5_0 = 6, CLLM_TYPE_Q5_1 = 7, CLLM_TYPE_Q2_K = 10, CLLM_TYPE_Q3_K = 11, CLLM_TYPE_IQ4_NL = 20, CLLM_TYPE_IQ2_XXS = 16, CLLM_TYPE_IQ2_XS = 17, CLLM_TYPE_IQ3_XXS = 18, CLLM_TYPE_IQ1_S = 19, CLLM_TYPE_IQ3_S = 21, CLLM_TYPE_IQ2_S = 22, CLLM_TYPE_IQ4_XS = 23, CLLM_TYPE_IQ1_M = 29, CLLM_TYPE_TQ1_0 = 34, CLLM_TYPE_TQ2_0 = 35, CLLM_TYPE_MXFP4 = 39,     /* MUL_MAT (any columns) and GET_ROWS */
     CLLM_TYPE_I32 = 26, CLLM_TYPE_I64 = 27,
 } cllm_type;
 

@@ -37,6 +37,7 @@ size_t orc_type_size(int type) {
         case ORC_TQ1_0: return sizeof(orc_block_tq1_0);  case ORC_TQ2_0: return sizeof(orc_block_tq2_0);
         case ORC_IQ2_XXS: return sizeof(orc_block_iq2_xxs);  case ORC_IQ2_XS: return sizeof(orc_block_iq2_xs);  case ORC_IQ2_S: return sizeof(orc_block_iq2_s);
         case ORC_IQ3_XXS: return sizeof(orc_block_iq3_xxs);  case ORC_IQ3_S: return sizeof(orc_block_iq3_s);
+        case ORC_IQ1_S: return sizeof(orc_block_iq1_s);  case ORC_IQ1_M: return sizeof(orc_block_iq1_m);
         case ORC_Q2_K: return sizeof(orc_block_q2_K);  case ORC_Q3_K: return sizeof(orc_block_q3_K);
     }
     return 0;
@@ -44,7 +45,7 @@ size_t orc_type_size(int type) {
 int orc_blck_size(int type) {
     switch (type) {
         case ORC_Q4_0: case ORC_Q8_0: case ORC_Q4_1: case ORC_Q8_1: case ORC_Q5_0: case ORC_Q5_1: case ORC_IQ4_NL: case ORC_MXFP4: return ORC_QK;
-        case ORC_Q4_K: case ORC_Q5_K: case ORC_Q6_K: case ORC_Q8_K: case ORC_Q2_K: case ORC_Q3_K: case ORC_IQ4_XS: case ORC_TQ1_0: case ORC_TQ2_0: case ORC_IQ2_XXS: case ORC_IQ2_XS: case ORC_IQ2_S: case ORC_IQ3_XXS: case ORC_IQ3_S: return ORC_QK_K;
+        case ORC_Q4_K: case ORC_Q5_K: case ORC_Q6_K: case ORC_Q8_K: case ORC_Q2_K: case ORC_Q3_K: case ORC_IQ4_XS: case ORC_TQ1_0: case ORC_TQ2_0: case ORC_IQ2_XXS: case ORC_IQ2_XS: case ORC_IQ2_S: case ORC_IQ3_XXS: case ORC_IQ3_S: case ORC_IQ1_S: case ORC_IQ1_M: return ORC_QK_K;
         case ORC_F32: case ORC_F16: case ORC_I32: case ORC_I64: return 1;
     }
     return 0;
@@ -419,6 +420,86 @@ float orc_vec_dot_iq_grid_q8_K_avx2(int type, int64_t n, const void * x, const o
     }
     return (type == ORC_IQ3_S ? 1.0f : type == ORC_IQ3_XXS ? 0.25f : 0.125f) * hsum8(acc);
 }
+/* ---- IQ1_S / IQ1_M: per sub-block ib and 8-group l the grid index, the delta sign and the odd scale ---- */
+#ifndef ORC_IQ1S_FMA
+#define ORC_IQ1S_FMA 0        /* accum1 += d * sumi1: the reference build keeps the multiply and the add apart (1 fails the pin in tests/test_oracle_vs_reference.py) */
+#endif
+static void orc_iq1_vals8(uint32_t idx, int8_t v[8]) {
+    const uint32_t code = IQ1S_CODE[idx], a = iq1_code_bytes4(code, 0), b = iq1_code_bytes4(code, 4);
+    for (int k = 0; k < 4; k++) { v[k] = (int8_t)((a >> (8 * k)) & 0xff); v[4 + k] = (int8_t)((b >> (8 * k)) & 0xff); }
+}
+static uint32_t orc_iq1s_idx(const orc_block_iq1_s * b, int ib, int l) { return b->qs[4 * ib + l] | (((b->qh[ib] >> (3 * l)) & 7u) << 8); }
+static uint32_t orc_iq1m_idx(const orc_block_iq1_m * b, int ib, int l) { const uint32_t h = b->qh[2 * ib + (l >> 1)]; return b->qs[4 * ib + l] | (((l & 1) ? (h << 4) : (h << 8)) & 0x700u); }
+static int      orc_iq1m_neg(const orc_block_iq1_m * b, int ib, int l) { return (b->qh[2 * ib + (l >> 1)] & ((l & 1) ? 0x80 : 0x08)) != 0; }
+static int      orc_iq1m_ls(const orc_block_iq1_m * b, int ib, int h) { uint16_t sc[4]; memcpy(sc, b->scales, 8); return 2 * ((sc[ib / 2] >> (6 * (ib % 2) + 3 * h)) & 7) + 1; }
+static float    orc_iq1m_d(const orc_block_iq1_m * b) {
+    uint16_t sc[4]; memcpy(sc, b->scales, 8);
+    return orc_fp16_to_fp32((uint16_t)((sc[0] >> 12) | ((sc[1] >> 8) & 0x00f0) | ((sc[2] >> 4) & 0x0f00) | (sc[3] & 0xf000)));
+}
+void orc_dequantize_row_iq1_s(const orc_block_iq1_s * x, float * y, int64_t k) {
+    const int64_t nb = k / ORC_QK_K;
+    for (int64_t i = 0; i < nb; i++) {
+        const float d = orc_fp16_to_fp32(x[i].d);
+        for (int ib = 0; ib < 8; ib++) {
+            const float dl = d * (float)(2 * ((x[i].qh[ib] >> 12) & 7) + 1), delta = (x[i].qh[ib] & 0x8000) ? -0.125f : 0.125f;
+            for (int l = 0; l < 4; l++) {
+                int8_t v[8]; orc_iq1_vals8(orc_iq1s_idx(&x[i], ib, l), v);
+                for (int j = 0; j < 8; j++) y[i*256 + 32*ib + 8*l + j] = dl * ((float) v[j] + delta);
+            }
+        }
+    }
+}
+void orc_dequantize_row_iq1_m(const orc_block_iq1_m * x, float * y, int64_t k) {
+    const int64_t nb = k / ORC_QK_K;
+    for (int64_t i = 0; i < nb; i++) {
+        const float d = orc_iq1m_d(&x[i]);
+        for (int ib = 0; ib < 8; ib++)
+            for (int l = 0; l < 4; l++) {
+                const float dl = d * (float) orc_iq1m_ls(&x[i], ib, l >> 1), delta = orc_iq1m_neg(&x[i], ib, l) ? -0.125f : 0.125f;
+                int8_t v[8]; orc_iq1_vals8(orc_iq1m_idx(&x[i], ib, l), v);
+                for (int j = 0; j < 8; j++) y[i*256 + 32*ib + 8*l + j] = dl * ((float) v[j] + delta);
+            }
+    }
+}
+static inline float hsum8(const float x[8]);
+float orc_vec_dot_iq1_s_q8_K_avx2(int64_t n, const orc_block_iq1_s * x, const orc_block_q8_K * y) {
+    const int64_t nb = n / ORC_QK_K;
+    float acc[8] = {0}, accum1 = 0.0f;
+    for (int64_t i = 0; i < nb; i++) {
+        int32_t sumi[8] = {0}, sumi1 = 0;
+        for (int ib = 0; ib < 8; ib++) {
+            const int ls = 2 * ((x[i].qh[ib] >> 12) & 7) + 1;
+            for (int l = 0; l < 4; l++) {
+                int8_t v[8]; orc_iq1_vals8(orc_iq1s_idx(&x[i], ib, l), v);
+                for (int j = 0; j < 8; j++) sumi[2 * l + j / 4] += ls * (int) v[j] * (int) y[i].qs[32 * ib + 8 * l + j];
+            }
+            sumi1 += ((int) y[i].bsums[2 * ib] + (int) y[i].bsums[2 * ib + 1]) * ((x[i].qh[ib] & 0x8000) ? -1 : 1) * ls;
+        }
+        const float d = y[i].d * orc_fp16_to_fp32(x[i].d);
+        for (int L = 0; L < 8; L++) acc[L] = fmaf(d, (float) sumi[L], acc[L]);
+        accum1 = ORC_IQ1S_FMA ? fmaf(d, (float) sumi1, accum1) : accum1 + d * (float) sumi1;
+    }
+    return hsum8(acc) + 0.125f * accum1;
+}
+float orc_vec_dot_iq1_m_q8_K_avx2(int64_t n, const orc_block_iq1_m * x, const orc_block_q8_K * y) {
+    const int64_t nb = n / ORC_QK_K;
+    float acc1[8] = {0}, acc2[8] = {0};
+    for (int64_t i = 0; i < nb; i++) {
+        int32_t s1[8] = {0}, s2[8] = {0};
+        for (int ib = 0; ib < 8; ib++)
+            for (int l = 0; l < 4; l++) {
+                const int ls = orc_iq1m_ls(&x[i], ib, l >> 1), sg = orc_iq1m_neg(&x[i], ib, l) ? -1 : 1;
+                int8_t v[8]; orc_iq1_vals8(orc_iq1m_idx(&x[i], ib, l), v);
+                for (int j = 0; j < 8; j++) {
+                    s1[2 * l + j / 4] += ls * (int) v[j] * (int) y[i].qs[32 * ib + 8 * l + j];
+                    s2[2 * l + j / 4] += ls * sg * (int) y[i].qs[32 * ib + 8 * l + j];
+                }
+            }
+        const float d = y[i].d * orc_iq1m_d(&x[i]);
+        for (int L = 0; L < 8; L++) { acc1[L] = fmaf(d, (float) s1[L], acc1[L]); acc2[L] = fmaf(d, (float) s2[L], acc2[L]); }
+    }
+    return hsum8(acc1) + 0.125f * hsum8(acc2);
+}
 /* the trit of element e (dequantize order, ggml-quants.c:2215-2252): 160 elements from qs[0..31] (plane n = e / 32: byte * 3^n mod 256, times 3, top two bits), 80 from
  * qs[32..47] (planes of 16), 16 from qh (4 planes of 4) */
 static int orc_tq1_trit(const orc_block_tq1_0 * b, int e) {
@@ -497,6 +578,8 @@ void orc_dequantize_row(int type, const void * x, float * y, int64_t k) {
         case ORC_TQ1_0: orc_dequantize_row_tq1_0((const orc_block_tq1_0 *) x, y, k); break;
         case ORC_TQ2_0: orc_dequantize_row_tq2_0((const orc_block_tq2_0 *) x, y, k); break;
         case ORC_IQ2_XXS: case ORC_IQ2_XS: case ORC_IQ2_S: case ORC_IQ3_XXS: case ORC_IQ3_S: orc_dequantize_row_iq_grid(type, x, y, k); break;
+        case ORC_IQ1_S: orc_dequantize_row_iq1_s((const orc_block_iq1_s *) x, y, k); break;
+        case ORC_IQ1_M: orc_dequantize_row_iq1_m((const orc_block_iq1_m *) x, y, k); break;
         case ORC_MXFP4: orc_dequantize_row_mxfp4((const orc_block_mxfp4 *) x, y, k); break;
         case ORC_Q2_K: orc_dequantize_row_q2_K((const orc_block_q2_K *) x, y, k); break;
         case ORC_Q3_K: orc_dequantize_row_q3_K((const orc_block_q3_K *) x, y, k); break;
@@ -1182,7 +1265,7 @@ static int vec_dot_type_of(int wtype) {
     switch (wtype) {             /* type_traits_cpu[], ggml-cpu/ggml-cpu.c:207-390 */
         case ORC_Q4_0: case ORC_Q8_0: case ORC_Q5_0: case ORC_IQ4_NL: case ORC_MXFP4: return ORC_Q8_0;
         case ORC_Q4_1: case ORC_Q5_1: return ORC_Q8_1;
-        case ORC_Q4_K: case ORC_Q5_K: case ORC_Q6_K: case ORC_Q2_K: case ORC_Q3_K: case ORC_IQ4_XS: case ORC_TQ1_0: case ORC_TQ2_0: case ORC_IQ2_XXS: case ORC_IQ2_XS: case ORC_IQ2_S: case ORC_IQ3_XXS: case ORC_IQ3_S: return ORC_Q8_K;
+        case ORC_Q4_K: case ORC_Q5_K: case ORC_Q6_K: case ORC_Q2_K: case ORC_Q3_K: case ORC_IQ4_XS: case ORC_TQ1_0: case ORC_TQ2_0: case ORC_IQ2_XXS: case ORC_IQ2_XS: case ORC_IQ2_S: case ORC_IQ3_XXS: case ORC_IQ3_S: case ORC_IQ1_S: case ORC_IQ1_M: return ORC_Q8_K;
         case ORC_F16:  return ORC_F16;
         case ORC_F32:  return ORC_F32;
     }
@@ -1219,6 +1302,8 @@ static float vec_dot(int wtype, int64_t n, const void * w, const void * a) {
         case ORC_TQ1_0: return orc_vec_dot_tq1_0_q8_K_avx2(n, (const orc_block_tq1_0 *) w, (const orc_block_q8_K *) a);
         case ORC_TQ2_0: return orc_vec_dot_tq2_0_q8_K_avx2(n, (const orc_block_tq2_0 *) w, (const orc_block_q8_K *) a);
         case ORC_IQ2_XXS: case ORC_IQ2_XS: case ORC_IQ2_S: case ORC_IQ3_XXS: case ORC_IQ3_S: return orc_vec_dot_iq_grid_q8_K_avx2(wtype, n, w, (const orc_block_q8_K *) a);
+        case ORC_IQ1_S: return orc_vec_dot_iq1_s_q8_K_avx2(n, (const orc_block_iq1_s *) w, (const orc_block_q8_K *) a);
+        case ORC_IQ1_M: return orc_vec_dot_iq1_m_q8_K_avx2(n, (const orc_block_iq1_m *) w, (const orc_block_q8_K *) a);
         case ORC_Q2_K: return orc_vec_dot_q2_K_q8_K_avx2(n, (const orc_block_q2_K *) w, (const orc_block_q8_K *) a);
         case ORC_Q3_K: return orc_vec_dot_q3_K_q8_K_avx2(n, (const orc_block_q3_K *) w, (const orc_block_q8_K *) a);
         case ORC_F16: {

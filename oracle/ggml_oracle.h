@@ -25,7 +25,7 @@ extern "C" {
 
 /* numeric values equal the reference's enum ggml_type (ggml/include/ggml.h:386-428) */
 enum orc_type {
-    ORC_F32 = 0, ORC_F16 = 1, ORC_Q4_0 = 2, ORC_Q4_1 = 3, ORC_Q5_0 = 6, ORC_Q5_1 = 7, ORC_Q8_0 = 8, ORC_Q8_1 = 9, ORC_Q2_K = 10, ORC_Q3_K = 11, ORC_Q4_K = 12, ORC_Q5_K = 13, ORC_Q6_K = 14, ORC_Q8_K = 15, ORC_IQ4_NL = 20, ORC_IQ2_XXS = 16, ORC_IQ2_XS = 17, ORC_IQ3_XXS = 18, ORC_IQ3_S = 21, ORC_IQ2_S = 22, ORC_IQ4_XS = 23, ORC_TQ1_0 = 34, ORC_TQ2_0 = 35, ORC_I32 = 26, ORC_I64 = 27, ORC_MXFP4 = 39,
+    ORC_F32 = 0, ORC_F16 = 1, ORC_Q4_0 = 2, ORC_Q4_1 = 3, ORC_Q5_0 = 6, ORC_Q5_1 = 7, ORC_Q8_0 = 8, ORC_Q8_1 = 9, ORC_Q2_K = 10, ORC_Q3_K = 11, ORC_Q4_K = 12, ORC_Q5_K = 13, ORC_Q6_K = 14, ORC_Q8_K = 15, ORC_IQ4_NL = 20, ORC_IQ2_XXS = 16, ORC_IQ2_XS = 17, ORC_IQ3_XXS = 18, ORC_IQ1_S = 19, ORC_IQ1_M = 29, ORC_IQ3_S = 21, ORC_IQ2_S = 22, ORC_IQ4_XS = 23, ORC_TQ1_0 = 34, ORC_TQ2_0 = 35, ORC_I32 = 26, ORC_I64 = 27, ORC_MXFP4 = 39,
 };
 
 /* a strided 4-D tensor view: same meaning as ggml_tensor {type, ne, nb, data} (ggml.h:656-688) */
@@ -59,6 +59,8 @@ typedef struct { uint16_t d; uint16_t qs[32]; uint8_t scales[8]; } orc_block_iq2
 typedef struct { uint16_t d; uint8_t qs[64]; uint8_t qh[8]; uint8_t scales[8]; } orc_block_iq2_s;              /* 82 B: qs[0..31] grid index low bytes, qs[32..63] sign bytes, qh 2 high bits per 8 */
 typedef struct { uint16_t d; uint8_t qs[96]; } orc_block_iq3_xxs;                                               /* 98 B: qs[0..63] grid indices (4 weights each), then per 32: 4 x 7 sign bits + 4-bit scale */
 typedef struct { uint16_t d; uint8_t qs[64]; uint8_t qh[8]; uint8_t signs[32]; uint8_t scales[4]; } orc_block_iq3_s;   /* 110 B: 9-bit grid indices (qs | qh bit), sign bytes, a 4-bit scale per 32 */
+typedef struct { uint16_t d; uint8_t qs[32]; uint16_t qh[8]; } orc_block_iq1_s;                                  /* 50 B: 11-bit grid index per 8 (qs | 3 bits of qh), per 32: 3-bit scale, delta sign (ggml-common.h:392-398) */
+typedef struct { uint8_t qs[32]; uint8_t qh[16]; uint8_t scales[8]; } orc_block_iq1_m;                          /* 56 B: per 8: index (qs | 3 bits of a qh nibble), delta sign (its 4th bit); 3-bit scale per 16; fp16 d in the scales' top nibbles */
 typedef struct { uint8_t qs[48]; uint8_t qh[4]; uint16_t d; } orc_block_tq1_0;     /* 54 B: 256 ternary weights, 5 per byte of qs (base 3), 4 per byte of qh; w = (trit - 1) * d (ggml-common.h:241-249) */
 typedef struct { uint8_t qs[64]; uint16_t d; } orc_block_tq2_0;                    /* 66 B: 256 ternary weights, 2 bits each; w = (q - 1) * d (ggml-common.h:251-256) */
 typedef struct { uint8_t e; uint8_t qs[16]; }                              orc_block_mxfp4;  /* 17 B: w = kvalues_mxfp4[nib] * 2^(e - 128) */
@@ -152,6 +154,13 @@ float orc_vec_dot_iq4_xs_q8_K_avx2(int64_t n, const orc_block_iq4_xs * x, const 
  * sub-block; sumi[L] = sum over sub-blocks of (odd integer scale of the lane's 16) * (signed codebook magnitudes . activation), ONE fma(d_x * d_y, (float) sumi[L], acc[L]) per
  * super-block, result = c * hsum_float_8(acc), c = 1/8 (IQ2), 1/4 (IQ3_XXS), 1 (IQ3_S) */
 float orc_vec_dot_iq_grid_q8_K_avx2(int type, int64_t n, const void * x, const orc_block_q8_K * y);
+/* ggml_vec_dot_iq1_s_q8_K / iq1_m (arch/x86/quants.c:3306-3362, 3425-3535): values -1 / 0 / 1 from iq1s_grid plus a per-group delta of +-1/8.  IQ1_S: the 8 lanes fold
+ * fma(d, (float) sumi[L], acc[L]); the delta part is ONE scalar chain accum1 += d * sumi1 per super-block (sumi1 from the activation's bsums); result hsum(acc) + 0.125 accum1.
+ * IQ1_M: two sets of 8 lanes (grid part, delta part), both fma per super-block; result hsum(acc1) + 0.125 hsum(acc2); d = fp16 assembled from the scales' top nibbles */
+float orc_vec_dot_iq1_s_q8_K_avx2(int64_t n, const orc_block_iq1_s * x, const orc_block_q8_K * y);
+float orc_vec_dot_iq1_m_q8_K_avx2(int64_t n, const orc_block_iq1_m * x, const orc_block_q8_K * y);
+void orc_dequantize_row_iq1_s(const orc_block_iq1_s * x, float * y, int64_t k);    /* ggml-quants.c:2464-2486 */
+void orc_dequantize_row_iq1_m(const orc_block_iq1_m * x, float * y, int64_t k);    /* ggml-quants.c:2488-2536 */
 float orc_vec_dot_tq1_0_q8_K_avx2(int64_t n, const orc_block_tq1_0 * x, const orc_block_q8_K * y);
 float orc_vec_dot_tq2_0_q8_K_avx2(int64_t n, const orc_block_tq2_0 * x, const orc_block_q8_K * y);
 float orc_vec_dot_mxfp4_q8_0_avx2(int64_t n, const orc_block_mxfp4 * x, const orc_block_q8_0 * y);

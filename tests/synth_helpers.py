@@ -2,8 +2,8 @@
 scale bytes so that every bit pattern of the 6-bit scale packing is exercised)"""
 import numpy as np
 
-TYPE_SIZE = {2: 18, 3: 20, 8: 34, 12: 144, 13: 176, 14: 210, 6: 22, 7: 24, 10: 84, 11: 110, 20: 18, 39: 17, 23: 136, 34: 54, 35: 66, 16: 66, 17: 74, 22: 82, 18: 98, 21: 110}
-BLCK = {2: 32, 3: 32, 8: 32, 12: 256, 13: 256, 14: 256, 6: 32, 7: 32, 10: 256, 11: 256, 20: 32, 39: 32, 23: 256, 34: 256, 35: 256, 16: 256, 17: 256, 22: 256, 18: 256, 21: 256}
+TYPE_SIZE = {2: 18, 3: 20, 8: 34, 12: 144, 13: 176, 14: 210, 6: 22, 7: 24, 10: 84, 11: 110, 20: 18, 39: 17, 23: 136, 34: 54, 35: 66, 16: 66, 17: 74, 22: 82, 18: 98, 21: 110, 19: 50, 29: 56}
+BLCK = {2: 32, 3: 32, 8: 32, 12: 256, 13: 256, 14: 256, 6: 32, 7: 32, 10: 256, 11: 256, 20: 32, 39: 32, 23: 256, 34: 256, 35: 256, 16: 256, 17: 256, 22: 256, 18: 256, 21: 256, 19: 256, 29: 256}
 
 
 def rand_blocks(t, rows, K, rng, d_scale=0.01):
@@ -21,6 +21,13 @@ def rand_blocks(t, rows, K, rng, d_scale=0.01):
         dm = (rng.uniform(0.25, 1.0, (rows, nb)) * d_scale).astype(np.float16)
         out[:, :, 80:82] = d.view(np.uint8).reshape(rows, nb, 2)
         out[:, :, 82:84] = dm.view(np.uint8).reshape(rows, nb, 2)
+        return np.ascontiguousarray(out.reshape(rows, nb * TYPE_SIZE[t]))
+    if t == 29:         # IQ1_M: no d field -- the fp16 scale lives in the top nibbles of the four 16-bit scale words (qs[32] qh[16] scales[8])
+        sc = out[:, :, 48:56].copy().view(np.uint16).reshape(rows, nb, 4)
+        dv = d.view(np.uint16).astype(np.uint32)
+        for k in range(4):
+            sc[:, :, k] = (sc[:, :, k] & 0x0fff) | (((dv >> (4 * k)) & 0xf) << 12).astype(np.uint16)
+        out[:, :, 48:56] = sc.view(np.uint8).reshape(rows, nb, 8)
         return np.ascontiguousarray(out.reshape(rows, nb * TYPE_SIZE[t]))
     if t in (34, 35):   # TQ1_0: qs[48] qh[4] d (any byte decodes to trits 0..2); TQ2_0: qs[64] d, 2-bit values 0..2 (and a few 3s: "should not be", but the arithmetic is defined)
         off = 52 if t == 34 else 64

@@ -455,11 +455,11 @@ def test_reference_host_other_k_quants_bit_identical(gpu, tmp_path, name, wt, mi
     ("legacy mix, long prompt", 2, {"wq": 6, "wk": 7, "wv": 20, "wo": 11, "wgate": 10, "wup": 6, "wdown": 7, "lm_head": 20, "tok_embd": 6}, 50),
     ("q5_0", 6, None, 9), ("q5_1", 7, None, 9), ("iq4_nl", 20, None, 40), ("q2_k", 10, None, 9), ("q3_k", 11, None, 40), ("mxfp4", 39, None, 9), ("iq4_xs", 23, None, 40),
     ("tq2_0", 35, None, 9), ("tq1_0", 34, None, 40), ("ternary mix", 35, {"wq": 34, "wo": 34, "wdown": 34, "lm_head": 35, "tok_embd": 34}, 9),
-    ("iq2_xxs", 16, None, 9), ("iq2_xs", 17, None, 40), ("iq2_s", 22, None, 9), ("iq3_xxs", 18, None, 9), ("iq3_s", 21, None, 40),
+    ("iq2_xxs", 16, None, 9), ("iq2_xs", 17, None, 40), ("iq2_s", 22, None, 9), ("iq3_xxs", 18, None, 9), ("iq3_s", 21, None, 40), ("iq1_s", 19, None, 9), ("iq1_m", 29, None, 40),
     ("codebook mix", 2, {"wq": 16, "wk": 17, "wv": 22, "wo": 21, "wgate": 17, "wup": 22, "wdown": 18, "lm_head": 22, "tok_embd": 17}, 9)])      # (a codebook BASE type with differing per-tensor
     # types makes the reference host re-quantize into it, which needs ggml_quantize_init: it aborts on its own CPU backend too)
 def test_reference_host_other_formats_bit_identical(gpu, tmp_path, name, wt, mix, nprompt):
-    """model files in the formats older and third-party converters write -- Q5_0, Q5_1, IQ4_NL, IQ4_XS, Q2_K, Q3_K, MXFP4, TQ1_0, TQ2_0, IQ2_XXS, IQ2_XS, IQ2_S, IQ3_XXS, IQ3_S, pure and mixed per tensor -- through the unmodified
+    """model files in the formats older and third-party converters write -- Q5_0, Q5_1, IQ4_NL, IQ4_XS, Q2_K, Q3_K, MXFP4, TQ1_0, TQ2_0, IQ2_XXS, IQ2_XS, IQ2_S, IQ3_XXS, IQ3_S, IQ1_S, IQ1_M, pure and mixed per tensor -- through the unmodified
     host: every node stays on the module (no CPU fallback) and the free-running generation has the bits of the reference's CPU run, for one-token graphs, short
     prompts (one-column order) and long ones (IQ4_NL's other order under tinyBLAS)"""
     sys.path.insert(0, os.path.join(ROOT, "tools"))

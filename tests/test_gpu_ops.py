@@ -220,7 +220,7 @@ def test_mul_mat_k_quants_any_columns_bit_exact(gpu, t, K, N, M, ne02, ne12):
     assert np.array_equal(got.view(np.uint32).ravel(), want.view(np.uint32).ravel()), rel_err(got, want)
 
 
-@pytest.mark.parametrize("t", [O.Q5_0, O.Q5_1, O.IQ4_NL, O.MXFP4, O.Q2_K, O.Q3_K, O.IQ4_XS, O.TQ1_0, O.TQ2_0, O.IQ2_XXS, O.IQ2_XS, O.IQ2_S, O.IQ3_XXS, O.IQ3_S])
+@pytest.mark.parametrize("t", [O.Q5_0, O.Q5_1, O.IQ4_NL, O.MXFP4, O.Q2_K, O.Q3_K, O.IQ4_XS, O.TQ1_0, O.TQ2_0, O.IQ2_XXS, O.IQ2_XS, O.IQ2_S, O.IQ3_XXS, O.IQ3_S, O.IQ1_S, O.IQ1_M])
 @pytest.mark.parametrize("K,N,M,ne02,ne12", [(256, 1, 1, 1, 1), (512, 7, 1, 1, 1), (4096, 130, 1, 1, 1), (2048, 64, 2, 1, 1), (1024, 33, 5, 1, 1), (1280, 24, 8, 1, 1), (768, 40, 9, 1, 1),
                                              (512, 19, 40, 1, 1), (256, 12, 3, 2, 4), (14336, 48, 1, 1, 1), (96, 10, 1, 1, 1), (96, 10, 3, 1, 1), (2080, 9, 1, 1, 1)])
 def test_mul_mat_other_formats_any_columns_bit_exact(gpu, t, K, N, M, ne02, ne12):
@@ -337,7 +337,7 @@ def test_mul_mat_empty(gpu):
     assert out.ne[:2] == [4, 0]
 
 
-@pytest.mark.parametrize("t", [O.Q4_K, O.Q8_0, O.Q4_0, O.Q4_1, O.Q5_K, O.Q6_K, O.Q2_K, O.Q3_K, O.Q5_0, O.Q5_1, O.IQ4_NL, O.MXFP4, O.IQ4_XS, O.TQ1_0, O.TQ2_0, O.IQ2_XXS, O.IQ2_XS, O.IQ2_S, O.IQ3_XXS, O.IQ3_S])
+@pytest.mark.parametrize("t", [O.Q4_K, O.Q8_0, O.Q4_0, O.Q4_1, O.Q5_K, O.Q6_K, O.Q2_K, O.Q3_K, O.Q5_0, O.Q5_1, O.IQ4_NL, O.MXFP4, O.IQ4_XS, O.TQ1_0, O.TQ2_0, O.IQ2_XXS, O.IQ2_XS, O.IQ2_S, O.IQ3_XXS, O.IQ3_S, O.IQ1_S, O.IQ1_M])
 def test_mul_mat_id(gpu, t):
     """expert weights of every quantized type (Q4_K_M-style Mixtral files keep expert tensors in Q5_K / Q6_K; GPT-OSS experts are MXFP4): the tuned types through
     mmvq / the decode mat-vec, the coverage types one grid slice per (token, slot) of gemv_kq.hip -- always vec_dot's one-column order"""
@@ -576,7 +576,7 @@ def test_weight_quantizers_on_the_device_are_byte_identical(gpu, t):
     assert L.cllm_op_quantize_rows(None, O.Q6_K, dx.data_ptr(), out.data_ptr(), K, rows) != 0 and b"no device quantizer" in L.cllm_last_error()
 
 
-@pytest.mark.parametrize("t", [O.Q4_0, O.Q4_1, O.Q8_0, O.Q4_K, O.Q5_K, O.Q6_K, O.F16, O.F32, O.Q5_0, O.Q5_1, O.IQ4_NL, O.MXFP4, O.Q2_K, O.Q3_K, O.IQ4_XS, O.TQ1_0, O.TQ2_0, O.IQ2_XXS, O.IQ2_XS, O.IQ2_S, O.IQ3_XXS, O.IQ3_S])
+@pytest.mark.parametrize("t", [O.Q4_0, O.Q4_1, O.Q8_0, O.Q4_K, O.Q5_K, O.Q6_K, O.F16, O.F32, O.Q5_0, O.Q5_1, O.IQ4_NL, O.MXFP4, O.Q2_K, O.Q3_K, O.IQ4_XS, O.TQ1_0, O.TQ2_0, O.IQ2_XXS, O.IQ2_XS, O.IQ2_S, O.IQ3_XXS, O.IQ3_S, O.IQ1_S, O.IQ1_M])
 def test_get_rows_bit_exact(gpu, t):
     n0, rows, n = 512, 30, 7
     table = rng.standard_normal((rows, n0)).astype(O.NP_OF[t]) if t in (O.F16, O.F32) else rand_blocks(t, rows, n0, rng)

@@ -88,7 +88,7 @@ def test_weight_quantizers_bit_exact(t):
             assert np.array_equal(got, ref), (K, scale, int(np.argmax(got != ref)))
 
 
-@pytest.mark.parametrize("t", [O.Q4_0, O.Q4_1, O.Q8_0, O.Q4_K, O.Q5_K, O.Q6_K, O.Q5_0, O.Q5_1, O.Q2_K, O.Q3_K, O.IQ4_NL, O.MXFP4, O.IQ4_XS, O.TQ1_0, O.TQ2_0, O.IQ2_XXS, O.IQ2_XS, O.IQ2_S, O.IQ3_XXS, O.IQ3_S])
+@pytest.mark.parametrize("t", [O.Q4_0, O.Q4_1, O.Q8_0, O.Q4_K, O.Q5_K, O.Q6_K, O.Q5_0, O.Q5_1, O.Q2_K, O.Q3_K, O.IQ4_NL, O.MXFP4, O.IQ4_XS, O.TQ1_0, O.TQ2_0, O.IQ2_XXS, O.IQ2_XS, O.IQ2_S, O.IQ3_XXS, O.IQ3_S, O.IQ1_S, O.IQ1_M])
 def test_dequantize_bit_exact(t):
     R = O.ref()
     K = 2048
@@ -140,14 +140,15 @@ def test_vec_dot_k_quants_avx2_order_bit_exact(t):
             assert np.float32(f(C.c_int64(K), P(np.ascontiguousarray(w)), P(np.ascontiguousarray(a)))).view(np.uint32) == np.float32(s.value).view(np.uint32)
 
 
-@pytest.mark.parametrize("t", [O.Q5_0, O.Q5_1, O.IQ4_NL, O.MXFP4, O.Q2_K, O.Q3_K, O.IQ4_XS, O.TQ1_0, O.TQ2_0, O.IQ2_XXS, O.IQ2_XS, O.IQ2_S, O.IQ3_XXS, O.IQ3_S])
+@pytest.mark.parametrize("t", [O.Q5_0, O.Q5_1, O.IQ4_NL, O.MXFP4, O.Q2_K, O.Q3_K, O.IQ4_XS, O.TQ1_0, O.TQ2_0, O.IQ2_XXS, O.IQ2_XS, O.IQ2_S, O.IQ3_XXS, O.IQ3_S, O.IQ1_S, O.IQ1_M])
 def test_vec_dot_other_formats_avx2_order_bit_exact(t):
     """Q5_0 / Q5_1 / IQ4_NL / MXFP4 / Q2_K / Q3_K: the x86 AVX2 order restated (8 lane accumulators; the codebook formats pair their blocks over two of them and
     finish an unpaired block in scalar code)"""
     R = O.ref()
     fn = {O.Q5_0: "orc_vec_dot_q5_0_q8_0_avx2", O.Q5_1: "orc_vec_dot_q5_1_q8_1_avx2", O.IQ4_NL: "orc_vec_dot_iq4_nl_q8_0_avx2", O.MXFP4: "orc_vec_dot_mxfp4_q8_0_avx2",
           O.Q2_K: "orc_vec_dot_q2_K_q8_K_avx2", O.Q3_K: "orc_vec_dot_q3_K_q8_K_avx2", O.IQ4_XS: "orc_vec_dot_iq4_xs_q8_K_avx2",
-          O.TQ1_0: "orc_vec_dot_tq1_0_q8_K_avx2", O.TQ2_0: "orc_vec_dot_tq2_0_q8_K_avx2"}.get(t, "orc_vec_dot_iq_grid_q8_K_avx2")
+          O.TQ1_0: "orc_vec_dot_tq1_0_q8_K_avx2", O.TQ2_0: "orc_vec_dot_tq2_0_q8_K_avx2",
+          O.IQ1_S: "orc_vec_dot_iq1_s_q8_K_avx2", O.IQ1_M: "orc_vec_dot_iq1_m_q8_K_avx2"}.get(t, "orc_vec_dot_iq_grid_q8_K_avx2")
     grid = t in (O.IQ2_XXS, O.IQ2_XS, O.IQ2_S, O.IQ3_XXS, O.IQ3_S)
     f = getattr(O.lib(), fn); f.restype = C.c_float
     f.argtypes = ([C.c_int] if grid else []) + [C.c_int64, C.c_void_p, C.c_void_p] + ([C.c_int] if t == O.IQ4_NL else [])
@@ -167,7 +168,8 @@ def test_vec_dot_other_formats_avx2_order_bit_exact(t):
                                      (O.MXFP4, 256, 40, 1), (O.MXFP4, 96, 17, 7), (O.IQ4_XS, 512, 48, 1), (O.IQ4_XS, 1024, 33, 5), (O.IQ4_XS, 256, 16, 40),
                                      (O.TQ1_0, 512, 48, 1), (O.TQ1_0, 1024, 33, 5), (O.TQ1_0, 256, 16, 40), (O.TQ2_0, 512, 48, 1), (O.TQ2_0, 1024, 33, 5), (O.TQ2_0, 256, 16, 40),
                                      (O.IQ2_XXS, 512, 48, 1), (O.IQ2_XXS, 1024, 33, 5), (O.IQ2_XS, 512, 48, 1), (O.IQ2_XS, 256, 16, 40), (O.IQ2_S, 512, 48, 1), (O.IQ2_S, 1024, 33, 5),
-                                     (O.IQ3_XXS, 512, 48, 1), (O.IQ3_XXS, 256, 16, 40), (O.IQ3_S, 512, 48, 1), (O.IQ3_S, 1024, 33, 5), (O.Q2_K, 512, 48, 1), (O.Q2_K, 1024, 33, 5), (O.Q3_K, 512, 48, 1), (O.Q3_K, 2048, 17, 7),
+                                     (O.IQ3_XXS, 512, 48, 1), (O.IQ3_XXS, 256, 16, 40), (O.IQ3_S, 512, 48, 1), (O.IQ3_S, 1024, 33, 5),
+                                     (O.IQ1_S, 512, 48, 1), (O.IQ1_S, 1024, 33, 5), (O.IQ1_S, 256, 16, 40), (O.IQ1_M, 512, 48, 1), (O.IQ1_M, 1024, 33, 5), (O.IQ1_M, 256, 16, 40), (O.Q2_K, 512, 48, 1), (O.Q2_K, 1024, 33, 5), (O.Q3_K, 512, 48, 1), (O.Q3_K, 2048, 17, 7),
                                      (O.Q5_K, 512, 48, 1), (O.Q5_K, 1024, 33, 5), (O.Q6_K, 512, 48, 1), (O.Q6_K, 2048, 17, 7), (O.Q6_K, 256, 16, 40),
                                      (O.Q4_K, 512, 48, 1), (O.Q4_K, 1024, 33, 5), (O.Q4_K, 4096, 16, 40), (O.Q4_0, 256, 40, 1), (O.Q4_0, 512, 17, 7), (O.Q4_0, 4096, 64, 33),
                                      (O.Q4_1, 256, 40, 1), (O.Q4_1, 1024, 19, 6),
@@ -203,7 +205,7 @@ def test_mul_mat_broadcast_heads():
     assert rel_err(got, ref) < 1e-5
 
 
-@pytest.mark.parametrize("t", [O.Q4_K, O.Q8_0, O.Q4_1, O.Q4_0, O.Q5_K, O.Q6_K, O.Q2_K, O.Q3_K, O.Q5_0, O.Q5_1, O.IQ4_NL, O.MXFP4, O.IQ4_XS, O.TQ1_0, O.TQ2_0, O.IQ2_XXS, O.IQ2_XS, O.IQ2_S, O.IQ3_XXS, O.IQ3_S])
+@pytest.mark.parametrize("t", [O.Q4_K, O.Q8_0, O.Q4_1, O.Q4_0, O.Q5_K, O.Q6_K, O.Q2_K, O.Q3_K, O.Q5_0, O.Q5_1, O.IQ4_NL, O.MXFP4, O.IQ4_XS, O.TQ1_0, O.TQ2_0, O.IQ2_XXS, O.IQ2_XS, O.IQ2_S, O.IQ3_XXS, O.IQ3_S, O.IQ1_S, O.IQ1_M])
 def test_mul_mat_id(t):
     R = O.ref()
     K, N, E, U, T = 512, 24, 4, 2, 3
