@@ -562,7 +562,13 @@ def main():
     rccl_ranks = None
     allreduce_kind = None
     tp_setup = world > 1 or os.environ.get("CLLM_BENCH_TP_SELFTEST") == "1"          # (self-test: walk the communicator set-up with one rank)
+    json_fd = None
     if tp_setup:
+        # RCCL (torch's and /opt/rocm's) prints its version banner with printf -- C stdio, flushed at exit, i.e. BEHIND the JSON line on a redirected stdout.  The contract is ONE
+        # line on stdout: the process's fd 1 becomes stderr from here on, the JSON line goes to a duplicate of the real stdout.
+        sys.stdout.flush()
+        json_fd = os.dup(1)
+        os.dup2(2, 1)
         # torch FIRST: it bundles its own HIP runtime; initialised after libchatllm_hip.so has loaded /opt/rocm's, it finds "No HIP GPUs"
         import torch
         import torch.distributed as dist_mod
@@ -854,7 +860,10 @@ def main():
                         res["prefill"] = prefill_cfg3(pkg, args.model)
                     except Exception as e:
                         res["prefill"] = {"error": str(e)}
-        print(json.dumps(res), flush=True)
+        if json_fd is not None:
+            os.write(json_fd, (json.dumps(res) + "\n").encode())
+        else:
+            print(json.dumps(res), flush=True)
     if m is not None:
         m.close()
     if dist is not None:
