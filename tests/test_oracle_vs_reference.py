@@ -4,6 +4,7 @@ oracle/ref_ops.c).  The reference ships no tests, so this is the 
 Skipped where oracle/_ref has not been built (it always is in the build container and it
 travels to the GPU box as a prebuilt .so)."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -540,3 +541,34 @@ def test_flash_attn_ext_other_orders_within_tolerance(N, n_kv, n_past, threads, 
         assert rel_err(got, ref) < tol           # fp16 V accumulation (oracle, one_chunk) vs fp32 tiles / partials
     finally:
         R.ref_set_threads(C.c_int(min(8, __import__("os").cpu_count() or 1)))
+
+
+@pytest.mark.skipif(not os.path.exists("/root/reference/ggml/src/ggml-common.h"), reason="the reference sources are not on this machine")
+def test_packed_codebooks_decode_to_the_reference_grids():
+    """chatllm.cpp_amd/csrc/iq_grids.h keeps the IQ1 / IQ2 / IQ3 codebooks as one uint16 per entry (base-3 digits / 3-bit levels); decoded the way iq_grids.h decodes them they
+    must be the reference's tables entry for entry (ggml-common.h:528-1615) -- and the sign table must be 7 bits + even parity"""
+    import re
+    src = open("/root/reference/ggml/src/ggml-common.h").read()
+    hdr = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "chatllm.cpp_amd", "csrc", "iq_grids.h")).read()
+
+    def ref_table(name):
+        m = re.search(r"GGML_TABLE_BEGIN\(\w+, %s, \w+\)(.*?)GGML_TABLE_END" % name, src, re.S)
+        body = m.group(1)
+        return [int(x, 16) for x in re.findall(r"0x[0-9a-fA-F]+", body)] or [int(x) for x in re.findall(r"\d+", body)]
+
+    def codes(name):
+        m = re.search(r"%s\[\d+\] = \{(.*?)\};" % name, hdr, re.S)
+        return [int(x) for x in re.findall(r"\d+", m.group(1))]
+
+    def iq2(code):
+        v = 0
+        for k in range(8):
+            t = (code // 3 ** k) % 3
+            v |= (8 + 17 * t + (t >> 1)) << (8 * k)
+        return v
+    for name, cname in (("iq2xxs_grid", "IQ2XXS_CODE"), ("iq2xs_grid", "IQ2XS_CODE"), ("iq2s_grid", "IQ2S_CODE")):
+        assert [iq2(c) for c in codes(cname)] == ref_table(name), name
+    assert [sum((62 if ((c >> (3 * k)) & 7) == 7 else 4 + 8 * ((c >> (3 * k)) & 7)) << (8 * k) for k in range(4)) for c in codes("IQ3XXS_CODE")] == ref_table("iq3xxs_grid")
+    assert [sum((1 + 2 * ((c >> (3 * k)) & 7)) << (8 * k) for k in range(4)) for c in codes("IQ3S_CODE")] == ref_table("iq3s_grid")
+    assert [sum((((c // 3 ** k) % 3 - 1) & 0xff) << (8 * k) for k in range(8)) for c in codes("IQ1S_CODE")] == ref_table("iq1s_grid")
+    assert ref_table("ksigns_iq2xs") == [i | ((bin(i).count("1") & 1) << 7) for i in range(128)]
