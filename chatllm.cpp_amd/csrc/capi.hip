@@ -154,11 +154,13 @@ void * stream_scratch(hipStream_t st, int kind, size_t need) {
     e.p = np; e.bytes = want;
     return np;
 }
-// every block of `st`, whatever device is current now (the key's device is where the block lives; hipFree takes any device's pointer)
+// every block of `st`, whatever device is current now (the key's device is where the block lives; hipFree takes any device's pointer).  The NULL stream handle is the
+// same on every device: only the CURRENT device's entries go then (the caller vouches for that device being idle, not for the others)
 void stream_scratch_release(hipStream_t st) {
+    int dev = 0; (void) hipGetDevice(&dev);
     std::lock_guard<std::mutex> lock(g_scratch_m);
     for (auto it = g_scratch.begin(); it != g_scratch.end(); ) {
-        if (std::get<1>(it->first) == st) {
+        if (std::get<1>(it->first) == st && (st != nullptr || std::get<0>(it->first) == dev)) {
             if (it->second.p) (void) hipFree(it->second.p);
             for (void * q : it->second.outgrown) (void) hipFree(q);
             it = g_scratch.erase(it);
@@ -166,7 +168,7 @@ void stream_scratch_release(hipStream_t st) {
     }
 }
 // scratch of streams the library did not create (the null stream, a host's own): cllm_stream_destroy never sees them.  Call with the device idle.
-extern "C" int cllm_scratch_release(void * stream) { stream_scratch_release((hipStream_t) stream); return CLLM_OK; }
+extern "C" CLLM_API int cllm_scratch_release(void * stream) { stream_scratch_release((hipStream_t) stream); return CLLM_OK; }
 extern "C" int cllm_stream_destroy(void * stream) {
     if (stream) { HIP_TRY(hipStreamSynchronize((hipStream_t) stream)); stream_scratch_release((hipStream_t) stream); HIP_TRY(hipStreamDestroy((hipStream_t) stream)); }
     return CLLM_OK;
@@ -272,6 +274,21 @@ extern "C" int cllm_set_prefill_mode(int mode) {
     return CLLM_OK;
 }
 extern "C" int cllm_get_prefill_mode(void) { return prefill_mode(); }
+// the prompt's ATTENTION block on its own switch (round 6: which half of the fast mode owns its deviation from the CPU run -- profiles/r06_prefill_mode_decomposition.txt):
+//   CLLM_PREFILL_ATTN=exact | fast overrides what CLLM_PREFILL / cllm_set_prefill_mode say for K.Q / soft_max / V.P; unset (-1): follows prefill_mode()
+static int g_prefill_attn_mode = -2;
+int prefill_attn_mode() {
+    if (g_prefill_attn_mode == -2) {
+        const char * e = getenv("CLLM_PREFILL_ATTN");
+        g_prefill_attn_mode = !e ? -1 : !strcmp(e, "fast") ? 0 : !strcmp(e, "exact") ? 1 : -1;
+    }
+    return g_prefill_attn_mode >= 0 ? g_prefill_attn_mode : prefill_mode();
+}
+extern "C" int cllm_set_prefill_attn_mode(int mode) {
+    if (mode < -1 || mode > 1) FAIL(CLLM_E_INVALID, "set_prefill_attn_mode: -1 (follow the prefill mode), 0 (flash kernel) or 1 (exact order)");
+    g_prefill_attn_mode = mode;
+    return CLLM_OK;
+}
 
 extern "C" size_t cllm_mul_mat_wsize(const cllm_tensor * src0, const cllm_tensor * src1) {
     if (!src0 || !src1 || !is_quant(src0->type)) return 0;
@@ -690,7 +707,7 @@ extern "C" int cllm_op_attn_prefill(void * stream, const cllm_tensor * q, const 
     if (q->type != CLLM_TYPE_F32 || dst->type != CLLM_TYPE_F32 || k->type != CLLM_TYPE_F16 || vt->type != CLLM_TYPE_F16 || n_past < 0) FAIL(CLLM_E_UNSUPPORTED, "attn_prefill: types");
     if (dst->ne[0] != vt->ne[1] || dst->ne[1] != q->ne[1] || dst->ne[2] != q->ne[2] || dst->ne[3] != q->ne[3] || dst->nb[0] != 4 || k->nb[0] != 2 || vt->nb[0] != 2) FAIL(CLLM_E_INVALID, "attn_prefill: shapes");
     if (k->ne[1] != n_past + q->ne[1]) FAIL(CLLM_E_INVALID, "attn_prefill: n_kv != n_past + qlen");
-    if (prefill_mode() == 1 && q->ne[3] == 1 && k->ne[3] == 1) {       // the reference's order: K.Q, soft_max, V.P on the exact kernels (mmf_exact.hip)
+    if (prefill_attn_mode() == 1 && q->ne[3] == 1 && k->ne[3] == 1) {       // the reference's order: K.Q, soft_max, V.P on the exact kernels (mmf_exact.hip)
         tview ve = tv(vt); ve.ne[0] = k->ne[1];
         const int rc = attn_prefill_exact((hipStream_t) stream, tv(q), tv(k), ve, (char *) dst->data, (int64_t) dst->nb[1], (int64_t) dst->nb[2], scale, n_past);
         if (rc != CLLM_E_UNSUPPORTED) return rc;

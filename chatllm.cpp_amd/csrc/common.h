@@ -450,6 +450,7 @@ bool prefill_f16_enabled();
 //   1 (default) exact: mmx.hip + mmf_exact.hip, the reference's accumulation order -- bit-identical to the CPU for every prompt length
 //   0 fast: int8-MFMA GEMM (mmq.hip) + flash kernel (fattn.hip), their own fp32 summation order (tolerance tier)
 int prefill_mode();
+int prefill_attn_mode();          // the same for the prompt's attention block alone (CLLM_PREFILL_ATTN / cllm_set_prefill_attn_mode; default: follows prefill_mode())
 int launch_mmx(hipStream_t st, int wtype, const tview & w, const void * act, size_t act_stride, const tview & src1_geom, const tview & dst, const float * resid = nullptr, int64_t ldr = 0, int epi = 0);
 int launch_mmf_exact(hipStream_t st, const tview & w, const tview & x, const tview & d, int causal, int n_past, bool x_f16 = false);
 int launch_soft_max_causal_f16out(hipStream_t st, const tview & sv, float scale, int n_past);      // ops.hip

@@ -193,7 +193,9 @@ static int tp_allreduce(cllm_llama * m, hipStream_t st, float * buf, int64_t n) 
     if (m->allreduce) { m->allreduce(m->allreduce_user, st, buf, n); return CLLM_OK; }
     FAIL(CLLM_E_INVALID, "llama: tp_size > 1 needs cllm_llama_set_tp_comm or cllm_llama_set_allreduce (cllm_llama_set_tp_oneshot covers messages up to its max_n)");
 }
-static bool tp_on(const cllm_llama * m) { return m->cfg.tp_size > 1 && (m->tp_comm || m->tp_oneshot || m->allreduce); }
+// a sharded model: o / down produce PARTIAL sums.  (tp_fused alone carries the single-token steps only: a prompt through forward_general still needs a collective --
+// tp_allreduce fails loudly without one instead of adding partial sums to the residual stream)
+static bool tp_on(const cllm_llama * m) { return m->cfg.tp_size > 1 && (m->tp_comm || m->tp_oneshot || m->allreduce || m->tp_fused); }
 extern "C" int cllm_llama_use_graph(cllm_llama * m, int enable) { if (!m) FAIL(CLLM_E_INVALID, "null"); m->use_graph = enable != 0; return CLLM_OK; }
 extern "C" size_t cllm_llama_weight_bytes(const cllm_llama * m) { return m ? m->weight_bytes : 0; }
 
@@ -235,7 +237,7 @@ static int interleave_rows(hipStream_t st, dweight & dst, dweight & a, dweight &
 static int finalize(cllm_llama * m, int qlen) {
     const cllm_llama_config & c = m->cfg;
     // a sharded model without a collective would silently produce logits from partial o / down sums
-    if (c.tp_size > 1 && !m->tp_comm && !m->tp_oneshot && !m->allreduce) FAIL(CLLM_E_INVALID, "llama: tp_size %d needs cllm_llama_set_tp_comm or cllm_llama_set_allreduce before the first forward", c.tp_size);
+    if (c.tp_size > 1 && !m->tp_comm && !m->tp_oneshot && !m->allreduce && !(m->tp_fused && qlen == 1)) FAIL(CLLM_E_INVALID, "llama: tp_size %d needs cllm_llama_set_tp_comm, cllm_llama_set_tp_oneshot or cllm_llama_set_allreduce before the first forward (cllm_llama_set_tp_fused alone carries single-token steps only)", c.tp_size);
     const int64_t H = c.hidden, hd = c.head_dim, QD = (int64_t) m->nh * hd, KD = (int64_t) m->nkv * hd, F = m->F, V = c.vocab, ML = c.max_len;
     if (!m->finalized) {
         TRY(expect(m->tok_embd, "tok_embd", -1, cllm_row_size(m->tok_embd.type, H) * (size_t) V, false));
@@ -408,7 +410,7 @@ static int forward_general(cllm_llama * m, int qlen, int n_past) {
             cllm_tensor Qv = TS(CLLM_TYPE_F32, q, hd, qlen, nh, (size_t) QKV * 4, (size_t) hd * 4);
             cllm_tensor Vv = TS(CLLM_TYPE_F16, L.v_cache, n_kv, hd, nkv, (size_t) ML * 2, (size_t) ML * hd * 2);
             int frc = CLLM_E_UNSUPPORTED;
-            if (qlen >= flash_prefill_min_cols() && prefill_mode() != 1) {     // fast mode, the tolerance tier (as the MFMA mat-muls below): one flash kernel, the scores never reach HBM
+            if (qlen >= flash_prefill_min_cols() && prefill_attn_mode() != 1) {     // fast mode, the tolerance tier (as the MFMA mat-muls below): one flash kernel, the scores never reach HBM
                 tview vt = tv(&Vv); vt.ne[0] = ML;
                 frc = launch_fattn((hipStream_t) st, tv(&Qv), tv(&Kv), CLLM_TYPE_F16, vt, 1, nullptr, n_past, (char *) m->att, (int64_t) QD * 4, (int64_t) hd * 4,
                                    (int64_t) QD * 4 * qlen, 1.0f / sqrtf((float) hd), nullptr, 0);
@@ -421,7 +423,7 @@ static int forward_general(cllm_llama * m, int qlen, int n_past) {
             cllm_tensor C  = T(CLLM_TYPE_F32, m->ctx, hd, qlen, nh);
             // exact mode, a prompt: the probabilities stay fp16 between the soft-max and V.P (the rounding V.P's src1 conversion would apply: same bits, half the bytes)
             int prc = CLLM_E_UNSUPPORTED;
-            if (prefill_mode() == 1 && qlen > 32 && n_kv % 8 == 0 && hd % 4 == 0) {
+            if (prefill_attn_mode() == 1 && qlen > 32 && n_kv % 8 == 0 && hd % 4 == 0) {
                 prc = launch_soft_max_causal_f16out((hipStream_t) st, tv(&S), 1.0f / sqrtf((float) hd), n_past);
                 if (prc == CLLM_OK) { tview P = tv(&S); P.nb[0] = 2; prc = launch_mmf_exact((hipStream_t) st, tv(&Vv), P, tv(&C), 2, n_past, true); }
                 if (prc != CLLM_OK && prc != CLLM_E_UNSUPPORTED) return prc;

@@ -156,7 +156,7 @@ int launch_mul_mat_f(hipStream_t st, int wtype, const tview & w, const tview & x
     static const int mma_min_cols = getenv("CLLM_MMA_MIN_COLS") ? atoi(getenv("CLLM_MMA_MIN_COLS")) : 33;      // (below: the exact-order kernels, so that prompts of <= 32 tokens stay bit-identical to the CPU path)
     // (the exact-order matrix-core kernel has the lane-group kernels' bits: it takes over where it is faster -- CLLM_MMF_EXACT_MIN_COLS)
     static const int mmf_min_cols = getenv("CLLM_MMF_EXACT_MIN_COLS") ? atoi(getenv("CLLM_MMF_EXACT_MIN_COLS")) : 2;         // measured: faster from 2 columns on (profiles/r03_short_prompt_crossover.txt)
-    const bool fast = wtype == CLLM_TYPE_F16 && x.ne[1] >= mma_min_cols && prefill_mode() != 1;
+    const bool fast = wtype == CLLM_TYPE_F16 && x.ne[1] >= mma_min_cols && prefill_attn_mode() != 1;
     if (fast || (wtype == CLLM_TYPE_F16 && x.ne[1] >= mmf_min_cols)) {
         const int rc = fast ? launch_mma_f16(st, w, x, d, causal, n_past)
                             : launch_mmf_exact(st, w, x, d, causal, n_past);       // the reference's order on the f32 matrix cores (mmf_exact.hip)

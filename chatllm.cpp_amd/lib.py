@@ -54,6 +54,7 @@ SIGNATURES = {
     "cllm_stream_create": (C.c_int, [C.POINTER(C.c_void_p)]),
     "cllm_stream_destroy": (C.c_int, [_P]),
     "cllm_stream_sync": (C.c_int, [_P]),
+    "cllm_scratch_release": (C.c_int, [_P]),
     "cllm_check_kernel_errors": (C.c_int, []),
     "cllm_graph_capture_begin": (C.c_int, [_P]),
     "cllm_graph_capture_end": (C.c_int, [_P, C.POINTER(C.c_void_p)]),
@@ -71,6 +72,7 @@ SIGNATURES = {
     "cllm_mul_mat_ex_min_cols": (C.c_int, []),
     "cllm_set_prefill_mode": (C.c_int, [C.c_int]),
     "cllm_get_prefill_mode": (C.c_int, []),
+    "cllm_set_prefill_attn_mode": (C.c_int, [C.c_int]),
     "cllm_op_mul_mat_ex": (C.c_int, [_P, _T, _T, _T, _P, C.c_size_t, C.c_int, _T, C.c_float, C.c_int, _T]),
     "cllm_op_mul_mat_vec_fused": (C.c_int, [_P, _T, C.c_int, _P, _P, C.c_float, C.c_int, _P, _P]),
     "cllm_pack_rows": (C.c_int, [_P, _P, C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.c_int, C.c_size_t, C.c_int]),

@@ -76,6 +76,9 @@ CLLM_API int  cllm_host_free(void * ptr);
 CLLM_API int  cllm_stream_create(void ** stream);
 CLLM_API int  cllm_stream_destroy(void * stream);
 CLLM_API int  cllm_stream_sync(void * stream);                 /* backend_i.synchronize */
+/* library-owned scratch of a stream the library did not create (a host's own stream; NULL = the legacy stream of the CURRENT device only): cllm_stream_destroy
+ * never sees those.  Call with that stream idle. */
+CLLM_API int  cllm_scratch_release(void * stream);
 /* capture of everything launched on `stream` between begin and end into one replayable graph (ggml_backend_i.graph_plan_create /
  * graph_plan_compute, ggml-backend-impl.h:104-113); capture_end: CLLM_E_UNSUPPORTED and *graph_exec = NULL if the sequence cannot be captured */
 /* after a synchronize: CLLM_E_HIP if a bounded in-kernel wait of the current device timed out since the last call (the launch wound down, its results are void) */
@@ -132,6 +135,9 @@ CLLM_API int    cllm_mul_mat_ex_min_cols(void);
  * Process-wide; not meant to change while work is in flight. */
 CLLM_API int    cllm_set_prefill_mode(int mode);
 CLLM_API int    cllm_get_prefill_mode(void);
+/* The prompt's attention block (K.Q -> soft_max -> V.P) on a switch of its own: -1 (default) follows the mode above, 0 the flash kernel, 1 the reference's order
+ * (CLLM_PREFILL_ATTN=fast | exact).  "CLLM_PREFILL=fast CLLM_PREFILL_ATTN=exact" = int8-MFMA mat-muls + exact attention (profiles/r06_prefill_mode_decomposition.txt). */
+CLLM_API int    cllm_set_prefill_attn_mode(int mode);
 CLLM_API int    cllm_op_mul_mat_ex(void * stream, const cllm_tensor * src0, const cllm_tensor * src1, cllm_tensor * dst, void * wdata, size_t wsize,
                                    int pro, const cllm_tensor * norm_w, float eps, int epi, const cllm_tensor * resid);
 

@@ -272,6 +272,29 @@ def test_baseline_cfg4_qwen2_72b_shapes_q4_k_free_running(gpu, tmp_path):
     _real_shape_case(gpu, tmp_path, "qwen2", "qwen2-72b", 12, [(13 * i + 7) % 150000 for i in range(16)], 32, dict(max_len=512, n_layer=2))
 
 
+_REF_BUILT = pytest.mark.skipif(not (os.path.exists(os.path.join(REF, "ref_chat")) and os.path.exists(os.path.join(REF, "libggml-hip.so"))),
+                                reason="oracle/_ref (reference host + module) not built")
+
+
+@_REF_BUILT
+def test_full_depth_80_layers_qwen2_arch_reduced_width_free_running(gpu, tmp_path):
+    """BASELINE cfg4's DEPTH in every run of the suite: all 80 layers of the Qwen2 architecture (q/k/v biases, NEOX RoPE, GQA 8 : 2) at reduced width -- hidden 1024,
+    ffn 3 * 256 + 32 = 800, so the Q4_K file's down_proj still falls back to Q8_0 as Qwen2-72B's 29568 does (convert.py:811-829) -- Q4_K, 230 MB.  The reference host on
+    its CPU backend vs every layer on the module, free-running greedy over a 16-token prompt + 24 tokens: equal ids, zero differing logit words.  HeterogeneousModel::forward
+    walks all layers (src/models.cpp:1399-1424): an error that compounds with depth (a residual stream kept in the wrong buffer, a KV cache of the wrong layer, the
+    launch list of one layer replayed for another) shows here; the real-width cases above run 2 of the 80."""
+    _real_shape_case(gpu, tmp_path, "qwen2", "qwen2-72b", 12, [(13 * i + 7) % 2000 for i in range(16)], 24,
+                     dict(max_len=256, hidden=1024, n_head=8, n_kv_head=2, ffn=800, vocab=2048), threads=8)
+
+
+@_REF_BUILT
+def test_full_depth_32_layers_mixtral_arch_reduced_width_free_running(gpu, tmp_path):
+    """BASELINE cfg5's DEPTH in every run of the suite: all 32 layers of the Mixtral architecture (8 experts, top 2, one token per graph through the prompt) at
+    hidden 1024 / ffn 768, Q4_K, 390 MB: CPU host vs every layer on the module, free-running, equal ids and zero differing logit words over 16 + 24 steps."""
+    _real_shape_case(gpu, tmp_path, "mixtral", "mixtral-8x7b", 12, [(11 * i + 5) % 2000 for i in range(16)], 24,
+                     dict(max_len=256, hidden=1024, n_head=8, n_kv_head=2, ffn=768, vocab=2048), threads=8)
+
+
 _FULL = pytest.mark.skipif(not os.environ.get("CLLM_FULL_DEPTH"), reason="CLLM_FULL_DEPTH=1 runs BASELINE cfg4 / cfg5 at FULL depth (26 / 50 GB GGMM files in /tmp, minutes of "
                                                                     "CPU time for the reference's own run); their last record: profiles/r05_full_depth_parity_cfg4_cfg5.txt")
 

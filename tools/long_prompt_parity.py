@@ -21,6 +21,11 @@ MODES = {
     # every mat-mul and both attention contractions on the exact-order kernels whatever the prompt length
     "exact": {"CLLM_PREFILL": "exact"},
     "fast": {"CLLM_PREFILL": "fast"},
+    # round 6: the two halves of the fast mode on their own (CLLM_PREFILL_ATTN, capi.hip): which one owns its deviation from the CPU run?
+    "mmq+exact-attn": {"CLLM_PREFILL": "fast", "CLLM_PREFILL_ATTN": "exact"},       # int8-MFMA mat-muls (own fp32 fold order), attention in the reference's order
+    "exact-mm+flash": {"CLLM_PREFILL": "exact", "CLLM_PREFILL_ATTN": "fast"},       # mat-muls in the reference's order, flash attention kernel
+    "f16": {"CLLM_PREFILL": "f16"},
+    "f16+exact-attn": {"CLLM_PREFILL": "f16", "CLLM_PREFILL_ATTN": "exact"},
     # round 2's switches: the <= 32-column exact kernels forced for every length (slow: weights re-read per 4-column chunk)
     "exact-r02": {"CLLM_MMQ_MIN_COLS": "100000", "CLLM_MMA_MIN_COLS": "100000"},
 }
