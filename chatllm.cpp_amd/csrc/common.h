@@ -478,6 +478,10 @@ int launch_gemv_kq(hipStream_t st, int wtype, const tview & w, const void * act,
 int launch_gemv_kq_id(hipStream_t st, int wtype, const tview & as, const void * act, size_t act_stride, int64_t ne11, const tview & ids, const tview & dst);
 int launch_dense_f16(hipStream_t st, int wtype, const tview & w, const tview & x, const tview & d, const float * resid = nullptr, int64_t ldr = 0, int epi = 0);
 int launch_gemv_rows(hipStream_t st, const void * W, int64_t K, int64_t nrows, int pro, const float * px, const float * pw, float eps, int epi, float * dst, const float * bias, const float * resid);
+// ffn_fused.hip: the decode step's FFN block (norm + gate/up + SiLU*up + down + residual) as ONE launch; CLLM_E_UNSUPPORTED: the caller issues the two launches
+size_t ffn_fused_state_bytes(int64_t F);
+int launch_ffn_fused(hipStream_t st, const void * Wgu, const void * Wd, int64_t H, int64_t F, const float * x, const float * norm_w, float eps, void * state, bool * state_ready, float * xout);
+int ffn_fused_mode();
 int kernel_error_word(unsigned ** dev_ptr);      // gemv_team32.hip: the device's mapped error word (bounded in-kernel waits report there)
 int launch_gemv_decode_tp_scatter(hipStream_t st, int wtype, const void * W, int64_t K, int64_t nrows, int pro, const float * px, const void * ctx_dev, int site);      // gemv_tp.hip
 int launch_gemv_decode_tp_gather(hipStream_t st, int wtype, const void * W, int64_t K, int64_t nrows, const float * px, const float * pw, float eps, int epi, float * dst,

@@ -57,6 +57,7 @@ struct cllm_llama {
     int32_t * out_ring = nullptr, * counter_dev = nullptr;   // device-side greedy loop: generated ids + how many
     bool own_stream = false, fused_ok = false, fused_warm = false, fused_warm_long = false;
     size_t weight_bytes = 0;
+    void * ffn_state = nullptr; bool ffn_state_ready = false;          // ffn_fused.hip: epoch word + granules of the fused FFN launch
 };
 
 #define TRY(expr) do { int _rc = (expr); if (_rc) return _rc; } while (0)
@@ -115,7 +116,7 @@ extern "C" void cllm_llama_destroy(cllm_llama * m) {
         if (L.v_cache) (void) hipFree(L.v_cache);
     }
     for (void * p : { (void *) m->x, (void *) m->xn, (void *) m->qkv, (void *) m->att, (void *) m->ctx, (void *) m->o, (void *) m->gu, (void *) m->g, (void *) m->scores,
-                      (void *) m->logits, m->wdata, (void *) m->tokens_dev, (void *) m->pos_dev, (void *) m->next_tok_dev, (void *) m->out_ring, (void *) m->counter_dev }) if (p) (void) hipFree(p);
+                      (void *) m->logits, m->wdata, (void *) m->tokens_dev, (void *) m->pos_dev, (void *) m->next_tok_dev, (void *) m->out_ring, (void *) m->counter_dev, m->ffn_state }) if (p) (void) hipFree(p);
     if (m->own_stream) { stream_scratch_release(m->st); (void) hipStreamDestroy(m->st); }
     delete m;
 }
@@ -285,6 +286,7 @@ static int finalize(cllm_llama * m, int qlen) {
         HIP_TRY(hipMalloc((void **) &m->next_tok_dev, 16));
         HIP_TRY(hipMalloc((void **) &m->out_ring, (size_t) ML * 4));
         HIP_TRY(hipMalloc((void **) &m->counter_dev, (16 + 512 + 512) * 4));    // loop counter + 256 (value, index) argmax partials + cos/sin table of the position
+        HIP_TRY(hipMalloc(&m->ffn_state, ffn_fused_state_bytes(F)));
         // the fused single-token path needs the row-concatenated projections and block-aligned widths
         m->fused_ok = m->own_stream && H % 256 == 0 && QD % 256 == 0 && hd % 8 == 0 && ML % 8 == 0 && (size_t)(hd + ML) * 4 <= 150 * 1024 &&
                       H <= 16384 && QD <= 32768 && F <= 32768 && F % 8 == 0;      // row lengths the decode mat-vec takes (gemv_decode.hip)
@@ -585,6 +587,12 @@ static int decode_step_fused(cllm_llama * m, bool sample, bool long_ctx, bool he
         const bool silu_epi = F % 8 == 0 && H <= 16384;       // (every quantized type the decode kernel takes)
         const float * dsrc = silu_epi ? m->g : m->gu;
         const int dpro = silu_epi ? 2 : 3;
+        // opt-in (CLLM_FFN_FUSED=1; bit-identical, slower: profiles/r06_ffn_fused_persistent_bound.txt): the whole FFN block as ONE launch where the shapes allow (ffn_fused.hip)
+        if (ffn_fused_mode() && !tp && silu_epi && L.wgu.type == CLLM_TYPE_Q4_K && L.wdown.type == CLLM_TYPE_Q4_K) {
+            const int frc = launch_ffn_fused(st, L.wgu.data, L.wdown.data, H, F, xc, (const float *) L.ffn_norm.data, c.rms_eps, m->ffn_state, &m->ffn_state_ready, xc);
+            if (frc == CLLM_OK) continue;
+            if (frc != CLLM_E_UNSUPPORTED) return frc;
+        }
         TRY(norm_gemv(L.wgu, 2*F, (const float *) L.ffn_norm.data, silu_epi ? 1 : 0, silu_epi ? m->g : m->gu, nullptr));
         if (!tp) TRY(launch_mmvq_fused(st, L.wdown.type, L.wdown.data, F, H, dpro, dsrc, nullptr, 0.0f, 0, xc, nullptr, xc));   // x = down + x
         else if (fused_ar) {

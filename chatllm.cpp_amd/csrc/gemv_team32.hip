@@ -362,7 +362,7 @@ int gemv_team32_check() {
     const unsigned e = *h;
     if (e) {
         *h = 0;
-        if (e >= 200) FAIL(CLLM_E_HIP, "gemv_ldr: a wait between the loader and the consumer waves of a workgroup timed out (code %u); set CLLM_GEMV_LDR=0", e);
+        if (e >= 300) FAIL(CLLM_E_HIP, "ffn_fused: the gather of a block of SiLU(gate) * up timed out (code %u: job %u): a workgroup of the launch never produced its features; set CLLM_FFN_FUSED=0", e, e - 300);
         FAIL(CLLM_E_HIP, "gemv_team32: a hand-off between the waves of a workgroup timed out (code %u); set CLLM_GEMV_TEAM32=0", e);
     }
     return CLLM_OK;

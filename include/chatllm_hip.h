@@ -141,6 +141,15 @@ CLLM_API int    cllm_set_prefill_attn_mode(int mode);
 CLLM_API int    cllm_op_mul_mat_ex(void * stream, const cllm_tensor * src0, const cllm_tensor * src1, cllm_tensor * dst, void * wdata, size_t wsize,
                                    int pro, const cllm_tensor * norm_w, float eps, int epi, const cllm_tensor * resid);
 
+/* The FFN block of ONE token (BaseMLP::forward src/layers.cpp:2475-2497 behind LMBlock1Forward's post_attention_layernorm and residual add :2744-2758) as ONE launch:
+ *     xout = Wdown . q8_K(SiLU(Wgate . a) * (Wup . a)) + x,   a = q8_K(RMS_NORM(x, eps) * norm_w)
+ * i.e. the nodes RMS_NORM -> MUL -> MUL_MAT x 2 -> UNARY(SILU) -> MUL -> MUL_MAT -> ADD, bit for bit (ggml_compute_forward_mul_mat ggml-cpu.c:1229-1421 per mat-mul).
+ * w_gate_up: Q4_K [H, 2 F], rows alternate gate_u, up_u (cllm_pack_rows, interleave); w_down: Q4_K [F, H]; x, norm_w F32 [H]; xout may be x.
+ * state: cllm_ffn_fused_state_bytes(F) bytes of device memory, zero-filled before the first call, private to one stream (the launch's hand-off granules and epoch).
+ * CLLM_E_UNSUPPORTED (nothing launched) outside its shapes (H <= 4096, 4096 <= F, multiples of 256, a 256-CU device): issue the two cllm_op_mul_mat_vec_fused calls. */
+CLLM_API size_t cllm_ffn_fused_state_bytes(int64_t F);
+CLLM_API int    cllm_op_ffn_fused(void * stream, const cllm_tensor * w_gate_up, const cllm_tensor * w_down, const float * x, const float * norm_w, float eps, void * state, float * xout);
+
 /* One launch for a node pattern around a single-column quantized MUL_MAT -- what a ggml backend's graph_compute can fuse
  * (chatllm.cpp_amd/host/ggml-hip.cpp does, with ggml's use counts):
  *   pro 1: RMS_NORM(px, eps) -> MUL(pw) -> MUL_MAT(src0)      pro 2: MUL_MAT(src0, px)      pro 4: UNARY(SILU)(px) -> MUL(pw) -> MUL_MAT(src0)
@@ -178,6 +187,10 @@ CLLM_API int    cllm_bench_mul_mat_id(void * stream, const cllm_tensor * as, con
 CLLM_API int    cllm_bench_read_bw(void * stream, size_t bytes, int iters, float * gb_per_s);
 CLLM_API int    cllm_bench_gemv_fused(void * stream, int wtype, void * const * w_datas, int n_w, int64_t K, int64_t nrows, int pro,
                                       const float * px, const float * pw, float eps, int epi, float * dst, const float * resid, int iters, float * avg_us);
+/* measurement helper (tools/ffn_bench.py): the FFN block of a token `iters` times over n_w copies of its weights -- fused 0: the two launches of the five-launch layer,
+ * 1: cllm_op_ffn_fused's launch, 2: the same with a hand-off that costs nothing (NOT a correct computation: the design's bound); x is updated in place */
+CLLM_API int    cllm_bench_ffn(void * stream, void * const * w_gate_up, void * const * w_down, int n_w, int64_t H, int64_t F, float * x, const float * norm_w, float eps,
+                               float * g, void * state, int fused, int iters, float * avg_us);
 
 /* GGML_OP_MUL_MAT_ID -- ggml_compute_forward_mul_mat_id (ggml-cpu.c:1432-1678), chatllm MultiLinear::forward
  * (src/layers.cpp:2145-2151):  dst[:, s, t] = as[:, :, ids[s,t]]^T . b[:, s % b.ne1, t]              */

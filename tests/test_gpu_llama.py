@@ -274,6 +274,47 @@ def test_fused_decode_path_is_bit_identical_to_the_node_by_node_path(gpu, wtype,
     b.close()
 
 
+@pytest.mark.parametrize("over", [dict(hidden=512, n_head=4, n_kv_head=2, ffn=4608), dict(ffn=8960), dict(ffn=12288), dict(ffn=4096, qkv_bias=1, rope_mode=2, rope_theta=1e6),
+                                  dict(hidden=4096, n_head=32, n_kv_head=8, ffn=14336, vocab=1024)])
+def test_fused_ffn_launch_is_bit_identical_to_the_two_launches_and_the_node_path(gpu, over):
+    """ffn_fused.hip: RMS_NORM -> MUL -> gate / up mat-vecs -> SiLU * up -> down mat-vec -> residual ADD as ONE launch (the weight stream runs through the gate/up -> down edge in
+    per-wave LDS rings, SiLU(gate) * up handed off as epoch-tagged granules and gathered progressively): the same logits, bit for bit, as the two launches it replaces and as the
+    node-by-node path -- partial last rounds (ffn = 4608: 2 blocks, 8960: 3, 4096 / 12288: none), a lone step per row and ragged down rows (18 / 35 / 48 / 56 blocks), the
+    Llama-3-8B block itself; then the greedy loop replayed from the captured graph against the stepwise ids"""
+    L = gpu.lib.get()
+    cfg = gpu.synth.config("small", max_len=64, n_layer=2, **over)
+    w = gpu.synth.make_model(cfg, O.Q4_K, seed=21)
+    a, b, c = gpu.Llama(cfg, w), gpu.Llama(cfg, w), gpu.Llama(cfg, w)
+    prompt = np.random.default_rng(21).integers(0, cfg["vocab"], 6).astype(np.int32)
+    la = a.forward(prompt)
+    assert np.array_equal(la, b.forward(prompt)) and np.array_equal(la, c.forward(prompt))
+    try:
+        n0 = L.cllm_debug_ffn_fused_launches()
+        toks = []
+        for i in range(14):
+            t = int(np.argmax(la)) if i % 2 else int(np.random.default_rng(22 + i).integers(0, cfg["vocab"]))
+            toks.append(t)
+            L.cllm_debug_set_ffn_fused(0)
+            la = a.forward([t])
+            lc = c.decode_fused_logits(t)
+            L.cllm_debug_set_ffn_fused(1)
+            lb = b.decode_fused_logits(t)
+            assert np.array_equal(la.view(np.uint32), lb.view(np.uint32)), (i, int(np.sum(la.view(np.uint32) != lb.view(np.uint32))))
+            assert np.array_equal(lc.view(np.uint32), lb.view(np.uint32))
+        assert L.cllm_debug_ffn_fused_launches() - n0 == 14 * cfg["n_layer"]          # the fused launch really ran (every layer of every step of b)
+        assert L.cllm_check_kernel_errors() == 0
+        first = int(np.argmax(lb))
+        L.cllm_debug_set_ffn_fused(0)
+        want = c.decode_greedy(first, 20)
+        L.cllm_debug_set_ffn_fused(1)
+        got = b.decode_greedy(first, 20)                   # eager warm-up step + captured graph
+        assert np.array_equal(want, got)
+        assert L.cllm_check_kernel_errors() == 0
+    finally:
+        L.cllm_debug_set_ffn_fused(0)                      # the default: the two launches (the fused launch is opt-in, CLLM_FFN_FUSED=1)
+    a.close(); b.close(); c.close()
+
+
 @pytest.mark.parametrize("wtype", [O.Q4_0, O.Q8_0, O.Q4_1])
 @pytest.mark.parametrize("team,over", [(4, {}), (5, dict(qkv_bias=1, rope_mode=2, rope_theta=1e6)), (4, dict(ffn=2848))])
 def test_fused_decode_through_the_team_kernel_is_bit_identical_to_the_node_path(gpu, wtype, team, over):
