@@ -326,12 +326,14 @@ def run_ref_chat(mp, ngl, threads, n_decode, env=None, timeout=900, ref_dir=None
 
 
 def cpu_host_end_to_end(mp, n_tokens=64, n_probe=16):
-    """the reference's own HOST decoding the synthetic model end to end on its CPU backend -- what a user of the reference gets on this box (all cores, -n passed
-    explicitly): a sweep over {all cores, 128, 64, 32, 16} threads on short probe runs (the reference's thread pool stops scaling long before a 256-core host is full), then the
-    median of 3 runs of n_tokens decoded tokens at the best count.  The parity oracle is the x86-64-v3 build; where oracle/_ref/avx512 exists (the same sources with the AVX-512 /
-    VNNI branches compiled in, `make -C oracle ref-avx512`) and runs on this host, it is timed the same way and the FASTER of the two is the reported value (`build` says which)."""
+    """the reference's own HOST decoding the synthetic model end to end on its CPU backend -- what a user of the reference gets on this box (-n passed explicitly).
+    Thread sweep on short probe runs, ASCENDING {8, 16, 32, 64, 128, all cores}, stopped after two counts in a row below 0.7 x the best so far (each probe bounded to 60 s): on
+    the 256-core host of the MI355X box the reference's thread pool peaks at 16 threads (43.8 tok/s) and collapses beyond -- 23.6 at 32, 8.0 at 64, 3.0 at 128, no 16-token
+    probe within 300 s at all 256 (profiles/r06_cpu_baseline_thread_sweep.txt: the full sweep, which cost the bench 10 minutes).  Then the median of 3 runs of n_tokens decoded
+    tokens at the best count.  The parity oracle is the x86-64-v3 build; where oracle/_ref/avx512 exists (the same sources with the AVX-512 / VNNI branches compiled in,
+    `make -C oracle ref-avx512`) and runs on this host, it is timed the same way and the FASTER of the two is the reported value (`build` says which)."""
     cores = host_cores()
-    cand = sorted({c for c in (cores, 128, 64, 32, 16) if 1 <= c <= cores}, reverse=True)
+    cand = sorted({c for c in (8, 16, 32, 64, 128, cores) if 1 <= c <= cores})
     out = {"unit": "tokens/s", "host_cores": cores, "kind": "reference"}
     builds = {"x86-64-v3": None}
     d512 = os.path.join(ROOT, "oracle", "_ref", "avx512")
@@ -340,13 +342,18 @@ def cpu_host_end_to_end(mp, n_tokens=64, n_probe=16):
     sweeps, best = {}, None
     for bname, bdir in builds.items():
         try:
-            probe = {}
+            probe, top, below = {}, 0.0, 0
             for th in cand:
                 try:
-                    probe[th] = round(run_ref_chat(mp, "cpu", th, n_probe, ref_dir=bdir, timeout=300)[0], 2)
+                    probe[th] = round(run_ref_chat(mp, "cpu", th, n_probe, ref_dir=bdir, timeout=60)[0], 2)
                 except Exception as e:      # noqa: BLE001  (a thread count that times out is a data point, not a failure)
                     probe[th] = None
-                    log(f"cpu baseline probe {bname} @ {th} threads: {e!r}")
+                    log(f"cpu baseline probe {bname} @ {th} threads: {str(e)[:120]!r}")
+                v = probe[th] or 0.0
+                top = max(top, v)
+                below = below + 1 if v < 0.7 * top else 0
+                if below >= 2:
+                    break
             sweeps[bname] = probe
             ok = {t: v for t, v in probe.items() if v}
             if not ok:
@@ -362,8 +369,8 @@ def cpu_host_end_to_end(mp, n_tokens=64, n_probe=16):
     out.update(best)
     out["thread_sweep_tok_s"] = sweeps
     out["sample"] = ("oracle/_ref/ref_chat (chatllm.cpp's host + ggml CPU backend, built from /root/reference) decoding %d tokens after a 16-token prompt, same synthetic model as a GGMM "
-                     "file; thread sweep %s on %d-token probes per build, then the median of 3 runs at the best count; builds timed: %s, reported: %s at %d threads"
-                     % (n_tokens, cand, n_probe, list(builds), best["build"], best["cores"]))
+                     "file; ascending thread sweep over %s on %d-token probes per build (stopped once two counts in a row fall below 0.7 x the best), then the median of 3 runs at the "
+                     "best count; builds timed: %s, reported: %s at %d threads" % (n_tokens, cand, n_probe, list(builds), best["build"], best["cores"]))
     return out
 
 

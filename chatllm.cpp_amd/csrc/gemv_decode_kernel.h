@@ -44,36 +44,51 @@
 //   units = rows (or gate/up row pairs), dealt as kfull full rounds of nwaves units + nrem (host-computed: no division here)
 
 
-// the weight stream's cache policy.  -DGEMV_NT (non-temporal global_load into VGPRs) measured 580 vs 681 tok/s, gate/up 18.4 vs 14.6 us: the guide's
-// nt gain is for the LDS-DMA stream (global_load_lds ... nt), not for this register path -- default policy stays
-#ifdef GEMV_NT
-#define GEMV_WLOAD(p) __builtin_nontemporal_load(p)
-#else
-#define GEMV_WLOAD(p) (*(p))
-#endif
+// the weight stream's cache policy: default.  (Non-temporal global_load into VGPRs measured 580 vs 681 tok/s, gate/up 18.4 vs 14.6 us -- the guide's nt gain is for the LDS-DMA
+// stream, global_load_lds ... nt, not for this register path: profiles/r03_ldsdma_nt_decode_matvecs.txt.  The A/B macro is retired.)
 #define TS(k) do { if (ts && threadIdx.x == 0) ts[blockIdx.x * 8 + (k)] = wall_clock64(); } while (0)
 
 // device-side context of the fused tensor-parallel all-reduce (tp_oneshot.hip cllm_tp_fused_*): receive buffers [site][rank][max_n] x 8-byte granules {value, step}
 struct tp_fuse_dev { char * peer[16]; int rank, nranks; unsigned max_n, pad; const unsigned * step; unsigned * err; };
 __device__ __forceinline__ u32x4 tpf_load16(const void * p) { u32x4 v; asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(v) : "v"(p) : "memory"); return v; }
-// the four elements e .. e + 3 of the all-reduced vector of `site`: every rank's granules from this rank's own buffer, summed in rank order (bounded wait)
+__device__ __forceinline__ void tpf_issue16(u32x4 & v, const void * p) { asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1" : "=&v"(v) : "v"(p) : "memory"); }      // no wait: tpf_land8
+__device__ __forceinline__ void tpf_land8(u32x4 (&h)[8]) {      // ONE wait for the eight loads in flight; the values are usable only behind this statement
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(h[0]), "+v"(h[1]), "+v"(h[2]), "+v"(h[3]), "+v"(h[4]), "+v"(h[5]), "+v"(h[6]), "+v"(h[7]) :: "memory");
+}
+// the four elements e .. e + 3 of the all-reduced vector of `site`: every rank's granules from this rank's own buffer, summed in rank order (bounded wait).
+// The loads of FOUR ranks go out together and are waited for once (eight ranks: two round trips where a load-wait per granule pair took sixteen -- each 0.7-1 us under load);
+// only a rank whose granules do not carry this step's number yet is polled again, alone.
 __device__ __forceinline__ f32x4 tpf_gather4(const tp_fuse_dev * cx, const char * own, int nranks, unsigned max_n, unsigned step, int site, int e) {
     f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
-    for (int r = 0; r < nranks; r++) {
-        const char * src = own + ((size_t)(site * nranks + r) * max_n + (size_t) e) * 8;
-        u32x4 h0, h1;
-        int spins = 0;
-        for (;;) {
-            h0 = tpf_load16(src); h1 = tpf_load16(src + 16);
-            if (h0.y == step && h0.w == step && h1.y == step && h1.w == step) break;
-            __builtin_amdgcn_s_sleep(1);
-            // (bounded, and a time-out anywhere ends every later wait at its next look: a dead peer costs one time-out, not one per slot and launch)
-            if ((++spins & 1023) == 0 && (spins > (1 << 21) || __hip_atomic_load(cx->err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
-                __hip_atomic_store(cx->err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break;
-            }
+    for (int r0 = 0; r0 < nranks; r0 += 4) {
+        u32x4 h[8];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int r = r0 + i < nranks ? r0 + i : nranks - 1;
+            const char * src = own + ((size_t)(site * nranks + r) * max_n + (size_t) e) * 8;
+            tpf_issue16(h[2 * i], src); tpf_issue16(h[2 * i + 1], src + 16);
         }
-        const f32x4 v = { __uint_as_float(h0.x), __uint_as_float(h0.z), __uint_as_float(h1.x), __uint_as_float(h1.z) };
-        if (r == 0) acc = v; else { acc.x = acc.x + v.x; acc.y = acc.y + v.y; acc.z = acc.z + v.z; acc.w = acc.w + v.w; }
+        tpf_land8(h);
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            if (r0 + i >= nranks) break;
+            u32x4 h0 = h[2 * i], h1 = h[2 * i + 1];
+            if (!(h0.y == step && h0.w == step && h1.y == step && h1.w == step)) {
+                const char * src = own + ((size_t)(site * nranks + r0 + i) * max_n + (size_t) e) * 8;
+                int spins = 0;
+                for (;;) {
+                    h0 = tpf_load16(src); h1 = tpf_load16(src + 16);
+                    if (h0.y == step && h0.w == step && h1.y == step && h1.w == step) break;
+                    __builtin_amdgcn_s_sleep(1);
+                    // (bounded, and a time-out anywhere ends every later wait at its next look: a dead peer costs one time-out, not one per slot and launch)
+                    if ((++spins & 1023) == 0 && (spins > (1 << 21) || __hip_atomic_load(cx->err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+                        __hip_atomic_store(cx->err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break;
+                    }
+                }
+            }
+            const f32x4 v = { __uint_as_float(h0.x), __uint_as_float(h0.z), __uint_as_float(h1.x), __uint_as_float(h1.z) };
+            if (r0 + i == 0) acc = v; else { acc.x = acc.x + v.x; acc.y = acc.y + v.y; acc.z = acc.z + v.z; acc.w = acc.w + v.w; }
+        }
     }
     return acc;
 }
@@ -92,26 +107,42 @@ __global__ void __launch_bounds__(1024) k_gemv_dec(const float * __restrict__ px
     //  chain records in the dynamic LDS, so that the kernel-argument block and the static LDS of every other instantiation stay what they were: a 16-byte
     //  longer argument block + 8 bytes of static LDS measured +2..4 % on all of them)
     extern __shared__ __attribute__((aligned(16))) char lds[];
+    // ---- the argument slots BY FAMILY.  The physical signature is one and the same for every instantiation (its size and order are part of the tuned launch, see above); what a
+    //      slot means in a family is said HERE, once, and the code below uses these names only: ----
+    //   plain:           padd = all-reduced partial folded into the residual (PRO 1, NPRE 1), xout = where the new residual stream goes
+    //   sparse MoE:      ids = the TOP_K output (MOE / EPI 3: read; EPI 2 / 5: WRITTEN), pw = the probabilities (EPI 3), padd = the router's weight rows (EPI 5),
+    //                    px_slot_stride = activation stride per slot (MOE, EPI 3) | number of experts (EPI 5), dst_slot_stride = dst stride per slot (MOE, EPI 5) | k of TOP_K (EPI 2),
+    //                    xout = the normalised activation out (EPI 2) | the probabilities out (EPI 5)
+    //   tensor parallel: ids = the tp_fuse_dev context, px_slot_stride = the site gathered (PRO 5), dst_slot_stride = the site scattered to (EPI 4)
+    const tp_fuse_dev * const tp_ctx    = (PRO == 5 || EPI == 4) ? (const tp_fuse_dev *) ids : nullptr;
+    const int                 tp_site_in = px_slot_stride, tp_site_out = dst_slot_stride;
+    const int32_t * const     moe_ids   = ids;                                             // MOE / EPI 3: the experts picked by an earlier launch
+    int32_t * const           topk_out  = const_cast<int32_t *>(ids);                      // EPI 2 / EPI 5: where this launch writes its picks
+    const int                 topk_k    = dst_slot_stride;                                 // EPI 2
+    const int                 n_experts = px_slot_stride;                                  // EPI 5
+    const char * const        router_w  = (const char *) padd;                             // EPI 5
+    const float * const       moe_probs = pw;                                              // EPI 3
+    float * const             probs_out = xout;                                            // EPI 5
+    const int                 act_slot_stride = px_slot_stride, out_slot_stride = dst_slot_stride;      // MOE / EPI 3 / EPI 5: per-slot strides
     if constexpr (MOE && EPI != 5) {
         int e;
-        asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(e) : "s"(ids + blockIdx.y) : "memory");
+        asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(e) : "s"(moe_ids + blockIdx.y) : "memory");
         W += (unsigned long long)(unsigned) e * w_expert_bytes;
-        px += (long) blockIdx.y * px_slot_stride; dst += (long) blockIdx.y * dst_slot_stride;
+        px += (long) blockIdx.y * act_slot_stride; dst += (long) blockIdx.y * out_slot_stride;
     }
     const char * W0 = W, * W1 = W;
     float cw0 = 0.0f, cw1 = 0.0f;
     if constexpr (EPI == 3) {
         int e0, e1;
-        asm volatile("s_load_dword %0, %2, 0x0\n\ts_load_dword %1, %2, 0x4\n\ts_waitcnt lgkmcnt(0)" : "=&s"(e0), "=&s"(e1) : "s"(ids) : "memory");
+        asm volatile("s_load_dword %0, %2, 0x0\n\ts_load_dword %1, %2, 0x4\n\ts_waitcnt lgkmcnt(0)" : "=&s"(e0), "=&s"(e1) : "s"(moe_ids) : "memory");
         W0 = W + (unsigned long long)(unsigned) e0 * w_expert_bytes; W1 = W + (unsigned long long)(unsigned) e1 * w_expert_bytes;
-        const float p0 = uniform_load_f32(pw + e0), p1 = uniform_load_f32(pw + e1);      // k_moe_combine's order: double sum from 0, IEEE divisions
+        const float p0 = uniform_load_f32(moe_probs + e0), p1 = uniform_load_f32(moe_probs + e1);      // k_moe_combine's order: double sum from 0, IEEE divisions
         const float sum = (float)(((double) 0.0 + (double) p0) + (double) p1);
         cw0 = __fdiv_rn(p0, sum); cw1 = __fdiv_rn(p1, sum);
     }
-#ifndef GEMV_P
-#define GEMV_P 2
-#endif
-    constexpr int P = (FMT == CLLM_TYPE_Q4_K) ? (GEMV_P + 1) / 2 : GEMV_P, RU = (EPI == 1 || EPI == 3 || EPI == 5) ? 2 : 1;      // steps of prefetch (a Q4_K step is 16 super-blocks = 2304 B per wave, the others' 64 blocks)
+    // steps of weight prefetch per wave: ONE 2304-byte step for Q4_K, two 64-block steps for the others (a third step at entry or mid-prologue only delays the prologue:
+    // profiles/r05_ring_per_wave_prefetch.txt; the A/B macro of the depth is retired)
+    constexpr int P = (FMT == CLLM_TYPE_Q4_K) ? 1 : 2, RU = (EPI == 1 || EPI == 3 || EPI == 5) ? 2 : 1;      // steps of prefetch (a Q4_K step is 16 super-blocks = 2304 B per wave, the others' 64 blocks)
     constexpr bool IS_K = FMT == CLLM_TYPE_Q4_K, IS_Q8 = FMT == CLLM_TYPE_Q8_0, IS_Q41 = FMT == CLLM_TYPE_Q4_1;
     constexpr int KIND = IS_K ? 256 : 32;                           // elements per weight block = activation quantization block
     constexpr int BS = IS_K ? 144 : q32_fmt<IS_K ? CLLM_TYPE_Q4_0 : FMT>::BS;      // bytes per weight block
@@ -129,11 +160,8 @@ __global__ void __launch_bounds__(1024) k_gemv_dec(const float * __restrict__ px
     // row, four blocks per wave (quant16_q8_K, quant_dev.h).  The prologue is redone by all 256 workgroups and is VALU-THROUGHPUT-bound inside each for long rows: down's
     // 56 blocks cost every CU 56 x ~90 wave-instructions with four values per lane, 14 x ~110 here (its prologue barrier opens at 2.5 instead of 3.4 us, the launch takes
     // 9.8 instead of 10.6 us: profiles/r05_prologue_quant16.txt).  NOT for 4096-value rows: there four waves would do serially what sixteen do side by side (o +0.2 us;
-    // the RMS_NORM prologue of qkv / gate-up in this form, GEMV_Q16 = 2: +1.2 us each -- measured, same file).
-#ifndef GEMV_Q16
-#define GEMV_Q16 1          // (A/B builds: 0 = four values per lane everywhere, 1 = the plain-quantize prologue of long rows, 2 = + every RMS_NORM / plain prologue)
-#endif
-    constexpr bool Q16 = FMT == CLLM_TYPE_Q4_K && ((GEMV_Q16 >= 1 && PRO == 2 && (NPRE >= 4 || (GEMV_Q16 >= 2 && EPI != 3))) || (GEMV_Q16 >= 2 && PRO == 1));
+    // the RMS_NORM prologue of qkv / gate-up in this form: +1.2 us each -- measured, same file).
+    constexpr bool Q16 = FMT == CLLM_TYPE_Q4_K && PRO == 2 && NPRE >= 4;      // (the A/B macro is retired: its other settings lost, same profile)
     constexpr int NSL = EPI == 3 ? 2 : 1;                        // activation rows (EPI 3: the two slots of a sparse-MoE block's down projection, quantized back to back)
     constexpr int NQ = (NPRE == 8 ? 2 : 1) * NSL;                // passes of 64 blocks
     const int nbt = NSL * nblk;
@@ -144,7 +172,7 @@ __global__ void __launch_bounds__(1024) k_gemv_dec(const float * __restrict__ px
 #pragma unroll
         for (int q = 0; q < NQ; q++) {
             const int bi = (qwave + 16 * q) * 4 + qrow, sl = (NSL > 1 && bi >= nblk) ? 1 : 0, blk = bi - sl * nblk;
-            const int o = (bi < nbt ? blk : 0) * 256 + 16 * qp + (NSL > 1 ? sl * px_slot_stride : 0);
+            const int o = (bi < nbt ? blk : 0) * 256 + 16 * qp + (NSL > 1 ? sl * act_slot_stride : 0);
 #pragma unroll
             for (int i = 0; i < 4; i++) w16[q][i] = *(const f32x4 *)(px + o + 4 * i);
             if constexpr (PRO == 1) {
@@ -158,7 +186,7 @@ __global__ void __launch_bounds__(1024) k_gemv_dec(const float * __restrict__ px
         const int e = e0 + u * 4096, ec = e < K ? e : 0;
         vv[u] = *(const f32x4 *)(px + ec * vmul);
         if (PRO != 2) gg[u] = *(const f32x4 *)(gp + ec * vmul);
-        if (EPI == 3) gg[u] = *(const f32x4 *)(px + px_slot_stride + ec);
+        if (EPI == 3) gg[u] = *(const f32x4 *)(px + act_slot_stride + ec);
     }
     }
     // tensor parallel (PRO 1, NPRE 1): the all-reduced partial of the previous mat-vec is added to the residual stream here
@@ -168,14 +196,14 @@ __global__ void __launch_bounds__(1024) k_gemv_dec(const float * __restrict__ px
     if constexpr (PRO == 5) {
         // the all-reduce of the previous o / down projection, folded in: every rank's partial rows wait (or arrive) as granules in this rank's buffer.  Polled BEFORE the
         // weight prefetch goes out (the polls wait with vmcnt(0): behind the prefetch they would drain it anyway) -- a tensor-parallel step is bound by these arrivals
-        const tp_fuse_dev * cx = (const tp_fuse_dev *) ids;
+        const tp_fuse_dev * cx = tp_ctx;
         const int nr = cx->nranks, rk = cx->rank; const unsigned mxn = cx->max_n, stp = *cx->step;
         const char * own = cx->peer[rk];
 #pragma unroll
         for (int u = 0; u < NPRE; u++) {
             const int e = e0 + u * 4096;
             if (e < K) {
-                const f32x4 g = tpf_gather4(cx, own, nr, mxn, stp, px_slot_stride, e);
+                const f32x4 g = tpf_gather4(cx, own, nr, mxn, stp, tp_site_in, e);
                 vv[u].x = vv[u].x + g.x; vv[u].y = vv[u].y + g.y; vv[u].z = vv[u].z + g.z; vv[u].w = vv[u].w + g.w;
                 if (blockIdx.x == 0) *(f32x4 *)(xout + e) = vv[u];
             }
@@ -191,10 +219,10 @@ __global__ void __launch_bounds__(1024) k_gemv_dec(const float * __restrict__ px
     // EPI 4: where this rank's partial rows go (lane r: rank r's receive buffer)
     char * tp_dst = nullptr; unsigned tp_step = 0;
     if constexpr (EPI == 4) {
-        const tp_fuse_dev * cx = (const tp_fuse_dev *) ids;
+        const tp_fuse_dev * cx = tp_ctx;
         const int nr = cx->nranks;
         tp_step = *cx->step;
-        if (lane < nr) tp_dst = cx->peer[lane] + (size_t)(dst_slot_stride * nr + cx->rank) * cx->max_n * 8;
+        if (lane < nr) tp_dst = cx->peer[lane] + (size_t)(tp_site_out * nr + cx->rank) * cx->max_n * 8;
     }
     TS(0);
 
@@ -219,9 +247,9 @@ __global__ void __launch_bounds__(1024) k_gemv_dec(const float * __restrict__ px
         if (EPI == 3) { if (ok) bp = (isub ? W1 : W0) + (unsigned long long)(unsigned) unit_of(ik) * nb01 + __umul24((unsigned) b, (unsigned) BS); }
         else if (ok) bp = W + (unsigned long long)(unsigned)(unit_of(ik) * RU + isub) * nb01 + __umul24((unsigned) b, (unsigned) BS);      // (b < 2^24: the 32-bit v_mul_lo_u32 runs at a quarter rate)
         if (IS_K) {
-            hh[p] = GEMV_WLOAD((const u32x4 *) bp);
-            qq[p] = GEMV_WLOAD((const u32x4 *)(bp + 16 + 32 * j));
-            q2[(IS_Q8 || IS_K) ? p : 0] = GEMV_WLOAD((const u32x4 *)(bp + 32 + 32 * j));
+            hh[p] = *(const u32x4 *) bp;
+            qq[p] = *(const u32x4 *)(bp + 16 + 32 * j);
+            q2[(IS_Q8 || IS_K) ? p : 0] = *(const u32x4 *)(bp + 32 + 32 * j);
         } else {
             uint32_t t, odd;             // the aligned window as loaded; q32_align() at the point of use
             q32_load_raw<IS_K ? CLLM_TYPE_Q4_0 : FMT>(bp, qq[p], q2[IS_Q8 ? p : 0], t, odd);
@@ -281,13 +309,11 @@ __global__ void __launch_bounds__(1024) k_gemv_dec(const float * __restrict__ px
         vv[0].x = vv[0].x + pa.x; vv[0].y = vv[0].y + pa.y; vv[0].z = vv[0].z + pa.z; vv[0].w = vv[0].w + pa.w;
         if (blockIdx.x == 0 && e0 < K) *(f32x4 *)(xout + e0) = vv[0];
     }
-#ifndef GEMV_SCALE1
-#define GEMV_SCALE1 1       // 1 = ONE wave adds the 16 partial sums and derives the scale; the other 15 wait at a second barrier instead of redoing ~90 instructions each
-                            // (qkv 6.3 -> 6.1 us, decode +0.4 %: profiles/r05_prologue_scale_one_wave.txt; 0 = every wave redoes it)
-#endif
+    // NPRE == 1: ONE wave adds the 16 partial sums and derives the scale; the other 15 wait at a second barrier instead of redoing ~90 instructions each
+    // (qkv 6.3 -> 6.1 us, decode +0.4 %: profiles/r05_prologue_scale_one_wave.txt; the A/B macro is retired)
     if (PRO == 1) {
         __shared__ double part[16];
-        if constexpr (GEMV_SCALE1 && NPRE == 1) {
+        if constexpr (NPRE == 1) {
             __shared__ float scale_w;
             double sum = 0.0;
             if (e0 < K) { const f32x4 v = vv[0]; sum += (double)(v.x * v.x); sum += (double)(v.y * v.y); sum += (double)(v.z * v.z); sum += (double)(v.w * v.w); }
@@ -399,8 +425,8 @@ __global__ void __launch_bounds__(1024) k_gemv_dec(const float * __restrict__ px
     if constexpr (EPI == 5) {
         // ---- the block's router (GenericSparseMLP::forward src/layers.cpp:3792-3830: MUL_MAT(gate) -> SOFT_MAX -> TOP_K), redone by every workgroup: one wave per expert row
         //      over the activation row just built, the records and chains of the row loop below; then one wave runs k_soft_max's partition and k_top_k's picks ----
-        const int ne = px_slot_stride;
-        const char * Wr = (const char *) padd;
+        const int ne = n_experts;
+        const char * Wr = router_w;
         float * r_logit = (float *)(lds + arb + 16 * CHB), * r_prob = r_logit + 64;
         int32_t * r_ids = (int32_t *)(r_prob + 64);
         for (int row = wave_in_wg; row < ne; row += 16) {
@@ -430,13 +456,13 @@ __global__ void __launch_bounds__(1024) k_gemv_dec(const float * __restrict__ px
             wave_soft_max_plain(r_logit, r_prob, ne, lane);
             if (lane == 0) top_k_row(r_prob, ne, (int) gridDim.y, r_ids);
             if (blockIdx.x == 0 && blockIdx.y == 0) {                   // one workgroup publishes for the down + combine launch
-                for (int i = lane; i < ne; i += 64) xout[i] = r_prob[i];
-                if (lane == 0) for (int i = 0; i < (int) gridDim.y; i++) const_cast<int32_t *>(ids)[i] = r_ids[i];
+                for (int i = lane; i < ne; i += 64) probs_out[i] = r_prob[i];
+                if (lane == 0) for (int i = 0; i < (int) gridDim.y; i++) topk_out[i] = r_ids[i];
             }
         }
         __syncthreads();
         W += (unsigned long long)(unsigned) r_ids[blockIdx.y] * w_expert_bytes;
-        dst += (long) blockIdx.y * dst_slot_stride;
+        dst += (long) blockIdx.y * out_slot_stride;
 #pragma unroll
         for (int p = 0; p < P; p++) issue(p);
     }
@@ -497,7 +523,7 @@ __global__ void __launch_bounds__(1024) k_gemv_dec(const float * __restrict__ px
             float * r_logit = (float *)(lds + arb + 16 * CHB), * r_prob = r_logit + 64;
             wave_soft_max_plain(r_logit, r_prob, n, lane);
             for (int i = lane; i < n; i += 64) dst[i] = r_prob[i];
-            if (lane == 0) top_k_row(r_prob, n, dst_slot_stride, const_cast<int32_t *>(ids));
+            if (lane == 0) top_k_row(r_prob, n, topk_k, topk_out);
         }
     }
     if (ts) { __syncthreads(); TS(5); }

@@ -69,3 +69,25 @@ int launch_gemv_decode_tp_gather(hipStream_t st, int wtype, const void * W, int6
     LAUNCH_CHECK();
     return CLLM_OK;
 }
+
+// ---- C ABI (include/chatllm_hip.h): the two forms as operators of their own -- what the ggml module's logical tensor-parallel device issues once per rank (host/ggml-hip.cpp) ----
+extern "C" const void * cllm_tp_fused_dev(void * os);
+extern "C" int cllm_tp_fused_sites(void * os);
+extern "C" size_t cllm_tp_fused_max_n(void * os);
+// partial rows of a K-sharded o / down projection -> granules of `site` in every rank's receive buffer.  pro 2: quantize(px); pro 3: quantize(silu(gate) * up) over interleaved pairs
+extern "C" CLLM_API int cllm_op_mul_mat_vec_tp_scatter(void * stream, const cllm_tensor * src0, int pro, const float * px, void * tp_fused, int site) {
+    if (!src0 || !px || !tp_fused || (pro != 2 && pro != 3) || site < 0 || site >= cllm_tp_fused_sites(tp_fused)) FAIL(CLLM_E_INVALID, "mul_mat_vec_tp_scatter: arguments");
+    if (!is_quant_type(src0->type) || src0->ne[2] != 1 || src0->ne[3] != 1 || src0->nb[1] != cllm_row_size(src0->type, src0->ne[0])) FAIL(CLLM_E_UNSUPPORTED, "mul_mat_vec_tp_scatter: src0 must be a dense 2-D quantized matrix");
+    if ((size_t) src0->ne[1] > cllm_tp_fused_max_n(tp_fused)) FAIL(CLLM_E_INVALID, "mul_mat_vec_tp_scatter: %lld rows, the receive buffers hold %zu", (long long) src0->ne[1], cllm_tp_fused_max_n(tp_fused));
+    if (((uintptr_t) px | (uintptr_t) src0->data) & 15) FAIL(CLLM_E_UNSUPPORTED, "mul_mat_vec_tp_scatter: alignment");
+    return launch_gemv_decode_tp_scatter((hipStream_t) stream, src0->type, src0->data, src0->ne[0], src0->ne[1], pro, px, cllm_tp_fused_dev(tp_fused), site);
+}
+// dst = W . quantize(RMS_NORM(px + all-reduced partials of `site`) * pw) (+ bias | epi 1: SiLU(gate) * up over alternating rows); xout (!= px) receives the new residual stream
+extern "C" CLLM_API int cllm_op_mul_mat_vec_tp_gather(void * stream, const cllm_tensor * src0, const float * px, const float * pw, float eps, int epi, const float * bias, float * dst,
+                                                      void * tp_fused, int site, float * xout) {
+    if (!src0 || !px || !pw || !dst || !xout || !tp_fused || (epi != 0 && epi != 1) || site < 0 || site >= cllm_tp_fused_sites(tp_fused)) FAIL(CLLM_E_INVALID, "mul_mat_vec_tp_gather: arguments");
+    if (!is_quant_type(src0->type) || src0->ne[2] != 1 || src0->ne[3] != 1 || src0->nb[1] != cllm_row_size(src0->type, src0->ne[0])) FAIL(CLLM_E_UNSUPPORTED, "mul_mat_vec_tp_gather: src0 must be a dense 2-D quantized matrix");
+    if ((size_t) src0->ne[0] > cllm_tp_fused_max_n(tp_fused)) FAIL(CLLM_E_INVALID, "mul_mat_vec_tp_gather: rows of %lld values, the receive buffers hold %zu", (long long) src0->ne[0], cllm_tp_fused_max_n(tp_fused));
+    if (((uintptr_t) px | (uintptr_t) pw | (uintptr_t) src0->data | (uintptr_t) xout) & 15) FAIL(CLLM_E_UNSUPPORTED, "mul_mat_vec_tp_gather: alignment");
+    return launch_gemv_decode_tp_gather((hipStream_t) stream, src0->type, src0->data, src0->ne[0], src0->ne[1], px, pw, eps, epi, dst, bias, cllm_tp_fused_dev(tp_fused), site, xout);
+}

@@ -228,6 +228,50 @@ int cllm_tp_fused_connect(void * os, const void * handles) {
     HIP_TRY(hipMemcpy(o->dev, &hd, sizeof(hd), hipMemcpyHostToDevice));
     return CLLM_OK;
 }
+extern "C" int cllm_tp_fused_destroy(void * os);
+// All ranks inside ONE process (the ggml module's logical tensor-parallel device, chatllm.cpp_amd/host/ggml-hip.cpp: the reference's host is one process that drives every GPU,
+// src/backend.cpp:677-778): rank r's buffers live on devices[r]; peers are plain pointers (peer access is enabled between distinct GPUs), no IPC handles.  Several ranks may share
+// a GPU (virtual ranks: the one-GPU test vehicle) -- their launches must then be issued on ONE stream in site order, so that a gather never polls for a launch that cannot start.
+extern "C" __attribute__((visibility("default")))
+int cllm_tp_fused_create_group(int nranks, const int * devices, int n_sites, size_t max_n, void ** out) {
+    if (!out || !devices || nranks < 1 || nranks > TPO_MAX_RANKS || n_sites < 1 || max_n == 0 || max_n % 4) FAIL(CLLM_E_INVALID, "tp_fused_create_group: arguments");
+    int keep = 0;
+    HIP_TRY(hipGetDevice(&keep));
+    bool distinct = false;
+    for (int r = 1; r < nranks; r++) distinct = distinct || devices[r] != devices[0];
+    const size_t bytes = ((size_t) n_sites * nranks * max_n * 8 + 255) & ~(size_t) 255;
+    tp_fused * os[TPO_MAX_RANKS] = {};
+    auto undo = [&]() { for (int r = 0; r < nranks; r++) if (os[r]) { (void) hipSetDevice(devices[r]); (void) cllm_tp_fused_destroy(os[r]); } (void) hipSetDevice(keep); };
+    for (int r = 0; r < nranks; r++) {
+        if (hipSetDevice(devices[r]) != hipSuccess) { undo(); FAIL(CLLM_E_HIP, "tp_fused_create_group: device %d", devices[r]); }
+        tp_fused * o = new tp_fused();
+        os[r] = o;
+        o->rank = r; o->nranks = nranks; o->n_sites = n_sites; o->max_n = max_n;
+        // what a REMOTE GPU writes and this one polls must be fine-grained; ranks that all share one GPU meet in its L2 (plain memory)
+        hipError_t e = distinct ? hipExtMallocWithFlags((void **) &o->local, bytes, hipDeviceMallocFinegrained) : hipMalloc((void **) &o->local, bytes);
+        o->fine_grained = distinct && e == hipSuccess;
+        if (e == hipSuccess) e = hipMemset(o->local, 0, bytes);
+        if (e == hipSuccess) e = hipMalloc((void **) &o->words, 16);
+        if (e == hipSuccess) e = hipMemset(o->words, 0, 16);
+        if (e == hipSuccess) e = hipMalloc((void **) &o->dev, sizeof(tp_fuse_dev_h));
+        if (e != hipSuccess) { (void) hipGetLastError(); undo(); FAIL(CLLM_E_ALLOC, "tp_fused_create_group: rank %d on device %d: %s", r, devices[r], hipGetErrorString(e)); }
+        for (int q = 0; q < nranks; q++) if (devices[q] != devices[r]) {
+            const hipError_t pe = hipDeviceEnablePeerAccess(devices[q], 0);
+            if (pe != hipSuccess && pe != hipErrorPeerAccessAlreadyEnabled) { (void) hipGetLastError(); undo(); FAIL(CLLM_E_UNSUPPORTED, "tp_fused_create_group: no peer access from device %d to %d (%s)", devices[r], devices[q], hipGetErrorString(pe)); }
+            (void) hipGetLastError();
+        }
+    }
+    for (int r = 0; r < nranks; r++) {
+        tp_fuse_dev_h hd;
+        memset(&hd, 0, sizeof(hd));
+        for (int q = 0; q < nranks; q++) { os[r]->peer[q] = os[q]->local; hd.peer[q] = os[q]->local; }
+        hd.rank = r; hd.nranks = nranks; hd.max_n = (unsigned) max_n; hd.step = os[r]->words; hd.err = os[r]->words + 1;
+        if (hipSetDevice(devices[r]) != hipSuccess || hipMemcpy(os[r]->dev, &hd, sizeof(hd), hipMemcpyHostToDevice) != hipSuccess || hipDeviceSynchronize() != hipSuccess) { undo(); FAIL(CLLM_E_HIP, "tp_fused_create_group: context of rank %d", r); }
+    }
+    HIP_TRY(hipSetDevice(keep));
+    for (int r = 0; r < nranks; r++) out[r] = os[r];
+    return CLLM_OK;
+}
 // the device-side context (kernel argument of the EPI 4 / PRO 5 launches), the number of sites and the vector length the buffers hold
 extern "C" __attribute__((visibility("default"))) const void * cllm_tp_fused_dev(void * os) { return os ? (const void *) ((tp_fused *) os)->dev : nullptr; }
 extern "C" __attribute__((visibility("default"))) int cllm_tp_fused_sites(void * os) { return os ? ((tp_fused *) os)->n_sites : 0; }
@@ -249,6 +293,15 @@ int cllm_tp_fused_error(void * os) {
     unsigned e = 0;
     if (hipMemcpy(&e, o->words + 1, 4, hipMemcpyDeviceToHost) != hipSuccess) return 1;
     return (int) e;
+}
+// the error word was sticky with no way back.  After the host has reported the time-out (cllm_tp_fused_error) and brought every rank to a common step boundary
+// (all streams idle), this clears it; the step numbers are untouched (they only ever advance together).
+extern "C" __attribute__((visibility("default")))
+int cllm_tp_fused_clear_error(void * os) {
+    tp_fused * o = (tp_fused *) os;
+    if (!o) FAIL(CLLM_E_INVALID, "tp_fused_clear_error: null");
+    HIP_TRY(hipMemset(o->words + 1, 0, 4));
+    return CLLM_OK;
 }
 extern "C" __attribute__((visibility("default")))
 int cllm_tp_fused_destroy(void * os) {

@@ -41,6 +41,7 @@ struct hip_backend_ctx {
     struct scalar_set { const void * ptr; int32_t val; };
     struct {
         bool armed = false, inflight = false;
+        bool chained = false;          // the step running ahead was queued BEHIND the step the host is still waiting for (ahead_launch(c, true)): synchronize() waits for `ev`, not for the stream
         bool snap_ready = false;       // the outputs' snapshot is complete although the step did not start (ahead_launch failed behind its argmax write): serve the pending read from it
         void * ev = nullptr, * table_dev = nullptr, * scratch = nullptr, * snap = nullptr; size_t snap_bytes = 0; int32_t * tok_host = nullptr;
         struct set_rec { const void * ptr; int32_t val, pad; }; set_rec * tab_host = nullptr;      // page-locked: the (pointer, absolute value) records of the step started ahead
@@ -68,6 +69,19 @@ struct ws_scope {        // time inside one of our entry points goes to `slot`, 
     ~ws_scope() { if (g_stats) { const auto t1 = wall_stats::clk::now(); slot += wall_stats::us(t0, t1); g_ws.last_exit = t1; } }
 };
 
+std::atomic<uint64_t> g_tp_kv_epoch{1};          // tensor parallel (tp_graph_compute): bumped by everything that may have changed the host's KV caches behind the ranks' shards
+struct tp_piece { const void * src; size_t spitch, width, rows, doff, dpitch; };
+struct tp_shard { void * data = nullptr; size_t bytes = 0; int n = 0; const void * src[3] = {}; uint64_t uid[3] = {}, gen[3] = {}; };
+struct tp_rank {
+    int gpu = 0; void * stream = nullptr; bool own_stream = false; void * fused = nullptr, * ev = nullptr;
+    char * scratch = nullptr; size_t scratch_bytes = 0;
+    std::unordered_map<const void *, tp_shard> shards;                   // keyed by the first source tensor's data pointer (a weight tensor has one role)
+    std::vector<const void *> kv_sig; std::vector<void *> kv_mem; void * kv_table = nullptr; int64_t kv_valid = 0; uint64_t kv_epoch = 0; size_t kv_dims[3] = {};
+};
+struct tp_group {
+    int n = 0; std::vector<tp_rank> r; bool fused_ready = false, broken = false, told = false, last_tp = false; int sites = 0; size_t max_n = 0; void * ev0 = nullptr;
+    long steps = 0, plain = 0; const void * owner = nullptr;      // owner: the backend context whose stream rank 0 runs on
+} g_tp;
 std::vector<hip_device_ctx *> g_devices;
 ggml_backend_reg g_reg;
 
@@ -103,9 +117,10 @@ std::unordered_map<const void *, int32_t> g_i32_vals;
 std::vector<hip_backend_ctx::scalar_set> g_scalar_sets[64];
 hip_backend_ctx * g_ahead_ctx[64] = {};          // the backend whose captured step may be running ahead on that device
 // a write through the buffer interface that is not one of those scalars must not race a step running ahead (it may target memory that step uses)
+void ahead_finish_event(hip_backend_ctx * c);
 void ahead_quiesce(int device) {
     hip_backend_ctx * c = device >= 0 && device < 64 ? g_ahead_ctx[device] : nullptr;
-    if (c && c->ahead.inflight) { cllm_set_device(c->device); cllm_stream_sync(c->stream); }
+    if (c && c->ahead.inflight) { ahead_finish_event(c); cllm_set_device(c->device); cllm_stream_sync(c->stream); }
 }
 void i32_forget(const void * lo, size_t n) {          // caller holds g_ring.m
     if (g_i32_vals.empty()) return;
@@ -165,7 +180,7 @@ void buf_free(ggml_backend_buffer_t b) {
 void * buf_base(ggml_backend_buffer_t b) { return ((hip_buffer_ctx *) b->context)->base; }
 void buf_memset(ggml_backend_buffer_t b, ggml_tensor * t, uint8_t v, size_t off, size_t size) {
     ahead_quiesce(((hip_buffer_ctx *) b->context)->device);
-    cllm_set_device(((hip_buffer_ctx *) b->context)->device); ((hip_buffer_ctx *) b->context)->gen++;
+    cllm_set_device(((hip_buffer_ctx *) b->context)->device); ((hip_buffer_ctx *) b->context)->gen++; g_tp_kv_epoch++;
     { std::lock_guard<std::mutex> lock(g_ring.m); i32_forget((char *) t->data + off, size); }
     if (cllm_memset((char *) t->data + off, v, size, nullptr) != CLLM_OK || cllm_stream_sync(nullptr) != CLLM_OK) GGML_LOG_ERROR("[ggml-hip] memset_tensor '%s' failed: %s\n", t->name, cllm_last_error());
 }
@@ -185,7 +200,7 @@ void buf_set(ggml_backend_buffer_t b, ggml_tensor * t, const void * data, size_t
             else scalar = false;                          // not recorded: must not be held back either (written through below, after the step running ahead has finished)
         } else scalar = false;
     }
-    if (!scalar) ahead_quiesce(c->device);
+    if (!scalar) { ahead_quiesce(c->device); g_tp_kv_epoch++; }
     // While a step runs ahead the device already holds the scalars that step needs, and ggml-alloc may have handed their memory to later nodes of the
     // same graph (the token id's block becomes part of the logits): a write now would land in the middle of -- or after -- the run and clobber it.
     // The value is recorded above; graph_compute either finds it equal to the prediction (nothing to write) or writes all of them before the real run.
@@ -198,7 +213,7 @@ void buf_set(ggml_backend_buffer_t b, ggml_tensor * t, const void * data, size_t
 void * g_stage = nullptr; size_t g_stage_size = 0;
 constexpr size_t k_stage_chunk = 4u << 20;
 std::mutex g_stage_mutex;
-void ahead_launch(hip_backend_ctx * c);
+void ahead_launch(hip_backend_ctx * c, bool chained = false);
 void buf_get_impl(ggml_backend_buffer_t b, const char * src, const char * name, void * data, size_t size);
 void buf_get(ggml_backend_buffer_t b, const ggml_tensor * t, void * data, size_t off, size_t size) {
     ws_scope ws(g_ws.get_us); g_ws.gets++;
@@ -213,6 +228,7 @@ void buf_get(ggml_backend_buffer_t b, const ggml_tensor * t, void * data, size_t
     if (is_logits_read && !ahead_late) ahead_launch(ac);
     if (ac && (ac->ahead.inflight || (is_logits_read && ac->ahead.snap_ready))) {
         bool served = false;
+        if (ac->ahead.inflight) ahead_finish_event(ac);      // (a host that reads without synchronize(): the snapshot must be complete)
         for (const auto & o : ac->ahead.outs)      // the step running ahead overwrites the graph's outputs: their snapshots
             if (src >= o.ptr && src + size <= o.ptr + o.bytes) { src = (const char *) ac->ahead.snap + o.snap_off + (src - o.ptr); served = true; break; }
         if (!served && ac->ahead.inflight) ahead_quiesce(device);        // anything else: what the step running ahead leaves behind
@@ -248,7 +264,7 @@ bool buf_cpy(ggml_backend_buffer_t b, const ggml_tensor * src, ggml_tensor * dst
     flush_sets();
     ahead_quiesce(((hip_buffer_ctx *) b->context)->device);
     if (src->buffer && src->buffer->iface.get_base == buf_base) ahead_quiesce(((hip_buffer_ctx *) src->buffer->context)->device);
-    cllm_set_device(((hip_buffer_ctx *) b->context)->device); ((hip_buffer_ctx *) b->context)->gen++;
+    cllm_set_device(((hip_buffer_ctx *) b->context)->device); ((hip_buffer_ctx *) b->context)->gen++; g_tp_kv_epoch++;
     { std::lock_guard<std::mutex> lock(g_ring.m); i32_forget(dst->data, ggml_nbytes(dst)); }
     if (ggml_backend_buffer_is_host(src->buffer)) {
         if (cllm_memcpy_h2d(dst->data, src->data, ggml_nbytes(src), nullptr) != CLLM_OK || cllm_stream_sync(nullptr) != CLLM_OK) { GGML_LOG_ERROR("[ggml-hip] cpy_tensor (host -> '%s') failed: %s\n", dst->name, cllm_last_error()); return false; }
@@ -261,7 +277,7 @@ bool buf_cpy(ggml_backend_buffer_t b, const ggml_tensor * src, ggml_tensor * dst
     return false;
 }
 void buf_clear(ggml_backend_buffer_t b, uint8_t v) {
-    auto * c = (hip_buffer_ctx *) b->context; ahead_quiesce(c->device); cllm_set_device(c->device); c->gen++;
+    auto * c = (hip_buffer_ctx *) b->context; ahead_quiesce(c->device); cllm_set_device(c->device); c->gen++; g_tp_kv_epoch++;
     { std::lock_guard<std::mutex> lock(g_ring.m); i32_forget(c->base, b->size); }
     if (cllm_memset(c->base, v, b->size, nullptr) != CLLM_OK || cllm_stream_sync(nullptr) != CLLM_OK) GGML_LOG_ERROR("[ggml-hip] clear failed: %s\n", cllm_last_error());
 }
@@ -410,6 +426,9 @@ bool dev_supports_op(ggml_backend_dev_t, const ggml_tensor * op) {
 // ---------------------------------------------------------------------------------------------------------------------------
 // backend (stream): graph_compute
 // ---------------------------------------------------------------------------------------------------------------------------
+void tp_free_all();
+bool tp_check_errors();
+void ahead_finish_event(hip_backend_ctx * c);
 const char * be_name(ggml_backend_t b) { return ((hip_device_ctx *) b->device->context)->name.c_str(); }      // (the ggml device's name: several of them can sit on one GPU, CLLM_HIP_VIRTUAL_DEVICES)
 void be_free(ggml_backend_t b) {
     auto * c = (hip_backend_ctx *) b->context;
@@ -419,6 +438,7 @@ void be_free(ggml_backend_t b) {
     if (c->graph_exec) cllm_graph_destroy(c->graph_exec);
     if (c->copy_event) cllm_event_destroy(c->copy_event);
     if (c->device < 64 && g_ahead_ctx[c->device] == c) g_ahead_ctx[c->device] = nullptr;
+    if (g_tp.owner == c) { tp_free_all(); cllm_set_device(c->device); }      // (tensor parallel: the ranks' streams, shards and receive buffers hang off this backend's stream)
     if (c->ahead.ev) cllm_event_destroy(c->ahead.ev);
     if (c->ahead.tok_host) cllm_host_free(c->ahead.tok_host);
     if (c->ahead.table_dev) cllm_free(c->ahead.table_dev);
@@ -431,10 +451,14 @@ void be_free(ggml_backend_t b) {
 void be_sync(ggml_backend_t b) {
     ws_scope ws(g_ws.sync_us);
     flush_sets();
-    auto * c = (hip_backend_ctx *) b->context; cllm_set_device(c->device); cllm_stream_sync(c->stream); cllm_stream_sync(nullptr);
+    auto * c = (hip_backend_ctx *) b->context; cllm_set_device(c->device);
+    // a step queued behind the one the host waits for (ahead_launch chained): the host's step is complete -- outputs snapshotted -- when the event behind its arg-max has fired
+    if (c->ahead.inflight && c->ahead.chained) ahead_finish_event(c); else cllm_stream_sync(c->stream);
+    cllm_stream_sync(nullptr);
     // a bounded wait inside a kernel that timed out leaves void results behind: synchronize() cannot return a status (ggml-backend-impl.h:96), so it is said
     // loudly here and the next graph_compute of this backend fails
     if (cllm_check_kernel_errors() != CLLM_OK) { GGML_LOG_ERROR("[ggml-hip] %s\n", cllm_last_error()); c->kernel_error = true; }
+    if (!tp_check_errors()) { GGML_LOG_ERROR("[ggml-hip] tensor parallel: a granule wait of the fused all-reduce timed out (a rank is late, dead or out of step): the step's logits are void\n"); c->kernel_error = true; }
 }
 
 int ensure_wdata(hip_backend_ctx * c, size_t need) {
@@ -1098,9 +1122,22 @@ struct sig_writer {
 //      Guards: only after a replayed step; only if the logits are the graph's single output; positions stay inside the caches; any other access through
 //      the buffer interface waits for the step running ahead (ahead_quiesce) and the logits stay readable from a snapshot; two misses in a row switch
 //      it off for the next 64 graphs (a sampling host costs itself at most a few % that way).  CLLM_HIP_AHEAD=0 turns it off.
-void ahead_launch(hip_backend_ctx * c) {
+// chained (round 6): called from graph_compute itself, right behind the launch of the step the host asked for -- the snapshot of that step's outputs, the arg-max and the next
+// step are queued on the stream before the host has even synchronized; synchronize() then waits for `ev` (outputs snapshotted, next token known) instead of the whole stream, and
+// the GPU goes from one step into the next without waiting for the host to wake up, read and come back (~80 us per token: 682 vs 722 tok/s through the host in round 5).
+// Still at most ONE step runs ahead of what the host has asked for.
+void ahead_finish_event(hip_backend_ctx * c) {       // the chained step's event has not been waited for yet: wait, and bring the host-side mirror of the scalars in step
     auto & A = c->ahead;
-    A.armed = false; A.snap_ready = false;
+    if (!A.chained) return;
+    A.chained = false;
+    cllm_set_device(c->device);
+    cllm_event_sync(A.ev);
+    std::lock_guard<std::mutex> lock(g_ring.m);
+    for (const auto & ss : A.pred) { const int32_t v = ss.ptr == A.ids_ptr ? A.tok_host[0] : ss.val; auto it = g_i32_vals.find(ss.ptr); if (it != g_i32_vals.end()) it->second = v; }
+}
+void ahead_launch(hip_backend_ctx * c, bool chained) {
+    auto & A = c->ahead;
+    A.armed = false; A.snap_ready = false; A.chained = false;
     cllm_set_device(c->device);
     if (!A.ev && cllm_event_create(&A.ev) != CLLM_OK) return;
     if (!A.tok_host) { void * p = nullptr; if (cllm_host_malloc(&p, 64) != CLLM_OK) return; A.tok_host = (int32_t *) p; }
@@ -1137,12 +1174,426 @@ void ahead_launch(hip_backend_ctx * c) {
     if (cllm_graph_launch(c->graph_exec, st) != CLLM_OK) { fail_behind_the_snapshot(); return; }
     static const bool ahead_sync = getenv("CLLM_HIP_AHEAD_SYNC") != nullptr;       // (debugging: run the step ahead to completion before returning)
     if (ahead_sync) cllm_stream_sync(st);
-    cllm_event_sync(A.ev);                 // the snapshot and the scalars are in place before the host goes on (its own writes of the same scalars come later)
-    {   // the device now holds the predicted scalars: keep the host-side mirror in step (the host will write the same values again)
-        std::lock_guard<std::mutex> lock(g_ring.m);
-        for (const auto & ss : A.pred) { const int32_t v = ss.ptr == A.ids_ptr ? A.tok_host[0] : ss.val; auto it = g_i32_vals.find(ss.ptr); if (it != g_i32_vals.end()) it->second = v; }
+    A.inflight = true; A.launched++; A.chained = true;
+    // not chained: the snapshot and the scalars are in place before the host goes on (its own writes of the same scalars come later); the device then holds the predicted
+    // scalars: the host-side mirror is brought in step (the host will write the same values again).  Chained: synchronize() does both.
+    if (!chained) ahead_finish_event(c);
+}
+
+
+// ---- tensor parallel BEHIND the boundary (CLLM_HIP_TP=N): ONE logical ggml device over N ranks ---------------------------------------------------------------
+// The reference's own slot for this is SplitMethod::Row -- "TODO: WIP" (src/backend.h:322-327; device assignment src/backend.cpp:677-778 only splits by layer, which at
+// batch 1 buys capacity, not speed).  Here the unmodified host sees a single device "HIP0"; its buffers -- weights, KV caches, activations -- live in rank 0's HBM exactly as
+// on one GPU, and every graph that is not a recognised decode step (prompts, anything unusual) runs there un-sharded, bit-identical to the single-device module.  A graph that IS
+// the five-launch-per-layer decode step (GET_ROWS, then per layer q|k|v -> attention -> o + residual -> gate/up -> down + residual, then norm + lm_head: the same patterns
+// make_plan fuses) runs tensor-parallel:
+//   * shards are cut ON THE DEVICE from the tensors the host uploaded, the first time a step needs them (like the packed copies above; validity = the source buffers' generation
+//     counters): q / k / v and gate / up by ROWS (whole KV groups; F by the down projection's quant blocks, cllm_tp_split, uneven allowed), o / down by whole quant blocks of K;
+//   * every rank keeps the residual stream itself; o / down send their partial rows as granules into every rank's receive buffer and the next RMS_NORM mat-vec adds them in rank
+//     order (cllm_op_mul_mat_vec_tp_scatter / _gather: NO all-reduce launch, five launches per layer and rank as on one GPU); the lm_head runs on rank 0 into the host's logits;
+//   * one KV shard per rank (dense, the rank's KV heads only), refreshed from the host's cache after any un-sharded graph or buffer write, and written back row by row after
+//     every step (cllm_op_kv_shard_copy), so the host's cache stays what the reference expects.
+// Ranks on distinct GPUs run on their own streams (the gathers poll for the peers' granules); ranks that share a GPU (N > GPUs: the one-GPU test vehicle) share rank 0's stream and
+// are issued site by site, so a gather never waits for a launch that cannot start.  Everything joins rank 0's stream at the end of the step: synchronize() is unchanged.
+// Results: the fp32 sums of o / down are split into N partial chains -> tolerance tier (SURVEY 8e "T1/T2"), NOT the bit-exact tier of the single device.
+struct tp_layer { int gq = -1, attn = -1, o = -1, ggu = -1, down = -1; };
+struct tp_desc { int embed = -1, head = -1; std::vector<tp_layer> layers; };
+
+// is this graph the decode step the tensor-parallel path takes?  (node order: GET_ROWS, L x { q|k|v group, attention level 2, o + residual, gate/up group, down + residual }, head)
+bool tp_extract(ggml_cgraph * g, const fuse_plan & P, tp_desc & D) {
+    enum { S_EMBED, S_QKV, S_ATTN, S_O, S_GU, S_DOWN, S_DONE } st = S_EMBED;
+    std::vector<uint8_t> seen(P.groups.size(), 0);
+    tp_layer cur;
+    for (int i = 0; i < ggml_graph_n_nodes(g); i++) {
+        const ggml_tensor * t = ggml_graph_node(g, i);
+        if (ggml_is_empty(t) || P.skip[i]) continue;
+        if (t->op == GGML_OP_NONE || t->op == GGML_OP_RESHAPE || t->op == GGML_OP_VIEW || t->op == GGML_OP_PERMUTE || t->op == GGML_OP_TRANSPOSE) continue;
+        if (t->op == GGML_OP_GET_ROWS) { if (st != S_EMBED) return false; D.embed = i; st = S_QKV; continue; }
+        if (t->op == GGML_OP_MUL_MAT && P.mv[i] >= 0 && P.alt[i] == ALT_NONE) {
+            const fused_mv & f = P.mvs[P.mv[i]];
+            if (f.group >= 0) {
+                if (seen[f.group]) continue;                  // a later member of a group already taken
+                seen[f.group] = 1;
+                const merge_group & G = P.groups[f.group];
+                if (!G.interleave && G.n == 3 && st == S_QKV) { cur = tp_layer(); cur.gq = f.group; st = S_ATTN; continue; }
+                if (G.interleave && G.n == 2 && st == S_GU) { cur.ggu = f.group; st = S_DOWN; continue; }
+                return false;
+            }
+            if (f.pro == 2 && f.resid && st == S_O) { cur.o = P.mv[i]; st = S_GU; continue; }
+            if (f.pro == 4 && f.resid && st == S_DOWN && P.groups[cur.ggu].consumer == P.mv[i]) { cur.down = P.mv[i]; D.layers.push_back(cur); st = S_QKV; continue; }
+            if (f.pro == 1 && !f.resid && st == S_QKV && !D.layers.empty()) { D.head = P.mv[i]; st = S_DONE; continue; }
+            return false;
+        }
+        if ((t->op == GGML_OP_CPY || t->op == GGML_OP_DUP || t->op == GGML_OP_CONT) && P.attn[i] >= 0 && st == S_ATTN && P.attns[P.attn[i]].level == 2) { cur.attn = P.attn[i]; st = S_O; continue; }
+        return false;
     }
-    A.inflight = true; A.launched++;
+    return st == S_DONE;
+}
+
+struct tp_dims { int64_t H = 0, F = 0, hd = 0; int nh = 0, nkv = 0, gs = 0; int64_t ML = 0; };
+struct tp_split { int64_t kv0 = 0, kvc = 0, f0 = 0, fc = 0; };        // this rank's KV heads [kv0, kv0 + kvc) and FFN features [f0, f0 + fc)
+
+#define FAIL_TP(msg) do { HIPB_LOG("tensor parallel: %s", msg); return CLLM_E_UNSUPPORTED; } while (0)
+int tp_ensure_group(hip_backend_ctx * c, int n_sites, size_t max_n) {
+    auto & T = g_tp;
+    if (!T.r.empty() && T.owner != c) FAIL_TP("another backend context of this process owns the tensor-parallel ranks");
+    if (T.r.empty()) {
+        T.owner = c;
+        const int phys = cllm_device_count();
+        T.r.resize(T.n);
+        for (int k = 0; k < T.n; k++) {
+            tp_rank & R = T.r[k];
+            R.gpu = (c->device + k) % (phys > 0 ? phys : 1);
+            if (R.gpu == c->device) R.stream = c->stream;
+            else {
+                cllm_set_device(R.gpu);
+                if (int rc = cllm_stream_create(&R.stream)) { cllm_set_device(c->device); return rc; }
+                if (int rc = cllm_event_create(&R.ev)) { cllm_set_device(c->device); return rc; }
+                R.own_stream = true;
+            }
+        }
+        cllm_set_device(c->device);
+        if (int rc = cllm_event_create(&T.ev0)) return rc;
+    }
+    if (T.fused_ready && (T.sites < n_sites || T.max_n < max_n)) {              // another model on the same logical device: bigger buffers
+        for (tp_rank & R : T.r) { cllm_set_device(R.gpu); cllm_stream_sync(R.stream); if (R.fused) cllm_tp_fused_destroy(R.fused); R.fused = nullptr; }
+        cllm_set_device(c->device);
+        T.fused_ready = false;
+    }
+    if (!T.fused_ready) {
+        std::vector<int> devs(T.n); std::vector<void *> os(T.n, nullptr);
+        for (int k = 0; k < T.n; k++) devs[k] = T.r[k].gpu;
+        const size_t mn = (max_n + 3) & ~(size_t) 3;
+        if (int rc = cllm_tp_fused_create_group(T.n, devs.data(), n_sites, mn, os.data())) return rc;
+        for (int k = 0; k < T.n; k++) T.r[k].fused = os[k];
+        T.sites = n_sites; T.max_n = mn; T.fused_ready = true;
+    }
+    return CLLM_OK;
+}
+
+// rank k's shard made of 2-D pieces of up to three source tensors; built on rank 0's GPU (where the sources live), moved to the rank's GPU if that is another one
+void * tp_get_shard(hip_backend_ctx * c, int k, const ggml_tensor * const * srcs, int n, const tp_piece * pieces, int np, size_t bytes, bool * built) {
+    tp_rank & R = g_tp.r[k];
+    for (int i = 0; i < n; i++) if (!ours(srcs[i]) || ((const hip_buffer_ctx *) srcs[i]->buffer->context)->device != c->device) return nullptr;
+    tp_shard & e = R.shards[srcs[0]->data];
+    bool valid = e.data && e.n == n && e.bytes == bytes;
+    for (int i = 0; i < n && valid; i++) { const auto * bc = (const hip_buffer_ctx *) srcs[i]->buffer->context; valid = e.src[i] == srcs[i]->data && e.uid[i] == bc->uid && e.gen[i] == bc->gen.load(); }
+    if (valid) return e.data;
+    if (e.data) { cllm_set_device(R.gpu); cllm_stream_sync(R.stream); cllm_free(e.data); cllm_set_device(c->device); }
+    e = tp_shard(); e.n = n; e.bytes = bytes;
+    for (int i = 0; i < n; i++) { const auto * bc = (const hip_buffer_ctx *) srcs[i]->buffer->context; e.src[i] = srcs[i]->data; e.uid[i] = bc->uid; e.gen[i] = bc->gen.load(); }
+    void * local = nullptr;
+    cllm_set_device(c->device);
+    if (cllm_malloc(&local, bytes ? bytes : 1) != CLLM_OK) return nullptr;
+    for (int i = 0; i < np; i++)
+        if (cllm_copy_2d(c->stream, (char *) local + pieces[i].doff, pieces[i].dpitch, pieces[i].src, pieces[i].spitch, pieces[i].width, pieces[i].rows) != CLLM_OK) { cllm_stream_sync(c->stream); cllm_free(local); return nullptr; }
+    if (R.gpu == c->device) e.data = local;
+    else {
+        void * remote = nullptr;
+        cllm_set_device(R.gpu);
+        const int rc = cllm_malloc(&remote, bytes ? bytes : 1);
+        cllm_set_device(c->device);
+        if (rc != CLLM_OK || cllm_memcpy_peer_async(remote, R.gpu, local, c->device, bytes, c->stream) != CLLM_OK || cllm_stream_sync(c->stream) != CLLM_OK) {
+            cllm_stream_sync(c->stream); cllm_free(local);
+            if (remote) { cllm_set_device(R.gpu); cllm_free(remote); cllm_set_device(c->device); }
+            return nullptr;
+        }
+        cllm_free(local);
+        e.data = remote;
+    }
+    *built = true;
+    return e.data;
+}
+
+// after a synchronize: did a bounded granule wait of the last tensor-parallel step time out?
+bool tp_check_errors() {
+    auto & T = g_tp;
+    if (T.n <= 1 || !T.last_tp || !T.fused_ready) return true;
+    T.last_tp = false;
+    bool ok = true;
+    for (tp_rank & R : T.r) { cllm_set_device(R.gpu); if (R.fused && cllm_tp_fused_error(R.fused)) ok = false; }
+    cllm_set_device(T.r[0].gpu);
+    return ok;
+}
+void tp_free_all() {
+    auto & T = g_tp;
+    for (tp_rank & R : T.r) {
+        cllm_set_device(R.gpu);
+        if (R.stream) cllm_stream_sync(R.stream);
+        for (auto & kv : R.shards) if (kv.second.data) cllm_free(kv.second.data);
+        R.shards.clear();
+        for (void * p : R.kv_mem) if (p) cllm_free(p);
+        R.kv_mem.clear(); R.kv_sig.clear();
+        if (R.kv_table) cllm_free(R.kv_table);
+        if (R.scratch) cllm_free(R.scratch);
+        if (R.fused) cllm_tp_fused_destroy(R.fused);
+        if (R.ev) cllm_event_destroy(R.ev);
+        if (R.own_stream && R.stream) cllm_stream_destroy(R.stream);
+    }
+    if (T.ev0) cllm_event_destroy(T.ev0);
+    T.r.clear(); T.fused_ready = false; T.ev0 = nullptr; T.owner = nullptr;
+}
+
+// one decode step, tensor-parallel.  GGML_STATUS_ABORTED = "not taken, nothing launched" (the caller runs the graph un-sharded on rank 0)
+ggml_status tp_graph_compute(hip_backend_ctx * c, ggml_cgraph * g, fuse_plan & P) {
+    auto & T = g_tp;
+    tp_desc D;
+    if (T.broken || !tp_extract(g, P, D)) return GGML_STATUS_ABORTED;
+    auto node = [&](int i) { return ggml_graph_node(g, i); };
+    const int N = T.n, L = (int) D.layers.size();
+    // ---- the chain of residual streams and the shapes: everything is checked BEFORE the first launch ----
+    const ggml_tensor * emb = node(D.embed);
+    if (!f32_vec(emb)) return GGML_STATUS_ABORTED;
+    tp_dims d; d.H = emb->ne[0];
+    const float * curx = (const float *) emb->data;
+    const fused_attn & A0 = P.attns[D.layers[0].attn];
+    d.hd = A0.hd; d.nh = A0.nh; d.nkv = A0.nkv; d.ML = A0.ML;
+    if (d.nkv < N || d.nh % d.nkv) return GGML_STATUS_ABORTED;
+    d.gs = d.nh / d.nkv;
+    struct lw { const ggml_tensor * wq, * wk, * wv, * bq, * bk, * bv, * wo, * wg, * wu, * wd; const float * an, * fn; float an_eps, fn_eps; };
+    std::vector<lw> W((size_t) L);
+    for (int l = 0; l < L; l++) {
+        const tp_layer & Y = D.layers[l];
+        const merge_group & G = P.groups[Y.gq]; const fused_attn & A = P.attns[Y.attn];
+        if (G.member[0] != A.wq || G.member[1] != A.wk || G.member[2] != A.wv) return GGML_STATUS_ABORTED;
+        const fused_mv & fq = P.mvs[A.wq], & fk = P.mvs[A.wk], & fv = P.mvs[A.wv], & fo = P.mvs[Y.o], & fd = P.mvs[Y.down];
+        const merge_group & GG = P.groups[Y.ggu];
+        const fused_mv & fg = P.mvs[GG.member[0]], & fu = P.mvs[GG.member[1]];
+        lw & w = W[(size_t) l];
+        w.wq = node(fq.node)->src[0]; w.wk = node(fk.node)->src[0]; w.wv = node(fv.node)->src[0]; w.wo = node(fo.node)->src[0];
+        w.wg = node(fg.node)->src[0]; w.wu = node(fu.node)->src[0]; w.wd = node(fd.node)->src[0];
+        w.bq = G.bias ? fq.resid_t : nullptr; w.bk = G.bias ? fk.resid_t : nullptr; w.bv = G.bias ? fv.resid_t : nullptr;
+        w.an = fq.pw; w.an_eps = fq.eps; w.fn = fg.pw; w.fn_eps = fg.eps;
+        if (A.hd != d.hd || A.nh != d.nh || A.nkv != d.nkv || A.ML != d.ML || A.mode != A0.mode || A.freq_base != A0.freq_base || A.n_kv != A0.n_kv) return GGML_STATUS_ABORTED;
+        if (fq.px != curx || fo.px != A.out || fo.resid != curx) return GGML_STATUS_ABORTED;
+        curx = fo.dst;
+        if (fg.px != curx || fd.resid != curx) return GGML_STATUS_ABORTED;
+        curx = fd.dst;
+        if (w.wq->ne[0] != d.H || w.wq->ne[1] != d.nh * d.hd || w.wk->ne[1] != d.nkv * d.hd || w.wv->ne[1] != d.nkv * d.hd || w.wo->ne[0] != d.nh * d.hd || w.wo->ne[1] != d.H) return GGML_STATUS_ABORTED;
+        if (l == 0) d.F = w.wg->ne[1];
+        if (w.wg->ne[0] != d.H || w.wg->ne[1] != d.F || w.wu->ne[1] != d.F || w.wd->ne[0] != d.F || w.wd->ne[1] != d.H || w.wg->type != w.wu->type) return GGML_STATUS_ABORTED;
+        if (w.wq->type != W[0].wq->type || w.wo->type != W[0].wo->type || w.wg->type != W[0].wg->type || w.wd->type != W[0].wd->type) return GGML_STATUS_ABORTED;
+    }
+    const fused_mv & fh = P.mvs[D.head];
+    if (fh.px != curx) return GGML_STATUS_ABORTED;
+    const ggml_tensor * wh = node(fh.node)->src[0];
+    float * logits = fh.dst;
+    auto kind = [](ggml_type t) { return (int64_t)(t == GGML_TYPE_Q4_K ? 256 : 32); };
+    const ggml_type tq = W[0].wq->type, to = W[0].wo->type, tg = W[0].wg->type, td = W[0].wd->type;
+    // what the two tensor-parallel forms take (gemv_tp.hip) -- and the whole-KV-group / whole-quant-block splits
+    if (d.H % kind(tq) || d.H % kind(tg) || d.H % kind(wh->type) || d.H > 16384 || d.H % 4) return GGML_STATUS_ABORTED;
+    const int64_t fblk = ggml_blck_size(td), nfb = d.F / fblk;
+    if (d.F % fblk || nfb < N || d.F % 8) return GGML_STATUS_ABORTED;
+    std::vector<tp_split> S((size_t) N);
+    for (int k = 0; k < N; k++) {
+        tp_split & s = S[(size_t) k];
+        int64_t b0, bc;
+        cllm_tp_split(d.nkv, N, k, &s.kv0, &s.kvc); cllm_tp_split(nfb, N, k, &b0, &bc);
+        s.f0 = b0 * fblk; s.fc = bc * fblk;
+        const int64_t qc = s.kvc * d.gs * d.hd, q0 = s.kv0 * d.gs * d.hd;
+        if (s.kvc < 1 || qc % kind(to) || q0 % ggml_blck_size(to) || qc > 32768 || s.fc % kind(td) || s.fc > 32768 || (s.fc % 8) ||
+            !cllm_attn_decode_supported((int)(s.kvc * d.gs), (int) s.kvc, (int) d.hd, d.ML)) return GGML_STATUS_ABORTED;
+    }
+    if (tp_ensure_group(c, 2 * L, (size_t) d.H) != CLLM_OK) { HIPB_LOG("tensor parallel: %s -- running un-sharded on rank 0 from now on", cllm_last_error()); T.broken = true; cllm_set_device(c->device); return GGML_STATUS_ABORTED; }
+    if (!T.told) { T.told = true; HIPB_LOG("tensor parallel: %d ranks behind one ggml device (%d layers; KV heads / FFN features of rank 0: %lld / %lld of %d / %lld)", N, L, (long long) S[0].kvc, (long long) S[0].fc, d.nkv, (long long) d.F); }
+
+    // ---- shards (first step, or after the host rewrote a weight) ----
+    struct ls { void * qkv, * bias, * o, * gu, * dn; const float * an, * fn; };
+    std::vector<std::vector<ls>> SH((size_t) N, std::vector<ls>((size_t) L));
+    std::vector<const float *> out_norm((size_t) N, nullptr);
+    bool built = false;
+    auto fail_shard = [&]() { HIPB_LOG("tensor parallel: a weight shard could not be made (%s) -- running un-sharded on rank 0 from now on", cllm_last_error()); T.broken = true; cllm_set_device(c->device); return GGML_STATUS_ABORTED; };
+    auto replicate = [&](int k, const float * p, size_t bytes, const ggml_tensor * owner) -> const float * {      // a small F32 tensor every rank reads (norm weights)
+        if (T.r[(size_t) k].gpu == c->device) return p;
+        const ggml_tensor * src[1] = { owner };
+        tp_piece pc = { p, bytes, bytes, 1, 0, bytes };
+        return (const float *) tp_get_shard(c, k, src, 1, &pc, 1, bytes, &built);
+    };
+    auto norm_owner = [&](const fused_mv & f) { return node(f.node)->src[1]->src[1]; };                        // MUL_MAT(w, MUL(RMS_NORM(x), weight)): the weight tensor
+    for (int k = 0; k < N; k++) {
+        const tp_split & s = S[(size_t) k];
+        const int64_t qr0 = s.kv0 * d.gs * d.hd, qrc = s.kvc * d.gs * d.hd, kr0 = s.kv0 * d.hd, krc = s.kvc * d.hd;
+        for (int l = 0; l < L; l++) {
+            const lw & w = W[(size_t) l]; ls & o = SH[(size_t) k][(size_t) l];
+            const tp_layer & Y = D.layers[l];
+            {   // q | k | v rows of this rank's KV groups
+                const size_t rb = w.wq->nb[1];
+                const ggml_tensor * src[3] = { w.wq, w.wk, w.wv };
+                tp_piece pc[3] = { { (const char *) w.wq->data + qr0 * rb, qrc * rb, qrc * rb, 1, 0, qrc * rb }, { (const char *) w.wk->data + kr0 * rb, krc * rb, krc * rb, 1, (size_t) qrc * rb, krc * rb },
+                                   { (const char *) w.wv->data + kr0 * rb, krc * rb, krc * rb, 1, (size_t)(qrc + krc) * rb, krc * rb } };
+                if (w.wk->nb[1] != rb || w.wv->nb[1] != rb || !(o.qkv = tp_get_shard(c, k, src, 3, pc, 3, (size_t)(qrc + 2 * krc) * rb, &built))) return fail_shard();
+                o.bias = nullptr;
+                if (w.bq) {
+                    const ggml_tensor * bs[3] = { w.bq, w.bk, w.bv };
+                    tp_piece bp[3] = { { (const char *) w.bq->data + qr0 * 4, (size_t) qrc * 4, (size_t) qrc * 4, 1, 0, (size_t) qrc * 4 }, { (const char *) w.bk->data + kr0 * 4, (size_t) krc * 4, (size_t) krc * 4, 1, (size_t) qrc * 4, (size_t) krc * 4 },
+                                       { (const char *) w.bv->data + kr0 * 4, (size_t) krc * 4, (size_t) krc * 4, 1, (size_t)(qrc + krc) * 4, (size_t) krc * 4 } };
+                    if (!(o.bias = tp_get_shard(c, k, bs, 3, bp, 3, (size_t)(qrc + 2 * krc) * 4, &built))) return fail_shard();
+                }
+            }
+            {   // o: the quant blocks of K that belong to this rank's heads
+                const size_t wb = ggml_row_size(to, qrc), ob = ggml_row_size(to, qr0);
+                const ggml_tensor * src[1] = { w.wo };
+                tp_piece pc = { (const char *) w.wo->data + ob, w.wo->nb[1], wb, (size_t) d.H, 0, wb };
+                if (!(o.o = tp_get_shard(c, k, src, 1, &pc, 1, wb * (size_t) d.H, &built))) return fail_shard();
+            }
+            {   // gate / up rows [f0, f0 + fc), alternating
+                const size_t rb = w.wg->nb[1];
+                const ggml_tensor * src[2] = { w.wg, w.wu };
+                tp_piece pc[2] = { { (const char *) w.wg->data + s.f0 * rb, rb, rb, (size_t) s.fc, 0, 2 * rb }, { (const char *) w.wu->data + s.f0 * rb, rb, rb, (size_t) s.fc, rb, 2 * rb } };
+                if (w.wu->nb[1] != rb || !(o.gu = tp_get_shard(c, k, src, 2, pc, 2, 2 * (size_t) s.fc * rb, &built))) return fail_shard();
+            }
+            {   // down: the quant blocks [f0 / blk, (f0 + fc) / blk) of every row
+                const size_t wb = ggml_row_size(td, s.fc), ob = ggml_row_size(td, s.f0);
+                const ggml_tensor * src[1] = { w.wd };
+                tp_piece pc = { (const char *) w.wd->data + ob, w.wd->nb[1], wb, (size_t) d.H, 0, wb };
+                if (!(o.dn = tp_get_shard(c, k, src, 1, &pc, 1, wb * (size_t) d.H, &built))) return fail_shard();
+            }
+            o.an = replicate(k, w.an, (size_t) d.H * 4, norm_owner(P.mvs[P.attns[Y.attn].wq]));
+            o.fn = replicate(k, w.fn, (size_t) d.H * 4, norm_owner(P.mvs[P.groups[Y.ggu].member[0]]));
+            if (!o.an || !o.fn) return fail_shard();
+        }
+    }
+    out_norm[0] = fh.pw;
+    // ---- per-rank scratch: [cos/sin 1 KB][pos 256 B][x ping][x pong][q|k|v][attention out][SiLU*up][scores of the long-context attention] ----
+    auto al = [](size_t b) { return (b + 255) & ~(size_t) 255; };
+    const bool table = d.hd == 64 || d.hd == 128;
+    for (int k = 0; k < N; k++) {
+        tp_rank & R = T.r[(size_t) k]; const tp_split & s = S[(size_t) k];
+        const size_t need = 1024 + 256 + 2 * al((size_t) d.H * 4) + al((size_t)(s.kvc * (d.gs + 2) * d.hd) * 4) + al((size_t)(s.kvc * d.gs * d.hd) * 4) + al((size_t) s.fc * 4) +
+                            al(cllm_attn_decode_wsize(A0.n_kv, (int)(s.kvc * d.gs), d.ML));
+        if (need > R.scratch_bytes) {
+            cllm_set_device(R.gpu); cllm_stream_sync(R.stream);
+            if (R.scratch) cllm_free(R.scratch);
+            R.scratch = nullptr; R.scratch_bytes = 0;
+            void * p = nullptr;
+            if (cllm_malloc(&p, need + need / 4) != CLLM_OK) { cllm_set_device(c->device); return GGML_STATUS_ALLOC_FAILED; }
+            R.scratch = (char *) p; R.scratch_bytes = need + need / 4;
+        }
+    }
+    // ---- KV shards: table of { host K, host V, shard K, shard V } per layer on every rank's GPU ----
+    const uint64_t epoch = g_tp_kv_epoch.load();
+    for (int k = 0; k < N; k++) {
+        tp_rank & R = T.r[(size_t) k]; const tp_split & s = S[(size_t) k];
+        std::vector<const void *> sig; sig.reserve((size_t) 2 * L);
+        for (int l = 0; l < L; l++) { const fused_attn & A = P.attns[D.layers[l].attn]; sig.push_back(A.k_cache); sig.push_back(A.v_cache); }
+        const size_t kd = (size_t)(s.kvc * d.hd);
+        if (sig != R.kv_sig || R.kv_dims[0] != kd || R.kv_dims[1] != (size_t) d.ML || R.kv_dims[2] != (size_t) s.kv0) {
+            cllm_set_device(R.gpu); cllm_stream_sync(R.stream);
+            for (void * p : R.kv_mem) if (p) cllm_free(p);
+            R.kv_mem.assign((size_t) 2 * L, nullptr);
+            if (!R.kv_table && cllm_malloc(&R.kv_table, 4096 * 32) != CLLM_OK) { cllm_set_device(c->device); return GGML_STATUS_ALLOC_FAILED; }
+            if (L > 4096) { cllm_set_device(c->device); return GGML_STATUS_ABORTED; }
+            std::vector<void *> tab((size_t) 4 * L);
+            for (int l = 0; l < L; l++) {
+                for (int h = 0; h < 2; h++) if (cllm_malloc(&R.kv_mem[(size_t)(2 * l + h)], kd * (size_t) d.ML * 2) != CLLM_OK) { cllm_set_device(c->device); return GGML_STATUS_ALLOC_FAILED; }
+                tab[(size_t) 4 * l] = (void *) sig[(size_t) 2 * l]; tab[(size_t) 4 * l + 1] = (void *) sig[(size_t) 2 * l + 1]; tab[(size_t) 4 * l + 2] = R.kv_mem[(size_t) 2 * l]; tab[(size_t) 4 * l + 3] = R.kv_mem[(size_t) 2 * l + 1];
+            }
+            if (cllm_memcpy_h2d(R.kv_table, tab.data(), tab.size() * sizeof(void *), nullptr) != CLLM_OK || cllm_stream_sync(nullptr) != CLLM_OK) { cllm_set_device(c->device); return GGML_STATUS_FAILED; }
+            R.kv_sig = sig; R.kv_dims[0] = kd; R.kv_dims[1] = (size_t) d.ML; R.kv_dims[2] = (size_t) s.kv0; R.kv_valid = 0;
+        }
+        if (R.kv_epoch != epoch) { R.kv_valid = 0; R.kv_epoch = epoch; }
+    }
+    cllm_set_device(c->device);
+    if (built && cllm_stream_sync(c->stream) != CLLM_OK) return GGML_STATUS_FAILED;
+
+    // ---- the step ----
+    void * st0 = c->stream;
+#define TPC(expr) do { const int rc_ = (expr); if (rc_ != CLLM_OK) { HIPB_LOG("tensor-parallel step: %s failed: %s", #expr, cllm_last_error()); cllm_set_device(c->device); return rc_ == CLLM_E_ALLOC ? GGML_STATUS_ALLOC_FAILED : GGML_STATUS_FAILED; } } while (0)
+    struct rk { float * cs, * xa, * xb, * qkv, * att, * act; int32_t * pos; void * scores; size_t score_bytes; float * cur; };
+    std::vector<rk> X((size_t) N);
+    {
+        cllm_tensor da = desc(emb->src[0]), db = desc(emb->src[1]), dd = desc(emb);
+        TPC(cllm_op_get_rows(st0, &da, &db, &dd));
+    }
+    bool remote = false;
+    for (int k = 0; k < N; k++) {
+        tp_rank & R = T.r[(size_t) k]; const tp_split & s = S[(size_t) k]; rk & x = X[(size_t) k];
+        char * b = R.scratch;
+        x.cs = (float *) b; b += 1024; x.pos = (int32_t *) b; b += 256;
+        x.xa = (float *) b; b += al((size_t) d.H * 4); x.xb = (float *) b; b += al((size_t) d.H * 4);
+        x.qkv = (float *) b; b += al((size_t)(s.kvc * (d.gs + 2) * d.hd) * 4); x.att = (float *) b; b += al((size_t)(s.kvc * d.gs * d.hd) * 4);
+        x.act = (float *) b; b += al((size_t) s.fc * 4);
+        x.score_bytes = cllm_attn_decode_wsize(A0.n_kv, (int)(s.kvc * d.gs), d.ML); x.scores = x.score_bytes ? (void *) b : nullptr;
+        x.cur = x.xa;
+        // the embedding row and the position from rank 0 (queued on rank 0's stream: behind the GET_ROWS, and behind everything an earlier un-sharded graph wrote)
+        TPC(cllm_memcpy_peer_async(x.xa, R.gpu, emb->data, c->device, (size_t) d.H * 4, st0));
+        TPC(cllm_memcpy_peer_async(x.pos, R.gpu, A0.pos, c->device, 4, st0));
+        remote = remote || R.own_stream;
+    }
+    if (remote) {
+        TPC(cllm_event_record(T.ev0, st0));
+        for (int k = 0; k < N; k++) if (T.r[(size_t) k].own_stream) { cllm_set_device(T.r[(size_t) k].gpu); TPC(cllm_stream_wait_event(T.r[(size_t) k].stream, T.ev0)); }
+    }
+    for (int k = 0; k < N; k++) {
+        tp_rank & R = T.r[(size_t) k]; const tp_split & s = S[(size_t) k]; rk & x = X[(size_t) k];
+        cllm_set_device(R.gpu);
+        if (R.kv_valid < A0.n_kv - 1) {          // rows the host's cache has and the shard has not (a prompt ran un-sharded, a session was loaded ...)
+            TPC(cllm_op_kv_shard_copy(R.stream, R.kv_table, L, (int)(s.kvc * d.hd), (int)(d.nkv * d.hd), (int)(s.kv0 * d.hd), d.ML, R.kv_valid, A0.n_kv - 1, nullptr, 0));
+        }
+        R.kv_valid = A0.n_kv;
+        TPC(cllm_tp_fused_advance(R.fused, R.stream));
+        if (table) TPC(cllm_op_rope_table(R.stream, x.pos, (int) d.hd, A0.freq_base, x.cs));
+    }
+    auto wdesc = [](ggml_type t, int64_t K, int64_t rows, void * data) {
+        cllm_tensor w; w.type = (int32_t) t; w.ne[0] = K; w.ne[1] = rows; w.ne[2] = w.ne[3] = 1;
+        w.nb[0] = ggml_type_size(t); w.nb[1] = ggml_row_size(t, K); w.nb[2] = w.nb[3] = w.nb[1] * (size_t) rows; w.data = data; return w;
+    };
+    int pend = -1;                                // the site whose partial sums are not yet in the residual stream
+    for (int l = 0; l < L; l++) {
+        const fused_attn & A = P.attns[D.layers[l].attn];
+        for (int k = 0; k < N; k++) {             // q | k | v (+ the all-reduce of the previous down projection + residual + RMS_NORM)
+            tp_rank & R = T.r[(size_t) k]; const tp_split & s = S[(size_t) k]; rk & x = X[(size_t) k]; const ls & o = SH[(size_t) k][(size_t) l];
+            cllm_set_device(R.gpu);
+            cllm_tensor w = wdesc(tq, d.H, s.kvc * (d.gs + 2) * d.hd, o.qkv);
+            if (pend < 0) TPC(cllm_op_mul_mat_vec_fused(R.stream, &w, 1, x.cur, o.an, W[(size_t) l].an_eps, 0, (const float *) o.bias, x.qkv));
+            else { float * nx = x.cur == x.xa ? x.xb : x.xa; TPC(cllm_op_mul_mat_vec_tp_gather(R.stream, &w, x.cur, o.an, W[(size_t) l].an_eps, 0, (const float *) o.bias, x.qkv, R.fused, pend, nx)); x.cur = nx; }
+        }
+        for (int k = 0; k < N; k++) {             // RoPE + cache rows + attention over this rank's heads
+            tp_rank & R = T.r[(size_t) k]; const tp_split & s = S[(size_t) k]; rk & x = X[(size_t) k];
+            cllm_set_device(R.gpu);
+            TPC(cllm_op_rope_kv_attn_decode(R.stream, x.qkv, x.pos, table ? x.cs : nullptr, A.freq_base, A.n_kv, (int)(s.kvc * d.gs), (int) s.kvc, (int) d.hd, A.mode, R.kv_mem[(size_t) 2 * l], R.kv_mem[(size_t) 2 * l + 1], d.ML,
+                                            x.att, x.scores, x.score_bytes));
+        }
+        for (int k = 0; k < N; k++) {             // o: partial rows -> every rank
+            tp_rank & R = T.r[(size_t) k]; const tp_split & s = S[(size_t) k]; rk & x = X[(size_t) k]; const ls & o = SH[(size_t) k][(size_t) l];
+            cllm_set_device(R.gpu);
+            cllm_tensor w = wdesc(to, s.kvc * d.gs * d.hd, d.H, o.o);
+            TPC(cllm_op_mul_mat_vec_tp_scatter(R.stream, &w, 2, x.att, R.fused, 2 * l));
+        }
+        for (int k = 0; k < N; k++) {             // gate / up with SiLU * up (+ the all-reduce of o + residual + RMS_NORM)
+            tp_rank & R = T.r[(size_t) k]; const tp_split & s = S[(size_t) k]; rk & x = X[(size_t) k]; const ls & o = SH[(size_t) k][(size_t) l];
+            cllm_set_device(R.gpu);
+            cllm_tensor w = wdesc(tg, d.H, 2 * s.fc, o.gu);
+            float * nx = x.cur == x.xa ? x.xb : x.xa;
+            TPC(cllm_op_mul_mat_vec_tp_gather(R.stream, &w, x.cur, o.fn, W[(size_t) l].fn_eps, 1, nullptr, x.act, R.fused, 2 * l, nx));
+            x.cur = nx;
+        }
+        for (int k = 0; k < N; k++) {             // down: partial rows -> every rank
+            tp_rank & R = T.r[(size_t) k]; const tp_split & s = S[(size_t) k]; rk & x = X[(size_t) k]; const ls & o = SH[(size_t) k][(size_t) l];
+            cllm_set_device(R.gpu);
+            cllm_tensor w = wdesc(td, s.fc, d.H, o.dn);
+            TPC(cllm_op_mul_mat_vec_tp_scatter(R.stream, &w, 2, x.act, R.fused, 2 * l + 1));
+        }
+        pend = 2 * l + 1;
+    }
+    {   // the lm_head on rank 0, straight into the host's logits (its RMS_NORM prologue takes the last all-reduce)
+        rk & x = X[0];
+        cllm_set_device(c->device);
+        cllm_tensor w = desc(wh);
+        float * nx = x.cur == x.xa ? x.xb : x.xa;
+        TPC(cllm_op_mul_mat_vec_tp_gather(st0, &w, x.cur, out_norm[0], fh.eps, 0, nullptr, logits, T.r[0].fused, pend, nx));
+    }
+    for (int k = 0; k < N; k++) {                 // this step's cache row back into the host's caches; then everything joins rank 0's stream
+        tp_rank & R = T.r[(size_t) k]; const tp_split & s = S[(size_t) k]; rk & x = X[(size_t) k];
+        cllm_set_device(R.gpu);
+        TPC(cllm_op_kv_shard_copy(R.stream, R.kv_table, L, (int)(s.kvc * d.hd), (int)(d.nkv * d.hd), (int)(s.kv0 * d.hd), d.ML, 0, 0, x.pos, 1));
+        if (R.own_stream) { TPC(cllm_event_record(R.ev, R.stream)); cllm_set_device(c->device); TPC(cllm_stream_wait_event(st0, R.ev)); }
+    }
+#undef TPC
+    cllm_set_device(c->device);
+    T.steps++; T.last_tp = true;
+    if (g_stats) HIPB_LOG("HIP0 graph_compute: %d nodes -> tensor parallel over %d ranks: %d launches per rank (%d layers x 5 + head), all-reduce fused into the mat-vecs", ggml_graph_n_nodes(g), N, 5 * L + 4, L);
+    return GGML_STATUS_SUCCESS;
 }
 
 ggml_status be_graph_compute(ggml_backend_t backend, ggml_cgraph * g) {
@@ -1177,6 +1628,13 @@ ggml_status be_graph_compute(ggml_backend_t backend, ggml_cgraph * g) {
     }
     c->ahead.graphs++;
     fuse_plan plan = make_plan(g);
+    if (g_tp.n > 1) {
+        // the logical tensor-parallel device: a recognised decode step runs sharded over the ranks (tp_graph_compute); anything else runs below, un-sharded on rank 0 -- and may
+        // write the KV caches behind the shards' back
+        const ggml_status ts = tp_graph_compute(c, g, plan);
+        if (ts != GGML_STATUS_ABORTED) { c->last_sig.clear(); return ts; }
+        g_tp_kv_epoch++; g_tp.plain++; g_tp.last_tp = false;
+    }
     if (trace) {
         for (const fused_mv & f : plan.mvs) if (f.node >= 0) fprintf(stderr, "  plan: mat-vec node %d pro %d%s%s%s\n", f.node, f.pro, f.resid ? " +resid" : "", f.alias ? " STAGED (dst overlaps an input)" : "", f.group >= 0 ? " grouped" : "");
         for (const fused_attn & A : plan.attns) fprintf(stderr, "  plan: attention level %d%s\n", A.level, A.alias ? " STAGED" : "");
@@ -1445,6 +1903,7 @@ ggml_status be_graph_compute(ggml_backend_t backend, ggml_cgraph * g) {
         bool ahead_hit = false;
         if (c->ahead.inflight) {                   // a step is running ahead: is it the one the host is asking for?
             auto & A = c->ahead;
+            ahead_finish_event(c);                 // (a host that did not synchronize since: the predicted token must be known before the comparison below)
             A.inflight = false;
             bool ok = c->graph_exec && sig == c->graph_sig && cur_sets.size() == A.pred.size();
             for (size_t k = 0; ok && k < cur_sets.size(); k++)
@@ -1503,7 +1962,7 @@ ggml_status be_graph_compute(ggml_backend_t backend, ggml_cgraph * g) {
         auto & A = c->ahead;
         A.armed = false;
         const int nn = ggml_graph_n_nodes(g);
-        if (!ahead_off && replayed && c->graph_exec && A.graphs >= A.skip_until && !cur_sets.empty() && nn > 0 && !plan.attns.empty() && c->device < 64) {
+        if (!ahead_off && g_tp.n <= 1 && replayed && c->graph_exec && A.graphs >= A.skip_until && !cur_sets.empty() && nn > 0 && !plan.attns.empty() && c->device < 64) {
             const ggml_tensor * out = ggml_graph_node(g, nn - 1), * ids = nullptr;
             int n_out = 0; A.outs.clear(); bool ok = out->type == GGML_TYPE_F32 && ggml_is_contiguous(out) && out->data && ggml_nbytes(out) % 4 == 0 && ggml_nbytes(out) >= 8;
             int64_t min_ml = INT64_MAX;
@@ -1523,6 +1982,9 @@ ggml_status be_graph_compute(ggml_backend_t backend, ggml_cgraph * g) {
             if (ok && has_ids) {
                 A.ids_ptr = ids->data; A.logits_ptr = out->data; A.logits_bytes = ggml_nbytes(out); A.last_sets = cur_sets;
                 A.armed = true; g_ahead_ctx[c->device] = c;
+                // the next step goes out NOW, behind the one just launched (CLLM_HIP_AHEAD_CHAIN=0: when the host reads the logits, round 5's order)
+                static const bool chain = !getenv("CLLM_HIP_AHEAD_CHAIN") || atoi(getenv("CLLM_HIP_AHEAD_CHAIN")) != 0;
+                if (chain) ahead_launch(c, true);
             }
         }
     }
@@ -1572,7 +2034,7 @@ bool be_cpy_tensor_async(ggml_backend_t bs, ggml_backend_t bd, const ggml_tensor
     auto * xs = (hip_buffer_ctx *) src->buffer->context; auto * xd = (hip_buffer_ctx *) dst->buffer->context;
     if (xs->device != cs->device || xd->device != cd->device) return false;       // (a tensor living on a third device: the blocking path)
     flush_sets();                                  // staged host writes to either tensor are ordered before the copy
-    xd->gen++;
+    xd->gen++; g_tp_kv_epoch++;
     { std::lock_guard<std::mutex> lock(g_ring.m); i32_forget(dst->data, ggml_nbytes(dst)); }
     cllm_set_device(cs->device);
     if (cllm_memcpy_peer_async(dst->data, cd->device, src->data, cs->device, ggml_nbytes(src), cs->stream) != CLLM_OK) { GGML_LOG_ERROR("[ggml-hip] cpy_tensor_async ('%s' -> '%s') failed: %s\n", src->name, dst->name, cllm_last_error()); return false; }
@@ -1661,13 +2123,16 @@ ggml_backend_reg_t ggml_backend_init(void) {
         const int phys = cllm_device_count();
         int n = phys;
         if (const char * v = getenv("CLLM_HIP_VIRTUAL_DEVICES")) { const int k = atoi(v); if (k > 0 && phys > 0) n = k > 64 ? 64 : k; }
+        // CLLM_HIP_TP=N: ONE logical device over N tensor-parallel ranks (rank r on GPU r % physical: more ranks than GPUs = virtual ranks sharing a GPU) -- tp_graph_compute
+        if (const char * v = getenv("CLLM_HIP_TP")) { const int k = atoi(v); if (k > 1 && phys > 0) { g_tp.n = k > 16 ? 16 : k; n = 1; } }
         g_dev_objs.reserve(n);
         for (int i = 0; i < n; i++) {
             auto * d = new hip_device_ctx();
             char name[256] = "MI355X"; int cus = 0;
             const int gpu = i % phys;
             cllm_device_info(gpu, name, sizeof(name), nullptr, nullptr, &cus);
-            d->id = gpu; d->name = "HIP" + std::to_string(i); d->desc = std::string(name) + ", " + std::to_string(cus) + " CUs (chatllm.cpp_amd" + (n != phys ? ", GPU " + std::to_string(gpu) : std::string()) + ")";
+            d->id = gpu; d->name = "HIP" + std::to_string(i); d->desc = std::string(name) + ", " + std::to_string(cus) + " CUs (chatllm.cpp_amd" + (n != phys ? ", GPU " + std::to_string(gpu) : std::string()) +
+                      (g_tp.n > 1 ? ", tensor parallel over " + std::to_string(g_tp.n) + " ranks on " + std::to_string(g_tp.n < phys ? g_tp.n : phys) + " GPU(s)" : std::string()) + ")";
             g_devices.push_back(d);
             g_dev_objs.push_back(ggml_backend_device{ k_device_i, &g_reg, d });
             d->buft = ggml_backend_buffer_type{ k_buft_i, &g_dev_objs.back(), d };

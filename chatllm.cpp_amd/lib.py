@@ -152,6 +152,12 @@ SIGNATURES = {
     "cllm_tp_fused_advance": (C.c_int, [_P, _P]),
     "cllm_tp_fused_error": (C.c_int, [_P]),
     "cllm_tp_fused_destroy": (C.c_int, [_P]),
+    "cllm_tp_fused_create_group": (C.c_int, [C.c_int, C.POINTER(C.c_int), C.c_int, C.c_size_t, C.POINTER(C.c_void_p)]),
+    "cllm_tp_fused_clear_error": (C.c_int, [_P]),
+    "cllm_op_mul_mat_vec_tp_scatter": (C.c_int, [_P, _T, C.c_int, _P, _P, C.c_int]),
+    "cllm_op_mul_mat_vec_tp_gather": (C.c_int, [_P, _T, _P, _P, C.c_float, C.c_int, _P, _P, _P, C.c_int, _P]),
+    "cllm_op_kv_shard_copy": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_int64, _P, C.c_int]),
+    "cllm_copy_2d": (C.c_int, [_P, _P, C.c_size_t, _P, C.c_size_t, C.c_size_t, C.c_size_t]),
     "cllm_llama_set_tp_fused": (C.c_int, [_P, _P]),
     "cllm_llama_forward": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, _P]),
     "cllm_llama_decode_greedy": (C.c_int, [_P, C.c_int32, C.c_int, C.c_int, _P]),

@@ -396,6 +396,27 @@ CLLM_API int          cllm_tp_fused_advance(void * os, void * stream);   /* next
 CLLM_API int          cllm_tp_fused_error(void * os);         /* 1: a granule wait timed out since creation */
 CLLM_API int          cllm_tp_fused_destroy(void * os);
 CLLM_API int          cllm_llama_set_tp_fused(cllm_llama * m, void * os);
+/* The same buffers for ranks that live in ONE process (the logical tensor-parallel device of the ggml module, chatllm.cpp_amd/host/ggml-hip.cpp -- the reference's host is a
+ * single process that drives every GPU, src/backend.cpp:677-778; its own slot for this is SplitMethod::Row, "TODO: WIP", src/backend.h:322-327): out[r] = rank r's object on
+ * devices[r]; peers are plain pointers with peer access enabled between distinct GPUs.  Ranks may share a GPU (virtual ranks); their launches must then go to ONE stream in
+ * site order.  Every object is destroyed with cllm_tp_fused_destroy. */
+CLLM_API int          cllm_tp_fused_create_group(int nranks, const int * devices, int n_sites, size_t max_n, void ** out);
+CLLM_API int          cllm_tp_fused_clear_error(void * os);   /* after a reported time-out: clears the sticky error word (the ranks must restart from a common step boundary) */
+/* The two tensor-parallel forms of the single-column mat-vec as operators (gemv_tp.hip; what a sharded Linear::forward src/layers.cpp:2111-2129 + the residual ADD become):
+ *   scatter: src0 = this rank's K-shard of an o / down projection [K_r, N]; its partial rows go out as granules of `site` into every rank's buffer (no dst).
+ *            pro 2: act = quantize(px); pro 3: act = quantize(silu(px[2i]) * px[2i+1])
+ *   gather:  x' = px + sum over ranks (rank order) of the granules of `site`; dst = src0 . quantize(RMS_NORM(x', eps) * pw) (+ bias | epi 1: SiLU(gate)*up over alternating
+ *            rows); xout (!= px) = x' (the new residual stream, every rank computes the same bits). */
+CLLM_API int          cllm_op_mul_mat_vec_tp_scatter(void * stream, const cllm_tensor * src0, int pro, const float * px, void * tp_fused, int site);
+CLLM_API int          cllm_op_mul_mat_vec_tp_gather(void * stream, const cllm_tensor * src0, const float * px, const float * pw, float eps, int epi, const float * bias, float * dst,
+                                                    void * tp_fused, int site, float * xout);
+/* KV-cache shards of the logical tensor-parallel device (tp_kv.hip; the host's cache: KVCacheAttention src/layers.cpp:3044-3123): rows [p0, p1) -- or, pos_dev != NULL, the one
+ * row at *pos_dev -- of columns [kd_offset, kd_offset + kd_shard) between the host's caches (K [n][kd_full], V [kd_full][max_len], F16) and a rank's dense shards
+ * (K [n][kd_shard], V [kd_shard][max_len]).  table_dev: n_layers x 4 device pointers { host K, host V, shard K, shard V }. */
+CLLM_API int          cllm_op_kv_shard_copy(void * stream, const void * table_dev, int n_layers, int kd_shard, int kd_full, int kd_offset, int64_t max_len, int64_t p0, int64_t p1,
+                                            const int32_t * pos_dev, int to_authoritative);
+/* pitched device-to-device copy: the K-split of a quantized matrix (whole quant blocks of every row) for the shards above */
+CLLM_API int          cllm_copy_2d(void * stream, void * dst, size_t dst_pitch, const void * src, size_t src_pitch, size_t width_bytes, size_t rows);
 /* run qlen tokens (host int32) at positions n_past..; writes logits[vocab] of the last token to
  * logits_dev (device, may be NULL) and/or logits_host (may be NULL; implies a stream sync).               */
 CLLM_API int  cllm_llama_forward(cllm_llama * m, const int32_t * tokens, int qlen, int n_past, float * logits_dev,

@@ -19,6 +19,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <fstream>
+#include <sstream>
 #include <string>
 #include <vector>
 
@@ -34,6 +35,9 @@ int main(int argc, char ** argv) {
     for (int i = 6; i < argc; i++) ids.push_back(atoi(argv[i]));
     std::vector<int> teacher;
     if (const char * t = getenv("TEACHER")) { std::ifstream f(t); int v; while (f >> v) teacher.push_back(v); }
+    /* REF_CHAT_CHUNK_AT=k REF_CHAT_CHUNK="id id ...": decode step k feeds its token followed by these ids as ONE chunk (a second turn's prompt over the live cache) */
+    int chunk_at = -1; std::vector<int> chunk;
+    if (getenv("REF_CHAT_CHUNK_AT") && getenv("REF_CHAT_CHUNK")) { chunk_at = atoi(getenv("REF_CHAT_CHUNK_AT")); std::istringstream f(getenv("REF_CHAT_CHUNK")); int v; while (f >> v) chunk.push_back(v); }
 
     std::string exe_dir = argv[0];
     const size_t slash = exe_dir.find_last_of('/');
@@ -75,6 +79,7 @@ int main(int argc, char ** argv) {
             const int tok = (int)(std::max_element(logits.begin(), logits.end()) - logits.begin());
             printf("%d%s", tok, s == n_decode ? "\n" : " ");
             in.assign(1, s < (int) teacher.size() ? teacher[s] : tok);
+            if (s + 1 == chunk_at) in.insert(in.end(), chunk.begin(), chunk.end());      // a second prompt in the middle of the decode: the next graph is a multi-token one
         }
         if (fo) fclose(fo);
         if (n_decode > skip) {

@@ -589,3 +589,35 @@ def test_reference_host_partial_offload_and_layer_split_are_bit_identical(gpu, t
             assert f"HIP{nvirt - 1}" in err, (spec, err[-600:])                # ... with its last device in use
         assert ids_s == ids_c, (spec, ids_s, ids_c)
         assert np.array_equal(lg_s.view(np.uint32), lg_c.view(np.uint32)), (spec, int(np.sum(lg_s.view(np.uint32) != lg_c.view(np.uint32))))
+
+
+@_REF_BUILT
+@pytest.mark.parametrize("arch,wt,over", [("llama3", 12, dict(hidden=2048, n_head=16, n_kv_head=8, head_dim=128, ffn=2816, vocab=2048, n_layer=3)),
+                                          ("qwen2", 12, dict(hidden=2048, n_head=16, n_kv_head=8, head_dim=128, ffn=1824, vocab=2048, n_layer=2, qkv_bias=1, rope_mode=2, rope_theta=1e6)),
+                                          ("llama3", 2, dict(hidden=512, n_head=8, n_kv_head=8, head_dim=64, ffn=1056, vocab=1024, n_layer=2))])
+def test_tensor_parallel_behind_the_ggml_boundary(gpu, tmp_path, arch, wt, over):
+    """CLLM_HIP_TP=N: the UNMODIFIED host sees ONE ggml device; the module shards every decode step over N ranks behind it (host/ggml-hip.cpp tp_graph_compute -- the reference's
+    own slot is SplitMethod::Row, "TODO: WIP", src/backend.h:322-327).  N = 2, 4, 8 virtual ranks on the one GPU of the box: weight shards cut on the device from the tensors the
+    host uploaded (q|k|v / gate|up by rows, o / down by whole quant blocks: ffn 2816 = 11 Q4_K blocks -> 8 ranks get 2,2,2,1,1,1,1,1; Qwen2's Q8_0 down_proj: 57 blocks of 32;
+    Q4_0: 33 blocks), one KV shard per rank refreshed from the host's cache after the un-sharded prompt and written back every step, the all-reduce fused into the mat-vecs.
+    Tolerance tier (the fp32 sums of o / down become N partial chains): teacher-forced logits within 0.25 sigma of the single-device run, argmax equal wherever the margin is
+    clear; then a second prompt (un-sharded, attends over the cache rows the sharded steps wrote back) and more sharded steps in the same process."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import make_ggmm
+    cfg = gpu.synth.config("small", max_len=128, **over)
+    mp = str(tmp_path / "m.bin")
+    make_ggmm.write_model(mp, cfg, wt, seed=31, fast=True, arch=arch)
+    prompt = [(17 * i + 3) % cfg["vocab"] for i in range(9)]
+    n_dec = 14
+    turn2 = dict(REF_CHAT_CHUNK_AT="8", REF_CHAT_CHUNK=" ".join(str((29 * i + 11) % cfg["vocab"]) for i in range(5)))      # step 8: its token + 5 more ids as one graph
+    ids_1, lg_1, err_1 = _host_run(tmp_path, mp, "all", n_dec, prompt, cfg["vocab"], threads=4, **turn2)
+    assert "tensor parallel" not in err_1
+    for n in (2, 4, 8):
+        ids_n, lg_n, err = _host_run(tmp_path, mp, "all", n_dec, prompt, cfg["vocab"], teacher=ids_1, threads=4, CLLM_HIP_TP=str(n), **turn2)
+        assert f"tensor parallel: {n} ranks behind one ggml device" in err, err[-1500:]
+        steps = [ln for ln in err.splitlines() if "-> tensor parallel over" in ln]
+        assert len(steps) == n_dec - 1, (len(steps), err[-1500:])                 # every single-token step ran sharded; the prompt and the second turn's chunk did not
+        assert "timed out" not in err
+        assert np.array_equal(lg_1[0].view(np.uint32), lg_n[0].view(np.uint32))   # the prompt ran un-sharded on rank 0: the single device's bits
+        dev, clear = _tolerance_tier(lg_1, lg_n, ids_1, 0.25)
+        print(f"{arch} wtype {wt}: {n} ranks behind one device: max|dlogit| {dev:.3e} sigma, steps with a clear margin {clear:.2f}")
