@@ -656,6 +656,68 @@ extern "C" int cllm_op_argmax_set(void * stream, const float * logits, int64_t n
     LAUNCH_CHECK();
     return CLLM_OK;
 }
+// Snapshot + greedy sampler + scalar updates of a step started ahead of the host (host/ggml-hip.cpp ahead_launch) as ONE launch: through the unmodified host these were five
+// (three device-to-device copies of the graph's outputs, k_argmax_partial, k_argmax_publish_set: 24 us of kernels + their boundaries in front of every token,
+// profiles/r06_token_timeline_through_the_host.txt).  256 workgroups copy the ranges of `ranges_dev` (16-byte words where both sides are aligned, else 4-byte) and reduce their
+// slice of the logits (k_argmax_partial's slices and tie rule: first maximum); the LAST workgroup to arrive (ticket) reduces the 256 partials in slice order, publishes the token
+// and stores the (pointer, value) records -- every read of the logits has finished by then (the token id's block may be part of them: ggml-alloc).
+struct snap_range { const char * src; char * dst; unsigned long long bytes; };
+__global__ void __launch_bounds__(256) k_snapshot_argmax_set(const snap_range * __restrict__ rng, int n_rng, const float * __restrict__ x, int n, float * pv, int * pi, unsigned * ticket,
+                                                             int32_t * __restrict__ tok_dev, int32_t * __restrict__ tok_host, const argmax_set_rec * __restrict__ recs, int n_set) {
+    __shared__ float bv[4]; __shared__ int bi[4]; __shared__ int last_s;
+    const int tid = threadIdx.x, gsz = gridDim.x * 256, gid = blockIdx.x * 256 + tid;
+    for (int r = 0; r < n_rng; r++) {
+        const snap_range R = rng[r];
+        if ((((uintptr_t) R.src | (uintptr_t) R.dst | R.bytes) & 15) == 0) { for (unsigned long long i = gid; i < R.bytes / 16; i += gsz) ((u32x4 *) R.dst)[i] = ((const u32x4 *) R.src)[i]; }
+        else                                                               { for (unsigned long long i = gid; i < R.bytes / 4; i += gsz) ((uint32_t *) R.dst)[i] = ((const uint32_t *) R.src)[i]; }
+    }
+    const int per = (n + gridDim.x - 1) / gridDim.x;
+    const int lo = blockIdx.x * per, hi = min(n, lo + per);
+    float best = -INFINITY; int idx = 0x7fffffff;
+    for (int i = lo + tid; i < hi; i += 256) { const float v = x[i]; if (v > best) { best = v; idx = i; } }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) argmax_combine(best, idx, __shfl_xor(best, o, 64), __shfl_xor(idx, o, 64));
+    if ((tid & 63) == 0) { bv[tid >> 6] = best; bi[tid >> 6] = idx; }
+    __syncthreads();                                               // (also: every thread's copies and logit reads are issued and their values consumed)
+    if (tid == 0) {
+        for (int w = 1; w < 4; w++) argmax_combine(best, idx, bv[w], bi[w]);
+        __hip_atomic_store(pv + blockIdx.x, best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(pi + blockIdx.x, idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __threadfence();                                           // this workgroup's stores (snapshot, partial) before its ticket
+        const unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        last_s = t == gridDim.x - 1;
+    }
+    __syncthreads();
+    if (!last_s) return;
+    __threadfence();
+    best = -INFINITY; idx = 0x7fffffff;
+    for (int i = tid; i < (int) gridDim.x; i += 256)
+        argmax_combine(best, idx, __hip_atomic_load(pv + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), __hip_atomic_load(pi + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) argmax_combine(best, idx, __shfl_xor(best, o, 64), __shfl_xor(idx, o, 64));
+    __syncthreads();
+    if ((tid & 63) == 0) { bv[tid >> 6] = best; bi[tid >> 6] = idx; }
+    __syncthreads();
+    if (tid == 0) {
+        for (int w = 1; w < 4; w++) argmax_combine(best, idx, bv[w], bi[w]);
+        if (idx == 0x7fffffff) idx = 0;
+        tok_dev[0] = idx;
+        if (tok_host) { tok_host[0] = idx; __threadfence_system(); }
+        __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // the next launch starts from zero
+    }
+    for (int i = tid; i < n_set; i += 256) recs[i].ptr[0] = recs[i].val;
+}
+// ranges_dev: n_ranges x { src, dst, bytes } (device table; bytes % 4 == 0); scratch: 4096 bytes of device memory, ZEROED by the caller before the first use (partials + ticket)
+extern "C" __attribute__((visibility("default")))
+int cllm_op_snapshot_argmax_set(void * stream, const void * ranges_dev, int n_ranges, const float * logits, int64_t n, int32_t * tok_dev, int32_t * tok_host,
+                                const void * set_table_dev, int n_set, void * scratch) {
+    if (!logits || n <= 0 || n > INT32_MAX || !tok_dev || !scratch || n_set < 0 || (n_set && !set_table_dev) || n_ranges < 0 || (n_ranges && !ranges_dev)) FAIL(CLLM_E_INVALID, "snapshot_argmax_set: arguments");
+    float * pv = (float *) scratch; int * pi = (int *)((char *) scratch + 1024); unsigned * ticket = (unsigned *)((char *) scratch + 2048);
+    hipLaunchKernelGGL(k_snapshot_argmax_set, dim3(256), dim3(256), 0, (hipStream_t) stream, (const snap_range *) ranges_dev, n_ranges, logits, (int) n, pv, pi, ticket, tok_dev, tok_host,
+                       (const argmax_set_rec *) set_table_dev, n_set);
+    LAUNCH_CHECK();
+    return CLLM_OK;
+}
 extern "C" int cllm_op_argmax_advance(void * stream, const float * logits, int64_t n, int32_t * tok_dev, int32_t * tok_host, int32_t * const * inc_ptrs_dev, int n_inc,
                                       void * scratch) {
     if (!logits || n <= 0 || n > INT32_MAX || !tok_dev || !scratch || n_inc < 0 || (n_inc && !inc_ptrs_dev)) FAIL(CLLM_E_INVALID, "argmax_advance: arguments");

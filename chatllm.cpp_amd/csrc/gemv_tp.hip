@@ -70,6 +70,17 @@ int launch_gemv_decode_tp_gather(hipStream_t st, int wtype, const void * W, int6
     return CLLM_OK;
 }
 
+// the all-reduce of `site` alone: xout = px + sum over ranks (rank order) of the granules -- the gather prologue's arithmetic without a mat-vec behind it (the last residual
+// stream of a step whose head is not a fusable mat-vec: chatllm's LMFinalSteps keeps the normalised hidden state as a graph OUTPUT, src/models.cpp:1754-1755)
+__global__ void __launch_bounds__(256) k_tpf_residual(const float * __restrict__ px, const tp_fuse_dev * __restrict__ cx, int site, int n, float * __restrict__ xout) {
+    const int e = (blockIdx.x * 256 + threadIdx.x) * 4;
+    if (e >= n) return;
+    const f32x4 g = tpf_gather4(cx, cx->peer[cx->rank], cx->nranks, cx->max_n, *cx->step, site, e);
+    f32x4 v = *(const f32x4 *)(px + e);
+    v.x = v.x + g.x; v.y = v.y + g.y; v.z = v.z + g.z; v.w = v.w + g.w;
+    *(f32x4 *)(xout + e) = v;
+}
+
 // ---- C ABI (include/chatllm_hip.h): the two forms as operators of their own -- what the ggml module's logical tensor-parallel device issues once per rank (host/ggml-hip.cpp) ----
 extern "C" const void * cllm_tp_fused_dev(void * os);
 extern "C" int cllm_tp_fused_sites(void * os);
@@ -90,4 +101,12 @@ extern "C" CLLM_API int cllm_op_mul_mat_vec_tp_gather(void * stream, const cllm_
     if ((size_t) src0->ne[0] > cllm_tp_fused_max_n(tp_fused)) FAIL(CLLM_E_INVALID, "mul_mat_vec_tp_gather: rows of %lld values, the receive buffers hold %zu", (long long) src0->ne[0], cllm_tp_fused_max_n(tp_fused));
     if (((uintptr_t) px | (uintptr_t) pw | (uintptr_t) src0->data | (uintptr_t) xout) & 15) FAIL(CLLM_E_UNSUPPORTED, "mul_mat_vec_tp_gather: alignment");
     return launch_gemv_decode_tp_gather((hipStream_t) stream, src0->type, src0->data, src0->ne[0], src0->ne[1], px, pw, eps, epi, dst, bias, cllm_tp_fused_dev(tp_fused), site, xout);
+}
+// xout[0..n) = px + the all-reduced partials of `site` (n % 4 == 0; xout may be px): the residual stream after the last down projection of a step
+extern "C" CLLM_API int cllm_op_tp_gather_residual(void * stream, const float * px, int64_t n, void * tp_fused, int site, float * xout) {
+    if (!px || !xout || !tp_fused || n <= 0 || n % 4 || site < 0 || site >= cllm_tp_fused_sites(tp_fused) || (size_t) n > cllm_tp_fused_max_n(tp_fused)) FAIL(CLLM_E_INVALID, "tp_gather_residual: arguments");
+    if (((uintptr_t) px | (uintptr_t) xout) & 15) FAIL(CLLM_E_UNSUPPORTED, "tp_gather_residual: alignment");
+    hipLaunchKernelGGL(k_tpf_residual, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, (hipStream_t) stream, px, (const tp_fuse_dev *) cllm_tp_fused_dev(tp_fused), site, (int) n, xout);
+    LAUNCH_CHECK();
+    return CLLM_OK;
 }

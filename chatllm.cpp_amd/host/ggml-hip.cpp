@@ -44,6 +44,7 @@ struct hip_backend_ctx {
         bool chained = false;          // the step running ahead was queued BEHIND the step the host is still waiting for (ahead_launch(c, true)): synchronize() waits for `ev`, not for the stream
         bool snap_ready = false;       // the outputs' snapshot is complete although the step did not start (ahead_launch failed behind its argmax write): serve the pending read from it
         void * ev = nullptr, * table_dev = nullptr, * scratch = nullptr, * snap = nullptr; size_t snap_bytes = 0; int32_t * tok_host = nullptr;
+        struct snap_rng { const void * src; void * dst; uint64_t bytes; }; void * rng_dev = nullptr; snap_rng * rng_host = nullptr; std::vector<snap_rng> rng_cur;      // the snapshot's ranges as the device holds them
         struct set_rec { const void * ptr; int32_t val, pad; }; set_rec * tab_host = nullptr;      // page-locked: the (pointer, absolute value) records of the step started ahead
         const void * ids_ptr = nullptr, * logits_ptr = nullptr; size_t logits_bytes = 0;
         struct out_range { const char * ptr; size_t bytes, snap_off; }; std::vector<out_range> outs;      // every OUTPUT tensor of the graph (snapshots)
@@ -444,6 +445,8 @@ void be_free(ggml_backend_t b) {
     if (c->ahead.table_dev) cllm_free(c->ahead.table_dev);
     if (c->ahead.tab_host) cllm_host_free(c->ahead.tab_host);
     if (c->ahead.scratch) cllm_free(c->ahead.scratch);
+    if (c->ahead.rng_dev) cllm_free(c->ahead.rng_dev);
+    if (c->ahead.rng_host) cllm_host_free(c->ahead.rng_host);
     if (c->ahead.snap) cllm_free(c->ahead.snap);
     cllm_stream_destroy(c->stream);
     delete c; delete b;
@@ -1143,11 +1146,13 @@ void ahead_launch(hip_backend_ctx * c, bool chained) {
     if (!A.tok_host) { void * p = nullptr; if (cllm_host_malloc(&p, 64) != CLLM_OK) return; A.tok_host = (int32_t *) p; }
     if (!A.table_dev && cllm_malloc(&A.table_dev, 1024 * 16) != CLLM_OK) return;
     if (!A.tab_host) { void * p = nullptr; if (cllm_host_malloc(&p, 1024 * 16) != CLLM_OK) return; A.tab_host = (decltype(A.tab_host)) p; }
-    if (!A.scratch && cllm_malloc(&A.scratch, 2048) != CLLM_OK) return;
+    if (!A.scratch) { if (cllm_malloc(&A.scratch, 4096) != CLLM_OK) return; if (cllm_memset(A.scratch, 0, 4096, nullptr) != CLLM_OK || cllm_stream_sync(nullptr) != CLLM_OK) return; }
+    if (!A.rng_dev && cllm_malloc(&A.rng_dev, 16 * 24) != CLLM_OK) return;
+    if (!A.rng_host) { void * p = nullptr; if (cllm_host_malloc(&p, 16 * 24) != CLLM_OK) return; A.rng_host = (decltype(A.rng_host)) p; }
     size_t snap_need = 0;
     for (auto & o : A.outs) { o.snap_off = snap_need; snap_need += (o.bytes + 255) & ~(size_t) 255; }
     if (A.snap_bytes < snap_need) {
-        if (A.snap) { cllm_stream_sync(c->stream); cllm_free(A.snap); A.snap = nullptr; A.snap_bytes = 0; }
+        if (A.snap) { cllm_stream_sync(c->stream); cllm_free(A.snap); A.snap = nullptr; A.snap_bytes = 0; A.rng_cur.clear(); }
         if (cllm_malloc(&A.snap, snap_need) != CLLM_OK) return;
         A.snap_bytes = snap_need;
     }
@@ -1165,10 +1170,26 @@ void ahead_launch(hip_backend_ctx * c, bool chained) {
     }
     void * st = c->stream;
     if (n_rec && cllm_memcpy_h2d(A.table_dev, A.tab_host, (size_t) n_rec * 16, st) != CLLM_OK) return;      // queued on the step's stream from page-locked memory; done before the event below
-    for (const auto & o : A.outs) if (cllm_memcpy_d2d((char *) A.snap + o.snap_off, o.ptr, o.bytes, st) != CLLM_OK) { cllm_stream_sync(st); return; }
+    // the snapshot of the outputs, the arg-max and the scalar updates: ONE launch (cllm_op_snapshot_argmax_set; CLLM_HIP_AHEAD_ONE=0: round 5's copies + two launches)
+    static const bool one_launch = !getenv("CLLM_HIP_AHEAD_ONE") || atoi(getenv("CLLM_HIP_AHEAD_ONE")) != 0;
+    bool fused_prep = one_launch && A.outs.size() <= 16;
+    for (const auto & o : A.outs) fused_prep = fused_prep && o.bytes % 4 == 0;
+    if (fused_prep) {
+        bool same = A.rng_cur.size() == A.outs.size();
+        for (size_t k = 0; same && k < A.outs.size(); k++) same = A.rng_cur[k].src == (const void *) A.outs[k].ptr && A.rng_cur[k].dst == (void *)((char *) A.snap + A.outs[k].snap_off) && A.rng_cur[k].bytes == A.outs[k].bytes;
+        if (!same) {                               // (the ranges move only when ggml-alloc moves the outputs: the table is uploaded once per captured graph)
+            cllm_stream_sync(st);                  // a queued launch may still read the table
+            A.rng_cur.clear();
+            for (size_t k = 0; k < A.outs.size(); k++) { A.rng_cur.push_back({ (const void *) A.outs[k].ptr, (void *)((char *) A.snap + A.outs[k].snap_off), (uint64_t) A.outs[k].bytes }); A.rng_host[k] = A.rng_cur.back(); }
+            if (cllm_memcpy_h2d(A.rng_dev, A.rng_host, A.outs.size() * 24, st) != CLLM_OK) { A.rng_cur.clear(); return; }
+        }
+    } else for (const auto & o : A.outs) if (cllm_memcpy_d2d((char *) A.snap + o.snap_off, o.ptr, o.bytes, st) != CLLM_OK) { cllm_stream_sync(st); return; }
     // From here on the arg-max below may already have written the token id -- into a block ggml-alloc may have made part of the logits.  If anything fails now the
     // step does not run ahead, but the host's pending read must still see the logits as they were: the snapshot (complete once the stream is idle) serves it.
     auto fail_behind_the_snapshot = [&]() { if (cllm_stream_sync(st) == CLLM_OK) A.snap_ready = true; };
+    if (fused_prep) {
+        if (cllm_op_snapshot_argmax_set(st, A.rng_dev, (int) A.outs.size(), (const float *) A.logits_ptr, (int64_t)(A.logits_bytes / 4), (int32_t *) A.ids_ptr, A.tok_host, A.table_dev, n_rec, A.scratch) != CLLM_OK) { cllm_stream_sync(st); return; }
+    } else
     if (cllm_op_argmax_set(st, (const float *) A.logits_ptr, (int64_t)(A.logits_bytes / 4), (int32_t *) A.ids_ptr, A.tok_host, A.table_dev, n_rec, A.scratch) != CLLM_OK) { fail_behind_the_snapshot(); return; }
     if (cllm_event_record(A.ev, st) != CLLM_OK) { fail_behind_the_snapshot(); return; }
     if (cllm_graph_launch(c->graph_exec, st) != CLLM_OK) { fail_behind_the_snapshot(); return; }
@@ -1197,11 +1218,11 @@ void ahead_launch(hip_backend_ctx * c, bool chained) {
 // are issued site by site, so a gather never waits for a launch that cannot start.  Everything joins rank 0's stream at the end of the step: synchronize() is unchanged.
 // Results: the fp32 sums of o / down are split into N partial chains -> tolerance tier (SURVEY 8e "T1/T2"), NOT the bit-exact tier of the single device.
 struct tp_layer { int gq = -1, attn = -1, o = -1, ggu = -1, down = -1; };
-struct tp_desc { int embed = -1, head = -1; std::vector<tp_layer> layers; };
+struct tp_desc { int embed = -1, head = -1, head_norm = -1, head_mm = -1; std::vector<tp_layer> layers; };      // head: a fused norm + mat-vec (mvs entry), or the two nodes
 
 // is this graph the decode step the tensor-parallel path takes?  (node order: GET_ROWS, L x { q|k|v group, attention level 2, o + residual, gate/up group, down + residual }, head)
 bool tp_extract(ggml_cgraph * g, const fuse_plan & P, tp_desc & D) {
-    enum { S_EMBED, S_QKV, S_ATTN, S_O, S_GU, S_DOWN, S_DONE } st = S_EMBED;
+    enum { S_EMBED, S_QKV, S_ATTN, S_O, S_GU, S_DOWN, S_HEAD_MM, S_DONE } st = S_EMBED;
     std::vector<uint8_t> seen(P.groups.size(), 0);
     tp_layer cur;
     for (int i = 0; i < ggml_graph_n_nodes(g); i++) {
@@ -1209,6 +1230,13 @@ bool tp_extract(ggml_cgraph * g, const fuse_plan & P, tp_desc & D) {
         if (ggml_is_empty(t) || P.skip[i]) continue;
         if (t->op == GGML_OP_NONE || t->op == GGML_OP_RESHAPE || t->op == GGML_OP_VIEW || t->op == GGML_OP_PERMUTE || t->op == GGML_OP_TRANSPOSE) continue;
         if (t->op == GGML_OP_GET_ROWS) { if (st != S_EMBED) return false; D.embed = i; st = S_QKV; continue; }
+        // the head as chatllm builds it (LMFinalSteps, src/models.cpp:1736-1784): the normalised hidden state is a graph OUTPUT, so the norm stays a launch of its own
+        if (t->op == GGML_OP_MUL && P.alt[i] == ALT_RMS_NORM_MUL && st == S_QKV && !D.layers.empty()) { D.head_norm = i; st = S_HEAD_MM; continue; }
+        if (t->op == GGML_OP_MUL_MAT && st == S_HEAD_MM && P.mv[i] < 0 && P.pf[i] < 0 && P.alt[i] == ALT_NONE) {
+            const ggml_tensor * hn = ggml_graph_node(g, D.head_norm);
+            if (!t->src[1] || t->src[1]->data != hn->data || ggml_nelements(t->src[1]) != hn->ne[0] || !f32_vec(t) || !is_q(t->src[0]->type)) return false;
+            D.head_mm = i; st = S_DONE; continue;
+        }
         if (t->op == GGML_OP_MUL_MAT && P.mv[i] >= 0 && P.alt[i] == ALT_NONE) {
             const fused_mv & f = P.mvs[P.mv[i]];
             if (f.group >= 0) {
@@ -1338,24 +1366,31 @@ void tp_free_all() {
 ggml_status tp_graph_compute(hip_backend_ctx * c, ggml_cgraph * g, fuse_plan & P) {
     auto & T = g_tp;
     tp_desc D;
-    if (T.broken || !tp_extract(g, P, D)) return GGML_STATUS_ABORTED;
+    static const bool tp_dbg = getenv("CLLM_HIP_TP_DEBUG") != nullptr;
+#define TP_NO() (tp_dbg ? (fprintf(stderr, "[ggml-hip] tensor parallel: decode step not taken (ggml-hip.cpp:%d): un-sharded on rank 0\n", __LINE__), GGML_STATUS_ABORTED) : GGML_STATUS_ABORTED)
+    if (T.broken) return GGML_STATUS_ABORTED;
+    if (!tp_extract(g, P, D)) {
+        static const bool dbg = getenv("CLLM_HIP_TP_DEBUG") != nullptr;
+        if (dbg) HIPB_LOG("tensor parallel: a %d-node graph is not the decode step (%zu layers matched, embed %d, head %d/%d/%d): un-sharded on rank 0", ggml_graph_n_nodes(g), D.layers.size(), D.embed, D.head, D.head_norm, D.head_mm);
+        return GGML_STATUS_ABORTED;
+    }
     auto node = [&](int i) { return ggml_graph_node(g, i); };
     const int N = T.n, L = (int) D.layers.size();
     // ---- the chain of residual streams and the shapes: everything is checked BEFORE the first launch ----
     const ggml_tensor * emb = node(D.embed);
-    if (!f32_vec(emb)) return GGML_STATUS_ABORTED;
+    if (!f32_vec(emb)) return TP_NO();
     tp_dims d; d.H = emb->ne[0];
     const float * curx = (const float *) emb->data;
     const fused_attn & A0 = P.attns[D.layers[0].attn];
     d.hd = A0.hd; d.nh = A0.nh; d.nkv = A0.nkv; d.ML = A0.ML;
-    if (d.nkv < N || d.nh % d.nkv) return GGML_STATUS_ABORTED;
+    if (d.nkv < N || d.nh % d.nkv) return TP_NO();
     d.gs = d.nh / d.nkv;
     struct lw { const ggml_tensor * wq, * wk, * wv, * bq, * bk, * bv, * wo, * wg, * wu, * wd; const float * an, * fn; float an_eps, fn_eps; };
     std::vector<lw> W((size_t) L);
     for (int l = 0; l < L; l++) {
         const tp_layer & Y = D.layers[l];
         const merge_group & G = P.groups[Y.gq]; const fused_attn & A = P.attns[Y.attn];
-        if (G.member[0] != A.wq || G.member[1] != A.wk || G.member[2] != A.wv) return GGML_STATUS_ABORTED;
+        if (G.member[0] != A.wq || G.member[1] != A.wk || G.member[2] != A.wv) return TP_NO();
         const fused_mv & fq = P.mvs[A.wq], & fk = P.mvs[A.wk], & fv = P.mvs[A.wv], & fo = P.mvs[Y.o], & fd = P.mvs[Y.down];
         const merge_group & GG = P.groups[Y.ggu];
         const fused_mv & fg = P.mvs[GG.member[0]], & fu = P.mvs[GG.member[1]];
@@ -1364,26 +1399,32 @@ ggml_status tp_graph_compute(hip_backend_ctx * c, ggml_cgraph * g, fuse_plan & P
         w.wg = node(fg.node)->src[0]; w.wu = node(fu.node)->src[0]; w.wd = node(fd.node)->src[0];
         w.bq = G.bias ? fq.resid_t : nullptr; w.bk = G.bias ? fk.resid_t : nullptr; w.bv = G.bias ? fv.resid_t : nullptr;
         w.an = fq.pw; w.an_eps = fq.eps; w.fn = fg.pw; w.fn_eps = fg.eps;
-        if (A.hd != d.hd || A.nh != d.nh || A.nkv != d.nkv || A.ML != d.ML || A.mode != A0.mode || A.freq_base != A0.freq_base || A.n_kv != A0.n_kv) return GGML_STATUS_ABORTED;
-        if (fq.px != curx || fo.px != A.out || fo.resid != curx) return GGML_STATUS_ABORTED;
+        if (A.hd != d.hd || A.nh != d.nh || A.nkv != d.nkv || A.ML != d.ML || A.mode != A0.mode || A.freq_base != A0.freq_base || A.n_kv != A0.n_kv) return TP_NO();
+        if (fq.px != curx || fo.px != A.out || fo.resid != curx) return TP_NO();
         curx = fo.dst;
-        if (fg.px != curx || fd.resid != curx) return GGML_STATUS_ABORTED;
+        if (fg.px != curx || fd.resid != curx) return TP_NO();
         curx = fd.dst;
-        if (w.wq->ne[0] != d.H || w.wq->ne[1] != d.nh * d.hd || w.wk->ne[1] != d.nkv * d.hd || w.wv->ne[1] != d.nkv * d.hd || w.wo->ne[0] != d.nh * d.hd || w.wo->ne[1] != d.H) return GGML_STATUS_ABORTED;
+        if (w.wq->ne[0] != d.H || w.wq->ne[1] != d.nh * d.hd || w.wk->ne[1] != d.nkv * d.hd || w.wv->ne[1] != d.nkv * d.hd || w.wo->ne[0] != d.nh * d.hd || w.wo->ne[1] != d.H) return TP_NO();
         if (l == 0) d.F = w.wg->ne[1];
-        if (w.wg->ne[0] != d.H || w.wg->ne[1] != d.F || w.wu->ne[1] != d.F || w.wd->ne[0] != d.F || w.wd->ne[1] != d.H || w.wg->type != w.wu->type) return GGML_STATUS_ABORTED;
-        if (w.wq->type != W[0].wq->type || w.wo->type != W[0].wo->type || w.wg->type != W[0].wg->type || w.wd->type != W[0].wd->type) return GGML_STATUS_ABORTED;
+        if (w.wg->ne[0] != d.H || w.wg->ne[1] != d.F || w.wu->ne[1] != d.F || w.wd->ne[0] != d.F || w.wd->ne[1] != d.H || w.wg->type != w.wu->type) return TP_NO();
+        if (w.wq->type != W[0].wq->type || w.wo->type != W[0].wo->type || w.wg->type != W[0].wg->type || w.wd->type != W[0].wd->type) return TP_NO();
     }
-    const fused_mv & fh = P.mvs[D.head];
-    if (fh.px != curx) return GGML_STATUS_ABORTED;
-    const ggml_tensor * wh = node(fh.node)->src[0];
-    float * logits = fh.dst;
+    const ggml_tensor * wh = nullptr;
+    if (D.head >= 0) {
+        const fused_mv & fh = P.mvs[D.head];
+        if (fh.px != curx) return TP_NO();
+        wh = node(fh.node)->src[0];
+    } else {
+        const ggml_tensor * hn = node(D.head_norm);
+        if (!hn->src[0]->src[0] || hn->src[0]->src[0]->data != (const void *) curx || ggml_nelements(hn) != d.H) return TP_NO();
+        wh = node(D.head_mm)->src[0];
+    }
     auto kind = [](ggml_type t) { return (int64_t)(t == GGML_TYPE_Q4_K ? 256 : 32); };
     const ggml_type tq = W[0].wq->type, to = W[0].wo->type, tg = W[0].wg->type, td = W[0].wd->type;
     // what the two tensor-parallel forms take (gemv_tp.hip) -- and the whole-KV-group / whole-quant-block splits
-    if (d.H % kind(tq) || d.H % kind(tg) || d.H % kind(wh->type) || d.H > 16384 || d.H % 4) return GGML_STATUS_ABORTED;
+    if (d.H % kind(tq) || d.H % kind(tg) || d.H % kind(wh->type) || d.H > 16384 || d.H % 4) return TP_NO();
     const int64_t fblk = ggml_blck_size(td), nfb = d.F / fblk;
-    if (d.F % fblk || nfb < N || d.F % 8) return GGML_STATUS_ABORTED;
+    if (d.F % fblk || nfb < N || d.F % 8) return TP_NO();
     std::vector<tp_split> S((size_t) N);
     for (int k = 0; k < N; k++) {
         tp_split & s = S[(size_t) k];
@@ -1392,17 +1433,16 @@ ggml_status tp_graph_compute(hip_backend_ctx * c, ggml_cgraph * g, fuse_plan & P
         s.f0 = b0 * fblk; s.fc = bc * fblk;
         const int64_t qc = s.kvc * d.gs * d.hd, q0 = s.kv0 * d.gs * d.hd;
         if (s.kvc < 1 || qc % kind(to) || q0 % ggml_blck_size(to) || qc > 32768 || s.fc % kind(td) || s.fc > 32768 || (s.fc % 8) ||
-            !cllm_attn_decode_supported((int)(s.kvc * d.gs), (int) s.kvc, (int) d.hd, d.ML)) return GGML_STATUS_ABORTED;
+            !cllm_attn_decode_supported((int)(s.kvc * d.gs), (int) s.kvc, (int) d.hd, d.ML)) return TP_NO();
     }
-    if (tp_ensure_group(c, 2 * L, (size_t) d.H) != CLLM_OK) { HIPB_LOG("tensor parallel: %s -- running un-sharded on rank 0 from now on", cllm_last_error()); T.broken = true; cllm_set_device(c->device); return GGML_STATUS_ABORTED; }
+    if (tp_ensure_group(c, 2 * L, (size_t) d.H) != CLLM_OK) { HIPB_LOG("tensor parallel: %s -- running un-sharded on rank 0 from now on", cllm_last_error()); T.broken = true; cllm_set_device(c->device); return TP_NO(); }
     if (!T.told) { T.told = true; HIPB_LOG("tensor parallel: %d ranks behind one ggml device (%d layers; KV heads / FFN features of rank 0: %lld / %lld of %d / %lld)", N, L, (long long) S[0].kvc, (long long) S[0].fc, d.nkv, (long long) d.F); }
 
     // ---- shards (first step, or after the host rewrote a weight) ----
     struct ls { void * qkv, * bias, * o, * gu, * dn; const float * an, * fn; };
     std::vector<std::vector<ls>> SH((size_t) N, std::vector<ls>((size_t) L));
-    std::vector<const float *> out_norm((size_t) N, nullptr);
     bool built = false;
-    auto fail_shard = [&]() { HIPB_LOG("tensor parallel: a weight shard could not be made (%s) -- running un-sharded on rank 0 from now on", cllm_last_error()); T.broken = true; cllm_set_device(c->device); return GGML_STATUS_ABORTED; };
+    auto fail_shard = [&]() { HIPB_LOG("tensor parallel: a weight shard could not be made (%s) -- running un-sharded on rank 0 from now on", cllm_last_error()); T.broken = true; cllm_set_device(c->device); return TP_NO(); };
     auto replicate = [&](int k, const float * p, size_t bytes, const ggml_tensor * owner) -> const float * {      // a small F32 tensor every rank reads (norm weights)
         if (T.r[(size_t) k].gpu == c->device) return p;
         const ggml_tensor * src[1] = { owner };
@@ -1453,7 +1493,6 @@ ggml_status tp_graph_compute(hip_backend_ctx * c, ggml_cgraph * g, fuse_plan & P
             if (!o.an || !o.fn) return fail_shard();
         }
     }
-    out_norm[0] = fh.pw;
     // ---- per-rank scratch: [cos/sin 1 KB][pos 256 B][x ping][x pong][q|k|v][attention out][SiLU*up][scores of the long-context attention] ----
     auto al = [](size_t b) { return (b + 255) & ~(size_t) 255; };
     const bool table = d.hd == 64 || d.hd == 128;
@@ -1482,7 +1521,7 @@ ggml_status tp_graph_compute(hip_backend_ctx * c, ggml_cgraph * g, fuse_plan & P
             for (void * p : R.kv_mem) if (p) cllm_free(p);
             R.kv_mem.assign((size_t) 2 * L, nullptr);
             if (!R.kv_table && cllm_malloc(&R.kv_table, 4096 * 32) != CLLM_OK) { cllm_set_device(c->device); return GGML_STATUS_ALLOC_FAILED; }
-            if (L > 4096) { cllm_set_device(c->device); return GGML_STATUS_ABORTED; }
+            if (L > 4096) { cllm_set_device(c->device); return TP_NO(); }
             std::vector<void *> tab((size_t) 4 * L);
             for (int l = 0; l < L; l++) {
                 for (int h = 0; h < 2; h++) if (cllm_malloc(&R.kv_mem[(size_t)(2 * l + h)], kd * (size_t) d.ML * 2) != CLLM_OK) { cllm_set_device(c->device); return GGML_STATUS_ALLOC_FAILED; }
@@ -1576,12 +1615,25 @@ ggml_status tp_graph_compute(hip_backend_ctx * c, ggml_cgraph * g, fuse_plan & P
         }
         pend = 2 * l + 1;
     }
-    {   // the lm_head on rank 0, straight into the host's logits (its RMS_NORM prologue takes the last all-reduce)
+    {   // the head on rank 0, straight into the host's tensors
         rk & x = X[0];
         cllm_set_device(c->device);
-        cllm_tensor w = desc(wh);
-        float * nx = x.cur == x.xa ? x.xb : x.xa;
-        TPC(cllm_op_mul_mat_vec_tp_gather(st0, &w, x.cur, out_norm[0], fh.eps, 0, nullptr, logits, T.r[0].fused, pend, nx));
+        if (D.head >= 0) {                        // a fused norm + lm_head: its RMS_NORM prologue takes the last all-reduce
+            const fused_mv & fh = P.mvs[D.head];
+            cllm_tensor w = desc(wh);
+            float * nx = x.cur == x.xa ? x.xb : x.xa;
+            TPC(cllm_op_mul_mat_vec_tp_gather(st0, &w, x.cur, fh.pw, fh.eps, 0, nullptr, fh.dst, T.r[0].fused, pend, nx));
+        } else {                                  // chatllm's head: the last all-reduce lands in the host's residual tensor, then the two nodes run as on one device
+            ggml_tensor * hn = node(D.head_norm), * hm = node(D.head_mm);
+            TPC(cllm_op_tp_gather_residual(st0, x.cur, d.H, T.r[0].fused, pend, (float *) curx));
+            float eps; memcpy(&eps, hn->src[0]->op_params, 4);
+            cllm_tensor dx = desc(hn->src[0]->src[0]), dwt = desc(hn->src[1]), dn = desc(hn);
+            dwt.ne[0] = hn->ne[0]; dwt.ne[1] = dwt.ne[2] = dwt.ne[3] = 1; dwt.nb[1] = dwt.nb[2] = dwt.nb[3] = (size_t) hn->ne[0] * 4;
+            TPC(cllm_op_rms_norm_mul(st0, &dx, &dwt, &dn, eps));
+            cllm_tensor da = desc(hm->src[0]), db = desc(hm->src[1]), dd = desc(hm);
+            TPC(ensure_wdata(c, cllm_mul_mat_wsize(&da, &db)));
+            TPC(cllm_op_mul_mat(st0, &da, &db, &dd, c->wdata, c->wsize));
+        }
     }
     for (int k = 0; k < N; k++) {                 // this step's cache row back into the host's caches; then everything joins rank 0's stream
         tp_rank & R = T.r[(size_t) k]; const tp_split & s = S[(size_t) k]; rk & x = X[(size_t) k];
@@ -1590,9 +1642,10 @@ ggml_status tp_graph_compute(hip_backend_ctx * c, ggml_cgraph * g, fuse_plan & P
         if (R.own_stream) { TPC(cllm_event_record(R.ev, R.stream)); cllm_set_device(c->device); TPC(cllm_stream_wait_event(st0, R.ev)); }
     }
 #undef TPC
+#undef TP_NO
     cllm_set_device(c->device);
     T.steps++; T.last_tp = true;
-    if (g_stats) HIPB_LOG("HIP0 graph_compute: %d nodes -> tensor parallel over %d ranks: %d launches per rank (%d layers x 5 + head), all-reduce fused into the mat-vecs", ggml_graph_n_nodes(g), N, 5 * L + 4, L);
+    if (g_stats) HIPB_LOG("HIP0 graph_compute: %d nodes -> tensor parallel over %d ranks: %d launches per rank (%d layers x 5 + head), all-reduce fused into the mat-vecs", ggml_graph_n_nodes(g), N, 5 * L + 6, L);
     return GGML_STATUS_SUCCESS;
 }
 
@@ -1686,6 +1739,14 @@ ggml_status be_graph_compute(ggml_backend_t backend, ggml_cgraph * g) {
             if (act != R.xnorm || ggml_nelements(gm->src[1]) != R.xnorm->ne[0]) continue;
             bool ok = R.xn_users.size() == 2 && ((R.xn_users[0] == G.gate && R.xn_users[1] == G.up) || (R.xn_users[0] == G.up && R.xn_users[1] == G.gate));
             for (int u : R.out_users) if (u != G.gate && u != G.up && !plan.skip[u] && u <= G.mul) ok = false;
+            // the fold moves the router from the TOP_K node to the later MUL node: the launch there still READS R.x, and its fallback (two launches) WRITES R.xnorm -- blocks
+            // ggml-alloc may have handed to a node in between (their last readers precede the MUL).  Nothing launched in (TOP_K, MUL] may overlap either.
+            for (int j = R.itk + 1; ok && j <= G.mul; j++) {
+                const ggml_tensor * t = ggml_graph_node(g, j);
+                if (plan.skip[j] || !t->data || t->op == GGML_OP_NONE || t->op == GGML_OP_RESHAPE || t->op == GGML_OP_VIEW || t->op == GGML_OP_PERMUTE || t->op == GGML_OP_TRANSPOSE) continue;
+                const size_t kb = (size_t) R.xnorm->ne[0] * 4;
+                if (overlap(t->data, ggml_nbytes(t), R.x->data, kb) || overlap(t->data, ggml_nbytes(t), R.xnorm->data, kb)) ok = false;
+            }
             if (!ok) continue;
             G.router = (int) ri; plan.skip[R.itk] = 1;
             break;

@@ -87,6 +87,7 @@ SIGNATURES = {
     "cllm_op_mul_mat_id": (C.c_int, [_P, _T, _T, _T, _T, _P, C.c_size_t]),
     "cllm_op_argmax_advance": (C.c_int, [_P, _P, C.c_int64, _P, _P, _P, C.c_int, _P]),
     "cllm_op_argmax_set": (C.c_int, [_P, _P, C.c_int64, _P, _P, _P, C.c_int, _P]),
+    "cllm_op_snapshot_argmax_set": (C.c_int, [_P, _P, C.c_int, _P, C.c_int64, _P, _P, _P, C.c_int, _P]),
     "cllm_flash_attn_wsize": (C.c_size_t, [_T]),
     "cllm_op_flash_attn_ext": (C.c_int, [_P, _T, _T, _T, _T, _T, C.c_float, C.c_float, C.c_float, _P, C.c_size_t]),
     "cllm_attn_prefill_min_cols": (C.c_int, []),
@@ -156,6 +157,7 @@ SIGNATURES = {
     "cllm_tp_fused_clear_error": (C.c_int, [_P]),
     "cllm_op_mul_mat_vec_tp_scatter": (C.c_int, [_P, _T, C.c_int, _P, _P, C.c_int]),
     "cllm_op_mul_mat_vec_tp_gather": (C.c_int, [_P, _T, _P, _P, C.c_float, C.c_int, _P, _P, _P, C.c_int, _P]),
+    "cllm_op_tp_gather_residual": (C.c_int, [_P, _P, C.c_int64, _P, C.c_int, _P]),
     "cllm_op_kv_shard_copy": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_int64, _P, C.c_int]),
     "cllm_copy_2d": (C.c_int, [_P, _P, C.c_size_t, _P, C.c_size_t, C.c_size_t, C.c_size_t]),
     "cllm_llama_set_tp_fused": (C.c_int, [_P, _P]),

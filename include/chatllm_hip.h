@@ -257,6 +257,11 @@ CLLM_API int cllm_op_argmax_advance(void * stream, const float * logits, int64_t
  * *ptr = val for every record (distinct pointers).  What the module's decode-ahead uses: the memory of a per-token scalar may have been reused by later nodes
  * of the previous graph, so its old content is not something to increment. */
 CLLM_API int cllm_op_argmax_set(void * stream, const float * logits, int64_t n, int32_t * tok_dev, int32_t * tok_host, const void * set_table_dev, int n_set, void * scratch);
+/* ... and with the snapshot of the graph's outputs in the same launch (what stood in front of every token through the unmodified host as five launches): ranges_dev[] =
+ * n_ranges records { const void * src; void * dst; uint64_t bytes; } (24 bytes each, device memory, bytes % 4 == 0) copied before the token is published;
+ * scratch: 4096 bytes of device memory zeroed before the first use.  Replaces the host side of the greedy loop the module hides (src/models.cpp:941-1086). */
+CLLM_API int cllm_op_snapshot_argmax_set(void * stream, const void * ranges_dev, int n_ranges, const float * logits, int64_t n, int32_t * tok_dev, int32_t * tok_host,
+                                         const void * set_table_dev, int n_set, void * scratch);
 
 /* fused single-token attention as chatllm's eager path emits it for qlen == 1 (src/layers.cpp:2541-2561, 2499-2539):
  *   MUL_MAT(K view, Q) + SCALE(1/sqrt(hd)) + DIAG_MASK_INF + SOFT_MAX + MUL_MAT(V view, P) + PERMUTE + CONT
@@ -410,6 +415,9 @@ CLLM_API int          cllm_tp_fused_clear_error(void * os);   /* after a reporte
 CLLM_API int          cllm_op_mul_mat_vec_tp_scatter(void * stream, const cllm_tensor * src0, int pro, const float * px, void * tp_fused, int site);
 CLLM_API int          cllm_op_mul_mat_vec_tp_gather(void * stream, const cllm_tensor * src0, const float * px, const float * pw, float eps, int epi, const float * bias, float * dst,
                                                     void * tp_fused, int site, float * xout);
+/* xout[0..n) = px + the all-reduced partials of `site`: the gather's residual fold alone (a step whose head is not a fusable mat-vec -- LMFinalSteps keeps the normalised hidden
+ * state as a graph output, src/models.cpp:1754-1755) */
+CLLM_API int          cllm_op_tp_gather_residual(void * stream, const float * px, int64_t n, void * tp_fused, int site, float * xout);
 /* KV-cache shards of the logical tensor-parallel device (tp_kv.hip; the host's cache: KVCacheAttention src/layers.cpp:3044-3123): rows [p0, p1) -- or, pos_dev != NULL, the one
  * row at *pos_dev -- of columns [kd_offset, kd_offset + kd_shard) between the host's caches (K [n][kd_full], V [kd_full][max_len], F16) and a rank's dense shards
  * (K [n][kd_shard], V [kd_shard][max_len]).  table_dev: n_layers x 4 device pointers { host K, host V, shard K, shard V }. */

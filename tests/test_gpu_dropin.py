@@ -613,7 +613,7 @@ def test_tensor_parallel_behind_the_ggml_boundary(gpu, tmp_path, arch, wt, over)
     ids_1, lg_1, err_1 = _host_run(tmp_path, mp, "all", n_dec, prompt, cfg["vocab"], threads=4, **turn2)
     assert "tensor parallel" not in err_1
     for n in (2, 4, 8):
-        ids_n, lg_n, err = _host_run(tmp_path, mp, "all", n_dec, prompt, cfg["vocab"], teacher=ids_1, threads=4, CLLM_HIP_TP=str(n), **turn2)
+        ids_n, lg_n, err = _host_run(tmp_path, mp, "all", n_dec, prompt, cfg["vocab"], teacher=ids_1, threads=4, CLLM_HIP_TP=str(n), CLLM_HIP_TP_DEBUG="1", **turn2)
         assert f"tensor parallel: {n} ranks behind one ggml device" in err, err[-1500:]
         steps = [ln for ln in err.splitlines() if "-> tensor parallel over" in ln]
         assert len(steps) == n_dec - 1, (len(steps), err[-1500:])                 # every single-token step ran sharded; the prompt and the second turn's chunk did not
