@@ -42,6 +42,7 @@ struct hip_backend_ctx {
     struct {
         bool armed = false, inflight = false;
         bool chained = false;          // the step running ahead was queued BEHIND the step the host is still waiting for (ahead_launch(c, true)): synchronize() waits for `ev`, not for the stream
+        bool ev_pending = false;       // ... and that event has not been waited for yet (EVERY synchronize() while the step runs ahead must stay off the stream: the host calls it more than once per token)
         bool snap_ready = false;       // the outputs' snapshot is complete although the step did not start (ahead_launch failed behind its argmax write): serve the pending read from it
         void * ev = nullptr, * table_dev = nullptr, * scratch = nullptr, * snap = nullptr; size_t snap_bytes = 0; int32_t * tok_host = nullptr;
         struct snap_rng { const void * src; void * dst; uint64_t bytes; }; void * rng_dev = nullptr; snap_rng * rng_host = nullptr; std::vector<snap_rng> rng_cur;      // the snapshot's ranges as the device holds them
@@ -60,7 +61,7 @@ std::atomic<uint64_t> g_next_buffer_uid{1};     // (accessory models own their o
 struct wall_stats {
     using clk = std::chrono::steady_clock;
     clk::time_point last_exit = clk::now();
-    double host_us = 0, plan_us = 0, issue_us = 0, sync_us = 0, set_us = 0, get_us = 0, alloc_us = 0; long graphs = 0, calls = 0, sets = 0, gets = 0, allocs = 0;
+    double host_us = 0, plan_us = 0, issue_us = 0, sync_us = 0, set_us = 0, get_us = 0, alloc_us = 0; long graphs = 0, calls = 0, sets = 0, gets = 0, allocs = 0, syncs = 0;
     static double us(clk::time_point a, clk::time_point b) { return std::chrono::duration<double, std::micro>(b - a).count(); }
 } g_ws;
 const bool g_stats = getenv("CLLM_HIP_STATS") != nullptr;
@@ -452,7 +453,7 @@ void be_free(ggml_backend_t b) {
     delete c; delete b;
 }
 void be_sync(ggml_backend_t b) {
-    ws_scope ws(g_ws.sync_us);
+    ws_scope ws(g_ws.sync_us); g_ws.syncs++;
     flush_sets();
     auto * c = (hip_backend_ctx *) b->context; cllm_set_device(c->device);
     // a step queued behind the one the host waits for (ahead_launch chained): the host's step is complete -- outputs snapshotted -- when the event behind its arg-max has fired
@@ -1131,8 +1132,8 @@ struct sig_writer {
 // Still at most ONE step runs ahead of what the host has asked for.
 void ahead_finish_event(hip_backend_ctx * c) {       // the chained step's event has not been waited for yet: wait, and bring the host-side mirror of the scalars in step
     auto & A = c->ahead;
-    if (!A.chained) return;
-    A.chained = false;
+    if (!A.ev_pending) return;
+    A.ev_pending = false;
     cllm_set_device(c->device);
     cllm_event_sync(A.ev);
     std::lock_guard<std::mutex> lock(g_ring.m);
@@ -1140,7 +1141,7 @@ void ahead_finish_event(hip_backend_ctx * c) {       // the chained step's event
 }
 void ahead_launch(hip_backend_ctx * c, bool chained) {
     auto & A = c->ahead;
-    A.armed = false; A.snap_ready = false; A.chained = false;
+    A.armed = false; A.snap_ready = false; A.chained = false; A.ev_pending = false;
     cllm_set_device(c->device);
     if (!A.ev && cllm_event_create(&A.ev) != CLLM_OK) return;
     if (!A.tok_host) { void * p = nullptr; if (cllm_host_malloc(&p, 64) != CLLM_OK) return; A.tok_host = (int32_t *) p; }
@@ -1169,6 +1170,21 @@ void ahead_launch(hip_backend_ctx * c, bool chained) {
         A.tab_host[k].ptr = ss.ptr; A.tab_host[k].val = ss.val + 1; A.tab_host[k].pad = 0;
     }
     void * st = c->stream;
+    // CLLM_HIP_AHEAD_TIMING=1 (diagnosis): per step, on the GPU's clock -- the captured step alone, what stands in front of it (table copy, prep launch, event), and the token
+    // period; a ring of four event triples, read two launches later (the host has synchronized on a later event by then, also with the chain on)
+    static void * t_p[4] = {}, * t_g0[4] = {}, * t_g1[4] = {}; static long t_n = 0; static double acc_graph = 0, acc_prep = 0, acc_period = 0; static long acc_n = 0;
+    static const bool timing = getenv("CLLM_HIP_AHEAD_TIMING") != nullptr;
+    const int t_k = (int)(t_n & 3);
+    if (timing) {
+        if (!t_p[0]) for (int i = 0; i < 4; i++) { cllm_event_create(&t_p[i]); cllm_event_create(&t_g0[i]); cllm_event_create(&t_g1[i]); }
+        if (t_n >= 3) {
+            const int a = (int)((t_n - 3) & 3), b = (int)((t_n - 2) & 3);
+            float g = 0, q = 0, per = 0;
+            if (cllm_event_elapsed_ms(t_g0[a], t_g1[a], &g) == CLLM_OK && cllm_event_elapsed_ms(t_p[a], t_g0[a], &q) == CLLM_OK && cllm_event_elapsed_ms(t_g0[a], t_g0[b], &per) == CLLM_OK) { acc_graph += g; acc_prep += q; acc_period += per; acc_n++; }
+            if (acc_n == 64) { HIPB_LOG("ahead timing over 64 steps (GPU clock): token period %.1f us = captured step %.1f + table copy / prep launch / event in front of it %.1f + idle %.1f", acc_period / 64 * 1e3, acc_graph / 64 * 1e3, acc_prep / 64 * 1e3, (acc_period - acc_graph - acc_prep) / 64 * 1e3); acc_graph = acc_prep = acc_period = 0; acc_n = 0; }
+        }
+        cllm_event_record(t_p[t_k], st);
+    }
     if (n_rec && cllm_memcpy_h2d(A.table_dev, A.tab_host, (size_t) n_rec * 16, st) != CLLM_OK) return;      // queued on the step's stream from page-locked memory; done before the event below
     // the snapshot of the outputs, the arg-max and the scalar updates: ONE launch (cllm_op_snapshot_argmax_set; CLLM_HIP_AHEAD_ONE=0: round 5's copies + two launches)
     static const bool one_launch = !getenv("CLLM_HIP_AHEAD_ONE") || atoi(getenv("CLLM_HIP_AHEAD_ONE")) != 0;
@@ -1192,10 +1208,12 @@ void ahead_launch(hip_backend_ctx * c, bool chained) {
     } else
     if (cllm_op_argmax_set(st, (const float *) A.logits_ptr, (int64_t)(A.logits_bytes / 4), (int32_t *) A.ids_ptr, A.tok_host, A.table_dev, n_rec, A.scratch) != CLLM_OK) { fail_behind_the_snapshot(); return; }
     if (cllm_event_record(A.ev, st) != CLLM_OK) { fail_behind_the_snapshot(); return; }
+    if (timing) cllm_event_record(t_g0[t_k], st);
     if (cllm_graph_launch(c->graph_exec, st) != CLLM_OK) { fail_behind_the_snapshot(); return; }
+    if (timing) { cllm_event_record(t_g1[t_k], st); t_n++; }
     static const bool ahead_sync = getenv("CLLM_HIP_AHEAD_SYNC") != nullptr;       // (debugging: run the step ahead to completion before returning)
     if (ahead_sync) cllm_stream_sync(st);
-    A.inflight = true; A.launched++; A.chained = true;
+    A.inflight = true; A.launched++; A.chained = chained; A.ev_pending = true;
     // not chained: the snapshot and the scalars are in place before the host goes on (its own writes of the same scalars come later); the device then holds the predicted
     // scalars: the host-side mirror is brought in step (the host will write the same values again).  Chained: synchronize() does both.
     if (!chained) ahead_finish_event(c);
@@ -1272,7 +1290,10 @@ int tp_ensure_group(hip_backend_ctx * c, int n_sites, size_t max_n) {
         for (int k = 0; k < T.n; k++) {
             tp_rank & R = T.r[k];
             R.gpu = (c->device + k) % (phys > 0 ? phys : 1);
-            if (R.gpu == c->device) R.stream = c->stream;
+            // CLLM_HIP_TP_STREAMS=1 (tests): ranks that share rank 0's GPU get streams of their own as well -- the event / cross-stream path of distinct GPUs on a one-GPU box.
+            // Only for shapes whose launches can all be resident at once (a gather polls for scatters of other streams): the test shapes; bounded waits otherwise report a time-out.
+            static const bool force_streams = getenv("CLLM_HIP_TP_STREAMS") && atoi(getenv("CLLM_HIP_TP_STREAMS")) != 0;
+            if (R.gpu == c->device && !(force_streams && k > 0)) R.stream = c->stream;
             else {
                 cllm_set_device(R.gpu);
                 if (int rc = cllm_stream_create(&R.stream)) { cllm_set_device(c->device); return rc; }
@@ -2063,12 +2084,12 @@ ggml_status be_graph_compute(ggml_backend_t backend, ggml_cgraph * g) {
         g_ws.calls += launches;
         if (++g_ws.graphs % 64 == 0) {
             const double n = 64.0;
-            HIPB_LOG("per graph over the last 64: host %.0f us | graph_compute %.0f us (of which planning %.0f us, %.0f calls) | synchronize %.0f us | "
+            HIPB_LOG("per graph over the last 64: host %.0f us | graph_compute %.0f us (of which planning %.0f us, %.0f calls) | synchronize %.0f us (%.1f calls) | "
                      "set_tensor %.0f us (%.1f calls) | get_tensor %.0f us (%.1f calls) | buffer alloc/free %.0f us (%.2f calls)",
-                     g_ws.host_us / n, g_ws.issue_us / n, g_ws.plan_us / n, g_ws.calls / n, g_ws.sync_us / n, g_ws.set_us / n, g_ws.sets / n, g_ws.get_us / n, g_ws.gets / n,
+                     g_ws.host_us / n, g_ws.issue_us / n, g_ws.plan_us / n, g_ws.calls / n, g_ws.sync_us / n, g_ws.syncs / n, g_ws.set_us / n, g_ws.sets / n, g_ws.get_us / n, g_ws.gets / n,
                      g_ws.alloc_us / n, g_ws.allocs / n);
             HIPB_LOG("launch lists replayed from a captured graph so far: %ld (captures: %ld); steps started ahead of the host: %ld, of which the host then asked for: %ld", c->replays, c->captures, c->ahead.launched, c->ahead.hits);
-            g_ws.host_us = g_ws.plan_us = g_ws.issue_us = g_ws.sync_us = g_ws.set_us = g_ws.get_us = g_ws.alloc_us = 0; g_ws.calls = g_ws.sets = g_ws.gets = g_ws.allocs = 0;
+            g_ws.host_us = g_ws.plan_us = g_ws.issue_us = g_ws.sync_us = g_ws.set_us = g_ws.get_us = g_ws.alloc_us = 0; g_ws.calls = g_ws.sets = g_ws.gets = g_ws.allocs = g_ws.syncs = 0;
         }
     }
     return GGML_STATUS_SUCCESS;       // asynchronous: the host calls synchronize() before it reads (src/backend.cpp:824-825)

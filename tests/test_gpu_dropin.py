@@ -621,3 +621,28 @@ def test_tensor_parallel_behind_the_ggml_boundary(gpu, tmp_path, arch, wt, over)
         assert np.array_equal(lg_1[0].view(np.uint32), lg_n[0].view(np.uint32))   # the prompt ran un-sharded on rank 0: the single device's bits
         dev, clear = _tolerance_tier(lg_1, lg_n, ids_1, 0.25)
         print(f"{arch} wtype {wt}: {n} ranks behind one device: max|dlogit| {dev:.3e} sigma, steps with a clear margin {clear:.2f}")
+    # the cross-stream path distinct GPUs take (every rank its own stream, the embedding row / position handed over behind an event, the ranks' streams joined into rank 0's at the
+    # end of the step, gathers polling for scatters that run concurrently) on the one GPU: small shapes, every launch resident at once
+    ids_s, lg_s, err = _host_run(tmp_path, mp, "all", n_dec, prompt, cfg["vocab"], teacher=ids_1, threads=4, CLLM_HIP_TP="2", CLLM_HIP_TP_STREAMS="1", CLLM_HIP_TP_DEBUG="1", **turn2)
+    assert len([ln for ln in err.splitlines() if "-> tensor parallel over" in ln]) == n_dec - 1 and "timed out" not in err, err[-1500:]
+    dev, clear = _tolerance_tier(lg_1, lg_s, ids_1, 0.25)
+    print(f"{arch} wtype {wt}: 2 ranks on streams of their own: max|dlogit| {dev:.3e} sigma")
+
+
+@_REF_BUILT
+def test_tensor_parallel_device_runs_everything_else_unsharded_and_bit_identical(gpu, tmp_path):
+    """CLLM_HIP_TP=N changes nothing for graphs that are not the dense decode step: a sparse-MoE model (router, MUL_MAT_ID: tp_extract declines), a partial offload (`-ngl 1`: the
+    scheduler splits the graph, no split is a whole step) and a flash-attention host (`-fa 1`: FLASH_ATTN_EXT instead of the fused attention block) all run un-sharded on rank 0 --
+    ids and every logit word equal to the run without CLLM_HIP_TP"""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import make_ggmm
+    cfg = gpu.synth.config("tiny", max_len=64)
+    prompt = [5, 9, 42, 300, 7, 99, 250]
+    mx, ml = str(tmp_path / "mx.bin"), str(tmp_path / "ml.bin")
+    make_ggmm.write_mixtral(mx, cfg, 12, seed=91)
+    make_ggmm.write_model(ml, cfg, 12, seed=92)
+    for mp, ngl, extra in ((mx, "all", {}), (ml, "1", {}), (ml, "all", dict(REF_CHAT_FA="1"))):
+        ids_a, lg_a, _ = _host_run(tmp_path, mp, ngl, 10, prompt, cfg["vocab"], **extra)
+        ids_b, lg_b, err = _host_run(tmp_path, mp, ngl, 10, prompt, cfg["vocab"], CLLM_HIP_TP="2", CLLM_HIP_TP_DEBUG="1", **extra)
+        assert "-> tensor parallel over" not in err                              # no step was taken sharded ...
+        assert ids_a == ids_b and np.array_equal(lg_a.view(np.uint32), lg_b.view(np.uint32)), (mp, ngl, extra)      # ... and nothing changed
