@@ -82,7 +82,8 @@ struct tp_rank {
 };
 struct tp_group {
     int n = 0; std::vector<tp_rank> r; bool fused_ready = false, broken = false, told = false, last_tp = false; int sites = 0; size_t max_n = 0; void * ev0 = nullptr;
-    long steps = 0, plain = 0; const void * owner = nullptr;      // owner: the backend context whose stream rank 0 runs on
+    long steps = 0, plain = 0, replays = 0, captures = 0; const void * owner = nullptr;
+    std::vector<uint64_t> last_sig, graph_sig; std::vector<void *> execs; bool graph_broken = false;      // launch-list replay of the sharded step: one captured graph per distinct stream      // owner: the backend context whose stream rank 0 runs on
 } g_tp;
 std::vector<hip_device_ctx *> g_devices;
 ggml_backend_reg g_reg;
@@ -1379,6 +1380,8 @@ void tp_free_all() {
         if (R.ev) cllm_event_destroy(R.ev);
         if (R.own_stream && R.stream) cllm_stream_destroy(R.stream);
     }
+    for (void * e : T.execs) if (e) cllm_graph_destroy(e);
+    T.execs.clear(); T.graph_sig.clear(); T.last_sig.clear();
     if (T.ev0) cllm_event_destroy(T.ev0);
     T.r.clear(); T.fused_ready = false; T.ev0 = nullptr; T.owner = nullptr;
 }
@@ -1442,6 +1445,7 @@ ggml_status tp_graph_compute(hip_backend_ctx * c, ggml_cgraph * g, fuse_plan & P
     }
     auto kind = [](ggml_type t) { return (int64_t)(t == GGML_TYPE_Q4_K ? 256 : 32); };
     const ggml_type tq = W[0].wq->type, to = W[0].wo->type, tg = W[0].wg->type, td = W[0].wd->type;
+    const bool mv_head_ok = is_q(wh->type) && wh->ne[2] == 1 && wh->ne[3] == 1 && wh->nb[1] == ggml_row_size(wh->type, wh->ne[0]) && !((uintptr_t) wh->data & 15) && !(wh->nb[1] & 15) && wh->ne[0] == d.H;
     // what the two tensor-parallel forms take (gemv_tp.hip) -- and the whole-KV-group / whole-quant-block splits
     if (d.H % kind(tq) || d.H % kind(tg) || d.H % kind(wh->type) || d.H > 16384 || d.H % 4) return TP_NO();
     const int64_t fblk = ggml_blck_size(td), nfb = d.F / fblk;
@@ -1585,88 +1589,197 @@ ggml_status tp_graph_compute(hip_backend_ctx * c, ggml_cgraph * g, fuse_plan & P
         for (int k = 0; k < N; k++) if (T.r[(size_t) k].own_stream) { cllm_set_device(T.r[(size_t) k].gpu); TPC(cllm_stream_wait_event(T.r[(size_t) k].stream, T.ev0)); }
     }
     for (int k = 0; k < N; k++) {
-        tp_rank & R = T.r[(size_t) k]; const tp_split & s = S[(size_t) k]; rk & x = X[(size_t) k];
+        tp_rank & R = T.r[(size_t) k]; const tp_split & s = S[(size_t) k];
         cllm_set_device(R.gpu);
         if (R.kv_valid < A0.n_kv - 1) {          // rows the host's cache has and the shard has not (a prompt ran un-sharded, a session was loaded ...)
             TPC(cllm_op_kv_shard_copy(R.stream, R.kv_table, L, (int)(s.kvc * d.hd), (int)(d.nkv * d.hd), (int)(s.kv0 * d.hd), d.ML, R.kv_valid, A0.n_kv - 1, nullptr, 0));
         }
         R.kv_valid = A0.n_kv;
-        TPC(cllm_tp_fused_advance(R.fused, R.stream));
-        if (table) TPC(cllm_op_rope_table(R.stream, x.pos, (int) d.hd, A0.freq_base, x.cs));
     }
     auto wdesc = [](ggml_type t, int64_t K, int64_t rows, void * data) {
         cllm_tensor w; w.type = (int32_t) t; w.ne[0] = K; w.ne[1] = rows; w.ne[2] = w.ne[3] = 1;
         w.nb[0] = ggml_type_size(t); w.nb[1] = ggml_row_size(t, K); w.nb[2] = w.nb[3] = w.nb[1] * (size_t) rows; w.data = data; return w;
     };
-    int pend = -1;                                // the site whose partial sums are not yet in the residual stream
-    for (int l = 0; l < L; l++) {
-        const fused_attn & A = P.attns[D.layers[l].attn];
-        for (int k = 0; k < N; k++) {             // q | k | v (+ the all-reduce of the previous down projection + residual + RMS_NORM)
-            tp_rank & R = T.r[(size_t) k]; const tp_split & s = S[(size_t) k]; rk & x = X[(size_t) k]; const ls & o = SH[(size_t) k][(size_t) l];
-            cllm_set_device(R.gpu);
-            cllm_tensor w = wdesc(tq, d.H, s.kvc * (d.gs + 2) * d.hd, o.qkv);
-            if (pend < 0) TPC(cllm_op_mul_mat_vec_fused(R.stream, &w, 1, x.cur, o.an, W[(size_t) l].an_eps, 0, (const float *) o.bias, x.qkv));
-            else { float * nx = x.cur == x.xa ? x.xb : x.xa; TPC(cllm_op_mul_mat_vec_tp_gather(R.stream, &w, x.cur, o.an, W[(size_t) l].an_eps, 0, (const float *) o.bias, x.qkv, R.fused, pend, nx)); x.cur = nx; }
+    // ---- the head's operands.  Sharded by ROWS of the lm_head (default; CLLM_HIP_TP_HEAD=0: all of it on rank 0): every rank folds the last all-reduce into its own residual
+    //      stream and writes its logit rows straight into the host's logits tensor in rank 0's memory (a peer store from another GPU); a row's arithmetic does not change, so the
+    //      logits are the bits rank 0 alone would have produced from the same residual stream.  chatllm keeps the normalised hidden state as a graph OUTPUT: rank 0 also runs that node.
+    static const bool shard_head = !getenv("CLLM_HIP_TP_HEAD") || atoi(getenv("CLLM_HIP_TP_HEAD")) != 0;
+    const fused_mv * fh = D.head >= 0 ? &P.mvs[D.head] : nullptr;
+    ggml_tensor * hn = D.head >= 0 ? nullptr : node(D.head_norm), * hm = D.head >= 0 ? nullptr : node(D.head_mm);
+    const float * norm_w = fh ? fh->pw : (const float *) hn->src[1]->data;
+    const ggml_tensor * norm_t = fh ? norm_owner(*fh) : hn->src[1];
+    float eps_h = fh ? fh->eps : 0.0f;
+    if (!fh) memcpy(&eps_h, hn->src[0]->op_params, 4);
+    float * logits = fh ? fh->dst : (float *) hm->data;
+    const int64_t V = wh->ne[1];
+    const bool sharded = shard_head && V >= 8 * (int64_t) N && mv_head_ok;
+    struct hw { const void * wrows; const float * nw; int64_t v0, vc; };
+    std::vector<hw> HW((size_t) N);
+    for (int k = 0; k < (sharded ? N : 1); k++) {
+        tp_rank & R = T.r[(size_t) k]; hw & h = HW[(size_t) k];
+        h.v0 = 0; h.vc = V;
+        if (sharded) cllm_tp_split(V, N, k, &h.v0, &h.vc);
+        // this rank's rows of the lm_head: the host's tensor itself where the rank shares rank 0's GPU, else a copy made on first use
+        h.wrows = (const char *) wh->data + (size_t) h.v0 * wh->nb[1]; h.nw = norm_w;
+        if (R.gpu != c->device) {
+            const ggml_tensor * src[1] = { wh };
+            tp_piece pc = { h.wrows, (size_t) h.vc * wh->nb[1], (size_t) h.vc * wh->nb[1], 1, 0, (size_t) h.vc * wh->nb[1] };
+            bool b2 = false;
+            h.wrows = tp_get_shard(c, k, src, 1, &pc, 1, (size_t) h.vc * wh->nb[1], &b2);
+            h.nw = replicate(k, norm_w, (size_t) d.H * 4, norm_t);
+            if (!h.wrows || !h.nw) { HIPB_LOG("tensor parallel: the lm_head shard of rank %d could not be made (%s)", k, cllm_last_error()); cllm_set_device(c->device); return GGML_STATUS_FAILED; }
         }
-        for (int k = 0; k < N; k++) {             // RoPE + cache rows + attention over this rank's heads
+    }
+    if (!fh && !sharded) { cllm_tensor da = desc(hm->src[0]), db = desc(hm->src[1]); cllm_set_device(c->device); TPC(ensure_wdata(c, cllm_mul_mat_wsize(&da, &db))); }
+
+    // ---- the launches of the step proper.  only == nullptr: every rank, site by site (ranks that share a stream must be issued in this order: a gather never polls for a launch
+    //      behind it); only == a stream: the ranks of that stream alone, same order -- what is captured into that stream's graph ----
+    auto issue = [&](void * only) -> ggml_status {
+        auto mine = [&](int k) { return !only || T.r[(size_t) k].stream == only; };
+        for (int k = 0; k < N; k++) if (mine(k)) {
+            tp_rank & R = T.r[(size_t) k]; rk & x = X[(size_t) k];
+            cllm_set_device(R.gpu);
+            x.cur = x.xa;
+            TPC(cllm_tp_fused_advance(R.fused, R.stream));
+            if (table) TPC(cllm_op_rope_table(R.stream, x.pos, (int) d.hd, A0.freq_base, x.cs));
+        }
+        int pend = -1;                                // the site whose partial sums are not yet in the residual stream
+        for (int l = 0; l < L; l++) {
+            const fused_attn & A = P.attns[D.layers[l].attn];
+            for (int k = 0; k < N; k++) if (mine(k)) {    // q | k | v (+ the all-reduce of the previous down projection + residual + RMS_NORM)
+                tp_rank & R = T.r[(size_t) k]; const tp_split & s = S[(size_t) k]; rk & x = X[(size_t) k]; const ls & o = SH[(size_t) k][(size_t) l];
+                cllm_set_device(R.gpu);
+                cllm_tensor w = wdesc(tq, d.H, s.kvc * (d.gs + 2) * d.hd, o.qkv);
+                if (pend < 0) TPC(cllm_op_mul_mat_vec_fused(R.stream, &w, 1, x.cur, o.an, W[(size_t) l].an_eps, 0, (const float *) o.bias, x.qkv));
+                else { float * nx = x.cur == x.xa ? x.xb : x.xa; TPC(cllm_op_mul_mat_vec_tp_gather(R.stream, &w, x.cur, o.an, W[(size_t) l].an_eps, 0, (const float *) o.bias, x.qkv, R.fused, pend, nx)); x.cur = nx; }
+            }
+            for (int k = 0; k < N; k++) if (mine(k)) {    // RoPE + cache rows + attention over this rank's heads
+                tp_rank & R = T.r[(size_t) k]; const tp_split & s = S[(size_t) k]; rk & x = X[(size_t) k];
+                cllm_set_device(R.gpu);
+                TPC(cllm_op_rope_kv_attn_decode(R.stream, x.qkv, x.pos, table ? x.cs : nullptr, A.freq_base, A.n_kv, (int)(s.kvc * d.gs), (int) s.kvc, (int) d.hd, A.mode, R.kv_mem[(size_t) 2 * l], R.kv_mem[(size_t) 2 * l + 1], d.ML,
+                                                x.att, x.scores, x.score_bytes));
+            }
+            for (int k = 0; k < N; k++) if (mine(k)) {    // o: partial rows -> every rank
+                tp_rank & R = T.r[(size_t) k]; const tp_split & s = S[(size_t) k]; rk & x = X[(size_t) k]; const ls & o = SH[(size_t) k][(size_t) l];
+                cllm_set_device(R.gpu);
+                cllm_tensor w = wdesc(to, s.kvc * d.gs * d.hd, d.H, o.o);
+                TPC(cllm_op_mul_mat_vec_tp_scatter(R.stream, &w, 2, x.att, R.fused, 2 * l));
+            }
+            for (int k = 0; k < N; k++) if (mine(k)) {    // gate / up with SiLU * up (+ the all-reduce of o + residual + RMS_NORM)
+                tp_rank & R = T.r[(size_t) k]; const tp_split & s = S[(size_t) k]; rk & x = X[(size_t) k]; const ls & o = SH[(size_t) k][(size_t) l];
+                cllm_set_device(R.gpu);
+                cllm_tensor w = wdesc(tg, d.H, 2 * s.fc, o.gu);
+                float * nx = x.cur == x.xa ? x.xb : x.xa;
+                TPC(cllm_op_mul_mat_vec_tp_gather(R.stream, &w, x.cur, o.fn, W[(size_t) l].fn_eps, 1, nullptr, x.act, R.fused, 2 * l, nx));
+                x.cur = nx;
+            }
+            for (int k = 0; k < N; k++) if (mine(k)) {    // down: partial rows -> every rank
+                tp_rank & R = T.r[(size_t) k]; const tp_split & s = S[(size_t) k]; rk & x = X[(size_t) k]; const ls & o = SH[(size_t) k][(size_t) l];
+                cllm_set_device(R.gpu);
+                cllm_tensor w = wdesc(td, s.fc, d.H, o.dn);
+                TPC(cllm_op_mul_mat_vec_tp_scatter(R.stream, &w, 2, x.act, R.fused, 2 * l + 1));
+            }
+            pend = 2 * l + 1;
+        }
+        for (int k = 0; k < (sharded ? N : 1); k++) if (mine(k)) {      // the head
+            tp_rank & R = T.r[(size_t) k]; rk & x = X[(size_t) k]; const hw & h = HW[(size_t) k];
+            cllm_set_device(R.gpu);
+            cllm_tensor w = wdesc(wh->type, d.H, h.vc, (void *) h.wrows);
+            float * nx = x.cur == x.xa ? x.xb : x.xa;
+            if (fh) {                             // a fused norm + lm_head: its RMS_NORM prologue takes the last all-reduce
+                TPC(cllm_op_mul_mat_vec_tp_gather(R.stream, &w, x.cur, h.nw, eps_h, 0, nullptr, logits + h.v0, R.fused, pend, nx));
+            } else {                              // chatllm's head: the last all-reduce lands in the residual stream (rank 0: the host's tensor), then norm + rows
+                // (sharded: into the rank's own scratch -- ggml-alloc may have placed the logits on the freed block of the host's residual tensor, and the other ranks' rows land
+                //  there while this rank's launch still reads its input; un-sharded: the host's residual tensor, as on one device)
+                float * xfin = (k == 0 && !sharded) ? (float *) curx : nx;
+                TPC(cllm_op_tp_gather_residual(R.stream, x.cur, d.H, R.fused, pend, xfin));
+                if (k == 0) {
+                    cllm_tensor dx = desc(hn->src[0]->src[0]), dwt = desc(hn->src[1]), dn = desc(hn);
+                    dx.data = xfin;
+                    dwt.ne[0] = hn->ne[0]; dwt.ne[1] = dwt.ne[2] = dwt.ne[3] = 1; dwt.nb[1] = dwt.nb[2] = dwt.nb[3] = (size_t) hn->ne[0] * 4;
+                    TPC(cllm_op_rms_norm_mul(R.stream, &dx, &dwt, &dn, eps_h));
+                }
+                if (sharded) TPC(cllm_op_mul_mat_vec_fused(R.stream, &w, 1, xfin, h.nw, eps_h, 0, nullptr, logits + h.v0));      // (norm + quantize in the prologue: the bits of the two nodes)
+                else {
+                    cllm_tensor da = desc(hm->src[0]), db = desc(hm->src[1]), dd = desc(hm);
+                    TPC(cllm_op_mul_mat(R.stream, &da, &db, &dd, c->wdata, c->wsize));
+                }
+            }
+        }
+        for (int k = 0; k < N; k++) if (mine(k)) {    // this step's cache row back into the host's caches
             tp_rank & R = T.r[(size_t) k]; const tp_split & s = S[(size_t) k]; rk & x = X[(size_t) k];
             cllm_set_device(R.gpu);
-            TPC(cllm_op_rope_kv_attn_decode(R.stream, x.qkv, x.pos, table ? x.cs : nullptr, A.freq_base, A.n_kv, (int)(s.kvc * d.gs), (int) s.kvc, (int) d.hd, A.mode, R.kv_mem[(size_t) 2 * l], R.kv_mem[(size_t) 2 * l + 1], d.ML,
-                                            x.att, x.scores, x.score_bytes));
+            TPC(cllm_op_kv_shard_copy(R.stream, R.kv_table, L, (int)(s.kvc * d.hd), (int)(d.nkv * d.hd), (int)(s.kv0 * d.hd), d.ML, 0, 0, x.pos, 1));
         }
-        for (int k = 0; k < N; k++) {             // o: partial rows -> every rank
-            tp_rank & R = T.r[(size_t) k]; const tp_split & s = S[(size_t) k]; rk & x = X[(size_t) k]; const ls & o = SH[(size_t) k][(size_t) l];
-            cllm_set_device(R.gpu);
-            cllm_tensor w = wdesc(to, s.kvc * d.gs * d.hd, d.H, o.o);
-            TPC(cllm_op_mul_mat_vec_tp_scatter(R.stream, &w, 2, x.att, R.fused, 2 * l));
-        }
-        for (int k = 0; k < N; k++) {             // gate / up with SiLU * up (+ the all-reduce of o + residual + RMS_NORM)
-            tp_rank & R = T.r[(size_t) k]; const tp_split & s = S[(size_t) k]; rk & x = X[(size_t) k]; const ls & o = SH[(size_t) k][(size_t) l];
-            cllm_set_device(R.gpu);
-            cllm_tensor w = wdesc(tg, d.H, 2 * s.fc, o.gu);
-            float * nx = x.cur == x.xa ? x.xb : x.xa;
-            TPC(cllm_op_mul_mat_vec_tp_gather(R.stream, &w, x.cur, o.fn, W[(size_t) l].fn_eps, 1, nullptr, x.act, R.fused, 2 * l, nx));
-            x.cur = nx;
-        }
-        for (int k = 0; k < N; k++) {             // down: partial rows -> every rank
-            tp_rank & R = T.r[(size_t) k]; const tp_split & s = S[(size_t) k]; rk & x = X[(size_t) k]; const ls & o = SH[(size_t) k][(size_t) l];
-            cllm_set_device(R.gpu);
-            cllm_tensor w = wdesc(td, s.fc, d.H, o.dn);
-            TPC(cllm_op_mul_mat_vec_tp_scatter(R.stream, &w, 2, x.act, R.fused, 2 * l + 1));
-        }
-        pend = 2 * l + 1;
-    }
-    {   // the head on rank 0, straight into the host's tensors
-        rk & x = X[0];
-        cllm_set_device(c->device);
-        if (D.head >= 0) {                        // a fused norm + lm_head: its RMS_NORM prologue takes the last all-reduce
-            const fused_mv & fh = P.mvs[D.head];
-            cllm_tensor w = desc(wh);
-            float * nx = x.cur == x.xa ? x.xb : x.xa;
-            TPC(cllm_op_mul_mat_vec_tp_gather(st0, &w, x.cur, fh.pw, fh.eps, 0, nullptr, fh.dst, T.r[0].fused, pend, nx));
-        } else {                                  // chatllm's head: the last all-reduce lands in the host's residual tensor, then the two nodes run as on one device
-            ggml_tensor * hn = node(D.head_norm), * hm = node(D.head_mm);
-            TPC(cllm_op_tp_gather_residual(st0, x.cur, d.H, T.r[0].fused, pend, (float *) curx));
-            float eps; memcpy(&eps, hn->src[0]->op_params, 4);
-            cllm_tensor dx = desc(hn->src[0]->src[0]), dwt = desc(hn->src[1]), dn = desc(hn);
-            dwt.ne[0] = hn->ne[0]; dwt.ne[1] = dwt.ne[2] = dwt.ne[3] = 1; dwt.nb[1] = dwt.nb[2] = dwt.nb[3] = (size_t) hn->ne[0] * 4;
-            TPC(cllm_op_rms_norm_mul(st0, &dx, &dwt, &dn, eps));
-            cllm_tensor da = desc(hm->src[0]), db = desc(hm->src[1]), dd = desc(hm);
-            TPC(ensure_wdata(c, cllm_mul_mat_wsize(&da, &db)));
-            TPC(cllm_op_mul_mat(st0, &da, &db, &dd, c->wdata, c->wsize));
+        return GGML_STATUS_SUCCESS;
+    };
+    // ---- launch-list replay per stream (as be_graph_compute does for one stream): everything a launch depends on goes into a signature; the second identical step is captured,
+    //      one graph per distinct stream (ranks on distinct GPUs: one each; virtual ranks: one for all), and replayed from then on.  CLLM_HIP_TP_GRAPH=0: every launch issued ----
+    static const bool tp_graph = !getenv("CLLM_HIP_TP_GRAPH") || atoi(getenv("CLLM_HIP_TP_GRAPH")) != 0;
+    std::vector<uint64_t> sig;
+    {
+        auto put = [&](const void * p) { sig.push_back((uint64_t)(uintptr_t) p); };
+        auto putf = [&](float f) { uint32_t u; memcpy(&u, &f, 4); sig.push_back(u); };
+        sig.push_back((uint64_t) N); sig.push_back((uint64_t) L); sig.push_back((uint64_t) d.H); sig.push_back((uint64_t) d.F); sig.push_back((uint64_t) d.hd); sig.push_back((uint64_t) d.ML);
+        sig.push_back((uint64_t) tq | (uint64_t) to << 8 | (uint64_t) tg << 16 | (uint64_t) td << 24 | (uint64_t) wh->type << 32); sig.push_back((uint64_t) A0.mode); putf(A0.freq_base); putf(eps_h);
+        sig.push_back((uint64_t) sharded | (uint64_t)(fh != nullptr) << 1 | (uint64_t) table << 2);
+        put(logits); put(curx); put(hn ? hn->data : nullptr); put(hn ? hn->src[0]->src[0]->data : nullptr); put(hm ? hm->src[0]->data : nullptr); put(hm ? hm->src[1]->data : nullptr); put(c->wdata);
+        for (int k = 0; k < N; k++) {
+            const tp_rank & R = T.r[(size_t) k]; const tp_split & s0 = S[(size_t) k]; const rk & x = X[(size_t) k];
+            put(R.stream); put(R.fused); put(R.scratch); put(R.kv_table); sig.push_back((uint64_t) s0.kv0 << 32 | (uint64_t) s0.kvc); sig.push_back((uint64_t) s0.f0 << 32 | (uint64_t) s0.fc);
+            sig.push_back((uint64_t)(x.score_bytes != 0));
+            put(HW[(size_t) k].wrows); put(HW[(size_t) k].nw); sig.push_back((uint64_t) HW[(size_t) k].v0); sig.push_back((uint64_t) HW[(size_t) k].vc);
+            for (int l = 0; l < L; l++) { const ls & o = SH[(size_t) k][(size_t) l]; put(o.qkv); put(o.bias); put(o.o); put(o.gu); put(o.dn); put(o.an); put(o.fn); put(R.kv_mem[(size_t) 2 * l]); put(R.kv_mem[(size_t) 2 * l + 1]); putf(W[(size_t) l].an_eps); putf(W[(size_t) l].fn_eps); }
         }
     }
-    for (int k = 0; k < N; k++) {                 // this step's cache row back into the host's caches; then everything joins rank 0's stream
-        tp_rank & R = T.r[(size_t) k]; const tp_split & s = S[(size_t) k]; rk & x = X[(size_t) k];
-        cllm_set_device(R.gpu);
-        TPC(cllm_op_kv_shard_copy(R.stream, R.kv_table, L, (int)(s.kvc * d.hd), (int)(d.nkv * d.hd), (int)(s.kv0 * d.hd), d.ML, 0, 0, x.pos, 1));
-        if (R.own_stream) { TPC(cllm_event_record(R.ev, R.stream)); cllm_set_device(c->device); TPC(cllm_stream_wait_event(st0, R.ev)); }
+    std::vector<void *> streams;                   // the distinct streams, rank order
+    for (int k = 0; k < N; k++) { bool seen = false; for (void * q : streams) seen = seen || q == T.r[(size_t) k].stream; if (!seen) streams.push_back(T.r[(size_t) k].stream); }
+    auto gpu_of = [&](void * q) { for (int k = 0; k < N; k++) if (T.r[(size_t) k].stream == q) return T.r[(size_t) k].gpu; return c->device; };
+    bool replayed = false;
+    if (tp_graph && !T.graph_broken && T.execs.size() == streams.size() && !T.execs.empty() && sig == T.graph_sig) {
+        for (size_t q = 0; q < streams.size(); q++) { cllm_set_device(gpu_of(streams[q])); TPC(cllm_graph_launch(T.execs[q], streams[q])); }
+        replayed = true; T.replays++;
+    } else if (tp_graph && !T.graph_broken && sig == T.last_sig) {      // second time in a row: capture one graph per stream, then launch them
+        if (!T.execs.empty()) { for (void * q : streams) { cllm_set_device(gpu_of(q)); cllm_stream_sync(q); } }      // (a replaced graph may still be running)
+        for (void * e : T.execs) if (e) cllm_graph_destroy(e);
+        T.execs.clear(); T.graph_sig.clear();
+        bool ok = true;
+        for (size_t q = 0; q < streams.size() && ok; q++) {
+            cllm_set_device(gpu_of(streams[q]));
+            if (cllm_graph_capture_begin(streams[q]) != CLLM_OK) { ok = false; break; }
+            const ggml_status rs = issue(streams[q]);
+            void * exec = nullptr;
+            cllm_set_device(gpu_of(streams[q]));
+            const int rc = cllm_graph_capture_end(streams[q], &exec);
+            if (rs != GGML_STATUS_SUCCESS || rc != CLLM_OK || !exec) { if (exec) cllm_graph_destroy(exec); ok = false; break; }
+            T.execs.push_back(exec);
+        }
+        if (!ok) {                                 // nothing ran (captures execute nothing): issue the step the plain way, and stop trying
+            HIPB_LOG("tensor parallel: launch-list capture failed (%s): issuing the launches of every step from now on", cllm_last_error());
+            for (void * e : T.execs) if (e) cllm_graph_destroy(e);
+            T.execs.clear(); T.graph_broken = true;
+            const ggml_status rs = issue(nullptr);
+            if (rs != GGML_STATUS_SUCCESS) return rs;
+        } else {
+            T.graph_sig = sig; T.captures++;
+            for (size_t q = 0; q < streams.size(); q++) { cllm_set_device(gpu_of(streams[q])); TPC(cllm_graph_launch(T.execs[q], streams[q])); }
+            replayed = true;
+        }
+    } else {
+        const ggml_status rs = issue(nullptr);
+        if (rs != GGML_STATUS_SUCCESS) return rs;
+    }
+    T.last_sig.swap(sig);
+    for (int k = 0; k < N; k++) {                 // everything joins rank 0's stream
+        tp_rank & R = T.r[(size_t) k];
+        if (R.own_stream) { cllm_set_device(R.gpu); TPC(cllm_event_record(R.ev, R.stream)); cllm_set_device(c->device); TPC(cllm_stream_wait_event(st0, R.ev)); }
     }
 #undef TPC
 #undef TP_NO
     cllm_set_device(c->device);
     T.steps++; T.last_tp = true;
-    if (g_stats) HIPB_LOG("HIP0 graph_compute: %d nodes -> tensor parallel over %d ranks: %d launches per rank (%d layers x 5 + head), all-reduce fused into the mat-vecs", ggml_graph_n_nodes(g), N, 5 * L + 6, L);
+    if (g_stats) HIPB_LOG("HIP0 graph_compute: %d nodes -> tensor parallel over %d ranks: %d launches per rank (%d layers x 5 + head%s)%s, all-reduce fused into the mat-vecs", ggml_graph_n_nodes(g), N, 5 * L + 6, L,
+                          sharded ? ", lm_head rows sharded" : "", replayed ? ", replayed from the captured graphs" : "");
     return GGML_STATUS_SUCCESS;
 }
 

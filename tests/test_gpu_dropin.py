@@ -617,14 +617,22 @@ def test_tensor_parallel_behind_the_ggml_boundary(gpu, tmp_path, arch, wt, over)
         assert f"tensor parallel: {n} ranks behind one ggml device" in err, err[-1500:]
         steps = [ln for ln in err.splitlines() if "-> tensor parallel over" in ln]
         assert len(steps) == n_dec - 1, (len(steps), err[-1500:])                 # every single-token step ran sharded; the prompt and the second turn's chunk did not
+        assert sum("replayed from the captured graphs" in ln for ln in steps) >= 4, steps[-3:]      # the sharded step's launch list is captured (2nd identical step) and replayed, before and after the chunk
+        assert all("lm_head rows sharded" in ln for ln in steps)
         assert "timed out" not in err
         assert np.array_equal(lg_1[0].view(np.uint32), lg_n[0].view(np.uint32))   # the prompt ran un-sharded on rank 0: the single device's bits
         dev, clear = _tolerance_tier(lg_1, lg_n, ids_1, 0.25)
+        if n == 4:
+            lg_4 = lg_n
         print(f"{arch} wtype {wt}: {n} ranks behind one device: max|dlogit| {dev:.3e} sigma, steps with a clear margin {clear:.2f}")
     # the cross-stream path distinct GPUs take (every rank its own stream, the embedding row / position handed over behind an event, the ranks' streams joined into rank 0's at the
     # end of the step, gathers polling for scatters that run concurrently) on the one GPU: small shapes, every launch resident at once
     ids_s, lg_s, err = _host_run(tmp_path, mp, "all", n_dec, prompt, cfg["vocab"], teacher=ids_1, threads=4, CLLM_HIP_TP="2", CLLM_HIP_TP_STREAMS="1", CLLM_HIP_TP_DEBUG="1", **turn2)
     assert len([ln for ln in err.splitlines() if "-> tensor parallel over" in ln]) == n_dec - 1 and "timed out" not in err, err[-1500:]
+    assert sum("replayed from the captured graphs" in ln for ln in err.splitlines()) >= 4                 # one captured graph per stream
+    ids_e, lg_e, err = _host_run(tmp_path, mp, "all", n_dec, prompt, cfg["vocab"], teacher=ids_1, threads=4, CLLM_HIP_TP="4", CLLM_HIP_TP_GRAPH="0", CLLM_HIP_TP_HEAD="0", **turn2)
+    assert "replayed from the captured graphs" not in err and "lm_head rows sharded" not in err
+    assert np.array_equal(lg_e.view(np.uint32), lg_4.view(np.uint32))                                         # replay and the sharded head change no bit of the sharded run
     dev, clear = _tolerance_tier(lg_1, lg_s, ids_1, 0.25)
     print(f"{arch} wtype {wt}: 2 ranks on streams of their own: max|dlogit| {dev:.3e} sigma")
 
