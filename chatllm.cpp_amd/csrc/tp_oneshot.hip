@@ -157,6 +157,15 @@ int cllm_tp_oneshot_error(void * os) {
     if (hipMemcpy(&e, o->err, 4, hipMemcpyDeviceToHost) != hipSuccess) return 1;
     return (int) e;
 }
+// the error word is sticky.  After the host has reported the time-out (cllm_tp_oneshot_error) and brought every rank to a common boundary (all streams idle, the
+// same number of all-reduces issued on every rank), this clears it; the sequence numbers are untouched (they only ever advance together).
+extern "C" __attribute__((visibility("default")))
+int cllm_tp_oneshot_clear_error(void * os) {
+    tp_oneshot * o = (tp_oneshot *) os;
+    if (!o || !o->seq) FAIL(CLLM_E_INVALID, "tp_oneshot_clear_error: null");
+    HIP_TRY(hipMemset(o->seq + 1, 0, 4));
+    return CLLM_OK;
+}
 extern "C" __attribute__((visibility("default")))
 int cllm_tp_oneshot_destroy(void * os) {
     tp_oneshot * o = (tp_oneshot *) os;

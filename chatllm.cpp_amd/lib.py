@@ -142,6 +142,7 @@ SIGNATURES = {
     "cllm_tp_oneshot_all_reduce_f32": (C.c_int, [_P, _P, _P, C.c_size_t]),
     "cllm_tp_oneshot_error": (C.c_int, [_P]),
     "cllm_tp_oneshot_fine_grained": (C.c_int, [_P]),
+    "cllm_tp_oneshot_clear_error": (C.c_int, [_P]),
     "cllm_tp_oneshot_destroy": (C.c_int, [_P]),
     "cllm_llama_set_tp_oneshot": (C.c_int, [_P, _P]),
     "cllm_tp_fused_create": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_size_t, C.POINTER(C.c_void_p), _P]),

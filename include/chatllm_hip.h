@@ -385,6 +385,7 @@ CLLM_API int  cllm_tp_oneshot_connect(void * os, const void * handles);
 CLLM_API int  cllm_tp_oneshot_all_reduce_f32(void * os, void * stream, float * buf, size_t n);
 CLLM_API int  cllm_tp_oneshot_error(void * os);           /* 1: a flag wait timed out since creation (the runner checks it after every step's synchronize and fails the step) */
 CLLM_API int  cllm_tp_oneshot_fine_grained(void * os);    /* 1: fine-grained (cross-GPU coherent) receive buffer; 0: coarse-grained, only accepted with CLLM_TP_ONESHOT_SAME_DEVICE=1 */
+CLLM_API int  cllm_tp_oneshot_clear_error(void * os);     /* after a reported time-out, every rank at a common boundary: clears the sticky error word */
 CLLM_API int  cllm_tp_oneshot_destroy(void * os);
 CLLM_API int  cllm_llama_set_tp_oneshot(cllm_llama * m, void * os);
 /* The all-reduce FUSED into the neighbouring mat-vecs of a single-token step (gemv_tp.hip; nothing in the reference to replace: SplitMethod::Row is a TODO,
