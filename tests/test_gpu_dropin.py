@@ -654,3 +654,28 @@ def test_tensor_parallel_device_runs_everything_else_unsharded_and_bit_identical
         ids_b, lg_b, err = _host_run(tmp_path, mp, ngl, 10, prompt, cfg["vocab"], CLLM_HIP_TP="2", CLLM_HIP_TP_DEBUG="1", **extra)
         assert "-> tensor parallel over" not in err                              # no step was taken sharded ...
         assert ids_a == ids_b and np.array_equal(lg_a.view(np.uint32), lg_b.view(np.uint32)), (mp, ngl, extra)      # ... and nothing changed
+
+
+@_BIG
+@pytest.mark.parametrize("arch,cname,over,prompt_mod", [("qwen2", "qwen2-72b", dict(max_len=256, n_layer=2), 150000), ("llama3", "llama3-8b", dict(max_len=256, n_layer=2), 128000)])
+def test_tensor_parallel_behind_the_boundary_at_real_block_shapes(gpu, tmp_path, arch, cname, over, prompt_mod):
+    """BASELINE cfg4's and cfg2's BLOCK shapes under CLLM_HIP_TP=8 through the unmodified host (2 of the layers: 2.6 / 1.5 GB files): Qwen2-72B -- hidden 8192 (the gather prologue's
+    four-values-per-lane x 4 passes form, 8 ranks' granules per element), 64 heads / 8 KV heads (one KV group per rank), ffn 29568 with the Q8_0 down projection (924 blocks ->
+    4 x 116 + 4 x 115, gate/up rows follow), q/k/v biases sharded, a 152064-row lm_head sharded by rows; Llama-3-8B -- hidden 4096, ffn 14336 = 56 Q4_K blocks -> 7 per rank.
+    Teacher-forced against the single-device run: tolerance tier; every step sharded and replayed from the captured graph."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import make_ggmm
+    cfg = gpu.synth.config(cname, **over)
+    mp = str(tmp_path / "m.bin")
+    make_ggmm.write_model(mp, cfg, 12, seed=41, fast=True, arch=arch)
+    prompt = [(13 * i + 7) % prompt_mod for i in range(12)]
+    n_dec = 10
+    ids_1, lg_1, _ = _host_run(tmp_path, mp, "all", n_dec, prompt, cfg["vocab"], threads=8)
+    ids_8, lg_8, err = _host_run(tmp_path, mp, "all", n_dec, prompt, cfg["vocab"], teacher=ids_1, threads=8, CLLM_HIP_TP="8", CLLM_HIP_TP_DEBUG="1")
+    os.remove(mp)
+    steps = [ln for ln in err.splitlines() if "-> tensor parallel over 8 ranks" in ln]
+    assert len(steps) == n_dec and "timed out" not in err, err[-1500:]
+    assert all("lm_head rows sharded" in ln for ln in steps) and sum("replayed from the captured graphs" in ln for ln in steps) >= n_dec - 2
+    assert np.array_equal(lg_1[0].view(np.uint32), lg_8[0].view(np.uint32))          # the prompt: un-sharded
+    dev, clear = _tolerance_tier(lg_1, lg_8, ids_1, 0.25)
+    print(f"{cname} block shapes, 8 ranks behind one device: max|dlogit| {dev:.3e} sigma, steps with a clear margin {clear:.2f}")
