@@ -16,7 +16,9 @@ Extra objects on the JSON line (rank 0, N = 1):
                  pass that bench.py spawns over the same kernel (--no-pmc: null)
   "cpu_baseline" the reference HOST itself (oracle/_ref/ref_chat = chatllm.cpp's graph builder + ggml scheduler + CPU backend, compiled from
                  /root/reference) decoding the same synthetic model end to end on this box's cores: median of 3 runs; "host_cores" = cores of the
-                 box, "cores" = threads used (best of a sweep that includes all cores), "build" = x86-64-v3 (the parity oracle) or avx512 (baseline only), whichever is faster
+                 box, "cores" = threads used (best of an ascending sweep 8 .. all cores with an early stop: the reference's thread pool peaks at 16 on the 256-core box),
+                 "build" = x86-64-v3 (the parity oracle) or avx512 (baseline only), whichever is faster
+  "other_types"  the north star's other two weight types at the same shapes (Q4_0, Q8_0): tok/s and model-level roofline fraction of the same 20-step measurement
   "dropin"       the SAME unmodified host with every layer on our ggml module (-ngl all): the through-the-boundary number (also "dropin_tok_s")
   "prefill"      BASELINE cfg3: Llama-3-8B shapes, Q4_0, one 4096-token prompt through the runner (median of 3), fraction of the matrix-core peak, in the default
                  (exact-order) mode and in the opt-in fast mode
