@@ -149,7 +149,7 @@ def measure_dominant_kernel(pkg, cfg, wtype, iters=64):
     pkg.lib.check(L.cllm_bench_gemv_fused(None, wtype, ptrs, n_copies, H, rows, 1, x.data_ptr(), g.data_ptr(), cfg["rms_eps"], epi, y.data_ptr(), None,
                                           iters, C.byref(us)), "bench_gemv_fused")
     dur_s = us.value / 1e6
-    name = "k_gemv_dec<%d, 1, %d, %d>" % (wtype, epi, 1 if H <= 4096 else 4)
+    name = "k_gemv_dec<%d, 1, %d, %d, false, false>" % (wtype, epi, 1 if H <= 4096 else 4)      # (as rocprofv3 prints it: FMT, PRO, EPI, NPRE, MOE, FREE)
     return {"kernel": "%s (gate/up GEMV %dx%d, decode form)" % (name, rows, H), "bytes_per_launch": nbytes, "avg_us": dur_s * 1e6, "gbs": nbytes / dur_s / 1e9}
 
 
@@ -456,8 +456,11 @@ def prefill_cfg3(pkg, model_name, n_prompt=4096, reps=3):
     return res
 
 
-def other_type_decode(pkg, cfg, wt, prompt, steps=20, warmup=5):
-    """the headline measurement for another weight type: same shapes, same prompt, `steps` greedy tokens after `warmup`; model-level fraction of the 8 TB/s roofline"""
+def other_type_decode(pkg, cfg, wt, prompt, steps=20, warmup=5, free_order=False):
+    """the headline measurement for another weight type: same shapes, same prompt, `steps` greedy tokens after `warmup`; model-level fraction of the 8 TB/s roofline.
+    free_order: the opt-in tolerance tier of the 32-weight block formats (gemv_free32.hip) instead of the exact order -- priced next to it, never the default"""
+    L = pkg.lib.get()
+    L.cllm_set_decode_free_order(1 if free_order else 0)
     m = build_model(pkg, cfg, wt, 0, 1)
     try:
         tok = int(np.argmax(m.forward(prompt, n_past=0)))
@@ -470,9 +473,11 @@ def other_type_decode(pkg, cfg, wt, prompt, steps=20, warmup=5):
         b = pkg.synth.weight_bytes_per_token(cfg, wt) + pkg.synth.kv_bytes_per_token(cfg, len(prompt) + warmup + steps // 2)
         return {"value": steps / dt, "unit": "tokens/s", "steps": steps, "warmup": warmup, "ms_per_step": dt / steps * 1e3, "algorithmic_bytes_per_token": b,
                 "model_hbm_frac": b * steps / dt / (HBM_PEAK_GBS * 1e9), "greedy_tail": [int(t) for t in out[-4:]],
-                "contract": "exact order (every logit bit-identical to the reference's x86-64-v3 CPU build), the only decode path"}
+                "contract": ("FREE fp32 fold order (opt-in CLLM_DECODE_FREE_ORDER=1; integer block sums exact): a tolerance tier, NOT the default -- tests/test_gpu_llama.py says what it keeps"
+                             if free_order else "exact order (every logit bit-identical to the reference's x86-64-v3 CPU build): the default")}
     finally:
         m.close()
+        L.cllm_set_decode_free_order(0)
 
 
 def layer_split(pkg, cfg, iters=16):
@@ -857,6 +862,7 @@ def main():
                     for ot in ("q4_0", "q8_0"):
                         try:
                             res["other_types"][ot] = other_type_decode(pkg, cfg, WTYPES[ot], prompt)
+                            res["other_types"][ot + "_free_order"] = other_type_decode(pkg, cfg, WTYPES[ot], prompt, free_order=True)
                         except Exception as e:      # noqa: BLE001
                             res["other_types"][ot] = {"error": str(e)}
                 if not args.no_prefill and args.model == "llama3-8b":

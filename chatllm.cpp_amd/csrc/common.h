@@ -477,6 +477,8 @@ int launch_gemv_decode_id_router_silu(hipStream_t st, int wtype, const void * W,
 int launch_gemv_kq(hipStream_t st, int wtype, const tview & w, const void * act, size_t act_stride, int64_t M, float * dst, int64_t ldd);
 int launch_gemv_kq_id(hipStream_t st, int wtype, const tview & as, const void * act, size_t act_stride, int64_t ne11, const tview & ids, const tview & dst);
 int launch_dense_f16(hipStream_t st, int wtype, const tview & w, const tview & x, const tview & d, const float * resid = nullptr, int64_t ldr = 0, int epi = 0);
+int decode_free_order();                          // gemv_free32.hip: 1 = the opt-in free-order tier of the 32-weight block formats' decode mat-vec
+int launch_gemv_decode_free(hipStream_t st, int wtype, const void * W, int64_t K, int64_t nrows, int pro, const float * px, const float * pw, float eps, int epi, float * dst, const float * bias, const float * resid);
 int launch_gemv_rows(hipStream_t st, const void * W, int64_t K, int64_t nrows, int pro, const float * px, const float * pw, float eps, int epi, float * dst, const float * bias, const float * resid);
 // ffn_fused.hip: the decode step's FFN block (norm + gate/up + SiLU*up + down + residual) as ONE launch; CLLM_E_UNSUPPORTED: the caller issues the two launches
 size_t ffn_fused_state_bytes(int64_t F);

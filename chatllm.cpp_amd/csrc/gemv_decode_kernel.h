@@ -97,7 +97,8 @@ __device__ __forceinline__ f32x4 tpf_gather4(const tp_fuse_dev * cx, const char 
 // 18 / 20 / 34-byte block, activation quantized to Q8_0 / Q8_1).  nblk = weight blocks per row.
 // MOE (MUL_MAT_ID for one token, ggml_compute_forward_mul_mat_id ggml-cpu.c:1432-1678): blockIdx.y is the slot; the slot's expert comes from
 // device memory (ids[slot], the TOP_K node's output), W / px / dst move by the slot: dst[:, slot] = W[:, :, ids[slot]]^T . x[:, slot or 0]
-template <int FMT, int PRO, int EPI, int NPRE, bool MOE = false>
+// FREE (gemv_free32.hip only, the 32-weight block formats): the opt-in free-order tier -- q32_block_free instead of the chain records; every other instantiation is untouched
+template <int FMT, int PRO, int EPI, int NPRE, bool MOE = false, bool FREE = false>
 __global__ void __launch_bounds__(1024) k_gemv_dec(const float * __restrict__ px, const float * __restrict__ pw, const float * __restrict__ padd,
                                                         const char * __restrict__ W, int nblk, int kfull, int nrem, float eps,
                                                         float * __restrict__ dst, float * __restrict__ xout,
@@ -477,16 +478,17 @@ __global__ void __launch_bounds__(1024) k_gemv_dec(const float * __restrict__ px
             else {
                 uint32_t h; u32x4 w0, w1 = {0, 0, 0, 0};
                 q32_align<IS_K ? CLLM_TYPE_Q4_0 : FMT>(qq[p], q2[IS_Q8 ? p : 0], hh[p].x, hh[p].y, h, w0, w1);
-                q32_emit<IS_K ? CLLM_TYPE_Q4_0 : FMT>(h, w0, w1, arow, off_d, off_s, ok ? b : 0, ok, lane, chain);
+                if constexpr (FREE) acc = acc + q32_block_free<IS_K ? CLLM_TYPE_Q4_0 : FMT>(h, w0, w1, arow, off_d, off_s, ok ? b : 0, ok);
+                else q32_emit<IS_K ? CLLM_TYPE_Q4_0 : FMT>(h, w0, w1, arow, off_d, off_s, ok ? b : 0, ok, lane, chain);
             }
             issue(p);
-            {                                                       // every step: 16 super-blocks (Q4_K) / 64 blocks of records
+            if constexpr (!FREE) {                                  // every step: 16 super-blocks (Q4_K) / 64 blocks of records
                 wave_lds_fence();
                 if (IS_K) q4k_chain(chain, 8, l16, acc); else q32_chain<IS_K ? CLLM_TYPE_Q4_0 : FMT>(chain, l16, acc);
                 wave_lds_fence();
             }
             if (++cs == S) {                                        // row complete: finish the chains, epilogue, store (lane 0)
-                float v = chain_finish<IS_K ? 1 : IS_Q41 ? 2 : 0>(acc);
+                float v = FREE ? wave_sum(acc) : chain_finish<IS_K ? 1 : IS_Q41 ? 2 : 0>(acc);
                 if (ck < nmine) {                                   // wave-uniform; bias / resid come through the scalar cache
                     const int cunit = unit_of(ck), crow = cunit * RU + csub;
                     if (EPI == 1 || EPI == 5) {

@@ -123,3 +123,29 @@ __device__ __forceinline__ void q32_chain(const char * chain, int l16, float & a
         }
     }
 }
+
+// ---- the FREE-ORDER tier (opt-in, CLLM_DECODE_FREE_ORDER=1; gemv_free32.hip): the same exact int32 block dot products, folded as  d_w d_a (float) sumi  with ONE integer sum per
+// block (the eight AVX-lane sums added as integers) into a per-lane fp32 partial sum over the lane's blocks (64 apart), the lanes summed by the wave at the end of the row.  NOT
+// the reference's fp32 order: a tolerance tier by construction (what round 1's kernels were); it exists to price the exact order.
+template <int FMT>
+__device__ __forceinline__ float q32_block_free(uint32_t h, const u32x4 q0, const u32x4 q1, const char * ar, int off_d, int off_s, int bb, bool ok) {
+    const float d = h2f((uint16_t) h);
+    const u32x4 a0 = *(const u32x4 *)(ar + bb * 32);
+    const u32x4 a1 = *(const u32x4 *)(ar + bb * 32 + 16);
+    const float yd = ((const float *)(ar + off_d))[bb];
+    int s = 0;
+    if constexpr (q32_fmt<FMT>::IS_Q8) {
+        s = dot4(q0.x, a0.x, s); s = dot4(q0.y, a0.y, s); s = dot4(q0.z, a0.z, s); s = dot4(q0.w, a0.w, s);
+        s = dot4(q1.x, a1.x, s); s = dot4(q1.y, a1.y, s); s = dot4(q1.z, a1.z, s); s = dot4(q1.w, a1.w, s);
+    } else {
+        s = dot4(q0.x & 0x0f0f0f0fu, a0.x, s); s = dot4(q0.y & 0x0f0f0f0fu, a0.y, s); s = dot4(q0.z & 0x0f0f0f0fu, a0.z, s); s = dot4(q0.w & 0x0f0f0f0fu, a0.w, s);
+        s = dot4((q0.x >> 4) & 0x0f0f0f0fu, a1.x, s); s = dot4((q0.y >> 4) & 0x0f0f0f0fu, a1.y, s); s = dot4((q0.z >> 4) & 0x0f0f0f0fu, a1.z, s); s = dot4((q0.w >> 4) & 0x0f0f0f0fu, a1.w, s);
+        if constexpr (!q32_fmt<FMT>::IS_Q41) {          // Q4_0: (nib - 8) . a = nib . a - 8 sum(a)
+            s = dot4(0xf8f8f8f8u, a0.x, s); s = dot4(0xf8f8f8f8u, a0.y, s); s = dot4(0xf8f8f8f8u, a0.z, s); s = dot4(0xf8f8f8f8u, a0.w, s);
+            s = dot4(0xf8f8f8f8u, a1.x, s); s = dot4(0xf8f8f8f8u, a1.y, s); s = dot4(0xf8f8f8f8u, a1.z, s); s = dot4(0xf8f8f8f8u, a1.w, s);
+        }
+    }
+    float v = (d * yd) * (float) s;
+    if constexpr (q32_fmt<FMT>::IS_Q41) v = __builtin_fmaf(h2f((uint16_t)(h >> 16)), ((const float *)(ar + off_s))[bb], v);      // + m_w s_a
+    return ok ? v : 0.0f;
+}

@@ -74,6 +74,8 @@ SIGNATURES = {
     "cllm_get_prefill_mode": (C.c_int, []),
     "cllm_set_prefill_attn_mode": (C.c_int, [C.c_int]),
     "cllm_op_mul_mat_ex": (C.c_int, [_P, _T, _T, _T, _P, C.c_size_t, C.c_int, _T, C.c_float, C.c_int, _T]),
+    "cllm_set_decode_free_order": (C.c_int, [C.c_int]),
+    "cllm_get_decode_free_order": (C.c_int, []),
     "cllm_ffn_fused_state_bytes": (C.c_size_t, [C.c_int64]),
     "cllm_op_ffn_fused": (C.c_int, [_P, _T, _T, _P, _P, C.c_float, _P, _P]),
     "cllm_bench_ffn": (C.c_int, [_P, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_int, C.c_int64, C.c_int64, _P, _P, C.c_float, _P, _P, C.c_int, C.c_int, C.POINTER(C.c_float)]),

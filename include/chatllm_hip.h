@@ -141,6 +141,12 @@ CLLM_API int    cllm_set_prefill_attn_mode(int mode);
 CLLM_API int    cllm_op_mul_mat_ex(void * stream, const cllm_tensor * src0, const cllm_tensor * src1, cllm_tensor * dst, void * wdata, size_t wsize,
                                    int pro, const cllm_tensor * norm_w, float eps, int epi, const cllm_tensor * resid);
 
+/* OPT-IN tolerance tier of the single-column mat-vec for the 32-weight block formats (Q4_0 / Q4_1 / Q8_0; gemv_free32.hip; also CLLM_DECODE_FREE_ORDER=1): the exact int32 block
+ * dot products of ggml_vec_dot_q4_0_q8_0 / q4_1_q8_1 / q8_0_q8_0 (ggml-cpu/arch/x86/quants.c:543-577, 701-760, 1012-1040) folded in a FREE fp32 order (per lane, then across the
+ * wave) instead of the reference's eight per-AVX-lane chains.  Default 0: every decode mat-vec is bit-identical to the reference's CPU build. */
+CLLM_API int    cllm_set_decode_free_order(int on);
+CLLM_API int    cllm_get_decode_free_order(void);
+
 /* The FFN block of ONE token (BaseMLP::forward src/layers.cpp:2475-2497 behind LMBlock1Forward's post_attention_layernorm and residual add :2744-2758) as ONE launch:
  *     xout = Wdown . q8_K(SiLU(Wgate . a) * (Wup . a)) + x,   a = q8_K(RMS_NORM(x, eps) * norm_w)
  * i.e. the nodes RMS_NORM -> MUL -> MUL_MAT x 2 -> UNARY(SILU) -> MUL -> MUL_MAT -> ADD, bit for bit (ggml_compute_forward_mul_mat ggml-cpu.c:1229-1421 per mat-mul).

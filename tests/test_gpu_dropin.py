@@ -679,3 +679,38 @@ def test_tensor_parallel_behind_the_boundary_at_real_block_shapes(gpu, tmp_path,
     assert np.array_equal(lg_1[0].view(np.uint32), lg_8[0].view(np.uint32))          # the prompt: un-sharded
     dev, clear = _tolerance_tier(lg_1, lg_8, ids_1, 0.25)
     print(f"{cname} block shapes, 8 ranks behind one device: max|dlogit| {dev:.3e} sigma, steps with a clear margin {clear:.2f}")
+
+
+@_BIG
+@pytest.mark.parametrize("wname,wt", [("q4_0", 2), ("q8_0", 8)])
+def test_free_order_tier_at_llama3_8b_shapes_against_the_exact_order(gpu, wname, wt):
+    """the review's contract question for the north star's other two weight types: the opt-in free-order decode (gemv_free32.hip) at BASELINE cfg2's shapes, FREE-RUNNING greedy
+    from the same 16-token prompt against the exact-order default.  MEASURED (round 6): the 32 greedy ids are identical, the logits are NOT within the north star's 1e-3
+    (max|dlogit| ~ 0.1 at sigma ~ 1: the Q8_0 activation quantizers of 32 layers turn last-bit differences of the fp32 fold into flipped int8 steps) -- which is why the exact
+    order is the decode contract and this tier is opt-in only.  Asserted: what the tier does keep (ids over 32 steps, logits within 0.25 sigma), and that it is outside 1e-3."""
+    sys.path.insert(0, ROOT)
+    import bench
+    L = gpu.lib.get()
+    cfg = gpu.synth.config("llama3-8b", max_len=256)
+    prompt = np.asarray(bench.PROMPT_IDS, np.int32)
+    out = {}
+    try:
+        for mode in (0, 1):
+            L.cllm_set_decode_free_order(mode)
+            m = bench.build_model(gpu, cfg, wt, 0, 1)
+            lg = [m.forward(prompt, n_past=0)]
+            ids = []
+            for _ in range(32):
+                ids.append(int(np.argmax(lg[-1])))
+                lg.append(m.decode_fused_logits(ids[-1]))
+            out[mode] = (ids, np.stack(lg))
+            m.close()
+    finally:
+        L.cllm_set_decode_free_order(0)
+    (ids_e, lg_e), (ids_f, lg_f) = out[0], out[1]
+    mism = sum(int(a != b) for a, b in zip(ids_e, ids_f))
+    same = min([i for i, (a, b) in enumerate(zip(ids_e, ids_f)) if a != b] or [len(ids_e)])
+    dev = float(np.max(np.abs(lg_e[:same + 1] - lg_f[:same + 1])))
+    print(f"llama3-8b {wname}: free order vs exact order, free-running: id mismatches {mism}/32, max|dlogit| over the common prefix {dev:.3e} (sigma {float(np.std(lg_e)):.3f})")
+    assert mism == 0 and dev < 0.25 * float(np.std(lg_e)), (mism, dev)
+    assert dev > 1e-3                              # (the day this fails, the contract question is open again)

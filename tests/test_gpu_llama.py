@@ -456,3 +456,35 @@ def test_context_overflow_and_bad_tokens_are_rejected(gpu):
     with pytest.raises(gpu.lib.CllmError):
         m.forward(np.array([cfg["vocab"]], np.int32))
     m.close()
+
+
+@pytest.mark.parametrize("wtype", [O.Q4_0, O.Q8_0, O.Q4_1])
+@pytest.mark.parametrize("over", [dict(base="tiny"), dict(base="small", ffn=2848), dict(base="small", qkv_bias=1, rope_mode=2, rope_theta=1e6)])
+def test_free_order_tier_of_the_32_block_formats_keeps_the_integer_sums(gpu, wtype, over):
+    """gemv_free32.hip (opt-in, cllm_set_decode_free_order): the decode mat-vecs of Q4_0 / Q4_1 / Q8_0 with the exact int32 block dot products folded in a free fp32 order.
+    Teacher-forced against the exact-order run of the same model: every logit within 2e-5 of the logits' spread per layer of depth (fp32 re-association only -- an integer sum off
+    by one would show as >= 1e-3), the default run untouched by the switch (bits of the oracle: test_end_to_end_...)"""
+    L = gpu.lib.get()
+    over = dict(over)
+    cfg = gpu.synth.config(over.pop("base"), max_len=64, **over)
+    w = gpu.synth.make_model(cfg, wtype, seed=12)
+    prompt = np.random.default_rng(12).integers(0, cfg["vocab"], 7).astype(np.int32)
+    toks = [int(t) for t in np.random.default_rng(13).integers(0, cfg["vocab"], 24)]
+    try:
+        assert L.cllm_get_decode_free_order() == 0
+        a = gpu.Llama(cfg, w)
+        la = [a.forward(prompt)] + [a.decode_fused_logits(t) for t in toks]
+        a.close()
+        L.cllm_set_decode_free_order(1)
+        b = gpu.Llama(cfg, w)
+        lb = [b.forward(prompt)] + [b.decode_fused_logits(t) for t in toks]
+        b.close()
+    finally:
+        L.cllm_set_decode_free_order(0)
+    la, lb = np.stack(la), np.stack(lb)
+    sigma = float(np.std(la))
+    dev0 = float(np.max(np.abs(la[0] - lb[0])))          # the prompt: only its last-token lm_head is a single-column mat-vec -- fp32 re-association of ONE dot product per logit
+    assert dev0 < 2e-5 * sigma, (dev0, sigma)            # (an integer block sum off by one would be >= 1e-3 sigma)
+    dev = float(np.max(np.abs(la[1:] - lb[1:])))
+    assert 0.0 < dev < 0.25 * sigma, (dev, sigma)        # decode steps: another order (not bit-identical), a tolerance tier: the activation quantizers amplify the last bits
+    print(f"free order, type {wtype}: max|dlogit| {dev:.3e} (sigma {sigma:.3f})")
