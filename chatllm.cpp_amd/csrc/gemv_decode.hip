@@ -12,7 +12,7 @@ int launch_gemv_decode(hipStream_t st, int wtype, const void * W, int64_t K, int
                        int epi, float * dst, const float * bias, const float * resid, const float * padd, float * xout) {
     const int kind = wtype == CLLM_TYPE_Q4_K ? 256 : 32;
     if (!is_quant_type(wtype)) return CLLM_E_UNSUPPORTED;
-    if (wtype != CLLM_TYPE_Q4_K && !padd && !g_gemv_ts && decode_free_order()) {      // opt-in: the free-order tier of the 32-weight block formats (gemv_free32.hip)
+    if ((wtype != CLLM_TYPE_Q4_K || decode_free_order() >= 2) && !padd && !g_gemv_ts && decode_free_order()) {      // opt-in: the free-order tier of the 32-weight block formats (gemv_free32.hip)
         const int rc = launch_gemv_decode_free(st, wtype, W, K, nrows, pro, px, pw, eps, epi, dst, bias, resid);
         if (rc != CLLM_E_UNSUPPORTED) return rc;
     }

@@ -474,8 +474,10 @@ __global__ void __launch_bounds__(1024) k_gemv_dec(const float * __restrict__ px
             const int b = IS_K ? 16 * cs + grp : 64 * cs + lane;
             const bool ok = ck < nmine && b < nblk;
             const char * arow = EPI == 3 ? lds + csub * arb : lds;
-            if (IS_K) q4k_emit4(hh[p], qq[p], q2[(IS_Q8 || IS_K) ? p : 0], arow, off_d, off_s, ok ? b : 0, ok, L, chain);
-            else {
+            if (IS_K) {
+                if constexpr (FREE) acc = acc + q4k_block_free4(hh[p], qq[p], q2[(IS_Q8 || IS_K) ? p : 0], arow, off_d, off_s, ok ? b : 0, ok, L);
+                else q4k_emit4(hh[p], qq[p], q2[(IS_Q8 || IS_K) ? p : 0], arow, off_d, off_s, ok ? b : 0, ok, L, chain);
+            } else {
                 uint32_t h; u32x4 w0, w1 = {0, 0, 0, 0};
                 q32_align<IS_K ? CLLM_TYPE_Q4_0 : FMT>(qq[p], q2[IS_Q8 ? p : 0], hh[p].x, hh[p].y, h, w0, w1);
                 if constexpr (FREE) acc = acc + q32_block_free<IS_K ? CLLM_TYPE_Q4_0 : FMT>(h, w0, w1, arow, off_d, off_s, ok ? b : 0, ok);

@@ -9,23 +9,26 @@
 
 static int g_free_order = -1;
 int decode_free_order() { if (g_free_order < 0) g_free_order = getenv("CLLM_DECODE_FREE_ORDER") ? atoi(getenv("CLLM_DECODE_FREE_ORDER")) : 0; return g_free_order; }
-extern "C" CLLM_API int cllm_set_decode_free_order(int on) { g_free_order = on ? 1 : 0; return CLLM_OK; }
+extern "C" CLLM_API int cllm_set_decode_free_order(int on) { g_free_order = on < 0 ? 0 : on > 2 ? 2 : on; return CLLM_OK; }
 extern "C" CLLM_API int cllm_get_decode_free_order(void) { return decode_free_order(); }
 
 // the forms the decode step uses: pro 1 (RMS_NORM, + SiLU * up epilogue), pro 2 (plain quantize); anything else: CLLM_E_UNSUPPORTED -> the exact kernels
 int launch_gemv_decode_free(hipStream_t st, int wtype, const void * W, int64_t K, int64_t nrows, int pro, const float * px, const float * pw, float eps,
                             int epi, float * dst, const float * bias, const float * resid) {
-    if (wtype != CLLM_TYPE_Q4_0 && wtype != CLLM_TYPE_Q4_1 && wtype != CLLM_TYPE_Q8_0) return CLLM_E_UNSUPPORTED;
+    // Q4_K: only with CLLM_DECODE_FREE_ORDER=2 -- a PRICING experiment (what the exact order costs the headline kernel), never a product tier: see q4k_block_free4
+    if (wtype == CLLM_TYPE_Q4_K) { if (decode_free_order() < 2) return CLLM_E_UNSUPPORTED; }
+    else if (wtype != CLLM_TYPE_Q4_0 && wtype != CLLM_TYPE_Q4_1 && wtype != CLLM_TYPE_Q8_0) return CLLM_E_UNSUPPORTED;
+    const int kind = wtype == CLLM_TYPE_Q4_K ? 256 : 32;
     if ((pro != 1 && pro != 2) || (epi != 0 && epi != 1) || (epi == 1 && pro != 1)) return CLLM_E_UNSUPPORTED;
-    if (K % 32 || K > (pro == 2 ? 32768 : 16384) || nrows <= 0 || (uint64_t) nrows * (uint64_t) cllm_row_size(wtype, K) >= (1ull << 32)) return CLLM_E_UNSUPPORTED;
-    if (act_row_bytes(K, 32) + 16 * Q32_CHAIN_BYTES > 160 * 1024) return CLLM_E_UNSUPPORTED;
+    if (K % kind || K > (pro == 2 ? 32768 : 16384) || nrows <= 0 || (uint64_t) nrows * (uint64_t) cllm_row_size(wtype, K) >= (1ull << 32)) return CLLM_E_UNSUPPORTED;
+    if (act_row_bytes(K, kind) + 16 * Q32_CHAIN_BYTES > 160 * 1024) return CLLM_E_UNSUPPORTED;
     if (epi == 1 && (nrows % 2 || (nrows / 2) % 8 || bias || resid)) return CLLM_E_UNSUPPORTED;
     const int64_t units = epi == 1 ? nrows / 2 : nrows;
     int64_t grid = (units + 15) / 16;
     if (grid > device_cu_count()) grid = device_cu_count();
     const int64_t nwaves = grid * 16;
-    const int kfull = (int)(units / nwaves), nrem = (int)(units % nwaves), nblk = (int)(K / 32);
-    const size_t lds = act_row_bytes(K, 32) + 16 * (size_t) Q32_CHAIN_BYTES;      // (the record area stays: the kernel's LDS layout is k_gemv_dec's)
+    const int kfull = (int)(units / nwaves), nrem = (int)(units % nwaves), nblk = (int)(K / kind);
+    const size_t lds = act_row_bytes(K, kind) + 16 * (size_t)(wtype == CLLM_TYPE_Q4_K ? Q4K_CHAIN_BYTES : Q32_CHAIN_BYTES);      // (the record area stays: the kernel's LDS layout is k_gemv_dec's)
     const int npre = K <= 4096 ? 1 : K <= 16384 ? 4 : 8;
     if (pro == 1 && npre == 8) return CLLM_E_UNSUPPORTED;
 #define GOF3(FMT_, PRO_, EPI_, NPRE_) do { \
@@ -37,7 +40,7 @@ int launch_gemv_decode_free(hipStream_t st, int wtype, const void * W, int64_t K
         if (pro == 1 && epi == 1) { if (npre == 1) GOF3(FMT_, 1, 1, 1); else GOF3(FMT_, 1, 1, 4); } \
         else if (pro == 1)        { if (npre == 1) GOF3(FMT_, 1, 0, 1); else GOF3(FMT_, 1, 0, 4); } \
         else                      { if (npre == 1) GOF3(FMT_, 2, 0, 1); else if (npre == 4) GOF3(FMT_, 2, 0, 4); else GOF3(FMT_, 2, 0, 8); } } while (0)
-    if (wtype == CLLM_TYPE_Q4_0) GOF(CLLM_TYPE_Q4_0); else if (wtype == CLLM_TYPE_Q4_1) GOF(CLLM_TYPE_Q4_1); else GOF(CLLM_TYPE_Q8_0);
+    if (wtype == CLLM_TYPE_Q4_K) GOF(CLLM_TYPE_Q4_K); else if (wtype == CLLM_TYPE_Q4_0) GOF(CLLM_TYPE_Q4_0); else if (wtype == CLLM_TYPE_Q4_1) GOF(CLLM_TYPE_Q4_1); else GOF(CLLM_TYPE_Q8_0);
 #undef GOF
 #undef GOF3
     LAUNCH_CHECK();

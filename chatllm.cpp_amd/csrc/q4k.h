@@ -165,6 +165,36 @@ __device__ __forceinline__ void q4k_emit4(const u32x4 h, const u32x4 qa, const u
     *(float2 *)(rec + L.wm_off)     = float2{(float) pm, dm};
 }
 
+// FREE-ORDER pricing form (gemv_free32.hip, CLLM_DECODE_FREE_ORDER=2 only -- never a product path: Q4_K's Q8_K activations put any other fp32 order 0.5 sigma away at depth,
+// profiles/r06_prefill_mode_decomposition.txt): q4k_emit4's exact integer sums of this lane's 64-weight chunk, folded at once  dd (float) sum_A t[A] + dm (float) pm  -- the four
+// lanes of a super-block and all its blocks meet in the wave's final sum.  What it measures: how much of the decode mat-vec's time is the reference's accumulation order.
+__device__ __forceinline__ float q4k_block_free4(const u32x4 h, const u32x4 qa, const u32x4 qb, const char * ar, int off_d, int off_s, int bb, bool ok, const q4k_sel4 & L) {
+    const float d    = h2f((uint16_t)(h.x & 0xffff));
+    const float dmin = h2f((uint16_t)(h.x >> 16));
+    const uint32_t u0 = h.y & 0x3f3f3f3fu;
+    const uint32_t u2 = h.z & 0x3f3f3f3fu;
+    const uint32_t u1 = (h.w & 0x0f0f0f0fu) | (((h.y >> 6) & 0x03030303u) << 4);
+    const uint32_t u3 = ((h.w >> 4) & 0x0f0f0f0fu) | (((h.z >> 6) & 0x03030303u) << 4);
+    const uint32_t scp = (L.hi ? u1 : u0) >> L.sh16, mnp = (L.hi ? u3 : u2) >> L.sh16;
+    const int sc_lo = (int)(scp & 0xff), sc_hi = (int)((scp >> 8) & 0xff), m_lo = (int)(mnp & 0xff), m_hi = (int)((mnp >> 8) & 0xff);
+    const char * ab = ar + bb * 256 + L.a_off;
+    const u32x4 al0 = *(const u32x4 *) ab, al1 = *(const u32x4 *)(ab + 16), ah0 = *(const u32x4 *)(ab + 32), ah1 = *(const u32x4 *)(ab + 48);
+    const float yd = ((const float *)(ar + off_d))[bb];
+    const u32x2 ys = *(const u32x2 *)(ar + off_s + bb * 32 + L.s_off);
+    const uint32_t wl[8] = { qa.x & 0x0f0f0f0fu, qa.y & 0x0f0f0f0fu, qa.z & 0x0f0f0f0fu, qa.w & 0x0f0f0f0fu, qb.x & 0x0f0f0f0fu, qb.y & 0x0f0f0f0fu, qb.z & 0x0f0f0f0fu, qb.w & 0x0f0f0f0fu };
+    const uint32_t wh[8] = { (qa.x >> 4) & 0x0f0f0f0fu, (qa.y >> 4) & 0x0f0f0f0fu, (qa.z >> 4) & 0x0f0f0f0fu, (qa.w >> 4) & 0x0f0f0f0fu,
+                             (qb.x >> 4) & 0x0f0f0f0fu, (qb.y >> 4) & 0x0f0f0f0fu, (qb.z >> 4) & 0x0f0f0f0fu, (qb.w >> 4) & 0x0f0f0f0fu };
+    const uint32_t xl[8] = { al0.x, al0.y, al0.z, al0.w, al1.x, al1.y, al1.z, al1.w };
+    const uint32_t xh[8] = { ah0.x, ah0.y, ah0.z, ah0.w, ah1.x, ah1.y, ah1.z, ah1.w };
+    int sl = 0, sh = 0;
+#pragma unroll
+    for (int A = 0; A < 8; A++) { sl = dot4(wl[A], xl[A], sl); sh = dot4(wh[A], xh[A], sh); }
+    const int tot = __mul24(sc_lo, sl) + __mul24(sc_hi, sh);
+    const int pm = __mul24(m_lo, (int) ys.x) + __mul24(m_hi, (int) ys.y);
+    const float v = __builtin_fmaf((-yd) * dmin, (float) pm, (yd * d) * (float) tot);
+    return ok ? v : 0.0f;
+}
+
 // walk `npairs` (a multiple of 4) pairs of records in block order; l16 = lane & 15 (lanes 0..7: acc[], 8..11: acc_m[], 12..15: idle)
 __device__ __forceinline__ void q4k_chain(const char * chain, int npairs, int l16, float & acc) {
     for (int q0 = 0; q0 < npairs; q0 += 4) {
