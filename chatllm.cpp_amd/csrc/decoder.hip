@@ -169,12 +169,20 @@ extern "C" int cllm_tp_fused_sites(void * os);
 extern "C" size_t cllm_tp_fused_max_n(void * os);
 extern "C" int cllm_tp_fused_advance(void * os, void * stream);
 extern "C" int cllm_tp_fused_error(void * os);
+extern "C" int cllm_tp_fused_fine_grained(void * os);
 // bind the receive buffers of the fused all-reduce (cllm_tp_fused_create / _connect): 2 n_layer sites of `hidden` values.  The single-token steps then run without
 // all-reduce launches; multi-token graphs (prompts) still need cllm_llama_set_tp_comm / _set_tp_oneshot / _set_allreduce.  NULL: back to the collective per all-reduce.
 extern "C" int cllm_llama_set_tp_fused(cllm_llama * m, void * os) {
     if (!m) FAIL(CLLM_E_INVALID, "null");
     if (os && (cllm_tp_fused_sites(os) < 2 * m->cfg.n_layer || cllm_tp_fused_max_n(os) < (size_t) m->cfg.hidden))
         FAIL(CLLM_E_INVALID, "llama_set_tp_fused: the buffers hold %d sites of %zu values, the model needs %d of %d", cllm_tp_fused_sites(os), cllm_tp_fused_max_n(os), 2 * m->cfg.n_layer, m->cfg.hidden);
+    // ranks of DIFFERENT processes that share one GPU (coarse-grained buffers, CLLM_TP_ONESHOT_SAME_DEVICE=1: a test vehicle) poll for each other's launches from
+    // separate queues -- that only terminates if both ranks' 1024-thread workgroups can be resident at once, i.e. at small shapes.  At hidden sizes whose gather launch fills the
+    // GPU by itself the peer's scatter cannot start and every step would end in the bounded wait's time-out: refuse instead.  (Ranks inside one process on one GPU -- the ggml
+    // module's virtual ranks -- share a stream and are issued site by site: no such limit.)
+    if (os && cllm_tp_fused_fine_grained(os) == 0 && m->cfg.tp_size > 1 && m->cfg.hidden > 2048 && !getenv("CLLM_TP_FUSED_SAME_DEVICE_ANY_SIZE"))
+        FAIL(CLLM_E_UNSUPPORTED, "llama_set_tp_fused: ranks of different processes on ONE GPU (coarse-grained receive buffers) cannot co-reside at hidden %d: the fused all-reduce needs distinct GPUs "
+                                 "(fine-grained buffers) here; use the collective (cllm_llama_set_tp_oneshot / _set_tp_comm), or CLLM_TP_FUSED_SAME_DEVICE_ANY_SIZE=1 to try anyway", m->cfg.hidden);
     if (m->decode_graph) { (void) hipGraphExecDestroy(m->decode_graph); m->decode_graph = nullptr; }            // (captured with the other form of the all-reduce)
     if (m->decode_graph_long) { (void) hipGraphExecDestroy(m->decode_graph_long); m->decode_graph_long = nullptr; }
     m->tp_fused = os;
