@@ -55,41 +55,49 @@ __device__ __forceinline__ void tpf_issue16(u32x4 & v, const void * p) { asm vol
 __device__ __forceinline__ void tpf_land8(u32x4 (&h)[8]) {      // ONE wait for the eight loads in flight; the values are usable only behind this statement
     asm volatile("s_waitcnt vmcnt(0)" : "+v"(h[0]), "+v"(h[1]), "+v"(h[2]), "+v"(h[3]), "+v"(h[4]), "+v"(h[5]), "+v"(h[6]), "+v"(h[7]) :: "memory");
 }
+__device__ __forceinline__ void tpf_land16(u32x4 (&h)[16]) {
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(h[0]), "+v"(h[1]), "+v"(h[2]), "+v"(h[3]), "+v"(h[4]), "+v"(h[5]), "+v"(h[6]), "+v"(h[7]),
+                                        "+v"(h[8]), "+v"(h[9]), "+v"(h[10]), "+v"(h[11]), "+v"(h[12]), "+v"(h[13]), "+v"(h[14]), "+v"(h[15]) :: "memory");
+}
 // the four elements e .. e + 3 of the all-reduced vector of `site`: every rank's granules from this rank's own buffer, summed in rank order (bounded wait).
-// The loads of FOUR ranks go out together and are waited for once (eight ranks: two round trips where a load-wait per granule pair took sixteen -- each 0.7-1 us under load);
-// only a rank whose granules do not carry this step's number yet is polled again, alone.
-__device__ __forceinline__ f32x4 tpf_gather4(const tp_fuse_dev * cx, const char * own, int nranks, unsigned max_n, unsigned step, int site, int e) {
-    f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
-    for (int r0 = 0; r0 < nranks; r0 += 4) {
-        u32x4 h[8];
+// The loads of B ranks (4; 8 when there are more than four ranks) go out together and are waited for ONCE -- a load-wait per granule pair took 2 N dependent round trips of
+// 0.7-1.4 us each; measured with all granules present (tools/tp_gather_probe.py): 1 / 2 / 4 ranks 1.32 / 1.36 / 1.48 us, 8 ranks 2.88 us in two batches of four.
+// Only a rank whose granules do not carry this step's number yet is polled again, alone.
+template <int B>
+__device__ __forceinline__ void tpf_gather_batch(const tp_fuse_dev * cx, const char * own, int nranks, unsigned max_n, unsigned step, int site, int e, int r0, f32x4 & acc) {
+    u32x4 h[2 * B];
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
-            const int r = r0 + i < nranks ? r0 + i : nranks - 1;
-            const char * src = own + ((size_t)(site * nranks + r) * max_n + (size_t) e) * 8;
-            tpf_issue16(h[2 * i], src); tpf_issue16(h[2 * i + 1], src + 16);
-        }
-        tpf_land8(h);
+    for (int i = 0; i < B; i++) {
+        const int r = r0 + i < nranks ? r0 + i : nranks - 1;
+        const char * src = own + ((size_t)(site * nranks + r) * max_n + (size_t) e) * 8;
+        tpf_issue16(h[2 * i], src); tpf_issue16(h[2 * i + 1], src + 16);
+    }
+    if constexpr (B == 8) tpf_land16(h); else tpf_land8(h);
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
-            if (r0 + i >= nranks) break;
-            u32x4 h0 = h[2 * i], h1 = h[2 * i + 1];
-            if (!(h0.y == step && h0.w == step && h1.y == step && h1.w == step)) {
-                const char * src = own + ((size_t)(site * nranks + r0 + i) * max_n + (size_t) e) * 8;
-                int spins = 0;
-                for (;;) {
-                    h0 = tpf_load16(src); h1 = tpf_load16(src + 16);
-                    if (h0.y == step && h0.w == step && h1.y == step && h1.w == step) break;
-                    __builtin_amdgcn_s_sleep(1);
-                    // (bounded, and a time-out anywhere ends every later wait at its next look: a dead peer costs one time-out, not one per slot and launch)
-                    if ((++spins & 1023) == 0 && (spins > (1 << 21) || __hip_atomic_load(cx->err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
-                        __hip_atomic_store(cx->err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break;
-                    }
+    for (int i = 0; i < B; i++) {
+        if (r0 + i >= nranks) break;
+        u32x4 h0 = h[2 * i], h1 = h[2 * i + 1];
+        if (!(h0.y == step && h0.w == step && h1.y == step && h1.w == step)) {
+            const char * src = own + ((size_t)(site * nranks + r0 + i) * max_n + (size_t) e) * 8;
+            int spins = 0;
+            for (;;) {
+                h0 = tpf_load16(src); h1 = tpf_load16(src + 16);
+                if (h0.y == step && h0.w == step && h1.y == step && h1.w == step) break;
+                __builtin_amdgcn_s_sleep(1);
+                // (bounded, and a time-out anywhere ends every later wait at its next look: a dead peer costs one time-out, not one per slot and launch)
+                if ((++spins & 1023) == 0 && (spins > (1 << 21) || __hip_atomic_load(cx->err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+                    __hip_atomic_store(cx->err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break;
                 }
             }
-            const f32x4 v = { __uint_as_float(h0.x), __uint_as_float(h0.z), __uint_as_float(h1.x), __uint_as_float(h1.z) };
-            if (r0 + i == 0) acc = v; else { acc.x = acc.x + v.x; acc.y = acc.y + v.y; acc.z = acc.z + v.z; acc.w = acc.w + v.w; }
         }
+        const f32x4 v = { __uint_as_float(h0.x), __uint_as_float(h0.z), __uint_as_float(h1.x), __uint_as_float(h1.z) };
+        if (r0 + i == 0) acc = v; else { acc.x = acc.x + v.x; acc.y = acc.y + v.y; acc.z = acc.z + v.z; acc.w = acc.w + v.w; }
     }
+}
+__device__ __forceinline__ f32x4 tpf_gather4(const tp_fuse_dev * cx, const char * own, int nranks, unsigned max_n, unsigned step, int site, int e) {
+    f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+    if (nranks > 4) { for (int r0 = 0; r0 < nranks; r0 += 8) tpf_gather_batch<8>(cx, own, nranks, max_n, step, site, e, r0, acc); }
+    else tpf_gather_batch<4>(cx, own, nranks, max_n, step, site, e, 0, acc);
     return acc;
 }
 
@@ -195,6 +203,7 @@ __global__ void __launch_bounds__(1024) k_gemv_dec(const float * __restrict__ px
     f32x4 pa = {0, 0, 0, 0}, pa16[(Q16 && PRO == 1 && NPRE == 1) ? 4 : 1];
     const bool add = PRO == 1 && NPRE == 1 && EPI != 5 && padd != nullptr;        // (EPI 5: padd carries the router's weights)
     if constexpr (PRO == 5) {
+        if (ts && threadIdx.x == 0) ts[blockIdx.x * 8 + 6] = wall_clock64();      // (tools/tp_gather_probe.py: the gather's duration = stamp 0 - stamp 6)
         // the all-reduce of the previous o / down projection, folded in: every rank's partial rows wait (or arrive) as granules in this rank's buffer.  Polled BEFORE the
         // weight prefetch goes out (the polls wait with vmcnt(0): behind the prefetch they would drain it anyway) -- a tensor-parallel step is bound by these arrivals
         const tp_fuse_dev * cx = tp_ctx;

@@ -13,6 +13,9 @@
 // These instantiations live in their own code object: the single-GPU kernels' layout (and launch-to-launch time) is untouched.
 #include "gemv_decode_kernel.h"
 
+static unsigned long long * g_tp_ts = nullptr;
+extern "C" __attribute__((visibility("default"))) void cllm_debug_set_tp_ts(unsigned long long * dev_buf) { g_tp_ts = dev_buf; }   // tools only: stamps of the gather launches (8 per workgroup)
+
 // partial rows of an o / down projection -> granules in every rank's receive buffer.  pro 2: quantize(px); pro 3: quantize(silu(gate) * up) on interleaved pairs
 int launch_gemv_decode_tp_scatter(hipStream_t st, int wtype, const void * W, int64_t K, int64_t nrows, int pro, const float * px, const void * ctx_dev, int site) {
     const int kind = wtype == CLLM_TYPE_Q4_K ? 256 : 32;
@@ -59,7 +62,7 @@ int launch_gemv_decode_tp_gather(hipStream_t st, int wtype, const void * W, int6
         static uint64_t attr = 0; \
         if (lds > 64 * 1024 && dev_flag_unset(attr)) { HIP_TRY(hipFuncSetAttribute((const void *) k_gemv_dec<FMT_, 5, EPI_, NPRE_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256)); dev_flag_set(attr); } \
         hipLaunchKernelGGL((k_gemv_dec<FMT_, 5, EPI_, NPRE_>), dim3((unsigned) grid), dim3(1024), lds, st, px, pw, (const float *) nullptr, (const char *) W, nblk, kfull, nrem, eps, \
-                           dst, xout, bias, (const float *) nullptr, (unsigned long long *) nullptr, (const int32_t *) ctx_dev, 0ull, site, 0); } while (0)
+                           dst, xout, bias, (const float *) nullptr, g_tp_ts, (const int32_t *) ctx_dev, 0ull, site, 0); } while (0)
 #define GOGF(FMT_) do { \
         if (epi == 1) { if (npre == 1) GOG(FMT_, 1, 1); else GOG(FMT_, 1, 4); } \
         else          { if (npre == 1) GOG(FMT_, 0, 1); else GOG(FMT_, 0, 4); } } while (0)
