@@ -42,6 +42,7 @@ struct hip_backend_ctx {
     struct {
         bool armed = false, inflight = false;
         bool chained = false;          // the step running ahead was queued BEHIND the step the host is still waiting for (ahead_launch(c, true)): synchronize() waits for `ev`, not for the stream
+        bool tp = false;               // the step armed / running ahead is a tensor-parallel one (replayed through tp_ahead_replay, not graph_exec)
         bool ev_pending = false;       // ... and that event has not been waited for yet (EVERY synchronize() while the step runs ahead must stay off the stream: the host calls it more than once per token)
         bool snap_ready = false;       // the outputs' snapshot is complete although the step did not start (ahead_launch failed behind its argmax write): serve the pending read from it
         void * ev = nullptr, * table_dev = nullptr, * scratch = nullptr, * snap = nullptr; size_t snap_bytes = 0; int32_t * tok_host = nullptr;
@@ -83,6 +84,8 @@ struct tp_rank {
 struct tp_group {
     int n = 0; std::vector<tp_rank> r; bool fused_ready = false, broken = false, told = false, last_tp = false; int sites = 0; size_t max_n = 0; void * ev0 = nullptr;
     long steps = 0, plain = 0, replays = 0, captures = 0; const void * owner = nullptr;
+    // what a step started AHEAD of the host needs besides the captured graphs (tp_ahead_replay): the embedding gather's operands, where the position lives, every rank's inputs
+    struct { cllm_tensor ea, eb, ed; const void * pos_src = nullptr; size_t hbytes = 0; std::vector<void *> xa, pos; std::vector<void *> streams; std::vector<int> sgpu; int64_t n_kv = 0; bool valid = false; } rp;
     std::vector<uint64_t> last_sig, graph_sig; std::vector<void *> execs; bool graph_broken = false;      // launch-list replay of the sharded step: one captured graph per distinct stream      // owner: the backend context whose stream rank 0 runs on
 } g_tp;
 std::vector<hip_device_ctx *> g_devices;
@@ -213,6 +216,7 @@ void buf_set(ggml_backend_buffer_t b, ggml_tensor * t, const void * data, size_t
 }
 // get_tensor (the logits of every token: 513 KB for Llama-3): through a page-locked staging area -- the D2H copy into the host's pageable
 // destination is several times slower than DMA into pinned memory + a memcpy
+int tp_ahead_replay(hip_backend_ctx * c);
 void * g_stage = nullptr; size_t g_stage_size = 0;
 constexpr size_t k_stage_chunk = 4u << 20;
 std::mutex g_stage_mutex;
@@ -431,6 +435,7 @@ bool dev_supports_op(ggml_backend_dev_t, const ggml_tensor * op) {
 // ---------------------------------------------------------------------------------------------------------------------------
 void tp_free_all();
 bool tp_check_errors();
+struct fuse_plan;
 void ahead_finish_event(hip_backend_ctx * c);
 const char * be_name(ggml_backend_t b) { return ((hip_device_ctx *) b->device->context)->name.c_str(); }      // (the ggml device's name: several of them can sit on one GPU, CLLM_HIP_VIRTUAL_DEVICES)
 void be_free(ggml_backend_t b) {
@@ -1210,7 +1215,7 @@ void ahead_launch(hip_backend_ctx * c, bool chained) {
     if (cllm_op_argmax_set(st, (const float *) A.logits_ptr, (int64_t)(A.logits_bytes / 4), (int32_t *) A.ids_ptr, A.tok_host, A.table_dev, n_rec, A.scratch) != CLLM_OK) { fail_behind_the_snapshot(); return; }
     if (cllm_event_record(A.ev, st) != CLLM_OK) { fail_behind_the_snapshot(); return; }
     if (timing) cllm_event_record(t_g0[t_k], st);
-    if (cllm_graph_launch(c->graph_exec, st) != CLLM_OK) { fail_behind_the_snapshot(); return; }
+    if ((A.tp ? tp_ahead_replay(c) : cllm_graph_launch(c->graph_exec, st)) != CLLM_OK) { fail_behind_the_snapshot(); return; }
     if (timing) { cllm_event_record(t_g1[t_k], st); t_n++; }
     static const bool ahead_sync = getenv("CLLM_HIP_AHEAD_SYNC") != nullptr;       // (debugging: run the step ahead to completion before returning)
     if (ahead_sync) cllm_stream_sync(st);
@@ -1220,6 +1225,33 @@ void ahead_launch(hip_backend_ctx * c, bool chained) {
     if (!chained) ahead_finish_event(c);
 }
 
+
+// a step is running ahead: is it the one the host is asking for?  1: yes (nothing to launch), 0: no -- the step was allowed to finish and the host's scalars are in place (buf_set
+// held them back), -1: error.  sig_equal: the host's launch list equals the captured one the step was started with.
+int ahead_resolve(hip_backend_ctx * c, bool sig_equal, const std::vector<hip_backend_ctx::scalar_set> & cur_sets) {
+    auto & A = c->ahead;
+    ahead_finish_event(c);                 // (a host that did not synchronize since: the predicted token must be known before the comparison below)
+    A.inflight = false;
+    bool ok = sig_equal && cur_sets.size() == A.pred.size();
+    for (size_t k = 0; ok && k < cur_sets.size(); k++)
+        ok = cur_sets[k].ptr == A.pred[k].ptr && cur_sets[k].val == (A.pred[k].ptr == A.ids_ptr ? A.tok_host[0] : A.pred[k].val);
+    if (ok) { A.hits++; A.misses = 0; return 1; }
+    static const bool adbg = getenv("CLLM_HIP_AHEAD_DEBUG") != nullptr;
+    if (adbg) {
+        HIPB_LOG("ahead: MISS sig_equal=%d sets %zu predicted %zu", (int) sig_equal, cur_sets.size(), A.pred.size());
+        for (size_t k = 0; k < cur_sets.size() && k < A.pred.size(); k++) {
+            const int32_t want = A.pred[k].ptr == A.ids_ptr ? A.tok_host[0] : A.pred[k].val;
+            if (cur_sets[k].ptr != A.pred[k].ptr || cur_sets[k].val != want)
+                HIPB_LOG("ahead:   set %zu: host wrote %p = %d, predicted %p = %d%s", k, cur_sets[k].ptr, (int) cur_sets[k].val, A.pred[k].ptr, (int) want, A.pred[k].ptr == A.ids_ptr ? " (token id)" : "");
+        }
+    }
+    if (++A.misses >= 2) { A.skip_until = A.graphs + 64; A.misses = 0; }
+    cllm_set_device(c->device);
+    cllm_stream_sync(c->stream);           // the step that ran ahead is not the one asked for: let it finish (every rank's stream joins this one), then put the host's scalars in place
+    for (const auto & ss : cur_sets) if (cllm_memcpy_h2d((void *) ss.ptr, &ss.val, 4, nullptr) != CLLM_OK) { HIPB_LOG("scalar write failed: %s", cllm_last_error()); return -1; }
+    if (cllm_stream_sync(nullptr) != CLLM_OK) return -1;
+    return 0;
+}
 
 // ---- tensor parallel BEHIND the boundary (CLLM_HIP_TP=N): ONE logical ggml device over N ranks ---------------------------------------------------------------
 // The reference's own slot for this is SplitMethod::Row -- "TODO: WIP" (src/backend.h:322-327; device assignment src/backend.cpp:677-778 only splits by layer, which at
@@ -1387,7 +1419,8 @@ void tp_free_all() {
 }
 
 // one decode step, tensor-parallel.  GGML_STATUS_ABORTED = "not taken, nothing launched" (the caller runs the graph un-sharded on rank 0)
-ggml_status tp_graph_compute(hip_backend_ctx * c, ggml_cgraph * g, fuse_plan & P) {
+int ahead_resolve(hip_backend_ctx * c, bool sig_equal, const std::vector<hip_backend_ctx::scalar_set> & cur_sets);
+ggml_status tp_graph_compute(hip_backend_ctx * c, ggml_cgraph * g, fuse_plan & P, const std::vector<hip_backend_ctx::scalar_set> & cur_sets, bool * replayed_out) {
     auto & T = g_tp;
     tp_desc D;
     static const bool tp_dbg = getenv("CLLM_HIP_TP_DEBUG") != nullptr;
@@ -1565,12 +1598,7 @@ ggml_status tp_graph_compute(hip_backend_ctx * c, ggml_cgraph * g, fuse_plan & P
 #define TPC(expr) do { const int rc_ = (expr); if (rc_ != CLLM_OK) { HIPB_LOG("tensor-parallel step: %s failed: %s", #expr, cllm_last_error()); cllm_set_device(c->device); return rc_ == CLLM_E_ALLOC ? GGML_STATUS_ALLOC_FAILED : GGML_STATUS_FAILED; } } while (0)
     struct rk { float * cs, * xa, * xb, * qkv, * att, * act; int32_t * pos; void * scores; size_t score_bytes; float * cur; };
     std::vector<rk> X((size_t) N);
-    {
-        cllm_tensor da = desc(emb->src[0]), db = desc(emb->src[1]), dd = desc(emb);
-        TPC(cllm_op_get_rows(st0, &da, &db, &dd));
-    }
-    bool remote = false;
-    for (int k = 0; k < N; k++) {
+    for (int k = 0; k < N; k++) {                 // where every rank keeps its inputs and intermediates (pointer arithmetic only: nothing is launched before the signature is known)
         tp_rank & R = T.r[(size_t) k]; const tp_split & s = S[(size_t) k]; rk & x = X[(size_t) k];
         char * b = R.scratch;
         x.cs = (float *) b; b += 1024; x.pos = (int32_t *) b; b += 256;
@@ -1579,23 +1607,34 @@ ggml_status tp_graph_compute(hip_backend_ctx * c, ggml_cgraph * g, fuse_plan & P
         x.act = (float *) b; b += al((size_t) s.fc * 4);
         x.score_bytes = cllm_attn_decode_wsize(A0.n_kv, (int)(s.kvc * d.gs), d.ML); x.scores = x.score_bytes ? (void *) b : nullptr;
         x.cur = x.xa;
-        // the embedding row and the position from rank 0 (queued on rank 0's stream: behind the GET_ROWS, and behind everything an earlier un-sharded graph wrote)
-        TPC(cllm_memcpy_peer_async(x.xa, R.gpu, emb->data, c->device, (size_t) d.H * 4, st0));
-        TPC(cllm_memcpy_peer_async(x.pos, R.gpu, A0.pos, c->device, 4, st0));
-        remote = remote || R.own_stream;
     }
-    if (remote) {
-        TPC(cllm_event_record(T.ev0, st0));
-        for (int k = 0; k < N; k++) if (T.r[(size_t) k].own_stream) { cllm_set_device(T.r[(size_t) k].gpu); TPC(cllm_stream_wait_event(T.r[(size_t) k].stream, T.ev0)); }
-    }
-    for (int k = 0; k < N; k++) {
-        tp_rank & R = T.r[(size_t) k]; const tp_split & s = S[(size_t) k];
-        cllm_set_device(R.gpu);
-        if (R.kv_valid < A0.n_kv - 1) {          // rows the host's cache has and the shard has not (a prompt ran un-sharded, a session was loaded ...)
-            TPC(cllm_op_kv_shard_copy(R.stream, R.kv_table, L, (int)(s.kvc * d.hd), (int)(d.nkv * d.hd), (int)(s.kv0 * d.hd), d.ML, R.kv_valid, A0.n_kv - 1, nullptr, 0));
+    // what stands in front of the sharded launches: the embedding row on rank 0, that row and the position handed to every rank (queued on rank 0's stream: behind the GET_ROWS and
+    // behind everything an earlier un-sharded graph wrote), the ranks' streams made to wait for them, the cache shards brought up to date
+    auto pre_step = [&]() -> ggml_status {
+        cllm_set_device(c->device);
+        cllm_tensor da = desc(emb->src[0]), db = desc(emb->src[1]), dd = desc(emb);
+        TPC(cllm_op_get_rows(st0, &da, &db, &dd));
+        bool remote = false;
+        for (int k = 0; k < N; k++) {
+            tp_rank & R = T.r[(size_t) k]; rk & x = X[(size_t) k];
+            TPC(cllm_memcpy_peer_async(x.xa, R.gpu, emb->data, c->device, (size_t) d.H * 4, st0));
+            TPC(cllm_memcpy_peer_async(x.pos, R.gpu, A0.pos, c->device, 4, st0));
+            remote = remote || R.own_stream;
         }
-        R.kv_valid = A0.n_kv;
-    }
+        if (remote) {
+            TPC(cllm_event_record(T.ev0, st0));
+            for (int k = 0; k < N; k++) if (T.r[(size_t) k].own_stream) { cllm_set_device(T.r[(size_t) k].gpu); TPC(cllm_stream_wait_event(T.r[(size_t) k].stream, T.ev0)); }
+        }
+        for (int k = 0; k < N; k++) {
+            tp_rank & R = T.r[(size_t) k]; const tp_split & s = S[(size_t) k];
+            cllm_set_device(R.gpu);
+            if (R.kv_valid < A0.n_kv - 1) {          // rows the host's cache has and the shard has not (a prompt ran un-sharded, a session was loaded ...)
+                TPC(cllm_op_kv_shard_copy(R.stream, R.kv_table, L, (int)(s.kvc * d.hd), (int)(d.nkv * d.hd), (int)(s.kv0 * d.hd), d.ML, R.kv_valid, A0.n_kv - 1, nullptr, 0));
+            }
+            R.kv_valid = A0.n_kv;
+        }
+        return GGML_STATUS_SUCCESS;
+    };
     auto wdesc = [](ggml_type t, int64_t K, int64_t rows, void * data) {
         cllm_tensor w; w.type = (int32_t) t; w.ne[0] = K; w.ne[1] = rows; w.ne[2] = w.ne[3] = 1;
         w.nb[0] = ggml_type_size(t); w.nb[1] = ggml_row_size(t, K); w.nb[2] = w.nb[3] = w.nb[1] * (size_t) rows; w.data = data; return w;
@@ -1735,8 +1774,16 @@ ggml_status tp_graph_compute(hip_backend_ctx * c, ggml_cgraph * g, fuse_plan & P
     std::vector<void *> streams;                   // the distinct streams, rank order
     for (int k = 0; k < N; k++) { bool seen = false; for (void * q : streams) seen = seen || q == T.r[(size_t) k].stream; if (!seen) streams.push_back(T.r[(size_t) k].stream); }
     auto gpu_of = [&](void * q) { for (int k = 0; k < N; k++) if (T.r[(size_t) k].stream == q) return T.r[(size_t) k].gpu; return c->device; };
-    bool replayed = false;
-    if (tp_graph && !T.graph_broken && T.execs.size() == streams.size() && !T.execs.empty() && sig == T.graph_sig) {
+    bool replayed = false, ahead_hit = false;
+    if (c->ahead.inflight) {                       // a sharded step is running ahead of the host (tp_ahead_replay): is it this one?
+        const int hr = ahead_resolve(c, c->ahead.tp && T.rp.valid && !T.execs.empty() && sig == T.graph_sig && T.rp.n_kv == A0.n_kv, cur_sets);
+        if (hr < 0) return GGML_STATUS_FAILED;
+        ahead_hit = hr == 1;
+    }
+    if (ahead_hit) { replayed = true; T.replays++; }
+    else if (const ggml_status ps = pre_step(); ps != GGML_STATUS_SUCCESS) return ps;
+    if (ahead_hit) {}
+    else if (tp_graph && !T.graph_broken && T.execs.size() == streams.size() && !T.execs.empty() && sig == T.graph_sig) {
         for (size_t q = 0; q < streams.size(); q++) { cllm_set_device(gpu_of(streams[q])); TPC(cllm_graph_launch(T.execs[q], streams[q])); }
         replayed = true; T.replays++;
     } else if (tp_graph && !T.graph_broken && sig == T.last_sig) {      // second time in a row: capture one graph per stream, then launch them
@@ -1770,17 +1817,95 @@ ggml_status tp_graph_compute(hip_backend_ctx * c, ggml_cgraph * g, fuse_plan & P
         if (rs != GGML_STATUS_SUCCESS) return rs;
     }
     T.last_sig.swap(sig);
-    for (int k = 0; k < N; k++) {                 // everything joins rank 0's stream
+    if (!ahead_hit) for (int k = 0; k < N; k++) {   // everything joins rank 0's stream
         tp_rank & R = T.r[(size_t) k];
         if (R.own_stream) { cllm_set_device(R.gpu); TPC(cllm_event_record(R.ev, R.stream)); cllm_set_device(c->device); TPC(cllm_stream_wait_event(st0, R.ev)); }
     }
+    {   // what a step started ahead of the host will need (tp_ahead_replay): valid while the captured graphs are
+        auto & Q = T.rp;
+        Q.valid = replayed && !T.execs.empty();
+        if (Q.valid) {
+            Q.ea = desc(emb->src[0]); Q.eb = desc(emb->src[1]); Q.ed = desc(emb); Q.pos_src = A0.pos; Q.hbytes = (size_t) d.H * 4; Q.n_kv = A0.n_kv;
+            Q.xa.clear(); Q.pos.clear();
+            for (int k = 0; k < N; k++) { Q.xa.push_back(X[(size_t) k].xa); Q.pos.push_back(X[(size_t) k].pos); }
+            Q.streams = streams; Q.sgpu.clear();
+            for (void * q : streams) Q.sgpu.push_back(gpu_of(q));
+        }
+    }
+    *replayed_out = replayed;
 #undef TPC
 #undef TP_NO
     cllm_set_device(c->device);
     T.steps++; T.last_tp = true;
     if (g_stats) HIPB_LOG("HIP0 graph_compute: %d nodes -> tensor parallel over %d ranks: %d launches per rank (%d layers x 5 + head%s)%s, all-reduce fused into the mat-vecs", ggml_graph_n_nodes(g), N, 5 * L + 6, L,
-                          sharded ? ", lm_head rows sharded" : "", replayed ? ", replayed from the captured graphs" : "");
+                          sharded ? ", lm_head rows sharded" : "", ahead_hit ? ", started ahead of the host" : replayed ? ", replayed from the captured graphs" : "");
     return GGML_STATUS_SUCCESS;
+}
+
+// the NEXT sharded step, started ahead of the host (ahead_launch): the token id and the positions are already on rank 0 (the prep launch in front of this wrote them); what
+// tp_graph_compute's pre_step does -- embedding row, hand-over to the ranks, events -- then the captured graphs and the joins.  The cache shards need no refresh: the previous
+// step left them one row short of this one, and this step writes that row.
+int tp_ahead_replay(hip_backend_ctx * c) {
+    auto & T = g_tp; auto & Q = T.rp;
+    if (!Q.valid || T.execs.empty() || T.execs.size() != Q.streams.size()) return CLLM_E_INVALID;
+    void * st0 = c->stream;
+    const int N = T.n;
+#define TRY_(expr) do { const int rc_ = (expr); if (rc_ != CLLM_OK) { cllm_set_device(c->device); return rc_; } } while (0)
+    cllm_set_device(c->device);
+    TRY_(cllm_op_get_rows(st0, &Q.ea, &Q.eb, &Q.ed));
+    bool remote = false;
+    for (int k = 0; k < N; k++) {
+        tp_rank & R = T.r[(size_t) k];
+        TRY_(cllm_memcpy_peer_async(Q.xa[(size_t) k], R.gpu, Q.ed.data, c->device, Q.hbytes, st0));
+        TRY_(cllm_memcpy_peer_async(Q.pos[(size_t) k], R.gpu, Q.pos_src, c->device, 4, st0));
+        remote = remote || R.own_stream;
+    }
+    if (remote) {
+        TRY_(cllm_event_record(T.ev0, st0));
+        for (int k = 0; k < N; k++) if (T.r[(size_t) k].own_stream) { cllm_set_device(T.r[(size_t) k].gpu); TRY_(cllm_stream_wait_event(T.r[(size_t) k].stream, T.ev0)); }
+    }
+    for (size_t q = 0; q < Q.streams.size(); q++) { cllm_set_device(Q.sgpu[q]); TRY_(cllm_graph_launch(T.execs[q], Q.streams[q])); }
+    for (int k = 0; k < N; k++) {
+        tp_rank & R = T.r[(size_t) k];
+        if (R.own_stream) { cllm_set_device(R.gpu); TRY_(cllm_event_record(R.ev, R.stream)); cllm_set_device(c->device); TRY_(cllm_stream_wait_event(st0, R.ev)); }
+        R.kv_valid = Q.n_kv + 1;
+    }
+#undef TRY_
+    cllm_set_device(c->device);
+    Q.n_kv += 1; T.steps++; T.last_tp = true;
+    return CLLM_OK;
+}
+
+// arm decode-ahead for the token after this one (see ahead_launch) -- and, with the chain on, start that step right away.  have_graph: this step was replayed from a captured
+// launch list (one graph, or the tensor-parallel device's graph per stream) that the next step can be started with.
+void ahead_arm(hip_backend_ctx * c, ggml_cgraph * g, const fuse_plan & plan, const std::vector<hip_backend_ctx::scalar_set> & cur_sets, bool have_graph, bool tp) {
+    static const bool ahead_off = getenv("CLLM_HIP_AHEAD") && atoi(getenv("CLLM_HIP_AHEAD")) == 0;
+    auto & A = c->ahead;
+    A.armed = false;
+    const int nn = ggml_graph_n_nodes(g);
+    if (ahead_off || !have_graph || A.graphs < A.skip_until || cur_sets.empty() || nn <= 0 || plan.attns.empty() || c->device >= 64) return;
+    const ggml_tensor * out = ggml_graph_node(g, nn - 1), * ids = nullptr;
+    int n_out = 0; A.outs.clear(); bool ok = out->type == GGML_TYPE_F32 && ggml_is_contiguous(out) && out->data && ggml_nbytes(out) % 4 == 0 && ggml_nbytes(out) >= 8;
+    int64_t min_ml = INT64_MAX;
+    for (const fused_attn & F : plan.attns) { ok = ok && F.level == 2; if (F.ML < min_ml) min_ml = F.ML; }
+    for (int i = 0; ok && i < nn; i++) {
+        const ggml_tensor * t = ggml_graph_node(g, i);
+        if (t->flags & GGML_TENSOR_FLAG_OUTPUT) { n_out++; if (t->data && ggml_is_contiguous(t)) A.outs.push_back({ (const char *) t->data, ggml_nbytes(t), 0 }); else ok = false; }
+        if (!plan.skip[i] && (t->op == GGML_OP_SET_ROWS || t->op == GGML_OP_FLASH_ATTN_EXT)) ok = false;      // cache writes outside the fused block, growing masks: not predicted (experts are picked on the device: nothing to predict)
+        if (!ids && t->op == GGML_OP_GET_ROWS && t->src[1] && t->src[1]->type == GGML_TYPE_I32 && ggml_nelements(t->src[1]) == 1) ids = t->src[1];
+    }
+    if (!(out->flags & GGML_TENSOR_FLAG_OUTPUT)) A.outs.push_back({ (const char *) out->data, ggml_nbytes(out), 0 });
+    ok = ok && ids && ids->data && n_out <= 8;
+    bool has_ids = false;
+    for (const auto & ss : cur_sets) { if (ids && ss.ptr == ids->data) has_ids = true; else if ((int64_t) ss.val + 1 >= min_ml || ss.val < 0) ok = false; }
+    static const bool dbg = getenv("CLLM_HIP_AHEAD_DEBUG") != nullptr;
+    if (dbg) HIPB_LOG("ahead: ok=%d has_ids=%d ids=%p n_out=%d out_flag=%d min_ml=%lld sets=%zu out=%s(%s) bytes=%zu", (int) ok, (int) has_ids, ids ? ids->data : nullptr, n_out, (int)((out->flags & GGML_TENSOR_FLAG_OUTPUT) != 0), (long long) min_ml, cur_sets.size(), out->name, ggml_op_name(out->op), ggml_nbytes(out));
+    if (!ok || !has_ids) return;
+    A.ids_ptr = ids->data; A.logits_ptr = out->data; A.logits_bytes = ggml_nbytes(out); A.last_sets = cur_sets;
+    A.armed = true; A.tp = tp; g_ahead_ctx[c->device] = c;
+    // the next step goes out NOW, behind the one just launched (CLLM_HIP_AHEAD_CHAIN=0: when the host reads the logits, round 5's order)
+    static const bool chain = !getenv("CLLM_HIP_AHEAD_CHAIN") || atoi(getenv("CLLM_HIP_AHEAD_CHAIN")) != 0;
+    if (chain) ahead_launch(c, true);
 }
 
 ggml_status be_graph_compute(ggml_backend_t backend, ggml_cgraph * g) {
@@ -1818,9 +1943,17 @@ ggml_status be_graph_compute(ggml_backend_t backend, ggml_cgraph * g) {
     if (g_tp.n > 1) {
         // the logical tensor-parallel device: a recognised decode step runs sharded over the ranks (tp_graph_compute); anything else runs below, un-sharded on rank 0 -- and may
         // write the KV caches behind the shards' back
-        const ggml_status ts = tp_graph_compute(c, g, plan);
-        if (ts != GGML_STATUS_ABORTED) { c->last_sig.clear(); return ts; }
-        g_tp_kv_epoch++; g_tp.plain++; g_tp.last_tp = false;
+        bool tp_replayed = false;
+        const ggml_status ts = tp_graph_compute(c, g, plan, cur_sets, &tp_replayed);
+        if (ts != GGML_STATUS_ABORTED) {
+            c->last_sig.clear();
+            if (ts == GGML_STATUS_SUCCESS) ahead_arm(c, g, plan, cur_sets, tp_replayed, true);      // the next sharded step may start ahead of the host, as on one device
+            return ts;
+        }
+        if (c->ahead.inflight && c->ahead.tp) {       // a sharded step runs ahead and the host asks for something else (a prompt, another model): let it finish, put the host's scalars in place
+            if (ahead_resolve(c, false, cur_sets) < 0) return GGML_STATUS_FAILED;
+        }
+        g_tp_kv_epoch++; g_tp.plain++; g_tp.last_tp = false; g_tp.rp.valid = false;
     }
     if (trace) {
         for (const fused_mv & f : plan.mvs) if (f.node >= 0) fprintf(stderr, "  plan: mat-vec node %d pro %d%s%s%s\n", f.node, f.pro, f.resid ? " +resid" : "", f.alias ? " STAGED (dst overlaps an input)" : "", f.group >= 0 ? " grouped" : "");
@@ -2097,28 +2230,9 @@ ggml_status be_graph_compute(ggml_backend_t backend, ggml_cgraph * g) {
         const int n_calls = launches;
         bool ahead_hit = false;
         if (c->ahead.inflight) {                   // a step is running ahead: is it the one the host is asking for?
-            auto & A = c->ahead;
-            ahead_finish_event(c);                 // (a host that did not synchronize since: the predicted token must be known before the comparison below)
-            A.inflight = false;
-            bool ok = c->graph_exec && sig == c->graph_sig && cur_sets.size() == A.pred.size();
-            for (size_t k = 0; ok && k < cur_sets.size(); k++)
-                ok = cur_sets[k].ptr == A.pred[k].ptr && cur_sets[k].val == (A.pred[k].ptr == A.ids_ptr ? A.tok_host[0] : A.pred[k].val);
-            if (ok) { ahead_hit = true; A.hits++; A.misses = 0; }
-            else {
-                static const bool adbg = getenv("CLLM_HIP_AHEAD_DEBUG") != nullptr;
-                if (adbg) {
-                    HIPB_LOG("ahead: MISS graph_exec=%d sig_equal=%d (sig %zu bytes, captured %zu) sets %zu predicted %zu", (int)(c->graph_exec != nullptr), (int)(sig == c->graph_sig), sig.size(), c->graph_sig.size(), cur_sets.size(), A.pred.size());
-                    for (size_t k = 0; k < cur_sets.size() && k < A.pred.size(); k++) {
-                        const int32_t want = A.pred[k].ptr == A.ids_ptr ? A.tok_host[0] : A.pred[k].val;
-                        if (cur_sets[k].ptr != A.pred[k].ptr || cur_sets[k].val != want)
-                            HIPB_LOG("ahead:   set %zu: host wrote %p = %d, predicted %p = %d%s", k, cur_sets[k].ptr, (int) cur_sets[k].val, A.pred[k].ptr, (int) want, A.pred[k].ptr == A.ids_ptr ? " (token id)" : "");
-                    }
-                }
-                if (++A.misses >= 2) { A.skip_until = A.graphs + 64; A.misses = 0; }
-                cllm_stream_sync(st);              // the step that ran ahead is not the one asked for: let it finish, then put the host's scalars in place (buf_set held them back)
-                for (const auto & ss : cur_sets) if (cllm_memcpy_h2d((void *) ss.ptr, &ss.val, 4, nullptr) != CLLM_OK) { HIPB_LOG("scalar write failed: %s", cllm_last_error()); return GGML_STATUS_FAILED; }
-                if (cllm_stream_sync(nullptr) != CLLM_OK) return GGML_STATUS_FAILED;
-            }
+            const int hr = ahead_resolve(c, c->graph_exec && sig == c->graph_sig, cur_sets);
+            if (hr < 0) return GGML_STATUS_FAILED;
+            ahead_hit = hr == 1;
         }
         if (ahead_hit) {
             replayed = true; c->replays++;         // nothing to launch
@@ -2152,37 +2266,7 @@ ggml_status be_graph_compute(ggml_backend_t backend, ggml_cgraph * g) {
         }
         c->last_sig.swap(sig);
     }
-    {   // arm decode-ahead for the token after this one (see ahead_launch)
-        static const bool ahead_off = getenv("CLLM_HIP_AHEAD") && atoi(getenv("CLLM_HIP_AHEAD")) == 0;
-        auto & A = c->ahead;
-        A.armed = false;
-        const int nn = ggml_graph_n_nodes(g);
-        if (!ahead_off && g_tp.n <= 1 && replayed && c->graph_exec && A.graphs >= A.skip_until && !cur_sets.empty() && nn > 0 && !plan.attns.empty() && c->device < 64) {
-            const ggml_tensor * out = ggml_graph_node(g, nn - 1), * ids = nullptr;
-            int n_out = 0; A.outs.clear(); bool ok = out->type == GGML_TYPE_F32 && ggml_is_contiguous(out) && out->data && ggml_nbytes(out) % 4 == 0 && ggml_nbytes(out) >= 8;
-            int64_t min_ml = INT64_MAX;
-            for (const fused_attn & F : plan.attns) { ok = ok && F.level == 2; if (F.ML < min_ml) min_ml = F.ML; }
-            for (int i = 0; ok && i < nn; i++) {
-                const ggml_tensor * t = ggml_graph_node(g, i);
-                if (t->flags & GGML_TENSOR_FLAG_OUTPUT) { n_out++; if (t->data && ggml_is_contiguous(t)) A.outs.push_back({ (const char *) t->data, ggml_nbytes(t), 0 }); else ok = false; }
-                if (!plan.skip[i] && (t->op == GGML_OP_SET_ROWS || t->op == GGML_OP_FLASH_ATTN_EXT)) ok = false;      // cache writes outside the fused block, growing masks: not predicted (experts are picked on the device: nothing to predict)
-                if (!ids && t->op == GGML_OP_GET_ROWS && t->src[1] && t->src[1]->type == GGML_TYPE_I32 && ggml_nelements(t->src[1]) == 1) ids = t->src[1];
-            }
-            if (!(out->flags & GGML_TENSOR_FLAG_OUTPUT)) A.outs.push_back({ (const char *) out->data, ggml_nbytes(out), 0 });
-            ok = ok && ids && ids->data && n_out <= 8;
-            bool has_ids = false;
-            for (const auto & ss : cur_sets) { if (ids && ss.ptr == ids->data) has_ids = true; else if ((int64_t) ss.val + 1 >= min_ml || ss.val < 0) ok = false; }
-            static const bool dbg = getenv("CLLM_HIP_AHEAD_DEBUG") != nullptr;
-            if (dbg) HIPB_LOG("ahead: ok=%d has_ids=%d ids=%p n_out=%d out_flag=%d min_ml=%lld sets=%zu out=%s(%s) bytes=%zu", (int) ok, (int) has_ids, ids ? ids->data : nullptr, n_out, (int)((out->flags & GGML_TENSOR_FLAG_OUTPUT) != 0), (long long) min_ml, cur_sets.size(), out->name, ggml_op_name(out->op), ggml_nbytes(out));
-            if (ok && has_ids) {
-                A.ids_ptr = ids->data; A.logits_ptr = out->data; A.logits_bytes = ggml_nbytes(out); A.last_sets = cur_sets;
-                A.armed = true; g_ahead_ctx[c->device] = c;
-                // the next step goes out NOW, behind the one just launched (CLLM_HIP_AHEAD_CHAIN=0: when the host reads the logits, round 5's order)
-                static const bool chain = !getenv("CLLM_HIP_AHEAD_CHAIN") || atoi(getenv("CLLM_HIP_AHEAD_CHAIN")) != 0;
-                if (chain) ahead_launch(c, true);
-            }
-        }
-    }
+    ahead_arm(c, g, plan, cur_sets, replayed && c->graph_exec != nullptr, false);
     if (g_stats) {
         int a1 = 0, a2 = 0;
         for (const fused_attn & A : plan.attns) (A.level == 2 ? a2 : a1)++;

@@ -617,7 +617,7 @@ def test_tensor_parallel_behind_the_ggml_boundary(gpu, tmp_path, arch, wt, over)
         assert f"tensor parallel: {n} ranks behind one ggml device" in err, err[-1500:]
         steps = [ln for ln in err.splitlines() if "-> tensor parallel over" in ln]
         assert len(steps) == n_dec - 1, (len(steps), err[-1500:])                 # every single-token step ran sharded; the prompt and the second turn's chunk did not
-        assert sum("replayed from the captured graphs" in ln for ln in steps) >= 4, steps[-3:]      # the sharded step's launch list is captured (2nd identical step) and replayed, before and after the chunk
+        assert sum("replayed from the captured graphs" in ln or "started ahead of the host" in ln for ln in steps) >= 4, steps[-3:]      # the sharded step's launch list is captured (2nd identical step) and replayed -- by the host's request or ahead of it --, before and after the chunk
         assert all("lm_head rows sharded" in ln for ln in steps)
         assert "timed out" not in err
         assert np.array_equal(lg_1[0].view(np.uint32), lg_n[0].view(np.uint32))   # the prompt ran un-sharded on rank 0: the single device's bits
@@ -625,11 +625,17 @@ def test_tensor_parallel_behind_the_ggml_boundary(gpu, tmp_path, arch, wt, over)
         if n == 4:
             lg_4 = lg_n
         print(f"{arch} wtype {wt}: {n} ranks behind one device: max|dlogit| {dev:.3e} sigma, steps with a clear margin {clear:.2f}")
+    # FREE-RUNNING (each run feeds its own argmax back): the sharded steps are started AHEAD of the host from the third one on (decode-ahead, as on one device) -- the same bits
+    # as with it switched off
+    ids_a, lg_a, err_a = _host_run(tmp_path, mp, "all", n_dec, prompt, cfg["vocab"], threads=4, CLLM_HIP_TP="4", **turn2)
+    ids_b, lg_b, err_b = _host_run(tmp_path, mp, "all", n_dec, prompt, cfg["vocab"], threads=4, CLLM_HIP_TP="4", CLLM_HIP_AHEAD="0", **turn2)
+    assert sum("started ahead of the host" in ln for ln in err_a.splitlines()) >= 3 and "started ahead of the host" not in err_b, err_a[-1500:]
+    assert ids_a == ids_b and np.array_equal(lg_a.view(np.uint32), lg_b.view(np.uint32))
     # the cross-stream path distinct GPUs take (every rank its own stream, the embedding row / position handed over behind an event, the ranks' streams joined into rank 0's at the
     # end of the step, gathers polling for scatters that run concurrently) on the one GPU: small shapes, every launch resident at once
     ids_s, lg_s, err = _host_run(tmp_path, mp, "all", n_dec, prompt, cfg["vocab"], teacher=ids_1, threads=4, CLLM_HIP_TP="2", CLLM_HIP_TP_STREAMS="1", CLLM_HIP_TP_DEBUG="1", **turn2)
     assert len([ln for ln in err.splitlines() if "-> tensor parallel over" in ln]) == n_dec - 1 and "timed out" not in err, err[-1500:]
-    assert sum("replayed from the captured graphs" in ln for ln in err.splitlines()) >= 4                 # one captured graph per stream
+    assert sum("replayed from the captured graphs" in ln or "started ahead of the host" in ln for ln in err.splitlines()) >= 4                 # one captured graph per stream
     ids_e, lg_e, err = _host_run(tmp_path, mp, "all", n_dec, prompt, cfg["vocab"], teacher=ids_1, threads=4, CLLM_HIP_TP="4", CLLM_HIP_TP_GRAPH="0", CLLM_HIP_TP_HEAD="0", **turn2)
     assert "replayed from the captured graphs" not in err and "lm_head rows sharded" not in err
     assert np.array_equal(lg_e.view(np.uint32), lg_4.view(np.uint32))                                         # replay and the sharded head change no bit of the sharded run
@@ -675,7 +681,7 @@ def test_tensor_parallel_behind_the_boundary_at_real_block_shapes(gpu, tmp_path,
     os.remove(mp)
     steps = [ln for ln in err.splitlines() if "-> tensor parallel over 8 ranks" in ln]
     assert len(steps) == n_dec and "timed out" not in err, err[-1500:]
-    assert all("lm_head rows sharded" in ln for ln in steps) and sum("replayed from the captured graphs" in ln for ln in steps) >= n_dec - 2
+    assert all("lm_head rows sharded" in ln for ln in steps) and sum("replayed from the captured graphs" in ln or "started ahead of the host" in ln for ln in steps) >= n_dec - 2
     assert np.array_equal(lg_1[0].view(np.uint32), lg_8[0].view(np.uint32))          # the prompt: un-sharded
     dev, clear = _tolerance_tier(lg_1, lg_8, ids_1, 0.25)
     print(f"{cname} block shapes, 8 ranks behind one device: max|dlogit| {dev:.3e} sigma, steps with a clear margin {clear:.2f}")
